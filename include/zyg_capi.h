@@ -1,0 +1,91 @@
+/*
+ * zyg_capi.h — outer C ABI: the `su_*` surface of the reference's libzyg.so
+ * (reference src/capi/capi.zig:57-738; callers: src/capi-test/test.py:57-261,
+ * src/capi-test/test_progressive.py, src/blender-plugin/engine.py:49-381).
+ *
+ * Same names, argument meaning and error convention (int32: 0 = ok, >= 0 = created id,
+ * -1 = failure / not initialised, -2 = AOV inactive, -3/-4 = material update errors).
+ * One process-global engine, single client thread, caller-owned inputs are copied.
+ * The render calls run on the MI355X through the inner ABI (zygpu.h); there is no CPU path.
+ *
+ * `su_ext_*` entries are additions without a reference counterpart; each says why it exists.
+ */
+#ifndef ZYG_CAPI_H
+#define ZYG_CAPI_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#include "zygpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void (*su_log_func)(uint32_t level, const char* text);  /* core/log.zig:42-55 */
+typedef void (*su_progress_start_func)(uint32_t resolution);    /* core/progress.zig:3-77 */
+typedef void (*su_progress_tick_func)(void);
+
+int32_t su_init(void);                                                   /* capi.zig:57-117 */
+int32_t su_release(void);                                                /* capi.zig:119-133 */
+int32_t su_mount(const char* folder);                                    /* capi.zig:135-141 */
+int32_t su_perspective_camera_create(uint32_t width, uint32_t height);  /* capi.zig:143-167; returns camera entity */
+int32_t su_camera_set_fov(float fov);                                    /* capi.zig:169-176; radians */
+int32_t su_camera_sensor_dimensions(int32_t* dimensions);                /* capi.zig:178-187 */
+int32_t su_exporters_create(const char* json);                           /* capi.zig:189-200 */
+int32_t su_aovs_create(const char* json);                                /* capi.zig:202-213 */
+int32_t su_sampler_create(uint32_t num_samples);                         /* capi.zig:215-221; always returns -1, as the reference */
+int32_t su_integrators_create(const char* json);                         /* capi.zig:223-234 */
+int32_t su_image_create(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height,
+                        uint32_t depth, uint32_t pixel_stride, const uint8_t* data); /* capi.zig:236-297 */
+int32_t su_image_update(uint32_t id, uint32_t pixel_stride, const uint8_t* data);   /* capi.zig:299-338 */
+int32_t su_material_create(uint32_t id, const char* json);               /* capi.zig:340-351 */
+int32_t su_material_update(uint32_t id, const char* json);               /* capi.zig:353-376 */
+int32_t su_triangle_mesh_create(uint32_t id, uint32_t num_parts, const uint32_t* parts, uint32_t num_triangles,
+                                const uint32_t* indices, uint32_t num_vertices, const float* positions,
+                                uint32_t positions_stride, const float* normals, uint32_t normals_stride,
+                                const float* tangents, uint32_t tangents_stride, const float* uvs, uint32_t uvs_stride,
+                                bool asyncr); /* capi.zig:378-424; parts = {start_index, num_indices, material} x num_parts */
+int32_t su_prop_create(uint32_t shape, uint32_t num_materials, const uint32_t* materials); /* capi.zig:426-456 */
+int32_t su_prop_create_instance(uint32_t entity);                        /* capi.zig:458-470 */
+int32_t su_light_create(uint32_t prop);                                  /* capi.zig:472-484 */
+int32_t su_prop_set_transformation(uint32_t prop, const float* trafo);   /* capi.zig:486-506; 16 floats, row-major, translation in [12..14] */
+int32_t su_prop_set_transformation_frame(uint32_t prop, uint32_t frame, const float* trafo); /* capi.zig:508-536 */
+int32_t su_prop_set_visibility(uint32_t prop, uint32_t in_camera, uint32_t in_reflection, uint32_t in_sss); /* capi.zig:538-549 */
+int32_t su_render_frame(uint32_t frame);                                 /* capi.zig:551-572 */
+int32_t su_export_frame(void);                                           /* capi.zig:574-584 */
+int32_t su_start_frame(uint32_t frame);                                  /* capi.zig:586-605 */
+int32_t su_render_iterations(uint32_t num_steps);                        /* capi.zig:607-616 */
+int32_t su_resolve_frame(uint32_t aov);                                  /* capi.zig:618-629 */
+int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height, float* buffer); /* capi.zig:631-646 */
+int32_t su_copy_framebuffer(uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height,
+                            uint8_t* destination);                       /* capi.zig:648-729 */
+int32_t su_register_log(su_log_func post);                              /* capi.zig:731-734 */
+int32_t su_register_progress(su_progress_start_func start, su_progress_tick_func tick); /* capi.zig:736-743 */
+
+/* ---- additions (no reference counterpart) ---- */
+
+/* Scene.createPropShape with `unoccluding` exposed: the reference only reaches unoccluding=true through the scene
+ * loader's "Light" entity (util/scene_loader.zig:249,365-366); su_prop_create always passes false (capi.zig:449). */
+int32_t su_ext_prop_create(uint32_t shape, uint32_t num_materials, const uint32_t* materials, uint32_t unoccluding);
+/* The take's "sensor" node (cli/take_loader.zig:193-230): {"clamp": {...}, "filter": {"Mitchell"|"Blackman": {}}};
+ * without "filter" the sensor is the box / radius-0 one.  The reference C ABI always uses Mitchell r=2 (take.zig:59-64). */
+int32_t su_ext_sensor_create(const char* json);
+/* Camera "parameters" node (camera_perspective.zig:260-270): fov (degrees), lens.radius, focus.distance. */
+int32_t su_ext_camera_set_parameters(const char* json);
+/* HIP device the engine renders on (default: env ZYG_DEVICE, else LOCAL_RANK, else 0). */
+int32_t su_ext_set_device(int32_t device_id);
+/* Scene.compile + camera.update only (driver.zig:154-180), no device work; fills the descriptors below. */
+int32_t su_ext_compile(uint32_t frame);
+const ZygpuSceneDesc* su_ext_scene_desc(void);
+const ZygpuViewDesc*  su_ext_view_desc(void);
+/* su_render_iterations restricted to film rows [y_begin, y_end): the unit ranks shard. */
+int32_t su_ext_render_rows(uint32_t num_steps, int32_t y_begin, int32_t y_end);
+/* Inner-ABI context of the engine (valid after su_start_frame / su_render_frame). */
+ZygpuContext* su_ext_context(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ZYG_CAPI_H */

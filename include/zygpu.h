@@ -1,0 +1,319 @@
+/*
+ * zygpu.h — inner C ABI of the MI355X wavefront path-tracing core.
+ *
+ * This is the seam at which the reference hands tiles to its CPU workers:
+ * after `Scene.compile` + `camera.update` (reference src/core/rendering/driver.zig:154-180)
+ * and instead of `threads.runParallel(self, renderTiles, 0)` (driver.zig:293-348).
+ * The reference has no plugin interface at this point (integrator dispatch is a closed
+ * Zig tagged union, src/core/rendering/integrator/surface/integrator.zig:10-21), so the
+ * entry points below are what a Zig host would bind with `extern fn`.
+ *
+ * Everything is plain C: pointers + sizes, caller-owned host memory, int return
+ * (0 = ok, negative = error).  All arrays describe the *compiled* scene of the reference
+ * (SURVEY.md Appendix B), camera-relative (origin already subtracted,
+ * src/core/scene/space.zig:99-108), static transforms only.
+ */
+#ifndef ZYGPU_H
+#define ZYGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZYGPU_NULL 0xFFFFFFFFu
+
+/* reference src/core/scene/bvh/node.zig:9-20 — 32 B BVH2 node; children are (a, a+1); leaf iff count != 0 */
+typedef struct ZygpuBvhNode {
+    float    min[3];
+    uint32_t children_or_first;
+    float    max[3];
+    uint32_t count;
+} ZygpuBvhNode;
+
+/* reference src/core/scene/composed_transformation.zig:11-29 — rotation rows, row.w = scale component; position */
+typedef struct ZygpuTrafo {
+    float r[3][4];
+    float position[4];
+} ZygpuTrafo;
+
+/* reference src/base/math/aabb.zig:11 + cacheRadius (137-144): max[3] = cached radius, min[3] = 0
+ * (light AABBs: min[3] = light power, src/core/scene/scene.zig:496) */
+typedef struct ZygpuAabb {
+    float min[4];
+    float max[4];
+} ZygpuAabb;
+
+/* shape classes: built-in resource ids of the reference (src/core/resource/manager.zig:36-44) */
+enum ZygpuShape {
+    ZYGPU_SHAPE_CANOPY = 0,
+    ZYGPU_SHAPE_CUBE = 1,
+    ZYGPU_SHAPE_DISK = 2,
+    ZYGPU_SHAPE_DISTANT = 3,
+    ZYGPU_SHAPE_DOME = 4,
+    ZYGPU_SHAPE_RECTANGLE = 5,
+    ZYGPU_SHAPE_SPHERE = 6,
+    ZYGPU_SHAPE_TRIANGLE_MESH = 7 /* prop.mesh indexes ZygpuSceneDesc.meshes */
+};
+
+/* reference src/core/scene/prop/prop.zig:23-49 — Properties bits, same order */
+enum ZygpuPropFlags {
+    ZYGPU_PROP_VISIBLE_IN_CAMERA = 1u << 0,
+    ZYGPU_PROP_VISIBLE_IN_REFLECTION = 1u << 1,
+    ZYGPU_PROP_VISIBLE_IN_SHADOW = 1u << 2,
+    ZYGPU_PROP_VISIBLE_IN_SSS = 1u << 3,
+    ZYGPU_PROP_EVALUATE_VISIBILITY = 1u << 4,
+    ZYGPU_PROP_UNOCCLUDING = 1u << 5,
+    ZYGPU_PROP_SOLID = 1u << 6,
+    ZYGPU_PROP_VOLUME = 1u << 7,
+    ZYGPU_PROP_CAUSTIC = 1u << 8,
+    ZYGPU_PROP_STATIC = 1u << 9,
+    ZYGPU_PROP_INSTANCER = 1u << 10,
+    ZYGPU_PROP_SHADOW_CATCHER = 1u << 11,
+    ZYGPU_PROP_SHADOW_CATCHER_LIGHT = 1u << 12
+};
+
+/* reference src/core/scene/prop/prop.zig:51-53 + scene.zig:84 (prop_parts) */
+typedef struct ZygpuProp {
+    uint32_t shape;       /* enum ZygpuShape */
+    uint32_t flags;       /* enum ZygpuPropFlags */
+    uint32_t parts_start; /* index into material_ids / light_ids (scene.zig:539-556) */
+    uint32_t mesh;        /* index into meshes, or ZYGPU_NULL */
+} ZygpuProp;
+
+/* reference src/core/scene/shape/triangle/triangle_tree.zig:25-27 + triangle_data.zig:22-29 */
+typedef struct ZygpuMesh {
+    const ZygpuBvhNode* nodes;
+    const uint32_t*     triangles; /* 3 vertex indices per triangle, leaf order (builder reorders) */
+    const uint16_t*     triangle_parts;
+    const float*        positions; /* 3*num_vertices + 1 floats (unaligned 16 B reads, triangle_data.zig:62-64) */
+    const uint16_t*     normals;   /* 2 per vertex, oct + snorm16 (base/encoding.zig:82-108) */
+    const float*        uvs;       /* 2 per vertex */
+    const float*        part_areas;
+    uint32_t num_nodes;
+    uint32_t num_triangles;
+    uint32_t num_vertices;
+    uint32_t num_parts;
+} ZygpuMesh;
+
+/* material classes: union order of the reference (src/core/scene/material/material.zig:35-43) */
+enum ZygpuMaterialKind {
+    ZYGPU_MAT_DEBUG = 0,
+    ZYGPU_MAT_GLASS = 1,
+    ZYGPU_MAT_HAIR = 2,
+    ZYGPU_MAT_LIGHT = 3,
+    ZYGPU_MAT_SKY = 4,
+    ZYGPU_MAT_SUBSTITUTE = 5,
+    ZYGPU_MAT_VOLUMETRIC = 6
+};
+
+/* reference src/core/scene/material/material_base.zig:13-22 */
+enum ZygpuMaterialFlags {
+    ZYGPU_MATF_TWO_SIDED = 1u << 0,
+    ZYGPU_MATF_EVALUATE_VISIBILITY = 1u << 1,
+    ZYGPU_MATF_CAUSTIC = 1u << 2,
+    ZYGPU_MATF_EMISSIVE = 1u << 3
+};
+
+/* Uniform-texture subset of the reference materials (all colours ACES AP1, base/json.zig:247-277).
+ * Debug: color_a/color_b = front/back albedo (debug_material.zig:11-12);
+ * Substitute: color_a = color, see substitute_material.zig:32-60; emittance: light/emittance.zig:18-27 */
+typedef struct ZygpuMaterial {
+    uint32_t kind;
+    uint32_t flags;
+    float    color_a[3];
+    float    color_b[3];
+    float    roughness;
+    float    metallic;
+    float    specular;
+    float    ior;
+    float    anisotropy;
+    float    emission[3]; /* emittance.value */
+    float    cos_a;
+    float    camera_weight;
+    uint32_t emission_normalize;
+    uint32_t emission_num_samples;
+} ZygpuMaterial;
+
+/* reference src/core/scene/light/light.zig:32-47 */
+enum ZygpuLightClass { ZYGPU_LIGHT_PORTAL_IMAGE = 0, ZYGPU_LIGHT_PROP = 1, ZYGPU_LIGHT_PROP_IMAGE = 2,
+                       ZYGPU_LIGHT_VOLUME = 3, ZYGPU_LIGHT_VOLUME_IMAGE = 4 };
+
+typedef struct ZygpuLight {
+    uint32_t prop;
+    uint32_t part;
+    uint32_t num_samples; /* shape_sampler.num_samples (shape/shape_sampler.zig:28-41) */
+    uint8_t  light_class;
+    uint8_t  two_sided;
+    uint8_t  shadow_catcher_light;
+    uint8_t  prototype;
+} ZygpuLight;
+
+/* reference src/core/scene/light/light_tree.zig:25-35 — 32 B compressed node */
+typedef struct ZygpuLightNode {
+    uint16_t center[4]; /* unorm16 of (centre - bounds.min)/extent; [3] = radius / bounds radius */
+    uint16_t cone[4];   /* snorm16 axis.xyz, cos */
+    float    power;
+    float    variance;
+    uint32_t meta;      /* bit0 has_children, bit1 two_sided, bits 2.. children_or_light */
+    uint32_t num_lights;
+} ZygpuLightNode;
+
+/* reference src/core/scene/light/light_tree.zig:247-273 (Tree) */
+typedef struct ZygpuLightTree {
+    const ZygpuLightNode* nodes;
+    const uint32_t*       node_middles;
+    const uint32_t*       light_orders;
+    const uint32_t*       light_mapping;
+    ZygpuAabb bounds;
+    float     infinite_weight;
+    float     infinite_guard;
+    uint32_t  infinite_end;
+    uint32_t  max_split_depth;
+    uint32_t  num_lights;
+    uint32_t  num_infinite_lights;
+    uint32_t  num_nodes;
+} ZygpuLightTree;
+
+/* top-level BVH over props (reference src/core/scene/prop/prop_tree.zig:22-27) */
+typedef struct ZygpuPropTree {
+    const ZygpuBvhNode* nodes;
+    const uint32_t*     indices;
+    uint32_t num_nodes;
+    uint32_t num_indices;
+} ZygpuPropTree;
+
+/* albedo LUTs of the GGX energy compensation (reference material/ggx_integral.zig:3,166,175,979,1048) */
+typedef struct ZygpuLuts {
+    const float* e_m;     /* 32 x 32 */
+    const float* e_m_avg; /* 32 */
+    const float* e;       /* 16 x 16 x 16 */
+    const float* e_avg;   /* 16 x 16 */
+    const float* e_s;     /* 16 x 16 x 16 */
+} ZygpuLuts;
+
+typedef struct ZygpuSceneDesc {
+    const ZygpuProp*     props;
+    const ZygpuTrafo*    trafos; /* per prop, camera-relative (space.zig:99-108) */
+    const ZygpuAabb*     aabbs;  /* per prop, camera-relative world bounds (space.zig:60-97) */
+    const uint32_t*      material_ids; /* per (prop.parts_start + part) */
+    const uint32_t*      light_ids;    /* per (prop.parts_start + part), ZYGPU_NULL if none */
+    const ZygpuMesh*     meshes;
+    const ZygpuMaterial* materials;
+    const ZygpuLight*    lights;
+    const ZygpuAabb*     light_aabbs; /* min[3] = power, max[3] = radius (scene.zig:654-676) */
+    const float*         light_cones; /* 4 per light: axis.xyz, cos */
+    ZygpuPropTree        solid;       /* finite occluding props (scene.zig:77) */
+    ZygpuPropTree        unoccluding; /* finite, purely emissive `Light` entities (scene.zig:78) */
+    ZygpuLightTree       light_tree;
+    ZygpuLuts            luts;
+    float    specular_threshold; /* resources.specular_threshold (resource/manager.zig:57) */
+    uint32_t num_props;
+    uint32_t num_parts;  /* length of material_ids / light_ids */
+    uint32_t num_meshes;
+    uint32_t num_materials;
+    uint32_t num_lights;
+} ZygpuSceneDesc;
+
+enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };
+enum ZygpuSampler { ZYGPU_SAMPLER_RANDOM = 0, ZYGPU_SAMPLER_SOBOL = 1 };
+
+#define ZYGPU_FILTER_TAPS 30 /* reference sensor.zig:72: InterpolatedFunction1DN(30) */
+
+/* camera (camera_perspective.zig:79-150), integrator (take/take.zig:131-271) and sensor (sensor.zig:27-120) state */
+typedef struct ZygpuViewDesc {
+    int32_t  resolution[2];
+    int32_t  crop[4]; /* x0, y0, x1, y1 (exclusive end), camera_base.zig:31-41 */
+    float    left_top[4];
+    float    d_x[4];
+    float    d_y[4];
+    float    eye_offset[4];
+    float    lens_radius;
+    float    focus_distance;
+    ZygpuTrafo camera_trafo; /* camera prop transformation, camera-relative */
+    uint64_t frame_step;     /* ticks, camera_base.zig:25 */
+    uint64_t frame_duration; /* ticks, camera_base.zig:26 */
+    uint32_t integrator;     /* enum ZygpuIntegrator */
+    uint32_t max_depth_surface;
+    uint32_t max_depth_volume;
+    float    split_threshold; /* already st^4 (take.zig:263-271) */
+    uint32_t caustics_path;
+    float    regularize_roughness;
+    uint32_t sampler;         /* enum ZygpuSampler */
+    uint32_t num_expected_samples; /* view.num_samples_per_pixel (driver.zig:298) */
+    int32_t  filter_radius_int;    /* sensor.filter_radius_int */
+    float    filter_radius;        /* range end of the tabulated filter */
+    float    filter_samples[ZYGPU_FILTER_TAPS + 1]; /* normalised table (base/math/interpolated_function.zig) */
+    float    clamp_emission, clamp_direct, clamp_indirect; /* sensor.zig:60-70 */
+    float    exposure_factor; /* 2^exposure, tonemapper.zig:15 (Linear tonemapper) */
+} ZygpuViewDesc;
+
+/* traversal / path statistics (no reference counterpart; they define the algorithmic bytes of SURVEY §8(d)) */
+typedef struct ZygpuStats {
+    uint64_t camera_samples;
+    uint64_t extension_rays;
+    uint64_t shadow_rays;
+    uint64_t nodes_fetched;      /* both children of every inner step count (triangle_tree.zig:76-80) */
+    uint64_t triangles_tested;
+    uint64_t instances_tested;
+} ZygpuStats;
+
+typedef struct ZygpuContext ZygpuContext;
+
+/* Creates a device context on HIP device `device_id`.  Replaces Driver.init (driver.zig:60-72). */
+int zygpu_create(int device_id, ZygpuContext** out_ctx);
+int zygpu_destroy(ZygpuContext* ctx);
+
+/* Copies the compiled scene to HBM (re-laid out for wave64 traversal).  Replaces what
+ * Scene.compile leaves in host memory for the workers (scene.zig:185-223). */
+int zygpu_upload_scene(ZygpuContext* ctx, const ZygpuSceneDesc* scene);
+
+/* Camera/integrator/sensor state.  Replaces Driver.configure + camera.update (driver.zig:86-113,167-169). */
+int zygpu_set_view(ZygpuContext* ctx, const ZygpuViewDesc* view);
+
+/* buffer.clear(weight) (buffer_opaque.zig:26-30) on the device film. */
+int zygpu_clear_film(ZygpuContext* ctx, float weight);
+
+/* Driver.renderIterations semantics in progressive form (driver.zig:182-187,338-348): renders iterations
+ * [iteration, iteration + num_iterations), one camera sample per pixel and iteration, each (pixel, iteration)
+ * reseeded as worker.zig:141-149, and accumulates into the device film.  Rows [y_begin, y_end) of the crop
+ * window only (whole frame: 0, resolution[1]); this is what lets ranks shard the frame.
+ * Asynchronous on the context's stream. */
+int zygpu_render(ZygpuContext* ctx, uint32_t frame, uint32_t iteration, uint32_t num_iterations,
+                 int32_t y_begin, int32_t y_end);
+
+/* Waits for all queued work on the context's stream. */
+int zygpu_synchronize(ZygpuContext* ctx);
+
+/* Raw film {sum w*r, sum w*g, sum w*b, sum w} (buffer_opaque.zig:12-13), resolution[0]*resolution[1]*4 floats. */
+int zygpu_download_film(ZygpuContext* ctx, float* host_rgbw);
+int zygpu_upload_film(ZygpuContext* ctx, const float* host_rgbw);
+
+/* Device pointer of the film (for an RCCL reduce by the caller); not owned by the caller. */
+int zygpu_film_device_ptr(ZygpuContext* ctx, void** out_ptr, uint64_t* out_num_floats);
+/* Makes the kernels accumulate into a caller-owned device buffer of resolution[0]*resolution[1]*4 floats
+ * (e.g. a torch tensor that is then reduced with RCCL in place); NULL switches back to the internal film.
+ * Call after zygpu_set_view. */
+int zygpu_set_external_film(ZygpuContext* ctx, void* device_rgbw);
+
+/* resolveTonemap (buffer_opaque.zig:73-79, tonemapper.zig:18-46, Linear): |rgb / w| * exposure -> AP1 -> sRGB,
+ * alpha 1; writes min(num_pixels, film pixels) * 4 floats to host memory. */
+int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
+
+/* Counters accumulated since the last reset (only maintained when enabled). */
+int zygpu_enable_stats(ZygpuContext* ctx, int enabled);
+int zygpu_get_stats(ZygpuContext* ctx, ZygpuStats* out_stats);
+int zygpu_reset_stats(ZygpuContext* ctx);
+
+/* Sum of the durations (ms, HIP events on the context's stream) and launch count of the dominant
+ * kernel (`wf_trace`, the closest-hit / any-hit traversal stage) since the last reset. */
+int zygpu_kernel_time(ZygpuContext* ctx, double* out_ms, uint64_t* out_launches, int reset);
+
+const char* zygpu_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ZYGPU_H */

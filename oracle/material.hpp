@@ -1,0 +1,413 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see omath.hpp).
+//
+// Material closures restated from the reference (uniform textures only):
+//   Material.sample dispatch    src/core/scene/material/material.zig:184-194
+//   sample Base / bxdf types    material/sample_base.zig:11-108, material/bxdf.zig:5-80
+//   Debug (Lambert)             material/debug/debug_material.zig:20-28, debug_sample.zig:15-47
+//   Light (no scattering)       material/light/light_sample.zig:7-13, material_sample.zig:47-60
+//   Substitute (opaque base)    material/substitute/substitute_material.zig:114-221,
+//                               substitute_sample.zig:38-86 (init), 88-145 (evaluate), 147-234 (sample),
+//                               236-302 (baseEvaluate/baseSample), 338-410 (diffuseSample/glossSample)
+//   diffuse.Micro               material/diffuse.zig:42-110
+//   ggx Iso/Aniso, dspbrMicroEc material/ggx.zig:30-46, 60-130, 228-449
+//   fresnel.Schlick             material/fresnel.zig:5-29
+//   LUT evaluation              base/math/interpolated_function.zig:105-271, base/math/math.zig:172-191
+#pragma once
+
+#include "sampler.hpp"
+#include "scene.hpp"
+
+namespace orc {
+
+enum class Scattering : uint8_t { Diffuse, Glossy, Specular, None };
+enum class PathEvent : uint8_t { Reflection, Transmission, Straight };
+
+struct PathInfo {  // bxdf.zig:34-70
+    float      reg_alpha;
+    Scattering scattering;
+    PathEvent  event;
+    bool       singular() const { return 0.f == reg_alpha; }
+    static PathInfo diffuseReflection() { return {1.f, Scattering::Diffuse, PathEvent::Reflection}; }
+    static PathInfo reflection(float alpha, float specular_threshold) {
+        return {alpha, alpha <= specular_threshold ? Scattering::Specular : Scattering::Glossy, PathEvent::Reflection};
+    }
+};
+
+struct BxdfResult {
+    V4    reflection;
+    float pdf;
+};
+
+struct BxdfSample {
+    V4       reflection, wi;
+    float    pdf, split_weight, wavelength;
+    PathInfo path;
+};
+
+struct Renderstate {  // renderstate.zig:10-45 (subset in scope)
+    Trafo    trafo;
+    V4       p, geo_n, t, b, n, origin, uvw;
+    float    stochastic_r, ior;
+    uint32_t prop, part;
+    bool     caustics;
+};
+
+struct Luts {
+    const ZygpuLuts* l;
+    static float bilinear(const float c[4], float s, float t) {  // math.zig:172-179
+        const float _s = 1.f - s, _t = 1.f - t;
+        return _t * (_s * c[0] + s * c[1]) + t * (_s * c[2] + s * c[3]);
+    }
+    static float eval1(const float* samples, int N, float x) {  // InterpolatedFunction1DN.fromArray/eval
+        const float    cx = mn(x, 1.f);
+        const float    o = cx * float(N - 1);
+        const uint32_t offset = uint32_t(o);
+        const float    t = o - float(offset);
+        return lerpf(samples[offset], samples[std::min<uint32_t>(offset + 1, uint32_t(N - 1))], t);
+    }
+    static float eval2(const float* samples, int X, int Y, float x, float y) {
+        const float   ox = mn(x, 1.f) * float(X - 1), oy = mn(y, 1.f) * float(Y - 1);
+        const int32_t o0 = int32_t(ox), o1 = int32_t(oy);
+        const float   t0 = ox - float(o0), t1 = oy - float(o1);
+        const int32_t col1 = std::min(o0 + 1, X - 1);
+        const int32_t row0 = o1 * X, row1 = std::min(o1 + 1, Y - 1) * X;
+        const float   c[4] = {samples[o0 + row0], samples[col1 + row0], samples[o0 + row1], samples[col1 + row1]};
+        return bilinear(c, t0, t1);
+    }
+    static float eval3(const float* samples, int X, int Y, int Z, float x, float y, float z) {
+        const float   ox = mn(x, 1.f) * float(X - 1), oy = mn(y, 1.f) * float(Y - 1), oz = mn(z, 1.f) * float(Z - 1);
+        const int32_t o0 = int32_t(ox), o1 = int32_t(oy), o2 = int32_t(oz);
+        const float   t0 = ox - float(o0), t1 = oy - float(o1), t2 = oz - float(o2);
+        const int32_t col1 = std::min(o0 + 1, X - 1);
+        const int32_t row0 = o1 * X, row1 = std::min(o1 + 1, Y - 1) * X;
+        const int32_t area = X * Y;
+        const int32_t s0 = o2 * area, s1 = std::min(o2 + 1, Z - 1) * area;
+        const float   ca[4] = {samples[o0 + row0 + s0], samples[col1 + row0 + s0], samples[o0 + row1 + s0],
+                               samples[col1 + row1 + s0]};
+        const float   cb[4] = {samples[o0 + row0 + s1], samples[col1 + row0 + s1], samples[o0 + row1 + s1],
+                               samples[col1 + row1 + s1]};
+        return lerpf(bilinear(ca, t0, t1), bilinear(cb, t0, t1), t2);
+    }
+    float E_m(float n_dot, float alpha) const { return eval2(l->e_m, 32, 32, n_dot, alpha); }
+    float E_m_avg(float alpha) const { return eval1(l->e_m_avg, 32, alpha); }
+    float E(float n_dot, float alpha, float f0) const { return eval3(l->e, 16, 16, 16, n_dot, alpha, f0); }
+    float E_avg(float alpha, float f0) const { return eval2(l->e_avg, 16, 16, alpha, f0); }
+};
+
+namespace fresnel {
+inline float pow5(float x) {
+    const float x2 = x * x, x4 = x2 * x2;
+    return x4 * x;
+}
+inline V4    schlick(V4 f0, float wo_dot_h) { return fma4(S(pow5(1.f - wo_dot_h)), S(1.f) - f0, f0); }
+inline float iorToF0(float n0, float n1) {
+    const float t = (n0 - n1) / (n0 + n1);
+    return t * t;
+}
+}  // namespace fresnel
+
+namespace ggx {
+
+constexpr float kMinRoughness = 0.01314f;
+inline float    clampRoughness(float r) { return mx(r, kMinRoughness); }
+
+struct Micro {
+    V4    h;
+    float n_dot_wi, h_dot_wi;
+};
+
+inline V4 dspbrMicroEc(const Luts& L, V4 f0, float n_dot_wi, float n_dot_wo, float alpha) {  // ggx.zig:34-46
+    const float e_wo = L.E_m(n_dot_wo, alpha), e_wi = L.E_m(n_dot_wi, alpha), e_avg = L.E_m_avg(alpha);
+    const float m = ((1.f - e_wo) * (1.f - e_wi)) / (kPi * (1.f - e_avg));
+    const V4    f_avg = fma4(S(20.f / 21.f), f0, S(1.f / 21.f));
+    const V4    f = ((f_avg * f_avg) * S(e_avg)) / fma4(-f_avg, S(1.f - e_avg), S(1.f));
+    return S(m) * f;
+}
+
+inline float pdfVisible(float d, float g1_wo) { return (0.5f * d) / g1_wo; }
+
+inline float isoDistribution(float n_dot_h, float a2) {  // ggx.zig:228-231
+    const float d = std::fmaf(n_dot_h * n_dot_h, a2 - 1.f, 1.f);
+    return a2 / (kPi * d * d);
+}
+inline void isoVisibilityAndG1Wo(float n_dot_wi, float n_dot_wo, float alpha2, float g[2]) {  // :233-243
+    const float t_wi = std::sqrt(std::fmaf(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
+    const float t_wo = std::sqrt(std::fmaf(1.f - alpha2, n_dot_wo * n_dot_wo, alpha2));
+    g[0] = 0.5f / (n_dot_wi * t_wo + n_dot_wo * t_wi);
+    g[1] = t_wo + n_dot_wo;
+}
+inline float anisoDistribution(float n_dot_h, float x_dot_h, float y_dot_h, const float a[2]) {  // :416-424
+    const float a20 = a[0] * a[0], a21 = a[1] * a[1];
+    const float x = (x_dot_h * x_dot_h) / a20, y = (y_dot_h * y_dot_h) / a21;
+    const float d = (x + y) + (n_dot_h * n_dot_h);
+    return 1.f / (kPi * (a[0] * a[1]) * (d * d));
+}
+inline void anisoVisibilityAndG1Wo(float t_dot_wi, float t_dot_wo, float b_dot_wi, float b_dot_wo, float n_dot_wi,
+                                   float n_dot_wo, const float a[2], float g[2]) {  // :426-440
+    const float t_wo = length3(mk(a[0] * t_dot_wo, a[1] * b_dot_wo, n_dot_wo));
+    const float t_wi = length3(mk(a[0] * t_dot_wi, a[1] * b_dot_wi, n_dot_wi));
+    g[0] = 0.5f / (n_dot_wi * t_wo + n_dot_wo * t_wi);
+    g[1] = t_wo + n_dot_wo;
+}
+
+// ggx.zig:396-414 (VNDF, spherical caps)
+inline V4 anisoSample(V4 wo, const float alpha[2], float xi0, float xi1, const Frame& frame, float& n_dot_h) {
+    const V4    wo_l = frame.worldToFrame(wo);
+    const V4    v = normalize3(mk(alpha[0] * wo_l[0], alpha[1] * wo_l[1], wo_l[2]));
+    const float phi = (2.f * kPi) * xi0;
+    const float z = std::fmaf(1.f - xi1, 1.f + v[2], -v[2]);
+    const float sin_theta = std::sqrt(saturate(1.f - z * z));
+    const float x = sin_theta * std::cos(phi), y = sin_theta * std::sin(phi);
+    const V4    h = mk(x, y, z) + v;
+    const V4    m = normalize3(mk(alpha[0] * h[0], alpha[1] * h[1], h[2]));
+    n_dot_h = clampf(m[2], kDotMin, 1.f);
+    return frame.frameToWorld(m);
+}
+
+// Aniso.reflection (ggx.zig:250-300), falling to Iso.reflectionF (74-97) when alpha is isotropic
+inline BxdfResult reflection(V4 wi, V4 wo, V4 h, float n_dot_wi, float n_dot_wo, float wo_dot_h, const float alpha[2], V4 f0,
+                             const Frame& frame) {
+    float d, g[2];
+    if (alpha[0] == alpha[1]) {
+        const float alpha2 = alpha[0] * alpha[0];
+        const float n_dot_h = saturate(dot3(frame.z, h));
+        d = isoDistribution(n_dot_h, alpha2);
+        isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g);
+    } else {
+        const float n_dot_h = saturate(dot3(frame.z, h));
+        d = anisoDistribution(n_dot_h, dot3(frame.x, h), dot3(frame.y, h), alpha);
+        anisoVisibilityAndG1Wo(dot3(frame.x, wi), dot3(frame.x, wo), dot3(frame.y, wi), dot3(frame.y, wo), n_dot_wi, n_dot_wo,
+                               alpha, g);
+    }
+    const V4 f = fresnel::schlick(f0, wo_dot_h);
+    return {S(d * g[0]) * f, pdfVisible(d, g[1])};
+}
+
+// Aniso.reflect (ggx.zig:302-345) / Iso.reflect (99-130)
+inline Micro reflect(V4 wo, float n_dot_wo, const float alpha[2], float specular_threshold, float xi0, float xi1, V4 f0,
+                     const Frame& frame, BxdfSample& result) {
+    float       n_dot_h;
+    const V4    h = anisoSample(wo, alpha, xi0, xi1, frame, n_dot_h);
+    const float wo_dot_h = clampDot(wo, h);
+    const V4    wi = normalize3(fma4(S(2.f * wo_dot_h), h, -wo));
+    const float n_dot_wi = frame.clampNdot(wi);
+    float       d, g[2];
+    if (alpha[0] == alpha[1]) {
+        const float alpha2 = alpha[0] * alpha[0];
+        d = isoDistribution(n_dot_h, alpha2);
+        isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g);
+    } else {
+        d = anisoDistribution(n_dot_h, dot3(frame.x, h), dot3(frame.y, h), alpha);
+        anisoVisibilityAndG1Wo(dot3(frame.x, wi), dot3(frame.x, wo), dot3(frame.y, wi), dot3(frame.y, wo), n_dot_wi, n_dot_wo,
+                               alpha, g);
+    }
+    const V4 f = fresnel::schlick(f0, wo_dot_h);
+    result.reflection = S(d * g[0]) * f;
+    result.wi = wi;
+    result.pdf = pdfVisible(d, g[1]);
+    result.path = PathInfo::reflection(alpha[1], specular_threshold);
+    return {h, n_dot_wi, wo_dot_h};
+}
+
+}  // namespace ggx
+
+namespace diffuse_micro {  // diffuse.zig:42-110
+
+inline float estimateContribution(const Luts& L, float alpha, float f0, float albedo) {
+    const float e_avg = L.E_avg(alpha, f0);
+    const float a = e_avg;
+    const float b = 1.f / (kPi * (1.f - e_avg)) * albedo;
+    return b / (a + b);
+}
+inline V4 evaluate(const Luts& L, V4 color, float n_dot_wi, float n_dot_wo, float alpha, float f0) {
+    const float e_wo = L.E(n_dot_wo, alpha, f0), e_wi = L.E(n_dot_wi, alpha, f0), e_avg = L.E_avg(alpha, f0);
+    return S(((1.f - e_wo) * (1.f - e_wi)) / (kPi * (1.f - e_avg))) * color;
+}
+inline BxdfResult reflection(const Luts& L, V4 color, float f0, float n_dot_wi, float n_dot_wo, float alpha) {
+    return {evaluate(L, color, n_dot_wi, n_dot_wo, alpha, f0), n_dot_wi * kPiInv};
+}
+inline ggx::Micro reflect(const Luts& L, V4 color, float f0, V4 wo, float n_dot_wo, const Frame& frame, float alpha, float xi0,
+                          float xi1, BxdfSample& result) {
+    const V4    is = hemisphereCosine(xi0, xi1);
+    const V4    wi = normalize3(frame.frameToWorld(is));
+    const V4    h = normalize3(wo + wi);
+    const float h_dot_wi = clampDot(h, wi);
+    const float n_dot_wi = frame.clampNdot(wi);
+    result.reflection = evaluate(L, color, n_dot_wi, n_dot_wo, alpha, f0);
+    result.wi = wi;
+    result.pdf = n_dot_wi * kPiInv;
+    result.path = PathInfo::diffuseReflection();
+    return {h, n_dot_wi, h_dot_wi};
+}
+
+}  // namespace diffuse_micro
+
+struct MaterialSample {
+    uint32_t kind;
+    Frame    frame;
+    V4       geo_n, n, wo;
+    float    alpha[2];
+    bool     can_evaluate, translucent, avoid_caustics;
+    // Debug
+    V4 albedo;
+    // Substitute
+    V4    f0;
+    float metallic, specular, specular_threshold, opacity;
+    Luts  luts;
+
+    bool sameHemisphere(V4 v) const { return dot3(geo_n, v) > 0.f; }
+
+    // ---- Substitute ----
+    BxdfResult baseEvaluate(V4 wi, V4 woo, V4 h, float wo_dot_h, bool force_disable_caustics) const {
+        const float n_dot_wi = frame.clampNdot(wi);
+        const float n_dot_wo = frame.clampAbsNdot(woo);
+        BxdfResult  d{S(0.f), 0.f};
+        float       dw = 0.f;
+        if (1.f != metallic) {
+            const V4    alb = S(opacity) * albedo;
+            const float f0m = hmax3(f0);
+            d = diffuse_micro::reflection(luts, alb, f0m, n_dot_wi, n_dot_wo, alpha[1]);
+            const float am = hmax3(albedo);
+            dw = diffuse_micro::estimateContribution(luts, alpha[1], f0m, am);
+        }
+        if ((force_disable_caustics || avoid_caustics) && alpha[1] <= specular_threshold) {
+            return {S(n_dot_wi) * d.reflection, dw * d.pdf};
+        }
+        const float      s = specular;
+        const BxdfResult gg = ggx::reflection(wi, woo, h, n_dot_wi, n_dot_wo, wo_dot_h, alpha, f0, frame);
+        const V4         mms = ggx::dspbrMicroEc(luts, f0, n_dot_wi, n_dot_wo, alpha[1]);
+        const float      pdf = dw * d.pdf + (1.f - dw) * gg.pdf;
+        return {S(n_dot_wi) * (d.reflection + S(s) * (gg.reflection + mms)), pdf};
+    }
+
+    void diffuseSample(float diffuse_weight, float xi0, float xi1, BxdfSample& result) const {
+        const float      n_dot_wo = frame.clampAbsNdot(wo);
+        const V4         alb = S(opacity) * albedo;
+        const float      f0m = hmax3(f0);
+        const ggx::Micro micro = diffuse_micro::reflect(luts, alb, f0m, wo, n_dot_wo, frame, alpha[1], xi0, xi1, result);
+        const BxdfResult gg = ggx::reflection(result.wi, wo, micro.h, micro.n_dot_wi, n_dot_wo, micro.h_dot_wi, alpha, f0, frame);
+        const V4         mms = ggx::dspbrMicroEc(luts, f0, micro.n_dot_wi, frame.clampNdot(wo), alpha[1]);
+        const float      s = specular;
+        result.reflection = S(micro.n_dot_wi) * (result.reflection + S(s) * (gg.reflection + mms));
+        result.pdf = diffuse_weight * result.pdf + (1.f - diffuse_weight) * gg.pdf;
+    }
+
+    void glossSample(float diffuse_weight, float xi0, float xi1, BxdfSample& result) const {
+        const float      s = specular;
+        const float      n_dot_wo = frame.clampAbsNdot(wo);
+        const ggx::Micro micro = ggx::reflect(wo, n_dot_wo, alpha, specular_threshold, xi0, xi1, f0, frame, result);
+        const V4         mms = ggx::dspbrMicroEc(luts, f0, micro.n_dot_wi, frame.clampNdot(wo), alpha[1]);
+        BxdfResult       d{S(0.f), 0.f};
+        if (diffuse_weight > 0.f) {
+            const V4    alb = S(opacity) * albedo;
+            const float f0m = hmax3(f0);
+            d = diffuse_micro::reflection(luts, alb, f0m, micro.n_dot_wi, n_dot_wo, alpha[1]);
+        }
+        result.reflection = S(micro.n_dot_wi) * (S(s) * (result.reflection + mms) + d.reflection);
+        result.pdf = (1.f - diffuse_weight) * result.pdf + diffuse_weight * d.pdf;
+    }
+
+    // ---- dispatch: material_sample.zig:47-60 ----
+    BxdfResult evaluate(V4 wi, bool force_disable_caustics) const {
+        if (ZYGPU_MAT_LIGHT == kind) return {S(0.f), 0.f};
+        if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:19-26
+            const float n_dot_wi = frame.clampNdot(wi);
+            const float pdf = n_dot_wi * kPiInv;
+            return {S(pdf) * albedo, pdf};
+        }
+        // Substitute.evaluate (opaque, uncoated): substitute_sample.zig:88-145
+        if (!sameHemisphere(wo)) return {S(0.f), 0.f};
+        const V4    h = normalize3(wo + wi);
+        const float wo_dot_h = clampDot(wo, h);
+        return baseEvaluate(wi, wo, h, wo_dot_h, force_disable_caustics);
+    }
+
+    // returns number of samples (0 or 1)
+    uint32_t sample(Sampler& sampler, BxdfSample& result) const {
+        if (ZYGPU_MAT_LIGHT == kind) return 0;
+        if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:28-47
+            float s2d[2];
+            sampler.sample2D(s2d);
+            const V4    is = hemisphereCosine(s2d[0], s2d[1]);
+            const V4    wi = normalize3(frame.frameToWorld(is));
+            const float n_dot_wi = frame.clampNdot(wi);
+            const float pdf = n_dot_wi * kPiInv;
+            result.reflection = S(pdf) * albedo;
+            result.wi = wi;
+            result.pdf = pdf;
+            result.split_weight = 1.f;
+            result.wavelength = 0.f;
+            result.path = PathInfo::diffuseReflection();
+            return 1;
+        }
+        // Substitute.sample (opaque, uncoated): substitute_sample.zig:147-234 -> baseSample 281-302
+        if (!sameHemisphere(wo)) return 0;
+        result.split_weight = 1.f;
+        result.wavelength = 0.f;
+        float dw = 0.f;
+        if (1.f != metallic) {
+            const float n_dot_wo = frame.clampAbsNdot(wo);
+            dw = diffuse_micro::estimateContribution(luts, alpha[1], hmax3(f0), hmax3(albedo));
+            (void)n_dot_wo;
+        }
+        float s3[3];
+        sampler.sample3D(s3);
+        if (s3[0] < dw) diffuseSample(dw, s3[1], s3[2], result);
+        else glossSample(dw, s3[1], s3[2], result);
+        if (0.f == result.pdf) return 0;
+        return 1;
+    }
+};
+
+// Material.sample (material.zig:184-194) for the kinds in scope
+inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDesc& scene, V4 wo, const Renderstate& rs) {
+    MaterialSample s{};
+    s.kind = m.kind;
+    s.geo_n = rs.geo_n;
+    s.n = rs.n;
+    s.wo = wo;
+    s.translucent = false;
+    s.avoid_caustics = !rs.caustics;
+    s.luts.l = &scene.luts;
+    if (ZYGPU_MAT_DEBUG == m.kind) {
+        // debug_material.zig:20-28 + Base.initTBN (sample_base.zig:49-62)
+        const V4   n = cross3(rs.t, rs.b);
+        const bool same_side = dot3(n, rs.n) > 0.f;
+        s.albedo = same_side ? ld3(m.color_a) : ld3(m.color_b);
+        s.frame = {rs.t, rs.b, rs.n};
+        s.alpha[0] = s.alpha[1] = 1.f;
+        s.can_evaluate = true;
+    } else if (ZYGPU_MAT_LIGHT == m.kind) {
+        s.frame = {rs.t, rs.b, rs.n};  // light_sample.zig:9-11
+        s.alpha[0] = s.alpha[1] = 0.f;
+        s.can_evaluate = false;
+    } else {
+        // substitute_material.zig:114-221 (uniform values, no coating / flakes / normal map / rotation)
+        const V4    color = ld3(m.color_a);
+        const float roughness = ggx::clampRoughness(m.roughness);
+        float       alpha[2];
+        if (m.anisotropy > 0.f) {  // anisotropicAlpha, substitute_material.zig:298-305
+            const float rv = ggx::clampRoughness(roughness * (1.f - m.anisotropy));
+            alpha[0] = roughness * roughness;
+            alpha[1] = rv * rv;
+        } else {
+            alpha[0] = alpha[1] = roughness * roughness;
+        }
+        const float ior = m.ior, ior_outer = rs.ior, ior_medium = rs.ior;
+        // Surface.init (substitute_sample.zig:38-86); regularizeAlpha is the identity for reg_weight == 0
+        s.albedo = S(1.f - m.metallic) * color;
+        s.alpha[0] = alpha[0];
+        s.alpha[1] = alpha[1];
+        s.can_evaluate = ior != ior_medium;
+        const float f0 = fresnel::iorToF0(ior, ior_outer);
+        s.f0 = lerp4(S(f0), color, S(m.metallic));
+        s.metallic = m.metallic;
+        s.specular = m.specular;
+        s.specular_threshold = scene.specular_threshold;
+        s.opacity = 1.f - (0.5f * 0.f);
+        s.frame = {rs.t, rs.b, rs.n};
+    }
+    return s;
+}
+
+}  // namespace orc

@@ -1,0 +1,145 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing in zyg_amd/ (the product) may include, link or call this.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+//
+// CPU restatement of the reference's base/math subset used by the integration loop.
+// Lane-wise f32, no implicit contraction (build with -ffp-contract=off); fused multiply-add only
+// where the reference writes @mulAdd.  min/max are the x86 `a < b ? a : b` forms
+// (reference src/base/math/util.zig:17-29).
+#pragma once
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace orc {
+
+struct V4 {
+    float v[4];
+    float& operator[](int i) { return v[i]; }
+    float operator[](int i) const { return v[i]; }
+};
+
+inline V4 S(float s) { return {{s, s, s, s}}; }
+inline V4 mk(float x, float y, float z, float w = 0.f) { return {{x, y, z, w}}; }
+inline V4 ld3(const float* p) { return {{p[0], p[1], p[2], 0.f}}; }
+inline V4 ld4(const float* p) { return {{p[0], p[1], p[2], p[3]}}; }
+
+inline V4 operator+(V4 a, V4 b) { return {{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]}}; }
+inline V4 operator-(V4 a, V4 b) { return {{a[0] - b[0], a[1] - b[1], a[2] - b[2], a[3] - b[3]}}; }
+inline V4 operator*(V4 a, V4 b) { return {{a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]}}; }
+inline V4 operator/(V4 a, V4 b) { return {{a[0] / b[0], a[1] / b[1], a[2] / b[2], a[3] / b[3]}}; }
+inline V4 operator-(V4 a) { return {{-a[0], -a[1], -a[2], -a[3]}}; }
+inline V4& operator+=(V4& a, V4 b) { return a = a + b; }
+inline V4& operator*=(V4& a, V4 b) { return a = a * b; }
+inline V4& operator/=(V4& a, V4 b) { return a = a / b; }
+
+inline float mn(float x, float y) { return x < y ? x : y; }
+inline float mx(float x, float y) { return y < x ? x : y; }
+inline float clampf(float x, float lo, float hi) { return mn(mx(x, lo), hi); }
+inline float saturate(float x) { return clampf(x, 0.f, 1.f); }
+// std.math.clamp (used by rectangle.zig SphQuad): max(lower, min(val, upper)) via @max/@min
+inline float stdClamp(float val, float lo, float hi) { return std::fmax(lo, std::fmin(val, hi)); }
+
+inline V4 min4(V4 a, V4 b) { return {{mn(a[0], b[0]), mn(a[1], b[1]), mn(a[2], b[2]), mn(a[3], b[3])}}; }
+inline V4 max4(V4 a, V4 b) { return {{mx(a[0], b[0]), mx(a[1], b[1]), mx(a[2], b[2]), mx(a[3], b[3])}}; }
+inline V4 fma4(V4 a, V4 b, V4 c) {
+    return {{std::fmaf(a[0], b[0], c[0]), std::fmaf(a[1], b[1], c[1]), std::fmaf(a[2], b[2], c[2]), std::fmaf(a[3], b[3], c[3])}};
+}
+inline V4 sqrt4(V4 a) { return {{std::sqrt(a[0]), std::sqrt(a[1]), std::sqrt(a[2]), std::sqrt(a[3])}}; }
+
+// vector4.zig:37-60
+inline float dot3(V4 a, V4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline float squaredLength3(V4 a) { return dot3(a, a); }
+inline float length3(V4 a) { return std::sqrt(dot3(a, a)); }
+inline float squaredDistance3(V4 a, V4 b) { return squaredLength3(a - b); }
+inline float distance3(V4 a, V4 b) { return length3(a - b); }
+inline V4    normalize3(V4 a) { return a / S(length3(a)); }
+inline float hmax3(V4 a) { return mx(a[0], mx(a[1], a[2])); }
+inline float hmin3(V4 a) { return mn(a[0], mn(a[1], a[2])); }
+inline float hmax4(V4 a) { return mx(a[0], mx(a[1], mx(a[2], a[3]))); }
+inline float hmin4(V4 a) { return mn(a[0], mn(a[1], mn(a[2], a[3]))); }
+inline float average3(V4 a) { return (a[0] + a[1] + a[2]) / 3.f; }
+
+// vector4.zig:73-92
+inline V4 cross3(V4 a, V4 b) {
+    const V4 t0 = {{b[1], b[2], b[0], b[3]}};
+    const V4 t1 = {{a[1], a[2], a[0], a[3]}};
+    const V4 t2 = fma4(t0, a, -(t1 * b));
+    return {{t2[1], t2[2], t2[0], t2[3]}};
+}
+
+// vector4.zig:121 gramSchmidt; util.zig:3-16 lerp
+inline V4    gramSchmidt(V4 v, V4 w) { return fma4(S(-dot3(v, w)), w, v); }
+inline float lerpf(float a, float b, float t) { return std::fmaf(1.f - t, a, t * b); }
+inline V4    lerp4(V4 a, V4 b, V4 t) { return fma4(S(1.f) - t, a, t * b); }
+
+// vector4.zig:98-110 (Duff et al.)
+inline void orthonormalBasis3(V4 n, V4& t, V4& b) {
+    const float sign = std::copysign(1.f, n[2]);
+    const float c = -1.f / (sign + n[2]);
+    const float d = n[0] * n[1] * c;
+    t = mk(1.f + sign * n[0] * n[0] * c, sign * d, -sign * n[0]);
+    b = mk(d, sign + n[1] * n[1] * c, -n[1]);
+}
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kPiInv = float(1.0 / 3.14159265358979323846);  // math.zig:112
+constexpr float kDotMin = 0.00001f;                            // safe.zig:5
+inline float    clampDot(V4 a, V4 b) { return clampf(dot3(a, b), kDotMin, 1.f); }
+inline float    clampAbsDot(V4 a, V4 b) { return clampf(std::fabs(dot3(a, b)), kDotMin, 1.f); }
+
+struct Frame {  // frame.zig:5-69
+    V4 x, y, z;
+    V4 frameToWorld(V4 v) const {
+        V4 r = S(v[0]) * x;
+        r = fma4(S(v[1]), y, r);
+        return fma4(S(v[2]), z, r);
+    }
+    V4 worldToFrame(V4 v) const {
+        const V4 t = v * x, b = v * y, n = v * z;
+        return mk(t[0] + t[1] + t[2], b[0] + b[1] + b[2], n[0] + n[1] + n[2]);
+    }
+    float clampNdot(V4 v) const { return clampDot(z, v); }
+    float clampAbsNdot(V4 v) const { return clampAbsDot(z, v); }
+    float nDot(V4 v) const { return dot3(z, v); }
+};
+
+// sampling.zig:8-54
+inline void diskConcentric(float u0, float u1, float& ox, float& oy) {
+    const float s0 = (u0 * 2.f) - 1.f, s1 = (u1 * 2.f) - 1.f;
+    if (0.f == s0 && 0.f == s1) {
+        ox = oy = 0.f;
+        return;
+    }
+    float r, theta;
+    if (std::fabs(s0) > std::fabs(s1)) {
+        r = s0;
+        theta = (kPi / 4.f) * (s1 / s0);
+    } else {
+        r = s1;
+        theta = (kPi / 2.f) - (kPi / 4.f) * (s0 / s1);
+    }
+    const float sin_theta = std::sin(theta), cos_theta = std::cos(theta);
+    ox = cos_theta * r;
+    oy = sin_theta * r;
+}
+inline V4 hemisphereCosine(float u0, float u1) {
+    float x, y;
+    diskConcentric(u0, u1, x, y);
+    const float z = std::sqrt(mx(0.f, 1.f - x * x - y * y));
+    return mk(x, y, z);
+}
+
+// encoding.zig:56-108
+inline float unorm16ToFloat(uint16_t n) { return float(n) * (1.f / 65535.f); }
+inline float snorm16ToFloat(uint16_t n) { return std::fmaf(float(n), 1.f / 32768.f, -1.f); }
+inline V4    octDecode(float o0, float o1) {
+    V4          v = mk(o0, o1, -1.f + std::fabs(o0) + std::fabs(o1));
+    const float t = mx(v[2], 0.f);
+    v[0] += v[0] > 0.f ? -t : t;
+    v[1] += v[1] > 0.f ? -t : t;
+    return normalize3(v);
+}
+
+}  // namespace orc

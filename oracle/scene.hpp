@@ -1,0 +1,521 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see omath.hpp).
+//
+// Scene access + ray casting over the compiled scene (include/zygpu.h), restating:
+//   Ray                         src/base/math/ray.zig:11-29
+//   ComposedTransformation      src/core/scene/composed_transformation.zig:70-130
+//   bvh.Node.intersect          src/core/scene/bvh/node.zig:73-87,  NodeStack node_stack.zig:1-30
+//   AABB.intersect              src/base/math/aabb.zig:46-60
+//   PropBvh intersect/visibility src/core/scene/prop/prop_tree.zig:56-116,185-240
+//   Prop intersect/visibility   src/core/scene/prop/prop.zig:163-237
+//   TriangleTree                src/core/scene/shape/triangle/triangle_tree.zig:46-109,197-242
+//   triangle.intersect          src/core/scene/shape/triangle/triangle.zig:26-80
+//   TriangleMesh.fragment       src/core/scene/shape/triangle/triangle_mesh.zig:310-335, triangle_data.zig:106-130
+//   Rectangle                   src/core/scene/shape/rectangle.zig:30-152
+//   ray offset                  src/core/scene/ray_offset.zig:5-31, shape/intersection.zig:115-123
+#pragma once
+
+#include "../include/zygpu.h"
+#include "omath.hpp"
+
+namespace orc {
+
+constexpr float    kRayMaxT = 2.14748313e+09f;  // ray_offset.zig:5
+constexpr uint32_t kNull = 0xFFFFFFFFu;
+
+struct Ray {
+    V4    origin, direction, inv_direction;
+    float min_t, max_t;
+    static Ray init(V4 o, V4 d, float mint, float maxt) {
+        Ray r;
+        r.origin = o;
+        r.direction = d;
+        r.inv_direction = S(1.f) / mk(d[0], d[1], d[2], 1.f);
+        r.min_t = mint;
+        r.max_t = maxt;
+        return r;
+    }
+    V4 point(float t) const { return fma4(S(t), direction, origin); }
+};
+
+struct Trafo {  // rotation rows carry the scale in w
+    V4 r[3];
+    V4 position;
+    static Trafo from(const ZygpuTrafo& t) { return {{ld4(t.r[0]), ld4(t.r[1]), ld4(t.r[2])}, ld4(t.position)}; }
+    float scaleX() const { return r[0][3]; }
+    float scaleY() const { return r[1][3]; }
+    float scaleZ() const { return r[2][3]; }
+    V4    scale() const { return mk(r[0][3], r[1][3], r[2][3], 1.f); }
+    V4    transformVector(V4 v) const {  // matrix3x3.zig:113-126
+        V4 res = S(v[0]) * r[0];
+        res = fma4(S(v[1]), r[1], res);
+        return fma4(S(v[2]), r[2], res);
+    }
+    V4 transformVectorTransposed(V4 v) const {  // matrix3x3.zig:128-139
+        const V4 x = v * r[0], y = v * r[1], z = v * r[2];
+        return mk(x[0] + x[1] + x[2], y[0] + y[1] + y[2], z[0] + z[1] + z[2]);
+    }
+    V4 objectToWorldVector(V4 v) const {
+        const V4 s = scale();
+        const V4 a = r[0] * S(s[0]), b = r[1] * S(s[1]), c = r[2] * S(s[2]);
+        V4       res = S(v[0]) * a;
+        res = fma4(S(v[1]), b, res);
+        return fma4(S(v[2]), c, res);
+    }
+    V4  objectToWorldPoint(V4 p) const { return objectToWorldVector(p) + position; }
+    V4  objectToWorldNormal(V4 n) const { return transformVector(n); }
+    V4  frameToWorldPoint(V4 p) const { return objectToWorldNormal(p) + position; }
+    V4  worldToObjectNormal(V4 n) const { return transformVectorTransposed(n); }
+    V4  worldToObjectVector(V4 v) const { return transformVectorTransposed(v) / scale(); }
+    V4  worldToObjectPoint(V4 p) const { return worldToObjectVector(p - position); }
+    V4  worldToFramePoint(V4 p) const { return worldToObjectNormal(p - position); }
+    Ray worldToObjectRay(const Ray& ray) const {
+        return Ray::init(worldToObjectPoint(ray.origin), worldToObjectVector(ray.direction), ray.min_t, ray.max_t);
+    }
+};
+
+struct Intersection {  // shape/intersection.zig:46-62
+    float    t, u, v;
+    uint32_t primitive;
+    Trafo    trafo;
+};
+
+struct Fragment {  // shape/intersection.zig:64-124 (event is always .Pass: no volumes in scope)
+    Intersection isec;
+    uint32_t     prop = kNull, part = 0;
+    V4           p, geo_n, t, b, n, uvw;
+
+    bool hit() const { return kNull != prop; }
+    bool sameHemisphere(V4 v) const { return dot3(geo_n, v) > 0.f; }
+};
+
+// ray_offset.zig:14-31
+inline V4 offsetRay(V4 p, V4 n) {
+    const float origin = 1.f / 32.f, float_scale = 1.f / 65536.f, int_scale = 256.f;
+    V4          r;
+    for (int i = 0; i < 4; ++i) {
+        const int32_t of_i = int32_t(int_scale * n[i]);
+        int32_t       p_ii;
+        std::memcpy(&p_ii, &p.v[i], 4);
+        const int32_t in = int32_t(uint32_t(p_ii) - uint32_t(of_i)), ip = int32_t(uint32_t(p_ii) + uint32_t(of_i));
+        float         p_in, p_ip;
+        std::memcpy(&p_in, &in, 4);
+        std::memcpy(&p_ip, &ip, 4);
+        const float p_i = p[i] < 0.f ? p_in : p_ip;
+        const float mad = std::fmaf(float_scale, n[i], p[i]);
+        r[i] = std::fabs(p[i]) < origin ? mad : p_i;
+    }
+    r[3] = 0.f;
+    return r;
+}
+
+inline V4 fragOffsetP(const Fragment& f, V4 v) {  // intersection.zig:115-119
+    const V4 n = f.sameHemisphere(v) ? f.geo_n : -f.geo_n;
+    return offsetRay(fma4(S(f.uvw[3]), n, f.p), n);
+}
+inline Ray fragOffsetRay(const Fragment& f, V4 dir) { return Ray::init(fragOffsetP(f, dir), dir, 0.f, kRayMaxT); }
+
+struct Counters {  // what B_trav is computed from
+    uint64_t camera_samples = 0, extension_rays = 0, shadow_rays = 0, nodes_fetched = 0, triangles_tested = 0,
+             instances_tested = 0;
+    void add(const Counters& o) {
+        camera_samples += o.camera_samples;
+        extension_rays += o.extension_rays;
+        shadow_rays += o.shadow_rays;
+        nodes_fetched += o.nodes_fetched;
+        triangles_tested += o.triangles_tested;
+        instances_tested += o.instances_tested;
+    }
+};
+
+struct NodeStack {  // node_stack.zig
+    uint32_t end = 0;
+    uint32_t stack[127];
+    void     push(uint32_t v) { stack[end++] = v; }
+    uint32_t pop() { return 0 == end ? kNull : stack[--end]; }
+};
+
+// node.zig:73-87
+inline float nodeIntersect(const ZygpuBvhNode& n, const Ray& ray) {
+    const V4    lower = (mk(n.min[0], n.min[1], n.min[2], 0.f) - ray.origin) * ray.inv_direction;
+    const V4    upper = (mk(n.max[0], n.max[1], n.max[2], 0.f) - ray.origin) * ray.inv_direction;
+    const V4    t0 = min4(lower, upper), t1 = max4(lower, upper);
+    const float tboxmin = hmax4(mk(t0[0], t0[1], t0[2], ray.min_t));
+    const float tboxmax = hmin4(mk(t1[0], t1[1], t1[2], ray.max_t));
+    return tboxmin <= tboxmax ? tboxmin : FLT_MAX;
+}
+
+// aabb.zig:46-60
+inline bool aabbIntersect(const ZygpuAabb& a, const Ray& ray) {
+    const V4    lower = (ld4(a.min) - ray.origin) * ray.inv_direction;
+    const V4    upper = (ld4(a.max) - ray.origin) * ray.inv_direction;
+    const V4    t0 = min4(lower, upper), t1 = max4(lower, upper);
+    const float tboxmin = hmax4(mk(t0[0], t0[1], t0[2], ray.min_t));
+    const float tboxmax = hmin4(mk(t1[0], t1[1], t1[2], ray.max_t));
+    return tboxmin <= tboxmax;
+}
+
+// triangle.zig:26-52; returns hit flag
+inline bool triangleIntersect(const Ray& ray, V4 a, V4 b, V4 c, float& ht, float& hu, float& hv) {
+    const V4    e1 = b - a, e2 = c - a;
+    const V4    tvec = ray.origin - a;
+    const V4    pvec = cross3(ray.direction, e2);
+    const V4    qvec = cross3(tvec, e1);
+    const float e1_d_pv = dot3(e1, pvec), tv_d_pv = dot3(tvec, pvec);
+    const float di_d_qv = dot3(ray.direction, qvec), e2_d_qv = dot3(e2, qvec);
+    const float inv_det = 1.f / e1_d_pv;
+    const float u = tv_d_pv * inv_det, v = di_d_qv * inv_det, hit_t = e2_d_qv * inv_det;
+    const float uv = u + v;
+    if (u >= 0.f && 1.f >= u && v >= 0.f && 1.f >= uv && hit_t >= ray.min_t && ray.max_t >= hit_t) {
+        ht = hit_t;
+        hu = u;
+        hv = v;
+        return true;
+    }
+    return false;
+}
+
+struct MeshView {
+    const ZygpuMesh* m;
+    // triangle_data.zig:62-64: an unaligned 16-byte read; lane w is the next float in the array
+    V4 position(uint32_t index) const { return ld4(m->positions + size_t(index) * 3); }
+    V4 shadingNormal(uint32_t index) const {
+        return octDecode(snorm16ToFloat(m->normals[2 * index]), snorm16ToFloat(m->normals[2 * index + 1]));
+    }
+};
+
+// triangle_tree.zig:46-109 (closest hit; ray already in object space)
+inline bool meshIntersect(const ZygpuMesh& mesh, Ray local_ray, Intersection& isec, Counters& cnt) {
+    const MeshView mv{&mesh};
+    NodeStack      stack;
+    uint32_t       n = 0;
+    float          ht = 0.f, hu = 0.f, hv = 0.f;
+    uint32_t       primitive = kNull;
+    cnt.nodes_fetched += 1;  // root
+    while (kNull != n) {
+        const ZygpuBvhNode& node = mesh.nodes[n];
+        if (0 != node.count) {
+            for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
+                cnt.triangles_tested += 1;
+                const uint32_t* tri = mesh.triangles + size_t(i) * 3;
+                float           t, u, v;
+                if (triangleIntersect(local_ray, mv.position(tri[0]), mv.position(tri[1]), mv.position(tri[2]), t, u, v)) {
+                    local_ray.max_t = t;
+                    ht = t;
+                    hu = u;
+                    hv = v;
+                    primitive = i;
+                }
+            }
+            n = stack.pop();
+            continue;
+        }
+        uint32_t a = node.children_or_first, b = a + 1;
+        cnt.nodes_fetched += 2;
+        float dista = nodeIntersect(mesh.nodes[a], local_ray);
+        float distb = nodeIntersect(mesh.nodes[b], local_ray);
+        if (dista > distb) {
+            std::swap(a, b);
+            std::swap(dista, distb);
+        }
+        if (FLT_MAX == dista) {
+            n = stack.pop();
+        } else {
+            n = a;
+            if (FLT_MAX != distb) stack.push(b);
+        }
+    }
+    if (kNull == primitive) return false;
+    isec.t = ht;
+    isec.u = hu;
+    isec.v = hv;
+    isec.primitive = primitive;
+    return true;
+}
+
+// triangle_tree.zig:197-242 (any hit)
+inline bool meshIntersectP(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt) {
+    const MeshView mv{&mesh};
+    NodeStack      stack;
+    uint32_t       n = 0;
+    cnt.nodes_fetched += 1;
+    while (kNull != n) {
+        const ZygpuBvhNode& node = mesh.nodes[n];
+        if (0 != node.count) {
+            for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
+                cnt.triangles_tested += 1;
+                const uint32_t* tri = mesh.triangles + size_t(i) * 3;
+                float           t, u, v;
+                if (triangleIntersect(ray, mv.position(tri[0]), mv.position(tri[1]), mv.position(tri[2]), t, u, v)) return true;
+            }
+            n = stack.pop();
+            continue;
+        }
+        uint32_t a = node.children_or_first, b = a + 1;
+        cnt.nodes_fetched += 2;
+        float dista = nodeIntersect(mesh.nodes[a], ray);
+        float distb = nodeIntersect(mesh.nodes[b], ray);
+        if (dista > distb) {
+            std::swap(a, b);
+            std::swap(dista, distb);
+        }
+        if (FLT_MAX == dista) {
+            n = stack.pop();
+        } else {
+            n = a;
+            if (FLT_MAX != distb) stack.push(b);
+        }
+    }
+    return false;
+}
+
+// rectangle.zig:30-62 / 126-152 (intersect and intersectP share the test)
+inline bool rectangleIntersect(const Ray& ray, const Trafo& trafo, float& out_t, float& out_u, float& out_v) {
+    const V4    n = trafo.r[2];
+    const float d = dot3(n, trafo.position);
+    const float hit_t = -(dot3(n, ray.origin) - d) / dot3(n, ray.direction);
+    if (hit_t >= ray.min_t && ray.max_t >= hit_t) {
+        const V4    p = ray.point(hit_t);
+        const V4    k = p - trafo.position;
+        const V4    t = -trafo.r[0];
+        const float u = dot3(t, k) / (0.5f * trafo.scaleX());
+        if (u > 1.f || u < -1.f) return false;
+        const V4    b = -trafo.r[1];
+        const float v = dot3(b, k) / (0.5f * trafo.scaleY());
+        if (v > 1.f || v < -1.f) return false;
+        out_t = hit_t;
+        out_u = u;
+        out_v = v;
+        return true;
+    }
+    return false;
+}
+
+// rectangle.zig:102-124
+inline void rectangleFragment(const Ray& ray, Fragment& frag) {
+    const Trafo& tr = frag.isec.trafo;
+    const V4     p = ray.point(frag.isec.t);
+    const V4     n = tr.r[2], t = -tr.r[0], b = -tr.r[1];
+    frag.p = p;
+    frag.t = t;
+    frag.b = b;
+    frag.n = n;
+    frag.geo_n = n;
+    if (tr.scaleZ() < 0.f) {
+        const V4    k = p - tr.position;
+        const float u = dot3(t, k) * 2.f, v = dot3(b, k) * 2.f;
+        frag.uvw = mk(0.5f * (u + 1.f), 0.5f * (v + 1.f), 0.f, 0.f);
+    } else {
+        frag.uvw = mk(0.5f * (frag.isec.u + 1.f), 0.5f * (frag.isec.v + 1.f), 0.f, 0.f);
+    }
+    frag.part = 0;
+}
+
+// triangle.zig:102-149
+inline void interpolate2(const float* a, const float* b, const float* c, float u, float v, float out[2]) {
+    const float w = 1.f - u - v;
+    for (int i = 0; i < 2; ++i) out[i] = std::fmaf(a[i], w, std::fmaf(b[i], u, c[i] * v));
+}
+inline V4 interpolate3(V4 a, V4 b, V4 c, float u, float v) {
+    const float w = 1.f - u - v;
+    return fma4(a, S(w), fma4(b, S(u), c * S(v)));
+}
+inline void positionDifferentials(V4 pa, V4 pb, V4 pc, const float* uva, const float* uvb, const float* uvc, V4& dpdu, V4& dpdv) {
+    const float duv02[2] = {uva[0] - uvc[0], uva[1] - uvc[1]};
+    const float duv12[2] = {uvb[0] - uvc[0], uvb[1] - uvc[1]};
+    const float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+    const V4    dp02 = pa - pc, dp12 = pb - pc;
+    if (0.f == std::fabs(determinant)) {
+        const V4 ng = normalize3(cross3(pc - pa, pb - pa));
+        if (std::fabs(ng[0]) > std::fabs(ng[1])) {
+            dpdu = mk(-ng[2], 0.f, ng[0], 0.f) / S(std::sqrt(ng[0] * ng[0] + ng[2] * ng[2]));
+        } else {
+            dpdu = mk(0.f, ng[2], -ng[1], 0.f) / S(std::sqrt(ng[1] * ng[1] + ng[2] * ng[2]));
+        }
+        dpdv = cross3(ng, dpdu);
+    } else {
+        const float invdet = 1.f / determinant;
+        dpdu = S(invdet) * fma4(S(duv12[1]), dp02, S(-duv02[1]) * dp12);
+        dpdv = S(invdet) * fma4(S(-duv12[0]), dp02, S(duv02[0]) * dp12);
+    }
+}
+
+// triangle_mesh.zig:310-335 + triangle_data.zig:106-149
+inline void meshFragment(const ZygpuMesh& mesh, Fragment& frag) {
+    const MeshView mv{&mesh};
+    const uint32_t prim = frag.isec.primitive;
+    frag.part = mesh.triangle_parts[prim];
+    const float     hit_u = frag.isec.u, hit_v = frag.isec.v;
+    const uint32_t* tri = mesh.triangles + size_t(prim) * 3;
+    const V4        pa = mv.position(tri[0]), pb = mv.position(tri[1]), pc = mv.position(tri[2]);
+
+    const V4 geo_n = normalize3(cross3(pb - pa, pc - pa));
+    frag.geo_n = frag.isec.trafo.objectToWorldNormal(geo_n);
+
+    const V4     p = interpolate3(pa, pb, pc, hit_u, hit_v);
+    const float* uva = mesh.uvs + size_t(tri[0]) * 2;
+    const float* uvb = mesh.uvs + size_t(tri[1]) * 2;
+    const float* uvc = mesh.uvs + size_t(tri[2]) * 2;
+    float        uv[2];
+    interpolate2(uva, uvb, uvc, hit_u, hit_v, uv);
+
+    const V4 nb = mv.shadingNormal(tri[1]), na = mv.shadingNormal(tri[0]), nc = mv.shadingNormal(tri[2]);
+    const V4 ni = normalize3(interpolate3(na, nb, nc, hit_u, hit_v));
+
+    V4 dpdu, dpdv;
+    positionDifferentials(pa, pb, pc, uva, uvb, uvc, dpdu, dpdv);
+    const V4 t = normalize3(gramSchmidt(dpdu, ni));
+    const V4 b = normalize3(gramSchmidt(dpdv, ni));
+
+    const Trafo& tr = frag.isec.trafo;
+    frag.p = tr.objectToWorldPoint(p);
+    frag.t = tr.objectToWorldNormal(t);
+    frag.b = tr.objectToWorldNormal(b);
+    frag.n = tr.objectToWorldNormal(ni);
+    frag.uvw = mk(uv[0], uv[1], 0.f, 0.f);
+}
+
+struct SceneView {
+    const ZygpuSceneDesc* d;
+
+    Trafo propTrafo(uint32_t p) const { return Trafo::from(d->trafos[p]); }
+    const ZygpuMaterial& propMaterial(uint32_t prop, uint32_t part) const {
+        return d->materials[d->material_ids[d->props[prop].parts_start + part]];
+    }
+    uint32_t propLightId(uint32_t prop, uint32_t part) const { return d->light_ids[d->props[prop].parts_start + part]; }
+
+    // prop.zig:39-49
+    static bool visible(uint32_t flags, uint32_t depth_surface) {
+        if (0 == depth_surface) return 0 != (flags & ZYGPU_PROP_VISIBLE_IN_CAMERA);
+        return 0 != (flags & ZYGPU_PROP_VISIBLE_IN_REFLECTION);
+    }
+
+    // prop.zig:163-197
+    bool propIntersect(uint32_t p, const Ray& ray, uint32_t depth_surface, Intersection& isec, Counters& cnt) const {
+        const ZygpuProp& prop = d->props[p];
+        if (!visible(prop.flags, depth_surface)) return false;
+        cnt.instances_tested += 1;
+        if (!aabbIntersect(d->aabbs[p], ray)) return false;
+        const Trafo trafo = propTrafo(p);
+        if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
+            float t, u, v;
+            if (!rectangleIntersect(ray, trafo, t, u, v)) return false;
+            isec.t = t;
+            isec.u = u;
+            isec.v = v;
+            isec.primitive = 0;
+            isec.trafo = trafo;
+            return true;
+        }
+        if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+            if (!meshIntersect(d->meshes[prop.mesh], trafo.worldToObjectRay(ray), isec, cnt)) return false;
+            isec.trafo = trafo;
+            return true;
+        }
+        return false;
+    }
+
+    // prop.zig:199-237 (non-volumetric, no opacity masks): true = unoccluded
+    bool propVisibility(uint32_t p, const Ray& ray, Counters& cnt) const {
+        const ZygpuProp& prop = d->props[p];
+        if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) return true;
+        cnt.instances_tested += 1;
+        if (!aabbIntersect(d->aabbs[p], ray)) return true;
+        const Trafo trafo = propTrafo(p);
+        if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
+            float t, u, v;
+            return !rectangleIntersect(ray, trafo, t, u, v);
+        }
+        if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+            return !meshIntersectP(d->meshes[prop.mesh], trafo.worldToObjectRay(ray), cnt);
+        }
+        return true;
+    }
+
+    void shapeFragment(uint32_t prop, const Ray& ray, Fragment& frag) const {
+        const ZygpuProp& p = d->props[prop];
+        if (ZYGPU_SHAPE_RECTANGLE == p.shape) rectangleFragment(ray, frag);
+        else meshFragment(d->meshes[p.mesh], frag);
+    }
+
+    // prop_tree.zig:56-116 over the solid TLAS; shrinks ray.max_t
+    bool intersect(Ray& ray, uint32_t depth_surface, Fragment& frag, Counters& cnt) const {
+        const ZygpuPropTree& tree = d->solid;
+        NodeStack            stack;
+        uint32_t             n = 0 == tree.num_nodes ? kNull : 0;
+        Intersection         isec{};
+        uint32_t             prop = kNull;
+        if (kNull != n) cnt.nodes_fetched += 1;
+        while (kNull != n) {
+            const ZygpuBvhNode& node = tree.nodes[n];
+            if (0 != node.count) {
+                for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
+                    const uint32_t p = tree.indices[i];
+                    Intersection   candidate = isec;
+                    if (propIntersect(p, ray, depth_surface, candidate, cnt)) {
+                        isec = candidate;
+                        ray.max_t = isec.t;
+                        prop = p;
+                    }
+                }
+                n = stack.pop();
+                continue;
+            }
+            uint32_t a = node.children_or_first, b = a + 1;
+            cnt.nodes_fetched += 2;
+            float dista = nodeIntersect(tree.nodes[a], ray);
+            float distb = nodeIntersect(tree.nodes[b], ray);
+            if (dista > distb) {
+                std::swap(a, b);
+                std::swap(dista, distb);
+            }
+            if (FLT_MAX == dista) {
+                n = stack.pop();
+            } else {
+                n = a;
+                if (FLT_MAX != distb) stack.push(b);
+            }
+        }
+        const bool hit = kNull != prop;
+        if (hit) {
+            frag.isec = isec;
+            shapeFragment(prop, ray, frag);
+        }
+        frag.prop = prop;
+        return hit;
+    }
+
+    // prop_tree.zig:185-240 (solid TLAS; the volume TLAS is empty in scope, scene.zig:229-235)
+    bool visibility(const Ray& ray, Counters& cnt) const {
+        const ZygpuPropTree& tree = d->solid;
+        NodeStack            stack;
+        uint32_t             n = 0 == tree.num_nodes ? kNull : 0;
+        if (kNull != n) cnt.nodes_fetched += 1;
+        while (kNull != n) {
+            const ZygpuBvhNode& node = tree.nodes[n];
+            if (0 != node.count) {
+                for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
+                    if (!propVisibility(tree.indices[i], ray, cnt)) return false;
+                }
+                n = stack.pop();
+                continue;
+            }
+            uint32_t a = node.children_or_first, b = a + 1;
+            cnt.nodes_fetched += 2;
+            float dista = nodeIntersect(tree.nodes[a], ray);
+            float distb = nodeIntersect(tree.nodes[b], ray);
+            if (dista > distb) {
+                std::swap(a, b);
+                std::swap(dista, distb);
+            }
+            if (FLT_MAX == dista) {
+                n = stack.pop();
+            } else {
+                n = a;
+                if (FLT_MAX != distb) stack.push(b);
+            }
+        }
+        return true;
+    }
+};
+
+}  // namespace orc

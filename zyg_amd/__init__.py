@@ -1,0 +1,309 @@
+"""zyg_amd — MI355X wavefront path-tracing core behind zyg's `su_*` C ABI.
+
+Python host mirror of the reference's ctypes clients (reference src/capi-test/test.py:45-261,
+src/blender-plugin/engine.py:25-381): a thin ctypes layer over `libzyg_amd.so`, which exports the
+`su_*` surface (include/zyg_capi.h) and the inner `zygpu_*` ABI (include/zygpu.h).  There is no
+CPU fallback: rendering needs the HIP library and a GPU and fails loudly otherwise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("ZYG_AMD_LIB", os.path.join(_HERE, "libzyg_amd.so"))
+
+NULL = 0xFFFFFFFF
+FILTER_TAPS = 30
+
+
+class BvhNode(ctypes.Structure):
+    _fields_ = [("min", ctypes.c_float * 3), ("children_or_first", ctypes.c_uint32),
+                ("max", ctypes.c_float * 3), ("count", ctypes.c_uint32)]
+
+
+class Trafo(ctypes.Structure):
+    _fields_ = [("r", (ctypes.c_float * 4) * 3), ("position", ctypes.c_float * 4)]
+
+
+class Aabb(ctypes.Structure):
+    _fields_ = [("min", ctypes.c_float * 4), ("max", ctypes.c_float * 4)]
+
+
+class Prop(ctypes.Structure):
+    _fields_ = [("shape", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("parts_start", ctypes.c_uint32),
+                ("mesh", ctypes.c_uint32)]
+
+
+class Mesh(ctypes.Structure):
+    _fields_ = [("nodes", ctypes.POINTER(BvhNode)), ("triangles", ctypes.POINTER(ctypes.c_uint32)),
+                ("triangle_parts", ctypes.POINTER(ctypes.c_uint16)), ("positions", ctypes.POINTER(ctypes.c_float)),
+                ("normals", ctypes.POINTER(ctypes.c_uint16)), ("uvs", ctypes.POINTER(ctypes.c_float)),
+                ("part_areas", ctypes.POINTER(ctypes.c_float)), ("num_nodes", ctypes.c_uint32),
+                ("num_triangles", ctypes.c_uint32), ("num_vertices", ctypes.c_uint32), ("num_parts", ctypes.c_uint32)]
+
+
+class Material(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("color_a", ctypes.c_float * 3),
+                ("color_b", ctypes.c_float * 3), ("roughness", ctypes.c_float), ("metallic", ctypes.c_float),
+                ("specular", ctypes.c_float), ("ior", ctypes.c_float), ("anisotropy", ctypes.c_float),
+                ("emission", ctypes.c_float * 3), ("cos_a", ctypes.c_float), ("camera_weight", ctypes.c_float),
+                ("emission_normalize", ctypes.c_uint32), ("emission_num_samples", ctypes.c_uint32)]
+
+
+class Light(ctypes.Structure):
+    _fields_ = [("prop", ctypes.c_uint32), ("part", ctypes.c_uint32), ("num_samples", ctypes.c_uint32),
+                ("light_class", ctypes.c_uint8), ("two_sided", ctypes.c_uint8),
+                ("shadow_catcher_light", ctypes.c_uint8), ("prototype", ctypes.c_uint8)]
+
+
+class LightNode(ctypes.Structure):
+    _fields_ = [("center", ctypes.c_uint16 * 4), ("cone", ctypes.c_uint16 * 4), ("power", ctypes.c_float),
+                ("variance", ctypes.c_float), ("meta", ctypes.c_uint32), ("num_lights", ctypes.c_uint32)]
+
+
+class LightTree(ctypes.Structure):
+    _fields_ = [("nodes", ctypes.POINTER(LightNode)), ("node_middles", ctypes.POINTER(ctypes.c_uint32)),
+                ("light_orders", ctypes.POINTER(ctypes.c_uint32)), ("light_mapping", ctypes.POINTER(ctypes.c_uint32)),
+                ("bounds", Aabb), ("infinite_weight", ctypes.c_float), ("infinite_guard", ctypes.c_float),
+                ("infinite_end", ctypes.c_uint32), ("max_split_depth", ctypes.c_uint32),
+                ("num_lights", ctypes.c_uint32), ("num_infinite_lights", ctypes.c_uint32),
+                ("num_nodes", ctypes.c_uint32)]
+
+
+class PropTree(ctypes.Structure):
+    _fields_ = [("nodes", ctypes.POINTER(BvhNode)), ("indices", ctypes.POINTER(ctypes.c_uint32)),
+                ("num_nodes", ctypes.c_uint32), ("num_indices", ctypes.c_uint32)]
+
+
+class Luts(ctypes.Structure):
+    _fields_ = [("e_m", ctypes.POINTER(ctypes.c_float)), ("e_m_avg", ctypes.POINTER(ctypes.c_float)),
+                ("e", ctypes.POINTER(ctypes.c_float)), ("e_avg", ctypes.POINTER(ctypes.c_float)),
+                ("e_s", ctypes.POINTER(ctypes.c_float))]
+
+
+class SceneDesc(ctypes.Structure):
+    _fields_ = [("props", ctypes.POINTER(Prop)), ("trafos", ctypes.POINTER(Trafo)), ("aabbs", ctypes.POINTER(Aabb)),
+                ("material_ids", ctypes.POINTER(ctypes.c_uint32)), ("light_ids", ctypes.POINTER(ctypes.c_uint32)),
+                ("meshes", ctypes.POINTER(Mesh)), ("materials", ctypes.POINTER(Material)),
+                ("lights", ctypes.POINTER(Light)), ("light_aabbs", ctypes.POINTER(Aabb)),
+                ("light_cones", ctypes.POINTER(ctypes.c_float)), ("solid", PropTree), ("unoccluding", PropTree),
+                ("light_tree", LightTree), ("luts", Luts), ("specular_threshold", ctypes.c_float),
+                ("num_props", ctypes.c_uint32), ("num_parts", ctypes.c_uint32), ("num_meshes", ctypes.c_uint32),
+                ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32)]
+
+
+class ViewDesc(ctypes.Structure):
+    _fields_ = [("resolution", ctypes.c_int32 * 2), ("crop", ctypes.c_int32 * 4), ("left_top", ctypes.c_float * 4),
+                ("d_x", ctypes.c_float * 4), ("d_y", ctypes.c_float * 4), ("eye_offset", ctypes.c_float * 4),
+                ("lens_radius", ctypes.c_float), ("focus_distance", ctypes.c_float), ("camera_trafo", Trafo),
+                ("frame_step", ctypes.c_uint64), ("frame_duration", ctypes.c_uint64), ("integrator", ctypes.c_uint32),
+                ("max_depth_surface", ctypes.c_uint32), ("max_depth_volume", ctypes.c_uint32),
+                ("split_threshold", ctypes.c_float), ("caustics_path", ctypes.c_uint32),
+                ("regularize_roughness", ctypes.c_float), ("sampler", ctypes.c_uint32),
+                ("num_expected_samples", ctypes.c_uint32), ("filter_radius_int", ctypes.c_int32),
+                ("filter_radius", ctypes.c_float), ("filter_samples", ctypes.c_float * (FILTER_TAPS + 1)),
+                ("clamp_emission", ctypes.c_float), ("clamp_direct", ctypes.c_float),
+                ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("camera_samples", ctypes.c_uint64), ("extension_rays", ctypes.c_uint64),
+                ("shadow_rays", ctypes.c_uint64), ("nodes_fetched", ctypes.c_uint64),
+                ("triangles_tested", ctypes.c_uint64), ("instances_tested", ctypes.c_uint64)]
+
+    def algorithmic_bytes(self, filter_radius_int=0):
+        """B = B_film + sum_ext (224 + B_trav) + sum_shadow (96 + B_trav)."""
+        b_trav = 32 * self.nodes_fetched + 48 * self.triangles_tested + 104 * self.instances_tested
+        taps = (2 * filter_radius_int + 1) ** 2
+        return 32 * taps * self.camera_samples + 224 * self.extension_rays + 96 * self.shadow_rays + b_trav
+
+
+_LOG_FUNC = ctypes.CFUNCTYPE(None, ctypes.c_uint32, ctypes.c_char_p)
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libzyg_amd.so (built by `python -m zyg_amd.build` / __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build the HIP library first (python -m zyg_amd.build); "
+                           "there is no CPU fallback for the render path")
+    lib = ctypes.CDLL(p)
+    lib.su_ext_scene_desc.restype = ctypes.POINTER(SceneDesc)
+    lib.su_ext_view_desc.restype = ctypes.POINTER(ViewDesc)
+    lib.su_ext_context.restype = ctypes.c_void_p
+    lib.zygpu_last_error.restype = ctypes.c_char_p
+    lib.su_camera_set_fov.argtypes = [ctypes.c_float]
+    lib.zygpu_clear_film.argtypes = [ctypes.c_void_p, ctypes.c_float]
+    for name in ("zygpu_destroy", "zygpu_synchronize", "zygpu_reset_stats"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.zygpu_render.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32,
+                                 ctypes.c_int32]
+    lib.zygpu_download_film.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.zygpu_upload_film.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.zygpu_set_external_film.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.zygpu_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.zygpu_enable_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.zygpu_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+    lib.zygpu_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+    lib.zygpu_upload_scene.argtypes = [ctypes.c_void_p, ctypes.POINTER(SceneDesc)]
+    lib.zygpu_set_view.argtypes = [ctypes.c_void_p, ctypes.POINTER(ViewDesc)]
+    lib.zygpu_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class Engine:
+    """The `su_*` protocol of the reference's clients (capi-test/test.py), one global engine per process."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or load_library()
+        self._log = None
+        if self.lib.su_init() != 0:
+            raise RuntimeError("su_init failed (engine already initialised?)")
+
+    def release(self):
+        if self.lib is not None:
+            self.lib.su_release()
+            self.lib = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.release()
+
+    # --- view ---
+    def camera(self, width, height, fov_deg=None):
+        cam = self.lib.su_perspective_camera_create(width, height)
+        if cam < 0:
+            raise RuntimeError("su_perspective_camera_create failed")
+        if fov_deg is not None:
+            self.lib.su_camera_set_fov(ctypes.c_float(np.float32(np.radians(fov_deg))))
+        return cam
+
+    def samples_per_pixel(self, n):
+        self.lib.su_sampler_create(n)  # returns -1 by design (capi.zig:215-221)
+
+    def integrators(self, json_text):
+        if self.lib.su_integrators_create(json_text.encode()) != 0:
+            raise RuntimeError("su_integrators_create failed")
+
+    def sensor(self, json_text):
+        if self.lib.su_ext_sensor_create(json_text.encode()) != 0:
+            raise RuntimeError("su_ext_sensor_create failed")
+
+    # --- resources / scene ---
+    def material(self, json_text, id=NULL):
+        m = self.lib.su_material_create(id, json_text.encode())
+        if m < 0:
+            raise RuntimeError("su_material_create failed: " + json_text)
+        return m
+
+    def triangle_mesh(self, indices, positions, normals, uvs=None, parts=None):
+        indices = _u32(indices).reshape(-1)
+        positions = _f32(positions).reshape(-1, 3)
+        normals = _f32(normals).reshape(-1, 3)
+        num_parts = 0
+        parts_p = None
+        if parts is not None:
+            parts = _u32(parts).reshape(-1, 3)
+            num_parts = parts.shape[0]
+            parts_p = parts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        uvs_p = None
+        if uvs is not None:
+            uvs = _f32(uvs).reshape(-1, 2)
+            uvs_p = uvs.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        fp = ctypes.POINTER(ctypes.c_float)
+        m = self.lib.su_triangle_mesh_create(
+            NULL, num_parts, parts_p, indices.size // 3, indices.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+            positions.shape[0], positions.ctypes.data_as(fp), 3, normals.ctypes.data_as(fp), 3, None, 0, uvs_p, 2,
+            False)
+        if m < 0:
+            raise RuntimeError("su_triangle_mesh_create failed")
+        return m
+
+    def prop(self, shape, materials, unoccluding=False):
+        mats = _u32(materials)
+        p = self.lib.su_ext_prop_create(shape, mats.size, mats.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                        1 if unoccluding else 0)
+        if p < 0:
+            raise RuntimeError("su_prop_create failed")
+        return p
+
+    def light(self, prop):
+        if self.lib.su_light_create(prop) != 0:
+            raise RuntimeError("su_light_create failed")
+
+    def transformation(self, prop, m16):
+        m = _f32(m16).reshape(16)
+        if self.lib.su_prop_set_transformation(prop, m.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) != 0:
+            raise RuntimeError("su_prop_set_transformation failed")
+
+    def visibility(self, prop, in_camera=True, in_reflection=True, in_sss=False):
+        self.lib.su_prop_set_visibility(prop, int(in_camera), int(in_reflection), int(in_sss))
+
+    # --- compile / render ---
+    def compile(self, frame=0):
+        """Scene.compile + camera.update only; returns (SceneDesc, ViewDesc) views valid until the next compile."""
+        if self.lib.su_ext_compile(frame) != 0:
+            raise RuntimeError("su_ext_compile failed (feature outside the hot-path scope?)")
+        return self.lib.su_ext_scene_desc().contents, self.lib.su_ext_view_desc().contents
+
+    def set_device(self, device_id):
+        self.lib.su_ext_set_device(device_id)
+
+    def start_frame(self, frame=0):
+        if self.lib.su_start_frame(frame) != 0:
+            raise RuntimeError("su_start_frame failed: " + (self.lib.zygpu_last_error() or b"").decode())
+
+    def render_iterations(self, n):
+        if self.lib.su_render_iterations(n) != 0:
+            raise RuntimeError("su_render_iterations failed: " + (self.lib.zygpu_last_error() or b"").decode())
+
+    def render_rows(self, n, y_begin, y_end):
+        if self.lib.su_ext_render_rows(n, y_begin, y_end) != 0:
+            raise RuntimeError("su_ext_render_rows failed: " + (self.lib.zygpu_last_error() or b"").decode())
+
+    def render_frame(self, frame=0):
+        if self.lib.su_render_frame(frame) != 0:
+            raise RuntimeError("su_render_frame failed: " + (self.lib.zygpu_last_error() or b"").decode())
+
+    def context(self):
+        return ctypes.c_void_p(self.lib.su_ext_context())
+
+    def synchronize(self):
+        self.lib.zygpu_synchronize(self.context())
+
+    def resolve(self, width, height):
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        rc = self.lib.su_resolve_frame_to_buffer(NULL, width, height, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        if rc != 0:
+            raise RuntimeError("su_resolve_frame_to_buffer failed")
+        return out
+
+    def download_film(self, width, height):
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        if self.lib.zygpu_download_film(self.context(), out.ctypes.data) != 0:
+            raise RuntimeError("zygpu_download_film failed")
+        return out
+
+    def stats(self):
+        s = Stats()
+        self.lib.zygpu_get_stats(self.context(), ctypes.byref(s))
+        return s

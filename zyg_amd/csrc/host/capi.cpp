@@ -1,0 +1,341 @@
+// The su_* C ABI (include/zyg_capi.h) on top of the host Engine and the inner zygpu_* ABI.
+// Call protocol and error codes follow reference src/capi/capi.zig:57-738.
+#include "../../../include/zyg_capi.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+
+#include "engine.hpp"
+
+namespace {
+
+struct Capi {
+    zyg::Engine        engine;
+    ZygpuContext*      ctx = nullptr;
+    int                device_id = -1;
+    uint32_t           frame = 0;
+    uint32_t           iteration = 0;
+    std::vector<float> target;  // Float4 image (driver.zig target)
+    bool               uploaded = false;
+};
+
+std::unique_ptr<Capi> g;
+su_log_func            g_log = nullptr;
+su_progress_start_func g_progress_start = nullptr;
+su_progress_tick_func  g_progress_tick = nullptr;
+
+void logf(uint32_t level, const char* fmt, ...) {  // core/log.zig:9-68: <= 256 byte line, valid during the call only
+    char    buffer[256];
+    va_list args;
+    va_start(args, fmt);
+    std::vsnprintf(buffer, sizeof(buffer), fmt, args);
+    va_end(args);
+    if (g_log) g_log(level, buffer);
+    else std::fprintf(level >= 2 ? stderr : stdout, "%s\n", buffer);
+}
+
+int defaultDevice() {
+    if (const char* e = std::getenv("ZYG_DEVICE")) return std::atoi(e);
+    if (const char* e = std::getenv("LOCAL_RANK")) return std::atoi(e);
+    return 0;
+}
+
+bool parse(const char* text, zyg::JsonValue& v) { return text && zyg::JsonParser::parse(text, v); }
+
+// su_start_frame's body: compile, upload, set view (driver.configure + startFrame, capi.zig:586-605)
+int32_t prepareFrame(uint32_t frame, bool clear) {
+    Capi& c = *g;
+    if (0 != c.engine.compile(frame)) {
+        logf(2, "scene uses a feature outside the hot-path scope (volumes, infinite or non-rectangle lights)");
+        return -1;
+    }
+    if (!c.ctx) {
+        const int dev = c.device_id >= 0 ? c.device_id : defaultDevice();
+        if (0 != zygpu_create(dev, &c.ctx)) {
+            logf(2, "zygpu_create failed: %s", zygpu_last_error());
+            c.ctx = nullptr;
+            return -1;
+        }
+    }
+    if (0 != zygpu_upload_scene(c.ctx, &c.engine.sceneDesc())) {
+        logf(2, "zygpu_upload_scene failed: %s", zygpu_last_error());
+        return -1;
+    }
+    if (0 != zygpu_set_view(c.ctx, &c.engine.viewDesc())) {
+        logf(2, "zygpu_set_view failed: %s", zygpu_last_error());
+        return -1;
+    }
+    c.target.assign(size_t(c.engine.resolution[0]) * size_t(c.engine.resolution[1]) * 4, 0.f);
+    c.frame = frame;
+    if (clear) {
+        c.iteration = 0;
+        if (0 != zygpu_clear_film(c.ctx, 0.f)) return -1;
+    }
+    c.uploaded = true;
+    return 0;
+}
+
+float linearToGamma(float x) {  // base/spectrum/srgb.zig:6-16
+    if (x <= 0.f) return 0.f;
+    if (x < 0.0031308f) return 12.92f * x;
+    if (x < 1.f) return 1.055f * std::pow(x, 1.f / 2.4f) - 0.055f;
+    return 1.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t su_init(void) {
+    if (g) return -1;
+    g.reset(new Capi());
+    return 0;
+}
+
+int32_t su_release(void) {
+    if (!g) return -1;
+    if (g->ctx) zygpu_destroy(g->ctx);
+    g.reset();
+    return 0;
+}
+
+int32_t su_mount(const char* folder) {
+    (void)folder;  // file system mounts only matter to file-backed resources
+    return g ? 0 : -1;
+}
+
+int32_t su_perspective_camera_create(uint32_t width, uint32_t height) {
+    if (!g) return -1;
+    g->engine.cameraCreate(width, height);
+    return int32_t(g->engine.camera_entity);
+}
+
+int32_t su_camera_set_fov(float fov) {
+    if (!g) return -1;
+    g->engine.fov = fov;
+    return 0;
+}
+
+int32_t su_camera_sensor_dimensions(int32_t* dimensions) {
+    if (!g) return -1;
+    dimensions[0] = g->engine.resolution[0];
+    dimensions[1] = g->engine.resolution[1];
+    return 0;
+}
+
+int32_t su_exporters_create(const char* json) {
+    if (!g) return -1;
+    zyg::JsonValue v;
+    if (!parse(json, v)) return -1;
+    return 0;  // exporters are configured but writing image files is out of the hot-path scope (su_export_frame)
+}
+
+int32_t su_aovs_create(const char* json) {
+    if (!g) return -1;
+    zyg::JsonValue v;
+    if (!parse(json, v)) return -1;
+    return 0;  // AOV buffers are out of scope; su_resolve_frame(aov < NumClasses) reports -2 (inactive)
+}
+
+int32_t su_sampler_create(uint32_t num_samples) {
+    if (g) g->engine.num_samples_per_pixel = num_samples;
+    return -1;  // capi.zig:215-221: sets the count and falls through to -1
+}
+
+int32_t su_integrators_create(const char* json) {
+    if (!g) return -1;
+    zyg::JsonValue v;
+    if (!parse(json, v)) return -1;
+    g->engine.loadIntegrators(v);
+    return 0;
+}
+
+int32_t su_image_create(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t*) {
+    return -1;  // image textures: SURVEY §2.2 (texture) — out of scope
+}
+
+int32_t su_image_update(uint32_t, uint32_t, const uint8_t*) { return -1; }
+
+int32_t su_material_create(uint32_t id, const char* json) {
+    if (!g) return -1;
+    zyg::JsonValue v;
+    if (!parse(json, v)) return -1;
+    const uint32_t m = g->engine.createMaterial(id, v);
+    return ZYGPU_NULL == m ? -1 : int32_t(m);
+}
+
+int32_t su_material_update(uint32_t id, const char* json) {
+    if (!g) return -1;
+    zyg::JsonValue v;
+    if (!parse(json, v)) return -1;
+    return g->engine.updateMaterial(id, v);
+}
+
+int32_t su_triangle_mesh_create(uint32_t id, uint32_t num_parts, const uint32_t* parts, uint32_t num_triangles,
+                                const uint32_t* indices, uint32_t num_vertices, const float* positions,
+                                uint32_t positions_stride, const float* normals, uint32_t normals_stride,
+                                const float* tangents, uint32_t tangents_stride, const float* uvs, uint32_t uvs_stride,
+                                bool asyncr) {
+    (void)tangents;
+    (void)tangents_stride;
+    (void)asyncr;  // the build is synchronous, so the caller's arrays are free to go on return (a superset of capi.zig:413-417)
+    if (!g || !positions || !normals) return -1;
+    return int32_t(g->engine.createMesh(id, num_parts, parts, num_triangles, indices, num_vertices, positions,
+                                        positions_stride, normals, normals_stride, uvs, uvs ? uvs_stride : 0));
+}
+
+int32_t su_ext_prop_create(uint32_t shape, uint32_t num_materials, const uint32_t* materials, uint32_t unoccluding) {
+    if (!g) return -1;
+    zyg::Engine& e = g->engine;
+    if (shape >= e.numShapes()) return -1;
+    const uint32_t        num_expected = e.shapeNumMaterials(shape);
+    std::vector<uint32_t> mats;
+    for (uint32_t i = 0; i < num_materials; ++i) mats.push_back(materials[i] >= e.numMaterials() ? e.fallbackMaterial() : materials[i]);
+    while (mats.size() < num_expected) mats.push_back(e.fallbackMaterial());
+    return e.createPropShape(shape, mats.data(), uint32_t(mats.size()), 0 != unoccluding);
+}
+
+int32_t su_prop_create(uint32_t shape, uint32_t num_materials, const uint32_t* materials) {
+    return su_ext_prop_create(shape, num_materials, materials, 0);
+}
+
+int32_t su_prop_create_instance(uint32_t entity) { return g ? g->engine.createPropInstance(entity) : -1; }
+
+int32_t su_light_create(uint32_t prop) { return g ? g->engine.createLight(prop) : -1; }
+
+int32_t su_prop_set_transformation(uint32_t prop, const float* trafo) {
+    return g ? g->engine.setTransformation(prop, trafo) : -1;
+}
+
+int32_t su_prop_set_transformation_frame(uint32_t prop, uint32_t frame, const float* trafo) {
+    (void)prop;
+    (void)frame;
+    (void)trafo;
+    return -1;  // keyframe animation: SURVEY §2.2 (animated props) — out of scope
+}
+
+int32_t su_prop_set_visibility(uint32_t prop, uint32_t in_camera, uint32_t in_reflection, uint32_t in_sss) {
+    return g ? g->engine.setVisibility(prop, in_camera > 0, in_reflection > 0, in_sss > 0) : -1;
+}
+
+int32_t su_start_frame(uint32_t frame) {
+    if (!g) return -1;
+    return prepareFrame(frame, true);
+}
+
+int32_t su_ext_render_rows(uint32_t num_steps, int32_t y_begin, int32_t y_end) {
+    if (!g || !g->uploaded) return -1;
+    if (g_progress_start) g_progress_start(num_steps);
+    if (0 != zygpu_render(g->ctx, g->frame, g->iteration, num_steps, y_begin, y_end)) {
+        logf(2, "zygpu_render failed: %s", zygpu_last_error());
+        return -1;
+    }
+    if (g_progress_tick)
+        for (uint32_t i = 0; i < num_steps; ++i) g_progress_tick();
+    g->iteration += num_steps;
+    return 0;
+}
+
+int32_t su_render_iterations(uint32_t num_steps) {
+    if (!g) return -1;
+    return su_ext_render_rows(num_steps, 0, g->engine.resolution[1]);
+}
+
+int32_t su_render_frame(uint32_t frame) {
+    if (!g) return -1;
+    if (0 != prepareFrame(frame, true)) return -1;
+    const uint32_t spp = g->engine.num_samples_per_pixel;
+    if (0 != su_render_iterations(spp)) return -1;
+    return 0 == zygpu_synchronize(g->ctx) ? 0 : -1;
+}
+
+int32_t su_export_frame(void) {
+    if (!g) return -1;
+    logf(1, "su_export_frame: image encoders are outside the hot-path scope; use su_resolve_frame_to_buffer");
+    return -1;
+}
+
+int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height, float* buffer) {
+    if (!g || !g->uploaded) return -1;
+    if (aov < 9) return -2;  // View.AovValue.NumClasses == 9, none active (capi.zig:637)
+    const uint32_t film_pixels = uint32_t(g->engine.resolution[0]) * uint32_t(g->engine.resolution[1]);
+    const uint32_t num_pixels = std::min(width * height, film_pixels);
+    return 0 == zygpu_resolve(g->ctx, buffer, num_pixels) ? 0 : -1;
+}
+
+int32_t su_resolve_frame(uint32_t aov) {
+    if (!g || !g->uploaded) return -1;
+    return su_resolve_frame_to_buffer(aov, uint32_t(g->engine.resolution[0]), uint32_t(g->engine.resolution[1]),
+                                      g->target.data());
+}
+
+int32_t su_copy_framebuffer(uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height, uint8_t* destination) {
+    if (!g) return -1;
+    const uint32_t dw = uint32_t(g->engine.resolution[0]), dh = uint32_t(g->engine.resolution[1]);
+    if (g->target.size() < size_t(dw) * dh * 4) return -1;
+    const uint32_t used_height = std::min(height, dh), used_width = std::min(width, dw);
+    (void)format;
+    if (3 == num_channels) {
+        for (uint32_t y = 0; y < used_height; ++y) {
+            uint32_t o = y * width * 3;
+            for (uint32_t x = 0; x < used_width; ++x) {
+                const float* c = &g->target[(size_t(y) * dw + x) * 4];
+                for (int k = 0; k < 3; ++k) destination[o + k] = uint8_t(linearToGamma(c[k]) * 255.f + 0.5f);
+                o += 3;
+            }
+        }
+    } else if (4 == num_channels) {
+        float* dst = reinterpret_cast<float*>(destination);
+        for (uint32_t y = 0; y < used_height; ++y)
+            for (uint32_t x = 0; x < used_width; ++x)
+                std::memcpy(dst + (size_t(y) * width + x) * 4, &g->target[(size_t(y) * dw + x) * 4], 16);
+    }
+    return 0;
+}
+
+int32_t su_register_log(su_log_func post) {
+    g_log = post;
+    return 0;
+}
+
+int32_t su_register_progress(su_progress_start_func start, su_progress_tick_func tick) {
+    if (!g) return -1;
+    g_progress_start = start;
+    g_progress_tick = tick;
+    return 0;
+}
+
+int32_t su_ext_sensor_create(const char* json) {
+    if (!g) return -1;
+    zyg::JsonValue v;
+    if (!parse(json, v)) return -1;
+    g->engine.loadSensor(v);
+    return 0;
+}
+
+int32_t su_ext_camera_set_parameters(const char* json) {
+    if (!g) return -1;
+    zyg::JsonValue v;
+    if (!parse(json, v)) return -1;
+    g->engine.loadCameraParameters(v);
+    return 0;
+}
+
+int32_t su_ext_set_device(int32_t device_id) {
+    if (!g || g->ctx) return -1;
+    g->device_id = device_id;
+    return 0;
+}
+
+int32_t su_ext_compile(uint32_t frame) {
+    if (!g) return -1;
+    return 0 == g->engine.compile(frame) ? 0 : -1;
+}
+
+const ZygpuSceneDesc* su_ext_scene_desc(void) { return g ? &g->engine.sceneDesc() : nullptr; }
+const ZygpuViewDesc*  su_ext_view_desc(void) { return g ? &g->engine.viewDesc() : nullptr; }
+ZygpuContext*         su_ext_context(void) { return g ? g->ctx : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,832 @@
+#include "engine.hpp"
+
+#include <algorithm>
+
+namespace zyg {
+
+static const float kMinRoughness = 0.01314f;  // material/ggx.zig:14-15
+
+static Vec4f readVec4f3(const JsonValue& v) {  // base/json.zig:130-140
+    if (JsonValue::Array == v.type && v.arr.size() >= 3) return vec(v.arr[0].f32(), v.arr[1].f32(), v.arr[2].f32(), 0.f);
+    return splat(v.f32());
+}
+
+// base/json.zig:251-277 (array / number, or {"sRGB": [...]}); temperature + gamma forms are out of scope
+static Vec4f readColor(const JsonValue& v) {
+    if (JsonValue::Object == v.type) {
+        Vec4f rgb = splat(0.f);
+        if (const JsonValue* s = v.get("sRGB")) rgb = readVec4f3(*s);
+        return sRGBtoAP1(rgb);
+    }
+    return sRGBtoAP1(readVec4f3(v));
+}
+
+static ZygpuTrafo composedTrafo(const Transformation& t, const Vec4f& origin) {  // composed_transformation.zig:17-29
+    const Mat3x3 r = quaternionToMat3x3(t.rotation);
+    ZygpuTrafo   out;
+    for (int i = 0; i < 3; ++i) {
+        out.r[i][0] = r.r[i][0];
+        out.r[i][1] = r.r[i][1];
+        out.r[i][2] = r.r[i][2];
+        out.r[i][3] = t.scale[i];
+    }
+    const Vec4f p = t.position - origin;  // space.zig:101-105 translate(-origin)
+    for (int i = 0; i < 4; ++i) out.position[i] = p[i];
+    return out;
+}
+
+static Mat4x4 objectToWorld(const Transformation& t) {  // composed_transformation.zig:47-49
+    const Mat3x3 r = quaternionToMat3x3(t.rotation);
+    return compose(r, vec(t.scale[0], t.scale[1], t.scale[2], 1.f), t.position);
+}
+
+struct Mitchell {  // sensor.zig:43-58
+    float b, c;
+    float eval(float x) const {
+        const float xx = x * x;
+        if (x > 1.f) {
+            return ((-b - 6.f * c) * xx * x + (6.f * b + 30.f * c) * xx + (-12.f * b - 48.f * c) * x + (8.f * b + 24.f * c)) / 6.f;
+        }
+        return ((12.f - 9.f * b - 6.f * c) * xx * x + (-18.f + 12.f * b + 6.f * c) * xx + (6.f - 2.f * b)) / 6.f;
+    }
+};
+
+struct Blackman {  // sensor.zig:27-41
+    float r;
+    float eval(float x) const {
+        const float a0 = 0.35875f, a1 = 0.48829f, a2 = 0.14128f, a3 = 0.01168f;
+        const float b = (float(M_PI) * (x + r)) / r;
+        return a0 - a1 * std::cos(b) + a2 * std::cos(2.f * b) - a3 * std::cos(3.f * b);
+    }
+};
+
+static float filterEval(const SensorSettings& s, float x) {  // interpolated_function.zig:154-166
+    const float    inverse_interval = 1.f / (s.filter_radius / float(ZYGPU_FILTER_TAPS - 1));
+    const float    cx = fmin_(std::fabs(x), s.filter_radius);
+    const float    o = cx * inverse_interval;
+    const uint32_t offset = uint32_t(o);
+    const float    t = o - float(offset);
+    const float    a = s.filter_samples[offset];
+    const float    b = s.filter_samples[std::min<uint32_t>(offset + 1, ZYGPU_FILTER_TAPS - 1)];
+    return std::fmaf(1.f - t, a, t * b);
+}
+
+void Engine::setFilter(float radius, int kind) {  // sensor.zig:105-120, 630-645
+    sensor.filter_radius = radius;
+    sensor.filter_radius_int = int32_t(std::ceil(radius));
+    std::fill(sensor.filter_samples, sensor.filter_samples + ZYGPU_FILTER_TAPS + 1, 0.f);
+    if (!(radius > 0.f)) return;
+
+    const float interval = radius / float(ZYGPU_FILTER_TAPS - 1);
+    float       s = 0.f;
+    for (int i = 0; i < ZYGPU_FILTER_TAPS; ++i) {
+        sensor.filter_samples[i] = 0 == kind ? Mitchell{1.f / 3.f, 1.f / 3.f}.eval(s) : Blackman{radius}.eval(s);
+        s += interval;
+    }
+
+    const uint32_t num_samples = 64;
+    const float    iv = radius / float(num_samples);
+    float          x = 0.5f * iv, sum = 0.f;
+    for (uint32_t i = 0; i < num_samples; ++i) {
+        sum += filterEval(sensor, x) * iv;
+        x += iv;
+    }
+    const float scale = 1.f / (sum + sum);
+    for (int i = 0; i < ZYGPU_FILTER_TAPS; ++i) sensor.filter_samples[i] *= scale;
+}
+
+Engine::Engine() {
+    shapes_.resize(7);  // resource/manager.zig:36-44
+    for (uint32_t i = 0; i < 7; ++i) shapes_[i].kind = i;
+
+    specular_threshold = kMinRoughness * kMinRoughness;  // resource/manager.zig:57
+
+    // Resources.MaterialProvider.createFallbackMaterial (material_provider.zig:127-129)
+    ZygpuMaterial fb{};
+    parseMaterial(fb, JsonValue(), ZYGPU_MAT_DEBUG);
+    commitMaterial(fb);
+    materials_.push_back(fb);
+    fallback_material_ = 0;
+
+    setFilter(2.f, 0);  // take.zig:59-64: Opaque + Mitchell(1/3, 1/3), radius 2
+}
+
+// material_provider.zig:131-162, 262-342, 411-436 (uniform values only; image textures are SURVEY §8(f))
+void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) {
+    std::memset(&m, 0, sizeof(m));
+    m.kind = kind;
+    m.cos_a = -1.f;
+    m.camera_weight = 1.f;
+    m.emission_num_samples = 1;
+    m.roughness = 0.8f;
+    m.metallic = 0.f;
+    m.specular = 1.f;
+    m.ior = 1.f;
+
+    auto loadEmittance = [&](const JsonValue& e) {
+        Vec4f color = splat(1.f);
+        if (const JsonValue* s = e.get("spectrum")) color = readColor(*s);
+        const float value = e.memberF32("value", 1.f);
+        const Vec4f em = splat(value) * color;
+        m.emission[0] = em[0];
+        m.emission[1] = em[1];
+        m.emission[2] = em[2];
+        m.emission_normalize = e.memberBool("normalize", false) ? 1u : 0u;
+        // angleFromProfile without a profile = pi (emittance.zig:75-78) -> 180 degrees
+        const float profile_angle = float(M_PI) * (180.f / float(M_PI));
+        m.cos_a = std::cos(e.memberF32("angle", profile_angle) * (float(M_PI) / 180.f));
+        m.camera_weight = e.memberF32("camera_weight", 1.f);
+        m.emission_num_samples = std::min<uint32_t>(e.memberU32("num_samples", 1), 64u);
+    };
+
+    if (ZYGPU_MAT_DEBUG == kind) {
+        // debug_material.zig:11-18: two-sided, fixed front/back albedo.
+        // Extension (SURVEY §8(d) cfg2 "Lambert with per-wall albedo"): {"Debug": {"color": [r,g,b]}}.
+        m.flags |= ZYGPU_MATF_TWO_SIDED;
+        const float front[3] = {0.4f, 0.9f, 0.1f}, back[3] = {0.9f, 0.1f, 0.4f};
+        for (int i = 0; i < 3; ++i) {
+            m.color_a[i] = front[i];
+            m.color_b[i] = back[i];
+        }
+        if (const JsonValue* c = v.get("color")) {
+            const Vec4f col = readColor(*c);
+            for (int i = 0; i < 3; ++i) m.color_a[i] = m.color_b[i] = col[i];
+        }
+    } else if (ZYGPU_MAT_LIGHT == kind) {
+        m.emission[0] = m.emission[1] = m.emission[2] = 1.f;  // light_material.zig:43
+        if (JsonValue::Object == v.type) {
+            for (const auto& kv : v.obj) {
+                if (kv.first == "emittance")
+                    loadEmittance(kv.second);
+                else if (kv.first == "two_sided" && kv.second.b)
+                    m.flags |= ZYGPU_MATF_TWO_SIDED;
+            }
+        }
+    } else if (ZYGPU_MAT_SUBSTITUTE == kind) {
+        // substitute_material.zig:32-60 defaults
+        const Vec4f half = splat(0.5f);
+        for (int i = 0; i < 3; ++i) m.color_a[i] = half[i];
+        m.ior = 1.46f;
+        if (JsonValue::Object == v.type) {
+            for (const auto& kv : v.obj) {
+                const std::string& k = kv.first;
+                const JsonValue&   x = kv.second;
+                if (k == "color") {
+                    const Vec4f col = readColor(x);
+                    for (int i = 0; i < 3; ++i) m.color_a[i] = col[i];
+                } else if (k == "roughness") {
+                    m.roughness = x.f32(m.roughness);
+                } else if (k == "metallic") {
+                    m.metallic = x.f32(m.metallic);
+                } else if (k == "specular") {
+                    m.specular = x.f32(m.specular);
+                } else if (k == "ior") {
+                    m.ior = x.f32(m.ior);
+                } else if (k == "anisotropy") {
+                    m.anisotropy = x.f32(0.f);
+                } else if (k == "two_sided") {
+                    if (x.b) m.flags |= ZYGPU_MATF_TWO_SIDED;
+                } else if (k == "emittance") {
+                    loadEmittance(x);
+                }
+            }
+        }
+    }
+}
+
+void Engine::commitMaterial(ZygpuMaterial& m) {
+    // light_material.zig:45-51 / substitute_material.zig:62-75
+    if (ZYGPU_MAT_LIGHT == m.kind || ZYGPU_MAT_SUBSTITUTE == m.kind) {
+        if (m.emission[0] > 0.f || m.emission[1] > 0.f || m.emission[2] > 0.f) m.flags |= ZYGPU_MATF_EMISSIVE;
+        else m.flags &= ~uint32_t(ZYGPU_MATF_EMISSIVE);
+    }
+    if (ZYGPU_MAT_SUBSTITUTE == m.kind) {
+        if (m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
+        else m.flags &= ~uint32_t(ZYGPU_MATF_CAUSTIC);
+    }
+}
+
+static bool materialKind(const JsonValue& v, uint32_t& kind, const JsonValue*& body) {
+    const JsonValue* rendering = v.get("rendering");
+    if (!rendering || JsonValue::Object != rendering->type) return false;
+    for (const auto& kv : rendering->obj) {  // first recognised entry wins (material_provider.zig:136-160)
+        body = &kv.second;
+        if (kv.first == "Debug") { kind = ZYGPU_MAT_DEBUG; return true; }
+        if (kv.first == "Light") { kind = ZYGPU_MAT_LIGHT; return true; }
+        if (kv.first == "Substitute") { kind = ZYGPU_MAT_SUBSTITUTE; return true; }
+    }
+    return false;  // Glass / Hair / Volumetric: SURVEY §8 row a20 / out of scope
+}
+
+uint32_t Engine::createMaterial(uint32_t id, const JsonValue& v) {
+    uint32_t         kind;
+    const JsonValue* body = nullptr;
+    if (!materialKind(v, kind, body)) return ZYGPU_NULL;
+    ZygpuMaterial m;
+    parseMaterial(m, *body, kind);
+    commitMaterial(m);
+    if (id < materials_.size()) {  // resource/cache.zig store(): overwrite an existing id
+        materials_[id] = m;
+        return id;
+    }
+    materials_.push_back(m);
+    return uint32_t(materials_.size() - 1);
+}
+
+int Engine::updateMaterial(uint32_t id, const JsonValue& v) {
+    if (id >= materials_.size()) return -3;  // capi.zig:360-362
+    ZygpuMaterial& m = materials_[id];
+    // capi.zig:366-371 passes the *inner* object to updateMaterial (e.g. {"roughness": 0.2}); update in place
+    if (JsonValue::Object != v.type) return -4;
+    auto setColor = [&](const JsonValue& x, float* dst) {
+        const Vec4f c = readColor(x);
+        for (int i = 0; i < 3; ++i) dst[i] = c[i];
+    };
+    for (const auto& kv : v.obj) {
+        if (kv.first == "roughness") m.roughness = kv.second.f32(m.roughness);
+        else if (kv.first == "metallic") m.metallic = kv.second.f32(m.metallic);
+        else if (kv.first == "specular") m.specular = kv.second.f32(m.specular);
+        else if (kv.first == "ior") m.ior = kv.second.f32(m.ior);
+        else if (kv.first == "color") {
+            setColor(kv.second, m.color_a);
+            if (ZYGPU_MAT_DEBUG == m.kind) setColor(kv.second, m.color_b);
+        } else if (kv.first == "emittance") {
+            ZygpuMaterial tmp;
+            JsonValue     wrap;
+            wrap.type = JsonValue::Object;
+            wrap.obj.emplace_back("emittance", kv.second);
+            parseMaterial(tmp, wrap, ZYGPU_MAT_LIGHT);
+            std::memcpy(m.emission, tmp.emission, sizeof(m.emission));
+            m.cos_a = tmp.cos_a;
+            m.camera_weight = tmp.camera_weight;
+            m.emission_normalize = tmp.emission_normalize;
+            m.emission_num_samples = tmp.emission_num_samples;
+        }
+    }
+    commitMaterial(m);
+    return 0;
+}
+
+// shape_provider.zig:274-306 (loadData) + 847-913 (buildDescAsync) + triangle_tree_builder.zig:33-65,166-206
+uint32_t Engine::createMesh(uint32_t id, uint32_t num_parts_in, const uint32_t* parts_in, uint32_t num_triangles,
+                            const uint32_t* indices, uint32_t num_vertices, const float* positions,
+                            uint32_t positions_stride, const float* normals, uint32_t normals_stride, const float* uvs,
+                            uint32_t uvs_stride) {
+    (void)id;
+    HostMesh mesh;
+
+    const uint32_t num_parts = num_parts_in > 0 ? num_parts_in : 1;
+    mesh.part_materials.assign(num_parts, 0);
+    if (num_parts_in > 0 && parts_in) {
+        for (uint32_t i = 0; i < num_parts; ++i) mesh.part_materials[i] = parts_in[i * 3 + 2];
+    }
+
+    struct IndexTriangle {
+        uint32_t i[3];
+        uint32_t part;
+    };
+    std::vector<IndexTriangle> triangles(num_triangles, IndexTriangle{{0, 0, 0}, 0});
+
+    const uint32_t  empty_part[3] = {0, num_triangles * 3, 0};
+    const uint32_t* parts = (num_parts_in > 0 && parts_in) ? parts_in : empty_part;
+    for (uint32_t p = 0; p < num_parts; ++p) {
+        const uint32_t start_index = parts[p * 3 + 0];
+        const uint32_t num_indices = parts[p * 3 + 1];
+        const uint32_t tb = start_index / 3, te = std::min((start_index + num_indices) / 3, num_triangles);
+        for (uint32_t i = tb; i < te; ++i) {
+            const uint32_t t = i * 3;
+            if (indices) {
+                triangles[i].i[0] = indices[t + 0];
+                triangles[i].i[1] = indices[t + 1];
+                triangles[i].i[2] = indices[t + 2];
+            } else {
+                triangles[i].i[0] = t + 0;
+                triangles[i].i[1] = t + 1;
+                triangles[i].i[2] = t + 2;
+            }
+            triangles[i].part = p;
+        }
+    }
+
+    // vertex_buffer.zig:214-245 (CAPI.copy)
+    mesh.num_vertices = num_vertices;
+    mesh.positions.assign(size_t(num_vertices) * 3 + 1, 0.f);
+    mesh.normals.assign(size_t(num_vertices) * 2, 0);
+    mesh.uvs.assign(size_t(num_vertices) * 2, 0.f);
+    for (uint32_t i = 0; i < num_vertices; ++i) {
+        const size_t s = size_t(i) * positions_stride;
+        mesh.positions[3 * i + 0] = positions[s + 0];
+        mesh.positions[3 * i + 1] = positions[s + 1];
+        mesh.positions[3 * i + 2] = positions[s + 2];
+    }
+    for (uint32_t i = 0; i < num_vertices; ++i) {
+        const size_t s = size_t(i) * normals_stride;
+        float        o[2];
+        octEncode(vec(normals[s + 0], normals[s + 1], normals[s + 2], 0.f), o);
+        mesh.normals[2 * i + 0] = floatToSnorm16(o[0]);
+        mesh.normals[2 * i + 1] = floatToSnorm16(o[1]);
+    }
+    if (uvs) {
+        for (uint32_t i = 0; i < num_vertices; ++i) {
+            const size_t s = size_t(i) * uvs_stride;
+            mesh.uvs[2 * i + 0] = uvs[s + 0];
+            mesh.uvs[2 * i + 1] = uvs[s + 1];
+        }
+    }
+
+    // references (triangle_tree_builder.zig:113-135)
+    std::vector<BvhReference> refs(num_triangles);
+    AABB                      bounds = emptyAabb();
+    for (uint32_t r = 0; r < num_triangles; ++r) {
+        const Vec4f a = mesh.position(triangles[r].i[0]);
+        const Vec4f b = mesh.position(triangles[r].i[1]);
+        const Vec4f c = mesh.position(triangles[r].i[2]);
+        const Vec4f mn = min4(a, min4(b, c));
+        const Vec4f mx = max4(a, max4(b, c));
+        for (int k = 0; k < 3; ++k) {
+            refs[r].mn[k] = mn[k];
+            refs[r].mx[k] = mx[k];
+        }
+        refs[r].prim = r;
+        bounds.b[0] = min4(bounds.b[0], mn);
+        bounds.b[1] = max4(bounds.b[1], mx);
+    }
+
+    BvhBuilder            builder(BvhSettings{16, 64, 4});  // shape_provider.zig:922
+    std::vector<uint32_t> prim_ids;
+    builder.build(std::move(refs), bounds, mesh.nodes, prim_ids);
+
+    mesh.triangles.resize(prim_ids.size() * 3);
+    mesh.triangle_parts.resize(prim_ids.size());
+    for (size_t i = 0; i < prim_ids.size(); ++i) {
+        const IndexTriangle& t = triangles[prim_ids[i]];
+        mesh.triangles[3 * i + 0] = t.i[0];
+        mesh.triangles[3 * i + 1] = t.i[1];
+        mesh.triangles[3 * i + 2] = t.i[2];
+        mesh.triangle_parts[i] = uint16_t(t.part);
+    }
+
+    // triangle_mesh.zig:705-720 (calculateAreas; duplicated triangles count twice, as in the reference)
+    mesh.part_areas.assign(num_parts, 0.f);
+    for (size_t t = 0; t < prim_ids.size(); ++t) {
+        const Vec4f a = mesh.position(mesh.triangles[3 * t + 0]);
+        const Vec4f b = mesh.position(mesh.triangles[3 * t + 1]);
+        const Vec4f c = mesh.position(mesh.triangles[3 * t + 2]);
+        mesh.part_areas[mesh.triangle_parts[t]] += 0.5f * length3(cross3(b - a, c - a));
+    }
+
+    meshes_.push_back(std::move(mesh));
+    HostShape s;
+    s.kind = ZYGPU_SHAPE_TRIANGLE_MESH;
+    s.mesh = uint32_t(meshes_.size() - 1);
+    shapes_.push_back(s);
+    return uint32_t(shapes_.size() - 1);
+}
+
+bool Engine::shapeFinite(uint32_t shape) const {  // shape.zig:92-97
+    const uint32_t k = shapes_[shape].kind;
+    return !(ZYGPU_SHAPE_CANOPY == k || ZYGPU_SHAPE_DISTANT == k || ZYGPU_SHAPE_DOME == k);
+}
+
+AABB Engine::shapeAabb(uint32_t shape) const {  // shape.zig:106-113
+    const HostShape& s = shapes_[shape];
+    switch (s.kind) {
+        case ZYGPU_SHAPE_CANOPY:
+        case ZYGPU_SHAPE_DISTANT:
+        case ZYGPU_SHAPE_DOME: return emptyAabb();
+        case ZYGPU_SHAPE_DISK:
+        case ZYGPU_SHAPE_RECTANGLE: return {{vec(-0.5f, -0.5f, 0.f, 0.f), vec(0.5f, 0.5f, 0.f, 0.f)}};
+        case ZYGPU_SHAPE_CUBE:
+        case ZYGPU_SHAPE_SPHERE: return {{splat(-0.5f), splat(0.5f)}};
+        default: return meshes_[s.mesh].aabb();
+    }
+}
+
+uint32_t Engine::shapeNumParts(uint32_t shape) const {
+    const HostShape& s = shapes_[shape];
+    return ZYGPU_SHAPE_TRIANGLE_MESH == s.kind ? meshes_[s.mesh].numParts() : 1;
+}
+
+uint32_t Engine::createEntity() {  // scene.zig:259-265: a Distant-shaped prop without materials, not classified
+    HostProp p;
+    p.shape = ZYGPU_SHAPE_DISTANT;
+    // configureShape with no materials: not mono -> solid, not unoccluding
+    props_.push_back(p);
+    Transformation t;
+    t.position = splat(0.f);
+    t.scale = vec(1.f, 1.f, 1.f, 0.f);
+    t.rotation = vec(0.f, 0.f, 0.f, 1.f);
+    world_transformations_.push_back(t);
+    return uint32_t(props_.size() - 1);
+}
+
+void Engine::classifyProp(uint32_t p) {  // scene.zig:324-342
+    const HostProp& po = props_[p];
+    if (po.flags & ZYGPU_PROP_VOLUME) volume_props_.push_back(p);
+    if (po.flags & ZYGPU_PROP_SOLID) {
+        if (shapeFinite(po.shape)) {
+            if (po.flags & ZYGPU_PROP_UNOCCLUDING) unoccluding_props_.push_back(p);
+            else finite_props_.push_back(p);
+        } else {
+            infinite_props_.push_back(p);
+        }
+    }
+}
+
+// scene.zig:267-293 + prop.zig:96-135
+int32_t Engine::createPropShape(uint32_t shape, const uint32_t* materials, uint32_t num_materials, bool unocc) {
+    if (shape >= shapes_.size()) return -1;
+
+    HostProp p;
+    p.shape = shape;
+
+    bool mono = false, pure_emissive = true;
+    if (num_materials > 0) {
+        mono = true;
+        const uint32_t mid0 = materials[0];
+        for (uint32_t i = 0; i < num_materials; ++i) {
+            const ZygpuMaterial& m = materials_[materials[i]];
+            if (m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY) p.flags |= ZYGPU_PROP_EVALUATE_VISIBILITY;
+            if (m.flags & ZYGPU_MATF_CAUSTIC) p.flags |= ZYGPU_PROP_CAUSTIC;
+            if (ZYGPU_MAT_LIGHT != m.kind) pure_emissive = false;
+            if (materials[i] != mid0) mono = false;
+        }
+    }
+
+    auto materialIor = [&](uint32_t mid) {  // material.zig:140-146
+        const ZygpuMaterial& m = materials_[mid];
+        return (ZYGPU_MAT_SUBSTITUTE == m.kind || ZYGPU_MAT_GLASS == m.kind) ? m.ior : 1.f;
+    };
+    const bool finite = shapeFinite(shape);
+    const bool volumetric = finite && mono && materialIor(materials[0]) < 1.f;
+    if (volumetric) {
+        p.flags &= ~uint32_t(ZYGPU_PROP_SOLID);
+        p.flags |= ZYGPU_PROP_VOLUME;
+    }
+    if (unocc && finite && pure_emissive) p.flags |= ZYGPU_PROP_UNOCCLUDING;
+
+    p.parts_start = uint32_t(material_ids_.size());
+    const uint32_t   num_parts = shapeNumParts(shape);
+    const HostShape& s = shapes_[shape];
+    for (uint32_t i = 0; i < num_parts; ++i) {
+        const uint32_t part_mat = ZYGPU_SHAPE_TRIANGLE_MESH == s.kind ? meshes_[s.mesh].part_materials[i] : i;
+        uint32_t       material_id = 0;
+        if (num_materials > 0) material_id = part_mat < num_materials ? materials[part_mat] : fallback_material_;
+        material_ids_.push_back(material_id);
+        light_ids_.push_back(ZYGPU_NULL);
+    }
+
+    props_.push_back(p);
+    Transformation t;
+    t.position = splat(0.f);
+    t.scale = vec(1.f, 1.f, 1.f, 0.f);
+    t.rotation = vec(0.f, 0.f, 0.f, 1.f);
+    world_transformations_.push_back(t);
+
+    const uint32_t id = uint32_t(props_.size() - 1);
+    classifyProp(id);
+    return int32_t(id);
+}
+
+int32_t Engine::createPropInstance(uint32_t entity) {  // scene.zig:307-316
+    if (entity >= props_.size()) return -1;
+    props_.push_back(props_[entity]);
+    world_transformations_.push_back(world_transformations_[entity]);
+    const uint32_t id = uint32_t(props_.size() - 1);
+    classifyProp(id);
+    return int32_t(id);
+}
+
+int Engine::createLight(uint32_t entity) {  // scene.zig:344-372
+    if (entity >= props_.size()) return -1;
+    const HostProp& p = props_[entity];
+    const uint32_t  num_parts = shapeNumParts(p.shape);
+    for (uint32_t i = 0; i < num_parts; ++i) {
+        const ZygpuMaterial& m = materials_[material_ids_[p.parts_start + i]];
+        if (!(m.flags & ZYGPU_MATF_EMISSIVE)) continue;
+        ZygpuLight l{};
+        l.prop = entity;
+        l.part = i;
+        l.num_samples = 1;
+        l.light_class = ZYGPU_LIGHT_PROP;
+        l.two_sided = (m.flags & ZYGPU_MATF_TWO_SIDED) ? 1 : 0;
+        l.shadow_catcher_light = (p.flags & ZYGPU_PROP_SHADOW_CATCHER_LIGHT) ? 1 : 0;
+        l.prototype = 0;
+        lights_.push_back(l);
+    }
+    return 0;
+}
+
+int Engine::setTransformation(uint32_t prop, const float* m16) {  // capi.zig:482-503
+    if (prop >= props_.size()) return -1;
+    Mat4x4 m;
+    for (int r = 0; r < 4; ++r) m.r[r] = vec(m16[4 * r + 0], m16[4 * r + 1], m16[4 * r + 2], m16[4 * r + 3]);
+    Mat3x3         basis;
+    Transformation t;
+    decompose(m, basis, t.scale, t.position);
+    t.rotation = quaternionFromMat3x3(basis);
+    world_transformations_[prop] = t;
+    return 0;
+}
+
+int Engine::setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss) {  // prop.zig:75-88
+    if (prop >= props_.size()) return -1;
+    uint32_t& f = props_[prop].flags;
+    auto      set = [&](uint32_t bit, bool on) { f = on ? (f | bit) : (f & ~bit); };
+    set(ZYGPU_PROP_VISIBLE_IN_CAMERA, in_camera);
+    set(ZYGPU_PROP_VISIBLE_IN_REFLECTION, in_reflection);
+    set(ZYGPU_PROP_VISIBLE_IN_SSS, in_sss);
+    set(ZYGPU_PROP_SHADOW_CATCHER_LIGHT, false);
+    set(ZYGPU_PROP_VISIBLE_IN_SHADOW, (f & ZYGPU_PROP_SHADOW_CATCHER) ? false : in_reflection);
+    return 0;
+}
+
+void Engine::cameraCreate(uint32_t width, uint32_t height) {  // capi.zig:143-167
+    resolution[0] = int32_t(width);
+    resolution[1] = int32_t(height);
+    crop[0] = 0;
+    crop[1] = 0;
+    crop[2] = resolution[0];
+    crop[3] = resolution[1];
+    fov = float(80.0 * (M_PI / 180.0));
+    if (ZYGPU_NULL == camera_entity) camera_entity = createEntity();
+}
+
+void Engine::loadCameraParameters(const JsonValue& v) {  // camera_perspective.zig:260-270 (fov / lens / focus distance)
+    if (JsonValue::Object != v.type) return;
+    for (const auto& kv : v.obj) {
+        if (kv.first == "fov") fov = kv.second.f32() * float(M_PI / 180.0);
+        else if (kv.first == "lens" || kv.first == "aperture") lens_radius = kv.second.memberF32("radius", lens_radius);
+        else if (kv.first == "focus") focus_distance = kv.second.memberF32("distance", focus_distance);
+    }
+}
+
+// take/take.zig:131-271
+void Engine::loadIntegrators(const JsonValue& v) {
+    if (JsonValue::Object != v.type) return;
+    if (const JsonValue* st = v.get("specular_threshold")) {
+        const float x = st->f32();
+        specular_threshold = x * x;
+    }
+    const JsonValue* surface = v.get("surface");
+    if (!surface || JsonValue::Object != surface->type) return;
+
+    auto loadDepth = [&](const JsonValue& n) {
+        max_depth_surface = 16;
+        max_depth_volume = 256;
+        if (const JsonValue* d = n.get("depth")) {
+            max_depth_surface = uint16_t(d->memberU32("surface", 16));
+            max_depth_volume = uint16_t(d->memberU32("surface", 256));  // reads "surface" for both (take.zig:257-258)
+        }
+    };
+    auto loadLightSampling = [&](const JsonValue& n) {
+        float st = 0.5f;
+        if (const JsonValue* ls = n.get("light_sampling")) st = clamp_(ls->memberF32("split_threshold", 0.5f), 0.f, 1.f);
+        const float st2 = st * st;
+        split_threshold = st2 * st2;
+    };
+
+    for (const auto& kv : surface->obj) {
+        const JsonValue& n = kv.second;
+        if (kv.first == "PT") {
+            integrator = ZYGPU_INTEGRATOR_PT;
+            caustics_path = n.memberBool("caustics", true);
+            loadDepth(n);
+        } else if (kv.first == "PTDL") {
+            integrator = ZYGPU_INTEGRATOR_PTDL;
+            caustics_path = n.memberBool("caustics", true);
+            loadDepth(n);
+            loadLightSampling(n);
+        } else if (kv.first == "PTMIS") {
+            integrator = ZYGPU_INTEGRATOR_PTMIS;
+            regularize_roughness = n.memberF32("regularize_roughness", 0.f);
+            caustics_path = n.memberBool("caustics", true);
+            loadDepth(n);
+            loadLightSampling(n);
+        }
+    }
+}
+
+// cli/take_loader.zig:193-230 (sensor node of a take); the reference C ABI has no entry for it
+void Engine::loadSensor(const JsonValue& v) {
+    sensor.clamp_emission = sensor.clamp_direct = sensor.clamp_indirect = FLT_MAX;
+    if (const JsonValue* c = v.get("clamp")) {
+        if (JsonValue::Object == c->type) {
+            sensor.clamp_emission = c->memberF32("emission", sensor.clamp_emission);
+            sensor.clamp_direct = c->memberF32("direct", sensor.clamp_direct);
+            sensor.clamp_indirect = c->memberF32("indirect", sensor.clamp_indirect);
+        }
+    }
+    if (const JsonValue* f = v.get("filter")) {
+        if (JsonValue::Object == f->type) {
+            for (const auto& kv : f->obj) {
+                if (kv.first == "Blackman") { setFilter(2.f, 1); return; }
+                if (kv.first == "Mitchell") { setFilter(2.f, 0); return; }
+            }
+        }
+    }
+    setFilter(0.f, 1);
+}
+
+void Engine::buildPropTree(const std::vector<uint32_t>& indices, std::vector<ZygpuBvhNode>& nodes,
+                           std::vector<uint32_t>& out_indices) {  // prop_tree_builder.zig:24-62
+    nodes.clear();
+    out_indices.clear();
+    if (indices.empty()) return;
+    std::vector<BvhReference> refs(indices.size());
+    AABB                      bounds = emptyAabb();
+    for (size_t i = 0; i < indices.size(); ++i) {
+        const ZygpuAabb& b = c_aabbs_[indices[i]];
+        for (int k = 0; k < 3; ++k) {
+            refs[i].mn[k] = b.min[k];
+            refs[i].mx[k] = b.max[k];
+        }
+        refs[i].prim = indices[i];
+        aabbMerge(bounds, {{vec(b.min[0], b.min[1], b.min[2], b.min[3]), vec(b.max[0], b.max[1], b.max[2], b.max[3])}});
+    }
+    BvhBuilder builder(BvhSettings{16, 64, 4});  // prop_tree_builder.zig:17
+    builder.build(std::move(refs), bounds, nodes, out_indices);
+}
+
+int Engine::compile(uint32_t frame) {
+    (void)frame;  // static scenes only: every keyframe-free prop ignores time (space.zig:99-108)
+    if (ZYGPU_NULL == camera_entity) return -1;
+
+    const Vec4f    camera_pos = world_transformations_[camera_entity].position;  // driver.zig:164
+    const uint32_t np = uint32_t(props_.size());
+
+    c_props_.resize(np);
+    c_trafos_.resize(np);
+    c_aabbs_.resize(np);
+
+    c_meshes_.resize(meshes_.size());
+    for (size_t i = 0; i < meshes_.size(); ++i) {
+        const HostMesh& m = meshes_[i];
+        ZygpuMesh&      d = c_meshes_[i];
+        d.nodes = m.nodes.data();
+        d.triangles = m.triangles.data();
+        d.triangle_parts = m.triangle_parts.data();
+        d.positions = m.positions.data();
+        d.normals = m.normals.data();
+        d.uvs = m.uvs.data();
+        d.part_areas = m.part_areas.data();
+        d.num_nodes = uint32_t(m.nodes.size());
+        d.num_triangles = m.numTriangles();
+        d.num_vertices = m.num_vertices;
+        d.num_parts = m.numParts();
+    }
+
+    for (uint32_t p = 0; p < np; ++p) {
+        const HostProp&  hp = props_[p];
+        const HostShape& s = shapes_[hp.shape];
+        c_props_[p].shape = s.kind;
+        c_props_[p].flags = hp.flags;
+        c_props_[p].parts_start = hp.parts_start;
+        c_props_[p].mesh = s.mesh;
+
+        const Transformation& t = world_transformations_[p];
+        c_trafos_[p] = composedTrafo(t, camera_pos);
+
+        // space.zig:60-97 (calculateWorldBounds, static branch)
+        AABB bounds = aabbTransform(shapeAabb(hp.shape), objectToWorld(t));
+        bounds.b[0] = bounds.b[0] + (-camera_pos);
+        bounds.b[1] = bounds.b[1] + (-camera_pos);
+        aabbCacheRadius(bounds);
+        for (int i = 0; i < 4; ++i) {
+            c_aabbs_[p].min[i] = bounds.b[0][i];
+            c_aabbs_[p].max[i] = bounds.b[1][i];
+        }
+    }
+
+    buildPropTree(finite_props_, solid_nodes_, solid_indices_);
+    buildPropTree(unoccluding_props_, unoccluding_nodes_, unoccluding_indices_);
+    if (!volume_props_.empty() || !infinite_props_.empty()) return -2;  // out of scope
+
+    // lights: scene.zig:402-497 (propPrepareSampling, static branch)
+    std::fill(light_ids_.begin(), light_ids_.end(), ZYGPU_NULL);
+    const uint32_t nl = uint32_t(lights_.size());
+    c_light_aabbs_.resize(nl);
+    c_light_cones_.resize(size_t(nl) * 4);
+    c_light_two_sided_.resize(nl);
+    for (uint32_t li = 0; li < nl; ++li) {
+        ZygpuLight&      l = lights_[li];
+        const HostProp&  hp = props_[l.prop];
+        const HostShape& s = shapes_[hp.shape];
+        const uint32_t   p = hp.parts_start + l.part;
+        light_ids_[p] = li;
+        const ZygpuMaterial& m = materials_[material_ids_[p]];
+
+        if (ZYGPU_SHAPE_RECTANGLE != s.kind) return -3;  // mesh / sphere / disk emitters: SURVEY §8(f)
+
+        l.num_samples = m.emission_num_samples;  // light_material.zig:68-74 / substitute_material.zig:96-111
+        l.two_sided = (m.flags & ZYGPU_MATF_TWO_SIDED) ? 1 : 0;
+        c_light_two_sided_[li] = l.two_sided;
+
+        const Transformation& t = world_transformations_[l.prop];
+        Transformation        rel = t;
+        rel.position = t.position - camera_pos;
+
+        AABB bb = aabbTransform(shapeAabb(hp.shape), objectToWorld(rel));
+        aabbCacheRadius(bb);
+
+        const Vec4f  part_cone = vec(0.f, 0.f, 1.f, 1.f);  // shape.zig:115-120
+        const Mat3x3 rot = quaternionToMat3x3(t.rotation);
+        Mat3x3       rot_s = rot;  // rows carry the scale in w, as the reference's ComposedTransformation does
+        for (int i = 0; i < 3; ++i) rot_s.r[i][3] = t.scale[i];
+        const Vec4f tc = transformVector(rot_s, part_cone);
+        c_light_cones_[4 * li + 0] = tc[0];
+        c_light_cones_[4 * li + 1] = tc[1];
+        c_light_cones_[4 * li + 2] = tc[2];
+        c_light_cones_[4 * li + 3] = part_cone[3];
+
+        const float extent = t.scale[0] * t.scale[1];  // shape.zig:148 Rectangle area
+        Vec4f       emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f);
+        // emittance.zig:61-71 totalEmission; light.zig:67-77 power (finite shape)
+        Vec4f power = splat(0.f);
+        if (extent > 0.f) power = m.emission_normalize ? emission : emission * splat(extent);
+        bb.b[0][3] = hmax3(power);
+
+        for (int i = 0; i < 4; ++i) {
+            c_light_aabbs_[li].min[i] = bb.b[0][i];
+            c_light_aabbs_[li].max[i] = bb.b[1][i];
+        }
+    }
+
+    LightTreeInput lin;
+    lin.aabbs = c_light_aabbs_.data();
+    lin.cones = c_light_cones_.data();
+    lin.two_sided = c_light_two_sided_.data();
+    lin.num_lights = nl;
+    LightTreeBuilder ltb;
+    ltb.build(lin, light_tree_);
+
+    ZygpuSceneDesc& d = scene_desc_;
+    std::memset(&d, 0, sizeof(d));
+    d.props = c_props_.data();
+    d.trafos = c_trafos_.data();
+    d.aabbs = c_aabbs_.data();
+    d.material_ids = material_ids_.data();
+    d.light_ids = light_ids_.data();
+    d.meshes = c_meshes_.data();
+    d.materials = materials_.data();
+    d.lights = lights_.data();
+    d.light_aabbs = c_light_aabbs_.data();
+    d.light_cones = c_light_cones_.data();
+    d.solid = ZygpuPropTree{solid_nodes_.data(), solid_indices_.data(), uint32_t(solid_nodes_.size()),
+                            uint32_t(solid_indices_.size())};
+    d.unoccluding = ZygpuPropTree{unoccluding_nodes_.data(), unoccluding_indices_.data(),
+                                  uint32_t(unoccluding_nodes_.size()), uint32_t(unoccluding_indices_.size())};
+    d.light_tree = light_tree_.tree;
+    d.specular_threshold = specular_threshold;
+    d.num_props = np;
+    d.num_parts = uint32_t(material_ids_.size());
+    d.num_meshes = uint32_t(c_meshes_.size());
+    d.num_materials = uint32_t(materials_.size());
+    d.num_lights = nl;
+
+    // camera.update (camera_perspective.zig:79-122, mono / no focus point)
+    ZygpuViewDesc& v = view_desc_;
+    std::memset(&v, 0, sizeof(v));
+    v.resolution[0] = resolution[0];
+    v.resolution[1] = resolution[1];
+    for (int i = 0; i < 4; ++i) v.crop[i] = crop[i];
+    {
+        const float fr0 = float(resolution[0]), fr1 = float(resolution[1]);
+        const float ratio = fr1 / fr0;
+        const float z = 1.f / std::tan(0.5f * fov);
+        const Vec4f left_top = vec(-1.f, ratio, z, 0.f);
+        const Vec4f right_top = vec(1.f, ratio, z, 0.f);
+        const Vec4f left_bottom = vec(-1.f, -ratio, z, 0.f);
+        const Vec4f d_x = (right_top - left_top) / splat(fr0);
+        const Vec4f d_y = (left_bottom - left_top) / splat(fr1);
+        for (int i = 0; i < 4; ++i) {
+            v.left_top[i] = left_top[i];
+            v.d_x[i] = d_x[i];
+            v.d_y[i] = d_y[i];
+            v.eye_offset[i] = 0.f;
+        }
+    }
+    v.lens_radius = lens_radius;
+    v.focus_distance = focus_distance;
+    v.camera_trafo = c_trafos_[camera_entity];
+    v.frame_step = 705600000ull / 60;      // camera_base.zig:16,25
+    v.frame_duration = 705600000ull / 60;  // camera_base.zig:26
+    v.integrator = integrator;
+    v.max_depth_surface = max_depth_surface;
+    v.max_depth_volume = max_depth_volume;
+    v.split_threshold = split_threshold;
+    v.caustics_path = caustics_path ? 1u : 0u;
+    v.regularize_roughness = regularize_roughness;
+    v.sampler = sampler_kind;
+    v.num_expected_samples = num_samples_per_pixel;
+    v.filter_radius_int = sensor.filter_radius_int;
+    v.filter_radius = sensor.filter_radius;
+    std::memcpy(v.filter_samples, sensor.filter_samples, sizeof(v.filter_samples));
+    v.clamp_emission = sensor.clamp_emission;
+    v.clamp_direct = sensor.clamp_direct;
+    v.clamp_indirect = sensor.clamp_indirect;
+    v.exposure_factor = std::exp2(sensor.exposure);
+    return 0;
+}
+
+}  // namespace zyg

@@ -1,0 +1,168 @@
+// Host side of the drop-in: resources, scene graph, scene compile, camera, view.
+// Mirrors the parts of the reference that sit above the integration loop and feed it:
+//   resources / built-in shapes   src/core/resource/manager.zig:36-82
+//   Scene.createProp*/createLight  src/core/scene/scene.zig:254-342
+//   Prop.configureShape            src/core/scene/prop/prop.zig:96-135
+//   Scene.compile                  src/core/scene/scene.zig:185-223, 402-497
+//   Space world bounds / trafos    src/core/scene/space.zig:60-111
+//   Perspective.update             src/core/camera/camera_perspective.zig:79-122
+//   Sensor.init (filter table)     src/core/rendering/sensor/sensor.zig:27-58,105-120,630-645
+// Output: ZygpuSceneDesc + ZygpuViewDesc (include/zygpu.h) for zygpu_upload_scene / zygpu_set_view.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../../include/zygpu.h"
+#include "bvh_builder.hpp"
+#include "hmath.hpp"
+#include "json.hpp"
+#include "light_tree_builder.hpp"
+
+namespace zyg {
+
+struct HostMesh {
+    std::vector<ZygpuBvhNode> nodes;
+    std::vector<uint32_t>     triangles;  // 3 per triangle, leaf order
+    std::vector<uint16_t>     triangle_parts;
+    std::vector<float>        positions;  // 3 * nv + 1
+    std::vector<uint16_t>     normals;    // 2 * nv
+    std::vector<float>        uvs;        // 2 * nv
+    std::vector<uint32_t>     part_materials;
+    std::vector<float>        part_areas;
+    uint32_t                  num_vertices = 0;
+
+    uint32_t numTriangles() const { return uint32_t(triangles.size() / 3); }
+    uint32_t numParts() const { return uint32_t(part_materials.size()); }
+    uint32_t numMaterials() const {  // triangle_mesh.zig:262-270
+        uint32_t id = 0;
+        for (uint32_t m : part_materials) id = m > id ? m : id;
+        return id + 1;
+    }
+    AABB aabb() const {
+        const ZygpuBvhNode& n = nodes[0];
+        return {{vec(n.min[0], n.min[1], n.min[2], 0.f), vec(n.max[0], n.max[1], n.max[2], 0.f)}};
+    }
+    Vec4f position(uint32_t i) const { return vec(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2], 0.f); }
+};
+
+struct HostShape {
+    uint32_t kind = ZYGPU_SHAPE_RECTANGLE;
+    uint32_t mesh = ZYGPU_NULL;
+};
+
+struct HostProp {
+    uint32_t shape = ZYGPU_NULL;  // resource id
+    uint32_t flags = ZYGPU_PROP_VISIBLE_IN_CAMERA | ZYGPU_PROP_VISIBLE_IN_REFLECTION | ZYGPU_PROP_VISIBLE_IN_SHADOW |
+                     ZYGPU_PROP_SOLID | ZYGPU_PROP_STATIC;
+    uint32_t parts_start = 0;
+};
+
+struct SensorSettings {  // sensor.zig:60-120
+    int32_t filter_radius_int = 2;
+    float   filter_radius = 2.f;
+    float   filter_samples[ZYGPU_FILTER_TAPS + 1] = {};
+    float   clamp_emission = FLT_MAX, clamp_direct = FLT_MAX, clamp_indirect = FLT_MAX;
+    float   exposure = 0.f;
+};
+
+class Engine {
+  public:
+    Engine();
+
+    // --- resources ---
+    uint32_t createMaterial(uint32_t id, const JsonValue& v);  // returns id or ZYGPU_NULL
+    int      updateMaterial(uint32_t id, const JsonValue& v);
+    uint32_t createMesh(uint32_t id, uint32_t num_parts, const uint32_t* parts, uint32_t num_triangles,
+                        const uint32_t* indices, uint32_t num_vertices, const float* positions, uint32_t positions_stride,
+                        const float* normals, uint32_t normals_stride, const float* uvs, uint32_t uvs_stride);
+
+    // --- scene ---
+    uint32_t createEntity();
+    int32_t  createPropShape(uint32_t shape, const uint32_t* materials, uint32_t num_materials, bool unoccluding);
+    int32_t  createPropInstance(uint32_t entity);
+    int      createLight(uint32_t entity);
+    int      setTransformation(uint32_t prop, const float* m16);
+    int      setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss);
+
+    // --- view ---
+    void cameraCreate(uint32_t width, uint32_t height);
+    void loadIntegrators(const JsonValue& v);
+    void loadSensor(const JsonValue& v);
+    void loadCameraParameters(const JsonValue& v);
+
+    // Scene.compile + camera.update: fills scene_desc / view_desc (pointers stay valid until the next compile)
+    int compile(uint32_t frame);
+
+    const ZygpuSceneDesc& sceneDesc() const { return scene_desc_; }
+    const ZygpuViewDesc&  viewDesc() const { return view_desc_; }
+
+    size_t numShapes() const { return shapes_.size(); }
+    size_t numProps() const { return props_.size(); }
+    size_t numMaterials() const { return materials_.size(); }
+    uint32_t shapeNumMaterials(uint32_t shape) const {
+        const HostShape& s = shapes_[shape];
+        return ZYGPU_SHAPE_TRIANGLE_MESH == s.kind ? meshes_[s.mesh].numMaterials() : 1;
+    }
+    uint32_t fallbackMaterial() const { return fallback_material_; }
+
+    int32_t  resolution[2] = {0, 0};
+    int32_t  crop[4] = {0, 0, 0, 0};
+    float    fov = 0.f;
+    float    lens_radius = 0.f;
+    float    focus_distance = 0.f;
+    uint32_t camera_entity = ZYGPU_NULL;
+    uint32_t num_samples_per_pixel = 1;  // capi.zig:99
+    uint32_t sampler_kind = ZYGPU_SAMPLER_SOBOL;
+    float    specular_threshold;
+
+    // integrator (take/take.zig:131-271); default mirrors View's AOV placeholder by PTMIS defaults once configured
+    uint32_t integrator = ZYGPU_INTEGRATOR_PTMIS;
+    uint32_t max_depth_surface = 16, max_depth_volume = 256;
+    float    split_threshold = 0.5f * 0.5f * 0.5f * 0.5f;
+    bool     caustics_path = true;
+    float    regularize_roughness = 0.f;
+
+    SensorSettings sensor;
+
+  private:
+    void     parseMaterial(ZygpuMaterial& m, const JsonValue& rendering_value, uint32_t kind);
+    void     commitMaterial(ZygpuMaterial& m);
+    void     classifyProp(uint32_t p);
+    bool     shapeFinite(uint32_t shape) const;
+    AABB     shapeAabb(uint32_t shape) const;
+    uint32_t shapeNumParts(uint32_t shape) const;
+    void     buildPropTree(const std::vector<uint32_t>& indices, std::vector<ZygpuBvhNode>& nodes,
+                           std::vector<uint32_t>& out_indices);
+    void     setFilter(float radius, int kind);
+
+    std::vector<HostShape>     shapes_;
+    std::vector<HostMesh>      meshes_;
+    std::vector<ZygpuMaterial> materials_;
+    uint32_t                   fallback_material_ = 0;
+
+    std::vector<HostProp>       props_;
+    std::vector<Transformation> world_transformations_;
+    std::vector<uint32_t>       material_ids_;
+    std::vector<uint32_t>       light_ids_;
+    std::vector<ZygpuLight>     lights_;
+    std::vector<uint32_t>       finite_props_, infinite_props_, unoccluding_props_, volume_props_;
+
+    // compiled products (backing store of scene_desc_)
+    std::vector<ZygpuProp>    c_props_;
+    std::vector<ZygpuTrafo>   c_trafos_;
+    std::vector<ZygpuAabb>    c_aabbs_;
+    std::vector<ZygpuMesh>    c_meshes_;
+    std::vector<ZygpuAabb>    c_light_aabbs_;
+    std::vector<float>        c_light_cones_;
+    std::vector<uint8_t>      c_light_two_sided_;
+    std::vector<ZygpuBvhNode> solid_nodes_, unoccluding_nodes_;
+    std::vector<uint32_t>     solid_indices_, unoccluding_indices_;
+    LightTreeOutput           light_tree_;
+    std::vector<float>        luts_[5];
+
+    ZygpuSceneDesc scene_desc_{};
+    ZygpuViewDesc  view_desc_{};
+};
+
+}  // namespace zyg

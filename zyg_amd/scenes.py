@@ -1,0 +1,214 @@
+"""Synthetic scenes of BASELINE.json's configs, built through the `su_*` protocol.
+
+The reference ships no scenes (its data/ directory is git-ignored), so these are
+generated: a Cornell box out of `Rectangle` props (reference built-in shape id 5,
+src/core/resource/manager.zig:36-44), two emissive quads as unoccluding `Light` entities
+(util/scene_loader.zig:249,365-366), the classic short/tall boxes as triangle meshes, and a
+procedural ~1 M-triangle displaced heightfield.
+"""
+import json
+
+import numpy as np
+
+RECTANGLE = 5
+
+WHITE = [0.725, 0.71, 0.68]
+RED = [0.63, 0.065, 0.05]
+GREEN = [0.14, 0.45, 0.091]
+
+
+def trafo(r0, r1, scale, position):
+    """Row-major 4x4 as su_prop_set_transformation expects: rows = scaled basis vectors, row 3 = translation
+    (reference src/capi/capi.zig:491-499).  r2 = r0 x r1 is the Rectangle's normal (rectangle.zig:30-32)."""
+    r0 = np.asarray(r0, dtype=np.float64)
+    r1 = np.asarray(r1, dtype=np.float64)
+    r2 = np.cross(r0, r1)
+    m = np.zeros((4, 4), dtype=np.float32)
+    m[0, :3] = r0 * scale[0]
+    m[1, :3] = r1 * scale[1]
+    m[2, :3] = r2 * scale[2]
+    m[3, :3] = position
+    m[3, 3] = 1.0
+    return m
+
+
+def lambert(color):
+    # Debug-style Lambert with a per-material albedo (debug_sample.zig:19-47)
+    return json.dumps({"rendering": {"Debug": {"color": color}}})
+
+
+def substitute(color, roughness=0.8, metallic=0.0):
+    return json.dumps({"rendering": {"Substitute": {"color": color, "roughness": roughness, "metallic": metallic}}})
+
+
+def light_material(spectrum=(17.0, 12.0, 4.0), value=1.0, num_samples=1):
+    return json.dumps({"rendering": {"Light": {"emittance": {"spectrum": list(spectrum), "value": value,
+                                                             "num_samples": num_samples}}}})
+
+
+def box_mesh(lo, hi, rot_y_deg=0.0):
+    """Axis-aligned box [lo, hi] rotated about the y axis through its centre: 24 vertices, 12 triangles,
+    face normals pointing outward."""
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    c = 0.5 * (lo + hi)
+    h = 0.5 * (hi - lo)
+    faces = [  # (normal, u axis, v axis) with u x v = normal
+        ((1, 0, 0), (0, 1, 0), (0, 0, 1)), ((-1, 0, 0), (0, 0, 1), (0, 1, 0)),
+        ((0, 1, 0), (0, 0, 1), (1, 0, 0)), ((0, -1, 0), (1, 0, 0), (0, 0, 1)),
+        ((0, 0, 1), (1, 0, 0), (0, 1, 0)), ((0, 0, -1), (0, 1, 0), (1, 0, 0)),
+    ]
+    a = np.radians(rot_y_deg)
+    rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    pos, nrm, uv, idx = [], [], [], []
+    for n, u, v in faces:
+        n, u, v = (np.asarray(x, dtype=np.float64) for x in (n, u, v))
+        base = len(pos)
+        for su, sv in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+            p = (n + su * u + sv * v) * h
+            pos.append(rot @ p + c)
+            nrm.append(rot @ n)
+            uv.append((0.5 * (su + 1), 0.5 * (sv + 1)))
+        idx += [base, base + 1, base + 2, base, base + 2, base + 3]
+    return (np.asarray(idx, dtype=np.uint32), np.asarray(pos, dtype=np.float32), np.asarray(nrm, dtype=np.float32),
+            np.asarray(uv, dtype=np.float32))
+
+
+def _value_noise_lattice(n, seed_seq):
+    """n x n lattice of PCG32 floats (seed 0, sequence seed_seq), pure numpy-free loop kept tiny."""
+    state = 0
+    inc = ((seed_seq << 1) | 1) & 0xFFFFFFFFFFFFFFFF
+    mul = 6364136223846793005
+    mask = 0xFFFFFFFFFFFFFFFF
+
+    def step():
+        nonlocal state
+        old = state
+        state = (old * mul + inc) & mask
+        xrs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xrs >> rot) | (xrs << ((-rot) & 31))) & 0xFFFFFFFF
+
+    step()
+    step()
+    out = np.empty(n * n, dtype=np.float32)
+    for i in range(n * n):
+        out[i] = step() / 4294967296.0
+    return out.reshape(n, n)
+
+
+def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
+    """n x n vertices -> 2 (n-1)^2 triangles (n = 708: 999 698), 5-octave value noise displacement over
+    a square of edge `size` centred at the origin in the xz plane; smooth normals; uvs."""
+    u = np.linspace(0.0, 1.0, n, dtype=np.float64)
+    uu, vv = np.meshgrid(u, u, indexing="xy")
+    hgt = np.zeros((n, n), dtype=np.float64)
+    amp = 1.0
+    total = 0.0
+    for o in range(octaves):
+        cells = 4 << o
+        lat = _value_noise_lattice(cells + 1, o + 1).astype(np.float64)
+        x = uu * cells
+        y = vv * cells
+        x0 = np.minimum(x.astype(np.int64), cells - 1)
+        y0 = np.minimum(y.astype(np.int64), cells - 1)
+        fx = x - x0
+        fy = y - y0
+        fx = fx * fx * (3 - 2 * fx)
+        fy = fy * fy * (3 - 2 * fy)
+        v00 = lat[y0, x0]
+        v10 = lat[y0, x0 + 1]
+        v01 = lat[y0 + 1, x0]
+        v11 = lat[y0 + 1, x0 + 1]
+        hgt += amp * ((v00 * (1 - fx) + v10 * fx) * (1 - fy) + (v01 * (1 - fx) + v11 * fx) * fy)
+        total += amp
+        amp *= 0.5
+    hgt = hgt / total
+    # dome-like envelope so the mesh sits inside the box
+    env = np.sin(np.pi * uu) * np.sin(np.pi * vv)
+    y = height * (0.25 + 0.75 * hgt) * env
+    px = (uu - 0.5) * size
+    pz = (vv - 0.5) * size
+    pos = np.stack([px, y, pz], axis=-1)
+
+    dx = np.gradient(y, axis=1) / (size / (n - 1))
+    dz = np.gradient(y, axis=0) / (size / (n - 1))
+    nrm = np.stack([-dx, np.ones_like(dx), -dz], axis=-1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+
+    ii, jj = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="xy")
+    v0 = (jj * n + ii).reshape(-1)
+    v1 = v0 + 1
+    v2 = v0 + n
+    v3 = v2 + 1
+    # counter-clockwise seen from +y
+    idx = np.stack([v0, v2, v1, v1, v2, v3], axis=-1).reshape(-1).astype(np.uint32)
+    uv = np.stack([uu, vv], axis=-1)
+    return (idx, pos.reshape(-1, 3).astype(np.float32), nrm.reshape(-1, 3).astype(np.float32),
+            uv.reshape(-1, 2).astype(np.float32))
+
+
+def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
+            max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
+            mesh_material=None):
+    """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
+
+    material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
+    Returns a dict with prop ids.
+    """
+    mk = lambert if material == "lambert" else substitute
+    cam = engine.camera(width, height, fov_deg=39.3)
+    engine.samples_per_pixel(spp)
+    node = {"depth": {"surface": max_depth}}
+    if split_threshold is not None:
+        node["light_sampling"] = {"split_threshold": split_threshold}
+    engine.integrators(json.dumps({"surface": {integrator: node}}))
+    sensor = {}
+    if filter_name:
+        sensor["filter"] = {filter_name: {}}
+    engine.sensor(json.dumps(sensor))
+
+    white = engine.material(mk(WHITE))
+    red = engine.material(mk(RED))
+    green = engine.material(mk(GREEN))
+    lamp = engine.material(light_material(num_samples=light_samples))
+
+    ids = {"camera": cam, "walls": [], "lights": [], "meshes": []}
+
+    def wall(mat, r0, r1, scale, position):
+        p = engine.prop(RECTANGLE, [mat])
+        engine.transformation(p, trafo(r0, r1, scale, position))
+        ids["walls"].append(p)
+        return p
+
+    # box: x in [-1, 1], y in [0, 2], z in [-1, 1]; all normals point inward; open towards -z (camera side)
+    wall(white, (1, 0, 0), (0, 0, -1), (2, 2, 1), (0, 0, 0))   # floor, n = +y
+    wall(white, (1, 0, 0), (0, 0, 1), (2, 2, 1), (0, 2, 0))    # ceiling, n = -y
+    wall(white, (-1, 0, 0), (0, 1, 0), (2, 2, 1), (0, 1, 1))   # back, n = -z
+    wall(red, (0, 0, -1), (0, 1, 0), (2, 2, 1), (-1, 1, 0))    # left, n = +x
+    wall(green, (0, 0, 1), (0, 1, 0), (2, 2, 1), (1, 1, 0))    # right, n = -x
+
+    for lx in (-0.45, 0.45):  # two emissive quads just below the ceiling, facing down
+        p = engine.prop(RECTANGLE, [lamp], unoccluding=unoccluding_lights)
+        engine.transformation(p, trafo((1, 0, 0), (0, 0, 1), (0.5, 0.5, 1), (lx, 1.98, 0.0)))
+        engine.light(p)
+        ids["lights"].append(p)
+
+    identity = trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))
+    if boxes:
+        for lo, hi, rot in (((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0)):
+            idx, pos, nrm, uv = box_mesh(lo, hi, rot)
+            shape = engine.triangle_mesh(idx, pos, nrm, uv)
+            p = engine.prop(shape, [white])
+            engine.transformation(p, identity)
+            ids["meshes"].append(p)
+    if mesh is not None:
+        idx, pos, nrm, uv = mesh
+        shape = engine.triangle_mesh(idx, pos, nrm, uv)
+        mm = white if mesh_material is None else mesh_material
+        p = engine.prop(shape, [mm])
+        engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0.02, 0.1)))
+        ids["meshes"].append(p)
+
+    engine.transformation(cam, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, -3.9)))
+    return ids
