@@ -306,8 +306,9 @@ int zygpu_enable_stats(ZygpuContext* ctx, int enabled);
 int zygpu_get_stats(ZygpuContext* ctx, ZygpuStats* out_stats);
 int zygpu_reset_stats(ZygpuContext* ctx);
 
-/* Sum of the durations (ms, HIP events on the context's stream) and launch count of the dominant
- * kernel (`wf_trace`, the closest-hit / any-hit traversal stage) since the last reset. */
+/* Sums of the durations (ms, HIP events on the context's stream, one pair per launch) and launch counts of the
+ * two wavefront kernels since the last reset: index 0 = `wf_trace` (closest-hit + any-hit traversal),
+ * index 1 = `wf_shade` (integrator state machine).  Both out arrays hold 2 entries. */
 int zygpu_kernel_time(ZygpuContext* ctx, double* out_ms, uint64_t* out_launches, int reset);
 
 const char* zygpu_last_error(void);

@@ -1,0 +1,33 @@
+import ctypes
+import os
+
+import numpy as np
+
+import zyg_amd
+
+
+def oracle_render(oracle, scene_desc, view_desc, iterations, threads=None, iteration0=0, y_range=None, stats=None,
+                  samples_per_call=1):
+    w, h = view_desc.resolution[0], view_desc.resolution[1]
+    film = np.zeros((h, w, 4), dtype=np.float32)
+    y0, y1 = y_range if y_range else (0, h)
+    st = stats if stats is not None else zyg_amd.Stats()
+    rc = oracle.zyg_oracle_render(ctypes.addressof(scene_desc), ctypes.addressof(view_desc), 0, iteration0, iterations,
+                                  samples_per_call, y0, y1, film.ctypes.data, threads or (os.cpu_count() or 1),
+                                  ctypes.byref(st))
+    assert rc == 0
+    return film
+
+
+def oracle_resolve(oracle, view_desc, film):
+    h, w = film.shape[:2]
+    out = np.zeros_like(film)
+    oracle.zyg_oracle_resolve(ctypes.addressof(view_desc), film.ctypes.data, out.ctypes.data, w * h)
+    return out
+
+
+def rms(a, b):
+    """Per-pixel RMS over RGB of the resolved linear image, values clamped to [0, 1]."""
+    a = np.clip(np.nan_to_num(a[..., :3]), 0.0, 1.0).astype(np.float64)
+    b = np.clip(np.nan_to_num(b[..., :3]), 0.0, 1.0).astype(np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))

@@ -1,0 +1,389 @@
+// Device light sampling.  Behaviour follows the reference:
+//   light BVH (adaptive splitting)  src/core/scene/light/light_tree.zig:25-227 (Node, importance), 346-517 (Tree)
+//   Rectangle solid-angle sampling  src/core/scene/shape/rectangle.zig:199-357, 554-575 (Urena et al.)
+//   shadow ray                      src/core/scene/shape/shape.zig:401-416
+//   Emittance.radiance              src/core/scene/light/emittance.zig:29-59
+#pragma once
+
+#include "dsampler.hpp"
+#include "dscene.hpp"
+
+namespace zd {
+
+constexpr float kLowThreshold = 0.00000001f;  // integrator/helper.zig:29
+constexpr int   kMaxLightPicks = 64;          // light_tree.zig:249
+
+ZD uint32_t numSamples(uint32_t num, float split_threshold) { return split_threshold <= kLowThreshold ? 1u : num; }
+
+struct LightPick {
+    uint32_t offset;
+    float    pdf;
+};
+
+ZD float clampedCosSub(float cos_a, float cos_b, float sin_a, float sin_b) {
+    const float angle = __fmaf_rn(cos_a, cos_b, sin_a * sin_b);
+    return cos_a > cos_b ? 1.f : angle;
+}
+ZD float clampedSinSub(float cos_a, float cos_b, float sin_a, float sin_b) {
+    const float angle = __fmaf_rn(sin_a, cos_b, -sin_b * cos_a);
+    return cos_a > cos_b ? 0.f : angle;
+}
+
+// light_tree.zig:186-227
+ZD float importance(f3 p, f3 n, f3 center, f3 cone_axis, float cos_cone, float radius, float power, bool two_sided,
+                    bool total_sphere) {
+    const f3    axis = p - center;
+    const float l = length3(axis);
+    const f3    na = axis / S3(l);
+
+    const float sin_cu = mn(radius / l, 1.f);
+    const float dd = dot3(cone_axis, na);
+    const float cos_a = two_sided ? fabsf(dd) : dd;
+    const float cos_n = mx(-dot3(n, na), 0.f);
+
+    const float cos_cu = __fsqrt_rn(mx(__fmaf_rn(sin_cu, -sin_cu, 1.f), 0.f));
+    const float sin_cone = __fsqrt_rn(mx(__fmaf_rn(cos_cone, -cos_cone, 1.f), 0.f));
+    const float sin_a = __fsqrt_rn(mx(__fmaf_rn(cos_a, -cos_a, 1.f), 0.f));
+    const float sin_n = __fsqrt_rn(mx(__fmaf_rn(cos_n, -cos_n, 1.f), 0.f));
+
+    const float ta = clampedCosSub(cos_a, cos_cone, sin_a, sin_cone);
+    const float tb = clampedSinSub(cos_a, cos_cone, sin_a, sin_cone);
+    const float tc = clampedCosSub(ta, cos_cu, tb, sin_cu);
+    const float tn = clampedCosSub(cos_n, cos_cu, sin_n, sin_cu);
+
+    const float ra = total_sphere ? 1.f : tn;
+    const float rb = mx(tc, 0.f);
+
+    const float clamped_dist = mx(l, 0.5f * radius);
+    const float rc = power / (clamped_dist * clamped_dist);
+
+    return mx(ra * rb * rc, 0.f);
+}
+
+struct LightTree {
+    const DScene& s;
+
+    ZD static bool     hasChildren(const ZygpuLightNode& n) { return 0 != (n.meta & 1u); }
+    ZD static bool     nodeTwoSided(const ZygpuLightNode& n) { return 0 != (n.meta & 2u); }
+    ZD static uint32_t childrenOrLight(const ZygpuLightNode& n) { return n.meta >> 2; }
+
+    ZD void decompressCenter(const ZygpuLightNode& n, f3& c, float& r) const {  // light_tree.zig:37-40
+        const f3 bmin = xyz(s.lt_bounds_min), bmax = xyz(s.lt_bounds_max);
+        const f3 t = {unorm16ToFloat(n.center[0]), unorm16ToFloat(n.center[1]), unorm16ToFloat(n.center[2])};
+        c = lerp3(bmin, bmax, t);
+        r = lerpf(s.lt_bounds_min.w, s.lt_bounds_max.w, unorm16ToFloat(n.center[3]));
+    }
+
+    ZD float nodeWeight(const ZygpuLightNode& n, f3 p, f3 nrm, bool total_sphere) const {
+        f3    c;
+        float r;
+        decompressCenter(n, c, r);
+        const f3 axis = {snorm16ToFloat(n.cone[0]), snorm16ToFloat(n.cone[1]), snorm16ToFloat(n.cone[2])};
+        return importance(p, nrm, c, axis, snorm16ToFloat(n.cone[3]), r, n.power, nodeTwoSided(n), total_sphere);
+    }
+
+    ZD bool nodeSplit(const ZygpuLightNode& n, f3 p, float threshold) const {  // light_tree.zig:64-88
+        f3    c;
+        float r;
+        decompressCenter(n, c, r);
+        const float dd = mn(distance3(p, c), 1.0e6f);
+        const float a = mx(dd - r, 0.001f);
+        const float b = dd + r;
+        const float eg = 1.f / (a * b);
+        const float eg2 = eg * eg;
+        const float a3 = a * a * a, b3 = b * b * b;
+        const float e2g = (b3 - a3) / (3.f * (b - a) * a3 * b3);
+        const float vg = e2g - eg2;
+        const float ve = n.variance, ee = n.power;
+        const float s2 = mx(ve * vg + ve * eg2 + ee * ee * vg, 0.f);
+        const float ns = 1.f / (1.f + __fsqrt_rn(s2));
+        return ns < threshold;
+    }
+
+    ZD float lightWeight(f3 p, f3 n, bool total_sphere, uint32_t light) const {  // light_tree.zig:229-235; scene.zig:664-676
+        const float4 bmin = s.light_aabbs[2 * light], bmax = s.light_aabbs[2 * light + 1];
+        const f3     pos = S3(0.5f) * (xyz(bmin) + xyz(bmax));
+        const float4 cone = s.light_cones[light];
+        return importance(p, n, pos, xyz(cone), cone.w, bmax.w, bmin.w, 0 != s.lights[light].two_sided, total_sphere);
+    }
+
+    ZD LightPick nodeRandomLight(const ZygpuLightNode& node, f3 p, f3 n, bool total_sphere, float random) const {  // :90-147
+        const uint32_t num_lights = node.num_lights;
+        const uint32_t light = childrenOrLight(node);
+        if (1 == num_lights) return {s.lt_mapping[light], 1.f};
+
+        uint32_t front = light, back = light + num_lights - 1;
+        float    w_front = lightWeight(p, n, total_sphere, s.lt_mapping[front]);
+        float    w_back = lightWeight(p, n, total_sphere, s.lt_mapping[back]);
+        float    w_sum_front = w_front, w_sum_back = w_back, w_sum = 0.f;
+        while (front != back) {
+            w_sum = w_sum_front + w_sum_back;
+            if (w_sum_front <= random * w_sum) {
+                front += 1;
+                if (front != back) {
+                    w_front = lightWeight(p, n, total_sphere, s.lt_mapping[front]);
+                    w_sum_front += w_front;
+                } else {
+                    w_front = w_back;
+                }
+            } else {
+                back -= 1;
+                if (front != back) {
+                    w_back = lightWeight(p, n, total_sphere, s.lt_mapping[back]);
+                    w_sum_back += w_back;
+                }
+            }
+        }
+        if (0.f == w_sum) return {0, 0.f};
+        return {s.lt_mapping[front], w_front / w_sum};
+    }
+
+    ZD float nodePdf(const ZygpuLightNode& node, f3 p, f3 n, bool total_sphere, uint32_t id) const {  // :149-183
+        const uint32_t num_lights = node.num_lights;
+        if (1 == num_lights) return 1.f;
+        const uint32_t light = childrenOrLight(node), end = light + num_lights;
+        float          w_id = 0.f, sum = 0.f;
+        for (uint32_t i = light; i < end; ++i) {
+            const float lw = lightWeight(p, n, total_sphere, s.lt_mapping[i]);
+            sum += lw;
+            if (id == i) w_id = lw;
+        }
+        if (0.f == sum) return 0.f;
+        return w_id / sum;
+    }
+
+    // Tree.randomLight (light_tree.zig:346-447), finite lights only.  Calls visit(index, pick) for every pick in
+    // the reference's order; returns the number of picks.
+    template <typename Visit>
+    ZD uint32_t randomLight(f3 p, f3 n, bool total_sphere, float random, float split_threshold, Visit&& visit) const {
+        uint32_t   current_light = 0;
+        float      ip = 0.f;
+        const bool split = split_threshold > 0.f;
+        if (!(split && s.lt_num_infinite < kMaxLightPicks - 1)) ip = s.lt_infinite_weight;
+        if (0 == s.lt_num_nodes) return 0;
+
+        const float    pd = 1.f - ip;
+        const uint32_t max_split_depth = s.lt_max_split_depth;
+
+        // traversal stack of at most MaxSplitDepth + 1 entries (light_tree.zig:721-751)
+        float    st_pdf[12], st_random[12];
+        uint32_t st_node[12], st_depth[12];
+        int      end = 0;
+
+        float    t_pdf = pd, t_random = (random - ip) / pd;
+        uint32_t t_node = 0, t_depth = split ? 0u : max_split_depth;
+        st_pdf[0] = t_pdf;
+        st_random[0] = t_random;
+        st_node[0] = t_node;
+        st_depth[0] = t_depth;
+        end = 1;
+
+        while (0 != end) {
+            const ZygpuLightNode node = s.lt_nodes[t_node];
+            if (hasChildren(node)) {
+                const bool     do_split = t_depth < max_split_depth && nodeSplit(node, p, split_threshold);
+                const uint32_t c0 = childrenOrLight(node), c1 = c0 + 1;
+                if (do_split) {
+                    t_depth += 1;
+                    t_node = c0;
+                    st_pdf[end] = t_pdf;
+                    st_random[end] = t_random;
+                    st_node[end] = c1;
+                    st_depth[end] = t_depth;
+                    end += 1;
+                } else {
+                    t_depth = max_split_depth;
+                    float       p0 = nodeWeight(s.lt_nodes[c0], p, n, total_sphere);
+                    float       p1 = nodeWeight(s.lt_nodes[c1], p, n, total_sphere);
+                    const float pt = p0 + p1;
+                    if (0.f == pt) {
+                        end -= 1;
+                        t_pdf = st_pdf[end];
+                        t_random = st_random[end];
+                        t_node = st_node[end];
+                        t_depth = st_depth[end];
+                        continue;
+                    }
+                    p0 /= pt;
+                    p1 /= pt;
+                    if (t_random < p0) {
+                        t_node = c0;
+                        t_pdf *= p0;
+                        t_random /= p0;
+                    } else {
+                        t_node = c1;
+                        t_pdf *= p1;
+                        t_random = mn((t_random - p0) / p1, 1.f);
+                    }
+                }
+            } else {
+                const LightPick pick = nodeRandomLight(node, p, n, total_sphere, t_random);
+                if (pick.pdf > 0.f) {
+                    visit(current_light, LightPick{pick.offset, pick.pdf * t_pdf});
+                    current_light += 1;
+                }
+                end -= 1;
+                t_pdf = st_pdf[end];
+                t_random = st_random[end];
+                t_node = st_node[end];
+                t_depth = st_depth[end];
+            }
+        }
+        return current_light;
+    }
+
+    // Tree.pdf (light_tree.zig:449-517)
+    ZD float pdf(f3 p, f3 n, bool total_sphere, float split_threshold, uint32_t id) const {
+        const uint32_t lo = s.lt_orders[id];
+        const bool     split = split_threshold > 0.f;
+        const bool     split_infinite = split && s.lt_num_infinite < kMaxLightPicks - 1;
+        if (0 == s.lt_num_nodes) return 0.f;
+        const float    ip = split_infinite ? 0.f : s.lt_infinite_weight;
+        const uint32_t max_split_depth = s.lt_max_split_depth;
+        float          pd = 1.f - ip;
+        uint32_t       nid = 0;
+        uint32_t       depth = split ? 0u : max_split_depth;
+        for (;;) {
+            const ZygpuLightNode node = s.lt_nodes[nid];
+            if (hasChildren(node)) {
+                const bool     do_split = depth < max_split_depth && nodeSplit(node, p, split_threshold);
+                const uint32_t c0 = childrenOrLight(node), c1 = c0 + 1;
+                const uint32_t middle = s.lt_middles[nid];
+                if (do_split) {
+                    depth += 1;
+                    nid = lo < middle ? c0 : c1;
+                } else {
+                    depth = max_split_depth;
+                    const float p0 = nodeWeight(s.lt_nodes[c0], p, n, total_sphere);
+                    const float p1 = nodeWeight(s.lt_nodes[c1], p, n, total_sphere);
+                    const float pt = p0 + p1;
+                    if (0.f == pt) return 0.f;
+                    if (lo < middle) {
+                        nid = c0;
+                        pd *= p0 / pt;
+                    } else {
+                        nid = c1;
+                        pd *= p1 / pt;
+                    }
+                }
+            } else {
+                return pd * nodePdf(node, p, n, total_sphere, lo);
+            }
+        }
+    }
+};
+
+struct SphQuad {  // rectangle.zig:199-303
+    f3    o, x, y, z;
+    float z0, x0, y0, x1, y1, b0, b1, k, Sa;
+
+    ZD static SphQuad init(f3 scale, f3 o) {
+        const f3 sv = {-0.5f * scale.x, -0.5f * scale.y, 0.f};
+        const f3 ex = {scale.x, 0.f, 0.f};
+        const f3 ey = {0.f, scale.y, 0.f};
+        SphQuad  q;
+        q.o = o;
+        const float exl = length3(ex), eyl = length3(ey);
+        q.x = ex / S3(exl);
+        q.y = ey / S3(eyl);
+        q.z = cross3(q.x, q.y);
+        const f3 d = sv - o;
+        q.z0 = dot3(d, q.z);
+        if (q.z0 > 0.f) {
+            q.z = -q.z;
+            q.z0 = -q.z0;
+        }
+        q.x0 = dot3(d, q.x);
+        q.y0 = dot3(d, q.y);
+        q.x1 = q.x0 + exl;
+        q.y1 = q.y0 + eyl;
+        const f3 v00 = {q.x0, q.y0, q.z0}, v01 = {q.x0, q.y1, q.z0}, v10 = {q.x1, q.y0, q.z0}, v11 = {q.x1, q.y1, q.z0};
+        const f3 n0 = normalize3(cross3(v00, v10));
+        const f3 n1 = normalize3(cross3(v10, v11));
+        const f3 n2 = normalize3(cross3(v11, v01));
+        const f3 n3 = normalize3(cross3(v01, v00));
+        const float g0 = acosf(-dot3(n0, n1));
+        const float g1 = acosf(-dot3(n1, n2));
+        const float g2 = acosf(-dot3(n2, n3));
+        const float g3 = acosf(-dot3(n3, n0));
+        q.b0 = n0.z;
+        q.b1 = n2.z;
+        q.k = 2.f * kPi - g2 - g3;
+        q.Sa = g0 + g1 - q.k;
+        return q;
+    }
+
+    ZD f3 sample(float u0, float u1) const {
+        const float au = u0 * Sa + k;
+        const float fu = (cosf(au) * b0 - b1) / sinf(au);
+        float       cu = 1.f / __fsqrt_rn(fu * fu + b0 * b0) * (fu > 0.f ? 1.f : -1.f);
+        cu = stdClamp(cu, -1.f, 1.f);
+        float xu = -(cu * z0) / __fsqrt_rn(1.f - cu * cu);
+        xu = stdClamp(xu, x0, x1);
+        const float dd = __fsqrt_rn(xu * xu + z0 * z0);
+        const float h0 = y0 / __fsqrt_rn(dd * dd + y0 * y0);
+        const float h1 = y1 / __fsqrt_rn(dd * dd + y1 * y1);
+        const float hv = h0 + u1 * (h1 - h0);
+        const float hv2 = hv * hv;
+        const float eps = __uint_as_float(0x35800000u);
+        const float yv = hv2 < 1.f - eps ? ((hv * dd) / __fsqrt_rn(1.f - hv2)) : y1;
+        return o + S3(xu) * x + S3(yv) * y + S3(z0) * z;
+    }
+
+    ZD float pdf(f3 scale) const {
+        const float sqr_dist = squaredLength3(o);
+        const float area = scale.x * scale.y;
+        const float numer = area * fabsf(o.z);
+        const float denom = sqr_dist * __fsqrt_rn(sqr_dist);
+        return numer > denom * kDotMin ? (1.f / Sa) : (denom / numer);
+    }
+};
+
+struct SampleTo {  // shape/sample.zig:7-29
+    f3    p, n, wi;
+    float pdf;
+};
+
+// rectangle.zig:305-357 for one sample (lights with num_samples > 1 are rejected at upload)
+ZD bool rectangleSampleTo(f3 p, f3 n, const Trafo& trafo, bool two_sided, bool total_sphere, Sampler& sampler, SampleTo& out) {
+    const f3      lp = trafo.worldToFramePoint(p);
+    const SphQuad squad = SphQuad::init(trafo.scale, lp);
+    const float   sample_pdf = 1.f * squad.pdf(trafo.scale);
+    float         u0, u1;
+    sampler.sample2D(u0, u1);
+    const f3 ls = squad.sample(u0, u1);
+    const f3 ws = trafo.frameToWorldPoint(ls);
+    const f3 dir = normalize3(ws - p);
+    f3       wn = trafo.r2;
+    if (two_sided && dot3(wn, dir) > 0.f) wn = -wn;
+    if (-dot3(wn, dir) < kDotMin || 0.f == squad.Sa || (dot3(dir, n) <= 0.f && !total_sphere)) return false;
+    out.p = ws;
+    out.n = wn;
+    out.wi = dir;
+    out.pdf = sample_pdf;
+    return true;
+}
+
+ZD float rectanglePdf(f3 p, const Trafo& frag_trafo) {  // rectangle.zig:554-575, one sample
+    const SphQuad squad = SphQuad::init(frag_trafo.scale, frag_trafo.worldToFramePoint(p));
+    return 1.f * squad.pdf(frag_trafo.scale);
+}
+
+// shape.zig:401-416
+ZD void shadowRay(f3 origin, const SampleTo& sample, f3& dir, float& len) {
+    const f3 light_pos = offsetRay(sample.p, sample.n);
+    const f3 shadow_axis = light_pos - origin;
+    len = length3(shadow_axis);
+    dir = shadow_axis / S3(len);
+}
+
+// emittance.zig:29-59, uniform emission map, no profile
+ZD f3 emittanceRadiance(const ZygpuMaterial& m, f3 wi, f3 trafo_r2, float area, bool in_camera) {
+    if (-dot3(wi, trafo_r2) < m.cos_a) return S3(0.f);
+    const float factor = in_camera ? m.camera_weight : 1.f;
+    const f3    intensity = mk3(m.emission[0], m.emission[1], m.emission[2]) * S3(1.f);
+    if (m.emission_normalize) return S3(factor / area) * intensity;
+    return S3(factor) * intensity;
+}
+
+}  // namespace zd

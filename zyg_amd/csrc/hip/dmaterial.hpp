@@ -1,0 +1,322 @@
+// Device material closures (uniform textures).  Behaviour follows the reference:
+//   Debug (Lambert)          material/debug/debug_material.zig:20-28, debug_sample.zig:15-47
+//   Light                    material/light/light_sample.zig:7-13
+//   Substitute (opaque base) material/substitute/substitute_material.zig:114-221, substitute_sample.zig:38-410
+//   diffuse.Micro            material/diffuse.zig:42-110;  ggx: material/ggx.zig:30-46,60-130,228-449
+//   fresnel.Schlick          material/fresnel.zig:5-29;   LUT eval: base/math/interpolated_function.zig:105-271
+#pragma once
+
+#include "dlight.hpp"
+
+namespace zd {
+
+enum : uint32_t { kScatterDiffuse = 0, kScatterGlossy = 1, kScatterSpecular = 2 };
+
+struct BxdfResult {
+    f3    reflection;
+    float pdf;
+};
+
+struct BxdfSample {
+    f3       reflection, wi;
+    float    pdf;
+    float    reg_alpha;   // bxdf.zig Path.reg_alpha
+    uint32_t scattering;  // all samples in scope are reflections
+};
+
+struct Luts {
+    const DScene& s;
+    ZD static float bilinear(float c0, float c1, float c2, float c3, float sx, float t) {  // math.zig:172-179
+        const float _s = 1.f - sx, _t = 1.f - t;
+        return _t * (_s * c0 + sx * c1) + t * (_s * c2 + sx * c3);
+    }
+    ZD static float eval1(const float* smp, int N, float x) {
+        const float    o = mn(x, 1.f) * float(N - 1);
+        const uint32_t offset = uint32_t(o);
+        const float    t = o - float(offset);
+        return lerpf(smp[offset], smp[min(offset + 1, uint32_t(N - 1))], t);
+    }
+    ZD static float eval2(const float* smp, int X, int Y, float x, float y) {
+        const float ox = mn(x, 1.f) * float(X - 1), oy = mn(y, 1.f) * float(Y - 1);
+        const int   o0 = int(ox), o1 = int(oy);
+        const float t0 = ox - float(o0), t1 = oy - float(o1);
+        const int   col1 = min(o0 + 1, X - 1);
+        const int   row0 = o1 * X, row1 = min(o1 + 1, Y - 1) * X;
+        return bilinear(smp[o0 + row0], smp[col1 + row0], smp[o0 + row1], smp[col1 + row1], t0, t1);
+    }
+    ZD static float eval3(const float* smp, int X, int Y, int Z, float x, float y, float z) {
+        const float ox = mn(x, 1.f) * float(X - 1), oy = mn(y, 1.f) * float(Y - 1), oz = mn(z, 1.f) * float(Z - 1);
+        const int   o0 = int(ox), o1 = int(oy), o2 = int(oz);
+        const float t0 = ox - float(o0), t1 = oy - float(o1), t2 = oz - float(o2);
+        const int   col1 = min(o0 + 1, X - 1);
+        const int   row0 = o1 * X, row1 = min(o1 + 1, Y - 1) * X;
+        const int   area = X * Y;
+        const int   s0 = o2 * area, s1 = min(o2 + 1, Z - 1) * area;
+        const float c0 = bilinear(smp[o0 + row0 + s0], smp[col1 + row0 + s0], smp[o0 + row1 + s0], smp[col1 + row1 + s0], t0, t1);
+        const float c1 = bilinear(smp[o0 + row0 + s1], smp[col1 + row0 + s1], smp[o0 + row1 + s1], smp[col1 + row1 + s1], t0, t1);
+        return lerpf(c0, c1, t2);
+    }
+    ZD float E_m(float n_dot, float alpha) const { return eval2(s.lut_e_m, 32, 32, n_dot, alpha); }
+    ZD float E_m_avg(float alpha) const { return eval1(s.lut_e_m_avg, 32, alpha); }
+    ZD float E(float n_dot, float alpha, float f0) const { return eval3(s.lut_e, 16, 16, 16, n_dot, alpha, f0); }
+    ZD float E_avg(float alpha, float f0) const { return eval2(s.lut_e_avg, 16, 16, alpha, f0); }
+};
+
+ZD float pow5(float x) {
+    const float x2 = x * x, x4 = x2 * x2;
+    return x4 * x;
+}
+ZD f3 schlick(f3 f0, float wo_dot_h) { return fma3(S3(pow5(1.f - wo_dot_h)), S3(1.f) - f0, f0); }
+
+constexpr float kMinRoughness = 0.01314f;  // ggx.zig:14
+
+struct Micro {
+    f3    h;
+    float n_dot_wi, h_dot_wi;
+};
+
+ZD f3 dspbrMicroEc(const Luts& L, f3 f0, float n_dot_wi, float n_dot_wo, float alpha) {  // ggx.zig:34-46
+    const float e_wo = L.E_m(n_dot_wo, alpha), e_wi = L.E_m(n_dot_wi, alpha), e_avg = L.E_m_avg(alpha);
+    const float m = ((1.f - e_wo) * (1.f - e_wi)) / (kPi * (1.f - e_avg));
+    const f3    f_avg = fma3(S3(20.f / 21.f), f0, S3(1.f / 21.f));
+    const f3    f = ((f_avg * f_avg) * S3(e_avg)) / fma3(-f_avg, S3(1.f - e_avg), S3(1.f));
+    return S3(m) * f;
+}
+
+ZD float pdfVisible(float d, float g1_wo) { return (0.5f * d) / g1_wo; }
+ZD float isoDistribution(float n_dot_h, float a2) {
+    const float d = __fmaf_rn(n_dot_h * n_dot_h, a2 - 1.f, 1.f);
+    return a2 / (kPi * d * d);
+}
+ZD void isoVisibilityAndG1Wo(float n_dot_wi, float n_dot_wo, float alpha2, float& g0, float& g1) {
+    const float t_wi = __fsqrt_rn(__fmaf_rn(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
+    const float t_wo = __fsqrt_rn(__fmaf_rn(1.f - alpha2, n_dot_wo * n_dot_wo, alpha2));
+    g0 = 0.5f / (n_dot_wi * t_wo + n_dot_wo * t_wi);
+    g1 = t_wo + n_dot_wo;
+}
+ZD float anisoDistribution(float n_dot_h, float x_dot_h, float y_dot_h, float a0, float a1) {
+    const float a20 = a0 * a0, a21 = a1 * a1;
+    const float x = (x_dot_h * x_dot_h) / a20, y = (y_dot_h * y_dot_h) / a21;
+    const float d = (x + y) + (n_dot_h * n_dot_h);
+    return 1.f / (kPi * (a0 * a1) * (d * d));
+}
+ZD void anisoVisibilityAndG1Wo(float t_dot_wi, float t_dot_wo, float b_dot_wi, float b_dot_wo, float n_dot_wi, float n_dot_wo,
+                               float a0, float a1, float& g0, float& g1) {
+    const float t_wo = length3(mk3(a0 * t_dot_wo, a1 * b_dot_wo, n_dot_wo));
+    const float t_wi = length3(mk3(a0 * t_dot_wi, a1 * b_dot_wi, n_dot_wi));
+    g0 = 0.5f / (n_dot_wi * t_wo + n_dot_wo * t_wi);
+    g1 = t_wo + n_dot_wo;
+}
+
+ZD f3 ggxSample(f3 wo, float a0, float a1, float xi0, float xi1, const Frame& frame, float& n_dot_h) {  // ggx.zig:396-414
+    const f3    wo_l = frame.worldToFrame(wo);
+    const f3    v = normalize3(mk3(a0 * wo_l.x, a1 * wo_l.y, wo_l.z));
+    const float phi = (2.f * kPi) * xi0;
+    const float z = __fmaf_rn(1.f - xi1, 1.f + v.z, -v.z);
+    const float sin_theta = __fsqrt_rn(saturate(1.f - z * z));
+    const float x = sin_theta * cosf(phi), y = sin_theta * sinf(phi);
+    const f3    h = mk3(x, y, z) + v;
+    const f3    m = normalize3(mk3(a0 * h.x, a1 * h.y, h.z));
+    n_dot_h = clampf(m.z, kDotMin, 1.f);
+    return frame.frameToWorld(m);
+}
+
+ZD BxdfResult ggxReflection(f3 wi, f3 wo, f3 h, float n_dot_wi, float n_dot_wo, float wo_dot_h, float a0, float a1, f3 f0,
+                            const Frame& frame) {
+    float       d, g0, g1;
+    const float n_dot_h = saturate(dot3(frame.z, h));
+    if (a0 == a1) {
+        const float alpha2 = a0 * a0;
+        d = isoDistribution(n_dot_h, alpha2);
+        isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g0, g1);
+    } else {
+        d = anisoDistribution(n_dot_h, dot3(frame.x, h), dot3(frame.y, h), a0, a1);
+        anisoVisibilityAndG1Wo(dot3(frame.x, wi), dot3(frame.x, wo), dot3(frame.y, wi), dot3(frame.y, wo), n_dot_wi, n_dot_wo, a0, a1,
+                               g0, g1);
+    }
+    const f3 f = schlick(f0, wo_dot_h);
+    return {S3(d * g0) * f, pdfVisible(d, g1)};
+}
+
+ZD Micro ggxReflect(f3 wo, float n_dot_wo, float a0, float a1, float specular_threshold, float xi0, float xi1, f3 f0,
+                    const Frame& frame, BxdfSample& result) {
+    float       n_dot_h;
+    const f3    h = ggxSample(wo, a0, a1, xi0, xi1, frame, n_dot_h);
+    const float wo_dot_h = clampDot(wo, h);
+    const f3    wi = normalize3(fma3(S3(2.f * wo_dot_h), h, -wo));
+    const float n_dot_wi = frame.clampNdot(wi);
+    float       d, g0, g1;
+    if (a0 == a1) {
+        const float alpha2 = a0 * a0;
+        d = isoDistribution(n_dot_h, alpha2);
+        isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g0, g1);
+    } else {
+        d = anisoDistribution(n_dot_h, dot3(frame.x, h), dot3(frame.y, h), a0, a1);
+        anisoVisibilityAndG1Wo(dot3(frame.x, wi), dot3(frame.x, wo), dot3(frame.y, wi), dot3(frame.y, wo), n_dot_wi, n_dot_wo, a0, a1,
+                               g0, g1);
+    }
+    const f3 f = schlick(f0, wo_dot_h);
+    result.reflection = S3(d * g0) * f;
+    result.wi = wi;
+    result.pdf = pdfVisible(d, g1);
+    result.reg_alpha = a1;
+    result.scattering = a1 <= specular_threshold ? kScatterSpecular : kScatterGlossy;
+    return {h, n_dot_wi, wo_dot_h};
+}
+
+struct MaterialSample {
+    uint32_t kind;
+    Frame    frame;
+    f3       geo_n, n, wo;
+    float    a0, a1;
+    bool     can_evaluate, translucent, avoid_caustics;
+    f3       albedo;
+    f3       f0;
+    float    metallic, specular, specular_threshold, opacity;
+
+    ZD bool sameHemisphere(f3 v) const { return dot3(geo_n, v) > 0.f; }
+
+    ZD float diffuseWeight(const Luts& L) const {  // diffuse.zig:50-73 estimateContribution
+        const float e_avg = L.E_avg(a1, hmax3(f0));
+        const float a = e_avg;
+        const float b = 1.f / (kPi * (1.f - e_avg)) * hmax3(albedo);
+        return b / (a + b);
+    }
+    ZD f3 microEvaluate(const Luts& L, f3 color, float n_dot_wi, float n_dot_wo, float f0m) const {  // diffuse.zig:103-110
+        const float e_wo = L.E(n_dot_wo, a1, f0m), e_wi = L.E(n_dot_wi, a1, f0m), e_avg = L.E_avg(a1, f0m);
+        return S3(((1.f - e_wo) * (1.f - e_wi)) / (kPi * (1.f - e_avg))) * color;
+    }
+
+    ZD BxdfResult baseEvaluate(const Luts& L, f3 wi, f3 h, float wo_dot_h, bool force_disable_caustics) const {
+        const float n_dot_wi = frame.clampNdot(wi);
+        const float n_dot_wo = frame.clampAbsNdot(wo);
+        BxdfResult  d{S3(0.f), 0.f};
+        float       dw = 0.f;
+        if (1.f != metallic) {
+            d.reflection = microEvaluate(L, S3(opacity) * albedo, n_dot_wi, n_dot_wo, hmax3(f0));
+            d.pdf = n_dot_wi * kPiInv;
+            dw = diffuseWeight(L);
+        }
+        if ((force_disable_caustics || avoid_caustics) && a1 <= specular_threshold) return {S3(n_dot_wi) * d.reflection, dw * d.pdf};
+        const BxdfResult gg = ggxReflection(wi, wo, h, n_dot_wi, n_dot_wo, wo_dot_h, a0, a1, f0, frame);
+        const f3         mms = dspbrMicroEc(L, f0, n_dot_wi, n_dot_wo, a1);
+        const float      pdf = dw * d.pdf + (1.f - dw) * gg.pdf;
+        return {S3(n_dot_wi) * (d.reflection + S3(specular) * (gg.reflection + mms)), pdf};
+    }
+
+    ZD BxdfResult evaluate(const DScene& s, f3 wi) const {  // material_sample.zig:47-53
+        if (ZYGPU_MAT_LIGHT == kind) return {S3(0.f), 0.f};
+        if (ZYGPU_MAT_DEBUG == kind) {
+            const float n_dot_wi = frame.clampNdot(wi);
+            const float pdf = n_dot_wi * kPiInv;
+            return {S3(pdf) * albedo, pdf};
+        }
+        if (!sameHemisphere(wo)) return {S3(0.f), 0.f};
+        const f3    h = normalize3(wo + wi);
+        const float wo_dot_h = clampDot(wo, h);
+        return baseEvaluate(Luts{s}, wi, h, wo_dot_h, false);
+    }
+
+    ZD bool sample(const DScene& s, Sampler& sampler, BxdfSample& result) const {  // material_sample.zig:55-70
+        if (ZYGPU_MAT_LIGHT == kind) return false;
+        if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:28-47
+            float u0, u1;
+            sampler.sample2D(u0, u1);
+            const f3    is = hemisphereCosine(u0, u1);
+            const f3    wi = normalize3(frame.frameToWorld(is));
+            const float n_dot_wi = frame.clampNdot(wi);
+            const float pdf = n_dot_wi * kPiInv;
+            result.reflection = S3(pdf) * albedo;
+            result.wi = wi;
+            result.pdf = pdf;
+            result.reg_alpha = 1.f;
+            result.scattering = kScatterDiffuse;
+            return true;
+        }
+        // Substitute.sample, opaque / uncoated (substitute_sample.zig:147-234, 281-302, 338-410)
+        if (!sameHemisphere(wo)) return false;
+        const Luts L{s};
+        float      dw = 0.f;
+        if (1.f != metallic) dw = diffuseWeight(L);
+        float p, xi0, xi1;
+        sampler.sample3D(p, xi0, xi1);
+        const float n_dot_wo = frame.clampAbsNdot(wo);
+        if (p < dw) {  // diffuseSample
+            const f3    is = hemisphereCosine(xi0, xi1);
+            const f3    wi = normalize3(frame.frameToWorld(is));
+            const f3    h = normalize3(wo + wi);
+            const float h_dot_wi = clampDot(h, wi);
+            const float n_dot_wi = frame.clampNdot(wi);
+            const f3    refl = microEvaluate(L, S3(opacity) * albedo, n_dot_wi, n_dot_wo, hmax3(f0));
+            const float dpdf = n_dot_wi * kPiInv;
+            const BxdfResult gg = ggxReflection(wi, wo, h, n_dot_wi, n_dot_wo, h_dot_wi, a0, a1, f0, frame);
+            const f3         mms = dspbrMicroEc(L, f0, n_dot_wi, frame.clampNdot(wo), a1);
+            result.reflection = S3(n_dot_wi) * (refl + S3(specular) * (gg.reflection + mms));
+            result.wi = wi;
+            result.pdf = dw * dpdf + (1.f - dw) * gg.pdf;
+            result.reg_alpha = 1.f;
+            result.scattering = kScatterDiffuse;
+        } else {  // glossSample
+            const Micro micro = ggxReflect(wo, n_dot_wo, a0, a1, specular_threshold, xi0, xi1, f0, frame, result);
+            const f3    mms = dspbrMicroEc(L, f0, micro.n_dot_wi, frame.clampNdot(wo), a1);
+            BxdfResult  d{S3(0.f), 0.f};
+            if (dw > 0.f) {
+                d.reflection = microEvaluate(L, S3(opacity) * albedo, micro.n_dot_wi, n_dot_wo, hmax3(f0));
+                d.pdf = micro.n_dot_wi * kPiInv;
+            }
+            result.reflection = S3(micro.n_dot_wi) * (S3(specular) * (result.reflection + mms) + d.reflection);
+            result.pdf = (1.f - dw) * result.pdf + dw * d.pdf;
+        }
+        return 0.f != result.pdf;
+    }
+};
+
+// Material.sample (material.zig:184-194) from a fragment; `two-sided flip` of vertex.zig:155-161 is done by the caller
+ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, bool caustics) {
+    MaterialSample ms;
+    ms.kind = m.kind;
+    ms.geo_n = geo_n;
+    ms.n = n;
+    ms.wo = wo;
+    ms.translucent = false;
+    ms.avoid_caustics = !caustics;
+    ms.frame = {t, b, n};
+    ms.albedo = S3(0.f);
+    ms.f0 = S3(0.f);
+    ms.metallic = 0.f;
+    ms.specular = 1.f;
+    ms.specular_threshold = s.specular_threshold;
+    ms.opacity = 1.f;
+    if (ZYGPU_MAT_DEBUG == m.kind) {
+        const f3   nn = cross3(t, b);
+        const bool same_side = dot3(nn, n) > 0.f;
+        ms.albedo = same_side ? mk3(m.color_a[0], m.color_a[1], m.color_a[2]) : mk3(m.color_b[0], m.color_b[1], m.color_b[2]);
+        ms.a0 = ms.a1 = 1.f;
+        ms.can_evaluate = true;
+    } else if (ZYGPU_MAT_LIGHT == m.kind) {
+        ms.a0 = ms.a1 = 0.f;
+        ms.can_evaluate = false;
+    } else {
+        const f3    color = mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
+        const float roughness = mx(m.roughness, kMinRoughness);
+        if (m.anisotropy > 0.f) {
+            const float rv = mx(roughness * (1.f - m.anisotropy), kMinRoughness);
+            ms.a0 = roughness * roughness;
+            ms.a1 = rv * rv;
+        } else {
+            ms.a0 = ms.a1 = roughness * roughness;
+        }
+        const float ior = m.ior, ior_outer = 1.f, ior_medium = 1.f;
+        ms.albedo = S3(1.f - m.metallic) * color;
+        ms.can_evaluate = ior != ior_medium;
+        const float t_ = (ior - ior_outer) / (ior + ior_outer);
+        const float f0 = t_ * t_;
+        ms.f0 = lerp3(S3(f0), color, S3(m.metallic));
+        ms.metallic = m.metallic;
+        ms.specular = m.specular;
+        ms.opacity = 1.f - (0.5f * 0.f);
+    }
+    return ms;
+}
+
+}  // namespace zd

@@ -1,0 +1,180 @@
+// Device math for the gfx950 kernels.  3-lane vectors in registers (the reference's 4th SIMD lane never
+// carries information through dot3/cross3/normalize3); arithmetic order and explicit-FMA placement follow
+// the reference's base/math (file:line cited per function).  Built with -ffp-contract=off: only the
+// __fmaf_rn sites below fuse, exactly where the reference writes @mulAdd.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#define ZD __device__ __forceinline__
+
+namespace zd {
+
+struct f3 {
+    float x, y, z;
+};
+
+ZD f3 mk3(float x, float y, float z) { return {x, y, z}; }
+ZD f3 S3(float s) { return {s, s, s}; }
+ZD f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+ZD f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+ZD f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+ZD f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+ZD f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+ZD f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+ZD f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+ZD f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+
+// base/math/util.zig:17-29 (x86 forms)
+ZD float mn(float x, float y) { return x < y ? x : y; }
+ZD float mx(float x, float y) { return y < x ? x : y; }
+ZD float clampf(float x, float lo, float hi) { return mn(mx(x, lo), hi); }
+ZD float saturate(float x) { return clampf(x, 0.f, 1.f); }
+ZD float stdClamp(float v, float lo, float hi) { return fmaxf(lo, fminf(v, hi)); }  // std.math.clamp
+ZD f3    min3v(f3 a, f3 b) { return {mn(a.x, b.x), mn(a.y, b.y), mn(a.z, b.z)}; }
+ZD f3    max3v(f3 a, f3 b) { return {mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z)}; }
+ZD f3    fma3(f3 a, f3 b, f3 c) { return {__fmaf_rn(a.x, b.x, c.x), __fmaf_rn(a.y, b.y, c.y), __fmaf_rn(a.z, b.z, c.z)}; }
+
+// base/math/vector4.zig:37-60
+ZD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+ZD float squaredLength3(f3 a) { return dot3(a, a); }
+ZD float length3(f3 a) { return __fsqrt_rn(dot3(a, a)); }
+ZD float distance3(f3 a, f3 b) { return length3(a - b); }
+ZD f3    normalize3(f3 a) { return a / S3(length3(a)); }
+ZD float hmax3(f3 a) { return mx(a.x, mx(a.y, a.z)); }
+ZD float hmin3(f3 a) { return mn(a.x, mn(a.y, a.z)); }
+ZD float average3(f3 a) { return (a.x + a.y + a.z) / 3.f; }
+
+// base/math/vector4.zig:73-92: tmp2 = fma(b.yzx, a, -(a.yzx * b)); result = tmp2.yzx
+ZD f3 cross3(f3 a, f3 b) {
+    const float t0 = __fmaf_rn(b.y, a.x, -(a.y * b.x));
+    const float t1 = __fmaf_rn(b.z, a.y, -(a.z * b.y));
+    const float t2 = __fmaf_rn(b.x, a.z, -(a.x * b.z));
+    return {t1, t2, t0};
+}
+
+ZD f3    gramSchmidt(f3 v, f3 w) { return fma3(S3(-dot3(v, w)), w, v); }  // vector4.zig:121
+ZD float lerpf(float a, float b, float t) { return __fmaf_rn(1.f - t, a, t * b); }  // util.zig:3-16
+ZD f3    lerp3(f3 a, f3 b, f3 t) { return fma3(S3(1.f) - t, a, t * b); }
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kPiInv = float(1.0 / 3.14159265358979323846);
+constexpr float kDotMin = 0.00001f;  // safe.zig:5
+ZD float clampDot(f3 a, f3 b) { return clampf(dot3(a, b), kDotMin, 1.f); }
+ZD float clampAbsDot(f3 a, f3 b) { return clampf(fabsf(dot3(a, b)), kDotMin, 1.f); }
+
+struct Frame {  // frame.zig:5-69
+    f3 x, y, z;
+    ZD f3 frameToWorld(f3 v) const {
+        f3 r = S3(v.x) * x;
+        r = fma3(S3(v.y), y, r);
+        return fma3(S3(v.z), z, r);
+    }
+    ZD f3 worldToFrame(f3 v) const {
+        const f3 t = v * x, b = v * y, n = v * z;
+        return {t.x + t.y + t.z, b.x + b.y + b.z, n.x + n.y + n.z};
+    }
+    ZD float clampNdot(f3 v) const { return clampDot(z, v); }
+    ZD float clampAbsNdot(f3 v) const { return clampAbsDot(z, v); }
+};
+
+// sampling.zig:8-54
+ZD void diskConcentric(float u0, float u1, float& ox, float& oy) {
+    const float s0 = (u0 * 2.f) - 1.f, s1 = (u1 * 2.f) - 1.f;
+    if (0.f == s0 && 0.f == s1) {
+        ox = oy = 0.f;
+        return;
+    }
+    float r, theta;
+    if (fabsf(s0) > fabsf(s1)) {
+        r = s0;
+        theta = (kPi / 4.f) * (s1 / s0);
+    } else {
+        r = s1;
+        theta = (kPi / 2.f) - (kPi / 4.f) * (s0 / s1);
+    }
+    const float sin_theta = sinf(theta), cos_theta = cosf(theta);
+    ox = cos_theta * r;
+    oy = sin_theta * r;
+}
+ZD f3 hemisphereCosine(float u0, float u1) {
+    float x, y;
+    diskConcentric(u0, u1, x, y);
+    const float z = __fsqrt_rn(mx(0.f, 1.f - x * x - y * y));
+    return {x, y, z};
+}
+
+// encoding.zig:56-108
+ZD float unorm16ToFloat(uint32_t n) { return float(n) * (1.f / 65535.f); }
+ZD float snorm16ToFloat(uint32_t n) { return __fmaf_rn(float(n), 1.f / 32768.f, -1.f); }
+ZD f3    octDecode(float o0, float o1) {
+    f3          v = {o0, o1, -1.f + fabsf(o0) + fabsf(o1)};
+    const float t = mx(v.z, 0.f);
+    v.x += v.x > 0.f ? -t : t;
+    v.y += v.y > 0.f ? -t : t;
+    return normalize3(v);
+}
+
+// rotation rows + scale + position of a prop (composed_transformation.zig:11-130)
+struct Trafo {
+    f3 r0, r1, r2;
+    f3 scale;
+    f3 position;
+
+    ZD f3 transformVector(f3 v) const {  // matrix3x3.zig:113-126
+        f3 res = S3(v.x) * r0;
+        res = fma3(S3(v.y), r1, res);
+        return fma3(S3(v.z), r2, res);
+    }
+    ZD f3 transformVectorTransposed(f3 v) const {  // matrix3x3.zig:128-139
+        const f3 x = v * r0, y = v * r1, z = v * r2;
+        return {x.x + x.y + x.z, y.x + y.y + y.z, z.x + z.y + z.z};
+    }
+    ZD f3 objectToWorldVector(f3 v) const {
+        const f3 a = r0 * S3(scale.x), b = r1 * S3(scale.y), c = r2 * S3(scale.z);
+        f3       res = S3(v.x) * a;
+        res = fma3(S3(v.y), b, res);
+        return fma3(S3(v.z), c, res);
+    }
+    ZD f3 objectToWorldPoint(f3 p) const { return objectToWorldVector(p) + position; }
+    ZD f3 objectToWorldNormal(f3 n) const { return transformVector(n); }
+    ZD f3 frameToWorldPoint(f3 p) const { return transformVector(p) + position; }
+    ZD f3 worldToObjectVector(f3 v) const { return transformVectorTransposed(v) / scale; }
+    ZD f3 worldToObjectPoint(f3 p) const { return worldToObjectVector(p - position); }
+    ZD f3 worldToFramePoint(f3 p) const { return transformVectorTransposed(p - position); }
+};
+
+struct Ray {
+    f3    origin, direction, inv_direction;
+    float min_t, max_t;
+    ZD static Ray init(f3 o, f3 d, float mint, float maxt) {  // ray.zig:11-20
+        Ray r;
+        r.origin = o;
+        r.direction = d;
+        r.inv_direction = S3(1.f) / d;
+        r.min_t = mint;
+        r.max_t = maxt;
+        return r;
+    }
+    ZD f3 point(float t) const { return fma3(S3(t), direction, origin); }  // ray.zig:27-29
+};
+
+constexpr float kRayMaxT = 2.14748313e+09f;  // ray_offset.zig:5
+
+// ray_offset.zig:14-31
+ZD float offsetRay1(float p, float n) {
+    const float   origin = 1.f / 32.f, float_scale = 1.f / 65536.f, int_scale = 256.f;
+    const int32_t of_i = int32_t(int_scale * n);
+    const int32_t p_ii = __float_as_int(p);
+    const float   p_in = __int_as_float(int32_t(uint32_t(p_ii) - uint32_t(of_i)));
+    const float   p_ip = __int_as_float(int32_t(uint32_t(p_ii) + uint32_t(of_i)));
+    const float   p_i = p < 0.f ? p_in : p_ip;
+    const float   mad = __fmaf_rn(float_scale, n, p);
+    return fabsf(p) < origin ? mad : p_i;
+}
+ZD f3 offsetRay(f3 p, f3 n) { return {offsetRay1(p.x, n.x), offsetRay1(p.y, n.y), offsetRay1(p.z, n.z)}; }
+
+}  // namespace zd

@@ -1,0 +1,396 @@
+// Device view of the compiled scene and the ray casting over it.  Behaviour follows the reference:
+//   bvh.Node.intersect           src/core/scene/bvh/node.zig:73-87
+//   AABB.intersect               src/base/math/aabb.zig:46-60
+//   PropBvh.intersect/visibility src/core/scene/prop/prop_tree.zig:56-116,185-240
+//   Prop.intersect/visibility    src/core/scene/prop/prop.zig:163-237
+//   TriangleTree.intersect(P)    src/core/scene/shape/triangle/triangle_tree.zig:46-109,197-242
+//   triangle.intersect           src/core/scene/shape/triangle/triangle.zig:26-52
+//   Rectangle.intersect/fragment src/core/scene/shape/rectangle.zig:30-62,102-124
+//   TriangleMesh.fragment        src/core/scene/shape/triangle/triangle_mesh.zig:310-335, triangle_data.zig:106-130
+// HBM layout: BVH2 nodes stay in the reference's 32 B form (two float4), so that one inner step fetches the
+// two adjacent children as one 64 B run; triangles are pre-gathered to 3 x float4 (a, b, c) in leaf order so
+// that a leaf is one contiguous run and a test needs no index indirection.
+#pragma once
+
+#include "../../../include/zygpu.h"
+#include "dmath.hpp"
+
+namespace zd {
+
+constexpr uint32_t kNull = 0xFFFFFFFFu;
+constexpr int      kStackSize = 64;
+
+struct DMesh {
+    const float4*   nodes;     // 2 per node
+    const float4*   tri_verts; // 3 per triangle (leaf order)
+    const uint32_t* triangles; // 3 vertex indices per triangle (shading only)
+    const uint16_t* triangle_parts;
+    const float*    positions;
+    const uint16_t* normals;
+    const float*    uvs;
+    const float*    part_areas;
+};
+
+struct DScene {
+    const ZygpuProp*     props;
+    const float4*        trafos; // 4 per prop: r0(+sx), r1(+sy), r2(+sz), position
+    const float4*        aabbs;  // 2 per prop
+    const uint32_t*      material_ids;
+    const uint32_t*      light_ids;
+    const DMesh*         meshes;
+    const ZygpuMaterial* materials;
+    const ZygpuLight*    lights;
+    const float4*        light_aabbs; // 2 per light
+    const float4*        light_cones;
+    const float4*        solid_nodes;
+    const uint32_t*      solid_indices;
+    const float4*        unocc_nodes;
+    const uint32_t*      unocc_indices;
+    const ZygpuLightNode* lt_nodes;
+    const uint32_t*      lt_middles;
+    const uint32_t*      lt_orders;
+    const uint32_t*      lt_mapping;
+    float4               lt_bounds_min, lt_bounds_max;
+    float                lt_infinite_weight;
+    uint32_t             lt_max_split_depth, lt_num_nodes, lt_num_infinite;
+    const float*         lut_e_m;
+    const float*         lut_e_m_avg;
+    const float*         lut_e;
+    const float*         lut_e_avg;
+    float                specular_threshold;
+    uint32_t             num_solid_nodes, num_unocc_nodes;
+};
+
+struct Counters {
+    unsigned long long nodes, tris, instances;
+};
+
+struct Hit {
+    float    t, u, v;
+    uint32_t primitive, prop;
+};
+
+ZD Trafo loadTrafo(const DScene& s, uint32_t p) {
+    const float4 a = s.trafos[4 * p + 0], b = s.trafos[4 * p + 1], c = s.trafos[4 * p + 2], d = s.trafos[4 * p + 3];
+    Trafo        t;
+    t.r0 = {a.x, a.y, a.z};
+    t.r1 = {b.x, b.y, b.z};
+    t.r2 = {c.x, c.y, c.z};
+    t.scale = {a.w, b.w, c.w};
+    t.position = {d.x, d.y, d.z};
+    return t;
+}
+
+// node.zig:73-87; n0 = (min.xyz, children_or_first), n1 = (max.xyz, count)
+ZD float nodeIntersect(float4 n0, float4 n1, const Ray& ray) {
+    const f3    lower = (mk3(n0.x, n0.y, n0.z) - ray.origin) * ray.inv_direction;
+    const f3    upper = (mk3(n1.x, n1.y, n1.z) - ray.origin) * ray.inv_direction;
+    const f3    t0 = min3v(lower, upper), t1 = max3v(lower, upper);
+    const float tboxmin = mx(t0.x, mx(t0.y, mx(t0.z, ray.min_t)));
+    const float tboxmax = mn(t1.x, mn(t1.y, mn(t1.z, ray.max_t)));
+    return tboxmin <= tboxmax ? tboxmin : FLT_MAX;
+}
+
+ZD bool aabbIntersect(float4 bmin, float4 bmax, const Ray& ray) {
+    return FLT_MAX != nodeIntersect(bmin, bmax, ray);  // same arithmetic, boolean result (aabb.zig:46-60)
+}
+
+// triangle.zig:26-52
+ZD bool triangleIntersect(const Ray& ray, f3 a, f3 b, f3 c, float& ht, float& hu, float& hv) {
+    const f3    e1 = b - a, e2 = c - a;
+    const f3    tvec = ray.origin - a;
+    const f3    pvec = cross3(ray.direction, e2);
+    const f3    qvec = cross3(tvec, e1);
+    const float e1_d_pv = dot3(e1, pvec), tv_d_pv = dot3(tvec, pvec);
+    const float di_d_qv = dot3(ray.direction, qvec), e2_d_qv = dot3(e2, qvec);
+    const float inv_det = 1.f / e1_d_pv;
+    const float u = tv_d_pv * inv_det, v = di_d_qv * inv_det, hit_t = e2_d_qv * inv_det;
+    const float uv = u + v;
+    if (u >= 0.f && 1.f >= u && v >= 0.f && 1.f >= uv && hit_t >= ray.min_t && ray.max_t >= hit_t) {
+        ht = hit_t;
+        hu = u;
+        hv = v;
+        return true;
+    }
+    return false;
+}
+
+ZD f3 xyz(float4 v) { return {v.x, v.y, v.z}; }
+
+// Shared BVH2 walk: nearer child first, farther pushed (triangle_tree.zig:76-94 / prop_tree.zig:86-104).
+// `leaf(first, count)` returns true to stop the walk (any-hit).
+template <bool STATS, typename Leaf>
+ZD bool bvhWalk(const float4* nodes, uint32_t num_nodes, Ray& ray, Counters& cnt, Leaf&& leaf) {
+    if (0 == num_nodes) return false;
+    uint32_t stack[kStackSize];
+    int      sp = 0;
+    if (STATS) cnt.nodes += 1;
+    uint32_t data = __float_as_uint(nodes[0].w), count = __float_as_uint(nodes[1].w);
+    for (;;) {
+        if (0 != count) {
+            if (leaf(data, count)) return true;
+            if (0 == sp) return false;
+            const uint32_t n = stack[--sp];
+            data = __float_as_uint(nodes[2 * n].w);
+            count = __float_as_uint(nodes[2 * n + 1].w);
+            continue;
+        }
+        const uint32_t a = data;
+        const float4   a0 = nodes[2 * a], a1 = nodes[2 * a + 1], b0 = nodes[2 * a + 2], b1 = nodes[2 * a + 3];
+        if (STATS) cnt.nodes += 2;
+        const float dista = nodeIntersect(a0, a1, ray);
+        const float distb = nodeIntersect(b0, b1, ray);
+        const bool  swap = dista > distb;
+        const float dnear = swap ? distb : dista, dfar = swap ? dista : distb;
+        if (FLT_MAX == dnear) {
+            if (0 == sp) return false;
+            const uint32_t n = stack[--sp];
+            data = __float_as_uint(nodes[2 * n].w);
+            count = __float_as_uint(nodes[2 * n + 1].w);
+        } else {
+            data = __float_as_uint(swap ? b0.w : a0.w);
+            count = __float_as_uint(swap ? b1.w : a1.w);
+            if (FLT_MAX != dfar && sp < kStackSize) stack[sp++] = swap ? a : a + 1;
+        }
+    }
+}
+
+// triangle_tree.zig:46-109; ray in object space; shrinks ray.max_t
+template <bool STATS>
+ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt) {
+    uint32_t primitive = kNull;
+    float    ht = 0.f, hu = 0.f, hv = 0.f;
+    bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            if (STATS) cnt.tris += 1;
+            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            float    t, u, v;
+            if (triangleIntersect(local_ray, a, b, c, t, u, v)) {
+                local_ray.max_t = t;
+                ht = t;
+                hu = u;
+                hv = v;
+                primitive = i;
+            }
+        }
+        return false;
+    });
+    if (kNull == primitive) return false;
+    hit.t = ht;
+    hit.u = hu;
+    hit.v = hv;
+    hit.primitive = primitive;
+    return true;
+}
+
+// triangle_tree.zig:197-242
+template <bool STATS>
+ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
+    return bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            if (STATS) cnt.tris += 1;
+            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            float    t, u, v;
+            if (triangleIntersect(local_ray, a, b, c, t, u, v)) return true;
+        }
+        return false;
+    });
+}
+
+// rectangle.zig:30-62
+ZD bool rectangleIntersect(const Ray& ray, const Trafo& trafo, float& out_t, float& out_u, float& out_v) {
+    const f3    n = trafo.r2;
+    const float d = dot3(n, trafo.position);
+    const float hit_t = -(dot3(n, ray.origin) - d) / dot3(n, ray.direction);
+    if (hit_t >= ray.min_t && ray.max_t >= hit_t) {
+        const f3    p = ray.point(hit_t);
+        const f3    k = p - trafo.position;
+        const f3    t = -trafo.r0;
+        const float u = dot3(t, k) / (0.5f * trafo.scale.x);
+        if (u > 1.f || u < -1.f) return false;
+        const f3    b = -trafo.r1;
+        const float v = dot3(b, k) / (0.5f * trafo.scale.y);
+        if (v > 1.f || v < -1.f) return false;
+        out_t = hit_t;
+        out_u = u;
+        out_v = v;
+        return true;
+    }
+    return false;
+}
+
+ZD Ray worldToObjectRay(const Trafo& t, const Ray& ray) {  // composed_transformation.zig:123-130
+    return Ray::init(t.worldToObjectPoint(ray.origin), t.worldToObjectVector(ray.direction), ray.min_t, ray.max_t);
+}
+
+ZD bool propVisibleAtDepth(uint32_t flags, uint32_t depth_surface) {  // prop.zig:39-49
+    return 0 == depth_surface ? 0 != (flags & ZYGPU_PROP_VISIBLE_IN_CAMERA) : 0 != (flags & ZYGPU_PROP_VISIBLE_IN_REFLECTION);
+}
+
+// prop_tree.zig:56-116 over the solid TLAS (closest hit); shrinks ray.max_t
+template <bool STATS>
+ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt) {
+    hit.prop = kNull;
+    bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            const uint32_t  p = s.solid_indices[i];
+            const ZygpuProp prop = s.props[p];
+            if (!propVisibleAtDepth(prop.flags, depth_surface)) continue;
+            if (STATS) cnt.instances += 1;
+            if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
+            const Trafo trafo = loadTrafo(s, p);
+            if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
+                float t, u, v;
+                if (rectangleIntersect(ray, trafo, t, u, v)) {
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.primitive = 0;
+                    hit.prop = p;
+                    ray.max_t = t;
+                }
+            } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+                Ray local = worldToObjectRay(trafo, ray);
+                Hit h;
+                if (meshIntersect<STATS>(s.meshes[prop.mesh], local, h, cnt)) {
+                    hit.t = h.t;
+                    hit.u = h.u;
+                    hit.v = h.v;
+                    hit.primitive = h.primitive;
+                    hit.prop = p;
+                    ray.max_t = h.t;
+                }
+            }
+        }
+        return false;
+    });
+    return kNull != hit.prop;
+}
+
+// prop_tree.zig:185-240 + prop.zig:199-237: true = unoccluded
+template <bool STATS>
+ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
+    const bool blocked = bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            const uint32_t  p = s.solid_indices[i];
+            const ZygpuProp prop = s.props[p];
+            if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;
+            if (STATS) cnt.instances += 1;
+            if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
+            const Trafo trafo = loadTrafo(s, p);
+            if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
+                float t, u, v;
+                if (rectangleIntersect(ray, trafo, t, u, v)) return true;
+            } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+                Ray local = worldToObjectRay(trafo, ray);
+                if (meshIntersectP<STATS>(s.meshes[prop.mesh], local, cnt)) return true;
+            }
+        }
+        return false;
+    });
+    return !blocked;
+}
+
+struct Fragment {  // shape/intersection.zig:64-124
+    Trafo    trafo;
+    float    t_hit, u, v;
+    uint32_t primitive, prop, part;
+    f3       p, geo_n, t, b, n;
+    float    uv0, uv1;
+
+    ZD bool sameHemisphere(f3 v_) const { return dot3(geo_n, v_) > 0.f; }
+    ZD f3 offsetP(f3 v_) const {  // intersection.zig:115-119; uvw[3] (the offset) is 0 for rectangles and meshes
+        const f3 nn = sameHemisphere(v_) ? geo_n : -geo_n;
+        return offsetRay(fma3(S3(0.f), nn, p), nn);
+    }
+};
+
+ZD void rectangleFragment(const Ray& ray, Fragment& f) {  // rectangle.zig:102-124
+    const f3 p = ray.point(f.t_hit);
+    const f3 n = f.trafo.r2, t = -f.trafo.r0, b = -f.trafo.r1;
+    f.p = p;
+    f.t = t;
+    f.b = b;
+    f.n = n;
+    f.geo_n = n;
+    if (f.trafo.scale.z < 0.f) {
+        const f3    k = p - f.trafo.position;
+        const float u = dot3(t, k) * 2.f, v = dot3(b, k) * 2.f;
+        f.uv0 = 0.5f * (u + 1.f);
+        f.uv1 = 0.5f * (v + 1.f);
+    } else {
+        f.uv0 = 0.5f * (f.u + 1.f);
+        f.uv1 = 0.5f * (f.v + 1.f);
+    }
+    f.part = 0;
+}
+
+ZD f3 interpolate3(f3 a, f3 b, f3 c, float u, float v) {  // triangle.zig:141-149
+    const float w = 1.f - u - v;
+    return fma3(a, S3(w), fma3(b, S3(u), c * S3(v)));
+}
+
+ZD f3 meshPosition(const DMesh& m, uint32_t i) { return {m.positions[3 * i], m.positions[3 * i + 1], m.positions[3 * i + 2]}; }
+ZD f3 meshShadingNormal(const DMesh& m, uint32_t i) {
+    return octDecode(snorm16ToFloat(m.normals[2 * i]), snorm16ToFloat(m.normals[2 * i + 1]));
+}
+
+ZD void meshFragment(const DMesh& mesh, Fragment& f) {  // triangle_mesh.zig:310-335 + triangle_data.zig:106-149
+    const uint32_t prim = f.primitive;
+    f.part = mesh.triangle_parts[prim];
+    const uint32_t ia = mesh.triangles[3 * prim], ib = mesh.triangles[3 * prim + 1], ic = mesh.triangles[3 * prim + 2];
+    const f3       pa = meshPosition(mesh, ia), pb = meshPosition(mesh, ib), pc = meshPosition(mesh, ic);
+
+    const f3 geo_n = normalize3(cross3(pb - pa, pc - pa));
+    f.geo_n = f.trafo.objectToWorldNormal(geo_n);
+
+    const f3    p = interpolate3(pa, pb, pc, f.u, f.v);
+    const float uva0 = mesh.uvs[2 * ia], uva1 = mesh.uvs[2 * ia + 1];
+    const float uvb0 = mesh.uvs[2 * ib], uvb1 = mesh.uvs[2 * ib + 1];
+    const float uvc0 = mesh.uvs[2 * ic], uvc1 = mesh.uvs[2 * ic + 1];
+    const float w = 1.f - f.u - f.v;
+    f.uv0 = __fmaf_rn(uva0, w, __fmaf_rn(uvb0, f.u, uvc0 * f.v));
+    f.uv1 = __fmaf_rn(uva1, w, __fmaf_rn(uvb1, f.u, uvc1 * f.v));
+
+    const f3 nb = meshShadingNormal(mesh, ib), na = meshShadingNormal(mesh, ia), nc = meshShadingNormal(mesh, ic);
+    const f3 ni = normalize3(interpolate3(na, nb, nc, f.u, f.v));
+
+    // triangle.zig:102-131 positionDifferentials
+    const float duv02_0 = uva0 - uvc0, duv02_1 = uva1 - uvc1;
+    const float duv12_0 = uvb0 - uvc0, duv12_1 = uvb1 - uvc1;
+    const float determinant = duv02_0 * duv12_1 - duv02_1 * duv12_0;
+    const f3    dp02 = pa - pc, dp12 = pb - pc;
+    f3          dpdu, dpdv;
+    if (0.f == fabsf(determinant)) {
+        const f3 ng = normalize3(cross3(pc - pa, pb - pa));
+        if (fabsf(ng.x) > fabsf(ng.y)) dpdu = mk3(-ng.z, 0.f, ng.x) / S3(__fsqrt_rn(ng.x * ng.x + ng.z * ng.z));
+        else dpdu = mk3(0.f, ng.z, -ng.y) / S3(__fsqrt_rn(ng.y * ng.y + ng.z * ng.z));
+        dpdv = cross3(ng, dpdu);
+    } else {
+        const float invdet = 1.f / determinant;
+        dpdu = S3(invdet) * fma3(S3(duv12_1), dp02, S3(-duv02_1) * dp12);
+        dpdv = S3(invdet) * fma3(S3(-duv12_0), dp02, S3(duv02_0) * dp12);
+    }
+    const f3 t = normalize3(gramSchmidt(dpdu, ni));
+    const f3 b = normalize3(gramSchmidt(dpdv, ni));
+
+    f.p = f.trafo.objectToWorldPoint(p);
+    f.t = f.trafo.objectToWorldNormal(t);
+    f.b = f.trafo.objectToWorldNormal(b);
+    f.n = f.trafo.objectToWorldNormal(ni);
+}
+
+// Shape.fragment for a recorded hit (deterministic recomputation from the hit record + the traced ray)
+ZD void makeFragment(const DScene& s, const Ray& ray, const Hit& hit, Fragment& f) {
+    f.prop = hit.prop;
+    f.t_hit = hit.t;
+    f.u = hit.u;
+    f.v = hit.v;
+    f.primitive = hit.primitive;
+    f.trafo = loadTrafo(s, hit.prop);
+    const ZygpuProp prop = s.props[hit.prop];
+    if (ZYGPU_SHAPE_RECTANGLE == prop.shape) rectangleFragment(ray, f);
+    else meshFragment(s.meshes[prop.mesh], f);
+}
+
+}  // namespace zd
