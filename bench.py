@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the wavefront path tracer on BASELINE.json configs[1]
+(Cornell box + Lambertian BSDF, 1920x1080, PTMIS, radius-0 sensor), one rank per GPU.
+
+A step is one pass of the hot path over one batch: ITER_PER_STEP iterations (samples per pixel) of the full frame on
+each rank.  With the defaults (--steps 16, 16 iterations per step) one GPU renders the configuration's 256 spp.
+Ranks shard the *iterations* of the frame (rank r renders iterations [r*K*I, (r+1)*K*I), every (pixel, iteration)
+is independent); the scene is replicated, there is no data-path collective, and the per-rank films
+{sum w*rgb, sum w} are summed once per run with an RCCL reduce over xGMI.  Scaling is weak: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ITER_PER_STEP = 16
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--iters-per-step", type=int, default=ITER_PER_STEP)
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_mesh"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    n = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n > 1 and world != n:
+        raise SystemExit(f"--gpus {n} needs WORLD_SIZE={n} (launch with torch.distributed.run)")
+    dist = None
+    if n > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import zyg_amd
+    from zyg_amd import build as zbuild, scenes
+    if not zbuild.up_to_date():
+        if rank == 0:
+            zbuild.build(verbose=False)
+        if dist:
+            dist.barrier()
+
+    w, h, ips, k, wu = args.width, args.height, args.iters_per_step, args.steps, args.warmup
+    total_spp = n * k * ips
+    eng = zyg_amd.Engine()
+    eng.set_device(local_rank)
+    mesh = scenes.heightfield_mesh() if args.scene == "cornell_mesh" else None
+    scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material="lambert", boxes=mesh is None, mesh=mesh)
+    eng.start_frame(0)
+    lib, ctx = eng.lib, eng.context()
+
+    film = torch.zeros((h, w, 4), dtype=torch.float32, device=device)
+    assert lib.zygpu_set_external_film(ctx, ctypes.c_void_p(film.data_ptr())) == 0
+
+    def render(first_iteration, count):
+        rc = lib.zygpu_render(ctx, 0, first_iteration, count, 0, h)
+        if rc != 0:
+            raise RuntimeError("zygpu_render: " + lib.zygpu_last_error().decode())
+
+    # algorithmic bytes per sample from the device traversal counters of one stats-enabled iteration
+    lib.zygpu_enable_stats(ctx, 1)
+    lib.zygpu_reset_stats(ctx)
+    render(0, 1)
+    assert lib.zygpu_synchronize(ctx) == 0
+    st = eng.stats()
+    lib.zygpu_enable_stats(ctx, 0)
+    samples_stat = max(st.camera_samples, 1)
+    b_trav = 32 * st.nodes_fetched + 48 * st.triangles_tested + 104 * st.instances_tested
+    bytes_sample_total = st.algorithmic_bytes(0) / samples_stat
+    # split of the §8(d) queue terms between the two kernels (DESIGN.md "Algorithmic bytes"):
+    #   wf_trace: ray read 32 + hit write 16 per extension ray, ray read 32 + flag 16 per shadow ray, + all B_trav
+    #   wf_shade: the rest of the 224 / 96 (ray write, hit read, path state read+write) + B_film
+    bytes_sample_trace = (48 * st.extension_rays + 48 * st.shadow_rays + b_trav) / samples_stat
+    bytes_sample_shade = bytes_sample_total - bytes_sample_trace
+
+    for i in range(wu):
+        render(i * ips, ips)
+    assert lib.zygpu_synchronize(ctx) == 0
+    film.zero_()
+    dtmp = ctypes.c_double * 2
+    ltmp = ctypes.c_uint64 * 2
+    lib.zygpu_kernel_time(ctx, dtmp(), ltmp(), 1)
+
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    base = rank * k * ips
+    for s in range(k):
+        render(base + s * ips, ips)
+    assert lib.zygpu_synchronize(ctx) == 0
+    if dist:
+        dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms, launches = dtmp(), ltmp()
+    lib.zygpu_kernel_time(ctx, ms, launches, 0)
+
+    out = None
+    if rank == 0:
+        samples_total = float(w) * h * ips * k * n
+        samples_rank = float(w) * h * ips * k
+        value = samples_total / elapsed / 1e6
+        kernels = [("wf_trace", ms[0], launches[0], bytes_sample_trace), ("wf_shade", ms[1], launches[1], bytes_sample_shade)]
+        dom = max(kernels, key=lambda t: t[1])
+        avg_ms = dom[1] / max(dom[2], 1)
+        bytes_per_launch = dom[3] * samples_rank / max(dom[2], 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        weights = film[..., 3]
+        out = {
+            "metric": "Msamples/sec (whole node) at 1080p/256spp; RMS vs CPU reference",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": n,
+            "steps": k,
+            "warmup": wu,
+            "ms_per_step": round(elapsed / k * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Cornell box (5 Rectangle walls, 2 boxes, 2 unoccluding Rectangle lights) + Lambertian BSDF, "
+                                   f"{w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
+                                   f"{k * ips} spp per GPU", "scene": args.scene, "parallelism": f"iterations x{n}"},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 5), "launches": int(dom[2]),
+                         "algorithmic_bytes_per_sample": round(bytes_sample_total, 1),
+                         "kernel_bytes_per_sample": round(dom[3], 1),
+                         "kernel_ms": {"wf_trace": round(ms[0], 3), "wf_shade": round(ms[1], 3)}},
+            "film_weight_min_max": [float(weights.min().item()), float(weights.max().item())],
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"], out["rms_vs_oracle"] = cpu_baseline(eng, w, h, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    lib.zygpu_set_external_film(ctx, None)
+    eng.release()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(eng, w, h, budget_s):
+    """Times the CPU oracle (a port of the reference's loop; the Zig reference cannot be built here) on the host cores
+    over a bounded sample of the same workload, and checks the GPU image against it on exactly those iterations."""
+    import subprocess
+
+    import numpy as np
+
+    import zyg_amd
+    oracle_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(oracle_so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    oracle = ctypes.CDLL(oracle_so)
+    oracle.zyg_oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                         ctypes.c_void_p]
+    sd = eng.lib.su_ext_scene_desc().contents
+    vd = eng.lib.su_ext_view_desc().contents
+    cores = os.cpu_count() or 1
+    film = np.zeros((h, w, 4), dtype=np.float32)
+    st = zyg_amd.Stats()
+    iters = 0
+    t0 = time.perf_counter()
+    while True:
+        oracle.zyg_oracle_render(ctypes.addressof(sd), ctypes.addressof(vd), 0, iters, 1, 1, 0, h, film.ctypes.data, cores,
+                                 ctypes.byref(st))
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or dt / iters * (iters + 1) > budget_s * 1.5:
+            break
+    cpu_val = w * h * iters / dt / 1e6
+
+    # parity on the same iterations: GPU film for iterations [0, iters) vs the oracle film
+    lib, ctx = eng.lib, eng.context()
+    lib.zygpu_set_external_film(ctx, None)
+    lib.zygpu_clear_film(ctx, ctypes.c_float(0.0))
+    lib.zygpu_render(ctx, 0, 0, iters, 0, h)
+    lib.zygpu_synchronize(ctx)
+    gpu_img = eng.resolve(w, h)
+    cpu_img = np.zeros_like(film)
+    oracle.zyg_oracle_resolve(ctypes.addressof(vd), film.ctypes.data, cpu_img.ctypes.data, w * h)
+    a = np.clip(np.nan_to_num(gpu_img[..., :3]), 0, 1).astype(np.float64)
+    b = np.clip(np.nan_to_num(cpu_img[..., :3]), 0, 1).astype(np.float64)
+    rms = float(np.sqrt(np.mean((a - b) ** 2)))
+    gpu_film = eng.download_film(w, h)
+    identical = float(np.mean(np.all(gpu_film == film, axis=-1)))
+    base = {"value": round(cpu_val, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} iteration(s) of the same {w}x{h} frame ({w * h * iters} camera samples), {dt:.1f} s"}
+    return base, {"rms": rms, "iterations": iters, "bit_identical_pixels": identical}
+
+
+if __name__ == "__main__":
+    main()

@@ -311,6 +311,11 @@ int zygpu_reset_stats(ZygpuContext* ctx);
  * index 1 = `wf_shade` (integrator state machine).  Both out arrays hold 2 entries. */
 int zygpu_kernel_time(ZygpuContext* ctx, double* out_ms, uint64_t* out_launches, int reset);
 
+/* Unit-test hook: evaluates small device functions (op: 0 sin/cos/acos, 1 SphQuad, 2 Sobol stream, 3 PCG,
+ * 4 offsetRay; strides in floats per item) on host arrays; see tests/test_gpu_units.py. */
+int zygpu_test_eval(ZygpuContext* ctx, uint32_t op, uint32_t n, const float* in, uint32_t in_stride, float* out,
+                    uint32_t out_stride);
+
 const char* zygpu_last_error(void);
 
 #ifdef __cplusplus

@@ -323,10 +323,10 @@ struct SphQuad {  // rectangle.zig:199-303 (Ureña et al.)
         const V4 n1 = normalize3(cross3(v10, v11));
         const V4 n2 = normalize3(cross3(v11, v01));
         const V4 n3 = normalize3(cross3(v01, v00));
-        const float g0 = std::acos(-dot3(n0, n1));
-        const float g1 = std::acos(-dot3(n1, n2));
-        const float g2 = std::acos(-dot3(n2, n3));
-        const float g3 = std::acos(-dot3(n3, n0));
+        const float g0 = acosF(-dot3(n0, n1));
+        const float g1 = acosF(-dot3(n1, n2));
+        const float g2 = acosF(-dot3(n2, n3));
+        const float g3 = acosF(-dot3(n3, n0));
         q.b0 = n0[2];
         q.b1 = n2[2];
         q.k = 2.f * kPi - g2 - g3;
@@ -336,7 +336,7 @@ struct SphQuad {  // rectangle.zig:199-303 (Ureña et al.)
 
     V4 sample(float u0, float u1) const {
         const float au = u0 * Sa + k;
-        const float fu = (std::cos(au) * b0 - b1) / std::sin(au);
+        const float fu = (cosF(au) * b0 - b1) / sinF(au);
         float       cu = 1.f / std::sqrt(fu * fu + b0 * b0) * (fu > 0.f ? 1.f : -1.f);
         cu = stdClamp(cu, -1.f, 1.f);
         float xu = -(cu * z0) / std::sqrt(1.f - cu * cu);

@@ -157,7 +157,7 @@ inline V4 anisoSample(V4 wo, const float alpha[2], float xi0, float xi1, const F
     const float phi = (2.f * kPi) * xi0;
     const float z = std::fmaf(1.f - xi1, 1.f + v[2], -v[2]);
     const float sin_theta = std::sqrt(saturate(1.f - z * z));
-    const float x = sin_theta * std::cos(phi), y = sin_theta * std::sin(phi);
+    const float x = sin_theta * cosF(phi), y = sin_theta * sinF(phi);
     const V4    h = mk(x, y, z) + v;
     const V4    m = normalize3(mk(alpha[0] * h[0], alpha[1] * h[1], h[2]));
     n_dot_h = clampf(m[2], kDotMin, 1.f);

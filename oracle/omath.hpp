@@ -83,6 +83,92 @@ inline void orthonormalBasis3(V4 n, V4& t, V4& b) {
     b = mk(d, sign + n[1] * n[1] * c, -n[1]);
 }
 
+
+// sin / cos / acos of the reference, restated.  rectangle.zig calls std.math.acos, whose f32 path in Zig's std
+// (lib/std/math/acos.zig, not vendored in /root/reference; Zig toolchain of build.zig, unpinned) is the musl /
+// FreeBSD msun e_acosf.c algorithm; @sin/@cos lower to compiler-rt's sinf/cosf, ports of musl's sinf.c/cosf.c
+// (k_sinf/k_cosf double-precision kernels).  Arguments in the integration loop stay within |x| <= 9*pi/4
+// (diskConcentric: [-pi/4, 3pi/4]; SphQuad and GGX: [0, 2pi]); larger ones fall back to libm.
+namespace m32 {
+inline uint32_t bits(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return u;
+}
+inline float fromBits(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+inline float sindf(double x) {  // musl __sindf
+    const double S1 = -0x1.5555554cbac77p-3, S2 = 0x1.11110896efbb2p-7, S3 = -0x1.a00f9e2cae774p-13, S4 = 0x1.6cd878c3b46a7p-19;
+    const double z = x * x, w = z * z, r = S3 + z * S4, s = z * x;
+    return float((x + s * (S1 + z * S2)) + s * w * r);
+}
+inline float cosdf(double x) {  // musl __cosdf
+    const double C0 = -0x1.ffffffd0c5e81p-2, C1 = 0x1.55553e1053a42p-5, C2 = -0x1.6c087e80f1e27p-10, C3 = 0x1.99342e0ee5069p-16;
+    const double z = x * x, w = z * z, r = C2 + z * C3;
+    return float(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+constexpr double kPio2 = 1.57079632679489661923;
+}  // namespace m32
+
+inline float sinF(float x) {
+    const uint32_t hx = m32::bits(x), ix = hx & 0x7fffffffu;
+    const bool     sign = 0 != (hx >> 31);
+    const double   xd = double(x);
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? x : m32::sindf(xd);
+    if (ix <= 0x407b53d1u) {
+        if (ix <= 0x4016cbe3u) return sign ? -m32::cosdf(xd + m32::kPio2) : m32::cosdf(xd - m32::kPio2);
+        return m32::sindf(sign ? -(xd + 2 * m32::kPio2) : -(xd - 2 * m32::kPio2));
+    }
+    if (ix <= 0x40e231d5u) {
+        if (ix <= 0x40afeddfu) return sign ? m32::cosdf(xd + 3 * m32::kPio2) : -m32::cosdf(xd - 3 * m32::kPio2);
+        return m32::sindf(sign ? xd + 4 * m32::kPio2 : xd - 4 * m32::kPio2);
+    }
+    return std::sin(x);
+}
+inline float cosF(float x) {
+    const uint32_t hx = m32::bits(x), ix = hx & 0x7fffffffu;
+    const bool     sign = 0 != (hx >> 31);
+    const double   xd = double(x);
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? 1.f : m32::cosdf(xd);
+    if (ix <= 0x407b53d1u) {
+        if (ix > 0x4016cbe3u) return -m32::cosdf(sign ? xd + 2 * m32::kPio2 : xd - 2 * m32::kPio2);
+        return sign ? m32::sindf(xd + m32::kPio2) : m32::sindf(m32::kPio2 - xd);
+    }
+    if (ix <= 0x40e231d5u) {
+        if (ix > 0x40afeddfu) return m32::cosdf(sign ? xd + 4 * m32::kPio2 : xd - 4 * m32::kPio2);
+        return sign ? m32::sindf(-xd - 3 * m32::kPio2) : m32::sindf(xd - 3 * m32::kPio2);
+    }
+    return std::cos(x);
+}
+inline float acosR(float z) {
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    const float p = z * (pS0 + z * (pS1 + z * pS2)), q = 1.f + z * qS1;
+    return p / q;
+}
+inline float acosF(float x) {
+    const float    pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const uint32_t hx = m32::bits(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x3f800000u) {
+        if (ix == 0x3f800000u) return (hx >> 31) ? 2.f * pio2_hi + 0x1p-120f : 0.f;
+        return std::nanf("");
+    }
+    if (ix < 0x3f000000u) {
+        if (ix <= 0x32800000u) return pio2_hi + 0x1p-120f;
+        return pio2_hi - (x - (pio2_lo - x * acosR(x * x)));
+    }
+    if (hx >> 31) {
+        const float z = (1.f + x) * 0.5f, s = std::sqrt(z), w = acosR(z) * s - pio2_lo;
+        return 2.f * (pio2_hi - (s + w));
+    }
+    const float z = (1.f - x) * 0.5f, s = std::sqrt(z);
+    const float df = m32::fromBits(m32::bits(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df), w = acosR(z) * s + c;
+    return 2.f * (df + w);
+}
+
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kPiInv = float(1.0 / 3.14159265358979323846);  // math.zig:112
 constexpr float kDotMin = 0.00001f;                            // safe.zig:5
@@ -120,7 +206,7 @@ inline void diskConcentric(float u0, float u1, float& ox, float& oy) {
         r = s1;
         theta = (kPi / 2.f) - (kPi / 4.f) * (s0 / s1);
     }
-    const float sin_theta = std::sin(theta), cos_theta = std::cos(theta);
+    const float sin_theta = sinF(theta), cos_theta = cosF(theta);
     ox = cos_theta * r;
     oy = sin_theta * r;
 }

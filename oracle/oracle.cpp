@@ -757,6 +757,15 @@ void zyg_oracle_sobol_stream(uint32_t sample, uint32_t seed, uint32_t n, uint32_
 
 void zyg_oracle_gilbert(int32_t idx, int32_t w, int32_t h, int32_t* out_xy) { gilbertD2xy(idx, w, h, out_xy); }
 
+// the restated sin / cos / acos (omath.hpp), for accuracy tests against a float64 reference
+void zyg_oracle_trig(uint32_t n, const float* x, float* out_sin, float* out_cos, float* out_acos) {
+    for (uint32_t i = 0; i < n; ++i) {
+        out_sin[i] = sinF(x[i]);
+        out_cos[i] = cosF(x[i]);
+        out_acos[i] = acosF(x[i]);
+    }
+}
+
 void zyg_oracle_offset_ray(const float* p, const float* n, float* out) {
     const V4 r = offsetRay(mk(p[0], p[1], p[2]), mk(n[0], n[1], n[2]));
     out[0] = r[0];
@@ -792,3 +801,34 @@ void zyg_oracle_sphquad(const ZygpuTrafo* trafo, const float* p, float* out_soli
 }
 
 }  // extern "C"
+
+extern "C" {
+// SphQuad on explicit inputs: in = scale.xy, o.xyz, u0, u1 -> out = S, pdf, sample.xyz
+void zyg_oracle_sphquad_eval(uint32_t n, const float* in, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float*  a = in + 7 * i;
+        const V4      scale = mk(a[0], a[1], 1.f, 1.f);
+        const SphQuad q = SphQuad::init(scale, mk(a[2], a[3], a[4]));
+        const V4      sp = q.sample(a[5], a[6]);
+        float*        o = out + 5 * i;
+        o[0] = q.Sa;
+        o[1] = q.pdf(scale);
+        o[2] = sp[0];
+        o[3] = sp[1];
+        o[4] = sp[2];
+    }
+}
+}
+
+extern "C" void zyg_oracle_basic_ops(uint32_t n, const float* in, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float a = in[2 * i], b = in[2 * i + 1];
+        out[6 * i] = a / b;
+        out[6 * i + 1] = std::sqrt(std::fabs(a));
+        out[6 * i + 2] = a * b + a;
+        out[6 * i + 3] = 1.f / a;
+        out[6 * i + 4] = acosR(std::fabs(a) * 0.25f);
+        const float z = std::fabs(a) * 0.25f;
+        out[6 * i + 5] = z * (1.6666586697e-01f + z * (-4.2743422091e-02f + z * -8.6563630030e-03f));
+    }
+}

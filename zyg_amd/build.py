@@ -29,8 +29,7 @@ def hipcc():
 
 def build(verbose=True, extra=()):
     cmd = [hipcc(), "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-x", "hip", SOURCES[0], "-x", "c++", SOURCES[1], SOURCES[2],
-           "-o", OUT, *extra]
+           "-Wall", "-Wno-unused-function", "-x", "hip", *SOURCES, "-o", OUT, *extra]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -41,10 +41,10 @@ ZD float importance(f3 p, f3 n, f3 center, f3 cone_axis, float cos_cone, float r
     const float cos_a = two_sided ? fabsf(dd) : dd;
     const float cos_n = mx(-dot3(n, na), 0.f);
 
-    const float cos_cu = __fsqrt_rn(mx(__fmaf_rn(sin_cu, -sin_cu, 1.f), 0.f));
-    const float sin_cone = __fsqrt_rn(mx(__fmaf_rn(cos_cone, -cos_cone, 1.f), 0.f));
-    const float sin_a = __fsqrt_rn(mx(__fmaf_rn(cos_a, -cos_a, 1.f), 0.f));
-    const float sin_n = __fsqrt_rn(mx(__fmaf_rn(cos_n, -cos_n, 1.f), 0.f));
+    const float cos_cu = sqrtf(mx(__fmaf_rn(sin_cu, -sin_cu, 1.f), 0.f));
+    const float sin_cone = sqrtf(mx(__fmaf_rn(cos_cone, -cos_cone, 1.f), 0.f));
+    const float sin_a = sqrtf(mx(__fmaf_rn(cos_a, -cos_a, 1.f), 0.f));
+    const float sin_n = sqrtf(mx(__fmaf_rn(cos_n, -cos_n, 1.f), 0.f));
 
     const float ta = clampedCosSub(cos_a, cos_cone, sin_a, sin_cone);
     const float tb = clampedSinSub(cos_a, cos_cone, sin_a, sin_cone);
@@ -96,7 +96,7 @@ struct LightTree {
         const float vg = e2g - eg2;
         const float ve = n.variance, ee = n.power;
         const float s2 = mx(ve * vg + ve * eg2 + ee * ee * vg, 0.f);
-        const float ns = 1.f / (1.f + __fsqrt_rn(s2));
+        const float ns = 1.f / (1.f + sqrtf(s2));
         return ns < threshold;
     }
 
@@ -302,10 +302,10 @@ struct SphQuad {  // rectangle.zig:199-303
         const f3 n1 = normalize3(cross3(v10, v11));
         const f3 n2 = normalize3(cross3(v11, v01));
         const f3 n3 = normalize3(cross3(v01, v00));
-        const float g0 = acosf(-dot3(n0, n1));
-        const float g1 = acosf(-dot3(n1, n2));
-        const float g2 = acosf(-dot3(n2, n3));
-        const float g3 = acosf(-dot3(n3, n0));
+        const float g0 = acosF(-dot3(n0, n1));
+        const float g1 = acosF(-dot3(n1, n2));
+        const float g2 = acosF(-dot3(n2, n3));
+        const float g3 = acosF(-dot3(n3, n0));
         q.b0 = n0.z;
         q.b1 = n2.z;
         q.k = 2.f * kPi - g2 - g3;
@@ -315,18 +315,18 @@ struct SphQuad {  // rectangle.zig:199-303
 
     ZD f3 sample(float u0, float u1) const {
         const float au = u0 * Sa + k;
-        const float fu = (cosf(au) * b0 - b1) / sinf(au);
-        float       cu = 1.f / __fsqrt_rn(fu * fu + b0 * b0) * (fu > 0.f ? 1.f : -1.f);
+        const float fu = (cosF(au) * b0 - b1) / sinF(au);
+        float       cu = 1.f / sqrtf(fu * fu + b0 * b0) * (fu > 0.f ? 1.f : -1.f);
         cu = stdClamp(cu, -1.f, 1.f);
-        float xu = -(cu * z0) / __fsqrt_rn(1.f - cu * cu);
+        float xu = -(cu * z0) / sqrtf(1.f - cu * cu);
         xu = stdClamp(xu, x0, x1);
-        const float dd = __fsqrt_rn(xu * xu + z0 * z0);
-        const float h0 = y0 / __fsqrt_rn(dd * dd + y0 * y0);
-        const float h1 = y1 / __fsqrt_rn(dd * dd + y1 * y1);
+        const float dd = sqrtf(xu * xu + z0 * z0);
+        const float h0 = y0 / sqrtf(dd * dd + y0 * y0);
+        const float h1 = y1 / sqrtf(dd * dd + y1 * y1);
         const float hv = h0 + u1 * (h1 - h0);
         const float hv2 = hv * hv;
         const float eps = __uint_as_float(0x35800000u);
-        const float yv = hv2 < 1.f - eps ? ((hv * dd) / __fsqrt_rn(1.f - hv2)) : y1;
+        const float yv = hv2 < 1.f - eps ? ((hv * dd) / sqrtf(1.f - hv2)) : y1;
         return o + S3(xu) * x + S3(yv) * y + S3(z0) * z;
     }
 
@@ -334,7 +334,7 @@ struct SphQuad {  // rectangle.zig:199-303
         const float sqr_dist = squaredLength3(o);
         const float area = scale.x * scale.y;
         const float numer = area * fabsf(o.z);
-        const float denom = sqr_dist * __fsqrt_rn(sqr_dist);
+        const float denom = sqr_dist * sqrtf(sqr_dist);
         return numer > denom * kDotMin ? (1.f / Sa) : (denom / numer);
     }
 };

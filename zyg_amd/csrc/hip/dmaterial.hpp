@@ -89,8 +89,8 @@ ZD float isoDistribution(float n_dot_h, float a2) {
     return a2 / (kPi * d * d);
 }
 ZD void isoVisibilityAndG1Wo(float n_dot_wi, float n_dot_wo, float alpha2, float& g0, float& g1) {
-    const float t_wi = __fsqrt_rn(__fmaf_rn(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
-    const float t_wo = __fsqrt_rn(__fmaf_rn(1.f - alpha2, n_dot_wo * n_dot_wo, alpha2));
+    const float t_wi = sqrtf(__fmaf_rn(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
+    const float t_wo = sqrtf(__fmaf_rn(1.f - alpha2, n_dot_wo * n_dot_wo, alpha2));
     g0 = 0.5f / (n_dot_wi * t_wo + n_dot_wo * t_wi);
     g1 = t_wo + n_dot_wo;
 }
@@ -113,8 +113,8 @@ ZD f3 ggxSample(f3 wo, float a0, float a1, float xi0, float xi1, const Frame& fr
     const f3    v = normalize3(mk3(a0 * wo_l.x, a1 * wo_l.y, wo_l.z));
     const float phi = (2.f * kPi) * xi0;
     const float z = __fmaf_rn(1.f - xi1, 1.f + v.z, -v.z);
-    const float sin_theta = __fsqrt_rn(saturate(1.f - z * z));
-    const float x = sin_theta * cosf(phi), y = sin_theta * sinf(phi);
+    const float sin_theta = sqrtf(saturate(1.f - z * z));
+    const float x = sin_theta * cosF(phi), y = sin_theta * sinF(phi);
     const f3    h = mk3(x, y, z) + v;
     const f3    m = normalize3(mk3(a0 * h.x, a1 * h.y, h.z));
     n_dot_h = clampf(m.z, kDotMin, 1.f);

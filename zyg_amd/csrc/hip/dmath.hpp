@@ -41,7 +41,7 @@ ZD f3    fma3(f3 a, f3 b, f3 c) { return {__fmaf_rn(a.x, b.x, c.x), __fmaf_rn(a.
 // base/math/vector4.zig:37-60
 ZD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 ZD float squaredLength3(f3 a) { return dot3(a, a); }
-ZD float length3(f3 a) { return __fsqrt_rn(dot3(a, a)); }
+ZD float length3(f3 a) { return sqrtf(dot3(a, a)); }
 ZD float distance3(f3 a, f3 b) { return length3(a - b); }
 ZD f3    normalize3(f3 a) { return a / S3(length3(a)); }
 ZD float hmax3(f3 a) { return mx(a.x, mx(a.y, a.z)); }
@@ -59,6 +59,77 @@ ZD f3 cross3(f3 a, f3 b) {
 ZD f3    gramSchmidt(f3 v, f3 w) { return fma3(S3(-dot3(v, w)), w, v); }  // vector4.zig:121
 ZD float lerpf(float a, float b, float t) { return __fmaf_rn(1.f - t, a, t * b); }  // util.zig:3-16
 ZD f3    lerp3(f3 a, f3 b, f3 t) { return fma3(S3(1.f) - t, a, t * b); }
+
+
+// sin / cos / acos with the reference's algorithms (Zig std.math.acos = msun e_acosf.c; compiler-rt sinf/cosf =
+// musl sinf.c/cosf.c with the double-precision k_sinf/k_cosf kernels) so that device results are reproducible
+// bit for bit on the host.  |x| <= 9*pi/4 is the range the integration loop produces; beyond it OCML is used.
+ZD float sindf(double x) {
+    const double S1 = -0x1.5555554cbac77p-3, S2 = 0x1.11110896efbb2p-7, S3 = -0x1.a00f9e2cae774p-13, S4 = 0x1.6cd878c3b46a7p-19;
+    const double z = x * x, w = z * z, r = S3 + z * S4, s = z * x;
+    return float((x + s * (S1 + z * S2)) + s * w * r);
+}
+ZD float cosdf(double x) {
+    const double C0 = -0x1.ffffffd0c5e81p-2, C1 = 0x1.55553e1053a42p-5, C2 = -0x1.6c087e80f1e27p-10, C3 = 0x1.99342e0ee5069p-16;
+    const double z = x * x, w = z * z, r = C2 + z * C3;
+    return float(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+constexpr double kPio2d = 1.57079632679489661923;
+ZD float sinF(float x) {
+    const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
+    const bool     sign = 0 != (hx >> 31);
+    const double   xd = double(x);
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? x : sindf(xd);
+    if (ix <= 0x407b53d1u) {
+        if (ix <= 0x4016cbe3u) return sign ? -cosdf(xd + kPio2d) : cosdf(xd - kPio2d);
+        return sindf(sign ? -(xd + 2 * kPio2d) : -(xd - 2 * kPio2d));
+    }
+    if (ix <= 0x40e231d5u) {
+        if (ix <= 0x40afeddfu) return sign ? cosdf(xd + 3 * kPio2d) : -cosdf(xd - 3 * kPio2d);
+        return sindf(sign ? xd + 4 * kPio2d : xd - 4 * kPio2d);
+    }
+    return sinf(x);
+}
+ZD float cosF(float x) {
+    const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
+    const bool     sign = 0 != (hx >> 31);
+    const double   xd = double(x);
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? 1.f : cosdf(xd);
+    if (ix <= 0x407b53d1u) {
+        if (ix > 0x4016cbe3u) return -cosdf(sign ? xd + 2 * kPio2d : xd - 2 * kPio2d);
+        return sign ? sindf(xd + kPio2d) : sindf(kPio2d - xd);
+    }
+    if (ix <= 0x40e231d5u) {
+        if (ix > 0x40afeddfu) return cosdf(sign ? xd + 4 * kPio2d : xd - 4 * kPio2d);
+        return sign ? sindf(-xd - 3 * kPio2d) : sindf(xd - 3 * kPio2d);
+    }
+    return cosf(x);
+}
+ZD float acosR(float z) {
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    const float p = z * (pS0 + z * (pS1 + z * pS2)), q = 1.f + z * qS1;
+    return p / q;
+}
+ZD float acosF(float x) {
+    const float    pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x3f800000u) {
+        if (ix == 0x3f800000u) return (hx >> 31) ? 2.f * pio2_hi + 0x1p-120f : 0.f;
+        return __uint_as_float(0x7fc00000u);
+    }
+    if (ix < 0x3f000000u) {
+        if (ix <= 0x32800000u) return pio2_hi + 0x1p-120f;
+        return pio2_hi - (x - (pio2_lo - x * acosR(x * x)));
+    }
+    if (hx >> 31) {
+        const float z = (1.f + x) * 0.5f, s = sqrtf(z), w = acosR(z) * s - pio2_lo;
+        return 2.f * (pio2_hi - (s + w));
+    }
+    const float z = (1.f - x) * 0.5f, s = sqrtf(z);
+    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df), w = acosR(z) * s + c;
+    return 2.f * (df + w);
+}
 
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kPiInv = float(1.0 / 3.14159265358979323846);
@@ -96,14 +167,14 @@ ZD void diskConcentric(float u0, float u1, float& ox, float& oy) {
         r = s1;
         theta = (kPi / 2.f) - (kPi / 4.f) * (s0 / s1);
     }
-    const float sin_theta = sinf(theta), cos_theta = cosf(theta);
+    const float sin_theta = sinF(theta), cos_theta = cosF(theta);
     ox = cos_theta * r;
     oy = sin_theta * r;
 }
 ZD f3 hemisphereCosine(float u0, float u1) {
     float x, y;
     diskConcentric(u0, u1, x, y);
-    const float z = __fsqrt_rn(mx(0.f, 1.f - x * x - y * y));
+    const float z = sqrtf(mx(0.f, 1.f - x * x - y * y));
     return {x, y, z};
 }
 

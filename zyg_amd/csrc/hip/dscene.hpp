@@ -363,8 +363,8 @@ ZD void meshFragment(const DMesh& mesh, Fragment& f) {  // triangle_mesh.zig:310
     f3          dpdu, dpdv;
     if (0.f == fabsf(determinant)) {
         const f3 ng = normalize3(cross3(pc - pa, pb - pa));
-        if (fabsf(ng.x) > fabsf(ng.y)) dpdu = mk3(-ng.z, 0.f, ng.x) / S3(__fsqrt_rn(ng.x * ng.x + ng.z * ng.z));
-        else dpdu = mk3(0.f, ng.z, -ng.y) / S3(__fsqrt_rn(ng.y * ng.y + ng.z * ng.z));
+        if (fabsf(ng.x) > fabsf(ng.y)) dpdu = mk3(-ng.z, 0.f, ng.x) / S3(sqrtf(ng.x * ng.x + ng.z * ng.z));
+        else dpdu = mk3(0.f, ng.z, -ng.y) / S3(sqrtf(ng.y * ng.y + ng.z * ng.z));
         dpdv = cross3(ng, dpdu);
     } else {
         const float invdet = 1.f / determinant;

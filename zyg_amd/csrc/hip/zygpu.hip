@@ -704,6 +704,64 @@ __global__ void film_resolve(const float4* film, float4* out, uint32_t n, float 
     out[i] = make_float4(srgb.x, srgb.y, srgb.z, 1.f);
 }
 
+
+// ---------------------------------------------------------------- device unit-test hook
+// Evaluates small device functions on caller-provided inputs so that tests can compare them with the oracle:
+//  op 0: x -> sinF, cosF, acosF                       (1 in, 3 out)
+//  op 1: scale.xy, o.xyz, u0, u1 -> SphQuad S, pdf, sample.xyz (7 in, 5 out)
+//  op 2: sample, seed -> the first 10 Sobol 1D draws with a padding increment after 5 (2 in as bits, 10 out)
+//  op 3: state.lo, state.hi(seq) -> 4 PCG floats      (2 in as bits, 4 out)
+//  op 4: p.xyz, n.xyz -> offsetRay                    (6 in, 3 out)
+__global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (0 == op) {
+        const float x = in[i];
+        out[3 * i] = sinF(x);
+        out[3 * i + 1] = cosF(x);
+        out[3 * i + 2] = acosF(x);
+    } else if (1 == op) {
+        const float*  a = in + 7 * i;
+        const f3      scale = mk3(a[0], a[1], 1.f);
+        const SphQuad q = SphQuad::init(scale, mk3(a[2], a[3], a[4]));
+        const f3      sp = q.sample(a[5], a[6]);
+        float*        o = out + 5 * i;
+        o[0] = q.Sa;
+        o[1] = q.pdf(scale);
+        o[2] = sp.x;
+        o[3] = sp.y;
+        o[4] = sp.z;
+    } else if (2 == op) {
+        Sampler smp;
+        smp.sobol_kind = true;
+        smp.use_primary = true;
+        smp.startPixel(__float_as_uint(in[2 * i]), __float_as_uint(in[2 * i + 1]));
+        for (int k = 0; k < 10; ++k) {
+            out[10 * i + k] = smp.sample1D();
+            if (4 == k) smp.incrementPadding();
+        }
+    } else if (3 == op) {
+        Pcg g;
+        g.start(uint64_t(__float_as_uint(in[2 * i])), uint64_t(__float_as_uint(in[2 * i + 1])));
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = g.randomFloat();
+    } else if (5 == op) {
+        const float a = in[2 * i], b = in[2 * i + 1];
+        out[6 * i] = a / b;
+        out[6 * i + 1] = sqrtf(fabsf(a));
+        out[6 * i + 2] = a * b + a;
+        out[6 * i + 3] = 1.f / a;
+        out[6 * i + 4] = acosR(fabsf(a) * 0.25f);
+        const float z = fabsf(a) * 0.25f;
+        out[6 * i + 5] = z * (1.6666586697e-01f + z * (-4.2743422091e-02f + z * -8.6563630030e-03f));
+    } else if (4 == op) {
+        const float* a = in + 6 * i;
+        const f3     r = offsetRay(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]));
+        out[3 * i] = r.x;
+        out[3 * i + 1] = r.y;
+        out[3 * i + 2] = r.z;
+    }
+}
+
 // ---------------------------------------------------------------- host side
 
 thread_local std::string g_error;
@@ -1156,6 +1214,22 @@ int zygpu_resolve(ZygpuContext* c, float* host_rgba, uint32_t num_pixels) {
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(host_rgba, c->resolve_tmp, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int zygpu_test_eval(ZygpuContext* c, uint32_t op, uint32_t n, const float* in, uint32_t in_stride, float* out, uint32_t out_stride) {
+    if (!c || !in || !out) return -1;
+    HIP_OK(hipSetDevice(c->device));
+    float *din = nullptr, *dout = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&din), size_t(n) * in_stride * sizeof(float)));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&dout), size_t(n) * out_stride * sizeof(float)));
+    HIP_OK(hipMemcpy(din, in, size_t(n) * in_stride * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(test_eval, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, n, din, dout);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out, dout, size_t(n) * out_stride * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(din);
+    (void)hipFree(dout);
     return 0;
 }
 
