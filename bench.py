@@ -187,6 +187,7 @@ def cpu_baseline(eng, w, h, budget_s):
     oracle.zyg_oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                          ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                          ctypes.c_void_p]
+    oracle.zyg_oracle_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     sd = eng.lib.su_ext_scene_desc().contents
     vd = eng.lib.su_ext_view_desc().contents
     cores = os.cpu_count() or 1
