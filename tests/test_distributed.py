@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` processes shard the iterations (and, separately, the rows) of one frame,
+render their shard with the CPU oracle standing in for the device, and reduce the films; rank 0 compares the sum with
+the single-process film.  This is the same sharding + reduce bench.py runs with RCCL."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import zyg_amd
+    from zyg_amd import distributed, scenes
+    from util import oracle_render
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import conftest
+    oracle = ctypes.CDLL(conftest._build_oracle())
+    oracle.zyg_oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(zyg_amd.Stats)]
+    w, h, k = 40, 30, 2
+    with zyg_amd.Engine() as e:
+        scenes.cornell(e, w, h, world * k)
+        sd, vd = e.compile()
+        if mode == "iterations":
+            first, count = distributed.iteration_shard(rank, world, k)
+            film = oracle_render(oracle, sd, vd, count, threads=2, iteration0=first)
+        else:
+            y0, y1 = distributed.row_shard(rank, world, h)
+            film = oracle_render(oracle, sd, vd, world * k, threads=2, y_range=(y0, y1))
+        t = torch.from_numpy(film)
+        distributed.reduce_film(t, dist, dst=0)
+        if rank == 0:
+            full = oracle_render(oracle, sd, vd, world * k, threads=2)
+            np.savez(out_path, reduced=t.numpy(), full=full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["iterations", "rows"])
+def test_two_rank_sharding_matches_single_process(tmp_path, mode):
+    import torch.multiprocessing as mp
+    conftest = __import__("conftest")
+    conftest._build_oracle()
+    conftest._build_product()
+    out = str(tmp_path / "films.npz")
+    mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    d = np.load(out)
+    if mode == "rows":
+        assert np.array_equal(d["reduced"], d["full"])  # disjoint pixels: exact
+    else:
+        assert np.array_equal(d["reduced"][..., 3], d["full"][..., 3])
+        np.testing.assert_allclose(d["reduced"], d["full"], rtol=1e-6, atol=1e-7)  # float association only
+
+
+def test_shard_helpers():
+    from zyg_amd import distributed
+    assert [distributed.row_shard(r, 3, 10) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert [distributed.iteration_shard(r, 4, 16) for r in range(4)] == [(0, 16), (16, 16), (32, 16), (48, 16)]

@@ -1,0 +1,269 @@
+"""Host-side logic without a GPU: the C-ABI library loads and exports every declared symbol, the su_* protocol keeps
+the reference's error convention (src/capi/capi.zig), and the scene-build products (SAH BVH with spatial splits,
+top-level trees, light tree) satisfy their invariants and agree with brute force."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import zyg_amd
+from zyg_amd import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:su|zygpu)_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header", ["zygpu.h", "zyg_capi.h"])
+def test_library_exports_every_declared_symbol(product_lib, header):
+    names = _declared_functions(header)
+    assert len(names) >= (15 if header == "zygpu.h" else 30)
+    for n in names:
+        assert hasattr(product_lib, n), n
+
+
+def test_reference_c_abi_has_30_entries():
+    names = [n for n in _declared_functions("zyg_capi.h") if n.startswith("su_") and not n.startswith("su_ext_")]
+    assert len(names) == 30
+
+
+def test_su_protocol_error_codes(product_lib):
+    lib = product_lib
+    assert lib.su_release() == -1  # not initialised
+    assert lib.su_init() == 0
+    try:
+        assert lib.su_init() == -1  # capi.zig:58-60
+        assert lib.su_sampler_create(16) == -1  # capi.zig:215-221: always -1
+        assert lib.su_material_update(12345, b'{"roughness": 0.2}') == -3
+        assert lib.su_material_create(zyg_amd.NULL, b"not json") == -1
+        assert lib.su_material_create(zyg_amd.NULL, b'{"rendering": {"Hair": {}}}') == -1
+        m = lib.su_material_create(zyg_amd.NULL, b'{"rendering": {"Substitute": {"color": [1, 0, 0], "roughness": 0.5}}}')
+        assert m >= 1  # id 0 is the fallback material
+        assert lib.su_material_update(m, b'{"roughness": 0.25}') == 0
+        assert lib.su_prop_create(999, 0, None) == -1
+        assert lib.su_prop_create_instance(999) == -1
+        assert lib.su_light_create(999) == -1
+        assert lib.su_prop_set_visibility(999, 1, 1, 0) == -1
+        cam = lib.su_perspective_camera_create(64, 32)
+        assert cam == 0
+        dims = (ctypes.c_int32 * 2)()
+        assert lib.su_camera_sensor_dimensions(dims) == 0 and list(dims) == [64, 32]
+        p = lib.su_prop_create(scenes.RECTANGLE, 0, None)  # materials padded with the fallback (capi.zig:441-447)
+        assert p == 1
+        inst = lib.su_prop_create_instance(p)
+        assert inst == 2
+        assert lib.su_render_iterations(1) == -1  # before su_start_frame
+        assert lib.su_resolve_frame(zyg_amd.NULL) == -1
+        assert lib.su_image_create(zyg_amd.NULL, 0, 3, 4, 4, 1, 3, None) == -1  # image textures are out of scope
+    finally:
+        assert lib.su_release() == 0
+
+
+def test_cornell_compile_products(engine):
+    ids = scenes.cornell(engine, 64, 48, 4)
+    sd, vd = engine.compile()
+    assert sd.num_props == 10 and sd.num_lights == 2 and sd.num_meshes == 2
+    # lights are unoccluding `Light` entities: not in the solid tree (scene.zig:324-342)
+    solid = {sd.solid.indices[i] for i in range(sd.solid.num_indices)}
+    unocc = {sd.unoccluding.indices[i] for i in range(sd.unoccluding.num_indices)}
+    assert unocc == set(ids["lights"]) and solid == set(ids["walls"]) | set(ids["meshes"])
+    # camera-relative world: the camera prop sits at the origin (space.zig:99-108)
+    assert list(vd.camera_trafo.position)[:3] == [0.0, 0.0, 0.0]
+    # light power = max(emission) * area (emittance.zig:61-71, light.zig:67-77)
+    mat = sd.materials[sd.material_ids[sd.props[ids["lights"][0]].parts_start]]
+    assert sd.light_aabbs[0].min[3] == pytest.approx(max(mat.emission) * 0.25, rel=1e-6)
+    assert vd.integrator == 3 and vd.max_depth_surface == 16 and vd.split_threshold == pytest.approx(0.5 ** 4)
+    assert vd.filter_radius_int == 0 and vd.num_expected_samples == 4
+
+
+def test_default_sensor_is_mitchell_radius_2(engine):
+    engine.camera(8, 8)
+    sd, vd = engine.compile()
+    assert vd.filter_radius_int == 2 and vd.filter_radius == 2.0  # take.zig:59-64
+    taps = np.array(vd.filter_samples[:30])
+    # normalised so that 2 * sum(midpoint rule over [0, r]) = 1 (sensor.zig:105-120, 630-645)
+    xs = (np.arange(64) + 0.5) * (2.0 / 64)
+    vals = np.interp(xs, np.linspace(0, 2, 30), taps)
+    assert 2 * vals.sum() * (2.0 / 64) == pytest.approx(1.0, rel=1e-4)
+    assert taps[0] > 0 and taps[-1] == pytest.approx(0.0, abs=1e-6)
+
+
+def _mesh_desc(engine, n=40):
+    idx, pos, nrm, uv = scenes.heightfield_mesh(n=n, size=1.5, height=0.6)
+    engine.camera(16, 16)
+    shape = engine.triangle_mesh(idx, pos, nrm, uv)
+    p = engine.prop(shape, [0])
+    engine.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0)))
+    sd, vd = engine.compile()
+    return sd, idx, pos, p
+
+
+def test_triangle_bvh_invariants(engine):
+    sd, idx, pos, _ = _mesh_desc(engine)
+    m = sd.meshes[0]
+    ntri_in = idx.size // 3
+    assert m.num_triangles >= ntri_in  # spatial splits may duplicate references
+    tris = np.ctypeslib.as_array(m.triangles, shape=(m.num_triangles, 3))
+    # every input triangle survives (as a vertex-index triple) in at least one leaf
+    have = {tuple(t) for t in tris.tolist()}
+    assert {tuple(t) for t in idx.reshape(-1, 3).tolist()} <= have
+    P = np.ctypeslib.as_array(m.positions, shape=(m.num_vertices * 3 + 1,))[:-1].reshape(-1, 3)
+    covered = np.zeros(m.num_triangles, dtype=bool)
+    leaves = 0
+    stack = [0]
+    while stack:
+        n = m.nodes[stack.pop()]
+        lo, hi = np.array(n.min[:]), np.array(n.max[:])
+        assert np.all(lo <= hi)
+        if n.count:
+            leaves += 1
+            assert n.count <= 0x2FF
+            first = n.children_or_first
+            assert not covered[first:first + n.count].any()
+            covered[first:first + n.count] = True
+            for t in tris[first:first + n.count]:
+                tri_lo, tri_hi = P[t].min(axis=0), P[t].max(axis=0)
+                # the (possibly clipped) reference overlaps the leaf box
+                assert np.all(tri_lo <= hi + 1e-6) and np.all(tri_hi >= lo - 1e-6)
+        else:
+            a = n.children_or_first
+            assert a % 2 == 1  # children are adjacent pairs (a, a + 1) allocated right after the root
+            for c in (a, a + 1):
+                cn = m.nodes[c]
+                assert np.all(np.array(cn.min[:]) >= lo - 1e-6) and np.all(np.array(cn.max[:]) <= hi + 1e-6)
+            stack += [a, a + 1]
+    assert covered.all() and leaves > ntri_in // 8
+    areas = np.ctypeslib.as_array(m.part_areas, shape=(m.num_parts,))
+    e1, e2 = P[tris[:, 1]] - P[tris[:, 0]], P[tris[:, 2]] - P[tris[:, 0]]
+    assert areas[0] == pytest.approx(0.5 * np.linalg.norm(np.cross(e1, e2), axis=1).sum(), rel=1e-4)
+
+
+def test_oct_normals_round_trip(engine):
+    sd, idx, pos, _ = _mesh_desc(engine, n=24)
+    m = sd.meshes[0]
+    enc = np.ctypeslib.as_array(m.normals, shape=(m.num_vertices, 2)).astype(np.float64)
+    o = enc / 32768.0 - 1.0
+    v = np.stack([o[:, 0], o[:, 1], -1.0 + np.abs(o[:, 0]) + np.abs(o[:, 1])], axis=1)
+    t = np.maximum(v[:, 2], 0.0)
+    v[:, 0] += np.where(v[:, 0] > 0, -t, t)
+    v[:, 1] += np.where(v[:, 1] > 0, -t, t)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    _, _, nrm, _ = scenes.heightfield_mesh(n=24, size=1.5, height=0.6)
+    assert np.max(np.abs(v - nrm)) < 3e-4  # snorm16 quantisation of the octahedral map
+
+
+def test_oracle_traversal_matches_brute_force(engine, oracle):
+    """Closest hits through TLAS + BLAS (oracle) against an O(N) float64 Moeller-Trumbore over the input triangles."""
+    sd, idx, pos, prop = _mesh_desc(engine, n=32)
+    rng = np.random.default_rng(11)
+    n = 3000
+    o = np.stack([rng.uniform(-1, 1, n), rng.uniform(0.8, 2.0, n), rng.uniform(-1, 1, n)], axis=1)
+    target = np.stack([rng.uniform(-0.9, 0.9, n), np.zeros(n), rng.uniform(-0.9, 0.9, n)], axis=1)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 0.0, d, 2.14748313e9
+    hits = np.zeros((n, 8), dtype=np.uint32)
+    oracle.zyg_oracle_intersect(ctypes.byref(sd), n, rays.ctypes.data_as(ctypes.c_void_p), 0, hits.ctypes.data_as(ctypes.c_void_p))
+    t_oracle = hits[:, 0].view(np.float32)
+    hit_oracle = hits[:, 4] != zyg_amd.NULL
+
+    tri = pos[idx.reshape(-1, 3)].astype(np.float64)
+    a, e1, e2 = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    ro, rd = rays[:, 0:3].astype(np.float64), rays[:, 4:7].astype(np.float64)
+    best = np.full(n, np.inf)
+    for i in range(n):
+        pvec = np.cross(rd[i], e2)
+        det = np.einsum("ij,ij->i", e1, pvec)
+        inv = 1.0 / np.where(det == 0, np.nan, det)
+        tvec = ro[i] - a
+        u = np.einsum("ij,ij->i", tvec, pvec) * inv
+        qvec = np.cross(tvec, e1)
+        v = (qvec @ rd[i]) * inv
+        t = np.einsum("ij,ij->i", e2, qvec) * inv
+        ok = (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t >= 0)
+        if ok.any():
+            best[i] = t[ok].min()
+    hit_bf = np.isfinite(best)
+    disagree = hit_bf != hit_oracle
+    assert disagree.mean() < 0.002  # edge-grazing rays only
+    both = hit_bf & hit_oracle
+    assert both.sum() > n // 2
+    np.testing.assert_allclose(t_oracle[both], best[both], rtol=2e-4)
+
+
+def test_light_tree_pick_pdf_consistency(engine, oracle):
+    """randomLight without splitting returns one pick whose pdf equals Tree.pdf of that light (light_tree.zig:346-517),
+    and the pdfs over all lights sum to 1."""
+    scenes.cornell(engine, 16, 16, 1)
+    sd, vd = engine.compile()
+    rng = np.random.default_rng(2)
+    offs = (ctypes.c_uint32 * 64)()
+    pdfs = (ctypes.c_float * 64)()
+    for _ in range(200):
+        p = rng.uniform(-0.9, 0.9, 3).astype(np.float32)
+        p[1] = rng.uniform(0.05, 1.5)
+        p[2] += 3.9  # camera-relative
+        p[1] -= 1.0
+        nrm = np.array([0, 1, 0], dtype=np.float32)
+        r = float(rng.uniform())
+        vp = lambda v: v.ctypes.data_as(ctypes.c_void_p)
+        c = oracle.zyg_oracle_random_light(ctypes.addressof(sd), vp(p), vp(nrm), 0, r, 0.0, offs, pdfs)
+        assert c == 1
+        pdf = oracle.zyg_oracle_light_pdf(ctypes.addressof(sd), vp(p), vp(nrm), 0, 0.0, offs[0])
+        assert pdf == pytest.approx(pdfs[0], rel=1e-6)
+        total = sum(oracle.zyg_oracle_light_pdf(ctypes.addressof(sd), vp(p), vp(nrm), 0, 0.0, l) for l in range(sd.num_lights))
+        assert total == pytest.approx(1.0, rel=1e-5)
+        # with splitting enabled every light with non-zero importance is returned with pdf 1 (max_split_depth >= 1)
+        c2 = oracle.zyg_oracle_random_light(ctypes.addressof(sd), vp(p), vp(nrm), 0, r, 1.0, offs, pdfs)
+        assert 1 <= c2 <= sd.num_lights
+
+
+def test_many_lights_tree(engine, oracle):
+    """A 5 x 5 grid of quad lights: the light BVH covers every light exactly once and pdfs still sum to one."""
+    engine.camera(8, 8)
+    lamp = engine.material(scenes.light_material())
+    for i in range(5):
+        for j in range(5):
+            p = engine.prop(scenes.RECTANGLE, [lamp], unoccluding=True)
+            engine.transformation(p, scenes.trafo((1, 0, 0), (0, 0, 1), (0.2 + 0.02 * i, 0.2, 1), (i - 2.0, 2.0, j + 1.0)))
+            engine.light(p)
+    sd, vd = engine.compile()
+    lt = sd.light_tree
+    assert lt.num_lights == 25 and lt.num_nodes >= 25
+    mapping = sorted(lt.light_mapping[i] for i in range(25))
+    assert mapping == list(range(25))
+    orders = sorted(lt.light_orders[i] for i in range(25))
+    assert orders == list(range(25))
+    p = np.array([0.1, 0.0, 3.0], dtype=np.float32)
+    nrm = np.array([0, 1, 0], dtype=np.float32)
+    vp = lambda v: v.ctypes.data_as(ctypes.c_void_p)
+    total = sum(oracle.zyg_oracle_light_pdf(ctypes.addressof(sd), vp(p), vp(nrm), 0, 0.0, l) for l in range(25))
+    assert total == pytest.approx(1.0, rel=1e-4)
+
+
+def test_unsupported_features_fail_loudly(engine):
+    """A sphere light is outside the hot-path scope: compile reports it instead of silently rendering something else."""
+    engine.camera(8, 8)
+    lamp = engine.material(scenes.light_material())
+    p = engine.prop(6, [lamp])  # built-in Sphere (resource/manager.zig:36-44)
+    engine.light(p)
+    with pytest.raises(RuntimeError):
+        engine.compile()
+
+
+def test_render_without_gpu_fails_loudly(engine):
+    """No CPU fallback in the product path: without a HIP device su_start_frame reports an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    scenes.cornell(engine, 16, 16, 1)
+    with pytest.raises(RuntimeError, match="su_start_frame failed"):
+        engine.start_frame(0)

@@ -1,0 +1,232 @@
+"""Pins the CPU oracle (test infrastructure) against known answers: the reference ships no tests or golden vectors
+(SURVEY §4), so these are the vectors SURVEY §8(c) lists — public PCG32 demo vector, sobol5/hash answers derived from
+the reference's direction table and hash constants (tests/golden), curve/geometry properties and closed-form
+radiometry."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zyg_amd
+from zyg_amd import scenes
+
+from util import oracle_render, oracle_resolve
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sampler_golden.json")))
+
+
+def test_pcg32_demo_vector(oracle):
+    g = GOLDEN["pcg32_demo"]
+    u = (ctypes.c_uint32 * 6)()
+    f = (ctypes.c_float * 6)()
+    oracle.zyg_oracle_pcg(g["state"], g["sequence"], 6, u, f)
+    assert list(u) == g["out"]
+    for bits, fl in zip(g["out"], f):  # generator.zig:25-33 mantissa trick
+        expect = np.array([(bits & 0x007FFFFF) | 0x3F800000], dtype=np.uint32).view(np.float32)[0] - np.float32(1.0)
+        assert fl == expect and 0.0 <= fl < 1.0
+
+
+def test_hash_golden(oracle):
+    for e in GOLDEN["hash"]:
+        assert oracle.zyg_oracle_hash(e["in"]) == e["out"]
+
+
+def test_sobol5_golden(oracle):
+    out = (ctypes.c_uint32 * 5)()
+    for e in GOLDEN["sobol5"]:
+        oracle.zyg_oracle_sobol5(ctypes.c_uint32(e["index"]), out)
+        assert list(out) == e["out"], e["index"]
+        # dimension 0 is the van der Corput sequence (sobol.zig:195-204)
+        assert out[0] == int(f"{e['index']:032b}"[::-1], 2)
+
+
+def test_sobol_stratification(oracle):
+    """Owen scrambling keeps the net property: 2^k consecutive samples of one pixel hit each of 2^k strata once, per
+    dimension (first draw of each sample = dimension 0 of the first refill)."""
+    k = 6
+    n = 1 << k
+    firsts = np.zeros((n, 5), dtype=np.float32)
+    buf = (ctypes.c_float * 5)()
+    for i in range(n):
+        oracle.zyg_oracle_sobol_stream(ctypes.c_uint32(i), ctypes.c_uint32(1234), 5, 0, buf)
+        firsts[i] = list(buf)
+    for d in range(5):
+        strata = np.floor(firsts[:, d].astype(np.float64) * n).astype(int)
+        assert sorted(np.clip(strata, 0, n - 1)) == list(range(n)), d
+
+
+def test_sobol_padding_forces_refill(oracle):
+    a = (ctypes.c_float * 10)()
+    b = (ctypes.c_float * 10)()
+    oracle.zyg_oracle_sobol_stream(7, 99, 10, 0, a)
+    oracle.zyg_oracle_sobol_stream(7, 99, 10, 2, b)  # padding after every 2 draws: dims 2..4 of each refill are dropped
+    assert list(a)[:2] == list(b)[:2]
+    assert list(a)[5:7] == list(b)[2:4]  # second refill starts right after the padding
+
+
+@pytest.mark.parametrize("dim", [(60, 34), (16, 16), (7, 13), (1, 9)])
+def test_gilbert_curve_is_a_unit_step_bijection(oracle, dim):
+    w, h = dim
+    xy = (ctypes.c_int32 * 2)()
+    pts = []
+    for i in range(w * h):
+        oracle.zyg_oracle_gilbert(i, w, h, xy)
+        pts.append((xy[0], xy[1]))
+    assert sorted(pts) == sorted((x, y) for y in range(h) for x in range(w))
+    steps = [abs(a[0] - b[0]) + abs(a[1] - b[1]) for a, b in zip(pts, pts[1:])]
+    # generalized Hilbert curve: unit steps, except that odd x odd-ish shapes may contain one diagonal step
+    assert max(steps, default=1) <= 2 and sum(s != 1 for s in steps) <= 1
+
+
+def test_offset_ray_properties(oracle):
+    """Waechter-Binder offset (ray_offset.zig:14-31): moves along n, by >= 1 ulp-scaled step, float path near 0."""
+    rng = np.random.default_rng(5)
+    out = (ctypes.c_float * 3)()
+    for _ in range(200):
+        p = rng.uniform(-50, 50, 3).astype(np.float32)
+        n = rng.normal(size=3)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        oracle.zyg_oracle_offset_ray(p.ctypes.data_as(ctypes.c_void_p), n.ctypes.data_as(ctypes.c_void_p), out)
+        q = np.array(list(out), dtype=np.float32)
+        d = (q.astype(np.float64) - p.astype(np.float64))
+        assert np.dot(d, n.astype(np.float64)) > 0
+        assert np.linalg.norm(d) < 1e-2
+    p = np.array([0.01, -0.02, 0.0], dtype=np.float32)
+    n = np.array([0.0, 0.0, 1.0], dtype=np.float32)
+    oracle.zyg_oracle_offset_ray(p.ctypes.data_as(ctypes.c_void_p), n.ctypes.data_as(ctypes.c_void_p), out)
+    assert out[2] == np.float32(1.0 / 65536.0) and out[0] == p[0] and out[1] == p[1]
+
+
+def test_trig_accuracy(oracle):
+    """The restated sin / cos / acos (musl algorithms) stay within their published error bounds."""
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-7, 7, 200000).astype(np.float32)
+    s, c, a = (np.zeros_like(x) for _ in range(3))
+    vp = lambda v: v.ctypes.data_as(ctypes.c_void_p)
+    oracle.zyg_oracle_trig(x.size, vp(x), vp(s), vp(c), vp(a))
+
+    def ulp(got, ref):
+        return np.max(np.abs(got.astype(np.float64) - ref) / np.spacing(np.abs(ref.astype(np.float32))).astype(np.float64))
+
+    assert ulp(s, np.sin(x.astype(np.float64))) < 0.51
+    assert ulp(c, np.cos(x.astype(np.float64))) < 0.51
+    xa = rng.uniform(-1, 1, 200000).astype(np.float32)
+    oracle.zyg_oracle_trig(xa.size, vp(xa), vp(s), vp(c), vp(a))
+    assert ulp(a, np.arccos(xa.astype(np.float64))) < 1.0
+
+
+def _quad_trafo(size, pos):
+    t = zyg_amd.Trafo()
+    rows = [(1, 0, 0, size[0]), (0, 1, 0, size[1]), (0, 0, 1, 1.0)]
+    for i, r in enumerate(rows):
+        for j in range(4):
+            t.r[i][j] = r[j]
+    for j in range(3):
+        t.position[j] = pos[j]
+    return t
+
+
+def test_sphquad_solid_angle_closed_form(oracle):
+    """SphQuad.S (rectangle.zig:199-262) vs the closed form for a point on the axis of an a x b rectangle at height d:
+    Omega = 4 atan(a b / (2 d sqrt(4 d^2 + a^2 + b^2)))."""
+    sa = ctypes.c_float()
+    pdf = ctypes.c_float()
+    for a, b, d in [(1.0, 1.0, 1.0), (0.5, 0.5, 1.98), (2.0, 0.7, 0.3), (0.3, 3.0, 5.0)]:
+        t = _quad_trafo((a, b), (0, 0, 0))
+        p = (ctypes.c_float * 3)(0.0, 0.0, d)
+        oracle.zyg_oracle_sphquad(ctypes.byref(t), p, ctypes.byref(sa), ctypes.byref(pdf))
+        omega = 4.0 * np.arctan(a * b / (2.0 * d * np.sqrt(4.0 * d * d + a * a + b * b)))
+        assert sa.value == pytest.approx(omega, rel=2e-5)
+        assert pdf.value == pytest.approx(1.0 / omega, rel=2e-5)
+
+
+def _irradiance_from_rect(a, b, d):
+    """Irradiance on a plane parallel to an a x b Lambertian rectangle of radiance 1 at distance d, below its centre:
+    4 x the corner formula E = 1/2 [ X/sqrt(1+X^2) atan(Y/sqrt(1+X^2)) + Y/sqrt(1+Y^2) atan(X/sqrt(1+Y^2)) ], X=a/2d, Y=b/2d."""
+    x, y = a / (2 * d), b / (2 * d)
+    return 4 * 0.5 * (x / np.sqrt(1 + x * x) * np.arctan(y / np.sqrt(1 + x * x)) + y / np.sqrt(1 + y * y) * np.arctan(x / np.sqrt(1 + y * y)))
+
+
+@pytest.mark.parametrize("integrator", ["PT", "PTDL", "PTMIS"])
+def test_quad_light_irradiance_closed_form(engine, oracle, integrator):
+    """One emissive quad above a Lambert floor, depth 1: radiance towards the camera = albedo/pi * E (closed form)."""
+    w = h = 8
+    spp = 2048 if integrator == "PT" else 256
+    cam = engine.camera(w, h, fov_deg=0.2)  # a thin pencil of rays around the floor point below the light
+    engine.samples_per_pixel(spp)
+    engine.integrators(json.dumps({"surface": {integrator: {"depth": {"surface": 1}}}}))
+    engine.sensor("{}")
+    albedo = 0.6
+    floor = engine.material(scenes.lambert([albedo, albedo, albedo]))
+    lamp = engine.material(scenes.light_material(spectrum=(1.0, 1.0, 1.0)))
+    p = engine.prop(scenes.RECTANGLE, [floor])
+    engine.transformation(p, scenes.trafo((1, 0, 0), (0, 0, -1), (50, 50, 1), (0, 0, 0)))
+    lp = engine.prop(scenes.RECTANGLE, [lamp], unoccluding=True)
+    a, b, d = 1.0, 0.6, 0.8
+    engine.transformation(lp, scenes.trafo((1, 0, 0), (0, 0, 1), (a, b, 1), (0, d, 0)))
+    engine.light(lp)
+    # camera above the light's side, looking at the origin: +z is the view direction
+    eye = np.array([0.0, 3.0, -4.0])
+    fwd = -eye / np.linalg.norm(eye)
+    right = np.cross([0, 1, 0], fwd)
+    right /= np.linalg.norm(right)
+    up = np.cross(fwd, right)
+    m = np.zeros((4, 4), dtype=np.float32)
+    m[0, :3], m[1, :3], m[2, :3], m[3, :3], m[3, 3] = right, up, fwd, eye, 1
+    engine.transformation(cam, m)
+    sd, vd = engine.compile()
+    film = oracle_render(oracle, sd, vd, spp)
+    rgb = film[..., :3].sum(axis=(0, 1)) / film[..., 3].sum()
+    # json colours are sRGB -> AP1 on load (base/json.zig:247-277); grey stays (almost) grey, so compare luminance-free means
+    albedo_ap1 = np.array(sd.materials[floor].color_a[:], dtype=np.float64)
+    emission_ap1 = np.array(sd.materials[lamp].emission[:], dtype=np.float64)
+    expect = albedo_ap1 / np.pi * _irradiance_from_rect(a, b, d) * emission_ap1
+    np.testing.assert_allclose(rgb, expect, rtol=0.03 if integrator == "PT" else 0.01)
+
+
+def test_integrators_agree_on_cornell(product_lib, oracle):
+    """PT, PTDL and PTMIS estimate the same integral: equal means within Monte-Carlo noise."""
+    w, h, spp = 48, 36, 96
+    means = {}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator=integ)
+            sd, vd = e.compile()
+            film = oracle_render(oracle, sd, vd, spp)
+            means[integ] = oracle_resolve(oracle, vd, film)[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.01)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)
+
+
+def test_progressive_iterations_are_independent(engine, oracle):
+    """Rendering iterations [0,2) then [2,4) equals rendering [0,4) (worker.zig:141-149 reseeds per (pixel, iteration))."""
+    scenes.cornell(engine, 40, 30, 4)
+    sd, vd = engine.compile()
+    a = oracle_render(oracle, sd, vd, 2, threads=2) + 0
+    b = oracle_render(oracle, sd, vd, 2, threads=3, iteration0=2)
+    c = oracle_render(oracle, sd, vd, 4, threads=1)
+    # film sums: (s0 + s1) + (s2 + s3) vs ((s0 + s1) + s2) + s3 differ only by float association
+    np.testing.assert_allclose(a + b, c, rtol=1e-6, atol=1e-7)
+
+
+def test_row_ranges_partition_the_frame(engine, oracle):
+    scenes.cornell(engine, 40, 30, 2)
+    sd, vd = engine.compile()
+    full = oracle_render(oracle, sd, vd, 2)
+    parts = oracle_render(oracle, sd, vd, 2, y_range=(0, 11)) + oracle_render(oracle, sd, vd, 2, y_range=(11, 30))
+    assert np.array_equal(full, parts)
+
+
+def test_empty_scene_and_zero_iterations(engine, oracle):
+    """Edge cases: a camera looking at nothing gives a black film with exact weights; zero iterations leave it untouched."""
+    cam = engine.camera(16, 8)
+    engine.samples_per_pixel(1)
+    engine.integrators(json.dumps({"surface": {"PTMIS": {}}}))
+    engine.sensor("{}")
+    sd, vd = engine.compile()
+    assert sd.solid.num_nodes == 0 and sd.num_lights == 0
+    film = oracle_render(oracle, sd, vd, 3)
+    assert np.all(film[..., :3] == 0) and np.all(film[..., 3] == 3)
+    assert np.all(oracle_render(oracle, sd, vd, 0) == 0)
