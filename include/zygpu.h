@@ -301,6 +301,10 @@ int zygpu_set_external_film(ZygpuContext* ctx, void* device_rgbw);
  * alpha 1; writes min(num_pixels, film pixels) * 4 floats to host memory. */
 int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
 
+/* Tuning switches.  "inline_shadows" (default 1): any-hit shadow rays are traced inside wf_shade; 0 routes them
+ * through the shadow queue and wf_trace (one extra tick per light pick).  Both give identical results. */
+int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
+
 /* Counters accumulated since the last reset (only maintained when enabled). */
 int zygpu_enable_stats(ZygpuContext* ctx, int enabled);
 int zygpu_get_stats(ZygpuContext* ctx, ZygpuStats* out_stats);

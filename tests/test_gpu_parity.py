@@ -17,10 +17,11 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-3
 
 
-def _render_both(engine, oracle, w, h, spp, stats=True, **kw):
+def _render_both(engine, oracle, w, h, spp, stats=True, inline_shadows=1, **kw):
     scenes.cornell(engine, w, h, spp, **kw)
     engine.start_frame(0)
     ctx = engine.context()
+    assert engine.lib.zygpu_set_option(ctx, b"inline_shadows", inline_shadows) == 0
     if stats:
         engine.lib.zygpu_enable_stats(ctx, 1)
         engine.lib.zygpu_reset_stats(ctx)
@@ -54,9 +55,11 @@ def _check(gpu_film, gpu_img, gpu_stats, cpu_film, cpu_img, cpu_stats, spp):
             assert g == c, f"{name}: gpu {g} vs oracle {c}"
 
 
+@pytest.mark.parametrize("inline_shadows", [1, 0])
 @pytest.mark.parametrize("integrator", ["PT", "PTDL", "PTMIS"])
-def test_cornell_lambert_integrators(engine, oracle, integrator):
-    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator)
+def test_cornell_lambert_integrators(engine, oracle, integrator, inline_shadows):
+    """Both shadow-ray routings (traced inside wf_shade / through the shadow queue + wf_trace) match the oracle."""
+    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator, inline_shadows=inline_shadows)
     _check(*out, 4)
 
 
@@ -119,4 +122,10 @@ def test_mesh_heightfield(engine, oracle):
     """A 2 x 63^2 triangle heightfield in the box: BLAS traversal + interpolated normals against the oracle."""
     mesh = scenes.heightfield_mesh(n=64)
     out = _render_both(engine, oracle, 80, 60, 2, boxes=False, mesh=mesh)
+    _check(*out, 2)
+
+
+def test_mesh_heightfield_queued_shadows(engine, oracle):
+    mesh = scenes.heightfield_mesh(n=48)
+    out = _render_both(engine, oracle, 64, 48, 2, boxes=False, mesh=mesh, inline_shadows=0)
     _check(*out, 2)

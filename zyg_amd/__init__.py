@@ -149,6 +149,7 @@ def load_library(path=None):
     lib.zygpu_set_external_film.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.zygpu_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     lib.zygpu_enable_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.zygpu_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
     lib.zygpu_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
     lib.zygpu_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]

@@ -394,8 +394,9 @@ ZD void finalize(const Params& P, uint32_t slot, const PathState& st) {  // Sens
     P.stage_color[slot] = make_float4(summed.x, summed.y, summed.z, alpha);
 }
 
-template <bool STATS>
-ZD void shadeSlot(const Params& P, uint32_t slot, bool from_shadow, Counters& cnt, bool& push_ext, bool& push_sh) {
+template <bool STATS, bool INLINE_SH>
+ZD void shadeSlot(const Params& P, uint32_t slot, bool from_shadow, Counters& cnt, unsigned long long& shadow_rays, bool& push_ext,
+                  bool& push_sh) {
     const DScene&  s = P.scene;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -499,60 +500,82 @@ ZD void shadeSlot(const Params& P, uint32_t slot, bool from_shadow, Counters& cn
     const bool do_nee = ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate;
     if (do_nee) {
         const float nee_threshold = splitThreshold(st.depth_surface);  // MIS: vertex.light_split_threshold; DL: the same value
-        if (!from_shadow) {
-            st.select = st.smp.sample1D();
-            st.pick = 0;
-            st.nee = S3(0.f);
-        } else {
-            const float4 ns = P.pool.nee[slot];
-            st.nee = mk3(ns.x, ns.y, ns.z);
-            if (P.pool.visible[slot]) {
-                (void)st.smp.sample1D();  // light.zig:127 rs.stochastic_r, drawn only for unoccluded samples
-                const float4 c = P.pool.contrib[slot];
-                st.nee = st.nee + mk3(c.x, c.y, c.z);
-            }
-            st.pick += 1;
-        }
-
-        LightPick       picks[kMaxLightPicks];
         const LightTree lt{s};
-        const uint32_t  num_picks = lt.randomLight(frag.p, ms.geo_n, ms.translucent, st.select, nee_threshold,
-                                                   [&](uint32_t i, LightPick pk) { picks[i] = pk; });
-        while (st.pick < num_picks) {
-            const LightPick      pick = picks[st.pick];
+        // one light pick: Light.sampleTo -> shadow ray -> pre-weighted contribution (pathtracer_mis.zig:214-278)
+        auto prepare = [&](const LightPick& pick, f3& sorigin, f3& sdir, float& slen, f3& contribution) -> bool {
             const ZygpuLight     light = s.lights[pick.offset];
             const Trafo          trafo = loadTrafo(s, light.prop);
             const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
             SampleTo             ls;
-            if (rectangleSampleTo(frag.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, st.smp, ls)) {
-                f3    sdir;
-                float slen;
-                const f3 sorigin = frag.offsetP(ls.wi);
-                shadowRay(sorigin, ls, sdir, slen);
-                const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
-                const BxdfResult bx = ms.evaluate(s, ls.wi);
-                f3               contribution;
-                if (mis) {
-                    const float light_pdf = ls.pdf * pick.pdf;
-                    const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
-                    contribution = S3(weight) * radiance * bx.reflection;
-                } else {
-                    const float weight = 1.f / (pick.pdf * ls.pdf);
-                    contribution = S3(weight) * (S3(1.f) * radiance * bx.reflection);
-                }
-                P.pool.sh_o[slot] = make_float4(sorigin.x, sorigin.y, sorigin.z, slen);
-                P.pool.sh_d[slot] = make_float4(sdir.x, sdir.y, sdir.z, 0.f);
-                P.pool.contrib[slot] = make_float4(contribution.x, contribution.y, contribution.z, 0.f);
-                P.pool.nee[slot] = make_float4(st.nee.x, st.nee.y, st.nee.z, 0.f);
-                P.pool.thr[slot] = make_float4(st.throughput.x, st.throughput.y, st.throughput.z, st.select);
-                P.pool.emission[slot] = make_float4(st.emission.x, st.emission.y, st.emission.z, 0.f);
-                P.pool.direct[slot] = make_float4(st.direct.x, st.direct.y, st.direct.z, 0.f);
-                P.pool.indirect[slot] = make_float4(st.indirect.x, st.indirect.y, st.indirect.z, 0.f);
-                storeSampler(P, slot, st, PH_SHADOW);
-                push_sh = true;
-                return;
+            if (!rectangleSampleTo(frag.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, st.smp, ls)) return false;
+            sorigin = frag.offsetP(ls.wi);
+            shadowRay(sorigin, ls, sdir, slen);
+            const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
+            const BxdfResult bx = ms.evaluate(s, ls.wi);
+            if (mis) {
+                const float light_pdf = ls.pdf * pick.pdf;
+                const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
+                contribution = S3(weight) * radiance * bx.reflection;
+            } else {
+                const float weight = 1.f / (pick.pdf * ls.pdf);
+                contribution = S3(weight) * (S3(1.f) * radiance * bx.reflection);
             }
-            st.pick += 1;
+            return true;
+        };
+
+        if (INLINE_SH) {
+            // shadow rays traced in place: the sampler draw that follows a successful test (light.zig:127) makes the
+            // light picks of one vertex strictly sequential anyway, so nothing is lost by not queueing them
+            st.select = st.smp.sample1D();
+            st.nee = S3(0.f);
+            lt.randomLight(frag.p, ms.geo_n, ms.translucent, st.select, nee_threshold, [&](uint32_t, LightPick pick) {
+                f3    sorigin, sdir, contribution;
+                float slen;
+                if (!prepare(pick, sorigin, sdir, slen, contribution)) return;
+                Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
+                if (STATS) shadow_rays += 1;
+                if (sceneVisibility<STATS>(s, shadow, cnt)) {
+                    (void)st.smp.sample1D();
+                    st.nee = st.nee + contribution;
+                }
+            });
+        } else {
+            if (!from_shadow) {
+                st.select = st.smp.sample1D();
+                st.pick = 0;
+                st.nee = S3(0.f);
+            } else {
+                const float4 ns = P.pool.nee[slot];
+                st.nee = mk3(ns.x, ns.y, ns.z);
+                if (P.pool.visible[slot]) {
+                    (void)st.smp.sample1D();  // light.zig:127 rs.stochastic_r, drawn only for unoccluded samples
+                    const float4 c = P.pool.contrib[slot];
+                    st.nee = st.nee + mk3(c.x, c.y, c.z);
+                }
+                st.pick += 1;
+            }
+
+            LightPick      picks[kMaxLightPicks];
+            const uint32_t num_picks = lt.randomLight(frag.p, ms.geo_n, ms.translucent, st.select, nee_threshold,
+                                                      [&](uint32_t i, LightPick pk) { picks[i] = pk; });
+            while (st.pick < num_picks) {
+                f3    sorigin, sdir, contribution;
+                float slen;
+                if (prepare(picks[st.pick], sorigin, sdir, slen, contribution)) {
+                    P.pool.sh_o[slot] = make_float4(sorigin.x, sorigin.y, sorigin.z, slen);
+                    P.pool.sh_d[slot] = make_float4(sdir.x, sdir.y, sdir.z, 0.f);
+                    P.pool.contrib[slot] = make_float4(contribution.x, contribution.y, contribution.z, 0.f);
+                    P.pool.nee[slot] = make_float4(st.nee.x, st.nee.y, st.nee.z, 0.f);
+                    P.pool.thr[slot] = make_float4(st.throughput.x, st.throughput.y, st.throughput.z, st.select);
+                    P.pool.emission[slot] = make_float4(st.emission.x, st.emission.y, st.emission.z, 0.f);
+                    P.pool.direct[slot] = make_float4(st.direct.x, st.direct.y, st.direct.z, 0.f);
+                    P.pool.indirect[slot] = make_float4(st.indirect.x, st.indirect.y, st.indirect.z, 0.f);
+                    storeSampler(P, slot, st, PH_SHADOW);
+                    push_sh = true;
+                    return;
+                }
+                st.pick += 1;
+            }
         }
         ivalueAdd(st, st.throughput * st.nee, total_depth, 1u, false, false);
     }
@@ -599,29 +622,31 @@ ZD void shadeSlot(const Params& P, uint32_t slot, bool from_shadow, Counters& cn
     push_ext = true;
 }
 
-template <bool STATS>
+template <bool STATS, bool INLINE_SH>
 __global__ void __launch_bounds__(256) wf_shade(Params P) {
     const uint32_t cur = P.parity, nxt = cur ^ 1u;
     const uint32_t n_ext = P.ctl->ext_count[cur], n_sh = P.ctl->sh_count[cur];
     const uint32_t total = n_ext + n_sh;
-    Counters       cnt{0, 0, 0};
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounded = (total + 63u) & ~63u;  // whole waves stay converged for the ballot in queuePush
+    Counters           cnt{0, 0, 0};
+    unsigned long long shadow_rays = 0;
+    const uint32_t     stride = gridDim.x * blockDim.x;
+    const uint32_t     rounded = (total + 63u) & ~63u;  // whole waves stay converged for the ballot in queuePush
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
         bool     push_ext = false, push_sh = false;
         uint32_t slot = 0;
         if (i < total) {
             const bool from_shadow = i >= n_ext;
             slot = from_shadow ? P.q.sh[cur][i - n_ext] : P.q.ext[cur][i];
-            shadeSlot<STATS>(P, slot, from_shadow, cnt, push_ext, push_sh);
+            shadeSlot<STATS, INLINE_SH>(P, slot, from_shadow, cnt, shadow_rays, push_ext, push_sh);
         }
         queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], push_ext, slot);
-        queuePush(P.q.sh[nxt], &P.ctl->sh_count[nxt], push_sh, slot);
+        if (!INLINE_SH) queuePush(P.q.sh[nxt], &P.ctl->sh_count[nxt], push_sh, slot);
     }
     if (STATS) {
         atomicAdd(&P.ctl->stat_nodes, cnt.nodes);
         atomicAdd(&P.ctl->stat_tris, cnt.tris);
         atomicAdd(&P.ctl->stat_instances, cnt.instances);
+        atomicAdd(&P.ctl->stat_shadow, shadow_rays);
     }
 }
 
@@ -825,6 +850,7 @@ struct ZygpuContext {
     size_t        pool_capacity = 0;      // paths
     size_t        film_pixels = 0;
     bool          stats = false;
+    bool          inline_shadows = true;  // shadow rays traced inside wf_shade (default) or through the shadow queue
     uint32_t      max_light_picks = 1;
     int           num_cus = 256;
     // kernel timing
@@ -1105,7 +1131,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     P.film = c->film_active;
     P.parity = 0;
 
-    const uint32_t picks = ZYGPU_INTEGRATOR_PT == v.integrator ? 0u : c->max_light_picks;
+    const uint32_t picks = (ZYGPU_INTEGRATOR_PT == v.integrator || c->inline_shadows) ? 0u : c->max_light_picks;
     const uint32_t ticks = (v.max_depth_surface + 1) * (1 + picks);
     const dim3     block(256);
     const dim3     grid_persistent(uint32_t(c->num_cus) * 8u);
@@ -1138,8 +1164,13 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             if (te) (void)hipEventRecord(te->second, c->stream);
             auto* se = c->timing ? nextEvents(c->shade_events, c->shade_used) : nullptr;
             if (se) (void)hipEventRecord(se->first, c->stream);
-            if (c->stats) hipLaunchKernelGGL(wf_shade<true>, grid_persistent, block, 0, c->stream, P);
-            else hipLaunchKernelGGL(wf_shade<false>, grid_persistent, block, 0, c->stream, P);
+            if (c->inline_shadows) {
+                if (c->stats) hipLaunchKernelGGL((wf_shade<true, true>), grid_persistent, block, 0, c->stream, P);
+                else hipLaunchKernelGGL((wf_shade<false, true>), grid_persistent, block, 0, c->stream, P);
+            } else {
+                if (c->stats) hipLaunchKernelGGL((wf_shade<true, false>), grid_persistent, block, 0, c->stream, P);
+                else hipLaunchKernelGGL((wf_shade<false, false>), grid_persistent, block, 0, c->stream, P);
+            }
             if (se) (void)hipEventRecord(se->second, c->stream);
             P.parity ^= 1u;
         }
@@ -1231,6 +1262,16 @@ int zygpu_test_eval(ZygpuContext* c, uint32_t op, uint32_t n, const float* in, u
     (void)hipFree(din);
     (void)hipFree(dout);
     return 0;
+}
+
+int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
+    if (!c || !name) return -1;
+    if (0 == std::strcmp(name, "inline_shadows")) {
+        c->inline_shadows = 0 != value;
+        return 0;
+    }
+    g_error = std::string("unknown option ") + name;
+    return -1;
 }
 
 int zygpu_enable_stats(ZygpuContext* c, int enabled) {
