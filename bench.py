@@ -88,20 +88,32 @@ def main():
     st = eng.stats()
     lib.zygpu_enable_stats(ctx, 0)
     samples_stat = max(st.camera_samples, 1)
-    b_trav = 32 * st.nodes_fetched + 48 * st.triangles_tested + 104 * st.instances_tested
     bytes_sample_total = st.algorithmic_bytes(0) / samples_stat
-    # split of the §8(d) queue terms between the two kernels (DESIGN.md "Algorithmic bytes"):
-    #   wf_trace: ray read 32 + hit write 16 per extension ray, ray read 32 + flag 16 per shadow ray, + all B_trav
-    #   wf_shade: the rest of the 224 / 96 (ray write, hit read, path state read+write) + B_film
-    bytes_sample_trace = (48 * st.extension_rays + 48 * st.shadow_rays + b_trav) / samples_stat
-    bytes_sample_shade = bytes_sample_total - bytes_sample_trace
+    # split of the §8(d) terms over the three wavefront kernels (DESIGN.md "Algorithmic bytes"); B_trav is counted per
+    # kernel (zygpu_get_kernel_stats): wf_intersect walks for extension rays, wf_shade for the unoccluding lights,
+    # wf_scatter for shadow rays.
+    #   per extension ray, 224 = ray read 32 + hit write 16 (wf_intersect) + hit read 16 + state read 64 (wf_shade)
+    #                            + state write 64 + ray write 32 (wf_scatter)
+    #   per shadow ray,     96 = ray write 32 + ray read 32 + visibility 16 + 16, all inside wf_scatter (never leaves the CU)
+    #   B_film 32 per camera sample: staged by wf_shade's finalize, gathered by film_accumulate (not a wavefront kernel)
+    ks = (zyg_amd.Stats * 3)()
+    assert lib.zygpu_get_kernel_stats(ctx, ks) == 0
+
+    def trav(x):
+        return 32 * x.nodes_fetched + 48 * x.triangles_tested + 104 * x.instances_tested
+
+    kernel_bytes_sample = {
+        "wf_intersect": (48 * st.extension_rays + trav(ks[0])) / samples_stat,
+        "wf_shade": (80 * st.extension_rays + trav(ks[1])) / samples_stat,
+        "wf_scatter": (96 * st.extension_rays + 96 * st.shadow_rays + trav(ks[2])) / samples_stat,
+    }
 
     for i in range(wu):
         render(i * ips, ips)
     assert lib.zygpu_synchronize(ctx) == 0
     film.zero_()
-    dtmp = ctypes.c_double * 2
-    ltmp = ctypes.c_uint64 * 2
+    dtmp = ctypes.c_double * 3
+    ltmp = ctypes.c_uint64 * 3
     lib.zygpu_kernel_time(ctx, dtmp(), ltmp(), 1)
 
     if dist:
@@ -131,7 +143,8 @@ def main():
         samples_total = float(w) * h * ips * k * n
         samples_rank = float(w) * h * ips * k
         value = samples_total / elapsed / 1e6
-        kernels = [("wf_trace", ms[0], launches[0], bytes_sample_trace), ("wf_shade", ms[1], launches[1], bytes_sample_shade)]
+        names = ("wf_intersect", "wf_shade", "wf_scatter")
+        kernels = [(nm, ms[i], launches[i], kernel_bytes_sample[nm]) for i, nm in enumerate(names)]
         dom = max(kernels, key=lambda t: t[1])
         avg_ms = dom[1] / max(dom[2], 1)
         bytes_per_launch = dom[3] * samples_rank / max(dom[2], 1)
@@ -158,7 +171,8 @@ def main():
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(dom[2]),
                          "algorithmic_bytes_per_sample": round(bytes_sample_total, 1),
                          "kernel_bytes_per_sample": round(dom[3], 1),
-                         "kernel_ms": {"wf_trace": round(ms[0], 3), "wf_shade": round(ms[1], 3)}},
+                         "kernel_ms": {nm: round(ms[i], 3) for i, nm in enumerate(names)},
+                         "kernel_bytes": {nm: round(v, 1) for nm, v in kernel_bytes_sample.items()}},
             "film_weight_min_max": [float(weights.min().item()), float(weights.max().item())],
         }
         if n == 1 and not args.no_cpu_baseline:

@@ -301,18 +301,21 @@ int zygpu_set_external_film(ZygpuContext* ctx, void* device_rgbw);
  * alpha 1; writes min(num_pixels, film pixels) * 4 floats to host memory. */
 int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
 
-/* Tuning switches.  "inline_shadows" (default 1): any-hit shadow rays are traced inside wf_shade; 0 routes them
- * through the shadow queue and wf_trace (one extra tick per light pick).  Both give identical results. */
+/* Switches: "kernel_timing" (default 1) records a HIP event pair around every wavefront launch. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Counters accumulated since the last reset (only maintained when enabled). */
 int zygpu_enable_stats(ZygpuContext* ctx, int enabled);
 int zygpu_get_stats(ZygpuContext* ctx, ZygpuStats* out_stats);
+/* The same counters split by kernel, ZYGPU_NUM_KERNELS entries: wf_intersect (extension rays), wf_shade
+ * (unoccluding-light walk), wf_scatter (shadow rays). */
+int zygpu_get_kernel_stats(ZygpuContext* ctx, ZygpuStats* out_stats3);
 int zygpu_reset_stats(ZygpuContext* ctx);
 
 /* Sums of the durations (ms, HIP events on the context's stream, one pair per launch) and launch counts of the
- * two wavefront kernels since the last reset: index 0 = `wf_trace` (closest-hit + any-hit traversal),
- * index 1 = `wf_shade` (integrator state machine).  Both out arrays hold 2 entries. */
+ * wavefront kernels since the last reset; both out arrays hold ZYGPU_NUM_KERNELS entries:
+ * 0 wf_intersect, 1 wf_shade, 2 wf_scatter. */
+#define ZYGPU_NUM_KERNELS 3
 int zygpu_kernel_time(ZygpuContext* ctx, double* out_ms, uint64_t* out_launches, int reset);
 
 /* Unit-test hook: evaluates small device functions (op: 0 sin/cos/acos, 1 SphQuad, 2 Sobol stream, 3 PCG,

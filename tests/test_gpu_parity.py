@@ -17,11 +17,10 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-3
 
 
-def _render_both(engine, oracle, w, h, spp, stats=True, inline_shadows=1, **kw):
+def _render_both(engine, oracle, w, h, spp, stats=True, **kw):
     scenes.cornell(engine, w, h, spp, **kw)
     engine.start_frame(0)
     ctx = engine.context()
-    assert engine.lib.zygpu_set_option(ctx, b"inline_shadows", inline_shadows) == 0
     if stats:
         engine.lib.zygpu_enable_stats(ctx, 1)
         engine.lib.zygpu_reset_stats(ctx)
@@ -55,11 +54,9 @@ def _check(gpu_film, gpu_img, gpu_stats, cpu_film, cpu_img, cpu_stats, spp):
             assert g == c, f"{name}: gpu {g} vs oracle {c}"
 
 
-@pytest.mark.parametrize("inline_shadows", [1, 0])
 @pytest.mark.parametrize("integrator", ["PT", "PTDL", "PTMIS"])
-def test_cornell_lambert_integrators(engine, oracle, integrator, inline_shadows):
-    """Both shadow-ray routings (traced inside wf_shade / through the shadow queue + wf_trace) match the oracle."""
-    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator, inline_shadows=inline_shadows)
+def test_cornell_lambert_integrators(engine, oracle, integrator):
+    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator)
     _check(*out, 4)
 
 
@@ -125,7 +122,12 @@ def test_mesh_heightfield(engine, oracle):
     _check(*out, 2)
 
 
-def test_mesh_heightfield_queued_shadows(engine, oracle):
-    mesh = scenes.heightfield_mesh(n=48)
-    out = _render_both(engine, oracle, 64, 48, 2, boxes=False, mesh=mesh, inline_shadows=0)
-    _check(*out, 2)
+def test_kernel_stats_add_up(engine, oracle):
+    """The per-kernel counters (wf_intersect / wf_shade / wf_connect) sum to the totals the oracle counts."""
+    out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS")
+    total = out[2]
+    ks = (zyg_amd.Stats * 3)()
+    assert engine.lib.zygpu_get_kernel_stats(engine.context(), ks) == 0
+    for name in ("extension_rays", "shadow_rays", "nodes_fetched", "triangles_tested", "instances_tested"):
+        assert sum(getattr(k, name) for k in ks) == getattr(total, name), name
+    assert ks[0].extension_rays == total.extension_rays and ks[2].shadow_rays == total.shadow_rays

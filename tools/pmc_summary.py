@@ -1,5 +1,5 @@
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + '/*/*counter_collection.csv')
+f = glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*counter_collection.csv')
 rows = list(csv.DictReader(open(f[0])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in rows:

@@ -129,7 +129,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("ZYG_AMD_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build the HIP library first (python -m zyg_amd.build); "
                            "there is no CPU fallback for the render path")
@@ -151,6 +151,7 @@ def load_library(path=None):
     lib.zygpu_enable_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.zygpu_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
     lib.zygpu_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+    lib.zygpu_get_kernel_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
     lib.zygpu_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     lib.zygpu_upload_scene.argtypes = [ctypes.c_void_p, ctypes.POINTER(SceneDesc)]

@@ -1,0 +1,618 @@
+// The wavefront stages (gfx950, wave64).  One batch = B iterations x every sample pixel of the row range, one path
+// per (pixel, iteration), path slot == sample index.  Per tick (= one path vertex) the stages run over device-side
+// queues of slot indices:
+//   wf_intersect : closest hit of the extension rays            Scene.intersect   (reference prop_tree.zig:56-116)
+//   wf_shade     : emission at the hit + unoccluding lights, MIS weight, termination, Russian roulette, closure set-up;
+//                  writes the compacted hit record               connectLight + Vertex.sample (pathtracer_mis.zig:45-92, 280-341)
+//   wf_scatter   : light-tree pick, Rectangle sampling, shadow rays (any-hit, traced in place), NEE accumulation,
+//                  then the bxdf sample, path state update and the next extension ray
+//                                                                sampleLights / evaluateLight (pathtracer_mis.zig:174-278), 123-166
+// Shadow rays are traced inside wf_scatter rather than queued: the reference draws a sampler dimension *after* each
+// successful shadow test (light/light.zig:127), so the light picks of one vertex are strictly sequential anyway.
+// Every launch is one thread per queue entry (no grid-stride loop: hoisted loop invariants cost ~60 VGPRs here); the
+// queue lengths live on the device, so a launch covers the upper bound and surplus waves retire at once.
+#pragma once
+
+#include "dmaterial.hpp"
+
+namespace zd {
+
+// meta word: [0:2] sobol dimension, [3:7] depth_surface, [8:12] vertex.depth, [13:18] state flags (vertex.zig:19-28)
+enum : uint32_t {
+    ST_PRIMARY = 1u << 0,
+    ST_TRANSPARENT = 1u << 1,
+    ST_SINGULAR = 1u << 2,
+    ST_SPECULAR = 1u << 3,
+    ST_TRANSLUCENT = 1u << 4,
+    ST_STARTED_SPECULAR = 1u << 5
+};
+
+struct Pool {  // SoA of 16 B records, indexed by path slot
+    uint4*    q0;       // sobol run_seed, meta, sobol buffer[4] bits, -
+    float4*   q1;       // sobol buffer[0..3]
+    uint2*    pcg;      // PCG state
+    float4*   ray_o;    // extension ray origin.xyz, max_t
+    float4*   ray_d;    // extension ray direction.xyz, vertex.bxdf_pdf
+    float4*   thr;      // throughput.xyz
+    float4*   vorigin;  // vertex.origin
+    float4*   vgeo_n;   // vertex.geo_n
+    float4*   emission; // IValue (helper.zig:6-19)
+    float4*   direct;
+    float4*   indirect;
+    uint4*    hit;      // t, u, v (bits), primitive
+    uint32_t* hit_prop;
+    float4*   rec_p;    // compacted hit record: p.xyz, material index (bits)
+    float4*   rec_gn;   //   geometric normal after the two-sided flip (vertex.zig:155-161), w = 1 if flipped
+    float4*   rec_n;    //   shading normal (flipped likewise)
+    float4*   rec_t;    //   tangent
+    float4*   rec_b;    //   bitangent
+};
+
+struct Queues {
+    uint32_t* ext[2];  // extension rays, ping-pong per tick
+    uint32_t* alive;   // paths that survived wf_shade in this tick
+};
+
+struct KernelCounters {
+    unsigned long long nodes, tris, instances, rays;
+};
+
+struct Control {  // device-resident
+    uint32_t       ext_count[2];
+    uint32_t       alive_count;
+    uint32_t       error;
+    KernelCounters k[3];  // 0 wf_intersect, 1 wf_shade, 2 wf_scatter
+};
+
+struct View {
+    ZygpuViewDesc v;
+    int32_t       y_begin, y_end;  // sample rows incl. filter padding
+    int32_t       x_begin, x_end;  // sample columns incl. filter padding
+    uint32_t      frame, iteration0, batch_iterations;
+    uint32_t      npix;  // samples per iteration in this batch
+};
+
+struct Params {
+    DScene   scene;
+    Pool     pool;
+    Queues   q;
+    Control* ctl;
+    float4*  stage_color;  // per sample: clamped composed colour, alpha
+    float2*  stage_uv;     // per sample: pixel_uv
+    float4*  film;
+    uint32_t parity;  // current extension-queue side
+};
+
+__constant__ View c_view;
+
+// occupancy targets (waves per SIMD) the register allocator is held to, per kernel; see DESIGN.md "Occupancy"
+#ifndef ZYG_SHADE_WAVES
+#define ZYG_SHADE_WAVES 2
+#endif
+#ifndef ZYG_SCATTER_WAVES
+#define ZYG_SCATTER_WAVES 3
+#endif
+#define ZYG_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+// ---------------------------------------------------------------- helpers
+
+// ordered append of the active lanes' values to a queue: one atomic per wave
+ZD void queuePush(uint32_t* queue, uint32_t* count, bool active, uint32_t value) {
+    const unsigned long long mask = __ballot(active);
+    if (0 == mask) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = uint32_t(__ffsll((long long)mask) - 1);
+    uint32_t       base = 0;
+    if (lane == leader) base = atomicAdd(count, uint32_t(__popcll(mask)));
+    base = __shfl(base, int(leader));
+    if (active) queue[base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)))] = value;
+}
+
+ZD void slotPixel(uint32_t slot, int& x, int& y, uint32_t& iteration) {
+    const uint32_t it = slot / c_view.npix, pix = slot - it * c_view.npix;
+    const uint32_t w = uint32_t(c_view.x_end - c_view.x_begin);
+    y = c_view.y_begin + int(pix / w);
+    x = c_view.x_begin + int(pix % w);
+    iteration = c_view.iteration0 + it;
+}
+
+ZD uint32_t pixelId(int x, int y) {  // worker.zig:127-128,136,141
+    const int fr = c_view.v.filter_radius_int;
+    const int r0 = c_view.v.resolution[0] + 2 * fr;
+    return uint32_t((y + fr) * r0) + uint32_t(x + fr);
+}
+
+ZD uint64_t pcgSequence(uint32_t pixel_id, uint32_t iteration) {  // worker.zig:129-130,143
+    const int      fr = c_view.v.filter_radius_int;
+    const uint32_t a = uint32_t(c_view.v.resolution[0] + 2 * fr) * uint32_t(c_view.v.resolution[1] + 2 * fr);
+    return uint64_t(pixel_id) + uint64_t(iteration) * a;
+}
+
+ZD float splitThreshold(uint32_t total_depth) {  // integrator/helper.zig:33-39
+    const float t = c_view.v.split_threshold;
+    return mn(total_depth < 4 ? t : kLowThreshold, t);
+}
+ZD float powerHeuristic(float f_pdf, float g_pdf) {  // helper.zig:64-67
+    const float f2 = f_pdf * f_pdf;
+    return f2 / __fmaf_rn(g_pdf, g_pdf, f2);
+}
+ZD float predividedPowerHeuristic(float f_pdf, float g_pdf) {  // helper.zig:70-73
+    const float f2 = f_pdf * f_pdf;
+    return f_pdf / __fmaf_rn(g_pdf, g_pdf, f2);
+}
+
+struct PathHead {  // sampler + packed flags of one path
+    Sampler  smp;
+    uint32_t depth_surface, vdepth, flags;
+};
+
+ZD void loadHead(const Params& P, uint32_t slot, PathHead& h) {
+    int      px, py;
+    uint32_t iteration;
+    slotPixel(slot, px, py, iteration);
+    const uint32_t pixel_id = pixelId(px, py);
+    const uint4    a = P.pool.q0[slot];
+    const float4   b = P.pool.q1[slot];
+    const uint2    g = P.pool.pcg[slot];
+    const uint32_t meta = a.y;
+    h.smp.run_seed = a.x;
+    h.smp.buffer[0] = b.x;
+    h.smp.buffer[1] = b.y;
+    h.smp.buffer[2] = b.z;
+    h.smp.buffer[3] = b.w;
+    h.smp.buffer[4] = __uint_as_float(a.z);
+    h.smp.dimension = meta & 7u;
+    const uint64_t sample_index = uint64_t(pixel_id) * uint64_t(c_view.v.num_expected_samples) + uint64_t(iteration);
+    h.smp.sample = uint32_t(sample_index);
+    h.smp.rng.state = uint64_t(g.x) | (uint64_t(g.y) << 32);
+    h.smp.rng.inc = (pcgSequence(pixel_id, iteration) << 1) | 1ull;
+    h.smp.sobol_kind = ZYGPU_SAMPLER_SOBOL == c_view.v.sampler;
+    h.depth_surface = (meta >> 3) & 31u;
+    h.vdepth = (meta >> 8) & 31u;
+    h.flags = (meta >> 13) & 63u;
+    h.smp.use_primary = h.depth_surface < 3;  // worker.zig:201-207
+}
+
+ZD void storeHead(const Params& P, uint32_t slot, const PathHead& h) {
+    const uint32_t meta = (h.smp.dimension & 7u) | ((h.depth_surface & 31u) << 3) | ((h.vdepth & 31u) << 8) | ((h.flags & 63u) << 13);
+    P.pool.q0[slot] = make_uint4(h.smp.run_seed, meta, __float_as_uint(h.smp.buffer[4]), 0u);
+    P.pool.q1[slot] = make_float4(h.smp.buffer[0], h.smp.buffer[1], h.smp.buffer[2], h.smp.buffer[3]);
+    P.pool.pcg[slot] = make_uint2(uint32_t(h.smp.rng.state), uint32_t(h.smp.rng.state >> 32));
+}
+
+ZD f3 xyz4(float4 v) { return {v.x, v.y, v.z}; }
+ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
+
+// IValue.add (helper.zig:11-19) as a read-modify-write of the one accumulator it touches.  Adding an exact zero vector
+// is skipped: the accumulators start at +0 and only ever receive non-negative terms, so x + 0 == x bit for bit.
+ZD void ivalueAdd(const Params& P, uint32_t slot, f3 value, uint32_t depth, uint32_t direct_cutoff, bool is_emission, bool singular) {
+    if (0.f == value.x && 0.f == value.y && 0.f == value.z) return;
+    float4* target = is_emission ? P.pool.emission : (singular || depth < direct_cutoff) ? P.pool.direct : P.pool.indirect;
+    const float4 old = target[slot];
+    target[slot] = f4(xyz4(old) + value);
+}
+
+ZD f3 clampColor(f3 color, float max) {  // sensor.zig:615-624
+    const float mc = hmax3(color);
+    if (mc > max) return S3(max / mc) * color;
+    return color;
+}
+
+// end of a path: Sensor.addSample's colour part (sensor.zig:177-181) into the staging buffer
+ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags) {
+    const f3    e = clampColor(xyz4(P.pool.emission[slot]), c_view.v.clamp_emission);
+    const f3    d = clampColor(xyz4(P.pool.direct[slot]), c_view.v.clamp_direct);
+    const f3    i = clampColor(xyz4(P.pool.indirect[slot]), c_view.v.clamp_indirect);
+    const f3    summed = e + d + i;
+    const float alpha = (flags & ST_TRANSPARENT) ? mx(1.f - average3(throughput), 0.f) : 1.f;
+    P.stage_color[slot] = f4(summed, alpha);
+}
+
+ZD void flushCounters(const Params& P, int k, const Counters& cnt, unsigned long long rays) {
+    atomicAdd(&P.ctl->k[k].nodes, cnt.nodes);
+    atomicAdd(&P.ctl->k[k].tris, cnt.tris);
+    atomicAdd(&P.ctl->k[k].instances, cnt.instances);
+    if (rays) atomicAdd(&P.ctl->k[k].rays, rays);
+}
+
+// ---------------------------------------------------------------- wf_generate
+// Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
+// Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
+__global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= num_paths) return;
+
+    int      x, y;
+    uint32_t iteration;
+    slotPixel(slot, x, y, iteration);
+    const uint32_t pixel_id = pixelId(x, y);
+
+    PathHead h;
+    h.smp.sobol_kind = ZYGPU_SAMPLER_SOBOL == c_view.v.sampler;
+    h.smp.use_primary = true;
+    h.smp.rng.start(0, pcgSequence(pixel_id, iteration));
+
+    const uint32_t nexp = c_view.v.num_expected_samples;
+    const uint64_t sample_index = uint64_t(pixel_id) * uint64_t(nexp) + uint64_t(iteration);
+    const uint32_t seed = uint32_t(sample_index >> 32) + iteration / nexp;
+    h.smp.buffer[0] = h.smp.buffer[1] = h.smp.buffer[2] = h.smp.buffer[3] = h.smp.buffer[4] = 0.f;
+    h.smp.startPixel(uint32_t(sample_index), seed);
+
+    float s0, s1, s2, s3;
+    h.smp.sample4D(s0, s1, s2, s3);
+    (void)h.smp.sample1D();  // shutter time: static scenes only use it to select keyframes (space.zig:99-108)
+    h.smp.incrementPadding();
+
+    const float          cx = float(x) + s0, cy = float(y) + s1;
+    const ZygpuViewDesc& v = c_view.v;
+    f3 direction = mk3(v.left_top[0], v.left_top[1], v.left_top[2]) + mk3(v.d_x[0], v.d_x[1], v.d_x[2]) * S3(cx) +
+                   mk3(v.d_y[0], v.d_y[1], v.d_y[2]) * S3(cy);
+    f3 origin;
+    if (v.lens_radius > 0.f) {
+        float lx, ly;
+        diskConcentric(s2, s3, lx, ly);
+        origin = mk3(lx * v.lens_radius, ly * v.lens_radius, 0.f);
+        const f3 focus = S3(v.focus_distance / direction.z) * direction;
+        direction = focus - origin;
+    } else {
+        origin = mk3(v.eye_offset[0], v.eye_offset[1], v.eye_offset[2]);
+    }
+    Trafo ct;
+    ct.r0 = mk3(v.camera_trafo.r[0][0], v.camera_trafo.r[0][1], v.camera_trafo.r[0][2]);
+    ct.r1 = mk3(v.camera_trafo.r[1][0], v.camera_trafo.r[1][1], v.camera_trafo.r[1][2]);
+    ct.r2 = mk3(v.camera_trafo.r[2][0], v.camera_trafo.r[2][1], v.camera_trafo.r[2][2]);
+    ct.scale = mk3(v.camera_trafo.r[0][3], v.camera_trafo.r[1][3], v.camera_trafo.r[2][3]);
+    ct.position = mk3(v.camera_trafo.position[0], v.camera_trafo.position[1], v.camera_trafo.position[2]);
+    const f3 origin_w = ct.objectToWorldPoint(origin);
+    const f3 direction_w = ct.objectToWorldVector(normalize3(direction));
+
+    h.depth_surface = 0;
+    h.vdepth = 0;
+    h.flags = ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR;
+    storeHead(P, slot, h);
+    P.pool.ray_o[slot] = f4(origin_w, kRayMaxT);
+    P.pool.ray_d[slot] = f4(direction_w, 0.f);
+    P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+    P.pool.vorigin[slot] = f4(origin_w);
+    P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    P.pool.emission[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    P.pool.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    P.pool.indirect[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    P.stage_uv[slot] = make_float2(s0, s1);
+    P.q.ext[P.parity][slot] = slot;
+    if (0 == slot) P.ctl->ext_count[P.parity] = num_paths;
+}
+
+// ---------------------------------------------------------------- wf_intersect
+template <bool STATS>
+__global__ void __launch_bounds__(256) wf_intersect(Params P) {
+    const uint32_t cur = P.parity;
+    const uint32_t n = P.ctl->ext_count[cur];
+    if (0 == blockIdx.x && 0 == threadIdx.x) {  // this tick's wf_shade / wf_scatter fill these
+        P.ctl->ext_count[cur ^ 1u] = 0;
+        P.ctl->alive_count = 0;
+    }
+    Counters       cnt{0, 0, 0};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t slot = P.q.ext[cur][i];
+        const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+        const uint32_t depth = (P.pool.q0[slot].y >> 3) & 31u;
+        Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+        Hit            hit;
+        sceneIntersect<STATS>(P.scene, ray, depth, hit, cnt);
+        if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+        P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+        P.pool.hit_prop[slot] = hit.prop;
+    }
+    if (STATS) flushCounters(P, 0, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
+}
+
+// ---------------------------------------------------------------- wf_shade
+
+ZD float shapeArea(const DScene& s, uint32_t prop, uint32_t part, const Trafo& trafo) {  // shape.zig:132-152
+    const ZygpuProp p = s.props[prop];
+    if (ZYGPU_SHAPE_RECTANGLE == p.shape) return trafo.scale.x * trafo.scale.y;
+    return s.meshes[p.mesh].part_areas[part] * (trafo.scale.x * trafo.scale.y);
+}
+
+// Material.evaluateRadiance for Light / Substitute (material.zig:196-212, light_material.zig:131-140)
+ZD f3 materialRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, const Trafo& trafo, uint32_t prop, uint32_t part,
+                       bool in_camera) {
+    if (ZYGPU_MAT_LIGHT != m.kind && ZYGPU_MAT_SUBSTITUTE != m.kind) return S3(0.f);
+    const float area = m.emission_normalize ? shapeArea(s, prop, part, trafo) : 1.f;
+    return emittanceRadiance(m, wi, trafo.r2, area, in_camera);
+}
+
+struct VertexIn {  // what connectLight needs of the previous vertex (vertex.zig:45-65)
+    f3       vorigin, vgeo_n;
+    float    bxdf_pdf, light_split_threshold;
+    uint32_t flags, depth_surface;
+};
+
+// Scene.lightPdf (scene.zig:624-634)
+ZD float lightPdf(const DScene& s, const VertexIn& v, const Fragment& frag) {
+    const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
+    if ((v.flags & ST_SINGULAR) || kNull == light_id) return 1.f;
+    const LightTree lt{s};
+    const float     select_pdf = lt.pdf(v.vorigin, v.vgeo_n, 0 != (v.flags & ST_TRANSLUCENT), v.light_split_threshold, light_id);
+    const float     sample_pdf = rectanglePdf(v.vorigin, frag.trafo);
+    return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
+}
+
+// Vertex.evaluateRadiance (vertex.zig:183-212)
+ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment& frag, Sampler& smp) {
+    const ZygpuMaterial& m = s.materials[s.material_ids[s.props[frag.prop].parts_start + frag.part]];
+    if (!(m.flags & ZYGPU_MATF_EMISSIVE) || (!(m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo))) return S3(0.f);
+    (void)smp.sample1D();  // rs.stochastic_r
+    const f3    energy = materialRadiance(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface);
+    const float weight = lightPdf(s, v, frag);
+    return S3(weight) * energy;
+}
+
+// PropBvh.emission over the unoccluding TLAS (prop_tree.zig:302-356, prop.zig:239-264, rectangle.zig:188-196)
+template <bool STATS>
+ZD f3 unoccludingEmission(const DScene& s, const VertexIn& v, const Ray& ray_in, Sampler& smp, Counters& cnt) {
+    f3  energy = S3(0.f);
+    Ray ray = ray_in;
+    const f3 wo = -ray.direction;
+    bvhWalk<STATS>(s.unocc_nodes, s.num_unocc_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            const uint32_t  p = s.unocc_indices[i];
+            const ZygpuProp prop = s.props[p];
+            if (!propVisibleAtDepth(prop.flags, v.depth_surface)) continue;
+            if (STATS) cnt.instances += 1;
+            if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
+            if (ZYGPU_SHAPE_RECTANGLE != prop.shape) continue;
+            Fragment frag;
+            frag.trafo = loadTrafo(s, p);
+            frag.prop = p;
+            float t, u, vv;
+            if (!rectangleIntersect(ray, frag.trafo, t, u, vv)) continue;
+            frag.t_hit = t;
+            frag.u = u;
+            frag.v = vv;
+            frag.primitive = 0;
+            rectangleFragment(ray, frag);
+            energy = energy + evaluateRadiance(s, v, wo, frag, smp);
+        }
+        return false;
+    });
+    return energy;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Params P) {
+    const DScene&  s = P.scene;
+    const uint32_t cur = P.parity;
+    const uint32_t total = P.ctl->ext_count[cur];
+    const uint32_t kind = c_view.v.integrator;
+    const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
+    Counters       cnt{0, 0, 0};
+    const uint32_t rounded = (total + 63u) & ~63u;  // whole waves stay converged for the ballot in queuePush
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rounded) {
+        bool     alive = false;
+        uint32_t slot = 0;
+        if (i < total) {
+            slot = P.q.ext[cur][i];
+            PathHead h;
+            loadHead(P, slot, h);
+
+            const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
+            const uint4    hr = P.pool.hit[slot];
+            const uint32_t hit_prop = P.pool.hit_prop[slot];
+            const Hit      hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, hit_prop};
+            const bool     has_hit = kNull != hit_prop;
+            // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
+            const Ray ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, has_hit ? hit.t : ro.w);
+            const f3  wo = -ray.direction;
+
+            Fragment frag;
+            if (has_hit) makeFragment(s, ray, hit, frag);
+
+            // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
+            f3 energy = S3(0.f);
+            if (!(!c_view.v.caustics_path && (h.flags & ST_SPECULAR) && !(h.flags & ST_PRIMARY))) {
+                VertexIn v;
+                v.vorigin = xyz4(P.pool.vorigin[slot]);
+                v.vgeo_n = xyz4(P.pool.vgeo_n[slot]);
+                v.bxdf_pdf = rd.w;
+                v.flags = h.flags;
+                v.depth_surface = h.depth_surface;
+                v.light_split_threshold = 0.f;
+                if (ZYGPU_INTEGRATOR_PT == kind) {
+                    v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
+                    if (has_hit) energy = evaluateRadiance(s, v, wo, frag, h.smp);
+                    energy = energy + unoccludingEmission<STATS>(s, v, ray, h.smp, cnt);
+                } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
+                    if (has_hit) {
+                        const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
+                        if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance(s, v, wo, frag, h.smp);
+                    }
+                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<STATS>(s, v, ray, h.smp, cnt);
+                } else {
+                    v.light_split_threshold = splitThreshold(h.vdepth);
+                    if (has_hit) energy = evaluateRadiance(s, v, wo, frag, h.smp);
+                    energy = energy + unoccludingEmission<STATS>(s, v, ray, h.smp, cnt);
+                }
+            }
+            f3 throughput = xyz4(P.pool.thr[slot]);
+            ivalueAdd(P, slot, throughput * energy, h.depth_surface, mis ? 2u : 1u, 0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
+
+            bool done = false;
+            if (!has_hit || h.depth_surface >= c_view.v.max_depth_surface || 0 >= c_view.v.max_depth_volume) {
+                if (mis && (h.flags & ST_TRANSPARENT)) throughput = throughput * (S3(1.f) - min3v(energy, S3(1.f)));
+                done = true;
+            } else {
+                // russianRoulette (helper.zig:75-89); the draw happens whether or not it is needed
+                const float r = h.smp.sample1D();
+                const float continuation_probability = hmax3(throughput) / 0.1f;
+                if (continuation_probability < 1.f) {
+                    if (r >= continuation_probability) done = true;
+                    else throughput = throughput / S3(continuation_probability);
+                }
+            }
+
+            if (!done) {
+                // ---- Vertex.sample (vertex.zig:137-181): two-sided flip + the stochastic_r draw; the closure itself is
+                // rebuilt from the record by wf_scatter
+                const uint32_t       mat_id = s.material_ids[s.props[frag.prop].parts_start + frag.part];
+                const ZygpuMaterial& m = s.materials[mat_id];
+                f3                   geo_n = frag.geo_n, n = frag.n;
+                const bool           flipped = (m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo);
+                if (flipped) {
+                    geo_n = -geo_n;
+                    n = -n;
+                }
+                (void)h.smp.sample1D();  // rs.stochastic_r
+                if (ZYGPU_MAT_LIGHT == m.kind) {
+                    // a pure emitter neither evaluates nor scatters (light_sample.zig:9-11, material_sample.zig:55-59):
+                    // no NEE draw, no bxdf sample, throughput = 0 (pathtracer_mis.zig:127-129)
+                    throughput = S3(0.f);
+                    done = true;
+                } else {
+                    P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
+                    P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
+                    P.pool.rec_n[slot] = f4(n);
+                    P.pool.rec_t[slot] = f4(frag.t);
+                    P.pool.rec_b[slot] = f4(frag.b);
+                    P.pool.thr[slot] = f4(throughput);
+                    storeHead(P, slot, h);
+                    alive = true;
+                }
+            }
+            if (done) finalize(P, slot, throughput, h.flags);
+        }
+        queuePush(P.q.alive, &P.ctl->alive_count, alive, slot);
+    }
+    if (STATS) flushCounters(P, 1, cnt, 0);
+}
+
+// ---------------------------------------------------------------- closure from the hit record
+
+struct Surface {
+    f3             p;
+    f3             frag_geo_n;  // the fragment's own geometric normal (before the two-sided flip), for Fragment.offsetP
+    MaterialSample ms;
+};
+
+ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
+    const float4 rp = P.pool.rec_p[slot];
+    const float4 rg = P.pool.rec_gn[slot];
+    const f3     geo_n = xyz4(rg), n = xyz4(P.pool.rec_n[slot]);
+    const f3     t = xyz4(P.pool.rec_t[slot]), b = xyz4(P.pool.rec_b[slot]);
+    const f3     wo = -xyz4(P.pool.ray_d[slot]);
+    const ZygpuMaterial& m = P.scene.materials[__float_as_uint(rp.w)];
+    const bool   caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
+    Surface      sf;
+    sf.p = xyz4(rp);
+    sf.frag_geo_n = 0.f != rg.w ? -geo_n : geo_n;
+    sf.ms = makeMaterialSample(P.scene, m, wo, geo_n, t, b, n, caustics);
+    return sf;
+}
+
+// Fragment.offsetP (intersection.zig:115-119; uvw[3], the offset, is 0 for rectangles and meshes)
+ZD f3 surfaceOffsetP(f3 p, f3 geo_n, f3 v) {
+    const f3 nn = dot3(geo_n, v) > 0.f ? geo_n : -geo_n;
+    return offsetRay(fma3(S3(0.f), nn, p), nn);
+}
+
+// ---------------------------------------------------------------- wf_scatter
+// sampleLights (next-event estimation) followed by the bxdf sample and the path extension, for every path wf_shade
+// kept alive.  One kernel: both halves need the same closure, and the sampler stream runs straight through them.
+template <bool STATS>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(Params P) {
+    const DScene&      s = P.scene;
+    const uint32_t     nxt = P.parity ^ 1u;
+    const uint32_t     total = P.ctl->alive_count;
+    const uint32_t     kind = c_view.v.integrator;
+    const bool         mis = ZYGPU_INTEGRATOR_PTMIS == kind;
+    Counters           cnt{0, 0, 0};
+    unsigned long long shadow_rays = 0;
+    const uint32_t     rounded = (total + 63u) & ~63u;  // whole waves stay converged for the ballot in queuePush
+    const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rounded) return;
+    bool     push = false;
+    uint32_t slot = 0;
+    if (i < total) {
+        slot = P.q.alive[i];
+        PathHead h;
+        loadHead(P, slot, h);
+        const Surface         sf = loadSurface(P, slot, h.flags);
+        const MaterialSample& ms = sf.ms;
+        f3                    throughput = xyz4(P.pool.thr[slot]);
+
+        // ---- sampleLights / evaluateLight (pathtracer_mis.zig:174-278, pathtracer_dl.zig:100-167)
+        if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
+            const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
+            const float     select = h.smp.sample1D();
+            const LightTree lt{s};
+            f3              nee = S3(0.f);
+            lt.randomLight(sf.p, ms.geo_n, ms.translucent, select, nee_threshold, [&](uint32_t, LightPick pick) {
+                const ZygpuLight     light = s.lights[pick.offset];
+                const Trafo          trafo = loadTrafo(s, light.prop);
+                const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
+                SampleTo             ls;
+                if (!rectangleSampleTo(sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, h.smp, ls)) return;
+                const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
+                f3       sdir;
+                float    slen;
+                shadowRay(sorigin, ls, sdir, slen);
+                Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
+                if (STATS) shadow_rays += 1;
+                if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
+                const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
+                const BxdfResult bx = ms.evaluate(s, ls.wi);
+                (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
+                if (mis) {
+                    const float light_pdf = ls.pdf * pick.pdf;
+                    const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
+                    nee = nee + S3(weight) * radiance * bx.reflection;
+                } else {
+                    const float weight = 1.f / (pick.pdf * ls.pdf);
+                    nee = nee + S3(weight) * (S3(1.f) * radiance * bx.reflection);
+                }
+            });
+            ivalueAdd(P, slot, throughput * nee, h.depth_surface, 1u, false, false);
+        }
+
+        // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
+        BxdfSample bs;
+        if (!ms.sample(s, h.smp, bs)) {
+            finalize(P, slot, S3(0.f), h.flags);
+        } else {
+            // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
+            if (kScatterSpecular == bs.scattering) {
+                h.flags |= ST_SPECULAR;
+                h.flags = (0.f == bs.reg_alpha) ? (h.flags | ST_SINGULAR) : (h.flags & ~uint32_t(ST_SINGULAR));
+                if (h.flags & ST_PRIMARY) h.flags |= ST_STARTED_SPECULAR;
+            } else {
+                h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
+            }
+            float bxdf_pdf = P.pool.ray_d[slot].w;
+            if (mis) {
+                h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
+                h.vdepth = h.depth_surface;
+                bxdf_pdf = bs.pdf;
+                P.pool.vgeo_n[slot] = f4(ms.geo_n);
+            }
+            throughput = throughput * (bs.reflection / S3(bs.pdf));
+            const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
+            h.depth_surface += 1;
+            h.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight): a reflection clears it
+            h.smp.incrementPadding();
+
+            P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
+            P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
+            P.pool.thr[slot] = f4(throughput);
+            P.pool.vorigin[slot] = f4(sf.p);
+            storeHead(P, slot, h);
+            push = true;
+        }
+    }
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], push, slot);
+    if (STATS) flushCounters(P, 2, cnt, shadow_rays);
+}
+
+}  // namespace zd
