@@ -54,3 +54,24 @@ golden = {
 }
 json.dump(golden, open(OUT, "w"), indent=1)
 print("wrote", OUT)
+
+# ---- GGX albedo tables: a sample of the entries the reference carries in material/ggx_integral.zig (data the
+# reference's own integrator printed, {d:.8}); zyg_amd/csrc/host/ggx_lut.hpp has to reproduce them.
+LUT_REF = "/root/reference/src/core/scene/material/ggx_integral.zig"
+LUT_OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ggx_lut_golden.json")
+lut_src = open(LUT_REF).read()
+
+
+def lut_table(name):
+    body = re.search(r"pub const " + name + r" = \[[^\]]*\]f32\{(.*?)\};", lut_src, re.S).group(1)
+    body = re.sub(r"//[^\n]*", "", body)
+    return [float(x) for x in body.replace("\n", " ").split(",") if x.strip()]
+
+
+lut_golden = {}
+for which, (name, stride) in enumerate([("E_m", 13), ("E_m_avg", 3), ("E", 41), ("E_avg", 7)]):
+    t = lut_table(name)
+    idx = sorted(set(list(range(0, len(t), stride)) + [len(t) - 1]))
+    lut_golden[name] = {"which": which, "length": len(t), "index": idx, "value": [t[i] for i in idx]}
+json.dump(lut_golden, open(LUT_OUT, "w"), indent=1)
+print("wrote", LUT_OUT)

@@ -131,3 +131,19 @@ def test_kernel_stats_add_up(engine, oracle):
     for name in ("extension_rays", "shadow_rays", "nodes_fetched", "triangles_tested", "instances_tested"):
         assert sum(getattr(k, name) for k in ks) == getattr(total, name), name
     assert ks[0].extension_rays == total.extension_rays and ks[2].shadow_rays == total.shadow_rays
+
+
+@pytest.mark.parametrize("integrator", ["PTDL", "PTMIS"])
+def test_cornell_substitute(engine, oracle, integrator):
+    """BASELINE.json configs[1]'s reference-material variant: Substitute{color, roughness 0.8, metallic 0} walls and
+    boxes (substitute_sample.zig base lobe + GGX with the compile-time albedo tables)."""
+    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator, material="substitute")
+    _check(*out, 4)
+
+
+def test_mesh_heightfield_substitute_rough_metal(engine, oracle):
+    """cfg3's shape: a heightfield mesh with one Substitute material (here glossy: roughness 0.3, metallic 1)."""
+    mesh = scenes.heightfield_mesh(n=48)
+    out = _render_both(engine, oracle, 72, 54, 3, boxes=False, mesh=mesh, material="substitute",
+                       mesh_material=scenes.substitute((0.9, 0.6, 0.3), roughness=0.3, metallic=1.0))
+    _check(*out, 3)

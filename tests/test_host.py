@@ -267,3 +267,20 @@ def test_render_without_gpu_fails_loudly(engine):
     scenes.cornell(engine, 16, 16, 1)
     with pytest.raises(RuntimeError, match="su_start_frame failed"):
         engine.start_frame(0)
+
+
+def test_ggx_albedo_tables_match_reference_entries(product_lib):
+    """The scene-compile-time LUT generator (ggx_lut.hpp) against a sample of the entries the reference ships in
+    material/ggx_integral.zig (tests/golden/ggx_lut_golden.json; 8 printed decimals, so 1e-6 absolute)."""
+    import json
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ggx_lut_golden.json")))
+    product_lib.su_ext_ggx_lut.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    product_lib.su_ext_ggx_lut.restype = ctypes.c_uint32
+    for name, g in golden.items():
+        n = g["length"]
+        table = np.zeros(n, dtype=np.float32)
+        assert product_lib.su_ext_ggx_lut(g["which"], table.ctypes.data, n) == n, name
+        got = table[np.array(g["index"])]
+        np.testing.assert_allclose(got, np.array(g["value"], dtype=np.float32), rtol=0, atol=1e-6, err_msg=name)
+        assert np.all((table >= 0.0) & (table <= 1.0)), name
+    assert product_lib.su_ext_ggx_lut(9, None, 0) == 0

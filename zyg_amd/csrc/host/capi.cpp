@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "engine.hpp"
+#include "ggx_lut.hpp"
 
 namespace {
 
@@ -337,5 +338,13 @@ int32_t su_ext_compile(uint32_t frame) {
 const ZygpuSceneDesc* su_ext_scene_desc(void) { return g ? &g->engine.sceneDesc() : nullptr; }
 const ZygpuViewDesc*  su_ext_view_desc(void) { return g ? &g->engine.viewDesc() : nullptr; }
 ZygpuContext*         su_ext_context(void) { return g ? g->ctx : nullptr; }
+
+uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity) {
+    const zyg::ggxlut::Tables& t = zyg::ggxlut::tables();
+    const std::vector<float>*  v = 0 == which ? &t.e_m : 1 == which ? &t.e_m_avg : 2 == which ? &t.e : 3 == which ? &t.e_avg : nullptr;
+    if (!v) return 0;
+    if (out) std::copy(v->begin(), v->begin() + std::min<size_t>(capacity, v->size()), out);
+    return uint32_t(v->size());
+}
 
 }  // extern "C"

@@ -1,5 +1,7 @@
 #include "engine.hpp"
 
+#include "ggx_lut.hpp"
+
 #include <algorithm>
 
 namespace zyg {
@@ -777,6 +779,15 @@ int Engine::compile(uint32_t frame) {
     d.unoccluding = ZygpuPropTree{unoccluding_nodes_.data(), unoccluding_indices_.data(),
                                   uint32_t(unoccluding_nodes_.size()), uint32_t(unoccluding_indices_.size())};
     d.light_tree = light_tree_.tree;
+    for (const ZygpuMaterial& m : materials_) {
+        if (ZYGPU_MAT_SUBSTITUTE != m.kind) continue;
+        const ggxlut::Tables& t = ggxlut::tables();  // computed once per process (ggx_lut.hpp)
+        d.luts.e_m = t.e_m.data();
+        d.luts.e_m_avg = t.e_m_avg.data();
+        d.luts.e = t.e.data();
+        d.luts.e_avg = t.e_avg.data();
+        break;
+    }
     d.specular_threshold = specular_threshold;
     d.num_props = np;
     d.num_parts = uint32_t(material_ids_.size());

@@ -206,6 +206,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         idx, pos, nrm, uv = mesh
         shape = engine.triangle_mesh(idx, pos, nrm, uv)
         mm = white if mesh_material is None else mesh_material
+        if isinstance(mm, str):  # a material JSON instead of an id
+            mm = engine.material(mm)
         p = engine.prop(shape, [mm])
         engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0.02, 0.1)))
         ids["meshes"].append(p)
