@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters-per-step", type=int, default=ITER_PER_STEP)
     ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_mesh"])
+    ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -68,7 +69,10 @@ def main():
     eng = zyg_amd.Engine()
     eng.set_device(local_rank)
     mesh = scenes.heightfield_mesh() if args.scene == "cornell_mesh" else None
-    scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material="lambert", boxes=mesh is None, mesh=mesh)
+    # cornell_mesh = BASELINE.json configs[2]: the 999 698-triangle heightfield with one grey Substitute material
+    mesh_material = scenes.substitute((0.5, 0.5, 0.5)) if mesh is not None else None
+    scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=args.material, boxes=mesh is None, mesh=mesh,
+                   mesh_material=mesh_material)
     eng.start_frame(0)
     lib, ctx = eng.lib, eng.context()
 
@@ -150,6 +154,8 @@ def main():
         bytes_per_launch = dom[3] * samples_rank / max(dom[2], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         weights = film[..., 3]
+        geometry = "2 boxes" if mesh is None else "999698-triangle heightfield mesh (Substitute)"
+        bsdf = "Lambertian" if args.material == "lambert" else "Substitute (roughness 0.8)"
         out = {
             "metric": "Msamples/sec (whole node) at 1080p/256spp; RMS vs CPU reference",
             "value": round(value, 3),
@@ -163,9 +169,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"Cornell box (5 Rectangle walls, 2 boxes, 2 unoccluding Rectangle lights) + Lambertian BSDF, "
-                                   f"{w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
-                                   f"{k * ips} spp per GPU", "scene": args.scene, "parallelism": f"iterations x{n}"},
+            "config": {"workload": f"Cornell box (5 Rectangle walls, {geometry}, 2 unoccluding Rectangle lights) + "
+                                   f"{bsdf} BSDF, {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
+                                   f"{k * ips} spp per GPU", "scene": args.scene, "material": args.material,
+                       "parallelism": f"iterations x{n}"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(dom[2]),

@@ -204,6 +204,8 @@ struct MaterialSample {
         return {S3(n_dot_wi) * (d.reflection + S3(specular) * (gg.reflection + mms)), pdf};
     }
 
+    // SUBST = false compiles the Substitute branch out (kernels specialised for scenes without that material)
+    template <bool SUBST = true>
     ZD BxdfResult evaluate(const DScene& s, f3 wi) const {  // material_sample.zig:47-53
         if (ZYGPU_MAT_LIGHT == kind) return {S3(0.f), 0.f};
         if (ZYGPU_MAT_DEBUG == kind) {
@@ -211,12 +213,14 @@ struct MaterialSample {
             const float pdf = n_dot_wi * kPiInv;
             return {S3(pdf) * albedo, pdf};
         }
+        if (!SUBST) return {S3(0.f), 0.f};
         if (!sameHemisphere(wo)) return {S3(0.f), 0.f};
         const f3    h = normalize3(wo + wi);
         const float wo_dot_h = clampDot(wo, h);
         return baseEvaluate(Luts{s}, wi, h, wo_dot_h, false);
     }
 
+    template <bool SUBST = true>
     ZD bool sample(const DScene& s, Sampler& sampler, BxdfSample& result) const {  // material_sample.zig:55-70
         if (ZYGPU_MAT_LIGHT == kind) return false;
         if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:28-47
@@ -233,6 +237,7 @@ struct MaterialSample {
             result.scattering = kScatterDiffuse;
             return true;
         }
+        if (!SUBST) return false;
         // Substitute.sample, opaque / uncoated (substitute_sample.zig:147-234, 281-302, 338-410)
         if (!sameHemisphere(wo)) return false;
         const Luts L{s};

@@ -73,7 +73,6 @@ struct View {
 };
 
 struct Params {
-    DScene   scene;
     Pool     pool;
     Queues   q;
     Control* ctl;
@@ -83,7 +82,8 @@ struct Params {
     uint32_t parity;  // current extension-queue side
 };
 
-__constant__ View c_view;
+__constant__ View   c_view;
+__constant__ DScene c_scene;  // the compiled scene's device arrays: read on demand through the scalar cache
 
 // occupancy targets (waves per SIMD) the register allocator is held to, per kernel; see DESIGN.md "Occupancy"
 #ifndef ZYG_SHADE_WAVES
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
         const uint32_t depth = (P.pool.q0[slot].y >> 3) & 31u;
         Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
         Hit            hit;
-        sceneIntersect<STATS>(P.scene, ray, depth, hit, cnt);
+        sceneIntersect<STATS>(c_scene, ray, depth, hit, cnt);
         if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
         P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
         P.pool.hit_prop[slot] = hit.prop;
@@ -383,7 +383,7 @@ ZD f3 unoccludingEmission(const DScene& s, const VertexIn& v, const Ray& ray_in,
 
 template <bool STATS>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Params P) {
-    const DScene&  s = P.scene;
+    const DScene&  s = c_scene;
     const uint32_t cur = P.parity;
     const uint32_t total = P.ctl->ext_count[cur];
     const uint32_t kind = c_view.v.integrator;
@@ -503,12 +503,12 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     const f3     geo_n = xyz4(rg), n = xyz4(P.pool.rec_n[slot]);
     const f3     t = xyz4(P.pool.rec_t[slot]), b = xyz4(P.pool.rec_b[slot]);
     const f3     wo = -xyz4(P.pool.ray_d[slot]);
-    const ZygpuMaterial& m = P.scene.materials[__float_as_uint(rp.w)];
+    const ZygpuMaterial& m = c_scene.materials[__float_as_uint(rp.w)];
     const bool   caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
     Surface      sf;
     sf.p = xyz4(rp);
     sf.frag_geo_n = 0.f != rg.w ? -geo_n : geo_n;
-    sf.ms = makeMaterialSample(P.scene, m, wo, geo_n, t, b, n, caustics);
+    sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics);
     return sf;
 }
 
@@ -521,9 +521,10 @@ ZD f3 surfaceOffsetP(f3 p, f3 geo_n, f3 v) {
 // ---------------------------------------------------------------- wf_scatter
 // sampleLights (next-event estimation) followed by the bxdf sample and the path extension, for every path wf_shade
 // kept alive.  One kernel: both halves need the same closure, and the sampler stream runs straight through them.
-template <bool STATS>
+// SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
+template <bool STATS, bool SUBST>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(Params P) {
-    const DScene&      s = P.scene;
+    const DScene&      s = c_scene;
     const uint32_t     nxt = P.parity ^ 1u;
     const uint32_t     total = P.ctl->alive_count;
     const uint32_t     kind = c_view.v.integrator;
@@ -563,7 +564,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
                 if (STATS) shadow_rays += 1;
                 if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
                 const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
-                const BxdfResult bx = ms.evaluate(s, ls.wi);
+                const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
                 (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                 if (mis) {
                     const float light_pdf = ls.pdf * pick.pdf;
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
 
         // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
         BxdfSample bs;
-        if (!ms.sample(s, h.smp, bs)) {
+        if (!ms.template sample<SUBST>(s, h.smp, bs)) {
             finalize(P, slot, S3(0.f), h.flags);
         } else {
             // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)

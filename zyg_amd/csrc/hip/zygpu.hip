@@ -217,6 +217,7 @@ struct ZygpuContext {
     size_t        pool_capacity = 0;      // paths
     size_t        film_pixels = 0;
     bool          stats = false;
+    bool          has_substitute = false;  // selects the wf_scatter instantiation
     uint64_t      camera_samples = 0;
     uint32_t      max_light_picks = 1;
     int           num_cus = 256;
@@ -383,7 +384,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     ok = ok && m.upload(d->luts.e_avg, d->luts.e_avg ? 16 * 16 : 0, &s.lut_e_avg);
     if (!ok) return -1;
 
+    c->has_substitute = false;
     for (uint32_t mi = 0; mi < d->num_materials; ++mi) {
+        if (ZYGPU_MAT_SUBSTITUTE == d->materials[mi].kind) c->has_substitute = true;
         if (ZYGPU_MAT_SUBSTITUTE == d->materials[mi].kind && !d->luts.e_m) {
             g_error = "Substitute materials need the albedo LUTs in ZygpuSceneDesc.luts";
             return -2;
@@ -424,6 +427,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     s.specular_threshold = d->specular_threshold;
     s.num_solid_nodes = d->solid.num_nodes;
     s.num_unocc_nodes = d->unoccluding.num_nodes;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_scene), &s, sizeof(DScene), 0, hipMemcpyHostToDevice));
     c->has_scene = true;
     return 0;
 }
@@ -494,7 +499,6 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     if (0 != ensurePool(c, npix * per_batch)) return -1;
 
     Params P;
-    P.scene = c->scene;
     P.pool = c->pool;
     P.q = c->queues;
     P.ctl = c->ctl;
@@ -537,8 +541,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 else hipLaunchKernelGGL(wf_shade<false>, grid, block, 0, c->stream, P);
             });
             timedLaunch(c, 2, [&] {
-                if (c->stats) hipLaunchKernelGGL(wf_scatter<true>, grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL(wf_scatter<false>, grid, block, 0, c->stream, P);
+                if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true>), grid, block, 0, c->stream, P);
+                else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true>), grid, block, 0, c->stream, P);
+                else hipLaunchKernelGGL((wf_scatter<false, false>), grid, block, 0, c->stream, P);
             });
             P.parity ^= 1u;
         }
