@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--iters-per-step", type=int, default=ITER_PER_STEP)
     ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_mesh"])
     ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
+    ap.add_argument("--nee", default="in-place", choices=["in-place", "staged"],
+                    help="zygpu option nee_in_place: wf_scatter (default) or the wf_nee / wf_shadow rounds + wf_extend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -75,6 +77,8 @@ def main():
                    mesh_material=mesh_material)
     eng.start_frame(0)
     lib, ctx = eng.lib, eng.context()
+    nee_in_place = args.nee == "in-place"
+    assert lib.zygpu_set_option(ctx, b"nee_in_place", 1 if nee_in_place else 0) == 0
 
     film = torch.zeros((h, w, 4), dtype=torch.float32, device=device)
     assert lib.zygpu_set_external_film(ctx, ctypes.c_void_p(film.data_ptr())) == 0
@@ -93,14 +97,15 @@ def main():
     lib.zygpu_enable_stats(ctx, 0)
     samples_stat = max(st.camera_samples, 1)
     bytes_sample_total = st.algorithmic_bytes(0) / samples_stat
-    # split of the §8(d) terms over the three wavefront kernels (DESIGN.md "Algorithmic bytes"); B_trav is counted per
-    # kernel (zygpu_get_kernel_stats): wf_intersect walks for extension rays, wf_shade for the unoccluding lights,
-    # wf_scatter for shadow rays.
+    # split of the §8(d) terms over the wavefront kernels (DESIGN.md "Algorithmic bytes"); B_trav is counted per kernel
+    # (zygpu_get_kernel_stats): wf_intersect walks for extension rays, wf_shade for the unoccluding lights, wf_shadow
+    # for shadow rays.
     #   per extension ray, 224 = ray read 32 + hit write 16 (wf_intersect) + hit read 16 + state read 64 (wf_shade)
-    #                            + state write 64 + ray write 32 (wf_scatter)
-    #   per shadow ray,     96 = ray write 32 + ray read 32 + visibility 16 + 16, all inside wf_scatter (never leaves the CU)
-    #   B_film 32 per camera sample: staged by wf_shade's finalize, gathered by film_accumulate (not a wavefront kernel)
-    ks = (zyg_amd.Stats * 3)()
+    #                            + state write 64 + ray write 32 (wf_extend)
+    #   per shadow ray,     96 = ray write 32 + contribution write 16 (wf_nee) + ray read 32 + visibility 16 (wf_shadow)
+    #   B_film 32 per camera sample: staged by finalize, gathered by film_accumulate (not a wavefront kernel)
+    names = ("wf_intersect", "wf_shade", "wf_nee", "wf_shadow", "wf_extend", "wf_scatter")
+    ks = (zyg_amd.Stats * len(names))()
     assert lib.zygpu_get_kernel_stats(ctx, ks) == 0
 
     def trav(x):
@@ -109,15 +114,20 @@ def main():
     kernel_bytes_sample = {
         "wf_intersect": (48 * st.extension_rays + trav(ks[0])) / samples_stat,
         "wf_shade": (80 * st.extension_rays + trav(ks[1])) / samples_stat,
-        "wf_scatter": (96 * st.extension_rays + 96 * st.shadow_rays + trav(ks[2])) / samples_stat,
+        "wf_nee": (48 * st.shadow_rays) / samples_stat,
+        "wf_shadow": (48 * st.shadow_rays + trav(ks[3])) / samples_stat,
+        "wf_extend": (96 * st.extension_rays) / samples_stat,
+        "wf_scatter": (96 * st.extension_rays + 96 * st.shadow_rays + trav(ks[5])) / samples_stat,
     }
+    if nee_in_place:
+        kernel_bytes_sample["wf_nee"] = kernel_bytes_sample["wf_shadow"] = kernel_bytes_sample["wf_extend"] = 0.0
 
     for i in range(wu):
         render(i * ips, ips)
     assert lib.zygpu_synchronize(ctx) == 0
     film.zero_()
-    dtmp = ctypes.c_double * 3
-    ltmp = ctypes.c_uint64 * 3
+    dtmp = ctypes.c_double * len(names)
+    ltmp = ctypes.c_uint64 * len(names)
     lib.zygpu_kernel_time(ctx, dtmp(), ltmp(), 1)
 
     if dist:
@@ -147,7 +157,6 @@ def main():
         samples_total = float(w) * h * ips * k * n
         samples_rank = float(w) * h * ips * k
         value = samples_total / elapsed / 1e6
-        names = ("wf_intersect", "wf_shade", "wf_scatter")
         kernels = [(nm, ms[i], launches[i], kernel_bytes_sample[nm]) for i, nm in enumerate(names)]
         dom = max(kernels, key=lambda t: t[1])
         avg_ms = dom[1] / max(dom[2], 1)

@@ -301,21 +301,28 @@ int zygpu_set_external_film(ZygpuContext* ctx, void* device_rgbw);
  * alpha 1; writes min(num_pixels, film pixels) * 4 floats to host memory. */
 int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
 
-/* Switches: "kernel_timing" (default 1) records a HIP event pair around every wavefront launch. */
+/* Switches: "kernel_timing" (default 1) records a HIP event pair around every wavefront launch;
+ * "nee_in_place" (default 1) runs next-event estimation, shadow rays and the bxdf sample of a vertex in one kernel
+ * (wf_scatter); 0 runs them as wf_nee / wf_shadow rounds + wf_extend: same results, different cost profile (in place
+ * is faster with the couple of light picks per vertex of BASELINE's scenes; the rounds keep every lane busy when a
+ * vertex picks many lights). */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Counters accumulated since the last reset (only maintained when enabled). */
 int zygpu_enable_stats(ZygpuContext* ctx, int enabled);
 int zygpu_get_stats(ZygpuContext* ctx, ZygpuStats* out_stats);
-/* The same counters split by kernel, ZYGPU_NUM_KERNELS entries: wf_intersect (extension rays), wf_shade
- * (unoccluding-light walk), wf_scatter (shadow rays). */
-int zygpu_get_kernel_stats(ZygpuContext* ctx, ZygpuStats* out_stats3);
+/* The same counters split by kernel, ZYGPU_NUM_KERNELS entries in the order below: traversal happens in wf_intersect
+ * (extension rays), wf_shade (unoccluding-light walk) and wf_shadow or wf_scatter (shadow rays); the rest stay zero. */
+int zygpu_get_kernel_stats(ZygpuContext* ctx, ZygpuStats* out_stats);
 int zygpu_reset_stats(ZygpuContext* ctx);
+/* Profiling builds only (-DZYG_PROFILE_SECTIONS, tools/sections.py): shader cycles per code section summed over waves,
+ * [0..15] wf_shade, [16..31] wf_scatter; all zero in the shipped build.  Cleared by zygpu_reset_stats. */
+int zygpu_get_section_cycles(ZygpuContext* ctx, uint64_t* out32);
 
 /* Sums of the durations (ms, HIP events on the context's stream, one pair per launch) and launch counts of the
  * wavefront kernels since the last reset; both out arrays hold ZYGPU_NUM_KERNELS entries:
- * 0 wf_intersect, 1 wf_shade, 2 wf_scatter. */
-#define ZYGPU_NUM_KERNELS 3
+ * 0 wf_intersect, 1 wf_shade, 2 wf_nee, 3 wf_shadow, 4 wf_extend, 5 wf_scatter (only with option "nee_in_place"). */
+#define ZYGPU_NUM_KERNELS 6
 int zygpu_kernel_time(ZygpuContext* ctx, double* out_ms, uint64_t* out_launches, int reset);
 
 /* Unit-test hook: evaluates small device functions (op: 0 sin/cos/acos, 1 SphQuad, 2 Sobol stream, 3 PCG,

@@ -17,10 +17,11 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-3
 
 
-def _render_both(engine, oracle, w, h, spp, stats=True, **kw):
+def _render_both(engine, oracle, w, h, spp, stats=True, nee_in_place=0, **kw):
     scenes.cornell(engine, w, h, spp, **kw)
     engine.start_frame(0)
     ctx = engine.context()
+    assert engine.lib.zygpu_set_option(ctx, b"nee_in_place", nee_in_place) == 0
     if stats:
         engine.lib.zygpu_enable_stats(ctx, 1)
         engine.lib.zygpu_reset_stats(ctx)
@@ -54,9 +55,11 @@ def _check(gpu_film, gpu_img, gpu_stats, cpu_film, cpu_img, cpu_stats, spp):
             assert g == c, f"{name}: gpu {g} vs oracle {c}"
 
 
+@pytest.mark.parametrize("nee_in_place", [0, 1])
 @pytest.mark.parametrize("integrator", ["PT", "PTDL", "PTMIS"])
-def test_cornell_lambert_integrators(engine, oracle, integrator):
-    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator)
+def test_cornell_lambert_integrators(engine, oracle, integrator, nee_in_place):
+    """Both NEE routings (wf_nee / wf_shadow rounds + wf_extend, and the single wf_scatter) match the oracle."""
+    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator, nee_in_place=nee_in_place)
     _check(*out, 4)
 
 
@@ -123,14 +126,15 @@ def test_mesh_heightfield(engine, oracle):
 
 
 def test_kernel_stats_add_up(engine, oracle):
-    """The per-kernel counters (wf_intersect / wf_shade / wf_connect) sum to the totals the oracle counts."""
+    """The per-kernel counters (wf_intersect / wf_shade / wf_shadow) sum to the totals the oracle counts."""
     out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS")
     total = out[2]
-    ks = (zyg_amd.Stats * 3)()
+    ks = (zyg_amd.Stats * 6)()  # ZYGPU_NUM_KERNELS: wf_intersect, wf_shade, wf_nee, wf_shadow, wf_extend, wf_scatter
     assert engine.lib.zygpu_get_kernel_stats(engine.context(), ks) == 0
     for name in ("extension_rays", "shadow_rays", "nodes_fetched", "triangles_tested", "instances_tested"):
         assert sum(getattr(k, name) for k in ks) == getattr(total, name), name
-    assert ks[0].extension_rays == total.extension_rays and ks[2].shadow_rays == total.shadow_rays
+    assert ks[0].extension_rays == total.extension_rays and ks[3].shadow_rays == total.shadow_rays
+    assert ks[2].nodes_fetched == 0 and ks[4].nodes_fetched == 0
 
 
 @pytest.mark.parametrize("integrator", ["PTDL", "PTMIS"])
@@ -138,6 +142,8 @@ def test_cornell_substitute(engine, oracle, integrator):
     """BASELINE.json configs[1]'s reference-material variant: Substitute{color, roughness 0.8, metallic 0} walls and
     boxes (substitute_sample.zig base lobe + GGX with the compile-time albedo tables)."""
     out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator, material="substitute")
+    _check(*out, 4)
+    out = _render_both(engine, oracle, 96, 64, 4, integrator=integrator, material="substitute", nee_in_place=1)
     _check(*out, 4)
 
 

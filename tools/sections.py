@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Section-cycle attribution of wf_shade / wf_scatter.  Needs a library built with -DZYG_PROFILE_SECTIONS
+(ZYG_AMD_LIB=variants/lib_prof.so python3 tools/sections.py); prints each section's share of the summed wave cycles."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zyg_amd
+from zyg_amd import scenes
+
+w, h, iters = 1920, 1080, 8
+material = sys.argv[1] if len(sys.argv) > 1 else "lambert"
+eng = zyg_amd.Engine()
+scenes.cornell(eng, w, h, iters, integrator="PTMIS", material=material)
+eng.start_frame(0)
+lib, ctx = eng.lib, eng.context()
+lib.zygpu_get_section_cycles.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+lib.zygpu_reset_stats(ctx)
+lib.zygpu_render(ctx, 0, 0, iters, 0, h)
+lib.zygpu_synchronize(ctx)
+out = (ctypes.c_uint64 * 32)()
+lib.zygpu_get_section_cycles(ctx, out)
+names = {0: "shade: state loads + fragment", 1: "shade: hit emission (evaluateRadiance)", 2: "shade: unoccluding lights walk",
+         3: "shade: IValue add, RR, record write", 4: "shade: finalize", 5: "shade: queue push",
+         16: "scatter: state + closure load", 17: "scatter: light tree, rest (pops, to next visit)",
+         18: "scatter: Rectangle sampleTo (SphQuad)",
+         19: "scatter: shadow visibility", 20: "scatter: radiance + bsdf evaluate + draw", 21: "scatter: bxdf sample",
+         22: "scatter: state update, stores, queue push", 23: "scatter: light-select draw",
+         24: "scatter: tree inner node load", 25: "scatter: tree nodeSplit", 26: "scatter: tree leaf node load / child weights",
+         27: "scatter: tree leaf pick (nodeRandomLight)"}
+for base, label in ((0, "wf_shade"), (16, "wf_scatter")):
+    tot = sum(out[base:base + 16]) or 1
+    print(f"{label}: {tot / 1e9:.2f} G wave-cycles")
+    for i in range(base, base + 16):
+        if out[i]:
+            print(f"  {100.0 * out[i] / tot:5.1f} %  {names.get(i, i)}")
+eng.release()

@@ -28,7 +28,10 @@ def hipcc():
 
 
 def build(verbose=True, extra=()):
+    # -disable-promote-alloca-to-vector: the per-lane traversal stacks stay in (sparsely touched) scratch instead of
+    # being turned into ~110 VGPRs with waterfall indexing, which is what keeps wf_scatter / wf_nee at 2 waves/SIMD
     cmd = [hipcc(), "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+           "-mllvm", "-disable-promote-alloca-to-vector",
            "-Wall", "-Wno-unused-function", "-x", "hip", *SOURCES, "-o", OUT, *extra]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -154,8 +154,8 @@ struct LightTree {
 
     // Tree.randomLight (light_tree.zig:346-447), finite lights only.  Calls visit(index, pick) for every pick in
     // the reference's order; returns the number of picks.
-    template <typename Visit>
-    ZD uint32_t randomLight(f3 p, f3 n, bool total_sphere, float random, float split_threshold, Visit&& visit) const {
+    template <typename Timer, typename Visit>
+    ZD uint32_t randomLight(Timer& tm, f3 p, f3 n, bool total_sphere, float random, float split_threshold, Visit&& visit) const {
         uint32_t   current_light = 0;
         float      ip = 0.f;
         const bool split = split_threshold > 0.f;
@@ -181,7 +181,9 @@ struct LightTree {
         while (0 != end) {
             const ZygpuLightNode node = s.lt_nodes[t_node];
             if (hasChildren(node)) {
+                tm.mark(8);
                 const bool     do_split = t_depth < max_split_depth && nodeSplit(node, p, split_threshold);
+                tm.mark(9);
                 const uint32_t c0 = childrenOrLight(node), c1 = c0 + 1;
                 if (do_split) {
                     t_depth += 1;
@@ -217,7 +219,9 @@ struct LightTree {
                     }
                 }
             } else {
+                tm.mark(10);
                 const LightPick pick = nodeRandomLight(node, p, n, total_sphere, t_random);
+                tm.mark(11);
                 if (pick.pdf > 0.f) {
                     visit(current_light, LightPick{pick.offset, pick.pdf * t_pdf});
                     current_light += 1;

@@ -4,11 +4,10 @@
 //   wf_intersect : closest hit of the extension rays            Scene.intersect   (reference prop_tree.zig:56-116)
 //   wf_shade     : emission at the hit + unoccluding lights, MIS weight, termination, Russian roulette, closure set-up;
 //                  writes the compacted hit record               connectLight + Vertex.sample (pathtracer_mis.zig:45-92, 280-341)
-//   wf_scatter   : light-tree pick, Rectangle sampling, shadow rays (any-hit, traced in place), NEE accumulation,
-//                  then the bxdf sample, path state update and the next extension ray
-//                                                                sampleLights / evaluateLight (pathtracer_mis.zig:174-278), 123-166
-// Shadow rays are traced inside wf_scatter rather than queued: the reference draws a sampler dimension *after* each
-// successful shadow test (light/light.zig:127), so the light picks of one vertex are strictly sequential anyway.
+//   wf_nee(r)    : round r of next-event estimation: light-tree picks (r = 0), Rectangle sampling, shadow ray + the
+//                  pre-weighted contribution into the pool           sampleLights / evaluateLight (pathtracer_mis.zig:174-278)
+//   wf_shadow    : any-hit test of the round's shadow rays       Scene.visibility  (prop_tree.zig:185-240)
+//   wf_extend    : last pick's tail, bxdf sample, path state update, next extension ray (pathtracer_mis.zig:123-166)
 // Every launch is one thread per queue entry (no grid-stride loop: hoisted loop invariants cost ~60 VGPRs here); the
 // queue lengths live on the device, so a launch covers the upper bound and surplus waves retire at once.
 #pragma once
@@ -28,7 +27,7 @@ enum : uint32_t {
 };
 
 struct Pool {  // SoA of 16 B records, indexed by path slot
-    uint4*    q0;       // sobol run_seed, meta, sobol buffer[4] bits, -
+    uint4*    q0;       // sobol run_seed, meta, sobol buffer[4] bits, NEE state
     float4*   q1;       // sobol buffer[0..3]
     uint2*    pcg;      // PCG state
     float4*   ray_o;    // extension ray origin.xyz, max_t
@@ -46,11 +45,31 @@ struct Pool {  // SoA of 16 B records, indexed by path slot
     float4*   rec_n;    //   shading normal (flipped likewise)
     float4*   rec_t;    //   tangent
     float4*   rec_b;    //   bitangent
+    uint2*    picks;    // light picks 1.. of the current vertex, [pick][slot]: light, pdf bits (pick 0 never leaves registers)
+    float4*   sh_o;     // shadow ray of the running pick: origin.xyz, max_t
+    float4*   sh_d;     //   direction.xyz
+    float4*   contrib;  //   its pre-weighted contribution weight * radiance * bsdf
+    float4*   nee;      // sum of the unoccluded contributions of this vertex
+    uint32_t* vis;      // wf_shadow's verdict on the running pick
 };
 
 struct Queues {
     uint32_t* ext[2];  // extension rays, ping-pong per tick
     uint32_t* alive;   // paths that survived wf_shade in this tick
+    uint32_t* shadow;  // paths with a shadow ray in flight (one NEE round)
+};
+
+// A queue is kSubQueues independent runs, each with its own length word in its own 64 B line; blocks append to run
+// blockIdx % kSubQueues.  Measured on configs[1]: one atomic per wave on a single word 248 Msamples/s, one per block
+// 303, one per block spread over 64 runs 278 (the consumers' prefix over the run lengths costs more than the remaining
+// contention), so the shipped value is 1; 64 is the other supported value (one run length per lane in queueOpen).
+#ifndef ZYG_SUB_QUEUES
+#define ZYG_SUB_QUEUES 1
+#endif
+constexpr uint32_t kSubQueues = ZYG_SUB_QUEUES, kCountStride = 16;
+static_assert(1 == kSubQueues || 64 == kSubQueues, "queueOpen handles 1 or 64 runs");
+struct QueueCounts {
+    uint32_t n[kSubQueues * kCountStride];
 };
 
 struct KernelCounters {
@@ -58,10 +77,14 @@ struct KernelCounters {
 };
 
 struct Control {  // device-resident
-    uint32_t       ext_count[2];
-    uint32_t       alive_count;
-    uint32_t       error;
-    KernelCounters k[3];  // 0 wf_intersect, 1 wf_shade, 2 wf_scatter
+    QueueCounts        ext_count[2];
+    QueueCounts        alive_count;
+    QueueCounts        shadow_count[2];  // ping-pong per NEE round
+    uint32_t           bound[2];  // [parity of the tick]: length of the tick's extension queue = upper bound of every later
+                                  // queue of that tick; surplus blocks leave on this one scalar load
+    uint32_t           error;
+    KernelCounters     k[3];  // 0 wf_intersect, 1 wf_shade, 2 wf_shadow
+    unsigned long long sections[32];  // -DZYG_PROFILE_SECTIONS builds: shader cycles per code section, summed over waves
 };
 
 struct View {
@@ -80,6 +103,7 @@ struct Params {
     float2*  stage_uv;     // per sample: pixel_uv
     float4*  film;
     uint32_t parity;  // current extension-queue side
+    uint32_t sub_capacity;  // entries each of a queue's kSubQueues runs can hold
 };
 
 __constant__ View   c_view;
@@ -90,22 +114,101 @@ __constant__ DScene c_scene;  // the compiled scene's device arrays: read on dem
 #define ZYG_SHADE_WAVES 2
 #endif
 #ifndef ZYG_SCATTER_WAVES
-#define ZYG_SCATTER_WAVES 3
+#define ZYG_SCATTER_WAVES 2
+#endif
+#ifndef ZYG_NEE_WAVES
+#define ZYG_NEE_WAVES 2
+#endif
+#ifndef ZYG_EXTEND_WAVES
+#define ZYG_EXTEND_WAVES 3
 #endif
 #define ZYG_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 // ---------------------------------------------------------------- helpers
 
-// ordered append of the active lanes' values to a queue: one atomic per wave
-ZD void queuePush(uint32_t* queue, uint32_t* count, bool active, uint32_t value) {
+// Section timer of the profiling build (tools/sections.sh): s_memtime deltas per wave, summed into Control::sections.
+#ifdef ZYG_PROFILE_SECTIONS
+struct SectionTimer {
+    unsigned long long last, acc[16];
+    ZD void start() {
+        for (int i = 0; i < 16; ++i) acc[i] = 0;
+        last = clock64();
+    }
+    ZD void mark(int id) {
+        const unsigned long long t = clock64();
+        acc[id] += t - last;
+        last = t;
+    }
+    ZD void flush(Control* ctl, int base) {
+        // every lane of a wave holds the same sums for the sections it passed; take the per-wave maximum
+        for (int i = 0; i < 16; ++i) {
+            unsigned long long v = acc[i];
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long w = __shfl_xor(v, o);
+                v = w > v ? w : v;
+            }
+            if (0 == __lane_id() && v) atomicAdd(&ctl->sections[base + i], v);
+        }
+    }
+};
+#else
+struct SectionTimer {
+    ZD void start() {}
+    ZD void mark(int) {}
+    ZD void flush(Control*, int) {}
+};
+#endif
+
+// Append of the active lanes' values to a queue: one atomic per 256-thread block (every wave of the block that has not
+// returned must call it; waves count their lanes by ballot, the block total is claimed by one atomicAdd on the run this
+// block appends to, each wave writes its part).  Queue order is free: all results are addressed by slot.
+ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t sub_capacity, bool active, uint32_t value) {
+    __shared__ uint32_t wave_count[4];
+    __shared__ uint32_t block_base;
     const unsigned long long mask = __ballot(active);
-    if (0 == mask) return;
-    const uint32_t lane = __lane_id();
-    const uint32_t leader = uint32_t(__ffsll((long long)mask) - 1);
-    uint32_t       base = 0;
-    if (lane == leader) base = atomicAdd(count, uint32_t(__popcll(mask)));
-    base = __shfl(base, int(leader));
+    const uint32_t           lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (0 == lane) wave_count[wave] = uint32_t(__popcll(mask));
+    __syncthreads();
+    if (0 == threadIdx.x) {
+        const uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        const uint32_t run = blockIdx.x % kSubQueues;
+        block_base = run * sub_capacity + (total ? atomicAdd(&counts->n[run * kCountStride], total) : 0u);
+    }
+    __syncthreads();
+    uint32_t base = block_base;
+    for (uint32_t w = 0; w < wave; ++w) base += wave_count[w];
     if (active) queue[base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)))] = value;
+    __syncthreads();  // wave_count / block_base are reused by the next call
+}
+
+// Consumer side, called by whole waves at kernel entry: the queue's total length and, for entry i of the
+// concatenated runs, its position in the queue array.
+ZD uint32_t queueOpen(const QueueCounts* counts, uint32_t sub_capacity, uint32_t i, uint32_t& position) {
+    if (1 == kSubQueues) {
+        position = i;
+        return counts->n[0];
+    }
+    const uint32_t lane = __lane_id();
+    const uint32_t mine = counts->n[lane * kCountStride];  // kSubQueues == 64 lanes
+    uint32_t       incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= uint32_t(o)) incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t       run = 0;  // number of runs that end at or before i
+    for (uint32_t step = 32; step > 0; step >>= 1) {
+        const uint32_t end = __shfl(incl, int(run + step - 1));
+        if (end <= i) run += step;
+    }
+    run = run < kSubQueues ? run : kSubQueues - 1;
+    const uint32_t begin = __shfl(incl, int(run)) - __shfl(mine, int(run));
+    position = run * sub_capacity + (i - begin);
+    return total;
+}
+
+ZD void queueReset(QueueCounts* counts) {  // by one wave
+    if (__lane_id() < kSubQueues) counts->n[__lane_id() * kCountStride] = 0;
 }
 
 ZD void slotPixel(uint32_t slot, int& x, int& y, uint32_t& iteration) {
@@ -144,6 +247,7 @@ ZD float predividedPowerHeuristic(float f_pdf, float g_pdf) {  // helper.zig:70-
 struct PathHead {  // sampler + packed flags of one path
     Sampler  smp;
     uint32_t depth_surface, vdepth, flags;
+    uint32_t nee;  // next-event-estimation state of the current vertex (kNee*)
 };
 
 ZD void loadHead(const Params& P, uint32_t slot, PathHead& h) {
@@ -170,12 +274,13 @@ ZD void loadHead(const Params& P, uint32_t slot, PathHead& h) {
     h.depth_surface = (meta >> 3) & 31u;
     h.vdepth = (meta >> 8) & 31u;
     h.flags = (meta >> 13) & 63u;
+    h.nee = a.w;
     h.smp.use_primary = h.depth_surface < 3;  // worker.zig:201-207
 }
 
 ZD void storeHead(const Params& P, uint32_t slot, const PathHead& h) {
     const uint32_t meta = (h.smp.dimension & 7u) | ((h.depth_surface & 31u) << 3) | ((h.vdepth & 31u) << 8) | ((h.flags & 63u) << 13);
-    P.pool.q0[slot] = make_uint4(h.smp.run_seed, meta, __float_as_uint(h.smp.buffer[4]), 0u);
+    P.pool.q0[slot] = make_uint4(h.smp.run_seed, meta, __float_as_uint(h.smp.buffer[4]), h.nee);
     P.pool.q1[slot] = make_float4(h.smp.buffer[0], h.smp.buffer[1], h.smp.buffer[2], h.smp.buffer[3]);
     P.pool.pcg[slot] = make_uint2(uint32_t(h.smp.rng.state), uint32_t(h.smp.rng.state >> 32));
 }
@@ -218,9 +323,7 @@ ZD void flushCounters(const Params& P, int k, const Counters& cnt, unsigned long
 // ---------------------------------------------------------------- wf_generate
 // Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
 // Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
-__global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= num_paths) return;
+ZD void generatePath(const Params& P, uint32_t slot) {
 
     int      x, y;
     uint32_t iteration;
@@ -269,6 +372,7 @@ __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths)
     h.depth_surface = 0;
     h.vdepth = 0;
     h.flags = ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR;
+    h.nee = 0;
     storeHead(P, slot, h);
     P.pool.ray_o[slot] = f4(origin_w, kRayMaxT);
     P.pool.ray_d[slot] = f4(direction_w, 0.f);
@@ -279,23 +383,34 @@ __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths)
     P.pool.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.pool.indirect[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.stage_uv[slot] = make_float2(s0, s1);
-    P.q.ext[P.parity][slot] = slot;
-    if (0 == slot) P.ctl->ext_count[P.parity] = num_paths;
+}
+
+__global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool     valid = slot < num_paths;
+    if (0 == slot) P.ctl->bound[1] = num_paths;  // tick 0's wf_intersect reads the previous tick's bound
+    if (valid) generatePath(P, slot);
+    queuePush(P.q.ext[P.parity], &P.ctl->ext_count[P.parity], P.sub_capacity, valid, slot);
 }
 
 // ---------------------------------------------------------------- wf_intersect
 template <bool STATS>
 __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     const uint32_t cur = P.parity;
-    const uint32_t n = P.ctl->ext_count[cur];
-    if (0 == blockIdx.x && 0 == threadIdx.x) {  // this tick's wf_shade / wf_scatter fill these
-        P.ctl->ext_count[cur ^ 1u] = 0;
-        P.ctl->alive_count = 0;
-    }
-    Counters       cnt{0, 0, 0};
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t n = queueOpen(&P.ctl->ext_count[cur], P.sub_capacity, i, at);
+    if (0 == i) P.ctl->bound[cur] = n;
+    if (0 == blockIdx.x && threadIdx.x < 64) {  // this tick's wf_shade / wf_nee / wf_extend fill these
+        queueReset(&P.ctl->ext_count[cur ^ 1u]);
+        queueReset(&P.ctl->alive_count);
+        queueReset(&P.ctl->shadow_count[0]);
+        queueReset(&P.ctl->shadow_count[1]);
+    }
+    Counters cnt{0, 0, 0};
     if (i < n) {
-        const uint32_t slot = P.q.ext[cur][i];
+        const uint32_t slot = P.q.ext[cur][at];
         const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
         const uint32_t depth = (P.pool.q0[slot].y >> 3) & 31u;
         Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
@@ -385,17 +500,21 @@ template <bool STATS>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Params P) {
     const DScene&  s = c_scene;
     const uint32_t cur = P.parity;
-    const uint32_t total = P.ctl->ext_count[cur];
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t total = queueOpen(&P.ctl->ext_count[cur], P.sub_capacity, i, at);
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters       cnt{0, 0, 0};
-    const uint32_t rounded = (total + 63u) & ~63u;  // whole waves stay converged for the ballot in queuePush
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i < rounded) {
+        SectionTimer tm;
+        tm.start();
         bool     alive = false;
         uint32_t slot = 0;
         if (i < total) {
-            slot = P.q.ext[cur][i];
+            slot = P.q.ext[cur][at];
             PathHead h;
             loadHead(P, slot, h);
 
@@ -410,6 +529,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
 
             Fragment frag;
             if (has_hit) makeFragment(s, ray, hit, frag);
+            tm.mark(0);
 
             // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
             f3 energy = S3(0.f);
@@ -434,7 +554,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
                 } else {
                     v.light_split_threshold = splitThreshold(h.vdepth);
                     if (has_hit) energy = evaluateRadiance(s, v, wo, frag, h.smp);
+                    tm.mark(1);
                     energy = energy + unoccludingEmission<STATS>(s, v, ray, h.smp, cnt);
+                    tm.mark(2);
                 }
             }
             f3 throughput = xyz4(P.pool.thr[slot]);
@@ -456,7 +578,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
 
             if (!done) {
                 // ---- Vertex.sample (vertex.zig:137-181): two-sided flip + the stochastic_r draw; the closure itself is
-                // rebuilt from the record by wf_scatter
+                // rebuilt from the record by wf_nee / wf_extend
                 const uint32_t       mat_id = s.material_ids[s.props[frag.prop].parts_start + frag.part];
                 const ZygpuMaterial& m = s.materials[mat_id];
                 f3                   geo_n = frag.geo_n, n = frag.n;
@@ -482,9 +604,13 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
                     alive = true;
                 }
             }
+            tm.mark(3);
             if (done) finalize(P, slot, throughput, h.flags);
+            tm.mark(4);
         }
-        queuePush(P.q.alive, &P.ctl->alive_count, alive, slot);
+        queuePush(P.q.alive, &P.ctl->alive_count, P.sub_capacity, alive, slot);
+        tm.mark(5);
+        tm.flush(P.ctl, 0);
     }
     if (STATS) flushCounters(P, 1, cnt, 0);
 }
@@ -518,26 +644,232 @@ ZD f3 surfaceOffsetP(f3 p, f3 geo_n, f3 v) {
     return offsetRay(fma3(S3(0.f), nn, p), nn);
 }
 
+// ---------------------------------------------------------------- next-event estimation, staged
+// sampleLights (pathtracer_mis.zig:174-212, pathtracer_dl.zig:100-137) picks the lights first (light tree, one sampler
+// draw), then handles them one after the other: evaluateLight draws the light sample (2-D), tests the shadow ray and,
+// only if it is unoccluded, draws one more dimension (light/light.zig:127).  That draw makes the picks of a vertex
+// sequential, so they run as rounds:  wf_nee(r) finishes pick r-1 (adds its contribution if wf_shadow found the ray
+// unoccluded, performs the draw) and starts pick r (light sample, shadow ray + the pre-weighted contribution into the
+// pool, slot into the shadow queue);  wf_shadow traces the queue with every lane busy;  wf_extend finishes the last
+// pick, then samples the bxdf.  Radiance, bsdf value and MIS weight of a pick do not depend on the visibility test, so
+// they are computed when the pick starts and the result is bit-identical to the reference's order.
+
+constexpr uint32_t kNeeCountMask = 127u;  // PathHead::nee [0:6] number of picks of this vertex
+constexpr uint32_t kNeePending = 128u;    //               [7]   the previous round issued a shadow ray
+
+ZD uint32_t batchPaths() { return c_view.npix * c_view.batch_iterations; }
+
+// evaluateLight up to the shadow test (pathtracer_mis.zig:214-278 / pathtracer_dl.zig:139-167); true = shadow ray issued
+template <bool SUBST>
+ZD bool startLightPick(const Params& P, uint32_t slot, PathHead& h, const Surface& sf, LightPick pick, bool mis) {
+    const DScene&         s = c_scene;
+    const MaterialSample& ms = sf.ms;
+    const ZygpuLight      light = s.lights[pick.offset];
+    const Trafo           trafo = loadTrafo(s, light.prop);
+    const ZygpuMaterial&  lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
+    SampleTo              ls;
+    if (!rectangleSampleTo(sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, h.smp, ls)) return false;
+    const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
+    f3       sdir;
+    float    slen;
+    shadowRay(sorigin, ls, sdir, slen);
+    const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
+    const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
+    f3               contrib;
+    if (mis) {
+        const float light_pdf = ls.pdf * pick.pdf;
+        const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
+        contrib = S3(weight) * radiance * bx.reflection;
+    } else {
+        const float weight = 1.f / (pick.pdf * ls.pdf);
+        contrib = S3(weight) * (S3(1.f) * radiance * bx.reflection);
+    }
+    P.pool.sh_o[slot] = f4(sorigin, slen);
+    P.pool.sh_d[slot] = f4(sdir);
+    P.pool.contrib[slot] = f4(contrib);
+    return true;
+}
+
+// the tail of evaluateLight for the pick started in the previous round
+ZD void finishLightPick(const Params& P, uint32_t slot, PathHead& h) {
+    if (0 != P.pool.vis[slot]) {
+        (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
+        const float4 acc = P.pool.nee[slot], c = P.pool.contrib[slot];
+        P.pool.nee[slot] = f4(xyz4(acc) + xyz4(c));
+    }
+    h.nee &= ~kNeePending;
+}
+
+struct NoTimer {
+    ZD void mark(int) {}
+};
+
+// SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
+template <bool FIRST, bool SUBST>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P, uint32_t round) {
+    const DScene&  s = c_scene;
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t total = queueOpen(&P.ctl->alive_count, P.sub_capacity, i, at);
+    const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
+    const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
+    if (i >= rounded) return;
+    bool     push = false;
+    uint32_t slot = 0;
+    if (i < total) {
+        slot = P.q.alive[at];
+        if (FIRST) {
+            PathHead h;
+            loadHead(P, slot, h);
+            const Surface sf = loadSurface(P, slot, h.flags);
+            if (sf.ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
+                const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
+                const float     select = h.smp.sample1D();
+                const LightTree lt{s};
+                const uint32_t  stride = batchPaths();
+                LightPick       first{0, 0.f};
+                NoTimer         tm;
+                const uint32_t  count = lt.randomLight(tm, sf.p, sf.ms.geo_n, sf.ms.translucent, select, nee_threshold,
+                                                       [&](uint32_t k, LightPick pick) {
+                                                           if (0 == k) first = pick;
+                                                           else P.pool.picks[size_t(k) * stride + slot] = make_uint2(pick.offset, __float_as_uint(pick.pdf));
+                                                       });
+                h.nee = count & kNeeCountMask;
+                if (count > 0) {
+                    P.pool.nee[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (startLightPick<SUBST>(P, slot, h, sf, first, mis)) {
+                        h.nee |= kNeePending;
+                        push = true;
+                    }
+                }
+                storeHead(P, slot, h);
+            }
+        } else {
+            const uint32_t st = P.pool.q0[slot].w;
+            if ((st & kNeePending) || (st & kNeeCountMask) > round) {
+                PathHead h;
+                loadHead(P, slot, h);
+                if (h.nee & kNeePending) finishLightPick(P, slot, h);
+                if ((h.nee & kNeeCountMask) > round) {
+                    const Surface sf = loadSurface(P, slot, h.flags);
+                    const uint2   pk = P.pool.picks[size_t(round) * batchPaths() + slot];
+                    if (startLightPick<SUBST>(P, slot, h, sf, LightPick{pk.x, __uint_as_float(pk.y)}, mis)) {
+                        h.nee |= kNeePending;
+                        push = true;
+                    }
+                }
+                storeHead(P, slot, h);
+            }
+        }
+    }
+    queuePush(P.q.shadow, &P.ctl->shadow_count[round & 1u], P.sub_capacity, push, slot);
+}
+
+// Scene.visibility (prop_tree.zig:185-240) for the shadow queue of one round
+template <bool STATS>
+__global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t n = queueOpen(&P.ctl->shadow_count[round & 1u], P.sub_capacity, i, at);
+    if (0 == blockIdx.x && threadIdx.x < 64) queueReset(&P.ctl->shadow_count[(round + 1u) & 1u]);  // the next round's wf_nee fills it
+    Counters cnt{0, 0, 0};
+    if (i < n) {
+        const uint32_t slot = P.q.shadow[at];
+        const float4   o = P.pool.sh_o[slot], d = P.pool.sh_d[slot];
+        Ray            shadow = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+        P.pool.vis[slot] = sceneVisibility<STATS>(c_scene, shadow, cnt) ? 1u : 0u;
+    }
+    if (STATS) flushCounters(P, 2, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
+}
+
+// ---------------------------------------------------------------- wf_extend
+// the last pick's tail, the NEE sum into the IValue, then the bxdf sample and the path extension (pathtracer_mis.zig:123-166)
+template <bool SUBST>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Params P) {
+    const DScene&  s = c_scene;
+    const uint32_t nxt = P.parity ^ 1u;
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t total = queueOpen(&P.ctl->alive_count, P.sub_capacity, i, at);
+    const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
+    const uint32_t rounded = (total + 255u) & ~255u;
+    if (i >= rounded) return;
+    bool     push = false;
+    uint32_t slot = 0;
+    if (i < total) {
+        slot = P.q.alive[at];
+        PathHead h;
+        loadHead(P, slot, h);
+        const Surface         sf = loadSurface(P, slot, h.flags);
+        const MaterialSample& ms = sf.ms;
+        f3                    throughput = xyz4(P.pool.thr[slot]);
+
+        if (h.nee & kNeePending) finishLightPick(P, slot, h);
+        if (h.nee & kNeeCountMask) ivalueAdd(P, slot, throughput * xyz4(P.pool.nee[slot]), h.depth_surface, 1u, false, false);
+        h.nee = 0;
+
+        BxdfSample bs;
+        if (!ms.template sample<SUBST>(s, h.smp, bs)) {
+            finalize(P, slot, S3(0.f), h.flags);
+        } else {
+            // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
+            if (kScatterSpecular == bs.scattering) {
+                h.flags |= ST_SPECULAR;
+                h.flags = (0.f == bs.reg_alpha) ? (h.flags | ST_SINGULAR) : (h.flags & ~uint32_t(ST_SINGULAR));
+                if (h.flags & ST_PRIMARY) h.flags |= ST_STARTED_SPECULAR;
+            } else {
+                h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
+            }
+            float bxdf_pdf = P.pool.ray_d[slot].w;
+            if (mis) {
+                h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
+                h.vdepth = h.depth_surface;
+                bxdf_pdf = bs.pdf;
+                P.pool.vgeo_n[slot] = f4(ms.geo_n);
+            }
+            throughput = throughput * (bs.reflection / S3(bs.pdf));
+            const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
+            h.depth_surface += 1;
+            h.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight): a reflection clears it
+            h.smp.incrementPadding();
+
+            P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
+            P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
+            P.pool.thr[slot] = f4(throughput);
+            P.pool.vorigin[slot] = f4(sf.p);
+            storeHead(P, slot, h);
+            push = true;
+        }
+    }
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot);
+}
+
 // ---------------------------------------------------------------- wf_scatter
-// sampleLights (next-event estimation) followed by the bxdf sample and the path extension, for every path wf_shade
-// kept alive.  One kernel: both halves need the same closure, and the sampler stream runs straight through them.
+// The in-place alternative to wf_nee / wf_shadow / wf_extend (option "nee_in_place"): sampleLights with the shadow rays
+// traced inside the pick loop, then the bxdf sample and the path extension, in one kernel.  Fewer launches and no state
+// round trips, but every lane waits for the longest pick loop of its wave and the kernel needs ~240 VGPRs.
 // SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
 template <bool STATS, bool SUBST>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     const DScene&      s = c_scene;
     const uint32_t     nxt = P.parity ^ 1u;
-    const uint32_t     total = P.ctl->alive_count;
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t           at;
+    const uint32_t     total = queueOpen(&P.ctl->alive_count, P.sub_capacity, i, at);
     const uint32_t     kind = c_view.v.integrator;
     const bool         mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters           cnt{0, 0, 0};
     unsigned long long shadow_rays = 0;
-    const uint32_t     rounded = (total + 63u) & ~63u;  // whole waves stay converged for the ballot in queuePush
-    const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t     rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i >= rounded) return;
     bool     push = false;
     uint32_t slot = 0;
     if (i < total) {
-        slot = P.q.alive[i];
+        slot = P.q.alive[at];
         PathHead h;
         loadHead(P, slot, h);
         const Surface         sf = loadSurface(P, slot, h.flags);
@@ -549,8 +881,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
             const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
             const float     select = h.smp.sample1D();
             const LightTree lt{s};
+            NoTimer         notimer;
             f3              nee = S3(0.f);
-            lt.randomLight(sf.p, ms.geo_n, ms.translucent, select, nee_threshold, [&](uint32_t, LightPick pick) {
+            lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold, [&](uint32_t, LightPick pick) {
                 const ZygpuLight     light = s.lights[pick.offset];
                 const Trafo          trafo = loadTrafo(s, light.prop);
                 const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
@@ -612,7 +945,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
             push = true;
         }
     }
-    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], push, slot);
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot);
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
 }
 

@@ -1,5 +1,5 @@
 // MI355X (gfx950) wavefront path-tracing core: film kernels + the zygpu_* C ABI (include/zygpu.h).
-// The wavefront stages themselves (wf_generate / wf_intersect / wf_shade / wf_scatter) are in wavefront.hpp.
+// The wavefront stages themselves (wf_generate / wf_intersect / wf_shade / wf_nee / wf_shadow / wf_extend) are in wavefront.hpp.
 //
 // The film is accumulated from a per-sample staging buffer in iteration order (no float atomics), so it is
 // deterministic and, for the radius-0 sensor, bit-identical to sequential accumulation.
@@ -215,38 +215,57 @@ struct ZygpuContext {
     float4*       film_active = nullptr;  // internal or external
     float4*       resolve_tmp = nullptr;
     size_t        pool_capacity = 0;      // paths
+    uint32_t      pool_rounds = 0;        // NEE rounds the pick buffer holds
+    uint32_t      num_lights = 0;
     size_t        film_pixels = 0;
     bool          stats = false;
-    bool          has_substitute = false;  // selects the wf_scatter instantiation
+    bool          has_substitute = false;  // selects the kernels' material instantiation
+    bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     uint64_t      camera_samples = 0;
-    uint32_t      max_light_picks = 1;
     int           num_cus = 256;
     // kernel timing
     bool                                          timing = true;
-    // per kernel: 0 wf_intersect, 1 wf_shade, 2 wf_scatter
+    // per kernel: 0 wf_intersect, 1 wf_shade, 2 wf_nee, 3 wf_shadow, 4 wf_extend, 5 wf_scatter
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[ZYGPU_NUM_KERNELS];
-    size_t                                        events_used[ZYGPU_NUM_KERNELS] = {0, 0, 0};
-    double                                        kernel_ms[ZYGPU_NUM_KERNELS] = {0, 0, 0};
-    uint64_t                                      kernel_launches[ZYGPU_NUM_KERNELS] = {0, 0, 0};
+    size_t                                        events_used[ZYGPU_NUM_KERNELS] = {};
+    double                                        kernel_ms[ZYGPU_NUM_KERNELS] = {};
+    uint64_t                                      kernel_launches[ZYGPU_NUM_KERNELS] = {};
 };
 
 namespace {
 
-int ensurePool(ZygpuContext* c, size_t paths) {
-    if (paths <= c->pool_capacity) return 0;
+// a queue = kSubQueues runs; run r takes the appends of blocks r, r + kSubQueues, ... of a launch over `paths` threads
+uint32_t subCapacity(size_t paths) {
+    const size_t blocks = (paths + 255) / 256;
+    return uint32_t((blocks + kSubQueues - 1) / kSubQueues * 256);
+}
+size_t queueCapacity(size_t paths) { return size_t(subCapacity(paths)) * kSubQueues; }
+
+int ensurePool(ZygpuContext* c, size_t paths, uint32_t rounds) {
+    if (paths <= c->pool_capacity && rounds <= c->pool_rounds) return 0;
+    paths = std::max(paths, c->pool_capacity);
+    rounds = std::max(rounds, c->pool_rounds);
     HIP_OK(hipStreamSynchronize(c->stream));
     c->pool_mem.release();
     DeviceBuffers& m = c->pool_mem;
     Pool&          p = c->pool;
+    const size_t   qcap = queueCapacity(paths);
     bool           ok = m.alloc(paths, &p.q0) && m.alloc(paths, &p.q1) && m.alloc(paths, &p.pcg) && m.alloc(paths, &p.ray_o) &&
               m.alloc(paths, &p.ray_d) && m.alloc(paths, &p.thr) && m.alloc(paths, &p.vorigin) && m.alloc(paths, &p.vgeo_n) &&
               m.alloc(paths, &p.emission) && m.alloc(paths, &p.direct) && m.alloc(paths, &p.indirect) && m.alloc(paths, &p.hit) &&
               m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) && m.alloc(paths, &p.rec_n) &&
-              m.alloc(paths, &p.rec_t) && m.alloc(paths, &p.rec_b) && m.alloc(paths, &c->queues.ext[0]) &&
-              m.alloc(paths, &c->queues.ext[1]) && m.alloc(paths, &c->queues.alive) && m.alloc(paths, &c->stage_color) &&
-              m.alloc(paths, &c->stage_uv);
-    if (!ok) return -1;
+              m.alloc(paths, &p.rec_t) && m.alloc(paths, &p.rec_b) && m.alloc(qcap, &c->queues.ext[0]) &&
+              m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) && m.alloc(paths, &c->stage_color) &&
+              m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) && m.alloc(paths, &p.sh_o) &&
+              m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
+              m.alloc(qcap, &c->queues.shadow);
+    if (!ok) {
+        c->pool_capacity = 0;
+        c->pool_rounds = 0;
+        return -1;
+    }
     c->pool_capacity = paths;
+    c->pool_rounds = rounds;
     return 0;
 }
 
@@ -359,7 +378,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             return -2;
         }
     }
-    c->max_light_picks = std::max<uint32_t>(1, std::min<uint32_t>(64, d->num_lights));
+    c->num_lights = d->num_lights;
 
     bool ok = m.upload(d->props, d->num_props, &s.props);
     ok = ok && m.upload(reinterpret_cast<const float4*>(d->trafos), size_t(d->num_props) * 4, &s.trafos);
@@ -496,7 +515,10 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     // batch size: as many iterations as fit ~8M paths (bounded by what is left)
     const size_t   target_paths = size_t(8) << 20;
     const uint32_t per_batch = uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
-    if (0 != ensurePool(c, npix * per_batch)) return -1;
+    // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
+    const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
+    const uint32_t rounds = nee ? std::min<uint32_t>(c->num_lights, 64u) : 0u;
+    if (0 != ensurePool(c, npix * per_batch, rounds)) return -1;
 
     Params P;
     P.pool = c->pool;
@@ -525,10 +547,12 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_view), &view, sizeof(View), 0, hipMemcpyHostToDevice, c->stream));
 
         const uint32_t num_paths = uint32_t(npix * b);
+        P.sub_capacity = subCapacity(c->pool_capacity);
         // one thread per queue entry; the queue lengths live on the device, so every launch covers the upper bound and
         // surplus waves retire on their first (scalar) load
         const dim3     grid((num_paths + 255) / 256);
         P.parity = 0;
+        HIP_OK(hipMemsetAsync(&c->ctl->ext_count[0], 0, sizeof(QueueCounts), c->stream));  // wf_generate appends to it
         hipLaunchKernelGGL(wf_generate, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
         c->camera_samples += num_paths;
         for (uint32_t t = 0; t < ticks; ++t) {
@@ -540,10 +564,33 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 if (c->stats) hipLaunchKernelGGL(wf_shade<true>, grid, block, 0, c->stream, P);
                 else hipLaunchKernelGGL(wf_shade<false>, grid, block, 0, c->stream, P);
             });
-            timedLaunch(c, 2, [&] {
-                if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true>), grid, block, 0, c->stream, P);
-                else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true>), grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL((wf_scatter<false, false>), grid, block, 0, c->stream, P);
+            if (nee && c->nee_in_place) {
+                timedLaunch(c, 5, [&] {
+                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true>), grid, block, 0, c->stream, P);
+                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true>), grid, block, 0, c->stream, P);
+                    else hipLaunchKernelGGL((wf_scatter<false, false>), grid, block, 0, c->stream, P);
+                });
+                P.parity ^= 1u;
+                continue;
+            }
+            for (uint32_t r = 0; r < rounds; ++r) {
+                timedLaunch(c, 2, [&] {
+                    if (0 == r) {
+                        if (c->has_substitute) hipLaunchKernelGGL((wf_nee<true, true>), grid, block, 0, c->stream, P, r);
+                        else hipLaunchKernelGGL((wf_nee<true, false>), grid, block, 0, c->stream, P, r);
+                    } else {
+                        if (c->has_substitute) hipLaunchKernelGGL((wf_nee<false, true>), grid, block, 0, c->stream, P, r);
+                        else hipLaunchKernelGGL((wf_nee<false, false>), grid, block, 0, c->stream, P, r);
+                    }
+                });
+                timedLaunch(c, 3, [&] {
+                    if (c->stats) hipLaunchKernelGGL(wf_shadow<true>, grid, block, 0, c->stream, P, r);
+                    else hipLaunchKernelGGL(wf_shadow<false>, grid, block, 0, c->stream, P, r);
+                });
+            }
+            timedLaunch(c, 4, [&] {
+                if (c->has_substitute) hipLaunchKernelGGL(wf_extend<true>, grid, block, 0, c->stream, P);
+                else hipLaunchKernelGGL(wf_extend<false>, grid, block, 0, c->stream, P);
             });
             P.parity ^= 1u;
         }
@@ -634,6 +681,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->timing = 0 != value;
         return 0;
     }
+    if (0 == std::strcmp(name, "nee_in_place")) {
+        c->nee_in_place = 0 != value;
+        return 0;
+    }
     g_error = std::string("unknown option ") + name;
     return -1;
 }
@@ -644,32 +695,34 @@ int zygpu_enable_stats(ZygpuContext* c, int enabled) {
     return 0;
 }
 
-static int readKernelStats(ZygpuContext* c, ZygpuStats out[3]) {
+static int readKernelStats(ZygpuContext* c, ZygpuStats out[ZYGPU_NUM_KERNELS]) {
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
     Control h;
     HIP_OK(hipMemcpy(&h, c->ctl, sizeof(Control), hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof(ZygpuStats) * ZYGPU_NUM_KERNELS);
+    // traversal happens in wf_intersect, wf_shade and wf_shadow (or wf_scatter, which traces its shadow rays itself)
+    const int where[3] = {0, 1, c->nee_in_place ? 5 : 3};
     for (int k = 0; k < 3; ++k) {
-        std::memset(&out[k], 0, sizeof(ZygpuStats));
-        out[k].nodes_fetched = h.k[k].nodes;
-        out[k].triangles_tested = h.k[k].tris;
-        out[k].instances_tested = h.k[k].instances;
+        out[where[k]].nodes_fetched = h.k[k].nodes;
+        out[where[k]].triangles_tested = h.k[k].tris;
+        out[where[k]].instances_tested = h.k[k].instances;
     }
     out[0].extension_rays = h.k[0].rays;
-    out[2].shadow_rays = h.k[2].rays;
+    out[where[2]].shadow_rays = h.k[2].rays;
     out[0].camera_samples = c->camera_samples;
     return 0;
 }
 
 int zygpu_get_stats(ZygpuContext* c, ZygpuStats* out) {
     if (!c || !out) return -1;
-    ZygpuStats k[3];
+    ZygpuStats k[ZYGPU_NUM_KERNELS];
     if (0 != readKernelStats(c, k)) return -1;
     std::memset(out, 0, sizeof(*out));
     out->camera_samples = k[0].camera_samples;
     out->extension_rays = k[0].extension_rays;
-    out->shadow_rays = k[2].shadow_rays;
-    for (int i = 0; i < 3; ++i) {
+    out->shadow_rays = k[3].shadow_rays + k[5].shadow_rays;
+    for (int i = 0; i < ZYGPU_NUM_KERNELS; ++i) {
         out->nodes_fetched += k[i].nodes_fetched;
         out->triangles_tested += k[i].triangles_tested;
         out->instances_tested += k[i].instances_tested;
@@ -677,9 +730,19 @@ int zygpu_get_stats(ZygpuContext* c, ZygpuStats* out) {
     return 0;
 }
 
-int zygpu_get_kernel_stats(ZygpuContext* c, ZygpuStats* out3) {
-    if (!c || !out3) return -1;
-    return readKernelStats(c, out3);
+int zygpu_get_kernel_stats(ZygpuContext* c, ZygpuStats* out) {
+    if (!c || !out) return -1;
+    return readKernelStats(c, out);
+}
+
+int zygpu_get_section_cycles(ZygpuContext* c, uint64_t* out32) {
+    if (!c || !out32) return -1;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    Control h;
+    HIP_OK(hipMemcpy(&h, c->ctl, sizeof(Control), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32; ++i) out32[i] = h.sections[i];
+    return 0;
 }
 
 int zygpu_reset_stats(ZygpuContext* c) {
