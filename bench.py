@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
     ap.add_argument("--nee", default="in-place", choices=["in-place", "staged"],
                     help="zygpu option nee_in_place: wf_scatter (default) or the wf_nee / wf_shadow rounds + wf_extend")
+    ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -77,6 +78,8 @@ def main():
                    mesh_material=mesh_material)
     eng.start_frame(0)
     lib, ctx = eng.lib, eng.context()
+    if args.batch_mpaths:
+        assert lib.zygpu_set_option(ctx, b"batch_mpaths", args.batch_mpaths) == 0
     nee_in_place = args.nee == "in-place"
     assert lib.zygpu_set_option(ctx, b"nee_in_place", 1 if nee_in_place else 0) == 0
 

@@ -40,6 +40,8 @@ struct Pool {  // SoA of 16 B records, indexed by path slot
     float4*   indirect;
     uint4*    hit;      // t, u, v (bits), primitive
     uint32_t* hit_prop;
+    uint32_t* ucount;   // unoccluding lights the extension ray crosses in front of its hit (PropBvh.emission's candidates)
+    uint4*    ucand;    //   [candidate][slot]: prop, t, u, v (bits), in traversal order
     float4*   rec_p;    // compacted hit record: p.xyz, material index (bits)
     float4*   rec_gn;   //   geometric normal after the two-sided flip (vertex.zig:155-161), w = 1 if flipped
     float4*   rec_n;    //   shading normal (flipped likewise)
@@ -219,6 +221,8 @@ ZD void slotPixel(uint32_t slot, int& x, int& y, uint32_t& iteration) {
     iteration = c_view.iteration0 + it;
 }
 
+ZD uint32_t batchPaths() { return c_view.npix * c_view.batch_iterations; }
+
 ZD uint32_t pixelId(int x, int y) {  // worker.zig:127-128,136,141
     const int fr = c_view.v.filter_radius_int;
     const int r0 = c_view.v.resolution[0] + 2 * fr;
@@ -393,6 +397,45 @@ __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths)
     queuePush(P.q.ext[P.parity], &P.ctl->ext_count[P.parity], P.sub_capacity, valid, slot);
 }
 
+// PropBvh.emission over the unoccluding TLAS (prop_tree.zig:302-356, prop.zig:239-264, rectangle.zig:188-196), split in
+// two: wf_intersect walks the tree right after the closest hit (ray.max_t already shrunk to it) and records the lights
+// the ray crosses, in traversal order; wf_shade evaluates them (sampler draws + MIS weights) in that order.
+constexpr uint32_t kMaxUnoccludingCandidates = 4;
+
+// whether connectLight looks at emission at all for this vertex, and at the unoccluding lights in particular
+// (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
+ZD bool connectsLights(uint32_t flags) { return !(!c_view.v.caustics_path && (flags & ST_SPECULAR) && !(flags & ST_PRIMARY)); }
+ZD bool walksUnoccluding(uint32_t flags) {
+    return connectsLights(flags) && (ZYGPU_INTEGRATOR_PTDL != c_view.v.integrator || (flags & ST_SINGULAR));
+}
+
+template <bool STATS>
+ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, uint32_t depth_surface, const Ray& ray_in, Counters& cnt) {
+    uint32_t n = 0;
+    Ray      ray = ray_in;
+    bvhWalk<STATS>(s.unocc_nodes, s.num_unocc_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            const uint32_t  p = s.unocc_indices[i];
+            const ZygpuProp prop = s.props[p];
+            if (!propVisibleAtDepth(prop.flags, depth_surface)) continue;
+            if (STATS) cnt.instances += 1;
+            if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
+            if (ZYGPU_SHAPE_RECTANGLE != prop.shape) continue;
+            const Trafo trafo = loadTrafo(s, p);
+            float       t, u, v;
+            if (!rectangleIntersect(ray, trafo, t, u, v)) continue;
+            if (n < kMaxUnoccludingCandidates) {
+                P.pool.ucand[size_t(n) * batchPaths() + slot] = make_uint4(p, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
+            } else {
+                atomicOr(&P.ctl->error, 2u);  // reported by zygpu_synchronize: more overlapping unoccluding lights than slots
+            }
+            n += 1;
+        }
+        return false;
+    });
+    return n;
+}
+
 // ---------------------------------------------------------------- wf_intersect
 template <bool STATS>
 __global__ void __launch_bounds__(256) wf_intersect(Params P) {
@@ -412,13 +455,16 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     if (i < n) {
         const uint32_t slot = P.q.ext[cur][at];
         const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
-        const uint32_t depth = (P.pool.q0[slot].y >> 3) & 31u;
+        const uint32_t meta = P.pool.q0[slot].y;
+        const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
         Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
         Hit            hit;
         sceneIntersect<STATS>(c_scene, ray, depth, hit, cnt);
         if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
         P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
         P.pool.hit_prop[slot] = hit.prop;
+        // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
+        P.pool.ucount[slot] = walksUnoccluding(flags) ? unoccludingCandidates<STATS>(P, c_scene, slot, depth, ray, cnt) : 0u;
     }
     if (STATS) flushCounters(P, 0, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
 }
@@ -465,34 +511,23 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
     return S3(weight) * energy;
 }
 
-// PropBvh.emission over the unoccluding TLAS (prop_tree.zig:302-356, prop.zig:239-264, rectangle.zig:188-196)
-template <bool STATS>
-ZD f3 unoccludingEmission(const DScene& s, const VertexIn& v, const Ray& ray_in, Sampler& smp, Counters& cnt) {
-    f3  energy = S3(0.f);
-    Ray ray = ray_in;
-    const f3 wo = -ray.direction;
-    bvhWalk<STATS>(s.unocc_nodes, s.num_unocc_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
-        for (uint32_t i = first, e = first + count; i < e; ++i) {
-            const uint32_t  p = s.unocc_indices[i];
-            const ZygpuProp prop = s.props[p];
-            if (!propVisibleAtDepth(prop.flags, v.depth_surface)) continue;
-            if (STATS) cnt.instances += 1;
-            if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            if (ZYGPU_SHAPE_RECTANGLE != prop.shape) continue;
-            Fragment frag;
-            frag.trafo = loadTrafo(s, p);
-            frag.prop = p;
-            float t, u, vv;
-            if (!rectangleIntersect(ray, frag.trafo, t, u, vv)) continue;
-            frag.t_hit = t;
-            frag.u = u;
-            frag.v = vv;
-            frag.primitive = 0;
-            rectangleFragment(ray, frag);
-            energy = energy + evaluateRadiance(s, v, wo, frag, smp);
-        }
-        return false;
-    });
+// the evaluation half of PropBvh.emission: the candidates wf_intersect recorded, in its traversal order
+ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, const VertexIn& v, const Ray& ray, Sampler& smp) {
+    f3             energy = S3(0.f);
+    const uint32_t n = min(P.pool.ucount[slot], kMaxUnoccludingCandidates);
+    const f3       wo = -ray.direction;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint4 c = P.pool.ucand[size_t(k) * batchPaths() + slot];
+        Fragment    frag;
+        frag.trafo = loadTrafo(s, c.x);
+        frag.prop = c.x;
+        frag.t_hit = __uint_as_float(c.y);
+        frag.u = __uint_as_float(c.z);
+        frag.v = __uint_as_float(c.w);
+        frag.primitive = 0;
+        rectangleFragment(ray, frag);
+        energy = energy + evaluateRadiance(s, v, wo, frag, smp);
+    }
     return energy;
 }
 
@@ -533,7 +568,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
 
             // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
             f3 energy = S3(0.f);
-            if (!(!c_view.v.caustics_path && (h.flags & ST_SPECULAR) && !(h.flags & ST_PRIMARY))) {
+            if (connectsLights(h.flags)) {
                 VertexIn v;
                 v.vorigin = xyz4(P.pool.vorigin[slot]);
                 v.vgeo_n = xyz4(P.pool.vgeo_n[slot]);
@@ -544,18 +579,18 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
                 if (ZYGPU_INTEGRATOR_PT == kind) {
                     v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
                     if (has_hit) energy = evaluateRadiance(s, v, wo, frag, h.smp);
-                    energy = energy + unoccludingEmission<STATS>(s, v, ray, h.smp, cnt);
+                    energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
                 } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
                     if (has_hit) {
                         const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
                         if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance(s, v, wo, frag, h.smp);
                     }
-                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<STATS>(s, v, ray, h.smp, cnt);
+                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
                 } else {
                     v.light_split_threshold = splitThreshold(h.vdepth);
                     if (has_hit) energy = evaluateRadiance(s, v, wo, frag, h.smp);
                     tm.mark(1);
-                    energy = energy + unoccludingEmission<STATS>(s, v, ray, h.smp, cnt);
+                    energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
                     tm.mark(2);
                 }
             }
@@ -657,7 +692,6 @@ ZD f3 surfaceOffsetP(f3 p, f3 geo_n, f3 v) {
 constexpr uint32_t kNeeCountMask = 127u;  // PathHead::nee [0:6] number of picks of this vertex
 constexpr uint32_t kNeePending = 128u;    //               [7]   the previous round issued a shadow ray
 
-ZD uint32_t batchPaths() { return c_view.npix * c_view.batch_iterations; }
 
 // evaluateLight up to the shadow test (pathtracer_mis.zig:214-278 / pathtracer_dl.zig:139-167); true = shadow ray issued
 template <bool SUBST>

@@ -220,6 +220,7 @@ struct ZygpuContext {
     size_t        film_pixels = 0;
     bool          stats = false;
     bool          has_substitute = false;  // selects the kernels' material instantiation
+    uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     uint64_t      camera_samples = 0;
     int           num_cus = 256;
@@ -253,7 +254,7 @@ int ensurePool(ZygpuContext* c, size_t paths, uint32_t rounds) {
     bool           ok = m.alloc(paths, &p.q0) && m.alloc(paths, &p.q1) && m.alloc(paths, &p.pcg) && m.alloc(paths, &p.ray_o) &&
               m.alloc(paths, &p.ray_d) && m.alloc(paths, &p.thr) && m.alloc(paths, &p.vorigin) && m.alloc(paths, &p.vgeo_n) &&
               m.alloc(paths, &p.emission) && m.alloc(paths, &p.direct) && m.alloc(paths, &p.indirect) && m.alloc(paths, &p.hit) &&
-              m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) && m.alloc(paths, &p.rec_n) &&
+              m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.ucount) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) && m.alloc(paths, &p.rec_n) &&
               m.alloc(paths, &p.rec_t) && m.alloc(paths, &p.rec_b) && m.alloc(qcap, &c->queues.ext[0]) &&
               m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) && m.alloc(paths, &c->stage_color) &&
               m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) && m.alloc(paths, &p.sh_o) &&
@@ -513,7 +514,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     const size_t npix = size_t(xe - xb) * size_t(ye - yb);
 
     // batch size: as many iterations as fit ~8M paths (bounded by what is left)
-    const size_t   target_paths = size_t(8) << 20;
+    const size_t   target_paths = size_t(c->batch_mpaths) << 20;
     const uint32_t per_batch = uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
     // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
@@ -615,6 +616,7 @@ int zygpu_synchronize(ZygpuContext* c) {
     HIP_OK(hipMemcpy(&h, c->ctl, sizeof(Control), hipMemcpyDeviceToHost));
     if (h.error) {
         g_error = "device error flags: " + std::to_string(h.error);
+        if (h.error & 2u) g_error += " (a ray crossed more than 4 unoccluding lights in front of its hit: kMaxUnoccludingCandidates)";
         return -3;
     }
     return 0;
@@ -679,6 +681,14 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     if (!c || !name) return -1;
     if (0 == std::strcmp(name, "kernel_timing")) {
         c->timing = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "batch_mpaths")) {
+        if (value < 1 || value > 512) {
+            g_error = "batch_mpaths out of range [1, 512]";
+            return -1;
+        }
+        c->batch_mpaths = uint32_t(value);
         return 0;
     }
     if (0 == std::strcmp(name, "nee_in_place")) {
