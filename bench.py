@@ -165,6 +165,18 @@ def main():
         avg_ms = dom[1] / max(dom[2], 1)
         bytes_per_launch = dom[3] * samples_rank / max(dom[2], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same configuration
+        # (tools/pmc_traffic.py -> profiles/traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so they cannot
+        # be collected from inside this process); null for any other configuration
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        default_cfg = (args.scene == "cornell" and args.material == "lambert" and (w, h, ips) == (1920, 1080, ITER_PER_STEP)
+                       and not args.batch_mpaths)
+        if default_cfg and os.path.exists(tpath):
+            prof = json.load(open(tpath))
+            for key, val in prof.items():
+                if key.startswith(dom[0]) and "true" not in key:
+                    traffic = round(val["hbm_bytes_per_launch"], 1)
         weights = film[..., 3]
         geometry = "2 boxes" if mesh is None else "999698-triangle heightfield mesh (Substitute)"
         bsdf = "Lambertian" if args.material == "lambert" else "Substitute (roughness 0.8)"
@@ -186,7 +198,8 @@ def main():
                                    f"{k * ips} spp per GPU", "scene": args.scene, "material": args.material,
                        "parallelism": f"iterations x{n}"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(dom[2]),
                          "algorithmic_bytes_per_sample": round(bytes_sample_total, 1),
                          "kernel_bytes_per_sample": round(dom[3], 1),

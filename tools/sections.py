@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Section-cycle attribution of wf_shade / wf_scatter.  Needs a library built with -DZYG_PROFILE_SECTIONS
+"""Section-cycle attribution of wf_shade (marks: SectionTimer in wavefront.hpp; add more where needed).  Needs a library built with -DZYG_PROFILE_SECTIONS
 (ZYG_AMD_LIB=variants/lib_prof.so python3 tools/sections.py); prints each section's share of the summed wave cycles."""
 import ctypes
 import os
@@ -21,15 +21,10 @@ lib.zygpu_render(ctx, 0, 0, iters, 0, h)
 lib.zygpu_synchronize(ctx)
 out = (ctypes.c_uint64 * 32)()
 lib.zygpu_get_section_cycles(ctx, out)
-names = {0: "shade: state loads + fragment", 1: "shade: hit emission (evaluateRadiance)", 2: "shade: unoccluding lights walk",
+names = {0: "shade: state loads + fragment", 1: "shade: hit emission (evaluateRadiance)", 2: "shade: unoccluding-light candidates (evaluateRadiance)",
          3: "shade: IValue add, RR, record write", 4: "shade: finalize", 5: "shade: queue push",
-         16: "scatter: state + closure load", 17: "scatter: light tree, rest (pops, to next visit)",
-         18: "scatter: Rectangle sampleTo (SphQuad)",
-         19: "scatter: shadow visibility", 20: "scatter: radiance + bsdf evaluate + draw", 21: "scatter: bxdf sample",
-         22: "scatter: state update, stores, queue push", 23: "scatter: light-select draw",
-         24: "scatter: tree inner node load", 25: "scatter: tree nodeSplit", 26: "scatter: tree leaf node load / child weights",
-         27: "scatter: tree leaf pick (nodeRandomLight)"}
-for base, label in ((0, "wf_shade"), (16, "wf_scatter")):
+         }
+for base, label in ((0, "wf_shade"),):
     tot = sum(out[base:base + 16]) or 1
     print(f"{label}: {tot / 1e9:.2f} G wave-cycles")
     for i in range(base, base + 16):
