@@ -153,3 +153,18 @@ def test_mesh_heightfield_substitute_rough_metal(engine, oracle):
     out = _render_both(engine, oracle, 72, 54, 3, boxes=False, mesh=mesh, material="substitute",
                        mesh_material=scenes.substitute((0.9, 0.6, 0.3), roughness=0.3, metallic=1.0))
     _check(*out, 3)
+
+
+@pytest.mark.parametrize("integrator", ["PTDL", "PTMIS"])
+def test_multi_sample_lights(engine, oracle, integrator):
+    """Emittance num_samples = 4 (shape_sampler.zig:35-41): four solid-angle samples per light pick above the low split
+    threshold, all drawn before the first shadow test (rectangle.zig:321-352), one per pick below it."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, light_samples=4)
+    _check(*out, 3)
+    assert out[2].shadow_rays > 0
+
+
+def test_multi_sample_lights_take_the_in_place_path(engine, oracle):
+    """The staged NEE rounds take one sample per pick; a scene with multi-sample lights runs wf_scatter whatever the option."""
+    out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS", light_samples=3, nee_in_place=0)
+    _check(*out, 2)

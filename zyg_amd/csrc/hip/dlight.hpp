@@ -348,29 +348,43 @@ struct SampleTo {  // shape/sample.zig:7-29
     float pdf;
 };
 
-// rectangle.zig:305-357 for one sample (lights with num_samples > 1 are rejected at upload)
+// rectangle.zig:305-357 (UseSphericalSampling): the set-up shared by a light's samples, then one sample per 2-D draw
+struct RectangleSampler {
+    SphQuad squad;
+    float   sample_pdf;
+
+    ZD static RectangleSampler init(f3 p, const Trafo& trafo, uint32_t num_samples) {
+        RectangleSampler r;
+        r.squad = SphQuad::init(trafo.scale, trafo.worldToFramePoint(p));
+        r.sample_pdf = float(num_samples) * r.squad.pdf(trafo.scale);
+        return r;
+    }
+    ZD bool sample(float u0, float u1, f3 p, f3 n, const Trafo& trafo, bool two_sided, bool total_sphere, SampleTo& out) const {
+        const f3 ls = squad.sample(u0, u1);
+        const f3 ws = trafo.frameToWorldPoint(ls);
+        const f3 dir = normalize3(ws - p);
+        f3       wn = trafo.r2;
+        if (two_sided && dot3(wn, dir) > 0.f) wn = -wn;
+        if (-dot3(wn, dir) < kDotMin || 0.f == squad.Sa || (dot3(dir, n) <= 0.f && !total_sphere)) return false;
+        out.p = ws;
+        out.n = wn;
+        out.wi = dir;
+        out.pdf = sample_pdf;
+        return true;
+    }
+};
+
+// one-sample form (what the staged NEE rounds use)
 ZD bool rectangleSampleTo(f3 p, f3 n, const Trafo& trafo, bool two_sided, bool total_sphere, Sampler& sampler, SampleTo& out) {
-    const f3      lp = trafo.worldToFramePoint(p);
-    const SphQuad squad = SphQuad::init(trafo.scale, lp);
-    const float   sample_pdf = 1.f * squad.pdf(trafo.scale);
-    float         u0, u1;
+    const RectangleSampler rs = RectangleSampler::init(p, trafo, 1);
+    float                  u0, u1;
     sampler.sample2D(u0, u1);
-    const f3 ls = squad.sample(u0, u1);
-    const f3 ws = trafo.frameToWorldPoint(ls);
-    const f3 dir = normalize3(ws - p);
-    f3       wn = trafo.r2;
-    if (two_sided && dot3(wn, dir) > 0.f) wn = -wn;
-    if (-dot3(wn, dir) < kDotMin || 0.f == squad.Sa || (dot3(dir, n) <= 0.f && !total_sphere)) return false;
-    out.p = ws;
-    out.n = wn;
-    out.wi = dir;
-    out.pdf = sample_pdf;
-    return true;
+    return rs.sample(u0, u1, p, n, trafo, two_sided, total_sphere, out);
 }
 
-ZD float rectanglePdf(f3 p, const Trafo& frag_trafo) {  // rectangle.zig:554-575, one sample
+ZD float rectanglePdf(f3 p, const Trafo& frag_trafo, uint32_t num_samples) {  // rectangle.zig:554-575 via shape.zig:469-492
     const SphQuad squad = SphQuad::init(frag_trafo.scale, frag_trafo.worldToFramePoint(p));
-    return 1.f * squad.pdf(frag_trafo.scale);
+    return float(num_samples) * squad.pdf(frag_trafo.scale);
 }
 
 // shape.zig:401-416

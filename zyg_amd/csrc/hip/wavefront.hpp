@@ -497,7 +497,8 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, const Fragment& frag) {
     if ((v.flags & ST_SINGULAR) || kNull == light_id) return 1.f;
     const LightTree lt{s};
     const float     select_pdf = lt.pdf(v.vorigin, v.vgeo_n, 0 != (v.flags & ST_TRANSLUCENT), v.light_split_threshold, light_id);
-    const float     sample_pdf = rectanglePdf(v.vorigin, frag.trafo);
+    // light.zig:149-157 -> shape_sampler.zig:35-41: the light's sample count under the previous vertex's split threshold
+    const float     sample_pdf = rectanglePdf(v.vorigin, frag.trafo, numSamples(s.lights[light_id].num_samples, v.light_split_threshold));
     return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
 }
 
@@ -886,7 +887,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 // traced inside the pick loop, then the bxdf sample and the path extension, in one kernel.  Fewer launches and no state
 // round trips, but every lane waits for the longest pick loop of its wave and the kernel needs ~240 VGPRs.
 // SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
-template <bool STATS, bool SUBST>
+// MULTI: a light has emittance num_samples > 1
+template <bool STATS, bool SUBST, bool MULTI>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     const DScene&      s = c_scene;
     const uint32_t     nxt = P.parity ^ 1u;
@@ -921,26 +923,45 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
                 const ZygpuLight     light = s.lights[pick.offset];
                 const Trafo          trafo = loadTrafo(s, light.prop);
                 const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
-                SampleTo             ls;
-                if (!rectangleSampleTo(sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, h.smp, ls)) return;
-                const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
-                f3       sdir;
-                float    slen;
-                shadowRay(sorigin, ls, sdir, slen);
-                Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
-                if (STATS) shadow_rays += 1;
-                if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
-                const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
-                const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
-                (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
-                if (mis) {
-                    const float light_pdf = ls.pdf * pick.pdf;
-                    const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
-                    nee = nee + S3(weight) * radiance * bx.reflection;
-                } else {
-                    const float weight = 1.f / (pick.pdf * ls.pdf);
-                    nee = nee + S3(weight) * (S3(1.f) * radiance * bx.reflection);
+                // shape_sampler.zig:35-41; PathtracerDL samples its lights with threshold 0 (pathtracer_dl.zig:139-167)
+                const uint32_t         n = MULTI ? numSamples(light.num_samples, mis ? nee_threshold : 0.f) : 1u;
+                const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
+                // Rectangle.sampleTo draws all n light samples before the first shadow test (rectangle.zig:321-352); instead
+                // of buffering them, a copy of the sampler replays those draws while the path's sampler runs ahead
+                Sampler replay = h.smp;
+                if (MULTI) {
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float a, b;
+                        h.smp.sample2D(a, b);
+                    }
                 }
+                f3 occluded = S3(0.f);
+                for (uint32_t j = 0; j < n; ++j) {
+                    float u0, u1;
+                    if (MULTI) replay.sample2D(u0, u1);
+                    else h.smp.sample2D(u0, u1);
+                    SampleTo ls;
+                    if (!rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) continue;
+                    const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
+                    f3       sdir;
+                    float    slen;
+                    shadowRay(sorigin, ls, sdir, slen);
+                    Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
+                    if (STATS) shadow_rays += 1;
+                    if (!sceneVisibility<STATS>(s, shadow, cnt)) continue;
+                    const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
+                    const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
+                    (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
+                    if (mis) {
+                        const float light_pdf = ls.pdf * pick.pdf;
+                        const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
+                        occluded = occluded + S3(weight) * radiance * bx.reflection;
+                    } else {
+                        const float weight = 1.f / (pick.pdf * ls.pdf);
+                        occluded = occluded + S3(weight) * (S3(1.f) * radiance * bx.reflection);
+                    }
+                }
+                nee = nee + occluded;
             });
             ivalueAdd(P, slot, throughput * nee, h.depth_surface, 1u, false, false);
         }

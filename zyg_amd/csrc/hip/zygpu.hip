@@ -220,6 +220,7 @@ struct ZygpuContext {
     size_t        film_pixels = 0;
     bool          stats = false;
     bool          has_substitute = false;  // selects the kernels' material instantiation
+    bool          multi_sample_lights = false;  // a light has emittance num_samples > 1: wf_scatter<.., MULTI>
     uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     uint64_t      camera_samples = 0;
@@ -360,11 +361,13 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     DScene&        s = c->scene;
     std::memset(&s, 0, sizeof(s));
 
+    c->multi_sample_lights = false;
     for (uint32_t l = 0; l < d->num_lights; ++l) {
-        if (d->lights[l].num_samples > 1) {
-            g_error = "lights with emittance num_samples > 1 are not supported on the device path";
+        if (d->lights[l].num_samples > 64) {  // shape.zig:44 MaxSamples
+            g_error = "a light's emittance num_samples exceeds 64";
             return -2;
         }
+        if (d->lights[l].num_samples > 1) c->multi_sample_lights = true;
         if (ZYGPU_SHAPE_RECTANGLE != d->props[d->lights[l].prop].shape) {
             g_error = "only Rectangle lights are supported on the device path";
             return -2;
@@ -565,11 +568,12 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 if (c->stats) hipLaunchKernelGGL(wf_shade<true>, grid, block, 0, c->stream, P);
                 else hipLaunchKernelGGL(wf_shade<false>, grid, block, 0, c->stream, P);
             });
-            if (nee && c->nee_in_place) {
+            if (nee && (c->nee_in_place || c->multi_sample_lights)) {  // the staged rounds take one sample per pick
                 timedLaunch(c, 5, [&] {
-                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true>), grid, block, 0, c->stream, P);
-                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true>), grid, block, 0, c->stream, P);
-                    else hipLaunchKernelGGL((wf_scatter<false, false>), grid, block, 0, c->stream, P);
+                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true>), grid, block, 0, c->stream, P);
+                    else if (c->multi_sample_lights) hipLaunchKernelGGL((wf_scatter<false, true, true>), grid, block, 0, c->stream, P);
+                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false>), grid, block, 0, c->stream, P);
+                    else hipLaunchKernelGGL((wf_scatter<false, false, false>), grid, block, 0, c->stream, P);
                 });
                 P.parity ^= 1u;
                 continue;
@@ -712,7 +716,7 @@ static int readKernelStats(ZygpuContext* c, ZygpuStats out[ZYGPU_NUM_KERNELS]) {
     HIP_OK(hipMemcpy(&h, c->ctl, sizeof(Control), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(ZygpuStats) * ZYGPU_NUM_KERNELS);
     // traversal happens in wf_intersect, wf_shade and wf_shadow (or wf_scatter, which traces its shadow rays itself)
-    const int where[3] = {0, 1, c->nee_in_place ? 5 : 3};
+    const int where[3] = {0, 1, (c->nee_in_place || c->multi_sample_lights) ? 5 : 3};
     for (int k = 0; k < 3; ++k) {
         out[where[k]].nodes_fetched = h.k[k].nodes;
         out[where[k]].triangles_tested = h.k[k].tris;
