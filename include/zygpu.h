@@ -91,6 +91,8 @@ typedef struct ZygpuMesh {
     const uint16_t*     normals;   /* 2 per vertex, oct + snorm16 (base/encoding.zig:82-108) */
     const float*        uvs;       /* 2 per vertex */
     const float*        part_areas;
+    const uint32_t*     primitive_mapping; /* triangle -> its index among the triangles of its part (triangle_mesh.zig:729-746);
+                                              NULL unless a part of the mesh is a light */
     uint32_t num_nodes;
     uint32_t num_triangles;
     uint32_t num_vertices;
@@ -148,6 +150,7 @@ typedef struct ZygpuLight {
     uint8_t  two_sided;
     uint8_t  shadow_catcher_light;
     uint8_t  prototype;
+    uint32_t sampler;     /* index into ZygpuSceneDesc.mesh_lights for TriangleMesh emitters, else ZYGPU_NULL (light.zig:41-47) */
 } ZygpuLight;
 
 /* reference src/core/scene/light/light_tree.zig:25-35 — 32 B compressed node */
@@ -175,6 +178,20 @@ typedef struct ZygpuLightTree {
     uint32_t  num_infinite_lights;
     uint32_t  num_nodes;
 } ZygpuLightTree;
+
+/* An emissive part of a triangle mesh, in the mesh's object space: shape_sampler.zig:160-258 (MeshImpl) +
+ * triangle_mesh.zig:46-150 (Part.configure).  The primitive tree is light_tree.zig:520-720 (PrimitiveTree: split depth 6,
+ * no infinite lights), stored in the scene tree's layout. */
+typedef struct ZygpuMeshLight {
+    const uint32_t* triangle_mapping; /* part-local triangle -> triangle of the mesh (leaf order) */
+    const float*    tri_props;        /* 8 per part-local triangle: centre.xyz, radius, normal.xyz, relative power
+                                         (MeshImpl.lightProperties, shape_sampler.zig:199-223) */
+    ZygpuLightTree  tree;
+    uint32_t mesh;
+    uint32_t part;
+    uint32_t num_triangles;
+    uint32_t two_sided;
+} ZygpuMeshLight;
 
 /* top-level BVH over props (reference src/core/scene/prop/prop_tree.zig:22-27) */
 typedef struct ZygpuPropTree {
@@ -207,6 +224,7 @@ typedef struct ZygpuSceneDesc {
     ZygpuPropTree        solid;       /* finite occluding props (scene.zig:77) */
     ZygpuPropTree        unoccluding; /* finite, purely emissive `Light` entities (scene.zig:78) */
     ZygpuLightTree       light_tree;
+    const ZygpuMeshLight* mesh_lights;
     ZygpuLuts            luts;
     float    specular_threshold; /* resources.specular_threshold (resource/manager.zig:57) */
     uint32_t num_props;
@@ -214,6 +232,7 @@ typedef struct ZygpuSceneDesc {
     uint32_t num_meshes;
     uint32_t num_materials;
     uint32_t num_lights;
+    uint32_t num_mesh_lights;
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };

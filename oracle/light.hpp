@@ -88,9 +88,12 @@ inline float importance(V4 p, V4 n, V4 center, V4 cone, float radius, float powe
     return mx(ra * rb * rc, 0.f);
 }
 
+// The scene's tree over lights, or (ml set) the primitive tree over the emissive triangles of one mesh part
+// (light_tree.zig:520-720: same traversal, split depth 6, no infinite lights, properties from shape_sampler.zig:199-223).
 struct LightTreeView {
     const ZygpuSceneDesc* d;
-    const ZygpuLightTree& t() const { return d->light_tree; }
+    const ZygpuMeshLight* ml = nullptr;
+    const ZygpuLightTree& t() const { return ml ? ml->tree : d->light_tree; }
 
     static bool     hasChildren(const ZygpuLightNode& n) { return 0 != (n.meta & 1u); }
     static bool     nodeTwoSided(const ZygpuLightNode& n) { return 0 != (n.meta & 2u); }
@@ -127,6 +130,10 @@ struct LightTreeView {
     }
 
     float lightWeight(V4 p, V4 n, bool total_sphere, uint32_t light) const {  // :229-235
+        if (ml) {
+            const float* q = ml->tri_props + size_t(light) * 8;
+            return importance(p, n, mk(q[0], q[1], q[2], q[3]), mk(q[4], q[5], q[6], 1.f), q[3], q[7], 0 != ml->two_sided, total_sphere);
+        }
         const LightProps lp = lightProperties(*d, light);
         return importance(p, n, lp.sphere, lp.cone, lp.sphere[3], lp.power, lp.two_sided, total_sphere);
     }
@@ -399,6 +406,172 @@ inline float rectanglePdf(V4 p, const Trafo& frag_trafo, float split_threshold, 
     const V4      lp = frag_trafo.worldToFramePoint(p);
     const SphQuad squad = SphQuad::init(scale, lp);
     return nsf * squad.pdf(scale);
+}
+
+// ---------- TriangleMesh lights: triangle_mesh.zig:391-703 ----------
+
+inline V4 orthogonalize(V4 a, V4 b) { return normalize3(fma4(S(-dot3(a, b)), a, b)); }  // a is normalised (391-394)
+
+struct SphericalSample {
+    V4    dir;
+    float u, v, pdf;
+};
+
+// triangle.zig:82-100
+inline void barycentricCoords(V4 dir, V4 a, V4 b, V4 c, float& u, float& v) {
+    const V4    e1 = b - a, e2 = c - a, tvec = -a;
+    const V4    pvec = cross3(dir, e2), qvec = cross3(tvec, e1);
+    const float e1_d_pv = dot3(e1, pvec), tv_d_pv = dot3(tvec, pvec), di_d_qv = dot3(dir, qvec);
+    const float inv_det = 1.f / e1_d_pv;
+    u = tv_d_pv * inv_det;
+    v = di_d_qv * inv_det;
+}
+
+// Stratified Sampling of Spherical Triangles, James Arvo (triangle_mesh.zig:402-459)
+inline bool sampleSpherical(V4 pos, V4 pa, V4 pb, V4 pc, float r0, float r1, SphericalSample& out) {
+    const V4 pap = pa - pos, pbp = pb - pos, pcp = pc - pos;
+    const V4 A = normalize3(pap), B = normalize3(pbp), C = normalize3(pcp);
+    const V4 BA = orthogonalize(A, B - A), CA = orthogonalize(A, C - A);
+    const V4 AB = orthogonalize(B, A - B), CB = orthogonalize(B, C - B);
+    const V4 BC = orthogonalize(C, B - C), AC = orthogonalize(C, A - C);
+    const float cos_alpha = clampf(dot3(BA, CA), -1.f, 1.f);
+    const float alpha = acosF(cos_alpha);
+    const float beta = acosF(clampf(dot3(AB, CB), -1.f, 1.f));
+    const float gamma = acosF(clampf(dot3(BC, AC), -1.f, 1.f));
+    const float sarea = alpha + beta + gamma - kPi;
+    if (0.f == sarea) return false;
+    const float cos_c = clampf(dot3(A, B), -1.f, 1.f);
+    const float area_S = r0 * sarea;
+    const float angle_delta = area_S - alpha;
+    const float p = sinF(angle_delta), q = cosF(angle_delta);
+    const float sin_alpha = std::sqrt(1.f - cos_alpha * cos_alpha);
+    const float u = q - cos_alpha, v = p + sin_alpha * cos_c;
+    const float s = clampf(((v * q - u * p) * cos_alpha - v) / ((v * p + u * q) * sin_alpha), -1.f, 1.f);
+    const V4    C_s = S(s) * A + S(std::sqrt(1.f - s * s)) * orthogonalize(A, C);
+    const float cs_b = dot3(C_s, B);
+    const float z = 1.f - r1 * (1.f - cs_b);
+    const V4    P = S(z) * B + S(std::sqrt(1.f - z * z)) * orthogonalize(B, C_s);
+    out.dir = P;
+    barycentricCoords(P, pap, pbp, pcp, out.u, out.v);
+    out.pdf = 1.f / sarea;
+    return true;
+}
+
+inline float pdfSpherical(V4 pos, V4 pa, V4 pb, V4 pc) {  // triangle_mesh.zig:461-485
+    const V4 A = normalize3(pa - pos), B = normalize3(pb - pos), C = normalize3(pc - pos);
+    const V4 BA = orthogonalize(A, B - A), CA = orthogonalize(A, C - A);
+    const V4 AB = orthogonalize(B, A - B), CB = orthogonalize(B, C - B);
+    const V4 BC = orthogonalize(C, B - C), AC = orthogonalize(C, A - C);
+    const float alpha = acosF(clampf(dot3(BA, CA), -1.f, 1.f));
+    const float beta = acosF(clampf(dot3(AB, CB), -1.f, 1.f));
+    const float gamma = acosF(clampf(dot3(BC, AC), -1.f, 1.f));
+    const float sarea = alpha + beta + gamma - kPi;
+    return 1.f / sarea;
+}
+
+inline void triangleUniform(float u0, float u1, float& x, float& y) {  // sampling.zig:39-47 (Heitz)
+    if (u1 > u0) {
+        x = 0.5f * u0;
+        y = u1 - x;
+    } else {
+        y = 0.5f * u1;
+        x = u0 - y;
+    }
+}
+
+constexpr float kAreaDistanceRatio = 0.001f;  // triangle_mesh.zig:487
+
+// Mesh.sampleTo (triangle_mesh.zig:489-597): the part's primitive tree picks triangles (one 1-D draw), every picked
+// triangle takes one 2-D draw: solid-angle sampling when the triangle is large for its distance, area sampling else
+inline uint32_t meshSampleTo(const ZygpuSceneDesc& d, const ZygpuMeshLight& ml, V4 p, V4 n, const Trafo& trafo, bool two_sided,
+                             bool total_sphere, float split_threshold, Sampler& sampler, SampleTo* buffer) {
+    const ZygpuMesh& mesh = d.meshes[ml.mesh];
+    const MeshView   mv{&mesh};
+    const V4         op = trafo.worldToObjectPoint(p), on = trafo.worldToObjectNormal(n);
+    const V4         scale = trafo.scale();
+    const V4         scale_squared = scale * scale;
+
+    LightPick           picks[64];
+    const LightTreeView tree{&d, &ml};
+    const uint32_t      num_picks = tree.randomLight(op, on, total_sphere, sampler.sample1D(), split_threshold, picks);
+
+    uint32_t current_sample = 0;
+    for (uint32_t i = 0; i < num_picks; ++i) {
+        const LightPick& s = picks[i];
+        const uint32_t   global = ml.triangle_mapping[s.offset];
+        const uint32_t*  tri = mesh.triangles + size_t(global) * 3;
+        const V4         a = mv.position(tri[0]), b = mv.position(tri[1]), c = mv.position(tri[2]);
+        const V4         e1 = b - a, e2 = c - a;
+        const V4         cross_axis = cross3(e1, e2);
+        const V4         ca = scale_squared * cross_axis;
+        const float      lca = length3(ca);
+        const V4         sn = ca / S(lca);
+        V4               wn = trafo.objectToWorldNormal(sn);
+        const float      tri_area = 0.5f * lca;
+        const V4         center = (a + b + c) / S(3.f);
+
+        V4    dir, v;
+        float bu, bv, sample_pdf, n_dot_dir;
+        float r2[2];
+        if (tri_area / distance3(center, op) > kAreaDistanceRatio) {
+            sampler.sample2D(r2);
+            SphericalSample ss;
+            if (!sampleSpherical(op, a, b, c, r2[0], r2[1], ss)) continue;
+            if (dot3(ss.dir, on) <= 0.f && !total_sphere) continue;
+            bu = ss.u;
+            bv = ss.v;
+            dir = trafo.objectToWorldNormal(ss.dir);
+            v = trafo.objectToWorldPoint(interpolate3(a, b, c, bu, bv));
+            sample_pdf = s.pdf * ss.pdf;
+            if (two_sided && dot3(wn, dir) > 0.f) wn = -wn;
+            n_dot_dir = -dot3(wn, dir);
+        } else {
+            sampler.sample2D(r2);
+            triangleUniform(r2[0], r2[1], bu, bv);
+            v = trafo.objectToWorldPoint(interpolate3(a, b, c, bu, bv));
+            const V4    axis = v - p;
+            const float sl = squaredLength3(axis);
+            const float dd = std::sqrt(sl);
+            dir = axis / S(dd);
+            if (dot3(dir, n) <= 0.f && !total_sphere) continue;
+            if (two_sided && dot3(wn, dir) > 0.f) wn = -wn;
+            n_dot_dir = -dot3(wn, dir);
+            sample_pdf = (s.pdf * sl) / (n_dot_dir * tri_area);
+        }
+        if (n_dot_dir < kDotMin) continue;
+
+        float tc[2];
+        interpolate2(mesh.uvs + size_t(tri[0]) * 2, mesh.uvs + size_t(tri[1]) * 2, mesh.uvs + size_t(tri[2]) * 2, bu, bv, tc);
+        SampleTo& out = buffer[current_sample++];
+        out.p = mk(v[0], v[1], v[2], sample_pdf);
+        out.n = wn;
+        out.wi = dir;
+        out.uvw = mk(tc[0], tc[1], 0.f, 0.f);
+    }
+    return current_sample;
+}
+
+// Mesh.pdf (triangle_mesh.zig:647-691): the density sampleTo would have had for the triangle a ray hit
+inline float meshPdf(const ZygpuSceneDesc& d, const ZygpuMeshLight& ml, V4 dir, V4 p, V4 n, const Fragment& frag, bool total_sphere,
+                     float split_threshold) {
+    const ZygpuMesh& mesh = d.meshes[ml.mesh];
+    const MeshView   mv{&mesh};
+    const Trafo&     trafo = frag.isec.trafo;
+    const float      n_dot_dir = std::fabs(dot3(frag.geo_n, dir));
+    const V4         op = trafo.worldToObjectPoint(p), on = trafo.worldToObjectNormal(n);
+    const uint32_t   pm = mesh.primitive_mapping[frag.isec.primitive];
+    const float      tri_pdf = LightTreeView{&d, &ml}.pdf(op, on, total_sphere, split_threshold, pm);
+
+    const uint32_t* tri = mesh.triangles + size_t(frag.isec.primitive) * 3;
+    const V4        a = mv.position(tri[0]), b = mv.position(tri[1]), c = mv.position(tri[2]);
+    const V4        cross_axis = cross3(b - a, c - a);
+    const V4        scale = trafo.scale();
+    const V4        ca = (scale * scale) * cross_axis;
+    const float     tri_area = 0.5f * length3(ca);
+    const V4        center = (a + b + c) / S(3.f);
+    if (tri_area / distance3(center, op) > kAreaDistanceRatio) return tri_pdf * pdfSpherical(op, a, b, c);
+    const float sl = squaredDistance3(p, frag.p);
+    return (tri_pdf * sl) / (n_dot_dir * tri_area);
 }
 
 // shape.zig:401-416 (finite shapes)

@@ -143,8 +143,12 @@ struct Worker {
         if (v.state.singular || kNull == light_id) return 1.f;
         const float       select_pdf = rc->lt.pdf(v.origin, v.geo_n, v.state.translucent, v.light_split_threshold, light_id);
         const ZygpuLight& l = rc->scene->lights[light_id];
-        // light.zig:149-157 -> shape.zig:469-492 -> rectangle.zig:554-575
-        const float sample_pdf = rectanglePdf(v.origin, frag.isec.trafo, v.light_split_threshold, l.num_samples);
+        // light.zig:149-157 -> shape.zig:469-492 -> rectangle.zig:554-575 / triangle_mesh.zig:647-691
+        const float sample_pdf =
+            kNull != l.sampler
+                ? meshPdf(*rc->scene, rc->scene->mesh_lights[l.sampler], v.ray.direction, v.origin, v.geo_n, frag, v.state.translucent,
+                          v.light_split_threshold)
+                : rectanglePdf(v.origin, frag.isec.trafo, v.light_split_threshold, l.num_samples);
         return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
     }
 
@@ -285,8 +289,13 @@ struct Worker {
             const ZygpuMaterial& lm = rc->sv.propMaterial(light.prop, light.part);
 
             SampleTo       samples[64];
-            const uint32_t num_samples = rectangleSampleTo(p, n, trafo, 0 != light.two_sided, translucent,
-                                                           mis ? v.light_split_threshold : 0.f, light.num_samples, sampler, samples);
+            const float    sample_threshold = mis ? v.light_split_threshold : 0.f;
+            const uint32_t num_samples =
+                kNull != light.sampler
+                    ? meshSampleTo(*rc->scene, rc->scene->mesh_lights[light.sampler], p, n, trafo, 0 != light.two_sided, translucent,
+                                   sample_threshold, sampler, samples)
+                    : rectangleSampleTo(p, n, trafo, 0 != light.two_sided, translucent, sample_threshold, light.num_samples, sampler,
+                                        samples);
 
             V4 occluded = S(0.f);
             for (uint32_t si = 0; si < num_samples; ++si) {

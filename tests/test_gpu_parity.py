@@ -168,3 +168,18 @@ def test_multi_sample_lights_take_the_in_place_path(engine, oracle):
     """The staged NEE rounds take one sample per pick; a scene with multi-sample lights runs wf_scatter whatever the option."""
     out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS", light_samples=3, nee_in_place=0)
     _check(*out, 2)
+
+
+@pytest.mark.parametrize("integrator,grid", [("PT", 2), ("PTDL", 4), ("PTMIS", 1), ("PTMIS", 4)])
+def test_mesh_lights(engine, oracle, integrator, grid):
+    """TriangleMesh emitters (2 * grid^2 triangles per quad): primitive light tree, Arvo spherical-triangle sampling or area
+    sampling per picked triangle, Mesh.pdf for MIS (triangle_mesh.zig:391-703, light_tree.zig:520-720)."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, mesh_lights=True, light_grid=grid,
+                       unoccluding_lights=False)
+    _check(*out, 3)
+
+
+def test_mesh_lights_with_substitute_and_split(engine, oracle):
+    out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS", mesh_lights=True, light_grid=6, unoccluding_lights=False,
+                       material="substitute", split_threshold=0.8)
+    _check(*out, 2)

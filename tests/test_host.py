@@ -284,3 +284,38 @@ def test_ggx_albedo_tables_match_reference_entries(product_lib):
         np.testing.assert_allclose(got, np.array(g["value"], dtype=np.float32), rtol=0, atol=1e-6, err_msg=name)
         assert np.all((table >= 0.0) & (table <= 1.0)), name
     assert product_lib.su_ext_ggx_lut(9, None, 0) == 0
+
+
+def test_mesh_light_products(engine):
+    """Part.configure / buildPrimitive products for an 8 x 8 emissive quad mesh: mappings are permutations, the relative powers
+    sum to 1, the primitive tree's leaves hold at most 4 triangles and cover every triangle once."""
+    idx, pos, nrm, uv = scenes.quad_mesh(8, 0.5)
+    engine.camera(8, 8)
+    lamp = engine.material(scenes.light_material())
+    p = engine.prop(engine.triangle_mesh(idx, pos, nrm, uv), [lamp])
+    engine.transformation(p, scenes.trafo((1, 0, 0), (0, 0, 1), (1, 1, 1), (0, 1.98, 0)))
+    engine.light(p)
+    sd, _ = engine.compile()
+    assert sd.num_mesh_lights == 1 and sd.lights[0].sampler == 0
+    ml = sd.mesh_lights[0]
+    n = ml.num_triangles
+    assert n == 128
+    mapping = np.array([ml.triangle_mapping[i] for i in range(n)])
+    assert sorted(mapping.tolist()) == list(range(n))
+    props = np.array([ml.tri_props[i] for i in range(8 * n)], dtype=np.float32).reshape(n, 8)
+    np.testing.assert_allclose(props[:, 7].sum(), 1.0, rtol=1e-5)
+    np.testing.assert_allclose(props[:, 4:7], np.tile([[0, 0, 1]], (n, 1)), atol=1e-6)
+    t = ml.tree
+    assert t.max_split_depth == 6 and t.num_lights == n and t.num_infinite_lights == 0
+    seen = []
+    for i in range(t.num_nodes):
+        node = t.nodes[i]
+        if not (node.meta & 1):
+            assert 1 <= node.num_lights <= 4
+            first = node.meta >> 2
+            seen += [t.light_mapping[j] for j in range(first, first + node.num_lights)]
+    assert sorted(seen) == list(range(n))
+    orders = sorted(t.light_orders[i] for i in range(n))
+    assert orders == list(range(n))
+    pm = sd.meshes[ml.mesh].primitive_mapping
+    assert sorted(pm[i] for i in range(n)) == list(range(n))

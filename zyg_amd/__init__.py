@@ -39,7 +39,8 @@ class Mesh(ctypes.Structure):
     _fields_ = [("nodes", ctypes.POINTER(BvhNode)), ("triangles", ctypes.POINTER(ctypes.c_uint32)),
                 ("triangle_parts", ctypes.POINTER(ctypes.c_uint16)), ("positions", ctypes.POINTER(ctypes.c_float)),
                 ("normals", ctypes.POINTER(ctypes.c_uint16)), ("uvs", ctypes.POINTER(ctypes.c_float)),
-                ("part_areas", ctypes.POINTER(ctypes.c_float)), ("num_nodes", ctypes.c_uint32),
+                ("part_areas", ctypes.POINTER(ctypes.c_float)), ("primitive_mapping", ctypes.POINTER(ctypes.c_uint32)),
+                ("num_nodes", ctypes.c_uint32),
                 ("num_triangles", ctypes.c_uint32), ("num_vertices", ctypes.c_uint32), ("num_parts", ctypes.c_uint32)]
 
 
@@ -54,7 +55,7 @@ class Material(ctypes.Structure):
 class Light(ctypes.Structure):
     _fields_ = [("prop", ctypes.c_uint32), ("part", ctypes.c_uint32), ("num_samples", ctypes.c_uint32),
                 ("light_class", ctypes.c_uint8), ("two_sided", ctypes.c_uint8),
-                ("shadow_catcher_light", ctypes.c_uint8), ("prototype", ctypes.c_uint8)]
+                ("shadow_catcher_light", ctypes.c_uint8), ("prototype", ctypes.c_uint8), ("sampler", ctypes.c_uint32)]
 
 
 class LightNode(ctypes.Structure):
@@ -69,6 +70,12 @@ class LightTree(ctypes.Structure):
                 ("infinite_end", ctypes.c_uint32), ("max_split_depth", ctypes.c_uint32),
                 ("num_lights", ctypes.c_uint32), ("num_infinite_lights", ctypes.c_uint32),
                 ("num_nodes", ctypes.c_uint32)]
+
+
+class MeshLight(ctypes.Structure):
+    _fields_ = [("triangle_mapping", ctypes.POINTER(ctypes.c_uint32)), ("tri_props", ctypes.POINTER(ctypes.c_float)),
+                ("tree", LightTree), ("mesh", ctypes.c_uint32), ("part", ctypes.c_uint32),
+                ("num_triangles", ctypes.c_uint32), ("two_sided", ctypes.c_uint32)]
 
 
 class PropTree(ctypes.Structure):
@@ -88,9 +95,10 @@ class SceneDesc(ctypes.Structure):
                 ("meshes", ctypes.POINTER(Mesh)), ("materials", ctypes.POINTER(Material)),
                 ("lights", ctypes.POINTER(Light)), ("light_aabbs", ctypes.POINTER(Aabb)),
                 ("light_cones", ctypes.POINTER(ctypes.c_float)), ("solid", PropTree), ("unoccluding", PropTree),
-                ("light_tree", LightTree), ("luts", Luts), ("specular_threshold", ctypes.c_float),
+                ("light_tree", LightTree), ("mesh_lights", ctypes.POINTER(MeshLight)), ("luts", Luts),
+                ("specular_threshold", ctypes.c_float),
                 ("num_props", ctypes.c_uint32), ("num_parts", ctypes.c_uint32), ("num_meshes", ctypes.c_uint32),
-                ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32)]
+                ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32), ("num_mesh_lights", ctypes.c_uint32)]
 
 
 class ViewDesc(ctypes.Structure):

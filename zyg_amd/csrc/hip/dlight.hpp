@@ -61,17 +61,18 @@ ZD float importance(f3 p, f3 n, f3 center, f3 cone_axis, float cos_cone, float r
 }
 
 struct LightTree {
-    const DScene& s;
+    const DScene&     s;
+    const DLightTree& t;  // s.light_tree, or a mesh part's primitive tree
 
     ZD static bool     hasChildren(const ZygpuLightNode& n) { return 0 != (n.meta & 1u); }
     ZD static bool     nodeTwoSided(const ZygpuLightNode& n) { return 0 != (n.meta & 2u); }
     ZD static uint32_t childrenOrLight(const ZygpuLightNode& n) { return n.meta >> 2; }
 
     ZD void decompressCenter(const ZygpuLightNode& n, f3& c, float& r) const {  // light_tree.zig:37-40
-        const f3 bmin = xyz(s.lt_bounds_min), bmax = xyz(s.lt_bounds_max);
-        const f3 t = {unorm16ToFloat(n.center[0]), unorm16ToFloat(n.center[1]), unorm16ToFloat(n.center[2])};
-        c = lerp3(bmin, bmax, t);
-        r = lerpf(s.lt_bounds_min.w, s.lt_bounds_max.w, unorm16ToFloat(n.center[3]));
+        const f3 bmin = xyz(t.bounds_min), bmax = xyz(t.bounds_max);
+        const f3 tt = {unorm16ToFloat(n.center[0]), unorm16ToFloat(n.center[1]), unorm16ToFloat(n.center[2])};
+        c = lerp3(bmin, bmax, tt);
+        r = lerpf(t.bounds_min.w, t.bounds_max.w, unorm16ToFloat(n.center[3]));
     }
 
     ZD float nodeWeight(const ZygpuLightNode& n, f3 p, f3 nrm, bool total_sphere) const {
@@ -101,6 +102,10 @@ struct LightTree {
     }
 
     ZD float lightWeight(f3 p, f3 n, bool total_sphere, uint32_t light) const {  // light_tree.zig:229-235; scene.zig:664-676
+        if (t.tri_props) {  // shape_sampler.zig:199-223
+            const float4 c = t.tri_props[2 * light], q = t.tri_props[2 * light + 1];
+            return importance(p, n, xyz(c), xyz(q), 1.f, c.w, q.w, 0 != t.two_sided, total_sphere);
+        }
         const float4 bmin = s.light_aabbs[2 * light], bmax = s.light_aabbs[2 * light + 1];
         const f3     pos = S3(0.5f) * (xyz(bmin) + xyz(bmax));
         const float4 cone = s.light_cones[light];
@@ -110,18 +115,18 @@ struct LightTree {
     ZD LightPick nodeRandomLight(const ZygpuLightNode& node, f3 p, f3 n, bool total_sphere, float random) const {  // :90-147
         const uint32_t num_lights = node.num_lights;
         const uint32_t light = childrenOrLight(node);
-        if (1 == num_lights) return {s.lt_mapping[light], 1.f};
+        if (1 == num_lights) return {t.mapping[light], 1.f};
 
         uint32_t front = light, back = light + num_lights - 1;
-        float    w_front = lightWeight(p, n, total_sphere, s.lt_mapping[front]);
-        float    w_back = lightWeight(p, n, total_sphere, s.lt_mapping[back]);
+        float    w_front = lightWeight(p, n, total_sphere, t.mapping[front]);
+        float    w_back = lightWeight(p, n, total_sphere, t.mapping[back]);
         float    w_sum_front = w_front, w_sum_back = w_back, w_sum = 0.f;
         while (front != back) {
             w_sum = w_sum_front + w_sum_back;
             if (w_sum_front <= random * w_sum) {
                 front += 1;
                 if (front != back) {
-                    w_front = lightWeight(p, n, total_sphere, s.lt_mapping[front]);
+                    w_front = lightWeight(p, n, total_sphere, t.mapping[front]);
                     w_sum_front += w_front;
                 } else {
                     w_front = w_back;
@@ -129,13 +134,13 @@ struct LightTree {
             } else {
                 back -= 1;
                 if (front != back) {
-                    w_back = lightWeight(p, n, total_sphere, s.lt_mapping[back]);
+                    w_back = lightWeight(p, n, total_sphere, t.mapping[back]);
                     w_sum_back += w_back;
                 }
             }
         }
         if (0.f == w_sum) return {0, 0.f};
-        return {s.lt_mapping[front], w_front / w_sum};
+        return {t.mapping[front], w_front / w_sum};
     }
 
     ZD float nodePdf(const ZygpuLightNode& node, f3 p, f3 n, bool total_sphere, uint32_t id) const {  // :149-183
@@ -144,7 +149,7 @@ struct LightTree {
         const uint32_t light = childrenOrLight(node), end = light + num_lights;
         float          w_id = 0.f, sum = 0.f;
         for (uint32_t i = light; i < end; ++i) {
-            const float lw = lightWeight(p, n, total_sphere, s.lt_mapping[i]);
+            const float lw = lightWeight(p, n, total_sphere, t.mapping[i]);
             sum += lw;
             if (id == i) w_id = lw;
         }
@@ -159,11 +164,11 @@ struct LightTree {
         uint32_t   current_light = 0;
         float      ip = 0.f;
         const bool split = split_threshold > 0.f;
-        if (!(split && s.lt_num_infinite < kMaxLightPicks - 1)) ip = s.lt_infinite_weight;
-        if (0 == s.lt_num_nodes) return 0;
+        if (!(split && t.num_infinite < kMaxLightPicks - 1)) ip = t.infinite_weight;
+        if (0 == t.num_nodes) return 0;
 
         const float    pd = 1.f - ip;
-        const uint32_t max_split_depth = s.lt_max_split_depth;
+        const uint32_t max_split_depth = t.max_split_depth;
 
         // traversal stack of at most MaxSplitDepth + 1 entries (light_tree.zig:721-751)
         float    st_pdf[12], st_random[12];
@@ -179,7 +184,7 @@ struct LightTree {
         end = 1;
 
         while (0 != end) {
-            const ZygpuLightNode node = s.lt_nodes[t_node];
+            const ZygpuLightNode node = t.nodes[t_node];
             if (hasChildren(node)) {
                 tm.mark(8);
                 const bool     do_split = t_depth < max_split_depth && nodeSplit(node, p, split_threshold);
@@ -195,8 +200,8 @@ struct LightTree {
                     end += 1;
                 } else {
                     t_depth = max_split_depth;
-                    float       p0 = nodeWeight(s.lt_nodes[c0], p, n, total_sphere);
-                    float       p1 = nodeWeight(s.lt_nodes[c1], p, n, total_sphere);
+                    float       p0 = nodeWeight(t.nodes[c0], p, n, total_sphere);
+                    float       p1 = nodeWeight(t.nodes[c1], p, n, total_sphere);
                     const float pt = p0 + p1;
                     if (0.f == pt) {
                         end -= 1;
@@ -238,28 +243,28 @@ struct LightTree {
 
     // Tree.pdf (light_tree.zig:449-517)
     ZD float pdf(f3 p, f3 n, bool total_sphere, float split_threshold, uint32_t id) const {
-        const uint32_t lo = s.lt_orders[id];
+        const uint32_t lo = t.orders[id];
         const bool     split = split_threshold > 0.f;
-        const bool     split_infinite = split && s.lt_num_infinite < kMaxLightPicks - 1;
-        if (0 == s.lt_num_nodes) return 0.f;
-        const float    ip = split_infinite ? 0.f : s.lt_infinite_weight;
-        const uint32_t max_split_depth = s.lt_max_split_depth;
+        const bool     split_infinite = split && t.num_infinite < kMaxLightPicks - 1;
+        if (0 == t.num_nodes) return 0.f;
+        const float    ip = split_infinite ? 0.f : t.infinite_weight;
+        const uint32_t max_split_depth = t.max_split_depth;
         float          pd = 1.f - ip;
         uint32_t       nid = 0;
         uint32_t       depth = split ? 0u : max_split_depth;
         for (;;) {
-            const ZygpuLightNode node = s.lt_nodes[nid];
+            const ZygpuLightNode node = t.nodes[nid];
             if (hasChildren(node)) {
                 const bool     do_split = depth < max_split_depth && nodeSplit(node, p, split_threshold);
                 const uint32_t c0 = childrenOrLight(node), c1 = c0 + 1;
-                const uint32_t middle = s.lt_middles[nid];
+                const uint32_t middle = t.middles[nid];
                 if (do_split) {
                     depth += 1;
                     nid = lo < middle ? c0 : c1;
                 } else {
                     depth = max_split_depth;
-                    const float p0 = nodeWeight(s.lt_nodes[c0], p, n, total_sphere);
-                    const float p1 = nodeWeight(s.lt_nodes[c1], p, n, total_sphere);
+                    const float p0 = nodeWeight(t.nodes[c0], p, n, total_sphere);
+                    const float p1 = nodeWeight(t.nodes[c1], p, n, total_sphere);
                     const float pt = p0 + p1;
                     if (0.f == pt) return 0.f;
                     if (lo < middle) {
@@ -385,6 +390,145 @@ ZD bool rectangleSampleTo(f3 p, f3 n, const Trafo& trafo, bool two_sided, bool t
 ZD float rectanglePdf(f3 p, const Trafo& frag_trafo, uint32_t num_samples) {  // rectangle.zig:554-575 via shape.zig:469-492
     const SphQuad squad = SphQuad::init(frag_trafo.scale, frag_trafo.worldToFramePoint(p));
     return float(num_samples) * squad.pdf(frag_trafo.scale);
+}
+
+// ---------------------------------------------------------------- TriangleMesh lights (triangle_mesh.zig:391-703)
+
+ZD f3 orthogonalize(f3 a, f3 b) { return normalize3(fma3(S3(-dot3(a, b)), a, b)); }  // a is normalised (391-394)
+
+ZD void barycentricCoords(f3 dir, f3 a, f3 b, f3 c, float& u, float& v) {  // triangle.zig:82-100
+    const f3    e1 = b - a, e2 = c - a, tvec = -a;
+    const f3    pvec = cross3(dir, e2), qvec = cross3(tvec, e1);
+    const float e1_d_pv = dot3(e1, pvec), tv_d_pv = dot3(tvec, pvec), di_d_qv = dot3(dir, qvec);
+    const float inv_det = 1.f / e1_d_pv;
+    u = tv_d_pv * inv_det;
+    v = di_d_qv * inv_det;
+}
+
+// Stratified Sampling of Spherical Triangles, James Arvo (triangle_mesh.zig:402-459)
+ZD bool sampleSpherical(f3 pos, f3 pa, f3 pb, f3 pc, float r0, float r1, f3& dir, float& bu, float& bv, float& pdf) {
+    const f3 pap = pa - pos, pbp = pb - pos, pcp = pc - pos;
+    const f3 A = normalize3(pap), B = normalize3(pbp), C = normalize3(pcp);
+    const f3 BA = orthogonalize(A, B - A), CA = orthogonalize(A, C - A);
+    const f3 AB = orthogonalize(B, A - B), CB = orthogonalize(B, C - B);
+    const f3 BC = orthogonalize(C, B - C), AC = orthogonalize(C, A - C);
+    const float cos_alpha = clampf(dot3(BA, CA), -1.f, 1.f);
+    const float alpha = acosF(cos_alpha);
+    const float beta = acosF(clampf(dot3(AB, CB), -1.f, 1.f));
+    const float gamma = acosF(clampf(dot3(BC, AC), -1.f, 1.f));
+    const float sarea = alpha + beta + gamma - kPi;
+    if (0.f == sarea) return false;
+    const float cos_c = clampf(dot3(A, B), -1.f, 1.f);
+    const float area_S = r0 * sarea;
+    const float angle_delta = area_S - alpha;
+    const float p = sinF(angle_delta), q = cosF(angle_delta);
+    const float sin_alpha = sqrtf(1.f - cos_alpha * cos_alpha);
+    const float u = q - cos_alpha, v = p + sin_alpha * cos_c;
+    const float sc = clampf(((v * q - u * p) * cos_alpha - v) / ((v * p + u * q) * sin_alpha), -1.f, 1.f);
+    const f3    C_s = S3(sc) * A + S3(sqrtf(1.f - sc * sc)) * orthogonalize(A, C);
+    const float cs_b = dot3(C_s, B);
+    const float z = 1.f - r1 * (1.f - cs_b);
+    const f3    P = S3(z) * B + S3(sqrtf(1.f - z * z)) * orthogonalize(B, C_s);
+    dir = P;
+    barycentricCoords(P, pap, pbp, pcp, bu, bv);
+    pdf = 1.f / sarea;
+    return true;
+}
+
+ZD float pdfSpherical(f3 pos, f3 pa, f3 pb, f3 pc) {  // triangle_mesh.zig:461-485
+    const f3 A = normalize3(pa - pos), B = normalize3(pb - pos), C = normalize3(pc - pos);
+    const f3 BA = orthogonalize(A, B - A), CA = orthogonalize(A, C - A);
+    const f3 AB = orthogonalize(B, A - B), CB = orthogonalize(B, C - B);
+    const f3 BC = orthogonalize(C, B - C), AC = orthogonalize(C, A - C);
+    const float alpha = acosF(clampf(dot3(BA, CA), -1.f, 1.f));
+    const float beta = acosF(clampf(dot3(AB, CB), -1.f, 1.f));
+    const float gamma = acosF(clampf(dot3(BC, AC), -1.f, 1.f));
+    const float sarea = alpha + beta + gamma - kPi;
+    return 1.f / sarea;
+}
+
+ZD void triangleUniform(float u0, float u1, float& x, float& y) {  // sampling.zig:39-47 (Heitz)
+    if (u1 > u0) {
+        x = 0.5f * u0;
+        y = u1 - x;
+    } else {
+        y = 0.5f * u1;
+        x = u0 - y;
+    }
+}
+
+constexpr float kAreaDistanceRatio = 0.001f;  // triangle_mesh.zig:487
+
+// The object-space set-up of Mesh.sampleTo (triangle_mesh.zig:505-511) and its per-triangle body (518-592): one 2-D draw
+// (r0, r1) per picked triangle; solid-angle sampling when the triangle is large for its distance, area sampling else.
+struct MeshLightSampler {
+    f3 op, on, scale_squared;
+
+    ZD static MeshLightSampler init(f3 p, f3 n, const Trafo& trafo) {
+        return {trafo.worldToObjectPoint(p), trafo.worldToObjectNormal(n), trafo.scale * trafo.scale};
+    }
+
+    ZD bool sample(const DMesh& mesh, const DMeshLight& ml, LightPick tri, float r0, float r1, f3 p, f3 n, const Trafo& trafo,
+                   bool two_sided, bool total_sphere, SampleTo& out) const {
+        const uint32_t global = ml.triangle_mapping[tri.offset];
+        const f3       a = xyz(mesh.tri_verts[3 * global]), b = xyz(mesh.tri_verts[3 * global + 1]), c = xyz(mesh.tri_verts[3 * global + 2]);
+        const f3       cross_axis = cross3(b - a, c - a);
+        const f3       ca = scale_squared * cross_axis;
+        const float    lca = length3(ca);
+        const f3       sn = ca / S3(lca);
+        f3             wn = trafo.objectToWorldNormal(sn);
+        const float    tri_area = 0.5f * lca;
+        const f3       center = (a + b + c) / S3(3.f);
+
+        f3    dir, v;
+        float bu, bv, sample_pdf, n_dot_dir;
+        if (tri_area / distance3(center, op) > kAreaDistanceRatio) {
+            f3    sdir;
+            float spdf;
+            if (!sampleSpherical(op, a, b, c, r0, r1, sdir, bu, bv, spdf)) return false;
+            if (dot3(sdir, on) <= 0.f && !total_sphere) return false;
+            dir = trafo.objectToWorldNormal(sdir);
+            v = trafo.objectToWorldPoint(interpolate3(a, b, c, bu, bv));
+            sample_pdf = tri.pdf * spdf;
+            if (two_sided && dot3(wn, dir) > 0.f) wn = -wn;
+            n_dot_dir = -dot3(wn, dir);
+        } else {
+            triangleUniform(r0, r1, bu, bv);
+            v = trafo.objectToWorldPoint(interpolate3(a, b, c, bu, bv));
+            const f3    axis = v - p;
+            const float sl = squaredLength3(axis);
+            const float dd = sqrtf(sl);
+            dir = axis / S3(dd);
+            if (dot3(dir, n) <= 0.f && !total_sphere) return false;
+            if (two_sided && dot3(wn, dir) > 0.f) wn = -wn;
+            n_dot_dir = -dot3(wn, dir);
+            sample_pdf = (tri.pdf * sl) / (n_dot_dir * tri_area);
+        }
+        if (n_dot_dir < kDotMin) return false;
+        out.p = v;
+        out.n = wn;
+        out.wi = dir;
+        out.pdf = sample_pdf;
+        return true;
+    }
+};
+
+// Mesh.pdf (triangle_mesh.zig:647-691): the density sampleTo would have had for the triangle a ray hit
+ZD float meshLightPdf(const DScene& s, const DMeshLight& ml, f3 dir, f3 p, f3 n, const Trafo& trafo, f3 frag_p, f3 frag_geo_n,
+                      uint32_t primitive, bool total_sphere, float split_threshold) {
+    const DMesh&    mesh = s.meshes[ml.mesh];
+    const float     n_dot_dir = fabsf(dot3(frag_geo_n, dir));
+    const f3        op = trafo.worldToObjectPoint(p), on = trafo.worldToObjectNormal(n);
+    const uint32_t  pm = mesh.primitive_mapping[primitive];
+    const LightTree tree{s, ml.tree};
+    const float     tri_pdf = tree.pdf(op, on, total_sphere, split_threshold, pm);
+    const f3        a = xyz(mesh.tri_verts[3 * primitive]), b = xyz(mesh.tri_verts[3 * primitive + 1]), c = xyz(mesh.tri_verts[3 * primitive + 2]);
+    const f3        ca = (trafo.scale * trafo.scale) * cross3(b - a, c - a);
+    const float     tri_area = 0.5f * length3(ca);
+    const f3        center = (a + b + c) / S3(3.f);
+    if (tri_area / distance3(center, op) > kAreaDistanceRatio) return tri_pdf * pdfSpherical(op, a, b, c);
+    const float sl = squaredLength3(p - frag_p);
+    return (tri_pdf * sl) / (n_dot_dir * tri_area);
 }
 
 // shape.zig:401-416

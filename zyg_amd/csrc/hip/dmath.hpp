@@ -215,6 +215,7 @@ struct Trafo {
     ZD f3 frameToWorldPoint(f3 p) const { return transformVector(p) + position; }
     ZD f3 worldToObjectVector(f3 v) const { return transformVectorTransposed(v) / scale; }
     ZD f3 worldToObjectPoint(f3 p) const { return worldToObjectVector(p - position); }
+    ZD f3 worldToObjectNormal(f3 n) const { return transformVectorTransposed(n); }
     ZD f3 worldToFramePoint(f3 p) const { return transformVectorTransposed(p - position); }
 };
 

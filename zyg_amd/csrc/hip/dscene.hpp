@@ -29,6 +29,27 @@ struct DMesh {
     const uint16_t* normals;
     const float*    uvs;
     const float*    part_areas;
+    const uint32_t* primitive_mapping;  // triangle -> index within its part; set when a part is a light
+};
+
+// what a light-tree walk reads: the scene's tree over lights, or the primitive tree of one emissive mesh part
+// (ZygpuMeshLight; light_tree.zig:520-720), whose leaves are triangles described by tri_props
+struct DLightTree {
+    const ZygpuLightNode* nodes;
+    const uint32_t*       middles;
+    const uint32_t*       orders;
+    const uint32_t*       mapping;
+    const float4*         tri_props;  // mesh part: 2 per triangle (centre.xyz, radius) (normal.xyz, relative power); scene: null
+    float4                bounds_min, bounds_max;
+    float                 infinite_weight;
+    uint32_t              max_split_depth, num_nodes, num_infinite;
+    uint32_t              two_sided;  // mesh part only
+};
+
+struct DMeshLight {
+    DLightTree      tree;
+    const uint32_t* triangle_mapping;
+    uint32_t        mesh, part;
 };
 
 struct DScene {
@@ -46,13 +67,8 @@ struct DScene {
     const uint32_t*      solid_indices;
     const float4*        unocc_nodes;
     const uint32_t*      unocc_indices;
-    const ZygpuLightNode* lt_nodes;
-    const uint32_t*      lt_middles;
-    const uint32_t*      lt_orders;
-    const uint32_t*      lt_mapping;
-    float4               lt_bounds_min, lt_bounds_max;
-    float                lt_infinite_weight;
-    uint32_t             lt_max_split_depth, lt_num_nodes, lt_num_infinite;
+    DLightTree           light_tree;
+    const DMeshLight*    mesh_lights;
     const float*         lut_e_m;
     const float*         lut_e_m_avg;
     const float*         lut_e;

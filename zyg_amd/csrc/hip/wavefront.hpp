@@ -491,24 +491,33 @@ struct VertexIn {  // what connectLight needs of the previous vertex (vertex.zig
     uint32_t flags, depth_surface;
 };
 
-// Scene.lightPdf (scene.zig:624-634)
-ZD float lightPdf(const DScene& s, const VertexIn& v, const Fragment& frag) {
+// Scene.lightPdf (scene.zig:624-634); MESHL: the scene has TriangleMesh lights
+template <bool MESHL>
+ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fragment& frag) {
     const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
     if ((v.flags & ST_SINGULAR) || kNull == light_id) return 1.f;
-    const LightTree lt{s};
-    const float     select_pdf = lt.pdf(v.vorigin, v.vgeo_n, 0 != (v.flags & ST_TRANSLUCENT), v.light_split_threshold, light_id);
-    // light.zig:149-157 -> shape_sampler.zig:35-41: the light's sample count under the previous vertex's split threshold
-    const float     sample_pdf = rectanglePdf(v.vorigin, frag.trafo, numSamples(s.lights[light_id].num_samples, v.light_split_threshold));
+    const LightTree  lt{s, s.light_tree};
+    const bool       translucent = 0 != (v.flags & ST_TRANSLUCENT);
+    const float      select_pdf = lt.pdf(v.vorigin, v.vgeo_n, translucent, v.light_split_threshold, light_id);
+    const ZygpuLight light = s.lights[light_id];
+    float            sample_pdf;
+    if (MESHL && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
+        sample_pdf = meshLightPdf(s, s.mesh_lights[light.sampler], ray_direction, v.vorigin, v.vgeo_n, frag.trafo, frag.p, frag.geo_n,
+                                  frag.primitive, translucent, v.light_split_threshold);
+    } else {  // -> rectangle.zig:554-575, with the light's sample count under the previous vertex's split threshold
+        sample_pdf = rectanglePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
+    }
     return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
 }
 
 // Vertex.evaluateRadiance (vertex.zig:183-212)
+template <bool MESHL>
 ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment& frag, Sampler& smp) {
     const ZygpuMaterial& m = s.materials[s.material_ids[s.props[frag.prop].parts_start + frag.part]];
     if (!(m.flags & ZYGPU_MATF_EMISSIVE) || (!(m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo))) return S3(0.f);
     (void)smp.sample1D();  // rs.stochastic_r
     const f3    energy = materialRadiance(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface);
-    const float weight = lightPdf(s, v, frag);
+    const float weight = lightPdf<MESHL>(s, v, -wo, frag);
     return S3(weight) * energy;
 }
 
@@ -527,12 +536,12 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, const
         frag.v = __uint_as_float(c.w);
         frag.primitive = 0;
         rectangleFragment(ray, frag);
-        energy = energy + evaluateRadiance(s, v, wo, frag, smp);
+        energy = energy + evaluateRadiance<false>(s, v, wo, frag, smp);  // candidates are Rectangles
     }
     return energy;
 }
 
-template <bool STATS>
+template <bool STATS, bool MESHL>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Params P) {
     const DScene&  s = c_scene;
     const uint32_t cur = P.parity;
@@ -579,17 +588,17 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
                 v.light_split_threshold = 0.f;
                 if (ZYGPU_INTEGRATOR_PT == kind) {
                     v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
-                    if (has_hit) energy = evaluateRadiance(s, v, wo, frag, h.smp);
+                    if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
                 } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
                     if (has_hit) {
                         const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
-                        if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance(s, v, wo, frag, h.smp);
+                        if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     }
                     if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
                 } else {
                     v.light_split_threshold = splitThreshold(h.vdepth);
-                    if (has_hit) energy = evaluateRadiance(s, v, wo, frag, h.smp);
+                    if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     tm.mark(1);
                     energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
                     tm.mark(2);
@@ -761,7 +770,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
             if (sf.ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
                 const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
                 const float     select = h.smp.sample1D();
-                const LightTree lt{s};
+                const LightTree lt{s, s.light_tree};
                 const uint32_t  stride = batchPaths();
                 LightPick       first{0, 0.f};
                 NoTimer         tm;
@@ -887,8 +896,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 // traced inside the pick loop, then the bxdf sample and the path extension, in one kernel.  Fewer launches and no state
 // round trips, but every lane waits for the longest pick loop of its wave and the kernel needs ~240 VGPRs.
 // SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
-// MULTI: a light has emittance num_samples > 1
-template <bool STATS, bool SUBST, bool MULTI>
+// MULTI: a light has emittance num_samples > 1; MESHL: the scene has TriangleMesh lights
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     const DScene&      s = c_scene;
     const uint32_t     nxt = P.parity ^ 1u;
@@ -916,39 +925,26 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
         if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
             const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
             const float     select = h.smp.sample1D();
-            const LightTree lt{s};
+            const LightTree lt{s, s.light_tree};
             NoTimer         notimer;
             f3              nee = S3(0.f);
             lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold, [&](uint32_t, LightPick pick) {
                 const ZygpuLight     light = s.lights[pick.offset];
                 const Trafo          trafo = loadTrafo(s, light.prop);
                 const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
-                // shape_sampler.zig:35-41; PathtracerDL samples its lights with threshold 0 (pathtracer_dl.zig:139-167)
-                const uint32_t         n = MULTI ? numSamples(light.num_samples, mis ? nee_threshold : 0.f) : 1u;
-                const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
-                // Rectangle.sampleTo draws all n light samples before the first shadow test (rectangle.zig:321-352); instead
-                // of buffering them, a copy of the sampler replays those draws while the path's sampler runs ahead
-                Sampler replay = h.smp;
-                if (MULTI) {
-                    for (uint32_t j = 0; j < n; ++j) {
-                        float a, b;
-                        h.smp.sample2D(a, b);
-                    }
-                }
-                f3 occluded = S3(0.f);
-                for (uint32_t j = 0; j < n; ++j) {
-                    float u0, u1;
-                    if (MULTI) replay.sample2D(u0, u1);
-                    else h.smp.sample2D(u0, u1);
-                    SampleTo ls;
-                    if (!rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) continue;
+                // PathtracerDL samples its lights with threshold 0 (pathtracer_dl.zig:139-167)
+                const float sample_threshold = mis ? nee_threshold : 0.f;
+                f3          occluded = S3(0.f);
+
+                // evaluateLight's loop body for one light sample (pathtracer_mis.zig:248-272 / pathtracer_dl.zig:150-166)
+                auto connect = [&](const SampleTo& ls) {
                     const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
                     f3       sdir;
                     float    slen;
                     shadowRay(sorigin, ls, sdir, slen);
                     Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
                     if (STATS) shadow_rays += 1;
-                    if (!sceneVisibility<STATS>(s, shadow, cnt)) continue;
+                    if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
                     const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
                     const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
                     (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
@@ -959,6 +955,47 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
                     } else {
                         const float weight = 1.f / (pick.pdf * ls.pdf);
                         occluded = occluded + S3(weight) * (S3(1.f) * radiance * bx.reflection);
+                    }
+                };
+
+                // A shape's sampleTo draws all of its light samples before the first shadow test (rectangle.zig:321-352,
+                // triangle_mesh.zig:513-592); instead of buffering them, a copy of the sampler replays those draws while
+                // the path's sampler runs ahead to where the post-visibility draws continue.
+                if (MESHL && kNull != light.sampler) {
+                    const DMeshLight&      ml = s.mesh_lights[light.sampler];
+                    const DMesh&           mesh = s.meshes[ml.mesh];
+                    const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
+                    const float            r = h.smp.sample1D();
+                    const LightTree        ptree{s, ml.tree};
+                    Sampler                replay = h.smp;
+                    const uint32_t         npicks =
+                        ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [](uint32_t, LightPick) {});
+                    for (uint32_t j = 0; j < npicks; ++j) {
+                        float a, b;
+                        h.smp.sample2D(a, b);
+                    }
+                    ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [&](uint32_t, LightPick tri) {
+                        float r0, r1;
+                        replay.sample2D(r0, r1);
+                        SampleTo ls;
+                        if (msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
+                    });
+                } else {
+                    const uint32_t         n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
+                    const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
+                    Sampler                replay = h.smp;
+                    if (MULTI) {
+                        for (uint32_t j = 0; j < n; ++j) {
+                            float a, b;
+                            h.smp.sample2D(a, b);
+                        }
+                    }
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float u0, u1;
+                        if (MULTI) replay.sample2D(u0, u1);
+                        else h.smp.sample2D(u0, u1);
+                        SampleTo ls;
+                        if (rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
                     }
                 }
                 nee = nee + occluded;

@@ -221,6 +221,7 @@ struct ZygpuContext {
     bool          stats = false;
     bool          has_substitute = false;  // selects the kernels' material instantiation
     bool          multi_sample_lights = false;  // a light has emittance num_samples > 1: wf_scatter<.., MULTI>
+    bool          mesh_lights = false;          // TriangleMesh emitters: wf_shade<.., MESHL>, wf_scatter<.., MESHL>
     uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     uint64_t      camera_samples = 0;
@@ -242,6 +243,21 @@ uint32_t subCapacity(size_t paths) {
     return uint32_t((blocks + kSubQueues - 1) / kSubQueues * 256);
 }
 size_t queueCapacity(size_t paths) { return size_t(subCapacity(paths)) * kSubQueues; }
+
+bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out) {
+    std::memset(out, 0, sizeof(*out));
+    bool ok = m.upload(lt.nodes, lt.num_nodes, &out->nodes);
+    ok = ok && m.upload(lt.node_middles, lt.num_nodes, &out->middles);
+    ok = ok && m.upload(lt.light_orders, lt.num_lights, &out->orders);
+    ok = ok && m.upload(lt.light_mapping, lt.num_lights, &out->mapping);
+    out->bounds_min = make_float4(lt.bounds.min[0], lt.bounds.min[1], lt.bounds.min[2], lt.bounds.min[3]);
+    out->bounds_max = make_float4(lt.bounds.max[0], lt.bounds.max[1], lt.bounds.max[2], lt.bounds.max[3]);
+    out->infinite_weight = lt.infinite_weight;
+    out->max_split_depth = lt.max_split_depth;
+    out->num_nodes = lt.num_nodes;
+    out->num_infinite = lt.num_infinite_lights;
+    return ok;
+}
 
 int ensurePool(ZygpuContext* c, size_t paths, uint32_t rounds) {
     if (paths <= c->pool_capacity && rounds <= c->pool_rounds) return 0;
@@ -362,15 +378,29 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     std::memset(&s, 0, sizeof(s));
 
     c->multi_sample_lights = false;
+    c->mesh_lights = false;
     for (uint32_t l = 0; l < d->num_lights; ++l) {
         if (d->lights[l].num_samples > 64) {  // shape.zig:44 MaxSamples
             g_error = "a light's emittance num_samples exceeds 64";
             return -2;
         }
         if (d->lights[l].num_samples > 1) c->multi_sample_lights = true;
-        if (ZYGPU_SHAPE_RECTANGLE != d->props[d->lights[l].prop].shape) {
-            g_error = "only Rectangle lights are supported on the device path";
+        const ZygpuProp& lp = d->props[d->lights[l].prop];
+        const bool       is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == lp.shape;
+        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh) {
+            g_error = "only Rectangle and TriangleMesh lights are supported on the device path";
             return -2;
+        }
+        if (is_mesh) {
+            if (d->lights[l].sampler >= d->num_mesh_lights) {
+                g_error = "a TriangleMesh light without its ZygpuMeshLight (ZygpuLight.sampler)";
+                return -2;
+            }
+            if (lp.flags & ZYGPU_PROP_UNOCCLUDING) {  // would need TriangleTree.emission (triangle_tree.zig:447) in the walk
+                g_error = "unoccluding TriangleMesh lights are not supported on the device path";
+                return -2;
+            }
+            c->mesh_lights = true;
         }
     }
     for (uint32_t p = 0; p < d->num_props; ++p) {
@@ -397,10 +427,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     ok = ok && m.upload(d->solid.indices, d->solid.num_indices, &s.solid_indices);
     ok = ok && m.upload(reinterpret_cast<const float4*>(d->unoccluding.nodes), size_t(d->unoccluding.num_nodes) * 2, &s.unocc_nodes);
     ok = ok && m.upload(d->unoccluding.indices, d->unoccluding.num_indices, &s.unocc_indices);
-    ok = ok && m.upload(d->light_tree.nodes, d->light_tree.num_nodes, &s.lt_nodes);
-    ok = ok && m.upload(d->light_tree.node_middles, d->light_tree.num_nodes, &s.lt_middles);
-    ok = ok && m.upload(d->light_tree.light_orders, d->light_tree.num_lights, &s.lt_orders);
-    ok = ok && m.upload(d->light_tree.light_mapping, d->light_tree.num_lights, &s.lt_mapping);
+    ok = ok && uploadLightTree(m, d->light_tree, &s.light_tree);
     ok = ok && m.upload(d->luts.e_m, d->luts.e_m ? 32 * 32 : 0, &s.lut_e_m);
     ok = ok && m.upload(d->luts.e_m_avg, d->luts.e_m_avg ? 32 : 0, &s.lut_e_m_avg);
     ok = ok && m.upload(d->luts.e, d->luts.e ? 16 * 16 * 16 : 0, &s.lut_e);
@@ -436,17 +463,29 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         ok = ok && m.upload(hm.normals, size_t(hm.num_vertices) * 2, &dm.normals);
         ok = ok && m.upload(hm.uvs, size_t(hm.num_vertices) * 2, &dm.uvs);
         ok = ok && m.upload(hm.part_areas, hm.num_parts, &dm.part_areas);
+        ok = ok && m.upload(hm.primitive_mapping, hm.primitive_mapping ? hm.num_triangles : 0, &dm.primitive_mapping);
         if (!ok) return -1;
     }
     if (!m.upload(meshes.data(), meshes.size(), &s.meshes)) return -1;
 
-    const ZygpuLightTree& lt = d->light_tree;
-    s.lt_bounds_min = make_float4(lt.bounds.min[0], lt.bounds.min[1], lt.bounds.min[2], lt.bounds.min[3]);
-    s.lt_bounds_max = make_float4(lt.bounds.max[0], lt.bounds.max[1], lt.bounds.max[2], lt.bounds.max[3]);
-    s.lt_infinite_weight = lt.infinite_weight;
-    s.lt_max_split_depth = lt.max_split_depth;
-    s.lt_num_nodes = lt.num_nodes;
-    s.lt_num_infinite = lt.num_infinite_lights;
+    // emissive mesh parts: primitive trees + per-triangle properties
+    std::vector<DMeshLight> mesh_lights(d->num_mesh_lights);
+    for (uint32_t i = 0; i < d->num_mesh_lights; ++i) {
+        const ZygpuMeshLight& hl = d->mesh_lights[i];
+        DMeshLight&           dl = mesh_lights[i];
+        if (hl.mesh >= d->num_meshes || !d->meshes[hl.mesh].primitive_mapping) {
+            g_error = "ZygpuMeshLight: bad mesh index or mesh without primitive_mapping";
+            return -2;
+        }
+        ok = uploadLightTree(m, hl.tree, &dl.tree);
+        ok = ok && m.upload(reinterpret_cast<const float4*>(hl.tri_props), size_t(hl.num_triangles) * 2, &dl.tree.tri_props);
+        ok = ok && m.upload(hl.triangle_mapping, hl.num_triangles, &dl.triangle_mapping);
+        if (!ok) return -1;
+        dl.tree.two_sided = hl.two_sided;
+        dl.mesh = hl.mesh;
+        dl.part = hl.part;
+    }
+    if (!m.upload(mesh_lights.data(), mesh_lights.size(), &s.mesh_lights)) return -1;
     s.specular_threshold = d->specular_threshold;
     s.num_solid_nodes = d->solid.num_nodes;
     s.num_unocc_nodes = d->unoccluding.num_nodes;
@@ -565,15 +604,17 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 else hipLaunchKernelGGL(wf_intersect<false>, grid, block, 0, c->stream, P);
             });
             timedLaunch(c, 1, [&] {
-                if (c->stats) hipLaunchKernelGGL(wf_shade<true>, grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL(wf_shade<false>, grid, block, 0, c->stream, P);
+                if (c->stats) hipLaunchKernelGGL((wf_shade<true, true>), grid, block, 0, c->stream, P);
+                else if (c->mesh_lights) hipLaunchKernelGGL((wf_shade<false, true>), grid, block, 0, c->stream, P);
+                else hipLaunchKernelGGL((wf_shade<false, false>), grid, block, 0, c->stream, P);
             });
-            if (nee && (c->nee_in_place || c->multi_sample_lights)) {  // the staged rounds take one sample per pick
+            if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
-                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true>), grid, block, 0, c->stream, P);
-                    else if (c->multi_sample_lights) hipLaunchKernelGGL((wf_scatter<false, true, true>), grid, block, 0, c->stream, P);
-                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false>), grid, block, 0, c->stream, P);
-                    else hipLaunchKernelGGL((wf_scatter<false, false, false>), grid, block, 0, c->stream, P);
+                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true>), grid, block, 0, c->stream, P);
+                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, true>), grid, block, 0, c->stream, P);
+                    else if (c->multi_sample_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, false>), grid, block, 0, c->stream, P);
+                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false, false>), grid, block, 0, c->stream, P);
+                    else hipLaunchKernelGGL((wf_scatter<false, false, false, false>), grid, block, 0, c->stream, P);
                 });
                 P.parity ^= 1u;
                 continue;
@@ -716,7 +757,7 @@ static int readKernelStats(ZygpuContext* c, ZygpuStats out[ZYGPU_NUM_KERNELS]) {
     HIP_OK(hipMemcpy(&h, c->ctl, sizeof(Control), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(ZygpuStats) * ZYGPU_NUM_KERNELS);
     // traversal happens in wf_intersect, wf_shade and wf_shadow (or wf_scatter, which traces its shadow rays itself)
-    const int where[3] = {0, 1, (c->nee_in_place || c->multi_sample_lights) ? 5 : 3};
+    const int where[3] = {0, 1, (c->nee_in_place || c->multi_sample_lights || c->mesh_lights) ? 5 : 3};
     for (int k = 0; k < 3; ++k) {
         out[where[k]].nodes_fetched = h.k[k].nodes;
         out[where[k]].triangles_tested = h.k[k].tris;

@@ -650,6 +650,119 @@ void Engine::buildPropTree(const std::vector<uint32_t>& indices, std::vector<Zyg
     builder.build(std::move(refs), bounds, nodes, out_indices);
 }
 
+// triangle_mesh.zig:721-749 (Mesh.prepareSampling) + 57-149 (Part.configure), uniform emission, one task
+uint32_t Engine::prepareMeshLight(uint32_t mesh_id, uint32_t part, uint32_t material, bool two_sided) {
+    for (size_t i = 0; i < mesh_lights_.size(); ++i) {
+        const HostMeshLight& ml = mesh_lights_[i];
+        if (ml.mesh == mesh_id && ml.part == part && ml.material == material) return uint32_t(i);
+    }
+    HostMesh&      mesh = meshes_[mesh_id];
+    const uint32_t nt = mesh.numTriangles();
+    if (mesh.primitive_mapping.empty()) {
+        mesh.primitive_mapping.resize(nt);
+        std::vector<uint32_t> per_part(mesh.numParts(), 0);
+        for (uint32_t t = 0; t < nt; ++t) mesh.primitive_mapping[t] = per_part[mesh.triangle_parts[t]]++;
+    }
+
+    mesh_lights_.emplace_back();
+    HostMeshLight& ml = mesh_lights_.back();
+    ml.mesh = mesh_id;
+    ml.part = part;
+    ml.material = material;
+    ml.two_sided = two_sided;
+    for (uint32_t t = 0; t < nt; ++t)
+        if (mesh.triangle_parts[t] == part) ml.triangle_mapping.push_back(t);
+    const uint32_t num = uint32_t(ml.triangle_mapping.size());
+
+    auto tri = [&](uint32_t local, Vec4f& a, Vec4f& b, Vec4f& c) {
+        const uint32_t t = ml.triangle_mapping[local];
+        a = mesh.position(mesh.triangles[3 * t + 0]);
+        b = mesh.position(mesh.triangles[3 * t + 1]);
+        c = mesh.position(mesh.triangles[3 * t + 2]);
+    };
+
+    std::vector<float>     powers(num);
+    std::vector<ZygpuAabb> boxes(num);
+    std::vector<float>     cones(size_t(num) * 4);
+    AABB                   bb = emptyAabb();
+    Vec4f                  dominant_axis = splat(0.f);
+    float                  total_power = 0.f;
+    for (uint32_t i = 0; i < num; ++i) {
+        Vec4f a, b, c;
+        tri(i, a, b, c);
+        const float pow = 0.5f * length3(cross3(b - a, c - a));  // triangle.area; uniform emission: pow = area
+        powers[i] = pow;
+        const Vec4f n = normalize3(cross3(b - a, c - a));
+        const AABB  box = {{min4(a, min4(b, c)), max4(a, max4(b, c))}};
+        for (int k = 0; k < 4; ++k) {
+            boxes[i].min[k] = box.b[0][k];
+            boxes[i].max[k] = box.b[1][k];
+            cones[4 * i + k] = k < 3 ? n[k] : 1.f;
+        }
+        if (pow > 0.f) {
+            dominant_axis = dominant_axis + splat(pow) * n;
+            aabbMerge(bb, box);
+            total_power += pow;
+        }
+    }
+
+    if (dominant_axis[0] == dominant_axis[1] && dominant_axis[1] == dominant_axis[2]) {
+        ml.cone = vec(0.f, 0.f, 1.f, -1.f);
+    } else {
+        const Vec4f da = normalize3(dominant_axis / splat(total_power));
+        float       angle = 0.f;
+        for (uint32_t i = 0; i < num; ++i) angle = fmax_(angle, std::acos(dot3(da, vec(cones[4 * i], cones[4 * i + 1], cones[4 * i + 2]))));
+        ml.cone = vec(da[0], da[1], da[2], std::cos(angle));
+    }
+    ml.aabb = bb;
+
+    // Distribution1D.precomputePdfCdf (base/math/distribution_1d.zig:87-124); pdfI = cdf[i+1] - cdf[i]
+    std::vector<float> cdf(size_t(num) + 1, 0.f);
+    float              integral = 0.f;
+    for (float d : powers) integral += d;
+    std::vector<float> rel(num, 0.f);
+    if (integral > 0.f) {
+        const float ii = 1.f / integral;
+        float       p = 0.f;
+        for (uint32_t i = 0; i + 1 < num; ++i) {
+            const float cc = std::fmaf(powers[i], ii, p);
+            cdf[i + 1] = cc;
+            p = cc;
+        }
+        cdf[num] = 1.f;
+        for (uint32_t i = 0; i < num; ++i) rel[i] = cdf[i + 1] - cdf[i];
+    }
+
+    // MeshImpl.lightProperties (shape_sampler.zig:199-223)
+    ml.tri_props.resize(size_t(num) * 8);
+    for (uint32_t i = 0; i < num; ++i) {
+        Vec4f a, b, c;
+        tri(i, a, b, c);
+        const Vec4f center = (a + b + c) / splat(3.f);
+        const float radius = std::sqrt(fmax_(squaredLength3(a - center), fmax_(squaredLength3(b - center), squaredLength3(c - center))));
+        float*      o = ml.tri_props.data() + size_t(i) * 8;
+        o[0] = center[0];
+        o[1] = center[1];
+        o[2] = center[2];
+        o[3] = radius;
+        o[4] = cones[4 * i + 0];
+        o[5] = cones[4 * i + 1];
+        o[6] = cones[4 * i + 2];
+        o[7] = rel[i];
+    }
+
+    LightTreeInput lin;
+    lin.aabbs = boxes.data();
+    lin.cones = cones.data();
+    lin.two_sided = nullptr;
+    lin.all_two_sided = two_sided;
+    lin.powers = rel.data();  // lightPower = distribution.pdfI (shape_sampler.zig:193-197)
+    lin.num_lights = num;
+    LightTreeBuilder builder;
+    builder.buildPrimitive(lin, bb, ml.cone, integral, ml.tree);  // shape_sampler.power() = distribution.integral
+    return uint32_t(mesh_lights_.size() - 1);
+}
+
 int Engine::compile(uint32_t frame) {
     (void)frame;  // static scenes only: every keyframe-free prop ignores time (space.zig:99-108)
     if (ZYGPU_NULL == camera_entity) return -1;
@@ -672,6 +785,7 @@ int Engine::compile(uint32_t frame) {
         d.normals = m.normals.data();
         d.uvs = m.uvs.data();
         d.part_areas = m.part_areas.data();
+        d.primitive_mapping = nullptr;
         d.num_nodes = uint32_t(m.nodes.size());
         d.num_triangles = m.numTriangles();
         d.num_vertices = m.num_vertices;
@@ -705,6 +819,7 @@ int Engine::compile(uint32_t frame) {
     if (!volume_props_.empty() || !infinite_props_.empty()) return -2;  // out of scope
 
     // lights: scene.zig:402-497 (propPrepareSampling, static branch)
+    mesh_lights_.clear();
     std::fill(light_ids_.begin(), light_ids_.end(), ZYGPU_NULL);
     const uint32_t nl = uint32_t(lights_.size());
     c_light_aabbs_.resize(nl);
@@ -718,20 +833,23 @@ int Engine::compile(uint32_t frame) {
         light_ids_[p] = li;
         const ZygpuMaterial& m = materials_[material_ids_[p]];
 
-        if (ZYGPU_SHAPE_RECTANGLE != s.kind) return -3;  // mesh / sphere / disk emitters: SURVEY §8(f)
+        const bool is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == s.kind;
+        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh) return -3;  // sphere / disk / ... emitters: SURVEY §8(f)
 
         l.num_samples = m.emission_num_samples;  // light_material.zig:68-74 / substitute_material.zig:96-111
         l.two_sided = (m.flags & ZYGPU_MATF_TWO_SIDED) ? 1 : 0;
         c_light_two_sided_[li] = l.two_sided;
+        l.sampler = is_mesh ? prepareMeshLight(s.mesh, l.part, material_ids_[p], 0 != l.two_sided) : ZYGPU_NULL;
 
         const Transformation& t = world_transformations_[l.prop];
         Transformation        rel = t;
         rel.position = t.position - camera_pos;
 
-        AABB bb = aabbTransform(shapeAabb(hp.shape), objectToWorld(rel));
+        // shape_sampler.zig:108-120: a mesh part brings its own box and cone, the analytic shapes use the shape's
+        AABB bb = aabbTransform(is_mesh ? mesh_lights_[l.sampler].aabb : shapeAabb(hp.shape), objectToWorld(rel));
         aabbCacheRadius(bb);
 
-        const Vec4f  part_cone = vec(0.f, 0.f, 1.f, 1.f);  // shape.zig:115-120
+        const Vec4f  part_cone = is_mesh ? mesh_lights_[l.sampler].cone : vec(0.f, 0.f, 1.f, 1.f);  // shape.zig:115-120
         const Mat3x3 rot = quaternionToMat3x3(t.rotation);
         Mat3x3       rot_s = rot;  // rows carry the scale in w, as the reference's ComposedTransformation does
         for (int i = 0; i < 3; ++i) rot_s.r[i][3] = t.scale[i];
@@ -741,7 +859,8 @@ int Engine::compile(uint32_t frame) {
         c_light_cones_[4 * li + 2] = tc[2];
         c_light_cones_[4 * li + 3] = part_cone[3];
 
-        const float extent = t.scale[0] * t.scale[1];  // shape.zig:148 Rectangle area
+        // shape.zig:132-152: Rectangle area, TriangleMesh part area (triangle_mesh.zig:376-380)
+        const float extent = is_mesh ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1]) : t.scale[0] * t.scale[1];
         Vec4f       emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f);
         // emittance.zig:61-71 totalEmission; light.zig:67-77 power (finite shape)
         Vec4f power = splat(0.f);
@@ -779,6 +898,21 @@ int Engine::compile(uint32_t frame) {
     d.unoccluding = ZygpuPropTree{unoccluding_nodes_.data(), unoccluding_indices_.data(),
                                   uint32_t(unoccluding_nodes_.size()), uint32_t(unoccluding_indices_.size())};
     d.light_tree = light_tree_.tree;
+    c_mesh_lights_.resize(mesh_lights_.size());
+    for (size_t i = 0; i < mesh_lights_.size(); ++i) {
+        const HostMeshLight& ml = mesh_lights_[i];
+        ZygpuMeshLight&      o = c_mesh_lights_[i];
+        o.triangle_mapping = ml.triangle_mapping.data();
+        o.tri_props = ml.tri_props.data();
+        o.tree = ml.tree.tree;
+        o.mesh = ml.mesh;
+        o.part = ml.part;
+        o.num_triangles = uint32_t(ml.triangle_mapping.size());
+        o.two_sided = ml.two_sided ? 1 : 0;
+        c_meshes_[ml.mesh].primitive_mapping = meshes_[ml.mesh].primitive_mapping.data();
+    }
+    d.mesh_lights = c_mesh_lights_.data();
+    d.num_mesh_lights = uint32_t(c_mesh_lights_.size());
     for (const ZygpuMaterial& m : materials_) {
         if (ZYGPU_MAT_SUBSTITUTE != m.kind) continue;
         const ggxlut::Tables& t = ggxlut::tables();  // computed once per process (ggx_lut.hpp)

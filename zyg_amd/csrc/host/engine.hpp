@@ -10,6 +10,7 @@
 // Output: ZygpuSceneDesc + ZygpuViewDesc (include/zygpu.h) for zygpu_upload_scene / zygpu_set_view.
 #pragma once
 
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ struct HostMesh {
     std::vector<float>        uvs;        // 2 * nv
     std::vector<uint32_t>     part_materials;
     std::vector<float>        part_areas;
+    std::vector<uint32_t>     primitive_mapping;  // triangle -> index within its part; filled when a part becomes a light
     uint32_t                  num_vertices = 0;
 
     uint32_t numTriangles() const { return uint32_t(triangles.size() / 3); }
@@ -44,6 +46,17 @@ struct HostMesh {
         return {{vec(n.min[0], n.min[1], n.min[2], 0.f), vec(n.max[0], n.max[1], n.max[2], 0.f)}};
     }
     Vec4f position(uint32_t i) const { return vec(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2], 0.f); }
+};
+
+// One emissive mesh part prepared for sampling: triangle_mesh.zig:57-149 (Part.configure) + shape_sampler.zig:160-258
+struct HostMeshLight {
+    uint32_t              mesh = 0, part = 0, material = 0;
+    bool                  two_sided = false;
+    std::vector<uint32_t> triangle_mapping;
+    std::vector<float>    tri_props;  // 8 per triangle
+    LightTreeOutput       tree;
+    AABB                  aabb;       // of the emitting triangles, object space
+    Vec4f                 cone;       // power-weighted dominant axis + cos of the widest deviation
 };
 
 struct HostShape {
@@ -153,6 +166,9 @@ class Engine {
     std::vector<ZygpuTrafo>   c_trafos_;
     std::vector<ZygpuAabb>    c_aabbs_;
     std::vector<ZygpuMesh>    c_meshes_;
+    std::deque<HostMeshLight>   mesh_lights_;   // stable addresses: the trees point into their own vectors
+    std::vector<ZygpuMeshLight> c_mesh_lights_;
+    uint32_t prepareMeshLight(uint32_t mesh, uint32_t part, uint32_t material, bool two_sided);
     std::vector<ZygpuAabb>    c_light_aabbs_;
     std::vector<float>        c_light_cones_;
     std::vector<uint8_t>      c_light_two_sided_;

@@ -14,10 +14,12 @@
 namespace zyg {
 
 struct LightTreeInput {
-    const ZygpuAabb* aabbs;   // min[3] = power, max[3] = radius
+    const ZygpuAabb* aabbs;   // scene lights: min[3] = power, max[3] = radius; mesh triangles: plain boxes
     const float*     cones;   // 4 per light
-    const uint8_t*   two_sided;
+    const uint8_t*   two_sided;         // per light, or nullptr with all_two_sided (a mesh part)
     uint32_t         num_lights;
+    const float*     powers = nullptr;  // per light; nullptr: aabbs[l].min[3]
+    bool             all_two_sided = false;
 };
 
 struct LightTreeOutput {
@@ -38,6 +40,8 @@ class LightTreeBuilder {
     void build(const LightTreeInput& in, LightTreeOutput& out) {
         in_ = &in;
         out_ = &out;
+        sweep_threshold_ = SceneSweepThreshold;
+        primitive_ = false;
 
         const uint32_t num_lights = in.num_lights;
         out.light_mapping.resize(num_lights);
@@ -117,6 +121,49 @@ class LightTreeBuilder {
         tree.light_mapping = out.light_mapping.data();
     }
 
+    // light_tree_builder.zig:389-428 (buildPrimitive): the tree over the emissive triangles of one mesh part.
+    // `in` holds per-triangle boxes, (normal, 1) cones and relative powers; the part's own box, cone and power seed the root.
+    void buildPrimitive(const LightTreeInput& in, const AABB& part_bounds, const Vec4f& part_cone, float total_power,
+                        LightTreeOutput& out) {
+        in_ = &in;
+        out_ = &out;
+        sweep_threshold_ = PartSweepThreshold;
+        primitive_ = true;
+
+        const uint32_t num_lights = in.num_lights;
+        out.light_mapping.resize(num_lights);
+        out.light_orders.assign(num_lights, 0);
+        light_order_ = 0;
+        for (uint32_t l = 0; l < num_lights; ++l) out.light_mapping[l] = l;
+
+        ZygpuLightTree& tree = out.tree;
+        std::memset(&tree, 0, sizeof(tree));
+        if (num_lights > 0) {
+            build_nodes_.assign(2 * num_lights - 1, BuildNode{});
+            current_node_ = 1;
+            splitPrimitive(0, 0, num_lights, part_bounds, part_cone, total_power);
+            out.nodes.resize(current_node_);
+            out.node_middles.resize(current_node_);
+            aabbCacheRadius(build_nodes_[0].bounds);
+            serialize(build_nodes_[0].bounds);
+            const AABB& b = build_nodes_[0].bounds;
+            for (int i = 0; i < 4; ++i) {
+                tree.bounds.min[i] = b.b[0][i];
+                tree.bounds.max[i] = b.b[1][i];
+            }
+        }
+        tree.max_split_depth = PrimitiveMaxSplitDepth;
+        tree.num_lights = num_lights;
+        tree.num_nodes = uint32_t(out.nodes.size());
+        tree.nodes = out.nodes.data();
+        tree.node_middles = out.node_middles.data();
+        tree.light_orders = out.light_orders.data();
+        tree.light_mapping = out.light_mapping.data();
+    }
+
+    static constexpr uint32_t PartSweepThreshold = 32;       // light_tree_builder.zig:24
+    static constexpr uint32_t PrimitiveMaxSplitDepth = 6;    // light_tree.zig:523
+
   private:
     struct BuildNode {  // light_tree_builder.zig:27-58
         AABB     bounds;
@@ -153,8 +200,8 @@ class LightTreeBuilder {
         const float* c = in_->cones + 4 * l;
         return vec(c[0], c[1], c[2], c[3]);
     }
-    bool  lightTwoSided(uint32_t l) const { return 0 != in_->two_sided[l]; }
-    float lightPower(uint32_t l) const { return in_->aabbs[l].min[3]; }
+    bool  lightTwoSided(uint32_t l) const { return in_->two_sided ? 0 != in_->two_sided[l] : in_->all_two_sided; }
+    float lightPower(uint32_t l) const { return in_->powers ? in_->powers[l] : in_->aabbs[l].min[3]; }
 
     bool leftSide(const Candidate& c, uint32_t l) const {
         switch (c.kind) {
@@ -227,6 +274,63 @@ class LightTreeBuilder {
         }
     }
 
+    // light_tree_builder.zig:197-266 (evaluateSampler): the side cones come from the power-weighted dominant axis
+    void evaluateSampler(Candidate& c, const uint32_t* lights, uint32_t len, const AABB& bounds, float cone_weight) const {
+        uint32_t num_sides[2] = {0, 0};
+        AABB     boxs[2] = {emptyAabb(), emptyAabb()};
+        Vec4f    dominant_axis[2] = {splat(0.f), splat(0.f)};
+        float    powers[2] = {0.f, 0.f};
+
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t l = lights[i];
+            const float    power = lightPower(l);
+            if (0.f == power) continue;
+            const uint32_t side = leftSide(c, l) ? 0 : 1;
+            num_sides[side] += 1;
+            aabbMerge(boxs[side], lightAabb(l));
+            dominant_axis[side] = dominant_axis[side] + splat(power) * lightCone(l);
+            powers[side] += power;
+        }
+        dominant_axis[0] = normalize3(dominant_axis[0] / splat(powers[0]));
+        dominant_axis[1] = normalize3(dominant_axis[1] / splat(powers[1]));
+
+        float angles[2] = {0.f, 0.f};
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t l = lights[i];
+            if (0.f == lightPower(l)) continue;
+            const uint32_t side = leftSide(c, l) ? 0 : 1;
+            const float    cs = clamp_(dot3(dominant_axis[side], lightCone(l)), -1.f, 1.f);
+            angles[side] = fmax_(angles[side], std::acos(cs));
+        }
+
+        const bool two_sided = in_->all_two_sided;
+        for (int i = 0; i < 2; ++i) {
+            c.aabbs[i] = boxs[i];
+            c.cones[i] = vec(dominant_axis[i][0], dominant_axis[i][1], dominant_axis[i][2], std::cos(angles[i]));
+            c.powers[i] = powers[i];
+            c.two_sided[i] = two_sided;
+        }
+
+        const Vec4f extent = aabbExtent(bounds);
+        const bool  empty_side = 0 == num_sides[0] || 0 == num_sides[1];
+        if (empty_side) {
+            const float reg = hmax3(extent) / hmin3(extent);
+            c.cost = float(len) * reg * (powers[0] + powers[1]);
+            c.exhausted = true;
+        } else {
+            const float surface_area = aabbSurfaceArea(bounds);
+            const float maxe = hmax3(extent);
+            const float reg = Candidate::Axis == c.kind ? maxe / extent[c.axis] : maxe / hmin3(extent);
+            const float cone_weight_a = coneCost(c.cones[0][3], two_sided);
+            const float cone_weight_b = coneCost(c.cones[1][3], two_sided);
+            const float surface_area_a = aabbSurfaceArea(boxs[0]);
+            const float surface_area_b = aabbSurfaceArea(boxs[1]);
+            c.cost = reg * (((powers[0] * cone_weight_a * surface_area_a) + (powers[1] * cone_weight_b * surface_area_b)) /
+                            (surface_area * cone_weight));
+            c.exhausted = false;
+        }
+    }
+
     static Candidate axisCandidate(const Vec4f& p, uint32_t axis) {
         Candidate c{};
         c.kind = Candidate::Axis;
@@ -260,7 +364,7 @@ class LightTreeBuilder {
             for (int i = 0; i < 4; ++i) candidates_.push_back(partitionCandidate(lights[i]));
             for (int i = 1; i < 4; ++i) candidates_.push_back(partitionCandidate(lights[0], lights[i]));
         } else {
-            if (len <= SceneSweepThreshold) {
+            if (len <= sweep_threshold_) {
                 for (uint32_t i = 0; i < len; ++i) {
                     const Vec4f mx = lightAabb(lights[i]).b[1];
                     for (uint32_t a = 0; a < 3; ++a) candidates_.push_back(axisCandidate(mx, a));
@@ -294,7 +398,10 @@ class LightTreeBuilder {
 
         const float cone_weight = coneCost(cone[3], two_sided);
 
-        for (auto& c : candidates_) evaluate(c, lights, len, bounds, cone_weight);
+        for (auto& c : candidates_) {
+            if (primitive_) evaluateSampler(c, lights, len, bounds, cone_weight);
+            else evaluate(c, lights, len, bounds, cone_weight);
+        }
 
         float  min_cost = candidates_[0].cost;
         size_t sc = 0;
@@ -401,6 +508,52 @@ class LightTreeBuilder {
         return c1_end;
     }
 
+    // light_tree_builder.zig:494-541 (splitPrimitive) + 596-620 (assignPrimitive)
+    uint32_t splitPrimitive(uint32_t node_id, uint32_t begin, uint32_t end, const AABB& bounds, const Vec4f& cone, float total_power) {
+        uint32_t*      lights = out_->light_mapping.data() + begin;
+        const uint32_t len = end - begin;
+        const bool     two_sided = in_->all_two_sided;
+
+        auto assign_leaf = [&]() {
+            for (uint32_t i = 0; i < len; ++i) {
+                out_->light_orders[lights[i]] = light_order_;
+                light_order_ += 1;
+            }
+            BuildNode& node = build_nodes_[node_id];
+            node.bounds = bounds;
+            node.cone = cone;
+            node.power = total_power;
+            node.variance = variance(lights, len);
+            node.middle = 0;
+            node.children_or_light = begin;
+            node.num_lights = len;
+            node.two_sided = two_sided;
+            return begin + len;
+        };
+
+        if (len <= 4) return assign_leaf();
+
+        const uint32_t  child0 = current_node_;
+        const Candidate sc = evaluateSplits(lights, len, bounds, cone, two_sided);
+        if (sc.exhausted) return assign_leaf();
+
+        const uint32_t split_node = begin + partition(lights, len, sc);
+        current_node_ += 2;
+        const uint32_t c0_end = splitPrimitive(child0, begin, split_node, sc.aabbs[0], sc.cones[0], sc.powers[0]);
+        const uint32_t c1_end = splitPrimitive(child0 + 1, split_node, end, sc.aabbs[1], sc.cones[1], sc.powers[1]);
+
+        BuildNode& node = build_nodes_[node_id];
+        node.bounds = bounds;
+        node.cone = cone;
+        node.power = total_power;
+        node.variance = variance(lights, len);
+        node.middle = c0_end;
+        node.children_or_light = child0;
+        node.num_lights = len;
+        node.two_sided = two_sided;
+        return c1_end;
+    }
+
     void countPotentialLights(uint32_t node_id, uint32_t depth, uint32_t num_lights[MaxSplitDepth][2]) const {
         const BuildNode& n = build_nodes_[node_id];
         if (!(n.middle > 0)) {
@@ -442,6 +595,8 @@ class LightTreeBuilder {
         }
     }
 
+    uint32_t               sweep_threshold_ = SceneSweepThreshold;
+    bool                   primitive_ = false;  // evaluateSampler instead of evaluateScene
     const LightTreeInput*  in_ = nullptr;
     LightTreeOutput*       out_ = nullptr;
     std::vector<BuildNode> build_nodes_;

@@ -74,6 +74,23 @@ def box_mesh(lo, hi, rot_y_deg=0.0):
             np.asarray(uv, dtype=np.float32))
 
 
+def quad_mesh(n=1, size=1.0):
+    """The Rectangle shape (xy in [-size/2, size/2], normal +z, rectangle.zig:30-62) as an n x n grid of quads, two
+    triangles each, wound so that cross(e1, e2) points along +z like the Rectangle's normal."""
+    xs = np.linspace(-0.5 * size, 0.5 * size, n + 1, dtype=np.float32)
+    gx, gy = np.meshgrid(xs, xs, indexing="xy")
+    pos = np.stack([gx.ravel(), gy.ravel(), np.zeros((n + 1) * (n + 1), dtype=np.float32)], axis=1).astype(np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (pos.shape[0], 1))
+    uv = (pos[:, :2] / size + 0.5).astype(np.float32)
+    tris = []
+    for j in range(n):
+        for i in range(n):
+            a = j * (n + 1) + i
+            b, c, d = a + 1, a + n + 2, a + n + 1
+            tris += [(a, b, c), (a, c, d)]
+    return np.array(tris, dtype=np.uint32), pos, nrm, uv
+
+
 def _value_noise_lattice(n, seed_seq):
     """n x n lattice of PCG32 floats (seed 0, sequence seed_seq), pure numpy-free loop kept tiny."""
     state = 0
@@ -150,10 +167,11 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
-            mesh_material=None):
+            mesh_material=None, mesh_lights=False, light_grid=1):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
+    mesh_lights: the two emissive quads are triangle meshes (2 * light_grid^2 triangles each) instead of Rectangles.
     Returns a dict with prop ids.
     """
     mk = lambert if material == "lambert" else substitute
@@ -189,8 +207,15 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     wall(green, (0, 0, 1), (0, 1, 0), (2, 2, 1), (1, 1, 0))    # right, n = -x
 
     for lx in (-0.45, 0.45):  # two emissive quads just below the ceiling, facing down
-        p = engine.prop(RECTANGLE, [lamp], unoccluding=unoccluding_lights)
-        engine.transformation(p, trafo((1, 0, 0), (0, 0, 1), (0.5, 0.5, 1), (lx, 1.98, 0.0)))
+        if mesh_lights:
+            # the size is baked into the vertices: the reference's mesh-light areas and solid angles only hold for
+            # uniform scales (triangle_mesh.zig:289-292 "HACK", 524-531)
+            idx, pos, nrm, uv = quad_mesh(light_grid, 0.5)
+            p = engine.prop(engine.triangle_mesh(idx, pos, nrm, uv), [lamp], unoccluding=unoccluding_lights)
+            engine.transformation(p, trafo((1, 0, 0), (0, 0, 1), (1, 1, 1), (lx, 1.98, 0.0)))
+        else:
+            p = engine.prop(RECTANGLE, [lamp], unoccluding=unoccluding_lights)
+            engine.transformation(p, trafo((1, 0, 0), (0, 0, 1), (0.5, 0.5, 1), (lx, 1.98, 0.0)))
         engine.light(p)
         ids["lights"].append(p)
 
