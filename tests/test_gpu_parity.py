@@ -183,3 +183,38 @@ def test_mesh_lights_with_substitute_and_split(engine, oracle):
     out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS", mesh_lights=True, light_grid=6, unoccluding_lights=False,
                        material="substitute", split_threshold=0.8)
     _check(*out, 2)
+
+
+def test_full_size_frame_properties_and_slice_parity(engine, oracle):
+    """BASELINE.json configs[1] at its full 1920x1080: size-independent properties of the whole film (every weight equals the
+    sample count, finite, two half-renders equal one full render) and exact parity with the oracle on a slice of rows."""
+    w, h, spp = 1920, 1080, 2
+    scenes.cornell(engine, w, h, spp, integrator="PTMIS")
+    engine.start_frame(0)
+    engine.render_iterations(spp)
+    engine.synchronize()
+    film = engine.download_film(w, h)
+    assert np.isfinite(film).all()
+    assert np.all(film[..., 3] == float(spp))
+    assert film[..., :3].min() >= 0.0 and film[..., :3].max() > 0.0
+
+    engine.start_frame(0)
+    engine.render_iterations(1)
+    engine.render_iterations(1)
+    engine.synchronize()
+    assert np.array_equal(film, engine.download_film(w, h))
+
+    sd = engine.lib.su_ext_scene_desc().contents
+    vd = engine.lib.su_ext_view_desc().contents
+    y0, y1 = 536, 544
+    cpu = oracle_render(oracle, sd, vd, spp, y_range=(y0, y1))
+    assert np.array_equal(film[y0:y1], cpu[y0:y1])
+
+
+def test_million_triangle_mesh(engine, oracle):
+    """BASELINE.json configs[2]'s geometry at full size (999 698 triangles, one Substitute material) on a small frame:
+    BLAS depth, stack use and leaf sizes of a real mesh against the oracle."""
+    mesh = scenes.heightfield_mesh()
+    out = _render_both(engine, oracle, 96, 54, 2, boxes=False, mesh=mesh, mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
+    _check(*out, 2)
+    assert out[2].triangles_tested > 0
