@@ -180,7 +180,7 @@ ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t sub_capacity, b
     uint32_t base = block_base;
     for (uint32_t w = 0; w < wave; ++w) base += wave_count[w];
     if (active) queue[base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)))] = value;
-    __syncthreads();  // wave_count / block_base are reused by the next call
+    // no trailing barrier: every kernel pushes once, so wave_count / block_base are not reused
 }
 
 // Consumer side, called by whole waves at kernel entry: the queue's total length and, for entry i of the
