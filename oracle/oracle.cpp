@@ -180,10 +180,28 @@ struct Worker {
                     if (!SceneView::visible(prop.flags, v.depth_surface)) continue;
                     cnt.instances_tested += 1;
                     if (!aabbIntersect(rc->scene->aabbs[p], v.ray)) continue;
-                    if (ZYGPU_SHAPE_RECTANGLE != prop.shape) continue;  // only rectangle emitters in scope
                     Fragment frag;
                     frag.isec.trafo = rc->sv.propTrafo(p);
                     frag.prop = p;
+                    if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {  // triangle_mesh.zig:379-388 -> triangle_tree.zig:405-483
+                        const ZygpuMesh& mesh = rc->scene->meshes[prop.mesh];
+                        const MeshView   mv{&mesh};
+                        const Ray        local_ray = frag.isec.trafo.worldToObjectRay(v.ray);
+                        meshEmissionWalk(mesh, local_ray, cnt, [&](uint32_t i, float t, float u, float vv) {
+                            frag.isec.t = t;
+                            frag.isec.u = u;
+                            frag.isec.v = vv;
+                            frag.isec.primitive = i;
+                            frag.part = mesh.triangle_parts[i];
+                            const uint32_t* tri = mesh.triangles + size_t(i) * 3;
+                            const V4        a = mv.position(tri[0]), b = mv.position(tri[1]), c = mv.position(tri[2]);
+                            frag.p = frag.isec.trafo.objectToWorldPoint(interpolate3(a, b, c, u, vv));
+                            frag.geo_n = frag.isec.trafo.objectToWorldNormal(normalize3(cross3(b - a, c - a)));
+                            energy += evaluateRadiance(v, frag, sampler);
+                        });
+                        continue;
+                    }
+                    if (ZYGPU_SHAPE_RECTANGLE != prop.shape) continue;
                     float t, u, vv;
                     if (!rectangleIntersect(v.ray, frag.isec.trafo, t, u, vv)) continue;
                     frag.isec.t = t;

@@ -268,6 +268,42 @@ inline bool meshIntersectP(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt)
     return false;
 }
 
+// triangle_tree.zig:405-483 (emission): every triangle the ray crosses inside [min_t, max_t], in traversal order
+template <typename Visit>
+inline void meshEmissionWalk(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt, Visit&& visit) {
+    const MeshView mv{&mesh};
+    NodeStack      stack;
+    uint32_t       n = 0;
+    cnt.nodes_fetched += 1;
+    while (kNull != n) {
+        const ZygpuBvhNode& node = mesh.nodes[n];
+        if (0 != node.count) {
+            for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
+                cnt.triangles_tested += 1;
+                const uint32_t* tri = mesh.triangles + size_t(i) * 3;
+                float           t, u, v;
+                if (triangleIntersect(ray, mv.position(tri[0]), mv.position(tri[1]), mv.position(tri[2]), t, u, v)) visit(i, t, u, v);
+            }
+            n = stack.pop();
+            continue;
+        }
+        uint32_t a = node.children_or_first, b = a + 1;
+        cnt.nodes_fetched += 2;
+        float dista = nodeIntersect(mesh.nodes[a], ray);
+        float distb = nodeIntersect(mesh.nodes[b], ray);
+        if (dista > distb) {
+            std::swap(a, b);
+            std::swap(dista, distb);
+        }
+        if (FLT_MAX == dista) {
+            n = stack.pop();
+        } else {
+            n = a;
+            if (FLT_MAX != distb) stack.push(b);
+        }
+    }
+}
+
 // rectangle.zig:30-62 / 126-152 (intersect and intersectP share the test)
 inline bool rectangleIntersect(const Ray& ray, const Trafo& trafo, float& out_t, float& out_u, float& out_v) {
     const V4    n = trafo.r[2];

@@ -218,3 +218,11 @@ def test_million_triangle_mesh(engine, oracle):
     out = _render_both(engine, oracle, 96, 54, 2, boxes=False, mesh=mesh, mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
     _check(*out, 2)
     assert out[2].triangles_tested > 0
+
+
+@pytest.mark.parametrize("integrator", ["PT", "PTMIS"])
+def test_unoccluding_mesh_lights(engine, oracle, integrator):
+    """`Light` entities (unoccluding, scene.zig:78) whose shape is a TriangleMesh: TriangleTree.emission walks every triangle
+    the ray crosses in front of its hit (triangle_tree.zig:405-483)."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, mesh_lights=True, light_grid=3, unoccluding_lights=True)
+    _check(*out, 3)

@@ -42,6 +42,7 @@ struct Pool {  // SoA of 16 B records, indexed by path slot
     uint32_t* hit_prop;
     uint32_t* ucount;   // unoccluding lights the extension ray crosses in front of its hit (PropBvh.emission's candidates)
     uint4*    ucand;    //   [candidate][slot]: prop, t, u, v (bits), in traversal order
+    uint32_t* ucand_prim; //                    triangle (mesh lights)
     float4*   rec_p;    // compacted hit record: p.xyz, material index (bits)
     float4*   rec_gn;   //   geometric normal after the two-sided flip (vertex.zig:155-161), w = 1 if flipped
     float4*   rec_n;    //   shading normal (flipped likewise)
@@ -413,6 +414,16 @@ template <bool STATS>
 ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, uint32_t depth_surface, const Ray& ray_in, Counters& cnt) {
     uint32_t n = 0;
     Ray      ray = ray_in;
+    auto     record = [&](uint32_t prop, uint32_t primitive, float t, float u, float v) {
+        if (n < kMaxUnoccludingCandidates) {
+            const size_t at = size_t(n) * batchPaths() + slot;
+            P.pool.ucand[at] = make_uint4(prop, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
+            P.pool.ucand_prim[at] = primitive;
+        } else {
+            atomicOr(&P.ctl->error, 2u);  // reported by zygpu_synchronize: more crossed unoccluding emitters than slots
+        }
+        n += 1;
+    };
     bvhWalk<STATS>(s.unocc_nodes, s.num_unocc_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             const uint32_t  p = s.unocc_indices[i];
@@ -420,16 +431,24 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             if (!propVisibleAtDepth(prop.flags, depth_surface)) continue;
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            if (ZYGPU_SHAPE_RECTANGLE != prop.shape) continue;
             const Trafo trafo = loadTrafo(s, p);
-            float       t, u, v;
-            if (!rectangleIntersect(ray, trafo, t, u, v)) continue;
-            if (n < kMaxUnoccludingCandidates) {
-                P.pool.ucand[size_t(n) * batchPaths() + slot] = make_uint4(p, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
-            } else {
-                atomicOr(&P.ctl->error, 2u);  // reported by zygpu_synchronize: more overlapping unoccluding lights than slots
+            if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
+                float t, u, v;
+                if (rectangleIntersect(ray, trafo, t, u, v)) record(p, 0, t, u, v);
+            } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+                // TriangleTree.emission (triangle_tree.zig:405-483): every triangle the ray crosses, no max_t shrinking
+                const DMesh& mesh = s.meshes[prop.mesh];
+                Ray          local = worldToObjectRay(trafo, ray);
+                bvhWalk<STATS>(mesh.nodes, 1u, local, cnt, [&](uint32_t tfirst, uint32_t tcount) {
+                    for (uint32_t k = tfirst, ke = tfirst + tcount; k < ke; ++k) {
+                        if (STATS) cnt.tris += 1;
+                        const f3 a = xyz(mesh.tri_verts[3 * k]), b = xyz(mesh.tri_verts[3 * k + 1]), c = xyz(mesh.tri_verts[3 * k + 2]);
+                        float    t, u, v;
+                        if (triangleIntersect(local, a, b, c, t, u, v)) record(p, k, t, u, v);
+                    }
+                    return false;
+                });
             }
-            n += 1;
         }
         return false;
     });
@@ -522,21 +541,35 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
 }
 
 // the evaluation half of PropBvh.emission: the candidates wf_intersect recorded, in its traversal order
+template <bool MESHL>
 ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, const VertexIn& v, const Ray& ray, Sampler& smp) {
     f3             energy = S3(0.f);
     const uint32_t n = min(P.pool.ucount[slot], kMaxUnoccludingCandidates);
     const f3       wo = -ray.direction;
     for (uint32_t k = 0; k < n; ++k) {
-        const uint4 c = P.pool.ucand[size_t(k) * batchPaths() + slot];
-        Fragment    frag;
+        const size_t    at = size_t(k) * batchPaths() + slot;
+        const uint4     c = P.pool.ucand[at];
+        const ZygpuProp prop = s.props[c.x];
+        Fragment        frag;
         frag.trafo = loadTrafo(s, c.x);
         frag.prop = c.x;
         frag.t_hit = __uint_as_float(c.y);
         frag.u = __uint_as_float(c.z);
         frag.v = __uint_as_float(c.w);
-        frag.primitive = 0;
-        rectangleFragment(ray, frag);
-        energy = energy + evaluateRadiance<false>(s, v, wo, frag, smp);  // candidates are Rectangles
+        if (MESHL && ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+            // the partial fragment TriangleTree.emission fills (triangle_tree.zig:428-447): p, geometric normal, part
+            const DMesh&   mesh = s.meshes[prop.mesh];
+            const uint32_t prim = P.pool.ucand_prim[at];
+            const f3       a = xyz(mesh.tri_verts[3 * prim]), b = xyz(mesh.tri_verts[3 * prim + 1]), cc = xyz(mesh.tri_verts[3 * prim + 2]);
+            frag.primitive = prim;
+            frag.part = mesh.triangle_parts[prim];
+            frag.p = frag.trafo.objectToWorldPoint(interpolate3(a, b, cc, frag.u, frag.v));
+            frag.geo_n = frag.trafo.objectToWorldNormal(normalize3(cross3(b - a, cc - a)));
+        } else {
+            frag.primitive = 0;
+            rectangleFragment(ray, frag);
+        }
+        energy = energy + evaluateRadiance<MESHL>(s, v, wo, frag, smp);
     }
     return energy;
 }
@@ -589,18 +622,18 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
                 if (ZYGPU_INTEGRATOR_PT == kind) {
                     v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
                     if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-                    energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
+                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
                 } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
                     if (has_hit) {
                         const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
                         if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     }
-                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
+                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
                 } else {
                     v.light_split_threshold = splitThreshold(h.vdepth);
                     if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     tm.mark(1);
-                    energy = energy + unoccludingEmission(P, s, slot, v, ray, h.smp);
+                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
                     tm.mark(2);
                 }
             }

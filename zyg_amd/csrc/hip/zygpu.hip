@@ -271,7 +271,7 @@ int ensurePool(ZygpuContext* c, size_t paths, uint32_t rounds) {
     bool           ok = m.alloc(paths, &p.q0) && m.alloc(paths, &p.q1) && m.alloc(paths, &p.pcg) && m.alloc(paths, &p.ray_o) &&
               m.alloc(paths, &p.ray_d) && m.alloc(paths, &p.thr) && m.alloc(paths, &p.vorigin) && m.alloc(paths, &p.vgeo_n) &&
               m.alloc(paths, &p.emission) && m.alloc(paths, &p.direct) && m.alloc(paths, &p.indirect) && m.alloc(paths, &p.hit) &&
-              m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.ucount) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) && m.alloc(paths, &p.rec_n) &&
+              m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.ucount) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) && m.alloc(paths, &p.rec_n) &&
               m.alloc(paths, &p.rec_t) && m.alloc(paths, &p.rec_b) && m.alloc(qcap, &c->queues.ext[0]) &&
               m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) && m.alloc(paths, &c->stage_color) &&
               m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) && m.alloc(paths, &p.sh_o) &&
@@ -394,10 +394,6 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (is_mesh) {
             if (d->lights[l].sampler >= d->num_mesh_lights) {
                 g_error = "a TriangleMesh light without its ZygpuMeshLight (ZygpuLight.sampler)";
-                return -2;
-            }
-            if (lp.flags & ZYGPU_PROP_UNOCCLUDING) {  // would need TriangleTree.emission (triangle_tree.zig:447) in the walk
-                g_error = "unoccluding TriangleMesh lights are not supported on the device path";
                 return -2;
             }
             c->mesh_lights = true;
@@ -661,7 +657,7 @@ int zygpu_synchronize(ZygpuContext* c) {
     HIP_OK(hipMemcpy(&h, c->ctl, sizeof(Control), hipMemcpyDeviceToHost));
     if (h.error) {
         g_error = "device error flags: " + std::to_string(h.error);
-        if (h.error & 2u) g_error += " (a ray crossed more than 4 unoccluding lights in front of its hit: kMaxUnoccludingCandidates)";
+        if (h.error & 2u) g_error += " (a ray crossed more than 4 unoccluding emitters (Rectangles / mesh triangles) in front of its hit: kMaxUnoccludingCandidates)";
         return -3;
     }
     return 0;
