@@ -266,6 +266,7 @@ typedef struct ZygpuViewDesc {
     float    filter_samples[ZYGPU_FILTER_TAPS + 1]; /* normalised table (base/math/interpolated_function.zig) */
     float    clamp_emission, clamp_direct, clamp_indirect; /* sensor.zig:60-70 */
     float    exposure_factor; /* 2^exposure, tonemapper.zig:15 (Linear tonemapper) */
+    uint32_t alpha_transparency; /* sensor buffer class Transparent (take_loader.zig:193-196, buffer_transparent.zig) */
 } ZygpuViewDesc;
 
 /* traversal / path statistics (no reference counterpart; they define the algorithmic bytes of SURVEY §8(d)) */
@@ -316,8 +317,14 @@ int zygpu_film_device_ptr(ZygpuContext* ctx, void** out_ptr, uint64_t* out_num_f
  * Call after zygpu_set_view. */
 int zygpu_set_external_film(ZygpuContext* ctx, void* device_rgbw);
 
-/* resolveTonemap (buffer_opaque.zig:73-79, tonemapper.zig:18-46, Linear): |rgb / w| * exposure -> AP1 -> sRGB,
- * alpha 1; writes min(num_pixels, film pixels) * 4 floats to host memory. */
+/* Transparent sensor (ZygpuViewDesc.alpha_transparency): the second plane of buffer_transparent.zig:11-59, one float per
+ * pixel = sum of weight * alpha (the film's float4 keeps {sum w r, sum w g, sum w b, sum w}).  download returns -1 for
+ * an opaque sensor; an external plane (device pointer, W*H floats) follows the same rules as zygpu_set_external_film. */
+int zygpu_download_film_alpha(ZygpuContext* ctx, float* host_alpha);
+int zygpu_set_external_film_alpha(ZygpuContext* ctx, void* device_alpha);
+
+/* resolveTonemap (buffer_opaque.zig:73-79 / buffer_transparent.zig:84-94, tonemapper.zig:18-46, Linear): |rgb / w| * exposure
+ * -> AP1 -> sRGB; alpha 1, or |sum w alpha / w| for a Transparent sensor; writes min(num_pixels, film pixels) * 4 floats. */
 int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
 
 /* Switches: "kernel_timing" (default 1) records a HIP event pair around every wavefront launch;

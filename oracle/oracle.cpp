@@ -457,6 +457,7 @@ static void gilbertD2xy(int idx, int w, int h, int out[2]) {
 struct Film {
     const ZygpuViewDesc* view;
     float*               pixels;  // {sum w r, sum w g, sum w b, sum w}
+    float*               alpha = nullptr;  // Transparent sensor: sum of w * alpha per pixel (buffer_transparent.zig:46-55)
 
     static V4 clampColor(V4 color, float max) {  // sensor.zig:615-624
         const float mc = hmax3(color);
@@ -486,18 +487,21 @@ struct Film {
     }
     void add(int px, int py, float weight, V4 color, const int bounds[4], const int isolated[4]) {  // sensor.zig:559-574
         if (uint32_t(px - bounds[0]) <= uint32_t(bounds[2]) && uint32_t(py - bounds[1]) <= uint32_t(bounds[3])) {
-            float*   p = pixels + (size_t(view->resolution[0]) * size_t(py) + size_t(px)) * 4;
-            const V4 wc = S(weight) * color;
+            const size_t id = size_t(view->resolution[0]) * size_t(py) + size_t(px);
+            float*       p = pixels + id * 4;
+            const V4     wc = S(weight) * color;
             if (uint32_t(px - isolated[0]) <= uint32_t(isolated[2]) && uint32_t(py - isolated[1]) <= uint32_t(isolated[3])) {
                 p[0] += wc[0];
                 p[1] += wc[1];
                 p[2] += wc[2];
                 p[3] += weight;
+                if (alpha) alpha[id] += wc[3];
             } else {
                 atomicAdd(p + 0, wc[0]);
                 atomicAdd(p + 1, wc[1]);
                 atomicAdd(p + 2, wc[2]);
                 atomicAdd(p + 3, weight);
+                if (alpha) atomicAdd(alpha + id, wc[3]);
             }
         }
     }
@@ -512,8 +516,10 @@ struct Film {
         const int   fr = view->filter_radius_int;
         const float ox = pu - 0.5f, oy = pv - 0.5f;
         if (0 == fr) {
-            float* p = pixels + (size_t(view->resolution[0]) * size_t(y) + size_t(x)) * 4;
-            const V4 wc = S(1.f) * composed;
+            const size_t id = size_t(view->resolution[0]) * size_t(y) + size_t(x);
+            float*       p = pixels + id * 4;
+            const V4     wc = S(1.f) * composed;
+            if (alpha) alpha[id] += wc[3];
             p[0] += wc[0];
             p[1] += wc[1];
             p[2] += wc[2];
@@ -649,9 +655,21 @@ extern "C" {
 // (accumulating).  samples_per_call = 1 is the progressive form every parity run uses (one sample per
 // (pixel, iteration), reseeded as worker.zig:141-149); samples_per_call = n > 1 reproduces the reference's one-shot
 // loop (worker.zig:153-165) for a single call at `iteration` with num_iterations ignored.
+// film_alpha: the Transparent sensor's second plane (one float per pixel), or null for the Opaque sensor
+int zyg_oracle_render_alpha(const ZygpuSceneDesc* scene, const ZygpuViewDesc* view, uint32_t frame, uint32_t iteration,
+                            uint32_t num_iterations, uint32_t samples_per_call, int32_t y_begin, int32_t y_end, float* film_rgbw,
+                            float* film_alpha, int32_t num_threads, ZygpuStats* stats);
+
 int zyg_oracle_render(const ZygpuSceneDesc* scene, const ZygpuViewDesc* view, uint32_t frame, uint32_t iteration,
                       uint32_t num_iterations, uint32_t samples_per_call, int32_t y_begin, int32_t y_end, float* film_rgbw,
                       int32_t num_threads, ZygpuStats* stats) {
+    return zyg_oracle_render_alpha(scene, view, frame, iteration, num_iterations, samples_per_call, y_begin, y_end, film_rgbw, nullptr,
+                                   num_threads, stats);
+}
+
+int zyg_oracle_render_alpha(const ZygpuSceneDesc* scene, const ZygpuViewDesc* view, uint32_t frame, uint32_t iteration,
+                            uint32_t num_iterations, uint32_t samples_per_call, int32_t y_begin, int32_t y_end, float* film_rgbw,
+                            float* film_alpha, int32_t num_threads, ZygpuStats* stats) {
     if (!scene || !view || !film_rgbw) return -1;
     RenderCtx rc{scene, view, SceneView{scene}, LightTreeView{scene}};
 
@@ -672,7 +690,7 @@ int zyg_oracle_render(const ZygpuSceneDesc* scene, const ZygpuViewDesc* view, ui
         w.samplers[1].rng = &w.rng;
     }
 
-    Film film{view, film_rgbw};
+    Film film{view, film_rgbw, film_alpha};
 
     const uint32_t passes = samples_per_call > 1 ? 1 : num_iterations;
     const uint32_t ns = samples_per_call > 1 ? samples_per_call : 1;
@@ -706,7 +724,16 @@ int zyg_oracle_render(const ZygpuSceneDesc* scene, const ZygpuViewDesc* view, ui
 }
 
 // buffer_opaque.zig:73-79 + tonemapper.zig:18-46 (Linear) + aces.zig:19-27
+int zyg_oracle_resolve_alpha(const ZygpuViewDesc* view, const float* film_rgbw, const float* film_alpha, float* out_rgba,
+                             uint32_t num_pixels);
+
 int zyg_oracle_resolve(const ZygpuViewDesc* view, const float* film_rgbw, float* out_rgba, uint32_t num_pixels) {
+    return zyg_oracle_resolve_alpha(view, film_rgbw, nullptr, out_rgba, num_pixels);
+}
+
+// buffer_opaque.zig:73-79 / buffer_transparent.zig:84-94 (resolveTonemap), Linear tonemapper
+int zyg_oracle_resolve_alpha(const ZygpuViewDesc* view, const float* film_rgbw, const float* film_alpha, float* out_rgba,
+                             uint32_t num_pixels) {
     const uint32_t n = std::min<uint32_t>(num_pixels, uint32_t(view->resolution[0]) * uint32_t(view->resolution[1]));
     for (uint32_t i = 0; i < n; ++i) {
         const float* p = film_rgbw + size_t(i) * 4;
@@ -720,7 +747,7 @@ int zyg_oracle_resolve(const ZygpuViewDesc* view, const float* film_rgbw, float*
         o[0] = srgb[0];
         o[1] = srgb[1];
         o[2] = srgb[2];
-        o[3] = 1.f;
+        o[3] = film_alpha ? std::fabs(film_alpha[i] / p[3]) : 1.f;
     }
     return 0;
 }

@@ -10,7 +10,7 @@ import pytest
 import zyg_amd
 from zyg_amd import scenes
 
-from util import oracle_render, oracle_resolve, rms
+from util import oracle_render, oracle_render_alpha, oracle_resolve, rms
 
 pytestmark = pytest.mark.gpu
 
@@ -226,3 +226,42 @@ def test_unoccluding_mesh_lights(engine, oracle, integrator):
     the ray crosses in front of its hit (triangle_tree.zig:405-483)."""
     out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, mesh_lights=True, light_grid=3, unoccluding_lights=True)
     _check(*out, 3)
+
+
+@pytest.mark.parametrize("filter_name", [None, "Mitchell"])
+def test_transparent_sensor(engine, oracle, filter_name):
+    """Sensor buffer class Transparent (buffer_transparent.zig): with the camera pulled back the frame shows the void around the
+    box, where alpha = 0; inside it is 1; the alpha plane sums weight * alpha like the colour channels."""
+    w, h, spp = 96, 64, 3
+    scenes.cornell(engine, w, h, spp, alpha_transparency=True, camera_z=-7.5, filter_name=filter_name)
+    engine.start_frame(0)
+    engine.render_iterations(spp)
+    engine.synchronize()
+    film = engine.download_film(w, h)
+    alpha = np.zeros((h, w), dtype=np.float32)
+    g = engine.lib
+    g.zygpu_download_film_alpha.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert g.zygpu_download_film_alpha(engine.context(), alpha.ctypes.data) == 0
+    img = engine.resolve(w, h)
+
+    sd = g.su_ext_scene_desc().contents
+    vd = g.su_ext_view_desc().contents
+    assert vd.alpha_transparency == 1
+    cpu_film, cpu_alpha = oracle_render_alpha(oracle, sd, vd, spp)
+    if filter_name is None:
+        assert np.array_equal(film, cpu_film) and np.array_equal(alpha, cpu_alpha)
+        resolved_alpha = alpha / film[..., 3]
+        assert resolved_alpha.min() == 0.0 and resolved_alpha.max() == 1.0
+        np.testing.assert_array_equal(img[..., 3], np.abs(alpha / film[..., 3]))
+    else:  # only the float summation order differs
+        np.testing.assert_allclose(alpha, cpu_alpha, rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(film[..., 3], cpu_film[..., 3], rtol=2e-5, atol=1e-5)
+    assert img[0, 0, 3] == 0.0 and abs(img[h // 2, w // 2, 3] - 1.0) < 1e-6
+
+
+def test_opaque_sensor_has_no_alpha_plane(engine):
+    scenes.cornell(engine, 16, 16, 1)
+    engine.start_frame(0)
+    buf = np.zeros((16, 16), dtype=np.float32)
+    engine.lib.zygpu_download_film_alpha.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert engine.lib.zygpu_download_film_alpha(engine.context(), buf.ctypes.data) == -1

@@ -19,6 +19,21 @@ def oracle_render(oracle, scene_desc, view_desc, iterations, threads=None, itera
     return film
 
 
+def oracle_render_alpha(oracle, scene_desc, view_desc, iterations, threads=None):
+    """Transparent sensor: returns (film, alpha plane)."""
+    w, h = view_desc.resolution[0], view_desc.resolution[1]
+    film = np.zeros((h, w, 4), dtype=np.float32)
+    alpha = np.zeros((h, w), dtype=np.float32)
+    st = zyg_amd.Stats()
+    oracle.zyg_oracle_render_alpha.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                               ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(zyg_amd.Stats)]
+    rc = oracle.zyg_oracle_render_alpha(ctypes.addressof(scene_desc), ctypes.addressof(view_desc), 0, 0, iterations, 1, 0, h,
+                                        film.ctypes.data, alpha.ctypes.data, threads or (os.cpu_count() or 1), ctypes.byref(st))
+    assert rc == 0
+    return film, alpha
+
+
 def oracle_resolve(oracle, view_desc, film):
     h, w = film.shape[:2]
     out = np.zeros_like(film)

@@ -112,7 +112,8 @@ class ViewDesc(ctypes.Structure):
                 ("num_expected_samples", ctypes.c_uint32), ("filter_radius_int", ctypes.c_int32),
                 ("filter_radius", ctypes.c_float), ("filter_samples", ctypes.c_float * (FILTER_TAPS + 1)),
                 ("clamp_emission", ctypes.c_float), ("clamp_direct", ctypes.c_float),
-                ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float)]
+                ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float),
+                ("alpha_transparency", ctypes.c_uint32)]
 
 
 class Stats(ctypes.Structure):

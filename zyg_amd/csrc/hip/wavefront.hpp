@@ -105,6 +105,7 @@ struct Params {
     float4*  stage_color;  // per sample: clamped composed colour, alpha
     float2*  stage_uv;     // per sample: pixel_uv
     float4*  film;
+    float*   film_alpha;  // Transparent sensor only (else null): sum of weight * alpha per pixel
     uint32_t parity;  // current extension-queue side
     uint32_t sub_capacity;  // entries each of a queue's kSubQueues runs can hold
 };

@@ -41,8 +41,11 @@ __global__ void __launch_bounds__(256) film_accumulate(Params P) {
     if (idx >= fw * fh) return;
     const int x = fx0 + idx % fw, y = fy0 + idx / fw;
 
-    float4* pixel = P.film + (size_t(c_view.v.resolution[0]) * size_t(y) + size_t(x));
-    float4  value = *pixel;
+    const size_t pixel_id = size_t(c_view.v.resolution[0]) * size_t(y) + size_t(x);
+    float4*      pixel = P.film + pixel_id;
+    float4       value = *pixel;
+    // Transparent.addPixel (buffer_transparent.zig:46-55): the fourth lane of `pixels` sums weight * alpha
+    float alpha = P.film_alpha ? P.film_alpha[pixel_id] : 0.f;
     for (uint32_t it = 0; it < c_view.batch_iterations; ++it) {
         const size_t base = size_t(it) * c_view.npix;
         if (0 == fr) {
@@ -53,6 +56,7 @@ __global__ void __launch_bounds__(256) film_accumulate(Params P) {
                 value.y += wc.y;
                 value.z += wc.z;
                 value.w += 1.f;
+                alpha += 1.f * c.w;
             }
         } else {
             for (int sy = y - fr; sy <= y + fr; ++sy) {
@@ -71,20 +75,25 @@ __global__ void __launch_bounds__(256) film_accumulate(Params P) {
                     value.y += wc.y;
                     value.z += wc.z;
                     value.w += weight;
+                    alpha += weight * c.w;
                 }
             }
         }
     }
     *pixel = value;
+    if (P.film_alpha) P.film_alpha[pixel_id] = alpha;
 }
 
-__global__ void film_clear(float4* film, uint32_t n, float weight) {
+__global__ void film_clear(float4* film, float* film_alpha, uint32_t n, float weight) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) film[i] = make_float4(0.f, 0.f, 0.f, weight);
+    if (i < n) {
+        film[i] = make_float4(0.f, 0.f, 0.f, weight);
+        if (film_alpha) film_alpha[i] = 0.f;
+    }
 }
 
 // resolveTonemap (buffer_opaque.zig:73-79) with the Linear tonemapper (tonemapper.zig:36-39, aces.zig:19-27)
-__global__ void film_resolve(const float4* film, float4* out, uint32_t n, float exposure_factor) {
+__global__ void film_resolve(const float4* film, const float* film_alpha, float4* out, uint32_t n, float exposure_factor) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = film[i];
@@ -93,7 +102,7 @@ __global__ void film_resolve(const float4* film, float4* out, uint32_t n, float 
     const f3     scaled = S3(exposure_factor) * color;
     const f3     srgb = mk3(1.70505155f, -0.13025714f, -0.02400328f) * S3(scaled.x) + mk3(-0.62179068f, 1.14080289f, -0.12896877f) * S3(scaled.y) +
                     mk3(-0.08325840f, -0.01054853f, 1.15297171f) * S3(scaled.z);
-    out[i] = make_float4(srgb.x, srgb.y, srgb.z, 1.f);
+    out[i] = make_float4(srgb.x, srgb.y, srgb.z, film_alpha ? fabsf(film_alpha[i] / p.w) : 1.f);
 }
 
 
@@ -213,6 +222,9 @@ struct ZygpuContext {
     float2*       stage_uv = nullptr;
     float4*       film = nullptr;         // internal film
     float4*       film_active = nullptr;  // internal or external
+    float*        film_alpha = nullptr;   // Transparent sensor: sum of weight * alpha (own allocation)
+    float*        film_alpha_active = nullptr;
+    size_t        film_alpha_pixels = 0;
     float4*       resolve_tmp = nullptr;
     size_t        pool_capacity = 0;      // paths
     uint32_t      pool_rounds = 0;        // NEE rounds the pick buffer holds
@@ -362,6 +374,7 @@ int zygpu_destroy(ZygpuContext* c) {
         }
     if (c->ctl) (void)hipFree(c->ctl);
     if (c->resolve_tmp) (void)hipFree(c->resolve_tmp);
+    if (c->film_alpha) (void)hipFree(c->film_alpha);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -511,6 +524,16 @@ int zygpu_set_view(ZygpuContext* c, const ZygpuViewDesc* v) {
         c->resolve_tmp = nullptr;
     }
     c->film_active = c->film;
+    if (c->film_alpha && (!v->alpha_transparency || pixels != c->film_alpha_pixels)) {
+        (void)hipFree(c->film_alpha);
+        c->film_alpha = nullptr;
+    }
+    if (v->alpha_transparency && !c->film_alpha) {
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->film_alpha), pixels * sizeof(float)));
+        HIP_OK(hipMemset(c->film_alpha, 0, pixels * sizeof(float)));
+        c->film_alpha_pixels = pixels;
+    }
+    c->film_alpha_active = c->film_alpha;
     c->has_view = true;
     return 0;
 }
@@ -526,7 +549,7 @@ int zygpu_clear_film(ZygpuContext* c, float weight) {
     if (!c || !c->has_view) return -1;
     HIP_OK(hipSetDevice(c->device));
     const uint32_t n = uint32_t(c->film_pixels);
-    hipLaunchKernelGGL(film_clear, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->film_active, n, weight);
+    hipLaunchKernelGGL(film_clear, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->film_active, c->film_alpha_active, n, weight);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -566,6 +589,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     P.stage_color = c->stage_color;
     P.stage_uv = c->stage_uv;
     P.film = c->film_active;
+    P.film_alpha = c->film_alpha_active;
     P.parity = 0;
 
     const uint32_t ticks = v.max_depth_surface + 1;  // one tick per path vertex
@@ -686,6 +710,25 @@ int zygpu_film_device_ptr(ZygpuContext* c, void** out_ptr, uint64_t* out_num_flo
     return 0;
 }
 
+int zygpu_download_film_alpha(ZygpuContext* c, float* host_alpha) {
+    if (!c || !c->has_view || !host_alpha) return -1;
+    if (!c->film_alpha_active) {
+        g_error = "zygpu_download_film_alpha: the sensor is opaque (ZygpuViewDesc.alpha_transparency = 0)";
+        return -1;
+    }
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(host_alpha, c->film_alpha_active, c->film_pixels * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int zygpu_set_external_film_alpha(ZygpuContext* c, void* device_alpha) {
+    if (!c || !c->has_view || !c->view.alpha_transparency) return -1;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->film_alpha_active = device_alpha ? static_cast<float*>(device_alpha) : c->film_alpha;
+    return 0;
+}
+
 int zygpu_resolve(ZygpuContext* c, float* host_rgba, uint32_t num_pixels) {
     if (!c || !c->has_view || !host_rgba) return -1;
     HIP_OK(hipSetDevice(c->device));
@@ -695,7 +738,8 @@ int zygpu_resolve(ZygpuContext* c, float* host_rgba, uint32_t num_pixels) {
         HIP_OK(hipMalloc(&d, c->film_pixels * sizeof(float4)));
         c->resolve_tmp = static_cast<float4*>(d);
     }
-    hipLaunchKernelGGL(film_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->film_active, c->resolve_tmp, n, c->view.exposure_factor);
+    hipLaunchKernelGGL(film_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->film_active, c->film_alpha_active, c->resolve_tmp, n,
+                       c->view.exposure_factor);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(host_rgba, c->resolve_tmp, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));

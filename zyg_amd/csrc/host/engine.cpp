@@ -611,6 +611,7 @@ void Engine::loadIntegrators(const JsonValue& v) {
 
 // cli/take_loader.zig:193-230 (sensor node of a take); the reference C ABI has no entry for it
 void Engine::loadSensor(const JsonValue& v) {
+    sensor.alpha_transparency = v.memberBool("alpha_transparency", false);  // take_loader.zig:193-196
     sensor.clamp_emission = sensor.clamp_direct = sensor.clamp_indirect = FLT_MAX;
     if (const JsonValue* c = v.get("clamp")) {
         if (JsonValue::Object == c->type) {
@@ -971,6 +972,7 @@ int Engine::compile(uint32_t frame) {
     v.clamp_direct = sensor.clamp_direct;
     v.clamp_indirect = sensor.clamp_indirect;
     v.exposure_factor = std::exp2(sensor.exposure);
+    v.alpha_transparency = sensor.alpha_transparency ? 1 : 0;
     return 0;
 }
 

@@ -77,6 +77,7 @@ struct SensorSettings {  // sensor.zig:60-120
     float   filter_samples[ZYGPU_FILTER_TAPS + 1] = {};
     float   clamp_emission = FLT_MAX, clamp_direct = FLT_MAX, clamp_indirect = FLT_MAX;
     float   exposure = 0.f;
+    bool    alpha_transparency = false;  // buffer class Transparent instead of Opaque
 };
 
 class Engine {

@@ -167,7 +167,7 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
-            mesh_material=None, mesh_lights=False, light_grid=1):
+            mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -182,6 +182,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         node["light_sampling"] = {"split_threshold": split_threshold}
     engine.integrators(json.dumps({"surface": {integrator: node}}))
     sensor = {}
+    if alpha_transparency:
+        sensor["alpha_transparency"] = True
     if filter_name:
         sensor["filter"] = {filter_name: {}}
     engine.sensor(json.dumps(sensor))
@@ -237,5 +239,5 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0.02, 0.1)))
         ids["meshes"].append(p)
 
-    engine.transformation(cam, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, -3.9)))
+    engine.transformation(cam, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, camera_z)))
     return ids
