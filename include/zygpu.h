@@ -328,6 +328,10 @@ int zygpu_set_external_film_alpha(ZygpuContext* ctx, void* device_alpha);
 int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
 
 /* Switches: "kernel_timing" (default 1) records a HIP event pair around every wavefront launch;
+ * "tick_sync" (default 0) reads the next tick's queue length back after every tick (exact launch sizes, a batch ends with
+ * its last living path; zygpu_render then returns only when the traced work is done) instead of keeping a batch fully
+ * asynchronous with every launch sized for the whole batch - measured equal on BASELINE configs[1] (surplus blocks
+ * leave on one scalar load), useful when max_depth is far above the depth paths really reach;
  * "nee_in_place" (default 1) runs next-event estimation, shadow rays and the bxdf sample of a vertex in one kernel
  * (wf_scatter); 0 runs them as wf_nee / wf_shadow rounds + wf_extend: same results, different cost profile (in place
  * is faster with the couple of light picks per vertex of BASELINE's scenes; the rounds keep every lane busy when a

@@ -234,6 +234,8 @@ struct ZygpuContext {
     bool          has_substitute = false;  // selects the kernels' material instantiation
     bool          multi_sample_lights = false;  // a light has emittance num_samples > 1: wf_scatter<.., MULTI>
     bool          mesh_lights = false;          // TriangleMesh emitters: wf_shade<.., MESHL>, wf_scatter<.., MESHL>
+    bool          tick_sync = false;       // option "tick_sync": read the queue length back after every tick
+    uint32_t*     host_count = nullptr;    // pinned
     uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     uint64_t      camera_samples = 0;
@@ -359,6 +361,13 @@ int zygpu_create(int device_id, ZygpuContext** out_ctx) {
         return -1;
     }
     c->ctl = static_cast<Control*>(ctl);
+    void* pinned = nullptr;
+    if (!check(hipHostMalloc(&pinned, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc")) {
+        (void)hipFree(ctl);
+        delete c;
+        return -1;
+    }
+    c->host_count = static_cast<uint32_t*>(pinned);
     *out_ctx = c;
     return 0;
 }
@@ -375,6 +384,7 @@ int zygpu_destroy(ZygpuContext* c) {
     if (c->ctl) (void)hipFree(c->ctl);
     if (c->resolve_tmp) (void)hipFree(c->resolve_tmp);
     if (c->film_alpha) (void)hipFree(c->film_alpha);
+    if (c->host_count) (void)hipHostFree(c->host_count);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -613,7 +623,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         P.sub_capacity = subCapacity(c->pool_capacity);
         // one thread per queue entry; the queue lengths live on the device, so every launch covers the upper bound and
         // surplus waves retire on their first (scalar) load
-        const dim3     grid((num_paths + 255) / 256);
+        dim3           grid((num_paths + 255) / 256);
         P.parity = 0;
         HIP_OK(hipMemsetAsync(&c->ctl->ext_count[0], 0, sizeof(QueueCounts), c->stream));  // wf_generate appends to it
         hipLaunchKernelGGL(wf_generate, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
@@ -636,9 +646,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                     else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false, false>), grid, block, 0, c->stream, P);
                     else hipLaunchKernelGGL((wf_scatter<false, false, false, false>), grid, block, 0, c->stream, P);
                 });
-                P.parity ^= 1u;
-                continue;
-            }
+            } else {
             for (uint32_t r = 0; r < rounds; ++r) {
                 timedLaunch(c, 2, [&] {
                     if (0 == r) {
@@ -658,7 +666,18 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 if (c->has_substitute) hipLaunchKernelGGL(wf_extend<true>, grid, block, 0, c->stream, P);
                 else hipLaunchKernelGGL(wf_extend<false>, grid, block, 0, c->stream, P);
             });
+            }
             P.parity ^= 1u;
+            if (c->tick_sync && 1 == kSubQueues && t + 1 < ticks) {
+                // the next tick's extension-queue length, read back once per tick: exact grids instead of launches over
+                // the whole batch, and the batch ends with its last living path (one ~20 us host round trip per tick
+                // against ~1 ns per surplus block per launch)
+                HIP_OK(hipMemcpyAsync(c->host_count, &c->ctl->ext_count[P.parity].n[0], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                HIP_OK(hipStreamSynchronize(c->stream));
+                const uint32_t next = *c->host_count;
+                if (0 == next) break;
+                grid = dim3((next + 255) / 256);
+            }
         }
         const int fh = std::min(ye + fr, v.crop[3]) - std::max(yb - fr, v.crop[1]);
         const int fw = v.crop[2] - v.crop[0];
@@ -774,6 +793,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
             return -1;
         }
         c->batch_mpaths = uint32_t(value);
+        return 0;
+    }
+    if (0 == std::strcmp(name, "tick_sync")) {
+        c->tick_sync = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "nee_in_place")) {
