@@ -60,6 +60,7 @@ struct Queues {
     uint32_t* ext[2];  // extension rays, ping-pong per tick
     uint32_t* alive;   // paths that survived wf_shade in this tick
     uint32_t* shadow;  // paths with a shadow ray in flight (one NEE round)
+    uint32_t* heavy;   // extension rays whose vertex has emission to evaluate (wf_shade's second pass)
 };
 
 // A queue is kSubQueues independent runs, each with its own length word in its own 64 B line; blocks append to run
@@ -83,6 +84,7 @@ struct Control {  // device-resident
     QueueCounts        ext_count[2];
     QueueCounts        alive_count;
     QueueCounts        shadow_count[2];  // ping-pong per NEE round
+    QueueCounts        heavy_count;
     uint32_t           bound[2];  // [parity of the tick]: length of the tick's extension queue = upper bound of every later
                                   // queue of that tick; surplus blocks leave on this one scalar load
     uint32_t           error;
@@ -116,6 +118,9 @@ __constant__ DScene c_scene;  // the compiled scene's device arrays: read on dem
 // occupancy targets (waves per SIMD) the register allocator is held to, per kernel; see DESIGN.md "Occupancy"
 #ifndef ZYG_SHADE_WAVES
 #define ZYG_SHADE_WAVES 2
+#endif
+#ifndef ZYG_SHADE_LIGHT_WAVES
+#define ZYG_SHADE_LIGHT_WAVES 3
 #endif
 #ifndef ZYG_SCATTER_WAVES
 #define ZYG_SCATTER_WAVES 2
@@ -470,6 +475,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
         queueReset(&P.ctl->alive_count);
         queueReset(&P.ctl->shadow_count[0]);
         queueReset(&P.ctl->shadow_count[1]);
+        queueReset(&P.ctl->heavy_count);
     }
     Counters cnt{0, 0, 0};
     if (i < n) {
@@ -575,14 +581,18 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, const
     return energy;
 }
 
-template <bool STATS, bool MESHL>
-__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Params P) {
+// Two passes share this body.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
+// emissive and whose ray crossed no unoccluding light has no emission to evaluate (no sampler draw, no light-tree pdf,
+// no SphQuad), so that instantiation is small enough for twice the occupancy; the others go to the `heavy` queue, which
+// the HEAVY = true pass processes with the complete connectLight.
+template <bool STATS, bool MESHL, bool HEAVY>
+__global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_SHADE_LIGHT_WAVES) wf_shade(Params P) {
     const DScene&  s = c_scene;
     const uint32_t cur = P.parity;
     if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->ext_count[cur], P.sub_capacity, i, at);
+    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count : &P.ctl->ext_count[cur], P.sub_capacity, i, at);
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters       cnt{0, 0, 0};
@@ -590,10 +600,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
     if (i < rounded) {
         SectionTimer tm;
         tm.start();
-        bool     alive = false;
+        bool     alive = false, defer = false;
         uint32_t slot = 0;
         if (i < total) {
-            slot = P.q.ext[cur][at];
+            slot = HEAVY ? P.q.heavy[at] : P.q.ext[cur][at];
             PathHead h;
             loadHead(P, slot, h);
 
@@ -606,13 +616,23 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
             const Ray ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, has_hit ? hit.t : ro.w);
             const f3  wo = -ray.direction;
 
+            if (!HEAVY) {  // anything that could make connectLight draw or evaluate goes to the heavy pass
+                bool emissive = false;
+                if (has_hit) {
+                    const ZygpuProp hp = s.props[hit_prop];
+                    const uint32_t  part = ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[hit.primitive]) : 0u;
+                    emissive = 0 != (s.materials[s.material_ids[hp.parts_start + part]].flags & ZYGPU_MATF_EMISSIVE);
+                }
+                defer = connectsLights(h.flags) && (emissive || 0 != P.pool.ucount[slot]);
+            }
+            if (!defer) {
             Fragment frag;
             if (has_hit) makeFragment(s, ray, hit, frag);
             tm.mark(0);
 
             // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
             f3 energy = S3(0.f);
-            if (connectsLights(h.flags)) {
+            if (HEAVY && connectsLights(h.flags)) {
                 VertexIn v;
                 v.vorigin = xyz4(P.pool.vorigin[slot]);
                 v.vgeo_n = xyz4(P.pool.vgeo_n[slot]);
@@ -686,6 +706,11 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADE_WAVES) wf_shade(Param
             tm.mark(3);
             if (done) finalize(P, slot, throughput, h.flags);
             tm.mark(4);
+            }
+        }
+        if (!HEAVY) {
+            queuePush(P.q.heavy, &P.ctl->heavy_count, P.sub_capacity, defer, slot);
+            __syncthreads();  // queuePush's shared words are reused below
         }
         queuePush(P.q.alive, &P.ctl->alive_count, P.sub_capacity, alive, slot);
         tm.mark(5);

@@ -290,7 +290,7 @@ int ensurePool(ZygpuContext* c, size_t paths, uint32_t rounds) {
               m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) && m.alloc(paths, &c->stage_color) &&
               m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) && m.alloc(paths, &p.sh_o) &&
               m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
-              m.alloc(qcap, &c->queues.shadow);
+              m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy);
     if (!ok) {
         c->pool_capacity = 0;
         c->pool_rounds = 0;
@@ -634,9 +634,16 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 else hipLaunchKernelGGL(wf_intersect<false>, grid, block, 0, c->stream, P);
             });
             timedLaunch(c, 1, [&] {
-                if (c->stats) hipLaunchKernelGGL((wf_shade<true, true>), grid, block, 0, c->stream, P);
-                else if (c->mesh_lights) hipLaunchKernelGGL((wf_shade<false, true>), grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL((wf_shade<false, false>), grid, block, 0, c->stream, P);
+                if (c->stats) {
+                    hipLaunchKernelGGL((wf_shade<true, true, false>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<true, true, true>), grid, block, 0, c->stream, P);
+                } else if (c->mesh_lights) {
+                    hipLaunchKernelGGL((wf_shade<false, true, false>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<false, true, true>), grid, block, 0, c->stream, P);
+                } else {
+                    hipLaunchKernelGGL((wf_shade<false, false, false>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<false, false, true>), grid, block, 0, c->stream, P);
+                }
             });
             if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
