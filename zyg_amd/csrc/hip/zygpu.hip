@@ -236,6 +236,7 @@ struct ZygpuContext {
     bool          mesh_lights = false;          // TriangleMesh emitters: wf_shade<.., MESHL>, wf_scatter<.., MESHL>
     bool          tick_sync = false;       // option "tick_sync": read the queue length back after every tick
     uint32_t*     host_count = nullptr;    // pinned
+    uint4*        sobol_lut = nullptr;     // dsampler.hpp c_sobol_lut
     uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     uint64_t      camera_samples = 0;
@@ -368,6 +369,18 @@ int zygpu_create(int device_id, ZygpuContext** out_ctx) {
         return -1;
     }
     c->host_count = static_cast<uint32_t*>(pinned);
+    void* lut = nullptr;
+    if (!check(hipMalloc(&lut, 1024 * sizeof(uint4)), "hipMalloc")) {
+        zygpu_destroy(c);
+        return -1;
+    }
+    c->sobol_lut = static_cast<uint4*>(lut);
+    hipLaunchKernelGGL(sobol::sobol_lut_init, dim3(4), dim3(256), 0, c->stream, c->sobol_lut);
+    if (!check(hipStreamSynchronize(c->stream), "sobol_lut_init") ||
+        !check(hipMemcpyToSymbol(HIP_SYMBOL(sobol::c_sobol_lut), &c->sobol_lut, sizeof(c->sobol_lut), 0, hipMemcpyHostToDevice), "c_sobol_lut")) {
+        zygpu_destroy(c);
+        return -1;
+    }
     *out_ctx = c;
     return 0;
 }
@@ -385,6 +398,7 @@ int zygpu_destroy(ZygpuContext* c) {
     if (c->resolve_tmp) (void)hipFree(c->resolve_tmp);
     if (c->film_alpha) (void)hipFree(c->film_alpha);
     if (c->host_count) (void)hipHostFree(c->host_count);
+    if (c->sobol_lut) (void)hipFree(c->sobol_lut);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
