@@ -117,16 +117,16 @@ __constant__ DScene c_scene;  // the compiled scene's device arrays: read on dem
 
 // occupancy targets (waves per SIMD) the register allocator is held to, per kernel; see DESIGN.md "Occupancy"
 #ifndef ZYG_SHADE_WAVES
-#define ZYG_SHADE_WAVES 2
+#define ZYG_SHADE_WAVES 3
 #endif
 #ifndef ZYG_SHADE_LIGHT_WAVES
 #define ZYG_SHADE_LIGHT_WAVES 3
 #endif
 #ifndef ZYG_SCATTER_WAVES
-#define ZYG_SCATTER_WAVES 2
+#define ZYG_SCATTER_WAVES 3
 #endif
 #ifndef ZYG_NEE_WAVES
-#define ZYG_NEE_WAVES 2
+#define ZYG_NEE_WAVES 3
 #endif
 #ifndef ZYG_EXTEND_WAVES
 #define ZYG_EXTEND_WAVES 3
