@@ -120,7 +120,7 @@ __constant__ DScene c_scene;  // the compiled scene's device arrays: read on dem
 #define ZYG_SHADE_WAVES 3
 #endif
 #ifndef ZYG_SHADE_LIGHT_WAVES
-#define ZYG_SHADE_LIGHT_WAVES 3
+#define ZYG_SHADE_LIGHT_WAVES 5
 #endif
 #ifndef ZYG_SCATTER_WAVES
 #define ZYG_SCATTER_WAVES 3
