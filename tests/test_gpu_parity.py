@@ -265,3 +265,12 @@ def test_opaque_sensor_has_no_alpha_plane(engine):
     buf = np.zeros((16, 16), dtype=np.float32)
     engine.lib.zygpu_download_film_alpha.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     assert engine.lib.zygpu_download_film_alpha(engine.context(), buf.ctypes.data) == -1
+
+
+@pytest.mark.parametrize("nee_in_place", [1, 0])
+def test_many_lights(engine, oracle, nee_in_place):
+    """A 6 x 6 grid of quad lights: a light tree several levels deep, adaptive splitting into many picks per vertex
+    (split threshold 0.9), both NEE routings (the staged one runs up to 36 rounds per tick)."""
+    out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS", many_lights=6, split_threshold=0.9, nee_in_place=nee_in_place)
+    _check(*out, 2)
+    assert out[2].shadow_rays > 4 * out[2].camera_samples  # splitting really produced several picks per vertex

@@ -167,11 +167,12 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
-            mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9):
+            mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
     mesh_lights: the two emissive quads are triangle meshes (2 * light_grid^2 triangles each) instead of Rectangles.
+    many_lights: n > 0 replaces the two quads by an n x n grid of small Rectangle lights under the ceiling (light-tree depth).
     Returns a dict with prop ids.
     """
     mk = lambert if material == "lambert" else substitute
@@ -208,7 +209,17 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     wall(red, (0, 0, -1), (0, 1, 0), (2, 2, 1), (-1, 1, 0))    # left, n = +x
     wall(green, (0, 0, 1), (0, 1, 0), (2, 2, 1), (1, 1, 0))    # right, n = -x
 
-    for lx in (-0.45, 0.45):  # two emissive quads just below the ceiling, facing down
+    if many_lights:
+        n = many_lights
+        side = 1.6 / n
+        for j in range(n):
+            for i in range(n):
+                p = engine.prop(RECTANGLE, [lamp], unoccluding=unoccluding_lights)
+                cx, cz = -0.8 + (i + 0.5) * side, -0.8 + (j + 0.5) * side
+                engine.transformation(p, trafo((1, 0, 0), (0, 0, 1), (0.6 * side, 0.5 * side, 1), (cx, 1.98 - 0.01 * ((i + j) % 3), cz)))
+                engine.light(p)
+                ids["lights"].append(p)
+    for lx in (() if many_lights else (-0.45, 0.45)):  # two emissive quads just below the ceiling, facing down
         if mesh_lights:
             # the size is baked into the vertices: the reference's mesh-light areas and solid angles only hold for
             # uniform scales (triangle_mesh.zig:289-292 "HACK", 524-531)
