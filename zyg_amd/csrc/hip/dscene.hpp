@@ -75,6 +75,8 @@ struct DScene {
     const float*         lut_e_avg;
     float                specular_threshold;
     uint32_t             num_solid_nodes, num_unocc_nodes;
+    float4               heavy_aabbs[16];  // world bounds (2 each) of the up to 8 largest mesh props: queue grouping hint
+    uint32_t             num_heavy;
 };
 
 struct Counters {

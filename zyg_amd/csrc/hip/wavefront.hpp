@@ -63,17 +63,12 @@ struct Queues {
     uint32_t* heavy;   // extension rays whose vertex has emission to evaluate (wf_shade's second pass)
 };
 
-// A queue is kSubQueues independent runs, each with its own length word in its own 64 B line; blocks append to run
-// blockIdx % kSubQueues.  Measured on configs[1]: one atomic per wave on a single word 248 Msamples/s, one per block
-// 303, one per block spread over 64 runs 278 (the consumers' prefix over the run lengths costs more than the remaining
-// contention), so the shipped value is 1; 64 is the other supported value (one run length per lane in queueOpen).
-#ifndef ZYG_SUB_QUEUES
-#define ZYG_SUB_QUEUES 1
-#endif
-constexpr uint32_t kSubQueues = ZYG_SUB_QUEUES, kCountStride = 16;
-static_assert(1 == kSubQueues || 64 == kSubQueues, "queueOpen handles 1 or 64 runs");
+// Queue lengths live on the device: the front and the back end's counts in separate 64 B lines (their atomics do not
+// share an address).  Measured on configs[1]: one atomic per wave on one word 248 Msamples/s, one per block 303; spreading
+// the appends over 64 run counters cost more in the consumers than the remaining contention (278), so there is one run.
+constexpr uint32_t kCountStride = 16;
 struct QueueCounts {
-    uint32_t n[kSubQueues * kCountStride];
+    uint32_t n[2 * kCountStride];  // [0] entries appended at the front, [kCountStride] at the back
 };
 
 struct KernelCounters {
@@ -109,7 +104,7 @@ struct Params {
     float4*  film;
     float*   film_alpha;  // Transparent sensor only (else null): sum of weight * alpha per pixel
     uint32_t parity;  // current extension-queue side
-    uint32_t sub_capacity;  // entries each of a queue's kSubQueues runs can hold
+    uint32_t sub_capacity;  // capacity of every queue array (entries)
 };
 
 __constant__ View   c_view;
@@ -168,56 +163,46 @@ struct SectionTimer {
 };
 #endif
 
-// Append of the active lanes' values to a queue: one atomic per 256-thread block (every wave of the block that has not
-// returned must call it; waves count their lanes by ballot, the block total is claimed by one atomicAdd on the run this
-// block appends to, each wave writes its part).  Queue order is free: all results are addressed by slot.
-ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t sub_capacity, bool active, uint32_t value) {
-    __shared__ uint32_t wave_count[4];
-    __shared__ uint32_t block_base;
-    const unsigned long long mask = __ballot(active);
+// Append of the active lanes' values to a queue: one atomic per 256-thread block and queue end (every wave of the block that
+// has not returned must call it; waves count their lanes by ballot, the block totals are claimed by one atomicAdd each,
+// every wave writes its part).  Queue order is free: all results are addressed by slot.
+// A queue has two ends: `back` entries grow down from the last element.  The extension queue uses that to keep the rays
+// that will enter a mesh's bounding box (deep BLAS walks) apart from the rest, so that the lanes of a wave have similar
+// work: measured lane utilisation of wf_intersect on the 1 M-triangle scene was 11 % with mixed waves.
+ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool active, uint32_t value, bool back = false) {
+    __shared__ uint32_t wave_count[4][2];
+    __shared__ uint32_t block_base[2];
+    const bool               front = active && !back, rear = active && back;
+    const unsigned long long fmask = __ballot(front), rmask = __ballot(rear);
     const uint32_t           lane = __lane_id(), wave = threadIdx.x >> 6;
-    if (0 == lane) wave_count[wave] = uint32_t(__popcll(mask));
-    __syncthreads();
-    if (0 == threadIdx.x) {
-        const uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-        const uint32_t run = blockIdx.x % kSubQueues;
-        block_base = run * sub_capacity + (total ? atomicAdd(&counts->n[run * kCountStride], total) : 0u);
+    if (0 == lane) {
+        wave_count[wave][0] = uint32_t(__popcll(fmask));
+        wave_count[wave][1] = uint32_t(__popcll(rmask));
     }
     __syncthreads();
-    uint32_t base = block_base;
-    for (uint32_t w = 0; w < wave; ++w) base += wave_count[w];
-    if (active) queue[base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)))] = value;
-    // no trailing barrier: every kernel pushes once, so wave_count / block_base are not reused
+    if (threadIdx.x < 2) {
+        const uint32_t e = threadIdx.x;
+        const uint32_t total = wave_count[0][e] + wave_count[1][e] + wave_count[2][e] + wave_count[3][e];
+        block_base[e] = total ? atomicAdd(&counts->n[e * kCountStride], total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t e = rear ? 1u : 0u;
+    uint32_t       index = block_base[e];
+    for (uint32_t w = 0; w < wave; ++w) index += wave_count[w][e];
+    index += uint32_t(__popcll((rear ? rmask : fmask) & ((1ull << lane) - 1ull)));
+    if (active) queue[rear ? capacity - 1u - index : index] = value;
+    // no trailing barrier: a kernel that pushes twice puts its own barrier between the calls
 }
 
-// Consumer side, called by whole waves at kernel entry: the queue's total length and, for entry i of the
-// concatenated runs, its position in the queue array.
-ZD uint32_t queueOpen(const QueueCounts* counts, uint32_t sub_capacity, uint32_t i, uint32_t& position) {
-    if (1 == kSubQueues) {
-        position = i;
-        return counts->n[0];
-    }
-    const uint32_t lane = __lane_id();
-    const uint32_t mine = counts->n[lane * kCountStride];  // kSubQueues == 64 lanes
-    uint32_t       incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o);
-        if (lane >= uint32_t(o)) incl += up;
-    }
-    const uint32_t total = __shfl(incl, 63);
-    uint32_t       run = 0;  // number of runs that end at or before i
-    for (uint32_t step = 32; step > 0; step >>= 1) {
-        const uint32_t end = __shfl(incl, int(run + step - 1));
-        if (end <= i) run += step;
-    }
-    run = run < kSubQueues ? run : kSubQueues - 1;
-    const uint32_t begin = __shfl(incl, int(run)) - __shfl(mine, int(run));
-    position = run * sub_capacity + (i - begin);
-    return total;
+// Consumer side: the queue's total length and, for entry i (front entries first, then the back ones), its position.
+ZD uint32_t queueOpen(const QueueCounts* counts, uint32_t capacity, uint32_t i, uint32_t& position) {
+    const uint32_t front = counts->n[0], rear = counts->n[kCountStride];
+    position = i < front ? i : capacity - 1u - (i - front);
+    return front + rear;
 }
 
 ZD void queueReset(QueueCounts* counts) {  // by one wave
-    if (__lane_id() < kSubQueues) counts->n[__lane_id() * kCountStride] = 0;
+    if (__lane_id() < 2) counts->n[__lane_id() * kCountStride] = 0;
 }
 
 ZD void slotPixel(uint32_t slot, int& x, int& y, uint32_t& iteration) {
@@ -331,6 +316,17 @@ ZD void flushCounters(const Params& P, int k, const Counters& cnt, unsigned long
     if (rays) atomicAdd(&P.ctl->k[k].rays, rays);
 }
 
+// whether a new extension ray will enter the bounding box of one of the scene's (largest) mesh props: such rays go to
+// the back of the extension queue (see queuePush).  Purely a grouping hint: every ray is traced the same way.
+ZD bool entersMeshBounds(f3 origin, f3 direction) {
+    const DScene& s = c_scene;
+    if (0 == s.num_heavy) return false;
+    const Ray ray = Ray::init(origin, direction, 0.f, kRayMaxT);
+    bool      hit = false;
+    for (uint32_t k = 0; k < s.num_heavy; ++k) hit = hit || aabbIntersect(s.heavy_aabbs[2 * k], s.heavy_aabbs[2 * k + 1], ray);
+    return hit;
+}
+
 // ---------------------------------------------------------------- wf_generate
 // Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
 // Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
@@ -401,7 +397,8 @@ __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths)
     const bool     valid = slot < num_paths;
     if (0 == slot) P.ctl->bound[1] = num_paths;  // tick 0's wf_intersect reads the previous tick's bound
     if (valid) generatePath(P, slot);
-    queuePush(P.q.ext[P.parity], &P.ctl->ext_count[P.parity], P.sub_capacity, valid, slot);
+    const bool back = valid && entersMeshBounds(xyz4(P.pool.ray_o[slot]), xyz4(P.pool.ray_d[slot]));
+    queuePush(P.q.ext[P.parity], &P.ctl->ext_count[P.parity], P.sub_capacity, valid, slot, back);
 }
 
 // PropBvh.emission over the unoccluding TLAS (prop_tree.zig:302-356, prop.zig:239-264, rectangle.zig:188-196), split in
@@ -900,7 +897,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;
     if (i >= rounded) return;
-    bool     push = false;
+    bool     push = false, back = false;
     uint32_t slot = 0;
     if (i < total) {
         slot = P.q.alive[at];
@@ -941,13 +938,14 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 
             P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
             P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
+            back = entersMeshBounds(new_origin, bs.wi);
             P.pool.thr[slot] = f4(throughput);
             P.pool.vorigin[slot] = f4(sf.p);
             storeHead(P, slot, h);
             push = true;
         }
     }
-    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot);
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot, back);
 }
 
 // ---------------------------------------------------------------- wf_scatter
@@ -970,7 +968,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
     unsigned long long shadow_rays = 0;
     const uint32_t     rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i >= rounded) return;
-    bool     push = false;
+    bool     push = false, back = false;
     uint32_t slot = 0;
     if (i < total) {
         slot = P.q.alive[at];
@@ -1090,13 +1088,14 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
 
             P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
             P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
+            back = entersMeshBounds(new_origin, bs.wi);
             P.pool.thr[slot] = f4(throughput);
             P.pool.vorigin[slot] = f4(sf.p);
             storeHead(P, slot, h);
             push = true;
         }
     }
-    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot);
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot, back);
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
 }
 

@@ -252,12 +252,9 @@ struct ZygpuContext {
 
 namespace {
 
-// a queue = kSubQueues runs; run r takes the appends of blocks r, r + kSubQueues, ... of a launch over `paths` threads
-uint32_t subCapacity(size_t paths) {
-    const size_t blocks = (paths + 255) / 256;
-    return uint32_t((blocks + kSubQueues - 1) / kSubQueues * 256);
-}
-size_t queueCapacity(size_t paths) { return size_t(subCapacity(paths)) * kSubQueues; }
+// queue arrays hold one entry per path, rounded up to whole blocks
+uint32_t subCapacity(size_t paths) { return uint32_t((paths + 255) / 256 * 256); }
+size_t   queueCapacity(size_t paths) { return subCapacity(paths); }
 
 bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out) {
     std::memset(out, 0, sizeof(*out));
@@ -363,7 +360,7 @@ int zygpu_create(int device_id, ZygpuContext** out_ctx) {
     }
     c->ctl = static_cast<Control*>(ctl);
     void* pinned = nullptr;
-    if (!check(hipHostMalloc(&pinned, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc")) {
+    if (!check(hipHostMalloc(&pinned, sizeof(QueueCounts), hipHostMallocDefault), "hipHostMalloc")) {
         (void)hipFree(ctl);
         delete c;
         return -1;
@@ -522,6 +519,25 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     s.specular_threshold = d->specular_threshold;
     s.num_solid_nodes = d->solid.num_nodes;
     s.num_unocc_nodes = d->unoccluding.num_nodes;
+    // The mesh props whose bounds sort extension rays into the two ends of the queue: the (up to 8) largest meshes with
+    // at least 4096 triangles.  Splitting the queue halves the slot density of each group, which costs the
+    // bandwidth-bound stages up to 2x in touched cache lines: worth it for deep BLAS walks (1 M triangles: wf_intersect
+    // 67 -> 39 ms per step), not for the 12-triangle boxes of the Cornell scene (measured 427 -> 340 Msamples/s).
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> mesh_props;  // (triangles, prop)
+        for (uint32_t p = 0; p < d->num_props; ++p) {
+            if (ZYGPU_SHAPE_TRIANGLE_MESH == d->props[p].shape && !(d->props[p].flags & ZYGPU_PROP_UNOCCLUDING) &&
+                d->meshes[d->props[p].mesh].num_triangles >= 4096)
+                mesh_props.emplace_back(d->meshes[d->props[p].mesh].num_triangles, p);
+        }
+        std::sort(mesh_props.begin(), mesh_props.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+        s.num_heavy = uint32_t(std::min<size_t>(mesh_props.size(), 8));
+        for (uint32_t k = 0; k < s.num_heavy; ++k) {
+            const ZygpuAabb& b = d->aabbs[mesh_props[k].second];
+            s.heavy_aabbs[2 * k] = make_float4(b.min[0], b.min[1], b.min[2], b.min[3]);
+            s.heavy_aabbs[2 * k + 1] = make_float4(b.max[0], b.max[1], b.max[2], b.max[3]);
+        }
+    }
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_scene), &s, sizeof(DScene), 0, hipMemcpyHostToDevice));
     c->has_scene = true;
@@ -689,13 +705,13 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             });
             }
             P.parity ^= 1u;
-            if (c->tick_sync && 1 == kSubQueues && t + 1 < ticks) {
+            if (c->tick_sync && t + 1 < ticks) {
                 // the next tick's extension-queue length, read back once per tick: exact grids instead of launches over
                 // the whole batch, and the batch ends with its last living path (one ~20 us host round trip per tick
                 // against ~1 ns per surplus block per launch)
-                HIP_OK(hipMemcpyAsync(c->host_count, &c->ctl->ext_count[P.parity].n[0], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                HIP_OK(hipMemcpyAsync(c->host_count, &c->ctl->ext_count[P.parity], sizeof(QueueCounts), hipMemcpyDeviceToHost, c->stream));
                 HIP_OK(hipStreamSynchronize(c->stream));
-                const uint32_t next = *c->host_count;
+                const uint32_t next = c->host_count[0] + c->host_count[kCountStride];
                 if (0 == next) break;
                 grid = dim3((next + 255) / 256);
             }
