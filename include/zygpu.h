@@ -335,7 +335,9 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * "nee_in_place" (default 1) runs next-event estimation, shadow rays and the bxdf sample of a vertex in one kernel
  * (wf_scatter); 0 runs them as wf_nee / wf_shadow rounds + wf_extend: same results, different cost profile (in place
  * is faster with the couple of light picks per vertex of BASELINE's scenes; the rounds keep every lane busy when a
- * vertex picks many lights). */
+ * vertex picks many lights; scenes with multi-sample or TriangleMesh lights always run in place);
+ * "batch_mpaths" (default 32, 1..512) sets the number of paths per batch in units of 2^20 (the path pool takes about
+ * 450 B per path). */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Counters accumulated since the last reset (only maintained when enabled). */

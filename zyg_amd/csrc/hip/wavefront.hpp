@@ -104,7 +104,7 @@ struct Params {
     float4*  film;
     float*   film_alpha;  // Transparent sensor only (else null): sum of weight * alpha per pixel
     uint32_t parity;  // current extension-queue side
-    uint32_t sub_capacity;  // capacity of every queue array (entries)
+    uint32_t queue_capacity;  // entries every queue array holds
 };
 
 __constant__ View   c_view;
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths)
     if (0 == slot) P.ctl->bound[1] = num_paths;  // tick 0's wf_intersect reads the previous tick's bound
     if (valid) generatePath(P, slot);
     const bool back = valid && entersMeshBounds(xyz4(P.pool.ray_o[slot]), xyz4(P.pool.ray_d[slot]));
-    queuePush(P.q.ext[P.parity], &P.ctl->ext_count[P.parity], P.sub_capacity, valid, slot, back);
+    queuePush(P.q.ext[P.parity], &P.ctl->ext_count[P.parity], P.queue_capacity, valid, slot, back);
 }
 
 // PropBvh.emission over the unoccluding TLAS (prop_tree.zig:302-356, prop.zig:239-264, rectangle.zig:188-196), split in
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     if (blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t n = queueOpen(&P.ctl->ext_count[cur], P.sub_capacity, i, at);
+    const uint32_t n = queueOpen(&P.ctl->ext_count[cur], P.queue_capacity, i, at);
     if (0 == i) P.ctl->bound[cur] = n;
     if (0 == blockIdx.x && threadIdx.x < 64) {  // this tick's wf_shade / wf_nee / wf_extend fill these
         queueReset(&P.ctl->ext_count[cur ^ 1u]);
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
     if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count : &P.ctl->ext_count[cur], P.sub_capacity, i, at);
+    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count : &P.ctl->ext_count[cur], P.queue_capacity, i, at);
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters       cnt{0, 0, 0};
@@ -706,10 +706,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
             }
         }
         if (!HEAVY) {
-            queuePush(P.q.heavy, &P.ctl->heavy_count, P.sub_capacity, defer, slot);
+            queuePush(P.q.heavy, &P.ctl->heavy_count, P.queue_capacity, defer, slot);
             __syncthreads();  // queuePush's shared words are reused below
         }
-        queuePush(P.q.alive, &P.ctl->alive_count, P.sub_capacity, alive, slot);
+        queuePush(P.q.alive, &P.ctl->alive_count, P.queue_capacity, alive, slot);
         tm.mark(5);
         tm.flush(P.ctl, 0);
     }
@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->alive_count, P.sub_capacity, i, at);
+    const uint32_t total = queueOpen(&P.ctl->alive_count, P.queue_capacity, i, at);
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i >= rounded) return;
@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
             }
         }
     }
-    queuePush(P.q.shadow, &P.ctl->shadow_count[round & 1u], P.sub_capacity, push, slot);
+    queuePush(P.q.shadow, &P.ctl->shadow_count[round & 1u], P.queue_capacity, push, slot);
 }
 
 // Scene.visibility (prop_tree.zig:185-240) for the shadow queue of one round
@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t n = queueOpen(&P.ctl->shadow_count[round & 1u], P.sub_capacity, i, at);
+    const uint32_t n = queueOpen(&P.ctl->shadow_count[round & 1u], P.queue_capacity, i, at);
     if (0 == blockIdx.x && threadIdx.x < 64) queueReset(&P.ctl->shadow_count[(round + 1u) & 1u]);  // the next round's wf_nee fills it
     Counters cnt{0, 0, 0};
     if (i < n) {
@@ -893,7 +893,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->alive_count, P.sub_capacity, i, at);
+    const uint32_t total = queueOpen(&P.ctl->alive_count, P.queue_capacity, i, at);
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;
     if (i >= rounded) return;
@@ -945,7 +945,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
             push = true;
         }
     }
-    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot, back);
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
 }
 
 // ---------------------------------------------------------------- wf_scatter
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t           at;
-    const uint32_t     total = queueOpen(&P.ctl->alive_count, P.sub_capacity, i, at);
+    const uint32_t     total = queueOpen(&P.ctl->alive_count, P.queue_capacity, i, at);
     const uint32_t     kind = c_view.v.integrator;
     const bool         mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters           cnt{0, 0, 0};
@@ -1095,7 +1095,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
             push = true;
         }
     }
-    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.sub_capacity, push, slot, back);
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
 }
 

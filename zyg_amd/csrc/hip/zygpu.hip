@@ -253,8 +253,8 @@ struct ZygpuContext {
 namespace {
 
 // queue arrays hold one entry per path, rounded up to whole blocks
-uint32_t subCapacity(size_t paths) { return uint32_t((paths + 255) / 256 * 256); }
-size_t   queueCapacity(size_t paths) { return subCapacity(paths); }
+uint32_t queueEntries(size_t paths) { return uint32_t((paths + 255) / 256 * 256); }
+size_t   queueCapacity(size_t paths) { return queueEntries(paths); }
 
 bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out) {
     std::memset(out, 0, sizeof(*out));
@@ -650,7 +650,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_view), &view, sizeof(View), 0, hipMemcpyHostToDevice, c->stream));
 
         const uint32_t num_paths = uint32_t(npix * b);
-        P.sub_capacity = subCapacity(c->pool_capacity);
+        P.queue_capacity = queueEntries(c->pool_capacity);
         // one thread per queue entry; the queue lengths live on the device, so every launch covers the upper bound and
         // surplus waves retire on their first (scalar) load
         dim3           grid((num_paths + 255) / 256);
