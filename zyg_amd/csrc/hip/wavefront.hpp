@@ -985,7 +985,13 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
             const LightTree lt{s, s.light_tree};
             NoTimer         notimer;
             f3              nee = S3(0.f);
-            lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold, [&](uint32_t, LightPick pick) {
+            // the picks first (Scene.randomLightSpatial fills a buffer too, scene.zig:592-610), then one loop over them: the
+            // lanes of a wave leave the tree walk together instead of interleaving it with their shadow rays
+            LightPick      picks[kMaxLightPicks];
+            const uint32_t num_picks = lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold,
+                                                      [&](uint32_t k, LightPick pick) { picks[k] = pick; });
+            for (uint32_t pk = 0; pk < num_picks; ++pk) {
+                const LightPick      pick = picks[pk];
                 const ZygpuLight     light = s.lights[pick.offset];
                 const Trafo          trafo = loadTrafo(s, light.prop);
                 const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
@@ -1056,7 +1062,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(P
                     }
                 }
                 nee = nee + occluded;
-            });
+            }
             ivalueAdd(P, slot, throughput * nee, h.depth_surface, 1u, false, false);
         }
 
