@@ -145,31 +145,32 @@ ZD bool bvhWalk(const float4* nodes, uint32_t num_nodes, Ray& ray, Counters& cnt
     if (STATS) cnt.nodes += 1;
     uint32_t data = __float_as_uint(nodes[0].w), count = __float_as_uint(nodes[1].w);
     for (;;) {
-        if (0 != count) {
-            if (leaf(data, count)) return true;
-            if (0 == sp) return false;
-            const uint32_t n = stack[--sp];
-            data = __float_as_uint(nodes[2 * n].w);
-            count = __float_as_uint(nodes[2 * n + 1].w);
-            continue;
+        // "while-while": every lane first descends to its next leaf, then the leaves (the expensive part: prop tests with
+        // nested walks, triangle tests) are processed with the wave converged again
+        while (0 == count) {
+            const uint32_t a = data;
+            const float4   a0 = nodes[2 * a], a1 = nodes[2 * a + 1], b0 = nodes[2 * a + 2], b1 = nodes[2 * a + 3];
+            if (STATS) cnt.nodes += 2;
+            const float dista = nodeIntersect(a0, a1, ray);
+            const float distb = nodeIntersect(b0, b1, ray);
+            const bool  swap = dista > distb;
+            const float dnear = swap ? distb : dista, dfar = swap ? dista : distb;
+            if (FLT_MAX == dnear) {
+                if (0 == sp) return false;
+                const uint32_t n = stack[--sp];
+                data = __float_as_uint(nodes[2 * n].w);
+                count = __float_as_uint(nodes[2 * n + 1].w);
+            } else {
+                data = __float_as_uint(swap ? b0.w : a0.w);
+                count = __float_as_uint(swap ? b1.w : a1.w);
+                if (FLT_MAX != dfar && sp < kStackSize) stack[sp++] = swap ? a : a + 1;
+            }
         }
-        const uint32_t a = data;
-        const float4   a0 = nodes[2 * a], a1 = nodes[2 * a + 1], b0 = nodes[2 * a + 2], b1 = nodes[2 * a + 3];
-        if (STATS) cnt.nodes += 2;
-        const float dista = nodeIntersect(a0, a1, ray);
-        const float distb = nodeIntersect(b0, b1, ray);
-        const bool  swap = dista > distb;
-        const float dnear = swap ? distb : dista, dfar = swap ? dista : distb;
-        if (FLT_MAX == dnear) {
-            if (0 == sp) return false;
-            const uint32_t n = stack[--sp];
-            data = __float_as_uint(nodes[2 * n].w);
-            count = __float_as_uint(nodes[2 * n + 1].w);
-        } else {
-            data = __float_as_uint(swap ? b0.w : a0.w);
-            count = __float_as_uint(swap ? b1.w : a1.w);
-            if (FLT_MAX != dfar && sp < kStackSize) stack[sp++] = swap ? a : a + 1;
-        }
+        if (leaf(data, count)) return true;
+        if (0 == sp) return false;
+        const uint32_t n = stack[--sp];
+        data = __float_as_uint(nodes[2 * n].w);
+        count = __float_as_uint(nodes[2 * n + 1].w);
     }
 }
 
