@@ -120,6 +120,9 @@ __constant__ DScene c_scene;  // the compiled scene's device arrays: read on dem
 #ifndef ZYG_SCATTER_WAVES
 #define ZYG_SCATTER_WAVES 3
 #endif
+#ifndef ZYG_SCATTER_BIG_WAVES  // instantiations with Substitute / multi-sample / mesh-light code: 2 waves with ~20 spilled
+#define ZYG_SCATTER_BIG_WAVES 2  // registers beat 3 waves with 120-250 (measured on configs[2]: 174 -> 158 ms per 3 steps)
+#endif
 #ifndef ZYG_NEE_WAVES
 #define ZYG_NEE_WAVES 3
 #endif
@@ -955,7 +958,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 // SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
 // MULTI: a light has emittance num_samples > 1; MESHL: the scene has TriangleMesh lights
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL>
-__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SCATTER_WAVES) wf_scatter(Params P) {
+__global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     const DScene&      s = c_scene;
     const uint32_t     nxt = P.parity ^ 1u;
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
