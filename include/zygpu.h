@@ -136,7 +136,21 @@ typedef struct ZygpuMaterial {
     float    camera_weight;
     uint32_t emission_normalize;
     uint32_t emission_num_samples;
+    uint32_t color_image;   /* Substitute colour map: index into ZygpuSceneDesc.images, ZYGPU_NULL = the uniform color_a */
+    uint32_t color_sampler; /* ZYGPU_TEX_* bits (texture/sampler_mode.zig:7-68) */
+    float    color_scale[2];/* texture.data.image.scale */
 } ZygpuMaterial;
+
+enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u };
+
+/* 2-D images behind textures (capi.zig:236-298, texture_provider.zig:67-84): Byte3 is read as sRGB and converted to AP1 per
+ * fetch (texture.zig:196-199), Float3 is taken as is (213-216) */
+enum ZygpuImageFormat { ZYGPU_IMAGE_BYTE3_SRGB = 0, ZYGPU_IMAGE_FLOAT3 = 1 };
+typedef struct ZygpuImage {
+    const void* pixels; /* row-major, 3 bytes or 3 floats per pixel */
+    int32_t     width, height;
+    uint32_t    format;
+} ZygpuImage;
 
 /* reference src/core/scene/light/light.zig:32-47 */
 enum ZygpuLightClass { ZYGPU_LIGHT_PORTAL_IMAGE = 0, ZYGPU_LIGHT_PROP = 1, ZYGPU_LIGHT_PROP_IMAGE = 2,
@@ -225,6 +239,8 @@ typedef struct ZygpuSceneDesc {
     ZygpuPropTree        unoccluding; /* finite, purely emissive `Light` entities (scene.zig:78) */
     ZygpuLightTree       light_tree;
     const ZygpuMeshLight* mesh_lights;
+    const ZygpuImage*    images;
+    const float*         srgb_to_float; /* 256 entries: spectrum/srgb.zig:28-38 of i/255 (texture/encoding.zig:11,41-51) */
     ZygpuLuts            luts;
     float    specular_threshold; /* resources.specular_threshold (resource/manager.zig:57) */
     uint32_t num_props;
@@ -233,6 +249,7 @@ typedef struct ZygpuSceneDesc {
     uint32_t num_materials;
     uint32_t num_lights;
     uint32_t num_mesh_lights;
+    uint32_t num_images;
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };

@@ -274,3 +274,18 @@ def test_many_lights(engine, oracle, nee_in_place):
     out = _render_both(engine, oracle, 64, 48, 2, integrator="PTMIS", many_lights=6, split_threshold=0.9, nee_in_place=nee_in_place)
     _check(*out, 2)
     assert out[2].shadow_rays > 4 * out[2].camera_samples  # splitting really produced several picks per vertex
+
+
+@pytest.mark.parametrize("dtype,sampler,scale", [(np.float32, None, None), (np.uint8, {"filter": "Nearest", "address": "Clamp"}, 3.0),
+                                                  (np.uint8, {"filter": "Linear", "address": ["Repeat", "Clamp"]}, [2.5, 0.75])])
+def test_color_map(engine, oracle, dtype, sampler, scale):
+    """Image colour maps on Substitute (texture_sampler.zig:84-168): stochastic bilinear (the stochastic_r draw picks the texel)
+    or nearest fetch, Repeat / Clamp addressing, scale; Byte3 images decode sRGB -> AP1 per fetch, Float3 as is.  The floor
+    (a Rectangle) and a heightfield mesh (interpolated uvs) carry the map."""
+    image = engine.image(scenes.checker_image(8, dtype))
+    textured = scenes.substitute_textured(image, sampler=sampler, scale=scale)
+    mesh = scenes.heightfield_mesh(n=24)
+    out = _render_both(engine, oracle, 80, 60, 3, integrator="PTMIS", boxes=False, mesh=mesh, mesh_material=textured,
+                       floor_material=textured)
+    _check(*out, 3)
+    assert np.std(out[1][40:, :, 0]) > 0.01  # the pattern is visible on the floor

@@ -319,3 +319,32 @@ def test_mesh_light_products(engine):
     assert orders == list(range(n))
     pm = sd.meshes[ml.mesh].primitive_mapping
     assert sorted(pm[i] for i in range(n)) == list(range(n))
+
+
+def test_images_and_color_maps(engine):
+    """su_image_create accepts tightly packed UInt8 x 3 and Float32 x 3 2-D images (capi.zig:236-298 accepts more; the rest
+    reports -1) and a Substitute colour map refers to them by id."""
+    img = engine.image(scenes.checker_image(4, np.uint8))
+    img2 = engine.image(scenes.checker_image(5, np.float32))
+    assert (img, img2) == (0, 1)
+    lib = engine.lib
+    lib.su_image_create.argtypes = [ctypes.c_uint32] * 7 + [ctypes.c_void_p]
+    buf = np.zeros((2, 2, 4), dtype=np.float32)
+    assert lib.su_image_create(0xFFFFFFFF, 4, 4, 2, 2, 1, 16, buf.ctypes.data) == -1  # 4 channels: not supported here
+    assert lib.su_image_create(0xFFFFFFFF, 4, 3, 2, 2, 1, 16, buf.ctypes.data) == -1  # padded pixels are not copied
+    engine.camera(8, 8)
+    m = engine.material(scenes.substitute_textured(img2, sampler={"filter": "Nearest", "address": "Clamp"}, scale=[2, 3]))
+    p = engine.prop(scenes.RECTANGLE, [m])
+    engine.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 2)))
+    sd, _ = engine.compile()
+    mat = sd.materials[m]
+    assert mat.color_image == img2 and mat.color_sampler == 0 and tuple(mat.color_scale) == (2.0, 3.0)
+    assert sd.num_images == 2 and sd.images[1].width == 5 and sd.images[0].format == 0
+    table = np.array([sd.srgb_to_float[i] for i in range(256)])
+    assert table[0] == 0.0 and table[255] == 1.0 and np.all(np.diff(table) > 0)
+    np.testing.assert_allclose(table[128], ((128 / 255 + 0.055) / 1.055) ** 2.4, rtol=1e-6)
+    bad = engine.material(scenes.substitute_textured(7))
+    q = engine.prop(scenes.RECTANGLE, [bad])
+    engine.transformation(q, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 3)))
+    with pytest.raises(RuntimeError):
+        engine.compile()

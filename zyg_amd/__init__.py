@@ -49,7 +49,12 @@ class Material(ctypes.Structure):
                 ("color_b", ctypes.c_float * 3), ("roughness", ctypes.c_float), ("metallic", ctypes.c_float),
                 ("specular", ctypes.c_float), ("ior", ctypes.c_float), ("anisotropy", ctypes.c_float),
                 ("emission", ctypes.c_float * 3), ("cos_a", ctypes.c_float), ("camera_weight", ctypes.c_float),
-                ("emission_normalize", ctypes.c_uint32), ("emission_num_samples", ctypes.c_uint32)]
+                ("emission_normalize", ctypes.c_uint32), ("emission_num_samples", ctypes.c_uint32),
+                ("color_image", ctypes.c_uint32), ("color_sampler", ctypes.c_uint32), ("color_scale", ctypes.c_float * 2)]
+
+
+class Image(ctypes.Structure):
+    _fields_ = [("pixels", ctypes.c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("format", ctypes.c_uint32)]
 
 
 class Light(ctypes.Structure):
@@ -95,10 +100,12 @@ class SceneDesc(ctypes.Structure):
                 ("meshes", ctypes.POINTER(Mesh)), ("materials", ctypes.POINTER(Material)),
                 ("lights", ctypes.POINTER(Light)), ("light_aabbs", ctypes.POINTER(Aabb)),
                 ("light_cones", ctypes.POINTER(ctypes.c_float)), ("solid", PropTree), ("unoccluding", PropTree),
-                ("light_tree", LightTree), ("mesh_lights", ctypes.POINTER(MeshLight)), ("luts", Luts),
+                ("light_tree", LightTree), ("mesh_lights", ctypes.POINTER(MeshLight)), ("images", ctypes.POINTER(Image)),
+                ("srgb_to_float", ctypes.POINTER(ctypes.c_float)), ("luts", Luts),
                 ("specular_threshold", ctypes.c_float),
                 ("num_props", ctypes.c_uint32), ("num_parts", ctypes.c_uint32), ("num_meshes", ctypes.c_uint32),
-                ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32), ("num_mesh_lights", ctypes.c_uint32)]
+                ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32), ("num_mesh_lights", ctypes.c_uint32),
+                ("num_images", ctypes.c_uint32)]
 
 
 class ViewDesc(ctypes.Structure):
@@ -225,6 +232,18 @@ class Engine:
         if m < 0:
             raise RuntimeError("su_material_create failed: " + json_text)
         return m
+
+    def image(self, pixels):
+        """su_image_create (capi.zig:236-298) for an (H, W, 3) array: uint8 (read as sRGB) or float32 (taken as is)."""
+        a = np.ascontiguousarray(pixels)
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype not in (np.uint8, np.float32):
+            raise ValueError("image: (H, W, 3) uint8 or float32")
+        fmt, bpc = (0, 1) if a.dtype == np.uint8 else (4, 4)  # capi.zig:31-37 Format
+        self.lib.su_image_create.argtypes = [ctypes.c_uint32] * 7 + [ctypes.c_void_p]
+        i = self.lib.su_image_create(NULL, fmt, 3, a.shape[1], a.shape[0], 1, 3 * bpc, a.ctypes.data)
+        if i < 0:
+            raise RuntimeError("su_image_create failed")
+        return i
 
     def triangle_mesh(self, indices, positions, normals, uvs=None, parts=None):
         indices = _u32(indices).reshape(-1)

@@ -46,6 +46,12 @@ struct DLightTree {
     uint32_t              two_sided;  // mesh part only
 };
 
+struct DImage {  // ZygpuImage on the device
+    const void* pixels;
+    int32_t     width, height;
+    uint32_t    format;
+};
+
 struct DMeshLight {
     DLightTree      tree;
     const uint32_t* triangle_mapping;
@@ -69,6 +75,8 @@ struct DScene {
     const uint32_t*      unocc_indices;
     DLightTree           light_tree;
     const DMeshLight*    mesh_lights;
+    const DImage*        images;
+    const float*         srgb_to_float;
     const float*         lut_e_m;
     const float*         lut_e_m_avg;
     const float*         lut_e;

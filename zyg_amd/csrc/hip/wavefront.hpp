@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                     geo_n = -geo_n;
                     n = -n;
                 }
-                (void)h.smp.sample1D();  // rs.stochastic_r
+                const float stochastic_r = h.smp.sample1D();  // rs.stochastic_r (vertex.zig:165)
                 if (ZYGPU_MAT_LIGHT == m.kind) {
                     // a pure emitter neither evaluates nor scatters (light_sample.zig:9-11, material_sample.zig:55-59):
                     // no NEE draw, no bxdf sample, throughput = 0 (pathtracer_mis.zig:127-129)
@@ -695,9 +695,11 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                 } else {
                     P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
                     P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
-                    P.pool.rec_n[slot] = f4(n);
-                    P.pool.rec_t[slot] = f4(frag.t);
-                    P.pool.rec_b[slot] = f4(frag.b);
+                    f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
+                    if (kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
+                    P.pool.rec_n[slot] = f4(n, color.x);
+                    P.pool.rec_t[slot] = f4(frag.t, color.y);
+                    P.pool.rec_b[slot] = f4(frag.b, color.z);
                     P.pool.thr[slot] = f4(throughput);
                     storeHead(P, slot, h);
                     alive = true;
@@ -730,15 +732,18 @@ struct Surface {
 ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     const float4 rp = P.pool.rec_p[slot];
     const float4 rg = P.pool.rec_gn[slot];
-    const f3     geo_n = xyz4(rg), n = xyz4(P.pool.rec_n[slot]);
-    const f3     t = xyz4(P.pool.rec_t[slot]), b = xyz4(P.pool.rec_b[slot]);
+    const float4 rn = P.pool.rec_n[slot], rt = P.pool.rec_t[slot], rb = P.pool.rec_b[slot];
+    const f3     geo_n = xyz4(rg), n = xyz4(rn);
+    const f3     t = xyz4(rt), b = xyz4(rb);
     const f3     wo = -xyz4(P.pool.ray_d[slot]);
     const ZygpuMaterial& m = c_scene.materials[__float_as_uint(rp.w)];
+    // a colour map was sampled by wf_shade (it has the uv and the stochastic_r draw) into the records' spare lanes
+    const f3     color = kNull != m.color_image ? mk3(rn.w, rt.w, rb.w) : mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
     const bool   caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
     Surface      sf;
     sf.p = xyz4(rp);
     sf.frag_geo_n = 0.f != rg.w ? -geo_n : geo_n;
-    sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics);
+    sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color);
     return sf;
 }
 

@@ -498,6 +498,28 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     }
     if (!m.upload(meshes.data(), meshes.size(), &s.meshes)) return -1;
 
+    // images behind colour maps
+    std::vector<DImage> images(d->num_images);
+    for (uint32_t i = 0; i < d->num_images; ++i) {
+        const ZygpuImage& hi = d->images[i];
+        const size_t      bytes = size_t(hi.width) * size_t(hi.height) * (ZYGPU_IMAGE_BYTE3_SRGB == hi.format ? 3 : 12);
+        const uint8_t*    pixels = nullptr;
+        if (hi.width <= 0 || hi.height <= 0 || hi.format > ZYGPU_IMAGE_FLOAT3 || !m.upload(static_cast<const uint8_t*>(hi.pixels), bytes, &pixels)) {
+            g_error = "ZygpuImage: bad dimensions / format, or out of device memory";
+            return -2;
+        }
+        images[i] = DImage{pixels, hi.width, hi.height, hi.format};
+    }
+    if (!m.upload(images.data(), images.size(), &s.images)) return -1;
+    if (!m.upload(d->srgb_to_float, d->srgb_to_float ? 256 : 0, &s.srgb_to_float)) return -1;
+    for (uint32_t mi = 0; mi < d->num_materials; ++mi) {
+        const ZygpuMaterial& mat = d->materials[mi];
+        if (ZYGPU_NULL != mat.color_image && (mat.color_image >= d->num_images || !d->srgb_to_float)) {
+            g_error = "a material's colour map names an image that is not in ZygpuSceneDesc.images";
+            return -2;
+        }
+    }
+
     // emissive mesh parts: primitive trees + per-triangle properties
     std::vector<DMeshLight> mesh_lights(d->num_mesh_lights);
     for (uint32_t i = 0; i < d->num_mesh_lights; ++i) {

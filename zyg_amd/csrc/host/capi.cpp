@@ -153,8 +153,11 @@ int32_t su_integrators_create(const char* json) {
     return 0;
 }
 
-int32_t su_image_create(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t*) {
-    return -1;  // image textures: SURVEY §2.2 (texture) — out of scope
+int32_t su_image_create(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height, uint32_t depth,
+                        uint32_t pixel_stride, const uint8_t* data) {
+    if (!g) return -1;
+    const uint32_t image = g->engine.createImage(id, format, num_channels, width, height, depth, pixel_stride, data);
+    return ZYGPU_NULL == image ? -1 : int32_t(image);  // other formats / channel counts: -1, as capi.zig:268-294 for its own gaps
 }
 
 int32_t su_image_update(uint32_t, uint32_t, const uint8_t*) { return -1; }

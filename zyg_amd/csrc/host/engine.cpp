@@ -23,6 +23,46 @@ static Vec4f readColor(const JsonValue& v) {
     return sRGBtoAP1(readVec4f3(v));
 }
 
+// material_provider.zig:438-632 (TextureDescriptor) + 634-678 (readTextureSampler), image ids only: {"usage": "Color", "id": n,
+// "sampler": {"filter": "Nearest" | "Linear", "address": "Clamp" | "Repeat" | [u, v]}, "scale": s | [sx, sy]}
+static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) {
+    if (JsonValue::Object != v.type) return false;
+    const JsonValue* id = v.get("id");
+    if (!id) return false;
+    m.color_image = uint32_t(id->f32(0.f));
+    m.color_sampler = ZYGPU_TEX_LINEAR | ZYGPU_TEX_REPEAT_U | ZYGPU_TEX_REPEAT_V;  // texture.zig:22-27 DefaultMode
+    m.color_scale[0] = m.color_scale[1] = 1.f;
+    auto address = [](const JsonValue& a) { return JsonValue::String == a.type && a.str == "Clamp" ? 0u : 1u; };
+    if (const JsonValue* smp = v.get("sampler")) {
+        if (JsonValue::Object == smp->type) {
+            for (const auto& kv : smp->obj) {
+                if (kv.first == "filter" && JsonValue::String == kv.second.type) {
+                    if (kv.second.str == "Nearest") m.color_sampler &= ~uint32_t(ZYGPU_TEX_LINEAR);
+                    else if (kv.second.str == "Linear") m.color_sampler |= ZYGPU_TEX_LINEAR;
+                } else if (kv.first == "address") {
+                    uint32_t au, av;
+                    if (JsonValue::Array == kv.second.type && kv.second.arr.size() >= 2) {
+                        au = address(kv.second.arr[0]);
+                        av = address(kv.second.arr[1]);
+                    } else {
+                        au = av = address(kv.second);
+                    }
+                    m.color_sampler = (m.color_sampler & ZYGPU_TEX_LINEAR) | (au ? ZYGPU_TEX_REPEAT_U : 0u) | (av ? ZYGPU_TEX_REPEAT_V : 0u);
+                }
+            }
+        }
+    }
+    if (const JsonValue* sc = v.get("scale")) {
+        if (JsonValue::Array == sc->type && sc->arr.size() >= 2) {
+            m.color_scale[0] = sc->arr[0].f32(1.f);
+            m.color_scale[1] = sc->arr[1].f32(1.f);
+        } else {
+            m.color_scale[0] = m.color_scale[1] = sc->f32(1.f);
+        }
+    }
+    return true;
+}
+
 static ZygpuTrafo composedTrafo(const Transformation& t, const Vec4f& origin) {  // composed_transformation.zig:17-29
     const Mat3x3 r = quaternionToMat3x3(t.rotation);
     ZygpuTrafo   out;
@@ -120,6 +160,7 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
     m.cos_a = -1.f;
     m.camera_weight = 1.f;
     m.emission_num_samples = 1;
+    m.color_image = ZYGPU_NULL;
     m.roughness = 0.8f;
     m.metallic = 0.f;
     m.specular = 1.f;
@@ -174,8 +215,10 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
                 const std::string& k = kv.first;
                 const JsonValue&   x = kv.second;
                 if (k == "color") {
-                    const Vec4f col = readColor(x);
-                    for (int i = 0; i < 3; ++i) m.color_a[i] = col[i];
+                    if (!readColorTexture(x, m)) {
+                        const Vec4f col = readColor(x);
+                        for (int i = 0; i < 3; ++i) m.color_a[i] = col[i];
+                    }
                 } else if (k == "roughness") {
                     m.roughness = x.f32(m.roughness);
                 } else if (k == "metallic") {
@@ -383,6 +426,22 @@ uint32_t Engine::createMesh(uint32_t id, uint32_t num_parts_in, const uint32_t* 
     s.mesh = uint32_t(meshes_.size() - 1);
     shapes_.push_back(s);
     return uint32_t(shapes_.size() - 1);
+}
+
+uint32_t Engine::createImage(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height, uint32_t depth,
+                             uint32_t pixel_stride, const uint8_t* data) {
+    (void)id;  // ids are assigned in creation order, like the other resources created with id = NULL
+    const bool u8 = 0 == format, f32 = 4 == format;  // capi.zig:31-37 Format: UInt8, UInt16, UInt32, Float16, Float32
+    if (!(u8 || f32) || 3 != num_channels || 1 != depth || 0 == width || 0 == height || !data) return ZYGPU_NULL;
+    const uint32_t bpp = (u8 ? 1u : 4u) * num_channels;
+    if (bpp != pixel_stride) return ZYGPU_NULL;  // the reference only copies tightly packed pixels (capi.zig:264-266)
+    HostImage img;
+    img.format = u8 ? ZYGPU_IMAGE_BYTE3_SRGB : ZYGPU_IMAGE_FLOAT3;
+    img.width = int32_t(width);
+    img.height = int32_t(height);
+    img.pixels.assign(data, data + size_t(width) * height * bpp);
+    images_.push_back(std::move(img));
+    return uint32_t(images_.size() - 1);
 }
 
 bool Engine::shapeFinite(uint32_t shape) const {  // shape.zig:92-97
@@ -914,6 +973,21 @@ int Engine::compile(uint32_t frame) {
     }
     d.mesh_lights = c_mesh_lights_.data();
     d.num_mesh_lights = uint32_t(c_mesh_lights_.size());
+    c_images_.resize(images_.size());
+    for (size_t i = 0; i < images_.size(); ++i)
+        c_images_[i] = ZygpuImage{images_[i].pixels.data(), images_[i].width, images_[i].height, images_[i].format};
+    d.images = c_images_.data();
+    d.num_images = uint32_t(c_images_.size());
+    if (srgb_to_float_.empty()) {  // texture/encoding.zig:41-51 over spectrum/srgb.zig:28-38
+        srgb_to_float_.resize(256);
+        for (int i = 0; i < 256; ++i) {
+            const float c = float(i) / 255.f;
+            srgb_to_float_[i] = c <= 0.f ? 0.f : c < 0.04045f ? c / 12.92f : c < 1.f ? std::pow((c + 0.055f) / 1.055f, 2.4f) : 1.f;
+        }
+    }
+    d.srgb_to_float = srgb_to_float_.data();
+    for (const ZygpuMaterial& m : materials_)
+        if (ZYGPU_NULL != m.color_image && m.color_image >= images_.size()) return -4;  // a colour map without its image
     for (const ZygpuMaterial& m : materials_) {
         if (ZYGPU_MAT_SUBSTITUTE != m.kind) continue;
         const ggxlut::Tables& t = ggxlut::tables();  // computed once per process (ggx_lut.hpp)

@@ -59,6 +59,12 @@ struct HostMeshLight {
     Vec4f                 cone;       // power-weighted dominant axis + cos of the widest deviation
 };
 
+struct HostImage {  // image/typed_image.zig: 2-D only
+    uint32_t             format = ZYGPU_IMAGE_FLOAT3;
+    int32_t              width = 0, height = 0;
+    std::vector<uint8_t> pixels;
+};
+
 struct HostShape {
     uint32_t kind = ZYGPU_SHAPE_RECTANGLE;
     uint32_t mesh = ZYGPU_NULL;
@@ -85,6 +91,9 @@ class Engine {
     Engine();
 
     // --- resources ---
+    // capi.zig:236-298: UInt8 x 3 (read as sRGB) and Float32 x 3, depth 1; returns the image id or ZYGPU_NULL
+    uint32_t createImage(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height, uint32_t depth,
+                         uint32_t pixel_stride, const uint8_t* data);
     uint32_t createMaterial(uint32_t id, const JsonValue& v);  // returns id or ZYGPU_NULL
     int      updateMaterial(uint32_t id, const JsonValue& v);
     uint32_t createMesh(uint32_t id, uint32_t num_parts, const uint32_t* parts, uint32_t num_triangles,
@@ -167,6 +176,9 @@ class Engine {
     std::vector<ZygpuTrafo>   c_trafos_;
     std::vector<ZygpuAabb>    c_aabbs_;
     std::vector<ZygpuMesh>    c_meshes_;
+    std::vector<HostImage>    images_;
+    std::vector<ZygpuImage>   c_images_;
+    std::vector<float>        srgb_to_float_;
     std::deque<HostMeshLight>   mesh_lights_;   // stable addresses: the trees point into their own vectors
     std::vector<ZygpuMeshLight> c_mesh_lights_;
     uint32_t prepareMeshLight(uint32_t mesh, uint32_t part, uint32_t material, bool two_sided);

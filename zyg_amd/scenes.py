@@ -41,6 +41,24 @@ def substitute(color, roughness=0.8, metallic=0.0):
     return json.dumps({"rendering": {"Substitute": {"color": color, "roughness": roughness, "metallic": metallic}}})
 
 
+def substitute_textured(image_id, roughness=0.8, metallic=0.0, sampler=None, scale=None):
+    """Substitute with an image colour map (material_provider.zig:438-632: {"usage": "Color", "id": n, ...})."""
+    color = {"usage": "Color", "id": int(image_id)}
+    if sampler:
+        color["sampler"] = sampler
+    if scale is not None:
+        color["scale"] = scale
+    return json.dumps({"rendering": {"Substitute": {"color": color, "roughness": roughness, "metallic": metallic}}})
+
+
+def checker_image(n=8, dtype=np.float32):
+    """n x n test image with distinct texels (a smooth ramp times a checker), float32 linear or uint8 sRGB."""
+    y, x = np.mgrid[0:n, 0:n]
+    ramp = np.stack([(x + 1) / n, (y + 1) / n, 1.0 - (x + y) / (2.0 * n)], axis=-1)
+    img = ramp * np.where((x + y) % 2 == 0, 0.85, 0.35)[..., None]
+    return (img * 255.0 + 0.5).astype(np.uint8) if dtype == np.uint8 else img.astype(np.float32)
+
+
 def light_material(spectrum=(17.0, 12.0, 4.0), value=1.0, num_samples=1):
     return json.dumps({"rendering": {"Light": {"emittance": {"spectrum": list(spectrum), "value": value,
                                                              "num_samples": num_samples}}}})
@@ -167,7 +185,8 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
-            mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0):
+            mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
+            floor_material=None):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -203,7 +222,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         return p
 
     # box: x in [-1, 1], y in [0, 2], z in [-1, 1]; all normals point inward; open towards -z (camera side)
-    wall(white, (1, 0, 0), (0, 0, -1), (2, 2, 1), (0, 0, 0))   # floor, n = +y
+    floor = white if floor_material is None else engine.material(floor_material)
+    wall(floor, (1, 0, 0), (0, 0, -1), (2, 2, 1), (0, 0, 0))   # floor, n = +y
     wall(white, (1, 0, 0), (0, 0, 1), (2, 2, 1), (0, 2, 0))    # ceiling, n = -y
     wall(white, (-1, 0, 0), (0, 1, 0), (2, 2, 1), (0, 1, 1))   # back, n = -z
     wall(red, (0, 0, -1), (0, 1, 0), (2, 2, 1), (-1, 1, 0))    # left, n = +x
