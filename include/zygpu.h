@@ -183,6 +183,8 @@ typedef struct ZygpuLightTree {
     const uint32_t*       node_middles;
     const uint32_t*       light_orders;
     const uint32_t*       light_mapping;
+    const float*          infinite_cdf; /* Distribution1D cdf over the infinite lights' powers, num_infinite_lights + 1 entries
+                                           (light_tree.zig:260, base/math/distribution_1d.zig:87-124); NULL without infinite lights */
     ZygpuAabb bounds;
     float     infinite_weight;
     float     infinite_guard;
@@ -239,6 +241,7 @@ typedef struct ZygpuSceneDesc {
     ZygpuPropTree        unoccluding; /* finite, purely emissive `Light` entities (scene.zig:78) */
     ZygpuLightTree       light_tree;
     const ZygpuMeshLight* mesh_lights;
+    const uint32_t*      infinite_props; /* props with an infinite shape (scene.zig:76), tested when a ray escapes */
     const ZygpuImage*    images;
     const float*         srgb_to_float; /* 256 entries: spectrum/srgb.zig:28-38 of i/255 (texture/encoding.zig:11,41-51) */
     ZygpuLuts            luts;
@@ -250,6 +253,7 @@ typedef struct ZygpuSceneDesc {
     uint32_t num_lights;
     uint32_t num_mesh_lights;
     uint32_t num_images;
+    uint32_t num_infinite_props;
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };

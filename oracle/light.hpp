@@ -194,9 +194,19 @@ struct LightTreeView {
         float                 ip = 0.f;
         const bool            split = split_threshold > 0.f;
 
-        if (!(split && tr.num_infinite_lights < 64 - 1)) {
+        if (split && tr.num_infinite_lights < 64 - 1) {
+            for (uint32_t i = 0; i < tr.num_infinite_lights; ++i) buffer[current_light++] = {tr.light_mapping[i], 1.f};
+        } else {
             ip = tr.infinite_weight;
-            // random < infinite_guard never holds without infinite lights (guard == 0 or infinite_weight == 0)
+            if (random < tr.infinite_guard) {
+                // Distribution1D.sampleDiscrete (distribution_1d.zig:49-59, 209-217; the lut only shortens the search)
+                const uint32_t size = tr.num_infinite_lights + 1;
+                uint32_t       i = 1;
+                while (i < size - 1 && !(tr.infinite_cdf[i] >= random)) ++i;
+                const uint32_t offset = i - 1;
+                buffer[0] = {tr.light_mapping[offset], (tr.infinite_cdf[offset + 1] - tr.infinite_cdf[offset]) * ip};
+                return 1;
+            }
         }
         if (0 == tr.num_nodes) return current_light;
 
@@ -261,7 +271,7 @@ struct LightTreeView {
         const uint32_t        lo = tr.light_orders[id];
         const bool            split = split_threshold > 0.f;
         const bool            split_infinite = split && tr.num_infinite_lights < 64 - 1;
-        if (lo < tr.infinite_end) return split_infinite ? 1.f : 0.f;
+        if (lo < tr.infinite_end) return split_infinite ? 1.f : tr.infinite_weight * (tr.infinite_cdf[lo + 1] - tr.infinite_cdf[lo]);
         if (0 == tr.num_nodes) return 0.f;
 
         const float    ip = split_infinite ? 0.f : tr.infinite_weight;
@@ -406,6 +416,45 @@ inline float rectanglePdf(V4 p, const Trafo& frag_trafo, float split_threshold, 
     const V4      lp = frag_trafo.worldToFramePoint(p);
     const SphQuad squad = SphQuad::init(scale, lp);
     return nsf * squad.pdf(scale);
+}
+
+// ---------- Distant lights: distant.zig:21-146 ----------
+
+inline float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - std::sqrt(1.f / (radius * radius + 1.f))); }
+
+inline uint32_t distantSampleTo(V4 n, const Trafo& trafo, bool total_sphere, Sampler& sampler, SampleTo* buffer) {
+    const float radius = trafo.scaleX();
+    if (radius <= 0.f) return 0;
+    float r2[2];
+    sampler.sample2D(r2);
+    float x, y;
+    diskConcentric(r2[0], r2[1], x, y);
+    const V4 ws = S(radius) * trafo.transformVector(mk(x, y, 0.f));
+    const V4 dir = normalize3(ws - trafo.r[2]);
+    if (dot3(dir, n) <= 0.f && !total_sphere) return 0;
+    const V4 p = S(kRayMaxT) * dir;
+    buffer[0].p = mk(p[0], p[1], p[2], 1.f / distantSolidAngle(radius));
+    buffer[0].n = trafo.r[2];
+    buffer[0].wi = dir;
+    buffer[0].uvw = S(0.f);
+    return 1;
+}
+
+// Distant.intersect (distant.zig:22-52): only rays that left the scene (max_t == RayMaxT)
+inline bool distantIntersect(const Ray& ray, const Trafo& trafo, float& u, float& v) {
+    const float radius = trafo.scaleX();
+    const V4    n = trafo.r[2];
+    const float b = dot3(n, ray.direction);
+    if (b > 0.f || ray.max_t < kRayMaxT || radius <= 0.f) return false;
+    const float det = (b * b) - dot3(n, n) + (radius * radius);
+    if (det >= 0.f) {
+        const V4 k = ray.direction - n;
+        const V4 sk = k / S(radius);
+        u = dot3(trafo.r[0], sk);
+        v = dot3(trafo.r[1], sk);
+        return true;
+    }
+    return false;
 }
 
 // ---------- TriangleMesh lights: triangle_mesh.zig:391-703 ----------
@@ -574,8 +623,9 @@ inline float meshPdf(const ZygpuSceneDesc& d, const ZygpuMeshLight& ml, V4 dir, 
     return (tri_pdf * sl) / (n_dot_dir * tri_area);
 }
 
-// shape.zig:401-416 (finite shapes)
-inline Ray shadowRay(V4 origin, const SampleTo& sample) {
+// shape.zig:401-416
+inline Ray shadowRay(V4 origin, const SampleTo& sample, bool infinite_shape = false) {
+    if (infinite_shape) return Ray::init(origin, sample.wi, 0.f, kRayMaxT);
     const V4    light_pos = offsetRay(sample.p, sample.n);
     const V4    shadow_axis = light_pos - origin;
     const float shadow_len = length3(shadow_axis);

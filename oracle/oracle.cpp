@@ -126,6 +126,7 @@ struct Worker {
         const ZygpuProp& p = rc->scene->props[prop];
         const V4         s = trafo.scale();
         if (ZYGPU_SHAPE_RECTANGLE == p.shape) return s[0] * s[1];
+        if (ZYGPU_SHAPE_DISTANT == p.shape) return distantSolidAngle(s[0]);  // "the solid angle, not the area" (shape.zig:140-142)
         return rc->scene->meshes[p.mesh].part_areas[part] * (s[0] * s[1]);
     }
 
@@ -148,6 +149,8 @@ struct Worker {
             kNull != l.sampler
                 ? meshPdf(*rc->scene, rc->scene->mesh_lights[l.sampler], v.ray.direction, v.origin, v.geo_n, frag, v.state.translucent,
                           v.light_split_threshold)
+            : ZYGPU_SHAPE_DISTANT == rc->scene->props[l.prop].shape
+                ? 1.f / distantSolidAngle(frag.isec.trafo.scaleX())  // distant.zig:139-141
                 : rectanglePdf(v.origin, frag.isec.trafo, v.light_split_threshold, l.num_samples);
         return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
     }
@@ -260,6 +263,37 @@ struct Worker {
 
     bool causticsResolve(const VState& s) const { return s.primary_ray ? true : 0 != rc->view->caustics_path; }
 
+    // the infinite props a ray reaches when it leaves the scene (Distant only): Context.propIntersect + Distant.intersect /
+    // fragment (prop.zig:163-197, distant.zig:22-74), then Vertex.evaluateRadiance; `only_non_lights`: PathtracerDL's filter
+    V4 infiniteEmission(const Vertex& v, Sampler& sampler, bool only_non_lights) {
+        V4 energy = S(0.f);
+        for (uint32_t i = 0; i < rc->scene->num_infinite_props; ++i) {
+            const uint32_t   p = rc->scene->infinite_props[i];
+            const ZygpuProp& prop = rc->scene->props[p];
+            if (!SceneView::visible(prop.flags, v.depth_surface)) continue;
+            cnt.instances_tested += 1;
+            if (!aabbIntersect(rc->scene->aabbs[p], v.ray)) continue;
+            Fragment frag;
+            frag.isec.trafo = rc->sv.propTrafo(p);
+            float u, vv;
+            if (!distantIntersect(v.ray, frag.isec.trafo, u, vv)) continue;
+            frag.prop = p;
+            frag.isec.t = kRayMaxT;
+            frag.isec.u = u;
+            frag.isec.v = vv;
+            frag.isec.primitive = 0;
+            frag.p = S(kRayMaxT) * v.ray.direction;
+            frag.geo_n = frag.n = frag.isec.trafo.r[2];
+            frag.t = frag.isec.trafo.r[0];
+            frag.b = frag.isec.trafo.r[1];
+            frag.uvw = mk((u + 1.f) * 0.5f, (vv + 1.f) * 0.5f, 0.f, 0.f);
+            frag.part = 0;
+            if (only_non_lights && !(v.state.singular || kNull == rc->sv.propLightId(p, 0))) continue;
+            energy += evaluateRadiance(v, frag, sampler);
+        }
+        return energy;
+    }
+
     // connectLight of the three integrators: pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341
     V4 connectLight(Vertex& v, const Fragment& frag, Sampler& sampler) {
         const uint32_t kind = rc->view->integrator;
@@ -271,18 +305,21 @@ struct Worker {
             v.state.singular = true;
             if (frag.hit()) energy = evaluateRadiance(v, frag, sampler);
             energy += emission(v, sampler);
+            energy += infiniteEmission(v, sampler, false);
             v.state.singular = singular;
         } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
             if (frag.hit()) {
                 if (v.state.singular || kNull == rc->sv.propLightId(frag.prop, frag.part)) energy = evaluateRadiance(v, frag, sampler);
             }
             if (v.state.singular) energy += emission(v, sampler);
+            energy += infiniteEmission(v, sampler, true);
         } else {
             v.light_split_threshold = splitThreshold(rc->view->split_threshold, v.depth);
             if (frag.hit()) energy = evaluateRadiance(v, frag, sampler);
             energy += emission(v, sampler);
+            if (kRayMaxT == v.ray.max_t) energy += infiniteEmission(v, sampler, false);
         }
-        return energy;  // no infinite props in scope
+        return energy;
     }
 
     // pathtracer_mis.zig:174-278 (MIS) / pathtracer_dl.zig:120-171 (DL)
@@ -308,17 +345,19 @@ struct Worker {
 
             SampleTo       samples[64];
             const float    sample_threshold = mis ? v.light_split_threshold : 0.f;
+            const bool     distant = ZYGPU_SHAPE_DISTANT == rc->scene->props[light.prop].shape;
             const uint32_t num_samples =
                 kNull != light.sampler
                     ? meshSampleTo(*rc->scene, rc->scene->mesh_lights[light.sampler], p, n, trafo, 0 != light.two_sided, translucent,
                                    sample_threshold, sampler, samples)
+                : distant ? distantSampleTo(n, trafo, translucent, sampler, samples)
                     : rectangleSampleTo(p, n, trafo, 0 != light.two_sided, translucent, sample_threshold, light.num_samples, sampler,
                                         samples);
 
             V4 occluded = S(0.f);
             for (uint32_t si = 0; si < num_samples; ++si) {
                 const SampleTo& ls = samples[si];
-                const Ray       shadow = shadowRay(fragOffsetP(frag, ls.wi), ls);
+                const Ray       shadow = shadowRay(fragOffsetP(frag, ls.wi), ls, distant);
                 cnt.shadow_rays += 1;
                 if (!rc->sv.visibility(shadow, cnt)) continue;
 

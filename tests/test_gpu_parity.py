@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-3
 
 
-def _render_both(engine, oracle, w, h, spp, stats=True, nee_in_place=0, **kw):
-    scenes.cornell(engine, w, h, spp, **kw)
+def _render_both(engine, oracle, w, h, spp, stats=True, nee_in_place=0, scene=None, **kw):
+    (scene or scenes.cornell)(engine, w, h, spp, **kw)
     engine.start_frame(0)
     ctx = engine.context()
     assert engine.lib.zygpu_set_option(ctx, b"nee_in_place", nee_in_place) == 0
@@ -289,3 +289,12 @@ def test_color_map(engine, oracle, dtype, sampler, scale):
                        floor_material=textured)
     _check(*out, 3)
     assert np.std(out[1][40:, :, 0]) > 0.01  # the pattern is visible on the floor
+
+
+@pytest.mark.parametrize("integrator,quad", [("PT", False), ("PTDL", True), ("PTMIS", False), ("PTMIS", True)])
+def test_distant_light(engine, oracle, integrator, quad):
+    """An infinite (Distant) light over an open scene: picked from the tree's infinite-light distribution (light_tree.zig:357-376),
+    sampled as a disc of directions, shadow rays to infinity, emission when a ray leaves the scene (distant.zig:21-146)."""
+    out = _render_both(engine, oracle, 80, 60, 3, scene=scenes.outdoor, integrator=integrator, sun_radius=0.08, extra_quad_light=quad)
+    _check(*out, 3)
+    assert integrator == "PT" or out[2].shadow_rays > 0

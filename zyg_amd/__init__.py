@@ -71,7 +71,7 @@ class LightNode(ctypes.Structure):
 class LightTree(ctypes.Structure):
     _fields_ = [("nodes", ctypes.POINTER(LightNode)), ("node_middles", ctypes.POINTER(ctypes.c_uint32)),
                 ("light_orders", ctypes.POINTER(ctypes.c_uint32)), ("light_mapping", ctypes.POINTER(ctypes.c_uint32)),
-                ("bounds", Aabb), ("infinite_weight", ctypes.c_float), ("infinite_guard", ctypes.c_float),
+                ("infinite_cdf", ctypes.POINTER(ctypes.c_float)), ("bounds", Aabb), ("infinite_weight", ctypes.c_float), ("infinite_guard", ctypes.c_float),
                 ("infinite_end", ctypes.c_uint32), ("max_split_depth", ctypes.c_uint32),
                 ("num_lights", ctypes.c_uint32), ("num_infinite_lights", ctypes.c_uint32),
                 ("num_nodes", ctypes.c_uint32)]
@@ -100,12 +100,12 @@ class SceneDesc(ctypes.Structure):
                 ("meshes", ctypes.POINTER(Mesh)), ("materials", ctypes.POINTER(Material)),
                 ("lights", ctypes.POINTER(Light)), ("light_aabbs", ctypes.POINTER(Aabb)),
                 ("light_cones", ctypes.POINTER(ctypes.c_float)), ("solid", PropTree), ("unoccluding", PropTree),
-                ("light_tree", LightTree), ("mesh_lights", ctypes.POINTER(MeshLight)), ("images", ctypes.POINTER(Image)),
+                ("light_tree", LightTree), ("mesh_lights", ctypes.POINTER(MeshLight)), ("infinite_props", ctypes.POINTER(ctypes.c_uint32)), ("images", ctypes.POINTER(Image)),
                 ("srgb_to_float", ctypes.POINTER(ctypes.c_float)), ("luts", Luts),
                 ("specular_threshold", ctypes.c_float),
                 ("num_props", ctypes.c_uint32), ("num_parts", ctypes.c_uint32), ("num_meshes", ctypes.c_uint32),
                 ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32), ("num_mesh_lights", ctypes.c_uint32),
-                ("num_images", ctypes.c_uint32)]
+                ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32)]
 
 
 class ViewDesc(ctypes.Structure):

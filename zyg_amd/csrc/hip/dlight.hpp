@@ -164,8 +164,26 @@ struct LightTree {
         uint32_t   current_light = 0;
         float      ip = 0.f;
         const bool split = split_threshold > 0.f;
-        if (!(split && t.num_infinite < kMaxLightPicks - 1)) ip = t.infinite_weight;
-        if (0 == t.num_nodes) return 0;
+        // infinite lights are never part of the BVH (light_tree.zig:357-376): all of them when splitting, else one from the
+        // discrete distribution over their powers when the random number falls below the guard
+        if (split && t.num_infinite < kMaxLightPicks - 1) {
+            for (uint32_t i = 0; i < t.num_infinite; ++i) {
+                visit(current_light, LightPick{t.mapping[i], 1.f});
+                current_light += 1;
+            }
+        } else {
+            ip = t.infinite_weight;
+            if (random < t.infinite_guard) {
+                // Distribution1D.sampleDiscrete (distribution_1d.zig:49-59, 209-217; the lut only shortens the search)
+                const uint32_t size = t.num_infinite + 1;
+                uint32_t       i = 1;
+                while (i < size - 1 && !(t.infinite_cdf[i] >= random)) ++i;
+                const uint32_t offset = i - 1;
+                visit(0u, LightPick{t.mapping[offset], (t.infinite_cdf[offset + 1] - t.infinite_cdf[offset]) * ip});
+                return 1;
+            }
+        }
+        if (0 == t.num_nodes) return current_light;
 
         const float    pd = 1.f - ip;
         const uint32_t max_split_depth = t.max_split_depth;
@@ -246,6 +264,7 @@ struct LightTree {
         const uint32_t lo = t.orders[id];
         const bool     split = split_threshold > 0.f;
         const bool     split_infinite = split && t.num_infinite < kMaxLightPicks - 1;
+        if (lo < t.infinite_end) return split_infinite ? 1.f : t.infinite_weight * (t.infinite_cdf[lo + 1] - t.infinite_cdf[lo]);
         if (0 == t.num_nodes) return 0.f;
         const float    ip = split_infinite ? 0.f : t.infinite_weight;
         const uint32_t max_split_depth = t.max_split_depth;
@@ -392,6 +411,44 @@ ZD float rectanglePdf(f3 p, const Trafo& frag_trafo, uint32_t num_samples) {  //
     return float(num_samples) * squad.pdf(frag_trafo.scale);
 }
 
+// ---------------------------------------------------------------- Distant lights (distant.zig:21-146)
+
+ZD float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - sqrtf(1.f / (radius * radius + 1.f))); }
+
+ZD bool distantSampleTo(f3 n, const Trafo& trafo, bool total_sphere, Sampler& sampler, SampleTo& out) {
+    const float radius = trafo.scale.x;
+    if (radius <= 0.f) return false;
+    float r0, r1;
+    sampler.sample2D(r0, r1);
+    float x, y;
+    diskConcentric(r0, r1, x, y);
+    const f3 ws = S3(radius) * trafo.transformVector(mk3(x, y, 0.f));
+    const f3 dir = normalize3(ws - trafo.r2);
+    if (dot3(dir, n) <= 0.f && !total_sphere) return false;
+    out.p = S3(kRayMaxT) * dir;
+    out.n = trafo.r2;
+    out.wi = dir;
+    out.pdf = 1.f / distantSolidAngle(radius);
+    return true;
+}
+
+// Distant.intersect (distant.zig:22-52): only rays that left the scene (max_t == RayMaxT)
+ZD bool distantIntersect(const Ray& ray, const Trafo& trafo, float& u, float& v) {
+    const float radius = trafo.scale.x;
+    const f3    n = trafo.r2;
+    const float b = dot3(n, ray.direction);
+    if (b > 0.f || ray.max_t < kRayMaxT || radius <= 0.f) return false;
+    const float det = (b * b) - dot3(n, n) + (radius * radius);
+    if (det >= 0.f) {
+        const f3 k = ray.direction - n;
+        const f3 sk = k / S3(radius);
+        u = dot3(trafo.r0, sk);
+        v = dot3(trafo.r1, sk);
+        return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------- TriangleMesh lights (triangle_mesh.zig:391-703)
 
 ZD f3 orthogonalize(f3 a, f3 b) { return normalize3(fma3(S3(-dot3(a, b)), a, b)); }  // a is normalised (391-394)
@@ -532,7 +589,12 @@ ZD float meshLightPdf(const DScene& s, const DMeshLight& ml, f3 dir, f3 p, f3 n,
 }
 
 // shape.zig:401-416
-ZD void shadowRay(f3 origin, const SampleTo& sample, f3& dir, float& len) {
+ZD void shadowRay(f3 origin, const SampleTo& sample, f3& dir, float& len, bool infinite_shape = false) {
+    if (infinite_shape) {
+        dir = sample.wi;
+        len = kRayMaxT;
+        return;
+    }
     const f3 light_pos = offsetRay(sample.p, sample.n);
     const f3 shadow_axis = light_pos - origin;
     len = length3(shadow_axis);

@@ -40,9 +40,10 @@ struct DLightTree {
     const uint32_t*       orders;
     const uint32_t*       mapping;
     const float4*         tri_props;  // mesh part: 2 per triangle (centre.xyz, radius) (normal.xyz, relative power); scene: null
+    const float*          infinite_cdf;  // discrete distribution over the infinite lights (num_infinite + 1 entries)
     float4                bounds_min, bounds_max;
-    float                 infinite_weight;
-    uint32_t              max_split_depth, num_nodes, num_infinite;
+    float                 infinite_weight, infinite_guard;
+    uint32_t              max_split_depth, num_nodes, num_infinite, infinite_end;
     uint32_t              two_sided;  // mesh part only
 };
 
@@ -75,6 +76,8 @@ struct DScene {
     const uint32_t*      unocc_indices;
     DLightTree           light_tree;
     const DMeshLight*    mesh_lights;
+    const uint32_t*      infinite_props;
+    uint32_t             num_infinite_props;
     const DImage*        images;
     const float*         srgb_to_float;
     const float*         lut_e_m;

@@ -500,6 +500,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
 ZD float shapeArea(const DScene& s, uint32_t prop, uint32_t part, const Trafo& trafo) {  // shape.zig:132-152
     const ZygpuProp p = s.props[prop];
     if (ZYGPU_SHAPE_RECTANGLE == p.shape) return trafo.scale.x * trafo.scale.y;
+    if (ZYGPU_SHAPE_DISTANT == p.shape) return distantSolidAngle(trafo.scale.x);  // "the solid angle, not the area" (shape.zig:140-142)
     return s.meshes[p.mesh].part_areas[part] * (trafo.scale.x * trafo.scale.y);
 }
 
@@ -530,6 +531,8 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
     if (MESHL && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
         sample_pdf = meshLightPdf(s, s.mesh_lights[light.sampler], ray_direction, v.vorigin, v.vgeo_n, frag.trafo, frag.p, frag.geo_n,
                                   frag.primitive, translucent, v.light_split_threshold);
+    } else if (MESHL && ZYGPU_SHAPE_DISTANT == s.props[light.prop].shape) {  // -> distant.zig:139-141
+        sample_pdf = 1.f / distantSolidAngle(frag.trafo.scale.x);
     } else {  // -> rectangle.zig:554-575, with the light's sample count under the previous vertex's split threshold
         sample_pdf = rectanglePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
     }
@@ -545,6 +548,40 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
     const f3    energy = materialRadiance(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface);
     const float weight = lightPdf<MESHL>(s, v, -wo, frag);
     return S3(weight) * energy;
+}
+
+// the infinite props a ray reaches when it leaves the scene (Distant only): Context.propIntersect + Distant.intersect /
+// fragment (prop.zig:163-197, distant.zig:22-74), then Vertex.evaluateRadiance; `only_non_lights`: PathtracerDL's filter
+template <bool STATS>
+ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampler& smp, bool only_non_lights, Counters& cnt) {
+    f3       energy = S3(0.f);
+    const f3 wo = -ray.direction;
+    for (uint32_t i = 0; i < s.num_infinite_props; ++i) {
+        const uint32_t  p = s.infinite_props[i];
+        const ZygpuProp prop = s.props[p];
+        if (!propVisibleAtDepth(prop.flags, v.depth_surface)) continue;
+        if (STATS) cnt.instances += 1;
+        if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
+        Fragment frag;
+        frag.trafo = loadTrafo(s, p);
+        float u, vv;
+        if (!distantIntersect(ray, frag.trafo, u, vv)) continue;
+        frag.prop = p;
+        frag.t_hit = kRayMaxT;
+        frag.u = u;
+        frag.v = vv;
+        frag.primitive = 0;
+        frag.p = S3(kRayMaxT) * ray.direction;
+        frag.geo_n = frag.n = frag.trafo.r2;
+        frag.t = frag.trafo.r0;
+        frag.b = frag.trafo.r1;
+        frag.uv0 = (u + 1.f) * 0.5f;
+        frag.uv1 = (vv + 1.f) * 0.5f;
+        frag.part = 0;
+        if (only_non_lights && !((v.flags & ST_SINGULAR) || kNull == s.light_ids[prop.parts_start])) continue;
+        energy = energy + evaluateRadiance<true>(s, v, wo, frag, smp);
+    }
+    return energy;
 }
 
 // the evaluation half of PropBvh.emission: the candidates wf_intersect recorded, in its traversal order
@@ -623,7 +660,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                     const uint32_t  part = ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[hit.primitive]) : 0u;
                     emissive = 0 != (s.materials[s.material_ids[hp.parts_start + part]].flags & ZYGPU_MATF_EMISSIVE);
                 }
-                defer = connectsLights(h.flags) && (emissive || 0 != P.pool.ucount[slot]);
+                // infinite props: PathtracerMIS looks at them when the ray left the scene, the other two always walk the list
+                const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || !has_hit);
+                defer = connectsLights(h.flags) && (emissive || 0 != P.pool.ucount[slot] || infinite);
             }
             if (!defer) {
             Fragment frag;
@@ -644,18 +683,21 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                     v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
                     if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
+                    if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
                 } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
                     if (has_hit) {
                         const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
                         if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     }
                     if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
+                    if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, true, cnt);
                 } else {
                     v.light_split_threshold = splitThreshold(h.vdepth);
                     if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     tm.mark(1);
                     energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
                     tm.mark(2);
+                    if (MESHL && !has_hit) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);  // RayMaxT == max_t
                 }
             }
             f3 throughput = xyz4(P.pool.thr[slot]);
@@ -1008,11 +1050,12 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 f3          occluded = S3(0.f);
 
                 // evaluateLight's loop body for one light sample (pathtracer_mis.zig:248-272 / pathtracer_dl.zig:150-166)
-                auto connect = [&](const SampleTo& ls) {
+                const bool distant = MESHL && ZYGPU_SHAPE_DISTANT == s.props[light.prop].shape;
+                auto       connect = [&](const SampleTo& ls) {
                     const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
                     f3       sdir;
                     float    slen;
-                    shadowRay(sorigin, ls, sdir, slen);
+                    shadowRay(sorigin, ls, sdir, slen, distant);
                     Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
                     if (STATS) shadow_rays += 1;
                     if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
@@ -1051,6 +1094,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                         SampleTo ls;
                         if (msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
                     });
+                } else if (distant) {
+                    SampleTo ls;
+                    if (distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
                 } else {
                     const uint32_t         n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
                     const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);

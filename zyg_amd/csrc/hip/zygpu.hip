@@ -264,10 +264,13 @@ bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out
     ok = ok && m.upload(lt.light_mapping, lt.num_lights, &out->mapping);
     out->bounds_min = make_float4(lt.bounds.min[0], lt.bounds.min[1], lt.bounds.min[2], lt.bounds.min[3]);
     out->bounds_max = make_float4(lt.bounds.max[0], lt.bounds.max[1], lt.bounds.max[2], lt.bounds.max[3]);
+    ok = ok && m.upload(lt.infinite_cdf, lt.infinite_cdf ? lt.num_infinite_lights + 1 : 0, &out->infinite_cdf);
     out->infinite_weight = lt.infinite_weight;
+    out->infinite_guard = lt.infinite_cdf ? lt.infinite_guard : 0.f;
+    out->infinite_end = lt.infinite_cdf ? lt.infinite_end : 0;
     out->max_split_depth = lt.max_split_depth;
     out->num_nodes = lt.num_nodes;
-    out->num_infinite = lt.num_infinite_lights;
+    out->num_infinite = lt.infinite_cdf ? lt.num_infinite_lights : 0;
     return ok;
 }
 
@@ -421,10 +424,11 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (d->lights[l].num_samples > 1) c->multi_sample_lights = true;
         const ZygpuProp& lp = d->props[d->lights[l].prop];
         const bool       is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == lp.shape;
-        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh) {
-            g_error = "only Rectangle and TriangleMesh lights are supported on the device path";
+        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && ZYGPU_SHAPE_DISTANT != lp.shape) {
+            g_error = "only Rectangle, TriangleMesh and Distant lights are supported on the device path";
             return -2;
         }
+        if (ZYGPU_SHAPE_DISTANT == lp.shape) c->mesh_lights = true;  // the same kernel instantiations carry the Distant code
         if (is_mesh) {
             if (d->lights[l].sampler >= d->num_mesh_lights) {
                 g_error = "a TriangleMesh light without its ZygpuMeshLight (ZygpuLight.sampler)";
@@ -497,6 +501,16 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (!ok) return -1;
     }
     if (!m.upload(meshes.data(), meshes.size(), &s.meshes)) return -1;
+
+    for (uint32_t i = 0; i < d->num_infinite_props; ++i) {
+        if (d->infinite_props[i] >= d->num_props || ZYGPU_SHAPE_DISTANT != d->props[d->infinite_props[i]].shape) {
+            g_error = "infinite props other than Distant are not supported on the device path";
+            return -2;
+        }
+        c->mesh_lights = true;
+    }
+    if (!m.upload(d->infinite_props, d->num_infinite_props, &s.infinite_props)) return -1;
+    s.num_infinite_props = d->num_infinite_props;
 
     // images behind colour maps
     std::vector<DImage> images(d->num_images);

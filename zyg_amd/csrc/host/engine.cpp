@@ -876,7 +876,9 @@ int Engine::compile(uint32_t frame) {
 
     buildPropTree(finite_props_, solid_nodes_, solid_indices_);
     buildPropTree(unoccluding_props_, unoccluding_nodes_, unoccluding_indices_);
-    if (!volume_props_.empty() || !infinite_props_.empty()) return -2;  // out of scope
+    if (!volume_props_.empty()) return -2;  // out of scope
+    for (uint32_t p : infinite_props_)
+        if (ZYGPU_SHAPE_DISTANT != shapes_[props_[p].shape].kind) return -2;  // Canopy / Dome (sky, image lights): row a20
 
     // lights: scene.zig:402-497 (propPrepareSampling, static branch)
     mesh_lights_.clear();
@@ -885,6 +887,13 @@ int Engine::compile(uint32_t frame) {
     c_light_aabbs_.resize(nl);
     c_light_cones_.resize(size_t(nl) * 4);
     c_light_two_sided_.resize(nl);
+    c_light_infinite_.assign(nl, 0);
+    // Scene.aabb() = the solid tree's bounds (scene.zig:173-175): scales the power of infinite lights (light.zig:67-77)
+    AABB scene_bb = emptyAabb();
+    if (!solid_nodes_.empty()) {
+        const ZygpuBvhNode& r = solid_nodes_[0];
+        scene_bb = {{vec(r.min[0], r.min[1], r.min[2], 0.f), vec(r.max[0], r.max[1], r.max[2], 0.f)}};
+    }
     for (uint32_t li = 0; li < nl; ++li) {
         ZygpuLight&      l = lights_[li];
         const HostProp&  hp = props_[l.prop];
@@ -893,8 +902,9 @@ int Engine::compile(uint32_t frame) {
         light_ids_[p] = li;
         const ZygpuMaterial& m = materials_[material_ids_[p]];
 
-        const bool is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == s.kind;
-        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh) return -3;  // sphere / disk / ... emitters: SURVEY §8(f)
+        const bool is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == s.kind, is_distant = ZYGPU_SHAPE_DISTANT == s.kind;
+        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh && !is_distant) return -3;  // sphere / disk / ... emitters: SURVEY §8(f)
+        c_light_infinite_[li] = is_distant ? 1 : 0;
 
         l.num_samples = m.emission_num_samples;  // light_material.zig:68-74 / substitute_material.zig:96-111
         l.two_sided = (m.flags & ZYGPU_MATF_TWO_SIDED) ? 1 : 0;
@@ -919,12 +929,15 @@ int Engine::compile(uint32_t frame) {
         c_light_cones_[4 * li + 2] = tc[2];
         c_light_cones_[4 * li + 3] = part_cone[3];
 
-        // shape.zig:132-152: Rectangle area, TriangleMesh part area (triangle_mesh.zig:376-380)
-        const float extent = is_mesh ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1]) : t.scale[0] * t.scale[1];
+        // shape.zig:132-152: Rectangle area, TriangleMesh part area (triangle_mesh.zig:376-380), Distant solid angle (distant.zig:143-145)
+        const float extent = is_distant ? (2.f * float(M_PI)) * (1.f - std::sqrt(1.f / (t.scale[0] * t.scale[0] + 1.f)))
+                             : is_mesh  ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1])
+                                        : t.scale[0] * t.scale[1];
         Vec4f       emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f);
-        // emittance.zig:61-71 totalEmission; light.zig:67-77 power (finite shape)
+        // emittance.zig:61-71 totalEmission; light.zig:67-77 power: infinite lights scale with the scene's extent
         Vec4f power = splat(0.f);
         if (extent > 0.f) power = m.emission_normalize ? emission : emission * splat(extent);
+        if (is_distant && !solid_nodes_.empty()) power = splat(squaredLength3(aabbExtent(scene_bb))) * power;
         bb.b[0][3] = hmax3(power);
 
         for (int i = 0; i < 4; ++i) {
@@ -937,6 +950,7 @@ int Engine::compile(uint32_t frame) {
     lin.aabbs = c_light_aabbs_.data();
     lin.cones = c_light_cones_.data();
     lin.two_sided = c_light_two_sided_.data();
+    lin.infinite = c_light_infinite_.data();
     lin.num_lights = nl;
     LightTreeBuilder ltb;
     ltb.build(lin, light_tree_);
@@ -973,6 +987,8 @@ int Engine::compile(uint32_t frame) {
     }
     d.mesh_lights = c_mesh_lights_.data();
     d.num_mesh_lights = uint32_t(c_mesh_lights_.size());
+    d.infinite_props = infinite_props_.data();
+    d.num_infinite_props = uint32_t(infinite_props_.size());
     c_images_.resize(images_.size());
     for (size_t i = 0; i < images_.size(); ++i)
         c_images_[i] = ZygpuImage{images_[i].pixels.data(), images_[i].width, images_[i].height, images_[i].format};

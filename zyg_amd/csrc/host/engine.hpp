@@ -179,6 +179,7 @@ class Engine {
     std::vector<HostImage>    images_;
     std::vector<ZygpuImage>   c_images_;
     std::vector<float>        srgb_to_float_;
+    std::vector<uint8_t>        c_light_infinite_;
     std::deque<HostMeshLight>   mesh_lights_;   // stable addresses: the trees point into their own vectors
     std::vector<ZygpuMeshLight> c_mesh_lights_;
     uint32_t prepareMeshLight(uint32_t mesh, uint32_t part, uint32_t material, bool two_sided);

@@ -20,6 +20,7 @@ struct LightTreeInput {
     uint32_t         num_lights;
     const float*     powers = nullptr;  // per light; nullptr: aabbs[l].min[3]
     bool             all_two_sided = false;
+    const uint8_t*   infinite = nullptr;  // per light: its shape is infinite (Distant); nullptr: all finite
 };
 
 struct LightTreeOutput {
@@ -27,6 +28,7 @@ struct LightTreeOutput {
     std::vector<uint32_t>       node_middles;
     std::vector<uint32_t>       light_orders;
     std::vector<uint32_t>       light_mapping;
+    std::vector<float>          infinite_cdf;  // Distribution1D over the infinite lights' powers (num_infinite + 1 entries)
     ZygpuLightTree              tree{};
 };
 
@@ -48,17 +50,52 @@ class LightTreeBuilder {
         out.light_orders.assign(num_lights, 0);
         light_order_ = 0;
 
-        // all lights in scope are finite: mapping = identity order (light_tree_builder.zig:289-313)
-        const uint32_t num_infinite_lights = 0;
-        for (uint32_t l = 0; l < num_lights; ++l) out.light_mapping[l] = l;
+        // light_tree_builder.zig:289-330: infinite lights first (sampled from a discrete distribution over their powers, never
+        // part of the BVH), then the finite ones
+        uint32_t lm = 0;
+        for (uint32_t l = 0; l < num_lights; ++l)
+            if (in.infinite && in.infinite[l]) out.light_mapping[lm++] = l;
+        const uint32_t num_infinite_lights = lm;
+        for (uint32_t l = 0; l < num_lights; ++l)
+            if (!(in.infinite && in.infinite[l])) out.light_mapping[lm++] = l;
+
+        float              infinite_total_power = 0.f;
+        std::vector<float> infinite_powers(num_infinite_lights);
+        for (uint32_t i = 0; i < num_infinite_lights; ++i) {
+            const uint32_t l = out.light_mapping[i];
+            infinite_powers[i] = lightPower(l);
+            out.light_orders[l] = light_order_;
+            light_order_ += 1;
+            infinite_total_power += infinite_powers[i];
+        }
+        const uint32_t infinite_end = light_order_;
+        // Distribution1D.precomputePdfCdf (base/math/distribution_1d.zig:87-124)
+        out.infinite_cdf.assign(size_t(num_infinite_lights) + 1, 0.f);
+        if (num_infinite_lights > 0) {
+            float integral = 0.f;
+            for (float d : infinite_powers) integral += d;
+            if (0.f == integral) {
+                out.infinite_cdf.assign(2, 1.f);
+            } else {
+                const float ii = 1.f / integral;
+                float       p = 0.f;
+                for (uint32_t i = 0; i + 1 < num_infinite_lights; ++i) {
+                    const float c = std::fmaf(infinite_powers[i], ii, p);
+                    out.infinite_cdf[i + 1] = c;
+                    p = c;
+                }
+                out.infinite_cdf[num_infinite_lights] = 1.f;
+            }
+        }
+        const uint32_t num_finite_lights = num_lights - num_infinite_lights;
 
         uint32_t max_split_depth = MaxSplitDepth;
 
         ZygpuLightTree& tree = out.tree;
         std::memset(&tree, 0, sizeof(tree));
 
-        if (num_lights > 0) {
-            build_nodes_.assign(2 * num_lights - 1, BuildNode{});
+        if (num_finite_lights > 0) {
+            build_nodes_.assign(2 * num_finite_lights - 1, BuildNode{});
             current_node_ = 1;
 
             AABB  bounds = emptyAabb();
@@ -66,7 +103,7 @@ class LightTreeBuilder {
             bool  two_sided = false;
             float total_power = 0.f;
 
-            for (uint32_t i = 0; i < num_lights; ++i) {
+            for (uint32_t i = num_infinite_lights; i < num_lights; ++i) {
                 const uint32_t l = out.light_mapping[i];
                 aabbMerge(bounds, lightAabb(l));
                 cone = coneMerge(cone, lightCone(l));
@@ -74,7 +111,7 @@ class LightTreeBuilder {
                 total_power += lightPower(l);
             }
 
-            split(0, 0, num_lights, bounds, cone, two_sided, total_power, 0);
+            split(0, num_infinite_lights, num_lights, bounds, cone, two_sided, total_power, 0);
 
             out.nodes.resize(current_node_);
             out.node_middles.resize(current_node_);
@@ -104,14 +141,16 @@ class LightTreeBuilder {
 
         tree.max_split_depth = max_split_depth;
 
-        const float p0 = 0.f;  // infinite_total_power
-        const float p1 = 0 == num_lights ? 0.f : build_nodes_[0].power;
+        const float p0 = infinite_total_power;
+        const float p1 = 0 == num_finite_lights ? 0.f : build_nodes_[0].power;
         const float pt = p0 + p1;
         const float infinite_weight = (0 == num_lights || 0.f == pt) ? 0.f : p0 / pt;
 
         tree.infinite_weight = infinite_weight;
-        tree.infinite_guard = 0 == num_lights ? 0.f : infinite_weight;
-        tree.infinite_end = 0;
+        // light_tree_builder.zig:381-385 ("afraid of the 1.0 == random case")
+        tree.infinite_guard = 0 == num_finite_lights ? (0 == num_infinite_lights ? 0.f : 1.1f) : infinite_weight;
+        tree.infinite_end = infinite_end;
+        tree.infinite_cdf = out.infinite_cdf.data();
         tree.num_lights = num_lights;
         tree.num_infinite_lights = num_infinite_lights;
         tree.num_nodes = uint32_t(out.nodes.size());

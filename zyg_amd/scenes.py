@@ -272,3 +272,55 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
 
     engine.transformation(cam, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, camera_z)))
     return ids
+
+
+DISTANT = 3  # built-in Distant shape (resource/manager.zig:36-44)
+
+
+def _basis_for(n):
+    """Orthonormal r0, r1 with r0 x r1 = n."""
+    n = np.asarray(n, dtype=np.float64)
+    n = n / np.linalg.norm(n)
+    a = np.array([1.0, 0.0, 0.0]) if abs(n[0]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    r0 = np.cross(a, n)
+    r0 /= np.linalg.norm(r0)
+    r1 = np.cross(n, r0)
+    return tuple(r0), tuple(r1)
+
+
+def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
+            extra_quad_light=False, max_depth=8):
+    """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
+    distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
+    light tree mixes the infinite-light distribution with the BVH."""
+    mk = lambert if material == "lambert" else substitute
+    cam = engine.camera(width, height, fov_deg=45.0)
+    engine.samples_per_pixel(spp)
+    engine.integrators(json.dumps({"surface": {integrator: {"depth": {"surface": max_depth}}}}))
+    engine.sensor(json.dumps({}))
+    white = engine.material(mk(WHITE))
+    red = engine.material(mk(RED))
+    sun = engine.material(light_material(spectrum=(12.0, 11.0, 9.0)))
+    ids = {"camera": cam}
+
+    ground = engine.prop(RECTANGLE, [white])
+    engine.transformation(ground, trafo((1, 0, 0), (0, 0, -1), (12, 12, 1), (0, 0, 0)))
+    identity = trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))
+    for lo, hi, rot, mat in (((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0, white), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0, red)):
+        idx, pos, nrm, uv = box_mesh(lo, hi, rot)
+        p = engine.prop(engine.triangle_mesh(idx, pos, nrm, uv), [mat])
+        engine.transformation(p, identity)
+
+    to_light = np.asarray(sun_direction, dtype=np.float64)
+    r0, r1 = _basis_for(-to_light)  # the light's z axis points from the light into the scene
+    s = engine.prop(DISTANT, [sun])
+    engine.transformation(s, trafo(r0, r1, (sun_radius, sun_radius, sun_radius), (0, 0, 0)))
+    engine.light(s)
+    ids["sun"] = s
+    if extra_quad_light:
+        lamp = engine.material(light_material(spectrum=(6.0, 6.0, 8.0)))
+        q = engine.prop(RECTANGLE, [lamp])
+        engine.transformation(q, trafo((1, 0, 0), (0, 0, 1), (0.6, 0.6, 1), (-1.2, 1.6, 0.4)))
+        engine.light(q)
+    engine.transformation(cam, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1.1, -4.5)))
+    return ids
