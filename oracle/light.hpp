@@ -418,6 +418,65 @@ inline float rectanglePdf(V4 p, const Trafo& frag_trafo, float split_threshold, 
     return nsf * squad.pdf(scale);
 }
 
+// ---------- Sphere lights: sphere.zig:318-400 (sampleTo, uniform cone of directions), 469-485 (pdf) ----------
+
+inline float conePdfUniform(float one_minus_cos_theta_max) {  // sampling.zig:103-106
+    return 1.f / ((2.f * kPi) * mx(one_minus_cos_theta_max, 1.0e-20f));
+}
+
+inline uint32_t sphereSampleTo(V4 p, V4 n, const Trafo& trafo, bool total_sphere, float split_threshold, uint32_t light_num_samples,
+                               Sampler& sampler, SampleTo* buffer) {
+    const V4    v = trafo.position - p;
+    const float l = length3(v);
+    const float r = 0.5f * trafo.scaleX();
+    if (l <= (r + 0.0000001f)) return 0;
+    const V4 z = S(1.f / l) * v;
+    V4       fx, fy;
+    orthonormalBasis3(z, fx, fy);  // Frame.init (frame.zig:10-13)
+    const uint32_t num_samples = numSamples(light_num_samples, split_threshold);
+    const float    nsf = float(num_samples);
+    uint32_t       current_sample = 0;
+    for (uint32_t i = 0; i < num_samples; ++i) {
+        const float sin_theta_max = r / l;
+        const float sin2_theta_max = sin_theta_max * sin_theta_max;
+        const float cos_theta_max = std::sqrt(1.f - sin2_theta_max);
+        float       one_minus_cos_theta_max = 1.f - cos_theta_max;
+        float       s2[2];
+        sampler.sample2D(s2);
+        float cos_theta = (cos_theta_max - 1.f) * s2[0] + 1.f;
+        float sin2_theta = 1.f - (cos_theta * cos_theta);
+        if (sin2_theta_max < 0.00068523f) {
+            sin2_theta = sin2_theta_max * s2[0];
+            cos_theta = std::sqrt(1.f - sin2_theta);
+            one_minus_cos_theta_max = 0.5f * sin2_theta_max;
+        }
+        const float cos_alpha = mn(sin2_theta / sin_theta_max + cos_theta * std::sqrt(1.f - mn(sin2_theta / sin2_theta_max, 1.f)), 1.f);
+        const float sin_alpha = std::sqrt(1.f - cos_alpha * cos_alpha);
+        const float phi = s2[1] * (2.f * kPi);
+        const V4    w = mk(cosF(phi) * sin_alpha, sinF(phi) * sin_alpha, cos_alpha);  // sampling.zig:78-83 sphereDirection
+        const V4    mw = -w;
+        const V4    wn = fma4(S(mw[2]), z, fma4(S(mw[1]), fy, S(mw[0]) * fx));  // frame.frameToWorld (frame.zig:23-37)
+        const V4    lp = trafo.position + S(r) * wn;
+        const V4    dir = normalize3(lp - p);
+        if (dot3(dir, n) <= 0.f && !total_sphere) continue;
+        SampleTo& out = buffer[current_sample++];
+        out.p = mk(lp[0], lp[1], lp[2], nsf * conePdfUniform(one_minus_cos_theta_max));
+        out.n = wn;
+        out.wi = dir;
+        out.uvw = S(0.f);
+    }
+    return current_sample;
+}
+
+inline float spherePdf(V4 p, const Trafo& trafo, float split_threshold, uint32_t light_num_samples) {
+    const V4    v = trafo.position - p;
+    const float l2 = squaredLength3(v);
+    const float r = 0.5f * trafo.scaleX();
+    const float sin2_theta_max = (r * r) / l2;
+    const float one_minus_cos_theta_max = sin2_theta_max < 0.00068523f ? 0.5f * sin2_theta_max : 1.f - std::sqrt(mx(1.f - sin2_theta_max, 0.f));
+    return float(numSamples(light_num_samples, split_threshold)) * conePdfUniform(one_minus_cos_theta_max);
+}
+
 // ---------- Distant lights: distant.zig:21-146 ----------
 
 inline float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - std::sqrt(1.f / (radius * radius + 1.f))); }

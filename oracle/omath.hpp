@@ -169,6 +169,74 @@ inline float acosF(float x) {
     return 2.f * (df + w);
 }
 
+// atanf / atan2f with the msun algorithms (Zig std.math.atan / atan2 are ports of musl's s_atanf.c / e_atan2f.c)
+inline float atanF(float x) {
+    const float    atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float    atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float    aT[5] = {3.3333328366e-01f, -1.9999158382e-01f, 1.4253635705e-01f, -1.0648017377e-01f, 6.1687607318e-02f};
+    uint32_t       ix = m32::bits(x);
+    const uint32_t sign = ix >> 31;
+    ix &= 0x7fffffffu;
+    int id;
+    if (ix >= 0x4c800000u) {  // |x| >= 2^26
+        if (x != x) return x;
+        const float z = atanhi[3] + 0x1p-120f;
+        return sign ? -z : z;
+    }
+    if (ix < 0x3ee00000u) {  // |x| < 0.4375
+        if (ix < 0x39800000u) return x;  // |x| < 2^-12
+        id = -1;
+    } else {
+        x = std::fabs(x);
+        if (ix < 0x3f980000u) {  // |x| < 1.1875
+            if (ix < 0x3f300000u) {
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else if (ix < 0x401c0000u) {  // |x| < 2.4375
+            id = 2;
+            x = (x - 1.5f) / (1.0f + 1.5f * x);
+        } else {
+            id = 3;
+            x = -1.0f / x;
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * aT[4]));
+    const float s2 = w * (aT[1] + w * aT[3]);
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return sign ? -r : r;
+}
+inline float atan2F(float y, float x) {
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    if (x != x || y != y) return x + y;
+    uint32_t ix = m32::bits(x), iy = m32::bits(y);
+    if (ix == 0x3f800000u) return atanF(y);
+    const uint32_t m = ((iy >> 31) & 1u) | ((ix >> 30) & 2u);
+    ix &= 0x7fffffffu;
+    iy &= 0x7fffffffu;
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi : -pi);
+    if (ix == 0) return (m & 1u) ? -pi / 2 : pi / 2;
+    if (ix == 0x7f800000u) {
+        if (iy == 0x7f800000u) return m == 0 ? pi / 4 : m == 1 ? -pi / 4 : m == 2 ? 3 * pi / 4 : -3 * pi / 4;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi : -pi;
+    }
+    if (ix + (26u << 23) < iy || iy == 0x7f800000u) return (m & 1u) ? -pi / 2 : pi / 2;
+    float z;
+    if ((m & 2u) && iy + (26u << 23) < ix) z = 0.0f;
+    else z = atanF(std::fabs(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return -z;
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kPiInv = float(1.0 / 3.14159265358979323846);  // math.zig:112
 constexpr float kDotMin = 0.00001f;                            // safe.zig:5

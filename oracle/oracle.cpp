@@ -127,6 +127,7 @@ struct Worker {
         const V4         s = trafo.scale();
         if (ZYGPU_SHAPE_RECTANGLE == p.shape) return s[0] * s[1];
         if (ZYGPU_SHAPE_DISTANT == p.shape) return distantSolidAngle(s[0]);  // "the solid angle, not the area" (shape.zig:140-142)
+        if (ZYGPU_SHAPE_SPHERE == p.shape) return (4.f * kPi) * ((0.5f * s[0]) * (0.5f * s[0]));  // shape.zig:148
         return rc->scene->meshes[p.mesh].part_areas[part] * (s[0] * s[1]);
     }
 
@@ -151,6 +152,8 @@ struct Worker {
                           v.light_split_threshold)
             : ZYGPU_SHAPE_DISTANT == rc->scene->props[l.prop].shape
                 ? 1.f / distantSolidAngle(frag.isec.trafo.scaleX())  // distant.zig:139-141
+            : ZYGPU_SHAPE_SPHERE == rc->scene->props[l.prop].shape
+                ? spherePdf(v.origin, frag.isec.trafo, v.light_split_threshold, l.num_samples)  // sphere.zig:469-485
                 : rectanglePdf(v.origin, frag.isec.trafo, v.light_split_threshold, l.num_samples);
         return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
     }
@@ -202,6 +205,16 @@ struct Worker {
                             frag.geo_n = frag.isec.trafo.objectToWorldNormal(normalize3(cross3(b - a, c - a)));
                             energy += evaluateRadiance(v, frag, sampler);
                         });
+                        continue;
+                    }
+                    if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:269-277
+                        float t;
+                        if (!sphereIntersect(v.ray, frag.isec.trafo, t)) continue;
+                        frag.isec.t = t;
+                        frag.isec.u = frag.isec.v = 0.f;
+                        frag.isec.primitive = 0;
+                        sphereFragment(v.ray, frag);
+                        energy += evaluateRadiance(v, frag, sampler);
                         continue;
                     }
                     if (ZYGPU_SHAPE_RECTANGLE != prop.shape) continue;
@@ -351,6 +364,8 @@ struct Worker {
                     ? meshSampleTo(*rc->scene, rc->scene->mesh_lights[light.sampler], p, n, trafo, 0 != light.two_sided, translucent,
                                    sample_threshold, sampler, samples)
                 : distant ? distantSampleTo(n, trafo, translucent, sampler, samples)
+                : ZYGPU_SHAPE_SPHERE == rc->scene->props[light.prop].shape
+                    ? sphereSampleTo(p, n, trafo, translucent, sample_threshold, light.num_samples, sampler, samples)
                     : rectangleSampleTo(p, n, trafo, 0 != light.two_sided, translucent, sample_threshold, light.num_samples, sampler,
                                         samples);
 
@@ -857,6 +872,10 @@ void zyg_oracle_trig(uint32_t n, const float* x, float* out_sin, float* out_cos,
         out_cos[i] = cosF(x[i]);
         out_acos[i] = acosF(x[i]);
     }
+}
+
+void zyg_oracle_atan2(uint32_t n, const float* y, const float* x, float* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = atan2F(y[i], x[i]);
 }
 
 void zyg_oracle_offset_ray(const float* p, const float* n, float* out) {

@@ -326,6 +326,51 @@ inline bool rectangleIntersect(const Ray& ray, const Trafo& trafo, float& out_t,
     return false;
 }
 
+// sphere.zig:28-60 (nearer root first); unit-diameter sphere scaled by trafo.scaleX()
+inline bool sphereIntersect(const Ray& ray, const Trafo& trafo, float& out_t) {
+    const float idl = 1.f / length3(ray.direction);
+    const V4    nd = ray.direction * S(idl);
+    const V4    v = trafo.position - ray.origin;
+    const float b = dot3(nd, v);
+    const V4    remedy_term = v - S(b) * nd;
+    const float radius = 0.5f * trafo.scaleX();
+    const float discriminant = radius * radius - dot3(remedy_term, remedy_term);
+    if (discriminant > 0.f) {
+        const float dist = std::sqrt(discriminant);
+        const float t0 = (b - dist) * idl;
+        if (t0 >= ray.min_t && ray.max_t >= t0) {
+            out_t = t0;
+            return true;
+        }
+        const float t1 = (b + dist) * idl;
+        if (t1 >= ray.min_t && ray.max_t >= t1) {
+            out_t = t1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// sphere.zig:62-90
+inline void sphereFragment(const Ray& ray, Fragment& frag) {
+    const Trafo& tr = frag.isec.trafo;
+    const V4     p = ray.point(frag.isec.t);
+    const V4     n = normalize3(p - tr.position);
+    frag.p = p;
+    frag.geo_n = n;
+    frag.n = n;
+    frag.part = 0;
+    const V4    xyz = normalize3(tr.worldToObjectNormal(n));
+    const float phi = -atan2F(xyz[0], xyz[2]) + kPi;
+    const float theta = acosF(xyz[1]);
+    const float sin_phi = sinF(phi), cos_phi = cosF(phi);
+    const float sin_theta = mx(sinF(theta), 0.00001f);  // avoid the singularity at the poles
+    const V4    t = normalize3(tr.objectToWorldNormal(mk(sin_theta * cos_phi, 0.f, sin_theta * sin_phi)));
+    frag.t = t;
+    frag.b = -cross3(t, n);
+    frag.uvw = mk(phi * (0.5f * kPiInv), theta * kPiInv, 0.f, 0.f);
+}
+
 // rectangle.zig:102-124
 inline void rectangleFragment(const Ray& ray, Fragment& frag) {
     const Trafo& tr = frag.isec.trafo;
@@ -447,6 +492,15 @@ struct SceneView {
             isec.trafo = trafo;
             return true;
         }
+        if (ZYGPU_SHAPE_SPHERE == prop.shape) {
+            float t;
+            if (!sphereIntersect(ray, trafo, t)) return false;
+            isec.t = t;
+            isec.u = isec.v = 0.f;
+            isec.primitive = 0;
+            isec.trafo = trafo;
+            return true;
+        }
         return false;
     }
 
@@ -464,12 +518,17 @@ struct SceneView {
         if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
             return !meshIntersectP(d->meshes[prop.mesh], trafo.worldToObjectRay(ray), cnt);
         }
+        if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:148-172 intersectP: the same two roots
+            float t;
+            return !sphereIntersect(ray, trafo, t);
+        }
         return true;
     }
 
     void shapeFragment(uint32_t prop, const Ray& ray, Fragment& frag) const {
         const ZygpuProp& p = d->props[prop];
         if (ZYGPU_SHAPE_RECTANGLE == p.shape) rectangleFragment(ray, frag);
+        else if (ZYGPU_SHAPE_SPHERE == p.shape) sphereFragment(ray, frag);
         else meshFragment(d->meshes[p.mesh], frag);
     }
 

@@ -298,3 +298,12 @@ def test_distant_light(engine, oracle, integrator, quad):
     out = _render_both(engine, oracle, 80, 60, 3, scene=scenes.outdoor, integrator=integrator, sun_radius=0.08, extra_quad_light=quad)
     _check(*out, 3)
     assert integrator == "PT" or out[2].shadow_rays > 0
+
+
+@pytest.mark.parametrize("integrator,unoccluding,samples", [("PT", True, 1), ("PTDL", False, 1), ("PTMIS", True, 1), ("PTMIS", False, 3)])
+def test_spheres(engine, oracle, integrator, unoccluding, samples):
+    """Analytic Spheres as geometry (intersection, spherical uv frame through atan2 / acos) and as lights (uniform cone of
+    directions, sphere.zig:28-90, 318-400, 469-485), occluding or as unoccluding `Light` entities, 1 or 3 samples."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, spheres=True, sphere_lights=True,
+                       unoccluding_lights=unoccluding, light_samples=samples, boxes=False)
+    _check(*out, 3)

@@ -292,3 +292,18 @@ def test_distant_light_integrators_agree(product_lib, oracle):
             means[integ] = img[..., :3].mean(axis=(0, 1))
     np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.01)
     np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.06)
+
+
+def test_sphere_lights_integrators_agree(product_lib, oracle):
+    """Sphere lights and Sphere geometry: PT (no light sampling), PTDL and PTMIS estimate the same image."""
+    w, h, spp = 40, 30, 256
+    means = {}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator=integ, spheres=True, sphere_lights=True, unoccluding_lights=False, boxes=False)
+            sd, vd = e.compile()
+            img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(img).all()
+            means[integ] = img[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.01)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)

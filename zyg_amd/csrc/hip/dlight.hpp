@@ -411,6 +411,73 @@ ZD float rectanglePdf(f3 p, const Trafo& frag_trafo, uint32_t num_samples) {  //
     return float(num_samples) * squad.pdf(frag_trafo.scale);
 }
 
+// ---------------------------------------------------------------- Sphere lights (sphere.zig:318-400, 469-485)
+
+ZD float conePdfUniform(float one_minus_cos_theta_max) {  // sampling.zig:103-106
+    return 1.f / ((2.f * kPi) * mx(one_minus_cos_theta_max, 1.0e-20f));
+}
+
+// Sphere.sampleTo: the set-up shared by a light's samples (frame around the direction to the centre), then one sample
+// of the uniform cone of directions per 2-D draw
+struct SphereSampler {
+    f3    fx, fy, z;
+    float l, r, nsf;
+    bool  valid;
+
+    ZD static SphereSampler init(f3 p, const Trafo& trafo, uint32_t num_samples) {
+        SphereSampler q;
+        const f3      v = trafo.position - p;
+        q.l = length3(v);
+        q.r = 0.5f * trafo.scale.x;
+        q.valid = !(q.l <= (q.r + 0.0000001f));
+        q.z = S3(1.f / q.l) * v;
+        // Frame.init -> orthonormalBasis3 (vector4.zig:98-110)
+        const float sign = copysignf(1.f, q.z.z);
+        const float c = -1.f / (sign + q.z.z);
+        const float d = q.z.x * q.z.y * c;
+        q.fx = mk3(1.f + sign * q.z.x * q.z.x * c, sign * d, -sign * q.z.x);
+        q.fy = mk3(d, sign + q.z.y * q.z.y * c, -q.z.y);
+        q.nsf = float(num_samples);
+        return q;
+    }
+    ZD bool sample(float s0, float s1, f3 p, f3 n, const Trafo& trafo, bool total_sphere, SampleTo& out) const {
+        if (!valid) return false;
+        const float sin_theta_max = r / l;
+        const float sin2_theta_max = sin_theta_max * sin_theta_max;
+        const float cos_theta_max = sqrtf(1.f - sin2_theta_max);
+        float       one_minus_cos_theta_max = 1.f - cos_theta_max;
+        float       cos_theta = (cos_theta_max - 1.f) * s0 + 1.f;
+        float       sin2_theta = 1.f - (cos_theta * cos_theta);
+        if (sin2_theta_max < 0.00068523f) {
+            sin2_theta = sin2_theta_max * s0;
+            cos_theta = sqrtf(1.f - sin2_theta);
+            one_minus_cos_theta_max = 0.5f * sin2_theta_max;
+        }
+        const float cos_alpha = mn(sin2_theta / sin_theta_max + cos_theta * sqrtf(1.f - mn(sin2_theta / sin2_theta_max, 1.f)), 1.f);
+        const float sin_alpha = sqrtf(1.f - cos_alpha * cos_alpha);
+        const float phi = s1 * (2.f * kPi);
+        const f3    mw = -mk3(cosF(phi) * sin_alpha, sinF(phi) * sin_alpha, cos_alpha);  // sampling.zig:78-83 sphereDirection
+        const f3    wn = fma3(S3(mw.z), z, fma3(S3(mw.y), fy, S3(mw.x) * fx));             // frame.frameToWorld (frame.zig:23-37)
+        const f3    lp = trafo.position + S3(r) * wn;
+        const f3    dir = normalize3(lp - p);
+        if (dot3(dir, n) <= 0.f && !total_sphere) return false;
+        out.p = lp;
+        out.n = wn;
+        out.wi = dir;
+        out.pdf = nsf * conePdfUniform(one_minus_cos_theta_max);
+        return true;
+    }
+};
+
+ZD float spherePdf(f3 p, const Trafo& trafo, uint32_t num_samples) {  // sphere.zig:469-485
+    const f3    v = trafo.position - p;
+    const float l2 = squaredLength3(v);
+    const float r = 0.5f * trafo.scale.x;
+    const float sin2_theta_max = (r * r) / l2;
+    const float one_minus_cos_theta_max = sin2_theta_max < 0.00068523f ? 0.5f * sin2_theta_max : 1.f - sqrtf(mx(1.f - sin2_theta_max, 0.f));
+    return float(num_samples) * conePdfUniform(one_minus_cos_theta_max);
+}
+
 // ---------------------------------------------------------------- Distant lights (distant.zig:21-146)
 
 ZD float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - sqrtf(1.f / (radius * radius + 1.f))); }

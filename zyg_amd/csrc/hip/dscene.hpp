@@ -146,6 +146,31 @@ ZD bool triangleIntersect(const Ray& ray, f3 a, f3 b, f3 c, float& ht, float& hu
 
 ZD f3 xyz(float4 v) { return {v.x, v.y, v.z}; }
 
+// sphere.zig:28-60 (nearer root first); unit-diameter sphere scaled by trafo.scale.x
+ZD bool sphereIntersect(const Ray& ray, const Trafo& trafo, float& out_t) {
+    const float idl = 1.f / length3(ray.direction);
+    const f3    nd = ray.direction * S3(idl);
+    const f3    v = trafo.position - ray.origin;
+    const float b = dot3(nd, v);
+    const f3    remedy_term = v - S3(b) * nd;
+    const float radius = 0.5f * trafo.scale.x;
+    const float discriminant = radius * radius - dot3(remedy_term, remedy_term);
+    if (discriminant > 0.f) {
+        const float dist = sqrtf(discriminant);
+        const float t0 = (b - dist) * idl;
+        if (t0 >= ray.min_t && ray.max_t >= t0) {
+            out_t = t0;
+            return true;
+        }
+        const float t1 = (b + dist) * idl;
+        if (t1 >= ray.min_t && ray.max_t >= t1) {
+            out_t = t1;
+            return true;
+        }
+    }
+    return false;
+}
+
 // Shared BVH2 walk: nearer child first, farther pushed (triangle_tree.zig:76-94 / prop_tree.zig:86-104).
 // `leaf(first, count)` returns true to stop the walk (any-hit).
 template <bool STATS, typename Leaf>
@@ -279,6 +304,15 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                     hit.prop = p;
                     ray.max_t = t;
                 }
+            } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {
+                float t;
+                if (sphereIntersect(ray, trafo, t)) {
+                    hit.t = t;
+                    hit.u = hit.v = 0.f;
+                    hit.primitive = 0;
+                    hit.prop = p;
+                    ray.max_t = t;
+                }
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 Ray local = worldToObjectRay(trafo, ray);
                 Hit h;
@@ -311,6 +345,9 @@ ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) return true;
+            } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:148-172 intersectP: the same two roots
+                float t;
+                if (sphereIntersect(ray, trafo, t)) return true;
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 Ray local = worldToObjectRay(trafo, ray);
                 if (meshIntersectP<STATS>(s.meshes[prop.mesh], local, cnt)) return true;
@@ -353,6 +390,25 @@ ZD void rectangleFragment(const Ray& ray, Fragment& f) {  // rectangle.zig:102-1
         f.uv1 = 0.5f * (f.v + 1.f);
     }
     f.part = 0;
+}
+
+ZD void sphereFragment(const Ray& ray, Fragment& f) {  // sphere.zig:62-90
+    const f3 p = ray.point(f.t_hit);
+    const f3 n = normalize3(p - f.trafo.position);
+    f.p = p;
+    f.geo_n = n;
+    f.n = n;
+    f.part = 0;
+    const f3    xyz_ = normalize3(f.trafo.worldToObjectNormal(n));
+    const float phi = -atan2F(xyz_.x, xyz_.z) + kPi;
+    const float theta = acosF(xyz_.y);
+    const float sin_phi = sinF(phi), cos_phi = cosF(phi);
+    const float sin_theta = mx(sinF(theta), 0.00001f);  // avoid the singularity at the poles
+    const f3    t = normalize3(f.trafo.objectToWorldNormal(mk3(sin_theta * cos_phi, 0.f, sin_theta * sin_phi)));
+    f.t = t;
+    f.b = -cross3(t, n);
+    f.uv0 = phi * (0.5f * kPiInv);
+    f.uv1 = theta * kPiInv;
 }
 
 ZD f3 interpolate3(f3 a, f3 b, f3 c, float u, float v) {  // triangle.zig:141-149
@@ -420,6 +476,7 @@ ZD void makeFragment(const DScene& s, const Ray& ray, const Hit& hit, Fragment& 
     f.trafo = loadTrafo(s, hit.prop);
     const ZygpuProp prop = s.props[hit.prop];
     if (ZYGPU_SHAPE_RECTANGLE == prop.shape) rectangleFragment(ray, f);
+    else if (ZYGPU_SHAPE_SPHERE == prop.shape) sphereFragment(ray, f);
     else meshFragment(s.meshes[prop.mesh], f);
 }
 

@@ -441,6 +441,9 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) record(p, 0, t, u, v);
+            } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // Sphere.emission (sphere.zig:269-277)
+                float t;
+                if (sphereIntersect(ray, trafo, t)) record(p, 0, t, 0.f, 0.f);
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 // TriangleTree.emission (triangle_tree.zig:405-483): every triangle the ray crosses, no max_t shrinking
                 const DMesh& mesh = s.meshes[prop.mesh];
@@ -501,6 +504,7 @@ ZD float shapeArea(const DScene& s, uint32_t prop, uint32_t part, const Trafo& t
     const ZygpuProp p = s.props[prop];
     if (ZYGPU_SHAPE_RECTANGLE == p.shape) return trafo.scale.x * trafo.scale.y;
     if (ZYGPU_SHAPE_DISTANT == p.shape) return distantSolidAngle(trafo.scale.x);  // "the solid angle, not the area" (shape.zig:140-142)
+    if (ZYGPU_SHAPE_SPHERE == p.shape) return (4.f * kPi) * ((0.5f * trafo.scale.x) * (0.5f * trafo.scale.x));  // shape.zig:148
     return s.meshes[p.mesh].part_areas[part] * (trafo.scale.x * trafo.scale.y);
 }
 
@@ -533,6 +537,8 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
                                   frag.primitive, translucent, v.light_split_threshold);
     } else if (MESHL && ZYGPU_SHAPE_DISTANT == s.props[light.prop].shape) {  // -> distant.zig:139-141
         sample_pdf = 1.f / distantSolidAngle(frag.trafo.scale.x);
+    } else if (MESHL && ZYGPU_SHAPE_SPHERE == s.props[light.prop].shape) {  // -> sphere.zig:469-485
+        sample_pdf = spherePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
     } else {  // -> rectangle.zig:554-575, with the light's sample count under the previous vertex's split threshold
         sample_pdf = rectanglePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
     }
@@ -609,6 +615,9 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, const
             frag.part = mesh.triangle_parts[prim];
             frag.p = frag.trafo.objectToWorldPoint(interpolate3(a, b, cc, frag.u, frag.v));
             frag.geo_n = frag.trafo.objectToWorldNormal(normalize3(cross3(b - a, cc - a)));
+        } else if (MESHL && ZYGPU_SHAPE_SPHERE == prop.shape) {
+            frag.primitive = 0;
+            sphereFragment(ray, frag);
         } else {
             frag.primitive = 0;
             rectangleFragment(ray, frag);
@@ -1097,6 +1106,22 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 } else if (distant) {
                     SampleTo ls;
                     if (distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
+                } else if (MESHL && ZYGPU_SHAPE_SPHERE == s.props[light.prop].shape) {
+                    const uint32_t      n = numSamples(light.num_samples, sample_threshold);
+                    const SphereSampler ss = SphereSampler::init(sf.p, trafo, n);
+                    if (ss.valid) {  // sphere.zig:331-337: a point inside the sphere takes no sample and no draw
+                        Sampler replay = h.smp;
+                        for (uint32_t j = 0; j < n; ++j) {
+                            float a, b;
+                            h.smp.sample2D(a, b);
+                        }
+                        for (uint32_t j = 0; j < n; ++j) {
+                            float s0, s1;
+                            replay.sample2D(s0, s1);
+                            SampleTo ls;
+                            if (ss.sample(s0, s1, sf.p, ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
+                        }
+                    }
                 } else {
                     const uint32_t         n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
                     const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);

@@ -424,11 +424,12 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (d->lights[l].num_samples > 1) c->multi_sample_lights = true;
         const ZygpuProp& lp = d->props[d->lights[l].prop];
         const bool       is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == lp.shape;
-        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && ZYGPU_SHAPE_DISTANT != lp.shape) {
-            g_error = "only Rectangle, TriangleMesh and Distant lights are supported on the device path";
+        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && ZYGPU_SHAPE_DISTANT != lp.shape && ZYGPU_SHAPE_SPHERE != lp.shape) {
+            g_error = "only Rectangle, TriangleMesh, Sphere and Distant lights are supported on the device path";
             return -2;
         }
-        if (ZYGPU_SHAPE_DISTANT == lp.shape) c->mesh_lights = true;  // the same kernel instantiations carry the Distant code
+        // the same kernel instantiations carry the Distant and Sphere light code
+        if (ZYGPU_SHAPE_DISTANT == lp.shape || ZYGPU_SHAPE_SPHERE == lp.shape) c->mesh_lights = true;
         if (is_mesh) {
             if (d->lights[l].sampler >= d->num_mesh_lights) {
                 g_error = "a TriangleMesh light without its ZygpuMeshLight (ZygpuLight.sampler)";
@@ -441,7 +442,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         const uint32_t sh = d->props[p].shape;
         const bool     in_tree = 0 != (d->props[p].flags & ZYGPU_PROP_SOLID);
         (void)in_tree;
-        if (ZYGPU_SHAPE_RECTANGLE != sh && ZYGPU_SHAPE_TRIANGLE_MESH != sh && ZYGPU_SHAPE_DISTANT != sh) {
+        if (ZYGPU_SHAPE_RECTANGLE != sh && ZYGPU_SHAPE_TRIANGLE_MESH != sh && ZYGPU_SHAPE_DISTANT != sh && ZYGPU_SHAPE_SPHERE != sh) {
             g_error = "unsupported shape class on the device path";
             return -2;
         }

@@ -903,7 +903,8 @@ int Engine::compile(uint32_t frame) {
         const ZygpuMaterial& m = materials_[material_ids_[p]];
 
         const bool is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == s.kind, is_distant = ZYGPU_SHAPE_DISTANT == s.kind;
-        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh && !is_distant) return -3;  // sphere / disk / ... emitters: SURVEY §8(f)
+        const bool is_sphere = ZYGPU_SHAPE_SPHERE == s.kind;
+        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh && !is_distant && !is_sphere) return -3;  // disk / cube / ... emitters: SURVEY §8(f)
         c_light_infinite_[li] = is_distant ? 1 : 0;
 
         l.num_samples = m.emission_num_samples;  // light_material.zig:68-74 / substitute_material.zig:96-111
@@ -919,7 +920,8 @@ int Engine::compile(uint32_t frame) {
         AABB bb = aabbTransform(is_mesh ? mesh_lights_[l.sampler].aabb : shapeAabb(hp.shape), objectToWorld(rel));
         aabbCacheRadius(bb);
 
-        const Vec4f  part_cone = is_mesh ? mesh_lights_[l.sampler].cone : vec(0.f, 0.f, 1.f, 1.f);  // shape.zig:115-120
+        // shape.zig:115-120: Disk / Rectangle / Distant emit into a half space, the other analytic shapes everywhere
+        const Vec4f  part_cone = is_mesh ? mesh_lights_[l.sampler].cone : vec(0.f, 0.f, 1.f, is_sphere ? -1.f : 1.f);
         const Mat3x3 rot = quaternionToMat3x3(t.rotation);
         Mat3x3       rot_s = rot;  // rows carry the scale in w, as the reference's ComposedTransformation does
         for (int i = 0; i < 3; ++i) rot_s.r[i][3] = t.scale[i];
@@ -930,7 +932,8 @@ int Engine::compile(uint32_t frame) {
         c_light_cones_[4 * li + 3] = part_cone[3];
 
         // shape.zig:132-152: Rectangle area, TriangleMesh part area (triangle_mesh.zig:376-380), Distant solid angle (distant.zig:143-145)
-        const float extent = is_distant ? (2.f * float(M_PI)) * (1.f - std::sqrt(1.f / (t.scale[0] * t.scale[0] + 1.f)))
+        const float extent = is_sphere  ? (4.f * float(M_PI)) * ((0.5f * t.scale[0]) * (0.5f * t.scale[0]))
+                             : is_distant ? (2.f * float(M_PI)) * (1.f - std::sqrt(1.f / (t.scale[0] * t.scale[0] + 1.f)))
                              : is_mesh  ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1])
                                         : t.scale[0] * t.scale[1];
         Vec4f       emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f);

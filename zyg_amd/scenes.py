@@ -186,12 +186,14 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
-            floor_material=None):
+            floor_material=None, spheres=False, sphere_lights=False):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
     mesh_lights: the two emissive quads are triangle meshes (2 * light_grid^2 triangles each) instead of Rectangles.
     many_lights: n > 0 replaces the two quads by an n x n grid of small Rectangle lights under the ceiling (light-tree depth).
+    spheres: two analytic Spheres (one Substitute-ish via `material`, one red) instead of / next to the boxes;
+    sphere_lights: the two emitters are Spheres of diameter 0.3 instead of quads.
     Returns a dict with prop ids.
     """
     mk = lambert if material == "lambert" else substitute
@@ -239,7 +241,18 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
                 engine.transformation(p, trafo((1, 0, 0), (0, 0, 1), (0.6 * side, 0.5 * side, 1), (cx, 1.98 - 0.01 * ((i + j) % 3), cz)))
                 engine.light(p)
                 ids["lights"].append(p)
+    if spheres:
+        for pos_, d_, mat_ in (((-0.45, 0.4, 0.2), 0.8, white), ((0.5, 0.25, -0.3), 0.5, red)):
+            p = engine.prop(SPHERE, [mat_])
+            engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (d_, d_, d_), pos_))
+            ids["meshes"].append(p)
     for lx in (() if many_lights else (-0.45, 0.45)):  # two emissive quads just below the ceiling, facing down
+        if sphere_lights:
+            p = engine.prop(SPHERE, [lamp], unoccluding=unoccluding_lights)
+            engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (0.3, 0.3, 0.3), (lx, 1.7, 0.0)))
+            engine.light(p)
+            ids["lights"].append(p)
+            continue
         if mesh_lights:
             # the size is baked into the vertices: the reference's mesh-light areas and solid angles only hold for
             # uniform scales (triangle_mesh.zig:289-292 "HACK", 524-531)
@@ -275,6 +288,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
 
 
 DISTANT = 3  # built-in Distant shape (resource/manager.zig:36-44)
+SPHERE = 6   # built-in Sphere: unit diameter, scaled by the transformation
 
 
 def _basis_for(n):
