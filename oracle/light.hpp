@@ -477,6 +477,60 @@ inline float spherePdf(V4 p, const Trafo& trafo, float split_threshold, uint32_t
     return float(numSamples(light_num_samples, split_threshold)) * conePdfUniform(one_minus_cos_theta_max);
 }
 
+// ---------- Dome / Canopy with uniform emission: dome.zig:26-103, 214-220; canopy.zig:24-92 ----------
+
+inline V4 hemisphereUniform(float u0, float u1) {  // sampling.zig:56-65
+    const float z = 1.f - u0;
+    const float r = std::sqrt(mx(0.f, 1.f - z * z));
+    const float phi = u1 * (2.f * kPi);
+    return mk(cosF(phi) * r, sinF(phi) * r, z);
+}
+inline V4 sphereUniform(float u0, float u1) {  // sampling.zig:67-76
+    const float z = 1.f - 2.f * u0;
+    const float r = std::sqrt(mx(0.f, 1.f - z * z));
+    const float phi = u1 * (2.f * kPi);
+    return mk(cosF(phi) * r, sinF(phi) * r, z);
+}
+constexpr float kCanopyEps = -0.0005f;  // canopy.zig:25
+
+inline uint32_t domeSampleTo(V4 n, bool total_sphere, Sampler& sampler, SampleTo* buffer) {
+    float uv[2];
+    sampler.sample2D(uv);
+    V4    dir;
+    float pdf;
+    if (total_sphere) {
+        dir = sphereUniform(uv[0], uv[1]);
+        pdf = 1.f / (4.f * kPi);
+    } else {
+        const V4 dl = hemisphereUniform(uv[0], uv[1]);
+        V4       fx, fy;
+        orthonormalBasis3(n, fx, fy);
+        dir = fma4(S(dl[2]), n, fma4(S(dl[1]), fy, S(dl[0]) * fx));
+        if (dot3(dir, n) <= 0.f) return 0;
+        pdf = 1.f / (2.f * kPi);
+    }
+    const V4 p = S(kRayMaxT) * dir;
+    buffer[0].p = mk(p[0], p[1], p[2], pdf);
+    buffer[0].n = -dir;
+    buffer[0].wi = dir;
+    buffer[0].uvw = S(0.f);  // the uv only addresses emission maps, which are not in scope
+    return 1;
+}
+
+inline uint32_t canopySampleTo(V4 n, const Trafo& trafo, bool total_sphere, Sampler& sampler, SampleTo* buffer) {
+    float uv[2];
+    sampler.sample2D(uv);
+    const V4 dl = hemisphereUniform(uv[0], uv[1]);
+    const V4 dir = fma4(S(dl[2]), trafo.r[2], fma4(S(dl[1]), trafo.r[1], S(dl[0]) * trafo.r[0]));
+    if (dot3(dir, n) <= 0.f && !total_sphere) return 0;
+    const V4 p = S(kRayMaxT) * dir;
+    buffer[0].p = mk(p[0], p[1], p[2], 1.f / (2.f * kPi));
+    buffer[0].n = -dir;
+    buffer[0].wi = dir;
+    buffer[0].uvw = S(0.f);
+    return 1;
+}
+
 // ---------- Distant lights: distant.zig:21-146 ----------
 
 inline float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - std::sqrt(1.f / (radius * radius + 1.f))); }

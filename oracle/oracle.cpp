@@ -128,6 +128,8 @@ struct Worker {
         if (ZYGPU_SHAPE_RECTANGLE == p.shape) return s[0] * s[1];
         if (ZYGPU_SHAPE_DISTANT == p.shape) return distantSolidAngle(s[0]);  // "the solid angle, not the area" (shape.zig:140-142)
         if (ZYGPU_SHAPE_SPHERE == p.shape) return (4.f * kPi) * ((0.5f * s[0]) * (0.5f * s[0]));  // shape.zig:148
+        if (ZYGPU_SHAPE_DOME == p.shape) return 4.f * kPi;
+        if (ZYGPU_SHAPE_CANOPY == p.shape) return 2.f * kPi;
         return rc->scene->meshes[p.mesh].part_areas[part] * (s[0] * s[1]);
     }
 
@@ -154,6 +156,8 @@ struct Worker {
                 ? 1.f / distantSolidAngle(frag.isec.trafo.scaleX())  // distant.zig:139-141
             : ZYGPU_SHAPE_SPHERE == rc->scene->props[l.prop].shape
                 ? spherePdf(v.origin, frag.isec.trafo, v.light_split_threshold, l.num_samples)  // sphere.zig:469-485
+            : ZYGPU_SHAPE_DOME == rc->scene->props[l.prop].shape ? (v.state.translucent ? 1.f / (4.f * kPi) : 1.f / (2.f * kPi))  // dome.zig:214-220
+            : ZYGPU_SHAPE_CANOPY == rc->scene->props[l.prop].shape ? 1.f / (2.f * kPi)  // shape.zig:483
                 : rectanglePdf(v.origin, frag.isec.trafo, v.light_split_threshold, l.num_samples);
         return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
     }
@@ -288,18 +292,25 @@ struct Worker {
             if (!aabbIntersect(rc->scene->aabbs[p], v.ray)) continue;
             Fragment frag;
             frag.isec.trafo = rc->sv.propTrafo(p);
-            float u, vv;
-            if (!distantIntersect(v.ray, frag.isec.trafo, u, vv)) continue;
+            float u = 0.f, vv = 0.f;
+            if (ZYGPU_SHAPE_DISTANT == prop.shape) {
+                if (!distantIntersect(v.ray, frag.isec.trafo, u, vv)) continue;
+                frag.geo_n = frag.n = frag.isec.trafo.r[2];
+                frag.uvw = mk((u + 1.f) * 0.5f, (vv + 1.f) * 0.5f, 0.f, 0.f);
+            } else {  // dome.zig:26-56, canopy.zig:27-58: the whole sphere / the hemisphere around the prop's z axis
+                if (v.ray.max_t < kRayMaxT) continue;
+                if (ZYGPU_SHAPE_CANOPY == prop.shape && dot3(v.ray.direction, frag.isec.trafo.r[2]) < kCanopyEps) continue;
+                frag.geo_n = frag.n = -v.ray.direction;
+                frag.uvw = S(0.f);  // only addresses emission maps
+            }
             frag.prop = p;
             frag.isec.t = kRayMaxT;
             frag.isec.u = u;
             frag.isec.v = vv;
             frag.isec.primitive = 0;
             frag.p = S(kRayMaxT) * v.ray.direction;
-            frag.geo_n = frag.n = frag.isec.trafo.r[2];
             frag.t = frag.isec.trafo.r[0];
             frag.b = frag.isec.trafo.r[1];
-            frag.uvw = mk((u + 1.f) * 0.5f, (vv + 1.f) * 0.5f, 0.f, 0.f);
             frag.part = 0;
             if (only_non_lights && !(v.state.singular || kNull == rc->sv.propLightId(p, 0))) continue;
             energy += evaluateRadiance(v, frag, sampler);
@@ -358,11 +369,14 @@ struct Worker {
 
             SampleTo       samples[64];
             const float    sample_threshold = mis ? v.light_split_threshold : 0.f;
-            const bool     distant = ZYGPU_SHAPE_DISTANT == rc->scene->props[light.prop].shape;
+            const uint32_t light_shape = rc->scene->props[light.prop].shape;
+            const bool     distant = ZYGPU_SHAPE_DISTANT == light_shape || ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_CANOPY == light_shape;
             const uint32_t num_samples =
                 kNull != light.sampler
                     ? meshSampleTo(*rc->scene, rc->scene->mesh_lights[light.sampler], p, n, trafo, 0 != light.two_sided, translucent,
                                    sample_threshold, sampler, samples)
+                : ZYGPU_SHAPE_DOME == light_shape   ? domeSampleTo(n, translucent, sampler, samples)
+                : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(n, trafo, translucent, sampler, samples)
                 : distant ? distantSampleTo(n, trafo, translucent, sampler, samples)
                 : ZYGPU_SHAPE_SPHERE == rc->scene->props[light.prop].shape
                     ? sphereSampleTo(p, n, trafo, translucent, sample_threshold, light.num_samples, sampler, samples)

@@ -300,6 +300,17 @@ def test_distant_light(engine, oracle, integrator, quad):
     assert integrator == "PT" or out[2].shadow_rays > 0
 
 
+@pytest.mark.parametrize("integrator,sky,sun", [("PT", "dome", True), ("PTDL", "canopy", True), ("PTMIS", "dome", True),
+                                                ("PTMIS", "canopy", False), ("PTMIS", "dome", False)])
+def test_sky_lights(engine, oracle, integrator, sky, sun):
+    """Uniform Dome / Canopy environment lights: uniform (hemi)sphere direction sampling around the shading normal or the
+    canopy's axis, constant pdf, emission for every ray that leaves the scene (dome.zig:26-103, canopy.zig:27-92)."""
+    out = _render_both(engine, oracle, 80, 60, 3, scene=scenes.outdoor, integrator=integrator, sun_radius=0.08, sky=sky, sun=sun,
+                       material="substitute" if "PTMIS" == integrator and sun else "lambert")
+    _check(*out, 3)
+    assert integrator == "PT" or out[2].shadow_rays > 0
+
+
 @pytest.mark.parametrize("integrator,unoccluding,samples", [("PT", True, 1), ("PTDL", False, 1), ("PTMIS", True, 1), ("PTMIS", False, 3)])
 def test_spheres(engine, oracle, integrator, unoccluding, samples):
     """Analytic Spheres as geometry (intersection, spherical uv frame through atan2 / acos) and as lights (uniform cone of

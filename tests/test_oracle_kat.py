@@ -294,6 +294,29 @@ def test_distant_light_integrators_agree(product_lib, oracle):
     np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.06)
 
 
+@pytest.mark.parametrize("sky", ["dome", "canopy"])
+def test_sky_light_integrators_agree(product_lib, oracle, sky):
+    """Uniform Dome / Canopy environment lights (dome.zig, canopy.zig) next to the sun: PTDL, PTMIS and PT agree, and the
+    image is brighter than with the sun alone."""
+    w, h, spp = 40, 30, 256
+    means = {}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.outdoor(e, w, h, spp, integrator=integ, sun_radius=0.12, sky=sky, max_depth=5)
+            sd, vd = e.compile()
+            assert sd.light_tree.num_infinite_lights == 2 and sd.num_infinite_props == 2
+            img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(img).all()
+            means[integ] = img[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.01)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.06)
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.outdoor(e, w, h, spp, integrator="PTMIS", sun_radius=0.12, max_depth=5)
+        sd, vd = e.compile()
+        sun_only = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
+    assert (means["PTMIS"] > 1.2 * sun_only).all()
+
+
 def test_sphere_lights_integrators_agree(product_lib, oracle):
     """Sphere lights and Sphere geometry: PT (no light sampling), PTDL and PTMIS estimate the same image."""
     w, h, spp = 40, 30, 256

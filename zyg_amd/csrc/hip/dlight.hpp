@@ -516,6 +516,56 @@ ZD bool distantIntersect(const Ray& ray, const Trafo& trafo, float& u, float& v)
     return false;
 }
 
+// ---------------------------------------------------------------- Dome / Canopy, uniform emission (dome.zig, canopy.zig)
+
+ZD f3 hemisphereUniform(float u0, float u1) {  // sampling.zig:56-65
+    const float z = 1.f - u0;
+    const float r = sqrtf(mx(0.f, 1.f - z * z));
+    const float phi = u1 * (2.f * kPi);
+    return mk3(cosF(phi) * r, sinF(phi) * r, z);
+}
+ZD f3 sphereUniform(float u0, float u1) {  // sampling.zig:67-76
+    const float z = 1.f - 2.f * u0;
+    const float r = sqrtf(mx(0.f, 1.f - z * z));
+    const float phi = u1 * (2.f * kPi);
+    return mk3(cosF(phi) * r, sinF(phi) * r, z);
+}
+constexpr float kCanopyEps = -0.0005f;  // canopy.zig:25
+
+// Dome.sampleTo (dome.zig:58-103)
+ZD bool domeSampleTo(f3 n, bool total_sphere, Sampler& sampler, SampleTo& out) {
+    float u0, u1;
+    sampler.sample2D(u0, u1);
+    f3 dir;
+    if (total_sphere) {
+        dir = sphereUniform(u0, u1);
+        out.pdf = 1.f / (4.f * kPi);
+    } else {
+        const f3 dl = hemisphereUniform(u0, u1);
+        dir = Frame::init(n).frameToWorld(dl);
+        if (dot3(dir, n) <= 0.f) return false;
+        out.pdf = 1.f / (2.f * kPi);
+    }
+    out.p = S3(kRayMaxT) * dir;
+    out.n = -dir;
+    out.wi = dir;
+    return true;
+}
+
+// Canopy.sampleTo (canopy.zig:60-92)
+ZD bool canopySampleTo(f3 n, const Trafo& trafo, bool total_sphere, Sampler& sampler, SampleTo& out) {
+    float u0, u1;
+    sampler.sample2D(u0, u1);
+    const f3 dl = hemisphereUniform(u0, u1);
+    const f3 dir = Frame{trafo.r0, trafo.r1, trafo.r2}.frameToWorld(dl);
+    if (dot3(dir, n) <= 0.f && !total_sphere) return false;
+    out.p = S3(kRayMaxT) * dir;
+    out.n = -dir;
+    out.wi = dir;
+    out.pdf = 1.f / (2.f * kPi);
+    return true;
+}
+
 // ---------------------------------------------------------------- TriangleMesh lights (triangle_mesh.zig:391-703)
 
 ZD f3 orthogonalize(f3 a, f3 b) { return normalize3(fma3(S3(-dot3(a, b)), a, b)); }  // a is normalised (391-394)

@@ -207,6 +207,12 @@ ZD float clampAbsDot(f3 a, f3 b) { return clampf(fabsf(dot3(a, b)), kDotMin, 1.f
 
 struct Frame {  // frame.zig:5-69
     f3 x, y, z;
+    ZD static Frame init(f3 n) {  // frame.zig:10-13 -> orthonormalBasis3 (vector4.zig:98-110)
+        const float sign = copysignf(1.f, n.z);
+        const float c = -1.f / (sign + n.z);
+        const float d = n.x * n.y * c;
+        return {{1.f + sign * n.x * n.x * c, sign * d, -sign * n.x}, {d, sign + n.y * n.y * c, -n.y}, n};
+    }
     ZD f3 frameToWorld(f3 v) const {
         f3 r = S3(v.x) * x;
         r = fma3(S3(v.y), y, r);

@@ -505,6 +505,8 @@ ZD float shapeArea(const DScene& s, uint32_t prop, uint32_t part, const Trafo& t
     if (ZYGPU_SHAPE_RECTANGLE == p.shape) return trafo.scale.x * trafo.scale.y;
     if (ZYGPU_SHAPE_DISTANT == p.shape) return distantSolidAngle(trafo.scale.x);  // "the solid angle, not the area" (shape.zig:140-142)
     if (ZYGPU_SHAPE_SPHERE == p.shape) return (4.f * kPi) * ((0.5f * trafo.scale.x) * (0.5f * trafo.scale.x));  // shape.zig:148
+    if (ZYGPU_SHAPE_DOME == p.shape) return 4.f * kPi;
+    if (ZYGPU_SHAPE_CANOPY == p.shape) return 2.f * kPi;
     return s.meshes[p.mesh].part_areas[part] * (trafo.scale.x * trafo.scale.y);
 }
 
@@ -539,6 +541,10 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
         sample_pdf = 1.f / distantSolidAngle(frag.trafo.scale.x);
     } else if (MESHL && ZYGPU_SHAPE_SPHERE == s.props[light.prop].shape) {  // -> sphere.zig:469-485
         sample_pdf = spherePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
+    } else if (MESHL && ZYGPU_SHAPE_DOME == s.props[light.prop].shape) {  // -> dome.zig:214-220
+        sample_pdf = translucent ? 1.f / (4.f * kPi) : 1.f / (2.f * kPi);
+    } else if (MESHL && ZYGPU_SHAPE_CANOPY == s.props[light.prop].shape) {  // shape.zig:483
+        sample_pdf = 1.f / (2.f * kPi);
     } else {  // -> rectangle.zig:554-575, with the light's sample count under the previous vertex's split threshold
         sample_pdf = rectanglePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
     }
@@ -556,8 +562,9 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
     return S3(weight) * energy;
 }
 
-// the infinite props a ray reaches when it leaves the scene (Distant only): Context.propIntersect + Distant.intersect /
-// fragment (prop.zig:163-197, distant.zig:22-74), then Vertex.evaluateRadiance; `only_non_lights`: PathtracerDL's filter
+// the infinite props a ray reaches when it leaves the scene: Context.propIntersect + the shape's intersect / fragment
+// (prop.zig:163-197; distant.zig:22-74, dome.zig:26-56, canopy.zig:27-58), then Vertex.evaluateRadiance;
+// `only_non_lights`: PathtracerDL's filter
 template <bool STATS>
 ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampler& smp, bool only_non_lights, Counters& cnt) {
     f3       energy = S3(0.f);
@@ -570,19 +577,26 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
         if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
         Fragment frag;
         frag.trafo = loadTrafo(s, p);
-        float u, vv;
-        if (!distantIntersect(ray, frag.trafo, u, vv)) continue;
+        float u = 0.f, vv = 0.f;
+        if (ZYGPU_SHAPE_DISTANT == prop.shape) {
+            if (!distantIntersect(ray, frag.trafo, u, vv)) continue;
+            frag.geo_n = frag.n = frag.trafo.r2;
+            frag.uv0 = (u + 1.f) * 0.5f;
+            frag.uv1 = (vv + 1.f) * 0.5f;
+        } else {  // the whole sphere / the hemisphere around the prop's z axis
+            if (ray.max_t < kRayMaxT) continue;
+            if (ZYGPU_SHAPE_CANOPY == prop.shape && dot3(ray.direction, frag.trafo.r2) < kCanopyEps) continue;
+            frag.geo_n = frag.n = -ray.direction;
+            frag.uv0 = frag.uv1 = 0.f;  // only addresses emission maps
+        }
         frag.prop = p;
         frag.t_hit = kRayMaxT;
         frag.u = u;
         frag.v = vv;
         frag.primitive = 0;
         frag.p = S3(kRayMaxT) * ray.direction;
-        frag.geo_n = frag.n = frag.trafo.r2;
         frag.t = frag.trafo.r0;
         frag.b = frag.trafo.r1;
-        frag.uv0 = (u + 1.f) * 0.5f;
-        frag.uv1 = (vv + 1.f) * 0.5f;
         frag.part = 0;
         if (only_non_lights && !((v.flags & ST_SINGULAR) || kNull == s.light_ids[prop.parts_start])) continue;
         energy = energy + evaluateRadiance<true>(s, v, wo, frag, smp);
@@ -1059,8 +1073,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 f3          occluded = S3(0.f);
 
                 // evaluateLight's loop body for one light sample (pathtracer_mis.zig:248-272 / pathtracer_dl.zig:150-166)
-                const bool distant = MESHL && ZYGPU_SHAPE_DISTANT == s.props[light.prop].shape;
-                auto       connect = [&](const SampleTo& ls) {
+                const uint32_t light_shape = MESHL ? s.props[light.prop].shape : uint32_t(ZYGPU_SHAPE_RECTANGLE);
+                const bool     distant =
+                    ZYGPU_SHAPE_DISTANT == light_shape || ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_CANOPY == light_shape;
+                auto connect = [&](const SampleTo& ls) {
                     const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
                     f3       sdir;
                     float    slen;
@@ -1104,9 +1120,12 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                         if (msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
                     });
                 } else if (distant) {
-                    SampleTo ls;
-                    if (distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
-                } else if (MESHL && ZYGPU_SHAPE_SPHERE == s.props[light.prop].shape) {
+                    SampleTo   ls;
+                    const bool got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(ms.geo_n, ms.translucent, h.smp, ls)
+                                     : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)
+                                                                         : distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls);
+                    if (got) connect(ls);
+                } else if (ZYGPU_SHAPE_SPHERE == light_shape) {
                     const uint32_t      n = numSamples(light.num_samples, sample_threshold);
                     const SphereSampler ss = SphereSampler::init(sf.p, trafo, n);
                     if (ss.valid) {  // sphere.zig:331-337: a point inside the sphere takes no sample and no draw

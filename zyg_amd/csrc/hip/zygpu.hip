@@ -424,12 +424,13 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (d->lights[l].num_samples > 1) c->multi_sample_lights = true;
         const ZygpuProp& lp = d->props[d->lights[l].prop];
         const bool       is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == lp.shape;
-        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && ZYGPU_SHAPE_DISTANT != lp.shape && ZYGPU_SHAPE_SPHERE != lp.shape) {
-            g_error = "only Rectangle, TriangleMesh, Sphere and Distant lights are supported on the device path";
+        const bool is_infinite = ZYGPU_SHAPE_DISTANT == lp.shape || ZYGPU_SHAPE_DOME == lp.shape || ZYGPU_SHAPE_CANOPY == lp.shape;
+        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && !is_infinite && ZYGPU_SHAPE_SPHERE != lp.shape) {
+            g_error = "only Rectangle, TriangleMesh, Sphere, Distant, Dome and Canopy lights are supported on the device path";
             return -2;
         }
-        // the same kernel instantiations carry the Distant and Sphere light code
-        if (ZYGPU_SHAPE_DISTANT == lp.shape || ZYGPU_SHAPE_SPHERE == lp.shape) c->mesh_lights = true;
+        // the same kernel instantiations carry the infinite and Sphere light code
+        if (is_infinite || ZYGPU_SHAPE_SPHERE == lp.shape) c->mesh_lights = true;
         if (is_mesh) {
             if (d->lights[l].sampler >= d->num_mesh_lights) {
                 g_error = "a TriangleMesh light without its ZygpuMeshLight (ZygpuLight.sampler)";
@@ -442,7 +443,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         const uint32_t sh = d->props[p].shape;
         const bool     in_tree = 0 != (d->props[p].flags & ZYGPU_PROP_SOLID);
         (void)in_tree;
-        if (ZYGPU_SHAPE_RECTANGLE != sh && ZYGPU_SHAPE_TRIANGLE_MESH != sh && ZYGPU_SHAPE_DISTANT != sh && ZYGPU_SHAPE_SPHERE != sh) {
+        if (ZYGPU_SHAPE_RECTANGLE != sh && ZYGPU_SHAPE_TRIANGLE_MESH != sh && ZYGPU_SHAPE_DISTANT != sh && ZYGPU_SHAPE_SPHERE != sh &&
+            ZYGPU_SHAPE_DOME != sh && ZYGPU_SHAPE_CANOPY != sh) {
             g_error = "unsupported shape class on the device path";
             return -2;
         }
@@ -504,8 +506,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     if (!m.upload(meshes.data(), meshes.size(), &s.meshes)) return -1;
 
     for (uint32_t i = 0; i < d->num_infinite_props; ++i) {
-        if (d->infinite_props[i] >= d->num_props || ZYGPU_SHAPE_DISTANT != d->props[d->infinite_props[i]].shape) {
-            g_error = "infinite props other than Distant are not supported on the device path";
+        const uint32_t sh = d->infinite_props[i] < d->num_props ? d->props[d->infinite_props[i]].shape : kNull;
+        if (ZYGPU_SHAPE_DISTANT != sh && ZYGPU_SHAPE_DOME != sh && ZYGPU_SHAPE_CANOPY != sh) {
+            g_error = "an infinite prop must be a Distant, Dome or Canopy";
             return -2;
         }
         c->mesh_lights = true;

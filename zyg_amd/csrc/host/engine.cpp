@@ -877,8 +877,7 @@ int Engine::compile(uint32_t frame) {
     buildPropTree(finite_props_, solid_nodes_, solid_indices_);
     buildPropTree(unoccluding_props_, unoccluding_nodes_, unoccluding_indices_);
     if (!volume_props_.empty()) return -2;  // out of scope
-    for (uint32_t p : infinite_props_)
-        if (ZYGPU_SHAPE_DISTANT != shapes_[props_[p].shape].kind) return -2;  // Canopy / Dome (sky, image lights): row a20
+    // Distant, Dome and Canopy props with uniform emission; sky models and image lights (emission maps) are row a20's rest
 
     // lights: scene.zig:402-497 (propPrepareSampling, static branch)
     mesh_lights_.clear();
@@ -903,9 +902,10 @@ int Engine::compile(uint32_t frame) {
         const ZygpuMaterial& m = materials_[material_ids_[p]];
 
         const bool is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == s.kind, is_distant = ZYGPU_SHAPE_DISTANT == s.kind;
-        const bool is_sphere = ZYGPU_SHAPE_SPHERE == s.kind;
-        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh && !is_distant && !is_sphere) return -3;  // disk / cube / ... emitters: SURVEY §8(f)
-        c_light_infinite_[li] = is_distant ? 1 : 0;
+        const bool is_sphere = ZYGPU_SHAPE_SPHERE == s.kind, is_dome = ZYGPU_SHAPE_DOME == s.kind, is_canopy = ZYGPU_SHAPE_CANOPY == s.kind;
+        const bool is_infinite = is_distant || is_dome || is_canopy;
+        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh && !is_infinite && !is_sphere) return -3;  // disk / cube emitters: SURVEY §8(f)
+        c_light_infinite_[li] = is_infinite ? 1 : 0;
 
         l.num_samples = m.emission_num_samples;  // light_material.zig:68-74 / substitute_material.zig:96-111
         l.two_sided = (m.flags & ZYGPU_MATF_TWO_SIDED) ? 1 : 0;
@@ -921,7 +921,7 @@ int Engine::compile(uint32_t frame) {
         aabbCacheRadius(bb);
 
         // shape.zig:115-120: Disk / Rectangle / Distant emit into a half space, the other analytic shapes everywhere
-        const Vec4f  part_cone = is_mesh ? mesh_lights_[l.sampler].cone : vec(0.f, 0.f, 1.f, is_sphere ? -1.f : 1.f);
+        const Vec4f  part_cone = is_mesh ? mesh_lights_[l.sampler].cone : vec(0.f, 0.f, 1.f, (is_sphere || is_dome || is_canopy) ? -1.f : 1.f);
         const Mat3x3 rot = quaternionToMat3x3(t.rotation);
         Mat3x3       rot_s = rot;  // rows carry the scale in w, as the reference's ComposedTransformation does
         for (int i = 0; i < 3; ++i) rot_s.r[i][3] = t.scale[i];
@@ -932,7 +932,9 @@ int Engine::compile(uint32_t frame) {
         c_light_cones_[4 * li + 3] = part_cone[3];
 
         // shape.zig:132-152: Rectangle area, TriangleMesh part area (triangle_mesh.zig:376-380), Distant solid angle (distant.zig:143-145)
-        const float extent = is_sphere  ? (4.f * float(M_PI)) * ((0.5f * t.scale[0]) * (0.5f * t.scale[0]))
+        const float extent = is_canopy  ? 2.f * float(M_PI)
+                             : is_dome  ? 4.f * float(M_PI)
+                             : is_sphere ? (4.f * float(M_PI)) * ((0.5f * t.scale[0]) * (0.5f * t.scale[0]))
                              : is_distant ? (2.f * float(M_PI)) * (1.f - std::sqrt(1.f / (t.scale[0] * t.scale[0] + 1.f)))
                              : is_mesh  ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1])
                                         : t.scale[0] * t.scale[1];
@@ -940,7 +942,7 @@ int Engine::compile(uint32_t frame) {
         // emittance.zig:61-71 totalEmission; light.zig:67-77 power: infinite lights scale with the scene's extent
         Vec4f power = splat(0.f);
         if (extent > 0.f) power = m.emission_normalize ? emission : emission * splat(extent);
-        if (is_distant && !solid_nodes_.empty()) power = splat(squaredLength3(aabbExtent(scene_bb))) * power;
+        if (is_infinite && !solid_nodes_.empty()) power = splat(squaredLength3(aabbExtent(scene_bb))) * power;
         bb.b[0][3] = hmax3(power);
 
         for (int i = 0; i < 4; ++i) {

@@ -289,6 +289,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
 
 DISTANT = 3  # built-in Distant shape (resource/manager.zig:36-44)
 SPHERE = 6   # built-in Sphere: unit diameter, scaled by the transformation
+CANOPY = 0   # infinite: the hemisphere of directions around the prop's z axis
+DOME = 4     # infinite: the whole sphere of directions
 
 
 def _basis_for(n):
@@ -303,10 +305,12 @@ def _basis_for(n):
 
 
 def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
-            extra_quad_light=False, max_depth=8):
+            extra_quad_light=False, max_depth=8, sky=None, sun=True):
     """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
     distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
-    light tree mixes the infinite-light distribution with the BVH."""
+    light tree mixes the infinite-light distribution with the BVH.  `sky`: "dome" (dome.zig, the whole sphere of
+    directions) or "canopy" (canopy.zig, the hemisphere above the ground) with uniform emission; `sun=False` drops the
+    Distant light."""
     mk = lambert if material == "lambert" else substitute
     cam = engine.camera(width, height, fov_deg=45.0)
     engine.samples_per_pixel(spp)
@@ -314,7 +318,7 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
     engine.sensor(json.dumps({}))
     white = engine.material(mk(WHITE))
     red = engine.material(mk(RED))
-    sun = engine.material(light_material(spectrum=(12.0, 11.0, 9.0)))
+    sun_mat = engine.material(light_material(spectrum=(12.0, 11.0, 9.0)))
     ids = {"camera": cam}
 
     ground = engine.prop(RECTANGLE, [white])
@@ -325,12 +329,20 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
         p = engine.prop(engine.triangle_mesh(idx, pos, nrm, uv), [mat])
         engine.transformation(p, identity)
 
-    to_light = np.asarray(sun_direction, dtype=np.float64)
-    r0, r1 = _basis_for(-to_light)  # the light's z axis points from the light into the scene
-    s = engine.prop(DISTANT, [sun])
-    engine.transformation(s, trafo(r0, r1, (sun_radius, sun_radius, sun_radius), (0, 0, 0)))
-    engine.light(s)
-    ids["sun"] = s
+    if sun:
+        to_light = np.asarray(sun_direction, dtype=np.float64)
+        r0, r1 = _basis_for(-to_light)  # the light's z axis points from the light into the scene
+        s = engine.prop(DISTANT, [sun_mat])
+        engine.transformation(s, trafo(r0, r1, (sun_radius, sun_radius, sun_radius), (0, 0, 0)))
+        engine.light(s)
+        ids["sun"] = s
+    if sky is not None:
+        sky_mat = engine.material(light_material(spectrum=(0.35, 0.5, 0.8)))
+        k = engine.prop(DOME if "dome" == sky else CANOPY, [sky_mat])
+        # the canopy's z axis is "up": r0 = x, r1 = -z gives r2 = r0 x r1 = +y
+        engine.transformation(k, trafo((1, 0, 0), (0, 0, -1), (1, 1, 1), (0, 0, 0)))
+        engine.light(k)
+        ids["sky"] = k
     if extra_quad_light:
         lamp = engine.material(light_material(spectrum=(6.0, 6.0, 8.0)))
         q = engine.prop(RECTANGLE, [lamp])
