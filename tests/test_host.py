@@ -348,3 +348,27 @@ def test_images_and_color_maps(engine):
     engine.transformation(q, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 3)))
     with pytest.raises(RuntimeError):
         engine.compile()
+
+
+def test_metal_preset_is_a_metallic_substitute(engine):
+    """{"metal_preset": name} -> Substitute with metallic 1 and colour = fresnel.conductor(eta, k, 1) of the metal's optical
+    constants (material_provider.zig:277-280, fresnel.zig:45-57); unknown names take eta 1.5, k 1."""
+    engine.camera(8, 8)
+    gold = engine.material(json.dumps({"rendering": {"Substitute": {"metal_preset": "Gold", "roughness": 0.2}}}))
+    other = engine.material(json.dumps({"rendering": {"Substitute": {"metal_preset": "Unobtainium"}}}))
+    p = engine.prop(scenes.RECTANGLE, [gold])
+    engine.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 2)))
+    sd, _ = engine.compile()
+
+    def conductor(eta, k):
+        eta, k = np.float32(eta), np.float32(k)
+        f = eta * eta + k * k
+        a = np.float32(2.0) * eta
+        one = np.float32(1.0)
+        return np.float32(0.5) * ((f - a + one) / (f + a + one) + (f - a + one) / (f + a + one))
+
+    g = sd.materials[gold]
+    assert g.metallic == 1.0 and abs(g.roughness - 0.2) < 1e-7
+    np.testing.assert_allclose(list(g.color_a)[:3], conductor([0.18267, 0.49447, 1.3761], [3.1178, 2.3515, 1.8324]), rtol=2e-6)
+    assert g.color_a[0] > g.color_a[1] > g.color_a[2]  # gold reflects red most
+    np.testing.assert_allclose(list(sd.materials[other].color_a)[:3], conductor([1.5] * 3, [1.0] * 3), rtol=2e-6)

@@ -153,6 +153,31 @@ Engine::Engine() {
     setFilter(2.f, 0);  // take.zig:59-64: Opaque + Mitchell(1/3, 1/3), radius 2
 }
 
+// measured optical constants (eta, k) at RGB of the named metals, and fresnel.conductor at wo.h = 1
+static Vec4f conductorColor(const std::string& name) {
+    struct Preset { const char* name; float eta[3], k[3]; };
+    static const Preset presets[] = {
+        {"Aluminium", {1.50694f, 0.926041f, 0.68251f}, {7.6307f, 6.3849f, 5.6230f}},
+        {"Gold", {0.18267f, 0.49447f, 1.3761f}, {3.1178f, 2.3515f, 1.8324f}},
+        {"Silver", {0.13708f, 0.12945f, 0.14075f}, {4.0625f, 3.1692f, 2.6034f}},
+        {"Iron", {2.9038f, 2.8857f, 2.6420f}, {3.0798f, 2.9157f, 2.8025f}},
+    };
+    Vec4f eta = splat(1.5f), k = splat(1.f);
+    for (const Preset& p : presets)
+        if (name == p.name) {
+            eta = vec(p.eta[0], p.eta[1], p.eta[2], 0.f);
+            k = vec(p.k[0], p.k[1], p.k[2], 0.f);
+        }
+    const float wo_dot_h = 1.f;
+    const Vec4f tmp_f = eta * eta + k * k;
+    const Vec4f wo_dot_h2 = splat(wo_dot_h * wo_dot_h);
+    const Vec4f tmp = wo_dot_h2 * tmp_f;
+    const Vec4f a = splat(2.f * wo_dot_h) * eta;
+    const Vec4f r_p = (tmp - a + splat(1.f)) / (tmp + a + splat(1.f));
+    const Vec4f r_o = (tmp_f - a + wo_dot_h2) / (tmp_f + a + wo_dot_h2);
+    return splat(0.5f) * (r_p + r_o);
+}
+
 // material_provider.zig:131-162, 262-342, 411-436 (uniform values only; image textures are SURVEY §8(f))
 void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) {
     std::memset(&m, 0, sizeof(m));
@@ -223,6 +248,12 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
                     m.roughness = x.f32(m.roughness);
                 } else if (k == "metallic") {
                     m.metallic = x.f32(m.metallic);
+                } else if (k == "metal_preset") {
+                    // material_provider.zig:277-280: a conductor is Substitute with metallic = 1 and the normal-incidence
+                    // Fresnel reflectance of the metal's (eta, k) as colour (fresnel.zig:45-57, metal_presets.zig:6-39)
+                    const Vec4f f = conductorColor(JsonValue::String == x.type ? x.str : std::string());
+                    for (int i = 0; i < 3; ++i) m.color_a[i] = f[i];
+                    m.metallic = 1.f;
                 } else if (k == "specular") {
                     m.specular = x.f32(m.specular);
                 } else if (k == "ior") {
