@@ -120,7 +120,9 @@ enum ZygpuMaterialFlags {
 
 /* Uniform-texture subset of the reference materials (all colours ACES AP1, base/json.zig:247-277).
  * Debug: color_a/color_b = front/back albedo (debug_material.zig:11-12);
- * Substitute: color_a = color, see substitute_material.zig:32-60; emittance: light/emittance.zig:18-27 */
+ * Substitute: color_a = color, see substitute_material.zig:32-60; emittance: light/emittance.zig:18-27;
+ * Glass: thick, perfectly specular dielectric (roughness 0, thickness 0, abbe 0; anything else is refused by
+ * zygpu_upload_scene): glass_material.zig:46-115, glass_sample.zig:165-292 */
 typedef struct ZygpuMaterial {
     uint32_t kind;
     uint32_t flags;
@@ -139,6 +141,12 @@ typedef struct ZygpuMaterial {
     uint32_t color_image;   /* Substitute colour map: index into ZygpuSceneDesc.images, ZYGPU_NULL = the uniform color_a */
     uint32_t color_sampler; /* ZYGPU_TEX_* bits (texture/sampler_mode.zig:7-68) */
     float    color_scale[2];/* texture.data.image.scale */
+    /* Glass (glass_material.zig:19-47): the absorption coefficient ccoef.attenuationCoefficient(attenuation_color,
+     * attenuation_distance) (collision_coefficients.zig:35-44); ior / roughness / specular above */
+    float    absorption[3];
+    float    thickness;
+    float    abbe;
+    int32_t  priority;      /* material_base.zig:27: nested dielectrics, the higher priority wins (sample_base.zig:44) */
 } ZygpuMaterial;
 
 enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u };

@@ -12,6 +12,9 @@
 //   ggx Iso/Aniso, dspbrMicroEc material/ggx.zig:30-46, 60-130, 228-449
 //   fresnel.Schlick             material/fresnel.zig:5-29
 //   LUT evaluation              base/math/interpolated_function.zig:105-271, base/math/math.zig:172-191
+//   Glass (thick, specular)     material/glass/glass_material.zig:46-80, glass_sample.zig:33-66 (init), 68-80 (evaluate: empty),
+//                               165-254 (specularSample), 425-435 (reflect), 519-537 (thickSpecularRefract);
+//                               fresnel.dielectric material/fresnel.zig:31-43
 #pragma once
 
 #include "sampler.hpp"
@@ -28,6 +31,8 @@ struct PathInfo {  // bxdf.zig:34-70
     PathEvent  event;
     bool       singular() const { return 0.f == reg_alpha; }
     static PathInfo diffuseReflection() { return {1.f, Scattering::Diffuse, PathEvent::Reflection}; }
+    static PathInfo singularReflection() { return {0.f, Scattering::Specular, PathEvent::Reflection}; }
+    static PathInfo singularTransmission() { return {0.f, Scattering::Specular, PathEvent::Transmission}; }
     static PathInfo reflection(float alpha, float specular_threshold) {
         return {alpha, alpha <= specular_threshold ? Scattering::Specular : Scattering::Glossy, PathEvent::Reflection};
     }
@@ -50,6 +55,7 @@ struct Renderstate {  // renderstate.zig:10-45 (subset in scope)
     float    stochastic_r, ior;
     uint32_t prop, part;
     bool     caustics;
+    int32_t  highest_priority = -128;  // mediums.highestPriority() (prop/medium.zig:75-83)
 };
 
 struct Luts {
@@ -103,6 +109,13 @@ inline V4    schlick(V4 f0, float wo_dot_h) { return fma4(S(pow5(1.f - wo_dot_h)
 inline float iorToF0(float n0, float n1) {
     const float t = (n0 - n1) / (n0 + n1);
     return t * t;
+}
+inline float dielectric(float cos_theta_i, float cos_theta_t, float eta_i, float eta_t) {  // fresnel.zig:31-43
+    const float t0 = eta_t * cos_theta_i, t1 = eta_i * cos_theta_t;
+    const float r_p = (t0 - t1) / (t0 + t1);
+    const float t2 = eta_i * cos_theta_i, t3 = eta_t * cos_theta_t;
+    const float r_o = (t2 - t3) / (t2 + t3);
+    return 0.5f * (r_p * r_p + r_o * r_o);
 }
 }  // namespace fresnel
 
@@ -254,6 +267,10 @@ struct MaterialSample {
     V4    f0;
     float metallic, specular, specular_threshold, opacity;
     Luts  luts;
+    // Glass
+    V4    absorption;
+    float ior, ior_outside;
+    bool  lower_priority;
 
     bool sameHemisphere(V4 v) const { return dot3(geo_n, v) > 0.f; }
 
@@ -309,7 +326,7 @@ struct MaterialSample {
 
     // ---- dispatch: material_sample.zig:47-60 ----
     BxdfResult evaluate(V4 wi, bool force_disable_caustics) const {
-        if (ZYGPU_MAT_LIGHT == kind) return {S(0.f), 0.f};
+        if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return {S(0.f), 0.f};  // glass_sample.zig:72-78: not rough
         if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:19-26
             const float n_dot_wi = frame.clampNdot(wi);
             const float pdf = n_dot_wi * kPiInv;
@@ -322,8 +339,66 @@ struct MaterialSample {
         return baseEvaluate(wi, wo, h, wo_dot_h, force_disable_caustics);
     }
 
+    // Glass.specularSample, thick (glass_sample.zig:165-254); `split`: both the reflected and the refracted direction,
+    // weighted by the Fresnel term, instead of a choice between them
+    uint32_t glassSample(Sampler& sampler, bool split, BxdfSample out[2]) const {
+        float eta_i = ior_outside, eta_t = ior;
+        auto  fill = [&](BxdfSample& r, V4 wi, V4 reflection, float split_weight, PathInfo path) {
+            r.reflection = reflection;
+            r.wi = wi;
+            r.pdf = 1.f;
+            r.split_weight = split_weight;
+            r.wavelength = 0.f;
+            r.path = path;
+        };
+        if (eta_i == eta_t || lower_priority) {
+            fill(out[0], -wo, S(1.f), 1.f, PathInfo::singularTransmission());
+            return 1;
+        }
+        V4 nn = frame.z;
+        if (!sameHemisphere(wo)) {
+            nn = -nn;
+            std::swap(eta_i, eta_t);
+        }
+        const float n_dot_wo = mn(std::fabs(dot3(nn, wo)), 1.f);
+        const float eta = eta_i / eta_t;
+        const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
+        float       n_dot_t, f;
+        if (sint2 >= 1.f) {
+            n_dot_t = 0.f;
+            f = 1.f;
+        } else {
+            n_dot_t = std::sqrt(1.f - sint2);
+            f = fresnel::dielectric(n_dot_wo, n_dot_t, eta_i, eta_t);
+        }
+        const V4 reflected = normalize3(S(2.f * n_dot_wo) * nn - wo);                       // reflect, 425-435
+        const V4 refracted = normalize3(S(eta * n_dot_wo - n_dot_t) * nn - S(eta) * wo);  // thickSpecularRefract, 519-537
+        if (split) {
+            fill(out[0], reflected, S(specular) * S(1.f), f, PathInfo::singularReflection());
+            if (1.f == f) return 1;
+            fill(out[1], refracted, S(1.f), 1.f - f, PathInfo::singularTransmission());
+            return 2;
+        }
+        const float p = sampler.sample1D();
+        if (p <= f) fill(out[0], reflected, S(specular) * S(1.f), 1.f, PathInfo::singularReflection());
+        else fill(out[0], refracted, S(1.f), 1.f, PathInfo::singularTransmission());
+        return 1;
+    }
+
+    // MaterialSample.sample with the integrator's split budget (pathtracer_mis.zig:123-124): up to two samples
+    uint32_t sampleSplit(Sampler& sampler, uint32_t max_splits, BxdfSample out[2]) const {
+        if (ZYGPU_MAT_GLASS == kind) return glassSample(sampler, max_splits > 1, out);
+        return sample(sampler, out[0]);
+    }
+
     // returns number of samples (0 or 1)
     uint32_t sample(Sampler& sampler, BxdfSample& result) const {
+        if (ZYGPU_MAT_GLASS == kind) {
+            BxdfSample two[2];
+            const uint32_t n = glassSample(sampler, false, two);
+            result = two[0];
+            return n;
+        }
         if (ZYGPU_MAT_LIGHT == kind) return 0;
         if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:28-47
             float s2d[2];
@@ -427,6 +502,16 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.frame = {rs.t, rs.b, rs.n};  // light_sample.zig:9-11
         s.alpha[0] = s.alpha[1] = 0.f;
         s.can_evaluate = false;
+    } else if (ZYGPU_MAT_GLASS == m.kind) {
+        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66) with roughness 0: alpha 0, f0 0
+        s.frame = {rs.t, rs.b, rs.n};
+        s.alpha[0] = s.alpha[1] = 0.f;
+        s.can_evaluate = false;  // rough and ...
+        s.absorption = ld3(m.absorption);
+        s.ior = m.ior;
+        s.ior_outside = rs.ior;
+        s.specular = m.specular;
+        s.lower_priority = m.priority < rs.highest_priority;  // sample_base.zig:44
     } else {
         // substitute_material.zig:114-221 (uniform values, no coating / flakes / normal map / rotation)
         const V4    color = kNull != m.color_image ? sampleColorMap(scene, m, rs.uvw[0], rs.uvw[1], rs.stochastic_r) : ld3(m.color_a);

@@ -97,6 +97,38 @@ struct VState {
     }
 };
 
+// prop/medium.zig:30-153: the dielectrics the path is inside of.  ior, priority and the absorption coefficient of an
+// entry are those of its material (vertex.zig:96-108 pushes material.ior(), priority and the sample's cc, which for
+// Glass is the material's coefficient), so an entry is the (prop, part) pair
+struct MediumStack {
+    static constexpr uint32_t kNumEntries = 4;
+    uint32_t index = 0;
+    uint32_t prop[kNumEntries], part[kNumEntries];
+
+    bool empty() const { return 0 == index; }
+    bool matches(uint32_t i, const Fragment& frag) const { return prop[i] == frag.prop && part[i] == frag.part; }
+    void push(const Fragment& frag) {
+        if (index < kNumEntries - 1) {
+            prop[index] = frag.prop;
+            part[index] = frag.part;
+            index += 1;
+        }
+    }
+    void remove(const Fragment& frag) {
+        const int32_t back = int32_t(index) - 1;
+        for (int32_t i = back; i >= 0; --i) {
+            if (matches(uint32_t(i), frag)) {
+                for (int32_t j = i; j < back; ++j) {
+                    prop[j] = prop[j + 1];
+                    part[j] = part[j + 1];
+                }
+                index -= 1;
+                return;
+            }
+        }
+    }
+};
+
 struct Vertex {
     Ray      ray;
     uint32_t depth_surface = 0;  // probe.depth (volume depth is always 0 in scope)
@@ -104,7 +136,10 @@ struct Vertex {
     VState   state;
     uint32_t depth = 0;  // Vertex.depth: probe.depth at the last scattering vertex
     float    bxdf_pdf = 0.f, light_split_threshold = 0.f;
+    float    split_weight = 1.f;
+    uint32_t path_count = 1;
     V4       throughput = S(1.f), origin, geo_n = S(0.f);
+    MediumStack mediums;
 };
 
 struct RenderCtx {
@@ -252,6 +287,60 @@ struct Worker {
         return energy;
     }
 
+    // ---- the medium stack's views of the scene (prop/medium.zig:55-116)
+    const ZygpuMaterial& mediumMaterial(const MediumStack& m, uint32_t i) const { return rc->sv.propMaterial(m.prop[i], m.part[i]); }
+    float mediumIor(const MediumStack& m, uint32_t i) const {  // material.zig:140-146
+        const ZygpuMaterial& mat = mediumMaterial(m, i);
+        return (ZYGPU_MAT_GLASS == mat.kind || ZYGPU_MAT_SUBSTITUTE == mat.kind) ? mat.ior : 1.f;
+    }
+    float topIor(const MediumStack& m) const { return m.index > 0 ? mediumIor(m, m.index - 1) : 1.f; }
+    float peekIor(const MediumStack& m, const Fragment& frag) const {
+        if (m.index <= 1) return 1.f;
+        const uint32_t back = m.index - 1;
+        return m.matches(back, frag) ? mediumIor(m, back - 1) : mediumIor(m, back);
+    }
+    int32_t highestPriority(const MediumStack& m) const {
+        int32_t priority = -128;
+        for (uint32_t i = 0; i < m.index; ++i) priority = std::max(priority, mediumMaterial(m, i).priority);
+        return priority;
+    }
+    V4 topAbsorption(const MediumStack& m) const {  // topCC: the last entry of the highest priority
+        int32_t  priority = -128;
+        uint32_t highest = 0;
+        for (uint32_t i = 0; i < m.index; ++i) {
+            const int32_t lp = mediumMaterial(m, i).priority;
+            if (lp >= priority) {
+                priority = lp;
+                highest = i;
+            }
+        }
+        return ld3(mediumMaterial(m, highest).absorption);
+    }
+
+    // Context.nextEvent (context.zig:54-69); inside a dielectric: VolumeIntegrator.integrate's branch for materials that do
+    // not scatter (volume_integrator.zig:84-129, 62-65): the ray ends at the far side of the medium's bounding box, and
+    // the segment to the hit attenuates the throughput by Beer-Lambert
+    void nextEvent(Vertex& vertex, Fragment& frag) {
+        cnt.extension_rays += 1;
+        if (vertex.mediums.empty()) {
+            rc->sv.intersect(vertex.ray, vertex.depth_surface, frag, cnt);
+            return;
+        }
+        const uint32_t medium_prop = vertex.mediums.prop[vertex.mediums.index - 1];
+        const float    ray_max_t = vertex.ray.max_t;
+        const float    limit = aabbIntersectP(rc->scene->aabbs[medium_prop], vertex.ray);
+        vertex.ray.max_t = mn(offsetF(limit), ray_max_t);
+        if (!rc->sv.intersect(vertex.ray, vertex.depth_surface, frag, cnt)) return;
+        const float d = vertex.ray.max_t;
+        vertex.throughput *= attenuation3(topAbsorption(vertex.mediums), d - vertex.ray.min_t);
+    }
+
+    // Vertex.interfaceChange (vertex.zig:94-108)
+    void interfaceChange(Vertex& vertex, V4 dir, const Fragment& frag) const {
+        if (frag.sameHemisphere(dir)) vertex.mediums.remove(frag);
+        else vertex.mediums.push(frag);
+    }
+
     // vertex.zig:137-181
     MaterialSample vertexSample(const Vertex& v, const Fragment& frag, Sampler& sampler, bool caustics) const {
         const V4             wo = -v.ray.direction;
@@ -271,10 +360,11 @@ struct Worker {
         rs.origin = v.origin;
         rs.uvw = frag.uvw;
         rs.stochastic_r = sampler.sample1D();
-        rs.ior = 1.f;  // empty medium stack: topIor / peekIor = 1 (prop/medium.zig)
+        rs.ior = frag.sameHemisphere(wo) ? topIor(v.mediums) : peekIor(v.mediums, frag);  // iorOutside, vertex.zig:87-92
         rs.prop = frag.prop;
         rs.part = frag.part;
         rs.caustics = caustics;
+        rs.highest_priority = highestPriority(v.mediums);
         return materialSample(m, *rc->scene, wo, rs);
     }
 
@@ -410,20 +500,128 @@ struct Worker {
         return result;
     }
 
+    // Vertex.Pool (vertex.zig:214-310): the vertices of one camera sample, level by level; a level's vertices are consumed
+    // in order and share the worker's samplers
+    struct VertexPool {
+        static constexpr uint32_t kNumVertices = 4;
+        V4       transparency = S(0.f);
+        Vertex   buffer[2 * kNumVertices];
+        uint32_t terminated = 0, current_id = kNumVertices, current_start = kNumVertices, current_end = kNumVertices, next_start = 0,
+                 next_end = 1;
+
+        explicit VertexPool(const Vertex& v) { buffer[0] = v; }
+        Vertex* iterate(uint32_t id) {
+            terminated |= 1u << (id & 31u);
+            current_id = id + 1;
+            return &buffer[id];
+        }
+        Vertex* consume() {
+            const uint32_t old_end = current_end;
+            if (current_id < old_end) return iterate(current_id);
+            for (uint32_t i = current_start; i < old_end; ++i) {
+                if (0 == (terminated & (1u << (i & 31u)))) continue;
+                const Vertex& v = buffer[i];
+                if (v.state.transparent) {
+                    transparency[3] += mx((1.f - average3(v.throughput)) * v.split_weight, 0.f);
+                } else {  // no shadow catchers: shadow_catcher_emission = 0
+                    const float alpha = transparency[3];
+                    transparency += S(0.f) * S(v.split_weight);
+                    transparency[3] = alpha + v.split_weight;
+                }
+            }
+            current_id = current_start = next_start;
+            current_end = next_end;
+            next_start = next_end = (kNumVertices == current_start) ? 0 : kNumVertices;
+            if (current_start < current_end) return iterate(current_start);
+            return nullptr;
+        }
+        Vertex* newVertex() {
+            terminated &= ~(1u << ((current_id - 1) & 31u));
+            return &buffer[next_end++];
+        }
+        static uint32_t maxSplits(const Vertex& v, uint32_t depth) {
+            const uint32_t m = kNumVertices / v.path_count;
+            return m - (v.state.primary_ray ? 0u : std::min(depth, m - 1));
+        }
+    };
+
+    // PathtracerMIS.li (pathtracer_mis.zig:37-172)
+    IValue liMis(const Vertex& input) {
+        const ZygpuViewDesc& view = *rc->view;
+        IValue               result;
+        VertexPool           vertices(input);
+        while (Vertex* vp = vertices.consume()) {
+            Vertex&        vertex = *vp;
+            const uint32_t total_depth = vertex.depth_surface;
+            Sampler&       sampler = pickSampler(total_depth);
+
+            Fragment frag;
+            nextEvent(vertex, frag);
+
+            const V4 energy = connectLight(vertex, frag, sampler);
+            const V4 split_weight = S(vertex.split_weight);
+            V4       split_throughput = vertex.throughput * split_weight;
+            result.add(split_throughput * energy, total_depth, 2, 0 == total_depth, vertex.state.singular);
+
+            if (!frag.hit() || vertex.depth_surface >= view.max_depth_surface || 0 >= view.max_depth_volume) {
+                if (vertex.state.transparent) vertex.throughput *= S(1.f) - min4(energy, S(1.f));
+                continue;
+            }
+            if (russianRoulette(vertex.throughput, sampler.sample1D())) continue;
+
+            const bool           caustics = causticsResolve(vertex.state);
+            const MaterialSample ms = vertexSample(vertex, frag, sampler, caustics);
+            split_throughput = vertex.throughput * split_weight;
+
+            vertex.light_split_threshold = splitThreshold(view.split_threshold, vertex.depth_surface);
+            const uint32_t max_splits = VertexPool::maxSplits(vertex, total_depth);
+            const V4       lighting = sampleLights(vertex, frag, ms, sampler, true);
+            result.add(split_throughput * lighting, total_depth, 1, false, false);
+
+            BxdfSample     samples[2];
+            const uint32_t path_count = ms.sampleSplit(sampler, max_splits, samples);
+            if (0 == path_count) vertex.throughput = S(0.f);
+            for (uint32_t i = 0; i < path_count; ++i) {
+                const BxdfSample& bs = samples[i];
+                Vertex&           next = *vertices.newVertex();
+                next = vertex;
+                next.path_count = vertex.path_count * path_count;
+                next.split_weight = vertex.split_weight * bs.split_weight;
+                next.state.update(bs.path);
+                if (PathEvent::Straight != bs.path.event) {
+                    next.state.translucent = ms.translucent;
+                    next.depth = next.depth_surface;
+                    next.bxdf_pdf = bs.pdf;
+                    next.origin = frag.p;
+                    next.geo_n = ms.geo_n;
+                }
+                next.throughput *= bs.reflection / S(bs.pdf);
+                next.ray = fragOffsetRay(frag, bs.wi);
+                next.depth_surface += 1;
+                if (PathEvent::Transmission == bs.path.event) interfaceChange(next, bs.wi, frag);
+                next.state.transparent =
+                    next.state.transparent && (PathEvent::Transmission == bs.path.event || PathEvent::Straight == bs.path.event);
+            }
+            sampler.incrementPadding();
+        }
+        result.direct[3] = 0.f;
+        result.direct += vertices.transparency;
+        return result;
+    }
+
     IValue li(Vertex vertex) {
         const ZygpuViewDesc& view = *rc->view;
         const uint32_t       kind = view.integrator;
         const bool           mis = ZYGPU_INTEGRATOR_PTMIS == kind;
-        IValue               result;
+        if (mis) return liMis(vertex);
+        IValue result;
 
         for (;;) {
             const uint32_t total_depth = vertex.depth_surface;
             Sampler&       sampler = pickSampler(total_depth);
 
-            // Context.nextEvent (context.zig:54-69), no media
             Fragment frag;
-            cnt.extension_rays += 1;
-            rc->sv.intersect(vertex.ray, vertex.depth_surface, frag, cnt);
+            nextEvent(vertex, frag);
 
             const V4 energy = connectLight(vertex, frag, sampler);
             result.add(vertex.throughput * energy, total_depth, mis ? 2 : 1, 0 == total_depth, vertex.state.singular);
@@ -464,6 +662,7 @@ struct Worker {
             vertex.throughput *= bs.reflection / S(bs.pdf);
             vertex.ray = fragOffsetRay(frag, bs.wi);
             vertex.depth_surface += 1;
+            if (PathEvent::Transmission == bs.path.event) interfaceChange(vertex, bs.wi, frag);
             vertex.state.transparent =
                 vertex.state.transparent && (PathEvent::Transmission == bs.path.event || PathEvent::Straight == bs.path.event);
 
@@ -890,6 +1089,10 @@ void zyg_oracle_trig(uint32_t n, const float* x, float* out_sin, float* out_cos,
 
 void zyg_oracle_atan2(uint32_t n, const float* y, const float* x, float* out) {
     for (uint32_t i = 0; i < n; ++i) out[i] = atan2F(y[i], x[i]);
+}
+
+void zyg_oracle_exp(uint32_t n, const float* x, float* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = expF(x[i]);
 }
 
 void zyg_oracle_offset_ray(const float* p, const float* n, float* out) {

@@ -154,6 +154,37 @@ inline bool aabbIntersect(const ZygpuAabb& a, const Ray& ray) {
     return tboxmin <= tboxmax;
 }
 
+// AABB.intersectP (base/math/aabb.zig:62-83): the entry distance, or the exit distance when the origin is inside
+inline float aabbIntersectP(const ZygpuAabb& a, const Ray& ray) {
+    const V4    lower = (ld4(a.min) - ray.origin) * ray.inv_direction;
+    const V4    upper = (ld4(a.max) - ray.origin) * ray.inv_direction;
+    const V4    t0 = min4(lower, upper), t1 = max4(lower, upper);
+    const float imin = mx(mx(t0[0], t0[1]), t0[2]);
+    const float imax = mn(mn(t1[0], t1[1]), t1[2]);
+    const float tboxmin = mx(imin, ray.min_t);
+    const float tboxmax = mn(imax, ray.max_t);
+    if (tboxmin <= tboxmax) return imin < ray.min_t ? imax : imin;
+    return FLT_MAX;
+}
+
+// ray_offset.zig:29-31
+inline float offsetF(float t) {
+    const float origin = 1.f / 32.f, float_scale = 1.f / 65536.f, int_scale = 256.f;
+    if (t < origin) return t + float_scale;
+    int32_t bits;
+    std::memcpy(&bits, &t, 4);
+    bits = int32_t(uint32_t(bits) + uint32_t(int32_t(int_scale)));
+    float r;
+    std::memcpy(&r, &bits, 4);
+    return r;
+}
+
+// collision_coefficients.zig:67-69
+inline V4 attenuation3(V4 c, float distance) {
+    const V4 x = S(-distance) * c;
+    return mk(expF(x[0]), expF(x[1]), expF(x[2]), 1.f);
+}
+
 // triangle.zig:26-52; returns hit flag
 inline bool triangleIntersect(const Ray& ray, V4 a, V4 b, V4 c, float& ht, float& hu, float& hv) {
     const V4    e1 = b - a, e2 = c - a;

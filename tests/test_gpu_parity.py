@@ -318,3 +318,44 @@ def test_spheres(engine, oracle, integrator, unoccluding, samples):
     out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, spheres=True, sphere_lights=True,
                        unoccluding_lights=unoccluding, light_samples=samples, boxes=False)
     _check(*out, 3)
+
+
+GLASS_BOX = scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3)
+
+
+@pytest.mark.parametrize("integrator,objects", [
+    ("PT", {"box": GLASS_BOX, "sphere": scenes.glass(1.5)}),
+    ("PTDL", {"box": GLASS_BOX, "sphere": scenes.glass(1.5)}),
+    ("PTMIS", {"box": GLASS_BOX, "sphere": scenes.glass(1.5)}),
+    ("PTMIS", {"sphere": scenes.glass(1.5, (0.9, 0.6, 0.5), 0.2), "inner": scenes.glass(1.33, (0.5, 0.7, 0.95), 0.1, priority=1)}),
+    ("PTMIS", {"sphere": scenes.glass(1.5, priority=2), "inner": scenes.glass(1.33, (0.5, 0.7, 0.95), 0.1, priority=1)}),
+    ("PTMIS", {"box": scenes.glass(1.0), "sphere": scenes.glass(1.8, (0.8, 0.8, 0.3), 0.5)}),
+])
+def test_glass(engine, oracle, integrator, objects):
+    """Thick specular Glass (glass_sample.zig:165-254): Fresnel reflection / refraction, the medium stack with nested
+    dielectrics and priorities (prop/medium.zig), Beer-Lambert absorption between the interfaces
+    (volume_integrator.zig:62-65), and PathtracerMIS's path splitting with the shared samplers (vertex.zig:214-310)."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, glass_objects=objects, material="substitute")
+    _check(*out, 3)
+
+
+def test_glass_alpha(engine, oracle):
+    """Transparent sensor behind glass: the alpha of a split sample is the sum over its terminated vertices
+    (Pool.consume, vertex.zig:240-262)."""
+    w, h, spp = 96, 64, 3
+    scenes.cornell(engine, w, h, spp, alpha_transparency=True, camera_z=-7.5,
+                   glass_objects={"outside": scenes.glass(1.5, (0.7, 0.8, 0.9), 0.5), "sphere": scenes.glass(1.5)})
+    engine.start_frame(0)
+    engine.render_iterations(spp)
+    engine.synchronize()
+    film = engine.download_film(w, h)
+    alpha = np.zeros((h, w), dtype=np.float32)
+    g = engine.lib
+    g.zygpu_download_film_alpha.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert g.zygpu_download_film_alpha(engine.context(), alpha.ctypes.data) == 0
+    sd = g.su_ext_scene_desc().contents
+    vd = g.su_ext_view_desc().contents
+    cpu_film, cpu_alpha = oracle_render_alpha(oracle, sd, vd, spp)
+    assert np.array_equal(film, cpu_film) and np.array_equal(alpha, cpu_alpha)
+    resolved = alpha / film[..., 3]
+    assert np.any((resolved > 0.02) & (resolved < 0.98))  # partially transparent pixels: the sphere in front of the void

@@ -47,6 +47,23 @@ def test_trig_bit_exact(product_lib, oracle, ctx):
     assert np.all((g[:, 2].view(np.uint32) == a.view(np.uint32)) | both_nan)
 
 
+def test_exp_atan2_bit_exact(product_lib, oracle, ctx):
+    """Beer-Lambert attenuation inside glass (exp) and the spherical uv of Sphere fragments (atan2)."""
+    rng = np.random.default_rng(12)
+    n = 200000
+    inp = np.zeros((n, 2), np.float32)
+    inp[:, 0] = -rng.exponential(3.0, n)
+    inp[: n // 4, 0] = rng.uniform(-100, 2, n // 4)
+    inp[:6, 0] = [0.0, -0.0, -1e-5, -0.3, -0.4, -88.0]
+    inp[:, 1] = rng.uniform(-3, 3, n)
+    g = _eval(product_lib, ctx, 6, inp, 2)
+    e, a = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    oracle.zyg_oracle_exp(n, _vp(np.ascontiguousarray(inp[:, 0])), _vp(e))
+    oracle.zyg_oracle_atan2(n, _vp(np.ascontiguousarray(inp[:, 1])), _vp(np.ascontiguousarray(inp[:, 0])), _vp(a))
+    assert np.array_equal(g[:, 0].view(np.uint32), e.view(np.uint32))
+    assert np.array_equal(g[:, 1].view(np.uint32), a.view(np.uint32))
+
+
 def test_sphquad_bit_exact(product_lib, oracle, ctx):
     rng = np.random.default_rng(4)
     n = 100000

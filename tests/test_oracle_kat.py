@@ -117,6 +117,21 @@ def test_trig_accuracy(oracle):
     assert ulp(a, np.arccos(xa.astype(np.float64))) < 1.0
 
 
+def test_exp_accuracy(oracle):
+    """The restated expf (msun e_expf.c) stays under 1 ulp, and agrees with libm's correctly rounded result almost always."""
+    rng = np.random.default_rng(2)
+    x = np.concatenate([-rng.exponential(3.0, 150000), rng.uniform(-87, 5, 50000)]).astype(np.float32)
+    e = np.zeros_like(x)
+    oracle.zyg_oracle_exp(x.size, x.ctypes.data_as(ctypes.c_void_p), e.ctypes.data_as(ctypes.c_void_p))
+    ref = np.exp(x.astype(np.float64))
+    err = np.abs(e.astype(np.float64) - ref) / np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert err.max() < 1.0
+    assert np.mean(e == ref.astype(np.float32)) > 0.9
+    one = np.array([0.0, -0.0], dtype=np.float32)
+    oracle.zyg_oracle_exp(2, one.ctypes.data_as(ctypes.c_void_p), e.ctypes.data_as(ctypes.c_void_p))
+    assert e[0] == 1.0 and e[1] == 1.0
+
+
 def _quad_trafo(size, pos):
     t = zyg_amd.Trafo()
     rows = [(1, 0, 0, size[0]), (0, 1, 0, size[1]), (0, 0, 1, 1.0)]
@@ -330,3 +345,28 @@ def test_sphere_lights_integrators_agree(product_lib, oracle):
             means[integ] = img[..., :3].mean(axis=(0, 1))
     np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.01)
     np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)
+
+
+def test_glass_integrators_agree(product_lib, oracle):
+    """Glass: PT and PTDL (one random choice between reflection and refraction) and PTMIS (both, as split paths weighted
+    by the Fresnel term) estimate the same image; a dielectric with the ior of its surroundings is invisible."""
+    w, h, spp = 40, 30, 256
+    objs = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)}
+    means = {}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator=integ, glass_objects=objs, max_depth=12)
+            sd, vd = e.compile()
+            img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(img).all()
+            means[integ] = img[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.015)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)
+    plain = {}
+    for key, objs in (("none", None), ("ghost", {"sphere": scenes.glass(1.0), "inner": scenes.glass(1.0)})):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator="PTMIS", glass_objects=objs, max_depth=12)
+            sd, vd = e.compile()
+            plain[key] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(plain["ghost"], plain["none"], rtol=0.01)
+    assert abs(means["PTMIS"][0] - plain["none"][0]) > 0.005  # real glass does change the picture

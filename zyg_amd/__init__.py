@@ -50,7 +50,9 @@ class Material(ctypes.Structure):
                 ("specular", ctypes.c_float), ("ior", ctypes.c_float), ("anisotropy", ctypes.c_float),
                 ("emission", ctypes.c_float * 3), ("cos_a", ctypes.c_float), ("camera_weight", ctypes.c_float),
                 ("emission_normalize", ctypes.c_uint32), ("emission_num_samples", ctypes.c_uint32),
-                ("color_image", ctypes.c_uint32), ("color_sampler", ctypes.c_uint32), ("color_scale", ctypes.c_float * 2)]
+                ("color_image", ctypes.c_uint32), ("color_sampler", ctypes.c_uint32), ("color_scale", ctypes.c_float * 2),
+                ("absorption", ctypes.c_float * 3), ("thickness", ctypes.c_float), ("abbe", ctypes.c_float),
+                ("priority", ctypes.c_int32)]
 
 
 class Image(ctypes.Structure):

@@ -21,8 +21,19 @@ struct BxdfSample {
     f3       reflection, wi;
     float    pdf;
     float    reg_alpha;   // bxdf.zig Path.reg_alpha
-    uint32_t scattering;  // all samples in scope are reflections
+    uint32_t scattering;
+    // set by Glass only (every other sample in scope is a reflection with split weight 1)
+    bool     transmission;
+    float    split_weight;
 };
+
+ZD float fresnelDielectric(float cos_theta_i, float cos_theta_t, float eta_i, float eta_t) {  // fresnel.zig:31-43
+    const float t0 = eta_t * cos_theta_i, t1 = eta_i * cos_theta_t;
+    const float r_p = (t0 - t1) / (t0 + t1);
+    const float t2 = eta_i * cos_theta_i, t3 = eta_t * cos_theta_t;
+    const float r_o = (t2 - t3) / (t2 + t3);
+    return 0.5f * (r_p * r_p + r_o * r_o);
+}
 
 struct Luts {
     const DScene& s;
@@ -173,8 +184,59 @@ struct MaterialSample {
     f3       albedo;
     f3       f0;
     float    metallic, specular, specular_threshold, opacity;
+    float    ior, ior_outside;  // Glass
+    bool     lower_priority;
 
     ZD bool sameHemisphere(f3 v) const { return dot3(geo_n, v) > 0.f; }
+
+    // Glass.specularSample, thick (glass_sample.zig:165-254, reflect 425-435, thickSpecularRefract 519-537); `split`: both
+    // directions, weighted by the Fresnel term, instead of a choice between them.  Returns the number of samples.
+    ZD uint32_t glassSample(Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
+        float eta_i = ior_outside, eta_t = ior;
+        auto  fill = [&](BxdfSample& r, f3 wi, f3 reflection, float split_weight, bool transmission) {
+            r.reflection = reflection;
+            r.wi = wi;
+            r.pdf = 1.f;
+            r.reg_alpha = 0.f;
+            r.scattering = kScatterSpecular;
+            r.transmission = transmission;
+            r.split_weight = split_weight;
+        };
+        if (eta_i == eta_t || lower_priority) {
+            fill(r0, -wo, S3(1.f), 1.f, true);
+            return 1;
+        }
+        f3 nn = frame.z;
+        if (!sameHemisphere(wo)) {
+            nn = -nn;
+            const float e = eta_i;
+            eta_i = eta_t;
+            eta_t = e;
+        }
+        const float n_dot_wo = mn(fabsf(dot3(nn, wo)), 1.f);
+        const float eta = eta_i / eta_t;
+        const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
+        float       n_dot_t, f;
+        if (sint2 >= 1.f) {
+            n_dot_t = 0.f;
+            f = 1.f;
+        } else {
+            n_dot_t = sqrtf(1.f - sint2);
+            f = fresnelDielectric(n_dot_wo, n_dot_t, eta_i, eta_t);
+        }
+        const f3 reflected = normalize3(S3(2.f * n_dot_wo) * nn - wo);
+        const f3 refracted = normalize3(S3(eta * n_dot_wo - n_dot_t) * nn - S3(eta) * wo);
+        if (split) {
+            fill(r0, reflected, S3(specular) * S3(1.f), f, false);
+            if (1.f == f) return 1;
+            fill(r1, refracted, S3(1.f), 1.f - f, true);
+            return 2;
+        }
+        const float p = sampler.sample1D();
+        if (p <= f) fill(r0, reflected, S3(specular) * S3(1.f), 1.f, false);
+        else fill(r0, refracted, S3(1.f), 1.f, true);
+        return 1;
+    }
 
     ZD float diffuseWeight(const Luts& L) const {  // diffuse.zig:50-73 estimateContribution
         const float e_avg = L.E_avg(a1, hmax3(f0));
@@ -207,7 +269,7 @@ struct MaterialSample {
     // SUBST = false compiles the Substitute branch out (kernels specialised for scenes without that material)
     template <bool SUBST = true>
     ZD BxdfResult evaluate(const DScene& s, f3 wi) const {  // material_sample.zig:47-53
-        if (ZYGPU_MAT_LIGHT == kind) return {S3(0.f), 0.f};
+        if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return {S3(0.f), 0.f};  // glass_sample.zig:72-78: not rough
         if (ZYGPU_MAT_DEBUG == kind) {
             const float n_dot_wi = frame.clampNdot(wi);
             const float pdf = n_dot_wi * kPiInv;
@@ -222,7 +284,9 @@ struct MaterialSample {
 
     template <bool SUBST = true>
     ZD bool sample(const DScene& s, Sampler& sampler, BxdfSample& result) const {  // material_sample.zig:55-70
-        if (ZYGPU_MAT_LIGHT == kind) return false;
+        result.transmission = false;
+        result.split_weight = 1.f;
+        if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return false;  // Glass: glassSample (pool kernels only)
         if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:28-47
             float u0, u1;
             sampler.sample2D(u0, u1);
@@ -325,8 +389,13 @@ ZD f3 sampleColorMap(const DScene& s, const ZygpuMaterial& m, float u, float v, 
 
 // Material.sample (material.zig:184-194) from a fragment; `two-sided flip` of vertex.zig:155-161 is done by the caller
 // `color`: the Substitute colour at the hit (uniform value or colour map sample)
-ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, bool caustics, f3 color) {
+// `ior_outside`: Vertex.iorOutside (vertex.zig:87-92), 1 outside every dielectric; `lower_priority`: sample_base.zig:44
+ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, bool caustics, f3 color,
+                                     float ior_outside = 1.f, bool lower_priority = false) {
     MaterialSample ms;
+    ms.ior = m.ior;
+    ms.ior_outside = ior_outside;
+    ms.lower_priority = lower_priority;
     ms.kind = m.kind;
     ms.geo_n = geo_n;
     ms.n = n;
@@ -346,9 +415,11 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         ms.albedo = same_side ? mk3(m.color_a[0], m.color_a[1], m.color_a[2]) : mk3(m.color_b[0], m.color_b[1], m.color_b[2]);
         ms.a0 = ms.a1 = 1.f;
         ms.can_evaluate = true;
-    } else if (ZYGPU_MAT_LIGHT == m.kind) {
+    } else if (ZYGPU_MAT_LIGHT == m.kind || ZYGPU_MAT_GLASS == m.kind) {
+        // Glass.sample / Sample.init with roughness 0 (glass_material.zig:49-79, glass_sample.zig:33-66): alpha 0, f0 0
         ms.a0 = ms.a1 = 0.f;
         ms.can_evaluate = false;
+        ms.specular = m.specular;
     } else {
         const float roughness = mx(m.roughness, kMinRoughness);
         if (m.anisotropy > 0.f) {
@@ -358,7 +429,7 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         } else {
             ms.a0 = ms.a1 = roughness * roughness;
         }
-        const float ior = m.ior, ior_outer = 1.f, ior_medium = 1.f;
+        const float ior = m.ior, ior_outer = ior_outside, ior_medium = ior_outside;
         ms.albedo = S3(1.f - m.metallic) * color;
         ms.can_evaluate = ior != ior_medium;
         const float t_ = (ior - ior_outer) / (ior + ior_outer);

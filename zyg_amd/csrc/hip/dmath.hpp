@@ -199,6 +199,41 @@ ZD float atan2F(float y, float x) {
     }
 }
 
+// expf with the msun e_expf.c algorithm (Zig's @exp on f32 lowers to compiler-rt's expf, a port of musl's older expf.c):
+// argument reduction by k*ln2 in two pieces, degree-2 rational kernel, scaling by 2^k
+ZD float expF(float x) {
+    const float    ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
+    const float    P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    uint32_t       hx = __float_as_uint(x);
+    const uint32_t sign = hx >> 31;
+    hx &= 0x7fffffffu;
+    if (hx >= 0x42aeac50u) {  // |x| >= 87.33655 or NaN
+        if (hx > 0x7f800000u) return x;
+        if (hx >= 0x42b17218u && !sign) return x * 0x1p127f;
+        if (sign && hx >= 0x42cff1b5u) return 0.f;
+    }
+    int   k;
+    float hi, lo;
+    if (hx > 0x3eb17218u) {  // |x| > 0.5 ln2
+        if (hx > 0x3f851592u) k = int(invln2 * x + (sign ? -0.5f : 0.5f));  // |x| > 1.5 ln2
+        else k = 1 - int(sign) - int(sign);
+        hi = x - float(k) * ln2hi;
+        lo = float(k) * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x39000000u) {  // |x| > 2^-14
+        k = 0;
+        hi = x;
+        lo = 0.f;
+    } else {
+        return 1.f + x;
+    }
+    const float xx = x * x;
+    const float c = x - xx * (P1 + xx * P2);
+    const float y = 1.f + (x * c / (2.f - c) - lo + hi);
+    if (0 == k) return y;
+    return ldexpf(y, k);
+}
+
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kPiInv = float(1.0 / 3.14159265358979323846);
 constexpr float kDotMin = 0.00001f;  // safe.zig:5
@@ -322,5 +357,9 @@ ZD float offsetRay1(float p, float n) {
     return fabsf(p) < origin ? mad : p_i;
 }
 ZD f3 offsetRay(f3 p, f3 n) { return {offsetRay1(p.x, n.x), offsetRay1(p.y, n.y), offsetRay1(p.z, n.z)}; }
+ZD float offsetF(float t) {  // ray_offset.zig:29-31
+    const float origin = 1.f / 32.f, float_scale = 1.f / 65536.f;
+    return t < origin ? t + float_scale : __uint_as_float(__float_as_uint(t) + 256u);
+}
 
 }  // namespace zd

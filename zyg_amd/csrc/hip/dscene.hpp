@@ -124,6 +124,19 @@ ZD bool aabbIntersect(float4 bmin, float4 bmax, const Ray& ray) {
     return FLT_MAX != nodeIntersect(bmin, bmax, ray);  // same arithmetic, boolean result (aabb.zig:46-60)
 }
 
+// AABB.intersectP (base/math/aabb.zig:62-83): the entry distance, or the exit distance when the origin is inside
+ZD float aabbIntersectP(float4 bmin, float4 bmax, const Ray& ray) {
+    const f3    lower = (mk3(bmin.x, bmin.y, bmin.z) - ray.origin) * ray.inv_direction;
+    const f3    upper = (mk3(bmax.x, bmax.y, bmax.z) - ray.origin) * ray.inv_direction;
+    const f3    t0 = min3v(lower, upper), t1 = max3v(lower, upper);
+    const float imin = mx(mx(t0.x, t0.y), t0.z);
+    const float imax = mn(mn(t1.x, t1.y), t1.z);
+    const float tboxmin = mx(imin, ray.min_t);
+    const float tboxmax = mn(imax, ray.max_t);
+    if (tboxmin <= tboxmax) return imin < ray.min_t ? imax : imin;
+    return FLT_MAX;
+}
+
 // triangle.zig:26-52
 ZD bool triangleIntersect(const Ray& ray, f3 a, f3 b, f3 c, float& ht, float& hu, float& hv) {
     const f3    e1 = b - a, e2 = c - a;

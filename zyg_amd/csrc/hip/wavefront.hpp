@@ -10,6 +10,12 @@
 //   wf_extend    : last pick's tail, bxdf sample, path state update, next extension ray (pathtracer_mis.zig:123-166)
 // Every launch is one thread per queue entry (no grid-stride loop: hoisted loop invariants cost ~60 VGPRs here); the
 // queue lengths live on the device, so a launch covers the upper bound and surplus waves retire at once.
+//
+// POOL instantiations (scenes with Glass): PathtracerMIS splits a path at dielectric interfaces into a reflected and a
+// refracted one, up to 4 per camera sample (Vertex.Pool, vertex.zig:214-310).  The vertices of one level are consumed in
+// order and share the sample's samplers, so a tick runs 4 rounds of intersect / shade / scatter: round k handles vertex k of
+// every sample's current level.  Records are then indexed by vertex = (half * 4 + k) * batch + slot (two halves: current
+// and next level), the samplers, the IValue accumulators and the alpha sum by slot.
 #pragma once
 
 #include "dmaterial.hpp"
@@ -54,10 +60,20 @@ struct Pool {  // SoA of 16 B records, indexed by path slot
     float4*   contrib;  //   its pre-weighted contribution weight * radiance * bsdf
     float4*   nee;      // sum of the unoccluded contributions of this vertex
     uint32_t* vis;      // wf_shadow's verdict on the running pick
+    // POOL only
+    uint32_t* vmeta;    // per vertex: depth_surface, vertex.depth, state flags (the bits of q0.y above the sobol dimension)
+    uint4*    med0;     // per vertex: medium stack (prop/medium.zig:30-153): index, prop0, part0, prop1
+    uint4*    med1;     //             part1, prop2, part2
+    float2*   rec_ior;  // per vertex: rs.ior (Vertex.iorOutside), 1 if the material has lower priority than the stack
+    uint32_t* pstate;   // per slot: [0:7] vertices in flight, [8:15] children created for the next level
+    float*    transp;   // per slot: Pool.transparency[3], the alpha sum over terminated vertices
 };
+
+constexpr uint32_t kPoolVertices = 4;  // Vertex.Pool.NumVertices
 
 struct Queues {
     uint32_t* ext[2];  // extension rays, ping-pong per tick
+    uint32_t* ext_pool[2][kPoolVertices];  // POOL: one queue per round, [1] = the extra queues of rounds 1..3
     uint32_t* alive;   // paths that survived wf_shade in this tick
     uint32_t* shadow;  // paths with a shadow ray in flight (one NEE round)
     uint32_t* heavy;   // extension rays whose vertex has emission to evaluate (wf_shade's second pass)
@@ -77,6 +93,7 @@ struct KernelCounters {
 
 struct Control {  // device-resident
     QueueCounts        ext_count[2];
+    QueueCounts        ext_pool_count[2][kPoolVertices];  // POOL
     QueueCounts        alive_count;
     QueueCounts        shadow_count[2];  // ping-pong per NEE round
     QueueCounts        heavy_count;
@@ -105,6 +122,7 @@ struct Params {
     float*   film_alpha;  // Transparent sensor only (else null): sum of weight * alpha per pixel
     uint32_t parity;  // current extension-queue side
     uint32_t queue_capacity;  // entries every queue array holds
+    uint32_t round;   // POOL: which vertex of the level this launch handles
 };
 
 __constant__ View   c_view;
@@ -218,6 +236,88 @@ ZD void slotPixel(uint32_t slot, int& x, int& y, uint32_t& iteration) {
 
 ZD uint32_t batchPaths() { return c_view.npix * c_view.batch_iterations; }
 
+// POOL addressing: a queue entry is a vertex index; the camera sample it belongs to; the stride between the planes of
+// per-vertex multi-entry arrays (candidates)
+template <bool POOL> ZD uint32_t sampleSlot(uint32_t vertex) { return POOL ? vertex % batchPaths() : vertex; }
+template <bool POOL> ZD size_t   vertexPlane() { return POOL ? size_t(2 * kPoolVertices) * batchPaths() : size_t(batchPaths()); }
+template <bool POOL> ZD uint32_t* extQueue(const Params& P, uint32_t side, uint32_t round) {
+    return POOL ? P.q.ext_pool[side][round] : P.q.ext[side];
+}
+template <bool POOL> ZD QueueCounts* extCount(const Params& P, uint32_t side, uint32_t round) {
+    return POOL ? &P.ctl->ext_pool_count[side][round] : &P.ctl->ext_count[side];
+}
+
+struct Mediums {  // prop/medium.zig:30-153; an entry is its (prop, part): ior, priority and absorption are the material's
+    uint32_t index;
+    uint32_t prop[3], part[3];  // push() stops at Num_entries - 1 = 3 entries
+    ZD void load(const Params& P, uint32_t vertex) {
+        const uint4 a = P.pool.med0[vertex], b = P.pool.med1[vertex];
+        index = a.x;
+        prop[0] = a.y, part[0] = a.z, prop[1] = a.w, part[1] = b.x, prop[2] = b.y, part[2] = b.z;
+    }
+    ZD void store(const Params& P, uint32_t vertex) const {
+        P.pool.med0[vertex] = make_uint4(index, prop[0], part[0], prop[1]);
+        P.pool.med1[vertex] = make_uint4(part[1], prop[2], part[2], 0u);
+    }
+    ZD const ZygpuMaterial& material(uint32_t i) const {
+        return c_scene.materials[c_scene.material_ids[c_scene.props[prop[i]].parts_start + part[i]]];
+    }
+    ZD float ior(uint32_t i) const {  // material.zig:140-146
+        const ZygpuMaterial& m = material(i);
+        return (ZYGPU_MAT_GLASS == m.kind || ZYGPU_MAT_SUBSTITUTE == m.kind) ? m.ior : 1.f;
+    }
+    ZD bool  matches(uint32_t i, uint32_t fprop, uint32_t fpart) const { return prop[i] == fprop && part[i] == fpart; }
+    ZD float topIor() const { return index > 0 ? ior(index - 1) : 1.f; }
+    ZD float peekIor(uint32_t fprop, uint32_t fpart) const {
+        if (index <= 1) return 1.f;
+        const uint32_t back = index - 1;
+        return matches(back, fprop, fpart) ? ior(back - 1) : ior(back);
+    }
+    ZD int32_t highestPriority() const {
+        int32_t priority = -128;
+        for (uint32_t i = 0; i < index; ++i) priority = max(priority, material(i).priority);
+        return priority;
+    }
+    ZD f3 topAbsorption() const {  // topCC: the last entry of the highest priority
+        int32_t  priority = -128;
+        uint32_t highest = 0;
+        for (uint32_t i = 0; i < index; ++i) {
+            const int32_t lp = material(i).priority;
+            if (lp >= priority) {
+                priority = lp;
+                highest = i;
+            }
+        }
+        const ZygpuMaterial& m = material(highest);
+        return mk3(m.absorption[0], m.absorption[1], m.absorption[2]);
+    }
+    ZD void push(uint32_t fprop, uint32_t fpart) {
+        if (index < 3) {
+            prop[index] = fprop;
+            part[index] = fpart;
+            index += 1;
+        }
+    }
+    ZD void remove(uint32_t fprop, uint32_t fpart) {
+        const int32_t back = int32_t(index) - 1;
+        for (int32_t i = back; i >= 0; --i) {
+            if (matches(uint32_t(i), fprop, fpart)) {
+                for (int32_t j = i; j < back; ++j) {
+                    prop[j] = prop[j + 1];
+                    part[j] = part[j + 1];
+                }
+                index -= 1;
+                return;
+            }
+        }
+    }
+};
+
+ZD f3 attenuation3(f3 c, float distance) {  // collision_coefficients.zig:67-69
+    const f3 x = S3(-distance) * c;
+    return mk3(expF(x.x), expF(x.y), expF(x.z));
+}
+
 ZD uint32_t pixelId(int x, int y) {  // worker.zig:127-128,136,141
     const int fr = c_view.v.filter_radius_int;
     const int r0 = c_view.v.resolution[0] + 2 * fr;
@@ -249,7 +349,10 @@ struct PathHead {  // sampler + packed flags of one path
     uint32_t nee;  // next-event-estimation state of the current vertex (kNee*)
 };
 
-ZD void loadHead(const Params& P, uint32_t slot, PathHead& h) {
+// POOL: `vertex` is a vertex index; the samplers are those of its camera sample, depth and flags are the vertex's own
+template <bool POOL = false>
+ZD void loadHead(const Params& P, uint32_t vertex, PathHead& h) {
+    const uint32_t slot = sampleSlot<POOL>(vertex);
     int      px, py;
     uint32_t iteration;
     slotPixel(slot, px, py, iteration);
@@ -257,7 +360,7 @@ ZD void loadHead(const Params& P, uint32_t slot, PathHead& h) {
     const uint4    a = P.pool.q0[slot];
     const float4   b = P.pool.q1[slot];
     const uint2    g = P.pool.pcg[slot];
-    const uint32_t meta = a.y;
+    const uint32_t meta = POOL ? ((a.y & 7u) | (P.pool.vmeta[vertex] & ~7u)) : a.y;
     h.smp.run_seed = a.x;
     h.smp.buffer[0] = b.x;
     h.smp.buffer[1] = b.y;
@@ -277,11 +380,21 @@ ZD void loadHead(const Params& P, uint32_t slot, PathHead& h) {
     h.smp.use_primary = h.depth_surface < 3;  // worker.zig:201-207
 }
 
-ZD void storeHead(const Params& P, uint32_t slot, const PathHead& h) {
-    const uint32_t meta = (h.smp.dimension & 7u) | ((h.depth_surface & 31u) << 3) | ((h.vdepth & 31u) << 8) | ((h.flags & 63u) << 13);
-    P.pool.q0[slot] = make_uint4(h.smp.run_seed, meta, __float_as_uint(h.smp.buffer[4]), h.nee);
+ZD uint32_t packMeta(const PathHead& h) {
+    return (h.smp.dimension & 7u) | ((h.depth_surface & 31u) << 3) | ((h.vdepth & 31u) << 8) | ((h.flags & 63u) << 13);
+}
+
+// the samplers of a camera sample (POOL: shared by the vertices of the sample, so stored after every vertex)
+ZD void storeSamplers(const Params& P, uint32_t slot, const PathHead& h) {
+    P.pool.q0[slot] = make_uint4(h.smp.run_seed, packMeta(h), __float_as_uint(h.smp.buffer[4]), h.nee);
     P.pool.q1[slot] = make_float4(h.smp.buffer[0], h.smp.buffer[1], h.smp.buffer[2], h.smp.buffer[3]);
     P.pool.pcg[slot] = make_uint2(uint32_t(h.smp.rng.state), uint32_t(h.smp.rng.state >> 32));
+}
+
+template <bool POOL = false>
+ZD void storeHead(const Params& P, uint32_t vertex, const PathHead& h) {
+    storeSamplers(P, sampleSlot<POOL>(vertex), h);
+    if (POOL) P.pool.vmeta[vertex] = packMeta(h);
 }
 
 ZD f3 xyz4(float4 v) { return {v.x, v.y, v.z}; }
@@ -312,6 +425,23 @@ ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags) 
     P.stage_color[slot] = f4(summed, alpha);
 }
 
+// POOL: a vertex ends without children: Pool.consume's bookkeeping for terminated vertices (vertex.zig:240-262; no shadow
+// catchers), done when the vertex ends instead of at the end of its level (same order: vertices end in index order).
+// The camera sample ends with its last vertex: result.direct[3] = 0 + transparency[3] (pathtracer_mis.zig:168-170)
+ZD void terminateVertex(const Params& P, uint32_t slot, f3 throughput, float split_weight, uint32_t flags) {
+    float alpha = P.pool.transp[slot];
+    alpha = (flags & ST_TRANSPARENT) ? alpha + mx((1.f - average3(throughput)) * split_weight, 0.f) : alpha + split_weight;
+    P.pool.transp[slot] = alpha;
+    const uint32_t st = P.pool.pstate[slot] - 1u;
+    P.pool.pstate[slot] = st;
+    if (0 == (st & 255u)) {
+        const f3 e = clampColor(xyz4(P.pool.emission[slot]), c_view.v.clamp_emission);
+        const f3 d = clampColor(xyz4(P.pool.direct[slot]), c_view.v.clamp_direct);
+        const f3 i = clampColor(xyz4(P.pool.indirect[slot]), c_view.v.clamp_indirect);
+        P.stage_color[slot] = f4(e + d + i, 0.f + alpha);
+    }
+}
+
 ZD void flushCounters(const Params& P, int k, const Counters& cnt, unsigned long long rays) {
     atomicAdd(&P.ctl->k[k].nodes, cnt.nodes);
     atomicAdd(&P.ctl->k[k].tris, cnt.tris);
@@ -333,6 +463,7 @@ ZD bool entersMeshBounds(f3 origin, f3 direction) {
 // ---------------------------------------------------------------- wf_generate
 // Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
 // Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
+template <bool POOL>
 ZD void generatePath(const Params& P, uint32_t slot) {
 
     int      x, y;
@@ -383,11 +514,16 @@ ZD void generatePath(const Params& P, uint32_t slot) {
     h.vdepth = 0;
     h.flags = ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR;
     h.nee = 0;
-    storeHead(P, slot, h);
+    storeHead<POOL>(P, slot, h);  // POOL: vertex 0 of half 0 has the slot's own index
     P.pool.ray_o[slot] = f4(origin_w, kRayMaxT);
     P.pool.ray_d[slot] = f4(direction_w, 0.f);
-    P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
-    P.pool.vorigin[slot] = f4(origin_w);
+    P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, POOL ? 1.f : 0.f);                  // POOL: w = vertex.split_weight
+    P.pool.vorigin[slot] = f4(origin_w, POOL ? __uint_as_float(1u) : 0.f);            //       w = vertex.path_count
+    if (POOL) {
+        P.pool.med0[slot] = make_uint4(0u, 0u, 0u, 0u);
+        P.pool.pstate[slot] = 1u;
+        P.pool.transp[slot] = 0.f;
+    }
     P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.pool.emission[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.pool.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -395,13 +531,14 @@ ZD void generatePath(const Params& P, uint32_t slot) {
     P.stage_uv[slot] = make_float2(s0, s1);
 }
 
+template <bool POOL>
 __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const bool     valid = slot < num_paths;
     if (0 == slot) P.ctl->bound[1] = num_paths;  // tick 0's wf_intersect reads the previous tick's bound
-    if (valid) generatePath(P, slot);
+    if (valid) generatePath<POOL>(P, slot);
     const bool back = valid && entersMeshBounds(xyz4(P.pool.ray_o[slot]), xyz4(P.pool.ray_d[slot]));
-    queuePush(P.q.ext[P.parity], &P.ctl->ext_count[P.parity], P.queue_capacity, valid, slot, back);
+    queuePush(extQueue<POOL>(P, P.parity, 0), extCount<POOL>(P, P.parity, 0), P.queue_capacity, valid, slot, back);
 }
 
 // PropBvh.emission over the unoccluding TLAS (prop_tree.zig:302-356, prop.zig:239-264, rectangle.zig:188-196), split in
@@ -417,12 +554,13 @@ ZD bool walksUnoccluding(uint32_t flags) {
 }
 
 template <bool STATS>
-ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, uint32_t depth_surface, const Ray& ray_in, Counters& cnt) {
+ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, size_t plane, uint32_t depth_surface, const Ray& ray_in,
+                                  Counters& cnt) {
     uint32_t n = 0;
     Ray      ray = ray_in;
     auto     record = [&](uint32_t prop, uint32_t primitive, float t, float u, float v) {
         if (n < kMaxUnoccludingCandidates) {
-            const size_t at = size_t(n) * batchPaths() + slot;
+            const size_t at = size_t(n) * plane + slot;
             P.pool.ucand[at] = make_uint4(prop, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
             P.pool.ucand_prim[at] = primitive;
         } else {
@@ -465,16 +603,19 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
 }
 
 // ---------------------------------------------------------------- wf_intersect
-template <bool STATS>
+template <bool STATS, bool POOL>
 __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     const uint32_t cur = P.parity;
-    if (blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
+    // the previous tick's queue was no longer (POOL: a level can have more vertices than the one before)
+    if (!POOL && blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t n = queueOpen(&P.ctl->ext_count[cur], P.queue_capacity, i, at);
+    const uint32_t n = queueOpen(extCount<POOL>(P, cur, P.round), P.queue_capacity, i, at);
     if (0 == i) P.ctl->bound[cur] = n;
     if (0 == blockIdx.x && threadIdx.x < 64) {  // this tick's wf_shade / wf_nee / wf_extend fill these
-        queueReset(&P.ctl->ext_count[cur ^ 1u]);
+        if (!POOL) queueReset(&P.ctl->ext_count[cur ^ 1u]);
+        if (POOL && 0 == P.round)
+            for (uint32_t k = 0; k < kPoolVertices; ++k) queueReset(&P.ctl->ext_pool_count[cur ^ 1u][k]);
         queueReset(&P.ctl->alive_count);
         queueReset(&P.ctl->shadow_count[0]);
         queueReset(&P.ctl->shadow_count[1]);
@@ -482,18 +623,30 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     }
     Counters cnt{0, 0, 0};
     if (i < n) {
-        const uint32_t slot = P.q.ext[cur][at];
+        const uint32_t slot = extQueue<POOL>(P, cur, P.round)[at];  // POOL: a vertex index
         const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
-        const uint32_t meta = P.pool.q0[slot].y;
+        const uint32_t meta = POOL ? P.pool.vmeta[slot] : P.pool.q0[slot].y;
         const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
         Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+        if (POOL) {
+            // inside a dielectric the ray ends where it leaves the medium prop's bounding box
+            // (VolumeIntegrator.integrate, volume_integrator.zig:98-103); wf_shade sees the shortened ray
+            Mediums md;
+            md.load(P, slot);
+            if (md.index > 0) {
+                const uint32_t mp = md.prop[md.index - 1];
+                const float    limit = aabbIntersectP(c_scene.aabbs[2 * mp], c_scene.aabbs[2 * mp + 1], ray);
+                ray.max_t = mn(offsetF(limit), o.w);
+                P.pool.ray_o[slot].w = ray.max_t;
+            }
+        }
         Hit            hit;
         sceneIntersect<STATS>(c_scene, ray, depth, hit, cnt);
         if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
         P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
         P.pool.hit_prop[slot] = hit.prop;
         // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
-        P.pool.ucount[slot] = walksUnoccluding(flags) ? unoccludingCandidates<STATS>(P, c_scene, slot, depth, ray, cnt) : 0u;
+        P.pool.ucount[slot] = walksUnoccluding(flags) ? unoccludingCandidates<STATS>(P, c_scene, slot, vertexPlane<POOL>(), depth, ray, cnt) : 0u;
     }
     if (STATS) flushCounters(P, 0, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
 }
@@ -606,12 +759,12 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
 
 // the evaluation half of PropBvh.emission: the candidates wf_intersect recorded, in its traversal order
 template <bool MESHL>
-ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, const VertexIn& v, const Ray& ray, Sampler& smp) {
+ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_t plane, const VertexIn& v, const Ray& ray, Sampler& smp) {
     f3             energy = S3(0.f);
     const uint32_t n = min(P.pool.ucount[slot], kMaxUnoccludingCandidates);
     const f3       wo = -ray.direction;
     for (uint32_t k = 0; k < n; ++k) {
-        const size_t    at = size_t(k) * batchPaths() + slot;
+        const size_t    at = size_t(k) * plane + slot;
         const uint4     c = P.pool.ucand[at];
         const ZygpuProp prop = s.props[c.x];
         Fragment        frag;
@@ -645,14 +798,15 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, const
 // emissive and whose ray crossed no unoccluding light has no emission to evaluate (no sampler draw, no light-tree pdf,
 // no SphQuad), so that instantiation is small enough for twice the occupancy; the others go to the `heavy` queue, which
 // the HEAVY = true pass processes with the complete connectLight.
-template <bool STATS, bool MESHL, bool HEAVY>
+// POOL: `slot` below is a vertex index, `ps` the camera sample it belongs to
+template <bool STATS, bool MESHL, bool HEAVY, bool POOL>
 __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_SHADE_LIGHT_WAVES) wf_shade(Params P) {
     const DScene&  s = c_scene;
     const uint32_t cur = P.parity;
     if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count : &P.ctl->ext_count[cur], P.queue_capacity, i, at);
+    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count : extCount<POOL>(P, cur, P.round), P.queue_capacity, i, at);
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters       cnt{0, 0, 0};
@@ -663,9 +817,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
         bool     alive = false, defer = false;
         uint32_t slot = 0;
         if (i < total) {
-            slot = HEAVY ? P.q.heavy[at] : P.q.ext[cur][at];
+            slot = HEAVY ? P.q.heavy[at] : extQueue<POOL>(P, cur, P.round)[at];
+            const uint32_t ps = sampleSlot<POOL>(slot);
             PathHead h;
-            loadHead(P, slot, h);
+            loadHead<POOL>(P, slot, h);
 
             const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
             const uint4    hr = P.pool.hit[slot];
@@ -705,26 +860,38 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                 if (ZYGPU_INTEGRATOR_PT == kind) {
                     v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
                     if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
+                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
                     if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
                 } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
                     if (has_hit) {
                         const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
                         if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     }
-                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
+                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
                     if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, true, cnt);
                 } else {
                     v.light_split_threshold = splitThreshold(h.vdepth);
                     if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
                     tm.mark(1);
-                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, v, ray, h.smp);
+                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
                     tm.mark(2);
                     if (MESHL && !has_hit) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);  // RayMaxT == max_t
                 }
             }
-            f3 throughput = xyz4(P.pool.thr[slot]);
-            ivalueAdd(P, slot, throughput * energy, h.depth_surface, mis ? 2u : 1u, 0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
+            const float4 thr4 = P.pool.thr[slot];
+            f3           throughput = xyz4(thr4);
+            const float  split_weight = POOL ? thr4.w : 1.f;
+            Mediums      md;
+            if (POOL) {
+                if (0 == P.round) P.pool.pstate[ps] &= 255u;  // a new level: no children yet
+                md.load(P, slot);
+                // VolumeIntegrator.integrate for a medium that only absorbs (volume_integrator.zig:62-65, 105-128):
+                // Beer-Lambert over the segment to the hit; Context.nextEvent runs before connectLight
+                if (has_hit && md.index > 0) throughput = throughput * attenuation3(md.topAbsorption(), hit.t - 0.f);
+            }
+            // split_throughput = vertex.throughput * split_weight (pathtracer_mis.zig:61-62)
+            ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * energy, h.depth_surface, mis ? 2u : 1u,
+                      0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
 
             bool done = false;
             if (!has_hit || h.depth_surface >= c_view.v.max_depth_surface || 0 >= c_view.v.max_depth_volume) {
@@ -765,13 +932,25 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                     P.pool.rec_n[slot] = f4(n, color.x);
                     P.pool.rec_t[slot] = f4(frag.t, color.y);
                     P.pool.rec_b[slot] = f4(frag.b, color.z);
-                    P.pool.thr[slot] = f4(throughput);
-                    storeHead(P, slot, h);
+                    P.pool.thr[slot] = f4(throughput, split_weight);
+                    if (POOL) {
+                        // rs.ior = Vertex.iorOutside (vertex.zig:87-92), rs.highest_priority (vertex.zig:178)
+                        const float ior_outside = frag.sameHemisphere(wo) ? md.topIor() : md.peekIor(frag.prop, frag.part);
+                        P.pool.rec_ior[slot] = make_float2(ior_outside, m.priority < md.highestPriority() ? 1.f : 0.f);
+                    }
+                    storeHead<POOL>(P, slot, h);
                     alive = true;
                 }
             }
             tm.mark(3);
-            if (done) finalize(P, slot, throughput, h.flags);
+            if (done) {
+                if (POOL) {
+                    storeSamplers(P, ps, h);  // the sample's other vertices go on with these samplers
+                    terminateVertex(P, ps, throughput, split_weight, h.flags);
+                } else {
+                    finalize(P, slot, throughput, h.flags);
+                }
+            }
             tm.mark(4);
             }
         }
@@ -794,6 +973,7 @@ struct Surface {
     MaterialSample ms;
 };
 
+template <bool POOL = false>
 ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     const float4 rp = P.pool.rec_p[slot];
     const float4 rg = P.pool.rec_gn[slot];
@@ -808,7 +988,12 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     Surface      sf;
     sf.p = xyz4(rp);
     sf.frag_geo_n = 0.f != rg.w ? -geo_n : geo_n;
-    sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color);
+    if (POOL) {
+        const float2 ri = P.pool.rec_ior[slot];
+        sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y);
+    } else {
+        sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color);
+    }
     return sf;
 }
 
@@ -1027,7 +1212,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 // round trips, but every lane waits for the longest pick loop of its wave and the kernel needs ~240 VGPRs.
 // SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
 // MULTI: a light has emittance num_samples > 1; MESHL: the scene has TriangleMesh lights
-template <bool STATS, bool SUBST, bool MULTI, bool MESHL>
+// POOL: `slot` below is a vertex index, `ps` the camera sample it belongs to; Glass may return two bxdf samples
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL>
 __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     const DScene&      s = c_scene;
     const uint32_t     nxt = P.parity ^ 1u;
@@ -1043,13 +1229,19 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
     if (i >= rounded) return;
     bool     push = false, back = false;
     uint32_t slot = 0;
+    // POOL: the children of this vertex: their vertex index, their place in the next level (= the round that handles them)
+    uint32_t child[2] = {0, 0}, child_round[2] = {kNull, kNull};
+    bool     child_back[2] = {false, false};
     if (i < total) {
         slot = P.q.alive[at];
+        const uint32_t ps = sampleSlot<POOL>(slot);
         PathHead h;
-        loadHead(P, slot, h);
-        const Surface         sf = loadSurface(P, slot, h.flags);
+        loadHead<POOL>(P, slot, h);
+        const Surface         sf = loadSurface<POOL>(P, slot, h.flags);
         const MaterialSample& ms = sf.ms;
-        f3                    throughput = xyz4(P.pool.thr[slot]);
+        const float4          thr4 = P.pool.thr[slot];
+        f3                    throughput = xyz4(thr4);
+        const float           split_weight = POOL ? thr4.w : 1.f;
 
         // ---- sampleLights / evaluateLight (pathtracer_mis.zig:174-278, pathtracer_dl.zig:100-167)
         if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
@@ -1161,12 +1353,85 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 }
                 nee = nee + occluded;
             }
-            ivalueAdd(P, slot, throughput * nee, h.depth_surface, 1u, false, false);
+            ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
         }
 
         // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
         BxdfSample bs;
-        if (!ms.template sample<SUBST>(s, h.smp, bs)) {
+        if (POOL) {
+            // mat_sample.sample(sampler, max_splits, ..): Glass splits into reflection and refraction while the sample has
+            // vertices left (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only, pathtracer.zig:73, pathtracer_dl.zig:82)
+            BxdfSample     bs1;
+            uint32_t       count;
+            const uint32_t path_count = __float_as_uint(P.pool.vorigin[slot].w);
+            if (ZYGPU_MAT_GLASS == ms.kind) {
+                uint32_t max_splits = 1;
+                if (mis) {
+                    const uint32_t m = kPoolVertices / path_count;
+                    max_splits = m - ((h.flags & ST_PRIMARY) ? 0u : min(h.depth_surface, m - 1u));
+                }
+                count = ms.glassSample(h.smp, max_splits > 1, bs, bs1);
+            } else {
+                count = ms.template sample<SUBST>(s, h.smp, bs) ? 1u : 0u;
+            }
+            h.smp.incrementPadding();  // after the children, none of which draws (pathtracer_mis.zig:165)
+            storeSamplers(P, ps, h);
+            if (0 == count) {
+                terminateVertex(P, ps, S3(0.f), split_weight, h.flags);  // vertex.throughput = 0 (pathtracer_mis.zig:127-129)
+            } else {
+                Mediums md;
+                md.load(P, slot);
+                const uint32_t st = P.pool.pstate[ps];
+                const uint32_t first = (st >> 8) & 255u;
+                P.pool.pstate[ps] = st + (count << 8) + (count - 1u);  // children created; vertices in flight: -1 + count
+                const float  parent_pdf = P.pool.ray_d[slot].w;
+                const float4 parent_vgeo_n = P.pool.vgeo_n[slot];
+                for (uint32_t c = 0; c < count; ++c) {
+                    const BxdfSample& b = c ? bs1 : bs;
+                    const uint32_t    cv = (nxt * kPoolVertices + first + c) * batchPaths() + ps;
+                    PathHead          ch = h;
+                    // Vertex.State.update (vertex.zig:30-43); no .Straight event in scope
+                    if (kScatterSpecular == b.scattering) {
+                        ch.flags |= ST_SPECULAR;
+                        ch.flags = (0.f == b.reg_alpha) ? (ch.flags | ST_SINGULAR) : (ch.flags & ~uint32_t(ST_SINGULAR));
+                        if (ch.flags & ST_PRIMARY) ch.flags |= ST_STARTED_SPECULAR;
+                    } else {
+                        ch.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
+                    }
+                    float bxdf_pdf = parent_pdf;
+                    if (mis) {
+                        ch.flags = ms.translucent ? (ch.flags | ST_TRANSLUCENT) : (ch.flags & ~uint32_t(ST_TRANSLUCENT));
+                        ch.vdepth = h.depth_surface;
+                        bxdf_pdf = b.pdf;
+                    }
+                    const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, b.wi);
+                    ch.depth_surface = h.depth_surface + 1;
+                    Mediums cm = md;
+                    if (b.transmission) {
+                        // Vertex.interfaceChange (vertex.zig:94-108): leaving if the new direction is on the side of the
+                        // fragment's geometric normal
+                        const uint32_t  hit_prop = P.pool.hit_prop[slot];
+                        const ZygpuProp hp = s.props[hit_prop];
+                        const uint32_t  part =
+                            ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[P.pool.hit[slot].w]) : 0u;
+                        if (dot3(sf.frag_geo_n, b.wi) > 0.f) cm.remove(hit_prop, part);
+                        else cm.push(hit_prop, part);
+                    } else {
+                        ch.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight)
+                    }
+                    P.pool.ray_o[cv] = f4(new_origin, kRayMaxT);
+                    P.pool.ray_d[cv] = f4(b.wi, bxdf_pdf);
+                    P.pool.thr[cv] = f4(throughput * (b.reflection / S3(b.pdf)), split_weight * b.split_weight);
+                    P.pool.vorigin[cv] = f4(sf.p, __uint_as_float(path_count * count));
+                    P.pool.vgeo_n[cv] = mis ? f4(ms.geo_n) : parent_vgeo_n;
+                    P.pool.vmeta[cv] = packMeta(ch);
+                    cm.store(P, cv);
+                    child[c] = cv;
+                    child_round[c] = first + c;
+                    child_back[c] = entersMeshBounds(new_origin, b.wi);
+                }
+            }
+        } else if (!ms.template sample<SUBST>(s, h.smp, bs)) {
             finalize(P, slot, S3(0.f), h.flags);
         } else {
             // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
@@ -1199,7 +1464,16 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
             push = true;
         }
     }
-    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
+    if (POOL) {
+        for (uint32_t r = 0; r < kPoolVertices; ++r) {  // child `first + c` of a sample is vertex `first + c` of the next level
+            const bool c0 = r == child_round[0], c1 = r == child_round[1];
+            if (r) __syncthreads();  // queuePush's shared words are reused
+            queuePush(P.q.ext_pool[nxt][r], &P.ctl->ext_pool_count[nxt][r], P.queue_capacity, c0 || c1, c1 ? child[1] : child[0],
+                      c1 ? child_back[1] : child_back[0]);
+        }
+    } else {
+        queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
+    }
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
 }
 

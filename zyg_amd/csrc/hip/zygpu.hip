@@ -113,6 +113,7 @@ __global__ void film_resolve(const float4* film, const float* film_alpha, float4
 //  op 2: sample, seed -> the first 10 Sobol 1D draws with a padding increment after 5 (2 in as bits, 10 out)
 //  op 3: state.lo, state.hi(seq) -> 4 PCG floats      (2 in as bits, 4 out)
 //  op 4: p.xyz, n.xyz -> offsetRay                    (6 in, 3 out)
+//  op 6: x, y -> expF(x), atan2F(y, x)                 (2 in, 2 out)
 __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -154,6 +155,9 @@ __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) 
         out[6 * i + 4] = acosR(fabsf(a) * 0.25f);
         const float z = fabsf(a) * 0.25f;
         out[6 * i + 5] = z * (1.6666586697e-01f + z * (-4.2743422091e-02f + z * -8.6563630030e-03f));
+    } else if (6 == op) {
+        out[2 * i] = expF(in[2 * i]);
+        out[2 * i + 1] = atan2F(in[2 * i + 1], in[2 * i]);
     } else if (4 == op) {
         const float* a = in + 6 * i;
         const f3     r = offsetRay(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]));
@@ -234,6 +238,8 @@ struct ZygpuContext {
     bool          has_substitute = false;  // selects the kernels' material instantiation
     bool          multi_sample_lights = false;  // a light has emittance num_samples > 1: wf_scatter<.., MULTI>
     bool          mesh_lights = false;          // TriangleMesh emitters: wf_shade<.., MESHL>, wf_scatter<.., MESHL>
+    bool          pool_mode = false;            // Glass in the scene: the POOL instantiations (split paths, medium stack)
+    bool          pool_allocated = false;       // the path pool has the POOL layout
     bool          tick_sync = false;       // option "tick_sync": read the queue length back after every tick
     uint32_t*     host_count = nullptr;    // pinned
     uint4*        sobol_lut = nullptr;     // dsampler.hpp c_sobol_lut
@@ -274,15 +280,19 @@ bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out
     return ok;
 }
 
-int ensurePool(ZygpuContext* c, size_t paths, uint32_t rounds) {
-    if (paths <= c->pool_capacity && rounds <= c->pool_rounds) return 0;
-    paths = std::max(paths, c->pool_capacity);
+int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
+    if (slots <= c->pool_capacity && rounds <= c->pool_rounds && c->pool_mode == c->pool_allocated) return 0;
+    slots = std::max(slots, c->pool_capacity);
     rounds = std::max(rounds, c->pool_rounds);
     HIP_OK(hipStreamSynchronize(c->stream));
     c->pool_mem.release();
     DeviceBuffers& m = c->pool_mem;
     Pool&          p = c->pool;
-    const size_t   qcap = queueCapacity(paths);
+    const size_t   qcap = queueCapacity(slots);
+    // POOL: records per vertex, 2 levels x 4 vertices per camera sample (the per-sample arrays are simply oversized)
+    const size_t   paths = c->pool_mode ? slots * 2 * kPoolVertices : slots;
+    std::memset(&p, 0, sizeof(p));
+    std::memset(&c->queues, 0, sizeof(c->queues));
     bool           ok = m.alloc(paths, &p.q0) && m.alloc(paths, &p.q1) && m.alloc(paths, &p.pcg) && m.alloc(paths, &p.ray_o) &&
               m.alloc(paths, &p.ray_d) && m.alloc(paths, &p.thr) && m.alloc(paths, &p.vorigin) && m.alloc(paths, &p.vgeo_n) &&
               m.alloc(paths, &p.emission) && m.alloc(paths, &p.direct) && m.alloc(paths, &p.indirect) && m.alloc(paths, &p.hit) &&
@@ -292,13 +302,22 @@ int ensurePool(ZygpuContext* c, size_t paths, uint32_t rounds) {
               m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) && m.alloc(paths, &p.sh_o) &&
               m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
               m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy);
+    if (ok && c->pool_mode) {
+        ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) &&
+             m.alloc(slots, &p.pstate) && m.alloc(slots, &p.transp);
+        for (uint32_t side = 0; side < 2; ++side) {
+            c->queues.ext_pool[side][0] = c->queues.ext[side];
+            for (uint32_t k = 1; k < kPoolVertices; ++k) ok = ok && m.alloc(qcap, &c->queues.ext_pool[side][k]);
+        }
+    }
     if (!ok) {
         c->pool_capacity = 0;
         c->pool_rounds = 0;
         return -1;
     }
-    c->pool_capacity = paths;
+    c->pool_capacity = slots;
     c->pool_rounds = rounds;
+    c->pool_allocated = c->pool_mode;
     return 0;
 }
 
@@ -471,6 +490,16 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     ok = ok && m.upload(d->luts.e_avg, d->luts.e_avg ? 16 * 16 : 0, &s.lut_e_avg);
     if (!ok) return -1;
 
+    c->pool_mode = false;
+    for (uint32_t pi = 0; pi < d->num_parts; ++pi) {
+        const ZygpuMaterial& gm = d->materials[d->material_ids[pi]];
+        if (ZYGPU_MAT_GLASS != gm.kind) continue;
+        if (gm.roughness > 0.f || gm.thickness > 0.f || gm.abbe > 0.f) {
+            g_error = "Glass: only thick, perfectly specular, non-dispersive glass (roughness 0, thickness 0, abbe 0) is supported";
+            return -2;
+        }
+        c->pool_mode = true;  // split paths + medium stack: the POOL kernels
+    }
     c->has_substitute = false;
     for (uint32_t mi = 0; mi < d->num_materials; ++mi) {
         if (ZYGPU_MAT_SUBSTITUTE == d->materials[mi].kind) c->has_substitute = true;
@@ -655,7 +684,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     const size_t npix = size_t(xe - xb) * size_t(ye - yb);
 
     // batch size: as many iterations as fit ~8M paths (bounded by what is left)
-    const size_t   target_paths = size_t(c->batch_mpaths) << 20;
+    const size_t   target_paths = (size_t(c->batch_mpaths) << 20) / (c->pool_mode ? 2 * kPoolVertices : 1);
     const uint32_t per_batch = uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
     // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
@@ -671,6 +700,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     P.film = c->film_active;
     P.film_alpha = c->film_alpha_active;
     P.parity = 0;
+    P.round = 0;
 
     const uint32_t ticks = v.max_depth_surface + 1;  // one tick per path vertex
     const dim3     block(256);
@@ -696,32 +726,63 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         dim3           grid((num_paths + 255) / 256);
         P.parity = 0;
         HIP_OK(hipMemsetAsync(&c->ctl->ext_count[0], 0, sizeof(QueueCounts), c->stream));  // wf_generate appends to it
-        hipLaunchKernelGGL(wf_generate, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
+        if (c->pool_mode) {
+            HIP_OK(hipMemsetAsync(&c->ctl->ext_pool_count[0][0], 0, sizeof(QueueCounts) * kPoolVertices, c->stream));
+            hipLaunchKernelGGL(wf_generate<true>, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
+        } else {
+            hipLaunchKernelGGL(wf_generate<false>, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
+        }
         c->camera_samples += num_paths;
         for (uint32_t t = 0; t < ticks; ++t) {
+            if (c->pool_mode) {
+                // one level of every sample's vertex pool: round k = vertex k of the level, in order (shared samplers)
+                for (uint32_t k = 0; k < kPoolVertices; ++k) {
+                    P.round = k;
+                    timedLaunch(c, 0, [&] {
+                        if (c->stats) hipLaunchKernelGGL((wf_intersect<true, true>), grid, block, 0, c->stream, P);
+                        else hipLaunchKernelGGL((wf_intersect<false, true>), grid, block, 0, c->stream, P);
+                    });
+                    timedLaunch(c, 1, [&] {
+                        if (c->stats) {
+                            hipLaunchKernelGGL((wf_shade<true, true, false, true>), grid, block, 0, c->stream, P);
+                            hipLaunchKernelGGL((wf_shade<true, true, true, true>), grid, block, 0, c->stream, P);
+                        } else {
+                            hipLaunchKernelGGL((wf_shade<false, true, false, true>), grid, block, 0, c->stream, P);
+                            hipLaunchKernelGGL((wf_shade<false, true, true, true>), grid, block, 0, c->stream, P);
+                        }
+                    });
+                    timedLaunch(c, 5, [&] {
+                        if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, true>), grid, block, 0, c->stream, P);
+                        else hipLaunchKernelGGL((wf_scatter<false, true, true, true, true>), grid, block, 0, c->stream, P);
+                    });
+                }
+                P.round = 0;
+                P.parity ^= 1u;
+                continue;
+            }
             timedLaunch(c, 0, [&] {
-                if (c->stats) hipLaunchKernelGGL(wf_intersect<true>, grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL(wf_intersect<false>, grid, block, 0, c->stream, P);
+                if (c->stats) hipLaunchKernelGGL((wf_intersect<true, false>), grid, block, 0, c->stream, P);
+                else hipLaunchKernelGGL((wf_intersect<false, false>), grid, block, 0, c->stream, P);
             });
             timedLaunch(c, 1, [&] {
                 if (c->stats) {
-                    hipLaunchKernelGGL((wf_shade<true, true, false>), grid, block, 0, c->stream, P);
-                    hipLaunchKernelGGL((wf_shade<true, true, true>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<true, true, false, false>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<true, true, true, false>), grid, block, 0, c->stream, P);
                 } else if (c->mesh_lights) {
-                    hipLaunchKernelGGL((wf_shade<false, true, false>), grid, block, 0, c->stream, P);
-                    hipLaunchKernelGGL((wf_shade<false, true, true>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<false, true, false, false>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<false, true, true, false>), grid, block, 0, c->stream, P);
                 } else {
-                    hipLaunchKernelGGL((wf_shade<false, false, false>), grid, block, 0, c->stream, P);
-                    hipLaunchKernelGGL((wf_shade<false, false, true>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<false, false, false, false>), grid, block, 0, c->stream, P);
+                    hipLaunchKernelGGL((wf_shade<false, false, true, false>), grid, block, 0, c->stream, P);
                 }
             });
             if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
-                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true>), grid, block, 0, c->stream, P);
-                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, true>), grid, block, 0, c->stream, P);
-                    else if (c->multi_sample_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, false>), grid, block, 0, c->stream, P);
-                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false, false>), grid, block, 0, c->stream, P);
-                    else hipLaunchKernelGGL((wf_scatter<false, false, false, false>), grid, block, 0, c->stream, P);
+                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, false>), grid, block, 0, c->stream, P);
+                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, true, false>), grid, block, 0, c->stream, P);
+                    else if (c->multi_sample_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, false, false>), grid, block, 0, c->stream, P);
+                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false, false, false>), grid, block, 0, c->stream, P);
+                    else hipLaunchKernelGGL((wf_scatter<false, false, false, false, false>), grid, block, 0, c->stream, P);
                 });
             } else {
             for (uint32_t r = 0; r < rounds; ++r) {

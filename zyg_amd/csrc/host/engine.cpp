@@ -264,8 +264,37 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
                     if (x.b) m.flags |= ZYGPU_MATF_TWO_SIDED;
                 } else if (k == "emittance") {
                     loadEmittance(x);
+                } else if (k == "priority") {
+                    m.priority = int32_t(x.f32(0.f));
                 }
             }
+        }
+    } else if (ZYGPU_MAT_GLASS == kind) {
+        // glass_material.zig:19-33 defaults; material_provider.zig:172-201
+        m.roughness = 0.f;
+        m.specular = 1.f;
+        m.ior = 1.46f;
+        Vec4f attenuation_color = splat(1.f);
+        float attenuation_distance = 1.f;
+        if (JsonValue::Object == v.type) {
+            for (const auto& kv : v.obj) {
+                const std::string& k = kv.first;
+                const JsonValue&   x = kv.second;
+                if (k == "color" || k == "attenuation_color") attenuation_color = readColor(x);
+                else if (k == "attenuation_distance") attenuation_distance = x.f32(attenuation_distance);
+                else if (k == "roughness") m.roughness = x.f32(m.roughness);
+                else if (k == "specular") m.specular = x.f32(m.specular);
+                else if (k == "priority") m.priority = int32_t(x.f32(0.f));
+                else if (k == "ior") m.ior = x.f32(m.ior);
+                else if (k == "abbe") m.abbe = x.f32(0.f);
+                else if (k == "thickness") m.thickness = x.f32(0.f);
+            }
+        }
+        // setVolumetric -> ccoef.attenuationCoefficient (collision_coefficients.zig:35-44)
+        for (int i = 0; i < 3; ++i) {
+            m.color_a[i] = attenuation_color[i];
+            const float ca = std::max(std::min(attenuation_color[i], 0.991102f), 0.01f);
+            m.absorption[i] = 0.f == attenuation_distance ? 0.f : -std::log(ca) / attenuation_distance;
         }
     }
 }
@@ -280,6 +309,12 @@ void Engine::commitMaterial(ZygpuMaterial& m) {
         if (m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
         else m.flags &= ~uint32_t(ZYGPU_MATF_CAUSTIC);
     }
+    if (ZYGPU_MAT_GLASS == m.kind) {  // glass_material.zig:35-42
+        const bool thin = m.thickness > 0.f;
+        m.flags &= ~uint32_t(ZYGPU_MATF_TWO_SIDED | ZYGPU_MATF_EVALUATE_VISIBILITY | ZYGPU_MATF_CAUSTIC);
+        if (thin) m.flags |= ZYGPU_MATF_TWO_SIDED | ZYGPU_MATF_EVALUATE_VISIBILITY;
+        if (m.roughness * m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
+    }
 }
 
 static bool materialKind(const JsonValue& v, uint32_t& kind, const JsonValue*& body) {
@@ -290,8 +325,9 @@ static bool materialKind(const JsonValue& v, uint32_t& kind, const JsonValue*& b
         if (kv.first == "Debug") { kind = ZYGPU_MAT_DEBUG; return true; }
         if (kv.first == "Light") { kind = ZYGPU_MAT_LIGHT; return true; }
         if (kv.first == "Substitute") { kind = ZYGPU_MAT_SUBSTITUTE; return true; }
+        if (kv.first == "Glass") { kind = ZYGPU_MAT_GLASS; return true; }
     }
-    return false;  // Glass / Hair / Volumetric: SURVEY §8 row a20 / out of scope
+    return false;  // Hair / Volumetric / Sky: out of scope
 }
 
 uint32_t Engine::createMaterial(uint32_t id, const JsonValue& v) {
@@ -1040,6 +1076,10 @@ int Engine::compile(uint32_t frame) {
     d.srgb_to_float = srgb_to_float_.data();
     for (const ZygpuMaterial& m : materials_)
         if (ZYGPU_NULL != m.color_image && m.color_image >= images_.size()) return -4;  // a colour map without its image
+    for (uint32_t mid : material_ids_) {  // rough / thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 293-460)
+        const ZygpuMaterial& m = materials_[mid];
+        if (ZYGPU_MAT_GLASS == m.kind && (m.roughness > 0.f || m.thickness > 0.f || m.abbe > 0.f)) return -5;
+    }
     for (const ZygpuMaterial& m : materials_) {
         if (ZYGPU_MAT_SUBSTITUTE != m.kind) continue;
         const ggxlut::Tables& t = ggxlut::tables();  // computed once per process (ggx_lut.hpp)

@@ -59,6 +59,13 @@ def checker_image(n=8, dtype=np.float32):
     return (img * 255.0 + 0.5).astype(np.uint8) if dtype == np.uint8 else img.astype(np.float32)
 
 
+def glass(ior=1.5, color=(1.0, 1.0, 1.0), distance=1.0, priority=0, **more):
+    """Thick specular dielectric (glass_material.zig); `color` is reached after `distance` inside the medium."""
+    body = {"ior": ior, "attenuation_color": list(color), "attenuation_distance": distance, "priority": priority}
+    body.update(more)
+    return json.dumps({"rendering": {"Glass": body}})
+
+
 def light_material(spectrum=(17.0, 12.0, 4.0), value=1.0, num_samples=1):
     return json.dumps({"rendering": {"Light": {"emittance": {"spectrum": list(spectrum), "value": value,
                                                              "num_samples": num_samples}}}})
@@ -186,7 +193,7 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
-            floor_material=None, spheres=False, sphere_lights=False):
+            floor_material=None, spheres=False, sphere_lights=False, glass_objects=None):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -194,6 +201,9 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     many_lights: n > 0 replaces the two quads by an n x n grid of small Rectangle lights under the ceiling (light-tree depth).
     spheres: two analytic Spheres (one Substitute-ish via `material`, one red) instead of / next to the boxes;
     sphere_lights: the two emitters are Spheres of diameter 0.3 instead of quads.
+    glass_objects: None, or a dict: the short box turns into glass (`box` = a glass(...) JSON), a glass Sphere (`sphere`)
+    stands in front of the tall box, optionally with a second dielectric inside it (`inner`, nested dielectrics);
+    `outside`: a glass Sphere next to the box, in front of the void (alpha through glass with a Transparent sensor).
     Returns a dict with prop ids.
     """
     mk = lambert if material == "lambert" else substitute
@@ -266,11 +276,18 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         ids["lights"].append(p)
 
     identity = trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))
+    glass_objects = glass_objects or {}
+    for key, pos_, d_ in (("sphere", (-0.35, 0.36, -0.5), 0.7), ("inner", (-0.35, 0.36, -0.5), 0.4), ("outside", (1.7, 1.0, -1.2), 0.9)):
+        if key in glass_objects:
+            p = engine.prop(SPHERE, [engine.material(glass_objects[key])])
+            engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (d_, d_, d_), pos_))
+            ids["meshes"].append(p)
     if boxes:
-        for lo, hi, rot in (((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0)):
+        for k, (lo, hi, rot) in enumerate((((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0))):
             idx, pos, nrm, uv = box_mesh(lo, hi, rot)
             shape = engine.triangle_mesh(idx, pos, nrm, uv)
-            p = engine.prop(shape, [white])
+            box_mat = engine.material(glass_objects["box"]) if 1 == k and "box" in glass_objects else white
+            p = engine.prop(shape, [box_mat])
             engine.transformation(p, identity)
             ids["meshes"].append(p)
     if mesh is not None:
