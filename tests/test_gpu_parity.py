@@ -359,3 +359,13 @@ def test_glass_alpha(engine, oracle):
     assert np.array_equal(film, cpu_film) and np.array_equal(alpha, cpu_alpha)
     resolved = alpha / film[..., 3]
     assert np.any((resolved > 0.02) & (resolved < 0.98))  # partially transparent pixels: the sphere in front of the void
+
+
+@pytest.mark.parametrize("integrator", ["PTMIS", "PTDL"])
+def test_outdoor_showcase(engine, oracle, integrator):
+    """The ingredients of BASELINE.json's configs[4] in one scene: ground, a mesh in polished metal (metal_preset), glass
+    (box and Sphere), a gold Sphere, a uniform Canopy sky and a Distant sun."""
+    mesh = scenes.heightfield_mesh(48, size=1.2, height=0.5)
+    out = _render_both(engine, oracle, 96, 54, 2, scene=scenes.outdoor, integrator=integrator, sun_radius=0.05, sky="canopy",
+                       showcase=True, mesh=mesh, material="substitute", max_depth=10)
+    _check(*out, 2)

@@ -322,12 +322,13 @@ def _basis_for(n):
 
 
 def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
-            extra_quad_light=False, max_depth=8, sky=None, sun=True):
+            extra_quad_light=False, max_depth=8, sky=None, sun=True, showcase=False, mesh=None):
     """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
     distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
     light tree mixes the infinite-light distribution with the BVH.  `sky`: "dome" (dome.zig, the whole sphere of
     directions) or "canopy" (canopy.zig, the hemisphere above the ground) with uniform emission; `sun=False` drops the
-    Distant light."""
+    Distant light.  showcase: the materials of BASELINE.json's configs[4] -- the red box turns into green glass, a glass
+    Sphere and a gold (metal_preset) Sphere stand on the ground; `mesh`: optional (idx, pos, nrm, uv) in polished iron."""
     mk = lambert if material == "lambert" else substitute
     cam = engine.camera(width, height, fov_deg=45.0)
     engine.samples_per_pixel(spp)
@@ -341,6 +342,16 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
     ground = engine.prop(RECTANGLE, [white])
     engine.transformation(ground, trafo((1, 0, 0), (0, 0, -1), (12, 12, 1), (0, 0, 0)))
     identity = trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))
+    if showcase:
+        red = engine.material(glass(1.5, (0.55, 0.9, 0.6), 0.4))
+        for pos_, d_, mat_ in (((-1.3, 0.35, -0.9), 0.7, glass(1.45)),
+                               ((1.4, 0.3, -0.4), 0.6, json.dumps({"rendering": {"Substitute": {"metal_preset": "Gold", "roughness": 0.25}}}))):
+            p = engine.prop(SPHERE, [engine.material(mat_)])
+            engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (d_, d_, d_), pos_))
+    if mesh is not None:
+        iron = engine.material(json.dumps({"rendering": {"Substitute": {"metal_preset": "Iron", "roughness": 0.1}}}))
+        p = engine.prop(engine.triangle_mesh(*mesh), [iron])
+        engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0.0, 0.01, -1.6)))
     for lo, hi, rot, mat in (((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0, white), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0, red)):
         idx, pos, nrm, uv = box_mesh(lo, hi, rot)
         p = engine.prop(engine.triangle_mesh(idx, pos, nrm, uv), [mat])
