@@ -147,6 +147,10 @@ typedef struct ZygpuMaterial {
     float    thickness;
     float    abbe;
     int32_t  priority;      /* material_base.zig:27: nested dielectrics, the higher priority wins (sample_base.zig:44) */
+    /* Light: emittance.emission_map as an image (emittance.zig:19, 49): radiance = emission * texel */
+    uint32_t emission_image;   /* index into ZygpuSceneDesc.images, ZYGPU_NULL = uniform */
+    uint32_t emission_sampler; /* ZYGPU_TEX_* bits */
+    float    emission_scale[2];
 } ZygpuMaterial;
 
 enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u };
@@ -217,6 +221,20 @@ typedef struct ZygpuMeshLight {
     uint32_t two_sided;
 } ZygpuMeshLight;
 
+/* Importance sampling of an emission map (light_material.zig:52-125 prepareSampling -> shape_sampler.zig:128-152 ImageImpl):
+ * a Distribution2D (base/math/distribution_2d.zig) over the texels' MIS-compensated luminance x shape.uvWeight.
+ * `rows`: 4 words per Distribution1D -- offset into cdf, size (entries of its cdf), offset into lut, lut_range (float bits);
+ * the conditional rows first, the marginal last (distribution_1d.zig:19-27) */
+typedef struct ZygpuImageLight {
+    const float*    cdf;
+    const uint32_t* lut;
+    const uint32_t* rows;
+    uint32_t num_rows;      /* conditional distributions = image height */
+    float    total_weight;  /* sum of the uv weights */
+    uint32_t sampler;       /* ZYGPU_TEX_* address bits of the emission map (ImageImpl.mode) */
+    uint32_t num_cdf, num_lut;
+} ZygpuImageLight;
+
 /* top-level BVH over props (reference src/core/scene/prop/prop_tree.zig:22-27) */
 typedef struct ZygpuPropTree {
     const ZygpuBvhNode* nodes;
@@ -249,6 +267,7 @@ typedef struct ZygpuSceneDesc {
     ZygpuPropTree        unoccluding; /* finite, purely emissive `Light` entities (scene.zig:78) */
     ZygpuLightTree       light_tree;
     const ZygpuMeshLight* mesh_lights;
+    const ZygpuImageLight* image_lights; /* ZygpuLight.sampler of the ZYGPU_LIGHT_PROP_IMAGE lights */
     const uint32_t*      infinite_props; /* props with an infinite shape (scene.zig:76), tested when a ray escapes */
     const ZygpuImage*    images;
     const float*         srgb_to_float; /* 256 entries: spectrum/srgb.zig:28-38 of i/255 (texture/encoding.zig:11,41-51) */
@@ -262,6 +281,7 @@ typedef struct ZygpuSceneDesc {
     uint32_t num_mesh_lights;
     uint32_t num_images;
     uint32_t num_infinite_props;
+    uint32_t num_image_lights;
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };

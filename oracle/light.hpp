@@ -10,6 +10,7 @@
 
 #include "sampler.hpp"
 #include "scene.hpp"
+#include "texture.hpp"
 
 namespace orc {
 
@@ -531,6 +532,87 @@ inline uint32_t canopySampleTo(V4 n, const Trafo& trafo, bool total_sphere, Samp
     return 1;
 }
 
+// ---------- Dome / Canopy with an emission map: dome.zig:40-56, 105-158, 222-234; canopy.zig:44-58, 94-133, 175-211 ----------
+
+inline void domeUv(V4 dir, const Trafo& trafo, float& u, float& v) {  // Dome.fragment's uvw
+    const V4 xyz = normalize3(trafo.transformVectorTransposed(dir));
+    u = atan2F(xyz[0], xyz[2]) * (kPiInv * 0.5f) + 0.5f;
+    v = acosF(xyz[1]) * kPiInv;
+}
+inline void hemisphereToDiskEquidistant(V4 dir, float& dx, float& dy) {
+    const float colatitude = acosF(dir[2]);
+    const float longitude = atan2F(-dir[1], dir[0]);
+    const float r = colatitude * (kPiInv * 2.f);
+    dx = r * cosF(longitude);
+    dy = r * sinF(longitude);
+}
+inline V4 diskToHemisphereEquidistant(float x, float y) {
+    const float longitude = atan2F(-y, x);
+    const float r = std::sqrt(x * x + y * y);
+    const float colatitude = r * (kPi / 2.f);
+    const float sin_col = sinF(colatitude), cos_col = cosF(colatitude);
+    const float sin_lon = sinF(longitude), cos_lon = cosF(longitude);
+    return mk(sin_col * cos_lon, sin_col * sin_lon, cos_col);
+}
+inline void canopyUv(V4 dir, const Trafo& trafo, float& u, float& v) {  // Canopy.fragment's uvw
+    const V4 xyz = normalize3(trafo.transformVectorTransposed(dir));
+    float    dx, dy;
+    hemisphereToDiskEquidistant(xyz, dx, dy);
+    u = 0.5f * dx + 0.5f;
+    v = 0.5f * dy + 0.5f;
+}
+
+inline uint32_t domeSampleMaterialTo(const ZygpuImageLight& il, V4 n, const Trafo& trafo, bool total_sphere, float split_threshold,
+                                     uint32_t light_samples, Sampler& sampler, SampleTo* buffer) {
+    const uint32_t num_samples = numSamples(light_samples, split_threshold);
+    const float    nsf = float(num_samples);
+    uint32_t       current = 0;
+    for (uint32_t i = 0; i < num_samples; ++i) {
+        float r2[2];
+        sampler.sample2D(r2);
+        float       u, v;
+        const float pdf = imageLightSample(il, r2[0], r2[1], u, v);
+        if (0.f == pdf) continue;
+        const float phi = (u - 0.5f) * (2.f * kPi), theta = v * kPi;
+        const float sin_phi = sinF(phi), cos_phi = cosF(phi), sin_theta = sinF(theta), cos_theta = cosF(theta);
+        const V4    dir = trafo.transformVector(mk(sin_phi * sin_theta, cos_theta, cos_phi * sin_theta));
+        if (dot3(dir, n) <= 0.f && !total_sphere) continue;
+        const V4 p = S(kRayMaxT) * dir;
+        buffer[current].p = mk(p[0], p[1], p[2], (nsf * pdf) / ((4.f * kPi) * sin_theta));
+        buffer[current].n = -dir;
+        buffer[current].wi = dir;
+        buffer[current].uvw = mk(u, v, 0.f, 0.f);
+        current += 1;
+    }
+    return current;
+}
+inline float domeMaterialPdf(const ZygpuImageLight& il, float u, float v, float split_threshold, uint32_t light_samples) {
+    const float sin_theta = sinF(v * kPi);
+    if (0.f == sin_theta) return 0.f;
+    const uint32_t num_samples = numSamples(light_samples, split_threshold);
+    const float    material_pdf = imageLightPdf(il, u, v) * float(num_samples);
+    return material_pdf / ((4.f * kPi) * sin_theta);
+}
+
+inline uint32_t canopySampleMaterialTo(const ZygpuImageLight& il, V4 n, const Trafo& trafo, bool total_sphere, Sampler& sampler,
+                                       SampleTo* buffer) {
+    float r2[2];
+    sampler.sample2D(r2);
+    float       u, v;
+    const float pdf = imageLightSample(il, r2[0], r2[1], u, v);
+    if (0.f == pdf) return 0;
+    const float dx = 2.f * u - 1.f, dy = 2.f * v - 1.f;
+    if (dx * dx + dy * dy > 1.f) return 0;
+    const V4 dir = trafo.transformVector(diskToHemisphereEquidistant(dx, dy));
+    if (dot3(dir, n) <= 0.f && !total_sphere) return 0;
+    const V4 p = S(kRayMaxT) * dir;
+    buffer[0].p = mk(p[0], p[1], p[2], pdf / (2.f * kPi));
+    buffer[0].n = -dir;
+    buffer[0].wi = dir;
+    buffer[0].uvw = mk(u, v, 0.f, 0.f);
+    return 1;
+}
+
 // ---------- Distant lights: distant.zig:21-146 ----------
 
 inline float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - std::sqrt(1.f / (radius * radius + 1.f))); }
@@ -745,11 +827,14 @@ inline Ray shadowRay(V4 origin, const SampleTo& sample, bool infinite_shape = fa
     return Ray::init(origin, shadow_axis / S(shadow_len), 0.f, shadow_len);
 }
 
-// emittance.zig:29-59 with uniform emission map / no profile; trafo_r2 = rs.trafo.rotation.r[2]
-inline V4 emittanceRadiance(const ZygpuMaterial& m, V4 wi, V4 trafo_r2, float area, bool in_camera) {
+// emittance.zig:29-59, no profile; trafo_r2 = rs.trafo.rotation.r[2]; (u, v) = rs.uv(), r = rs.stochastic_r for an emission map
+inline V4 emittanceRadiance(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, V4 wi, V4 trafo_r2, float area, bool in_camera, float u,
+                            float v, float r) {
     if (-dot3(wi, trafo_r2) < m.cos_a) return S(0.f);
     const float factor = in_camera ? m.camera_weight : 1.f;
-    const V4    intensity = mk(m.emission[0], m.emission[1], m.emission[2], 0.f) * S(1.f);
+    const V4    texel = kNull != m.emission_image ? sampleImageMap(scene, m.emission_image, m.emission_sampler, m.emission_scale, u, v, r)
+                                                  : S(1.f);
+    const V4    intensity = mk(m.emission[0], m.emission[1], m.emission[2], 0.f) * texel;
     if (m.emission_normalize) return S(factor / area) * intensity;
     return S(factor) * intensity;
 }

@@ -19,6 +19,7 @@
 
 #include "sampler.hpp"
 #include "scene.hpp"
+#include "texture.hpp"
 
 namespace orc {
 
@@ -435,52 +436,6 @@ struct MaterialSample {
 };
 
 // Material.sample (material.zig:184-194) for the kinds in scope
-// ---- 2-D image textures: texture_sampler.zig:84-168 (Nearest2D / LinearStochastic2D), sampler_mode.zig:20-88, texture.zig:188-219
-inline float texAddress(bool repeat, float x) { return repeat ? x - std::floor(x) : clampf(x, 0.f, 1.f); }
-inline int   texCoord(bool repeat, int c, int end) {
-    if (repeat) {
-        const int m = c % end;  // @mod: the result has the sign of the divisor
-        return m < 0 ? m + end : m;
-    }
-    return std::max(std::min(c, end - 1), 0);
-}
-inline V4 imageFetch3(const ZygpuSceneDesc& scene, const ZygpuImage& img, int x, int y) {
-    const size_t i = size_t(y) * size_t(img.width) + size_t(x);
-    if (ZYGPU_IMAGE_BYTE3_SRGB == img.format) {
-        const uint8_t* p = static_cast<const uint8_t*>(img.pixels) + 3 * i;
-        const float    r = scene.srgb_to_float[p[0]], g = scene.srgb_to_float[p[1]], b = scene.srgb_to_float[p[2]];
-        return mk(0.61309732f, 0.07019422f, 0.02061560f) * S(r) + mk(0.33952285f, 0.91635557f, 0.10956983f) * S(g) +
-               mk(0.04737928f, 0.01345259f, 0.86981512f) * S(b);  // aces.zig:9-17
-    }
-    const float* p = static_cast<const float*>(img.pixels) + 3 * i;
-    return mk(p[0], p[1], p[2]);
-}
-// ts.sample2D_3 for an image texture (rs.uv(), rs.stochastic_r)
-inline V4 sampleColorMap(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, float u, float v, float r) {
-    const ZygpuImage& img = scene.images[m.color_image];
-    const bool        ru = 0 != (m.color_sampler & ZYGPU_TEX_REPEAT_U), rv = 0 != (m.color_sampler & ZYGPU_TEX_REPEAT_V);
-    const float       su = m.color_scale[0] * u, sv = m.color_scale[1] * v;
-    const float       dw = float(img.width), dh = float(img.height);
-    if (!(m.color_sampler & ZYGPU_TEX_LINEAR)) {
-        const int x = std::min(int(texAddress(ru, su) * dw), img.width - 1), y = std::min(int(texAddress(rv, sv) * dh), img.height - 1);
-        return imageFetch3(scene, img, x, y);
-    }
-    const float mx_ = texAddress(ru, su) * dw - 0.5f, my_ = texAddress(rv, sv) * dh - 0.5f;
-    const float fx = std::floor(mx_), fy = std::floor(my_);
-    const float wx = mx_ - fx, wy = my_ - fy;
-    const float ox = 1.f - wx, oy = 1.f - wy;
-    int         x = int(fx), y = int(fy), index = 0;
-    float       threshold = ox * oy;
-    index += r > threshold ? 1 : 0;
-    threshold = std::fmaf(wx, oy, threshold);
-    index += r > threshold ? 1 : 0;
-    threshold = std::fmaf(ox, wy, threshold);
-    index += r > threshold ? 1 : 0;
-    x += index & 1;
-    y += (index & 2) >> 1;
-    return imageFetch3(scene, img, texCoord(ru, x, img.width), texCoord(rv, y, img.height));
-}
-
 inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDesc& scene, V4 wo, const Renderstate& rs) {
     MaterialSample s{};
     s.kind = m.kind;

@@ -170,10 +170,12 @@ struct Worker {
 
     // Material.evaluateRadiance for Light / Substitute (material.zig:196-212; light_material.zig:131-140;
     // substitute_material.zig:275-296 without coating)
-    V4 materialRadiance(const ZygpuMaterial& m, V4 wi, const Trafo& trafo, uint32_t prop, uint32_t part, bool in_camera) const {
+    // (u, v) = rs.uv(), r = rs.stochastic_r: the emission map's stochastic-bilinear fetch (emittance.zig:49)
+    V4 materialRadiance(const ZygpuMaterial& m, V4 wi, const Trafo& trafo, uint32_t prop, uint32_t part, bool in_camera, float u = 0.f,
+                        float v = 0.f, float r = 0.f) const {
         if (ZYGPU_MAT_LIGHT != m.kind && ZYGPU_MAT_SUBSTITUTE != m.kind) return S(0.f);
         const float area = m.emission_normalize ? shapeArea(prop, part, trafo) : 1.f;
-        return emittanceRadiance(m, wi, trafo.r[2], area, in_camera);
+        return emittanceRadiance(*rc->scene, m, wi, trafo.r[2], area, in_camera, u, v, r);
     }
 
     // scene.zig:624-634
@@ -184,7 +186,11 @@ struct Worker {
         const ZygpuLight& l = rc->scene->lights[light_id];
         // light.zig:149-157 -> shape.zig:469-492 -> rectangle.zig:554-575 / triangle_mesh.zig:647-691
         const float sample_pdf =
-            kNull != l.sampler
+            ZYGPU_LIGHT_PROP_IMAGE == l.light_class  // light.zig:371-374 -> shape.zig:509-526
+                ? (ZYGPU_SHAPE_DOME == rc->scene->props[l.prop].shape
+                       ? domeMaterialPdf(rc->scene->image_lights[l.sampler], frag.uvw[0], frag.uvw[1], v.light_split_threshold, l.num_samples)
+                       : imageLightPdf(rc->scene->image_lights[l.sampler], frag.uvw[0], frag.uvw[1]) / (2.f * kPi))
+            : kNull != l.sampler
                 ? meshPdf(*rc->scene, rc->scene->mesh_lights[l.sampler], v.ray.direction, v.origin, v.geo_n, frag, v.state.translucent,
                           v.light_split_threshold)
             : ZYGPU_SHAPE_DISTANT == rc->scene->props[l.prop].shape
@@ -202,9 +208,9 @@ struct Worker {
         const V4             wo = -v.ray.direction;
         const ZygpuMaterial& m = rc->sv.propMaterial(frag.prop, frag.part);
         if (!(m.flags & ZYGPU_MATF_EMISSIVE) || (!(m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo))) return S(0.f);
-        (void)sampler.sample1D();  // rs.stochastic_r
+        const float stochastic_r = sampler.sample1D();  // rs.stochastic_r
         const bool  in_camera = 0 == v.depth_surface;
-        const V4    energy = materialRadiance(m, wo, frag.isec.trafo, frag.prop, frag.part, in_camera);
+        const V4    energy = materialRadiance(m, wo, frag.isec.trafo, frag.prop, frag.part, in_camera, frag.uvw[0], frag.uvw[1], stochastic_r);
         const float weight = lightPdf(v, frag);
         return S(weight) * energy;
     }
@@ -391,7 +397,10 @@ struct Worker {
                 if (v.ray.max_t < kRayMaxT) continue;
                 if (ZYGPU_SHAPE_CANOPY == prop.shape && dot3(v.ray.direction, frag.isec.trafo.r[2]) < kCanopyEps) continue;
                 frag.geo_n = frag.n = -v.ray.direction;
-                frag.uvw = S(0.f);  // only addresses emission maps
+                float eu, ev;
+                if (ZYGPU_SHAPE_DOME == prop.shape) domeUv(v.ray.direction, frag.isec.trafo, eu, ev);
+                else canopyUv(v.ray.direction, frag.isec.trafo, eu, ev);
+                frag.uvw = mk(eu, ev, 0.f, 0.f);
             }
             frag.prop = p;
             frag.isec.t = kRayMaxT;
@@ -462,7 +471,12 @@ struct Worker {
             const uint32_t light_shape = rc->scene->props[light.prop].shape;
             const bool     distant = ZYGPU_SHAPE_DISTANT == light_shape || ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_CANOPY == light_shape;
             const uint32_t num_samples =
-                kNull != light.sampler
+                ZYGPU_LIGHT_PROP_IMAGE == light.light_class  // light.zig:191-215 -> shape.zig:348-371
+                    ? (ZYGPU_SHAPE_DOME == light_shape
+                           ? domeSampleMaterialTo(rc->scene->image_lights[light.sampler], n, trafo, translucent, sample_threshold,
+                                                  light.num_samples, sampler, samples)
+                           : canopySampleMaterialTo(rc->scene->image_lights[light.sampler], n, trafo, translucent, sampler, samples))
+                : kNull != light.sampler
                     ? meshSampleTo(*rc->scene, rc->scene->mesh_lights[light.sampler], p, n, trafo, 0 != light.two_sided, translucent,
                                    sample_threshold, sampler, samples)
                 : ZYGPU_SHAPE_DOME == light_shape   ? domeSampleTo(n, translucent, sampler, samples)
@@ -481,16 +495,16 @@ struct Worker {
                 if (!rc->sv.visibility(shadow, cnt)) continue;
 
                 if (mis) {
-                    (void)sampler.sample1D();  // light.zig:127 rs.stochastic_r
-                    const V4         radiance = materialRadiance(lm, ls.wi, trafo, light.prop, light.part, false);
+                    const float      lr = sampler.sample1D();  // light.zig:127 rs.stochastic_r
+                    const V4         radiance = materialRadiance(lm, ls.wi, trafo, light.prop, light.part, false, ls.uvw[0], ls.uvw[1], lr);
                     const BxdfResult bx = ms.evaluate(ls.wi, false);
                     const float      light_pdf = ls.pdf() * pick.pdf;
                     const float      weight = predividedPowerHeuristic(light_pdf, bx.pdf);
                     occluded += S(weight) * radiance * bx.reflection;
                 } else {
                     const BxdfResult bx = ms.evaluate(ls.wi, false);
-                    (void)sampler.sample1D();
-                    const V4    radiance = materialRadiance(lm, ls.wi, trafo, light.prop, light.part, false);
+                    const float lr = sampler.sample1D();
+                    const V4    radiance = materialRadiance(lm, ls.wi, trafo, light.prop, light.part, false, ls.uvw[0], ls.uvw[1], lr);
                     const float weight = 1.f / (pick.pdf * ls.pdf());
                     occluded += S(weight) * (S(1.f) * radiance * bx.reflection);
                 }

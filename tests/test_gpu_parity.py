@@ -369,3 +369,28 @@ def test_outdoor_showcase(engine, oracle, integrator):
     out = _render_both(engine, oracle, 96, 54, 2, scene=scenes.outdoor, integrator=integrator, sun_radius=0.05, sky="canopy",
                        showcase=True, mesh=mesh, material="substitute", max_depth=10)
     _check(*out, 2)
+
+
+@pytest.mark.parametrize("integrator,sky,samples,sun", [("PT", "dome", 1, False), ("PTDL", "canopy", 1, True), ("PTMIS", "dome", 1, True),
+                                                         ("PTMIS", "dome", 4, False), ("PTMIS", "canopy", 1, False)])
+def test_image_lights(engine, oracle, integrator, sky, samples, sun):
+    """Environment maps: a Light material with an emission map on a Dome (lat-long) or Canopy (equidistant disc), sampled
+    through the map's Distribution2D (light_material.zig:52-125, dome.zig:105-158, 222-234, canopy.zig:94-133), evaluated
+    with the stochastic-bilinear fetch for escaping rays and light samples alike."""
+    out = _render_both(engine, oracle, 80, 60, 3, scene=scenes.outdoor, integrator=integrator, sun=sun, sun_radius=0.06, sky=sky,
+                       sky_map=scenes.sky_image(), sky_samples=samples, sky_spectrum=(1.0, 1.0, 1.0), material="substitute")
+    _check(*out, 3)
+    assert integrator == "PT" or out[2].shadow_rays > 0
+
+
+def test_image_light_srgb_map(engine, oracle):
+    """An 8-bit sRGB emission map with nearest filtering and clamped addressing."""
+    img = (np.clip(scenes.sky_image(48, 24) / 3.0, 0, 1) * 255).astype(np.uint8)
+
+    def scene(e, w, h, spp, **kw):
+        ids = scenes.outdoor(e, w, h, spp, **kw)
+        return ids
+
+    out = _render_both(engine, oracle, 64, 48, 2, scene=scenes.outdoor, integrator="PTMIS", sun=False, sky="dome", sky_map=img,
+                       sky_spectrum=(2.0, 2.0, 2.0))
+    _check(*out, 2)

@@ -370,3 +370,41 @@ def test_glass_integrators_agree(product_lib, oracle):
             plain[key] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
     np.testing.assert_allclose(plain["ghost"], plain["none"], rtol=0.01)
     assert abs(means["PTMIS"][0] - plain["none"][0]) > 0.005  # real glass does change the picture
+
+
+@pytest.mark.parametrize("sky", ["dome", "canopy"])
+def test_image_light_matches_uniform_light(product_lib, oracle, sky):
+    """An emission map of constant value c is the uniform light of radiance c: the importance-sampled image light
+    (Distribution2D over luminance x uv weight, dome.zig:105-158 / canopy.zig:94-133) and the uniformly sampled
+    Dome / Canopy estimate the same image."""
+    w, h, spp = 40, 30, 256
+    means = {}
+    for key, kw in (("uniform", dict(sky_spectrum=(0.7, 1.0, 1.6))),
+                    ("map", dict(sky_spectrum=(0.35, 0.5, 0.8), sky_map=scenes.sky_image(32, 16, uniform=2.0)))):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.outdoor(e, w, h, spp, integrator="PTMIS", sun=False, sky=sky, max_depth=5, **kw)
+            sd, vd = e.compile()
+            assert sd.num_image_lights == (1 if key == "map" else 0)
+            img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(img).all()
+            means[key] = img[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["map"], means["uniform"], rtol=0.015)
+
+
+@pytest.mark.parametrize("sky", ["dome", "canopy"])
+def test_image_light_integrators_agree(product_lib, oracle, sky):
+    """A non-uniform environment map (gradient + a small bright blob): light sampling by the map (PTDL), MIS and plain path
+    tracing agree; so does splitting the light into 4 samples."""
+    w, h, spp = 40, 30, 512
+    means = {}
+    for key, integ, n in (("PT", "PT", 1), ("PTDL", "PTDL", 1), ("PTMIS", "PTMIS", 1), ("PTMIS4", "PTMIS", 4)):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.outdoor(e, w, h, spp, integrator=integ, sun=False, sky=sky, max_depth=4, sky_map=scenes.sky_image(), sky_samples=n,
+                           sky_spectrum=(1.0, 1.0, 1.0))
+            sd, vd = e.compile()
+            img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(img).all()
+            means[key] = img[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.02)
+    np.testing.assert_allclose(means["PTMIS4"], means["PTMIS"], rtol=0.02)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.1)

@@ -52,7 +52,8 @@ class Material(ctypes.Structure):
                 ("emission_normalize", ctypes.c_uint32), ("emission_num_samples", ctypes.c_uint32),
                 ("color_image", ctypes.c_uint32), ("color_sampler", ctypes.c_uint32), ("color_scale", ctypes.c_float * 2),
                 ("absorption", ctypes.c_float * 3), ("thickness", ctypes.c_float), ("abbe", ctypes.c_float),
-                ("priority", ctypes.c_int32)]
+                ("priority", ctypes.c_int32), ("emission_image", ctypes.c_uint32), ("emission_sampler", ctypes.c_uint32),
+                ("emission_scale", ctypes.c_float * 2)]
 
 
 class Image(ctypes.Structure):
@@ -85,6 +86,12 @@ class MeshLight(ctypes.Structure):
                 ("num_triangles", ctypes.c_uint32), ("two_sided", ctypes.c_uint32)]
 
 
+class ImageLight(ctypes.Structure):
+    _fields_ = [("cdf", ctypes.POINTER(ctypes.c_float)), ("lut", ctypes.POINTER(ctypes.c_uint32)),
+                ("rows", ctypes.POINTER(ctypes.c_uint32)), ("num_rows", ctypes.c_uint32), ("total_weight", ctypes.c_float),
+                ("sampler", ctypes.c_uint32), ("num_cdf", ctypes.c_uint32), ("num_lut", ctypes.c_uint32)]
+
+
 class PropTree(ctypes.Structure):
     _fields_ = [("nodes", ctypes.POINTER(BvhNode)), ("indices", ctypes.POINTER(ctypes.c_uint32)),
                 ("num_nodes", ctypes.c_uint32), ("num_indices", ctypes.c_uint32)]
@@ -102,12 +109,13 @@ class SceneDesc(ctypes.Structure):
                 ("meshes", ctypes.POINTER(Mesh)), ("materials", ctypes.POINTER(Material)),
                 ("lights", ctypes.POINTER(Light)), ("light_aabbs", ctypes.POINTER(Aabb)),
                 ("light_cones", ctypes.POINTER(ctypes.c_float)), ("solid", PropTree), ("unoccluding", PropTree),
-                ("light_tree", LightTree), ("mesh_lights", ctypes.POINTER(MeshLight)), ("infinite_props", ctypes.POINTER(ctypes.c_uint32)), ("images", ctypes.POINTER(Image)),
+                ("light_tree", LightTree), ("mesh_lights", ctypes.POINTER(MeshLight)), ("image_lights", ctypes.POINTER(ImageLight)),
+                ("infinite_props", ctypes.POINTER(ctypes.c_uint32)), ("images", ctypes.POINTER(Image)),
                 ("srgb_to_float", ctypes.POINTER(ctypes.c_float)), ("luts", Luts),
                 ("specular_threshold", ctypes.c_float),
                 ("num_props", ctypes.c_uint32), ("num_parts", ctypes.c_uint32), ("num_meshes", ctypes.c_uint32),
                 ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32), ("num_mesh_lights", ctypes.c_uint32),
-                ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32)]
+                ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32), ("num_image_lights", ctypes.c_uint32)]
 
 
 class ViewDesc(ctypes.Structure):

@@ -7,6 +7,7 @@
 
 #include "dsampler.hpp"
 #include "dscene.hpp"
+#include "dtexture.hpp"
 
 namespace zd {
 
@@ -370,6 +371,7 @@ struct SphQuad {  // rectangle.zig:199-303
 struct SampleTo {  // shape/sample.zig:7-29
     f3    p, n, wi;
     float pdf;
+    float u = 0.f, v = 0.f;  // uvw: set by the image lights only (it addresses the emission map)
 };
 
 // rectangle.zig:305-357 (UseSphericalSampling): the set-up shared by a light's samples, then one sample per 2-D draw
@@ -566,6 +568,125 @@ ZD bool canopySampleTo(f3 n, const Trafo& trafo, bool total_sphere, Sampler& sam
     return true;
 }
 
+// ---------------------------------------------------------------- image lights: emission maps on Dome / Canopy
+// Distribution1D / 2D over the flattened rows (base/math/distribution_1d.zig:49-102, 209-217, distribution_2d.zig:67-90),
+// ImageImpl (shape_sampler.zig:128-152)
+struct Dist1D {
+    const float*    cdf;
+    const uint32_t* lut;
+    uint32_t        size;
+    float           lut_range;
+    ZD static Dist1D row(const DImageLight& il, uint32_t r) {
+        const uint4 w = il.rows[r];
+        return {il.cdf + w.x, il.lut + w.z, w.y, __uint_as_float(w.w)};
+    }
+    ZD uint32_t sample(float r) const {
+        const uint32_t bucket = uint32_t(r * lut_range);
+        uint32_t       i = lut[bucket];
+        const uint32_t end = size - 1;
+        for (; i < end; ++i)
+            if (cdf[i] >= r) break;
+        return i - 1;
+    }
+    ZD void sampleContinuous(float r, float& offset_out, float& pdf) const {
+        const uint32_t offset = sample(r);
+        const float    c = cdf[offset + 1];
+        const float    v = c - cdf[offset];
+        if (0.f == v) {
+            offset_out = 0.f;
+            pdf = 0.f;
+            return;
+        }
+        const float t = (c - r) / v;
+        offset_out = (float(offset) + t) / float(size - 1);
+        pdf = v;
+    }
+    ZD float pdfF(float u) const {
+        const uint32_t o = min(uint32_t(u * float(size - 1)), size - 2);
+        return cdf[o + 1] - cdf[o];
+    }
+};
+
+ZD float imageLightSample(const DImageLight& il, float r0, float r1, float& u, float& v) {  // pdf * total_weight
+    float v_pdf, u_pdf;
+    Dist1D::row(il, il.num_rows).sampleContinuous(r1, v, v_pdf);
+    const uint32_t c = min(uint32_t(v * float(il.num_rows)), il.num_rows - 1);
+    Dist1D::row(il, c).sampleContinuous(r0, u, u_pdf);
+    return (u_pdf * v_pdf) * il.total_weight;
+}
+ZD float imageLightPdf(const DImageLight& il, float u, float v) {
+    const float    au = texAddress(0 != (il.sampler & ZYGPU_TEX_REPEAT_U), u), av = texAddress(0 != (il.sampler & ZYGPU_TEX_REPEAT_V), v);
+    const float    v_pdf = Dist1D::row(il, il.num_rows).pdfF(av);
+    const uint32_t c = min(uint32_t(av * float(il.num_rows)), il.num_rows - 1);
+    const float    u_pdf = Dist1D::row(il, c).pdfF(au);
+    return (u_pdf * v_pdf) * il.total_weight;
+}
+
+ZD void domeUv(f3 dir, const Trafo& trafo, float& u, float& v) {  // Dome.fragment's uvw (dome.zig:40-49)
+    const f3 xyz = normalize3(trafo.transformVectorTransposed(dir));
+    u = atan2F(xyz.x, xyz.z) * (kPiInv * 0.5f) + 0.5f;
+    v = acosF(xyz.y) * kPiInv;
+}
+ZD void canopyUv(f3 dir, const Trafo& trafo, float& u, float& v) {  // Canopy.fragment's uvw (canopy.zig:44-52, 175-187)
+    const f3    xyz = normalize3(trafo.transformVectorTransposed(dir));
+    const float colatitude = acosF(xyz.z);
+    const float longitude = atan2F(-xyz.y, xyz.x);
+    const float r = colatitude * (kPiInv * 2.f);
+    u = 0.5f * (r * cosF(longitude)) + 0.5f;
+    v = 0.5f * (r * sinF(longitude)) + 0.5f;
+}
+ZD f3 diskToHemisphereEquidistant(float x, float y) {  // canopy.zig:189-211
+    const float longitude = atan2F(-y, x);
+    const float r = sqrtf(x * x + y * y);
+    const float colatitude = r * (kPi / 2.f);
+    const float sin_col = sinF(colatitude), cos_col = cosF(colatitude);
+    const float sin_lon = sinF(longitude), cos_lon = cosF(longitude);
+    return mk3(sin_col * cos_lon, sin_col * sin_lon, cos_col);
+}
+
+// one sample of Dome.sampleMaterialTo (dome.zig:105-158) from its 2-D draw; nsf = the light's sample count
+ZD bool domeSampleMaterial(const DImageLight& il, float r0, float r1, float nsf, f3 n, const Trafo& trafo, bool total_sphere, SampleTo& out) {
+    float       u, v;
+    const float pdf = imageLightSample(il, r0, r1, u, v);
+    if (0.f == pdf) return false;
+    const float phi = (u - 0.5f) * (2.f * kPi), theta = v * kPi;
+    const float sin_phi = sinF(phi), cos_phi = cosF(phi), sin_theta = sinF(theta), cos_theta = cosF(theta);
+    const f3    dir = trafo.transformVector(mk3(sin_phi * sin_theta, cos_theta, cos_phi * sin_theta));
+    if (dot3(dir, n) <= 0.f && !total_sphere) return false;
+    out.p = S3(kRayMaxT) * dir;
+    out.n = -dir;
+    out.wi = dir;
+    out.pdf = (nsf * pdf) / ((4.f * kPi) * sin_theta);
+    out.u = u;
+    out.v = v;
+    return true;
+}
+ZD float domeMaterialPdf(const DImageLight& il, float u, float v, uint32_t num_samples) {  // dome.zig:222-234
+    const float sin_theta = sinF(v * kPi);
+    if (0.f == sin_theta) return 0.f;
+    const float material_pdf = imageLightPdf(il, u, v) * float(num_samples);
+    return material_pdf / ((4.f * kPi) * sin_theta);
+}
+// Canopy.sampleMaterialTo (canopy.zig:94-133)
+ZD bool canopySampleMaterialTo(const DImageLight& il, f3 n, const Trafo& trafo, bool total_sphere, Sampler& sampler, SampleTo& out) {
+    float r0, r1;
+    sampler.sample2D(r0, r1);
+    float       u, v;
+    const float pdf = imageLightSample(il, r0, r1, u, v);
+    if (0.f == pdf) return false;
+    const float dx = 2.f * u - 1.f, dy = 2.f * v - 1.f;
+    if (dx * dx + dy * dy > 1.f) return false;
+    const f3 dir = trafo.transformVector(diskToHemisphereEquidistant(dx, dy));
+    if (dot3(dir, n) <= 0.f && !total_sphere) return false;
+    out.p = S3(kRayMaxT) * dir;
+    out.n = -dir;
+    out.wi = dir;
+    out.pdf = pdf / (2.f * kPi);
+    out.u = u;
+    out.v = v;
+    return true;
+}
+
 // ---------------------------------------------------------------- TriangleMesh lights (triangle_mesh.zig:391-703)
 
 ZD f3 orthogonalize(f3 a, f3 b) { return normalize3(fma3(S3(-dot3(a, b)), a, b)); }  // a is normalised (391-394)
@@ -718,11 +839,14 @@ ZD void shadowRay(f3 origin, const SampleTo& sample, f3& dir, float& len, bool i
     dir = shadow_axis / S3(len);
 }
 
-// emittance.zig:29-59, uniform emission map, no profile
-ZD f3 emittanceRadiance(const ZygpuMaterial& m, f3 wi, f3 trafo_r2, float area, bool in_camera) {
+// emittance.zig:29-59, no profile; TEX: the scene can have emission maps, (u, v) = rs.uv(), r = rs.stochastic_r
+template <bool TEX>
+ZD f3 emittanceRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, f3 trafo_r2, float area, bool in_camera, float u, float v, float r) {
     if (-dot3(wi, trafo_r2) < m.cos_a) return S3(0.f);
     const float factor = in_camera ? m.camera_weight : 1.f;
-    const f3    intensity = mk3(m.emission[0], m.emission[1], m.emission[2]) * S3(1.f);
+    const f3    texel = (TEX && kNull != m.emission_image) ? sampleImageMap(s, m.emission_image, m.emission_sampler, m.emission_scale, u, v, r)
+                                                           : S3(1.f);
+    const f3    intensity = mk3(m.emission[0], m.emission[1], m.emission[2]) * texel;
     if (m.emission_normalize) return S3(factor / area) * intensity;
     return S3(factor) * intensity;
 }

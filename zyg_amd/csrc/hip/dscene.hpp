@@ -59,6 +59,15 @@ struct DMeshLight {
     uint32_t        mesh, part;
 };
 
+struct DImageLight {  // ZygpuImageLight on the device
+    const float*    cdf;
+    const uint32_t* lut;
+    const uint4*    rows;  // cdf offset, size, lut offset, lut_range bits
+    uint32_t        num_rows;
+    float           total_weight;
+    uint32_t        sampler;
+};
+
 struct DScene {
     const ZygpuProp*     props;
     const float4*        trafos; // 4 per prop: r0(+sx), r1(+sy), r2(+sz), position
@@ -76,6 +85,7 @@ struct DScene {
     const uint32_t*      unocc_indices;
     DLightTree           light_tree;
     const DMeshLight*    mesh_lights;
+    const DImageLight*   image_lights;
     const uint32_t*      infinite_props;
     uint32_t             num_infinite_props;
     const DImage*        images;

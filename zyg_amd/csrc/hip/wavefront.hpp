@@ -664,11 +664,13 @@ ZD float shapeArea(const DScene& s, uint32_t prop, uint32_t part, const Trafo& t
 }
 
 // Material.evaluateRadiance for Light / Substitute (material.zig:196-212, light_material.zig:131-140)
+// TEX (= the MESHL instantiations): emission maps, addressed by (u, v) with the stochastic filter's r
+template <bool TEX = false>
 ZD f3 materialRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, const Trafo& trafo, uint32_t prop, uint32_t part,
-                       bool in_camera) {
+                       bool in_camera, float u = 0.f, float v = 0.f, float r = 0.f) {
     if (ZYGPU_MAT_LIGHT != m.kind && ZYGPU_MAT_SUBSTITUTE != m.kind) return S3(0.f);
     const float area = m.emission_normalize ? shapeArea(s, prop, part, trafo) : 1.f;
-    return emittanceRadiance(m, wi, trafo.r2, area, in_camera);
+    return emittanceRadiance<TEX>(s, m, wi, trafo.r2, area, in_camera, u, v, r);
 }
 
 struct VertexIn {  // what connectLight needs of the previous vertex (vertex.zig:45-65)
@@ -687,7 +689,12 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
     const float      select_pdf = lt.pdf(v.vorigin, v.vgeo_n, translucent, v.light_split_threshold, light_id);
     const ZygpuLight light = s.lights[light_id];
     float            sample_pdf;
-    if (MESHL && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
+    if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {  // light.zig:371-374 -> shape.zig:509-526
+        const DImageLight& il = s.image_lights[light.sampler];
+        sample_pdf = ZYGPU_SHAPE_DOME == s.props[light.prop].shape
+                         ? domeMaterialPdf(il, frag.uv0, frag.uv1, numSamples(light.num_samples, v.light_split_threshold))
+                         : imageLightPdf(il, frag.uv0, frag.uv1) / (2.f * kPi);
+    } else if (MESHL && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
         sample_pdf = meshLightPdf(s, s.mesh_lights[light.sampler], ray_direction, v.vorigin, v.vgeo_n, frag.trafo, frag.p, frag.geo_n,
                                   frag.primitive, translucent, v.light_split_threshold);
     } else if (MESHL && ZYGPU_SHAPE_DISTANT == s.props[light.prop].shape) {  // -> distant.zig:139-141
@@ -709,8 +716,8 @@ template <bool MESHL>
 ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment& frag, Sampler& smp) {
     const ZygpuMaterial& m = s.materials[s.material_ids[s.props[frag.prop].parts_start + frag.part]];
     if (!(m.flags & ZYGPU_MATF_EMISSIVE) || (!(m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo))) return S3(0.f);
-    (void)smp.sample1D();  // rs.stochastic_r
-    const f3    energy = materialRadiance(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface);
+    const float stochastic_r = smp.sample1D();  // rs.stochastic_r
+    const f3    energy = materialRadiance<MESHL>(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface, frag.uv0, frag.uv1, stochastic_r);
     const float weight = lightPdf<MESHL>(s, v, -wo, frag);
     return S3(weight) * energy;
 }
@@ -740,7 +747,8 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
             if (ray.max_t < kRayMaxT) continue;
             if (ZYGPU_SHAPE_CANOPY == prop.shape && dot3(ray.direction, frag.trafo.r2) < kCanopyEps) continue;
             frag.geo_n = frag.n = -ray.direction;
-            frag.uv0 = frag.uv1 = 0.f;  // only addresses emission maps
+            if (ZYGPU_SHAPE_DOME == prop.shape) domeUv(ray.direction, frag.trafo, frag.uv0, frag.uv1);
+            else canopyUv(ray.direction, frag.trafo, frag.uv0, frag.uv1);
         }
         frag.prop = p;
         frag.t_hit = kRayMaxT;
@@ -839,7 +847,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                     emissive = 0 != (s.materials[s.material_ids[hp.parts_start + part]].flags & ZYGPU_MATF_EMISSIVE);
                 }
                 // infinite props: PathtracerMIS looks at them when the ray left the scene, the other two always walk the list
-                const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || !has_hit);
+                const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || (!has_hit && kRayMaxT == ro.w));
                 defer = connectsLights(h.flags) && (emissive || 0 != P.pool.ucount[slot] || infinite);
             }
             if (!defer) {
@@ -875,7 +883,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                     tm.mark(1);
                     energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
                     tm.mark(2);
-                    if (MESHL && !has_hit) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);  // RayMaxT == max_t
+                    // RayMaxT == max_t (pathtracer_mis.zig:313): not for a ray that ended at its medium's bounds
+                    if (MESHL && !has_hit && kRayMaxT == ray.max_t) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
                 }
             }
             const float4 thr4 = P.pool.thr[slot];
@@ -1276,9 +1285,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
                     if (STATS) shadow_rays += 1;
                     if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
-                    const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
+                    const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
+                    const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                     const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
-                    (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     if (mis) {
                         const float light_pdf = ls.pdf * pick.pdf;
                         const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
@@ -1292,7 +1301,27 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 // A shape's sampleTo draws all of its light samples before the first shadow test (rectangle.zig:321-352,
                 // triangle_mesh.zig:513-592); instead of buffering them, a copy of the sampler replays those draws while
                 // the path's sampler runs ahead to where the post-visibility draws continue.
-                if (MESHL && kNull != light.sampler) {
+                if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
+                    // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
+                    const DImageLight& il = s.image_lights[light.sampler];
+                    if (ZYGPU_SHAPE_DOME == light_shape) {
+                        const uint32_t n = numSamples(light.num_samples, sample_threshold);
+                        Sampler        replay = h.smp;
+                        for (uint32_t j = 0; j < n; ++j) {
+                            float a, b;
+                            h.smp.sample2D(a, b);
+                        }
+                        for (uint32_t j = 0; j < n; ++j) {
+                            float r0, r1;
+                            replay.sample2D(r0, r1);
+                            SampleTo ls;
+                            if (domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
+                        }
+                    } else {
+                        SampleTo ls;
+                        if (canopySampleMaterialTo(il, ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
+                    }
+                } else if (MESHL && kNull != light.sampler) {
                     const DMeshLight&      ml = s.mesh_lights[light.sampler];
                     const DMesh&           mesh = s.meshes[ml.mesh];
                     const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);

@@ -450,7 +450,12 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
         // the same kernel instantiations carry the infinite and Sphere light code
         if (is_infinite || ZYGPU_SHAPE_SPHERE == lp.shape) c->mesh_lights = true;
-        if (is_mesh) {
+        if (ZYGPU_LIGHT_PROP_IMAGE == d->lights[l].light_class) {
+            if ((ZYGPU_SHAPE_DOME != lp.shape && ZYGPU_SHAPE_CANOPY != lp.shape) || d->lights[l].sampler >= d->num_image_lights) {
+                g_error = "image lights (emission maps) are supported on Dome and Canopy, with their ZygpuImageLight";
+                return -2;
+            }
+        } else if (is_mesh) {
             if (d->lights[l].sampler >= d->num_mesh_lights) {
                 g_error = "a TriangleMesh light without its ZygpuMeshLight (ZygpuLight.sampler)";
                 return -2;
@@ -585,6 +590,23 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         dl.part = hl.part;
     }
     if (!m.upload(mesh_lights.data(), mesh_lights.size(), &s.mesh_lights)) return -1;
+    std::vector<DImageLight> image_lights(d->num_image_lights);
+    for (uint32_t i = 0; i < d->num_image_lights; ++i) {
+        const ZygpuImageLight& hl = d->image_lights[i];
+        DImageLight&           dl = image_lights[i];
+        ok = m.upload(hl.cdf, hl.num_cdf, &dl.cdf) && m.upload(hl.lut, hl.num_lut, &dl.lut) &&
+             m.upload(reinterpret_cast<const uint4*>(hl.rows), size_t(hl.num_rows) + 1, &dl.rows);
+        if (!ok) return -1;
+        dl.num_rows = hl.num_rows;
+        dl.total_weight = hl.total_weight;
+        dl.sampler = hl.sampler;
+    }
+    if (!m.upload(image_lights.data(), image_lights.size(), &s.image_lights)) return -1;
+    for (uint32_t mi = 0; mi < d->num_materials; ++mi)
+        if (ZYGPU_NULL != d->materials[mi].emission_image && d->materials[mi].emission_image >= d->num_images) {
+            g_error = "a material's emission map refers to an image that does not exist";
+            return -2;
+        }
     s.specular_threshold = d->specular_threshold;
     s.num_solid_nodes = d->solid.num_nodes;
     s.num_unocc_nodes = d->unoccluding.num_nodes;

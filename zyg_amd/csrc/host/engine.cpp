@@ -25,10 +25,15 @@ static Vec4f readColor(const JsonValue& v) {
 
 // material_provider.zig:438-632 (TextureDescriptor) + 634-678 (readTextureSampler), image ids only: {"usage": "Color", "id": n,
 // "sampler": {"filter": "Nearest" | "Linear", "address": "Clamp" | "Repeat" | [u, v]}, "scale": s | [sx, sy]}
-static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) {
+static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler, float scale[2]);
+static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) { return readImageTexture(v, m.color_image, m.color_sampler, m.color_scale); }
+
+// material_provider.zig:438-632: {"usage": .., "id": n, "sampler": {"filter", "address"}, "scale"}
+static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler_out, float scale_out[2]) {
     if (JsonValue::Object != v.type) return false;
     const JsonValue* id = v.get("id");
     if (!id) return false;
+    struct { uint32_t color_image, color_sampler; float color_scale[2]; } m;
     m.color_image = uint32_t(id->f32(0.f));
     m.color_sampler = ZYGPU_TEX_LINEAR | ZYGPU_TEX_REPEAT_U | ZYGPU_TEX_REPEAT_V;  // texture.zig:22-27 DefaultMode
     m.color_scale[0] = m.color_scale[1] = 1.f;
@@ -60,6 +65,10 @@ static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) {
             m.color_scale[0] = m.color_scale[1] = sc->f32(1.f);
         }
     }
+    image = m.color_image;
+    sampler_out = m.color_sampler;
+    scale_out[0] = m.color_scale[0];
+    scale_out[1] = m.color_scale[1];
     return true;
 }
 
@@ -186,6 +195,7 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
     m.camera_weight = 1.f;
     m.emission_num_samples = 1;
     m.color_image = ZYGPU_NULL;
+    m.emission_image = ZYGPU_NULL;
     m.roughness = 0.8f;
     m.metallic = 0.f;
     m.specular = 1.f;
@@ -205,6 +215,7 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
         m.cos_a = std::cos(e.memberF32("angle", profile_angle) * (float(M_PI) / 180.f));
         m.camera_weight = e.memberF32("camera_weight", 1.f);
         m.emission_num_samples = std::min<uint32_t>(e.memberU32("num_samples", 1), 64u);
+        if (const JsonValue* em = e.get("emission_map")) readImageTexture(*em, m.emission_image, m.emission_sampler, m.emission_scale);
     };
 
     if (ZYGPU_MAT_DEBUG == kind) {
@@ -778,6 +789,121 @@ void Engine::buildPropTree(const std::vector<uint32_t>& indices, std::vector<Zyg
 }
 
 // triangle_mesh.zig:721-749 (Mesh.prepareSampling) + 57-149 (Part.configure), uniform emission, one task
+void Engine::ensureSrgbTable() {  // texture/encoding.zig:41-51 over spectrum/srgb.zig:28-38
+    if (!srgb_to_float_.empty()) return;
+    srgb_to_float_.resize(256);
+    for (int i = 0; i < 256; ++i) {
+        const float c = float(i) / 255.f;
+        srgb_to_float_[i] = c <= 0.f ? 0.f : c < 0.04045f ? c / 12.92f : c < 1.f ? std::pow((c + 0.055f) / 1.055f, 2.4f) : 1.f;
+    }
+}
+
+namespace {
+// Distribution1D.configure(data, 0) (base/math/distribution_1d.zig:29-36, 104-171), appended to the flat arrays;
+// returns the distribution's integral
+float appendDistribution1D(const std::vector<float>& data, HostImageLight& out) {
+    const uint32_t cdf_offset = uint32_t(out.cdf.size()), lut_offset = uint32_t(out.lut.size());
+    float integral = 0.f;
+    for (float d : data) integral += d;
+    uint32_t size;
+    if (0.f == integral) {
+        size = 2;
+        out.cdf.push_back(1.f);
+        out.cdf.push_back(1.f);
+    } else {
+        size = uint32_t(data.size()) + 1;
+        const float ii = 1.f / integral;
+        float       p = 0.f;
+        out.cdf.push_back(0.f);
+        for (size_t i = 0; i + 1 < data.size(); ++i) {
+            p = std::fmaf(data[i], ii, p);
+            out.cdf.push_back(p);
+        }
+        out.cdf.push_back(1.f);
+    }
+    uint32_t lut_size = uint32_t(data.size() / 16);
+    lut_size = std::min(std::max(lut_size, 1u), size);
+    const float lut_range = float(lut_size);
+    out.lut.resize(lut_offset + lut_size + 1, 0u);
+    uint32_t*    lut = out.lut.data() + lut_offset;
+    const float* cdf = out.cdf.data() + cdf_offset;
+    lut[0] = 1;
+    uint32_t border = 0;
+    for (uint32_t i = 1; i < size; ++i) {
+        const uint32_t mapped = uint32_t(cdf[i] * lut_range);
+        if (mapped > border) {
+            for (uint32_t k = border + 1; k <= mapped; ++k) lut[k] = i;
+            border = mapped;
+        }
+    }
+    uint32_t range_bits;
+    std::memcpy(&range_bits, &lut_range, 4);
+    out.rows.insert(out.rows.end(), {cdf_offset, size, lut_offset, range_bits});
+    return integral;
+}
+}  // namespace
+
+// Light.Material.prepareSampling for an emission map (light_material.zig:52-125, 201-271): uv-weighted luminance per texel,
+// MIS compensation (luminance minus 0.6 x the mean), one Distribution1D per row and the marginal over the rows' integrals
+uint32_t Engine::prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m) {
+    ensureSrgbTable();
+    const HostImage& img = images_[m.emission_image];
+    const int        w = img.width, h = img.height;
+    image_lights_.emplace_back();
+    HostImageLight& il = image_lights_.back();
+    il.num_rows = uint32_t(h);
+    il.sampler = m.emission_sampler;
+
+    auto texel = [&](int x, int y) {  // Texture.image2D_3 (texture.zig:188-219)
+        const size_t i = size_t(y) * size_t(w) + size_t(x);
+        if (ZYGPU_IMAGE_BYTE3_SRGB == img.format) {
+            const uint8_t* p = img.pixels.data() + 3 * i;
+            const float    r = srgb_to_float_[p[0]], g = srgb_to_float_[p[1]], b = srgb_to_float_[p[2]];
+            return vec(0.61309732f, 0.07019422f, 0.02061560f, 0.f) * splat(r) + vec(0.33952285f, 0.91635557f, 0.10956983f, 0.f) * splat(g) +
+                   vec(0.04737928f, 0.01345259f, 0.86981512f, 0.f) * splat(b);
+        }
+        const float* p = reinterpret_cast<const float*>(img.pixels.data()) + 3 * i;
+        return vec(p[0], p[1], p[2], 0.f);
+    };
+    auto uvWeight = [&](float u, float v) {  // shape.zig:535-542
+        if (ZYGPU_SHAPE_DOME == shape_kind) return std::sin(v * float(M_PI));
+        if (ZYGPU_SHAPE_CANOPY == shape_kind) {
+            const float dx = 2.f * u - 1.f, dy = 2.f * v - 1.f;
+            return dx * dx + dy * dy > 1.f ? 0.f : 1.f;
+        }
+        return 1.f;
+    };
+
+    std::vector<float> luminance(size_t(w) * size_t(h));
+    const float        idf0 = 1.f / float(w), idf1 = 1.f / float(h);
+    Vec4f              avg = splat(0.f);
+    for (int y = 0; y < h; ++y) {
+        const float v = idf1 * (float(y) + 0.5f);
+        for (int x = 0; x < w; ++x) {
+            const float u = idf0 * (float(x) + 0.5f);
+            const float uv_weight = uvWeight(u, v);
+            const Vec4f wr = splat(uv_weight) * texel(x, y);
+            avg = avg + vec(wr[0], wr[1], wr[2], uv_weight);
+            luminance[size_t(y) * w + x] = std::max(std::max(wr[0], wr[1]), wr[2]);
+        }
+    }
+    const Vec4f average = avg / splat(avg[3]);
+    il.total_weight = avg[3];
+    il.average_emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f) * average;
+
+    const float        al = 0.6f * std::max(std::max(average[0], average[1]), average[2]);
+    std::vector<float> integrals(h), row(w);
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w; ++x) {
+            const float l = luminance[size_t(y) * w + x];
+            row[x] = std::max(l - al, std::min(l, 0.0025f));
+        }
+        integrals[y] = appendDistribution1D(row, il);
+    }
+    appendDistribution1D(integrals, il);
+    return uint32_t(image_lights_.size() - 1);
+}
+
 uint32_t Engine::prepareMeshLight(uint32_t mesh_id, uint32_t part, uint32_t material, bool two_sided) {
     for (size_t i = 0; i < mesh_lights_.size(); ++i) {
         const HostMeshLight& ml = mesh_lights_[i];
@@ -948,6 +1074,7 @@ int Engine::compile(uint32_t frame) {
 
     // lights: scene.zig:402-497 (propPrepareSampling, static branch)
     mesh_lights_.clear();
+    image_lights_.clear();
     std::fill(light_ids_.begin(), light_ids_.end(), ZYGPU_NULL);
     const uint32_t nl = uint32_t(lights_.size());
     c_light_aabbs_.resize(nl);
@@ -978,6 +1105,15 @@ int Engine::compile(uint32_t frame) {
         l.two_sided = (m.flags & ZYGPU_MATF_TWO_SIDED) ? 1 : 0;
         c_light_two_sided_[li] = l.two_sided;
         l.sampler = is_mesh ? prepareMeshLight(s.mesh, l.part, material_ids_[p], 0 != l.two_sided) : ZYGPU_NULL;
+        // scene.zig:430-470: an emission map makes the light a PropImage with its own sampler (light.zig:95-101)
+        const bool image_light = ZYGPU_MAT_LIGHT == m.kind && ZYGPU_NULL != m.emission_image;
+        l.light_class = ZYGPU_LIGHT_PROP;
+        if (image_light) {
+            if (m.emission_image >= images_.size()) return -4;
+            if (!is_dome && !is_canopy) return -3;  // Rectangle / Disk / Sphere.sampleMaterialTo: not restated
+            l.sampler = prepareImageLight(s.kind, m);
+            l.light_class = ZYGPU_LIGHT_PROP_IMAGE;
+        }
 
         const Transformation& t = world_transformations_[l.prop];
         Transformation        rel = t;
@@ -1005,7 +1141,7 @@ int Engine::compile(uint32_t frame) {
                              : is_distant ? (2.f * float(M_PI)) * (1.f - std::sqrt(1.f / (t.scale[0] * t.scale[0] + 1.f)))
                              : is_mesh  ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1])
                                         : t.scale[0] * t.scale[1];
-        Vec4f       emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f);
+        Vec4f       emission = image_light ? image_lights_[l.sampler].average_emission : vec(m.emission[0], m.emission[1], m.emission[2], 0.f);
         // emittance.zig:61-71 totalEmission; light.zig:67-77 power: infinite lights scale with the scene's extent
         Vec4f power = splat(0.f);
         if (extent > 0.f) power = m.emission_normalize ? emission : emission * splat(extent);
@@ -1066,14 +1202,16 @@ int Engine::compile(uint32_t frame) {
         c_images_[i] = ZygpuImage{images_[i].pixels.data(), images_[i].width, images_[i].height, images_[i].format};
     d.images = c_images_.data();
     d.num_images = uint32_t(c_images_.size());
-    if (srgb_to_float_.empty()) {  // texture/encoding.zig:41-51 over spectrum/srgb.zig:28-38
-        srgb_to_float_.resize(256);
-        for (int i = 0; i < 256; ++i) {
-            const float c = float(i) / 255.f;
-            srgb_to_float_[i] = c <= 0.f ? 0.f : c < 0.04045f ? c / 12.92f : c < 1.f ? std::pow((c + 0.055f) / 1.055f, 2.4f) : 1.f;
-        }
-    }
+    ensureSrgbTable();
     d.srgb_to_float = srgb_to_float_.data();
+    c_image_lights_.resize(image_lights_.size());
+    for (size_t i = 0; i < image_lights_.size(); ++i) {
+        const HostImageLight& il = image_lights_[i];
+        c_image_lights_[i] = ZygpuImageLight{il.cdf.data(), il.lut.data(), il.rows.data(), il.num_rows, il.total_weight, il.sampler,
+                                             uint32_t(il.cdf.size()), uint32_t(il.lut.size())};
+    }
+    d.image_lights = c_image_lights_.data();
+    d.num_image_lights = uint32_t(c_image_lights_.size());
     for (const ZygpuMaterial& m : materials_)
         if (ZYGPU_NULL != m.color_image && m.color_image >= images_.size()) return -4;  // a colour map without its image
     for (uint32_t mid : material_ids_) {  // rough / thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 293-460)

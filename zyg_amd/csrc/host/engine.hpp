@@ -59,6 +59,15 @@ struct HostMeshLight {
     Vec4f                 cone;       // power-weighted dominant axis + cos of the widest deviation
 };
 
+// An emission map prepared for importance sampling: light_material.zig:52-125 + Distribution2D (flattened, see zygpu.h)
+struct HostImageLight {
+    std::vector<float>    cdf;
+    std::vector<uint32_t> lut, rows;
+    uint32_t              num_rows = 0, sampler = 0;
+    float                 total_weight = 0.f;
+    Vec4f                 average_emission;  // emittance.value * the uv-weighted mean of the map
+};
+
 struct HostImage {  // image/typed_image.zig: 2-D only
     uint32_t             format = ZYGPU_IMAGE_FLOAT3;
     int32_t              width = 0, height = 0;
@@ -182,6 +191,10 @@ class Engine {
     std::vector<uint8_t>        c_light_infinite_;
     std::deque<HostMeshLight>   mesh_lights_;   // stable addresses: the trees point into their own vectors
     std::vector<ZygpuMeshLight> c_mesh_lights_;
+    std::deque<HostImageLight>   image_lights_;
+    std::vector<ZygpuImageLight> c_image_lights_;
+    uint32_t prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m);
+    void     ensureSrgbTable();
     uint32_t prepareMeshLight(uint32_t mesh, uint32_t part, uint32_t material, bool two_sided);
     std::vector<ZygpuAabb>    c_light_aabbs_;
     std::vector<float>        c_light_cones_;

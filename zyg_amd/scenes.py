@@ -66,9 +66,29 @@ def glass(ior=1.5, color=(1.0, 1.0, 1.0), distance=1.0, priority=0, **more):
     return json.dumps({"rendering": {"Glass": body}})
 
 
-def light_material(spectrum=(17.0, 12.0, 4.0), value=1.0, num_samples=1):
-    return json.dumps({"rendering": {"Light": {"emittance": {"spectrum": list(spectrum), "value": value,
-                                                             "num_samples": num_samples}}}})
+def light_material(spectrum=(17.0, 12.0, 4.0), value=1.0, num_samples=1, emission_map=None, sampler=None):
+    """Light material; emission_map: an image id -> the emittance is multiplied by the map (emittance.zig:49) and the light
+    is importance-sampled by it (light_material.zig:52-125)."""
+    e = {"spectrum": list(spectrum), "value": value, "num_samples": num_samples}
+    if emission_map is not None:
+        e["emission_map"] = {"usage": "Emission", "id": int(emission_map)}
+        if sampler:
+            e["emission_map"]["sampler"] = sampler
+    return json.dumps({"rendering": {"Light": {"emittance": e}}})
+
+
+def sky_image(width=64, height=32, sun=(0.62, 0.3), uniform=None):
+    """A small float32 lat-long / disc environment map: a vertical gradient plus a bright blob ("sun") around uv = sun;
+    uniform: a constant value instead."""
+    if uniform is not None:
+        return np.full((height, width, 3), uniform, dtype=np.float32)
+    v, u = np.mgrid[0:height, 0:width]
+    u = (u + 0.5) / width
+    v = (v + 0.5) / height
+    base = np.stack([0.25 + 0.3 * v, 0.4 + 0.25 * v, 0.9 - 0.5 * v], axis=-1)
+    d2 = (u - sun[0]) ** 2 + ((v - sun[1]) * height / width) ** 2
+    blob = 40.0 * np.exp(-d2 / 0.002)
+    return (base + blob[..., None] * np.array([1.0, 0.9, 0.7])).astype(np.float32)
 
 
 def box_mesh(lo, hi, rot_y_deg=0.0):
@@ -322,7 +342,8 @@ def _basis_for(n):
 
 
 def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
-            extra_quad_light=False, max_depth=8, sky=None, sun=True, showcase=False, mesh=None):
+            extra_quad_light=False, max_depth=8, sky=None, sun=True, showcase=False, mesh=None, sky_map=None, sky_samples=1,
+            sky_spectrum=(0.35, 0.5, 0.8)):
     """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
     distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
     light tree mixes the infinite-light distribution with the BVH.  `sky`: "dome" (dome.zig, the whole sphere of
@@ -365,7 +386,9 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
         engine.light(s)
         ids["sun"] = s
     if sky is not None:
-        sky_mat = engine.material(light_material(spectrum=(0.35, 0.5, 0.8)))
+        # sky_map: a numpy image -> image light (emission map x spectrum), importance-sampled
+        sky_img = None if sky_map is None else engine.image(sky_map)
+        sky_mat = engine.material(light_material(spectrum=sky_spectrum, emission_map=sky_img, num_samples=sky_samples))
         k = engine.prop(DOME if "dome" == sky else CANOPY, [sky_mat])
         # the canopy's z axis is "up": r0 = x, r1 = -z gives r2 = r0 x r1 = +y
         engine.transformation(k, trafo((1, 0, 0), (0, 0, -1), (1, 1, 1), (0, 0, 0)))
