@@ -87,6 +87,12 @@ ZygpuContext* su_ext_context(void);
  * 175,979): which = 0 E_m[32*32], 1 E_m_avg[32], 2 E[16*16*16], 3 E_avg[16*16].  Copies up to capacity floats,
  * returns the table's length (0 for an unknown table).  Host-only: needs no device. */
 uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity);
+/* The image encoders behind su_export_frame on a caller-provided Float4 image (core/exporting/image_sequence.zig,
+ * image/encoding/{srgb,png/png_writer,exr/exr_writer,rgbe/rgbe_writer}.zig): format 0 PNG (flags bit 0 = alpha,
+ * bit 1 = error diffusion), 1 EXR (bit 0 = alpha, bit 2 = 32-bit float instead of half), 2 RGBE; crop = x0, y0, x1, y1.
+ * Writes up to capacity bytes to out, returns the encoded size.  Host-only: needs no device. */
+uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,
+                             uint8_t* out, uint64_t capacity);
 
 #ifdef __cplusplus
 }

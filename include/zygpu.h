@@ -314,9 +314,13 @@ typedef struct ZygpuViewDesc {
     float    filter_radius;        /* range end of the tabulated filter */
     float    filter_samples[ZYGPU_FILTER_TAPS + 1]; /* normalised table (base/math/interpolated_function.zig) */
     float    clamp_emission, clamp_direct, clamp_indirect; /* sensor.zig:60-70 */
-    float    exposure_factor; /* 2^exposure, tonemapper.zig:15 (Linear tonemapper) */
+    float    exposure_factor; /* 2^exposure, tonemapper.zig:15 */
     uint32_t alpha_transparency; /* sensor buffer class Transparent (take_loader.zig:193-196, buffer_transparent.zig) */
+    uint32_t tonemapper;      /* enum ZygpuTonemapper (tonemapper.zig:9) */
 } ZygpuViewDesc;
+
+/* tonemapper.zig:9; AgX with the look the take loader picks (take_loader.zig:268-270: Substitute) */
+enum ZygpuTonemapper { ZYGPU_TONEMAP_LINEAR = 0, ZYGPU_TONEMAP_ACES = 1, ZYGPU_TONEMAP_AGX = 2, ZYGPU_TONEMAP_PBR_NEUTRAL = 3 };
 
 /* traversal / path statistics (no reference counterpart; they define the algorithmic bytes of SURVEY §8(d)) */
 typedef struct ZygpuStats {

@@ -1004,7 +1004,60 @@ int zyg_oracle_render_alpha(const ZygpuSceneDesc* scene, const ZygpuViewDesc* vi
     return 0;
 }
 
-// buffer_opaque.zig:73-79 + tonemapper.zig:18-46 (Linear) + aces.zig:19-27
+}  // extern "C"
+
+// Tonemapper.tonemap (tonemapper.zig:18-71) with aces.zig:19-64 and agx.zig:14-101 (look Substitute, take_loader.zig:268-270)
+static V4 tonemap(uint32_t cls, V4 scaled) {
+    auto ap1ToSrgb = [](V4 c) {
+        return mk(1.70505155f, -0.13025714f, -0.02400328f) * S(c[0]) + mk(-0.62179068f, 1.14080289f, -0.12896877f) * S(c[1]) +
+               mk(-0.08325840f, -0.01054853f, 1.15297171f) * S(c[2]);
+    };
+    if (ZYGPU_TONEMAP_ACES == cls) {
+        const V4 rrt = mk(0.970889f * scaled[0] + 0.026963f * scaled[1] + 0.002148f * scaled[2],
+                          0.010889f * scaled[0] + 0.986963f * scaled[1] + 0.002148f * scaled[2],
+                          0.010889f * scaled[0] + 0.026963f * scaled[1] + 0.962148f * scaled[2]);
+        const V4 a = rrt * (rrt + S(0.0245786f)) - S(0.000090537f);
+        const V4 b = rrt * (S(0.983729f) * rrt + S(0.4329510f)) + S(0.238081f);
+        const V4 odt = mk(a[0] / b[0], a[1] / b[1], a[2] / b[2]);
+        return mk(1.60475f * odt[0] - 0.53108f * odt[1] - 0.07367f * odt[2], -0.10208f * odt[0] + 1.10813f * odt[1] - 0.00605f * odt[2],
+                  -0.00327f * odt[0] - 0.07276f * odt[1] + 1.07602f * odt[2]);
+    }
+    const V4 srgb = ap1ToSrgb(scaled);
+    if (ZYGPU_TONEMAP_AGX == cls) {
+        V4 val = mk(0.8424790622530940f * srgb[0] + 0.0784335999999992f * srgb[1] + 0.0792237451477643f * srgb[2],
+                    0.0423282422610123f * srgb[0] + 0.8784686364697720f * srgb[1] + 0.0791661274605434f * srgb[2],
+                    0.0423756549057051f * srgb[0] + 0.0784336000000000f * srgb[1] + 0.8791429737931040f * srgb[2]);
+        const float min_ev = -12.47393f, max_ev = 4.026069f;
+        for (int k = 0; k < 3; ++k) val[k] = (clampf(std::log2(val[k]), min_ev, max_ev) - min_ev) / (max_ev - min_ev);
+        const V4 x = val, x2 = x * x, x4 = x2 * x2;
+        V4 c = S(15.5f) * x4 * x2 - S(40.14f) * x4 * x + S(31.96f) * x4 - S(6.868f) * x2 * x + S(0.4298f) * x2 + S(0.1191f) * x - S(0.00232f);
+        for (int k = 0; k < 3; ++k) c[k] = mx(c[k], 0.f);
+        const float luma = dot3(c, mk(0.2126f, 0.7152f, 0.072f));
+        V4          l;
+        for (int k = 0; k < 3; ++k) l[k] = luma + 1.05f * (std::pow(c[k] * 1.f, 1.1f) - luma);
+        const V4 lin = mk(1.19687900512017f * l[0] - 0.0980208811401368f * l[1] - 0.0990297440797205f * l[2],
+                          -0.0528968517574562f * l[0] + 1.15190312990417f * l[1] - 0.0989611768448433f * l[2],
+                          -0.0529716355144438f * l[0] - 0.0980434501171241f * l[1] + 1.15107367264116f * l[2]);
+        return mk(mx(std::pow(lin[0], 2.2f), 0.f), mx(std::pow(lin[1], 2.2f), 0.f), mx(std::pow(lin[2], 2.2f), 0.f));
+    }
+    if (ZYGPU_TONEMAP_PBR_NEUTRAL == cls) {
+        const float start_compression = 0.8f - 0.04f, desaturation = 0.15f;
+        const float x = mn(srgb[0], mn(srgb[1], srgb[2]));
+        const float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+        V4          color = srgb - S(offset);
+        const float peak = hmax3(color);
+        if (peak < start_compression) return color;
+        const float d = 1.f - start_compression;
+        const float new_peak = 1.f - d * d / (peak + d - start_compression);
+        color = color * S(new_peak / peak);
+        const float g = 1.f - 1.f / (desaturation * (peak - new_peak) + 1.f);
+        return lerp4(color, S(new_peak), S(g));
+    }
+    return srgb;
+}
+
+extern "C" {
+// buffer_opaque.zig:73-79 + tonemapper.zig:18-46 + aces.zig:19-27
 int zyg_oracle_resolve_alpha(const ZygpuViewDesc* view, const float* film_rgbw, const float* film_alpha, float* out_rgba,
                              uint32_t num_pixels);
 
@@ -1021,9 +1074,7 @@ int zyg_oracle_resolve_alpha(const ZygpuViewDesc* view, const float* film_rgbw, 
         const V4     q = mk(p[0], p[1], p[2], 0.f) / S(p[3]);
         const V4     color = mk(std::fabs(q[0]), std::fabs(q[1]), std::fabs(q[2]), std::fabs(q[3]));
         const V4     scaled = S(view->exposure_factor) * color;
-        const V4     srgb = mk(1.70505155f, -0.13025714f, -0.02400328f) * S(scaled[0]) +
-                        mk(-0.62179068f, 1.14080289f, -0.12896877f) * S(scaled[1]) +
-                        mk(-0.08325840f, -0.01054853f, 1.15297171f) * S(scaled[2]);
+        const V4     srgb = tonemap(view->tonemapper, scaled);
         float* o = out_rgba + size_t(i) * 4;
         o[0] = srgb[0];
         o[1] = srgb[1];

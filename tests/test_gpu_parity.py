@@ -3,6 +3,7 @@ compiled scene and the same (pixel, iteration) set.  Tolerance for the floating-
 of the resolved linear image <= 1e-3 (BASELINE.json north_star); integer work (ray counts) must match exactly
 exactly (ray, node, triangle and instance counters)."""
 import ctypes
+import json
 
 import numpy as np
 import pytest
@@ -394,3 +395,28 @@ def test_image_light_srgb_map(engine, oracle):
     out = _render_both(engine, oracle, 64, 48, 2, scene=scenes.outdoor, integrator="PTMIS", sun=False, sky="dome", sky_map=img,
                        sky_spectrum=(2.0, 2.0, 2.0))
     _check(*out, 2)
+
+
+@pytest.mark.parametrize("tonemapper,exposure", [("ACES", 0.0), ("ACES", 1.5), ("PbrNeutral", 0.5), ("AgX", 0.0), ("Linear", -1.0)])
+def test_tonemappers(engine, oracle, tonemapper, exposure):
+    """Sensor.resolveTonemap with the four tonemapper classes (tonemapper.zig:18-71, aces.zig:29-64, agx.zig): ACES, PbrNeutral
+    and Linear are plain arithmetic and match the oracle bit for bit; AgX goes through log2 / pow, compared to 5e-4."""
+    w, h, spp = 64, 48, 4
+    scenes.cornell(engine, w, h, spp)
+    engine.sensor(json.dumps({"tonemapper": {tonemapper: {"exposure": exposure}}}))
+    engine.start_frame(0)
+    engine.render_iterations(spp)
+    engine.synchronize()
+    film = engine.download_film(w, h)
+    img = engine.resolve(w, h)
+    vd = engine.lib.su_ext_view_desc().contents
+    assert abs(vd.exposure_factor - 2.0 ** exposure) < 1e-5
+    cpu = oracle_resolve(oracle, vd, film)
+    assert np.isfinite(img).all()
+    if "AgX" == tonemapper:
+        np.testing.assert_allclose(img, cpu, rtol=5e-4, atol=1e-5)  # device log2f / powf vs libm
+        assert img[..., :3].min() >= 0.0 and img[..., :3].max() <= 1.1  # the Substitute look's saturation overshoots a little
+    else:
+        assert np.array_equal(img, cpu)
+    if tonemapper in ("ACES", "PbrNeutral"):
+        assert img[..., :3].max() <= 1.25  # both compress into the display range (ACES' output matrix overshoots a little)

@@ -408,3 +408,32 @@ def test_image_light_integrators_agree(product_lib, oracle, sky):
     np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.02)
     np.testing.assert_allclose(means["PTMIS4"], means["PTMIS"], rtol=0.02)
     np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.1)
+
+
+def test_tonemapper_known_answers(product_lib, oracle):
+    """Tonemapper.tonemap (tonemapper.zig:18-71): Linear is AP1 -> sRGB; PbrNeutral leaves small values alone but for the
+    0.04 toe offset; ACES maps black to ~0 and compresses large values below 1; the exposure is 2^e."""
+    film = np.zeros((1, 4, 4), dtype=np.float32)
+    film[0, :, 3] = 1.0
+    film[0, 1, :3] = 0.18
+    film[0, 2, :3] = 4.0
+    film[0, 3, :3] = (0.5, 0.05, 0.01)
+    out = {}
+    for name, exposure in (("Linear", 0.0), ("Linear", 1.0), ("ACES", 0.0), ("PbrNeutral", 0.0), ("AgX", 0.0)):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, 4, 1, 1)
+            e.sensor(json.dumps({"tonemapper": {name: {"exposure": exposure}}}))
+            _, vd = e.compile()
+            out[(name, exposure)] = oracle_resolve(oracle, vd, film)[0, :, :3]
+    lin = out[("Linear", 0.0)]
+    m = np.array([[1.70505155, -0.13025714, -0.02400328], [-0.62179068, 1.14080289, -0.12896877], [-0.08325840, -0.01054853, 1.15297171]])
+    np.testing.assert_allclose(lin[3], np.array([0.5, 0.05, 0.01]) @ m, rtol=1e-6)
+    np.testing.assert_allclose(out[("Linear", 1.0)], 2.0 * lin, rtol=1e-6)
+    aces = out[("ACES", 0.0)]
+    assert abs(aces[0]).max() < 1e-3 and 0.9 < aces[2].max() <= 1.01 and aces[1].max() < aces[2].max()
+    pbr = out[("PbrNeutral", 0.0)]
+    x = lin[1].min()
+    np.testing.assert_allclose(pbr[1], lin[1] - 0.04, rtol=1e-5)  # below the compression start, toe offset 0.04 (x >= 0.08)
+    assert x >= 0.08 and pbr[2].max() < 1.0
+    agx = out[("AgX", 0.0)]
+    assert agx.min() >= 0.0 and agx.max() <= 1.1 and agx[2].mean() > agx[1].mean() > agx[0].mean()

@@ -130,7 +130,7 @@ class ViewDesc(ctypes.Structure):
                 ("filter_radius", ctypes.c_float), ("filter_samples", ctypes.c_float * (FILTER_TAPS + 1)),
                 ("clamp_emission", ctypes.c_float), ("clamp_direct", ctypes.c_float),
                 ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float),
-                ("alpha_transparency", ctypes.c_uint32)]
+                ("alpha_transparency", ctypes.c_uint32), ("tonemapper", ctypes.c_uint32)]
 
 
 class Stats(ctypes.Structure):

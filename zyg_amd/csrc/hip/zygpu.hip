@@ -92,17 +92,69 @@ __global__ void film_clear(float4* film, float* film_alpha, uint32_t n, float we
     }
 }
 
-// resolveTonemap (buffer_opaque.zig:73-79) with the Linear tonemapper (tonemapper.zig:36-39, aces.zig:19-27)
-__global__ void film_resolve(const float4* film, const float* film_alpha, float4* out, uint32_t n, float exposure_factor) {
+ZD f3 ap1ToSrgb(f3 c) {  // aces.zig:19-27
+    return mk3(1.70505155f, -0.13025714f, -0.02400328f) * S3(c.x) + mk3(-0.62179068f, 1.14080289f, -0.12896877f) * S3(c.y) +
+           mk3(-0.08325840f, -0.01054853f, 1.15297171f) * S3(c.z);
+}
+ZD f3 pow3(f3 v, f3 e) { return mk3(powf(v.x, e.x), powf(v.y, e.y), powf(v.z, e.z)); }
+
+// Tonemapper.tonemap (tonemapper.zig:18-46) on the exposed AP1 colour
+ZD f3 tonemap(uint32_t cls, f3 scaled) {
+    if (ZYGPU_TONEMAP_ACES == cls) {  // aces.zig:29-36, 50-57, 60-64
+        const f3 rrt = mk3(0.970889f * scaled.x + 0.026963f * scaled.y + 0.002148f * scaled.z,
+                           0.010889f * scaled.x + 0.986963f * scaled.y + 0.002148f * scaled.z,
+                           0.010889f * scaled.x + 0.026963f * scaled.y + 0.962148f * scaled.z);
+        const f3 a = rrt * (rrt + S3(0.0245786f)) - S3(0.000090537f);
+        const f3 b = rrt * (S3(0.983729f) * rrt + S3(0.4329510f)) + S3(0.238081f);
+        const f3 odt = a / b;
+        return mk3(1.60475f * odt.x - 0.53108f * odt.y - 0.07367f * odt.z, -0.10208f * odt.x + 1.10813f * odt.y - 0.00605f * odt.z,
+                   -0.00327f * odt.x - 0.07276f * odt.y + 1.07602f * odt.z);
+    }
+    const f3 srgb = ap1ToSrgb(scaled);
+    if (ZYGPU_TONEMAP_AGX == cls) {  // agx.zig:14-101, look Substitute (take_loader.zig:268-270)
+        f3 val = mk3(0.8424790622530940f * srgb.x + 0.0784335999999992f * srgb.y + 0.0792237451477643f * srgb.z,
+                     0.0423282422610123f * srgb.x + 0.8784686364697720f * srgb.y + 0.0791661274605434f * srgb.z,
+                     0.0423756549057051f * srgb.x + 0.0784336000000000f * srgb.y + 0.8791429737931040f * srgb.z);
+        const float min_ev = -12.47393f, max_ev = 4.026069f;
+        val = mk3(clampf(log2f(val.x), min_ev, max_ev), clampf(log2f(val.y), min_ev, max_ev), clampf(log2f(val.z), min_ev, max_ev));
+        val = (val - S3(min_ev)) / S3(max_ev - min_ev);
+        const f3 x = val, x2 = x * x, x4 = x2 * x2;
+        f3 c = S3(15.5f) * x4 * x2 - S3(40.14f) * x4 * x + S3(31.96f) * x4 - S3(6.868f) * x2 * x + S3(0.4298f) * x2 + S3(0.1191f) * x -
+               S3(0.00232f);
+        c = max3v(c, S3(0.f));
+        const float luma = dot3(c, mk3(0.2126f, 0.7152f, 0.072f));
+        const f3    p = pow3(c * S3(1.f), S3(1.1f));
+        const f3    l = S3(luma) + S3(1.05f) * (p - S3(luma));
+        const f3    lin = mk3(1.19687900512017f * l.x - 0.0980208811401368f * l.y - 0.0990297440797205f * l.z,
+                              -0.0528968517574562f * l.x + 1.15190312990417f * l.y - 0.0989611768448433f * l.z,
+                              -0.0529716355144438f * l.x - 0.0980434501171241f * l.y + 1.15107367264116f * l.z);
+        return max3v(pow3(lin, S3(2.2f)), S3(0.f));
+    }
+    if (ZYGPU_TONEMAP_PBR_NEUTRAL == cls) {  // tonemapper.zig:52-71
+        const float start_compression = 0.8f - 0.04f, desaturation = 0.15f;
+        const float x = mn(srgb.x, mn(srgb.y, srgb.z));
+        const float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+        f3          color = srgb - S3(offset);
+        const float peak = hmax3(color);
+        if (peak < start_compression) return color;
+        const float d = 1.f - start_compression;
+        const float new_peak = 1.f - d * d / (peak + d - start_compression);
+        color = color * S3(new_peak / peak);
+        const float g = 1.f - 1.f / (desaturation * (peak - new_peak) + 1.f);
+        return lerp3(color, S3(new_peak), S3(g));
+    }
+    return srgb;
+}
+
+// resolveTonemap (buffer_opaque.zig:73-79, buffer_transparent.zig:84-94)
+__global__ void film_resolve(const float4* film, const float* film_alpha, float4* out, uint32_t n, float exposure_factor, uint32_t tonemapper) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = film[i];
     const f3     q = mk3(p.x, p.y, p.z) / S3(p.w);
     const f3     color = mk3(fabsf(q.x), fabsf(q.y), fabsf(q.z));
-    const f3     scaled = S3(exposure_factor) * color;
-    const f3     srgb = mk3(1.70505155f, -0.13025714f, -0.02400328f) * S3(scaled.x) + mk3(-0.62179068f, 1.14080289f, -0.12896877f) * S3(scaled.y) +
-                    mk3(-0.08325840f, -0.01054853f, 1.15297171f) * S3(scaled.z);
-    out[i] = make_float4(srgb.x, srgb.y, srgb.z, film_alpha ? fabsf(film_alpha[i] / p.w) : 1.f);
+    const f3     mapped = tonemap(tonemapper, S3(exposure_factor) * color);
+    out[i] = make_float4(mapped.x, mapped.y, mapped.z, film_alpha ? fabsf(film_alpha[i] / p.w) : 1.f);
 }
 
 
@@ -918,7 +970,7 @@ int zygpu_resolve(ZygpuContext* c, float* host_rgba, uint32_t num_pixels) {
         c->resolve_tmp = static_cast<float4*>(d);
     }
     hipLaunchKernelGGL(film_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->film_active, c->film_alpha_active, c->resolve_tmp, n,
-                       c->view.exposure_factor);
+                       c->view.exposure_factor, c->view.tonemapper);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(host_rgba, c->resolve_tmp, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));

@@ -9,6 +9,7 @@
 
 #include "engine.hpp"
 #include "ggx_lut.hpp"
+#include "image_writers.hpp"
 
 namespace {
 
@@ -20,6 +21,7 @@ struct Capi {
     uint32_t           iteration = 0;
     std::vector<float> target;  // Float4 image (driver.zig target)
     bool               uploaded = false;
+    std::vector<zyg::imgw::Exporter> exporters;  // take.exporters (take.zig:303-331)
 };
 
 std::unique_ptr<Capi> g;
@@ -78,12 +80,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
     return 0;
 }
 
-float linearToGamma(float x) {  // base/spectrum/srgb.zig:6-16
-    if (x <= 0.f) return 0.f;
-    if (x < 0.0031308f) return 12.92f * x;
-    if (x < 1.f) return 1.055f * std::pow(x, 1.f / 2.4f) - 0.055f;
-    return 1.f;
-}
+using zyg::imgw::linearToGamma;
 
 }  // namespace
 
@@ -129,8 +126,26 @@ int32_t su_camera_sensor_dimensions(int32_t* dimensions) {
 int32_t su_exporters_create(const char* json) {
     if (!g) return -1;
     zyg::JsonValue v;
-    if (!parse(json, v)) return -1;
-    return 0;  // exporters are configured but writing image files is out of the hot-path scope (su_export_frame)
+    if (!parse(json, v) || zyg::JsonValue::Object != v.type) return -1;
+    // Take.loadExporters (take.zig:303-360): image sequences; "Video" (a pipe into ffmpeg) is not provided
+    g->exporters.clear();
+    for (const auto& kv : v.obj) {
+        if (kv.first != "Image") continue;
+        zyg::imgw::Exporter e;
+        const zyg::JsonValue* f = kv.second.get("format");
+        const std::string     format = (f && zyg::JsonValue::String == f->type) ? f->str : "PNG";
+        if ("EXR" == format) {
+            e.format = zyg::imgw::Exporter::EXR;
+            e.half = 16 == kv.second.memberU32("bitdepth", 16);
+        } else if ("RGBE" == format) {
+            e.format = zyg::imgw::Exporter::RGBE;
+        } else {
+            e.format = zyg::imgw::Exporter::PNG;
+            e.error_diffusion = kv.second.memberBool("error_diffusion", false);
+        }
+        g->exporters.push_back(e);
+    }
+    return 0;
 }
 
 int32_t su_aovs_create(const char* json) {
@@ -255,10 +270,29 @@ int32_t su_render_frame(uint32_t frame) {
     return 0 == zygpu_synchronize(g->ctx) ? 0 : -1;
 }
 
+int32_t su_resolve_frame(uint32_t aov);
+
+// capi.zig:556-566 -> Driver.exportFrame (driver.zig:232-262): resolve, then every exporter writes image_CC_FFFFFF.ext
+// into the working directory (or $ZYG_EXPORT_DIR)
 int32_t su_export_frame(void) {
-    if (!g) return -1;
-    logf(1, "su_export_frame: image encoders are outside the hot-path scope; use su_resolve_frame_to_buffer");
-    return -1;
+    if (!g || !g->uploaded) return -1;
+    if (0 != su_resolve_frame(0xFFFFFFFFu)) return -1;
+    const char*          dir = std::getenv("ZYG_EXPORT_DIR");
+    zyg::imgw::ImageView im;
+    im.rgba = g->target.data();
+    im.width = g->engine.resolution[0];
+    im.height = g->engine.resolution[1];
+    for (int i = 0; i < 4; ++i) im.crop[i] = g->engine.crop[i];
+    const bool alpha = g->engine.sensor.alpha_transparency;
+    for (const zyg::imgw::Exporter& e : g->exporters) {
+        std::string path;
+        if (!zyg::imgw::exportImage(e, im, alpha, 0, g->frame, dir ? dir : "", &path)) {
+            logf(2, "su_export_frame: cannot write %s", path.c_str());
+            return -1;
+        }
+        logf(0, "su_export_frame: wrote %s", path.c_str());
+    }
+    return 0;
 }
 
 int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height, float* buffer) {
@@ -341,6 +375,24 @@ int32_t su_ext_compile(uint32_t frame) {
 const ZygpuSceneDesc* su_ext_scene_desc(void) { return g ? &g->engine.sceneDesc() : nullptr; }
 const ZygpuViewDesc*  su_ext_view_desc(void) { return g ? &g->engine.viewDesc() : nullptr; }
 ZygpuContext*         su_ext_context(void) { return g ? g->ctx : nullptr; }
+
+uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,
+                             uint8_t* out, uint64_t capacity) {
+    if (!rgba || !crop) return 0;
+    zyg::imgw::ImageView im{rgba, int(width), int(height), {crop[0], crop[1], crop[2], crop[3]}};
+    const bool           alpha = 0 != (flags & 1u);
+    std::vector<uint8_t> bytes;
+    if (0 == format) {
+        const std::vector<uint8_t> px = zyg::imgw::toSrgb(im, alpha, 0 != (flags & 2u));
+        bytes = zyg::imgw::encodePng(px.data(), im.width, im.height, alpha ? 4 : 3);
+    } else if (1 == format) {
+        bytes = zyg::imgw::encodeExr(im, alpha, 0 == (flags & 4u));
+    } else if (2 == format) {
+        bytes = zyg::imgw::encodeRgbe(im);
+    }
+    if (out) std::memcpy(out, bytes.data(), size_t(std::min<uint64_t>(capacity, bytes.size())));
+    return bytes.size();
+}
 
 uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity) {
     const zyg::ggxlut::Tables& t = zyg::ggxlut::tables();

@@ -757,6 +757,27 @@ void Engine::loadSensor(const JsonValue& v) {
             sensor.clamp_indirect = c->memberF32("indirect", sensor.clamp_indirect);
         }
     }
+    // the take's post-processor (take_loader.zig:245-283), accepted here next to the sensor's own settings:
+    // {"tonemapper": {"ACES" | "AgX" | "Linear" | "PbrNeutral": {"exposure": e}}}
+    sensor.tonemapper = ZYGPU_TONEMAP_LINEAR;
+    sensor.exposure = 0.f;
+    if (const JsonValue* t = v.get("tonemapper")) {
+        if (JsonValue::Object == t->type) {
+            for (const auto& kv : t->obj) {
+                const float exposure = JsonValue::Object == kv.second.type ? kv.second.memberF32("exposure", 0.f) : 0.f;
+                uint32_t    cls = ZYGPU_NULL;
+                if (kv.first == "ACES") cls = ZYGPU_TONEMAP_ACES;
+                else if (kv.first == "AgX") cls = ZYGPU_TONEMAP_AGX;
+                else if (kv.first == "Linear") cls = ZYGPU_TONEMAP_LINEAR;
+                else if (kv.first == "PbrNeutral") cls = ZYGPU_TONEMAP_PBR_NEUTRAL;
+                if (ZYGPU_NULL != cls) {
+                    sensor.tonemapper = cls;
+                    sensor.exposure = exposure;
+                    break;
+                }
+            }
+        }
+    }
     if (const JsonValue* f = v.get("filter")) {
         if (JsonValue::Object == f->type) {
             for (const auto& kv : f->obj) {
@@ -1277,6 +1298,7 @@ int Engine::compile(uint32_t frame) {
     v.clamp_indirect = sensor.clamp_indirect;
     v.exposure_factor = std::exp2(sensor.exposure);
     v.alpha_transparency = sensor.alpha_transparency ? 1 : 0;
+    v.tonemapper = sensor.tonemapper;
     return 0;
 }
 

@@ -92,6 +92,7 @@ struct SensorSettings {  // sensor.zig:60-120
     float   filter_samples[ZYGPU_FILTER_TAPS + 1] = {};
     float   clamp_emission = FLT_MAX, clamp_direct = FLT_MAX, clamp_indirect = FLT_MAX;
     float   exposure = 0.f;
+    uint32_t tonemapper = ZYGPU_TONEMAP_LINEAR;
     bool    alpha_transparency = false;  // buffer class Transparent instead of Opaque
 };
 
