@@ -91,6 +91,10 @@ uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity);
  * image/encoding/{srgb,png/png_writer,exr/exr_writer,rgbe/rgbe_writer}.zig): format 0 PNG (flags bit 0 = alpha,
  * bit 1 = error diffusion), 1 EXR (bit 0 = alpha, bit 2 = 32-bit float instead of half), 2 RGBE; crop = x0, y0, x1, y1.
  * Writes up to capacity bytes to out, returns the encoded size.  Host-only: needs no device. */
+/* Loads a take file and the scene it names into the (initialised, empty) engine: camera, sampler, integrator, sensor,
+ * post-processor and exporters of cli/take_loader.zig:27-283, materials / entities / shapes of util/scene_loader.zig:115-702,
+ * JSON and "SUB\0" binary meshes of shape_provider.zig:334-805.  0, or -1 with the reason in the log.  Host-only. */
+int32_t su_ext_load_take(const char* take_filename);
 uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,
                              uint8_t* out, uint64_t capacity);
 

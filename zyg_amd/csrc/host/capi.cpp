@@ -10,6 +10,7 @@
 #include "engine.hpp"
 #include "ggx_lut.hpp"
 #include "image_writers.hpp"
+#include "loaders.hpp"
 
 namespace {
 
@@ -375,6 +376,17 @@ int32_t su_ext_compile(uint32_t frame) {
 const ZygpuSceneDesc* su_ext_scene_desc(void) { return g ? &g->engine.sceneDesc() : nullptr; }
 const ZygpuViewDesc*  su_ext_view_desc(void) { return g ? &g->engine.viewDesc() : nullptr; }
 ZygpuContext*         su_ext_context(void) { return g ? g->ctx : nullptr; }
+
+int32_t su_ext_load_take(const char* take_filename) {
+    if (!g || !take_filename) return -1;
+    zyg::TakeLoader loader(g->engine);
+    if (!loader.loadTake(take_filename)) {
+        logf(2, "su_ext_load_take: %s", loader.error.c_str());
+        return -1;
+    }
+    g->exporters = loader.exporters;
+    return 0;
+}
 
 uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,
                              uint8_t* out, uint64_t capacity) {

@@ -668,6 +668,12 @@ int Engine::setTransformation(uint32_t prop, const float* m16) {  // capi.zig:48
     return 0;
 }
 
+int Engine::setWorldTransformation(uint32_t prop, const Transformation& t) {
+    if (prop >= props_.size()) return -1;
+    world_transformations_[prop] = t;
+    return 0;
+}
+
 int Engine::setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss) {  // prop.zig:75-88
     if (prop >= props_.size()) return -1;
     uint32_t& f = props_[prop].flags;

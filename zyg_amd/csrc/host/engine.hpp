@@ -116,6 +116,7 @@ class Engine {
     int32_t  createPropInstance(uint32_t entity);
     int      createLight(uint32_t entity);
     int      setTransformation(uint32_t prop, const float* m16);
+    int      setWorldTransformation(uint32_t prop, const Transformation& t);  // the loaders' path (scene_graph.zig:178-230)
     int      setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss);
 
     // --- view ---

@@ -33,6 +33,10 @@ struct JsonValue {
         const JsonValue* v = get(key);
         return (v && Number == v->type) ? uint32_t(v->num) : def;
     }
+    double memberF64(const char* key, double def) const {
+        const JsonValue* v = get(key);
+        return (v && Number == v->type) ? v->num : def;
+    }
     bool memberBool(const char* key, bool def) const {
         const JsonValue* v = get(key);
         return (v && Bool == v->type) ? v->b : def;

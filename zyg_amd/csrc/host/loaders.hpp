@@ -1,0 +1,493 @@
+// On-disk formats of the reference, read on the host into the Engine:
+//   take JSON        src/cli/take_loader.zig:27-283, src/core/take/take.zig:303-331
+//   scene JSON       src/util/scene_loader.zig:115-326, 612-702 (materials by name, entities with children, shapes by
+//                    type or file, transformations base/json.zig:165-245, visibility)
+//   mesh JSON        src/core/scene/shape/shape_provider.zig:334-525 ("geometry": parts, vertices, indices)
+//   mesh .sub        src/core/scene/shape/shape_provider.zig:527-805, 965-994 ("SUB\0", u64 json size, JSON header, binary
+//                    vertex streams + indices, delta-encoded Int16 / Int32 or plain UInt16 / UInt32)
+// File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
+// core/file/system.zig, reduced to these two levels).  Not read: glTF, instancers, scatterers, portals, animations, Sky
+// entities, gzip-compressed files.
+#pragma once
+
+#include <cstdio>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+
+#include "engine.hpp"
+#include "image_writers.hpp"
+
+namespace zyg {
+
+class TakeLoader {
+  public:
+    explicit TakeLoader(Engine& e) : engine_(e) {}
+
+    std::string                 error;
+    std::vector<imgw::Exporter> exporters;
+
+    bool loadTake(const std::string& path) {
+        JsonValue root;
+        if (!readJson(path, root) || JsonValue::Object != root.type) return fail("cannot read take \"" + path + "\"");
+        take_dir_ = parentDirectory(path);
+        const JsonValue* scene = root.get("scene");
+        if (!scene || JsonValue::String != scene->type || scene->str.empty()) return fail("the take names no scene");
+
+        const JsonValue *integrator = nullptr, *post = nullptr, *exporter = nullptr, *sensor = nullptr;
+        for (const auto& kv : root.obj) {
+            if (kv.first == "sensor") sensor = &kv.second;
+            else if (kv.first == "camera") loadCamera(kv.second);
+            else if (kv.first == "cameras" && JsonValue::Array == kv.second.type && !kv.second.arr.empty()) loadCamera(kv.second.arr[0]);
+            else if (kv.first == "export") exporter = &kv.second;
+            else if (kv.first == "integrator") integrator = &kv.second;
+            else if (kv.first == "post") post = &kv.second;
+            else if (kv.first == "sampler") loadSampler(kv.second);
+        }
+        if (ZYGPU_NULL == engine_.camera_entity) return fail("the take defines no Perspective camera");
+        if (integrator) engine_.loadIntegrators(*integrator);
+        {
+            // the post-processor chain's tonemapper belongs to the sensor here (Engine::loadSensor reads both)
+            JsonValue merged = sensor ? *sensor : JsonValue();
+            if (JsonValue::Object != merged.type) {
+                merged = JsonValue();
+                merged.type = JsonValue::Object;
+            }
+            if (post && JsonValue::Array == post->type)
+                for (const JsonValue& pp : post->arr)
+                    if (const JsonValue* t = pp.get("tonemapper")) merged.obj.emplace_back("tonemapper", *t);
+            engine_.loadSensor(merged);
+        }
+        if (exporter) loadExporters(*exporter);
+        return loadSceneFile(scene->str, take_dir_, identity());
+    }
+
+  private:
+    struct Node {  // scene_graph.zig Node.world_trafo
+        Transformation world;
+    };
+
+    Engine&                         engine_;
+    std::string                     take_dir_;
+    std::map<std::string, uint32_t> materials_by_name_, shapes_by_file_;
+
+    bool fail(const std::string& what) {
+        error = what;
+        return false;
+    }
+    static Transformation identity() { return {splat(0.f), splat(1.f), vec(0.f, 0.f, 0.f, 1.f)}; }
+    static std::string    parentDirectory(const std::string& p) {
+        const size_t at = p.find_last_of('/');
+        return std::string::npos == at ? std::string() : p.substr(0, at);
+    }
+    static bool readFile(const std::string& path, std::string& out) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return false;
+        std::ostringstream ss;
+        ss << f.rdbuf();
+        out = ss.str();
+        return true;
+    }
+    static bool readJson(const std::string& path, JsonValue& v) {
+        std::string text;
+        return readFile(path, text) && JsonParser::parse(text.c_str(), v);
+    }
+    std::string resolve(const std::string& name, const std::string& dir) const {
+        if (!name.empty() && '/' == name[0]) return name;
+        for (const std::string& d : {dir, take_dir_}) {
+            const std::string p = d.empty() ? name : d + "/" + name;
+            if (std::ifstream(p)) return p;
+        }
+        return name;
+    }
+
+    // ---- base/json.zig:165-245
+    static Vec4f readVec3(const JsonValue& v, Vec4f def) {
+        if (JsonValue::Array != v.type || v.arr.size() < 3) return def;
+        return vec(v.arr[0].f32(), v.arr[1].f32(), v.arr[2].f32(), 0.f);
+    }
+    static Mat3x3 rotationX(float a) {
+        const float c = std::cos(a), s = std::sin(a);
+        return {{vec(1.f, 0.f, 0.f), vec(0.f, c, -s), vec(0.f, s, c)}};
+    }
+    static Mat3x3 rotationY(float a) {
+        const float c = std::cos(a), s = std::sin(a);
+        return {{vec(c, 0.f, s), vec(0.f, 1.f, 0.f), vec(-s, 0.f, c)}};
+    }
+    static Mat3x3 rotationZ(float a) {
+        const float c = std::cos(a), s = std::sin(a);
+        return {{vec(c, -s, 0.f), vec(s, c, 0.f), vec(0.f, 0.f, 1.f)}};
+    }
+    static Mat3x3 mul(const Mat3x3& a, const Mat3x3& b) {  // matrix3x3.zig:99-111
+        Mat3x3 o;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) o.r[i][j] = a.r[i][0] * b.r[0][j] + a.r[i][1] * b.r[1][j] + a.r[i][2] * b.r[2][j];
+        for (int i = 0; i < 3; ++i) o.r[i][3] = 0.f;
+        return o;
+    }
+    static void readTransformation(const JsonValue& v, Transformation& t) {
+        if (JsonValue::Object == v.type) {
+            Vec4f up = vec(0.f, 1.f, 0.f), look_at = vec(0.f, 0.f, 1.f);
+            bool  look = false;
+            for (const auto& kv : v.obj) {
+                if (kv.first == "position") t.position = readVec3(kv.second, t.position);
+                else if (kv.first == "scale") t.scale = readVec3(kv.second, t.scale);
+                else if (kv.first == "rotation") {
+                    const Vec4f d = readVec3(kv.second, splat(0.f));
+                    const float k = float(M_PI / 180.0);
+                    t.rotation = quaternionFromMat3x3(mul(mul(rotationZ(d[2] * k), rotationX(d[0] * k)), rotationY(d[1] * k)));
+                } else if (kv.first == "look_at") {
+                    look_at = readVec3(kv.second, look_at);
+                    look = true;
+                } else if (kv.first == "up") {
+                    up = readVec3(kv.second, up);
+                }
+            }
+            if (look) {
+                const Vec4f dir = normalize3(look_at - t.position);
+                const Vec4f right = -cross3(dir, up);
+                t.rotation = quaternionFromMat3x3(Mat3x3{{right, up, dir}});
+            }
+        } else if (JsonValue::Array == v.type && v.arr.size() >= 16) {
+            Mat4x4 m;
+            for (int r = 0; r < 4; ++r) m.r[r] = vec(v.arr[4 * r].f32(), v.arr[4 * r + 1].f32(), v.arr[4 * r + 2].f32(), v.arr[4 * r + 3].f32());
+            Mat3x3 basis;
+            decompose(m, basis, t.scale, t.position);
+            t.position[3] = 0.f;
+            t.rotation = quaternionFromMat3x3(basis);
+        }
+    }
+    static Vec4f quaternionMul(const Vec4f& a, const Vec4f& b) {  // quaternion.zig:208-215
+        return vec((a[3] * b[0] + a[0] * b[3]) + (a[1] * b[2] - a[2] * b[1]), (a[3] * b[1] + a[1] * b[3]) + (a[2] * b[0] - a[0] * b[2]),
+                   (a[3] * b[2] + a[2] * b[3]) + (a[0] * b[1] - a[1] * b[0]), (a[3] * b[3] - a[0] * b[0]) - (a[1] * b[1] + a[2] * b[2]));
+    }
+    static Transformation transform(const Transformation& parent, const Transformation& child) {  // transformation.zig:30-36
+        const Mat4x4 m = compose(quaternionToMat3x3(parent.rotation), parent.scale, parent.position);
+        Vec4f        p = splat(child.position[0]) * m.r[0] + splat(child.position[1]) * m.r[1] + splat(child.position[2]) * m.r[2] + m.r[3];
+        p[3] = 0.f;
+        return {p, parent.scale * child.scale, quaternionMul(child.rotation, parent.rotation)};
+    }
+    void setWorld(uint32_t entity, const Transformation& world) { engine_.setWorldTransformation(entity, world); }
+
+    // ---- take_loader.zig:92-151, 232-243
+    void loadCamera(const JsonValue& v) {
+        if (JsonValue::Object != v.type) return;
+        const JsonValue* cam = v.get("Perspective");
+        if (!cam || JsonValue::Object != cam->type) return;  // Orthographic cameras are not provided
+        int32_t res[2] = {0, 0};
+        if (const JsonValue* r = cam->get("resolution"))
+            if (JsonValue::Array == r->type && r->arr.size() >= 2) {
+                res[0] = int32_t(r->arr[0].f32());
+                res[1] = int32_t(r->arr[1].f32());
+            }
+        engine_.cameraCreate(uint32_t(res[0]), uint32_t(res[1]));
+        if (const JsonValue* c = cam->get("crop"))
+            if (JsonValue::Array == c->type && c->arr.size() >= 4)
+                for (int i = 0; i < 4; ++i) engine_.crop[i] = int32_t(c->arr[i].f32());
+        if (const JsonValue* p = cam->get("parameters")) engine_.loadCameraParameters(*p);
+        Transformation t = identity();
+        if (const JsonValue* tr = cam->get("transformation")) readTransformation(*tr, t);
+        setWorld(engine_.camera_entity, t);
+    }
+    void loadSampler(const JsonValue& v) {
+        if (JsonValue::Object != v.type) return;
+        engine_.sampler_kind = ZYGPU_SAMPLER_SOBOL;
+        for (const auto& kv : v.obj) {
+            engine_.num_samples_per_pixel = kv.second.memberU32("samples_per_pixel", 1);
+            if (kv.first == "Random") {
+                engine_.sampler_kind = ZYGPU_SAMPLER_RANDOM;
+                return;
+            }
+        }
+    }
+    void loadExporters(const JsonValue& v) {  // take.zig:303-331
+        exporters.clear();
+        if (JsonValue::Object != v.type) return;
+        for (const auto& kv : v.obj) {
+            if (kv.first != "Image") continue;
+            imgw::Exporter   e;
+            const JsonValue* f = kv.second.get("format");
+            const std::string format = (f && JsonValue::String == f->type) ? f->str : "PNG";
+            if ("EXR" == format) {
+                e.format = imgw::Exporter::EXR;
+                e.half = 16 == kv.second.memberU32("bitdepth", 16);
+            } else if ("RGBE" == format) {
+                e.format = imgw::Exporter::RGBE;
+            } else {
+                e.error_diffusion = kv.second.memberBool("error_diffusion", false);
+            }
+            exporters.push_back(e);
+        }
+    }
+
+    // ---- scene_loader.zig:132-230
+    bool loadSceneFile(const std::string& name, const std::string& dir, const Transformation& parent) {
+        const std::string path = resolve(name, dir);
+        JsonValue         root;
+        if (!readJson(path, root) || JsonValue::Object != root.type) return fail("cannot read scene \"" + path + "\"");
+        const std::string                       here = parentDirectory(path);
+        std::map<std::string, const JsonValue*> local_materials;
+        if (const JsonValue* ms = root.get("materials"))
+            if (JsonValue::Array == ms->type)
+                for (const JsonValue& m : ms->arr)
+                    if (const JsonValue* n = m.get("name"))
+                        if (JsonValue::String == n->type) local_materials[n->str] = &m;
+        if (const JsonValue* es = root.get("entities")) return loadEntities(*es, parent, local_materials, here);
+        return true;
+    }
+    bool loadEntities(const JsonValue& v, const Transformation& parent, const std::map<std::string, const JsonValue*>& local_materials,
+                      const std::string& dir) {
+        if (JsonValue::Array != v.type) return true;
+        for (const JsonValue& e : v.arr) {
+            if (JsonValue::Object != e.type) continue;
+            if (const JsonValue* file = e.get("file")) {
+                if (JsonValue::String == file->type && !loadSceneFile(file->str, dir, parent)) return false;
+                continue;
+            }
+            Transformation world;
+            if (!loadEntity(e, parent, local_materials, dir, world)) continue;  // scene_loader.zig:220 `catch continue`
+            if (const JsonValue* children = e.get("entities"))
+                if (!loadEntities(*children, world, local_materials, dir)) return false;
+        }
+        return true;
+    }
+    bool loadEntity(const JsonValue& v, const Transformation& parent, const std::map<std::string, const JsonValue*>& local_materials,
+                    const std::string& dir, Transformation& world) {
+        const JsonValue* type = v.get("type");
+        if (!type || JsonValue::String != type->type) return false;
+        uint32_t entity = ZYGPU_NULL;
+        bool     is_light = false;
+        if (type->str == "Light") {
+            entity = loadProp(v, local_materials, dir, true);
+            is_light = true;
+        } else if (type->str == "Prop") {
+            entity = loadProp(v, local_materials, dir, false);
+        } else if (type->str != "Dummy") {
+            return false;  // Portal, Instancer, Sky, Scatterer
+        }
+        Transformation local = identity();
+        if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
+        world = transform(parent, local);
+        if (ZYGPU_NULL == entity) return "Dummy" == type->str;
+        setWorld(entity, world);
+        bool in_reflection = true;
+        if (const JsonValue* vis = v.get("visibility")) {
+            in_reflection = vis->memberBool("in_reflection", true);
+            engine_.setVisibility(entity, vis->memberBool("in_camera", true), in_reflection, vis->memberBool("in_sss", false));
+        }
+        if (is_light && in_reflection) engine_.createLight(entity);
+        return true;
+    }
+    uint32_t loadProp(const JsonValue& v, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir,
+                      bool unoccluding_default) {
+        const JsonValue* sv = v.get("shape");
+        if (!sv || JsonValue::Object != sv->type) return ZYGPU_NULL;
+        const uint32_t shape = loadShape(*sv, dir);
+        if (ZYGPU_NULL == shape) return ZYGPU_NULL;
+        const uint32_t        num_materials = engine_.shapeNumMaterials(shape);
+        std::vector<uint32_t> materials;
+        if (const JsonValue* ms = v.get("materials"))
+            if (JsonValue::Array == ms->type)
+                for (size_t i = 0; i < ms->arr.size() && i < num_materials; ++i)
+                    materials.push_back(JsonValue::String == ms->arr[i].type ? loadMaterial(ms->arr[i].str, local_materials, dir)
+                                                                              : engine_.fallbackMaterial());
+        while (materials.size() < num_materials) materials.push_back(engine_.fallbackMaterial());
+        const bool    unoccluding = !v.memberBool("occluding", !unoccluding_default);
+        const int32_t p = engine_.createPropShape(shape, materials.data(), uint32_t(materials.size()), unoccluding);
+        return p < 0 ? ZYGPU_NULL : uint32_t(p);
+    }
+    uint32_t loadMaterial(const std::string& name, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir) {
+        const auto cached = materials_by_name_.find(name);
+        if (materials_by_name_.end() != cached) return cached->second;
+        uint32_t   id = ZYGPU_NULL;
+        const auto local = local_materials.find(name);
+        if (local_materials.end() != local) {
+            id = engine_.createMaterial(ZYGPU_NULL, *local->second);
+        } else {
+            JsonValue file;
+            if (readJson(resolve(name, dir), file)) id = engine_.createMaterial(ZYGPU_NULL, file);
+        }
+        if (ZYGPU_NULL == id) id = engine_.fallbackMaterial();
+        materials_by_name_[name] = id;
+        return id;
+    }
+    uint32_t loadShape(const JsonValue& v, const std::string& dir) {  // scene_loader.zig:630-668
+        if (const JsonValue* t = v.get("type")) {
+            if (JsonValue::String != t->type) return ZYGPU_NULL;
+            static const char* names[] = {"Canopy", "Cube", "Disk", "Distant", "Dome", "Rectangle", "Sphere"};  // manager.zig:36-44
+            for (uint32_t i = 0; i < 7; ++i)
+                if (t->str == names[i]) return i;
+            return ZYGPU_NULL;
+        }
+        const JsonValue* f = v.get("file");
+        if (!f || JsonValue::String != f->type) return ZYGPU_NULL;
+        const std::string path = resolve(f->str, dir);
+        const auto        cached = shapes_by_file_.find(path);
+        if (shapes_by_file_.end() != cached) return cached->second;
+        const uint32_t shape = loadMeshFile(path);
+        shapes_by_file_[path] = shape;
+        return shape;
+    }
+
+    // ---- shape_provider.zig:146-272: "SUB\0" -> binary, else JSON
+    uint32_t loadMeshFile(const std::string& path) {
+        std::string data;
+        if (!readFile(path, data)) return ZYGPU_NULL;
+        if (data.size() >= 12 && 0 == std::memcmp(data.data(), "SUB\0", 4)) return loadSub(data);
+        JsonValue root;
+        if (!JsonParser::parse(data.c_str(), root)) return ZYGPU_NULL;
+        const JsonValue* g = root.get("geometry");
+        if (!g || JsonValue::Object != g->type) return ZYGPU_NULL;
+        std::vector<uint32_t> parts, indices;
+        std::vector<float>    positions, normals, uvs;
+        readParts(*g, parts);
+        auto floats = [](const JsonValue* a, std::vector<float>& out) {
+            if (!a || JsonValue::Array != a->type) return;
+            const JsonValue* src = a;
+            if (!a->arr.empty() && JsonValue::Array == a->arr[0].type) src = &a->arr[0];  // animated: the first frame
+            out.reserve(src->arr.size());
+            for (const JsonValue& x : src->arr) out.push_back(x.f32());
+        };
+        if (const JsonValue* vs = g->get("vertices")) {
+            floats(vs->get("positions"), positions);
+            floats(vs->get("normals"), normals);
+            floats(vs->get("texture_coordinates_0"), uvs);
+        }
+        if (const JsonValue* is = g->get("indices"))
+            if (JsonValue::Array == is->type)
+                for (const JsonValue& x : is->arr) indices.push_back(uint32_t(x.f32()));
+        return createMesh(parts, indices, positions, normals, uvs);
+    }
+    static void readParts(const JsonValue& geometry, std::vector<uint32_t>& parts) {
+        if (const JsonValue* ps = geometry.get("parts"))
+            if (JsonValue::Array == ps->type)
+                for (const JsonValue& p : ps->arr) {
+                    parts.push_back(p.memberU32("start_index", 0));
+                    parts.push_back(p.memberU32("num_indices", 0));
+                    parts.push_back(p.memberU32("material_index", 0));
+                }
+    }
+    uint32_t createMesh(const std::vector<uint32_t>& parts, const std::vector<uint32_t>& indices, const std::vector<float>& positions,
+                        const std::vector<float>& normals, const std::vector<float>& uvs) {
+        const uint32_t num_vertices = uint32_t(positions.size() / 3);
+        if (0 == num_vertices || indices.size() < 3 || normals.size() < size_t(num_vertices) * 3) return ZYGPU_NULL;
+        return engine_.createMesh(ZYGPU_NULL, uint32_t(parts.size() / 3), parts.empty() ? nullptr : parts.data(), uint32_t(indices.size() / 3),
+                                  indices.data(), num_vertices, positions.data(), 3, normals.data(), 3,
+                                  uvs.size() >= size_t(num_vertices) * 2 ? uvs.data() : nullptr, 2);
+    }
+    uint32_t loadSub(const std::string& data) {
+        uint64_t json_size;
+        std::memcpy(&json_size, data.data() + 4, 8);
+        if (12 + json_size > data.size()) return ZYGPU_NULL;
+        std::string header(data.data() + 12, size_t(json_size));
+        while (!header.empty() && 0 == header.back()) header.pop_back();
+        JsonValue root;
+        if (!JsonParser::parse(header.c_str(), root)) return ZYGPU_NULL;
+        const JsonValue* g = root.get("geometry");
+        if (!g || JsonValue::Object != g->type) return ZYGPU_NULL;
+
+        std::vector<uint32_t> parts;
+        readParts(*g, parts);
+        uint64_t vertices_offset = 0, indices_offset = 0, indices_size = 0, index_bytes = 4;
+        uint32_t num_vertices = 0, num_indices = 0, position_frames = 1, normal_frames = 1;
+        bool     quat = false, has_uvs = false, has_tangents = false, delta = false, interleaved = false;
+        if (const JsonValue* vs = g->get("vertices")) {
+            if (const JsonValue* b = vs->get("binary")) vertices_offset = uint64_t(b->memberF64("offset", 0.0));
+            num_vertices = vs->memberU32("num_vertices", 0);
+            if (const JsonValue* layout = vs->get("layout"))
+                if (JsonValue::Array == layout->type)
+                    for (const JsonValue& l : layout->arr) {
+                        const JsonValue*  sn = l.get("semantic_name");
+                        const std::string name = (sn && JsonValue::String == sn->type) ? sn->str : "";
+                        if ("Position" == name) position_frames = l.memberU32("num_frames", 1);
+                        else if ("Normal" == name) normal_frames = l.memberU32("num_frames", 1);
+                        else if ("Tangent" == name) has_tangents = true;
+                        else if ("Tangent_space" == name) quat = true;
+                        else if ("TextureCoordinate" == name || "Texture_coordinate" == name) has_uvs = true;
+                        else if ("Bitangent_sign" == name && 0 == l.memberU32("stream", 0)) interleaved = true;
+                    }
+        }
+        if (const JsonValue* is = g->get("indices")) {
+            if (const JsonValue* b = is->get("binary")) {
+                indices_offset = uint64_t(b->memberF64("offset", 0.0));
+                indices_size = uint64_t(b->memberF64("size", 0.0));
+            }
+            num_indices = is->memberU32("num_indices", 0);
+            if (const JsonValue* e = is->get("encoding"))
+                if (JsonValue::String == e->type) {
+                    index_bytes = ("Int16" == e->str || "UInt16" == e->str) ? 2 : 4;
+                    delta = "Int16" == e->str || "Int32" == e->str;
+                }
+        }
+        if (interleaved || 0 == num_vertices) return ZYGPU_NULL;  // legacy interleaved streams
+        const size_t binary_start = size_t(json_size) + 12;
+        const char*  at = data.data() + binary_start + vertices_offset;
+        const char*  end = data.data() + data.size();
+        auto         take = [&](size_t bytes, void* dst) {
+            if (at + bytes > end) return false;
+            if (dst) std::memcpy(dst, at, bytes);
+            at += bytes;
+            return true;
+        };
+        std::vector<float> positions(size_t(num_vertices) * 3), normals(size_t(num_vertices) * 3), uvs;
+        bool               ok = take(positions.size() * 4, positions.data()) && take(size_t(position_frames - 1) * num_vertices * 12, nullptr);
+        if (quat) {  // vertex_buffer.zig:163-174: the normal is the z axis of the tangent-space quaternion
+            std::vector<float> ts(size_t(num_vertices) * 4);
+            uvs.resize(size_t(num_vertices) * 2);
+            ok = ok && take(ts.size() * 4, ts.data()) && take(uvs.size() * 4, uvs.data());
+            for (uint32_t i = 0; ok && i < num_vertices; ++i) {
+                const float q[4] = {ts[4 * i], ts[4 * i + 1], ts[4 * i + 2], std::fabs(ts[4 * i + 3])};
+                const float xz = (q[2] + q[2]) * q[0], yz = (q[1] + q[1]) * q[2];
+                const float w0 = (q[0] + q[0]) * q[3], w1 = (q[1] + q[1]) * q[3];
+                const float t2 = (q[3] + q[0]) * (q[3] - q[0]), t3 = (q[1] + q[2]) * (q[1] - q[2]);
+                normals[3 * i] = xz - w1;  // quaternion.zig:173-205 toNormal
+                normals[3 * i + 1] = yz + w0;
+                normals[3 * i + 2] = t2 - t3;
+            }
+        } else {
+            ok = ok && take(normals.size() * 4, normals.data()) && take(size_t(normal_frames - 1) * num_vertices * 12, nullptr);
+            if (has_uvs && has_tangents) ok = ok && take(size_t(num_vertices) * 12, nullptr);
+            if (has_uvs) {
+                uvs.resize(size_t(num_vertices) * 2);
+                ok = ok && take(uvs.size() * 4, uvs.data());
+            }
+        }
+        if (!ok) return ZYGPU_NULL;
+        if (0 == num_indices) num_indices = uint32_t(indices_size / index_bytes);
+        const char* ib = data.data() + binary_start + indices_offset;
+        if (ib + size_t(num_indices) * index_bytes > end) return ZYGPU_NULL;
+        std::vector<uint32_t> indices(num_indices);
+        int64_t               previous = 0;
+        for (uint32_t i = 0; i < num_indices; ++i) {
+            int64_t v;
+            if (2 == index_bytes) {
+                if (delta) {
+                    int16_t x;
+                    std::memcpy(&x, ib + size_t(i) * 2, 2);
+                    v = x;
+                } else {
+                    uint16_t x;
+                    std::memcpy(&x, ib + size_t(i) * 2, 2);
+                    v = x;
+                }
+            } else if (delta) {
+                int32_t x;
+                std::memcpy(&x, ib + size_t(i) * 4, 4);
+                v = x;
+            } else {
+                uint32_t x;
+                std::memcpy(&x, ib + size_t(i) * 4, 4);
+                v = x;
+            }
+            if (delta) {  // shape_provider.zig:965-994: every index is relative to the one before it
+                previous += v;
+                v = previous;
+            }
+            indices[i] = uint32_t(v);
+        }
+        return createMesh(parts, indices, positions, normals, uvs);
+    }
+};
+
+}  // namespace zyg

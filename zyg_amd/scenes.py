@@ -401,3 +401,92 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
         engine.light(q)
     engine.transformation(cam, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1.1, -4.5)))
     return ids
+
+
+# ---------------------------------------------------------------- on-disk formats (take / scene JSON, mesh JSON, .sub)
+
+def write_sub_mesh(path, idx, pos, nrm, uv, parts=None, delta=True):
+    """A "SUB\\0" binary mesh (reference shape_provider.zig:527-805): u64 JSON size, JSON header, then separate vertex streams
+    (positions, normals, uvs) and the index stream, delta-encoded Int32 (every index relative to the one before) or UInt32."""
+    import struct
+    idx = np.asarray(idx, dtype=np.int64).reshape(-1)
+    pos = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
+    nrm = np.asarray(nrm, dtype=np.float32).reshape(-1, 3)
+    uv = np.asarray(uv, dtype=np.float32).reshape(-1, 2)
+    vertex_bytes = pos.tobytes() + nrm.tobytes() + uv.tobytes()
+    if delta:
+        enc = np.diff(np.concatenate([[0], idx])).astype(np.int32).tobytes()
+    else:
+        enc = idx.astype(np.uint32).tobytes()
+    parts = parts or [{"start_index": 0, "num_indices": int(idx.size), "material_index": 0}]
+    header = {"geometry": {
+        "parts": parts,
+        "vertices": {"binary": {"offset": 0, "size": len(vertex_bytes)}, "num_vertices": int(pos.shape[0]),
+                     "layout": [{"semantic_name": "Position", "encoding": "Float32x3", "stream": 0},
+                                {"semantic_name": "Normal", "encoding": "Float32x3", "stream": 1},
+                                {"semantic_name": "Texture_coordinate", "encoding": "Float32x2", "stream": 2}]},
+        "indices": {"binary": {"offset": len(vertex_bytes), "size": len(enc)}, "num_indices": int(idx.size),
+                    "encoding": "Int32" if delta else "UInt32"}}}
+    text = json.dumps(header).encode()
+    text += b"\0" * ((8 - len(text) % 8) % 8)
+    with open(path, "wb") as f:
+        f.write(b"SUB\0" + struct.pack("<Q", len(text)) + text + vertex_bytes + enc)
+
+
+def write_json_mesh(path, idx, pos, nrm, uv):
+    """The JSON mesh format (shape_provider.zig:334-525)."""
+    g = {"geometry": {"parts": [{"start_index": 0, "num_indices": int(np.asarray(idx).size), "material_index": 0}],
+                      "primitive_topology": "triangle_list",
+                      "vertices": {"positions": [float(x) for x in np.asarray(pos, dtype=np.float32).reshape(-1)],
+                                   "normals": [float(x) for x in np.asarray(nrm, dtype=np.float32).reshape(-1)],
+                                   "texture_coordinates_0": [float(x) for x in np.asarray(uv, dtype=np.float32).reshape(-1)]},
+                      "indices": [int(i) for i in np.asarray(idx).reshape(-1)]}}
+    with open(path, "w") as f:
+        json.dump(g, f)
+
+
+def write_cornell_take(directory, width, height, spp, integrator="PTMIS", max_depth=16):
+    """Writes cornell.take / cornell.scene / the two box meshes (one JSON, one .sub) describing exactly what
+    cornell(engine, width, height, spp, material="substitute") builds through the API; returns the take's path."""
+    import os
+
+    def m16(r0, r1, scale, position):
+        return [float(x) for x in trafo(r0, r1, scale, position).reshape(-1)]
+
+    def mat(name, text):
+        d = json.loads(text)
+        d["name"] = name
+        return d
+
+    materials = [mat("white", substitute(WHITE)), mat("red", substitute(RED)), mat("green", substitute(GREEN)),
+                 mat("lamp", light_material())]
+    entities = []
+    for name, r0, r1, pos in (("white", (1, 0, 0), (0, 0, -1), (0, 0, 0)), ("white", (1, 0, 0), (0, 0, 1), (0, 2, 0)),
+                              ("white", (-1, 0, 0), (0, 1, 0), (0, 1, 1)), ("red", (0, 0, -1), (0, 1, 0), (-1, 1, 0)),
+                              ("green", (0, 0, 1), (0, 1, 0), (1, 1, 0))):
+        entities.append({"type": "Prop", "shape": {"type": "Rectangle"}, "materials": [name],
+                         "transformation": m16(r0, r1, (2, 2, 1), pos)})
+    for lx in (-0.45, 0.45):
+        entities.append({"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"],
+                         "transformation": m16((1, 0, 0), (0, 0, 1), (0.5, 0.5, 1), (lx, 1.98, 0.0))})
+    boxes = (((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0))
+    write_json_mesh(os.path.join(directory, "tall_box.json"), *box_mesh(*boxes[0]))
+    write_sub_mesh(os.path.join(directory, "short_box.sub"), *box_mesh(*boxes[1]))
+    for f in ("tall_box.json", "short_box.sub"):
+        entities.append({"type": "Prop", "shape": {"file": f}, "materials": ["white"],
+                         "transformation": m16((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))})
+    with open(os.path.join(directory, "cornell.scene"), "w") as f:
+        json.dump({"materials": materials, "entities": entities}, f)
+    take = {"scene": "cornell.scene",
+            "camera": {"Perspective": {"parameters": {"fov": 39.3}, "resolution": [width, height],
+                                       "transformation": m16((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, -3.9)),
+                                       "shutter": {"motion_blur": False}}},
+            "sampler": {"Sobol": {"samples_per_pixel": spp}},
+            "integrator": {"surface": {integrator: {"depth": {"surface": max_depth}}}},
+            "sensor": {},
+            "post": [{"tonemapper": {"Linear": {"exposure": 0.0}}}],
+            "export": {"Image": {"format": "PNG"}}}
+    path = os.path.join(directory, "cornell.take")
+    with open(path, "w") as f:
+        json.dump(take, f)
+    return path
