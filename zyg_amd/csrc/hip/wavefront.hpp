@@ -32,28 +32,76 @@ enum : uint32_t {
     ST_STARTED_SPECULAR = 1u << 5
 };
 
-struct Pool {  // SoA of 16 B records, indexed by path slot
-    uint4*    q0;       // sobol run_seed, meta, sobol buffer[4] bits, NEE state
-    float4*   q1;       // sobol buffer[0..3]
-    uint2*    pcg;      // PCG state
-    float4*   ray_o;    // extension ray origin.xyz, max_t
-    float4*   ray_d;    // extension ray direction.xyz, vertex.bxdf_pdf
-    float4*   thr;      // throughput.xyz
-    float4*   vorigin;  // vertex.origin
-    float4*   vgeo_n;   // vertex.geo_n
-    float4*   emission; // IValue (helper.zig:6-19)
-    float4*   direct;
-    float4*   indirect;
-    uint4*    hit;      // t, u, v (bits), primitive
-    uint32_t* hit_prop;
-    uint32_t* ucount;   // unoccluding lights the extension ray crosses in front of its hit (PropBvh.emission's candidates)
+// The records every stage touches live interleaved, one 256 B block (two 128 B lines) per path slot, instead of in one array
+// each: slot == sample index, so the living slots thin out with depth (Cornell: ~80 % survive a bounce), and a 16 B record
+// of a separate array then costs a whole 64 B sector / 128 B line of which a quarter or less is used.  Measured with
+// separate arrays (PMC FETCH_SIZE, profiles/): wf_shade's first pass fetched 320 B per vertex for ~110 B of records.
+// With the block, a path's records share their lines at any density.  ZYG_POOL_STRIDE 0 restores the separate arrays.
+#ifndef ZYG_POOL_STRIDE
+#define ZYG_POOL_STRIDE 256
+#endif
+// hit, hit_prop, ucount: 32 = a block of their own, one 32 B sector per path, written by wf_intersect and read by wf_shade
+// (inside the 256 B block, ZYG_HIT_STRIDE 0, wf_intersect's partial-line writes cost it 8 %; measured 414 vs 427 Msamples/s)
+#ifndef ZYG_HIT_STRIDE
+#define ZYG_HIT_STRIDE 32
+#endif
+#if ZYG_POOL_STRIDE
+template <typename T, int STRIDE = ZYG_POOL_STRIDE>
+struct Rec {
+    char* base;  // block base + the member's offset (RecOffsets)
+    ZD T& operator[](size_t i) const { return *reinterpret_cast<T*>(base + i * size_t(STRIDE)); }
+};
+template <typename T>
+using HitRec = Rec<T, ZYG_HIT_STRIDE ? ZYG_HIT_STRIDE : ZYG_POOL_STRIDE>;
+#else
+template <typename T>
+using Rec = T*;
+template <typename T>
+using HitRec = T*;
+#endif
+// line A: what wf_intersect and wf_shade's first pass touch; line B: the rest of the hit record and the previous vertex
+enum RecOffsets : uint32_t {
+    kOffQ0 = 0, kOffQ1 = 16, kOffPcg = 32, kOffRayO = 48, kOffRayD = 64, kOffThr = 80,
+#ifdef ZYG_ACC_SEPARATE
+    kOffRecP = 112,
+#else
+    // the IValue accumulator wf_scatter adds to at every bounce (indirect) sits in the line it rewrites anyway (as a separate
+    // array each add was a read-modify-write of one more sparse sector); the two others share a sector nobody else touches
+    kOffIndirect = 96, kOffRecP = 112, kOffEmission = 224, kOffDirect = 240,
+#endif
+    kOffRecGn = 128, kOffRecN = 144, kOffRecT = 160, kOffRecB = 176, kOffVorigin = 192, kOffVgeoN = 208,
+    kOffHit = 96, kOffHitProp = 40, kOffUcount = 44  // with ZYG_HIT_STRIDE 0 only
+};
+#if ZYG_POOL_STRIDE && !defined(ZYG_ACC_SEPARATE)
+template <typename T>
+using AccRec = Rec<T>;
+#else
+template <typename T>
+using AccRec = T*;
+#endif
+
+struct Pool {  // 16 B records, indexed by path slot
+    Rec<uint4>    q0;       // sobol run_seed, meta, sobol buffer[4] bits, NEE state
+    Rec<float4>   q1;       // sobol buffer[0..3]
+    Rec<uint2>    pcg;      // PCG state
+    Rec<float4>   ray_o;    // extension ray origin.xyz, max_t
+    Rec<float4>   ray_d;    // extension ray direction.xyz, vertex.bxdf_pdf
+    Rec<float4>   thr;      // throughput.xyz
+    Rec<float4>   vorigin;  // vertex.origin
+    Rec<float4>   vgeo_n;   // vertex.geo_n
+    AccRec<float4> emission; // IValue (helper.zig:6-19)
+    AccRec<float4> direct;
+    AccRec<float4> indirect;
+    HitRec<uint4>    hit;      // t, u, v (bits), primitive
+    HitRec<uint32_t> hit_prop;
+    HitRec<uint32_t> ucount;   // unoccluding lights the extension ray crosses in front of its hit (PropBvh.emission's candidates)
     uint4*    ucand;    //   [candidate][slot]: prop, t, u, v (bits), in traversal order
     uint32_t* ucand_prim; //                    triangle (mesh lights)
-    float4*   rec_p;    // compacted hit record: p.xyz, material index (bits)
-    float4*   rec_gn;   //   geometric normal after the two-sided flip (vertex.zig:155-161), w = 1 if flipped
-    float4*   rec_n;    //   shading normal (flipped likewise)
-    float4*   rec_t;    //   tangent
-    float4*   rec_b;    //   bitangent
+    Rec<float4>   rec_p;    // compacted hit record: p.xyz, material index (bits)
+    Rec<float4>   rec_gn;   //   geometric normal after the two-sided flip (vertex.zig:155-161), w = 1 if flipped
+    Rec<float4>   rec_n;    //   shading normal (flipped likewise)
+    Rec<float4>   rec_t;    //   tangent
+    Rec<float4>   rec_b;    //   bitangent
     uint2*    picks;    // light picks 1.. of the current vertex, [pick][slot]: light, pdf bits (pick 0 never leaves registers)
     float4*   sh_o;     // shadow ray of the running pick: origin.xyz, max_t
     float4*   sh_d;     //   direction.xyz
@@ -404,9 +452,9 @@ ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
 // is skipped: the accumulators start at +0 and only ever receive non-negative terms, so x + 0 == x bit for bit.
 ZD void ivalueAdd(const Params& P, uint32_t slot, f3 value, uint32_t depth, uint32_t direct_cutoff, bool is_emission, bool singular) {
     if (0.f == value.x && 0.f == value.y && 0.f == value.z) return;
-    float4* target = is_emission ? P.pool.emission : (singular || depth < direct_cutoff) ? P.pool.direct : P.pool.indirect;
-    const float4 old = target[slot];
-    target[slot] = f4(xyz4(old) + value);
+    float4& target = is_emission ? P.pool.emission[slot] : (singular || depth < direct_cutoff) ? P.pool.direct[slot] : P.pool.indirect[slot];
+    const float4 old = target;
+    target = f4(xyz4(old) + value);
 }
 
 ZD f3 clampColor(f3 color, float max) {  // sensor.zig:615-624

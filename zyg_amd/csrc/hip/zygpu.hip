@@ -345,15 +345,38 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
     const size_t   paths = c->pool_mode ? slots * 2 * kPoolVertices : slots;
     std::memset(&p, 0, sizeof(p));
     std::memset(&c->queues, 0, sizeof(c->queues));
-    bool           ok = m.alloc(paths, &p.q0) && m.alloc(paths, &p.q1) && m.alloc(paths, &p.pcg) && m.alloc(paths, &p.ray_o) &&
-              m.alloc(paths, &p.ray_d) && m.alloc(paths, &p.thr) && m.alloc(paths, &p.vorigin) && m.alloc(paths, &p.vgeo_n) &&
-              m.alloc(paths, &p.emission) && m.alloc(paths, &p.direct) && m.alloc(paths, &p.indirect) && m.alloc(paths, &p.hit) &&
-              m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.ucount) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) && m.alloc(paths, &p.rec_n) &&
-              m.alloc(paths, &p.rec_t) && m.alloc(paths, &p.rec_b) && m.alloc(qcap, &c->queues.ext[0]) &&
-              m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) && m.alloc(paths, &c->stage_color) &&
-              m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) && m.alloc(paths, &p.sh_o) &&
-              m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
-              m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy);
+    bool ok = true;
+#if ZYG_POOL_STRIDE
+    {  // the interleaved record block (wavefront.hpp Rec / RecOffsets)
+        char* block = nullptr;
+        ok = m.alloc(paths * size_t(ZYG_POOL_STRIDE), &block);
+        p.q0.base = block + kOffQ0, p.q1.base = block + kOffQ1, p.pcg.base = block + kOffPcg, p.hit_prop.base = block + kOffHitProp;
+        p.ucount.base = block + kOffUcount, p.ray_o.base = block + kOffRayO, p.ray_d.base = block + kOffRayD, p.thr.base = block + kOffThr;
+        p.hit.base = block + kOffHit, p.rec_p.base = block + kOffRecP, p.rec_gn.base = block + kOffRecGn, p.rec_n.base = block + kOffRecN;
+        p.rec_t.base = block + kOffRecT, p.rec_b.base = block + kOffRecB, p.vorigin.base = block + kOffVorigin, p.vgeo_n.base = block + kOffVgeoN;
+#ifndef ZYG_ACC_SEPARATE
+        p.emission.base = block + kOffEmission, p.direct.base = block + kOffDirect, p.indirect.base = block + kOffIndirect;
+#endif
+#if ZYG_HIT_STRIDE
+        char* hits = nullptr;
+        ok = ok && m.alloc(paths * size_t(ZYG_HIT_STRIDE), &hits);
+        p.hit.base = hits, p.hit_prop.base = hits + 16, p.ucount.base = hits + 20;
+#endif
+    }
+#else
+    ok = m.alloc(paths, &p.q0) && m.alloc(paths, &p.q1) && m.alloc(paths, &p.pcg) && m.alloc(paths, &p.ray_o) && m.alloc(paths, &p.ray_d) &&
+         m.alloc(paths, &p.thr) && m.alloc(paths, &p.vorigin) && m.alloc(paths, &p.vgeo_n) && m.alloc(paths, &p.hit) &&
+         m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.ucount) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) &&
+         m.alloc(paths, &p.rec_n) && m.alloc(paths, &p.rec_t) && m.alloc(paths, &p.rec_b);
+#endif
+#if !ZYG_POOL_STRIDE || defined(ZYG_ACC_SEPARATE)
+    ok = ok && m.alloc(paths, &p.emission) && m.alloc(paths, &p.direct) && m.alloc(paths, &p.indirect);
+#endif
+    ok = ok && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) &&
+         m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) &&
+         m.alloc(paths, &c->stage_color) && m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) &&
+         m.alloc(paths, &p.sh_o) && m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
+         m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy);
     if (ok && c->pool_mode) {
         ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) &&
              m.alloc(slots, &p.pstate) && m.alloc(slots, &p.transp);
