@@ -84,7 +84,7 @@ int32_t su_ext_render_rows(uint32_t num_steps, int32_t y_begin, int32_t y_end);
 /* Inner-ABI context of the engine (valid after su_start_frame / su_render_frame). */
 ZygpuContext* su_ext_context(void);
 /* The GGX albedo tables Substitute scenes are compiled with (replaces the constants of material/ggx_integral.zig:3,166,
- * 175,979): which = 0 E_m[32*32], 1 E_m_avg[32], 2 E[16*16*16], 3 E_avg[16*16].  Copies up to capacity floats,
+ * 175,979, 1048): which = 0 E_m[32*32], 1 E_m_avg[32], 2 E[16*16*16], 3 E_avg[16*16], 4 E_s[16*16*16].  Copies up to capacity floats,
  * returns the table's length (0 for an unknown table).  Host-only: needs no device. */
 uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity);
 /* The image encoders behind su_export_frame on a caller-provided Float4 image (core/exporting/image_sequence.zig,

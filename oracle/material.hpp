@@ -99,6 +99,8 @@ struct Luts {
     float E_m_avg(float alpha) const { return eval1(l->e_m_avg, 32, alpha); }
     float E(float n_dot, float alpha, float f0) const { return eval3(l->e, 16, 16, 16, n_dot, alpha, f0); }
     float E_avg(float alpha, float f0) const { return eval2(l->e_avg, 16, 16, alpha, f0); }
+    // ggx.ilmEpDielectric (ggx.zig:30-32): E_s over f0 in [0, 0.25] (ggx_integral.zig:1045 E_s_inverse_max_f0 = 4)
+    float ilmEpDielectric(float n_dot_wo, float alpha, float f0) const { return 1.f / eval3(l->e_s, 16, 16, 16, n_dot_wo, alpha, f0 * 4.f); }
 };
 
 namespace fresnel {
@@ -223,6 +225,82 @@ inline Micro reflect(V4 wo, float n_dot_wo, const float alpha[2], float specular
     return {h, n_dot_wi, wo_dot_h};
 }
 
+// ---- rough dielectrics: ggx.Iso.reflectNoFresnel / refractNoFresnel / reflectionF / refractionF (ggx.zig:73-95, 127-227)
+inline float gSmithCorrelated(float n_dot_wi, float n_dot_wo, float alpha2) {  // :246-251
+    const float a = n_dot_wo * std::sqrt(std::fmaf(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
+    const float b = n_dot_wi * std::sqrt(std::fmaf(1.f - alpha2, n_dot_wo * n_dot_wo, alpha2));
+    return (2.f * n_dot_wi * n_dot_wo) / (a + b);
+}
+inline float pdfVisibleRefract(float n_dot_wo, float wo_dot_h, float d, float alpha2) {  // :441-449
+    const float g1 = (2.f * n_dot_wo) / (n_dot_wo + std::sqrt(alpha2 + (1.f - alpha2) * (n_dot_wo * n_dot_wo)));
+    return g1 * wo_dot_h * d / n_dot_wo;
+}
+inline float clampAbs(float x) { return clampf(std::fabs(x), kDotMin, 1.f); }  // safe.zig:16-18
+
+inline float reflectNoFresnel(V4 wo, V4 h, float n_dot_wo, float n_dot_h, float wo_dot_h, float alpha, float specular_threshold,
+                              const Frame& frame, BxdfSample& result) {
+    const V4    wi = normalize3(fma4(S(2.f * wo_dot_h), h, -wo));
+    const float n_dot_wi = frame.clampNdot(wi);
+    const float alpha2 = alpha * alpha;
+    const float d = isoDistribution(n_dot_h, alpha2);
+    float       g[2];
+    isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g);
+    result.reflection = S(d * g[0]);
+    result.wi = wi;
+    result.pdf = pdfVisible(d, g[1]);
+    result.path = PathInfo::reflection(alpha, specular_threshold);
+    return n_dot_wi;
+}
+inline float refractNoFresnel(V4 wo, V4 h, float n_dot_wo, float n_dot_h, float wi_dot_h, float wo_dot_h, float alpha,
+                              float specular_threshold, float eta_i, float eta_t, const Frame& frame, BxdfSample& result) {
+    const float eta = eta_i / eta_t;
+    const float abs_wi_dot_h = clampAbs(wi_dot_h), abs_wo_dot_h = clampAbs(wo_dot_h);
+    const V4    wi = normalize3(S(std::fmaf(eta, abs_wo_dot_h, -abs_wi_dot_h)) * h - S(eta) * wo);
+    const float n_dot_wi = frame.clampAbsNdot(wi);
+    const float alpha2 = alpha * alpha;
+    const float d = isoDistribution(n_dot_h, alpha2);
+    const float g = gSmithCorrelated(n_dot_wi, n_dot_wo, alpha2);
+    const float refr = d * g;
+    const float factor = (abs_wi_dot_h * abs_wo_dot_h) / (n_dot_wi * n_dot_wo);
+    const float dn = eta_i * wo_dot_h + eta_t * wi_dot_h, denom = dn * dn;
+    const float sqr_eta_t = eta_t * eta_t;
+    const float pdf = pdfVisibleRefract(n_dot_wo, abs_wo_dot_h, d, alpha2);
+    result.reflection = S((factor * sqr_eta_t / denom) * refr);
+    result.wi = wi;
+    result.pdf = pdf * (abs_wi_dot_h * sqr_eta_t / denom);
+    result.path = {alpha, alpha <= specular_threshold ? Scattering::Specular : Scattering::Glossy, PathEvent::Transmission};
+    return n_dot_wi;
+}
+struct ResultF {
+    BxdfResult r;
+    float      f;
+};
+inline ResultF reflectionF(V4 h, V4 n, float n_dot_wi, float n_dot_wo, float wo_dot_h, float alpha, float f0) {
+    const float alpha2 = alpha * alpha;
+    const float n_dot_h = saturate(dot3(n, h));
+    const float d = isoDistribution(n_dot_h, alpha2);
+    float       g[2];
+    isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g);
+    const V4 f = fresnel::schlick(S(f0), wo_dot_h);
+    return {{S(d * g[0]) * f, pdfVisible(d, g[1])}, f[0]};
+}
+inline ResultF refractionF(float n_dot_wi, float n_dot_wo, float wi_dot_h, float wo_dot_h, float n_dot_h, float alpha, float eta_i,
+                           float eta_t, float f0) {
+    const float alpha2 = alpha * alpha;
+    const float abs_wi_dot_h = clampAbs(wi_dot_h), abs_wo_dot_h = clampAbs(wo_dot_h);
+    const float d = isoDistribution(n_dot_h, alpha2);
+    const float g = gSmithCorrelated(n_dot_wi, n_dot_wo, alpha2);
+    const float cos_x = eta_i > eta_t ? abs_wi_dot_h : abs_wo_dot_h;
+    const float f = 1.f - fresnel::schlick(S(f0), cos_x)[0];
+    const float sqr_eta_t = eta_t * eta_t;
+    const float factor = (abs_wi_dot_h * abs_wo_dot_h) / (n_dot_wi * n_dot_wo);
+    const float dn = eta_i * wo_dot_h + eta_t * wi_dot_h, denom = dn * dn;
+    const float refr = d * g * f;
+    const float refl = (factor * sqr_eta_t / denom) * refr;
+    const float pdf = pdfVisibleRefract(n_dot_wo, abs_wo_dot_h, d, alpha2);
+    return {{S(refl), pdf * (abs_wi_dot_h * sqr_eta_t / denom)}, f};
+}
+
 }  // namespace ggx
 
 namespace diffuse_micro {  // diffuse.zig:42-110
@@ -270,7 +348,7 @@ struct MaterialSample {
     Luts  luts;
     // Glass
     V4    absorption;
-    float ior, ior_outside;
+    float ior, ior_outside, glass_f0;
     bool  lower_priority;
 
     bool sameHemisphere(V4 v) const { return dot3(geo_n, v) > 0.f; }
@@ -326,8 +404,115 @@ struct MaterialSample {
     }
 
     // ---- dispatch: material_sample.zig:47-60 ----
-    BxdfResult evaluate(V4 wi, bool force_disable_caustics) const {
-        if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return {S(0.f), 0.f};  // glass_sample.zig:72-78: not rough
+    // Glass.Sample.evaluate (glass_sample.zig:68-146): rough interfaces only; `split`: max_splits > 1
+    BxdfResult glassEvaluate(V4 wi, bool split, bool force_disable_caustics) const {
+        const float a = alpha[0];
+        if (ior == ior_outside || !(a > 0.f) || lower_priority || ((force_disable_caustics || avoid_caustics) && a <= specular_threshold))
+            return {S(0.f), 0.f};
+        const float s = specular;
+        if (!sameHemisphere(wo)) {  // thick refraction from inside
+            const float eta_i = ior, eta_t = ior_outside;
+            const V4    h = -normalize3(S(eta_t) * wi + S(eta_i) * wo);
+            const float wi_dot_h = dot3(wi, h);
+            if (wi_dot_h <= 0.f) return {S(0.f), 0.f};
+            const float wo_dot_h = dot3(wo, h);
+            const float eta = eta_i / eta_t;
+            const float sint2 = (eta * eta) * (1.f - wo_dot_h * wo_dot_h);
+            if (sint2 >= 1.f) return {S(0.f), 0.f};
+            const float n_dot_wi = frame.clampNdot(wi), n_dot_wo = frame.clampAbsNdot(wo);
+            const float n_dot_h = saturate(dot3(frame.z, h));
+            const ggx::ResultF gg = ggx::refractionF(n_dot_wi, n_dot_wo, wi_dot_h, wo_dot_h, n_dot_h, a, eta_i, eta_t, glass_f0);
+            const float comp = luts.ilmEpDielectric(n_dot_wo, a, glass_f0);
+            const float split_pdf = split ? 1.f : gg.f;
+            return {S(mn(n_dot_wi, n_dot_wo) * comp * s) * gg.r.reflection, split_pdf * gg.r.pdf};
+        }
+        if (sameHemisphere(wi)) {
+            const float n_dot_wi = frame.clampNdot(wi), n_dot_wo = frame.clampAbsNdot(wo);
+            const V4    h = normalize3(wo + wi);
+            const float wo_dot_h = clampDot(wo, h);
+            const ggx::ResultF gg = ggx::reflectionF(h, frame.z, n_dot_wi, n_dot_wo, wo_dot_h, a, glass_f0);
+            const float comp = luts.ilmEpDielectric(n_dot_wo, a, glass_f0);
+            const float split_pdf = split ? 1.f : gg.f;
+            return {S(n_dot_wi * comp * s) * gg.r.reflection, split_pdf * gg.r.pdf};
+        }
+        return {S(0.f), 0.f};
+    }
+
+    // Glass.roughSample, thick (glass_sample.zig:294-422)
+    uint32_t glassRoughSample(Sampler& sampler, bool split, BxdfSample out[2]) const {
+        float eta_i = ior_outside, eta_t = ior;
+        if (std::fabs(eta_i - eta_t) <= 2.e-7f || lower_priority) {
+            out[0].reflection = S(1.f);
+            out[0].wi = -wo;
+            out[0].pdf = 1.f;
+            out[0].split_weight = 1.f;
+            out[0].wavelength = 0.f;
+            out[0].path = PathInfo::singularTransmission();
+            return 1;
+        }
+        const float a = alpha[0];
+        const bool  same_side = sameHemisphere(wo);
+        Frame       fr = frame;
+        if (!same_side) {
+            fr.z = -fr.z;
+            std::swap(eta_i, eta_t);
+        }
+        float s3[3];
+        sampler.sample3D(s3);
+        float       n_dot_h;
+        const V4    h = ggx::anisoSample(wo, alpha, s3[1], s3[2], fr, n_dot_h);
+        const float n_dot_wo = fr.clampAbsNdot(wo);
+        const float wo_dot_h = clampDot(wo, h);
+        const float eta = eta_i / eta_t;
+        const float sint2 = (eta * eta) * (1.f - wo_dot_h * wo_dot_h);
+        const float s = specular;
+        float       wi_dot_h, f;
+        if (sint2 >= 1.f) {
+            wi_dot_h = 0.f;
+            f = 1.f;
+        } else {
+            wi_dot_h = std::sqrt(1.f - sint2);
+            const float cos_x = eta_i > eta_t ? wi_dot_h : wo_dot_h;
+            f = fresnel::schlick(S(glass_f0), cos_x)[0];  // fresnel.schlick1
+        }
+        const float ep = luts.ilmEpDielectric(n_dot_wo, a, glass_f0);
+        const float r_wo_dot_h = same_side ? -wo_dot_h : wo_dot_h;
+        if (split) {
+            {
+                const float n_dot_wi = ggx::reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, out[0]);
+                out[0].reflection *= S(n_dot_wi * ep * s) * S(1.f);
+                out[0].split_weight = f;
+                out[0].wavelength = 0.f;
+            }
+            if (1.f == f) return 1;
+            const float n_dot_wi =
+                ggx::refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, out[1]);
+            out[1].reflection *= S(n_dot_wi * ep) * S(1.f);
+            out[1].split_weight = 1.f - f;
+            out[1].wavelength = 0.f;
+            return 2;
+        }
+        const float p = s3[0];
+        if (p <= f) {
+            const float n_dot_wi = ggx::reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, out[0]);
+            out[0].reflection *= S(f * n_dot_wi * ep * s) * S(1.f);
+            out[0].pdf *= f;
+        } else {
+            const float n_dot_wi =
+                ggx::refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, out[0]);
+            const float omf = 1.f - f;
+            out[0].reflection *= S(omf * n_dot_wi * ep) * S(1.f);
+            out[0].pdf *= omf;
+        }
+        out[0].split_weight = 1.f;
+        out[0].wavelength = 0.f;
+        return 1;
+    }
+
+    // max_splits: the integrator's split budget (pathtracer_mis.zig:107-124); only rough Glass looks at it here
+    BxdfResult evaluate(V4 wi, bool force_disable_caustics, uint32_t max_splits = 1) const {
+        if (ZYGPU_MAT_GLASS == kind) return glassEvaluate(wi, max_splits > 1, force_disable_caustics);
+        if (ZYGPU_MAT_LIGHT == kind) return {S(0.f), 0.f};
         if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:19-26
             const float n_dot_wi = frame.clampNdot(wi);
             const float pdf = n_dot_wi * kPiInv;
@@ -343,6 +528,7 @@ struct MaterialSample {
     // Glass.specularSample, thick (glass_sample.zig:165-254); `split`: both the reflected and the refracted direction,
     // weighted by the Fresnel term, instead of a choice between them
     uint32_t glassSample(Sampler& sampler, bool split, BxdfSample out[2]) const {
+        if (alpha[0] > 0.f) return glassRoughSample(sampler, split, out);
         float eta_i = ior_outside, eta_t = ior;
         auto  fill = [&](BxdfSample& r, V4 wi, V4 reflection, float split_weight, PathInfo path) {
             r.reflection = reflection;
@@ -458,13 +644,18 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.alpha[0] = s.alpha[1] = 0.f;
         s.can_evaluate = false;
     } else if (ZYGPU_MAT_GLASS == m.kind) {
-        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66) with roughness 0: alpha 0, f0 0
+        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66); regularizeAlpha is the identity for
+        // reg_weight == 0
         s.frame = {rs.t, rs.b, rs.n};
-        s.alpha[0] = s.alpha[1] = 0.f;
-        s.can_evaluate = false;  // rough and ...
+        const float r = 0.f == m.roughness ? 0.f : ggx::clampRoughness(m.roughness);
+        const bool  rough = r * r > 0.f;
+        s.alpha[0] = s.alpha[1] = r * r;
+        s.can_evaluate = rough && m.ior != rs.ior;
         s.absorption = ld3(m.absorption);
         s.ior = m.ior;
         s.ior_outside = rs.ior;
+        s.glass_f0 = rough ? fresnel::iorToF0(m.ior, rs.ior) : 0.f;
+        s.specular_threshold = scene.specular_threshold;
         s.specular = m.specular;
         s.lower_priority = m.priority < rs.highest_priority;  // sample_base.zig:44
     } else {

@@ -446,7 +446,7 @@ struct Worker {
     }
 
     // pathtracer_mis.zig:174-278 (MIS) / pathtracer_dl.zig:120-171 (DL)
-    V4 sampleLights(const Vertex& v, const Fragment& frag, const MaterialSample& ms, Sampler& sampler, bool mis) {
+    V4 sampleLights(const Vertex& v, const Fragment& frag, const MaterialSample& ms, Sampler& sampler, bool mis, uint32_t max_splits = 1) {
         V4 result = S(0.f);
         if (!ms.can_evaluate) return result;
 
@@ -497,7 +497,7 @@ struct Worker {
                 if (mis) {
                     const float      lr = sampler.sample1D();  // light.zig:127 rs.stochastic_r
                     const V4         radiance = materialRadiance(lm, ls.wi, trafo, light.prop, light.part, false, ls.uvw[0], ls.uvw[1], lr);
-                    const BxdfResult bx = ms.evaluate(ls.wi, false);
+                    const BxdfResult bx = ms.evaluate(ls.wi, false, max_splits);
                     const float      light_pdf = ls.pdf() * pick.pdf;
                     const float      weight = predividedPowerHeuristic(light_pdf, bx.pdf);
                     occluded += S(weight) * radiance * bx.reflection;
@@ -589,7 +589,7 @@ struct Worker {
 
             vertex.light_split_threshold = splitThreshold(view.split_threshold, vertex.depth_surface);
             const uint32_t max_splits = VertexPool::maxSplits(vertex, total_depth);
-            const V4       lighting = sampleLights(vertex, frag, ms, sampler, true);
+            const V4       lighting = sampleLights(vertex, frag, ms, sampler, true, max_splits);
             result.add(split_throughput * lighting, total_depth, 1, false, false);
 
             BxdfSample     samples[2];

@@ -69,7 +69,7 @@ def lut_table(name):
 
 
 lut_golden = {}
-for which, (name, stride) in enumerate([("E_m", 13), ("E_m_avg", 3), ("E", 41), ("E_avg", 7)]):
+for which, (name, stride) in enumerate([("E_m", 13), ("E_m_avg", 3), ("E", 41), ("E_avg", 7), ("E_s", 37)]):
     t = lut_table(name)
     idx = sorted(set(list(range(0, len(t), stride)) + [len(t) - 1]))
     lut_golden[name] = {"which": which, "length": len(t), "index": idx, "value": [t[i] for i in idx]}

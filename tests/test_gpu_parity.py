@@ -331,6 +331,12 @@ GLASS_BOX = scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3)
     ("PTMIS", {"sphere": scenes.glass(1.5, (0.9, 0.6, 0.5), 0.2), "inner": scenes.glass(1.33, (0.5, 0.7, 0.95), 0.1, priority=1)}),
     ("PTMIS", {"sphere": scenes.glass(1.5, priority=2), "inner": scenes.glass(1.33, (0.5, 0.7, 0.95), 0.1, priority=1)}),
     ("PTMIS", {"box": scenes.glass(1.0), "sphere": scenes.glass(1.8, (0.8, 0.8, 0.3), 0.5)}),
+    # rough interfaces: GGX reflection / refraction (ggx.zig:127-227), energy compensation from the E_s table, light samples
+    # evaluated through the interface with the split budget (glass_sample.zig:68-146, 294-422)
+    ("PT", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, roughness=0.3), "sphere": scenes.glass(1.5, roughness=0.1)}),
+    ("PTDL", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, roughness=0.3), "sphere": scenes.glass(1.5, roughness=0.1)}),
+    ("PTMIS", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, roughness=0.3), "sphere": scenes.glass(1.5, roughness=0.1)}),
+    ("PTMIS", {"sphere": scenes.glass(1.5, (0.9, 0.6, 0.5), 0.2, roughness=0.2), "inner": scenes.glass(1.33, roughness=0.05, priority=1)}),
 ])
 def test_glass(engine, oracle, integrator, objects):
     """Thick specular Glass (glass_sample.zig:165-254): Fresnel reflection / refraction, the medium stack with nested

@@ -437,3 +437,21 @@ def test_tonemapper_known_answers(product_lib, oracle):
     assert x >= 0.08 and pbr[2].max() < 1.0
     agx = out[("AgX", 0.0)]
     assert agx.min() >= 0.0 and agx.max() <= 1.1 and agx[2].mean() > agx[1].mean() > agx[0].mean()
+
+
+def test_rough_glass_integrators_agree(product_lib, oracle):
+    """Rough dielectrics: path tracing with and without light sampling through the interface (Glass.evaluate) and with the
+    split paths estimate the same image; energy stays close to the smooth case (the E_s compensation, ggx.zig:30-32)."""
+    w, h, spp = 40, 30, 512
+    means = {}
+    for integ in ("PT", "PTMIS"):
+        for rough in (0.0, 0.3):
+            objs = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, roughness=rough), "sphere": scenes.glass(1.5, roughness=rough)}
+            with zyg_amd.Engine(product_lib) as e:
+                scenes.cornell(e, w, h, spp, integrator=integ, glass_objects=objs, max_depth=12)
+                sd, vd = e.compile()
+                img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+                assert np.isfinite(img).all()
+                means[(integ, rough)] = img[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means[("PT", 0.3)], means[("PTMIS", 0.3)], rtol=0.02)
+    np.testing.assert_allclose(means[("PTMIS", 0.3)], means[("PTMIS", 0.0)], rtol=0.03)

@@ -71,6 +71,8 @@ struct Luts {
     ZD float E_m_avg(float alpha) const { return eval1(s.lut_e_m_avg, 32, alpha); }
     ZD float E(float n_dot, float alpha, float f0) const { return eval3(s.lut_e, 16, 16, 16, n_dot, alpha, f0); }
     ZD float E_avg(float alpha, float f0) const { return eval2(s.lut_e_avg, 16, 16, alpha, f0); }
+    // ggx.ilmEpDielectric (ggx.zig:30-32): E_s over f0 in [0, 0.25]
+    ZD float ilmEpDielectric(float n_dot_wo, float alpha, float f0) const { return 1.f / eval3(s.lut_e_s, 16, 16, 16, n_dot_wo, alpha, f0 * 4.f); }
 };
 
 ZD float pow5(float x) {
@@ -175,6 +177,60 @@ ZD Micro ggxReflect(f3 wo, float n_dot_wo, float a0, float a1, float specular_th
     return {h, n_dot_wi, wo_dot_h};
 }
 
+// ---- rough dielectrics: ggx.Iso.reflectNoFresnel / refractNoFresnel / reflectionF / refractionF (ggx.zig:73-95, 127-227)
+ZD float gSmithCorrelated(float n_dot_wi, float n_dot_wo, float alpha2) {
+    const float a = n_dot_wo * sqrtf(__fmaf_rn(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
+    const float b = n_dot_wi * sqrtf(__fmaf_rn(1.f - alpha2, n_dot_wo * n_dot_wo, alpha2));
+    return (2.f * n_dot_wi * n_dot_wo) / (a + b);
+}
+ZD float pdfVisibleRefract(float n_dot_wo, float wo_dot_h, float d, float alpha2) {
+    const float g1 = (2.f * n_dot_wo) / (n_dot_wo + sqrtf(alpha2 + (1.f - alpha2) * (n_dot_wo * n_dot_wo)));
+    return g1 * wo_dot_h * d / n_dot_wo;
+}
+ZD float clampAbs(float x) { return clampf(fabsf(x), kDotMin, 1.f); }
+ZD float schlick1(float wo_dot_h, float f0) {  // fresnel.zig:5-7
+    const float om = 1.f - wo_dot_h, om2 = om * om;
+    return __fmaf_rn((om2 * om2) * om, 1.f - f0, f0);
+}
+ZD float reflectNoFresnel(f3 wo, f3 h, float n_dot_wo, float n_dot_h, float wo_dot_h, float alpha, float specular_threshold,
+                          const Frame& frame, BxdfSample& result) {
+    const f3    wi = normalize3(fma3(S3(2.f * wo_dot_h), h, -wo));
+    const float n_dot_wi = frame.clampNdot(wi);
+    const float alpha2 = alpha * alpha;
+    const float d = isoDistribution(n_dot_h, alpha2);
+    float       g0, g1;
+    isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g0, g1);
+    result.reflection = S3(d * g0);
+    result.wi = wi;
+    result.pdf = pdfVisible(d, g1);
+    result.reg_alpha = alpha;
+    result.scattering = alpha <= specular_threshold ? kScatterSpecular : kScatterGlossy;
+    result.transmission = false;
+    return n_dot_wi;
+}
+ZD float refractNoFresnel(f3 wo, f3 h, float n_dot_wo, float n_dot_h, float wi_dot_h, float wo_dot_h, float alpha, float specular_threshold,
+                          float eta_i, float eta_t, const Frame& frame, BxdfSample& result) {
+    const float eta = eta_i / eta_t;
+    const float abs_wi_dot_h = clampAbs(wi_dot_h), abs_wo_dot_h = clampAbs(wo_dot_h);
+    const f3    wi = normalize3(S3(__fmaf_rn(eta, abs_wo_dot_h, -abs_wi_dot_h)) * h - S3(eta) * wo);
+    const float n_dot_wi = frame.clampAbsNdot(wi);
+    const float alpha2 = alpha * alpha;
+    const float d = isoDistribution(n_dot_h, alpha2);
+    const float g = gSmithCorrelated(n_dot_wi, n_dot_wo, alpha2);
+    const float refr = d * g;
+    const float factor = (abs_wi_dot_h * abs_wo_dot_h) / (n_dot_wi * n_dot_wo);
+    const float dn = eta_i * wo_dot_h + eta_t * wi_dot_h, denom = dn * dn;
+    const float sqr_eta_t = eta_t * eta_t;
+    const float pdf = pdfVisibleRefract(n_dot_wo, abs_wo_dot_h, d, alpha2);
+    result.reflection = S3((factor * sqr_eta_t / denom) * refr);
+    result.wi = wi;
+    result.pdf = pdf * (abs_wi_dot_h * sqr_eta_t / denom);
+    result.reg_alpha = alpha;
+    result.scattering = alpha <= specular_threshold ? kScatterSpecular : kScatterGlossy;
+    result.transmission = true;
+    return n_dot_wi;
+}
+
 struct MaterialSample {
     uint32_t kind;
     Frame    frame;
@@ -184,14 +240,131 @@ struct MaterialSample {
     f3       albedo;
     f3       f0;
     float    metallic, specular, specular_threshold, opacity;
-    float    ior, ior_outside;  // Glass
+    float    ior, ior_outside, glass_f0;  // Glass
     bool     lower_priority;
+
+    // Glass.Sample.evaluate (glass_sample.zig:68-146): rough interfaces only; `split`: max_splits > 1
+    ZD BxdfResult glassEvaluate(const DScene& s, f3 wi, bool split) const {
+        const float a = a0;
+        if (ior == ior_outside || !(a > 0.f) || lower_priority || (avoid_caustics && a <= specular_threshold)) return {S3(0.f), 0.f};
+        const Luts L{s};
+        if (!sameHemisphere(wo)) {  // thick refraction from inside
+            const float eta_i = ior, eta_t = ior_outside;
+            const f3    h = -normalize3(S3(eta_t) * wi + S3(eta_i) * wo);
+            const float wi_dot_h = dot3(wi, h);
+            if (wi_dot_h <= 0.f) return {S3(0.f), 0.f};
+            const float wo_dot_h = dot3(wo, h);
+            const float eta = eta_i / eta_t;
+            const float sint2 = (eta * eta) * (1.f - wo_dot_h * wo_dot_h);
+            if (sint2 >= 1.f) return {S3(0.f), 0.f};
+            const float n_dot_wi = frame.clampNdot(wi), n_dot_wo = frame.clampAbsNdot(wo);
+            const float n_dot_h = saturate(dot3(frame.z, h));
+            // Iso.refractionF
+            const float alpha2 = a * a;
+            const float abs_wi_dot_h = clampAbs(wi_dot_h), abs_wo_dot_h = clampAbs(wo_dot_h);
+            const float d = isoDistribution(n_dot_h, alpha2);
+            const float g = gSmithCorrelated(n_dot_wi, n_dot_wo, alpha2);
+            const float cos_x = eta_i > eta_t ? abs_wi_dot_h : abs_wo_dot_h;
+            const float f = 1.f - schlick(S3(glass_f0), cos_x).x;
+            const float sqr_eta_t = eta_t * eta_t;
+            const float factor = (abs_wi_dot_h * abs_wo_dot_h) / (n_dot_wi * n_dot_wo);
+            const float dn = eta_i * wo_dot_h + eta_t * wi_dot_h, denom = dn * dn;
+            const float refr = d * g * f;
+            const float refl = (factor * sqr_eta_t / denom) * refr;
+            const float pdf = pdfVisibleRefract(n_dot_wo, abs_wo_dot_h, d, alpha2) * (abs_wi_dot_h * sqr_eta_t / denom);
+            const float comp = L.ilmEpDielectric(n_dot_wo, a, glass_f0);
+            const float split_pdf = split ? 1.f : f;
+            return {S3(mn(n_dot_wi, n_dot_wo) * comp * specular) * S3(refl), split_pdf * pdf};
+        }
+        if (sameHemisphere(wi)) {
+            const float n_dot_wi = frame.clampNdot(wi), n_dot_wo = frame.clampAbsNdot(wo);
+            const f3    h = normalize3(wo + wi);
+            const float wo_dot_h = clampDot(wo, h);
+            // Iso.reflectionF
+            const float alpha2 = a * a;
+            const float n_dot_h = saturate(dot3(frame.z, h));
+            const float d = isoDistribution(n_dot_h, alpha2);
+            float       g0, g1;
+            isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g0, g1);
+            const f3    f = schlick(S3(glass_f0), wo_dot_h);
+            const float comp = L.ilmEpDielectric(n_dot_wo, a, glass_f0);
+            const float split_pdf = split ? 1.f : f.x;
+            return {S3(n_dot_wi * comp * specular) * (S3(d * g0) * f), split_pdf * pdfVisible(d, g1)};
+        }
+        return {S3(0.f), 0.f};
+    }
+
+    // Glass.roughSample, thick (glass_sample.zig:294-422)
+    ZD uint32_t glassRoughSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
+        float eta_i = ior_outside, eta_t = ior;
+        if (fabsf(eta_i - eta_t) <= 2.e-7f || lower_priority) {
+            r0.reflection = S3(1.f);
+            r0.wi = -wo;
+            r0.pdf = 1.f;
+            r0.reg_alpha = 0.f;
+            r0.scattering = kScatterSpecular;
+            r0.transmission = true;
+            r0.split_weight = 1.f;
+            return 1;
+        }
+        const Luts  L{s};
+        const float a = a0;
+        const bool  same_side = sameHemisphere(wo);
+        Frame       fr = frame;
+        if (!same_side) {
+            fr.z = -fr.z;
+            const float e = eta_i;
+            eta_i = eta_t;
+            eta_t = e;
+        }
+        float p, xi0, xi1;
+        sampler.sample3D(p, xi0, xi1);
+        float       n_dot_h;
+        const f3    h = ggxSample(wo, a0, a1, xi0, xi1, fr, n_dot_h);
+        const float n_dot_wo = fr.clampAbsNdot(wo);
+        const float wo_dot_h = clampDot(wo, h);
+        const float eta = eta_i / eta_t;
+        const float sint2 = (eta * eta) * (1.f - wo_dot_h * wo_dot_h);
+        float       wi_dot_h, f;
+        if (sint2 >= 1.f) {
+            wi_dot_h = 0.f;
+            f = 1.f;
+        } else {
+            wi_dot_h = sqrtf(1.f - sint2);
+            f = schlick1(eta_i > eta_t ? wi_dot_h : wo_dot_h, glass_f0);
+        }
+        const float ep = L.ilmEpDielectric(n_dot_wo, a, glass_f0);
+        const float r_wo_dot_h = same_side ? -wo_dot_h : wo_dot_h;
+        if (split) {
+            const float n_dot_wi = reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, r0);
+            r0.reflection = r0.reflection * (S3(n_dot_wi * ep * specular) * S3(1.f));
+            r0.split_weight = f;
+            if (1.f == f) return 1;
+            const float n_dot_wt = refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, r1);
+            r1.reflection = r1.reflection * (S3(n_dot_wt * ep) * S3(1.f));
+            r1.split_weight = 1.f - f;
+            return 2;
+        }
+        if (p <= f) {
+            const float n_dot_wi = reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, r0);
+            r0.reflection = r0.reflection * (S3(f * n_dot_wi * ep * specular) * S3(1.f));
+            r0.pdf *= f;
+        } else {
+            const float n_dot_wt = refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, r0);
+            const float omf = 1.f - f;
+            r0.reflection = r0.reflection * (S3(omf * n_dot_wt * ep) * S3(1.f));
+            r0.pdf *= omf;
+        }
+        r0.split_weight = 1.f;
+        return 1;
+    }
 
     ZD bool sameHemisphere(f3 v) const { return dot3(geo_n, v) > 0.f; }
 
     // Glass.specularSample, thick (glass_sample.zig:165-254, reflect 425-435, thickSpecularRefract 519-537); `split`: both
     // directions, weighted by the Fresnel term, instead of a choice between them.  Returns the number of samples.
-    ZD uint32_t glassSample(Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
+    ZD uint32_t glassSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
+        if (a0 > 0.f) return glassRoughSample(s, sampler, split, r0, r1);
         float eta_i = ior_outside, eta_t = ior;
         auto  fill = [&](BxdfSample& r, f3 wi, f3 reflection, float split_weight, bool transmission) {
             r.reflection = reflection;
@@ -266,10 +439,12 @@ struct MaterialSample {
         return {S3(n_dot_wi) * (d.reflection + S3(specular) * (gg.reflection + mms)), pdf};
     }
 
-    // SUBST = false compiles the Substitute branch out (kernels specialised for scenes without that material)
-    template <bool SUBST = true>
-    ZD BxdfResult evaluate(const DScene& s, f3 wi) const {  // material_sample.zig:47-53
-        if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return {S3(0.f), 0.f};  // glass_sample.zig:72-78: not rough
+    // SUBST = false compiles the Substitute branch out (kernels specialised for scenes without that material); GLASS: the
+    // pool kernels, the only ones that see Glass
+    template <bool SUBST = true, bool GLASS = false>
+    ZD BxdfResult evaluate(const DScene& s, f3 wi, bool split = false) const {  // material_sample.zig:47-53
+        if (GLASS && ZYGPU_MAT_GLASS == kind) return glassEvaluate(s, wi, split);
+        if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return {S3(0.f), 0.f};
         if (ZYGPU_MAT_DEBUG == kind) {
             const float n_dot_wi = frame.clampNdot(wi);
             const float pdf = n_dot_wi * kPiInv;
@@ -352,6 +527,7 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
     MaterialSample ms;
     ms.ior = m.ior;
     ms.ior_outside = ior_outside;
+    ms.glass_f0 = 0.f;
     ms.lower_priority = lower_priority;
     ms.kind = m.kind;
     ms.geo_n = geo_n;
@@ -372,10 +548,17 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         ms.albedo = same_side ? mk3(m.color_a[0], m.color_a[1], m.color_a[2]) : mk3(m.color_b[0], m.color_b[1], m.color_b[2]);
         ms.a0 = ms.a1 = 1.f;
         ms.can_evaluate = true;
-    } else if (ZYGPU_MAT_LIGHT == m.kind || ZYGPU_MAT_GLASS == m.kind) {
-        // Glass.sample / Sample.init with roughness 0 (glass_material.zig:49-79, glass_sample.zig:33-66): alpha 0, f0 0
+    } else if (ZYGPU_MAT_LIGHT == m.kind) {
         ms.a0 = ms.a1 = 0.f;
         ms.can_evaluate = false;
+    } else if (ZYGPU_MAT_GLASS == m.kind) {
+        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66)
+        const float r = 0.f == m.roughness ? 0.f : mx(m.roughness, kMinRoughness);
+        const bool  rough = r * r > 0.f;
+        ms.a0 = ms.a1 = r * r;
+        ms.can_evaluate = rough && m.ior != ior_outside;
+        const float t_ = (m.ior - ior_outside) / (m.ior + ior_outside);
+        ms.glass_f0 = rough ? t_ * t_ : 0.f;
         ms.specular = m.specular;
     } else {
         const float roughness = mx(m.roughness, kMinRoughness);

@@ -94,6 +94,7 @@ struct DScene {
     const float*         lut_e_m_avg;
     const float*         lut_e;
     const float*         lut_e_avg;
+    const float*         lut_e_s;
     float                specular_threshold;
     uint32_t             num_solid_nodes, num_unocc_nodes;
     float4               heavy_aabbs[16];  // world bounds (2 each) of the up to 8 largest mesh props: queue grouping hint

@@ -1300,6 +1300,14 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
         f3                    throughput = xyz4(thr4);
         const float           split_weight = POOL ? thr4.w : 1.f;
 
+        // POOL: the split budget of this vertex (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only: pathtracer.zig:73,
+        // pathtracer_dl.zig:82, 160): rough Glass evaluates light samples with it, Glass splits its bxdf sample by it
+        uint32_t max_splits = 1;
+        if (POOL && mis) {
+            const uint32_t m = kPoolVertices / __float_as_uint(P.pool.vorigin[slot].w);
+            max_splits = m - ((h.flags & ST_PRIMARY) ? 0u : min(h.depth_surface, m - 1u));
+        }
+
         // ---- sampleLights / evaluateLight (pathtracer_mis.zig:174-278, pathtracer_dl.zig:100-167)
         if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
             const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
@@ -1335,7 +1343,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
                     const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
-                    const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
+                    const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
                     if (mis) {
                         const float light_pdf = ls.pdf * pick.pdf;
                         const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
@@ -1442,12 +1450,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
             uint32_t       count;
             const uint32_t path_count = __float_as_uint(P.pool.vorigin[slot].w);
             if (ZYGPU_MAT_GLASS == ms.kind) {
-                uint32_t max_splits = 1;
-                if (mis) {
-                    const uint32_t m = kPoolVertices / path_count;
-                    max_splits = m - ((h.flags & ST_PRIMARY) ? 0u : min(h.depth_surface, m - 1u));
-                }
-                count = ms.glassSample(h.smp, max_splits > 1, bs, bs1);
+                count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1);
             } else {
                 count = ms.template sample<SUBST>(s, h.smp, bs) ? 1u : 0u;
             }

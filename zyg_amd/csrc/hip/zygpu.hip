@@ -568,14 +568,19 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     ok = ok && m.upload(d->luts.e_m_avg, d->luts.e_m_avg ? 32 : 0, &s.lut_e_m_avg);
     ok = ok && m.upload(d->luts.e, d->luts.e ? 16 * 16 * 16 : 0, &s.lut_e);
     ok = ok && m.upload(d->luts.e_avg, d->luts.e_avg ? 16 * 16 : 0, &s.lut_e_avg);
+    ok = ok && m.upload(d->luts.e_s, d->luts.e_s ? 16 * 16 * 16 : 0, &s.lut_e_s);
     if (!ok) return -1;
 
     c->pool_mode = false;
     for (uint32_t pi = 0; pi < d->num_parts; ++pi) {
         const ZygpuMaterial& gm = d->materials[d->material_ids[pi]];
         if (ZYGPU_MAT_GLASS != gm.kind) continue;
-        if (gm.roughness > 0.f || gm.thickness > 0.f || gm.abbe > 0.f) {
-            g_error = "Glass: only thick, perfectly specular, non-dispersive glass (roughness 0, thickness 0, abbe 0) is supported";
+        if (gm.thickness > 0.f || gm.abbe > 0.f) {
+            g_error = "Glass: only thick, non-dispersive glass (thickness 0, abbe 0) is supported";
+            return -2;
+        }
+        if (gm.roughness > 0.f && !d->luts.e_s) {
+            g_error = "rough Glass needs the E_s table in ZygpuSceneDesc.luts";
             return -2;
         }
         c->pool_mode = true;  // split paths + medium stack: the POOL kernels

@@ -408,7 +408,7 @@ uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, ui
 
 uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity) {
     const zyg::ggxlut::Tables& t = zyg::ggxlut::tables();
-    const std::vector<float>*  v = 0 == which ? &t.e_m : 1 == which ? &t.e_m_avg : 2 == which ? &t.e : 3 == which ? &t.e_avg : nullptr;
+    const std::vector<float>*  v = 0 == which ? &t.e_m : 1 == which ? &t.e_m_avg : 2 == which ? &t.e : 3 == which ? &t.e_avg : 4 == which ? &t.e_s : nullptr;
     if (!v) return 0;
     if (out) std::copy(v->begin(), v->begin() + std::min<size_t>(capacity, v->size()), out);
     return uint32_t(v->size());

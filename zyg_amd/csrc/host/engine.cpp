@@ -1241,17 +1241,18 @@ int Engine::compile(uint32_t frame) {
     d.num_image_lights = uint32_t(c_image_lights_.size());
     for (const ZygpuMaterial& m : materials_)
         if (ZYGPU_NULL != m.color_image && m.color_image >= images_.size()) return -4;  // a colour map without its image
-    for (uint32_t mid : material_ids_) {  // rough / thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 293-460)
+    for (uint32_t mid : material_ids_) {  // thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 437-517)
         const ZygpuMaterial& m = materials_[mid];
-        if (ZYGPU_MAT_GLASS == m.kind && (m.roughness > 0.f || m.thickness > 0.f || m.abbe > 0.f)) return -5;
+        if (ZYGPU_MAT_GLASS == m.kind && (m.thickness > 0.f || m.abbe > 0.f)) return -5;
     }
     for (const ZygpuMaterial& m : materials_) {
-        if (ZYGPU_MAT_SUBSTITUTE != m.kind) continue;
+        if (ZYGPU_MAT_SUBSTITUTE != m.kind && !(ZYGPU_MAT_GLASS == m.kind && m.roughness > 0.f)) continue;
         const ggxlut::Tables& t = ggxlut::tables();  // computed once per process (ggx_lut.hpp)
         d.luts.e_m = t.e_m.data();
         d.luts.e_m_avg = t.e_m_avg.data();
         d.luts.e = t.e.data();
         d.luts.e_avg = t.e_avg.data();
+        d.luts.e_s = t.e_s.data();
         break;
     }
     d.specular_threshold = specular_threshold;

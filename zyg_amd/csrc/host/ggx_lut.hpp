@@ -6,6 +6,7 @@
 //   E_m_avg  [32 alpha]                   integrate_micro_average_albedo       ggx_integrate.zig:61-76, 259-299
 //   E        [16 f0][16 alpha][16 n.wo]   integrate_directional_albedo         ggx_integrate.zig:92-120, 301-364
 //   E_avg    [16 f0][16 alpha]            integrate_average_albedo (<= 0.9997) ggx_integrate.zig:122-137, 366-414
+//   E_s      [16 f0 <= 0.25][16 alpha][16 n.wo]  integrate_f_s_ss (rough dielectrics) ggx_integrate.zig:134-205, 418-486
 // 1024 Hammersley points per entry (base/math/sample_distribution.zig:3-18), shading frame = identity, wo = (sin, 0, cos),
 // isotropic GGX reflection sampled by visible normals (ggx.zig:96-125, 396-414) with Schlick Fresnel (fresnel.zig:5-29).
 // The reference prints each entry with 8 decimals; tests/golden/ggx_lut_golden.json holds a sample of those entries and
@@ -131,8 +132,78 @@ inline ReflectSample isoReflect(float wo_x, float wo_z, float n_dot_wo, float al
 }
 
 struct Tables {
-    std::vector<float> e_m, e_m_avg, e, e_avg;
+    std::vector<float> e_m, e_m_avg, e, e_avg, e_s;
 };
+
+// integrate_f_s_ss (ggx_integrate.zig:134-205): reflected + refracted energy of a rough dielectric interface seen from
+// outside (eta_i = 1), with ggx.Iso.reflectNoFresnel / refractNoFresnel (ggx.zig:161-227) and fresnel.schlick1
+inline float fsSs(float alpha, float f0, float ior_t, float n_dot_wo) {
+    if (alpha < kMinAlpha || ior_t <= 1.f) return 1.f;
+    const float cn_dot_wo = clampf(n_dot_wo, kDotMin, 1.f);
+    const float wo_x = std::sqrt(1.f - cn_dot_wo * cn_dot_wo), wo_z = cn_dot_wo;
+    const float eta_i = 1.f, eta_t = ior_t;
+    const float alpha2 = alpha * alpha;
+    float       accum = 0.f;
+    for (uint32_t i = 0; i < uint32_t(kSamples); ++i) {
+        float xi0, xi1;
+        hammersley(i, kSamples, xi0, xi1);
+        // Aniso.sample (ggx.zig:393-409)
+        const float vx = alpha * wo_x, vz = wo_z;
+        const float vl = std::sqrt(vx * vx + 0.f + vz * vz);
+        const float nvx = vx / vl, nvy = 0.f / vl, nvz = vz / vl;
+        const float phi = (2.f * kPiF) * xi0;
+        const float z = std::fmaf(1.f - xi1, 1.f + nvz, -nvz);
+        const float sin_theta = std::sqrt(clampf(1.f - z * z, 0.f, 1.f));
+        const float x = sin_theta * std::cos(phi), y = sin_theta * std::sin(phi);
+        const float hx = x + nvx, hy = y + nvy, hz = z + nvz;
+        const float mx_ = alpha * hx, my_ = alpha * hy, mz_ = hz;
+        const float ml = std::sqrt(mx_ * mx_ + my_ * my_ + mz_ * mz_);
+        const float h0 = mx_ / ml, h1 = my_ / ml, h2 = mz_ / ml;
+        const float n_dot_h = clampf(h2, kDotMin, 1.f);
+
+        const float wo_dot_h = clampf(wo_x * h0 + 0.f * h1 + wo_z * h2, kDotMin, 1.f);
+        const float eta = eta_i / eta_t;
+        const float sint2 = (eta * eta) * (1.f - wo_dot_h * wo_dot_h);
+        const float wi_dot_h = std::sqrt(1.f - sint2);
+        const float cos_x = eta_i > eta_t ? wi_dot_h : wo_dot_h;
+        const float om = 1.f - cos_x, om2 = om * om;
+        const float f = std::fmaf((om2 * om2) * om, 1.f - f0, f0);
+
+        const float dd = std::fmaf(n_dot_h * n_dot_h, alpha2 - 1.f, 1.f);
+        const float d = alpha2 / (kPiF * dd * dd);
+        {  // reflectNoFresnel
+            const float s2 = 2.f * wo_dot_h;
+            const float w0 = std::fmaf(s2, h0, -wo_x), w1 = std::fmaf(s2, h1, -0.f), w2 = std::fmaf(s2, h2, -wo_z);
+            const float wl = std::sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+            const float n_dot_wi = clampf(w2 / wl, kDotMin, 1.f);
+            const float t_wi = std::sqrt(std::fmaf(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
+            const float t_wo = std::sqrt(std::fmaf(1.f - alpha2, cn_dot_wo * cn_dot_wo, alpha2));
+            const float g0 = 0.5f / (n_dot_wi * t_wo + cn_dot_wo * t_wi), g1 = t_wo + cn_dot_wo;
+            accum += (mnf(n_dot_wi, n_dot_wo) * f * (d * g0)) / ((0.5f * d) / g1);
+        }
+        {  // refractNoFresnel(wo, h, cn_dot_wo, n_dot_h, -wi_dot_h, -wo_dot_h, alpha, ior)
+            const float wi_dot_h_r = -wi_dot_h, wo_dot_h_r = -wo_dot_h;
+            const float abs_wi = clampf(std::fabs(wi_dot_h_r), kDotMin, 1.f), abs_wo = clampf(std::fabs(wo_dot_h_r), kDotMin, 1.f);
+            const float k = std::fmaf(eta, abs_wo, -abs_wi);
+            const float w0 = k * h0 - eta * wo_x, w1 = k * h1 - eta * 0.f, w2 = k * h2 - eta * wo_z;
+            const float wl = std::sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+            const float n_dot_wi = clampf(std::fabs(w2 / wl), kDotMin, 1.f);
+            const float ga = cn_dot_wo * std::sqrt(std::fmaf(1.f - alpha2, n_dot_wi * n_dot_wi, alpha2));
+            const float gb = n_dot_wi * std::sqrt(std::fmaf(1.f - alpha2, cn_dot_wo * cn_dot_wo, alpha2));
+            const float g = (2.f * n_dot_wi * cn_dot_wo) / (ga + gb);
+            const float refr = d * g;
+            const float factor = (abs_wi * abs_wo) / (n_dot_wi * cn_dot_wo);
+            const float dn = eta_i * wo_dot_h_r + eta_t * wi_dot_h_r, denom = dn * dn;
+            const float sqr_eta_t = eta_t * eta_t;
+            const float g1 = (2.f * cn_dot_wo) / (cn_dot_wo + std::sqrt(alpha2 + (1.f - alpha2) * (cn_dot_wo * cn_dot_wo)));
+            const float pdf_vr = g1 * abs_wo * d / cn_dot_wo;
+            const float reflection = (factor * sqr_eta_t / denom) * refr;
+            const float pdf = pdf_vr * (abs_wi * sqr_eta_t / denom);
+            accum += (n_dot_wi * (1.f - f) * reflection) / pdf;
+        }
+    }
+    return accum / float(kSamples);
+}
 
 inline float microDirectionalAlbedo(float alpha, float n_dot_wo) {
     if (0.f == alpha) return 1.f;
@@ -219,6 +290,20 @@ inline const Tables& tables() {
                     accum += eval3(t.e.data(), kESize, kESize, kESize, hemisphereCosineZ(xi0, xi1), alpha, f0) / float(kSamples);
                 }
                 t.e_avg[size_t(z) * kESize + a] = mnf(accum, 0.9997f);
+            }
+        }
+
+        // make_f_s_ss_table (ggx_integrate.zig:418-486): f0 in [0, 0.25], ior = Schlick.F0ToIor(f0) (fresnel.zig:26-29)
+        t.e_s.resize(size_t(kESize) * kESize * kESize);
+        f0 = 0.f;
+        count = 0;
+        for (int z = 0; z < kESize; ++z, f0 += 0.25f * step_e) {
+            const float r = std::sqrt(f0);
+            const float ior = ((-f0 - 1.f) / (f0 - 1.f)) - ((2.f * r) / ((r - 1.f) * (r + 1.f)));
+            alpha = 0.f;
+            for (int a = 0; a < kESize; ++a, alpha += step_e) {
+                float n_dot_wo = 0.f;
+                for (int i = 0; i < kESize; ++i, n_dot_wo += step_e) t.e_s[count++] = fsSs(alpha, f0, ior, n_dot_wo);
             }
         }
         return t;
