@@ -34,6 +34,7 @@ struct PathInfo {  // bxdf.zig:34-70
     static PathInfo diffuseReflection() { return {1.f, Scattering::Diffuse, PathEvent::Reflection}; }
     static PathInfo singularReflection() { return {0.f, Scattering::Specular, PathEvent::Reflection}; }
     static PathInfo singularTransmission() { return {0.f, Scattering::Specular, PathEvent::Transmission}; }
+    static PathInfo straight() { return {1.f, Scattering::None, PathEvent::Straight}; }
     static PathInfo reflection(float alpha, float specular_threshold) {
         return {alpha, alpha <= specular_threshold ? Scattering::Specular : Scattering::Glossy, PathEvent::Reflection};
     }
@@ -348,7 +349,7 @@ struct MaterialSample {
     Luts  luts;
     // Glass
     V4    absorption;
-    float ior, ior_outside, glass_f0;
+    float ior, ior_outside, glass_f0, thickness;
     bool  lower_priority;
 
     bool sameHemisphere(V4 v) const { return dot3(geo_n, v) > 0.f; }
@@ -542,8 +543,9 @@ struct MaterialSample {
             fill(out[0], -wo, S(1.f), 1.f, PathInfo::singularTransmission());
             return 1;
         }
-        V4 nn = frame.z;
-        if (!sameHemisphere(wo)) {
+        const bool thin = thickness > 0.f;
+        V4         nn = frame.z;
+        if (!thin && !sameHemisphere(wo)) {  // thin material is always double sided (glass_sample.zig:203-209)
             nn = -nn;
             std::swap(eta_i, eta_t);
         }
@@ -560,14 +562,18 @@ struct MaterialSample {
         }
         const V4 reflected = normalize3(S(2.f * n_dot_wo) * nn - wo);                       // reflect, 425-435
         const V4 refracted = normalize3(S(eta * n_dot_wo - n_dot_t) * nn - S(eta) * wo);  // thickSpecularRefract, 519-537
+        // thinSpecularRefract (glass_sample.zig:505-517): straight through, attenuated over the slab
+        const V4 thin_attenuation = thin ? attenuation3(absorption, thickness / clampf(n_dot_wo, kDotMin, 1.f)) : S(1.f);
         if (split) {
             fill(out[0], reflected, S(specular) * S(1.f), f, PathInfo::singularReflection());
             if (1.f == f) return 1;
-            fill(out[1], refracted, S(1.f), 1.f - f, PathInfo::singularTransmission());
+            if (thin) fill(out[1], -wo, thin_attenuation, 1.f - f, PathInfo::straight());
+            else fill(out[1], refracted, S(1.f), 1.f - f, PathInfo::singularTransmission());
             return 2;
         }
         const float p = sampler.sample1D();
         if (p <= f) fill(out[0], reflected, S(specular) * S(1.f), 1.f, PathInfo::singularReflection());
+        else if (thin) fill(out[0], -wo, thin_attenuation, 1.f, PathInfo::straight());
         else fill(out[0], refracted, S(1.f), 1.f, PathInfo::singularTransmission());
         return 1;
     }
@@ -655,6 +661,8 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.ior = m.ior;
         s.ior_outside = rs.ior;
         s.glass_f0 = rough ? fresnel::iorToF0(m.ior, rs.ior) : 0.f;
+        s.thickness = m.thickness;
+        s.translucent = m.thickness > 0.f;
         s.specular_threshold = scene.specular_threshold;
         s.specular = m.specular;
         s.lower_priority = m.priority < rs.highest_priority;  // sample_base.zig:44

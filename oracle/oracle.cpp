@@ -492,7 +492,8 @@ struct Worker {
                 const SampleTo& ls = samples[si];
                 const Ray       shadow = shadowRay(fragOffsetP(frag, ls.wi), ls, distant);
                 cnt.shadow_rays += 1;
-                if (!rc->sv.visibility(shadow, cnt)) continue;
+                V4 tr = S(1.f);
+                if (!rc->sv.visibility(shadow, cnt, tr)) continue;
 
                 if (mis) {
                     const float      lr = sampler.sample1D();  // light.zig:127 rs.stochastic_r
@@ -500,13 +501,13 @@ struct Worker {
                     const BxdfResult bx = ms.evaluate(ls.wi, false, max_splits);
                     const float      light_pdf = ls.pdf() * pick.pdf;
                     const float      weight = predividedPowerHeuristic(light_pdf, bx.pdf);
-                    occluded += S(weight) * radiance * bx.reflection;
+                    occluded += tr * (S(weight) * radiance * bx.reflection);
                 } else {
                     const BxdfResult bx = ms.evaluate(ls.wi, false);
                     const float lr = sampler.sample1D();
                     const V4    radiance = materialRadiance(lm, ls.wi, trafo, light.prop, light.part, false, ls.uvw[0], ls.uvw[1], lr);
                     const float weight = 1.f / (pick.pdf * ls.pdf());
-                    occluded += S(weight) * (S(1.f) * radiance * bx.reflection);
+                    occluded += S(weight) * (tr * radiance * bx.reflection);
                 }
             }
             result += occluded;

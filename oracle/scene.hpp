@@ -299,6 +299,75 @@ inline bool meshIntersectP(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt)
     return false;
 }
 
+// Glass.visibility for thin glass without a mask (glass_material.zig:82-115): Fresnel transmission x absorption over the
+// slab; false = blocked (total internal reflection)
+inline bool thinGlassVisibility(const ZygpuMaterial& m, V4 wi, V4 geo_n, V4& tr) {
+    const float eta_i = 1.f, eta_t = m.ior;
+    const float n_dot_wo = mn(std::fabs(dot3(geo_n, wi)), 1.f);
+    const float eta = eta_i / eta_t;
+    const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
+    if (sint2 >= 1.f) return false;
+    const float n_dot_t = std::sqrt(1.f - sint2);
+    const float t0 = eta_t * n_dot_wo, t1 = eta_i * n_dot_t;  // fresnel.dielectric (fresnel.zig:31-43)
+    const float r_p = (t0 - t1) / (t0 + t1);
+    const float t2 = eta_i * n_dot_wo, t3 = eta_t * n_dot_t;
+    const float r_o = (t2 - t3) / (t2 + t3);
+    const float f = 0.5f * (r_p * r_p + r_o * r_o);
+    const float n_dot_wi = clampf(n_dot_wo, 0.00001f, 1.f);
+    const float approx_dist = m.thickness / n_dot_wi;
+    const V4    attenuation = attenuation3(ld3(m.absorption), approx_dist);
+    const V4    ta = min4(S(1.f - 1.f) + attenuation, S(1.f));
+    tr *= S(1.f - f) * ta;
+    return true;
+}
+// Material.visibility (material.zig:227-248): Glass evaluates, everything else (opacity 1) blocks
+inline bool materialVisibility(const ZygpuMaterial& m, V4 wi, V4 geo_n, V4& tr) {
+    if (ZYGPU_MAT_GLASS == m.kind && m.thickness > 0.f) return thinGlassVisibility(m, wi, geo_n, tr);
+    return false;
+}
+
+// TriangleTree.visibility (triangle_tree.zig:244-306): every triangle the ray crosses multiplies the transmittance
+template <typename Material>
+inline bool meshVisibility(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt, V4& tr, Material&& materialOfPart) {
+    const MeshView mv{&mesh};
+    NodeStack      stack;
+    uint32_t       n = 0;
+    cnt.nodes_fetched += 1;
+    while (kNull != n) {
+        const ZygpuBvhNode& node = mesh.nodes[n];
+        if (0 != node.count) {
+            for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
+                cnt.triangles_tested += 1;
+                const uint32_t* tri = mesh.triangles + size_t(i) * 3;
+                const V4        a = mv.position(tri[0]), b = mv.position(tri[1]), c = mv.position(tri[2]);
+                float           t, u, v;
+                if (!triangleIntersect(ray, a, b, c, t, u, v)) continue;
+                const ZygpuMaterial& m = materialOfPart(mesh.triangle_parts[i]);
+                if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return false;
+                const V4 geo_n = normalize3(cross3(b - a, c - a));  // data.normal (triangle_data.zig:129-135), object space
+                if (!materialVisibility(m, ray.direction, geo_n, tr)) return false;
+            }
+            n = stack.pop();
+            continue;
+        }
+        uint32_t a = node.children_or_first, b = a + 1;
+        cnt.nodes_fetched += 2;
+        float dista = nodeIntersect(mesh.nodes[a], ray);
+        float distb = nodeIntersect(mesh.nodes[b], ray);
+        if (dista > distb) {
+            std::swap(a, b);
+            std::swap(dista, distb);
+        }
+        if (FLT_MAX == dista) {
+            n = stack.pop();
+        } else {
+            n = a;
+            if (FLT_MAX != distb) stack.push(b);
+        }
+    }
+    return true;
+}
+
 // triangle_tree.zig:405-483 (emission): every triangle the ray crosses inside [min_t, max_t], in traversal order
 template <typename Visit>
 inline void meshEmissionWalk(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt, Visit&& visit) {
@@ -536,12 +605,44 @@ struct SceneView {
     }
 
     // prop.zig:199-237 (non-volumetric, no opacity masks): true = unoccluded
-    bool propVisibility(uint32_t p, const Ray& ray, Counters& cnt) const {
+    // `tr`: the transmittance of the thin-glass surfaces the ray crosses (shape.visibility for props with evaluate_visibility)
+    bool propVisibility(uint32_t p, const Ray& ray, Counters& cnt, V4& tr) const {
         const ZygpuProp& prop = d->props[p];
         if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) return true;
         cnt.instances_tested += 1;
         if (!aabbIntersect(d->aabbs[p], ray)) return true;
         const Trafo trafo = propTrafo(p);
+        if (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY) {
+            if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {  // rectangle.zig:154-186
+                float t, u, v;
+                if (!rectangleIntersect(ray, trafo, t, u, v)) return true;
+                return materialVisibility(propMaterial(p, 0), ray.direction, trafo.r[2], tr);
+            }
+            if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:176-228: both roots
+                const float idl = 1.f / length3(ray.direction);
+                const V4    nd = ray.direction * S(idl);
+                const V4    v = trafo.position - ray.origin;
+                const float b = dot3(nd, v);
+                const V4    remedy_term = v - S(b) * nd;
+                const float radius = 0.5f * trafo.scaleX();
+                const float discriminant = radius * radius - dot3(remedy_term, remedy_term);
+                if (discriminant > 0.f) {
+                    const float dist = std::sqrt(discriminant);
+                    for (const float t : {(b - dist) * idl, (b + dist) * idl}) {
+                        if (t >= ray.min_t && ray.max_t >= t) {
+                            const V4 n = normalize3(ray.point(t) - trafo.position);
+                            if (!materialVisibility(propMaterial(p, 0), ray.direction, n, tr)) return false;
+                        }
+                    }
+                }
+                return true;
+            }
+            if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+                return meshVisibility(d->meshes[prop.mesh], trafo.worldToObjectRay(ray), cnt, tr,
+                                      [&](uint32_t part) -> const ZygpuMaterial& { return propMaterial(p, part); });
+            }
+            return true;
+        }
         if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
             float t, u, v;
             return !rectangleIntersect(ray, trafo, t, u, v);
@@ -612,6 +713,10 @@ struct SceneView {
 
     // prop_tree.zig:185-240 (solid TLAS; the volume TLAS is empty in scope, scene.zig:229-235)
     bool visibility(const Ray& ray, Counters& cnt) const {
+        V4 tr = S(1.f);
+        return visibility(ray, cnt, tr);
+    }
+    bool visibility(const Ray& ray, Counters& cnt, V4& tr) const {
         const ZygpuPropTree& tree = d->solid;
         NodeStack            stack;
         uint32_t             n = 0 == tree.num_nodes ? kNull : 0;
@@ -620,7 +725,7 @@ struct SceneView {
             const ZygpuBvhNode& node = tree.nodes[n];
             if (0 != node.count) {
                 for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
-                    if (!propVisibility(tree.indices[i], ray, cnt)) return false;
+                    if (!propVisibility(tree.indices[i], ray, cnt, tr)) return false;
                 }
                 n = stack.pop();
                 continue;

@@ -337,6 +337,12 @@ GLASS_BOX = scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3)
     ("PTDL", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, roughness=0.3), "sphere": scenes.glass(1.5, roughness=0.1)}),
     ("PTMIS", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, roughness=0.3), "sphere": scenes.glass(1.5, roughness=0.1)}),
     ("PTMIS", {"sphere": scenes.glass(1.5, (0.9, 0.6, 0.5), 0.2, roughness=0.2), "inner": scenes.glass(1.33, roughness=0.05, priority=1)}),
+    # thin glass: two-sided, .Straight path events, shadow rays attenuated instead of blocked (glass_material.zig:82-115,
+    # glass_sample.zig:505-517; Scene.visibility's transmittance through Rectangle / Sphere / mesh visibility)
+    ("PT", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01)}),
+    ("PTDL", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01)}),
+    ("PTMIS", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01)}),
+    ("PTMIS", {"sphere": scenes.glass(1.5, thickness=0.01), "inner": scenes.glass(1.4, (0.5, 0.7, 0.95), 0.1), "outside": scenes.glass(1.5, (0.7, 0.8, 0.9), 0.5, thickness=0.05)}),
 ])
 def test_glass(engine, oracle, integrator, objects):
     """Thick specular Glass (glass_sample.zig:165-254): Fresnel reflection / refraction, the medium stack with nested

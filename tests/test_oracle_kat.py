@@ -455,3 +455,22 @@ def test_rough_glass_integrators_agree(product_lib, oracle):
                 means[(integ, rough)] = img[..., :3].mean(axis=(0, 1))
     np.testing.assert_allclose(means[("PT", 0.3)], means[("PTMIS", 0.3)], rtol=0.02)
     np.testing.assert_allclose(means[("PTMIS", 0.3)], means[("PTMIS", 0.0)], rtol=0.03)
+
+
+def test_thin_glass_integrators_agree(product_lib, oracle):
+    """Thin glass: light sampling attenuated through the panes (Scene.visibility's transmittance) against plain path
+    tracing, which passes them as .Straight events; both darker than the scene without glass absorption would be."""
+    w, h, spp = 40, 30, 512
+    objs = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01)}
+    means = {}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator=integ, glass_objects=objs, max_depth=12)
+            sd, vd = e.compile()
+            flags = [sd.props[i].flags for i in range(sd.num_props)]
+            assert sum(1 for f in flags if f & 16) == 2  # ZYGPU_PROP_EVALUATE_VISIBILITY on the two glass props
+            img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(img).all()
+            means[integ] = img[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.01)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.02)

@@ -10,7 +10,7 @@
 
 namespace zd {
 
-enum : uint32_t { kScatterDiffuse = 0, kScatterGlossy = 1, kScatterSpecular = 2 };
+enum : uint32_t { kScatterDiffuse = 0, kScatterGlossy = 1, kScatterSpecular = 2, kScatterNone = 3 };
 
 struct BxdfResult {
     f3    reflection;
@@ -24,6 +24,7 @@ struct BxdfSample {
     uint32_t scattering;
     // set by Glass only (every other sample in scope is a reflection with split weight 1)
     bool     transmission;
+    bool     straight;  // bxdf.Path.straight: thin glass passes the ray on unbent (no scattering event for the vertex state)
     float    split_weight;
 };
 
@@ -206,6 +207,7 @@ ZD float reflectNoFresnel(f3 wo, f3 h, float n_dot_wo, float n_dot_h, float wo_d
     result.reg_alpha = alpha;
     result.scattering = alpha <= specular_threshold ? kScatterSpecular : kScatterGlossy;
     result.transmission = false;
+    result.straight = false;
     return n_dot_wi;
 }
 ZD float refractNoFresnel(f3 wo, f3 h, float n_dot_wo, float n_dot_h, float wi_dot_h, float wo_dot_h, float alpha, float specular_threshold,
@@ -228,6 +230,7 @@ ZD float refractNoFresnel(f3 wo, f3 h, float n_dot_wo, float n_dot_h, float wi_d
     result.reg_alpha = alpha;
     result.scattering = alpha <= specular_threshold ? kScatterSpecular : kScatterGlossy;
     result.transmission = true;
+    result.straight = false;
     return n_dot_wi;
 }
 
@@ -240,7 +243,8 @@ struct MaterialSample {
     f3       albedo;
     f3       f0;
     float    metallic, specular, specular_threshold, opacity;
-    float    ior, ior_outside, glass_f0;  // Glass
+    float    ior, ior_outside, glass_f0, thickness;  // Glass
+    f3       absorption;
     bool     lower_priority;
 
     // Glass.Sample.evaluate (glass_sample.zig:68-146): rough interfaces only; `split`: max_splits > 1
@@ -304,6 +308,7 @@ struct MaterialSample {
             r0.reg_alpha = 0.f;
             r0.scattering = kScatterSpecular;
             r0.transmission = true;
+            r0.straight = false;
             r0.split_weight = 1.f;
             return 1;
         }
@@ -366,21 +371,23 @@ struct MaterialSample {
     ZD uint32_t glassSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
         if (a0 > 0.f) return glassRoughSample(s, sampler, split, r0, r1);
         float eta_i = ior_outside, eta_t = ior;
-        auto  fill = [&](BxdfSample& r, f3 wi, f3 reflection, float split_weight, bool transmission) {
+        auto  fill = [&](BxdfSample& r, f3 wi, f3 reflection, float split_weight, bool transmission, bool straight = false) {
             r.reflection = reflection;
             r.wi = wi;
             r.pdf = 1.f;
-            r.reg_alpha = 0.f;
-            r.scattering = kScatterSpecular;
+            r.reg_alpha = straight ? 1.f : 0.f;
+            r.scattering = straight ? kScatterNone : kScatterSpecular;
             r.transmission = transmission;
+            r.straight = straight;
             r.split_weight = split_weight;
         };
         if (eta_i == eta_t || lower_priority) {
             fill(r0, -wo, S3(1.f), 1.f, true);
             return 1;
         }
-        f3 nn = frame.z;
-        if (!sameHemisphere(wo)) {
+        const bool thin = thickness > 0.f;
+        f3         nn = frame.z;
+        if (!thin && !sameHemisphere(wo)) {  // thin material is always double sided (glass_sample.zig:203-209)
             nn = -nn;
             const float e = eta_i;
             eta_i = eta_t;
@@ -399,14 +406,18 @@ struct MaterialSample {
         }
         const f3 reflected = normalize3(S3(2.f * n_dot_wo) * nn - wo);
         const f3 refracted = normalize3(S3(eta * n_dot_wo - n_dot_t) * nn - S3(eta) * wo);
+        // thinSpecularRefract (glass_sample.zig:505-517): straight through, attenuated over the slab
+        const f3 thin_attenuation = thin ? attenuation3(absorption, thickness / clampf(n_dot_wo, kDotMin, 1.f)) : S3(1.f);
         if (split) {
             fill(r0, reflected, S3(specular) * S3(1.f), f, false);
             if (1.f == f) return 1;
-            fill(r1, refracted, S3(1.f), 1.f - f, true);
+            if (thin) fill(r1, -wo, thin_attenuation, 1.f - f, false, true);
+            else fill(r1, refracted, S3(1.f), 1.f - f, true);
             return 2;
         }
         const float p = sampler.sample1D();
         if (p <= f) fill(r0, reflected, S3(specular) * S3(1.f), 1.f, false);
+        else if (thin) fill(r0, -wo, thin_attenuation, 1.f, false, true);
         else fill(r0, refracted, S3(1.f), 1.f, true);
         return 1;
     }
@@ -460,6 +471,7 @@ struct MaterialSample {
     template <bool SUBST = true>
     ZD bool sample(const DScene& s, Sampler& sampler, BxdfSample& result) const {  // material_sample.zig:55-70
         result.transmission = false;
+        result.straight = false;
         result.split_weight = 1.f;
         if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return false;  // Glass: glassSample (pool kernels only)
         if (ZYGPU_MAT_DEBUG == kind) {  // debug_sample.zig:28-47
@@ -528,6 +540,8 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
     ms.ior = m.ior;
     ms.ior_outside = ior_outside;
     ms.glass_f0 = 0.f;
+    ms.thickness = 0.f;
+    ms.absorption = S3(0.f);
     ms.lower_priority = lower_priority;
     ms.kind = m.kind;
     ms.geo_n = geo_n;
@@ -560,6 +574,9 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         const float t_ = (m.ior - ior_outside) / (m.ior + ior_outside);
         ms.glass_f0 = rough ? t_ * t_ : 0.f;
         ms.specular = m.specular;
+        ms.thickness = m.thickness;
+        ms.absorption = mk3(m.absorption[0], m.absorption[1], m.absorption[2]);
+        ms.translucent = m.thickness > 0.f;
     } else {
         const float roughness = mx(m.roughness, kMinRoughness);
         if (m.anisotropy > 0.f) {

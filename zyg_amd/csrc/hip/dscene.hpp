@@ -382,6 +382,105 @@ ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
     return !blocked;
 }
 
+ZD f3 attenuation3(f3 c, float distance) {  // collision_coefficients.zig:67-69
+    const f3 x = S3(-distance) * c;
+    return mk3(expF(x.x), expF(x.y), expF(x.z));
+}
+
+// Glass.visibility for thin glass without a mask (glass_material.zig:82-115): Fresnel transmission x absorption over the
+// slab; false = blocked (total internal reflection)
+ZD bool thinGlassVisibility(const ZygpuMaterial& m, f3 wi, f3 geo_n, f3& tr) {
+    const float eta_i = 1.f, eta_t = m.ior;
+    const float n_dot_wo = mn(fabsf(dot3(geo_n, wi)), 1.f);
+    const float eta = eta_i / eta_t;
+    const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
+    if (sint2 >= 1.f) return false;
+    const float n_dot_t = sqrtf(1.f - sint2);
+    const float t0 = eta_t * n_dot_wo, t1 = eta_i * n_dot_t;  // fresnel.dielectric (fresnel.zig:31-43)
+    const float r_p = (t0 - t1) / (t0 + t1);
+    const float t2 = eta_i * n_dot_wo, t3 = eta_t * n_dot_t;
+    const float r_o = (t2 - t3) / (t2 + t3);
+    const float f = 0.5f * (r_p * r_p + r_o * r_o);
+    const float n_dot_wi = clampf(n_dot_wo, 0.00001f, 1.f);
+    const float approx_dist = m.thickness / n_dot_wi;
+    const f3    attenuation = attenuation3(mk3(m.absorption[0], m.absorption[1], m.absorption[2]), approx_dist);
+    const f3    ta = min3v(S3(1.f - 1.f) + attenuation, S3(1.f));
+    tr = tr * (S3(1.f - f) * ta);
+    return true;
+}
+// Material.visibility (material.zig:227-248): Glass evaluates, everything else (opacity 1) blocks
+ZD bool materialVisibility(const ZygpuMaterial& m, f3 wi, f3 geo_n, f3& tr) {
+    if (ZYGPU_MAT_GLASS == m.kind && m.thickness > 0.f) return thinGlassVisibility(m, wi, geo_n, tr);
+    return false;
+}
+
+// Scene.visibility with transmittance (prop_tree.zig:185-240, prop.zig:199-237, shape.zig:235-245): props whose materials
+// evaluate visibility (thin Glass) attenuate `tr` instead of blocking (rectangle.zig:154-186, sphere.zig:176-228,
+// triangle_tree.zig:244-306); true = not blocked
+template <bool STATS>
+ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
+    const bool blocked = bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            const uint32_t  p = s.solid_indices[i];
+            const ZygpuProp prop = s.props[p];
+            if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;
+            if (STATS) cnt.instances += 1;
+            if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
+            const Trafo trafo = loadTrafo(s, p);
+            const bool  evaluate = 0 != (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
+            if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
+                float t, u, v;
+                if (!rectangleIntersect(ray, trafo, t, u, v)) continue;
+                if (!evaluate || !materialVisibility(s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, tr)) return true;
+            } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {
+                if (!evaluate) {
+                    float t;
+                    if (sphereIntersect(ray, trafo, t)) return true;
+                    continue;
+                }
+                const float idl = 1.f / length3(ray.direction);
+                const f3    nd = ray.direction * S3(idl);
+                const f3    v = trafo.position - ray.origin;
+                const float b = dot3(nd, v);
+                const f3    remedy_term = v - S3(b) * nd;
+                const float radius = 0.5f * trafo.scale.x;
+                const float discriminant = radius * radius - dot3(remedy_term, remedy_term);
+                if (discriminant > 0.f) {
+                    const float          dist = sqrtf(discriminant);
+                    const ZygpuMaterial& m = s.materials[s.material_ids[prop.parts_start]];
+                    const float          t0 = (b - dist) * idl, t1 = (b + dist) * idl;
+                    if (t0 >= ray.min_t && ray.max_t >= t0 && !materialVisibility(m, ray.direction, normalize3(ray.point(t0) - trafo.position), tr))
+                        return true;
+                    if (t1 >= ray.min_t && ray.max_t >= t1 && !materialVisibility(m, ray.direction, normalize3(ray.point(t1) - trafo.position), tr))
+                        return true;
+                }
+            } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+                Ray          local = worldToObjectRay(trafo, ray);
+                const DMesh& mesh = s.meshes[prop.mesh];
+                if (!evaluate) {
+                    if (meshIntersectP<STATS>(mesh, local, cnt)) return true;
+                    continue;
+                }
+                const bool mesh_blocked = bvhWalk<STATS>(mesh.nodes, 1u, local, cnt, [&](uint32_t tfirst, uint32_t tcount) {
+                    for (uint32_t k = tfirst, ke = tfirst + tcount; k < ke; ++k) {
+                        if (STATS) cnt.tris += 1;
+                        const f3 a = xyz(mesh.tri_verts[3 * k]), b = xyz(mesh.tri_verts[3 * k + 1]), c = xyz(mesh.tri_verts[3 * k + 2]);
+                        float    t, u, v;
+                        if (!triangleIntersect(local, a, b, c, t, u, v)) continue;
+                        const ZygpuMaterial& m = s.materials[s.material_ids[prop.parts_start + mesh.triangle_parts[k]]];
+                        if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return true;
+                        if (!materialVisibility(m, local.direction, normalize3(cross3(b - a, c - a)), tr)) return true;
+                    }
+                    return false;
+                });
+                if (mesh_blocked) return true;
+            }
+        }
+        return false;
+    });
+    return !blocked;
+}
+
 struct Fragment {  // shape/intersection.zig:64-124
     Trafo    trafo;
     float    t_hit, u, v;

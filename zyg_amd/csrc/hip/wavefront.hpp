@@ -361,10 +361,6 @@ struct Mediums {  // prop/medium.zig:30-153; an entry is its (prop, part): ior, 
     }
 };
 
-ZD f3 attenuation3(f3 c, float distance) {  // collision_coefficients.zig:67-69
-    const f3 x = S3(-distance) * c;
-    return mk3(expF(x.x), expF(x.y), expF(x.z));
-}
 
 ZD uint32_t pixelId(int x, int y) {  // worker.zig:127-128,136,141
     const int fr = c_view.v.filter_radius_int;
@@ -1340,17 +1336,19 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     shadowRay(sorigin, ls, sdir, slen, distant);
                     Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
                     if (STATS) shadow_rays += 1;
-                    if (!sceneVisibility<STATS>(s, shadow, cnt)) return;
+                    f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)
+                    if (POOL ? !sceneVisibilityTr<STATS>(s, shadow, cnt, tr) : !sceneVisibility<STATS>(s, shadow, cnt)) return;
                     const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                     const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
                     if (mis) {
                         const float light_pdf = ls.pdf * pick.pdf;
                         const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
-                        occluded = occluded + S3(weight) * radiance * bx.reflection;
+                        const f3    unocc = S3(weight) * radiance * bx.reflection;
+                        occluded = occluded + (POOL ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
                     } else {
                         const float weight = 1.f / (pick.pdf * ls.pdf);
-                        occluded = occluded + S3(weight) * (S3(1.f) * radiance * bx.reflection);
+                        occluded = occluded + S3(weight) * ((POOL ? tr : S3(1.f)) * radiance * bx.reflection);
                     }
                 };
 
@@ -1465,21 +1463,21 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 const uint32_t first = (st >> 8) & 255u;
                 P.pool.pstate[ps] = st + (count << 8) + (count - 1u);  // children created; vertices in flight: -1 + count
                 const float  parent_pdf = P.pool.ray_d[slot].w;
-                const float4 parent_vgeo_n = P.pool.vgeo_n[slot];
+                const float4 parent_vgeo_n = P.pool.vgeo_n[slot], parent_vorigin = P.pool.vorigin[slot];
                 for (uint32_t c = 0; c < count; ++c) {
                     const BxdfSample& b = c ? bs1 : bs;
                     const uint32_t    cv = (nxt * kPoolVertices + first + c) * batchPaths() + ps;
                     PathHead          ch = h;
-                    // Vertex.State.update (vertex.zig:30-43); no .Straight event in scope
+                    // Vertex.State.update (vertex.zig:30-43): a .Straight event (thin glass) leaves the state alone
                     if (kScatterSpecular == b.scattering) {
                         ch.flags |= ST_SPECULAR;
                         ch.flags = (0.f == b.reg_alpha) ? (ch.flags | ST_SINGULAR) : (ch.flags & ~uint32_t(ST_SINGULAR));
                         if (ch.flags & ST_PRIMARY) ch.flags |= ST_STARTED_SPECULAR;
-                    } else {
+                    } else if (!b.straight) {
                         ch.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
                     }
                     float bxdf_pdf = parent_pdf;
-                    if (mis) {
+                    if (mis && !b.straight) {  // pathtracer_mis.zig:141-148: not for .Straight
                         ch.flags = ms.translucent ? (ch.flags | ST_TRANSLUCENT) : (ch.flags & ~uint32_t(ST_TRANSLUCENT));
                         ch.vdepth = h.depth_surface;
                         bxdf_pdf = b.pdf;
@@ -1496,14 +1494,15 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                             ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[P.pool.hit[slot].w]) : 0u;
                         if (dot3(sf.frag_geo_n, b.wi) > 0.f) cm.remove(hit_prop, part);
                         else cm.push(hit_prop, part);
-                    } else {
+                    } else if (!b.straight) {
                         ch.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight)
                     }
                     P.pool.ray_o[cv] = f4(new_origin, kRayMaxT);
                     P.pool.ray_d[cv] = f4(b.wi, bxdf_pdf);
                     P.pool.thr[cv] = f4(throughput * (b.reflection / S3(b.pdf)), split_weight * b.split_weight);
-                    P.pool.vorigin[cv] = f4(sf.p, __uint_as_float(path_count * count));
-                    P.pool.vgeo_n[cv] = mis ? f4(ms.geo_n) : parent_vgeo_n;
+                    // vertex.origin / geo_n move with every event but .Straight (pathtracer_mis.zig:141-148, pathtracer.zig:88-90)
+                    P.pool.vorigin[cv] = f4(b.straight ? xyz4(parent_vorigin) : sf.p, __uint_as_float(path_count * count));
+                    P.pool.vgeo_n[cv] = (mis && !b.straight) ? f4(ms.geo_n) : parent_vgeo_n;
                     P.pool.vmeta[cv] = packMeta(ch);
                     cm.store(P, cv);
                     child[c] = cv;

@@ -575,8 +575,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t pi = 0; pi < d->num_parts; ++pi) {
         const ZygpuMaterial& gm = d->materials[d->material_ids[pi]];
         if (ZYGPU_MAT_GLASS != gm.kind) continue;
-        if (gm.thickness > 0.f || gm.abbe > 0.f) {
-            g_error = "Glass: only thick, non-dispersive glass (thickness 0, abbe 0) is supported";
+        if ((gm.thickness > 0.f && gm.roughness > 0.f) || gm.abbe > 0.f) {
+            g_error = "Glass: rough thin glass and dispersion (abbe) are not supported";
             return -2;
         }
         if (gm.roughness > 0.f && !d->luts.e_s) {

@@ -1241,9 +1241,9 @@ int Engine::compile(uint32_t frame) {
     d.num_image_lights = uint32_t(c_image_lights_.size());
     for (const ZygpuMaterial& m : materials_)
         if (ZYGPU_NULL != m.color_image && m.color_image >= images_.size()) return -4;  // a colour map without its image
-    for (uint32_t mid : material_ids_) {  // thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 437-517)
+    for (uint32_t mid : material_ids_) {  // rough thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 437-503)
         const ZygpuMaterial& m = materials_[mid];
-        if (ZYGPU_MAT_GLASS == m.kind && (m.thickness > 0.f || m.abbe > 0.f)) return -5;
+        if (ZYGPU_MAT_GLASS == m.kind && ((m.thickness > 0.f && m.roughness > 0.f) || m.abbe > 0.f)) return -5;
     }
     for (const ZygpuMaterial& m : materials_) {
         if (ZYGPU_MAT_SUBSTITUTE != m.kind && !(ZYGPU_MAT_GLASS == m.kind && m.roughness > 0.f)) continue;
