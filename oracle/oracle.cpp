@@ -163,6 +163,8 @@ struct Worker {
         if (ZYGPU_SHAPE_RECTANGLE == p.shape) return s[0] * s[1];
         if (ZYGPU_SHAPE_DISTANT == p.shape) return distantSolidAngle(s[0]);  // "the solid angle, not the area" (shape.zig:140-142)
         if (ZYGPU_SHAPE_SPHERE == p.shape) return (4.f * kPi) * ((0.5f * s[0]) * (0.5f * s[0]));  // shape.zig:148
+        if (ZYGPU_SHAPE_DISK == p.shape) return kPi * ((0.5f * s[0]) * (0.5f * s[0]));
+        if (ZYGPU_SHAPE_CUBE == p.shape) return 2.f * (s[0] * s[1] + s[0] * s[2] + s[1] * s[2]);
         if (ZYGPU_SHAPE_DOME == p.shape) return 4.f * kPi;
         if (ZYGPU_SHAPE_CANOPY == p.shape) return 2.f * kPi;
         return rc->scene->meshes[p.mesh].part_areas[part] * (s[0] * s[1]);

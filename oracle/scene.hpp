@@ -491,6 +491,69 @@ inline void rectangleFragment(const Ray& ray, Fragment& frag) {
     frag.part = 0;
 }
 
+// ---- Disk (disk.zig:28-60, 100-116) and Cube (cube.zig:23-67): geometry only
+inline bool diskIntersect(const Ray& ray, const Trafo& trafo, float& out_t, float& out_u, float& out_v) {
+    const V4    normal = trafo.r[2];
+    const float d = dot3(normal, trafo.position);
+    const float denom = -dot3(normal, ray.direction);
+    const float numer = dot3(normal, ray.origin) - d;
+    const float hit_t = numer / denom;
+    if (hit_t >= ray.min_t && ray.max_t >= hit_t) {
+        const V4    k = ray.point(hit_t) - trafo.position;
+        const float l = dot3(k, k);
+        const float radius = 0.5f * trafo.scaleX();
+        if (l <= radius * radius) {
+            const V4 sk = k / S(radius);
+            out_u = -dot3(trafo.r[0], sk);
+            out_v = -dot3(trafo.r[1], sk);
+            out_t = hit_t;
+            return true;
+        }
+    }
+    return false;
+}
+inline void diskFragment(const Ray& ray, Fragment& frag) {
+    const Trafo& tr = frag.isec.trafo;
+    frag.p = ray.point(frag.isec.t);
+    frag.t = -tr.r[0];
+    frag.b = -tr.r[1];
+    frag.n = frag.geo_n = tr.r[2];
+    frag.uvw = mk(0.5f * (frag.isec.u + 1.f), 0.5f * (frag.isec.v + 1.f), 0.f, 0.f);
+    frag.part = 0;
+}
+inline ZygpuAabb unitCube() {
+    ZygpuAabb a;
+    for (int i = 0; i < 4; ++i) {
+        a.min[i] = -0.5f;
+        a.max[i] = 0.5f;
+    }
+    return a;
+}
+inline bool cubeIntersect(const Ray& ray, const Trafo& trafo, float& out_t) {
+    const float hit_t = aabbIntersectP(unitCube(), trafo.worldToObjectRay(ray));
+    if (hit_t < ray.max_t) {
+        out_t = hit_t;
+        return true;
+    }
+    return false;
+}
+inline bool cubeIntersectP(const Ray& ray, const Trafo& trafo) { return aabbIntersect(unitCube(), trafo.worldToObjectRay(ray)); }
+inline void cubeFragment(const Ray& ray, Fragment& frag) {
+    const Trafo& tr = frag.isec.trafo;
+    const float  hit_t = frag.isec.t;
+    frag.p = ray.point(hit_t);
+    const V4 local_p = tr.worldToObjectRay(ray).point(hit_t);
+    float    distance[3];
+    for (int i = 0; i < 3; ++i) distance[i] = std::fabs(0.5f - std::fabs(local_p[i]));
+    const int   i = distance[0] < distance[1] ? (distance[0] < distance[2] ? 0 : 2) : (distance[1] < distance[2] ? 1 : 2);  // indexMinComponent3
+    const float sgn = std::copysign(1.f, local_p[i]);
+    const V4    n = S(sgn) * tr.r[i];
+    frag.part = 0;
+    frag.geo_n = frag.n = n;
+    frag.uvw = S(0.f);
+    orthonormalBasis3(n, frag.t, frag.b);
+}
+
 // triangle.zig:102-149
 inline void interpolate2(const float* a, const float* b, const float* c, float u, float v, float out[2]) {
     const float w = 1.f - u - v;
@@ -592,11 +655,21 @@ struct SceneView {
             isec.trafo = trafo;
             return true;
         }
-        if (ZYGPU_SHAPE_SPHERE == prop.shape) {
+        if (ZYGPU_SHAPE_SPHERE == prop.shape || ZYGPU_SHAPE_CUBE == prop.shape) {
             float t;
-            if (!sphereIntersect(ray, trafo, t)) return false;
+            if (!(ZYGPU_SHAPE_SPHERE == prop.shape ? sphereIntersect(ray, trafo, t) : cubeIntersect(ray, trafo, t))) return false;
             isec.t = t;
             isec.u = isec.v = 0.f;
+            isec.primitive = 0;
+            isec.trafo = trafo;
+            return true;
+        }
+        if (ZYGPU_SHAPE_DISK == prop.shape) {
+            float t, u, v;
+            if (!diskIntersect(ray, trafo, t, u, v)) return false;
+            isec.t = t;
+            isec.u = u;
+            isec.v = v;
             isec.primitive = 0;
             isec.trafo = trafo;
             return true;
@@ -654,6 +727,11 @@ struct SceneView {
             float t;
             return !sphereIntersect(ray, trafo, t);
         }
+        if (ZYGPU_SHAPE_DISK == prop.shape) {  // disk.zig:115-133
+            float t, u, v;
+            return !diskIntersect(ray, trafo, t, u, v);
+        }
+        if (ZYGPU_SHAPE_CUBE == prop.shape) return !cubeIntersectP(ray, trafo);  // cube.zig:63-67
         return true;
     }
 
@@ -661,6 +739,8 @@ struct SceneView {
         const ZygpuProp& p = d->props[prop];
         if (ZYGPU_SHAPE_RECTANGLE == p.shape) rectangleFragment(ray, frag);
         else if (ZYGPU_SHAPE_SPHERE == p.shape) sphereFragment(ray, frag);
+        else if (ZYGPU_SHAPE_DISK == p.shape) diskFragment(ray, frag);
+        else if (ZYGPU_SHAPE_CUBE == p.shape) cubeFragment(ray, frag);
         else meshFragment(d->meshes[p.mesh], frag);
     }
 

@@ -432,3 +432,11 @@ def test_tonemappers(engine, oracle, tonemapper, exposure):
         assert np.array_equal(img, cpu)
     if tonemapper in ("ACES", "PbrNeutral"):
         assert img[..., :3].max() <= 1.25  # both compress into the display range (ACES' output matrix overshoots a little)
+
+
+@pytest.mark.parametrize("integrator,material", [("PT", "lambert"), ("PTMIS", "substitute")])
+def test_disk_and_cube(engine, oracle, integrator, material):
+    """The remaining analytic shapes as geometry: Disk (disk.zig:28-60, 100-133) and Cube (cube.zig:23-80: the object-space
+    slab test, face normal from the nearest face, orthonormal tangent frame)."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, material=material, disk_and_cube=True, boxes=False)
+    _check(*out, 3)

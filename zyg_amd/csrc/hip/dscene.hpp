@@ -306,8 +306,45 @@ ZD bool propVisibleAtDepth(uint32_t flags, uint32_t depth_surface) {  // prop.zi
     return 0 == depth_surface ? 0 != (flags & ZYGPU_PROP_VISIBLE_IN_CAMERA) : 0 != (flags & ZYGPU_PROP_VISIBLE_IN_REFLECTION);
 }
 
+// ---- Disk (disk.zig:28-60, 100-116) and Cube (cube.zig:23-67): geometry only
+ZD bool diskIntersect(const Ray& ray, const Trafo& trafo, float& out_t, float& out_u, float& out_v) {
+    const f3    normal = trafo.r2;
+    const float d = dot3(normal, trafo.position);
+    const float denom = -dot3(normal, ray.direction);
+    const float numer = dot3(normal, ray.origin) - d;
+    const float hit_t = numer / denom;
+    if (hit_t >= ray.min_t && ray.max_t >= hit_t) {
+        const f3    k = ray.point(hit_t) - trafo.position;
+        const float l = dot3(k, k);
+        const float radius = 0.5f * trafo.scale.x;
+        if (l <= radius * radius) {
+            const f3 sk = k / S3(radius);
+            out_u = -dot3(trafo.r0, sk);
+            out_v = -dot3(trafo.r1, sk);
+            out_t = hit_t;
+            return true;
+        }
+    }
+    return false;
+}
+ZD bool cubeIntersect(const Ray& ray, const Trafo& trafo, float& out_t) {
+    const Ray   local = worldToObjectRay(trafo, ray);
+    const float hit_t = aabbIntersectP(make_float4(-0.5f, -0.5f, -0.5f, -0.5f), make_float4(0.5f, 0.5f, 0.5f, 0.5f), local);
+    if (hit_t < ray.max_t) {
+        out_t = hit_t;
+        return true;
+    }
+    return false;
+}
+ZD bool cubeIntersectP(const Ray& ray, const Trafo& trafo) {
+    const Ray local = worldToObjectRay(trafo, ray);
+    return aabbIntersect(make_float4(-0.5f, -0.5f, -0.5f, -0.5f), make_float4(0.5f, 0.5f, 0.5f, 0.5f), local);
+}
+
 // prop_tree.zig:56-116 over the solid TLAS (closest hit); shrinks ray.max_t
-template <bool STATS>
+// EXTRA: the scene has analytic shapes other than Rectangle (Sphere, Disk, Cube); kept out of the common instantiations,
+// where their code cost 12 % (registers of wf_shade's first pass and wf_intersect; measured 426 vs 374 Msamples/s)
+template <bool STATS, bool EXTRA>
 ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt) {
     hit.prop = kNull;
     bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
@@ -328,11 +365,21 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                     hit.prop = p;
                     ray.max_t = t;
                 }
-            } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {
+            } else if (EXTRA && (ZYGPU_SHAPE_SPHERE == prop.shape || ZYGPU_SHAPE_CUBE == prop.shape)) {
                 float t;
-                if (sphereIntersect(ray, trafo, t)) {
+                if (ZYGPU_SHAPE_SPHERE == prop.shape ? sphereIntersect(ray, trafo, t) : cubeIntersect(ray, trafo, t)) {
                     hit.t = t;
                     hit.u = hit.v = 0.f;
+                    hit.primitive = 0;
+                    hit.prop = p;
+                    ray.max_t = t;
+                }
+            } else if (EXTRA && ZYGPU_SHAPE_DISK == prop.shape) {
+                float t, u, v;
+                if (diskIntersect(ray, trafo, t, u, v)) {
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
                     hit.primitive = 0;
                     hit.prop = p;
                     ray.max_t = t;
@@ -356,7 +403,7 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
 }
 
 // prop_tree.zig:185-240 + prop.zig:199-237: true = unoccluded
-template <bool STATS>
+template <bool STATS, bool EXTRA>
 ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
     const bool blocked = bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
@@ -369,12 +416,17 @@ ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) return true;
-            } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:148-172 intersectP: the same two roots
-                float t;
-                if (sphereIntersect(ray, trafo, t)) return true;
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 Ray local = worldToObjectRay(trafo, ray);
                 if (meshIntersectP<STATS>(s.meshes[prop.mesh], local, cnt)) return true;
+            } else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:148-172 intersectP: the same two roots
+                float t;
+                if (sphereIntersect(ray, trafo, t)) return true;
+            } else if (EXTRA && ZYGPU_SHAPE_DISK == prop.shape) {
+                float t, u, v;
+                if (diskIntersect(ray, trafo, t, u, v)) return true;
+            } else if (EXTRA && ZYGPU_SHAPE_CUBE == prop.shape) {
+                if (cubeIntersectP(ray, trafo)) return true;
             }
         }
         return false;
@@ -474,6 +526,12 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
                     return false;
                 });
                 if (mesh_blocked) return true;
+            } else if (ZYGPU_SHAPE_DISK == prop.shape) {  // the material decides (Material.visibility): thin glass attenuates
+                float t, u, v;
+                if (!diskIntersect(ray, trafo, t, u, v)) continue;
+                if (!evaluate || !materialVisibility(s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, tr)) return true;
+            } else if (ZYGPU_SHAPE_CUBE == prop.shape) {  // cube.zig:69-80: always blocks
+                if (cubeIntersectP(ray, trafo)) return true;
             }
         }
         return false;
@@ -590,6 +648,32 @@ ZD void meshFragment(const DMesh& mesh, Fragment& f) {  // triangle_mesh.zig:310
 }
 
 // Shape.fragment for a recorded hit (deterministic recomputation from the hit record + the traced ray)
+ZD void diskFragment(const Ray& ray, Fragment& f) {  // disk.zig:100-116
+    f.p = ray.point(f.t_hit);
+    f.t = -f.trafo.r0;
+    f.b = -f.trafo.r1;
+    f.n = f.geo_n = f.trafo.r2;
+    f.uv0 = 0.5f * (f.u + 1.f);
+    f.uv1 = 0.5f * (f.v + 1.f);
+    f.part = 0;
+}
+ZD void cubeFragment(const Ray& ray, Fragment& f) {  // cube.zig:41-61
+    f.p = ray.point(f.t_hit);
+    const f3    local_p = worldToObjectRay(f.trafo, ray).point(f.t_hit);
+    const float d0 = fabsf(0.5f - fabsf(local_p.x)), d1 = fabsf(0.5f - fabsf(local_p.y)), d2 = fabsf(0.5f - fabsf(local_p.z));
+    const int   i = d0 < d1 ? (d0 < d2 ? 0 : 2) : (d1 < d2 ? 1 : 2);  // indexMinComponent3
+    const float c = 0 == i ? local_p.x : 1 == i ? local_p.y : local_p.z;
+    const f3    axis = 0 == i ? f.trafo.r0 : 1 == i ? f.trafo.r1 : f.trafo.r2;
+    const f3    n = S3(copysignf(1.f, c)) * axis;
+    f.part = 0;
+    f.geo_n = f.n = n;
+    f.uv0 = f.uv1 = 0.f;
+    const Frame fr = Frame::init(n);  // orthonormalBasis3
+    f.t = fr.x;
+    f.b = fr.y;
+}
+
+template <bool EXTRA>
 ZD void makeFragment(const DScene& s, const Ray& ray, const Hit& hit, Fragment& f) {
     f.prop = hit.prop;
     f.t_hit = hit.t;
@@ -599,7 +683,9 @@ ZD void makeFragment(const DScene& s, const Ray& ray, const Hit& hit, Fragment& 
     f.trafo = loadTrafo(s, hit.prop);
     const ZygpuProp prop = s.props[hit.prop];
     if (ZYGPU_SHAPE_RECTANGLE == prop.shape) rectangleFragment(ray, f);
-    else if (ZYGPU_SHAPE_SPHERE == prop.shape) sphereFragment(ray, f);
+    else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) sphereFragment(ray, f);
+    else if (EXTRA && ZYGPU_SHAPE_DISK == prop.shape) diskFragment(ray, f);
+    else if (EXTRA && ZYGPU_SHAPE_CUBE == prop.shape) cubeFragment(ray, f);
     else meshFragment(s.meshes[prop.mesh], f);
 }
 

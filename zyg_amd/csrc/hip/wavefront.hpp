@@ -597,7 +597,7 @@ ZD bool walksUnoccluding(uint32_t flags) {
     return connectsLights(flags) && (ZYGPU_INTEGRATOR_PTDL != c_view.v.integrator || (flags & ST_SINGULAR));
 }
 
-template <bool STATS>
+template <bool STATS, bool EXTRA>
 ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, size_t plane, uint32_t depth_surface, const Ray& ray_in,
                                   Counters& cnt) {
     uint32_t n = 0;
@@ -623,7 +623,7 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) record(p, 0, t, u, v);
-            } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // Sphere.emission (sphere.zig:269-277)
+            } else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) {  // Sphere.emission (sphere.zig:269-277)
                 float t;
                 if (sphereIntersect(ray, trafo, t)) record(p, 0, t, 0.f, 0.f);
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
@@ -647,7 +647,8 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
 }
 
 // ---------------------------------------------------------------- wf_intersect
-template <bool STATS, bool POOL>
+// EXTRA: Sphere / Disk / Cube code (dscene.hpp)
+template <bool STATS, bool POOL, bool EXTRA>
 __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     const uint32_t cur = P.parity;
     // the previous tick's queue was no longer (POOL: a level can have more vertices than the one before)
@@ -685,12 +686,12 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
             }
         }
         Hit            hit;
-        sceneIntersect<STATS>(c_scene, ray, depth, hit, cnt);
+        sceneIntersect<STATS, EXTRA>(c_scene, ray, depth, hit, cnt);
         if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
         P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
         P.pool.hit_prop[slot] = hit.prop;
         // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
-        P.pool.ucount[slot] = walksUnoccluding(flags) ? unoccludingCandidates<STATS>(P, c_scene, slot, vertexPlane<POOL>(), depth, ray, cnt) : 0u;
+        P.pool.ucount[slot] = walksUnoccluding(flags) ? unoccludingCandidates<STATS, EXTRA>(P, c_scene, slot, vertexPlane<POOL>(), depth, ray, cnt) : 0u;
     }
     if (STATS) flushCounters(P, 0, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
 }
@@ -704,6 +705,8 @@ ZD float shapeArea(const DScene& s, uint32_t prop, uint32_t part, const Trafo& t
     if (ZYGPU_SHAPE_SPHERE == p.shape) return (4.f * kPi) * ((0.5f * trafo.scale.x) * (0.5f * trafo.scale.x));  // shape.zig:148
     if (ZYGPU_SHAPE_DOME == p.shape) return 4.f * kPi;
     if (ZYGPU_SHAPE_CANOPY == p.shape) return 2.f * kPi;
+    if (ZYGPU_SHAPE_DISK == p.shape) return kPi * ((0.5f * trafo.scale.x) * (0.5f * trafo.scale.x));
+    if (ZYGPU_SHAPE_CUBE == p.shape) return 2.f * (trafo.scale.x * trafo.scale.y + trafo.scale.x * trafo.scale.z + trafo.scale.y * trafo.scale.z);
     return s.meshes[p.mesh].part_areas[part] * (trafo.scale.x * trafo.scale.y);
 }
 
@@ -896,7 +899,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
             }
             if (!defer) {
             Fragment frag;
-            if (has_hit) makeFragment(s, ray, hit, frag);
+            if (has_hit) makeFragment<MESHL>(s, ray, hit, frag);
             tm.mark(0);
 
             // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
@@ -1190,7 +1193,7 @@ __global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
         const uint32_t slot = P.q.shadow[at];
         const float4   o = P.pool.sh_o[slot], d = P.pool.sh_d[slot];
         Ray            shadow = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
-        P.pool.vis[slot] = sceneVisibility<STATS>(c_scene, shadow, cnt) ? 1u : 0u;
+        P.pool.vis[slot] = sceneVisibility<STATS, true>(c_scene, shadow, cnt) ? 1u : 0u;
     }
     if (STATS) flushCounters(P, 2, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
 }
@@ -1337,7 +1340,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
                     if (STATS) shadow_rays += 1;
                     f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)
-                    if (POOL ? !sceneVisibilityTr<STATS>(s, shadow, cnt, tr) : !sceneVisibility<STATS>(s, shadow, cnt)) return;
+                    if (POOL ? !sceneVisibilityTr<STATS>(s, shadow, cnt, tr) : !sceneVisibility<STATS, MESHL>(s, shadow, cnt)) return;
                     const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                     const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);

@@ -290,6 +290,7 @@ struct ZygpuContext {
     bool          has_substitute = false;  // selects the kernels' material instantiation
     bool          multi_sample_lights = false;  // a light has emittance num_samples > 1: wf_scatter<.., MULTI>
     bool          mesh_lights = false;          // TriangleMesh emitters: wf_shade<.., MESHL>, wf_scatter<.., MESHL>
+    bool          extra_shapes = false;         // Sphere / Disk / Cube props: wf_intersect<.., EXTRA> and the MESHL instantiations
     bool          pool_mode = false;            // Glass in the scene: the POOL instantiations (split paths, medium stack)
     bool          pool_allocated = false;       // the path pool has the POOL layout
     bool          tick_sync = false;       // option "tick_sync": read the queue length back after every tick
@@ -538,12 +539,14 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             c->mesh_lights = true;
         }
     }
+    c->extra_shapes = false;
     for (uint32_t p = 0; p < d->num_props; ++p) {
         const uint32_t sh = d->props[p].shape;
+        if (ZYGPU_SHAPE_SPHERE == sh || ZYGPU_SHAPE_DISK == sh || ZYGPU_SHAPE_CUBE == sh) c->extra_shapes = c->mesh_lights = true;
         const bool     in_tree = 0 != (d->props[p].flags & ZYGPU_PROP_SOLID);
         (void)in_tree;
         if (ZYGPU_SHAPE_RECTANGLE != sh && ZYGPU_SHAPE_TRIANGLE_MESH != sh && ZYGPU_SHAPE_DISTANT != sh && ZYGPU_SHAPE_SPHERE != sh &&
-            ZYGPU_SHAPE_DOME != sh && ZYGPU_SHAPE_CANOPY != sh) {
+            ZYGPU_SHAPE_DOME != sh && ZYGPU_SHAPE_CANOPY != sh && ZYGPU_SHAPE_DISK != sh && ZYGPU_SHAPE_CUBE != sh) {
             g_error = "unsupported shape class on the device path";
             return -2;
         }
@@ -841,8 +844,8 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 for (uint32_t k = 0; k < kPoolVertices; ++k) {
                     P.round = k;
                     timedLaunch(c, 0, [&] {
-                        if (c->stats) hipLaunchKernelGGL((wf_intersect<true, true>), grid, block, 0, c->stream, P);
-                        else hipLaunchKernelGGL((wf_intersect<false, true>), grid, block, 0, c->stream, P);
+                        if (c->stats) hipLaunchKernelGGL((wf_intersect<true, true, true>), grid, block, 0, c->stream, P);
+                        else hipLaunchKernelGGL((wf_intersect<false, true, true>), grid, block, 0, c->stream, P);
                     });
                     timedLaunch(c, 1, [&] {
                         if (c->stats) {
@@ -863,8 +866,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 continue;
             }
             timedLaunch(c, 0, [&] {
-                if (c->stats) hipLaunchKernelGGL((wf_intersect<true, false>), grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL((wf_intersect<false, false>), grid, block, 0, c->stream, P);
+                if (c->stats) hipLaunchKernelGGL((wf_intersect<true, false, true>), grid, block, 0, c->stream, P);
+                else if (c->extra_shapes) hipLaunchKernelGGL((wf_intersect<false, false, true>), grid, block, 0, c->stream, P);
+                else hipLaunchKernelGGL((wf_intersect<false, false, false>), grid, block, 0, c->stream, P);
             });
             timedLaunch(c, 1, [&] {
                 if (c->stats) {

@@ -213,7 +213,7 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
-            floor_material=None, spheres=False, sphere_lights=False, glass_objects=None):
+            floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -295,6 +295,14 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         engine.light(p)
         ids["lights"].append(p)
 
+    if disk_and_cube:  # a tilted Disk (shape 2) and a rotated, non-uniformly scaled Cube (shape 1)
+        p = engine.prop(2, [red])
+        engine.transformation(p, trafo((0.8, 0, -0.6), (0, 1, 0), (0.7, 0.7, 0.7), (-0.4, 0.45, -0.55)))
+        ids["meshes"].append(p)
+        c, s_ = np.cos(np.radians(25.0)), np.sin(np.radians(25.0))
+        p = engine.prop(1, [green])
+        engine.transformation(p, trafo((c, 0, -s_), (0, 1, 0), (0.5, 0.3, 0.4), (0.45, 0.15, -0.45)))
+        ids["meshes"].append(p)
     identity = trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))
     glass_objects = glass_objects or {}
     for key, pos_, d_ in (("sphere", (-0.35, 0.36, -0.5), 0.7), ("inner", (-0.35, 0.36, -0.5), 0.4), ("outside", (1.7, 1.0, -1.2), 0.9)):
