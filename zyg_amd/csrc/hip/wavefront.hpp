@@ -626,7 +626,7 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             } else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) {  // Sphere.emission (sphere.zig:269-277)
                 float t;
                 if (sphereIntersect(ray, trafo, t)) record(p, 0, t, 0.f, 0.f);
-            } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
+            } else if (EXTRA && ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 // TriangleTree.emission (triangle_tree.zig:405-483): every triangle the ray crosses, no max_t shrinking
                 const DMesh& mesh = s.meshes[prop.mesh];
                 Ray          local = worldToObjectRay(trafo, ray);
@@ -647,7 +647,8 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
 }
 
 // ---------------------------------------------------------------- wf_intersect
-// EXTRA: Sphere / Disk / Cube code (dscene.hpp)
+// EXTRA (= the scenes that run the MESHL instantiations): Sphere / Disk / Cube code (dscene.hpp), mesh lights as unoccluding
+// candidates
 template <bool STATS, bool POOL, bool EXTRA>
 __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     const uint32_t cur = P.parity;
@@ -984,7 +985,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_S
                     P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
                     P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
                     f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
-                    if (kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
+                    if (MESHL && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
                     P.pool.rec_n[slot] = f4(n, color.x);
                     P.pool.rec_t[slot] = f4(frag.t, color.y);
                     P.pool.rec_b[slot] = f4(frag.b, color.z);

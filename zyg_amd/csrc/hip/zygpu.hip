@@ -539,6 +539,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             c->mesh_lights = true;
         }
     }
+    for (uint32_t mi = 0; mi < d->num_materials; ++mi)  // texture fetches live in the MESHL instantiations, too
+        if (ZYGPU_NULL != d->materials[mi].color_image || ZYGPU_NULL != d->materials[mi].emission_image) c->mesh_lights = true;
     c->extra_shapes = false;
     for (uint32_t p = 0; p < d->num_props; ++p) {
         const uint32_t sh = d->props[p].shape;
@@ -867,7 +869,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             }
             timedLaunch(c, 0, [&] {
                 if (c->stats) hipLaunchKernelGGL((wf_intersect<true, false, true>), grid, block, 0, c->stream, P);
-                else if (c->extra_shapes) hipLaunchKernelGGL((wf_intersect<false, false, true>), grid, block, 0, c->stream, P);
+                else if (c->mesh_lights) hipLaunchKernelGGL((wf_intersect<false, false, true>), grid, block, 0, c->stream, P);
                 else hipLaunchKernelGGL((wf_intersect<false, false, false>), grid, block, 0, c->stream, P);
             });
             timedLaunch(c, 1, [&] {
