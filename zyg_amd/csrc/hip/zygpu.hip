@@ -791,7 +791,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     const size_t npix = size_t(xe - xb) * size_t(ye - yb);
 
     // batch size: as many iterations as fit ~8M paths (bounded by what is left)
-    const size_t   target_paths = (size_t(c->batch_mpaths) << 20) / (c->pool_mode ? 2 * kPoolVertices : 1);
+    // POOL: 8 vertex records per slot, but rounds 1-3 are sparse; measured on a 1080p glass Cornell box 106 / 112 / 127
+    // Msamples/s at 4 / 8 / 16 M slots (and a collapse at 32 M, ~130 GB of pool)
+    const size_t   target_paths = (size_t(c->batch_mpaths) << 20) / (c->pool_mode ? 2 : 1);
     const uint32_t per_batch = uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
     // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
