@@ -19,7 +19,7 @@ with zyg_amd.Engine() as e:
     e.start_frame(0)
     if len(sys.argv) > 3:
         assert e.lib.zygpu_set_option(e.context(), b"batch_mpaths", int(sys.argv[3])) == 0
-    e.render_iterations(2)
+    e.render_iterations(iters)  # same batch size as the timed call: (re)allocating the path pool takes seconds
     e.synchronize()
     import ctypes
     ms = (ctypes.c_double * 6)()
