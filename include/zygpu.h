@@ -121,8 +121,8 @@ enum ZygpuMaterialFlags {
 /* Uniform-texture subset of the reference materials (all colours ACES AP1, base/json.zig:247-277).
  * Debug: color_a/color_b = front/back albedo (debug_material.zig:11-12);
  * Substitute: color_a = color, see substitute_material.zig:32-60; emittance: light/emittance.zig:18-27;
- * Glass: thick, perfectly specular dielectric (roughness 0, thickness 0, abbe 0; anything else is refused by
- * zygpu_upload_scene): glass_material.zig:46-115, glass_sample.zig:165-292 */
+ * Glass: dielectric, thick (smooth or rough: roughness) or a thin pane (thickness > 0, smooth); rough thin glass and
+ * dispersion (abbe) are refused by zygpu_upload_scene: glass_material.zig:46-115, glass_sample.zig:33-538 */
 typedef struct ZygpuMaterial {
     uint32_t kind;
     uint32_t flags;
