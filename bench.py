@@ -32,7 +32,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters-per-step", type=int, default=ITER_PER_STEP)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_mesh"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_mesh", "cornell_glass", "outdoor"],
+                    help="cornell = BASELINE.json configs[1] (default), cornell_mesh = configs[2]; cornell_glass and outdoor "
+                         "(configs[4]'s ingredients: glass, metal presets, 1 M-triangle mesh, image-lit canopy + sun) run the "
+                         "POOL kernels")
     ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
     ap.add_argument("--nee", default="in-place", choices=["in-place", "staged"],
                     help="zygpu option nee_in_place: wf_scatter (default) or the wf_nee / wf_shadow rounds + wf_extend")
@@ -74,8 +77,13 @@ def main():
     mesh = scenes.heightfield_mesh() if args.scene == "cornell_mesh" else None
     # cornell_mesh = BASELINE.json configs[2]: the 999 698-triangle heightfield with one grey Substitute material
     mesh_material = scenes.substitute((0.5, 0.5, 0.5)) if mesh is not None else None
-    scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=args.material, boxes=mesh is None, mesh=mesh,
-                   mesh_material=mesh_material)
+    if args.scene == "outdoor":
+        scenes.outdoor(eng, w, h, total_spp, integrator="PTMIS", material="substitute", sky="canopy", sky_map=scenes.sky_image(1024, 1024),
+                       sky_spectrum=(1.0, 1.0, 1.0), showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16)
+    else:
+        glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if args.scene == "cornell_glass" else None
+        scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=args.material, boxes=mesh is None, mesh=mesh,
+                       mesh_material=mesh_material, glass_objects=glass)
     eng.start_frame(0)
     lib, ctx = eng.lib, eng.context()
     if args.batch_mpaths:
@@ -179,6 +187,8 @@ def main():
                     traffic = round(val["hbm_bytes_per_launch"], 1)
         weights = film[..., 3]
         geometry = "2 boxes" if mesh is None else "999698-triangle heightfield mesh (Substitute)"
+        if args.scene == "cornell_glass":
+            geometry = "tall box, glass box (ior 1.5, absorbing), glass Sphere"
         bsdf = "Lambertian" if args.material == "lambert" else "Substitute (roughness 0.8)"
         out = {
             "metric": "Msamples/sec (whole node) at 1080p/256spp; RMS vs CPU reference",
@@ -193,9 +203,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"Cornell box (5 Rectangle walls, {geometry}, 2 unoccluding Rectangle lights) + "
-                                   f"{bsdf} BSDF, {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
-                                   f"{k * ips} spp per GPU", "scene": args.scene, "material": args.material,
+            "config": {"workload": (f"outdoor scene (ground, 2 boxes (one glass), glass + gold Spheres, 999698-triangle mesh in "
+                                    f"polished iron, 1024^2 canopy image light + Distant sun), {w}x{h}, PTMIS depth 16, Sobol, box "
+                                    f"sensor, {ips} iterations per step, {k * ips} spp per GPU" if args.scene == "outdoor" else
+                                    f"Cornell box (5 Rectangle walls, {geometry}, 2 unoccluding Rectangle lights) + "
+                                    f"{bsdf} BSDF, {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
+                                    f"{k * ips} spp per GPU"), "scene": args.scene, "material": args.material,
                        "parallelism": f"iterations x{n}"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
