@@ -847,14 +847,20 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 // one level of every sample's vertex pool: round k = vertex k of the level, in order (shared samplers)
                 for (uint32_t k = 0; k < kPoolVertices; ++k) {
                     P.round = k;
+                    // the plain instantiations (Rectangle / mesh geometry, single-sample Rectangle lights) or the full ones
+                    const bool plain = !c->stats && !c->mesh_lights && !c->multi_sample_lights;
                     timedLaunch(c, 0, [&] {
                         if (c->stats) hipLaunchKernelGGL((wf_intersect<true, true, true>), grid, block, 0, c->stream, P);
+                        else if (plain) hipLaunchKernelGGL((wf_intersect<false, true, false>), grid, block, 0, c->stream, P);
                         else hipLaunchKernelGGL((wf_intersect<false, true, true>), grid, block, 0, c->stream, P);
                     });
                     timedLaunch(c, 1, [&] {
                         if (c->stats) {
                             hipLaunchKernelGGL((wf_shade<true, true, false, true>), grid, block, 0, c->stream, P);
                             hipLaunchKernelGGL((wf_shade<true, true, true, true>), grid, block, 0, c->stream, P);
+                        } else if (plain) {
+                            hipLaunchKernelGGL((wf_shade<false, false, false, true>), grid, block, 0, c->stream, P);
+                            hipLaunchKernelGGL((wf_shade<false, false, true, true>), grid, block, 0, c->stream, P);
                         } else {
                             hipLaunchKernelGGL((wf_shade<false, true, false, true>), grid, block, 0, c->stream, P);
                             hipLaunchKernelGGL((wf_shade<false, true, true, true>), grid, block, 0, c->stream, P);
@@ -862,6 +868,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                     });
                     timedLaunch(c, 5, [&] {
                         if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, true>), grid, block, 0, c->stream, P);
+                        else if (plain) hipLaunchKernelGGL((wf_scatter<false, true, false, false, true>), grid, block, 0, c->stream, P);
                         else hipLaunchKernelGGL((wf_scatter<false, true, true, true, true>), grid, block, 0, c->stream, P);
                     });
                 }
