@@ -185,6 +185,23 @@ def main():
             for key, val in prof.items():
                 if key.startswith(dom[0]) and "true" not in key:
                     traffic = round(val["hbm_bytes_per_launch"], 1)
+        # a measured ceiling beside the nominal peak: device-to-device copy of 2 GiB, read + written bytes
+        copy_gbs = None
+        try:
+            src = torch.empty(1 << 29, dtype=torch.float32, device=device)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize(device)
+            copy_gbs = round(4 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except RuntimeError:
+            pass
         weights = film[..., 3]
         geometry = "2 boxes" if mesh is None else "999698-triangle heightfield mesh (Substitute)"
         if args.scene == "cornell_glass":
@@ -212,6 +229,7 @@ def main():
                        "parallelism": f"iterations x{n}"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "measured_copy_gbs": copy_gbs,
                          "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(dom[2]),
                          "algorithmic_bytes_per_sample": round(bytes_sample_total, 1),

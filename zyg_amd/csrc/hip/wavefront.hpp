@@ -180,6 +180,9 @@ __constant__ DScene c_scene;  // the compiled scene's device arrays: read on dem
 #ifndef ZYG_SHADE_WAVES
 #define ZYG_SHADE_WAVES 3
 #endif
+#ifndef ZYG_SHADE_BIG_WAVES  // the second pass with mesh / sphere / infinite / image light code: 2 waves instead of ~250 spilled registers
+#define ZYG_SHADE_BIG_WAVES 2
+#endif
 #ifndef ZYG_SHADE_LIGHT_WAVES
 #define ZYG_SHADE_LIGHT_WAVES 5
 #endif
@@ -856,7 +859,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 // the HEAVY = true pass processes with the complete connectLight.
 // POOL: `slot` below is a vertex index, `ps` the camera sample it belongs to
 template <bool STATS, bool MESHL, bool HEAVY, bool POOL>
-__global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? ZYG_SHADE_WAVES : ZYG_SHADE_LIGHT_WAVES) wf_shade(Params P) {
+__global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_WAVES : ZYG_SHADE_WAVES) : ZYG_SHADE_LIGHT_WAVES) wf_shade(Params P) {
     const DScene&  s = c_scene;
     const uint32_t cur = P.parity;
     if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
