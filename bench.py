@@ -37,6 +37,9 @@ def main():
                          "(configs[4]'s ingredients: glass, metal presets, 1 M-triangle mesh, image-lit canopy + sun) run the "
                          "POOL kernels")
     ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
+    ap.add_argument("--fuse", type=int, default=1, choices=[0, 1],
+                    help="zygpu option fuse_trace_shade: wf_trace_shade (closest hit + first shading pass in one kernel, default) "
+                         "or wf_intersect and wf_shade apart")
     ap.add_argument("--nee", default="in-place", choices=["in-place", "staged"],
                     help="zygpu option nee_in_place: wf_scatter (default) or the wf_nee / wf_shadow rounds + wf_extend")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
@@ -88,6 +91,8 @@ def main():
     lib, ctx = eng.lib, eng.context()
     if args.batch_mpaths:
         assert lib.zygpu_set_option(ctx, b"batch_mpaths", args.batch_mpaths) == 0
+    assert lib.zygpu_set_option(ctx, b"fuse_trace_shade", args.fuse) == 0
+    fused = bool(args.fuse) and args.scene in ("cornell", "cornell_mesh")  # POOL scenes always run the kernels apart
     nee_in_place = args.nee == "in-place"
     assert lib.zygpu_set_option(ctx, b"nee_in_place", 1 if nee_in_place else 0) == 0
 
@@ -132,6 +137,9 @@ def main():
     }
     if nee_in_place:
         kernel_bytes_sample["wf_nee"] = kernel_bytes_sample["wf_shadow"] = kernel_bytes_sample["wf_extend"] = 0.0
+    if fused:  # wf_trace_shade is timed as kernel 0 and does both kernels' work; kernel 1 is wf_shade's second pass only
+        kernel_bytes_sample["wf_intersect"] += kernel_bytes_sample["wf_shade"]
+        kernel_bytes_sample["wf_shade"] = 0.0
 
     for i in range(wu):
         render(i * ips, ips)

@@ -18,11 +18,12 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-3
 
 
-def _render_both(engine, oracle, w, h, spp, stats=True, nee_in_place=0, scene=None, **kw):
+def _render_both(engine, oracle, w, h, spp, stats=True, nee_in_place=0, scene=None, fuse=1, **kw):
     (scene or scenes.cornell)(engine, w, h, spp, **kw)
     engine.start_frame(0)
     ctx = engine.context()
     assert engine.lib.zygpu_set_option(ctx, b"nee_in_place", nee_in_place) == 0
+    assert engine.lib.zygpu_set_option(ctx, b"fuse_trace_shade", fuse) == 0
     if stats:
         engine.lib.zygpu_enable_stats(ctx, 1)
         engine.lib.zygpu_reset_stats(ctx)
@@ -440,3 +441,14 @@ def test_disk_and_cube(engine, oracle, integrator, material):
     slab test, face normal from the nearest face, orthonormal tangent frame)."""
     out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, material=material, disk_and_cube=True, boxes=False)
     _check(*out, 3)
+
+
+@pytest.mark.parametrize("nee_in_place", [0, 1])
+@pytest.mark.parametrize("integrator", ["PT", "PTDL", "PTMIS"])
+def test_kernels_apart(engine, oracle, integrator, nee_in_place):
+    """Option fuse_trace_shade = 0: wf_intersect and wf_shade's first pass as separate kernels (the default runs them as
+    wf_trace_shade); same film, same counters."""
+    out = _render_both(engine, oracle, 96, 64, 3, integrator=integrator, nee_in_place=nee_in_place, fuse=0, material="substitute")
+    _check(*out, 3)
+    out = _render_both(engine, oracle, 64, 48, 2, integrator=integrator, nee_in_place=nee_in_place, fuse=0, mesh_lights=True, light_grid=2)
+    _check(*out, 2)

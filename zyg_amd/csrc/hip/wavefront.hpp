@@ -142,9 +142,9 @@ struct KernelCounters {
 struct Control {  // device-resident
     QueueCounts        ext_count[2];
     QueueCounts        ext_pool_count[2][kPoolVertices];  // POOL
-    QueueCounts        alive_count;
+    QueueCounts        alive_count[2];   // [parity of the tick]: wf_trace_shade fills this tick's and resets the next one's
     QueueCounts        shadow_count[2];  // ping-pong per NEE round
-    QueueCounts        heavy_count;
+    QueueCounts        heavy_count[2];
     uint32_t           bound[2];  // [parity of the tick]: length of the tick's extension queue = upper bound of every later
                                   // queue of that tick; surplus blocks leave on this one scalar load
     uint32_t           error;
@@ -185,6 +185,9 @@ __constant__ DScene c_scene;  // the compiled scene's device arrays: read on dem
 #endif
 #ifndef ZYG_SHADE_LIGHT_WAVES
 #define ZYG_SHADE_LIGHT_WAVES 5
+#endif
+#ifndef ZYG_TRACE_SHADE_WAVES
+#define ZYG_TRACE_SHADE_WAVES 4
 #endif
 #ifndef ZYG_SCATTER_WAVES
 #define ZYG_SCATTER_WAVES 3
@@ -665,10 +668,10 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
         if (!POOL) queueReset(&P.ctl->ext_count[cur ^ 1u]);
         if (POOL && 0 == P.round)
             for (uint32_t k = 0; k < kPoolVertices; ++k) queueReset(&P.ctl->ext_pool_count[cur ^ 1u][k]);
-        queueReset(&P.ctl->alive_count);
+        queueReset(&P.ctl->alive_count[cur]);
         queueReset(&P.ctl->shadow_count[0]);
         queueReset(&P.ctl->shadow_count[1]);
-        queueReset(&P.ctl->heavy_count);
+        queueReset(&P.ctl->heavy_count[cur]);
     }
     Counters cnt{0, 0, 0};
     if (i < n) {
@@ -853,21 +856,162 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
     return energy;
 }
 
-// Two passes share this body.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
+// One vertex of wf_shade: connectLight, termination, Russian roulette, Vertex.sample's record (pathtracer_mis.zig:45-92,
+// 280-341, vertex.zig:137-212).  The ray, the hit and the candidate count come from the caller: wf_shade reads them from the
+// pool, wf_trace_shade still has them in registers.  `defer` (first pass only): the vertex has emission to evaluate and
+// goes to the second pass untouched.
+template <bool STATS, bool MESHL, bool HEAVY, bool POOL>
+ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
+                    Counters& cnt, SectionTimer& tm) {
+    const DScene&  s = c_scene;
+    const uint32_t kind = c_view.v.integrator;
+    const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
+    const uint32_t ps = sampleSlot<POOL>(slot);
+    PathHead       h;
+    loadHead<POOL>(P, slot, h);
+    const uint32_t hit_prop = hit.prop;
+    const bool     has_hit = kNull != hit_prop;
+    // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
+    const Ray ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, has_hit ? hit.t : ro.w);
+    const f3  wo = -ray.direction;
+
+    if (!HEAVY) {  // anything that could make connectLight draw or evaluate goes to the heavy pass
+        bool emissive = false;
+        if (has_hit) {
+            const ZygpuProp hp = s.props[hit_prop];
+            const uint32_t  part = ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[hit.primitive]) : 0u;
+            emissive = 0 != (s.materials[s.material_ids[hp.parts_start + part]].flags & ZYGPU_MATF_EMISSIVE);
+        }
+        // infinite props: PathtracerMIS looks at them when the ray left the scene, the other two always walk the list
+        const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || (!has_hit && kRayMaxT == ro.w));
+        defer = connectsLights(h.flags) && (emissive || 0 != ucount || infinite);
+    }
+    if (!defer) {
+    Fragment frag;
+    if (has_hit) makeFragment<MESHL>(s, ray, hit, frag);
+    tm.mark(0);
+
+    // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
+    f3 energy = S3(0.f);
+    if (HEAVY && connectsLights(h.flags)) {
+        VertexIn v;
+        v.vorigin = xyz4(P.pool.vorigin[slot]);
+        v.vgeo_n = xyz4(P.pool.vgeo_n[slot]);
+        v.bxdf_pdf = rd.w;
+        v.flags = h.flags;
+        v.depth_surface = h.depth_surface;
+        v.light_split_threshold = 0.f;
+        if (ZYGPU_INTEGRATOR_PT == kind) {
+            v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
+            if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
+            energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
+            if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
+        } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
+            if (has_hit) {
+                const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
+                if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
+            }
+            if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
+            if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, true, cnt);
+        } else {
+            v.light_split_threshold = splitThreshold(h.vdepth);
+            if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
+            tm.mark(1);
+            energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
+            tm.mark(2);
+            // RayMaxT == max_t (pathtracer_mis.zig:313): not for a ray that ended at its medium's bounds
+            if (MESHL && !has_hit && kRayMaxT == ray.max_t) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
+        }
+    }
+    const float4 thr4 = P.pool.thr[slot];
+    f3           throughput = xyz4(thr4);
+    const float  split_weight = POOL ? thr4.w : 1.f;
+    Mediums      md;
+    if (POOL) {
+        if (0 == P.round) P.pool.pstate[ps] &= 255u;  // a new level: no children yet
+        md.load(P, slot);
+        // VolumeIntegrator.integrate for a medium that only absorbs (volume_integrator.zig:62-65, 105-128):
+        // Beer-Lambert over the segment to the hit; Context.nextEvent runs before connectLight
+        if (has_hit && md.index > 0) throughput = throughput * attenuation3(md.topAbsorption(), hit.t - 0.f);
+    }
+    // split_throughput = vertex.throughput * split_weight (pathtracer_mis.zig:61-62)
+    ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * energy, h.depth_surface, mis ? 2u : 1u,
+              0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
+
+    bool done = false;
+    if (!has_hit || h.depth_surface >= c_view.v.max_depth_surface || 0 >= c_view.v.max_depth_volume) {
+        if (mis && (h.flags & ST_TRANSPARENT)) throughput = throughput * (S3(1.f) - min3v(energy, S3(1.f)));
+        done = true;
+    } else {
+        // russianRoulette (helper.zig:75-89); the draw happens whether or not it is needed
+        const float r = h.smp.sample1D();
+        const float continuation_probability = hmax3(throughput) / 0.1f;
+        if (continuation_probability < 1.f) {
+            if (r >= continuation_probability) done = true;
+            else throughput = throughput / S3(continuation_probability);
+        }
+    }
+
+    if (!done) {
+        // ---- Vertex.sample (vertex.zig:137-181): two-sided flip + the stochastic_r draw; the closure itself is
+        // rebuilt from the record by wf_nee / wf_extend
+        const uint32_t       mat_id = s.material_ids[s.props[frag.prop].parts_start + frag.part];
+        const ZygpuMaterial& m = s.materials[mat_id];
+        f3                   geo_n = frag.geo_n, n = frag.n;
+        const bool           flipped = (m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo);
+        if (flipped) {
+            geo_n = -geo_n;
+            n = -n;
+        }
+        const float stochastic_r = h.smp.sample1D();  // rs.stochastic_r (vertex.zig:165)
+        if (ZYGPU_MAT_LIGHT == m.kind) {
+            // a pure emitter neither evaluates nor scatters (light_sample.zig:9-11, material_sample.zig:55-59):
+            // no NEE draw, no bxdf sample, throughput = 0 (pathtracer_mis.zig:127-129)
+            throughput = S3(0.f);
+            done = true;
+        } else {
+            P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
+            P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
+            f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
+            if (MESHL && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
+            P.pool.rec_n[slot] = f4(n, color.x);
+            P.pool.rec_t[slot] = f4(frag.t, color.y);
+            P.pool.rec_b[slot] = f4(frag.b, color.z);
+            P.pool.thr[slot] = f4(throughput, split_weight);
+            if (POOL) {
+                // rs.ior = Vertex.iorOutside (vertex.zig:87-92), rs.highest_priority (vertex.zig:178)
+                const float ior_outside = frag.sameHemisphere(wo) ? md.topIor() : md.peekIor(frag.prop, frag.part);
+                P.pool.rec_ior[slot] = make_float2(ior_outside, m.priority < md.highestPriority() ? 1.f : 0.f);
+            }
+            storeHead<POOL>(P, slot, h);
+            alive = true;
+        }
+    }
+    tm.mark(3);
+    if (done) {
+        if (POOL) {
+            storeSamplers(P, ps, h);  // the sample's other vertices go on with these samplers
+            terminateVertex(P, ps, throughput, split_weight, h.flags);
+        } else {
+            finalize(P, slot, throughput, h.flags);
+        }
+    }
+    tm.mark(4);
+    }
+}
+
+// Two passes share shadeVertex.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
 // emissive and whose ray crossed no unoccluding light has no emission to evaluate (no sampler draw, no light-tree pdf,
 // no SphQuad), so that instantiation is small enough for twice the occupancy; the others go to the `heavy` queue, which
 // the HEAVY = true pass processes with the complete connectLight.
-// POOL: `slot` below is a vertex index, `ps` the camera sample it belongs to
+// POOL: `slot` below is a vertex index
 template <bool STATS, bool MESHL, bool HEAVY, bool POOL>
 __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_WAVES : ZYG_SHADE_WAVES) : ZYG_SHADE_LIGHT_WAVES) wf_shade(Params P) {
-    const DScene&  s = c_scene;
     const uint32_t cur = P.parity;
     if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count : extCount<POOL>(P, cur, P.round), P.queue_capacity, i, at);
-    const uint32_t kind = c_view.v.integrator;
-    const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
+    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count[cur] : extCount<POOL>(P, cur, P.round), P.queue_capacity, i, at);
     Counters       cnt{0, 0, 0};
     const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i < rounded) {
@@ -877,152 +1021,74 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
         uint32_t slot = 0;
         if (i < total) {
             slot = HEAVY ? P.q.heavy[at] : extQueue<POOL>(P, cur, P.round)[at];
-            const uint32_t ps = sampleSlot<POOL>(slot);
-            PathHead h;
-            loadHead<POOL>(P, slot, h);
-
-            const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
-            const uint4    hr = P.pool.hit[slot];
-            const uint32_t hit_prop = P.pool.hit_prop[slot];
-            const Hit      hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, hit_prop};
-            const bool     has_hit = kNull != hit_prop;
-            // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
-            const Ray ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, has_hit ? hit.t : ro.w);
-            const f3  wo = -ray.direction;
-
-            if (!HEAVY) {  // anything that could make connectLight draw or evaluate goes to the heavy pass
-                bool emissive = false;
-                if (has_hit) {
-                    const ZygpuProp hp = s.props[hit_prop];
-                    const uint32_t  part = ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[hit.primitive]) : 0u;
-                    emissive = 0 != (s.materials[s.material_ids[hp.parts_start + part]].flags & ZYGPU_MATF_EMISSIVE);
-                }
-                // infinite props: PathtracerMIS looks at them when the ray left the scene, the other two always walk the list
-                const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || (!has_hit && kRayMaxT == ro.w));
-                defer = connectsLights(h.flags) && (emissive || 0 != P.pool.ucount[slot] || infinite);
-            }
-            if (!defer) {
-            Fragment frag;
-            if (has_hit) makeFragment<MESHL>(s, ray, hit, frag);
-            tm.mark(0);
-
-            // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
-            f3 energy = S3(0.f);
-            if (HEAVY && connectsLights(h.flags)) {
-                VertexIn v;
-                v.vorigin = xyz4(P.pool.vorigin[slot]);
-                v.vgeo_n = xyz4(P.pool.vgeo_n[slot]);
-                v.bxdf_pdf = rd.w;
-                v.flags = h.flags;
-                v.depth_surface = h.depth_surface;
-                v.light_split_threshold = 0.f;
-                if (ZYGPU_INTEGRATOR_PT == kind) {
-                    v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
-                    if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
-                    if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
-                } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
-                    if (has_hit) {
-                        const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
-                        if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-                    }
-                    if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
-                    if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, true, cnt);
-                } else {
-                    v.light_split_threshold = splitThreshold(h.vdepth);
-                    if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-                    tm.mark(1);
-                    energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
-                    tm.mark(2);
-                    // RayMaxT == max_t (pathtracer_mis.zig:313): not for a ray that ended at its medium's bounds
-                    if (MESHL && !has_hit && kRayMaxT == ray.max_t) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
-                }
-            }
-            const float4 thr4 = P.pool.thr[slot];
-            f3           throughput = xyz4(thr4);
-            const float  split_weight = POOL ? thr4.w : 1.f;
-            Mediums      md;
-            if (POOL) {
-                if (0 == P.round) P.pool.pstate[ps] &= 255u;  // a new level: no children yet
-                md.load(P, slot);
-                // VolumeIntegrator.integrate for a medium that only absorbs (volume_integrator.zig:62-65, 105-128):
-                // Beer-Lambert over the segment to the hit; Context.nextEvent runs before connectLight
-                if (has_hit && md.index > 0) throughput = throughput * attenuation3(md.topAbsorption(), hit.t - 0.f);
-            }
-            // split_throughput = vertex.throughput * split_weight (pathtracer_mis.zig:61-62)
-            ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * energy, h.depth_surface, mis ? 2u : 1u,
-                      0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
-
-            bool done = false;
-            if (!has_hit || h.depth_surface >= c_view.v.max_depth_surface || 0 >= c_view.v.max_depth_volume) {
-                if (mis && (h.flags & ST_TRANSPARENT)) throughput = throughput * (S3(1.f) - min3v(energy, S3(1.f)));
-                done = true;
-            } else {
-                // russianRoulette (helper.zig:75-89); the draw happens whether or not it is needed
-                const float r = h.smp.sample1D();
-                const float continuation_probability = hmax3(throughput) / 0.1f;
-                if (continuation_probability < 1.f) {
-                    if (r >= continuation_probability) done = true;
-                    else throughput = throughput / S3(continuation_probability);
-                }
-            }
-
-            if (!done) {
-                // ---- Vertex.sample (vertex.zig:137-181): two-sided flip + the stochastic_r draw; the closure itself is
-                // rebuilt from the record by wf_nee / wf_extend
-                const uint32_t       mat_id = s.material_ids[s.props[frag.prop].parts_start + frag.part];
-                const ZygpuMaterial& m = s.materials[mat_id];
-                f3                   geo_n = frag.geo_n, n = frag.n;
-                const bool           flipped = (m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo);
-                if (flipped) {
-                    geo_n = -geo_n;
-                    n = -n;
-                }
-                const float stochastic_r = h.smp.sample1D();  // rs.stochastic_r (vertex.zig:165)
-                if (ZYGPU_MAT_LIGHT == m.kind) {
-                    // a pure emitter neither evaluates nor scatters (light_sample.zig:9-11, material_sample.zig:55-59):
-                    // no NEE draw, no bxdf sample, throughput = 0 (pathtracer_mis.zig:127-129)
-                    throughput = S3(0.f);
-                    done = true;
-                } else {
-                    P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
-                    P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
-                    f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
-                    if (MESHL && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
-                    P.pool.rec_n[slot] = f4(n, color.x);
-                    P.pool.rec_t[slot] = f4(frag.t, color.y);
-                    P.pool.rec_b[slot] = f4(frag.b, color.z);
-                    P.pool.thr[slot] = f4(throughput, split_weight);
-                    if (POOL) {
-                        // rs.ior = Vertex.iorOutside (vertex.zig:87-92), rs.highest_priority (vertex.zig:178)
-                        const float ior_outside = frag.sameHemisphere(wo) ? md.topIor() : md.peekIor(frag.prop, frag.part);
-                        P.pool.rec_ior[slot] = make_float2(ior_outside, m.priority < md.highestPriority() ? 1.f : 0.f);
-                    }
-                    storeHead<POOL>(P, slot, h);
-                    alive = true;
-                }
-            }
-            tm.mark(3);
-            if (done) {
-                if (POOL) {
-                    storeSamplers(P, ps, h);  // the sample's other vertices go on with these samplers
-                    terminateVertex(P, ps, throughput, split_weight, h.flags);
-                } else {
-                    finalize(P, slot, throughput, h.flags);
-                }
-            }
-            tm.mark(4);
-            }
+            const uint4 hr = P.pool.hit[slot];
+            const Hit   hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
+            shadeVertex<STATS, MESHL, HEAVY, POOL>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, P.pool.ucount[slot], alive, defer,
+                                                   cnt, tm);
         }
         if (!HEAVY) {
-            queuePush(P.q.heavy, &P.ctl->heavy_count, P.queue_capacity, defer, slot);
+            queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
             __syncthreads();  // queuePush's shared words are reused below
         }
-        queuePush(P.q.alive, &P.ctl->alive_count, P.queue_capacity, alive, slot);
+        queuePush(P.q.alive, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
         tm.mark(5);
         tm.flush(P.ctl, 0);
     }
     if (STATS) flushCounters(P, 1, cnt, 0);
+}
+
+// wf_intersect and wf_shade's first pass in one kernel (non-POOL): the ray, the hit and the candidate count stay in
+// registers, so the path's line is read once instead of twice and the 32 B hit record is only written for the few vertices
+// the second pass will look at.  The alive / heavy queue counters are per tick parity here: this kernel appends to the
+// tick's and resets the next tick's (wf_intersect, a kernel of its own, could reset the ones wf_shade was about to fill).
+template <bool STATS, bool MESHL>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P) {
+    const uint32_t cur = P.parity;
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t n = queueOpen(&P.ctl->ext_count[cur], P.queue_capacity, i, at);
+    if (0 == i) P.ctl->bound[cur] = n;
+    if (0 == blockIdx.x && threadIdx.x < 64) {
+        queueReset(&P.ctl->ext_count[cur ^ 1u]);  // this tick's wf_scatter fills it
+        queueReset(&P.ctl->alive_count[cur ^ 1u]);
+        queueReset(&P.ctl->heavy_count[cur ^ 1u]);
+        queueReset(&P.ctl->shadow_count[0]);  // staged NEE: this tick's wf_nee rounds
+        queueReset(&P.ctl->shadow_count[1]);
+    }
+    Counters       cnt{0, 0, 0}, shade_cnt{0, 0, 0};
+    const uint32_t rounded = (n + 255u) & ~255u;  // whole blocks take part in queuePush
+    if (i < rounded) {
+        SectionTimer tm;
+        tm.start();
+        bool     alive = false, defer = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = P.q.ext[cur][at];
+            const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+            const uint32_t meta = P.pool.q0[slot].y;
+            const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
+            Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+            Hit            hit;
+            sceneIntersect<STATS, MESHL>(c_scene, ray, depth, hit, cnt);
+            if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+            const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL>(P, c_scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
+            shadeVertex<STATS, MESHL, false, false>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm);
+            if (defer) {  // the second pass reads them from the pool
+                P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+                P.pool.hit_prop[slot] = hit.prop;
+                P.pool.ucount[slot] = ucount;
+            }
+        }
+        queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
+        __syncthreads();  // queuePush's shared words are reused below
+        queuePush(P.q.alive, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+        tm.flush(P.ctl, 0);
+    }
+    if (STATS) {
+        flushCounters(P, 0, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
+        flushCounters(P, 1, shade_cnt, 0);
+    }
 }
 
 // ---------------------------------------------------------------- closure from the hit record
@@ -1129,7 +1195,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->alive_count, P.queue_capacity, i, at);
+    const uint32_t total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i >= rounded) return;
@@ -1211,7 +1277,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->alive_count, P.queue_capacity, i, at);
+    const uint32_t total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;
     if (i >= rounded) return;
@@ -1280,7 +1346,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t           at;
-    const uint32_t     total = queueOpen(&P.ctl->alive_count, P.queue_capacity, i, at);
+    const uint32_t     total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
     const uint32_t     kind = c_view.v.integrator;
     const bool         mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters           cnt{0, 0, 0};

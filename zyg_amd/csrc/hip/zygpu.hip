@@ -298,6 +298,7 @@ struct ZygpuContext {
     uint4*        sobol_lut = nullptr;     // dsampler.hpp c_sobol_lut
     uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
+    bool          fuse_trace_shade = true; // option "fuse_trace_shade": wf_trace_shade instead of wf_intersect + wf_shade's first pass
     uint64_t      camera_samples = 0;
     int           num_cus = 256;
     // kernel timing
@@ -835,6 +836,8 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         dim3           grid((num_paths + 255) / 256);
         P.parity = 0;
         HIP_OK(hipMemsetAsync(&c->ctl->ext_count[0], 0, sizeof(QueueCounts), c->stream));  // wf_generate appends to it
+        HIP_OK(hipMemsetAsync(&c->ctl->alive_count[0], 0, 2 * sizeof(QueueCounts), c->stream));
+        HIP_OK(hipMemsetAsync(&c->ctl->heavy_count[0], 0, 2 * sizeof(QueueCounts), c->stream));
         if (c->pool_mode) {
             HIP_OK(hipMemsetAsync(&c->ctl->ext_pool_count[0][0], 0, sizeof(QueueCounts) * kPoolVertices, c->stream));
             hipLaunchKernelGGL(wf_generate<true>, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
@@ -876,6 +879,19 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 P.parity ^= 1u;
                 continue;
             }
+            if (c->fuse_trace_shade) {
+                // closest hit + the first shading pass in one kernel (timed as kernel 0), then the second pass
+                timedLaunch(c, 0, [&] {
+                    if (c->stats) hipLaunchKernelGGL((wf_trace_shade<true, true>), grid, block, 0, c->stream, P);
+                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_trace_shade<false, true>), grid, block, 0, c->stream, P);
+                    else hipLaunchKernelGGL((wf_trace_shade<false, false>), grid, block, 0, c->stream, P);
+                });
+                timedLaunch(c, 1, [&] {
+                    if (c->stats) hipLaunchKernelGGL((wf_shade<true, true, true, false>), grid, block, 0, c->stream, P);
+                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_shade<false, true, true, false>), grid, block, 0, c->stream, P);
+                    else hipLaunchKernelGGL((wf_shade<false, false, true, false>), grid, block, 0, c->stream, P);
+                });
+            } else {
             timedLaunch(c, 0, [&] {
                 if (c->stats) hipLaunchKernelGGL((wf_intersect<true, false, true>), grid, block, 0, c->stream, P);
                 else if (c->mesh_lights) hipLaunchKernelGGL((wf_intersect<false, false, true>), grid, block, 0, c->stream, P);
@@ -893,6 +909,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                     hipLaunchKernelGGL((wf_shade<false, false, true, false>), grid, block, 0, c->stream, P);
                 }
             });
+            }
             if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
                     if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, false>), grid, block, 0, c->stream, P);
@@ -1052,6 +1069,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "tick_sync")) {
         c->tick_sync = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "fuse_trace_shade")) {
+        c->fuse_trace_shade = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "nee_in_place")) {
