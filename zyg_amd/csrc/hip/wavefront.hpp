@@ -886,7 +886,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || (!has_hit && kRayMaxT == ro.w));
         defer = connectsLights(h.flags) && (emissive || 0 != ucount || infinite);
     }
-    if (!defer) {
+    if (defer) return;
     Fragment frag;
     if (has_hit) makeFragment<MESHL>(s, ray, hit, frag);
     tm.mark(0);
@@ -997,7 +997,6 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         }
     }
     tm.mark(4);
-    }
 }
 
 // Two passes share shadeVertex.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
@@ -1041,13 +1040,15 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
 // registers, so the path's line is read once instead of twice and the 32 B hit record is only written for the few vertices
 // the second pass will look at.  The alive / heavy queue counters are per tick parity here: this kernel appends to the
 // tick's and resets the next tick's (wf_intersect, a kernel of its own, could reset the ones wf_shade was about to fill).
-template <bool STATS, bool MESHL>
-__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P) {
+// FIRST: the batch's first tick generates its camera rays itself (wf_generate's body) instead of reading them back from the
+// pool through the extension queue: entry i is slot i, `first_paths` of them.
+template <bool STATS, bool MESHL, bool FIRST>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P, uint32_t first_paths) {
     const uint32_t cur = P.parity;
-    if (blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
+    if (!FIRST && blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t       at;
-    const uint32_t n = queueOpen(&P.ctl->ext_count[cur], P.queue_capacity, i, at);
+    uint32_t       at = i;
+    const uint32_t n = FIRST ? first_paths : queueOpen(&P.ctl->ext_count[cur], P.queue_capacity, i, at);
     if (0 == i) P.ctl->bound[cur] = n;
     if (0 == blockIdx.x && threadIdx.x < 64) {
         queueReset(&P.ctl->ext_count[cur ^ 1u]);  // this tick's wf_scatter fills it
@@ -1064,9 +1065,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
         bool     alive = false, defer = false;
         uint32_t slot = 0;
         if (i < n) {
-            slot = P.q.ext[cur][at];
+            slot = FIRST ? i : P.q.ext[cur][at];
+            if (FIRST) generatePath<false>(P, slot);
             const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
-            const uint32_t meta = P.pool.q0[slot].y;
+            const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0[slot].y;
             const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
             Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
             Hit            hit;

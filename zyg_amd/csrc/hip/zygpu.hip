@@ -838,10 +838,12 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         HIP_OK(hipMemsetAsync(&c->ctl->ext_count[0], 0, sizeof(QueueCounts), c->stream));  // wf_generate appends to it
         HIP_OK(hipMemsetAsync(&c->ctl->alive_count[0], 0, 2 * sizeof(QueueCounts), c->stream));
         HIP_OK(hipMemsetAsync(&c->ctl->heavy_count[0], 0, 2 * sizeof(QueueCounts), c->stream));
+        // the fused first tick generates the camera rays itself
+        const bool generate_in_trace = !c->pool_mode && c->fuse_trace_shade;
         if (c->pool_mode) {
             HIP_OK(hipMemsetAsync(&c->ctl->ext_pool_count[0][0], 0, sizeof(QueueCounts) * kPoolVertices, c->stream));
             hipLaunchKernelGGL(wf_generate<true>, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
-        } else {
+        } else if (!generate_in_trace) {
             hipLaunchKernelGGL(wf_generate<false>, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
         }
         c->camera_samples += num_paths;
@@ -882,9 +884,17 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             if (c->fuse_trace_shade) {
                 // closest hit + the first shading pass in one kernel (timed as kernel 0), then the second pass
                 timedLaunch(c, 0, [&] {
-                    if (c->stats) hipLaunchKernelGGL((wf_trace_shade<true, true>), grid, block, 0, c->stream, P);
-                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_trace_shade<false, true>), grid, block, 0, c->stream, P);
-                    else hipLaunchKernelGGL((wf_trace_shade<false, false>), grid, block, 0, c->stream, P);
+                    if (0 == t) {
+                        if (c->stats) hipLaunchKernelGGL((wf_trace_shade<true, true, true>), grid, block, 0, c->stream, P, num_paths);
+                        else if (c->mesh_lights) hipLaunchKernelGGL((wf_trace_shade<false, true, true>), grid, block, 0, c->stream, P, num_paths);
+                        else hipLaunchKernelGGL((wf_trace_shade<false, false, true>), grid, block, 0, c->stream, P, num_paths);
+                    } else if (c->stats) {
+                        hipLaunchKernelGGL((wf_trace_shade<true, true, false>), grid, block, 0, c->stream, P, 0u);
+                    } else if (c->mesh_lights) {
+                        hipLaunchKernelGGL((wf_trace_shade<false, true, false>), grid, block, 0, c->stream, P, 0u);
+                    } else {
+                        hipLaunchKernelGGL((wf_trace_shade<false, false, false>), grid, block, 0, c->stream, P, 0u);
+                    }
                 });
                 timedLaunch(c, 1, [&] {
                     if (c->stats) hipLaunchKernelGGL((wf_shade<true, true, true, false>), grid, block, 0, c->stream, P);
