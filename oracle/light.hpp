@@ -613,6 +613,50 @@ inline uint32_t canopySampleMaterialTo(const ZygpuImageLight& il, V4 n, const Tr
     return 1;
 }
 
+// ---------- Rectangle with an emission map: rectangle.zig:399-456, 577-595 ----------
+inline uint32_t rectangleSampleMaterialTo(const ZygpuImageLight& il, V4 p, V4 n, const Trafo& trafo, bool two_sided, bool total_sphere,
+                                          float split_threshold, uint32_t light_samples, Sampler& sampler, SampleTo* buffer) {
+    const uint32_t num_samples = numSamples(light_samples, split_threshold);
+    const float    nsf = float(num_samples);
+    const V4       scale = trafo.scale();
+    const float    area = scale[0] * scale[1];
+    uint32_t       current = 0;
+    for (uint32_t i = 0; i < num_samples; ++i) {
+        float r2[2];
+        sampler.sample2D(r2);
+        float       u, v;
+        const float pdf = imageLightSample(il, r2[0], r2[1], u, v);
+        if (0.f == pdf) continue;
+        const V4 ls = mk(-1.f * u + 0.5f, -1.f * v + 0.5f, 0.f, 0.f);
+        const V4 ws = trafo.objectToWorldPoint(ls);
+        const V4 axis = ws - p;
+        V4       wn = trafo.r[2];
+        if (two_sided && dot3(wn, axis) > 0.f) wn = -wn;
+        const float sl = squaredLength3(axis);
+        const float t = std::sqrt(sl);
+        const V4    dir = axis / S(t);
+        const float c = -dot3(wn, dir);
+        if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) continue;
+        buffer[current].p = mk(ws[0], ws[1], ws[2], (nsf * pdf * sl) / (c * area));
+        buffer[current].n = wn;
+        buffer[current].wi = dir;
+        buffer[current].uvw = mk(u, v, 0.f, 0.f);
+        current += 1;
+    }
+    return current;
+}
+inline float rectangleMaterialPdf(const ZygpuImageLight& il, V4 dir, V4 p, const Trafo& trafo, V4 frag_p, float u, float v,
+                                  float split_threshold, uint32_t light_samples) {
+    const float c = std::fabs(dot3(trafo.r[2], dir));
+    const V4    scale = trafo.scale();
+    const float area = scale[0] * scale[1];
+    const V4    dp = p - frag_p;
+    const float sl = dot3(dp, dp);
+    const uint32_t num_samples = numSamples(light_samples, split_threshold);
+    const float    material_pdf = imageLightPdf(il, u, v) * float(num_samples);
+    return (material_pdf * sl) / (c * area);
+}
+
 // ---------- Distant lights: distant.zig:21-146 ----------
 
 inline float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - std::sqrt(1.f / (radius * radius + 1.f))); }

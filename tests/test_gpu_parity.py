@@ -452,3 +452,12 @@ def test_kernels_apart(engine, oracle, integrator, nee_in_place):
     _check(*out, 3)
     out = _render_both(engine, oracle, 64, 48, 2, integrator=integrator, nee_in_place=nee_in_place, fuse=0, mesh_lights=True, light_grid=2)
     _check(*out, 2)
+
+
+@pytest.mark.parametrize("integrator,unoccluding,samples", [("PT", True, 1), ("PTDL", False, 1), ("PTMIS", True, 1), ("PTMIS", False, 3)])
+def test_textured_rectangle_lights(engine, oracle, integrator, unoccluding, samples):
+    """Rectangle lights with an emission map: area sampling through the map's Distribution2D, the texture fetch for light
+    samples, emissive hits and the unoccluding candidates (rectangle.zig:399-456, 577-595)."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, unoccluding_lights=unoccluding, light_samples=samples,
+                       light_map=scenes.checker_image(8, np.float32), material="substitute")
+    _check(*out, 3)

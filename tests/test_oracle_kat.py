@@ -474,3 +474,26 @@ def test_thin_glass_integrators_agree(product_lib, oracle):
             means[integ] = img[..., :3].mean(axis=(0, 1))
     np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.01)
     np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.02)
+
+
+def test_textured_rectangle_light_matches_uniform(product_lib, oracle):
+    """A Rectangle light with a constant emission map c (Rectangle.sampleMaterialTo: area sampling by the map's
+    distribution, rectangle.zig:399-456, 577-595) estimates the same image as the solid-angle-sampled uniform light of
+    radiance c x spectrum; PT agrees with PTMIS for a patterned map."""
+    w, h, spp = 40, 30, 256
+    means = {}
+    for key, kw in (("uniform", dict(light_spectrum=(8.5, 6.0, 2.0))),
+                    ("map", dict(light_spectrum=(17.0, 12.0, 4.0), light_map=np.full((8, 8, 3), 0.5, dtype=np.float32)))):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator="PTMIS", unoccluding_lights=False, **kw)
+            sd, vd = e.compile()
+            assert sd.num_image_lights == (2 if key == "map" else 0)
+            means[key] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["map"], means["uniform"], rtol=0.02)
+    pattern = scenes.checker_image(8, np.float32)
+    for integ in ("PT", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, 512, integrator=integ, light_map=pattern, light_samples=2 if integ == "PTMIS" else 1)
+            sd, vd = e.compile()
+            means[integ] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, 512))[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)

@@ -687,6 +687,39 @@ ZD bool canopySampleMaterialTo(const DImageLight& il, f3 n, const Trafo& trafo, 
     return true;
 }
 
+// one sample of Rectangle.sampleMaterialTo (rectangle.zig:399-456) from its 2-D draw; nsf = the light's sample count
+ZD bool rectangleSampleMaterial(const DImageLight& il, float r0, float r1, float nsf, f3 p, f3 n, const Trafo& trafo, bool two_sided,
+                                bool total_sphere, SampleTo& out) {
+    float       u, v;
+    const float pdf = imageLightSample(il, r0, r1, u, v);
+    if (0.f == pdf) return false;
+    const float area = trafo.scale.x * trafo.scale.y;
+    const f3    ws = trafo.objectToWorldPoint(mk3(-1.f * u + 0.5f, -1.f * v + 0.5f, 0.f));
+    const f3    axis = ws - p;
+    f3          wn = trafo.r2;
+    if (two_sided && dot3(wn, axis) > 0.f) wn = -wn;
+    const float sl = dot3(axis, axis);
+    const float t = sqrtf(sl);
+    const f3    dir = axis / S3(t);
+    const float c = -dot3(wn, dir);
+    if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) return false;
+    out.p = ws;
+    out.n = wn;
+    out.wi = dir;
+    out.pdf = (nsf * pdf * sl) / (c * area);
+    out.u = u;
+    out.v = v;
+    return true;
+}
+ZD float rectangleMaterialPdf(const DImageLight& il, f3 dir, f3 p, const Trafo& trafo, f3 frag_p, float u, float v, uint32_t num_samples) {
+    const float c = fabsf(dot3(trafo.r2, dir));
+    const float area = trafo.scale.x * trafo.scale.y;
+    const f3    dp = p - frag_p;
+    const float sl = dot3(dp, dp);
+    const float material_pdf = imageLightPdf(il, u, v) * float(num_samples);
+    return (material_pdf * sl) / (c * area);
+}
+
 // ---------------------------------------------------------------- TriangleMesh lights (triangle_mesh.zig:391-703)
 
 ZD f3 orthogonalize(f3 a, f3 b) { return normalize3(fma3(S3(-dot3(a, b)), a, b)); }  // a is normalised (391-394)

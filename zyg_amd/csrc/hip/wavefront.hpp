@@ -745,8 +745,11 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
     float            sample_pdf;
     if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {  // light.zig:371-374 -> shape.zig:509-526
         const DImageLight& il = s.image_lights[light.sampler];
-        sample_pdf = ZYGPU_SHAPE_DOME == s.props[light.prop].shape
-                         ? domeMaterialPdf(il, frag.uv0, frag.uv1, numSamples(light.num_samples, v.light_split_threshold))
+        const uint32_t image_shape = s.props[light.prop].shape;
+        sample_pdf = ZYGPU_SHAPE_DOME == image_shape ? domeMaterialPdf(il, frag.uv0, frag.uv1, numSamples(light.num_samples, v.light_split_threshold))
+                     : ZYGPU_SHAPE_RECTANGLE == image_shape  // rectangle.zig:577-595
+                         ? rectangleMaterialPdf(il, ray_direction, v.vorigin, frag.trafo, frag.p, frag.uv0, frag.uv1,
+                                                numSamples(light.num_samples, v.light_split_threshold))
                          : imageLightPdf(il, frag.uv0, frag.uv1) / (2.f * kPi);
     } else if (MESHL && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
         sample_pdf = meshLightPdf(s, s.mesh_lights[light.sampler], ray_direction, v.vorigin, v.vgeo_n, frag.trafo, frag.p, frag.geo_n,
@@ -1433,7 +1436,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
                     // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
                     const DImageLight& il = s.image_lights[light.sampler];
-                    if (ZYGPU_SHAPE_DOME == light_shape) {
+                    if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape) {
                         const uint32_t n = numSamples(light.num_samples, sample_threshold);
                         Sampler        replay = h.smp;
                         for (uint32_t j = 0; j < n; ++j) {
@@ -1443,8 +1446,12 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                         for (uint32_t j = 0; j < n; ++j) {
                             float r0, r1;
                             replay.sample2D(r0, r1);
-                            SampleTo ls;
-                            if (domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
+                            SampleTo   ls;
+                            const bool got = ZYGPU_SHAPE_DOME == light_shape
+                                                 ? domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)
+                                                 : rectangleSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided,
+                                                                           ms.translucent, ls);
+                            if (got) connect(ls);
                         }
                     } else {
                         SampleTo ls;

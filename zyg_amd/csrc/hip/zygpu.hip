@@ -528,10 +528,12 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         // the same kernel instantiations carry the infinite and Sphere light code
         if (is_infinite || ZYGPU_SHAPE_SPHERE == lp.shape) c->mesh_lights = true;
         if (ZYGPU_LIGHT_PROP_IMAGE == d->lights[l].light_class) {
-            if ((ZYGPU_SHAPE_DOME != lp.shape && ZYGPU_SHAPE_CANOPY != lp.shape) || d->lights[l].sampler >= d->num_image_lights) {
-                g_error = "image lights (emission maps) are supported on Dome and Canopy, with their ZygpuImageLight";
+            if ((ZYGPU_SHAPE_DOME != lp.shape && ZYGPU_SHAPE_CANOPY != lp.shape && ZYGPU_SHAPE_RECTANGLE != lp.shape) ||
+                d->lights[l].sampler >= d->num_image_lights) {
+                g_error = "image lights (emission maps) are supported on Dome, Canopy and Rectangle, with their ZygpuImageLight";
                 return -2;
             }
+            c->mesh_lights = true;  // the sampling code lives in the MESHL instantiations
         } else if (is_mesh) {
             if (d->lights[l].sampler >= d->num_mesh_lights) {
                 g_error = "a TriangleMesh light without its ZygpuMeshLight (ZygpuLight.sampler)";

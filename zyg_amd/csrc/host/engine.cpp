@@ -1137,7 +1137,7 @@ int Engine::compile(uint32_t frame) {
         l.light_class = ZYGPU_LIGHT_PROP;
         if (image_light) {
             if (m.emission_image >= images_.size()) return -4;
-            if (!is_dome && !is_canopy) return -3;  // Rectangle / Disk / Sphere.sampleMaterialTo: not restated
+            if (!is_dome && !is_canopy && ZYGPU_SHAPE_RECTANGLE != s.kind) return -3;  // Disk / Sphere.sampleMaterialTo: not restated
             l.sampler = prepareImageLight(s.kind, m);
             l.light_class = ZYGPU_LIGHT_PROP_IMAGE;
         }

@@ -213,7 +213,8 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
-            floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False):
+            floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
+            light_spectrum=(17.0, 12.0, 4.0)):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -243,7 +244,9 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     white = engine.material(mk(WHITE))
     red = engine.material(mk(RED))
     green = engine.material(mk(GREEN))
-    lamp = engine.material(light_material(num_samples=light_samples))
+    # light_map: a numpy image -> the quad lights are textured (emission map x spectrum) and importance-sampled by it
+    lamp = engine.material(light_material(spectrum=light_spectrum, num_samples=light_samples,
+                                          emission_map=None if light_map is None else engine.image(light_map)))
 
     ids = {"camera": cam, "walls": [], "lights": [], "meshes": []}
 
