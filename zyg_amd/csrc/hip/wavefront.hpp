@@ -42,9 +42,7 @@ enum : uint32_t {
 #endif
 // hit, hit_prop, ucount: 32 = a block of their own, one 32 B sector per path, written by wf_intersect and read by wf_shade
 // (inside the 256 B block, ZYG_HIT_STRIDE 0, wf_intersect's partial-line writes cost it 8 %; measured 414 vs 427 Msamples/s)
-#ifndef ZYG_HIT_STRIDE
 #define ZYG_HIT_STRIDE 32
-#endif
 #if ZYG_POOL_STRIDE
 template <typename T, int STRIDE = ZYG_POOL_STRIDE>
 struct Rec {
@@ -94,6 +92,7 @@ struct Pool {  // 16 B records, indexed by path slot
     AccRec<float4> indirect;
     HitRec<uint4>    hit;      // t, u, v (bits), primitive
     HitRec<uint32_t> hit_prop;
+    HitRec<float>    hit_sr;   // rs.stochastic_r of Vertex.sample (vertex.zig:165), drawn by wf_shade, used by the closure set-up
     HitRec<uint32_t> ucount;   // unoccluding lights the extension ray crosses in front of its hit (PropBvh.emission's candidates)
     uint4*    ucand;    //   [candidate][slot]: prop, t, u, v (bits), in traversal order
     uint32_t* ucand_prim; //                    triangle (mesh lights)
@@ -890,8 +889,19 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         defer = connectsLights(h.flags) && (emissive || 0 != ucount || infinite);
     }
     if (defer) return;
+    // the fragment: needed here for emission (second pass) and by the POOL record; otherwise wf_scatter rebuilds it from
+    // the hit (loadSurface) and this kernel only needs the hit's part
     Fragment frag;
-    if (has_hit) makeFragment<MESHL>(s, ray, hit, frag);
+    frag.prop = hit.prop;
+    frag.part = 0;
+    if (has_hit) {
+        if (HEAVY || POOL) {
+            makeFragment<MESHL>(s, ray, hit, frag);
+        } else {
+            const ZygpuProp hp = s.props[hit_prop];
+            frag.part = ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[hit.primitive]) : 0u;
+        }
+    }
     tm.mark(0);
 
     // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
@@ -956,16 +966,10 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     }
 
     if (!done) {
-        // ---- Vertex.sample (vertex.zig:137-181): two-sided flip + the stochastic_r draw; the closure itself is
-        // rebuilt from the record by wf_nee / wf_extend
+        // ---- Vertex.sample (vertex.zig:137-181): the stochastic_r draw; the closure itself is rebuilt by wf_scatter /
+        // wf_nee / wf_extend (loadSurface): from the hit, or in the POOL kernels from the record written here
         const uint32_t       mat_id = s.material_ids[s.props[frag.prop].parts_start + frag.part];
         const ZygpuMaterial& m = s.materials[mat_id];
-        f3                   geo_n = frag.geo_n, n = frag.n;
-        const bool           flipped = (m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo);
-        if (flipped) {
-            geo_n = -geo_n;
-            n = -n;
-        }
         const float stochastic_r = h.smp.sample1D();  // rs.stochastic_r (vertex.zig:165)
         if (ZYGPU_MAT_LIGHT == m.kind) {
             // a pure emitter neither evaluates nor scatters (light_sample.zig:9-11, material_sample.zig:55-59):
@@ -973,15 +977,22 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             throughput = S3(0.f);
             done = true;
         } else {
-            P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
-            P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
-            f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
-            if (MESHL && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
-            P.pool.rec_n[slot] = f4(n, color.x);
-            P.pool.rec_t[slot] = f4(frag.t, color.y);
-            P.pool.rec_b[slot] = f4(frag.b, color.z);
+            P.pool.hit_sr[slot] = stochastic_r;
             P.pool.thr[slot] = f4(throughput, split_weight);
             if (POOL) {
+                f3         geo_n = frag.geo_n, n = frag.n;
+                const bool flipped = (m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo);
+                if (flipped) {
+                    geo_n = -geo_n;
+                    n = -n;
+                }
+                P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
+                P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
+                f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
+                if (MESHL && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
+                P.pool.rec_n[slot] = f4(n, color.x);
+                P.pool.rec_t[slot] = f4(frag.t, color.y);
+                P.pool.rec_b[slot] = f4(frag.b, color.z);
                 // rs.ior = Vertex.iorOutside (vertex.zig:87-92), rs.highest_priority (vertex.zig:178)
                 const float ior_outside = frag.sameHemisphere(wo) ? md.topIor() : md.peekIor(frag.prop, frag.part);
                 P.pool.rec_ior[slot] = make_float2(ior_outside, m.priority < md.highestPriority() ? 1.f : 0.f);
@@ -1079,7 +1090,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
             if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL>(P, c_scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             shadeVertex<STATS, MESHL, false, false>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm);
-            if (defer) {  // the second pass reads them from the pool
+            if (defer || alive) {  // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool
                 P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
                 P.pool.hit_prop[slot] = hit.prop;
                 P.pool.ucount[slot] = ucount;
@@ -1104,8 +1115,35 @@ struct Surface {
     MaterialSample ms;
 };
 
-template <bool POOL = false>
+// POOL: from the record wf_shade wrote.  Otherwise from the hit: the fragment is rebuilt here (Shape.fragment), followed by
+// Vertex.sample's two-sided flip (vertex.zig:155-161) and the colour-map fetch with the stochastic_r wf_shade drew: the path
+// carries 36 B of hit instead of an 80 B record.  EXTRA: Sphere / Disk / Cube fragments.
+template <bool POOL = false, bool EXTRA = false>
 ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
+    if (!POOL) {
+        const DScene&  s = c_scene;
+        const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
+        const uint4    hr = P.pool.hit[slot];
+        const Hit      hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
+        const Ray      ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, hit.t);
+        Fragment       frag;
+        makeFragment<EXTRA>(s, ray, hit, frag);
+        const f3             wo = -ray.direction;
+        const ZygpuMaterial& m = s.materials[s.material_ids[s.props[frag.prop].parts_start + frag.part]];
+        f3                   geo_n = frag.geo_n, n = frag.n;
+        if ((m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo)) {
+            geo_n = -geo_n;
+            n = -n;
+        }
+        f3 color = mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
+        if (EXTRA && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, P.pool.hit_sr[slot]);
+        const bool caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
+        Surface    sf;
+        sf.p = frag.p;
+        sf.frag_geo_n = frag.geo_n;
+        sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color);
+        return sf;
+    }
     const float4 rp = P.pool.rec_p[slot];
     const float4 rg = P.pool.rec_gn[slot];
     const float4 rn = P.pool.rec_n[slot], rt = P.pool.rec_t[slot], rb = P.pool.rec_b[slot];
@@ -1275,7 +1313,8 @@ __global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
 
 // ---------------------------------------------------------------- wf_extend
 // the last pick's tail, the NEE sum into the IValue, then the bxdf sample and the path extension (pathtracer_mis.zig:123-166)
-template <bool SUBST>
+// EXTRA: the scene runs the MESHL instantiations (PathTracer has no light sampling, so it ends its ticks here whatever the scene)
+template <bool SUBST, bool EXTRA>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Params P) {
     const DScene&  s = c_scene;
     const uint32_t nxt = P.parity ^ 1u;
@@ -1292,7 +1331,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
         slot = P.q.alive[at];
         PathHead h;
         loadHead(P, slot, h);
-        const Surface         sf = loadSurface(P, slot, h.flags);
+        const Surface         sf = loadSurface<false, EXTRA>(P, slot, h.flags);
         const MaterialSample& ms = sf.ms;
         f3                    throughput = xyz4(P.pool.thr[slot]);
 
@@ -1368,7 +1407,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
         const uint32_t ps = sampleSlot<POOL>(slot);
         PathHead h;
         loadHead<POOL>(P, slot, h);
-        const Surface         sf = loadSurface<POOL>(P, slot, h.flags);
+        const Surface         sf = loadSurface<POOL, MESHL>(P, slot, h.flags);
         const MaterialSample& ms = sf.ms;
         const float4          thr4 = P.pool.thr[slot];
         f3                    throughput = xyz4(thr4);

@@ -362,13 +362,13 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
 #if ZYG_HIT_STRIDE
         char* hits = nullptr;
         ok = ok && m.alloc(paths * size_t(ZYG_HIT_STRIDE), &hits);
-        p.hit.base = hits, p.hit_prop.base = hits + 16, p.ucount.base = hits + 20;
+        p.hit.base = hits, p.hit_prop.base = hits + 16, p.ucount.base = hits + 20, p.hit_sr.base = hits + 24;
 #endif
     }
 #else
     ok = m.alloc(paths, &p.q0) && m.alloc(paths, &p.q1) && m.alloc(paths, &p.pcg) && m.alloc(paths, &p.ray_o) && m.alloc(paths, &p.ray_d) &&
          m.alloc(paths, &p.thr) && m.alloc(paths, &p.vorigin) && m.alloc(paths, &p.vgeo_n) && m.alloc(paths, &p.hit) &&
-         m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.ucount) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) &&
+         m.alloc(paths, &p.hit_prop) && m.alloc(paths, &p.ucount) && m.alloc(paths, &p.hit_sr) && m.alloc(paths, &p.rec_p) && m.alloc(paths, &p.rec_gn) &&
          m.alloc(paths, &p.rec_n) && m.alloc(paths, &p.rec_t) && m.alloc(paths, &p.rec_b);
 #endif
 #if !ZYG_POOL_STRIDE || defined(ZYG_ACC_SEPARATE)
@@ -947,8 +947,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 });
             }
             timedLaunch(c, 4, [&] {
-                if (c->has_substitute) hipLaunchKernelGGL(wf_extend<true>, grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL(wf_extend<false>, grid, block, 0, c->stream, P);
+                if (c->mesh_lights) hipLaunchKernelGGL((wf_extend<true, true>), grid, block, 0, c->stream, P);
+                else if (c->has_substitute) hipLaunchKernelGGL((wf_extend<true, false>), grid, block, 0, c->stream, P);
+                else hipLaunchKernelGGL((wf_extend<false, false>), grid, block, 0, c->stream, P);
             });
             }
             P.parity ^= 1u;
