@@ -151,15 +151,21 @@ typedef struct ZygpuMaterial {
     uint32_t emission_image;   /* index into ZygpuSceneDesc.images, ZYGPU_NULL = uniform */
     uint32_t emission_sampler; /* ZYGPU_TEX_* bits */
     float    emission_scale[2];
+    /* material_base.zig:29 `mask`: a one-channel image of opacities, evaluated stochastically by the closest-hit traversal
+     * (stochasticOpacity, material_base.zig:44-55) and as a transmittance by shadow rays (material.zig:238-245) */
+    uint32_t mask_image;   /* index into ZygpuSceneDesc.images, ZYGPU_NULL = opaque */
+    uint32_t mask_sampler; /* ZYGPU_TEX_* bits */
+    float    mask_scale[2];
 } ZygpuMaterial;
 
 enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u };
 
 /* 2-D images behind textures (capi.zig:236-298, texture_provider.zig:67-84): Byte3 is read as sRGB and converted to AP1 per
- * fetch (texture.zig:196-199), Float3 is taken as is (213-216) */
-enum ZygpuImageFormat { ZYGPU_IMAGE_BYTE3_SRGB = 0, ZYGPU_IMAGE_FLOAT3 = 1 };
+ * fetch (texture.zig:196-199), Float3 is taken as is (213-216); the one-channel formats serve masks: Byte1 is unorm
+ * (byte / 255, texture.zig:170, encoding.zig:23), Float1 as is (172) */
+enum ZygpuImageFormat { ZYGPU_IMAGE_BYTE3_SRGB = 0, ZYGPU_IMAGE_FLOAT3 = 1, ZYGPU_IMAGE_BYTE1_UNORM = 2, ZYGPU_IMAGE_FLOAT1 = 3 };
 typedef struct ZygpuImage {
-    const void* pixels; /* row-major, 3 bytes or 3 floats per pixel */
+    const void* pixels; /* row-major, 1 or 3 bytes or floats per pixel */
     int32_t     width, height;
     uint32_t    format;
 } ZygpuImage;

@@ -16,6 +16,7 @@
 
 #include "../include/zygpu.h"
 #include "omath.hpp"
+#include "sampler.hpp"
 
 namespace orc {
 
@@ -205,6 +206,66 @@ inline bool triangleIntersect(const Ray& ray, V4 a, V4 b, V4 c, float& ht, float
     return false;
 }
 
+// ---- 2-D image textures: texture_sampler.zig:84-168 (Nearest2D / LinearStochastic2D), sampler_mode.zig:20-88, texture.zig:166-219
+inline float texAddress(bool repeat, float x) { return repeat ? x - std::floor(x) : clampf(x, 0.f, 1.f); }
+inline int   texCoord(bool repeat, int c, int end) {
+    if (repeat) {
+        const int m = c % end;  // @mod: the result has the sign of the divisor
+        return m < 0 ? m + end : m;
+    }
+    return std::max(std::min(c, end - 1), 0);
+}
+// the texel a lookup reads: the nearest one, or the one of the four of the bilinear footprint that r picks
+inline void texelPick(const ZygpuImage& img, uint32_t sampler, const float scale[2], float u, float v, float r, int& x, int& y) {
+    const bool  ru = 0 != (sampler & ZYGPU_TEX_REPEAT_U), rv = 0 != (sampler & ZYGPU_TEX_REPEAT_V);
+    const float su = scale[0] * u, sv = scale[1] * v;
+    const float dw = float(img.width), dh = float(img.height);
+    if (!(sampler & ZYGPU_TEX_LINEAR)) {
+        x = std::min(int(texAddress(ru, su) * dw), img.width - 1);
+        y = std::min(int(texAddress(rv, sv) * dh), img.height - 1);
+        return;
+    }
+    const float mx_ = texAddress(ru, su) * dw - 0.5f, my_ = texAddress(rv, sv) * dh - 0.5f;
+    const float fx = std::floor(mx_), fy = std::floor(my_);
+    const float wx = mx_ - fx, wy = my_ - fy;
+    const float ox = 1.f - wx, oy = 1.f - wy;
+    int         index = 0;
+    float       threshold = ox * oy;
+    index += r > threshold ? 1 : 0;
+    threshold = std::fmaf(wx, oy, threshold);
+    index += r > threshold ? 1 : 0;
+    threshold = std::fmaf(ox, wy, threshold);
+    index += r > threshold ? 1 : 0;
+    x = texCoord(ru, int(fx) + (index & 1), img.width);
+    y = texCoord(rv, int(fy) + ((index & 2) >> 1), img.height);
+}
+inline float imageFetch1(const ZygpuImage& img, int x, int y) {  // texture.zig:166-175; unorm8ToFloat (base/encoding.zig:10-12)
+    const size_t i = size_t(y) * size_t(img.width) + size_t(x);
+    if (ZYGPU_IMAGE_BYTE1_UNORM == img.format) return float(static_cast<const uint8_t*>(img.pixels)[i]) * (1.f / 255.f);
+    return static_cast<const float*>(img.pixels)[i];
+}
+// ts.sampleImage2D_1 (texture_sampler.zig:15-20)
+inline float sampleImageMap1(const ZygpuSceneDesc& scene, uint32_t image, uint32_t sampler, const float scale[2], float u, float v, float r) {
+    const ZygpuImage& img = scene.images[image];
+    int               x, y;
+    texelPick(img, sampler, scale, u, v, r, x, y);
+    return imageFetch1(img, x, y);
+}
+// the traversal's mask draws come from the path's sampler; the trace-only test entry points have none
+inline float maskDraw(Sampler* sampler) { return sampler ? sampler->sample1D() : 0.f; }
+// Base.stochasticOpacity (material_base.zig:44-55): does the closest-hit traversal accept this hit?
+inline bool stochasticOpacity(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, float u, float v, Sampler* sampler) {
+    if (kNull == m.mask_image) return true;
+    const float o = sampleImageMap1(scene, m.mask_image, m.mask_sampler, m.mask_scale, u, v, maskDraw(sampler));
+    if (0.f == o || (o < 1.f && o <= maskDraw(sampler))) return false;
+    return true;
+}
+// Base.opacity (material_base.zig:35-41)
+inline float maskOpacity(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, float u, float v, Sampler* sampler) {
+    if (kNull == m.mask_image) return 1.f;
+    return sampleImageMap1(scene, m.mask_image, m.mask_sampler, m.mask_scale, u, v, maskDraw(sampler));
+}
+
 struct MeshView {
     const ZygpuMesh* m;
     // triangle_data.zig:62-64: an unaligned 16-byte read; lane w is the next float in the array
@@ -214,8 +275,10 @@ struct MeshView {
     }
 };
 
-// triangle_tree.zig:46-109 (closest hit; ray already in object space)
-inline bool meshIntersect(const ZygpuMesh& mesh, Ray local_ray, Intersection& isec, Counters& cnt) {
+// triangle_tree.zig:46-109 (closest hit; ray already in object space); accept(triangle, u, v) = intersectOpacity's
+// stochastic mask test (triangle_tree.zig:111-195)
+template <typename Accept>
+inline bool meshIntersect(const ZygpuMesh& mesh, Ray local_ray, Intersection& isec, Counters& cnt, Accept&& accept) {
     const MeshView mv{&mesh};
     NodeStack      stack;
     uint32_t       n = 0;
@@ -229,7 +292,7 @@ inline bool meshIntersect(const ZygpuMesh& mesh, Ray local_ray, Intersection& is
                 cnt.triangles_tested += 1;
                 const uint32_t* tri = mesh.triangles + size_t(i) * 3;
                 float           t, u, v;
-                if (triangleIntersect(local_ray, mv.position(tri[0]), mv.position(tri[1]), mv.position(tri[2]), t, u, v)) {
+                if (triangleIntersect(local_ray, mv.position(tri[0]), mv.position(tri[1]), mv.position(tri[2]), t, u, v) && accept(i, u, v)) {
                     local_ray.max_t = t;
                     ht = t;
                     hu = u;
@@ -261,6 +324,16 @@ inline bool meshIntersect(const ZygpuMesh& mesh, Ray local_ray, Intersection& is
     isec.v = hv;
     isec.primitive = primitive;
     return true;
+}
+
+inline bool meshIntersect(const ZygpuMesh& mesh, Ray local_ray, Intersection& isec, Counters& cnt) {
+    return meshIntersect(mesh, local_ray, isec, cnt, [](uint32_t, float, float) { return true; });
+}
+inline void meshInterpolateUv(const ZygpuMesh& mesh, uint32_t prim, float u, float v, float& uv0, float& uv1) {  // triangle_data.zig:137-149
+    const uint32_t* tri = mesh.triangles + size_t(prim) * 3;
+    const float     w = 1.f - u - v;
+    uv0 = std::fmaf(mesh.uvs[2 * tri[0]], w, std::fmaf(mesh.uvs[2 * tri[1]], u, mesh.uvs[2 * tri[2]] * v));
+    uv1 = std::fmaf(mesh.uvs[2 * tri[0] + 1], w, std::fmaf(mesh.uvs[2 * tri[1] + 1], u, mesh.uvs[2 * tri[2] + 1] * v));
 }
 
 // triangle_tree.zig:197-242 (any hit)
@@ -299,36 +372,55 @@ inline bool meshIntersectP(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt)
     return false;
 }
 
-// Glass.visibility for thin glass without a mask (glass_material.zig:82-115): Fresnel transmission x absorption over the
-// slab; false = blocked (total internal reflection)
-inline bool thinGlassVisibility(const ZygpuMaterial& m, V4 wi, V4 geo_n, V4& tr) {
-    const float eta_i = 1.f, eta_t = m.ior;
-    const float n_dot_wo = mn(std::fabs(dot3(geo_n, wi)), 1.f);
-    const float eta = eta_i / eta_t;
-    const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
-    if (sint2 >= 1.f) return false;
-    const float n_dot_t = std::sqrt(1.f - sint2);
-    const float t0 = eta_t * n_dot_wo, t1 = eta_i * n_dot_t;  // fresnel.dielectric (fresnel.zig:31-43)
-    const float r_p = (t0 - t1) / (t0 + t1);
-    const float t2 = eta_i * n_dot_wo, t3 = eta_t * n_dot_t;
-    const float r_o = (t2 - t3) / (t2 + t3);
-    const float f = 0.5f * (r_p * r_p + r_o * r_o);
-    const float n_dot_wi = clampf(n_dot_wo, 0.00001f, 1.f);
-    const float approx_dist = m.thickness / n_dot_wi;
-    const V4    attenuation = attenuation3(ld3(m.absorption), approx_dist);
-    const V4    ta = min4(S(1.f - 1.f) + attenuation, S(1.f));
-    tr *= S(1.f - f) * ta;
-    return true;
+// Glass.visibility (glass_material.zig:69-115): thin glass = Fresnel transmission x absorption over the slab, let through
+// further by the mask's openings; o = the mask's opacity at the hit; false = blocked
+inline bool glassVisibility(const ZygpuMaterial& m, V4 wi, V4 geo_n, float o, V4& tr) {
+    if (m.thickness > 0.f) {
+        const float eta_i = 1.f, eta_t = m.ior;
+        const float n_dot_wo = mn(std::fabs(dot3(geo_n, wi)), 1.f);
+        const float eta = eta_i / eta_t;
+        const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
+        if (sint2 >= 1.f) {
+            if (o < 1.f) {
+                tr *= S(1.f - o);
+                return true;
+            }
+            return false;
+        }
+        const float n_dot_t = std::sqrt(1.f - sint2);
+        const float t0 = eta_t * n_dot_wo, t1 = eta_i * n_dot_t;  // fresnel.dielectric (fresnel.zig:31-43)
+        const float r_p = (t0 - t1) / (t0 + t1);
+        const float t2 = eta_i * n_dot_wo, t3 = eta_t * n_dot_t;
+        const float r_o = (t2 - t3) / (t2 + t3);
+        const float f = 0.5f * (r_p * r_p + r_o * r_o);
+        const float n_dot_wi = clampf(n_dot_wo, 0.00001f, 1.f);
+        const float approx_dist = m.thickness / n_dot_wi;
+        const V4    attenuation = attenuation3(ld3(m.absorption), approx_dist);
+        const V4    ta = min4(S(1.f - o) + attenuation, S(1.f));
+        tr *= S(1.f - f) * ta;
+        return true;
+    }
+    if (o < 1.f) {
+        tr *= S(1.f - o);
+        return true;
+    }
+    return false;
 }
-// Material.visibility (material.zig:227-248): Glass evaluates, everything else (opacity 1) blocks
-inline bool materialVisibility(const ZygpuMaterial& m, V4 wi, V4 geo_n, V4& tr) {
-    if (ZYGPU_MAT_GLASS == m.kind && m.thickness > 0.f) return thinGlassVisibility(m, wi, geo_n, tr);
+// Material.visibility (material.zig:227-248): the mask's opacity, drawn with the path's sampler, scales the transmittance
+inline bool materialVisibility(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, V4 wi, V4 geo_n, float u, float v, Sampler* sampler, V4& tr) {
+    const float o = maskOpacity(scene, m, u, v, sampler);
+    if (ZYGPU_MAT_GLASS == m.kind) return glassVisibility(m, wi, geo_n, o, tr);
+    if (o < 1.f) {
+        tr *= S(1.f - o);
+        return true;
+    }
     return false;
 }
 
 // TriangleTree.visibility (triangle_tree.zig:244-306): every triangle the ray crosses multiplies the transmittance
 template <typename Material>
-inline bool meshVisibility(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt, V4& tr, Material&& materialOfPart) {
+inline bool meshVisibility(const ZygpuSceneDesc& scene, const ZygpuMesh& mesh, const Ray& ray, Counters& cnt, V4& tr, Sampler* sampler,
+                           Material&& materialOfPart) {
     const MeshView mv{&mesh};
     NodeStack      stack;
     uint32_t       n = 0;
@@ -345,7 +437,9 @@ inline bool meshVisibility(const ZygpuMesh& mesh, const Ray& ray, Counters& cnt,
                 const ZygpuMaterial& m = materialOfPart(mesh.triangle_parts[i]);
                 if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return false;
                 const V4 geo_n = normalize3(cross3(b - a, c - a));  // data.normal (triangle_data.zig:129-135), object space
-                if (!materialVisibility(m, ray.direction, geo_n, tr)) return false;
+                float    uv0 = 0.f, uv1 = 0.f;
+                if (kNull != m.mask_image) meshInterpolateUv(mesh, i, u, v, uv0, uv1);
+                if (!materialVisibility(scene, m, ray.direction, geo_n, uv0, uv1, sampler, tr)) return false;
             }
             n = stack.pop();
             continue;
@@ -452,6 +546,40 @@ inline bool sphereIntersect(const Ray& ray, const Trafo& trafo, float& out_t) {
 }
 
 // sphere.zig:62-90
+// the uv of a point on the sphere with world normal n (sphere.zig:110-115)
+inline void sphereUv(const Trafo& trafo, V4 n, float& u, float& v) {
+    const V4    xyz = normalize3(trafo.worldToObjectNormal(n));
+    const float phi = -atan2F(xyz[0], xyz[2]) + kPi;
+    const float theta = acosF(xyz[1]);
+    u = phi * (0.5f * kPiInv);
+    v = theta * kPiInv;
+}
+// sphere.zig:94-146: the nearer root the mask lets through
+inline bool sphereIntersectOpacity(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, const Ray& ray, const Trafo& trafo, float& out_t,
+                                   Sampler* sampler) {
+    const float idl = 1.f / length3(ray.direction);
+    const V4    nd = ray.direction * S(idl);
+    const V4    v = trafo.position - ray.origin;
+    const float b = dot3(nd, v);
+    const V4    remedy_term = v - S(b) * nd;
+    const float radius = 0.5f * trafo.scaleX();
+    const float discriminant = radius * radius - dot3(remedy_term, remedy_term);
+    if (discriminant > 0.f) {
+        const float dist = std::sqrt(discriminant);
+        for (const float t : {(b - dist) * idl, (b + dist) * idl}) {
+            if (t >= ray.min_t && ray.max_t >= t) {
+                float uu, vv;
+                sphereUv(trafo, normalize3(ray.point(t) - trafo.position), uu, vv);
+                if (stochasticOpacity(scene, m, uu, vv, sampler)) {
+                    out_t = t;
+                    return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+
 inline void sphereFragment(const Ray& ray, Fragment& frag) {
     const Trafo& tr = frag.isec.trafo;
     const V4     p = ray.point(frag.isec.t);
@@ -634,15 +762,19 @@ struct SceneView {
     }
 
     // prop.zig:163-197
-    bool propIntersect(uint32_t p, const Ray& ray, uint32_t depth_surface, Intersection& isec, Counters& cnt) const {
+    // `sampler`: props with evaluate_visibility take shape.intersectOpacity (prop.zig:191-195), whose stochastic mask tests
+    // draw from the path's sampler (rectangle.zig:64-100, sphere.zig:94-146, disk.zig:60-96, triangle_tree.zig:111-195)
+    bool propIntersect(uint32_t p, const Ray& ray, uint32_t depth_surface, Intersection& isec, Counters& cnt, Sampler* sampler = nullptr) const {
         const ZygpuProp& prop = d->props[p];
         if (!visible(prop.flags, depth_surface)) return false;
         cnt.instances_tested += 1;
         if (!aabbIntersect(d->aabbs[p], ray)) return false;
         const Trafo trafo = propTrafo(p);
+        const bool  masked = 0 != (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
         if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
             float t, u, v;
             if (!rectangleIntersect(ray, trafo, t, u, v)) return false;
+            if (masked && !stochasticOpacity(*d, propMaterial(p, 0), 0.5f * (u + 1.f), 0.5f * (v + 1.f), sampler)) return false;
             isec.t = t;
             isec.u = u;
             isec.v = v;
@@ -651,13 +783,26 @@ struct SceneView {
             return true;
         }
         if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
-            if (!meshIntersect(d->meshes[prop.mesh], trafo.worldToObjectRay(ray), isec, cnt)) return false;
+            const ZygpuMesh& mesh = d->meshes[prop.mesh];
+            const bool       found = masked ? meshIntersect(mesh, trafo.worldToObjectRay(ray), isec, cnt,
+                                                            [&](uint32_t k, float u, float v) {
+                                                                const ZygpuMaterial& m = propMaterial(p, mesh.triangle_parts[k]);
+                                                                if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return true;
+                                                                float uv0, uv1;
+                                                                meshInterpolateUv(mesh, k, u, v, uv0, uv1);
+                                                                return stochasticOpacity(*d, m, uv0, uv1, sampler);
+                                                            })
+                                            : meshIntersect(mesh, trafo.worldToObjectRay(ray), isec, cnt);
+            if (!found) return false;
             isec.trafo = trafo;
             return true;
         }
         if (ZYGPU_SHAPE_SPHERE == prop.shape || ZYGPU_SHAPE_CUBE == prop.shape) {
             float t;
-            if (!(ZYGPU_SHAPE_SPHERE == prop.shape ? sphereIntersect(ray, trafo, t) : cubeIntersect(ray, trafo, t))) return false;
+            if (!(ZYGPU_SHAPE_SPHERE == prop.shape
+                      ? (masked ? sphereIntersectOpacity(*d, propMaterial(p, 0), ray, trafo, t, sampler) : sphereIntersect(ray, trafo, t))
+                      : cubeIntersect(ray, trafo, t)))
+                return false;
             isec.t = t;
             isec.u = isec.v = 0.f;
             isec.primitive = 0;
@@ -667,6 +812,7 @@ struct SceneView {
         if (ZYGPU_SHAPE_DISK == prop.shape) {
             float t, u, v;
             if (!diskIntersect(ray, trafo, t, u, v)) return false;
+            if (masked && !stochasticOpacity(*d, propMaterial(p, 0), 0.5f * (u + 1.f), 0.5f * (v + 1.f), sampler)) return false;
             isec.t = t;
             isec.u = u;
             isec.v = v;
@@ -677,9 +823,10 @@ struct SceneView {
         return false;
     }
 
-    // prop.zig:199-237 (non-volumetric, no opacity masks): true = unoccluded
-    // `tr`: the transmittance of the thin-glass surfaces the ray crosses (shape.visibility for props with evaluate_visibility)
-    bool propVisibility(uint32_t p, const Ray& ray, Counters& cnt, V4& tr) const {
+    // prop.zig:199-237 (non-volumetric): true = unoccluded
+    // `tr`: the transmittance of the thin-glass and masked surfaces the ray crosses (shape.visibility for props with
+    // evaluate_visibility); the masks' stochastic texel picks draw from `sampler`
+    bool propVisibility(uint32_t p, const Ray& ray, Counters& cnt, V4& tr, Sampler* sampler = nullptr) const {
         const ZygpuProp& prop = d->props[p];
         if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) return true;
         cnt.instances_tested += 1;
@@ -689,7 +836,12 @@ struct SceneView {
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {  // rectangle.zig:154-186
                 float t, u, v;
                 if (!rectangleIntersect(ray, trafo, t, u, v)) return true;
-                return materialVisibility(propMaterial(p, 0), ray.direction, trafo.r[2], tr);
+                return materialVisibility(*d, propMaterial(p, 0), ray.direction, trafo.r[2], 0.5f * (u + 1.f), 0.5f * (v + 1.f), sampler, tr);
+            }
+            if (ZYGPU_SHAPE_DISK == prop.shape) {  // disk.zig:136-170
+                float t, u, v;
+                if (!diskIntersect(ray, trafo, t, u, v)) return true;
+                return materialVisibility(*d, propMaterial(p, 0), ray.direction, trafo.r[2], 0.5f * (1.f + u), 0.5f * (1.f + v), sampler, tr);
             }
             if (ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:176-228: both roots
                 const float idl = 1.f / length3(ray.direction);
@@ -704,14 +856,16 @@ struct SceneView {
                     for (const float t : {(b - dist) * idl, (b + dist) * idl}) {
                         if (t >= ray.min_t && ray.max_t >= t) {
                             const V4 n = normalize3(ray.point(t) - trafo.position);
-                            if (!materialVisibility(propMaterial(p, 0), ray.direction, n, tr)) return false;
+                            float    uu = 0.f, vv = 0.f;
+                            if (kNull != propMaterial(p, 0).mask_image) sphereUv(trafo, n, uu, vv);
+                            if (!materialVisibility(*d, propMaterial(p, 0), ray.direction, n, uu, vv, sampler, tr)) return false;
                         }
                     }
                 }
                 return true;
             }
             if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
-                return meshVisibility(d->meshes[prop.mesh], trafo.worldToObjectRay(ray), cnt, tr,
+                return meshVisibility(*d, d->meshes[prop.mesh], trafo.worldToObjectRay(ray), cnt, tr, sampler,
                                       [&](uint32_t part) -> const ZygpuMaterial& { return propMaterial(p, part); });
             }
             return true;
@@ -745,7 +899,7 @@ struct SceneView {
     }
 
     // prop_tree.zig:56-116 over the solid TLAS; shrinks ray.max_t
-    bool intersect(Ray& ray, uint32_t depth_surface, Fragment& frag, Counters& cnt) const {
+    bool intersect(Ray& ray, uint32_t depth_surface, Fragment& frag, Counters& cnt, Sampler* sampler = nullptr) const {
         const ZygpuPropTree& tree = d->solid;
         NodeStack            stack;
         uint32_t             n = 0 == tree.num_nodes ? kNull : 0;
@@ -758,7 +912,7 @@ struct SceneView {
                 for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
                     const uint32_t p = tree.indices[i];
                     Intersection   candidate = isec;
-                    if (propIntersect(p, ray, depth_surface, candidate, cnt)) {
+                    if (propIntersect(p, ray, depth_surface, candidate, cnt, sampler)) {
                         isec = candidate;
                         ray.max_t = isec.t;
                         prop = p;
@@ -796,7 +950,7 @@ struct SceneView {
         V4 tr = S(1.f);
         return visibility(ray, cnt, tr);
     }
-    bool visibility(const Ray& ray, Counters& cnt, V4& tr) const {
+    bool visibility(const Ray& ray, Counters& cnt, V4& tr, Sampler* sampler = nullptr) const {
         const ZygpuPropTree& tree = d->solid;
         NodeStack            stack;
         uint32_t             n = 0 == tree.num_nodes ? kNull : 0;
@@ -805,7 +959,7 @@ struct SceneView {
             const ZygpuBvhNode& node = tree.nodes[n];
             if (0 != node.count) {
                 for (uint32_t i = node.children_or_first, e = i + node.count; i < e; ++i) {
-                    if (!propVisibility(tree.indices[i], ray, cnt, tr)) return false;
+                    if (!propVisibility(tree.indices[i], ray, cnt, tr, sampler)) return false;
                 }
                 n = stack.pop();
                 continue;

@@ -10,15 +10,7 @@
 
 namespace orc {
 
-// ---- 2-D image textures: texture_sampler.zig:84-168 (Nearest2D / LinearStochastic2D), sampler_mode.zig:20-88, texture.zig:188-219
-inline float texAddress(bool repeat, float x) { return repeat ? x - std::floor(x) : clampf(x, 0.f, 1.f); }
-inline int   texCoord(bool repeat, int c, int end) {
-    if (repeat) {
-        const int m = c % end;  // @mod: the result has the sign of the divisor
-        return m < 0 ? m + end : m;
-    }
-    return std::max(std::min(c, end - 1), 0);
-}
+// ---- 3-channel fetches (texAddress / texCoord / texelPick: scene.hpp)
 inline V4 imageFetch3(const ZygpuSceneDesc& scene, const ZygpuImage& img, int x, int y) {
     const size_t i = size_t(y) * size_t(img.width) + size_t(x);
     if (ZYGPU_IMAGE_BYTE3_SRGB == img.format) {
@@ -33,27 +25,9 @@ inline V4 imageFetch3(const ZygpuSceneDesc& scene, const ZygpuImage& img, int x,
 // ts.sample2D_3 for an image texture (rs.uv(), rs.stochastic_r)
 inline V4 sampleImageMap(const ZygpuSceneDesc& scene, uint32_t image, uint32_t sampler, const float scale[2], float u, float v, float r) {
     const ZygpuImage& img = scene.images[image];
-    const bool        ru = 0 != (sampler & ZYGPU_TEX_REPEAT_U), rv = 0 != (sampler & ZYGPU_TEX_REPEAT_V);
-    const float       su = scale[0] * u, sv = scale[1] * v;
-    const float       dw = float(img.width), dh = float(img.height);
-    if (!(sampler & ZYGPU_TEX_LINEAR)) {
-        const int x = std::min(int(texAddress(ru, su) * dw), img.width - 1), y = std::min(int(texAddress(rv, sv) * dh), img.height - 1);
-        return imageFetch3(scene, img, x, y);
-    }
-    const float mx_ = texAddress(ru, su) * dw - 0.5f, my_ = texAddress(rv, sv) * dh - 0.5f;
-    const float fx = std::floor(mx_), fy = std::floor(my_);
-    const float wx = mx_ - fx, wy = my_ - fy;
-    const float ox = 1.f - wx, oy = 1.f - wy;
-    int         x = int(fx), y = int(fy), index = 0;
-    float       threshold = ox * oy;
-    index += r > threshold ? 1 : 0;
-    threshold = std::fmaf(wx, oy, threshold);
-    index += r > threshold ? 1 : 0;
-    threshold = std::fmaf(ox, wy, threshold);
-    index += r > threshold ? 1 : 0;
-    x += index & 1;
-    y += (index & 2) >> 1;
-    return imageFetch3(scene, img, texCoord(ru, x, img.width), texCoord(rv, y, img.height));
+    int               x, y;
+    texelPick(img, sampler, scale, u, v, r, x, y);
+    return imageFetch3(scene, img, x, y);
 }
 inline V4 sampleColorMap(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, float u, float v, float r) {
     return sampleImageMap(scene, m.color_image, m.color_sampler, m.color_scale, u, v, r);

@@ -461,3 +461,31 @@ def test_textured_rectangle_lights(engine, oracle, integrator, unoccluding, samp
     out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, unoccluding_lights=unoccluding, light_samples=samples,
                        light_map=scenes.checker_image(8, np.float32), material="substitute")
     _check(*out, 3)
+
+
+@pytest.mark.parametrize("integrator,dtype,sampler,extras", [
+    ("PTMIS", np.uint8, None, {}),
+    ("PTDL", np.float32, {"filter": "Nearest", "address": "Clamp"}, {}),
+    ("PT", np.uint8, {"filter": "Linear", "address": ["Repeat", "Clamp"]}, {"scale": [2.0, 3.0]}),
+    ("PTMIS", np.float32, None, {"lights": True, "pane": True}),
+])
+def test_opacity_masks(engine, oracle, integrator, dtype, sampler, extras):
+    """Opacity masks (material_base.zig:29-55): the closest-hit traversal accepts a masked hit stochastically
+    (shape.intersectOpacity: rectangle.zig:64-100, sphere.zig:94-146, disk.zig:60-96, triangle_tree.zig:111-195), shadow rays
+    are attenuated by 1 - opacity (material.zig:238-245, glass_material.zig:69-115); the draws come from the path's sampler,
+    in traversal order."""
+    masked = {"image": scenes.mask_image(16, dtype), "sampler": sampler}
+    masked.update(extras)
+    out = _render_both(engine, oracle, 96, 72, 4, integrator=integrator, material="substitute", masked=masked)
+    _check(*out, 4)
+    gpu_film = out[0]
+    # the masks are seen: the same scene without them renders differently
+    plain = _render_both(engine, oracle, 96, 72, 4, integrator=integrator, material="substitute")[0] if integrator == "PT" else None
+    assert plain is None or not np.array_equal(plain, gpu_film)
+
+
+def test_opacity_masks_kernels_apart(engine, oracle):
+    """wf_intersect (fuse_trace_shade = 0) draws the mask samples the same way."""
+    masked = {"image": scenes.mask_image(16, np.uint8)}
+    out = _render_both(engine, oracle, 80, 60, 3, integrator="PTMIS", material="substitute", masked=masked, fuse=0)
+    _check(*out, 3)

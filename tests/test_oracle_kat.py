@@ -497,3 +497,49 @@ def test_textured_rectangle_light_matches_uniform(product_lib, oracle):
             sd, vd = e.compile()
             means[integ] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, 512))[..., :3].mean(axis=(0, 1))
     np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)
+
+
+def test_opacity_mask_limits_and_integrators_agree(product_lib, oracle):
+    """Opacity masks (material_base.zig:29-55, material.zig:238-245): a mask of zeros removes the masked objects (the image
+    of the scene without them, up to noise), a half-opaque mask lies between that and the solid objects; light sampling
+    through masks (PTDL / PTMIS: transmittance 1 - o) estimates what plain path tracing does (stochastic hits)."""
+    w, h, spp = 40, 30, 384
+    means = {}
+
+    def render(key, integ="PTMIS", **kw):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator=integ, material="substitute", max_depth=8, **kw)
+            sd, vd = e.compile()
+            if "masked" in kw:
+                flags = [sd.props[i].flags for i in range(sd.num_props)]
+                assert sum(1 for f in flags if f & 16) == 4  # ZYGPU_PROP_EVALUATE_VISIBILITY: Rectangle, Sphere, Disk, tall box
+                masks = {sd.materials[i].mask_image for i in range(sd.num_materials)} - {zyg_amd.NULL}
+                assert len(masks) == 1 and sd.images[masks.pop()].format in (2, 3)  # one-channel formats
+            means[key] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
+
+    render("zeros", masked={"image": np.zeros((4, 4), dtype=np.uint8)})
+    render("half", masked={"image": np.full((4, 4), 0.5, dtype=np.float32)})
+    render("ones", masked={"image": np.full((4, 4), 255, dtype=np.uint8)})
+    with zyg_amd.Engine(product_lib) as e:  # the scene without the masked objects and without the tall box
+        scenes.cornell(e, w, h, spp, integrator="PTMIS", material="substitute", max_depth=8, boxes=False)
+        idx, pos, nrm, uv = scenes.box_mesh((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0)
+        p = e.prop(e.triangle_mesh(idx, pos, nrm, uv), [e.material(scenes.substitute(scenes.WHITE))])
+        e.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0)))
+        sd, vd = e.compile()
+        means["without"] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["zeros"], means["without"], rtol=0.02)
+    assert np.all(means["ones"] < means["half"]) and np.all(means["half"] < means["zeros"])  # the objects shade the box
+    pattern = {"image": scenes.mask_image(16, np.uint8)}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        render(integ, integ=integ, masked=pattern)
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.02)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)
+
+
+def test_mask_needs_a_one_channel_image(product_lib):
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 8, 8, 1, material="substitute")
+        rgb = e.image(scenes.checker_image(4, np.float32))
+        p = e.prop(scenes.RECTANGLE, [e.material(scenes.with_mask(scenes.substitute(scenes.RED), rgb))])
+        e.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, 0)))
+        assert e.lib.su_ext_compile(0) != 0

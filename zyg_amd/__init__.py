@@ -53,7 +53,8 @@ class Material(ctypes.Structure):
                 ("color_image", ctypes.c_uint32), ("color_sampler", ctypes.c_uint32), ("color_scale", ctypes.c_float * 2),
                 ("absorption", ctypes.c_float * 3), ("thickness", ctypes.c_float), ("abbe", ctypes.c_float),
                 ("priority", ctypes.c_int32), ("emission_image", ctypes.c_uint32), ("emission_sampler", ctypes.c_uint32),
-                ("emission_scale", ctypes.c_float * 2)]
+                ("emission_scale", ctypes.c_float * 2),
+                ("mask_image", ctypes.c_uint32), ("mask_sampler", ctypes.c_uint32), ("mask_scale", ctypes.c_float * 2)]
 
 
 class Image(ctypes.Structure):
@@ -244,13 +245,16 @@ class Engine:
         return m
 
     def image(self, pixels):
-        """su_image_create (capi.zig:236-298) for an (H, W, 3) array: uint8 (read as sRGB) or float32 (taken as is)."""
+        """su_image_create (capi.zig:236-298) for an (H, W, 3) array: uint8 (read as sRGB) or float32 (taken as is); an
+        (H, W) or (H, W, 1) array makes a one-channel image (masks: uint8 = unorm)."""
         a = np.ascontiguousarray(pixels)
-        if a.ndim != 3 or a.shape[2] != 3 or a.dtype not in (np.uint8, np.float32):
-            raise ValueError("image: (H, W, 3) uint8 or float32")
+        if a.ndim == 2:
+            a = a[:, :, None]
+        if a.ndim != 3 or a.shape[2] not in (1, 3) or a.dtype not in (np.uint8, np.float32):
+            raise ValueError("image: (H, W, 3) or (H, W) uint8 or float32")
         fmt, bpc = (0, 1) if a.dtype == np.uint8 else (4, 4)  # capi.zig:31-37 Format
         self.lib.su_image_create.argtypes = [ctypes.c_uint32] * 7 + [ctypes.c_void_p]
-        i = self.lib.su_image_create(NULL, fmt, 3, a.shape[1], a.shape[0], 1, 3 * bpc, a.ctypes.data)
+        i = self.lib.su_image_create(NULL, fmt, a.shape[2], a.shape[1], a.shape[0], 1, a.shape[2] * bpc, a.ctypes.data)
         if i < 0:
             raise RuntimeError("su_image_create failed")
         return i

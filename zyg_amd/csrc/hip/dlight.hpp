@@ -7,7 +7,7 @@
 
 #include "dsampler.hpp"
 #include "dscene.hpp"
-#include "dtexture.hpp"
+#include "dscene.hpp"
 
 namespace zd {
 

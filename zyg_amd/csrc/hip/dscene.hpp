@@ -105,6 +105,92 @@ struct Counters {
     unsigned long long nodes, tris, instances;
 };
 
+// ---- 2-D image textures: fetch, address modes, nearest / stochastic-bilinear filter
+// (reference src/core/texture/texture_sampler.zig:84-168, sampler_mode.zig:20-88, texture.zig:166-219)
+ZD float texAddress(bool repeat, float x) { return repeat ? x - floorf(x) : clampf(x, 0.f, 1.f); }
+ZD int   texCoord(bool repeat, int c, int end) {
+    if (repeat) {
+        const int m = c % end;  // @mod: the result has the sign of the divisor
+        return m < 0 ? m + end : m;
+    }
+    return max(min(c, end - 1), 0);
+}
+ZD f3 imageFetch3(const DScene& s, const DImage& img, int x, int y) {
+    const size_t i = size_t(y) * size_t(img.width) + size_t(x);
+    if (ZYGPU_IMAGE_BYTE3_SRGB == img.format) {
+        const uint8_t* p = static_cast<const uint8_t*>(img.pixels) + 3 * i;
+        const float    r = s.srgb_to_float[p[0]], g = s.srgb_to_float[p[1]], b = s.srgb_to_float[p[2]];
+        // aces.zig:9-17 sRGBtoAP1
+        return mk3(0.61309732f, 0.07019422f, 0.02061560f) * S3(r) + mk3(0.33952285f, 0.91635557f, 0.10956983f) * S3(g) +
+               mk3(0.04737928f, 0.01345259f, 0.86981512f) * S3(b);
+    }
+    const float* p = static_cast<const float*>(img.pixels) + 3 * i;
+    return mk3(p[0], p[1], p[2]);
+}
+ZD float imageFetch1(const DImage& img, int x, int y) {  // texture.zig:166-175; unorm8ToFloat (base/encoding.zig:10-12)
+    const size_t i = size_t(y) * size_t(img.width) + size_t(x);
+    if (ZYGPU_IMAGE_BYTE1_UNORM == img.format) return float(static_cast<const uint8_t*>(img.pixels)[i]) * (1.f / 255.f);
+    return static_cast<const float*>(img.pixels)[i];
+}
+// the texel a lookup reads: the nearest one, or the one of the four of the bilinear footprint that r picks
+ZD void texelPick(const DImage& img, uint32_t sampler, const float* scale, float u, float v, float r, int& x, int& y) {
+    const bool  ru = 0 != (sampler & ZYGPU_TEX_REPEAT_U), rv = 0 != (sampler & ZYGPU_TEX_REPEAT_V);
+    const float su = scale[0] * u, sv = scale[1] * v;
+    const float dw = float(img.width), dh = float(img.height);
+    if (!(sampler & ZYGPU_TEX_LINEAR)) {
+        x = min(int(texAddress(ru, su) * dw), img.width - 1);
+        y = min(int(texAddress(rv, sv) * dh), img.height - 1);
+        return;
+    }
+    const float mx_ = texAddress(ru, su) * dw - 0.5f, my_ = texAddress(rv, sv) * dh - 0.5f;
+    const float fx = floorf(mx_), fy = floorf(my_);
+    const float wx = mx_ - fx, wy = my_ - fy;
+    const float ox = 1.f - wx, oy = 1.f - wy;
+    int         index = 0;
+    float       threshold = ox * oy;
+    index += r > threshold ? 1 : 0;
+    threshold = __fmaf_rn(wx, oy, threshold);
+    index += r > threshold ? 1 : 0;
+    threshold = __fmaf_rn(ox, wy, threshold);
+    index += r > threshold ? 1 : 0;
+    x = texCoord(ru, int(fx) + (index & 1), img.width);
+    y = texCoord(rv, int(fy) + ((index & 2) >> 1), img.height);
+}
+// ts.sample2D_3 for an image texture; r = rs.stochastic_r
+ZD f3 sampleImageMap(const DScene& s, uint32_t image, uint32_t sampler, const float* scale, float u, float v, float r) {
+    const DImage img = s.images[image];
+    int          x, y;
+    texelPick(img, sampler, scale, u, v, r, x, y);
+    return imageFetch3(s, img, x, y);
+}
+// ts.sampleImage2D_1 (texture_sampler.zig:15-20)
+ZD float sampleImageMap1(const DScene& s, uint32_t image, uint32_t sampler, const float* scale, float u, float v, float r) {
+    const DImage img = s.images[image];
+    int          x, y;
+    texelPick(img, sampler, scale, u, v, r, x, y);
+    return imageFetch1(img, x, y);
+}
+
+// Opacity masks draw from the path's sampler while the ray is traversed; `Draw` is that sampler's sample1D. NoDraw stands
+// in where no material of the scene has a mask (the calls are compiled out with EXTRA = false).
+struct NoDraw {
+    ZD float operator()() const { return 0.f; }
+};
+// Base.stochasticOpacity (material_base.zig:44-55): does the closest-hit traversal accept this hit?
+template <typename Draw>
+ZD bool stochasticOpacity(const DScene& s, const ZygpuMaterial& m, float u, float v, Draw& draw) {
+    if (kNull == m.mask_image) return true;
+    const float o = sampleImageMap1(s, m.mask_image, m.mask_sampler, m.mask_scale, u, v, draw());
+    if (0.f == o || (o < 1.f && o <= draw())) return false;
+    return true;
+}
+// Base.opacity (material_base.zig:35-41)
+template <typename Draw>
+ZD float maskOpacity(const DScene& s, const ZygpuMaterial& m, float u, float v, Draw& draw) {
+    if (kNull == m.mask_image) return 1.f;
+    return sampleImageMap1(s, m.mask_image, m.mask_sampler, m.mask_scale, u, v, draw());
+}
+
 struct Hit {
     float    t, u, v;
     uint32_t primitive, prop;
@@ -235,8 +321,9 @@ ZD bool bvhWalk(const float4* nodes, uint32_t num_nodes, Ray& ray, Counters& cnt
 }
 
 // triangle_tree.zig:46-109; ray in object space; shrinks ray.max_t
-template <bool STATS>
-ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt) {
+// `accept(triangle, u, v)`: intersectOpacity's stochastic mask test (triangle_tree.zig:111-195)
+template <bool STATS, typename Accept>
+ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt, Accept&& accept) {
     uint32_t primitive = kNull;
     float    ht = 0.f, hu = 0.f, hv = 0.f;
     bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, [&](uint32_t first, uint32_t count) {
@@ -244,7 +331,7 @@ ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt
             if (STATS) cnt.tris += 1;
             const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
             float    t, u, v;
-            if (triangleIntersect(local_ray, a, b, c, t, u, v)) {
+            if (triangleIntersect(local_ray, a, b, c, t, u, v) && accept(i, u, v)) {
                 local_ray.max_t = t;
                 ht = t;
                 hu = u;
@@ -260,6 +347,17 @@ ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt
     hit.v = hv;
     hit.primitive = primitive;
     return true;
+}
+
+template <bool STATS>
+ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt) {
+    return meshIntersect<STATS>(mesh, local_ray, hit, cnt, [](uint32_t, float, float) { return true; });
+}
+ZD void meshInterpolateUv(const DMesh& mesh, uint32_t prim, float u, float v, float& uv0, float& uv1) {  // triangle_data.zig:137-149
+    const uint32_t ia = mesh.triangles[3 * prim], ib = mesh.triangles[3 * prim + 1], ic = mesh.triangles[3 * prim + 2];
+    const float    w = 1.f - u - v;
+    uv0 = __fmaf_rn(mesh.uvs[2 * ia], w, __fmaf_rn(mesh.uvs[2 * ib], u, mesh.uvs[2 * ic] * v));
+    uv1 = __fmaf_rn(mesh.uvs[2 * ia + 1], w, __fmaf_rn(mesh.uvs[2 * ib + 1], u, mesh.uvs[2 * ic + 1] * v));
 }
 
 // triangle_tree.zig:197-242
@@ -341,11 +439,49 @@ ZD bool cubeIntersectP(const Ray& ray, const Trafo& trafo) {
     return aabbIntersect(make_float4(-0.5f, -0.5f, -0.5f, -0.5f), make_float4(0.5f, 0.5f, 0.5f, 0.5f), local);
 }
 
+// the uv of a point on the sphere with world normal n (sphere.zig:110-115)
+ZD void sphereUv(const Trafo& trafo, f3 n, float& u, float& v) {
+    const f3    xyz_ = normalize3(trafo.worldToObjectNormal(n));
+    const float phi = -atan2F(xyz_.x, xyz_.z) + kPi;
+    const float theta = acosF(xyz_.y);
+    u = phi * (0.5f * kPiInv);
+    v = theta * kPiInv;
+}
+// sphere.zig:94-146: the nearer root the mask lets through
+template <typename Draw>
+ZD bool sphereIntersectOpacity(const DScene& s, const ZygpuMaterial& m, const Ray& ray, const Trafo& trafo, float& out_t, Draw& draw) {
+    const float idl = 1.f / length3(ray.direction);
+    const f3    nd = ray.direction * S3(idl);
+    const f3    v = trafo.position - ray.origin;
+    const float b = dot3(nd, v);
+    const f3    remedy_term = v - S3(b) * nd;
+    const float radius = 0.5f * trafo.scale.x;
+    const float discriminant = radius * radius - dot3(remedy_term, remedy_term);
+    if (discriminant > 0.f) {
+        const float dist = sqrtf(discriminant);
+        const float ts[2] = {(b - dist) * idl, (b + dist) * idl};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float t = ts[i];
+            if (t >= ray.min_t && ray.max_t >= t) {
+                float uu, vv;
+                sphereUv(trafo, normalize3(ray.point(t) - trafo.position), uu, vv);
+                if (stochasticOpacity(s, m, uu, vv, draw)) {
+                    out_t = t;
+                    return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+
 // prop_tree.zig:56-116 over the solid TLAS (closest hit); shrinks ray.max_t
 // EXTRA: the scene has analytic shapes other than Rectangle (Sphere, Disk, Cube); kept out of the common instantiations,
 // where their code cost 12 % (registers of wf_shade's first pass and wf_intersect; measured 426 vs 374 Msamples/s)
-template <bool STATS, bool EXTRA>
-ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt) {
+// `draw`: the path sampler's sample1D for the opacity masks (prop.zig:191-195 -> shape.intersectOpacity), EXTRA only
+template <bool STATS, bool EXTRA, typename Draw>
+ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt, Draw& draw) {
     hit.prop = kNull;
     bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
@@ -355,9 +491,11 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
             const Trafo trafo = loadTrafo(s, p);
+            const bool  masked = EXTRA && 0 != (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
-                if (rectangleIntersect(ray, trafo, t, u, v)) {
+                if (rectangleIntersect(ray, trafo, t, u, v) &&  // rectangle.zig:64-100
+                    !(masked && !stochasticOpacity(s, s.materials[s.material_ids[prop.parts_start]], 0.5f * (u + 1.f), 0.5f * (v + 1.f), draw))) {
                     hit.t = t;
                     hit.u = u;
                     hit.v = v;
@@ -367,7 +505,9 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                 }
             } else if (EXTRA && (ZYGPU_SHAPE_SPHERE == prop.shape || ZYGPU_SHAPE_CUBE == prop.shape)) {
                 float t;
-                if (ZYGPU_SHAPE_SPHERE == prop.shape ? sphereIntersect(ray, trafo, t) : cubeIntersect(ray, trafo, t)) {
+                if (ZYGPU_SHAPE_SPHERE == prop.shape
+                        ? (masked ? sphereIntersectOpacity(s, s.materials[s.material_ids[prop.parts_start]], ray, trafo, t, draw) : sphereIntersect(ray, trafo, t))
+                        : cubeIntersect(ray, trafo, t)) {
                     hit.t = t;
                     hit.u = hit.v = 0.f;
                     hit.primitive = 0;
@@ -376,7 +516,8 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                 }
             } else if (EXTRA && ZYGPU_SHAPE_DISK == prop.shape) {
                 float t, u, v;
-                if (diskIntersect(ray, trafo, t, u, v)) {
+                if (diskIntersect(ray, trafo, t, u, v) &&  // disk.zig:60-96
+                    !(masked && !stochasticOpacity(s, s.materials[s.material_ids[prop.parts_start]], 0.5f * (u + 1.f), 0.5f * (v + 1.f), draw))) {
                     hit.t = t;
                     hit.u = u;
                     hit.v = v;
@@ -385,9 +526,22 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                     ray.max_t = t;
                 }
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
-                Ray local = worldToObjectRay(trafo, ray);
-                Hit h;
-                if (meshIntersect<STATS>(s.meshes[prop.mesh], local, h, cnt)) {
+                Ray          local = worldToObjectRay(trafo, ray);
+                const DMesh& mesh = s.meshes[prop.mesh];
+                Hit          h;
+                bool         found;
+                if (masked) {
+                    found = meshIntersect<STATS>(mesh, local, h, cnt, [&](uint32_t k, float u, float v) {
+                        const ZygpuMaterial& m = s.materials[s.material_ids[prop.parts_start + mesh.triangle_parts[k]]];
+                        if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return true;
+                        float uv0, uv1;
+                        meshInterpolateUv(mesh, k, u, v, uv0, uv1);
+                        return stochasticOpacity(s, m, uv0, uv1, draw);
+                    });
+                } else {
+                    found = meshIntersect<STATS>(mesh, local, h, cnt);
+                }
+                if (found) {
                     hit.t = h.t;
                     hit.u = h.u;
                     hit.v = h.v;
@@ -400,6 +554,12 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
         return false;
     });
     return kNull != hit.prop;
+}
+
+template <bool STATS, bool EXTRA>
+ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt) {
+    NoDraw none;
+    return sceneIntersect<STATS, EXTRA>(s, ray, depth_surface, hit, cnt, none);
 }
 
 // prop_tree.zig:185-240 + prop.zig:199-237: true = unoccluded
@@ -439,38 +599,57 @@ ZD f3 attenuation3(f3 c, float distance) {  // collision_coefficients.zig:67-69
     return mk3(expF(x.x), expF(x.y), expF(x.z));
 }
 
-// Glass.visibility for thin glass without a mask (glass_material.zig:82-115): Fresnel transmission x absorption over the
-// slab; false = blocked (total internal reflection)
-ZD bool thinGlassVisibility(const ZygpuMaterial& m, f3 wi, f3 geo_n, f3& tr) {
-    const float eta_i = 1.f, eta_t = m.ior;
-    const float n_dot_wo = mn(fabsf(dot3(geo_n, wi)), 1.f);
-    const float eta = eta_i / eta_t;
-    const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
-    if (sint2 >= 1.f) return false;
-    const float n_dot_t = sqrtf(1.f - sint2);
-    const float t0 = eta_t * n_dot_wo, t1 = eta_i * n_dot_t;  // fresnel.dielectric (fresnel.zig:31-43)
-    const float r_p = (t0 - t1) / (t0 + t1);
-    const float t2 = eta_i * n_dot_wo, t3 = eta_t * n_dot_t;
-    const float r_o = (t2 - t3) / (t2 + t3);
-    const float f = 0.5f * (r_p * r_p + r_o * r_o);
-    const float n_dot_wi = clampf(n_dot_wo, 0.00001f, 1.f);
-    const float approx_dist = m.thickness / n_dot_wi;
-    const f3    attenuation = attenuation3(mk3(m.absorption[0], m.absorption[1], m.absorption[2]), approx_dist);
-    const f3    ta = min3v(S3(1.f - 1.f) + attenuation, S3(1.f));
-    tr = tr * (S3(1.f - f) * ta);
-    return true;
+// Glass.visibility (glass_material.zig:69-115): thin glass = Fresnel transmission x absorption over the slab, let through
+// further by the mask's openings; o = the mask's opacity at the hit; false = blocked
+ZD bool glassVisibility(const ZygpuMaterial& m, f3 wi, f3 geo_n, float o, f3& tr) {
+    if (m.thickness > 0.f) {
+        const float eta_i = 1.f, eta_t = m.ior;
+        const float n_dot_wo = mn(fabsf(dot3(geo_n, wi)), 1.f);
+        const float eta = eta_i / eta_t;
+        const float sint2 = (eta * eta) * (1.f - n_dot_wo * n_dot_wo);
+        if (sint2 >= 1.f) {
+            if (o < 1.f) {
+                tr = tr * S3(1.f - o);
+                return true;
+            }
+            return false;
+        }
+        const float n_dot_t = sqrtf(1.f - sint2);
+        const float t0 = eta_t * n_dot_wo, t1 = eta_i * n_dot_t;  // fresnel.dielectric (fresnel.zig:31-43)
+        const float r_p = (t0 - t1) / (t0 + t1);
+        const float t2 = eta_i * n_dot_wo, t3 = eta_t * n_dot_t;
+        const float r_o = (t2 - t3) / (t2 + t3);
+        const float f = 0.5f * (r_p * r_p + r_o * r_o);
+        const float n_dot_wi = clampf(n_dot_wo, 0.00001f, 1.f);
+        const float approx_dist = m.thickness / n_dot_wi;
+        const f3    attenuation = attenuation3(mk3(m.absorption[0], m.absorption[1], m.absorption[2]), approx_dist);
+        const f3    ta = min3v(S3(1.f - o) + attenuation, S3(1.f));
+        tr = tr * (S3(1.f - f) * ta);
+        return true;
+    }
+    if (o < 1.f) {
+        tr = tr * S3(1.f - o);
+        return true;
+    }
+    return false;
 }
-// Material.visibility (material.zig:227-248): Glass evaluates, everything else (opacity 1) blocks
-ZD bool materialVisibility(const ZygpuMaterial& m, f3 wi, f3 geo_n, f3& tr) {
-    if (ZYGPU_MAT_GLASS == m.kind && m.thickness > 0.f) return thinGlassVisibility(m, wi, geo_n, tr);
+// Material.visibility (material.zig:227-248): the mask's opacity, drawn with the path's sampler, scales the transmittance
+template <typename Draw>
+ZD bool materialVisibility(const DScene& s, const ZygpuMaterial& m, f3 wi, f3 geo_n, float u, float v, Draw& draw, f3& tr) {
+    const float o = maskOpacity(s, m, u, v, draw);
+    if (ZYGPU_MAT_GLASS == m.kind) return glassVisibility(m, wi, geo_n, o, tr);
+    if (o < 1.f) {
+        tr = tr * S3(1.f - o);
+        return true;
+    }
     return false;
 }
 
 // Scene.visibility with transmittance (prop_tree.zig:185-240, prop.zig:199-237, shape.zig:235-245): props whose materials
-// evaluate visibility (thin Glass) attenuate `tr` instead of blocking (rectangle.zig:154-186, sphere.zig:176-228,
-// triangle_tree.zig:244-306); true = not blocked
-template <bool STATS>
-ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
+// evaluate visibility (thin Glass, opacity masks) attenuate `tr` instead of blocking (rectangle.zig:154-186,
+// sphere.zig:176-228, disk.zig:136-170, triangle_tree.zig:244-306); true = not blocked
+template <bool STATS, typename Draw>
+ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw& draw) {
     const bool blocked = bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             const uint32_t  p = s.solid_indices[i];
@@ -483,7 +662,9 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (!rectangleIntersect(ray, trafo, t, u, v)) continue;
-                if (!evaluate || !materialVisibility(s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, tr)) return true;
+                if (!evaluate || !materialVisibility(s, s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, 0.5f * (u + 1.f),
+                                                     0.5f * (v + 1.f), draw, tr))
+                    return true;
             } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {
                 if (!evaluate) {
                     float t;
@@ -500,11 +681,14 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
                 if (discriminant > 0.f) {
                     const float          dist = sqrtf(discriminant);
                     const ZygpuMaterial& m = s.materials[s.material_ids[prop.parts_start]];
-                    const float          t0 = (b - dist) * idl, t1 = (b + dist) * idl;
-                    if (t0 >= ray.min_t && ray.max_t >= t0 && !materialVisibility(m, ray.direction, normalize3(ray.point(t0) - trafo.position), tr))
-                        return true;
-                    if (t1 >= ray.min_t && ray.max_t >= t1 && !materialVisibility(m, ray.direction, normalize3(ray.point(t1) - trafo.position), tr))
-                        return true;
+                    const float          ts[2] = {(b - dist) * idl, (b + dist) * idl};
+                    for (int k = 0; k < 2; ++k) {
+                        if (!(ts[k] >= ray.min_t && ray.max_t >= ts[k])) continue;
+                        const f3 n = normalize3(ray.point(ts[k]) - trafo.position);
+                        float    uu = 0.f, vv = 0.f;
+                        if (kNull != m.mask_image) sphereUv(trafo, n, uu, vv);
+                        if (!materialVisibility(s, m, ray.direction, n, uu, vv, draw, tr)) return true;
+                    }
                 }
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 Ray          local = worldToObjectRay(trafo, ray);
@@ -521,15 +705,19 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
                         if (!triangleIntersect(local, a, b, c, t, u, v)) continue;
                         const ZygpuMaterial& m = s.materials[s.material_ids[prop.parts_start + mesh.triangle_parts[k]]];
                         if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return true;
-                        if (!materialVisibility(m, local.direction, normalize3(cross3(b - a, c - a)), tr)) return true;
+                        float uv0 = 0.f, uv1 = 0.f;
+                        if (kNull != m.mask_image) meshInterpolateUv(mesh, k, u, v, uv0, uv1);
+                        if (!materialVisibility(s, m, local.direction, normalize3(cross3(b - a, c - a)), uv0, uv1, draw, tr)) return true;
                     }
                     return false;
                 });
                 if (mesh_blocked) return true;
-            } else if (ZYGPU_SHAPE_DISK == prop.shape) {  // the material decides (Material.visibility): thin glass attenuates
+            } else if (ZYGPU_SHAPE_DISK == prop.shape) {  // the material decides (Material.visibility)
                 float t, u, v;
                 if (!diskIntersect(ray, trafo, t, u, v)) continue;
-                if (!evaluate || !materialVisibility(s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, tr)) return true;
+                if (!evaluate || !materialVisibility(s, s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, 0.5f * (1.f + u),
+                                                     0.5f * (1.f + v), draw, tr))
+                    return true;
             } else if (ZYGPU_SHAPE_CUBE == prop.shape) {  // cube.zig:69-80: always blocks
                 if (cubeIntersectP(ray, trafo)) return true;
             }
@@ -537,6 +725,11 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
         return false;
     });
     return !blocked;
+}
+template <bool STATS>
+ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
+    NoDraw none;
+    return sceneVisibilityTr<STATS>(s, ray, cnt, tr, none);
 }
 
 struct Fragment {  // shape/intersection.zig:64-124

@@ -446,6 +446,38 @@ ZD void storeHead(const Params& P, uint32_t vertex, const PathHead& h) {
     if (POOL) P.pool.vmeta[vertex] = packMeta(h);
 }
 
+// The path sampler as the traversal's source of opacity-mask draws (prop.zig:191-195). Each draw loads the sampler from the
+// pool and stores it back: held in registers across the traversal loop instead, it cost the EXTRA instantiations 10-16 % on
+// scenes without any mask (cornell_glass 129 -> 109, outdoor 249 -> 225 Msamples/s); masked hits are rare, the walk is not.
+// Only the EXTRA instantiations carry it; NoHeadDraw is its stand-in elsewhere.
+template <bool POOL>
+struct HeadDraw {
+    const Params& P;
+    uint32_t      vertex;
+    ZD HeadDraw(const Params& P_, uint32_t vertex_) : P(P_), vertex(vertex_) {}
+    ZD float operator()() {
+        PathHead h;
+        loadHead<POOL>(P, vertex, h);
+        const float r = h.smp.sample1D();
+        storeHead<POOL>(P, vertex, h);
+        return r;
+    }
+    ZD void flush() const {}
+};
+struct NoHeadDraw {
+    ZD NoHeadDraw(const Params&, uint32_t) {}
+    ZD float operator()() const { return 0.f; }
+    ZD void flush() const {}
+};
+template <bool POOL, bool EXTRA>
+struct MaskDraw {
+    using type = HeadDraw<POOL>;
+};
+template <bool POOL>
+struct MaskDraw<POOL, false> {
+    using type = NoHeadDraw;
+};
+
 ZD f3 xyz4(float4 v) { return {v.x, v.y, v.z}; }
 ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
 
@@ -692,7 +724,9 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
             }
         }
         Hit            hit;
-        sceneIntersect<STATS, EXTRA>(c_scene, ray, depth, hit, cnt);
+        typename MaskDraw<POOL, EXTRA>::type draw(P, slot);
+        sceneIntersect<STATS, EXTRA>(c_scene, ray, depth, hit, cnt, draw);
+        draw.flush();
         if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
         P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
         P.pool.hit_prop[slot] = hit.prop;
@@ -1086,7 +1120,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
             const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
             Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
             Hit            hit;
-            sceneIntersect<STATS, MESHL>(c_scene, ray, depth, hit, cnt);
+            typename MaskDraw<false, MESHL>::type draw(P, slot);
+            sceneIntersect<STATS, MESHL>(c_scene, ray, depth, hit, cnt, draw);
+            draw.flush();
             if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL>(P, c_scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             shadeVertex<STATS, MESHL, false, false>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm);
@@ -1454,7 +1490,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
                     if (STATS) shadow_rays += 1;
                     f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)
-                    if (POOL ? !sceneVisibilityTr<STATS>(s, shadow, cnt, tr) : !sceneVisibility<STATS, MESHL>(s, shadow, cnt)) return;
+                    // MESHL: the scene may have opacity masks, whose draws come from the path's sampler (material.zig:238-245)
+                    auto draw = [&]() { return h.smp.sample1D(); };
+                    if ((POOL || MESHL) ? !sceneVisibilityTr<STATS>(s, shadow, cnt, tr, draw) : !sceneVisibility<STATS, MESHL>(s, shadow, cnt)) return;
                     const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                     const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
@@ -1462,10 +1500,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                         const float light_pdf = ls.pdf * pick.pdf;
                         const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
                         const f3    unocc = S3(weight) * radiance * bx.reflection;
-                        occluded = occluded + (POOL ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
+                        occluded = occluded + ((POOL || MESHL) ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
                     } else {
                         const float weight = 1.f / (pick.pdf * ls.pdf);
-                        occluded = occluded + S3(weight) * ((POOL ? tr : S3(1.f)) * radiance * bx.reflection);
+                        occluded = occluded + S3(weight) * (((POOL || MESHL) ? tr : S3(1.f)) * radiance * bx.reflection);
                     }
                 };
 

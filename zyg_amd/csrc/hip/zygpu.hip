@@ -543,7 +543,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
     }
     for (uint32_t mi = 0; mi < d->num_materials; ++mi)  // texture fetches live in the MESHL instantiations, too
-        if (ZYGPU_NULL != d->materials[mi].color_image || ZYGPU_NULL != d->materials[mi].emission_image) c->mesh_lights = true;
+        if (ZYGPU_NULL != d->materials[mi].color_image || ZYGPU_NULL != d->materials[mi].emission_image || ZYGPU_NULL != d->materials[mi].mask_image)
+            c->mesh_lights = true;
     c->extra_shapes = false;
     for (uint32_t p = 0; p < d->num_props; ++p) {
         const uint32_t sh = d->props[p].shape;
@@ -642,9 +643,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     std::vector<DImage> images(d->num_images);
     for (uint32_t i = 0; i < d->num_images; ++i) {
         const ZygpuImage& hi = d->images[i];
-        const size_t      bytes = size_t(hi.width) * size_t(hi.height) * (ZYGPU_IMAGE_BYTE3_SRGB == hi.format ? 3 : 12);
+        const size_t      bytes = size_t(hi.width) * size_t(hi.height) * (ZYGPU_IMAGE_BYTE3_SRGB == hi.format ? 3 : ZYGPU_IMAGE_FLOAT3 == hi.format ? 12 : ZYGPU_IMAGE_BYTE1_UNORM == hi.format ? 1 : 4);
         const uint8_t*    pixels = nullptr;
-        if (hi.width <= 0 || hi.height <= 0 || hi.format > ZYGPU_IMAGE_FLOAT3 || !m.upload(static_cast<const uint8_t*>(hi.pixels), bytes, &pixels)) {
+        if (hi.width <= 0 || hi.height <= 0 || hi.format > ZYGPU_IMAGE_FLOAT1 || !m.upload(static_cast<const uint8_t*>(hi.pixels), bytes, &pixels)) {
             g_error = "ZygpuImage: bad dimensions / format, or out of device memory";
             return -2;
         }
@@ -656,6 +657,11 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         const ZygpuMaterial& mat = d->materials[mi];
         if (ZYGPU_NULL != mat.color_image && (mat.color_image >= d->num_images || !d->srgb_to_float)) {
             g_error = "a material's colour map names an image that is not in ZygpuSceneDesc.images";
+            return -2;
+        }
+        if (ZYGPU_NULL != mat.mask_image && (mat.mask_image >= d->num_images || (ZYGPU_IMAGE_BYTE1_UNORM != d->images[mat.mask_image].format &&
+                                                                                 ZYGPU_IMAGE_FLOAT1 != d->images[mat.mask_image].format))) {
+            g_error = "a material's mask names an image that is not a one-channel image of ZygpuSceneDesc.images";
             return -2;
         }
     }

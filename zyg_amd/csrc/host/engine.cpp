@@ -196,6 +196,7 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
     m.emission_num_samples = 1;
     m.color_image = ZYGPU_NULL;
     m.emission_image = ZYGPU_NULL;
+    m.mask_image = ZYGPU_NULL;
     m.roughness = 0.8f;
     m.metallic = 0.f;
     m.specular = 1.f;
@@ -217,6 +218,10 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
         m.emission_num_samples = std::min<uint32_t>(e.memberU32("num_samples", 1), 64u);
         if (const JsonValue* em = e.get("emission_map")) readImageTexture(*em, m.emission_image, m.emission_sampler, m.emission_scale);
     };
+
+    // material_provider.zig:177-178, 244-245, 265-266: Glass, Light and Substitute read "mask" (usage Opacity)
+    if (ZYGPU_MAT_DEBUG != kind)
+        if (const JsonValue* mask = v.get("mask")) readImageTexture(*mask, m.mask_image, m.mask_sampler, m.mask_scale);
 
     if (ZYGPU_MAT_DEBUG == kind) {
         // debug_material.zig:11-18: two-sided, fixed front/back albedo.
@@ -312,9 +317,12 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
 
 void Engine::commitMaterial(ZygpuMaterial& m) {
     // light_material.zig:45-51 / substitute_material.zig:62-75
+    const bool masked = ZYGPU_NULL != m.mask_image;  // mask.isImage()
     if (ZYGPU_MAT_LIGHT == m.kind || ZYGPU_MAT_SUBSTITUTE == m.kind) {
         if (m.emission[0] > 0.f || m.emission[1] > 0.f || m.emission[2] > 0.f) m.flags |= ZYGPU_MATF_EMISSIVE;
         else m.flags &= ~uint32_t(ZYGPU_MATF_EMISSIVE);
+        if (masked) m.flags |= ZYGPU_MATF_EVALUATE_VISIBILITY;  // light_material.zig:47, substitute_material.zig:65
+        else m.flags &= ~uint32_t(ZYGPU_MATF_EVALUATE_VISIBILITY);
     }
     if (ZYGPU_MAT_SUBSTITUTE == m.kind) {
         if (m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
@@ -323,7 +331,8 @@ void Engine::commitMaterial(ZygpuMaterial& m) {
     if (ZYGPU_MAT_GLASS == m.kind) {  // glass_material.zig:35-42
         const bool thin = m.thickness > 0.f;
         m.flags &= ~uint32_t(ZYGPU_MATF_TWO_SIDED | ZYGPU_MATF_EVALUATE_VISIBILITY | ZYGPU_MATF_CAUSTIC);
-        if (thin) m.flags |= ZYGPU_MATF_TWO_SIDED | ZYGPU_MATF_EVALUATE_VISIBILITY;
+        if (thin) m.flags |= ZYGPU_MATF_TWO_SIDED;
+        if (thin || masked) m.flags |= ZYGPU_MATF_EVALUATE_VISIBILITY;
         if (m.roughness * m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
     }
 }
@@ -510,11 +519,11 @@ uint32_t Engine::createImage(uint32_t id, uint32_t format, uint32_t num_channels
                              uint32_t pixel_stride, const uint8_t* data) {
     (void)id;  // ids are assigned in creation order, like the other resources created with id = NULL
     const bool u8 = 0 == format, f32 = 4 == format;  // capi.zig:31-37 Format: UInt8, UInt16, UInt32, Float16, Float32
-    if (!(u8 || f32) || 3 != num_channels || 1 != depth || 0 == width || 0 == height || !data) return ZYGPU_NULL;
+    if (!(u8 || f32) || (3 != num_channels && 1 != num_channels) || 1 != depth || 0 == width || 0 == height || !data) return ZYGPU_NULL;
     const uint32_t bpp = (u8 ? 1u : 4u) * num_channels;
     if (bpp != pixel_stride) return ZYGPU_NULL;  // the reference only copies tightly packed pixels (capi.zig:264-266)
     HostImage img;
-    img.format = u8 ? ZYGPU_IMAGE_BYTE3_SRGB : ZYGPU_IMAGE_FLOAT3;
+    img.format = 3 == num_channels ? (u8 ? ZYGPU_IMAGE_BYTE3_SRGB : ZYGPU_IMAGE_FLOAT3) : (u8 ? ZYGPU_IMAGE_BYTE1_UNORM : ZYGPU_IMAGE_FLOAT1);
     img.width = int32_t(width);
     img.height = int32_t(height);
     img.pixels.assign(data, data + size_t(width) * height * bpp);
@@ -1239,8 +1248,12 @@ int Engine::compile(uint32_t frame) {
     }
     d.image_lights = c_image_lights_.data();
     d.num_image_lights = uint32_t(c_image_lights_.size());
-    for (const ZygpuMaterial& m : materials_)
-        if (ZYGPU_NULL != m.color_image && m.color_image >= images_.size()) return -4;  // a colour map without its image
+    auto channels = [&](uint32_t image) { return ZYGPU_IMAGE_BYTE3_SRGB == images_[image].format || ZYGPU_IMAGE_FLOAT3 == images_[image].format ? 3 : 1; };
+    for (const ZygpuMaterial& m : materials_) {
+        if (ZYGPU_NULL != m.color_image && (m.color_image >= images_.size() || 3 != channels(m.color_image))) return -4;  // a colour map without its image
+        if (ZYGPU_NULL != m.emission_image && m.emission_image < images_.size() && 3 != channels(m.emission_image)) return -4;
+        if (ZYGPU_NULL != m.mask_image && (m.mask_image >= images_.size() || 1 != channels(m.mask_image))) return -4;  // image2D_1 reads one channel
+    }
     for (uint32_t mid : material_ids_) {  // rough thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 437-503)
         const ZygpuMaterial& m = materials_[mid];
         if (ZYGPU_MAT_GLASS == m.kind && ((m.thickness > 0.f && m.roughness > 0.f) || m.abbe > 0.f)) return -5;

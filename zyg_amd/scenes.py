@@ -59,6 +59,28 @@ def checker_image(n=8, dtype=np.float32):
     return (img * 255.0 + 0.5).astype(np.uint8) if dtype == np.uint8 else img.astype(np.float32)
 
 
+def mask_image(n=16, dtype=np.uint8):
+    """n x n one-channel opacity mask: holes (0), solid parts (1) and a band of partial opacities, so that both draws of
+    stochasticOpacity (material_base.zig:44-55) happen."""
+    y, x = np.mgrid[0:n, 0:n]
+    r = np.hypot(x - (n - 1) / 2.0, y - (n - 1) / 2.0) / (n / 2.0)
+    o = np.where((x // 2 + y // 2) % 3 == 0, 0.0, 1.0)
+    o = np.where((r > 0.45) & (r < 0.8), 0.25 + 0.5 * ((x * 7 + y * 3) % 8) / 8.0, o)
+    return (o * 255.0 + 0.5).astype(np.uint8) if dtype == np.uint8 else o.astype(np.float32)
+
+
+def with_mask(material_json, image_id, sampler=None, scale=None):
+    """Adds "mask" (material_provider.zig:177, 244, 265: usage Opacity) to a Glass / Light / Substitute material JSON."""
+    m = json.loads(material_json)
+    (body,) = m["rendering"].values()
+    body["mask"] = {"usage": "Opacity", "id": int(image_id)}
+    if sampler:
+        body["mask"]["sampler"] = sampler
+    if scale is not None:
+        body["mask"]["scale"] = scale
+    return json.dumps(m)
+
+
 def glass(ior=1.5, color=(1.0, 1.0, 1.0), distance=1.0, priority=0, **more):
     """Thick specular dielectric (glass_material.zig); `color` is reached after `distance` inside the medium."""
     body = {"ior": ior, "attenuation_color": list(color), "attenuation_distance": distance, "priority": priority}
@@ -214,7 +236,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
-            light_spectrum=(17.0, 12.0, 4.0)):
+            light_spectrum=(17.0, 12.0, 4.0), masked=None):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -225,6 +247,9 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     glass_objects: None, or a dict: the short box turns into glass (`box` = a glass(...) JSON), a glass Sphere (`sphere`)
     stands in front of the tall box, optionally with a second dielectric inside it (`inner`, nested dielectrics);
     `outside`: a glass Sphere next to the box, in front of the void (alpha through glass with a Transparent sensor).
+    masked: None, or a dict: `image` (a one-channel numpy mask) and optionally `sampler`, `scale`, `lights` (the lamps are masked
+    too), `pane` (a masked thin-glass Rectangle): a masked Rectangle, Sphere and Disk stand in the box and the tall box's
+    material is masked (opacity masks need Substitute / Light / Glass materials).
     Returns a dict with prop ids.
     """
     mk = lambert if material == "lambert" else substitute
@@ -247,6 +272,13 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     # light_map: a numpy image -> the quad lights are textured (emission map x spectrum) and importance-sampled by it
     lamp = engine.material(light_material(spectrum=light_spectrum, num_samples=light_samples,
                                           emission_map=None if light_map is None else engine.image(light_map)))
+
+    mask_id = None
+    if masked:
+        mask_id = engine.image(masked["image"])
+        mask_kw = {"sampler": masked.get("sampler"), "scale": masked.get("scale")}
+        if masked.get("lights"):
+            lamp = engine.material(with_mask(light_material(spectrum=light_spectrum, num_samples=light_samples), mask_id, **mask_kw))
 
     ids = {"camera": cam, "walls": [], "lights": [], "meshes": []}
 
@@ -306,6 +338,23 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         p = engine.prop(1, [green])
         engine.transformation(p, trafo((c, 0, -s_), (0, 1, 0), (0.5, 0.3, 0.4), (0.45, 0.15, -0.45)))
         ids["meshes"].append(p)
+    if masked:
+        cut_red = engine.material(with_mask(substitute(RED, 0.6), mask_id, **mask_kw))
+        cut_green = engine.material(with_mask(substitute(GREEN, 0.3, 1.0), mask_id, **mask_kw))
+        p = engine.prop(RECTANGLE, [cut_red])  # a screen facing the camera, in front of the short box
+        engine.transformation(p, trafo((-1, 0, 0), (0, 1, 0), (0.9, 0.9, 1), (0.45, 0.8, -0.8)))
+        ids["meshes"].append(p)
+        p = engine.prop(SPHERE, [cut_green])
+        engine.transformation(p, trafo((0.8, 0, 0.6), (0, 1, 0), (0.6, 0.6, 0.6), (-0.5, 1.55, -0.3)))
+        ids["meshes"].append(p)
+        p = engine.prop(2, [cut_red])  # Disk, lying above the floor: its shadow shows the mask
+        engine.transformation(p, trafo((1, 0, 0), (0, 0.6, -0.8), (0.8, 0.8, 0.8), (-0.45, 0.5, -0.6)))
+        ids["meshes"].append(p)
+        if masked.get("pane"):
+            pane = engine.material(with_mask(glass(1.5, (0.6, 0.9, 0.7), 0.05, thickness=0.02), mask_id, **mask_kw))
+            p = engine.prop(RECTANGLE, [pane])
+            engine.transformation(p, trafo((-1, 0, 0), (0, 0.96, 0.28), (1.2, 0.8, 1), (0.0, 1.3, 0.2)))
+            ids["meshes"].append(p)
     identity = trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))
     glass_objects = glass_objects or {}
     for key, pos_, d_ in (("sphere", (-0.35, 0.36, -0.5), 0.7), ("inner", (-0.35, 0.36, -0.5), 0.4), ("outside", (1.7, 1.0, -1.2), 0.9)):
@@ -318,6 +367,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             idx, pos, nrm, uv = box_mesh(lo, hi, rot)
             shape = engine.triangle_mesh(idx, pos, nrm, uv)
             box_mat = engine.material(glass_objects["box"]) if 1 == k and "box" in glass_objects else white
+            if masked and 0 == k:
+                box_mat = engine.material(with_mask(substitute(WHITE), mask_id, sampler=mask_kw["sampler"], scale=[2.0, 2.0]))
             p = engine.prop(shape, [box_mat])
             engine.transformation(p, identity)
             ids["meshes"].append(p)
