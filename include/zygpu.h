@@ -417,7 +417,7 @@ int zygpu_get_section_cycles(ZygpuContext* ctx, uint64_t* out32);
 int zygpu_kernel_time(ZygpuContext* ctx, double* out_ms, uint64_t* out_launches, int reset);
 
 /* Unit-test hook: evaluates small device functions (op: 0 sin/cos/acos, 1 SphQuad, 2 Sobol stream, 3 PCG,
- * 4 offsetRay; strides in floats per item) on host arrays; see tests/test_gpu_units.py. */
+ * 4 offsetRay, 6 exp / atan2, 7 tan; strides in floats per item) on host arrays; see tests/test_gpu_units.py. */
 int zygpu_test_eval(ZygpuContext* ctx, uint32_t op, uint32_t n, const float* in, uint32_t in_stride, float* out,
                     uint32_t out_stride);
 

@@ -478,6 +478,115 @@ inline float spherePdf(V4 p, const Trafo& trafo, float split_threshold, uint32_t
     return float(numSamples(light_num_samples, split_threshold)) * conePdfUniform(one_minus_cos_theta_max);
 }
 
+// ---------- Disk lights: equi-angular sampling of the chord through the projected shading point, then of the chord
+// across it (disk.zig:180-251, 252-359, 492-533; UseEquiAngularSampling = true) ----------
+
+struct DiskSamplerData {  // disk.zig:181-194
+    V4 xd, yd;
+    static DiskSamplerData init(V4 p) {
+        const V4 td = mk(p[1], -p[0], 0.f, 0.f);
+        const V4 xd = (0.f == td[0] && 0.f == td[1] && 0.f == td[2]) ? mk(1.f, 0.f, 0.f, 0.f) : normalize3(td);
+        return {xd, mk(-xd[1], xd[0], 0.f, 0.f)};
+    }
+};
+struct EquiAngularSampling {  // disk.zig:196-250
+    float offset, min_t, max_t, scale, scale_sqr, angle_min, angle_extent;
+    static EquiAngularSampling init(V4 source, V4 origin, V4 direction, float min_t, float max_t) {
+        const float offset = dot3(direction, source - origin) / squaredLength3(direction);
+        const float scale_sqr = squaredLength3((origin + S(offset) * direction) - source);
+        const float scale = std::sqrt(scale_sqr);
+        const float inv_scale = 0.f == scale ? 0.f : 1.f / scale;
+        const float angle_min = atanF((min_t - offset) * inv_scale);
+        const float angle_max = atanF((max_t - offset) * inv_scale);
+        return {offset, min_t, max_t, scale, scale_sqr, angle_min, angle_max - angle_min};
+    }
+    float sample(float u, float& t) const {
+        const float lt = scale * tanF(angle_min + u * angle_extent);
+        const float p = scale / (angle_extent * (scale_sqr + lt * lt));
+        t = clampf(lt + offset, min_t, max_t);
+        return p;
+    }
+    float pdf(float t) const {
+        if (min_t <= t && t < max_t) {
+            const float lt = t - offset;
+            return scale / (angle_extent * (scale_sqr + lt * lt));
+        }
+        return 0.f;
+    }
+    float pdfAndSample(float t, float& u) const {
+        const float lt = t - offset;
+        u = clampf((atanF(lt / scale) - angle_min) / angle_extent, 0.f, 1.f);  // math.saturate
+        return scale / (angle_extent * (scale_sqr + lt * lt));
+    }
+};
+
+inline uint32_t diskSampleTo(V4 p, V4 n, const Trafo& trafo, bool two_sided, bool total_sphere, float split_threshold,
+                             uint32_t light_num_samples, Sampler& sampler, SampleTo* buffer) {
+    const uint32_t num_samples = numSamples(light_num_samples, split_threshold);
+    const float    nsf = float(num_samples);
+    const float    radius = 0.5f * trafo.scaleX();
+    const V4       lp = trafo.worldToFramePoint(p);
+    const auto     dsd = DiskSamplerData::init(lp);
+    const auto     eas0 = EquiAngularSampling::init(lp, S(0.f), dsd.yd, -radius, radius);
+    if (0.f == eas0.angle_extent) return 0;
+    uint32_t current_sample = 0;
+    for (uint32_t i = 0; i < num_samples; ++i) {
+        float r2[2];
+        sampler.sample2D(r2);
+        float x, y;
+        diskConcentric(r2[0], r2[1], x, y);
+        float u = x;
+        float pdf_ = std::sqrt(1.f - u * u) / (0.25f * kPi);
+        u = (u + 1.f) * 0.5f;
+        float y_coord;
+        pdf_ *= eas0.sample(u, y_coord);
+        const float x_chord = std::sqrt(radius * radius - y_coord * y_coord);
+        if (0.f == x_chord) continue;
+        const auto eas1 = EquiAngularSampling::init(lp, S(y_coord) * dsd.yd, dsd.xd, -x_chord, x_chord);
+        if (0.f == eas1.angle_extent) continue;
+        float x_coord;
+        pdf_ *= eas1.sample(sampler.sample1D(), x_coord);
+        const V4 l_direction = S(x_coord) * dsd.xd + S(y_coord) * dsd.yd - lp;
+        const V4 axis = trafo.objectToWorldNormal(l_direction);
+        const V4 ws = p + axis;
+        V4       wn = trafo.r[2];
+        if (two_sided && dot3(wn, ws - p) > 0.f) wn = -wn;
+        const float sl = squaredLength3(axis);
+        const V4    dir = axis / S(std::sqrt(sl));
+        const float c = -dot3(wn, dir);
+        if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) continue;
+        const float v = (y + 1.f) * 0.5f;
+        SampleTo&   out = buffer[current_sample++];
+        out.p = mk(ws[0], ws[1], ws[2], (nsf * pdf_ * sl) / c);
+        out.n = wn;
+        out.wi = dir;
+        out.uvw = mk(u, v, 0.f, 0.f);
+    }
+    return current_sample;
+}
+
+inline float diskPdf(V4 dir, V4 p, const Trafo& trafo, V4 frag_p, float split_threshold, uint32_t light_num_samples) {
+    const float c = std::fabs(dot3(trafo.r[2], dir));
+    const float nsf = float(numSamples(light_num_samples, split_threshold));
+    const float radius = 0.5f * trafo.scaleX();
+    const float sl = squaredDistance3(p, frag_p);
+    const V4    lp = trafo.worldToFramePoint(p);
+    const auto  dsd = DiskSamplerData::init(lp);
+    const auto  eas0 = EquiAngularSampling::init(lp, S(0.f), dsd.yd, -radius, radius);
+    const V4    l_point = trafo.worldToFramePoint(frag_p);
+    const float y_coord = dot3(l_point, dsd.yd);
+    float       u;
+    const float eas_pdf = eas0.pdfAndSample(y_coord, u);
+    u = u * 2.f - 1.f;
+    float pdf_ = std::sqrt(1.f - u * u) / (0.25f * kPi);
+    pdf_ *= eas_pdf;
+    const float x_chord = std::sqrt(radius * radius - y_coord * y_coord);
+    const auto  eas1 = EquiAngularSampling::init(lp, S(y_coord) * dsd.yd, dsd.xd, -x_chord, x_chord);
+    const float x_coord = dot3(l_point, dsd.xd);
+    pdf_ *= eas1.pdf(x_coord);
+    return (nsf * pdf_ * sl) / c;
+}
+
 // ---------- Dome / Canopy with uniform emission: dome.zig:26-103, 214-220; canopy.zig:24-92 ----------
 
 inline V4 hemisphereUniform(float u0, float u1) {  // sampling.zig:56-65

@@ -143,6 +143,31 @@ inline float cosF(float x) {
     }
     return std::cos(x);
 }
+// @tan lowers to compiler-rt's tanf, a port of musl's tanf.c (__tandf in double precision); the disk light's equi-angular
+// sampling calls it with angles from atan, |x| < pi/2 (disk.zig:229-234); larger arguments fall back to libm
+inline float tandf(double x, bool odd) {
+    const double T0 = 0x15554d3418c99f.0p-54, T1 = 0x1112fd38999f72.0p-55, T2 = 0x1b54c91d865afe.0p-57, T3 = 0x191df3908c33ce.0p-58,
+                 T4 = 0x185dadfcecf44e.0p-61, T5 = 0x1362b9bf971bcd.0p-59;
+    const double z = x * x;
+    const double r = T4 + z * T5;
+    const double t = T2 + z * T3;
+    const double w = z * z;
+    const double s = z * x;
+    const double u = T0 + z * T1;
+    const double r0 = (x + s * u) + (s * w) * (t + w * r);
+    return float(odd ? -1.0 / r0 : r0);
+}
+inline float tanF(float x) {
+    const uint32_t hx = m32::bits(x), ix = hx & 0x7fffffffu;
+    const bool     sign = 0 != (hx >> 31);
+    const double   xd = double(x);
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? x : tandf(xd, false);
+    if (ix <= 0x407b53d1u) {
+        if (ix <= 0x4016cbe3u) return tandf(sign ? xd + m32::kPio2 : xd - m32::kPio2, true);
+        return tandf(sign ? xd + 2 * m32::kPio2 : xd - 2 * m32::kPio2, false);
+    }
+    return std::tan(x);
+}
 inline float acosR(float z) {
     const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
     const float p = z * (pS0 + z * (pS1 + z * pS2)), q = 1.f + z * qS1;

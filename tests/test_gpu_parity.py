@@ -489,3 +489,23 @@ def test_opacity_masks_kernels_apart(engine, oracle):
     masked = {"image": scenes.mask_image(16, np.uint8)}
     out = _render_both(engine, oracle, 80, 60, 3, integrator="PTMIS", material="substitute", masked=masked, fuse=0)
     _check(*out, 3)
+
+
+def test_opacity_masks_without_counters(engine, oracle):
+    """The MASKS instantiations of wf_scatter that run without the statistics counters (the counted ones always carry the
+    mask code)."""
+    masked = {"image": scenes.mask_image(16, np.uint8), "lights": True}
+    out = _render_both(engine, oracle, 80, 60, 3, stats=False, integrator="PTMIS", material="substitute", masked=masked)
+    _check(*out, 3)
+    out = _render_both(engine, oracle, 80, 60, 3, stats=False, integrator="PTMIS", material="substitute", masked=dict(masked, pane=True))
+    _check(*out, 3)
+
+
+@pytest.mark.parametrize("integrator,unoccluding,samples,two_sided", [("PT", True, 1, False), ("PTDL", False, 1, True), ("PTMIS", True, 1, False),
+                                                                       ("PTMIS", False, 3, True), ("PTMIS", True, 4, False)])
+def test_disk_lights(engine, oracle, integrator, unoccluding, samples, two_sided):
+    """Disk emitters: equi-angular sampling of the disk's chords (disk.zig:180-359: atan / tan restated bit-exactly), their pdf
+    for emissive hits (disk.zig:492-533) and the unoccluding candidates (disk.zig:171-179)."""
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, unoccluding_lights=unoccluding, light_samples=samples,
+                       disk_lights=True, two_sided_lights=two_sided, material="substitute")
+    _check(*out, 3)

@@ -64,6 +64,20 @@ def test_exp_atan2_bit_exact(product_lib, oracle, ctx):
     assert np.array_equal(g[:, 1].view(np.uint32), a.view(np.uint32))
 
 
+def test_tan_bit_exact(product_lib, oracle, ctx):
+    """The disk light's equi-angular sampling: tan of angles in (-pi/2, pi/2) (disk.zig:229-234), musl's tanf on both sides."""
+    rng = np.random.default_rng(21)
+    n = 200000
+    x = rng.uniform(-1.5707, 1.5707, n).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1e-5, -1e-5, 0.7853982, -0.7853982, 1.5707, -1.5707]
+    g = _eval(product_lib, ctx, 7, x.reshape(-1, 1), 1)
+    c = np.zeros(n, np.float32)
+    oracle.zyg_oracle_tan(n, _vp(x), _vp(c))
+    assert np.array_equal(g[:, 0].view(np.uint32), c.view(np.uint32))
+    ref = np.tan(x.astype(np.float64))
+    assert np.max(np.abs(c - ref) / np.maximum(np.abs(ref), 1e-30)) < 2e-7  # within an ulp of the true tangent
+
+
 def test_sphquad_bit_exact(product_lib, oracle, ctx):
     rng = np.random.default_rng(4)
     n = 100000

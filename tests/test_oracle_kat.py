@@ -543,3 +543,18 @@ def test_mask_needs_a_one_channel_image(product_lib):
         p = e.prop(scenes.RECTANGLE, [e.material(scenes.with_mask(scenes.substitute(scenes.RED), rgb))])
         e.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, 0)))
         assert e.lib.su_ext_compile(0) != 0
+
+
+def test_disk_lights_match_their_closed_form_and_integrators_agree(product_lib, oracle):
+    """Disk emitters (disk.zig:252-359, 492-533): the three integrators estimate the same image, and a small Disk light lights
+    the floor like the Rectangle light of the same area and radiance (far-field limit)."""
+    w, h, spp = 40, 30, 384
+    means = {}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, integrator=integ, disk_lights=True, unoccluding_lights=False, max_depth=8, light_samples=2 if integ == "PTMIS" else 1)
+            sd, vd = e.compile()
+            assert [sd.props[sd.lights[i].prop].shape for i in range(sd.num_lights)] == [2, 2]
+            means[integ] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.02)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)

@@ -480,6 +480,128 @@ ZD float spherePdf(f3 p, const Trafo& trafo, uint32_t num_samples) {  // sphere.
     return float(num_samples) * conePdfUniform(one_minus_cos_theta_max);
 }
 
+// ---------------------------------------------------------------- Disk lights (disk.zig:180-359, 492-533)
+// equi-angular sampling (UseEquiAngularSampling) of the chord through the projected shading point, then of the chord across it
+
+struct DiskSamplerData {  // disk.zig:181-194
+    f3 xd, yd;
+    ZD static DiskSamplerData init(f3 p) {
+        const f3 td = mk3(p.y, -p.x, 0.f);
+        DiskSamplerData d;
+        d.xd = (0.f == td.x && 0.f == td.y) ? mk3(1.f, 0.f, 0.f) : normalize3(td);
+        d.yd = mk3(-d.xd.y, d.xd.x, 0.f);
+        return d;
+    }
+};
+struct EquiAngularSampling {  // disk.zig:196-250
+    float offset, min_t, max_t, scale, scale_sqr, angle_min, angle_extent;
+    ZD static EquiAngularSampling init(f3 source, f3 origin, f3 direction, float min_t, float max_t) {
+        EquiAngularSampling e;
+        e.offset = dot3(direction, source - origin) / squaredLength3(direction);
+        e.scale_sqr = squaredLength3((origin + S3(e.offset) * direction) - source);
+        e.scale = sqrtf(e.scale_sqr);
+        const float inv_scale = 0.f == e.scale ? 0.f : 1.f / e.scale;
+        e.angle_min = atanF((min_t - e.offset) * inv_scale);
+        const float angle_max = atanF((max_t - e.offset) * inv_scale);
+        e.angle_extent = angle_max - e.angle_min;
+        e.min_t = min_t;
+        e.max_t = max_t;
+        return e;
+    }
+    ZD float sample(float u, float& t) const {
+        const float lt = scale * tanF(angle_min + u * angle_extent);
+        const float p = scale / (angle_extent * (scale_sqr + lt * lt));
+        t = clampf(lt + offset, min_t, max_t);
+        return p;
+    }
+    ZD float pdf(float t) const {
+        if (min_t <= t && t < max_t) {
+            const float lt = t - offset;
+            return scale / (angle_extent * (scale_sqr + lt * lt));
+        }
+        return 0.f;
+    }
+    ZD float pdfAndSample(float t, float& u) const {
+        const float lt = t - offset;
+        u = clampf((atanF(lt / scale) - angle_min) / angle_extent, 0.f, 1.f);
+        return scale / (angle_extent * (scale_sqr + lt * lt));
+    }
+};
+// Disk.sampleTo (disk.zig:252-324): the set-up shared by a light's samples; sample() makes one sample's draws (a 2-D one,
+// then a 1-D one unless the chord degenerates) from `smp`
+struct DiskSampler {
+    f3                  lp;
+    DiskSamplerData     dsd;
+    EquiAngularSampling eas0;
+    float               radius, nsf;
+    bool                valid;
+    ZD static DiskSampler init(f3 p, const Trafo& trafo, uint32_t num_samples) {
+        DiskSampler d;
+        d.radius = 0.5f * trafo.scale.x;
+        d.nsf = float(num_samples);
+        d.lp = trafo.worldToObjectNormal(p - trafo.position);  // worldToFramePoint
+        d.dsd = DiskSamplerData::init(d.lp);
+        d.eas0 = EquiAngularSampling::init(d.lp, S3(0.f), d.dsd.yd, -d.radius, d.radius);
+        d.valid = 0.f != d.eas0.angle_extent;
+        return d;
+    }
+    ZD bool sample(Sampler& smp, f3 p, f3 n, const Trafo& trafo, bool two_sided, bool total_sphere, SampleTo& out) const {
+        float r0, r1;
+        smp.sample2D(r0, r1);
+        float x, y;
+        diskConcentric(r0, r1, x, y);
+        float u = x;
+        float pdf_ = sqrtf(1.f - u * u) / (0.25f * kPi);
+        u = (u + 1.f) * 0.5f;
+        float y_coord;
+        pdf_ *= eas0.sample(u, y_coord);
+        const float x_chord = sqrtf(radius * radius - y_coord * y_coord);
+        if (0.f == x_chord) return false;
+        const EquiAngularSampling eas1 = EquiAngularSampling::init(lp, S3(y_coord) * dsd.yd, dsd.xd, -x_chord, x_chord);
+        if (0.f == eas1.angle_extent) return false;
+        float x_coord;
+        pdf_ *= eas1.sample(smp.sample1D(), x_coord);
+        const f3 l_direction = S3(x_coord) * dsd.xd + S3(y_coord) * dsd.yd - lp;
+        const f3 axis = trafo.objectToWorldNormal(l_direction);
+        const f3 ws = p + axis;
+        f3       wn = trafo.r2;
+        if (two_sided && dot3(wn, ws - p) > 0.f) wn = -wn;
+        const float sl = squaredLength3(axis);
+        const f3    dir = axis / S3(sqrtf(sl));
+        const float c = -dot3(wn, dir);
+        if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) return false;
+        out.p = ws;
+        out.n = wn;
+        out.wi = dir;
+        out.pdf = (nsf * pdf_ * sl) / c;
+        out.u = u;
+        out.v = (y + 1.f) * 0.5f;
+        return true;
+    }
+};
+ZD float diskPdf(f3 dir, f3 p, const Trafo& trafo, f3 frag_p, uint32_t num_samples) {  // disk.zig:492-533
+    const float               c = fabsf(dot3(trafo.r2, dir));
+    const float               nsf = float(num_samples);
+    const float               radius = 0.5f * trafo.scale.x;
+    const f3                  d = p - frag_p;
+    const float               sl = dot3(d, d);  // squaredDistance3
+    const f3                  lp = trafo.worldToObjectNormal(p - trafo.position);
+    const DiskSamplerData     dsd = DiskSamplerData::init(lp);
+    const EquiAngularSampling eas0 = EquiAngularSampling::init(lp, S3(0.f), dsd.yd, -radius, radius);
+    const f3                  l_point = trafo.worldToObjectNormal(frag_p - trafo.position);
+    const float               y_coord = dot3(l_point, dsd.yd);
+    float                     u;
+    const float               eas_pdf = eas0.pdfAndSample(y_coord, u);
+    u = u * 2.f - 1.f;
+    float pdf_ = sqrtf(1.f - u * u) / (0.25f * kPi);
+    pdf_ *= eas_pdf;
+    const float               x_chord = sqrtf(radius * radius - y_coord * y_coord);
+    const EquiAngularSampling eas1 = EquiAngularSampling::init(lp, S3(y_coord) * dsd.yd, dsd.xd, -x_chord, x_chord);
+    const float               x_coord = dot3(l_point, dsd.xd);
+    pdf_ *= eas1.pdf(x_coord);
+    return (nsf * pdf_ * sl) / c;
+}
+
 // ---------------------------------------------------------------- Distant lights (distant.zig:21-146)
 
 ZD float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - sqrtf(1.f / (radius * radius + 1.f))); }

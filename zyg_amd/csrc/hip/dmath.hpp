@@ -131,6 +131,30 @@ ZD float acosF(float x) {
     return 2.f * (df + w);
 }
 
+// @tan -> compiler-rt tanf = musl tanf.c (__tandf in double precision); called with angles from atan, |x| < pi/2
+// (disk.zig:229-234); beyond 5 pi / 4 the device has no libm fallback and returns tanf of the reduced argument's class
+ZD float tandf(double x, bool odd) {
+    const double T0 = 0x15554d3418c99f.0p-54, T1 = 0x1112fd38999f72.0p-55, T2 = 0x1b54c91d865afe.0p-57, T3 = 0x191df3908c33ce.0p-58,
+                 T4 = 0x185dadfcecf44e.0p-61, T5 = 0x1362b9bf971bcd.0p-59;
+    const double z = x * x;
+    const double r = T4 + z * T5;
+    const double t = T2 + z * T3;
+    const double w = z * z;
+    const double s = z * x;
+    const double u = T0 + z * T1;
+    const double r0 = (x + s * u) + (s * w) * (t + w * r);
+    return float(odd ? -1.0 / r0 : r0);
+}
+ZD float tanF(float x) {
+    const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
+    const bool     sign = 0 != (hx >> 31);
+    const double   xd = double(x);
+    const double   pio2 = 1.57079632679489661923;
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? x : tandf(xd, false);
+    if (ix <= 0x4016cbe3u) return tandf(sign ? xd + pio2 : xd - pio2, true);
+    return tandf(sign ? xd + 2 * pio2 : xd - 2 * pio2, false);
+}
+
 // atanf / atan2f with the msun algorithms (Zig std.math.atan / atan2 are ports of musl's s_atanf.c / e_atan2f.c)
 ZD float atanF(float x) {
     const float    atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};

@@ -634,9 +634,10 @@ ZD bool glassVisibility(const ZygpuMaterial& m, f3 wi, f3 geo_n, float o, f3& tr
     return false;
 }
 // Material.visibility (material.zig:227-248): the mask's opacity, drawn with the path's sampler, scales the transmittance
-template <typename Draw>
+// MASKS = false: no material of the scene has a mask (opacity 1); the texture code stays out of the kernel
+template <bool MASKS, typename Draw>
 ZD bool materialVisibility(const DScene& s, const ZygpuMaterial& m, f3 wi, f3 geo_n, float u, float v, Draw& draw, f3& tr) {
-    const float o = maskOpacity(s, m, u, v, draw);
+    const float o = MASKS ? maskOpacity(s, m, u, v, draw) : 1.f;
     if (ZYGPU_MAT_GLASS == m.kind) return glassVisibility(m, wi, geo_n, o, tr);
     if (o < 1.f) {
         tr = tr * S3(1.f - o);
@@ -648,7 +649,7 @@ ZD bool materialVisibility(const DScene& s, const ZygpuMaterial& m, f3 wi, f3 ge
 // Scene.visibility with transmittance (prop_tree.zig:185-240, prop.zig:199-237, shape.zig:235-245): props whose materials
 // evaluate visibility (thin Glass, opacity masks) attenuate `tr` instead of blocking (rectangle.zig:154-186,
 // sphere.zig:176-228, disk.zig:136-170, triangle_tree.zig:244-306); true = not blocked
-template <bool STATS, typename Draw>
+template <bool STATS, bool MASKS, typename Draw>
 ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw& draw) {
     const bool blocked = bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
@@ -662,7 +663,7 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (!rectangleIntersect(ray, trafo, t, u, v)) continue;
-                if (!evaluate || !materialVisibility(s, s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, 0.5f * (u + 1.f),
+                if (!evaluate || !materialVisibility<MASKS>(s, s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, 0.5f * (u + 1.f),
                                                      0.5f * (v + 1.f), draw, tr))
                     return true;
             } else if (ZYGPU_SHAPE_SPHERE == prop.shape) {
@@ -686,8 +687,8 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
                         if (!(ts[k] >= ray.min_t && ray.max_t >= ts[k])) continue;
                         const f3 n = normalize3(ray.point(ts[k]) - trafo.position);
                         float    uu = 0.f, vv = 0.f;
-                        if (kNull != m.mask_image) sphereUv(trafo, n, uu, vv);
-                        if (!materialVisibility(s, m, ray.direction, n, uu, vv, draw, tr)) return true;
+                        if (MASKS && kNull != m.mask_image) sphereUv(trafo, n, uu, vv);
+                        if (!materialVisibility<MASKS>(s, m, ray.direction, n, uu, vv, draw, tr)) return true;
                     }
                 }
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
@@ -706,8 +707,8 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
                         const ZygpuMaterial& m = s.materials[s.material_ids[prop.parts_start + mesh.triangle_parts[k]]];
                         if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return true;
                         float uv0 = 0.f, uv1 = 0.f;
-                        if (kNull != m.mask_image) meshInterpolateUv(mesh, k, u, v, uv0, uv1);
-                        if (!materialVisibility(s, m, local.direction, normalize3(cross3(b - a, c - a)), uv0, uv1, draw, tr)) return true;
+                        if (MASKS && kNull != m.mask_image) meshInterpolateUv(mesh, k, u, v, uv0, uv1);
+                        if (!materialVisibility<MASKS>(s, m, local.direction, normalize3(cross3(b - a, c - a)), uv0, uv1, draw, tr)) return true;
                     }
                     return false;
                 });
@@ -715,7 +716,7 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
             } else if (ZYGPU_SHAPE_DISK == prop.shape) {  // the material decides (Material.visibility)
                 float t, u, v;
                 if (!diskIntersect(ray, trafo, t, u, v)) continue;
-                if (!evaluate || !materialVisibility(s, s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, 0.5f * (1.f + u),
+                if (!evaluate || !materialVisibility<MASKS>(s, s.materials[s.material_ids[prop.parts_start]], ray.direction, trafo.r2, 0.5f * (1.f + u),
                                                      0.5f * (1.f + v), draw, tr))
                     return true;
             } else if (ZYGPU_SHAPE_CUBE == prop.shape) {  // cube.zig:69-80: always blocks
@@ -729,7 +730,7 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
 template <bool STATS>
 ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr) {
     NoDraw none;
-    return sceneVisibilityTr<STATS>(s, ray, cnt, tr, none);
+    return sceneVisibilityTr<STATS, false>(s, ray, cnt, tr, none);
 }
 
 struct Fragment {  // shape/intersection.zig:64-124

@@ -663,6 +663,9 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             } else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) {  // Sphere.emission (sphere.zig:269-277)
                 float t;
                 if (sphereIntersect(ray, trafo, t)) record(p, 0, t, 0.f, 0.f);
+            } else if (EXTRA && ZYGPU_SHAPE_DISK == prop.shape) {  // Disk.emission (disk.zig:171-179)
+                float t, u, v;
+                if (diskIntersect(ray, trafo, t, u, v)) record(p, 0, t, u, v);
             } else if (EXTRA && ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 // TriangleTree.emission (triangle_tree.zig:405-483): every triangle the ray crosses, no max_t shrinking
                 const DMesh& mesh = s.meshes[prop.mesh];
@@ -791,6 +794,8 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
         sample_pdf = 1.f / distantSolidAngle(frag.trafo.scale.x);
     } else if (MESHL && ZYGPU_SHAPE_SPHERE == s.props[light.prop].shape) {  // -> sphere.zig:469-485
         sample_pdf = spherePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
+    } else if (MESHL && ZYGPU_SHAPE_DISK == s.props[light.prop].shape) {  // -> disk.zig:492-533
+        sample_pdf = diskPdf(ray_direction, v.vorigin, frag.trafo, frag.p, numSamples(light.num_samples, v.light_split_threshold));
     } else if (MESHL && ZYGPU_SHAPE_DOME == s.props[light.prop].shape) {  // -> dome.zig:214-220
         sample_pdf = translucent ? 1.f / (4.f * kPi) : 1.f / (2.f * kPi);
     } else if (MESHL && ZYGPU_SHAPE_CANOPY == s.props[light.prop].shape) {  // shape.zig:483
@@ -883,6 +888,9 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
         } else if (MESHL && ZYGPU_SHAPE_SPHERE == prop.shape) {
             frag.primitive = 0;
             sphereFragment(ray, frag);
+        } else if (MESHL && ZYGPU_SHAPE_DISK == prop.shape) {
+            frag.primitive = 0;
+            diskFragment(ray, frag);
         } else {
             frag.primitive = 0;
             rectangleFragment(ray, frag);
@@ -1419,7 +1427,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 // SUBST: the scene holds Substitute materials (zygpu_upload_scene picks the instantiation)
 // MULTI: a light has emittance num_samples > 1; MESHL: the scene has TriangleMesh lights
 // POOL: `slot` below is a vertex index, `ps` the camera sample it belongs to; Glass may return two bxdf samples
-template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL>
+// MASKS: a material of the scene has an opacity mask (shadow rays evaluate it); always on in the STATS instantiations
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS>
 __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     const DScene&      s = c_scene;
     const uint32_t     nxt = P.parity ^ 1u;
@@ -1492,7 +1501,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)
                     // MESHL: the scene may have opacity masks, whose draws come from the path's sampler (material.zig:238-245)
                     auto draw = [&]() { return h.smp.sample1D(); };
-                    if ((POOL || MESHL) ? !sceneVisibilityTr<STATS>(s, shadow, cnt, tr, draw) : !sceneVisibility<STATS, MESHL>(s, shadow, cnt)) return;
+                    constexpr bool kMasks = MASKS && MESHL;
+                    if ((POOL || kMasks) ? !sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw) : !sceneVisibility<STATS, MESHL>(s, shadow, cnt)) return;
                     const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                     const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
@@ -1500,10 +1510,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                         const float light_pdf = ls.pdf * pick.pdf;
                         const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
                         const f3    unocc = S3(weight) * radiance * bx.reflection;
-                        occluded = occluded + ((POOL || MESHL) ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
+                        occluded = occluded + ((POOL || kMasks) ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
                     } else {
                         const float weight = 1.f / (pick.pdf * ls.pdf);
-                        occluded = occluded + S3(weight) * (((POOL || MESHL) ? tr : S3(1.f)) * radiance * bx.reflection);
+                        occluded = occluded + S3(weight) * (((POOL || kMasks) ? tr : S3(1.f)) * radiance * bx.reflection);
                     }
                 };
 
@@ -1573,6 +1583,22 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                             replay.sample2D(s0, s1);
                             SampleTo ls;
                             if (ss.sample(s0, s1, sf.p, ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
+                        }
+                    }
+                } else if (MESHL && ZYGPU_SHAPE_DISK == light_shape) {
+                    const uint32_t    n = numSamples(light.num_samples, sample_threshold);
+                    const DiskSampler ds = DiskSampler::init(sf.p, trafo, n);
+                    if (ds.valid) {  // disk.zig:273-276: no sample, no draw
+                        // a sample's second draw depends on its first: the path's sampler runs the sampling once for its
+                        // draws alone, the copy once more for the samples
+                        Sampler replay = h.smp;
+                        for (uint32_t j = 0; j < n; ++j) {
+                            SampleTo ls;
+                            ds.sample(h.smp, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                        }
+                        for (uint32_t j = 0; j < n; ++j) {
+                            SampleTo ls;
+                            if (ds.sample(replay, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
                         }
                     }
                 } else {

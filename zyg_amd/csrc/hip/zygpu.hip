@@ -210,6 +210,8 @@ __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) 
     } else if (6 == op) {
         out[2 * i] = expF(in[2 * i]);
         out[2 * i + 1] = atan2F(in[2 * i + 1], in[2 * i]);
+    } else if (7 == op) {
+        out[i] = tanF(in[i]);
     } else if (4 == op) {
         const float* a = in + 6 * i;
         const f3     r = offsetRay(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]));
@@ -290,6 +292,7 @@ struct ZygpuContext {
     bool          has_substitute = false;  // selects the kernels' material instantiation
     bool          multi_sample_lights = false;  // a light has emittance num_samples > 1: wf_scatter<.., MULTI>
     bool          mesh_lights = false;          // TriangleMesh emitters: wf_shade<.., MESHL>, wf_scatter<.., MESHL>
+    bool          masks = false;                // a material has an opacity mask: wf_scatter<.., MASKS>
     bool          extra_shapes = false;         // Sphere / Disk / Cube props: wf_intersect<.., EXTRA> and the MESHL instantiations
     bool          pool_mode = false;            // Glass in the scene: the POOL instantiations (split paths, medium stack)
     bool          pool_allocated = false;       // the path pool has the POOL layout
@@ -521,12 +524,12 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         const ZygpuProp& lp = d->props[d->lights[l].prop];
         const bool       is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == lp.shape;
         const bool is_infinite = ZYGPU_SHAPE_DISTANT == lp.shape || ZYGPU_SHAPE_DOME == lp.shape || ZYGPU_SHAPE_CANOPY == lp.shape;
-        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && !is_infinite && ZYGPU_SHAPE_SPHERE != lp.shape) {
+        if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && !is_infinite && ZYGPU_SHAPE_SPHERE != lp.shape && ZYGPU_SHAPE_DISK != lp.shape) {
             g_error = "only Rectangle, TriangleMesh, Sphere, Distant, Dome and Canopy lights are supported on the device path";
             return -2;
         }
         // the same kernel instantiations carry the infinite and Sphere light code
-        if (is_infinite || ZYGPU_SHAPE_SPHERE == lp.shape) c->mesh_lights = true;
+        if (is_infinite || ZYGPU_SHAPE_SPHERE == lp.shape || ZYGPU_SHAPE_DISK == lp.shape) c->mesh_lights = true;
         if (ZYGPU_LIGHT_PROP_IMAGE == d->lights[l].light_class) {
             if ((ZYGPU_SHAPE_DOME != lp.shape && ZYGPU_SHAPE_CANOPY != lp.shape && ZYGPU_SHAPE_RECTANGLE != lp.shape) ||
                 d->lights[l].sampler >= d->num_image_lights) {
@@ -542,6 +545,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             c->mesh_lights = true;
         }
     }
+    c->masks = false;
+    for (uint32_t mi = 0; mi < d->num_materials; ++mi)
+        if (ZYGPU_NULL != d->materials[mi].mask_image) c->masks = true;
     for (uint32_t mi = 0; mi < d->num_materials; ++mi)  // texture fetches live in the MESHL instantiations, too
         if (ZYGPU_NULL != d->materials[mi].color_image || ZYGPU_NULL != d->materials[mi].emission_image || ZYGPU_NULL != d->materials[mi].mask_image)
             c->mesh_lights = true;
@@ -881,6 +887,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                     });
                     timedLaunch(c, 5, [&] {
                         if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, true>), grid, block, 0, c->stream, P);
+                        else if (c->masks) hipLaunchKernelGGL((wf_scatter<false, true, true, true, true, true>), grid, block, 0, c->stream, P);
                         else if (plain) hipLaunchKernelGGL((wf_scatter<false, true, false, false, true>), grid, block, 0, c->stream, P);
                         else hipLaunchKernelGGL((wf_scatter<false, true, true, true, true>), grid, block, 0, c->stream, P);
                     });
@@ -931,6 +938,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
                     if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, false>), grid, block, 0, c->stream, P);
+                    else if (c->masks) hipLaunchKernelGGL((wf_scatter<false, true, true, true, false, true>), grid, block, 0, c->stream, P);
                     else if (c->mesh_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, true, false>), grid, block, 0, c->stream, P);
                     else if (c->multi_sample_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, false, false>), grid, block, 0, c->stream, P);
                     else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false, false, false>), grid, block, 0, c->stream, P);

@@ -1134,7 +1134,8 @@ int Engine::compile(uint32_t frame) {
         const bool is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == s.kind, is_distant = ZYGPU_SHAPE_DISTANT == s.kind;
         const bool is_sphere = ZYGPU_SHAPE_SPHERE == s.kind, is_dome = ZYGPU_SHAPE_DOME == s.kind, is_canopy = ZYGPU_SHAPE_CANOPY == s.kind;
         const bool is_infinite = is_distant || is_dome || is_canopy;
-        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh && !is_infinite && !is_sphere) return -3;  // disk / cube emitters: SURVEY §8(f)
+        const bool is_disk = ZYGPU_SHAPE_DISK == s.kind;
+        if (ZYGPU_SHAPE_RECTANGLE != s.kind && !is_mesh && !is_infinite && !is_sphere && !is_disk) return -3;  // cube emitters: SURVEY §8(f)
         c_light_infinite_[li] = is_infinite ? 1 : 0;
 
         l.num_samples = m.emission_num_samples;  // light_material.zig:68-74 / substitute_material.zig:96-111
@@ -1174,6 +1175,7 @@ int Engine::compile(uint32_t frame) {
         const float extent = is_canopy  ? 2.f * float(M_PI)
                              : is_dome  ? 4.f * float(M_PI)
                              : is_sphere ? (4.f * float(M_PI)) * ((0.5f * t.scale[0]) * (0.5f * t.scale[0]))
+                             : is_disk  ? float(M_PI) * ((0.5f * t.scale[0]) * (0.5f * t.scale[0]))  // shape.zig:143
                              : is_distant ? (2.f * float(M_PI)) * (1.f - std::sqrt(1.f / (t.scale[0] * t.scale[0] + 1.f)))
                              : is_mesh  ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1])
                                         : t.scale[0] * t.scale[1];

@@ -236,7 +236,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
-            light_spectrum=(17.0, 12.0, 4.0), masked=None):
+            light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -247,6 +247,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     glass_objects: None, or a dict: the short box turns into glass (`box` = a glass(...) JSON), a glass Sphere (`sphere`)
     stands in front of the tall box, optionally with a second dielectric inside it (`inner`, nested dielectrics);
     `outside`: a glass Sphere next to the box, in front of the void (alpha through glass with a Transparent sensor).
+    disk_lights: the two emitters are Disks (diameter 0.5, the second one tilted) instead of quads; two_sided_lights: the
+    lamp material is two-sided.
     masked: None, or a dict: `image` (a one-channel numpy mask) and optionally `sampler`, `scale`, `lights` (the lamps are masked
     too), `pane` (a masked thin-glass Rectangle): a masked Rectangle, Sphere and Disk stand in the box and the tall box's
     material is masked (opacity masks need Substitute / Light / Glass materials).
@@ -280,6 +282,10 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         if masked.get("lights"):
             lamp = engine.material(with_mask(light_material(spectrum=light_spectrum, num_samples=light_samples), mask_id, **mask_kw))
 
+    if two_sided_lights:
+        lm = json.loads(light_material(spectrum=light_spectrum, num_samples=light_samples))
+        lm["rendering"]["Light"]["two_sided"] = True
+        lamp = engine.material(json.dumps(lm))
     ids = {"camera": cam, "walls": [], "lights": [], "meshes": []}
 
     def wall(mat, r0, r1, scale, position):
@@ -312,6 +318,15 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (d_, d_, d_), pos_))
             ids["meshes"].append(p)
     for lx in (() if many_lights else (-0.45, 0.45)):  # two emissive quads just below the ceiling, facing down
+        if disk_lights:  # Disk = shape 2; the second one tilted and lower, so that points see it at grazing angles
+            p = engine.prop(2, [lamp], unoccluding=unoccluding_lights)
+            if lx < 0:
+                engine.transformation(p, trafo((1, 0, 0), (0, 0, 1), (0.5, 0.5, 1), (lx, 1.98, 0.0)))
+            else:
+                engine.transformation(p, trafo((0.8, 0.6, 0), (0, 0, 1), (0.6, 0.6, 1), (lx, 1.6, 0.1)))
+            engine.light(p)
+            ids["lights"].append(p)
+            continue
         if sphere_lights:
             p = engine.prop(SPHERE, [lamp], unoccluding=unoccluding_lights)
             engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (0.3, 0.3, 0.3), (lx, 1.7, 0.0)))
