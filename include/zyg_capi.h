@@ -33,7 +33,7 @@ int32_t su_perspective_camera_create(uint32_t width, uint32_t height);  /* capi.
 int32_t su_camera_set_fov(float fov);                                    /* capi.zig:169-176; radians */
 int32_t su_camera_sensor_dimensions(int32_t* dimensions);                /* capi.zig:178-187 */
 int32_t su_exporters_create(const char* json);                           /* capi.zig:189-200 */
-int32_t su_aovs_create(const char* json);                                /* capi.zig:202-213 */
+int32_t su_aovs_create(const char* json);                                /* capi.zig:202-213, take.zig:106-129: {"Albedo": true, ...} */
 int32_t su_sampler_create(uint32_t num_samples);                         /* capi.zig:215-221; always returns -1, as the reference */
 int32_t su_integrators_create(const char* json);                         /* capi.zig:223-234 */
 int32_t su_image_create(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height,

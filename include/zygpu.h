@@ -296,6 +296,11 @@ enum ZygpuSampler { ZYGPU_SAMPLER_RANDOM = 0, ZYGPU_SAMPLER_SOBOL = 1 };
 #define ZYGPU_FILTER_TAPS 30 /* reference sensor.zig:72: InterpolatedFunction1DN(30) */
 
 /* camera (camera_perspective.zig:79-150), integrator (take/take.zig:131-271) and sensor (sensor.zig:27-120) state */
+/* reference rendering/sensor/aov/aov_value.zig:11-21; resolved per class as aov_buffer.zig:48-78 says */
+enum ZygpuAovClass { ZYGPU_AOV_ALBEDO = 0, ZYGPU_AOV_DEPTH = 1, ZYGPU_AOV_MATERIAL_ID = 2, ZYGPU_AOV_GEOMETRIC_NORMAL = 3,
+                     ZYGPU_AOV_SHADING_NORMAL = 4, ZYGPU_AOV_ROUGHNESS = 5, ZYGPU_AOV_EMISSION = 6, ZYGPU_AOV_DIRECT = 7,
+                     ZYGPU_AOV_INDIRECT = 8, ZYGPU_AOV_NUM_CLASSES = 9 };
+
 typedef struct ZygpuViewDesc {
     int32_t  resolution[2];
     int32_t  crop[4]; /* x0, y0, x1, y1 (exclusive end), camera_base.zig:31-41 */
@@ -323,6 +328,8 @@ typedef struct ZygpuViewDesc {
     float    exposure_factor; /* 2^exposure, tonemapper.zig:15 */
     uint32_t alpha_transparency; /* sensor buffer class Transparent (take_loader.zig:193-196, buffer_transparent.zig) */
     uint32_t tonemapper;      /* enum ZygpuTonemapper (tonemapper.zig:9) */
+    /* AOVs (sensor/aov/aov_value.zig:11-48): bit k = class k is recorded; ZygpuAovClass */
+    uint32_t aov_slots;
 } ZygpuViewDesc;
 
 /* tonemapper.zig:9; AgX with the look the take loader picks (take_loader.zig:268-270: Substitute) */
@@ -420,6 +427,11 @@ int zygpu_kernel_time(ZygpuContext* ctx, double* out_ms, uint64_t* out_launches,
  * 4 offsetRay, 6 exp / atan2, 7 tan; strides in floats per item) on host arrays; see tests/test_gpu_units.py. */
 int zygpu_test_eval(ZygpuContext* ctx, uint32_t op, uint32_t n, const float* in, uint32_t in_stride, float* out,
                     uint32_t out_stride);
+
+/* AOVs: Sensor.resolveAov (sensor.zig:491-494, aov_buffer.zig:48-78) of one class into RGBA floats; -2 = the view does not
+ * record that class (capi.zig:620, 637). zygpu_download_aov: the class' raw Pack4f plane (tests). */
+int zygpu_resolve_aov(ZygpuContext* ctx, uint32_t aov_class, float* host_rgba, uint32_t num_pixels);
+int zygpu_download_aov(ZygpuContext* ctx, uint32_t aov_class, float* host_plane);
 
 const char* zygpu_last_error(void);
 

@@ -509,3 +509,58 @@ def test_disk_lights(engine, oracle, integrator, unoccluding, samples, two_sided
     out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, unoccluding_lights=unoccluding, light_samples=samples,
                        disk_lights=True, two_sided_lights=two_sided, material="substitute")
     _check(*out, 3)
+
+
+@pytest.mark.parametrize("integrator,filter_name,kw", [
+    ("PTMIS", None, dict(material="substitute", spheres=True)),
+    ("PT", None, dict(material="lambert")),
+    ("PTDL", "Mitchell", dict(material="substitute", disk_and_cube=True)),
+    ("PTMIS", "Blackman", dict(material="substitute", glass_objects={"sphere": scenes.glass(1.5), "box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, roughness=0.3)})),
+])
+def test_aovs(engine, oracle, integrator, filter_name, kw):
+    """AOVs (worker.zig:209-241, sensor.zig:197-218 / 244-277 / 328-380, aov_buffer.zig): all nine classes, raw planes and
+    resolved images against the oracle; radius-0 sensors bit-identical, filtered ones within the film tolerance (the oracle's
+    tiles splat their borders with atomics in thread order)."""
+    from util import AOV_NAMES, oracle_render_aovs, oracle_resolve_aov
+    w, h, spp = 72, 54, 3
+    engine.aovs(AOV_NAMES)
+    scenes.cornell(engine, w, h, spp, integrator=integrator, filter_name=filter_name, **kw)
+    engine.start_frame(0)
+    engine.render_iterations(spp)
+    engine.synchronize()
+    film = engine.download_film(w, h)
+    sd = engine.lib.su_ext_scene_desc().contents
+    vd = engine.lib.su_ext_view_desc().contents
+    assert vd.aov_slots == 0x1FF
+    cpu_film, cpu_planes = oracle_render_aovs(oracle, sd, vd, spp, threads=1 if filter_name else None)
+    exact = filter_name is None
+    assert np.array_equal(film, cpu_film) if exact else np.allclose(film, cpu_film, rtol=1e-4, atol=2e-4)
+    for k, name in enumerate(AOV_NAMES):
+        plane = engine.download_aov(k, w, h)
+        if exact or k in (1, 2):  # Depth and MaterialId take no filter weights
+            assert np.array_equal(plane, cpu_planes[k]), name
+        else:
+            np.testing.assert_allclose(plane, cpu_planes[k], rtol=1e-4, atol=2e-4, err_msg=name)
+        resolved = engine.resolve_aov(k, w, h)
+        ref = oracle_resolve_aov(oracle, vd, k, cpu_planes[k])
+        tol = 1e-6 if exact or k in (1, 2) else 2e-3
+        same = np.isclose(resolved, ref, rtol=tol, atol=tol) | (np.isnan(resolved) & np.isnan(ref))
+        assert same.all(), name
+    # what the classes mean: normals at most unit length (samples that end before their first material sample leave zeros),
+    # ids of the scene's materials
+    gn = engine.resolve_aov(3, w, h)[..., :3]
+    if exact:
+        assert np.nanmax(np.linalg.norm(gn, axis=-1)) <= 1.0 + 1e-5 and np.nanmax(np.linalg.norm(gn, axis=-1)) > 0.99
+    ids = engine.download_aov(2, w, h)[..., 0]
+    assert 1 <= ids.max() <= sd.num_materials
+
+
+def test_aov_inactive_class_reports_minus_two(engine):
+    """capi.zig:620, 637: resolving a class the take does not record returns -2."""
+    engine.aovs(["Depth"])
+    scenes.cornell(engine, 32, 24, 1)
+    engine.start_frame(0)
+    engine.render_iterations(1)
+    engine.synchronize()
+    assert engine.resolve_aov(1, 32, 24) is not None
+    assert engine.resolve_aov(0, 32, 24) is None and engine.resolve_aov(8, 32, 24) is None

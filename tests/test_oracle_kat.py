@@ -558,3 +558,36 @@ def test_disk_lights_match_their_closed_form_and_integrators_agree(product_lib, 
             means[integ] = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))[..., :3].mean(axis=(0, 1))
     np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.02)
     np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.04)
+
+
+def test_aov_known_answers(product_lib, oracle):
+    """AOVs of the open Cornell box seen from the front (worker.zig:209-241, aov_buffer.zig:48-78): the back wall's pixels
+    carry its normal (0, 0, -1), its depth along the ray, its albedo and material id; Emission + Direct + Indirect resolve to
+    the beauty image (Linear tonemapper, exposure 0); inactive classes stay out."""
+    from util import AOV_NAMES, oracle_render_aovs, oracle_resolve_aov
+    w, h, spp = 48, 36, 16
+    with zyg_amd.Engine(product_lib) as e:
+        e.aovs(AOV_NAMES)
+        ids = scenes.cornell(e, w, h, spp, integrator="PTMIS", boxes=False)
+        sd, vd = e.compile()
+        assert vd.aov_slots == 0x1FF
+        film, planes = oracle_render_aovs(oracle, sd, vd, spp)
+        beauty = oracle_resolve(oracle, vd, film)
+        res = {k: oracle_resolve_aov(oracle, vd, k, planes[k]) for k in range(9)}
+        back_material = sd.material_ids[sd.props[ids["walls"][2]].parts_start]
+        ap1 = np.array(list(sd.materials[back_material].color_a))
+    cy, cx = h // 2, w // 2  # the back wall, z = +1, seen from z = -3.9 at height 1
+    np.testing.assert_allclose(res[3][cy, cx, :3], [0, 0, -1], atol=1e-6)
+    np.testing.assert_allclose(res[4][cy, cx, :3], [0, 0, -1], atol=1e-6)
+    assert abs(res[1][cy, cx, 0] - 4.9) < 0.02  # the nearest of the pixel's samples
+    np.testing.assert_allclose(res[5][cy, cx, 0], 1.0, atol=1e-6)  # Debug material: alpha 1
+    assert res[2][cy, cx, 0] == 1 + back_material
+    # albedo = the wall's colour (AP1 -> sRGB primaries on resolve)
+    to_srgb = np.array([[1.70505155, -0.62179068, -0.08325840], [-0.13025714, 1.14080289, -0.01054853], [-0.02400328, -0.12896877, 1.15297171]])
+    np.testing.assert_allclose(res[0][cy, cx, :3], to_srgb @ ap1, rtol=1e-5)
+    np.testing.assert_allclose((res[6] + res[7] + res[8])[..., :3], beauty[..., :3], rtol=2e-4, atol=1e-5)
+    with zyg_amd.Engine(product_lib) as e:
+        e.aovs(["Depth", "Albedo"])
+        scenes.cornell(e, 16, 12, 1)
+        _, vd = e.compile()
+        assert vd.aov_slots == 0b11

@@ -34,6 +34,40 @@ def oracle_render_alpha(oracle, scene_desc, view_desc, iterations, threads=None)
     return film, alpha
 
 
+AOV_NAMES = ["Albedo", "Depth", "MaterialId", "GeometricNormal", "ShadingNormal", "Roughness", "Emission", "Direct", "Indirect"]
+
+
+def oracle_render_aovs(oracle, scene_desc, view_desc, iterations, threads=None):
+    """Returns (film, {class: raw plane}) for the classes view_desc.aov_slots names; planes cleared as aov_buffer.zig:36-46."""
+    w, h = view_desc.resolution[0], view_desc.resolution[1]
+    film = np.zeros((h, w, 4), dtype=np.float32)
+    planes = {}
+    ptrs = (ctypes.c_void_p * 9)()
+    for k in range(9):
+        if view_desc.aov_slots & (1 << k):
+            planes[k] = np.zeros((h, w, 4), dtype=np.float32)
+            if k == 1:
+                planes[k][..., :3] = np.finfo(np.float32).max
+            ptrs[k] = planes[k].ctypes.data
+    st = zyg_amd.Stats()
+    oracle.zyg_oracle_render_aovs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                              ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(zyg_amd.Stats)]
+    rc = oracle.zyg_oracle_render_aovs(ctypes.addressof(scene_desc), ctypes.addressof(view_desc), 0, 0, iterations, 1, 0, h,
+                                       film.ctypes.data, None, ctypes.cast(ptrs, ctypes.c_void_p), threads or (os.cpu_count() or 1),
+                                       ctypes.byref(st))
+    assert rc == 0
+    return film, planes
+
+
+def oracle_resolve_aov(oracle, view_desc, aov_class, plane):
+    h, w = plane.shape[:2]
+    out = np.zeros_like(plane)
+    oracle.zyg_oracle_resolve_aov.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    assert oracle.zyg_oracle_resolve_aov(ctypes.addressof(view_desc), aov_class, plane.ctypes.data, out.ctypes.data, w * h) == 0
+    return out
+
+
 def oracle_resolve(oracle, view_desc, film):
     h, w = film.shape[:2]
     out = np.zeros_like(film)

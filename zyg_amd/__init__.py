@@ -6,6 +6,7 @@ src/blender-plugin/engine.py:25-381): a thin ctypes layer over `libzyg_amd.so`, 
 CPU fallback: rendering needs the HIP library and a GPU and fails loudly otherwise.
 """
 import ctypes
+import json
 import os
 
 import numpy as np
@@ -131,7 +132,8 @@ class ViewDesc(ctypes.Structure):
                 ("filter_radius", ctypes.c_float), ("filter_samples", ctypes.c_float * (FILTER_TAPS + 1)),
                 ("clamp_emission", ctypes.c_float), ("clamp_direct", ctypes.c_float),
                 ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float),
-                ("alpha_transparency", ctypes.c_uint32), ("tonemapper", ctypes.c_uint32)]
+                ("alpha_transparency", ctypes.c_uint32), ("tonemapper", ctypes.c_uint32),
+                ("aov_slots", ctypes.c_uint32)]
 
 
 class Stats(ctypes.Structure):
@@ -232,6 +234,33 @@ class Engine:
     def integrators(self, json_text):
         if self.lib.su_integrators_create(json_text.encode()) != 0:
             raise RuntimeError("su_integrators_create failed")
+
+    def aovs(self, names):
+        """su_aovs_create (capi.zig:202-213): e.g. ["Albedo", "Depth"]."""
+        if self.lib.su_aovs_create(json.dumps({n: True for n in names}).encode()) != 0:
+            raise RuntimeError("su_aovs_create failed")
+
+    def download_aov(self, aov_class, width, height):
+        """The raw {sum w v, sum w} plane of one AOV class, or None when the view does not record it."""
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        self.lib.zygpu_download_aov.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        rc = self.lib.zygpu_download_aov(self.context(), aov_class, out.ctypes.data)
+        if rc == -2:
+            return None
+        if rc != 0:
+            raise RuntimeError("zygpu_download_aov failed")
+        return out
+
+    def resolve_aov(self, aov_class, width, height):
+        """su_resolve_frame_to_buffer(aov < 9, ...): the resolved AOV, or None for rc -2 (class not recorded)."""
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        self.lib.su_resolve_frame_to_buffer.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        rc = self.lib.su_resolve_frame_to_buffer(aov_class, width, height, out.ctypes.data)
+        if rc == -2:
+            return None
+        if rc != 0:
+            raise RuntimeError("su_resolve_frame_to_buffer failed")
+        return out
 
     def sensor(self, json_text):
         if self.lib.su_ext_sensor_create(json_text.encode()) != 0:

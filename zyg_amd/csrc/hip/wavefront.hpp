@@ -167,6 +167,11 @@ struct Params {
     float2*  stage_uv;     // per sample: pixel_uv
     float4*  film;
     float*   film_alpha;  // Transparent sensor only (else null): sum of weight * alpha per pixel
+    // AOVs (c_view.v.aov_slots != 0): per sample the worker's aov.Value, classes Albedo .. Roughness in planes of `aov_plane`
+    // samples; per pixel the Pack4f plane of the class film_accumulate_aov is launched for
+    float4*  stage_aov;
+    size_t   aov_plane;
+    float4*  aov_film;
     uint32_t parity;  // current extension-queue side
     uint32_t queue_capacity;  // entries every queue array holds
     uint32_t round;   // POOL: which vertex of the level this launch handles
@@ -544,8 +549,15 @@ ZD bool entersMeshBounds(f3 origin, f3 direction) {
 // ---------------------------------------------------------------- wf_generate
 // Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
 // Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
-template <bool POOL>
+template <bool POOL, bool AOV = false>
 ZD void generatePath(const Params& P, uint32_t slot) {
+    if (AOV && c_view.v.aov_slots) {  // aov.Value.clear (aov_value.zig:62-73): Depth starts at f32 max
+#pragma unroll
+        for (uint32_t k = 0; k < 6; ++k) {
+            const float d = ZYGPU_AOV_DEPTH == k ? FLT_MAX : 0.f;
+            P.stage_aov[k * P.aov_plane + slot] = make_float4(d, d, d, d);
+        }
+    }
 
     int      x, y;
     uint32_t iteration;
@@ -617,7 +629,7 @@ __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths)
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const bool     valid = slot < num_paths;
     if (0 == slot) P.ctl->bound[1] = num_paths;  // tick 0's wf_intersect reads the previous tick's bound
-    if (valid) generatePath<POOL>(P, slot);
+    if (valid) generatePath<POOL, true>(P, slot);
     const bool back = valid && entersMeshBounds(xyz4(P.pool.ray_o[slot]), xyz4(P.pool.ray_d[slot]));
     queuePush(extQueue<POOL>(P, P.parity, 0), extCount<POOL>(P, P.parity, 0), P.queue_capacity, valid, slot, back);
 }
@@ -1122,7 +1134,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
         uint32_t slot = 0;
         if (i < n) {
             slot = FIRST ? i : P.q.ext[cur][at];
-            if (FIRST) generatePath<false>(P, slot);
+            if (FIRST) generatePath<false, MESHL>(P, slot);
             const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
             const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0[slot].y;
             const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
@@ -1156,6 +1168,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
 struct Surface {
     f3             p;
     f3             frag_geo_n;  // the fragment's own geometric normal (before the two-sided flip), for Fragment.offsetP
+    uint32_t       material;    // scene.propMaterialId(frag.prop, frag.part)
     MaterialSample ms;
 };
 
@@ -1185,6 +1198,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
         Surface    sf;
         sf.p = frag.p;
         sf.frag_geo_n = frag.geo_n;
+        sf.material = s.material_ids[s.props[frag.prop].parts_start + frag.part];
         sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color);
         return sf;
     }
@@ -1201,6 +1215,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     Surface      sf;
     sf.p = xyz4(rp);
     sf.frag_geo_n = 0.f != rg.w ? -geo_n : geo_n;
+    sf.material = __float_as_uint(rp.w);
     if (POOL) {
         const float2 ri = P.pool.rec_ior[slot];
         sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y);
@@ -1208,6 +1223,28 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
         sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color);
     }
     return sf;
+}
+
+// Worker.commonAOV (worker.zig:209-241) into the sample's staged aov.Value; POOL: the sample's vertices in their order
+ZD void commonAov(const Params& P, uint32_t slot, uint32_t ps, const PathHead& h, const Surface& sf, f3 throughput) {
+    const MaterialSample& ms = sf.ms;
+    const uint32_t        slots = c_view.v.aov_slots;
+    float4*               av = P.stage_aov + ps;
+    if ((h.flags & ST_PRIMARY) && (slots & (1u << ZYGPU_AOV_ALBEDO)) && ms.can_evaluate) {
+        // MaterialSample.aovAlbedo (material_sample.zig:38-45, substitute_sample.zig:80-86)
+        const f3 a = ZYGPU_MAT_SUBSTITUTE == ms.kind ? lerp3(ms.albedo, ms.f0, S3(ms.metallic))
+                     : ZYGPU_MAT_DEBUG == ms.kind    ? ms.albedo
+                     : ZYGPU_MAT_GLASS == ms.kind    ? S3(1.f)
+                                                     : S3(0.f);
+        av[ZYGPU_AOV_ALBEDO * P.aov_plane] = f4(throughput * a);
+    }
+    if (0 == h.depth_surface) {
+        if (slots & (1u << ZYGPU_AOV_GEOMETRIC_NORMAL)) av[ZYGPU_AOV_GEOMETRIC_NORMAL * P.aov_plane] = f4(ms.geo_n);
+        if (slots & (1u << ZYGPU_AOV_SHADING_NORMAL)) av[ZYGPU_AOV_SHADING_NORMAL * P.aov_plane] = f4(ms.frame.z);
+        if (slots & (1u << ZYGPU_AOV_ROUGHNESS)) av[ZYGPU_AOV_ROUGHNESS * P.aov_plane].x = sqrtf(ms.a0);
+        if (slots & (1u << ZYGPU_AOV_DEPTH)) av[ZYGPU_AOV_DEPTH * P.aov_plane].x = __uint_as_float(P.pool.hit[slot].x);
+        if (slots & (1u << ZYGPU_AOV_MATERIAL_ID)) av[ZYGPU_AOV_MATERIAL_ID * P.aov_plane].x = float(1u + sf.material);
+    }
 }
 
 // Fragment.offsetP (intersection.zig:115-119; uvw[3], the offset, is 0 for rectangles and meshes)
@@ -1378,6 +1415,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
         const Surface         sf = loadSurface<false, EXTRA>(P, slot, h.flags);
         const MaterialSample& ms = sf.ms;
         f3                    throughput = xyz4(P.pool.thr[slot]);
+        if (EXTRA && c_view.v.aov_slots) commonAov(P, slot, slot, h, sf, throughput);
 
         if (h.nee & kNeePending) finishLightPick(P, slot, h);
         if (h.nee & kNeeCountMask) ivalueAdd(P, slot, throughput * xyz4(P.pool.nee[slot]), h.depth_surface, 1u, false, false);
@@ -1457,6 +1495,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
         const float4          thr4 = P.pool.thr[slot];
         f3                    throughput = xyz4(thr4);
         const float           split_weight = POOL ? thr4.w : 1.f;
+
+        if (MESHL && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput);
 
         // POOL: the split budget of this vertex (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only: pathtracer.zig:73,
         // pathtracer_dl.zig:82, 160): rough Glass evaluates light samples with it, Glass splits its bxdf sample by it

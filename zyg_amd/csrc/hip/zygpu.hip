@@ -84,6 +84,78 @@ __global__ void __launch_bounds__(256) film_accumulate(Params P) {
     if (P.film_alpha) P.film_alpha[pixel_id] = alpha;
 }
 
+// The AOV part of Sensor.addSample (sensor.zig:197-218, 244-277, 328-380) for one class, as the same gather: Emission /
+// Direct / Indirect are the clamped accumulators of the sample (still in the path pool), the other classes the staged
+// aov.Value; Depth keeps the minimum and MaterialId the heaviest sample of the pixel's own samples (aov_buffer.zig:101-119)
+__global__ void __launch_bounds__(256) film_accumulate_aov(Params P, uint32_t cls) {
+    const int fr = c_view.v.filter_radius_int;
+    const int w = c_view.x_end - c_view.x_begin;
+    const int fy0 = max(c_view.y_begin - fr, c_view.v.crop[1]), fy1 = min(c_view.y_end + fr, c_view.v.crop[3]);
+    const int fx0 = c_view.v.crop[0], fx1 = c_view.v.crop[2];
+    const int fw = fx1 - fx0, fh = fy1 - fy0;
+    const int idx = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= fw * fh) return;
+    const int x = fx0 + idx % fw, y = fy0 + idx / fw;
+
+    float4* pixel = P.aov_film + size_t(c_view.v.resolution[0]) * size_t(y) + size_t(x);
+    float4  value = *pixel;
+    auto    sampleValue = [&](size_t si) {
+        if (ZYGPU_AOV_EMISSION == cls) return clampColor(xyz4(P.pool.emission[si]), c_view.v.clamp_emission);
+        if (ZYGPU_AOV_DIRECT == cls) return clampColor(xyz4(P.pool.direct[si]), c_view.v.clamp_direct);
+        if (ZYGPU_AOV_INDIRECT == cls) return clampColor(xyz4(P.pool.indirect[si]), c_view.v.clamp_indirect);
+        return xyz4(P.stage_aov[cls * P.aov_plane + si]);
+    };
+    const bool own_only = ZYGPU_AOV_DEPTH == cls || ZYGPU_AOV_MATERIAL_ID == cls;
+    for (uint32_t it = 0; it < c_view.batch_iterations; ++it) {
+        const size_t base = size_t(it) * c_view.npix;
+        if (0 == fr || own_only) {
+            if (y < c_view.y_begin || y >= c_view.y_end || x < c_view.x_begin || x >= c_view.x_end) continue;
+            const size_t si = base + size_t(y - c_view.y_begin) * w + size_t(x - c_view.x_begin);
+            const f3     v = sampleValue(si);
+            if (ZYGPU_AOV_DEPTH == cls) {
+                if (v.x < value.x) value.x = v.x;
+            } else if (ZYGPU_AOV_MATERIAL_ID == cls) {
+                float weight = 1.f;
+                if (fr > 0) {  // "wx2 * wy2" for both filter radii (sensor.zig:260, 344): wx[i] = eval(ox + fr - i)
+                    const float2 uv = P.stage_uv[si];
+                    weight = filterEval(uv.x - 0.5f + float(fr - 2)) * filterEval(uv.y - 0.5f + float(fr - 2));
+                }
+                if (weight > value.w) {
+                    value.x = v.x;
+                    value.w = weight;
+                }
+            } else {
+                const f3 wc = S3(1.f) * v;
+                value.x += wc.x;
+                value.y += wc.y;
+                value.z += wc.z;
+                value.w += 1.f;
+            }
+        } else {
+            for (int sy = y - fr; sy <= y + fr; ++sy) {
+                if (sy < c_view.y_begin || sy >= c_view.y_end) continue;
+                for (int sx = x - fr; sx <= x + fr; ++sx) {
+                    if (sx < c_view.x_begin || sx >= c_view.x_end) continue;
+                    const size_t si = base + size_t(sy - c_view.y_begin) * w + size_t(sx - c_view.x_begin);
+                    const float2 uv = P.stage_uv[si];
+                    const float  ox = uv.x - 0.5f, oy = uv.y - 0.5f;
+                    const float  weight = filterEval(ox + float(sx - x)) * filterEval(oy + float(sy - y));
+                    const f3     wc = S3(weight) * sampleValue(si);
+                    value.x += wc.x;
+                    value.y += wc.y;
+                    value.z += wc.z;
+                    value.w += weight;
+                }
+            }
+        }
+    }
+    *pixel = value;
+}
+__global__ void aov_clear(float4* plane, uint32_t n, float value) {  // aov_buffer.zig:36-46
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) plane[i] = make_float4(value, value, value, 0.f);
+}
+
 __global__ void film_clear(float4* film, float* film_alpha, uint32_t n, float weight) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -166,6 +238,23 @@ __global__ void film_resolve(const float4* film, const float* film_alpha, float4
 //  op 3: state.lo, state.hi(seq) -> 4 PCG floats      (2 in as bits, 4 out)
 //  op 4: p.xyz, n.xyz -> offsetRay                    (6 in, 3 out)
 //  op 6: x, y -> expF(x), atan2F(y, x)                 (2 in, 2 out)
+// aov_buffer.zig:48-78
+__global__ void aov_resolve(const float4* plane, float4* out, uint32_t n, uint32_t cls) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = plane[i];
+    if (ZYGPU_AOV_ALBEDO == cls || cls >= ZYGPU_AOV_EMISSION) {
+        const f3 srgb = ap1ToSrgb(mk3(fabsf(p.x), fabsf(p.y), fabsf(p.z)) / S3(p.w));
+        out[i] = make_float4(srgb.x, srgb.y, srgb.z, 1.f);
+    } else if (ZYGPU_AOV_GEOMETRIC_NORMAL == cls || ZYGPU_AOV_SHADING_NORMAL == cls) {
+        out[i] = make_float4(p.x / p.w, p.y / p.w, p.z / p.w, 1.f);
+    } else if (ZYGPU_AOV_ROUGHNESS == cls) {
+        out[i] = make_float4(p.x / p.w, 0.f, 0.f, 1.f);
+    } else {
+        out[i] = make_float4(p.x, 0.f, 0.f, 1.f);
+    }
+}
+
 __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -280,6 +369,9 @@ struct ZygpuContext {
     float2*       stage_uv = nullptr;
     float4*       film = nullptr;         // internal film
     float4*       film_active = nullptr;  // internal or external
+    float4*       aov_film[ZYGPU_AOV_NUM_CLASSES] = {};  // the planes of the view's active AOV classes
+    float4*       stage_aov = nullptr;                   // 6 planes of stage_aov_plane samples
+    size_t        stage_aov_plane = 0;
     float*        film_alpha = nullptr;   // Transparent sensor: sum of weight * alpha (own allocation)
     float*        film_alpha_active = nullptr;
     size_t        film_alpha_pixels = 0;
@@ -755,6 +847,16 @@ int zygpu_set_view(ZygpuContext* c, const ZygpuViewDesc* v) {
         c->resolve_tmp = nullptr;
     }
     c->film_active = c->film;
+    for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES; ++k) {  // aov_buffer.zig:25-34 resize + 36-46 clear
+        if (c->aov_film[k]) (void)hipFree(c->aov_film[k]);
+        c->aov_film[k] = nullptr;
+        if (!(v->aov_slots & (1u << k))) continue;
+        void* d = nullptr;
+        HIP_OK(hipMalloc(&d, pixels * sizeof(float4)));
+        c->aov_film[k] = static_cast<float4*>(d);
+        hipLaunchKernelGGL(aov_clear, dim3((uint32_t(pixels) + 255) / 256), dim3(256), 0, c->stream, c->aov_film[k], uint32_t(pixels),
+                           ZYGPU_AOV_DEPTH == k ? FLT_MAX : 0.f);
+    }
     if (c->film_alpha && (!v->alpha_transparency || pixels != c->film_alpha_pixels)) {
         (void)hipFree(c->film_alpha);
         c->film_alpha = nullptr;
@@ -781,6 +883,9 @@ int zygpu_clear_film(ZygpuContext* c, float weight) {
     HIP_OK(hipSetDevice(c->device));
     const uint32_t n = uint32_t(c->film_pixels);
     hipLaunchKernelGGL(film_clear, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->film_active, c->film_alpha_active, n, weight);
+    for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES; ++k)
+        if (c->aov_film[k])
+            hipLaunchKernelGGL(aov_clear, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->aov_film[k], n, ZYGPU_AOV_DEPTH == k ? FLT_MAX : 0.f);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -814,6 +919,26 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
     const uint32_t rounds = nee ? std::min<uint32_t>(c->num_lights, 64u) : 0u;
     if (0 != ensurePool(c, npix * per_batch, rounds)) return -1;
+    // AOVs: the staged aov.Value of every sample, and the kernel instantiations that write it (the MESHL ones)
+    struct MeshlOverride {
+        ZygpuContext* c;
+        bool          saved;
+        ~MeshlOverride() { c->mesh_lights = saved; }
+    } meshl_override{c, c->mesh_lights};
+    if (v.aov_slots) {
+        c->mesh_lights = true;
+        const size_t need = size_t(npix) * per_batch;
+        if (need > c->stage_aov_plane) {
+            HIP_OK(hipStreamSynchronize(c->stream));
+            if (c->stage_aov) (void)hipFree(c->stage_aov);
+            c->stage_aov = nullptr;
+            c->stage_aov_plane = 0;
+            void* d = nullptr;
+            HIP_OK(hipMalloc(&d, need * 6 * sizeof(float4)));
+            c->stage_aov = static_cast<float4*>(d);
+            c->stage_aov_plane = need;
+        }
+    }
 
     Params P;
     P.pool = c->pool;
@@ -822,6 +947,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     P.stage_color = c->stage_color;
     P.stage_uv = c->stage_uv;
     P.film = c->film_active;
+    P.stage_aov = c->stage_aov;
+    P.aov_plane = c->stage_aov_plane;
+    P.aov_film = nullptr;
     P.film_alpha = c->film_alpha_active;
     P.parity = 0;
     P.round = 0;
@@ -982,6 +1110,12 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         const int fw = v.crop[2] - v.crop[0];
         const uint32_t fn = uint32_t(std::max(0, fh) * std::max(0, fw));
         if (fn) hipLaunchKernelGGL(film_accumulate, dim3((fn + 255) / 256), block, 0, c->stream, P);
+        for (uint32_t k = 0; fn && k < ZYGPU_AOV_NUM_CLASSES; ++k) {
+            if (!c->aov_film[k]) continue;
+            Params pa = P;
+            pa.aov_film = c->aov_film[k];
+            hipLaunchKernelGGL(film_accumulate_aov, dim3((fn + 255) / 256), block, 0, c->stream, pa, k);
+        }
         HIP_OK(hipGetLastError());
         if (c->timing && c->events_used[0] > 4096) {
             HIP_OK(hipStreamSynchronize(c->stream));
@@ -1044,6 +1178,32 @@ int zygpu_set_external_film_alpha(ZygpuContext* c, void* device_alpha) {
     if (!c || !c->has_view || !c->view.alpha_transparency) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     c->film_alpha_active = device_alpha ? static_cast<float*>(device_alpha) : c->film_alpha;
+    return 0;
+}
+
+// Driver.resolveAovToBuffer (capi.zig:626-641): -2 for a class the view does not record
+int zygpu_resolve_aov(ZygpuContext* c, uint32_t cls, float* host_rgba, uint32_t num_pixels) {
+    if (!c || !c->has_view || !host_rgba || cls >= ZYGPU_AOV_NUM_CLASSES) return -1;
+    if (!c->aov_film[cls]) return -2;
+    HIP_OK(hipSetDevice(c->device));
+    const uint32_t n = std::min<uint32_t>(num_pixels, uint32_t(c->film_pixels));
+    if (!c->resolve_tmp) {
+        void* d = nullptr;
+        HIP_OK(hipMalloc(&d, c->film_pixels * sizeof(float4)));
+        c->resolve_tmp = static_cast<float4*>(d);
+    }
+    hipLaunchKernelGGL(aov_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->aov_film[cls], c->resolve_tmp, n, cls);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(host_rgba, c->resolve_tmp, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+int zygpu_download_aov(ZygpuContext* c, uint32_t cls, float* host_plane) {
+    if (!c || !c->has_view || !host_plane || cls >= ZYGPU_AOV_NUM_CLASSES) return -1;
+    if (!c->aov_film[cls]) return -2;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(host_plane, c->aov_film[cls], c->film_pixels * sizeof(float4), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -153,7 +153,17 @@ int32_t su_aovs_create(const char* json) {
     if (!g) return -1;
     zyg::JsonValue v;
     if (!parse(json, v)) return -1;
-    return 0;  // AOV buffers are out of scope; su_resolve_frame(aov < NumClasses) reports -2 (inactive)
+    // View.loadAOV (take.zig:106-129): {"Albedo": true, "Depth": true, ...}
+    static const char* const names[ZYGPU_AOV_NUM_CLASSES] = {"Albedo", "Depth", "MaterialId", "GeometricNormal", "ShadingNormal",
+                                                             "Roughness", "Emission", "Direct", "Indirect"};
+    if (zyg::JsonValue::Object != v.type) return -1;
+    for (const auto& kv : v.obj)
+        for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES; ++k)
+            if (kv.first == names[k]) {
+                if (kv.second.b) g->engine.aov_slots |= 1u << k;
+                else g->engine.aov_slots &= ~(1u << k);
+            }
+    return 0;
 }
 
 int32_t su_sampler_create(uint32_t num_samples) {
@@ -298,9 +308,12 @@ int32_t su_export_frame(void) {
 
 int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height, float* buffer) {
     if (!g || !g->uploaded) return -1;
-    if (aov < 9) return -2;  // View.AovValue.NumClasses == 9, none active (capi.zig:637)
     const uint32_t film_pixels = uint32_t(g->engine.resolution[0]) * uint32_t(g->engine.resolution[1]);
     const uint32_t num_pixels = std::min(width * height, film_pixels);
+    if (aov < ZYGPU_AOV_NUM_CLASSES) {  // capi.zig:637: -2 for a class the take does not record
+        const int r = zygpu_resolve_aov(g->ctx, aov, buffer, num_pixels);
+        return 0 == r ? 0 : -2 == r ? -2 : -1;
+    }
     return 0 == zygpu_resolve(g->ctx, buffer, num_pixels) ? 0 : -1;
 }
 

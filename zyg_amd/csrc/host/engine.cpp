@@ -1321,6 +1321,7 @@ int Engine::compile(uint32_t frame) {
     v.exposure_factor = std::exp2(sensor.exposure);
     v.alpha_transparency = sensor.alpha_transparency ? 1 : 0;
     v.tonemapper = sensor.tonemapper;
+    v.aov_slots = aov_slots;
     return 0;
 }
 

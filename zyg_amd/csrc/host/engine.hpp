@@ -147,6 +147,7 @@ class Engine {
     float    focus_distance = 0.f;
     uint32_t camera_entity = ZYGPU_NULL;
     uint32_t num_samples_per_pixel = 1;  // capi.zig:99
+    uint32_t aov_slots = 0;              // take.view.aovs (take.zig:106-129): bit = ZygpuAovClass
     uint32_t sampler_kind = ZYGPU_SAMPLER_SOBOL;
     float    specular_threshold;
 
