@@ -250,10 +250,10 @@ def test_many_lights_tree(engine, oracle):
 
 
 def test_unsupported_features_fail_loudly(engine):
-    """A disk light is outside the hot-path scope: compile reports it instead of silently rendering something else."""
+    """A Cube light is outside the hot-path scope: compile reports it instead of silently rendering something else."""
     engine.camera(8, 8)
     lamp = engine.material(scenes.light_material())
-    p = engine.prop(2, [lamp])  # built-in Disk (resource/manager.zig:36-44)
+    p = engine.prop(1, [lamp])  # built-in Cube (resource/manager.zig:36-44)
     engine.light(p)
     with pytest.raises(RuntimeError):
         engine.compile()
