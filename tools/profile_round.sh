@@ -14,6 +14,8 @@ python3 tools/pmc_summary.py $O/write > $O/pmc_tcc.txt 2>&1
 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --scene cornell_mesh > $O/bench_cfg2.json 2>/dev/null
 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --material substitute > $O/bench_substitute.json 2>/dev/null
 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --nee staged > $O/bench_staged.json 2>/dev/null
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --scene outdoor > $O/bench_outdoor.json 2>/dev/null
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --scene cornell_glass > $O/bench_glass.json 2>/dev/null
 find $O -name "*kernel_stats.csv" | head; ls $O
 # keep only small files
 find $O -name "*.csv" -size +3M -delete
