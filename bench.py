@@ -42,6 +42,10 @@ def main():
                          "or wf_intersect and wf_shade apart")
     ap.add_argument("--nee", default="in-place", choices=["in-place", "staged"],
                     help="zygpu option nee_in_place: wf_scatter (default) or the wf_nee / wf_shadow rounds + wf_extend")
+    ap.add_argument("--precise", type=int, default=1, choices=[0, 1],
+                    help="zygpu option precise: 1 = the reference's arithmetic bit for bit (verification mode, film identical to "
+                         "the oracle's), 0 = relaxed arithmetic (native divide / sqrt, contraction, OCML f32 functions) within the "
+                         "RMS <= 1e-3 contract")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -92,6 +96,7 @@ def main():
     if args.batch_mpaths:
         assert lib.zygpu_set_option(ctx, b"batch_mpaths", args.batch_mpaths) == 0
     assert lib.zygpu_set_option(ctx, b"fuse_trace_shade", args.fuse) == 0
+    assert lib.zygpu_set_option(ctx, b"precise", args.precise) == 0, lib.zygpu_last_error().decode()
     fused = bool(args.fuse) and args.scene in ("cornell", "cornell_mesh")  # POOL scenes always run the kernels apart
     nee_in_place = args.nee == "in-place"
     assert lib.zygpu_set_option(ctx, b"nee_in_place", 1 if nee_in_place else 0) == 0

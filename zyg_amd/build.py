@@ -1,23 +1,40 @@
 """Builds libzyg_amd.so in-tree: host C++ (scene compile + su_* ABI) and the gfx950 HIP kernels.
 
-    python -m zyg_amd.build
+    python -m zyg_amd.build [--mode both|precise|relaxed] [--units 0,4,6] [--jobs N] [extra hipcc flags]
 
--ffp-contract=off everywhere: the reference (Zig) fuses a*b+c only at its explicit @mulAdd sites, which the
-sources reproduce with fmaf / __fmaf_rn; correctly rounded f32 divide/sqrt is hipcc's default.
+The device code is compiled as translation units in parallel (csrc/hip/kernel_table.hpp): zygpu.hip (film kernels + the
+zygpu_* ABI) and kernels.hip once per unit and arithmetic mode.  Objects are kept in zyg_amd/build/ and reused while they
+are newer than every source and header; `--units` recompiles only the named kernel units (development: the others must
+already be built).
+
+Precise units: -ffp-contract=off (the reference, Zig, fuses a*b+c only at its explicit @mulAdd sites, which the sources
+reproduce with fmaf / __fmaf_rn); correctly rounded f32 divide/sqrt is hipcc's default.  Relaxed units (-DZYG_FAST=1): native
+divide / sqrt, contraction allowed, OCML f32 transcendentals (dmath.hpp); no -ffast-math: the slab tests rely on inf and NaN.
 """
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(HERE, "libzyg_amd.so")
+OBJ = os.path.join(HERE, "build")
+HIP = os.path.join(HERE, "csrc", "hip")
+HOST = os.path.join(HERE, "csrc", "host")
+NUM_UNITS = 8  # kernel_table.hpp ZYG_NUM_UNITS
 
-SOURCES = [
-    os.path.join(HERE, "csrc", "hip", "zygpu.hip"),
-    os.path.join(HERE, "csrc", "host", "engine.cpp"),
-    os.path.join(HERE, "csrc", "host", "capi.cpp"),
-]
+SOURCES = [os.path.join(HIP, "zygpu.hip"), os.path.join(HIP, "kernels.hip"), os.path.join(HOST, "engine.cpp"),
+           os.path.join(HOST, "capi.cpp")]
+
+# -disable-promote-alloca-to-vector: the per-lane traversal stacks stay in (sparsely touched) scratch instead of
+# being turned into ~110 VGPRs with waterfall indexing, which is what keeps wf_scatter / wf_nee at 2 waves/SIMD
+COMMON = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-mllvm", "-disable-promote-alloca-to-vector", "-Wall",
+          "-Wno-unused-function"]
+PRECISE = ["-ffp-contract=off"]
+RELAXED = ["-DZYG_FAST=1", "-Dzd=zdf", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 
 
 def hipcc():
@@ -27,14 +44,67 @@ def hipcc():
     return "hipcc"
 
 
-def build(verbose=True, extra=()):
-    # -disable-promote-alloca-to-vector: the per-lane traversal stacks stay in (sparsely touched) scratch instead of
-    # being turned into ~110 VGPRs with waterfall indexing, which is what keeps wf_scatter / wf_nee at 2 waves/SIMD
-    cmd = [hipcc(), "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-           "-mllvm", "-disable-promote-alloca-to-vector",
-           "-Wall", "-Wno-unused-function", "-x", "hip", *SOURCES, "-o", OUT, *extra]
+def _deps():
+    deps = []
+    for d in (HIP, HOST, os.path.join(ROOT, "include")):
+        deps += [os.path.join(d, f) for f in os.listdir(d)]
+    deps.append(os.path.abspath(__file__))
+    return deps
+
+
+def _objects(mode):
+    """(object path, source, flags) of every translation unit"""
+    objs = [("zygpu.o", os.path.join(HIP, "zygpu.hip"), PRECISE), ("engine.o", os.path.join(HOST, "engine.cpp"), PRECISE),
+            ("capi.o", os.path.join(HOST, "capi.cpp"), PRECISE)]
+    for u in range(NUM_UNITS):
+        if mode in ("both", "precise"):
+            objs.append((f"unit{u}.o", os.path.join(HIP, "kernels.hip"), PRECISE + [f"-DZYG_TU={u}"]))
+        if mode in ("both", "relaxed"):
+            objs.append((f"unit{u}f.o", os.path.join(HIP, "kernels.hip"), RELAXED + [f"-DZYG_TU={u}"]))
+    return objs
+
+
+def _compile(job):
+    name, src, flags, extra, verbose = job
+    out = os.path.join(OBJ, name)
+    cmd = [hipcc(), *COMMON, *flags, *extra, "-x", "hip", "-c", src, "-o", out]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode:
+        sys.stderr.write(f"[{time.time() - t0:6.1f} s] {name}\n{r.stderr}")
+    if r.returncode:
+        raise RuntimeError(f"hipcc failed for {name}: {' '.join(cmd)}")
+    return out
+
+
+def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    extra = list(extra)
+    # objects are reused only when they were built with the same flags
+    tag = hashlib.sha1(" ".join(COMMON + PRECISE + RELAXED + extra).encode()).hexdigest()[:12]
+    tag_file = os.path.join(OBJ, "flags.tag")
+    same_flags = os.path.exists(tag_file) and open(tag_file).read() == tag
+    newest = max(os.path.getmtime(p) for p in _deps())
+    todo, objs = [], []
+    for name, src, flags in _objects(mode):
+        out = os.path.join(OBJ, name)
+        objs.append(out)
+        fresh = same_flags and os.path.exists(out) and os.path.getmtime(out) >= newest
+        if units is not None and name.startswith("unit"):
+            unit = int(name[4:].rstrip("f.o"))
+            if unit in units or not os.path.exists(out):
+                todo.append((name, src, flags, extra, verbose))
+        elif not fresh:
+            todo.append((name, src, flags, extra, verbose))
+    # the largest units first (kernel_table.hpp keeps the wf_scatter instantiations in the low unit numbers)
+    todo.sort(key=lambda j: (not j[0].startswith("unit"), j[0]))
+    t0 = time.time()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(_compile, todo))
+    open(tag_file, "w").write(tag)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
     if verbose:
-        print(" ".join(cmd), flush=True)
+        print(f"compiled {len(todo)} of {len(objs)} translation units in {time.time() - t0:.0f} s; linking", flush=True)
     subprocess.run(cmd, check=True)
     return OUT
 
@@ -43,11 +113,14 @@ def up_to_date():
     if not os.path.exists(OUT):
         return False
     t = os.path.getmtime(OUT)
-    deps = list(SOURCES)
-    for d in (os.path.join(HERE, "csrc", "hip"), os.path.join(HERE, "csrc", "host"), os.path.join(ROOT, "include")):
-        deps += [os.path.join(d, f) for f in os.listdir(d)]
-    return all(os.path.getmtime(p) <= t for p in deps)
+    return all(os.path.getmtime(p) <= t for p in _deps() if not p.endswith("build.py"))
 
 
 if __name__ == "__main__":
-    build(extra=sys.argv[1:])
+    args = sys.argv[1:]
+    kw = {}
+    while args and args[0] in ("--mode", "--units", "--jobs"):
+        key, val = args[0][2:], args[1]
+        kw[key] = val if "mode" == key else int(val) if "jobs" == key else {int(v) for v in val.split(",")}
+        args = args[2:]
+    build(extra=args, **kw)

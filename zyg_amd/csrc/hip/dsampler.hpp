@@ -81,9 +81,9 @@ static_assert(kDirections.v[0][1] == 0xc0000000u && kDirections.v[1][4] == 0xe80
 // The 32-step XOR of sobol.zig:176-192 folded per index byte: c_sobol_lut[k * 256 + b] holds, for dimensions 2..5, the XOR of
 // the direction words 8k..8k+7 selected by the bits of b (16 KB, L1-resident; filled once by sobol_lut_init).  Four 16 B
 // loads and twelve XORs replace ~290 VALU instructions per refill; XOR is exact, so the result is the same word for word.
-__constant__ const uint4* c_sobol_lut;
+static __constant__ const uint4* c_sobol_lut;  // per translation unit, like c_view / c_scene (wavefront.hpp)
 
-__global__ void sobol_lut_init(uint4* lut) {  // <<<4, 256>>>
+static __global__ void sobol_lut_init(uint4* lut) {  // <<<4, 256>>>
     const uint32_t k = blockIdx.x, b = threadIdx.x;
     uint32_t       x[4] = {0, 0, 0, 0};
     for (uint32_t j = 0; j < 8; ++j) {

@@ -1,0 +1,75 @@
+// Every wavefront-kernel instantiation the library ships, with the translation unit that compiles it.
+//
+// The device code is built as several translation units in parallel (zyg_amd/build.py): kernels.hip is compiled once per
+// ZYG_TU value and arithmetic mode, and instantiates exactly the entries of this table whose first column equals its
+// ZYG_TU.  No relocatable device code: each unit has its own copy of the three __constant__ blocks (view, scene, Sobol
+// table pointer), set through the unit's `set` entry.  zygpu.hip launches by id through the unit's `launch` entry.
+//
+//   X(unit, id, kernel instantiation, kernel arguments)       arguments: P = Params, arg = the launch's uint32_t
+//
+// Template parameters (wavefront.hpp):
+//   wf_generate<POOL>   wf_intersect<STATS, POOL, EXTRA>   wf_shade<STATS, MESHL, HEAVY, POOL>
+//   wf_trace_shade<STATS, MESHL, FIRST>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS>
+//   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_extend<SUBST, EXTRA>
+#pragma once
+
+#define ZYG_NUM_UNITS 8
+
+// clang-format off
+#define ZYG_KERNEL_TABLE(X)                                                                 \
+    X(0, K_SCATTER_STATS_POOL,   (wf_scatter<true, true, true, true, true>),          (P))  \
+    X(1, K_SCATTER_MASKS_POOL,   (wf_scatter<false, true, true, true, true, true>),   (P))  \
+    X(2, K_SCATTER_FULL_POOL,    (wf_scatter<false, true, true, true, true>),         (P))  \
+    X(2, K_SCATTER_PLAIN_POOL,   (wf_scatter<false, true, false, false, true>),       (P))  \
+    X(3, K_SCATTER_STATS,        (wf_scatter<true, true, true, true, false>),         (P))  \
+    X(7, K_SCATTER_MASKS,        (wf_scatter<false, true, true, true, false, true>),  (P))  \
+    X(4, K_SCATTER_FULL,         (wf_scatter<false, true, true, true, false>),        (P))  \
+    X(4, K_SCATTER_MULTI,        (wf_scatter<false, true, true, false, false>),       (P))  \
+    X(4, K_SCATTER_SUBST,        (wf_scatter<false, true, false, false, false>),      (P))  \
+    X(4, K_SCATTER_LAMBERT,      (wf_scatter<false, false, false, false, false>),     (P))  \
+    X(5, K_SHADE_STATS_LIGHT_POOL, (wf_shade<true, true, false, true>),               (P))  \
+    X(5, K_SHADE_STATS_HEAVY_POOL, (wf_shade<true, true, true, true>),                (P))  \
+    X(5, K_SHADE_PLAIN_LIGHT_POOL, (wf_shade<false, false, false, true>),             (P))  \
+    X(5, K_SHADE_PLAIN_HEAVY_POOL, (wf_shade<false, false, true, true>),              (P))  \
+    X(5, K_SHADE_MESHL_LIGHT_POOL, (wf_shade<false, true, false, true>),              (P))  \
+    X(5, K_SHADE_MESHL_HEAVY_POOL, (wf_shade<false, true, true, true>),               (P))  \
+    X(5, K_SHADE_STATS_HEAVY,    (wf_shade<true, true, true, false>),                 (P))  \
+    X(5, K_SHADE_MESHL_HEAVY,    (wf_shade<false, true, true, false>),                (P))  \
+    X(5, K_SHADE_PLAIN_HEAVY,    (wf_shade<false, false, true, false>),               (P))  \
+    X(5, K_SHADE_STATS_LIGHT,    (wf_shade<true, true, false, false>),                (P))  \
+    X(5, K_SHADE_MESHL_LIGHT,    (wf_shade<false, true, false, false>),               (P))  \
+    X(5, K_SHADE_PLAIN_LIGHT,    (wf_shade<false, false, false, false>),              (P))  \
+    X(6, K_TRACE_SHADE_STATS_FIRST, (wf_trace_shade<true, true, true>),               (P, arg)) \
+    X(6, K_TRACE_SHADE_MESHL_FIRST, (wf_trace_shade<false, true, true>),              (P, arg)) \
+    X(6, K_TRACE_SHADE_PLAIN_FIRST, (wf_trace_shade<false, false, true>),             (P, arg)) \
+    X(6, K_TRACE_SHADE_STATS,    (wf_trace_shade<true, true, false>),                 (P, arg)) \
+    X(6, K_TRACE_SHADE_MESHL,    (wf_trace_shade<false, true, false>),                (P, arg)) \
+    X(6, K_TRACE_SHADE_PLAIN,    (wf_trace_shade<false, false, false>),               (P, arg)) \
+    X(6, K_GENERATE_POOL,        (wf_generate<true>),                                 (P, arg)) \
+    X(6, K_GENERATE,             (wf_generate<false>),                                (P, arg)) \
+    X(7, K_INTERSECT_STATS_POOL, (wf_intersect<true, true, true>),                    (P))  \
+    X(7, K_INTERSECT_PLAIN_POOL, (wf_intersect<false, true, false>),                  (P))  \
+    X(7, K_INTERSECT_EXTRA_POOL, (wf_intersect<false, true, true>),                   (P))  \
+    X(7, K_INTERSECT_STATS,      (wf_intersect<true, false, true>),                   (P))  \
+    X(7, K_INTERSECT_EXTRA,      (wf_intersect<false, false, true>),                  (P))  \
+    X(7, K_INTERSECT_PLAIN,      (wf_intersect<false, false, false>),                 (P))  \
+    X(7, K_NEE_FIRST_SUBST,      (wf_nee<true, true>),                                (P, arg)) \
+    X(7, K_NEE_FIRST,            (wf_nee<true, false>),                               (P, arg)) \
+    X(7, K_NEE_SUBST,            (wf_nee<false, true>),                               (P, arg)) \
+    X(7, K_NEE,                  (wf_nee<false, false>),                              (P, arg)) \
+    X(7, K_SHADOW_STATS,         (wf_shadow<true>),                                   (P, arg)) \
+    X(7, K_SHADOW,               (wf_shadow<false>),                                  (P, arg)) \
+    X(7, K_EXTEND_EXTRA,         (wf_extend<true, true>),                             (P))  \
+    X(7, K_EXTEND_SUBST,         (wf_extend<true, false>),                            (P))  \
+    X(7, K_EXTEND,               (wf_extend<false, false>),                           (P))
+// clang-format on
+
+enum ZygKernelId : unsigned {
+#define ZYG_X(unit, id, kernel, args) id,
+    ZYG_KERNEL_TABLE(ZYG_X)
+#undef ZYG_X
+        K_NUM_KERNELS
+};
+
+// the per-unit entries (C linkage, one pair per unit and arithmetic mode: zyg_unit<k>_launch / zyg_unit<k>f_launch)
+enum ZygUnitConstant : int { ZYG_CONST_VIEW = 0, ZYG_CONST_SCENE = 1, ZYG_CONST_SOBOL_LUT = 2 };

@@ -177,8 +177,9 @@ struct Params {
     uint32_t round;   // POOL: which vertex of the level this launch handles
 };
 
-__constant__ View   c_view;
-__constant__ DScene c_scene;  // the compiled scene's device arrays: read on demand through the scalar cache
+// one copy per translation unit (kernel_table.hpp): the units are built without relocatable device code
+static __constant__ View   c_view;
+static __constant__ DScene c_scene;  // the compiled scene's device arrays: read on demand through the scalar cache
 
 // occupancy targets (waves per SIMD) the register allocator is held to, per kernel; see DESIGN.md "Occupancy"
 #ifndef ZYG_SHADE_WAVES

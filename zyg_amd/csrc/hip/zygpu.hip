@@ -11,9 +11,24 @@
 #include <string>
 #include <vector>
 
+#include "kernel_table.hpp"
 #include "wavefront.hpp"
 
 using namespace zd;
+
+// The wavefront kernels are compiled in ZYG_NUM_UNITS translation units per arithmetic mode (kernels.hip, kernel_table.hpp);
+// this unit holds the film kernels and the host side.  Weak: a development build may leave a mode out (build.py --mode),
+// and asking for a mode that is not in the library is an error, never a silent switch to the other one.
+extern "C" {
+#define ZYG_DECL_UNIT(k)                                                                                      \
+    __attribute__((weak)) int zyg_unit##k##_launch(unsigned, unsigned, void*, const void*, unsigned);        \
+    __attribute__((weak)) int zyg_unit##k##_set(int, const void*, size_t, void*);                            \
+    __attribute__((weak)) int zyg_unit##k##f_launch(unsigned, unsigned, void*, const void*, unsigned);       \
+    __attribute__((weak)) int zyg_unit##k##f_set(int, const void*, size_t, void*);
+ZYG_DECL_UNIT(0) ZYG_DECL_UNIT(1) ZYG_DECL_UNIT(2) ZYG_DECL_UNIT(3) ZYG_DECL_UNIT(4) ZYG_DECL_UNIT(5) ZYG_DECL_UNIT(6) ZYG_DECL_UNIT(7)
+#undef ZYG_DECL_UNIT
+}
+static_assert(8 == ZYG_NUM_UNITS, "declare the units above");
 
 namespace {
 
@@ -314,6 +329,35 @@ __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) 
 
 thread_local std::string g_error;
 
+using UnitLaunch = int (*)(unsigned, unsigned, void*, const void*, unsigned);
+using UnitSet = int (*)(int, const void*, size_t, void*);
+#define ZYG_UNITS(suffix) {zyg_unit0##suffix, zyg_unit1##suffix, zyg_unit2##suffix, zyg_unit3##suffix, zyg_unit4##suffix, zyg_unit5##suffix, zyg_unit6##suffix, zyg_unit7##suffix}
+const UnitLaunch kUnitLaunch[2][ZYG_NUM_UNITS] = {ZYG_UNITS(_launch), ZYG_UNITS(f_launch)};  // [0] precise, [1] relaxed
+const UnitSet    kUnitSet[2][ZYG_NUM_UNITS] = {ZYG_UNITS(_set), ZYG_UNITS(f_set)};
+#undef ZYG_UNITS
+const unsigned char kUnitOf[K_NUM_KERNELS] = {
+#define ZYG_X(unit, id, kernel, args) unit,
+    ZYG_KERNEL_TABLE(ZYG_X)
+#undef ZYG_X
+};
+
+bool modeAvailable(int mode) {
+    for (int u = 0; u < ZYG_NUM_UNITS; ++u)
+        if (!kUnitLaunch[mode][u] || !kUnitSet[mode][u]) return false;
+    return true;
+}
+
+// one __constant__ block into every kernel unit that is in the library (both modes: a context may switch)
+bool setUnitConstants(int which, const void* src, size_t bytes, hipStream_t stream) {
+    for (int mode = 0; mode < 2; ++mode)
+        for (int u = 0; u < ZYG_NUM_UNITS; ++u)
+            if (kUnitSet[mode][u] && 0 != kUnitSet[mode][u](which, src, bytes, stream)) {
+                g_error = "setting a kernel unit's __constant__ block failed";
+                return false;
+            }
+    return true;
+}
+
 bool check(hipError_t e, const char* what) {
     if (hipSuccess == e) return true;
     g_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -394,6 +438,13 @@ struct ZygpuContext {
     uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     bool          fuse_trace_shade = true; // option "fuse_trace_shade": wf_trace_shade instead of wf_intersect + wf_shade's first pass
+    // option "precise": 1 = the reference's arithmetic bit for bit (IEEE divide / sqrt, no contraction, the restated libm
+    // functions): the verification mode, film identical to the oracle's.  0 = relaxed arithmetic (native rcp / sqrt, fused
+    // multiply-adds, OCML f32 transcendentals), within the RMS <= 1e-3 contract but not bit-identical.
+    bool          relaxed = false;
+    bool          launch_failed = false;
+    View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
+    uint64_t      view_epoch = 0;
     uint64_t      camera_samples = 0;
     int           num_cus = 256;
     // kernel timing
@@ -516,6 +567,19 @@ std::pair<hipEvent_t, hipEvent_t>* nextEvents(ZygpuContext* c, int k) {
     return &ev[c->events_used[k]++];
 }
 
+// the __constant__ blocks are per process (one engine at a time, like the reference's global engine, capi.zig:55)
+uint64_t g_view_epoch = 0, g_unit_view_epoch[2][ZYG_NUM_UNITS] = {};
+
+// A unit's copy of the view block is brought up to date (in stream order) before the first launch that needs it
+void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params& P, uint32_t arg) {
+    const int mode = c->relaxed ? 1 : 0, unit = kUnitOf[id];
+    if (g_unit_view_epoch[mode][unit] != c->view_epoch) {
+        if (0 != kUnitSet[mode][unit](ZYG_CONST_VIEW, &c->batch_view, sizeof(View), c->stream)) c->launch_failed = true;
+        g_unit_view_epoch[mode][unit] = c->view_epoch;
+    }
+    if (0 != kUnitLaunch[mode][unit](id, blocks, c->stream, &P, arg)) c->launch_failed = true;
+}
+
 template <typename Launch>
 void timedLaunch(ZygpuContext* c, int k, Launch&& launch) {
     auto* e = c->timing ? nextEvents(c, k) : nullptr;
@@ -567,11 +631,16 @@ int zygpu_create(int device_id, ZygpuContext** out_ctx) {
     }
     c->sobol_lut = static_cast<uint4*>(lut);
     hipLaunchKernelGGL(sobol::sobol_lut_init, dim3(4), dim3(256), 0, c->stream, c->sobol_lut);
-    if (!check(hipStreamSynchronize(c->stream), "sobol_lut_init") ||
-        !check(hipMemcpyToSymbol(HIP_SYMBOL(sobol::c_sobol_lut), &c->sobol_lut, sizeof(c->sobol_lut), 0, hipMemcpyHostToDevice), "c_sobol_lut")) {
+    if (!modeAvailable(0) && !modeAvailable(1)) g_error = "libzyg_amd.so holds no complete set of kernel units";
+    if ((!modeAvailable(0) && !modeAvailable(1)) || !check(hipStreamSynchronize(c->stream), "sobol_lut_init") ||
+        !setUnitConstants(ZYG_CONST_SOBOL_LUT, &c->sobol_lut, sizeof(c->sobol_lut), c->stream) ||
+        // this unit's own copy: the unit-test hook (test_eval) draws from the Sobol sampler
+        !check(hipMemcpyToSymbol(HIP_SYMBOL(sobol::c_sobol_lut), &c->sobol_lut, sizeof(c->sobol_lut), 0, hipMemcpyHostToDevice), "c_sobol_lut") ||
+        !check(hipStreamSynchronize(c->stream), "c_sobol_lut")) {
         zygpu_destroy(c);
         return -1;
     }
+    c->relaxed = !modeAvailable(0);
     *out_ctx = c;
     return 0;
 }
@@ -822,7 +891,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
     }
     HIP_OK(hipStreamSynchronize(c->stream));
-    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_scene), &s, sizeof(DScene), 0, hipMemcpyHostToDevice));
+    if (!setUnitConstants(ZYG_CONST_SCENE, &s, sizeof(DScene), c->stream)) return -1;
+    HIP_OK(hipStreamSynchronize(c->stream));
     c->has_scene = true;
     return 0;
 }
@@ -959,7 +1029,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
 
     for (uint32_t done = 0; done < num_iterations; done += per_batch) {
         const uint32_t b = std::min(per_batch, num_iterations - done);
-        View           view;
+        View&          view = c->batch_view;
         view.v = v;
         view.y_begin = yb;
         view.y_end = ye;
@@ -969,7 +1039,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         view.iteration0 = iteration + done;
         view.batch_iterations = b;
         view.npix = uint32_t(npix);
+        // this unit's copy (the film kernels); the kernel units' copies follow in launchKernel
         HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_view), &view, sizeof(View), 0, hipMemcpyHostToDevice, c->stream));
+        c->view_epoch = ++g_view_epoch;  // launchKernel refreshes the kernel units' copies on demand
 
         const uint32_t num_paths = uint32_t(npix * b);
         P.queue_capacity = queueEntries(c->pool_capacity);
@@ -984,9 +1056,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         const bool generate_in_trace = !c->pool_mode && c->fuse_trace_shade;
         if (c->pool_mode) {
             HIP_OK(hipMemsetAsync(&c->ctl->ext_pool_count[0][0], 0, sizeof(QueueCounts) * kPoolVertices, c->stream));
-            hipLaunchKernelGGL(wf_generate<true>, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
+            launchKernel(c, K_GENERATE_POOL, (num_paths + 255) / 256, P, num_paths);
         } else if (!generate_in_trace) {
-            hipLaunchKernelGGL(wf_generate<false>, dim3((num_paths + 255) / 256), block, 0, c->stream, P, num_paths);
+            launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
         }
         c->camera_samples += num_paths;
         for (uint32_t t = 0; t < ticks; ++t) {
@@ -997,27 +1069,27 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                     // the plain instantiations (Rectangle / mesh geometry, single-sample Rectangle lights) or the full ones
                     const bool plain = !c->stats && !c->mesh_lights && !c->multi_sample_lights;
                     timedLaunch(c, 0, [&] {
-                        if (c->stats) hipLaunchKernelGGL((wf_intersect<true, true, true>), grid, block, 0, c->stream, P);
-                        else if (plain) hipLaunchKernelGGL((wf_intersect<false, true, false>), grid, block, 0, c->stream, P);
-                        else hipLaunchKernelGGL((wf_intersect<false, true, true>), grid, block, 0, c->stream, P);
+                        if (c->stats) launchKernel(c, K_INTERSECT_STATS_POOL, grid.x, P, 0u);
+                        else if (plain) launchKernel(c, K_INTERSECT_PLAIN_POOL, grid.x, P, 0u);
+                        else launchKernel(c, K_INTERSECT_EXTRA_POOL, grid.x, P, 0u);
                     });
                     timedLaunch(c, 1, [&] {
                         if (c->stats) {
-                            hipLaunchKernelGGL((wf_shade<true, true, false, true>), grid, block, 0, c->stream, P);
-                            hipLaunchKernelGGL((wf_shade<true, true, true, true>), grid, block, 0, c->stream, P);
+                            launchKernel(c, K_SHADE_STATS_LIGHT_POOL, grid.x, P, 0u);
+                            launchKernel(c, K_SHADE_STATS_HEAVY_POOL, grid.x, P, 0u);
                         } else if (plain) {
-                            hipLaunchKernelGGL((wf_shade<false, false, false, true>), grid, block, 0, c->stream, P);
-                            hipLaunchKernelGGL((wf_shade<false, false, true, true>), grid, block, 0, c->stream, P);
+                            launchKernel(c, K_SHADE_PLAIN_LIGHT_POOL, grid.x, P, 0u);
+                            launchKernel(c, K_SHADE_PLAIN_HEAVY_POOL, grid.x, P, 0u);
                         } else {
-                            hipLaunchKernelGGL((wf_shade<false, true, false, true>), grid, block, 0, c->stream, P);
-                            hipLaunchKernelGGL((wf_shade<false, true, true, true>), grid, block, 0, c->stream, P);
+                            launchKernel(c, K_SHADE_MESHL_LIGHT_POOL, grid.x, P, 0u);
+                            launchKernel(c, K_SHADE_MESHL_HEAVY_POOL, grid.x, P, 0u);
                         }
                     });
                     timedLaunch(c, 5, [&] {
-                        if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, true>), grid, block, 0, c->stream, P);
-                        else if (c->masks) hipLaunchKernelGGL((wf_scatter<false, true, true, true, true, true>), grid, block, 0, c->stream, P);
-                        else if (plain) hipLaunchKernelGGL((wf_scatter<false, true, false, false, true>), grid, block, 0, c->stream, P);
-                        else hipLaunchKernelGGL((wf_scatter<false, true, true, true, true>), grid, block, 0, c->stream, P);
+                        if (c->stats) launchKernel(c, K_SCATTER_STATS_POOL, grid.x, P, 0u);
+                        else if (c->masks) launchKernel(c, K_SCATTER_MASKS_POOL, grid.x, P, 0u);
+                        else if (plain) launchKernel(c, K_SCATTER_PLAIN_POOL, grid.x, P, 0u);
+                        else launchKernel(c, K_SCATTER_FULL_POOL, grid.x, P, 0u);
                     });
                 }
                 P.round = 0;
@@ -1028,70 +1100,70 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                 // closest hit + the first shading pass in one kernel (timed as kernel 0), then the second pass
                 timedLaunch(c, 0, [&] {
                     if (0 == t) {
-                        if (c->stats) hipLaunchKernelGGL((wf_trace_shade<true, true, true>), grid, block, 0, c->stream, P, num_paths);
-                        else if (c->mesh_lights) hipLaunchKernelGGL((wf_trace_shade<false, true, true>), grid, block, 0, c->stream, P, num_paths);
-                        else hipLaunchKernelGGL((wf_trace_shade<false, false, true>), grid, block, 0, c->stream, P, num_paths);
+                        if (c->stats) launchKernel(c, K_TRACE_SHADE_STATS_FIRST, grid.x, P, num_paths);
+                        else if (c->mesh_lights) launchKernel(c, K_TRACE_SHADE_MESHL_FIRST, grid.x, P, num_paths);
+                        else launchKernel(c, K_TRACE_SHADE_PLAIN_FIRST, grid.x, P, num_paths);
                     } else if (c->stats) {
-                        hipLaunchKernelGGL((wf_trace_shade<true, true, false>), grid, block, 0, c->stream, P, 0u);
+                        launchKernel(c, K_TRACE_SHADE_STATS, grid.x, P, 0u);
                     } else if (c->mesh_lights) {
-                        hipLaunchKernelGGL((wf_trace_shade<false, true, false>), grid, block, 0, c->stream, P, 0u);
+                        launchKernel(c, K_TRACE_SHADE_MESHL, grid.x, P, 0u);
                     } else {
-                        hipLaunchKernelGGL((wf_trace_shade<false, false, false>), grid, block, 0, c->stream, P, 0u);
+                        launchKernel(c, K_TRACE_SHADE_PLAIN, grid.x, P, 0u);
                     }
                 });
                 timedLaunch(c, 1, [&] {
-                    if (c->stats) hipLaunchKernelGGL((wf_shade<true, true, true, false>), grid, block, 0, c->stream, P);
-                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_shade<false, true, true, false>), grid, block, 0, c->stream, P);
-                    else hipLaunchKernelGGL((wf_shade<false, false, true, false>), grid, block, 0, c->stream, P);
+                    if (c->stats) launchKernel(c, K_SHADE_STATS_HEAVY, grid.x, P, 0u);
+                    else if (c->mesh_lights) launchKernel(c, K_SHADE_MESHL_HEAVY, grid.x, P, 0u);
+                    else launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u);
                 });
             } else {
             timedLaunch(c, 0, [&] {
-                if (c->stats) hipLaunchKernelGGL((wf_intersect<true, false, true>), grid, block, 0, c->stream, P);
-                else if (c->mesh_lights) hipLaunchKernelGGL((wf_intersect<false, false, true>), grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL((wf_intersect<false, false, false>), grid, block, 0, c->stream, P);
+                if (c->stats) launchKernel(c, K_INTERSECT_STATS, grid.x, P, 0u);
+                else if (c->mesh_lights) launchKernel(c, K_INTERSECT_EXTRA, grid.x, P, 0u);
+                else launchKernel(c, K_INTERSECT_PLAIN, grid.x, P, 0u);
             });
             timedLaunch(c, 1, [&] {
                 if (c->stats) {
-                    hipLaunchKernelGGL((wf_shade<true, true, false, false>), grid, block, 0, c->stream, P);
-                    hipLaunchKernelGGL((wf_shade<true, true, true, false>), grid, block, 0, c->stream, P);
+                    launchKernel(c, K_SHADE_STATS_LIGHT, grid.x, P, 0u);
+                    launchKernel(c, K_SHADE_STATS_HEAVY, grid.x, P, 0u);
                 } else if (c->mesh_lights) {
-                    hipLaunchKernelGGL((wf_shade<false, true, false, false>), grid, block, 0, c->stream, P);
-                    hipLaunchKernelGGL((wf_shade<false, true, true, false>), grid, block, 0, c->stream, P);
+                    launchKernel(c, K_SHADE_MESHL_LIGHT, grid.x, P, 0u);
+                    launchKernel(c, K_SHADE_MESHL_HEAVY, grid.x, P, 0u);
                 } else {
-                    hipLaunchKernelGGL((wf_shade<false, false, false, false>), grid, block, 0, c->stream, P);
-                    hipLaunchKernelGGL((wf_shade<false, false, true, false>), grid, block, 0, c->stream, P);
+                    launchKernel(c, K_SHADE_PLAIN_LIGHT, grid.x, P, 0u);
+                    launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u);
                 }
             });
             }
             if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
-                    if (c->stats) hipLaunchKernelGGL((wf_scatter<true, true, true, true, false>), grid, block, 0, c->stream, P);
-                    else if (c->masks) hipLaunchKernelGGL((wf_scatter<false, true, true, true, false, true>), grid, block, 0, c->stream, P);
-                    else if (c->mesh_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, true, false>), grid, block, 0, c->stream, P);
-                    else if (c->multi_sample_lights) hipLaunchKernelGGL((wf_scatter<false, true, true, false, false>), grid, block, 0, c->stream, P);
-                    else if (c->has_substitute) hipLaunchKernelGGL((wf_scatter<false, true, false, false, false>), grid, block, 0, c->stream, P);
-                    else hipLaunchKernelGGL((wf_scatter<false, false, false, false, false>), grid, block, 0, c->stream, P);
+                    if (c->stats) launchKernel(c, K_SCATTER_STATS, grid.x, P, 0u);
+                    else if (c->masks) launchKernel(c, K_SCATTER_MASKS, grid.x, P, 0u);
+                    else if (c->mesh_lights) launchKernel(c, K_SCATTER_FULL, grid.x, P, 0u);
+                    else if (c->multi_sample_lights) launchKernel(c, K_SCATTER_MULTI, grid.x, P, 0u);
+                    else if (c->has_substitute) launchKernel(c, K_SCATTER_SUBST, grid.x, P, 0u);
+                    else launchKernel(c, K_SCATTER_LAMBERT, grid.x, P, 0u);
                 });
             } else {
             for (uint32_t r = 0; r < rounds; ++r) {
                 timedLaunch(c, 2, [&] {
                     if (0 == r) {
-                        if (c->has_substitute) hipLaunchKernelGGL((wf_nee<true, true>), grid, block, 0, c->stream, P, r);
-                        else hipLaunchKernelGGL((wf_nee<true, false>), grid, block, 0, c->stream, P, r);
+                        if (c->has_substitute) launchKernel(c, K_NEE_FIRST_SUBST, grid.x, P, r);
+                        else launchKernel(c, K_NEE_FIRST, grid.x, P, r);
                     } else {
-                        if (c->has_substitute) hipLaunchKernelGGL((wf_nee<false, true>), grid, block, 0, c->stream, P, r);
-                        else hipLaunchKernelGGL((wf_nee<false, false>), grid, block, 0, c->stream, P, r);
+                        if (c->has_substitute) launchKernel(c, K_NEE_SUBST, grid.x, P, r);
+                        else launchKernel(c, K_NEE, grid.x, P, r);
                     }
                 });
                 timedLaunch(c, 3, [&] {
-                    if (c->stats) hipLaunchKernelGGL(wf_shadow<true>, grid, block, 0, c->stream, P, r);
-                    else hipLaunchKernelGGL(wf_shadow<false>, grid, block, 0, c->stream, P, r);
+                    if (c->stats) launchKernel(c, K_SHADOW_STATS, grid.x, P, r);
+                    else launchKernel(c, K_SHADOW, grid.x, P, r);
                 });
             }
             timedLaunch(c, 4, [&] {
-                if (c->mesh_lights) hipLaunchKernelGGL((wf_extend<true, true>), grid, block, 0, c->stream, P);
-                else if (c->has_substitute) hipLaunchKernelGGL((wf_extend<true, false>), grid, block, 0, c->stream, P);
-                else hipLaunchKernelGGL((wf_extend<false, false>), grid, block, 0, c->stream, P);
+                if (c->mesh_lights) launchKernel(c, K_EXTEND_EXTRA, grid.x, P, 0u);
+                else if (c->has_substitute) launchKernel(c, K_EXTEND_SUBST, grid.x, P, 0u);
+                else launchKernel(c, K_EXTEND, grid.x, P, 0u);
             });
             }
             P.parity ^= 1u;
@@ -1117,6 +1189,11 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             hipLaunchKernelGGL(film_accumulate_aov, dim3((fn + 255) / 256), block, 0, c->stream, pa, k);
         }
         HIP_OK(hipGetLastError());
+        if (c->launch_failed) {
+            c->launch_failed = false;
+            g_error = "a wavefront kernel is missing from its translation unit (kernel_table.hpp)";
+            return -1;
+        }
         if (c->timing && c->events_used[0] > 4096) {
             HIP_OK(hipStreamSynchronize(c->stream));
             collectTimings(c);
@@ -1260,6 +1337,16 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "fuse_trace_shade")) {
         c->fuse_trace_shade = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "precise")) {
+        const int mode = value ? 0 : 1;
+        if (!modeAvailable(mode)) {
+            g_error = mode ? "the relaxed-arithmetic kernel units are not in this build of libzyg_amd.so"
+                           : "the precise kernel units are not in this build of libzyg_amd.so";
+            return -1;
+        }
+        c->relaxed = 1 == mode;
         return 0;
     }
     if (0 == std::strcmp(name, "nee_in_place")) {
