@@ -4,9 +4,10 @@
 
 A step is one pass of the hot path over one batch: ITER_PER_STEP iterations (samples per pixel) of the full frame on
 each rank.  With the defaults (--steps 16, 16 iterations per step) one GPU renders the configuration's 256 spp.
-Ranks shard the *iterations* of the frame (rank r renders iterations [r*K*I, (r+1)*K*I), every (pixel, iteration)
-is independent); the scene is replicated, there is no data-path collective, and the per-rank films
-{sum w*rgb, sum w} are summed once per run with an RCCL reduce over xGMI.  Scaling is weak: per-GPU work is fixed.
+Ranks shard the *iterations* of the frame (zyg_amd.distributed.ShardedFrame: rank r renders iterations
+[r*K*I, (r+1)*K*I), every (pixel, iteration) is independent); the scene is replicated, there is no data-path
+collective, and the per-rank films {sum w*rgb, sum w} are summed once per run with an RCCL reduce over xGMI.  Scaling is
+weak: per-GPU work is fixed.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -14,6 +15,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,9 +24,15 @@ sys.path.insert(0, ROOT)
 
 ITER_PER_STEP = 16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNELS = ("wf_intersect", "wf_shade", "wf_nee", "wf_shadow", "wf_extend", "wf_scatter")
+
+# The bytes of SURVEY §8(d)'s formula that have to cross HBM whatever the caches do: the path state / ray / hit records of
+# every extension ray (B_q = 224), the shadow ray records (B_sq = 96) and the film tap (B_film = 32 at radius 0).  B_trav (the
+# BVH nodes, triangles and instances a ray touches) is the cache-resident part for scenes that fit the 256 MB Infinity Cache.
+B_Q, B_SQ, B_FILM = 224, 96, 32
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -42,162 +50,317 @@ def main():
                          "or wf_intersect and wf_shade apart")
     ap.add_argument("--nee", default="in-place", choices=["in-place", "staged"],
                     help="zygpu option nee_in_place: wf_scatter (default) or the wf_nee / wf_shadow rounds + wf_extend")
-    ap.add_argument("--precise", type=int, default=1, choices=[0, 1],
-                    help="zygpu option precise: 1 = the reference's arithmetic bit for bit (verification mode, film identical to "
-                         "the oracle's), 0 = relaxed arithmetic (native divide / sqrt, contraction, OCML f32 functions) within the "
-                         "RMS <= 1e-3 contract")
+    ap.add_argument("--precise", type=int, default=0, choices=[0, 1],
+                    help="zygpu option precise: 1 = the reference's arithmetic bit for bit (verification mode: the film is "
+                         "identical to the oracle's), 0 = relaxed arithmetic (native divide / sqrt, contraction, OCML f32 "
+                         "functions), inside the contract's RMS <= 1e-3 (default)")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed oracle sample (and again of the parity band)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] (1 M-triangle mesh) measurement in `extra`")
+    return ap.parse_args()
 
+
+def build_scene(eng, scenes, name, material, w, h, total_spp):
+    mesh = scenes.heightfield_mesh() if name == "cornell_mesh" else None
+    # cornell_mesh = BASELINE.json configs[2]: the 999 698-triangle heightfield with one grey Substitute material
+    mesh_material = scenes.substitute((0.5, 0.5, 0.5)) if mesh is not None else None
+    if name == "outdoor":
+        scenes.outdoor(eng, w, h, total_spp, integrator="PTMIS", material="substitute", sky="canopy", sky_map=scenes.sky_image(1024, 1024),
+                       sky_spectrum=(1.0, 1.0, 1.0), showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16)
+    else:
+        glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if name == "cornell_glass" else None
+        scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=material, boxes=mesh is None, mesh=mesh,
+                       mesh_material=mesh_material, glass_objects=glass)
+
+
+def describe(name, material, w, h, ips, k, precise):
+    mode = "precise arithmetic (film bit-identical to the CPU oracle)" if precise else "relaxed arithmetic (RMS <= 1e-3 contract)"
+    if name == "outdoor":
+        return (f"outdoor scene (ground, 2 boxes (one glass), glass + gold Spheres, 999698-triangle mesh in polished iron, 1024^2 "
+                f"canopy image light + Distant sun), {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
+                f"{k * ips} spp per GPU, {mode}")
+    geometry = {"cornell": "2 boxes", "cornell_mesh": "999698-triangle heightfield mesh (Substitute)",
+                "cornell_glass": "tall box, glass box (ior 1.5, absorbing), glass Sphere"}[name]
+    bsdf = "Lambertian" if material == "lambert" else "Substitute (roughness 0.8)"
+    return (f"Cornell box (5 Rectangle walls, {geometry}, 2 unoccluding Rectangle lights) + {bsdf} BSDF, {w}x{h}, PTMIS depth 16, "
+            f"Sobol, box sensor, {ips} iterations per step, {k * ips} spp per GPU, {mode}")
+
+
+class Measurement:
+    """One scene on this rank's GPU: the stats iteration (algorithmic bytes), warm-up, the timed steps."""
+
+    def __init__(self, args, zyg_amd, scenes, torch, frame, device, scene, material, steps, warmup):
+        self.args, self.zyg_amd, self.torch, self.frame, self.device = args, zyg_amd, torch, frame, device
+        self.scene, self.material, self.steps, self.warmup = scene, material, steps, warmup
+        self.w, self.h, self.ips = args.width, args.height, args.iters_per_step
+        self.eng = zyg_amd.Engine()
+        self.eng.set_device(device.index)
+        build_scene(self.eng, scenes, scene, material, self.w, self.h, frame.world * steps * self.ips)
+        self.eng.start_frame(0)
+        self.lib, self.ctx = self.eng.lib, self.eng.context()
+        if args.batch_mpaths:
+            self.eng.set_option("batch_mpaths", args.batch_mpaths)
+        self.eng.set_option("fuse_trace_shade", args.fuse)
+        self.eng.set_option("precise", args.precise)
+        self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)
+        self.fused = bool(args.fuse) and scene in ("cornell", "cornell_mesh")  # POOL scenes always run the kernels apart
+        self.film = torch.zeros((self.h, self.w, 4), dtype=torch.float32, device=device)
+        assert self.lib.zygpu_set_external_film(self.ctx, ctypes.c_void_p(self.film.data_ptr())) == 0
+
+    def render(self, first_iteration, count, y_begin, y_end):
+        if 0 != self.lib.zygpu_render(self.ctx, 0, first_iteration, count, y_begin, y_end):
+            raise RuntimeError("zygpu_render: " + self.lib.zygpu_last_error().decode())
+
+    def synchronize(self):
+        self.eng.synchronize()
+        self.torch.cuda.synchronize(self.device)
+
+    def run(self):
+        lib, ctx, zyg_amd = self.lib, self.ctx, self.zyg_amd
+        # algorithmic bytes per sample (SURVEY §8(d)) from the device traversal counters of one stats-enabled iteration
+        # (they equal the oracle's counters exactly: tests/test_gpu_parity.py)
+        lib.zygpu_enable_stats(ctx, 1)
+        lib.zygpu_reset_stats(ctx)
+        self.render(0, 1, 0, self.h)
+        self.synchronize()
+        st = self.eng.stats()
+        lib.zygpu_enable_stats(ctx, 0)
+        ks = (zyg_amd.Stats * len(KERNELS))()
+        assert lib.zygpu_get_kernel_stats(ctx, ks) == 0
+        n_stat = float(max(st.camera_samples, 1))
+
+        def trav(x):
+            return 32 * x.nodes_fetched + 48 * x.triangles_tested + 104 * x.instances_tested
+
+        # split of the §8(d) terms over the wavefront kernels (DESIGN.md "Algorithmic bytes"); B_trav is counted per kernel:
+        #   per extension ray, 224 = ray read 32 + hit write 16 (wf_intersect) + hit read 16 + state read 64 (wf_shade)
+        #                            + state write 64 + ray write 32 (wf_extend / wf_scatter)
+        #   per shadow ray,     96 = ray write 32 + contribution write 16 (wf_nee) + ray read 32 + visibility 16 (wf_shadow)
+        #   B_film 32 per camera sample: staged by finalize, gathered by film_accumulate (not a wavefront kernel)
+        kb = {"wf_intersect": (48 * st.extension_rays + trav(ks[0])) / n_stat,
+              "wf_shade": (80 * st.extension_rays + trav(ks[1])) / n_stat,
+              "wf_nee": (48 * st.shadow_rays) / n_stat,
+              "wf_shadow": (48 * st.shadow_rays + trav(ks[3])) / n_stat,
+              "wf_extend": (96 * st.extension_rays) / n_stat,
+              "wf_scatter": (96 * st.extension_rays + 96 * st.shadow_rays + trav(ks[5])) / n_stat}
+        # the same split for the bytes that must cross HBM (no B_trav)
+        sb = {"wf_intersect": 48 * st.extension_rays / n_stat, "wf_shade": 80 * st.extension_rays / n_stat,
+              "wf_nee": 48 * st.shadow_rays / n_stat, "wf_shadow": 48 * st.shadow_rays / n_stat,
+              "wf_extend": 96 * st.extension_rays / n_stat, "wf_scatter": (96 * st.extension_rays + 96 * st.shadow_rays) / n_stat}
+        if self.args.nee == "in-place":
+            for d in (kb, sb):
+                d["wf_nee"] = d["wf_shadow"] = d["wf_extend"] = 0.0
+        if self.fused:  # wf_trace_shade is timed as kernel 0 and does both kernels' work; kernel 1 is wf_shade's second pass only
+            for d in (kb, sb):
+                d["wf_intersect"] += d["wf_shade"]
+                d["wf_shade"] = 0.0
+
+        for i in range(self.warmup):
+            self.render(i * self.ips, self.ips, 0, self.h)
+        self.synchronize()
+        self.film.zero_()
+        dtmp, ltmp = ctypes.c_double * len(KERNELS), ctypes.c_uint64 * len(KERNELS)
+        lib.zygpu_kernel_time(ctx, dtmp(), ltmp(), 1)
+
+        def body():
+            for s in range(self.steps):
+                self.frame.render_step(self.render, s, self.ips, self.steps)
+            self.eng.synchronize()
+            self.frame.reduce(self.film)
+
+        elapsed = self.frame.timed(body, lambda: self.torch.cuda.synchronize(self.device))
+        ms, launches = dtmp(), ltmp()
+        lib.zygpu_kernel_time(ctx, ms, launches, 0)
+        samples_rank = float(self.w) * self.h * self.ips * self.steps
+        kernels = [(nm, ms[i], int(launches[i]), kb[nm], sb[nm]) for i, nm in enumerate(KERNELS)]
+        dom = max(kernels, key=lambda t: t[1])
+        avg_ms = dom[1] / max(dom[2], 1)
+        per_launch = samples_rank / max(dom[2], 1)
+        achieved = dom[3] * per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return {
+            "elapsed": elapsed, "value": samples_rank * self.frame.world / elapsed / 1e6, "dominant": dom[0],
+            "avg_ms": avg_ms, "launches": dom[2], "achieved": achieved,
+            "algorithmic_bytes_per_launch": dom[3] * per_launch, "state_bytes_per_launch": dom[4] * per_launch,
+            "kernel_bytes_per_sample": dom[3], "kernel_state_bytes_per_sample": dom[4],
+            "bytes_per_sample": st.algorithmic_bytes(0) / n_stat,
+            "state_bytes_per_sample": (B_FILM * st.camera_samples + B_Q * st.extension_rays + B_SQ * st.shadow_rays) / n_stat,
+            "kernel_ms": {nm: round(ms[i], 3) for i, nm in enumerate(KERNELS)},
+            "kernel_bytes": {nm: round(v, 1) for nm, v in kb.items()},
+        }
+
+    def close(self):
+        self.lib.zygpu_set_external_film(self.ctx, None)
+        self.eng.release()
+
+
+def committed_traffic(args, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py ->
+    profiles/traffic.json): FETCH_SIZE and WRITE_SIZE need separate profiler passes, so this process cannot collect them.
+    The profile names the bench arguments and the source commit it was taken with; any other configuration gets null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    prof = json.load(open(path))
+    meta = prof.get("_meta", {})
+    this = {"scene": args.scene, "material": args.material, "size": [args.width, args.height, args.iters_per_step],
+            "fuse": args.fuse, "nee": args.nee, "precise": args.precise, "batch_mpaths": args.batch_mpaths, "gpus": args.gpus}
+    if meta.get("config") != this:
+        return None, None
+    for key, val in prof.items():
+        if key.startswith(kernel) and "true" not in key.split("<")[-1].split(",")[0]:  # the non-counting instantiation
+            return val, {"profile": "profiles/traffic.json", "source_commit": meta.get("source_commit"),
+                         "fetch_size_factor": meta.get("fetch_size_factor")}
+    return None, None
+
+
+def host_cpu():
+    """CPU model, logical / physical core counts, and the CPUs this process may really use (affinity and cgroup quota)."""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return {"model": model, "logical": logical, "physical": len(cores) or None, "usable": usable, "cgroup_quota": quota}
+
+
+class Oracle:
+    """The CPU oracle (a port of the reference's loop; the Zig reference cannot be built here).  Checker and reported
+    baseline only: nothing of it is on the measured path."""
+
+    def __init__(self, zyg_amd):
+        so = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(so):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+        self.lib = ctypes.CDLL(so)
+        self.lib.zyg_oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                               ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                               ctypes.c_void_p]
+        self.lib.zyg_oracle_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        self.zyg_amd = zyg_amd
+
+    def render(self, eng, film, first, count, y0, y1, threads):
+        sd, vd = eng.lib.su_ext_scene_desc().contents, eng.lib.su_ext_view_desc().contents
+        st = self.zyg_amd.Stats()
+        t0 = time.perf_counter()
+        rc = self.lib.zyg_oracle_render(ctypes.addressof(sd), ctypes.addressof(vd), 0, first, count, 1, y0, y1, film.ctypes.data,
+                                        threads, ctypes.byref(st))
+        assert rc == 0
+        return time.perf_counter() - t0
+
+    def resolve(self, eng, film):
+        import numpy as np
+        vd = eng.lib.su_ext_view_desc().contents
+        out = np.zeros_like(film)
+        self.lib.zyg_oracle_resolve(ctypes.addressof(vd), film.ctypes.data, out.ctypes.data, film.shape[0] * film.shape[1])
+        return out
+
+
+def cpu_baseline(m, oracle, budget_s):
+    """Times the oracle on the host cores over a bounded sample of the same workload: one probe iteration per candidate
+    thread count (all usable CPUs / one per physical core), then ONE call of N iterations of the full frame with the better
+    count, N sized to the budget."""
     import numpy as np
-    import torch
+    w, h = m.w, m.h
+    cpu = host_cpu()
+    candidates = sorted({cpu["usable"], max(1, min(cpu["usable"], cpu["physical"] or cpu["usable"]))}, reverse=True)
+    film = np.zeros((h, w, 4), dtype=np.float32)
+    oracle.render(m.eng, film, 0, 1, 0, min(h, 64), candidates[0])  # page in the library and the film
+    probes = {}
+    for t in candidates:
+        film[:] = 0
+        probes[t] = oracle.render(m.eng, film, 0, 1, 0, h, t)
+    threads = min(probes, key=probes.get)
+    iters = max(1, int(budget_s / probes[threads]))
+    film[:] = 0
+    dt = oracle.render(m.eng, film, 0, iters, 0, h, threads)
+    rate = w * h * iters / dt / 1e6
+    return {"value": round(rate, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "per_thread": round(rate / threads, 5), "cpu": cpu,
+            "probe_seconds_per_iteration": {str(t): round(s, 3) for t, s in probes.items()},
+            "sample": f"one call, {iters} iteration(s) of the same {w}x{h} frame ({w * h * iters} camera samples), {dt:.1f} s"}, rate, threads
 
+
+def parity_band(m, oracle, cpu_rate, threads, budget_s, iterations):
+    """The timed render's own film against the oracle: the same `iterations` samples per pixel on a band of rows sized to
+    the budget (whole 32-row tiles around the middle of the frame).  RMS over RGB of the resolved image, clamped to [0, 1]
+    (SURVEY §8(d)); in the precise mode also the share of film pixels that are the same bits."""
+    import numpy as np
+    w, h = m.w, m.h
+    rows = int(cpu_rate * 1e6 * budget_s / max(1, w * iterations))
+    rows = max(8, min(h, rows // 32 * 32 if rows >= 32 else rows))
+    y0 = max(0, (h - rows) // 2 // 32 * 32)
+    y1 = min(h, y0 + rows)
+    cpu_film = np.zeros((h, w, 4), dtype=np.float32)
+    dt = oracle.render(m.eng, cpu_film, 0, iterations, y0, y1, threads)
+    gpu_film = m.film.cpu().numpy()
+    a = np.clip(np.nan_to_num(_resolve_rows(oracle, m, gpu_film, y0, y1)), 0, 1).astype(np.float64)
+    b = np.clip(np.nan_to_num(_resolve_rows(oracle, m, cpu_film, y0, y1)), 0, 1).astype(np.float64)
+    return {"rms": float(np.sqrt(np.mean((a - b) ** 2))), "iterations": iterations, "rows": [y0, y1],
+            "bit_identical_pixels": float(np.mean(np.all(gpu_film[y0:y1] == cpu_film[y0:y1], axis=-1))),
+            "tolerance": 1e-3, "oracle_seconds": round(dt, 1)}
+
+
+def _resolve_rows(oracle, m, film, y0, y1):
+    return oracle.resolve(m.eng, film)[y0:y1, :, :3]
+
+
+def main():
+    args = parse_args()
     n = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if n > 1 and world != n:
         raise SystemExit(f"--gpus {n} needs WORLD_SIZE={n} (launch with torch.distributed.run)")
-    dist = None
-    if n > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+
+    # The library is built before any process group exists: a one-GPU run builds it when it is missing or stale, a
+    # multi-rank run never builds (ranks racing on one output file) and refuses to start without it.
+    from zyg_amd import build as zbuild
+    if not os.path.exists(zbuild.OUT) or not zbuild.up_to_date():
+        if n > 1:
+            if not os.path.exists(zbuild.OUT):
+                raise SystemExit("libzyg_amd.so is missing: run `python -m zyg_amd.build` before a multi-GPU launch")
+            if 0 == rank:
+                print("bench.py: libzyg_amd.so is older than its sources; using it as it is", file=sys.stderr)
+        else:
+            zbuild.build(verbose=False)
+
+    import numpy as np  # noqa: F401
+    import torch
 
     import zyg_amd
-    from zyg_amd import build as zbuild, scenes
-    if not zbuild.up_to_date():
-        if rank == 0:
-            zbuild.build(verbose=False)
-        if dist:
-            dist.barrier()
+    from zyg_amd import distributed, scenes
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = distributed.init_process_group("nccl", rank, world, device) if n > 1 else None
+    frame = distributed.ShardedFrame(rank, n, dist, "iterations", args.height)
 
-    w, h, ips, k, wu = args.width, args.height, args.iters_per_step, args.steps, args.warmup
-    total_spp = n * k * ips
-    eng = zyg_amd.Engine()
-    eng.set_device(local_rank)
-    mesh = scenes.heightfield_mesh() if args.scene == "cornell_mesh" else None
-    # cornell_mesh = BASELINE.json configs[2]: the 999 698-triangle heightfield with one grey Substitute material
-    mesh_material = scenes.substitute((0.5, 0.5, 0.5)) if mesh is not None else None
-    if args.scene == "outdoor":
-        scenes.outdoor(eng, w, h, total_spp, integrator="PTMIS", material="substitute", sky="canopy", sky_map=scenes.sky_image(1024, 1024),
-                       sky_spectrum=(1.0, 1.0, 1.0), showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16)
-    else:
-        glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if args.scene == "cornell_glass" else None
-        scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=args.material, boxes=mesh is None, mesh=mesh,
-                       mesh_material=mesh_material, glass_objects=glass)
-    eng.start_frame(0)
-    lib, ctx = eng.lib, eng.context()
-    if args.batch_mpaths:
-        assert lib.zygpu_set_option(ctx, b"batch_mpaths", args.batch_mpaths) == 0
-    assert lib.zygpu_set_option(ctx, b"fuse_trace_shade", args.fuse) == 0
-    assert lib.zygpu_set_option(ctx, b"precise", args.precise) == 0, lib.zygpu_last_error().decode()
-    fused = bool(args.fuse) and args.scene in ("cornell", "cornell_mesh")  # POOL scenes always run the kernels apart
-    nee_in_place = args.nee == "in-place"
-    assert lib.zygpu_set_option(ctx, b"nee_in_place", 1 if nee_in_place else 0) == 0
+    m = Measurement(args, zyg_amd, scenes, torch, frame, device, args.scene, args.material, args.steps, args.warmup)
+    r = m.run()
 
-    film = torch.zeros((h, w, 4), dtype=torch.float32, device=device)
-    assert lib.zygpu_set_external_film(ctx, ctypes.c_void_p(film.data_ptr())) == 0
-
-    def render(first_iteration, count):
-        rc = lib.zygpu_render(ctx, 0, first_iteration, count, 0, h)
-        if rc != 0:
-            raise RuntimeError("zygpu_render: " + lib.zygpu_last_error().decode())
-
-    # algorithmic bytes per sample from the device traversal counters of one stats-enabled iteration
-    lib.zygpu_enable_stats(ctx, 1)
-    lib.zygpu_reset_stats(ctx)
-    render(0, 1)
-    assert lib.zygpu_synchronize(ctx) == 0
-    st = eng.stats()
-    lib.zygpu_enable_stats(ctx, 0)
-    samples_stat = max(st.camera_samples, 1)
-    bytes_sample_total = st.algorithmic_bytes(0) / samples_stat
-    # split of the §8(d) terms over the wavefront kernels (DESIGN.md "Algorithmic bytes"); B_trav is counted per kernel
-    # (zygpu_get_kernel_stats): wf_intersect walks for extension rays, wf_shade for the unoccluding lights, wf_shadow
-    # for shadow rays.
-    #   per extension ray, 224 = ray read 32 + hit write 16 (wf_intersect) + hit read 16 + state read 64 (wf_shade)
-    #                            + state write 64 + ray write 32 (wf_extend)
-    #   per shadow ray,     96 = ray write 32 + contribution write 16 (wf_nee) + ray read 32 + visibility 16 (wf_shadow)
-    #   B_film 32 per camera sample: staged by finalize, gathered by film_accumulate (not a wavefront kernel)
-    names = ("wf_intersect", "wf_shade", "wf_nee", "wf_shadow", "wf_extend", "wf_scatter")
-    ks = (zyg_amd.Stats * len(names))()
-    assert lib.zygpu_get_kernel_stats(ctx, ks) == 0
-
-    def trav(x):
-        return 32 * x.nodes_fetched + 48 * x.triangles_tested + 104 * x.instances_tested
-
-    kernel_bytes_sample = {
-        "wf_intersect": (48 * st.extension_rays + trav(ks[0])) / samples_stat,
-        "wf_shade": (80 * st.extension_rays + trav(ks[1])) / samples_stat,
-        "wf_nee": (48 * st.shadow_rays) / samples_stat,
-        "wf_shadow": (48 * st.shadow_rays + trav(ks[3])) / samples_stat,
-        "wf_extend": (96 * st.extension_rays) / samples_stat,
-        "wf_scatter": (96 * st.extension_rays + 96 * st.shadow_rays + trav(ks[5])) / samples_stat,
-    }
-    if nee_in_place:
-        kernel_bytes_sample["wf_nee"] = kernel_bytes_sample["wf_shadow"] = kernel_bytes_sample["wf_extend"] = 0.0
-    if fused:  # wf_trace_shade is timed as kernel 0 and does both kernels' work; kernel 1 is wf_shade's second pass only
-        kernel_bytes_sample["wf_intersect"] += kernel_bytes_sample["wf_shade"]
-        kernel_bytes_sample["wf_shade"] = 0.0
-
-    for i in range(wu):
-        render(i * ips, ips)
-    assert lib.zygpu_synchronize(ctx) == 0
-    film.zero_()
-    dtmp = ctypes.c_double * len(names)
-    ltmp = ctypes.c_uint64 * len(names)
-    lib.zygpu_kernel_time(ctx, dtmp(), ltmp(), 1)
-
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    base = rank * k * ips
-    for s in range(k):
-        render(base + s * ips, ips)
-    assert lib.zygpu_synchronize(ctx) == 0
-    if dist:
-        dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    ms, launches = dtmp(), ltmp()
-    lib.zygpu_kernel_time(ctx, ms, launches, 0)
-
-    out = None
-    if rank == 0:
-        samples_total = float(w) * h * ips * k * n
-        samples_rank = float(w) * h * ips * k
-        value = samples_total / elapsed / 1e6
-        kernels = [(nm, ms[i], launches[i], kernel_bytes_sample[nm]) for i, nm in enumerate(names)]
-        dom = max(kernels, key=lambda t: t[1])
-        avg_ms = dom[1] / max(dom[2], 1)
-        bytes_per_launch = dom[3] * samples_rank / max(dom[2], 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same configuration
-        # (tools/pmc_traffic.py -> profiles/traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so they cannot
-        # be collected from inside this process); null for any other configuration
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        default_cfg = (args.scene == "cornell" and args.material == "lambert" and (w, h, ips) == (1920, 1080, ITER_PER_STEP)
-                       and not args.batch_mpaths)
-        if default_cfg and os.path.exists(tpath):
-            prof = json.load(open(tpath))
-            for key, val in prof.items():
-                if key.startswith(dom[0]) and "true" not in key:
-                    traffic = round(val["hbm_bytes_per_launch"], 1)
+    if 0 == rank:
+        traffic, source = committed_traffic(args, "wf_trace_shade" if (m.fused and "wf_intersect" == r["dominant"]) else r["dominant"])
+        hbm_bytes = traffic["hbm_bytes_per_launch"] if traffic else None
         # a measured ceiling beside the nominal peak (SURVEY §8(d)): device-to-device copy of 2 GiB, read + written bytes
         copy_gbs = None
         try:
@@ -215,102 +378,72 @@ def main():
             del src, dst
         except RuntimeError:
             pass
-        weights = film[..., 3]
-        geometry = "2 boxes" if mesh is None else "999698-triangle heightfield mesh (Substitute)"
-        if args.scene == "cornell_glass":
-            geometry = "tall box, glass box (ior 1.5, absorbing), glass Sphere"
-        bsdf = "Lambertian" if args.material == "lambert" else "Substitute (roughness 0.8)"
+        weights = m.film[..., 3]
         out = {
             "metric": "Msamples/sec (whole node) at 1080p/256spp; RMS vs CPU reference",
-            "value": round(value, 3),
+            "value": round(r["value"], 3),
             "unit": "Msamples/s",
             "n_gpus": n,
-            "steps": k,
-            "warmup": wu,
-            "ms_per_step": round(elapsed / k * 1e3, 3),
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"outdoor scene (ground, 2 boxes (one glass), glass + gold Spheres, 999698-triangle mesh in "
-                                    f"polished iron, 1024^2 canopy image light + Distant sun), {w}x{h}, PTMIS depth 16, Sobol, box "
-                                    f"sensor, {ips} iterations per step, {k * ips} spp per GPU" if args.scene == "outdoor" else
-                                    f"Cornell box (5 Rectangle walls, {geometry}, 2 unoccluding Rectangle lights) + "
-                                    f"{bsdf} BSDF, {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
-                                    f"{k * ips} spp per GPU"), "scene": args.scene, "material": args.material,
+            "config": {"workload": describe(args.scene, args.material, args.width, args.height, args.iters_per_step, args.steps, args.precise),
+                       "scene": args.scene, "material": args.material, "arithmetic": "precise" if args.precise else "relaxed",
                        "parallelism": f"iterations x{n}"},
-            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            # `achieved` / `frac`: the contract's figure, SURVEY §8(d)'s cache-less algorithmic bytes over the kernel's
+            # measured duration.  For scenes that fit the caches most of those bytes (B_trav) never reach HBM: the bytes
+            # that must (`state_bytes_per_launch`: the ray / hit / state records) and the measured HBM-side traffic of the
+            # same kernel stand beside it, `waste` = traffic / state bytes is what there is to remove.
+            "roofline": {"bound": "hbm", "kernel": r["dominant"], "achieved": round(r["achieved"], 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(r["achieved"] / HBM_PEAK_GBS, 5),
+                         "traffic": round(hbm_bytes, 1) if hbm_bytes else None, "traffic_source": source,
+                         "traffic_frac": round(hbm_bytes / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if hbm_bytes else None,
+                         "state_bytes_per_launch": round(r["state_bytes_per_launch"], 1),
+                         "waste": round(hbm_bytes / r["state_bytes_per_launch"], 3) if hbm_bytes and r["state_bytes_per_launch"] else None,
                          "measured_copy_gbs": copy_gbs,
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
-                         "avg_launch_ms": round(avg_ms, 5), "launches": int(dom[2]),
-                         "algorithmic_bytes_per_sample": round(bytes_sample_total, 1),
-                         "kernel_bytes_per_sample": round(dom[3], 1),
-                         "kernel_ms": {nm: round(ms[i], 3) for i, nm in enumerate(names)},
-                         "kernel_bytes": {nm: round(v, 1) for nm, v in kernel_bytes_sample.items()}},
+                         "algorithmic_bytes_per_launch": round(r["algorithmic_bytes_per_launch"], 1),
+                         "avg_launch_ms": round(r["avg_ms"], 5), "launches": r["launches"],
+                         "algorithmic_bytes_per_sample": round(r["bytes_per_sample"], 1),
+                         "state_bytes_per_sample": round(r["state_bytes_per_sample"], 1),
+                         "kernel_bytes_per_sample": round(r["kernel_bytes_per_sample"], 1),
+                         "kernel_ms": r["kernel_ms"], "kernel_bytes": r["kernel_bytes"]},
             "film_weight_min_max": [float(weights.min().item()), float(weights.max().item())],
         }
-        if n == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["rms_vs_oracle"] = cpu_baseline(eng, w, h, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        oracle = None
+        if 1 == n and not args.no_cpu_baseline:
+            oracle = Oracle(zyg_amd)
+            out["cpu_baseline"], cpu_rate, threads = cpu_baseline(m, oracle, args.cpu_seconds)
+            out["rms_vs_oracle"] = parity_band(m, oracle, cpu_rate, threads, args.cpu_seconds, args.steps * args.iters_per_step)
+    m.close()
 
-    lib.zygpu_set_external_film(ctx, None)
-    eng.release()
+    # BASELINE.json configs[2] (the 1 M-triangle mesh in the box) in the same run, so that its number is witnessed by whoever
+    # runs this file: fewer steps, same sizes, its own roofline figures and parity band
+    if 0 == rank and 1 == n and not args.no_extra and args.scene == "cornell":
+        m2 = Measurement(args, zyg_amd, scenes, torch, frame, device, "cornell_mesh", "lambert", max(2, args.steps // 4), 1)
+        r2 = m2.run()
+        extra = {"value": round(r2["value"], 3), "unit": "Msamples/s", "steps": m2.steps, "ms_per_step": round(r2["elapsed"] / m2.steps * 1e3, 3),
+                 "workload": describe("cornell_mesh", "lambert", args.width, args.height, args.iters_per_step, m2.steps, args.precise),
+                 "kernel": r2["dominant"], "achieved": round(r2["achieved"], 2), "frac": round(r2["achieved"] / HBM_PEAK_GBS, 5),
+                 "avg_launch_ms": round(r2["avg_ms"], 5), "algorithmic_bytes_per_sample": round(r2["bytes_per_sample"], 1),
+                 "state_bytes_per_sample": round(r2["state_bytes_per_sample"], 1), "kernel_ms": r2["kernel_ms"]}
+        if oracle is not None:
+            film = np.zeros((m2.h, m2.w, 4), dtype=np.float32)
+            probe = oracle.render(m2.eng, film, 0, 1, 0, 64, threads)
+            rate = m2.w * 64 / probe / 1e6
+            extra["rms_vs_oracle"] = parity_band(m2, oracle, rate, threads, args.cpu_seconds, m2.steps * args.iters_per_step)
+        out["extra"] = {"cornell_mesh": extra}
+        m2.close()
+
+    if 0 == rank:
+        print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def cpu_baseline(eng, w, h, budget_s):
-    """Times the CPU oracle (a port of the reference's loop; the Zig reference cannot be built here) on the host cores
-    over a bounded sample of the same workload, and checks the GPU image against it on exactly those iterations."""
-    import subprocess
-
-    import numpy as np
-
-    import zyg_amd
-    oracle_so = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not os.path.exists(oracle_so):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
-    oracle = ctypes.CDLL(oracle_so)
-    oracle.zyg_oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
-                                         ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
-                                         ctypes.c_void_p]
-    oracle.zyg_oracle_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
-    sd = eng.lib.su_ext_scene_desc().contents
-    vd = eng.lib.su_ext_view_desc().contents
-    cores = os.cpu_count() or 1
-    film = np.zeros((h, w, 4), dtype=np.float32)
-    st = zyg_amd.Stats()
-    iters = 0
-    t0 = time.perf_counter()
-    while True:
-        oracle.zyg_oracle_render(ctypes.addressof(sd), ctypes.addressof(vd), 0, iters, 1, 1, 0, h, film.ctypes.data, cores,
-                                 ctypes.byref(st))
-        iters += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or dt / iters * (iters + 1) > budget_s * 1.5:
-            break
-    cpu_val = w * h * iters / dt / 1e6
-
-    # parity on the same iterations: GPU film for iterations [0, iters) vs the oracle film
-    lib, ctx = eng.lib, eng.context()
-    lib.zygpu_set_external_film(ctx, None)
-    lib.zygpu_clear_film(ctx, ctypes.c_float(0.0))
-    lib.zygpu_render(ctx, 0, 0, iters, 0, h)
-    lib.zygpu_synchronize(ctx)
-    gpu_img = eng.resolve(w, h)
-    cpu_img = np.zeros_like(film)
-    oracle.zyg_oracle_resolve(ctypes.addressof(vd), film.ctypes.data, cpu_img.ctypes.data, w * h)
-    a = np.clip(np.nan_to_num(gpu_img[..., :3]), 0, 1).astype(np.float64)
-    b = np.clip(np.nan_to_num(cpu_img[..., :3]), 0, 1).astype(np.float64)
-    rms = float(np.sqrt(np.mean((a - b) ** 2)))
-    gpu_film = eng.download_film(w, h)
-    identical = float(np.mean(np.all(gpu_film == film, axis=-1)))
-    base = {"value": round(cpu_val, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} iteration(s) of the same {w}x{h} frame ({w * h * iters} camera samples), {dt:.1f} s"}
-    return base, {"rms": rms, "iterations": iters, "bit_identical_pixels": identical}
 
 
 if __name__ == "__main__":

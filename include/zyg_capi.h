@@ -26,9 +26,9 @@ typedef void (*su_log_func)(uint32_t level, const char* text);  /* core/log.zig:
 typedef void (*su_progress_start_func)(uint32_t resolution);    /* core/progress.zig:3-77 */
 typedef void (*su_progress_tick_func)(void);
 
-int32_t su_init(void);                                                   /* capi.zig:57-117 */
-int32_t su_release(void);                                                /* capi.zig:119-133 */
-int32_t su_mount(const char* folder);                                    /* capi.zig:135-141 */
+int32_t su_init(void);                                                   /* capi.zig:57-114 */
+int32_t su_release(void);                                                /* capi.zig:116-129 */
+int32_t su_mount(const char* folder);                                    /* capi.zig:131-141 */
 int32_t su_perspective_camera_create(uint32_t width, uint32_t height);  /* capi.zig:143-167; returns camera entity */
 int32_t su_camera_set_fov(float fov);                                    /* capi.zig:169-176; radians */
 int32_t su_camera_sensor_dimensions(int32_t* dimensions);                /* capi.zig:178-187 */
@@ -37,31 +37,31 @@ int32_t su_aovs_create(const char* json);                                /* capi
 int32_t su_sampler_create(uint32_t num_samples);                         /* capi.zig:215-221; always returns -1, as the reference */
 int32_t su_integrators_create(const char* json);                         /* capi.zig:223-234 */
 int32_t su_image_create(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height,
-                        uint32_t depth, uint32_t pixel_stride, const uint8_t* data); /* capi.zig:236-297 */
-int32_t su_image_update(uint32_t id, uint32_t pixel_stride, const uint8_t* data);   /* capi.zig:299-338 */
-int32_t su_material_create(uint32_t id, const char* json);               /* capi.zig:340-351 */
-int32_t su_material_update(uint32_t id, const char* json);               /* capi.zig:353-376 */
+                        uint32_t depth, uint32_t pixel_stride, const uint8_t* data); /* capi.zig:236-298 */
+int32_t su_image_update(uint32_t id, uint32_t pixel_stride, const uint8_t* data);   /* capi.zig:300-340 */
+int32_t su_material_create(uint32_t id, const char* json);               /* capi.zig:342-353 */
+int32_t su_material_update(uint32_t id, const char* json);               /* capi.zig:355-377 */
 int32_t su_triangle_mesh_create(uint32_t id, uint32_t num_parts, const uint32_t* parts, uint32_t num_triangles,
                                 const uint32_t* indices, uint32_t num_vertices, const float* positions,
                                 uint32_t positions_stride, const float* normals, uint32_t normals_stride,
                                 const float* tangents, uint32_t tangents_stride, const float* uvs, uint32_t uvs_stride,
-                                bool asyncr); /* capi.zig:378-424; parts = {start_index, num_indices, material} x num_parts */
-int32_t su_prop_create(uint32_t shape, uint32_t num_materials, const uint32_t* materials); /* capi.zig:426-456 */
-int32_t su_prop_create_instance(uint32_t entity);                        /* capi.zig:458-470 */
-int32_t su_light_create(uint32_t prop);                                  /* capi.zig:472-484 */
-int32_t su_prop_set_transformation(uint32_t prop, const float* trafo);   /* capi.zig:486-506; 16 floats, row-major, translation in [12..14] */
-int32_t su_prop_set_transformation_frame(uint32_t prop, uint32_t frame, const float* trafo); /* capi.zig:508-536 */
-int32_t su_prop_set_visibility(uint32_t prop, uint32_t in_camera, uint32_t in_reflection, uint32_t in_sss); /* capi.zig:538-549 */
-int32_t su_render_frame(uint32_t frame);                                 /* capi.zig:551-572 */
-int32_t su_export_frame(void);                                           /* capi.zig:574-584 */
-int32_t su_start_frame(uint32_t frame);                                  /* capi.zig:586-605 */
-int32_t su_render_iterations(uint32_t num_steps);                        /* capi.zig:607-616 */
-int32_t su_resolve_frame(uint32_t aov);                                  /* capi.zig:618-629 */
-int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height, float* buffer); /* capi.zig:631-646 */
+                                bool asyncr); /* capi.zig:379-423; parts = {start_index, num_indices, material} x num_parts */
+int32_t su_prop_create(uint32_t shape, uint32_t num_materials, const uint32_t* materials); /* capi.zig:425-455 */
+int32_t su_prop_create_instance(uint32_t entity);                        /* capi.zig:457-469 */
+int32_t su_light_create(uint32_t prop);                                  /* capi.zig:471-483 */
+int32_t su_prop_set_transformation(uint32_t prop, const float* trafo);   /* capi.zig:485-504; 16 floats, row-major, translation in [12..14] */
+int32_t su_prop_set_transformation_frame(uint32_t prop, uint32_t frame, const float* trafo); /* capi.zig:506-533 */
+int32_t su_prop_set_visibility(uint32_t prop, uint32_t in_camera, uint32_t in_reflection, uint32_t in_sss); /* capi.zig:535-546 */
+int32_t su_render_frame(uint32_t frame);                                 /* capi.zig:548-567 */
+int32_t su_export_frame(void);                                           /* capi.zig:569-579 */
+int32_t su_start_frame(uint32_t frame);                                  /* capi.zig:581-600 */
+int32_t su_render_iterations(uint32_t num_steps);                        /* capi.zig:602-611 */
+int32_t su_resolve_frame(uint32_t aov);                                  /* capi.zig:613-624 */
+int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height, float* buffer); /* capi.zig:626-641 */
 int32_t su_copy_framebuffer(uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height,
-                            uint8_t* destination);                       /* capi.zig:648-729 */
-int32_t su_register_log(su_log_func post);                              /* capi.zig:731-734 */
-int32_t su_register_progress(su_progress_start_func start, su_progress_tick_func tick); /* capi.zig:736-743 */
+                            uint8_t* destination);                       /* capi.zig:643-724 */
+int32_t su_register_log(su_log_func post);                              /* capi.zig:726-729 */
+int32_t su_register_progress(su_progress_start_func start, su_progress_tick_func tick); /* capi.zig:731-738 */
 
 /* ---- additions (no reference counterpart) ---- */
 

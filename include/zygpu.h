@@ -301,6 +301,14 @@ enum ZygpuAovClass { ZYGPU_AOV_ALBEDO = 0, ZYGPU_AOV_DEPTH = 1, ZYGPU_AOV_MATERI
                      ZYGPU_AOV_SHADING_NORMAL = 4, ZYGPU_AOV_ROUGHNESS = 5, ZYGPU_AOV_EMISSION = 6, ZYGPU_AOV_DIRECT = 7,
                      ZYGPU_AOV_INDIRECT = 8, ZYGPU_AOV_NUM_CLASSES = 9 };
 
+/* reference base/math/transformation.zig: one keyframe of an animated entity (rotation is a quaternion x, y, z, w) */
+typedef struct ZygpuKeyframe {
+    float position[4];
+    float scale[4];
+    float rotation[4];
+} ZygpuKeyframe;
+#define ZYGPU_MAX_CAMERA_KEYFRAMES 4
+
 typedef struct ZygpuViewDesc {
     int32_t  resolution[2];
     int32_t  crop[4]; /* x0, y0, x1, y1 (exclusive end), camera_base.zig:31-41 */
@@ -330,6 +338,14 @@ typedef struct ZygpuViewDesc {
     uint32_t tonemapper;      /* enum ZygpuTonemapper (tonemapper.zig:9) */
     /* AOVs (sensor/aov/aov_value.zig:11-48): bit k = class k is recorded; ZygpuAovClass */
     uint32_t aov_slots;
+    /* Animated camera (su_prop_set_transformation_frame on the camera entity; space.zig:23-26, 99-137): keyframes one tick
+     * (1/60 s, space.zig:19) apart, the first at the frame's start (scene.zig:186-187), in world space.  A camera sample's
+     * shutter time picks the interval and the weight (camera_base.zig:121-136, space.zig:127-137), the two keyframes are
+     * interpolated (transformation.zig:36-44: lerp, lerp, slerp) and the scene origin (= keyframe 0's position, everything
+     * else in the scene is relative to it) is subtracted from the result (space.zig:121-124).  0 = static: camera_trafo. */
+    uint32_t      camera_num_keyframes;
+    float         camera_origin[4];
+    ZygpuKeyframe camera_keyframes[ZYGPU_MAX_CAMERA_KEYFRAMES];
 } ZygpuViewDesc;
 
 /* tonemapper.zig:9; AgX with the look the take loader picks (take_loader.zig:268-270: Substitute) */
@@ -405,6 +421,11 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * "batch_mpaths" (default 32, 1..512) sets the number of paths per batch in units of 2^20 (the path pool takes about
  * 450 B per path). */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
+
+/* Measurement support (tools/calibrate_fetch.py): `repeats` launches of a kernel whose lane i reads the 16 B record at
+ * i * stride_bytes (stride 16 / 64 / 128 / 256 / 512) of a zero-filled buffer of num_records records; average ms per launch.
+ * Run under `rocprofv3 --pmc FETCH_SIZE` it calibrates that counter on the access shape of the path-state blocks. */
+int zygpu_calibrate_gather(ZygpuContext* ctx, uint32_t stride_bytes, uint32_t num_records, uint32_t repeats, double* out_ms_per_launch);
 
 /* Counters accumulated since the last reset (only maintained when enabled). */
 int zygpu_enable_stats(ZygpuContext* ctx, int enabled);

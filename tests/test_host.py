@@ -372,3 +372,36 @@ def test_metal_preset_is_a_metallic_substitute(engine):
     np.testing.assert_allclose(list(g.color_a)[:3], conductor([0.18267, 0.49447, 1.3761], [3.1178, 2.3515, 1.8324]), rtol=2e-6)
     assert g.color_a[0] > g.color_a[1] > g.color_a[2]  # gold reflects red most
     np.testing.assert_allclose(list(sd.materials[other].color_a)[:3], conductor([1.5] * 3, [1.0] * 3), rtol=2e-6)
+
+
+def test_malformed_meshes_are_refused(product_lib):
+    """su_triangle_mesh_create validates client data: an index beyond the vertex count, a part range beyond the index
+    buffer, more than 65535 parts (part ids are u16) or an absurd material slot return -1 instead of reading out of bounds."""
+    import ctypes
+
+    import numpy as np
+    lib = product_lib
+    assert lib.su_init() == 0
+    try:
+        pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+        nrm = np.array([[0, 0, 1]] * 3, dtype=np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        up = ctypes.POINTER(ctypes.c_uint32)
+
+        def create(indices, parts=None, num_parts=None):
+            idx = np.asarray(indices, dtype=np.uint32)
+            pr = None if parts is None else np.asarray(parts, dtype=np.uint32)
+            n = (0 if pr is None else len(pr) // 3) if num_parts is None else num_parts
+            return lib.su_triangle_mesh_create(0xFFFFFFFF, n, None if pr is None else pr.ctypes.data_as(up), len(idx) // 3,
+                                               idx.ctypes.data_as(up), 3, pos.ctypes.data_as(fp), 3, nrm.ctypes.data_as(fp), 3,
+                                               None, 0, None, 0, False)
+
+        assert create([0, 1, 2]) >= 7
+        assert create([0, 1, 2], [0, 3, 0]) >= 7
+        assert create([0, 1, 3]) == -1             # index >= num_vertices
+        assert create([0, 1, 2], [0, 6, 0]) == -1  # part range beyond the index buffer
+        assert create([0, 1, 2], [3, 3, 0]) == -1
+        assert create([0, 1, 2], [0, 3, 70000]) == -1  # material slot
+        assert create([0, 1, 2], [0, 3, 0] * 70000) == -1  # 70000 parts
+    finally:
+        lib.su_release()

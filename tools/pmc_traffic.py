@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs) into per-kernel HBM-side bytes per launch.
 
-    python3 tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+    python3 tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [--factor F | --calibration cal.json] [--commit SHA] [--bench-args "..."]
 
-FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3 derived metrics over TCC_EA0_RDREQ / WRREQ).  Corrections per
-/opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies the 128 B requests of wide
-(16 B/lane) loads at 64 B, so it is doubled; WRITE_SIZE is exact for 16 B/lane stores.  The calibration check the guide
-asks for uses wf_generate, whose byte count is known (it only writes: 10 x 16 B + 2 x 8 B + 4 B per path)."""
+FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3 derived metrics over TCC_EA0_RDREQ / WRREQ).  Per
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section) gfx950's FETCH_SIZE tallies the 128 B requests of wide streaming loads at
+64 B, and "other access widths are uncalibrated".  These kernels gather 16 B records out of 256 B blocks, so the factor comes
+from tools/calibrate_fetch.py's measurement on that shape (profiles/r02_fetch_calibration.json, stride 256); --factor overrides.
+WRITE_SIZE is exact for 16 B/lane stores.  The output names the source commit and the bench configuration it was taken
+with: bench.py reports it as `roofline.traffic` only for that configuration."""
+import argparse
 import collections
 import csv
 import glob
 import json
-import sys
 
 
 def load(d, counter):
@@ -28,16 +30,31 @@ def load(d, counter):
     return per
 
 
-fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
-out = {}
+ap = argparse.ArgumentParser()
+ap.add_argument("fetch_dir")
+ap.add_argument("write_dir")
+ap.add_argument("out")
+ap.add_argument("--factor", type=float, default=None)
+ap.add_argument("--calibration", default=None)
+ap.add_argument("--commit", default=None)
+ap.add_argument("--config", default=None, help="JSON object: the bench configuration (bench.py committed_traffic)")
+a = ap.parse_args()
+factor = a.factor
+if factor is None and a.calibration:
+    factor = json.load(open(a.calibration))["strides"]["256"]["fetch_size_factor"]
+if factor is None:
+    factor = 2.0
+fetch, write = load(a.fetch_dir, 'FETCH_SIZE'), load(a.write_dir, 'WRITE_SIZE')
+out = {"_meta": {"fetch_size_factor": factor, "source_commit": a.commit, "config": json.loads(a.config) if a.config else None}}
 for k in sorted(set(fetch) | set(write)):
     if not ('wf_' in k or 'film' in k):
         continue
     fb, fl = fetch.get(k, [0.0, 0])
     wb, wl = write.get(k, [0.0, 0])
     launches = max(fl, wl, 1)
-    out[k] = {"launches": launches, "fetch_bytes_per_launch_raw": fb / launches, "fetch_bytes_per_launch": 2.0 * fb / launches,
-              "write_bytes_per_launch": wb / launches, "hbm_bytes_per_launch": (2.0 * fb + wb) / launches}
-json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    out[k] = {"launches": launches, "fetch_bytes_per_launch_raw": fb / launches, "fetch_bytes_per_launch": factor * fb / launches,
+              "write_bytes_per_launch": wb / launches, "hbm_bytes_per_launch": (factor * fb + wb) / launches}
+json.dump(out, open(a.out, 'w'), indent=1)
 for k, v in out.items():
-    print(f"{k:42s} launches {v['launches']:5d}  fetch x2 {v['fetch_bytes_per_launch'] / 1e6:10.2f} MB  write {v['write_bytes_per_launch'] / 1e6:10.2f} MB")
+    if k != "_meta":
+        print(f"{k:42s} launches {v['launches']:5d}  fetch x{factor:.2f} {v['fetch_bytes_per_launch'] / 1e6:10.2f} MB  write {v['write_bytes_per_launch'] / 1e6:10.2f} MB")

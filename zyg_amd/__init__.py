@@ -120,6 +120,10 @@ class SceneDesc(ctypes.Structure):
                 ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32), ("num_image_lights", ctypes.c_uint32)]
 
 
+class Keyframe(ctypes.Structure):
+    _fields_ = [("position", ctypes.c_float * 4), ("scale", ctypes.c_float * 4), ("rotation", ctypes.c_float * 4)]
+
+
 class ViewDesc(ctypes.Structure):
     _fields_ = [("resolution", ctypes.c_int32 * 2), ("crop", ctypes.c_int32 * 4), ("left_top", ctypes.c_float * 4),
                 ("d_x", ctypes.c_float * 4), ("d_y", ctypes.c_float * 4), ("eye_offset", ctypes.c_float * 4),
@@ -133,7 +137,8 @@ class ViewDesc(ctypes.Structure):
                 ("clamp_emission", ctypes.c_float), ("clamp_direct", ctypes.c_float),
                 ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float),
                 ("alpha_transparency", ctypes.c_uint32), ("tonemapper", ctypes.c_uint32),
-                ("aov_slots", ctypes.c_uint32)]
+                ("aov_slots", ctypes.c_uint32), ("camera_num_keyframes", ctypes.c_uint32), ("camera_origin", ctypes.c_float * 4),
+                ("camera_keyframes", Keyframe * 4)]
 
 
 class Stats(ctypes.Structure):
@@ -266,6 +271,17 @@ class Engine:
         if self.lib.su_ext_sensor_create(json_text.encode()) != 0:
             raise RuntimeError("su_ext_sensor_create failed")
 
+    def camera_parameters(self, json_text):
+        """The take's camera "parameters" object (camera_perspective.zig:260-270): fov (degrees), lens / aperture radius,
+        focus distance.  The reference's C ABI only has su_camera_set_fov; this is an su_ext_* addition."""
+        if self.lib.su_ext_camera_set_parameters(json_text.encode()) != 0:
+            raise RuntimeError("su_ext_camera_set_parameters failed")
+
+    def set_option(self, name, value):
+        """zygpu_set_option on the engine's context (after start_frame): e.g. "precise", "nee_in_place"."""
+        if self.lib.zygpu_set_option(self.context(), name.encode(), int(value)) != 0:
+            raise RuntimeError("zygpu_set_option failed: " + (self.lib.zygpu_last_error() or b"").decode())
+
     # --- resources / scene ---
     def material(self, json_text, id=NULL):
         m = self.lib.su_material_create(id, json_text.encode())
@@ -361,7 +377,10 @@ class Engine:
         return ctypes.c_void_p(self.lib.su_ext_context())
 
     def synchronize(self):
-        self.lib.zygpu_synchronize(self.context())
+        """Waits for the device and raises on a device error flag (e.g. more crossed unoccluding emitters than slots)."""
+        rc = self.lib.zygpu_synchronize(self.context())
+        if rc != 0:
+            raise RuntimeError(f"zygpu_synchronize failed ({rc}): " + (self.lib.zygpu_last_error() or b"").decode())
 
     def resolve(self, width, height):
         out = np.zeros((height, width, 4), dtype=np.float32)

@@ -347,7 +347,7 @@ struct SphQuad {  // rectangle.zig:199-303
         const float fu = (cosF(au) * b0 - b1) / sinF(au);
         float       cu = 1.f / sqrtf(fu * fu + b0 * b0) * (fu > 0.f ? 1.f : -1.f);
         cu = stdClamp(cu, -1.f, 1.f);
-        float xu = -(cu * z0) / sqrtf(1.f - cu * cu);
+        float xu = -(cu * z0) / sqrtD(1.f - cu * cu);
         xu = stdClamp(xu, x0, x1);
         const float dd = sqrtf(xu * xu + z0 * z0);
         const float h0 = y0 / sqrtf(dd * dd + y0 * y0);
@@ -355,7 +355,7 @@ struct SphQuad {  // rectangle.zig:199-303
         const float hv = h0 + u1 * (h1 - h0);
         const float hv2 = hv * hv;
         const float eps = __uint_as_float(0x35800000u);
-        const float yv = hv2 < 1.f - eps ? ((hv * dd) / sqrtf(1.f - hv2)) : y1;
+        const float yv = hv2 < 1.f - eps ? ((hv * dd) / sqrtD(1.f - hv2)) : y1;
         return o + S3(xu) * x + S3(yv) * y + S3(z0) * z;
     }
 
@@ -446,17 +446,17 @@ struct SphereSampler {
         if (!valid) return false;
         const float sin_theta_max = r / l;
         const float sin2_theta_max = sin_theta_max * sin_theta_max;
-        const float cos_theta_max = sqrtf(1.f - sin2_theta_max);
+        const float cos_theta_max = sqrtD(1.f - sin2_theta_max);
         float       one_minus_cos_theta_max = 1.f - cos_theta_max;
         float       cos_theta = (cos_theta_max - 1.f) * s0 + 1.f;
         float       sin2_theta = 1.f - (cos_theta * cos_theta);
         if (sin2_theta_max < 0.00068523f) {
             sin2_theta = sin2_theta_max * s0;
-            cos_theta = sqrtf(1.f - sin2_theta);
+            cos_theta = sqrtD(1.f - sin2_theta);
             one_minus_cos_theta_max = 0.5f * sin2_theta_max;
         }
-        const float cos_alpha = mn(sin2_theta / sin_theta_max + cos_theta * sqrtf(1.f - mn(sin2_theta / sin2_theta_max, 1.f)), 1.f);
-        const float sin_alpha = sqrtf(1.f - cos_alpha * cos_alpha);
+        const float cos_alpha = mn(sin2_theta / sin_theta_max + cos_theta * sqrtD(1.f - mn(sin2_theta / sin2_theta_max, 1.f)), 1.f);
+        const float sin_alpha = sqrtD(1.f - cos_alpha * cos_alpha);
         const float phi = s1 * (2.f * kPi);
         const f3    mw = -mk3(cosF(phi) * sin_alpha, sinF(phi) * sin_alpha, cos_alpha);  // sampling.zig:78-83 sphereDirection
         const f3    wn = fma3(S3(mw.z), z, fma3(S3(mw.y), fy, S3(mw.x) * fx));             // frame.frameToWorld (frame.zig:23-37)
@@ -551,11 +551,11 @@ struct DiskSampler {
         float x, y;
         diskConcentric(r0, r1, x, y);
         float u = x;
-        float pdf_ = sqrtf(1.f - u * u) / (0.25f * kPi);
+        float pdf_ = sqrtD(1.f - u * u) / (0.25f * kPi);
         u = (u + 1.f) * 0.5f;
         float y_coord;
         pdf_ *= eas0.sample(u, y_coord);
-        const float x_chord = sqrtf(radius * radius - y_coord * y_coord);
+        const float x_chord = sqrtD(radius * radius - y_coord * y_coord);
         if (0.f == x_chord) return false;
         const EquiAngularSampling eas1 = EquiAngularSampling::init(lp, S3(y_coord) * dsd.yd, dsd.xd, -x_chord, x_chord);
         if (0.f == eas1.angle_extent) return false;
@@ -593,9 +593,9 @@ ZD float diskPdf(f3 dir, f3 p, const Trafo& trafo, f3 frag_p, uint32_t num_sampl
     float                     u;
     const float               eas_pdf = eas0.pdfAndSample(y_coord, u);
     u = u * 2.f - 1.f;
-    float pdf_ = sqrtf(1.f - u * u) / (0.25f * kPi);
+    float pdf_ = sqrtD(1.f - u * u) / (0.25f * kPi);
     pdf_ *= eas_pdf;
-    const float               x_chord = sqrtf(radius * radius - y_coord * y_coord);
+    const float               x_chord = sqrtD(radius * radius - y_coord * y_coord);
     const EquiAngularSampling eas1 = EquiAngularSampling::init(lp, S3(y_coord) * dsd.yd, dsd.xd, -x_chord, x_chord);
     const float               x_coord = dot3(l_point, dsd.xd);
     pdf_ *= eas1.pdf(x_coord);
@@ -872,13 +872,13 @@ ZD bool sampleSpherical(f3 pos, f3 pa, f3 pb, f3 pc, float r0, float r1, f3& dir
     const float area_S = r0 * sarea;
     const float angle_delta = area_S - alpha;
     const float p = sinF(angle_delta), q = cosF(angle_delta);
-    const float sin_alpha = sqrtf(1.f - cos_alpha * cos_alpha);
+    const float sin_alpha = sqrtD(1.f - cos_alpha * cos_alpha);
     const float u = q - cos_alpha, v = p + sin_alpha * cos_c;
     const float sc = clampf(((v * q - u * p) * cos_alpha - v) / ((v * p + u * q) * sin_alpha), -1.f, 1.f);
-    const f3    C_s = S3(sc) * A + S3(sqrtf(1.f - sc * sc)) * orthogonalize(A, C);
+    const f3    C_s = S3(sc) * A + S3(sqrtD(1.f - sc * sc)) * orthogonalize(A, C);
     const float cs_b = dot3(C_s, B);
     const float z = 1.f - r1 * (1.f - cs_b);
-    const f3    P = S3(z) * B + S3(sqrtf(1.f - z * z)) * orthogonalize(B, C_s);
+    const f3    P = S3(z) * B + S3(sqrtD(1.f - z * z)) * orthogonalize(B, C_s);
     dir = P;
     barycentricCoords(P, pap, pbp, pcp, bu, bv);
     pdf = 1.f / sarea;

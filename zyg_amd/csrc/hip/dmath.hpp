@@ -68,7 +68,9 @@ ZD f3    lerp3(f3 a, f3 b, f3 t) { return fma3(S3(1.f) - t, a, t * b); }
 #if ZYG_FAST
 ZD float sinF(float x) { return sinf(x); }
 ZD float cosF(float x) { return cosf(x); }
-ZD float acosF(float x) { return acosf(x); }
+// normalised vectors are unit length only to an ulp or two here (native rsqrt / rcp): a dot product of 1 + 1e-7 must not
+// turn into a NaN solid angle
+ZD float acosF(float x) { return acosf(fminf(fmaxf(x, -1.f), 1.f)); }
 ZD float tanF(float x) { return tanf(x); }
 ZD float atanF(float x) { return atanf(x); }
 ZD float atan2F(float y, float x) { return atan2f(y, x); }
@@ -276,6 +278,15 @@ ZD float expF(float x) {
 }
 
 #endif  // ZYG_FAST
+
+// The square root of a difference that exact arithmetic keeps >= 0 (1 - cos^2, r^2 - y^2 ...).  With native reciprocals and
+// fused multiply-adds the difference can come out a few ulps below zero where the precise units' stays at or above it; the
+// relaxed units clamp instead of returning NaN (one NaN sample blackens its pixel for good).
+#if ZYG_FAST
+ZD float sqrtD(float x) { return sqrtf(fmaxf(x, 0.f)); }
+#else
+ZD float sqrtD(float x) { return sqrtf(x); }
+#endif
 
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kPiInv = float(1.0 / 3.14159265358979323846);

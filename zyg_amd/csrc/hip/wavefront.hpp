@@ -484,6 +484,17 @@ struct MaskDraw<POOL, false> {
     using type = NoHeadDraw;
 };
 
+// -DZYG_NAN_TRACE builds (development): a non-finite value at a named site sets bit `site` of Control::error
+#ifdef ZYG_NAN_TRACE
+ZD void nanTrace(const Params& P, float v, uint32_t site) {
+    if (!(fabsf(v) <= FLT_MAX)) atomicOr(&P.ctl->error, 1u << site);
+}
+ZD void nanTrace(const Params& P, f3 v, uint32_t site) { nanTrace(P, v.x + v.y + v.z, site); }
+#else
+ZD void nanTrace(const Params&, float, uint32_t) {}
+ZD void nanTrace(const Params&, f3, uint32_t) {}
+#endif
+
 ZD f3 xyz4(float4 v) { return {v.x, v.y, v.z}; }
 ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
 
@@ -547,6 +558,61 @@ ZD bool entersMeshBounds(f3 origin, f3 direction) {
     return hit;
 }
 
+// The camera entity's transformation at a sample's time (scene.propTransformationAt, scene.zig:382-385): Space.frameAt picks the
+// keyframe interval and the weight (space.zig:127-137), math.Transformation.lerp interpolates position and scale linearly and
+// the rotation with quaternion.slerp (transformation.zig:36-44, quaternion.zig:217-245), ComposedTransformation.init rebuilds
+// the rotation rows (composed_transformation.zig:17-29, quaternion.zig:72-116).  Keyframes are one tick (1/60 s) apart.
+ZD Trafo cameraTrafoAt(const ZygpuViewDesc& v, uint32_t frame, float shutter_sample) {
+    const uint64_t tick = 705600000ull / 60;  // space.zig:18-19
+    // Base.absoluteTime (camera_base.zig:129-136); no shutter distribution, so the shutter time is the sample (121-127)
+    const uint64_t fdi = uint64_t(llround(double(shutter_sample) * double(v.frame_duration)));
+    const uint64_t start_time = uint64_t(frame) * v.frame_step;
+    const uint64_t time = start_time + fdi;
+    const uint64_t frame_start = start_time - (start_time % tick);  // scene.zig:186-187
+    uint64_t       i = (time - frame_start) / tick;
+    const uint64_t a_time = frame_start + i * tick;
+    float          wgt = float(double(time - a_time) / double(tick));
+    // a shutter sample of exactly 1.0 lands on the last keyframe, where the reference reads one keyframe past its array
+    if (i + 1 >= v.camera_num_keyframes) {
+        i = v.camera_num_keyframes - 2;
+        wgt = 1.f;
+    }
+    const ZygpuKeyframe& ka = v.camera_keyframes[i];
+    const ZygpuKeyframe& kb = v.camera_keyframes[i + 1];
+    const f3 t3 = S3(wgt);
+    Trafo    out;
+    out.position = lerp3(mk3(ka.position[0], ka.position[1], ka.position[2]), mk3(kb.position[0], kb.position[1], kb.position[2]), t3) -
+                   mk3(v.camera_origin[0], v.camera_origin[1], v.camera_origin[2]);  // space.zig:121-124
+    out.scale = lerp3(mk3(ka.scale[0], ka.scale[1], ka.scale[2]), mk3(kb.scale[0], kb.scale[1], kb.scale[2]), t3);
+    const float qa[4] = {ka.rotation[0], ka.rotation[1], ka.rotation[2], ka.rotation[3]};
+    float       end[4] = {kb.rotation[0], kb.rotation[1], kb.rotation[2], kb.rotation[3]};
+    float       cosom = qa[0] * end[0] + qa[1] * end[1] + qa[2] * end[2] + qa[3] * end[3];
+    if (cosom < 0.f) {
+        cosom = -cosom;
+        for (int k = 0; k < 4; ++k) end[k] = -end[k];
+    }
+    float sclp, sclq;
+    if (1.f - cosom > 0.00001f) {
+        const float omega = acosF(cosom), sinom = sinF(omega);
+        sclp = sinF((1.f - wgt) * omega) / sinom;
+        sclq = sinF(wgt * omega) / sinom;
+    } else {
+        sclp = 1.f - wgt;
+        sclq = wgt;
+    }
+    float q[4];
+    for (int k = 0; k < 4; ++k) q[k] = sclp * qa[k] + sclq * end[k];
+    const float tq[4] = {q[0] + q[0], q[1] + q[1], q[2] + q[2], q[3] + q[3]};
+    const float xy = tq[1] * q[0], xz = tq[2] * q[0], yz = tq[1] * q[2];
+    const float w0 = tq[0] * q[3], w1 = tq[1] * q[3], w2 = tq[2] * q[3];
+    const float t0 = (q[3] + q[1]) * (q[3] - q[1]), t1 = (q[0] + q[2]) * (q[0] - q[2]);
+    const float t2 = (q[3] + q[0]) * (q[3] - q[0]), t3q = (q[1] + q[2]) * (q[1] - q[2]);
+    out.r0 = mk3(t0 + t1, xy - w2, xz + w1);
+    out.r1 = mk3(xy + w2, t2 + t3q, yz - w0);
+    out.r2 = mk3(xz - w1, yz + w0, t2 - t3q);
+    return out;
+}
+
 // ---------------------------------------------------------------- wf_generate
 // Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
 // Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
@@ -578,7 +644,7 @@ ZD void generatePath(const Params& P, uint32_t slot) {
 
     float s0, s1, s2, s3;
     h.smp.sample4D(s0, s1, s2, s3);
-    (void)h.smp.sample1D();  // shutter time: static scenes only use it to select keyframes (space.zig:99-108)
+    const float shutter_sample = h.smp.sample1D();  // sensor.zig:157: the camera sample's time
     h.smp.incrementPadding();
 
     const float          cx = float(x) + s0, cy = float(y) + s1;
@@ -596,11 +662,15 @@ ZD void generatePath(const Params& P, uint32_t slot) {
         origin = mk3(v.eye_offset[0], v.eye_offset[1], v.eye_offset[2]);
     }
     Trafo ct;
-    ct.r0 = mk3(v.camera_trafo.r[0][0], v.camera_trafo.r[0][1], v.camera_trafo.r[0][2]);
-    ct.r1 = mk3(v.camera_trafo.r[1][0], v.camera_trafo.r[1][1], v.camera_trafo.r[1][2]);
-    ct.r2 = mk3(v.camera_trafo.r[2][0], v.camera_trafo.r[2][1], v.camera_trafo.r[2][2]);
-    ct.scale = mk3(v.camera_trafo.r[0][3], v.camera_trafo.r[1][3], v.camera_trafo.r[2][3]);
-    ct.position = mk3(v.camera_trafo.position[0], v.camera_trafo.position[1], v.camera_trafo.position[2]);
+    if (v.camera_num_keyframes > 1) {  // an animated camera: its transformation at the sample's time
+        ct = cameraTrafoAt(v, c_view.frame, shutter_sample);
+    } else {
+        ct.r0 = mk3(v.camera_trafo.r[0][0], v.camera_trafo.r[0][1], v.camera_trafo.r[0][2]);
+        ct.r1 = mk3(v.camera_trafo.r[1][0], v.camera_trafo.r[1][1], v.camera_trafo.r[1][2]);
+        ct.r2 = mk3(v.camera_trafo.r[2][0], v.camera_trafo.r[2][1], v.camera_trafo.r[2][2]);
+        ct.scale = mk3(v.camera_trafo.r[0][3], v.camera_trafo.r[1][3], v.camera_trafo.r[2][3]);
+        ct.position = mk3(v.camera_trafo.position[0], v.camera_trafo.position[1], v.camera_trafo.position[2]);
+    }
     const f3 origin_w = ct.objectToWorldPoint(origin);
     const f3 direction_w = ct.objectToWorldVector(normalize3(direction));
 
@@ -1002,6 +1072,8 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         // Beer-Lambert over the segment to the hit; Context.nextEvent runs before connectLight
         if (has_hit && md.index > 0) throughput = throughput * attenuation3(md.topAbsorption(), hit.t - 0.f);
     }
+    nanTrace(P, energy, 8);
+    nanTrace(P, throughput, 9);
     // split_throughput = vertex.throughput * split_weight (pathtracer_mis.zig:61-62)
     ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * energy, h.depth_surface, mis ? 2u : 1u,
               0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
@@ -1547,6 +1619,12 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                     const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
+                    nanTrace(P, ls.wi, 10);
+                    nanTrace(P, ls.pdf, 11);
+                    nanTrace(P, radiance, 12);
+                    nanTrace(P, bx.reflection, 13);
+                    nanTrace(P, bx.pdf, 14);
+                    nanTrace(P, pick.pdf, 15);
                     if (mis) {
                         const float light_pdf = ls.pdf * pick.pdf;
                         const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
@@ -1755,6 +1833,11 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 P.pool.vgeo_n[slot] = f4(ms.geo_n);
             }
             throughput = throughput * (bs.reflection / S3(bs.pdf));
+            nanTrace(P, bs.reflection, 16);
+            nanTrace(P, bs.pdf, 17);
+            nanTrace(P, bs.wi, 18);
+            nanTrace(P, sf.p, 19);
+            nanTrace(P, throughput, 20);
             const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
             h.depth_surface += 1;
             h.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight): a reflection clears it

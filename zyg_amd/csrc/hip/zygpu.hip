@@ -270,6 +270,17 @@ __global__ void aov_resolve(const float4* plane, float4* out, uint32_t n, uint32
     }
 }
 
+// Calibration of the rocprofv3 FETCH_SIZE counter on this library's access shape (tools/calibrate_fetch.py, MI355X_MICROARCH.md
+// "calibrate on a known byte count in your own access pattern"): lane i reads one 16 B record at i * STRIDE bytes of a buffer
+// far larger than the 256 MB Infinity Cache, as the kernels read 16 B records of the 256 B path blocks.
+template <uint32_t STRIDE>
+__global__ void __launch_bounds__(256) calib_gather(const char* data, uint32_t n, uint32_t* sink) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 v = *reinterpret_cast<const uint4*>(data + size_t(i) * STRIDE);
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u) sink[0] = i;  // never true for the zero-filled buffer: keeps the load alive
+}
+
 __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -571,6 +582,20 @@ std::pair<hipEvent_t, hipEvent_t>* nextEvents(ZygpuContext* c, int k) {
 uint64_t g_view_epoch = 0, g_unit_view_epoch[2][ZYG_NUM_UNITS] = {};
 
 // A unit's copy of the view block is brought up to date (in stream order) before the first launch that needs it
+// The device error flags (Control::error), read after the stream has drained.  Set by the kernels when a result would be
+// wrong (bit 1: a ray crossed more unoccluding emitters than kMaxUnoccludingCandidates holds, the extra emission is lost);
+// reported by every call that hands pixels to the caller, cleared at the start of a frame (zygpu_clear_film / zygpu_upload_scene).
+int deviceErrorFlags(ZygpuContext* c) {
+    uint32_t flags = 0;
+    if (!check(hipMemcpy(&flags, &c->ctl->error, sizeof(flags), hipMemcpyDeviceToHost), "hipMemcpy(Control::error)")) return -1;
+    if (0 == flags) return 0;
+    g_error = "device error flags: " + std::to_string(flags);
+    if (flags & 2u)
+        g_error += " (a ray crossed more than 4 unoccluding emitters (Rectangles / mesh triangles) in front of its hit: "
+                   "kMaxUnoccludingCandidates; their emission is missing from the film)";
+    return -3;
+}
+
 void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params& P, uint32_t arg) {
     const int mode = c->relaxed ? 1 : 0, unit = kUnitOf[id];
     if (g_unit_view_epoch[mode][unit] != c->view_epoch) {
@@ -891,6 +916,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
     }
     HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemsetAsync(&c->ctl->error, 0, sizeof(uint32_t), c->stream));
     if (!setUnitConstants(ZYG_CONST_SCENE, &s, sizeof(DScene), c->stream)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     c->has_scene = true;
@@ -951,6 +977,7 @@ int zygpu_set_external_film(ZygpuContext* c, void* device_rgbw) {
 int zygpu_clear_film(ZygpuContext* c, float weight) {
     if (!c || !c->has_view) return -1;
     HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemsetAsync(&c->ctl->error, 0, sizeof(uint32_t), c->stream));  // a new frame: the flags of the last one are history
     const uint32_t n = uint32_t(c->film_pixels);
     hipLaunchKernelGGL(film_clear, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->film_active, c->film_alpha_active, n, weight);
     for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES; ++k)
@@ -1206,14 +1233,7 @@ int zygpu_synchronize(ZygpuContext* c) {
     if (!c) return -1;
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
-    Control h;
-    HIP_OK(hipMemcpy(&h, c->ctl, sizeof(Control), hipMemcpyDeviceToHost));
-    if (h.error) {
-        g_error = "device error flags: " + std::to_string(h.error);
-        if (h.error & 2u) g_error += " (a ray crossed more than 4 unoccluding emitters (Rectangles / mesh triangles) in front of its hit: kMaxUnoccludingCandidates)";
-        return -3;
-    }
-    return 0;
+    return deviceErrorFlags(c);
 }
 
 int zygpu_download_film(ZygpuContext* c, float* host_rgbw) {
@@ -1221,7 +1241,7 @@ int zygpu_download_film(ZygpuContext* c, float* host_rgbw) {
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(host_rgbw, c->film_active, c->film_pixels * sizeof(float4), hipMemcpyDeviceToHost));
-    return 0;
+    return deviceErrorFlags(c);
 }
 
 int zygpu_upload_film(ZygpuContext* c, const float* host_rgbw) {
@@ -1273,7 +1293,7 @@ int zygpu_resolve_aov(ZygpuContext* c, uint32_t cls, float* host_rgba, uint32_t 
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(host_rgba, c->resolve_tmp, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));
-    return 0;
+    return deviceErrorFlags(c);
 }
 int zygpu_download_aov(ZygpuContext* c, uint32_t cls, float* host_plane) {
     if (!c || !c->has_view || !host_plane || cls >= ZYGPU_AOV_NUM_CLASSES) return -1;
@@ -1298,7 +1318,7 @@ int zygpu_resolve(ZygpuContext* c, float* host_rgba, uint32_t num_pixels) {
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(host_rgba, c->resolve_tmp, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));
-    return 0;
+    return deviceErrorFlags(c);
 }
 
 int zygpu_test_eval(ZygpuContext* c, uint32_t op, uint32_t n, const float* in, uint32_t in_stride, float* out, uint32_t out_stride) {
@@ -1315,6 +1335,47 @@ int zygpu_test_eval(ZygpuContext* c, uint32_t op, uint32_t n, const float* in, u
     (void)hipFree(din);
     (void)hipFree(dout);
     return 0;
+}
+
+int zygpu_calibrate_gather(ZygpuContext* c, uint32_t stride_bytes, uint32_t num_records, uint32_t repeats, double* out_ms_per_launch) {
+    if (!c || !out_ms_per_launch || 0 == num_records || 0 == repeats) return -1;
+    HIP_OK(hipSetDevice(c->device));
+    char*     data = nullptr;
+    uint32_t* sink = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&data), size_t(num_records) * stride_bytes + 16));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&sink), 64));
+    HIP_OK(hipMemsetAsync(data, 0, size_t(num_records) * stride_bytes + 16, c->stream));
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    const dim3 grid((num_records + 255) / 256), block(256);
+    auto       launch = [&]() {
+        switch (stride_bytes) {
+            case 16: hipLaunchKernelGGL(calib_gather<16>, grid, block, 0, c->stream, data, num_records, sink); return true;
+            case 64: hipLaunchKernelGGL(calib_gather<64>, grid, block, 0, c->stream, data, num_records, sink); return true;
+            case 128: hipLaunchKernelGGL(calib_gather<128>, grid, block, 0, c->stream, data, num_records, sink); return true;
+            case 256: hipLaunchKernelGGL(calib_gather<256>, grid, block, 0, c->stream, data, num_records, sink); return true;
+            case 512: hipLaunchKernelGGL(calib_gather<512>, grid, block, 0, c->stream, data, num_records, sink); return true;
+            default: return false;
+        }
+    };
+    int rc = 0;
+    if (!launch()) {  // warm-up launch, and the check of the stride
+        g_error = "zygpu_calibrate_gather: stride must be 16, 64, 128, 256 or 512";
+        rc = -1;
+    } else {
+        (void)hipEventRecord(a, c->stream);
+        for (uint32_t r = 0; r < repeats; ++r) launch();
+        (void)hipEventRecord(b, c->stream);
+        float ms = 0.f;
+        if (!check(hipStreamSynchronize(c->stream), "calib_gather") || !check(hipEventElapsedTime(&ms, a, b), "hipEventElapsedTime")) rc = -1;
+        *out_ms_per_launch = double(ms) / repeats;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(data);
+    (void)hipFree(sink);
+    return rc;
 }
 
 int zygpu_set_option(ZygpuContext* c, const char* name, int value) {

@@ -55,6 +55,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
         logf(2, "scene uses a feature outside the hot-path scope (volumes, infinite or non-rectangle lights)");
         return -1;
     }
+    for (const std::string& w : c.engine.warnings()) logf(1, "%s", w.c_str());
     if (!c.ctx) {
         const int dev = c.device_id >= 0 ? c.device_id : defaultDevice();
         if (0 != zygpu_create(dev, &c.ctx)) {
@@ -186,7 +187,10 @@ int32_t su_image_create(uint32_t id, uint32_t format, uint32_t num_channels, uin
     return ZYGPU_NULL == image ? -1 : int32_t(image);  // other formats / channel counts: -1, as capi.zig:268-294 for its own gaps
 }
 
-int32_t su_image_update(uint32_t, uint32_t, const uint8_t*) { return -1; }
+int32_t su_image_update(uint32_t id, uint32_t pixel_stride, const uint8_t* data) {
+    // the next su_start_frame / su_render_frame compiles and uploads the scene again, images included
+    return g ? g->engine.updateImage(id, pixel_stride, data) : -1;
+}
 
 int32_t su_material_create(uint32_t id, const char* json) {
     if (!g) return -1;
@@ -240,10 +244,7 @@ int32_t su_prop_set_transformation(uint32_t prop, const float* trafo) {
 }
 
 int32_t su_prop_set_transformation_frame(uint32_t prop, uint32_t frame, const float* trafo) {
-    (void)prop;
-    (void)frame;
-    (void)trafo;
-    return -1;  // keyframe animation: SURVEY §2.2 (animated props) — out of scope
+    return g ? g->engine.setTransformationFrame(prop, frame, trafo) : -1;
 }
 
 int32_t su_prop_set_visibility(uint32_t prop, uint32_t in_camera, uint32_t in_reflection, uint32_t in_sss) {
@@ -278,7 +279,11 @@ int32_t su_render_frame(uint32_t frame) {
     if (0 != prepareFrame(frame, true)) return -1;
     const uint32_t spp = g->engine.num_samples_per_pixel;
     if (0 != su_render_iterations(spp)) return -1;
-    return 0 == zygpu_synchronize(g->ctx) ? 0 : -1;
+    if (0 != zygpu_synchronize(g->ctx)) {
+        logf(2, "su_render_frame: %s", zygpu_last_error());
+        return -1;
+    }
+    return 0;
 }
 
 int32_t su_resolve_frame(uint32_t aov);
@@ -312,9 +317,12 @@ int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height
     const uint32_t num_pixels = std::min(width * height, film_pixels);
     if (aov < ZYGPU_AOV_NUM_CLASSES) {  // capi.zig:637: -2 for a class the take does not record
         const int r = zygpu_resolve_aov(g->ctx, aov, buffer, num_pixels);
+        if (0 != r && -2 != r) logf(2, "su_resolve_frame: %s", zygpu_last_error());
         return 0 == r ? 0 : -2 == r ? -2 : -1;
     }
-    return 0 == zygpu_resolve(g->ctx, buffer, num_pixels) ? 0 : -1;
+    const int r = zygpu_resolve(g->ctx, buffer, num_pixels);
+    if (0 != r) logf(2, "su_resolve_frame: %s", zygpu_last_error());  // e.g. the device error flags: the image is incomplete
+    return 0 == r ? 0 : -1;
 }
 
 int32_t su_resolve_frame(uint32_t aov) {

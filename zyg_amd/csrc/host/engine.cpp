@@ -407,7 +407,24 @@ uint32_t Engine::createMesh(uint32_t id, uint32_t num_parts_in, const uint32_t* 
     (void)id;
     HostMesh mesh;
 
+    // Client and file data (su_triangle_mesh_create, .sub / JSON meshes) is not trusted: every index must name a vertex, part
+    // ids are stored as u16 (triangle_data.zig:22-29), a part's index range must lie inside the index buffer, and a part's
+    // material slot must be small enough to size the prop's material list.  The reference reads such a mesh out of bounds.
     const uint32_t num_parts = num_parts_in > 0 ? num_parts_in : 1;
+    if (0 == num_triangles || 0 == num_vertices || num_parts > 65535u || !positions || !normals) return ZYGPU_NULL;
+    if (num_triangles > 0x55555555u) return ZYGPU_NULL;  // 3 * num_triangles must fit 32 bits
+    if (indices) {
+        for (size_t i = 0, n = size_t(num_triangles) * 3; i < n; ++i)
+            if (indices[i] >= num_vertices) return ZYGPU_NULL;
+    } else if (size_t(num_triangles) * 3 > num_vertices) {
+        return ZYGPU_NULL;
+    }
+    if (num_parts_in > 0 && parts_in) {
+        for (uint32_t i = 0; i < num_parts; ++i) {
+            const uint64_t start = parts_in[i * 3 + 0], count = parts_in[i * 3 + 1];
+            if (start + count > uint64_t(num_triangles) * 3 || parts_in[i * 3 + 2] > 65535u) return ZYGPU_NULL;
+        }
+    }
     mesh.part_materials.assign(num_parts, 0);
     if (num_parts_in > 0 && parts_in) {
         for (uint32_t i = 0; i < num_parts; ++i) mesh.part_materials[i] = parts_in[i * 3 + 2];
@@ -674,6 +691,38 @@ int Engine::setTransformation(uint32_t prop, const float* m16) {  // capi.zig:48
     decompose(m, basis, t.scale, t.position);
     t.rotation = quaternionFromMat3x3(basis);
     world_transformations_[prop] = t;
+    return 0;
+}
+
+uint32_t Engine::numInterpolationFrames() const {  // scene.zig:254-257 + countFrames (724-734)
+    const uint64_t tick = 705600000ull / 60, frame_step = tick, frame_duration = tick;  // camera_base.zig:16,25-26
+    auto matching = [](uint64_t a, uint64_t b) { return 0 == (a > b ? a % b : (0 == a ? 0 : b % a)); };
+    const uint32_t a = std::max<uint32_t>(uint32_t(frame_duration / tick), 1u);
+    const uint32_t b = matching(frame_step, tick) ? 0u : 1u, c = matching(frame_duration, tick) ? 0u : 1u;
+    return a + b + c + 1;
+}
+
+int Engine::setTransformationFrame(uint32_t prop, uint32_t frame, const float* m16) {  // capi.zig:506-533
+    if (prop >= props_.size() || frame >= numInterpolationFrames() || !m16) return -1;
+    Mat4x4 m;
+    for (int r = 0; r < 4; ++r) m.r[r] = vec(m16[4 * r + 0], m16[4 * r + 1], m16[4 * r + 2], m16[4 * r + 3]);
+    Mat3x3         basis;
+    Transformation t;
+    decompose(m, basis, t.scale, t.position);
+    t.rotation = quaternionFromMat3x3(basis);
+    if (keyframes_.size() < props_.size()) keyframes_.resize(props_.size());
+    // propAllocateFrames (scene.zig:317-322) leaves new keyframes uninitialised; here they start as the static transformation
+    if (keyframes_[prop].empty()) keyframes_[prop].assign(numInterpolationFrames(), world_transformations_[prop]);
+    keyframes_[prop][frame] = t;
+    return 0;
+}
+
+int Engine::updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data) {  // capi.zig:300-338
+    if (id >= images_.size() || !data) return -1;
+    HostImage&     img = images_[id];
+    const uint32_t bpp = ZYGPU_IMAGE_BYTE3_SRGB == img.format ? 3u : ZYGPU_IMAGE_FLOAT3 == img.format ? 12u : ZYGPU_IMAGE_BYTE1_UNORM == img.format ? 1u : 4u;
+    // a stride that does not match the image's pixel size copies nothing and still succeeds (capi.zig:316-334)
+    if (bpp == pixel_stride) std::memcpy(img.pixels.data(), data, img.pixels.size());
     return 0;
 }
 
@@ -1056,7 +1105,13 @@ int Engine::compile(uint32_t frame) {
     (void)frame;  // static scenes only: every keyframe-free prop ignores time (space.zig:99-108)
     if (ZYGPU_NULL == camera_entity) return -1;
 
-    const Vec4f    camera_pos = world_transformations_[camera_entity].position;  // driver.zig:164
+    // driver.zig:164 -> scene.propWorldPosition (scene.zig:372-380): an animated entity's first keyframe
+    const Vec4f    camera_pos = frameStartTransformation(camera_entity).position;
+    warnings_.clear();
+    for (uint32_t p = 0; p < keyframes_.size(); ++p)
+        if (!keyframes_[p].empty() && p != camera_entity)
+            warnings_.push_back("prop " + std::to_string(p) + " has keyframes (su_prop_set_transformation_frame): animated props are outside the "
+                                "device path's scope, it is rendered at its transformation at the frame's start (keyframe 0)");
     const uint32_t np = uint32_t(props_.size());
 
     c_props_.resize(np);
@@ -1089,7 +1144,7 @@ int Engine::compile(uint32_t frame) {
         c_props_[p].parts_start = hp.parts_start;
         c_props_[p].mesh = s.mesh;
 
-        const Transformation& t = world_transformations_[p];
+        const Transformation& t = frameStartTransformation(p);
         c_trafos_[p] = composedTrafo(t, camera_pos);
 
         // space.zig:60-97 (calculateWorldBounds, static branch)
@@ -1152,7 +1207,7 @@ int Engine::compile(uint32_t frame) {
             l.light_class = ZYGPU_LIGHT_PROP_IMAGE;
         }
 
-        const Transformation& t = world_transformations_[l.prop];
+        const Transformation& t = frameStartTransformation(l.prop);
         Transformation        rel = t;
         rel.position = t.position - camera_pos;
 
@@ -1302,6 +1357,18 @@ int Engine::compile(uint32_t frame) {
     v.lens_radius = lens_radius;
     v.focus_distance = focus_distance;
     v.camera_trafo = c_trafos_[camera_entity];
+    if (camera_entity < keyframes_.size() && !keyframes_[camera_entity].empty()) {
+        const std::vector<Transformation>& kf = keyframes_[camera_entity];
+        v.camera_num_keyframes = uint32_t(std::min<size_t>(kf.size(), ZYGPU_MAX_CAMERA_KEYFRAMES));
+        for (int i = 0; i < 4; ++i) v.camera_origin[i] = camera_pos[i];
+        for (uint32_t k = 0; k < v.camera_num_keyframes; ++k) {
+            for (int i = 0; i < 4; ++i) {
+                v.camera_keyframes[k].position[i] = kf[k].position[i];
+                v.camera_keyframes[k].scale[i] = kf[k].scale[i];
+                v.camera_keyframes[k].rotation[i] = kf[k].rotation[i];
+            }
+        }
+    }
     v.frame_step = 705600000ull / 60;      // camera_base.zig:16,25
     v.frame_duration = 705600000ull / 60;  // camera_base.zig:26
     v.integrator = integrator;

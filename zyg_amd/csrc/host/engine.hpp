@@ -117,6 +117,15 @@ class Engine {
     int      createLight(uint32_t entity);
     int      setTransformation(uint32_t prop, const float* m16);
     int      setWorldTransformation(uint32_t prop, const Transformation& t);  // the loaders' path (scene_graph.zig:178-230)
+    // su_prop_set_transformation_frame (capi.zig:506-533): keyframe `frame` (< numInterpolationFrames()) of the prop.  The
+    // camera entity's keyframes drive the camera at every sample's time (ZygpuViewDesc.camera_keyframes); any other prop is
+    // rendered at its transformation at the frame's start and compile() says so in warnings() (animated props are outside the
+    // hot-path scope: the inner ABI carries static transforms only).
+    int      setTransformationFrame(uint32_t prop, uint32_t frame, const float* m16);
+    uint32_t numInterpolationFrames() const;  // scene.zig:254-257, 724-734 with the C ABI camera's frame step / duration
+    // su_image_update (capi.zig:300-338): new pixels for an existing image, same format and dimensions
+    int      updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data);
+    const std::vector<std::string>& warnings() const { return warnings_; }  // of the last compile()
     int      setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss);
 
     // --- view ---
@@ -178,6 +187,11 @@ class Engine {
 
     std::vector<HostProp>       props_;
     std::vector<Transformation> world_transformations_;
+    std::vector<std::vector<Transformation>> keyframes_;  // per prop; empty = static (space.zig:23-26 frames / keyframes)
+    std::vector<std::string>    warnings_;
+    const Transformation& frameStartTransformation(uint32_t p) const {  // space.zig:99-125 at the frame's start: keyframe 0
+        return (p < keyframes_.size() && !keyframes_[p].empty()) ? keyframes_[p][0] : world_transformations_[p];
+    }
     std::vector<uint32_t>       material_ids_;
     std::vector<uint32_t>       light_ids_;
     std::vector<ZygpuLight>     lights_;

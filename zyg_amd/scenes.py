@@ -236,7 +236,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
-            light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False):
+            light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -252,10 +252,15 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     masked: None, or a dict: `image` (a one-channel numpy mask) and optionally `sampler`, `scale`, `lights` (the lamps are masked
     too), `pane` (a masked thin-glass Rectangle): a masked Rectangle, Sphere and Disk stand in the box and the tall box's
     material is masked (opacity masks need Substitute / Light / Glass materials).
+    clamp: the sensor's per-channel clamp, e.g. {"direct": 4, "indirect": 2} (sensor.zig:177-181, take_loader.zig "clamp").
+    lens: thin-lens camera parameters, e.g. {"lens": {"radius": 0.05}, "focus": {"distance": 3.9}}
+    (camera_perspective.zig:124-150, 260-270, aperture.zig:46-53).
     Returns a dict with prop ids.
     """
     mk = lambert if material == "lambert" else substitute
     cam = engine.camera(width, height, fov_deg=39.3)
+    if lens:
+        engine.camera_parameters(json.dumps(lens))
     engine.samples_per_pixel(spp)
     node = {"depth": {"surface": max_depth}}
     if split_threshold is not None:
@@ -266,6 +271,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         sensor["alpha_transparency"] = True
     if filter_name:
         sensor["filter"] = {filter_name: {}}
+    if clamp:
+        sensor["clamp"] = clamp
     engine.sensor(json.dumps(sensor))
 
     white = engine.material(mk(WHITE))
