@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zyg_amd
 from zyg_amd import scenes
 
-w, h, iters = 1920, 1080, 8
+w, h, iters = 1920, 1080, 16
 material = sys.argv[1] if len(sys.argv) > 1 else "lambert"
 eng = zyg_amd.Engine()
 scenes.cornell(eng, w, h, iters, integrator="PTMIS", material=material)
@@ -23,8 +23,15 @@ out = (ctypes.c_uint64 * 32)()
 lib.zygpu_get_section_cycles(ctx, out)
 names = {0: "shade: state loads + fragment", 1: "shade: hit emission (evaluateRadiance)", 2: "shade: unoccluding-light candidates (evaluateRadiance)",
          3: "shade: IValue add, RR, record write", 4: "shade: finalize", 5: "shade: queue push",
+         8: "trace: queue read (+ camera ray generation in the first tick)", 9: "trace: closest hit (TLAS + BLAS)",
+         10: "trace: unoccluding-light walk", 11: "trace: queue pushes",
+         16: "scatter: state loads + fragment + closure", 17: "scatter: light tree picks", 18: "scatter: light sample (SphQuad) + shadow ray set-up",
+         19: "scatter: shadow ray traversal", 20: "scatter: radiance, bsdf evaluate, MIS", 21: "scatter: IValue add",
+         22: "scatter: bxdf sample, state update, stores", 23: "scatter: queue push",
          }
-for base, label in ((0, "wf_shade"),):
+precise = int(os.environ.get("ZYG_PRECISE", "0"))
+lib.zygpu_set_option(ctx, b"precise", precise)
+for base, label in ((0, "wf_trace_shade + wf_shade"), (16, "wf_scatter")):
     tot = sum(out[base:base + 16]) or 1
     print(f"{label}: {tot / 1e9:.2f} G wave-cycles")
     for i in range(base, base + 16):

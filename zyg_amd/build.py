@@ -77,6 +77,27 @@ def _compile(job):
     return out
 
 
+def build_variant(name, units, extra, mode="both", verbose=True):
+    """Development: variants/lib_<name>.so = the main build's objects with the kernel units `units` (and zygpu.o when
+    `units` holds -1) recompiled with `extra` flags into build/<name>/.  Load it with ZYG_AMD_LIB=variants/lib_<name>.so."""
+    vdir = os.path.join(OBJ, name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
+    todo, objs = [], []
+    for oname, src, flags in _objects(mode):
+        mine = (oname.startswith("unit") and int(oname[4:].rstrip("f.o")) in units) or (oname == "zygpu.o" and -1 in units)
+        if mine:
+            todo.append((os.path.join(name, oname), src, flags, list(extra), verbose))
+            objs.append(os.path.join(vdir, oname))
+        else:
+            objs.append(os.path.join(OBJ, oname))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(_compile, todo))
+    out = os.path.join(ROOT, "variants", f"lib_{name}.so")
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], check=True)
+    return out
+
+
 def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     extra = list(extra)
@@ -119,8 +140,15 @@ def up_to_date():
 if __name__ == "__main__":
     args = sys.argv[1:]
     kw = {}
-    while args and args[0] in ("--mode", "--units", "--jobs"):
+    variant = None
+    while args and args[0] in ("--mode", "--units", "--jobs", "--variant"):
         key, val = args[0][2:], args[1]
-        kw[key] = val if "mode" == key else int(val) if "jobs" == key else {int(v) for v in val.split(",")}
+        if "variant" == key:
+            variant = val
+        else:
+            kw[key] = val if "mode" == key else int(val) if "jobs" == key else {int(v) for v in val.split(",")}
         args = args[2:]
-    build(extra=args, **kw)
+    if variant:
+        print(build_variant(variant, kw.get("units", set(range(NUM_UNITS))), args, kw.get("mode", "both")))
+    else:
+        build(extra=args, **kw)

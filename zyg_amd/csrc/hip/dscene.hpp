@@ -21,6 +21,7 @@ constexpr uint32_t kNull = 0xFFFFFFFFu;
 constexpr int      kStackSize = 64;
 
 struct DMesh {
+    const float4*   nodes4;    // the wide re-layout (bvh4.hpp): 8 per BVH4 node
     const float4*   nodes;     // 2 per node
     const float4*   tri_verts; // 3 per triangle (leaf order)
     const uint32_t* triangles; // 3 vertex indices per triangle (shading only)
@@ -68,7 +69,20 @@ struct DImageLight {  // ZygpuImageLight on the device
     uint32_t        sampler;
 };
 
+// A small top-level scene as a table in the __constant__ block itself (zygpu_upload_scene fills it when the solid props are
+// at most kUniformProps Rectangles and TriangleMeshes): every lane of a wave tests the same prop at the same time, the
+// prop's bounds and transformation arrive through the scalar cache in SGPRs (sceneIntersectUniform, sceneVisibilityUniform).
+constexpr uint32_t kUniformProps = 16;
+struct TlasEntry {
+    float4   bmin, bmax;        // world bounds (s.aabbs)
+    float4   r0, r1, r2, pos;   // transformation (s.trafos)
+    uint32_t shape, flags, prop, mesh;
+};
+
 struct DScene {
+    TlasEntry            solid_table[kUniformProps];  // cheap shapes first; num_solid_table = 0: not available
+    TlasEntry            unocc_table[4];              // the unoccluding tree's single leaf, in leaf order; 0: not available
+    uint32_t             num_solid_table, num_unocc_table;
     const ZygpuProp*     props;
     const float4*        trafos; // 4 per prop: r0(+sx), r1(+sy), r2(+sz), position
     const float4*        aabbs;  // 2 per prop
@@ -97,6 +111,7 @@ struct DScene {
     const float*         lut_e_s;
     float                specular_threshold;
     uint32_t             num_solid_nodes, num_unocc_nodes;
+    uint32_t             num_props, num_solid_indices, num_unocc_indices;
     float4               heavy_aabbs[16];  // world bounds (2 each) of the up to 8 largest mesh props: queue grouping hint
     uint32_t             num_heavy;
 };
@@ -320,13 +335,83 @@ ZD bool bvhWalk(const float4* nodes, uint32_t num_nodes, Ray& ray, Counters& cnt
     }
 }
 
+// The walk of a mesh's wide re-layout (bvh4.hpp): one 128 B node = four child slots per step, the children a ray enters
+// visited nearest first, the rest parked with their entry distances (skipped on return if the ray has been shortened past
+// them).  Same leaves, same triangle order inside a leaf as the BVH2; `leaf` as in bvhWalk.
+constexpr int kStack4 = 48;
+template <typename Leaf>
+ZD bool bvh4Walk(const float4* nodes, Ray& ray, Leaf&& leaf) {
+    uint32_t stack_ref[kStack4], stack_count[kStack4];
+    float    stack_dist[kStack4];
+    int      sp = 0;
+    uint32_t cur = 0, cur_count = 0;  // the root node
+    // the next parked child the (possibly shortened) ray still reaches
+    auto pop = [&]() {
+        while (sp > 0) {
+            --sp;
+            if (stack_dist[sp] <= ray.max_t) {
+                cur = stack_ref[sp];
+                cur_count = stack_count[sp];
+                return true;
+            }
+        }
+        return false;
+    };
+    for (;;) {
+        while (0 == cur_count) {
+            const float4* n = nodes + size_t(cur) * 8;
+            const float4  a0 = n[0], a1 = n[1], b0 = n[2], b1 = n[3], c0 = n[4], c1 = n[5], d0 = n[6], d1 = n[7];
+            float    t0 = nodeIntersect(a0, a1, ray), t1 = nodeIntersect(b0, b1, ray);
+            float    t2 = nodeIntersect(c0, c1, ray), t3 = nodeIntersect(d0, d1, ray);
+            uint32_t r0 = __float_as_uint(a0.w), r1 = __float_as_uint(b0.w), r2 = __float_as_uint(c0.w), r3 = __float_as_uint(d0.w);
+            uint32_t n0 = __float_as_uint(a1.w), n1 = __float_as_uint(b1.w), n2 = __float_as_uint(c1.w), n3 = __float_as_uint(d1.w);
+            // sorting network (0,1)(2,3)(0,2)(1,3)(1,2): ascending entry distance, misses (FLT_MAX) last
+#define ZYG_CSWAP(i, j)                        \
+    if (t##j < t##i) {                         \
+        const float    tt = t##i;              \
+        const uint32_t rr = r##i, nn = n##i;   \
+        t##i = t##j, r##i = r##j, n##i = n##j; \
+        t##j = tt, r##j = rr, n##j = nn;       \
+    }
+            ZYG_CSWAP(0, 1)
+            ZYG_CSWAP(2, 3)
+            ZYG_CSWAP(0, 2)
+            ZYG_CSWAP(1, 3)
+            ZYG_CSWAP(1, 2)
+#undef ZYG_CSWAP
+            if (FLT_MAX != t3 && sp < kStack4) stack_ref[sp] = r3, stack_count[sp] = n3, stack_dist[sp] = t3, ++sp;
+            if (FLT_MAX != t2 && sp < kStack4) stack_ref[sp] = r2, stack_count[sp] = n2, stack_dist[sp] = t2, ++sp;
+            if (FLT_MAX != t1 && sp < kStack4) stack_ref[sp] = r1, stack_count[sp] = n1, stack_dist[sp] = t1, ++sp;
+            if (FLT_MAX != t0) {
+                cur = r0;
+                cur_count = n0;
+            } else if (!pop()) {  // the node's slots are all missed: back to what was parked before it
+                return false;
+            }
+        }
+        if (leaf(cur, cur_count)) return true;
+        if (!pop()) return false;
+    }
+}
+
 // triangle_tree.zig:46-109; ray in object space; shrinks ray.max_t
 // `accept(triangle, u, v)`: intersectOpacity's stochastic mask test (triangle_tree.zig:111-195)
-template <bool STATS, typename Accept>
+// WIDE: walk the mesh's four-wide re-layout instead of the reference's BVH2: the kernel instantiations for scenes with a large
+// mesh, in the relaxed-arithmetic units only (kWideBlas), and not where something depends on the reference's traversal order:
+// the counters (STATS) and `accept` when it draws from the path's sampler.  The precise units always walk the BVH2: their
+// result is the reference's bit for bit, exact ties between triangles (a ray through a shared edge) included, which the wide
+// walk may resolve the other way round.  (For the 12-triangle boxes of the Cornell scene the wide walk's registers cost more
+// than its shorter chain saves: measured 643 vs 600 Msamples/s, so scenes without a large mesh run the BVH2 instantiations.)
+#if ZYG_FAST
+constexpr bool kWideBlas = true;
+#else
+constexpr bool kWideBlas = false;
+#endif
+template <bool STATS, bool WIDE, typename Accept>
 ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt, Accept&& accept) {
     uint32_t primitive = kNull;
     float    ht = 0.f, hu = 0.f, hv = 0.f;
-    bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, [&](uint32_t first, uint32_t count) {
+    auto     leaf = [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             if (STATS) cnt.tris += 1;
             const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
@@ -340,7 +425,10 @@ ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt
             }
         }
         return false;
-    });
+    };
+    // the wide re-layout where the mesh has one (large meshes) and nothing is counted: the counters are the BVH2 walk's
+    if (!STATS && WIDE) bvh4Walk(mesh.nodes4, local_ray, leaf);
+    else bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, leaf);
     if (kNull == primitive) return false;
     hit.t = ht;
     hit.u = hu;
@@ -349,9 +437,9 @@ ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt
     return true;
 }
 
-template <bool STATS>
+template <bool STATS, bool WIDE = false>
 ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt) {
-    return meshIntersect<STATS>(mesh, local_ray, hit, cnt, [](uint32_t, float, float) { return true; });
+    return meshIntersect<STATS, WIDE && kWideBlas>(mesh, local_ray, hit, cnt, [](uint32_t, float, float) { return true; });
 }
 ZD void meshInterpolateUv(const DMesh& mesh, uint32_t prim, float u, float v, float& uv0, float& uv1) {  // triangle_data.zig:137-149
     const uint32_t ia = mesh.triangles[3 * prim], ib = mesh.triangles[3 * prim + 1], ic = mesh.triangles[3 * prim + 2];
@@ -361,9 +449,9 @@ ZD void meshInterpolateUv(const DMesh& mesh, uint32_t prim, float u, float v, fl
 }
 
 // triangle_tree.zig:197-242
-template <bool STATS>
+template <bool STATS, bool WIDE = false>
 ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
-    return bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, [&](uint32_t first, uint32_t count) {
+    auto leaf = [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             if (STATS) cnt.tris += 1;
             const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
@@ -371,7 +459,9 @@ ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
             if (triangleIntersect(local_ray, a, b, c, t, u, v)) return true;
         }
         return false;
-    });
+    };
+    if (!STATS && WIDE && kWideBlas) return bvh4Walk(mesh.nodes4, local_ray, leaf);
+    return bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, leaf);
 }
 
 // rectangle.zig:30-62
@@ -531,7 +621,7 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                 Hit          h;
                 bool         found;
                 if (masked) {
-                    found = meshIntersect<STATS>(mesh, local, h, cnt, [&](uint32_t k, float u, float v) {
+                    found = meshIntersect<STATS, false>(mesh, local, h, cnt, [&](uint32_t k, float u, float v) {
                         const ZygpuMaterial& m = s.materials[s.material_ids[prop.parts_start + mesh.triangle_parts[k]]];
                         if (!(m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY)) return true;
                         float uv0, uv1;
@@ -560,6 +650,100 @@ template <bool STATS, bool EXTRA>
 ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt) {
     NoDraw none;
     return sceneIntersect<STATS, EXTRA>(s, ray, depth_surface, hit, cnt, none);
+}
+
+// ---------------------------------------------------------------- small scenes: the wave walks the prop table together
+// In a scene of a few props nearly every ray overlaps nearly every prop's bounds (Cornell box: 8.2 instance tests per ray
+// for 7 + 2 props), so the top-level tree orders nothing and its per-lane walk only scatters the wave: lanes sit in
+// different props and shapes, every step is a dependent vector load.  Here all lanes test prop k at the same time, with its
+// record in SGPRs, cheap shapes first (their hits shorten the ray before the meshes' bounds are tested), and a mesh's BLAS
+// is entered by all its lanes at once.
+//
+// Same result as the tree walk: the closest hit is the minimum over the props whatever the order; inside a mesh the walk is
+// the reference's.  Only an exact tie between two props (bit-equal t) depends on the reference's order, where the prop
+// tested later wins (`max_t >= hit_t`): then the two props' places in this ray's walk of the tree decide (tlasOrderLater).
+ZD Trafo entryTrafo(const TlasEntry& e) {
+    Trafo t;
+    t.r0 = {e.r0.x, e.r0.y, e.r0.z};
+    t.r1 = {e.r1.x, e.r1.y, e.r1.z};
+    t.r2 = {e.r2.x, e.r2.y, e.r2.z};
+    t.scale = {e.r0.w, e.r1.w, e.r2.w};
+    t.position = {e.pos.x, e.pos.y, e.pos.z};
+    return t;
+}
+
+// whether prop `b` comes after prop `a` when `ray` walks the solid tree nearer child first (prop_tree.zig:86-104); the
+// order of two props does not depend on how far the ray reaches, so the walk runs without culling by max_t
+ZD bool tlasOrderLater(const DScene& s, const Ray& ray_in, uint32_t a, uint32_t b) {
+    Ray ray = ray_in;
+    ray.max_t = kRayMaxT;
+    Counters none{0, 0, 0};
+    uint32_t seen = kNull;
+    bvhWalk<false>(s.solid_nodes, s.num_solid_nodes, ray, none, [&](uint32_t first, uint32_t count) {
+        for (uint32_t i = first, e = first + count; i < e; ++i) {
+            const uint32_t p = s.solid_indices[i];
+            if (p == a || p == b) {
+                seen = p;
+                return true;
+            }
+        }
+        return false;
+    });
+    return seen == a;  // a was met first: b is the later one
+}
+
+// closest hit over the solid props (the semantics of sceneIntersect<false, false>); WIDE: meshes through their wide re-layout
+template <bool EXACT_TIES, bool WIDE>
+ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit) {
+    hit.prop = kNull;
+    Counters none{0, 0, 0};
+    for (uint32_t k = 0; k < s.num_solid_table; ++k) {
+        const TlasEntry& e = s.solid_table[k];
+        if (!propVisibleAtDepth(e.flags, depth_surface)) continue;  // uniform
+        if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
+        const Trafo trafo = entryTrafo(e);
+        Hit         h;
+        bool        found;
+        if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
+            h.primitive = 0;
+            found = rectangleIntersect(ray, trafo, h.t, h.u, h.v);
+        } else {
+            Ray local = worldToObjectRay(trafo, ray);
+            found = meshIntersect<false, WIDE>(s.meshes[e.mesh], local, h, none);
+        }
+        if (found && (h.t < ray.max_t || kNull == hit.prop || !EXACT_TIES || tlasOrderLater(s, ray, hit.prop, e.prop))) {
+            hit.t = h.t;
+            hit.u = h.u;
+            hit.v = h.v;
+            hit.primitive = h.primitive;
+            hit.prop = e.prop;
+            ray.max_t = h.t;
+        }
+    }
+    return kNull != hit.prop;
+}
+
+// any-hit over the solid props (the semantics of sceneVisibility<false, false>): true = unoccluded
+template <bool WIDE>
+ZD bool sceneVisibilityUniform(const DScene& s, Ray& ray) {
+    Counters none{0, 0, 0};
+    bool     blocked = false;
+    for (uint32_t k = 0; k < s.num_solid_table; ++k) {
+        const TlasEntry& e = s.solid_table[k];
+        if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;  // uniform
+        if (!blocked && aabbIntersect(e.bmin, e.bmax, ray)) {
+            const Trafo trafo = entryTrafo(e);
+            if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
+                float t, u, v;
+                blocked = rectangleIntersect(ray, trafo, t, u, v);
+            } else {
+                Ray local = worldToObjectRay(trafo, ray);
+                blocked = meshIntersectP<false, WIDE>(s.meshes[e.mesh], local, none);
+            }
+        }
+        if (0 == __ballot(!blocked)) break;  // every lane of the wave has its occluder
+    }
+    return !blocked;
 }
 
 // prop_tree.zig:185-240 + prop.zig:199-237: true = unoccluded

@@ -9,11 +9,19 @@
 //
 // Template parameters (wavefront.hpp):
 //   wf_generate<POOL>   wf_intersect<STATS, POOL, EXTRA>   wf_shade<STATS, MESHL, HEAVY, POOL>
-//   wf_trace_shade<STATS, MESHL, FIRST>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS>
+//   wf_trace_shade<STATS, MESHL, FIRST, UTLAS>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS>
 //   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_extend<SUBST, EXTRA>
 #pragma once
 
 #define ZYG_NUM_UNITS 8
+
+// the WIDE instantiations exist in the relaxed-arithmetic units only; in the precise ones their ids launch the BVH2 kernels
+// (an alias must sit in the unit of the kernel it names: a kernel reads its own unit's __constant__ blocks)
+#if ZYG_FAST
+#define ZYG_WIDE(wide, plain) wide
+#else
+#define ZYG_WIDE(wide, plain) plain
+#endif
 
 // clang-format off
 #define ZYG_KERNEL_TABLE(X)                                                                 \
@@ -27,6 +35,12 @@
     X(4, K_SCATTER_MULTI,        (wf_scatter<false, true, true, false, false>),       (P))  \
     X(4, K_SCATTER_SUBST,        (wf_scatter<false, true, false, false, false>),      (P))  \
     X(4, K_SCATTER_LAMBERT,      (wf_scatter<false, false, false, false, false>),     (P))  \
+    X(3, K_SCATTER_MULTI_U,      (wf_scatter<false, true, true, false, false, false, true>),   (P))  \
+    X(6, K_SCATTER_SUBST_U,      (wf_scatter<false, true, false, false, false, false, true>),  (P))  \
+    X(6, K_SCATTER_LAMBERT_U,    (wf_scatter<false, false, false, false, false, false, true>), (P))  \
+    X(3, K_SCATTER_MULTI_UW,     ZYG_WIDE((wf_scatter<false, true, true, false, false, false, true, true>), (wf_scatter<false, true, true, false, false, false, true>)), (P)) \
+    X(6, K_SCATTER_SUBST_UW,     ZYG_WIDE((wf_scatter<false, true, false, false, false, false, true, true>), (wf_scatter<false, true, false, false, false, false, true>)), (P)) \
+    X(6, K_SCATTER_LAMBERT_UW,   ZYG_WIDE((wf_scatter<false, false, false, false, false, false, true, true>), (wf_scatter<false, false, false, false, false, false, true>)), (P)) \
     X(5, K_SHADE_STATS_LIGHT_POOL, (wf_shade<true, true, false, true>),               (P))  \
     X(5, K_SHADE_STATS_HEAVY_POOL, (wf_shade<true, true, true, true>),                (P))  \
     X(5, K_SHADE_PLAIN_LIGHT_POOL, (wf_shade<false, false, false, true>),             (P))  \
@@ -45,6 +59,10 @@
     X(6, K_TRACE_SHADE_STATS,    (wf_trace_shade<true, true, false>),                 (P, arg)) \
     X(6, K_TRACE_SHADE_MESHL,    (wf_trace_shade<false, true, false>),                (P, arg)) \
     X(6, K_TRACE_SHADE_PLAIN,    (wf_trace_shade<false, false, false>),               (P, arg)) \
+    X(6, K_TRACE_SHADE_PLAIN_FIRST_U, (wf_trace_shade<false, false, true, true>),     (P, arg)) \
+    X(6, K_TRACE_SHADE_PLAIN_U,  (wf_trace_shade<false, false, false, true>),         (P, arg)) \
+    X(6, K_TRACE_SHADE_PLAIN_FIRST_UW, ZYG_WIDE((wf_trace_shade<false, false, true, true, true>), (wf_trace_shade<false, false, true, true>)), (P, arg)) \
+    X(6, K_TRACE_SHADE_PLAIN_UW, ZYG_WIDE((wf_trace_shade<false, false, false, true, true>), (wf_trace_shade<false, false, false, true>)), (P, arg)) \
     X(6, K_GENERATE_POOL,        (wf_generate<true>),                                 (P, arg)) \
     X(6, K_GENERATE,             (wf_generate<false>),                                (P, arg)) \
     X(7, K_INTERSECT_STATS_POOL, (wf_intersect<true, true, true>),                    (P))  \

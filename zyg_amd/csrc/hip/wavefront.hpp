@@ -44,10 +44,24 @@ enum : uint32_t {
 // (inside the 256 B block, ZYG_HIT_STRIDE 0, wf_intersect's partial-line writes cost it 8 %; measured 414 vs 427 Msamples/s)
 #define ZYG_HIT_STRIDE 32
 #if ZYG_POOL_STRIDE
+// A record of the pool behind a proxy, so that the access is in one place.  (Measured and dropped: the non-temporal hint on
+// these loads and stores, meant to keep the scene data in the vector L1: 556 -> 266 Msamples/s, the hint also costs the records
+// their L2 hits between the stage that writes them and the stage that reads them.)
+template <typename T>
+struct RecRef {
+    T* p;
+    ZD operator T() const { return *p; }
+    ZD const RecRef& operator=(const T& v) const {
+        *p = v;
+        return *this;
+    }
+    ZD const RecRef& operator=(const RecRef& o) const { return *this = T(o); }
+};
 template <typename T, int STRIDE = ZYG_POOL_STRIDE>
 struct Rec {
     char* base;  // block base + the member's offset (RecOffsets)
-    ZD T& operator[](size_t i) const { return *reinterpret_cast<T*>(base + i * size_t(STRIDE)); }
+    ZD RecRef<T> operator[](size_t i) const { return RecRef<T>{reinterpret_cast<T*>(base + i * size_t(STRIDE))}; }
+    ZD T get(size_t i) const { return T((*this)[i]); }
 };
 template <typename T>
 using HitRec = Rec<T, ZYG_HIT_STRIDE ? ZYG_HIT_STRIDE : ZYG_POOL_STRIDE>;
@@ -502,7 +516,7 @@ ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
 // is skipped: the accumulators start at +0 and only ever receive non-negative terms, so x + 0 == x bit for bit.
 ZD void ivalueAdd(const Params& P, uint32_t slot, f3 value, uint32_t depth, uint32_t direct_cutoff, bool is_emission, bool singular) {
     if (0.f == value.x && 0.f == value.y && 0.f == value.z) return;
-    float4& target = is_emission ? P.pool.emission[slot] : (singular || depth < direct_cutoff) ? P.pool.direct[slot] : P.pool.indirect[slot];
+    const auto   target = is_emission ? P.pool.emission[slot] : (singular || depth < direct_cutoff) ? P.pool.direct[slot] : P.pool.indirect[slot];
     const float4 old = target;
     target = f4(xyz4(old) + value);
 }
@@ -717,7 +731,7 @@ ZD bool walksUnoccluding(uint32_t flags) {
     return connectsLights(flags) && (ZYGPU_INTEGRATOR_PTDL != c_view.v.integrator || (flags & ST_SINGULAR));
 }
 
-template <bool STATS, bool EXTRA>
+template <bool STATS, bool EXTRA, bool UTLAS = false>
 ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, size_t plane, uint32_t depth_surface, const Ray& ray_in,
                                   Counters& cnt) {
     uint32_t n = 0;
@@ -732,6 +746,16 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
         }
         n += 1;
     };
+    if (UTLAS) {  // the unoccluding tree is one leaf of Rectangles (dscene.hpp TlasEntry): its order is the leaf's order
+        for (uint32_t k = 0; k < s.num_unocc_table; ++k) {
+            const TlasEntry& e = s.unocc_table[k];
+            if (!propVisibleAtDepth(e.flags, depth_surface)) continue;
+            if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
+            float t, u, v;
+            if (rectangleIntersect(ray, entryTrafo(e), t, u, v)) record(e.prop, 0, t, u, v);
+        }
+        return n;
+    }
     bvhWalk<STATS>(s.unocc_nodes, s.num_unocc_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             const uint32_t  p = s.unocc_indices[i];
@@ -794,7 +818,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     if (i < n) {
         const uint32_t slot = extQueue<POOL>(P, cur, P.round)[at];  // POOL: a vertex index
         const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
-        const uint32_t meta = POOL ? P.pool.vmeta[slot] : P.pool.q0[slot].y;
+        const uint32_t meta = POOL ? P.pool.vmeta[slot] : P.pool.q0.get(slot).y;
         const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
         Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
         if (POOL) {
@@ -806,7 +830,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
                 const uint32_t mp = md.prop[md.index - 1];
                 const float    limit = aabbIntersectP(c_scene.aabbs[2 * mp], c_scene.aabbs[2 * mp + 1], ray);
                 ray.max_t = mn(offsetF(limit), o.w);
-                P.pool.ray_o[slot].w = ray.max_t;
+                P.pool.ray_o[slot] = f4(ray.origin, ray.max_t);
             }
         }
         Hit            hit;
@@ -947,7 +971,7 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
 template <bool MESHL>
 ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_t plane, const VertexIn& v, const Ray& ray, Sampler& smp) {
     f3             energy = S3(0.f);
-    const uint32_t n = min(P.pool.ucount[slot], kMaxUnoccludingCandidates);
+    const uint32_t n = min(uint32_t(P.pool.ucount[slot]), kMaxUnoccludingCandidates);
     const f3       wo = -ray.direction;
     for (uint32_t k = 0; k < n; ++k) {
         const size_t    at = size_t(k) * plane + slot;
@@ -1183,8 +1207,11 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
 // tick's and resets the next tick's (wf_intersect, a kernel of its own, could reset the ones wf_shade was about to fill).
 // FIRST: the batch's first tick generates its camera rays itself (wf_generate's body) instead of reading them back from the
 // pool through the extension queue: entry i is slot i, `first_paths` of them.
-template <bool STATS, bool MESHL, bool FIRST>
+// UTLAS: the solid and unoccluding props are walked as the scene's tables (dscene.hpp TlasEntry; not with STATS or MESHL)
+// WIDE (with UTLAS, relaxed units): meshes are walked through their four-wide re-layout (bvh4.hpp)
+template <bool STATS, bool MESHL, bool FIRST, bool UTLAS = false, bool WIDE = false>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P, uint32_t first_paths) {
+    static_assert(!UTLAS || (!STATS && !MESHL), "the prop tables hold Rectangles and meshes only and count nothing");
     const uint32_t cur = P.parity;
     if (!FIRST && blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1200,6 +1227,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
     }
     Counters       cnt{0, 0, 0}, shade_cnt{0, 0, 0};
     const uint32_t rounded = (n + 255u) & ~255u;  // whole blocks take part in queuePush
+    const DScene& scene = c_scene;
     if (i < rounded) {
         SectionTimer tm;
         tm.start();
@@ -1208,16 +1236,27 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
         if (i < n) {
             slot = FIRST ? i : P.q.ext[cur][at];
             if (FIRST) generatePath<false, MESHL>(P, slot);
+            tm.mark(8);
             const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
-            const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0[slot].y;
+            const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0.get(slot).y;
             const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
             Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
             Hit            hit;
-            typename MaskDraw<false, MESHL>::type draw(P, slot);
-            sceneIntersect<STATS, MESHL>(c_scene, ray, depth, hit, cnt, draw);
-            draw.flush();
+            if (UTLAS) {
+#if ZYG_FAST
+                sceneIntersectUniform<false, WIDE>(scene, ray, depth, hit);
+#else
+                sceneIntersectUniform<true, false>(scene, ray, depth, hit);
+#endif
+            } else {
+                typename MaskDraw<false, MESHL>::type draw(P, slot);
+                sceneIntersect<STATS, MESHL>(scene, ray, depth, hit, cnt, draw);
+                draw.flush();
+            }
+            tm.mark(9);
             if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
-            const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL>(P, c_scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
+            const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL, UTLAS>(P, scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
+            tm.mark(10);
             shadeVertex<STATS, MESHL, false, false>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm);
             if (defer || alive) {  // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool
                 P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
@@ -1228,6 +1267,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
         queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
         __syncthreads();  // queuePush's shared words are reused below
         queuePush(P.q.alive, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+        tm.mark(11);
         tm.flush(P.ctl, 0);
     }
     if (STATS) {
@@ -1315,7 +1355,7 @@ ZD void commonAov(const Params& P, uint32_t slot, uint32_t ps, const PathHead& h
         if (slots & (1u << ZYGPU_AOV_GEOMETRIC_NORMAL)) av[ZYGPU_AOV_GEOMETRIC_NORMAL * P.aov_plane] = f4(ms.geo_n);
         if (slots & (1u << ZYGPU_AOV_SHADING_NORMAL)) av[ZYGPU_AOV_SHADING_NORMAL * P.aov_plane] = f4(ms.frame.z);
         if (slots & (1u << ZYGPU_AOV_ROUGHNESS)) av[ZYGPU_AOV_ROUGHNESS * P.aov_plane].x = sqrtf(ms.a0);
-        if (slots & (1u << ZYGPU_AOV_DEPTH)) av[ZYGPU_AOV_DEPTH * P.aov_plane].x = __uint_as_float(P.pool.hit[slot].x);
+        if (slots & (1u << ZYGPU_AOV_DEPTH)) av[ZYGPU_AOV_DEPTH * P.aov_plane].x = __uint_as_float(P.pool.hit.get(slot).x);
         if (slots & (1u << ZYGPU_AOV_MATERIAL_ID)) av[ZYGPU_AOV_MATERIAL_ID * P.aov_plane].x = float(1u + sf.material);
     }
 }
@@ -1427,7 +1467,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
                 storeHead(P, slot, h);
             }
         } else {
-            const uint32_t st = P.pool.q0[slot].w;
+            const uint32_t st = P.pool.q0.get(slot).w;
             if ((st & kNeePending) || (st & kNeeCountMask) > round) {
                 PathHead h;
                 loadHead(P, slot, h);
@@ -1506,7 +1546,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
             } else {
                 h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
             }
-            float bxdf_pdf = P.pool.ray_d[slot].w;
+            float bxdf_pdf = P.pool.ray_d.get(slot).w;
             if (mis) {
                 h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
                 h.vdepth = h.depth_surface;
@@ -1539,9 +1579,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 // MULTI: a light has emittance num_samples > 1; MESHL: the scene has TriangleMesh lights
 // POOL: `slot` below is a vertex index, `ps` the camera sample it belongs to; Glass may return two bxdf samples
 // MASKS: a material of the scene has an opacity mask (shadow rays evaluate it); always on in the STATS instantiations
-template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS>
+// UTLAS: shadow rays walk the scene's prop table (dscene.hpp TlasEntry; not with STATS, MESHL, POOL or MASKS)
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false>
 __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
-    const DScene&      s = c_scene;
+    static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
     const uint32_t     nxt = P.parity ^ 1u;
     if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1553,8 +1594,11 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
     unsigned long long shadow_rays = 0;
     const uint32_t     rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i >= rounded) return;
+    const DScene& s = c_scene;
     bool     push = false, back = false;
     uint32_t slot = 0;
+    SectionTimer tm;  // -DZYG_PROFILE_SECTIONS builds: Control::sections[16..]
+    tm.start();
     // POOL: the children of this vertex: their vertex index, their place in the next level (= the round that handles them)
     uint32_t child[2] = {0, 0}, child_round[2] = {kNull, kNull};
     bool     child_back[2] = {false, false};
@@ -1570,12 +1614,13 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
         const float           split_weight = POOL ? thr4.w : 1.f;
 
         if (MESHL && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput);
+        tm.mark(0);
 
         // POOL: the split budget of this vertex (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only: pathtracer.zig:73,
         // pathtracer_dl.zig:82, 160): rough Glass evaluates light samples with it, Glass splits its bxdf sample by it
         uint32_t max_splits = 1;
         if (POOL && mis) {
-            const uint32_t m = kPoolVertices / __float_as_uint(P.pool.vorigin[slot].w);
+            const uint32_t m = kPoolVertices / __float_as_uint(P.pool.vorigin.get(slot).w);
             max_splits = m - ((h.flags & ST_PRIMARY) ? 0u : min(h.depth_surface, m - 1u));
         }
 
@@ -1591,6 +1636,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
             LightPick      picks[kMaxLightPicks];
             const uint32_t num_picks = lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold,
                                                       [&](uint32_t k, LightPick pick) { picks[k] = pick; });
+            tm.mark(1);
             for (uint32_t pk = 0; pk < num_picks; ++pk) {
                 const LightPick      pick = picks[pk];
                 const ZygpuLight     light = s.lights[pick.offset];
@@ -1610,12 +1656,17 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                     float    slen;
                     shadowRay(sorigin, ls, sdir, slen, distant);
                     Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
+                    tm.mark(2);
                     if (STATS) shadow_rays += 1;
                     f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)
                     // MESHL: the scene may have opacity masks, whose draws come from the path's sampler (material.zig:238-245)
                     auto draw = [&]() { return h.smp.sample1D(); };
                     constexpr bool kMasks = MASKS && MESHL;
-                    if ((POOL || kMasks) ? !sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw) : !sceneVisibility<STATS, MESHL>(s, shadow, cnt)) return;
+                    const bool visible = UTLAS                ? sceneVisibilityUniform<WIDE>(s, shadow)
+                                         : (POOL || kMasks) ? sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw)
+                                                            : sceneVisibility<STATS, MESHL>(s, shadow, cnt);
+                    tm.mark(3);
+                    if (!visible) return;
                     const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                     const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                     const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
@@ -1634,6 +1685,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                         const float weight = 1.f / (pick.pdf * ls.pdf);
                         occluded = occluded + S3(weight) * (((POOL || kMasks) ? tr : S3(1.f)) * radiance * bx.reflection);
                     }
+                    tm.mark(4);
                 };
 
                 // A shape's sampleTo draws all of its light samples before the first shadow test (rectangle.zig:321-352,
@@ -1741,6 +1793,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 nee = nee + occluded;
             }
             ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
+            tm.mark(5);
         }
 
         // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
@@ -1750,7 +1803,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
             // vertices left (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only, pathtracer.zig:73, pathtracer_dl.zig:82)
             BxdfSample     bs1;
             uint32_t       count;
-            const uint32_t path_count = __float_as_uint(P.pool.vorigin[slot].w);
+            const uint32_t path_count = __float_as_uint(P.pool.vorigin.get(slot).w);
             if (ZYGPU_MAT_GLASS == ms.kind) {
                 count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1);
             } else {
@@ -1766,7 +1819,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                 const uint32_t st = P.pool.pstate[ps];
                 const uint32_t first = (st >> 8) & 255u;
                 P.pool.pstate[ps] = st + (count << 8) + (count - 1u);  // children created; vertices in flight: -1 + count
-                const float  parent_pdf = P.pool.ray_d[slot].w;
+                const float  parent_pdf = P.pool.ray_d.get(slot).w;
                 const float4 parent_vgeo_n = P.pool.vgeo_n[slot], parent_vorigin = P.pool.vorigin[slot];
                 for (uint32_t c = 0; c < count; ++c) {
                     const BxdfSample& b = c ? bs1 : bs;
@@ -1795,7 +1848,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
                         const uint32_t  hit_prop = P.pool.hit_prop[slot];
                         const ZygpuProp hp = s.props[hit_prop];
                         const uint32_t  part =
-                            ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[P.pool.hit[slot].w]) : 0u;
+                            ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[P.pool.hit.get(slot).w]) : 0u;
                         if (dot3(sf.frag_geo_n, b.wi) > 0.f) cm.remove(hit_prop, part);
                         else cm.push(hit_prop, part);
                     } else if (!b.straight) {
@@ -1825,7 +1878,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
             } else {
                 h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
             }
-            float bxdf_pdf = P.pool.ray_d[slot].w;
+            float bxdf_pdf = P.pool.ray_d.get(slot).w;
             if (mis) {
                 h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
                 h.vdepth = h.depth_surface;
@@ -1851,6 +1904,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
             storeHead(P, slot, h);
             push = true;
         }
+        tm.mark(6);
     }
     if (POOL) {
         for (uint32_t r = 0; r < kPoolVertices; ++r) {  // child `first + c` of a sample is vertex `first + c` of the next level
@@ -1862,6 +1916,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
     } else {
         queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
     }
+    tm.mark(7);
+    tm.flush(P.ctl, 16);
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
 }
 

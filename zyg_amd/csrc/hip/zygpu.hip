@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh4.hpp"
 #include "kernel_table.hpp"
 #include "wavefront.hpp"
 
@@ -454,6 +455,10 @@ struct ZygpuContext {
     // multiply-adds, OCML f32 transcendentals), within the RMS <= 1e-3 contract but not bit-identical.
     bool          relaxed = false;
     bool          launch_failed = false;
+    // option "uniform_tlas" (default on): scenes whose props fit the tables of dscene.hpp TlasEntry run the kernels that
+    // walk them wave-wide instead of the top-level trees lane by lane (not the counting / MESHL / POOL instantiations)
+    bool          uniform_tlas = true, uniform_tables = false;
+    bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
     uint64_t      camera_samples = 0;
@@ -468,6 +473,8 @@ struct ZygpuContext {
 };
 
 namespace {
+
+constexpr uint32_t kWideBlasMinTriangles = 4096;
 
 // queue arrays hold one entry per path, rounded up to whole blocks
 uint32_t queueEntries(size_t paths) { return uint32_t((paths + 255) / 256 * 256); }
@@ -795,6 +802,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
     }
 
+    c->large_mesh = false;
     std::vector<DMesh> meshes(d->num_meshes);
     for (uint32_t i = 0; i < d->num_meshes; ++i) {
         const ZygpuMesh& hm = d->meshes[i];
@@ -808,6 +816,11 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             }
         }
         ok = m.upload(reinterpret_cast<const float4*>(hm.nodes), size_t(hm.num_nodes) * 2, &dm.nodes);
+        if (hm.num_triangles >= kWideBlasMinTriangles) c->large_mesh = true;
+        {  // bvh4.hpp: the same tree, four children per 128 B node; what the relaxed-arithmetic units walk
+            const std::vector<zyg::Bvh4Slot> wide = zyg::collapse4(hm.nodes, hm.num_nodes);
+            ok = ok && !wide.empty() && m.upload(reinterpret_cast<const float4*>(wide.data()), wide.size() * 2, &dm.nodes4);
+        }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
         ok = ok && m.upload(hm.triangles, size_t(hm.num_triangles) * 3, &dm.triangles);
         ok = ok && m.upload(hm.triangle_parts, hm.num_triangles, &dm.triangle_parts);
@@ -896,6 +909,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     s.specular_threshold = d->specular_threshold;
     s.num_solid_nodes = d->solid.num_nodes;
     s.num_unocc_nodes = d->unoccluding.num_nodes;
+    s.num_props = d->num_props;
+    s.num_solid_indices = d->solid.num_indices;
+    s.num_unocc_indices = d->unoccluding.num_indices;
     // The mesh props whose bounds sort extension rays into the two ends of the queue: the (up to 8) largest meshes with
     // at least 4096 triangles.  Splitting the queue halves the slot density of each group, which costs the
     // bandwidth-bound stages up to 2x in touched cache lines: worth it for deep BLAS walks (1 M triangles: wf_intersect
@@ -915,6 +931,49 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             s.heavy_aabbs[2 * k + 1] = make_float4(b.max[0], b.max[1], b.max[2], b.max[3]);
         }
     }
+    // The prop tables of a small scene (dscene.hpp TlasEntry): at most kUniformProps solid props, Rectangles and TriangleMeshes
+    // only (what the kernels without the EXTRA shapes know), Rectangles first; the unoccluding props when their tree is a
+    // single leaf of at most 4 Rectangles, in the leaf's order.
+    s.num_solid_table = s.num_unocc_table = 0;
+    {
+        auto entry = [&](uint32_t p) {
+            TlasEntry e;
+            const ZygpuAabb&  b = d->aabbs[p];
+            const ZygpuTrafo& t = d->trafos[p];
+            e.bmin = make_float4(b.min[0], b.min[1], b.min[2], b.min[3]);
+            e.bmax = make_float4(b.max[0], b.max[1], b.max[2], b.max[3]);
+            e.r0 = make_float4(t.r[0][0], t.r[0][1], t.r[0][2], t.r[0][3]);
+            e.r1 = make_float4(t.r[1][0], t.r[1][1], t.r[1][2], t.r[1][3]);
+            e.r2 = make_float4(t.r[2][0], t.r[2][1], t.r[2][2], t.r[2][3]);
+            e.pos = make_float4(t.position[0], t.position[1], t.position[2], t.position[3]);
+            e.shape = d->props[p].shape;
+            e.flags = d->props[p].flags;
+            e.prop = p;
+            e.mesh = d->props[p].mesh;
+            return e;
+        };
+        bool ok_solid = d->solid.num_indices > 0 && d->solid.num_indices <= kUniformProps;
+        for (uint32_t i = 0; ok_solid && i < d->solid.num_indices; ++i) {
+            const uint32_t sh = d->props[d->solid.indices[i]].shape;
+            ok_solid = ZYGPU_SHAPE_RECTANGLE == sh || ZYGPU_SHAPE_TRIANGLE_MESH == sh;
+        }
+        bool ok_unocc = 0 == d->unoccluding.num_nodes || (d->unoccluding.num_nodes >= 1 && 0 != d->unoccluding.nodes[0].count &&
+                                                           d->unoccluding.nodes[0].count <= 4);
+        if (ok_unocc && d->unoccluding.num_nodes)
+            for (uint32_t i = 0; i < d->unoccluding.nodes[0].count; ++i)
+                ok_unocc = ok_unocc && ZYGPU_SHAPE_RECTANGLE == d->props[d->unoccluding.indices[d->unoccluding.nodes[0].children_or_first + i]].shape;
+        if (ok_solid && ok_unocc) {
+            // Rectangles first, then meshes by size: the cheap tests shorten the ray before the expensive bounds are tested
+            std::vector<uint32_t> order(d->solid.indices, d->solid.indices + d->solid.num_indices);
+            auto weight = [&](uint32_t p) { return ZYGPU_SHAPE_RECTANGLE == d->props[p].shape ? 0u : 1u + d->meshes[d->props[p].mesh].num_triangles; };
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight(a) < weight(b); });
+            for (uint32_t p : order) s.solid_table[s.num_solid_table++] = entry(p);
+            if (d->unoccluding.num_nodes)
+                for (uint32_t i = 0; i < d->unoccluding.nodes[0].count; ++i)
+                    s.unocc_table[s.num_unocc_table++] = entry(d->unoccluding.indices[d->unoccluding.nodes[0].children_or_first + i]);
+        }
+    }
+    c->uniform_tables = s.num_solid_table > 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemsetAsync(&c->ctl->error, 0, sizeof(uint32_t), c->stream));
     if (!setUnitConstants(ZYG_CONST_SCENE, &s, sizeof(DScene), c->stream)) return -1;
@@ -1051,6 +1110,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     P.parity = 0;
     P.round = 0;
 
+    // the wave-wide walk of the prop tables: plain instantiations only (no counters, no MESHL shapes / masks, no POOL)
+    const bool     utlas = c->uniform_tlas && c->uniform_tables && !c->stats && !c->mesh_lights && !c->masks && !c->pool_mode;
+    const bool     wide = utlas && c->large_mesh;  // the wide-BLAS instantiations (relaxed units; the precise ones alias the BVH2 kernels)
     const uint32_t ticks = v.max_depth_surface + 1;  // one tick per path vertex
     const dim3     block(256);
 
@@ -1129,11 +1191,14 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                     if (0 == t) {
                         if (c->stats) launchKernel(c, K_TRACE_SHADE_STATS_FIRST, grid.x, P, num_paths);
                         else if (c->mesh_lights) launchKernel(c, K_TRACE_SHADE_MESHL_FIRST, grid.x, P, num_paths);
+                        else if (utlas) launchKernel(c, wide ? K_TRACE_SHADE_PLAIN_FIRST_UW : K_TRACE_SHADE_PLAIN_FIRST_U, grid.x, P, num_paths);
                         else launchKernel(c, K_TRACE_SHADE_PLAIN_FIRST, grid.x, P, num_paths);
                     } else if (c->stats) {
                         launchKernel(c, K_TRACE_SHADE_STATS, grid.x, P, 0u);
                     } else if (c->mesh_lights) {
                         launchKernel(c, K_TRACE_SHADE_MESHL, grid.x, P, 0u);
+                    } else if (utlas) {
+                        launchKernel(c, wide ? K_TRACE_SHADE_PLAIN_UW : K_TRACE_SHADE_PLAIN_U, grid.x, P, 0u);
                     } else {
                         launchKernel(c, K_TRACE_SHADE_PLAIN, grid.x, P, 0u);
                     }
@@ -1167,9 +1232,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
                     if (c->stats) launchKernel(c, K_SCATTER_STATS, grid.x, P, 0u);
                     else if (c->masks) launchKernel(c, K_SCATTER_MASKS, grid.x, P, 0u);
                     else if (c->mesh_lights) launchKernel(c, K_SCATTER_FULL, grid.x, P, 0u);
-                    else if (c->multi_sample_lights) launchKernel(c, K_SCATTER_MULTI, grid.x, P, 0u);
-                    else if (c->has_substitute) launchKernel(c, K_SCATTER_SUBST, grid.x, P, 0u);
-                    else launchKernel(c, K_SCATTER_LAMBERT, grid.x, P, 0u);
+                    else if (c->multi_sample_lights) launchKernel(c, wide ? K_SCATTER_MULTI_UW : utlas ? K_SCATTER_MULTI_U : K_SCATTER_MULTI, grid.x, P, 0u);
+                    else if (c->has_substitute) launchKernel(c, wide ? K_SCATTER_SUBST_UW : utlas ? K_SCATTER_SUBST_U : K_SCATTER_SUBST, grid.x, P, 0u);
+                    else launchKernel(c, wide ? K_SCATTER_LAMBERT_UW : utlas ? K_SCATTER_LAMBERT_U : K_SCATTER_LAMBERT, grid.x, P, 0u);
                 });
             } else {
             for (uint32_t r = 0; r < rounds; ++r) {
@@ -1408,6 +1473,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
             return -1;
         }
         c->relaxed = 1 == mode;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "uniform_tlas")) {
+        c->uniform_tlas = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "nee_in_place")) {
