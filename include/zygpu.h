@@ -422,6 +422,13 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * 450 B per path). */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
+/* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.
+ * mode 0: the reference's walk (top-level tree, BVH2); 1: the prop tables + BVH2; 2: the prop tables + the four-wide BLAS
+ * re-layout (modes 1 and 2 need a scene the tables hold: -1 otherwise).  hits: 8 words per ray (t, u, v as float bits,
+ * primitive, prop or ZYGPU_NULL, 3 x 0), the layout of the oracle's zyg_oracle_intersect; visible: 1 = unoccluded. */
+int zygpu_test_intersect(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits);
+int zygpu_test_visibility(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible);
+
 /* Measurement support (tools/calibrate_fetch.py): `repeats` launches of a kernel whose lane i reads the 16 B record at
  * i * stride_bytes (stride 16 / 64 / 128 / 256 / 512) of a zero-filled buffer of num_records records; average ms per launch.
  * Run under `rocprofv3 --pmc FETCH_SIZE` it calibrates that counter on the access shape of the path-state blocks. */

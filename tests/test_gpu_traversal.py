@@ -1,0 +1,122 @@
+"""Ray-level parity of the device's three ways through a scene against the CPU oracle's walk (zyg_oracle_intersect /
+zyg_oracle_visibility): the reference's own traversal (top-level tree lane by lane, BVH2), the wave-wide walk of the prop tables
+(dscene.hpp sceneIntersectUniform), and the same with the four-wide re-layout of the meshes' trees (bvh4.hpp).  All in
+precise arithmetic, so (t, u, v, primitive, prop) must be the oracle's bits ray for ray; only the four-wide walk may resolve an
+exact tie between two triangles (a ray through a shared edge, bit-equal t) the other way round, which is counted and bounded.
+
+Also: the kernels built on these walks give the same film as the ones they replace (options uniform_tlas, persistent)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import zyg_amd
+from zyg_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(n, seed):
+    """origins inside the Cornell box, directions uniform on the sphere; a few axis-parallel and grazing ones"""
+    rng = np.random.default_rng(seed)
+    o = np.stack([rng.uniform(-0.95, 0.95, n), rng.uniform(0.05, 1.95, n), rng.uniform(-0.95, 0.95, n)], axis=1)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:64] = np.eye(3)[rng.integers(0, 3, 64)] * rng.choice([-1.0, 1.0], (64, 1))
+    d[64:128, 1] *= 1e-4
+    d[64:128] /= np.linalg.norm(d[64:128], axis=1, keepdims=True)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = o
+    rays[:, 4:7] = d
+    rays[:, 7] = 2.14748313e+09
+    rays[n // 2:, 7] = rng.uniform(0.2, 3.0, n - n // 2)  # shadow-ray-like finite extents
+    return rays
+
+
+def _camera_relative(engine, rays):
+    """the compiled scene is relative to the camera position (space.zig:99-108)"""
+    out = rays.copy()
+    out[:, 0:3] -= np.array([0.0, 1.0, -3.9], dtype=np.float32)
+    return out
+
+
+def _both(engine, oracle, rays, depth=1):
+    lib, ctx = engine.lib, engine.context()
+    n = rays.shape[0]
+    sd = lib.su_ext_scene_desc().contents
+    ref_hits = np.zeros((n, 8), dtype=np.uint32)
+    ref_vis = np.zeros(n, dtype=np.uint32)
+    oracle.zyg_oracle_intersect.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    oracle.zyg_oracle_visibility.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    assert oracle.zyg_oracle_intersect(ctypes.addressof(sd), n, rays.ctypes.data, depth, ref_hits.ctypes.data) == 0
+    assert oracle.zyg_oracle_visibility(ctypes.addressof(sd), n, rays.ctypes.data, ref_vis.ctypes.data) == 0
+    lib.zygpu_test_intersect.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    lib.zygpu_test_visibility.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    out = {}
+    for mode in (0, 1, 2):
+        hits = np.zeros((n, 8), dtype=np.uint32)
+        vis = np.zeros(n, dtype=np.uint32)
+        assert lib.zygpu_test_intersect(ctx, n, rays.ctypes.data, depth, mode, hits.ctypes.data) == 0, lib.zygpu_last_error()
+        assert lib.zygpu_test_visibility(ctx, n, rays.ctypes.data, mode, vis.ctypes.data) == 0
+        out[mode] = (hits, vis)
+    return ref_hits, ref_vis, out
+
+
+@pytest.mark.parametrize("scene", ["boxes", "mesh"])
+def test_ray_dump_against_the_oracle(engine, oracle, scene):
+    n = 1 << 18
+    if scene == "boxes":
+        scenes.cornell(engine, 64, 48, 1)
+    else:
+        scenes.cornell(engine, 64, 48, 1, boxes=False, mesh=scenes.heightfield_mesh(n=400), mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
+    engine.start_frame(0)
+    rays = _camera_relative(engine, _rays(n, 11))
+    ref_hits, ref_vis, out = _both(engine, oracle, rays)
+    assert (ref_hits[:, 4] != zyg_amd.NULL).mean() > 0.5 and 0.1 < ref_vis.mean() < 0.99
+    if scene == "mesh":
+        sd = engine.lib.su_ext_scene_desc().contents
+        mesh_props = [p for p in range(sd.num_props) if sd.props[p].shape == 7]
+        assert np.isin(ref_hits[:, 4], mesh_props).mean() > 0.03  # the mesh is really hit (it lies low in the box)
+    for mode in (0, 1):  # the reference's walk and the prop tables: the oracle's bits, every ray
+        hits, vis = out[mode]
+        assert np.array_equal(hits, ref_hits), (mode, int(np.any(hits != ref_hits, axis=1).sum()))
+        assert np.array_equal(vis, ref_vis), mode
+    hits, vis = out[2]  # four-wide BLAS: same boolean, same hit except exact ties between triangles
+    assert np.array_equal(vis, ref_vis)
+    bad = np.any(hits != ref_hits, axis=1)
+    assert bad.mean() <= 1e-5, int(bad.sum())
+    # where it differs the distance is the same: it is the other triangle of a shared edge
+    assert np.array_equal(hits[bad, 0], ref_hits[bad, 0])
+
+
+def _film(product_lib, build, w, h, spp, **options):
+    with zyg_amd.Engine(product_lib) as e:
+        build(e)
+        e.start_frame(0)
+        for k, v in options.items():
+            e.set_option(k, v)
+        e.render_iterations(spp)
+        e.synchronize()
+        return e.download_film(w, h)
+
+
+@pytest.mark.parametrize("scene", ["lambert", "substitute", "mesh", "three_lights"])
+def test_prop_table_and_persistent_kernels_give_the_same_film(product_lib, scene):
+    """precise arithmetic: the wave-wide walk of the prop tables (default) == the per-lane tree walk (uniform_tlas = 0) ==
+    the persistent kernel with the path state in LDS (persistent = 1), bit for bit; with regeneration (more samples than
+    resident lanes) for the persistent one."""
+    w, h, spp = 320, 180, 4
+    build = {
+        "lambert": lambda e: scenes.cornell(e, w, h, spp),
+        "substitute": lambda e: scenes.cornell(e, w, h, spp, material="substitute", integrator="PTDL"),
+        "mesh": lambda e: scenes.cornell(e, w, h, spp, boxes=False, mesh=scenes.heightfield_mesh(n=96), mesh_material=scenes.substitute((0.5, 0.5, 0.5))),
+        "three_lights": lambda e: scenes.cornell(e, w, h, spp, many_lights=2),
+    }[scene]
+    base = _film(product_lib, build, w, h, spp, precise=1, uniform_tlas=0)
+    assert np.isfinite(base).all() and base[..., :3].max() > 0
+    assert np.array_equal(base, _film(product_lib, build, w, h, spp, precise=1, uniform_tlas=1))
+    assert np.array_equal(base, _film(product_lib, build, w, h, spp, precise=1, persistent=1))
+    # relaxed arithmetic: the two kernel families see the same samples; the persistent one only keeps the state elsewhere
+    r0 = _film(product_lib, build, w, h, spp, precise=0)
+    r1 = _film(product_lib, build, w, h, spp, precise=0, persistent=1)
+    assert np.array_equal(r0, r1)

@@ -397,16 +397,11 @@ ZD bool bvh4Walk(const float4* nodes, Ray& ray, Leaf&& leaf) {
 // triangle_tree.zig:46-109; ray in object space; shrinks ray.max_t
 // `accept(triangle, u, v)`: intersectOpacity's stochastic mask test (triangle_tree.zig:111-195)
 // WIDE: walk the mesh's four-wide re-layout instead of the reference's BVH2: the kernel instantiations for scenes with a large
-// mesh, in the relaxed-arithmetic units only (kWideBlas), and not where something depends on the reference's traversal order:
+// mesh, in the relaxed-arithmetic units only (kernel_table.hpp ZYG_WIDE), and not where something depends on the reference's traversal order:
 // the counters (STATS) and `accept` when it draws from the path's sampler.  The precise units always walk the BVH2: their
 // result is the reference's bit for bit, exact ties between triangles (a ray through a shared edge) included, which the wide
 // walk may resolve the other way round.  (For the 12-triangle boxes of the Cornell scene the wide walk's registers cost more
 // than its shorter chain saves: measured 643 vs 600 Msamples/s, so scenes without a large mesh run the BVH2 instantiations.)
-#if ZYG_FAST
-constexpr bool kWideBlas = true;
-#else
-constexpr bool kWideBlas = false;
-#endif
 template <bool STATS, bool WIDE, typename Accept>
 ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt, Accept&& accept) {
     uint32_t primitive = kNull;
@@ -439,7 +434,7 @@ ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt
 
 template <bool STATS, bool WIDE = false>
 ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt) {
-    return meshIntersect<STATS, WIDE && kWideBlas>(mesh, local_ray, hit, cnt, [](uint32_t, float, float) { return true; });
+    return meshIntersect<STATS, WIDE>(mesh, local_ray, hit, cnt, [](uint32_t, float, float) { return true; });
 }
 ZD void meshInterpolateUv(const DMesh& mesh, uint32_t prim, float u, float v, float& uv0, float& uv1) {  // triangle_data.zig:137-149
     const uint32_t ia = mesh.triangles[3 * prim], ib = mesh.triangles[3 * prim + 1], ic = mesh.triangles[3 * prim + 2];
@@ -460,7 +455,7 @@ ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
         }
         return false;
     };
-    if (!STATS && WIDE && kWideBlas) return bvh4Walk(mesh.nodes4, local_ray, leaf);
+    if (!STATS && WIDE) return bvh4Walk(mesh.nodes4, local_ray, leaf);
     return bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, leaf);
 }
 

@@ -27,11 +27,12 @@ template <int UNIT>
 static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Params& P, uint32_t arg) {
     (void)arg;
     const dim3 grid(blocks), block(256);
+    const dim3 persistent_block(kPersistentThreads);
     switch (id) {
 #define ZYG_X(unit, kid, kernel, args)                                                       \
     case kid:                                                                                \
         if constexpr (unit == UNIT) {                                                        \
-            hipLaunchKernelGGL(kernel, grid, block, 0, stream, ZYG_UNPAREN args);            \
+            hipLaunchKernelGGL(kernel, grid, (kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W) ? persistent_block : block, 0, stream, ZYG_UNPAREN args); \
             return 0;                                                                        \
         } else {                                                                             \
             return -1;                                                                       \

@@ -57,10 +57,15 @@ struct RecRef {
     }
     ZD const RecRef& operator=(const RecRef& o) const { return *this = T(o); }
 };
+// `mask` / `local`: the wavefront kernels index the records by path slot (mask = ~0, local = 0); wf_persistent keeps one
+// path's block per lane in LDS and reaches it whatever the slot (mask = 0, local = the lane's index in the block).
 template <typename T, int STRIDE = ZYG_POOL_STRIDE>
 struct Rec {
-    char* base;  // block base + the member's offset (RecOffsets)
-    ZD RecRef<T> operator[](size_t i) const { return RecRef<T>{reinterpret_cast<T*>(base + i * size_t(STRIDE))}; }
+    char*    base;  // block base + the member's offset (RecOffsets)
+    uint32_t mask, local;
+    ZD RecRef<T> operator[](size_t i) const {
+        return RecRef<T>{reinterpret_cast<T*>(base + size_t((uint32_t(i) & mask) + local) * size_t(STRIDE))};
+    }
     ZD T get(size_t i) const { return T((*this)[i]); }
 };
 template <typename T>
@@ -153,6 +158,7 @@ struct KernelCounters {
 };
 
 struct Control {  // device-resident
+    unsigned long long next_sample;  // wf_persistent: the next camera sample of the batch to hand out
     QueueCounts        ext_count[2];
     QueueCounts        ext_pool_count[2][kPoolVertices];  // POOL
     QueueCounts        alive_count[2];   // [parity of the tick]: wf_trace_shade fills this tick's and resets the next one's
@@ -1580,6 +1586,331 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 // POOL: `slot` below is a vertex index, `ps` the camera sample it belongs to; Glass may return two bxdf samples
 // MASKS: a material of the scene has an opacity mask (shadow rays evaluate it); always on in the STATS instantiations
 // UTLAS: shadow rays walk the scene's prop table (dscene.hpp TlasEntry; not with STATS, MESHL, POOL or MASKS)
+// what a vertex of wf_scatter hands to the queues
+struct ScatterOut {
+    bool     push = false, back = false;
+    // POOL: the children of this vertex: their vertex index, their place in the next level (= the round that handles them)
+    uint32_t child[2] = {0, 0}, child_round[2] = {kNull, kNull};
+    bool     child_back[2] = {false, false};
+};
+
+// One vertex of wf_scatter: sampleLights / evaluateLight with the shadow rays traced in the pick loop, then the bxdf sample
+// and the path extension (pathtracer_mis.zig:123-278).  Template parameters as wf_scatter's.
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE>
+ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOut& out, Counters& cnt, unsigned long long& shadow_rays,
+                      SectionTimer& tm) {
+    const uint32_t nxt = P.parity ^ 1u;
+    const uint32_t kind = c_view.v.integrator;
+    const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
+    bool&          push = out.push;
+    bool&          back = out.back;
+    uint32_t(&child)[2] = out.child;
+    uint32_t(&child_round)[2] = out.child_round;
+    bool(&child_back)[2] = out.child_back;
+    (void)nxt;
+    const uint32_t ps = sampleSlot<POOL>(slot);
+    PathHead h;
+    loadHead<POOL>(P, slot, h);
+    const Surface         sf = loadSurface<POOL, MESHL>(P, slot, h.flags);
+    const MaterialSample& ms = sf.ms;
+    const float4          thr4 = P.pool.thr[slot];
+    f3                    throughput = xyz4(thr4);
+    const float           split_weight = POOL ? thr4.w : 1.f;
+
+    if (MESHL && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput);
+    tm.mark(0);
+
+    // POOL: the split budget of this vertex (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only: pathtracer.zig:73,
+    // pathtracer_dl.zig:82, 160): rough Glass evaluates light samples with it, Glass splits its bxdf sample by it
+    uint32_t max_splits = 1;
+    if (POOL && mis) {
+        const uint32_t m = kPoolVertices / __float_as_uint(P.pool.vorigin.get(slot).w);
+        max_splits = m - ((h.flags & ST_PRIMARY) ? 0u : min(h.depth_surface, m - 1u));
+    }
+
+    // ---- sampleLights / evaluateLight (pathtracer_mis.zig:174-278, pathtracer_dl.zig:100-167)
+    if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
+        const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
+        const float     select = h.smp.sample1D();
+        const LightTree lt{s, s.light_tree};
+        NoTimer         notimer;
+        f3              nee = S3(0.f);
+        // the picks first (Scene.randomLightSpatial fills a buffer too, scene.zig:592-610), then one loop over them: the
+        // lanes of a wave leave the tree walk together instead of interleaving it with their shadow rays
+        LightPick      picks[kMaxLightPicks];
+        const uint32_t num_picks = lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold,
+                                                  [&](uint32_t k, LightPick pick) { picks[k] = pick; });
+        tm.mark(1);
+        for (uint32_t pk = 0; pk < num_picks; ++pk) {
+            const LightPick      pick = picks[pk];
+            const ZygpuLight     light = s.lights[pick.offset];
+            const Trafo          trafo = loadTrafo(s, light.prop);
+            const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
+            // PathtracerDL samples its lights with threshold 0 (pathtracer_dl.zig:139-167)
+            const float sample_threshold = mis ? nee_threshold : 0.f;
+            f3          occluded = S3(0.f);
+
+            // evaluateLight's loop body for one light sample (pathtracer_mis.zig:248-272 / pathtracer_dl.zig:150-166)
+            const uint32_t light_shape = MESHL ? s.props[light.prop].shape : uint32_t(ZYGPU_SHAPE_RECTANGLE);
+            const bool     distant =
+                ZYGPU_SHAPE_DISTANT == light_shape || ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_CANOPY == light_shape;
+            auto connect = [&](const SampleTo& ls) {
+                const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
+                f3       sdir;
+                float    slen;
+                shadowRay(sorigin, ls, sdir, slen, distant);
+                Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
+                tm.mark(2);
+                if (STATS) shadow_rays += 1;
+                f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)
+                // MESHL: the scene may have opacity masks, whose draws come from the path's sampler (material.zig:238-245)
+                auto draw = [&]() { return h.smp.sample1D(); };
+                constexpr bool kMasks = MASKS && MESHL;
+                const bool visible = UTLAS                ? sceneVisibilityUniform<WIDE>(s, shadow)
+                                     : (POOL || kMasks) ? sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw)
+                                                        : sceneVisibility<STATS, MESHL>(s, shadow, cnt);
+                tm.mark(3);
+                if (!visible) return;
+                const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
+                const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
+                const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
+                nanTrace(P, ls.wi, 10);
+                nanTrace(P, ls.pdf, 11);
+                nanTrace(P, radiance, 12);
+                nanTrace(P, bx.reflection, 13);
+                nanTrace(P, bx.pdf, 14);
+                nanTrace(P, pick.pdf, 15);
+                if (mis) {
+                    const float light_pdf = ls.pdf * pick.pdf;
+                    const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
+                    const f3    unocc = S3(weight) * radiance * bx.reflection;
+                    occluded = occluded + ((POOL || kMasks) ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
+                } else {
+                    const float weight = 1.f / (pick.pdf * ls.pdf);
+                    occluded = occluded + S3(weight) * (((POOL || kMasks) ? tr : S3(1.f)) * radiance * bx.reflection);
+                }
+                tm.mark(4);
+            };
+
+            // A shape's sampleTo draws all of its light samples before the first shadow test (rectangle.zig:321-352,
+            // triangle_mesh.zig:513-592); instead of buffering them, a copy of the sampler replays those draws while
+            // the path's sampler runs ahead to where the post-visibility draws continue.
+            if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
+                // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
+                const DImageLight& il = s.image_lights[light.sampler];
+                if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape) {
+                    const uint32_t n = numSamples(light.num_samples, sample_threshold);
+                    Sampler        replay = h.smp;
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float a, b;
+                        h.smp.sample2D(a, b);
+                    }
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float r0, r1;
+                        replay.sample2D(r0, r1);
+                        SampleTo   ls;
+                        const bool got = ZYGPU_SHAPE_DOME == light_shape
+                                             ? domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)
+                                             : rectangleSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided,
+                                                                       ms.translucent, ls);
+                        if (got) connect(ls);
+                    }
+                } else {
+                    SampleTo ls;
+                    if (canopySampleMaterialTo(il, ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
+                }
+            } else if (MESHL && kNull != light.sampler) {
+                const DMeshLight&      ml = s.mesh_lights[light.sampler];
+                const DMesh&           mesh = s.meshes[ml.mesh];
+                const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
+                const float            r = h.smp.sample1D();
+                const LightTree        ptree{s, ml.tree};
+                Sampler                replay = h.smp;
+                const uint32_t         npicks =
+                    ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [](uint32_t, LightPick) {});
+                for (uint32_t j = 0; j < npicks; ++j) {
+                    float a, b;
+                    h.smp.sample2D(a, b);
+                }
+                ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [&](uint32_t, LightPick tri) {
+                    float r0, r1;
+                    replay.sample2D(r0, r1);
+                    SampleTo ls;
+                    if (msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
+                });
+            } else if (distant) {
+                SampleTo   ls;
+                const bool got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(ms.geo_n, ms.translucent, h.smp, ls)
+                                 : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)
+                                                                     : distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls);
+                if (got) connect(ls);
+            } else if (ZYGPU_SHAPE_SPHERE == light_shape) {
+                const uint32_t      n = numSamples(light.num_samples, sample_threshold);
+                const SphereSampler ss = SphereSampler::init(sf.p, trafo, n);
+                if (ss.valid) {  // sphere.zig:331-337: a point inside the sphere takes no sample and no draw
+                    Sampler replay = h.smp;
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float a, b;
+                        h.smp.sample2D(a, b);
+                    }
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float s0, s1;
+                        replay.sample2D(s0, s1);
+                        SampleTo ls;
+                        if (ss.sample(s0, s1, sf.p, ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
+                    }
+                }
+            } else if (MESHL && ZYGPU_SHAPE_DISK == light_shape) {
+                const uint32_t    n = numSamples(light.num_samples, sample_threshold);
+                const DiskSampler ds = DiskSampler::init(sf.p, trafo, n);
+                if (ds.valid) {  // disk.zig:273-276: no sample, no draw
+                    // a sample's second draw depends on its first: the path's sampler runs the sampling once for its
+                    // draws alone, the copy once more for the samples
+                    Sampler replay = h.smp;
+                    for (uint32_t j = 0; j < n; ++j) {
+                        SampleTo ls;
+                        ds.sample(h.smp, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                    }
+                    for (uint32_t j = 0; j < n; ++j) {
+                        SampleTo ls;
+                        if (ds.sample(replay, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
+                    }
+                }
+            } else {
+                const uint32_t         n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
+                const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
+                Sampler                replay = h.smp;
+                if (MULTI) {
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float a, b;
+                        h.smp.sample2D(a, b);
+                    }
+                }
+                for (uint32_t j = 0; j < n; ++j) {
+                    float u0, u1;
+                    if (MULTI) replay.sample2D(u0, u1);
+                    else h.smp.sample2D(u0, u1);
+                    SampleTo ls;
+                    if (rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
+                }
+            }
+            nee = nee + occluded;
+        }
+        ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
+        tm.mark(5);
+    }
+
+    // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
+    BxdfSample bs;
+    if (POOL) {
+        // mat_sample.sample(sampler, max_splits, ..): Glass splits into reflection and refraction while the sample has
+        // vertices left (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only, pathtracer.zig:73, pathtracer_dl.zig:82)
+        BxdfSample     bs1;
+        uint32_t       count;
+        const uint32_t path_count = __float_as_uint(P.pool.vorigin.get(slot).w);
+        if (ZYGPU_MAT_GLASS == ms.kind) {
+            count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1);
+        } else {
+            count = ms.template sample<SUBST>(s, h.smp, bs) ? 1u : 0u;
+        }
+        h.smp.incrementPadding();  // after the children, none of which draws (pathtracer_mis.zig:165)
+        storeSamplers(P, ps, h);
+        if (0 == count) {
+            terminateVertex(P, ps, S3(0.f), split_weight, h.flags);  // vertex.throughput = 0 (pathtracer_mis.zig:127-129)
+        } else {
+            Mediums md;
+            md.load(P, slot);
+            const uint32_t st = P.pool.pstate[ps];
+            const uint32_t first = (st >> 8) & 255u;
+            P.pool.pstate[ps] = st + (count << 8) + (count - 1u);  // children created; vertices in flight: -1 + count
+            const float  parent_pdf = P.pool.ray_d.get(slot).w;
+            const float4 parent_vgeo_n = P.pool.vgeo_n[slot], parent_vorigin = P.pool.vorigin[slot];
+            for (uint32_t c = 0; c < count; ++c) {
+                const BxdfSample& b = c ? bs1 : bs;
+                const uint32_t    cv = (nxt * kPoolVertices + first + c) * batchPaths() + ps;
+                PathHead          ch = h;
+                // Vertex.State.update (vertex.zig:30-43): a .Straight event (thin glass) leaves the state alone
+                if (kScatterSpecular == b.scattering) {
+                    ch.flags |= ST_SPECULAR;
+                    ch.flags = (0.f == b.reg_alpha) ? (ch.flags | ST_SINGULAR) : (ch.flags & ~uint32_t(ST_SINGULAR));
+                    if (ch.flags & ST_PRIMARY) ch.flags |= ST_STARTED_SPECULAR;
+                } else if (!b.straight) {
+                    ch.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
+                }
+                float bxdf_pdf = parent_pdf;
+                if (mis && !b.straight) {  // pathtracer_mis.zig:141-148: not for .Straight
+                    ch.flags = ms.translucent ? (ch.flags | ST_TRANSLUCENT) : (ch.flags & ~uint32_t(ST_TRANSLUCENT));
+                    ch.vdepth = h.depth_surface;
+                    bxdf_pdf = b.pdf;
+                }
+                const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, b.wi);
+                ch.depth_surface = h.depth_surface + 1;
+                Mediums cm = md;
+                if (b.transmission) {
+                    // Vertex.interfaceChange (vertex.zig:94-108): leaving if the new direction is on the side of the
+                    // fragment's geometric normal
+                    const uint32_t  hit_prop = P.pool.hit_prop[slot];
+                    const ZygpuProp hp = s.props[hit_prop];
+                    const uint32_t  part =
+                        ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[P.pool.hit.get(slot).w]) : 0u;
+                    if (dot3(sf.frag_geo_n, b.wi) > 0.f) cm.remove(hit_prop, part);
+                    else cm.push(hit_prop, part);
+                } else if (!b.straight) {
+                    ch.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight)
+                }
+                P.pool.ray_o[cv] = f4(new_origin, kRayMaxT);
+                P.pool.ray_d[cv] = f4(b.wi, bxdf_pdf);
+                P.pool.thr[cv] = f4(throughput * (b.reflection / S3(b.pdf)), split_weight * b.split_weight);
+                // vertex.origin / geo_n move with every event but .Straight (pathtracer_mis.zig:141-148, pathtracer.zig:88-90)
+                P.pool.vorigin[cv] = f4(b.straight ? xyz4(parent_vorigin) : sf.p, __uint_as_float(path_count * count));
+                P.pool.vgeo_n[cv] = (mis && !b.straight) ? f4(ms.geo_n) : parent_vgeo_n;
+                P.pool.vmeta[cv] = packMeta(ch);
+                cm.store(P, cv);
+                child[c] = cv;
+                child_round[c] = first + c;
+                child_back[c] = entersMeshBounds(new_origin, b.wi);
+            }
+        }
+    } else if (!ms.template sample<SUBST>(s, h.smp, bs)) {
+        finalize(P, slot, S3(0.f), h.flags);
+    } else {
+        // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
+        if (kScatterSpecular == bs.scattering) {
+            h.flags |= ST_SPECULAR;
+            h.flags = (0.f == bs.reg_alpha) ? (h.flags | ST_SINGULAR) : (h.flags & ~uint32_t(ST_SINGULAR));
+            if (h.flags & ST_PRIMARY) h.flags |= ST_STARTED_SPECULAR;
+        } else {
+            h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
+        }
+        float bxdf_pdf = P.pool.ray_d.get(slot).w;
+        if (mis) {
+            h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
+            h.vdepth = h.depth_surface;
+            bxdf_pdf = bs.pdf;
+            P.pool.vgeo_n[slot] = f4(ms.geo_n);
+        }
+        throughput = throughput * (bs.reflection / S3(bs.pdf));
+        nanTrace(P, bs.reflection, 16);
+        nanTrace(P, bs.pdf, 17);
+        nanTrace(P, bs.wi, 18);
+        nanTrace(P, sf.p, 19);
+        nanTrace(P, throughput, 20);
+        const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
+        h.depth_surface += 1;
+        h.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight): a reflection clears it
+        h.smp.incrementPadding();
+
+        P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
+        P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
+        back = entersMeshBounds(new_origin, bs.wi);
+        P.pool.thr[slot] = f4(throughput);
+        P.pool.vorigin[slot] = f4(sf.p);
+        storeHead(P, slot, h);
+        push = true;
+    }
+    tm.mark(6);
+}
+
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false>
 __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
@@ -1588,337 +1919,125 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t           at;
     const uint32_t     total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
-    const uint32_t     kind = c_view.v.integrator;
-    const bool         mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     Counters           cnt{0, 0, 0};
     unsigned long long shadow_rays = 0;
     const uint32_t     rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i >= rounded) return;
     const DScene& s = c_scene;
-    bool     push = false, back = false;
     uint32_t slot = 0;
     SectionTimer tm;  // -DZYG_PROFILE_SECTIONS builds: Control::sections[16..]
     tm.start();
-    // POOL: the children of this vertex: their vertex index, their place in the next level (= the round that handles them)
-    uint32_t child[2] = {0, 0}, child_round[2] = {kNull, kNull};
-    bool     child_back[2] = {false, false};
+    ScatterOut out;
     if (i < total) {
         slot = P.q.alive[at];
-        const uint32_t ps = sampleSlot<POOL>(slot);
-        PathHead h;
-        loadHead<POOL>(P, slot, h);
-        const Surface         sf = loadSurface<POOL, MESHL>(P, slot, h.flags);
-        const MaterialSample& ms = sf.ms;
-        const float4          thr4 = P.pool.thr[slot];
-        f3                    throughput = xyz4(thr4);
-        const float           split_weight = POOL ? thr4.w : 1.f;
-
-        if (MESHL && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput);
-        tm.mark(0);
-
-        // POOL: the split budget of this vertex (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only: pathtracer.zig:73,
-        // pathtracer_dl.zig:82, 160): rough Glass evaluates light samples with it, Glass splits its bxdf sample by it
-        uint32_t max_splits = 1;
-        if (POOL && mis) {
-            const uint32_t m = kPoolVertices / __float_as_uint(P.pool.vorigin.get(slot).w);
-            max_splits = m - ((h.flags & ST_PRIMARY) ? 0u : min(h.depth_surface, m - 1u));
-        }
-
-        // ---- sampleLights / evaluateLight (pathtracer_mis.zig:174-278, pathtracer_dl.zig:100-167)
-        if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
-            const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
-            const float     select = h.smp.sample1D();
-            const LightTree lt{s, s.light_tree};
-            NoTimer         notimer;
-            f3              nee = S3(0.f);
-            // the picks first (Scene.randomLightSpatial fills a buffer too, scene.zig:592-610), then one loop over them: the
-            // lanes of a wave leave the tree walk together instead of interleaving it with their shadow rays
-            LightPick      picks[kMaxLightPicks];
-            const uint32_t num_picks = lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold,
-                                                      [&](uint32_t k, LightPick pick) { picks[k] = pick; });
-            tm.mark(1);
-            for (uint32_t pk = 0; pk < num_picks; ++pk) {
-                const LightPick      pick = picks[pk];
-                const ZygpuLight     light = s.lights[pick.offset];
-                const Trafo          trafo = loadTrafo(s, light.prop);
-                const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
-                // PathtracerDL samples its lights with threshold 0 (pathtracer_dl.zig:139-167)
-                const float sample_threshold = mis ? nee_threshold : 0.f;
-                f3          occluded = S3(0.f);
-
-                // evaluateLight's loop body for one light sample (pathtracer_mis.zig:248-272 / pathtracer_dl.zig:150-166)
-                const uint32_t light_shape = MESHL ? s.props[light.prop].shape : uint32_t(ZYGPU_SHAPE_RECTANGLE);
-                const bool     distant =
-                    ZYGPU_SHAPE_DISTANT == light_shape || ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_CANOPY == light_shape;
-                auto connect = [&](const SampleTo& ls) {
-                    const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
-                    f3       sdir;
-                    float    slen;
-                    shadowRay(sorigin, ls, sdir, slen, distant);
-                    Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
-                    tm.mark(2);
-                    if (STATS) shadow_rays += 1;
-                    f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)
-                    // MESHL: the scene may have opacity masks, whose draws come from the path's sampler (material.zig:238-245)
-                    auto draw = [&]() { return h.smp.sample1D(); };
-                    constexpr bool kMasks = MASKS && MESHL;
-                    const bool visible = UTLAS                ? sceneVisibilityUniform<WIDE>(s, shadow)
-                                         : (POOL || kMasks) ? sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw)
-                                                            : sceneVisibility<STATS, MESHL>(s, shadow, cnt);
-                    tm.mark(3);
-                    if (!visible) return;
-                    const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
-                    const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
-                    const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
-                    nanTrace(P, ls.wi, 10);
-                    nanTrace(P, ls.pdf, 11);
-                    nanTrace(P, radiance, 12);
-                    nanTrace(P, bx.reflection, 13);
-                    nanTrace(P, bx.pdf, 14);
-                    nanTrace(P, pick.pdf, 15);
-                    if (mis) {
-                        const float light_pdf = ls.pdf * pick.pdf;
-                        const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
-                        const f3    unocc = S3(weight) * radiance * bx.reflection;
-                        occluded = occluded + ((POOL || kMasks) ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
-                    } else {
-                        const float weight = 1.f / (pick.pdf * ls.pdf);
-                        occluded = occluded + S3(weight) * (((POOL || kMasks) ? tr : S3(1.f)) * radiance * bx.reflection);
-                    }
-                    tm.mark(4);
-                };
-
-                // A shape's sampleTo draws all of its light samples before the first shadow test (rectangle.zig:321-352,
-                // triangle_mesh.zig:513-592); instead of buffering them, a copy of the sampler replays those draws while
-                // the path's sampler runs ahead to where the post-visibility draws continue.
-                if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
-                    // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
-                    const DImageLight& il = s.image_lights[light.sampler];
-                    if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape) {
-                        const uint32_t n = numSamples(light.num_samples, sample_threshold);
-                        Sampler        replay = h.smp;
-                        for (uint32_t j = 0; j < n; ++j) {
-                            float a, b;
-                            h.smp.sample2D(a, b);
-                        }
-                        for (uint32_t j = 0; j < n; ++j) {
-                            float r0, r1;
-                            replay.sample2D(r0, r1);
-                            SampleTo   ls;
-                            const bool got = ZYGPU_SHAPE_DOME == light_shape
-                                                 ? domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)
-                                                 : rectangleSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided,
-                                                                           ms.translucent, ls);
-                            if (got) connect(ls);
-                        }
-                    } else {
-                        SampleTo ls;
-                        if (canopySampleMaterialTo(il, ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
-                    }
-                } else if (MESHL && kNull != light.sampler) {
-                    const DMeshLight&      ml = s.mesh_lights[light.sampler];
-                    const DMesh&           mesh = s.meshes[ml.mesh];
-                    const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
-                    const float            r = h.smp.sample1D();
-                    const LightTree        ptree{s, ml.tree};
-                    Sampler                replay = h.smp;
-                    const uint32_t         npicks =
-                        ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [](uint32_t, LightPick) {});
-                    for (uint32_t j = 0; j < npicks; ++j) {
-                        float a, b;
-                        h.smp.sample2D(a, b);
-                    }
-                    ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [&](uint32_t, LightPick tri) {
-                        float r0, r1;
-                        replay.sample2D(r0, r1);
-                        SampleTo ls;
-                        if (msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
-                    });
-                } else if (distant) {
-                    SampleTo   ls;
-                    const bool got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(ms.geo_n, ms.translucent, h.smp, ls)
-                                     : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)
-                                                                         : distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls);
-                    if (got) connect(ls);
-                } else if (ZYGPU_SHAPE_SPHERE == light_shape) {
-                    const uint32_t      n = numSamples(light.num_samples, sample_threshold);
-                    const SphereSampler ss = SphereSampler::init(sf.p, trafo, n);
-                    if (ss.valid) {  // sphere.zig:331-337: a point inside the sphere takes no sample and no draw
-                        Sampler replay = h.smp;
-                        for (uint32_t j = 0; j < n; ++j) {
-                            float a, b;
-                            h.smp.sample2D(a, b);
-                        }
-                        for (uint32_t j = 0; j < n; ++j) {
-                            float s0, s1;
-                            replay.sample2D(s0, s1);
-                            SampleTo ls;
-                            if (ss.sample(s0, s1, sf.p, ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
-                        }
-                    }
-                } else if (MESHL && ZYGPU_SHAPE_DISK == light_shape) {
-                    const uint32_t    n = numSamples(light.num_samples, sample_threshold);
-                    const DiskSampler ds = DiskSampler::init(sf.p, trafo, n);
-                    if (ds.valid) {  // disk.zig:273-276: no sample, no draw
-                        // a sample's second draw depends on its first: the path's sampler runs the sampling once for its
-                        // draws alone, the copy once more for the samples
-                        Sampler replay = h.smp;
-                        for (uint32_t j = 0; j < n; ++j) {
-                            SampleTo ls;
-                            ds.sample(h.smp, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
-                        }
-                        for (uint32_t j = 0; j < n; ++j) {
-                            SampleTo ls;
-                            if (ds.sample(replay, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
-                        }
-                    }
-                } else {
-                    const uint32_t         n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
-                    const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
-                    Sampler                replay = h.smp;
-                    if (MULTI) {
-                        for (uint32_t j = 0; j < n; ++j) {
-                            float a, b;
-                            h.smp.sample2D(a, b);
-                        }
-                    }
-                    for (uint32_t j = 0; j < n; ++j) {
-                        float u0, u1;
-                        if (MULTI) replay.sample2D(u0, u1);
-                        else h.smp.sample2D(u0, u1);
-                        SampleTo ls;
-                        if (rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
-                    }
-                }
-                nee = nee + occluded;
-            }
-            ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
-            tm.mark(5);
-        }
-
-        // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
-        BxdfSample bs;
-        if (POOL) {
-            // mat_sample.sample(sampler, max_splits, ..): Glass splits into reflection and refraction while the sample has
-            // vertices left (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only, pathtracer.zig:73, pathtracer_dl.zig:82)
-            BxdfSample     bs1;
-            uint32_t       count;
-            const uint32_t path_count = __float_as_uint(P.pool.vorigin.get(slot).w);
-            if (ZYGPU_MAT_GLASS == ms.kind) {
-                count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1);
-            } else {
-                count = ms.template sample<SUBST>(s, h.smp, bs) ? 1u : 0u;
-            }
-            h.smp.incrementPadding();  // after the children, none of which draws (pathtracer_mis.zig:165)
-            storeSamplers(P, ps, h);
-            if (0 == count) {
-                terminateVertex(P, ps, S3(0.f), split_weight, h.flags);  // vertex.throughput = 0 (pathtracer_mis.zig:127-129)
-            } else {
-                Mediums md;
-                md.load(P, slot);
-                const uint32_t st = P.pool.pstate[ps];
-                const uint32_t first = (st >> 8) & 255u;
-                P.pool.pstate[ps] = st + (count << 8) + (count - 1u);  // children created; vertices in flight: -1 + count
-                const float  parent_pdf = P.pool.ray_d.get(slot).w;
-                const float4 parent_vgeo_n = P.pool.vgeo_n[slot], parent_vorigin = P.pool.vorigin[slot];
-                for (uint32_t c = 0; c < count; ++c) {
-                    const BxdfSample& b = c ? bs1 : bs;
-                    const uint32_t    cv = (nxt * kPoolVertices + first + c) * batchPaths() + ps;
-                    PathHead          ch = h;
-                    // Vertex.State.update (vertex.zig:30-43): a .Straight event (thin glass) leaves the state alone
-                    if (kScatterSpecular == b.scattering) {
-                        ch.flags |= ST_SPECULAR;
-                        ch.flags = (0.f == b.reg_alpha) ? (ch.flags | ST_SINGULAR) : (ch.flags & ~uint32_t(ST_SINGULAR));
-                        if (ch.flags & ST_PRIMARY) ch.flags |= ST_STARTED_SPECULAR;
-                    } else if (!b.straight) {
-                        ch.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
-                    }
-                    float bxdf_pdf = parent_pdf;
-                    if (mis && !b.straight) {  // pathtracer_mis.zig:141-148: not for .Straight
-                        ch.flags = ms.translucent ? (ch.flags | ST_TRANSLUCENT) : (ch.flags & ~uint32_t(ST_TRANSLUCENT));
-                        ch.vdepth = h.depth_surface;
-                        bxdf_pdf = b.pdf;
-                    }
-                    const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, b.wi);
-                    ch.depth_surface = h.depth_surface + 1;
-                    Mediums cm = md;
-                    if (b.transmission) {
-                        // Vertex.interfaceChange (vertex.zig:94-108): leaving if the new direction is on the side of the
-                        // fragment's geometric normal
-                        const uint32_t  hit_prop = P.pool.hit_prop[slot];
-                        const ZygpuProp hp = s.props[hit_prop];
-                        const uint32_t  part =
-                            ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[P.pool.hit.get(slot).w]) : 0u;
-                        if (dot3(sf.frag_geo_n, b.wi) > 0.f) cm.remove(hit_prop, part);
-                        else cm.push(hit_prop, part);
-                    } else if (!b.straight) {
-                        ch.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight)
-                    }
-                    P.pool.ray_o[cv] = f4(new_origin, kRayMaxT);
-                    P.pool.ray_d[cv] = f4(b.wi, bxdf_pdf);
-                    P.pool.thr[cv] = f4(throughput * (b.reflection / S3(b.pdf)), split_weight * b.split_weight);
-                    // vertex.origin / geo_n move with every event but .Straight (pathtracer_mis.zig:141-148, pathtracer.zig:88-90)
-                    P.pool.vorigin[cv] = f4(b.straight ? xyz4(parent_vorigin) : sf.p, __uint_as_float(path_count * count));
-                    P.pool.vgeo_n[cv] = (mis && !b.straight) ? f4(ms.geo_n) : parent_vgeo_n;
-                    P.pool.vmeta[cv] = packMeta(ch);
-                    cm.store(P, cv);
-                    child[c] = cv;
-                    child_round[c] = first + c;
-                    child_back[c] = entersMeshBounds(new_origin, b.wi);
-                }
-            }
-        } else if (!ms.template sample<SUBST>(s, h.smp, bs)) {
-            finalize(P, slot, S3(0.f), h.flags);
-        } else {
-            // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
-            if (kScatterSpecular == bs.scattering) {
-                h.flags |= ST_SPECULAR;
-                h.flags = (0.f == bs.reg_alpha) ? (h.flags | ST_SINGULAR) : (h.flags & ~uint32_t(ST_SINGULAR));
-                if (h.flags & ST_PRIMARY) h.flags |= ST_STARTED_SPECULAR;
-            } else {
-                h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
-            }
-            float bxdf_pdf = P.pool.ray_d.get(slot).w;
-            if (mis) {
-                h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
-                h.vdepth = h.depth_surface;
-                bxdf_pdf = bs.pdf;
-                P.pool.vgeo_n[slot] = f4(ms.geo_n);
-            }
-            throughput = throughput * (bs.reflection / S3(bs.pdf));
-            nanTrace(P, bs.reflection, 16);
-            nanTrace(P, bs.pdf, 17);
-            nanTrace(P, bs.wi, 18);
-            nanTrace(P, sf.p, 19);
-            nanTrace(P, throughput, 20);
-            const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
-            h.depth_surface += 1;
-            h.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight): a reflection clears it
-            h.smp.incrementPadding();
-
-            P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
-            P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
-            back = entersMeshBounds(new_origin, bs.wi);
-            P.pool.thr[slot] = f4(throughput);
-            P.pool.vorigin[slot] = f4(sf.p);
-            storeHead(P, slot, h);
-            push = true;
-        }
-        tm.mark(6);
+        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE>(P, s, slot, out, cnt, shadow_rays, tm);
     }
     if (POOL) {
         for (uint32_t r = 0; r < kPoolVertices; ++r) {  // child `first + c` of a sample is vertex `first + c` of the next level
-            const bool c0 = r == child_round[0], c1 = r == child_round[1];
+            const bool c0 = r == out.child_round[0], c1 = r == out.child_round[1];
             if (r) __syncthreads();  // queuePush's shared words are reused
-            queuePush(P.q.ext_pool[nxt][r], &P.ctl->ext_pool_count[nxt][r], P.queue_capacity, c0 || c1, c1 ? child[1] : child[0],
-                      c1 ? child_back[1] : child_back[0]);
+            queuePush(P.q.ext_pool[nxt][r], &P.ctl->ext_pool_count[nxt][r], P.queue_capacity, c0 || c1, c1 ? out.child[1] : out.child[0],
+                      c1 ? out.child_back[1] : out.child_back[0]);
         }
     } else {
-        queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
+        queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, out.push, slot, out.back);
     }
     tm.mark(7);
     tm.flush(P.ctl, 16);
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
+}
+
+// ---------------------------------------------------------------- wf_persistent
+// The whole path in one kernel (option "persistent"; north_star: persistent threads, path state staged in LDS): a lane
+// generates a camera sample, then loops trace -> shade -> scatter on it with the path's record block (the same 256 B + 32 B
+// the wavefront kernels keep in HBM) in LDS, and takes the next sample of the batch when its path ends.  No queues, no state
+// round trips through HBM; the price is one wave running every stage's code (the registers of the largest one, lanes idling
+// through the rare heavy branches) and lanes of one wave sitting at different path depths.
+// The film is still accumulated from the staging buffer in slot order, so the result is the wavefront kernels' bit for bit.
+constexpr uint32_t kPersistentThreads = 128;
+template <bool SUBST, bool MULTI, bool WIDE>
+__global__ void __launch_bounds__(kPersistentThreads) ZYG_WAVES(2) wf_persistent(Params P, uint32_t num_paths) {
+    __shared__ uint4 blocks[kPersistentThreads * (ZYG_POOL_STRIDE + ZYG_HIT_STRIDE) / 16];
+    const DScene&    s = c_scene;
+    Params           L = P;
+    char*            block = reinterpret_cast<char*>(blocks);
+    char*            hits = block + kPersistentThreads * ZYG_POOL_STRIDE;
+    const uint32_t   lane_block = threadIdx.x;
+#define ZYG_LOCAL(rec, ptr) L.pool.rec.base = (ptr), L.pool.rec.mask = 0u, L.pool.rec.local = lane_block
+    ZYG_LOCAL(q0, block + kOffQ0);
+    ZYG_LOCAL(q1, block + kOffQ1);
+    ZYG_LOCAL(pcg, block + kOffPcg);
+    ZYG_LOCAL(ray_o, block + kOffRayO);
+    ZYG_LOCAL(ray_d, block + kOffRayD);
+    ZYG_LOCAL(thr, block + kOffThr);
+    ZYG_LOCAL(rec_p, block + kOffRecP);
+    ZYG_LOCAL(rec_gn, block + kOffRecGn);
+    ZYG_LOCAL(rec_n, block + kOffRecN);
+    ZYG_LOCAL(rec_t, block + kOffRecT);
+    ZYG_LOCAL(rec_b, block + kOffRecB);
+    ZYG_LOCAL(vorigin, block + kOffVorigin);
+    ZYG_LOCAL(vgeo_n, block + kOffVgeoN);
+    ZYG_LOCAL(emission, block + kOffEmission);
+    ZYG_LOCAL(direct, block + kOffDirect);
+    ZYG_LOCAL(indirect, block + kOffIndirect);
+    ZYG_LOCAL(hit, hits);
+    ZYG_LOCAL(hit_prop, hits + 16);
+    ZYG_LOCAL(ucount, hits + 20);
+    ZYG_LOCAL(hit_sr, hits + 24);
+#undef ZYG_LOCAL
+    Counters           none{0, 0, 0};
+    unsigned long long no_rays = 0;
+    SectionTimer       tm;
+    tm.start();
+    bool     active = false, exhausted = false;
+    uint32_t slot = 0;
+    for (;;) {
+        if (!active && !exhausted) {  // the next sample of the batch: one atomic per wave for the lanes that need one
+            const unsigned long long need = __ballot(true);
+            const uint32_t           count = uint32_t(__popcll(need)), rank = uint32_t(__popcll(need & ((1ull << __lane_id()) - 1ull)));
+            unsigned long long       first = 0;
+            if (0 == rank) first = atomicAdd(&P.ctl->next_sample, (unsigned long long)count);
+            first = __shfl(first, __ffsll(need) - 1);
+            const unsigned long long mine = first + rank;
+            if (mine < num_paths) {
+                slot = uint32_t(mine);
+                generatePath<false, false>(L, slot);
+                active = true;
+            } else {
+                exhausted = true;
+            }
+        }
+        if (0 == __ballot(active)) break;
+        if (active) {
+            const float4   o = L.pool.ray_o[slot], d = L.pool.ray_d[slot];
+            const uint32_t meta = L.pool.q0.get(slot).y;
+            const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
+            Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+            Hit            hit;
+#if ZYG_FAST
+            sceneIntersectUniform<false, WIDE>(s, ray, depth, hit);
+#else
+            sceneIntersectUniform<true, false>(s, ray, depth, hit);
+#endif
+            if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+            const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<false, false, true>(L, s, slot, vertexPlane<false>(), depth, ray, none) : 0u;
+            L.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+            L.pool.hit_prop[slot] = hit.prop;
+            L.pool.ucount[slot] = ucount;
+            bool alive = false, defer = false;
+            shadeVertex<false, false, false, false>(L, slot, o, d, hit, ucount, alive, defer, none, tm);
+            if (defer) {  // emission to evaluate: the complete connectLight (wf_shade's second pass)
+                defer = false;
+                shadeVertex<false, false, true, false>(L, slot, o, d, hit, ucount, alive, defer, none, tm);
+            }
+            if (alive) {
+                ScatterOut out;
+                scatterVertex<false, SUBST, MULTI, false, false, false, true, WIDE>(L, s, slot, out, none, no_rays, tm);
+                alive = out.push;
+            }
+            active = alive;
+        }
+    }
 }
 
 }  // namespace zd

@@ -282,6 +282,43 @@ __global__ void __launch_bounds__(256) calib_gather(const char* data, uint32_t n
     if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u) sink[0] = i;  // never true for the zero-filled buffer: keeps the load alive
 }
 
+// Ray-level hooks for the tests (zygpu_test_intersect / zygpu_test_visibility): rays of 8 floats (o.xyz, min_t, d.xyz, max_t)
+// against the uploaded scene, in this unit's precise arithmetic.  mode 0: the reference's walk (top-level tree lane by lane,
+// BVH2); 1: the prop tables (sceneIntersectUniform) + BVH2; 2: the prop tables + the four-wide BLAS re-layout.
+__global__ void test_intersect(uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + size_t(i) * 8;
+    Ray          ray = Ray::init(mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]);
+    Hit          hit;
+    Counters     cnt{0, 0, 0};
+    bool         found;
+    if (0 == mode) found = sceneIntersect<false, true>(c_scene, ray, depth_surface, hit, cnt);
+    else if (1 == mode) found = sceneIntersectUniform<true, false>(c_scene, ray, depth_surface, hit);
+    else found = sceneIntersectUniform<true, true>(c_scene, ray, depth_surface, hit);
+    uint32_t* h = hits + size_t(i) * 8;
+    for (int k = 0; k < 8; ++k) h[k] = 0;
+    if (found) {
+        h[0] = __float_as_uint(hit.t);
+        h[1] = __float_as_uint(hit.u);
+        h[2] = __float_as_uint(hit.v);
+        h[3] = hit.primitive;
+    }
+    h[4] = hit.prop;
+}
+__global__ void test_visibility(uint32_t n, const float* rays, uint32_t mode, uint32_t* visible) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + size_t(i) * 8;
+    Ray          ray = Ray::init(mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]);
+    Counters     cnt{0, 0, 0};
+    visible[i] = (0 == mode   ? sceneVisibility<false, true>(c_scene, ray, cnt)
+                  : 1 == mode ? sceneVisibilityUniform<false>(c_scene, ray)
+                              : sceneVisibilityUniform<true>(c_scene, ray))
+                     ? 1u
+                     : 0u;
+}
+
 __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -458,6 +495,9 @@ struct ZygpuContext {
     // option "uniform_tlas" (default on): scenes whose props fit the tables of dscene.hpp TlasEntry run the kernels that
     // walk them wave-wide instead of the top-level trees lane by lane (not the counting / MESHL / POOL instantiations)
     bool          uniform_tlas = true, uniform_tables = false;
+    // option "persistent": the whole path in one kernel with its state in LDS (wavefront.hpp wf_persistent) where the scene
+    // allows it (the plain instantiations with the prop tables, in-place NEE, single-sample lights)
+    bool          persistent = false;
     bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
@@ -537,6 +577,13 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
 #endif
 #if !ZYG_POOL_STRIDE || defined(ZYG_ACC_SEPARATE)
     ok = ok && m.alloc(paths, &p.emission) && m.alloc(paths, &p.direct) && m.alloc(paths, &p.indirect);
+#endif
+#if ZYG_POOL_STRIDE
+    // the wavefront kernels index the records by path slot (wavefront.hpp Rec)
+    for (auto* r : {&p.q0.mask, &p.q1.mask, &p.pcg.mask, &p.ray_o.mask, &p.ray_d.mask, &p.thr.mask, &p.vorigin.mask, &p.vgeo_n.mask,
+                    &p.emission.mask, &p.direct.mask, &p.indirect.mask, &p.hit.mask, &p.hit_prop.mask, &p.hit_sr.mask, &p.ucount.mask,
+                    &p.rec_p.mask, &p.rec_gn.mask, &p.rec_n.mask, &p.rec_t.mask, &p.rec_b.mask})
+        *r = 0xFFFFFFFFu;
 #endif
     ok = ok && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) &&
          m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) &&
@@ -977,6 +1024,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemsetAsync(&c->ctl->error, 0, sizeof(uint32_t), c->stream));
     if (!setUnitConstants(ZYG_CONST_SCENE, &s, sizeof(DScene), c->stream)) return -1;
+    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_scene), &s, sizeof(DScene), 0, hipMemcpyHostToDevice, c->stream));  // this unit's: the test hooks
     HIP_OK(hipStreamSynchronize(c->stream));
     c->has_scene = true;
     return 0;
@@ -1150,6 +1198,14 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
         }
         c->camera_samples += num_paths;
+        if (c->persistent && utlas && nee && !c->multi_sample_lights && c->fuse_trace_shade) {
+            HIP_OK(hipMemsetAsync(&c->ctl->next_sample, 0, sizeof(unsigned long long), c->stream));
+            const unsigned blocks = std::min<unsigned>(unsigned(c->num_cus) * 4u, (num_paths + kPersistentThreads - 1u) / kPersistentThreads);  // 4 x 36 KB of LDS per CU
+            timedLaunch(c, 5, [&] {
+                launchKernel(c, c->has_substitute ? (wide ? K_PERSISTENT_SUBST_W : K_PERSISTENT_SUBST) : (wide ? K_PERSISTENT_LAMBERT_W : K_PERSISTENT_LAMBERT),
+                             blocks, P, num_paths);
+            });
+        } else
         for (uint32_t t = 0; t < ticks; ++t) {
             if (c->pool_mode) {
                 // one level of every sample's vertex pool: round k = vertex k of the level, in order (shared samplers)
@@ -1402,6 +1458,40 @@ int zygpu_test_eval(ZygpuContext* c, uint32_t op, uint32_t n, const float* in, u
     return 0;
 }
 
+int zygpu_test_intersect(ZygpuContext* c, uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits) {
+    if (!c || !c->has_scene || !rays || !hits || mode > 2 || (mode > 0 && !c->uniform_tables)) return -1;
+    HIP_OK(hipSetDevice(c->device));
+    float*    din = nullptr;
+    uint32_t* dout = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&din), size_t(n) * 32));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&dout), size_t(n) * 32));
+    HIP_OK(hipMemcpy(din, rays, size_t(n) * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(test_intersect, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, din, depth_surface, mode, dout);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(hits, dout, size_t(n) * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return 0;
+}
+
+int zygpu_test_visibility(ZygpuContext* c, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible) {
+    if (!c || !c->has_scene || !rays || !visible || mode > 2 || (mode > 0 && !c->uniform_tables)) return -1;
+    HIP_OK(hipSetDevice(c->device));
+    float*    din = nullptr;
+    uint32_t* dout = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&din), size_t(n) * 32));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&dout), size_t(n) * 4));
+    HIP_OK(hipMemcpy(din, rays, size_t(n) * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(test_visibility, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, din, mode, dout);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(visible, dout, size_t(n) * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return 0;
+}
+
 int zygpu_calibrate_gather(ZygpuContext* c, uint32_t stride_bytes, uint32_t num_records, uint32_t repeats, double* out_ms_per_launch) {
     if (!c || !out_ms_per_launch || 0 == num_records || 0 == repeats) return -1;
     HIP_OK(hipSetDevice(c->device));
@@ -1473,6 +1563,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
             return -1;
         }
         c->relaxed = 1 == mode;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "persistent")) {
+        c->persistent = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "uniform_tlas")) {
