@@ -42,14 +42,18 @@ def _worker(rank, world, port, mode, out_path):
     with zyg_amd.Engine() as e:
         scenes.cornell(e, w, h, world * k)
         sd, vd = e.compile()
-        if mode == "iterations":
-            first, count = distributed.iteration_shard(rank, world, k)
-            film = oracle_render(oracle, sd, vd, count, threads=2, iteration0=first)
-        else:
-            y0, y1 = distributed.row_shard(rank, world, h)
-            film = oracle_render(oracle, sd, vd, world * k, threads=2, y_range=(y0, y1))
+        # the same ShardedFrame bench.py drives the device with; here the oracle renders the shard
+        frame = distributed.ShardedFrame(rank, world, dist, mode, h)
+        film = np.zeros((h, w, 4), dtype=np.float32)
+
+        def render(first, count, y0, y1):
+            film[...] += oracle_render(oracle, sd, vd, count, threads=2, iteration0=first, y_range=(y0, y1))
+
+        steps, ips = (1, k) if mode == "iterations" else (1, world * k)  # rows: every rank renders all world * k iterations
+        for s in range(steps):
+            frame.render_step(render, s, ips, steps)
         t = torch.from_numpy(film)
-        distributed.reduce_film(t, dist, dst=0)
+        frame.reduce(t)
         if rank == 0:
             full = oracle_render(oracle, sd, vd, world * k, threads=2)
             np.savez(out_path, reduced=t.numpy(), full=full)
@@ -77,3 +81,57 @@ def test_shard_helpers():
     from zyg_amd import distributed
     assert [distributed.row_shard(r, 3, 10) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
     assert [distributed.iteration_shard(r, 4, 16) for r in range(4)] == [(0, 16), (16, 16), (32, 16), (48, 16)]
+
+
+def _gpu_worker(rank, world, port, mode, out_path):
+    """one rank of a two-process run on the one GPU: its shard through the HIP path (zygpu_render), films summed over gloo"""
+    sys.path.insert(0, ROOT)
+    import torch
+
+    import zyg_amd
+    from zyg_amd import distributed, scenes
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist = distributed.init_process_group("gloo", rank, world)
+    w, h, steps, ips = 160, 90, 2, 2
+    total = world * steps * ips if mode == "iterations" else steps * ips
+    with zyg_amd.Engine() as e:
+        scenes.cornell(e, w, h, total)
+        e.start_frame(0)
+        e.set_option("precise", 1)
+        frame = distributed.ShardedFrame(rank, world, dist, mode, h)
+
+        def render(first, count, y0, y1):
+            assert e.lib.zygpu_render(e.context(), 0, first, count, y0, y1) == 0, e.lib.zygpu_last_error()
+
+        elapsed = frame.timed(lambda: [frame.render_step(render, s, ips, steps) for s in range(steps)] and e.synchronize(), e.synchronize)
+        assert elapsed > 0.0
+        film = torch.from_numpy(e.download_film(w, h))
+        frame.reduce(film)
+        if 0 == rank:
+            e.start_frame(0)
+            e.set_option("precise", 1)
+            e.render_iterations(total)
+            e.synchronize()
+            np.savez(out_path, reduced=film.numpy(), full=e.download_film(w, h))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["iterations", "rows"])
+def test_two_processes_on_one_gpu_shard_the_frame(tmp_path, mode):
+    """The N > 1 path with the device in it: two fresh processes (children, no re-exec of a process that touched the GPU),
+    each with its own engine and HIP context on the one GPU, shard the frame with zyg_amd.distributed.ShardedFrame exactly as
+    bench.py does and sum their films over gloo; rank 0 compares with its own single-process render."""
+    import torch.multiprocessing as mp
+    __import__("conftest")._build_product()
+    out = str(tmp_path / "films.npz")
+    mp.spawn(_gpu_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    d = np.load(out)
+    assert np.array_equal(d["reduced"][..., 3], d["full"][..., 3])
+    if mode == "rows":
+        assert np.array_equal(d["reduced"], d["full"])  # disjoint pixels: exact
+    else:
+        np.testing.assert_allclose(d["reduced"][..., :3], d["full"][..., :3], rtol=1e-6, atol=1e-7)  # float association only
