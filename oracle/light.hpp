@@ -766,6 +766,94 @@ inline float rectangleMaterialPdf(const ZygpuImageLight& il, V4 dir, V4 p, const
     return (material_pdf * sl) / (c * area);
 }
 
+// Disk.sampleMaterialTo (disk.zig:361-426) / materialPdf (535-553): area sampling by the emission map over the unit square
+// around the disc (uvWeight leaves the corners empty, disk.zig:428-436)
+inline uint32_t diskSampleMaterialTo(const ZygpuImageLight& il, V4 p, V4 n, const Trafo& trafo, bool two_sided, bool total_sphere,
+                                     float split_threshold, uint32_t light_samples, Sampler& sampler, SampleTo* buffer) {
+    const uint32_t num_samples = numSamples(light_samples, split_threshold);
+    const float    nsf = float(num_samples);
+    const float    radius = 0.5f * trafo.scaleX();
+    const float    area = kPi * (radius * radius);
+    uint32_t       current = 0;
+    for (uint32_t i = 0; i < num_samples; ++i) {
+        float r2[2];
+        sampler.sample2D(r2);
+        float       u, v;
+        const float pdf = imageLightSample(il, r2[0], r2[1], u, v);
+        if (0.f == pdf) continue;
+        const V4    ls = mk(-2.f * u + 1.f, -2.f * v + 1.f, 0.f, 0.f);
+        const V4    k = S(radius) * trafo.objectToWorldNormal(ls);
+        const float l = dot3(k, k);
+        if (l > radius * radius) continue;
+        const V4 ws = trafo.position + k;
+        V4       wn = trafo.r[2];
+        if (two_sided && dot3(wn, ws - p) > 0.f) wn = -wn;
+        const V4    axis = ws - p;
+        const float sl = squaredLength3(axis);
+        const float t = std::sqrt(sl);
+        const V4    dir = axis / S(t);
+        const float c = -dot3(wn, dir);
+        if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) continue;
+        buffer[current].p = mk(ws[0], ws[1], ws[2], (nsf * pdf * sl) / (c * area));
+        buffer[current].n = wn;
+        buffer[current].wi = dir;
+        buffer[current].uvw = mk(u, v, 0.f, 0.f);
+        current += 1;
+    }
+    return current;
+}
+inline float diskMaterialPdf(const ZygpuImageLight& il, V4 dir, V4 p, const Trafo& trafo, V4 frag_p, float u, float v, float split_threshold,
+                             uint32_t light_samples) {
+    const float    c = std::fabs(dot3(trafo.r[2], dir));
+    const float    radius = 0.5f * trafo.scaleX();
+    const float    area = kPi * (radius * radius);
+    const V4       dp = p - frag_p;
+    const float    sl = dot3(dp, dp);
+    const uint32_t num_samples = numSamples(light_samples, split_threshold);
+    const float    material_pdf = imageLightPdf(il, u, v) * float(num_samples);
+    return (material_pdf * sl) / (c * area);
+}
+
+// Sphere.sampleMaterialTo (sphere.zig:395-446) / materialPdf (489-502): one sample of the lat-long emission map
+inline uint32_t sphereSampleMaterialTo(const ZygpuImageLight& il, V4 p, V4 n, const Trafo& trafo, bool total_sphere, Sampler& sampler,
+                                       SampleTo* buffer) {
+    float r2[2];
+    sampler.sample2D(r2);
+    float       u, v;
+    const float pdf = imageLightSample(il, r2[0], r2[1], u, v);
+    if (0.f == pdf) return 0;
+    const float phi = (u + 0.75f) * (2.f * kPi);
+    const float theta = v * kPi;
+    const float sin_theta = mx(sinF(theta), 0.00001f);  // avoid singularity at poles
+    const float cos_theta = cosF(theta);
+    const float sin_phi = sinF(phi), cos_phi = cosF(phi);
+    const float r = 0.5f * trafo.scaleX();
+    const V4    ls = S(r) * mk(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi, 0.f);
+    const V4    ws = trafo.objectToWorldPoint(ls);
+    const V4    axis = ws - p;
+    const float sl = squaredLength3(axis);
+    const float t = std::sqrt(sl);
+    const V4    dir = axis / S(t);
+    const V4    wn = normalize3(ws - trafo.position);
+    const float c = -dot3(wn, dir);
+    if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) return 0;
+    const float area = (4.f * kPi) * (r * r);
+    buffer[0].p = mk(ws[0], ws[1], ws[2], (pdf * sl) / (c * area * sin_theta));
+    buffer[0].n = wn;
+    buffer[0].wi = dir;
+    buffer[0].uvw = mk(u, v, 0.f, 0.f);
+    return 1;
+}
+inline float sphereMaterialPdf(const ZygpuImageLight& il, V4 dir, V4 p, const Trafo& trafo, V4 frag_p, V4 frag_geo_n, float u, float v) {
+    const float sin_theta = mx(sinF(v * kPi), 0.00001f);
+    const V4    dp = p - frag_p;
+    const float sl = dot3(dp, dp);
+    const float c = -dot3(frag_geo_n, dir);
+    const float r = 0.5f * trafo.scaleX();
+    const float area = (4.f * kPi) * (r * r);
+    return (imageLightPdf(il, u, v) * sl) / (c * area * sin_theta);
+}
+
 // ---------- Distant lights: distant.zig:21-146 ----------
 
 inline float distantSolidAngle(float radius) { return (2.f * kPi) * (1.f - std::sqrt(1.f / (radius * radius + 1.f))); }

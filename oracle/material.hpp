@@ -478,6 +478,25 @@ struct MaterialSample {
         }
         const float ep = luts.ilmEpDielectric(n_dot_wo, a, glass_f0);
         const float r_wo_dot_h = same_side ? -wo_dot_h : wo_dot_h;
+        // roughRefract (glass_sample.zig:437-503): the thick branch refracts through the micro-facet; the thin branch
+        // (a slab without volume) reflects about the facet re-expressed in a frame around -wo, i.e. scatters the straight-through
+        // direction by the roughness, attenuates over the slab and calls the event .straight; < 0: no sample
+        auto roughRefract = [&](BxdfSample& result) {
+            if (thickness > 0.f) {
+                const Frame thin_frame = Frame::init(-wo);
+                const V4    tangent_h = fr.worldToFrame(h);
+                const V4    thin_h = thin_frame.frameToWorld(tangent_h);
+                const float thin_n_dot_wo = tangent_h[2], thin_n_dot_h = saturate(tangent_h[2]), thin_wo_dot_h = 1.f;
+                const float n_dot_wi = ggx::reflectNoFresnel(thin_h, thin_h, thin_n_dot_wo, thin_n_dot_h, thin_wo_dot_h, a,
+                                                             specular_threshold, thin_frame, result);
+                if (sameHemisphere(result.wi)) return -1.f;
+                const float approx_dist = thickness / n_dot_wo;
+                result.reflection *= attenuation3(absorption, approx_dist);
+                result.path = PathInfo::straight();
+                return n_dot_wi;
+            }
+            return ggx::refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, result);
+        };
         if (split) {
             {
                 const float n_dot_wi = ggx::reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, out[0]);
@@ -486,8 +505,8 @@ struct MaterialSample {
                 out[0].wavelength = 0.f;
             }
             if (1.f == f) return 1;
-            const float n_dot_wi =
-                ggx::refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, out[1]);
+            const float n_dot_wi = roughRefract(out[1]);
+            if (n_dot_wi < 0.f) return 1;
             out[1].reflection *= S(n_dot_wi * ep) * S(1.f);
             out[1].split_weight = 1.f - f;
             out[1].wavelength = 0.f;
@@ -499,8 +518,8 @@ struct MaterialSample {
             out[0].reflection *= S(f * n_dot_wi * ep * s) * S(1.f);
             out[0].pdf *= f;
         } else {
-            const float n_dot_wi =
-                ggx::refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, out[0]);
+            const float n_dot_wi = roughRefract(out[0]);
+            if (n_dot_wi < 0.f) return 0;
             const float omf = 1.f - f;
             out[0].reflection *= S(omf * n_dot_wi * ep) * S(1.f);
             out[0].pdf *= omf;

@@ -111,6 +111,24 @@ inline float cosdf(double x) {  // musl __cosdf
     return float(((1.0 + z * C0) + w * C1) + (w * z) * r);
 }
 constexpr double kPio2 = 1.57079632679489661923;
+// musl __rem_pio2f, medium size (|x| < 2^28 * pi/2): x = n * pi/2 + y, |y| <= pi/4, in double precision
+inline int remPio2f(float x, double& y) {
+    const double toint = 1.5 / 2.220446049250313e-16, pio4 = 0x1.921fb6p-1, invpio2 = 6.36619772367581382433e-01,
+                 pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08;
+    double  fn = double(x) * invpio2 + toint - toint;
+    int32_t n = int32_t(fn);
+    y = x - fn * pio2_1 - fn * pio2_1t;
+    if (y < -pio4) {
+        n--;
+        fn--;
+        y = x - fn * pio2_1 - fn * pio2_1t;
+    } else if (y > pio4) {
+        n++;
+        fn++;
+        y = x - fn * pio2_1 - fn * pio2_1t;
+    }
+    return n;
+}
 }  // namespace m32
 
 inline float sinF(float x) {
@@ -126,6 +144,16 @@ inline float sinF(float x) {
         if (ix <= 0x40afeddfu) return sign ? m32::cosdf(xd + 3 * m32::kPio2) : -m32::cosdf(xd - 3 * m32::kPio2);
         return m32::sindf(sign ? xd + 4 * m32::kPio2 : xd - 4 * m32::kPio2);
     }
+    if (ix < 0x4dc90fdbu) {  // sinf.c's general case with __rem_pio2f's medium-size reduction
+        double    y;
+        const int n = m32::remPio2f(x, y);
+        switch (n & 3) {
+            case 0: return m32::sindf(y);
+            case 1: return m32::cosdf(y);
+            case 2: return m32::sindf(-y);
+            default: return -m32::cosdf(y);
+        }
+    }
     return std::sin(x);
 }
 inline float cosF(float x) {
@@ -140,6 +168,16 @@ inline float cosF(float x) {
     if (ix <= 0x40e231d5u) {
         if (ix > 0x40afeddfu) return m32::cosdf(sign ? xd + 4 * m32::kPio2 : xd - 4 * m32::kPio2);
         return sign ? m32::sindf(-xd - 3 * m32::kPio2) : m32::sindf(xd - 3 * m32::kPio2);
+    }
+    if (ix < 0x4dc90fdbu) {  // cosf.c's general case
+        double    y;
+        const int n = m32::remPio2f(x, y);
+        switch (n & 3) {
+            case 0: return m32::cosdf(y);
+            case 1: return m32::sindf(-y);
+            case 2: return -m32::cosdf(y);
+            default: return m32::sindf(y);
+        }
     }
     return std::cos(x);
 }
@@ -306,6 +344,12 @@ inline float    clampAbsDot(V4 a, V4 b) { return clampf(std::fabs(dot3(a, b)), k
 
 struct Frame {  // frame.zig:5-69
     V4 x, y, z;
+    static Frame init(V4 n) {  // frame.zig:10-13 -> orthonormalBasis3 (vector4.zig:98-110)
+        const float sign = std::copysign(1.f, n[2]);
+        const float c = -1.f / (sign + n[2]);
+        const float d = n[0] * n[1] * c;
+        return {mk(1.f + sign * n[0] * n[0] * c, sign * d, -sign * n[0]), mk(d, sign + n[1] * n[1] * c, -n[1]), n};
+    }
     V4 frameToWorld(V4 v) const {
         V4 r = S(v[0]) * x;
         r = fma4(S(v[1]), y, r);

@@ -354,6 +354,11 @@ GLASS_BOX = scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3)
     ("PTDL", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01)}),
     ("PTMIS", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01)}),
     ("PTMIS", {"sphere": scenes.glass(1.5, thickness=0.01), "inner": scenes.glass(1.4, (0.5, 0.7, 0.95), 0.1), "outside": scenes.glass(1.5, (0.7, 0.8, 0.9), 0.5, thickness=0.05)}),
+    # rough thin glass: roughRefract's thin branch (glass_sample.zig:437-478): frosted panes
+    ("PT", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02, roughness=0.3), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01, roughness=0.1)}),
+    ("PTDL", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02, roughness=0.3), "sphere": scenes.glass(1.5, thickness=0.01, roughness=0.15)}),
+    ("PTMIS", {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3, thickness=0.02, roughness=0.3), "sphere": scenes.glass(1.5, (0.9, 0.7, 0.6), 0.1, thickness=0.01, roughness=0.1)}),
+    ("PTMIS", {"sphere": scenes.glass(1.5, thickness=0.01, roughness=0.01), "outside": scenes.glass(1.5, (0.7, 0.8, 0.9), 0.5, thickness=0.05, roughness=0.4)}),
 ])
 def test_glass(engine, oracle, integrator, objects):
     """Thick specular Glass (glass_sample.zig:165-254): Fresnel reflection / refraction, the medium stack with nested
@@ -471,6 +476,20 @@ def test_textured_rectangle_lights(engine, oracle, integrator, unoccluding, samp
     out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, unoccluding_lights=unoccluding, light_samples=samples,
                        light_map=scenes.checker_image(8, np.float32), material="substitute")
     _check(*out, 3)
+
+
+@pytest.mark.parametrize("integrator,shape,unoccluding,samples", [("PT", "sphere", True, 1), ("PTDL", "disk", False, 1), ("PTMIS", "sphere", False, 1),
+                                                                 ("PTMIS", "disk", True, 1), ("PTMIS", "disk", False, 3), ("PTDL", "sphere", True, 1)])
+def test_textured_sphere_and_disk_lights(engine, oracle, integrator, shape, unoccluding, samples):
+    """Sphere and Disk lights with an emission map: Sphere.sampleMaterialTo / materialPdf (sphere.zig:395-446, 489-502: one
+    sample of the lat-long map; its longitudes reach 3.5 pi, beyond the quick paths of sin / cos) and Disk.sampleMaterialTo /
+    materialPdf (disk.zig:361-426, 535-553: the map over the square around the disc, corners weightless)."""
+    kw = {"sphere_lights": True} if shape == "sphere" else {"disk_lights": True, "two_sided_lights": samples > 1}
+    out = _render_both(engine, oracle, 80, 60, 3, integrator=integrator, unoccluding_lights=unoccluding, light_samples=samples,
+                       light_map=scenes.checker_image(8, np.float32), material="substitute", **kw)
+    _check(*out, 3)
+    sd = engine.lib.su_ext_scene_desc().contents
+    assert sd.num_image_lights == 2 and all(sd.lights[i].light_class == 2 for i in range(sd.num_lights))  # ZYGPU_LIGHT_PROP_IMAGE
 
 
 @pytest.mark.parametrize("integrator,dtype,sampler,extras", [

@@ -842,6 +842,83 @@ ZD float rectangleMaterialPdf(const DImageLight& il, f3 dir, f3 p, const Trafo& 
     return (material_pdf * sl) / (c * area);
 }
 
+// one sample of Disk.sampleMaterialTo (disk.zig:361-426) from its 2-D draw; materialPdf (535-553)
+ZD bool diskSampleMaterial(const DImageLight& il, float r0, float r1, float nsf, f3 p, f3 n, const Trafo& trafo, bool two_sided,
+                           bool total_sphere, SampleTo& out) {
+    float       u, v;
+    const float pdf = imageLightSample(il, r0, r1, u, v);
+    if (0.f == pdf) return false;
+    const float radius = 0.5f * trafo.scale.x;
+    const float area = kPi * (radius * radius);
+    const f3    k = S3(radius) * trafo.objectToWorldNormal(mk3(-2.f * u + 1.f, -2.f * v + 1.f, 0.f));
+    const float l = dot3(k, k);
+    if (l > radius * radius) return false;
+    const f3 ws = trafo.position + k;
+    f3       wn = trafo.r2;
+    if (two_sided && dot3(wn, ws - p) > 0.f) wn = -wn;
+    const f3    axis = ws - p;
+    const float sl = squaredLength3(axis);
+    const float t = sqrtf(sl);
+    const f3    dir = axis / S3(t);
+    const float c = -dot3(wn, dir);
+    if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) return false;
+    out.p = ws;
+    out.n = wn;
+    out.wi = dir;
+    out.pdf = (nsf * pdf * sl) / (c * area);
+    out.u = u;
+    out.v = v;
+    return true;
+}
+ZD float diskMaterialPdf(const DImageLight& il, f3 dir, f3 p, const Trafo& trafo, f3 frag_p, float u, float v, uint32_t num_samples) {
+    const float c = fabsf(dot3(trafo.r2, dir));
+    const float radius = 0.5f * trafo.scale.x;
+    const float area = kPi * (radius * radius);
+    const f3    dp = p - frag_p;
+    const float sl = dot3(dp, dp);
+    const float material_pdf = imageLightPdf(il, u, v) * float(num_samples);
+    return (material_pdf * sl) / (c * area);
+}
+// Sphere.sampleMaterialTo (sphere.zig:395-446): one sample of the lat-long emission map; materialPdf (489-502)
+ZD bool sphereSampleMaterialTo(const DImageLight& il, f3 p, f3 n, const Trafo& trafo, bool total_sphere, Sampler& sampler, SampleTo& out) {
+    float r0, r1;
+    sampler.sample2D(r0, r1);
+    float       u, v;
+    const float pdf = imageLightSample(il, r0, r1, u, v);
+    if (0.f == pdf) return false;
+    const float phi = (u + 0.75f) * (2.f * kPi);
+    const float theta = v * kPi;
+    const float sin_theta = mx(sinF(theta), 0.00001f);  // avoid singularity at poles
+    const float cos_theta = cosF(theta);
+    const float sin_phi = sinF(phi), cos_phi = cosF(phi);
+    const float r = 0.5f * trafo.scale.x;
+    const f3    ws = trafo.objectToWorldPoint(S3(r) * mk3(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi));
+    const f3    axis = ws - p;
+    const float sl = squaredLength3(axis);
+    const float t = sqrtf(sl);
+    const f3    dir = axis / S3(t);
+    const f3    wn = normalize3(ws - trafo.position);
+    const float c = -dot3(wn, dir);
+    if (c < kDotMin || (dot3(dir, n) <= 0.f && !total_sphere)) return false;
+    const float area = (4.f * kPi) * (r * r);
+    out.p = ws;
+    out.n = wn;
+    out.wi = dir;
+    out.pdf = (pdf * sl) / (c * area * sin_theta);
+    out.u = u;
+    out.v = v;
+    return true;
+}
+ZD float sphereMaterialPdf(const DImageLight& il, f3 dir, f3 p, const Trafo& trafo, f3 frag_p, f3 frag_geo_n, float u, float v) {
+    const float sin_theta = mx(sinF(v * kPi), 0.00001f);
+    const f3    dp = p - frag_p;
+    const float sl = dot3(dp, dp);
+    const float c = -dot3(frag_geo_n, dir);
+    const float r = 0.5f * trafo.scale.x;
+    const float area = (4.f * kPi) * (r * r);
+    return (imageLightPdf(il, u, v) * sl) / (c * area * sin_theta);
+}
+
 // ---------------------------------------------------------------- TriangleMesh lights (triangle_mesh.zig:391-703)
 
 ZD f3 orthogonalize(f3 a, f3 b) { return normalize3(fma3(S3(-dot3(a, b)), a, b)); }  // a is normalised (391-394)

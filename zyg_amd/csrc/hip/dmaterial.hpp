@@ -340,12 +340,32 @@ struct MaterialSample {
         }
         const float ep = L.ilmEpDielectric(n_dot_wo, a, glass_f0);
         const float r_wo_dot_h = same_side ? -wo_dot_h : wo_dot_h;
+        // roughRefract (glass_sample.zig:437-503): thick = refraction through the micro-facet; thin (a slab without volume) =
+        // the straight-through direction scattered by the roughness (a reflection about the facet re-expressed in a frame around
+        // -wo), attenuated over the slab, event .straight; < 0: no sample
+        auto roughRefract = [&](BxdfSample& result) {
+            if (thickness > 0.f) {
+                const Frame thin_frame = Frame::init(-wo);
+                const f3    tangent_h = fr.worldToFrame(h);
+                const f3    thin_h = thin_frame.frameToWorld(tangent_h);
+                const float n_dot_wi = reflectNoFresnel(thin_h, thin_h, tangent_h.z, saturate(tangent_h.z), 1.f, a, specular_threshold, thin_frame, result);
+                if (sameHemisphere(result.wi)) return -1.f;
+                result.reflection = result.reflection * attenuation3(absorption, thickness / n_dot_wo);
+                result.reg_alpha = 1.f;  // bxdf.Path.straight (bxdf.zig:34-70): no scattering class, the vertex state stays
+                result.scattering = kScatterNone;
+                result.transmission = false;
+                result.straight = true;
+                return n_dot_wi;
+            }
+            return refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, result);
+        };
         if (split) {
             const float n_dot_wi = reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, r0);
             r0.reflection = r0.reflection * (S3(n_dot_wi * ep * specular) * S3(1.f));
             r0.split_weight = f;
             if (1.f == f) return 1;
-            const float n_dot_wt = refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, r1);
+            const float n_dot_wt = roughRefract(r1);
+            if (n_dot_wt < 0.f) return 1;
             r1.reflection = r1.reflection * (S3(n_dot_wt * ep) * S3(1.f));
             r1.split_weight = 1.f - f;
             return 2;
@@ -355,7 +375,8 @@ struct MaterialSample {
             r0.reflection = r0.reflection * (S3(f * n_dot_wi * ep * specular) * S3(1.f));
             r0.pdf *= f;
         } else {
-            const float n_dot_wt = refractNoFresnel(wo, h, n_dot_wo, n_dot_h, -wi_dot_h, r_wo_dot_h, a, specular_threshold, eta_i, eta_t, fr, r0);
+            const float n_dot_wt = roughRefract(r0);
+            if (n_dot_wt < 0.f) return 0;
             const float omf = 1.f - f;
             r0.reflection = r0.reflection * (S3(omf * n_dot_wt * ep) * S3(1.f));
             r0.pdf *= omf;

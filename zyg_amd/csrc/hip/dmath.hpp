@@ -82,7 +82,7 @@ ZD float acosR(float z) {  // only the unit-test hook calls it directly
 #else
 // sin / cos / acos with the reference's algorithms (Zig std.math.acos = msun e_acosf.c; compiler-rt sinf/cosf =
 // musl sinf.c/cosf.c with the double-precision k_sinf/k_cosf kernels) so that device results are reproducible
-// bit for bit on the host.  |x| <= 9*pi/4 is the range the integration loop produces; beyond it OCML is used.
+// bit for bit on the host.  Beyond 9*pi/4 musl's general case with the medium-size argument reduction (up to 2^28 * pi/2).
 ZD float sindf(double x) {
     const double S1 = -0x1.5555554cbac77p-3, S2 = 0x1.11110896efbb2p-7, S3 = -0x1.a00f9e2cae774p-13, S4 = 0x1.6cd878c3b46a7p-19;
     const double z = x * x, w = z * z, r = S3 + z * S4, s = z * x;
@@ -94,6 +94,24 @@ ZD float cosdf(double x) {
     return float(((1.0 + z * C0) + w * C1) + (w * z) * r);
 }
 constexpr double kPio2d = 1.57079632679489661923;
+// musl __rem_pio2f, medium size (|x| < 2^28 * pi/2): x = n * pi/2 + y, |y| <= pi/4, in double precision
+ZD int remPio2f(float x, double& y) {
+    const double toint = 1.5 / 2.220446049250313e-16, pio4 = 0x1.921fb6p-1, invpio2 = 6.36619772367581382433e-01,
+                 pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08;
+    double  fn = double(x) * invpio2 + toint - toint;
+    int32_t n = int32_t(fn);
+    y = x - fn * pio2_1 - fn * pio2_1t;
+    if (y < -pio4) {
+        n--;
+        fn--;
+        y = x - fn * pio2_1 - fn * pio2_1t;
+    } else if (y > pio4) {
+        n++;
+        fn++;
+        y = x - fn * pio2_1 - fn * pio2_1t;
+    }
+    return n;
+}
 ZD float sinF(float x) {
     const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
     const bool     sign = 0 != (hx >> 31);
@@ -106,6 +124,16 @@ ZD float sinF(float x) {
     if (ix <= 0x40e231d5u) {
         if (ix <= 0x40afeddfu) return sign ? cosdf(xd + 3 * kPio2d) : -cosdf(xd - 3 * kPio2d);
         return sindf(sign ? xd + 4 * kPio2d : xd - 4 * kPio2d);
+    }
+    if (ix < 0x4dc90fdbu) {  // sinf.c's general case with __rem_pio2f's medium-size reduction
+        double    y;
+        const int n = remPio2f(x, y);
+        switch (n & 3) {
+            case 0: return sindf(y);
+            case 1: return cosdf(y);
+            case 2: return sindf(-y);
+            default: return -cosdf(y);
+        }
     }
     return sinf(x);
 }
@@ -121,6 +149,16 @@ ZD float cosF(float x) {
     if (ix <= 0x40e231d5u) {
         if (ix > 0x40afeddfu) return cosdf(sign ? xd + 4 * kPio2d : xd - 4 * kPio2d);
         return sign ? sindf(-xd - 3 * kPio2d) : sindf(xd - 3 * kPio2d);
+    }
+    if (ix < 0x4dc90fdbu) {  // cosf.c's general case
+        double    y;
+        const int n = remPio2f(x, y);
+        switch (n & 3) {
+            case 0: return cosdf(y);
+            case 1: return sindf(-y);
+            case 2: return -cosdf(y);
+            default: return sindf(y);
+        }
     }
     return cosf(x);
 }

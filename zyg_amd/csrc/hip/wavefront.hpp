@@ -899,6 +899,11 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
                      : ZYGPU_SHAPE_RECTANGLE == image_shape  // rectangle.zig:577-595
                          ? rectangleMaterialPdf(il, ray_direction, v.vorigin, frag.trafo, frag.p, frag.uv0, frag.uv1,
                                                 numSamples(light.num_samples, v.light_split_threshold))
+                     : ZYGPU_SHAPE_DISK == image_shape  // disk.zig:535-553
+                         ? diskMaterialPdf(il, ray_direction, v.vorigin, frag.trafo, frag.p, frag.uv0, frag.uv1,
+                                           numSamples(light.num_samples, v.light_split_threshold))
+                     : ZYGPU_SHAPE_SPHERE == image_shape  // sphere.zig:489-502
+                         ? sphereMaterialPdf(il, ray_direction, v.vorigin, frag.trafo, frag.p, frag.geo_n, frag.uv0, frag.uv1)
                          : imageLightPdf(il, frag.uv0, frag.uv1) / (2.f * kPi);
     } else if (MESHL && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
         sample_pdf = meshLightPdf(s, s.mesh_lights[light.sampler], ray_direction, v.vorigin, v.vgeo_n, frag.trafo, frag.p, frag.geo_n,
@@ -1698,7 +1703,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
                 // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
                 const DImageLight& il = s.image_lights[light.sampler];
-                if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape) {
+                if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape || ZYGPU_SHAPE_DISK == light_shape) {
                     const uint32_t n = numSamples(light.num_samples, sample_threshold);
                     Sampler        replay = h.smp;
                     for (uint32_t j = 0; j < n; ++j) {
@@ -1711,10 +1716,15 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                         SampleTo   ls;
                         const bool got = ZYGPU_SHAPE_DOME == light_shape
                                              ? domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)
+                                         : ZYGPU_SHAPE_DISK == light_shape
+                                             ? diskSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)
                                              : rectangleSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided,
                                                                        ms.translucent, ls);
                         if (got) connect(ls);
                     }
+                } else if (ZYGPU_SHAPE_SPHERE == light_shape) {
+                    SampleTo ls;
+                    if (sphereSampleMaterialTo(il, sf.p, ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
                 } else {
                     SampleTo ls;
                     if (canopySampleMaterialTo(il, ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);

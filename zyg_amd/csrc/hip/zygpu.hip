@@ -771,9 +771,10 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         // the same kernel instantiations carry the infinite and Sphere light code
         if (is_infinite || ZYGPU_SHAPE_SPHERE == lp.shape || ZYGPU_SHAPE_DISK == lp.shape) c->mesh_lights = true;
         if (ZYGPU_LIGHT_PROP_IMAGE == d->lights[l].light_class) {
-            if ((ZYGPU_SHAPE_DOME != lp.shape && ZYGPU_SHAPE_CANOPY != lp.shape && ZYGPU_SHAPE_RECTANGLE != lp.shape) ||
+            if ((ZYGPU_SHAPE_DOME != lp.shape && ZYGPU_SHAPE_CANOPY != lp.shape && ZYGPU_SHAPE_RECTANGLE != lp.shape &&
+                 ZYGPU_SHAPE_DISK != lp.shape && ZYGPU_SHAPE_SPHERE != lp.shape) ||
                 d->lights[l].sampler >= d->num_image_lights) {
-                g_error = "image lights (emission maps) are supported on Dome, Canopy and Rectangle, with their ZygpuImageLight";
+                g_error = "image lights (emission maps) are supported on Dome, Canopy, Rectangle, Disk and Sphere, with their ZygpuImageLight";
                 return -2;
             }
             c->mesh_lights = true;  // the sampling code lives in the MESHL instantiations
@@ -830,8 +831,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t pi = 0; pi < d->num_parts; ++pi) {
         const ZygpuMaterial& gm = d->materials[d->material_ids[pi]];
         if (ZYGPU_MAT_GLASS != gm.kind) continue;
-        if ((gm.thickness > 0.f && gm.roughness > 0.f) || gm.abbe > 0.f) {
-            g_error = "Glass: rough thin glass and dispersion (abbe) are not supported";
+        if (gm.abbe > 0.f) {
+            g_error = "Glass: dispersion (abbe) is not supported";
             return -2;
         }
         if (gm.roughness > 0.f && !d->luts.e_s) {

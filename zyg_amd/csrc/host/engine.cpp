@@ -952,7 +952,7 @@ uint32_t Engine::prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m) 
     };
     auto uvWeight = [&](float u, float v) {  // shape.zig:535-542
         if (ZYGPU_SHAPE_DOME == shape_kind) return std::sin(v * float(M_PI));
-        if (ZYGPU_SHAPE_CANOPY == shape_kind) {
+        if (ZYGPU_SHAPE_CANOPY == shape_kind || ZYGPU_SHAPE_DISK == shape_kind) {  // canopy.zig uvWeight; disk.zig:428-436
             const float dx = 2.f * u - 1.f, dy = 2.f * v - 1.f;
             return dx * dx + dy * dy > 1.f ? 0.f : 1.f;
         }
@@ -1202,7 +1202,7 @@ int Engine::compile(uint32_t frame) {
         l.light_class = ZYGPU_LIGHT_PROP;
         if (image_light) {
             if (m.emission_image >= images_.size()) return -4;
-            if (!is_dome && !is_canopy && ZYGPU_SHAPE_RECTANGLE != s.kind) return -3;  // Disk / Sphere.sampleMaterialTo: not restated
+            if (is_mesh || is_distant) return -3;  // Shape.sampleMaterialTo has no case for them (shape.zig:348-371)
             l.sampler = prepareImageLight(s.kind, m);
             l.light_class = ZYGPU_LIGHT_PROP_IMAGE;
         }
@@ -1311,9 +1311,9 @@ int Engine::compile(uint32_t frame) {
         if (ZYGPU_NULL != m.emission_image && m.emission_image < images_.size() && 3 != channels(m.emission_image)) return -4;
         if (ZYGPU_NULL != m.mask_image && (m.mask_image >= images_.size() || 1 != channels(m.mask_image))) return -4;  // image2D_1 reads one channel
     }
-    for (uint32_t mid : material_ids_) {  // rough thin / dispersive glass in use: not restated (glass_sample.zig:148-163, 437-503)
+    for (uint32_t mid : material_ids_) {  // dispersive glass in use: not restated (glass_sample.zig:148-163: needs the Rainbow spectrum)
         const ZygpuMaterial& m = materials_[mid];
-        if (ZYGPU_MAT_GLASS == m.kind && ((m.thickness > 0.f && m.roughness > 0.f) || m.abbe > 0.f)) return -5;
+        if (ZYGPU_MAT_GLASS == m.kind && m.abbe > 0.f) return -5;
     }
     for (const ZygpuMaterial& m : materials_) {
         if (ZYGPU_MAT_SUBSTITUTE != m.kind && !(ZYGPU_MAT_GLASS == m.kind && m.roughness > 0.f)) continue;

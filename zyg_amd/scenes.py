@@ -279,8 +279,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     red = engine.material(mk(RED))
     green = engine.material(mk(GREEN))
     # light_map: a numpy image -> the quad lights are textured (emission map x spectrum) and importance-sampled by it
-    lamp = engine.material(light_material(spectrum=light_spectrum, num_samples=light_samples,
-                                          emission_map=None if light_map is None else engine.image(light_map)))
+    light_map_id = None if light_map is None else engine.image(light_map)
+    lamp = engine.material(light_material(spectrum=light_spectrum, num_samples=light_samples, emission_map=light_map_id))
 
     mask_id = None
     if masked:
@@ -290,7 +290,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             lamp = engine.material(with_mask(light_material(spectrum=light_spectrum, num_samples=light_samples), mask_id, **mask_kw))
 
     if two_sided_lights:
-        lm = json.loads(light_material(spectrum=light_spectrum, num_samples=light_samples))
+        lm = json.loads(light_material(spectrum=light_spectrum, num_samples=light_samples, emission_map=light_map_id))
         lm["rendering"]["Light"]["two_sided"] = True
         lamp = engine.material(json.dumps(lm))
     ids = {"camera": cam, "walls": [], "lights": [], "meshes": []}
