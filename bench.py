@@ -54,6 +54,8 @@ def parse_args():
                     help="zygpu option precise: 1 = the reference's arithmetic bit for bit (verification mode: the film is "
                          "identical to the oracle's), 0 = relaxed arithmetic (native divide / sqrt, contraction, OCML f32 "
                          "functions), inside the contract's RMS <= 1e-3 (default)")
+    ap.add_argument("--fuse-tick", type=int, default=0, choices=[0, 1],
+                    help="zygpu option fuse_tick: wf_scatter of vertex k and wf_trace_shade of vertex k + 1 in one launch (wf_tick)")
     ap.add_argument("--persistent", type=int, default=0, choices=[0, 1],
                     help="zygpu option persistent: one persistent kernel per batch, path state in LDS (wf_persistent)")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
@@ -106,6 +108,7 @@ class Measurement:
         self.eng.set_option("fuse_trace_shade", args.fuse)
         self.eng.set_option("precise", args.precise)
         self.eng.set_option("persistent", args.persistent)
+        self.eng.set_option("fuse_tick", args.fuse_tick)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)
         self.fused = bool(args.fuse) and scene in ("cornell", "cornell_mesh")  # POOL scenes always run the kernels apart
         self.film = torch.zeros((self.h, self.w, 4), dtype=torch.float32, device=device)

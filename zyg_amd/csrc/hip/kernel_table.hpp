@@ -10,7 +10,7 @@
 // Template parameters (wavefront.hpp):
 //   wf_generate<POOL>   wf_intersect<STATS, POOL, EXTRA>   wf_shade<STATS, MESHL, HEAVY, POOL>
 //   wf_trace_shade<STATS, MESHL, FIRST, UTLAS>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS>
-//   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_extend<SUBST, EXTRA>   wf_persistent<SUBST, MULTI, WIDE>
+//   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_extend<SUBST, EXTRA>   wf_persistent<SUBST, MULTI, WIDE>   wf_tick<SUBST, MULTI, WIDE>
 #pragma once
 
 #define ZYG_NUM_UNITS 8
@@ -61,6 +61,10 @@
     X(6, K_TRACE_SHADE_PLAIN,    (wf_trace_shade<false, false, false>),               (P, arg)) \
     X(6, K_TRACE_SHADE_PLAIN_FIRST_U, (wf_trace_shade<false, false, true, true>),     (P, arg)) \
     X(6, K_TRACE_SHADE_PLAIN_U,  (wf_trace_shade<false, false, false, true>),         (P, arg)) \
+    X(5, K_TICK_LAMBERT,         (wf_tick<false, false, false>),                      (P))  \
+    X(5, K_TICK_SUBST,           (wf_tick<true, false, false>),                       (P))  \
+    X(5, K_TICK_LAMBERT_W,       ZYG_WIDE((wf_tick<false, false, true>), (wf_tick<false, false, false>)), (P)) \
+    X(5, K_TICK_SUBST_W,         ZYG_WIDE((wf_tick<true, false, true>), (wf_tick<true, false, false>)), (P)) \
     X(4, K_PERSISTENT_LAMBERT,   (wf_persistent<false, false, false>),                (P, arg)) \
     X(4, K_PERSISTENT_SUBST,     (wf_persistent<true, false, false>),                 (P, arg)) \
     X(4, K_PERSISTENT_LAMBERT_W, ZYG_WIDE((wf_persistent<false, false, true>), (wf_persistent<false, false, false>)), (P, arg)) \

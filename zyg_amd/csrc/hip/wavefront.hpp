@@ -192,6 +192,11 @@ struct Params {
     float4*  stage_aov;
     size_t   aov_plane;
     float4*  aov_film;
+    // the queue of the paths that survived shading: wf_trace_shade / wf_shade append to alive_out, wf_scatter (wf_nee, wf_extend)
+    // read alive_in.  Both are q.alive when the stages of a tick run apart; wf_tick reads the previous tick's and writes this
+    // tick's (the two ext arrays, which it does not need).
+    uint32_t* alive_in;
+    uint32_t* alive_out;
     uint32_t parity;  // current extension-queue side
     uint32_t queue_capacity;  // entries every queue array holds
     uint32_t round;   // POOL: which vertex of the level this launch handles
@@ -1205,7 +1210,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
             __syncthreads();  // queuePush's shared words are reused below
         }
-        queuePush(P.q.alive, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+        queuePush(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
         tm.mark(5);
         tm.flush(P.ctl, 0);
     }
@@ -1277,7 +1282,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
         }
         queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
         __syncthreads();  // queuePush's shared words are reused below
-        queuePush(P.q.alive, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+        queuePush(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
         tm.mark(11);
         tm.flush(P.ctl, 0);
     }
@@ -1450,7 +1455,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
     bool     push = false;
     uint32_t slot = 0;
     if (i < total) {
-        slot = P.q.alive[at];
+        slot = P.alive_in[at];
         if (FIRST) {
             PathHead h;
             loadHead(P, slot, h);
@@ -1533,7 +1538,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
     bool     push = false, back = false;
     uint32_t slot = 0;
     if (i < total) {
-        slot = P.q.alive[at];
+        slot = P.alive_in[at];
         PathHead h;
         loadHead(P, slot, h);
         const Surface         sf = loadSurface<false, EXTRA>(P, slot, h.flags);
@@ -1939,7 +1944,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
     tm.start();
     ScatterOut out;
     if (i < total) {
-        slot = P.q.alive[at];
+        slot = P.alive_in[at];
         scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE>(P, s, slot, out, cnt, shadow_rays, tm);
     }
     if (POOL) {
@@ -1955,6 +1960,59 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
     tm.mark(7);
     tm.flush(P.ctl, 16);
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
+}
+
+// ---------------------------------------------------------------- wf_tick
+// wf_scatter for vertex k and wf_trace_shade for vertex k + 1 of the same path in one launch (option "fuse_tick"; scenes
+// walked through the prop tables): the new ray, the path's line and the hit are still in the caches when the closest hit and
+// the first shading pass use them, so per vertex one write and one read of the 128 B state line and of the hit block do not
+// reach HBM, and a tick is one launch (plus wf_shade's rare second pass) instead of two.  It reads the previous tick's alive
+// queue and appends to this tick's; the host zeroes this tick's counters before the launch.
+template <bool SUBST, bool MULTI, bool WIDE>
+__global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_tick(Params P) {
+    const uint32_t cur = P.parity, prev = cur ^ 1u;
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[prev]) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t total = queueOpen(&P.ctl->alive_count[prev], P.queue_capacity, i, at);
+    if (0 == i) P.ctl->bound[cur] = total;
+    const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
+    if (i >= rounded) return;
+    const DScene&      s = c_scene;
+    Counters           none{0, 0, 0};
+    unsigned long long no_rays = 0;
+    SectionTimer       tm;
+    tm.start();
+    bool     alive = false, defer = false;
+    uint32_t slot = 0;
+    if (i < total) {
+        slot = P.alive_in[at];
+        ScatterOut out;
+        scatterVertex<false, SUBST, MULTI, false, false, false, true, WIDE>(P, s, slot, out, none, no_rays, tm);
+        if (out.push) {
+            const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+            const uint32_t meta = P.pool.q0.get(slot).y;
+            const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
+            Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+            Hit            hit;
+#if ZYG_FAST
+            sceneIntersectUniform<false, WIDE>(s, ray, depth, hit);
+#else
+            sceneIntersectUniform<true, false>(s, ray, depth, hit);
+#endif
+            if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+            const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<false, false, true>(P, s, slot, vertexPlane<false>(), depth, ray, none) : 0u;
+            shadeVertex<false, false, false, false>(P, slot, o, d, hit, ucount, alive, defer, none, tm);
+            if (defer || alive) {  // wf_shade's second pass and the next tick's closure set-up read the hit from the pool
+                P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+                P.pool.hit_prop[slot] = hit.prop;
+                P.pool.ucount[slot] = ucount;
+            }
+        }
+    }
+    queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
+    __syncthreads();  // queuePush's shared words are reused below
+    queuePush(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
 }
 
 // ---------------------------------------------------------------- wf_persistent

@@ -498,13 +498,16 @@ struct ZygpuContext {
     // option "persistent": the whole path in one kernel with its state in LDS (wavefront.hpp wf_persistent) where the scene
     // allows it (the plain instantiations with the prop tables, in-place NEE, single-sample lights)
     bool          persistent = false;
+    // option "fuse_tick" (default off: measured 657 vs 662 Msamples/s on configs[1], 255 vs 453 on configs[2]): wf_scatter of vertex k and wf_trace_shade of vertex k + 1 in one launch (wf_tick), for
+    // the scenes and settings its instantiations cover (prop tables, in-place NEE, single-sample lights)
+    bool          fuse_tick = false;
     bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
     uint64_t      camera_samples = 0;
     int           num_cus = 256;
     // kernel timing
-    bool                                          timing = true;
+    bool                                          timing = true, timing_paused = false;
     // per kernel: 0 wf_intersect, 1 wf_shade, 2 wf_nee, 3 wf_shadow, 4 wf_extend, 5 wf_scatter
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[ZYGPU_NUM_KERNELS];
     size_t                                        events_used[ZYGPU_NUM_KERNELS] = {};
@@ -620,6 +623,7 @@ void collectTimings(ZygpuContext* c) {
         }
         c->events_used[k] = 0;
     }
+    c->timing_paused = false;
 }
 
 std::pair<hipEvent_t, hipEvent_t>* nextEvents(ZygpuContext* c, int k) {
@@ -661,7 +665,7 @@ void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params
 
 template <typename Launch>
 void timedLaunch(ZygpuContext* c, int k, Launch&& launch) {
-    auto* e = c->timing ? nextEvents(c, k) : nullptr;
+    auto* e = (c->timing && !c->timing_paused) ? nextEvents(c, k) : nullptr;
     if (e) (void)hipEventRecord(e->first, c->stream);
     launch();
     if (e) (void)hipEventRecord(e->second, c->stream);
@@ -1158,6 +1162,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     P.film_alpha = c->film_alpha_active;
     P.parity = 0;
     P.round = 0;
+    P.alive_in = P.alive_out = c->queues.alive;
 
     // the wave-wide walk of the prop tables: plain instantiations only (no counters, no MESHL shapes / masks, no POOL)
     const bool     utlas = c->uniform_tlas && c->uniform_tables && !c->stats && !c->mesh_lights && !c->masks && !c->pool_mode;
@@ -1199,7 +1204,28 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
         }
         c->camera_samples += num_paths;
-        if (c->persistent && utlas && nee && !c->multi_sample_lights && c->fuse_trace_shade) {
+        const bool plain_in_place = utlas && nee && c->nee_in_place && !c->multi_sample_lights && c->fuse_trace_shade;
+        if (c->fuse_tick && plain_in_place && !c->persistent) {
+            // tick 0: camera rays, closest hit, shading; then per tick one wf_tick (scatter vertex t - 1, trace + shade vertex t)
+            // and wf_shade's second pass; the alive queue ping-pongs between the two ext arrays
+            P.parity = 0;
+            P.alive_in = P.alive_out = c->queues.ext[0];
+            timedLaunch(c, 0, [&] { launchKernel(c, wide ? K_TRACE_SHADE_PLAIN_FIRST_UW : K_TRACE_SHADE_PLAIN_FIRST_U, grid.x, P, num_paths); });
+            timedLaunch(c, 1, [&] { launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u); });
+            for (uint32_t t = 1; t < ticks; ++t) {
+                P.parity = t & 1u;
+                P.alive_in = c->queues.ext[(t - 1u) & 1u];
+                P.alive_out = c->queues.ext[t & 1u];
+                HIP_OK(hipMemsetAsync(&c->ctl->alive_count[P.parity], 0, sizeof(QueueCounts), c->stream));
+                HIP_OK(hipMemsetAsync(&c->ctl->heavy_count[P.parity], 0, sizeof(QueueCounts), c->stream));
+                timedLaunch(c, 5, [&] {
+                    launchKernel(c, c->has_substitute ? (wide ? K_TICK_SUBST_W : K_TICK_SUBST) : (wide ? K_TICK_LAMBERT_W : K_TICK_LAMBERT), grid.x, P, 0u);
+                });
+                timedLaunch(c, 1, [&] { launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u); });
+            }
+            P.parity = 0;
+            P.alive_in = P.alive_out = c->queues.alive;
+        } else if (c->persistent && plain_in_place) {
             HIP_OK(hipMemsetAsync(&c->ctl->next_sample, 0, sizeof(unsigned long long), c->stream));
             const unsigned blocks = std::min<unsigned>(unsigned(c->num_cus) * 4u, (num_paths + kPersistentThreads - 1u) / kPersistentThreads);  // 4 x 36 KB of LDS per CU
             timedLaunch(c, 5, [&] {
@@ -1343,10 +1369,9 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
             g_error = "a wavefront kernel is missing from its translation unit (kernel_table.hpp)";
             return -1;
         }
-        if (c->timing && c->events_used[0] > 4096) {
-            HIP_OK(hipStreamSynchronize(c->stream));
-            collectTimings(c);
-        }
+        // the event pairs of the launches wait for zygpu_kernel_time / zygpu_synchronize to collect them; a caller that never
+        // asks (a long render) stops being timed at 64 K pending pairs instead of being stalled by a synchronisation here
+        if (c->timing && c->events_used[0] + c->events_used[5] > 65536) c->timing_paused = true;
     }
     return 0;
 }
@@ -1355,6 +1380,7 @@ int zygpu_synchronize(ZygpuContext* c) {
     if (!c) return -1;
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
+    collectTimings(c);
     return deviceErrorFlags(c);
 }
 
@@ -1564,6 +1590,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
             return -1;
         }
         c->relaxed = 1 == mode;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "fuse_tick")) {
+        c->fuse_tick = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "persistent")) {
