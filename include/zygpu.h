@@ -424,7 +424,8 @@ int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.
  * mode 0: the reference's walk (top-level tree, BVH2); 1: the prop tables + BVH2; 2: the prop tables + the four-wide BLAS
- * re-layout (modes 1 and 2 need a scene the tables hold: -1 otherwise).  hits: 8 words per ray (t, u, v as float bits,
+ * re-layout; 3: the relaxed units' walk (2 without the tie rule between props, small meshes triangle by triangle from the
+ * constant block) (modes 1-3 need a scene the tables hold: -1 otherwise).  hits: 8 words per ray (t, u, v as float bits,
  * primitive, prop or ZYGPU_NULL, 3 x 0), the layout of the oracle's zyg_oracle_intersect; visible: 1 = unoccluded. */
 int zygpu_test_intersect(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits);
 int zygpu_test_visibility(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible);

@@ -10,6 +10,9 @@
 #include <cstdint>
 
 #define ZD __device__ __forceinline__
+#ifndef ZYG_FAST
+#define ZYG_FAST 0  // 1 in the relaxed-arithmetic kernel units (zyg_amd/build.py)
+#endif
 
 namespace zd {
 

@@ -77,11 +77,17 @@ struct TlasEntry {
     float4   bmin, bmax;        // world bounds (s.aabbs)
     float4   r0, r1, r2, pos;   // transformation (s.trafos)
     uint32_t shape, flags, prop, mesh;
+    uint32_t small_first, small_count, pad0, pad1;  // a mesh of a few triangles: its range in DScene::small_tris (count 0: none)
 };
+// The triangles of the scene's smallest meshes (at most kSmallMeshTriangles each, kSmallTriangles in all), in the constant
+// block beside the prop tables: the relaxed-arithmetic units test all of them, every lane of the wave the same triangle at the
+// same time with its vertices in SGPRs, instead of walking a BVH of three levels lane by lane (sceneIntersectUniform).
+constexpr uint32_t kSmallTriangles = 64, kSmallMeshTriangles = 16;
 
 struct DScene {
     TlasEntry            solid_table[kUniformProps];  // cheap shapes first; num_solid_table = 0: not available
     TlasEntry            unocc_table[4];              // the unoccluding tree's single leaf, in leaf order; 0: not available
+    float4               small_tris[3 * kSmallTriangles];  // a, b, c per triangle, mesh (= leaf) order
     uint32_t             num_solid_table, num_unocc_table;
     const ZygpuProp*     props;
     const float4*        trafos; // 4 per prop: r0(+sx), r1(+sy), r2(+sz), position
@@ -702,6 +708,21 @@ ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface,
         if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
             h.primitive = 0;
             found = rectangleIntersect(ray, trafo, h.t, h.u, h.v);
+        } else if (!EXACT_TIES && e.small_count > 0) {
+            // every triangle of a small mesh, in the mesh's order (the reference's order only matters for exact ties)
+            Ray local = worldToObjectRay(trafo, ray);
+            found = false;
+            for (uint32_t k = e.small_first, ke = e.small_first + e.small_count; k < ke; ++k) {
+                float t, u, v;
+                if (triangleIntersect(local, xyz(s.small_tris[3 * k]), xyz(s.small_tris[3 * k + 1]), xyz(s.small_tris[3 * k + 2]), t, u, v)) {
+                    local.max_t = t;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.primitive = k - e.small_first;
+                    found = true;
+                }
+            }
         } else {
             Ray local = worldToObjectRay(trafo, ray);
             found = meshIntersect<false, WIDE>(s.meshes[e.mesh], local, h, none);
@@ -719,7 +740,7 @@ ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface,
 }
 
 // any-hit over the solid props (the semantics of sceneVisibility<false, false>): true = unoccluded
-template <bool WIDE>
+template <bool WIDE, bool SMALL = false>
 ZD bool sceneVisibilityUniform(const DScene& s, Ray& ray) {
     Counters none{0, 0, 0};
     bool     blocked = false;
@@ -731,6 +752,12 @@ ZD bool sceneVisibilityUniform(const DScene& s, Ray& ray) {
             if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
                 float t, u, v;
                 blocked = rectangleIntersect(ray, trafo, t, u, v);
+            } else if (SMALL && e.small_count > 0) {
+                const Ray local = worldToObjectRay(trafo, ray);
+                for (uint32_t k = e.small_first, ke = e.small_first + e.small_count; k < ke; ++k) {
+                    float t, u, v;
+                    blocked = blocked || triangleIntersect(local, xyz(s.small_tris[3 * k]), xyz(s.small_tris[3 * k + 1]), xyz(s.small_tris[3 * k + 2]), t, u, v);
+                }
             } else {
                 Ray local = worldToObjectRay(trafo, ray);
                 blocked = meshIntersectP<false, WIDE>(s.meshes[e.mesh], local, none);

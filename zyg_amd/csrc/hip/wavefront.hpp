@@ -1676,7 +1676,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 // MESHL: the scene may have opacity masks, whose draws come from the path's sampler (material.zig:238-245)
                 auto draw = [&]() { return h.smp.sample1D(); };
                 constexpr bool kMasks = MASKS && MESHL;
-                const bool visible = UTLAS                ? sceneVisibilityUniform<WIDE>(s, shadow)
+                const bool visible = UTLAS                ? sceneVisibilityUniform<WIDE, 0 != ZYG_FAST>(s, shadow)
                                      : (POOL || kMasks) ? sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw)
                                                         : sceneVisibility<STATS, MESHL>(s, shadow, cnt);
                 tm.mark(3);

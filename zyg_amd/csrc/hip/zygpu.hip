@@ -284,7 +284,8 @@ __global__ void __launch_bounds__(256) calib_gather(const char* data, uint32_t n
 
 // Ray-level hooks for the tests (zygpu_test_intersect / zygpu_test_visibility): rays of 8 floats (o.xyz, min_t, d.xyz, max_t)
 // against the uploaded scene, in this unit's precise arithmetic.  mode 0: the reference's walk (top-level tree lane by lane,
-// BVH2); 1: the prop tables (sceneIntersectUniform) + BVH2; 2: the prop tables + the four-wide BLAS re-layout.
+// BVH2); 1: the prop tables (sceneIntersectUniform) + BVH2; 2: the prop tables + the four-wide BLAS re-layout; 3: as the
+// relaxed units walk: 2 without the tie rule between props and with the small meshes tested triangle by triangle.
 __global__ void test_intersect(uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -295,7 +296,8 @@ __global__ void test_intersect(uint32_t n, const float* rays, uint32_t depth_sur
     bool         found;
     if (0 == mode) found = sceneIntersect<false, true>(c_scene, ray, depth_surface, hit, cnt);
     else if (1 == mode) found = sceneIntersectUniform<true, false>(c_scene, ray, depth_surface, hit);
-    else found = sceneIntersectUniform<true, true>(c_scene, ray, depth_surface, hit);
+    else if (2 == mode) found = sceneIntersectUniform<true, true>(c_scene, ray, depth_surface, hit);
+    else found = sceneIntersectUniform<false, true>(c_scene, ray, depth_surface, hit);  // no tie rule, small meshes triangle by triangle
     uint32_t* h = hits + size_t(i) * 8;
     for (int k = 0; k < 8; ++k) h[k] = 0;
     if (found) {
@@ -314,7 +316,8 @@ __global__ void test_visibility(uint32_t n, const float* rays, uint32_t mode, ui
     Counters     cnt{0, 0, 0};
     visible[i] = (0 == mode   ? sceneVisibility<false, true>(c_scene, ray, cnt)
                   : 1 == mode ? sceneVisibilityUniform<false>(c_scene, ray)
-                              : sceneVisibilityUniform<true>(c_scene, ray))
+                  : 2 == mode ? sceneVisibilityUniform<true>(c_scene, ray)
+                              : sceneVisibilityUniform<true, true>(c_scene, ray))
                      ? 1u
                      : 0u;
 }
@@ -988,6 +991,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     // single leaf of at most 4 Rectangles, in the leaf's order.
     s.num_solid_table = s.num_unocc_table = 0;
     {
+        uint32_t num_small = 0;
         auto entry = [&](uint32_t p) {
             TlasEntry e;
             const ZygpuAabb&  b = d->aabbs[p];
@@ -1002,6 +1006,22 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             e.flags = d->props[p].flags;
             e.prop = p;
             e.mesh = d->props[p].mesh;
+            e.small_first = e.small_count = e.pad0 = e.pad1 = 0;
+            // a mesh of a few triangles goes into the small-triangle table (dscene.hpp), in its own (leaf) order
+            if (ZYGPU_SHAPE_TRIANGLE_MESH == e.shape) {
+                const ZygpuMesh& hm = d->meshes[e.mesh];
+                if (hm.num_triangles <= kSmallMeshTriangles && num_small + hm.num_triangles <= kSmallTriangles) {
+                    e.small_first = num_small;
+                    e.small_count = hm.num_triangles;
+                    for (uint32_t t = 0; t < hm.num_triangles; ++t)
+                        for (int k = 0; k < 3; ++k) {
+                            const uint32_t vi = hm.triangles[size_t(t) * 3 + k];
+                            s.small_tris[3 * (num_small + t) + k] =
+                                make_float4(hm.positions[size_t(vi) * 3], hm.positions[size_t(vi) * 3 + 1], hm.positions[size_t(vi) * 3 + 2], 0.f);
+                        }
+                    num_small += hm.num_triangles;
+                }
+            }
             return e;
         };
         bool ok_solid = d->solid.num_indices > 0 && d->solid.num_indices <= kUniformProps;
@@ -1486,7 +1506,7 @@ int zygpu_test_eval(ZygpuContext* c, uint32_t op, uint32_t n, const float* in, u
 }
 
 int zygpu_test_intersect(ZygpuContext* c, uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits) {
-    if (!c || !c->has_scene || !rays || !hits || mode > 2 || (mode > 0 && !c->uniform_tables)) return -1;
+    if (!c || !c->has_scene || !rays || !hits || mode > 3 || (mode > 0 && !c->uniform_tables)) return -1;
     HIP_OK(hipSetDevice(c->device));
     float*    din = nullptr;
     uint32_t* dout = nullptr;
@@ -1503,7 +1523,7 @@ int zygpu_test_intersect(ZygpuContext* c, uint32_t n, const float* rays, uint32_
 }
 
 int zygpu_test_visibility(ZygpuContext* c, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible) {
-    if (!c || !c->has_scene || !rays || !visible || mode > 2 || (mode > 0 && !c->uniform_tables)) return -1;
+    if (!c || !c->has_scene || !rays || !visible || mode > 3 || (mode > 0 && !c->uniform_tables)) return -1;
     HIP_OK(hipSetDevice(c->device));
     float*    din = nullptr;
     uint32_t* dout = nullptr;
