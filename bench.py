@@ -173,7 +173,12 @@ class Measurement:
             for s in range(self.steps):
                 self.frame.render_step(self.render, s, self.ips, self.steps)
             self.eng.synchronize()
-            self.frame.reduce(self.film)
+            if self.frame.world > 1 and "gloo" == self.frame.dist.get_backend():  # test set-up only: through host copies
+                host = self.film.cpu()
+                self.frame.reduce(host)
+                self.film.copy_(host)
+            else:
+                self.frame.reduce(self.film)
 
         elapsed = self.frame.timed(body, lambda: self.torch.cuda.synchronize(self.device))
         ms, launches = dtmp(), ltmp()
@@ -356,9 +361,12 @@ def main():
 
     import zyg_amd
     from zyg_amd import distributed, scenes
-    device = torch.device("cuda", local_rank)
+    # ZYG_BENCH_BACKEND=gloo ZYG_BENCH_ONE_DEVICE=1: the N > 1 path of this file on a box with one GPU (tests/test_distributed.py):
+    # every rank on device 0, the films summed over gloo through host copies.  The measurement runs RCCL, one rank per GPU.
+    backend = os.environ.get("ZYG_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", 0 if os.environ.get("ZYG_BENCH_ONE_DEVICE") else local_rank)
     torch.cuda.set_device(device)
-    dist = distributed.init_process_group("nccl", rank, world, device) if n > 1 else None
+    dist = distributed.init_process_group(backend, rank, world, device) if n > 1 else None
     frame = distributed.ShardedFrame(rank, n, dist, "iterations", args.height)
 
     m = Measurement(args, zyg_amd, scenes, torch, frame, device, args.scene, args.material, args.steps, args.warmup)

@@ -135,3 +135,26 @@ def test_two_processes_on_one_gpu_shard_the_frame(tmp_path, mode):
         assert np.array_equal(d["reduced"], d["full"])  # disjoint pixels: exact
     else:
         np.testing.assert_allclose(d["reduced"][..., :3], d["full"][..., :3], rtol=1e-6, atol=1e-7)  # float association only
+
+
+@pytest.mark.gpu
+def test_bench_py_two_ranks_end_to_end(tmp_path):
+    """bench.py's own N > 1 path, launched the way the driver launches it (torch.distributed.run, one process per rank,
+    127.0.0.1), on the one GPU of this box: both ranks on device 0 and gloo instead of RCCL (ZYG_BENCH_*), everything else
+    the measured code: ShardedFrame's shards, timing protocol and reduce, rank 0's one JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, ZYG_BENCH_BACKEND="gloo", ZYG_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "320", "--height", "180", "--iters-per-step", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "iterations x2"
+    # two ranks x 2 steps x 4 iterations, summed into rank 0's film
+    assert out["film_weight_min_max"] == [16.0, 16.0]
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
