@@ -73,6 +73,9 @@ int32_t su_ext_prop_create(uint32_t shape, uint32_t num_materials, const uint32_
 int32_t su_ext_sensor_create(const char* json);
 /* Camera "parameters" node (camera_perspective.zig:260-270): fov (degrees), lens.radius, focus.distance. */
 int32_t su_ext_camera_set_parameters(const char* json);
+/* The take's sampler class (take_loader.zig:232-244: {"Random": ...} | {"Sobol": ...}): 0 = Random (PCG only), 1 = Sobol
+ * (the C ABI's default; su_sampler_create only sets the sample count, capi.zig:215-221). */
+int32_t su_ext_sampler_kind(uint32_t kind);
 /* HIP device the engine renders on (default: env ZYG_DEVICE, else LOCAL_RANK, else 0). */
 int32_t su_ext_set_device(int32_t device_id);
 /* Scene.compile + camera.update only (driver.zig:154-180), no device work; fills the descriptors below. */

@@ -385,6 +385,12 @@ int zygpu_clear_film(ZygpuContext* ctx, float weight);
 int zygpu_render(ZygpuContext* ctx, uint32_t frame, uint32_t iteration, uint32_t num_iterations,
                  int32_t y_begin, int32_t y_end);
 
+/* One-shot rendering: Worker.render with num_samples > 1 (reference src/core/rendering/worker.zig:141-165), what
+ * Driver.render runs for su_render_frame (driver.zig:115-152).  The samples of a pixel are the progressive ones except that
+ * the pixel's PCG stream (bounces >= 3, worker.zig:201-207) is started once, for `iteration`, and runs on across the samples.
+ * Same film layout and accumulation as zygpu_render. */
+int zygpu_render_frame(ZygpuContext* ctx, uint32_t frame, uint32_t iteration, uint32_t num_samples, int32_t y_begin, int32_t y_end);
+
 /* Waits for all queued work on the context's stream. */
 int zygpu_synchronize(ZygpuContext* ctx);
 

@@ -153,7 +153,8 @@ def _oracle_frame(oracle, sd, vd, frame):
     w, h = vd.resolution[0], vd.resolution[1]
     film = np.zeros((h, w, 4), dtype=np.float32)
     st = zyg_amd.Stats()
-    assert oracle.zyg_oracle_render(ctypes.addressof(sd), ctypes.addressof(vd), frame, 0, SPP, 1, 0, h, film.ctypes.data, 8,
+    # su_render_frame is the one-shot form: Worker.render with num_samples = spp (the pixel's PCG stream runs on across samples)
+    assert oracle.zyg_oracle_render(ctypes.addressof(sd), ctypes.addressof(vd), frame, 0, 1, SPP, 0, h, film.ctypes.data, 8,
                                     ctypes.byref(st)) == 0
     return film
 

@@ -844,3 +844,31 @@ def test_relaxed_arithmetic_meets_the_contract_at_config1(engine, oracle):
     a = oracle_resolve(oracle, vd, film)[y0:y1]
     b = oracle_resolve(oracle, vd, cpu)[y0:y1]
     assert rms(a, b) <= RMS_TOL, rms(a, b)
+
+
+@pytest.mark.parametrize("scene", ["lambert", "glass", "random_sampler"])
+def test_one_shot_render_frame(engine, oracle, scene):
+    """su_render_frame = Driver.render (driver.zig:115-152) = Worker.render with num_samples = spp (worker.zig:141-165): a pixel's
+    PCG stream is started once and runs on across its samples, where su_render_iterations starts one per (pixel, iteration).
+    The device renders the samples of a pixel batch after batch and hands the stream's state on; film == the oracle's one-shot
+    render, and != the progressive one (deep paths draw from the stream)."""
+    w, h, spp = 96, 64, 5
+    if scene == "glass":
+        scenes.cornell(engine, w, h, spp, glass_objects={"box": GLASS_BOX, "sphere": scenes.glass(1.5)})
+    else:
+        scenes.cornell(engine, w, h, spp, integrator="PTMIS")
+    if scene == "random_sampler":
+        engine.lib.su_ext_sampler_kind.argtypes = [ctypes.c_uint32]
+        assert engine.lib.su_ext_sampler_kind(0) == 0
+    engine.render_frame(0)
+    one_shot = engine.download_film(w, h)
+    sd = engine.lib.su_ext_scene_desc().contents
+    vd = engine.lib.su_ext_view_desc().contents
+    cpu = oracle_render(oracle, sd, vd, 1, samples_per_call=spp)
+    assert np.array_equal(one_shot, cpu)
+    engine.start_frame(0)
+    engine.render_iterations(spp)
+    engine.synchronize()
+    progressive = engine.download_film(w, h)
+    assert np.array_equal(progressive, oracle_render(oracle, sd, vd, spp))
+    assert np.array_equal(progressive[..., 3], one_shot[..., 3]) and not np.array_equal(progressive, one_shot)

@@ -177,12 +177,17 @@ struct View {
     int32_t       x_begin, x_end;  // sample columns incl. filter padding
     uint32_t      frame, iteration0, batch_iterations;
     uint32_t      npix;  // samples per iteration in this batch
+    // One-shot rendering (zygpu_render_frame = Worker.render with num_samples > 1, worker.zig:141-165): the pixel's PCG stream
+    // is started once, at `oneshot_base`, and runs on across its samples; a batch is one sample per pixel and
+    // iteration0 = oneshot_base + the sample's number.  0 = progressive: every (pixel, iteration) starts its own stream.
+    uint32_t      one_shot, oneshot_base;
 };
 
 struct Params {
     Pool     pool;
     Queues   q;
     Control* ctl;
+    uint2*   pixel_pcg;    // one-shot rendering: per sample pixel the PCG state its last sample left (else null)
     float4*  stage_color;  // per sample: clamped composed colour, alpha
     float2*  stage_uv;     // per sample: pixel_uv
     float4*  film;
@@ -410,6 +415,9 @@ ZD uint64_t pcgSequence(uint32_t pixel_id, uint32_t iteration) {  // worker.zig:
     return uint64_t(pixel_id) + uint64_t(iteration) * a;
 }
 
+// the iteration whose number selects the pixel's PCG stream: its own (progressive), or the call's first one (one-shot)
+ZD uint32_t pcgIteration(uint32_t iteration) { return c_view.one_shot ? c_view.oneshot_base : iteration; }
+
 ZD float splitThreshold(uint32_t total_depth) {  // integrator/helper.zig:33-39
     const float t = c_view.v.split_threshold;
     return mn(total_depth < 4 ? t : kLowThreshold, t);
@@ -451,7 +459,7 @@ ZD void loadHead(const Params& P, uint32_t vertex, PathHead& h) {
     const uint64_t sample_index = uint64_t(pixel_id) * uint64_t(c_view.v.num_expected_samples) + uint64_t(iteration);
     h.smp.sample = uint32_t(sample_index);
     h.smp.rng.state = uint64_t(g.x) | (uint64_t(g.y) << 32);
-    h.smp.rng.inc = (pcgSequence(pixel_id, iteration) << 1) | 1ull;
+    h.smp.rng.inc = (pcgSequence(pixel_id, pcgIteration(iteration)) << 1) | 1ull;
     h.smp.sobol_kind = ZYGPU_SAMPLER_SOBOL == c_view.v.sampler;
     h.depth_surface = (meta >> 3) & 31u;
     h.vdepth = (meta >> 8) & 31u;
@@ -539,7 +547,8 @@ ZD f3 clampColor(f3 color, float max) {  // sensor.zig:615-624
 }
 
 // end of a path: Sensor.addSample's colour part (sensor.zig:177-181) into the staging buffer
-ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags) {
+ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags, const Pcg& rng) {
+    if (P.pixel_pcg) P.pixel_pcg[slot] = make_uint2(uint32_t(rng.state), uint32_t(rng.state >> 32));  // one-shot: the next sample goes on
     const f3    e = clampColor(xyz4(P.pool.emission[slot]), c_view.v.clamp_emission);
     const f3    d = clampColor(xyz4(P.pool.direct[slot]), c_view.v.clamp_direct);
     const f3    i = clampColor(xyz4(P.pool.indirect[slot]), c_view.v.clamp_indirect);
@@ -558,6 +567,7 @@ ZD void terminateVertex(const Params& P, uint32_t slot, f3 throughput, float spl
     const uint32_t st = P.pool.pstate[slot] - 1u;
     P.pool.pstate[slot] = st;
     if (0 == (st & 255u)) {
+        if (P.pixel_pcg) P.pixel_pcg[slot] = P.pool.pcg[slot];  // one-shot: storeSamplers ran just before (shared samplers)
         const f3 e = clampColor(xyz4(P.pool.emission[slot]), c_view.v.clamp_emission);
         const f3 d = clampColor(xyz4(P.pool.direct[slot]), c_view.v.clamp_direct);
         const f3 i = clampColor(xyz4(P.pool.indirect[slot]), c_view.v.clamp_indirect);
@@ -659,11 +669,21 @@ ZD void generatePath(const Params& P, uint32_t slot) {
     PathHead h;
     h.smp.sobol_kind = ZYGPU_SAMPLER_SOBOL == c_view.v.sampler;
     h.smp.use_primary = true;
-    h.smp.rng.start(0, pcgSequence(pixel_id, iteration));
-
     const uint32_t nexp = c_view.v.num_expected_samples;
-    const uint64_t sample_index = uint64_t(pixel_id) * uint64_t(nexp) + uint64_t(iteration);
-    const uint32_t seed = uint32_t(sample_index >> 32) + iteration / nexp;
+    uint64_t       sample_index = uint64_t(pixel_id) * uint64_t(nexp) + uint64_t(iteration);
+    uint32_t       seed = uint32_t(sample_index >> 32) + iteration / nexp;
+    if (c_view.one_shot && iteration != c_view.oneshot_base) {
+        // sample s > 0 of a one-shot pixel: the stream goes on where the previous sample left it (worker.zig:143, 153-165);
+        // Sobol: incrementSample (sobol.zig:26-30) counts the sample index up and returns to the pixel's start seed
+        const uint2 st = P.pixel_pcg[slot];
+        h.smp.rng.state = uint64_t(st.x) | (uint64_t(st.y) << 32);
+        h.smp.rng.inc = (pcgSequence(pixel_id, c_view.oneshot_base) << 1) | 1ull;
+        const uint64_t first = uint64_t(pixel_id) * uint64_t(nexp) + uint64_t(c_view.oneshot_base);
+        sample_index = uint64_t(uint32_t(first) + (iteration - c_view.oneshot_base));
+        seed = uint32_t(first >> 32) + c_view.oneshot_base / nexp;
+    } else {
+        h.smp.rng.start(0, pcgSequence(pixel_id, iteration));
+    }
     h.smp.buffer[0] = h.smp.buffer[1] = h.smp.buffer[2] = h.smp.buffer[3] = h.smp.buffer[4] = 0.f;
     h.smp.startPixel(uint32_t(sample_index), seed);
 
@@ -1174,7 +1194,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             storeSamplers(P, ps, h);  // the sample's other vertices go on with these samplers
             terminateVertex(P, ps, throughput, split_weight, h.flags);
         } else {
-            finalize(P, slot, throughput, h.flags);
+            finalize(P, slot, throughput, h.flags, h.smp.rng);
         }
     }
     tm.mark(4);
@@ -1552,7 +1572,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
 
         BxdfSample bs;
         if (!ms.template sample<SUBST>(s, h.smp, bs)) {
-            finalize(P, slot, S3(0.f), h.flags);
+            finalize(P, slot, S3(0.f), h.flags, h.smp.rng);
         } else {
             // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
             if (kScatterSpecular == bs.scattering) {
@@ -1887,7 +1907,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             }
         }
     } else if (!ms.template sample<SUBST>(s, h.smp, bs)) {
-        finalize(P, slot, S3(0.f), h.flags);
+        finalize(P, slot, S3(0.f), h.flags, h.smp.rng);
     } else {
         // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
         if (kScatterSpecular == bs.scattering) {

@@ -487,6 +487,8 @@ struct ZygpuContext {
     bool          tick_sync = false;       // option "tick_sync": read the queue length back after every tick
     uint32_t*     host_count = nullptr;    // pinned
     uint4*        sobol_lut = nullptr;     // dsampler.hpp c_sobol_lut
+    uint2*        pixel_pcg = nullptr;     // zygpu_render_frame: per sample pixel the PCG state its last sample left
+    size_t        pixel_pcg_capacity = 0;
     uint32_t      batch_mpaths = 32;       // option "batch_mpaths": paths per batch, in units of 2^20
     bool          nee_in_place = true;     // option "nee_in_place": wf_scatter instead of wf_nee / wf_shadow / wf_extend
     bool          fuse_trace_shade = true; // option "fuse_trace_shade": wf_trace_shade instead of wf_intersect + wf_shade's first pass
@@ -745,6 +747,7 @@ int zygpu_destroy(ZygpuContext* c) {
     if (c->film_alpha) (void)hipFree(c->film_alpha);
     if (c->host_count) (void)hipHostFree(c->host_count);
     if (c->sobol_lut) (void)hipFree(c->sobol_lut);
+    if (c->pixel_pcg) (void)hipFree(c->pixel_pcg);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1119,7 +1122,20 @@ int zygpu_clear_film(ZygpuContext* c, float weight) {
     return 0;
 }
 
+static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t num_iterations, int32_t y_begin, int32_t y_end, bool one_shot);
+
 int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t num_iterations, int32_t y_begin, int32_t y_end) {
+    return renderRange(c, frame, iteration, num_iterations, y_begin, y_end, false);
+}
+
+// Worker.render with num_samples > 1 (worker.zig:141-165), what Driver.render runs for su_render_frame: a pixel's PCG stream
+// is started once and runs on across its samples (its Sobol samples are the progressive ones), so the samples of a pixel
+// are rendered one batch after the other and each leaves its stream's state for the next (Params::pixel_pcg).
+int zygpu_render_frame(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t num_samples, int32_t y_begin, int32_t y_end) {
+    return renderRange(c, frame, iteration, num_samples, y_begin, y_end, true);
+}
+
+static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t num_iterations, int32_t y_begin, int32_t y_end, bool one_shot) {
     if (!c || !c->has_scene || !c->has_view) {
         g_error = "zygpu_render before zygpu_upload_scene / zygpu_set_view";
         return -1;
@@ -1143,7 +1159,7 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     // POOL: 8 vertex records per slot, but rounds 1-3 are sparse; measured on a 1080p glass Cornell box 106 / 112 / 127
     // Msamples/s at 4 / 8 / 16 M slots (and a collapse at 32 M, ~130 GB of pool)
     const size_t   target_paths = (size_t(c->batch_mpaths) << 20) / (c->pool_mode ? 2 : 1);
-    const uint32_t per_batch = uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
+    const uint32_t per_batch = one_shot ? 1u : uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
     // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
     const uint32_t rounds = nee ? std::min<uint32_t>(c->num_lights, 64u) : 0u;
@@ -1183,6 +1199,18 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
     P.parity = 0;
     P.round = 0;
     P.alive_in = P.alive_out = c->queues.alive;
+    P.pixel_pcg = nullptr;
+    if (one_shot) {
+        if (c->pixel_pcg_capacity < npix) {
+            HIP_OK(hipStreamSynchronize(c->stream));
+            if (c->pixel_pcg) (void)hipFree(c->pixel_pcg);
+            c->pixel_pcg = nullptr;
+            c->pixel_pcg_capacity = 0;
+            HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pixel_pcg), npix * sizeof(uint2)));
+            c->pixel_pcg_capacity = npix;
+        }
+        P.pixel_pcg = c->pixel_pcg;
+    }
 
     // the wave-wide walk of the prop tables: plain instantiations only (no counters, no MESHL shapes / masks, no POOL)
     const bool     utlas = c->uniform_tlas && c->uniform_tables && !c->stats && !c->mesh_lights && !c->masks && !c->pool_mode;
@@ -1202,6 +1230,8 @@ int zygpu_render(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint32_t n
         view.iteration0 = iteration + done;
         view.batch_iterations = b;
         view.npix = uint32_t(npix);
+        view.one_shot = one_shot ? 1u : 0u;
+        view.oneshot_base = iteration;
         // this unit's copy (the film kernels); the kernel units' copies follow in launchKernel
         HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_view), &view, sizeof(View), 0, hipMemcpyHostToDevice, c->stream));
         c->view_epoch = ++g_view_epoch;  // launchKernel refreshes the kernel units' copies on demand

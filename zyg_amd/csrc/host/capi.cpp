@@ -277,8 +277,16 @@ int32_t su_render_iterations(uint32_t num_steps) {
 int32_t su_render_frame(uint32_t frame) {
     if (!g) return -1;
     if (0 != prepareFrame(frame, true)) return -1;
+    // Driver.render (driver.zig:115-152): one Worker.render call per tile with num_samples = the view's samples per pixel
     const uint32_t spp = g->engine.num_samples_per_pixel;
-    if (0 != su_render_iterations(spp)) return -1;
+    if (g_progress_start) g_progress_start(spp);
+    if (0 != zygpu_render_frame(g->ctx, g->frame, 0, spp, 0, g->engine.resolution[1])) {
+        logf(2, "zygpu_render_frame failed: %s", zygpu_last_error());
+        return -1;
+    }
+    if (g_progress_tick)
+        for (uint32_t i = 0; i < spp; ++i) g_progress_tick();
+    g->iteration = spp;
     if (0 != zygpu_synchronize(g->ctx)) {
         logf(2, "su_render_frame: %s", zygpu_last_error());
         return -1;
@@ -380,6 +388,12 @@ int32_t su_ext_camera_set_parameters(const char* json) {
     zyg::JsonValue v;
     if (!parse(json, v)) return -1;
     g->engine.loadCameraParameters(v);
+    return 0;
+}
+
+int32_t su_ext_sampler_kind(uint32_t kind) {
+    if (!g || kind > ZYGPU_SAMPLER_SOBOL) return -1;
+    g->engine.sampler_kind = kind;
     return 0;
 }
 
