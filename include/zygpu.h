@@ -258,6 +258,13 @@ typedef struct ZygpuLuts {
     const float* e_s;     /* 16 x 16 x 16 */
 } ZygpuLuts;
 
+/* reference base/math/transformation.zig: one keyframe of an animated entity (rotation is a quaternion x, y, z, w) */
+typedef struct ZygpuKeyframe {
+    float position[4];
+    float scale[4];
+    float rotation[4];
+} ZygpuKeyframe;
+
 typedef struct ZygpuSceneDesc {
     const ZygpuProp*     props;
     const ZygpuTrafo*    trafos; /* per prop, camera-relative (space.zig:99-108) */
@@ -288,6 +295,17 @@ typedef struct ZygpuSceneDesc {
     uint32_t num_images;
     uint32_t num_infinite_props;
     uint32_t num_image_lights;
+    /* Animated props (su_prop_set_transformation_frame; space.zig:23-26): prop_frames[p] = the prop's first keyframe in
+     * `keyframes`, or ZYGPU_NULL for a static prop (NULL pointer: no prop is animated).  num_interpolation_frames keyframes per
+     * animated prop (scene.zig:254-257), one tick (1/60 s) apart from the frame's start, in world space; `origin` is
+     * subtracted after the interpolation (space.zig:114-125).  An animated prop's flags lack ZYGPU_PROP_STATIC, its `trafos`
+     * entry is the transformation at the frame's start and its `aabbs` entry bounds the whole motion (space.zig:60-97).
+     * Lights must be static. */
+    const ZygpuKeyframe* keyframes;
+    const uint32_t*      prop_frames;
+    uint32_t             num_keyframes;
+    uint32_t             num_interpolation_frames;
+    float                origin[4];
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };
@@ -301,12 +319,6 @@ enum ZygpuAovClass { ZYGPU_AOV_ALBEDO = 0, ZYGPU_AOV_DEPTH = 1, ZYGPU_AOV_MATERI
                      ZYGPU_AOV_SHADING_NORMAL = 4, ZYGPU_AOV_ROUGHNESS = 5, ZYGPU_AOV_EMISSION = 6, ZYGPU_AOV_DIRECT = 7,
                      ZYGPU_AOV_INDIRECT = 8, ZYGPU_AOV_NUM_CLASSES = 9 };
 
-/* reference base/math/transformation.zig: one keyframe of an animated entity (rotation is a quaternion x, y, z, w) */
-typedef struct ZygpuKeyframe {
-    float position[4];
-    float scale[4];
-    float rotation[4];
-} ZygpuKeyframe;
 #define ZYGPU_MAX_CAMERA_KEYFRAMES 4
 
 typedef struct ZygpuViewDesc {

@@ -24,8 +24,9 @@ constexpr float    kRayMaxT = 2.14748313e+09f;  // ray_offset.zig:5
 constexpr uint32_t kNull = 0xFFFFFFFFu;
 
 struct Ray {
-    V4    origin, direction, inv_direction;
-    float min_t, max_t;
+    V4       origin, direction, inv_direction;
+    float    min_t, max_t;
+    uint32_t time = 0;  // Probe.time (probe.zig) as ticks since the frame's start: selects an animated prop's transformation
     static Ray init(V4 o, V4 d, float mint, float maxt) {
         Ray r;
         r.origin = o;
@@ -113,7 +114,11 @@ inline V4 fragOffsetP(const Fragment& f, V4 v) {  // intersection.zig:115-119
     const V4 n = f.sameHemisphere(v) ? f.geo_n : -f.geo_n;
     return offsetRay(fma4(S(f.uvw[3]), n, f.p), n);
 }
-inline Ray fragOffsetRay(const Fragment& f, V4 dir) { return Ray::init(fragOffsetP(f, dir), dir, 0.f, kRayMaxT); }
+inline Ray fragOffsetRay(const Fragment& f, V4 dir, uint32_t time = 0) {
+    Ray r = Ray::init(fragOffsetP(f, dir), dir, 0.f, kRayMaxT);
+    r.time = time;
+    return r;
+}
 
 struct Counters {  // what B_trav is computed from
     uint64_t camera_samples = 0, extension_rays = 0, shadow_rays = 0, nodes_fetched = 0, triangles_tested = 0,
@@ -746,10 +751,63 @@ inline void meshFragment(const ZygpuMesh& mesh, Fragment& frag) {
     frag.uvw = mk(uv[0], uv[1], 0.f, 0.f);
 }
 
+// math.Transformation.lerp (transformation.zig:36-44: lerp, lerp, quaternion.slerp 217-245), origin subtracted after the
+// interpolation (space.zig:121-124), ComposedTransformation.init with quaternion.toMat3x3 (quaternion.zig:72-116)
+inline Trafo interpolateKeyframes(const ZygpuKeyframe& ka, const ZygpuKeyframe& kb, float wgt, V4 origin) {
+    const V4 t4 = S(wgt);
+    const V4 position = lerp4(ld4(ka.position), ld4(kb.position), t4) - origin;
+    const V4 scale = lerp4(ld4(ka.scale), ld4(kb.scale), t4);
+    const V4 qa = ld4(ka.rotation);
+    V4       end = ld4(kb.rotation);
+    const V4 ab = qa * end;
+    float    cosom = ab[0] + ab[1] + ab[2] + ab[3];
+    if (cosom < 0.f) {
+        cosom = -cosom;
+        end = -end;
+    }
+    float sclp, sclq;
+    if (1.f - cosom > 0.00001f) {
+        const float omega = acosF(cosom), sinom = sinF(omega);
+        sclp = sinF((1.f - wgt) * omega) / sinom;
+        sclq = sinF(wgt * omega) / sinom;
+    } else {
+        sclp = 1.f - wgt;
+        sclq = wgt;
+    }
+    const V4    q = S(sclp) * qa + S(sclq) * end;
+    const V4    tq = q + q;
+    const float xy = tq[1] * q[0], xz = tq[2] * q[0], yz = tq[1] * q[2];
+    const V4    wq = tq * S(q[3]);
+    const V4    a = mk(q[3], q[0], q[3], q[1]), b = mk(q[1], q[2], q[0], q[2]);
+    const V4    t = (a + b) * (a - b);
+    Trafo       out;
+    out.r[0] = mk(t[0] + t[1], xy - wq[2], xz + wq[1], scale[0]);
+    out.r[1] = mk(xy + wq[2], t[2] + t[3], yz - wq[0], scale[1]);
+    out.r[2] = mk(xz - wq[1], yz + wq[0], t[2] - t[3], scale[2]);
+    out.position = position;
+    return out;
+}
+
 struct SceneView {
     const ZygpuSceneDesc* d;
 
     Trafo propTrafo(uint32_t p) const { return Trafo::from(d->trafos[p]); }
+    // Scene.propTransformationAtMaybeStatic (scene.zig:382-385 -> space.zig:99-137): a static prop's transformation, or an
+    // animated prop's keyframes interpolated at `time` (ticks since the frame's start): frameAt, Transformation.lerp with
+    // quaternion.slerp, the scene origin subtracted, ComposedTransformation.init
+    Trafo propTrafo(uint32_t p, uint32_t time) const {
+        if (!d->prop_frames || ZYGPU_NULL == d->prop_frames[p]) return propTrafo(p);
+        const uint32_t tick = uint32_t(705600000ull / 60);
+        uint32_t       i = time / tick;
+        float          wgt = float(double(time - i * tick) / double(tick));
+        if (i + 1 >= d->num_interpolation_frames) {  // a shutter sample of exactly 1.0: the last keyframe
+            i = d->num_interpolation_frames - 2;
+            wgt = 1.f;
+        }
+        const ZygpuKeyframe& ka = d->keyframes[d->prop_frames[p] + i];
+        const ZygpuKeyframe& kb = d->keyframes[d->prop_frames[p] + i + 1];
+        return interpolateKeyframes(ka, kb, wgt, ld4(d->origin));
+    }
     const ZygpuMaterial& propMaterial(uint32_t prop, uint32_t part) const {
         return d->materials[d->material_ids[d->props[prop].parts_start + part]];
     }
@@ -769,7 +827,7 @@ struct SceneView {
         if (!visible(prop.flags, depth_surface)) return false;
         cnt.instances_tested += 1;
         if (!aabbIntersect(d->aabbs[p], ray)) return false;
-        const Trafo trafo = propTrafo(p);
+        const Trafo trafo = propTrafo(p, ray.time);
         const bool  masked = 0 != (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
         if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
             float t, u, v;
@@ -831,7 +889,7 @@ struct SceneView {
         if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) return true;
         cnt.instances_tested += 1;
         if (!aabbIntersect(d->aabbs[p], ray)) return true;
-        const Trafo trafo = propTrafo(p);
+        const Trafo trafo = propTrafo(p, ray.time);
         if (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY) {
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {  // rectangle.zig:154-186
                 float t, u, v;

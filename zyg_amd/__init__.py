@@ -105,6 +105,10 @@ class Luts(ctypes.Structure):
                 ("e_s", ctypes.POINTER(ctypes.c_float))]
 
 
+class Keyframe(ctypes.Structure):
+    _fields_ = [("position", ctypes.c_float * 4), ("scale", ctypes.c_float * 4), ("rotation", ctypes.c_float * 4)]
+
+
 class SceneDesc(ctypes.Structure):
     _fields_ = [("props", ctypes.POINTER(Prop)), ("trafos", ctypes.POINTER(Trafo)), ("aabbs", ctypes.POINTER(Aabb)),
                 ("material_ids", ctypes.POINTER(ctypes.c_uint32)), ("light_ids", ctypes.POINTER(ctypes.c_uint32)),
@@ -117,11 +121,9 @@ class SceneDesc(ctypes.Structure):
                 ("specular_threshold", ctypes.c_float),
                 ("num_props", ctypes.c_uint32), ("num_parts", ctypes.c_uint32), ("num_meshes", ctypes.c_uint32),
                 ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32), ("num_mesh_lights", ctypes.c_uint32),
-                ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32), ("num_image_lights", ctypes.c_uint32)]
-
-
-class Keyframe(ctypes.Structure):
-    _fields_ = [("position", ctypes.c_float * 4), ("scale", ctypes.c_float * 4), ("rotation", ctypes.c_float * 4)]
+                ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32), ("num_image_lights", ctypes.c_uint32),
+                ("keyframes", ctypes.POINTER(Keyframe)), ("prop_frames", ctypes.POINTER(ctypes.c_uint32)),
+                ("num_keyframes", ctypes.c_uint32), ("num_interpolation_frames", ctypes.c_uint32), ("origin", ctypes.c_float * 4)]
 
 
 class ViewDesc(ctypes.Structure):

@@ -424,10 +424,12 @@ struct Trafo {
 };
 
 struct Ray {
-    f3    origin, direction, inv_direction;
-    float min_t, max_t;
+    f3       origin, direction, inv_direction;
+    float    min_t, max_t;
+    uint32_t time;  // Probe.time as ticks since the frame's start: selects an animated prop's transformation (0 elsewhere)
     ZD static Ray init(f3 o, f3 d, float mint, float maxt) {  // ray.zig:11-20
         Ray r;
+        r.time = 0;
         r.origin = o;
         r.direction = d;
         r.inv_direction = S3(1.f) / d;

@@ -90,6 +90,12 @@ struct DScene {
     float4               small_tris[3 * kSmallTriangles];  // a, b, c per triangle, mesh (= leaf) order
     uint32_t             num_solid_table, num_unocc_table;
     const ZygpuProp*     props;
+    // animated props (ZygpuSceneDesc.keyframes): 3 float4 per keyframe (position, scale, rotation quaternion); prop_frames[p] =
+    // first keyframe or kNull; null pointers: no prop is animated
+    const float4*        keyframes;
+    const uint32_t*      prop_frames;
+    float4               origin;
+    uint32_t             num_interpolation_frames;
     const float4*        trafos; // 4 per prop: r0(+sx), r1(+sy), r2(+sz), position
     const float4*        aabbs;  // 2 per prop
     const uint32_t*      material_ids;
@@ -226,6 +232,64 @@ ZD Trafo loadTrafo(const DScene& s, uint32_t p) {
     t.scale = {a.w, b.w, c.w};
     t.position = {d.x, d.y, d.z};
     return t;
+}
+
+// Two keyframes interpolated: math.Transformation.lerp (transformation.zig:36-44) with quaternion.slerp (quaternion.zig:217-245),
+// the scene origin subtracted after the interpolation (space.zig:121-124), ComposedTransformation.init with
+// quaternion.toMat3x3 (composed_transformation.zig:17-29, quaternion.zig:72-116)
+ZD Trafo interpolateKeyframes(float4 pa, float4 sa, float4 qa, float4 pb, float4 sb, float4 qb, float wgt, f3 origin) {
+    const f3 t3 = S3(wgt);
+    Trafo    out;
+    out.position = lerp3(mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), t3) - origin;
+    out.scale = lerp3(mk3(sa.x, sa.y, sa.z), mk3(sb.x, sb.y, sb.z), t3);
+    const float a[4] = {qa.x, qa.y, qa.z, qa.w};
+    float       end[4] = {qb.x, qb.y, qb.z, qb.w};
+    float       cosom = a[0] * end[0] + a[1] * end[1] + a[2] * end[2] + a[3] * end[3];
+    if (cosom < 0.f) {
+        cosom = -cosom;
+        for (int k = 0; k < 4; ++k) end[k] = -end[k];
+    }
+    float sclp, sclq;
+    if (1.f - cosom > 0.00001f) {
+        const float omega = acosF(cosom), sinom = sinF(omega);
+        sclp = sinF((1.f - wgt) * omega) / sinom;
+        sclq = sinF(wgt * omega) / sinom;
+    } else {
+        sclp = 1.f - wgt;
+        sclq = wgt;
+    }
+    float q[4];
+    for (int k = 0; k < 4; ++k) q[k] = sclp * a[k] + sclq * end[k];
+    const float tq[4] = {q[0] + q[0], q[1] + q[1], q[2] + q[2], q[3] + q[3]};
+    const float xy = tq[1] * q[0], xz = tq[2] * q[0], yz = tq[1] * q[2];
+    const float w0 = tq[0] * q[3], w1 = tq[1] * q[3], w2 = tq[2] * q[3];
+    const float t0 = (q[3] + q[1]) * (q[3] - q[1]), t1 = (q[0] + q[2]) * (q[0] - q[2]);
+    const float t2 = (q[3] + q[0]) * (q[3] - q[0]), t3q = (q[1] + q[2]) * (q[1] - q[2]);
+    out.r0 = mk3(t0 + t1, xy - w2, xz + w1);
+    out.r1 = mk3(xy + w2, t2 + t3q, yz - w0);
+    out.r2 = mk3(xz - w1, yz + w0, t2 - t3q);
+    return out;
+}
+
+// Scene.propTransformationAtMaybeStatic (scene.zig:382-385 -> space.zig:99-137); ANIM: the kernel instantiations that know
+// animated props (the EXTRA / MESHL ones: a scene with an animated prop runs them)
+template <bool ANIM>
+ZD Trafo propTrafoAt(const DScene& s, uint32_t p, uint32_t time) {
+    if (ANIM && s.prop_frames) {
+        const uint32_t f = s.prop_frames[p];
+        if (kNull != f) {
+            const uint32_t tick = uint32_t(705600000ull / 60);  // space.zig:18-19
+            uint32_t       i = time / tick;
+            float          wgt = float(double(time - i * tick) / double(tick));
+            if (i + 1 >= s.num_interpolation_frames) {  // a shutter sample of exactly 1.0: the last keyframe
+                i = s.num_interpolation_frames - 2;
+                wgt = 1.f;
+            }
+            const float4* k = s.keyframes + size_t(f + i) * 3;
+            return interpolateKeyframes(k[0], k[1], k[2], k[3], k[4], k[5], wgt, mk3(s.origin.x, s.origin.y, s.origin.z));
+        }
+    }
+    return loadTrafo(s, p);
 }
 
 // node.zig:73-87; n0 = (min.xyz, children_or_first), n1 = (max.xyz, count)
@@ -581,7 +645,7 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
             if (!propVisibleAtDepth(prop.flags, depth_surface)) continue;
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            const Trafo trafo = loadTrafo(s, p);
+            const Trafo trafo = propTrafoAt<EXTRA>(s, p, ray.time);
             const bool  masked = EXTRA && 0 != (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
@@ -778,7 +842,7 @@ ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
             if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            const Trafo trafo = loadTrafo(s, p);
+            const Trafo trafo = propTrafoAt<EXTRA>(s, p, ray.time);
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) return true;
@@ -864,7 +928,7 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
             if (0 == (prop.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            const Trafo trafo = loadTrafo(s, p);
+            const Trafo trafo = propTrafoAt<true>(s, p, ray.time);  // the POOL / mask kernels: all know animated props
             const bool  evaluate = 0 != (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
@@ -1080,7 +1144,7 @@ ZD void makeFragment(const DScene& s, const Ray& ray, const Hit& hit, Fragment& 
     f.u = hit.u;
     f.v = hit.v;
     f.primitive = hit.primitive;
-    f.trafo = loadTrafo(s, hit.prop);
+    f.trafo = propTrafoAt<EXTRA>(s, hit.prop, ray.time);
     const ZygpuProp prop = s.props[hit.prop];
     if (ZYGPU_SHAPE_RECTANGLE == prop.shape) rectangleFragment(ray, f);
     else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) sphereFragment(ray, f);

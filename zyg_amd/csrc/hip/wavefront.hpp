@@ -120,6 +120,7 @@ struct Pool {  // 16 B records, indexed by path slot
     Rec<float4>   rec_n;    //   shading normal (flipped likewise)
     Rec<float4>   rec_t;    //   tangent
     Rec<float4>   rec_b;    //   bitangent
+    uint32_t* time;     // per camera sample: Probe.time as ticks since the frame's start (written when the scene has animated props)
     uint2*    picks;    // light picks 1.. of the current vertex, [pick][slot]: light, pdf bits (pick 0 never leaves registers)
     float4*   sh_o;     // shadow ray of the running pick: origin.xyz, max_t
     float4*   sh_d;     //   direction.xyz
@@ -334,6 +335,12 @@ template <bool POOL> ZD uint32_t* extQueue(const Params& P, uint32_t side, uint3
 }
 template <bool POOL> ZD QueueCounts* extCount(const Params& P, uint32_t side, uint32_t round) {
     return POOL ? &P.ctl->ext_pool_count[side][round] : &P.ctl->ext_count[side];
+}
+
+// the time of the path a queue entry belongs to, for the instantiations that know animated props (ANIM = EXTRA / MESHL)
+template <bool POOL, bool ANIM>
+ZD uint32_t pathTime(const Params& P, uint32_t vertex) {
+    return (ANIM && c_scene.prop_frames) ? P.pool.time[sampleSlot<POOL>(vertex)] : 0u;
 }
 
 struct Mediums {  // prop/medium.zig:30-153; an entry is its (prop, part): ior, priority and absorption are the material's
@@ -738,6 +745,11 @@ ZD void generatePath(const Params& P, uint32_t slot) {
     P.pool.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.pool.indirect[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.stage_uv[slot] = make_float2(s0, s1);
+    if (AOV && c_scene.prop_frames) {  // AOV = the MESHL instantiations: Probe.time for the animated props (camera_base.zig:129-136)
+        const uint64_t tick = 705600000ull / 60, start_time = uint64_t(c_view.frame) * v.frame_step;
+        const uint64_t fdi = uint64_t(llround(double(shutter_sample) * double(v.frame_duration)));
+        P.pool.time[slot] = uint32_t(fdi + (start_time % tick));
+    }
 }
 
 template <bool POOL>
@@ -794,7 +806,7 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             if (!propVisibleAtDepth(prop.flags, depth_surface)) continue;
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            const Trafo trafo = loadTrafo(s, p);
+            const Trafo trafo = propTrafoAt<EXTRA>(s, p, ray.time);
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) record(p, 0, t, u, v);
@@ -852,6 +864,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
         const uint32_t meta = POOL ? P.pool.vmeta[slot] : P.pool.q0.get(slot).y;
         const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
         Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+        ray.time = pathTime<POOL, EXTRA>(P, slot);
         if (POOL) {
             // inside a dielectric the ray ends where it leaves the medium prop's bounding box
             // (VolumeIntegrator.integrate, volume_integrator.zig:98-103); wf_shade sees the shortened ray
@@ -1014,7 +1027,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
         const uint4     c = P.pool.ucand[at];
         const ZygpuProp prop = s.props[c.x];
         Fragment        frag;
-        frag.trafo = loadTrafo(s, c.x);
+        frag.trafo = propTrafoAt<MESHL>(s, c.x, ray.time);
         frag.prop = c.x;
         frag.t_hit = __uint_as_float(c.y);
         frag.u = __uint_as_float(c.z);
@@ -1059,8 +1072,9 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     const uint32_t hit_prop = hit.prop;
     const bool     has_hit = kNull != hit_prop;
     // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
-    const Ray ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, has_hit ? hit.t : ro.w);
-    const f3  wo = -ray.direction;
+    Ray ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, has_hit ? hit.t : ro.w);
+    ray.time = pathTime<POOL, MESHL>(P, slot);
+    const f3 wo = -ray.direction;
 
     if (!HEAVY) {  // anything that could make connectLight draw or evaluate goes to the heavy pass
         bool emissive = false;
@@ -1277,6 +1291,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
             const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0.get(slot).y;
             const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
             Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+            ray.time = pathTime<false, MESHL>(P, slot);
             Hit            hit;
             if (UTLAS) {
 #if ZYG_FAST
@@ -1331,7 +1346,8 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
         const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
         const uint4    hr = P.pool.hit[slot];
         const Hit      hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
-        const Ray      ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, hit.t);
+        Ray            ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, hit.t);
+        ray.time = pathTime<false, EXTRA>(P, slot);
         Fragment       frag;
         makeFragment<EXTRA>(s, ray, hit, frag);
         const f3             wo = -ray.direction;
@@ -1690,6 +1706,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 float    slen;
                 shadowRay(sorigin, ls, sdir, slen, distant);
                 Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
+                shadow.time = pathTime<POOL, MESHL>(P, slot);
                 tm.mark(2);
                 if (STATS) shadow_rays += 1;
                 f3 tr = S3(1.f);  // POOL: thin Glass lets shadow rays through, attenuated (Scene.visibility's tr)

@@ -597,6 +597,7 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
          m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) &&
          m.alloc(paths, &c->stage_color) && m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) &&
          m.alloc(paths, &p.sh_o) && m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
+         m.alloc(slots, &p.time) &&
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy);
     if (ok && c->pool_mode) {
         ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) &&
@@ -819,6 +820,25 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     bool ok = m.upload(d->props, d->num_props, &s.props);
     ok = ok && m.upload(reinterpret_cast<const float4*>(d->trafos), size_t(d->num_props) * 4, &s.trafos);
     ok = ok && m.upload(reinterpret_cast<const float4*>(d->aabbs), size_t(d->num_props) * 2, &s.aabbs);
+    // animated props: keyframes as 3 float4 each; the kernels that know them are the MESHL / EXTRA instantiations
+    s.keyframes = nullptr;
+    s.prop_frames = nullptr;
+    if (d->keyframes && d->prop_frames && d->num_keyframes) {
+        if (d->num_interpolation_frames < 2) {
+            g_error = "ZygpuSceneDesc: animated props need at least 2 interpolation frames";
+            return -2;
+        }
+        for (uint32_t l = 0; l < d->num_lights; ++l)
+            if (ZYGPU_NULL != d->prop_frames[d->lights[l].prop]) {
+                g_error = "an animated prop is a light: lights must be static";
+                return -2;
+            }
+        ok = ok && m.upload(reinterpret_cast<const float4*>(d->keyframes), size_t(d->num_keyframes) * 3, &s.keyframes) &&
+             m.upload(d->prop_frames, d->num_props, &s.prop_frames);
+        s.origin = make_float4(d->origin[0], d->origin[1], d->origin[2], d->origin[3]);
+        s.num_interpolation_frames = d->num_interpolation_frames;
+        c->mesh_lights = true;
+    }
     ok = ok && m.upload(d->material_ids, d->num_parts, &s.material_ids);
     ok = ok && m.upload(d->light_ids, d->num_parts, &s.light_ids);
     ok = ok && m.upload(d->materials, d->num_materials, &s.materials);
@@ -1027,7 +1047,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             }
             return e;
         };
-        bool ok_solid = d->solid.num_indices > 0 && d->solid.num_indices <= kUniformProps;
+        bool ok_solid = d->solid.num_indices > 0 && d->solid.num_indices <= kUniformProps && !s.prop_frames;  // static props only
         for (uint32_t i = 0; ok_solid && i < d->solid.num_indices; ++i) {
             const uint32_t sh = d->props[d->solid.indices[i]].shape;
             ok_solid = ZYGPU_SHAPE_RECTANGLE == sh || ZYGPU_SHAPE_TRIANGLE_MESH == sh;

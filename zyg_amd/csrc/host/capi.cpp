@@ -51,8 +51,10 @@ bool parse(const char* text, zyg::JsonValue& v) { return text && zyg::JsonParser
 // su_start_frame's body: compile, upload, set view (driver.configure + startFrame, capi.zig:586-605)
 int32_t prepareFrame(uint32_t frame, bool clear) {
     Capi& c = *g;
-    if (0 != c.engine.compile(frame)) {
-        logf(2, "scene uses a feature outside the hot-path scope (volumes, infinite or non-rectangle lights)");
+    const int rc = c.engine.compile(frame);
+    if (0 != rc) {
+        logf(2, -6 == rc ? "a light has keyframes (su_prop_set_transformation_frame): animated lights are not supported"
+                         : "scene uses a feature outside the hot-path scope (scattering volumes, dispersive glass, emission maps on meshes ...)");
         return -1;
     }
     for (const std::string& w : c.engine.warnings()) logf(1, "%s", w.c_str());

@@ -72,6 +72,27 @@ static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& samp
     return true;
 }
 
+// math.Transformation.lerp (transformation.zig:36-44) with quaternion.slerp (quaternion.zig:217-245); host side: bounds only
+static Transformation lerpTransformation(const Transformation& a, const Transformation& b, float t) {
+    Transformation r;
+    r.position = splat(1.f - t) * a.position + splat(t) * b.position;
+    r.scale = splat(1.f - t) * a.scale + splat(t) * b.scale;
+    Vec4f end = b.rotation;
+    float cosom = a.rotation[0] * end[0] + a.rotation[1] * end[1] + a.rotation[2] * end[2] + a.rotation[3] * end[3];
+    if (cosom < 0.f) {
+        cosom = -cosom;
+        end = splat(-1.f) * end;
+    }
+    float sclp = 1.f - t, sclq = t;
+    if (1.f - cosom > 0.00001f) {
+        const float omega = std::acos(cosom), sinom = std::sin(omega);
+        sclp = std::sin((1.f - t) * omega) / sinom;
+        sclq = std::sin(t * omega) / sinom;
+    }
+    r.rotation = splat(sclp) * a.rotation + splat(sclq) * end;
+    return r;
+}
+
 static ZygpuTrafo composedTrafo(const Transformation& t, const Vec4f& origin) {  // composed_transformation.zig:17-29
     const Mat3x3 r = quaternionToMat3x3(t.rotation);
     ZygpuTrafo   out;
@@ -1102,16 +1123,28 @@ uint32_t Engine::prepareMeshLight(uint32_t mesh_id, uint32_t part, uint32_t mate
 }
 
 int Engine::compile(uint32_t frame) {
-    (void)frame;  // static scenes only: every keyframe-free prop ignores time (space.zig:99-108)
+    (void)frame;  // keyframes are relative to the frame's start (space.zig:114-125): the compiled scene is the same for every frame
     if (ZYGPU_NULL == camera_entity) return -1;
 
     // driver.zig:164 -> scene.propWorldPosition (scene.zig:372-380): an animated entity's first keyframe
     const Vec4f    camera_pos = frameStartTransformation(camera_entity).position;
     warnings_.clear();
-    for (uint32_t p = 0; p < keyframes_.size(); ++p)
-        if (!keyframes_[p].empty() && p != camera_entity)
-            warnings_.push_back("prop " + std::to_string(p) + " has keyframes (su_prop_set_transformation_frame): animated props are outside the "
-                                "device path's scope, it is rendered at its transformation at the frame's start (keyframe 0)");
+    // animated props (space.zig:23-26): their keyframes travel with the compiled scene
+    c_keyframes_.clear();
+    c_prop_frames_.assign(props_.size(), ZYGPU_NULL);
+    for (uint32_t p = 0; p < keyframes_.size() && p < props_.size(); ++p) {
+        if (keyframes_[p].empty() || p == camera_entity) continue;
+        c_prop_frames_[p] = uint32_t(c_keyframes_.size());
+        for (const Transformation& k : keyframes_[p]) {
+            ZygpuKeyframe kf;
+            for (int i = 0; i < 4; ++i) {
+                kf.position[i] = k.position[i];
+                kf.scale[i] = k.scale[i];
+                kf.rotation[i] = k.rotation[i];
+            }
+            c_keyframes_.push_back(kf);
+        }
+    }
     const uint32_t np = uint32_t(props_.size());
 
     c_props_.resize(np);
@@ -1147,8 +1180,16 @@ int Engine::compile(uint32_t frame) {
         const Transformation& t = frameStartTransformation(p);
         c_trafos_[p] = composedTrafo(t, camera_pos);
 
-        // space.zig:60-97 (calculateWorldBounds, static branch)
+        // space.zig:60-97 (calculateWorldBounds): static, or the union over the keyframes and 3 steps between each pair
         AABB bounds = aabbTransform(shapeAabb(hp.shape), objectToWorld(t));
+        if (ZYGPU_NULL != c_prop_frames_[p]) {
+            c_props_[p].flags &= ~uint32_t(ZYGPU_PROP_STATIC);  // prop.zig configureAnimated
+            const std::vector<Transformation>& kf = keyframes_[p];
+            for (size_t i = 0; i + 1 < kf.size(); ++i) {
+                for (int j = 1; j < 4; ++j) aabbMerge(bounds, aabbTransform(shapeAabb(hp.shape), objectToWorld(lerpTransformation(kf[i], kf[i + 1], 0.25f * float(j)))));
+                aabbMerge(bounds, aabbTransform(shapeAabb(hp.shape), objectToWorld(kf[i + 1])));
+            }
+        }
         bounds.b[0] = bounds.b[0] + (-camera_pos);
         bounds.b[1] = bounds.b[1] + (-camera_pos);
         aabbCacheRadius(bounds);
@@ -1207,6 +1248,7 @@ int Engine::compile(uint32_t frame) {
             l.light_class = ZYGPU_LIGHT_PROP_IMAGE;
         }
 
+        if (ZYGPU_NULL != c_prop_frames_[l.prop]) return -6;  // an animated light: its bounds, cone and power would move (scene.zig:402-497)
         const Transformation& t = frameStartTransformation(l.prop);
         Transformation        rel = t;
         rel.position = t.position - camera_pos;
@@ -1331,6 +1373,11 @@ int Engine::compile(uint32_t frame) {
     d.num_meshes = uint32_t(c_meshes_.size());
     d.num_materials = uint32_t(materials_.size());
     d.num_lights = nl;
+    d.keyframes = c_keyframes_.empty() ? nullptr : c_keyframes_.data();
+    d.prop_frames = c_keyframes_.empty() ? nullptr : c_prop_frames_.data();
+    d.num_keyframes = uint32_t(c_keyframes_.size());
+    d.num_interpolation_frames = numInterpolationFrames();
+    for (int i = 0; i < 4; ++i) d.origin[i] = camera_pos[i];
 
     // camera.update (camera_perspective.zig:79-122, mono / no focus point)
     ZygpuViewDesc& v = view_desc_;

@@ -119,8 +119,8 @@ class Engine {
     int      setWorldTransformation(uint32_t prop, const Transformation& t);  // the loaders' path (scene_graph.zig:178-230)
     // su_prop_set_transformation_frame (capi.zig:506-533): keyframe `frame` (< numInterpolationFrames()) of the prop.  The
     // camera entity's keyframes drive the camera at every sample's time (ZygpuViewDesc.camera_keyframes); any other prop is
-    // rendered at its transformation at the frame's start and compile() says so in warnings() (animated props are outside the
-    // hot-path scope: the inner ABI carries static transforms only).
+    // carried as keyframes in the compiled scene and interpolated at every ray's time (ZygpuSceneDesc.keyframes); an animated
+    // *light* is refused by compile().
     int      setTransformationFrame(uint32_t prop, uint32_t frame, const float* m16);
     uint32_t numInterpolationFrames() const;  // scene.zig:254-257, 724-734 with the C ABI camera's frame step / duration
     // su_image_update (capi.zig:300-338): new pixels for an existing image, same format and dimensions
@@ -201,6 +201,8 @@ class Engine {
     std::vector<ZygpuProp>    c_props_;
     std::vector<ZygpuTrafo>   c_trafos_;
     std::vector<ZygpuAabb>    c_aabbs_;
+    std::vector<ZygpuKeyframe> c_keyframes_;    // the animated props' keyframes, flattened (ZygpuSceneDesc.keyframes)
+    std::vector<uint32_t>      c_prop_frames_;  // per prop: first keyframe or ZYGPU_NULL
     std::vector<ZygpuMesh>    c_meshes_;
     std::vector<HostImage>    images_;
     std::vector<ZygpuImage>   c_images_;
