@@ -115,14 +115,42 @@ enum ZygpuMaterialFlags {
     ZYGPU_MATF_TWO_SIDED = 1u << 0,
     ZYGPU_MATF_EVALUATE_VISIBILITY = 1u << 1,
     ZYGPU_MATF_CAUSTIC = 1u << 2,
-    ZYGPU_MATF_EMISSIVE = 1u << 3
+    ZYGPU_MATF_EMISSIVE = 1u << 3,
+    /* Substitute with anything beyond the uniform opaque base: a texture in one of `tex`, a normal map, a coating,
+     * translucency, flakes or a rotated tangent frame (set by the host; the device runs its complete closure for it) */
+    ZYGPU_MATF_EXTENDED = 1u << 4
 };
 
 /* Uniform-texture subset of the reference materials (all colours ACES AP1, base/json.zig:247-277).
  * Debug: color_a/color_b = front/back albedo (debug_material.zig:11-12);
  * Substitute: color_a = color, see substitute_material.zig:32-60; emittance: light/emittance.zig:18-27;
- * Glass: dielectric, thick (smooth or rough: roughness) or a thin pane (thickness > 0, smooth); rough thin glass and
- * dispersion (abbe) are refused by zygpu_upload_scene: glass_material.zig:46-115, glass_sample.zig:33-538 */
+ * Glass: dielectric, thick (smooth or rough: roughness) or a thin pane (thickness > 0); dispersion (abbe) is refused by
+ * zygpu_upload_scene: glass_material.zig:46-115, glass_sample.zig:33-538 */
+
+/* A texture of the reference (texture/texture.zig:14-60) that is either uniform (image == ZYGPU_NULL: the material's uniform
+ * field of the same name) or a 2-D image read at the fragment's uv */
+typedef struct ZygpuTexture {
+    uint32_t image;   /* index into ZygpuSceneDesc.images */
+    uint32_t sampler; /* ZYGPU_TEX_* bits */
+    float    scale[2];
+} ZygpuTexture;
+
+/* Substitute's textures beyond the colour map (substitute_material.zig:37-48; one channel each: Byte1 / Float1 images; the
+ * two normal maps: two channels, Byte2 read as snorm or Float2, material_helper.zig:16-20) */
+enum ZygpuSubstituteTexture {
+    ZYGPU_STEX_ROUGHNESS = 0,
+    ZYGPU_STEX_METALLIC,
+    ZYGPU_STEX_SPECULAR,
+    ZYGPU_STEX_ROTATION,
+    ZYGPU_STEX_TRANSLUCENCY,
+    ZYGPU_STEX_COATING_SCALE,
+    ZYGPU_STEX_COATING_ROUGHNESS,
+    ZYGPU_STEX_FLAKES_COVERAGE,
+    ZYGPU_STEX_NORMAL,
+    ZYGPU_STEX_COATING_NORMAL,
+    ZYGPU_STEX_COUNT
+};
+
 typedef struct ZygpuMaterial {
     uint32_t kind;
     uint32_t flags;
@@ -156,16 +184,34 @@ typedef struct ZygpuMaterial {
     uint32_t mask_image;   /* index into ZygpuSceneDesc.images, ZYGPU_NULL = opaque */
     uint32_t mask_sampler; /* ZYGPU_TEX_* bits */
     float    mask_scale[2];
+    /* Substitute beyond the uniform opaque base (substitute_material.zig:37-60, 114-221; material_provider.zig:262-342).
+     * Subsurface scattering (attenuation_distance > 0: a scattering volume) is refused by the host */
+    ZygpuTexture tex[ZYGPU_STEX_COUNT];
+    float    rotation;          /* "anisotropy_rotation", in turns */
+    float    translucency;
+    float    coating_scale;     /* 1 */
+    float    coating_roughness; /* 0.2 */
+    float    coating_thickness; /* 0 = uncoated */
+    float    coating_ior;       /* 1.5 */
+    float    coating_absorption[3]; /* setCoatingAttenuation: ccoef.attenuationCoefficient(color, distance) */
+    float    flakes_coverage;   /* 0 = none */
+    float    flakes_color[3];   /* 0.8 */
+    float    flakes_alpha;      /* setFlakesRoughness: clampRoughness(r)^2, 0.01 */
+    float    flakes_res;        /* setFlakesSize: max(4, ceil(sqrt(1.5396 / size^2 / 4))) */
+    float    attenuation_distance; /* > 0: subsurface scattering, refused (compile returns -7) */
 } ZygpuMaterial;
 
-enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u };
+/* ZYGPU_TEX_SNORM: a Byte2 image read as snorm (byte / 128 - 1, base/encoding.zig:18-20): what usage Normal makes of it
+ * (texture_provider.zig:70) */
+enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u, ZYGPU_TEX_SNORM = 8u };
 
 /* 2-D images behind textures (capi.zig:236-298, texture_provider.zig:67-84): Byte3 is read as sRGB and converted to AP1 per
  * fetch (texture.zig:196-199), Float3 is taken as is (213-216); the one-channel formats serve masks: Byte1 is unorm
  * (byte / 255, texture.zig:170, encoding.zig:23), Float1 as is (172) */
-enum ZygpuImageFormat { ZYGPU_IMAGE_BYTE3_SRGB = 0, ZYGPU_IMAGE_FLOAT3 = 1, ZYGPU_IMAGE_BYTE1_UNORM = 2, ZYGPU_IMAGE_FLOAT1 = 3 };
+enum ZygpuImageFormat { ZYGPU_IMAGE_BYTE3_SRGB = 0, ZYGPU_IMAGE_FLOAT3 = 1, ZYGPU_IMAGE_BYTE1_UNORM = 2, ZYGPU_IMAGE_FLOAT1 = 3,
+                        ZYGPU_IMAGE_BYTE2 = 4, ZYGPU_IMAGE_FLOAT2 = 5 }; /* two channels: normal maps (texture.zig:177-186) */
 typedef struct ZygpuImage {
-    const void* pixels; /* row-major, 1 or 3 bytes or floats per pixel */
+    const void* pixels; /* row-major, 1 to 3 bytes or floats per pixel */
     int32_t     width, height;
     uint32_t    format;
 } ZygpuImage;

@@ -110,6 +110,7 @@ inline float pow5(float x) {
     return x4 * x;
 }
 inline V4    schlick(V4 f0, float wo_dot_h) { return fma4(S(pow5(1.f - wo_dot_h)), S(1.f) - f0, f0); }
+inline float schlick1(float wo_dot_h, float f0) { return std::fmaf(pow5(1.f - wo_dot_h), 1.f - f0, f0); }  // fresnel.zig:5-7
 inline float iorToF0(float n0, float n1) {
     const float t = (n0 - n1) / (n0 + n1);
     return t * t;
@@ -351,6 +352,43 @@ struct MaterialSample {
     V4    absorption;
     float ior, ior_outside, glass_f0, thickness;
     bool  lower_priority;
+    // Substitute: clearcoat (substitute_coating.zig:15-113) and flakes (sample_base.zig:17)
+    struct Coating {
+        V4    n, absorption_coef;
+        float thickness = 0.f, f0, alpha, weight;
+        struct Result {
+            V4    reflection, attenuation;
+            float f, pdf;
+        };
+        V4 singleAttenuation(float n_dot_wo) const { return attenuation3(absorption_coef, thickness * (1.f / n_dot_wo)); }  // :97-105
+        V4 attenuation(float n_dot_wi, float n_dot_wo) const {  // :107-113
+            const float f = weight * fresnel::schlick1(mn(n_dot_wi, n_dot_wo), f0);
+            const float d = thickness * (1.f / n_dot_wi + 1.f / n_dot_wo);
+            return S(1.f - f) * attenuation3(absorption_coef, d);
+        }
+        Result evaluate(const Luts& L, V4 wi, V4 wo, V4 h, float wo_dot_h, float specular_threshold, bool avoid_caustics) const {  // :35-56
+            const float n_dot_wi = clampDot(n, wi), n_dot_wo = clampAbsDot(n, wo);
+            const V4    att = attenuation(n_dot_wi, n_dot_wo);
+            if (avoid_caustics && alpha <= specular_threshold) return {S(0.f), att, 0.f, 0.f};
+            const ggx::ResultF gg = ggx::reflectionF(h, n, n_dot_wi, n_dot_wo, wo_dot_h, alpha, f0);
+            const float        ep = L.ilmEpDielectric(n_dot_wo, alpha, f0);
+            return {S(ep * weight * n_dot_wi) * gg.r.reflection, att, gg.f, gg.r.pdf};
+        }
+        V4 reflect(const Luts& L, V4 wo, V4 h, float n_dot_wo, float n_dot_h, float wo_dot_h, float specular_threshold,
+                   BxdfSample& result) const {  // :58-85
+            const float n_dot_wi = ggx::reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, alpha, specular_threshold, Frame::init(n), result);
+            const float ep = L.ilmEpDielectric(n_dot_wo, alpha, f0);
+            result.reflection *= S(ep * weight * n_dot_wi);
+            return attenuation(n_dot_wi, n_dot_wo);
+        }
+        ggx::Micro sample(V4 wo, float xi0, float xi1, float& n_dot_h) const {  // :87-95: n_dot_wi carries the Fresnel term
+            const float a[2] = {alpha, alpha};
+            const V4    h = ggx::anisoSample(wo, a, xi0, xi1, Frame::init(n), n_dot_h);
+            const float wo_dot_h = clampDot(wo, h);
+            return {h, fresnel::schlick1(wo_dot_h, f0), wo_dot_h};
+        }
+    } coating;
+    bool flakes = false;
 
     bool sameHemisphere(V4 v) const { return dot3(geo_n, v) > 0.f; }
 
@@ -371,13 +409,28 @@ struct MaterialSample {
             return {S(n_dot_wi) * d.reflection, dw * d.pdf};
         }
         const float      s = specular;
+        if (flakes) {  // substitute_sample.zig:265-271: a flake reflects into a cone around the mirror direction
+            const float cos_cone = alpha[0];
+            const V4    r = reflect3(frame.z, woo);
+            const float f = dot3(wi, r) > cos_cone ? 1.f / solidAngleOfCone(cos_cone) : 0.f;
+            return {S(n_dot_wi * f * s) * f0, f};
+        }
         const BxdfResult gg = ggx::reflection(wi, woo, h, n_dot_wi, n_dot_wo, wo_dot_h, alpha, f0, frame);
         const V4         mms = ggx::dspbrMicroEc(luts, f0, n_dot_wi, n_dot_wo, alpha[1]);
         const float      pdf = dw * d.pdf + (1.f - dw) * gg.pdf;
         return {S(n_dot_wi) * (d.reflection + S(s) * (gg.reflection + mms)), pdf};
     }
 
-    void diffuseSample(float diffuse_weight, float xi0, float xi1, BxdfSample& result) const {
+    static float diffuseFresnelHack(float n_dot_wi, float n_dot_wo, float f0_) {  // substitute_sample.zig:440-442
+        return fresnel::schlick1(mx(n_dot_wi, n_dot_wo), f0_);
+    }
+
+    float diffuseWeight() const {  // the estimate shared by baseSample / coatingSample (substitute_sample.zig:284-294, 316-326)
+        if (1.f == metallic) return 0.f;
+        return diffuse_micro::estimateContribution(luts, alpha[1], hmax3(f0), hmax3(albedo));
+    }
+
+    ggx::Micro diffuseSample(float diffuse_weight, float xi0, float xi1, BxdfSample& result) const {
         const float      n_dot_wo = frame.clampAbsNdot(wo);
         const V4         alb = S(opacity) * albedo;
         const float      f0m = hmax3(f0);
@@ -387,10 +440,25 @@ struct MaterialSample {
         const float      s = specular;
         result.reflection = S(micro.n_dot_wi) * (result.reflection + S(s) * (gg.reflection + mms));
         result.pdf = diffuse_weight * result.pdf + (1.f - diffuse_weight) * gg.pdf;
+        return micro;
     }
 
-    void glossSample(float diffuse_weight, float xi0, float xi1, BxdfSample& result) const {
+    ggx::Micro glossSample(float diffuse_weight, float xi0, float xi1, BxdfSample& result) const {
         const float      s = specular;
+        if (flakes) {  // substitute_sample.zig:376-396
+            const float cos_cone = alpha[0];
+            const V4    wi_l = coneUniform(xi0, xi1, cos_cone);
+            const V4    h = reflect3(frame.z, wo);
+            const V4    wi = Frame::init(h).frameToWorld(wi_l);
+            const float wi_dot_h = clampDot(wi, h);
+            const float f = wi_dot_h > cos_cone ? 1.f / solidAngleOfCone(cos_cone) : 0.f;
+            const float n_dot_wi = frame.clampNdot(wi);
+            result.reflection = S(n_dot_wi * f * s) * f0;
+            result.wi = wi;
+            result.pdf = f;
+            result.path = PathInfo::reflection(alpha[1], specular_threshold);
+            return {h, n_dot_wi, wi_dot_h};
+        }
         const float      n_dot_wo = frame.clampAbsNdot(wo);
         const ggx::Micro micro = ggx::reflect(wo, n_dot_wo, alpha, specular_threshold, xi0, xi1, f0, frame, result);
         const V4         mms = ggx::dspbrMicroEc(luts, f0, micro.n_dot_wi, frame.clampNdot(wo), alpha[1]);
@@ -402,6 +470,41 @@ struct MaterialSample {
         }
         result.reflection = S(micro.n_dot_wi) * (S(s) * (result.reflection + mms) + d.reflection);
         result.pdf = (1.f - diffuse_weight) * result.pdf + diffuse_weight * d.pdf;
+        return micro;
+    }
+
+    void baseSample(Sampler& sampler, BxdfSample& result) const {  // substitute_sample.zig:281-302
+        const float dw = diffuseWeight();
+        float       s3[3];
+        sampler.sample3D(s3);
+        if (s3[0] < dw) diffuseSample(dw, s3[1], s3[2], result);
+        else glossSample(dw, s3[1], s3[2], result);
+    }
+
+    // substitute_sample.zig:304-336, coatingReflect 412-422, coatingBaseSample 426-433
+    void coatingSample(Sampler& sampler, BxdfSample& result) const {
+        float s2[2];
+        sampler.sample2D(s2);
+        float            coat_n_dot_h;
+        const ggx::Micro micro = coating.sample(wo, s2[0], s2[1], coat_n_dot_h);
+        const float      f = micro.n_dot_wi;
+        float            s3[3];
+        sampler.sample3D(s3);
+        const float p = s3[0];
+        if (p <= f) {
+            const float n_dot_wo = clampAbsDot(coating.n, wo);
+            const V4    coating_attenuation = coating.reflect(luts, wo, micro.h, n_dot_wo, coat_n_dot_h, micro.h_dot_wi, specular_threshold, result);
+            const BxdfResult base_result = baseEvaluate(result.wi, wo, micro.h, micro.h_dot_wi, false);
+            result.reflection = (result.reflection * S(f)) + coating_attenuation * base_result.reflection;
+            result.pdf = f * result.pdf + (1.f - f) * base_result.pdf;
+        } else {
+            const float      dw = diffuseWeight();
+            const float      p1 = (p - f) / (1.f - f);
+            const ggx::Micro bm = p1 < dw ? diffuseSample(dw, s3[1], s3[2], result) : glossSample(dw, s3[1], s3[2], result);
+            const Coating::Result c = coating.evaluate(luts, result.wi, wo, bm.h, bm.h_dot_wi, specular_threshold, avoid_caustics);
+            result.reflection = c.attenuation * result.reflection + c.reflection;
+            result.pdf = (1.f - f) * result.pdf + f * c.pdf;
+        }
     }
 
     // ---- dispatch: material_sample.zig:47-60 ----
@@ -538,11 +641,29 @@ struct MaterialSample {
             const float pdf = n_dot_wi * kPiInv;
             return {S(pdf) * albedo, pdf};
         }
-        // Substitute.evaluate (opaque, uncoated): substitute_sample.zig:88-145
-        if (!sameHemisphere(wo)) return {S(0.f), 0.f};
+        // Substitute.evaluate: substitute_sample.zig:88-145 (exit_sss / volumetric: subsurface scattering, out of scope)
+        const float op = opacity;
+        const bool  thin = op < 1.f;  // `translucent` there
+        if (thin) {
+            if (!sameHemisphere(wi)) {
+                const float n_dot_wi = frame.clampAbsNdot(wi), n_dot_wo = frame.clampAbsNdot(wo);
+                const float f = diffuseFresnelHack(n_dot_wi, n_dot_wo, f0[0]);
+                const float pdf = n_dot_wi * ((1.f - op) * kPiInv);
+                return {S(pdf * (1.f - f)) * albedo, pdf};
+            }
+        } else if (!sameHemisphere(wo)) {
+            return {S(0.f), 0.f};
+        }
         const V4    h = normalize3(wo + wi);
         const float wo_dot_h = clampDot(wo, h);
-        return baseEvaluate(wi, wo, h, wo_dot_h, force_disable_caustics);
+        BxdfResult  base_result = baseEvaluate(wi, wo, h, wo_dot_h, force_disable_caustics);
+        if (thin) base_result.pdf *= op;
+        if (coating.thickness > 0.f) {
+            const Coating::Result c = coating.evaluate(luts, wi, wo, h, wo_dot_h, specular_threshold, force_disable_caustics || avoid_caustics);
+            const float           pdf = c.f * c.pdf + (1.f - c.f) * base_result.pdf;
+            return {c.reflection + c.attenuation * base_result.reflection, pdf};
+        }
+        return base_result;
     }
 
     // Glass.specularSample, thick (glass_sample.zig:165-254); `split`: both the reflected and the refracted direction,
@@ -627,24 +748,134 @@ struct MaterialSample {
             result.path = PathInfo::diffuseReflection();
             return 1;
         }
-        // Substitute.sample (opaque, uncoated): substitute_sample.zig:147-234 -> baseSample 281-302
-        if (!sameHemisphere(wo)) return 0;
+        // Substitute.sample: substitute_sample.zig:147-234 (exit_sss / volumetric: subsurface scattering, out of scope)
         result.split_weight = 1.f;
         result.wavelength = 0.f;
-        float dw = 0.f;
-        if (1.f != metallic) {
-            const float n_dot_wo = frame.clampAbsNdot(wo);
-            dw = diffuse_micro::estimateContribution(luts, alpha[1], hmax3(f0), hmax3(albedo));
-            (void)n_dot_wo;
+        const float op = opacity;
+        if (op < 1.f) {  // translucent: diffuse transmission with probability 1 - opacity (:184-208)
+            const float tr = 1.f - op;
+            float       s3[3];
+            sampler.sample3D(s3);
+            if (s3[0] <= tr) {
+                float s2d[2];
+                sampler.sample2D(s2d);  // diffuse.Lambert.reflect (diffuse.zig:14-29)
+                const V4    is = hemisphereCosine(s2d[0], s2d[1]);
+                const V4    wi = normalize3(frame.frameToWorld(is));
+                const float n_dot_wi = frame.clampNdot(wi);
+                const float n_dot_wo = frame.clampAbsNdot(wo);
+                const float f = diffuseFresnelHack(n_dot_wi, n_dot_wo, f0[0]);
+                result.wi = -wi;
+                result.reflection = (S(kPiInv) * albedo) * S(tr * n_dot_wi * (1.f - f));
+                result.pdf = (n_dot_wi * kPiInv) * tr;
+                result.path = PathInfo::diffuseReflection();
+            } else {
+                baseSample(sampler, result);
+                result.pdf *= op;
+            }
+            return 1;
         }
-        float s3[3];
-        sampler.sample3D(s3);
-        if (s3[0] < dw) diffuseSample(dw, s3[1], s3[2], result);
-        else glossSample(dw, s3[1], s3[2], result);
+        if (!sameHemisphere(wo)) return 0;
+        if (coating.thickness > 0.f) coatingSample(sampler, result);
+        else baseSample(sampler, result);
         if (0.f == result.pdf) return 0;
         return 1;
     }
 };
+
+// hlp.sampleNormal (material_helper.zig:16-78), tex_coord UV0: the normal map's xy in the tangent frame, z reconstructed, then the
+// "iray" adaption that keeps the reflection of wo above the geometric surface
+inline V4 sampleNormal(const ZygpuSceneDesc& scene, const ZygpuTexture& map, V4 wo, const Renderstate& rs) {
+    float nmxy[2];
+    sampleImageMap2(scene, map.image, map.sampler, map.scale, rs.uvw[0], rs.uvw[1], rs.stochastic_r, nmxy);
+    const float nmz = std::sqrt(mx(1.f - (nmxy[0] * nmxy[0] + nmxy[1] * nmxy[1]), 0.01f));
+    // rs.tangentToWorld (renderstate.zig:51-58)
+    const V4 n = normalize3(mk(nmxy[0] * rs.t[0] + nmxy[1] * rs.b[0] + nmz * rs.n[0], nmxy[0] * rs.t[1] + nmxy[1] * rs.b[1] + nmz * rs.n[1],
+                               nmxy[0] * rs.t[2] + nmxy[1] * rs.b[2] + nmz * rs.n[2]));
+    const V4    ng = rs.geo_n;
+    const V4    r = reflect3(n, wo);
+    const float a = dot3(ng, r);
+    if (a >= 0.f) return n;
+    const float cos_threshold = 0.0017453f;  // cos(89.9 degrees)
+    if (dot3(ng, wo) < cos_threshold) return ng;
+    const float b = dot3(ng, n);
+    const float epsilon = 1e-4f;
+    V4          tangent;
+    if (b > epsilon) {
+        const float distance_to_surface_along_normal = std::fabs(a) / b;
+        tangent = normalize3(r + S(distance_to_surface_along_normal) * n);
+    } else {
+        tangent = n;
+    }
+    tangent += S(epsilon) * ng;
+    return normalize3(wo + tangent);
+}
+
+// hlp.triplanarMapping (material_helper.zig:81-93); p and n in object space
+inline void triplanarMapping(V4 p, V4 n, float uv[2]) {
+    const float an[3] = {std::fabs(n[0]), std::fabs(n[1]), std::fabs(n[2])};
+    if (an[0] > an[1] && an[0] > an[2]) {
+        const float sign = std::copysign(1.f, n[0]);
+        uv[0] = sign * p[2] + 0.5f;
+        uv[1] = -p[1] + 0.5f;
+    } else if (an[1] > an[0] && an[1] > an[2]) {
+        const float sign = std::copysign(1.f, n[1]);
+        uv[0] = sign * p[0] + 0.5f;
+        uv[1] = -p[2] + 0.5f;
+    } else {
+        const float sign = std::copysign(1.f, n[2]);
+        uv[0] = -sign * p[0] + 0.5f;
+        uv[1] = -p[1] + 0.5f;
+    }
+}
+
+// Material.sampleFlake (substitute_material.zig:235-273): four flakes per cell of a res x res grid, each with its own PCG stream
+// (base/random/generator.zig:49-93 SingleGenerator: increment 1); the nearest flake centre owns the point, and it exists with
+// probability `coverage`.  Returns the flake's 2-D number (which fixes its orientation).
+inline bool sampleFlake(const float uv[2], float res, float coverage, float xi_out[2]) {
+    const int32_t i = int32_t(res * (uv[0] - std::floor(uv[0]))), j = int32_t(res * (uv[1] - std::floor(uv[1])));  // gridCell: @mod(uv, 1)
+    const float   suv[2] = {res * uv[0], res * uv[1]};
+    float         nearest_d = std::numeric_limits<float>::max(), nearest_r = 0.f, nearest_xi[2] = {0.f, 0.f};
+    for (int32_t ii = i - 1; ii <= i + 1; ++ii) {
+        for (int32_t jj = j - 1; jj <= j + 1; ++jj) {
+            uint64_t state = 0;  // SingleGenerator.start(fuse(ii, jj))
+            auto     advance = [&]() {
+                const uint64_t old = state;
+                state = old * 6364136223846793005ull + 1ull;
+                const uint32_t xrs = uint32_t(((old >> 18) ^ old) >> 27);
+                const uint32_t rot = uint32_t(old >> 59);
+                return (xrs >> rot) | (xrs << ((0u - rot) & 31u));
+            };
+            auto randomFloat = [&]() {
+                uint32_t bits = (advance() & 0x007FFFFFu) | 0x3F800000u;
+                float    f;
+                std::memcpy(&f, &bits, 4);
+                return f - 1.f;
+            };
+            advance();
+            state += (uint64_t(uint32_t(ii)) << 32) | uint64_t(uint32_t(jj));
+            advance();
+            for (uint32_t fl = 0; fl < 4; ++fl) {
+                const float px = float(ii) + randomFloat(), py = float(jj) + randomFloat();
+                const float x0 = randomFloat(), x1 = randomFloat();
+                const float r = randomFloat();
+                const float dx = suv[0] - px, dy = suv[1] - py;
+                const float vcd = dx * dx + dy * dy;  // squaredLength2
+                if (vcd < nearest_d) {
+                    nearest_d = vcd;
+                    nearest_r = r;
+                    nearest_xi[0] = x0;
+                    nearest_xi[1] = x1;
+                }
+            }
+        }
+    }
+    if (nearest_r < coverage) {
+        xi_out[0] = nearest_xi[0];
+        xi_out[1] = nearest_xi[1];
+        return true;
+    }
+    return false;
+}
 
 // Material.sample (material.zig:184-194) for the kinds in scope
 inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDesc& scene, V4 wo, const Renderstate& rs) {
@@ -686,9 +917,15 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.specular = m.specular;
         s.lower_priority = m.priority < rs.highest_priority;  // sample_base.zig:44
     } else {
-        // substitute_material.zig:114-221 (uniform values, no coating / flakes / normal map / rotation)
+        // Substitute.sample (substitute_material.zig:114-221) without the volumetric branches
+        auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
+            const ZygpuTexture& t = m.tex[slot];
+            return kNull != t.image ? sampleImageMap1(scene, t.image, t.sampler, t.scale, rs.uvw[0], rs.uvw[1], rs.stochastic_r) : uniform;
+        };
         const V4    color = kNull != m.color_image ? sampleColorMap(scene, m, rs.uvw[0], rs.uvw[1], rs.stochastic_r) : ld3(m.color_a);
-        const float roughness = ggx::clampRoughness(m.roughness);
+        const float roughness = ggx::clampRoughness(weight(ZYGPU_STEX_ROUGHNESS, m.roughness));
+        const float metallic = weight(ZYGPU_STEX_METALLIC, m.metallic);
+        const float specular = weight(ZYGPU_STEX_SPECULAR, m.specular);
         float       alpha[2];
         if (m.anisotropy > 0.f) {  // anisotropicAlpha, substitute_material.zig:298-305
             const float rv = ggx::clampRoughness(roughness * (1.f - m.anisotropy));
@@ -697,19 +934,76 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         } else {
             alpha[0] = alpha[1] = roughness * roughness;
         }
-        const float ior = m.ior, ior_outer = rs.ior, ior_medium = rs.ior;
+        const float coating_scale = weight(ZYGPU_STEX_COATING_SCALE, m.coating_scale);
+        const float coating_thickness = coating_scale * m.coating_thickness;
+        const float coating_weight = coating_scale > 0.1f ? 1.f : coating_scale;
+        const float coating_ior = lerpf(rs.ior, m.coating_ior, coating_weight);
+        const float ior = m.ior, ior_outer = coating_thickness > 0.f ? coating_ior : rs.ior, ior_medium = rs.ior;
+        const float translucency = weight(ZYGPU_STEX_TRANSLUCENCY, m.translucency);
         // Surface.init (substitute_sample.zig:38-86); regularizeAlpha is the identity for reg_weight == 0
-        s.albedo = S(1.f - m.metallic) * color;
+        s.albedo = S(1.f - metallic) * color;
         s.alpha[0] = alpha[0];
         s.alpha[1] = alpha[1];
         s.can_evaluate = ior != ior_medium;
+        s.translucent = translucency > 0.f;
         const float f0 = fresnel::iorToF0(ior, ior_outer);
-        s.f0 = lerp4(S(f0), color, S(m.metallic));
-        s.metallic = m.metallic;
-        s.specular = m.specular;
+        s.f0 = lerp4(S(f0), color, S(metallic));
+        s.metallic = metallic;
+        s.specular = specular;
         s.specular_threshold = scene.specular_threshold;
-        s.opacity = 1.f - (0.5f * 0.f);
-        s.frame = {rs.t, rs.b, rs.n};
+        s.opacity = 1.f - (0.5f * translucency);
+        if (kNull != m.tex[ZYGPU_STEX_NORMAL].image) s.frame = Frame::init(sampleNormal(scene, m.tex[ZYGPU_STEX_NORMAL], wo, rs));
+        else s.frame = {rs.t, rs.b, rs.n};
+        if (coating_thickness > 0.f) {  // substitute_material.zig:164-181
+            const ZygpuTexture &nm = m.tex[ZYGPU_STEX_NORMAL], &cnm = m.tex[ZYGPU_STEX_COATING_NORMAL];
+            // Texture.equal: the same description (two uniform maps are equal, too)
+            const bool same = nm.image == cnm.image && (kNull == nm.image || (nm.sampler == cnm.sampler && nm.scale[0] == cnm.scale[0] && nm.scale[1] == cnm.scale[1]));
+            if (same) s.coating.n = s.frame.z;
+            else if (kNull != cnm.image) s.coating.n = sampleNormal(scene, cnm, wo, rs);
+            else s.coating.n = rs.n;
+            const float r = ggx::clampRoughness(weight(ZYGPU_STEX_COATING_ROUGHNESS, m.coating_roughness));
+            s.coating.absorption_coef = ld3(m.coating_absorption);
+            s.coating.thickness = coating_thickness;
+            s.coating.f0 = fresnel::iorToF0(coating_ior, rs.ior);
+            s.coating.alpha = r * r;
+            s.coating.weight = coating_weight;
+        }
+        // the rotation applies to the base frame only, after the coating took its normal
+        const float rotation = weight(ZYGPU_STEX_ROTATION, m.rotation) * (2.f * kPi);
+        if (rotation > 0.f) {  // Frame.rotateTangenFrame (frame.zig:64-73)
+            const V4 t = s.frame.x, b = s.frame.y;
+            const V4 sin_a = S(sinF(rotation)), cos_a = S(cosF(rotation));
+            s.frame.x = cos_a * t + sin_a * b;
+            s.frame.y = -sin_a * t + cos_a * b;
+        }
+        const float flakes_coverage = weight(ZYGPU_STEX_FLAKES_COVERAGE, m.flakes_coverage);
+        if (flakes_coverage > 0.f) {  // substitute_material.zig:190-215
+            const V4 op = rs.trafo.worldToObjectNormal(rs.p - rs.trafo.position);
+            const V4 on = rs.trafo.worldToObjectNormal(s.frame.z);
+            float    uv[2];
+            triplanarMapping(op, on, uv);
+            uv[0] -= std::floor(uv[0]);  // math.frac
+            uv[1] -= std::floor(uv[1]);
+            float xi[2];
+            if (sampleFlake(uv, m.flakes_res, flakes_coverage, xi)) {
+                const float fa = m.flakes_alpha;
+                // flakesA2cone (substitute_material.zig:222-227): the cone of 7 degrees bounds the flake's lobe
+                const float target_angle = solidAngleOfCone(0.992546151641322f);  // cos(7 degrees)
+                const float limit = target_angle / ((4.f * kPi) - target_angle);
+                const float a2_cone = mn(limit, 0.5f * fa);
+                const float fa2 = fa - a2_cone;
+                const float cos_cone = 1.f - (2.f * a2_cone) / (1.f + a2_cone);
+                const float a[2] = {fa2, fa2};
+                float       n_dot_h;
+                const V4    mh = ggx::anisoSample(wo, a, xi[0], xi[1], s.frame, n_dot_h);
+                s.metallic = 1.f;
+                s.f0 = ld3(m.flakes_color);
+                s.alpha[0] = cos_cone;
+                s.alpha[1] = a2_cone;
+                s.frame = Frame::init(mh);
+                s.flakes = true;
+            }
+        }
     }
     return s;
 }

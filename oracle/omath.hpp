@@ -364,6 +364,16 @@ struct Frame {  // frame.zig:5-69
     float nDot(V4 v) const { return dot3(z, v); }
 };
 
+inline V4    reflect3(V4 n, V4 v) { return S(2.f * dot3(v, n)) * n - v; }      // vector4.zig:94-96
+inline float solidAngleOfCone(float c) { return (2.f * kPi) * (1.f - c); }  // math.zig:218-220
+inline V4    coneUniform(float u0, float u1, float cos_theta_max) {         // sampling.zig:85-94
+    const float cos_theta = (1.f - u0) + (u0 * cos_theta_max);
+    const float sin_theta = std::sqrt(mx(0.f, 1.f - cos_theta * cos_theta));
+    const float phi = u1 * (2.f * kPi);
+    const float sin_phi = sinF(phi), cos_phi = cosF(phi);
+    return mk(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+}
+
 // sampling.zig:8-54
 inline void diskConcentric(float u0, float u1, float& ox, float& oy) {
     const float s0 = (u0 * 2.f) - 1.f, s1 = (u1 * 2.f) - 1.f;

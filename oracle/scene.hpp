@@ -256,6 +256,22 @@ inline float sampleImageMap1(const ZygpuSceneDesc& scene, uint32_t image, uint32
     texelPick(img, sampler, scale, u, v, r, x, y);
     return imageFetch1(img, x, y);
 }
+// ts.sample2D_2 for an image texture (texture.zig:177-186): Byte2 as unorm or, for usage Normal, snorm (base/encoding.zig:10-20)
+inline void sampleImageMap2(const ZygpuSceneDesc& scene, uint32_t image, uint32_t sampler, const float scale[2], float u, float v, float r,
+                            float out[2]) {
+    const ZygpuImage& img = scene.images[image];
+    int               x, y;
+    texelPick(img, sampler, scale, u, v, r, x, y);
+    const size_t i = size_t(y) * size_t(img.width) + size_t(x);
+    if (ZYGPU_IMAGE_BYTE2 == img.format) {
+        const uint8_t* p = static_cast<const uint8_t*>(img.pixels) + 2 * i;
+        for (int c = 0; c < 2; ++c) out[c] = (sampler & ZYGPU_TEX_SNORM) ? std::fmaf(float(p[c]), 1.f / 128.f, -1.f) : float(p[c]) * (1.f / 255.f);
+    } else {
+        const float* p = static_cast<const float*>(img.pixels) + 2 * i;
+        out[0] = p[0];
+        out[1] = p[1];
+    }
+}
 // the traversal's mask draws come from the path's sampler; the trace-only test entry points have none
 inline float maskDraw(Sampler* sampler) { return sampler ? sampler->sample1D() : 0.f; }
 // Base.stochasticOpacity (material_base.zig:44-55): does the closest-hit traversal accept this hit?

@@ -872,3 +872,84 @@ def test_one_shot_render_frame(engine, oracle, scene):
     progressive = engine.download_film(w, h)
     assert np.array_equal(progressive, oracle_render(oracle, sd, vd, spp))
     assert np.array_equal(progressive[..., 3], one_shot[..., 3]) and not np.array_equal(progressive, one_shot)
+
+
+def _substitute_showcase(engine, which):
+    """Material overrides for the Cornell box that exercise the complete Substitute closure."""
+    S = scenes.substitute_full
+    if "coating" == which:  # clearcoat over diffuse, over metal, thin (scale < 0.1 fades the coating's weight) and tinted
+        return {"tall": S((0.8, 0.2, 0.1), roughness=0.5, coating={"thickness": 0.1, "ior": 1.6, "roughness": 0.1, "color": [0.9, 0.6, 0.3], "attenuation_distance": 0.2}),
+                "short": S((0.9, 0.8, 0.5), roughness=0.3, metallic=1.0, coating={"thickness": 0.05, "roughness": 0.3}),
+                "floor": S((0.6, 0.6, 0.6), roughness=0.7, coating={"thickness": 0.2, "scale": 0.05, "roughness": 0.02}),
+                "sphere_a": S((0.2, 0.3, 0.8), roughness=0.2, coating={"thickness": 0.02, "roughness": 0.0})}
+    if "translucent" == which:  # leaves: thin two-sided surfaces that pass diffuse light
+        return {"tall": S((0.3, 0.8, 0.2), roughness=0.6, translucency=0.8, two_sided=True),
+                "short": S((0.8, 0.7, 0.2), roughness=0.4, translucency=0.3, two_sided=True),
+                "back": S((0.7, 0.7, 0.7), roughness=0.9, translucency=1.0, two_sided=True)}
+    if "flakes" == which:  # car paint: flakes under a coating, bare flakes, sparse flakes
+        return {"tall": S((0.6, 0.05, 0.05), roughness=0.5, flakes={"coverage": 0.7, "size": 0.02, "roughness": 0.2, "color": [0.9, 0.7, 0.5]},
+                          coating={"thickness": 0.02, "roughness": 0.05}),
+                "short": S((0.1, 0.2, 0.6), roughness=0.4, flakes={"coverage": 1.0, "size": 0.005, "roughness": 0.4}),
+                "floor": S((0.5, 0.5, 0.5), roughness=0.8, flakes={"coverage": 0.2, "size": 0.05, "roughness": 0.1}),
+                "sphere_a": S((0.3, 0.3, 0.3), roughness=0.3, metallic=0.5, flakes={"coverage": 0.5, "size": 0.01, "roughness": 0.3})}
+    if "anisotropy" == which:  # brushed metal with a rotated tangent frame
+        return {"tall": S((0.9, 0.9, 0.9), roughness=0.4, metallic=1.0, anisotropy=0.8, anisotropy_rotation=0.125),
+                "short": S((0.9, 0.6, 0.3), roughness=0.3, metallic=1.0, anisotropy=0.5, anisotropy_rotation=0.7),
+                "sphere_a": S((0.8, 0.8, 0.9), roughness=0.5, metallic=1.0, anisotropy=0.9, anisotropy_rotation=0.3)}
+    if "textures" == which:  # every weight from an image, normal maps (snorm bytes and floats), a coating with its own normal map
+        rough = engine.image(scenes.weight_image(8, 0.05, 0.9))
+        metal = engine.image(scenes.weight_image(4, 0.0, 1.0, np.uint8))
+        spec = engine.image(scenes.weight_image(5, 0.2, 1.0))
+        rot = engine.image(scenes.weight_image(6, 0.0, 1.0))
+        trans = engine.image(scenes.weight_image(7, 0.0, 0.9))
+        cscale = engine.image(scenes.weight_image(6, 0.0, 1.0))
+        crough = engine.image(scenes.weight_image(5, 0.01, 0.5, np.uint8))
+        cover = engine.image(scenes.weight_image(9, 0.0, 1.0))
+        n8 = engine.image(scenes.normal_image(16, 0.5, np.uint8))
+        n32 = engine.image(scenes.normal_image(8, 0.3, np.float32))
+        color = engine.image(scenes.checker_image(8, np.uint8))
+        T = scenes.tex
+        near = {"filter": "Nearest", "address": "Clamp"}
+        return {"floor": S(T(color, "Color"), roughness=T(rough), metallic=T(metal, sampler=near), specular=T(spec, scale=[3.0, 2.0]),
+                           normal=T(n8, "Normal", scale=4.0)),
+                "tall": S((0.7, 0.7, 0.7), roughness=T(rough, scale=2.0), metallic=1.0, anisotropy=0.6, anisotropy_rotation=T(rot),
+                          normal=T(n32, "Normal", sampler=near)),
+                "short": S((0.2, 0.5, 0.8), roughness=0.5, normal=T(n8, "Normal"),
+                           coating={"thickness": 0.1, "scale": T(cscale), "roughness": T(crough), "normal": T(n32, "Normal", scale=2.0)}),
+                "back": S((0.6, 0.6, 0.5), roughness=0.8, translucency=T(trans), two_sided=True),
+                "left": S((0.6, 0.1, 0.1), roughness=0.5, normal=T(n8, "Normal"), coating={"thickness": 0.05, "normal": T(n8, "Normal")}),
+                "sphere_a": S((0.4, 0.4, 0.4), roughness=0.4, flakes={"coverage": T(cover), "size": 0.01, "roughness": 0.2})}
+    raise ValueError(which)
+
+
+@pytest.mark.parametrize("integrator,which", [("PTMIS", "coating"), ("PTDL", "coating"), ("PT", "coating"), ("PTMIS", "translucent"),
+                                              ("PTDL", "translucent"), ("PTMIS", "flakes"), ("PT", "flakes"), ("PTMIS", "anisotropy"),
+                                              ("PTMIS", "textures"), ("PTDL", "textures")])
+def test_substitute_complete_closure(engine, oracle, integrator, which):
+    """Substitute beyond the opaque uniform base (substitute_material.zig:114-221, substitute_sample.zig:88-433,
+    substitute_coating.zig): clearcoat, translucency, flakes, rotated anisotropy, textured weights and normal maps; boxes
+    (meshes with uvs), Rectangles and a Sphere carry the materials."""
+    ov = _substitute_showcase(engine, which)
+    out = _render_both(engine, oracle, 88, 66, 4, integrator=integrator, material="substitute", spheres=True, overrides=ov)
+    _check(*out, 4)
+    # the closure changes the picture: the same scene with plain Substitute in those places differs
+    engine.release()
+    engine.__init__(engine.lib)
+    plain = _render_both(engine, oracle, 88, 66, 4, stats=False, integrator=integrator, material="substitute", spheres=True)
+    assert rms(out[1], plain[1]) > 0.01
+
+
+def test_substitute_complete_closure_next_to_glass(engine, oracle):
+    """The pool kernels (path splitting at Glass) rebuild the extended closure from their hit record (uv and transformation)."""
+    ov = _substitute_showcase(engine, "textures")
+    ov.update({k: v for k, v in _substitute_showcase(engine, "flakes").items() if k in ("tall",)})
+    glass = {"box": scenes.glass(1.5, (0.8, 0.9, 1.0), 0.5), "sphere": scenes.glass(1.45, roughness=0.2)}
+    out = _render_both(engine, oracle, 80, 60, 3, integrator="PTMIS", material="substitute", glass_objects=glass, overrides=ov)
+    _check(*out, 3)
+
+
+def test_subsurface_substitute_is_refused(engine):
+    """attenuation_distance > 0 makes Substitute a scattering volume (substitute_material.zig:71-74): out of scope, loudly."""
+    scenes.cornell(engine, 16, 16, 1, material="substitute",
+                   overrides={"tall": scenes.substitute_full((0.8, 0.5, 0.4), attenuation_distance=0.1, attenuation_color=[0.9, 0.3, 0.2])})
+    assert engine.lib.su_ext_compile(0) != 0

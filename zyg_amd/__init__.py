@@ -45,6 +45,13 @@ class Mesh(ctypes.Structure):
                 ("num_triangles", ctypes.c_uint32), ("num_vertices", ctypes.c_uint32), ("num_parts", ctypes.c_uint32)]
 
 
+class Texture(ctypes.Structure):
+    _fields_ = [("image", ctypes.c_uint32), ("sampler", ctypes.c_uint32), ("scale", ctypes.c_float * 2)]
+
+
+STEX_COUNT = 10  # enum ZygpuSubstituteTexture
+
+
 class Material(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("color_a", ctypes.c_float * 3),
                 ("color_b", ctypes.c_float * 3), ("roughness", ctypes.c_float), ("metallic", ctypes.c_float),
@@ -55,7 +62,12 @@ class Material(ctypes.Structure):
                 ("absorption", ctypes.c_float * 3), ("thickness", ctypes.c_float), ("abbe", ctypes.c_float),
                 ("priority", ctypes.c_int32), ("emission_image", ctypes.c_uint32), ("emission_sampler", ctypes.c_uint32),
                 ("emission_scale", ctypes.c_float * 2),
-                ("mask_image", ctypes.c_uint32), ("mask_sampler", ctypes.c_uint32), ("mask_scale", ctypes.c_float * 2)]
+                ("mask_image", ctypes.c_uint32), ("mask_sampler", ctypes.c_uint32), ("mask_scale", ctypes.c_float * 2),
+                ("tex", Texture * STEX_COUNT), ("rotation", ctypes.c_float), ("translucency", ctypes.c_float),
+                ("coating_scale", ctypes.c_float), ("coating_roughness", ctypes.c_float), ("coating_thickness", ctypes.c_float),
+                ("coating_ior", ctypes.c_float), ("coating_absorption", ctypes.c_float * 3), ("flakes_coverage", ctypes.c_float),
+                ("flakes_color", ctypes.c_float * 3), ("flakes_alpha", ctypes.c_float), ("flakes_res", ctypes.c_float),
+                ("attenuation_distance", ctypes.c_float)]
 
 
 class Image(ctypes.Structure):
@@ -293,12 +305,13 @@ class Engine:
 
     def image(self, pixels):
         """su_image_create (capi.zig:236-298) for an (H, W, 3) array: uint8 (read as sRGB) or float32 (taken as is); an
-        (H, W) or (H, W, 1) array makes a one-channel image (masks: uint8 = unorm)."""
+        (H, W) or (H, W, 1) array makes a one-channel image (masks, weights: uint8 = unorm), an (H, W, 2) array a two-channel
+        one (normal maps: uint8 = snorm)."""
         a = np.ascontiguousarray(pixels)
         if a.ndim == 2:
             a = a[:, :, None]
-        if a.ndim != 3 or a.shape[2] not in (1, 3) or a.dtype not in (np.uint8, np.float32):
-            raise ValueError("image: (H, W, 3) or (H, W) uint8 or float32")
+        if a.ndim != 3 or a.shape[2] not in (1, 2, 3) or a.dtype not in (np.uint8, np.float32):
+            raise ValueError("image: (H, W, 3), (H, W, 2) or (H, W) uint8 or float32")
         fmt, bpc = (0, 1) if a.dtype == np.uint8 else (4, 4)  # capi.zig:31-37 Format
         self.lib.su_image_create.argtypes = [ctypes.c_uint32] * 7 + [ctypes.c_void_p]
         i = self.lib.su_image_create(NULL, fmt, a.shape[2], a.shape[1], a.shape[0], 1, a.shape[2] * bpc, a.ctypes.data)

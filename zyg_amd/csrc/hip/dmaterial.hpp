@@ -246,6 +246,49 @@ struct MaterialSample {
     float    ior, ior_outside, glass_f0, thickness;  // Glass
     f3       absorption;
     bool     lower_priority;
+    // Substitute: clearcoat (substitute_coating.zig:15-113) and flakes (sample_base.zig:17); only the EXT instantiations
+    // (the kernels that rebuild the whole fragment) look at them
+    struct Coating {
+        f3    n, absorption_coef;
+        float thickness, f0, alpha, weight;
+        struct Result {
+            f3    reflection, attenuation;
+            float f, pdf;
+        };
+        ZD f3 singleAttenuation(float n_dot_wo) const { return attenuation3(absorption_coef, thickness * (1.f / n_dot_wo)); }
+        ZD f3 attenuation(float n_dot_wi, float n_dot_wo) const {  // :107-113
+            const float f = weight * schlick1(mn(n_dot_wi, n_dot_wo), f0);
+            const float d = thickness * (1.f / n_dot_wi + 1.f / n_dot_wo);
+            return S3(1.f - f) * attenuation3(absorption_coef, d);
+        }
+        ZD Result evaluate(const Luts& L, f3 wi, f3 wo, f3 h, float wo_dot_h, float specular_threshold, bool avoid_caustics) const {  // :35-56
+            const float n_dot_wi = clampDot(n, wi), n_dot_wo = clampAbsDot(n, wo);
+            const f3    att = attenuation(n_dot_wi, n_dot_wo);
+            if (avoid_caustics && alpha <= specular_threshold) return {S3(0.f), att, 0.f, 0.f};
+            // Iso.reflectionF (ggx.zig:74-97)
+            const float alpha2 = alpha * alpha;
+            const float n_dot_h = saturate(dot3(n, h));
+            const float d = isoDistribution(n_dot_h, alpha2);
+            float       g0, g1;
+            isoVisibilityAndG1Wo(n_dot_wi, n_dot_wo, alpha2, g0, g1);
+            const f3    f = schlick(S3(f0), wo_dot_h);
+            const float ep = L.ilmEpDielectric(n_dot_wo, alpha, f0);
+            return {S3(ep * weight * n_dot_wi) * (S3(d * g0) * f), att, f.x, pdfVisible(d, g1)};
+        }
+        ZD f3 reflect(const Luts& L, f3 wo, f3 h, float n_dot_wo, float n_dot_h, float wo_dot_h, float specular_threshold,
+                      BxdfSample& result) const {  // :58-85
+            const float n_dot_wi = reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, alpha, specular_threshold, Frame::init(n), result);
+            const float ep = L.ilmEpDielectric(n_dot_wo, alpha, f0);
+            result.reflection = result.reflection * S3(ep * weight * n_dot_wi);
+            return attenuation(n_dot_wi, n_dot_wo);
+        }
+        ZD Micro sample(f3 wo, float xi0, float xi1, float& n_dot_h) const {  // :87-95: n_dot_wi carries the Fresnel term
+            const f3    h = ggxSample(wo, alpha, alpha, xi0, xi1, Frame::init(n), n_dot_h);
+            const float wo_dot_h = clampDot(wo, h);
+            return {h, schlick1(wo_dot_h, f0), wo_dot_h};
+        }
+    } coating;
+    bool flakes;
 
     // Glass.Sample.evaluate (glass_sample.zig:68-146): rough interfaces only; `split`: max_splits > 1
     ZD BxdfResult glassEvaluate(const DScene& s, f3 wi, bool split) const {
@@ -454,6 +497,7 @@ struct MaterialSample {
         return S3(((1.f - e_wo) * (1.f - e_wi)) / (kPi * (1.f - e_avg))) * color;
     }
 
+    template <bool EXT = false>
     ZD BxdfResult baseEvaluate(const Luts& L, f3 wi, f3 h, float wo_dot_h, bool force_disable_caustics) const {
         const float n_dot_wi = frame.clampNdot(wi);
         const float n_dot_wo = frame.clampAbsNdot(wo);
@@ -465,15 +509,113 @@ struct MaterialSample {
             dw = diffuseWeight(L);
         }
         if ((force_disable_caustics || avoid_caustics) && a1 <= specular_threshold) return {S3(n_dot_wi) * d.reflection, dw * d.pdf};
+        if (EXT && flakes) {  // substitute_sample.zig:265-271: a flake reflects into a cone around the mirror direction
+            const float cos_cone = a0;
+            const f3    r = reflect3(frame.z, wo);
+            const float f = dot3(wi, r) > cos_cone ? 1.f / solidAngleOfCone(cos_cone) : 0.f;
+            return {S3(n_dot_wi * f * specular) * f0, f};
+        }
         const BxdfResult gg = ggxReflection(wi, wo, h, n_dot_wi, n_dot_wo, wo_dot_h, a0, a1, f0, frame);
         const f3         mms = dspbrMicroEc(L, f0, n_dot_wi, n_dot_wo, a1);
         const float      pdf = dw * d.pdf + (1.f - dw) * gg.pdf;
         return {S3(n_dot_wi) * (d.reflection + S3(specular) * (gg.reflection + mms)), pdf};
     }
 
+    ZD static float diffuseFresnelHack(float n_dot_wi, float n_dot_wo, float f0_) {  // substitute_sample.zig:440-442
+        return schlick1(mx(n_dot_wi, n_dot_wo), f0_);
+    }
+
+    // substitute_sample.zig:338-361
+    ZD Micro diffuseSample(const Luts& L, float dw, float xi0, float xi1, BxdfSample& result) const {
+        const float n_dot_wo = frame.clampAbsNdot(wo);
+        const f3    is = hemisphereCosine(xi0, xi1);
+        const f3    wi = normalize3(frame.frameToWorld(is));
+        const f3    h = normalize3(wo + wi);
+        const float h_dot_wi = clampDot(h, wi);
+        const float n_dot_wi = frame.clampNdot(wi);
+        const f3    refl = microEvaluate(L, S3(opacity) * albedo, n_dot_wi, n_dot_wo, hmax3(f0));
+        const float dpdf = n_dot_wi * kPiInv;
+        const BxdfResult gg = ggxReflection(wi, wo, h, n_dot_wi, n_dot_wo, h_dot_wi, a0, a1, f0, frame);
+        const f3         mms = dspbrMicroEc(L, f0, n_dot_wi, frame.clampNdot(wo), a1);
+        result.reflection = S3(n_dot_wi) * (refl + S3(specular) * (gg.reflection + mms));
+        result.wi = wi;
+        result.pdf = dw * dpdf + (1.f - dw) * gg.pdf;
+        result.reg_alpha = 1.f;
+        result.scattering = kScatterDiffuse;
+        return {h, n_dot_wi, h_dot_wi};
+    }
+
+    // substitute_sample.zig:363-410
+    template <bool EXT = false>
+    ZD Micro glossSample(const Luts& L, float dw, float xi0, float xi1, BxdfSample& result) const {
+        if (EXT && flakes) {
+            const float cos_cone = a0;
+            const f3    wi_l = coneUniform(xi0, xi1, cos_cone);
+            const f3    h = reflect3(frame.z, wo);
+            const f3    wi = Frame::init(h).frameToWorld(wi_l);
+            const float wi_dot_h = clampDot(wi, h);
+            const float f = wi_dot_h > cos_cone ? 1.f / solidAngleOfCone(cos_cone) : 0.f;
+            const float n_dot_wi = frame.clampNdot(wi);
+            result.reflection = S3(n_dot_wi * f * specular) * f0;
+            result.wi = wi;
+            result.pdf = f;
+            result.reg_alpha = a1;
+            result.scattering = a1 <= specular_threshold ? kScatterSpecular : kScatterGlossy;
+            return {h, n_dot_wi, wi_dot_h};
+        }
+        const float n_dot_wo = frame.clampAbsNdot(wo);
+        const Micro micro = ggxReflect(wo, n_dot_wo, a0, a1, specular_threshold, xi0, xi1, f0, frame, result);
+        const f3    mms = dspbrMicroEc(L, f0, micro.n_dot_wi, frame.clampNdot(wo), a1);
+        BxdfResult  d{S3(0.f), 0.f};
+        if (dw > 0.f) {
+            d.reflection = microEvaluate(L, S3(opacity) * albedo, micro.n_dot_wi, n_dot_wo, hmax3(f0));
+            d.pdf = micro.n_dot_wi * kPiInv;
+        }
+        result.reflection = S3(micro.n_dot_wi) * (S3(specular) * (result.reflection + mms) + d.reflection);
+        result.pdf = (1.f - dw) * result.pdf + dw * d.pdf;
+        return micro;
+    }
+
+    template <bool EXT = false>
+    ZD void baseSample(const Luts& L, Sampler& sampler, BxdfSample& result) const {  // substitute_sample.zig:281-302
+        float dw = 0.f;
+        if (1.f != metallic) dw = diffuseWeight(L);
+        float p, xi0, xi1;
+        sampler.sample3D(p, xi0, xi1);
+        if (p < dw) diffuseSample(L, dw, xi0, xi1, result);
+        else glossSample<EXT>(L, dw, xi0, xi1, result);
+    }
+
+    // substitute_sample.zig:304-336, coatingReflect 412-422, coatingBaseSample 426-433
+    ZD void coatingSample(const Luts& L, Sampler& sampler, BxdfSample& result) const {
+        float c0, c1;
+        sampler.sample2D(c0, c1);
+        float       coat_n_dot_h;
+        const Micro micro = coating.sample(wo, c0, c1, coat_n_dot_h);
+        const float f = micro.n_dot_wi;
+        float       p, xi0, xi1;
+        sampler.sample3D(p, xi0, xi1);
+        if (p <= f) {
+            const float n_dot_wo = clampAbsDot(coating.n, wo);
+            const f3    coating_attenuation = coating.reflect(L, wo, micro.h, n_dot_wo, coat_n_dot_h, micro.h_dot_wi, specular_threshold, result);
+            const BxdfResult base_result = baseEvaluate<true>(L, result.wi, micro.h, micro.h_dot_wi, false);
+            result.reflection = (result.reflection * S3(f)) + coating_attenuation * base_result.reflection;
+            result.pdf = f * result.pdf + (1.f - f) * base_result.pdf;
+        } else {
+            float dw = 0.f;
+            if (1.f != metallic) dw = diffuseWeight(L);
+            const float p1 = (p - f) / (1.f - f);
+            const Micro bm = p1 < dw ? diffuseSample(L, dw, xi0, xi1, result) : glossSample<true>(L, dw, xi0, xi1, result);
+            const Coating::Result c = coating.evaluate(L, result.wi, wo, bm.h, bm.h_dot_wi, specular_threshold, avoid_caustics);
+            result.reflection = c.attenuation * result.reflection + c.reflection;
+            result.pdf = (1.f - f) * result.pdf + f * c.pdf;
+        }
+    }
+
     // SUBST = false compiles the Substitute branch out (kernels specialised for scenes without that material); GLASS: the
-    // pool kernels, the only ones that see Glass
-    template <bool SUBST = true, bool GLASS = false>
+    // pool kernels, the only ones that see Glass; EXT: Substitute's coating / translucency / flakes (the kernels that rebuild the
+    // whole fragment: a scene with a ZYGPU_MATF_EXTENDED material runs those)
+    template <bool SUBST = true, bool GLASS = false, bool EXT = false>
     ZD BxdfResult evaluate(const DScene& s, f3 wi, bool split = false) const {  // material_sample.zig:47-53
         if (GLASS && ZYGPU_MAT_GLASS == kind) return glassEvaluate(s, wi, split);
         if (ZYGPU_MAT_LIGHT == kind || ZYGPU_MAT_GLASS == kind) return {S3(0.f), 0.f};
@@ -483,13 +625,39 @@ struct MaterialSample {
             return {S3(pdf) * albedo, pdf};
         }
         if (!SUBST) return {S3(0.f), 0.f};
+        // Substitute.evaluate (substitute_sample.zig:88-145; exit_sss / volumetric: subsurface scattering, out of scope)
+        const Luts L{s};
+        if (EXT) {
+            const float op = opacity;
+            const bool  thin = op < 1.f;  // `translucent` there
+            if (thin) {
+                if (!sameHemisphere(wi)) {
+                    const float n_dot_wi = frame.clampAbsNdot(wi), n_dot_wo = frame.clampAbsNdot(wo);
+                    const float f = diffuseFresnelHack(n_dot_wi, n_dot_wo, f0.x);
+                    const float pdf = n_dot_wi * ((1.f - op) * kPiInv);
+                    return {S3(pdf * (1.f - f)) * albedo, pdf};
+                }
+            } else if (!sameHemisphere(wo)) {
+                return {S3(0.f), 0.f};
+            }
+            const f3    h = normalize3(wo + wi);
+            const float wo_dot_h = clampDot(wo, h);
+            BxdfResult  base_result = baseEvaluate<true>(L, wi, h, wo_dot_h, false);
+            if (thin) base_result.pdf *= op;
+            if (coating.thickness > 0.f) {
+                const Coating::Result c = coating.evaluate(L, wi, wo, h, wo_dot_h, specular_threshold, avoid_caustics);
+                const float           pdf = c.f * c.pdf + (1.f - c.f) * base_result.pdf;
+                return {c.reflection + c.attenuation * base_result.reflection, pdf};
+            }
+            return base_result;
+        }
         if (!sameHemisphere(wo)) return {S3(0.f), 0.f};
         const f3    h = normalize3(wo + wi);
         const float wo_dot_h = clampDot(wo, h);
-        return baseEvaluate(Luts{s}, wi, h, wo_dot_h, false);
+        return baseEvaluate(L, wi, h, wo_dot_h, false);
     }
 
-    template <bool SUBST = true>
+    template <bool SUBST = true, bool EXT = false>
     ZD bool sample(const DScene& s, Sampler& sampler, BxdfSample& result) const {  // material_sample.zig:55-70
         result.transmission = false;
         result.straight = false;
@@ -510,40 +678,34 @@ struct MaterialSample {
             return true;
         }
         if (!SUBST) return false;
-        // Substitute.sample, opaque / uncoated (substitute_sample.zig:147-234, 281-302, 338-410)
-        if (!sameHemisphere(wo)) return false;
+        // Substitute.sample (substitute_sample.zig:147-234; exit_sss / volumetric: subsurface scattering, out of scope)
         const Luts L{s};
-        float      dw = 0.f;
-        if (1.f != metallic) dw = diffuseWeight(L);
-        float p, xi0, xi1;
-        sampler.sample3D(p, xi0, xi1);
-        const float n_dot_wo = frame.clampAbsNdot(wo);
-        if (p < dw) {  // diffuseSample
-            const f3    is = hemisphereCosine(xi0, xi1);
-            const f3    wi = normalize3(frame.frameToWorld(is));
-            const f3    h = normalize3(wo + wi);
-            const float h_dot_wi = clampDot(h, wi);
-            const float n_dot_wi = frame.clampNdot(wi);
-            const f3    refl = microEvaluate(L, S3(opacity) * albedo, n_dot_wi, n_dot_wo, hmax3(f0));
-            const float dpdf = n_dot_wi * kPiInv;
-            const BxdfResult gg = ggxReflection(wi, wo, h, n_dot_wi, n_dot_wo, h_dot_wi, a0, a1, f0, frame);
-            const f3         mms = dspbrMicroEc(L, f0, n_dot_wi, frame.clampNdot(wo), a1);
-            result.reflection = S3(n_dot_wi) * (refl + S3(specular) * (gg.reflection + mms));
-            result.wi = wi;
-            result.pdf = dw * dpdf + (1.f - dw) * gg.pdf;
-            result.reg_alpha = 1.f;
-            result.scattering = kScatterDiffuse;
-        } else {  // glossSample
-            const Micro micro = ggxReflect(wo, n_dot_wo, a0, a1, specular_threshold, xi0, xi1, f0, frame, result);
-            const f3    mms = dspbrMicroEc(L, f0, micro.n_dot_wi, frame.clampNdot(wo), a1);
-            BxdfResult  d{S3(0.f), 0.f};
-            if (dw > 0.f) {
-                d.reflection = microEvaluate(L, S3(opacity) * albedo, micro.n_dot_wi, n_dot_wo, hmax3(f0));
-                d.pdf = micro.n_dot_wi * kPiInv;
+        if (EXT && opacity < 1.f) {  // translucent: diffuse transmission with probability 1 - opacity (:184-208)
+            const float op = opacity, tr = 1.f - op;
+            float       p, unused0, unused1;
+            sampler.sample3D(p, unused0, unused1);
+            if (p <= tr) {
+                float u0, u1;
+                sampler.sample2D(u0, u1);  // diffuse.Lambert.reflect (diffuse.zig:14-29)
+                const f3    is = hemisphereCosine(u0, u1);
+                const f3    wi = normalize3(frame.frameToWorld(is));
+                const float n_dot_wi = frame.clampNdot(wi);
+                const float n_dot_wo = frame.clampAbsNdot(wo);
+                const float f = diffuseFresnelHack(n_dot_wi, n_dot_wo, f0.x);
+                result.wi = -wi;
+                result.reflection = (S3(kPiInv) * albedo) * S3(tr * n_dot_wi * (1.f - f));
+                result.pdf = (n_dot_wi * kPiInv) * tr;
+                result.reg_alpha = 1.f;
+                result.scattering = kScatterDiffuse;
+            } else {
+                baseSample<true>(L, sampler, result);
+                result.pdf *= op;
             }
-            result.reflection = S3(micro.n_dot_wi) * (S3(specular) * (result.reflection + mms) + d.reflection);
-            result.pdf = (1.f - dw) * result.pdf + dw * d.pdf;
+            return true;
         }
+        if (!sameHemisphere(wo)) return false;
+        if (EXT && coating.thickness > 0.f) coatingSample(L, sampler, result);
+        else baseSample<EXT>(L, sampler, result);
         return 0.f != result.pdf;
     }
 };
@@ -552,11 +714,106 @@ ZD f3 sampleColorMap(const DScene& s, const ZygpuMaterial& m, float u, float v, 
     return sampleImageMap(s, m.color_image, m.color_sampler, m.color_scale, u, v, r);
 }
 
+// What the complete Substitute closure reads of the fragment beyond its frame (Renderstate: uv, stochastic_r, p, trafo)
+struct FragmentExtra {
+    float u, v, stochastic_r;
+    f3    p;
+    Trafo trafo;
+};
+
+// hlp.sampleNormal (material_helper.zig:16-78), tex_coord UV0: the normal map's xy in the tangent frame, z reconstructed, then the
+// "iray" adaption that keeps the reflection of wo above the geometric surface
+ZD f3 sampleNormal(const DScene& s, const ZygpuTexture& map, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, const FragmentExtra& fx) {
+    float nx, ny;
+    sampleImageMap2(s, map.image, map.sampler, map.scale, fx.u, fx.v, fx.stochastic_r, nx, ny);
+    const float nz = sqrtf(mx(1.f - (nx * nx + ny * ny), 0.01f));
+    // rs.tangentToWorld (renderstate.zig:51-58)
+    const f3 nn = normalize3(mk3(nx * t.x + ny * b.x + nz * n.x, nx * t.y + ny * b.y + nz * n.y, nx * t.z + ny * b.z + nz * n.z));
+    const f3    ng = geo_n;
+    const f3    r = reflect3(nn, wo);
+    const float a = dot3(ng, r);
+    if (a >= 0.f) return nn;
+    const float cos_threshold = 0.0017453f;  // cos(89.9 degrees)
+    if (dot3(ng, wo) < cos_threshold) return ng;
+    const float bb = dot3(ng, nn);
+    const float epsilon = 1e-4f;
+    f3          tangent;
+    if (bb > epsilon) {
+        const float distance_to_surface_along_normal = fabsf(a) / bb;
+        tangent = normalize3(r + S3(distance_to_surface_along_normal) * nn);
+    } else {
+        tangent = nn;
+    }
+    tangent = tangent + S3(epsilon) * ng;
+    return normalize3(wo + tangent);
+}
+
+// hlp.triplanarMapping (material_helper.zig:81-93); p and n in object space
+ZD void triplanarMapping(f3 p, f3 n, float& u, float& v) {
+    const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+    if (ax > ay && ax > az) {
+        const float sign = copysignf(1.f, n.x);
+        u = sign * p.z + 0.5f;
+        v = -p.y + 0.5f;
+    } else if (ay > ax && ay > az) {
+        const float sign = copysignf(1.f, n.y);
+        u = sign * p.x + 0.5f;
+        v = -p.z + 0.5f;
+    } else {
+        const float sign = copysignf(1.f, n.z);
+        u = -sign * p.x + 0.5f;
+        v = -p.y + 0.5f;
+    }
+}
+
+// Material.sampleFlake (substitute_material.zig:235-273): four flakes per cell of a res x res grid, each cell with its own PCG
+// stream (base/random/generator.zig:49-93 SingleGenerator: increment 1); the nearest flake centre owns the point, and the flake
+// exists with probability `coverage`.  Returns the flake's 2-D number (which fixes its orientation).
+ZD bool sampleFlake(float u, float v, float res, float coverage, float& xi0, float& xi1) {
+    const int32_t i = int32_t(res * (u - floorf(u))), j = int32_t(res * (v - floorf(v)));  // gridCell: @mod(uv, 1)
+    const float   su = res * u, sv = res * v;
+    float         nearest_d = 3.40282347e+38f, nearest_r = 0.f, n0 = 0.f, n1 = 0.f;
+    for (int32_t ii = i - 1; ii <= i + 1; ++ii) {
+        for (int32_t jj = j - 1; jj <= j + 1; ++jj) {
+            uint64_t state = 0;  // SingleGenerator.start(fuse(ii, jj))
+            auto     advance = [&]() {
+                const uint64_t old = state;
+                state = old * 6364136223846793005ull + 1ull;
+                const uint32_t xrs = uint32_t(((old >> 18) ^ old) >> 27);
+                const uint32_t rot = uint32_t(old >> 59);
+                return (xrs >> rot) | (xrs << ((0u - rot) & 31u));
+            };
+            auto randomFloat = [&]() { return __uint_as_float((advance() & 0x007FFFFFu) | 0x3F800000u) - 1.f; };
+            advance();
+            state += (uint64_t(uint32_t(ii)) << 32) | uint64_t(uint32_t(jj));
+            advance();
+            for (uint32_t fl = 0; fl < 4; ++fl) {
+                const float px = float(ii) + randomFloat(), py = float(jj) + randomFloat();
+                const float x0 = randomFloat(), x1 = randomFloat();
+                const float r = randomFloat();
+                const float dx = su - px, dy = sv - py;
+                const float vcd = dx * dx + dy * dy;  // squaredLength2
+                if (vcd < nearest_d) {
+                    nearest_d = vcd;
+                    nearest_r = r;
+                    n0 = x0;
+                    n1 = x1;
+                }
+            }
+        }
+    }
+    xi0 = n0;
+    xi1 = n1;
+    return nearest_r < coverage;
+}
+
 // Material.sample (material.zig:184-194) from a fragment; `two-sided flip` of vertex.zig:155-161 is done by the caller
 // `color`: the Substitute colour at the hit (uniform value or colour map sample)
 // `ior_outside`: Vertex.iorOutside (vertex.zig:87-92), 1 outside every dielectric; `lower_priority`: sample_base.zig:44
+// EXT with `fx`: a ZYGPU_MATF_EXTENDED Substitute gets its complete closure (substitute_material.zig:114-221)
+template <bool EXT = false>
 ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, bool caustics, f3 color,
-                                     float ior_outside = 1.f, bool lower_priority = false) {
+                                     float ior_outside = 1.f, bool lower_priority = false, const FragmentExtra* fx = nullptr) {
     MaterialSample ms;
     ms.ior = m.ior;
     ms.ior_outside = ior_outside;
@@ -577,6 +834,8 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
     ms.specular = 1.f;
     ms.specular_threshold = s.specular_threshold;
     ms.opacity = 1.f;
+    ms.coating.thickness = 0.f;
+    ms.flakes = false;
     if (ZYGPU_MAT_DEBUG == m.kind) {
         const f3   nn = cross3(t, b);
         const bool same_side = dot3(nn, n) > 0.f;
@@ -598,6 +857,87 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         ms.thickness = m.thickness;
         ms.absorption = mk3(m.absorption[0], m.absorption[1], m.absorption[2]);
         ms.translucent = m.thickness > 0.f;
+    } else if (EXT && (m.flags & ZYGPU_MATF_EXTENDED)) {
+        const FragmentExtra& f = *fx;
+        auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
+            const ZygpuTexture& tx = m.tex[slot];
+            return kNull != tx.image ? sampleImageMap1(s, tx.image, tx.sampler, tx.scale, f.u, f.v, f.stochastic_r) : uniform;
+        };
+        const float roughness = mx(weight(ZYGPU_STEX_ROUGHNESS, m.roughness), kMinRoughness);
+        const float metallic = weight(ZYGPU_STEX_METALLIC, m.metallic);
+        const float specular = weight(ZYGPU_STEX_SPECULAR, m.specular);
+        if (m.anisotropy > 0.f) {
+            const float rv = mx(roughness * (1.f - m.anisotropy), kMinRoughness);
+            ms.a0 = roughness * roughness;
+            ms.a1 = rv * rv;
+        } else {
+            ms.a0 = ms.a1 = roughness * roughness;
+        }
+        const float coating_scale = weight(ZYGPU_STEX_COATING_SCALE, m.coating_scale);
+        const float coating_thickness = coating_scale * m.coating_thickness;
+        const float coating_weight = coating_scale > 0.1f ? 1.f : coating_scale;
+        const float coating_ior = lerpf(ior_outside, m.coating_ior, coating_weight);
+        const float ior = m.ior, ior_outer = coating_thickness > 0.f ? coating_ior : ior_outside, ior_medium = ior_outside;
+        const float translucency = weight(ZYGPU_STEX_TRANSLUCENCY, m.translucency);
+        ms.albedo = S3(1.f - metallic) * color;
+        ms.can_evaluate = ior != ior_medium;
+        ms.translucent = translucency > 0.f;
+        const float t_ = (ior - ior_outer) / (ior + ior_outer);
+        ms.f0 = lerp3(S3(t_ * t_), color, S3(metallic));
+        ms.metallic = metallic;
+        ms.specular = specular;
+        ms.opacity = 1.f - (0.5f * translucency);
+        if (kNull != m.tex[ZYGPU_STEX_NORMAL].image) ms.frame = Frame::init(sampleNormal(s, m.tex[ZYGPU_STEX_NORMAL], wo, geo_n, t, b, n, f));
+        if (coating_thickness > 0.f) {  // substitute_material.zig:164-181
+            const ZygpuTexture &nm = m.tex[ZYGPU_STEX_NORMAL], &cnm = m.tex[ZYGPU_STEX_COATING_NORMAL];
+            // Texture.equal: the same description (two uniform maps are equal, too)
+            const bool same = nm.image == cnm.image && (kNull == nm.image || (nm.sampler == cnm.sampler && nm.scale[0] == cnm.scale[0] && nm.scale[1] == cnm.scale[1]));
+            if (same) ms.coating.n = ms.frame.z;
+            else if (kNull != cnm.image) ms.coating.n = sampleNormal(s, cnm, wo, geo_n, t, b, n, f);
+            else ms.coating.n = n;
+            const float r = mx(weight(ZYGPU_STEX_COATING_ROUGHNESS, m.coating_roughness), kMinRoughness);
+            ms.coating.absorption_coef = mk3(m.coating_absorption[0], m.coating_absorption[1], m.coating_absorption[2]);
+            ms.coating.thickness = coating_thickness;
+            const float ct = (coating_ior - ior_outside) / (coating_ior + ior_outside);
+            ms.coating.f0 = ct * ct;
+            ms.coating.alpha = r * r;
+            ms.coating.weight = coating_weight;
+        }
+        // the rotation applies to the base frame only, after the coating took its normal
+        const float rotation = weight(ZYGPU_STEX_ROTATION, m.rotation) * (2.f * kPi);
+        if (rotation > 0.f) {  // Frame.rotateTangenFrame (frame.zig:64-73)
+            const f3 ft = ms.frame.x, fb = ms.frame.y;
+            const f3 sin_a = S3(sinF(rotation)), cos_a = S3(cosF(rotation));
+            ms.frame.x = cos_a * ft + sin_a * fb;
+            ms.frame.y = -sin_a * ft + cos_a * fb;
+        }
+        const float flakes_coverage = weight(ZYGPU_STEX_FLAKES_COVERAGE, m.flakes_coverage);
+        if (flakes_coverage > 0.f) {  // substitute_material.zig:190-215
+            const f3 op = f.trafo.worldToObjectNormal(f.p - f.trafo.position);
+            const f3 on = f.trafo.worldToObjectNormal(ms.frame.z);
+            float    fu, fv;
+            triplanarMapping(op, on, fu, fv);
+            fu -= floorf(fu);  // math.frac
+            fv -= floorf(fv);
+            float xi0, xi1;
+            if (sampleFlake(fu, fv, m.flakes_res, flakes_coverage, xi0, xi1)) {
+                const float fa = m.flakes_alpha;
+                // flakesA2cone (substitute_material.zig:222-227): the cone of 7 degrees bounds the flake's lobe
+                const float target_angle = solidAngleOfCone(0.992546151641322f);  // cos(7 degrees)
+                const float limit = target_angle / ((4.f * kPi) - target_angle);
+                const float a2_cone = mn(limit, 0.5f * fa);
+                const float fa2 = fa - a2_cone;
+                const float cos_cone = 1.f - (2.f * a2_cone) / (1.f + a2_cone);
+                float       n_dot_h;
+                const f3    mh = ggxSample(wo, fa2, fa2, xi0, xi1, ms.frame, n_dot_h);
+                ms.metallic = 1.f;
+                ms.f0 = mk3(m.flakes_color[0], m.flakes_color[1], m.flakes_color[2]);
+                ms.a0 = cos_cone;
+                ms.a1 = a2_cone;
+                ms.frame = Frame::init(mh);
+                ms.flakes = true;
+            }
+        }
     } else {
         const float roughness = mx(m.roughness, kMinRoughness);
         if (m.anisotropy > 0.f) {

@@ -382,6 +382,16 @@ ZD f3 hemisphereCosine(float u0, float u1) {
     return {x, y, z};
 }
 
+ZD f3    reflect3(f3 n, f3 v) { return S3(2.f * dot3(v, n)) * n - v; }        // vector4.zig:94-96
+ZD float solidAngleOfCone(float c) { return (2.f * kPi) * (1.f - c); }  // math.zig:218-220
+ZD f3    coneUniform(float u0, float u1, float cos_theta_max) {         // sampling.zig:85-94
+    const float cos_theta = (1.f - u0) + (u0 * cos_theta_max);
+    const float sin_theta = sqrtf(mx(0.f, 1.f - cos_theta * cos_theta));
+    const float phi = u1 * (2.f * kPi);
+    const float sin_phi = sinF(phi), cos_phi = cosF(phi);
+    return {cos_phi * sin_theta, sin_phi * sin_theta, cos_theta};
+}
+
 // encoding.zig:56-108
 ZD float unorm16ToFloat(uint32_t n) { return float(n) * (1.f / 65535.f); }
 ZD float snorm16ToFloat(uint32_t n) { return __fmaf_rn(float(n), 1.f / 32768.f, -1.f); }

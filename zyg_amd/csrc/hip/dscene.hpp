@@ -190,6 +190,23 @@ ZD f3 sampleImageMap(const DScene& s, uint32_t image, uint32_t sampler, const fl
     texelPick(img, sampler, scale, u, v, r, x, y);
     return imageFetch3(s, img, x, y);
 }
+// ts.sample2D_2 for an image texture (texture.zig:177-186): Byte2 as unorm or, for usage Normal, snorm (base/encoding.zig:10-20)
+ZD void sampleImageMap2(const DScene& s, uint32_t image, uint32_t sampler, const float* scale, float u, float v, float r, float& o0, float& o1) {
+    const DImage img = s.images[image];
+    int          x, y;
+    texelPick(img, sampler, scale, u, v, r, x, y);
+    const size_t i = size_t(y) * size_t(img.width) + size_t(x);
+    if (ZYGPU_IMAGE_BYTE2 == img.format) {
+        const uint8_t* p = static_cast<const uint8_t*>(img.pixels) + 2 * i;
+        const bool     snorm = 0 != (sampler & ZYGPU_TEX_SNORM);
+        o0 = snorm ? __fmaf_rn(float(p[0]), 1.f / 128.f, -1.f) : float(p[0]) * (1.f / 255.f);
+        o1 = snorm ? __fmaf_rn(float(p[1]), 1.f / 128.f, -1.f) : float(p[1]) * (1.f / 255.f);
+    } else {
+        const float* p = static_cast<const float*>(img.pixels) + 2 * i;
+        o0 = p[0];
+        o1 = p[1];
+    }
+}
 // ts.sampleImage2D_1 (texture_sampler.zig:15-20)
 ZD float sampleImageMap1(const DScene& s, uint32_t image, uint32_t sampler, const float* scale, float u, float v, float r) {
     const DImage img = s.images[image];

@@ -132,6 +132,7 @@ struct Pool {  // 16 B records, indexed by path slot
     uint4*    med0;     // per vertex: medium stack (prop/medium.zig:30-153): index, prop0, part0, prop1
     uint4*    med1;     //             part1, prop2, part2
     float2*   rec_ior;  // per vertex: rs.ior (Vertex.iorOutside), 1 if the material has lower priority than the stack
+    float2*   rec_uv;   // per vertex: the fragment's uv, for the textures of an extended Substitute
     uint32_t* pstate;   // per slot: [0:7] vertices in flight, [8:15] children created for the next level
     float*    transp;   // per slot: Pool.transparency[3], the alpha sum over terminated vertices
 };
@@ -1197,6 +1198,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
                 // rs.ior = Vertex.iorOutside (vertex.zig:87-92), rs.highest_priority (vertex.zig:178)
                 const float ior_outside = frag.sameHemisphere(wo) ? md.topIor() : md.peekIor(frag.prop, frag.part);
                 P.pool.rec_ior[slot] = make_float2(ior_outside, m.priority < md.highestPriority() ? 1.f : 0.f);
+                if (MESHL && (m.flags & ZYGPU_MATF_EXTENDED)) P.pool.rec_uv[slot] = make_float2(frag.uv0, frag.uv1);
             }
             storeHead<POOL>(P, slot, h);
             alive = true;
@@ -1364,7 +1366,12 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
         sf.p = frag.p;
         sf.frag_geo_n = frag.geo_n;
         sf.material = s.material_ids[s.props[frag.prop].parts_start + frag.part];
-        sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color);
+        if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
+            const FragmentExtra fx{frag.uv0, frag.uv1, P.pool.hit_sr[slot], frag.p, frag.trafo};
+            sf.ms = makeMaterialSample<EXTRA>(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, &fx);
+        } else {
+            sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color);
+        }
         return sf;
     }
     const float4 rp = P.pool.rec_p[slot];
@@ -1383,7 +1390,14 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     sf.material = __float_as_uint(rp.w);
     if (POOL) {
         const float2 ri = P.pool.rec_ior[slot];
-        sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y);
+        if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
+            const float2        uv = P.pool.rec_uv[slot];
+            const FragmentExtra fx{uv.x, uv.y, P.pool.hit_sr[slot], sf.p,
+                                   propTrafoAt<true>(c_scene, P.pool.hit_prop[slot], pathTime<true, true>(P, slot))};
+            sf.ms = makeMaterialSample<EXTRA>(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, &fx);
+        } else {
+            sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y);
+        }
     } else {
         sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color);
     }
@@ -1587,7 +1601,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
         h.nee = 0;
 
         BxdfSample bs;
-        if (!ms.template sample<SUBST>(s, h.smp, bs)) {
+        if (!ms.template sample<SUBST, EXTRA>(s, h.smp, bs)) {
             finalize(P, slot, S3(0.f), h.flags, h.smp.rng);
         } else {
             // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
@@ -1720,7 +1734,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 if (!visible) return;
                 const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                 const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
-                const BxdfResult bx = ms.template evaluate<SUBST, POOL>(s, ls.wi, POOL && max_splits > 1);
+                const BxdfResult bx = ms.template evaluate<SUBST, POOL, MESHL>(s, ls.wi, POOL && max_splits > 1);
                 nanTrace(P, ls.wi, 10);
                 nanTrace(P, ls.pdf, 11);
                 nanTrace(P, radiance, 12);
@@ -1863,7 +1877,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         if (ZYGPU_MAT_GLASS == ms.kind) {
             count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1);
         } else {
-            count = ms.template sample<SUBST>(s, h.smp, bs) ? 1u : 0u;
+            count = ms.template sample<SUBST, MESHL>(s, h.smp, bs) ? 1u : 0u;
         }
         h.smp.incrementPadding();  // after the children, none of which draws (pathtracer_mis.zig:165)
         storeSamplers(P, ps, h);
@@ -1923,7 +1937,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 child_back[c] = entersMeshBounds(new_origin, b.wi);
             }
         }
-    } else if (!ms.template sample<SUBST>(s, h.smp, bs)) {
+    } else if (!ms.template sample<SUBST, MESHL>(s, h.smp, bs)) {
         finalize(P, slot, S3(0.f), h.flags, h.smp.rng);
     } else {
         // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)

@@ -600,7 +600,7 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
          m.alloc(slots, &p.time) &&
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy);
     if (ok && c->pool_mode) {
-        ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) &&
+        ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) && m.alloc(paths, &p.rec_uv) &&
              m.alloc(slots, &p.pstate) && m.alloc(slots, &p.transp);
         for (uint32_t side = 0; side < 2; ++side) {
             c->queues.ext_pool[side][0] = c->queues.ext[side];
@@ -926,9 +926,10 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     std::vector<DImage> images(d->num_images);
     for (uint32_t i = 0; i < d->num_images; ++i) {
         const ZygpuImage& hi = d->images[i];
-        const size_t      bytes = size_t(hi.width) * size_t(hi.height) * (ZYGPU_IMAGE_BYTE3_SRGB == hi.format ? 3 : ZYGPU_IMAGE_FLOAT3 == hi.format ? 12 : ZYGPU_IMAGE_BYTE1_UNORM == hi.format ? 1 : 4);
+        static const size_t kPixelBytes[6] = {3, 12, 1, 4, 2, 8};  // by ZygpuImageFormat
+        const size_t      bytes = size_t(hi.width) * size_t(hi.height) * kPixelBytes[hi.format <= ZYGPU_IMAGE_FLOAT2 ? hi.format : 0];
         const uint8_t*    pixels = nullptr;
-        if (hi.width <= 0 || hi.height <= 0 || hi.format > ZYGPU_IMAGE_FLOAT1 || !m.upload(static_cast<const uint8_t*>(hi.pixels), bytes, &pixels)) {
+        if (hi.width <= 0 || hi.height <= 0 || hi.format > ZYGPU_IMAGE_FLOAT2 || !m.upload(static_cast<const uint8_t*>(hi.pixels), bytes, &pixels)) {
             g_error = "ZygpuImage: bad dimensions / format, or out of device memory";
             return -2;
         }
@@ -946,6 +947,32 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                                                                                  ZYGPU_IMAGE_FLOAT1 != d->images[mat.mask_image].format))) {
             g_error = "a material's mask names an image that is not a one-channel image of ZygpuSceneDesc.images";
             return -2;
+        }
+        if (ZYGPU_MAT_SUBSTITUTE == mat.kind) {
+            for (uint32_t t = 0; t < ZYGPU_STEX_COUNT; ++t) {
+                const uint32_t image = mat.tex[t].image;
+                if (ZYGPU_NULL == image) continue;
+                const uint32_t f = image < d->num_images ? d->images[image].format : kNull;
+                const bool     normal = ZYGPU_STEX_NORMAL == t || ZYGPU_STEX_COATING_NORMAL == t;
+                if (normal ? (ZYGPU_IMAGE_BYTE2 != f && ZYGPU_IMAGE_FLOAT2 != f) : (ZYGPU_IMAGE_BYTE1_UNORM != f && ZYGPU_IMAGE_FLOAT1 != f)) {
+                    g_error = "a Substitute texture names an image that is missing or has the wrong number of channels";
+                    return -2;
+                }
+                if (!(mat.flags & ZYGPU_MATF_EXTENDED)) {
+                    g_error = "a Substitute material with textures must carry ZYGPU_MATF_EXTENDED";
+                    return -2;
+                }
+            }
+            if ((mat.flags & ZYGPU_MATF_EMISSIVE) && mat.coating_thickness > 0.f) {
+                g_error = "an emissive Substitute with a coating is not supported";
+                return -2;
+            }
+            if (mat.attenuation_distance > 0.f) {
+                g_error = "Substitute with an attenuation_distance (subsurface scattering) is a volume: not supported";
+                return -2;
+            }
+            // the complete Substitute closure lives in the kernels that rebuild the whole fragment
+            if (mat.flags & ZYGPU_MATF_EXTENDED) c->mesh_lights = true;
         }
     }
 

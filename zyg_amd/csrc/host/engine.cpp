@@ -222,6 +222,24 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
     m.metallic = 0.f;
     m.specular = 1.f;
     m.ior = 1.f;
+    for (ZygpuTexture& t : m.tex) t = ZygpuTexture{ZYGPU_NULL, 0u, {1.f, 1.f}};
+    m.coating_scale = 1.f;  // substitute_material.zig:37-60
+    m.coating_roughness = 0.2f;
+    m.coating_ior = 1.5f;
+    m.flakes_color[0] = m.flakes_color[1] = m.flakes_color[2] = 0.8f;
+    m.flakes_alpha = 0.01f;
+
+    // readValue (material_provider.zig:634-660): a number is the uniform value, an object names an image
+    auto readWeight = [&](const JsonValue& x, float& uniform, uint32_t slot) {
+        ZygpuTexture& t = m.tex[slot];
+        t.image = ZYGPU_NULL;
+        if (!readImageTexture(x, t.image, t.sampler, t.scale)) uniform = x.f32(uniform);
+    };
+    auto readNormal = [&](const JsonValue& x, uint32_t slot) {  // usage Normal: Byte2 is snorm (texture_provider.zig:70)
+        ZygpuTexture& t = m.tex[slot];
+        t.image = ZYGPU_NULL;
+        if (readImageTexture(x, t.image, t.sampler, t.scale)) t.sampler |= ZYGPU_TEX_SNORM;
+    };
 
     auto loadEmittance = [&](const JsonValue& e) {
         Vec4f color = splat(1.f);
@@ -282,9 +300,50 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
                         for (int i = 0; i < 3; ++i) m.color_a[i] = col[i];
                     }
                 } else if (k == "roughness") {
-                    m.roughness = x.f32(m.roughness);
+                    readWeight(x, m.roughness, ZYGPU_STEX_ROUGHNESS);
                 } else if (k == "metallic") {
-                    m.metallic = x.f32(m.metallic);
+                    readWeight(x, m.metallic, ZYGPU_STEX_METALLIC);
+                } else if (k == "normal") {
+                    readNormal(x, ZYGPU_STEX_NORMAL);
+                } else if (k == "anisotropy_rotation") {
+                    readWeight(x, m.rotation, ZYGPU_STEX_ROTATION);
+                } else if (k == "translucency") {
+                    readWeight(x, m.translucency, ZYGPU_STEX_TRANSLUCENCY);
+                } else if (k == "attenuation_distance") {
+                    m.attenuation_distance = x.f32(0.f);
+                } else if (k == "coating" && JsonValue::Object == x.type) {  // material_provider.zig:303-326
+                    Vec4f coating_color = splat(1.f);
+                    float coating_attenuation_distance = 0.1f;
+                    for (const auto& c : x.obj) {
+                        if (c.first == "color") coating_color = readColor(c.second);
+                        else if (c.first == "attenuation_distance") coating_attenuation_distance = c.second.f32(coating_attenuation_distance);
+                        else if (c.first == "ior") m.coating_ior = c.second.f32(m.coating_ior);
+                        else if (c.first == "normal") readNormal(c.second, ZYGPU_STEX_COATING_NORMAL);
+                        else if (c.first == "roughness") readWeight(c.second, m.coating_roughness, ZYGPU_STEX_COATING_ROUGHNESS);
+                        else if (c.first == "scale") readWeight(c.second, m.coating_scale, ZYGPU_STEX_COATING_SCALE);
+                        else if (c.first == "thickness") m.coating_thickness = c.second.f32(0.f);
+                    }
+                    // setCoatingAttenuation -> ccoef.attenuationCoefficient (collision_coefficients.zig:35-44)
+                    for (int i = 0; i < 3; ++i) {
+                        const float ca = std::max(std::min(coating_color[i], 0.991102f), 0.01f);
+                        m.coating_absorption[i] = 0.f == coating_attenuation_distance ? 0.f : -std::log(ca) / coating_attenuation_distance;
+                    }
+                } else if (k == "flakes" && JsonValue::Object == x.type) {  // material_provider.zig:327-340
+                    for (const auto& c : x.obj) {
+                        if (c.first == "color") {
+                            const Vec4f col = readColor(c.second);
+                            for (int i = 0; i < 3; ++i) m.flakes_color[i] = col[i];
+                        } else if (c.first == "coverage") {
+                            readWeight(c.second, m.flakes_coverage, ZYGPU_STEX_FLAKES_COVERAGE);
+                        } else if (c.first == "roughness") {  // setFlakesRoughness (substitute_material.zig:85-88)
+                            const float r = std::max(c.second.f32(0.f), 0.01314f);  // ggx.clampRoughness (ggx.zig:14, 48-50)
+                            m.flakes_alpha = r * r;
+                        } else if (c.first == "size") {  // setFlakesSize (substitute_material.zig:90-95)
+                            const float size = c.second.f32(0.f);
+                            const float N = 1.5396f / (size * size);
+                            m.flakes_res = std::max(4.f, std::ceil(std::sqrt(N / 4.f)));
+                        }
+                    }
                 } else if (k == "metal_preset") {
                     // material_provider.zig:277-280: a conductor is Substitute with metallic = 1 and the normal-incidence
                     // Fresnel reflectance of the metal's (eta, k) as colour (fresnel.zig:45-57, metal_presets.zig:6-39)
@@ -292,7 +351,7 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
                     for (int i = 0; i < 3; ++i) m.color_a[i] = f[i];
                     m.metallic = 1.f;
                 } else if (k == "specular") {
-                    m.specular = x.f32(m.specular);
+                    readWeight(x, m.specular, ZYGPU_STEX_SPECULAR);
                 } else if (k == "ior") {
                     m.ior = x.f32(m.ior);
                 } else if (k == "anisotropy") {
@@ -346,8 +405,13 @@ void Engine::commitMaterial(ZygpuMaterial& m) {
         else m.flags &= ~uint32_t(ZYGPU_MATF_EVALUATE_VISIBILITY);
     }
     if (ZYGPU_MAT_SUBSTITUTE == m.kind) {
-        if (m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
+        // properties.caustic = roughness.isUniform() and roughness <= specular_threshold (substitute_material.zig:69)
+        if (ZYGPU_NULL == m.tex[ZYGPU_STEX_ROUGHNESS].image && m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
         else m.flags &= ~uint32_t(ZYGPU_MATF_CAUSTIC);
+        bool extended = m.rotation > 0.f || m.translucency > 0.f || m.coating_thickness > 0.f || m.flakes_coverage > 0.f;
+        for (const ZygpuTexture& t : m.tex) extended = extended || ZYGPU_NULL != t.image;
+        if (extended) m.flags |= ZYGPU_MATF_EXTENDED;
+        else m.flags &= ~uint32_t(ZYGPU_MATF_EXTENDED);
     }
     if (ZYGPU_MAT_GLASS == m.kind) {  // glass_material.zig:35-42
         const bool thin = m.thickness > 0.f;
@@ -557,11 +621,13 @@ uint32_t Engine::createImage(uint32_t id, uint32_t format, uint32_t num_channels
                              uint32_t pixel_stride, const uint8_t* data) {
     (void)id;  // ids are assigned in creation order, like the other resources created with id = NULL
     const bool u8 = 0 == format, f32 = 4 == format;  // capi.zig:31-37 Format: UInt8, UInt16, UInt32, Float16, Float32
-    if (!(u8 || f32) || (3 != num_channels && 1 != num_channels) || 1 != depth || 0 == width || 0 == height || !data) return ZYGPU_NULL;
+    if (!(u8 || f32) || num_channels < 1 || num_channels > 3 || 1 != depth || 0 == width || 0 == height || !data) return ZYGPU_NULL;
     const uint32_t bpp = (u8 ? 1u : 4u) * num_channels;
     if (bpp != pixel_stride) return ZYGPU_NULL;  // the reference only copies tightly packed pixels (capi.zig:264-266)
     HostImage img;
-    img.format = 3 == num_channels ? (u8 ? ZYGPU_IMAGE_BYTE3_SRGB : ZYGPU_IMAGE_FLOAT3) : (u8 ? ZYGPU_IMAGE_BYTE1_UNORM : ZYGPU_IMAGE_FLOAT1);
+    img.format = 3 == num_channels   ? (u8 ? ZYGPU_IMAGE_BYTE3_SRGB : ZYGPU_IMAGE_FLOAT3)
+                 : 2 == num_channels ? (u8 ? ZYGPU_IMAGE_BYTE2 : ZYGPU_IMAGE_FLOAT2)
+                                     : (u8 ? ZYGPU_IMAGE_BYTE1_UNORM : ZYGPU_IMAGE_FLOAT1);
     img.width = int32_t(width);
     img.height = int32_t(height);
     img.pixels.assign(data, data + size_t(width) * height * bpp);
@@ -741,7 +807,8 @@ int Engine::setTransformationFrame(uint32_t prop, uint32_t frame, const float* m
 int Engine::updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data) {  // capi.zig:300-338
     if (id >= images_.size() || !data) return -1;
     HostImage&     img = images_[id];
-    const uint32_t bpp = ZYGPU_IMAGE_BYTE3_SRGB == img.format ? 3u : ZYGPU_IMAGE_FLOAT3 == img.format ? 12u : ZYGPU_IMAGE_BYTE1_UNORM == img.format ? 1u : 4u;
+    static const uint32_t kBpp[6] = {3u, 12u, 1u, 4u, 2u, 8u};  // by ZygpuImageFormat
+    const uint32_t        bpp = kBpp[img.format];
     // a stride that does not match the image's pixel size copies nothing and still succeeds (capi.zig:316-334)
     if (bpp == pixel_stride) std::memcpy(img.pixels.data(), data, img.pixels.size());
     return 0;
@@ -1347,8 +1414,20 @@ int Engine::compile(uint32_t frame) {
     }
     d.image_lights = c_image_lights_.data();
     d.num_image_lights = uint32_t(c_image_lights_.size());
-    auto channels = [&](uint32_t image) { return ZYGPU_IMAGE_BYTE3_SRGB == images_[image].format || ZYGPU_IMAGE_FLOAT3 == images_[image].format ? 3 : 1; };
+    auto channels = [&](uint32_t image) {
+        const uint32_t f = images_[image].format;
+        return (ZYGPU_IMAGE_BYTE3_SRGB == f || ZYGPU_IMAGE_FLOAT3 == f) ? 3 : (ZYGPU_IMAGE_BYTE2 == f || ZYGPU_IMAGE_FLOAT2 == f) ? 2 : 1;
+    };
     for (const ZygpuMaterial& m : materials_) {
+        if (ZYGPU_MAT_SUBSTITUTE == m.kind) {
+            // image2D_1 reads one channel, image2D_2 (the normal maps) two (texture.zig:166-186)
+            for (uint32_t t = 0; t < ZYGPU_STEX_COUNT; ++t) {
+                const uint32_t image = m.tex[t].image;
+                if (ZYGPU_NULL == image) continue;
+                const int want = (ZYGPU_STEX_NORMAL == t || ZYGPU_STEX_COATING_NORMAL == t) ? 2 : 1;
+                if (image >= images_.size() || want != channels(image)) return -4;
+            }
+        }
         if (ZYGPU_NULL != m.color_image && (m.color_image >= images_.size() || 3 != channels(m.color_image))) return -4;  // a colour map without its image
         if (ZYGPU_NULL != m.emission_image && m.emission_image < images_.size() && 3 != channels(m.emission_image)) return -4;
         if (ZYGPU_NULL != m.mask_image && (m.mask_image >= images_.size() || 1 != channels(m.mask_image))) return -4;  // image2D_1 reads one channel
@@ -1356,6 +1435,10 @@ int Engine::compile(uint32_t frame) {
     for (uint32_t mid : material_ids_) {  // dispersive glass in use: not restated (glass_sample.zig:148-163: needs the Rainbow spectrum)
         const ZygpuMaterial& m = materials_[mid];
         if (ZYGPU_MAT_GLASS == m.kind && m.abbe > 0.f) return -5;
+        // subsurface scattering (substitute_material.zig:71-74: a scattering volume inside the surface): volumes are out of scope
+        if (ZYGPU_MAT_SUBSTITUTE == m.kind && m.attenuation_distance > 0.f) return -7;
+        // an emitter under a clearcoat: evaluateRadiance attenuates by the coating (substitute_material.zig:283-293), not restated
+        if (ZYGPU_MAT_SUBSTITUTE == m.kind && (m.flags & ZYGPU_MATF_EMISSIVE) && m.coating_thickness > 0.f) return -8;
     }
     for (const ZygpuMaterial& m : materials_) {
         if (ZYGPU_MAT_SUBSTITUTE != m.kind && !(ZYGPU_MAT_GLASS == m.kind && m.roughness > 0.f)) continue;

@@ -51,6 +51,44 @@ def substitute_textured(image_id, roughness=0.8, metallic=0.0, sampler=None, sca
     return json.dumps({"rendering": {"Substitute": {"color": color, "roughness": roughness, "metallic": metallic}}})
 
 
+def substitute_full(color=(0.5, 0.5, 0.5), **body):
+    """Substitute with any of the reference's parameters (material_provider.zig:262-342): roughness, metallic, specular, ior,
+    anisotropy, anisotropy_rotation, translucency, normal, coating {color, attenuation_distance, ior, normal, roughness, scale,
+    thickness}, flakes {color, coverage, roughness, size}, two_sided ...; a texture is tex(image_id, usage)."""
+    b = {"color": color if isinstance(color, dict) else list(color)}
+    b.update(body)
+    return json.dumps({"rendering": {"Substitute": b}})
+
+
+def tex(image_id, usage="Weight", sampler=None, scale=None):
+    """A texture description (material_provider.zig:438-632)."""
+    t = {"usage": usage, "id": int(image_id)}
+    if sampler:
+        t["sampler"] = sampler
+    if scale is not None:
+        t["scale"] = scale
+    return t
+
+
+def weight_image(n=8, lo=0.1, hi=0.9, dtype=np.float32):
+    """n x n one-channel image with distinct texels in [lo, hi] (roughness / metallic / coating scale ... maps)."""
+    y, x = np.mgrid[0:n, 0:n]
+    w = lo + (hi - lo) * (((x * 5 + y * 3) % n) / (n - 1.0))
+    return (w * 255.0 + 0.5).astype(np.uint8) if dtype == np.uint8 else w.astype(np.float32)
+
+
+def normal_image(n=16, strength=0.5, dtype=np.uint8):
+    """n x n two-channel tangent-space normal map (xy of a bumpy normal; z is reconstructed, material_helper.zig:18-20):
+    uint8 = snorm (byte / 128 - 1), float32 as is."""
+    y, x = np.mgrid[0:n, 0:n]
+    nx = strength * np.sin(2.0 * np.pi * (x + 0.5) / n * 2.0)
+    ny = strength * np.cos(2.0 * np.pi * (y + 0.5) / n * 3.0)
+    xy = np.stack([nx, ny], axis=-1)
+    if dtype == np.uint8:
+        return np.clip(np.floor((xy + 1.0) * np.where(xy > 0.0, 127.5, 128.0)), 0, 255).astype(np.uint8)  # encoding.zig:14-16
+    return xy.astype(np.float32)
+
+
 def checker_image(n=8, dtype=np.float32):
     """n x n test image with distinct texels (a smooth ramp times a checker), float32 linear or uint8 sRGB."""
     y, x = np.mgrid[0:n, 0:n]
@@ -236,7 +274,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
-            light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None):
+            light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None,
+            overrides=None):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -255,8 +294,14 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     clamp: the sensor's per-channel clamp, e.g. {"direct": 4, "indirect": 2} (sensor.zig:177-181, take_loader.zig "clamp").
     lens: thin-lens camera parameters, e.g. {"lens": {"radius": 0.05}, "focus": {"distance": 3.9}}
     (camera_perspective.zig:124-150, 260-270, aperture.zig:46-53).
+    overrides: material JSONs by place: "floor", "back", "left", "right", "ceiling", "tall", "short", "sphere_a", "sphere_b".
     Returns a dict with prop ids.
     """
+    overrides = overrides or {}
+
+    def pick(place, default):
+        return engine.material(overrides[place]) if place in overrides else default
+
     mk = lambert if material == "lambert" else substitute
     cam = engine.camera(width, height, fov_deg=39.3)
     if lens:
@@ -302,12 +347,12 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         return p
 
     # box: x in [-1, 1], y in [0, 2], z in [-1, 1]; all normals point inward; open towards -z (camera side)
-    floor = white if floor_material is None else engine.material(floor_material)
+    floor = pick("floor", white) if floor_material is None else engine.material(floor_material)
     wall(floor, (1, 0, 0), (0, 0, -1), (2, 2, 1), (0, 0, 0))   # floor, n = +y
-    wall(white, (1, 0, 0), (0, 0, 1), (2, 2, 1), (0, 2, 0))    # ceiling, n = -y
-    wall(white, (-1, 0, 0), (0, 1, 0), (2, 2, 1), (0, 1, 1))   # back, n = -z
-    wall(red, (0, 0, -1), (0, 1, 0), (2, 2, 1), (-1, 1, 0))    # left, n = +x
-    wall(green, (0, 0, 1), (0, 1, 0), (2, 2, 1), (1, 1, 0))    # right, n = -x
+    wall(pick("ceiling", white), (1, 0, 0), (0, 0, 1), (2, 2, 1), (0, 2, 0))    # ceiling, n = -y
+    wall(pick("back", white), (-1, 0, 0), (0, 1, 0), (2, 2, 1), (0, 1, 1))   # back, n = -z
+    wall(pick("left", red), (0, 0, -1), (0, 1, 0), (2, 2, 1), (-1, 1, 0))    # left, n = +x
+    wall(pick("right", green), (0, 0, 1), (0, 1, 0), (2, 2, 1), (1, 1, 0))    # right, n = -x
 
     if many_lights:
         n = many_lights
@@ -320,7 +365,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
                 engine.light(p)
                 ids["lights"].append(p)
     if spheres:
-        for pos_, d_, mat_ in (((-0.45, 0.4, 0.2), 0.8, white), ((0.5, 0.25, -0.3), 0.5, red)):
+        for pos_, d_, mat_ in (((-0.45, 0.4, 0.2), 0.8, pick("sphere_a", white)), ((0.5, 0.25, -0.3), 0.5, pick("sphere_b", red))):
             p = engine.prop(SPHERE, [mat_])
             engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (d_, d_, d_), pos_))
             ids["meshes"].append(p)
@@ -388,7 +433,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         for k, (lo, hi, rot) in enumerate((((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0))):
             idx, pos, nrm, uv = box_mesh(lo, hi, rot)
             shape = engine.triangle_mesh(idx, pos, nrm, uv)
-            box_mat = engine.material(glass_objects["box"]) if 1 == k and "box" in glass_objects else white
+            box_mat = engine.material(glass_objects["box"]) if 1 == k and "box" in glass_objects else pick(("tall", "short")[k], white)
             if masked and 0 == k:
                 box_mat = engine.material(with_mask(substitute(WHITE), mask_id, sampler=mask_kw["sampler"], scale=[2.0, 2.0]))
             p = engine.prop(shape, [box_mat])
