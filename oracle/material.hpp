@@ -58,6 +58,15 @@ struct Renderstate {  // renderstate.zig:10-45 (subset in scope)
     uint32_t prop, part;
     bool     caustics;
     int32_t  highest_priority = -128;  // mediums.highestPriority() (prop/medium.zig:75-83)
+    float    reg_weight = 0.f, reg_alpha = 0.f;  // PathtracerMIS' regularize_roughness and Vertex.reg_alpha (vertex.zig:168-169)
+
+    // renderstate.zig:60-69: a path that has scattered diffusely sees later surfaces rougher
+    void regularizeAlpha(float alpha[2], float specular_threshold) const {
+        if (0.f == reg_weight || (alpha[0] <= specular_threshold && !caustics)) return;
+        const float k = 1.f - reg_weight * reg_alpha;
+        alpha[0] = 1.f - ((1.f - alpha[0]) * k);
+        alpha[1] = 1.f - ((1.f - alpha[1]) * k);
+    }
 };
 
 struct Luts {
@@ -900,12 +909,12 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.alpha[0] = s.alpha[1] = 0.f;
         s.can_evaluate = false;
     } else if (ZYGPU_MAT_GLASS == m.kind) {
-        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66); regularizeAlpha is the identity for
-        // reg_weight == 0
+        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66)
         s.frame = {rs.t, rs.b, rs.n};
         const float r = 0.f == m.roughness ? 0.f : ggx::clampRoughness(m.roughness);
-        const bool  rough = r * r > 0.f;
         s.alpha[0] = s.alpha[1] = r * r;
+        rs.regularizeAlpha(s.alpha, scene.specular_threshold);
+        const bool rough = s.alpha[0] > 0.f;
         s.can_evaluate = rough && m.ior != rs.ior;
         s.absorption = ld3(m.absorption);
         s.ior = m.ior;
@@ -940,7 +949,8 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         const float coating_ior = lerpf(rs.ior, m.coating_ior, coating_weight);
         const float ior = m.ior, ior_outer = coating_thickness > 0.f ? coating_ior : rs.ior, ior_medium = rs.ior;
         const float translucency = weight(ZYGPU_STEX_TRANSLUCENCY, m.translucency);
-        // Surface.init (substitute_sample.zig:38-86); regularizeAlpha is the identity for reg_weight == 0
+        // Surface.init (substitute_sample.zig:38-86)
+        rs.regularizeAlpha(alpha, scene.specular_threshold);
         s.albedo = S(1.f - metallic) * color;
         s.alpha[0] = alpha[0];
         s.alpha[1] = alpha[1];
@@ -965,7 +975,9 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
             s.coating.absorption_coef = ld3(m.coating_absorption);
             s.coating.thickness = coating_thickness;
             s.coating.f0 = fresnel::iorToF0(coating_ior, rs.ior);
-            s.coating.alpha = r * r;
+            float ca[2] = {r * r, r * r};
+            rs.regularizeAlpha(ca, scene.specular_threshold);
+            s.coating.alpha = ca[0];
             s.coating.weight = coating_weight;
         }
         // the rotation applies to the base frame only, after the coating took its normal

@@ -953,3 +953,40 @@ def test_subsurface_substitute_is_refused(engine):
     scenes.cornell(engine, 16, 16, 1, material="substitute",
                    overrides={"tall": scenes.substitute_full((0.8, 0.5, 0.4), attenuation_distance=0.1, attenuation_color=[0.9, 0.3, 0.2])})
     assert engine.lib.su_ext_compile(0) != 0
+
+
+@pytest.mark.parametrize("scene", ["metal", "glass", "coating"])
+def test_roughness_regularisation(engine, oracle, scene):
+    """PathtracerMIS' regularize_roughness (pathtracer_mis.zig:93, 147; renderstate.zig:60-69): after a rough bounce the path
+    sees later surfaces rougher: 1 - (1 - alpha)(1 - weight * alpha_of_the_last_event).  The roughness of the last event travels
+    with the path; Substitute, its coating and Glass regularise their alpha."""
+    kw = dict(integrator="PTMIS", material="substitute", regularize=0.75)
+    if "metal" == scene:
+        kw["overrides"] = {"tall": scenes.substitute_full((0.9, 0.9, 0.9), roughness=0.05, metallic=1.0),
+                           "short": scenes.substitute_full((0.9, 0.6, 0.3), roughness=0.2, metallic=1.0, anisotropy=0.5)}
+    elif "glass" == scene:
+        kw["glass_objects"] = {"box": scenes.glass(1.5, (0.8, 0.9, 1.0), 0.5), "sphere": scenes.glass(1.45, roughness=0.1)}
+    else:
+        kw["overrides"] = _substitute_showcase(engine, "coating")
+        kw["spheres"] = True
+    out = _render_both(engine, oracle, 80, 60, 4, **kw)
+    _check(*out, 4)
+    engine.release()
+    engine.__init__(engine.lib)
+    kw["regularize"] = None
+    if "coating" == scene:
+        kw["overrides"] = _substitute_showcase(engine, "coating")
+    plain = _render_both(engine, oracle, 80, 60, 4, stats=False, **kw)
+    assert rms(out[1], plain[1]) > 1e-3  # the setting changes the picture
+
+
+def test_roughness_regularisation_is_a_pathtracer_mis_setting(engine, oracle):
+    """The other integrators pass a weight of 0 (pathtracer.zig:64, pathtracer_dl.zig:68)."""
+    kw = dict(integrator="PTDL", material="substitute",
+              overrides={"tall": scenes.substitute_full((0.9, 0.9, 0.9), roughness=0.05, metallic=1.0)})
+    a = _render_both(engine, oracle, 64, 48, 2, regularize=0.75, **kw)
+    _check(*a, 2)
+    engine.release()
+    engine.__init__(engine.lib)
+    b = _render_both(engine, oracle, 64, 48, 2, **kw)
+    assert np.array_equal(a[0], b[0])

@@ -811,9 +811,21 @@ ZD bool sampleFlake(float u, float v, float res, float coverage, float& xi0, flo
 // `color`: the Substitute colour at the hit (uniform value or colour map sample)
 // `ior_outside`: Vertex.iorOutside (vertex.zig:87-92), 1 outside every dielectric; `lower_priority`: sample_base.zig:44
 // EXT with `fx`: a ZYGPU_MATF_EXTENDED Substitute gets its complete closure (substitute_material.zig:114-221)
+// renderstate.zig:60-69: a path that has scattered diffusely sees later surfaces rougher (PathtracerMIS' regularize_roughness)
+struct Regularize {
+    float weight = 0.f, alpha = 0.f;  // rs.reg_weight, rs.reg_alpha (vertex.zig:168-169)
+    ZD void apply(float& a0, float& a1, float specular_threshold, bool caustics) const {
+        if (0.f == weight || (a0 <= specular_threshold && !caustics)) return;
+        const float k = 1.f - weight * alpha;
+        a0 = 1.f - ((1.f - a0) * k);
+        a1 = 1.f - ((1.f - a1) * k);
+    }
+};
+
 template <bool EXT = false>
 ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, bool caustics, f3 color,
-                                     float ior_outside = 1.f, bool lower_priority = false, const FragmentExtra* fx = nullptr) {
+                                     float ior_outside = 1.f, bool lower_priority = false, const FragmentExtra* fx = nullptr,
+                                     Regularize reg = Regularize{}) {
     MaterialSample ms;
     ms.ior = m.ior;
     ms.ior_outside = ior_outside;
@@ -848,8 +860,9 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
     } else if (ZYGPU_MAT_GLASS == m.kind) {
         // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66)
         const float r = 0.f == m.roughness ? 0.f : mx(m.roughness, kMinRoughness);
-        const bool  rough = r * r > 0.f;
         ms.a0 = ms.a1 = r * r;
+        reg.apply(ms.a0, ms.a1, s.specular_threshold, caustics);
+        const bool rough = ms.a0 > 0.f;
         ms.can_evaluate = rough && m.ior != ior_outside;
         const float t_ = (m.ior - ior_outside) / (m.ior + ior_outside);
         ms.glass_f0 = rough ? t_ * t_ : 0.f;
@@ -873,6 +886,7 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         } else {
             ms.a0 = ms.a1 = roughness * roughness;
         }
+        reg.apply(ms.a0, ms.a1, s.specular_threshold, caustics);
         const float coating_scale = weight(ZYGPU_STEX_COATING_SCALE, m.coating_scale);
         const float coating_thickness = coating_scale * m.coating_thickness;
         const float coating_weight = coating_scale > 0.1f ? 1.f : coating_scale;
@@ -900,7 +914,9 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
             ms.coating.thickness = coating_thickness;
             const float ct = (coating_ior - ior_outside) / (coating_ior + ior_outside);
             ms.coating.f0 = ct * ct;
-            ms.coating.alpha = r * r;
+            float ca0 = r * r, ca1 = r * r;
+            reg.apply(ca0, ca1, s.specular_threshold, caustics);
+            ms.coating.alpha = ca0;
             ms.coating.weight = coating_weight;
         }
         // the rotation applies to the base frame only, after the coating took its normal
@@ -947,6 +963,7 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         } else {
             ms.a0 = ms.a1 = roughness * roughness;
         }
+        reg.apply(ms.a0, ms.a1, s.specular_threshold, caustics);
         const float ior = m.ior, ior_outer = ior_outside, ior_medium = ior_outside;
         ms.albedo = S3(1.f - m.metallic) * color;
         ms.can_evaluate = ior != ior_medium;

@@ -1338,6 +1338,18 @@ struct Surface {
     MaterialSample ms;
 };
 
+// rs.reg_weight / rs.reg_alpha (vertex.zig:168-169): PathtracerMIS' regularize_roughness and the roughness of the path's last
+// scattering event, which travels in the spare lane of vertex.geo_n (read only when the setting is on)
+ZD Regularize loadRegularize(const Params& P, uint32_t slot) {
+    Regularize   r;
+    const float  w = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator ? c_view.v.regularize_roughness : 0.f;
+    if (0.f != w) {
+        r.weight = w;
+        r.alpha = P.pool.vgeo_n.get(slot).w;
+    }
+    return r;
+}
+
 // POOL: from the record wf_shade wrote.  Otherwise from the hit: the fragment is rebuilt here (Shape.fragment), followed by
 // Vertex.sample's two-sided flip (vertex.zig:155-161) and the colour-map fetch with the stochastic_r wf_shade drew: the path
 // carries 36 B of hit instead of an 80 B record.  EXTRA: Sphere / Disk / Cube fragments.
@@ -1366,11 +1378,12 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
         sf.p = frag.p;
         sf.frag_geo_n = frag.geo_n;
         sf.material = s.material_ids[s.props[frag.prop].parts_start + frag.part];
+        const Regularize reg = loadRegularize(P, slot);
         if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
             const FragmentExtra fx{frag.uv0, frag.uv1, P.pool.hit_sr[slot], frag.p, frag.trafo};
-            sf.ms = makeMaterialSample<EXTRA>(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, &fx);
+            sf.ms = makeMaterialSample<EXTRA>(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, &fx, reg);
         } else {
-            sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color);
+            sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, nullptr, reg);
         }
         return sf;
     }
@@ -1388,18 +1401,19 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     sf.p = xyz4(rp);
     sf.frag_geo_n = 0.f != rg.w ? -geo_n : geo_n;
     sf.material = __float_as_uint(rp.w);
+    const Regularize reg = loadRegularize(P, slot);
     if (POOL) {
         const float2 ri = P.pool.rec_ior[slot];
         if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
             const float2        uv = P.pool.rec_uv[slot];
             const FragmentExtra fx{uv.x, uv.y, P.pool.hit_sr[slot], sf.p,
                                    propTrafoAt<true>(c_scene, P.pool.hit_prop[slot], pathTime<true, true>(P, slot))};
-            sf.ms = makeMaterialSample<EXTRA>(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, &fx);
+            sf.ms = makeMaterialSample<EXTRA>(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, &fx, reg);
         } else {
-            sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y);
+            sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, nullptr, reg);
         }
     } else {
-        sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color);
+        sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, 1.f, false, nullptr, reg);
     }
     return sf;
 }
@@ -1617,7 +1631,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
                 h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
                 h.vdepth = h.depth_surface;
                 bxdf_pdf = bs.pdf;
-                P.pool.vgeo_n[slot] = f4(ms.geo_n);
+                P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
             }
             throughput = throughput * (bs.reflection / S3(bs.pdf));
             const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
@@ -1929,7 +1943,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 P.pool.thr[cv] = f4(throughput * (b.reflection / S3(b.pdf)), split_weight * b.split_weight);
                 // vertex.origin / geo_n move with every event but .Straight (pathtracer_mis.zig:141-148, pathtracer.zig:88-90)
                 P.pool.vorigin[cv] = f4(b.straight ? xyz4(parent_vorigin) : sf.p, __uint_as_float(path_count * count));
-                P.pool.vgeo_n[cv] = (mis && !b.straight) ? f4(ms.geo_n) : parent_vgeo_n;
+                P.pool.vgeo_n[cv] = (mis && !b.straight) ? f4(ms.geo_n, b.reg_alpha) : parent_vgeo_n;
                 P.pool.vmeta[cv] = packMeta(ch);
                 cm.store(P, cv);
                 child[c] = cv;
@@ -1953,7 +1967,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
             h.vdepth = h.depth_surface;
             bxdf_pdf = bs.pdf;
-            P.pool.vgeo_n[slot] = f4(ms.geo_n);
+            P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
         }
         throughput = throughput * (bs.reflection / S3(bs.pdf));
         nanTrace(P, bs.reflection, 16);

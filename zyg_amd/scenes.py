@@ -275,7 +275,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
             light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None,
-            overrides=None):
+            overrides=None, regularize=None):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
@@ -310,6 +310,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     node = {"depth": {"surface": max_depth}}
     if split_threshold is not None:
         node["light_sampling"] = {"split_threshold": split_threshold}
+    if regularize is not None:  # PathtracerMIS' roughness regularisation (take.zig:211, renderstate.zig:60-69)
+        node["regularize_roughness"] = regularize
     engine.integrators(json.dumps({"surface": {integrator: node}}))
     sensor = {}
     if alpha_transparency:
