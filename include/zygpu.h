@@ -124,8 +124,8 @@ enum ZygpuMaterialFlags {
 /* Uniform-texture subset of the reference materials (all colours ACES AP1, base/json.zig:247-277).
  * Debug: color_a/color_b = front/back albedo (debug_material.zig:11-12);
  * Substitute: color_a = color, see substitute_material.zig:32-60; emittance: light/emittance.zig:18-27;
- * Glass: dielectric, thick (smooth or rough: roughness) or a thin pane (thickness > 0); dispersion (abbe) is refused by
- * zygpu_upload_scene: glass_material.zig:46-115, glass_sample.zig:33-538 */
+ * Glass: dielectric, thick (smooth or rough: roughness; dispersive with an Abbe number `abbe`) or a thin pane (thickness > 0):
+ * glass_material.zig:46-115, glass_sample.zig:33-538 */
 
 /* A texture of the reference (texture/texture.zig:14-60) that is either uniform (image == ZYGPU_NULL: the material's uniform
  * field of the same name) or a 2-D image read at the fragment's uv */

@@ -58,6 +58,7 @@ struct Renderstate {  // renderstate.zig:10-45 (subset in scope)
     uint32_t prop, part;
     bool     caustics;
     int32_t  highest_priority = -128;  // mediums.highestPriority() (prop/medium.zig:75-83)
+    float    wavelength = 0.f;                   // probe.wavelength (vertex.zig:167): 0 until a dispersive Glass picks one
     float    reg_weight = 0.f, reg_alpha = 0.f;  // PathtracerMIS' regularize_roughness and Vertex.reg_alpha (vertex.zig:168-169)
 
     // renderstate.zig:60-69: a path that has scattered diffusely sees later surfaces rougher
@@ -345,6 +346,30 @@ inline ggx::Micro reflect(const Luts& L, V4 color, float f0, V4 wo, float n_dot_
 
 }  // namespace diffuse_micro
 
+// The spectrum a dispersive Glass weights its wavelength draw with: rainbow_integral.zig:3-41 (a generated table: 32 bands
+// between 380 and 720 nm; tests/golden/reference_constants.json holds the reference's numbers), material_base.zig:56-73
+constexpr float kRainbowStart = 380.f, kRainbowEnd = 720.f;
+constexpr int   kRainbowBands = 32;
+static const float kRainbow[kRainbowBands][3] = {
+    {0.00118749f, 0.00000000f, 0.01277892f}, {0.00428908f, 0.00000000f, 0.04665186f}, {0.01393313f, 0.00000000f, 0.15397894f},
+    {0.04654151f, 0.00000000f, 0.52832049f}, {0.10802665f, 0.00000000f, 1.00000000f}, {0.13396028f, 0.00000000f, 1.00000000f},
+    {0.11002098f, 0.00000000f, 1.00000000f}, {0.05638582f, 0.00000000f, 1.00000000f}, {0.00323226f, 0.04778787f, 1.00000000f},
+    {0.00000000f, 0.19377914f, 0.82263476f}, {0.00000000f, 0.36241144f, 0.45633313f}, {0.00000000f, 0.60088211f, 0.25896370f},
+    {0.00000000f, 0.92129856f, 0.13798122f}, {0.00000000f, 1.00000000f, 0.06571960f}, {0.06015893f, 1.00000000f, 0.03276091f},
+    {0.25364995f, 1.00000000f, 0.01465140f}, {0.49281576f, 1.00000000f, 0.00740940f}, {0.76601928f, 1.00000000f, 0.00603952f},
+    {1.00000000f, 0.90572321f, 0.00713901f}, {1.00000000f, 0.63148290f, 0.00846385f}, {1.00000000f, 0.37303036f, 0.00921571f},
+    {1.00000000f, 0.17757514f, 0.00884298f}, {1.00000000f, 0.06006211f, 0.00760580f}, {0.90220016f, 0.00659840f, 0.00571195f},
+    {0.61788863f, 0.00000000f, 0.00391464f}, {0.38115984f, 0.00000000f, 0.00241280f}, {0.21279863f, 0.00000000f, 0.00134878f},
+    {0.10870021f, 0.00000000f, 0.00068967f}, {0.05491111f, 0.00000000f, 0.00034864f}, {0.02550786f, 0.00000000f, 0.00016202f},
+    {0.01237659f, 0.00000000f, 0.00007862f}, {0.00601408f, 0.00000000f, 0.00003820f}};
+inline V4 spectrumAtWavelength(float lambda, float value) {
+    const float    u = ((lambda - kRainbowStart) / (kRainbowEnd - kRainbowStart)) * float(kRainbowBands);
+    const uint32_t id = uint32_t(u);
+    const float    frac = u - float(id);
+    if (id >= uint32_t(kRainbowBands - 1)) return mk(kRainbow[kRainbowBands - 1][0], kRainbow[kRainbowBands - 1][1], kRainbow[kRainbowBands - 1][2]);
+    return S(value) * lerp4(mk(kRainbow[id][0], kRainbow[id][1], kRainbow[id][2]), mk(kRainbow[id + 1][0], kRainbow[id + 1][1], kRainbow[id + 1][2]), S(frac));
+}
+
 struct MaterialSample {
     uint32_t kind;
     Frame    frame;
@@ -360,6 +385,7 @@ struct MaterialSample {
     // Glass
     V4    absorption;
     float ior, ior_outside, glass_f0, thickness;
+    float abbe = 0.f, wavelength = 0.f;  // dispersion: the material's Abbe number, the path's wavelength (rs.wavelength)
     bool  lower_priority;
     // Substitute: clearcoat (substitute_coating.zig:15-113) and flakes (sample_base.zig:17)
     struct Coating {
@@ -552,14 +578,15 @@ struct MaterialSample {
     }
 
     // Glass.roughSample, thick (glass_sample.zig:294-422)
-    uint32_t glassRoughSample(Sampler& sampler, bool split, BxdfSample out[2]) const {
-        float eta_i = ior_outside, eta_t = ior;
+    // weight / ior_t / wl: the dispersion draw of Glass.sample (1, the material's ior and 0 without dispersion)
+    uint32_t glassRoughSample(Sampler& sampler, bool split, BxdfSample out[2], V4 weight, float ior_t, float wl) const {
+        float eta_i = ior_outside, eta_t = ior_t;
         if (std::fabs(eta_i - eta_t) <= 2.e-7f || lower_priority) {
-            out[0].reflection = S(1.f);
+            out[0].reflection = weight;
             out[0].wi = -wo;
             out[0].pdf = 1.f;
             out[0].split_weight = 1.f;
-            out[0].wavelength = 0.f;
+            out[0].wavelength = wl;
             out[0].path = PathInfo::singularTransmission();
             return 1;
         }
@@ -612,32 +639,32 @@ struct MaterialSample {
         if (split) {
             {
                 const float n_dot_wi = ggx::reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, out[0]);
-                out[0].reflection *= S(n_dot_wi * ep * s) * S(1.f);
+                out[0].reflection *= S(n_dot_wi * ep * s) * weight;
                 out[0].split_weight = f;
-                out[0].wavelength = 0.f;
+                out[0].wavelength = wl;
             }
             if (1.f == f) return 1;
             const float n_dot_wi = roughRefract(out[1]);
             if (n_dot_wi < 0.f) return 1;
-            out[1].reflection *= S(n_dot_wi * ep) * S(1.f);
+            out[1].reflection *= S(n_dot_wi * ep) * weight;
             out[1].split_weight = 1.f - f;
-            out[1].wavelength = 0.f;
+            out[1].wavelength = wl;
             return 2;
         }
         const float p = s3[0];
         if (p <= f) {
             const float n_dot_wi = ggx::reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, out[0]);
-            out[0].reflection *= S(f * n_dot_wi * ep * s) * S(1.f);
+            out[0].reflection *= S(f * n_dot_wi * ep * s) * weight;
             out[0].pdf *= f;
         } else {
             const float n_dot_wi = roughRefract(out[0]);
             if (n_dot_wi < 0.f) return 0;
             const float omf = 1.f - f;
-            out[0].reflection *= S(omf * n_dot_wi * ep) * S(1.f);
+            out[0].reflection *= S(omf * n_dot_wi * ep) * weight;
             out[0].pdf *= omf;
         }
         out[0].split_weight = 1.f;
-        out[0].wavelength = 0.f;
+        out[0].wavelength = wl;
         return 1;
     }
 
@@ -678,18 +705,33 @@ struct MaterialSample {
     // Glass.specularSample, thick (glass_sample.zig:165-254); `split`: both the reflected and the refracted direction,
     // weighted by the Fresnel term, instead of a choice between them
     uint32_t glassSample(Sampler& sampler, bool split, BxdfSample out[2]) const {
-        if (alpha[0] > 0.f) return glassRoughSample(sampler, split, out);
-        float eta_i = ior_outside, eta_t = ior;
+        // Glass.sample (glass_sample.zig:165-199): a thick dispersive glass (abbe != 0) first settles the path's wavelength (a
+        // uniform draw over the visible range, weighted by the Rainbow spectrum x 3; a path that has one keeps it, weight 1) and
+        // takes its index of refraction at that wavelength (Cauchy's equation through the Abbe number)
+        V4    weight = S(1.f);
+        float ior_t = ior, wl = 0.f;
+        if (!(thickness > 0.f) && 0.f != abbe) {
+            wl = wavelength;
+            const float r1 = sampler.sample1D();
+            if (0.f == wl) {  // wavelengthSpectrumWeight (glass_sample.zig:154-163)
+                wl = kRainbowStart + (kRainbowEnd - kRainbowStart) * r1;
+                weight = spectrumAtWavelength(wl, 1.f) * S(3.f);
+            }
+            const float sqr_wl = wl * wl;
+            ior_t = ior + ((ior - 1.f) / abbe) * (523655.f / sqr_wl - 1.5168f);
+        }
+        if (alpha[0] > 0.f) return glassRoughSample(sampler, split, out, weight, ior_t, wl);
+        float eta_i = ior_outside, eta_t = ior_t;
         auto  fill = [&](BxdfSample& r, V4 wi, V4 reflection, float split_weight, PathInfo path) {
             r.reflection = reflection;
             r.wi = wi;
             r.pdf = 1.f;
             r.split_weight = split_weight;
-            r.wavelength = 0.f;
+            r.wavelength = PathEvent::Straight == path.event ? 0.f : wl;  // thinSpecularRefract: 0 (glass_sample.zig:514)
             r.path = path;
         };
         if (eta_i == eta_t || lower_priority) {
-            fill(out[0], -wo, S(1.f), 1.f, PathInfo::singularTransmission());
+            fill(out[0], -wo, weight, 1.f, PathInfo::singularTransmission());
             return 1;
         }
         const bool thin = thickness > 0.f;
@@ -714,16 +756,16 @@ struct MaterialSample {
         // thinSpecularRefract (glass_sample.zig:505-517): straight through, attenuated over the slab
         const V4 thin_attenuation = thin ? attenuation3(absorption, thickness / clampf(n_dot_wo, kDotMin, 1.f)) : S(1.f);
         if (split) {
-            fill(out[0], reflected, S(specular) * S(1.f), f, PathInfo::singularReflection());
+            fill(out[0], reflected, S(specular) * weight, f, PathInfo::singularReflection());
             if (1.f == f) return 1;
             if (thin) fill(out[1], -wo, thin_attenuation, 1.f - f, PathInfo::straight());
-            else fill(out[1], refracted, S(1.f), 1.f - f, PathInfo::singularTransmission());
+            else fill(out[1], refracted, weight, 1.f - f, PathInfo::singularTransmission());
             return 2;
         }
         const float p = sampler.sample1D();
-        if (p <= f) fill(out[0], reflected, S(specular) * S(1.f), 1.f, PathInfo::singularReflection());
+        if (p <= f) fill(out[0], reflected, S(specular) * weight, 1.f, PathInfo::singularReflection());
         else if (thin) fill(out[0], -wo, thin_attenuation, 1.f, PathInfo::straight());
-        else fill(out[0], refracted, S(1.f), 1.f, PathInfo::singularTransmission());
+        else fill(out[0], refracted, weight, 1.f, PathInfo::singularTransmission());
         return 1;
     }
 
@@ -921,6 +963,8 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.ior_outside = rs.ior;
         s.glass_f0 = rough ? fresnel::iorToF0(m.ior, rs.ior) : 0.f;
         s.thickness = m.thickness;
+        s.abbe = m.abbe;
+        s.wavelength = rs.wavelength;
         s.translucent = m.thickness > 0.f;
         s.specular_threshold = scene.specular_threshold;
         s.specular = m.specular;

@@ -38,6 +38,11 @@ GROUPS = {
     "ggx_min_roughness": ("core/scene/material/ggx.zig", 14, 15, "MinRoughness"),
     "metal_presets": ("core/scene/material/metal_presets.zig", 6, 40, "ior and absorption of the metal presets"),
     "dot_min": ("base/math/safe.zig", 5, 5, "safe.DotMin"),
+    "rainbow": ("core/scene/material/rainbow_integral.zig", 3, 41, "wavelength range, band count and the Rainbow spectrum table (w = 1 per entry)"),
+    "glass_dispersion": ("core/scene/material/glass/glass_sample.zig", 190, 191, "Cauchy / Abbe dispersion constants"),
+    "sample_normal": ("core/scene/material/material_helper.zig", 19, 64, "normal-map reconstruction and shading-normal adaption thresholds"),
+    "flakes": ("core/scene/material/substitute/substitute_material.zig", 90, 95, "flake density constants (setFlakesSize)"),
+    "coating_defaults": ("core/scene/material/substitute/substitute_material.zig", 37, 60, "Substitute parameter defaults"),
 }
 
 

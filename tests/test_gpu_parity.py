@@ -990,3 +990,38 @@ def test_roughness_regularisation_is_a_pathtracer_mis_setting(engine, oracle):
     engine.__init__(engine.lib)
     b = _render_both(engine, oracle, 64, 48, 2, **kw)
     assert np.array_equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("integrator,rough", [("PTMIS", False), ("PT", False), ("PTDL", True), ("PTMIS", True)])
+def test_dispersive_glass(engine, oracle, integrator, rough):
+    """Glass with an Abbe number (glass_sample.zig:154-199): the first dispersive interface a path meets settles its wavelength
+    (one extra sampler draw, weight = Rainbow spectrum x 3), later ones reuse it (the draw still happens); the index of refraction
+    follows the wavelength.  The wavelength travels with the path (probe.wavelength)."""
+    extra = {"roughness": 0.15} if rough else {}
+    glass = {"box": scenes.glass(1.5, (0.9, 0.95, 1.0), 0.5, abbe=20.0, **extra),
+             "sphere": scenes.glass(1.6, abbe=35.0), "inner": scenes.glass(1.3, priority=1, abbe=50.0)}
+    out = _render_both(engine, oracle, 80, 60, 4, integrator=integrator, glass_objects=glass)
+    _check(*out, 4)
+    engine.release()
+    engine.__init__(engine.lib)
+    glass = {"box": scenes.glass(1.5, (0.9, 0.95, 1.0), 0.5, **extra), "sphere": scenes.glass(1.6), "inner": scenes.glass(1.3, priority=1)}
+    plain = _render_both(engine, oracle, 80, 60, 4, stats=False, integrator=integrator, glass_objects=glass)
+    assert rms(out[1], plain[1]) > 1e-3
+    # dispersion colours single samples: behind the glass the channels decorrelate
+    assert not np.array_equal(out[0], plain[0])
+
+
+def test_dispersion_conserves_energy_on_average(engine, oracle):
+    """The Rainbow weights average to one per channel over the wavelength draw (rainbow_integrate.zig normalises the table so):
+    a dispersive pane in front of a uniform emitter transmits, on average, what the same glass without dispersion does."""
+    def mean(abbe):
+        engine.release()
+        engine.__init__(engine.lib)
+        g = {"sphere": scenes.glass(1.5, abbe=abbe) if abbe else scenes.glass(1.5)}
+        scenes.cornell(engine, 48, 36, 64, integrator="PT", glass_objects=g, boxes=False)
+        engine.start_frame(0)
+        engine.render_iterations(64)
+        engine.synchronize()
+        return engine.resolve(48, 36)[..., :3].mean(axis=(0, 1))
+    a, b = mean(25.0), mean(0.0)
+    assert np.allclose(a, b, rtol=0.05), (a, b)

@@ -44,6 +44,12 @@ WHERE = {
     "ggx_min_roughness": (["oracle/material.hpp"], ["zyg_amd/csrc/hip/dmaterial.hpp"]),
     "metal_presets": (None, ["zyg_amd/csrc/host/engine.cpp"]),
     "dot_min": (["oracle/omath.hpp"], ["zyg_amd/csrc/hip/dmath.hpp"]),
+    "rainbow": (["oracle/material.hpp"], ["zyg_amd/csrc/hip/dmaterial.hpp"]),
+    "glass_dispersion": (["oracle/material.hpp"], ["zyg_amd/csrc/hip/dmaterial.hpp"]),
+    "sample_normal": (["oracle/material.hpp"], ["zyg_amd/csrc/hip/dmaterial.hpp"]),
+    # the host compiles the material: the oracle and the device read ZygpuMaterial
+    "flakes": (None, ["zyg_amd/csrc/host/engine.cpp"]),
+    "coating_defaults": (None, ["zyg_amd/csrc/host/engine.cpp"]),
 }
 
 
@@ -75,6 +81,18 @@ def test_constants_are_the_references(group):
         have = _literals(files)
         missing = [float(v) for v in vals if v not in have]
         assert not missing, f"{group} ({REF[group]['source']}): the {side} ({files}) lacks {missing}"
+
+
+@pytest.mark.parametrize("path", ["oracle/material.hpp", "zyg_amd/csrc/hip/dmaterial.hpp"])
+def test_rainbow_table_in_order(path):
+    """The 32 x 3 entries of the Rainbow spectrum (rainbow_integral.zig:8-41), in the reference's order, on both sides."""
+    ref = REF["rainbow"]["values"][2:]  # after Wavelength_start / Wavelength_end
+    assert 128 == len(ref)
+    ref_rgb = [v for i, v in enumerate(ref) if i % 4 != 3]
+    text = open(os.path.join(ROOT, path)).read()
+    body = re.search(r"kRainbow\[kRainbowBands\]\[3\] = \{(.*?)\}\};", text, re.S).group(1)
+    have = [float(x) for x in re.findall(r"(\d+\.\d+)f", body)]
+    assert have == ref_rgb
 
 
 def test_agx_looks_other_than_substitute_are_not_claimed():

@@ -26,7 +26,34 @@ struct BxdfSample {
     bool     transmission;
     bool     straight;  // bxdf.Path.straight: thin glass passes the ray on unbent (no scattering event for the vertex state)
     float    split_weight;
+    float    wavelength;  // set by Glass only: the wavelength a dispersive glass settled for the path (0: none)
 };
+
+// The spectrum a dispersive Glass weights its wavelength draw with: rainbow_integral.zig:3-41 (a generated table: 32 bands
+// between 380 and 720 nm; tests/golden/reference_constants.json holds the reference's numbers), material_base.zig:56-73
+constexpr float kRainbowStart = 380.f, kRainbowEnd = 720.f;
+constexpr int   kRainbowBands = 32;
+static __device__ const float kRainbow[kRainbowBands][3] = {
+    {0.00118749f, 0.00000000f, 0.01277892f}, {0.00428908f, 0.00000000f, 0.04665186f}, {0.01393313f, 0.00000000f, 0.15397894f},
+    {0.04654151f, 0.00000000f, 0.52832049f}, {0.10802665f, 0.00000000f, 1.00000000f}, {0.13396028f, 0.00000000f, 1.00000000f},
+    {0.11002098f, 0.00000000f, 1.00000000f}, {0.05638582f, 0.00000000f, 1.00000000f}, {0.00323226f, 0.04778787f, 1.00000000f},
+    {0.00000000f, 0.19377914f, 0.82263476f}, {0.00000000f, 0.36241144f, 0.45633313f}, {0.00000000f, 0.60088211f, 0.25896370f},
+    {0.00000000f, 0.92129856f, 0.13798122f}, {0.00000000f, 1.00000000f, 0.06571960f}, {0.06015893f, 1.00000000f, 0.03276091f},
+    {0.25364995f, 1.00000000f, 0.01465140f}, {0.49281576f, 1.00000000f, 0.00740940f}, {0.76601928f, 1.00000000f, 0.00603952f},
+    {1.00000000f, 0.90572321f, 0.00713901f}, {1.00000000f, 0.63148290f, 0.00846385f}, {1.00000000f, 0.37303036f, 0.00921571f},
+    {1.00000000f, 0.17757514f, 0.00884298f}, {1.00000000f, 0.06006211f, 0.00760580f}, {0.90220016f, 0.00659840f, 0.00571195f},
+    {0.61788863f, 0.00000000f, 0.00391464f}, {0.38115984f, 0.00000000f, 0.00241280f}, {0.21279863f, 0.00000000f, 0.00134878f},
+    {0.10870021f, 0.00000000f, 0.00068967f}, {0.05491111f, 0.00000000f, 0.00034864f}, {0.02550786f, 0.00000000f, 0.00016202f},
+    {0.01237659f, 0.00000000f, 0.00007862f}, {0.00601408f, 0.00000000f, 0.00003820f}};
+ZD f3 spectrumAtWavelength(float lambda, float value) {
+    const float    u = ((lambda - kRainbowStart) / (kRainbowEnd - kRainbowStart)) * float(kRainbowBands);
+    const uint32_t id = uint32_t(u);
+    const float    frac = u - float(id);
+    const uint32_t a = min(id, uint32_t(kRainbowBands - 1)), b = min(id + 1, uint32_t(kRainbowBands - 1));
+    const f3       ca = mk3(kRainbow[a][0], kRainbow[a][1], kRainbow[a][2]), cb = mk3(kRainbow[b][0], kRainbow[b][1], kRainbow[b][2]);
+    if (id >= uint32_t(kRainbowBands - 1)) return ca;
+    return S3(value) * lerp3(ca, cb, S3(frac));
+}
 
 ZD float fresnelDielectric(float cos_theta_i, float cos_theta_t, float eta_i, float eta_t) {  // fresnel.zig:31-43
     const float t0 = eta_t * cos_theta_i, t1 = eta_i * cos_theta_t;
@@ -244,6 +271,7 @@ struct MaterialSample {
     f3       f0;
     float    metallic, specular, specular_threshold, opacity;
     float    ior, ior_outside, glass_f0, thickness;  // Glass
+    float    abbe, wavelength;  // dispersion: the material's Abbe number, the path's wavelength (rs.wavelength; set by the caller)
     f3       absorption;
     bool     lower_priority;
     // Substitute: clearcoat (substitute_coating.zig:15-113) and flakes (sample_base.zig:17); only the EXT instantiations
@@ -342,10 +370,13 @@ struct MaterialSample {
     }
 
     // Glass.roughSample, thick (glass_sample.zig:294-422)
-    ZD uint32_t glassRoughSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
-        float eta_i = ior_outside, eta_t = ior;
+    // weight / ior_t / wl: the dispersion draw of Glass.sample (1, the material's ior and 0 without dispersion)
+    ZD uint32_t glassRoughSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1, f3 weight, float ior_t,
+                                 float wl) const {
+        float eta_i = ior_outside, eta_t = ior_t;
+        r0.wavelength = r1.wavelength = wl;
         if (fabsf(eta_i - eta_t) <= 2.e-7f || lower_priority) {
-            r0.reflection = S3(1.f);
+            r0.reflection = weight;
             r0.wi = -wo;
             r0.pdf = 1.f;
             r0.reg_alpha = 0.f;
@@ -404,24 +435,24 @@ struct MaterialSample {
         };
         if (split) {
             const float n_dot_wi = reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, r0);
-            r0.reflection = r0.reflection * (S3(n_dot_wi * ep * specular) * S3(1.f));
+            r0.reflection = r0.reflection * (S3(n_dot_wi * ep * specular) * weight);
             r0.split_weight = f;
             if (1.f == f) return 1;
             const float n_dot_wt = roughRefract(r1);
             if (n_dot_wt < 0.f) return 1;
-            r1.reflection = r1.reflection * (S3(n_dot_wt * ep) * S3(1.f));
+            r1.reflection = r1.reflection * (S3(n_dot_wt * ep) * weight);
             r1.split_weight = 1.f - f;
             return 2;
         }
         if (p <= f) {
             const float n_dot_wi = reflectNoFresnel(wo, h, n_dot_wo, n_dot_h, wo_dot_h, a, specular_threshold, fr, r0);
-            r0.reflection = r0.reflection * (S3(f * n_dot_wi * ep * specular) * S3(1.f));
+            r0.reflection = r0.reflection * (S3(f * n_dot_wi * ep * specular) * weight);
             r0.pdf *= f;
         } else {
             const float n_dot_wt = roughRefract(r0);
             if (n_dot_wt < 0.f) return 0;
             const float omf = 1.f - f;
-            r0.reflection = r0.reflection * (S3(omf * n_dot_wt * ep) * S3(1.f));
+            r0.reflection = r0.reflection * (S3(omf * n_dot_wt * ep) * weight);
             r0.pdf *= omf;
         }
         r0.split_weight = 1.f;
@@ -433,9 +464,25 @@ struct MaterialSample {
     // Glass.specularSample, thick (glass_sample.zig:165-254, reflect 425-435, thickSpecularRefract 519-537); `split`: both
     // directions, weighted by the Fresnel term, instead of a choice between them.  Returns the number of samples.
     ZD uint32_t glassSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
-        if (a0 > 0.f) return glassRoughSample(s, sampler, split, r0, r1);
-        float eta_i = ior_outside, eta_t = ior;
+        // Glass.sample (glass_sample.zig:165-199): a thick dispersive glass (abbe != 0) first settles the path's wavelength (a
+        // uniform draw over the visible range, weighted by the Rainbow spectrum x 3; a path that has one keeps it, weight 1) and
+        // takes its index of refraction at that wavelength (Cauchy's equation through the Abbe number)
+        f3    weight = S3(1.f);
+        float ior_t = ior, wl = 0.f;
+        if (!(thickness > 0.f) && 0.f != abbe) {
+            wl = wavelength;
+            const float r1d = sampler.sample1D();
+            if (0.f == wl) {  // wavelengthSpectrumWeight (glass_sample.zig:154-163)
+                wl = kRainbowStart + (kRainbowEnd - kRainbowStart) * r1d;
+                weight = spectrumAtWavelength(wl, 1.f) * S3(3.f);
+            }
+            const float sqr_wl = wl * wl;
+            ior_t = ior + ((ior - 1.f) / abbe) * (523655.f / sqr_wl - 1.5168f);
+        }
+        if (a0 > 0.f) return glassRoughSample(s, sampler, split, r0, r1, weight, ior_t, wl);
+        float eta_i = ior_outside, eta_t = ior_t;
         auto  fill = [&](BxdfSample& r, f3 wi, f3 reflection, float split_weight, bool transmission, bool straight = false) {
+            r.wavelength = straight ? 0.f : wl;  // thinSpecularRefract: 0 (glass_sample.zig:514)
             r.reflection = reflection;
             r.wi = wi;
             r.pdf = 1.f;
@@ -446,7 +493,7 @@ struct MaterialSample {
             r.split_weight = split_weight;
         };
         if (eta_i == eta_t || lower_priority) {
-            fill(r0, -wo, S3(1.f), 1.f, true);
+            fill(r0, -wo, weight, 1.f, true);
             return 1;
         }
         const bool thin = thickness > 0.f;
@@ -473,16 +520,16 @@ struct MaterialSample {
         // thinSpecularRefract (glass_sample.zig:505-517): straight through, attenuated over the slab
         const f3 thin_attenuation = thin ? attenuation3(absorption, thickness / clampf(n_dot_wo, kDotMin, 1.f)) : S3(1.f);
         if (split) {
-            fill(r0, reflected, S3(specular) * S3(1.f), f, false);
+            fill(r0, reflected, S3(specular) * weight, f, false);
             if (1.f == f) return 1;
             if (thin) fill(r1, -wo, thin_attenuation, 1.f - f, false, true);
-            else fill(r1, refracted, S3(1.f), 1.f - f, true);
+            else fill(r1, refracted, weight, 1.f - f, true);
             return 2;
         }
         const float p = sampler.sample1D();
-        if (p <= f) fill(r0, reflected, S3(specular) * S3(1.f), 1.f, false);
+        if (p <= f) fill(r0, reflected, S3(specular) * weight, 1.f, false);
         else if (thin) fill(r0, -wo, thin_attenuation, 1.f, false, true);
-        else fill(r0, refracted, S3(1.f), 1.f, true);
+        else fill(r0, refracted, weight, 1.f, true);
         return 1;
     }
 
@@ -831,6 +878,8 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
     ms.ior_outside = ior_outside;
     ms.glass_f0 = 0.f;
     ms.thickness = 0.f;
+    ms.abbe = 0.f;
+    ms.wavelength = 0.f;
     ms.absorption = S3(0.f);
     ms.lower_priority = lower_priority;
     ms.kind = m.kind;
@@ -868,6 +917,7 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         ms.glass_f0 = rough ? t_ * t_ : 0.f;
         ms.specular = m.specular;
         ms.thickness = m.thickness;
+        ms.abbe = m.abbe;
         ms.absorption = mk3(m.absorption[0], m.absorption[1], m.absorption[2]);
         ms.translucent = m.thickness > 0.f;
     } else if (EXT && (m.flags & ZYGPU_MATF_EXTENDED)) {

@@ -347,14 +347,16 @@ ZD uint32_t pathTime(const Params& P, uint32_t vertex) {
 struct Mediums {  // prop/medium.zig:30-153; an entry is its (prop, part): ior, priority and absorption are the material's
     uint32_t index;
     uint32_t prop[3], part[3];  // push() stops at Num_entries - 1 = 3 entries
+    float    wavelength;        // probe.wavelength rides in the record's spare word: 0 until a dispersive Glass settles it
     ZD void load(const Params& P, uint32_t vertex) {
         const uint4 a = P.pool.med0[vertex], b = P.pool.med1[vertex];
         index = a.x;
         prop[0] = a.y, part[0] = a.z, prop[1] = a.w, part[1] = b.x, prop[2] = b.y, part[2] = b.z;
+        wavelength = __uint_as_float(b.w);
     }
     ZD void store(const Params& P, uint32_t vertex) const {
         P.pool.med0[vertex] = make_uint4(index, prop[0], part[0], prop[1]);
-        P.pool.med1[vertex] = make_uint4(part[1], prop[2], part[2], 0u);
+        P.pool.med1[vertex] = make_uint4(part[1], prop[2], part[2], __float_as_uint(wavelength));
     }
     ZD const ZygpuMaterial& material(uint32_t i) const {
         return c_scene.materials[c_scene.material_ids[c_scene.props[prop[i]].parts_start + part[i]]];
@@ -738,6 +740,7 @@ ZD void generatePath(const Params& P, uint32_t slot) {
     P.pool.vorigin[slot] = f4(origin_w, POOL ? __uint_as_float(1u) : 0.f);            //       w = vertex.path_count
     if (POOL) {
         P.pool.med0[slot] = make_uint4(0u, 0u, 0u, 0u);
+        P.pool.med1[slot] = make_uint4(0u, 0u, 0u, 0u);  // .w: probe.wavelength = 0
         P.pool.pstate[slot] = 1u;
         P.pool.transp[slot] = 0.f;
     }
@@ -1889,8 +1892,11 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         uint32_t       count;
         const uint32_t path_count = __float_as_uint(P.pool.vorigin.get(slot).w);
         if (ZYGPU_MAT_GLASS == ms.kind) {
-            count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1);
+            MaterialSample gs = ms;
+            if (0.f != gs.abbe) gs.wavelength = __uint_as_float(P.pool.med1[slot].w);  // rs.wavelength (vertex.zig:167)
+            count = gs.glassSample(s, h.smp, max_splits > 1, bs, bs1);
         } else {
+            bs.wavelength = 0.f;
             count = ms.template sample<SUBST, MESHL>(s, h.smp, bs) ? 1u : 0u;
         }
         h.smp.incrementPadding();  // after the children, none of which draws (pathtracer_mis.zig:165)
@@ -1926,6 +1932,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, b.wi);
                 ch.depth_surface = h.depth_surface + 1;
                 Mediums cm = md;
+                if (0.f == cm.wavelength) cm.wavelength = b.wavelength;  // pathtracer_mis.zig:155-157
                 if (b.transmission) {
                     // Vertex.interfaceChange (vertex.zig:94-108): leaving if the new direction is on the side of the
                     // fragment's geometric normal

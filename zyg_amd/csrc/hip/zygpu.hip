@@ -861,10 +861,6 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t pi = 0; pi < d->num_parts; ++pi) {
         const ZygpuMaterial& gm = d->materials[d->material_ids[pi]];
         if (ZYGPU_MAT_GLASS != gm.kind) continue;
-        if (gm.abbe > 0.f) {
-            g_error = "Glass: dispersion (abbe) is not supported";
-            return -2;
-        }
         if (gm.roughness > 0.f && !d->luts.e_s) {
             g_error = "rough Glass needs the E_s table in ZygpuSceneDesc.luts";
             return -2;

@@ -56,7 +56,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
         logf(2, -6 == rc   ? "a light has keyframes (su_prop_set_transformation_frame): animated lights are not supported"
                 : -7 == rc ? "a Substitute material has an attenuation_distance: subsurface scattering is a volume, not supported"
                 : -8 == rc ? "an emissive Substitute material with a coating is not supported"
-                           : "scene uses a feature outside the hot-path scope (scattering volumes, dispersive glass, emission maps on meshes ...)");
+                           : "scene uses a feature outside the hot-path scope (scattering volumes, Portal lights, emission maps on meshes ...)");
         return -1;
     }
     for (const std::string& w : c.engine.warnings()) logf(1, "%s", w.c_str());

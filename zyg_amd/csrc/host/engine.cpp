@@ -1432,9 +1432,8 @@ int Engine::compile(uint32_t frame) {
         if (ZYGPU_NULL != m.emission_image && m.emission_image < images_.size() && 3 != channels(m.emission_image)) return -4;
         if (ZYGPU_NULL != m.mask_image && (m.mask_image >= images_.size() || 1 != channels(m.mask_image))) return -4;  // image2D_1 reads one channel
     }
-    for (uint32_t mid : material_ids_) {  // dispersive glass in use: not restated (glass_sample.zig:148-163: needs the Rainbow spectrum)
+    for (uint32_t mid : material_ids_) {
         const ZygpuMaterial& m = materials_[mid];
-        if (ZYGPU_MAT_GLASS == m.kind && m.abbe > 0.f) return -5;
         // subsurface scattering (substitute_material.zig:71-74: a scattering volume inside the surface): volumes are out of scope
         if (ZYGPU_MAT_SUBSTITUTE == m.kind && m.attenuation_distance > 0.f) return -7;
         // an emitter under a clearcoat: evaluateRadiance attenuates by the coating (substitute_material.zig:283-293), not restated
