@@ -118,7 +118,10 @@ enum ZygpuMaterialFlags {
     ZYGPU_MATF_EMISSIVE = 1u << 3,
     /* Substitute with anything beyond the uniform opaque base: a texture in one of `tex`, a normal map, a coating,
      * translucency, flakes or a rotated tangent frame (set by the host; the device runs its complete closure for it) */
-    ZYGPU_MATF_EXTENDED = 1u << 4
+    ZYGPU_MATF_EXTENDED = 1u << 4,
+    /* the description the material was made from asked for something that is not built (a procedural texture, an image file,
+     * a swizzle, Triplanar coordinates, an IES profile, a Glass normal map ...): zygpu_upload_scene refuses a scene that uses it */
+    ZYGPU_MATF_UNSUPPORTED = 1u << 31
 };
 
 /* Uniform-texture subset of the reference materials (all colours ACES AP1, base/json.zig:247-277).

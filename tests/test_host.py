@@ -405,3 +405,30 @@ def test_malformed_meshes_are_refused(product_lib):
         assert create([0, 1, 2], [0, 3, 0] * 70000) == -1  # 70000 parts
     finally:
         lib.su_release()
+
+
+@pytest.mark.parametrize("material", [
+    '{"rendering": {"Substitute": {"color": {"Checker": {"scale": 4}}}}}',                       # procedural texture
+    '{"rendering": {"Substitute": {"roughness": {"file": "rough.png"}}}}',                        # image file
+    '{"rendering": {"Substitute": {"roughness": {"id": 0, "swizzle": "Y"}}}}',
+    '{"rendering": {"Substitute": {"color": {"id": 0, "sampler": {"texcoord": "Triplanar"}}}}}',
+    '{"rendering": {"Glass": {"ior": 1.5, "normal": {"id": 0}}}}',
+    '{"rendering": {"Glass": {"ior": 1.5, "roughness": {"id": 0}}}}',
+    '{"rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "profile": {"file": "lamp.ies"}}}}}',
+])
+def test_unsupported_texture_features_do_not_compile(product_lib, material):
+    """A material description that asks for something outside the scope is accepted (su_material_create has no way to say
+    no to part of a description) but a scene that uses it does not compile: nothing renders with a silent default."""
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 8, 8, 1, material="substitute")
+        e.image(scenes.checker_image(4, np.float32))
+        p = e.prop(scenes.RECTANGLE, [e.material(material)])
+        e.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, 0)))
+        assert e.lib.su_ext_compile(0) == -1
+
+
+def test_unused_unsupported_material_is_harmless(product_lib):
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 8, 8, 1, material="substitute")
+        e.material('{"rendering": {"Substitute": {"color": {"Checker": {"scale": 4}}}}}')
+        assert e.lib.su_ext_compile(0) == 0

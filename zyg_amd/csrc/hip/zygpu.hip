@@ -944,6 +944,13 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             g_error = "a material's mask names an image that is not a one-channel image of ZygpuSceneDesc.images";
             return -2;
         }
+        if (mat.flags & ZYGPU_MATF_UNSUPPORTED) {
+            for (uint32_t pi = 0; pi < d->num_parts; ++pi)
+                if (d->material_ids[pi] == mi) {
+                    g_error = "a material in use carries ZYGPU_MATF_UNSUPPORTED";
+                    return -2;
+                }
+        }
         if (ZYGPU_MAT_SUBSTITUTE == mat.kind) {
             for (uint32_t t = 0; t < ZYGPU_STEX_COUNT; ++t) {
                 const uint32_t image = mat.tex[t].image;

@@ -28,11 +28,29 @@ static Vec4f readColor(const JsonValue& v) {
 static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler, float scale[2]);
 static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) { return readImageTexture(v, m.color_image, m.color_sampler, m.color_scale); }
 
+// Set while a material is parsed when its JSON asks for a texture feature that is not built (procedural textures, image
+// files, swizzles, inversion, Triplanar / ObjectPos coordinates): the material gets ZYGPU_MATF_UNSUPPORTED and a scene that
+// uses it does not compile, instead of rendering with a default in that place.
+static thread_local bool t_unsupported_texture = false;
+
 // material_provider.zig:438-632: {"usage": .., "id": n, "sampler": {"filter", "address"}, "scale"}
 static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler_out, float scale_out[2]) {
     if (JsonValue::Object != v.type) return false;
     const JsonValue* id = v.get("id");
-    if (!id) return false;
+    for (const auto& kv : v.obj) {
+        const std::string& k = kv.first;
+        if (k == "id" || k == "usage" || k == "scale") continue;
+        if (k == "sampler") {
+            if (const JsonValue* tc = kv.second.get("texcoord"))
+                if (!(JsonValue::String == tc->type && tc->str == "UV0")) t_unsupported_texture = true;
+            continue;
+        }
+        t_unsupported_texture = true;  // "file", "swizzle", "invert", ChannelMix, Checker, DetailNormal, Max, Mix, Mul, Noise ...
+    }
+    if (!id) {
+        t_unsupported_texture = true;
+        return false;
+    }
     struct { uint32_t color_image, color_sampler; float color_scale[2]; } m;
     m.color_image = uint32_t(id->f32(0.f));
     m.color_sampler = ZYGPU_TEX_LINEAR | ZYGPU_TEX_REPEAT_U | ZYGPU_TEX_REPEAT_V;  // texture.zig:22-27 DefaultMode
@@ -210,6 +228,12 @@ static Vec4f conductorColor(const std::string& name) {
 
 // material_provider.zig:131-162, 262-342, 411-436 (uniform values only; image textures are SURVEY §8(f))
 void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) {
+    t_unsupported_texture = false;
+    parseMaterialBody(m, v, kind);
+    if (t_unsupported_texture) m.flags |= ZYGPU_MATF_UNSUPPORTED;
+}
+
+void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) {
     std::memset(&m, 0, sizeof(m));
     m.kind = kind;
     m.cos_a = -1.f;
@@ -256,6 +280,8 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
         m.camera_weight = e.memberF32("camera_weight", 1.f);
         m.emission_num_samples = std::min<uint32_t>(e.memberU32("num_samples", 1), 64u);
         if (const JsonValue* em = e.get("emission_map")) readImageTexture(*em, m.emission_image, m.emission_sampler, m.emission_scale);
+        // IES profiles (emittance.zig:20, 60-78) and black-body temperature maps: not built
+        if (e.get("profile") || e.get("temperature_map")) t_unsupported_texture = true;
     };
 
     // material_provider.zig:177-178, 244-245, 265-266: Glass, Light and Substitute read "mask" (usage Opacity)
@@ -294,7 +320,7 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
             for (const auto& kv : v.obj) {
                 const std::string& k = kv.first;
                 const JsonValue&   x = kv.second;
-                if (k == "color") {
+                if (k == "color" || k == "subsurface_color") {  // material_provider.zig:267
                     if (!readColorTexture(x, m)) {
                         const Vec4f col = readColor(x);
                         for (int i = 0; i < 3; ++i) m.color_a[i] = col[i];
@@ -378,8 +404,12 @@ void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) 
                 const JsonValue&   x = kv.second;
                 if (k == "color" || k == "attenuation_color") attenuation_color = readColor(x);
                 else if (k == "attenuation_distance") attenuation_distance = x.f32(attenuation_distance);
-                else if (k == "roughness") m.roughness = x.f32(m.roughness);
-                else if (k == "specular") m.specular = x.f32(m.specular);
+                else if (k == "roughness" || k == "specular") {
+                    // readValue (material_provider.zig:188-191): Glass with a roughness / specular map is not built
+                    if (JsonValue::Object == x.type) t_unsupported_texture = true;
+                    else if (k == "roughness") m.roughness = x.f32(m.roughness);
+                    else m.specular = x.f32(m.specular);
+                } else if (k == "normal") t_unsupported_texture = true;  // Glass with a normal map (glass_material.zig:66-71)
                 else if (k == "priority") m.priority = int32_t(x.f32(0.f));
                 else if (k == "ior") m.ior = x.f32(m.ior);
                 else if (k == "abbe") m.abbe = x.f32(0.f);
@@ -1434,6 +1464,7 @@ int Engine::compile(uint32_t frame) {
     }
     for (uint32_t mid : material_ids_) {
         const ZygpuMaterial& m = materials_[mid];
+        if (m.flags & ZYGPU_MATF_UNSUPPORTED) return -9;
         // subsurface scattering (substitute_material.zig:71-74: a scattering volume inside the surface): volumes are out of scope
         if (ZYGPU_MAT_SUBSTITUTE == m.kind && m.attenuation_distance > 0.f) return -7;
         // an emitter under a clearcoat: evaluateRadiance attenuates by the coating (substitute_material.zig:283-293), not restated

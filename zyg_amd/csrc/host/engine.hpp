@@ -171,6 +171,7 @@ class Engine {
 
   private:
     void     parseMaterial(ZygpuMaterial& m, const JsonValue& rendering_value, uint32_t kind);
+    void     parseMaterialBody(ZygpuMaterial& m, const JsonValue& rendering_value, uint32_t kind);
     void     commitMaterial(ZygpuMaterial& m);
     void     classifyProp(uint32_t p);
     bool     shapeFinite(uint32_t shape) const;
