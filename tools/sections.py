@@ -12,7 +12,10 @@ from zyg_amd import scenes
 w, h, iters = 1920, 1080, 16
 material = sys.argv[1] if len(sys.argv) > 1 else "lambert"
 eng = zyg_amd.Engine()
-scenes.cornell(eng, w, h, iters, integrator="PTMIS", material=material)
+kw = {}
+if os.environ.get("ZYG_SCENE") == "mesh":  # BASELINE.json configs[2]
+    kw = dict(boxes=False, mesh=scenes.heightfield_mesh(), mesh_material=scenes.substitute((0.7, 0.7, 0.7)))
+scenes.cornell(eng, w, h, iters, integrator="PTMIS", material=material, **kw)
 eng.start_frame(0)
 lib, ctx = eng.lib, eng.context()
 lib.zygpu_get_section_cycles.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
