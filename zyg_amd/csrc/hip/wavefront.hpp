@@ -661,8 +661,10 @@ ZD Trafo cameraTrafoAt(const ZygpuViewDesc& v, uint32_t frame, float shutter_sam
 // ---------------------------------------------------------------- wf_generate
 // Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
 // Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
-template <bool POOL, bool AOV = false>
-ZD void generatePath(const Params& P, uint32_t slot) {
+// KEEP: the caller shades the new path at once (wf_trace_shade<FIRST>): the sampler and the throughput stay in registers
+// (`keep`) instead of going to the pool and straight back
+template <bool POOL, bool AOV = false, bool KEEP = false>
+ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr) {
     if (AOV && c_view.v.aov_slots) {  // aov.Value.clear (aov_value.zig:62-73): Depth starts at f32 max
 #pragma unroll
         for (uint32_t k = 0; k < 6; ++k) {
@@ -733,10 +735,14 @@ ZD void generatePath(const Params& P, uint32_t slot) {
     h.vdepth = 0;
     h.flags = ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR;
     h.nee = 0;
-    storeHead<POOL>(P, slot, h);  // POOL: vertex 0 of half 0 has the slot's own index
+    if (KEEP) {
+        *keep = h;
+    } else {
+        storeHead<POOL>(P, slot, h);  // POOL: vertex 0 of half 0 has the slot's own index
+        P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, POOL ? 1.f : 0.f);              // POOL: w = vertex.split_weight
+    }
     P.pool.ray_o[slot] = f4(origin_w, kRayMaxT);
     P.pool.ray_d[slot] = f4(direction_w, 0.f);
-    P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, POOL ? 1.f : 0.f);                  // POOL: w = vertex.split_weight
     P.pool.vorigin[slot] = f4(origin_w, POOL ? __uint_as_float(1u) : 0.f);            //       w = vertex.path_count
     if (POOL) {
         P.pool.med0[slot] = make_uint4(0u, 0u, 0u, 0u);
@@ -1064,15 +1070,17 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 // 280-341, vertex.zig:137-212).  The ray, the hit and the candidate count come from the caller: wf_shade reads them from the
 // pool, wf_trace_shade still has them in registers.  `defer` (first pass only): the vertex has emission to evaluate and
 // goes to the second pass untouched.
-template <bool STATS, bool MESHL, bool HEAVY, bool POOL>
+// PRE: a path generated in this kernel (`pre`: its sampler and flags, throughput 1): nothing of it is in the pool yet
+template <bool STATS, bool MESHL, bool HEAVY, bool POOL, bool PRE = false>
 ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
-                    Counters& cnt, SectionTimer& tm) {
+                    Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr) {
     const DScene&  s = c_scene;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
     const uint32_t ps = sampleSlot<POOL>(slot);
     PathHead       h;
-    loadHead<POOL>(P, slot, h);
+    if (PRE) h = *pre;
+    else loadHead<POOL>(P, slot, h);
     const uint32_t hit_prop = hit.prop;
     const bool     has_hit = kNull != hit_prop;
     // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
@@ -1091,7 +1099,13 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || (!has_hit && kRayMaxT == ro.w));
         defer = connectsLights(h.flags) && (emissive || 0 != ucount || infinite);
     }
-    if (defer) return;
+    if (defer) {
+        if (PRE) {  // the second pass reads the path from the pool
+            storeHead<POOL>(P, slot, h);
+            P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+        }
+        return;
+    }
     // the fragment: needed here for emission (second pass) and by the POOL record; otherwise wf_scatter rebuilds it from
     // the hit (loadSurface) and this kernel only needs the hit's part
     Fragment frag;
@@ -1139,7 +1153,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             if (MESHL && !has_hit && kRayMaxT == ray.max_t) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
         }
     }
-    const float4 thr4 = P.pool.thr[slot];
+    const float4 thr4 = PRE ? make_float4(1.f, 1.f, 1.f, 0.f) : float4(P.pool.thr[slot]);
     f3           throughput = xyz4(thr4);
     const float  split_weight = POOL ? thr4.w : 1.f;
     Mediums      md;
@@ -1290,7 +1304,11 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
         uint32_t slot = 0;
         if (i < n) {
             slot = FIRST ? i : P.q.ext[cur][at];
-            if (FIRST) generatePath<false, MESHL>(P, slot);
+            // the fresh path stays in registers until it is shaded, unless the traversal may draw from its sampler through the
+            // pool (opacity masks: the MESHL instantiations)
+            constexpr bool kFresh = FIRST && !MESHL;
+            PathHead       fresh;
+            if (FIRST) generatePath<false, MESHL, kFresh>(P, slot, &fresh);
             tm.mark(8);
             const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
             const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0.get(slot).y;
@@ -1313,7 +1331,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
             if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL, UTLAS>(P, scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             tm.mark(10);
-            shadeVertex<STATS, MESHL, false, false>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm);
+            shadeVertex<STATS, MESHL, false, false, kFresh>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh);
             if (defer || alive) {  // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool
                 P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
                 P.pool.hit_prop[slot] = hit.prop;
