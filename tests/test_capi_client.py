@@ -230,18 +230,48 @@ def test_animated_props(product_lib, oracle, integrator):
     assert not np.array_equal(films[0], films[1])
 
 
-def test_animated_light_is_refused(product_lib):
+@pytest.mark.gpu
+@pytest.mark.parametrize("integrator,kind", [("PTMIS", "quads"), ("PTDL", "quads"), ("PT", "quads"), ("PTMIS", "spheres"), ("PTMIS", "meshes"),
+                                             ("PTMIS", "sun")])
+def test_animated_lights(product_lib, oracle, integrator, kind):
+    """Lights with keyframes: a light sample is taken on the light where it is at the path's time (Light.sampleTo with
+    scene.propTransformationAt, light.zig:84-107), a ray that hits the light meets it at its own time, and the light tree holds
+    the light's swept bounds and merged cone (scene.zig:445-488).  Quad, Sphere, mesh and Distant emitters; film == the oracle's
+    and != the static scene's."""
     from zyg_amd import scenes
-    messages = []
-    log = ctypes.CFUNCTYPE(None, c_uint32, c_char_p)(lambda level, text: messages.append((level, text.decode())))
-    product_lib.su_register_log(log)
-    try:
+    w, h, spp = 80, 60, 4
+    films = []
+    for animate in (False, True):
         with zyg_amd.Engine(product_lib) as e:
-            ids = scenes.cornell(e, 32, 24, 1)
-            m = np.ascontiguousarray(scenes.trafo((1, 0, 0), (0, 0, 1), (0.5, 0.5, 1), (0, 1.9, 0)), dtype=np.float32).reshape(16)
-            assert e.lib.su_prop_set_transformation_frame(ids["lights"][0], 1, m.ctypes.data_as(POINTER(c_float))) == 0
-            assert e.lib.su_ext_compile(0) == -1 or e.lib.su_start_frame(0) == -1
-            assert e.lib.su_start_frame(0) == -1
-            assert any("animated lights" in text for _, text in messages), messages
-    finally:
-        product_lib.su_register_log(None)
+            if "sun" == kind:
+                ids = scenes.outdoor(e, w, h, spp, integrator=integrator)
+            else:
+                ids = scenes.cornell(e, w, h, spp, integrator=integrator, sphere_lights="spheres" == kind, mesh_lights="meshes" == kind,
+                                     unoccluding_lights="quads" != kind or "PTDL" != integrator)
+            if animate:
+                def frames(prop, m0, m1):
+                    for k, m in enumerate((m0, m1)):
+                        a = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+                        assert e.lib.su_prop_set_transformation_frame(prop, k, a.ctypes.data_as(POINTER(c_float))) == 0
+                c, s_ = np.cos(0.5), np.sin(0.5)
+                if "sun" == kind:
+                    sun = ids["sun"]
+                    r0, r1 = scenes._basis_for((-0.35, -0.8, 0.45))  # the light's z axis points from the light into the scene
+                    q0, q1 = scenes._basis_for((0.2, -0.9, 0.3))
+                    frames(sun, scenes.trafo(r0, r1, (0.05, 0.05, 0.05), (0, 0, 0)), scenes.trafo(q0, q1, (0.05, 0.05, 0.05), (0, 0, 0)))
+                else:
+                    size = (0.3, 0.3, 0.3) if "spheres" == kind else (1, 1, 1) if "meshes" == kind else (0.5, 0.5, 1)
+                    y = 1.7 if "spheres" == kind else 1.98
+                    a, b = ids["lights"]
+                    frames(a, scenes.trafo((1, 0, 0), (0, 0, 1), size, (-0.45, y, 0.0)), scenes.trafo((c, s_, 0), (0, 0, 1), size, (-0.2, y - 0.3, 0.3)))
+                    frames(b, scenes.trafo((1, 0, 0), (0, 0, 1), size, (0.45, y, 0.0)), scenes.trafo((1, 0, 0), (0, s_, c), size, (0.45, y - 0.1, -0.4)))
+            e.start_frame(0)
+            e.render_iterations(spp)
+            e.synchronize()
+            film = e.download_film(w, h)
+            sd = e.lib.su_ext_scene_desc().contents
+            vd = e.lib.su_ext_view_desc().contents
+            assert (sd.num_keyframes > 0) == animate
+            assert np.array_equal(film, oracle_render(oracle, sd, vd, spp)), animate
+            films.append(film)
+    assert not np.array_equal(films[0], films[1])

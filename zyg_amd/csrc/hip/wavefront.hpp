@@ -997,7 +997,7 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
         if (STATS) cnt.instances += 1;
         if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
         Fragment frag;
-        frag.trafo = loadTrafo(s, p);
+        frag.trafo = propTrafoAt<true>(s, p, ray.time);  // an infinite light may be animated like any prop (prop.zig:239-264)
         float u = 0.f, vv = 0.f;
         if (ZYGPU_SHAPE_DISTANT == prop.shape) {
             if (!distantIntersect(ray, frag.trafo, u, vv)) continue;
@@ -1739,7 +1739,8 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         for (uint32_t pk = 0; pk < num_picks; ++pk) {
             const LightPick      pick = picks[pk];
             const ZygpuLight     light = s.lights[pick.offset];
-            const Trafo          trafo = loadTrafo(s, light.prop);
+            // the light at the path's time (light.zig:84-107 <- scene.propTransformationAt): an animated light moves
+            const Trafo          trafo = propTrafoAt<MESHL>(s, light.prop, pathTime<POOL, MESHL>(P, slot));
             const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
             // PathtracerDL samples its lights with threshold 0 (pathtracer_dl.zig:139-167)
             const float sample_threshold = mis ? nee_threshold : 0.f;

@@ -828,11 +828,6 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             g_error = "ZygpuSceneDesc: animated props need at least 2 interpolation frames";
             return -2;
         }
-        for (uint32_t l = 0; l < d->num_lights; ++l)
-            if (ZYGPU_NULL != d->prop_frames[d->lights[l].prop]) {
-                g_error = "an animated prop is a light: lights must be static";
-                return -2;
-            }
         ok = ok && m.upload(reinterpret_cast<const float4*>(d->keyframes), size_t(d->num_keyframes) * 3, &s.keyframes) &&
              m.upload(d->prop_frames, d->num_props, &s.prop_frames);
         s.origin = make_float4(d->origin[0], d->origin[1], d->origin[2], d->origin[3]);

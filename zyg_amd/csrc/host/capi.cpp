@@ -53,8 +53,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
     Capi& c = *g;
     const int rc = c.engine.compile(frame);
     if (0 != rc) {
-        logf(2, -6 == rc   ? "a light has keyframes (su_prop_set_transformation_frame): animated lights are not supported"
-                : -7 == rc ? "a Substitute material has an attenuation_distance: subsurface scattering is a volume, not supported"
+        logf(2, -7 == rc ? "a Substitute material has an attenuation_distance: subsurface scattering is a volume, not supported"
                 : -8 == rc ? "an emissive Substitute material with a coating is not supported"
                 : -9 == rc ? "a material in use asks for a texture feature that is not supported (procedural textures, image files, swizzles, "
                              "Triplanar coordinates, IES profiles, Glass normal / roughness maps)"

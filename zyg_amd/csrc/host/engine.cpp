@@ -1345,25 +1345,44 @@ int Engine::compile(uint32_t frame) {
             l.light_class = ZYGPU_LIGHT_PROP_IMAGE;
         }
 
-        if (ZYGPU_NULL != c_prop_frames_[l.prop]) return -6;  // an animated light: its bounds, cone and power would move (scene.zig:402-497)
         const Transformation& t = frameStartTransformation(l.prop);
         Transformation        rel = t;
         rel.position = t.position - camera_pos;
 
         // shape_sampler.zig:108-120: a mesh part brings its own box and cone, the analytic shapes use the shape's
-        AABB bb = aabbTransform(is_mesh ? mesh_lights_[l.sampler].aabb : shapeAabb(hp.shape), objectToWorld(rel));
-        aabbCacheRadius(bb);
-
+        const AABB part_aabb = is_mesh ? mesh_lights_[l.sampler].aabb : shapeAabb(hp.shape);
         // shape.zig:115-120: Disk / Rectangle / Distant emit into a half space, the other analytic shapes everywhere
-        const Vec4f  part_cone = is_mesh ? mesh_lights_[l.sampler].cone : vec(0.f, 0.f, 1.f, (is_sphere || is_dome || is_canopy) ? -1.f : 1.f);
-        const Mat3x3 rot = quaternionToMat3x3(t.rotation);
-        Mat3x3       rot_s = rot;  // rows carry the scale in w, as the reference's ComposedTransformation does
-        for (int i = 0; i < 3; ++i) rot_s.r[i][3] = t.scale[i];
-        const Vec4f tc = transformVector(rot_s, part_cone);
-        c_light_cones_[4 * li + 0] = tc[0];
-        c_light_cones_[4 * li + 1] = tc[1];
-        c_light_cones_[4 * li + 2] = tc[2];
-        c_light_cones_[4 * li + 3] = part_cone[3];
+        const Vec4f part_cone = is_mesh ? mesh_lights_[l.sampler].cone : vec(0.f, 0.f, 1.f, (is_sphere || is_dome || is_canopy) ? -1.f : 1.f);
+        AABB        bb;
+        Vec4f       cone;
+        if (ZYGPU_NULL == c_prop_frames_[l.prop]) {
+            bb = aabbTransform(part_aabb, objectToWorld(rel));
+            const Mat3x3 rot = quaternionToMat3x3(t.rotation);
+            Mat3x3       rot_s = rot;  // rows carry the scale in w, as the reference's ComposedTransformation does
+            for (int i = 0; i < 3; ++i) rot_s.r[i][3] = t.scale[i];
+            const Vec4f tc = transformVector(rot_s, part_cone);
+            cone = vec(tc[0], tc[1], tc[2], part_cone[3]);
+        } else {
+            // an animated light (scene.zig:445-488): the box bounds the part at the keyframes and at NumSteps - 1 steps between
+            // them, the cone grows by merging.  Restated as written there: the keyframes' positions are taken as they are
+            // (not relative to the camera), and every step merges the running cone with the running cone turned by the step's
+            // rotation
+            const std::vector<Transformation>& kf = keyframes_[l.prop];
+            auto composed = [](const Transformation& k) { return objectToWorld(k); };
+            bb = aabbTransform(part_aabb, composed(kf[0]));
+            const Vec4f tc0 = transformVector(quaternionToMat3x3(kf[0].rotation), part_cone);
+            cone = vec(tc0[0], tc0[1], tc0[2], part_cone[3]);
+            auto step = [&](const Transformation& k) {
+                aabbMerge(bb, aabbTransform(part_aabb, composed(k)));
+                const Vec4f tc = transformVector(quaternionToMat3x3(k.rotation), cone);
+                cone = coneMerge(cone, vec(tc[0], tc[1], tc[2], cone[3]));
+            };
+            for (size_t i = 0; i + 1 < kf.size(); ++i)
+                for (int j = 1; j < 4; ++j) step(lerpTransformation(kf[i], kf[i + 1], 0.25f * float(j)));
+            step(kf.back());
+        }
+        aabbCacheRadius(bb);
+        for (int i = 0; i < 4; ++i) c_light_cones_[4 * li + i] = cone[i];
 
         // shape.zig:132-152: Rectangle area, TriangleMesh part area (triangle_mesh.zig:376-380), Distant solid angle (distant.zig:143-145)
         const float extent = is_canopy  ? 2.f * float(M_PI)
