@@ -120,7 +120,7 @@ enum ZygpuMaterialFlags {
      * translucency, flakes or a rotated tangent frame (set by the host; the device runs its complete closure for it) */
     ZYGPU_MATF_EXTENDED = 1u << 4,
     /* the description the material was made from asked for something that is not built (a procedural texture, an image file,
-     * a swizzle, Triplanar coordinates, an IES profile, a Glass normal map ...): zygpu_upload_scene refuses a scene that uses it */
+     * Triplanar coordinates, an IES profile ...): zygpu_upload_scene refuses a scene that uses it */
     ZYGPU_MATF_UNSUPPORTED = 1u << 31
 };
 
@@ -138,7 +138,8 @@ typedef struct ZygpuTexture {
     float    scale[2];
 } ZygpuTexture;
 
-/* Substitute's textures beyond the colour map (substitute_material.zig:37-48; one channel each: Byte1 / Float1 images; the
+/* Substitute's textures beyond the colour map (substitute_material.zig:37-48; Glass uses ROUGHNESS, SPECULAR and NORMAL,
+ * glass_material.zig:22-24; one channel each: Byte1 / Float1 images; the
  * two normal maps: two channels, Byte2 read as snorm or Float2, material_helper.zig:16-20) */
 enum ZygpuSubstituteTexture {
     ZYGPU_STEX_ROUGHNESS = 0,

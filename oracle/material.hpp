@@ -952,8 +952,14 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.can_evaluate = false;
     } else if (ZYGPU_MAT_GLASS == m.kind) {
         // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66)
-        s.frame = {rs.t, rs.b, rs.n};
-        const float r = 0.f == m.roughness ? 0.f : ggx::clampRoughness(m.roughness);
+        auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
+            const ZygpuTexture& t = m.tex[slot];
+            return kNull != t.image ? sampleImageMap1(scene, t.image, t.sampler, t.scale, rs.uvw[0], rs.uvw[1], rs.stochastic_r) : uniform;
+        };
+        const float raw_r = weight(ZYGPU_STEX_ROUGHNESS, m.roughness);
+        const float r = 0.f == raw_r ? 0.f : ggx::clampRoughness(raw_r);
+        if (kNull != m.tex[ZYGPU_STEX_NORMAL].image) s.frame = Frame::init(sampleNormal(scene, m.tex[ZYGPU_STEX_NORMAL], wo, rs));
+        else s.frame = {rs.t, rs.b, rs.n};
         s.alpha[0] = s.alpha[1] = r * r;
         rs.regularizeAlpha(s.alpha, scene.specular_threshold);
         const bool rough = s.alpha[0] > 0.f;
@@ -967,7 +973,7 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.wavelength = rs.wavelength;
         s.translucent = m.thickness > 0.f;
         s.specular_threshold = scene.specular_threshold;
-        s.specular = m.specular;
+        s.specular = weight(ZYGPU_STEX_SPECULAR, m.specular);
         s.lower_priority = m.priority < rs.highest_priority;  // sample_base.zig:44
     } else {
         // Substitute.sample (substitute_material.zig:114-221) without the volumetric branches

@@ -1025,3 +1025,22 @@ def test_dispersion_conserves_energy_on_average(engine, oracle):
         return engine.resolve(48, 36)[..., :3].mean(axis=(0, 1))
     a, b = mean(25.0), mean(0.0)
     assert np.allclose(a, b, rtol=0.05), (a, b)
+
+
+@pytest.mark.parametrize("integrator", ["PTMIS", "PT"])
+def test_glass_with_maps(engine, oracle, integrator):
+    """Glass whose roughness and specular weight come from images and whose shading normal comes from a normal map
+    (glass_material.zig:49-71, material_provider.zig:179-188): the pool kernels rebuild the closure from the vertex record's uv."""
+    rough = engine.image(scenes.weight_image(8, 0.0, 0.4))   # texels of exactly 0 keep that part of the surface smooth (:51)
+    spec = engine.image(scenes.weight_image(5, 0.3, 1.0, np.uint8))
+    normal = engine.image(scenes.normal_image(16, 0.4, np.uint8))
+    T = scenes.tex
+    glass = {"box": scenes.glass(1.5, (0.8, 0.9, 1.0), 0.5, roughness=T(rough, scale=3.0), normal=T(normal, "Normal", scale=2.0)),
+             "sphere": scenes.glass(1.45, roughness=0.1, specular=T(spec), normal=T(normal, "Normal"))}
+    out = _render_both(engine, oracle, 80, 60, 4, integrator=integrator, glass_objects=glass)
+    _check(*out, 4)
+    engine.release()
+    engine.__init__(engine.lib)
+    plain = _render_both(engine, oracle, 80, 60, 4, stats=False, integrator=integrator,
+                         glass_objects={"box": scenes.glass(1.5, (0.8, 0.9, 1.0), 0.5), "sphere": scenes.glass(1.45, roughness=0.1)})
+    assert rms(out[1], plain[1]) > 1e-3

@@ -410,10 +410,8 @@ def test_malformed_meshes_are_refused(product_lib):
 @pytest.mark.parametrize("material", [
     '{"rendering": {"Substitute": {"color": {"Checker": {"scale": 4}}}}}',                       # procedural texture
     '{"rendering": {"Substitute": {"roughness": {"file": "rough.png"}}}}',                        # image file
-    '{"rendering": {"Substitute": {"roughness": {"id": 0, "swizzle": "Y"}}}}',
     '{"rendering": {"Substitute": {"color": {"id": 0, "sampler": {"texcoord": "Triplanar"}}}}}',
-    '{"rendering": {"Glass": {"ior": 1.5, "normal": {"id": 0}}}}',
-    '{"rendering": {"Glass": {"ior": 1.5, "roughness": {"id": 0}}}}',
+    '{"rendering": {"Glass": {"ior": 1.5, "normal": {"Checker": {}}}}}',
     '{"rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "profile": {"file": "lamp.ies"}}}}}',
 ])
 def test_unsupported_texture_features_do_not_compile(product_lib, material):
@@ -425,6 +423,17 @@ def test_unsupported_texture_features_do_not_compile(product_lib, material):
         p = e.prop(scenes.RECTANGLE, [e.material(material)])
         e.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, 0)))
         assert e.lib.su_ext_compile(0) == -1
+
+
+def test_file_loader_options_on_an_image_id_are_ignored(product_lib):
+    """"swizzle" / "invert" belong to the image-file loader; createTexture (material_provider.zig:700-736) does not look at them
+    for an image id."""
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 8, 8, 1, material="substitute")
+        one = e.image(scenes.weight_image(4))
+        p = e.prop(scenes.RECTANGLE, [e.material('{"rendering": {"Substitute": {"roughness": {"id": %d, "swizzle": "Y", "invert": true}}}}' % one)])
+        e.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, 0)))
+        assert e.lib.su_ext_compile(0) == 0
 
 
 def test_unused_unsupported_material_is_harmless(product_lib):

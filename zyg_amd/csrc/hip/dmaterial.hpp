@@ -907,15 +907,24 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         ms.a0 = ms.a1 = 0.f;
         ms.can_evaluate = false;
     } else if (ZYGPU_MAT_GLASS == m.kind) {
-        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66)
-        const float r = 0.f == m.roughness ? 0.f : mx(m.roughness, kMinRoughness);
+        // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66); roughness, specular and the normal may
+        // come from maps (EXT, like the extended Substitute)
+        float raw_r = m.roughness, specular = m.specular;
+        if (EXT && (m.flags & ZYGPU_MATF_EXTENDED)) {
+            const FragmentExtra& f = *fx;
+            const ZygpuTexture & tr = m.tex[ZYGPU_STEX_ROUGHNESS], &tsp = m.tex[ZYGPU_STEX_SPECULAR], &tn = m.tex[ZYGPU_STEX_NORMAL];
+            if (kNull != tr.image) raw_r = sampleImageMap1(s, tr.image, tr.sampler, tr.scale, f.u, f.v, f.stochastic_r);
+            if (kNull != tsp.image) specular = sampleImageMap1(s, tsp.image, tsp.sampler, tsp.scale, f.u, f.v, f.stochastic_r);
+            if (kNull != tn.image) ms.frame = Frame::init(sampleNormal(s, tn, wo, geo_n, t, b, n, f));
+        }
+        const float r = 0.f == raw_r ? 0.f : mx(raw_r, kMinRoughness);
         ms.a0 = ms.a1 = r * r;
         reg.apply(ms.a0, ms.a1, s.specular_threshold, caustics);
         const bool rough = ms.a0 > 0.f;
         ms.can_evaluate = rough && m.ior != ior_outside;
         const float t_ = (m.ior - ior_outside) / (m.ior + ior_outside);
         ms.glass_f0 = rough ? t_ * t_ : 0.f;
-        ms.specular = m.specular;
+        ms.specular = specular;
         ms.thickness = m.thickness;
         ms.abbe = m.abbe;
         ms.absorption = mk3(m.absorption[0], m.absorption[1], m.absorption[2]);

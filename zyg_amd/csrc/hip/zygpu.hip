@@ -856,7 +856,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t pi = 0; pi < d->num_parts; ++pi) {
         const ZygpuMaterial& gm = d->materials[d->material_ids[pi]];
         if (ZYGPU_MAT_GLASS != gm.kind) continue;
-        if (gm.roughness > 0.f && !d->luts.e_s) {
+        if ((gm.roughness > 0.f || ZYGPU_NULL != gm.tex[ZYGPU_STEX_ROUGHNESS].image) && !d->luts.e_s) {
             g_error = "rough Glass needs the E_s table in ZygpuSceneDesc.luts";
             return -2;
         }
@@ -946,7 +946,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                     return -2;
                 }
         }
-        if (ZYGPU_MAT_SUBSTITUTE == mat.kind) {
+        if (ZYGPU_MAT_SUBSTITUTE == mat.kind || ZYGPU_MAT_GLASS == mat.kind) {
             for (uint32_t t = 0; t < ZYGPU_STEX_COUNT; ++t) {
                 const uint32_t image = mat.tex[t].image;
                 if (ZYGPU_NULL == image) continue;
@@ -961,11 +961,11 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                     return -2;
                 }
             }
-            if ((mat.flags & ZYGPU_MATF_EMISSIVE) && mat.coating_thickness > 0.f) {
+            if (ZYGPU_MAT_SUBSTITUTE == mat.kind && (mat.flags & ZYGPU_MATF_EMISSIVE) && mat.coating_thickness > 0.f) {
                 g_error = "an emissive Substitute with a coating is not supported";
                 return -2;
             }
-            if (mat.attenuation_distance > 0.f) {
+            if (ZYGPU_MAT_SUBSTITUTE == mat.kind && mat.attenuation_distance > 0.f) {
                 g_error = "Substitute with an attenuation_distance (subsurface scattering) is a volume: not supported";
                 return -2;
             }

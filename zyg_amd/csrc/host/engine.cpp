@@ -39,13 +39,15 @@ static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& samp
     const JsonValue* id = v.get("id");
     for (const auto& kv : v.obj) {
         const std::string& k = kv.first;
-        if (k == "id" || k == "usage" || k == "scale") continue;
+        // "swizzle" and "invert" are options of the image-file loader: with an image id the reference ignores them, too
+        // (createTexture, material_provider.zig:700-736)
+        if (k == "id" || k == "usage" || k == "scale" || k == "swizzle" || k == "invert") continue;
         if (k == "sampler") {
             if (const JsonValue* tc = kv.second.get("texcoord"))
                 if (!(JsonValue::String == tc->type && tc->str == "UV0")) t_unsupported_texture = true;
             continue;
         }
-        t_unsupported_texture = true;  // "file", "swizzle", "invert", ChannelMix, Checker, DetailNormal, Max, Mix, Mul, Noise ...
+        t_unsupported_texture = true;  // "file" (it wins over "id"), ChannelMix, Checker, DetailNormal, Max, Mix, Mul, Noise ...
     }
     if (!id) {
         t_unsupported_texture = true;
@@ -404,12 +406,9 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
                 const JsonValue&   x = kv.second;
                 if (k == "color" || k == "attenuation_color") attenuation_color = readColor(x);
                 else if (k == "attenuation_distance") attenuation_distance = x.f32(attenuation_distance);
-                else if (k == "roughness" || k == "specular") {
-                    // readValue (material_provider.zig:188-191): Glass with a roughness / specular map is not built
-                    if (JsonValue::Object == x.type) t_unsupported_texture = true;
-                    else if (k == "roughness") m.roughness = x.f32(m.roughness);
-                    else m.specular = x.f32(m.specular);
-                } else if (k == "normal") t_unsupported_texture = true;  // Glass with a normal map (glass_material.zig:66-71)
+                else if (k == "roughness") readWeight(x, m.roughness, ZYGPU_STEX_ROUGHNESS);  // material_provider.zig:179-188
+                else if (k == "specular") readWeight(x, m.specular, ZYGPU_STEX_SPECULAR);
+                else if (k == "normal") readNormal(x, ZYGPU_STEX_NORMAL);
                 else if (k == "priority") m.priority = int32_t(x.f32(0.f));
                 else if (k == "ior") m.ior = x.f32(m.ior);
                 else if (k == "abbe") m.abbe = x.f32(0.f);
@@ -448,7 +447,13 @@ void Engine::commitMaterial(ZygpuMaterial& m) {
         m.flags &= ~uint32_t(ZYGPU_MATF_TWO_SIDED | ZYGPU_MATF_EVALUATE_VISIBILITY | ZYGPU_MATF_CAUSTIC);
         if (thin) m.flags |= ZYGPU_MATF_TWO_SIDED;
         if (thin || masked) m.flags |= ZYGPU_MATF_EVALUATE_VISIBILITY;
-        if (m.roughness * m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
+        // properties.caustic = roughness.isUniform() and roughness^2 <= specular_threshold (glass_material.zig:41)
+        if (ZYGPU_NULL == m.tex[ZYGPU_STEX_ROUGHNESS].image && m.roughness * m.roughness <= specular_threshold) m.flags |= ZYGPU_MATF_CAUSTIC;
+        // a roughness / specular / normal map: the closure needs the fragment's uv
+        if (ZYGPU_NULL != m.tex[ZYGPU_STEX_ROUGHNESS].image || ZYGPU_NULL != m.tex[ZYGPU_STEX_SPECULAR].image ||
+            ZYGPU_NULL != m.tex[ZYGPU_STEX_NORMAL].image)
+            m.flags |= ZYGPU_MATF_EXTENDED;
+        else m.flags &= ~uint32_t(ZYGPU_MATF_EXTENDED);
     }
 }
 
@@ -1468,7 +1473,7 @@ int Engine::compile(uint32_t frame) {
         return (ZYGPU_IMAGE_BYTE3_SRGB == f || ZYGPU_IMAGE_FLOAT3 == f) ? 3 : (ZYGPU_IMAGE_BYTE2 == f || ZYGPU_IMAGE_FLOAT2 == f) ? 2 : 1;
     };
     for (const ZygpuMaterial& m : materials_) {
-        if (ZYGPU_MAT_SUBSTITUTE == m.kind) {
+        if (ZYGPU_MAT_SUBSTITUTE == m.kind || ZYGPU_MAT_GLASS == m.kind) {
             // image2D_1 reads one channel, image2D_2 (the normal maps) two (texture.zig:166-186)
             for (uint32_t t = 0; t < ZYGPU_STEX_COUNT; ++t) {
                 const uint32_t image = m.tex[t].image;
@@ -1490,7 +1495,9 @@ int Engine::compile(uint32_t frame) {
         if (ZYGPU_MAT_SUBSTITUTE == m.kind && (m.flags & ZYGPU_MATF_EMISSIVE) && m.coating_thickness > 0.f) return -8;
     }
     for (const ZygpuMaterial& m : materials_) {
-        if (ZYGPU_MAT_SUBSTITUTE != m.kind && !(ZYGPU_MAT_GLASS == m.kind && m.roughness > 0.f)) continue;
+        if (ZYGPU_MAT_SUBSTITUTE != m.kind &&
+            !(ZYGPU_MAT_GLASS == m.kind && (m.roughness > 0.f || ZYGPU_NULL != m.tex[ZYGPU_STEX_ROUGHNESS].image)))
+            continue;
         const ggxlut::Tables& t = ggxlut::tables();  // computed once per process (ggx_lut.hpp)
         d.luts.e_m = t.e_m.data();
         d.luts.e_m_avg = t.e_m_avg.data();
