@@ -441,3 +441,17 @@ def test_unused_unsupported_material_is_harmless(product_lib):
         scenes.cornell(e, 8, 8, 1, material="substitute")
         e.material('{"rendering": {"Substitute": {"color": {"Checker": {"scale": 4}}}}}')
         assert e.lib.su_ext_compile(0) == 0
+
+
+@pytest.mark.parametrize("integrators", ['{"surface": {"PTMIS": {}}, "particle": {"depth": {"surface": 4}}}',
+                                         '{"surface": {"PTMIS": {}}, "photon": {"num_photons": 1000}}',
+                                         '{"surface": {"AOV": {"value": "AO"}}}'])
+def test_other_integrators_are_refused(product_lib, integrators):
+    """The light tracer, photon mapping and the AOV surface integrator (take.zig:131-237) are not the path in scope: the frame
+    does not start, it is not rendered without them."""
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 8, 8, 1)
+        e.integrators(integrators)
+        assert e.lib.su_ext_compile(0) == -1
+        e.integrators('{"surface": {"PTMIS": {}}, "photon": {"num_photons": 0}}')
+        assert e.lib.su_ext_compile(0) == 0

@@ -894,8 +894,17 @@ void Engine::loadIntegrators(const JsonValue& v) {
         const float x = st->f32();
         specular_threshold = x * x;
     }
+    // the light tracer ("particle", take.zig:136-138, 227-237), photon mapping ("photon" with photons, 146-148) and the AOV
+    // surface integrator (154-187) are other algorithms than the path tracers in scope: a frame that asks for one does not
+    // start (compile returns -10) instead of rendering without it
+    unsupported_integrator_ = false;
+    if (const JsonValue* particle = v.get("particle"))
+        if (JsonValue::Object == particle->type && particle->memberU32("particles_per_pixel", 1) > 0) unsupported_integrator_ = true;
+    if (const JsonValue* photon = v.get("photon"))
+        if (JsonValue::Object == photon->type && photon->memberU32("num_photons", 0) > 0) unsupported_integrator_ = true;
     const JsonValue* surface = v.get("surface");
     if (!surface || JsonValue::Object != surface->type) return;
+    if (surface->get("AOV")) unsupported_integrator_ = true;
 
     auto loadDepth = [&](const JsonValue& n) {
         max_depth_surface = 16;
@@ -1486,6 +1495,7 @@ int Engine::compile(uint32_t frame) {
         if (ZYGPU_NULL != m.emission_image && m.emission_image < images_.size() && 3 != channels(m.emission_image)) return -4;
         if (ZYGPU_NULL != m.mask_image && (m.mask_image >= images_.size() || 1 != channels(m.mask_image))) return -4;  // image2D_1 reads one channel
     }
+    if (unsupported_integrator_) return -10;
     for (uint32_t mid : material_ids_) {
         const ZygpuMaterial& m = materials_[mid];
         if (m.flags & ZYGPU_MATF_UNSUPPORTED) return -9;

@@ -166,6 +166,7 @@ class Engine {
     float    split_threshold = 0.5f * 0.5f * 0.5f * 0.5f;
     bool     caustics_path = true;
     float    regularize_roughness = 0.f;
+    bool     unsupported_integrator_ = false;  // su_integrators_create asked for the light tracer, photons or the AOV integrator
 
     SensorSettings sensor;
 
