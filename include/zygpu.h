@@ -120,7 +120,7 @@ enum ZygpuMaterialFlags {
      * translucency, flakes or a rotated tangent frame (set by the host; the device runs its complete closure for it) */
     ZYGPU_MATF_EXTENDED = 1u << 4,
     /* the description the material was made from asked for something that is not built (a procedural texture, an image file,
-     * Triplanar coordinates, an IES profile ...): zygpu_upload_scene refuses a scene that uses it */
+     * an IES profile ...): zygpu_upload_scene refuses a scene that uses it */
     ZYGPU_MATF_UNSUPPORTED = 1u << 31
 };
 
@@ -207,7 +207,12 @@ typedef struct ZygpuMaterial {
 
 /* ZYGPU_TEX_SNORM: a Byte2 image read as snorm (byte / 128 - 1, base/encoding.zig:18-20): what usage Normal makes of it
  * (texture_provider.zig:70) */
-enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u, ZYGPU_TEX_SNORM = 8u };
+/* ZYGPU_TEX_TRIPLANAR / OBJECTPOS: the sampler's tex_coord (sampler_mode.zig, material_provider.zig:664-674): Triplanar reads
+ * the image at the fragment's object-space position projected along the dominant axis of its geometric normal
+ * (renderstate.zig:44-49), for a normal map both also choose the frame the mapped normal lives in (material_helper.zig:24-41);
+ * Substitute's and Glass' textures only (masks take the uv, material_base.zig:35-41) */
+enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u, ZYGPU_TEX_SNORM = 8u, ZYGPU_TEX_TRIPLANAR = 16u,
+       ZYGPU_TEX_OBJECTPOS = 32u };
 
 /* 2-D images behind textures (capi.zig:236-298, texture_provider.zig:67-84): Byte3 is read as sRGB and converted to AP1 per
  * fetch (texture.zig:196-199), Float3 is taken as is (213-216); the one-channel formats serve masks: Byte1 is unorm

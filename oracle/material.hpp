@@ -61,6 +61,9 @@ struct Renderstate {  // renderstate.zig:10-45 (subset in scope)
     float    wavelength = 0.f;                   // probe.wavelength (vertex.zig:167): 0 until a dispersive Glass picks one
     float    reg_weight = 0.f, reg_alpha = 0.f;  // PathtracerMIS' regularize_roughness and Vertex.reg_alpha (vertex.zig:168-169)
 
+    // the coordinates a texture is read at (texture_sampler.zig:22-35): rs.uv(), or rs.triplanarSt() (renderstate.zig:39-49)
+    void st(uint32_t sampler, float out[2]) const;
+
     // renderstate.zig:60-69: a path that has scattered diffusely sees later surfaces rougher
     void regularizeAlpha(float alpha[2], float specular_threshold) const {
         if (0.f == reg_weight || (alpha[0] <= specular_threshold && !caustics)) return;
@@ -833,15 +836,61 @@ struct MaterialSample {
     }
 };
 
+// hlp.triplanarMapping (material_helper.zig:81-93); p and n in object space
+inline void triplanarMapping(V4 p, V4 n, float uv[2]) {
+    const float an[3] = {std::fabs(n[0]), std::fabs(n[1]), std::fabs(n[2])};
+    if (an[0] > an[1] && an[0] > an[2]) {
+        const float sign = std::copysign(1.f, n[0]);
+        uv[0] = sign * p[2] + 0.5f;
+        uv[1] = -p[1] + 0.5f;
+    } else if (an[1] > an[0] && an[1] > an[2]) {
+        const float sign = std::copysign(1.f, n[1]);
+        uv[0] = sign * p[0] + 0.5f;
+        uv[1] = -p[2] + 0.5f;
+    } else {
+        const float sign = std::copysign(1.f, n[2]);
+        uv[0] = -sign * p[0] + 0.5f;
+        uv[1] = -p[1] + 0.5f;
+    }
+}
+
+inline void Renderstate::st(uint32_t sampler, float out[2]) const {
+    if (sampler & ZYGPU_TEX_TRIPLANAR) {
+        triplanarMapping(trafo.worldToObjectPoint(p), trafo.worldToObjectNormal(geo_n), out);
+    } else {
+        out[0] = uvw[0];
+        out[1] = uvw[1];
+    }
+}
+
 // hlp.sampleNormal (material_helper.zig:16-78), tex_coord UV0: the normal map's xy in the tangent frame, z reconstructed, then the
 // "iray" adaption that keeps the reflection of wo above the geometric surface
 inline V4 sampleNormal(const ZygpuSceneDesc& scene, const ZygpuTexture& map, V4 wo, const Renderstate& rs) {
-    float nmxy[2];
-    sampleImageMap2(scene, map.image, map.sampler, map.scale, rs.uvw[0], rs.uvw[1], rs.stochastic_r, nmxy);
+    float nmxy[2], st[2];
+    rs.st(map.sampler, st);
+    sampleImageMap2(scene, map.image, map.sampler, map.scale, st[0], st[1], rs.stochastic_r, nmxy);
     const float nmz = std::sqrt(mx(1.f - (nmxy[0] * nmxy[0] + nmxy[1] * nmxy[1]), 0.01f));
-    // rs.tangentToWorld (renderstate.zig:51-58)
-    const V4 n = normalize3(mk(nmxy[0] * rs.t[0] + nmxy[1] * rs.b[0] + nmz * rs.n[0], nmxy[0] * rs.t[1] + nmxy[1] * rs.b[1] + nmz * rs.n[1],
-                               nmxy[0] * rs.t[2] + nmxy[1] * rs.b[2] + nmz * rs.n[2]));
+    const V4    nm = mk(nmxy[0], nmxy[1], nmz);
+    V4          n;
+    if (map.sampler & ZYGPU_TEX_OBJECTPOS) {  // material_helper.zig:24-29
+        n = normalize3(Frame::init(rs.n).frameToWorld(nm));
+    } else if (map.sampler & ZYGPU_TEX_TRIPLANAR) {  // material_helper.zig:30-38, triplanarTangent 125-139
+        const V4    on = rs.trafo.worldToObjectNormal(rs.n);
+        const float an[3] = {std::fabs(on[0]), std::fabs(on[1]), std::fabs(on[2])};
+        V4          wt;
+        if (an[0] > an[1] && an[0] > an[2]) wt = S(std::copysign(1.f, on[0])) * rs.trafo.r[2];
+        else if (an[1] > an[0] && an[1] > an[2]) wt = S(std::copysign(1.f, on[1])) * rs.trafo.r[0];
+        else wt = S(-std::copysign(1.f, on[2])) * rs.trafo.r[0];
+        wt[3] = 0.f;
+        const V4    bt = cross3(rs.n, wt);
+        const V4    nt = cross3(bt, rs.n);
+        const Frame frame{nt, bt, rs.n};
+        n = normalize3(frame.frameToWorld(nm));
+    } else {
+        // rs.tangentToWorld (renderstate.zig:51-58)
+        n = normalize3(mk(nmxy[0] * rs.t[0] + nmxy[1] * rs.b[0] + nmz * rs.n[0], nmxy[0] * rs.t[1] + nmxy[1] * rs.b[1] + nmz * rs.n[1],
+                          nmxy[0] * rs.t[2] + nmxy[1] * rs.b[2] + nmz * rs.n[2]));
+    }
     const V4    ng = rs.geo_n;
     const V4    r = reflect3(n, wo);
     const float a = dot3(ng, r);
@@ -859,24 +908,6 @@ inline V4 sampleNormal(const ZygpuSceneDesc& scene, const ZygpuTexture& map, V4 
     }
     tangent += S(epsilon) * ng;
     return normalize3(wo + tangent);
-}
-
-// hlp.triplanarMapping (material_helper.zig:81-93); p and n in object space
-inline void triplanarMapping(V4 p, V4 n, float uv[2]) {
-    const float an[3] = {std::fabs(n[0]), std::fabs(n[1]), std::fabs(n[2])};
-    if (an[0] > an[1] && an[0] > an[2]) {
-        const float sign = std::copysign(1.f, n[0]);
-        uv[0] = sign * p[2] + 0.5f;
-        uv[1] = -p[1] + 0.5f;
-    } else if (an[1] > an[0] && an[1] > an[2]) {
-        const float sign = std::copysign(1.f, n[1]);
-        uv[0] = sign * p[0] + 0.5f;
-        uv[1] = -p[2] + 0.5f;
-    } else {
-        const float sign = std::copysign(1.f, n[2]);
-        uv[0] = -sign * p[0] + 0.5f;
-        uv[1] = -p[1] + 0.5f;
-    }
 }
 
 // Material.sampleFlake (substitute_material.zig:235-273): four flakes per cell of a res x res grid, each with its own PCG stream
@@ -954,7 +985,10 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66)
         auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
             const ZygpuTexture& t = m.tex[slot];
-            return kNull != t.image ? sampleImageMap1(scene, t.image, t.sampler, t.scale, rs.uvw[0], rs.uvw[1], rs.stochastic_r) : uniform;
+            if (kNull == t.image) return uniform;
+            float st[2];
+            rs.st(t.sampler, st);
+            return sampleImageMap1(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r);
         };
         const float raw_r = weight(ZYGPU_STEX_ROUGHNESS, m.roughness);
         const float r = 0.f == raw_r ? 0.f : ggx::clampRoughness(raw_r);
@@ -979,9 +1013,14 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         // Substitute.sample (substitute_material.zig:114-221) without the volumetric branches
         auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
             const ZygpuTexture& t = m.tex[slot];
-            return kNull != t.image ? sampleImageMap1(scene, t.image, t.sampler, t.scale, rs.uvw[0], rs.uvw[1], rs.stochastic_r) : uniform;
+            if (kNull == t.image) return uniform;
+            float st[2];
+            rs.st(t.sampler, st);
+            return sampleImageMap1(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r);
         };
-        const V4    color = kNull != m.color_image ? sampleColorMap(scene, m, rs.uvw[0], rs.uvw[1], rs.stochastic_r) : ld3(m.color_a);
+        float cst[2];
+        rs.st(m.color_sampler, cst);
+        const V4    color = kNull != m.color_image ? sampleColorMap(scene, m, cst[0], cst[1], rs.stochastic_r) : ld3(m.color_a);
         const float roughness = ggx::clampRoughness(weight(ZYGPU_STEX_ROUGHNESS, m.roughness));
         const float metallic = weight(ZYGPU_STEX_METALLIC, m.metallic);
         const float specular = weight(ZYGPU_STEX_SPECULAR, m.specular);

@@ -1044,3 +1044,42 @@ def test_glass_with_maps(engine, oracle, integrator):
     plain = _render_both(engine, oracle, 80, 60, 4, stats=False, integrator=integrator,
                          glass_objects={"box": scenes.glass(1.5, (0.8, 0.9, 1.0), 0.5), "sphere": scenes.glass(1.45, roughness=0.1)})
     assert rms(out[1], plain[1]) > 1e-3
+
+
+@pytest.mark.parametrize("integrator,glass", [("PTMIS", False), ("PTDL", False), ("PTMIS", True)])
+def test_triplanar_and_object_space_textures(engine, oracle, integrator, glass):
+    """Sampler tex_coord modes (material_provider.zig:664-674): Triplanar reads a texture at the fragment's object-space position
+    projected along the dominant axis of the geometric normal (renderstate.zig:44-49, material_helper.zig:81-93) and puts a mapped
+    normal into the triplanar tangent frame (125-139); ObjectPos puts it into a frame built around the interpolated normal (24-29).
+    Colour, weight and normal maps on Rectangles (rotated, scaled), meshes and a Sphere; next to Glass the pool kernels do the same
+    from their vertex record."""
+    color = engine.image(scenes.checker_image(8, np.uint8))
+    rough = engine.image(scenes.weight_image(8, 0.05, 0.9))
+    n8 = engine.image(scenes.normal_image(16, 0.5, np.uint8))
+    T, S = scenes.tex, scenes.substitute_full
+    tri = {"texcoord": "Triplanar"}
+    tri_near = {"texcoord": "Triplanar", "filter": "Nearest"}
+    obj = {"texcoord": "ObjectPos"}
+    ov = {"floor": S(T(color, "Color", sampler=tri, scale=2.0), roughness=T(rough, sampler=tri_near), normal=T(n8, "Normal", sampler=tri)),
+          "back": S(T(color, "Color", sampler=tri), roughness=0.6, metallic=T(rough, sampler=tri)),
+          "tall": S((0.7, 0.7, 0.7), roughness=0.3, metallic=1.0, normal=T(n8, "Normal", sampler=tri, scale=3.0)),
+          "short": S(T(color, "Color", sampler=tri, scale=4.0), roughness=0.5, normal=T(n8, "Normal", sampler=obj),
+                     coating={"thickness": 0.05, "normal": T(n8, "Normal", sampler=tri)}),
+          "sphere_a": S(T(color, "Color", sampler=tri), roughness=T(rough, sampler=tri), normal=T(n8, "Normal", sampler=obj))}
+    kw = dict(integrator=integrator, material="substitute", spheres=True, overrides=ov)
+    if glass:
+        kw["glass_objects"] = {"sphere": scenes.glass(1.5, roughness=T(rough, sampler=tri), normal=T(n8, "Normal", sampler=tri))}
+    out = _render_both(engine, oracle, 88, 66, 4, **kw)
+    _check(*out, 4)
+    # the same maps read at the uv give another picture
+    engine.release()
+    engine.__init__(engine.lib)
+    color = engine.image(scenes.checker_image(8, np.uint8))
+    rough = engine.image(scenes.weight_image(8, 0.05, 0.9))
+    n8 = engine.image(scenes.normal_image(16, 0.5, np.uint8))
+    uv = {k: json.dumps(json.loads(v)).replace('"texcoord": "Triplanar"', '"texcoord": "UV0"').replace('"texcoord": "ObjectPos"', '"texcoord": "UV0"')
+          for k, v in ov.items()}
+    kw["overrides"] = uv
+    kw.pop("glass_objects", None)
+    plain = _render_both(engine, oracle, 88, 66, 4, stats=False, **kw)
+    assert rms(out[1], plain[1]) > 5e-3

@@ -410,7 +410,7 @@ def test_malformed_meshes_are_refused(product_lib):
 @pytest.mark.parametrize("material", [
     '{"rendering": {"Substitute": {"color": {"Checker": {"scale": 4}}}}}',                       # procedural texture
     '{"rendering": {"Substitute": {"roughness": {"file": "rough.png"}}}}',                        # image file
-    '{"rendering": {"Substitute": {"color": {"id": 0, "sampler": {"texcoord": "Triplanar"}}}}}',
+    '{"rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "emission_map": {"id": 0, "sampler": {"texcoord": "Triplanar"}}}}}}',
     '{"rendering": {"Glass": {"ior": 1.5, "normal": {"Checker": {}}}}}',
     '{"rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "profile": {"file": "lamp.ies"}}}}}',
 ])

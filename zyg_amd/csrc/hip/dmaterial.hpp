@@ -757,8 +757,43 @@ struct MaterialSample {
     }
 };
 
+// hlp.triplanarMapping (material_helper.zig:81-93); p and n in object space
+ZD void triplanarMapping(f3 p, f3 n, float& u, float& v) {
+    const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+    if (ax > ay && ax > az) {
+        const float sign = copysignf(1.f, n.x);
+        u = sign * p.z + 0.5f;
+        v = -p.y + 0.5f;
+    } else if (ay > ax && ay > az) {
+        const float sign = copysignf(1.f, n.y);
+        u = sign * p.x + 0.5f;
+        v = -p.z + 0.5f;
+    } else {
+        const float sign = copysignf(1.f, n.z);
+        u = -sign * p.x + 0.5f;
+        v = -p.y + 0.5f;
+    }
+}
+
+// The coordinates a texture is read at (texture_sampler.zig:22-35): the fragment's uv, or for tex_coord Triplanar rs.triplanarSt()
+// (renderstate.zig:44-49): the object-space position projected along the dominant axis of the geometric normal
+ZD void textureSt(uint32_t sampler, float u, float v, f3 p, f3 geo_n, const Trafo& trafo, float& su, float& sv) {
+    if (sampler & ZYGPU_TEX_TRIPLANAR) {
+        triplanarMapping(trafo.worldToObjectPoint(p), trafo.worldToObjectNormal(geo_n), su, sv);
+    } else {
+        su = u;
+        sv = v;
+    }
+}
+
 ZD f3 sampleColorMap(const DScene& s, const ZygpuMaterial& m, float u, float v, float r) {
     return sampleImageMap(s, m.color_image, m.color_sampler, m.color_scale, u, v, r);
+}
+// geo_n: after Vertex.sample's two-sided flip (rs.geo_n)
+ZD f3 sampleColorMapAt(const DScene& s, const ZygpuMaterial& m, float u, float v, float r, f3 p, f3 geo_n, const Trafo& trafo) {
+    float su, sv;
+    textureSt(m.color_sampler, u, v, p, geo_n, trafo, su, sv);
+    return sampleImageMap(s, m.color_image, m.color_sampler, m.color_scale, su, sv, r);
 }
 
 // What the complete Substitute closure reads of the fragment beyond its frame (Renderstate: uv, stochastic_r, p, trafo)
@@ -771,11 +806,27 @@ struct FragmentExtra {
 // hlp.sampleNormal (material_helper.zig:16-78), tex_coord UV0: the normal map's xy in the tangent frame, z reconstructed, then the
 // "iray" adaption that keeps the reflection of wo above the geometric surface
 ZD f3 sampleNormal(const DScene& s, const ZygpuTexture& map, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, const FragmentExtra& fx) {
-    float nx, ny;
-    sampleImageMap2(s, map.image, map.sampler, map.scale, fx.u, fx.v, fx.stochastic_r, nx, ny);
+    float nx, ny, su, sv;
+    textureSt(map.sampler, fx.u, fx.v, fx.p, geo_n, fx.trafo, su, sv);
+    sampleImageMap2(s, map.image, map.sampler, map.scale, su, sv, fx.stochastic_r, nx, ny);
     const float nz = sqrtf(mx(1.f - (nx * nx + ny * ny), 0.01f));
-    // rs.tangentToWorld (renderstate.zig:51-58)
-    const f3 nn = normalize3(mk3(nx * t.x + ny * b.x + nz * n.x, nx * t.y + ny * b.y + nz * n.y, nx * t.z + ny * b.z + nz * n.z));
+    f3          nn;
+    if (map.sampler & ZYGPU_TEX_OBJECTPOS) {  // a frame around the interpolated normal (material_helper.zig:24-29)
+        nn = normalize3(Frame::init(n).frameToWorld(mk3(nx, ny, nz)));
+    } else if (map.sampler & ZYGPU_TEX_TRIPLANAR) {  // triplanarTangent (material_helper.zig:30-38, 125-139)
+        const f3    on = fx.trafo.worldToObjectNormal(n);
+        const float ax = fabsf(on.x), ay = fabsf(on.y), az = fabsf(on.z);
+        const f3    wt = (ax > ay && ax > az)   ? S3(copysignf(1.f, on.x)) * fx.trafo.r2
+                         : (ay > ax && ay > az) ? S3(copysignf(1.f, on.y)) * fx.trafo.r0
+                                                : S3(-copysignf(1.f, on.z)) * fx.trafo.r0;
+        const f3    bt = cross3(n, wt);
+        const f3    nt = cross3(bt, n);
+        const Frame fr{nt, bt, n};
+        nn = normalize3(fr.frameToWorld(mk3(nx, ny, nz)));
+    } else {
+        // rs.tangentToWorld (renderstate.zig:51-58)
+        nn = normalize3(mk3(nx * t.x + ny * b.x + nz * n.x, nx * t.y + ny * b.y + nz * n.y, nx * t.z + ny * b.z + nz * n.z));
+    }
     const f3    ng = geo_n;
     const f3    r = reflect3(nn, wo);
     const float a = dot3(ng, r);
@@ -793,24 +844,6 @@ ZD f3 sampleNormal(const DScene& s, const ZygpuTexture& map, f3 wo, f3 geo_n, f3
     }
     tangent = tangent + S3(epsilon) * ng;
     return normalize3(wo + tangent);
-}
-
-// hlp.triplanarMapping (material_helper.zig:81-93); p and n in object space
-ZD void triplanarMapping(f3 p, f3 n, float& u, float& v) {
-    const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
-    if (ax > ay && ax > az) {
-        const float sign = copysignf(1.f, n.x);
-        u = sign * p.z + 0.5f;
-        v = -p.y + 0.5f;
-    } else if (ay > ax && ay > az) {
-        const float sign = copysignf(1.f, n.y);
-        u = sign * p.x + 0.5f;
-        v = -p.z + 0.5f;
-    } else {
-        const float sign = copysignf(1.f, n.z);
-        u = -sign * p.x + 0.5f;
-        v = -p.y + 0.5f;
-    }
 }
 
 // Material.sampleFlake (substitute_material.zig:235-273): four flakes per cell of a res x res grid, each cell with its own PCG
@@ -913,8 +946,15 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         if (EXT && (m.flags & ZYGPU_MATF_EXTENDED)) {
             const FragmentExtra& f = *fx;
             const ZygpuTexture & tr = m.tex[ZYGPU_STEX_ROUGHNESS], &tsp = m.tex[ZYGPU_STEX_SPECULAR], &tn = m.tex[ZYGPU_STEX_NORMAL];
-            if (kNull != tr.image) raw_r = sampleImageMap1(s, tr.image, tr.sampler, tr.scale, f.u, f.v, f.stochastic_r);
-            if (kNull != tsp.image) specular = sampleImageMap1(s, tsp.image, tsp.sampler, tsp.scale, f.u, f.v, f.stochastic_r);
+            float su, sv;
+            if (kNull != tr.image) {
+                textureSt(tr.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
+                raw_r = sampleImageMap1(s, tr.image, tr.sampler, tr.scale, su, sv, f.stochastic_r);
+            }
+            if (kNull != tsp.image) {
+                textureSt(tsp.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
+                specular = sampleImageMap1(s, tsp.image, tsp.sampler, tsp.scale, su, sv, f.stochastic_r);
+            }
             if (kNull != tn.image) ms.frame = Frame::init(sampleNormal(s, tn, wo, geo_n, t, b, n, f));
         }
         const float r = 0.f == raw_r ? 0.f : mx(raw_r, kMinRoughness);
@@ -933,7 +973,10 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         const FragmentExtra& f = *fx;
         auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
             const ZygpuTexture& tx = m.tex[slot];
-            return kNull != tx.image ? sampleImageMap1(s, tx.image, tx.sampler, tx.scale, f.u, f.v, f.stochastic_r) : uniform;
+            if (kNull == tx.image) return uniform;
+            float su, sv;
+            textureSt(tx.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
+            return sampleImageMap1(s, tx.image, tx.sampler, tx.scale, su, sv, f.stochastic_r);
         };
         const float roughness = mx(weight(ZYGPU_STEX_ROUGHNESS, m.roughness), kMinRoughness);
         const float metallic = weight(ZYGPU_STEX_METALLIC, m.metallic);

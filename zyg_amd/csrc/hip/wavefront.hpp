@@ -1208,7 +1208,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
                 P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
                 P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
                 f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
-                if (MESHL && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, stochastic_r);
+                if (MESHL && kNull != m.color_image) color = sampleColorMapAt(s, m, frag.uv0, frag.uv1, stochastic_r, frag.p, geo_n, frag.trafo);
                 P.pool.rec_n[slot] = f4(n, color.x);
                 P.pool.rec_t[slot] = f4(frag.t, color.y);
                 P.pool.rec_b[slot] = f4(frag.b, color.z);
@@ -1393,7 +1393,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
             n = -n;
         }
         f3 color = mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
-        if (EXTRA && kNull != m.color_image) color = sampleColorMap(s, m, frag.uv0, frag.uv1, P.pool.hit_sr[slot]);
+        if (EXTRA && kNull != m.color_image) color = sampleColorMapAt(s, m, frag.uv0, frag.uv1, P.pool.hit_sr[slot], frag.p, geo_n, frag.trafo);
         const bool caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
         Surface    sf;
         sf.p = frag.p;

@@ -57,7 +57,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
                 : -8 == rc ? "an emissive Substitute material with a coating is not supported"
                 : -10 == rc ? "su_integrators_create asked for the light tracer (\"particle\"), photon mapping or the AOV integrator: only PT, PTDL and PTMIS are supported"
                 : -9 == rc ? "a material in use asks for a texture feature that is not supported (procedural textures, image files, "
-                             "Triplanar / ObjectPos coordinates, IES profiles)"
+                             "IES profiles, Triplanar emission maps)"
                            : "scene uses a feature outside the hot-path scope (scattering volumes, Portal lights, emission maps on meshes ...)");
         return -1;
     }

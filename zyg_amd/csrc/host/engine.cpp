@@ -42,11 +42,7 @@ static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& samp
         // "swizzle" and "invert" are options of the image-file loader: with an image id the reference ignores them, too
         // (createTexture, material_provider.zig:700-736)
         if (k == "id" || k == "usage" || k == "scale" || k == "swizzle" || k == "invert") continue;
-        if (k == "sampler") {
-            if (const JsonValue* tc = kv.second.get("texcoord"))
-                if (!(JsonValue::String == tc->type && tc->str == "UV0")) t_unsupported_texture = true;
-            continue;
-        }
+        if (k == "sampler") continue;
         t_unsupported_texture = true;  // "file" (it wins over "id"), ChannelMix, Checker, DetailNormal, Max, Mix, Mul, Noise ...
     }
     if (!id) {
@@ -72,7 +68,12 @@ static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& samp
                     } else {
                         au = av = address(kv.second);
                     }
-                    m.color_sampler = (m.color_sampler & ZYGPU_TEX_LINEAR) | (au ? ZYGPU_TEX_REPEAT_U : 0u) | (av ? ZYGPU_TEX_REPEAT_V : 0u);
+                    m.color_sampler = (m.color_sampler & ~uint32_t(ZYGPU_TEX_REPEAT_U | ZYGPU_TEX_REPEAT_V)) | (au ? ZYGPU_TEX_REPEAT_U : 0u) |
+                                      (av ? ZYGPU_TEX_REPEAT_V : 0u);
+                } else if (kv.first == "texcoord" && JsonValue::String == kv.second.type) {  // material_provider.zig:664-674
+                    m.color_sampler &= ~uint32_t(ZYGPU_TEX_TRIPLANAR | ZYGPU_TEX_OBJECTPOS);
+                    if (kv.second.str == "Triplanar") m.color_sampler |= ZYGPU_TEX_TRIPLANAR;
+                    else if (kv.second.str == "ObjectPos") m.color_sampler |= ZYGPU_TEX_OBJECTPOS;
                 }
             }
         }
@@ -281,14 +282,22 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
         m.cos_a = std::cos(e.memberF32("angle", profile_angle) * (float(M_PI) / 180.f));
         m.camera_weight = e.memberF32("camera_weight", 1.f);
         m.emission_num_samples = std::min<uint32_t>(e.memberU32("num_samples", 1), 64u);
-        if (const JsonValue* em = e.get("emission_map")) readImageTexture(*em, m.emission_image, m.emission_sampler, m.emission_scale);
+        if (const JsonValue* em = e.get("emission_map")) {
+            readImageTexture(*em, m.emission_image, m.emission_sampler, m.emission_scale);
+            // light samples carry no position for a Triplanar lookup (light.zig:119-132 leaves rs.p unset): uv only
+            if (m.emission_sampler & ZYGPU_TEX_TRIPLANAR) t_unsupported_texture = true;
+            m.emission_sampler &= ~uint32_t(ZYGPU_TEX_OBJECTPOS);
+        }
         // IES profiles (emittance.zig:20, 60-78) and black-body temperature maps: not built
         if (e.get("profile") || e.get("temperature_map")) t_unsupported_texture = true;
     };
 
     // material_provider.zig:177-178, 244-245, 265-266: Glass, Light and Substitute read "mask" (usage Opacity)
     if (ZYGPU_MAT_DEBUG != kind)
-        if (const JsonValue* mask = v.get("mask")) readImageTexture(*mask, m.mask_image, m.mask_sampler, m.mask_scale);
+        if (const JsonValue* mask = v.get("mask")) {
+            readImageTexture(*mask, m.mask_image, m.mask_sampler, m.mask_scale);
+            m.mask_sampler &= ~uint32_t(ZYGPU_TEX_TRIPLANAR | ZYGPU_TEX_OBJECTPOS);  // Base.opacity takes the uv (material_base.zig:35-41)
+        }
 
     if (ZYGPU_MAT_DEBUG == kind) {
         // debug_material.zig:11-18: two-sided, fixed front/back albedo.
@@ -439,6 +448,8 @@ void Engine::commitMaterial(ZygpuMaterial& m) {
         else m.flags &= ~uint32_t(ZYGPU_MATF_CAUSTIC);
         bool extended = m.rotation > 0.f || m.translucency > 0.f || m.coating_thickness > 0.f || m.flakes_coverage > 0.f;
         for (const ZygpuTexture& t : m.tex) extended = extended || ZYGPU_NULL != t.image;
+        // a Triplanar colour map reads the fragment's position, like the complete closure
+        extended = extended || (ZYGPU_NULL != m.color_image && (m.color_sampler & ZYGPU_TEX_TRIPLANAR));
         if (extended) m.flags |= ZYGPU_MATF_EXTENDED;
         else m.flags &= ~uint32_t(ZYGPU_MATF_EXTENDED);
     }
