@@ -1070,10 +1070,11 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 // 280-341, vertex.zig:137-212).  The ray, the hit and the candidate count come from the caller: wf_shade reads them from the
 // pool, wf_trace_shade still has them in registers.  `defer` (first pass only): the vertex has emission to evaluate and
 // goes to the second pass untouched.
-// PRE: a path generated in this kernel (`pre`: its sampler and flags, throughput 1): nothing of it is in the pool yet
-template <bool STATS, bool MESHL, bool HEAVY, bool POOL, bool PRE = false>
+// PRE: the caller holds the path's head (`pre`) and throughput (`pre_thr`).  1: a path generated in this kernel, nothing of it is
+// in the pool yet; 2: read from the pool before the traversal, so that the loads do not wait behind it
+template <bool STATS, bool MESHL, bool HEAVY, bool POOL, int PRE = 0>
 ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
-                    Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr) {
+                    Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr, float4 pre_thr = make_float4(1.f, 1.f, 1.f, 0.f)) {
     const DScene&  s = c_scene;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -1100,7 +1101,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         defer = connectsLights(h.flags) && (emissive || 0 != ucount || infinite);
     }
     if (defer) {
-        if (PRE) {  // the second pass reads the path from the pool
+        if (1 == PRE) {  // the second pass reads the path from the pool
             storeHead<POOL>(P, slot, h);
             P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
         }
@@ -1153,7 +1154,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             if (MESHL && !has_hit && kRayMaxT == ray.max_t) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
         }
     }
-    const float4 thr4 = PRE ? make_float4(1.f, 1.f, 1.f, 0.f) : float4(P.pool.thr[slot]);
+    const float4 thr4 = PRE ? pre_thr : float4(P.pool.thr[slot]);
     f3           throughput = xyz4(thr4);
     const float  split_weight = POOL ? thr4.w : 1.f;
     Mediums      md;
@@ -1307,8 +1308,16 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
             // the fresh path stays in registers until it is shaded, unless the traversal may draw from its sampler through the
             // pool (opacity masks: the MESHL instantiations)
             constexpr bool kFresh = FIRST && !MESHL;
+            // later ticks read the head and the throughput with the ray, before the traversal, instead of behind it (configs[1]:
+            // wf_trace_shade -5 %); not where the traversal may draw from the sampler through the pool (masks: MESHL)
+            constexpr int kPre = MESHL ? 0 : (FIRST ? 1 : 2);
             PathHead       fresh;
+            float4         fresh_thr = make_float4(1.f, 1.f, 1.f, 0.f);
             if (FIRST) generatePath<false, MESHL, kFresh>(P, slot, &fresh);
+            if (2 == kPre) {
+                loadHead(P, slot, fresh);
+                fresh_thr = P.pool.thr[slot];
+            }
             tm.mark(8);
             const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
             const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0.get(slot).y;
@@ -1331,7 +1340,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
             if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL, UTLAS>(P, scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             tm.mark(10);
-            shadeVertex<STATS, MESHL, false, false, kFresh>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh);
+            shadeVertex<STATS, MESHL, false, false, kPre>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh, fresh_thr);
             if (defer || alive) {  // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool
                 P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
                 P.pool.hit_prop[slot] = hit.prop;
@@ -1356,6 +1365,7 @@ struct Surface {
     f3             p;
     f3             frag_geo_n;  // the fragment's own geometric normal (before the two-sided flip), for Fragment.offsetP
     uint32_t       material;    // scene.propMaterialId(frag.prop, frag.part)
+    float          parent_pdf;  // POOL: vertex.bxdf_pdf as the ray carried it (ray_d.w), for the children of a .Straight event
     MaterialSample ms;
 };
 
@@ -1397,6 +1407,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
         const bool caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
         Surface    sf;
         sf.p = frag.p;
+        sf.parent_pdf = 0.f;  // POOL only
         sf.frag_geo_n = frag.geo_n;
         sf.material = s.material_ids[s.props[frag.prop].parts_start + frag.part];
         const Regularize reg = loadRegularize(P, slot);
@@ -1413,13 +1424,15 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
     const float4 rn = P.pool.rec_n[slot], rt = P.pool.rec_t[slot], rb = P.pool.rec_b[slot];
     const f3     geo_n = xyz4(rg), n = xyz4(rn);
     const f3     t = xyz4(rt), b = xyz4(rb);
-    const f3     wo = -xyz4(P.pool.ray_d[slot]);
+    const float4 prd = P.pool.ray_d[slot];
+    const f3     wo = -xyz4(prd);
     const ZygpuMaterial& m = c_scene.materials[__float_as_uint(rp.w)];
     // a colour map was sampled by wf_shade (it has the uv and the stochastic_r draw) into the records' spare lanes
     const f3     color = kNull != m.color_image ? mk3(rn.w, rt.w, rb.w) : mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
     const bool   caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
     Surface      sf;
     sf.p = xyz4(rp);
+    sf.parent_pdf = prd.w;
     sf.frag_geo_n = 0.f != rg.w ? -geo_n : geo_n;
     sf.material = __float_as_uint(rp.w);
     const Regularize reg = loadRegularize(P, slot);
@@ -1928,7 +1941,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             const uint32_t st = P.pool.pstate[ps];
             const uint32_t first = (st >> 8) & 255u;
             P.pool.pstate[ps] = st + (count << 8) + (count - 1u);  // children created; vertices in flight: -1 + count
-            const float  parent_pdf = P.pool.ray_d.get(slot).w;
+            const float  parent_pdf = sf.parent_pdf;
             const float4 parent_vgeo_n = P.pool.vgeo_n[slot], parent_vorigin = P.pool.vorigin[slot];
             for (uint32_t c = 0; c < count; ++c) {
                 const BxdfSample& b = c ? bs1 : bs;
@@ -1988,12 +2001,14 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         } else {
             h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
         }
-        float bxdf_pdf = P.pool.ray_d.get(slot).w;
+        float bxdf_pdf;
         if (mis) {
             h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
             h.vdepth = h.depth_surface;
             bxdf_pdf = bs.pdf;
             P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
+        } else {
+            bxdf_pdf = P.pool.ray_d.get(slot).w;  // the other integrators pass the camera ray's 0 on: read only there
         }
         throughput = throughput * (bs.reflection / S3(bs.pdf));
         nanTrace(P, bs.reflection, 16);
