@@ -1242,13 +1242,10 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
 template <bool STATS, bool MESHL, bool HEAVY, bool POOL>
 __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_WAVES : ZYG_SHADE_WAVES) : ZYG_SHADE_LIGHT_WAVES) wf_shade(Params P) {
     const uint32_t cur = P.parity;
-    if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t       at;
-    const uint32_t total = queueOpen(HEAVY ? &P.ctl->heavy_count[cur] : extCount<POOL>(P, cur, P.round), P.queue_capacity, i, at);
     Counters       cnt{0, 0, 0};
-    const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
-    if (i < rounded) {
+    const QueueCounts* counts = HEAVY ? &P.ctl->heavy_count[cur] : extCount<POOL>(P, cur, P.round);
+    // one queue entry: shade it, append the path to the queues it goes on in
+    auto entry = [&](uint32_t i, uint32_t at, uint32_t total) {
         SectionTimer tm;
         tm.start();
         bool     alive = false, defer = false;
@@ -1267,6 +1264,27 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
         queuePush(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
         tm.mark(5);
         tm.flush(P.ctl, 0);
+    };
+    if (HEAVY) {
+        // The second pass has few entries (vertices with emission to evaluate) and used to be launched like the others, one
+        // block per 256 slots of the tick, nearly all of them leaving at once (configs[1]: 1.30 -> 1.15 ms of a 43 ms step).
+        // Now a grid of a few blocks per CU walks the queue with the grid's stride (zygpu.hip heavyGrid).
+        uint32_t       at;
+        const uint32_t total = queueOpen(counts, P.queue_capacity, 0u, at);
+        const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
+        for (uint32_t base = blockIdx.x * blockDim.x; base < rounded; base += gridDim.x * blockDim.x) {
+            const uint32_t i = base + threadIdx.x;
+            queueOpen(counts, P.queue_capacity, i, at);
+            entry(i, at, total);
+            __syncthreads();  // queuePush's shared words are reused by the next round
+        }
+    } else {
+        if (blockIdx.x * blockDim.x >= P.ctl->bound[cur]) return;
+        const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t       at;
+        const uint32_t total = queueOpen(counts, P.queue_capacity, i, at);
+        const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
+        if (i < rounded) entry(i, at, total);
     }
     if (STATS) flushCounters(P, 1, cnt, 0);
 }

@@ -669,6 +669,9 @@ void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params
     if (0 != kUnitLaunch[mode][unit](id, blocks, c->stream, &P, arg)) c->launch_failed = true;
 }
 
+// wf_shade's second pass walks its (short) queue with a grid-wide stride: a few blocks per CU whatever the size of the tick
+unsigned heavyGrid(const ZygpuContext* c, unsigned tick_blocks) { return std::min(tick_blocks, unsigned(std::max(1, c->num_cus)) * 8u); }
+
 template <typename Launch>
 void timedLaunch(ZygpuContext* c, int k, Launch&& launch) {
     auto* e = (c->timing && !c->timing_paused) ? nextEvents(c, k) : nullptr;
@@ -1306,7 +1309,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             P.parity = 0;
             P.alive_in = P.alive_out = c->queues.ext[0];
             timedLaunch(c, 0, [&] { launchKernel(c, wide ? K_TRACE_SHADE_PLAIN_FIRST_UW : K_TRACE_SHADE_PLAIN_FIRST_U, grid.x, P, num_paths); });
-            timedLaunch(c, 1, [&] { launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u); });
+            timedLaunch(c, 1, [&] { launchKernel(c, K_SHADE_PLAIN_HEAVY, heavyGrid(c, grid.x), P, 0u); });
             for (uint32_t t = 1; t < ticks; ++t) {
                 P.parity = t & 1u;
                 P.alive_in = c->queues.ext[(t - 1u) & 1u];
@@ -1316,7 +1319,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 timedLaunch(c, 5, [&] {
                     launchKernel(c, c->has_substitute ? (wide ? K_TICK_SUBST_W : K_TICK_SUBST) : (wide ? K_TICK_LAMBERT_W : K_TICK_LAMBERT), grid.x, P, 0u);
                 });
-                timedLaunch(c, 1, [&] { launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u); });
+                timedLaunch(c, 1, [&] { launchKernel(c, K_SHADE_PLAIN_HEAVY, heavyGrid(c, grid.x), P, 0u); });
             }
             P.parity = 0;
             P.alive_in = P.alive_out = c->queues.alive;
@@ -1343,13 +1346,13 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                     timedLaunch(c, 1, [&] {
                         if (c->stats) {
                             launchKernel(c, K_SHADE_STATS_LIGHT_POOL, grid.x, P, 0u);
-                            launchKernel(c, K_SHADE_STATS_HEAVY_POOL, grid.x, P, 0u);
+                            launchKernel(c, K_SHADE_STATS_HEAVY_POOL, heavyGrid(c, grid.x), P, 0u);
                         } else if (plain) {
                             launchKernel(c, K_SHADE_PLAIN_LIGHT_POOL, grid.x, P, 0u);
-                            launchKernel(c, K_SHADE_PLAIN_HEAVY_POOL, grid.x, P, 0u);
+                            launchKernel(c, K_SHADE_PLAIN_HEAVY_POOL, heavyGrid(c, grid.x), P, 0u);
                         } else {
                             launchKernel(c, K_SHADE_MESHL_LIGHT_POOL, grid.x, P, 0u);
-                            launchKernel(c, K_SHADE_MESHL_HEAVY_POOL, grid.x, P, 0u);
+                            launchKernel(c, K_SHADE_MESHL_HEAVY_POOL, heavyGrid(c, grid.x), P, 0u);
                         }
                     });
                     timedLaunch(c, 5, [&] {
@@ -1382,9 +1385,9 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                     }
                 });
                 timedLaunch(c, 1, [&] {
-                    if (c->stats) launchKernel(c, K_SHADE_STATS_HEAVY, grid.x, P, 0u);
-                    else if (c->mesh_lights) launchKernel(c, K_SHADE_MESHL_HEAVY, grid.x, P, 0u);
-                    else launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u);
+                    if (c->stats) launchKernel(c, K_SHADE_STATS_HEAVY, heavyGrid(c, grid.x), P, 0u);
+                    else if (c->mesh_lights) launchKernel(c, K_SHADE_MESHL_HEAVY, heavyGrid(c, grid.x), P, 0u);
+                    else launchKernel(c, K_SHADE_PLAIN_HEAVY, heavyGrid(c, grid.x), P, 0u);
                 });
             } else {
             timedLaunch(c, 0, [&] {
@@ -1395,13 +1398,13 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             timedLaunch(c, 1, [&] {
                 if (c->stats) {
                     launchKernel(c, K_SHADE_STATS_LIGHT, grid.x, P, 0u);
-                    launchKernel(c, K_SHADE_STATS_HEAVY, grid.x, P, 0u);
+                    launchKernel(c, K_SHADE_STATS_HEAVY, heavyGrid(c, grid.x), P, 0u);
                 } else if (c->mesh_lights) {
                     launchKernel(c, K_SHADE_MESHL_LIGHT, grid.x, P, 0u);
-                    launchKernel(c, K_SHADE_MESHL_HEAVY, grid.x, P, 0u);
+                    launchKernel(c, K_SHADE_MESHL_HEAVY, heavyGrid(c, grid.x), P, 0u);
                 } else {
                     launchKernel(c, K_SHADE_PLAIN_LIGHT, grid.x, P, 0u);
-                    launchKernel(c, K_SHADE_PLAIN_HEAVY, grid.x, P, 0u);
+                    launchKernel(c, K_SHADE_PLAIN_HEAVY, heavyGrid(c, grid.x), P, 0u);
                 }
             });
             }
