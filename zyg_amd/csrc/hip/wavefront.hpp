@@ -206,6 +206,7 @@ struct Params {
     uint32_t* alive_out;
     uint32_t parity;  // current extension-queue side
     uint32_t queue_capacity;  // entries every queue array holds
+    uint32_t packed_acc;      // 1: the paths keep emission / direct in their first line (kPackedAccumulators; set for the non-POOL kernels)
     uint32_t round;   // POOL: which vertex of the level this launch handles
 };
 
@@ -541,11 +542,72 @@ ZD void nanTrace(const Params&, f3, uint32_t) {}
 ZD f3 xyz4(float4 v) { return {v.x, v.y, v.z}; }
 ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
 
+// Where the three IValue accumulators of a path live.  POOL (and the builds without the interleaved block): 16 B records of their
+// own, emission and direct in a sector of the path's second line.  Otherwise (PACKED): in the six words of the path's first line
+// that the non-POOL kernels leave free (40..47: emission.xy; 112..127: emission.z, direct.xyz; POOL has its hit record there):
+// the end of a path reads all three sums from the line its kernel read anyway, instead of waiting for a cold line once per wave
+// (measured: finalize without these loads at all would be worth 2.8 % on configs[1]; the relocation itself 0 ± 1 % there and
+// +1.6 % on configs[2]: -DZYG_NO_PACKED_ACC restores the separate records).
+#if ZYG_POOL_STRIDE == 256 && ZYG_HIT_STRIDE && !defined(ZYG_ACC_SEPARATE) && !defined(ZYG_NO_PACKED_ACC)
+constexpr bool kPackedAccumulators = true;
+ZD char* pathBlock(const Params& P, uint32_t slot) {
+    return P.pool.q0.base + size_t((slot & P.pool.q0.mask) + P.pool.q0.local) * size_t(ZYG_POOL_STRIDE);
+}
+#else
+constexpr bool kPackedAccumulators = false;
+ZD char* pathBlock(const Params&, uint32_t) { return nullptr; }
+#endif
+
+template <bool PACKED>
+ZD void loadEmissionDirect(const Params& P, uint32_t slot, f3& e, f3& d) {
+    if (PACKED && kPackedAccumulators) {
+        char*        b = pathBlock(P, slot);
+        const float2 lo = *reinterpret_cast<const float2*>(b + 40);
+        const float4 hi = *reinterpret_cast<const float4*>(b + 112);
+        e = mk3(lo.x, lo.y, hi.x);
+        d = mk3(hi.y, hi.z, hi.w);
+    } else {
+        e = xyz4(P.pool.emission[slot]);
+        d = xyz4(P.pool.direct[slot]);
+    }
+}
+template <bool PACKED>
+ZD void clearAccumulators(const Params& P, uint32_t slot) {
+    if (PACKED && kPackedAccumulators) {
+        char* b = pathBlock(P, slot);
+        *reinterpret_cast<float2*>(b + 40) = make_float2(0.f, 0.f);
+        *reinterpret_cast<float4*>(b + 112) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        P.pool.emission[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        P.pool.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    P.pool.indirect[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // IValue.add (helper.zig:11-19) as a read-modify-write of the one accumulator it touches.  Adding an exact zero vector
 // is skipped: the accumulators start at +0 and only ever receive non-negative terms, so x + 0 == x bit for bit.
+template <bool PACKED>
 ZD void ivalueAdd(const Params& P, uint32_t slot, f3 value, uint32_t depth, uint32_t direct_cutoff, bool is_emission, bool singular) {
     if (0.f == value.x && 0.f == value.y && 0.f == value.z) return;
-    const auto   target = is_emission ? P.pool.emission[slot] : (singular || depth < direct_cutoff) ? P.pool.direct[slot] : P.pool.indirect[slot];
+    const bool direct = singular || depth < direct_cutoff;
+    if (PACKED && kPackedAccumulators && (is_emission || direct)) {
+        char*   b = pathBlock(P, slot);
+        float4* hi = reinterpret_cast<float4*>(b + 112);
+        float4  h = *hi;
+        if (is_emission) {
+            float2*      lo = reinterpret_cast<float2*>(b + 40);
+            const float2 l = *lo;
+            *lo = make_float2(l.x + value.x, l.y + value.y);
+            h.x += value.z;
+        } else {
+            h.y += value.x;
+            h.z += value.y;
+            h.w += value.z;
+        }
+        *hi = h;
+        return;
+    }
+    const auto   target = is_emission ? P.pool.emission[slot] : direct ? P.pool.direct[slot] : P.pool.indirect[slot];
     const float4 old = target;
     target = f4(xyz4(old) + value);
 }
@@ -559,8 +621,10 @@ ZD f3 clampColor(f3 color, float max) {  // sensor.zig:615-624
 // end of a path: Sensor.addSample's colour part (sensor.zig:177-181) into the staging buffer
 ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags, const Pcg& rng) {
     if (P.pixel_pcg) P.pixel_pcg[slot] = make_uint2(uint32_t(rng.state), uint32_t(rng.state >> 32));  // one-shot: the next sample goes on
-    const f3    e = clampColor(xyz4(P.pool.emission[slot]), c_view.v.clamp_emission);
-    const f3    d = clampColor(xyz4(P.pool.direct[slot]), c_view.v.clamp_direct);
+    f3 e, d;
+    loadEmissionDirect<true>(P, slot, e, d);  // finalize: the non-POOL kernels
+    e = clampColor(e, c_view.v.clamp_emission);
+    d = clampColor(d, c_view.v.clamp_direct);
     const f3    i = clampColor(xyz4(P.pool.indirect[slot]), c_view.v.clamp_indirect);
     const f3    summed = e + d + i;
     const float alpha = (flags & ST_TRANSPARENT) ? mx(1.f - average3(throughput), 0.f) : 1.f;
@@ -751,9 +815,7 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr) {
         P.pool.transp[slot] = 0.f;
     }
     P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    P.pool.emission[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    P.pool.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    P.pool.indirect[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    clearAccumulators<!POOL>(P, slot);
     P.stage_uv[slot] = make_float2(s0, s1);
     if (AOV && c_scene.prop_frames) {  // AOV = the MESHL instantiations: Probe.time for the animated props (camera_base.zig:129-136)
         const uint64_t tick = 705600000ull / 60, start_time = uint64_t(c_view.frame) * v.frame_step;
@@ -1168,7 +1230,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     nanTrace(P, energy, 8);
     nanTrace(P, throughput, 9);
     // split_throughput = vertex.throughput * split_weight (pathtracer_mis.zig:61-62)
-    ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * energy, h.depth_surface, mis ? 2u : 1u,
+    ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * energy, h.depth_surface, mis ? 2u : 1u,
               0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
 
     bool done = false;
@@ -1663,7 +1725,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
         if (EXTRA && c_view.v.aov_slots) commonAov(P, slot, slot, h, sf, throughput);
 
         if (h.nee & kNeePending) finishLightPick(P, slot, h);
-        if (h.nee & kNeeCountMask) ivalueAdd(P, slot, throughput * xyz4(P.pool.nee[slot]), h.depth_surface, 1u, false, false);
+        if (h.nee & kNeeCountMask) ivalueAdd<true>(P, slot, throughput * xyz4(P.pool.nee[slot]), h.depth_surface, 1u, false, false);
         h.nee = 0;
 
         BxdfSample bs;
@@ -1929,7 +1991,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             }
             nee = nee + occluded;
         }
-        ivalueAdd(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
+        ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
         tm.mark(5);
     }
 

@@ -116,8 +116,12 @@ __global__ void __launch_bounds__(256) film_accumulate_aov(Params P, uint32_t cl
     float4* pixel = P.aov_film + size_t(c_view.v.resolution[0]) * size_t(y) + size_t(x);
     float4  value = *pixel;
     auto    sampleValue = [&](size_t si) {
-        if (ZYGPU_AOV_EMISSION == cls) return clampColor(xyz4(P.pool.emission[si]), c_view.v.clamp_emission);
-        if (ZYGPU_AOV_DIRECT == cls) return clampColor(xyz4(P.pool.direct[si]), c_view.v.clamp_direct);
+        if (ZYGPU_AOV_EMISSION == cls || ZYGPU_AOV_DIRECT == cls) {
+            f3 e, d;
+            if (P.packed_acc) loadEmissionDirect<true>(P, uint32_t(si), e, d);
+            else loadEmissionDirect<false>(P, uint32_t(si), e, d);
+            return ZYGPU_AOV_EMISSION == cls ? clampColor(e, c_view.v.clamp_emission) : clampColor(d, c_view.v.clamp_direct);
+        }
         if (ZYGPU_AOV_INDIRECT == cls) return clampColor(xyz4(P.pool.indirect[si]), c_view.v.clamp_indirect);
         return xyz4(P.stage_aov[cls * P.aov_plane + si]);
     };
@@ -1286,6 +1290,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
 
         const uint32_t num_paths = uint32_t(npix * b);
         P.queue_capacity = queueEntries(c->pool_capacity);
+        P.packed_acc = (kPackedAccumulators && !c->pool_mode) ? 1u : 0u;
         // one thread per queue entry; the queue lengths live on the device, so every launch covers the upper bound and
         // surplus waves retire on their first (scalar) load
         dim3           grid((num_paths + 255) / 256);
