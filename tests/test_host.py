@@ -455,3 +455,31 @@ def test_other_integrators_are_refused(product_lib, integrators):
         assert e.lib.su_ext_compile(0) == -1
         e.integrators('{"surface": {"PTMIS": {}}, "photon": {"num_photons": 0}}')
         assert e.lib.su_ext_compile(0) == 0
+
+
+def test_material_update_runs_the_kinds_parser(product_lib):
+    """su_material_update (capi.zig:352-380 -> material_provider.zig:108-125): the update goes through the same parser as a new
+    material, on top of the material as it is: anything a description can say can be updated, the rest stays."""
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 8, 8, 1, material="substitute")
+        m = e.material(scenes.substitute_full((0.2, 0.3, 0.4), roughness=0.3, metallic=0.5))
+        g = e.material(scenes.glass(1.5, (0.5, 0.6, 0.7), 2.0))
+        for mat in (m, g):
+            p = e.prop(scenes.RECTANGLE, [mat])
+            e.transformation(p, scenes.trafo((1, 0, 0), (0, 1, 0), (0.1, 0.1, 1), (0, 1, 0)))
+        lib = e.lib
+        assert lib.su_material_update(m, b'{"coating": {"thickness": 0.05, "ior": 1.7}, "translucency": 0.25, "two_sided": true}') == 0
+        assert lib.su_material_update(g, b'{"abbe": 30.0, "attenuation_distance": 4.0}') == 0
+        e.compile(0)
+        mats = e.lib.su_ext_scene_desc().contents.materials
+        sub, gl = mats[m], mats[g]
+        assert abs(sub.coating_thickness - 0.05) < 1e-7 and abs(sub.coating_ior - 1.7) < 1e-6 and abs(sub.translucency - 0.25) < 1e-7
+        assert abs(sub.roughness - 0.3) < 1e-7 and abs(sub.metallic - 0.5) < 1e-7  # untouched
+        assert sub.flags & 1 and sub.flags & 16  # two-sided, extended
+        assert abs(gl.abbe - 30.0) < 1e-6
+        # updateGlass' colour is a local that starts white again (material_provider.zig:173): the absorption is that of
+        # ccoef.attenuationCoefficient(1, 4) = -log(0.991102) / 4
+        assert np.allclose(list(gl.absorption), [-np.log(np.float32(0.991102)) / 4.0] * 3, rtol=1e-5)
+        assert lib.su_material_update(m, b'{"two_sided": false}') == 0
+        e.compile(0)
+        assert not (e.lib.su_ext_scene_desc().contents.materials[m].flags & 1)

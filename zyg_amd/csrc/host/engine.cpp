@@ -230,31 +230,39 @@ static Vec4f conductorColor(const std::string& name) {
 }
 
 // material_provider.zig:131-162, 262-342, 411-436 (uniform values only; image textures are SURVEY §8(f))
-void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) {
+// init = false: su_material_update (material_provider.zig:108-125: the same update* function a new material goes through, on top
+// of the material as it is)
+void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind, bool init) {
     t_unsupported_texture = false;
-    parseMaterialBody(m, v, kind);
+    parseMaterialBody(m, v, kind, init);
     if (t_unsupported_texture) m.flags |= ZYGPU_MATF_UNSUPPORTED;
 }
 
-void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t kind) {
-    std::memset(&m, 0, sizeof(m));
-    m.kind = kind;
-    m.cos_a = -1.f;
-    m.camera_weight = 1.f;
-    m.emission_num_samples = 1;
-    m.color_image = ZYGPU_NULL;
-    m.emission_image = ZYGPU_NULL;
-    m.mask_image = ZYGPU_NULL;
-    m.roughness = 0.8f;
-    m.metallic = 0.f;
-    m.specular = 1.f;
-    m.ior = 1.f;
-    for (ZygpuTexture& t : m.tex) t = ZygpuTexture{ZYGPU_NULL, 0u, {1.f, 1.f}};
-    m.coating_scale = 1.f;  // substitute_material.zig:37-60
-    m.coating_roughness = 0.2f;
-    m.coating_ior = 1.5f;
-    m.flakes_color[0] = m.flakes_color[1] = m.flakes_color[2] = 0.8f;
-    m.flakes_alpha = 0.01f;
+void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t kind, bool init) {
+    if (init) {
+        std::memset(&m, 0, sizeof(m));
+        m.kind = kind;
+        m.cos_a = -1.f;
+        m.camera_weight = 1.f;
+        m.emission_num_samples = 1;
+        m.color_image = ZYGPU_NULL;
+        m.emission_image = ZYGPU_NULL;
+        m.mask_image = ZYGPU_NULL;
+        m.roughness = 0.8f;
+        m.metallic = 0.f;
+        m.specular = 1.f;
+        m.ior = 1.f;
+        for (ZygpuTexture& t : m.tex) t = ZygpuTexture{ZYGPU_NULL, 0u, {1.f, 1.f}};
+        m.coating_scale = 1.f;  // substitute_material.zig:37-60
+        m.coating_roughness = 0.2f;
+        m.coating_ior = 1.5f;
+        m.flakes_color[0] = m.flakes_color[1] = m.flakes_color[2] = 0.8f;
+        m.flakes_alpha = 0.01f;
+    }
+    auto setTwoSided = [&](const JsonValue& x) {  // Base.setTwoSided (material_base.zig): set or cleared
+        if (x.b) m.flags |= ZYGPU_MATF_TWO_SIDED;
+        else m.flags &= ~uint32_t(ZYGPU_MATF_TWO_SIDED);
+    };
 
     // readValue (material_provider.zig:634-660): a number is the uniform value, an object names an image
     auto readWeight = [&](const JsonValue& x, float& uniform, uint32_t slot) {
@@ -304,7 +312,7 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
         // Extension (SURVEY §8(d) cfg2 "Lambert with per-wall albedo"): {"Debug": {"color": [r,g,b]}}.
         m.flags |= ZYGPU_MATF_TWO_SIDED;
         const float front[3] = {0.4f, 0.9f, 0.1f}, back[3] = {0.9f, 0.1f, 0.4f};
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; init && i < 3; ++i) {
             m.color_a[i] = front[i];
             m.color_b[i] = back[i];
         }
@@ -313,20 +321,20 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
             for (int i = 0; i < 3; ++i) m.color_a[i] = m.color_b[i] = col[i];
         }
     } else if (ZYGPU_MAT_LIGHT == kind) {
-        m.emission[0] = m.emission[1] = m.emission[2] = 1.f;  // light_material.zig:43
+        if (init) m.emission[0] = m.emission[1] = m.emission[2] = 1.f;  // light_material.zig:43
         if (JsonValue::Object == v.type) {
             for (const auto& kv : v.obj) {
                 if (kv.first == "emittance")
                     loadEmittance(kv.second);
-                else if (kv.first == "two_sided" && kv.second.b)
-                    m.flags |= ZYGPU_MATF_TWO_SIDED;
+                else if (kv.first == "two_sided")
+                    setTwoSided(kv.second);
             }
         }
     } else if (ZYGPU_MAT_SUBSTITUTE == kind) {
         // substitute_material.zig:32-60 defaults
         const Vec4f half = splat(0.5f);
-        for (int i = 0; i < 3; ++i) m.color_a[i] = half[i];
-        m.ior = 1.46f;
+        for (int i = 0; init && i < 3; ++i) m.color_a[i] = half[i];
+        if (init) m.ior = 1.46f;
         if (JsonValue::Object == v.type) {
             for (const auto& kv : v.obj) {
                 const std::string& k = kv.first;
@@ -394,7 +402,7 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
                 } else if (k == "anisotropy") {
                     m.anisotropy = x.f32(0.f);
                 } else if (k == "two_sided") {
-                    if (x.b) m.flags |= ZYGPU_MATF_TWO_SIDED;
+                    setTwoSided(x);
                 } else if (k == "emittance") {
                     loadEmittance(x);
                 } else if (k == "priority") {
@@ -403,12 +411,16 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
             }
         }
     } else if (ZYGPU_MAT_GLASS == kind) {
-        // glass_material.zig:19-33 defaults; material_provider.zig:172-201
-        m.roughness = 0.f;
-        m.specular = 1.f;
-        m.ior = 1.46f;
+        // glass_material.zig:19-33 defaults; material_provider.zig:172-201.  An update that names no colour recomputes the absorption
+        // from white, like updateGlass' local `attenuation_color` does
+        if (init) {
+            m.roughness = 0.f;
+            m.specular = 1.f;
+            m.ior = 1.46f;
+            m.attenuation_distance = 1.f;
+        }
         Vec4f attenuation_color = splat(1.f);
-        float attenuation_distance = 1.f;
+        float attenuation_distance = m.attenuation_distance;
         if (JsonValue::Object == v.type) {
             for (const auto& kv : v.obj) {
                 const std::string& k = kv.first;
@@ -430,6 +442,7 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
             const float ca = std::max(std::min(attenuation_color[i], 0.991102f), 0.01f);
             m.absorption[i] = 0.f == attenuation_distance ? 0.f : -std::log(ca) / attenuation_distance;
         }
+        m.attenuation_distance = attenuation_distance;
     }
 }
 
@@ -499,33 +512,10 @@ uint32_t Engine::createMaterial(uint32_t id, const JsonValue& v) {
 int Engine::updateMaterial(uint32_t id, const JsonValue& v) {
     if (id >= materials_.size()) return -3;  // capi.zig:360-362
     ZygpuMaterial& m = materials_[id];
-    // capi.zig:366-371 passes the *inner* object to updateMaterial (e.g. {"roughness": 0.2}); update in place
+    // capi.zig:366-371 passes the *inner* object to updateMaterial (e.g. {"roughness": 0.2}): the kind's own parser runs on top of
+    // the material as it is (material_provider.zig:108-125), so everything a description can say can be updated
     if (JsonValue::Object != v.type) return -4;
-    auto setColor = [&](const JsonValue& x, float* dst) {
-        const Vec4f c = readColor(x);
-        for (int i = 0; i < 3; ++i) dst[i] = c[i];
-    };
-    for (const auto& kv : v.obj) {
-        if (kv.first == "roughness") m.roughness = kv.second.f32(m.roughness);
-        else if (kv.first == "metallic") m.metallic = kv.second.f32(m.metallic);
-        else if (kv.first == "specular") m.specular = kv.second.f32(m.specular);
-        else if (kv.first == "ior") m.ior = kv.second.f32(m.ior);
-        else if (kv.first == "color") {
-            setColor(kv.second, m.color_a);
-            if (ZYGPU_MAT_DEBUG == m.kind) setColor(kv.second, m.color_b);
-        } else if (kv.first == "emittance") {
-            ZygpuMaterial tmp;
-            JsonValue     wrap;
-            wrap.type = JsonValue::Object;
-            wrap.obj.emplace_back("emittance", kv.second);
-            parseMaterial(tmp, wrap, ZYGPU_MAT_LIGHT);
-            std::memcpy(m.emission, tmp.emission, sizeof(m.emission));
-            m.cos_a = tmp.cos_a;
-            m.camera_weight = tmp.camera_weight;
-            m.emission_normalize = tmp.emission_normalize;
-            m.emission_num_samples = tmp.emission_num_samples;
-        }
-    }
+    parseMaterial(m, v, m.kind, false);
     commitMaterial(m);
     return 0;
 }

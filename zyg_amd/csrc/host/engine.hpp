@@ -171,8 +171,8 @@ class Engine {
     SensorSettings sensor;
 
   private:
-    void     parseMaterial(ZygpuMaterial& m, const JsonValue& rendering_value, uint32_t kind);
-    void     parseMaterialBody(ZygpuMaterial& m, const JsonValue& rendering_value, uint32_t kind);
+    void     parseMaterial(ZygpuMaterial& m, const JsonValue& rendering_value, uint32_t kind, bool init = true);
+    void     parseMaterialBody(ZygpuMaterial& m, const JsonValue& rendering_value, uint32_t kind, bool init);
     void     commitMaterial(ZygpuMaterial& m);
     void     classifyProp(uint32_t p);
     bool     shapeFinite(uint32_t shape) const;
