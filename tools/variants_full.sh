@@ -1,0 +1,16 @@
+# usage: bash tools/variants_full.sh name1 name2 ...   ("main" = zyg_amd/libzyg_amd.so): the scenes that run the full kernel instantiations
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/variants_full
+mkdir -p $O
+cd $R
+for v in "$@"; do
+  if [ "$v" = main ]; then unset ZYG_AMD_LIB; else export ZYG_AMD_LIB=$R/variants/lib_$v.so; fi
+  for cfg in "outdoor:--scene outdoor" "glass:--scene cornell_glass"; do
+    tag=${cfg%%:*}; args=${cfg#*:}
+    timeout 300 python3 bench.py --steps 4 --no-cpu-baseline --no-extra $args > $O/${v}_$tag.json 2> $O/${v}_$tag.err
+    python3 -c "
+import json
+d=json.load(open('$O/${v}_$tag.json')); k=d['roofline']['kernel_ms']; print('%-10s %-8s %8.1f  trace %.1f shade %.1f scatter %.1f' % ('$v','$tag', d['value'], k['wf_intersect'], k['wf_shade'], k['wf_scatter']))" || tail -3 $O/${v}_$tag.err
+  done
+done

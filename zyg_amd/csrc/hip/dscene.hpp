@@ -290,20 +290,47 @@ ZD Trafo interpolateKeyframes(float4 pa, float4 sa, float4 qa, float4 pb, float4
 
 // Scene.propTransformationAtMaybeStatic (scene.zig:382-385 -> space.zig:99-137); ANIM: the kernel instantiations that know
 // animated props (the EXTRA / MESHL ones: a scene with an animated prop runs them)
-template <bool ANIM>
+// The animated branch is a function of its own, not inlined: the slerp (acos, three sines, a 3 x 3 from the quaternion) inside every
+// traversal loop cost the kernels that know animated props their registers whether or not a scene has one (measured on the scenes
+// without: outdoor 238 -> 247 Msamples/s, cornell_glass 115 -> 124, wf_intersect<POOL> -24 %, with the branch compiled out).
+static __device__ __attribute__((noinline)) void propTrafoAnimated(const float4* keyframes, uint32_t first, uint32_t num_interpolation_frames,
+                                                                   float4 origin, uint32_t time, Trafo* out) {
+    const uint32_t tick = uint32_t(705600000ull / 60);  // space.zig:18-19
+    uint32_t       i = time / tick;
+    float          wgt = float(double(time - i * tick) / double(tick));
+    if (i + 1 >= num_interpolation_frames) {  // a shutter sample of exactly 1.0: the last keyframe
+        i = num_interpolation_frames - 2;
+        wgt = 1.f;
+    }
+    const float4* k = keyframes + size_t(first + i) * 3;
+    *out = interpolateKeyframes(k[0], k[1], k[2], k[3], k[4], k[5], wgt, mk3(origin.x, origin.y, origin.z));
+}
+
+// CALL: reach the animated branch through the function above (the closest-hit walks and wf_shade); the shadow-ray walks and
+// wf_scatter keep it inline (a call inside wf_scatter cost its POOL instantiation 7 %)
+template <bool ANIM, bool CALL = false>
 ZD Trafo propTrafoAt(const DScene& s, uint32_t p, uint32_t time) {
     if (ANIM && s.prop_frames) {
         const uint32_t f = s.prop_frames[p];
         if (kNull != f) {
-            const uint32_t tick = uint32_t(705600000ull / 60);  // space.zig:18-19
-            uint32_t       i = time / tick;
-            float          wgt = float(double(time - i * tick) / double(tick));
-            if (i + 1 >= s.num_interpolation_frames) {  // a shutter sample of exactly 1.0: the last keyframe
-                i = s.num_interpolation_frames - 2;
-                wgt = 1.f;
+            Trafo t;
+#ifndef ZYG_ANIM_INLINE
+#define ZYG_ANIM_INLINE 0
+#endif
+            if (CALL && !ZYG_ANIM_INLINE) {
+                propTrafoAnimated(s.keyframes, f, s.num_interpolation_frames, s.origin, time, &t);
+            } else {
+                const uint32_t tick = uint32_t(705600000ull / 60);  // space.zig:18-19
+                uint32_t       i = time / tick;
+                float          wgt = float(double(time - i * tick) / double(tick));
+                if (i + 1 >= s.num_interpolation_frames) {  // a shutter sample of exactly 1.0: the last keyframe
+                    i = s.num_interpolation_frames - 2;
+                    wgt = 1.f;
+                }
+                const float4* k = s.keyframes + size_t(f + i) * 3;
+                t = interpolateKeyframes(k[0], k[1], k[2], k[3], k[4], k[5], wgt, mk3(s.origin.x, s.origin.y, s.origin.z));
             }
-            const float4* k = s.keyframes + size_t(f + i) * 3;
-            return interpolateKeyframes(k[0], k[1], k[2], k[3], k[4], k[5], wgt, mk3(s.origin.x, s.origin.y, s.origin.z));
+            return t;
         }
     }
     return loadTrafo(s, p);
@@ -662,7 +689,7 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
             if (!propVisibleAtDepth(prop.flags, depth_surface)) continue;
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            const Trafo trafo = propTrafoAt<EXTRA>(s, p, ray.time);
+            const Trafo trafo = propTrafoAt<EXTRA, true>(s, p, ray.time);
             const bool  masked = EXTRA && 0 != (prop.flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
@@ -1154,14 +1181,14 @@ ZD void cubeFragment(const Ray& ray, Fragment& f) {  // cube.zig:41-61
     f.b = fr.y;
 }
 
-template <bool EXTRA>
+template <bool EXTRA, bool CALL = false>
 ZD void makeFragment(const DScene& s, const Ray& ray, const Hit& hit, Fragment& f) {
     f.prop = hit.prop;
     f.t_hit = hit.t;
     f.u = hit.u;
     f.v = hit.v;
     f.primitive = hit.primitive;
-    f.trafo = propTrafoAt<EXTRA>(s, hit.prop, ray.time);
+    f.trafo = propTrafoAt<EXTRA, CALL>(s, hit.prop, ray.time);
     const ZygpuProp prop = s.props[hit.prop];
     if (ZYGPU_SHAPE_RECTANGLE == prop.shape) rectangleFragment(ray, f);
     else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) sphereFragment(ray, f);

@@ -878,7 +878,7 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             if (!propVisibleAtDepth(prop.flags, depth_surface)) continue;
             if (STATS) cnt.instances += 1;
             if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
-            const Trafo trafo = propTrafoAt<EXTRA>(s, p, ray.time);
+            const Trafo trafo = propTrafoAt<EXTRA, true>(s, p, ray.time);
             if (ZYGPU_SHAPE_RECTANGLE == prop.shape) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) record(p, 0, t, u, v);
@@ -1059,7 +1059,7 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
         if (STATS) cnt.instances += 1;
         if (!aabbIntersect(s.aabbs[2 * p], s.aabbs[2 * p + 1], ray)) continue;
         Fragment frag;
-        frag.trafo = propTrafoAt<true>(s, p, ray.time);  // an infinite light may be animated like any prop (prop.zig:239-264)
+        frag.trafo = propTrafoAt<true, true>(s, p, ray.time);  // an infinite light may be animated like any prop (prop.zig:239-264)
         float u = 0.f, vv = 0.f;
         if (ZYGPU_SHAPE_DISTANT == prop.shape) {
             if (!distantIntersect(ray, frag.trafo, u, vv)) continue;
@@ -1099,7 +1099,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
         const uint4     c = P.pool.ucand[at];
         const ZygpuProp prop = s.props[c.x];
         Fragment        frag;
-        frag.trafo = propTrafoAt<MESHL>(s, c.x, ray.time);
+        frag.trafo = propTrafoAt<MESHL, true>(s, c.x, ray.time);
         frag.prop = c.x;
         frag.t_hit = __uint_as_float(c.y);
         frag.u = __uint_as_float(c.z);
@@ -1176,7 +1176,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     frag.part = 0;
     if (has_hit) {
         if (HEAVY || POOL) {
-            makeFragment<MESHL>(s, ray, hit, frag);
+            makeFragment<MESHL, true>(s, ray, hit, frag);
         } else {
             const ZygpuProp hp = s.props[hit_prop];
             frag.part = ZYGPU_SHAPE_TRIANGLE_MESH == hp.shape ? uint32_t(s.meshes[hp.mesh].triangle_parts[hit.primitive]) : 0u;
