@@ -271,7 +271,7 @@ struct MaterialSample {
     f3       f0;
     float    metallic, specular, specular_threshold, opacity;
     float    ior, ior_outside, glass_f0, thickness;  // Glass
-    float    abbe, wavelength;  // dispersion: the material's Abbe number, the path's wavelength (rs.wavelength; set by the caller)
+    float    abbe;  // dispersion: the material's Abbe number (the path's wavelength is an argument of glassSample)
     f3       absorption;
     bool     lower_priority;
     // Substitute: clearcoat (substitute_coating.zig:15-113) and flakes (sample_base.zig:17); only the EXT instantiations
@@ -463,14 +463,15 @@ struct MaterialSample {
 
     // Glass.specularSample, thick (glass_sample.zig:165-254, reflect 425-435, thickSpecularRefract 519-537); `split`: both
     // directions, weighted by the Fresnel term, instead of a choice between them.  Returns the number of samples.
-    ZD uint32_t glassSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1) const {
+    // path_wavelength: rs.wavelength, the wavelength the path already has (0: none yet)
+    ZD uint32_t glassSample(const DScene& s, Sampler& sampler, bool split, BxdfSample& r0, BxdfSample& r1, float path_wavelength = 0.f) const {
         // Glass.sample (glass_sample.zig:165-199): a thick dispersive glass (abbe != 0) first settles the path's wavelength (a
         // uniform draw over the visible range, weighted by the Rainbow spectrum x 3; a path that has one keeps it, weight 1) and
         // takes its index of refraction at that wavelength (Cauchy's equation through the Abbe number)
         f3    weight = S3(1.f);
         float ior_t = ior, wl = 0.f;
         if (!(thickness > 0.f) && 0.f != abbe) {
-            wl = wavelength;
+            wl = path_wavelength;
             const float r1d = sampler.sample1D();
             if (0.f == wl) {  // wavelengthSpectrumWeight (glass_sample.zig:154-163)
                 wl = kRainbowStart + (kRainbowEnd - kRainbowStart) * r1d;
@@ -912,7 +913,6 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
     ms.glass_f0 = 0.f;
     ms.thickness = 0.f;
     ms.abbe = 0.f;
-    ms.wavelength = 0.f;
     ms.absorption = S3(0.f);
     ms.lower_priority = lower_priority;
     ms.kind = m.kind;

@@ -2004,9 +2004,9 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         uint32_t       count;
         const uint32_t path_count = __float_as_uint(P.pool.vorigin.get(slot).w);
         if (ZYGPU_MAT_GLASS == ms.kind) {
-            MaterialSample gs = ms;
-            if (0.f != gs.abbe) gs.wavelength = __uint_as_float(P.pool.med1[slot].w);  // rs.wavelength (vertex.zig:167)
-            count = gs.glassSample(s, h.smp, max_splits > 1, bs, bs1);
+            // rs.wavelength (vertex.zig:167): only a dispersive glass looks at it
+            const float path_wavelength = 0.f != ms.abbe ? __uint_as_float(P.pool.med1[slot].w) : 0.f;
+            count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1, path_wavelength);
         } else {
             bs.wavelength = 0.f;
             count = ms.template sample<SUBST, MESHL>(s, h.smp, bs) ? 1u : 0u;
