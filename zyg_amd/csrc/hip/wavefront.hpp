@@ -649,10 +649,13 @@ ZD void terminateVertex(const Params& P, uint32_t slot, f3 throughput, float spl
     }
 }
 
+// (the counting instantiations only.)  Lanes that counted nothing stay away from the counters: the POOL kernels are launched
+// over every vertex a level could have, and 4 M idle lanes adding zeros to four words made each wf_intersect<STATS, POOL> launch
+// take 25 ms
 ZD void flushCounters(const Params& P, int k, const Counters& cnt, unsigned long long rays) {
-    atomicAdd(&P.ctl->k[k].nodes, cnt.nodes);
-    atomicAdd(&P.ctl->k[k].tris, cnt.tris);
-    atomicAdd(&P.ctl->k[k].instances, cnt.instances);
+    if (cnt.nodes) atomicAdd(&P.ctl->k[k].nodes, cnt.nodes);
+    if (cnt.tris) atomicAdd(&P.ctl->k[k].tris, cnt.tris);
+    if (cnt.instances) atomicAdd(&P.ctl->k[k].instances, cnt.instances);
     if (rays) atomicAdd(&P.ctl->k[k].rays, rays);
 }
 
