@@ -728,10 +728,11 @@ ZD Trafo cameraTrafoAt(const ZygpuViewDesc& v, uint32_t frame, float shutter_sam
 // ---------------------------------------------------------------- wf_generate
 // Worker.render seeding (worker.zig:141-149) + Sensor.cameraSample (sensor.zig:152-166) +
 // Perspective.generateVertex (camera_perspective.zig:124-150) + Vertex.init (vertex.zig:67-85)
-// KEEP: the caller shades the new path at once (wf_trace_shade<FIRST>): the sampler and the throughput stay in registers
-// (`keep`) instead of going to the pool and straight back
+// KEEP (non-POOL): the caller shades the new path at once (wf_trace_shade<FIRST>): the sampler (`keep`) and the ray (`keep_o`,
+// `keep_d`) stay in registers, and nothing of the path goes to the pool here: shadeVertex<PRE = 1> writes the records of a path
+// that goes on, all at once behind the traversal, and none for a path that ends at its first vertex
 template <bool POOL, bool AOV = false, bool KEEP = false>
-ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr) {
+ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, float4* keep_o = nullptr, float4* keep_d = nullptr) {
     if (AOV && c_view.v.aov_slots) {  // aov.Value.clear (aov_value.zig:62-73): Depth starts at f32 max
 #pragma unroll
         for (uint32_t k = 0; k < 6; ++k) {
@@ -804,21 +805,23 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr) {
     h.nee = 0;
     if (KEEP) {
         *keep = h;
+        *keep_o = f4(origin_w, kRayMaxT);
+        *keep_d = f4(direction_w, 0.f);
     } else {
         storeHead<POOL>(P, slot, h);  // POOL: vertex 0 of half 0 has the slot's own index
         P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, POOL ? 1.f : 0.f);              // POOL: w = vertex.split_weight
+        P.pool.ray_o[slot] = f4(origin_w, kRayMaxT);
+        P.pool.ray_d[slot] = f4(direction_w, 0.f);
+        P.pool.vorigin[slot] = f4(origin_w, POOL ? __uint_as_float(1u) : 0.f);        //       w = vertex.path_count
+        if (POOL) {
+            P.pool.med0[slot] = make_uint4(0u, 0u, 0u, 0u);
+            P.pool.med1[slot] = make_uint4(0u, 0u, 0u, 0u);  // .w: probe.wavelength = 0
+            P.pool.pstate[slot] = 1u;
+            P.pool.transp[slot] = 0.f;
+        }
+        P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        clearAccumulators<!POOL>(P, slot);
     }
-    P.pool.ray_o[slot] = f4(origin_w, kRayMaxT);
-    P.pool.ray_d[slot] = f4(direction_w, 0.f);
-    P.pool.vorigin[slot] = f4(origin_w, POOL ? __uint_as_float(1u) : 0.f);            //       w = vertex.path_count
-    if (POOL) {
-        P.pool.med0[slot] = make_uint4(0u, 0u, 0u, 0u);
-        P.pool.med1[slot] = make_uint4(0u, 0u, 0u, 0u);  // .w: probe.wavelength = 0
-        P.pool.pstate[slot] = 1u;
-        P.pool.transp[slot] = 0.f;
-    }
-    P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    clearAccumulators<!POOL>(P, slot);
     P.stage_uv[slot] = make_float2(s0, s1);
     if (AOV && c_scene.prop_frames) {  // AOV = the MESHL instantiations: Probe.time for the animated props (camera_base.zig:129-136)
         const uint64_t tick = 705600000ull / 60, start_time = uint64_t(c_view.frame) * v.frame_step;
@@ -1165,10 +1168,20 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || (!has_hit && kRayMaxT == ro.w));
         defer = connectsLights(h.flags) && (emissive || 0 != ucount || infinite);
     }
+    // PRE == 1: the records generatePath<KEEP> left to this point (Vertex.init, vertex.zig:67-85: origin = the ray's, geo_n = 0,
+    // the sums 0)
+    auto commitFresh = [&]() {
+        P.pool.ray_o[slot] = ro;
+        P.pool.ray_d[slot] = rd;
+        P.pool.vorigin[slot] = f4(xyz4(ro), 0.f);
+        P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        clearAccumulators<true>(P, slot);
+    };
     if (defer) {
         if (1 == PRE) {  // the second pass reads the path from the pool
             storeHead<POOL>(P, slot, h);
             P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+            commitFresh();
         }
         return;
     }
@@ -1284,6 +1297,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
                 if (MESHL && (m.flags & ZYGPU_MATF_EXTENDED)) P.pool.rec_uv[slot] = make_float2(frag.uv0, frag.uv1);
             }
             storeHead<POOL>(P, slot, h);
+            if (1 == PRE) commitFresh();
             alive = true;
         }
     }
@@ -1292,6 +1306,12 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         if (POOL) {
             storeSamplers(P, ps, h);  // the sample's other vertices go on with these samplers
             terminateVertex(P, ps, throughput, split_weight, h.flags);
+        } else if (1 == PRE) {
+            // a path that ends at its first vertex in this pass has gathered nothing (a hit with emission went to the second
+            // pass): Sensor.addSample's colour is 0, and none of the path's records was ever written
+            if (P.pixel_pcg) P.pixel_pcg[slot] = make_uint2(uint32_t(h.smp.rng.state), uint32_t(h.smp.rng.state >> 32));
+            const float alpha = (h.flags & ST_TRANSPARENT) ? mx(1.f - average3(throughput), 0.f) : 1.f;
+            P.stage_color[slot] = make_float4(0.f, 0.f, 0.f, alpha);
         } else {
             finalize(P, slot, throughput, h.flags, h.smp.rng);
         }
@@ -1396,13 +1416,14 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
             constexpr int kPre = MESHL ? 0 : (FIRST ? 1 : 2);
             PathHead       fresh;
             float4         fresh_thr = make_float4(1.f, 1.f, 1.f, 0.f);
-            if (FIRST) generatePath<false, MESHL, kFresh>(P, slot, &fresh);
+            float4         fresh_o, fresh_d;
+            if (FIRST) generatePath<false, MESHL, kFresh>(P, slot, &fresh, &fresh_o, &fresh_d);
             if (2 == kPre) {
                 loadHead(P, slot, fresh);
                 fresh_thr = P.pool.thr[slot];
             }
             tm.mark(8);
-            const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+            const float4   o = kFresh ? fresh_o : float4(P.pool.ray_o[slot]), d = kFresh ? fresh_d : float4(P.pool.ray_d[slot]);
             const uint32_t meta = FIRST ? uint32_t((ST_PRIMARY | ST_TRANSPARENT | ST_SINGULAR) << 13) : P.pool.q0.get(slot).y;
             const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
             Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
