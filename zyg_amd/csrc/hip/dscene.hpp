@@ -508,6 +508,50 @@ ZD bool bvh4Walk(const float4* nodes, Ray& ray, Leaf&& leaf) {
     }
 }
 
+// The any-hit form of the wide walk (shadow rays): the order the children are visited in does not change the answer, so nothing
+// is sorted and no entry distance is kept: a parked child is a reference and a count.
+template <typename Leaf>
+ZD bool bvh4WalkAny(const float4* nodes, const Ray& ray, Leaf&& leaf) {
+    uint32_t stack_ref[kStack4], stack_count[kStack4];
+    int      sp = 0;
+    uint32_t cur = 0, cur_count = 0;  // the root node
+    for (;;) {
+        while (0 == cur_count) {
+            const float4* n = nodes + size_t(cur) * 8;
+            const float4  a0 = n[0], a1 = n[1], b0 = n[2], b1 = n[3], c0 = n[4], c1 = n[5], d0 = n[6], d1 = n[7];
+            const bool    h0 = FLT_MAX != nodeIntersect(a0, a1, ray), h1 = FLT_MAX != nodeIntersect(b0, b1, ray);
+            const bool    h2 = FLT_MAX != nodeIntersect(c0, c1, ray), h3 = FLT_MAX != nodeIntersect(d0, d1, ray);
+            bool          have = false;
+            uint32_t      nr = 0, nc = 0;
+            auto          take = [&](bool h, uint32_t r, uint32_t c) {
+                if (!h) return;
+                if (have && sp < kStack4) stack_ref[sp] = nr, stack_count[sp] = nc, ++sp;
+                nr = r;
+                nc = c;
+                have = true;
+            };
+            take(h3, __float_as_uint(d0.w), __float_as_uint(d1.w));
+            take(h2, __float_as_uint(c0.w), __float_as_uint(c1.w));
+            take(h1, __float_as_uint(b0.w), __float_as_uint(b1.w));
+            take(h0, __float_as_uint(a0.w), __float_as_uint(a1.w));
+            if (have) {
+                cur = nr;
+                cur_count = nc;
+            } else {
+                if (0 == sp) return false;
+                --sp;
+                cur = stack_ref[sp];
+                cur_count = stack_count[sp];
+            }
+        }
+        if (leaf(cur, cur_count)) return true;
+        if (0 == sp) return false;
+        --sp;
+        cur = stack_ref[sp];
+        cur_count = stack_count[sp];
+    }
+}
+
 // triangle_tree.zig:46-109; ray in object space; shrinks ray.max_t
 // `accept(triangle, u, v)`: intersectOpacity's stochastic mask test (triangle_tree.zig:111-195)
 // WIDE: walk the mesh's four-wide re-layout instead of the reference's BVH2: the kernel instantiations for scenes with a large
@@ -569,7 +613,7 @@ ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
         }
         return false;
     };
-    if (!STATS && WIDE) return bvh4Walk(mesh.nodes4, local_ray, leaf);
+    if (!STATS && WIDE) return bvh4WalkAny(mesh.nodes4, local_ray, leaf);
     return bvhWalk<STATS>(mesh.nodes, 1u, local_ray, cnt, leaf);
 }
 
