@@ -12,6 +12,8 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "../../../include/zygpu.h"
@@ -98,6 +100,57 @@ inline std::vector<Bvh4Slot> collapse4(const ZygpuBvhNode* nodes, uint32_t num_n
                 s.count = 0;
             }
             out[size_t(t.node4) * 4 + k] = s;
+        }
+    }
+    return out;
+}
+
+// The four-wide nodes with their child boxes quantised to 8 bits per coordinate relative to the node's own box (64 B per node
+// instead of 128): word 0-2 the node's lower corner, word 3 the three scales as biased binary exponents (x | y << 8 | z << 16),
+// words 4-9 the children's qmin.x / .y / .z and qmax.x / .y / .z (child k in byte k), words 10-13 their references, word 14 their
+// leaf counts (byte k; 0 = inner node or empty), word 15 unused.  A child's box is corner + q * 2^(e - 127) per axis, rounded
+// outwards, so it contains the exact box: the walk visits a superset of the nodes, the triangles are tested as ever.  An empty
+// slot has reference 0xFFFFFFFF.  Returns nothing when a leaf holds more than 255 triangles.
+inline std::vector<uint32_t> compress4(const std::vector<Bvh4Slot>& slots) {
+    std::vector<uint32_t> out(slots.size() / 4 * 16, 0u);
+    for (size_t n = 0; n < slots.size() / 4; ++n) {
+        const Bvh4Slot* c = &slots[4 * n];
+        float           lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int k = 0; k < 4; ++k) {
+            if (0xFFFFFFFFu == c[k].ref) continue;
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], c[k].min[a]);
+                hi[a] = std::max(hi[a], c[k].max[a]);
+            }
+        }
+        uint32_t* w = &out[16 * n];
+        uint32_t  exps = 0;
+        float     scale[3];
+        for (int a = 0; a < 3; ++a) {
+            std::memcpy(&w[a], &lo[a], 4);
+            const float extent = hi[a] - lo[a];
+            int         e = 1;  // biased exponent: the smallest power of two with 250 steps covering the extent
+            while (e < 254 && std::ldexp(250.f, e - 127) < extent) ++e;
+            scale[a] = std::ldexp(1.f, e - 127);
+            exps |= uint32_t(e) << (8 * a);
+        }
+        w[3] = exps;
+        for (int k = 0; k < 4; ++k) {
+            w[10 + k] = c[k].ref;
+            if (0xFFFFFFFFu == c[k].ref) continue;
+            if (c[k].count > 255u) return {};
+            w[14] |= c[k].count << (8 * k);
+            for (int a = 0; a < 3; ++a) {
+                int qmin = int(std::floor((c[k].min[a] - lo[a]) / scale[a]));
+                int qmax = int(std::ceil((c[k].max[a] - lo[a]) / scale[a]));
+                qmin = std::max(0, std::min(qmin, 255));
+                qmax = std::max(0, std::min(qmax, 255));
+                while (qmin > 0 && std::fmaf(float(qmin), scale[a], lo[a]) > c[k].min[a]) --qmin;
+                while (qmax < 255 && std::fmaf(float(qmax), scale[a], lo[a]) < c[k].max[a]) ++qmax;
+                if (std::fmaf(float(qmin), scale[a], lo[a]) > c[k].min[a] || std::fmaf(float(qmax), scale[a], lo[a]) < c[k].max[a]) return {};
+                w[4 + a] |= uint32_t(qmin) << (8 * k);
+                w[7 + a] |= uint32_t(qmax) << (8 * k);
+            }
         }
     }
     return out;

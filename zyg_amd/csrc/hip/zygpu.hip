@@ -879,6 +879,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     }
 
     c->large_mesh = false;
+    bool wide_ok = true;
     std::vector<DMesh> meshes(d->num_meshes);
     for (uint32_t i = 0; i < d->num_meshes; ++i) {
         const ZygpuMesh& hm = d->meshes[i];
@@ -896,6 +897,11 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         {  // bvh4.hpp: the same tree, four children per 128 B node; what the relaxed-arithmetic units walk
             const std::vector<zyg::Bvh4Slot> wide = zyg::collapse4(hm.nodes, hm.num_nodes);
             ok = ok && !wide.empty() && m.upload(reinterpret_cast<const float4*>(wide.data()), wide.size() * 2, &dm.nodes4);
+            // ... and with the child boxes quantised (64 B per node): what the wide walks read.  A mesh whose leaves do not fit
+            // the packed form (more than 255 triangles in one) keeps the scene on the BVH2 kernels
+            const std::vector<uint32_t> packed = zyg::compress4(wide);
+            if (!packed.empty()) ok = ok && m.upload(reinterpret_cast<const uint4*>(packed.data()), packed.size() / 4, &dm.nodes4q);
+            else wide_ok = false;
         }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
         ok = ok && m.upload(hm.triangles, size_t(hm.num_triangles) * 3, &dm.triangles);
@@ -907,6 +913,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         ok = ok && m.upload(hm.primitive_mapping, hm.primitive_mapping ? hm.num_triangles : 0, &dm.primitive_mapping);
         if (!ok) return -1;
     }
+    if (!wide_ok) c->large_mesh = false;
     if (!m.upload(meshes.data(), meshes.size(), &s.meshes)) return -1;
 
     for (uint32_t i = 0; i < d->num_infinite_props; ++i) {
