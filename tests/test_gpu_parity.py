@@ -208,7 +208,7 @@ def test_full_size_frame_properties_and_slice_parity(engine, oracle):
     film = engine.download_film(w, h)
     assert np.isfinite(film).all()
     assert np.all(film[..., 3] == float(spp))
-    assert film[..., :3].min() >= floor and film[..., :3].max() > 0.0
+    assert film[..., :3].min() >= 0.0 and film[..., :3].max() > 0.0
 
     engine.start_frame(0)
     engine.render_iterations(1)
