@@ -1,7 +1,13 @@
-#!/bin/bash
-# like variants.sh, for BASELINE configs[2] (1M-triangle mesh)
-for so in variants/lib_*.so; do
-  ZYG_AMD_LIB=$PWD/$so python3 bench.py --steps 3 --warmup 1 --cpu-seconds 1 --scene cornell_mesh 2>/dev/null | tail -1 | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$so', d['value'], d['roofline']['kernel_ms'], d['rms_vs_oracle']['bit_identical_pixels'])"
+# usage: bash tools/variants_mesh.sh name1 name2 ...   ("main" = zyg_amd/libzyg_amd.so): configs[2] (the 1 M-triangle mesh) alone
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/variants_mesh
+mkdir -p $O
+cd $R
+for v in "$@"; do
+  if [ "$v" = main ]; then unset ZYG_AMD_LIB; else export ZYG_AMD_LIB=$R/variants/lib_$v.so; fi
+  timeout 300 python3 bench.py --steps 8 --no-cpu-baseline --no-extra --precise 0 --scene cornell_mesh > $O/${v}.json 2> $O/${v}.err
+  python3 -c "
+import json
+d=json.load(open('$O/${v}.json')); k=d['roofline']['kernel_ms']; print('%-10s %8.1f  trace %.1f shade %.1f scatter %.1f  rms %s' % ('$v', d['value'], k['wf_intersect'], k['wf_shade'], k['wf_scatter'], d.get('rms_vs_oracle', d.get('parity'))))" || tail -3 $O/${v}.err
 done

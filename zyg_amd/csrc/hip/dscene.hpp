@@ -536,18 +536,73 @@ struct Node4q {
     }
 };
 
+// The parked children of the quantised walks: the first kLdsStack entries of a lane live in LDS (a push is one ds_write instead
+// of three scratch stores through the vector memory path the node loads use), deeper ones in scratch.  An entry packs the child's
+// reference with its triangle count (reference < 2^24: zygpu_upload_scene keeps larger meshes on the BVH2 kernels).
+// -DZYG_LDS_STACK=0: everything in scratch (the persistent kernels' unit: their LDS holds the path states).
+#ifndef ZYG_LDS_STACK
+#define ZYG_LDS_STACK 1
+#endif
+constexpr int kLdsStack = ZYG_LDS_STACK ? 16 : 0;
+constexpr int kLdsStackThreads = 256;  // threads of the largest block that walks
+
+ZD uint2* wideStackLds() {
+    __shared__ uint2 entries[(kLdsStack ? kLdsStack : 1) * kLdsStackThreads];
+    return entries;
+}
+
+template <bool DIST>
+struct WideStack {
+    uint2*   lds;  // DIST: (reference | count, distance) per entry; otherwise one word, the lanes' words side by side
+    uint32_t spill_ref[kStack4 - kLdsStack];
+    float    spill_dist[DIST ? kStack4 - kLdsStack : 1];
+    int      sp = 0;
+    ZD WideStack() : lds(DIST ? wideStackLds() + threadIdx.x : reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(wideStackLds()) + threadIdx.x)) {}
+    ZD void push(uint32_t ref, uint32_t count, float dist) {
+        if (sp >= kStack4) return;
+        const uint32_t packed = ref | (count << 24);
+        if (sp < kLdsStack) {
+            if (DIST) lds[sp * kLdsStackThreads] = make_uint2(packed, __float_as_uint(dist));
+            else reinterpret_cast<uint32_t*>(lds)[sp * kLdsStackThreads] = packed;
+        } else {
+            spill_ref[sp - kLdsStack] = packed;
+            if (DIST) spill_dist[sp - kLdsStack] = dist;
+        }
+        ++sp;
+    }
+    // the top entry (sp > 0)
+    ZD void pop(uint32_t& ref, uint32_t& count, float& dist) {
+        --sp;
+        uint32_t packed;
+        if (sp < kLdsStack) {
+            if (DIST) {
+                const uint2 e = lds[sp * kLdsStackThreads];
+                packed = e.x;
+                dist = __uint_as_float(e.y);
+            } else {
+                packed = reinterpret_cast<const uint32_t*>(lds)[sp * kLdsStackThreads];
+            }
+        } else {
+            packed = spill_ref[sp - kLdsStack];
+            if (DIST) dist = spill_dist[sp - kLdsStack];
+        }
+        ref = packed & 0xFFFFFFu;
+        count = packed >> 24;
+    }
+};
+
 template <typename Leaf>
 ZD bool bvh4qWalk(const uint4* nodes, Ray& ray, Leaf&& leaf) {
-    uint32_t stack_ref[kStack4], stack_count[kStack4];
-    float    stack_dist[kStack4];
-    int      sp = 0;
-    uint32_t cur = 0, cur_count = 0;  // the root node
+    WideStack<true> stack;
+    uint32_t        cur = 0, cur_count = 0;  // the root node
     auto pop = [&]() {
-        while (sp > 0) {
-            --sp;
-            if (stack_dist[sp] <= ray.max_t) {
-                cur = stack_ref[sp];
-                cur_count = stack_count[sp];
+        while (stack.sp > 0) {
+            uint32_t r, n;
+            float    dist;
+            stack.pop(r, n, dist);
+            if (dist <= ray.max_t) {
+                cur = r;
+                cur_count = n;
                 return true;
             }
         }
@@ -571,9 +626,9 @@ ZD bool bvh4qWalk(const uint4* nodes, Ray& ray, Leaf&& leaf) {
             ZYG_CSWAP(1, 3)
             ZYG_CSWAP(1, 2)
 #undef ZYG_CSWAP
-            if (FLT_MAX != t3 && sp < kStack4) stack_ref[sp] = r3, stack_count[sp] = n3, stack_dist[sp] = t3, ++sp;
-            if (FLT_MAX != t2 && sp < kStack4) stack_ref[sp] = r2, stack_count[sp] = n2, stack_dist[sp] = t2, ++sp;
-            if (FLT_MAX != t1 && sp < kStack4) stack_ref[sp] = r1, stack_count[sp] = n1, stack_dist[sp] = t1, ++sp;
+            if (FLT_MAX != t3) stack.push(r3, n3, t3);
+            if (FLT_MAX != t2) stack.push(r2, n2, t2);
+            if (FLT_MAX != t1) stack.push(r1, n1, t1);
             if (FLT_MAX != t0) {
                 cur = r0;
                 cur_count = n0;
@@ -588,9 +643,9 @@ ZD bool bvh4qWalk(const uint4* nodes, Ray& ray, Leaf&& leaf) {
 
 template <typename Leaf>
 ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
-    uint32_t stack_ref[kStack4], stack_count[kStack4];
-    int      sp = 0;
-    uint32_t cur = 0, cur_count = 0;
+    WideStack<false> stack;
+    uint32_t         cur = 0, cur_count = 0;
+    float            unused = 0.f;
     for (;;) {
         while (0 == cur_count) {
             const Node4q n = Node4q::load(nodes, cur);
@@ -601,7 +656,7 @@ ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
             uint32_t     nr = 0, nc = 0;
             auto         take = [&](bool h, uint32_t r, uint32_t c) {
                 if (!h) return;
-                if (have && sp < kStack4) stack_ref[sp] = nr, stack_count[sp] = nc, ++sp;
+                if (have) stack.push(nr, nc, 0.f);
                 nr = r;
                 nc = c;
                 have = true;
@@ -614,17 +669,13 @@ ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
                 cur = nr;
                 cur_count = nc;
             } else {
-                if (0 == sp) return false;
-                --sp;
-                cur = stack_ref[sp];
-                cur_count = stack_count[sp];
+                if (0 == stack.sp) return false;
+                stack.pop(cur, cur_count, unused);
             }
         }
         if (leaf(cur, cur_count)) return true;
-        if (0 == sp) return false;
-        --sp;
-        cur = stack_ref[sp];
-        cur_count = stack_count[sp];
+        if (0 == stack.sp) return false;
+        stack.pop(cur, cur_count, unused);
     }
 }
 

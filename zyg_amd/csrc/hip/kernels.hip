@@ -6,12 +6,15 @@
 // (-Dzd=zdf) so that both modes' kernels live side by side in one library.
 #include <hip/hip_runtime.h>
 
-#include "kernel_table.hpp"
-#include "wavefront.hpp"
-
 #ifndef ZYG_TU
 #error "compile with -DZYG_TU=<unit>"
 #endif
+#if 4 == ZYG_TU && !defined(ZYG_LDS_STACK)
+#define ZYG_LDS_STACK 0  // the persistent kernels' unit: their LDS holds the path states, the wide walks' stack stays in scratch
+#endif
+
+#include "kernel_table.hpp"
+#include "wavefront.hpp"
 
 #define ZYG_CAT3_(a, b, c) a##b##c
 #define ZYG_CAT3(a, b, c) ZYG_CAT3_(a, b, c)
@@ -28,11 +31,13 @@ static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Para
     (void)arg;
     const dim3 grid(blocks), block(256);
     const dim3 persistent_block(kPersistentThreads);
+    const dim3 ts_grid(blocks * (256u / kTraceShadeBlock)), ts_block(kTraceShadeBlock);  // `blocks` counts 256 entries each
     switch (id) {
 #define ZYG_X(unit, kid, kernel, args)                                                       \
     case kid:                                                                                \
         if constexpr (unit == UNIT) {                                                        \
-            hipLaunchKernelGGL(kernel, grid, (kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W) ? persistent_block : block, 0, stream, ZYG_UNPAREN args); \
+            constexpr bool ts = (kid >= K_TRACE_SHADE_STATS_FIRST && kid <= K_TRACE_SHADE_PLAIN_U) || K_TRACE_SHADE_PLAIN_FIRST_UW == kid || K_TRACE_SHADE_PLAIN_UW == kid; \
+            hipLaunchKernelGGL(kernel, ts ? ts_grid : grid, ts ? ts_block : (kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W) ? persistent_block : block, 0, stream, ZYG_UNPAREN args); \
             return 0;                                                                        \
         } else {                                                                             \
             return -1;                                                                       \

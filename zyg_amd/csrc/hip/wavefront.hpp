@@ -282,8 +282,14 @@ struct SectionTimer {
 // A queue has two ends: `back` entries grow down from the last element.  The extension queue uses that to keep the rays
 // that will enter a mesh's bounding box (deep BLAS walks) apart from the rest, so that the lanes of a wave have similar
 // work: measured lane utilisation of wf_intersect on the 1 M-triangle scene was 11 % with mixed waves.
+#ifndef ZYG_TS_BLOCK
+#define ZYG_TS_BLOCK 256
+#endif
+constexpr uint32_t kTraceShadeBlock = ZYG_TS_BLOCK;  // threads of a wf_trace_shade block (kernels.hip launches it so)
+
+template <int WAVES = 4>
 ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool active, uint32_t value, bool back = false) {
-    __shared__ uint32_t wave_count[4][2];
+    __shared__ uint32_t wave_count[WAVES][2];
     __shared__ uint32_t block_base[2];
     const bool               front = active && !back, rear = active && back;
     const unsigned long long fmask = __ballot(front), rmask = __ballot(rear);
@@ -295,7 +301,8 @@ ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool 
     __syncthreads();
     if (threadIdx.x < 2) {
         const uint32_t e = threadIdx.x;
-        const uint32_t total = wave_count[0][e] + wave_count[1][e] + wave_count[2][e] + wave_count[3][e];
+        uint32_t       total = 0;
+        for (int w = 0; w < WAVES; ++w) total += wave_count[w][e];
         block_base[e] = total ? atomicAdd(&counts->n[e * kCountStride], total) : 0u;
     }
     __syncthreads();
@@ -1383,7 +1390,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
 // UTLAS: the solid and unoccluding props are walked as the scene's tables (dscene.hpp TlasEntry; not with STATS or MESHL)
 // WIDE (with UTLAS, relaxed units): meshes are walked through their four-wide re-layout (bvh4.hpp)
 template <bool STATS, bool MESHL, bool FIRST, bool UTLAS = false, bool WIDE = false>
-__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P, uint32_t first_paths) {
+__global__ void __launch_bounds__(kTraceShadeBlock) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P, uint32_t first_paths) {
     static_assert(!UTLAS || (!STATS && !MESHL), "the prop tables hold Rectangles and meshes only and count nothing");
     const uint32_t cur = P.parity;
     if (!FIRST && blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
@@ -1399,7 +1406,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
         queueReset(&P.ctl->shadow_count[1]);
     }
     Counters       cnt{0, 0, 0}, shade_cnt{0, 0, 0};
-    const uint32_t rounded = (n + 255u) & ~255u;  // whole blocks take part in queuePush
+    const uint32_t rounded = (n + (kTraceShadeBlock - 1u)) & ~(kTraceShadeBlock - 1u);  // whole blocks take part in queuePush
     const DScene& scene = c_scene;
     if (i < rounded) {
         SectionTimer tm;
@@ -1451,9 +1458,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace
                 P.pool.ucount[slot] = ucount;
             }
         }
-        queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
+        queuePush<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
         __syncthreads();  // queuePush's shared words are reused below
-        queuePush(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+        queuePush<kTraceShadeBlock / 64>(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
         tm.mark(11);
         tm.flush(P.ctl, 0);
     }

@@ -902,6 +902,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             const std::vector<uint32_t> packed = zyg::compress4(wide);
             if (!packed.empty()) ok = ok && m.upload(reinterpret_cast<const uint4*>(packed.data()), packed.size() / 4, &dm.nodes4q);
             else wide_ok = false;
+            if (hm.num_triangles >= (1u << 24)) wide_ok = false;  // the walks' stack entries hold a 24-bit reference (dscene.hpp WideStack)
         }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
         ok = ok && m.upload(hm.triangles, size_t(hm.num_triangles) * 3, &dm.triangles);
