@@ -543,7 +543,10 @@ struct Node4q {
 #ifndef ZYG_LDS_STACK
 #define ZYG_LDS_STACK 1
 #endif
-constexpr int kLdsStack = ZYG_LDS_STACK ? 16 : 0;
+#ifndef ZYG_LDS_STACK_ENTRIES
+#define ZYG_LDS_STACK_ENTRIES 16  // 32 KB per 256-thread block: four blocks of wf_trace_shade per CU
+#endif
+constexpr int kLdsStack = ZYG_LDS_STACK ? ZYG_LDS_STACK_ENTRIES : 0;
 constexpr int kLdsStackThreads = 256;  // threads of the largest block that walks
 
 ZD uint2* wideStackLds() {
