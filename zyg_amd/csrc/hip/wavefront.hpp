@@ -314,6 +314,32 @@ ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool 
     // no trailing barrier: a kernel that pushes twice puts its own barrier between the calls
 }
 
+// Two appends with one pair of barriers: the lanes with `a` go to the front of queue A, those with `b` to the front of queue B.
+template <int WAVES = 4>
+ZD void queuePushTwo(uint32_t* queue_a, QueueCounts* counts_a, bool a, uint32_t* queue_b, QueueCounts* counts_b, bool b, uint32_t value) {
+    __shared__ uint32_t wave_count[WAVES][2];
+    __shared__ uint32_t block_base[2];
+    const unsigned long long amask = __ballot(a), bmask = __ballot(b);
+    const uint32_t           lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (0 == lane) {
+        wave_count[wave][0] = uint32_t(__popcll(amask));
+        wave_count[wave][1] = uint32_t(__popcll(bmask));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const uint32_t e = threadIdx.x;
+        uint32_t       total = 0;
+        for (int w = 0; w < WAVES; ++w) total += wave_count[w][e];
+        block_base[e] = total ? atomicAdd(&(e ? counts_b : counts_a)->n[0], total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t e = b ? 1u : 0u;
+    uint32_t       index = block_base[e];
+    for (uint32_t w = 0; w < wave; ++w) index += wave_count[w][e];
+    index += uint32_t(__popcll((b ? bmask : amask) & ((1ull << lane) - 1ull)));
+    if (a || b) (b ? queue_b : queue_a)[index] = value;
+}
+
 // Consumer side: the queue's total length and, for entry i (front entries first, then the back ones), its position.
 ZD uint32_t queueOpen(const QueueCounts* counts, uint32_t capacity, uint32_t i, uint32_t& position) {
     const uint32_t front = counts->n[0], rear = counts->n[kCountStride];
@@ -1458,9 +1484,9 @@ __global__ void __launch_bounds__(kTraceShadeBlock) ZYG_WAVES(ZYG_TRACE_SHADE_WA
                 P.pool.ucount[slot] = ucount;
             }
         }
-        queuePush<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
-        __syncthreads();  // queuePush's shared words are reused below
-        queuePush<kTraceShadeBlock / 64>(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+        // one pair of barriers for both appends (a deferred vertex is appended to the alive queue by wf_shade's second pass):
+        // configs[1] wf_trace_shade 126.0 -> 123.9 ms per 8 steps against two queuePush calls
+        queuePushTwo<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], defer, P.alive_out, &P.ctl->alive_count[cur], alive && !defer, slot);
         tm.mark(11);
         tm.flush(P.ctl, 0);
     }
