@@ -31,13 +31,18 @@ static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Para
     (void)arg;
     const dim3 grid(blocks), block(256);
     const dim3 persistent_block(kPersistentThreads);
-    const dim3 ts_grid(blocks * (256u / kTraceShadeBlock)), ts_block(kTraceShadeBlock);  // `blocks` counts 256 entries each
+    // wf_trace_shade's block size follows its instantiation (wavefront.hpp traceShadeBlock); `blocks` counts 256 entries each
+    constexpr uint32_t kTsU = traceShadeBlock<true, false>(), kTsUW = traceShadeBlock<true, ZYG_WIDE(true, false)>();
+    const dim3 ts_u_grid((blocks * 256u + kTsU - 1u) / kTsU), ts_u_block(kTsU), ts_uw_grid((blocks * 256u + kTsUW - 1u) / kTsUW), ts_uw_block(kTsUW);
     switch (id) {
 #define ZYG_X(unit, kid, kernel, args)                                                       \
     case kid:                                                                                \
         if constexpr (unit == UNIT) {                                                        \
-            constexpr bool ts = (kid >= K_TRACE_SHADE_STATS_FIRST && kid <= K_TRACE_SHADE_PLAIN_U) || K_TRACE_SHADE_PLAIN_FIRST_UW == kid || K_TRACE_SHADE_PLAIN_UW == kid; \
-            hipLaunchKernelGGL(kernel, ts ? ts_grid : grid, ts ? ts_block : (kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W) ? persistent_block : block, 0, stream, ZYG_UNPAREN args); \
+            constexpr bool ts_u = K_TRACE_SHADE_PLAIN_FIRST_U == kid || K_TRACE_SHADE_PLAIN_U == kid;                \
+            constexpr bool ts_uw = K_TRACE_SHADE_PLAIN_FIRST_UW == kid || K_TRACE_SHADE_PLAIN_UW == kid;             \
+            constexpr bool persistent = kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W;                  \
+            hipLaunchKernelGGL(kernel, ts_u ? ts_u_grid : ts_uw ? ts_uw_grid : grid,                                 \
+                               ts_u ? ts_u_block : ts_uw ? ts_uw_block : persistent ? persistent_block : block, 0, stream, ZYG_UNPAREN args); \
             return 0;                                                                        \
         } else {                                                                             \
             return -1;                                                                       \

@@ -282,10 +282,17 @@ struct SectionTimer {
 // A queue has two ends: `back` entries grow down from the last element.  The extension queue uses that to keep the rays
 // that will enter a mesh's bounding box (deep BLAS walks) apart from the rest, so that the lanes of a wave have similar
 // work: measured lane utilisation of wf_intersect on the 1 M-triangle scene was 11 % with mixed waves.
+// Threads of a wf_trace_shade block (kernels.hip launches it so).  The instantiations that walk the prop tables and no wide BLAS
+// (configs[1]) run 512-thread blocks: half the appends (atomics), and the alive queue comes out in longer runs of neighbouring
+// paths: wf_trace_shade -1.1 %, wf_scatter -1 % against 256 in one call; 128: +6 %, 64: +90 %.  The wide-BLAS ones keep 256 (their
+// LDS stack is sized for it and their waves' walks differ more in length), the others were not measured.
 #ifndef ZYG_TS_BLOCK
-#define ZYG_TS_BLOCK 256
+#define ZYG_TS_BLOCK 512
 #endif
-constexpr uint32_t kTraceShadeBlock = ZYG_TS_BLOCK;  // threads of a wf_trace_shade block (kernels.hip launches it so)
+template <bool UTLAS, bool WIDE>
+constexpr uint32_t traceShadeBlock() {
+    return (UTLAS && !WIDE) ? uint32_t(ZYG_TS_BLOCK) : 256u;
+}
 
 template <int WAVES = 4>
 ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool active, uint32_t value, bool back = false) {
@@ -1416,7 +1423,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
 // UTLAS: the solid and unoccluding props are walked as the scene's tables (dscene.hpp TlasEntry; not with STATS or MESHL)
 // WIDE (with UTLAS, relaxed units): meshes are walked through their four-wide re-layout (bvh4.hpp)
 template <bool STATS, bool MESHL, bool FIRST, bool UTLAS = false, bool WIDE = false>
-__global__ void __launch_bounds__(kTraceShadeBlock) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P, uint32_t first_paths) {
+__global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_trace_shade(Params P, uint32_t first_paths) {
+    constexpr uint32_t kTraceShadeBlock = traceShadeBlock<UTLAS, WIDE>();
     static_assert(!UTLAS || (!STATS && !MESHL), "the prop tables hold Rectangles and meshes only and count nothing");
     const uint32_t cur = P.parity;
     if (!FIRST && blockIdx.x * blockDim.x >= P.ctl->bound[cur ^ 1u]) return;  // the previous tick's queue was no longer
