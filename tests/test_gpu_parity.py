@@ -826,6 +826,35 @@ def test_relaxed_arithmetic_stays_finite_and_close(product_lib, name):
     assert abs(float(np.clip(pi[..., :3], 0, 1).mean()) - float(np.clip(ri[..., :3], 0, 1).mean())) <= 5e-4
 
 
+@pytest.mark.parametrize("name", ["cornell", "substitute", "mesh"])
+def test_relaxed_units_are_deterministic_at_full_size(product_lib, name):
+    """bench.py's kernels (relaxed units: 512-thread wf_trace_shade blocks on the prop tables, the wide BLAS walks with their parked
+    children in LDS) at 1920x1080: the same frame rendered twice, and in two halves, gives the same film bit for bit: queue order is
+    free (every result is addressed by slot) and nothing races."""
+    w, h, spp = 1920, 1080, 8
+    build = {
+        "cornell": lambda e: scenes.cornell(e, w, h, spp),
+        "substitute": lambda e: scenes.cornell(e, w, h, spp, material="substitute"),
+        "mesh": lambda e: scenes.cornell(e, w, h, spp, boxes=False, mesh=scenes.heightfield_mesh(n=384),
+                                         mesh_material=scenes.substitute((0.5, 0.5, 0.5), roughness=0.3, metallic=1.0)),
+    }[name]
+
+    def film(chunks):
+        with zyg_amd.Engine(product_lib) as e:
+            build(e)
+            e.start_frame(0)
+            e.set_option("precise", 0)
+            for n in chunks:
+                e.render_iterations(n)
+            e.synchronize()
+            return e.download_film(w, h)
+
+    a = film([spp])
+    assert np.isfinite(a).all() and np.all(a[..., 3] == float(spp))
+    assert np.array_equal(a, film([spp]))
+    assert np.array_equal(a, film([spp // 2, spp // 2]))
+
+
 def test_relaxed_arithmetic_meets_the_contract_at_config1(engine, oracle):
     """BASELINE.json configs[1] at 1920x1080 / 256 spp in the relaxed mode (bench.py's default) against the CPU oracle on a
     band of rows: per-pixel RMS over RGB of the resolved, clamped image <= 1e-3 (north_star's tolerance)."""
