@@ -13,6 +13,10 @@
 #define ZYG_LDS_STACK 0  // the persistent kernels' unit: their LDS holds the path states, the wide walks' stack stays in scratch
 #endif
 
+#ifndef ZYG_TS_BLOCK_ALL
+#define ZYG_TS_BLOCK_ALL 0  // 1: every wf_trace_shade instantiation without a wide BLAS runs ZYG_TS_BLOCK threads (wavefront.hpp)
+#endif
+
 #include "kernel_table.hpp"
 #include "wavefront.hpp"
 
@@ -38,7 +42,8 @@ static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Para
 #define ZYG_X(unit, kid, kernel, args)                                                       \
     case kid:                                                                                \
         if constexpr (unit == UNIT) {                                                        \
-            constexpr bool ts_u = K_TRACE_SHADE_PLAIN_FIRST_U == kid || K_TRACE_SHADE_PLAIN_U == kid;                \
+            constexpr bool ts_u = K_TRACE_SHADE_PLAIN_FIRST_U == kid || K_TRACE_SHADE_PLAIN_U == kid ||              \
+                                  (ZYG_TS_BLOCK_ALL && kid >= K_TRACE_SHADE_STATS_FIRST && kid <= K_TRACE_SHADE_PLAIN);      \
             constexpr bool ts_uw = K_TRACE_SHADE_PLAIN_FIRST_UW == kid || K_TRACE_SHADE_PLAIN_UW == kid;             \
             constexpr bool persistent = kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W;                  \
             hipLaunchKernelGGL(kernel, ts_u ? ts_u_grid : ts_uw ? ts_uw_grid : grid,                                 \

@@ -285,13 +285,18 @@ struct SectionTimer {
 // Threads of a wf_trace_shade block (kernels.hip launches it so).  The instantiations that walk the prop tables and no wide BLAS
 // (configs[1]) run 512-thread blocks: half the appends (atomics), and the alive queue comes out in longer runs of neighbouring
 // paths: wf_trace_shade -1.1 %, wf_scatter -1 % against 256 in one call; 128: +6 %, 64: +90 %.  The wide-BLAS ones keep 256 (their
-// LDS stack is sized for it and their waves' walks differ more in length), the others were not measured.
+// LDS stack is sized for it and their waves' walks differ more in length); for the others (-DZYG_TS_BLOCK_ALL=1) 512 measures the same
+// on the outdoor scene.
 #ifndef ZYG_TS_BLOCK
 #define ZYG_TS_BLOCK 512
 #endif
 template <bool UTLAS, bool WIDE>
 constexpr uint32_t traceShadeBlock() {
+#if ZYG_TS_BLOCK_ALL
+    return !WIDE ? uint32_t(ZYG_TS_BLOCK) : 256u;
+#else
     return (UTLAS && !WIDE) ? uint32_t(ZYG_TS_BLOCK) : 256u;
+#endif
 }
 
 template <int WAVES = 4>
