@@ -547,7 +547,10 @@ struct Node4q {
 #define ZYG_LDS_STACK_ENTRIES 16  // 32 KB per 256-thread block: four blocks of wf_trace_shade per CU
 #endif
 constexpr int kLdsStack = ZYG_LDS_STACK ? ZYG_LDS_STACK_ENTRIES : 0;
-constexpr int kLdsStackThreads = 256;  // threads of the largest block that walks
+#ifndef ZYG_LDS_STACK_THREADS
+#define ZYG_LDS_STACK_THREADS 256
+#endif
+constexpr int kLdsStackThreads = ZYG_LDS_STACK_THREADS;  // threads of the largest block that walks
 
 ZD uint2* wideStackLds() {
     __shared__ uint2 entries[(kLdsStack ? kLdsStack : 1) * kLdsStackThreads];

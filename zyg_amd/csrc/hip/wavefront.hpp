@@ -290,12 +290,15 @@ struct SectionTimer {
 #ifndef ZYG_TS_BLOCK
 #define ZYG_TS_BLOCK 512
 #endif
+#ifndef ZYG_TS_BLOCK_WIDE
+#define ZYG_TS_BLOCK_WIDE 256  // with -DZYG_LDS_STACK_THREADS=<the same> (dscene.hpp)
+#endif
 template <bool UTLAS, bool WIDE>
 constexpr uint32_t traceShadeBlock() {
 #if ZYG_TS_BLOCK_ALL
-    return !WIDE ? uint32_t(ZYG_TS_BLOCK) : 256u;
+    return !WIDE ? uint32_t(ZYG_TS_BLOCK) : uint32_t(ZYG_TS_BLOCK_WIDE);
 #else
-    return (UTLAS && !WIDE) ? uint32_t(ZYG_TS_BLOCK) : 256u;
+    return (UTLAS && !WIDE) ? uint32_t(ZYG_TS_BLOCK) : WIDE ? uint32_t(ZYG_TS_BLOCK_WIDE) : 256u;
 #endif
 }
 
