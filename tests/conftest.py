@@ -24,9 +24,7 @@ def _build_oracle():
 
 def _build_product():
     from zyg_amd import build
-    if not build.up_to_date():
-        build.build(verbose=False)
-    return build.OUT
+    return build.ensure_built()
 
 
 @pytest.fixture(scope="session")

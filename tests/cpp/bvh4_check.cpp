@@ -69,7 +69,19 @@ int main(int argc, char** argv) {
             }
         }
     }
-    std::printf("OK nodes2 %zu nodes4 %zu leaves %zu mean slack %.3g\n", nodes.size(), wide.size() / 4, leaves4.size(),
-                slack / double(6 * wide.size()));
+    // depth4 against the BVH2's own depth: a BVH4 level swallows one or two BVH2 levels
+    std::vector<uint32_t> level2(nodes.size(), 0);
+    uint32_t              depth2 = 0;
+    level2[0] = 1;
+    for (size_t i = 0; i < nodes.size(); ++i) {  // children lie behind their parent in the array
+        if (0 == level2[i]) return 13;
+        if (nodes[i].count) continue;
+        depth2 = std::max(depth2, level2[i]);
+        level2[nodes[i].children_or_first] = level2[nodes[i].children_or_first + 1] = level2[i] + 1;
+    }
+    const uint32_t depth = zyg::depth4(wide);
+    if (depth > depth2 || 2 * depth < depth2) return 14;
+    std::printf("OK nodes2 %zu nodes4 %zu leaves %zu mean slack %.3g depth2 %u depth4 %u\n", nodes.size(), wide.size() / 4, leaves4.size(),
+                slack / double(6 * wide.size()), depth2, depth);
     return 0;
 }

@@ -137,24 +137,116 @@ def test_two_processes_on_one_gpu_shard_the_frame(tmp_path, mode):
         np.testing.assert_allclose(d["reduced"][..., :3], d["full"][..., :3], rtol=1e-6, atol=1e-7)  # float association only
 
 
-@pytest.mark.gpu
-def test_bench_py_two_ranks_end_to_end(tmp_path):
-    """bench.py's own N > 1 path, launched the way the driver launches it (torch.distributed.run, one process per rank,
-    127.0.0.1), on the one GPU of this box: both ranks on device 0 and gloo instead of RCCL (ZYG_BENCH_*), everything else
-    the measured code: ShardedFrame's shards, timing protocol and reduce, rank 0's one JSON line."""
+def _bench_two_ranks(launcher):
     import json
     import subprocess
     env = dict(os.environ, ZYG_BENCH_BACKEND="gloo", ZYG_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--width", "320", "--height", "180", "--iters-per-step", "4"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180", "--iters-per-step", "4"]
+    if "torchrun" == launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + bench
+    else:
+        cmd = [sys.executable] + bench
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["config"]["parallelism"] == "iterations x2"
-    # two ranks x 2 steps x 4 iterations, summed into rank 0's film
-    assert out["film_weight_min_max"] == [16.0, 16.0]
-    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_py_two_ranks_end_to_end():
+    """bench.py's own N > 1 path on the one GPU of this box: both ranks on device 0 and gloo instead of RCCL (ZYG_BENCH_*),
+    everything else the measured code: ShardedFrame's shards, timing protocol and reduce, rank 0's one JSON line.  Launched both
+    ways: the way the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1) and plainly
+    (`python bench.py --gpus 2`: it starts its own ranks as fresh child processes before touching the GPU); the same line but
+    for the measured times."""
+    outs = {launcher: _bench_two_ranks(launcher) for launcher in ("torchrun", "self")}
+    for out in outs.values():
+        assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+        assert out["config"]["parallelism"] == "iterations x2" and out["config"]["collective"] == "gloo"
+        # two ranks x 2 steps x 4 iterations, summed into rank 0's film
+        assert out["film_weight_min_max"] == [16.0, 16.0]
+        assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    a, b = outs["torchrun"], outs["self"]
+    assert a.keys() == b.keys() and a["config"] == b["config"] and a["rays_per_sample"] == b["rays_per_sample"]
+    assert a["roofline"]["kernel_bytes"] == b["roofline"]["kernel_bytes"]
+
+
+def _rccl_worker(port, out_path):
+    """a fresh process: a world of one over RCCL on cuda:0, the frame's collectives on the device film"""
+    sys.path.insert(0, ROOT)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+
+    import zyg_amd
+    from zyg_amd import distributed, scenes
+    device = torch.device("cuda", 0)
+    dist = distributed.init_process_group("nccl", 0, 1, device)
+    torch.cuda.set_device(device)
+    assert "nccl" == dist.get_backend()
+    w, h, steps, ips = 160, 90, 2, 2
+    with zyg_amd.Engine() as e:
+        scenes.cornell(e, w, h, steps * ips)
+        e.start_frame(0)
+        e.set_option("precise", 1)
+        film = torch.zeros((h, w, 4), dtype=torch.float32, device=device)
+        assert e.lib.zygpu_set_external_film(e.context(), ctypes.c_void_p(film.data_ptr())) == 0
+        frame = distributed.ShardedFrame(0, 1, dist, "iterations", h)
+
+        def render(first, count, y0, y1):
+            assert e.lib.zygpu_render(e.context(), 0, first, count, y0, y1) == 0, e.lib.zygpu_last_error()
+
+        def body():
+            for s in range(steps):
+                frame.render_step(render, s, ips, steps)
+            e.synchronize()
+            frame.reduce(film)  # dist.reduce over RCCL on the tensor the kernels accumulated into
+
+        elapsed = frame.timed(body, lambda: torch.cuda.synchronize(device))  # barrier + all_reduce(MAX) over RCCL
+        assert elapsed > 0.0
+        reduced = film.cpu().numpy()
+        e.lib.zygpu_set_external_film(e.context(), None)
+        e.start_frame(0)
+        e.set_option("precise", 1)
+        e.render_iterations(steps * ips)
+        e.synchronize()
+        np.savez(out_path, reduced=reduced, full=e.download_film(w, h))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_world_of_one_reduces_the_external_film(tmp_path):
+    """The RCCL code path on the hardware there is: init_process_group("nccl", world_size = 1, device_id = cuda:0) in a fresh
+    child process, the engine accumulating into a torch tensor (zygpu_set_external_film), ShardedFrame's barrier, reduce and
+    max-over-ranks running as RCCL collectives on it; the film is the single-process film bit for bit."""
+    import torch.multiprocessing as mp
+    __import__("conftest")._build_product()
+    out = str(tmp_path / "films.npz")
+    # spawn: the child must not inherit an initialised GPU
+    p = mp.get_context("spawn").Process(target=_rccl_worker, args=(_free_port(), out))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    d = np.load(out)
+    assert np.array_equal(d["reduced"], d["full"]) and np.all(d["full"][..., 3] == 4.0)
+
+
+@pytest.mark.gpu
+def test_bench_py_runs_its_collectives_over_rccl_on_one_gpu():
+    """bench.py itself with a process group of one rank over RCCL (ZYG_BENCH_GROUP=1): process group before the device is set,
+    the film reduce on the device tensor, barrier and max-over-ranks in the timed protocol."""
+    import json
+    import subprocess
+    env = dict(os.environ, ZYG_BENCH_GROUP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180",
+           "--iters-per-step", "4", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][0])
+    assert out["config"]["collective"] == "nccl" and out["film_weight_min_max"] == [8.0, 8.0] and out["value"] > 0

@@ -7,13 +7,19 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3 derived metrics over TCC_
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section) gfx950's FETCH_SIZE tallies the 128 B requests of wide streaming loads at
 64 B, and "other access widths are uncalibrated".  These kernels gather 16 B records out of 256 B blocks, so the factor comes
 from tools/calibrate_fetch.py's measurement on that shape (profiles/r02_fetch_calibration.json, stride 256); --factor overrides.
-WRITE_SIZE is exact for 16 B/lane stores.  The output names the source commit and the bench configuration it was taken
-with: bench.py reports it as `roofline.traffic` only for that configuration."""
+WRITE_SIZE is exact for 16 B/lane stores.  The output names the source commit, the hash of the sources the library was built from
+(zyg_amd.build.source_hash() of the tree the passes ran in) and the bench configuration it was taken with: bench.py reports it
+as `roofline.traffic` only for that configuration and those sources."""
 import argparse
 import collections
 import csv
 import glob
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zyg_amd import build  # noqa: E402
 
 
 def load(d, counter):
@@ -45,7 +51,7 @@ if factor is None and a.calibration:
 if factor is None:
     factor = 2.0
 fetch, write = load(a.fetch_dir, 'FETCH_SIZE'), load(a.write_dir, 'WRITE_SIZE')
-out = {"_meta": {"fetch_size_factor": factor, "source_commit": a.commit, "config": json.loads(a.config) if a.config else None}}
+out = {"_meta": {"fetch_size_factor": factor, "source_commit": a.commit, "source_hash": build.source_hash(), "config": json.loads(a.config) if a.config else None}}
 for k in sorted(set(fetch) | set(write)):
     if not ('wf_' in k or 'film' in k):
         continue

@@ -1,9 +1,8 @@
 # usage: bash tools/variants_bench.sh name1 name2 ...   ("main" = zyg_amd/libzyg_amd.so)
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+. "$(dirname "$0")/common.sh"
+set +e
 O=$R/gpurun_out/variants
 mkdir -p $O
-cd $R
 for v in "$@"; do
   if [ "$v" = main ]; then unset ZYG_AMD_LIB; else export ZYG_AMD_LIB=$R/variants/lib_$v.so; fi
   for cfg in "relaxed:--precise 0" "precise:--precise 1" "mesh:--precise 0 --scene cornell_mesh"; do

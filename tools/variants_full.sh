@@ -1,9 +1,8 @@
 # usage: bash tools/variants_full.sh name1 name2 ...   ("main" = zyg_amd/libzyg_amd.so): the scenes that run the full kernel instantiations
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+. "$(dirname "$0")/common.sh"
+set +e
 O=$R/gpurun_out/variants_full
 mkdir -p $O
-cd $R
 for v in "$@"; do
   if [ "$v" = main ]; then unset ZYG_AMD_LIB; else export ZYG_AMD_LIB=$R/variants/lib_$v.so; fi
   for cfg in "outdoor:--scene outdoor" "glass:--scene cornell_glass"; do

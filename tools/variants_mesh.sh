@@ -1,9 +1,8 @@
 # usage: bash tools/variants_mesh.sh name1 name2 ...   ("main" = zyg_amd/libzyg_amd.so): configs[2] (the 1 M-triangle mesh) alone
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+. "$(dirname "$0")/common.sh"
+set +e
 O=$R/gpurun_out/variants_mesh
 mkdir -p $O
-cd $R
 for v in "$@"; do
   if [ "$v" = main ]; then unset ZYG_AMD_LIB; else export ZYG_AMD_LIB=$R/variants/lib_$v.so; fi
   timeout 300 python3 bench.py --steps 8 --no-cpu-baseline --no-extra --precise 0 --scene cornell_mesh > $O/${v}.json 2> $O/${v}.err

@@ -4,8 +4,9 @@
 
 The device code is compiled as translation units in parallel (csrc/hip/kernel_table.hpp): zygpu.hip (film kernels + the
 zygpu_* ABI) and kernels.hip once per unit and arithmetic mode.  Objects are kept in zyg_amd/build/ and reused while they
-are newer than every source and header; `--units` recompiles only the named kernel units (development: the others must
-already be built).
+carry the tag of the flags and of the sources they were compiled from (a sidecar <object>.tag, written after a successful
+compile: contents are hashed, not mtimes); `--units` recompiles only the named kernel units (development: the others are
+linked as they are, and the library is marked partial, so up_to_date() is false and bench.py / the tests rebuild it in full).
 
 Precise units: -ffp-contract=off (the reference, Zig, fuses a*b+c only at its explicit @mulAdd sites, which the sources
 reproduce with fmaf / __fmaf_rn); correctly rounded f32 divide/sqrt is hipcc's default.  Relaxed units (-DZYG_FAST=1): native
@@ -52,6 +53,33 @@ def _deps():
     return deps
 
 
+def source_hash():
+    """Hash of the contents of every source and header the library is compiled from (csrc/hip, csrc/host, include/)."""
+    h = hashlib.sha256()
+    for p in sorted(_deps()):
+        if p.endswith("build.py") or not os.path.isfile(p):
+            continue
+        h.update(os.path.relpath(p, ROOT).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _flags_hash(flags, extra=()):
+    return hashlib.sha1(" ".join(COMMON + list(flags) + list(extra)).encode()).hexdigest()[:12]
+
+
+def _library_tag(extra=(), mode="both"):
+    """What a complete build of the current sources with these flags is tagged with (libzyg_amd.so.tag)."""
+    return f"{_flags_hash(PRECISE + RELAXED, extra)}:{mode}:{source_hash()}"
+
+
+def _read(path):
+    try:
+        return open(path).read()
+    except OSError:
+        return None
+
+
 def _objects(mode):
     """(object path, source, flags) of every translation unit"""
     objs = [("zygpu.o", os.path.join(HIP, "zygpu.hip"), PRECISE), ("engine.o", os.path.join(HOST, "engine.cpp"), PRECISE),
@@ -73,8 +101,14 @@ def _compile(job):
     if verbose or r.returncode:
         sys.stderr.write(f"[{time.time() - t0:6.1f} s] {name}\n{r.stderr}")
     if r.returncode:
+        if os.path.exists(out + ".tag"):
+            os.remove(out + ".tag")
         raise RuntimeError(f"hipcc failed for {name}: {' '.join(cmd)}")
+    open(out + ".tag", "w").write(_flags_hash(flags, extra) + ":" + _compile.sources)
     return out
+
+
+_compile.sources = ""
 
 
 def build_variant(name, units, extra, mode="both", verbose=True):
@@ -82,6 +116,7 @@ def build_variant(name, units, extra, mode="both", verbose=True):
     `units` holds -1) recompiled with `extra` flags into build/<name>/.  Load it with ZYG_AMD_LIB=variants/lib_<name>.so."""
     vdir = os.path.join(OBJ, name)
     os.makedirs(vdir, exist_ok=True)
+    _compile.sources = source_hash()
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
     todo, objs = [], []
     for oname, src, flags in _objects(mode):
@@ -101,40 +136,59 @@ def build_variant(name, units, extra, mode="both", verbose=True):
 def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     extra = list(extra)
-    # objects are reused only when they were built with the same flags
-    tag = hashlib.sha1(" ".join(COMMON + PRECISE + RELAXED + extra).encode()).hexdigest()[:12]
-    tag_file = os.path.join(OBJ, "flags.tag")
-    same_flags = os.path.exists(tag_file) and open(tag_file).read() == tag
-    newest = max(os.path.getmtime(p) for p in _deps())
-    todo, objs = [], []
+    sources = _compile.sources = source_hash()
+    todo, objs, stale_left = [], [], []
     for name, src, flags in _objects(mode):
         out = os.path.join(OBJ, name)
         objs.append(out)
-        fresh = same_flags and os.path.exists(out) and os.path.getmtime(out) >= newest
+        # an object is reused only when it was compiled from these sources with these flags
+        fresh = os.path.exists(out) and _read(out + ".tag") == _flags_hash(flags, extra) + ":" + sources
         if units is not None and name.startswith("unit"):
             unit = int(name[4:].rstrip("f.o"))
             if unit in units or not os.path.exists(out):
                 todo.append((name, src, flags, extra, verbose))
+            elif not fresh:
+                stale_left.append(name)
         elif not fresh:
             todo.append((name, src, flags, extra, verbose))
     # the largest units first (kernel_table.hpp keeps the wf_scatter instantiations in the low unit numbers)
     todo.sort(key=lambda j: (not j[0].startswith("unit"), j[0]))
     t0 = time.time()
+    if os.path.exists(OUT + ".tag"):
+        os.remove(OUT + ".tag")
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(_compile, todo))
-    open(tag_file, "w").write(tag)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
     if verbose:
         print(f"compiled {len(todo)} of {len(objs)} translation units in {time.time() - t0:.0f} s; linking", flush=True)
     subprocess.run(cmd, check=True)
+    if stale_left:
+        # development only: the library mixes objects of different source revisions; never taken for a complete build
+        print(f"PARTIAL build: {', '.join(stale_left)} were not recompiled for the current sources", file=sys.stderr, flush=True)
+        open(OUT + ".tag", "w").write("partial")
+    else:
+        open(OUT + ".tag", "w").write(_library_tag(extra, mode))
     return OUT
 
 
 def up_to_date():
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(p) <= t for p in _deps() if not p.endswith("build.py"))
+    """The library is a complete build (both arithmetic modes, the default flags) of the sources as they are now."""
+    return os.path.exists(OUT) and _read(OUT + ".tag") == _library_tag()
+
+
+def ensure_built(verbose=False):
+    """Builds the library unless it is up to date, under a file lock: ranks of one launch may all call this, the first one
+    builds, the others wait for it and find the library fresh."""
+    import fcntl
+    os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, "build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not up_to_date():
+                build(verbose=verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return OUT
 
 
 if __name__ == "__main__":

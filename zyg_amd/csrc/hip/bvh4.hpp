@@ -14,6 +14,8 @@
 #include <cstdint>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../../include/zygpu.h"
@@ -103,6 +105,24 @@ inline std::vector<Bvh4Slot> collapse4(const ZygpuBvhNode* nodes, uint32_t num_n
         }
     }
     return out;
+}
+
+// Levels of inner nodes below (and including) the root.  A walk parks at most three children per level it descends, so a tree
+// of depth d needs a stack of 3 d entries at most (dscene.hpp kStack4); zygpu_upload_scene keeps deeper trees on the BVH2 kernels.
+inline uint32_t depth4(const std::vector<Bvh4Slot>& slots) {
+    if (slots.empty()) return 0;
+    uint32_t deepest = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 1u}};  // (node, its level)
+    while (!todo.empty()) {
+        const auto [node, level] = todo.back();
+        todo.pop_back();
+        deepest = std::max(deepest, level);
+        for (uint32_t k = 0; k < 4; ++k) {
+            const Bvh4Slot& c = slots[size_t(node) * 4 + k];
+            if (0xFFFFFFFFu != c.ref && 0 == c.count) todo.push_back({c.ref, level + 1});
+        }
+    }
+    return deepest;
 }
 
 // The four-wide nodes with their child boxes quantised to 8 bits per coordinate relative to the node's own box (64 B per node

@@ -9,8 +9,12 @@
 #ifndef ZYG_TU
 #error "compile with -DZYG_TU=<unit>"
 #endif
-#if 4 == ZYG_TU && !defined(ZYG_LDS_STACK)
-#define ZYG_LDS_STACK 0  // the persistent kernels' unit: their LDS holds the path states, the wide walks' stack stays in scratch
+#if (4 == ZYG_TU || 5 == ZYG_TU) && !defined(ZYG_LDS_STACK)
+// unit 4, the persistent kernels: their LDS holds the path states, the wide walks' stack stays in scratch.  Unit 5, wf_tick: one
+// block runs the any-hit walk (one word per parked child) and the closest-hit walk (two words) with no barrier between them, and
+// the two entry layouts of dscene.hpp WideStack share one LDS array: a wave still in its shadow rays and a wave already in the
+// next closest-hit walk would overwrite each other's entries.  In scratch every lane's stack is its own.
+#define ZYG_LDS_STACK 0
 #endif
 
 #ifndef ZYG_TS_BLOCK_ALL
@@ -62,6 +66,50 @@ static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Para
 
 }  // namespace zd
 
+#if 7 == ZYG_TU
+namespace zd {
+// Ray-level hooks for the tests (zygpu_test_intersect / zygpu_test_visibility): rays of 8 floats (o.xyz, min_t, d.xyz, max_t)
+// against the uploaded scene, in this unit's arithmetic (option `precise` picks the unit).  mode 0: the reference's walk (top-level tree lane by lane,
+// BVH2); 1: the prop tables (sceneIntersectUniform) + BVH2; 2: the prop tables + the four-wide BLAS re-layout; 3: as the
+// relaxed units walk: 2 without the tie rule between props and with the small meshes tested triangle by triangle.
+__global__ void test_intersect(uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + size_t(i) * 8;
+    Ray          ray = Ray::init(mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]);
+    Hit          hit;
+    Counters     cnt{0, 0, 0};
+    bool         found;
+    if (0 == mode) found = sceneIntersect<false, true>(c_scene, ray, depth_surface, hit, cnt);
+    else if (1 == mode) found = sceneIntersectUniform<true, false>(c_scene, ray, depth_surface, hit);
+    else if (2 == mode) found = sceneIntersectUniform<true, true>(c_scene, ray, depth_surface, hit);
+    else found = sceneIntersectUniform<false, true>(c_scene, ray, depth_surface, hit);  // no tie rule, small meshes triangle by triangle
+    uint32_t* h = hits + size_t(i) * 8;
+    for (int k = 0; k < 8; ++k) h[k] = 0;
+    if (found) {
+        h[0] = __float_as_uint(hit.t);
+        h[1] = __float_as_uint(hit.u);
+        h[2] = __float_as_uint(hit.v);
+        h[3] = hit.primitive;
+    }
+    h[4] = hit.prop;
+}
+__global__ void test_visibility(uint32_t n, const float* rays, uint32_t mode, uint32_t* visible) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + size_t(i) * 8;
+    Ray          ray = Ray::init(mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]);
+    Counters     cnt{0, 0, 0};
+    visible[i] = (0 == mode   ? sceneVisibility<false, true>(c_scene, ray, cnt)
+                  : 1 == mode ? sceneVisibilityUniform<false>(c_scene, ray)
+                  : 2 == mode ? sceneVisibilityUniform<true>(c_scene, ray)
+                              : sceneVisibilityUniform<true, true>(c_scene, ray))
+                     ? 1u
+                     : 0u;
+}
+}  // namespace zd
+#endif
+
 extern "C" {
 
 int ZYG_UNIT_SYM(launch)(unsigned id, unsigned blocks, void* stream, const void* params, unsigned arg) {
@@ -79,5 +127,15 @@ int ZYG_UNIT_SYM(set)(int which, const void* src, size_t bytes, void* stream) {
         e = hipMemcpyToSymbolAsync(HIP_SYMBOL(zd::sobol::c_sobol_lut), src, bytes, 0, hipMemcpyHostToDevice, s);
     return hipSuccess == e ? 0 : -int(e);
 }
+
+#if 7 == ZYG_TU
+// kind 0: closest hit (8 words per ray), 1: visibility (one word per ray); device pointers
+int ZYG_UNIT_SYM(test_rays)(int kind, unsigned n, const float* rays, unsigned depth_surface, unsigned mode, unsigned* out, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (0 == kind) hipLaunchKernelGGL(zd::test_intersect, dim3((n + 255) / 256), dim3(256), 0, s, n, rays, depth_surface, mode, out);
+    else hipLaunchKernelGGL(zd::test_visibility, dim3((n + 255) / 256), dim3(256), 0, s, n, rays, mode, out);
+    return 0;
+}
+#endif
 
 }  // extern "C"

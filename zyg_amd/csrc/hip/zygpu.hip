@@ -26,6 +26,9 @@ extern "C" {
     __attribute__((weak)) int zyg_unit##k##_set(int, const void*, size_t, void*);                            \
     __attribute__((weak)) int zyg_unit##k##f_launch(unsigned, unsigned, void*, const void*, unsigned);       \
     __attribute__((weak)) int zyg_unit##k##f_set(int, const void*, size_t, void*);
+// the ray-level test hooks live in unit 7 of either mode (kernels.hip)
+__attribute__((weak)) int zyg_unit7_test_rays(int, unsigned, const float*, unsigned, unsigned, unsigned*, void*);
+__attribute__((weak)) int zyg_unit7f_test_rays(int, unsigned, const float*, unsigned, unsigned, unsigned*, void*);
 ZYG_DECL_UNIT(0) ZYG_DECL_UNIT(1) ZYG_DECL_UNIT(2) ZYG_DECL_UNIT(3) ZYG_DECL_UNIT(4) ZYG_DECL_UNIT(5) ZYG_DECL_UNIT(6) ZYG_DECL_UNIT(7)
 #undef ZYG_DECL_UNIT
 }
@@ -284,46 +287,6 @@ __global__ void __launch_bounds__(256) calib_gather(const char* data, uint32_t n
     if (i >= n) return;
     const uint4 v = *reinterpret_cast<const uint4*>(data + size_t(i) * STRIDE);
     if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u) sink[0] = i;  // never true for the zero-filled buffer: keeps the load alive
-}
-
-// Ray-level hooks for the tests (zygpu_test_intersect / zygpu_test_visibility): rays of 8 floats (o.xyz, min_t, d.xyz, max_t)
-// against the uploaded scene, in this unit's precise arithmetic.  mode 0: the reference's walk (top-level tree lane by lane,
-// BVH2); 1: the prop tables (sceneIntersectUniform) + BVH2; 2: the prop tables + the four-wide BLAS re-layout; 3: as the
-// relaxed units walk: 2 without the tie rule between props and with the small meshes tested triangle by triangle.
-__global__ void test_intersect(uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* r = rays + size_t(i) * 8;
-    Ray          ray = Ray::init(mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]);
-    Hit          hit;
-    Counters     cnt{0, 0, 0};
-    bool         found;
-    if (0 == mode) found = sceneIntersect<false, true>(c_scene, ray, depth_surface, hit, cnt);
-    else if (1 == mode) found = sceneIntersectUniform<true, false>(c_scene, ray, depth_surface, hit);
-    else if (2 == mode) found = sceneIntersectUniform<true, true>(c_scene, ray, depth_surface, hit);
-    else found = sceneIntersectUniform<false, true>(c_scene, ray, depth_surface, hit);  // no tie rule, small meshes triangle by triangle
-    uint32_t* h = hits + size_t(i) * 8;
-    for (int k = 0; k < 8; ++k) h[k] = 0;
-    if (found) {
-        h[0] = __float_as_uint(hit.t);
-        h[1] = __float_as_uint(hit.u);
-        h[2] = __float_as_uint(hit.v);
-        h[3] = hit.primitive;
-    }
-    h[4] = hit.prop;
-}
-__global__ void test_visibility(uint32_t n, const float* rays, uint32_t mode, uint32_t* visible) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* r = rays + size_t(i) * 8;
-    Ray          ray = Ray::init(mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]);
-    Counters     cnt{0, 0, 0};
-    visible[i] = (0 == mode   ? sceneVisibility<false, true>(c_scene, ray, cnt)
-                  : 1 == mode ? sceneVisibilityUniform<false>(c_scene, ray)
-                  : 2 == mode ? sceneVisibilityUniform<true>(c_scene, ray)
-                              : sceneVisibilityUniform<true, true>(c_scene, ray))
-                     ? 1u
-                     : 0u;
 }
 
 __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
@@ -903,6 +866,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             if (!packed.empty()) ok = ok && m.upload(reinterpret_cast<const uint4*>(packed.data()), packed.size() / 4, &dm.nodes4q);
             else wide_ok = false;
             if (hm.num_triangles >= (1u << 24)) wide_ok = false;  // the walks' stack entries hold a 24-bit reference (dscene.hpp WideStack)
+            // three parked children per level at most: a tree too deep for the walks' kStack4 entries would lose subtrees
+            if (3u * zyg::depth4(wide) > uint32_t(kStack4)) wide_ok = false;
         }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
         ok = ok && m.upload(hm.triangles, size_t(hm.num_triangles) * 3, &dm.triangles);
@@ -1604,7 +1569,11 @@ int zygpu_test_intersect(ZygpuContext* c, uint32_t n, const float* rays, uint32_
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&din), size_t(n) * 32));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&dout), size_t(n) * 32));
     HIP_OK(hipMemcpy(din, rays, size_t(n) * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(test_intersect, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, din, depth_surface, mode, dout);
+    auto hook = c->relaxed ? zyg_unit7f_test_rays : zyg_unit7_test_rays;  // in the arithmetic the context renders in
+    if (!hook || 0 != hook(0, n, din, depth_surface, mode, dout, c->stream)) {
+        g_error = "zygpu_test_intersect: the kernel unit with the ray hooks is not in this build";
+        return -1;
+    }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(hits, dout, size_t(n) * 32, hipMemcpyDeviceToHost));
@@ -1621,7 +1590,11 @@ int zygpu_test_visibility(ZygpuContext* c, uint32_t n, const float* rays, uint32
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&din), size_t(n) * 32));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&dout), size_t(n) * 4));
     HIP_OK(hipMemcpy(din, rays, size_t(n) * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(test_visibility, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, din, mode, dout);
+    auto hook = c->relaxed ? zyg_unit7f_test_rays : zyg_unit7_test_rays;
+    if (!hook || 0 != hook(1, n, din, 0, mode, dout, c->stream)) {
+        g_error = "zygpu_test_visibility: the kernel unit with the ray hooks is not in this build";
+        return -1;
+    }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(visible, dout, size_t(n) * 4, hipMemcpyDeviceToHost));

@@ -34,7 +34,10 @@ def init_process_group(backend, rank=None, world=None, device=None):
     binds the RCCL communicator to this rank's GPU up front.  Returns the torch.distributed module."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
+    # dmabuf IPC is the only mode the host driver supports.  HSA reads the flag once, when the process makes its first HIP call,
+    # so a caller that has touched the GPU already must have set it itself (bench.py does, before it imports torch); here it
+    # only helps a process that has not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
     kw = {"device_id": device} if (device is not None and "nccl" == backend) else {}
@@ -48,6 +51,9 @@ class ShardedFrame:
     mode "iterations": the run's `steps` x `iterations_per_step` iterations per rank are rank r's block
     [r * steps * ips, (r + 1) * steps * ips) of the frame's world * steps * ips samples per pixel, over all rows.
     mode "rows": every rank renders all steps * ips iterations of its own rows.
+
+    A frame with a process group runs its collectives whatever the world size (a world of one still goes through the backend:
+    that is how the RCCL path is exercised on a box with one GPU); without one (dist = None, world = 1) there is nothing to run.
     """
 
     def __init__(self, rank=0, world=1, dist=None, mode="iterations", height=0):
@@ -70,12 +76,12 @@ class ShardedFrame:
 
     def reduce(self, film, dst=0):
         """The one exchange step: the ranks' films summed into rank `dst` (in place on `dst`)."""
-        if self.world > 1:
+        if self.dist is not None:
             reduce_film(film, self.dist, dst)
         return film
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist is not None:
             self.dist.barrier()
 
     def timed(self, body, synchronize):
@@ -87,7 +93,7 @@ class ShardedFrame:
         synchronize()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        if self.world > 1:
+        if self.dist is not None:
             import torch
             t = torch.tensor([elapsed], dtype=torch.float64)
             if "nccl" == self.dist.get_backend():

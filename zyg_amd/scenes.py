@@ -4,7 +4,8 @@ The reference ships no scenes (its data/ directory is git-ignored), 
 generated: a Cornell box out of `Rectangle` props (reference built-in shape id 5,
 src/core/resource/manager.zig:36-44), two emissive quads as unoccluding `Light` entities
 (util/scene_loader.zig:249,365-366), the classic short/tall boxes as triangle meshes, and a
-procedural ~1 M-triangle displaced heightfield.
+procedural ~1 M-triangle mesh: a closed displaced sphere hanging in the box, and a displaced
+heightfield lying on its floor as a second, lighter variant.
 """
 import json
 
@@ -15,6 +16,7 @@ RECTANGLE = 5
 WHITE = [0.725, 0.71, 0.68]
 RED = [0.63, 0.065, 0.05]
 GREEN = [0.14, 0.45, 0.091]
+MESH_CENTRE = (0.0, 1.2, 0.0)  # the 1 M-triangle mesh centred in the box at ~60 % of its height (the box is 2 high)
 
 
 def trafo(r0, r1, scale, position):
@@ -270,15 +272,104 @@ def heightfield_mesh(n=708, size=1.2, height=0.35, octaves=5):
             uv.reshape(-1, 2).astype(np.float32))
 
 
+def _pcg32_floats(count, seed_seq):
+    """`count` PCG32 floats of the stream (seed 0, sequence seed_seq), vectorised: the LCG state after k steps is
+    a_k * s0 + c_k with (a_k, c_k) built by doubling, so the whole run is a handful of uint64 array operations."""
+    mul = np.uint64(6364136223846793005)
+    inc = np.uint64(((seed_seq << 1) | 1) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        a = np.ones(1, dtype=np.uint64)
+        c = np.zeros(1, dtype=np.uint64)
+        while a.size < count + 2:  # (a, c)[k] for k = 0 .. size-1; doubling: step size more from every entry
+            am, cm = a[-1] * mul, c[-1] * mul + inc  # the map of `size` steps
+            a, c = np.concatenate([a, a * am]), np.concatenate([c, c * am + cm])
+        # as _value_noise_lattice: state 0, two steps, then every output is computed from the state *before* its step
+        s0 = np.uint64(0)
+        old = (a * s0 + c)[2:count + 2]
+        xrs = (((old >> np.uint64(18)) ^ old) >> np.uint64(27)).astype(np.uint32)
+        rot = (old >> np.uint64(59)).astype(np.uint32)
+        out = (xrs >> rot) | (xrs << ((np.uint32(32) - rot) & np.uint32(31)))
+    return (out.astype(np.float64) / 4294967296.0).astype(np.float32)
+
+
+def displaced_sphere_mesh(n=708, radius=0.52, amplitude=0.22, octaves=5):
+    """a closed displaced sphere, n x n vertices -> 2 (n-1)^2 triangles (n = 708: 999 698), 5-octave value
+    noise displacement (3-D lattices of PCG32 floats, seed 0, sequences 1..octaves), smooth normals, uvs, centred at the origin.
+    The vertex grid is the octahedral map of [-1, 1]^2 onto the sphere; the square's border folds onto itself (the vertices
+    (u, 1) and (-u, 1) are the same point), so the surface is closed; the twins share their normals."""
+    assert 0 == n % 2
+    half = -1.0 + 2.0 * np.arange(n // 2, dtype=np.float64) / (n - 1)
+    u = np.concatenate([half, -half[::-1]])  # exactly symmetric: u[n-1-i] = -u[i]
+    uu, vv = np.meshgrid(u, u, indexing="xy")
+    z = 1.0 - np.abs(uu) - np.abs(vv)
+    lower = z < 0.0
+    x = np.where(lower, (1.0 - np.abs(vv)) * np.sign(uu), uu)
+    y = np.where(lower, (1.0 - np.abs(uu)) * np.sign(vv), vv)
+    d = np.stack([x, z, y], axis=-1)  # the octahedron's axis along +y: the poles are the top and the bottom of the mesh
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+
+    hgt = np.zeros((n, n), dtype=np.float64)
+    amp, total = 1.0, 0.0
+    for o in range(octaves):
+        cells = 4 << o
+        m = cells + 1
+        lat = _pcg32_floats(m * m * m, o + 1).astype(np.float64).reshape(m, m, m)
+        q = (d * 0.5 + 0.5) * cells
+        q0 = np.minimum(q.astype(np.int64), cells - 1)
+        f = q - q0
+        f = f * f * (3 - 2 * f)
+        acc = 0.0
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    wgt = (f[..., 0] if dx else 1 - f[..., 0]) * (f[..., 1] if dy else 1 - f[..., 1]) * (f[..., 2] if dz else 1 - f[..., 2])
+                    acc = acc + wgt * lat[q0[..., 2] + dz, q0[..., 1] + dy, q0[..., 0] + dx]
+        hgt += amp * acc
+        total += amp
+        amp *= 0.5
+    hgt /= total
+    r = radius * (1.0 + amplitude * (2.0 * hgt - 1.0))
+    pos = d * r[..., None]
+
+    ii, jj = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="xy")
+    v0 = (jj * n + ii).reshape(-1)
+    v1, v2 = v0 + 1, v0 + n
+    v3 = v2 + 1
+    # (u, v) -> (x, z): counter-clockwise seen from outside is clockwise in the (u, v) square with y = up taken from the z of the map
+    tri = np.stack([v0, v2, v1, v1, v2, v3], axis=-1).reshape(-1, 3)
+    p = pos.reshape(-1, 3)
+    fn = np.cross(p[tri[:, 1]] - p[tri[:, 0]], p[tri[:, 2]] - p[tri[:, 0]])
+    if np.sum(fn * p[tri[:, 0]]) < 0.0:  # outward winding, whatever the handedness of the axes above
+        tri = tri[:, [0, 2, 1]]
+        fn = -fn
+    nrm = np.zeros_like(p)
+    for k in range(3):
+        np.add.at(nrm, tri[:, k], fn)
+    nrm = nrm.reshape(n, n, 3)
+    # the folded border: a vertex and its twin are one point of the surface
+    for edge in (0, n - 1):
+        row = nrm[edge] + nrm[edge, ::-1]
+        nrm[edge] = row
+        col = nrm[:, edge] + nrm[::-1, edge]
+        nrm[:, edge] = col
+    corner = nrm[0, 0] + nrm[0, n - 1] + nrm[n - 1, 0] + nrm[n - 1, n - 1]
+    nrm[0, 0] = nrm[0, n - 1] = nrm[n - 1, 0] = nrm[n - 1, n - 1] = corner
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    uv = np.stack([uu * 0.5 + 0.5, vv * 0.5 + 0.5], axis=-1)
+    return (tri.reshape(-1).astype(np.uint32), p.astype(np.float32), nrm.reshape(-1, 3).astype(np.float32),
+            uv.reshape(-1, 2).astype(np.float32))
+
+
 def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", boxes=True, mesh=None,
             max_depth=16, filter_name=None, split_threshold=None, light_samples=1, unoccluding_lights=True,
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
             light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None,
-            overrides=None, regularize=None):
+            overrides=None, regularize=None, mesh_position=(0, 0.02, 0.1)):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
-    material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed on the floor.
+    material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed at mesh_position (the
+    default puts heightfield_mesh on the floor; displaced_sphere_mesh hangs at MESH_CENTRE, 60 % of the box's height).
     mesh_lights: the two emissive quads are triangle meshes (2 * light_grid^2 triangles each) instead of Rectangles.
     many_lights: n > 0 replaces the two quads by an n x n grid of small Rectangle lights under the ceiling (light-tree depth).
     spheres: two analytic Spheres (one Substitute-ish via `material`, one red) instead of / next to the boxes;
@@ -448,7 +539,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
         if isinstance(mm, str):  # a material JSON instead of an id
             mm = engine.material(mm)
         p = engine.prop(shape, [mm])
-        engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0.02, 0.1)))
+        engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), tuple(mesh_position)))
         ids["meshes"].append(p)
 
     engine.transformation(cam, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 1, camera_z)))
