@@ -237,7 +237,7 @@ def test_million_triangle_mesh(engine, oracle, shape):
     kw = _CONFIG2[shape]()
     out = _render_both(engine, oracle, 96, 54, 2, boxes=False, mesh_material=scenes.substitute((0.5, 0.5, 0.5)), **kw)
     _check(*out, 2)
-    assert out[2].triangles_tested > (40 if "sphere" == shape else 0) * out[2].camera_samples
+    assert out[2].triangles_tested > (10 if "sphere" == shape else 0) * out[2].camera_samples
 
 
 @pytest.mark.parametrize("integrator", ["PT", "PTMIS"])
@@ -635,7 +635,8 @@ def test_config2_million_triangles_at_1080p(engine, oracle, shape):
     """BASELINE.json configs[2] at its full size: the 999 698-triangle mesh (Substitute) in the Cornell box, 1920x1080."""
     w, h, spp = 1920, 1080, 2
     scenes.cornell(engine, w, h, spp, integrator="PTMIS", boxes=False, mesh_material=scenes.substitute((0.5, 0.5, 0.5)), **_CONFIG2[shape]())
-    _full_frame_checks(engine, oracle, w, h, spp, (420, 426) if "sphere" == shape else (700, 706))
+    # floor: the Substitute closure's formulas give a hair below zero in a handful of pixels (-2.5e-7 seen), the oracle's too
+    _full_frame_checks(engine, oracle, w, h, spp, (420, 426) if "sphere" == shape else (700, 706), floor=-1e-5)
 
 
 def test_config4_outdoor_at_4k_depth_16(engine, oracle):
@@ -757,36 +758,38 @@ def test_sensor_clamp_changes_the_image(product_lib):
     assert not np.array_equal(films[0], films[1]) and films[1][..., :3].max() < films[0][..., :3].max()
 
 
-def test_device_error_flag_is_reported_and_cleared(product_lib):
-    """Six unoccluding emitters stacked in front of the camera: a ray crosses more of them than the candidate list holds
-    (kMaxUnoccludingCandidates = 4), their emission would be missing, so every call that hands out pixels fails; the next
-    frame starts clean."""
-    with zyg_amd.Engine(product_lib) as e:
-        e.camera(64, 48, fov_deg=40.0)
-        e.samples_per_pixel(1)
-        e.integrators(json.dumps({"surface": {"PTMIS": {}}}))
-        e.sensor(json.dumps({}))
-        lamp = e.material(scenes.light_material(spectrum=(1.0, 1.0, 1.0)))
-        white = e.material(scenes.lambert((0.5, 0.5, 0.5)))
-        back = e.prop(scenes.RECTANGLE, [white])
-        e.transformation(back, scenes.trafo((1, 0, 0), (0, -1, 0), (8, 8, 1), (0, 0, 8)))
-        for k in range(6):
+def _stacked_lamps(e, w, h, spp, integrator="PTMIS", lamps=6, mesh_lamps=False, **_):
+    """`lamps` unoccluding emitters stacked in front of the camera, seen end-on, a grey wall behind them: a camera ray crosses
+    all of them in front of its hit ("Light" entities are unoccluding by default in the reference, scene_loader.zig:249)."""
+    e.camera(w, h, fov_deg=40.0)
+    e.samples_per_pixel(spp)
+    e.integrators(json.dumps({"surface": {integrator: {}}}))
+    e.sensor(json.dumps({}))
+    white = e.material(scenes.lambert((0.5, 0.5, 0.5)))
+    back = e.prop(scenes.RECTANGLE, [white])
+    e.transformation(back, scenes.trafo((1, 0, 0), (0, -1, 0), (8, 8, 1), (0, 0, 8)))
+    for k in range(lamps):
+        lamp = e.material(scenes.light_material(spectrum=(0.4 + 0.1 * k, 0.5, 1.0 - 0.1 * k)))
+        if mesh_lamps and k % 2:
+            idx, pos, nrm, uv = scenes.quad_mesh(2, 1.0)
+            p = e.prop(e.triangle_mesh(idx, pos, nrm, uv), [lamp], unoccluding=True)
+        else:
             p = e.prop(scenes.RECTANGLE, [lamp], unoccluding=True)
-            e.transformation(p, scenes.trafo((1, 0, 0), (0, -1, 0), (1, 1, 1), (0, 0, 2.0 + 0.5 * k)))
-            e.light(p)
-        e.start_frame(0)
-        e.render_iterations(1)
-        with pytest.raises(RuntimeError, match="kMaxUnoccludingCandidates"):
-            e.synchronize()
-        out = np.zeros((48, 64, 4), dtype=np.float32)
-        assert e.lib.su_resolve_frame_to_buffer(zyg_amd.NULL, 64, 48, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) == -1
-        assert e.lib.zygpu_download_film(e.context(), out.ctypes.data) == -3
-    with zyg_amd.Engine(product_lib) as e:  # a new engine on the same device context state: no stale flag
-        scenes.cornell(e, 32, 24, 1)
-        e.start_frame(0)
-        e.render_iterations(1)
-        e.synchronize()
-        assert np.isfinite(e.resolve(32, 24)).all()
+        # staggered sideways, so that pixels see 1 .. `lamps` of them
+        e.transformation(p, scenes.trafo((1, 0, 0), (0, -1, 0), (1, 1, 1), (0.12 * k - 0.3, 0.05 * k, 2.0 + 0.5 * k)))
+        e.light(p)
+
+
+@pytest.mark.parametrize("integrator", ["PT", "PTMIS"])
+@pytest.mark.parametrize("mesh_lamps", [False, True])
+def test_more_unoccluding_emitters_than_candidate_slots(engine, oracle, integrator, mesh_lamps):
+    """Six unoccluding emitters in a row: a ray crosses more of them than the path's candidate list holds
+    (kMaxUnoccludingCandidates = 4).  The shading pass then walks the unoccluding tree again and evaluates every crossing in
+    traversal order, as PropBvh.emission does (prop_tree.zig:302-356): film and counters are the oracle's."""
+    out = _render_both(engine, oracle, 96, 72, 3, scene=_stacked_lamps, integrator=integrator, mesh_lamps=mesh_lamps)
+    _check(*out, 3)
+    film = out[0]
+    assert film[36, 48, :3].sum() > 6 * 1.2  # the middle of the frame looks through all six
 
 
 # ---------------------------------------------------------------- the relaxed-arithmetic units (zygpu option "precise" = 0)

@@ -123,6 +123,61 @@ def test_missing_files_fail_loudly(product_lib, tmp_path):
         assert e.lib.su_ext_load_take(str(tmp_path / "a.take").encode()) == -1
 
 
+_REFUSED = {
+    "Sky": {"type": "Sky", "parameters": {"sun": {"rotation": [45, 0, 0]}}},
+    "Portal": {"type": "Portal", "shape": {"type": "Rectangle"}, "light": 0},
+    "Instancer": {"type": "Instancer", "prototypes": [], "instances": {"prototypes": [], "transformations": []}},
+    "Scatterer": {"type": "Scatterer", "prototypes": []},
+    "animation": {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"],
+                  "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]}},
+    "shadow_catcher": {"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["grey"], "shadow_catcher": {}},
+    "shadow_catcher_light": {"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"], "visibility": {"shadow_catcher_light": True}},
+}
+
+
+@pytest.mark.parametrize("what", sorted(_REFUSED))
+def test_unrendered_entities_and_keys_fail_the_load(product_lib, tmp_path, what):
+    """What the reference's scene loader reads (scene_loader.zig:241-326, 612-628) and this build does not render is refused by
+    name, logged at error level: a take is never rendered with a part of its scene dropped in silence.  Nested below a node of an
+    unknown type, which the reference treats as a plain transformation node (its children are loaded)."""
+    scene = {"materials": [{"name": "grey", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5]}}},
+                           {"name": "lamp", "rendering": {"Light": {"emittance": {"spectrum": [5, 5, 5]}}}}],
+             "entities": [{"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"], "transformation": {"position": [0, 3, 0]}},
+                          {"type": "Group", "transformation": {"position": [1, 0, 0]}, "entities": [_REFUSED[what]]}]}
+    with open(tmp_path / "s.scene", "w") as f:
+        json.dump(scene, f)
+    with open(tmp_path / "s.take", "w") as f:
+        json.dump({"scene": "s.scene", "camera": {"Perspective": {"resolution": [8, 8]}}}, f)
+    messages = []
+    callback = zyg_amd.LOG_CALLBACK(lambda level, text: messages.append((level, text.decode())))
+    with zyg_amd.Engine(product_lib) as e:
+        e.lib.su_register_log.argtypes = [zyg_amd.LOG_CALLBACK]
+        assert e.lib.su_register_log(callback) == 0
+        try:
+            assert e.lib.su_ext_load_take(str(tmp_path / "s.take").encode()) == -1
+        finally:
+            e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
+    assert any(level == 2 and what in text and "does not render" in text for level, text in messages), messages
+
+
+def test_unknown_entity_type_is_a_transformation_node(product_lib, tmp_path):
+    """scene_loader.zig:241-264: a type that names no entity class creates none, but its transformation and children count."""
+    scene = {"materials": [{"name": "grey", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5]}}}],
+             "entities": [{"type": "Group", "transformation": {"position": [0, 5, 0]},
+                           "entities": [{"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"], "transformation": {"position": [1, 0, 0]}}]},
+                          {"type": "Prop", "materials": ["grey"]}]}  # no shape: skipped (`catch continue`)
+    with open(tmp_path / "s.scene", "w") as f:
+        json.dump(scene, f)
+    with open(tmp_path / "s.take", "w") as f:
+        json.dump({"scene": "s.scene", "camera": {"Perspective": {"resolution": [8, 8], "transformation": {"position": [0, 0, -4]}}}}, f)
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(str(tmp_path / "s.take").encode()) == 0
+        sd, _ = e.compile()
+        spheres = [i for i in range(sd.num_props) if sd.props[i].shape == scenes.SPHERE]
+        assert len(spheres) == 1 and sd.num_props == 2  # the camera is a prop too
+        np.testing.assert_allclose(np.array(list(sd.trafos[spheres[0]].position)[:3]) + np.array([0, 0, -4]), [1, 5, 0], atol=1e-6)
+
+
 @pytest.mark.gpu
 def test_render_take_and_export(product_lib, tmp_path):
     """The whole drop-in chain on files: take -> scene -> meshes -> render -> image_00_000000.png, the film being the one the

@@ -14,12 +14,15 @@ material = sys.argv[1] if len(sys.argv) > 1 else "lambert"
 eng = zyg_amd.Engine()
 kw = {}
 if os.environ.get("ZYG_SCENE") == "mesh":  # BASELINE.json configs[2]
-    kw = dict(boxes=False, mesh=scenes.heightfield_mesh(), mesh_material=scenes.substitute((0.7, 0.7, 0.7)))
+    kw = dict(boxes=False, mesh=scenes.displaced_sphere_mesh(), mesh_position=scenes.MESH_CENTRE, mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
+elif os.environ.get("ZYG_SCENE") == "mound":
+    kw = dict(boxes=False, mesh=scenes.heightfield_mesh(), mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
 scenes.cornell(eng, w, h, iters, integrator="PTMIS", material=material, **kw)
 eng.start_frame(0)
 lib, ctx = eng.lib, eng.context()
 lib.zygpu_get_section_cycles.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 lib.zygpu_reset_stats(ctx)
+assert 0 == lib.zygpu_set_option(ctx, b"precise", int(os.environ.get("ZYG_PRECISE", "0")))  # the relaxed units unless asked otherwise
 lib.zygpu_render(ctx, 0, 0, iters, 0, h)
 lib.zygpu_synchronize(ctx)
 out = (ctypes.c_uint64 * 32)()
@@ -32,8 +35,6 @@ names = {0: "shade: state loads + fragment", 1: "shade: hit emission (evaluateRa
          19: "scatter: shadow ray traversal", 20: "scatter: radiance, bsdf evaluate, MIS", 21: "scatter: IValue add",
          22: "scatter: bxdf sample, state update, stores", 23: "scatter: queue push",
          }
-precise = int(os.environ.get("ZYG_PRECISE", "0"))
-lib.zygpu_set_option(ctx, b"precise", precise)
 for base, label in ((0, "wf_trace_shade + wf_shade"), (16, "wf_scatter")):
     tot = sum(out[base:base + 16]) or 1
     print(f"{label}: {tot / 1e9:.2f} G wave-cycles")

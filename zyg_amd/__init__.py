@@ -168,6 +168,7 @@ class Stats(ctypes.Structure):
 
 
 _LOG_FUNC = ctypes.CFUNCTYPE(None, ctypes.c_uint32, ctypes.c_char_p)
+LOG_CALLBACK = _LOG_FUNC  # su_register_log's callback type: (level, text); level 2 = error (core/log.zig)
 
 _lib = None
 

@@ -543,6 +543,9 @@ struct Node4q {
 #ifndef ZYG_LDS_STACK
 #define ZYG_LDS_STACK 1
 #endif
+#ifndef ZYG_ANY_NEAREST
+#define ZYG_ANY_NEAREST 0  // 1: the any-hit walk of the quantised nodes descends into the nearest child first (measured: see DESIGN)
+#endif
 #ifndef ZYG_LDS_STACK_ENTRIES
 #define ZYG_LDS_STACK_ENTRIES 16  // 32 KB per 256-thread block: four blocks of wf_trace_shade per CU
 #endif
@@ -656,6 +659,28 @@ ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
         while (0 == cur_count) {
             const Node4q n = Node4q::load(nodes, cur);
             uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
+#if ZYG_ANY_NEAREST
+            // the nearest child first, the others parked in storage order
+            const float  t0 = n.test<0>(ray, r0, n0), t1 = n.test<1>(ray, r1, n1), t2 = n.test<2>(ray, r2, n2), t3 = n.test<3>(ray, r3, n3);
+            const float  tmin = mn(mn(t0, t1), mn(t2, t3));
+            bool         have = FLT_MAX != tmin;
+            uint32_t     nr = 0, nc = 0;
+            bool         chosen = false;
+            auto         take = [&](float t, uint32_t r, uint32_t c) {
+                if (FLT_MAX == t) return;
+                if (!chosen && t == tmin) {
+                    chosen = true;
+                    nr = r;
+                    nc = c;
+                } else {
+                    stack.push(r, c, 0.f);
+                }
+            };
+            take(t3, r3, n3);
+            take(t2, r2, n2);
+            take(t1, r1, n1);
+            take(t0, r0, n0);
+#else
             const bool   h0 = FLT_MAX != n.test<0>(ray, r0, n0), h1 = FLT_MAX != n.test<1>(ray, r1, n1);
             const bool   h2 = FLT_MAX != n.test<2>(ray, r2, n2), h3 = FLT_MAX != n.test<3>(ray, r3, n3);
             bool         have = false;
@@ -671,6 +696,7 @@ ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
             take(h2, r2, n2);
             take(h1, r1, n1);
             take(h0, r0, n0);
+#endif
             if (have) {
                 cur = nr;
                 cur_count = nc;

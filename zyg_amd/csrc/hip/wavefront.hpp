@@ -890,7 +890,9 @@ __global__ void __launch_bounds__(256) wf_generate(Params P, uint32_t num_paths)
 
 // PropBvh.emission over the unoccluding TLAS (prop_tree.zig:302-356, prop.zig:239-264, rectangle.zig:188-196), split in
 // two: wf_intersect walks the tree right after the closest hit (ray.max_t already shrunk to it) and records the lights
-// the ray crosses, in traversal order; wf_shade evaluates them (sampler draws + MIS weights) in that order.
+// the ray crosses, in traversal order; wf_shade evaluates them (sampler draws + MIS weights) in that order.  The list holds
+// kMaxUnoccludingCandidates crossings; a ray that crosses more (a row of lamps seen end-on: "Light" entities are unoccluding by
+// default, scene_loader.zig:249) has its emission evaluated by a second walk in the shading pass, in the same order.
 constexpr uint32_t kMaxUnoccludingCandidates = 4;
 
 // whether connectLight looks at emission at all for this vertex, and at the unoccluding lights in particular
@@ -900,21 +902,11 @@ ZD bool walksUnoccluding(uint32_t flags) {
     return connectsLights(flags) && (ZYGPU_INTEGRATOR_PTDL != c_view.v.integrator || (flags & ST_SINGULAR));
 }
 
-template <bool STATS, bool EXTRA, bool UTLAS = false>
-ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, size_t plane, uint32_t depth_surface, const Ray& ray_in,
-                                  Counters& cnt) {
-    uint32_t n = 0;
-    Ray      ray = ray_in;
-    auto     record = [&](uint32_t prop, uint32_t primitive, float t, float u, float v) {
-        if (n < kMaxUnoccludingCandidates) {
-            const size_t at = size_t(n) * plane + slot;
-            P.pool.ucand[at] = make_uint4(prop, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
-            P.pool.ucand_prim[at] = primitive;
-        } else {
-            atomicOr(&P.ctl->error, 2u);  // reported by zygpu_synchronize: more crossed unoccluding emitters than slots
-        }
-        n += 1;
-    };
+// The walk itself: every unoccluding emitter the ray crosses in front of max_t, in traversal order, handed to
+// record(prop, primitive, t, u, v).
+template <bool STATS, bool EXTRA, bool UTLAS = false, typename Record>
+ZD void walkUnoccluding(const DScene& s, uint32_t depth_surface, const Ray& ray_in, Counters& cnt, Record&& record) {
+    Ray ray = ray_in;
     if (UTLAS) {  // the unoccluding tree is one leaf of Rectangles (dscene.hpp TlasEntry): its order is the leaf's order
         for (uint32_t k = 0; k < s.num_unocc_table; ++k) {
             const TlasEntry& e = s.unocc_table[k];
@@ -923,7 +915,7 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             float t, u, v;
             if (rectangleIntersect(ray, entryTrafo(e), t, u, v)) record(e.prop, 0, t, u, v);
         }
-        return n;
+        return;
     }
     bvhWalk<STATS>(s.unocc_nodes, s.num_unocc_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
@@ -958,6 +950,22 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
             }
         }
         return false;
+    });
+}
+
+// The traversal kernels' half: the first kMaxUnoccludingCandidates crossings go into the path's candidate list; the count
+// returned is the number of crossings, which may be larger: the shading pass then walks the tree again itself (unoccludingEmission).
+template <bool STATS, bool EXTRA, bool UTLAS = false>
+ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slot, size_t plane, uint32_t depth_surface, const Ray& ray_in,
+                                  Counters& cnt) {
+    uint32_t n = 0;
+    walkUnoccluding<STATS, EXTRA, UTLAS>(s, depth_surface, ray_in, cnt, [&](uint32_t prop, uint32_t primitive, float t, float u, float v) {
+        if (n < kMaxUnoccludingCandidates) {
+            const size_t at = size_t(n) * plane + slot;
+            P.pool.ucand[at] = make_uint4(prop, __float_as_uint(t), __float_as_uint(u), __float_as_uint(v));
+            P.pool.ucand_prim[at] = primitive;
+        }
+        n += 1;
     });
     return n;
 }
@@ -1146,23 +1154,20 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
 template <bool MESHL>
 ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_t plane, const VertexIn& v, const Ray& ray, Sampler& smp) {
     f3             energy = S3(0.f);
-    const uint32_t n = min(uint32_t(P.pool.ucount[slot]), kMaxUnoccludingCandidates);
+    const uint32_t n = P.pool.ucount[slot];
     const f3       wo = -ray.direction;
-    for (uint32_t k = 0; k < n; ++k) {
-        const size_t    at = size_t(k) * plane + slot;
-        const uint4     c = P.pool.ucand[at];
-        const ZygpuProp prop = s.props[c.x];
+    auto           evaluate = [&](uint32_t prop_id, uint32_t prim, float t, float fu, float fv) {
+        const ZygpuProp prop = s.props[prop_id];
         Fragment        frag;
-        frag.trafo = propTrafoAt<MESHL, true>(s, c.x, ray.time);
-        frag.prop = c.x;
-        frag.t_hit = __uint_as_float(c.y);
-        frag.u = __uint_as_float(c.z);
-        frag.v = __uint_as_float(c.w);
+        frag.trafo = propTrafoAt<MESHL, true>(s, prop_id, ray.time);
+        frag.prop = prop_id;
+        frag.t_hit = t;
+        frag.u = fu;
+        frag.v = fv;
         if (MESHL && ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
             // the partial fragment TriangleTree.emission fills (triangle_tree.zig:428-447): p, geometric normal, part
-            const DMesh&   mesh = s.meshes[prop.mesh];
-            const uint32_t prim = P.pool.ucand_prim[at];
-            const f3       a = xyz(mesh.tri_verts[3 * prim]), b = xyz(mesh.tri_verts[3 * prim + 1]), cc = xyz(mesh.tri_verts[3 * prim + 2]);
+            const DMesh& mesh = s.meshes[prop.mesh];
+            const f3     a = xyz(mesh.tri_verts[3 * prim]), b = xyz(mesh.tri_verts[3 * prim + 1]), cc = xyz(mesh.tri_verts[3 * prim + 2]);
             frag.primitive = prim;
             frag.part = mesh.triangle_parts[prim];
             frag.p = frag.trafo.objectToWorldPoint(interpolate3(a, b, cc, frag.u, frag.v));
@@ -1178,6 +1183,18 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
             rectangleFragment(ray, frag);
         }
         energy = energy + evaluateRadiance<MESHL>(s, v, wo, frag, smp);
+    };
+    if (n > kMaxUnoccludingCandidates) {
+        // more crossings than the list holds: walk the tree again, as PropBvh.emission itself does (prop_tree.zig:302-356), and
+        // evaluate every crossing where it is found; `ray` ends at the hit like the traversal kernel's.  Nothing is counted twice.
+        Counters none{0, 0, 0};
+        walkUnoccluding<false, MESHL>(s, v.depth_surface, ray, none, evaluate);
+        return energy;
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        const size_t at = size_t(k) * plane + slot;
+        const uint4  c = P.pool.ucand[at];
+        evaluate(c.x, MESHL ? P.pool.ucand_prim[at] : 0u, __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
     }
     return energy;
 }

@@ -614,16 +614,13 @@ uint64_t g_view_epoch = 0, g_unit_view_epoch[2][ZYG_NUM_UNITS] = {};
 
 // A unit's copy of the view block is brought up to date (in stream order) before the first launch that needs it
 // The device error flags (Control::error), read after the stream has drained.  Set by the kernels when a result would be
-// wrong (bit 1: a ray crossed more unoccluding emitters than kMaxUnoccludingCandidates holds, the extra emission is lost);
+// wrong (no kernel sets one at present: the unoccluding candidates' overflow, once bit 1, is handled by a second walk);
 // reported by every call that hands pixels to the caller, cleared at the start of a frame (zygpu_clear_film / zygpu_upload_scene).
 int deviceErrorFlags(ZygpuContext* c) {
     uint32_t flags = 0;
     if (!check(hipMemcpy(&flags, &c->ctl->error, sizeof(flags), hipMemcpyDeviceToHost), "hipMemcpy(Control::error)")) return -1;
     if (0 == flags) return 0;
     g_error = "device error flags: " + std::to_string(flags);
-    if (flags & 2u)
-        g_error += " (a ray crossed more than 4 unoccluding emitters (Rectangles / mesh triangles) in front of its hit: "
-                   "kMaxUnoccludingCandidates; their emission is missing from the film)";
     return -3;
 }
 

@@ -6,8 +6,8 @@
 //   mesh .sub        src/core/scene/shape/shape_provider.zig:527-805, 965-994 ("SUB\0", u64 json size, JSON header, binary
 //                    vertex streams + indices, delta-encoded Int16 / Int32 or plain UInt16 / UInt32)
 // File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
-// core/file/system.zig, reduced to these two levels).  Not read: glTF, instancers, scatterers, portals, animations, Sky
-// entities, gzip-compressed files.
+// core/file/system.zig, reduced to these two levels).  Refused by name (the load fails, nothing is skipped in silence): instancers,
+// scatterers, portals, Sky entities, animations, shadow catchers.  Not read: glTF, gzip-compressed files.
 #pragma once
 
 #include <cstdio>
@@ -246,33 +246,47 @@ class TakeLoader {
                 continue;
             }
             Transformation world;
-            if (!loadEntity(e, parent, local_materials, dir, world)) continue;  // scene_loader.zig:220 `catch continue`
+            if (!loadEntity(e, parent, local_materials, dir, world)) {
+                if (!error.empty()) return false;  // something this build cannot render: never skipped in silence
+                continue;                          // scene_loader.zig:220 `catch continue` (an entity without type or shape)
+            }
             if (const JsonValue* children = e.get("entities"))
                 if (!loadEntities(*children, world, local_materials, dir)) return false;
         }
         return true;
     }
+    // What the reference's loader reads and this build does not render fails the load by name: an entity type (scene_loader.zig:
+    // 252-264), or a key that changes the image (`animation` scene_graph.zig:184-203, `shadow_catcher` scene_loader.zig:312-313,
+    // visibility.shadow_catcher_light scene_loader.zig:612-619).  su_ext_load_take logs the message at error level and returns -1.
+    bool unsupported(const std::string& what) {
+        return fail("the scene uses " + what + ", which this build does not render");
+    }
     bool loadEntity(const JsonValue& v, const Transformation& parent, const std::map<std::string, const JsonValue*>& local_materials,
                     const std::string& dir, Transformation& world) {
         const JsonValue* type = v.get("type");
-        if (!type || JsonValue::String != type->type) return false;
+        if (!type || JsonValue::String != type->type) return false;  // Error.UndefinedType
         uint32_t entity = ZYGPU_NULL;
         bool     is_light = false;
         if (type->str == "Light") {
             entity = loadProp(v, local_materials, dir, true);
+            if (ZYGPU_NULL == entity) return false;  // Error.UndefinedShape
             is_light = true;
         } else if (type->str == "Prop") {
             entity = loadProp(v, local_materials, dir, false);
-        } else if (type->str != "Dummy") {
-            return false;  // Portal, Instancer, Sky, Scatterer
-        }
+            if (ZYGPU_NULL == entity) return false;
+        } else if (type->str == "Portal" || type->str == "Instancer" || type->str == "Sky" || type->str == "Scatterer") {
+            return unsupported("a \"" + type->str + "\" entity");
+        }  // any other type is a node without an entity: its transformation applies to its children (scene_loader.zig:241-264)
+        if (v.get("animation")) return unsupported("an entity with an \"animation\"");
+        if (v.get("shadow_catcher")) return unsupported("a \"shadow_catcher\" entity");
         Transformation local = identity();
         if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
         world = transform(parent, local);
-        if (ZYGPU_NULL == entity) return "Dummy" == type->str;
+        if (ZYGPU_NULL == entity) return true;
         setWorld(entity, world);
         bool in_reflection = true;
         if (const JsonValue* vis = v.get("visibility")) {
+            if (vis->memberBool("shadow_catcher_light", false)) return unsupported("a \"shadow_catcher_light\"");
             in_reflection = vis->memberBool("in_reflection", true);
             engine_.setVisibility(entity, vis->memberBool("in_camera", true), in_reflection, vis->memberBool("in_sss", false));
         }
