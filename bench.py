@@ -59,6 +59,8 @@ def parse_args():
                     help="zygpu option fuse_tick: wf_scatter of vertex k and wf_trace_shade of vertex k + 1 in one launch (wf_tick)")
     ap.add_argument("--persistent", type=int, default=0, choices=[0, 1],
                     help="zygpu option persistent: one persistent kernel per batch, path state in LDS (wf_persistent)")
+    ap.add_argument("--mesh-kernels", type=int, default=1, choices=[0, 1],
+                    help="zygpu option mesh_kernels: the large meshes' walks in persistent kernels whose lanes fetch their own rays")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed oracle sample (and again of the parity band)")
@@ -113,6 +115,7 @@ class Measurement:
         self.eng.set_option("precise", args.precise)
         self.eng.set_option("persistent", args.persistent)
         self.eng.set_option("fuse_tick", args.fuse_tick)
+        self.eng.set_option("mesh_kernels", args.mesh_kernels)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)
         self.fused = bool(args.fuse) and scene in ("cornell", "cornell_mesh", "cornell_mound")  # POOL scenes always run the kernels apart
         self.film = torch.zeros((self.h, self.w, 4), dtype=torch.float32, device=device)

@@ -832,8 +832,13 @@ def test_relaxed_arithmetic_stays_finite_and_close(product_lib, name):
     rf, ri = _render_mode(product_lib, build, w, h, spp, 0)
     assert np.isfinite(rf).all() and np.isfinite(ri).all()
     assert np.array_equal(pf[..., 3], rf[..., 3])
+    if name in ("glass", "outdoor"):
+        # a scene with Glass runs the precise units whatever the option says (chaotic paths: relaxed arithmetic there is an
+        # independent sample, above the contract's RMS at the configurations' sample counts)
+        assert np.array_equal(pf, rf)
+        return
     assert not np.array_equal(pf, rf)  # it is another set of kernels
-    assert rms(pi, ri) <= (8e-3 if name in ("glass", "outdoor") else 2.5e-3), rms(pi, ri)  # glass: caustic fireflies at 64 spp
+    assert rms(pi, ri) <= 2.5e-3, rms(pi, ri)  # 64 spp on a small frame; at the configurations' sizes: test_relaxed_arithmetic_meets_the_contract_*
     assert abs(float(np.clip(pi[..., :3], 0, 1).mean()) - float(np.clip(ri[..., :3], 0, 1).mean())) <= 5e-4
 
 
@@ -886,9 +891,10 @@ def test_relaxed_arithmetic_meets_the_contract_at_config1(engine, oracle):
     assert rms(a, b) <= RMS_TOL, rms(a, b)
 
 
-def _relaxed_against_the_oracle(engine, oracle, w, h, spp, bands, threads=16):
-    """The benched kernels (precise = 0) render the whole frame at its full sample count; the oracle renders the same (pixel,
-    iteration) samples on `bands` of rows; per-pixel RMS over RGB of the resolved, clamped image over the bands."""
+def _relaxed_against_the_oracle(engine, oracle, w, h, spp, bands, threads=16, identical=False):
+    """The benched kernels (option precise = 0) render the whole frame at its full sample count; the oracle renders the same
+    (pixel, iteration) samples on `bands` of rows; per-pixel RMS over RGB of the resolved, clamped image over the bands.
+    identical: the scene runs the precise units whatever the option says (Glass, below), so the film is the oracle's."""
     engine.start_frame(0)
     engine.set_option("precise", 0)
     engine.render_iterations(spp)
@@ -898,23 +904,30 @@ def _relaxed_against_the_oracle(engine, oracle, w, h, spp, bands, threads=16):
     sd = engine.lib.su_ext_scene_desc().contents
     vd = engine.lib.su_ext_view_desc().contents
     gpu = oracle_resolve(oracle, vd, film)
-    a, b, identical = [], [], []
+    a, b, same = [], [], []
     for y0, y1 in bands:
         cpu = oracle_render(oracle, sd, vd, spp, y_range=(y0, y1), threads=threads)
         a.append(gpu[y0:y1])
         b.append(oracle_resolve(oracle, vd, cpu)[y0:y1])
-        identical.append(np.all(film[y0:y1] == cpu[y0:y1], axis=-1).mean())
+        same.append(np.all(film[y0:y1] == cpu[y0:y1], axis=-1).mean())
     r = rms(np.concatenate(a), np.concatenate(b))
-    print(f"relaxed vs oracle: RMS {r:.3e} over {sum(y1 - y0 for y0, y1 in bands)} rows, bit-identical pixels {np.mean(identical):.4f}")
-    assert np.mean(identical) < 1.0  # it is the relaxed set of kernels, not the verification mode
+    print(f"relaxed vs oracle: RMS {r:.3e} over {sum(y1 - y0 for y0, y1 in bands)} rows, bit-identical pixels {np.mean(same):.4f}")
+    if identical:
+        assert np.mean(same) == 1.0
+    else:
+        assert np.mean(same) < 1.0  # it is the relaxed set of kernels, not the verification mode
     return r
 
 
 @pytest.mark.parametrize("config", ["config2_sphere", "config2_mound", "glass", "substitute"])
 def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
-    """The kernels bench.py times (relaxed units: the wave-wide prop-table walk, constant-block triangles, the quantised four-wide
-    BLAS with its LDS stack, the POOL kernels for Glass) against the CPU oracle directly, at 1920x1080 and the configuration's
-    256 spp: RMS <= 1e-3, north_star's number."""
+    """The kernels bench.py times (option precise = 0: the wave-wide prop-table walk, constant-block triangles, the quantised
+    four-wide BLAS with its LDS stack, the persistent mesh kernels) against the CPU oracle directly, at 1920x1080 and the
+    configuration's 256 spp: RMS <= 1e-3, north_star's number.
+    Glass: a path through a dielectric is chaotic, an ulp at one refraction is another path a few bounces on, so relaxed
+    arithmetic there is an independent sample of the same integral: its RMS against the reference is the Monte-Carlo noise
+    (measured against the precise film: 5.4e-3 / 2.7e-3 / 1.3e-3 / 6.9e-4 at 16 / 64 / 256 / 1024 spp, mean difference 1e-6), above
+    the contract at 256 spp.  Scenes with Glass therefore run the precise units whatever the option says: the film is the oracle's."""
     w, h, spp = 1920, 1080, 256
     if config.startswith("config2"):
         scenes.cornell(engine, w, h, spp, integrator="PTMIS", boxes=False, mesh_material=scenes.substitute((0.5, 0.5, 0.5)),
@@ -926,17 +939,18 @@ def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
     else:
         scenes.cornell(engine, w, h, spp, integrator="PTMIS", material="substitute")
         bands = ((536, 544),)
-    r = _relaxed_against_the_oracle(engine, oracle, w, h, spp, bands)
+    r = _relaxed_against_the_oracle(engine, oracle, w, h, spp, bands, identical="glass" == config)
     assert r <= RMS_TOL, r
 
 
 def test_relaxed_arithmetic_meets_the_contract_at_config4(engine, oracle):
-    """BASELINE.json configs[4]'s ingredients at 3840x2160, depth 16, in the relaxed units against the oracle: 128 iterations of
-    the whole frame (1.06e9 camera samples), two bands of rows (sky + sun side, ground + objects): RMS <= 1e-3."""
+    """BASELINE.json configs[4]'s ingredients at 3840x2160, depth 16, with option precise = 0 against the oracle: 128 iterations of
+    the whole frame (1.06e9 camera samples), three bands of rows (sky + sun side, ground + objects).  The scene holds Glass, so
+    it runs the precise units (see above): RMS 0."""
     w, h, spp = 3840, 2160, 128
     scenes.outdoor(engine, w, h, spp, integrator="PTMIS", material="substitute", sky="canopy", sky_map=scenes.sky_image(1024, 1024),
                    sky_spectrum=(1.0, 1.0, 1.0), showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16)
-    r = _relaxed_against_the_oracle(engine, oracle, w, h, spp, ((300, 302), (1500, 1502), (1700, 1702)))
+    r = _relaxed_against_the_oracle(engine, oracle, w, h, spp, ((300, 302), (1500, 1502), (1700, 1702)), identical=True)
     assert r <= RMS_TOL, r
 
 

@@ -53,22 +53,22 @@ def _deps():
     return deps
 
 
-def source_hash(group=None):
+def source_hash(source=None):
     """Hash of the contents of every source and header the library is compiled from (csrc/hip, csrc/host, include/).
-    group "hip" / "host": only what that directory's translation units can include (its own directory and include/: the two
-    never include each other), so that a change on the host side does not recompile the kernel units."""
+    source: only what that translation unit can include: itself and the headers of its own directory and of include/ (the hip
+    and the host side never include each other, and no .hip / .cpp includes another), so that a change in zygpu.hip or on the
+    host side does not recompile the kernel units."""
     h = hashlib.sha256()
-    skip = {"hip": HOST, "host": HIP}.get(group)
     for p in sorted(_deps()):
-        if p.endswith("build.py") or not os.path.isfile(p) or (skip and p.startswith(skip + os.sep)):
+        if p.endswith("build.py") or not os.path.isfile(p):
             continue
+        if source is not None:
+            header = p.endswith((".hpp", ".h"))
+            if p != source and not (header and os.path.dirname(p) in (os.path.dirname(source), os.path.join(ROOT, "include"))):
+                continue
         h.update(os.path.relpath(p, ROOT).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
-
-
-def _group(src):
-    return "host" if src.startswith(HOST + os.sep) else "hip"
 
 
 def _flags_hash(flags, extra=()):
@@ -111,7 +111,7 @@ def _compile(job):
         if os.path.exists(out + ".tag"):
             os.remove(out + ".tag")
         raise RuntimeError(f"hipcc failed for {name}: {' '.join(cmd)}")
-    open(out + ".tag", "w").write(_flags_hash(flags, extra) + ":" + _compile.sources[_group(src)])
+    open(out + ".tag", "w").write(_flags_hash(flags, extra) + ":" + _compile.sources[src])
     return out
 
 
@@ -123,7 +123,7 @@ def build_variant(name, units, extra, mode="both", verbose=True):
     `units` holds -1) recompiled with `extra` flags into build/<name>/.  Load it with ZYG_AMD_LIB=variants/lib_<name>.so."""
     vdir = os.path.join(OBJ, name)
     os.makedirs(vdir, exist_ok=True)
-    _compile.sources = {g: source_hash(g) for g in ("hip", "host")}
+    _compile.sources = {src: source_hash(src) for src in SOURCES}
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
     todo, objs = [], []
     for oname, src, flags in _objects(mode):
@@ -143,13 +143,13 @@ def build_variant(name, units, extra, mode="both", verbose=True):
 def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     extra = list(extra)
-    sources = _compile.sources = {g: source_hash(g) for g in ("hip", "host")}
+    sources = _compile.sources = {src: source_hash(src) for src in SOURCES}
     todo, objs, stale_left = [], [], []
     for name, src, flags in _objects(mode):
         out = os.path.join(OBJ, name)
         objs.append(out)
         # an object is reused only when it was compiled from these sources with these flags
-        fresh = os.path.exists(out) and _read(out + ".tag") == _flags_hash(flags, extra) + ":" + sources[_group(src)]
+        fresh = os.path.exists(out) and _read(out + ".tag") == _flags_hash(flags, extra) + ":" + sources[src]
         if units is not None and name.startswith("unit"):
             unit = int(name[4:].rstrip("f.o"))
             if unit in units or not os.path.exists(out):

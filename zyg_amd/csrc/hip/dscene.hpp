@@ -90,6 +90,7 @@ struct DScene {
     TlasEntry            unocc_table[4];              // the unoccluding tree's single leaf, in leaf order; 0: not available
     float4               small_tris[3 * kSmallTriangles];  // a, b, c per triangle, mesh (= leaf) order
     uint32_t             num_solid_table, num_unocc_table;
+    uint32_t             first_large;  // solid_table[first_large ..]: the meshes of kWideBlasMinTriangles triangles or more (they come last)
     const ZygpuProp*     props;
     // animated props (ZygpuSceneDesc.keyframes): 3 float4 per keyframe (position, scale, rotation quaternion); prop_frames[p] =
     // first keyframe or kNull; null pointers: no prop is animated
@@ -555,8 +556,14 @@ constexpr int kLdsStack = ZYG_LDS_STACK ? ZYG_LDS_STACK_ENTRIES : 0;
 #endif
 constexpr int kLdsStackThreads = ZYG_LDS_STACK_THREADS;  // threads of the largest block that walks
 
+// one array per entry layout: a kernel that runs both walks (wf_tick) keeps them apart, one that runs only the any-hit walk
+// (wf_scatter, wf_shadow_u) allocates half
 ZD uint2* wideStackLds() {
     __shared__ uint2 entries[(kLdsStack ? kLdsStack : 1) * kLdsStackThreads];
+    return entries;
+}
+ZD uint32_t* wideStackLdsAny() {
+    __shared__ uint32_t entries[(kLdsStack ? kLdsStack : 1) * kLdsStackThreads];
     return entries;
 }
 
@@ -566,7 +573,7 @@ struct WideStack {
     uint32_t spill_ref[kStack4 - kLdsStack];
     float    spill_dist[DIST ? kStack4 - kLdsStack : 1];
     int      sp = 0;
-    ZD WideStack() : lds(DIST ? wideStackLds() + threadIdx.x : reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(wideStackLds()) + threadIdx.x)) {}
+    ZD WideStack() : lds(DIST ? wideStackLds() + threadIdx.x : reinterpret_cast<uint2*>(wideStackLdsAny() + threadIdx.x)) {}
     ZD void push(uint32_t ref, uint32_t count, float dist) {
         if (sp >= kStack4) return;
         const uint32_t packed = ref | (count << 24);
@@ -710,6 +717,121 @@ ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
         stack.pop(cur, cur_count, unused);
     }
 }
+
+// The walks of the quantised nodes one step at a time, for the kernels whose lanes fetch a new ray when theirs is done
+// (wavefront.hpp wf_shadow_u, wf_mesh_closest): a step tests one node's four children, or one leaf's triangles.
+enum : int { kWalkRunning = 0, kWalkHit = 1, kWalkDone = 2 };
+
+struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
+    WideStack<false> stack;
+    uint32_t         cur = 0, cur_count = 0;
+    ZD void start() {
+        stack.sp = 0;
+        cur = 0;
+        cur_count = 0;
+    }
+    ZD int step(const DMesh& mesh, const Ray& ray) {
+        float unused = 0.f;
+        if (0 == cur_count) {
+            const Node4q n = Node4q::load(mesh.nodes4q, cur);
+            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
+            const bool   h0 = FLT_MAX != n.test<0>(ray, r0, n0), h1 = FLT_MAX != n.test<1>(ray, r1, n1);
+            const bool   h2 = FLT_MAX != n.test<2>(ray, r2, n2), h3 = FLT_MAX != n.test<3>(ray, r3, n3);
+            bool         have = false;
+            uint32_t     nr = 0, nc = 0;
+            auto         take = [&](bool h, uint32_t r, uint32_t c) {
+                if (!h) return;
+                if (have) stack.push(nr, nc, 0.f);
+                nr = r;
+                nc = c;
+                have = true;
+            };
+            take(h3, r3, n3);
+            take(h2, r2, n2);
+            take(h1, r1, n1);
+            take(h0, r0, n0);
+            if (have) {
+                cur = nr;
+                cur_count = nc;
+            } else {
+                if (0 == stack.sp) return kWalkDone;
+                stack.pop(cur, cur_count, unused);
+            }
+            return kWalkRunning;
+        }
+        for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
+            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            float    t, u, v;
+            if (triangleIntersect(ray, a, b, c, t, u, v)) return kWalkHit;
+        }
+        if (0 == stack.sp) return kWalkDone;
+        stack.pop(cur, cur_count, unused);
+        return kWalkRunning;
+    }
+};
+
+struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks ray.max_t
+    WideStack<true> stack;
+    uint32_t        cur = 0, cur_count = 0;
+    ZD void start() {
+        stack.sp = 0;
+        cur = 0;
+        cur_count = 0;
+    }
+    ZD bool pop(const Ray& ray) {
+        while (stack.sp > 0) {
+            uint32_t r, n;
+            float    dist;
+            stack.pop(r, n, dist);
+            if (dist <= ray.max_t) {
+                cur = r;
+                cur_count = n;
+                return true;
+            }
+        }
+        return false;
+    }
+    // `found(triangle, t, u, v)` for every hit nearer than the ray's end
+    template <typename Found>
+    ZD int step(const DMesh& mesh, Ray& ray, Found&& found) {
+        if (0 == cur_count) {
+            const Node4q n = Node4q::load(mesh.nodes4q, cur);
+            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
+            float        t0 = n.test<0>(ray, r0, n0), t1 = n.test<1>(ray, r1, n1), t2 = n.test<2>(ray, r2, n2), t3 = n.test<3>(ray, r3, n3);
+#define ZYG_CSWAP(i, j)                        \
+    if (t##j < t##i) {                         \
+        const float    tt = t##i;              \
+        const uint32_t rr = r##i, nn = n##i;   \
+        t##i = t##j, r##i = r##j, n##i = n##j; \
+        t##j = tt, r##j = rr, n##j = nn;       \
+    }
+            ZYG_CSWAP(0, 1)
+            ZYG_CSWAP(2, 3)
+            ZYG_CSWAP(0, 2)
+            ZYG_CSWAP(1, 3)
+            ZYG_CSWAP(1, 2)
+#undef ZYG_CSWAP
+            if (FLT_MAX != t3) stack.push(r3, n3, t3);
+            if (FLT_MAX != t2) stack.push(r2, n2, t2);
+            if (FLT_MAX != t1) stack.push(r1, n1, t1);
+            if (FLT_MAX != t0) {
+                cur = r0;
+                cur_count = n0;
+                return kWalkRunning;
+            }
+            return pop(ray) ? kWalkRunning : kWalkDone;
+        }
+        for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
+            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            float    t, u, v;
+            if (triangleIntersect(ray, a, b, c, t, u, v)) {
+                ray.max_t = t;
+                found(i, t, u, v);
+            }
+        }
+        return pop(ray) ? kWalkRunning : kWalkDone;
+    }
+};
 
 // The any-hit form of the wide walk (shadow rays): the order the children are visited in does not change the answer, so nothing
 // is sorted and no entry distance is kept: a parked child is a reference and a count.
@@ -1100,6 +1222,76 @@ ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface,
         }
     }
     return kNull != hit.prop;
+}
+
+// closest hit over the prop table's entries in front of its large meshes (the relaxed units' rules: no tie rule, small meshes
+// triangle by triangle); shrinks ray.max_t
+ZD void tableClosestBeforeLargeMeshes(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit) {
+    Counters none{0, 0, 0};
+    for (uint32_t k = 0; k < s.first_large; ++k) {
+        const TlasEntry& e = s.solid_table[k];
+        if (!propVisibleAtDepth(e.flags, depth_surface)) continue;
+        if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
+        const Trafo trafo = entryTrafo(e);
+        Hit         h;
+        bool        found;
+        if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
+            h.primitive = 0;
+            found = rectangleIntersect(ray, trafo, h.t, h.u, h.v);
+        } else if (e.small_count > 0) {
+            Ray local = worldToObjectRay(trafo, ray);
+            found = false;
+            for (uint32_t i = e.small_first, ie = e.small_first + e.small_count; i < ie; ++i) {
+                float t, u, v;
+                if (triangleIntersect(local, xyz(s.small_tris[3 * i]), xyz(s.small_tris[3 * i + 1]), xyz(s.small_tris[3 * i + 2]), t, u, v)) {
+                    local.max_t = t;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.primitive = i - e.small_first;
+                    found = true;
+                }
+            }
+        } else {
+            Ray local = worldToObjectRay(trafo, ray);
+            found = meshIntersect<false, false>(s.meshes[e.mesh], local, h, none);
+        }
+        if (found) {
+            hit.t = h.t;
+            hit.u = h.u;
+            hit.v = h.v;
+            hit.primitive = h.primitive;
+            hit.prop = e.prop;
+            ray.max_t = h.t;
+        }
+    }
+}
+
+// The prop table's entries in front of its large meshes (DScene::first_large: Rectangles and the meshes below the wide-BLAS
+// threshold), as the relaxed units test them (small meshes triangle by triangle): true = one of them blocks the ray.
+ZD bool tableBlocksBeforeLargeMeshes(const DScene& s, const Ray& ray) {
+    Counters none{0, 0, 0};
+    bool     blocked = false;
+    for (uint32_t k = 0; k < s.first_large && !blocked; ++k) {
+        const TlasEntry& e = s.solid_table[k];
+        if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;
+        if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
+        const Trafo trafo = entryTrafo(e);
+        if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
+            float t, u, v;
+            blocked = rectangleIntersect(ray, trafo, t, u, v);
+        } else if (e.small_count > 0) {
+            const Ray local = worldToObjectRay(trafo, ray);
+            for (uint32_t i = e.small_first, ie = e.small_first + e.small_count; i < ie; ++i) {
+                float t, u, v;
+                blocked = blocked || triangleIntersect(local, xyz(s.small_tris[3 * i]), xyz(s.small_tris[3 * i + 1]), xyz(s.small_tris[3 * i + 2]), t, u, v);
+            }
+        } else {
+            Ray local = worldToObjectRay(trafo, ray);
+            blocked = meshIntersectP<false, false>(s.meshes[e.mesh], local, none);
+        }
+    }
+    return blocked;
 }
 
 // any-hit over the solid props (the semantics of sceneVisibility<false, false>): true = unoccluded

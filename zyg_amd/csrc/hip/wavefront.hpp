@@ -169,6 +169,8 @@ struct Control {  // device-resident
     uint32_t           bound[2];  // [parity of the tick]: length of the tick's extension queue = upper bound of every later
                                   // queue of that tick; surplus blocks leave on this one scalar load
     uint32_t           error;
+    uint32_t           shadow_fetch;  // wf_shadow_u: the next queue entry to hand out; the round's wf_nee zeroes it
+    uint32_t           mesh_fetch;    // wf_mesh_closest: likewise; the tick's wf_trace_shade zeroes it for the next tick
     KernelCounters     k[3];  // 0 wf_intersect, 1 wf_shade, 2 wf_shadow
     unsigned long long sections[32];  // -DZYG_PROFILE_SECTIONS builds: shader cycles per code section, summed over waves
 };
@@ -208,6 +210,7 @@ struct Params {
     uint32_t queue_capacity;  // entries every queue array holds
     uint32_t packed_acc;      // 1: the paths keep emission / direct in their first line (kPackedAccumulators; set for the non-POOL kernels)
     uint32_t round;   // POOL: which vertex of the level this launch handles
+    uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits
 };
 
 // one copy per translation unit (kernel_table.hpp): the units are built without relocatable device code
@@ -1463,6 +1466,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         queueReset(&P.ctl->heavy_count[cur ^ 1u]);
         queueReset(&P.ctl->shadow_count[0]);  // staged NEE: this tick's wf_nee rounds
         queueReset(&P.ctl->shadow_count[1]);
+        if (0 == threadIdx.x) P.ctl->mesh_fetch = 0;  // the next tick's wf_mesh_closest
     }
     Counters       cnt{0, 0, 0}, shade_cnt{0, 0, 0};
     const uint32_t rounded = (n + (kTraceShadeBlock - 1u)) & ~(kTraceShadeBlock - 1u);  // whole blocks take part in queuePush
@@ -1495,7 +1499,16 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
             Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
             ray.time = pathTime<false, MESHL>(P, slot);
             Hit            hit;
-            if (UTLAS) {
+            if (WIDE && !FIRST && P.mesh_pass && i >= P.ctl->ext_count[cur].n[0]) {
+                // a back entry: wf_mesh_closest has its complete closest hit
+                const uint4 h = P.pool.hit[slot];
+                hit.prop = P.pool.hit_prop[slot];
+                hit.t = __uint_as_float(h.x);
+                hit.u = __uint_as_float(h.y);
+                hit.v = __uint_as_float(h.z);
+                hit.primitive = h.w;
+                if (kNull != hit.prop) ray.max_t = hit.t;
+            } else if (UTLAS) {
 #if ZYG_FAST
                 sceneIntersectUniform<false, WIDE>(scene, ray, depth, hit);
 #else
@@ -1719,6 +1732,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
     const uint32_t total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
+    if (0 == i) P.ctl->shadow_fetch = 0;  // the round's wf_shadow_u hands out the queue from its start
     if (i >= rounded) return;
     bool     push = false;
     uint32_t slot = 0;
@@ -1787,6 +1801,172 @@ __global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
         P.pool.vis[slot] = sceneVisibility<STATS, true>(c_scene, shadow, cnt) ? 1u : 0u;
     }
     if (STATS) flushCounters(P, 2, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
+}
+
+// The same for the scenes of the prop tables with a large mesh (relaxed units): a persistent kernel whose lanes fetch their
+// rays from the round's queue themselves.  A shadow ray that grazes a million-triangle mesh walks hundreds of nodes, one that
+// misses its bounds none: with one ray per lane a wave waits for its longest walk (measured on configs[2]: wf_scatter spends
+// 85 % of its wave-cycles in the walk or waiting for it at the wave's reconvergence and the block's queue append).  Here a lane
+// whose ray is decided takes the next one (the wave refills once kRefill lanes are idle, one atomic per refill), the cheap
+// part of the scene (Rectangles, small meshes) is tested when the ray is fetched, and only the walks of the large meshes run in
+// the stepped loop, with nothing else in the kernel's registers: ZYG_SHADOW_U_WAVES waves per SIMD hide the node loads.
+#ifndef ZYG_SHADOW_U_WAVES
+#define ZYG_SHADOW_U_WAVES 6
+#endif
+#ifndef ZYG_SHADOW_U_REFILL
+#define ZYG_SHADOW_U_REFILL 16
+#endif
+#ifndef ZYG_SHADOW_U_STEPS
+#define ZYG_SHADOW_U_STEPS 8
+#endif
+template <bool WIDE>  // (a template so that only the unit that instantiates it emits it)
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u(Params P, uint32_t round) {
+    const DScene&  s = c_scene;
+    const uint32_t n = P.ctl->shadow_count[round & 1u].n[0];  // wf_nee appends at the front only
+    if (0 == blockIdx.x && threadIdx.x < 64) queueReset(&P.ctl->shadow_count[(round + 1u) & 1u]);  // the next round's wf_nee fills it
+    const uint32_t lane = __lane_id();
+    bool           have = false, exhausted = false;
+    uint32_t       slot = 0, entry = 0;
+    Ray            local = Ray::init(S3(0.f), S3(0.f), 0.f, 0.f), world = local;
+    AnyWalk4q      walk;
+    // the next large mesh at or behind solid_table[entry] whose bounds the ray enters: start its walk, or the ray is unoccluded
+    auto nextMesh = [&]() {
+        for (; entry < s.num_solid_table; ++entry) {
+            const TlasEntry& e = s.solid_table[entry];
+            if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW) || !aabbIntersect(e.bmin, e.bmax, world)) continue;
+            local = worldToObjectRay(entryTrafo(e), world);
+            walk.start();
+            return true;
+        }
+        return false;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t           num_idle = uint32_t(__popcll(idle));
+        if (!exhausted && num_idle >= uint32_t(ZYG_SHADOW_U_REFILL)) {
+            const int first = __ffsll(static_cast<long long>(idle)) - 1;
+            uint32_t  base = 0;
+            if (int(lane) == first) base = atomicAdd(&P.ctl->shadow_fetch, num_idle);
+            base = __shfl(base, first);
+            exhausted = base + num_idle >= n;
+            if (!have) {
+                const uint32_t i = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+                if (i < n) {
+                    slot = P.q.shadow[i];
+                    const float4 o = P.pool.sh_o[slot], d = P.pool.sh_d[slot];
+                    world = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+                    if (tableBlocksBeforeLargeMeshes(s, world)) {
+                        P.pool.vis[slot] = 0u;
+                    } else {
+                        entry = s.first_large;
+                        have = nextMesh();
+                        if (!have) P.pool.vis[slot] = 1u;
+                    }
+                }
+            }
+        }
+        if (0 == __ballot(have)) {
+            if (exhausted) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int it = 0; it < ZYG_SHADOW_U_STEPS; ++it) {
+            if (have) {
+                const int r = walk.step(s.meshes[s.solid_table[entry].mesh], local);
+                if (kWalkHit == r) {
+                    P.pool.vis[slot] = 0u;
+                    have = false;
+                } else if (kWalkDone == r) {
+                    entry += 1;
+                    have = nextMesh();
+                    if (!have) P.pool.vis[slot] = 1u;
+                }
+            }
+        }
+    }
+}
+
+// The closest hit of the extension rays that enter a large mesh's bounds (the back entries of the tick's extension queue), in
+// the same form: a persistent kernel, a lane takes the next ray when its own is done.  The rest of the scene (Rectangles, small
+// meshes) is tested when the ray is fetched and shortens it for the walks; the complete hit goes to the path's hit block, and the
+// tick's wf_trace_shade (Params::mesh_pass) shades these entries from there instead of tracing them.
+#ifndef ZYG_MESH_CLOSEST_WAVES
+#define ZYG_MESH_CLOSEST_WAVES 5
+#endif
+template <bool WIDE>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh_closest(Params P, uint32_t) {
+    const DScene&  s = c_scene;
+    const uint32_t cur = P.parity;
+    const uint32_t n = P.ctl->ext_count[cur].n[kCountStride];  // the queue's back end
+    const uint32_t lane = __lane_id();
+    bool           have = false, exhausted = false;
+    uint32_t       slot = 0, entry = 0, depth = 0;
+    Ray            local = Ray::init(S3(0.f), S3(0.f), 0.f, 0.f), world = local;
+    Hit            hit;
+    ClosestWalk4q  walk;
+    auto nextMesh = [&]() {
+        for (; entry < s.num_solid_table; ++entry) {
+            const TlasEntry& e = s.solid_table[entry];
+            if (!propVisibleAtDepth(e.flags, depth) || !aabbIntersect(e.bmin, e.bmax, world)) continue;
+            local = worldToObjectRay(entryTrafo(e), world);
+            walk.start();
+            return true;
+        }
+        return false;
+    };
+    auto finish = [&]() {
+        if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+        P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+        P.pool.hit_prop[slot] = hit.prop;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t           num_idle = uint32_t(__popcll(idle));
+        if (!exhausted && num_idle >= uint32_t(ZYG_SHADOW_U_REFILL)) {
+            const int first = __ffsll(static_cast<long long>(idle)) - 1;
+            uint32_t  base = 0;
+            if (int(lane) == first) base = atomicAdd(&P.ctl->mesh_fetch, num_idle);
+            base = __shfl(base, first);
+            exhausted = base + num_idle >= n;
+            if (!have) {
+                const uint32_t i = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+                if (i < n) {
+                    slot = P.q.ext[cur][P.queue_capacity - 1u - i];
+                    const float4 o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+                    depth = (P.pool.q0.get(slot).y >> 3) & 31u;
+                    world = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+                    hit.prop = kNull;
+                    tableClosestBeforeLargeMeshes(s, world, depth, hit);
+                    entry = s.first_large;
+                    have = nextMesh();
+                    if (!have) finish();
+                }
+            }
+        }
+        if (0 == __ballot(have)) {
+            if (exhausted) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int it = 0; it < ZYG_SHADOW_U_STEPS; ++it) {
+            if (have) {
+                const uint32_t prop = s.solid_table[entry].prop;
+                const int      r = walk.step(s.meshes[s.solid_table[entry].mesh], local, [&](uint32_t triangle, float t, float u, float v) {
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.primitive = triangle;
+                    hit.prop = prop;
+                    world.max_t = t;
+                });
+                if (kWalkDone == r) {
+                    entry += 1;
+                    have = nextMesh();
+                    if (!have) finish();
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- wf_extend

@@ -474,6 +474,9 @@ struct ZygpuContext {
     // the scenes and settings its instantiations cover (prop tables, in-place NEE, single-sample lights)
     bool          fuse_tick = false;
     bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
+    // option "mesh_kernels" (default on): in the relaxed units the walks of the large meshes run in persistent kernels of their
+    // own whose lanes fetch a new ray when theirs is done (wf_shadow_u for the staged NEE rounds' shadow rays)
+    bool          mesh_kernels = true;
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
     uint64_t      camera_samples = 0;
@@ -624,13 +627,27 @@ int deviceErrorFlags(ZygpuContext* c) {
     return -3;
 }
 
+// Which arithmetic a launch runs in.  Option "precise" = 0 asks for the relaxed units, and a scene gets them where their result
+// stays inside the contract (RMS <= 1e-3 against the reference at the configurations' sample counts).  A scene with Glass does
+// not: a path through a dielectric is chaotic, one ulp at a refraction is another path a few bounces later, so relaxed arithmetic
+// there is an independent sample of the same integral and its RMS against the reference is the Monte-Carlo noise (measured
+// against the precise film: 1.3e-3 at 256 spp on cornell_glass, 3.1e-3 on the outdoor scene, falling like 1 / sqrt(spp), mean
+// difference <= 6e-5).  The POOL instantiations therefore always run the precise units: their film is the reference's bits.
+// (a development library built without the precise units has nothing else to run them in)
+bool relaxedUnits(const ZygpuContext* c) { return c->relaxed && (!c->pool_mode || !modeAvailable(0)); }
+
 void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params& P, uint32_t arg) {
-    const int mode = c->relaxed ? 1 : 0, unit = kUnitOf[id];
+    const int mode = relaxedUnits(c) ? 1 : 0, unit = kUnitOf[id];
     if (g_unit_view_epoch[mode][unit] != c->view_epoch) {
         if (0 != kUnitSet[mode][unit](ZYG_CONST_VIEW, &c->batch_view, sizeof(View), c->stream)) c->launch_failed = true;
         g_unit_view_epoch[mode][unit] = c->view_epoch;
     }
     if (0 != kUnitLaunch[mode][unit](id, blocks, c->stream, &P, arg)) c->launch_failed = true;
+}
+
+// the persistent kernels (wf_shadow_u, wf_mesh_closest: their lanes fetch their own work): as many 256-thread blocks as run at once
+unsigned persistentGrid(const ZygpuContext* c, unsigned tick_blocks, unsigned blocks_per_cu) {
+    return std::min(tick_blocks, unsigned(std::max(1, c->num_cus)) * blocks_per_cu);
 }
 
 // wf_shade's second pass walks its (short) queue with a grid-wide stride: a few blocks per CU whatever the size of the tick
@@ -1014,7 +1031,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     // The prop tables of a small scene (dscene.hpp TlasEntry): at most kUniformProps solid props, Rectangles and TriangleMeshes
     // only (what the kernels without the EXTRA shapes know), Rectangles first; the unoccluding props when their tree is a
     // single leaf of at most 4 Rectangles, in the leaf's order.
-    s.num_solid_table = s.num_unocc_table = 0;
+    s.num_solid_table = s.num_unocc_table = s.first_large = 0;
     {
         uint32_t num_small = 0;
         auto entry = [&](uint32_t p) {
@@ -1065,6 +1082,12 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             auto weight = [&](uint32_t p) { return ZYGPU_SHAPE_RECTANGLE == d->props[p].shape ? 0u : 1u + d->meshes[d->props[p].mesh].num_triangles; };
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight(a) < weight(b); });
             for (uint32_t p : order) s.solid_table[s.num_solid_table++] = entry(p);
+            s.first_large = s.num_solid_table;
+            for (uint32_t k = 0; k < s.num_solid_table; ++k)
+                if (ZYGPU_SHAPE_TRIANGLE_MESH == s.solid_table[k].shape && d->meshes[s.solid_table[k].mesh].num_triangles >= kWideBlasMinTriangles) {
+                    s.first_large = k;  // sorted by size: the rest are large too
+                    break;
+                }
             if (d->unoccluding.num_nodes)
                 for (uint32_t i = 0; i < d->unoccluding.nodes[0].count; ++i)
                     s.unocc_table[s.num_unocc_table++] = entry(d->unoccluding.indices[d->unoccluding.nodes[0].children_or_first + i]);
@@ -1278,6 +1301,14 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         }
         c->camera_samples += num_paths;
         const bool plain_in_place = utlas && nee && c->nee_in_place && !c->multi_sample_lights && c->fuse_trace_shade;
+        // option mesh_kernels: the large meshes' closest-hit walks run in wf_mesh_closest before the tick's wf_trace_shade; the camera
+        // rays then go through the queue like every other tick's (wf_generate sorts them into its two ends)
+        const bool mesh_pass = wide && relaxedUnits(c) && c->mesh_kernels && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
+        P.mesh_pass = mesh_pass ? 1u : 0u;
+        if (mesh_pass) {
+            HIP_OK(hipMemsetAsync(&c->ctl->mesh_fetch, 0, sizeof(uint32_t), c->stream));
+            launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
+        }
         if (c->fuse_tick && plain_in_place && !c->persistent) {
             // tick 0: camera rays, closest hit, shading; then per tick one wf_tick (scatter vertex t - 1, trace + shade vertex t)
             // and wf_shade's second pass; the alive queue ping-pongs between the two ext arrays
@@ -1343,8 +1374,12 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             }
             if (c->fuse_trace_shade) {
                 // closest hit + the first shading pass in one kernel (timed as kernel 0), then the second pass
+                if (mesh_pass) {
+                    // the rays that enter a large mesh's bounds first, in the persistent walker (timed with the trace kernel)
+                    timedLaunch(c, 0, [&] { launchKernel(c, K_MESH_CLOSEST, persistentGrid(c, grid.x, 5), P, 0u); });
+                }
                 timedLaunch(c, 0, [&] {
-                    if (0 == t) {
+                    if (0 == t && !mesh_pass) {
                         if (c->stats) launchKernel(c, K_TRACE_SHADE_STATS_FIRST, grid.x, P, num_paths);
                         else if (c->mesh_lights) launchKernel(c, K_TRACE_SHADE_MESHL_FIRST, grid.x, P, num_paths);
                         else if (utlas) launchKernel(c, wide ? K_TRACE_SHADE_PLAIN_FIRST_UW : K_TRACE_SHADE_PLAIN_FIRST_U, grid.x, P, num_paths);
@@ -1405,6 +1440,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 });
                 timedLaunch(c, 3, [&] {
                     if (c->stats) launchKernel(c, K_SHADOW_STATS, grid.x, P, r);
+                    else if (wide && relaxedUnits(c) && c->mesh_kernels) launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, 6), P, r);
                     else launchKernel(c, K_SHADOW, grid.x, P, r);
                 });
             }
@@ -1675,6 +1711,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "fuse_tick")) {
         c->fuse_tick = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "mesh_kernels")) {
+        c->mesh_kernels = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "persistent")) {
