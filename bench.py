@@ -61,6 +61,7 @@ def parse_args():
                     help="zygpu option persistent: one persistent kernel per batch, path state in LDS (wf_persistent)")
     ap.add_argument("--mesh-kernels", type=int, default=1, choices=[0, 1],
                     help="zygpu option mesh_kernels: the large meshes' walks in persistent kernels whose lanes fetch their own rays")
+    ap.add_argument("--mesh-closest", type=int, default=0, choices=[0, 1], help="zygpu option mesh_closest (wf_mesh_closest)")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed oracle sample (and again of the parity band)")
@@ -116,6 +117,7 @@ class Measurement:
         self.eng.set_option("persistent", args.persistent)
         self.eng.set_option("fuse_tick", args.fuse_tick)
         self.eng.set_option("mesh_kernels", args.mesh_kernels)
+        self.eng.set_option("mesh_closest", args.mesh_closest)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)
         self.fused = bool(args.fuse) and scene in ("cornell", "cornell_mesh", "cornell_mound")  # POOL scenes always run the kernels apart
         self.film = torch.zeros((self.h, self.w, 4), dtype=torch.float32, device=device)
@@ -191,7 +193,17 @@ class Measurement:
         ms, launches = dtmp(), ltmp()
         lib.zygpu_kernel_time(ctx, ms, launches, 0)
         samples_rank = float(self.w) * self.h * self.ips * self.steps
-        kernels = [(nm, ms[i], int(launches[i]), kb[nm], sb[nm]) for i, nm in enumerate(KERNELS)]
+        times = {nm: ms[i] for i, nm in enumerate(KERNELS)}
+        counts = {nm: int(launches[i]) for i, nm in enumerate(KERNELS)}
+        # option mesh_kernels on a scene with a large mesh: the in-place stage is wf_scatter_h (+ its resume launches, timed as
+        # wf_scatter) and wf_shadow_u, which walks the meshes for the suspended shadow rays (timed as wf_shadow): one stage, one
+        # share of the algorithmic bytes; a tick's launches are counted as one
+        self.mesh_stage = "in-place" == self.args.nee and times["wf_shadow"] > 0.0
+        if self.mesh_stage:
+            times["wf_scatter"] += times["wf_shadow"]
+            counts["wf_scatter"] = counts["wf_intersect"] if self.fused else counts["wf_scatter"]
+            times["wf_shadow"], counts["wf_shadow"] = 0.0, 0
+        kernels = [(nm, times[nm], counts[nm], kb[nm], sb[nm]) for nm in KERNELS]
         dom = max(kernels, key=lambda t: t[1])
         avg_ms = dom[1] / max(dom[2], 1)
         per_launch = samples_rank / max(dom[2], 1)
@@ -199,7 +211,7 @@ class Measurement:
         per_kernel = {}
         for nm, t_ms, ln, bytes_ps, state_ps in kernels:
             if ln and t_ms > 0:
-                shown = "wf_trace_shade" if (self.fused and "wf_intersect" == nm) else nm
+                shown = "wf_trace_shade" if (self.fused and "wf_intersect" == nm) else "wf_scatter_h+wf_shadow_u" if (self.mesh_stage and "wf_scatter" == nm) else nm
                 per_kernel[shown] = {"ms": round(t_ms, 3), "launches": ln, "avg_launch_ms": round(t_ms / ln, 5),
                                      "frac": round(bytes_ps * samples_rank / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                      "state_frac": round(state_ps * samples_rank / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -215,6 +227,7 @@ class Measurement:
             "bytes_per_sample": st.algorithmic_bytes(0) / n_stat,
             "state_bytes_per_sample": (B_FILM * st.camera_samples + B_Q * st.extension_rays + B_SQ * st.shadow_rays) / n_stat,
             "kernel_ms": {nm: round(ms[i], 3) for i, nm in enumerate(KERNELS)},
+            "mesh_stage": self.mesh_stage,
             "kernel_bytes": {nm: round(v, 1) for nm, v in kb.items()},
         }
 
@@ -540,7 +553,8 @@ def main():
                      "state_frac": round(r2["state_bytes_per_launch"] / (r2["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if r2["avg_ms"] else None,
                      "avg_launch_ms": round(r2["avg_ms"], 5), "algorithmic_bytes_per_sample": round(r2["bytes_per_sample"], 1),
                      "state_bytes_per_sample": round(r2["state_bytes_per_sample"], 1), "kernel_ms": r2["kernel_ms"],
-                     "per_kernel": r2["per_kernel"], "rays_per_sample": r2["rays_per_sample"]}
+                     "per_kernel": r2["per_kernel"], "rays_per_sample": r2["rays_per_sample"],
+                     "mesh_stage": "wf_scatter = wf_scatter_h + wf_shadow_u" if r2["mesh_stage"] else None}
             if oracle is not None:
                 film = np.zeros((m2.h, m2.w, 4), dtype=np.float32)
                 y_mid = m2.h // 2 // 32 * 32

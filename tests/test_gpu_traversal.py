@@ -183,3 +183,29 @@ def test_fused_tick_gives_the_same_film(product_lib, material):
     assert np.array_equal(r1, _film(product_lib, build, w, h, spp, precise=0, fuse_tick=1))
     close = np.isclose(r0, r1, rtol=1e-3, atol=1e-4).all(axis=-1)
     assert close.mean() > 0.98, close.mean()
+
+
+@pytest.mark.parametrize("scene", ["sphere_lambert", "sphere_substitute", "mound", "four_lights"])
+def test_mesh_kernels_give_the_film_of_the_in_place_kernel(product_lib, scene):
+    """Option mesh_kernels (default on; relaxed units, scenes of the prop tables with a mesh above the wide-BLAS threshold):
+    wf_scatter_h suspends the vertices whose shadow ray has to walk the large mesh, wf_shadow_u (persistent, its lanes fetch their
+    own rays) walks it, the resume launches take the vertices up again; wf_mesh_closest (option mesh_closest) does the same for the
+    closest hits.  The same samples as wf_scatter's with the walk in place: the same film up to the contractions of another kernel
+    family, deterministic, and with four lights (up to four suspensions per vertex) too."""
+    w, h, spp = 480, 270, 4
+    mesh = scenes.heightfield_mesh(n=96) if "mound" == scene else scenes.displaced_sphere_mesh(n=96)
+    kw = dict(boxes=False, mesh=mesh, material="substitute" if "substitute" in scene else "lambert")
+    if "mound" != scene:
+        kw["mesh_position"] = scenes.MESH_CENTRE
+    if "four_lights" == scene:
+        kw["many_lights"] = 2
+    build = lambda e: scenes.cornell(e, w, h, spp, **kw)
+    base = _film(product_lib, build, w, h, spp, precise=0, mesh_kernels=0)
+    assert np.isfinite(base).all() and base[..., :3].max() > 0
+    for options in ({"mesh_kernels": 1}, {"mesh_kernels": 1, "mesh_closest": 1}):
+        film = _film(product_lib, build, w, h, spp, precise=0, **options)
+        assert np.isfinite(film).all() and np.array_equal(base[..., 3], film[..., 3])
+        assert np.array_equal(film, _film(product_lib, build, w, h, spp, precise=0, **options))
+        close = np.isclose(base, film, rtol=1e-3, atol=1e-4).all(axis=-1)
+        assert close.mean() > 0.98, (options, close.mean())
+        assert abs(float(film[..., :3].mean()) - float(base[..., :3].mean())) <= 2e-4 * float(base[..., :3].mean())

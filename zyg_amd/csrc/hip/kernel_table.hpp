@@ -10,7 +10,7 @@
 // Template parameters (wavefront.hpp):
 //   wf_generate<POOL>   wf_intersect<STATS, POOL, EXTRA>   wf_shade<STATS, MESHL, HEAVY, POOL>
 //   wf_trace_shade<STATS, MESHL, FIRST, UTLAS>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS>
-//   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_shadow_u (persistent: launched with persistentGrid blocks)   wf_extend<SUBST, EXTRA>   wf_persistent<SUBST, MULTI, WIDE>   wf_tick<SUBST, MULTI, WIDE>
+//   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_shadow_u / wf_mesh_closest (persistent: launched with persistentGrid blocks)   wf_scatter_h<RESUME, SUBST>   wf_extend<SUBST, EXTRA>   wf_persistent<SUBST, MULTI, WIDE>   wf_tick<SUBST, MULTI, WIDE>
 #pragma once
 
 #define ZYG_NUM_UNITS 8
@@ -86,6 +86,10 @@
     X(7, K_SHADOW_STATS,         (wf_shadow<true>),                                   (P, arg)) \
     X(7, K_SHADOW,               (wf_shadow<false>),                                  (P, arg)) \
     X(7, K_SHADOW_U,             ZYG_WIDE((wf_shadow_u<true>), (wf_shadow<false>)),         (P, arg)) \
+    X(7, K_SCATTER_H,            ZYG_WIDE((wf_scatter_h<false, false>), (wf_shadow<false>)), (P, arg)) \
+    X(7, K_SCATTER_H_SUBST,      ZYG_WIDE((wf_scatter_h<false, true>), (wf_shadow<false>)),  (P, arg)) \
+    X(7, K_SCATTER_H_RESUME,     ZYG_WIDE((wf_scatter_h<true, false>), (wf_shadow<false>)),  (P, arg)) \
+    X(7, K_SCATTER_H_RESUME_SUBST, ZYG_WIDE((wf_scatter_h<true, true>), (wf_shadow<false>)), (P, arg)) \
     X(7, K_MESH_CLOSEST,         ZYG_WIDE((wf_mesh_closest<true>), (wf_shadow<false>)),     (P, arg)) \
     X(7, K_EXTEND_EXTRA,         (wf_extend<true, true>),                             (P))  \
     X(7, K_EXTEND_SUBST,         (wf_extend<true, false>),                            (P))  \

@@ -1732,7 +1732,6 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P,
     const uint32_t total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
-    if (0 == i) P.ctl->shadow_fetch = 0;  // the round's wf_shadow_u hands out the queue from its start
     if (i >= rounded) return;
     bool     push = false;
     uint32_t slot = 0;
@@ -1803,13 +1802,12 @@ __global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
     if (STATS) flushCounters(P, 2, cnt, (0 == blockIdx.x && 0 == threadIdx.x) ? n : 0);
 }
 
-// The same for the scenes of the prop tables with a large mesh (relaxed units): a persistent kernel whose lanes fetch their
-// rays from the round's queue themselves.  A shadow ray that grazes a million-triangle mesh walks hundreds of nodes, one that
-// misses its bounds none: with one ray per lane a wave waits for its longest walk (measured on configs[2]: wf_scatter spends
-// 85 % of its wave-cycles in the walk or waiting for it at the wave's reconvergence and the block's queue append).  Here a lane
-// whose ray is decided takes the next one (the wave refills once kRefill lanes are idle, one atomic per refill), the cheap
-// part of the scene (Rectangles, small meshes) is tested when the ray is fetched, and only the walks of the large meshes run in
-// the stepped loop, with nothing else in the kernel's registers: ZYG_SHADOW_U_WAVES waves per SIMD hide the node loads.
+// The large meshes' any-hit walks for the shadow rays wf_scatter_h suspended (scenes of the prop tables with a large mesh,
+// relaxed units): a persistent kernel whose lanes fetch their rays from the round's queue themselves.  A shadow ray that grazes a
+// million-triangle mesh walks hundreds of nodes, one that is blocked right away a few: with one ray per lane a wave waits for
+// its longest walk (measured on configs[2]: wf_scatter spent 85 % of its wave-cycles in the walk or waiting for it at the wave's
+// reconvergence and at the block's queue append).  Here a lane whose ray is decided takes the next one (the wave refills once
+// ZYG_SHADOW_U_REFILL lanes are idle, one atomic per refill), and nothing but the walk is in the kernel's registers.
 #ifndef ZYG_SHADOW_U_WAVES
 #define ZYG_SHADOW_U_WAVES 6
 #endif
@@ -1822,8 +1820,9 @@ __global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
 template <bool WIDE>  // (a template so that only the unit that instantiates it emits it)
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u(Params P, uint32_t round) {
     const DScene&  s = c_scene;
-    const uint32_t n = P.ctl->shadow_count[round & 1u].n[0];  // wf_nee appends at the front only
-    if (0 == blockIdx.x && threadIdx.x < 64) queueReset(&P.ctl->shadow_count[(round + 1u) & 1u]);  // the next round's wf_nee fills it
+    const uint32_t  n = P.ctl->shadow_count[round & 1u].n[0];  // wf_scatter_h appends at the front only
+    const uint32_t* queue = (round & 1u) ? P.q.heavy : P.q.shadow;
+    if (0 == blockIdx.x && threadIdx.x < 64) queueReset(&P.ctl->shadow_count[(round + 1u) & 1u]);  // the next round's wf_scatter_h fills it
     const uint32_t lane = __lane_id();
     bool           have = false, exhausted = false;
     uint32_t       slot = 0, entry = 0;
@@ -1852,16 +1851,12 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u
             if (!have) {
                 const uint32_t i = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
                 if (i < n) {
-                    slot = P.q.shadow[i];
+                    slot = queue[i];
                     const float4 o = P.pool.sh_o[slot], d = P.pool.sh_d[slot];
                     world = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
-                    if (tableBlocksBeforeLargeMeshes(s, world)) {
-                        P.pool.vis[slot] = 0u;
-                    } else {
-                        entry = s.first_large;
-                        have = nextMesh();
-                        if (!have) P.pool.vis[slot] = 1u;
-                    }
+                    entry = s.first_large;
+                    have = nextMesh();
+                    if (!have) P.pool.vis[slot] = 1u;
                 }
             }
         }
@@ -1969,6 +1964,48 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh
     }
 }
 
+// The bxdf sample and the path extension of a vertex whose light samples are done (pathtracer_mis.zig:123-166): the tail of
+// wf_extend and of wf_scatter_h.  `push`: the path goes on (its slot belongs into the next tick's extension queue, at the back
+// if the new ray enters a large mesh's bounds).
+template <bool SUBST, bool EXTRA>
+ZD void extendVertex(const Params& P, const DScene& s, uint32_t slot, PathHead& h, const Surface& sf, f3 throughput, bool& push, bool& back) {
+    const MaterialSample& ms = sf.ms;
+    const bool            mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
+    BxdfSample            bs;
+    if (!ms.template sample<SUBST, EXTRA>(s, h.smp, bs)) {
+        finalize(P, slot, S3(0.f), h.flags, h.smp.rng);
+        return;
+    }
+    // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
+    if (kScatterSpecular == bs.scattering) {
+        h.flags |= ST_SPECULAR;
+        h.flags = (0.f == bs.reg_alpha) ? (h.flags | ST_SINGULAR) : (h.flags & ~uint32_t(ST_SINGULAR));
+        if (h.flags & ST_PRIMARY) h.flags |= ST_STARTED_SPECULAR;
+    } else {
+        h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
+    }
+    float bxdf_pdf = P.pool.ray_d.get(slot).w;
+    if (mis) {
+        h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
+        h.vdepth = h.depth_surface;
+        bxdf_pdf = bs.pdf;
+        P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
+    }
+    throughput = throughput * (bs.reflection / S3(bs.pdf));
+    const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
+    h.depth_surface += 1;
+    h.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight): a reflection clears it
+    h.smp.incrementPadding();
+
+    P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
+    P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
+    back = entersMeshBounds(new_origin, bs.wi);
+    P.pool.thr[slot] = f4(throughput);
+    P.pool.vorigin[slot] = f4(sf.p);
+    storeHead(P, slot, h);
+    push = true;
+}
+
 // ---------------------------------------------------------------- wf_extend
 // the last pick's tail, the NEE sum into the IValue, then the bxdf sample and the path extension (pathtracer_mis.zig:123-166)
 // EXTRA: the scene runs the MESHL instantiations (PathTracer has no light sampling, so it ends its ticks here whatever the scene)
@@ -1980,7 +2017,6 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
     const uint32_t total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
-    const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     const uint32_t rounded = (total + 255u) & ~255u;
     if (i >= rounded) return;
     bool     push = false, back = false;
@@ -1989,49 +2025,142 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
         slot = P.alive_in[at];
         PathHead h;
         loadHead(P, slot, h);
-        const Surface         sf = loadSurface<false, EXTRA>(P, slot, h.flags);
-        const MaterialSample& ms = sf.ms;
-        f3                    throughput = xyz4(P.pool.thr[slot]);
+        const Surface sf = loadSurface<false, EXTRA>(P, slot, h.flags);
+        f3            throughput = xyz4(P.pool.thr[slot]);
         if (EXTRA && c_view.v.aov_slots) commonAov(P, slot, slot, h, sf, throughput);
 
         if (h.nee & kNeePending) finishLightPick(P, slot, h);
         if (h.nee & kNeeCountMask) ivalueAdd<true>(P, slot, throughput * xyz4(P.pool.nee[slot]), h.depth_surface, 1u, false, false);
         h.nee = 0;
 
-        BxdfSample bs;
-        if (!ms.template sample<SUBST, EXTRA>(s, h.smp, bs)) {
-            finalize(P, slot, S3(0.f), h.flags, h.smp.rng);
-        } else {
-            // Vertex.State.update (vertex.zig:30-43); every sample in scope is a reflection (never .Straight)
-            if (kScatterSpecular == bs.scattering) {
-                h.flags |= ST_SPECULAR;
-                h.flags = (0.f == bs.reg_alpha) ? (h.flags | ST_SINGULAR) : (h.flags & ~uint32_t(ST_SINGULAR));
-                if (h.flags & ST_PRIMARY) h.flags |= ST_STARTED_SPECULAR;
-            } else {
-                h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
-            }
-            float bxdf_pdf = P.pool.ray_d.get(slot).w;
-            if (mis) {
-                h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
-                h.vdepth = h.depth_surface;
-                bxdf_pdf = bs.pdf;
-                P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
-            }
-            throughput = throughput * (bs.reflection / S3(bs.pdf));
-            const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
-            h.depth_surface += 1;
-            h.flags &= ~uint32_t(ST_TRANSPARENT);  // transparent && (Transmission || Straight): a reflection clears it
-            h.smp.incrementPadding();
+        extendVertex<SUBST, EXTRA>(P, s, slot, h, sf, throughput, push, back);
+    }
+    queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
+}
 
-            P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
-            P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
-            back = entersMeshBounds(new_origin, bs.wi);
-            P.pool.thr[slot] = f4(throughput);
-            P.pool.vorigin[slot] = f4(sf.p);
+// ---------------------------------------------------------------- wf_scatter_h
+// wf_scatter for the scenes of the prop tables with a large mesh (relaxed units; option "mesh_kernels"): the light samples of a
+// vertex are taken in place as wf_scatter takes them, but a shadow ray is traced in place only through the cheap part of the
+// scene (the table's Rectangles and small meshes).  If none of them blocks it and it enters a large mesh's bounds, the vertex
+// is suspended: the ray, the pick's pre-weighted contribution (neither depends on the visibility), the sampler and the sum so
+// far go to the pool, the slot into the round's suspended queue, and wf_shadow_u walks the meshes for all suspended rays with its
+// lanes kept busy.  The next launch (RESUME) takes up the suspended vertices only: it finishes the pending pick with the answer
+// (the draw that follows an unoccluded sample, light.zig:127), goes on with the vertex' remaining picks (which may suspend it
+// again) and then, like wf_scatter, samples the bxdf and extends the path.  A vertex whose shadow rays never enter a large mesh's
+// bounds is done in the first launch: configs[2] with the mesh on the floor (few such rays) keeps wf_scatter's speed, with the
+// mesh in the middle of the box the divergent walks leave the kernel whose lanes would wait for them (measured: DESIGN 4).
+// Rectangle lights with one sample per pick (as the wf_nee rounds).  The suspended queues ping-pong between q.shadow and
+// q.heavy (wf_shade's second pass is done with it by now); their lengths are Control::shadow_count[round & 1].
+constexpr uint32_t kNeeNextShift = 8u;  // PathHead::nee [8:14]: the pick a suspended vertex goes on with
+
+template <bool SUBST>
+ZD bool entersLargeMeshBounds(const DScene& s, const Ray& ray) {
+    bool enters = false;
+    for (uint32_t k = s.first_large; k < s.num_solid_table; ++k) {
+        const TlasEntry& e = s.solid_table[k];
+        enters = enters || (0 != (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW) && aabbIntersect(e.bmin, e.bmax, ray));
+    }
+    return enters;
+}
+
+template <bool RESUME, bool SUBST>
+__global__ void __launch_bounds__(256) ZYG_WAVES(SUBST ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter_h(Params P, uint32_t round) {
+    const DScene&  s = c_scene;
+    const uint32_t nxt = P.parity ^ 1u;
+    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at = i;
+    // RESUME: the vertices the previous round suspended (its queue's front), else the tick's alive queue
+    const uint32_t  total = RESUME ? P.ctl->shadow_count[(round + 1u) & 1u].n[0] : queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
+    const uint32_t* in = RESUME ? (((round + 1u) & 1u) ? P.q.heavy : P.q.shadow) : P.alive_in;
+    uint32_t*       suspended_queue = (round & 1u) ? P.q.heavy : P.q.shadow;
+    const bool      mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
+    if (0 == i) P.ctl->shadow_fetch = 0;  // the round's wf_shadow_u hands out its queue from the start
+    const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in the queue appends
+    if (i >= rounded) return;
+    bool     push = false, back = false, suspend = false;
+    uint32_t slot = 0;
+    if (i < total) {
+        slot = in[at];
+        PathHead h;
+        loadHead(P, slot, h);
+        const Surface         sf = loadSurface(P, slot, h.flags);
+        const MaterialSample& ms = sf.ms;
+        const f3              throughput = xyz4(P.pool.thr[slot]);
+        const uint32_t        stride = batchPaths();
+        f3                    nee = S3(0.f);
+        uint32_t              count = 0, pk = 0;
+        LightPick             first{0, 0.f};
+        if (RESUME) {
+            count = h.nee & kNeeCountMask;
+            pk = (h.nee >> kNeeNextShift) & kNeeCountMask;
+            nee = xyz4(P.pool.nee[slot]);
+            if (0 != P.pool.vis[slot]) {
+                (void)h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
+                nee = nee + xyz4(P.pool.contrib[slot]);
+            }
+        } else if (ZYGPU_INTEGRATOR_PT != c_view.v.integrator && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
+            const float     nee_threshold = splitThreshold(h.depth_surface);
+            const float     select = h.smp.sample1D();
+            const LightTree lt{s, s.light_tree};
+            NoTimer         tm;
+            count = lt.randomLight(tm, sf.p, ms.geo_n, ms.translucent, select, nee_threshold, [&](uint32_t k, LightPick pick) {
+                if (0 == k) first = pick;
+                else P.pool.picks[size_t(k) * stride + slot] = make_uint2(pick.offset, __float_as_uint(pick.pdf));
+            });
+        }
+        for (; pk < count; ++pk) {
+            LightPick pick = first;
+            if (RESUME || pk > 0) {
+                const uint2 stored = P.pool.picks[size_t(pk) * stride + slot];
+                pick = LightPick{stored.x, __uint_as_float(stored.y)};
+            }
+            // evaluateLight up to the shadow test (startLightPick, with the ray and the contribution still in registers)
+            const ZygpuLight     light = s.lights[pick.offset];
+            const Trafo          trafo = loadTrafo(s, light.prop);
+            const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
+            SampleTo             ls;
+            if (!rectangleSampleTo(sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, h.smp, ls)) continue;
+            const f3 sorigin = surfaceOffsetP(sf.p, sf.frag_geo_n, ls.wi);
+            f3       sdir;
+            float    slen;
+            shadowRay(sorigin, ls, sdir, slen);
+            const Ray shadow = Ray::init(sorigin, sdir, 0.f, slen);
+            if (tableBlocksBeforeLargeMeshes(s, shadow)) continue;  // occluded: no contribution, no draw
+            const f3         radiance = materialRadiance(s, lm, ls.wi, trafo, light.prop, light.part, false);
+            const BxdfResult bx = ms.template evaluate<SUBST>(s, ls.wi);
+            f3               contrib;
+            if (mis) {
+                const float light_pdf = ls.pdf * pick.pdf;
+                const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
+                contrib = S3(weight) * radiance * bx.reflection;
+            } else {
+                const float weight = 1.f / (pick.pdf * ls.pdf);
+                contrib = S3(weight) * (S3(1.f) * radiance * bx.reflection);
+            }
+            if (!entersLargeMeshBounds<SUBST>(s, shadow)) {  // unoccluded
+                (void)h.smp.sample1D();
+                nee = nee + contrib;
+                continue;
+            }
+            P.pool.sh_o[slot] = f4(sorigin, slen);
+            P.pool.sh_d[slot] = f4(sdir);
+            P.pool.contrib[slot] = f4(contrib);
+            suspend = true;
+            break;
+        }
+        if (suspend) {
+            h.nee = (count & kNeeCountMask) | kNeePending | ((pk + 1u) << kNeeNextShift);
+            P.pool.nee[slot] = f4(nee);
             storeHead(P, slot, h);
-            push = true;
+        } else {
+            if (count > 0) ivalueAdd<true>(P, slot, throughput * nee, h.depth_surface, 1u, false, false);
+            h.nee = 0;
+            extendVertex<SUBST, false>(P, s, slot, h, sf, throughput, push, back);
         }
     }
+    queuePush(suspended_queue, &P.ctl->shadow_count[round & 1u], P.queue_capacity, suspend, slot);
+    __syncthreads();  // queuePush's shared words are reused
     queuePush(P.q.ext[nxt], &P.ctl->ext_count[nxt], P.queue_capacity, push, slot, back);
 }
 

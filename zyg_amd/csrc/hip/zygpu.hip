@@ -475,8 +475,12 @@ struct ZygpuContext {
     bool          fuse_tick = false;
     bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
     // option "mesh_kernels" (default on): in the relaxed units the walks of the large meshes run in persistent kernels of their
-    // own whose lanes fetch a new ray when theirs is done (wf_shadow_u for the staged NEE rounds' shadow rays)
+    // own whose lanes fetch a new ray when theirs is done: wf_scatter_h suspends the vertices whose shadow ray enters a large mesh's
+    // bounds, wf_shadow_u walks the meshes for them
     bool          mesh_kernels = true;
+    // option "mesh_closest" (default off: measured -8 % on configs[2] with the mesh on the floor, +0 ... +10 % with it in the middle
+    // of the box): the closest-hit walks of the rays that enter a large mesh's bounds in a persistent kernel too (wf_mesh_closest)
+    bool          mesh_closest = false;
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
     uint64_t      camera_samples = 0;
@@ -1303,7 +1307,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         const bool plain_in_place = utlas && nee && c->nee_in_place && !c->multi_sample_lights && c->fuse_trace_shade;
         // option mesh_kernels: the large meshes' closest-hit walks run in wf_mesh_closest before the tick's wf_trace_shade; the camera
         // rays then go through the queue like every other tick's (wf_generate sorts them into its two ends)
-        const bool mesh_pass = wide && relaxedUnits(c) && c->mesh_kernels && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
+        const bool mesh_pass = wide && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
         P.mesh_pass = mesh_pass ? 1u : 0u;
         if (mesh_pass) {
             HIP_OK(hipMemsetAsync(&c->ctl->mesh_fetch, 0, sizeof(uint32_t), c->stream));
@@ -1418,7 +1422,15 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 }
             });
             }
-            if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
+            if (nee && c->nee_in_place && wide && relaxedUnits(c) && c->mesh_kernels && !c->multi_sample_lights) {
+                // wf_scatter_h: in place, but a vertex whose shadow ray has to walk a large mesh is suspended; wf_shadow_u walks
+                // the meshes for the round's suspended rays, the next launch takes the suspended vertices up again
+                timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_SUBST : K_SCATTER_H, grid.x, P, 0u); });
+                for (uint32_t r = 1; r <= rounds; ++r) {
+                    timedLaunch(c, 3, [&] { launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, 6), P, r - 1u); });
+                    timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_RESUME_SUBST : K_SCATTER_H_RESUME, grid.x, P, r); });
+                }
+            } else if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
                     if (c->stats) launchKernel(c, K_SCATTER_STATS, grid.x, P, 0u);
                     else if (c->masks) launchKernel(c, K_SCATTER_MASKS, grid.x, P, 0u);
@@ -1440,7 +1452,6 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 });
                 timedLaunch(c, 3, [&] {
                     if (c->stats) launchKernel(c, K_SHADOW_STATS, grid.x, P, r);
-                    else if (wide && relaxedUnits(c) && c->mesh_kernels) launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, 6), P, r);
                     else launchKernel(c, K_SHADOW, grid.x, P, r);
                 });
             }
@@ -1715,6 +1726,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "mesh_kernels")) {
         c->mesh_kernels = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "mesh_closest")) {
+        c->mesh_closest = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "persistent")) {
