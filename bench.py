@@ -76,8 +76,8 @@ def build_scene(eng, scenes, name, material, w, h, total_spp):
     mesh_position = scenes.MESH_CENTRE if name == "cornell_mesh" else (0, 0.02, 0.1)
     mesh_material = scenes.substitute((0.5, 0.5, 0.5)) if mesh is not None else None
     if name == "outdoor":
-        scenes.outdoor(eng, w, h, total_spp, integrator="PTMIS", material="substitute", sky="canopy", sky_map=scenes.sky_image(1024, 1024),
-                       sky_spectrum=(1.0, 1.0, 1.0), showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16)
+        scenes.outdoor(eng, w, h, total_spp, integrator="PTMIS", material="substitute", showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16,
+                       sky_entity={"parameters": {"sun": {"rotation": [-55, 20, 0]}}})
     else:
         glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if name == "cornell_glass" else None
         scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=material, boxes=mesh is None, mesh=mesh,
@@ -87,8 +87,8 @@ def build_scene(eng, scenes, name, material, w, h, total_spp):
 def describe(name, material, w, h, ips, k, precise):
     mode = "precise arithmetic (film bit-identical to the CPU oracle)" if precise else "relaxed arithmetic (RMS <= 1e-3 contract)"
     if name == "outdoor":
-        return (f"outdoor scene (ground, 2 boxes (one glass), glass + gold Spheres, 999698-triangle mesh in polished iron, 1024^2 "
-                f"canopy image light + Distant sun), {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
+        return (f"outdoor scene (ground, 2 boxes (one glass), glass + gold Spheres, 999698-triangle mesh in polished iron, the Sky "
+                f"entity: sun with its radiance table + 1024^2 canopy image, both the procedural stand-in for the Prague bake), {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
                 f"{k * ips} spp per GPU, {mode}")
     geometry = {"cornell": "2 boxes", "cornell_mesh": "999698-triangle closed displaced sphere (Substitute) centred at 60 % of the box's height",
                 "cornell_mound": "999698-triangle heightfield mesh (Substitute) on the floor",

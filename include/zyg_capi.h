@@ -98,6 +98,16 @@ uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity);
  * post-processor and exporters of cli/take_loader.zig:27-283, materials / entities / shapes of util/scene_loader.zig:115-702,
  * JSON and "SUB\0" binary meshes of shape_provider.zig:334-805.  0, or -1 with the reason in the log.  Host-only. */
 int32_t su_ext_load_take(const char* take_filename);
+/* The Sky entity of the reference's scene loader (util/scene_loader.zig:262-263, 704-712 -> Scene.createSky; the reference's C
+ * ABI has no entry for it): creates the sun (a Distant light) and the sky (a Canopy light) once, applies `parameters_json`
+ * (Sky.setParameters, sky.zig:78-93: {"sun": {"rotation": [x, y, z]}, "turbidity" | "visibility", "albedo"}; NULL: the
+ * defaults) and returns the sun's prop id, or -1.  Scene.compile places both from the sun's rotation (sky.zig:95-134). */
+int32_t su_ext_sky_create(const char* parameters_json);
+/* The products of the sky bake (sky.zig:172-269; what the reference keeps in its cache files, sky.zig:138-168): the sun's
+ * radiance over its disc, 1024 rgb samples (Sky.BakeDimensionsSun), and the canopy image, sky_width x sky_height rgb floats
+ * (1024 x 1024 in the reference).  Without this call compile fills in a procedural stand-in and says so in the log: the Prague
+ * model's dataset does not ship with the reference. */
+int32_t su_ext_sky_tables(const float* sun_rgb, const float* sky_rgb, uint32_t sky_width, uint32_t sky_height);
 uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,
                              uint8_t* out, uint64_t capacity);
 

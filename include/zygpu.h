@@ -361,6 +361,15 @@ typedef struct ZygpuSceneDesc {
     uint32_t             num_keyframes;
     uint32_t             num_interpolation_frames;
     float                origin[4];
+    /* The Sky entity's sun (sky/sky.zig:36-76, sky_material.zig:40-168): a Distant light whose material is of kind ZYGPU_MAT_SKY
+     * with no emission map.  Its radiance varies over the sun's disc: Material.evaluateRadiance = sun_radiance.eval(sunV(
+     * trafo.rotation, wi)), an InterpolatedFunction1D over [0, 1] (interpolated_function.zig:11-47) of num_sun_radiance samples
+     * (Sky.BakeDimensionsSun = 1024), 4 floats each (rgb, 0): the baked table of sky.zig:214-221 (or what stands in for it).
+     * ZygpuMaterial.emission of that material is the table's average_emission (sky_material.zig:66-87), which the light's
+     * power is computed from.  The sky itself is a Canopy with an ordinary emission map (the baked 1024^2 image).
+     * NULL / 0: the scene has no Sky. */
+    const float*         sun_radiance;
+    uint32_t             num_sun_radiance;
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };

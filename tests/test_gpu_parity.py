@@ -19,6 +19,8 @@ RMS_TOL = 1e-3
 
 # BASELINE.json configs[2]'s mesh: SURVEY 8(d)'s closed displaced sphere at 60 % of the box's height, and the lighter heightfield
 # on the floor (round 1-2's stand-in) as the second variant
+# BASELINE.json configs[4]'s sky: the reference's Sky entity (sun at 55 degrees of elevation), its bake replaced by the stand-in
+_CONFIG4_SKY = {"parameters": {"sun": {"rotation": [-55, 20, 0]}}}
 _CONFIG2 = {"sphere": lambda n=708: {"mesh": scenes.displaced_sphere_mesh(n=n), "mesh_position": scenes.MESH_CENTRE},
             "mound": lambda n=708: {"mesh": scenes.heightfield_mesh(n=n)}}
 
@@ -641,11 +643,12 @@ def test_config2_million_triangles_at_1080p(engine, oracle, shape):
 
 def test_config4_outdoor_at_4k_depth_16(engine, oracle):
     """BASELINE.json configs[4]'s ingredients at its full size: 3840x2160, depth 16, glass + conductors + the 1 M-triangle mesh,
-    image-lit canopy + Distant sun (the Prague sky bake's dataset is absent: SURVEY 8(d) allows the stand-in), rendered as the
+    the Sky entity (sun table + 1024^2 canopy image; the Prague model's dataset is absent, so the bake's two products are the
+    engine's procedural stand-in: SURVEY 8(d) allows it), rendered as the
     last two of the configuration's 512 iterations (sample indices up to 8 294 400 * 512 = 4.25e9, just below 2^32)."""
     w, h, spp = 3840, 2160, 1
-    scenes.outdoor(engine, w, h, 512, integrator="PTMIS", material="substitute", sky="canopy", sky_map=scenes.sky_image(1024, 1024),
-                   sky_spectrum=(1.0, 1.0, 1.0), showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16)
+    scenes.outdoor(engine, w, h, 512, integrator="PTMIS", material="substitute", sky_entity=_CONFIG4_SKY, showcase=True,
+                   mesh=scenes.heightfield_mesh(), max_depth=16)
     engine.start_frame(0)
     ctx = engine.context()
     first = 510
@@ -790,6 +793,24 @@ def test_more_unoccluding_emitters_than_candidate_slots(engine, oracle, integrat
     _check(*out, 3)
     film = out[0]
     assert film[36, 48, :3].sum() > 6 * 1.2  # the middle of the frame looks through all six
+
+
+@pytest.mark.parametrize("integrator", ["PT", "PTDL", "PTMIS"])
+@pytest.mark.parametrize("variant", ["tables", "stand_in_glass"])
+def test_sky_entity(engine, oracle, integrator, variant):
+    """The Sky entity (sky.zig, sky_material.zig:150-168): the sun is a Distant light whose radiance is read from a table over its
+    disc (sunV from the light's rotation and the direction), both when a light sample picks it and when a ray leaves the scene
+    through its disc; the sky is a Canopy image light sampled by its map's plain luminance.  tables: a client-provided bake
+    (su_ext_sky_tables); stand_in_glass: the engine's procedural tables, with the glass and metal of configs[4] (POOL kernels)."""
+    sky = {"parameters": {"sun": {"rotation": [-35, 160, 0]}}}
+    if "tables" == variant:
+        sky["tables"] = scenes.sky_tables(elevation_deg=35.0)
+    out = _render_both(engine, oracle, 96, 54, 4, scene=scenes.outdoor, integrator=integrator, material="substitute",
+                       showcase="tables" != variant, sky_entity=sky, max_depth=6)
+    _check(*out, 4)
+    film = out[0]
+    assert film[4:12, :, 2].mean() > film[4:12, :, 0].mean() > 0.0  # a blue sky above
+    assert film[-8:, :, :3].mean() > 0.02  # a lit ground
 
 
 # ---------------------------------------------------------------- the relaxed-arithmetic units (zygpu option "precise" = 0)
@@ -948,8 +969,8 @@ def test_relaxed_arithmetic_meets_the_contract_at_config4(engine, oracle):
     the whole frame (1.06e9 camera samples), three bands of rows (sky + sun side, ground + objects).  The scene holds Glass, so
     it runs the precise units (see above): RMS 0."""
     w, h, spp = 3840, 2160, 128
-    scenes.outdoor(engine, w, h, spp, integrator="PTMIS", material="substitute", sky="canopy", sky_map=scenes.sky_image(1024, 1024),
-                   sky_spectrum=(1.0, 1.0, 1.0), showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16)
+    scenes.outdoor(engine, w, h, spp, integrator="PTMIS", material="substitute", sky_entity=_CONFIG4_SKY, showcase=True,
+                   mesh=scenes.heightfield_mesh(), max_depth=16)
     r = _relaxed_against_the_oracle(engine, oracle, w, h, spp, ((300, 302), (1500, 1502), (1700, 1702)), identical=True)
     assert r <= RMS_TOL, r
 

@@ -483,3 +483,79 @@ def test_material_update_runs_the_kinds_parser(product_lib):
         assert lib.su_material_update(m, b'{"two_sided": false}') == 0
         e.compile(0)
         assert not (e.lib.su_ext_scene_desc().contents.materials[m].flags & 1)
+
+
+def test_sky_entity_compile_products(engine, oracle):
+    """The Sky entity (sky/sky.zig, sky_material.zig; su_ext_sky_create): a Distant sun whose material reads its radiance from a
+    table over the sun's disc, a Canopy with the baked image as its emission map.  Scene.compile places both from the sun's rotation
+    (sky.zig:95-134); SkyMaterial.setSunRadiance's mean (sky_material.zig:66-87) is the sun's emission; the canopy's sampling
+    distribution is the map's luminance without the Light material's MIS compensation (sky_material.zig:89-133, 170-215)."""
+    sun_table, sky_image = scenes.sky_tables(size=32)
+    ids = scenes.outdoor(engine, 32, 18, 1, material="substitute", sky_entity={"parameters": {"sun": {"rotation": [-55, 20, 0]}},
+                                                                                "tables": (sun_table, sky_image)})
+    sd, _ = engine.compile()
+    sun = ids["sun"]
+    canopy = [p for p in range(sd.num_props) if sd.props[p].shape == scenes.CANOPY][0]
+    assert sd.props[sun].shape == scenes.DISTANT and sd.num_infinite_props == 2 and sd.num_lights == 2
+    # json.createRotationMatrix: Rz * Rx * Ry of the angles in degrees; its third row is the direction the sun shines in
+    a, b = np.radians(-55.0), np.radians(20.0)
+    rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    rot = rx @ ry
+    t = sd.trafos[sun]
+    np.testing.assert_allclose([list(t.r[k])[:3] for k in range(3)], rot, atol=2e-6)
+    radius = np.tan(np.radians(0.2667))  # Sky.Radius (sky.zig:46)
+    assert abs(t.r[0][3] - radius) < 1e-9 and abs(t.r[1][3] - radius) < 1e-9
+    # the canopy: X(90 degrees) * Y(azimuth), azimuth = -atan2(sun.x, sun.z): its z axis points up
+    tc = sd.trafos[canopy]
+    np.testing.assert_allclose(list(tc.r[2])[:3], [0, 1, 0], atol=2e-6)
+    # the sun's table and its weighted mean over the part of the disc above the horizon
+    assert sd.num_sun_radiance == 1024
+    table = np.ctypeslib.as_array(sd.sun_radiance, shape=(1024, 4))
+    assert np.array_equal(table[:, :3], sun_table) and not table[:, 3].any()
+    elevation = -np.arcsin(rot[2, 1])
+    v = (np.arange(1023) + 0.5) / 1024.0
+    wz = np.sin(elevation + (2 * v - 1) * radius)
+    wgt = np.sin(v)
+    mean = ((sun_table[:-1].astype(np.float64) + sun_table[1:]) * (0.5 * wgt * (wz >= 0))[:, None]).sum(0) / wgt.sum()
+    mat = sd.materials[sd.material_ids[sd.props[sun].parts_start]]
+    assert mat.kind == 4 and (mat.flags & 8)  # ZYGPU_MAT_SKY, emissive
+    np.testing.assert_allclose(list(mat.emission), mean, rtol=2e-5)
+    # the canopy's distribution: rows of hmax3(uv_weight * texel), no compensation
+    il = sd.image_lights[0]
+    n = 32
+    g = (np.arange(n) + 0.5) / n * 2 - 1
+    inside = (g[None, :] ** 2 + g[:, None] ** 2) <= 1.0
+    lum = sky_image.max(axis=2) * inside
+    rows = np.ctypeslib.as_array(il.rows, shape=(n + 1, 4))
+    cdf = np.ctypeslib.as_array(il.cdf, shape=(il.num_cdf,))
+    for y in (3, 11, 16):
+        assert rows[y, 1] == n + 1
+        expect = np.concatenate([[0.0], np.cumsum(lum[y] / lum[y].sum())])
+        np.testing.assert_allclose(cdf[rows[y, 0]:rows[y, 0] + n + 1], expect, atol=3e-6)
+    # and the oracle renders it: the sky is seen, the sun lights the ground
+    from util import oracle_render, oracle_resolve
+    img = oracle_resolve(oracle, engine.lib.su_ext_view_desc().contents, oracle_render(oracle, sd, engine.lib.su_ext_view_desc().contents, 4, threads=4))
+    assert np.isfinite(img).all() and img[2, :, 2].mean() > 0.3 and img[-2, :, :3].mean() > 0.05
+
+
+def test_sky_entity_without_tables_gets_the_stand_in_and_says_so(product_lib):
+    messages = []
+    callback = zyg_amd.LOG_CALLBACK(lambda level, text: messages.append((level, text.decode())))
+    with zyg_amd.Engine(product_lib) as e:
+        e.lib.su_register_log.argtypes = [zyg_amd.LOG_CALLBACK]
+        e.lib.su_register_log(callback)
+        try:
+            scenes.outdoor(e, 16, 9, 1, sky_entity={"parameters": {"sun": {"rotation": [-30, 0, 0]}}})
+            sd, _ = e.compile()
+            assert sd.num_sun_radiance == 1024 and sd.images[sd.num_images - 1].width == 1024
+            table = np.ctypeslib.as_array(sd.sun_radiance, shape=(1024, 4))
+            assert table[:, :3].min() >= 0 and table[512, 0] > 1e3
+        finally:
+            e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
+    assert any("stand-in" in text for _, text in messages), messages
+    # under the horizon: the sun's radius is zero (sky.zig:102-105)
+    with zyg_amd.Engine(product_lib) as e:
+        ids = scenes.outdoor(e, 16, 9, 1, sky_entity={"parameters": {"sun": {"rotation": [20, 0, 0]}}})
+        sd, _ = e.compile()
+        assert sd.trafos[ids["sun"]].r[0][3] == 0.0

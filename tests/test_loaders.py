@@ -124,7 +124,6 @@ def test_missing_files_fail_loudly(product_lib, tmp_path):
 
 
 _REFUSED = {
-    "Sky": {"type": "Sky", "parameters": {"sun": {"rotation": [45, 0, 0]}}},
     "Portal": {"type": "Portal", "shape": {"type": "Rectangle"}, "light": 0},
     "Instancer": {"type": "Instancer", "prototypes": [], "instances": {"prototypes": [], "transformations": []}},
     "Scatterer": {"type": "Scatterer", "prototypes": []},
@@ -158,6 +157,28 @@ def test_unrendered_entities_and_keys_fail_the_load(product_lib, tmp_path, what)
         finally:
             e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
     assert any(level == 2 and what in text and "does not render" in text for level, text in messages), messages
+
+
+def test_sky_entity_loads(product_lib, tmp_path):
+    """{"type": "Sky", "parameters": {...}} (scene_loader.zig:262-263, 704-712): the sun and the sky as two lights, placed by
+    Scene.compile from the sun's rotation; the entity's visibility is the sun's, and the sky follows it (sky.zig:100)."""
+    scene = {"materials": [{"name": "grey", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5]}}}],
+             "entities": [{"type": "Sky", "parameters": {"sun": {"rotation": [-40, 30, 0]}, "turbidity": 3.0}, "visibility": {"in_camera": False}},
+                          {"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["grey"], "transformation": {"rotation": [90, 0, 0], "scale": [8, 8, 1]}}]}
+    with open(tmp_path / "s.scene", "w") as f:
+        json.dump(scene, f)
+    with open(tmp_path / "s.take", "w") as f:
+        json.dump({"scene": "s.scene", "camera": {"Perspective": {"resolution": [8, 8], "transformation": {"position": [0, 1, -4]}}}}, f)
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(str(tmp_path / "s.take").encode()) == 0
+        sd, _ = e.compile()
+        assert sd.num_lights == 2 and sd.num_sun_radiance == 1024 and sd.num_infinite_props == 2
+        light_props = sorted(sd.lights[i].prop for i in range(2))
+        assert sorted(sd.props[p].shape for p in light_props) == [scenes.CANOPY, scenes.DISTANT]
+        for p in light_props:
+            assert not (sd.props[p].flags & 1) and (sd.props[p].flags & 2)  # hidden from the camera, seen in reflections
+        sun = [p for p in light_props if sd.props[p].shape == scenes.DISTANT][0]
+        assert abs(sd.trafos[sun].r[2][1] - np.sin(np.radians(-40.0))) < 1e-6
 
 
 def test_unknown_entity_type_is_a_transformation_node(product_lib, tmp_path):

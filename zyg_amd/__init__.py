@@ -135,7 +135,8 @@ class SceneDesc(ctypes.Structure):
                 ("num_materials", ctypes.c_uint32), ("num_lights", ctypes.c_uint32), ("num_mesh_lights", ctypes.c_uint32),
                 ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32), ("num_image_lights", ctypes.c_uint32),
                 ("keyframes", ctypes.POINTER(Keyframe)), ("prop_frames", ctypes.POINTER(ctypes.c_uint32)),
-                ("num_keyframes", ctypes.c_uint32), ("num_interpolation_frames", ctypes.c_uint32), ("origin", ctypes.c_float * 4)]
+                ("num_keyframes", ctypes.c_uint32), ("num_interpolation_frames", ctypes.c_uint32), ("origin", ctypes.c_float * 4),
+                ("sun_radiance", ctypes.POINTER(ctypes.c_float)), ("num_sun_radiance", ctypes.c_uint32)]
 
 
 class ViewDesc(ctypes.Structure):
@@ -359,6 +360,23 @@ class Engine:
         m = _f32(m16).reshape(16)
         if self.lib.su_prop_set_transformation(prop, m.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) != 0:
             raise RuntimeError("su_prop_set_transformation failed")
+
+    def sky(self, parameters=None, sun_table=None, sky_image=None):
+        """The reference's Sky entity (su_ext_sky_create): a Distant sun + a Canopy sky; parameters as the scene file's
+        {"sun": {"rotation": [x, y, z]}, "turbidity": t, ...}.  sun_table (1024 x 3) and sky_image (h x w x 3), both float32,
+        are the sky bake's products (su_ext_sky_tables); without them compile() generates a stand-in.  Returns the sun's prop."""
+        self.lib.su_ext_sky_create.argtypes = [ctypes.c_char_p]
+        sun = self.lib.su_ext_sky_create(json.dumps(parameters).encode() if parameters is not None else None)
+        if sun < 0:
+            raise RuntimeError("su_ext_sky_create failed")
+        if sun_table is not None:
+            sun_table = np.ascontiguousarray(sun_table, dtype=np.float32)
+            sky_image = np.ascontiguousarray(sky_image, dtype=np.float32)
+            assert sun_table.shape == (1024, 3) and 3 == sky_image.ndim and 3 == sky_image.shape[2]
+            self.lib.su_ext_sky_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+            if 0 != self.lib.su_ext_sky_tables(sun_table.ctypes.data, sky_image.ctypes.data, sky_image.shape[1], sky_image.shape[0]):
+                raise RuntimeError("su_ext_sky_tables failed")
+        return sun
 
     def visibility(self, prop, in_camera=True, in_reflection=True, in_sss=False):
         self.lib.su_prop_set_visibility(prop, int(in_camera), int(in_reflection), int(in_sss))

@@ -114,6 +114,8 @@ struct DScene {
     DLightTree           light_tree;
     const DMeshLight*    mesh_lights;
     const DImageLight*   image_lights;
+    const float4*        sun_radiance;  // the Sky entity's sun: radiance over its disc (ZygpuSceneDesc.sun_radiance)
+    uint32_t             num_sun_radiance;
     const uint32_t*      infinite_props;
     uint32_t             num_infinite_props;
     const DImage*        images;

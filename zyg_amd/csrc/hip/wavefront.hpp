@@ -1041,11 +1041,28 @@ ZD float shapeArea(const DScene& s, uint32_t prop, uint32_t part, const Trafo& t
     return s.meshes[p.mesh].part_areas[part] * (trafo.scale.x * trafo.scale.y);
 }
 
+// SkyMaterial.evaluateRadiance without a map (sky_material.zig:150-168): the sun's radiance over its disc,
+// sun_radiance.eval(sunV(rs.trafo.rotation, wi)): InterpolatedFunction1D.eval over [0, 1] (interpolated_function.zig:35-46)
+ZD f3 sunRadiance(const DScene& s, const Trafo& trafo, f3 wi) {
+    const float radius = 0.0046548266f;  // Sky.Radius = tan(0.2667 degrees) as f32 (sky.zig:46; ArPragueSkyModelGround.h:88)
+    const f3    k = wi - trafo.r2;
+    const float c = -dot3(trafo.r1, k) / radius;
+    const float x = mx((c + 1.f) * 0.5f, 0.f);
+    const float inverse_interval = 1.f / (1.f / float(s.num_sun_radiance - 1u));
+    const float cx = mn(x, 1.f);
+    const float o = cx * inverse_interval;
+    const uint32_t offset = uint32_t(o);
+    const float    t = o - float(offset);
+    const f3 a = xyz4(s.sun_radiance[offset]), b = xyz4(s.sun_radiance[min(offset + 1u, s.num_sun_radiance - 1u)]);
+    return lerp3(a, b, S3(t));
+}
+
 // Material.evaluateRadiance for Light / Substitute (material.zig:196-212, light_material.zig:131-140)
 // TEX (= the MESHL instantiations): emission maps, addressed by (u, v) with the stochastic filter's r
 template <bool TEX = false>
 ZD f3 materialRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, const Trafo& trafo, uint32_t prop, uint32_t part,
                        bool in_camera, float u = 0.f, float v = 0.f, float r = 0.f) {
+    if (TEX && ZYGPU_MAT_SKY == m.kind) return sunRadiance(s, trafo, wi);  // the Sky's sun (the sky itself is a Light with a map)
     if (ZYGPU_MAT_LIGHT != m.kind && ZYGPU_MAT_SUBSTITUTE != m.kind) return S3(0.f);
     const float area = m.emission_normalize ? shapeArea(s, prop, part, trafo) : 1.f;
     return emittanceRadiance<TEX>(s, m, wi, trafo.r2, area, in_camera, u, v, r);

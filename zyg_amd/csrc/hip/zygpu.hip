@@ -1002,6 +1002,14 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         dl.sampler = hl.sampler;
     }
     if (!m.upload(image_lights.data(), image_lights.size(), &s.image_lights)) return -1;
+    // the Sky entity's sun table (ZygpuSceneDesc.sun_radiance): 4 floats per sample
+    s.num_sun_radiance = d->sun_radiance ? d->num_sun_radiance : 0u;
+    if (!m.upload(reinterpret_cast<const float4*>(d->sun_radiance), s.num_sun_radiance, &s.sun_radiance)) return -1;
+    for (uint32_t mi = 0; mi < d->num_materials; ++mi)
+        if (ZYGPU_MAT_SKY == d->materials[mi].kind && s.num_sun_radiance < 2) {
+            g_error = "a Sky material needs the sun's radiance table (ZygpuSceneDesc.sun_radiance)";
+            return -2;
+        }
     for (uint32_t mi = 0; mi < d->num_materials; ++mi)
         if (ZYGPU_NULL != d->materials[mi].emission_image && d->materials[mi].emission_image >= d->num_images) {
             g_error = "a material's emission map refers to an image that does not exist";

@@ -411,7 +411,9 @@ int32_t su_ext_set_device(int32_t device_id) {
 
 int32_t su_ext_compile(uint32_t frame) {
     if (!g) return -1;
-    return 0 == g->engine.compile(frame) ? 0 : -1;
+    if (0 != g->engine.compile(frame)) return -1;
+    for (const std::string& w : g->engine.warnings()) logf(1, "%s", w.c_str());
+    return 0;
 }
 
 const ZygpuSceneDesc* su_ext_scene_desc(void) { return g ? &g->engine.sceneDesc() : nullptr; }
@@ -427,6 +429,23 @@ int32_t su_ext_load_take(const char* take_filename) {
     }
     g->exporters = loader.exporters;
     return 0;
+}
+
+int32_t su_ext_sky_create(const char* parameters_json) {
+    if (!g) return -1;
+    const int32_t sun = g->engine.createSky();
+    if (sun < 0) return -1;
+    if (parameters_json) {
+        zyg::JsonValue v;
+        if (!zyg::JsonParser::parse(parameters_json, v)) return -1;
+        g->engine.setSkyParameters(v);
+    }
+    return sun;
+}
+
+int32_t su_ext_sky_tables(const float* sun_rgb, const float* sky_rgb, uint32_t sky_width, uint32_t sky_height) {
+    if (!g) return -1;
+    return 0 == g->engine.setSkyTables(sun_rgb, sky_rgb, sky_width, sky_height) ? 0 : -1;
 }
 
 uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,

@@ -736,7 +736,7 @@ int32_t Engine::createPropShape(uint32_t shape, const uint32_t* materials, uint3
             const ZygpuMaterial& m = materials_[materials[i]];
             if (m.flags & ZYGPU_MATF_EVALUATE_VISIBILITY) p.flags |= ZYGPU_PROP_EVALUATE_VISIBILITY;
             if (m.flags & ZYGPU_MATF_CAUSTIC) p.flags |= ZYGPU_PROP_CAUSTIC;
-            if (ZYGPU_MAT_LIGHT != m.kind) pure_emissive = false;
+            if (ZYGPU_MAT_LIGHT != m.kind && ZYGPU_MAT_SKY != m.kind) pure_emissive = false;
             if (materials[i] != mid0) mono = false;
         }
     }
@@ -1063,7 +1063,7 @@ float appendDistribution1D(const std::vector<float>& data, HostImageLight& out) 
 
 // Light.Material.prepareSampling for an emission map (light_material.zig:52-125, 201-271): uv-weighted luminance per texel,
 // MIS compensation (luminance minus 0.6 x the mean), one Distribution1D per row and the marginal over the rows' integrals
-uint32_t Engine::prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m) {
+uint32_t Engine::prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m, bool compensate) {
     ensureSrgbTable();
     const HostImage& img = images_[m.emission_image];
     const int        w = img.width, h = img.height;
@@ -1109,12 +1109,13 @@ uint32_t Engine::prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m) 
     il.total_weight = avg[3];
     il.average_emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f) * average;
 
+    // the Sky material's map is sampled by its luminance as it is (sky_material.zig:89-133, 170-215: no compensation)
     const float        al = 0.6f * std::max(std::max(average[0], average[1]), average[2]);
     std::vector<float> integrals(h), row(w);
     for (int y = 0; y < h; ++y) {
         for (int x = 0; x < w; ++x) {
             const float l = luminance[size_t(y) * w + x];
-            row[x] = std::max(l - al, std::min(l, 0.0025f));
+            row[x] = compensate ? std::max(l - al, std::min(l, 0.0025f)) : l;
         }
         integrals[y] = appendDistribution1D(row, il);
     }
@@ -1234,13 +1235,201 @@ uint32_t Engine::prepareMeshLight(uint32_t mesh_id, uint32_t part, uint32_t mate
     return uint32_t(mesh_lights_.size() - 1);
 }
 
+
+// ---------------------------------------------------------------- Sky (sky/sky.zig, sky/sky_material.zig)
+namespace {
+// Model.AngularRadius = arp.PSMG_SUN_RADIUS = 0.2667 degrees (thirdparty/arpraguesky/ArPragueSkyModelGround.h:88);
+// Sky.Radius = tan of it as f32 (sky.zig:46)
+const float  kSunAngularRadius = float(0.2667 * (3.141592653589793 / 180.0));
+const float  kSkyRadius = 0.0046548266f;  // tan(kSunAngularRadius) as f32, the literal the device and the oracle use
+inline float sunWiDotZ(float elevation, float v) {  // sky.zig:271-275
+    const float y = (2.f * v) - 1.f;
+    return std::sin(elevation + y * kSkyRadius);
+}
+inline Vec4f quaternionMul(const Vec4f& a, const Vec4f& b) {  // quaternion.zig:208-215
+    return vec((a[3] * b[0] + a[0] * b[3]) + (a[1] * b[2] - a[2] * b[1]), (a[3] * b[1] + a[1] * b[3]) + (a[2] * b[0] - a[0] * b[2]),
+               (a[3] * b[2] + a[2] * b[3]) + (a[0] * b[1] - a[1] * b[0]), (a[3] * b[3] - a[0] * b[0]) - (a[1] * b[1] + a[2] * b[2]));
+}
+inline Mat3x3 mulMat3(const Mat3x3& a, const Mat3x3& b) {  // matrix3x3.zig:99-111
+    Mat3x3 o;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) o.r[i][j] = a.r[i][0] * b.r[0][j] + a.r[i][1] * b.r[1][j] + a.r[i][2] * b.r[2][j];
+        o.r[i][3] = 0.f;
+    }
+    return o;
+}
+}  // namespace
+
+int32_t Engine::createSky() {  // Scene.createSky -> Sky.configure (sky.zig:53-76)
+    if (ZYGPU_NULL != sky_.sun) return int32_t(sky_.sun);
+    // the sun: a Sky material with no map (its radiance is the table), on a Distant shape
+    JsonValue none;
+    none.type = JsonValue::Object;
+    ZygpuMaterial sun{};
+    parseMaterial(sun, none, ZYGPU_MAT_SKY);  // the defaults
+    sun.flags |= ZYGPU_MATF_EMISSIVE;  // SkyMaterial.commit (sky_material.zig:60-63)
+    materials_.push_back(sun);
+    sky_.sun_material = uint32_t(materials_.size() - 1);
+    const int32_t sun_prop = createPropShape(ZYGPU_SHAPE_DISTANT, &sky_.sun_material, 1, true);
+    // the sky: the baked image as the emission map of an emitter on a Canopy; evaluateRadiance is the map's texel
+    // (sky_material.zig:150-159), which is what a Light material with emittance 1 and that map gives
+    HostImage img;
+    img.format = ZYGPU_IMAGE_FLOAT3;
+    img.width = img.height = 1;
+    img.pixels.assign(12, 0);
+    images_.push_back(std::move(img));
+    sky_.image = uint32_t(images_.size() - 1);
+    ZygpuMaterial sky{};
+    parseMaterial(sky, none, ZYGPU_MAT_LIGHT);
+    sky.emission[0] = sky.emission[1] = sky.emission[2] = 1.f;
+    sky.emission_image = sky_.image;
+    sky.emission_sampler = ZYGPU_TEX_LINEAR;  // Texture.DefaultClampMode: clamp, the default (bilinear) filter
+    sky.emission_scale[0] = sky.emission_scale[1] = 1.f;
+    sky.flags |= ZYGPU_MATF_EMISSIVE;
+    materials_.push_back(sky);
+    sky_.sky_material = uint32_t(materials_.size() - 1);
+    const int32_t sky_prop = createPropShape(ZYGPU_SHAPE_CANOPY, &sky_.sky_material, 1, true);
+    if (sun_prop < 0 || sky_prop < 0) return -1;
+    sky_.sun = uint32_t(sun_prop);
+    sky_.sky = uint32_t(sky_prop);
+    createLight(sky_.sun);
+    createLight(sky_.sky);
+    return sun_prop;
+}
+
+void Engine::setSkyParameters(const JsonValue& v) {  // Sky.setParameters (sky.zig:78-93)
+    if (JsonValue::Object != v.type) return;
+    for (const auto& kv : v.obj) {
+        if (kv.first == "sun") {
+            Vec4f angles = splat(0.f);
+            if (const JsonValue* r = kv.second.get("rotation"))
+                if (JsonValue::Array == r->type && r->arr.size() >= 3) angles = vec(r->arr[0].f32(), r->arr[1].f32(), r->arr[2].f32());
+            // json.createRotationMatrix (base/json.zig:169-175): Rz * Rx * Ry of the angles in degrees
+            const float k = float(M_PI / 180.0);
+            auto rx = [](float a) { const float c = std::cos(a), s = std::sin(a); return Mat3x3{{vec(1.f, 0.f, 0.f), vec(0.f, c, -s), vec(0.f, s, c)}}; };
+            auto ry = [](float a) { const float c = std::cos(a), s = std::sin(a); return Mat3x3{{vec(c, 0.f, s), vec(0.f, 1.f, 0.f), vec(-s, 0.f, c)}}; };
+            auto rz = [](float a) { const float c = std::cos(a), s = std::sin(a); return Mat3x3{{vec(c, -s, 0.f), vec(s, c, 0.f), vec(0.f, 0.f, 1.f)}}; };
+            sky_.sun_rotation = mulMat3(mulMat3(rz(angles[2] * k), rx(angles[0] * k)), ry(angles[1] * k));
+        } else if (kv.first == "turbidity") {  // Model.turbidityToVisibility (sky_model.zig:140-142)
+            const float t = kv.second.f32();
+            sky_.visibility = 7487.f * std::exp(-3.41f * t) + 117.1f * std::exp(-0.4768f * t);
+        } else if (kv.first == "visibility") {
+            sky_.visibility = kv.second.f32();
+        } else if (kv.first == "albedo") {
+            sky_.albedo = kv.second.f32();
+        }
+    }
+}
+
+int Engine::setSkyTables(const float* sun_rgb, const float* sky_rgb, uint32_t sky_width, uint32_t sky_height) {
+    if (ZYGPU_NULL == sky_.sun || !sun_rgb || !sky_rgb || 0 == sky_width || 0 == sky_height) return -1;
+    sky_.sun_rgb.assign(sun_rgb, sun_rgb + size_t(kSkySunSamples) * 3);
+    HostImage& img = images_[sky_.image];
+    img.width = int32_t(sky_width);
+    img.height = int32_t(sky_height);
+    img.pixels.resize(size_t(sky_width) * sky_height * 12);
+    std::memcpy(img.pixels.data(), sky_rgb, img.pixels.size());
+    sky_.tables_given = true;
+    return 0;
+}
+
+// Sky.compile (sky.zig:95-170): the two props' transformations from the sun's rotation, then the bake's products
+void Engine::compileSky() {
+    if (ZYGPU_NULL == sky_.sun) return;
+    {  // the sky is seen where the sun is (sky.zig:100)
+        const uint32_t f = props_[sky_.sun].flags;
+        setVisibility(sky_.sky, 0 != (f & ZYGPU_PROP_VISIBLE_IN_CAMERA), 0 != (f & ZYGPU_PROP_VISIBLE_IN_REFLECTION), false);
+    }
+    // "HACK: artificially set sun radius to zero if under horizon to get an early out during light sampling" (sky.zig:102-105)
+    const bool  under_horizon = sky_.sun_rotation.r[2][1] > kSunAngularRadius;
+    const Vec4f scale = under_horizon ? splat(0.f) : vec(kSkyRadius, kSkyRadius, kSkyRadius, 1.f);
+    setWorldTransformation(sky_.sun, Transformation{splat(0.f), scale, quaternionFromMat3x3(sky_.sun_rotation)});
+    const Vec4f sun_direction = sky_.sun_rotation.r[2];
+    const float sun_azimuth = -std::atan2(sun_direction[0], sun_direction[2]);
+    const float half_x = float(90.0 * (M_PI / 180.0)) * 0.5f, half_y = sun_azimuth * 0.5f;
+    const Vec4f qx = vec(std::sin(half_x), 0.f, 0.f, std::cos(half_x)), qy = vec(0.f, std::sin(half_y), 0.f, std::cos(half_y));
+    setWorldTransformation(sky_.sky, Transformation{splat(0.f), splat(1.f), quaternionMul(qx, qy)});
+    const float sun_elevation = -std::asin(sun_direction[1]);
+
+    if (!sky_.tables_given) {
+        // The reference bakes both tables from the Prague sky model (sky.zig:172-269), whose dataset
+        // (sky/SkyModelDataset.dat.gz) does not ship with it.  What stands in, until a client hands over the products of a
+        // bake (setSkyTables): a solar disc with limb darkening whose colour reddens with the air mass, and a hemisphere that
+        // is bluer towards the zenith and brighter around the sun, written through the bake's own mappings (sunWiDotZ; the
+        // clipped canopy mapping with the model's axes: x right, y up, the sun in the direction -z at its elevation).
+        warnings_.push_back("Sky: the Prague sky model's dataset is not available; the sun's radiance table and the sky image are a procedural stand-in");
+        sky_.sun_rgb.resize(size_t(kSkySunSamples) * 3);
+        const float n = float(kSkySunSamples - 1);
+        for (uint32_t i = 0; i < kSkySunSamples; ++i) {
+            const float v = float(i) / n;
+            const float wi_dot_z = sunWiDotZ(sun_elevation, v);
+            const float y = 2.f * v - 1.f;
+            const float limb = 1.f - 0.6f * (1.f - std::sqrt(std::max(0.f, 1.f - y * y)));
+            const float air = 1.f / std::max(wi_dot_z, 0.05f);
+            const float tau[3] = {0.10f, 0.16f, 0.28f}, tint[3] = {1.f, 0.92f, 0.78f};
+            for (int c = 0; c < 3; ++c) sky_.sun_rgb[3 * i + c] = wi_dot_z < 0.f ? 0.f : 1.6e4f * tint[c] * limb * std::exp(-tau[c] * air);
+        }
+        HostImage& img = images_[sky_.image];
+        img.width = img.height = kSkyBakeDimension;
+        img.pixels.resize(size_t(kSkyBakeDimension) * kSkyBakeDimension * 12);
+        float*      px = reinterpret_cast<float*>(img.pixels.data());
+        const float idf = 1.f / float(kSkyBakeDimension), e = 3.5f * idf;
+        const float sin_el = sun_direction[1];
+        const Vec4f to_sun = vec(0.f, -sin_el, -std::sqrt(std::max(0.f, 1.f - sin_el * sin_el)));
+        for (int32_t yy = 0; yy < kSkyBakeDimension; ++yy) {
+            for (int32_t xx = 0; xx < kSkyBakeDimension; ++xx) {
+                float       dx = 2.f * (idf * (float(xx) + 0.5f)) - 1.f, dy = 2.f * (idf * (float(yy) + 0.5f)) - 1.f;
+                const float l = std::sqrt(dx * dx + dy * dy);
+                float*      o = px + 3 * (size_t(yy) * kSkyBakeDimension + xx);
+                if (l > 1.f + e) {
+                    o[0] = o[1] = o[2] = 0.f;
+                    continue;
+                }
+                if (l >= 1.f - e) {
+                    dx /= l + e;
+                    dy /= l + e;
+                }
+                // Canopy.diskToHemisphereEquidistant (canopy.zig:189-211), then the model's axes (sky.zig:340-341)
+                const float longitude = std::atan2(-dy, dx), colatitude = std::sqrt(dx * dx + dy * dy) * float(M_PI / 2.0);
+                const Vec4f dir = vec(std::sin(colatitude) * std::cos(longitude), std::sin(colatitude) * std::sin(longitude), std::cos(colatitude));
+                const Vec4f wi = normalize3(vec(dir[0], dir[2], -dir[1]));
+                const float up = clamp_(wi[1], 0.f, 1.f), cos_gamma = clamp_(dot3(wi, to_sun), -1.f, 1.f);
+                const float horizon = std::pow(1.f - up, 3.f), aureole = std::exp(-(1.f - cos_gamma) * 24.f);
+                const float day = clamp_(-sin_el * 4.f + 0.15f, 0.05f, 1.f);  // dimmer as the sun goes down
+                o[0] = day * (0.16f + 0.55f * horizon + 1.6f * aureole);
+                o[1] = day * (0.30f + 0.50f * horizon + 1.3f * aureole);
+                o[2] = day * (0.72f + 0.20f * horizon + 0.9f * aureole);
+            }
+        }
+    }
+    // SkyMaterial.setSunRadiance (sky_material.zig:66-87): the table, and its mean over the part of the disc above the horizon
+    c_sun_radiance_.assign(size_t(kSkySunSamples) * 4, 0.f);
+    for (uint32_t i = 0; i < kSkySunSamples; ++i)
+        for (int c = 0; c < 3; ++c) c_sun_radiance_[4 * i + c] = sky_.sun_rgb[3 * i + c];
+    Vec4f total = splat(0.f);
+    float tw = 0.f;
+    for (uint32_t i = 0; i + 1 < kSkySunSamples; ++i) {
+        const Vec4f s0 = vec(c_sun_radiance_[4 * i], c_sun_radiance_[4 * i + 1], c_sun_radiance_[4 * i + 2]);
+        const Vec4f s1 = vec(c_sun_radiance_[4 * i + 4], c_sun_radiance_[4 * i + 5], c_sun_radiance_[4 * i + 6]);
+        const float v = (float(i) + 0.5f) / float(kSkySunSamples);
+        const float wi_dot_z = sunWiDotZ(sun_elevation, v);
+        const float w = std::sin(v);
+        tw += w;
+        if (wi_dot_z >= 0.f) total = total + (s0 + s1) * splat(0.5f * w);
+    }
+    const Vec4f average = total / splat(tw);
+    ZygpuMaterial& sun = materials_[sky_.sun_material];
+    for (int c = 0; c < 3; ++c) sun.emission[c] = average[c];
+}
+
 int Engine::compile(uint32_t frame) {
     (void)frame;  // keyframes are relative to the frame's start (space.zig:114-125): the compiled scene is the same for every frame
     if (ZYGPU_NULL == camera_entity) return -1;
+    warnings_.clear();
+    compileSky();  // scene.compile -> sky.compile (scene.zig:196-198)
 
     // driver.zig:164 -> scene.propWorldPosition (scene.zig:372-380): an animated entity's first keyframe
     const Vec4f    camera_pos = frameStartTransformation(camera_entity).position;
-    warnings_.clear();
     // animated props (space.zig:23-26): their keyframes travel with the compiled scene
     c_keyframes_.clear();
     c_prop_frames_.assign(props_.size(), ZYGPU_NULL);
@@ -1351,12 +1540,13 @@ int Engine::compile(uint32_t frame) {
         c_light_two_sided_[li] = l.two_sided;
         l.sampler = is_mesh ? prepareMeshLight(s.mesh, l.part, material_ids_[p], 0 != l.two_sided) : ZYGPU_NULL;
         // scene.zig:430-470: an emission map makes the light a PropImage with its own sampler (light.zig:95-101)
+        const bool sky_map = ZYGPU_NULL != sky_.sky && l.prop == sky_.sky;
         const bool image_light = ZYGPU_MAT_LIGHT == m.kind && ZYGPU_NULL != m.emission_image;
         l.light_class = ZYGPU_LIGHT_PROP;
         if (image_light) {
             if (m.emission_image >= images_.size()) return -4;
             if (is_mesh || is_distant) return -3;  // Shape.sampleMaterialTo has no case for them (shape.zig:348-371)
-            l.sampler = prepareImageLight(s.kind, m);
+            l.sampler = prepareImageLight(s.kind, m, !sky_map);
             l.light_class = ZYGPU_LIGHT_PROP_IMAGE;
         }
 
@@ -1528,6 +1718,8 @@ int Engine::compile(uint32_t frame) {
     d.num_keyframes = uint32_t(c_keyframes_.size());
     d.num_interpolation_frames = numInterpolationFrames();
     for (int i = 0; i < 4; ++i) d.origin[i] = camera_pos[i];
+    d.sun_radiance = c_sun_radiance_.empty() ? nullptr : c_sun_radiance_.data();
+    d.num_sun_radiance = uint32_t(c_sun_radiance_.size() / 4);
 
     // camera.update (camera_perspective.zig:79-122, mono / no focus point)
     ZygpuViewDesc& v = view_desc_;

@@ -60,6 +60,9 @@ struct HostMeshLight {
 };
 
 // An emission map prepared for importance sampling: light_material.zig:52-125 + Distribution2D (flattened, see zygpu.h)
+constexpr uint32_t kSkySunSamples = 1024;      // Sky.BakeDimensionsSun (sky.zig:49)
+constexpr int32_t  kSkyBakeDimension = 1024;   // Sky.BakeDimensions (sky.zig:48)
+
 struct HostImageLight {
     std::vector<float>    cdf;
     std::vector<uint32_t> lut, rows;
@@ -127,6 +130,16 @@ class Engine {
     int      updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data);
     const std::vector<std::string>& warnings() const { return warnings_; }  // of the last compile()
     int      setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss);
+    // The Sky entity (sky/sky.zig; util/scene_loader.zig:704-712): a Distant sun and a Canopy sky, both lights.  createSky
+    // returns the sun's prop (Sky.configure, idempotent); the parameters are the entity's "parameters" node (Sky.setParameters).
+    // The bake's products (sky.zig:172-269: the sun's radiance over its disc, kSkySunSamples rgb samples, and the canopy image)
+    // come from the client with setSkyTables (what the reference reads back from its cache files, sky.zig:138-168); without
+    // them compile() fills in a procedural stand-in (the Prague model's dataset does not ship with the reference).
+    int32_t  createSky();
+    void     setSkyParameters(const JsonValue& v);
+    int      setSkyTables(const float* sun_rgb, const float* sky_rgb, uint32_t sky_width, uint32_t sky_height);
+    uint32_t skySun() const { return sky_.sun; }
+    uint32_t skyCanopy() const { return sky_.sky; }
 
     // --- view ---
     void cameraCreate(uint32_t width, uint32_t height);
@@ -214,7 +227,16 @@ class Engine {
     std::vector<ZygpuMeshLight> c_mesh_lights_;
     std::deque<HostImageLight>   image_lights_;
     std::vector<ZygpuImageLight> c_image_lights_;
-    uint32_t prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m);
+    uint32_t prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m, bool compensate = true);
+    struct HostSky {
+        uint32_t sun = ZYGPU_NULL, sky = ZYGPU_NULL, sun_material = ZYGPU_NULL, sky_material = ZYGPU_NULL, image = ZYGPU_NULL;
+        float    visibility = 100.f, albedo = 0.25f;                                                   // sky.zig:39-40
+        Mat3x3   sun_rotation{{vec(1.f, 0.f, 0.f), vec(0.f, 0.f, 1.f), vec(0.f, -1.f, 0.f)}};          // sky.zig:42
+        bool     tables_given = false;
+        std::vector<float> sun_rgb;  // kSkySunSamples x 3, as given or as generated
+    } sky_;
+    std::vector<float> c_sun_radiance_;  // 4 per sample
+    void compileSky();
     void     ensureSrgbTable();
     uint32_t prepareMeshLight(uint32_t mesh, uint32_t part, uint32_t material, bool two_sided);
     std::vector<ZygpuAabb>    c_light_aabbs_;

@@ -6,8 +6,9 @@
 //   mesh .sub        src/core/scene/shape/shape_provider.zig:527-805, 965-994 ("SUB\0", u64 json size, JSON header, binary
 //                    vertex streams + indices, delta-encoded Int16 / Int32 or plain UInt16 / UInt32)
 // File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
-// core/file/system.zig, reduced to these two levels).  Refused by name (the load fails, nothing is skipped in silence): instancers,
-// scatterers, portals, Sky entities, animations, shadow catchers.  Not read: glTF, gzip-compressed files.
+// core/file/system.zig, reduced to these two levels).  Sky entities create the sun and the sky (engine.cpp createSky; the bake's tables are a
+// procedural stand-in unless the client hands them over).  Refused by name (the load fails, nothing is skipped in silence):
+// instancers, scatterers, portals, animations, shadow catchers.  Not read: glTF, gzip-compressed files.
 #pragma once
 
 #include <cstdio>
@@ -274,7 +275,12 @@ class TakeLoader {
         } else if (type->str == "Prop") {
             entity = loadProp(v, local_materials, dir, false);
             if (ZYGPU_NULL == entity) return false;
-        } else if (type->str == "Portal" || type->str == "Instancer" || type->str == "Sky" || type->str == "Scatterer") {
+        } else if (type->str == "Sky") {  // loadSky (scene_loader.zig:704-712): the entity is the sky's sun
+            const int32_t sun = engine_.createSky();
+            if (sun < 0) return false;
+            if (const JsonValue* parameters = v.get("parameters")) engine_.setSkyParameters(*parameters);
+            entity = uint32_t(sun);
+        } else if (type->str == "Portal" || type->str == "Instancer" || type->str == "Scatterer") {
             return unsupported("a \"" + type->str + "\" entity");
         }  // any other type is a node without an entity: its transformation applies to its children (scene_loader.zig:241-264)
         if (v.get("animation")) return unsupported("an entity with an \"animation\"");

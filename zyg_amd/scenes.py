@@ -563,9 +563,26 @@ def _basis_for(n):
     return tuple(r0), tuple(r1)
 
 
+def sky_tables(elevation_deg=35.0, size=64):
+    """A stand-in for the products of the reference's sky bake (sky.zig:172-269), for the tests: the sun's radiance over its disc
+    (1024 x 3: bright, limb-darkened, reddened) and a canopy image (size x size x 3, zero outside the disc)."""
+    v = np.arange(1024, dtype=np.float64) / 1023.0
+    y = 2.0 * v - 1.0
+    limb = 1.0 - 0.6 * (1.0 - np.sqrt(np.maximum(0.0, 1.0 - y * y)))
+    sun = (2.0e4 * limb[:, None] * np.array([1.0, 0.9, 0.75])[None, :] * (0.8 + 0.2 * v[:, None])).astype(np.float32)
+    g = (np.arange(size, dtype=np.float64) + 0.5) / size * 2.0 - 1.0
+    dx, dy = np.meshgrid(g, g, indexing="xy")
+    r = np.sqrt(dx * dx + dy * dy)
+    up = np.cos(np.minimum(r, 1.0) * np.pi / 2.0)
+    img = np.stack([0.2 + 0.5 * (1 - up) ** 2, 0.35 + 0.45 * (1 - up) ** 2, 0.8 + 0.1 * (1 - up)], axis=-1)
+    img *= (1.0 + 1.5 * np.exp(-((dx - 0.0) ** 2 + (dy + np.cos(np.radians(elevation_deg))) ** 2) * 6.0))[..., None]
+    img[r > 1.0 + 3.5 / size] = 0.0
+    return sun, img.astype(np.float32)
+
+
 def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
             extra_quad_light=False, max_depth=8, sky=None, sun=True, showcase=False, mesh=None, sky_map=None, sky_samples=1,
-            sky_spectrum=(0.35, 0.5, 0.8)):
+            sky_spectrum=(0.35, 0.5, 0.8), sky_entity=None):
     """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
     distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
     light tree mixes the infinite-light distribution with the BVH.  `sky`: "dome" (dome.zig, the whole sphere of
@@ -600,6 +617,10 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
         p = engine.prop(engine.triangle_mesh(idx, pos, nrm, uv), [mat])
         engine.transformation(p, identity)
 
+    if sky_entity is not None:
+        tables = sky_entity.get("tables")
+        ids["sun"] = engine.sky(sky_entity.get("parameters"), *(tables if tables else (None, None)))
+        sun, sky = False, None
     if sun:
         to_light = np.asarray(sun_direction, dtype=np.float64)
         r0, r1 = _basis_for(-to_light)  # the light's z axis points from the light into the scene
