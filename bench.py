@@ -46,6 +46,10 @@ def parse_args():
                          "(the heightfield on the floor); cornell_glass and outdoor (configs[4]'s ingredients: glass, metal presets, "
                          "1 M-triangle mesh, image-lit canopy + sun) run the POOL kernels")
     ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
+    ap.add_argument("--box-triangles", type=int, default=12, choices=[12, 18, 108, 972],
+                    help="triangles of each of the two Cornell boxes (12 = BASELINE.json configs[1]); the others measure what a scene "
+                         "just past the kernels' thresholds costs (meshes of at most 16 triangles are tested from the constant block)")
+    ap.add_argument("--extra-props", type=int, default=0, help="small Rectangle plaques on the back wall (the prop tables hold 16 props)")
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1],
                     help="zygpu option fuse_trace_shade: wf_trace_shade (closest hit + first shading pass in one kernel, default) "
                          "or wf_intersect and wf_shade apart")
@@ -69,7 +73,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_scene(eng, scenes, name, material, w, h, total_spp):
+def build_scene(eng, scenes, name, material, w, h, total_spp, box_triangles=12, extra_props=0):
     # BASELINE.json configs[2]: 999 698 triangles with one grey Substitute material; cornell_mesh: SURVEY 8(d)'s closed displaced
     # sphere centred at 60 % of the box's height (most paths and shadow rays cross it), cornell_mound: the heightfield on the floor
     mesh = scenes.displaced_sphere_mesh() if name == "cornell_mesh" else scenes.heightfield_mesh() if name == "cornell_mound" else None
@@ -81,7 +85,9 @@ def build_scene(eng, scenes, name, material, w, h, total_spp):
     else:
         glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if name == "cornell_glass" else None
         scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=material, boxes=mesh is None, mesh=mesh,
-                       mesh_material=mesh_material, glass_objects=glass, mesh_position=mesh_position)
+                       mesh_material=mesh_material, glass_objects=glass, mesh_position=mesh_position,
+                       box_subdivide={12: 1, 18: 1, 108: 3, 972: 9}[box_triangles], box_first_face=(1, 4) if 18 == box_triangles else None,
+                       extra_props=extra_props)
 
 
 def describe(name, material, w, h, ips, k, precise):
@@ -107,7 +113,9 @@ class Measurement:
         self.w, self.h, self.ips = args.width, args.height, args.iters_per_step
         self.eng = zyg_amd.Engine()
         self.eng.set_device(device.index)
-        build_scene(self.eng, scenes, scene, material, self.w, self.h, frame.world * steps * self.ips)
+        main = scene == args.scene  # the variants' knobs are the main scene's
+        build_scene(self.eng, scenes, scene, material, self.w, self.h, frame.world * steps * self.ips,
+                    args.box_triangles if main else 12, args.extra_props if main else 0)
         self.eng.start_frame(0)
         self.lib, self.ctx = self.eng.lib, self.eng.context()
         if args.batch_mpaths:

@@ -42,3 +42,30 @@ def test_library_exports_every_declared_symbol():
     assert {"su_prop_set_transformation_frame", "su_image_update", "zygpu_render"} <= names
     for n in names:
         assert hasattr(lib, n), n
+
+
+def _struct_fields(header, name):
+    """Field names of `typedef struct <name> { ... } <name>;` in declaration order."""
+    body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + r";", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            fields.append(re.search(r"(\w+)(\[[^\]]*\])?$", decl).group(1))
+    return fields
+
+
+def test_integration_md_scene_desc_sketch_follows_the_header():
+    """INTEGRATION.md section B shows the `extern struct SceneDesc` a Zig maintainer would copy: the same fields in the same order
+    as include/zygpu.h's ZygpuSceneDesc, and the Python mirror zyg_amd.SceneDesc likewise."""
+    header = open(os.path.join(ROOT, "include", "zygpu.h")).read()
+    fields = _struct_fields(header, "ZygpuSceneDesc")
+    assert fields[0] == "props" and "sun_radiance" in fields
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sketch = re.search(r"pub const SceneDesc = extern struct \{(.*?)\n\};", text, re.S).group(1)
+    sketch = re.sub(r"//[^\n]*", "", sketch)
+    zig = re.findall(r"(\w+)\s*:", sketch)
+    assert zig == fields, (zig, fields)
+    import zyg_amd
+    assert [f[0] for f in zyg_amd.SceneDesc._fields_] == fields

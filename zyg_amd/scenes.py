@@ -153,9 +153,10 @@ def sky_image(width=64, height=32, sun=(0.62, 0.3), uniform=None):
     return (base + blob[..., None] * np.array([1.0, 0.9, 0.7])).astype(np.float32)
 
 
-def box_mesh(lo, hi, rot_y_deg=0.0):
-    """Axis-aligned box [lo, hi] rotated about the y axis through its centre: 24 vertices, 12 triangles,
-    face normals pointing outward."""
+def box_mesh(lo, hi, rot_y_deg=0.0, subdivide=1, first_face=None):
+    """Axis-aligned box [lo, hi] rotated about the y axis through its centre, face normals pointing outward.  Every face is a
+    subdivide x subdivide grid of quads, two triangles each (subdivide = 1: 24 vertices, 12 triangles; 3: 108; 9: 972);
+    first_face = (nu, nv): the first face's grid instead (e.g. (1, 4): 8 triangles there, 18 in all)."""
     lo = np.asarray(lo, dtype=np.float64)
     hi = np.asarray(hi, dtype=np.float64)
     c = 0.5 * (lo + hi)
@@ -168,15 +169,22 @@ def box_mesh(lo, hi, rot_y_deg=0.0):
     a = np.radians(rot_y_deg)
     rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
     pos, nrm, uv, idx = [], [], [], []
-    for n, u, v in faces:
+    for f, (n, u, v) in enumerate(faces):
         n, u, v = (np.asarray(x, dtype=np.float64) for x in (n, u, v))
+        nu, nv = first_face if (first_face and 0 == f) else (subdivide, subdivide)
         base = len(pos)
-        for su, sv in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
-            p = (n + su * u + sv * v) * h
-            pos.append(rot @ p + c)
-            nrm.append(rot @ n)
-            uv.append((0.5 * (su + 1), 0.5 * (sv + 1)))
-        idx += [base, base + 1, base + 2, base, base + 2, base + 3]
+        for j in range(nv + 1):
+            for i in range(nu + 1):
+                su, sv = 2.0 * i / nu - 1.0, 2.0 * j / nv - 1.0
+                p = (n + su * u + sv * v) * h
+                pos.append(rot @ p + c)
+                nrm.append(rot @ n)
+                uv.append((0.5 * (su + 1), 0.5 * (sv + 1)))
+        for j in range(nv):
+            for i in range(nu):
+                a0 = base + j * (nu + 1) + i
+                a1, a2, a3 = a0 + 1, a0 + nu + 2, a0 + nu + 1
+                idx += [a0, a1, a2, a0, a2, a3]
     return (np.asarray(idx, dtype=np.uint32), np.asarray(pos, dtype=np.float32), np.asarray(nrm, dtype=np.float32),
             np.asarray(uv, dtype=np.float32))
 
@@ -365,7 +373,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
             light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None,
-            overrides=None, regularize=None, mesh_position=(0, 0.02, 0.1)):
+            overrides=None, regularize=None, mesh_position=(0, 0.02, 0.1), box_subdivide=1, box_first_face=None, extra_props=0):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed at mesh_position (the
@@ -386,6 +394,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     lens: thin-lens camera parameters, e.g. {"lens": {"radius": 0.05}, "focus": {"distance": 3.9}}
     (camera_perspective.zig:124-150, 260-270, aperture.zig:46-53).
     overrides: material JSONs by place: "floor", "back", "left", "right", "ceiling", "tall", "short", "sphere_a", "sphere_b".
+    box_subdivide / box_first_face: the two boxes' triangle counts (box_mesh); extra_props: that many small Rectangle plaques on
+    the back wall (the prop count: the device's prop tables hold 16).
     Returns a dict with prop ids.
     """
     overrides = overrides or {}
@@ -524,7 +534,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             ids["meshes"].append(p)
     if boxes:
         for k, (lo, hi, rot) in enumerate((((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0))):
-            idx, pos, nrm, uv = box_mesh(lo, hi, rot)
+            idx, pos, nrm, uv = box_mesh(lo, hi, rot, subdivide=box_subdivide, first_face=box_first_face)
             shape = engine.triangle_mesh(idx, pos, nrm, uv)
             box_mat = engine.material(glass_objects["box"]) if 1 == k and "box" in glass_objects else pick(("tall", "short")[k], white)
             if masked and 0 == k:
@@ -532,6 +542,10 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             p = engine.prop(shape, [box_mat])
             engine.transformation(p, identity)
             ids["meshes"].append(p)
+    for k in range(extra_props):  # plaques a hair in front of the back wall, facing the camera
+        p = engine.prop(RECTANGLE, [red if k % 2 else green])
+        engine.transformation(p, trafo((-1, 0, 0), (0, 1, 0), (0.18, 0.18, 1), (-0.8 + 1.6 * (k % 6) / 5.0, 0.4 + 0.45 * (k // 6), 0.995)))
+        ids["walls"].append(p)
     if mesh is not None:
         idx, pos, nrm, uv = mesh
         shape = engine.triangle_mesh(idx, pos, nrm, uv)
