@@ -46,7 +46,7 @@ def parse_args():
                          "(the heightfield on the floor); cornell_glass and outdoor (configs[4]'s ingredients: glass, metal presets, "
                          "1 M-triangle mesh, image-lit canopy + sun) run the POOL kernels")
     ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
-    ap.add_argument("--box-triangles", type=int, default=12, choices=[12, 18, 108, 972],
+    ap.add_argument("--box-triangles", type=int, default=12, choices=[12, 18, 48, 108, 972],
                     help="triangles of each of the two Cornell boxes (12 = BASELINE.json configs[1]); the others measure what a scene "
                          "just past the kernels' thresholds costs (meshes of at most 16 triangles are tested from the constant block)")
     ap.add_argument("--extra-props", type=int, default=0, help="small Rectangle plaques on the back wall (the prop tables hold 16 props)")
@@ -86,7 +86,7 @@ def build_scene(eng, scenes, name, material, w, h, total_spp, box_triangles=12, 
         glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if name == "cornell_glass" else None
         scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=material, boxes=mesh is None, mesh=mesh,
                        mesh_material=mesh_material, glass_objects=glass, mesh_position=mesh_position,
-                       box_subdivide={12: 1, 18: 1, 108: 3, 972: 9}[box_triangles], box_first_face=(1, 4) if 18 == box_triangles else None,
+                       box_subdivide={12: 1, 18: 1, 48: 2, 108: 3, 972: 9}[box_triangles], box_first_face=(1, 4) if 18 == box_triangles else None,
                        extra_props=extra_props)
 
 

@@ -73,7 +73,7 @@ struct DImageLight {  // ZygpuImageLight on the device
 // A small top-level scene as a table in the __constant__ block itself (zygpu_upload_scene fills it when the solid props are
 // at most kUniformProps Rectangles and TriangleMeshes): every lane of a wave tests the same prop at the same time, the
 // prop's bounds and transformation arrive through the scalar cache in SGPRs (sceneIntersectUniform, sceneVisibilityUniform).
-constexpr uint32_t kUniformProps = 16;
+constexpr uint32_t kUniformProps = 32;  // 17 props through the per-lane tree walk: 461 Msamples/s against 773 with 16 in the table
 struct TlasEntry {
     float4   bmin, bmax;        // world bounds (s.aabbs)
     float4   r0, r1, r2, pos;   // transformation (s.trafos)
@@ -83,14 +83,22 @@ struct TlasEntry {
 // The triangles of the scene's smallest meshes (at most kSmallMeshTriangles each, kSmallTriangles in all), in the constant
 // block beside the prop tables: the relaxed-arithmetic units test all of them, every lane of the wave the same triangle at the
 // same time with its vertices in SGPRs, instead of walking a BVH of three levels lane by lane (sceneIntersectUniform).
-constexpr uint32_t kSmallTriangles = 64, kSmallMeshTriangles = 16;
+// (measured on configs[1] with its two boxes at 18 triangles each: 580 Msamples/s through the per-lane BVH2 walk, 759 from this
+// table, 813-817 at 12 triangles with either limit: DESIGN 4 "threshold edges")
+#ifndef ZYG_SMALL_TRIANGLES
+#define ZYG_SMALL_TRIANGLES 128
+#endif
+#ifndef ZYG_SMALL_MESH_TRIANGLES
+#define ZYG_SMALL_MESH_TRIANGLES 48
+#endif
+constexpr uint32_t kSmallTriangles = ZYG_SMALL_TRIANGLES, kSmallMeshTriangles = ZYG_SMALL_MESH_TRIANGLES;
 
 struct DScene {
     TlasEntry            solid_table[kUniformProps];  // cheap shapes first; num_solid_table = 0: not available
     TlasEntry            unocc_table[4];              // the unoccluding tree's single leaf, in leaf order; 0: not available
     float4               small_tris[3 * kSmallTriangles];  // a, b, c per triangle, mesh (= leaf) order
     uint32_t             num_solid_table, num_unocc_table;
-    uint32_t             first_large;  // solid_table[first_large ..]: the meshes of kWideBlasMinTriangles triangles or more (they come last)
+    uint32_t             first_large;  // solid_table[first_large ..]: the meshes of kMeshKernelMinTriangles triangles or more (they come last)
     const ZygpuProp*     props;
     // animated props (ZygpuSceneDesc.keyframes): 3 float4 per keyframe (position, scale, rotation quaternion); prop_frames[p] =
     // first keyframe or kNull; null pointers: no prop is animated
@@ -721,61 +729,54 @@ ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
 }
 
 // The walks of the quantised nodes one step at a time, for the kernels whose lanes fetch a new ray when theirs is done
-// (wavefront.hpp wf_shadow_u, wf_mesh_closest).
+// (wavefront.hpp wf_shadow_u, wf_mesh_closest): a step tests one node's four children, or one leaf's triangles.
 enum : int { kWalkRunning = 0, kWalkHit = 1, kWalkDone = 2 };
 
-// Lanes at an inner node and lanes at a leaf run different code, so a wave that serves both at every step executes both at a
-// fraction of its lanes (measured: 30 % lane utilisation in the any-hit kernel, a leaf's triangle loop being as long as a node's
-// four box tests and one lane in four being at a leaf).  The walks therefore come in two halves: nodeStep() for the lanes at an
-// inner node, triangleStep() tests ONE triangle for the lanes at a leaf, and the kernel decides which half the wave runs next
-// (a few node steps in a row while most lanes are at nodes; the leaf half once enough lanes wait at one).
 struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
     WideStack<false> stack;
-    uint32_t         cur = 0, cur_count = 0;  // an inner node (count 0), or the triangles [cur, cur + cur_count) of a leaf
+    uint32_t         cur = 0, cur_count = 0;
     ZD void start() {
         stack.sp = 0;
         cur = 0;
         cur_count = 0;
     }
-    ZD bool atNode() const { return 0 == cur_count; }
-    ZD int  pop() {
+    ZD int step(const DMesh& mesh, const Ray& ray) {
         float unused = 0.f;
+        if (0 == cur_count) {
+            const Node4q n = Node4q::load(mesh.nodes4q, cur);
+            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
+            const bool   h0 = FLT_MAX != n.test<0>(ray, r0, n0), h1 = FLT_MAX != n.test<1>(ray, r1, n1);
+            const bool   h2 = FLT_MAX != n.test<2>(ray, r2, n2), h3 = FLT_MAX != n.test<3>(ray, r3, n3);
+            bool         have = false;
+            uint32_t     nr = 0, nc = 0;
+            auto         take = [&](bool h, uint32_t r, uint32_t c) {
+                if (!h) return;
+                if (have) stack.push(nr, nc, 0.f);
+                nr = r;
+                nc = c;
+                have = true;
+            };
+            take(h3, r3, n3);
+            take(h2, r2, n2);
+            take(h1, r1, n1);
+            take(h0, r0, n0);
+            if (have) {
+                cur = nr;
+                cur_count = nc;
+            } else {
+                if (0 == stack.sp) return kWalkDone;
+                stack.pop(cur, cur_count, unused);
+            }
+            return kWalkRunning;
+        }
+        for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
+            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            float    t, u, v;
+            if (triangleIntersect(ray, a, b, c, t, u, v)) return kWalkHit;
+        }
         if (0 == stack.sp) return kWalkDone;
         stack.pop(cur, cur_count, unused);
         return kWalkRunning;
-    }
-    ZD int nodeStep(const DMesh& mesh, const Ray& ray) {
-        const Node4q n = Node4q::load(mesh.nodes4q, cur);
-        uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
-        const bool   h0 = FLT_MAX != n.test<0>(ray, r0, n0), h1 = FLT_MAX != n.test<1>(ray, r1, n1);
-        const bool   h2 = FLT_MAX != n.test<2>(ray, r2, n2), h3 = FLT_MAX != n.test<3>(ray, r3, n3);
-        bool         have = false;
-        uint32_t     nr = 0, nc = 0;
-        auto         take = [&](bool h, uint32_t r, uint32_t c) {
-            if (!h) return;
-            if (have) stack.push(nr, nc, 0.f);
-            nr = r;
-            nc = c;
-            have = true;
-        };
-        take(h3, r3, n3);
-        take(h2, r2, n2);
-        take(h1, r1, n1);
-        take(h0, r0, n0);
-        if (have) {
-            cur = nr;
-            cur_count = nc;
-            return kWalkRunning;
-        }
-        return pop();
-    }
-    ZD int triangleStep(const DMesh& mesh, const Ray& ray) {
-        const f3 a = xyz(mesh.tri_verts[3 * cur]), b = xyz(mesh.tri_verts[3 * cur + 1]), c = xyz(mesh.tri_verts[3 * cur + 2]);
-        float    t, u, v;
-        if (triangleIntersect(ray, a, b, c, t, u, v)) return kWalkHit;
-        cur += 1;
-        cur_count -= 1;
-        return 0 == cur_count ? pop() : kWalkRunning;
     }
 };
 
@@ -787,8 +788,7 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
         cur = 0;
         cur_count = 0;
     }
-    ZD bool atNode() const { return 0 == cur_count; }
-    ZD int  pop(const Ray& ray) {
+    ZD bool pop(const Ray& ray) {
         while (stack.sp > 0) {
             uint32_t r, n;
             float    dist;
@@ -796,15 +796,18 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
             if (dist <= ray.max_t) {
                 cur = r;
                 cur_count = n;
-                return kWalkRunning;
+                return true;
             }
         }
-        return kWalkDone;
+        return false;
     }
-    ZD int nodeStep(const DMesh& mesh, const Ray& ray) {
-        const Node4q n = Node4q::load(mesh.nodes4q, cur);
-        uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
-        float        t0 = n.test<0>(ray, r0, n0), t1 = n.test<1>(ray, r1, n1), t2 = n.test<2>(ray, r2, n2), t3 = n.test<3>(ray, r3, n3);
+    // `found(triangle, t, u, v)` for every hit nearer than the ray's end
+    template <typename Found>
+    ZD int step(const DMesh& mesh, Ray& ray, Found&& found) {
+        if (0 == cur_count) {
+            const Node4q n = Node4q::load(mesh.nodes4q, cur);
+            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
+            float        t0 = n.test<0>(ray, r0, n0), t1 = n.test<1>(ray, r1, n1), t2 = n.test<2>(ray, r2, n2), t3 = n.test<3>(ray, r3, n3);
 #define ZYG_CSWAP(i, j)                        \
     if (t##j < t##i) {                         \
         const float    tt = t##i;              \
@@ -812,34 +815,31 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
         t##i = t##j, r##i = r##j, n##i = n##j; \
         t##j = tt, r##j = rr, n##j = nn;       \
     }
-        ZYG_CSWAP(0, 1)
-        ZYG_CSWAP(2, 3)
-        ZYG_CSWAP(0, 2)
-        ZYG_CSWAP(1, 3)
-        ZYG_CSWAP(1, 2)
+            ZYG_CSWAP(0, 1)
+            ZYG_CSWAP(2, 3)
+            ZYG_CSWAP(0, 2)
+            ZYG_CSWAP(1, 3)
+            ZYG_CSWAP(1, 2)
 #undef ZYG_CSWAP
-        if (FLT_MAX != t3) stack.push(r3, n3, t3);
-        if (FLT_MAX != t2) stack.push(r2, n2, t2);
-        if (FLT_MAX != t1) stack.push(r1, n1, t1);
-        if (FLT_MAX != t0) {
-            cur = r0;
-            cur_count = n0;
-            return kWalkRunning;
+            if (FLT_MAX != t3) stack.push(r3, n3, t3);
+            if (FLT_MAX != t2) stack.push(r2, n2, t2);
+            if (FLT_MAX != t1) stack.push(r1, n1, t1);
+            if (FLT_MAX != t0) {
+                cur = r0;
+                cur_count = n0;
+                return kWalkRunning;
+            }
+            return pop(ray) ? kWalkRunning : kWalkDone;
         }
-        return pop(ray);
-    }
-    // `found(triangle, t, u, v)` for a hit nearer than the ray's end
-    template <typename Found>
-    ZD int triangleStep(const DMesh& mesh, Ray& ray, Found&& found) {
-        const f3 a = xyz(mesh.tri_verts[3 * cur]), b = xyz(mesh.tri_verts[3 * cur + 1]), c = xyz(mesh.tri_verts[3 * cur + 2]);
-        float    t, u, v;
-        if (triangleIntersect(ray, a, b, c, t, u, v)) {
-            ray.max_t = t;
-            found(cur, t, u, v);
+        for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
+            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            float    t, u, v;
+            if (triangleIntersect(ray, a, b, c, t, u, v)) {
+                ray.max_t = t;
+                found(i, t, u, v);
+            }
         }
-        cur += 1;
-        cur_count -= 1;
-        return 0 == cur_count ? pop(ray) : kWalkRunning;
+        return pop(ray) ? kWalkRunning : kWalkDone;
     }
 };
 
@@ -1264,7 +1264,7 @@ ZD void tableClosestBeforeLargeMeshes(const DScene& s, Ray& ray, uint32_t depth_
             }
         } else {
             Ray local = worldToObjectRay(trafo, ray);
-            found = meshIntersect<false, false>(s.meshes[e.mesh], local, h, none);
+            found = meshIntersect<false, true>(s.meshes[e.mesh], local, h, none);
         }
         if (found) {
             hit.t = h.t;
@@ -1298,7 +1298,7 @@ ZD bool tableBlocksBeforeLargeMeshes(const DScene& s, const Ray& ray) {
             }
         } else {
             Ray local = worldToObjectRay(trafo, ray);
-            blocked = meshIntersectP<false, false>(s.meshes[e.mesh], local, none);
+            blocked = meshIntersectP<false, true>(s.meshes[e.mesh], local, none);  // (only the wide-BLAS instantiations call this)
         }
     }
     return blocked;

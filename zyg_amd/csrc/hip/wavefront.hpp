@@ -1832,16 +1832,7 @@ __global__ void __launch_bounds__(256) wf_shadow(Params P, uint32_t round) {
 #define ZYG_SHADOW_U_REFILL 16
 #endif
 #ifndef ZYG_SHADOW_U_STEPS
-#define ZYG_SHADOW_U_STEPS 4  // rounds of (node half, leaf half) between two looks at the number of idle lanes
-#endif
-#ifndef ZYG_WALK_NODE_BURST
-#define ZYG_WALK_NODE_BURST 4  // node steps in a row ...
-#endif
-#ifndef ZYG_WALK_NODE_MIN
-#define ZYG_WALK_NODE_MIN 32   // ... while at least this many lanes are at an inner node
-#endif
-#ifndef ZYG_WALK_LEAF_MIN
-#define ZYG_WALK_LEAF_MIN 20   // the leaf half runs once this many lanes wait at a leaf (or no lane is at a node)
+#define ZYG_SHADOW_U_STEPS 8
 #endif
 template <bool WIDE>  // (a template so that only the unit that instantiates it emits it)
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u(Params P, uint32_t round) {
@@ -1892,8 +1883,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u
         }
 #pragma unroll 1
         for (int it = 0; it < ZYG_SHADOW_U_STEPS; ++it) {
-            // the outcome of a lane's half step
-            auto after = [&](int r) {
+            if (have) {
+                const int r = walk.step(s.meshes[s.solid_table[entry].mesh], local);
                 if (kWalkHit == r) {
                     P.pool.vis[slot] = 0u;
                     have = false;
@@ -1902,24 +1893,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u
                     have = nextMesh();
                     if (!have) P.pool.vis[slot] = 1u;
                 }
-            };
-            // node half: at least once if a lane is at a node, again while most of the wave is
-#pragma unroll 1
-            for (int burst = 0; burst < ZYG_WALK_NODE_BURST; ++burst) {
-                const bool     at_node = have && walk.atNode();
-                const uint32_t num = uint32_t(__popcll(__ballot(at_node)));
-                if (0 == num || (burst > 0 && num < uint32_t(ZYG_WALK_NODE_MIN))) break;
-                if (at_node) after(walk.nodeStep(s.meshes[s.solid_table[entry].mesh], local));
             }
-            // leaf half, a triangle at a time: once enough lanes wait at a leaf, or nothing else is left to do
-#pragma unroll 1
-            for (;;) {
-                const bool     at_leaf = have && !walk.atNode();
-                const uint32_t num = uint32_t(__popcll(__ballot(at_leaf)));
-                if (0 == num || (num < uint32_t(ZYG_WALK_LEAF_MIN) && 0 != __ballot(have && walk.atNode()))) break;
-                if (at_leaf) after(walk.triangleStep(s.meshes[s.solid_table[entry].mesh], local));
-            }
-            if (0 == __ballot(have)) break;
         }
     }
 }
@@ -1987,38 +1961,22 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh
         }
 #pragma unroll 1
         for (int it = 0; it < ZYG_SHADOW_U_STEPS; ++it) {
-            auto after = [&](int r) {
+            if (have) {
+                const uint32_t prop = s.solid_table[entry].prop;
+                const int      r = walk.step(s.meshes[s.solid_table[entry].mesh], local, [&](uint32_t triangle, float t, float u, float v) {
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.primitive = triangle;
+                    hit.prop = prop;
+                    world.max_t = t;
+                });
                 if (kWalkDone == r) {
                     entry += 1;
                     have = nextMesh();
                     if (!have) finish();
                 }
-            };
-#pragma unroll 1
-            for (int burst = 0; burst < ZYG_WALK_NODE_BURST; ++burst) {
-                const bool     at_node = have && walk.atNode();
-                const uint32_t num = uint32_t(__popcll(__ballot(at_node)));
-                if (0 == num || (burst > 0 && num < uint32_t(ZYG_WALK_NODE_MIN))) break;
-                if (at_node) after(walk.nodeStep(s.meshes[s.solid_table[entry].mesh], local));
             }
-#pragma unroll 1
-            for (;;) {
-                const bool     at_leaf = have && !walk.atNode();
-                const uint32_t num = uint32_t(__popcll(__ballot(at_leaf)));
-                if (0 == num || (num < uint32_t(ZYG_WALK_LEAF_MIN) && 0 != __ballot(have && walk.atNode()))) break;
-                if (at_leaf) {
-                    const uint32_t prop = s.solid_table[entry].prop;
-                    after(walk.triangleStep(s.meshes[s.solid_table[entry].mesh], local, [&](uint32_t triangle, float t, float u, float v) {
-                        hit.t = t;
-                        hit.u = u;
-                        hit.v = v;
-                        hit.primitive = triangle;
-                        hit.prop = prop;
-                        world.max_t = t;
-                    }));
-                }
-            }
-            if (0 == __ballot(have)) break;
         }
     }
 }

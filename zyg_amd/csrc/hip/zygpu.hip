@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -474,6 +475,7 @@ struct ZygpuContext {
     // the scenes and settings its instantiations cover (prop tables, in-place NEE, single-sample lights)
     bool          fuse_tick = false;
     bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
+    bool          huge_mesh = false;   // a mesh of kMeshKernelMinTriangles or more: wf_scatter_h + wf_shadow_u (option mesh_kernels)
     // option "mesh_kernels" (default on): in the relaxed units the walks of the large meshes run in persistent kernels of their
     // own whose lanes fetch a new ray when theirs is done: wf_scatter_h suspends the vertices whose shadow ray enters a large mesh's
     // bounds, wf_shadow_u walks the meshes for them
@@ -496,7 +498,27 @@ struct ZygpuContext {
 
 namespace {
 
-constexpr uint32_t kWideBlasMinTriangles = 4096;
+// Thresholds on a mesh's triangle count (measured with tools/threshold_edges.sh, DESIGN 4 "threshold edges"):
+//   <= kSmallMeshTriangles (dscene.hpp, 48): tested triangle by triangle from the constant block (relaxed units)
+//   >= kWideBlasMinTriangles (64): the scene runs the wide-BLAS kernel instantiations and extension rays that enter the mesh's
+//      bounds are grouped at the back of their queue (108-triangle boxes: 527 -> 607 Msamples/s, 972: 432 -> 527)
+//   >= kMeshKernelMinTriangles (4096): its shadow walks go to wf_shadow_u (wf_scatter_h suspends the vertex; for the small
+//      boxes that costs more than their short walks: 607 -> 524)
+// ZYG_WIDE_MIN_TRIANGLES / ZYG_MESH_KERNEL_MIN_TRIANGLES override them (development).
+uint32_t thresholdFromEnv(const char* name, uint32_t fallback) {
+    const char* e = std::getenv(name);
+    return e ? uint32_t(std::max(1, std::atoi(e))) : fallback;
+}
+uint32_t wideBlasMinTriangles() {
+    static const uint32_t value = thresholdFromEnv("ZYG_WIDE_MIN_TRIANGLES", 64u);
+    return value;
+}
+uint32_t meshKernelMinTriangles() {
+    static const uint32_t value = std::max(wideBlasMinTriangles(), thresholdFromEnv("ZYG_MESH_KERNEL_MIN_TRIANGLES", 4096u));
+    return value;
+}
+#define kWideBlasMinTriangles wideBlasMinTriangles()
+#define kMeshKernelMinTriangles meshKernelMinTriangles()
 
 // queue arrays hold one entry per path, rounded up to whole blocks
 uint32_t queueEntries(size_t paths) { return uint32_t((paths + 255) / 256 * 256); }
@@ -859,7 +881,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
     }
 
-    c->large_mesh = false;
+    c->large_mesh = c->huge_mesh = false;
     bool wide_ok = true;
     std::vector<DMesh> meshes(d->num_meshes);
     for (uint32_t i = 0; i < d->num_meshes; ++i) {
@@ -875,6 +897,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
         ok = m.upload(reinterpret_cast<const float4*>(hm.nodes), size_t(hm.num_nodes) * 2, &dm.nodes);
         if (hm.num_triangles >= kWideBlasMinTriangles) c->large_mesh = true;
+        if (hm.num_triangles >= kMeshKernelMinTriangles) c->huge_mesh = true;
         {  // bvh4.hpp: the same tree, four children per 128 B node; what the relaxed-arithmetic units walk
             const std::vector<zyg::Bvh4Slot> wide = zyg::collapse4(hm.nodes, hm.num_nodes);
             ok = ok && !wide.empty() && m.upload(reinterpret_cast<const float4*>(wide.data()), wide.size() * 2, &dm.nodes4);
@@ -897,7 +920,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         ok = ok && m.upload(hm.primitive_mapping, hm.primitive_mapping ? hm.num_triangles : 0, &dm.primitive_mapping);
         if (!ok) return -1;
     }
-    if (!wide_ok) c->large_mesh = false;
+    if (!wide_ok) c->large_mesh = c->huge_mesh = false;
     if (!m.upload(meshes.data(), meshes.size(), &s.meshes)) return -1;
 
     for (uint32_t i = 0; i < d->num_infinite_props; ++i) {
@@ -1029,7 +1052,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         std::vector<std::pair<uint32_t, uint32_t>> mesh_props;  // (triangles, prop)
         for (uint32_t p = 0; p < d->num_props; ++p) {
             if (ZYGPU_SHAPE_TRIANGLE_MESH == d->props[p].shape && !(d->props[p].flags & ZYGPU_PROP_UNOCCLUDING) &&
-                d->meshes[d->props[p].mesh].num_triangles >= 4096)
+                d->meshes[d->props[p].mesh].num_triangles >= kWideBlasMinTriangles)
                 mesh_props.emplace_back(d->meshes[d->props[p].mesh].num_triangles, p);
         }
         std::sort(mesh_props.begin(), mesh_props.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
@@ -1096,7 +1119,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             for (uint32_t p : order) s.solid_table[s.num_solid_table++] = entry(p);
             s.first_large = s.num_solid_table;
             for (uint32_t k = 0; k < s.num_solid_table; ++k)
-                if (ZYGPU_SHAPE_TRIANGLE_MESH == s.solid_table[k].shape && d->meshes[s.solid_table[k].mesh].num_triangles >= kWideBlasMinTriangles) {
+                if (ZYGPU_SHAPE_TRIANGLE_MESH == s.solid_table[k].shape && d->meshes[s.solid_table[k].mesh].num_triangles >= kMeshKernelMinTriangles) {
                     s.first_large = k;  // sorted by size: the rest are large too
                     break;
                 }
@@ -1315,7 +1338,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         const bool plain_in_place = utlas && nee && c->nee_in_place && !c->multi_sample_lights && c->fuse_trace_shade;
         // option mesh_kernels: the large meshes' closest-hit walks run in wf_mesh_closest before the tick's wf_trace_shade; the camera
         // rays then go through the queue like every other tick's (wf_generate sorts them into its two ends)
-        const bool mesh_pass = wide && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
+        const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
         P.mesh_pass = mesh_pass ? 1u : 0u;
         if (mesh_pass) {
             HIP_OK(hipMemsetAsync(&c->ctl->mesh_fetch, 0, sizeof(uint32_t), c->stream));
@@ -1430,7 +1453,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 }
             });
             }
-            if (nee && c->nee_in_place && wide && relaxedUnits(c) && c->mesh_kernels && !c->multi_sample_lights) {
+            if (nee && c->nee_in_place && wide && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels && !c->multi_sample_lights) {
                 // wf_scatter_h: in place, but a vertex whose shadow ray has to walk a large mesh is suspended; wf_shadow_u walks
                 // the meshes for the round's suspended rays, the next launch takes the suspended vertices up again
                 timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_SUBST : K_SCATTER_H, grid.x, P, 0u); });

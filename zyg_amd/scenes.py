@@ -544,7 +544,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             ids["meshes"].append(p)
     for k in range(extra_props):  # plaques a hair in front of the back wall, facing the camera
         p = engine.prop(RECTANGLE, [red if k % 2 else green])
-        engine.transformation(p, trafo((-1, 0, 0), (0, 1, 0), (0.18, 0.18, 1), (-0.8 + 1.6 * (k % 6) / 5.0, 0.4 + 0.45 * (k // 6), 0.995)))
+        engine.transformation(p, trafo((-1, 0, 0), (0, 1, 0), (0.18, 0.18, 1), (-0.8 + 1.6 * (k % 6) / 5.0, 0.3 + 0.3 * (k // 6), 0.995)))
         ids["walls"].append(p)
     if mesh is not None:
         idx, pos, nrm, uv = mesh
