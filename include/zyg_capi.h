@@ -98,6 +98,13 @@ uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity);
  * post-processor and exporters of cli/take_loader.zig:27-283, materials / entities / shapes of util/scene_loader.zig:115-702,
  * JSON and "SUB\0" binary meshes of shape_provider.zig:334-805.  0, or -1 with the reason in the log.  Host-only. */
 int32_t su_ext_load_take(const char* take_filename);
+/* Shadow catchers (the reference's scene loader only: util/scene_loader.zig:312-313 "shadow_catcher" -> Scene.propSetShadowCatcher,
+ * and 612-619 visibility.shadow_catcher_light; su_prop_set_visibility passes false for the latter, capi.zig:545-560).
+ * PathtracerMIS treats a hit on a shadow catcher as a hole onto the backplate, darkened where the shadow-catcher lights are
+ * occluded (pathtracer_mis.zig:56-70, 108-115, 248-276, 296-337; vertex.zig:252-266).  A light is created with the flag its prop
+ * has at that moment (scene.zig:344-372), so set the visibility before su_light_create. */
+int32_t su_ext_prop_set_shadow_catcher(uint32_t prop);
+int32_t su_ext_prop_set_visibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss, bool shadow_catcher_light);
 /* The Sky entity of the reference's scene loader (util/scene_loader.zig:262-263, 704-712 -> Scene.createSky; the reference's C
  * ABI has no entry for it): creates the sun (a Distant light) and the sky (a Canopy light) once, applies `parameters_json`
  * (Sky.setParameters, sky.zig:78-93: {"sun": {"rotation": [x, y, z]}, "turbidity" | "visibility", "albedo"}; NULL: the

@@ -813,6 +813,49 @@ def test_sky_entity(engine, oracle, integrator, variant):
     assert film[-8:, :, :3].mean() > 0.02  # a lit ground
 
 
+@pytest.mark.parametrize("integrator", ["PTMIS", "PTDL"])
+@pytest.mark.parametrize("variant", ["quad_light", "glass", "sky_entity"])
+def test_shadow_catcher(engine, oracle, integrator, variant):
+    """A shadow catcher under the objects, the sun and the sky as shadow-catcher lights (scene_loader.zig:312-313, 612-619).
+    PathtracerMIS (pathtracer_mis.zig:56-73, 106-115, 248-276, 296-337; vertex.zig:252-266): a camera ray on the catcher sees the
+    backplate's light through it, scaled per channel by occluded / unoccluded of what the shadow-catcher lights send there, and
+    leaves 1 - that ratio in alpha; light samples on the catcher are evaluated whether or not they are occluded; a path that reaches
+    the catcher after a bounce ends there.  The other integrators know nothing of it (the prop just casts no shadow).  Film and
+    alpha plane are the oracle's bits; quad_light: with an ordinary light beside the shadow-catcher lights; glass: split paths."""
+    w, h, spp = 96, 54, 4
+    kw = dict(integrator=integrator, material="substitute", shadow_catcher=True, alpha_transparency=True, max_depth=6)
+    if "sky_entity" == variant:
+        kw["sky_entity"] = {"parameters": {"sun": {"rotation": [-50, 150, 0]}}, "tables": scenes.sky_tables(elevation_deg=50.0)}
+    else:
+        kw.update(sky="canopy", sky_map=scenes.sky_image(64, 64), sky_spectrum=(1.0, 1.0, 1.0), extra_quad_light="quad_light" == variant,
+                  showcase="glass" == variant)
+    scenes.outdoor(engine, w, h, spp, **kw)
+    engine.start_frame(0)
+    engine.render_iterations(spp)
+    engine.synchronize()
+    film = engine.download_film(w, h)
+    alpha = np.zeros((h, w), dtype=np.float32)
+    g = engine.lib
+    g.zygpu_download_film_alpha.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert g.zygpu_download_film_alpha(engine.context(), alpha.ctypes.data) == 0
+    sd = g.su_ext_scene_desc().contents
+    vd = g.su_ext_view_desc().contents
+    assert sd.props[[p for p in range(sd.num_props) if sd.props[p].flags & (1 << 11)][0]].shape == scenes.RECTANGLE
+    cpu_film, cpu_alpha = oracle_render_alpha(oracle, sd, vd, spp)
+    assert np.isfinite(film).all() and np.array_equal(film, cpu_film) and np.array_equal(alpha, cpu_alpha)
+    a = alpha / film[..., 3]
+    ground = a[h - 12:, :]
+    if "PTMIS" != integrator:
+        assert ground[:, :16].min() > 0.99  # an ordinary opaque ground (the left of the frame: no glass there)
+    elif "sky_entity" == variant:
+        # the Sky's lights are created before any visibility can name them shadow-catcher lights (sky.zig:53-76): nothing the catcher
+        # could weigh, so it is a plain hole onto the backplate
+        assert ground[-4:, :16].max() < 1e-6
+    else:
+        # lit by the sun -> (nearly) transparent; in the boxes' shadow -> alpha towards 1
+        assert ground.min() < 0.2 and ground.max() > 0.5, (ground.min(), ground.max())
+
+
 # ---------------------------------------------------------------- the relaxed-arithmetic units (zygpu option "precise" = 0)
 
 def _render_mode(product_lib, build, w, h, spp, precise):

@@ -129,8 +129,6 @@ _REFUSED = {
     "Scatterer": {"type": "Scatterer", "prototypes": []},
     "animation": {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"],
                   "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]}},
-    "shadow_catcher": {"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["grey"], "shadow_catcher": {}},
-    "shadow_catcher_light": {"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"], "visibility": {"shadow_catcher_light": True}},
 }
 
 
@@ -157,6 +155,29 @@ def test_unrendered_entities_and_keys_fail_the_load(product_lib, tmp_path, what)
         finally:
             e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
     assert any(level == 2 and what in text and "does not render" in text for level, text in messages), messages
+
+
+def test_shadow_catcher_keys(product_lib, tmp_path):
+    """"shadow_catcher" on an entity (scene_loader.zig:312-313 -> Prop.setShadowCatcher: the prop casts no shadow) and
+    visibility.shadow_catcher_light (612-619), which a light carries from the moment it is created (scene.zig:344-372)."""
+    scene = {"materials": [{"name": "grey", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5]}}},
+                           {"name": "lamp", "rendering": {"Light": {"emittance": {"spectrum": [5, 5, 5]}}}}],
+             "entities": [{"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["grey"], "shadow_catcher": {},
+                           "transformation": {"rotation": [90, 0, 0], "scale": [8, 8, 1]}},
+                          {"type": "Light", "shape": {"type": "Distant"}, "materials": ["lamp"], "visibility": {"shadow_catcher_light": True},
+                           "transformation": {"rotation": [-60, 0, 0], "scale": [0.05, 0.05, 0.05]}},
+                          {"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"], "transformation": {"position": [0, 3, 0]}}]}
+    with open(tmp_path / "s.scene", "w") as f:
+        json.dump(scene, f)
+    with open(tmp_path / "s.take", "w") as f:
+        json.dump({"scene": "s.scene", "camera": {"Perspective": {"resolution": [8, 8], "transformation": {"position": [0, 1, -4]}}}}, f)
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(str(tmp_path / "s.take").encode()) == 0
+        sd, _ = e.compile()
+        catchers = [p for p in range(sd.num_props) if sd.props[p].flags & (1 << 11)]
+        assert len(catchers) == 1 and sd.props[catchers[0]].shape == scenes.RECTANGLE
+        flags = sorted((sd.props[sd.lights[i].prop].shape, sd.lights[i].shadow_catcher_light) for i in range(sd.num_lights))
+        assert flags == [(scenes.DISTANT, 1), (scenes.RECTANGLE, 0)]
 
 
 def test_sky_entity_loads(product_lib, tmp_path):

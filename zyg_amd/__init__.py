@@ -378,6 +378,19 @@ class Engine:
                 raise RuntimeError("su_ext_sky_tables failed")
         return sun
 
+    def shadow_catcher(self, prop):
+        """scene.propSetShadowCatcher (su_ext_prop_set_shadow_catcher): PathtracerMIS sees the backplate through the prop, darkened
+        where the shadow-catcher lights are occluded."""
+        self.lib.su_ext_prop_set_shadow_catcher.argtypes = [ctypes.c_uint32]
+        if self.lib.su_ext_prop_set_shadow_catcher(prop) != 0:
+            raise RuntimeError("su_ext_prop_set_shadow_catcher failed")
+
+    def shadow_catcher_light(self, prop, in_camera=True, in_reflection=True):
+        """The prop's visibility with shadow_catcher_light = true (scene_loader.zig:612-619); call before light(prop)."""
+        self.lib.su_ext_prop_set_visibility.argtypes = [ctypes.c_uint32] + [ctypes.c_bool] * 4
+        if self.lib.su_ext_prop_set_visibility(prop, in_camera, in_reflection, False, True) != 0:
+            raise RuntimeError("su_ext_prop_set_visibility failed")
+
     def visibility(self, prop, in_camera=True, in_reflection=True, in_sss=False):
         self.lib.su_prop_set_visibility(prop, int(in_camera), int(in_reflection), int(in_sss))
 

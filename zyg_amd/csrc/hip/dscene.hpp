@@ -83,13 +83,14 @@ struct TlasEntry {
 // The triangles of the scene's smallest meshes (at most kSmallMeshTriangles each, kSmallTriangles in all), in the constant
 // block beside the prop tables: the relaxed-arithmetic units test all of them, every lane of the wave the same triangle at the
 // same time with its vertices in SGPRs, instead of walking a BVH of three levels lane by lane (sceneIntersectUniform).
-// (measured on configs[1] with its two boxes at 18 triangles each: 580 Msamples/s through the per-lane BVH2 walk, 759 from this
-// table, 813-817 at 12 triangles with either limit: DESIGN 4 "threshold edges")
+// (measured on configs[1] with its two boxes at 18 triangles each: 580 Msamples/s through the per-lane BVH2 walk, 754-759 from
+// this table, 810-817 at 12 triangles with either limit; at 48 triangles the table's linear cost (516) is past what the wide BLAS
+// gives (605 at 108 triangles): the limit is 32, DESIGN 4 "threshold edges")
 #ifndef ZYG_SMALL_TRIANGLES
 #define ZYG_SMALL_TRIANGLES 128
 #endif
 #ifndef ZYG_SMALL_MESH_TRIANGLES
-#define ZYG_SMALL_MESH_TRIANGLES 48
+#define ZYG_SMALL_MESH_TRIANGLES 32
 #endif
 constexpr uint32_t kSmallTriangles = ZYG_SMALL_TRIANGLES, kSmallMeshTriangles = ZYG_SMALL_MESH_TRIANGLES;
 
@@ -136,6 +137,7 @@ struct DScene {
     float                specular_threshold;
     uint32_t             num_solid_nodes, num_unocc_nodes;
     uint32_t             num_props, num_solid_indices, num_unocc_indices;
+    uint32_t             has_catcher;  // a prop is a shadow catcher (ZYGPU_PROP_SHADOW_CATCHER): PathtracerMIS' bookkeeping for it
     float4               heavy_aabbs[16];  // world bounds (2 each) of the up to 8 largest mesh props: queue grouping hint
     uint32_t             num_heavy;
 };

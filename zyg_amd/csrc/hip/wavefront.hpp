@@ -29,7 +29,9 @@ enum : uint32_t {
     ST_SINGULAR = 1u << 2,
     ST_SPECULAR = 1u << 3,
     ST_TRANSLUCENT = 1u << 4,
-    ST_STARTED_SPECULAR = 1u << 5
+    ST_STARTED_SPECULAR = 1u << 5,
+    ST_FROM_CATCHER = 1u << 6,       // vertex.state.from_shadow_catcher (vertex.zig:26)
+    ST_CATCHER_IN_CAMERA = 1u << 7   // vertex.state.shadow_catcher_in_camera (vertex.zig:27)
 };
 
 // The records every stage touches live interleaved, one 256 B block (two 128 B lines) per path slot, instead of in one array
@@ -135,6 +137,12 @@ struct Pool {  // 16 B records, indexed by path slot
     float2*   rec_uv;   // per vertex: the fragment's uv, for the textures of an extended Substitute
     uint32_t* pstate;   // per slot: [0:7] vertices in flight, [8:15] children created for the next level
     float*    transp;   // per slot: Pool.transparency[3], the alpha sum over terminated vertices
+    // scenes with a shadow catcher only (else null), PathtracerMIS: per vertex what a catcher on the path has seen (vertex.zig:57-59),
+    // per slot Pool.transparency's colour (the backplate light a catcher lets through, vertex.zig:252-266)
+    float4*   sc_occ;
+    float4*   sc_unocc;
+    float4*   sc_emis;
+    float4*   transp_rgb;
 };
 
 constexpr uint32_t kPoolVertices = 4;  // Vertex.Pool.NumVertices
@@ -525,13 +533,13 @@ ZD void loadHead(const Params& P, uint32_t vertex, PathHead& h) {
     h.smp.sobol_kind = ZYGPU_SAMPLER_SOBOL == c_view.v.sampler;
     h.depth_surface = (meta >> 3) & 31u;
     h.vdepth = (meta >> 8) & 31u;
-    h.flags = (meta >> 13) & 63u;
+    h.flags = (meta >> 13) & 255u;
     h.nee = a.w;
     h.smp.use_primary = h.depth_surface < 3;  // worker.zig:201-207
 }
 
 ZD uint32_t packMeta(const PathHead& h) {
-    return (h.smp.dimension & 7u) | ((h.depth_surface & 31u) << 3) | ((h.vdepth & 31u) << 8) | ((h.flags & 63u) << 13);
+    return (h.smp.dimension & 7u) | ((h.depth_surface & 31u) << 3) | ((h.vdepth & 31u) << 8) | ((h.flags & 255u) << 13);
 }
 
 // the samplers of a camera sample (POOL: shared by the vertices of the sample, so stored after every vertex)
@@ -685,16 +693,35 @@ ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags, 
 // POOL: a vertex ends without children: Pool.consume's bookkeeping for terminated vertices (vertex.zig:240-262; no shadow
 // catchers), done when the vertex ends instead of at the end of its level (same order: vertices end in index order).
 // The camera sample ends with its last vertex: result.direct[3] = 0 + transparency[3] (pathtracer_mis.zig:168-170)
-ZD void terminateVertex(const Params& P, uint32_t slot, f3 throughput, float split_weight, uint32_t flags) {
+ZD void terminateVertex(const Params& P, uint32_t slot, f3 throughput, float split_weight, uint32_t flags, uint32_t vertex = 0) {
     float alpha = P.pool.transp[slot];
-    alpha = (flags & ST_TRANSPARENT) ? alpha + mx((1.f - average3(throughput)) * split_weight, 0.f) : alpha + split_weight;
+    f3    through = S3(0.f);  // Pool.transparency's colour: only shadow catchers add to it
+    if (P.pool.sc_emis) {     // a scene with shadow catchers (vertex.zig:252-266); `vertex`: the ending vertex' records
+        through = xyz4(P.pool.transp_rgb[slot]);
+        const f3 emission = xyz4(P.pool.sc_emis[vertex]);
+        if (flags & ST_CATCHER_IN_CAMERA) {
+            const f3 o = xyz4(P.pool.sc_occ[vertex]), u = xyz4(P.pool.sc_unocc[vertex]);
+            const f3 ratio = mk3(o.x < u.x ? o.x / u.x : 1.f, o.y < u.y ? o.y / u.y : 1.f, o.z < u.z ? o.z / u.z : 1.f);
+            through = through + ratio * emission * S3(split_weight);
+            alpha = alpha + mx((1.f - average3(ratio)) * split_weight, 0.f);
+        } else if (flags & ST_TRANSPARENT) {
+            alpha = alpha + mx((1.f - average3(throughput)) * split_weight, 0.f);
+        } else {
+            through = through + emission * S3(split_weight);
+            alpha = alpha + split_weight;
+        }
+        P.pool.transp_rgb[slot] = f4(through);
+    } else {
+        alpha = (flags & ST_TRANSPARENT) ? alpha + mx((1.f - average3(throughput)) * split_weight, 0.f) : alpha + split_weight;
+    }
     P.pool.transp[slot] = alpha;
     const uint32_t st = P.pool.pstate[slot] - 1u;
     P.pool.pstate[slot] = st;
     if (0 == (st & 255u)) {
         if (P.pixel_pcg) P.pixel_pcg[slot] = P.pool.pcg[slot];  // one-shot: storeSamplers ran just before (shared samplers)
         const f3 e = clampColor(xyz4(P.pool.emission[slot]), c_view.v.clamp_emission);
-        const f3 d = clampColor(xyz4(P.pool.direct[slot]), c_view.v.clamp_direct);
+        // result.direct += vertices.transparency (pathtracer_mis.zig:168-170), then the sensor's clamp
+        const f3 d = clampColor(P.pool.sc_emis ? xyz4(P.pool.direct[slot]) + through : xyz4(P.pool.direct[slot]), c_view.v.clamp_direct);
         const f3 i = clampColor(xyz4(P.pool.indirect[slot]), c_view.v.clamp_indirect);
         P.stage_color[slot] = f4(e + d + i, 0.f + alpha);
     }
@@ -869,6 +896,10 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
             P.pool.med1[slot] = make_uint4(0u, 0u, 0u, 0u);  // .w: probe.wavelength = 0
             P.pool.pstate[slot] = 1u;
             P.pool.transp[slot] = 0.f;
+            if (P.pool.sc_emis) {  // Vertex.init (vertex.zig:78-80), Pool.start (vertex.zig:229)
+                P.pool.sc_emis[slot] = P.pool.sc_occ[slot] = P.pool.sc_unocc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                P.pool.transp_rgb[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         clearAccumulators<!POOL>(P, slot);
@@ -1130,8 +1161,12 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
 // the infinite props a ray reaches when it leaves the scene: Context.propIntersect + the shape's intersect / fragment
 // (prop.zig:163-197; distant.zig:22-74, dome.zig:26-56, canopy.zig:27-58), then Vertex.evaluateRadiance;
 // `only_non_lights`: PathtracerDL's filter
+// `catcher` (PathtracerMIS on or behind a shadow catcher, pathtracer_mis.zig:303-337; `ray` then reaches to RayMaxT whatever was
+// hit): what a shadow-catcher light sends goes to catcher[1] (unoccluded) and, if the ray really left the scene (`escaped`), to
+// catcher[0] (occluded) as well, instead of into the returned emission
 template <bool STATS>
-ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampler& smp, bool only_non_lights, Counters& cnt) {
+ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampler& smp, bool only_non_lights, Counters& cnt,
+                       f3* catcher = nullptr, bool escaped = true) {
     f3       energy = S3(0.f);
     const f3 wo = -ray.direction;
     for (uint32_t i = 0; i < s.num_infinite_props; ++i) {
@@ -1165,7 +1200,13 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
         frag.b = frag.trafo.r1;
         frag.part = 0;
         if (only_non_lights && !((v.flags & ST_SINGULAR) || kNull == s.light_ids[prop.parts_start])) continue;
-        energy = energy + evaluateRadiance<true>(s, v, wo, frag, smp);
+        const f3 local_energy = evaluateRadiance<true>(s, v, wo, frag, smp);
+        if (catcher && (prop.flags & ZYGPU_PROP_SHADOW_CATCHER_LIGHT)) {
+            if (escaped) catcher[0] = catcher[0] + local_energy;  // "The light was not occluded"
+            catcher[1] = catcher[1] + local_energy;               // otherwise: "occluded, but we forced a hit"
+        } else {
+            energy = energy + local_energy;
+        }
     }
     return energy;
 }
@@ -1252,6 +1293,10 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         // infinite props: PathtracerMIS looks at them when the ray left the scene, the other two always walk the list
         const bool infinite = s.num_infinite_props > 0 && (ZYGPU_INTEGRATOR_PTMIS != kind || (!has_hit && kRayMaxT == ro.w));
         defer = connectsLights(h.flags) && (emissive || 0 != ucount || infinite);
+        // a scene with shadow catchers (PathtracerMIS): a vertex on a catcher, or the one behind it, has the complete pass decide
+        if (POOL && s.has_catcher && ZYGPU_INTEGRATOR_PTMIS == kind &&
+            ((h.flags & ST_FROM_CATCHER) || (has_hit && (s.props[hit_prop].flags & ZYGPU_PROP_SHADOW_CATCHER))))
+            defer = true;
     }
     // PRE == 1: the records generatePath<KEEP> left to this point (Vertex.init, vertex.zig:67-85: origin = the ray's, geo_n = 0,
     // the sums 0)
@@ -1286,7 +1331,9 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     tm.mark(0);
 
     // ---- connectLight (pathtracer.zig:110-143, pathtracer_dl.zig:173-207, pathtracer_mis.zig:280-341)
-    f3 energy = S3(0.f);
+    f3   energy = S3(0.f);
+    bool shadow_catcher = false;                    // PathtracerMIS: the hit is on a shadow catcher
+    f3   catcher_light[2] = {S3(0.f), S3(0.f)};     // this_light.occluded / .unoccluded
     if (HEAVY && connectsLights(h.flags)) {
         VertexIn v;
         v.vorigin = xyz4(P.pool.vorigin[slot]);
@@ -1313,8 +1360,21 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             tm.mark(1);
             energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
             tm.mark(2);
-            // RayMaxT == max_t (pathtracer_mis.zig:313): not for a ray that ended at its medium's bounds
-            if (MESHL && !has_hit && kRayMaxT == ray.max_t) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
+            if (POOL && MESHL && s.has_catcher) {
+                // pathtracer_mis.zig:296-337: on a shadow catcher, or behind one, the infinite props are looked at as if nothing had
+                // been hit (the probe's max_t is RayMaxT for the loop)
+                shadow_catcher = has_hit && 0 != (s.props[hit_prop].flags & ZYGPU_PROP_SHADOW_CATCHER);
+                const bool handle = (h.flags & ST_FROM_CATCHER) || shadow_catcher;
+                const bool escaped = kRayMaxT == ray.max_t;
+                if (handle || escaped) {
+                    Ray far = ray;
+                    far.max_t = kRayMaxT;
+                    energy = energy + infiniteEmission<STATS>(s, v, far, h.smp, false, cnt, handle ? catcher_light : nullptr, escaped);
+                }
+            } else if (MESHL && !has_hit && kRayMaxT == ray.max_t) {
+                // RayMaxT == max_t (pathtracer_mis.zig:313): not for a ray that ended at its medium's bounds
+                energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
+            }
         }
     }
     const float4 thr4 = PRE ? pre_thr : float4(P.pool.thr[slot]);
@@ -1330,6 +1390,23 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     }
     nanTrace(P, energy, 8);
     nanTrace(P, throughput, 9);
+    if (HEAVY && POOL && MESHL && mis && s.has_catcher) {
+        // pathtracer_mis.zig:56-73.  (connectLight may have returned early for a specular vertex: then shadow_catcher is still the
+        // hit's, decided here)
+        shadow_catcher = has_hit && 0 != (s.props[hit_prop].flags & ZYGPU_PROP_SHADOW_CATCHER);
+        const f3 split_throughput = throughput * S3(split_weight);
+        if (shadow_catcher) {
+            P.pool.sc_emis[slot] = f4(xyz4(P.pool.sc_emis[slot]) + split_throughput * catcher_light[1]);
+            if (!(h.flags & ST_TRANSPARENT)) {  // `continue`: the vertex ends here, nothing of it reaches the result
+                storeSamplers(P, ps, h);
+                terminateVertex(P, ps, throughput, split_weight, h.flags, slot);
+                return;
+            }
+        } else {
+            P.pool.sc_occ[slot] = f4(xyz4(P.pool.sc_occ[slot]) + split_throughput * catcher_light[0]);
+            P.pool.sc_unocc[slot] = f4(xyz4(P.pool.sc_unocc[slot]) + split_throughput * catcher_light[1]);
+        }
+    }
     // split_throughput = vertex.throughput * split_weight (pathtracer_mis.zig:61-62)
     ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * energy, h.depth_surface, mis ? 2u : 1u,
               0 == h.depth_surface, 0 != (h.flags & ST_SINGULAR));
@@ -1390,7 +1467,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     if (done) {
         if (POOL) {
             storeSamplers(P, ps, h);  // the sample's other vertices go on with these samplers
-            terminateVertex(P, ps, throughput, split_weight, h.flags);
+            terminateVertex(P, ps, throughput, split_weight, h.flags, slot);
         } else if (1 == PRE) {
             // a path that ends at its first vertex in this pass has gathered nothing (a hit with emission went to the second
             // pass): Sensor.addSample's colour is 0, and none of the path's records was ever written
@@ -2232,6 +2309,12 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         max_splits = m - ((h.flags & ST_PRIMARY) ? 0u : min(h.depth_surface, m - 1u));
     }
 
+    // PathtracerMIS on a shadow catcher (pathtracer_mis.zig:56, 106-115, 248-276): an occluded light sample is evaluated with tr = 0
+    // instead of dropped, and what the shadow-catcher lights send is kept apart, with and without the occluders
+    const bool catcher_scene = POOL && MESHL && mis && 0 != s.has_catcher;
+    const bool shadow_catcher = catcher_scene && 0 != (s.props[P.pool.hit_prop[slot]].flags & ZYGPU_PROP_SHADOW_CATCHER);
+    f3         catcher_occluded = S3(0.f), catcher_unoccluded = S3(0.f);
+
     // ---- sampleLights / evaluateLight (pathtracer_mis.zig:174-278, pathtracer_dl.zig:100-167)
     if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
         const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
@@ -2253,7 +2336,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             const ZygpuMaterial& lm = s.materials[s.material_ids[s.props[light.prop].parts_start + light.part]];
             // PathtracerDL samples its lights with threshold 0 (pathtracer_dl.zig:139-167)
             const float sample_threshold = mis ? nee_threshold : 0.f;
-            f3          occluded = S3(0.f);
+            f3          occluded = S3(0.f), unoccluded = S3(0.f);
 
             // evaluateLight's loop body for one light sample (pathtracer_mis.zig:248-272 / pathtracer_dl.zig:150-166)
             const uint32_t light_shape = MESHL ? s.props[light.prop].shape : uint32_t(ZYGPU_SHAPE_RECTANGLE);
@@ -2276,7 +2359,10 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                                      : (POOL || kMasks) ? sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw)
                                                         : sceneVisibility<STATS, MESHL>(s, shadow, cnt);
                 tm.mark(3);
-                if (!visible) return;
+                if (!visible) {
+                    if (!shadow_catcher) return;
+                    tr = S3(0.f);  // pathtracer_mis.zig:251-257
+                }
                 const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                 const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                 const BxdfResult bx = ms.template evaluate<SUBST, POOL, MESHL>(s, ls.wi, POOL && max_splits > 1);
@@ -2290,6 +2376,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                     const float light_pdf = ls.pdf * pick.pdf;
                     const float weight = predividedPowerHeuristic(light_pdf, bx.pdf);
                     const f3    unocc = S3(weight) * radiance * bx.reflection;
+                    if (catcher_scene) unoccluded = unoccluded + unocc;
                     occluded = occluded + ((POOL || kMasks) ? tr * unocc : unocc);  // pathtracer_mis.zig:267-270 (tr = 1 without thin glass)
                 } else {
                     const float weight = 1.f / (pick.pdf * ls.pdf);
@@ -2405,10 +2492,23 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                     if (rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
                 }
             }
-            nee = nee + occluded;
+            if (shadow_catcher && light.shadow_catcher_light) {  // pathtracer_mis.zig:274-276
+                catcher_occluded = catcher_occluded + occluded;
+                catcher_unoccluded = catcher_unoccluded + unoccluded;
+            } else {
+                nee = nee + occluded;
+            }
         }
         ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
         tm.mark(5);
+    }
+    if (catcher_scene) {  // pathtracer_mis.zig:108-115 (whether or not the material could be evaluated)
+        h.flags = shadow_catcher ? (h.flags | ST_FROM_CATCHER) : (h.flags & ~uint32_t(ST_FROM_CATCHER));
+        if (shadow_catcher) {
+            P.pool.sc_occ[slot] = f4(catcher_occluded);
+            P.pool.sc_unocc[slot] = f4(catcher_unoccluded);
+            h.flags |= ST_CATCHER_IN_CAMERA;
+        }
     }
 
     // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
@@ -2430,7 +2530,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         h.smp.incrementPadding();  // after the children, none of which draws (pathtracer_mis.zig:165)
         storeSamplers(P, ps, h);
         if (0 == count) {
-            terminateVertex(P, ps, S3(0.f), split_weight, h.flags);  // vertex.throughput = 0 (pathtracer_mis.zig:127-129)
+            terminateVertex(P, ps, S3(0.f), split_weight, h.flags, slot);  // vertex.throughput = 0 (pathtracer_mis.zig:127-129)
         } else {
             Mediums md;
             md.load(P, slot);
@@ -2480,6 +2580,11 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 P.pool.vorigin[cv] = f4(b.straight ? xyz4(parent_vorigin) : sf.p, __uint_as_float(path_count * count));
                 P.pool.vgeo_n[cv] = (mis && !b.straight) ? f4(ms.geo_n, b.reg_alpha) : parent_vgeo_n;
                 P.pool.vmeta[cv] = packMeta(ch);
+                if (catcher_scene) {  // next_vertex.* = vertex.* (pathtracer_mis.zig:133)
+                    P.pool.sc_occ[cv] = P.pool.sc_occ[slot];
+                    P.pool.sc_unocc[cv] = P.pool.sc_unocc[slot];
+                    P.pool.sc_emis[cv] = P.pool.sc_emis[slot];
+                }
                 cm.store(P, cv);
                 child[c] = cv;
                 child_round[c] = first + c;

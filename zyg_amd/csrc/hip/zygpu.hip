@@ -452,6 +452,7 @@ struct ZygpuContext {
     bool          extra_shapes = false;         // Sphere / Disk / Cube props: wf_intersect<.., EXTRA> and the MESHL instantiations
     bool          pool_mode = false;            // Glass in the scene: the POOL instantiations (split paths, medium stack)
     bool          pool_allocated = false;       // the path pool has the POOL layout
+    bool          catchers = false, catchers_allocated = false;  // a prop is a shadow catcher: POOL kernels + the records of vertex.zig:57-59
     bool          tick_sync = false;       // option "tick_sync": read the queue length back after every tick
     uint32_t*     host_count = nullptr;    // pinned
     uint4*        sobol_lut = nullptr;     // dsampler.hpp c_sobol_lut
@@ -499,8 +500,8 @@ struct ZygpuContext {
 namespace {
 
 // Thresholds on a mesh's triangle count (measured with tools/threshold_edges.sh, DESIGN 4 "threshold edges"):
-//   <= kSmallMeshTriangles (dscene.hpp, 48): tested triangle by triangle from the constant block (relaxed units)
-//   >= kWideBlasMinTriangles (64): the scene runs the wide-BLAS kernel instantiations and extension rays that enter the mesh's
+//   <= kSmallMeshTriangles (dscene.hpp, 32): tested triangle by triangle from the constant block (relaxed units)
+//   >= kWideBlasMinTriangles (33): the scene runs the wide-BLAS kernel instantiations and extension rays that enter the mesh's
 //      bounds are grouped at the back of their queue (108-triangle boxes: 527 -> 607 Msamples/s, 972: 432 -> 527)
 //   >= kMeshKernelMinTriangles (4096): its shadow walks go to wf_shadow_u (wf_scatter_h suspends the vertex; for the small
 //      boxes that costs more than their short walks: 607 -> 524)
@@ -510,7 +511,7 @@ uint32_t thresholdFromEnv(const char* name, uint32_t fallback) {
     return e ? uint32_t(std::max(1, std::atoi(e))) : fallback;
 }
 uint32_t wideBlasMinTriangles() {
-    static const uint32_t value = thresholdFromEnv("ZYG_WIDE_MIN_TRIANGLES", 64u);
+    static const uint32_t value = thresholdFromEnv("ZYG_WIDE_MIN_TRIANGLES", 33u);
     return value;
 }
 uint32_t meshKernelMinTriangles() {
@@ -543,7 +544,7 @@ bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out
 }
 
 int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
-    if (slots <= c->pool_capacity && rounds <= c->pool_rounds && c->pool_mode == c->pool_allocated) return 0;
+    if (slots <= c->pool_capacity && rounds <= c->pool_rounds && c->pool_mode == c->pool_allocated && c->catchers == c->catchers_allocated) return 0;
     slots = std::max(slots, c->pool_capacity);
     rounds = std::max(rounds, c->pool_rounds);
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -598,6 +599,8 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
     if (ok && c->pool_mode) {
         ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) && m.alloc(paths, &p.rec_uv) &&
              m.alloc(slots, &p.pstate) && m.alloc(slots, &p.transp);
+        if (ok && c->catchers)
+            ok = m.alloc(paths, &p.sc_occ) && m.alloc(paths, &p.sc_unocc) && m.alloc(paths, &p.sc_emis) && m.alloc(slots, &p.transp_rgb);
         for (uint32_t side = 0; side < 2; ++side) {
             c->queues.ext_pool[side][0] = c->queues.ext[side];
             for (uint32_t k = 1; k < kPoolVertices; ++k) ok = ok && m.alloc(qcap, &c->queues.ext_pool[side][k]);
@@ -611,6 +614,7 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
     c->pool_capacity = slots;
     c->pool_rounds = rounds;
     c->pool_allocated = c->pool_mode;
+    c->catchers_allocated = c->catchers;
     return 0;
 }
 
@@ -872,6 +876,14 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
         c->pool_mode = true;  // split paths + medium stack: the POOL kernels
     }
+    // A shadow catcher (scene.propSetShadowCatcher): PathtracerMIS keeps what it has seen per vertex and lets the backplate's light
+    // through at the path's end (pathtracer_mis.zig:56-115, vertex.zig:252-266): the POOL kernels' per-vertex records and
+    // termination bookkeeping, in their complete (MESHL) instantiations
+    c->catchers = false;
+    for (uint32_t p = 0; p < d->num_props; ++p)
+        if (d->props[p].flags & ZYGPU_PROP_SHADOW_CATCHER) c->catchers = true;
+    if (c->catchers) c->pool_mode = c->mesh_lights = true;
+    s.has_catcher = c->catchers ? 1u : 0u;
     c->has_substitute = false;
     for (uint32_t mi = 0; mi < d->num_materials; ++mi) {
         if (ZYGPU_MAT_SUBSTITUTE == d->materials[mi].kind) c->has_substitute = true;

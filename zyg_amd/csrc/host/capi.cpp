@@ -431,6 +431,16 @@ int32_t su_ext_load_take(const char* take_filename) {
     return 0;
 }
 
+int32_t su_ext_prop_set_shadow_catcher(uint32_t prop) {
+    if (!g) return -1;
+    return 0 == g->engine.setShadowCatcher(prop) ? 0 : -1;
+}
+
+int32_t su_ext_prop_set_visibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss, bool shadow_catcher_light) {
+    if (!g) return -1;
+    return 0 == g->engine.setVisibility(prop, in_camera, in_reflection, in_sss, shadow_catcher_light) ? 0 : -1;
+}
+
 int32_t su_ext_sky_create(const char* parameters_json) {
     if (!g) return -1;
     const int32_t sun = g->engine.createSky();

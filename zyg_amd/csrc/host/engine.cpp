@@ -856,15 +856,22 @@ int Engine::setWorldTransformation(uint32_t prop, const Transformation& t) {
     return 0;
 }
 
-int Engine::setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss) {  // prop.zig:75-88
+int Engine::setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss, bool shadow_catcher_light) {  // prop.zig:75-88
     if (prop >= props_.size()) return -1;
     uint32_t& f = props_[prop].flags;
     auto      set = [&](uint32_t bit, bool on) { f = on ? (f | bit) : (f & ~bit); };
     set(ZYGPU_PROP_VISIBLE_IN_CAMERA, in_camera);
     set(ZYGPU_PROP_VISIBLE_IN_REFLECTION, in_reflection);
     set(ZYGPU_PROP_VISIBLE_IN_SSS, in_sss);
-    set(ZYGPU_PROP_SHADOW_CATCHER_LIGHT, false);
+    set(ZYGPU_PROP_SHADOW_CATCHER_LIGHT, shadow_catcher_light);
     set(ZYGPU_PROP_VISIBLE_IN_SHADOW, (f & ZYGPU_PROP_SHADOW_CATCHER) ? false : in_reflection);
+    return 0;
+}
+
+int Engine::setShadowCatcher(uint32_t prop) {  // Prop.setShadowCatcher (prop.zig:89-92)
+    if (prop >= props_.size()) return -1;
+    props_[prop].flags |= ZYGPU_PROP_SHADOW_CATCHER;
+    props_[prop].flags &= ~uint32_t(ZYGPU_PROP_VISIBLE_IN_SHADOW);
     return 0;
 }
 

@@ -129,7 +129,8 @@ class Engine {
     // su_image_update (capi.zig:300-338): new pixels for an existing image, same format and dimensions
     int      updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data);
     const std::vector<std::string>& warnings() const { return warnings_; }  // of the last compile()
-    int      setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss);
+    int      setVisibility(uint32_t prop, bool in_camera, bool in_reflection, bool in_sss, bool shadow_catcher_light = false);
+    int      setShadowCatcher(uint32_t prop);  // scene.propSetShadowCatcher (scene.zig:398-400)
     // The Sky entity (sky/sky.zig; util/scene_loader.zig:704-712): a Distant sun and a Canopy sky, both lights.  createSky
     // returns the sun's prop (Sky.configure, idempotent); the parameters are the entity's "parameters" node (Sky.setParameters).
     // The bake's products (sky.zig:172-269: the sun's radiance over its disc, kSkySunSamples rgb samples, and the canopy image)

@@ -8,7 +8,7 @@
 // File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
 // core/file/system.zig, reduced to these two levels).  Sky entities create the sun and the sky (engine.cpp createSky; the bake's tables are a
 // procedural stand-in unless the client hands them over).  Refused by name (the load fails, nothing is skipped in silence):
-// instancers, scatterers, portals, animations, shadow catchers.  Not read: glTF, gzip-compressed files.
+// instancers, scatterers, portals, animations.  Not read: glTF, gzip-compressed files.
 #pragma once
 
 #include <cstdio>
@@ -257,8 +257,8 @@ class TakeLoader {
         return true;
     }
     // What the reference's loader reads and this build does not render fails the load by name: an entity type (scene_loader.zig:
-    // 252-264), or a key that changes the image (`animation` scene_graph.zig:184-203, `shadow_catcher` scene_loader.zig:312-313,
-    // visibility.shadow_catcher_light scene_loader.zig:612-619).  su_ext_load_take logs the message at error level and returns -1.
+    // 252-264), or a key that changes the image (`animation`, scene_graph.zig:184-203).  su_ext_load_take logs the message at error
+    // level and returns -1.
     bool unsupported(const std::string& what) {
         return fail("the scene uses " + what + ", which this build does not render");
     }
@@ -284,18 +284,18 @@ class TakeLoader {
             return unsupported("a \"" + type->str + "\" entity");
         }  // any other type is a node without an entity: its transformation applies to its children (scene_loader.zig:241-264)
         if (v.get("animation")) return unsupported("an entity with an \"animation\"");
-        if (v.get("shadow_catcher")) return unsupported("a \"shadow_catcher\" entity");
         Transformation local = identity();
         if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
         world = transform(parent, local);
         if (ZYGPU_NULL == entity) return true;
         setWorld(entity, world);
         bool in_reflection = true;
-        if (const JsonValue* vis = v.get("visibility")) {
-            if (vis->memberBool("shadow_catcher_light", false)) return unsupported("a \"shadow_catcher_light\"");
+        if (const JsonValue* vis = v.get("visibility")) {  // setVisibility (scene_loader.zig:612-619)
             in_reflection = vis->memberBool("in_reflection", true);
-            engine_.setVisibility(entity, vis->memberBool("in_camera", true), in_reflection, vis->memberBool("in_sss", false));
+            engine_.setVisibility(entity, vis->memberBool("in_camera", true), in_reflection, vis->memberBool("in_sss", false),
+                                  vis->memberBool("shadow_catcher_light", false));
         }
+        if (v.get("shadow_catcher")) engine_.setShadowCatcher(entity);  // scene_loader.zig:312-313
         if (is_light && in_reflection) engine_.createLight(entity);
         return true;
     }

@@ -596,7 +596,7 @@ def sky_tables(elevation_deg=35.0, size=64):
 
 def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
             extra_quad_light=False, max_depth=8, sky=None, sun=True, showcase=False, mesh=None, sky_map=None, sky_samples=1,
-            sky_spectrum=(0.35, 0.5, 0.8), sky_entity=None):
+            sky_spectrum=(0.35, 0.5, 0.8), sky_entity=None, shadow_catcher=False, alpha_transparency=False):
     """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
     distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
     light tree mixes the infinite-light distribution with the BVH.  `sky`: "dome" (dome.zig, the whole sphere of
@@ -607,7 +607,7 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
     cam = engine.camera(width, height, fov_deg=45.0)
     engine.samples_per_pixel(spp)
     engine.integrators(json.dumps({"surface": {integrator: {"depth": {"surface": max_depth}}}}))
-    engine.sensor(json.dumps({}))
+    engine.sensor(json.dumps({"alpha_transparency": True} if alpha_transparency else {}))
     white = engine.material(mk(WHITE))
     red = engine.material(mk(RED))
     sun_mat = engine.material(light_material(spectrum=(12.0, 11.0, 9.0)))
@@ -615,6 +615,9 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
 
     ground = engine.prop(RECTANGLE, [white])
     engine.transformation(ground, trafo((1, 0, 0), (0, 0, -1), (12, 12, 1), (0, 0, 0)))
+    if shadow_catcher:
+        engine.shadow_catcher(ground)
+    ids["ground"] = ground
     identity = trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0))
     if showcase:
         red = engine.material(glass(1.5, (0.55, 0.9, 0.6), 0.4))
@@ -640,6 +643,8 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
         r0, r1 = _basis_for(-to_light)  # the light's z axis points from the light into the scene
         s = engine.prop(DISTANT, [sun_mat])
         engine.transformation(s, trafo(r0, r1, (sun_radius, sun_radius, sun_radius), (0, 0, 0)))
+        if shadow_catcher:
+            engine.shadow_catcher_light(s)
         engine.light(s)
         ids["sun"] = s
     if sky is not None:
@@ -649,6 +654,8 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
         k = engine.prop(DOME if "dome" == sky else CANOPY, [sky_mat])
         # the canopy's z axis is "up": r0 = x, r1 = -z gives r2 = r0 x r1 = +y
         engine.transformation(k, trafo((1, 0, 0), (0, 0, -1), (1, 1, 1), (0, 0, 0)))
+        if shadow_catcher:
+            engine.shadow_catcher_light(k)
         engine.light(k)
         ids["sky"] = k
     if extra_quad_light:
