@@ -98,6 +98,12 @@ uint32_t su_ext_ggx_lut(uint32_t which, float* out, uint32_t capacity);
  * post-processor and exporters of cli/take_loader.zig:27-283, materials / entities / shapes of util/scene_loader.zig:115-702,
  * JSON and "SUB\0" binary meshes of shape_provider.zig:334-805.  0, or -1 with the reason in the log.  Host-only. */
 int32_t su_ext_load_take(const char* take_filename);
+/* Portal lights (the reference's scene loader only: util/scene_loader.zig:247-248, 371-397; su_light_create passes no link,
+ * capi.zig:477): su_ext_portal_create makes a prop of the built-in shape `shape` (a Rectangle) with the material of light
+ * `light_id` (a Dome with an emission map), hides that light's prop and turns the light into a prototype; place the prop, then
+ * su_ext_light_create_linked(prop, light_id) makes it the Portal light.  Returns the prop id / 0, or -1. */
+int32_t su_ext_portal_create(uint32_t shape, uint32_t light_id);
+int32_t su_ext_light_create_linked(uint32_t prop, uint32_t light_id);
 /* Shadow catchers (the reference's scene loader only: util/scene_loader.zig:312-313 "shadow_catcher" -> Scene.propSetShadowCatcher,
  * and 612-619 visibility.shadow_catcher_light; su_prop_set_visibility passes false for the latter, capi.zig:545-560).
  * PathtracerMIS treats a hit on a shadow catcher as a hole onto the backplate, darkened where the shadow-catcher lights are

@@ -296,6 +296,19 @@ typedef struct ZygpuImageLight {
     uint32_t num_cdf, num_lut;
 } ZygpuImageLight;
 
+/* A Portal light (scene/shape/portal.zig; shape_sampler.zig:263-299 PortalImpl; light_material.zig:142-199
+ * preparePortalSampling): a Rectangle that is a window onto an environment map.  Its material is the linked light's (a Dome with
+ * an emission map); `func` tabulates the map's luminance as the portal sees it, in the portal's own rectified image space
+ * (dim x dim, dim = the map's height), `sat` is its summed-area table ((dim + 1)^2, first row and column zero): a
+ * WindowedDistribution2D (base/math/windowed_distribution_2d.zig), sampled inside the window a shading point sees the
+ * portal through.  `light_link`: the linked (prototype) light, whose prop's rotation maps a direction to the map's uv. */
+typedef struct ZygpuPortalLight {
+    const float* sat;
+    const float* func;
+    uint32_t dim;
+    uint32_t light_link;
+} ZygpuPortalLight;
+
 /* top-level BVH over props (reference src/core/scene/prop/prop_tree.zig:22-27) */
 typedef struct ZygpuPropTree {
     const ZygpuBvhNode* nodes;
@@ -370,6 +383,9 @@ typedef struct ZygpuSceneDesc {
      * NULL / 0: the scene has no Sky. */
     const float*         sun_radiance;
     uint32_t             num_sun_radiance;
+    /* ZygpuLight.sampler of the ZYGPU_LIGHT_PORTAL_IMAGE lights */
+    uint32_t             num_portal_lights;
+    const ZygpuPortalLight* portal_lights;
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };

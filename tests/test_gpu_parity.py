@@ -813,6 +813,22 @@ def test_sky_entity(engine, oracle, integrator, variant):
     assert film[-8:, :, :3].mean() > 0.02  # a lit ground
 
 
+@pytest.mark.parametrize("integrator", ["PT", "PTDL", "PTMIS"])
+@pytest.mark.parametrize("samples", [1, 4])
+def test_portal_light(engine, oracle, integrator, samples):
+    """A Portal (scene/shape/portal.zig; rectangle.zig:458-513, 597-611; shape_sampler.zig:263-299; summed_area_table.zig;
+    windowed_distribution_2d.zig): the box lit through a window in the ceiling's place onto a Dome with an environment map.  Light
+    samples: the window a point sees the portal through, the map's windowed distribution inside it (bisection on the summed-area
+    table), the direction through the portal's rectified mapping; a ray that reaches the portal reads the map where it points
+    (lightPortalUvw) and weighs it with portalPdf.  Film and counters are the oracle's."""
+    out = _render_both(engine, oracle, 96, 72, 4, integrator=integrator, portal_map=scenes.sky_image(64, 32), light_samples=samples,
+                       material="substitute")
+    _check(*out, 4)
+    film = out[0]
+    assert film[40:, :, :3].mean() > 0.02  # the room is lit
+    assert film[2:6, 40:56, :3].mean() > film[40:, :, :3].mean()  # the sky through the window is brighter than the room
+
+
 @pytest.mark.parametrize("integrator", ["PTMIS", "PTDL"])
 @pytest.mark.parametrize("variant", ["quad_light", "glass", "sky_entity"])
 def test_shadow_catcher(engine, oracle, integrator, variant):

@@ -559,3 +559,48 @@ def test_sky_entity_without_tables_gets_the_stand_in_and_says_so(product_lib):
         ids = scenes.outdoor(e, 16, 9, 1, sky_entity={"parameters": {"sun": {"rotation": [20, 0, 0]}}})
         sd, _ = e.compile()
         assert sd.trafos[ids["sun"]].r[0][3] == 0.0
+
+
+def test_portal_light_compile_products(engine, oracle):
+    """A Portal (scene/shape/portal.zig, light_material.zig:142-199, summed_area_table.zig, scene_loader.zig:371-397): a Rectangle in
+    the ceiling's place takes the Dome's material; the Dome's light becomes a hidden prototype (not in the light tree, power 0); the
+    portal's sampler tabulates the map's brightest channel per texel of the portal's rectified image, times the mapping's weight."""
+    sky = scenes.sky_image(32, 16)
+    ids = scenes.cornell(engine, 32, 18, 1, portal_map=sky)
+    sd, vd = engine.compile()
+    assert sd.num_lights == 2 and sd.num_portal_lights == 1 and sd.light_tree.num_lights == 1
+    dome, portal = sd.lights[0], sd.lights[1]
+    assert dome.prototype == 1 and dome.light_class == 2 and sd.props[dome.prop].shape == scenes.DOME
+    assert not (sd.props[dome.prop].flags & 3)  # hidden from the camera and from reflections
+    assert portal.prototype == 0 and portal.light_class == 0 and sd.props[portal.prop].shape == scenes.RECTANGLE
+    assert sd.light_aabbs[0].min[3] == 0.0 and sd.light_aabbs[1].min[3] > 0.0  # the lights' powers
+    assert sd.material_ids[sd.props[portal.prop].parts_start] == sd.material_ids[sd.props[dome.prop].parts_start]
+    pl = sd.portal_lights[0]
+    dim = pl.dim
+    assert dim == 16 and pl.light_link == 0
+    func = np.ctypeslib.as_array(pl.func, shape=(dim, dim)).copy()
+    sat = np.ctypeslib.as_array(pl.sat, shape=(dim + 1, dim + 1)).copy()
+    assert not sat[0].any() and not sat[:, 0].any()
+    np.testing.assert_allclose(sat[1:, 1:], func.astype(np.float64).cumsum(0).cumsum(1), rtol=2e-5)
+    # one texel restated: Portal.imageToWorld of the 16 subsamples, the direction through the Dome's lat-long map (identity rotation),
+    # nearest texel, brightest channel, times the weight.  The portal's axes: r0 = x, r1 = z, r2 = -y (it looks down).
+    rot = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=np.float64)
+    for (px, py) in ((8, 8), (3, 12)):
+        acc = 0.0
+        for yy in range(4):
+            v = (py + 0.125 + yy / 4.0) / dim
+            for xx in range(4):
+                u = (px + 0.125 + xx / 4.0) / dim
+                w = np.array([np.tan(-np.pi / 2 + u * np.pi), np.tan(-np.pi / 2 + v * np.pi), 1.0])
+                w /= np.linalg.norm(w)
+                weight = np.pi ** 2 * (1 - w[0] ** 2) * (1 - w[1] ** 2) / w[2]
+                d = -(w @ rot)
+                du = np.arctan2(d[0], d[2]) / (2 * np.pi) + 0.5
+                dv = np.arccos(d[1]) / np.pi
+                tx, ty = min(int(du * 32), 31), min(int(dv * 16), 15)
+                acc += sky[ty, tx].max() * weight
+        assert abs(func[py, px] - acc / 16.0) <= 2e-4 * max(1.0, acc / 16.0), (px, py, func[py, px], acc / 16.0)
+    # the oracle renders the room lit through the window
+    from util import oracle_render, oracle_resolve
+    img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, 8, threads=4))
+    assert np.isfinite(img).all() and img[12:, 8:24, :3].mean() > 0.02

@@ -124,7 +124,6 @@ def test_missing_files_fail_loudly(product_lib, tmp_path):
 
 
 _REFUSED = {
-    "Portal": {"type": "Portal", "shape": {"type": "Rectangle"}, "light": 0},
     "Instancer": {"type": "Instancer", "prototypes": [], "instances": {"prototypes": [], "transformations": []}},
     "Scatterer": {"type": "Scatterer", "prototypes": []},
     "animation": {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"],
@@ -155,6 +154,28 @@ def test_unrendered_entities_and_keys_fail_the_load(product_lib, tmp_path, what)
         finally:
             e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
     assert any(level == 2 and what in text and "does not render" in text for level, text in messages), messages
+
+
+def test_portal_entity_loads(product_lib, tmp_path):
+    """{"type": "Portal", "shape": ..., "light": n} (scene_loader.zig:247-248, 371-397): the prop takes light n's material, light n is
+    hidden and becomes a prototype, and the Portal's own light is created with the link (scene_loader.zig:316-318)."""
+    scene = {"materials": [{"name": "grey", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5]}}},
+                           {"name": "env", "rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "emission_map": {"usage": "Emission", "id": 0}}}}}],
+             "entities": [{"type": "Light", "shape": {"type": "Dome"}, "materials": ["env"]},
+                          {"type": "Portal", "shape": {"type": "Rectangle"}, "light": 0,
+                           "transformation": {"position": [0, 2, 0], "rotation": [-90, 0, 0], "scale": [1.5, 1.5, 1]}},
+                          {"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["grey"], "transformation": {"rotation": [90, 0, 0], "scale": [4, 4, 1]}}]}
+    with open(tmp_path / "s.scene", "w") as f:
+        json.dump(scene, f)
+    with open(tmp_path / "s.take", "w") as f:
+        json.dump({"scene": "s.scene", "camera": {"Perspective": {"resolution": [8, 8], "transformation": {"position": [0, 1, -4]}}}}, f)
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.image(scenes.sky_image(32, 16)) == 0
+        assert e.lib.su_ext_load_take(str(tmp_path / "s.take").encode()) == 0
+        sd, _ = e.compile()
+        assert sd.num_lights == 2 and sd.num_portal_lights == 1
+        assert sd.lights[0].prototype == 1 and sd.lights[1].light_class == 0 and sd.portal_lights[0].light_link == 0
+        assert sd.props[sd.lights[1].prop].shape == scenes.RECTANGLE and not (sd.props[sd.lights[0].prop].flags & 3)
 
 
 def test_shadow_catcher_keys(product_lib, tmp_path):

@@ -106,6 +106,11 @@ class ImageLight(ctypes.Structure):
                 ("sampler", ctypes.c_uint32), ("num_cdf", ctypes.c_uint32), ("num_lut", ctypes.c_uint32)]
 
 
+class PortalLight(ctypes.Structure):
+    _fields_ = [("sat", ctypes.POINTER(ctypes.c_float)), ("func", ctypes.POINTER(ctypes.c_float)), ("dim", ctypes.c_uint32),
+                ("light_link", ctypes.c_uint32)]
+
+
 class PropTree(ctypes.Structure):
     _fields_ = [("nodes", ctypes.POINTER(BvhNode)), ("indices", ctypes.POINTER(ctypes.c_uint32)),
                 ("num_nodes", ctypes.c_uint32), ("num_indices", ctypes.c_uint32)]
@@ -136,7 +141,8 @@ class SceneDesc(ctypes.Structure):
                 ("num_images", ctypes.c_uint32), ("num_infinite_props", ctypes.c_uint32), ("num_image_lights", ctypes.c_uint32),
                 ("keyframes", ctypes.POINTER(Keyframe)), ("prop_frames", ctypes.POINTER(ctypes.c_uint32)),
                 ("num_keyframes", ctypes.c_uint32), ("num_interpolation_frames", ctypes.c_uint32), ("origin", ctypes.c_float * 4),
-                ("sun_radiance", ctypes.POINTER(ctypes.c_float)), ("num_sun_radiance", ctypes.c_uint32)]
+                ("sun_radiance", ctypes.POINTER(ctypes.c_float)), ("num_sun_radiance", ctypes.c_uint32),
+                ("num_portal_lights", ctypes.c_uint32), ("portal_lights", ctypes.POINTER(PortalLight))]
 
 
 class ViewDesc(ctypes.Structure):
@@ -377,6 +383,20 @@ class Engine:
             if 0 != self.lib.su_ext_sky_tables(sun_table.ctypes.data, sky_image.ctypes.data, sky_image.shape[1], sky_image.shape[0]):
                 raise RuntimeError("su_ext_sky_tables failed")
         return sun
+
+    def portal(self, light_id, shape=5):
+        """A Portal (su_ext_portal_create): a Rectangle prop with the material of light `light_id` (a Dome with an emission map),
+        which becomes a hidden prototype; place it with transformation(), then portal_light(prop, light_id)."""
+        self.lib.su_ext_portal_create.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        p = self.lib.su_ext_portal_create(shape, light_id)
+        if p < 0:
+            raise RuntimeError("su_ext_portal_create failed")
+        return p
+
+    def portal_light(self, prop, light_id):
+        self.lib.su_ext_light_create_linked.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        if self.lib.su_ext_light_create_linked(prop, light_id) != 0:
+            raise RuntimeError("su_ext_light_create_linked failed")
 
     def shadow_catcher(self, prop):
         """scene.propSetShadowCatcher (su_ext_prop_set_shadow_catcher): PathtracerMIS sees the backplate through the prop, darkened

@@ -809,6 +809,211 @@ ZD bool canopySampleMaterialTo(const DImageLight& il, f3 n, const Trafo& trafo, 
     return true;
 }
 
+// ---- Portal lights: a Rectangle that is a window onto an environment map
+//   Portal.imageToWorld / worldToImageWeighted / imageBounds      scene/shape/portal.zig:16-80
+//   SummedAreaTable.integral / lookup, EvaluatorX / EvaluatorY      base/math/summed_area_table.zig:59-289
+//   WindowedDistribution2D.sampleContinuous / pdf / eval            base/math/windowed_distribution_2d.zig:31-105
+//   PortalImpl.portalUvw                                            scene/shape/shape_sampler.zig:274-286
+//   Rectangle.samplePortalTo / portalPdf                            scene/shape/rectangle.zig:458-513, 597-611
+struct Bounds2 {
+    float min0, min1, max0, max1;
+};
+
+ZD bool portalWorldToImage(f3 dir, const Trafo& trafo, float& u, float& v) {
+    const f3 w = trafo.worldToObjectNormal(dir);
+    if (w.z <= 0.f) return false;
+    const float a = atan2F(w.x, w.z), b = atan2F(w.y, w.z);
+    u = clampf((a + kPi / 2.f) / kPi, 0.f, 1.f);
+    v = clampf((b + kPi / 2.f) / kPi, 0.f, 1.f);
+    return true;
+}
+ZD bool portalWorldToImageWeighted(f3 dir, const Trafo& trafo, float& u, float& v, float& weight) {
+    const f3 w = trafo.worldToObjectNormal(dir);
+    if (w.z <= 0.f) return false;
+    const float alpha = atan2F(w.x, w.z), beta = atan2F(w.y, w.z);
+    weight = (kPi * kPi) * (1.f - w.x * w.x) * (1.f - w.y * w.y) / w.z;
+    u = clampf((alpha + kPi / 2.f) / kPi, 0.f, 1.f);
+    v = clampf((beta + kPi / 2.f) / kPi, 0.f, 1.f);
+    return true;
+}
+ZD bool portalImageBounds(f3 p, const Trafo& trafo, Bounds2& out) {
+    const f3 a = trafo.r0 * S3(trafo.scale.x), b = trafo.r1 * S3(trafo.scale.y);
+    const f3 ab = a + b;
+    const f3 o = p - trafo.position;
+    const f3 c0 = S3(0.5f) * ab + o, c1 = S3(-0.5f) * ab + o;
+    float    u0, v0, u1, v1;
+    if (!portalWorldToImage(normalize3(c0), trafo, u0, v0)) return false;
+    if (!portalWorldToImage(normalize3(c1), trafo, u1, v1)) return false;
+    out.min0 = mn(u0, u1);
+    out.min1 = mn(v0, v1);
+    out.max0 = mx(u0, u1);
+    out.max1 = mx(v0, v1);
+    return true;
+}
+
+struct SatView {
+    const float* buffer;
+    const float* func;
+    int          dim;
+    ZD float lookup(int x0, int x1, int y0, int y1, float dx, float dy) const {
+        const int   w = dim + 1;
+        const float v00 = buffer[x0 + y0 * w], v10 = buffer[x1 + y0 * w], v01 = buffer[x0 + y1 * w], v11 = buffer[x1 + y1 * w];
+        const float odx = 1.f - dx, ody = 1.f - dy;
+        return ody * (odx * v00 + dx * v10) + dy * (odx * v01 + dx * v11);
+    }
+    ZD float integral(const Bounds2& e) const {
+        const float fd = float(dim);
+        const float ax = e.min0 * fd, ay = e.min1 * fd, bx = e.max0 * fd, by = e.max1 * fd;
+        const int   ax0 = int(ax), ay0 = int(ay), bx0 = int(bx), by0 = int(by);
+        const int   axx0 = min(ax0, dim), ayy0 = min(ay0, dim), axx1 = min(ax0 + 1, dim), ayy1 = min(ay0 + 1, dim);
+        const int   bxx0 = min(bx0, dim), byy0 = min(by0, dim), bxx1 = min(bx0 + 1, dim), byy1 = min(by0 + 1, dim);
+        const float adx = ax - float(ax0), ady = ay - float(ay0), bdx = bx - float(bx0), bdy = by - float(by0);
+        const float s = (lookup(bxx0, bxx1, byy0, byy1, bdx, bdy) - lookup(axx0, axx1, byy0, byy1, adx, bdy)) +
+                        (lookup(axx0, axx1, ayy0, ayy1, adx, ady) - lookup(bxx0, bxx1, ayy0, ayy1, bdx, ady));
+        return mx(s / (fd * fd), 0.f);
+    }
+    ZD float eval(float u, float v) const {
+        const uint32_t x = uint32_t(u * float(dim)), y = uint32_t(v * float(dim));
+        return func[min(y, uint32_t(dim - 1)) * uint32_t(dim) + min(x, uint32_t(dim - 1))];
+    }
+};
+
+struct SatEvaluatorX {
+    const SatView& sat;
+    int            ay0, by0;
+    float          lookup_b, lookup_c, ady, bdy, integral_area;
+    ZD SatEvaluatorX(const SatView& s, const Bounds2& e, float integral) : sat(s) {
+        const int   d = s.dim;
+        const float fd = float(d);
+        const float ax = e.min0 * fd, ay = e.min1 * fd, by = e.max1 * fd;
+        const int   ax0 = int(ax);
+        ay0 = int(ay);
+        by0 = int(by);
+        const int axx0 = min(ax0, d), ayy0 = min(ay0, d), axx1 = min(ax0 + 1, d), ayy1 = min(ay0 + 1, d);
+        const int byy0 = min(by0, d), byy1 = min(by0 + 1, d);
+        const float adx = ax - float(ax0);
+        ady = ay - float(ay0);
+        bdy = by - float(by0);
+        lookup_b = s.lookup(axx0, axx1, byy0, byy1, adx, bdy);
+        lookup_c = s.lookup(axx0, axx1, ayy0, ayy1, adx, ady);
+        integral_area = integral * (fd * fd);
+    }
+    ZD float eval(float x) const {
+        const int   d = sat.dim;
+        const float bx = x * float(d);
+        const int   bx0 = int(bx);
+        const int   ayy0 = min(ay0, d), ayy1 = min(ay0 + 1, d);
+        const int   bxx0 = min(bx0, d), byy0 = min(by0, d), bxx1 = min(bx0 + 1, d), byy1 = min(by0 + 1, d);
+        const float bdx = bx - float(bx0);
+        const float lookup_a = sat.lookup(bxx0, bxx1, byy0, byy1, bdx, bdy), lookup_d = sat.lookup(bxx0, bxx1, ayy0, ayy1, bdx, ady);
+        const float s = (lookup_a - lookup_b) + (lookup_c - lookup_d);
+        return mx(s / integral_area, 0.f);
+    }
+};
+
+struct SatEvaluatorY {
+    const SatView& sat;
+    int            ax0, bx0;
+    float          lookup_c, lookup_d, adx, bdx, integral_area;
+    ZD SatEvaluatorY(const SatView& s, const Bounds2& e, float integral) : sat(s) {
+        const int   d = s.dim;
+        const float fd = float(d);
+        const float ax = e.min0 * fd, ay = e.min1 * fd, bx = e.max0 * fd;
+        ax0 = int(ax);
+        const int ay0 = int(ay);
+        bx0 = int(bx);
+        const int axx0 = min(ax0, d), ayy0 = min(ay0, d), axx1 = min(ax0 + 1, d), ayy1 = min(ay0 + 1, d);
+        const int bxx0 = min(bx0, d), bxx1 = min(bx0 + 1, d);
+        adx = ax - float(ax0);
+        const float ady = ay - float(ay0);
+        bdx = bx - float(bx0);
+        lookup_c = s.lookup(axx0, axx1, ayy0, ayy1, adx, ady);
+        lookup_d = s.lookup(bxx0, bxx1, ayy0, ayy1, bdx, ady);
+        integral_area = integral * (fd * fd);
+    }
+    ZD float eval(float y) const {
+        const int   d = sat.dim;
+        const float by = y * float(d);
+        const int   by0 = int(by);
+        const int   axx0 = min(ax0, d), axx1 = min(ax0 + 1, d);
+        const int   bxx0 = min(bx0, d), byy0 = min(by0, d), bxx1 = min(bx0 + 1, d), byy1 = min(by0 + 1, d);
+        const float bdy = by - float(by0);
+        const float lookup_a = sat.lookup(bxx0, bxx1, byy0, byy1, bdx, bdy), lookup_b = sat.lookup(axx0, axx1, byy0, byy1, adx, bdy);
+        const float s = (lookup_a - lookup_b) + (lookup_c - lookup_d);
+        return mx(s / integral_area, 0.f);
+    }
+};
+
+template <typename Cdf>
+ZD float sampleBisection(const Cdf& cdf, float u, float imin, float imax, float nf) {
+    float lo = imin, hi = imax;
+    while (ceilf(nf * hi) - floorf(nf * lo) > 1.f) {
+        const float mid = (lo + hi) / 2.f;
+        if (cdf.eval(mid) > u) hi = mid;
+        else lo = mid;
+    }
+    const float pmin = cdf.eval(lo), pmax = cdf.eval(hi);
+    const float t = (u - pmin) / (pmax - pmin);
+    return clampf(lerpf(lo, hi, t), lo, hi);
+}
+
+ZD bool windowedSample(const SatView& sat, float r0, float r1, const Bounds2& b, float& u, float& v, float& pdf) {
+    const float integral = sat.integral(b);
+    if (0.f == integral) return false;
+    const SatEvaluatorX cdfx(sat, b, integral);
+    const float         nx = float(sat.dim);
+    u = sampleBisection(cdfx, r0, b.min0, b.max0, nx);
+    Bounds2 bcond{floorf(u * nx) / nx, b.min1, ceilf(u * nx) / nx, b.max1};
+    if (bcond.min0 == bcond.max0) bcond.max0 += 1.f / nx;
+    const float cond_int = sat.integral(bcond);
+    if (0.f == cond_int) return false;
+    const SatEvaluatorY cdfy(sat, bcond, cond_int);
+    v = sampleBisection(cdfy, r1, b.min1, b.max1, float(sat.dim));
+    pdf = sat.eval(u, v) / integral;
+    return true;
+}
+
+// the direction in the linked dome's frame, as its lat-long uv
+ZD void portalUvw(const Trafo& dome_trafo, f3 dir, float& u, float& v) {
+    const f3 xyz = normalize3(dome_trafo.transformVectorTransposed(dir));
+    u = atan2F(xyz.x, xyz.z) * ((1.f / kPi) * 0.5f) + 0.5f;
+    v = acosF(xyz.y) * (1.f / kPi);
+}
+
+// one sample of Rectangle.samplePortalTo from its 2-D draw; nsf = the light's sample count
+ZD bool rectangleSamplePortal(const DPortalLight& pl, const Trafo& dome_trafo, const Bounds2& bounds, float r0, float r1, float nsf, f3 p, f3 n,
+                              const Trafo& trafo, bool total_sphere, SampleTo& out) {
+    const SatView sat{pl.sat, pl.func, int(pl.dim)};
+    float         u, v, pdf;
+    if (!windowedSample(sat, r0, r1, bounds, u, v, pdf) || 0.f == pdf) return false;
+    // Portal.imageToWorld
+    const float a = -kPi * 0.5f + u * kPi, b = -kPi * 0.5f + v * kPi;
+    const f3    w = normalize3(mk3(tanF(a), tanF(b), 1.f));
+    const float weight = (kPi * kPi) * (1.f - w.x * w.x) * (1.f - w.y * w.y) / w.z;
+    const f3    dir = -trafo.objectToWorldNormal(w);
+    if ((dot3(dir, n) <= 0.f && !total_sphere) || 0.f == weight) return false;
+    const f3    wn = trafo.r2;
+    const float d = dot3(wn, trafo.position);
+    const float hit_t = -(dot3(wn, p) - d) / dot3(wn, dir);
+    out.p = p + S3(hit_t) * dir;
+    out.n = wn;
+    out.wi = dir;
+    out.pdf = (nsf * pdf) / weight;
+    portalUvw(dome_trafo, dir, out.u, out.v);
+    return true;
+}
+
+ZD float rectanglePortalPdf(const DPortalLight& pl, f3 dir, f3 p, const Trafo& frag_trafo, float nsf) {
+    float u, v, weight;
+    if (!portalWorldToImageWeighted(-dir, frag_trafo, u, v, weight)) return 0.f;
+    Bounds2 b;
+    if (!portalImageBounds(p, frag_trafo, b)) return 0.f;
+    const SatView sat{pl.sat, pl.func, int(pl.dim)};
+    const float   integral = sat.integral(b);
+    const float   ppdf = 0.f == integral ? 0.f : sat.eval(u, v) / integral;
+    return (ppdf * nsf) / weight;
+}
+
 // one sample of Rectangle.sampleMaterialTo (rectangle.zig:399-456) from its 2-D draw; nsf = the light's sample count
 ZD bool rectangleSampleMaterial(const DImageLight& il, float r0, float r1, float nsf, f3 p, f3 n, const Trafo& trafo, bool two_sided,
                                 bool total_sphere, SampleTo& out) {

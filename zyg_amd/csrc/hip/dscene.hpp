@@ -70,6 +70,12 @@ struct DImageLight {  // ZygpuImageLight on the device
     uint32_t        sampler;
 };
 
+struct DPortalLight {  // ZygpuPortalLight on the device
+    const float* sat;
+    const float* func;
+    uint32_t     dim, light_link;
+};
+
 // A small top-level scene as a table in the __constant__ block itself (zygpu_upload_scene fills it when the solid props are
 // at most kUniformProps Rectangles and TriangleMeshes): every lane of a wave tests the same prop at the same time, the
 // prop's bounds and transformation arrive through the scalar cache in SGPRs (sceneIntersectUniform, sceneVisibilityUniform).
@@ -86,6 +92,9 @@ struct TlasEntry {
 // (measured on configs[1] with its two boxes at 18 triangles each: 580 Msamples/s through the per-lane BVH2 walk, 754-759 from
 // this table, 810-817 at 12 triangles with either limit; at 48 triangles the table's linear cost (516) is past what the wide BLAS
 // gives (605 at 108 triangles): the limit is 32, DESIGN 4 "threshold edges")
+#ifndef ZYG_EXPERIMENT_SKIP_SMALL
+#define ZYG_EXPERIMENT_SKIP_SMALL 0  // 2: a timing experiment (wrong images): the meshes of the small-triangle table are skipped
+#endif
 #ifndef ZYG_SMALL_TRIANGLES
 #define ZYG_SMALL_TRIANGLES 128
 #endif
@@ -123,6 +132,7 @@ struct DScene {
     DLightTree           light_tree;
     const DMeshLight*    mesh_lights;
     const DImageLight*   image_lights;
+    const DPortalLight*  portal_lights;
     const float4*        sun_radiance;  // the Sky entity's sun: radiance over its disc (ZygpuSceneDesc.sun_radiance)
     uint32_t             num_sun_radiance;
     const uint32_t*      infinite_props;
@@ -1205,6 +1215,10 @@ ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface,
         if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
             h.primitive = 0;
             found = rectangleIntersect(ray, trafo, h.t, h.u, h.v);
+#if ZYG_EXPERIMENT_SKIP_SMALL  // timing experiment only: the small meshes are not there
+        } else if (!EXACT_TIES && e.small_count > 0 && ZYG_EXPERIMENT_SKIP_SMALL > 1) {
+            found = false;
+#endif
         } else if (!EXACT_TIES && e.small_count > 0) {
             // every triangle of a small mesh, in the mesh's order (the reference's order only matters for exact ties)
             Ray local = worldToObjectRay(trafo, ray);
@@ -1319,6 +1333,9 @@ ZD bool sceneVisibilityUniform(const DScene& s, Ray& ray) {
             if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
                 float t, u, v;
                 blocked = rectangleIntersect(ray, trafo, t, u, v);
+#if ZYG_EXPERIMENT_SKIP_SMALL
+            } else if (SMALL && e.small_count > 0 && ZYG_EXPERIMENT_SKIP_SMALL > 1) {
+#endif
             } else if (SMALL && e.small_count > 0) {
                 const Ray local = worldToObjectRay(trafo, ray);
                 for (uint32_t k = e.small_first, ke = e.small_first + e.small_count; k < ke; ++k) {

@@ -1115,7 +1115,10 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
     const float      select_pdf = lt.pdf(v.vorigin, v.vgeo_n, translucent, v.light_split_threshold, light_id);
     const ZygpuLight light = s.lights[light_id];
     float            sample_pdf;
-    if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {  // light.zig:371-374 -> shape.zig:509-526
+    if (MESHL && ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {  // light.zig:376-379 -> shape.zig:494-506 -> rectangle.zig:597-611
+        sample_pdf = rectanglePortalPdf(s.portal_lights[light.sampler], ray_direction, v.vorigin, frag.trafo,
+                                        float(numSamples(light.num_samples, v.light_split_threshold)));
+    } else if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {  // light.zig:371-374 -> shape.zig:509-526
         const DImageLight& il = s.image_lights[light.sampler];
         const uint32_t image_shape = s.props[light.prop].shape;
         sample_pdf = ZYGPU_SHAPE_DOME == image_shape ? domeMaterialPdf(il, frag.uv0, frag.uv1, numSamples(light.num_samples, v.light_split_threshold))
@@ -1152,8 +1155,17 @@ template <bool MESHL>
 ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment& frag, Sampler& smp) {
     const ZygpuMaterial& m = s.materials[s.material_ids[s.props[frag.prop].parts_start + frag.part]];
     if (!(m.flags & ZYGPU_MATF_EMISSIVE) || (!(m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo))) return S3(0.f);
+    // rs.uvw = scene.lightPortalUvw(vertex, frag) (scene.zig:636-648): through a Portal the map is read where the ray points
+    float u = frag.uv0, vv = frag.uv1;
+    if (MESHL && s.portal_lights) {
+        const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
+        if (kNull != light_id && ZYGPU_LIGHT_PORTAL_IMAGE == s.lights[light_id].light_class) {
+            const DPortalLight& pl = s.portal_lights[s.lights[light_id].sampler];
+            portalUvw(loadTrafo(s, s.lights[pl.light_link].prop), -wo, u, vv);  // (the host refuses an animated link)
+        }
+    }
     const float stochastic_r = smp.sample1D();  // rs.stochastic_r
-    const f3    energy = materialRadiance<MESHL>(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface, frag.uv0, frag.uv1, stochastic_r);
+    const f3    energy = materialRadiance<MESHL>(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface, u, vv, stochastic_r);
     const float weight = lightPdf<MESHL>(s, v, -wo, frag);
     return S3(weight) * energy;
 }
@@ -2388,7 +2400,27 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             // A shape's sampleTo draws all of its light samples before the first shadow test (rectangle.zig:321-352,
             // triangle_mesh.zig:513-592); instead of buffering them, a copy of the sampler replays those draws while
             // the path's sampler runs ahead to where the post-visibility draws continue.
-            if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
+            if (MESHL && ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {
+                // Light.propSamplePortalTo (light.zig:217-240) -> Rectangle.samplePortalTo (rectangle.zig:458-513): the window the
+                // point sees the portal through, then the map's windowed distribution; no window, no draw
+                const DPortalLight& pl = s.portal_lights[light.sampler];
+                Bounds2             bounds;
+                if (portalImageBounds(sf.p, trafo, bounds)) {
+                    const uint32_t n = numSamples(light.num_samples, sample_threshold);
+                    const Trafo    dome = loadTrafo(s, s.lights[pl.light_link].prop);  // (the host refuses an animated link)
+                    Sampler        replay = h.smp;
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float a, b;
+                        h.smp.sample2D(a, b);
+                    }
+                    for (uint32_t j = 0; j < n; ++j) {
+                        float r0, r1;
+                        replay.sample2D(r0, r1);
+                        SampleTo ls;
+                        if (rectangleSamplePortal(pl, dome, bounds, r0, r1, float(n), sf.p, ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
+                    }
+                }
+            } else if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
                 // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
                 const DImageLight& il = s.image_lights[light.sampler];
                 if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape || ZYGPU_SHAPE_DISK == light_shape) {

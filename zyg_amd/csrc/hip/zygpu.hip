@@ -525,11 +525,13 @@ uint32_t meshKernelMinTriangles() {
 uint32_t queueEntries(size_t paths) { return uint32_t((paths + 255) / 256 * 256); }
 size_t   queueCapacity(size_t paths) { return queueEntries(paths); }
 
-bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out) {
+// num_orders: light_orders has an entry per light of the scene, sampled by the tree or not (a Portal's linked light is a prototype:
+// in the scene's list, not in the tree's num_lights)
+bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out, uint32_t num_orders) {
     std::memset(out, 0, sizeof(*out));
     bool ok = m.upload(lt.nodes, lt.num_nodes, &out->nodes);
     ok = ok && m.upload(lt.node_middles, lt.num_nodes, &out->middles);
-    ok = ok && m.upload(lt.light_orders, lt.num_lights, &out->orders);
+    ok = ok && m.upload(lt.light_orders, std::max(num_orders, lt.num_lights), &out->orders);
     ok = ok && m.upload(lt.light_mapping, lt.num_lights, &out->mapping);
     out->bounds_min = make_float4(lt.bounds.min[0], lt.bounds.min[1], lt.bounds.min[2], lt.bounds.min[3]);
     out->bounds_max = make_float4(lt.bounds.max[0], lt.bounds.max[1], lt.bounds.max[2], lt.bounds.max[3]);
@@ -795,7 +797,14 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
         // the same kernel instantiations carry the infinite and Sphere light code
         if (is_infinite || ZYGPU_SHAPE_SPHERE == lp.shape || ZYGPU_SHAPE_DISK == lp.shape) c->mesh_lights = true;
-        if (ZYGPU_LIGHT_PROP_IMAGE == d->lights[l].light_class) {
+        if (ZYGPU_LIGHT_PORTAL_IMAGE == d->lights[l].light_class) {
+            if (ZYGPU_SHAPE_RECTANGLE != lp.shape || d->lights[l].sampler >= d->num_portal_lights ||
+                d->portal_lights[d->lights[l].sampler].light_link >= d->num_lights) {
+                g_error = "a Portal light is a Rectangle with its ZygpuPortalLight (ZygpuLight.sampler) and a linked light";
+                return -2;
+            }
+            c->mesh_lights = true;  // the sampling code lives in the MESHL instantiations
+        } else if (ZYGPU_LIGHT_PROP_IMAGE == d->lights[l].light_class) {
             if ((ZYGPU_SHAPE_DOME != lp.shape && ZYGPU_SHAPE_CANOPY != lp.shape && ZYGPU_SHAPE_RECTANGLE != lp.shape &&
                  ZYGPU_SHAPE_DISK != lp.shape && ZYGPU_SHAPE_SPHERE != lp.shape) ||
                 d->lights[l].sampler >= d->num_image_lights) {
@@ -858,7 +867,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     ok = ok && m.upload(d->solid.indices, d->solid.num_indices, &s.solid_indices);
     ok = ok && m.upload(reinterpret_cast<const float4*>(d->unoccluding.nodes), size_t(d->unoccluding.num_nodes) * 2, &s.unocc_nodes);
     ok = ok && m.upload(d->unoccluding.indices, d->unoccluding.num_indices, &s.unocc_indices);
-    ok = ok && uploadLightTree(m, d->light_tree, &s.light_tree);
+    ok = ok && uploadLightTree(m, d->light_tree, &s.light_tree, d->num_lights);
     ok = ok && m.upload(d->luts.e_m, d->luts.e_m ? 32 * 32 : 0, &s.lut_e_m);
     ok = ok && m.upload(d->luts.e_m_avg, d->luts.e_m_avg ? 32 : 0, &s.lut_e_m_avg);
     ok = ok && m.upload(d->luts.e, d->luts.e ? 16 * 16 * 16 : 0, &s.lut_e);
@@ -1016,7 +1025,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             g_error = "ZygpuMeshLight: bad mesh index or mesh without primitive_mapping";
             return -2;
         }
-        ok = uploadLightTree(m, hl.tree, &dl.tree);
+        ok = uploadLightTree(m, hl.tree, &dl.tree, hl.tree.num_lights);
         ok = ok && m.upload(reinterpret_cast<const float4*>(hl.tri_props), size_t(hl.num_triangles) * 2, &dl.tree.tri_props);
         ok = ok && m.upload(hl.triangle_mapping, hl.num_triangles, &dl.triangle_mapping);
         if (!ok) return -1;
@@ -1037,6 +1046,16 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         dl.sampler = hl.sampler;
     }
     if (!m.upload(image_lights.data(), image_lights.size(), &s.image_lights)) return -1;
+    std::vector<DPortalLight> portal_lights(d->num_portal_lights);
+    for (uint32_t i = 0; i < d->num_portal_lights; ++i) {
+        const ZygpuPortalLight& hl = d->portal_lights[i];
+        DPortalLight&           dl = portal_lights[i];
+        dl.dim = hl.dim;
+        dl.light_link = hl.light_link;
+        if (!m.upload(hl.sat, size_t(hl.dim + 1) * (hl.dim + 1), &dl.sat) || !m.upload(hl.func, size_t(hl.dim) * hl.dim, &dl.func)) return -1;
+    }
+    s.portal_lights = nullptr;
+    if (d->num_portal_lights && !m.upload(portal_lights.data(), portal_lights.size(), &s.portal_lights)) return -1;
     // the Sky entity's sun table (ZygpuSceneDesc.sun_radiance): 4 floats per sample
     s.num_sun_radiance = d->sun_radiance ? d->num_sun_radiance : 0u;
     if (!m.upload(reinterpret_cast<const float4*>(d->sun_radiance), s.num_sun_radiance, &s.sun_radiance)) return -1;

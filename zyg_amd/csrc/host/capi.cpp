@@ -431,6 +431,16 @@ int32_t su_ext_load_take(const char* take_filename) {
     return 0;
 }
 
+int32_t su_ext_portal_create(uint32_t shape, uint32_t light_id) {
+    if (!g) return -1;
+    return g->engine.createPortal(shape, light_id);
+}
+
+int32_t su_ext_light_create_linked(uint32_t prop, uint32_t light_id) {
+    if (!g) return -1;
+    return 0 == g->engine.createLight(prop, light_id) ? 0 : -1;
+}
+
 int32_t su_ext_prop_set_shadow_catcher(uint32_t prop) {
     if (!g) return -1;
     return 0 == g->engine.setShadowCatcher(prop) ? 0 : -1;

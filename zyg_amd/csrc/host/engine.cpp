@@ -785,7 +785,17 @@ int32_t Engine::createPropInstance(uint32_t entity) {  // scene.zig:307-316
     return int32_t(id);
 }
 
-int Engine::createLight(uint32_t entity) {  // scene.zig:344-372
+int32_t Engine::createPortal(uint32_t shape, uint32_t light_id) {  // scene_loader.zig:371-397
+    if (light_id >= lights_.size() || shape >= shapes_.size()) return -1;  // Error.UndefinedLight
+    const ZygpuLight& l = lights_[light_id];
+    setVisibility(l.prop, false, false, false, false);
+    lights_[light_id].prototype = 1;  // scene.lightSetPrototype
+    const uint32_t        material = material_ids_[props_[l.prop].parts_start + l.part];
+    std::vector<uint32_t> materials(shapeNumMaterials(shape), material);
+    return createPropShape(shape, materials.data(), uint32_t(materials.size()), true);
+}
+
+int Engine::createLight(uint32_t entity, uint32_t light_link) {  // scene.zig:344-372
     if (entity >= props_.size()) return -1;
     const HostProp& p = props_[entity];
     const uint32_t  num_parts = shapeNumParts(p.shape);
@@ -801,6 +811,8 @@ int Engine::createLight(uint32_t entity) {  // scene.zig:344-372
         l.shadow_catcher_light = (p.flags & ZYGPU_PROP_SHADOW_CATCHER_LIGHT) ? 1 : 0;
         l.prototype = 0;
         lights_.push_back(l);
+        light_links_.resize(lights_.size(), ZYGPU_NULL);
+        light_links_.back() = light_link;
     }
     return 0;
 }
@@ -1128,6 +1140,99 @@ uint32_t Engine::prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m, 
     }
     appendDistribution1D(integrals, il);
     return uint32_t(image_lights_.size() - 1);
+}
+
+// Light.Material.preparePortalSampling (light_material.zig:142-199, 275-375): the linked Dome's emission map seen through the
+// portal.  average_emission: the uv-weighted mean of the map over the hemisphere behind the portal (PortalHemisphereContext); the
+// function the WindowedDistribution2D tabulates: for every texel of the portal's own dim x dim image (Portal.imageToWorld, 4 x 4
+// subsamples) the map's brightest channel in that direction (nearest texel) times the mapping's weight (PortalLuminanceContext);
+// then its summed-area table (summed_area_table.zig:18-48).
+uint32_t Engine::preparePortalLight(const ZygpuMaterial& m, const Transformation& portal, const Transformation& dome, uint32_t light_link) {
+    ensureSrgbTable();
+    const HostImage& img = images_[m.emission_image];
+    const int        w = img.width, h = img.height;
+    portal_lights_.emplace_back();
+    HostPortalLight& pl = portal_lights_.back();
+    pl.light_link = light_link;
+    pl.dim = uint32_t(h);
+    auto texel = [&](int x, int y) {  // Texture.image2D_3 (texture.zig:188-219)
+        const size_t i = size_t(y) * size_t(w) + size_t(x);
+        if (ZYGPU_IMAGE_BYTE3_SRGB == img.format) {
+            const uint8_t* p = img.pixels.data() + 3 * i;
+            const float    r = srgb_to_float_[p[0]], g = srgb_to_float_[p[1]], b = srgb_to_float_[p[2]];
+            return vec(0.61309732f, 0.07019422f, 0.02061560f, 0.f) * splat(r) + vec(0.33952285f, 0.91635557f, 0.10956983f, 0.f) * splat(g) +
+                   vec(0.04737928f, 0.01345259f, 0.86981512f, 0.f) * splat(b);
+        }
+        const float* p = reinterpret_cast<const float*>(img.pixels.data()) + 3 * i;
+        return vec(p[0], p[1], p[2], 0.f);
+    };
+    const Mat3x3 portal_rot = quaternionToMat3x3(portal.rotation), dome_rot = quaternionToMat3x3(dome.rotation);
+    const float  pi = float(M_PI);
+    const Vec4f  portal_dir = portal_rot.r[2];
+    {  // PortalHemisphereContext
+        const float idf0 = 1.f / float(w), idf1 = 1.f / float(h);
+        Vec4f       avg = splat(0.f);
+        for (int y = 0; y < h; ++y) {
+            const float v = idf1 * (float(y) + 0.5f);
+            for (int x = 0; x < w; ++x) {
+                const float u = idf0 * (float(x) + 0.5f);
+                // Dome.imageToWorld (dome.zig:68-80)
+                const float phi = (u - 0.5f) * (2.f * pi), theta = v * pi;
+                const Vec4f ldir = vec(std::sin(phi) * std::sin(theta), std::cos(theta), std::cos(phi) * std::sin(theta));
+                const Vec4f dir = transformVector(dome_rot, ldir);
+                if (dot3(portal_dir, dir) <= 0.f) {  // "We see the hemisphere behind the portal"
+                    const float uv_weight = std::sin(v * pi);  // Shape.uvWeight of a Dome (shape.zig:539)
+                    const Vec4f wr = splat(uv_weight) * texel(x, y);
+                    avg = avg + vec(wr[0], wr[1], wr[2], uv_weight);
+                }
+            }
+        }
+        const Vec4f average = avg / splat(avg[3]);
+        pl.average_emission = vec(m.emission[0], m.emission[1], m.emission[2], 0.f) * average;
+    }
+    const uint32_t dim = pl.dim;
+    pl.func.assign(size_t(dim) * dim, 0.f);
+    {  // PortalLuminanceContext
+        const float idf = 1.f / float(dim), nsf = 4.f, so = 0.5f / nsf;
+        const bool  ru = 0 != (m.emission_sampler & ZYGPU_TEX_REPEAT_U), rv = 0 != (m.emission_sampler & ZYGPU_TEX_REPEAT_V);
+        auto address = [](bool repeat, float x) { return repeat ? x - std::floor(x) : std::min(std::max(x, 0.f), 1.f); };
+        for (uint32_t y = 0; y < dim; ++y) {
+            for (uint32_t x = 0; x < dim; ++x) {
+                float luminance = 0.f;
+                for (int yy = 0; yy < 4; ++yy) {
+                    const float v = idf * (float(y) + so + float(yy) / nsf);
+                    for (int xx = 0; xx < 4; ++xx) {
+                        const float u = idf * (float(x) + so + float(xx) / nsf);
+                        // Portal.imageToWorld (portal.zig:16-25)
+                        const float a = -pi * 0.5f + u * pi, b = -pi * 0.5f + v * pi;
+                        const Vec4f wv = normalize3(vec(std::tan(a), std::tan(b), 1.f));
+                        const float weight = (pi * pi) * (1.f - wv[0] * wv[0]) * (1.f - wv[1] * wv[1]) / wv[2];
+                        const Vec4f dir = -transformVector(portal_rot, wv);
+                        // Dome.worldToImage (dome.zig:59-66)
+                        const Vec4f xyz = normalize3(transformVectorTransposed(dome_rot, dir));
+                        const float du = std::atan2(xyz[0], xyz[2]) * ((1.f / pi) * 0.5f) + 0.5f, dv = std::acos(xyz[1]) * (1.f / pi);
+                        // ts.sampleImageNearest2D_3 (texture_sampler.zig:105-123)
+                        const float s_ = address(ru, m.emission_scale[0] * du), t_ = address(rv, m.emission_scale[1] * dv);
+                        const int   tx = std::min(int(s_ * float(w)), w - 1), ty = std::min(int(t_ * float(h)), h - 1);
+                        luminance += hmax3(texel(tx, ty)) * weight;
+                    }
+                }
+                pl.func[size_t(y) * dim + x] = luminance / (nsf * nsf);
+            }
+        }
+    }
+    {  // SummedAreaTable.init
+        const int32_t sw = int32_t(dim) + 1;
+        pl.sat.assign(size_t(sw) * sw, 0.f);
+        auto at = [&](int32_t x, int32_t y) -> float& { return pl.sat[size_t(y) * sw + x]; };
+        auto f = [&](int32_t x, int32_t y) { return pl.func[size_t(y) * dim + x]; };
+        at(1, 1) = f(0, 0);
+        for (int32_t x = 2; x < sw; ++x) at(x, 1) = f(x - 1, 0) + at(x - 1, 1);
+        for (int32_t y = 2; y < sw; ++y) at(1, y) = f(0, y - 1) + at(1, y - 1);
+        for (int32_t y = 2; y < sw; ++y)
+            for (int32_t x = 2; x < sw; ++x) at(x, y) = f(x - 1, y - 1) + at(x - 1, y) + at(x, y - 1) - at(x - 1, y - 1);
+    }
+    return uint32_t(portal_lights_.size() - 1);
 }
 
 uint32_t Engine::prepareMeshLight(uint32_t mesh_id, uint32_t part, uint32_t material, bool two_sided) {
@@ -1515,12 +1620,15 @@ int Engine::compile(uint32_t frame) {
     // lights: scene.zig:402-497 (propPrepareSampling, static branch)
     mesh_lights_.clear();
     image_lights_.clear();
+    portal_lights_.clear();
+    light_links_.resize(lights_.size(), ZYGPU_NULL);
     std::fill(light_ids_.begin(), light_ids_.end(), ZYGPU_NULL);
     const uint32_t nl = uint32_t(lights_.size());
     c_light_aabbs_.resize(nl);
     c_light_cones_.resize(size_t(nl) * 4);
     c_light_two_sided_.resize(nl);
     c_light_infinite_.assign(nl, 0);
+    c_light_prototype_.assign(nl, 0);
     // Scene.aabb() = the solid tree's bounds (scene.zig:173-175): scales the power of infinite lights (light.zig:67-77)
     AABB scene_bb = emptyAabb();
     if (!solid_nodes_.empty()) {
@@ -1550,7 +1658,18 @@ int Engine::compile(uint32_t frame) {
         const bool sky_map = ZYGPU_NULL != sky_.sky && l.prop == sky_.sky;
         const bool image_light = ZYGPU_MAT_LIGHT == m.kind && ZYGPU_NULL != m.emission_image;
         l.light_class = ZYGPU_LIGHT_PROP;
-        if (image_light) {
+        c_light_prototype_[li] = l.prototype;
+        const uint32_t light_link = light_links_[li];
+        if (image_light && ZYGPU_NULL != light_link) {
+            // scene.zig:361-364: a linked light with a mapped emission is a Portal; Shape.samplePortalTo knows Rectangles only
+            // (shape.zig:373-391: any other shape never yields a sample), and the link is a Dome (Dome.worldToImage)
+            if (m.emission_image >= images_.size() || light_link >= nl) return -4;
+            if (ZYGPU_SHAPE_RECTANGLE != s.kind || ZYGPU_SHAPE_DOME != shapes_[props_[lights_[light_link].prop].shape].kind) return -3;
+            // the device reads the map where the ray points through the linked Dome's transformation at the frame's start
+            if (ZYGPU_NULL != c_prop_frames_[lights_[light_link].prop] || ZYGPU_NULL != c_prop_frames_[l.prop]) return -3;
+            l.sampler = preparePortalLight(m, frameStartTransformation(l.prop), frameStartTransformation(lights_[light_link].prop), light_link);
+            l.light_class = ZYGPU_LIGHT_PORTAL_IMAGE;
+        } else if (image_light) {
             if (m.emission_image >= images_.size()) return -4;
             if (is_mesh || is_distant) return -3;  // Shape.sampleMaterialTo has no case for them (shape.zig:348-371)
             l.sampler = prepareImageLight(s.kind, m, !sky_map);
@@ -1604,11 +1723,14 @@ int Engine::compile(uint32_t frame) {
                              : is_distant ? (2.f * float(M_PI)) * (1.f - std::sqrt(1.f / (t.scale[0] * t.scale[0] + 1.f)))
                              : is_mesh  ? meshes_[s.mesh].part_areas[l.part] * (t.scale[0] * t.scale[1])
                                         : t.scale[0] * t.scale[1];
-        Vec4f       emission = image_light ? image_lights_[l.sampler].average_emission : vec(m.emission[0], m.emission[1], m.emission[2], 0.f);
+        Vec4f       emission = ZYGPU_LIGHT_PORTAL_IMAGE == l.light_class ? portal_lights_[l.sampler].average_emission
+                               : image_light                             ? image_lights_[l.sampler].average_emission
+                                                                         : vec(m.emission[0], m.emission[1], m.emission[2], 0.f);
         // emittance.zig:61-71 totalEmission; light.zig:67-77 power: infinite lights scale with the scene's extent
         Vec4f power = splat(0.f);
         if (extent > 0.f) power = m.emission_normalize ? emission : emission * splat(extent);
         if (is_infinite && !solid_nodes_.empty()) power = splat(squaredLength3(aabbExtent(scene_bb))) * power;
+        if (l.prototype) power = splat(0.f);  // light.zig:64-67
         bb.b[0][3] = hmax3(power);
 
         for (int i = 0; i < 4; ++i) {
@@ -1622,6 +1744,7 @@ int Engine::compile(uint32_t frame) {
     lin.cones = c_light_cones_.data();
     lin.two_sided = c_light_two_sided_.data();
     lin.infinite = c_light_infinite_.data();
+    lin.prototype = c_light_prototype_.data();
     lin.num_lights = nl;
     LightTreeBuilder ltb;
     ltb.build(lin, light_tree_);
@@ -1675,6 +1798,11 @@ int Engine::compile(uint32_t frame) {
     }
     d.image_lights = c_image_lights_.data();
     d.num_image_lights = uint32_t(c_image_lights_.size());
+    c_portal_lights_.resize(portal_lights_.size());
+    for (size_t i = 0; i < portal_lights_.size(); ++i)
+        c_portal_lights_[i] = ZygpuPortalLight{portal_lights_[i].sat.data(), portal_lights_[i].func.data(), portal_lights_[i].dim, portal_lights_[i].light_link};
+    d.portal_lights = c_portal_lights_.empty() ? nullptr : c_portal_lights_.data();
+    d.num_portal_lights = uint32_t(c_portal_lights_.size());
     auto channels = [&](uint32_t image) {
         const uint32_t f = images_[image].format;
         return (ZYGPU_IMAGE_BYTE3_SRGB == f || ZYGPU_IMAGE_FLOAT3 == f) ? 3 : (ZYGPU_IMAGE_BYTE2 == f || ZYGPU_IMAGE_FLOAT2 == f) ? 2 : 1;

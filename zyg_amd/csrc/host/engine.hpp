@@ -117,7 +117,13 @@ class Engine {
     uint32_t createEntity();
     int32_t  createPropShape(uint32_t shape, const uint32_t* materials, uint32_t num_materials, bool unoccluding);
     int32_t  createPropInstance(uint32_t entity);
-    int      createLight(uint32_t entity);
+    // light_link (scene.zig:344-372, 707): the light a Portal is a window onto, or ZYGPU_NULL
+    int      createLight(uint32_t entity, uint32_t light_link = ZYGPU_NULL);
+    // A Portal entity (util/scene_loader.zig:241-248, 371-397 loadPortal): a prop of `shape` (a Rectangle) that takes the material
+    // of light `light_id` (a Dome with an emission map), which it hides and turns into a prototype (never sampled itself); the
+    // caller places the prop and then calls createLight(prop, light_id).  Returns the prop or -1.
+    int32_t  createPortal(uint32_t shape, uint32_t light_id);
+    uint32_t numLights() const { return uint32_t(lights_.size()); }
     int      setTransformation(uint32_t prop, const float* m16);
     int      setWorldTransformation(uint32_t prop, const Transformation& t);  // the loaders' path (scene_graph.zig:178-230)
     // su_prop_set_transformation_frame (capi.zig:506-533): keyframe `frame` (< numInterpolationFrames()) of the prop.  The
@@ -229,6 +235,16 @@ class Engine {
     std::deque<HostImageLight>   image_lights_;
     std::vector<ZygpuImageLight> c_image_lights_;
     uint32_t prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m, bool compensate = true);
+    struct HostPortalLight {
+        std::vector<float> sat, func;
+        uint32_t           dim = 0, light_link = ZYGPU_NULL;
+        Vec4f              average_emission;
+    };
+    std::deque<HostPortalLight>   portal_lights_;
+    std::vector<ZygpuPortalLight> c_portal_lights_;
+    std::vector<uint32_t>         light_links_;  // per light (scene.light_links)
+    std::vector<uint8_t>          c_light_prototype_;
+    uint32_t preparePortalLight(const ZygpuMaterial& m, const Transformation& portal, const Transformation& dome, uint32_t light_link);
     struct HostSky {
         uint32_t sun = ZYGPU_NULL, sky = ZYGPU_NULL, sun_material = ZYGPU_NULL, sky_material = ZYGPU_NULL, image = ZYGPU_NULL;
         float    visibility = 100.f, albedo = 0.25f;                                                   // sky.zig:39-40

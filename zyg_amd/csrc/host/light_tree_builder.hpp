@@ -21,6 +21,7 @@ struct LightTreeInput {
     const float*     powers = nullptr;  // per light; nullptr: aabbs[l].min[3]
     bool             all_two_sided = false;
     const uint8_t*   infinite = nullptr;  // per light: its shape is infinite (Distant); nullptr: all finite
+    const uint8_t*   prototype = nullptr; // per light: never sampled itself (a Portal's linked light, scene.zig:558-576); nullptr: none
 };
 
 struct LightTreeOutput {
@@ -45,19 +46,23 @@ class LightTreeBuilder {
         sweep_threshold_ = SceneSweepThreshold;
         primitive_ = false;
 
-        const uint32_t num_lights = in.num_lights;
+        // scene.numLights() / numSampleableLights() (light_tree_builder.zig:281-282): prototypes are in neither list
+        const uint32_t num_all_lights = in.num_lights;
+        auto           sampleable = [&](uint32_t l) { return !(in.prototype && in.prototype[l]); };
+        uint32_t       num_lights = 0;
+        for (uint32_t l = 0; l < num_all_lights; ++l) num_lights += sampleable(l) ? 1u : 0u;
         out.light_mapping.resize(num_lights);
-        out.light_orders.assign(num_lights, 0);
+        out.light_orders.assign(num_all_lights, 0);
         light_order_ = 0;
 
         // light_tree_builder.zig:289-330: infinite lights first (sampled from a discrete distribution over their powers, never
         // part of the BVH), then the finite ones
         uint32_t lm = 0;
-        for (uint32_t l = 0; l < num_lights; ++l)
-            if (in.infinite && in.infinite[l]) out.light_mapping[lm++] = l;
+        for (uint32_t l = 0; l < num_all_lights; ++l)
+            if (sampleable(l) && in.infinite && in.infinite[l]) out.light_mapping[lm++] = l;
         const uint32_t num_infinite_lights = lm;
-        for (uint32_t l = 0; l < num_lights; ++l)
-            if (!(in.infinite && in.infinite[l])) out.light_mapping[lm++] = l;
+        for (uint32_t l = 0; l < num_all_lights; ++l)
+            if (sampleable(l) && !(in.infinite && in.infinite[l])) out.light_mapping[lm++] = l;
 
         float              infinite_total_power = 0.f;
         std::vector<float> infinite_powers(num_infinite_lights);

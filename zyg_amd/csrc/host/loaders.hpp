@@ -8,7 +8,7 @@
 // File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
 // core/file/system.zig, reduced to these two levels).  Sky entities create the sun and the sky (engine.cpp createSky; the bake's tables are a
 // procedural stand-in unless the client hands them over).  Refused by name (the load fails, nothing is skipped in silence):
-// instancers, scatterers, portals, animations.  Not read: glTF, gzip-compressed files.
+// instancers, scatterers, animations.  Not read: glTF, gzip-compressed files.
 #pragma once
 
 #include <cstdio>
@@ -266,7 +266,7 @@ class TakeLoader {
                     const std::string& dir, Transformation& world) {
         const JsonValue* type = v.get("type");
         if (!type || JsonValue::String != type->type) return false;  // Error.UndefinedType
-        uint32_t entity = ZYGPU_NULL;
+        uint32_t entity = ZYGPU_NULL, light_link = ZYGPU_NULL;
         bool     is_light = false;
         if (type->str == "Light") {
             entity = loadProp(v, local_materials, dir, true);
@@ -280,7 +280,17 @@ class TakeLoader {
             if (sun < 0) return false;
             if (const JsonValue* parameters = v.get("parameters")) engine_.setSkyParameters(*parameters);
             entity = uint32_t(sun);
-        } else if (type->str == "Portal" || type->str == "Instancer" || type->str == "Scatterer") {
+        } else if (type->str == "Portal") {  // loadPortal (scene_loader.zig:371-397): a window onto light `light`
+            const JsonValue* sv = v.get("shape");
+            if (!sv || JsonValue::Object != sv->type) return false;  // Error.UndefinedShape
+            const uint32_t shape = loadShape(*sv, dir);
+            if (ZYGPU_NULL == shape) return false;
+            light_link = v.memberU32("light", 0);
+            const int32_t p = engine_.createPortal(shape, light_link);
+            if (p < 0) return false;  // Error.UndefinedLight
+            entity = uint32_t(p);
+            is_light = true;
+        } else if (type->str == "Instancer" || type->str == "Scatterer") {
             return unsupported("a \"" + type->str + "\" entity");
         }  // any other type is a node without an entity: its transformation applies to its children (scene_loader.zig:241-264)
         if (v.get("animation")) return unsupported("an entity with an \"animation\"");
@@ -296,7 +306,7 @@ class TakeLoader {
                                   vis->memberBool("shadow_catcher_light", false));
         }
         if (v.get("shadow_catcher")) engine_.setShadowCatcher(entity);  // scene_loader.zig:312-313
-        if (is_light && in_reflection) engine_.createLight(entity);
+        if (is_light && in_reflection) engine_.createLight(entity, light_link);
         return true;
     }
     uint32_t loadProp(const JsonValue& v, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir,

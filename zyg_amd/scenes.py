@@ -373,7 +373,7 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
             light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None,
-            overrides=None, regularize=None, mesh_position=(0, 0.02, 0.1), box_subdivide=1, box_first_face=None, extra_props=0):
+            overrides=None, regularize=None, mesh_position=(0, 0.02, 0.1), box_subdivide=1, box_first_face=None, extra_props=0, portal_map=None):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed at mesh_position (the
@@ -394,6 +394,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     lens: thin-lens camera parameters, e.g. {"lens": {"radius": 0.05}, "focus": {"distance": 3.9}}
     (camera_perspective.zig:124-150, 260-270, aperture.zig:46-53).
     overrides: material JSONs by place: "floor", "back", "left", "right", "ceiling", "tall", "short", "sphere_a", "sphere_b".
+    portal_map: a lat-long environment image: instead of the ceiling and the two lamps the box is lit through a Portal in the
+    ceiling's place, a window onto a Dome with that map (scene/shape/portal.zig; the Dome itself becomes a hidden prototype).
     box_subdivide / box_first_face: the two boxes' triangle counts (box_mesh); extra_props: that many small Rectangle plaques on
     the back wall (the prop count: the device's prop tables hold 16).
     Returns a dict with prop ids.
@@ -452,7 +454,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     # box: x in [-1, 1], y in [0, 2], z in [-1, 1]; all normals point inward; open towards -z (camera side)
     floor = pick("floor", white) if floor_material is None else engine.material(floor_material)
     wall(floor, (1, 0, 0), (0, 0, -1), (2, 2, 1), (0, 0, 0))   # floor, n = +y
-    wall(pick("ceiling", white), (1, 0, 0), (0, 0, 1), (2, 2, 1), (0, 2, 0))    # ceiling, n = -y
+    if portal_map is None:
+        wall(pick("ceiling", white), (1, 0, 0), (0, 0, 1), (2, 2, 1), (0, 2, 0))    # ceiling, n = -y
     wall(pick("back", white), (-1, 0, 0), (0, 1, 0), (2, 2, 1), (0, 1, 1))   # back, n = -z
     wall(pick("left", red), (0, 0, -1), (0, 1, 0), (2, 2, 1), (-1, 1, 0))    # left, n = +x
     wall(pick("right", green), (0, 0, 1), (0, 1, 0), (2, 2, 1), (1, 1, 0))    # right, n = -x
@@ -472,7 +475,17 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             p = engine.prop(SPHERE, [mat_])
             engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (d_, d_, d_), pos_))
             ids["meshes"].append(p)
-    for lx in (() if many_lights else (-0.45, 0.45)):  # two emissive quads just below the ceiling, facing down
+    if portal_map is not None:
+        env = engine.material(light_material(spectrum=(1.0, 1.0, 1.0), emission_map=engine.image(portal_map), num_samples=light_samples))
+        dome = engine.prop(DOME, [env])
+        engine.transformation(dome, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 0)))
+        engine.light(dome)  # light 0: what the portal is a window onto
+        window = engine.portal(0)
+        engine.transformation(window, trafo((1, 0, 0), (0, 0, 1), (1.6, 1.6, 1), (0, 2.0, 0)))  # in the ceiling's plane, facing down
+        engine.portal_light(window, 0)
+        ids["lights"].append(window)
+        ids["dome"] = dome
+    for lx in (() if (many_lights or portal_map is not None) else (-0.45, 0.45)):  # two emissive quads just below the ceiling, facing down
         if disk_lights:  # Disk = shape 2; the second one tilted and lower, so that points see it at grazing angles
             p = engine.prop(2, [lamp], unoccluding=unoccluding_lights)
             if lx < 0:
