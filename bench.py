@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--mesh-kernels", type=int, default=1, choices=[0, 1],
                     help="zygpu option mesh_kernels: the large meshes' walks in persistent kernels whose lanes fetch their own rays")
     ap.add_argument("--mesh-closest", type=int, default=0, choices=[0, 1], help="zygpu option mesh_closest (wf_mesh_closest)")
+    ap.add_argument("--sort-alive", type=int, default=-1, choices=[-1, 0, 1],
+                    help="zygpu option sort_alive: the surviving paths in one sub-queue per hit prop, so that the consumer's waves stand on one "
+                         "surface (-1: the library's choice, on in the scenes of the mesh kernels)")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed oracle sample (and again of the parity band)")
@@ -126,6 +129,7 @@ class Measurement:
         self.eng.set_option("fuse_tick", args.fuse_tick)
         self.eng.set_option("mesh_kernels", args.mesh_kernels)
         self.eng.set_option("mesh_closest", args.mesh_closest)
+        self.eng.set_option("sort_alive", args.sort_alive)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)
         self.fused = bool(args.fuse) and scene in ("cornell", "cornell_mesh", "cornell_mound")  # POOL scenes always run the kernels apart
         self.film = torch.zeros((self.h, self.w, 4), dtype=torch.float32, device=device)
@@ -388,7 +392,8 @@ def launch_ranks(args):
     has initialised the GPU is never re-executed); rank 0's child prints the one JSON line on the inherited stdout."""
     import socket
     from zyg_amd import build as zbuild
-    zbuild.ensure_built()
+    if not os.environ.get("ZYG_AMD_LIB"):  # (a development variant is measured as it was built)
+        zbuild.ensure_built()
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -434,7 +439,8 @@ def main():
     # The library is built before any process group exists, under a file lock: whichever rank comes first builds it when it is
     # missing or older than its sources, the others wait and find it fresh.  Nothing is ever measured with a stale library.
     from zyg_amd import build as zbuild
-    zbuild.ensure_built()
+    if not os.environ.get("ZYG_AMD_LIB"):  # (a development variant, tools/variants_bench.sh, is measured as it was built)
+        zbuild.ensure_built()
     source_hash = zbuild.source_hash()
 
     import numpy as np  # noqa: F401

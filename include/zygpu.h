@@ -517,7 +517,10 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * is faster with the couple of light picks per vertex of BASELINE's scenes; the rounds keep every lane busy when a
  * vertex picks many lights; scenes with multi-sample or TriangleMesh lights always run in place);
  * "batch_mpaths" (default 32, 1..512) sets the number of paths per batch in units of 2^20 (the path pool takes about
- * 450 B per path). */
+ * 450 B per path);
+ * "sort_alive" (default -1: the library's choice, on in the scenes whose large meshes run in the mesh kernels; 1 / 0) keeps the
+ * paths that survive a tick's shading in one sub-queue per hit prop (16 of them), so that the waves of the kernel that
+ * scatters them stand on one surface each; results are addressed by path slot, the film is the same bits either way. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.

@@ -1312,3 +1312,36 @@ def test_regularised_smooth_glass_breaks_down_like_the_reference(engine, oracle)
     cpu = oracle_render(oracle, sd, vd, spp)
     assert np.array_equal(film, cpu, equal_nan=True)
     assert np.array_equal(np.isnan(film), np.isnan(cpu))
+
+
+@pytest.mark.parametrize("variant", ["boxes", "props", "mesh", "staged", "multi"])
+def test_sorted_alive_queue_is_only_an_order(engine, oracle, variant):
+    """Option sort_alive (by default on in the scenes of the mesh kernels; wavefront.hpp kAliveKeys): wf_trace_shade's prop-table instantiations append the surviving paths to
+    one sub-queue per hit prop (mod 16), every consumer (wf_scatter, wf_scatter_h, the staged wf_nee / wf_extend) reads whole blocks of one
+    sub-queue.  Every result is addressed by the path's slot, so the film may not depend on it: sorted and unsorted films are the same
+    bits in both arithmetic modes, and the precise one is the oracle's.  props: 21 props, so that prop numbers share sub-queues; mesh: a
+    mesh past the mesh-kernel threshold (wf_scatter_h + wf_shadow_u in the relaxed units); staged: wf_nee rounds; multi: two light samples
+    per pick (wf_scatter's MULTI instantiation)."""
+    w, h, spp = 96, 72, 4
+    kw = {"boxes": {}, "props": {"extra_props": 12}, "mesh": {"boxes": False, "mesh": scenes.heightfield_mesh(n=64)}, "staged": {},
+          "multi": {"light_samples": 2}}[variant]
+    scenes.cornell(engine, w, h, spp, integrator="PTMIS", **kw)
+    engine.start_frame(0)
+    engine.set_option("nee_in_place", 0 if "staged" == variant else 1)
+    films = {}
+    for precise in (1, 0):
+        for sort in (1, 0):
+            engine.set_option("precise", precise)
+            engine.set_option("sort_alive", sort)
+            assert engine.lib.zygpu_clear_film(engine.context(), ctypes.c_float(0.0)) == 0
+            assert engine.lib.zygpu_render(engine.context(), 0, 0, spp, 0, h) == 0
+            engine.synchronize()
+            films[precise, sort] = engine.download_film(w, h)
+    engine.set_option("sort_alive", -1)
+    engine.set_option("precise", 1)
+    for precise in (1, 0):
+        assert np.isfinite(films[precise, 1]).all()
+        assert np.array_equal(films[precise, 1], films[precise, 0]), f"precise {precise}: the sorted queue changes the film"
+    sd = engine.lib.su_ext_scene_desc().contents
+    vd = engine.lib.su_ext_view_desc().contents
+    assert np.array_equal(films[1, 1], oracle_render(oracle, sd, vd, spp))

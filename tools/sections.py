@@ -38,7 +38,10 @@ names = {0: "shade: state loads + fragment", 1: "shade: hit emission (evaluateRa
 for base, label in ((0, "wf_trace_shade + wf_shade"), (16, "wf_scatter")):
     tot = sum(out[base:base + 16]) or 1
     print(f"{label}: {tot / 1e9:.2f} G wave-cycles")
-    for i in range(base, base + 16):
+    if 16 == base:  # wf_scatter: sections 24-31 = cycles x lanes at the mark of sections 16-23
+        tot = sum(out[16:24]) or 1
+    for i in range(base, base + (8 if 16 == base else 16)):
         if out[i]:
-            print(f"  {100.0 * out[i] / tot:5.1f} %  {names.get(i, i)}")
+            lanes = f"  lanes at its mark {out[i + 8] / out[i]:5.1f} / 64" if 16 == base else ""
+            print(f"  {100.0 * out[i] / tot:5.1f} %  {names.get(i, i)}{lanes}")
 eng.release()

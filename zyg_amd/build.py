@@ -10,7 +10,8 @@ linked as they are, and the library is marked partial, so up_to_date() is false 
 
 Precise units: -ffp-contract=off (the reference, Zig, fuses a*b+c only at its explicit @mulAdd sites, which the sources
 reproduce with fmaf / __fmaf_rn); correctly rounded f32 divide/sqrt is hipcc's default.  Relaxed units (-DZYG_FAST=1): native
-divide / sqrt, contraction allowed, OCML f32 transcendentals (dmath.hpp); no -ffast-math: the slab tests rely on inf and NaN.
+divide / sqrt, contraction allowed, f32 denormals flushed, OCML f32 transcendentals (dmath.hpp); no -ffast-math: the slab tests
+rely on inf and NaN.
 """
 import concurrent.futures
 import hashlib
@@ -35,7 +36,9 @@ SOURCES = [os.path.join(HIP, "zygpu.hip"), os.path.join(HIP, "kernels.hip"), os.
 COMMON = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-mllvm", "-disable-promote-alloca-to-vector", "-Wall",
           "-Wno-unused-function"]
 PRECISE = ["-ffp-contract=off"]
-RELAXED = ["-DZYG_FAST=1", "-Dzd=zdf", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+# -fgpu-flush-denormals-to-zero: with f32 denormals on, LLVM wraps every native divide and sqrt in frexp / ldexp scaling (a
+# normalize = 24 instructions instead of 5): wf_scatter's Lambert instantiation 6467 -> 5790 instructions, configs[1] +1 %
+RELAXED = ["-DZYG_FAST=1", "-Dzd=zdf", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero"]
 
 
 def hipcc():
@@ -120,14 +123,17 @@ _compile.sources = {}
 
 def build_variant(name, units, extra, mode="both", verbose=True):
     """Development: variants/lib_<name>.so = the main build's objects with the kernel units `units` (and zygpu.o when
-    `units` holds -1) recompiled with `extra` flags into build/<name>/.  Load it with ZYG_AMD_LIB=variants/lib_<name>.so."""
+    `units` holds -1) recompiled with `extra` flags into build/<name>/ (mode "relaxed" / "precise": only the units of that
+    arithmetic mode; every other object is the main build's).  Load it with ZYG_AMD_LIB=variants/lib_<name>.so."""
     vdir = os.path.join(OBJ, name)
     os.makedirs(vdir, exist_ok=True)
     _compile.sources = {src: source_hash(src) for src in SOURCES}
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
     todo, objs = [], []
-    for oname, src, flags in _objects(mode):
+    for oname, src, flags in _objects("both"):
         mine = (oname.startswith("unit") and int(oname[4:].rstrip("f.o")) in units) or (oname == "zygpu.o" and -1 in units)
+        if oname.startswith("unit") and mode != "both" and ("relaxed" == mode) != oname.endswith("f.o"):
+            mine = False
         if mine:
             todo.append((os.path.join(name, oname), src, flags, list(extra), verbose))
             objs.append(os.path.join(vdir, oname))

@@ -159,6 +159,11 @@ struct Queues {
 // share an address).  Measured on configs[1]: one atomic per wave on one word 248 Msamples/s, one per block 303; spreading
 // the appends over 64 run counters cost more in the consumers than the remaining contention (278), so there is one run.
 constexpr uint32_t kCountStride = 16;
+// The alive queue sorted: sub-queue k holds the paths whose hit prop is k (mod kAliveKeys), each in its own array of
+// queue_capacity entries and consumed in whole 256-thread blocks, so that the lanes of a wf_scatter wave stand on one surface:
+// one fragment kind and one material per wave, the light sample succeeds or fails for the whole wave, the shadow rays start
+// side by side.  Params::alive_keys = 1: everything in sub-queue 0 (the plain queue).
+constexpr uint32_t kAliveKeys = 16;
 struct QueueCounts {
     uint32_t n[2 * kCountStride];  // [0] entries appended at the front, [kCountStride] at the back
 };
@@ -171,7 +176,7 @@ struct Control {  // device-resident
     unsigned long long next_sample;  // wf_persistent: the next camera sample of the batch to hand out
     QueueCounts        ext_count[2];
     QueueCounts        ext_pool_count[2][kPoolVertices];  // POOL
-    QueueCounts        alive_count[2];   // [parity of the tick]: wf_trace_shade fills this tick's and resets the next one's
+    QueueCounts        alive_count[2][kAliveKeys];  // [parity of the tick][sub-queue]: wf_trace_shade fills this tick's and resets the next one's
     QueueCounts        shadow_count[2];  // ping-pong per NEE round
     QueueCounts        heavy_count[2];
     uint32_t           bound[2];  // [parity of the tick]: length of the tick's extension queue = upper bound of every later
@@ -214,6 +219,7 @@ struct Params {
     // tick's (the two ext arrays, which it does not need).
     uint32_t* alive_in;
     uint32_t* alive_out;
+    uint32_t alive_keys;  // sub-queues of the alive queue in use: 1, or kAliveKeys (sorted by hit prop)
     uint32_t parity;  // current extension-queue side
     uint32_t queue_capacity;  // entries every queue array holds
     uint32_t packed_acc;      // 1: the paths keep emission / direct in their first line (kPackedAccumulators; set for the non-POOL kernels)
@@ -258,13 +264,16 @@ static __constant__ DScene c_scene;  // the compiled scene's device arrays: read
 #ifdef ZYG_PROFILE_SECTIONS
 struct SectionTimer {
     unsigned long long last, acc[16];
-    ZD void start() {
+    bool               lanes = false;  // sections 0-7 only: acc[8 + id] = the section's cycles x the lanes that reached its mark
+    ZD void start(bool with_lanes = false) {
         for (int i = 0; i < 16; ++i) acc[i] = 0;
+        lanes = with_lanes;
         last = clock64();
     }
     ZD void mark(int id) {
         const unsigned long long t = clock64();
         acc[id] += t - last;
+        if (lanes) acc[8 + id] += (t - last) * __popcll(__ballot(1));
         last = t;
     }
     ZD void flush(Control* ctl, int base) {
@@ -281,7 +290,7 @@ struct SectionTimer {
 };
 #else
 struct SectionTimer {
-    ZD void start() {}
+    ZD void start(bool = false) {}
     ZD void mark(int) {}
     ZD void flush(Control*, int) {}
 };
@@ -375,6 +384,67 @@ ZD uint32_t queueOpen(const QueueCounts* counts, uint32_t capacity, uint32_t i, 
 
 ZD void queueReset(QueueCounts* counts) {  // by one wave
     if (__lane_id() < 2) counts->n[__lane_id() * kCountStride] = 0;
+}
+ZD void aliveReset(QueueCounts (&counts)[kAliveKeys]) {  // by one wave
+    if (__lane_id() < kAliveKeys) counts[__lane_id()].n[0] = 0;
+}
+
+// Consumer side of the (sorted) alive queue for 256-thread blocks: thread i's entry.  Sub-queue k's entries come first to last in
+// whole blocks (its length rounded up to 256), so a block, and with it a wave, reads one sub-queue.  Returns whether the
+// thread belongs to a block that has entries at all (whole blocks take part in the queue appends that follow); `valid`: it has an
+// entry, at alive_in[at].
+ZD bool aliveOpen(const Params& P, uint32_t parity, uint32_t i, uint32_t& at, bool& valid) {
+    const uint32_t block_first = i & ~255u;  // (uniform over the block)
+    uint32_t       begin = 0;
+    valid = false;
+    at = 0;
+    for (uint32_t k = 0; k < P.alive_keys; ++k) {
+        const uint32_t n = P.ctl->alive_count[parity][k].n[0];
+        const uint32_t end = begin + ((n + 255u) & ~255u);
+        if (block_first < end) {
+            at = k * P.queue_capacity + (i - begin);
+            valid = i - begin < n;
+            return true;
+        }
+        begin = end;
+    }
+    return false;
+}
+// the surplus blocks of a launch leave on this: the tick's extension-queue length bounds the alive entries, each sub-queue
+// rounds its part up to a block
+ZD uint32_t aliveBound(const Params& P, uint32_t parity) { return P.ctl->bound[parity] + (P.alive_keys > 1 ? P.alive_keys * 256u : 0u); }
+
+// Producer side: the lanes with `defer` go to the heavy queue, those with `alive` to sub-queue `key` of the alive queue; one pair
+// of barriers, one atomic per block and non-empty queue.
+template <int WAVES>
+ZD void alivePushKeyed(const Params& P, uint32_t cur, bool defer, bool alive, uint32_t key, uint32_t value) {
+    constexpr uint32_t kHeavy = kAliveKeys;  // the heavy queue's index in the tables below
+    __shared__ uint32_t wave_count[WAVES][kAliveKeys + 1];
+    __shared__ uint32_t block_base[kAliveKeys + 1];
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t mine = defer ? kHeavy : alive ? key : ~0u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t rank = 0;
+    for (uint32_t k = 0; k <= kAliveKeys; ++k) {
+        const unsigned long long m = __ballot(mine == k);
+        if (0 == lane) wave_count[wave][k] = uint32_t(__popcll(m));
+        if (mine == k) rank = uint32_t(__popcll(m & below));
+    }
+    __syncthreads();
+    if (threadIdx.x <= kAliveKeys) {
+        const uint32_t k = threadIdx.x;
+        uint32_t       total = 0;
+        for (int w = 0; w < WAVES; ++w) total += wave_count[w][k];
+        QueueCounts* counts = kHeavy == k ? &P.ctl->heavy_count[cur] : &P.ctl->alive_count[cur][k];
+        block_base[k] = total ? atomicAdd(&counts->n[0], total) : 0u;
+    }
+    __syncthreads();
+    if (~0u != mine) {
+        uint32_t index = block_base[mine] + rank;
+        for (uint32_t w = 0; w < wave; ++w) index += wave_count[w][mine];
+        if (kHeavy == mine) P.q.heavy[index] = value;
+        else P.alive_out[size_t(mine) * P.queue_capacity + index] = value;
+    }
 }
 
 ZD void slotPixel(uint32_t slot, int& x, int& y, uint32_t& iteration) {
@@ -1020,7 +1090,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
         if (!POOL) queueReset(&P.ctl->ext_count[cur ^ 1u]);
         if (POOL && 0 == P.round)
             for (uint32_t k = 0; k < kPoolVertices; ++k) queueReset(&P.ctl->ext_pool_count[cur ^ 1u][k]);
-        queueReset(&P.ctl->alive_count[cur]);
+        aliveReset(P.ctl->alive_count[cur]);
         queueReset(&P.ctl->shadow_count[0]);
         queueReset(&P.ctl->shadow_count[1]);
         queueReset(&P.ctl->heavy_count[cur]);
@@ -1508,11 +1578,12 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
         SectionTimer tm;
         tm.start();
         bool     alive = false, defer = false;
-        uint32_t slot = 0;
+        uint32_t slot = 0, alive_key = 0;
         if (i < total) {
             slot = HEAVY ? P.q.heavy[at] : extQueue<POOL>(P, cur, P.round)[at];
             const uint4 hr = P.pool.hit[slot];
             const Hit   hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
+            alive_key = hit.prop;
             shadeVertex<STATS, MESHL, HEAVY, POOL>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, P.pool.ucount[slot], alive, defer,
                                                    cnt, tm);
         }
@@ -1520,7 +1591,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
             __syncthreads();  // queuePush's shared words are reused below
         }
-        queuePush(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+        if (!POOL && P.alive_keys > 1) alivePushKeyed<4>(P, cur, false, alive, alive_key & (kAliveKeys - 1u), slot);
+        else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
         tm.mark(5);
         tm.flush(P.ctl, 0);
     };
@@ -1568,7 +1640,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
     if (0 == i) P.ctl->bound[cur] = n;
     if (0 == blockIdx.x && threadIdx.x < 64) {
         queueReset(&P.ctl->ext_count[cur ^ 1u]);  // this tick's wf_scatter fills it
-        queueReset(&P.ctl->alive_count[cur ^ 1u]);
+        aliveReset(P.ctl->alive_count[cur ^ 1u]);
         queueReset(&P.ctl->heavy_count[cur ^ 1u]);
         queueReset(&P.ctl->shadow_count[0]);  // staged NEE: this tick's wf_nee rounds
         queueReset(&P.ctl->shadow_count[1]);
@@ -1581,7 +1653,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         SectionTimer tm;
         tm.start();
         bool     alive = false, defer = false;
-        uint32_t slot = 0;
+        uint32_t slot = 0, alive_key = 0;
         if (i < n) {
             slot = FIRST ? i : P.q.ext[cur][at];
             // the fresh path stays in registers until it is shaded, unless the traversal may draw from its sampler through the
@@ -1627,6 +1699,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
             }
             tm.mark(9);
             if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+            alive_key = hit.prop;
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL, UTLAS>(P, scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             tm.mark(10);
             shadeVertex<STATS, MESHL, false, false, kPre>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh, fresh_thr);
@@ -1638,7 +1711,8 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         }
         // one pair of barriers for both appends (a deferred vertex is appended to the alive queue by wf_shade's second pass):
         // configs[1] wf_trace_shade 126.0 -> 123.9 ms per 8 steps against two queuePush calls
-        queuePushTwo<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], defer, P.alive_out, &P.ctl->alive_count[cur], alive && !defer, slot);
+        if (UTLAS && P.alive_keys > 1) alivePushKeyed<kTraceShadeBlock / 64>(P, cur, defer, alive && !defer, alive_key & (kAliveKeys - 1u), slot);
+        else queuePushTwo<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], defer, P.alive_out, &P.ctl->alive_count[cur][0], alive && !defer, slot);
         tm.mark(11);
         tm.flush(P.ctl, 0);
     }
@@ -1832,16 +1906,15 @@ struct NoTimer {
 template <bool FIRST, bool SUBST>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_NEE_WAVES) wf_nee(Params P, uint32_t round) {
     const DScene&  s = c_scene;
-    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
+    bool           has_entry;
+    if (!aliveOpen(P, P.parity, i, at, has_entry)) return;  // whole blocks take part in queuePush
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
-    const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
-    if (i >= rounded) return;
     bool     push = false;
     uint32_t slot = 0;
-    if (i < total) {
+    if (has_entry) {
         slot = P.alive_in[at];
         if (FIRST) {
             PathHead h;
@@ -2119,15 +2192,14 @@ template <bool SUBST, bool EXTRA>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Params P) {
     const DScene&  s = c_scene;
     const uint32_t nxt = P.parity ^ 1u;
-    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
-    const uint32_t rounded = (total + 255u) & ~255u;
-    if (i >= rounded) return;
+    bool           has_entry;
+    if (!aliveOpen(P, P.parity, i, at, has_entry)) return;
     bool     push = false, back = false;
     uint32_t slot = 0;
-    if (i < total) {
+    if (has_entry) {
         slot = P.alive_in[at];
         PathHead h;
         loadHead(P, slot, h);
@@ -2173,20 +2245,25 @@ template <bool RESUME, bool SUBST>
 __global__ void __launch_bounds__(256) ZYG_WAVES(SUBST ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter_h(Params P, uint32_t round) {
     const DScene&  s = c_scene;
     const uint32_t nxt = P.parity ^ 1u;
-    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    if (blockIdx.x * blockDim.x >= (RESUME ? P.ctl->bound[P.parity] : aliveBound(P, P.parity))) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at = i;
     // RESUME: the vertices the previous round suspended (its queue's front), else the tick's alive queue
-    const uint32_t  total = RESUME ? P.ctl->shadow_count[(round + 1u) & 1u].n[0] : queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
     const uint32_t* in = RESUME ? (((round + 1u) & 1u) ? P.q.heavy : P.q.shadow) : P.alive_in;
     uint32_t*       suspended_queue = (round & 1u) ? P.q.heavy : P.q.shadow;
     const bool      mis = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator;
     if (0 == i) P.ctl->shadow_fetch = 0;  // the round's wf_shadow_u hands out its queue from the start
-    const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in the queue appends
-    if (i >= rounded) return;
+    bool has_entry;
+    if (RESUME) {
+        const uint32_t total = P.ctl->shadow_count[(round + 1u) & 1u].n[0];
+        if (i >= ((total + 255u) & ~255u)) return;  // whole blocks take part in the queue appends
+        has_entry = i < total;
+    } else if (!aliveOpen(P, P.parity, i, at, has_entry)) {
+        return;
+    }
     bool     push = false, back = false, suspend = false;
     uint32_t slot = 0;
-    if (i < total) {
+    if (has_entry) {
         slot = in[at];
         PathHead h;
         loadHead(P, slot, h);
@@ -2639,7 +2716,9 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
             h.vdepth = h.depth_surface;
             bxdf_pdf = bs.pdf;
+#if !ZYG_EXPERIMENT_NO_LINE_B
             P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
+#endif
         } else {
             bxdf_pdf = P.pool.ray_d.get(slot).w;  // the other integrators pass the camera ray's 0 on: read only there
         }
@@ -2658,7 +2737,9 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
         back = entersMeshBounds(new_origin, bs.wi);
         P.pool.thr[slot] = f4(throughput);
+#if !ZYG_EXPERIMENT_NO_LINE_B
         P.pool.vorigin[slot] = f4(sf.p);
+#endif
         storeHead(P, slot, h);
         push = true;
     }
@@ -2669,23 +2750,92 @@ template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS 
 __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
     const uint32_t     nxt = P.parity ^ 1u;
-    if (blockIdx.x * blockDim.x >= P.ctl->bound[P.parity]) return;
+    if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t           at;
-    const uint32_t     total = queueOpen(&P.ctl->alive_count[P.parity], P.queue_capacity, i, at);
+    bool               has_entry;
+    if (!aliveOpen(P, P.parity, i, at, has_entry)) return;  // whole blocks take part in queuePush
     Counters           cnt{0, 0, 0};
     unsigned long long shadow_rays = 0;
-    const uint32_t     rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
-    if (i >= rounded) return;
     const DScene& s = c_scene;
     uint32_t slot = 0;
     SectionTimer tm;  // -DZYG_PROFILE_SECTIONS builds: Control::sections[16..]
-    tm.start();
+    tm.start(true);
     ScatterOut out;
-    if (i < total) {
+#if 2 == ZYG_EXPERIMENT_SKELETON  // timing experiment (wrong images): the same bytes, but 8 lanes read / write one path's whole line
+    {
+        constexpr uint32_t kRow = 9;  // float4 per path row in LDS: the 128 B line + 16 B of padding
+        __shared__ float4 rows[256 * kRow];
+        __shared__ float4 hits[256 * 2];
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        slot = has_entry ? P.alive_in[at] : 0u;
+        float4* my_rows = rows + wave * 64 * kRow;
+        float4* my_hits = hits + wave * 64 * 2;
+        for (uint32_t j = 0; j < 8; ++j) {  // line A: lanes 8k .. 8k+7 load path 8j + k's eight records
+            const uint32_t src = 8u * j + (lane >> 3);
+            const uint32_t s2 = __shfl(slot, src);
+            const bool     ok = 0 != __shfl(has_entry ? 1 : 0, src);
+            float4         v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float4*>(pathBlock(P, s2) + (lane & 7u) * 16u);
+            my_rows[src * kRow + (lane & 7u)] = v;
+        }
+        for (uint32_t j = 0; j < 2; ++j) {  // hit block: 2 lanes per path
+            const uint32_t src = 32u * j + (lane >> 1);
+            const uint32_t s2 = __shfl(slot, src);
+            const bool     ok = 0 != __shfl(has_entry ? 1 : 0, src);
+            float4         v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float4*>(P.pool.hit.base + size_t(s2) * ZYG_HIT_STRIDE + (lane & 1u) * 16u);
+            my_hits[src * 2 + (lane & 1u)] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4* r = my_rows + lane * kRow;
+        const float4 hr = my_hits[lane * 2], hp = my_hits[lane * 2 + 1];
+        float4 ind = r[6];
+        ind.x += r[5].x * hr.x + hp.x;
+        r[6] = ind;
+        uint4 q0 = reinterpret_cast<uint4*>(r)[0];
+        q0.y += 8u;  // depth_surface + 1
+        reinterpret_cast<uint4*>(r)[0] = q0;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t src = 8u * j + (lane >> 3);
+            const uint32_t s2 = __shfl(slot, src);
+            const bool     ok = 0 != __shfl(has_entry ? 1 : 0, src);
+            if (ok) *reinterpret_cast<float4*>(pathBlock(P, s2) + (lane & 7u) * 16u) = my_rows[src * kRow + (lane & 7u)];
+        }
+        if (has_entry) {
+            P.pool.vorigin[slot] = r[3];
+            P.pool.vgeo_n[slot] = r[4];
+            out.push = true;
+        }
+    }
+#elif ZYG_EXPERIMENT_SKELETON  // timing experiment (wrong images): the kernel's path-state loads and stores with no work between them
+    if (has_entry) {
+        slot = P.alive_in[at];
+        PathHead h;
+        loadHead<POOL>(P, slot, h);
+        const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
+        const uint4    hr = P.pool.hit[slot];
+        const uint32_t hp = P.pool.hit_prop[slot];
+        const float4   thr = P.pool.thr[slot];
+        float4         ind = P.pool.indirect[slot];
+        ind.x += thr.x * __uint_as_float(hr.x) + float(hp);
+        P.pool.indirect[slot] = ind;
+        P.pool.ray_o[slot] = ro;
+        P.pool.ray_d[slot] = rd;
+        P.pool.thr[slot] = thr;
+        P.pool.vorigin[slot] = ro;
+        P.pool.vgeo_n[slot] = rd;
+        h.depth_surface += 1;
+        storeHead(P, slot, h);
+        out.push = true;
+    }
+#else
+    if (has_entry) {
         slot = P.alive_in[at];
         scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE>(P, s, slot, out, cnt, shadow_rays, tm);
     }
+#endif
     if (POOL) {
         for (uint32_t r = 0; r < kPoolVertices; ++r) {  // child `first + c` of a sample is vertex `first + c` of the next level
             const bool c0 = r == out.child_round[0], c1 = r == out.child_round[1];
@@ -2713,7 +2863,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI) ? ZYG_SCATTER_
     if (blockIdx.x * blockDim.x >= P.ctl->bound[prev]) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
-    const uint32_t total = queueOpen(&P.ctl->alive_count[prev], P.queue_capacity, i, at);
+    const uint32_t total = queueOpen(&P.ctl->alive_count[prev][0], P.queue_capacity, i, at);
     if (0 == i) P.ctl->bound[cur] = total;
     const uint32_t rounded = (total + 255u) & ~255u;  // whole blocks take part in queuePush
     if (i >= rounded) return;
@@ -2751,7 +2901,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI) ? ZYG_SCATTER_
     }
     queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
     __syncthreads();  // queuePush's shared words are reused below
-    queuePush(P.alive_out, &P.ctl->alive_count[cur], P.queue_capacity, alive, slot);
+    queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
 }
 
 // ---------------------------------------------------------------- wf_persistent

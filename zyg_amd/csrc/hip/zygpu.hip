@@ -484,6 +484,12 @@ struct ZygpuContext {
     // option "mesh_closest" (default off: measured -8 % on configs[2] with the mesh on the floor, +0 ... +10 % with it in the middle
     // of the box): the closest-hit walks of the rays that enter a large mesh's bounds in a persistent kernel too (wf_mesh_closest)
     bool          mesh_closest = false;
+    // option "sort_alive" (1 on, 0 off, default -1: on in the scenes of the mesh kernels): wf_trace_shade's prop-table instantiations
+    // append the surviving paths to one sub-queue per hit prop (mod kAliveKeys), the consumer's waves then read paths that stand on one
+    // surface (wavefront.hpp kAliveKeys).  Measured in one call: configs[2] 240.3 / 241.2 -> 246.3 / 246.4 Msamples/s (wf_scatter_h
+    // -4.5 %), configs[1] 835 / 840 -> 766 / 772: wf_scatter's waves are coherent then, but their 64 path blocks lie 8 times further apart,
+    // and that kernel is bound by how the path state moves, not by its divergence
+    int           sort_alive = -1;
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
     uint64_t      camera_samples = 0;
@@ -593,7 +599,8 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
         *r = 0xFFFFFFFFu;
 #endif
     ok = ok && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) &&
-         m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) && m.alloc(qcap, &c->queues.alive) &&
+         m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) &&
+         m.alloc(qcap * (c->pool_mode ? 1u : kAliveKeys), &c->queues.alive) &&  // a whole queue per sub-queue of the sorted alive queue: any one may get every path
          m.alloc(paths, &c->stage_color) && m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) &&
          m.alloc(paths, &p.sh_o) && m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
          m.alloc(slots, &p.time) &&
@@ -1310,6 +1317,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     P.parity = 0;
     P.round = 0;
     P.alive_in = P.alive_out = c->queues.alive;
+    P.alive_keys = 1;
     P.pixel_pcg = nullptr;
     if (one_shot) {
         if (c->pixel_pcg_capacity < npix) {
@@ -1355,7 +1363,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         dim3           grid((num_paths + 255) / 256);
         P.parity = 0;
         HIP_OK(hipMemsetAsync(&c->ctl->ext_count[0], 0, sizeof(QueueCounts), c->stream));  // wf_generate appends to it
-        HIP_OK(hipMemsetAsync(&c->ctl->alive_count[0], 0, 2 * sizeof(QueueCounts), c->stream));
+        HIP_OK(hipMemsetAsync(&c->ctl->alive_count[0][0], 0, sizeof(c->ctl->alive_count), c->stream));
         HIP_OK(hipMemsetAsync(&c->ctl->heavy_count[0], 0, 2 * sizeof(QueueCounts), c->stream));
         // the fused first tick generates the camera rays itself
         const bool generate_in_trace = !c->pool_mode && c->fuse_trace_shade;
@@ -1369,6 +1377,11 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         const bool plain_in_place = utlas && nee && c->nee_in_place && !c->multi_sample_lights && c->fuse_trace_shade;
         // option mesh_kernels: the large meshes' closest-hit walks run in wf_mesh_closest before the tick's wf_trace_shade; the camera
         // rays then go through the queue like every other tick's (wf_generate sorts them into its two ends)
+        // the alive queue sorted by hit prop: the producers that key their appends are wf_trace_shade's prop-table instantiations
+        // (and wf_shade's second pass behind them), every consumer of the tick loop below reads the sub-queues
+        const bool sort_alive = c->sort_alive < 0 ? (wide && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels) : 0 != c->sort_alive;
+        P.alive_keys = (sort_alive && utlas && c->fuse_trace_shade && !c->fuse_tick && !c->persistent) ? kAliveKeys : 1u;
+        auto aliveGrid = [&] { return grid.x + (P.alive_keys > 1 ? P.alive_keys : 0u); };  // each sub-queue rounds its entries up to a block
         const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
         P.mesh_pass = mesh_pass ? 1u : 0u;
         if (mesh_pass) {
@@ -1386,7 +1399,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 P.parity = t & 1u;
                 P.alive_in = c->queues.ext[(t - 1u) & 1u];
                 P.alive_out = c->queues.ext[t & 1u];
-                HIP_OK(hipMemsetAsync(&c->ctl->alive_count[P.parity], 0, sizeof(QueueCounts), c->stream));
+                HIP_OK(hipMemsetAsync(&c->ctl->alive_count[P.parity][0], 0, sizeof(QueueCounts), c->stream));
                 HIP_OK(hipMemsetAsync(&c->ctl->heavy_count[P.parity], 0, sizeof(QueueCounts), c->stream));
                 timedLaunch(c, 5, [&] {
                     launchKernel(c, c->has_substitute ? (wide ? K_TICK_SUBST_W : K_TICK_SUBST) : (wide ? K_TICK_LAMBERT_W : K_TICK_LAMBERT), grid.x, P, 0u);
@@ -1487,29 +1500,29 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             if (nee && c->nee_in_place && wide && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels && !c->multi_sample_lights) {
                 // wf_scatter_h: in place, but a vertex whose shadow ray has to walk a large mesh is suspended; wf_shadow_u walks
                 // the meshes for the round's suspended rays, the next launch takes the suspended vertices up again
-                timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_SUBST : K_SCATTER_H, grid.x, P, 0u); });
+                timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_SUBST : K_SCATTER_H, aliveGrid(), P, 0u); });
                 for (uint32_t r = 1; r <= rounds; ++r) {
                     timedLaunch(c, 3, [&] { launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, 6), P, r - 1u); });
                     timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_RESUME_SUBST : K_SCATTER_H_RESUME, grid.x, P, r); });
                 }
             } else if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
                 timedLaunch(c, 5, [&] {
-                    if (c->stats) launchKernel(c, K_SCATTER_STATS, grid.x, P, 0u);
-                    else if (c->masks) launchKernel(c, K_SCATTER_MASKS, grid.x, P, 0u);
-                    else if (c->mesh_lights) launchKernel(c, K_SCATTER_FULL, grid.x, P, 0u);
-                    else if (c->multi_sample_lights) launchKernel(c, wide ? K_SCATTER_MULTI_UW : utlas ? K_SCATTER_MULTI_U : K_SCATTER_MULTI, grid.x, P, 0u);
-                    else if (c->has_substitute) launchKernel(c, wide ? K_SCATTER_SUBST_UW : utlas ? K_SCATTER_SUBST_U : K_SCATTER_SUBST, grid.x, P, 0u);
-                    else launchKernel(c, wide ? K_SCATTER_LAMBERT_UW : utlas ? K_SCATTER_LAMBERT_U : K_SCATTER_LAMBERT, grid.x, P, 0u);
+                    if (c->stats) launchKernel(c, K_SCATTER_STATS, aliveGrid(), P, 0u);
+                    else if (c->masks) launchKernel(c, K_SCATTER_MASKS, aliveGrid(), P, 0u);
+                    else if (c->mesh_lights) launchKernel(c, K_SCATTER_FULL, aliveGrid(), P, 0u);
+                    else if (c->multi_sample_lights) launchKernel(c, wide ? K_SCATTER_MULTI_UW : utlas ? K_SCATTER_MULTI_U : K_SCATTER_MULTI, aliveGrid(), P, 0u);
+                    else if (c->has_substitute) launchKernel(c, wide ? K_SCATTER_SUBST_UW : utlas ? K_SCATTER_SUBST_U : K_SCATTER_SUBST, aliveGrid(), P, 0u);
+                    else launchKernel(c, wide ? K_SCATTER_LAMBERT_UW : utlas ? K_SCATTER_LAMBERT_U : K_SCATTER_LAMBERT, aliveGrid(), P, 0u);
                 });
             } else {
             for (uint32_t r = 0; r < rounds; ++r) {
                 timedLaunch(c, 2, [&] {
                     if (0 == r) {
-                        if (c->has_substitute) launchKernel(c, K_NEE_FIRST_SUBST, grid.x, P, r);
-                        else launchKernel(c, K_NEE_FIRST, grid.x, P, r);
+                        if (c->has_substitute) launchKernel(c, K_NEE_FIRST_SUBST, aliveGrid(), P, r);
+                        else launchKernel(c, K_NEE_FIRST, aliveGrid(), P, r);
                     } else {
-                        if (c->has_substitute) launchKernel(c, K_NEE_SUBST, grid.x, P, r);
-                        else launchKernel(c, K_NEE, grid.x, P, r);
+                        if (c->has_substitute) launchKernel(c, K_NEE_SUBST, aliveGrid(), P, r);
+                        else launchKernel(c, K_NEE, aliveGrid(), P, r);
                     }
                 });
                 timedLaunch(c, 3, [&] {
@@ -1518,9 +1531,9 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 });
             }
             timedLaunch(c, 4, [&] {
-                if (c->mesh_lights) launchKernel(c, K_EXTEND_EXTRA, grid.x, P, 0u);
-                else if (c->has_substitute) launchKernel(c, K_EXTEND_SUBST, grid.x, P, 0u);
-                else launchKernel(c, K_EXTEND, grid.x, P, 0u);
+                if (c->mesh_lights) launchKernel(c, K_EXTEND_EXTRA, aliveGrid(), P, 0u);
+                else if (c->has_substitute) launchKernel(c, K_EXTEND_SUBST, aliveGrid(), P, 0u);
+                else launchKernel(c, K_EXTEND, aliveGrid(), P, 0u);
             });
             }
             P.parity ^= 1u;
@@ -1792,6 +1805,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "mesh_closest")) {
         c->mesh_closest = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "sort_alive")) {
+        c->sort_alive = value < 0 ? -1 : (value ? 1 : 0);
         return 0;
     }
     if (0 == std::strcmp(name, "persistent")) {
