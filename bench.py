@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--sort-alive", type=int, default=-1, choices=[-1, 0, 1],
                     help="zygpu option sort_alive: the surviving paths in one sub-queue per hit prop, so that the consumer's waves stand on one "
                          "surface (-1: the library's choice, on in the scenes of the mesh kernels)")
+    ap.add_argument("--regenerate", type=int, default=0, choices=[0, 1],
+                    help="zygpu option regenerate: the regenerating kernels (a small pool whose slots are all alive, plain record arrays, no queues)")
+    ap.add_argument("--regen-kslots", type=int, default=0, help="zygpu option regen_kslots: slots of that pool in units of 1024 (0 = library default, 2048)")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed oracle sample (and again of the parity band)")
@@ -130,6 +133,9 @@ class Measurement:
         self.eng.set_option("mesh_kernels", args.mesh_kernels)
         self.eng.set_option("mesh_closest", args.mesh_closest)
         self.eng.set_option("sort_alive", args.sort_alive)
+        self.eng.set_option("regenerate", args.regenerate)
+        if args.regen_kslots:
+            self.eng.set_option("regen_kslots", args.regen_kslots)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)
         self.fused = bool(args.fuse) and scene in ("cornell", "cornell_mesh", "cornell_mound")  # POOL scenes always run the kernels apart
         self.film = torch.zeros((self.h, self.w, 4), dtype=torch.float32, device=device)

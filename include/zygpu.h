@@ -520,7 +520,11 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * 450 B per path);
  * "sort_alive" (default -1: the library's choice, on in the scenes whose large meshes run in the mesh kernels; 1 / 0) keeps the
  * paths that survive a tick's shading in one sub-queue per hit prop (16 of them), so that the waves of the kernel that
- * scatters them stand on one surface each; results are addressed by path slot, the film is the same bits either way. */
+ * scatters them stand on one surface each; results are addressed by path slot, the film is the same bits either way;
+ * "regenerate" (default 0) runs the regenerating kernels where the scene allows them (prop tables without a large mesh, in-place
+ * next-event estimation, single-sample lights, progressive sampling): a pool of "regen_kslots" x 1024 slots (default 2048,
+ * 1..65536) that are all alive, a slot taking the batch's next camera sample when its path ends; same film, measured slower
+ * than the tick loop on BASELINE's scenes. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.

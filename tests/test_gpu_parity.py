@@ -1345,3 +1345,40 @@ def test_sorted_alive_queue_is_only_an_order(engine, oracle, variant):
     sd = engine.lib.su_ext_scene_desc().contents
     vd = engine.lib.su_ext_view_desc().contents
     assert np.array_equal(films[1, 1], oracle_render(oracle, sd, vd, spp))
+
+
+@pytest.mark.parametrize("material", ["lambert", "substitute"])
+@pytest.mark.parametrize("integrator", ["PTMIS", "PTDL", "PT"])
+def test_regenerating_kernels(engine, oracle, integrator, material):
+    """Option regenerate (wavefront.hpp wf_rscatter / wf_rtrace): a pool of a few thousand slots, each of which takes the batch's next
+    camera sample when its path ends; plain record arrays, no queues; the slot is no longer the sample's index (Params::regen_sample).
+    The film is summed from the staging buffer in sample order, so it is the tick loop's and the oracle's bit for bit, whatever the
+    pool's size (here 1 K and 4 K slots for 27 648 samples of 4 iterations, so every slot carries several paths, and one larger
+    than the batch)."""
+    w, h, spp = 96, 72, 4
+    scenes.cornell(engine, w, h, spp, integrator=integrator, material=material)
+    engine.start_frame(0)
+    engine.set_option("nee_in_place", 1)
+    films = {}
+    try:
+        for precise in (1, 0):
+            engine.set_option("precise", precise)
+            for kslots in (0, 1, 4, 64):
+                engine.set_option("regenerate", 1 if kslots else 0)
+                if kslots:
+                    engine.set_option("regen_kslots", kslots)
+                assert engine.lib.zygpu_clear_film(engine.context(), ctypes.c_float(0.0)) == 0
+                assert engine.lib.zygpu_render(engine.context(), 0, 0, spp, 0, h) == 0
+                engine.synchronize()
+                films[precise, kslots] = engine.download_film(w, h)
+    finally:
+        engine.set_option("regenerate", 0)
+        engine.set_option("regen_kslots", 2048)
+        engine.set_option("precise", 1)
+    for precise in (1, 0):
+        assert np.isfinite(films[precise, 0]).all() and np.all(films[precise, 0][..., 3] == float(spp))
+        for kslots in (1, 4, 64):
+            assert np.array_equal(films[precise, kslots], films[precise, 0]), f"precise {precise}, {kslots} K slots"
+    sd = engine.lib.su_ext_scene_desc().contents
+    vd = engine.lib.su_ext_view_desc().contents
+    assert np.array_equal(films[1, 1], oracle_render(oracle, sd, vd, spp))

@@ -10,6 +10,7 @@
 // Template parameters (wavefront.hpp):
 //   wf_generate<POOL>   wf_intersect<STATS, POOL, EXTRA>   wf_shade<STATS, MESHL, HEAVY, POOL>
 //   wf_trace_shade<STATS, MESHL, FIRST, UTLAS>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS>
+//   wf_rgenerate (1024-thread blocks)   wf_rtrace<WIDE>   wf_rscatter<SUBST, WIDE> (the regenerating kernels; Params::regen_*)
 //   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_shadow_u / wf_mesh_closest (persistent: launched with persistentGrid blocks)   wf_scatter_h<RESUME, SUBST>   wf_extend<SUBST, EXTRA>   wf_persistent<SUBST, MULTI, WIDE>   wf_tick<SUBST, MULTI, WIDE>
 #pragma once
 
@@ -91,6 +92,10 @@
     X(7, K_SCATTER_H_RESUME,     ZYG_WIDE((wf_scatter_h<true, false>), (wf_shadow<false>)),  (P, arg)) \
     X(7, K_SCATTER_H_RESUME_SUBST, ZYG_WIDE((wf_scatter_h<true, true>), (wf_shadow<false>)), (P, arg)) \
     X(7, K_MESH_CLOSEST,         ZYG_WIDE((wf_mesh_closest<true>), (wf_shadow<false>)),     (P, arg)) \
+    X(6, K_RGENERATE,            (wf_rgenerate<false>),                               (P))  \
+    X(6, K_RTRACE,               (wf_rtrace<false>),                                  (P))  \
+    X(6, K_RSCATTER,             (wf_rscatter<false, false>),                         (P))  \
+    X(6, K_RSCATTER_SUBST,       (wf_rscatter<true, false>),                          (P))  \
     X(7, K_EXTEND_EXTRA,         (wf_extend<true, true>),                             (P))  \
     X(7, K_EXTEND_SUBST,         (wf_extend<true, false>),                            (P))  \
     X(7, K_EXTEND,               (wf_extend<false, false>),                           (P))

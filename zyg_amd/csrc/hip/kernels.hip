@@ -42,6 +42,7 @@ static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Para
     // wf_trace_shade's block size follows its instantiation (wavefront.hpp traceShadeBlock); `blocks` counts 256 entries each
     constexpr uint32_t kTsU = traceShadeBlock<true, false>(), kTsUW = traceShadeBlock<true, ZYG_WIDE(true, false)>();
     const dim3 ts_u_grid((blocks * 256u + kTsU - 1u) / kTsU), ts_u_block(kTsU), ts_uw_grid((blocks * 256u + kTsUW - 1u) / kTsUW), ts_uw_block(kTsUW);
+    const dim3 regen_grid((blocks * 256u + kRegenerateThreads - 1u) / kRegenerateThreads), regen_block(kRegenerateThreads);
     switch (id) {
 #define ZYG_X(unit, kid, kernel, args)                                                       \
     case kid:                                                                                \
@@ -50,8 +51,9 @@ static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Para
                                   (ZYG_TS_BLOCK_ALL && kid >= K_TRACE_SHADE_STATS_FIRST && kid <= K_TRACE_SHADE_PLAIN);      \
             constexpr bool ts_uw = K_TRACE_SHADE_PLAIN_FIRST_UW == kid || K_TRACE_SHADE_PLAIN_UW == kid;             \
             constexpr bool persistent = kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W;                  \
-            hipLaunchKernelGGL(kernel, ts_u ? ts_u_grid : ts_uw ? ts_uw_grid : grid,                                 \
-                               ts_u ? ts_u_block : ts_uw ? ts_uw_block : persistent ? persistent_block : block, 0, stream, ZYG_UNPAREN args); \
+            constexpr bool regenerate = K_RGENERATE == kid;                                                          \
+            hipLaunchKernelGGL(kernel, ts_u ? ts_u_grid : ts_uw ? ts_uw_grid : regenerate ? regen_grid : grid,       \
+                               ts_u ? ts_u_block : ts_uw ? ts_uw_block : persistent ? persistent_block : regenerate ? regen_block : block, 0, stream, ZYG_UNPAREN args); \
             return 0;                                                                        \
         } else {                                                                             \
             return -1;                                                                       \

@@ -61,12 +61,17 @@ struct RecRef {
 };
 // `mask` / `local`: the wavefront kernels index the records by path slot (mask = ~0, local = 0); wf_persistent keeps one
 // path's block per lane in LDS and reaches it whatever the slot (mask = 0, local = the lane's index in the block).
+// `stride`: the bytes between two slots' records: STRIDE (the interleaved block) in the pool of the tick loop; the regenerating
+// kernels (wf_rtrace / wf_rscatter), whose slots are all alive, keep every record in an array of its own (16 B, the hit block 32 B)
+// that a wave reads and writes 1 KB at a time.
 template <typename T, int STRIDE = ZYG_POOL_STRIDE>
 struct Rec {
+    static constexpr uint32_t kBlockStride = STRIDE;
     char*    base;  // block base + the member's offset (RecOffsets)
     uint32_t mask, local;
+    uint32_t stride;
     ZD RecRef<T> operator[](size_t i) const {
-        return RecRef<T>{reinterpret_cast<T*>(base + size_t((uint32_t(i) & mask) + local) * size_t(STRIDE))};
+        return RecRef<T>{reinterpret_cast<T*>(base + size_t((uint32_t(i) & mask) + local) * size_t(stride))};
     }
     ZD T get(size_t i) const { return T((*this)[i]); }
 };
@@ -184,6 +189,7 @@ struct Control {  // device-resident
     uint32_t           error;
     uint32_t           shadow_fetch;  // wf_shadow_u: the next queue entry to hand out; the round's wf_nee zeroes it
     uint32_t           mesh_fetch;    // wf_mesh_closest: likewise; the tick's wf_trace_shade zeroes it for the next tick
+    uint32_t           regen_live;    // wf_rscatter (asked to report): some slot still carries a path
     KernelCounters     k[3];  // 0 wf_intersect, 1 wf_shade, 2 wf_shadow
     unsigned long long sections[32];  // -DZYG_PROFILE_SECTIONS builds: shader cycles per code section, summed over waves
 };
@@ -220,6 +226,11 @@ struct Params {
     uint32_t* alive_in;
     uint32_t* alive_out;
     uint32_t alive_keys;  // sub-queues of the alive queue in use: 1, or kAliveKeys (sorted by hit prop)
+    // the regenerating kernels (option "regenerate"): per pool slot the camera sample (index in the batch) its path belongs to, kNull
+    // when the slot has none; null in the tick loop, where a path's slot is its sample's index
+    uint32_t* regen_sample;
+    uint32_t  regen_slots, regen_samples;  // slots of the pool, camera samples of the batch
+    uint32_t  regen_report;                // 1: the launch after which the host reads Control::regen_live
     uint32_t parity;  // current extension-queue side
     uint32_t queue_capacity;  // entries every queue array holds
     uint32_t packed_acc;      // 1: the paths keep emission / direct in their first line (kPackedAccumulators; set for the non-POOL kernels)
@@ -447,6 +458,9 @@ ZD void alivePushKeyed(const Params& P, uint32_t cur, bool defer, bool alive, ui
     }
 }
 
+// the camera sample (index in the batch: pixel and iteration, the staging buffer's entry) of the path in pool slot `slot`
+ZD uint32_t sampleOf(const Params& P, uint32_t slot) { return P.regen_sample ? P.regen_sample[slot] : slot; }
+
 ZD void slotPixel(uint32_t slot, int& x, int& y, uint32_t& iteration) {
     const uint32_t it = slot / c_view.npix, pix = slot - it * c_view.npix;
     const uint32_t w = uint32_t(c_view.x_end - c_view.x_begin);
@@ -583,7 +597,7 @@ ZD void loadHead(const Params& P, uint32_t vertex, PathHead& h) {
     const uint32_t slot = sampleSlot<POOL>(vertex);
     int      px, py;
     uint32_t iteration;
-    slotPixel(slot, px, py, iteration);
+    slotPixel(POOL ? slot : sampleOf(P, slot), px, py, iteration);
     const uint32_t pixel_id = pixelId(px, py);
     const uint4    a = P.pool.q0[slot];
     const float4   b = P.pool.q1[slot];
@@ -689,7 +703,7 @@ ZD char* pathBlock(const Params&, uint32_t) { return nullptr; }
 
 template <bool PACKED>
 ZD void loadEmissionDirect(const Params& P, uint32_t slot, f3& e, f3& d) {
-    if (PACKED && kPackedAccumulators) {
+    if (PACKED && kPackedAccumulators && P.packed_acc) {
         char*        b = pathBlock(P, slot);
         const float2 lo = *reinterpret_cast<const float2*>(b + 40);
         const float4 hi = *reinterpret_cast<const float4*>(b + 112);
@@ -702,7 +716,7 @@ ZD void loadEmissionDirect(const Params& P, uint32_t slot, f3& e, f3& d) {
 }
 template <bool PACKED>
 ZD void clearAccumulators(const Params& P, uint32_t slot) {
-    if (PACKED && kPackedAccumulators) {
+    if (PACKED && kPackedAccumulators && P.packed_acc) {
         char* b = pathBlock(P, slot);
         *reinterpret_cast<float2*>(b + 40) = make_float2(0.f, 0.f);
         *reinterpret_cast<float4*>(b + 112) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -719,7 +733,7 @@ template <bool PACKED>
 ZD void ivalueAdd(const Params& P, uint32_t slot, f3 value, uint32_t depth, uint32_t direct_cutoff, bool is_emission, bool singular) {
     if (0.f == value.x && 0.f == value.y && 0.f == value.z) return;
     const bool direct = singular || depth < direct_cutoff;
-    if (PACKED && kPackedAccumulators && (is_emission || direct)) {
+    if (PACKED && kPackedAccumulators && P.packed_acc && (is_emission || direct)) {
         char*   b = pathBlock(P, slot);
         float4* hi = reinterpret_cast<float4*>(b + 112);
         float4  h = *hi;
@@ -757,7 +771,7 @@ ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags, 
     const f3    i = clampColor(xyz4(P.pool.indirect[slot]), c_view.v.clamp_indirect);
     const f3    summed = e + d + i;
     const float alpha = (flags & ST_TRANSPARENT) ? mx(1.f - average3(throughput), 0.f) : 1.f;
-    P.stage_color[slot] = f4(summed, alpha);
+    P.stage_color[sampleOf(P, slot)] = f4(summed, alpha);
 }
 
 // POOL: a vertex ends without children: Pool.consume's bookkeeping for terminated vertices (vertex.zig:240-262; no shadow
@@ -880,7 +894,9 @@ ZD Trafo cameraTrafoAt(const ZygpuViewDesc& v, uint32_t frame, float shutter_sam
 // `keep_d`) stay in registers, and nothing of the path goes to the pool here: shadeVertex<PRE = 1> writes the records of a path
 // that goes on, all at once behind the traversal, and none for a path that ends at its first vertex
 template <bool POOL, bool AOV = false, bool KEEP = false>
-ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, float4* keep_o = nullptr, float4* keep_d = nullptr) {
+ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, float4* keep_o = nullptr, float4* keep_d = nullptr,
+                     uint32_t sample = kNull) {
+    if (kNull == sample) sample = slot;  // (the regenerating kernels name it: the slot is only where the path's records live)
     if (AOV && c_view.v.aov_slots) {  // aov.Value.clear (aov_value.zig:62-73): Depth starts at f32 max
 #pragma unroll
         for (uint32_t k = 0; k < 6; ++k) {
@@ -891,7 +907,7 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
 
     int      x, y;
     uint32_t iteration;
-    slotPixel(slot, x, y, iteration);
+    slotPixel(sample, x, y, iteration);
     const uint32_t pixel_id = pixelId(x, y);
 
     PathHead h;
@@ -974,7 +990,7 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
         P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         clearAccumulators<!POOL>(P, slot);
     }
-    P.stage_uv[slot] = make_float2(s0, s1);
+    P.stage_uv[sample] = make_float2(s0, s1);
     if (AOV && c_scene.prop_frames) {  // AOV = the MESHL instantiations: Probe.time for the animated props (camera_base.zig:129-136)
         const uint64_t tick = 705600000ull / 60, start_time = uint64_t(c_view.frame) * v.frame_step;
         const uint64_t fdi = uint64_t(llround(double(shutter_sample) * double(v.frame_duration)));
@@ -1587,12 +1603,17 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             shadeVertex<STATS, MESHL, HEAVY, POOL>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, P.pool.ucount[slot], alive, defer,
                                                    cnt, tm);
         }
-        if (!HEAVY) {
-            queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
-            __syncthreads();  // queuePush's shared words are reused below
+        if (HEAVY && !POOL && P.regen_sample) {
+            // the regenerating kernels: no queue behind this pass; a path that ended here leaves its slot to wf_rscatter
+            if (i < total && !alive) P.regen_sample[slot] = kNull;
+        } else {
+            if (!HEAVY) {
+                queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
+                __syncthreads();  // queuePush's shared words are reused below
+            }
+            if (!POOL && P.alive_keys > 1) alivePushKeyed<4>(P, cur, false, alive, alive_key & (kAliveKeys - 1u), slot);
+            else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
         }
-        if (!POOL && P.alive_keys > 1) alivePushKeyed<4>(P, cur, false, alive, alive_key & (kAliveKeys - 1u), slot);
-        else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
         tm.mark(5);
         tm.flush(P.ctl, 0);
     };
@@ -2902,6 +2923,134 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI) ? ZYG_SCATTER_
     queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
     __syncthreads();  // queuePush's shared words are reused below
     queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
+}
+
+// ---------------------------------------------------------------- regenerating kernels
+// Option "regenerate" (scenes walked through the prop tables, in-place NEE, single-sample lights): the pool is a few million slots,
+// every one of which carries a path all the time: a slot whose path ends takes the batch's next camera sample in the same launch
+// (wf_rscatter).  Thread i is slot i in both kernels: no extension / alive queues, no appends, no launches over thinning queues,
+// and the records are plain arrays (Rec::stride = 16) that a wave reads and writes 64 slots = 1 KB at a time, where the tick loop's
+// surviving slots thin out and every record costs its own line.  A slot is not its sample any more: Params::regen_sample names the
+// sample (sampler seed, pixel, staging entry); the film is accumulated from the staging buffer in sample order as before, so the
+// result is the tick loop's bit for bit.  A tick = wf_rscatter (scatter the living, start new paths in the free slots), wf_rtrace
+// (closest hit + first shading pass for every slot), wf_shade's second pass for the few vertices with emission to evaluate (the
+// heavy queue, one append per block).  The host asks every few ticks whether any slot is still alive.
+// The free slots of 1024 consecutive ones are gathered in LDS, then the block's first waves start a new path in each: full waves in
+// generatePath instead of every wave of wf_rscatter running it for its few free lanes, and one atomic per block on the batch's
+// sample counter.  (A template so that only the unit that instantiates it emits it.)
+constexpr uint32_t kRegenerateThreads = 1024;
+template <bool POOL>
+__global__ void __launch_bounds__(kRegenerateThreads) wf_rgenerate(Params P) {
+    static_assert(!POOL, "the regenerating kernels are the plain instantiations");
+    __shared__ uint32_t           free_slots[kRegenerateThreads];
+    __shared__ uint32_t           wave_count[kRegenerateThreads / 64];
+    __shared__ unsigned long long first_sample;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, lane = __lane_id(), wave = threadIdx.x >> 6;
+    const bool     in = slot < P.regen_slots;
+    const bool     is_free = in && kNull == P.regen_sample[slot];
+    const unsigned long long fmask = __ballot(is_free);
+    if (0 == lane) wave_count[wave] = uint32_t(__popcll(fmask));
+    __syncthreads();
+    uint32_t offset = uint32_t(__popcll(fmask & ((1ull << lane) - 1ull))), total = 0;
+    for (uint32_t w = 0; w < kRegenerateThreads / 64; ++w) {
+        const uint32_t n = wave_count[w];
+        if (w < wave) offset += n;
+        total += n;
+    }
+    if (is_free) free_slots[offset] = slot;
+    if (0 == threadIdx.x) first_sample = total ? atomicAdd(&P.ctl->next_sample, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    const unsigned long long mine = first_sample + threadIdx.x;
+    bool                     started = false;
+    if (threadIdx.x < total && mine < P.regen_samples) {
+        const uint32_t target = free_slots[threadIdx.x];
+        P.regen_sample[target] = uint32_t(mine);
+        generatePath<false, false, false>(P, target, nullptr, nullptr, nullptr, uint32_t(mine));
+        started = true;
+    }
+    if (P.regen_report) {  // the launch after which the host reads Control::regen_live
+        const bool live = started || (in && !is_free);
+        if (0 != __ballot(live) && 0 == lane) P.ctl->regen_live = 1u;
+    }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_WAVES) wf_rtrace(Params P) {
+    const uint32_t num_slots = P.regen_slots;
+    const uint32_t cur = P.parity;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (0 == blockIdx.x && threadIdx.x < 64) queueReset(&P.ctl->heavy_count[cur ^ 1u]);  // the next tick's
+    const DScene& scene = c_scene;
+    Counters      none{0, 0, 0};
+    SectionTimer  tm;
+    tm.start();
+    bool           alive = false, defer = false;
+    const uint32_t sample = slot < num_slots ? P.regen_sample[slot] : kNull;
+    if (kNull != sample) {
+        PathHead fresh;
+        loadHead(P, slot, fresh);
+        const float4   thr = P.pool.thr[slot];
+        const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+        const uint32_t depth = fresh.depth_surface, flags = fresh.flags & 63u;
+        Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+        Hit            hit;
+#if ZYG_FAST
+        sceneIntersectUniform<false, WIDE>(scene, ray, depth, hit);
+#else
+        sceneIntersectUniform<true, false>(scene, ray, depth, hit);
+#endif
+        if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+        const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<false, false, true>(P, scene, slot, vertexPlane<false>(), depth, ray, none) : 0u;
+        shadeVertex<false, false, false, false, 2>(P, slot, o, d, hit, ucount, alive, defer, none, tm, &fresh, thr);
+        if (defer || alive) {
+            P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+            P.pool.hit_prop[slot] = hit.prop;
+            P.pool.ucount[slot] = ucount;
+        } else {
+            P.regen_sample[slot] = kNull;  // the path ended: wf_rscatter starts a new one here
+        }
+    }
+    queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
+}
+
+template <bool SUBST, bool WIDE>
+__global__ void __launch_bounds__(256) ZYG_WAVES(SUBST ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_rscatter(Params P) {
+    const uint32_t     num_slots = P.regen_slots;
+    const uint32_t     slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const DScene&      s = c_scene;
+    Counters           none{0, 0, 0};
+    unsigned long long no_rays = 0;
+    SectionTimer       tm;
+    tm.start();
+    bool live = false;
+#if ZYG_EXPERIMENT_SKELETON  // timing experiment (wrong images): the path-state loads and stores of the plain-array layout alone
+    if (slot < num_slots && kNull != P.regen_sample[slot]) {
+        PathHead h;
+        loadHead(P, slot, h);
+        const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
+        const uint4    hr = P.pool.hit[slot];
+        const uint32_t hp = P.pool.hit_prop[slot];
+        const float4   thr = P.pool.thr[slot];
+        float4         ind = P.pool.indirect[slot];
+        ind.x += thr.x * __uint_as_float(hr.x) + float(hp);
+        P.pool.indirect[slot] = ind;
+        P.pool.ray_o[slot] = ro;
+        P.pool.ray_d[slot] = rd;
+        P.pool.thr[slot] = thr;
+        P.pool.vorigin[slot] = ro;
+        P.pool.vgeo_n[slot] = rd;
+        h.depth_surface += 1;
+        storeHead(P, slot, h);
+        live = true;
+    }
+#else
+    if (slot < num_slots && kNull != P.regen_sample[slot]) {
+        ScatterOut out;
+        scatterVertex<false, SUBST, false, false, false, false, true, WIDE>(P, s, slot, out, none, no_rays, tm);
+        live = out.push;
+    }
+#endif
+    if (slot < num_slots && !live) P.regen_sample[slot] = kNull;  // the path ended (or there was none): wf_rgenerate fills the slot
 }
 
 // ---------------------------------------------------------------- wf_persistent

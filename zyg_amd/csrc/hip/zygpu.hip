@@ -422,7 +422,7 @@ struct DeviceBuffers {
 struct ZygpuContext {
     int           device = 0;
     hipStream_t   stream = nullptr;
-    DeviceBuffers scene_mem, pool_mem, film_mem;
+    DeviceBuffers scene_mem, pool_mem, film_mem, regen_mem;
     DScene        scene{};
     bool          has_scene = false, has_view = false;
     ZygpuViewDesc view{};
@@ -440,6 +440,9 @@ struct ZygpuContext {
     float*        film_alpha_active = nullptr;
     size_t        film_alpha_pixels = 0;
     float4*       resolve_tmp = nullptr;
+    Pool          regen_pool{};           // the regenerating kernels' pool: every record in an array of its own (wavefront.hpp wf_rtrace)
+    uint32_t*     regen_sample = nullptr;
+    size_t        regen_slots = 0;
     size_t        pool_capacity = 0;      // paths
     uint32_t      pool_rounds = 0;        // NEE rounds the pick buffer holds
     uint32_t      num_lights = 0;
@@ -490,6 +493,11 @@ struct ZygpuContext {
     // -4.5 %), configs[1] 835 / 840 -> 766 / 772: wf_scatter's waves are coherent then, but their 64 path blocks lie 8 times further apart,
     // and that kernel is bound by how the path state moves, not by its divergence
     int           sort_alive = -1;
+    // option "regenerate" (default 0): the regenerating kernels (wf_rscatter / wf_rtrace: a pool of regen_kslots x 1024 slots that are
+    // all alive, plain record arrays, no queues) where the scene allows them: the prop tables without a large mesh, in-place NEE,
+    // single-sample lights, progressive sampling
+    bool          regenerate = false;
+    uint32_t      regen_kslots = 2048;
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
     uint64_t      camera_samples = 0;
@@ -597,6 +605,14 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
                     &p.emission.mask, &p.direct.mask, &p.indirect.mask, &p.hit.mask, &p.hit_prop.mask, &p.hit_sr.mask, &p.ucount.mask,
                     &p.rec_p.mask, &p.rec_gn.mask, &p.rec_n.mask, &p.rec_t.mask, &p.rec_b.mask})
         *r = 0xFFFFFFFFu;
+    auto blockStrides = [](Pool& q) {  // Rec::stride of the interleaved layout
+#define ZYG_STRIDE(rec) q.rec.stride = decltype(q.rec)::kBlockStride
+        ZYG_STRIDE(q0); ZYG_STRIDE(q1); ZYG_STRIDE(pcg); ZYG_STRIDE(ray_o); ZYG_STRIDE(ray_d); ZYG_STRIDE(thr); ZYG_STRIDE(vorigin); ZYG_STRIDE(vgeo_n);
+        ZYG_STRIDE(emission); ZYG_STRIDE(direct); ZYG_STRIDE(indirect); ZYG_STRIDE(hit); ZYG_STRIDE(hit_prop); ZYG_STRIDE(hit_sr); ZYG_STRIDE(ucount);
+        ZYG_STRIDE(rec_p); ZYG_STRIDE(rec_gn); ZYG_STRIDE(rec_n); ZYG_STRIDE(rec_t); ZYG_STRIDE(rec_b);
+#undef ZYG_STRIDE
+    };
+    blockStrides(p);
 #endif
     ok = ok && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) &&
          m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) &&
@@ -624,6 +640,40 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
     c->pool_rounds = rounds;
     c->pool_allocated = c->pool_mode;
     c->catchers_allocated = c->catchers;
+    return 0;
+}
+
+// The regenerating kernels' pool: `slots` paths, every record in a plain array (Rec::stride = the record's size; the hit block stays
+// 32 B per slot); the arrays that are not Recs (unoccluding candidates ...) are the tick loop's pool's, which ensurePool has sized.
+int ensureRegenPool(ZygpuContext* c, size_t slots) {
+    Pool& p = c->regen_pool;
+    if (slots > c->regen_slots) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        c->regen_mem.release();
+        c->regen_slots = 0;
+        DeviceBuffers& m = c->regen_mem;
+        std::memset(&p, 0, sizeof(p));
+        bool  ok = true;
+        auto  plain = [&](auto& rec, size_t bytes) {
+            char* a = nullptr;
+            ok = ok && m.alloc(slots * bytes, &a);
+            rec.base = a, rec.mask = 0xFFFFFFFFu, rec.local = 0u, rec.stride = uint32_t(bytes);
+        };
+        plain(p.q0, 16), plain(p.q1, 16), plain(p.pcg, 8), plain(p.ray_o, 16), plain(p.ray_d, 16), plain(p.thr, 16), plain(p.vorigin, 16);
+        plain(p.vgeo_n, 16), plain(p.emission, 16), plain(p.direct, 16), plain(p.indirect, 16);
+        char* hits = nullptr;
+        ok = ok && m.alloc(slots * size_t(ZYG_HIT_STRIDE), &hits);
+        p.hit.base = hits, p.hit_prop.base = hits + 16, p.ucount.base = hits + 20, p.hit_sr.base = hits + 24;
+        for (auto* r : {&p.hit.mask, &p.hit_prop.mask, &p.hit_sr.mask, &p.ucount.mask}) *r = 0xFFFFFFFFu;
+        p.hit.stride = p.hit_prop.stride = p.hit_sr.stride = p.ucount.stride = ZYG_HIT_STRIDE;
+        ok = ok && m.alloc(slots, &c->regen_sample);
+        if (!ok) return -1;
+        c->regen_slots = slots;
+    }
+    // (every call: ensurePool may have moved them)
+    const Pool& q = c->pool;
+    p.ucand = q.ucand, p.ucand_prim = q.ucand_prim, p.time = q.time, p.picks = q.picks, p.sh_o = q.sh_o, p.sh_d = q.sh_d, p.contrib = q.contrib;
+    p.nee = q.nee, p.vis = q.vis;
     return 0;
 }
 
@@ -1318,6 +1368,8 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     P.round = 0;
     P.alive_in = P.alive_out = c->queues.alive;
     P.alive_keys = 1;
+    P.regen_sample = nullptr;
+    P.regen_slots = P.regen_samples = P.regen_report = 0;
     P.pixel_pcg = nullptr;
     if (one_shot) {
         if (c->pixel_pcg_capacity < npix) {
@@ -1388,7 +1440,50 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             HIP_OK(hipMemsetAsync(&c->ctl->mesh_fetch, 0, sizeof(uint32_t), c->stream));
             launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
         }
-        if (c->fuse_tick && plain_in_place && !c->persistent) {
+        if (c->regenerate && plain_in_place && !wide && !one_shot && !c->fuse_tick && !c->persistent) {
+            // the regenerating kernels (wavefront.hpp wf_rscatter / wf_rgenerate / wf_rtrace): a small pool whose slots are all alive; a
+            // tick = scatter the living, start new paths in the free slots, closest hit + first shading pass, the second shading pass;
+            // every 8 ticks the host asks whether any slot is still alive (one 4-byte read back)
+            const uint32_t slots = uint32_t(std::min<size_t>(size_t(c->regen_kslots) << 10, (size_t(num_paths) + 255) / 256 * 256));
+            if (ensureRegenPool(c, slots) != 0) {
+                g_error = "zygpu_render: the regenerating kernels' pool could not be allocated";
+                return -1;
+            }
+            Params R = P;
+            R.pool = c->regen_pool;
+            R.regen_sample = c->regen_sample;
+            R.regen_slots = slots;
+            R.regen_samples = num_paths;
+            R.packed_acc = 0;
+            R.alive_keys = 1;
+            HIP_OK(hipMemsetAsync(c->regen_sample, 0xFF, size_t(slots) * sizeof(uint32_t), c->stream));  // kNull: every slot is free
+            HIP_OK(hipMemsetAsync(&c->ctl->next_sample, 0, sizeof(unsigned long long), c->stream));
+            const unsigned rgrid = (slots + 255u) / 256u;
+            const ZygKernelId scatter_kernel = c->has_substitute ? K_RSCATTER_SUBST : K_RSCATTER;
+            bool           live = true;
+            // (every slot ends a path in at most `ticks` ticks, so the batch cannot take longer than this)
+            const uint64_t tick_cap = (uint64_t(num_paths) / slots + 2u) * (ticks + 1u) + 16u;
+            for (uint32_t tick = 0; live; ++tick) {
+                if (tick > tick_cap) {
+                    g_error = "zygpu_render: the regenerating kernels did not finish the batch";
+                    return -1;
+                }
+                const bool ask = 7u == (tick & 7u);
+                R.parity = tick & 1u;
+                R.regen_report = ask ? 1u : 0u;
+                if (ask) HIP_OK(hipMemsetAsync(&c->ctl->regen_live, 0, sizeof(uint32_t), c->stream));
+                if (tick) timedLaunch(c, 5, [&] { launchKernel(c, scatter_kernel, rgrid, R, 0u); });
+                timedLaunch(c, 0, [&] { launchKernel(c, K_RGENERATE, rgrid, R, 0u); });  // (timed with the trace kernel, like the tick loop's first tick)
+                if (ask) {
+                    HIP_OK(hipMemcpyAsync(c->host_count, &c->ctl->regen_live, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                    HIP_OK(hipStreamSynchronize(c->stream));
+                    live = 0 != c->host_count[0];
+                    if (!live) break;
+                }
+                timedLaunch(c, 0, [&] { launchKernel(c, K_RTRACE, rgrid, R, 0u); });
+                timedLaunch(c, 1, [&] { launchKernel(c, K_SHADE_PLAIN_HEAVY, heavyGrid(c, rgrid), R, 0u); });
+            }
+        } else if (c->fuse_tick && plain_in_place && !c->persistent) {
             // tick 0: camera rays, closest hit, shading; then per tick one wf_tick (scatter vertex t - 1, trace + shade vertex t)
             // and wf_shade's second pass; the alive queue ping-pongs between the two ext arrays
             P.parity = 0;
@@ -1805,6 +1900,15 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "mesh_closest")) {
         c->mesh_closest = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "regenerate")) {
+        c->regenerate = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "regen_kslots")) {
+        if (value < 1 || value > 65536) return -1;
+        c->regen_kslots = uint32_t(value);
         return 0;
     }
     if (0 == std::strcmp(name, "sort_alive")) {
