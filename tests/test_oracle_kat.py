@@ -591,3 +591,52 @@ def test_aov_known_answers(product_lib, oracle):
         scenes.cornell(e, 16, 12, 1)
         _, vd = e.compile()
         assert vd.aov_slots == 0b11
+
+
+def test_portal_light_integrators_agree(product_lib, oracle):
+    """A Portal (rectangle.zig:458-513, windowed_distribution_2d.zig) only changes how PathtracerDL / PathtracerMIS *sample* the
+    environment map behind the window; Pathtracer finds the same light by letting its rays leave through the window.  All three
+    must estimate the same image: the windowed distribution's density, the rectified mapping's Jacobian and lightPortalUvw's lookup
+    are only consistent with each other if they do.  One and four samples per pick agree too."""
+    w, h, spp = 40, 30, 768
+    sky = scenes.sky_image(64, 32)
+    means = {}
+    for key, kw in (("PT", dict(integrator="PT")), ("PTDL", dict(integrator="PTDL")), ("PTMIS", dict(integrator="PTMIS")),
+                    ("PTMIS4", dict(integrator="PTMIS", light_samples=4))):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, portal_map=sky, **kw)
+            sd, vd = e.compile()
+            assert 1 == sd.num_portal_lights
+            img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(img).all()
+            means[key] = img[8:, :, :3].mean(axis=(0, 1))  # (below the window's rows, which every integrator sees directly)
+    assert (means["PTMIS"] > 0.01).all()
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.03)
+    np.testing.assert_allclose(means["PTMIS4"], means["PTMIS"], rtol=0.03)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.08)
+
+
+def test_sky_entity_integrators_agree(product_lib, oracle):
+    """The Sky entity's sun is a Distant light whose radiance varies across its disc (sky_material.zig:150-168: a table looked up by
+    sunV of the direction).  Light sampling (PTDL) and MIS must agree on what it sends to the ground, and plain path tracing, which
+    only finds the sun by chance, within its noise.  The sky here is a dim uniform image: the reference gives a sample of a Canopy
+    map the density pdf_uv / 2 pi (canopy.zig:94-133), which the equidistant disc only has at its rim (at the zenith the solid
+    angle per uv area is pi / 2 times larger), so PathtracerDL under-weights the zenith of a textured canopy by up to 36 %; the
+    restatement keeps that, and a map whose colours differ between zenith and horizon shows it as a colour shift between PTDL and
+    the other two (measured: blue -6 %, red +-0 for scenes.sky_tables' image).  A uniform map is unaffected in expectation."""
+    w, h, spp = 40, 30, 512
+    sun, _ = scenes.sky_tables(elevation_deg=50.0)
+    dim = np.full((32, 32, 3), 0.02, dtype=np.float32)
+    entity = {"parameters": {"sun": {"rotation": [-50, 150, 0]}}, "tables": (sun, dim)}
+    means = {}
+    for integ in ("PT", "PTDL", "PTMIS"):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.outdoor(e, w, h, spp, integrator=integ, sky_entity=entity, max_depth=5)
+            sd, vd = e.compile()
+            assert 1024 == sd.num_sun_radiance
+            out = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp))
+            assert np.isfinite(out).all()
+            means[integ] = out[h // 2:, :, :3].mean(axis=(0, 1))  # the ground and the boxes
+    assert (means["PTMIS"] > 0.05).all()
+    np.testing.assert_allclose(means["PTDL"], means["PTMIS"], rtol=0.02)
+    np.testing.assert_allclose(means["PT"], means["PTMIS"], rtol=0.25)  # (a sun of 0.27 degrees: plain path tracing rarely finds it)
