@@ -124,10 +124,11 @@ def test_missing_files_fail_loudly(product_lib, tmp_path):
 
 
 _REFUSED = {
-    "Instancer": {"type": "Instancer", "prototypes": [], "instances": {"prototypes": [], "transformations": []}},
     "Scatterer": {"type": "Scatterer", "prototypes": []},
-    "animation": {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"],
-                  "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]}},
+    "animation": {"type": "Group", "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]},
+                  "entities": [{"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"]}]},
+    "Instancer prototype": {"type": "Instancer", "prototypes": [{"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"]}],
+                            "instances": {"prototypes": [0], "transformations": [{}]}},
 }
 
 
@@ -154,6 +155,86 @@ def test_unrendered_entities_and_keys_fail_the_load(product_lib, tmp_path, what)
         finally:
             e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
     assert any(level == 2 and what in text and "does not render" in text for level, text in messages), messages
+
+
+def _write_take(tmp_path, scene, name="s"):
+    with open(tmp_path / f"{name}.scene", "w") as f:
+        json.dump(scene, f)
+    with open(tmp_path / f"{name}.take", "w") as f:
+        json.dump({"scene": f"{name}.scene", "camera": {"Perspective": {"resolution": [16, 12]}, "transformation": {"position": [0, 1, -6]}}}, f)
+    return str(tmp_path / f"{name}.take").encode()
+
+
+_MATERIALS = [{"name": "grey", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5]}}},
+              {"name": "red", "rendering": {"Substitute": {"color": [0.7, 0.1, 0.1]}}},
+              {"name": "lamp", "rendering": {"Light": {"emittance": {"spectrum": [5, 5, 5]}}}}]
+_LAMP = {"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"], "transformation": {"position": [0, 3, 0], "rotation": [90, 0, 0]}}
+
+
+def test_instancer_is_flattened_into_props(product_lib, tmp_path):
+    """An Instancer (scene_loader.zig:401-560, prop/instancer.zig): prototypes that are not rendered themselves, instances = (prototype,
+    transformation in the instancer's space).  The loader makes every instance a prop with the transformation instancer o instance and
+    the prototype's shape, materials and visibility: the scene compiles to the same arrays as one that names those props directly; an
+    index past the prototypes falls back to prototype 0 (scene_loader.zig:454-457); `source` reads the same members from a file."""
+    idx, pos, nrm, uv = scenes.box_mesh((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5))
+    scenes.write_sub_mesh(str(tmp_path / "cube.sub"), idx, pos, nrm, uv, delta=True)
+    instancer_t = {"position": [0.5, 0, 1], "rotation": [0, 30, 0], "scale": [2, 2, 2]}
+    instances = [{"position": [-1, 0.5, 0]}, {"position": [1, 0.5, 0], "rotation": [0, 45, 0], "scale": [0.5, 1, 0.5]}, {"position": [0, 2, 0]}]
+    members = {"prototypes": [{"type": "Prop", "shape": {"file": "cube.sub"}, "materials": ["grey"], "transformation": {"position": [9, 9, 9]}},
+                              {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["red"], "visibility": {"in_camera": False}}],
+               "instances": {"prototypes": [0, 1, 7], "transformations": instances}}
+    inline = {"materials": _MATERIALS, "entities": [_LAMP, dict({"type": "Instancer", "transformation": instancer_t}, **members)]}
+    with open(tmp_path / "forest.instancer", "w") as f:
+        json.dump(dict({"materials": _MATERIALS[:2]}, **members), f)
+    from_file = {"materials": _MATERIALS, "entities": [_LAMP, {"type": "Instancer", "transformation": instancer_t, "source": "forest.instancer"}]}
+    kinds = [({"shape": {"file": "cube.sub"}, "materials": ["grey"]}), ({"shape": {"type": "Sphere"}, "materials": ["red"], "visibility": {"in_camera": False}}),
+             ({"shape": {"file": "cube.sub"}, "materials": ["grey"]})]
+    flat = {"materials": _MATERIALS,
+            "entities": [_LAMP, {"type": "Group", "transformation": instancer_t,
+                                 "entities": [dict({"type": "Prop", "transformation": t}, **k) for k, t in zip(kinds, instances)]}]}
+    compiled = {}
+    for name, scene in (("inline", inline), ("file", from_file), ("flat", flat)):
+        with zyg_amd.Engine(product_lib) as e:
+            assert e.lib.su_ext_load_take(_write_take(tmp_path, scene, name)) == 0, name
+            compiled[name] = _compiled(e)
+    for name in ("inline", "file"):
+        a, b = compiled[name], compiled["flat"]
+        assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[6] == b[6], name
+        assert np.array_equal(a[1], b[1]), name
+    assert 5 == len(compiled["flat"][0])  # camera, lamp, three instances: no prop for a prototype
+
+
+def test_animation_keyframes_become_interpolation_frames(product_lib, tmp_path):
+    """An entity's "animation" (animation_loader.zig, animation.zig): keyframes with times in seconds; every compile resamples them
+    at the frame's two ticks (1/60 s apart: Graph.simulate, scene_graph.zig:106-118): position on the centripetal Catmull-Rom
+    spline through the neighbouring keyframes (ends extrapolated), scale lerped, rotation slerped; the static parent applies to the
+    keyframes.  Here: four keyframes 1/30 s apart on a straight line at constant speed, on which the spline is the straight line, so
+    frame f's two interpolation frames are known in closed form; the "transformations" / "times" form reads the same."""
+    keys = [{"time": k / 30.0, "transformation": {"position": [0.3 * k, 1.0, 0.0], "scale": [1.0 + 0.5 * k] * 3}} for k in range(4)]
+    forms = {"keyframes": {"keyframes": keys},
+             "arrays": {"transformations": [k["transformation"] for k in keys], "times": [k["time"] for k in keys]},
+             "fps": {"frames_per_second": 30, "keyframes": [{"transformation": k["transformation"]} for k in keys]}}
+    for name, animation in forms.items():
+        scene = {"materials": _MATERIALS,
+                 "entities": [_LAMP, {"type": "Group", "transformation": {"position": [10, 0, 0]},
+                                      "entities": [{"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"], "animation": animation}]}]}
+        with zyg_amd.Engine(product_lib) as e:
+            assert e.lib.su_ext_load_take(_write_take(tmp_path, scene, name)) == 0
+            for frame in (0, 1, 3, 5):
+                assert e.lib.su_ext_compile(frame) == 0
+                sd = e.lib.su_ext_scene_desc().contents
+                sphere = [p for p in range(sd.num_props) if sd.props[p].shape == scenes.SPHERE]
+                assert 1 == len(sphere) and 2 == sd.num_interpolation_frames
+                first = sd.prop_frames[sphere[0]]
+                assert first != 0xFFFFFFFF, "the animated prop has no keyframes"
+                for i in range(2):
+                    k = sd.keyframes[first + i]
+                    t = (frame + i) / 60.0  # seconds
+                    s = min(t * 30.0, 3.0)  # keyframe units; past the last keyframe the last one holds
+                    if t * 30.0 >= 3.0:
+                        s = 3.0
+                    np.testing.assert_allclose(list(k.position)[:3], [10.0 + 0.3 * s, 1.0, 0.0], rtol=0, atol=2e-5, err_msg=f"{name} frame {frame}.{i}")
+                    np.testing.assert_allclose(list(k.scale)[:3], [1.0 + 0.5 * s] * 3, rtol=0, atol=2e-5, err_msg=f"{name} frame {frame}.{i}")
 
 
 def test_portal_entity_loads(product_lib, tmp_path):

@@ -852,6 +852,104 @@ int Engine::setTransformationFrame(uint32_t prop, uint32_t frame, const float* m
     return 0;
 }
 
+int Engine::createAnimation(uint32_t prop, const std::vector<uint64_t>& times, const std::vector<Transformation>& frames) {
+    if (prop >= props_.size() || times.empty() || times.size() != frames.size()) return -1;
+    animations_.push_back({prop, times, frames});
+    return int(animations_.size() - 1);
+}
+
+namespace {
+// util/animation.zig:96-141
+float catmullT(Vec4f p0, Vec4f p1, float t, float alpha) {  // getT
+    const Vec4f d = p1 - p0;
+    const float a = dot3(d, d);
+    const float b = std::pow(a, alpha * 0.5f);
+    return b + t;
+}
+Vec4f catmullRom(Vec4f p0, Vec4f p1, Vec4f p2, Vec4f p3, float t, float alpha) {  // centripetal Catmull-Rom spline
+    const float t0 = 0.f;
+    const float t1 = catmullT(p0, p1, t0, alpha);
+    const float t2 = catmullT(p1, p2, t1, alpha);
+    const float t3 = catmullT(p2, p3, t2, alpha);
+    const float tt = std::fmaf(1.f - t, t1, t * t2);  // math.lerp (base/math/util.zig:3-8)
+    if (0.f == t1) return p1;
+    const Vec4f A1 = splat((t1 - tt) / (t1 - t0)) * p0 + splat((tt - t0) / (t1 - t0)) * p1;
+    const Vec4f A2 = splat((t2 - tt) / (t2 - t1)) * p1 + splat((tt - t1) / (t2 - t1)) * p2;
+    const Vec4f A3 = splat((t3 - tt) / (t3 - t2)) * p2 + splat((tt - t2) / (t3 - t2)) * p3;
+    const Vec4f B1 = splat((t2 - tt) / (t2 - t0)) * A1 + splat((tt - t0) / (t2 - t0)) * A2;
+    const Vec4f B2 = splat((t3 - tt) / (t3 - t1)) * A2 + splat((tt - t1) / (t3 - t1)) * A3;
+    return splat((t2 - tt) / (t2 - t1)) * B1 + splat((tt - t1) / (t2 - t1)) * B2;
+}
+Vec4f slerp(Vec4f a, Vec4f b, float t) {  // quaternion.slerp (quaternion.zig:217-245)
+    const Vec4f ab = a * b;
+    float       cosom = ab[0] + ab[1] + ab[2] + ab[3];
+    Vec4f       end = b;
+    if (cosom < 0.f) {
+        cosom = -cosom;
+        end = splat(0.f) - end;
+    }
+    float sclp, sclq;
+    if (1.f - cosom > 0.00001f) {
+        const float omega = std::acos(cosom), sinom = std::sin(omega);
+        sclp = std::sin((1.f - t) * omega) / sinom;
+        sclq = std::sin(t * omega) / sinom;
+    } else {
+        sclp = 1.f - t;
+        sclq = t;
+    }
+    return splat(sclp) * a + splat(sclq) * end;
+}
+Vec4f lerp4(Vec4f a, Vec4f b, float t) {  // math.lerp on vectors: mulAdd(1 - t, a, t * b)
+    Vec4f r;
+    for (int i = 0; i < 4; ++i) r[i] = std::fmaf(1.f - t, a[i], t * b[i]);
+    return r;
+}
+Transformation extrapolate(const Transformation& f1, const Transformation& f2) {
+    return {f2.position + (f2.position - f1.position), f2.scale + (f2.scale - f1.scale), f1.rotation};
+}
+Transformation interpolate(const Transformation& f0, const Transformation& f1, const Transformation& f2, const Transformation& f3, float t) {
+    return {catmullRom(f0.position, f1.position, f2.position, f3.position, t, 0.5f), lerp4(f1.scale, f2.scale, t), slerp(f1.rotation, f2.rotation, t)};
+}
+}  // namespace
+
+// Graph.simulate (scene_graph.zig:106-118) -> Animation.resample (animation.zig:48-93) -> Animation.update: the frame's ticks, from
+// the tick at or before its start to the tick at or after its end; a time outside the keyframes' span takes the last keyframe, as
+// the reference's search does
+void Engine::simulate(uint32_t frame) {
+    if (animations_.empty()) return;
+    const uint64_t tick = 705600000ull / 60, frame_step = tick, frame_duration = tick;  // camera_base.zig:16,25-26
+    const uint64_t start = uint64_t(frame) * frame_step, end = start + frame_duration;
+    const uint64_t frames_start = start - (start % tick);
+    const uint64_t end_rem = end % tick;
+    const uint64_t frames_end = end + (end_rem > 0 ? tick - end_rem : 0);
+    const uint32_t nif = numInterpolationFrames();
+    if (keyframes_.size() < props_.size()) keyframes_.resize(props_.size());
+    for (const HostAnimation& a : animations_) {
+        std::vector<Transformation>& out = keyframes_[a.prop];
+        if (out.empty()) out.assign(nif, world_transformations_[a.prop]);
+        const uint32_t frames_back = uint32_t(a.frames.size()) - 1u;
+        uint32_t       last_frame = 0, i = 0;
+        for (uint64_t time = frames_start; time <= frames_end && i < nif; time += tick, ++i) {
+            for (uint32_t j = last_frame; j < frames_back; ++j) {
+                const uint64_t        a_time = a.times[j], b_time = a.times[j + 1];
+                const Transformation &f1 = a.frames[j], &f2 = a.frames[j + 1];
+                if (time >= a_time && time < b_time) {
+                    const Transformation f0 = j > 0 ? a.frames[j - 1] : extrapolate(f2, f1);
+                    const Transformation f3 = j + 1 < frames_back ? a.frames[j + 2] : extrapolate(f1, f2);
+                    const float          t = float(double(time - a_time) / double(b_time - a_time));
+                    out[i] = interpolate(f0, f1, f2, f3, t);
+                    break;
+                }
+                if (j + 1 == frames_back) {
+                    out[i] = f2;
+                    break;
+                }
+                last_frame += 1;
+            }
+        }
+    }
+}
+
 int Engine::updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data) {  // capi.zig:300-338
     if (id >= images_.size() || !data) return -1;
     HostImage&     img = images_[id];
@@ -1535,8 +1633,9 @@ void Engine::compileSky() {
 }
 
 int Engine::compile(uint32_t frame) {
-    (void)frame;  // keyframes are relative to the frame's start (space.zig:114-125): the compiled scene is the same for every frame
+    // keyframes are relative to the frame's start (space.zig:114-125): without animations the compiled scene is the same for every frame
     if (ZYGPU_NULL == camera_entity) return -1;
+    simulate(frame);
     warnings_.clear();
     compileSky();  // scene.compile -> sky.compile (scene.zig:196-198)
 

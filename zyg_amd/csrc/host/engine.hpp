@@ -131,6 +131,11 @@ class Engine {
     // carried as keyframes in the compiled scene and interpolated at every ray's time (ZygpuSceneDesc.keyframes); an animated
     // *light* is refused by compile().
     int      setTransformationFrame(uint32_t prop, uint32_t frame, const float* m16);
+    // Scene files' "animation" (util/animation.zig, animation_loader.zig): keyframes of an entity's transformation with their times
+    // (in the scene's time units, 705 600 000 per second); compile(frame) resamples them at the frame's ticks (Graph.simulate,
+    // scene_graph.zig:106-118) into the entity's interpolation frames, which is what setTransformationFrame sets by hand
+    int      createAnimation(uint32_t prop, const std::vector<uint64_t>& times, const std::vector<Transformation>& frames);
+    void     simulate(uint32_t frame);
     uint32_t numInterpolationFrames() const;  // scene.zig:254-257, 724-734 with the C ABI camera's frame step / duration
     // su_image_update (capi.zig:300-338): new pixels for an existing image, same format and dimensions
     int      updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data);
@@ -235,6 +240,12 @@ class Engine {
     std::deque<HostImageLight>   image_lights_;
     std::vector<ZygpuImageLight> c_image_lights_;
     uint32_t prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m, bool compensate = true);
+    struct HostAnimation {
+        uint32_t                    prop;
+        std::vector<uint64_t>       times;
+        std::vector<Transformation> frames;
+    };
+    std::vector<HostAnimation> animations_;
     struct HostPortalLight {
         std::vector<float> sat, func;
         uint32_t           dim = 0, light_link = ZYGPU_NULL;

@@ -8,7 +8,7 @@
 // File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
 // core/file/system.zig, reduced to these two levels).  Sky entities create the sun and the sky (engine.cpp createSky; the bake's tables are a
 // procedural stand-in unless the client hands them over).  Refused by name (the load fails, nothing is skipped in silence):
-// instancers, scatterers, animations.  Not read: glTF, gzip-compressed files.
+// scatterers.  Instancers are flattened into props, animations resampled per frame by the engine.  Not read: glTF, gzip-compressed files.
 #pragma once
 
 #include <cstdio>
@@ -290,13 +290,20 @@ class TakeLoader {
             if (p < 0) return false;  // Error.UndefinedLight
             entity = uint32_t(p);
             is_light = true;
-        } else if (type->str == "Instancer" || type->str == "Scatterer") {
-            return unsupported("a \"" + type->str + "\" entity");
+        } else if (type->str == "Instancer") {
+            return loadInstancer(v, parent, local_materials, dir, world);
+        } else if (type->str == "Scatterer") {
+            return unsupported("a \"Scatterer\" entity");
         }  // any other type is a node without an entity: its transformation applies to its children (scene_loader.zig:241-264)
-        if (v.get("animation")) return unsupported("an entity with an \"animation\"");
         Transformation local = identity();
         if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
         world = transform(parent, local);
+        if (const JsonValue* animation = v.get("animation")) {
+            // scene_graph.zig:178-226: the keyframes become the entity's interpolation frames at every frame's compile.  Children
+            // of an animated entity would inherit its frames (propInheritTransformations): not built
+            if (ZYGPU_NULL == entity || v.get("entities")) return unsupported("an \"animation\" on an entity with children");
+            if (!loadAnimation(*animation, entity, local, parent)) return false;
+        }
         if (ZYGPU_NULL == entity) return true;
         setWorld(entity, world);
         bool in_reflection = true;
@@ -309,23 +316,154 @@ class TakeLoader {
         if (is_light && in_reflection) engine_.createLight(entity, light_link);
         return true;
     }
-    uint32_t loadProp(const JsonValue& v, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir,
-                      bool unoccluding_default) {
-        const JsonValue* sv = v.get("shape");
-        if (!sv || JsonValue::Object != sv->type) return ZYGPU_NULL;
-        const uint32_t shape = loadShape(*sv, dir);
-        if (ZYGPU_NULL == shape) return ZYGPU_NULL;
-        const uint32_t        num_materials = engine_.shapeNumMaterials(shape);
+    struct PropSource {  // what loadProp reads of a Prop / Light entity (scene_loader.zig:321-369)
+        uint32_t              shape = ZYGPU_NULL;
         std::vector<uint32_t> materials;
+        bool                  unoccluding = false;
+    };
+    bool readProp(const JsonValue& v, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir,
+                  bool unoccluding_default, PropSource& out) {
+        const JsonValue* sv = v.get("shape");
+        if (!sv || JsonValue::Object != sv->type) return false;
+        out.shape = loadShape(*sv, dir);
+        if (ZYGPU_NULL == out.shape) return false;
+        const uint32_t num_materials = engine_.shapeNumMaterials(out.shape);
         if (const JsonValue* ms = v.get("materials"))
             if (JsonValue::Array == ms->type)
                 for (size_t i = 0; i < ms->arr.size() && i < num_materials; ++i)
-                    materials.push_back(JsonValue::String == ms->arr[i].type ? loadMaterial(ms->arr[i].str, local_materials, dir)
-                                                                              : engine_.fallbackMaterial());
-        while (materials.size() < num_materials) materials.push_back(engine_.fallbackMaterial());
-        const bool    unoccluding = !v.memberBool("occluding", !unoccluding_default);
-        const int32_t p = engine_.createPropShape(shape, materials.data(), uint32_t(materials.size()), unoccluding);
+                    out.materials.push_back(JsonValue::String == ms->arr[i].type ? loadMaterial(ms->arr[i].str, local_materials, dir)
+                                                                                  : engine_.fallbackMaterial());
+        while (out.materials.size() < num_materials) out.materials.push_back(engine_.fallbackMaterial());
+        out.unoccluding = !v.memberBool("occluding", !unoccluding_default);
+        return true;
+    }
+    uint32_t createProp(const PropSource& src) {
+        const int32_t p = engine_.createPropShape(src.shape, src.materials.data(), uint32_t(src.materials.size()), src.unoccluding);
         return p < 0 ? ZYGPU_NULL : uint32_t(p);
+    }
+    uint32_t loadProp(const JsonValue& v, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir,
+                      bool unoccluding_default) {
+        PropSource src;
+        return readProp(v, local_materials, dir, unoccluding_default, src) ? createProp(src) : ZYGPU_NULL;
+    }
+
+    // An Instancer (scene_loader.zig:401-560, prop/instancer.zig): prototypes (entities that are not rendered themselves) and
+    // instances = (prototype, transformation in the instancer's space).  The reference gives the instancer a prop tree of its own,
+    // one more level under the scene's; here every instance becomes a prop of the scene with the composed transformation
+    // instancer o instance (what Instancer.intersect leaves in isec.trafo), sharing the prototype's shape and materials: the
+    // scene's own tree (or prop table) takes the place of the instancer's.  Prototypes are Props with a shape; `source` names a
+    // file with the same members (and its own `materials`).
+    bool loadInstancer(const JsonValue& v, const Transformation& parent, const std::map<std::string, const JsonValue*>& local_materials,
+                       const std::string& dir, Transformation& world) {
+        if (v.get("animation")) return unsupported("an animated \"Instancer\"");
+        Transformation local = identity();
+        if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
+        world = transform(parent, local);
+        if (const JsonValue* source = v.get("source")) {
+            if (JsonValue::String != source->type) return false;
+            const std::string path = resolve(source->str, dir);
+            JsonValue         root;
+            if (!readJson(path, root) || JsonValue::Object != root.type) return fail("cannot read instancer \"" + path + "\"");
+            std::map<std::string, const JsonValue*> file_materials;
+            if (const JsonValue* ms = root.get("materials"))
+                if (JsonValue::Array == ms->type)
+                    for (const JsonValue& m : ms->arr)
+                        if (const JsonValue* n = m.get("name"))
+                            if (JsonValue::String == n->type) file_materials[n->str] = &m;
+            return instantiate(root, world, file_materials, parentDirectory(path));
+        }
+        return instantiate(v, world, local_materials, dir);
+    }
+    bool instantiate(const JsonValue& v, const Transformation& world, const std::map<std::string, const JsonValue*>& local_materials,
+                     const std::string& dir) {
+        struct Prototype {
+            PropSource       src;
+            const JsonValue* visibility = nullptr;
+            bool             shadow_catcher = false;
+        };
+        std::vector<Prototype> prototypes;
+        if (const JsonValue* ps = v.get("prototypes"))
+            if (JsonValue::Array == ps->type)
+                for (const JsonValue& pv : ps->arr) {
+                    const JsonValue* type = pv.get("type");
+                    if (!type || JsonValue::String != type->type) continue;  // loadEntity's Error.UndefinedType: `catch continue`
+                    if (type->str != "Prop") return unsupported("an Instancer prototype of type \"" + type->str + "\"");
+                    if (pv.get("animation") || pv.get("entities")) return unsupported("an Instancer prototype with an animation or children");
+                    Prototype p;
+                    if (!readProp(pv, local_materials, dir, false, p.src)) continue;  // Error.UndefinedShape
+                    p.visibility = pv.get("visibility");
+                    p.shadow_catcher = nullptr != pv.get("shadow_catcher");
+                    prototypes.push_back(std::move(p));
+                }
+        const JsonValue* instances = v.get("instances");
+        if (!instances || JsonValue::Object != instances->type) return true;  // an instancer without instances renders nothing
+        const JsonValue *indices = instances->get("prototypes"), *trafos = instances->get("transformations");
+        if (!indices || !trafos || JsonValue::Array != indices->type || JsonValue::Array != trafos->type) return true;
+        if (prototypes.empty()) return true;
+        const size_t n = std::min(indices->arr.size(), trafos->arr.size());
+        for (size_t i = 0; i < n; ++i) {
+            size_t index = size_t(std::max(0.f, indices->arr[i].f32()));
+            if (index >= prototypes.size()) index = 0;
+            const Prototype& proto = prototypes[index];
+            Transformation   t = identity();
+            readTransformation(trafos->arr[i], t);
+            const uint32_t prop = createProp(proto.src);
+            if (ZYGPU_NULL == prop) return fail("an Instancer's instance could not be created");
+            setWorld(prop, transform(world, t));
+            if (proto.visibility)
+                engine_.setVisibility(prop, proto.visibility->memberBool("in_camera", true), proto.visibility->memberBool("in_reflection", true),
+                                      proto.visibility->memberBool("in_sss", false), proto.visibility->memberBool("shadow_catcher_light", false));
+            if (proto.shadow_catcher) engine_.setShadowCatcher(prop);
+        }
+        return true;
+    }
+
+    // animation_loader.zig:13-132: "keyframes" (objects with "time" in seconds and "transformation") or "transformations" + "times";
+    // a keyframe without a time follows the previous one at 1 / frames_per_second.  The entity's own transformation is each
+    // keyframe's default, the (static) parent's applies to the keyframes that name a transformation.
+    bool loadAnimation(const JsonValue& v, uint32_t entity, const Transformation& default_trafo, const Transformation& parent) {
+        if (JsonValue::Object != v.type) return true;
+        const double   units_per_second = 705600000.0;  // Scene.UnitsPerSecond
+        const float    fps = v.memberF32("frames_per_second", 0.f);
+        const uint64_t frame_step = fps > 0.f ? uint64_t(std::llround(units_per_second / double(fps))) : 0u;
+        auto           absolute = [&](const JsonValue& t) { return uint64_t(std::llround(units_per_second * (JsonValue::Number == t.type ? t.num : 0.0))); };
+        std::vector<uint64_t>       times;
+        std::vector<Transformation> frames;
+        uint64_t                    current = 0;
+        if (const JsonValue* keyframes = v.get("keyframes")) {
+            if (JsonValue::Array != keyframes->type) return true;
+            for (const JsonValue& k : keyframes->arr) {
+                Transformation t = default_trafo;
+                uint64_t       time = current;
+                if (JsonValue::Object == k.type) {
+                    if (const JsonValue* tv = k.get("time")) time = absolute(*tv);
+                    if (const JsonValue* tr = k.get("transformation")) {
+                        readTransformation(*tr, t);
+                        t = transform(parent, t);
+                    }
+                }
+                times.push_back(time);
+                frames.push_back(t);
+                current += frame_step;
+            }
+        } else if (const JsonValue* trafos = v.get("transformations")) {
+            if (JsonValue::Array != trafos->type) return true;
+            const JsonValue* tv = v.get("times");
+            for (size_t i = 0; i < trafos->arr.size(); ++i) {
+                Transformation t = default_trafo;
+                uint64_t       time = current;
+                if (tv && JsonValue::Array == tv->type && i < tv->arr.size()) time = absolute(tv->arr[i]);
+                readTransformation(trafos->arr[i], t);
+                t = transform(parent, t);
+                times.push_back(time);
+                frames.push_back(t);
+                current += frame_step;
+            }
+        } else {
+            return true;
+        }
+        if (times.empty()) return true;
+        return engine_.createAnimation(entity, times, frames) >= 0 || fail("the entity's animation could not be created");
     }
     uint32_t loadMaterial(const std::string& name, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir) {
         const auto cached = materials_by_name_.find(name);
