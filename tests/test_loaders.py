@@ -347,3 +347,39 @@ def test_render_take_and_export(product_lib, tmp_path):
         e.render_iterations(spp)
         e.synchronize()
         assert np.array_equal(film, e.download_film(w, h))
+
+
+@pytest.mark.gpu
+def test_render_take_with_instancer_and_animation(product_lib, oracle, tmp_path):
+    """A take whose scene has an Instancer (flattened into props) and an animated entity (its keyframes resampled into the frame's
+    interpolation frames): the device renders the oracle's film bit for bit, at frame 0 and at frame 2 (other interpolation frames),
+    and the moving sphere blurs (frame 2's film differs from frame 0's)."""
+    from util import oracle_render
+    idx, pos, nrm, uv = scenes.box_mesh((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5))
+    scenes.write_sub_mesh(str(tmp_path / "cube.sub"), idx, pos, nrm, uv, delta=True)
+    keys = [{"time": k / 30.0, "transformation": {"position": [-1.5 + 1.2 * k, 1.6, 0.5 * k], "scale": [0.6, 0.6, 0.6]}} for k in range(4)]
+    scene = {"materials": _MATERIALS,
+             "entities": [{"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"],
+                           "transformation": {"position": [0, 4, 0], "rotation": [-90, 0, 0], "scale": [2, 2, 1]}},
+                          {"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["grey"],
+                           "transformation": {"rotation": [90, 0, 0], "scale": [12, 12, 1]}},
+                          {"type": "Instancer", "transformation": {"position": [0, 0.5, 1]},
+                           "prototypes": [{"type": "Prop", "shape": {"file": "cube.sub"}, "materials": ["red"]}],
+                           "instances": {"prototypes": [0, 0, 0], "transformations": [{"position": [-1.5, 0, 0]}, {"position": [0, 0, 0.5], "rotation": [0, 30, 0]},
+                                                                                     {"position": [1.5, 0, 0], "scale": [0.5, 1.5, 0.5]}]}},
+                          {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"], "animation": {"keyframes": keys}}]}
+    take = _write_take(tmp_path, scene, "moving")
+    films = {}
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(take) == 0
+        for frame in (0, 2):
+            e.start_frame(frame)
+            e.render_iterations(8)
+            e.synchronize()
+            films[frame] = e.download_film(16, 12)
+            sd = e.lib.su_ext_scene_desc().contents
+            vd = e.lib.su_ext_view_desc().contents
+            assert np.isfinite(films[frame]).all() and films[frame][..., :3].max() > 0
+            assert np.array_equal(films[frame], oracle_render(oracle, sd, vd, 8)), f"frame {frame}"
+            assert e.lib.zygpu_clear_film(e.context(), ctypes.c_float(0.0)) == 0
+    assert not np.array_equal(films[0], films[2])
