@@ -125,8 +125,9 @@ def test_missing_files_fail_loudly(product_lib, tmp_path):
 
 _REFUSED = {
     "Scatterer": {"type": "Scatterer", "prototypes": []},
-    "animation": {"type": "Group", "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]},
-                  "entities": [{"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"]}]},
+    "animated \"Instancer\"": {"type": "Instancer", "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]},
+                              "prototypes": [{"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"]}],
+                              "instances": {"prototypes": [0], "transformations": [{}]}},
     "Instancer prototype": {"type": "Instancer", "prototypes": [{"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"]}],
                             "instances": {"prototypes": [0], "transformations": [{}]}},
 }
@@ -235,6 +236,45 @@ def test_animation_keyframes_become_interpolation_frames(product_lib, tmp_path):
                         s = 3.0
                     np.testing.assert_allclose(list(k.position)[:3], [10.0 + 0.3 * s, 1.0, 0.0], rtol=0, atol=2e-5, err_msg=f"{name} frame {frame}.{i}")
                     np.testing.assert_allclose(list(k.scale)[:3], [1.0 + 0.5 * s] * 3, rtol=0, atol=2e-5, err_msg=f"{name} frame {frame}.{i}")
+
+
+def test_animated_parents_move_their_children(product_lib, tmp_path):
+    """scene_graph.zig:178-226, 250-310: everything below an animated node inherits its frames: a child's world transformation at
+    tick i is the parent's frame i transforming the child's own (static, or its own resampled keyframes, which then do not take the
+    parent in).  A Group translating along x at constant speed carries a static Sphere and a Disk that itself moves up; a Group
+    turning about y (slerp: the angle is linear in time) carries a Sphere one unit off its axis."""
+    line = [{"time": k / 30.0, "transformation": {"position": [0.6 * k, 0.0, 0.0]}} for k in range(4)]
+    rise = [{"time": k / 30.0, "transformation": {"position": [0.0, 0.3 * k, 2.0]}} for k in range(4)]
+    turn = [{"time": k / 30.0, "transformation": {"rotation": [0, 20.0 * k, 0]}} for k in range(4)]
+    scene = {"materials": _MATERIALS,
+             "entities": [_LAMP,
+                          {"type": "Group", "animation": {"keyframes": line}, "entities": [
+                              {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"], "transformation": {"position": [0, 1, 0]}},
+                              {"type": "Prop", "shape": {"type": "Disk"}, "materials": ["red"], "animation": {"keyframes": rise}}]},
+                          {"type": "Group", "transformation": {"position": [0, 0, 5]}, "entities": [
+                              {"type": "Group", "animation": {"keyframes": turn}, "entities": [
+                                  {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["red"],
+                                   "transformation": {"position": [1, 0, 0], "scale": [0.5, 0.5, 0.5]}}]}]}]}
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(_write_take(tmp_path, scene, "graph")) == 0
+        for frame in (0, 1, 4):
+            assert e.lib.su_ext_compile(frame) == 0
+            sd = e.lib.su_ext_scene_desc().contents
+            spheres = [p for p in range(sd.num_props) if sd.props[p].shape == scenes.SPHERE]
+            disks = [p for p in range(sd.num_props) if sd.props[p].shape == 2]  # ZYGPU_SHAPE_DISK
+            assert 2 == len(spheres) and 1 == len(disks)
+            for i in range(2):
+                s = min((frame + i) / 2.0, 3.0)  # keyframe units (two ticks per keyframe interval)
+                carried, risen, turned = (sd.keyframes[sd.prop_frames[p] + i] for p in (spheres[0], disks[0], spheres[1]))
+                np.testing.assert_allclose(list(carried.position)[:3], [0.6 * s, 1.0, 0.0], atol=2e-5)
+                np.testing.assert_allclose(list(risen.position)[:3], [0.6 * s, 0.3 * s, 2.0], atol=2e-5)
+                angle = np.radians(20.0 * s)
+                # base/json.zig's rotation about y by a turns +x towards -z for a positive angle?  Only the radius, the height and the
+                # angle between consecutive ticks are asserted, not the sense of rotation
+                p = np.array(list(turned.position)[:3]) - np.array([0.0, 0.0, 5.0])
+                np.testing.assert_allclose([np.hypot(p[0], p[2]), p[1]], [1.0, 0.0], atol=2e-5)
+                np.testing.assert_allclose(abs(np.arctan2(p[2], p[0])), angle, atol=2e-5)
+                np.testing.assert_allclose(list(turned.scale)[:3], [0.5, 0.5, 0.5], atol=1e-6)
 
 
 def test_portal_entity_loads(product_lib, tmp_path):

@@ -852,10 +852,17 @@ int Engine::setTransformationFrame(uint32_t prop, uint32_t frame, const float* m
     return 0;
 }
 
-int Engine::createAnimation(uint32_t prop, const std::vector<uint64_t>& times, const std::vector<Transformation>& frames) {
-    if (prop >= props_.size() || times.empty() || times.size() != frames.size()) return -1;
-    animations_.push_back({prop, times, frames});
+int Engine::createAnimation(const std::vector<uint64_t>& times, const std::vector<Transformation>& frames) {
+    if (times.empty() || times.size() != frames.size()) return -1;
+    animations_.push_back({times, frames});
     return int(animations_.size() - 1);
+}
+
+int Engine::createGraphNode(uint32_t prop, int parent, int animation, const Transformation& local) {
+    if ((ZYGPU_NULL != prop && prop >= props_.size()) || parent >= int(graph_nodes_.size()) || animation >= int(animations_.size())) return -1;
+    if (parent < 0 && animation < 0) return -1;  // nothing moves it
+    graph_nodes_.push_back({prop, parent, animation, local, {}});
+    return int(graph_nodes_.size() - 1);
 }
 
 namespace {
@@ -916,17 +923,18 @@ Transformation interpolate(const Transformation& f0, const Transformation& f1, c
 // the tick at or before its start to the tick at or after its end; a time outside the keyframes' span takes the last keyframe, as
 // the reference's search does
 void Engine::simulate(uint32_t frame) {
-    if (animations_.empty()) return;
+    if (graph_nodes_.empty()) return;
     const uint64_t tick = 705600000ull / 60, frame_step = tick, frame_duration = tick;  // camera_base.zig:16,25-26
     const uint64_t start = uint64_t(frame) * frame_step, end = start + frame_duration;
     const uint64_t frames_start = start - (start % tick);
     const uint64_t end_rem = end % tick;
     const uint64_t frames_end = end + (end_rem > 0 ? tick - end_rem : 0);
     const uint32_t nif = numInterpolationFrames();
-    if (keyframes_.size() < props_.size()) keyframes_.resize(props_.size());
-    for (const HostAnimation& a : animations_) {
-        std::vector<Transformation>& out = keyframes_[a.prop];
-        if (out.empty()) out.assign(nif, world_transformations_[a.prop]);
+    std::vector<std::vector<Transformation>> resampled(animations_.size());
+    for (size_t k = 0; k < animations_.size(); ++k) {
+        const HostAnimation&         a = animations_[k];
+        std::vector<Transformation>& out = resampled[k];
+        out.assign(nif, a.frames.back());
         const uint32_t frames_back = uint32_t(a.frames.size()) - 1u;
         uint32_t       last_frame = 0, i = 0;
         for (uint64_t time = frames_start; time <= frames_end && i < nif; time += tick, ++i) {
@@ -947,6 +955,16 @@ void Engine::simulate(uint32_t frame) {
                 last_frame += 1;
             }
         }
+    }
+    // calculateWorldTransformations / propInheritTransformations (scene_graph.zig:250-310): parents before children
+    if (keyframes_.size() < props_.size()) keyframes_.resize(props_.size());
+    for (GraphNode& n : graph_nodes_) {
+        n.frames.resize(nif);
+        for (uint32_t i = 0; i < nif; ++i) {
+            const Transformation& own = n.animation >= 0 ? resampled[size_t(n.animation)][i] : n.local;
+            n.frames[i] = n.parent >= 0 ? transformBy(graph_nodes_[size_t(n.parent)].frames[i], own) : own;
+        }
+        if (ZYGPU_NULL != n.prop) keyframes_[n.prop] = n.frames;
     }
 }
 
@@ -1455,10 +1473,6 @@ const float  kSkyRadius = 0.0046548266f;  // tan(kSunAngularRadius) as f32, the 
 inline float sunWiDotZ(float elevation, float v) {  // sky.zig:271-275
     const float y = (2.f * v) - 1.f;
     return std::sin(elevation + y * kSkyRadius);
-}
-inline Vec4f quaternionMul(const Vec4f& a, const Vec4f& b) {  // quaternion.zig:208-215
-    return vec((a[3] * b[0] + a[0] * b[3]) + (a[1] * b[2] - a[2] * b[1]), (a[3] * b[1] + a[1] * b[3]) + (a[2] * b[0] - a[0] * b[2]),
-               (a[3] * b[2] + a[2] * b[3]) + (a[0] * b[1] - a[1] * b[0]), (a[3] * b[3] - a[0] * b[0]) - (a[1] * b[1] + a[2] * b[2]));
 }
 inline Mat3x3 mulMat3(const Mat3x3& a, const Mat3x3& b) {  // matrix3x3.zig:99-111
     Mat3x3 o;

@@ -134,7 +134,11 @@ class Engine {
     // Scene files' "animation" (util/animation.zig, animation_loader.zig): keyframes of an entity's transformation with their times
     // (in the scene's time units, 705 600 000 per second); compile(frame) resamples them at the frame's ticks (Graph.simulate,
     // scene_graph.zig:106-118) into the entity's interpolation frames, which is what setTransformationFrame sets by hand
-    int      createAnimation(uint32_t prop, const std::vector<uint64_t>& times, const std::vector<Transformation>& frames);
+    int      createAnimation(const std::vector<uint64_t>& times, const std::vector<Transformation>& frames);
+    // A node of the animated part of the scene graph (scene_graph.zig:178-226, 250-310): `prop` or ZYGPU_NULL (a node that only
+    // passes its frames on), its parent node (-1: none; the static ancestors are in the animation's keyframes already), its own
+    // animation (-1: the static `local`).  Frame i of a node = its parent's frame i transforming its own.  Parents come first.
+    int      createGraphNode(uint32_t prop, int parent, int animation, const Transformation& local);
     void     simulate(uint32_t frame);
     uint32_t numInterpolationFrames() const;  // scene.zig:254-257, 724-734 with the C ABI camera's frame step / duration
     // su_image_update (capi.zig:300-338): new pixels for an existing image, same format and dimensions
@@ -241,11 +245,17 @@ class Engine {
     std::vector<ZygpuImageLight> c_image_lights_;
     uint32_t prepareImageLight(uint32_t shape_kind, const ZygpuMaterial& m, bool compensate = true);
     struct HostAnimation {
-        uint32_t                    prop;
         std::vector<uint64_t>       times;
         std::vector<Transformation> frames;
     };
+    struct GraphNode {
+        uint32_t                    prop;
+        int                         parent, animation;
+        Transformation              local;
+        std::vector<Transformation> frames;  // simulate(): the node's world transformation at the frame's ticks
+    };
     std::vector<HostAnimation> animations_;
+    std::vector<GraphNode>     graph_nodes_;
     struct HostPortalLight {
         std::vector<float> sat, func;
         uint32_t           dim = 0, light_link = ZYGPU_NULL;

@@ -174,6 +174,18 @@ struct AABB {
     Vec4f b[2];
 };
 
+inline Vec4f quaternionMul(const Vec4f& a, const Vec4f& b) {  // quaternion.zig:208-215
+    return vec((a[3] * b[0] + a[0] * b[3]) + (a[1] * b[2] - a[2] * b[1]), (a[3] * b[1] + a[1] * b[3]) + (a[2] * b[0] - a[0] * b[2]),
+               (a[3] * b[2] + a[2] * b[3]) + (a[0] * b[1] - a[1] * b[0]), (a[3] * b[3] - a[0] * b[0]) - (a[1] * b[1] + a[2] * b[2]));
+}
+// Transformation.transform (transformation.zig:30-36): `child` in the space of `parent`
+inline Transformation transformBy(const Transformation& parent, const Transformation& child) {
+    const Mat4x4 m = compose(quaternionToMat3x3(parent.rotation), parent.scale, parent.position);
+    Vec4f        p = splat(child.position[0]) * m.r[0] + splat(child.position[1]) * m.r[1] + splat(child.position[2]) * m.r[2] + m.r[3];
+    p[3] = 0.f;
+    return {p, parent.scale * child.scale, quaternionMul(child.rotation, parent.rotation)};
+}
+
 inline AABB emptyAabb() { return {{splat(FLT_MAX), splat(-FLT_MAX)}}; }
 inline Vec4f aabbExtent(const AABB& a) { return a.b[1] - a.b[0]; }
 inline Vec4f aabbPosition(const AABB& a) { return splat(0.5f) * (a.b[0] + a.b[1]); }

@@ -70,6 +70,7 @@ class TakeLoader {
     };
 
     Engine&                         engine_;
+    int                             parent_node_ = -1;  // the animated graph node (Engine::createGraphNode) the entities being loaded hang below, or -1
     std::string                     take_dir_;
     std::map<std::string, uint32_t> materials_by_name_, shapes_by_file_;
 
@@ -159,16 +160,7 @@ class TakeLoader {
             t.rotation = quaternionFromMat3x3(basis);
         }
     }
-    static Vec4f quaternionMul(const Vec4f& a, const Vec4f& b) {  // quaternion.zig:208-215
-        return vec((a[3] * b[0] + a[0] * b[3]) + (a[1] * b[2] - a[2] * b[1]), (a[3] * b[1] + a[1] * b[3]) + (a[2] * b[0] - a[0] * b[2]),
-                   (a[3] * b[2] + a[2] * b[3]) + (a[0] * b[1] - a[1] * b[0]), (a[3] * b[3] - a[0] * b[0]) - (a[1] * b[1] + a[2] * b[2]));
-    }
-    static Transformation transform(const Transformation& parent, const Transformation& child) {  // transformation.zig:30-36
-        const Mat4x4 m = compose(quaternionToMat3x3(parent.rotation), parent.scale, parent.position);
-        Vec4f        p = splat(child.position[0]) * m.r[0] + splat(child.position[1]) * m.r[1] + splat(child.position[2]) * m.r[2] + m.r[3];
-        p[3] = 0.f;
-        return {p, parent.scale * child.scale, quaternionMul(child.rotation, parent.rotation)};
-    }
+    static Transformation transform(const Transformation& parent, const Transformation& child) { return transformBy(parent, child); }
     void setWorld(uint32_t entity, const Transformation& world) { engine_.setWorldTransformation(entity, world); }
 
     // ---- take_loader.zig:92-151, 232-243
@@ -247,12 +239,18 @@ class TakeLoader {
                 continue;
             }
             Transformation world;
-            if (!loadEntity(e, parent, local_materials, dir, world)) {
+            int            node = -1;
+            if (!loadEntity(e, parent, local_materials, dir, world, node)) {
                 if (!error.empty()) return false;  // something this build cannot render: never skipped in silence
                 continue;                          // scene_loader.zig:220 `catch continue` (an entity without type or shape)
             }
-            if (const JsonValue* children = e.get("entities"))
-                if (!loadEntities(*children, world, local_materials, dir)) return false;
+            if (const JsonValue* children = e.get("entities")) {
+                const int outer = parent_node_;
+                parent_node_ = node;  // (-1 below a static entity of a static parent)
+                const bool ok = loadEntities(*children, world, local_materials, dir);
+                parent_node_ = outer;
+                if (!ok) return false;
+            }
         }
         return true;
     }
@@ -263,7 +261,8 @@ class TakeLoader {
         return fail("the scene uses " + what + ", which this build does not render");
     }
     bool loadEntity(const JsonValue& v, const Transformation& parent, const std::map<std::string, const JsonValue*>& local_materials,
-                    const std::string& dir, Transformation& world) {
+                    const std::string& dir, Transformation& world, int& node) {
+        node = -1;
         const JsonValue* type = v.get("type");
         if (!type || JsonValue::String != type->type) return false;  // Error.UndefinedType
         uint32_t entity = ZYGPU_NULL, light_link = ZYGPU_NULL;
@@ -298,11 +297,18 @@ class TakeLoader {
         Transformation local = identity();
         if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
         world = transform(parent, local);
-        if (const JsonValue* animation = v.get("animation")) {
-            // scene_graph.zig:178-226: the keyframes become the entity's interpolation frames at every frame's compile.  Children
-            // of an animated entity would inherit its frames (propInheritTransformations): not built
-            if (ZYGPU_NULL == entity || v.get("entities")) return unsupported("an \"animation\" on an entity with children");
-            if (!loadAnimation(*animation, entity, local, parent)) return false;
+        // scene_graph.zig:178-226: an entity with an "animation", and everything below it, is a node of the animated graph: its
+        // world transformation at the frame's ticks = its parent node's frames transforming its own (keyframes resampled, or the
+        // static transformation).  Below a static parent the keyframes take the parent's transformation in (animation_loader.zig).
+        int animation = -1;
+        if (const JsonValue* av = v.get("animation")) {
+            if (!loadAnimation(*av, local, parent_node_ < 0 ? &parent : nullptr, animation)) return false;
+        }
+        if (animation >= 0 || parent_node_ >= 0) {
+            if (ZYGPU_NULL != entity || v.get("entities")) {  // (a childless node without an entity moves nothing)
+                node = engine_.createGraphNode(entity, parent_node_, animation, local);
+                if (node < 0) return fail("the animated entity could not be created");
+            }
         }
         if (ZYGPU_NULL == entity) return true;
         setWorld(entity, world);
@@ -355,7 +361,7 @@ class TakeLoader {
     // file with the same members (and its own `materials`).
     bool loadInstancer(const JsonValue& v, const Transformation& parent, const std::map<std::string, const JsonValue*>& local_materials,
                        const std::string& dir, Transformation& world) {
-        if (v.get("animation")) return unsupported("an animated \"Instancer\"");
+        if (v.get("animation") || parent_node_ >= 0) return unsupported("an animated \"Instancer\"");
         Transformation local = identity();
         if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
         world = transform(parent, local);
@@ -420,8 +426,10 @@ class TakeLoader {
 
     // animation_loader.zig:13-132: "keyframes" (objects with "time" in seconds and "transformation") or "transformations" + "times";
     // a keyframe without a time follows the previous one at 1 / frames_per_second.  The entity's own transformation is each
-    // keyframe's default, the (static) parent's applies to the keyframes that name a transformation.
-    bool loadAnimation(const JsonValue& v, uint32_t entity, const Transformation& default_trafo, const Transformation& parent) {
+    // keyframe's default; a static parent's applies to the keyframes that name a transformation (`parent`; null below an animated parent,
+    // whose frames apply at every compile instead).
+    bool loadAnimation(const JsonValue& v, const Transformation& default_trafo, const Transformation* parent, int& animation) {
+        animation = -1;
         if (JsonValue::Object != v.type) return true;
         const double   units_per_second = 705600000.0;  // Scene.UnitsPerSecond
         const float    fps = v.memberF32("frames_per_second", 0.f);
@@ -439,7 +447,7 @@ class TakeLoader {
                     if (const JsonValue* tv = k.get("time")) time = absolute(*tv);
                     if (const JsonValue* tr = k.get("transformation")) {
                         readTransformation(*tr, t);
-                        t = transform(parent, t);
+                        if (parent) t = transform(*parent, t);
                     }
                 }
                 times.push_back(time);
@@ -454,7 +462,7 @@ class TakeLoader {
                 uint64_t       time = current;
                 if (tv && JsonValue::Array == tv->type && i < tv->arr.size()) time = absolute(tv->arr[i]);
                 readTransformation(trafos->arr[i], t);
-                t = transform(parent, t);
+                if (parent) t = transform(*parent, t);
                 times.push_back(time);
                 frames.push_back(t);
                 current += frame_step;
@@ -463,7 +471,8 @@ class TakeLoader {
             return true;
         }
         if (times.empty()) return true;
-        return engine_.createAnimation(entity, times, frames) >= 0 || fail("the entity's animation could not be created");
+        animation = engine_.createAnimation(times, frames);
+        return animation >= 0 || fail("the entity's animation could not be created");
     }
     uint32_t loadMaterial(const std::string& name, const std::map<std::string, const JsonValue*>& local_materials, const std::string& dir) {
         const auto cached = materials_by_name_.find(name);
