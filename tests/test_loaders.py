@@ -277,6 +277,26 @@ def test_animated_parents_move_their_children(product_lib, tmp_path):
                 np.testing.assert_allclose(list(turned.scale)[:3], [0.5, 0.5, 0.5], atol=1e-6)
 
 
+def test_camera_animation_in_the_take(product_lib, tmp_path):
+    """take_loader.zig:142: a camera's "animation" makes it an animated entity like any other; the view carries its two interpolation
+    frames for the frame being compiled."""
+    keys = [{"time": k / 30.0, "transformation": {"position": [0.4 * k, 1.0, -6.0]}} for k in range(4)]
+    with open(tmp_path / "c.scene", "w") as f:
+        json.dump({"materials": _MATERIALS, "entities": [_LAMP]}, f)
+    with open(tmp_path / "c.take", "w") as f:
+        json.dump({"scene": "c.scene", "camera": {"Perspective": {"resolution": [16, 12], "transformation": {"position": [0, 1, -6]},
+                                                                 "animation": {"keyframes": keys}}}}, f)
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(str(tmp_path / "c.take").encode()) == 0
+        for frame in (0, 3):
+            assert e.lib.su_ext_compile(frame) == 0
+            vd = e.lib.su_ext_view_desc().contents
+            assert 2 == vd.camera_num_keyframes
+            for i in range(2):
+                s = (frame + i) / 2.0
+                np.testing.assert_allclose(list(vd.camera_keyframes[i].position)[:3], [0.4 * s, 1.0, -6.0], atol=2e-5)
+
+
 def test_portal_entity_loads(product_lib, tmp_path):
     """{"type": "Portal", "shape": ..., "light": n} (scene_loader.zig:247-248, 371-397): the prop takes light n's material, light n is
     hidden and becomes a prototype, and the Portal's own light is created with the link (scene_loader.zig:316-318)."""

@@ -47,6 +47,7 @@ class TakeLoader {
             else if (kv.first == "sampler") loadSampler(kv.second);
         }
         if (ZYGPU_NULL == engine_.camera_entity) return fail("the take defines no Perspective camera");
+        if (!error.empty()) return false;
         if (integrator) engine_.loadIntegrators(*integrator);
         {
             // the post-processor chain's tonemapper belongs to the sensor here (Engine::loadSensor reads both)
@@ -182,6 +183,13 @@ class TakeLoader {
         Transformation t = identity();
         if (const JsonValue* tr = cam->get("transformation")) readTransformation(*tr, t);
         setWorld(engine_.camera_entity, t);
+        if (const JsonValue* av = cam->get("animation")) {  // take_loader.zig:142: the camera's keyframes, below the (identity) root
+            const Transformation root = identity();
+            int                  animation = -1;
+            if (loadAnimation(*av, t, &root, animation) && animation >= 0 &&
+                engine_.createGraphNode(engine_.camera_entity, -1, animation, t) < 0)
+                fail("the camera's animation could not be created");
+        }
     }
     void loadSampler(const JsonValue& v) {
         if (JsonValue::Object != v.type) return;
