@@ -297,6 +297,34 @@ def test_camera_animation_in_the_take(product_lib, tmp_path):
                 np.testing.assert_allclose(list(vd.camera_keyframes[i].position)[:3], [0.4 * s, 1.0, -6.0], atol=2e-5)
 
 
+def test_take_aov_and_shutter_keys(product_lib, tmp_path):
+    """The take's "aov" (take.zig:106-129) reaches the view's AOV slots.  A camera "shutter" (take_loader.zig:153-191) other than the
+    reference's default changes nothing in a scene at rest and loads; with an animated entity it would change the motion blur, and the
+    load fails by name."""
+    def load(shutter, aov=None, moving=True):
+        lamp = dict(_LAMP, animation={"keyframes": [{"time": 0, "transformation": {"position": [0, 3, 0]}},
+                                                    {"time": 1, "transformation": {"position": [1, 3, 0]}}]}) if moving else _LAMP
+        with open(tmp_path / "c.scene", "w") as f:
+            json.dump({"materials": _MATERIALS, "entities": [lamp]}, f)
+        take = {"scene": "c.scene", "camera": {"Perspective": {"resolution": [16, 12], "shutter": shutter}}}
+        if aov:
+            take["aov"] = aov
+        with open(tmp_path / "c.take", "w") as f:
+            json.dump(take, f)
+        with zyg_amd.Engine(product_lib) as e:
+            rc = e.lib.su_ext_load_take(str(tmp_path / "c.take").encode())
+            slots = None
+            if 0 == rc:
+                assert e.lib.su_ext_compile(0) == 0
+                slots = e.lib.su_ext_view_desc().contents.aov_slots
+            return rc, slots
+    assert (0, 0b110) == load({"frames_per_second": 60, "motion_blur": True}, {"Depth": True, "MaterialId": True, "Albedo": False})
+    assert -1 == load({"frames_per_second": 24})[0]
+    assert -1 == load({"motion_blur": False})[0]
+    assert -1 == load({"open": 0.25, "close": 0.75})[0]
+    assert 0 == load({"motion_blur": False, "frames_per_second": 24}, moving=False)[0]
+
+
 def test_portal_entity_loads(product_lib, tmp_path):
     """{"type": "Portal", "shape": ..., "light": n} (scene_loader.zig:247-248, 371-397): the prop takes light n's material, light n is
     hidden and becomes a prototype, and the Portal's own light is created with the link (scene_loader.zig:316-318)."""

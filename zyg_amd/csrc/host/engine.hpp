@@ -140,6 +140,7 @@ class Engine {
     // animation (-1: the static `local`).  Frame i of a node = its parent's frame i transforming its own.  Parents come first.
     int      createGraphNode(uint32_t prop, int parent, int animation, const Transformation& local);
     void     simulate(uint32_t frame);
+    size_t   numGraphNodes() const { return graph_nodes_.size(); }
     uint32_t numInterpolationFrames() const;  // scene.zig:254-257, 724-734 with the C ABI camera's frame step / duration
     // su_image_update (capi.zig:300-338): new pixels for an existing image, same format and dimensions
     int      updateImage(uint32_t id, uint32_t pixel_stride, const uint8_t* data);

@@ -39,6 +39,7 @@ class TakeLoader {
         const JsonValue *integrator = nullptr, *post = nullptr, *exporter = nullptr, *sensor = nullptr;
         for (const auto& kv : root.obj) {
             if (kv.first == "sensor") sensor = &kv.second;
+            else if (kv.first == "aov") loadAov(kv.second);
             else if (kv.first == "camera") loadCamera(kv.second);
             else if (kv.first == "cameras" && JsonValue::Array == kv.second.type && !kv.second.arr.empty()) loadCamera(kv.second.arr[0]);
             else if (kv.first == "export") exporter = &kv.second;
@@ -62,7 +63,10 @@ class TakeLoader {
             engine_.loadSensor(merged);
         }
         if (exporter) loadExporters(*exporter);
-        return loadSceneFile(scene->str, take_dir_, identity());
+        if (!loadSceneFile(scene->str, take_dir_, identity())) return false;
+        if (other_shutter_ && engine_.numGraphNodes() > 0)
+            return unsupported("animations with a camera \"shutter\" other than the default (60 frames per second, open for the whole frame, motion blur on)");
+        return true;
     }
 
   private:
@@ -71,6 +75,7 @@ class TakeLoader {
     };
 
     Engine&                         engine_;
+    bool                            other_shutter_ = false;
     int                             parent_node_ = -1;  // the animated graph node (Engine::createGraphNode) the entities being loaded hang below, or -1
     std::string                     take_dir_;
     std::map<std::string, uint32_t> materials_by_name_, shapes_by_file_;
@@ -164,6 +169,18 @@ class TakeLoader {
     static Transformation transform(const Transformation& parent, const Transformation& child) { return transformBy(parent, child); }
     void setWorld(uint32_t entity, const Transformation& world) { engine_.setWorldTransformation(entity, world); }
 
+    // View.loadAOV (take.zig:106-129): {"Albedo": true, "Depth": true, ...}, as su_aovs_create reads it
+    void loadAov(const JsonValue& v) {
+        static const char* const names[ZYGPU_AOV_NUM_CLASSES] = {"Albedo", "Depth", "MaterialId", "GeometricNormal", "ShadingNormal",
+                                                                 "Roughness", "Emission", "Direct", "Indirect"};
+        if (JsonValue::Object != v.type) return;
+        for (const auto& kv : v.obj)
+            for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES; ++k)
+                if (kv.first == names[k]) {
+                    if (JsonValue::Bool == kv.second.type && kv.second.b) engine_.aov_slots |= 1u << k;
+                    else engine_.aov_slots &= ~(1u << k);
+                }
+    }
     // ---- take_loader.zig:92-151, 232-243
     void loadCamera(const JsonValue& v) {
         if (JsonValue::Object != v.type) return;
@@ -180,6 +197,22 @@ class TakeLoader {
             if (JsonValue::Array == c->type && c->arr.size() >= 4)
                 for (int i = 0; i < 4; ++i) engine_.crop[i] = int32_t(c->arr[i].f32());
         if (const JsonValue* p = cam->get("parameters")) engine_.loadCameraParameters(*p);
+        if (const JsonValue* sh = cam->get("shutter")) {
+            // loadShutter (take_loader.zig:153-191): the frame's length (frame_step / frames_per_second), the shutter's opening and
+            // slope, motion_blur off.  This build renders the reference's defaults (1/60 s frames, open the whole frame, motion blur
+            // on): any other setting changes the image of a scene in which something moves, and is refused by name there
+            bool other = false;
+            if (JsonValue::Object == sh->type)
+                for (const auto& kv : sh->obj) {
+                    if (kv.first == "frames_per_second") other |= 60.f != kv.second.f32(60.f);
+                    else if (kv.first == "frame_step") other |= std::fabs(kv.second.f32(1.f / 60.f) - 1.f / 60.f) > 1e-9f;
+                    else if (kv.first == "motion_blur") other |= !(JsonValue::Bool == kv.second.type && kv.second.b);
+                    else if (kv.first == "open") other |= 0.f != kv.second.f32(0.f);
+                    else if (kv.first == "close") other |= 1.f != kv.second.f32(1.f);
+                    else if (kv.first == "slope") other = true;
+                }
+            other_shutter_ = other;  // (only matters to a scene in which something moves: loadTake looks once the scene is read)
+        }
         Transformation t = identity();
         if (const JsonValue* tr = cam->get("transformation")) readTransformation(*tr, t);
         setWorld(engine_.camera_entity, t);
