@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--sort-alive", type=int, default=-1, choices=[-1, 0, 1],
                     help="zygpu option sort_alive: the surviving paths in one sub-queue per hit prop, so that the consumer's waves stand on one "
                          "surface (-1: the library's choice, on in the scenes of the mesh kernels)")
+    ap.add_argument("--pack-prev", type=int, default=1, choices=[0, 1],
+                    help="zygpu option pack_prev: the previous vertex's origin / normal in dead words of the path's first line (0: two records of the second line)")
+    ap.add_argument("--compact-blocks", type=int, default=0, choices=[0, 1],
+                    help="zygpu option compact_blocks: with pack_prev, path blocks 128 B apart (only their first line is used) instead of 256")
     ap.add_argument("--regenerate", type=int, default=0, choices=[0, 1],
                     help="zygpu option regenerate: the regenerating kernels (a small pool whose slots are all alive, plain record arrays, no queues)")
     ap.add_argument("--regen-kslots", type=int, default=0, help="zygpu option regen_kslots: slots of that pool in units of 1024 (0 = library default, 2048)")
@@ -134,6 +138,8 @@ class Measurement:
         self.eng.set_option("mesh_closest", args.mesh_closest)
         self.eng.set_option("sort_alive", args.sort_alive)
         self.eng.set_option("regenerate", args.regenerate)
+        self.eng.set_option("pack_prev", args.pack_prev)
+        self.eng.set_option("compact_blocks", args.compact_blocks)
         if args.regen_kslots:
             self.eng.set_option("regen_kslots", args.regen_kslots)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)

@@ -524,7 +524,10 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * "regenerate" (default 0) runs the regenerating kernels where the scene allows them (prop tables without a large mesh, in-place
  * next-event estimation, single-sample lights, progressive sampling): a pool of "regen_kslots" x 1024 slots (default 2048,
  * 1..65536) that are all alive, a slot taking the batch's next camera sample when its path ends; same film, measured slower
- * than the tick loop on BASELINE's scenes. */
+ * than the tick loop on BASELINE's scenes;
+ * "pack_prev" (default 1) keeps the previous vertex's origin / geometric normal / roughness in words of the path's first 128 B
+ * line that are dead while they are needed instead of in its second line (scenes without Glass and without opacity masks;
+ * same film), "compact_blocks" (default 0) then places the paths' blocks 128 B apart instead of 256. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.

@@ -1382,3 +1382,42 @@ def test_regenerating_kernels(engine, oracle, integrator, material):
     sd = engine.lib.su_ext_scene_desc().contents
     vd = engine.lib.su_ext_view_desc().contents
     assert np.array_equal(films[1, 1], oracle_render(oracle, sd, vd, spp))
+
+
+@pytest.mark.parametrize("variant", ["lambert", "regularize", "many_lights", "mesh_lights", "staged", "multi", "spheres", "ptdl", "stacked_lamps"])
+def test_previous_vertex_packed_into_the_first_line(engine, oracle, variant):
+    """Option pack_prev (default on; wavefront.hpp PrevVertex): the previous vertex's origin / geometric normal / roughness, which the
+    next vertex's emission pass needs for the light's pdf and the regularisation, travel in words of the path's first line that are
+    dead meanwhile (the stale Sobol buffer, two spare lanes) instead of in two records of its second line.  The film is the same
+    bits either way in both arithmetic modes, and the oracle's in the precise one.  The variants reach every writer and reader:
+    emission at hits with MIS (lamps seen by bounce rays), unoccluding lamps crossed by rays (stacked), mesh and sphere lights,
+    regularize_roughness, the staged wf_nee / wf_extend kernels, multi-sample lights, PathtracerDL (which leaves the normal behind)."""
+    w, h, spp = 96, 72, 4
+    kw = {"lambert": {}, "regularize": dict(material="substitute", regularize=0.75,
+                                           overrides={"tall": scenes.substitute_full((0.9, 0.9, 0.9), roughness=0.05, metallic=1.0)}),
+          "many_lights": dict(many_lights=4), "mesh_lights": dict(mesh_lights=True, light_grid=2), "staged": {}, "multi": dict(light_samples=4),
+          "spheres": dict(spheres=True, sphere_lights=True, material="substitute"), "ptdl": dict(integrator="PTDL"),
+          "stacked_lamps": dict(many_lights=2)}[variant]
+    kw.setdefault("integrator", "PTMIS")
+    scenes.cornell(engine, w, h, spp, **kw)
+    engine.start_frame(0)
+    engine.set_option("nee_in_place", 0 if "staged" == variant else 1)
+    films = {}
+    try:
+        for precise in (1, 0):
+            for pack in (1, 0):
+                engine.set_option("precise", precise)
+                engine.set_option("pack_prev", pack)
+                assert engine.lib.zygpu_clear_film(engine.context(), ctypes.c_float(0.0)) == 0
+                assert engine.lib.zygpu_render(engine.context(), 0, 0, spp, 0, h) == 0
+                engine.synchronize()
+                films[precise, pack] = engine.download_film(w, h)
+    finally:
+        engine.set_option("pack_prev", 1)
+        engine.set_option("precise", 1)
+    for precise in (1, 0):
+        assert np.isfinite(films[precise, 1]).all()
+        assert np.array_equal(films[precise, 1], films[precise, 0]), f"precise {precise}: the packed previous vertex changes the film"
+    sd = engine.lib.su_ext_scene_desc().contents
+    vd = engine.lib.su_ext_view_desc().contents
+    assert np.array_equal(films[1, 1], oracle_render(oracle, sd, vd, spp))

@@ -234,6 +234,10 @@ struct Params {
     uint32_t parity;  // current extension-queue side
     uint32_t queue_capacity;  // entries every queue array holds
     uint32_t packed_acc;      // 1: the paths keep emission / direct in their first line (kPackedAccumulators; set for the non-POOL kernels)
+    // 1: the previous vertex (vertex.origin, vertex.geo_n, its roughness) travels in words of the path's first line that are dead
+    // while it is needed (PrevVertex below) instead of in two records of the second line; the non-POOL kernels of the tick loop in
+    // scenes without opacity masks
+    uint32_t packed_prev;
     uint32_t round;   // POOL: which vertex of the level this launch handles
     uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits
 };
@@ -627,15 +631,38 @@ ZD uint32_t packMeta(const PathHead& h) {
 }
 
 // the samplers of a camera sample (POOL: shared by the vertices of the sample, so stored after every vertex)
-ZD void storeSamplers(const Params& P, uint32_t slot, const PathHead& h) {
-    P.pool.q0[slot] = make_uint4(h.smp.run_seed, packMeta(h), __float_as_uint(h.smp.buffer[4]), h.nee);
-    P.pool.q1[slot] = make_float4(h.smp.buffer[0], h.smp.buffer[1], h.smp.buffer[2], h.smp.buffer[3]);
+// Params::packed_prev: what the next vertex's emission pass needs of this one (vertex.zig:45-65: origin and geometric normal for the
+// light's pdf, PathtracerMIS only; the roughness of the event for regularize_roughness) rides in words of the path's first line
+// that are dead from the moment a vertex is left (scatter / camera-ray generation: incrementPadding has just made the Sobol buffer
+// stale, or the sampler is the PCG stream and never looks at it) until the next shading pass draws again: the five buffer words
+// (q1, q0.z) hold origin.xyz, geo_n.xy; geo_n.z sits in the spare lane of the indirect sum, the roughness in the throughput's.
+// The first shading pass that stores its samplers overwrites the buffer words, which by then only wf_shade's second pass could
+// have wanted, and that pass runs first on the vertices deferred to it.  wf_scatter then writes one line per path instead of two
+// (configs[1]: the kernel -8 % as an upper bound).
+struct PrevVertex {
+    f3    origin, geo_n;
+    float alpha;
+};
+ZD void storeSamplers(const Params& P, uint32_t slot, const PathHead& h, const PrevVertex* prev = nullptr) {
+    if (prev) {
+        P.pool.q0[slot] = make_uint4(h.smp.run_seed, packMeta(h), __float_as_uint(prev->geo_n.y), h.nee);
+        P.pool.q1[slot] = make_float4(prev->origin.x, prev->origin.y, prev->origin.z, prev->geo_n.x);
+    } else {
+        P.pool.q0[slot] = make_uint4(h.smp.run_seed, packMeta(h), __float_as_uint(h.smp.buffer[4]), h.nee);
+        P.pool.q1[slot] = make_float4(h.smp.buffer[0], h.smp.buffer[1], h.smp.buffer[2], h.smp.buffer[3]);
+    }
     P.pool.pcg[slot] = make_uint2(uint32_t(h.smp.rng.state), uint32_t(h.smp.rng.state >> 32));
+}
+// geo_n.z of a packed previous vertex: the spare lane of the indirect sum (IValue.add leaves it alone)
+ZD void storePrevTail(const Params& P, uint32_t slot, const PrevVertex& prev) {
+    float4 i = P.pool.indirect[slot];
+    i.w = prev.geo_n.z;
+    P.pool.indirect[slot] = i;
 }
 
 template <bool POOL = false>
-ZD void storeHead(const Params& P, uint32_t vertex, const PathHead& h) {
-    storeSamplers(P, sampleSlot<POOL>(vertex), h);
+ZD void storeHead(const Params& P, uint32_t vertex, const PathHead& h, const PrevVertex* prev = nullptr) {
+    storeSamplers(P, sampleSlot<POOL>(vertex), h, prev);
     if (POOL) P.pool.vmeta[vertex] = packMeta(h);
 }
 
@@ -694,7 +721,7 @@ ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
 #if ZYG_POOL_STRIDE == 256 && ZYG_HIT_STRIDE && !defined(ZYG_ACC_SEPARATE) && !defined(ZYG_NO_PACKED_ACC)
 constexpr bool kPackedAccumulators = true;
 ZD char* pathBlock(const Params& P, uint32_t slot) {
-    return P.pool.q0.base + size_t((slot & P.pool.q0.mask) + P.pool.q0.local) * size_t(ZYG_POOL_STRIDE);
+    return P.pool.q0.base + size_t((slot & P.pool.q0.mask) + P.pool.q0.local) * size_t(P.pool.q0.stride);
 }
 #else
 constexpr bool kPackedAccumulators = false;
@@ -752,7 +779,7 @@ ZD void ivalueAdd(const Params& P, uint32_t slot, f3 value, uint32_t depth, uint
     }
     const auto   target = is_emission ? P.pool.emission[slot] : direct ? P.pool.direct[slot] : P.pool.indirect[slot];
     const float4 old = target;
-    target = f4(xyz4(old) + value);
+    target = f4(xyz4(old) + value, old.w);  // (the indirect sum's spare lane may carry a packed previous vertex's geo_n.z)
 }
 
 ZD f3 clampColor(f3 color, float max) {  // sensor.zig:615-624
@@ -972,11 +999,13 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
         *keep_o = f4(origin_w, kRayMaxT);
         *keep_d = f4(direction_w, 0.f);
     } else {
-        storeHead<POOL>(P, slot, h);  // POOL: vertex 0 of half 0 has the slot's own index
+        const bool       packed = !POOL && 0 != P.packed_prev;
+        const PrevVertex camera{origin_w, S3(0.f), 0.f};  // Vertex.init (vertex.zig:67-85): origin = the ray's, geo_n = 0
+        storeHead<POOL>(P, slot, h, packed ? &camera : nullptr);  // POOL: vertex 0 of half 0 has the slot's own index
         P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, POOL ? 1.f : 0.f);              // POOL: w = vertex.split_weight
         P.pool.ray_o[slot] = f4(origin_w, kRayMaxT);
         P.pool.ray_d[slot] = f4(direction_w, 0.f);
-        P.pool.vorigin[slot] = f4(origin_w, POOL ? __uint_as_float(1u) : 0.f);        //       w = vertex.path_count
+        if (!packed) P.pool.vorigin[slot] = f4(origin_w, POOL ? __uint_as_float(1u) : 0.f);  //       w = vertex.path_count
         if (POOL) {
             P.pool.med0[slot] = make_uint4(0u, 0u, 0u, 0u);
             P.pool.med1[slot] = make_uint4(0u, 0u, 0u, 0u);  // .w: probe.wavelength = 0
@@ -987,8 +1016,8 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
                 P.pool.transp_rgb[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-        clearAccumulators<!POOL>(P, slot);
+        if (!packed) P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        clearAccumulators<!POOL>(P, slot);  // (the indirect sum's spare lane = 0 = the packed geo_n.z)
     }
     P.stage_uv[sample] = make_float2(s0, s1);
     if (AOV && c_scene.prop_frames) {  // AOV = the MESHL instantiations: Probe.time for the animated props (camera_base.zig:129-136)
@@ -1398,16 +1427,20 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     }
     // PRE == 1: the records generatePath<KEEP> left to this point (Vertex.init, vertex.zig:67-85: origin = the ray's, geo_n = 0,
     // the sums 0)
+    const bool packed_prev = !POOL && 0 != P.packed_prev;
     auto commitFresh = [&]() {
         P.pool.ray_o[slot] = ro;
         P.pool.ray_d[slot] = rd;
-        P.pool.vorigin[slot] = f4(xyz4(ro), 0.f);
-        P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!packed_prev) {  // (packed: only the second pass wants them, and a vertex deferred to it gets them with its head below)
+            P.pool.vorigin[slot] = f4(xyz4(ro), 0.f);
+            P.pool.vgeo_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         clearAccumulators<true>(P, slot);
     };
     if (defer) {
         if (1 == PRE) {  // the second pass reads the path from the pool
-            storeHead<POOL>(P, slot, h);
+            const PrevVertex camera{xyz4(ro), S3(0.f), 0.f};
+            storeHead<POOL>(P, slot, h, packed_prev ? &camera : nullptr);  // (nothing has drawn since the camera sample's padding)
             P.pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
             commitFresh();
         }
@@ -1434,8 +1467,13 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     f3   catcher_light[2] = {S3(0.f), S3(0.f)};     // this_light.occluded / .unoccluded
     if (HEAVY && connectsLights(h.flags)) {
         VertexIn v;
-        v.vorigin = xyz4(P.pool.vorigin[slot]);
-        v.vgeo_n = xyz4(P.pool.vgeo_n[slot]);
+        if (packed_prev) {  // the words loadHead has just read as the (stale) Sobol buffer; see PrevVertex
+            v.vorigin = mk3(h.smp.buffer[0], h.smp.buffer[1], h.smp.buffer[2]);
+            v.vgeo_n = mk3(h.smp.buffer[3], h.smp.buffer[4], P.pool.indirect.get(slot).w);
+        } else {
+            v.vorigin = xyz4(P.pool.vorigin[slot]);
+            v.vgeo_n = xyz4(P.pool.vgeo_n[slot]);
+        }
         v.bxdf_pdf = rd.w;
         v.flags = h.flags;
         v.depth_surface = h.depth_surface;
@@ -1536,7 +1574,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             done = true;
         } else {
             P.pool.hit_sr[slot] = stochastic_r;
-            P.pool.thr[slot] = f4(throughput, split_weight);
+            P.pool.thr[slot] = f4(throughput, POOL ? split_weight : thr4.w);  // (non-POOL: the spare lane may carry PrevVertex::alpha)
             if (POOL) {
                 f3         geo_n = frag.geo_n, n = frag.n;
                 const bool flipped = (m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo);
@@ -1760,7 +1798,7 @@ ZD Regularize loadRegularize(const Params& P, uint32_t slot) {
     const float  w = ZYGPU_INTEGRATOR_PTMIS == c_view.v.integrator ? c_view.v.regularize_roughness : 0.f;
     if (0.f != w) {
         r.weight = w;
-        r.alpha = P.pool.vgeo_n.get(slot).w;
+        r.alpha = P.packed_prev ? P.pool.thr.get(slot).w : P.pool.vgeo_n.get(slot).w;
     }
     return r;
 }
@@ -2184,12 +2222,13 @@ ZD void extendVertex(const Params& P, const DScene& s, uint32_t slot, PathHead& 
     } else {
         h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
     }
-    float bxdf_pdf = P.pool.ray_d.get(slot).w;
+    const bool packed_prev = 0 != P.packed_prev;
+    float      bxdf_pdf = P.pool.ray_d.get(slot).w;
     if (mis) {
         h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
         h.vdepth = h.depth_surface;
         bxdf_pdf = bs.pdf;
-        P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
+        if (!packed_prev) P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
     }
     throughput = throughput * (bs.reflection / S3(bs.pdf));
     const f3 new_origin = surfaceOffsetP(sf.p, sf.frag_geo_n, bs.wi);
@@ -2200,9 +2239,16 @@ ZD void extendVertex(const Params& P, const DScene& s, uint32_t slot, PathHead& 
     P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
     P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
     back = entersMeshBounds(new_origin, bs.wi);
-    P.pool.thr[slot] = f4(throughput);
-    P.pool.vorigin[slot] = f4(sf.p);
-    storeHead(P, slot, h);
+    if (packed_prev) {  // (only PathtracerMIS looks at geo_n and the roughness: the other integrators leave them behind)
+        const PrevVertex prev{sf.p, mis ? ms.geo_n : S3(0.f), mis ? bs.reg_alpha : 0.f};
+        P.pool.thr[slot] = f4(throughput, prev.alpha);
+        storeHead(P, slot, h, &prev);
+        storePrevTail(P, slot, prev);
+    } else {
+        P.pool.thr[slot] = f4(throughput);
+        P.pool.vorigin[slot] = f4(sf.p);
+        storeHead(P, slot, h);
+    }
     push = true;
 }
 
@@ -2732,13 +2778,14 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         } else {
             h.flags &= ~uint32_t(ST_SPECULAR | ST_SINGULAR | ST_PRIMARY);
         }
-        float bxdf_pdf;
+        const bool packed_prev = 0 != P.packed_prev;
+        float      bxdf_pdf;
         if (mis) {
             h.flags = ms.translucent ? (h.flags | ST_TRANSLUCENT) : (h.flags & ~uint32_t(ST_TRANSLUCENT));
             h.vdepth = h.depth_surface;
             bxdf_pdf = bs.pdf;
 #if !ZYG_EXPERIMENT_NO_LINE_B
-            P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
+            if (!packed_prev) P.pool.vgeo_n[slot] = f4(ms.geo_n, bs.reg_alpha);
 #endif
         } else {
             bxdf_pdf = P.pool.ray_d.get(slot).w;  // the other integrators pass the camera ray's 0 on: read only there
@@ -2757,11 +2804,18 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         P.pool.ray_o[slot] = f4(new_origin, kRayMaxT);
         P.pool.ray_d[slot] = f4(bs.wi, bxdf_pdf);
         back = entersMeshBounds(new_origin, bs.wi);
-        P.pool.thr[slot] = f4(throughput);
+        if (packed_prev) {  // (only PathtracerMIS looks at geo_n and the roughness: the other integrators leave them behind)
+            const PrevVertex prev{sf.p, mis ? ms.geo_n : S3(0.f), mis ? bs.reg_alpha : 0.f};
+            P.pool.thr[slot] = f4(throughput, prev.alpha);
+            storeHead(P, slot, h, &prev);
+            storePrevTail(P, slot, prev);
+        } else {
+            P.pool.thr[slot] = f4(throughput);
 #if !ZYG_EXPERIMENT_NO_LINE_B
-        P.pool.vorigin[slot] = f4(sf.p);
+            P.pool.vorigin[slot] = f4(sf.p);
 #endif
-        storeHead(P, slot, h);
+            storeHead(P, slot, h);
+        }
         push = true;
     }
     tm.mark(6);
@@ -3066,10 +3120,11 @@ __global__ void __launch_bounds__(kPersistentThreads) ZYG_WAVES(2) wf_persistent
     __shared__ uint4 blocks[kPersistentThreads * (ZYG_POOL_STRIDE + ZYG_HIT_STRIDE) / 16];
     const DScene&    s = c_scene;
     Params           L = P;
+    L.packed_prev = 0;  // (the lane's block in LDS has its second line at hand)
     char*            block = reinterpret_cast<char*>(blocks);
     char*            hits = block + kPersistentThreads * ZYG_POOL_STRIDE;
     const uint32_t   lane_block = threadIdx.x;
-#define ZYG_LOCAL(rec, ptr) L.pool.rec.base = (ptr), L.pool.rec.mask = 0u, L.pool.rec.local = lane_block
+#define ZYG_LOCAL(rec, ptr) L.pool.rec.base = (ptr), L.pool.rec.mask = 0u, L.pool.rec.local = lane_block, L.pool.rec.stride = decltype(L.pool.rec)::kBlockStride
     ZYG_LOCAL(q0, block + kOffQ0);
     ZYG_LOCAL(q1, block + kOffQ1);
     ZYG_LOCAL(pcg, block + kOffPcg);

@@ -497,6 +497,13 @@ struct ZygpuContext {
     // all alive, plain record arrays, no queues) where the scene allows them: the prop tables without a large mesh, in-place NEE,
     // single-sample lights, progressive sampling
     bool          regenerate = false;
+    // option "pack_prev" (default 1): the previous vertex's origin / normal / roughness in dead words of the path's first line
+    // instead of two records of its second line (wavefront.hpp PrevVertex); 0 = the layout of rounds 1-2, for the A/B
+    bool          pack_prev = true;
+    // option "compact_blocks" (default 0): with pack_prev, a path's block is its first line only: blocks 128 B apart instead of 256,
+    // consecutive slots in consecutive lines.  Measured in one call: configs[1] 915.9 / 916.8 -> 910.6 / 907.0, configs[2] 248.5 /
+    // 247.9 -> 252.7 / 252.6 Msamples/s: the unit of this traffic is the 128 B line, whether its neighbour is used or not
+    bool          compact_blocks = false;
     uint32_t      regen_kslots = 2048;
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
@@ -1410,6 +1417,16 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         const uint32_t num_paths = uint32_t(npix * b);
         P.queue_capacity = queueEntries(c->pool_capacity);
         P.packed_acc = (kPackedAccumulators && !c->pool_mode) ? 1u : 0u;
+        // the previous vertex in dead words of the path's first line (wavefront.hpp PrevVertex): not where the traversal draws from the
+        // path's sampler through the pool (opacity masks), which would overwrite those words before the emission pass reads them
+        P.packed_prev = (c->pack_prev && !c->pool_mode && !c->masks) ? 1u : 0u;
+        // with the sums and the previous vertex in the first line nothing touches a path's second line: the blocks are laid out 128 B
+        // apart (in the first half of the pool), so that consecutive slots are consecutive lines
+        P.pool = c->pool;
+        if (P.packed_prev && P.packed_acc && c->compact_blocks)
+            for (uint32_t* stride : {&P.pool.q0.stride, &P.pool.q1.stride, &P.pool.pcg.stride, &P.pool.ray_o.stride, &P.pool.ray_d.stride,
+                                     &P.pool.thr.stride, &P.pool.indirect.stride, &P.pool.rec_p.stride})
+                *stride = 128u;
         // one thread per queue entry; the queue lengths live on the device, so every launch covers the upper bound and
         // surplus waves retire on their first (scalar) load
         dim3           grid((num_paths + 255) / 256);
@@ -1455,6 +1472,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             R.regen_slots = slots;
             R.regen_samples = num_paths;
             R.packed_acc = 0;
+            R.packed_prev = 0;
             R.alive_keys = 1;
             HIP_OK(hipMemsetAsync(c->regen_sample, 0xFF, size_t(slots) * sizeof(uint32_t), c->stream));  // kNull: every slot is free
             HIP_OK(hipMemsetAsync(&c->ctl->next_sample, 0, sizeof(unsigned long long), c->stream));
@@ -1900,6 +1918,14 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "mesh_closest")) {
         c->mesh_closest = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "compact_blocks")) {
+        c->compact_blocks = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "pack_prev")) {
+        c->pack_prev = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "regenerate")) {
