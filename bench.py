@@ -71,6 +71,8 @@ def parse_args():
                          "surface (-1: the library's choice, on in the scenes of the mesh kernels)")
     ap.add_argument("--pack-prev", type=int, default=1, choices=[0, 1],
                     help="zygpu option pack_prev: the previous vertex's origin / normal in dead words of the path's first line (0: two records of the second line)")
+    ap.add_argument("--hit-by-queue", type=int, default=1, choices=[0, 1],
+                    help="zygpu option hit_by_queue: the hit records at their vertex' place in the alive queue (dense) instead of by path slot")
     ap.add_argument("--compact-blocks", type=int, default=0, choices=[0, 1],
                     help="zygpu option compact_blocks: with pack_prev, path blocks 128 B apart (only their first line is used) instead of 256")
     ap.add_argument("--regenerate", type=int, default=0, choices=[0, 1],
@@ -140,6 +142,7 @@ class Measurement:
         self.eng.set_option("regenerate", args.regenerate)
         self.eng.set_option("pack_prev", args.pack_prev)
         self.eng.set_option("compact_blocks", args.compact_blocks)
+        self.eng.set_option("hit_by_queue", args.hit_by_queue)
         if args.regen_kslots:
             self.eng.set_option("regen_kslots", args.regen_kslots)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)

@@ -527,7 +527,8 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * than the tick loop on BASELINE's scenes;
  * "pack_prev" (default 1) keeps the previous vertex's origin / geometric normal / roughness in words of the path's first 128 B
  * line that are dead while they are needed instead of in its second line (scenes without Glass and without opacity masks;
- * same film), "compact_blocks" (default 0) then places the paths' blocks 128 B apart instead of 256. */
+ * same film), "compact_blocks" (default 0) then places the paths' blocks 128 B apart instead of 256; "hit_by_queue" (default 1)
+ * stores the hit records of the vertices that go on to wf_scatter at their place in the alive queue instead of by path slot. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.

@@ -238,6 +238,12 @@ struct Params {
     // while it is needed (PrevVertex below) instead of in two records of the second line; the non-POOL kernels of the tick loop in
     // scenes without opacity masks
     uint32_t packed_prev;
+    // The hit records of the vertices that go on to wf_scatter, indexed by their position in the tick's alive queue instead of by path
+    // slot (else null): with depth the surviving slots thin out, and a 32 B hit block of the slot-indexed array then costs its whole
+    // 128 B line, as much as the path's state; at the queue's positions the records are dense: a wave of wf_scatter reads 2 KB in a
+    // row.  Two uint4 per entry: (t, u, v, primitive), (prop, unoccluding count, stochastic_r, -).  wf_trace_shade / wf_shade write
+    // them behind their append to the queue; the vertices deferred to wf_shade's second pass keep the slot-indexed record in between.
+    uint4* hit_q;
     uint32_t round;   // POOL: which vertex of the level this launch handles
     uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits
 };
@@ -338,7 +344,8 @@ constexpr uint32_t traceShadeBlock() {
 }
 
 template <int WAVES = 4>
-ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool active, uint32_t value, bool back = false) {
+ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool active, uint32_t value, bool back = false,
+                  uint32_t* position = nullptr) {
     __shared__ uint32_t wave_count[WAVES][2];
     __shared__ uint32_t block_base[2];
     const bool               front = active && !back, rear = active && back;
@@ -361,12 +368,14 @@ ZD void queuePush(uint32_t* queue, QueueCounts* counts, uint32_t capacity, bool 
     for (uint32_t w = 0; w < wave; ++w) index += wave_count[w][e];
     index += uint32_t(__popcll((rear ? rmask : fmask) & ((1ull << lane) - 1ull)));
     if (active) queue[rear ? capacity - 1u - index : index] = value;
+    if (position) *position = rear ? capacity - 1u - index : index;
     // no trailing barrier: a kernel that pushes twice puts its own barrier between the calls
 }
 
 // Two appends with one pair of barriers: the lanes with `a` go to the front of queue A, those with `b` to the front of queue B.
 template <int WAVES = 4>
-ZD void queuePushTwo(uint32_t* queue_a, QueueCounts* counts_a, bool a, uint32_t* queue_b, QueueCounts* counts_b, bool b, uint32_t value) {
+ZD void queuePushTwo(uint32_t* queue_a, QueueCounts* counts_a, bool a, uint32_t* queue_b, QueueCounts* counts_b, bool b, uint32_t value,
+                     uint32_t* position = nullptr) {
     __shared__ uint32_t wave_count[WAVES][2];
     __shared__ uint32_t block_base[2];
     const unsigned long long amask = __ballot(a), bmask = __ballot(b);
@@ -388,6 +397,7 @@ ZD void queuePushTwo(uint32_t* queue_a, QueueCounts* counts_a, bool a, uint32_t*
     for (uint32_t w = 0; w < wave; ++w) index += wave_count[w][e];
     index += uint32_t(__popcll((b ? bmask : amask) & ((1ull << lane) - 1ull)));
     if (a || b) (b ? queue_b : queue_a)[index] = value;
+    if (position) *position = index;
 }
 
 // Consumer side: the queue's total length and, for entry i (front entries first, then the back ones), its position.
@@ -1395,7 +1405,8 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 // in the pool yet; 2: read from the pool before the traversal, so that the loads do not wait behind it
 template <bool STATS, bool MESHL, bool HEAVY, bool POOL, int PRE = 0>
 ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
-                    Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr, float4 pre_thr = make_float4(1.f, 1.f, 1.f, 0.f)) {
+                    Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr, float4 pre_thr = make_float4(1.f, 1.f, 1.f, 0.f),
+                    float* sr_out = nullptr) {
     const DScene&  s = c_scene;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -1573,7 +1584,8 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             throughput = S3(0.f);
             done = true;
         } else {
-            P.pool.hit_sr[slot] = stochastic_r;
+            if (sr_out) *sr_out = stochastic_r;  // (the caller writes it with the hit, at the vertex' place in the alive queue)
+            else P.pool.hit_sr[slot] = stochastic_r;
             P.pool.thr[slot] = f4(throughput, POOL ? split_weight : thr4.w);  // (non-POOL: the spare lane may carry PrevVertex::alpha)
             if (POOL) {
                 f3         geo_n = frag.geo_n, n = frag.n;
@@ -1617,6 +1629,23 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     tm.mark(4);
 }
 
+struct HitRecord {  // what wf_scatter's closure set-up reads of the vertex' hit: by slot from the pool, or by queue position
+    uint4    hit;       // t, u, v (bits), primitive
+    uint32_t prop, ucount;
+    float    stochastic_r;
+};
+ZD HitRecord loadHitRecord(const Params& P, uint32_t slot) {
+    return {P.pool.hit[slot], P.pool.hit_prop[slot], P.pool.ucount[slot], P.pool.hit_sr[slot]};
+}
+ZD HitRecord loadQueuedHit(const Params& P, uint32_t position) {
+    const uint4 a = P.hit_q[2u * size_t(position)], b = P.hit_q[2u * size_t(position) + 1u];
+    return {a, b.x, b.y, __uint_as_float(b.z)};
+}
+ZD void storeQueuedHit(const Params& P, uint32_t position, const Hit& hit, uint32_t ucount, float stochastic_r) {
+    P.hit_q[2u * size_t(position)] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+    P.hit_q[2u * size_t(position) + 1u] = make_uint4(hit.prop, ucount, __float_as_uint(stochastic_r), 0u);
+}
+
 // Two passes share shadeVertex.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
 // emissive and whose ray crossed no unoccluding light has no emission to evaluate (no sampler draw, no light-tree pdf,
 // no SphQuad), so that instantiation is small enough for twice the occupancy; the others go to the `heavy` queue, which
@@ -1631,15 +1660,19 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
     auto entry = [&](uint32_t i, uint32_t at, uint32_t total) {
         SectionTimer tm;
         tm.start();
-        bool     alive = false, defer = false;
-        uint32_t slot = 0, alive_key = 0;
+        bool       alive = false, defer = false;
+        uint32_t   slot = 0, alive_key = 0, ucount = 0, position = 0;
+        Hit        hit{0.f, 0.f, 0.f, 0u, kNull};
+        float      stochastic_r = 0.f;
+        const bool queued = !POOL && nullptr != P.hit_q;
         if (i < total) {
             slot = HEAVY ? P.q.heavy[at] : extQueue<POOL>(P, cur, P.round)[at];
             const uint4 hr = P.pool.hit[slot];
-            const Hit   hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
+            hit = Hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
             alive_key = hit.prop;
-            shadeVertex<STATS, MESHL, HEAVY, POOL>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, P.pool.ucount[slot], alive, defer,
-                                                   cnt, tm);
+            ucount = P.pool.ucount[slot];
+            shadeVertex<STATS, MESHL, HEAVY, POOL>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, ucount, alive, defer, cnt, tm, nullptr,
+                                                   make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr);
         }
         if (HEAVY && !POOL && P.regen_sample) {
             // the regenerating kernels: no queue behind this pass; a path that ended here leaves its slot to wf_rscatter
@@ -1650,7 +1683,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
                 __syncthreads();  // queuePush's shared words are reused below
             }
             if (!POOL && P.alive_keys > 1) alivePushKeyed<4>(P, cur, false, alive, alive_key & (kAliveKeys - 1u), slot);
-            else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
+            else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot, false, &position);
+            if (queued && alive) storeQueuedHit(P, position, hit, ucount, stochastic_r);
         }
         tm.mark(5);
         tm.flush(P.ctl, 0);
@@ -1711,8 +1745,11 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
     if (i < rounded) {
         SectionTimer tm;
         tm.start();
-        bool     alive = false, defer = false;
-        uint32_t slot = 0, alive_key = 0;
+        bool       alive = false, defer = false;
+        uint32_t   slot = 0, alive_key = 0, queued_ucount = 0, position = 0;
+        Hit        queued_hit{0.f, 0.f, 0.f, 0u, kNull};
+        float      stochastic_r = 0.f;
+        const bool queued = nullptr != P.hit_q;
         if (i < n) {
             slot = FIRST ? i : P.q.ext[cur][at];
             // the fresh path stays in registers until it is shaded, unless the traversal may draw from its sampler through the
@@ -1761,17 +1798,23 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
             alive_key = hit.prop;
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL, UTLAS>(P, scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             tm.mark(10);
-            shadeVertex<STATS, MESHL, false, false, kPre>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh, fresh_thr);
-            if (defer || alive) {  // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool
+            shadeVertex<STATS, MESHL, false, false, kPre>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh, fresh_thr,
+                                                          queued ? &stochastic_r : nullptr);
+            // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool: by slot, or (the vertices that go
+            // straight on to wf_scatter, Params::hit_q) at their place in the alive queue, behind the append below
+            if (defer || (alive && !queued)) {
                 P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
                 P.pool.hit_prop[slot] = hit.prop;
                 P.pool.ucount[slot] = ucount;
             }
+            queued_hit = hit;
+            queued_ucount = ucount;
         }
         // one pair of barriers for both appends (a deferred vertex is appended to the alive queue by wf_shade's second pass):
         // configs[1] wf_trace_shade 126.0 -> 123.9 ms per 8 steps against two queuePush calls
         if (UTLAS && P.alive_keys > 1) alivePushKeyed<kTraceShadeBlock / 64>(P, cur, defer, alive && !defer, alive_key & (kAliveKeys - 1u), slot);
-        else queuePushTwo<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], defer, P.alive_out, &P.ctl->alive_count[cur][0], alive && !defer, slot);
+        else queuePushTwo<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], defer, P.alive_out, &P.ctl->alive_count[cur][0], alive && !defer, slot, &position);
+        if (queued && alive && !defer) storeQueuedHit(P, position, queued_hit, queued_ucount, stochastic_r);
         tm.mark(11);
         tm.flush(P.ctl, 0);
     }
@@ -1807,12 +1850,13 @@ ZD Regularize loadRegularize(const Params& P, uint32_t slot) {
 // Vertex.sample's two-sided flip (vertex.zig:155-161) and the colour-map fetch with the stochastic_r wf_shade drew: the path
 // carries 36 B of hit instead of an 80 B record.  EXTRA: Sphere / Disk / Cube fragments.
 template <bool POOL = false, bool EXTRA = false>
-ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
+ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const HitRecord* record = nullptr) {
     if (!POOL) {
         const DScene&  s = c_scene;
         const float4   ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
-        const uint4    hr = P.pool.hit[slot];
-        const Hit      hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
+        const uint4    hr = record ? record->hit : uint4(P.pool.hit[slot]);
+        const Hit      hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, record ? record->prop : uint32_t(P.pool.hit_prop[slot])};
+        const float    hit_sr = (EXTRA) ? (record ? record->stochastic_r : float(P.pool.hit_sr[slot])) : 0.f;
         Ray            ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, hit.t);
         ray.time = pathTime<false, EXTRA>(P, slot);
         Fragment       frag;
@@ -1825,7 +1869,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
             n = -n;
         }
         f3 color = mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
-        if (EXTRA && kNull != m.color_image) color = sampleColorMapAt(s, m, frag.uv0, frag.uv1, P.pool.hit_sr[slot], frag.p, geo_n, frag.trafo);
+        if (EXTRA && kNull != m.color_image) color = sampleColorMapAt(s, m, frag.uv0, frag.uv1, hit_sr, frag.p, geo_n, frag.trafo);
         const bool caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
         Surface    sf;
         sf.p = frag.p;
@@ -1834,7 +1878,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
         sf.material = s.material_ids[s.props[frag.prop].parts_start + frag.part];
         const Regularize reg = loadRegularize(P, slot);
         if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
-            const FragmentExtra fx{frag.uv0, frag.uv1, P.pool.hit_sr[slot], frag.p, frag.trafo};
+            const FragmentExtra fx{frag.uv0, frag.uv1, hit_sr, frag.p, frag.trafo};
             sf.ms = makeMaterialSample<EXTRA>(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, &fx, reg);
         } else {
             sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, nullptr, reg);
@@ -1875,7 +1919,8 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags) {
 }
 
 // Worker.commonAOV (worker.zig:209-241) into the sample's staged aov.Value; POOL: the sample's vertices in their order
-ZD void commonAov(const Params& P, uint32_t slot, uint32_t ps, const PathHead& h, const Surface& sf, f3 throughput) {
+ZD void commonAov(const Params& P, uint32_t slot, uint32_t ps, const PathHead& h, const Surface& sf, f3 throughput,
+                  const HitRecord* record = nullptr) {
     const MaterialSample& ms = sf.ms;
     const uint32_t        slots = c_view.v.aov_slots;
     float4*               av = P.stage_aov + ps;
@@ -1891,7 +1936,7 @@ ZD void commonAov(const Params& P, uint32_t slot, uint32_t ps, const PathHead& h
         if (slots & (1u << ZYGPU_AOV_GEOMETRIC_NORMAL)) av[ZYGPU_AOV_GEOMETRIC_NORMAL * P.aov_plane] = f4(ms.geo_n);
         if (slots & (1u << ZYGPU_AOV_SHADING_NORMAL)) av[ZYGPU_AOV_SHADING_NORMAL * P.aov_plane] = f4(ms.frame.z);
         if (slots & (1u << ZYGPU_AOV_ROUGHNESS)) av[ZYGPU_AOV_ROUGHNESS * P.aov_plane].x = sqrtf(ms.a0);
-        if (slots & (1u << ZYGPU_AOV_DEPTH)) av[ZYGPU_AOV_DEPTH * P.aov_plane].x = __uint_as_float(P.pool.hit.get(slot).x);
+        if (slots & (1u << ZYGPU_AOV_DEPTH)) av[ZYGPU_AOV_DEPTH * P.aov_plane].x = __uint_as_float(record ? record->hit.x : P.pool.hit.get(slot).x);
         if (slots & (1u << ZYGPU_AOV_MATERIAL_ID)) av[ZYGPU_AOV_MATERIAL_ID * P.aov_plane].x = float(1u + sf.material);
     }
 }
@@ -2435,7 +2480,7 @@ struct ScatterOut {
 // and the path extension (pathtracer_mis.zig:123-278).  Template parameters as wf_scatter's.
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE>
 ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOut& out, Counters& cnt, unsigned long long& shadow_rays,
-                      SectionTimer& tm) {
+                      SectionTimer& tm, const HitRecord* record = nullptr) {
     const uint32_t nxt = P.parity ^ 1u;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -2448,13 +2493,13 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     const uint32_t ps = sampleSlot<POOL>(slot);
     PathHead h;
     loadHead<POOL>(P, slot, h);
-    const Surface         sf = loadSurface<POOL, MESHL>(P, slot, h.flags);
+    const Surface         sf = loadSurface<POOL, MESHL>(P, slot, h.flags, record);
     const MaterialSample& ms = sf.ms;
     const float4          thr4 = P.pool.thr[slot];
     f3                    throughput = xyz4(thr4);
     const float           split_weight = POOL ? thr4.w : 1.f;
 
-    if (MESHL && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput);
+    if (MESHL && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput, record);
     tm.mark(0);
 
     // POOL: the split budget of this vertex (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only: pathtracer.zig:73,
@@ -2908,7 +2953,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG
 #else
     if (has_entry) {
         slot = P.alive_in[at];
-        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE>(P, s, slot, out, cnt, shadow_rays, tm);
+        // Params::hit_q: the vertex' hit record sits at its place in the alive queue (its address does not wait for the slot)
+        const HitRecord hr = (!POOL && P.hit_q) ? loadQueuedHit(P, at) : loadHitRecord(P, slot);
+        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE>(P, s, slot, out, cnt, shadow_rays, tm, &hr);
     }
 #endif
     if (POOL) {
@@ -2952,7 +2999,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI) ? ZYG_SCATTER_
     if (i < total) {
         slot = P.alive_in[at];
         ScatterOut out;
-        scatterVertex<false, SUBST, MULTI, false, false, false, true, WIDE>(P, s, slot, out, none, no_rays, tm);
+        const HitRecord hr = loadHitRecord(P, slot);
+        scatterVertex<false, SUBST, MULTI, false, false, false, true, WIDE>(P, s, slot, out, none, no_rays, tm, &hr);
         if (out.push) {
             const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
             const uint32_t meta = P.pool.q0.get(slot).y;
@@ -3100,7 +3148,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(SUBST ? ZYG_SCATTER_BIG_WAVES :
 #else
     if (slot < num_slots && kNull != P.regen_sample[slot]) {
         ScatterOut out;
-        scatterVertex<false, SUBST, false, false, false, false, true, WIDE>(P, s, slot, out, none, no_rays, tm);
+        const HitRecord hr = loadHitRecord(P, slot);
+        scatterVertex<false, SUBST, false, false, false, false, true, WIDE>(P, s, slot, out, none, no_rays, tm, &hr);
         live = out.push;
     }
 #endif
@@ -3193,7 +3242,8 @@ __global__ void __launch_bounds__(kPersistentThreads) ZYG_WAVES(2) wf_persistent
             }
             if (alive) {
                 ScatterOut out;
-                scatterVertex<false, SUBST, MULTI, false, false, false, true, WIDE>(L, s, slot, out, none, no_rays, tm);
+                const HitRecord hr = loadHitRecord(L, slot);
+                scatterVertex<false, SUBST, MULTI, false, false, false, true, WIDE>(L, s, slot, out, none, no_rays, tm, &hr);
                 alive = out.push;
             }
             active = alive;

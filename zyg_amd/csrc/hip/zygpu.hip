@@ -440,6 +440,7 @@ struct ZygpuContext {
     float*        film_alpha_active = nullptr;
     size_t        film_alpha_pixels = 0;
     float4*       resolve_tmp = nullptr;
+    uint4*        hit_q = nullptr;        // the hit records by alive-queue position (wavefront.hpp Params::hit_q)
     Pool          regen_pool{};           // the regenerating kernels' pool: every record in an array of its own (wavefront.hpp wf_rtrace)
     uint32_t*     regen_sample = nullptr;
     size_t        regen_slots = 0;
@@ -504,6 +505,9 @@ struct ZygpuContext {
     // consecutive slots in consecutive lines.  Measured in one call: configs[1] 915.9 / 916.8 -> 910.6 / 907.0, configs[2] 248.5 /
     // 247.9 -> 252.7 / 252.6 Msamples/s: the unit of this traffic is the 128 B line, whether its neighbour is used or not
     bool          compact_blocks = false;
+    // option "hit_by_queue" (default 1): the hit records of the vertices that go on to wf_scatter at their place in the alive queue
+    // (dense) instead of by path slot (a 128 B line per 32 B record once the slots thin out); wf_scatter's tick loop only
+    bool          hit_by_queue = true;
     uint32_t      regen_kslots = 2048;
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
@@ -627,7 +631,8 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
          m.alloc(paths, &c->stage_color) && m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) &&
          m.alloc(paths, &p.sh_o) && m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
          m.alloc(slots, &p.time) &&
-         m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy);
+         m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy) &&
+         (c->pool_mode || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
     if (ok && c->pool_mode) {
         ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) && m.alloc(paths, &p.rec_uv) &&
              m.alloc(slots, &p.pstate) && m.alloc(slots, &p.transp);
@@ -1377,6 +1382,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     P.alive_keys = 1;
     P.regen_sample = nullptr;
     P.regen_slots = P.regen_samples = P.regen_report = 0;
+    P.hit_q = nullptr;
     P.pixel_pcg = nullptr;
     if (one_shot) {
         if (c->pixel_pcg_capacity < npix) {
@@ -1451,6 +1457,15 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         const bool sort_alive = c->sort_alive < 0 ? (wide && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels) : 0 != c->sort_alive;
         P.alive_keys = (sort_alive && utlas && c->fuse_trace_shade && !c->fuse_tick && !c->persistent) ? kAliveKeys : 1u;
         auto aliveGrid = [&] { return grid.x + (P.alive_keys > 1 ? P.alive_keys : 0u); };  // each sub-queue rounds its entries up to a block
+        // the hit records at the alive queue's positions: where the tick loop's consumer of that queue is wf_scatter (not the hybrid
+        // wf_scatter_h, the staged rounds, wf_tick, the persistent or the regenerating kernels, which read them by slot) and the
+        // queue is one run
+        const bool hybrid = nee && c->nee_in_place && wide && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels && !c->multi_sample_lights;
+        const bool scatter_in_place = nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights) && !hybrid;
+        P.hit_q = (c->hit_by_queue && !c->pool_mode && 1u == P.alive_keys && scatter_in_place && !(c->fuse_tick && plain_in_place) &&
+                   !(c->persistent && plain_in_place) && !(c->regenerate && plain_in_place && !wide && !one_shot))
+                      ? c->hit_q
+                      : nullptr;
         const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
         P.mesh_pass = mesh_pass ? 1u : 0u;
         if (mesh_pass) {
@@ -1918,6 +1933,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "mesh_closest")) {
         c->mesh_closest = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "hit_by_queue")) {
+        c->hit_by_queue = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "compact_blocks")) {
