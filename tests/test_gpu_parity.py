@@ -1413,22 +1413,25 @@ def test_previous_vertex_packed_into_the_first_line(engine, oracle, variant):
     films = {}
     try:
         for precise in (1, 0):
-            for pack, by_queue in ((1, 1), (0, 1), (1, 0)):
+            for pack, by_queue, compact in ((1, 1, 0), (0, 1, 0), (1, 0, 0), (1, 1, 1)):
                 engine.set_option("precise", precise)
                 engine.set_option("pack_prev", pack)
                 engine.set_option("hit_by_queue", by_queue)  # (the hit records by alive-queue position or by slot: Params::hit_q)
+                engine.set_option("compact_blocks", compact)  # (the blocks 128 B apart: only with the packed previous vertex)
                 assert engine.lib.zygpu_clear_film(engine.context(), ctypes.c_float(0.0)) == 0
                 assert engine.lib.zygpu_render(engine.context(), 0, 0, spp, 0, h) == 0
                 engine.synchronize()
-                films[precise, pack, by_queue] = engine.download_film(w, h)
+                films[precise, pack, by_queue + 2 * compact] = engine.download_film(w, h)
     finally:
         engine.set_option("pack_prev", 1)
         engine.set_option("hit_by_queue", 1)
+        engine.set_option("compact_blocks", 0)
         engine.set_option("precise", 1)
     for precise in (1, 0):
         assert np.isfinite(films[precise, 1, 1]).all()
         assert np.array_equal(films[precise, 1, 1], films[precise, 0, 1]), f"precise {precise}: the packed previous vertex changes the film"
         assert np.array_equal(films[precise, 1, 1], films[precise, 1, 0]), f"precise {precise}: the queue-indexed hit records change the film"
+        assert np.array_equal(films[precise, 1, 1], films[precise, 1, 3]), f"precise {precise}: the compact blocks change the film"
     films = {(1, 1): films[1, 1, 1]}
     sd = engine.lib.su_ext_scene_desc().contents
     vd = engine.lib.su_ext_view_desc().contents
