@@ -273,7 +273,7 @@ def committed_profile(args, name, kernel, source_hash):
     """One kernel's entry of a committed rocprofv3 --pmc summary (profiles/<name>: traffic.json from tools/pmc_traffic.py, the
     FETCH_SIZE and WRITE_SIZE passes; pmc_sq.json from tools/pmc_summary.py, the SQ pass).  Counters need profiler passes of
     their own, so this process cannot collect them; a profile is quoted only for the bench arguments it names AND for the
-    sources it was taken with (`_meta.source_hash` = zyg_amd.build.source_hash(), the contents of csrc/ and include/): a
+    kernels' sources it was taken with (`_meta.device_hash` = zyg_amd.build.device_hash(), the contents of csrc/hip and include/): a
     profile of other kernels is refused, not reported as if it were this library's."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
@@ -282,11 +282,14 @@ def committed_profile(args, name, kernel, source_hash):
     meta = prof.get("_meta", {})
     if meta.get("config") != bench_config(args):
         return None, {"profile": "profiles/" + name, "refused": "taken with other bench arguments"}
-    if meta.get("source_hash") != source_hash:
-        return None, {"profile": "profiles/" + name, "refused": f"taken with other sources ({meta.get('source_hash')} != {source_hash})"}
+    # the kernels' sources (csrc/hip + include/: build.device_hash); a profile from before that field existed names all of csrc/
+    from zyg_amd import build as zbuild
+    mine, theirs = (zbuild.device_hash(), meta["device_hash"]) if "device_hash" in meta else (source_hash, meta.get("source_hash"))
+    if theirs != mine:
+        return None, {"profile": "profiles/" + name, "refused": f"taken with other sources ({theirs} != {mine})"}
     for key, val in prof.items():
         if key.startswith(kernel) and "true" not in key.split("<")[-1].split(",")[0]:  # the non-counting instantiation
-            return val, {"profile": "profiles/" + name, "source_commit": meta.get("source_commit"), "source_hash": source_hash,
+            return val, {"profile": "profiles/" + name, "source_commit": meta.get("source_commit"), "device_hash": mine,
                          "fetch_size_factor": meta.get("fetch_size_factor")}
     return None, {"profile": "profiles/" + name, "refused": "kernel not in the profile"}
 

@@ -3,7 +3,7 @@
 
     python3 tools/pmc_summary.py <pass dir> [--json out.json --commit SHA --config '{...}']
 
---json writes the sums with the bench configuration, the source commit and zyg_amd.build.source_hash() of the tree the pass
+--json writes the sums with the bench configuration, the source commit and zyg_amd.build.source_hash() and device_hash() of the tree the pass
 ran in (bench.py quotes profiles/pmc_sq.json only for the same sources and arguments)."""
 import argparse
 import collections
@@ -36,7 +36,7 @@ for k, d in sorted(agg.items()):
         print(k[:28], {n: f'{v:.3g}' for n, v in sorted(d.items())})
 if a.json:
     from zyg_amd import build
-    out = {"_meta": {"source_commit": a.commit, "source_hash": build.source_hash(), "config": json.loads(a.config) if a.config else None}}
+    out = {"_meta": {"source_commit": a.commit, "source_hash": build.source_hash(), "device_hash": build.device_hash(), "config": json.loads(a.config) if a.config else None}}
     for k, d in sorted(agg.items()):
         if 'wf_' in k or 'film' in k:
             out[k] = dict(d)

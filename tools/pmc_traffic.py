@@ -8,7 +8,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3 derived metrics over TCC_
 64 B, and "other access widths are uncalibrated".  These kernels gather 16 B records out of 256 B blocks, so the factor comes
 from tools/calibrate_fetch.py's measurement on that shape (profiles/r02_fetch_calibration.json, stride 256); --factor overrides.
 WRITE_SIZE is exact for 16 B/lane stores.  The output names the source commit, the hash of the sources the library was built from
-(zyg_amd.build.source_hash() of the tree the passes ran in) and the bench configuration it was taken with: bench.py reports it
+(zyg_amd.build.source_hash() and device_hash() of the tree the passes ran in) and the bench configuration it was taken with: bench.py reports it
 as `roofline.traffic` only for that configuration and those sources."""
 import argparse
 import collections
@@ -51,7 +51,7 @@ if factor is None and a.calibration:
 if factor is None:
     factor = 2.0
 fetch, write = load(a.fetch_dir, 'FETCH_SIZE'), load(a.write_dir, 'WRITE_SIZE')
-out = {"_meta": {"fetch_size_factor": factor, "source_commit": a.commit, "source_hash": build.source_hash(), "config": json.loads(a.config) if a.config else None}}
+out = {"_meta": {"fetch_size_factor": factor, "source_commit": a.commit, "source_hash": build.source_hash(), "device_hash": build.device_hash(), "config": json.loads(a.config) if a.config else None}}
 for k in sorted(set(fetch) | set(write)):
     if not ('wf_' in k or 'film' in k):
         continue

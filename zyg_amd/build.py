@@ -74,6 +74,19 @@ def source_hash(source=None):
     return h.hexdigest()[:16]
 
 
+def device_hash():
+    """Hash of what the device code is compiled from (csrc/hip and include/): what a committed rocprofv3 profile of the kernels is
+    valid for (bench.py committed_profile); a change on the host side (loaders, scene compile) leaves it alone."""
+    h = hashlib.sha256()
+    for d in (HIP, os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            p = os.path.join(d, f)
+            if os.path.isfile(p):
+                h.update(os.path.relpath(p, ROOT).encode())
+                h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _flags_hash(flags, extra=()):
     return hashlib.sha1(" ".join(COMMON + list(flags) + list(extra)).encode()).hexdigest()[:12]
 

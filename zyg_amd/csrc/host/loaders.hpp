@@ -8,7 +8,8 @@
 // File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
 // core/file/system.zig, reduced to these two levels).  Sky entities create the sun and the sky (engine.cpp createSky; the bake's tables are a
 // procedural stand-in unless the client hands them over).  Refused by name (the load fails, nothing is skipped in silence):
-// scatterers.  Instancers are flattened into props, animations resampled per frame by the engine.  Not read: glTF, gzip-compressed files.
+// scatterers.  Instancers are flattened into props, animations resampled per frame by the engine.  glTF 2 scene files (.gltf + .bin,
+// materials without image textures) are read as util/gltf_loader.zig reads them.  Not read: gzip-compressed files.
 #pragma once
 
 #include <cstdio>
@@ -261,6 +262,7 @@ class TakeLoader {
         JsonValue         root;
         if (!readJson(path, root) || JsonValue::Object != root.type) return fail("cannot read scene \"" + path + "\"");
         const std::string                       here = parentDirectory(path);
+        if (isGltf(root)) return loadGltf(root, here, parent);  // scene_loader.zig:170-174: a glTF 2 document is tried first
         std::map<std::string, const JsonValue*> local_materials;
         if (const JsonValue* ms = root.get("materials"))
             if (JsonValue::Array == ms->type)
@@ -546,6 +548,224 @@ class TakeLoader {
         const uint32_t shape = loadMeshFile(path);
         shapes_by_file_[path] = shape;
         return shape;
+    }
+
+    // ---- util/gltf_loader.zig: a scene file that is a glTF 2 document (its "asset" has a version >= 2).  As the reference reads it:
+    // every entry of "nodes" on its own (no "children"), a node with a "mesh" becomes a prop (its primitives the mesh's parts), a
+    // node with a "camera" adds a camera the take does not use (the take's own comes first); translations, rotations, positions,
+    // normals mirrored in z and the triangles' winding turned (right-handed -> left-handed); accessors / bufferViews / buffers with
+    // external .bin files, UInt16 / UInt32 indices, strided vertex attributes; materials: pbrMetallicRoughness -> Substitute (base
+    // colour, roughness, metallic, emissiveFactor, KHR_materials_ior / _clearcoat; _transmission / _volume set an attenuation
+    // distance, which makes the Substitute a scattering volume: refused at compile like every other).  Image textures are
+    // refused by name (this build reads no image files).
+    static bool isGltf(const JsonValue& root) {
+        const JsonValue* asset = root.get("asset");
+        if (!asset || JsonValue::Object != asset->type) return false;
+        const JsonValue* version = asset->get("version");
+        return version && JsonValue::String == version->type && !version->str.empty() && version->str[0] >= '2' && version->str[0] <= '9';
+    }
+    struct GltfAccessor {
+        uint32_t buffer_view = 0, byte_offset = 0, component_type = 0, count = 0;
+    };
+    struct GltfView {
+        uint32_t buffer = 0, byte_length = 0, byte_offset = 0, byte_stride = 0;
+    };
+    struct Gltf {
+        std::vector<GltfAccessor> accessors;
+        std::vector<GltfView>     views;
+        std::vector<std::string>  buffers;  // file contents, read on first use
+        std::vector<std::string>  uris;
+        std::vector<uint32_t>     materials;
+        std::string               dir;
+    };
+    static JsonValue jnum(double x) {
+        JsonValue v;
+        v.type = JsonValue::Number;
+        v.num = x;
+        return v;
+    }
+    static JsonValue jarr3(const Vec4f& c) {
+        JsonValue v;
+        v.type = JsonValue::Array;
+        for (int i = 0; i < 3; ++i) v.arr.push_back(jnum(c[i]));
+        return v;
+    }
+    static JsonValue jobj() {
+        JsonValue v;
+        v.type = JsonValue::Object;
+        return v;
+    }
+    bool gltfBuffer(Gltf& g, uint32_t index, const std::string*& out) {
+        if (index >= g.uris.size()) return fail("the glTF scene names a buffer it does not have");
+        if (g.buffers[index].empty() && !readFile(resolve(g.uris[index], g.dir), g.buffers[index]))
+            return fail("cannot read the glTF buffer \"" + g.uris[index] + "\"");
+        out = &g.buffers[index];
+        return true;
+    }
+    template <typename T>
+    bool gltfRead(Gltf& g, uint32_t accessor, uint32_t elements, std::vector<T>& out) {  // loadVertexAttributes / loadIndices
+        if (accessor >= g.accessors.size()) return fail("the glTF scene names an accessor it does not have");
+        const GltfAccessor& a = g.accessors[accessor];
+        if (a.buffer_view >= g.views.size()) return fail("the glTF scene names a bufferView it does not have");
+        const GltfView&    view = g.views[a.buffer_view];
+        const std::string* data = nullptr;
+        if (!gltfBuffer(g, view.buffer, data)) return false;
+        const size_t begin = size_t(a.byte_offset) + view.byte_offset, element_bytes = sizeof(T) * elements;
+        const size_t stride = view.byte_stride > element_bytes ? view.byte_stride : element_bytes;
+        if (a.count && begin + stride * (a.count - 1) + element_bytes > data->size()) return fail("a glTF accessor reaches past its buffer");
+        const size_t first = out.size();
+        out.resize(first + size_t(a.count) * elements);
+        for (uint32_t i = 0; i < a.count; ++i) std::memcpy(out.data() + first + size_t(i) * elements, data->data() + begin + stride * i, element_bytes);
+        return true;
+    }
+    bool loadGltf(const JsonValue& root, const std::string& dir, const Transformation& parent) {
+        Gltf g;
+        g.dir = dir;
+        auto each = [&](const char* key, auto&& f) {
+            if (const JsonValue* a = root.get(key))
+                if (JsonValue::Array == a->type)
+                    for (const JsonValue& n : a->arr) f(n);
+        };
+        each("accessors", [&](const JsonValue& n) {
+            g.accessors.push_back({n.memberU32("bufferView", 0), n.memberU32("byteOffset", 0), n.memberU32("componentType", 0), n.memberU32("count", 0)});
+        });
+        each("bufferViews", [&](const JsonValue& n) {
+            g.views.push_back({n.memberU32("buffer", 0), n.memberU32("byteLength", 0), n.memberU32("byteOffset", 0), n.memberU32("byteStride", 0)});
+        });
+        each("buffers", [&](const JsonValue& n) {
+            const JsonValue* uri = n.get("uri");
+            g.uris.push_back(uri && JsonValue::String == uri->type ? uri->str : std::string());
+        });
+        g.buffers.resize(g.uris.size());
+        bool ok = true;
+        each("materials", [&](const JsonValue& n) {
+            if (ok) g.materials.push_back(gltfMaterial(n, parent.scale[0], ok));
+        });
+        if (!ok) return false;
+        const JsonValue* nodes = root.get("nodes");
+        if (!nodes || JsonValue::Array != nodes->type) return fail("the glTF scene has no nodes");
+        const JsonValue* meshes = root.get("meshes");
+        for (const JsonValue& node : nodes->arr) {
+            const JsonValue* mesh_index = node.get("mesh");
+            if (!mesh_index || JsonValue::Number != mesh_index->type) continue;  // (a camera node: the take's camera is the one in use)
+            if (!meshes || JsonValue::Array != meshes->type || size_t(mesh_index->num) >= meshes->arr.size()) continue;
+            const Vec4f t = readVec3(node.get("translation") ? *node.get("translation") : JsonValue(), splat(0.f));
+            const Vec4f sc = readVec3(node.get("scale") ? *node.get("scale") : JsonValue(), splat(1.f));
+            Vec4f       q = vec(0.f, 0.f, 0.f, 1.f);
+            if (const JsonValue* r = node.get("rotation"))
+                if (JsonValue::Array == r->type && r->arr.size() >= 4) q = vec(r->arr[0].f32(), r->arr[1].f32(), r->arr[2].f32(), r->arr[3].f32());
+            const Transformation local{vec(t[0], t[1], -t[2], 0.f), sc, vec(q[0], q[1], -q[2], q[3])};
+            uint32_t             prop = ZYGPU_NULL;
+            if (!gltfMesh(g, meshes->arr[size_t(mesh_index->num)], prop)) return false;
+            setWorld(prop, transform(parent, local));
+        }
+        return true;
+    }
+    // loadMesh (gltf_loader.zig:279-445): the primitives' vertices one after the other, each primitive a part
+    bool gltfMesh(Gltf& g, const JsonValue& mesh, uint32_t& prop) {
+        const JsonValue* prims = mesh.get("primitives");
+        if (!prims || JsonValue::Array != prims->type || prims->arr.empty()) return fail("a glTF mesh has no primitives");
+        std::vector<uint32_t> parts, indices, materials;
+        std::vector<float>    positions, normals, uvs;
+        std::map<uint32_t, uint32_t> material_map;  // mappedMaterialIndex: the prop's materials in the order its parts first name them
+        bool all_uvs = true;
+        for (const JsonValue& p : prims->arr) {
+            const JsonValue* attributes = p.get("attributes");
+            const uint32_t   index_id = p.memberU32("indices", ZYGPU_NULL);
+            if (ZYGPU_NULL == index_id || !attributes || JsonValue::Object != attributes->type) return fail("a glTF primitive has no indices or attributes");
+            const uint32_t position_id = attributes->memberU32("POSITION", ZYGPU_NULL), normal_id = attributes->memberU32("NORMAL", ZYGPU_NULL);
+            const uint32_t uv_id = attributes->memberU32("TEXCOORD_0", ZYGPU_NULL);
+            if (ZYGPU_NULL == position_id || ZYGPU_NULL == normal_id) return fail("a glTF primitive without POSITION or NORMAL");
+            const uint32_t first_vertex = uint32_t(positions.size() / 3), first_index = uint32_t(indices.size());
+            if (index_id >= g.accessors.size()) return fail("the glTF scene names an accessor it does not have");
+            if (5125 == g.accessors[index_id].component_type) {  // UNSIGNED_INT
+                if (!gltfRead<uint32_t>(g, index_id, 1, indices)) return false;
+            } else if (5123 == g.accessors[index_id].component_type) {  // UNSIGNED_SHORT
+                std::vector<uint16_t> narrow;
+                if (!gltfRead<uint16_t>(g, index_id, 1, narrow)) return false;
+                indices.insert(indices.end(), narrow.begin(), narrow.end());
+            } else {
+                return fail("glTF indices that are neither UInt16 nor UInt32");
+            }
+            for (size_t i = first_index; i < indices.size(); ++i) indices[i] += first_vertex;
+            const uint32_t gltf_material = p.memberU32("material", ZYGPU_NULL);
+            auto           mapped = material_map.find(gltf_material);
+            if (material_map.end() == mapped) {
+                materials.push_back(gltf_material < g.materials.size() && ZYGPU_NULL != g.materials[gltf_material] ? g.materials[gltf_material]
+                                                                                                                      : engine_.fallbackMaterial());
+                mapped = material_map.emplace(gltf_material, uint32_t(materials.size() - 1)).first;
+            }
+            parts.insert(parts.end(), {first_index, uint32_t(indices.size()) - first_index, mapped->second});
+            if (!gltfRead<float>(g, position_id, 3, positions) || !gltfRead<float>(g, normal_id, 3, normals)) return false;
+            if (ZYGPU_NULL != uv_id) {
+                if (!gltfRead<float>(g, uv_id, 2, uvs)) return false;
+            } else {
+                all_uvs = false;
+            }
+        }
+        for (size_t i = 0; i + 2 < indices.size(); i += 3) std::swap(indices[i + 1], indices[i + 2]);
+        for (size_t i = 2; i < positions.size(); i += 3) positions[i] = -positions[i];
+        for (size_t i = 2; i < normals.size(); i += 3) normals[i] = -normals[i];
+        if (!all_uvs) uvs.clear();
+        const uint32_t shape = createMesh(parts, indices, positions, normals, uvs);
+        if (ZYGPU_NULL == shape) return fail("a glTF mesh could not be created");
+        const int32_t p = engine_.createPropShape(shape, materials.data(), uint32_t(materials.size()), false);
+        if (p < 0) return fail("a glTF mesh's prop could not be created");
+        prop = uint32_t(p);
+        return true;
+    }
+    // loadMaterial (gltf_loader.zig:543-733): the Substitute description the reference writes as JSON text
+    uint32_t gltfMaterial(const JsonValue& value, float global_scale, bool& ok) {
+        const JsonValue* pbr = value.get("pbrMetallicRoughness");
+        if (!pbr || JsonValue::Object != pbr->type) return ZYGPU_NULL;  // (the prop's fallback material)
+        for (const char* texture : {"normalTexture", "emissiveTexture"})
+            if (value.get(texture)) return ok = unsupported(std::string("a glTF material with an image texture (") + texture + ")"), ZYGPU_NULL;
+        for (const char* texture : {"baseColorTexture", "metallicRoughnessTexture"})
+            if (pbr->get(texture)) return ok = unsupported(std::string("a glTF material with an image texture (") + texture + ")"), ZYGPU_NULL;
+        float ior = 1.5f, attenuation_distance = 0.f, coat_roughness = 0.f;
+        Vec4f attenuation_color = splat(0.f);
+        bool  volume = false, coat = false;
+        if (const JsonValue* ext = value.get("extensions"))
+            if (JsonValue::Object == ext->type)
+                for (const auto& e : ext->obj) {
+                    if (e.first == "KHR_materials_ior") {
+                        ior = e.second.memberF32("ior", ior);
+                    } else if (e.first == "KHR_materials_transmission") {
+                        attenuation_distance = 1.f;
+                    } else if (e.first == "KHR_materials_volume") {
+                        volume = true;
+                        if (const JsonValue* c = e.second.get("attenuationColor")) attenuation_color = readVec3(*c, attenuation_color);
+                        attenuation_distance = e.second.memberF32("attenuationDistance", attenuation_distance);
+                    } else if (e.first == "KHR_materials_clearcoat") {
+                        if (e.second.get("clearcoatTexture")) return ok = unsupported("a glTF material with an image texture (clearcoatTexture)"), ZYGPU_NULL;
+                        coat = true;
+                        coat_roughness = e.second.memberF32("roughnessFactor", 0.f);
+                    }
+                }
+        JsonValue sub = jobj();
+        sub.obj.emplace_back("color", jarr3(pbr->get("baseColorFactor") ? readVec3(*pbr->get("baseColorFactor"), splat(0.7f)) : splat(0.7f)));
+        sub.obj.emplace_back("roughness", jnum(pbr->memberF32("roughnessFactor", 0.7f)));
+        sub.obj.emplace_back("metallic", jnum(pbr->memberF32("metallicFactor", 1.f)));
+        const Vec4f emissive = value.get("emissiveFactor") ? readVec3(*value.get("emissiveFactor"), splat(0.f)) : splat(0.f);
+        if (emissive[0] > 0.f || emissive[1] > 0.f || emissive[2] > 0.f) {
+            JsonValue e = jobj();
+            e.obj.emplace_back("spectrum", jarr3(emissive));
+            sub.obj.emplace_back("emittance", e);
+        }
+        sub.obj.emplace_back("ior", jnum(ior));
+        if (volume) sub.obj.emplace_back("attenuation_color", jarr3(attenuation_color));
+        if (attenuation_distance > 0.f) sub.obj.emplace_back("attenuation_distance", jnum(global_scale * attenuation_distance));
+        if (coat) {
+            JsonValue c = jobj();
+            c.obj.emplace_back("ior", jnum(1.5));
+            c.obj.emplace_back("roughness", jnum(coat_roughness));
+            c.obj.emplace_back("thickness", jnum(0.001));
+            sub.obj.emplace_back("coating", c);
+        }
+        JsonValue rendering = jobj(), material = jobj();
+        rendering.obj.emplace_back("Substitute", sub);
+        material.obj.emplace_back("rendering", rendering);
+        return engine_.createMaterial(ZYGPU_NULL, material);
     }
 
     // ---- shape_provider.zig:146-272: "SUB\0" -> binary, else JSON
