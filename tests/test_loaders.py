@@ -401,8 +401,23 @@ def test_gltf_scene(product_lib, tmp_path):
     assert from_gltf[0] == from_json[0] and from_gltf[2] == from_json[2] and from_gltf[3] == from_json[3] and from_gltf[4] == from_json[4]
     np.testing.assert_allclose(from_gltf[1], from_json[1], rtol=0, atol=1e-6)
     assert 0 == from_gltf[6] == from_json[6]  # (gltf_loader.zig creates props, never lights: an emissive part is only found by rays)
-    # image textures are refused by name
-    gltf["materials"][0]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+    # a base colour texture: textures[].source -> images[].uri, read as a file texture (PNG) with KHR_texture_transform's scale
+    texels = np.arange(4 * 4 * 3, dtype=np.uint8).reshape(4, 4, 3) * 5
+    _png(tmp_path / "albedo.png", texels, [0, 4])
+    gltf["images"] = [{"uri": "albedo.png"}]
+    gltf["textures"] = [{"source": 0}]
+    gltf["materials"][0]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0, "extensions": {"KHR_texture_transform": {"scale": [2.0, 3.0]}}}
+    with open(tmp_path / "g.gltf", "w") as f:
+        json.dump(gltf, f)
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(str(tmp_path / "g.take").encode()) == 0
+        assert e.lib.su_ext_compile(0) == 0
+        sd = e.lib.su_ext_scene_desc().contents
+        assert 1 == sd.num_images and (0, 4, 4, texels.tobytes()) == _image_bytes(sd, 0)
+        textured = [sd.materials[i] for i in range(sd.num_materials) if sd.materials[i].color_image == 0]
+        assert 1 == len(textured) and [2.0, 3.0] == list(textured[0].color_scale)
+    # what the Substitute of this build has no key for is refused by name
+    gltf["materials"][0]["pbrMetallicRoughness"]["metallicRoughnessTexture"] = {"index": 0}
     with open(tmp_path / "g.gltf", "w") as f:
         json.dump(gltf, f)
     with zyg_amd.Engine(product_lib) as e:
@@ -555,3 +570,113 @@ def test_render_take_with_instancer_and_animation(product_lib, oracle, tmp_path)
             assert np.array_equal(films[frame], oracle_render(oracle, sd, vd, 8)), f"frame {frame}"
             assert e.lib.zygpu_clear_film(e.context(), ctypes.c_float(0.0)) == 0
     assert not np.array_equal(films[0], films[2])
+
+
+def _png(path, pixels, filters):
+    """A PNG of (H, W, C) uint8 pixels (C: 1 grey, 3 RGB, 4 RGBA), row y filtered with filters[y % len(filters)] (0 None, 1 Sub, 2 Up,
+    3 Average, 4 Paeth), the image data in two IDAT chunks."""
+    import struct
+    import zlib
+    h, w, c = pixels.shape
+    raw = bytearray()
+    prev = np.zeros(w * c, dtype=np.int32)
+    for y in range(h):
+        row = pixels[y].astype(np.int32).ravel()
+        f = filters[y % len(filters)]
+        left = np.concatenate([np.zeros(c, dtype=np.int32), row[:-c]])
+        upleft = np.concatenate([np.zeros(c, dtype=np.int32), prev[:-c]])
+        if 0 == f:
+            pred = np.zeros_like(row)
+        elif 1 == f:
+            pred = left
+        elif 2 == f:
+            pred = prev
+        elif 3 == f:
+            pred = (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw.append(f)
+        raw.extend(((row - pred) & 255).astype(np.uint8).tobytes())
+        prev = row
+    data = zlib.compress(bytes(raw), 6)
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2, 4: 6}[c], 0, 0, 0)) +
+                chunk(b"IDAT", data[:len(data) // 2]) + chunk(b"IDAT", data[len(data) // 2:]) + chunk(b"IEND", b""))
+
+
+def _image_bytes(sd, i):
+    img = sd.images[i]
+    bpp = {0: 3, 1: 12, 2: 1, 3: 4, 4: 2, 5: 8}[img.format]
+    return img.format, img.width, img.height, bytes(ctypes.string_at(img.pixels, img.width * img.height * bpp))
+
+
+def test_file_textures(product_lib, tmp_path):
+    """Textures named by "file" (material_provider.zig:438-740, texture_provider.zig:27-65): PNG (png_reader.zig: 8 bits, grey / RGB /
+    RGBA, all five scanline filters, several IDAT chunks) and Radiance RGBE (rgbe_reader.zig: run-length encoded scanlines) files found
+    through the mounts, channels picked by the usage's default swizzle or the "swizzle" key, "invert" for one-channel images.  The
+    compiled images are the ones su_image_create gets for the same pixels; a file that cannot be read fails the compile by name."""
+    rng = np.random.default_rng(5)
+    rgba = rng.integers(0, 256, size=(9, 12, 4), dtype=np.uint8)
+    grey = rng.integers(0, 256, size=(5, 8, 1), dtype=np.uint8)
+    os.mkdir(tmp_path / "tex")
+    _png(tmp_path / "tex" / "rgba.png", rgba, [0, 1, 2, 3, 4])
+    _png(tmp_path / "tex" / "rgb.png", rgba[..., :3], [4, 3, 1])
+    _png(tmp_path / "tex" / "grey.png", grey, [2, 4])
+    # a Radiance picture: 16 x 4, run-length encoded scanlines with runs and literal spans
+    hdr = rng.integers(0, 256, size=(4, 16, 4), dtype=np.uint8)
+    hdr[..., 3] = rng.integers(120, 136, size=(4, 16), dtype=np.uint8)
+    hdr[:, 4:12, :] = hdr[:, 4:5, :]  # a run of 8 equal pixels per scanline
+    hdr[1, 2, 3] = 0  # a zero pixel
+    with open(tmp_path / "tex" / "sky.hdr", "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 4 +X 16\n")
+        for y in range(4):
+            f.write(bytes([2, 2, 0, 16]))
+            for c in range(4):
+                ch = hdr[y, :, c]
+                f.write(bytes([4]) + ch[0:4].tobytes() + bytes([128 + 8, int(ch[4])]) + bytes([4]) + ch[12:16].tobytes())
+    materials = [
+        {"name": "colour", "rendering": {"Substitute": {"color": {"file": "tex/rgba.png"}, "roughness": {"file": "tex/rgba.png", "swizzle": "Y"},
+                                                        "metallic": {"file": "tex/grey.png", "invert": True}, "normal": {"file": "tex/rgb.png"}}}},
+        {"name": "lamp", "rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "emission_map": {"file": "tex/sky.hdr"}}}}},
+        {"name": "masked", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5], "mask": {"file": "tex/rgba.png"}}}}]
+    scene = {"materials": materials,
+             "entities": [{"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"], "transformation": {"position": [0, 3, 0]}},
+                          {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["colour"]},
+                          {"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["masked"], "transformation": {"position": [2, 0, 0]}}]}
+    take = _write_take(tmp_path, scene, "textured")
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(take) == 0
+        assert e.lib.su_ext_compile(0) == 0
+        sd = e.lib.su_ext_scene_desc().contents
+        got = [_image_bytes(sd, i) for i in range(sd.num_images)]
+    expected = {"colour": (0, 12, 9, rgba[..., :3].tobytes()), "roughness": (2, 12, 9, rgba[..., 1].tobytes()),
+                "metallic": (2, 8, 5, (255 - grey[..., 0]).tobytes()), "normal": (4, 12, 9, rgba[..., :2].tobytes()),
+                "mask": (2, 12, 9, rgba[..., 3].tobytes())}
+    for name, image in expected.items():
+        assert image in got, name
+    # the Radiance picture: (mantissa + 0.5) * 2^(e - 136), sRGB -> AP1, rounded to f16
+    srgb = (hdr[..., :3].astype(np.float32) + 0.5) * np.exp2(hdr[..., 3:4].astype(np.float32) - 136.0).astype(np.float32)
+    srgb[hdr[..., 3] == 0] = 0.0
+    m = np.array([[0.61309732, 0.33952285, 0.04737928], [0.07019422, 0.91635557, 0.01345259], [0.02061560, 0.10956983, 0.86981512]], dtype=np.float32)
+    ap1 = (srgb.reshape(-1, 3) @ m.T).astype(np.float16).astype(np.float32).reshape(4, 16, 3)
+    floats = [np.frombuffer(b, dtype=np.float32).reshape(h, w, 3) for f, w, h, b in got if 1 == f]
+    assert 1 == len(floats)
+    np.testing.assert_allclose(floats[0], ap1, rtol=1e-3, atol=0)  # (the matrix product's rounding against numpy's; both round to f16)
+    # a missing file: the compile fails and names it
+    materials[0]["rendering"]["Substitute"]["color"] = {"file": "tex/nowhere.png"}
+    messages = []
+    callback = zyg_amd.LOG_CALLBACK(lambda level, text: messages.append((level, text.decode())))
+    with zyg_amd.Engine(product_lib) as e:
+        e.lib.su_register_log.argtypes = [zyg_amd.LOG_CALLBACK]
+        assert e.lib.su_register_log(callback) == 0
+        try:
+            assert e.lib.su_ext_load_take(_write_take(tmp_path, scene, "missing")) == 0
+            e.lib.zygpu_last_error.restype = ctypes.c_char_p
+            assert e.lib.su_ext_compile(0) != 0
+        finally:
+            e.lib.su_register_log(zyg_amd.LOG_CALLBACK())

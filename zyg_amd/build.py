@@ -155,7 +155,7 @@ def build_variant(name, units, extra, mode="both", verbose=True):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(_compile, todo))
     out = os.path.join(ROOT, "variants", f"lib_{name}.so")
-    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], check=True)
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", out], check=True)
     return out
 
 
@@ -184,7 +184,7 @@ def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
         os.remove(OUT + ".tag")
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(_compile, todo))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", OUT]  # libz: the PNG reader (host/image_readers.hpp)
     if verbose:
         print(f"compiled {len(todo)} of {len(objs)} translation units in {time.time() - t0:.0f} s; linking", flush=True)
     subprocess.run(cmd, check=True)

@@ -48,17 +48,23 @@ int defaultDevice() {
 
 bool parse(const char* text, zyg::JsonValue& v) { return text && zyg::JsonParser::parse(text, v); }
 
+void logCompileError(int rc) {
+    logf(2, -7 == rc ? "a Substitute material has an attenuation_distance: subsurface scattering is a volume, not supported"
+            : -8 == rc ? "an emissive Substitute material with a coating is not supported"
+            : -10 == rc ? "su_integrators_create asked for the light tracer (\"particle\"), photon mapping or the AOV integrator: only PT, PTDL and PTMIS are supported"
+            : -9 == rc ? "a material in use asks for a texture feature that is not supported (procedural textures, image files "
+                         "other than PNG / Radiance RGBE or that could not be read, IES profiles, Triplanar emission maps)"
+            : -4 == rc ? "a material names an image that does not exist or has the wrong number of channels for its use"
+                       : "scene uses a feature outside the hot-path scope (scattering volumes, emission maps on meshes ...)");
+    if (-9 == rc && !g->engine.file_error.empty()) logf(2, "%s", g->engine.file_error.c_str());
+}
+
 // su_start_frame's body: compile, upload, set view (driver.configure + startFrame, capi.zig:586-605)
 int32_t prepareFrame(uint32_t frame, bool clear) {
     Capi& c = *g;
     const int rc = c.engine.compile(frame);
     if (0 != rc) {
-        logf(2, -7 == rc ? "a Substitute material has an attenuation_distance: subsurface scattering is a volume, not supported"
-                : -8 == rc ? "an emissive Substitute material with a coating is not supported"
-                : -10 == rc ? "su_integrators_create asked for the light tracer (\"particle\"), photon mapping or the AOV integrator: only PT, PTDL and PTMIS are supported"
-                : -9 == rc ? "a material in use asks for a texture feature that is not supported (procedural textures, image files, "
-                             "IES profiles, Triplanar emission maps)"
-                           : "scene uses a feature outside the hot-path scope (scattering volumes, Portal lights, emission maps on meshes ...)");
+        logCompileError(rc);
         return -1;
     }
     for (const std::string& w : c.engine.warnings()) logf(1, "%s", w.c_str());
@@ -107,9 +113,10 @@ int32_t su_release(void) {
     return 0;
 }
 
-int32_t su_mount(const char* folder) {
-    (void)folder;  // file system mounts only matter to file-backed resources
-    return g ? 0 : -1;
+int32_t su_mount(const char* folder) {  // capi.zig: resources.fs.pushMount: where file-backed textures are looked for
+    if (!g || !folder) return -1;
+    g->engine.mounts.push_back(folder);
+    return 0;
 }
 
 int32_t su_perspective_camera_create(uint32_t width, uint32_t height) {
@@ -411,7 +418,11 @@ int32_t su_ext_set_device(int32_t device_id) {
 
 int32_t su_ext_compile(uint32_t frame) {
     if (!g) return -1;
-    if (0 != g->engine.compile(frame)) return -1;
+    const int rc = g->engine.compile(frame);
+    if (0 != rc) {
+        logCompileError(rc);
+        return -1;
+    }
     for (const std::string& w : g->engine.warnings()) logf(1, "%s", w.c_str());
     return 0;
 }

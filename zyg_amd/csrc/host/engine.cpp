@@ -1,8 +1,11 @@
 #include "engine.hpp"
 
 #include "ggx_lut.hpp"
+#include "image_readers.hpp"
 
 #include <algorithm>
+#include <fstream>
+#include <sstream>
 
 namespace zyg {
 
@@ -25,8 +28,13 @@ static Vec4f readColor(const JsonValue& v) {
 
 // material_provider.zig:438-632 (TextureDescriptor) + 634-678 (readTextureSampler), image ids only: {"usage": "Color", "id": n,
 // "sampler": {"filter": "Nearest" | "Linear", "address": "Clamp" | "Repeat" | [u, v]}, "scale": s | [sx, sy]}
-static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler, float scale[2]);
-static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) { return readImageTexture(v, m.color_image, m.color_sampler, m.color_scale); }
+enum TexUsage : uint32_t { kUsageColor = 0, kUsageEmission = 1, kUsageNormal = 2, kUsageOpacity = 3, kUsageWeight = 4 };
+static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler, float scale[2], uint32_t usage);
+static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) {
+    return readImageTexture(v, m.color_image, m.color_sampler, m.color_scale, kUsageColor);
+}
+// the engine whose material is being parsed (its mounts and image cache serve the "file" textures)
+static thread_local Engine* t_engine = nullptr;
 
 // Set while a material is parsed when its JSON asks for a texture feature that is not built (procedural textures, image
 // files, swizzles, inversion, Triplanar / ObjectPos coordinates): the material gets ZYGPU_MATF_UNSUPPORTED and a scene that
@@ -34,23 +42,32 @@ static bool readColorTexture(const JsonValue& v, ZygpuMaterial& m) { return read
 static thread_local bool t_unsupported_texture = false;
 
 // material_provider.zig:438-632: {"usage": .., "id": n, "sampler": {"filter", "address"}, "scale"}
-static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler_out, float scale_out[2]) {
+static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler_out, float scale_out[2], uint32_t usage) {
     if (JsonValue::Object != v.type) return false;
     const JsonValue* id = v.get("id");
+    const JsonValue* file = v.get("file");
     for (const auto& kv : v.obj) {
         const std::string& k = kv.first;
         // "swizzle" and "invert" are options of the image-file loader: with an image id the reference ignores them, too
         // (createTexture, material_provider.zig:700-736)
-        if (k == "id" || k == "usage" || k == "scale" || k == "swizzle" || k == "invert") continue;
+        if (k == "id" || k == "file" || k == "usage" || k == "scale" || k == "swizzle" || k == "invert") continue;
         if (k == "sampler") continue;
-        t_unsupported_texture = true;  // "file" (it wins over "id"), ChannelMix, Checker, DetailNormal, Max, Mix, Mul, Noise ...
+        t_unsupported_texture = true;  // ChannelMix, Checker, DetailNormal, Max, Mix, Mul, Noise ...
     }
-    if (!id) {
+    struct { uint32_t color_image, color_sampler; float color_scale[2]; } m;
+    if (file && JsonValue::String == file->type && t_engine) {  // "file" wins over "id" (createTexture, material_provider.zig:715-733)
+        const JsonValue* sw = v.get("swizzle");
+        m.color_image = t_engine->loadImageFile(file->str, usage, sw && JsonValue::String == sw->type ? sw->str : std::string(), v.memberBool("invert", false));
+        if (ZYGPU_NULL == m.color_image) {  // the reference logs and takes a uniform default; here the scene does not compile
+            t_unsupported_texture = true;
+            return false;
+        }
+    } else if (id) {
+        m.color_image = uint32_t(id->f32(0.f));
+    } else {
         t_unsupported_texture = true;
         return false;
     }
-    struct { uint32_t color_image, color_sampler; float color_scale[2]; } m;
-    m.color_image = uint32_t(id->f32(0.f));
     m.color_sampler = ZYGPU_TEX_LINEAR | ZYGPU_TEX_REPEAT_U | ZYGPU_TEX_REPEAT_V;  // texture.zig:22-27 DefaultMode
     m.color_scale[0] = m.color_scale[1] = 1.f;
     auto address = [](const JsonValue& a) { return JsonValue::String == a.type && a.str == "Clamp" ? 0u : 1u; };
@@ -232,9 +249,71 @@ static Vec4f conductorColor(const std::string& name) {
 // material_provider.zig:131-162, 262-342, 411-436 (uniform values only; image textures are SURVEY §8(f))
 // init = false: su_material_update (material_provider.zig:108-125: the same update* function a new material goes through, on top
 // of the material as it is)
+std::string Engine::resolveFile(const std::string& name) const {  // file/system.zig:73-120: the newest mount first, then the name as it is
+    if (!name.empty() && '/' == name[0]) return name;
+    for (auto it = mounts.rbegin(); it != mounts.rend(); ++it) {
+        const std::string p = it->empty() ? name : *it + "/" + name;
+        if (std::ifstream(p)) return p;
+    }
+    return name;
+}
+
+uint32_t Engine::loadImageFile(const std::string& name, uint32_t usage, const std::string& swizzle_in, bool invert) {
+    // texture_provider.zig:42-51: the usage's default swizzle
+    static const char* const kDefault[5] = {"XYZ", "XYZ", "XY", "W", "X"};
+    const std::string swizzle = swizzle_in.empty() ? std::string(kDefault[std::min<uint32_t>(usage, 4u)]) : swizzle_in;
+    const std::string path = resolveFile(name);
+    const std::string key = path + "|" + swizzle + (invert ? "|i" : "|");
+    const auto        cached = image_files_.find(key);
+    if (image_files_.end() != cached) return cached->second;
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return file_error = "cannot read the image \"" + name + "\"", ZYGPU_NULL;
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    const std::string data = ss.str();
+    uint32_t          image = ZYGPU_NULL;
+    int               w = 0, h = 0, channels = 0;
+    std::string       error;
+    if (data.size() >= 8 && 0 == std::memcmp(data.data(), "\x89PNG", 4)) {
+        std::vector<uint8_t> px;
+        if (!imgr::readPng(data, w, h, channels, px, error)) return file_error = "\"" + name + "\": " + error, ZYGPU_NULL;
+        // Info.allocateImage / fillImage (png_reader.zig:145-331): as many channels as the swizzle names, at most the file's
+        const uint32_t wanted = uint32_t(swizzle.size());
+        if (wanted > 3 && channels > 3) return file_error = "\"" + name + "\": four-channel images (usage ColorAndOpacity) are not provided", ZYGPU_NULL;
+        const uint32_t       out_channels = std::min<uint32_t>(std::min<uint32_t>(wanted, 3u), uint32_t(channels));
+        std::vector<uint8_t> out(size_t(w) * size_t(h) * out_channels);
+        for (size_t i = 0, n = size_t(w) * size_t(h); i < n; ++i) {
+            const uint8_t* in = px.data() + i * size_t(channels);
+            if (1 == out_channels) {
+                uint32_t c = swizzle == "Y" ? 1u : swizzle == "Z" ? 2u : swizzle == "W" ? 3u : 0u;
+                if (c >= uint32_t(channels)) c = 0;
+                out[i] = invert ? uint8_t(255 - in[c]) : in[c];
+            } else if (2 == out_channels) {
+                const bool yx = swizzle == "YX", yz = swizzle == "YZ" && channels >= 3;
+                out[2 * i] = in[(yx || yz) ? 1 : 0];
+                out[2 * i + 1] = in[yx ? 0 : yz ? 2 : 1];
+            } else {
+                out[3 * i] = in[0], out[3 * i + 1] = in[1], out[3 * i + 2] = in[2];
+            }
+        }
+        image = createImage(ZYGPU_NULL, 0, out_channels, uint32_t(w), uint32_t(h), 1, out_channels, out.data());
+    } else if (data.size() >= 2 && 0 == data.compare(0, 2, "#?")) {
+        std::vector<float> rgb;
+        if (!imgr::readRgbe(data, w, h, rgb, error)) return file_error = "\"" + name + "\": " + error, ZYGPU_NULL;
+        image = createImage(ZYGPU_NULL, 4, 3, uint32_t(w), uint32_t(h), 1, 12, reinterpret_cast<const uint8_t*>(rgb.data()));
+    } else {
+        return file_error = "\"" + name + "\": an image type this build does not read (PNG and Radiance RGBE are)", ZYGPU_NULL;
+    }
+    if (ZYGPU_NULL == image) return file_error = "\"" + name + "\": the image could not be created", ZYGPU_NULL;
+    image_files_[key] = image;
+    return image;
+}
+
 void Engine::parseMaterial(ZygpuMaterial& m, const JsonValue& v, uint32_t kind, bool init) {
     t_unsupported_texture = false;
+    t_engine = this;
     parseMaterialBody(m, v, kind, init);
+    t_engine = nullptr;
     if (t_unsupported_texture) m.flags |= ZYGPU_MATF_UNSUPPORTED;
 }
 
@@ -268,12 +347,12 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
     auto readWeight = [&](const JsonValue& x, float& uniform, uint32_t slot) {
         ZygpuTexture& t = m.tex[slot];
         t.image = ZYGPU_NULL;
-        if (!readImageTexture(x, t.image, t.sampler, t.scale)) uniform = x.f32(uniform);
+        if (!readImageTexture(x, t.image, t.sampler, t.scale, kUsageWeight)) uniform = x.f32(uniform);
     };
     auto readNormal = [&](const JsonValue& x, uint32_t slot) {  // usage Normal: Byte2 is snorm (texture_provider.zig:70)
         ZygpuTexture& t = m.tex[slot];
         t.image = ZYGPU_NULL;
-        if (readImageTexture(x, t.image, t.sampler, t.scale)) t.sampler |= ZYGPU_TEX_SNORM;
+        if (readImageTexture(x, t.image, t.sampler, t.scale, kUsageNormal)) t.sampler |= ZYGPU_TEX_SNORM;
     };
 
     auto loadEmittance = [&](const JsonValue& e) {
@@ -291,7 +370,7 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
         m.camera_weight = e.memberF32("camera_weight", 1.f);
         m.emission_num_samples = std::min<uint32_t>(e.memberU32("num_samples", 1), 64u);
         if (const JsonValue* em = e.get("emission_map")) {
-            readImageTexture(*em, m.emission_image, m.emission_sampler, m.emission_scale);
+            readImageTexture(*em, m.emission_image, m.emission_sampler, m.emission_scale, kUsageEmission);
             // light samples carry no position for a Triplanar lookup (light.zig:119-132 leaves rs.p unset): uv only
             if (m.emission_sampler & ZYGPU_TEX_TRIPLANAR) t_unsupported_texture = true;
             m.emission_sampler &= ~uint32_t(ZYGPU_TEX_OBJECTPOS);
@@ -303,7 +382,7 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
     // material_provider.zig:177-178, 244-245, 265-266: Glass, Light and Substitute read "mask" (usage Opacity)
     if (ZYGPU_MAT_DEBUG != kind)
         if (const JsonValue* mask = v.get("mask")) {
-            readImageTexture(*mask, m.mask_image, m.mask_sampler, m.mask_scale);
+            readImageTexture(*mask, m.mask_image, m.mask_sampler, m.mask_scale, kUsageOpacity);
             m.mask_sampler &= ~uint32_t(ZYGPU_TEX_TRIPLANAR | ZYGPU_TEX_OBJECTPOS);  // Base.opacity takes the uv (material_base.zig:35-41)
         }
 

@@ -12,6 +12,7 @@
 
 #include <deque>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../../include/zygpu.h"
@@ -105,6 +106,14 @@ class Engine {
 
     // --- resources ---
     // capi.zig:236-298: UInt8 x 3 (read as sRGB) and Float32 x 3, depth 1; returns the image id or ZYGPU_NULL
+    // File-backed textures (material_provider.zig:438-740 "file", texture_provider.zig:27-65, image_provider.zig:27-69): a PNG or
+    // Radiance picture found through the mounts (su_mount; the loaders push the directory of the file they are reading), decoded
+    // on the host and kept like an image handed over with su_image_create.  usage: 0 Color, 1 Emission, 2 Normal, 3 Opacity,
+    // 4 Weight (its default swizzle); swizzle: "" or X Y Z W XY YX YZ XYZ.  ZYGPU_NULL and a message in file_error on failure.
+    std::vector<std::string> mounts;
+    std::string              file_error;
+    std::string resolveFile(const std::string& name) const;
+    uint32_t    loadImageFile(const std::string& name, uint32_t usage, const std::string& swizzle, bool invert);
     uint32_t createImage(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height, uint32_t depth,
                          uint32_t pixel_stride, const uint8_t* data);
     uint32_t createMaterial(uint32_t id, const JsonValue& v);  // returns id or ZYGPU_NULL
@@ -256,6 +265,7 @@ class Engine {
         std::vector<Transformation> frames;  // simulate(): the node's world transformation at the frame's ticks
     };
     std::vector<HostAnimation> animations_;
+    std::map<std::string, uint32_t> image_files_;  // path | swizzle | invert -> image
     std::vector<GraphNode>     graph_nodes_;
     struct HostPortalLight {
         std::vector<float> sat, func;

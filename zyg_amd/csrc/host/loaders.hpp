@@ -34,6 +34,7 @@ class TakeLoader {
         JsonValue root;
         if (!readJson(path, root) || JsonValue::Object != root.type) return fail("cannot read take \"" + path + "\"");
         take_dir_ = parentDirectory(path);
+        engine_.mounts.push_back(take_dir_);  // (file-backed textures: the take's directory, then the scene file's, newest first)
         const JsonValue* scene = root.get("scene");
         if (!scene || JsonValue::String != scene->type || scene->str.empty()) return fail("the take names no scene");
 
@@ -262,6 +263,11 @@ class TakeLoader {
         JsonValue         root;
         if (!readJson(path, root) || JsonValue::Object != root.type) return fail("cannot read scene \"" + path + "\"");
         const std::string                       here = parentDirectory(path);
+        struct Mount {  // scene_loader.zig:167-168: fs.pushMount(parentDirectory) ... defer popMount
+            Engine& e;
+            Mount(Engine& e_, const std::string& d) : e(e_) { e.mounts.push_back(d); }
+            ~Mount() { e.mounts.pop_back(); }
+        } mount(engine_, here);
         if (isGltf(root)) return loadGltf(root, here, parent);  // scene_loader.zig:170-174: a glTF 2 document is tried first
         std::map<std::string, const JsonValue*> local_materials;
         if (const JsonValue* ms = root.get("materials"))
@@ -525,8 +531,13 @@ class TakeLoader {
         if (local_materials.end() != local) {
             id = engine_.createMaterial(ZYGPU_NULL, *local->second);
         } else {
-            JsonValue file;
-            if (readJson(resolve(name, dir), file)) id = engine_.createMaterial(ZYGPU_NULL, file);
+            JsonValue         file;
+            const std::string path = resolve(name, dir);
+            if (readJson(path, file)) {
+                engine_.mounts.push_back(parentDirectory(path));
+                id = engine_.createMaterial(ZYGPU_NULL, file);
+                engine_.mounts.pop_back();
+            }
         }
         if (ZYGPU_NULL == id) id = engine_.fallbackMaterial();
         materials_by_name_[name] = id;
@@ -556,8 +567,8 @@ class TakeLoader {
     // normals mirrored in z and the triangles' winding turned (right-handed -> left-handed); accessors / bufferViews / buffers with
     // external .bin files, UInt16 / UInt32 indices, strided vertex attributes; materials: pbrMetallicRoughness -> Substitute (base
     // colour, roughness, metallic, emissiveFactor, KHR_materials_ior / _clearcoat; _transmission / _volume set an attenuation
-    // distance, which makes the Substitute a scattering volume: refused at compile like every other).  Image textures are
-    // refused by name (this build reads no image files).
+    // distance, which makes the Substitute a scattering volume: refused at compile like every other); base colour and normal
+    // textures as "file" descriptors (PNG; engine.cpp loadImageFile); metallicRoughness / emissive / clearcoat textures refused by name.
     static bool isGltf(const JsonValue& root) {
         const JsonValue* asset = root.get("asset");
         if (!asset || JsonValue::Object != asset->type) return false;
@@ -618,9 +629,11 @@ class TakeLoader {
         for (uint32_t i = 0; i < a.count; ++i) std::memcpy(out.data() + first + size_t(i) * elements, data->data() + begin + stride * i, element_bytes);
         return true;
     }
+    const JsonValue* gltf_root_ = nullptr;
     bool loadGltf(const JsonValue& root, const std::string& dir, const Transformation& parent) {
         Gltf g;
         g.dir = dir;
+        gltf_root_ = &root;
         auto each = [&](const char* key, auto&& f) {
             if (const JsonValue* a = root.get(key))
                 if (JsonValue::Array == a->type)
@@ -718,10 +731,34 @@ class TakeLoader {
     uint32_t gltfMaterial(const JsonValue& value, float global_scale, bool& ok) {
         const JsonValue* pbr = value.get("pbrMetallicRoughness");
         if (!pbr || JsonValue::Object != pbr->type) return ZYGPU_NULL;  // (the prop's fallback material)
-        for (const char* texture : {"normalTexture", "emissiveTexture"})
-            if (value.get(texture)) return ok = unsupported(std::string("a glTF material with an image texture (") + texture + ")"), ZYGPU_NULL;
-        for (const char* texture : {"baseColorTexture", "metallicRoughnessTexture"})
-            if (pbr->get(texture)) return ok = unsupported(std::string("a glTF material with an image texture (") + texture + ")"), ZYGPU_NULL;
+        // loadTextureDescriptor (gltf_loader.zig:510-535): textures[index].source -> images[].uri, KHR_texture_transform's scale
+        auto texture = [&](const JsonValue& t, JsonValue& out) {
+            const uint32_t   index = t.memberU32("index", ZYGPU_NULL);
+            const JsonValue *textures = gltf_root_->get("textures"), *images = gltf_root_->get("images");
+            if (ZYGPU_NULL == index || !textures || JsonValue::Array != textures->type || index >= textures->arr.size()) return false;
+            const uint32_t source = textures->arr[index].memberU32("source", ZYGPU_NULL);
+            std::string    uri;
+            if (images && JsonValue::Array == images->type && source < images->arr.size())
+                if (const JsonValue* u = images->arr[source].get("uri"))
+                    if (JsonValue::String == u->type) uri = u->str;
+            out = jobj();
+            JsonValue name;
+            name.type = JsonValue::String;
+            name.str = uri;
+            out.obj.emplace_back("file", name);
+            JsonValue scale;
+            scale.type = JsonValue::Array;
+            scale.arr = {jnum(1.0), jnum(1.0)};
+            if (const JsonValue* ext = t.get("extensions"))
+                if (const JsonValue* tt = ext->get("KHR_texture_transform"))
+                    if (const JsonValue* sc = tt->get("scale"))
+                        if (JsonValue::Array == sc->type && sc->arr.size() >= 2) scale.arr = {jnum(sc->arr[0].num), jnum(sc->arr[1].num)};
+            out.obj.emplace_back("scale", scale);
+            return true;
+        };
+        // "surface" (metallicRoughnessTexture: roughness and metallic from one image's Y and Z) is not a key this build's Substitute reads
+        if (pbr->get("metallicRoughnessTexture")) return ok = unsupported("a glTF material with a metallicRoughnessTexture"), ZYGPU_NULL;
+        if (value.get("emissiveTexture")) return ok = unsupported("a glTF material with an emissiveTexture"), ZYGPU_NULL;
         float ior = 1.5f, attenuation_distance = 0.f, coat_roughness = 0.f;
         Vec4f attenuation_color = splat(0.f);
         bool  volume = false, coat = false;
@@ -742,8 +779,10 @@ class TakeLoader {
                         coat_roughness = e.second.memberF32("roughnessFactor", 0.f);
                     }
                 }
-        JsonValue sub = jobj();
-        sub.obj.emplace_back("color", jarr3(pbr->get("baseColorFactor") ? readVec3(*pbr->get("baseColorFactor"), splat(0.7f)) : splat(0.7f)));
+        JsonValue sub = jobj(), tex;
+        if (pbr->get("baseColorTexture") && texture(*pbr->get("baseColorTexture"), tex)) sub.obj.emplace_back("color", tex);
+        else sub.obj.emplace_back("color", jarr3(pbr->get("baseColorFactor") ? readVec3(*pbr->get("baseColorFactor"), splat(0.7f)) : splat(0.7f)));
+        if (value.get("normalTexture") && texture(*value.get("normalTexture"), tex)) sub.obj.emplace_back("normal", tex);
         sub.obj.emplace_back("roughness", jnum(pbr->memberF32("roughnessFactor", 0.7f)));
         sub.obj.emplace_back("metallic", jnum(pbr->memberF32("metallicFactor", 1.f)));
         const Vec4f emissive = value.get("emissiveFactor") ? readVec3(*value.get("emissiveFactor"), splat(0.f)) : splat(0.f);
