@@ -680,3 +680,81 @@ def test_file_textures(product_lib, tmp_path):
             assert e.lib.su_ext_compile(0) != 0
         finally:
             e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
+
+
+def _exr(path, planes, half, data_window=None, display=None):
+    """A ZIP-compressed scan-line OpenEXR file: planes = {channel name: (H, W) float array}; written in alphabetical channel order,
+    16-line blocks with the predictor (interleave the halves of the byte stream, delta-code), a block that does not shrink stored raw."""
+    import struct
+    import zlib
+    names = sorted(planes)
+    h, w = planes[names[0]].shape
+    dw = data_window or (0, 0, w - 1, h - 1)
+    disp = display or dw
+    dtype = np.float16 if half else np.float32
+    header = b"\x76\x2f\x31\x01" + struct.pack("<I", 2)
+
+    def attribute(name, kind, body):
+        return name.encode() + b"\0" + kind.encode() + b"\0" + struct.pack("<I", len(body)) + body
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<IBBBBII", 1 if half else 2, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    header += attribute("channels", "chlist", chlist) + attribute("compression", "compression", bytes([3]))
+    header += attribute("dataWindow", "box2i", struct.pack("<4i", *dw)) + attribute("displayWindow", "box2i", struct.pack("<4i", *disp))
+    header += attribute("lineOrder", "lineOrder", bytes([0])) + attribute("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    header += attribute("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attribute("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    blocks = []
+    for y0 in range(0, h, 16):
+        rows = min(16, h - y0)
+        raw = b"".join(planes[n][y].astype(dtype).tobytes() for y in range(y0, y0 + rows) for n in names)
+        a = np.frombuffer(raw, dtype=np.uint8)
+        split = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+        delta = np.concatenate([split[:1], (split[1:] - split[:-1] + 128 + 256) & 255]).astype(np.uint8).tobytes()
+        packed = zlib.compress(delta, 6)
+        body = packed if len(packed) < 16 * w * len(names) * (2 if half else 4) else raw
+        blocks.append(struct.pack("<iI", dw[1] + y0, len(body)) + body)
+    offset, table = len(header) + 8 * len(blocks), b""
+    for b in blocks:
+        table += struct.pack("<Q", offset)
+        offset += len(b)
+    with open(path, "wb") as f:
+        f.write(header + table + b"".join(blocks))
+
+
+def test_exr_file_textures(product_lib, tmp_path):
+    """OpenEXR textures as exr_reader.zig reads them: ZIP-compressed scan-line files, all channels half or all float, the channels in
+    alphabetical order (R last); a colour usage converts sRGB -> AP1 (a half image keeps f16 values); a Weight usage takes R; a data
+    window inside a larger display window lands at its place; other compressions are refused by name."""
+    rng = np.random.default_rng(11)
+    h, w = 20, 12  # two scan-line blocks
+    rgb = {c: rng.random((h, w)).astype(np.float32) * 4.0 for c in "RGB"}
+    _exr(tmp_path / "env_half.exr", rgb, half=True)
+    _exr(tmp_path / "weights.exr", {"B": rgb["B"], "G": rgb["G"], "R": rgb["R"]}, half=False)
+    _exr(tmp_path / "inset.exr", {"R": rgb["R"][:4, :6]}, half=False, data_window=(2, 0, 7, 3), display=(0, 0, 9, 3))
+    materials = [{"name": "lamp", "rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "emission_map": {"file": "env_half.exr"}}}}},
+                 {"name": "rough", "rendering": {"Substitute": {"color": [0.5, 0.5, 0.5], "roughness": {"file": "weights.exr"},
+                                                                "metallic": {"file": "inset.exr"}}}}]
+    scene = {"materials": materials,
+             "entities": [{"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"], "transformation": {"position": [0, 3, 0]}},
+                          {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["rough"]}]}
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(_write_take(tmp_path, scene, "exr")) == 0
+        assert e.lib.su_ext_compile(0) == 0
+        sd = e.lib.su_ext_scene_desc().contents
+        got = [_image_bytes(sd, i) for i in range(sd.num_images)]
+    colour = [np.frombuffer(b, dtype=np.float32).reshape(hh, ww, 3) for f, ww, hh, b in got if 1 == f]
+    assert 1 == len(colour)
+    m = np.array([[0.61309732, 0.33952285, 0.04737928], [0.07019422, 0.91635557, 0.01345259], [0.02061560, 0.10956983, 0.86981512]], dtype=np.float32)
+    srgb = np.stack([rgb[c].astype(np.float16).astype(np.float32) for c in "RGB"], axis=-1)
+    np.testing.assert_allclose(colour[0], (srgb.reshape(-1, 3) @ m.T).astype(np.float16).astype(np.float32).reshape(h, w, 3), rtol=1e-3)
+    singles = {(ww, hh): np.frombuffer(b, dtype=np.float32).reshape(hh, ww) for f, ww, hh, b in got if 3 == f}
+    assert np.array_equal(singles[w, h], rgb["R"])
+    inset = np.zeros((4, 10), dtype=np.float32)
+    inset[:, 2:8] = rgb["R"][:4, :6]
+    assert np.array_equal(singles[10, 4], inset)
+    # an uncompressed file: the reference reads ZIP only, and so does this
+    data = bytearray(open(tmp_path / "weights.exr", "rb").read())
+    at = data.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    data[at] = 0
+    open(tmp_path / "weights.exr", "wb").write(bytes(data))
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(_write_take(tmp_path, scene, "exr")) == 0
+        assert e.lib.su_ext_compile(0) != 0

@@ -301,8 +301,14 @@ uint32_t Engine::loadImageFile(const std::string& name, uint32_t usage, const st
         std::vector<float> rgb;
         if (!imgr::readRgbe(data, w, h, rgb, error)) return file_error = "\"" + name + "\": " + error, ZYGPU_NULL;
         image = createImage(ZYGPU_NULL, 4, 3, uint32_t(w), uint32_t(h), 1, 12, reinterpret_cast<const uint8_t*>(rgb.data()));
+    } else if (data.size() >= 4 && 0 == std::memcmp(data.data(), "\x76\x2f\x31\x01", 4)) {
+        std::vector<float> values;
+        uint32_t           out_channels = 0;
+        const bool         color = kUsageColor == usage || kUsageEmission == usage;  // texture_provider.zig:37-40
+        if (!imgr::readExr(data, uint32_t(swizzle.size()), color, w, h, out_channels, values, error)) return file_error = "\"" + name + "\": " + error, ZYGPU_NULL;
+        image = createImage(ZYGPU_NULL, 4, out_channels, uint32_t(w), uint32_t(h), 1, 4 * out_channels, reinterpret_cast<const uint8_t*>(values.data()));
     } else {
-        return file_error = "\"" + name + "\": an image type this build does not read (PNG and Radiance RGBE are)", ZYGPU_NULL;
+        return file_error = "\"" + name + "\": an image type this build does not read (PNG, Radiance RGBE and ZIP-compressed OpenEXR are)", ZYGPU_NULL;
     }
     if (ZYGPU_NULL == image) return file_error = "\"" + name + "\": the image could not be created", ZYGPU_NULL;
     image_files_[key] = image;

@@ -4,7 +4,10 @@
 //         zlib stream through libz (the reference links miniz), the five scanline filters (png_reader.zig:336-408)
 //   RGBE  core/image/encoding/rgbe/rgbe_reader.zig: "#?" header, FORMAT=32-bit_rle_rgbe, "-Y h +X w", new-style RLE scanlines or
 //         flat pixels; a pixel is (mantissa + 0.5) * 2^(e - 136) per channel (rgbeToVec4f), sRGB -> AP1, stored as f16
-// EXR and IES files are not read (refused by name where a material asks for them).
+//   EXR   core/image/encoding/exr/exr_reader.zig: scan-line files with ZIP compression (16-line blocks, a block whose size is the
+//         uncompressed one is stored as it is), all channels half or all float, the channels in the file's (alphabetical) order so
+//         that R is the last; a colour usage converts sRGB -> AP1
+// IES files are not read (refused by name where a material asks for them).
 #pragma once
 
 #include <zlib.h>
@@ -163,6 +166,141 @@ inline bool readRgbe(const std::string& file, int& width, int& height, std::vect
                                            scanline[3 * size_t(width) + size_t(x)]};
             store(size_t(y) * size_t(width) + size_t(x), rgbe);
         }
+    }
+    return true;
+}
+
+inline float halfToFloat(uint16_t h) {
+    const uint32_t sign = uint32_t(h & 0x8000u) << 16, exponent = (h >> 10) & 31u, mantissa = h & 1023u;
+    uint32_t       bits;
+    if (0 == exponent) {
+        if (0 == mantissa) {
+            bits = sign;
+        } else {  // subnormal: mantissa * 2^-24
+            const float    v = std::ldexp(float(mantissa), -24);
+            uint32_t       b;
+            std::memcpy(&b, &v, 4);
+            bits = sign | b;
+        }
+    } else if (31 == exponent) {
+        bits = sign | 0x7F800000u | (mantissa << 13);
+    } else {
+        bits = sign | ((exponent + 112u) << 23) | (mantissa << 13);
+    }
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// channels_wanted: 1 or 3 (the swizzle's channel count, at most the file's); out: the display window, rows of width * channels floats
+// (a half file's values as floats; with `color` the f16 rounding of the converted colour, as the reference's Half3 image keeps it)
+inline bool readExr(const std::string& file, uint32_t channels_wanted, bool color, int& width, int& height, uint32_t& channels, std::vector<float>& out,
+                    std::string& error) {
+    static const unsigned char kSignature[4] = {0x76, 0x2f, 0x31, 0x01};
+    if (file.size() < 8 || 0 != std::memcmp(file.data(), kSignature, 4)) return error = "not an OpenEXR file", false;
+    size_t at = 8;  // (the version word is skipped)
+    auto   text = [&](std::string& o) {
+        const size_t end = file.find('\0', at);
+        if (std::string::npos == end) return false;
+        o.assign(file, at, end - at);
+        at = end + 1;
+        return true;
+    };
+    auto read32 = [&](void* o) {
+        if (at + 4 > file.size()) return false;
+        std::memcpy(o, file.data() + at, 4);
+        at += 4;
+        return true;
+    };
+    int32_t               data_window[4] = {0, 0, 0, 0}, display_window[4] = {0, 0, 0, 0};
+    uint8_t               compression = 8;
+    std::vector<uint32_t> formats;  // per channel: 0 uint, 1 half, 2 float
+    for (;;) {
+        std::string name, type;
+        if (!text(name)) return error = "an OpenEXR header without an end", false;
+        if (name.empty()) break;
+        uint32_t size = 0;
+        if (!text(type) || !read32(&size) || at + size > file.size()) return error = "a broken OpenEXR attribute", false;
+        const size_t next = at + size;
+        if ("box2i" == type && 16 == size) {
+            int32_t* w = "dataWindow" == name ? data_window : "displayWindow" == name ? display_window : nullptr;
+            if (w) std::memcpy(w, file.data() + at, 16);
+        } else if ("chlist" == type) {
+            for (;;) {
+                std::string channel;
+                if (!text(channel)) return error = "a broken OpenEXR channel list", false;
+                if (channel.empty()) break;
+                uint32_t format = 0;
+                if (!read32(&format)) return error = "a broken OpenEXR channel list", false;
+                at += 12;  // pLinear, reserved, xSampling, ySampling
+                formats.push_back(format);
+            }
+        } else if ("compression" == type && size >= 1) {
+            compression = uint8_t(file[at]);
+        }
+        at = next;
+    }
+    if (data_window[0] < display_window[0] || data_window[1] < display_window[1] || data_window[2] > display_window[2] || data_window[3] > display_window[3])
+        return error = "an OpenEXR data window that is not inside the display window", false;
+    if (formats.empty()) return error = "an OpenEXR file without channels", false;
+    for (uint32_t f : formats)
+        if (f != formats[0]) return error = "an OpenEXR file with mixed channel formats", false;
+    if (1 != formats[0] && 2 != formats[0]) return error = "an OpenEXR file with integer channels", false;
+    if (3 != compression) return error = "an OpenEXR file that is not ZIP compressed", false;
+    const bool     half = 1 == formats[0];
+    const uint32_t file_channels = uint32_t(formats.size());
+    channels = std::min(channels_wanted, file_channels);
+    if (2 == channels) channels = 1;
+    if (channels > 3) return error = "four-channel OpenEXR images are not provided", false;
+    const uint32_t w = uint32_t(data_window[2] - data_window[0] + 1), h = uint32_t(data_window[3] - data_window[1] + 1);
+    width = display_window[2] - display_window[0] + 1;
+    height = display_window[3] - display_window[1] + 1;
+    const uint32_t bytes_per_pixel = file_channels * (half ? 2u : 4u), bytes_per_row = w * bytes_per_pixel, rows_per_block = 16u;
+    const uint32_t blocks = (h + rows_per_block - 1u) / rows_per_block;
+    at += size_t(blocks) * 8;  // the line offset table
+    out.assign(size_t(width) * size_t(height) * channels, 0.f);
+    std::vector<unsigned char> packed(size_t(bytes_per_row) * rows_per_block), plain(packed.size());
+    const uint32_t r_o = file_channels - 1u, g_o = file_channels >= 2 ? file_channels - 2u : 0u, b_o = file_channels >= 3 ? file_channels - 3u : 0u;
+    for (uint32_t b = 0; b < blocks; ++b) {
+        uint32_t row = 0, size = 0;
+        if (!read32(&row) || !read32(&size) || at + size > file.size() || size > packed.size()) return error = "a broken OpenEXR scan-line block", false;
+        const uint32_t rows_here = std::min<uint32_t>(uint32_t(height) - row, rows_per_block);
+        const size_t   bytes_here = size_t(rows_here) * bytes_per_row;
+        if (size < packed.size()) {
+            uLongf n = uLongf(plain.size());
+            if (Z_OK != uncompress(plain.data(), &n, reinterpret_cast<const Bytef*>(file.data() + at), size)) return error = "an OpenEXR block that does not inflate", false;
+            for (size_t t = 1; t < bytes_here; ++t) plain[t] = static_cast<unsigned char>(plain[t - 1] + plain[t] - 128);  // reconstructScalar
+            size_t t1 = 0, t2 = (bytes_here + 1) / 2;                                                                       // interleaveScalar
+            for (size_t s2 = 0; s2 < bytes_here;) {
+                packed[s2++] = plain[t1++];
+                if (s2 < bytes_here) packed[s2++] = plain[t2++];
+            }
+        } else {
+            std::memcpy(packed.data(), file.data() + at, size);
+        }
+        at += size;
+        auto value = [&](uint32_t y, uint32_t channel, uint32_t x) {
+            const size_t index = size_t(file_channels) * y * w + size_t(channel) * w + x;
+            if (half) {
+                uint16_t v;
+                std::memcpy(&v, packed.data() + 2 * index, 2);
+                return halfToFloat(v);
+            }
+            float v;
+            std::memcpy(&v, packed.data() + 4 * index, 4);
+            return v;
+        };
+        for (uint32_t y = 0; y < rows_here; ++y)
+            for (uint32_t x = 0; x < w; ++x) {
+                const size_t p = (size_t(row + y) * size_t(width) + size_t(data_window[0]) + x) * channels;
+                if (1 == channels) {
+                    out[p] = value(y, r_o, x);
+                } else {
+                    Vec4f c = vec(value(y, r_o, x), value(y, g_o, x), value(y, b_o, x), 0.f);
+                    if (color) c = sRGBtoAP1(c);
+                    for (int k = 0; k < 3; ++k) out[p + size_t(k)] = (half && color) ? halfRounded(c[k]) : c[k];
+                }
+            }
     }
     return true;
 }
