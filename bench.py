@@ -77,6 +77,8 @@ def parse_args():
                     help="zygpu option compact_blocks: with pack_prev, path blocks 128 B apart (only their first line is used) instead of 256")
     ap.add_argument("--regenerate", type=int, default=0, choices=[0, 1],
                     help="zygpu option regenerate: the regenerating kernels (a small pool whose slots are all alive, plain record arrays, no queues)")
+    ap.add_argument("--pair-small", type=int, default=1, choices=[0, 1],
+                    help="zygpu option pair_small: parallelogram halves of a small mesh as one item of the small-triangle table")
     ap.add_argument("--regen-kslots", type=int, default=0, help="zygpu option regen_kslots: slots of that pool in units of 1024 (0 = library default, 2048)")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,6 +131,9 @@ class Measurement:
         build_scene(self.eng, scenes, scene, material, self.w, self.h, frame.world * steps * self.ips,
                     args.box_triangles if main else 12, args.extra_props if main else 0)
         self.eng.start_frame(0)
+        if not args.pair_small:  # read when the scene is uploaded (the context exists from the first frame on): upload again
+            self.eng.set_option("pair_small", 0)
+            self.eng.start_frame(0)
         self.lib, self.ctx = self.eng.lib, self.eng.context()
         if args.batch_mpaths:
             self.eng.set_option("batch_mpaths", args.batch_mpaths)

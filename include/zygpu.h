@@ -528,13 +528,15 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * "pack_prev" (default 1) keeps the previous vertex's origin / geometric normal / roughness in words of the path's first 128 B
  * line that are dead while they are needed instead of in its second line (scenes without Glass and without opacity masks;
  * same film), "compact_blocks" (default 0) then places the paths' blocks 128 B apart instead of 256; "hit_by_queue" (default 1)
- * stores the hit records of the vertices that go on to wf_scatter at their place in the alive queue instead of by path slot. */
+ * stores the hit records of the vertices that go on to wf_scatter at their place in the alive queue instead of by path slot;
+ * "pair_small" (default 1; read by zygpu_upload_scene) lets two triangles of a small mesh that make a parallelogram be tested as
+ * one item by the relaxed-arithmetic kernels. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 
 /* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.
  * mode 0: the reference's walk (top-level tree, BVH2); 1: the prop tables + BVH2; 2: the prop tables + the four-wide BLAS
- * re-layout; 3: the relaxed units' walk (2 without the tie rule between props, small meshes triangle by triangle from the
- * constant block) (modes 1-3 need a scene the tables hold: -1 otherwise).  hits: 8 words per ray (t, u, v as float bits,
+ * re-layout; 3: the relaxed units' walk (2 without the tie rule between props, small meshes item by item from the
+ * constant block, in their unit-triangle form) (modes 1-3 need a scene the tables hold: -1 otherwise).  hits: 8 words per ray (t, u, v as float bits,
  * primitive, prop or ZYGPU_NULL, 3 x 0), the layout of the oracle's zyg_oracle_intersect; visible: 1 = unoccluded. */
 int zygpu_test_intersect(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits);
 int zygpu_test_visibility(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible);

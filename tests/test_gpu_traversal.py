@@ -82,13 +82,34 @@ def test_ray_dump_against_the_oracle(engine, oracle, scene):
         hits, vis = out[mode]
         assert np.array_equal(hits, ref_hits), (mode, int(np.any(hits != ref_hits, axis=1).sum()))
         assert np.array_equal(vis, ref_vis), mode
-    for mode in (2, 3):  # four-wide BLAS / the relaxed units' walk: same boolean, same hit except exact ties between triangles
-        hits, vis = out[mode]
-        assert np.array_equal(vis, ref_vis), mode
-        bad = np.any(hits != ref_hits, axis=1)
-        assert bad.mean() <= 1e-5, (mode, int(bad.sum()))
-        # where it differs the distance is the same: it is the other triangle of a shared edge
-        assert np.array_equal(hits[bad, 0], ref_hits[bad, 0])
+    # four-wide BLAS: same boolean, same hit except exact ties between triangles
+    hits, vis = out[2]
+    assert np.array_equal(vis, ref_vis)
+    bad = np.any(hits != ref_hits, axis=1)
+    assert bad.mean() <= 1e-5, int(bad.sum())
+    # where it differs the distance is the same: it is the other triangle of a shared edge
+    assert np.array_equal(hits[bad, 0], ref_hits[bad, 0])
+    # the relaxed units' walk in this unit's arithmetic: the small meshes are tested in their unit-triangle form (dscene.hpp
+    # smallTriangleIntersect), which rounds differently from the reference's test: bounded like the relaxed units' dump
+    _bounded(out[3], ref_hits, ref_vis, 3)
+
+
+def _bounded(result, ref_hits, ref_vis, mode):
+    hits, vis = result
+    assert (vis != ref_vis).mean() <= 2e-4, (mode, int((vis != ref_vis).sum()))
+    # another primitive or prop: where two surfaces coincide (the Cornell boxes stand on the floor: a ray from inside a box hits
+    # its bottom face and the floor at the same distance) an ulp decides which one is reported; never a hit against a miss,
+    # and the distance is the same
+    other = (hits[:, 3] != ref_hits[:, 3]) | (hits[:, 4] != ref_hits[:, 4])
+    assert other.mean() <= 2e-3, (mode, int(other.sum()))
+    assert np.array_equal(hits[:, 4] == zyg_amd.NULL, ref_hits[:, 4] == zyg_amd.NULL) or \
+        ((hits[:, 4] == zyg_amd.NULL) != (ref_hits[:, 4] == zyg_amd.NULL)).mean() <= 1e-5, mode
+    hit_both = (hits[:, 4] != zyg_amd.NULL) & (ref_hits[:, 4] != zyg_amd.NULL)
+    t, rt = hits[hit_both, 0].view(np.float32), ref_hits[hit_both, 0].view(np.float32)
+    assert np.all(np.abs(t - rt) <= 1e-4 * np.maximum(1.0, np.abs(rt))), mode
+    same = ~other & hit_both
+    uv, ruv = hits[same, 1:3].view(np.float32), ref_hits[same, 1:3].view(np.float32)
+    assert np.all(np.abs(uv - ruv) <= 2e-3)
 
 
 @pytest.mark.parametrize("scene", ["boxes", "mesh", "sphere"])
@@ -112,21 +133,7 @@ def test_relaxed_ray_dump_against_the_oracle(engine, oracle, scene):
         mesh_props = [p for p in range(sd.num_props) if sd.props[p].shape == 7]
         assert np.isin(ref_hits[:, 4], mesh_props).mean() > 0.15  # the sphere hangs in the middle of the box
     for mode in (0, 1, 2, 3):
-        hits, vis = out[mode]
-        assert (vis != ref_vis).mean() <= 2e-4, (mode, int((vis != ref_vis).sum()))
-        # another primitive or prop: where two surfaces coincide (the Cornell boxes stand on the floor: a ray from inside a box hits
-        # its bottom face and the floor at the same distance) an ulp decides which one is reported; never a hit against a miss,
-        # and the distance is the same
-        other = (hits[:, 3] != ref_hits[:, 3]) | (hits[:, 4] != ref_hits[:, 4])
-        assert other.mean() <= 2e-3, (mode, int(other.sum()))
-        assert np.array_equal(hits[:, 4] == zyg_amd.NULL, ref_hits[:, 4] == zyg_amd.NULL) or \
-            ((hits[:, 4] == zyg_amd.NULL) != (ref_hits[:, 4] == zyg_amd.NULL)).mean() <= 1e-5, mode
-        hit_both = (hits[:, 4] != zyg_amd.NULL) & (ref_hits[:, 4] != zyg_amd.NULL)
-        t, rt = hits[hit_both, 0].view(np.float32), ref_hits[hit_both, 0].view(np.float32)
-        assert np.all(np.abs(t - rt) <= 1e-4 * np.maximum(1.0, np.abs(rt))), mode
-        same = ~other & hit_both
-        uv, ruv = hits[same, 1:3].view(np.float32), ref_hits[same, 1:3].view(np.float32)
-        assert np.all(np.abs(uv - ruv) <= 2e-3)
+        _bounded(out[mode], ref_hits, ref_vis, mode)
 
 
 def _film(product_lib, build, w, h, spp, **options):
@@ -209,3 +216,73 @@ def test_mesh_kernels_give_the_film_of_the_in_place_kernel(product_lib, scene):
         close = np.isclose(base, film, rtol=1e-3, atol=1e-4).all(axis=-1)
         assert close.mean() > 0.98, (options, close.mean())
         assert abs(float(film[..., :3].mean()) - float(base[..., :3].mean())) <= 2e-4 * float(base[..., :3].mean())
+
+
+def _patchwork_mesh(seed=5):
+    """A small mesh (27 triangles) that exercises the small-triangle table's items (dscene.hpp SmallItem): ten parallelograms in
+    random planes, split along either diagonal, every triangle's vertex order turned and flipped at random and the triangles
+    shuffled (so that the halves of a pair are apart, in either order, and the pair's frame starts at any corner), five lone
+    triangles, and a quad whose fourth corner is off the parallelogram's (its halves must stay two items)."""
+    rng = np.random.default_rng(seed)
+    pos, tris = [], []
+
+    def corner(p):
+        pos.append(np.asarray(p, dtype=np.float32))
+        return len(pos) - 1
+
+    def triangle(i, j, k):
+        t = [i, j, k]
+        if rng.integers(0, 2):
+            t = [t[0], t[2], t[1]]
+        r = int(rng.integers(0, 3))
+        tris.append(t[r:] + t[:r])
+
+    for q in range(11):
+        a = rng.uniform(-0.6, 0.6, 3) + np.array([0.0, 1.0, 0.0])
+        e1, e2 = rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.5, 0.5, 3)
+        # corners on a 1/64 grid: b + c - a is exact in f32, as it is for a modelling tool's boxes
+        a, e1, e2 = (np.round(x * 64) / 64 for x in (a, e1, e2))
+        d = a + e1 + e2 + (np.array([0.0, 0.125, 0.0]) if 10 == q else 0.0)
+        i, j, k, m = corner(a), corner(a + e1), corner(d), corner(a + e2)
+        if rng.integers(0, 2):
+            triangle(i, j, k), triangle(i, k, m)
+        else:
+            triangle(i, j, m), triangle(j, k, m)
+    for _ in range(5):
+        a = rng.uniform(-0.6, 0.6, 3) + np.array([0.0, 1.0, 0.0])
+        triangle(corner(a), corner(a + rng.uniform(-0.5, 0.5, 3)), corner(a + rng.uniform(-0.5, 0.5, 3)))
+    order = rng.permutation(len(tris))
+    idx = np.asarray([tris[i] for i in order], dtype=np.uint32)
+    pos = np.asarray(pos, dtype=np.float32)
+    nrm = np.tile(np.array([[0, 1, 0]], dtype=np.float32), (pos.shape[0], 1))
+    return idx.ravel(), pos, nrm, np.zeros((pos.shape[0], 2), dtype=np.float32)
+
+
+@pytest.mark.parametrize("precise", [1, 0])
+def test_small_mesh_items_against_the_oracle(engine, oracle, precise):
+    """The relaxed units' test of the small meshes (unit-triangle frames, parallelogram halves as one item: dscene.hpp
+    smallItemIntersect) reports the reference's primitive and barycentric coordinates whichever corner an item's frame starts at;
+    option pair_small = 0 (every triangle its own item) gives the same answers."""
+    n = 1 << 18
+    mesh = _patchwork_mesh()
+    assert mesh[0].size // 3 == 27
+    scenes.cornell(engine, 64, 48, 1, boxes=False, mesh=mesh, mesh_position=(0, 0, 0))
+    engine.start_frame(0)
+    rays = _camera_relative(engine, _rays(n, 23))
+    ref_hits, ref_vis, out = _both(engine, oracle, rays, precise=precise)
+    sd = engine.lib.su_ext_scene_desc().contents
+    mesh_props = [p for p in range(sd.num_props) if sd.props[p].shape == 7]
+    on_mesh = np.isin(ref_hits[:, 4], mesh_props)
+    assert on_mesh.mean() > 0.1 and len(np.unique(ref_hits[on_mesh, 3])) == 27  # every triangle is hit
+    _bounded(out[3], ref_hits, ref_vis, 3)
+    paired = out[3]
+    engine.set_option("pair_small", 0)
+    engine.start_frame(0)  # the table is built when the scene is uploaded
+    _, _, out = _both(engine, oracle, rays, precise=precise)
+    engine.set_option("pair_small", 1)
+    _bounded(out[3], ref_hits, ref_vis, 3)
+    # the same primitive with and without pairs except where an ulp decides, the same barycentrics to float accuracy
+    same = (paired[0][:, 3] == out[3][0][:, 3]) & (paired[0][:, 4] == out[3][0][:, 4])
+    assert same.mean() >= 1 - 1e-4
+    hit = same & (paired[0][:, 4] != zyg_amd.NULL)
+    assert np.all(np.abs(paired[0][hit, 1:3].view(np.float32) - out[3][0][hit, 1:3].view(np.float32)) <= 1e-4)

@@ -81,7 +81,20 @@ static_assert(kDirections.v[0][1] == 0xc0000000u && kDirections.v[1][4] == 0xe80
 // The 32-step XOR of sobol.zig:176-192 folded per index byte: c_sobol_lut[k * 256 + b] holds, for dimensions 2..5, the XOR of
 // the direction words 8k..8k+7 selected by the bits of b (16 KB, L1-resident; filled once by sobol_lut_init).  Four 16 B
 // loads and twelve XORs replace ~290 VALU instructions per refill; XOR is exact, so the result is the same word for word.
-static __constant__ const uint4* c_sobol_lut;  // per translation unit, like c_view / c_scene (wavefront.hpp)
+// The __constant__ blocks (this one, c_view / c_scene in wavefront.hpp): one copy per translation unit (kernel_table.hpp), so each
+// carries its unit in its name; external linkage with protected visibility, so that the runtime finds the symbol
+// (hipMemcpyToSymbol) and the kernels address it pc-relative: as `static` variables every read went through a
+// global-offset-table entry first, a dependent scalar load (in the small-mesh loop: one per item).
+#define ZYG_BLOCK_CAT2(a, b) a##b
+#define ZYG_BLOCK_CAT(a, b) ZYG_BLOCK_CAT2(a, b)
+#ifdef ZYG_TU
+#define ZYG_BLOCK_NAME(name) ZYG_BLOCK_CAT(name##_u, ZYG_TU)
+#else
+#define ZYG_BLOCK_NAME(name) name##_main
+#endif
+#define ZYG_CONSTANT_BLOCK __constant__ __attribute__((visibility("protected")))
+#define c_sobol_lut ZYG_BLOCK_NAME(c_sobol_lut)
+ZYG_CONSTANT_BLOCK const uint4* c_sobol_lut;  // per translation unit, like c_view / c_scene (wavefront.hpp)
 
 static __global__ void sobol_lut_init(uint4* lut) {  // <<<4, 256>>>
     const uint32_t k = blockIdx.x, b = threadIdx.x;

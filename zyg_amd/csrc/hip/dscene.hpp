@@ -84,7 +84,7 @@ struct TlasEntry {
     float4   bmin, bmax;        // world bounds (s.aabbs)
     float4   r0, r1, r2, pos;   // transformation (s.trafos)
     uint32_t shape, flags, prop, mesh;
-    uint32_t small_first, small_count, pad0, pad1;  // a mesh of a few triangles: its range in DScene::small_tris (count 0: none)
+    uint32_t small_first, small_count, pad0, pad1;  // a mesh of a few triangles: its items in DScene::small_tris (count 0: none)
 };
 // The triangles of the scene's smallest meshes (at most kSmallMeshTriangles each, kSmallTriangles in all), in the constant
 // block beside the prop tables: the relaxed-arithmetic units test all of them, every lane of the wave the same triangle at the
@@ -102,11 +102,22 @@ struct TlasEntry {
 #define ZYG_SMALL_MESH_TRIANGLES 32
 #endif
 constexpr uint32_t kSmallTriangles = ZYG_SMALL_TRIANGLES, kSmallMeshTriangles = ZYG_SMALL_MESH_TRIANGLES;
+// An item of the table is four float4: 1 (default): the rows of the affine map that takes a triangle to the unit triangle
+// (a -> 0, b -> x, c -> y, a + e1 x e2 -> z), worked out in f64 at upload: a test is a transformed origin and direction instead of
+// the two cross products and four dot products of Moeller-Trumbore (smallItemIntersect; only the relaxed units read the table,
+// whose contract is the RMS bound, not the reference's rounding); 0: a, b, c and the reference's test.  The fourth holds, as
+// bits, x: the triangle's index in its mesh | the frame's weight (0: 1-u-v, 1: u, 2: v) that is the weight of its vertex 1 << 8 |
+// that of its vertex 2 << 10 (the frame may start at any of its corners); y: the same for the triangle that completes a
+// parallelogram with it (the unit square's other half; weights 0: u+v-1, 1: 1-v, 2: 1-u), or kNull (option pair_small).
+#ifndef ZYG_SMALL_UNIT
+#define ZYG_SMALL_UNIT 1
+#endif
+constexpr uint32_t kSmallItemWords = 4;
 
 struct DScene {
     TlasEntry            solid_table[kUniformProps];  // cheap shapes first; num_solid_table = 0: not available
     TlasEntry            unocc_table[4];              // the unoccluding tree's single leaf, in leaf order; 0: not available
-    float4               small_tris[3 * kSmallTriangles];  // a, b, c per triangle, mesh (= leaf) order
+    float4               small_tris[kSmallItemWords * kSmallTriangles];  // items of one or two triangles, mesh (= leaf) order
     uint32_t             num_solid_table, num_unocc_table;
     uint32_t             first_large;  // solid_table[first_large ..]: the meshes of kMeshKernelMinTriangles triangles or more (they come last)
     const ZygpuProp*     props;
@@ -408,6 +419,84 @@ ZD bool triangleIntersect(const Ray& ray, f3 a, f3 b, f3 c, float& ht, float& hu
 }
 
 ZD f3 xyz(float4 v) { return {v.x, v.y, v.z}; }
+
+// An item of DScene::small_tris against a ray in the mesh's space: rows r0, r1, r2 take a point to the first triangle's own frame
+// (u, v, height over its plane).  The acceptance rule of triangleIntersect, for the unit square's other half too when the item
+// holds a second triangle; ht / hu / hv / primitive as the reference reports them for the triangle that is hit.
+struct SmallItem {
+    float4 r0, r1, r2, names;
+};
+ZD float smallReciprocal(float x) {
+#if ZYG_FAST
+    return __builtin_amdgcn_rcpf(x);  // one instruction, 1 ulp; the divide's range scaling is of no use to a test that compares
+#else
+    return 1.f / x;
+#endif
+}
+ZD bool smallItemIntersect(const Ray& ray, const SmallItem& item, float& ht, float& hu, float& hv, uint32_t& primitive) {
+    const float4   r0 = item.r0, r1 = item.r1, r2 = item.r2;
+    const uint32_t first = __float_as_uint(item.names.x), second = __float_as_uint(item.names.y);
+#if ZYG_SMALL_UNIT
+    const float oz = fmaf(r2.x, ray.origin.x, fmaf(r2.y, ray.origin.y, fmaf(r2.z, ray.origin.z, r2.w)));
+    const float dz = fmaf(r2.x, ray.direction.x, fmaf(r2.y, ray.direction.y, r2.z * ray.direction.z));
+    const float hit_t = -oz * smallReciprocal(dz);
+    const float ox = fmaf(r0.x, ray.origin.x, fmaf(r0.y, ray.origin.y, fmaf(r0.z, ray.origin.z, r0.w)));
+    const float dx = fmaf(r0.x, ray.direction.x, fmaf(r0.y, ray.direction.y, r0.z * ray.direction.z));
+    const float oy = fmaf(r1.x, ray.origin.x, fmaf(r1.y, ray.origin.y, fmaf(r1.z, ray.origin.z, r1.w)));
+    const float dy = fmaf(r1.x, ray.direction.x, fmaf(r1.y, ray.direction.y, r1.z * ray.direction.z));
+    const float u = fmaf(hit_t, dx, ox), v = fmaf(hit_t, dy, oy);
+    const float uv = u + v;
+    if (!(u >= 0.f && v >= 0.f && hit_t >= ray.min_t && ray.max_t >= hit_t)) return false;
+    const bool lower = 1.f >= uv;
+    if (!lower && (kNull == second || !(1.f >= u && 1.f >= v))) return false;
+    const uint32_t which = lower ? first : second;
+    const float    w0 = lower ? 1.f - uv : uv - 1.f, w1 = lower ? u : 1.f - v, w2 = lower ? v : 1.f - u;
+    const uint32_t su = (which >> 8) & 3u, sv = (which >> 10) & 3u;
+    ht = hit_t;
+    hu = 0 == su ? w0 : 1 == su ? w1 : w2;
+    hv = 0 == sv ? w0 : 1 == sv ? w1 : w2;
+    primitive = which & 0xffu;
+    return true;
+#else
+    primitive = first & 0xffu;
+    return triangleIntersect(ray, xyz(r0), xyz(r1), xyz(r2), ht, hu, hv);
+#endif
+}
+
+// the same for a shadow ray: whether the item blocks it
+ZD bool smallItemBlocks(const Ray& ray, const SmallItem& item) {
+#if ZYG_SMALL_UNIT
+    const float4   r0 = item.r0, r1 = item.r1, r2 = item.r2;
+    const uint32_t second = __float_as_uint(item.names.y);
+    const float oz = fmaf(r2.x, ray.origin.x, fmaf(r2.y, ray.origin.y, fmaf(r2.z, ray.origin.z, r2.w)));
+    const float dz = fmaf(r2.x, ray.direction.x, fmaf(r2.y, ray.direction.y, r2.z * ray.direction.z));
+    const float hit_t = -oz * smallReciprocal(dz);
+    const float ox = fmaf(r0.x, ray.origin.x, fmaf(r0.y, ray.origin.y, fmaf(r0.z, ray.origin.z, r0.w)));
+    const float dx = fmaf(r0.x, ray.direction.x, fmaf(r0.y, ray.direction.y, r0.z * ray.direction.z));
+    const float oy = fmaf(r1.x, ray.origin.x, fmaf(r1.y, ray.origin.y, fmaf(r1.z, ray.origin.z, r1.w)));
+    const float dy = fmaf(r1.x, ray.direction.x, fmaf(r1.y, ray.direction.y, r1.z * ray.direction.z));
+    const float u = fmaf(hit_t, dx, ox), v = fmaf(hit_t, dy, oy);
+    return u >= 0.f && v >= 0.f && hit_t >= ray.min_t && ray.max_t >= hit_t && (1.f >= u + v || (kNull != second && 1.f >= u && 1.f >= v));
+#else
+    float    t, u, v;
+    uint32_t primitive;
+    return smallItemIntersect(ray, item, t, u, v, primitive);
+#endif
+}
+
+// The items of one small mesh, in order, handed to test(item).  The table is read through the scalar cache (every lane the same
+// item): the next item's words are asked for before the current one is tested, so that a test does not start with a load's latency.
+template <typename Test>
+ZD void forSmallItems(const DScene& s, uint32_t first, uint32_t count, Test&& test) {
+    const float4* words = s.small_tris + kSmallItemWords * first;
+    SmallItem     item{words[0], words[1], words[2], words[3]};
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4*   ahead = words + kSmallItemWords * (k + 1 < count ? k + 1 : k);
+        const SmallItem next{ahead[0], ahead[1], ahead[2], ahead[3]};
+        test(item);
+        item = next;
+    }
+}
 
 // sphere.zig:28-60 (nearer root first); unit-diameter sphere scaled by trafo.scale.x
 ZD bool sphereIntersect(const Ray& ray, const Trafo& trafo, float& out_t) {
@@ -1200,6 +1289,21 @@ ZD bool tlasOrderLater(const DScene& s, const Ray& ray_in, uint32_t a, uint32_t 
     return seen == a;  // a was met first: b is the later one
 }
 
+// Whether a ray has to be tested against a prop-table entry's shape.  The reference tests the prop's world bounds first
+// (prop.zig:199-237); for a Rectangle the shape's own test costs as much as the bounds' and decides the same thing (a hit lies
+// inside the bounds), and in a wave of incoherent rays some lane passes the bounds anyway: the relaxed units go straight to
+// the Rectangle (RELAXED_RULES; an ulp at the bounds' edge is within their contract, not within the precise units').  Closest hits
+// only: measured in one call on configs[1], wf_trace_shade 111.6 -> 108.4 ms per 8 steps; the shadow rays of wf_scatter, most of
+// which miss most bounds, 153.8 -> 154.7 with the same change, so they keep the bounds test.
+#ifndef ZYG_RECT_DIRECT
+#define ZYG_RECT_DIRECT 1
+#endif
+template <bool RELAXED_RULES>
+ZD bool entryBoundsHit(const TlasEntry& e, const Ray& ray) {
+    if (RELAXED_RULES && ZYG_RECT_DIRECT && ZYGPU_SHAPE_RECTANGLE == e.shape) return true;  // uniform
+    return aabbIntersect(e.bmin, e.bmax, ray);
+}
+
 // closest hit over the solid props (the semantics of sceneIntersect<false, false>); WIDE: meshes through their wide re-layout
 template <bool EXACT_TIES, bool WIDE>
 ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit) {
@@ -1208,7 +1312,7 @@ ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface,
     for (uint32_t k = 0; k < s.num_solid_table; ++k) {
         const TlasEntry& e = s.solid_table[k];
         if (!propVisibleAtDepth(e.flags, depth_surface)) continue;  // uniform
-        if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
+        if (!entryBoundsHit<!EXACT_TIES>(e, ray)) continue;
         const Trafo trafo = entryTrafo(e);
         Hit         h;
         bool        found;
@@ -1223,17 +1327,18 @@ ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface,
             // every triangle of a small mesh, in the mesh's order (the reference's order only matters for exact ties)
             Ray local = worldToObjectRay(trafo, ray);
             found = false;
-            for (uint32_t k = e.small_first, ke = e.small_first + e.small_count; k < ke; ++k) {
-                float t, u, v;
-                if (triangleIntersect(local, xyz(s.small_tris[3 * k]), xyz(s.small_tris[3 * k + 1]), xyz(s.small_tris[3 * k + 2]), t, u, v)) {
+            forSmallItems(s, e.small_first, e.small_count, [&](const SmallItem& item) {
+                float    t, u, v;
+                uint32_t primitive;
+                if (smallItemIntersect(local, item, t, u, v, primitive)) {
                     local.max_t = t;
                     h.t = t;
                     h.u = u;
                     h.v = v;
-                    h.primitive = k - e.small_first;
+                    h.primitive = primitive;
                     found = true;
                 }
-            }
+            });
         } else {
             Ray local = worldToObjectRay(trafo, ray);
             found = meshIntersect<false, WIDE>(s.meshes[e.mesh], local, h, none);
@@ -1257,7 +1362,7 @@ ZD void tableClosestBeforeLargeMeshes(const DScene& s, Ray& ray, uint32_t depth_
     for (uint32_t k = 0; k < s.first_large; ++k) {
         const TlasEntry& e = s.solid_table[k];
         if (!propVisibleAtDepth(e.flags, depth_surface)) continue;
-        if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
+        if (!entryBoundsHit<true>(e, ray)) continue;
         const Trafo trafo = entryTrafo(e);
         Hit         h;
         bool        found;
@@ -1267,17 +1372,18 @@ ZD void tableClosestBeforeLargeMeshes(const DScene& s, Ray& ray, uint32_t depth_
         } else if (e.small_count > 0) {
             Ray local = worldToObjectRay(trafo, ray);
             found = false;
-            for (uint32_t i = e.small_first, ie = e.small_first + e.small_count; i < ie; ++i) {
-                float t, u, v;
-                if (triangleIntersect(local, xyz(s.small_tris[3 * i]), xyz(s.small_tris[3 * i + 1]), xyz(s.small_tris[3 * i + 2]), t, u, v)) {
+            forSmallItems(s, e.small_first, e.small_count, [&](const SmallItem& item) {
+                float    t, u, v;
+                uint32_t primitive;
+                if (smallItemIntersect(local, item, t, u, v, primitive)) {
                     local.max_t = t;
                     h.t = t;
                     h.u = u;
                     h.v = v;
-                    h.primitive = i - e.small_first;
+                    h.primitive = primitive;
                     found = true;
                 }
-            }
+            });
         } else {
             Ray local = worldToObjectRay(trafo, ray);
             found = meshIntersect<false, true>(s.meshes[e.mesh], local, h, none);
@@ -1308,10 +1414,7 @@ ZD bool tableBlocksBeforeLargeMeshes(const DScene& s, const Ray& ray) {
             blocked = rectangleIntersect(ray, trafo, t, u, v);
         } else if (e.small_count > 0) {
             const Ray local = worldToObjectRay(trafo, ray);
-            for (uint32_t i = e.small_first, ie = e.small_first + e.small_count; i < ie; ++i) {
-                float t, u, v;
-                blocked = blocked || triangleIntersect(local, xyz(s.small_tris[3 * i]), xyz(s.small_tris[3 * i + 1]), xyz(s.small_tris[3 * i + 2]), t, u, v);
-            }
+            forSmallItems(s, e.small_first, e.small_count, [&](const SmallItem& item) { blocked = blocked || smallItemBlocks(local, item); });
         } else {
             Ray local = worldToObjectRay(trafo, ray);
             blocked = meshIntersectP<false, true>(s.meshes[e.mesh], local, none);  // (only the wide-BLAS instantiations call this)
@@ -1338,10 +1441,7 @@ ZD bool sceneVisibilityUniform(const DScene& s, Ray& ray) {
 #endif
             } else if (SMALL && e.small_count > 0) {
                 const Ray local = worldToObjectRay(trafo, ray);
-                for (uint32_t k = e.small_first, ke = e.small_first + e.small_count; k < ke; ++k) {
-                    float t, u, v;
-                    blocked = blocked || triangleIntersect(local, xyz(s.small_tris[3 * k]), xyz(s.small_tris[3 * k + 1]), xyz(s.small_tris[3 * k + 2]), t, u, v);
-                }
+                forSmallItems(s, e.small_first, e.small_count, [&](const SmallItem& item) { blocked = blocked || smallItemBlocks(local, item); });
             } else {
                 Ray local = worldToObjectRay(trafo, ray);
                 blocked = meshIntersectP<false, WIDE>(s.meshes[e.mesh], local, none);

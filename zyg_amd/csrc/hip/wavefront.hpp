@@ -249,8 +249,11 @@ struct Params {
 };
 
 // one copy per translation unit (kernel_table.hpp): the units are built without relocatable device code
-static __constant__ View   c_view;
-static __constant__ DScene c_scene;  // the compiled scene's device arrays: read on demand through the scalar cache
+// (names and visibility: dsampler.hpp ZYG_CONSTANT_BLOCK)
+#define c_view ZYG_BLOCK_NAME(c_view)
+#define c_scene ZYG_BLOCK_NAME(c_scene)
+ZYG_CONSTANT_BLOCK View   c_view;
+ZYG_CONSTANT_BLOCK DScene c_scene;  // the compiled scene's device arrays: read on demand through the scalar cache
 
 // occupancy targets (waves per SIMD) the register allocator is held to, per kernel; see DESIGN.md "Occupancy"
 #ifndef ZYG_SHADE_WAVES
@@ -1070,7 +1073,7 @@ ZD void walkUnoccluding(const DScene& s, uint32_t depth_surface, const Ray& ray_
         for (uint32_t k = 0; k < s.num_unocc_table; ++k) {
             const TlasEntry& e = s.unocc_table[k];
             if (!propVisibleAtDepth(e.flags, depth_surface)) continue;
-            if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
+            if (!entryBoundsHit<0 != ZYG_FAST>(e, ray)) continue;
             float t, u, v;
             if (rectangleIntersect(ray, entryTrafo(e), t, u, v)) record(e.prop, 0, t, u, v);
         }

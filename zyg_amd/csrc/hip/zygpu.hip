@@ -508,6 +508,9 @@ struct ZygpuContext {
     // option "hit_by_queue" (default 1): the hit records of the vertices that go on to wf_scatter at their place in the alive queue
     // (dense) instead of by path slot (a 128 B line per 32 B record once the slots thin out); wf_scatter's tick loop only
     bool          hit_by_queue = true;
+    // option "pair_small" (default 1; read when a scene is uploaded): two triangles of a small mesh that make a parallelogram are
+    // one item of the small-triangle table (dscene.hpp SmallItem)
+    bool          pair_small = true;
     uint32_t      regen_kslots = 2048;
     View          batch_view{};            // the running batch's view block; g_unit_view_epoch: which kernel units hold it
     uint64_t      view_epoch = 0;
@@ -1189,14 +1192,83 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                 const ZygpuMesh& hm = d->meshes[e.mesh];
                 if (hm.num_triangles <= kSmallMeshTriangles && num_small + hm.num_triangles <= kSmallTriangles) {
                     e.small_first = num_small;
-                    e.small_count = hm.num_triangles;
-                    for (uint32_t t = 0; t < hm.num_triangles; ++t)
-                        for (int k = 0; k < 3; ++k) {
-                            const uint32_t vi = hm.triangles[size_t(t) * 3 + k];
-                            s.small_tris[3 * (num_small + t) + k] =
-                                make_float4(hm.positions[size_t(vi) * 3], hm.positions[size_t(vi) * 3 + 1], hm.positions[size_t(vi) * 3 + 2], 0.f);
+                    // Two triangles that make a parallelogram (they share an edge and the fourth corner is b + c - a) become one item
+                    // of the table (option pair_small): one transformed ray point and direction decide both (dscene.hpp SmallItem).
+                    auto position = [&](uint32_t t, int k, double* o) {
+                        const uint32_t vi = hm.triangles[size_t(t) * 3 + k];
+                        for (int x = 0; x < 3; ++x) o[x] = hm.positions[size_t(vi) * 3 + x];
+                    };
+                    auto bits = [](uint32_t u) {
+                        float f;
+                        std::memcpy(&f, &u, 4);
+                        return f;
+                    };
+                    auto same = [](const double* x, const double* y, double eps) {
+                        return std::fabs(x[0] - y[0]) <= eps && std::fabs(x[1] - y[1]) <= eps && std::fabs(x[2] - y[2]) <= eps;
+                    };
+                    std::vector<char> taken(hm.num_triangles, 0);
+                    uint32_t          items = 0;
+                    for (uint32_t t = 0; t < hm.num_triangles; ++t) {
+                        if (taken[t]) continue;
+                        taken[t] = 1;
+                        // the item's frame: corner a' = the triangle's vertex `turn` (the one off the shared edge), b', c' the next two
+                        uint32_t turn = 0, second = kNull, su1 = 0, sv1 = 0;
+                        double   q[3][3];
+                        for (uint32_t r = 0; ZYG_SMALL_UNIT && c->pair_small && r < 3 && kNull == second; ++r) {
+                            double a[3], b[3], cc[3], dd[3];
+                            position(t, int(r), a), position(t, int((r + 1) % 3), b), position(t, int((r + 2) % 3), cc);
+                            double size = 0.;
+                            for (int k = 0; k < 3; ++k) {
+                                dd[k] = b[k] + cc[k] - a[k];
+                                size = std::max(size, std::max(std::fabs(a[k]), std::max(std::fabs(b[k]), std::fabs(cc[k]))));
+                            }
+                            for (uint32_t j = t + 1; j < hm.num_triangles && kNull == second; ++j) {
+                                if (taken[j]) continue;
+                                // which corner of the parallelogram each of j's vertices is: 0 = d', 1 = b', 2 = c' (b', c' exactly)
+                                uint32_t which[3], seen = 0;
+                                for (int k = 0; k < 3; ++k) {
+                                    double x[3];
+                                    position(j, k, x);
+                                    which[k] = same(x, b, 0.) ? 1u : same(x, cc, 0.) ? 2u : same(x, dd, 2e-7 * size) ? 0u : 3u;
+                                    if (which[k] < 3) seen |= 1u << which[k];
+                                }
+                                if (7 != seen) continue;
+                                second = j, turn = r, su1 = which[1], sv1 = which[2];
+                                taken[j] = 1;
+                            }
                         }
-                    num_small += hm.num_triangles;
+                        for (int k = 0; k < 3; ++k) position(t, int((turn + k) % 3), q[k]);
+                        float4* out = s.small_tris + kSmallItemWords * (num_small + items);
+#if ZYG_SMALL_UNIT
+                        // rows of [e1 e2 n]^-1 with n = e1 x e2 (its determinant is n.n), last column -row.a: dscene.hpp smallItemIntersect
+                        auto cross = [](const double* x, const double* y, double* o) {
+                            o[0] = x[1] * y[2] - x[2] * y[1], o[1] = x[2] * y[0] - x[0] * y[2], o[2] = x[0] * y[1] - x[1] * y[0];
+                        };
+                        double e1[3], e2[3], n[3], rows[3][3];
+                        for (int k = 0; k < 3; ++k) e1[k] = q[1][k] - q[0][k], e2[k] = q[2][k] - q[0][k];
+                        cross(e1, e2, n);
+                        const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                        cross(e2, n, rows[0]);
+                        cross(n, e1, rows[1]);
+                        for (int k = 0; k < 3; ++k) rows[2][k] = n[k];
+                        for (int r = 0; r < 3; ++r) {
+                            // a degenerate triangle (nn = 0) gets rows of NaN: no ray passes its test, as none passes the reference's
+                            for (int k = 0; k < 3; ++k) rows[r][k] /= nn;
+                            const double w = -(rows[r][0] * q[0][0] + rows[r][1] * q[0][1] + rows[r][2] * q[0][2]);
+                            out[r] = make_float4(float(rows[r][0]), float(rows[r][1]), float(rows[r][2]), float(w));
+                        }
+#else
+                        for (int k = 0; k < 3; ++k) out[k] = make_float4(float(q[k][0]), float(q[k][1]), float(q[k][2]), 0.f);
+#endif
+                        // primitive and which of the frame's weights are its u (vertex 1) and v (vertex 2): the first triangle's
+                        // vertex k is the frame's corner (k - turn) mod 3
+                        const uint32_t first = t | (((1 + 3 - turn) % 3) << 8) | (((2 + 3 - turn) % 3) << 10);
+                        const uint32_t other = kNull == second ? kNull : (second | (su1 << 8) | (sv1 << 10));
+                        out[3] = make_float4(bits(first), bits(other), 0.f, 0.f);
+                        ++items;
+                    }
+                    e.small_count = items;
+                    num_small += items;
                 }
             }
             return e;
@@ -1937,6 +2009,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "hit_by_queue")) {
         c->hit_by_queue = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "pair_small")) {
+        c->pair_small = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "compact_blocks")) {
