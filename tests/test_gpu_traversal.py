@@ -100,8 +100,9 @@ def _bounded(result, ref_hits, ref_vis, mode):
     # another primitive or prop: where two surfaces coincide (the Cornell boxes stand on the floor: a ray from inside a box hits
     # its bottom face and the floor at the same distance) an ulp decides which one is reported; never a hit against a miss,
     # and the distance is the same
+    # (mode 3 tests the Rectangles and the small meshes in their unit frames: the floor and a box's bottom face no longer round alike)
     other = (hits[:, 3] != ref_hits[:, 3]) | (hits[:, 4] != ref_hits[:, 4])
-    assert other.mean() <= 2e-3, (mode, int(other.sum()))
+    assert other.mean() <= (5e-3 if 3 == mode else 2e-3), (mode, int(other.sum()))
     assert np.array_equal(hits[:, 4] == zyg_amd.NULL, ref_hits[:, 4] == zyg_amd.NULL) or \
         ((hits[:, 4] == zyg_amd.NULL) != (ref_hits[:, 4] == zyg_amd.NULL)).mean() <= 1e-5, mode
     hit_both = (hits[:, 4] != zyg_amd.NULL) & (ref_hits[:, 4] != zyg_amd.NULL)

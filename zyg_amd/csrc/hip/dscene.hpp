@@ -85,6 +85,8 @@ struct TlasEntry {
     float4   r0, r1, r2, pos;   // transformation (s.trafos)
     uint32_t shape, flags, prop, mesh;
     uint32_t small_first, small_count, pad0, pad1;  // a mesh of a few triangles: its items in DScene::small_tris (count 0: none)
+    // a Rectangle: rows that take a world point to (u, v, height over the plane), |u|, |v| <= 1 inside (unitRectangleIntersect)
+    float4   fu, fv, fn;
 };
 // The triangles of the scene's smallest meshes (at most kSmallMeshTriangles each, kSmallTriangles in all), in the constant
 // block beside the prop tables: the relaxed-arithmetic units test all of them, every lane of the wave the same triangle at the
@@ -1304,6 +1306,34 @@ ZD bool entryBoundsHit(const TlasEntry& e, const Ray& ray) {
     return aabbIntersect(e.bmin, e.bmax, ray);
 }
 
+// A Rectangle of the prop tables as the relaxed units test it: the entry's rows, worked out in f64 at upload from the
+// transformation rectangleIntersect uses, give the ray's origin and direction in the Rectangle's own (u, v, height) frame: the
+// same t, u, v as rectangle.zig:30-62 to rounding, without the bounds test, the plane constant, the scaling divisions.
+#ifndef ZYG_RECT_UNIT
+#define ZYG_RECT_UNIT 1
+#endif
+#ifndef ZYG_RECT_UNIT_SHADOW
+#define ZYG_RECT_UNIT_SHADOW ZYG_RECT_UNIT  // the shadow rays too (they kept the bounds test in front of the reference's form)
+#endif
+ZD bool unitRectangleIntersect(const Ray& ray, const TlasEntry& e, float& out_t, float& out_u, float& out_v) {
+    const float4 r0 = e.fu, r1 = e.fv, r2 = e.fn;
+    const float  oz = fmaf(r2.x, ray.origin.x, fmaf(r2.y, ray.origin.y, fmaf(r2.z, ray.origin.z, r2.w)));
+    const float  dz = fmaf(r2.x, ray.direction.x, fmaf(r2.y, ray.direction.y, r2.z * ray.direction.z));
+    const float  hit_t = -oz * smallReciprocal(dz);
+    const float  ox = fmaf(r0.x, ray.origin.x, fmaf(r0.y, ray.origin.y, fmaf(r0.z, ray.origin.z, r0.w)));
+    const float  dx = fmaf(r0.x, ray.direction.x, fmaf(r0.y, ray.direction.y, r0.z * ray.direction.z));
+    const float  oy = fmaf(r1.x, ray.origin.x, fmaf(r1.y, ray.origin.y, fmaf(r1.z, ray.origin.z, r1.w)));
+    const float  dy = fmaf(r1.x, ray.direction.x, fmaf(r1.y, ray.direction.y, r1.z * ray.direction.z));
+    const float  u = fmaf(hit_t, dx, ox), v = fmaf(hit_t, dy, oy);
+    if (hit_t >= ray.min_t && ray.max_t >= hit_t && fabsf(u) <= 1.f && fabsf(v) <= 1.f) {
+        out_t = hit_t;
+        out_u = u;
+        out_v = v;
+        return true;
+    }
+    return false;
+}
+
 // closest hit over the solid props (the semantics of sceneIntersect<false, false>); WIDE: meshes through their wide re-layout
 template <bool EXACT_TIES, bool WIDE>
 ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit) {
@@ -1318,7 +1348,7 @@ ZD bool sceneIntersectUniform(const DScene& s, Ray& ray, uint32_t depth_surface,
         bool        found;
         if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
             h.primitive = 0;
-            found = rectangleIntersect(ray, trafo, h.t, h.u, h.v);
+            found = (!EXACT_TIES && ZYG_RECT_UNIT) ? unitRectangleIntersect(ray, e, h.t, h.u, h.v) : rectangleIntersect(ray, trafo, h.t, h.u, h.v);
 #if ZYG_EXPERIMENT_SKIP_SMALL  // timing experiment only: the small meshes are not there
         } else if (!EXACT_TIES && e.small_count > 0 && ZYG_EXPERIMENT_SKIP_SMALL > 1) {
             found = false;
@@ -1368,7 +1398,7 @@ ZD void tableClosestBeforeLargeMeshes(const DScene& s, Ray& ray, uint32_t depth_
         bool        found;
         if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
             h.primitive = 0;
-            found = rectangleIntersect(ray, trafo, h.t, h.u, h.v);
+            found = ZYG_RECT_UNIT ? unitRectangleIntersect(ray, e, h.t, h.u, h.v) : rectangleIntersect(ray, trafo, h.t, h.u, h.v);
         } else if (e.small_count > 0) {
             Ray local = worldToObjectRay(trafo, ray);
             found = false;
@@ -1407,6 +1437,11 @@ ZD bool tableBlocksBeforeLargeMeshes(const DScene& s, const Ray& ray) {
     for (uint32_t k = 0; k < s.first_large && !blocked; ++k) {
         const TlasEntry& e = s.solid_table[k];
         if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;
+        if (ZYG_RECT_UNIT_SHADOW && ZYGPU_SHAPE_RECTANGLE == e.shape) {  // uniform
+            float t, u, v;
+            blocked = unitRectangleIntersect(ray, e, t, u, v);
+            continue;
+        }
         if (!aabbIntersect(e.bmin, e.bmax, ray)) continue;
         const Trafo trafo = entryTrafo(e);
         if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
@@ -1431,7 +1466,10 @@ ZD bool sceneVisibilityUniform(const DScene& s, Ray& ray) {
     for (uint32_t k = 0; k < s.num_solid_table; ++k) {
         const TlasEntry& e = s.solid_table[k];
         if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;  // uniform
-        if (!blocked && aabbIntersect(e.bmin, e.bmax, ray)) {
+        if (SMALL && ZYG_RECT_UNIT_SHADOW && ZYGPU_SHAPE_RECTANGLE == e.shape) {  // uniform; SMALL: the relaxed units' rules
+            float t, u, v;
+            if (!blocked) blocked = unitRectangleIntersect(ray, e, t, u, v);
+        } else if (!blocked && aabbIntersect(e.bmin, e.bmax, ray)) {
             const Trafo trafo = entryTrafo(e);
             if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
                 float t, u, v;

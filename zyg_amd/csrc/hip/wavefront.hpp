@@ -1075,7 +1075,7 @@ ZD void walkUnoccluding(const DScene& s, uint32_t depth_surface, const Ray& ray_
             if (!propVisibleAtDepth(e.flags, depth_surface)) continue;
             if (!entryBoundsHit<0 != ZYG_FAST>(e, ray)) continue;
             float t, u, v;
-            if (rectangleIntersect(ray, entryTrafo(e), t, u, v)) record(e.prop, 0, t, u, v);
+            if ((ZYG_FAST && ZYG_RECT_UNIT) ? unitRectangleIntersect(ray, e, t, u, v) : rectangleIntersect(ray, entryTrafo(e), t, u, v)) record(e.prop, 0, t, u, v);
         }
         return;
     }
@@ -1409,7 +1409,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 template <bool STATS, bool MESHL, bool HEAVY, bool POOL, int PRE = 0>
 ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
                     Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr, float4 pre_thr = make_float4(1.f, 1.f, 1.f, 0.f),
-                    float* sr_out = nullptr) {
+                    float* sr_out = nullptr, uint32_t* material_out = nullptr) {
     const DScene&  s = c_scene;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -1589,6 +1589,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         } else {
             if (sr_out) *sr_out = stochastic_r;  // (the caller writes it with the hit, at the vertex' place in the alive queue)
             else P.pool.hit_sr[slot] = stochastic_r;
+            if (material_out) *material_out = mat_id;
             P.pool.thr[slot] = f4(throughput, POOL ? split_weight : thr4.w);  // (non-POOL: the spare lane may carry PrevVertex::alpha)
             if (POOL) {
                 f3         geo_n = frag.geo_n, n = frag.n;
@@ -1636,17 +1637,20 @@ struct HitRecord {  // what wf_scatter's closure set-up reads of the vertex' hit
     uint4    hit;       // t, u, v (bits), primitive
     uint32_t prop, ucount;
     float    stochastic_r;
+    // the hit part's material, which the shading pass has looked up (prop -> part -> material: three dependent loads that
+    // loadSurface then does not repeat), or kNull: not recorded (the records by slot have no word for it)
+    uint32_t material;
 };
 ZD HitRecord loadHitRecord(const Params& P, uint32_t slot) {
-    return {P.pool.hit[slot], P.pool.hit_prop[slot], P.pool.ucount[slot], P.pool.hit_sr[slot]};
+    return {P.pool.hit[slot], P.pool.hit_prop[slot], P.pool.ucount[slot], P.pool.hit_sr[slot], kNull};
 }
 ZD HitRecord loadQueuedHit(const Params& P, uint32_t position) {
     const uint4 a = P.hit_q[2u * size_t(position)], b = P.hit_q[2u * size_t(position) + 1u];
-    return {a, b.x, b.y, __uint_as_float(b.z)};
+    return {a, b.x, b.y, __uint_as_float(b.z), b.w};
 }
-ZD void storeQueuedHit(const Params& P, uint32_t position, const Hit& hit, uint32_t ucount, float stochastic_r) {
+ZD void storeQueuedHit(const Params& P, uint32_t position, const Hit& hit, uint32_t ucount, float stochastic_r, uint32_t material) {
     P.hit_q[2u * size_t(position)] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
-    P.hit_q[2u * size_t(position) + 1u] = make_uint4(hit.prop, ucount, __float_as_uint(stochastic_r), 0u);
+    P.hit_q[2u * size_t(position) + 1u] = make_uint4(hit.prop, ucount, __float_as_uint(stochastic_r), material);
 }
 
 // Two passes share shadeVertex.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
@@ -1667,6 +1671,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
         uint32_t   slot = 0, alive_key = 0, ucount = 0, position = 0;
         Hit        hit{0.f, 0.f, 0.f, 0u, kNull};
         float      stochastic_r = 0.f;
+        uint32_t   material = kNull;
         const bool queued = !POOL && nullptr != P.hit_q;
         if (i < total) {
             slot = HEAVY ? P.q.heavy[at] : extQueue<POOL>(P, cur, P.round)[at];
@@ -1675,7 +1680,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             alive_key = hit.prop;
             ucount = P.pool.ucount[slot];
             shadeVertex<STATS, MESHL, HEAVY, POOL>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, ucount, alive, defer, cnt, tm, nullptr,
-                                                   make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr);
+                                                   make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr, queued ? &material : nullptr);
         }
         if (HEAVY && !POOL && P.regen_sample) {
             // the regenerating kernels: no queue behind this pass; a path that ended here leaves its slot to wf_rscatter
@@ -1687,7 +1692,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             }
             if (!POOL && P.alive_keys > 1) alivePushKeyed<4>(P, cur, false, alive, alive_key & (kAliveKeys - 1u), slot);
             else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot, false, &position);
-            if (queued && alive) storeQueuedHit(P, position, hit, ucount, stochastic_r);
+            if (queued && alive) storeQueuedHit(P, position, hit, ucount, stochastic_r, material);
         }
         tm.mark(5);
         tm.flush(P.ctl, 0);
@@ -1749,7 +1754,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         SectionTimer tm;
         tm.start();
         bool       alive = false, defer = false;
-        uint32_t   slot = 0, alive_key = 0, queued_ucount = 0, position = 0;
+        uint32_t   slot = 0, alive_key = 0, queued_ucount = 0, position = 0, queued_material = kNull;
         Hit        queued_hit{0.f, 0.f, 0.f, 0u, kNull};
         float      stochastic_r = 0.f;
         const bool queued = nullptr != P.hit_q;
@@ -1802,7 +1807,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL, UTLAS>(P, scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             tm.mark(10);
             shadeVertex<STATS, MESHL, false, false, kPre>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh, fresh_thr,
-                                                          queued ? &stochastic_r : nullptr);
+                                                          queued ? &stochastic_r : nullptr, queued ? &queued_material : nullptr);
             // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool: by slot, or (the vertices that go
             // straight on to wf_scatter, Params::hit_q) at their place in the alive queue, behind the append below
             if (defer || (alive && !queued)) {
@@ -1817,7 +1822,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         // configs[1] wf_trace_shade 126.0 -> 123.9 ms per 8 steps against two queuePush calls
         if (UTLAS && P.alive_keys > 1) alivePushKeyed<kTraceShadeBlock / 64>(P, cur, defer, alive && !defer, alive_key & (kAliveKeys - 1u), slot);
         else queuePushTwo<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], defer, P.alive_out, &P.ctl->alive_count[cur][0], alive && !defer, slot, &position);
-        if (queued && alive && !defer) storeQueuedHit(P, position, queued_hit, queued_ucount, stochastic_r);
+        if (queued && alive && !defer) storeQueuedHit(P, position, queued_hit, queued_ucount, stochastic_r, queued_material);
         tm.mark(11);
         tm.flush(P.ctl, 0);
     }
@@ -1865,7 +1870,13 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
         Fragment       frag;
         makeFragment<EXTRA>(s, ray, hit, frag);
         const f3             wo = -ray.direction;
-        const ZygpuMaterial& m = s.materials[s.material_ids[s.props[frag.prop].parts_start + frag.part]];
+#ifndef ZYG_EXPERIMENT_MATERIAL_CHAIN
+#define ZYG_EXPERIMENT_MATERIAL_CHAIN 0  // 1: the A/B of HitRecord::material (the look-up is always repeated)
+#endif
+        const uint32_t       material = (!ZYG_EXPERIMENT_MATERIAL_CHAIN && record && kNull != record->material)
+                                            ? record->material
+                                            : uint32_t(s.material_ids[s.props[frag.prop].parts_start + frag.part]);
+        const ZygpuMaterial& m = s.materials[material];
         f3                   geo_n = frag.geo_n, n = frag.n;
         if ((m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo)) {
             geo_n = -geo_n;
@@ -1878,7 +1889,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
         sf.p = frag.p;
         sf.parent_pdf = 0.f;  // POOL only
         sf.frag_geo_n = frag.geo_n;
-        sf.material = s.material_ids[s.props[frag.prop].parts_start + frag.part];
+        sf.material = material;
         const Regularize reg = loadRegularize(P, slot);
         if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
             const FragmentExtra fx{frag.uv0, frag.uv1, hit_sr, frag.p, frag.trafo};

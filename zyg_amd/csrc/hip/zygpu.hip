@@ -1187,6 +1187,17 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             e.prop = p;
             e.mesh = d->props[p].mesh;
             e.small_first = e.small_count = e.pad0 = e.pad1 = 0;
+            e.fu = e.fv = e.fn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
+                // dscene.hpp unitRectangleIntersect: u = dot(-r0, p - position) / (scale.x / 2), v likewise with r1, scale.y; height = dot(r2, p - position)
+                const double half[3] = {0.5 * double(t.r[0][3]), 0.5 * double(t.r[1][3]), 1.};
+                float4*      rows[3] = {&e.fu, &e.fv, &e.fn};
+                for (int k = 0; k < 3; ++k) {
+                    const double sign = k < 2 ? -1. : 1.;
+                    const double x = sign * double(t.r[k][0]) / half[k], y = sign * double(t.r[k][1]) / half[k], z = sign * double(t.r[k][2]) / half[k];
+                    *rows[k] = make_float4(float(x), float(y), float(z), float(-(x * double(t.position[0]) + y * double(t.position[1]) + z * double(t.position[2]))));
+                }
+            }
             // a mesh of a few triangles goes into the small-triangle table (dscene.hpp), in its own (leaf) order
             if (ZYGPU_SHAPE_TRIANGLE_MESH == e.shape) {
                 const ZygpuMesh& hm = d->meshes[e.mesh];
