@@ -1000,7 +1000,7 @@ def _relaxed_against_the_oracle(engine, oracle, w, h, spp, bands, threads=16, id
     return r
 
 
-@pytest.mark.parametrize("config", ["config2_sphere", "config2_mound", "glass", "substitute"])
+@pytest.mark.parametrize("config", ["config2_sphere", "config2_mound", "glass", "substitute", "boxes48"])
 def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
     """The kernels bench.py times (option precise = 0: the wave-wide prop-table walk, constant-block triangles, the quantised
     four-wide BLAS with its LDS stack, the persistent mesh kernels) against the CPU oracle directly, at 1920x1080 and the
@@ -1017,6 +1017,9 @@ def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
     elif "glass" == config:
         scenes.cornell(engine, w, h, spp, integrator="PTMIS", glass_objects={"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)})
         bands = ((760, 764), (880, 884))  # the glass Sphere and box, the caustics on the floor
+    elif "boxes48" == config:  # the boxes' faces as 2 x 2 grids: 48 triangles each, 24 parallelogram items of the small-mesh table
+        scenes.cornell(engine, w, h, spp, integrator="PTMIS", box_subdivide=2)
+        bands = ((536, 544),)
     else:
         scenes.cornell(engine, w, h, spp, integrator="PTMIS", material="substitute")
         bands = ((536, 544),)

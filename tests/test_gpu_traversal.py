@@ -113,7 +113,7 @@ def _bounded(result, ref_hits, ref_vis, mode):
     assert np.all(np.abs(uv - ruv) <= 2e-3)
 
 
-@pytest.mark.parametrize("scene", ["boxes", "mesh", "sphere"])
+@pytest.mark.parametrize("scene", ["boxes", "boxes18", "boxes48", "boxes108", "mesh", "sphere"])
 def test_relaxed_ray_dump_against_the_oracle(engine, oracle, scene):
     """The same rays through the walks as the relaxed kernel units compile them (native divide, contraction: the hooks of
     kernels.hip built with -DZYG_FAST): an occlusion answer or a hit may flip only where a ray grazes an edge or a box within
@@ -121,6 +121,12 @@ def test_relaxed_ray_dump_against_the_oracle(engine, oracle, scene):
     n = 1 << 18
     if scene == "boxes":
         scenes.cornell(engine, 64, 48, 1)
+    elif scene == "boxes18":  # one face of each box as a 1 x 4 grid: 18 triangles, 9 items of the small-mesh table
+        scenes.cornell(engine, 64, 48, 1, box_first_face=(1, 4))
+    elif scene == "boxes48":  # 48 triangles that pair up into 24 items: still in the table (its limit is 32 items)
+        scenes.cornell(engine, 64, 48, 1, box_subdivide=2)
+    elif scene == "boxes108":  # 54 items: past the table, through the four-wide BLAS
+        scenes.cornell(engine, 64, 48, 1, box_subdivide=3)
     elif scene == "mesh":
         scenes.cornell(engine, 64, 48, 1, boxes=False, mesh=scenes.heightfield_mesh(n=400), mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
     else:

@@ -79,7 +79,12 @@ struct DPortalLight {  // ZygpuPortalLight on the device
 // A small top-level scene as a table in the __constant__ block itself (zygpu_upload_scene fills it when the solid props are
 // at most kUniformProps Rectangles and TriangleMeshes): every lane of a wave tests the same prop at the same time, the
 // prop's bounds and transformation arrive through the scalar cache in SGPRs (sceneIntersectUniform, sceneVisibilityUniform).
-constexpr uint32_t kUniformProps = 32;  // 17 props through the per-lane tree walk: 461 Msamples/s against 773 with 16 in the table
+// 17 props through the per-lane tree walk: 461 Msamples/s against 773 with 16 in the table (round 2); round 3's end: 947 / 867 / 436
+// at 16 / 28 / 32+ props with a table of 32 (the last through the tree), tools/prop_curve.sh
+#ifndef ZYG_UNIFORM_PROPS
+#define ZYG_UNIFORM_PROPS 64
+#endif
+constexpr uint32_t kUniformProps = ZYG_UNIFORM_PROPS;
 struct TlasEntry {
     float4   bmin, bmax;        // world bounds (s.aabbs)
     float4   r0, r1, r2, pos;   // transformation (s.trafos)

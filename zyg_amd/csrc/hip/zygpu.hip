@@ -479,6 +479,7 @@ struct ZygpuContext {
     // option "fuse_tick" (default off: measured 657 vs 662 Msamples/s on configs[1], 255 vs 453 on configs[2]): wf_scatter of vertex k and wf_trace_shade of vertex k + 1 in one launch (wf_tick), for
     // the scenes and settings its instantiations cover (prop tables, in-place NEE, single-sample lights)
     bool          fuse_tick = false;
+    bool          tables_deduplicated = false;  // the solid tree references some prop from more than one leaf (the table holds it once)
     bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
     bool          huge_mesh = false;   // a mesh of kMeshKernelMinTriangles or more: wf_scatter_h + wf_shadow_u (option mesh_kernels)
     // option "mesh_kernels" (default on): in the relaxed units the walks of the large meshes run in persistent kernels of their
@@ -528,7 +529,8 @@ struct ZygpuContext {
 namespace {
 
 // Thresholds on a mesh's triangle count (measured with tools/threshold_edges.sh, DESIGN 4 "threshold edges"):
-//   <= kSmallMeshTriangles (dscene.hpp, 32): tested triangle by triangle from the constant block (relaxed units)
+//   <= kSmallMeshTriangles (dscene.hpp, 32) items, an item being a triangle or the two halves of a parallelogram: tested item by
+//      item from the constant block (relaxed units)
 //   >= kWideBlasMinTriangles (33): the scene runs the wide-BLAS kernel instantiations and extension rays that enter the mesh's
 //      bounds are grouped at the back of their queue (108-triangle boxes: 527 -> 607 Msamples/s, 972: 432 -> 527)
 //   >= kMeshKernelMinTriangles (4096): its shadow walks go to wf_shadow_u (wf_scatter_h suspends the vertex; for the small
@@ -1172,6 +1174,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     s.num_solid_table = s.num_unocc_table = s.first_large = 0;
     {
         uint32_t num_small = 0;
+        bool     wide_needed = false;
         auto entry = [&](uint32_t p) {
             TlasEntry e;
             const ZygpuAabb&  b = d->aabbs[p];
@@ -1201,8 +1204,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             // a mesh of a few triangles goes into the small-triangle table (dscene.hpp), in its own (leaf) order
             if (ZYGPU_SHAPE_TRIANGLE_MESH == e.shape) {
                 const ZygpuMesh& hm = d->meshes[e.mesh];
-                if (hm.num_triangles <= kSmallMeshTriangles && num_small + hm.num_triangles <= kSmallTriangles) {
-                    e.small_first = num_small;
+                // (the table's cost is per item: a mesh of up to 2 x kSmallMeshTriangles triangles fits if enough of them pair up)
+                float4 staged[kSmallItemWords * 2 * kSmallMeshTriangles];
+                if (hm.num_triangles <= 2 * kSmallMeshTriangles && hm.num_triangles <= 255u) {
                     // Two triangles that make a parallelogram (they share an edge and the fourth corner is b + c - a) become one item
                     // of the table (option pair_small): one transformed ray point and direction decide both (dscene.hpp SmallItem).
                     auto position = [&](uint32_t t, int k, double* o) {
@@ -1249,7 +1253,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                             }
                         }
                         for (int k = 0; k < 3; ++k) position(t, int((turn + k) % 3), q[k]);
-                        float4* out = s.small_tris + kSmallItemWords * (num_small + items);
+                        float4* out = staged + kSmallItemWords * items;
 #if ZYG_SMALL_UNIT
                         // rows of [e1 e2 n]^-1 with n = e1 x e2 (its determinant is n.n), last column -row.a: dscene.hpp smallItemIntersect
                         auto cross = [](const double* x, const double* y, double* o) {
@@ -1278,15 +1282,25 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                         out[3] = make_float4(bits(first), bits(other), 0.f, 0.f);
                         ++items;
                     }
-                    e.small_count = items;
-                    num_small += items;
+                    if (items <= kSmallMeshTriangles && num_small + items <= kSmallTriangles) {
+                        std::copy(staged, staged + kSmallItemWords * items, s.small_tris + kSmallItemWords * num_small);
+                        e.small_first = num_small;
+                        e.small_count = items;
+                        num_small += items;
+                    }
                 }
+                // a mesh outside the table is walked: the wide-BLAS kernel instantiations if it is large enough for them
+                if (0 == e.small_count && hm.num_triangles >= kWideBlasMinTriangles) wide_needed = true;
             }
             return e;
         };
-        bool ok_solid = d->solid.num_indices > 0 && d->solid.num_indices <= kUniformProps && !s.prop_frames;  // static props only
-        for (uint32_t i = 0; ok_solid && i < d->solid.num_indices; ++i) {
-            const uint32_t sh = d->props[d->solid.indices[i]].shape;
+        // the solid props, each once (the tree's builder may reference a prop from two leaves: spatial splits)
+        std::vector<uint32_t> order(d->solid.indices, d->solid.indices + d->solid.num_indices);
+        std::sort(order.begin(), order.end());
+        order.erase(std::unique(order.begin(), order.end()), order.end());
+        bool ok_solid = !order.empty() && order.size() <= kUniformProps && !s.prop_frames;  // static props only
+        for (size_t i = 0; ok_solid && i < order.size(); ++i) {
+            const uint32_t sh = d->props[order[i]].shape;
             ok_solid = ZYGPU_SHAPE_RECTANGLE == sh || ZYGPU_SHAPE_TRIANGLE_MESH == sh;
         }
         bool ok_unocc = 0 == d->unoccluding.num_nodes || (d->unoccluding.num_nodes >= 1 && 0 != d->unoccluding.nodes[0].count &&
@@ -1296,7 +1310,6 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                 ok_unocc = ok_unocc && ZYGPU_SHAPE_RECTANGLE == d->props[d->unoccluding.indices[d->unoccluding.nodes[0].children_or_first + i]].shape;
         if (ok_solid && ok_unocc) {
             // Rectangles first, then meshes by size: the cheap tests shorten the ray before the expensive bounds are tested
-            std::vector<uint32_t> order(d->solid.indices, d->solid.indices + d->solid.num_indices);
             auto weight = [&](uint32_t p) { return ZYGPU_SHAPE_RECTANGLE == d->props[p].shape ? 0u : 1u + d->meshes[d->props[p].mesh].num_triangles; };
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight(a) < weight(b); });
             for (uint32_t p : order) s.solid_table[s.num_solid_table++] = entry(p);
@@ -1309,9 +1322,13 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             if (d->unoccluding.num_nodes)
                 for (uint32_t i = 0; i < d->unoccluding.nodes[0].count; ++i)
                     s.unocc_table[s.num_unocc_table++] = entry(d->unoccluding.indices[d->unoccluding.nodes[0].children_or_first + i]);
+            // every mesh of kWideBlasMinTriangles or more in the small-mesh table: nothing for the wide-BLAS instantiations to walk
+            // (the precise units, which do not read the table, walk such a mesh's BVH2 under either instantiation)
+            c->large_mesh = c->large_mesh && wide_needed;
         }
     }
     c->uniform_tables = s.num_solid_table > 0;
+    c->tables_deduplicated = c->uniform_tables && s.num_solid_table != d->solid.num_indices;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemsetAsync(&c->ctl->error, 0, sizeof(uint32_t), c->stream));
     if (!setUnitConstants(ZYG_CONST_SCENE, &s, sizeof(DScene), c->stream)) return -1;
@@ -1480,7 +1497,10 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     }
 
     // the wave-wide walk of the prop tables: plain instantiations only (no counters, no MESHL shapes / masks, no POOL)
-    const bool     utlas = c->uniform_tlas && c->uniform_tables && !c->stats && !c->mesh_lights && !c->masks && !c->pool_mode;
+    // (a tree that names a prop twice tests it twice, which can decide an exact tie between two props the other way: the precise
+    // units then walk the tree itself)
+    const bool     utlas = c->uniform_tlas && c->uniform_tables && !c->stats && !c->mesh_lights && !c->masks && !c->pool_mode &&
+                           (relaxedUnits(c) || !c->tables_deduplicated);
     const bool     wide = utlas && c->large_mesh;  // the wide-BLAS instantiations (relaxed units; the precise ones alias the BVH2 kernels)
     const uint32_t ticks = v.max_depth_surface + 1;  // one tick per path vertex
     const dim3     block(256);
