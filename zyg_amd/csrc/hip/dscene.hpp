@@ -82,7 +82,7 @@ struct DPortalLight {  // ZygpuPortalLight on the device
 // 17 props through the per-lane tree walk: 461 Msamples/s against 773 with 16 in the table (round 2); round 3's end: 947 / 867 / 436
 // at 16 / 28 / 32+ props with a table of 32 (the last through the tree), tools/prop_curve.sh
 #ifndef ZYG_UNIFORM_PROPS
-#define ZYG_UNIFORM_PROPS 64
+#define ZYG_UNIFORM_PROPS 96
 #endif
 constexpr uint32_t kUniformProps = ZYG_UNIFORM_PROPS;
 struct TlasEntry {
