@@ -1439,3 +1439,25 @@ def test_previous_vertex_packed_into_the_first_line(engine, oracle, variant):
     sd = engine.lib.su_ext_scene_desc().contents
     vd = engine.lib.su_ext_view_desc().contents
     assert np.array_equal(films[1, 1], oracle_render(oracle, sd, vd, spp))
+
+
+@pytest.mark.parametrize("extra", [26, 60])
+def test_many_props_past_the_first_table_size(engine, oracle, extra):
+    """Cornell with 33 / 67 solid props (plaques on the back wall).  The host's tree builder splits spatially, so the solid tree's
+    leaves name some props twice; the device's prop tables hold each prop once (96 at most).  The precise units walk the tree in
+    such a scene (a prop tested twice can decide an exact tie): the oracle's film and counters bit for bit; the relaxed units
+    walk the table: the same image within the contract."""
+    w, h, spp = 96, 64, 8
+    out = _render_both(engine, oracle, w, h, spp, integrator="PTMIS", nee_in_place=1, extra_props=extra)
+    _check(*out, spp)
+    sd = engine.lib.su_ext_scene_desc().contents
+    assert sd.solid.num_indices > len(set(sd.solid.indices[i] for i in range(sd.solid.num_indices))) == 7 + extra
+    ctx = engine.context()
+    assert engine.lib.zygpu_set_option(ctx, b"precise", 0) == 0
+    assert engine.lib.zygpu_clear_film(ctx, ctypes.c_float(0.0)) == 0
+    assert engine.lib.zygpu_render(ctx, 0, 0, spp, 0, h) == 0  # the same iterations again
+    engine.synchronize()
+    relaxed = engine.resolve(w, h)
+    assert engine.lib.zygpu_set_option(ctx, b"precise", 1) == 0
+    # (8 samples per pixel: a path that an ulp sends another way weighs 1 / 8 of its pixel; the contract's number is for 256 spp)
+    assert 0.0 < rms(relaxed, out[1]) <= 5e-3
