@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--box-triangles", type=int, default=12, choices=[12, 18, 48, 108, 972],
                     help="triangles of each of the two Cornell boxes (12 = BASELINE.json configs[1]); the others measure what a scene "
                          "just past the kernels' thresholds costs (meshes of at most 16 triangles are tested from the constant block)")
-    ap.add_argument("--extra-props", type=int, default=0, help="small Rectangle plaques on the back wall (the scene has 7 solid props without them; the prop tables hold 96)")
+    ap.add_argument("--extra-props", type=int, default=0, help="small Rectangle plaques on the back wall (the scene has 7 solid props without them; the prop tables hold 112)")
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1],
                     help="zygpu option fuse_trace_shade: wf_trace_shade (closest hit + first shading pass in one kernel, default) "
                          "or wf_intersect and wf_shade apart")

@@ -2,7 +2,7 @@
 . "$(dirname "$0")/common.sh"
 set +e
 O="$R/gpurun_out/prop_curve"; mkdir -p "$O"
-for n in 9 25 57 58 73 89 90; do
+for n in 9 25 57 89 105 106; do
   timeout 300 python3 bench.py --steps 8 --no-cpu-baseline --no-extra --extra-props $n > "$O/p$n.json" 2> "$O/p$n.err"
   python3 -c "
 import json,sys

@@ -1,6 +1,6 @@
 # usage: bash tools/threshold_edges.sh <tag>: configs[1] with its two boxes at 12 / 18 / 48 / 108 / 972 triangles each and with
 # 16 / 17 / 32 / 33 solid props: what a scene just past each of the kernels' thresholds costs (small_tris: meshes of <= 32
-# items; the wide BLAS: the meshes past that; the prop tables: <= 96 props, tools/prop_curve.sh goes past them).  ZYG_WIDE_MIN_TRIANGLES / ZYG_MESH_KERNEL_MIN_TRIANGLES move
+# items; the wide BLAS: the meshes past that; the prop tables: <= 112 props, tools/prop_curve.sh goes past them).  ZYG_WIDE_MIN_TRIANGLES / ZYG_MESH_KERNEL_MIN_TRIANGLES move
 # the thresholds for an experiment.
 . "$(dirname "$0")/common.sh"
 set +e

@@ -79,10 +79,11 @@ struct DPortalLight {  // ZygpuPortalLight on the device
 // A small top-level scene as a table in the __constant__ block itself (zygpu_upload_scene fills it when the solid props are
 // at most kUniformProps Rectangles and TriangleMeshes): every lane of a wave tests the same prop at the same time, the
 // prop's bounds and transformation arrive through the scalar cache in SGPRs (sceneIntersectUniform, sceneVisibilityUniform).
-// 17 props through the per-lane tree walk: 461 Msamples/s against 773 with 16 in the table (round 2); round 3's end: 947 / 867 / 436
-// at 16 / 28 / 32+ props with a table of 32 (the last through the tree), tools/prop_curve.sh
+// 17 props through the per-lane tree walk: 461 Msamples/s against 773 with 16 in the table (round 2); round 3's end
+// (tools/prop_curve.sh): from the table 949 / 836 / 613 / 465 / 393 / 321 at 16 / 32 / 64 / 96 / 112 / 128 props, through the tree
+// 436 / 456 / 394 / 396 at 33 / 65 / 97 / 129: the two meet at 112
 #ifndef ZYG_UNIFORM_PROPS
-#define ZYG_UNIFORM_PROPS 96
+#define ZYG_UNIFORM_PROPS 112
 #endif
 constexpr uint32_t kUniformProps = ZYG_UNIFORM_PROPS;
 struct TlasEntry {
