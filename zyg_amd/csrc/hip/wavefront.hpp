@@ -330,9 +330,11 @@ struct SectionTimer {
 // (configs[1]) run 512-thread blocks: half the appends (atomics), and the alive queue comes out in longer runs of neighbouring
 // paths: wf_trace_shade -1.1 %, wf_scatter -1 % against 256 in one call; 128: +6 %, 64: +90 %.  The wide-BLAS ones keep 256 (their
 // LDS stack is sized for it and their waves' walks differ more in length); for the others (-DZYG_TS_BLOCK_ALL=1) 512 measures the same
-// on the outdoor scene.
+// on the outdoor scene.  End of round 3: with the geometry tests in their own frames the kernel issues half the instructions, and what
+// a block of eight waves costs at the append's barriers outweighs the halved atomics: 1024 / 512 / 256 / 128 threads 964 / 989-997 /
+// 1009-1022 / 901 Msamples/s in one call each (wf_trace_shade 112.3 / 102.9-104.4 / 95.9-97.6 / 127.4 ms per 8 steps): 256 again.
 #ifndef ZYG_TS_BLOCK
-#define ZYG_TS_BLOCK 512
+#define ZYG_TS_BLOCK 256
 #endif
 #ifndef ZYG_TS_BLOCK_WIDE
 #define ZYG_TS_BLOCK_WIDE 256  // with -DZYG_LDS_STACK_THREADS=<the same> (dscene.hpp)
