@@ -7,7 +7,9 @@ each rank.  With the defaults (--steps 16, 16 iterations per step) one GPU rende
 Ranks shard the *iterations* of the frame (zyg_amd.distributed.ShardedFrame: rank r renders iterations
 [r*K*I, (r+1)*K*I), every (pixel, iteration) is independent); the scene is replicated, there is no data-path
 collective, and the per-rank films {sum w*rgb, sum w} are summed once per run with an RCCL reduce over xGMI.  Scaling is
-weak: per-GPU work is fixed.
+weak by default: per-GPU work is fixed.  `--spp-total N` fixes the whole job instead (strong scaling: BASELINE.json configs[3],
+1024 spp split over the ranks), sharded by `--shard iterations` (rank r renders N / world iterations of every row) or
+`--shard rows` (rank r renders all N iterations of its rows: the tile-sharded form, exact for the radius-0 sensor).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -81,10 +83,25 @@ def parse_args():
                     help="zygpu option pair_small: parallelogram halves of a small mesh as one item of the small-triangle table")
     ap.add_argument("--regen-kslots", type=int, default=0, help="zygpu option regen_kslots: slots of that pool in units of 1024 (0 = library default, 2048)")
     ap.add_argument("--batch-mpaths", type=int, default=0, help="zygpu option batch_mpaths (0 = library default)")
+    ap.add_argument("--shard", default="iterations", choices=["iterations", "rows"],
+                    help="how the ranks split the frame: its iterations (every rank renders all rows) or its rows (every rank renders all "
+                         "iterations of its own rows; always strong scaling: the frame's work is fixed)")
+    ap.add_argument("--spp-total", type=int, default=0,
+                    help="strong scaling: the whole job's samples per pixel, split over the ranks (and over --steps); 0 = weak scaling, "
+                         "--steps x --iters-per-step per rank")
+    ap.add_argument("--print-config", action="store_true", help="print bench_config() (the key a committed profile is quoted under) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed oracle sample (and again of the parity band)")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] (1 M-triangle mesh) measurement in `extra`")
-    return ap.parse_args()
+    args = ap.parse_args()
+    # strong scaling: the job's total spp is fixed, every rank renders its share of it in --steps steps
+    args.strong = bool(args.spp_total) or "rows" == args.shard
+    if args.spp_total:
+        per_rank = args.spp_total // (args.gpus if "iterations" == args.shard else 1)
+        if per_rank * (args.gpus if "iterations" == args.shard else 1) != args.spp_total or per_rank % args.steps:
+            ap.error(f"--spp-total {args.spp_total} must split evenly over {args.gpus} rank(s) and {args.steps} steps")
+        args.iters_per_step = per_rank // args.steps
+    return args
 
 
 def build_scene(eng, scenes, name, material, w, h, total_spp, box_triangles=12, extra_props=0):
@@ -104,8 +121,10 @@ def build_scene(eng, scenes, name, material, w, h, total_spp, box_triangles=12, 
                        extra_props=extra_props)
 
 
-def describe(name, material, w, h, ips, k, precise):
-    mode = "precise arithmetic (film bit-identical to the CPU oracle)" if precise else "relaxed arithmetic (RMS <= 1e-3 contract)"
+def describe(name, material, w, h, ips, k, relaxed):
+    """`relaxed`: the arithmetic the library really ran (zygpu_get_option "relaxed_units": a scene with Glass gets the precise
+    units whatever --precise says)."""
+    mode = "relaxed arithmetic (RMS <= 1e-3 contract)" if relaxed else "precise arithmetic (film bit-identical to the CPU oracle)"
     if name == "outdoor":
         return (f"outdoor scene (ground, 2 boxes (one glass), glass + gold Spheres, 999698-triangle mesh in polished iron, the Sky "
                 f"entity: sun with its radiance table + 1024^2 canopy image, both the procedural stand-in for the Prague bake), {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
@@ -121,14 +140,15 @@ def describe(name, material, w, h, ips, k, precise):
 class Measurement:
     """One scene on this rank's GPU: the stats iteration (algorithmic bytes), warm-up, the timed steps."""
 
-    def __init__(self, args, zyg_amd, scenes, torch, frame, device, scene, material, steps, warmup):
+    def __init__(self, args, zyg_amd, scenes, torch, frame, device, scene, material, steps, warmup, size=None):
         self.args, self.zyg_amd, self.torch, self.frame, self.device = args, zyg_amd, torch, frame, device
         self.scene, self.material, self.steps, self.warmup = scene, material, steps, warmup
-        self.w, self.h, self.ips = args.width, args.height, args.iters_per_step
+        self.w, self.h = size or (args.width, args.height)
+        self.ips = args.iters_per_step
         self.eng = zyg_amd.Engine()
         self.eng.set_device(device.index)
         main = scene == args.scene  # the variants' knobs are the main scene's
-        build_scene(self.eng, scenes, scene, material, self.w, self.h, frame.world * steps * self.ips,
+        build_scene(self.eng, scenes, scene, material, self.w, self.h, (frame.world if "iterations" == frame.mode else 1) * steps * self.ips,
                     args.box_triangles if main else 12, args.extra_props if main else 0)
         self.eng.start_frame(0)
         if not args.pair_small:  # read when the scene is uploaded (the context exists from the first frame on): upload again
@@ -151,7 +171,9 @@ class Measurement:
         if args.regen_kslots:
             self.eng.set_option("regen_kslots", args.regen_kslots)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)
-        self.fused = bool(args.fuse) and scene in ("cornell", "cornell_mesh", "cornell_mound")  # POOL scenes always run the kernels apart
+        self.pool_mode = bool(self.eng.get_option("pool_mode"))
+        self.relaxed = bool(self.eng.get_option("relaxed_units"))  # what really runs: Glass scenes get the precise units
+        self.fused = bool(args.fuse) and not self.pool_mode  # POOL scenes always run the kernels apart
         self.film = torch.zeros((self.h, self.w, 4), dtype=torch.float32, device=device)
         assert self.lib.zygpu_set_external_film(self.ctx, ctypes.c_void_p(self.film.data_ptr())) == 0
 
@@ -224,7 +246,9 @@ class Measurement:
         elapsed = self.frame.timed(body, lambda: self.torch.cuda.synchronize(self.device))
         ms, launches = dtmp(), ltmp()
         lib.zygpu_kernel_time(ctx, ms, launches, 0)
-        samples_rank = float(self.w) * self.h * self.ips * self.steps
+        _, _, y0, y1 = self.frame.step_range(0, self.ips, self.steps)
+        samples_rank = float(self.w) * (y1 - y0) * self.ips * self.steps
+        samples_job = samples_rank * self.frame.world if "iterations" == self.frame.mode else float(self.w) * self.h * self.ips * self.steps
         times = {nm: ms[i] for i, nm in enumerate(KERNELS)}
         counts = {nm: int(launches[i]) for i, nm in enumerate(KERNELS)}
         # option mesh_kernels on a scene with a large mesh: the in-place stage is wf_scatter_h (+ its resume launches, timed as
@@ -252,7 +276,7 @@ class Measurement:
             "rays_per_sample": {"extension": round(st.extension_rays / n_stat, 3), "shadow": round(st.shadow_rays / n_stat, 3),
                                 "nodes": round(st.nodes_fetched / n_stat, 2), "triangles": round(st.triangles_tested / n_stat, 2),
                                 "instances": round(st.instances_tested / n_stat, 2)},
-            "elapsed": elapsed, "value": samples_rank * self.frame.world / elapsed / 1e6, "dominant": dom[0],
+            "elapsed": elapsed, "value": samples_job / elapsed / 1e6, "dominant": dom[0],
             "avg_ms": avg_ms, "launches": dom[2], "achieved": achieved,
             "algorithmic_bytes_per_launch": dom[3] * per_launch, "state_bytes_per_launch": dom[4] * per_launch,
             "kernel_bytes_per_sample": dom[3], "kernel_state_bytes_per_sample": dom[4],
@@ -270,8 +294,31 @@ class Measurement:
 
 def bench_config(args):
     """The arguments a committed profile must have been taken with to be quoted for this run."""
-    return {"scene": args.scene, "material": args.material, "size": [args.width, args.height, args.iters_per_step],
-            "fuse": args.fuse, "nee": args.nee, "precise": args.precise, "batch_mpaths": args.batch_mpaths, "gpus": args.gpus}
+    cfg = {"scene": args.scene, "material": args.material, "size": [args.width, args.height, args.iters_per_step],
+           "fuse": args.fuse, "nee": args.nee, "precise": args.precise, "batch_mpaths": args.batch_mpaths, "gpus": args.gpus}
+    # every option that changes which kernels run, how they move their state, or the scene: named only when it is not at its
+    # default, so that a profile of the default configuration keeps its key and any other run is refused by it
+    defaults = parse_defaults()
+    for key in ("regenerate", "regen_kslots", "sort_alive", "pack_prev", "compact_blocks", "hit_by_queue", "mesh_kernels", "mesh_closest",
+                "pair_small", "box_triangles", "extra_props", "fuse_tick", "persistent", "shard", "spp_total"):
+        if getattr(args, key) != defaults[key]:
+            cfg[key] = getattr(args, key)
+    return cfg
+
+
+_DEFAULTS = None
+
+
+def parse_defaults():
+    global _DEFAULTS
+    if _DEFAULTS is None:
+        saved = sys.argv
+        sys.argv = [saved[0]]
+        try:
+            _DEFAULTS = vars(parse_args())
+        finally:
+            sys.argv = saved
+    return _DEFAULTS
 
 
 def committed_profile(args, name, kernel, source_hash):
@@ -450,6 +497,9 @@ def main():
     # set it before torch is imported
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
+    if args.print_config:
+        print(json.dumps(bench_config(args)))
+        return
     n = args.gpus
     if n > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -481,7 +531,7 @@ def main():
     grouped = n > 1 or bool(os.environ.get("ZYG_BENCH_GROUP"))
     dist = distributed.init_process_group(backend, rank, world, device) if grouped else None
     torch.cuda.set_device(device)
-    frame = distributed.ShardedFrame(rank, n, dist, "iterations", args.height)
+    frame = distributed.ShardedFrame(rank, n, dist, args.shard, args.height)
 
     m = Measurement(args, zyg_amd, scenes, torch, frame, device, args.scene, args.material, args.steps, args.warmup)
     r = m.run()
@@ -491,23 +541,13 @@ def main():
         traffic, source = committed_profile(args, "traffic.json", prof_kernel, source_hash)
         sq, sq_source = committed_profile(args, "pmc_sq.json", prof_kernel, source_hash)
         hbm_bytes = traffic["hbm_bytes_per_launch"] if traffic else None
-        # a measured ceiling beside the nominal peak: device-to-device copy of 2 GiB, read + written bytes
+        # a measured ceiling beside the nominal peak: the library's own float4 grid-stride copy kernel over 2 x 2 GiB
+        # (zygpu_measure_copy; MI355X_MICROARCH.md measures 6.29 TB/s in that shape), read + written bytes; torch's copy_ reaches
+        # ~4.9 TB/s on the same boxes and flattered `traffic_frac_of_measured_copy` until round 3
         copy_gbs = None
-        try:
-            src = torch.empty(1 << 29, dtype=torch.float32, device=device)
-            dst = torch.empty_like(src)
-            dst.copy_(src)
-            torch.cuda.synchronize(device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
-                dst.copy_(src)
-            e1.record()
-            torch.cuda.synchronize(device)
-            copy_gbs = round(4 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del src, dst
-        except RuntimeError:
-            pass
+        gbs = ctypes.c_double(0.0)
+        if 0 == m.lib.zygpu_measure_copy(m.ctx, ctypes.c_uint64(1 << 31), 4, ctypes.byref(gbs)) and gbs.value > 0:
+            copy_gbs = round(gbs.value, 1)
         weights = m.film[..., 3]
         seconds = r["avg_ms"] * 1e-3
         traffic_gbs = hbm_bytes / seconds / 1e9 if hbm_bytes else None
@@ -532,13 +572,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": describe(args.scene, args.material, args.width, args.height, args.iters_per_step, args.steps, args.precise),
-                       "scene": args.scene, "material": args.material, "arithmetic": "precise" if args.precise else "relaxed",
-                       "parallelism": f"iterations x{n}", "collective": (dist.get_backend() if dist else None)},
+            "config": {"workload": describe(args.scene, args.material, args.width, args.height, args.iters_per_step, args.steps, m.relaxed),
+                       "scene": args.scene, "material": args.material,
+                       # the arithmetic the library ran (zygpu_get_option "relaxed_units"), beside what was asked for
+                       "arithmetic": "relaxed" if m.relaxed else "precise", "arithmetic_requested": "precise" if args.precise else "relaxed",
+                       "parallelism": f"{args.shard} x{n}" + (f", {args.spp_total} spp in all (strong)" if args.spp_total else
+                                                             ", the frame's rows split (strong)" if "rows" == args.shard else " (weak)"),
+                       "spp_per_rank": args.steps * args.iters_per_step, "collective": (dist.get_backend() if dist else None)},
             # What bounds the dominant kernel, most believable figure first:
             #   hbm:    the bytes that really cross HBM.  `state_frac`: the ray / hit / state records it must move (B_q, B_sq of
             #           SURVEY 8(d), no traversal data) over its duration and the peak; `traffic_frac`: the HBM-side bytes rocprofv3
@@ -579,16 +623,20 @@ def main():
     # BASELINE.json configs[2] (the 1 M-triangle mesh in the box) in the same run, so that its number is witnessed by whoever
     # runs this file: fewer steps, same sizes, its own roofline figures and parity band.  cornell_mesh is the configuration
     # (SURVEY 8(d)'s closed displaced sphere hanging in the box), cornell_mound the lighter variant (the heightfield on the floor).
-    if 0 == rank and 1 == n and not args.no_extra and args.scene == "cornell":
+    if 0 == rank and 1 == n and not args.no_extra and args.scene == "cornell" and not args.strong:
         out["extra"] = {}
-        for name in ("cornell_mesh", "cornell_mound"):
-            m2 = Measurement(args, zyg_amd, scenes, torch, frame, device, name, "lambert", max(2, args.steps // 4), 1)
+        # configs[2] and its lighter variant at the run's size; configs[4]'s scene at its own 3840 x 2160 (depth 16, the Sky entity, glass
+        # and conductors: the POOL kernels) and the glass Cornell box at 1080p: each with its own roofline figures, parity band and
+        # the arithmetic the library really ran
+        for name, size in (("cornell_mesh", None), ("cornell_mound", None), ("outdoor", (3840, 2160)), ("cornell_glass", None)):
+            m2 = Measurement(args, zyg_amd, scenes, torch, frame, device, name, "lambert", max(2, args.steps // (8 if size else 4)), 1, size)
             r2 = m2.run()
             extra = {"value": round(r2["value"], 3), "unit": "Msamples/s", "steps": m2.steps, "ms_per_step": round(r2["elapsed"] / m2.steps * 1e3, 3),
-                     "workload": describe(name, "lambert", args.width, args.height, args.iters_per_step, m2.steps, args.precise),
+                     "workload": describe(name, "lambert", m2.w, m2.h, args.iters_per_step, m2.steps, m2.relaxed),
+                     "arithmetic": "relaxed" if m2.relaxed else "precise", "size": [m2.w, m2.h],
                      "kernel": r2["dominant"], "achieved": round(r2["achieved"], 2), "frac": round(r2["achieved"] / HBM_PEAK_GBS, 5),
                      "state_frac": round(r2["state_bytes_per_launch"] / (r2["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if r2["avg_ms"] else None,
-                     "avg_launch_ms": round(r2["avg_ms"], 5), "algorithmic_bytes_per_sample": round(r2["bytes_per_sample"], 1),
+                     "avg_launch_ms": round(r2["avg_ms"], 5), "launches": r2["launches"], "algorithmic_bytes_per_sample": round(r2["bytes_per_sample"], 1),
                      "state_bytes_per_sample": round(r2["state_bytes_per_sample"], 1), "kernel_ms": r2["kernel_ms"],
                      "per_kernel": r2["per_kernel"], "rays_per_sample": r2["rays_per_sample"],
                      "mesh_stage": "wf_scatter = wf_scatter_h + wf_shadow_u" if r2["mesh_stage"] else None}

@@ -532,8 +532,17 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * "pair_small" (default 1; read by zygpu_upload_scene) lets two triangles of a small mesh that make a parallelogram be tested as
  * one item by the relaxed-arithmetic kernels. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
+/* Reads an option back, and what the library derived from the options and the uploaded scene (valid after zygpu_upload_scene):
+ * "relaxed_units" 1 when the relaxed-arithmetic kernel units render this scene (option "precise" 0 and a scene they are inside
+ * the RMS contract for), 0 when the precise ones do whatever the option says; "pool_mode" 1 when the scene runs the POOL
+ * instantiations (Glass / shadow catchers: split paths, medium stack); "prop_tables" / "wide_blas" / "mesh_kernels_active":
+ * the prop-table walk, the four-wide BLAS and the persistent mesh kernels are what this scene renders with.
+ * bench.py reports `config.arithmetic` from it. -1: unknown name. */
+int zygpu_get_option(ZygpuContext* ctx, const char* name, int* out_value);
 
-/* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in precise arithmetic.
+/* Ray-level test hooks: n rays of 8 floats (o.xyz, min_t, d.xyz, max_t) against the uploaded scene, in the arithmetic option
+ * "precise" selects (the hooks live in kernel unit 7 of either mode; -1 when that unit is not in the build).  Modes 1-3 are
+ * compared with the oracle ray for ray only with precise = 1; the relaxed units' dump is bounded, not bit-equal.
  * mode 0: the reference's walk (top-level tree, BVH2); 1: the prop tables + BVH2; 2: the prop tables + the four-wide BLAS
  * re-layout; 3: the relaxed units' walk (2 without the tie rule between props, small meshes item by item from the
  * constant block, in their unit-triangle form) (modes 1-3 need a scene the tables hold: -1 otherwise).  hits: 8 words per ray (t, u, v as float bits,
@@ -545,6 +554,10 @@ int zygpu_test_visibility(ZygpuContext* ctx, uint32_t n, const float* rays, uint
  * i * stride_bytes (stride 16 / 64 / 128 / 256 / 512) of a zero-filled buffer of num_records records; average ms per launch.
  * Run under `rocprofv3 --pmc FETCH_SIZE` it calibrates that counter on the access shape of the path-state blocks. */
 int zygpu_calibrate_gather(ZygpuContext* ctx, uint32_t stride_bytes, uint32_t num_records, uint32_t repeats, double* out_ms_per_launch);
+/* The copy rate this device reaches (bench.py's measured ceiling beside the nominal 8 TB/s): `repeats` launches of a float4
+ * grid-stride copy kernel (2048 blocks of 256 threads, MI355X_MICROARCH.md's 6.29 TB/s shape) over two buffers of `bytes` each
+ * on the context's stream, timed with HIP events; out_gbs = read + written bytes per second / 1e9. */
+int zygpu_measure_copy(ZygpuContext* ctx, uint64_t bytes, uint32_t repeats, double* out_gbs);
 
 /* Counters accumulated since the last reset (only maintained when enabled). */
 int zygpu_enable_stats(ZygpuContext* ctx, int enabled);

@@ -206,6 +206,8 @@ def load_library(path=None):
     lib.zygpu_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     lib.zygpu_enable_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.zygpu_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    lib.zygpu_get_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    lib.zygpu_measure_copy.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
     lib.zygpu_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
     lib.zygpu_get_kernel_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
     lib.zygpu_kernel_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
@@ -303,6 +305,14 @@ class Engine:
         """zygpu_set_option on the engine's context (after start_frame): e.g. "precise", "nee_in_place"."""
         if self.lib.zygpu_set_option(self.context(), name.encode(), int(value)) != 0:
             raise RuntimeError("zygpu_set_option failed: " + (self.lib.zygpu_last_error() or b"").decode())
+
+    def get_option(self, name):
+        """zygpu_get_option: an option's value, or what the library derived for the uploaded scene ("relaxed_units", "pool_mode",
+        "prop_tables", "wide_blas", "mesh_kernels_active")."""
+        v = ctypes.c_int(0)
+        if self.lib.zygpu_get_option(self.context(), name.encode(), ctypes.byref(v)) != 0:
+            raise RuntimeError("zygpu_get_option failed: " + (self.lib.zygpu_last_error() or b"").decode())
+        return v.value
 
     # --- resources / scene ---
     def material(self, json_text, id=NULL):

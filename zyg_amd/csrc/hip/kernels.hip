@@ -11,9 +11,11 @@
 #endif
 #if (4 == ZYG_TU || 5 == ZYG_TU) && !defined(ZYG_LDS_STACK)
 // unit 4, the persistent kernels: their LDS holds the path states, the wide walks' stack stays in scratch.  Unit 5, wf_tick: one
-// block runs the any-hit walk (one word per parked child) and the closest-hit walk (two words) with no barrier between them, and
-// the two entry layouts of dscene.hpp WideStack share one LDS array: a wave still in its shadow rays and a wave already in the
-// next closest-hit walk would overwrite each other's entries.  In scratch every lane's stack is its own.
+// block runs the any-hit walk (one word per parked child, dscene.hpp wideStackLdsAny) and the closest-hit walk (two words,
+// wideStackLds).  The two layouts are separate LDS arrays since round 3, so the hazard that put this unit's stack in scratch (a
+// wave still in its shadow rays and a wave already in the next closest-hit walk overwriting each other) is gone; both arrays
+// together are 48 KB per 256-thread block though, which would take wf_tick from its 2-3 blocks per CU to one, and the kernel is
+// an option that measured slower than the tick loop either way: it keeps its stack in scratch.
 #define ZYG_LDS_STACK 0
 #endif
 

@@ -290,6 +290,12 @@ __global__ void __launch_bounds__(256) calib_gather(const char* data, uint32_t n
     if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u) sink[0] = i;  // never true for the zero-filled buffer: keeps the load alive
 }
 
+// bench.py's measured ceiling: a float4 grid-stride copy (MI355X_MICROARCH.md: 6.29 TB/s on this part in that shape)
+__global__ void __launch_bounds__(256) copy_float4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    const size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -444,6 +450,7 @@ struct ZygpuContext {
     Pool          regen_pool{};           // the regenerating kernels' pool: every record in an array of its own (wavefront.hpp wf_rtrace)
     uint32_t*     regen_sample = nullptr;
     size_t        regen_slots = 0;
+    uint32_t      alive_keys_allocated = 0;  // sub-queues the alive queue's array holds (1 or kAliveKeys)
     size_t        pool_capacity = 0;      // paths
     uint32_t      pool_rounds = 0;        // NEE rounds the pick buffer holds
     uint32_t      num_lights = 0;
@@ -575,10 +582,18 @@ bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out
     return ok;
 }
 
-int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
-    if (slots <= c->pool_capacity && rounds <= c->pool_rounds && c->pool_mode == c->pool_allocated && c->catchers == c->catchers_allocated) return 0;
+// `alive_keys`: sub-queues the alive queue must hold (1, or kAliveKeys when the sorted alive queue will run); `hit_q`: the hit records
+// by alive-queue position are wanted (option hit_by_queue in a scene that can use them).  Both are only allocated when asked for:
+// at the default batch the 16 sub-queues are 1.9 GiB and hit_q 1 GiB per context.
+int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_keys, bool hit_q) {
+    if (slots <= c->pool_capacity && rounds <= c->pool_rounds && c->pool_mode == c->pool_allocated && c->catchers == c->catchers_allocated &&
+        alive_keys <= c->alive_keys_allocated && (!hit_q || c->hit_q))
+        return 0;
     slots = std::max(slots, c->pool_capacity);
     rounds = std::max(rounds, c->pool_rounds);
+    alive_keys = std::max(alive_keys, c->alive_keys_allocated);
+    hit_q = hit_q || nullptr != c->hit_q;
+    c->hit_q = nullptr;
     HIP_OK(hipStreamSynchronize(c->stream));
     c->pool_mem.release();
     DeviceBuffers& m = c->pool_mem;
@@ -632,12 +647,12 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
 #endif
     ok = ok && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) &&
          m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) &&
-         m.alloc(qcap * (c->pool_mode ? 1u : kAliveKeys), &c->queues.alive) &&  // a whole queue per sub-queue of the sorted alive queue: any one may get every path
+         m.alloc(qcap * alive_keys, &c->queues.alive) &&  // a whole queue per sub-queue of the sorted alive queue: any one may get every path
          m.alloc(paths, &c->stage_color) && m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) &&
          m.alloc(paths, &p.sh_o) && m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
          m.alloc(slots, &p.time) &&
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy) &&
-         (c->pool_mode || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
+         (!hit_q || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
     if (ok && c->pool_mode) {
         ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) && m.alloc(paths, &p.rec_uv) &&
              m.alloc(slots, &p.pstate) && m.alloc(slots, &p.transp);
@@ -651,10 +666,13 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds) {
     if (!ok) {
         c->pool_capacity = 0;
         c->pool_rounds = 0;
+        c->alive_keys_allocated = 0;
+        c->hit_q = nullptr;
         return -1;
     }
     c->pool_capacity = slots;
     c->pool_rounds = rounds;
+    c->alive_keys_allocated = alive_keys;
     c->pool_allocated = c->pool_mode;
     c->catchers_allocated = c->catchers;
     return 0;
@@ -1443,7 +1461,10 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
     const uint32_t rounds = nee ? std::min<uint32_t>(c->num_lights, 64u) : 0u;
-    if (0 != ensurePool(c, npix * per_batch, rounds)) return -1;
+    // (supersets of the conditions the batch loop below decides with: what may run must have its arrays)
+    const bool want_sorted = !c->pool_mode && (c->sort_alive > 0 || (c->sort_alive < 0 && c->large_mesh && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels));
+    const bool want_hit_q = c->hit_by_queue && !c->pool_mode;
+    if (0 != ensurePool(c, npix * per_batch, rounds, want_sorted ? kAliveKeys : 1u, want_hit_q)) return -1;
     // AOVs: the staged aov.Value of every sample, and the kernel instantiations that write it (the MESHL ones)
     struct MeshlOverride {
         ZygpuContext* c;
@@ -1994,6 +2015,36 @@ int zygpu_calibrate_gather(ZygpuContext* c, uint32_t stride_bytes, uint32_t num_
     return rc;
 }
 
+int zygpu_measure_copy(ZygpuContext* c, uint64_t bytes, uint32_t repeats, double* out_gbs) {
+    if (!c || !out_gbs || bytes < 16 || 0 == repeats) return -1;
+    HIP_OK(hipSetDevice(c->device));
+    float4 *src = nullptr, *dst = nullptr;
+    const size_t n = size_t(bytes / 16);
+    if (hipSuccess != hipMalloc(reinterpret_cast<void**>(&src), n * 16) || hipSuccess != hipMalloc(reinterpret_cast<void**>(&dst), n * 16)) {
+        if (src) (void)hipFree(src);
+        g_error = "zygpu_measure_copy: out of device memory";
+        return -1;
+    }
+    HIP_OK(hipMemsetAsync(src, 0, n * 16, c->stream));
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    const dim3 grid(2048), block(256);
+    hipLaunchKernelGGL(copy_float4, grid, block, 0, c->stream, src, dst, n);  // warm-up
+    (void)hipEventRecord(a, c->stream);
+    for (uint32_t r = 0; r < repeats; ++r) hipLaunchKernelGGL(copy_float4, grid, block, 0, c->stream, src, dst, n);
+    (void)hipEventRecord(b, c->stream);
+    float ms = 0.f;
+    int   rc = 0;
+    if (!check(hipStreamSynchronize(c->stream), "copy_float4") || !check(hipEventElapsedTime(&ms, a, b), "hipEventElapsedTime")) rc = -1;
+    *out_gbs = ms > 0.f ? 2.0 * double(n) * 16.0 * repeats / (double(ms) * 1e-3) / 1e9 : 0.0;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    return rc;
+}
+
 int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     if (!c || !name) return -1;
     if (0 == std::strcmp(name, "kernel_timing")) {
@@ -2079,6 +2130,43 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->nee_in_place = 0 != value;
         return 0;
     }
+    g_error = std::string("unknown option ") + name;
+    return -1;
+}
+
+int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
+    if (!c || !name || !out) return -1;
+    const bool utlas = c->uniform_tlas && c->uniform_tables && !c->stats && !c->mesh_lights && !c->masks && !c->pool_mode &&
+                       (relaxedUnits(c) || !c->tables_deduplicated);
+    const struct {
+        const char* name;
+        int         value;
+    } table[] = {{"relaxed_units", relaxedUnits(c) ? 1 : 0},
+                 {"pool_mode", c->pool_mode ? 1 : 0},
+                 {"prop_tables", utlas ? 1 : 0},
+                 {"wide_blas", (utlas && c->large_mesh && relaxedUnits(c)) ? 1 : 0},
+                 {"mesh_kernels_active", (utlas && c->large_mesh && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels && c->nee_in_place && !c->multi_sample_lights) ? 1 : 0},
+                 {"precise", c->relaxed ? 0 : 1},
+                 {"batch_mpaths", int(c->batch_mpaths)},
+                 {"fuse_trace_shade", c->fuse_trace_shade ? 1 : 0},
+                 {"nee_in_place", c->nee_in_place ? 1 : 0},
+                 {"mesh_kernels", c->mesh_kernels ? 1 : 0},
+                 {"mesh_closest", c->mesh_closest ? 1 : 0},
+                 {"sort_alive", c->sort_alive},
+                 {"pack_prev", c->pack_prev ? 1 : 0},
+                 {"hit_by_queue", c->hit_by_queue ? 1 : 0},
+                 {"compact_blocks", c->compact_blocks ? 1 : 0},
+                 {"pair_small", c->pair_small ? 1 : 0},
+                 {"regenerate", c->regenerate ? 1 : 0},
+                 {"persistent", c->persistent ? 1 : 0},
+                 {"fuse_tick", c->fuse_tick ? 1 : 0},
+                 {"uniform_tlas", c->uniform_tlas ? 1 : 0},
+                 {"tick_sync", c->tick_sync ? 1 : 0}};
+    for (const auto& e : table)
+        if (0 == std::strcmp(name, e.name)) {
+            *out = e.value;
+            return 0;
+        }
     g_error = std::string("unknown option ") + name;
     return -1;
 }

@@ -259,6 +259,15 @@ std::string Engine::resolveFile(const std::string& name) const {  // file/system
 }
 
 uint32_t Engine::loadImageFile(const std::string& name, uint32_t usage, const std::string& swizzle_in, bool invert) {
+    // a file's sizes are bounded by the readers, but an allocation can still fail: no exception leaves through the extern "C" entries
+    try {
+        return loadImageFileUnguarded(name, usage, swizzle_in, invert);
+    } catch (const std::exception& e) {
+        return file_error = "\"" + name + "\": " + e.what(), ZYGPU_NULL;
+    }
+}
+
+uint32_t Engine::loadImageFileUnguarded(const std::string& name, uint32_t usage, const std::string& swizzle_in, bool invert) {
     // texture_provider.zig:42-51: the usage's default swizzle
     static const char* const kDefault[5] = {"XYZ", "XYZ", "XY", "W", "X"};
     const std::string swizzle = swizzle_in.empty() ? std::string(kDefault[std::min<uint32_t>(usage, 4u)]) : swizzle_in;

@@ -114,6 +114,7 @@ class Engine {
     std::string              file_error;
     std::string resolveFile(const std::string& name) const;
     uint32_t    loadImageFile(const std::string& name, uint32_t usage, const std::string& swizzle, bool invert);
+    uint32_t    loadImageFileUnguarded(const std::string& name, uint32_t usage, const std::string& swizzle, bool invert);
     uint32_t createImage(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height, uint32_t depth,
                          uint32_t pixel_stride, const uint8_t* data);
     uint32_t createMaterial(uint32_t id, const JsonValue& v);  // returns id or ZYGPU_NULL

@@ -55,7 +55,10 @@ inline bool readPng(const std::string& file, int& width, int& height, int& chann
         at += 12 + size_t(length);
     }
     if (!header || width <= 0 || height <= 0) return error = "a PNG without a header", false;
+    // sizes come from the file: bound them before anything is allocated from them (a deflate stream expands at most ~1032 times)
+    if (width > 65536 || height > 65536) return error = "a PNG larger than 65536 pixels on a side", false;
     const size_t         row = size_t(width) * size_t(channels);
+    if ((row + 1) * size_t(height) > 1032 * idat.size() + 65536) return error = "the PNG's image data does not inflate to its size", false;
     std::vector<uint8_t> raw((row + 1) * size_t(height));
     uLongf               raw_size = uLongf(raw.size());
     if (Z_OK != uncompress(raw.data(), &raw_size, reinterpret_cast<const Bytef*>(idat.data()), uLong(idat.size())) || raw_size != raw.size())
@@ -242,6 +245,11 @@ inline bool readExr(const std::string& file, uint32_t channels_wanted, bool colo
     }
     if (data_window[0] < display_window[0] || data_window[1] < display_window[1] || data_window[2] > display_window[2] || data_window[3] > display_window[3])
         return error = "an OpenEXR data window that is not inside the display window", false;
+    // the windows come from the file: the reference traps on what follows, here it is refused (origins at or above 0, a window that is
+    // not empty, sizes that fit the arithmetic below)
+    if (display_window[0] != 0 || display_window[1] != 0 || data_window[2] < data_window[0] || data_window[3] < data_window[1] ||
+        display_window[2] >= 65536 || display_window[3] >= 65536)
+        return error = "an OpenEXR display window that does not start at the origin, an empty data window, or an image larger than 65536 pixels on a side", false;
     if (formats.empty()) return error = "an OpenEXR file without channels", false;
     for (uint32_t f : formats)
         if (f != formats[0]) return error = "an OpenEXR file with mixed channel formats", false;
@@ -255,16 +263,20 @@ inline bool readExr(const std::string& file, uint32_t channels_wanted, bool colo
     const uint32_t w = uint32_t(data_window[2] - data_window[0] + 1), h = uint32_t(data_window[3] - data_window[1] + 1);
     width = display_window[2] - display_window[0] + 1;
     height = display_window[3] - display_window[1] + 1;
-    const uint32_t bytes_per_pixel = file_channels * (half ? 2u : 4u), bytes_per_row = w * bytes_per_pixel, rows_per_block = 16u;
+    if (file_channels > 64) return error = "an OpenEXR file with more than 64 channels", false;
+    const uint32_t bytes_per_pixel = file_channels * (half ? 2u : 4u), bytes_per_row = w * bytes_per_pixel, rows_per_block = 16u;  // < 2^16 * 2^8
     const uint32_t blocks = (h + rows_per_block - 1u) / rows_per_block;
     at += size_t(blocks) * 8;  // the line offset table
+    if (at > file.size()) return error = "an OpenEXR file shorter than its line offset table", false;
     out.assign(size_t(width) * size_t(height) * channels, 0.f);
     std::vector<unsigned char> packed(size_t(bytes_per_row) * rows_per_block), plain(packed.size());
     const uint32_t r_o = file_channels - 1u, g_o = file_channels >= 2 ? file_channels - 2u : 0u, b_o = file_channels >= 3 ? file_channels - 3u : 0u;
     for (uint32_t b = 0; b < blocks; ++b) {
         uint32_t row = 0, size = 0;
         if (!read32(&row) || !read32(&size) || at + size > file.size() || size > packed.size()) return error = "a broken OpenEXR scan-line block", false;
-        const uint32_t rows_here = std::min<uint32_t>(uint32_t(height) - row, rows_per_block);
+        // a block's first row is a file value too: it must lie in the data window (the rows below it that the window still holds)
+        if (int64_t(int32_t(row)) < data_window[1] || int64_t(int32_t(row)) > data_window[3]) return error = "an OpenEXR scan-line block outside the data window", false;
+        const uint32_t rows_here = std::min<uint32_t>(uint32_t(data_window[3]) + 1u - row, rows_per_block);
         const size_t   bytes_here = size_t(rows_here) * bytes_per_row;
         if (size < packed.size()) {
             uLongf n = uLongf(plain.size());
