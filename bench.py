@@ -90,6 +90,8 @@ def parse_args():
                     help="strong scaling: the whole job's samples per pixel, split over the ranks (and over --steps); 0 = weak scaling, "
                          "--steps x --iters-per-step per rank")
     ap.add_argument("--print-config", action="store_true", help="print bench_config() (the key a committed profile is quoted under) and exit")
+    ap.add_argument("--pool-relaxed", type=int, default=0, choices=[0, 1],
+                    help="zygpu option pool_relaxed: with --precise 0 the scenes with Glass run the relaxed units too (default: they get the precise ones)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the timed oracle sample (and again of the parity band)")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] (1 M-triangle mesh) measurement in `extra`")
@@ -146,6 +148,7 @@ class Measurement:
         self.w, self.h = size or (args.width, args.height)
         self.ips = args.iters_per_step
         self.eng = zyg_amd.Engine()
+        self.eng.log_to(sys.stderr)  # stdout carries the one JSON line and nothing else
         self.eng.set_device(device.index)
         main = scene == args.scene  # the variants' knobs are the main scene's
         build_scene(self.eng, scenes, scene, material, self.w, self.h, (frame.world if "iterations" == frame.mode else 1) * steps * self.ips,
@@ -158,6 +161,7 @@ class Measurement:
         if args.batch_mpaths:
             self.eng.set_option("batch_mpaths", args.batch_mpaths)
         self.eng.set_option("fuse_trace_shade", args.fuse)
+        self.eng.set_option("pool_relaxed", args.pool_relaxed)
         self.eng.set_option("precise", args.precise)
         self.eng.set_option("persistent", args.persistent)
         self.eng.set_option("fuse_tick", args.fuse_tick)
@@ -234,7 +238,7 @@ class Measurement:
 
         def body():
             for s in range(self.steps):
-                self.frame.render_step(self.render, s, self.ips, self.steps)
+                self.frame.render_step(self.render, s, self.ips, self.steps, self.h)
             self.eng.synchronize()
             if self.frame.world > 1 and "gloo" == self.frame.dist.get_backend():  # test set-up only: through host copies
                 host = self.film.cpu()
@@ -246,7 +250,7 @@ class Measurement:
         elapsed = self.frame.timed(body, lambda: self.torch.cuda.synchronize(self.device))
         ms, launches = dtmp(), ltmp()
         lib.zygpu_kernel_time(ctx, ms, launches, 0)
-        _, _, y0, y1 = self.frame.step_range(0, self.ips, self.steps)
+        _, _, y0, y1 = self.frame.step_range(0, self.ips, self.steps, self.h)
         samples_rank = float(self.w) * (y1 - y0) * self.ips * self.steps
         samples_job = samples_rank * self.frame.world if "iterations" == self.frame.mode else float(self.w) * self.h * self.ips * self.steps
         times = {nm: ms[i] for i, nm in enumerate(KERNELS)}
@@ -300,7 +304,7 @@ def bench_config(args):
     # default, so that a profile of the default configuration keeps its key and any other run is refused by it
     defaults = parse_defaults()
     for key in ("regenerate", "regen_kslots", "sort_alive", "pack_prev", "compact_blocks", "hit_by_queue", "mesh_kernels", "mesh_closest",
-                "pair_small", "box_triangles", "extra_props", "fuse_tick", "persistent", "shard", "spp_total"):
+                "pair_small", "box_triangles", "extra_props", "fuse_tick", "persistent", "shard", "spp_total", "pool_relaxed"):
         if getattr(args, key) != defaults[key]:
             cfg[key] = getattr(args, key)
     return cfg

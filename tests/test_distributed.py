@@ -166,7 +166,7 @@ def test_bench_py_two_ranks_end_to_end():
     outs = {launcher: _bench_two_ranks(launcher) for launcher in ("torchrun", "self")}
     for out in outs.values():
         assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-        assert out["config"]["parallelism"] == "iterations x2" and out["config"]["collective"] == "gloo"
+        assert out["config"]["parallelism"] == "iterations x2 (weak)" and out["config"]["collective"] == "gloo"
         # two ranks x 2 steps x 4 iterations, summed into rank 0's film
         assert out["film_weight_min_max"] == [16.0, 16.0]
         assert "cpu_baseline" not in out  # rank 0 at N = 1 only

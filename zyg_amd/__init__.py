@@ -239,6 +239,10 @@ class Engine:
 
     def release(self):
         if self.lib is not None:
+            if self._log is not None:  # the callback dies with this object: the library must not keep its address
+                self.lib.su_register_log.argtypes = [LOG_CALLBACK]
+                self.lib.su_register_log(LOG_CALLBACK())
+                self._log = None
             self.lib.su_release()
             self.lib = None
 
@@ -305,6 +309,15 @@ class Engine:
         """zygpu_set_option on the engine's context (after start_frame): e.g. "precise", "nee_in_place"."""
         if self.lib.zygpu_set_option(self.context(), name.encode(), int(value)) != 0:
             raise RuntimeError("zygpu_set_option failed: " + (self.lib.zygpu_last_error() or b"").decode())
+
+    def log_to(self, stream):
+        """su_register_log (capi.zig:128-141): the library's log lines (the reference prints them on stdout) go to `stream` instead,
+        e.g. sys.stderr for a program whose stdout is data (bench.py's one JSON line)."""
+        def forward(level, text):
+            stream.write(("Error: " if level >= 2 else "Warning: " if 1 == level else "") + (text or b"").decode(errors="replace") + "\n")
+        self._log = LOG_CALLBACK(forward)  # kept alive with the engine
+        self.lib.su_register_log.argtypes = [LOG_CALLBACK]
+        self.lib.su_register_log(self._log)
 
     def get_option(self, name):
         """zygpu_get_option: an option's value, or what the library derived for the uploaded scene ("relaxed_units", "pool_mode",

@@ -2605,113 +2605,153 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             // A shape's sampleTo draws all of its light samples before the first shadow test (rectangle.zig:321-352,
             // triangle_mesh.zig:513-592); instead of buffering them, a copy of the sampler replays those draws while
             // the path's sampler runs ahead to where the post-visibility draws continue.
-            if (MESHL && ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {
-                // Light.propSamplePortalTo (light.zig:217-240) -> Rectangle.samplePortalTo (rectangle.zig:458-513): the window the
-                // point sees the portal through, then the map's windowed distribution; no window, no draw
-                const DPortalLight& pl = s.portal_lights[light.sampler];
-                Bounds2             bounds;
-                if (portalImageBounds(sf.p, trafo, bounds)) {
-                    const uint32_t n = numSamples(light.num_samples, sample_threshold);
-                    const Trafo    dome = loadTrafo(s, s.lights[pl.light_link].prop);  // (the host refuses an animated link)
-                    Sampler        replay = h.smp;
-                    for (uint32_t j = 0; j < n; ++j) {
+            if (MESHL) {
+                // The instantiations that know every light kind: `connect` (the shadow ray's walk through every shape, the light's
+                // radiance, the complete closure's evaluation) is expanded at ONE place, behind a switch that only makes the light
+                // sample.  With one expansion per light kind (ten of them) wf_scatter<.., MESHL, POOL> was 1.16 MB of code with 886
+                // spilled registers: every wave's instruction stream missed the 64 KB instruction cache (profiles/r04a_*).
+                // Phase 1 decides how many samples the light takes and moves the path's sampler past the draws sampleTo makes before
+                // the first shadow test; phase 2 makes sample j from the replayed draws.  The per-light set-up (SphQuad, cone frame,
+                // chord, portal window) is made again in phase 2 instead of being carried across `connect`, whose registers it
+                // would add to: a light takes one sample but for the emittance's num_samples.
+                enum : uint32_t { LK_NONE, LK_PORTAL, LK_IMAGE_FLAT, LK_IMAGE_SPHERE, LK_IMAGE_CANOPY, LK_MESH, LK_INFINITE, LK_SPHERE, LK_DISK, LK_RECTANGLE };
+                uint32_t lk = LK_NONE, n = 0;
+                Sampler  replay = h.smp;
+                float    mesh_r = 0.f;
+                auto     advance2D = [&](uint32_t count) {
+                    for (uint32_t j = 0; j < count; ++j) {
                         float a, b;
                         h.smp.sample2D(a, b);
                     }
-                    for (uint32_t j = 0; j < n; ++j) {
-                        float r0, r1;
-                        replay.sample2D(r0, r1);
-                        SampleTo ls;
-                        if (rectangleSamplePortal(pl, dome, bounds, r0, r1, float(n), sf.p, ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
+                };
+                if (ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {
+                    // Light.propSamplePortalTo (light.zig:217-240) -> Rectangle.samplePortalTo (rectangle.zig:458-513): the window the
+                    // point sees the portal through, then the map's windowed distribution; no window, no draw
+                    Bounds2 bounds;
+                    if (portalImageBounds(sf.p, trafo, bounds)) {
+                        lk = LK_PORTAL;
+                        n = numSamples(light.num_samples, sample_threshold);
+                        advance2D(n);
                     }
-                }
-            } else if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
-                // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
-                const DImageLight& il = s.image_lights[light.sampler];
-                if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape || ZYGPU_SHAPE_DISK == light_shape) {
-                    const uint32_t n = numSamples(light.num_samples, sample_threshold);
-                    Sampler        replay = h.smp;
-                    for (uint32_t j = 0; j < n; ++j) {
-                        float a, b;
-                        h.smp.sample2D(a, b);
+                } else if (ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
+                    // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
+                    if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape || ZYGPU_SHAPE_DISK == light_shape) {
+                        lk = LK_IMAGE_FLAT;
+                        n = numSamples(light.num_samples, sample_threshold);
+                        advance2D(n);
+                    } else {
+                        lk = ZYGPU_SHAPE_SPHERE == light_shape ? LK_IMAGE_SPHERE : LK_IMAGE_CANOPY;  // one sample, drawn from the path's sampler
+                        n = 1;
                     }
-                    for (uint32_t j = 0; j < n; ++j) {
-                        float r0, r1;
-                        replay.sample2D(r0, r1);
-                        SampleTo   ls;
-                        const bool got = ZYGPU_SHAPE_DOME == light_shape
-                                             ? domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)
-                                         : ZYGPU_SHAPE_DISK == light_shape
-                                             ? diskSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)
-                                             : rectangleSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided,
-                                                                       ms.translucent, ls);
-                        if (got) connect(ls);
-                    }
+                } else if (kNull != light.sampler) {
+                    const DMeshLight&      ml = s.mesh_lights[light.sampler];
+                    const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
+                    mesh_r = h.smp.sample1D();
+                    const LightTree ptree{s, ml.tree};
+                    replay = h.smp;
+                    lk = LK_MESH;
+                    n = ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, mesh_r, sample_threshold, [](uint32_t, LightPick) {});
+                    advance2D(n);
+                } else if (distant) {
+                    lk = LK_INFINITE;
+                    n = 1;
                 } else if (ZYGPU_SHAPE_SPHERE == light_shape) {
-                    SampleTo ls;
-                    if (sphereSampleMaterialTo(il, sf.p, ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
+                    const uint32_t      ns = numSamples(light.num_samples, sample_threshold);
+                    const SphereSampler ss = SphereSampler::init(sf.p, trafo, ns);
+                    if (ss.valid) {  // sphere.zig:331-337: a point inside the sphere takes no sample and no draw
+                        lk = LK_SPHERE;
+                        n = ns;
+                        advance2D(n);
+                    }
+                } else if (ZYGPU_SHAPE_DISK == light_shape) {
+                    const uint32_t    ns = numSamples(light.num_samples, sample_threshold);
+                    const DiskSampler ds = DiskSampler::init(sf.p, trafo, ns);
+                    if (ds.valid) {  // disk.zig:273-276: no sample, no draw
+                        // a sample's second draw depends on its first: the path's sampler runs the sampling once for its
+                        // draws alone, the copy once more for the samples
+                        lk = LK_DISK;
+                        n = ns;
+                        for (uint32_t j = 0; j < n; ++j) {
+                            SampleTo ls;
+                            ds.sample(h.smp, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                        }
+                    }
                 } else {
+                    lk = LK_RECTANGLE;
+                    n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
+                    if (MULTI) advance2D(n);
+                }
+                for (uint32_t j = 0; j < n; ++j) {
                     SampleTo ls;
-                    if (canopySampleMaterialTo(il, ms.geo_n, trafo, ms.translucent, h.smp, ls)) connect(ls);
-                }
-            } else if (MESHL && kNull != light.sampler) {
-                const DMeshLight&      ml = s.mesh_lights[light.sampler];
-                const DMesh&           mesh = s.meshes[ml.mesh];
-                const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
-                const float            r = h.smp.sample1D();
-                const LightTree        ptree{s, ml.tree};
-                Sampler                replay = h.smp;
-                const uint32_t         npicks =
-                    ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [](uint32_t, LightPick) {});
-                for (uint32_t j = 0; j < npicks; ++j) {
-                    float a, b;
-                    h.smp.sample2D(a, b);
-                }
-                ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, r, sample_threshold, [&](uint32_t, LightPick tri) {
-                    float r0, r1;
-                    replay.sample2D(r0, r1);
-                    SampleTo ls;
-                    if (msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
-                });
-            } else if (distant) {
-                SampleTo   ls;
-                const bool got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(ms.geo_n, ms.translucent, h.smp, ls)
-                                 : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)
-                                                                     : distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls);
-                if (got) connect(ls);
-            } else if (ZYGPU_SHAPE_SPHERE == light_shape) {
-                const uint32_t      n = numSamples(light.num_samples, sample_threshold);
-                const SphereSampler ss = SphereSampler::init(sf.p, trafo, n);
-                if (ss.valid) {  // sphere.zig:331-337: a point inside the sphere takes no sample and no draw
-                    Sampler replay = h.smp;
-                    for (uint32_t j = 0; j < n; ++j) {
-                        float a, b;
-                        h.smp.sample2D(a, b);
+                    bool     got = false;
+                    switch (lk) {
+                        case LK_PORTAL: {
+                            const DPortalLight& pl = s.portal_lights[light.sampler];
+                            const Trafo         dome = loadTrafo(s, s.lights[pl.light_link].prop);  // (the host refuses an animated link)
+                            Bounds2             bounds;
+                            portalImageBounds(sf.p, trafo, bounds);
+                            float r0, r1;
+                            replay.sample2D(r0, r1);
+                            got = rectangleSamplePortal(pl, dome, bounds, r0, r1, float(n), sf.p, ms.geo_n, trafo, ms.translucent, ls);
+                            break;
+                        }
+                        case LK_IMAGE_FLAT: {
+                            const DImageLight& il = s.image_lights[light.sampler];
+                            float              r0, r1;
+                            replay.sample2D(r0, r1);
+                            got = ZYGPU_SHAPE_DOME == light_shape
+                                      ? domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)
+                                  : ZYGPU_SHAPE_DISK == light_shape
+                                      ? diskSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)
+                                      : rectangleSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                            break;
+                        }
+                        case LK_IMAGE_SPHERE: got = sphereSampleMaterialTo(s.image_lights[light.sampler], sf.p, ms.geo_n, trafo, ms.translucent, h.smp, ls); break;
+                        case LK_IMAGE_CANOPY: got = canopySampleMaterialTo(s.image_lights[light.sampler], ms.geo_n, trafo, ms.translucent, h.smp, ls); break;
+                        case LK_MESH: {
+                            const DMeshLight&      ml = s.mesh_lights[light.sampler];
+                            const DMesh&           mesh = s.meshes[ml.mesh];
+                            const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
+                            const LightTree        ptree{s, ml.tree};
+                            LightPick              tri{};
+                            // the primitive tree's picks again, keeping the j-th (they are a function of (point, normal, r) alone)
+                            ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, mesh_r, sample_threshold, [&](uint32_t k, LightPick t) {
+                                if (k == j) tri = t;
+                            });
+                            float r0, r1;
+                            replay.sample2D(r0, r1);
+                            got = msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                            break;
+                        }
+                        case LK_INFINITE:
+                            got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(ms.geo_n, ms.translucent, h.smp, ls)
+                                  : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)
+                                                                      : distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls);
+                            break;
+                        case LK_SPHERE: {
+                            const SphereSampler ss = SphereSampler::init(sf.p, trafo, n);
+                            float               s0, s1;
+                            replay.sample2D(s0, s1);
+                            got = ss.sample(s0, s1, sf.p, ms.geo_n, trafo, ms.translucent, ls);
+                            break;
+                        }
+                        case LK_DISK: {
+                            const DiskSampler ds = DiskSampler::init(sf.p, trafo, n);
+                            got = ds.sample(replay, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                            break;
+                        }
+                        default: {  // LK_RECTANGLE
+                            const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
+                            float                  u0, u1;
+                            if (MULTI) replay.sample2D(u0, u1);
+                            else h.smp.sample2D(u0, u1);
+                            got = rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                            break;
+                        }
                     }
-                    for (uint32_t j = 0; j < n; ++j) {
-                        float s0, s1;
-                        replay.sample2D(s0, s1);
-                        SampleTo ls;
-                        if (ss.sample(s0, s1, sf.p, ms.geo_n, trafo, ms.translucent, ls)) connect(ls);
-                    }
+                    if (got) connect(ls);
                 }
-            } else if (MESHL && ZYGPU_SHAPE_DISK == light_shape) {
-                const uint32_t    n = numSamples(light.num_samples, sample_threshold);
-                const DiskSampler ds = DiskSampler::init(sf.p, trafo, n);
-                if (ds.valid) {  // disk.zig:273-276: no sample, no draw
-                    // a sample's second draw depends on its first: the path's sampler runs the sampling once for its
-                    // draws alone, the copy once more for the samples
-                    Sampler replay = h.smp;
-                    for (uint32_t j = 0; j < n; ++j) {
-                        SampleTo ls;
-                        ds.sample(h.smp, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
-                    }
-                    for (uint32_t j = 0; j < n; ++j) {
-                        SampleTo ls;
-                        if (ds.sample(replay, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
-                    }
-                }
-            } else {
+            } else {  // the instantiations whose lights are all Rectangles
                 const uint32_t         n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
                 const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
                 Sampler                replay = h.smp;

@@ -476,6 +476,8 @@ struct ZygpuContext {
     // functions): the verification mode, film identical to the oracle's.  0 = relaxed arithmetic (native rcp / sqrt, fused
     // multiply-adds, OCML f32 transcendentals), within the RMS <= 1e-3 contract but not bit-identical.
     bool          relaxed = false;
+    // option "pool_relaxed" (default 0): with precise = 0, the POOL scenes (Glass, shadow catchers) run the relaxed units too
+    bool          pool_relaxed = false;
     bool          launch_failed = false;
     // option "uniform_tlas" (default on): scenes whose props fit the tables of dscene.hpp TlasEntry run the kernels that
     // walk them wave-wide instead of the top-level trees lane by lane (not the counting / MESHL / POOL instantiations)
@@ -758,7 +760,7 @@ int deviceErrorFlags(ZygpuContext* c) {
 // against the precise film: 1.3e-3 at 256 spp on cornell_glass, 3.1e-3 on the outdoor scene, falling like 1 / sqrt(spp), mean
 // difference <= 6e-5).  The POOL instantiations therefore always run the precise units: their film is the reference's bits.
 // (a development library built without the precise units has nothing else to run them in)
-bool relaxedUnits(const ZygpuContext* c) { return c->relaxed && (!c->pool_mode || !modeAvailable(0)); }
+bool relaxedUnits(const ZygpuContext* c) { return c->relaxed && (!c->pool_mode || c->pool_relaxed || !modeAvailable(0)); }
 
 void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params& P, uint32_t arg) {
     const int mode = relaxedUnits(c) ? 1 : 0, unit = kUnitOf[id];
@@ -2081,6 +2083,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->fuse_tick = 0 != value;
         return 0;
     }
+    if (0 == std::strcmp(name, "pool_relaxed")) {
+        c->pool_relaxed = 0 != value;
+        return 0;
+    }
     if (0 == std::strcmp(name, "mesh_kernels")) {
         c->mesh_kernels = 0 != value;
         return 0;
@@ -2161,6 +2167,7 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"persistent", c->persistent ? 1 : 0},
                  {"fuse_tick", c->fuse_tick ? 1 : 0},
                  {"uniform_tlas", c->uniform_tlas ? 1 : 0},
+                 {"pool_relaxed", c->pool_relaxed ? 1 : 0},
                  {"tick_sync", c->tick_sync ? 1 : 0}};
     for (const auto& e : table)
         if (0 == std::strcmp(name, e.name)) {

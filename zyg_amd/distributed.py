@@ -63,16 +63,18 @@ class ShardedFrame:
             raise ValueError("world > 1 needs an initialised torch.distributed")
         self.rank, self.world, self.dist, self.mode, self.height = rank, world, dist, mode, height
 
-    def step_range(self, step, iterations_per_step, steps):
-        """(first_iteration, count, y_begin, y_end) of this rank's part of step `step`."""
+    def step_range(self, step, iterations_per_step, steps, height=None):
+        """(first_iteration, count, y_begin, y_end) of this rank's part of step `step`; `height`: of the frame rendered, when it is
+        not the one the object was made for (bench.py measures scenes of other sizes with the same ranks)."""
+        height = self.height if height is None else height
         if "iterations" == self.mode:
             first, _ = iteration_shard(self.rank, self.world, steps * iterations_per_step)
-            return first + step * iterations_per_step, iterations_per_step, 0, self.height
-        y0, y1 = row_shard(self.rank, self.world, self.height)
+            return first + step * iterations_per_step, iterations_per_step, 0, height
+        y0, y1 = row_shard(self.rank, self.world, height)
         return step * iterations_per_step, iterations_per_step, y0, y1
 
-    def render_step(self, render, step, iterations_per_step, steps):
-        render(*self.step_range(step, iterations_per_step, steps))
+    def render_step(self, render, step, iterations_per_step, steps, height=None):
+        render(*self.step_range(step, iterations_per_step, steps, height))
 
     def reduce(self, film, dst=0):
         """The one exchange step: the ranks' films summed into rank `dst` (in place on `dst`)."""

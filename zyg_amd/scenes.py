@@ -373,7 +373,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             mesh_material=None, mesh_lights=False, light_grid=1, alpha_transparency=False, camera_z=-3.9, many_lights=0,
             floor_material=None, spheres=False, sphere_lights=False, glass_objects=None, disk_and_cube=False, light_map=None,
             light_spectrum=(17.0, 12.0, 4.0), masked=None, disk_lights=False, two_sided_lights=False, clamp=None, lens=None,
-            overrides=None, regularize=None, mesh_position=(0, 0.02, 0.1), box_subdivide=1, box_first_face=None, extra_props=0, portal_map=None):
+            overrides=None, regularize=None, mesh_position=(0, 0.02, 0.1), box_subdivide=1, box_first_face=None, extra_props=0, portal_map=None,
+            box_lift=0.0):
     """Builds the Cornell box of BASELINE.json's configs 1-3 on `engine` (zyg_amd.Engine).
 
     material: "lambert" (Debug-style Lambert) or "substitute"; mesh: optional (idx, pos, nrm, uv) placed at mesh_position (the
@@ -398,6 +399,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
     ceiling's place, a window onto a Dome with that map (scene/shape/portal.zig; the Dome itself becomes a hidden prototype).
     box_subdivide / box_first_face: the two boxes' triangle counts (box_mesh); extra_props: that many small Rectangle plaques on
     the back wall (the prop count: the device's prop tables hold 16).
+    box_lift: the two boxes stand that far above the floor instead of on it (0: their bottom faces lie in the floor's plane, and
+    which of the two coincident surfaces a ray meets first is decided by the last bit of two different formulas).
     Returns a dict with prop ids.
     """
     overrides = overrides or {}
@@ -547,6 +550,8 @@ def cornell(engine, width, height, spp, integrator="PTMIS", material="lambert", 
             ids["meshes"].append(p)
     if boxes:
         for k, (lo, hi, rot) in enumerate((((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0))):
+            if box_lift:
+                lo, hi = (lo[0], lo[1] + box_lift, lo[2]), (hi[0], hi[1] + box_lift, hi[2])
             idx, pos, nrm, uv = box_mesh(lo, hi, rot, subdivide=box_subdivide, first_face=box_first_face)
             shape = engine.triangle_mesh(idx, pos, nrm, uv)
             box_mat = engine.material(glass_objects["box"]) if 1 == k and "box" in glass_objects else pick(("tall", "short")[k], white)
@@ -609,7 +614,7 @@ def sky_tables(elevation_deg=35.0, size=64):
 
 def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
             extra_quad_light=False, max_depth=8, sky=None, sun=True, showcase=False, mesh=None, sky_map=None, sky_samples=1,
-            sky_spectrum=(0.35, 0.5, 0.8), sky_entity=None, shadow_catcher=False, alpha_transparency=False):
+            sky_spectrum=(0.35, 0.5, 0.8), sky_entity=None, shadow_catcher=False, alpha_transparency=False, box_lift=0.0):
     """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
     distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
     light tree mixes the infinite-light distribution with the BVH.  `sky`: "dome" (dome.zig, the whole sphere of
@@ -643,6 +648,8 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
         p = engine.prop(engine.triangle_mesh(*mesh), [iron])
         engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0.0, 0.01, -1.6)))
     for lo, hi, rot, mat in (((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0, white), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0, red)):
+        if box_lift:  # (see cornell's box_lift)
+            lo, hi = (lo[0], lo[1] + box_lift, lo[2]), (hi[0], hi[1] + box_lift, hi[2])
         idx, pos, nrm, uv = box_mesh(lo, hi, rot)
         p = engine.prop(engine.triangle_mesh(idx, pos, nrm, uv), [mat])
         engine.transformation(p, identity)
