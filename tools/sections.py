@@ -17,11 +17,18 @@ if os.environ.get("ZYG_SCENE") == "mesh":  # BASELINE.json configs[2]
     kw = dict(boxes=False, mesh=scenes.displaced_sphere_mesh(), mesh_position=scenes.MESH_CENTRE, mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
 elif os.environ.get("ZYG_SCENE") == "mound":
     kw = dict(boxes=False, mesh=scenes.heightfield_mesh(), mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
-scenes.cornell(eng, w, h, iters, integrator="PTMIS", material=material, **kw)
+if os.environ.get("ZYG_SCENE") == "outdoor":  # BASELINE.json configs[4]'s scene (POOL kernels)
+    scenes.outdoor(eng, w, h, iters, integrator="PTMIS", material="substitute", showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16,
+                   sky_entity={"parameters": {"sun": {"rotation": [-55, 20, 0]}}}, box_lift=1e-3)
+else:
+    if os.environ.get("ZYG_SCENE") == "glass":
+        kw = dict(glass_objects={"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)}, box_lift=1e-3)
+    scenes.cornell(eng, w, h, iters, integrator="PTMIS", material=material, **kw)
 eng.start_frame(0)
 lib, ctx = eng.lib, eng.context()
 lib.zygpu_get_section_cycles.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
 lib.zygpu_reset_stats(ctx)
+assert 0 == lib.zygpu_set_option(ctx, b"pool_relaxed", 1)
 assert 0 == lib.zygpu_set_option(ctx, b"precise", int(os.environ.get("ZYG_PRECISE", "0")))  # the relaxed units unless asked otherwise
 lib.zygpu_render(ctx, 0, 0, iters, 0, h)
 lib.zygpu_synchronize(ctx)

@@ -83,6 +83,17 @@ ZD float acosR(float z) {  // only the unit-test hook calls it directly
     return (z * (pS0 + z * (pS1 + z * pS2))) / (1.f + z * qS1);
 }
 #else
+// The restated functions are expanded at every call site by default (ZD).  -DZYG_LIBM_CALLS=1 makes them functions that are called:
+// the kernels that know every shape, light and closure hold several hundred expansions of them (wf_scatter<.., MESHL, POOL>: 10 K
+// f64 instructions and as many literal moves of 98 K), far past the instruction cache.
+#ifndef ZYG_LIBM_CALLS
+#define ZYG_LIBM_CALLS 0
+#endif
+#if ZYG_LIBM_CALLS
+#define ZD_LIBM __device__ __noinline__
+#else
+#define ZD_LIBM ZD
+#endif
 // sin / cos / acos with the reference's algorithms (Zig std.math.acos = msun e_acosf.c; compiler-rt sinf/cosf =
 // musl sinf.c/cosf.c with the double-precision k_sinf/k_cosf kernels) so that device results are reproducible
 // bit for bit on the host.  Beyond 9*pi/4 musl's general case with the medium-size argument reduction (up to 2^28 * pi/2).
@@ -115,7 +126,7 @@ ZD int remPio2f(float x, double& y) {
     }
     return n;
 }
-ZD float sinF(float x) {
+ZD_LIBM float sinF(float x) {
     const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
     const bool     sign = 0 != (hx >> 31);
     const double   xd = double(x);
@@ -140,7 +151,7 @@ ZD float sinF(float x) {
     }
     return sinf(x);
 }
-ZD float cosF(float x) {
+ZD_LIBM float cosF(float x) {
     const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
     const bool     sign = 0 != (hx >> 31);
     const double   xd = double(x);
@@ -170,7 +181,7 @@ ZD float acosR(float z) {
     const float p = z * (pS0 + z * (pS1 + z * pS2)), q = 1.f + z * qS1;
     return p / q;
 }
-ZD float acosF(float x) {
+ZD_LIBM float acosF(float x) {
     const float    pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
     const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
     if (ix >= 0x3f800000u) {
@@ -205,7 +216,7 @@ ZD float tandf(double x, bool odd) {
     const double r0 = (x + s * u) + (s * w) * (t + w * r);
     return float(odd ? -1.0 / r0 : r0);
 }
-ZD float tanF(float x) {
+ZD_LIBM float tanF(float x) {
     const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
     const bool     sign = 0 != (hx >> 31);
     const double   xd = double(x);
@@ -216,7 +227,7 @@ ZD float tanF(float x) {
 }
 
 // atanf / atan2f with the msun algorithms (Zig std.math.atan / atan2 are ports of musl's s_atanf.c / e_atan2f.c)
-ZD float atanF(float x) {
+ZD_LIBM float atanF(float x) {
     const float    atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
     const float    atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
     const float    aT[5] = {3.3333328366e-01f, -1.9999158382e-01f, 1.4253635705e-01f, -1.0648017377e-01f, 6.1687607318e-02f};
@@ -257,7 +268,7 @@ ZD float atanF(float x) {
     const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
     return sign ? -r : r;
 }
-ZD float atan2F(float y, float x) {
+ZD_LIBM float atan2F(float y, float x) {
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
     if (x != x || y != y) return x + y;
     uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
@@ -285,7 +296,7 @@ ZD float atan2F(float y, float x) {
 
 // expf with the msun e_expf.c algorithm (Zig's @exp on f32 lowers to compiler-rt's expf, a port of musl's older expf.c):
 // argument reduction by k*ln2 in two pieces, degree-2 rational kernel, scaling by 2^k
-ZD float expF(float x) {
+ZD_LIBM float expF(float x) {
     const float    ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
     const float    P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
     uint32_t       hx = __float_as_uint(x);

@@ -134,14 +134,19 @@ struct Pool {  // 16 B records, indexed by path slot
     float4*   contrib;  //   its pre-weighted contribution weight * radiance * bsdf
     float4*   nee;      // sum of the unoccluded contributions of this vertex
     uint32_t* vis;      // wf_shadow's verdict on the running pick
-    // POOL only
-    uint32_t* vmeta;    // per vertex: depth_surface, vertex.depth, state flags (the bits of q0.y above the sobol dimension)
-    uint4*    med0;     // per vertex: medium stack (prop/medium.zig:30-153): index, prop0, part0, prop1
-    uint4*    med1;     //             part1, prop2, part2
-    float2*   rec_ior;  // per vertex: rs.ior (Vertex.iorOutside), 1 if the material has lower priority than the stack
-    float2*   rec_uv;   // per vertex: the fragment's uv, for the textures of an extended Substitute
-    uint32_t* pstate;   // per slot: [0:7] vertices in flight, [8:15] children created for the next level
-    float*    transp;   // per slot: Pool.transparency[3], the alpha sum over terminated vertices
+    // POOL only.  The POOL pool's layout (zygpu.hip ensurePool): a vertex is two lines of its own 256 B block, a camera sample one
+    // 128 B line: wf_scatter<POOL> reads its vertex' two lines and the sample's, writes a child's first line and the sample's.  (Until
+    // round 4 these seven were arrays of their own beside the non-POOL block: ~20 lines per scattered vertex, 3.6 KB of HBM traffic.)
+    //   vertex, line A: ray_o 0, ray_d 16, thr 32, vorigin 48, vgeo_n 64, med0 80, med1 96, vmeta 112, hit_sr 116, rec_ior 120
+    //           line B: rec_p 128, rec_gn 144, rec_n 160, rec_t 176, rec_b 192, hit 208, hit_prop 224, ucount 228, rec_uv 232
+    //   sample:         q0 0, q1 16, pcg 32, pstate 40, transp 44, emission 48, direct 64, indirect 80
+    Rec<uint32_t> vmeta;    // per vertex: depth_surface, vertex.depth, state flags (the bits of q0.y above the sobol dimension)
+    Rec<uint4>    med0;     // per vertex: medium stack (prop/medium.zig:30-153): index, prop0, part0, prop1
+    Rec<uint4>    med1;     //             part1, prop2, part2
+    Rec<float2>   rec_ior;  // per vertex: rs.ior (Vertex.iorOutside), 1 if the material has lower priority than the stack
+    Rec<float2>   rec_uv;   // per vertex: the fragment's uv, for the textures of an extended Substitute
+    Rec<uint32_t> pstate;   // per slot: [0:7] vertices in flight, [8:15] children created for the next level
+    Rec<float>    transp;   // per slot: Pool.transparency[3], the alpha sum over terminated vertices
     // scenes with a shadow catcher only (else null), PathtracerMIS: per vertex what a catcher on the path has seen (vertex.zig:57-59),
     // per slot Pool.transparency's colour (the backplate light a catcher lets through, vertex.zig:252-266)
     float4*   sc_occ;
@@ -621,7 +626,7 @@ ZD void loadHead(const Params& P, uint32_t vertex, PathHead& h) {
     const uint4    a = P.pool.q0[slot];
     const float4   b = P.pool.q1[slot];
     const uint2    g = P.pool.pcg[slot];
-    const uint32_t meta = POOL ? ((a.y & 7u) | (P.pool.vmeta[vertex] & ~7u)) : a.y;
+    const uint32_t meta = POOL ? ((a.y & 7u) | (P.pool.vmeta.get(vertex) & ~7u)) : a.y;
     h.smp.run_seed = a.x;
     h.smp.buffer[0] = b.x;
     h.smp.buffer[1] = b.y;
@@ -724,6 +729,24 @@ ZD void nanTrace(const Params&, float, uint32_t) {}
 ZD void nanTrace(const Params&, f3, uint32_t) {}
 #endif
 
+// An optimisation barrier on values (no instruction): what is computed from them afterwards cannot be moved in front of this point.
+// In the kernels that know every light kind LLVM's loop-invariant code motion otherwise hoists the set-up of each kind (SphQuad, cone
+// frames, chords, portal windows) and the light-independent half of the closure's evaluation out of the light-sample loop and keeps
+// all of it in registers across the shadow ray's walk: wf_scatter<.., MESHL, POOL> 806 spilled registers, 189 with one light kind.
+#ifndef ZYG_PIN
+#define ZYG_PIN 1
+#endif
+ZD void pin(float& x) {
+#if ZYG_PIN
+    asm volatile("" : "+v"(x));
+#endif
+}
+ZD void pin(f3& v) {
+    pin(v.x);
+    pin(v.y);
+    pin(v.z);
+}
+
 ZD f3 xyz4(float4 v) { return {v.x, v.y, v.z}; }
 ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
 
@@ -820,7 +843,7 @@ ZD void finalize(const Params& P, uint32_t slot, f3 throughput, uint32_t flags, 
 // catchers), done when the vertex ends instead of at the end of its level (same order: vertices end in index order).
 // The camera sample ends with its last vertex: result.direct[3] = 0 + transparency[3] (pathtracer_mis.zig:168-170)
 ZD void terminateVertex(const Params& P, uint32_t slot, f3 throughput, float split_weight, uint32_t flags, uint32_t vertex = 0) {
-    float alpha = P.pool.transp[slot];
+    float alpha = P.pool.transp.get(slot);
     f3    through = S3(0.f);  // Pool.transparency's colour: only shadow catchers add to it
     if (P.pool.sc_emis) {     // a scene with shadow catchers (vertex.zig:252-266); `vertex`: the ending vertex' records
         through = xyz4(P.pool.transp_rgb[slot]);
@@ -841,7 +864,7 @@ ZD void terminateVertex(const Params& P, uint32_t slot, f3 throughput, float spl
         alpha = (flags & ST_TRANSPARENT) ? alpha + mx((1.f - average3(throughput)) * split_weight, 0.f) : alpha + split_weight;
     }
     P.pool.transp[slot] = alpha;
-    const uint32_t st = P.pool.pstate[slot] - 1u;
+    const uint32_t st = P.pool.pstate.get(slot) - 1u;
     P.pool.pstate[slot] = st;
     if (0 == (st & 255u)) {
         if (P.pixel_pcg) P.pixel_pcg[slot] = P.pool.pcg[slot];  // one-shot: storeSamplers ran just before (shared samplers)
@@ -1159,7 +1182,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     if (i < n) {
         const uint32_t slot = extQueue<POOL>(P, cur, P.round)[at];  // POOL: a vertex index
         const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
-        const uint32_t meta = POOL ? P.pool.vmeta[slot] : P.pool.q0.get(slot).y;
+        const uint32_t meta = POOL ? P.pool.vmeta.get(slot) : P.pool.q0.get(slot).y;
         const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
         Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
         ray.time = pathTime<POOL, EXTRA>(P, slot);
@@ -1534,7 +1557,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
     const float  split_weight = POOL ? thr4.w : 1.f;
     Mediums      md;
     if (POOL) {
-        if (0 == P.round) P.pool.pstate[ps] &= 255u;  // a new level: no children yet
+        if (0 == P.round) P.pool.pstate[ps] = P.pool.pstate.get(ps) & 255u;  // a new level: no children yet
         md.load(P, slot);
         // VolumeIntegrator.integrate for a medium that only absorbs (volume_integrator.zig:62-65, 105-128):
         // Beer-Lambert over the segment to the hit; Context.nextEvent runs before connectLight
@@ -2533,7 +2556,10 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     f3         catcher_occluded = S3(0.f), catcher_unoccluded = S3(0.f);
 
     // ---- sampleLights / evaluateLight (pathtracer_mis.zig:174-278, pathtracer_dl.zig:100-167)
-    if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
+#ifndef ZYG_EXPERIMENT_SCATTER_PART
+#define ZYG_EXPERIMENT_SCATTER_PART 0  // register-pressure experiments (wrong images): 1 = the light samples alone, 2 = the bxdf sample alone
+#endif
+    if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate && 2 != ZYG_EXPERIMENT_SCATTER_PART) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
         const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
         const float     select = h.smp.sample1D();
         const LightTree lt{s, s.light_tree};
@@ -2572,7 +2598,11 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 // MESHL: the scene may have opacity masks, whose draws come from the path's sampler (material.zig:238-245)
                 auto draw = [&]() { return h.smp.sample1D(); };
                 constexpr bool kMasks = MASKS && MESHL;
-                const bool visible = UTLAS                ? sceneVisibilityUniform<WIDE, 0 != ZYG_FAST>(s, shadow)
+#ifndef ZYG_EXPERIMENT_NEE_SKIP
+#define ZYG_EXPERIMENT_NEE_SKIP 0  // register-pressure experiments (wrong images): 1 no shadow test, 2 no closure evaluation, 4 Rectangle lights only, 8 no radiance
+#endif
+                const bool visible = (ZYG_EXPERIMENT_NEE_SKIP & 1) ? true
+                                     : UTLAS              ? sceneVisibilityUniform<WIDE, 0 != ZYG_FAST>(s, shadow)
                                      : (POOL || kMasks) ? sceneVisibilityTr<STATS, kMasks>(s, shadow, cnt, tr, draw)
                                                         : sceneVisibility<STATS, MESHL>(s, shadow, cnt);
                 tm.mark(3);
@@ -2581,8 +2611,15 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                     tr = S3(0.f);  // pathtracer_mis.zig:251-257
                 }
                 const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
-                const f3         radiance = materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
-                const BxdfResult bx = ms.template evaluate<SUBST, POOL, MESHL>(s, ls.wi, POOL && max_splits > 1);
+                const f3         radiance = (ZYG_EXPERIMENT_NEE_SKIP & 8) ? S3(lr) : materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
+                BxdfResult       bx;
+                if (ZYG_EXPERIMENT_NEE_SKIP & 2) bx.reflection = ls.wi, bx.pdf = ls.pdf;
+                else if (MESHL) {  // (pin: the closure's light-independent terms are computed here, not in front of the light loop)
+                    MaterialSample mj = ms;
+                    pin(mj.wo);
+                    pin(mj.n);
+                    bx = mj.template evaluate<SUBST, POOL, MESHL>(s, ls.wi, POOL && max_splits > 1);
+                } else bx = ms.template evaluate<SUBST, POOL, MESHL>(s, ls.wi, POOL && max_splits > 1);
                 nanTrace(P, ls.wi, 10);
                 nanTrace(P, ls.pdf, 11);
                 nanTrace(P, radiance, 12);
@@ -2624,7 +2661,10 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                         h.smp.sample2D(a, b);
                     }
                 };
-                if (ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {
+                if (ZYG_EXPERIMENT_NEE_SKIP & 4) {
+                    lk = LK_RECTANGLE;
+                    n = 1;
+                } else if (ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {
                     // Light.propSamplePortalTo (light.zig:217-240) -> Rectangle.samplePortalTo (rectangle.zig:458-513): the window the
                     // point sees the portal through, then the map's windowed distribution; no window, no draw
                     Bounds2 bounds;
@@ -2684,15 +2724,18 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 for (uint32_t j = 0; j < n; ++j) {
                     SampleTo ls;
                     bool     got = false;
+                    f3       pj = sf.p, nj = ms.geo_n;  // (pin: the light kinds' set-up stays inside its case)
+                    pin(pj);
+                    pin(nj);
                     switch (lk) {
                         case LK_PORTAL: {
                             const DPortalLight& pl = s.portal_lights[light.sampler];
                             const Trafo         dome = loadTrafo(s, s.lights[pl.light_link].prop);  // (the host refuses an animated link)
                             Bounds2             bounds;
-                            portalImageBounds(sf.p, trafo, bounds);
+                            portalImageBounds(pj, trafo, bounds);
                             float r0, r1;
                             replay.sample2D(r0, r1);
-                            got = rectangleSamplePortal(pl, dome, bounds, r0, r1, float(n), sf.p, ms.geo_n, trafo, ms.translucent, ls);
+                            got = rectangleSamplePortal(pl, dome, bounds, r0, r1, float(n), pj, nj, trafo, ms.translucent, ls);
                             break;
                         }
                         case LK_IMAGE_FLAT: {
@@ -2700,18 +2743,18 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                             float              r0, r1;
                             replay.sample2D(r0, r1);
                             got = ZYGPU_SHAPE_DOME == light_shape
-                                      ? domeSampleMaterial(il, r0, r1, float(n), ms.geo_n, trafo, ms.translucent, ls)
+                                      ? domeSampleMaterial(il, r0, r1, float(n), nj, trafo, ms.translucent, ls)
                                   : ZYGPU_SHAPE_DISK == light_shape
-                                      ? diskSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)
-                                      : rectangleSampleMaterial(il, r0, r1, float(n), sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                                      ? diskSampleMaterial(il, r0, r1, float(n), pj, nj, trafo, 0 != light.two_sided, ms.translucent, ls)
+                                      : rectangleSampleMaterial(il, r0, r1, float(n), pj, nj, trafo, 0 != light.two_sided, ms.translucent, ls);
                             break;
                         }
-                        case LK_IMAGE_SPHERE: got = sphereSampleMaterialTo(s.image_lights[light.sampler], sf.p, ms.geo_n, trafo, ms.translucent, h.smp, ls); break;
-                        case LK_IMAGE_CANOPY: got = canopySampleMaterialTo(s.image_lights[light.sampler], ms.geo_n, trafo, ms.translucent, h.smp, ls); break;
+                        case LK_IMAGE_SPHERE: got = sphereSampleMaterialTo(s.image_lights[light.sampler], pj, nj, trafo, ms.translucent, h.smp, ls); break;
+                        case LK_IMAGE_CANOPY: got = canopySampleMaterialTo(s.image_lights[light.sampler], nj, trafo, ms.translucent, h.smp, ls); break;
                         case LK_MESH: {
                             const DMeshLight&      ml = s.mesh_lights[light.sampler];
                             const DMesh&           mesh = s.meshes[ml.mesh];
-                            const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
+                            const MeshLightSampler msr = MeshLightSampler::init(pj, nj, trafo);
                             const LightTree        ptree{s, ml.tree};
                             LightPick              tri{};
                             // the primitive tree's picks again, keeping the j-th (they are a function of (point, normal, r) alone)
@@ -2720,32 +2763,32 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                             });
                             float r0, r1;
                             replay.sample2D(r0, r1);
-                            got = msr.sample(mesh, ml, tri, r0, r1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                            got = msr.sample(mesh, ml, tri, r0, r1, pj, nj, trafo, 0 != light.two_sided, ms.translucent, ls);
                             break;
                         }
                         case LK_INFINITE:
-                            got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(ms.geo_n, ms.translucent, h.smp, ls)
-                                  : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls)
-                                                                      : distantSampleTo(ms.geo_n, trafo, ms.translucent, h.smp, ls);
+                            got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(nj, ms.translucent, h.smp, ls)
+                                  : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(nj, trafo, ms.translucent, h.smp, ls)
+                                                                      : distantSampleTo(nj, trafo, ms.translucent, h.smp, ls);
                             break;
                         case LK_SPHERE: {
-                            const SphereSampler ss = SphereSampler::init(sf.p, trafo, n);
+                            const SphereSampler ss = SphereSampler::init(pj, trafo, n);
                             float               s0, s1;
                             replay.sample2D(s0, s1);
-                            got = ss.sample(s0, s1, sf.p, ms.geo_n, trafo, ms.translucent, ls);
+                            got = ss.sample(s0, s1, pj, nj, trafo, ms.translucent, ls);
                             break;
                         }
                         case LK_DISK: {
-                            const DiskSampler ds = DiskSampler::init(sf.p, trafo, n);
-                            got = ds.sample(replay, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                            const DiskSampler ds = DiskSampler::init(pj, trafo, n);
+                            got = ds.sample(replay, pj, nj, trafo, 0 != light.two_sided, ms.translucent, ls);
                             break;
                         }
                         default: {  // LK_RECTANGLE
-                            const RectangleSampler rs = RectangleSampler::init(sf.p, trafo, n);
+                            const RectangleSampler rs = RectangleSampler::init(pj, trafo, n);
                             float                  u0, u1;
                             if (MULTI) replay.sample2D(u0, u1);
                             else h.smp.sample2D(u0, u1);
-                            got = rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
+                            got = rs.sample(u0, u1, pj, nj, trafo, 0 != light.two_sided, ms.translucent, ls);
                             break;
                         }
                     }
@@ -2789,6 +2832,10 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     }
 
     // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
+    if (1 == ZYG_EXPERIMENT_SCATTER_PART) {
+        storeHead<POOL>(P, slot, h);
+        return;
+    }
     BxdfSample bs;
     if (POOL) {
         // mat_sample.sample(sampler, max_splits, ..): Glass splits into reflection and refraction while the sample has
@@ -2798,7 +2845,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         const uint32_t path_count = __float_as_uint(P.pool.vorigin.get(slot).w);
         if (ZYGPU_MAT_GLASS == ms.kind) {
             // rs.wavelength (vertex.zig:167): only a dispersive glass looks at it
-            const float path_wavelength = 0.f != ms.abbe ? __uint_as_float(P.pool.med1[slot].w) : 0.f;
+            const float path_wavelength = 0.f != ms.abbe ? __uint_as_float(P.pool.med1.get(slot).w) : 0.f;
             count = ms.glassSample(s, h.smp, max_splits > 1, bs, bs1, path_wavelength);
         } else {
             bs.wavelength = 0.f;
@@ -2811,7 +2858,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         } else {
             Mediums md;
             md.load(P, slot);
-            const uint32_t st = P.pool.pstate[ps];
+            const uint32_t st = P.pool.pstate.get(ps);
             const uint32_t first = (st >> 8) & 255u;
             P.pool.pstate[ps] = st + (count << 8) + (count - 1u);  // children created; vertices in flight: -1 + count
             const float  parent_pdf = sf.parent_pdf;

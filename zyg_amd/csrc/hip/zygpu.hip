@@ -618,9 +618,11 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_ke
         p.emission.base = block + kOffEmission, p.direct.base = block + kOffDirect, p.indirect.base = block + kOffIndirect;
 #endif
 #if ZYG_HIT_STRIDE
-        char* hits = nullptr;
-        ok = ok && m.alloc(paths * size_t(ZYG_HIT_STRIDE), &hits);
-        p.hit.base = hits, p.hit_prop.base = hits + 16, p.ucount.base = hits + 20, p.hit_sr.base = hits + 24;
+        if (!c->pool_mode) {  // (the POOL layout below keeps the hit in the vertex' second line)
+            char* hits = nullptr;
+            ok = ok && m.alloc(paths * size_t(ZYG_HIT_STRIDE), &hits);
+            p.hit.base = hits, p.hit_prop.base = hits + 16, p.ucount.base = hits + 20, p.hit_sr.base = hits + 24;
+        }
 #endif
     }
 #else
@@ -646,6 +648,24 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_ke
 #undef ZYG_STRIDE
     };
     blockStrides(p);
+    if (c->pool_mode) {
+        // The POOL layout (wavefront.hpp Pool): the records of a vertex in the two lines of its block, those of a camera sample (the
+        // samplers, the sums, the vertices in flight, the alpha sum) in one 128 B line of an array by slot.
+        char* block = p.q0.base;  // (kOffQ0 = 0: the block array allocated above)
+        char* samples = nullptr;
+        ok = ok && m.alloc(slots * size_t(128), &samples);
+        auto place = [](auto& rec, char* base, uint32_t offset, uint32_t stride) {
+            rec.base = base + offset, rec.mask = 0xFFFFFFFFu, rec.local = 0u, rec.stride = stride;
+        };
+        place(p.ray_o, block, 0, 256), place(p.ray_d, block, 16, 256), place(p.thr, block, 32, 256), place(p.vorigin, block, 48, 256);
+        place(p.vgeo_n, block, 64, 256), place(p.med0, block, 80, 256), place(p.med1, block, 96, 256), place(p.vmeta, block, 112, 256);
+        place(p.hit_sr, block, 116, 256), place(p.rec_ior, block, 120, 256);
+        place(p.rec_p, block, 128, 256), place(p.rec_gn, block, 144, 256), place(p.rec_n, block, 160, 256), place(p.rec_t, block, 176, 256);
+        place(p.rec_b, block, 192, 256), place(p.hit, block, 208, 256), place(p.hit_prop, block, 224, 256), place(p.ucount, block, 228, 256);
+        place(p.rec_uv, block, 232, 256);
+        place(p.q0, samples, 0, 128), place(p.q1, samples, 16, 128), place(p.pcg, samples, 32, 128), place(p.pstate, samples, 40, 128);
+        place(p.transp, samples, 44, 128), place(p.emission, samples, 48, 128), place(p.direct, samples, 64, 128), place(p.indirect, samples, 80, 128);
+    }
 #endif
     ok = ok && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) &&
          m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) &&
@@ -656,8 +676,6 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_ke
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy) &&
          (!hit_q || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
     if (ok && c->pool_mode) {
-        ok = m.alloc(paths, &p.vmeta) && m.alloc(paths, &p.med0) && m.alloc(paths, &p.med1) && m.alloc(paths, &p.rec_ior) && m.alloc(paths, &p.rec_uv) &&
-             m.alloc(slots, &p.pstate) && m.alloc(slots, &p.transp);
         if (ok && c->catchers)
             ok = m.alloc(paths, &p.sc_occ) && m.alloc(paths, &p.sc_unocc) && m.alloc(paths, &p.sc_emis) && m.alloc(slots, &p.transp_rgb);
         for (uint32_t side = 0; side < 2; ++side) {
