@@ -438,6 +438,11 @@ typedef struct ZygpuViewDesc {
     uint32_t      camera_num_keyframes;
     float         camera_origin[4];
     ZygpuKeyframe camera_keyframes[ZYGPU_MAX_CAMERA_KEYFRAMES];
+    /* The aperture's shape (camera/aperture.zig:22-53, camera_perspective.zig:270-283): the entry of the scene's `image_lights` that
+     * holds the Distribution2D over the shape image's values (no uv weight, no compensation, total_weight 1), or ZYGPU_NULL: the
+     * lens is sampled as a disc.  A lens sample is 2 * distribution.sampleContinuous(lens_uv).uv - 1, times lens_radius. */
+    uint32_t      aperture_shape;
+    uint32_t      reserved_;
 } ZygpuViewDesc;
 
 /* tonemapper.zig:9; AgX with the look the take loader picks (take_loader.zig:268-270: Substitute) */
@@ -530,7 +535,11 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * same film), "compact_blocks" (default 0) then places the paths' blocks 128 B apart instead of 256; "hit_by_queue" (default 1)
  * stores the hit records of the vertices that go on to wf_scatter at their place in the alive queue instead of by path slot;
  * "pair_small" (default 1; read by zygpu_upload_scene) lets two triangles of a small mesh that make a parallelogram be tested as
- * one item by the relaxed-arithmetic kernels. */
+ * one item by the relaxed-arithmetic kernels;
+ * "pool_relaxed" (default 1): with "precise" 0 the scenes of the POOL kernels (Glass, shadow catchers) run the relaxed units as
+ * every other scene does; 0 gives them the precise units whatever "precise" says (the reference's bits: where two surfaces of such
+ * a scene coincide, a glass box standing on the floor, which of them a ray meets first hangs on the last bit of two formulas, and
+ * only the precise units decide that as the reference does: DESIGN.md section 2). */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 /* Reads an option back, and what the library derived from the options and the uploaded scene (valid after zygpu_upload_scene):
  * "relaxed_units" 1 when the relaxed-arithmetic kernel units render this scene (option "precise" 0 and a scene they are inside
@@ -549,6 +558,10 @@ int zygpu_get_option(ZygpuContext* ctx, const char* name, int* out_value);
  * primitive, prop or ZYGPU_NULL, 3 x 0), the layout of the oracle's zyg_oracle_intersect; visible: 1 = unoccluded. */
 int zygpu_test_intersect(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits);
 int zygpu_test_visibility(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible);
+/* One closest-hit ray (8 floats as above) walked as the reference's Scene.intersect does (mode 0), always in precise arithmetic:
+ * the camera's focus probe (Perspective.updateFocus, camera_perspective.zig:322-347), which the host traces between
+ * zygpu_upload_scene and zygpu_set_view.  Returns 1 and the hit distance in *out_t, 0 for a miss, -1 on error. */
+int zygpu_probe_closest(ZygpuContext* ctx, const float* ray8, float* out_t);
 
 /* Measurement support (tools/calibrate_fetch.py): `repeats` launches of a kernel whose lane i reads the 16 B record at
  * i * stride_bytes (stride 16 / 64 / 128 / 256 / 512) of a zero-filled buffer of num_records records; average ms per launch.

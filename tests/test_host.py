@@ -604,3 +604,78 @@ def test_portal_light_compile_products(engine, oracle):
     from util import oracle_render, oracle_resolve
     img = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, 8, threads=4))
     assert np.isfinite(img).all() and img[12:, 8:24, :3].mean() > 0.02
+
+
+def _aperture_image(n=16):
+    """A one-channel aperture shape: a triangle of weights (not symmetric, so a flipped or transposed read shows), a few zero texels."""
+    y, x = np.mgrid[0:n, 0:n]
+    img = np.where(x <= y, 40 + 13 * ((x * 3 + y * 5) % 16), 0).astype(np.uint8)
+    img[n - 1, 0] = 255
+    return img
+
+
+def test_aperture_shape_distribution(product_lib, tmp_path):
+    """"aperture": {"shape": file} (camera_perspective.zig:270-283 -> aperture.zig:22-44): the file is read as a one-channel (Opacity)
+    texture, one Distribution1D per row over its values, the marginal over the rows' integrals; the view names the distribution, which
+    rides with the scene's image lights.  Checked against a numpy restatement of Distribution1D.configure (distribution_1d.zig:104-171)."""
+    from util import write_png
+    img = _aperture_image()
+    write_png(tmp_path / "iris.png", img[..., None], [0, 2])
+    with zyg_amd.Engine(product_lib) as e:
+        e.lib.su_mount(str(tmp_path).encode())
+        scenes.cornell(e, 32, 24, 1, lens={"aperture": {"radius": 0.1, "shape": "iris.png"}, "focus": {"distance": 3.0}})
+        sd, vd = e.compile()
+        assert vd.aperture_shape == sd.num_image_lights - 1 and vd.lens_radius == np.float32(0.1)
+        il = sd.image_lights[vd.aperture_shape]
+        n = img.shape[0]
+        assert il.num_rows == n and il.total_weight == 1.0
+        rows = np.ctypeslib.as_array(il.rows, shape=((n + 1) * 4,)).reshape(n + 1, 4)
+        cdf = np.ctypeslib.as_array(il.cdf, shape=(il.num_cdf,))
+        integrals = []
+        for y in range(n + 1):
+            data = (img[y].astype(np.float32) * np.float32(1.0 / 255.0)) if y < n else np.array(integrals, dtype=np.float32)
+            integral = np.float32(0)
+            for d in data:
+                integral = np.float32(integral + d)
+            integrals.append(integral)
+            offset, size = int(rows[y, 0]), int(rows[y, 1])
+            if integral == 0:
+                assert size == 2 and cdf[offset] == 1.0 and cdf[offset + 1] == 1.0
+                continue
+            assert size == len(data) + 1
+            ii = np.float32(1.0) / integral
+            acc, want = np.float64(0), [np.float32(0)]
+            for d in data[:-1]:  # p = @mulAdd(data[i], ii, p): one rounding
+                acc = np.float64(np.float32(np.float64(d) * np.float64(ii) + np.float64(want[-1])))
+                want.append(np.float32(acc))
+            want.append(np.float32(1))
+            assert np.array_equal(cdf[offset:offset + size], np.array(want, dtype=np.float32)), y
+
+
+@pytest.mark.parametrize("parameters,word", [({"aperture": {"radius": 0.1, "blades": 6}}, "blades"), ({"stereo": {"ipd": 0.062}}, "stereo"),
+                                             ({"aperture": {"radius": 0.1, "shape": "missing.png"}}, "missing.png")])
+def test_camera_parameters_refused_by_name(product_lib, parameters, word):
+    """camera_perspective.zig:284-303: an aperture drawn from `blades` (rendering/shaper.zig) and a stereo camera are not provided, and a
+    shape file that cannot be read is no aperture: su_ext_camera_set_parameters fails and the log names the key; a frame does not
+    start with the parameter silently ignored."""
+    lines = []
+    callback = zyg_amd.LOG_CALLBACK(lambda level, text: lines.append((level, text.decode())))
+    with zyg_amd.Engine(product_lib) as e:
+        e.lib.su_register_log.argtypes = [zyg_amd.LOG_CALLBACK]
+        e.lib.su_register_log(callback)
+        try:
+            scenes.cornell(e, 32, 24, 1)
+            assert e.lib.su_ext_camera_set_parameters(json.dumps(parameters).encode()) == -1
+            assert any(level == 2 and word in text for level, text in lines), lines
+            assert e.lib.su_ext_compile(0) != 0  # and the engine stays refused until the parameters are set right
+        finally:
+            e.lib.su_register_log(zyg_amd.LOG_CALLBACK())
+
+
+def test_focus_point_is_read(product_lib):
+    """"focus": {"point": [x, y, z]} (camera_perspective.zig:348-361): kept for the probe ray su_start_frame traces (the -m gpu tests
+    check the distance); without a lens radius nothing is probed and the pinhole view is what it was."""
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 32, 24, 1, lens={"focus": {"point": [0.25, 0.75, 0.5], "distance": 2.5}})
+        _, vd = e.compile()
+        assert vd.lens_radius == 0.0 and vd.focus_distance == np.float32(2.5) and vd.aperture_shape == zyg_amd.NULL

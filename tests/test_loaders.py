@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from util import write_png as _png
+
 import zyg_amd
 from zyg_amd import scenes
 
@@ -570,43 +572,6 @@ def test_render_take_with_instancer_and_animation(product_lib, oracle, tmp_path)
             assert np.array_equal(films[frame], oracle_render(oracle, sd, vd, 8)), f"frame {frame}"
             assert e.lib.zygpu_clear_film(e.context(), ctypes.c_float(0.0)) == 0
     assert not np.array_equal(films[0], films[2])
-
-
-def _png(path, pixels, filters):
-    """A PNG of (H, W, C) uint8 pixels (C: 1 grey, 3 RGB, 4 RGBA), row y filtered with filters[y % len(filters)] (0 None, 1 Sub, 2 Up,
-    3 Average, 4 Paeth), the image data in two IDAT chunks."""
-    import struct
-    import zlib
-    h, w, c = pixels.shape
-    raw = bytearray()
-    prev = np.zeros(w * c, dtype=np.int32)
-    for y in range(h):
-        row = pixels[y].astype(np.int32).ravel()
-        f = filters[y % len(filters)]
-        left = np.concatenate([np.zeros(c, dtype=np.int32), row[:-c]])
-        upleft = np.concatenate([np.zeros(c, dtype=np.int32), prev[:-c]])
-        if 0 == f:
-            pred = np.zeros_like(row)
-        elif 1 == f:
-            pred = left
-        elif 2 == f:
-            pred = prev
-        elif 3 == f:
-            pred = (left + prev) // 2
-        else:
-            p = left + prev - upleft
-            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
-            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
-        raw.append(f)
-        raw.extend(((row - pred) & 255).astype(np.uint8).tobytes())
-        prev = row
-    data = zlib.compress(bytes(raw), 6)
-
-    def chunk(kind, body):
-        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2, 4: 6}[c], 0, 0, 0)) +
-                chunk(b"IDAT", data[:len(data) // 2]) + chunk(b"IDAT", data[len(data) // 2:]) + chunk(b"IEND", b""))
 
 
 def _image_bytes(sd, i):

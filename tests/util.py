@@ -80,3 +80,40 @@ def rms(a, b):
     a = np.clip(np.nan_to_num(a[..., :3]), 0.0, 1.0).astype(np.float64)
     b = np.clip(np.nan_to_num(b[..., :3]), 0.0, 1.0).astype(np.float64)
     return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def write_png(path, pixels, filters=(0,)):
+    """A PNG of (H, W, C) uint8 pixels (C: 1 grey, 3 RGB, 4 RGBA), row y filtered with filters[y % len(filters)] (0 None, 1 Sub, 2 Up,
+    3 Average, 4 Paeth), the image data in two IDAT chunks."""
+    import struct
+    import zlib
+    h, w, c = pixels.shape
+    raw = bytearray()
+    prev = np.zeros(w * c, dtype=np.int32)
+    for y in range(h):
+        row = pixels[y].astype(np.int32).ravel()
+        f = filters[y % len(filters)]
+        left = np.concatenate([np.zeros(c, dtype=np.int32), row[:-c]])
+        upleft = np.concatenate([np.zeros(c, dtype=np.int32), prev[:-c]])
+        if 0 == f:
+            pred = np.zeros_like(row)
+        elif 1 == f:
+            pred = left
+        elif 2 == f:
+            pred = prev
+        elif 3 == f:
+            pred = (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw.append(f)
+        raw.extend(((row - pred) & 255).astype(np.uint8).tobytes())
+        prev = row
+    data = zlib.compress(bytes(raw), 6)
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2, 4: 6}[c], 0, 0, 0)) +
+                chunk(b"IDAT", data[:len(data) // 2]) + chunk(b"IDAT", data[len(data) // 2:]) + chunk(b"IEND", b""))

@@ -5,8 +5,8 @@ TAG="${1:?tag}"; shift
 O="$R/gpurun_out/$TAG"; mkdir -p "$O"
 for v in "$@"; do
   if [ "$v" = main ]; then unset ZYG_AMD_LIB; else export ZYG_AMD_LIB=$R/variants/lib_$v.so; fi
-  for cfg in "glass_precise:--scene cornell_glass --steps 4 --precise 1" "glass_relaxed:--scene cornell_glass --steps 4 --pool-relaxed 1" \
-             "outdoor4k_precise:--scene outdoor --width 3840 --height 2160 --steps 2 --precise 1" "outdoor4k_relaxed:--scene outdoor --width 3840 --height 2160 --steps 2 --pool-relaxed 1"; do
+  for cfg in "glass_precise:--scene cornell_glass --steps 4 --precise 1" "glass_relaxed:--scene cornell_glass --steps 4" \
+             "outdoor4k_precise:--scene outdoor --width 3840 --height 2160 --steps 2 --precise 1" "outdoor4k_relaxed:--scene outdoor --width 3840 --height 2160 --steps 2"; do
     name=${cfg%%:*}; args=${cfg#*:}
     timeout 600 python3 bench.py --no-cpu-baseline --no-extra $args > "$O/${v}_$name.json" 2> "$O/${v}_$name.err"
     python3 -c "

@@ -1008,7 +1008,14 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
     f3 origin;
     if (v.lens_radius > 0.f) {
         float lx, ly;
-        diskConcentric(s2, s3, lx, ly);
+        if (kNull != v.aperture_shape) {  // Aperture.sample with a shape (aperture.zig:46-53): 2 * sampleContinuous(uv).uv - 1
+            float u, w;
+            imageLightSample(c_scene.image_lights[v.aperture_shape], s2, s3, u, w);
+            lx = 2.f * u - 1.f;
+            ly = 2.f * w - 1.f;
+        } else {
+            diskConcentric(s2, s3, lx, ly);
+        }
         origin = mk3(lx * v.lens_radius, ly * v.lens_radius, 0.f);
         const f3 focus = S3(v.focus_distance / direction.z) * direction;
         direction = focus - origin;

@@ -54,6 +54,7 @@ void logCompileError(int rc) {
             : -10 == rc ? "su_integrators_create asked for the light tracer (\"particle\"), photon mapping or the AOV integrator: only PT, PTDL and PTMIS are supported"
             : -9 == rc ? "a material in use asks for a texture feature that is not supported (procedural textures, image files "
                          "other than PNG / Radiance RGBE or that could not be read, IES profiles, Triplanar emission maps)"
+            : -11 == rc ? g->engine.camera_error.c_str()
             : -4 == rc ? "a material names an image that does not exist or has the wrong number of channels for its use"
                        : "scene uses a feature outside the hot-path scope (scattering volumes, emission maps on meshes ...)");
     if (-9 == rc && !g->engine.file_error.empty()) logf(2, "%s", g->engine.file_error.c_str());
@@ -79,6 +80,18 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
     if (0 != zygpu_upload_scene(c.ctx, &c.engine.sceneDesc())) {
         logf(2, "zygpu_upload_scene failed: %s", zygpu_last_error());
         return -1;
+    }
+    // Perspective.updateFocus (camera_perspective.zig:322-347): a focus point is met by one closest-hit probe ray per camera update,
+    // traced on the device through the scene just uploaded (the reference's walk, precise arithmetic)
+    float probe[8];
+    if (c.engine.focusProbe(probe)) {
+        float t = 0.f;
+        const int hit = zygpu_probe_closest(c.ctx, probe, &t);
+        if (hit < 0) {
+            logf(2, "the focus probe failed: %s", zygpu_last_error());
+            return -1;
+        }
+        c.engine.applyFocusProbe(1 == hit, t);
     }
     if (0 != zygpu_set_view(c.ctx, &c.engine.viewDesc())) {
         logf(2, "zygpu_set_view failed: %s", zygpu_last_error());
@@ -400,7 +413,10 @@ int32_t su_ext_camera_set_parameters(const char* json) {
     if (!g) return -1;
     zyg::JsonValue v;
     if (!parse(json, v)) return -1;
-    g->engine.loadCameraParameters(v);
+    if (!g->engine.loadCameraParameters(v)) {
+        logf(2, "%s", g->engine.camera_error.c_str());
+        return -1;
+    }
     return 0;
 }
 

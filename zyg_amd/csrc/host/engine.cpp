@@ -1108,13 +1108,73 @@ void Engine::cameraCreate(uint32_t width, uint32_t height) {  // capi.zig:143-16
     if (ZYGPU_NULL == camera_entity) camera_entity = createEntity();
 }
 
-void Engine::loadCameraParameters(const JsonValue& v) {  // camera_perspective.zig:260-270 (fov / lens / focus distance)
-    if (JsonValue::Object != v.type) return;
+// Perspective.setParameters (camera_perspective.zig:260-304) + loadFocus (348-361)
+bool Engine::loadCameraParameters(const JsonValue& v) {
+    if (JsonValue::Object != v.type) return true;
     for (const auto& kv : v.obj) {
-        if (kv.first == "fov") fov = kv.second.f32() * float(M_PI / 180.0);
-        else if (kv.first == "lens" || kv.first == "aperture") lens_radius = kv.second.memberF32("radius", lens_radius);
-        else if (kv.first == "focus") focus_distance = kv.second.memberF32("distance", focus_distance);
+        if (kv.first == "fov") {
+            fov = kv.second.f32() * float(M_PI / 180.0);
+        } else if (kv.first == "lens") {
+            lens_radius = kv.second.memberF32("radius", lens_radius);
+        } else if (kv.first == "aperture") {
+            lens_radius = kv.second.memberF32("radius", lens_radius);
+            const JsonValue* shape = kv.second.get("shape");
+            if (shape && JsonValue::String == shape->type && !shape->str.empty()) {
+                // tx.Provider.loadFile with usage Opacity (camera_perspective.zig:274-283): one channel, the file's W (or only) one
+                aperture_shape_image = loadImageFile(shape->str, kUsageOpacity, std::string(), false);
+                if (ZYGPU_NULL == aperture_shape_image) return camera_error = "the camera's aperture shape: " + file_error, false;
+                const HostImage& img = images_[aperture_shape_image];
+                // Aperture.setShape (aperture.zig:22-44) sizes its row of weights by the image's height and fills it by its width: only
+                // a square image is read as it was meant
+                if (img.width != img.height) return camera_error = "the camera's aperture shape must be a square image (camera/aperture.zig:22-44 reads no other correctly)", false;
+                if (ZYGPU_IMAGE_BYTE1_UNORM != img.format && ZYGPU_IMAGE_FLOAT1 != img.format)
+                    return camera_error = "the camera's aperture shape must be a one-channel image", false;
+            } else if (kv.second.memberU32("blades", 0) > 3) {
+                // camera_perspective.zig:284-300 rasterises the blades with rendering/shaper.zig, which is outside the hot-path scope
+                return camera_error = "a camera aperture with \"blades\" (the reference draws it with rendering/shaper.zig: not provided; give the shape as an image with \"shape\")", false;
+            }
+        } else if (kv.first == "focus") {
+            if (JsonValue::Object != kv.second.type) continue;
+            for (const auto& f : kv.second.obj) {
+                if (f.first == "point" && JsonValue::Array == f.second.type && f.second.arr.size() >= 3) {
+                    for (int i = 0; i < 3; ++i) focus_point[i] = f.second.arr[size_t(i)].f32();
+                    focus_use_point = true;
+                } else if (f.first == "distance") {
+                    focus_distance = f.second.f32();
+                }
+            }
+        } else if (kv.first == "stereo") {
+            // camera_perspective.zig:99-113, 301-303: two eye layers; the film, the sensor and the C ABI's resolve here have one
+            return camera_error = "a \"stereo\" camera (two layers: camera_perspective.zig:99-113) is not provided", false;
+        }
     }
+    return true;
+}
+
+bool Engine::focusProbe(float ray[8]) const {
+    if (!focus_use_point || !(lens_radius > 0.f)) return false;  // (or stereo.ipd > 0: refused above)
+    const ZygpuViewDesc& v = view_desc_;
+    // setFocus scales the point by the resolution (camera_perspective.zig:306-313); updateFocus' direction (322-327)
+    const float px = focus_point[0] * float(resolution[0]), py = focus_point[1] * float(resolution[1]);
+    Vec4f       dir = vec(v.left_top[0], v.left_top[1], v.left_top[2], 0.f) + vec(v.d_x[0], v.d_x[1], v.d_x[2], 0.f) * splat(px) +
+                vec(v.d_y[0], v.d_y[1], v.d_y[2], 0.f) * splat(py);
+    dir = normalize3(dir);
+    // scene.propTransformationAt(camera, time) at the frame's start: the static transformation, or the first keyframe (whose position
+    // is the scene's origin, space.zig:121-124)
+    const ZygpuTrafo& t = v.camera_trafo;
+    const Vec4f r0 = vec(t.r[0][0], t.r[0][1], t.r[0][2], 0.f), r1 = vec(t.r[1][0], t.r[1][1], t.r[1][2], 0.f), r2 = vec(t.r[2][0], t.r[2][1], t.r[2][2], 0.f);
+    // ComposedTransformation.objectToWorldVector: rotation columns scaled (composed_transformation.zig:60-70)
+    const Vec4f a = r0 * splat(t.r[0][3]), b = r1 * splat(t.r[1][3]), c = r2 * splat(t.r[2][3]);
+    Vec4f       w = splat(dir[0]) * a;
+    w = vec(std::fmaf(dir[1], b[0], w[0]), std::fmaf(dir[1], b[1], w[1]), std::fmaf(dir[1], b[2], w[2]), 0.f);
+    w = vec(std::fmaf(dir[2], c[0], w[0]), std::fmaf(dir[2], c[1], w[1]), std::fmaf(dir[2], c[2], w[2]), 0.f);
+    ray[0] = t.position[0], ray[1] = t.position[1], ray[2] = t.position[2], ray[3] = 0.f;
+    ray[4] = w[0], ray[5] = w[1], ray[6] = w[2], ray[7] = 2.14748313e+09f;  // ro.RayMaxT (ray_offset.zig:5)
+    return true;
+}
+
+void Engine::applyFocusProbe(bool hit, float t) {
+    if (hit) view_desc_.focus_distance = t + focus_point[2];  // camera_perspective.zig:341-343; no hit: the distance stays
 }
 
 // take/take.zig:131-271
@@ -1743,6 +1803,7 @@ void Engine::compileSky() {
 int Engine::compile(uint32_t frame) {
     // keyframes are relative to the frame's start (space.zig:114-125): without animations the compiled scene is the same for every frame
     if (ZYGPU_NULL == camera_entity) return -1;
+    if (!camera_error.empty()) return -11;  // a camera parameter that was refused by name (loadCameraParameters)
     simulate(frame);
     warnings_.clear();
     compileSky();  // scene.compile -> sky.compile (scene.zig:196-198)
@@ -1997,6 +2058,26 @@ int Engine::compile(uint32_t frame) {
     d.num_images = uint32_t(c_images_.size());
     ensureSrgbTable();
     d.srgb_to_float = srgb_to_float_.data();
+    // the camera's aperture shape (camera/aperture.zig:22-44): its Distribution2D rides with the scene's image lights, as their last entry
+    // (no light names it; ZygpuViewDesc.aperture_shape does)
+    aperture_light_ = ZYGPU_NULL;
+    if (ZYGPU_NULL != aperture_shape_image && lens_radius > 0.f) {
+        const HostImage& img = images_[aperture_shape_image];
+        image_lights_.emplace_back();
+        HostImageLight& il = image_lights_.back();
+        il.num_rows = uint32_t(img.height);
+        il.total_weight = 1.f;
+        std::vector<float> integrals(size_t(img.height)), row(size_t(img.width));
+        for (int y = 0; y < img.height; ++y) {
+            for (int x = 0; x < img.width; ++x) {  // Texture.image2D_1 (texture.zig:166-175)
+                const size_t i = size_t(y) * size_t(img.width) + size_t(x);
+                row[size_t(x)] = ZYGPU_IMAGE_BYTE1_UNORM == img.format ? float(img.pixels[i]) * (1.f / 255.f) : reinterpret_cast<const float*>(img.pixels.data())[i];
+            }
+            integrals[size_t(y)] = appendDistribution1D(row, il);
+        }
+        appendDistribution1D(integrals, il);
+        aperture_light_ = uint32_t(image_lights_.size() - 1);
+    }
     c_image_lights_.resize(image_lights_.size());
     for (size_t i = 0; i < image_lights_.size(); ++i) {
         const HostImageLight& il = image_lights_[i];
@@ -2087,6 +2168,7 @@ int Engine::compile(uint32_t frame) {
     }
     v.lens_radius = lens_radius;
     v.focus_distance = focus_distance;
+    v.aperture_shape = aperture_light_;
     v.camera_trafo = c_trafos_[camera_entity];
     if (camera_entity < keyframes_.size() && !keyframes_[camera_entity].empty()) {
         const std::vector<Transformation>& kf = keyframes_[camera_entity];

@@ -172,7 +172,11 @@ class Engine {
     void cameraCreate(uint32_t width, uint32_t height);
     void loadIntegrators(const JsonValue& v);
     void loadSensor(const JsonValue& v);
-    void loadCameraParameters(const JsonValue& v);
+    bool loadCameraParameters(const JsonValue& v);  // false: camera_error names what was refused
+    // Perspective.updateFocus (camera_perspective.zig:322-347): whether this camera wants its focus distance from a probe ray, the ray
+    // (8 floats: origin, min_t, direction, max_t; camera-relative world space as the compiled scene), and the result's way back
+    bool focusProbe(float ray[8]) const;
+    void applyFocusProbe(bool hit, float t);
 
     // Scene.compile + camera.update: fills scene_desc / view_desc (pointers stay valid until the next compile)
     int compile(uint32_t frame);
@@ -194,6 +198,13 @@ class Engine {
     float    fov = 0.f;
     float    lens_radius = 0.f;
     float    focus_distance = 0.f;
+    // camera_perspective.zig:16-20, 306-347: "focus": {"point": [x, y, z]}: x, y in [0, 1] of the frame (scaled by the resolution at
+    // compile, setFocus), z added to the distance the probe ray finds there (updateFocus, one closest-hit ray per camera update)
+    float    focus_point[3] = {0.5f, 0.5f, 0.f};
+    bool     focus_use_point = false;
+    // camera/aperture.zig:22-53: "aperture": {"shape": file}: a one-channel image whose values weight the lens (Distribution2D)
+    uint32_t aperture_shape_image = ZYGPU_NULL;
+    std::string camera_error;  // a camera parameter this build refuses by name ("blades", "stereo"): compile() fails with it
     uint32_t camera_entity = ZYGPU_NULL;
     uint32_t num_samples_per_pixel = 1;  // capi.zig:99
     uint32_t aov_slots = 0;              // take.view.aovs (take.zig:106-129): bit = ZygpuAovClass
@@ -231,6 +242,7 @@ class Engine {
     std::vector<Transformation> world_transformations_;
     std::vector<std::vector<Transformation>> keyframes_;  // per prop; empty = static (space.zig:23-26 frames / keyframes)
     std::vector<std::string>    warnings_;
+    uint32_t                    aperture_light_ = ZYGPU_NULL;  // the aperture's Distribution2D among image_lights_ (compile)
     const Transformation& frameStartTransformation(uint32_t p) const {  // space.zig:99-125 at the frame's start: keyframe 0
         return (p < keyframes_.size() && !keyframes_[p].empty()) ? keyframes_[p][0] : world_transformations_[p];
     }

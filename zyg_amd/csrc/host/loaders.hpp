@@ -198,7 +198,8 @@ class TakeLoader {
         if (const JsonValue* c = cam->get("crop"))
             if (JsonValue::Array == c->type && c->arr.size() >= 4)
                 for (int i = 0; i < 4; ++i) engine_.crop[i] = int32_t(c->arr[i].f32());
-        if (const JsonValue* p = cam->get("parameters")) engine_.loadCameraParameters(*p);
+        if (const JsonValue* p = cam->get("parameters"))
+            if (!engine_.loadCameraParameters(*p)) error = engine_.camera_error;  // refused by name ("blades", "stereo", a shape that cannot be read)
         if (const JsonValue* sh = cam->get("shutter")) {
             // loadShutter (take_loader.zig:153-191): the frame's length (frame_step / frames_per_second), the shutter's opening and
             // slope, motion_blur off.  This build renders the reference's defaults (1/60 s frames, open the whole frame, motion blur
