@@ -137,13 +137,14 @@ def test_two_processes_on_one_gpu_shard_the_frame(tmp_path, mode):
         np.testing.assert_allclose(d["reduced"][..., :3], d["full"][..., :3], rtol=1e-6, atol=1e-7)  # float association only
 
 
-def _bench_two_ranks(launcher):
+def _bench_two_ranks(launcher, extra=()):
     import json
     import subprocess
     env = dict(os.environ, ZYG_BENCH_BACKEND="gloo", ZYG_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180", "--iters-per-step", "4"]
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180", "--iters-per-step", "4",
+             *extra]
     if "torchrun" == launcher:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + bench
@@ -173,6 +174,22 @@ def test_bench_py_two_ranks_end_to_end():
     a, b = outs["torchrun"], outs["self"]
     assert a.keys() == b.keys() and a["config"] == b["config"] and a["rays_per_sample"] == b["rays_per_sample"]
     assert a["roofline"]["kernel_bytes"] == b["roofline"]["kernel_bytes"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["iterations", "rows"])
+def test_bench_py_strong_scaling_modes(shard):
+    """BASELINE.json configs[3] as written: a fixed number of samples per pixel split over the ranks (`--spp-total 16`), by iterations
+    (every rank renders 8 iterations of all rows) or by rows (every rank renders all 16 iterations of half the rows): the line says
+    "strong", names the sharding, the film holds the job's 16 samples per pixel everywhere, and `value` counts the job's samples
+    once."""
+    out = _bench_two_ranks("torchrun", ("--spp-total", "16", "--shard", shard))
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["parallelism"].startswith(f"{shard} x2, 16 spp in all (strong)")
+    assert out["config"]["spp_per_rank"] == (8 if "iterations" == shard else 16)
+    assert out["film_weight_min_max"] == [16.0, 16.0]
+    samples = 320 * 180 * 16
+    assert abs(out["value"] * 1e6 * out["ms_per_step"] * 1e-3 * out["steps"] / samples - 1.0) < 0.02
 
 
 def _rccl_worker(port, out_path):

@@ -746,6 +746,11 @@ ZD void pin(f3& v) {
     pin(v.y);
     pin(v.z);
 }
+ZD void pin(uint32_t& x) {
+#if ZYG_PIN
+    asm volatile("" : "+v"(x));
+#endif
+}
 
 ZD f3 xyz4(float4 v) { return {v.x, v.y, v.z}; }
 ZD float4 f4(f3 v, float w = 0.f) { return make_float4(v.x, v.y, v.z, w); }
@@ -2539,7 +2544,15 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     const uint32_t ps = sampleSlot<POOL>(slot);
     PathHead h;
     loadHead<POOL>(P, slot, h);
-    const Surface         sf = loadSurface<POOL, MESHL>(P, slot, h.flags, record);
+    // -DZYG_REBUILD_SURFACE=1 (an experiment, kept): the instantiations that know every light kind build the closure again where it
+    // is used (for a light sample that reached its light; for the bxdf sample behind the light loop) instead of keeping its ~100
+    // registers alive across the light kinds' sampling code and the shadow ray's walk, where the register allocator spills them
+    // (wf_scatter<.., MESHL, POOL>: 554 spilled registers).  It trades spill traffic for the closure's set-up: no gain measured.
+#ifndef ZYG_REBUILD_SURFACE
+#define ZYG_REBUILD_SURFACE 0  // measured (gpurun_out/r04f, one call): cornell_glass 115.3 -> 113.6, the outdoor scene at 3840x2160 218.3 -> 224.8 Msamples/s: off
+#endif
+    constexpr bool        kRebuild = MESHL && 0 != ZYG_REBUILD_SURFACE;
+    Surface               sf = loadSurface<POOL, MESHL>(P, slot, h.flags, record);
     const MaterialSample& ms = sf.ms;
     const float4          thr4 = P.pool.thr[slot];
     f3                    throughput = xyz4(thr4);
@@ -2621,7 +2634,12 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 const f3         radiance = (ZYG_EXPERIMENT_NEE_SKIP & 8) ? S3(lr) : materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
                 BxdfResult       bx;
                 if (ZYG_EXPERIMENT_NEE_SKIP & 2) bx.reflection = ls.wi, bx.pdf = ls.pdf;
-                else if (MESHL) {  // (pin: the closure's light-independent terms are computed here, not in front of the light loop)
+                else if (kRebuild) {
+                    uint32_t again = slot;
+                    pin(again);  // (the loads behind it cannot be merged with the first build's)
+                    const Surface se = loadSurface<POOL, MESHL>(P, again, h.flags, record);
+                    bx = se.ms.template evaluate<SUBST, POOL, MESHL>(s, ls.wi, POOL && max_splits > 1);
+                } else if (MESHL) {  // (pin: the closure's light-independent terms are computed here, not in front of the light loop)
                     MaterialSample mj = ms;
                     pin(mj.wo);
                     pin(mj.n);
@@ -2839,6 +2857,11 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     }
 
     // ---- bxdf sample + path extension (pathtracer_mis.zig:123-166)
+    if (kRebuild && ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {  // (the light loop ran: the closure it let go of)
+        uint32_t again = slot;
+        pin(again);
+        sf = loadSurface<POOL, MESHL>(P, again, h.flags, record);
+    }
     if (1 == ZYG_EXPERIMENT_SCATTER_PART) {
         storeHead<POOL>(P, slot, h);
         return;
@@ -2976,8 +2999,16 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     tm.mark(6);
 }
 
+// Occupancy: the plain instantiations 3 waves per SIMD, those with Substitute / multi-sample / mesh-light code 2; the POOL instantiation
+// that knows everything (every light kind, the complete closures, Glass with its split paths) ONE: with 256 registers it spilled
+// 554 of them and its time was the scratch traffic (wf_scatter 3.3 KB of HBM traffic per scattered vertex against ~0.7 KB of state,
+// profiles/r04e_cfg4_*), with 512 it spills 147 (relaxed units) and runs faster on half the waves: cornell_glass 115.3 -> 130.0
+// Msamples/s, the outdoor scene 218.3 -> 223.6 (gpurun_out/r04f, one call).
+#ifndef ZYG_SCATTER_POOL_FULL_WAVES
+#define ZYG_SCATTER_POOL_FULL_WAVES 1
+#endif
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false>
-__global__ void __launch_bounds__(256) ZYG_WAVES((SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
+__global__ void __launch_bounds__(256) ZYG_WAVES((MESHL && POOL && !STATS) ? ZYG_SCATTER_POOL_FULL_WAVES : (SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
     const uint32_t     nxt = P.parity ^ 1u;
     if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;

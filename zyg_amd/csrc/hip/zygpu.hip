@@ -479,6 +479,9 @@ struct ZygpuContext {
     // option "pool_relaxed" (default 1): with precise = 0, the POOL scenes (Glass, shadow catchers) run the relaxed units too; 0: they
     // get the precise units whatever the option says (relaxedUnits() below)
     bool          pool_relaxed = true;
+    // option "pool_tick_sync" (default 1): the POOL tick loop reads a level's queue lengths back and launches only the rounds that
+    // have vertices, with exact grids (zygpu_render)
+    bool          pool_tick_sync = true;
     bool          launch_failed = false;
     // option "uniform_tlas" (default on): scenes whose props fit the tables of dscene.hpp TlasEntry run the kernels that
     // walk them wave-wide instead of the top-level trees lane by lane (not the counting / MESHL / POOL instantiations)
@@ -842,7 +845,7 @@ int zygpu_create(int device_id, ZygpuContext** out_ctx) {
     }
     c->ctl = static_cast<Control*>(ctl);
     void* pinned = nullptr;
-    if (!check(hipHostMalloc(&pinned, sizeof(QueueCounts), hipHostMallocDefault), "hipHostMalloc")) {
+    if (!check(hipHostMalloc(&pinned, sizeof(QueueCounts) * kPoolVertices, hipHostMallocDefault), "hipHostMalloc")) {
         (void)hipFree(ctl);
         delete c;
         return -1;
@@ -1698,7 +1701,27 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         for (uint32_t t = 0; t < ticks; ++t) {
             if (c->pool_mode) {
                 // one level of every sample's vertex pool: round k = vertex k of the level, in order (shared samplers)
+                // option pool_tick_sync (default on): the level's four queue lengths are read back once per tick (they are final: a
+                // level's vertices are the children the previous tick created).  A round without vertices is not launched at all, the
+                // others with exact grids, and the batch ends with its last living vertex.  Rounds 1-3 only carry the second to fourth
+                // vertex of split paths and are mostly empty, yet an empty round cost ~120 us (wf_shade's complete pass alone 67 us: its
+                // 2 KB of scratch per lane are set up whether or not a wave finds an entry): 51 rounds per batch,
+                // 8 % of the outdoor scene's frame at 3840x2160 (profiles/r04a_cfg4_launch_times.txt).
+                uint32_t round_entries[kPoolVertices] = {num_paths, num_paths, num_paths, num_paths};
+                if (c->pool_tick_sync) {
+                    HIP_OK(hipMemcpyAsync(c->host_count, &c->ctl->ext_pool_count[P.parity][0], sizeof(QueueCounts) * kPoolVertices, hipMemcpyDeviceToHost, c->stream));
+                    HIP_OK(hipStreamSynchronize(c->stream));
+                    uint32_t all = 0;
+                    for (uint32_t k = 0; k < kPoolVertices; ++k) {
+                        const uint32_t* n = c->host_count + k * (sizeof(QueueCounts) / sizeof(uint32_t));
+                        round_entries[k] = n[0] + n[kCountStride];
+                        all += round_entries[k];
+                    }
+                    if (0 == all) break;
+                }
                 for (uint32_t k = 0; k < kPoolVertices; ++k) {
+                    if (c->pool_tick_sync && k > 0 && 0 == round_entries[k]) continue;  // (round 0 also prepares the next level's queues)
+                    const dim3 grid((std::max(round_entries[k], 1u) + 255u) / 256u);    // (shadows the batch's: this round's entries)
                     P.round = k;
                     // the plain instantiations (Rectangle / mesh geometry, single-sample Rectangle lights) or the full ones
                     const bool plain = !c->stats && !c->mesh_lights && !c->multi_sample_lights;
@@ -2138,6 +2161,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->pool_relaxed = 0 != value;
         return 0;
     }
+    if (0 == std::strcmp(name, "pool_tick_sync")) {
+        c->pool_tick_sync = 0 != value;
+        return 0;
+    }
     if (0 == std::strcmp(name, "mesh_kernels")) {
         c->mesh_kernels = 0 != value;
         return 0;
@@ -2219,6 +2246,7 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"fuse_tick", c->fuse_tick ? 1 : 0},
                  {"uniform_tlas", c->uniform_tlas ? 1 : 0},
                  {"pool_relaxed", c->pool_relaxed ? 1 : 0},
+                 {"pool_tick_sync", c->pool_tick_sync ? 1 : 0},
                  {"tick_sync", c->tick_sync ? 1 : 0}};
     for (const auto& e : table)
         if (0 == std::strcmp(name, e.name)) {
