@@ -1011,12 +1011,14 @@ def _band_around(vd, point, camera, h, rows=64):
 
 _CORNELL_CAMERA = (0.0, 1.0, -3.9)   # scenes.cornell's camera
 _OUTDOOR_CAMERA = (0.0, 1.1, -4.5)   # scenes.outdoor's
-# what the three bands of a configuration look at (world points): through the object, its shadow / caustic on the floor, a wall
+# what the three bands of a configuration look at (world points): through the object, where its shadow / caustic falls, a wall.  (At
+# 16:9 the 39.3 degree camera sees 11.4 degrees up and down: the back wall from y = 0.02 to 1.98, nothing of the floor; at the boxes'
+# depth y = 0.3 .. 1.7.  A point outside the frame clips its band to the frame's edge.)
 _CORNELL_BANDS = {
-    "cornell": ((-0.42, 1.0, 0.25), (0.3, 0.0, -0.8), (0.0, 1.75, 1.0)),       # the tall box, the floor in front of the boxes, the back wall
-    "config2_sphere": ((0.0, 1.2, 0.0), (0.0, 0.0, -0.3), (0.0, 1.9, 1.0)),    # the displaced sphere, its shadow, the back wall above it
-    "config2_mound": ((0.0, 0.2, 0.1), (0.0, 0.0, -0.8), (0.0, 1.5, 1.0)),     # the heightfield, the floor in front of it, the back wall
-    "glass": ((-0.35, 0.36, -0.5), (0.45, 0.0, -0.9), (0.0, 1.6, 1.0)),        # the glass Sphere (and box), the caustics in front, the back wall
+    "cornell": ((-0.42, 1.0, 0.25), (0.0, 0.1, 1.0), (0.0, 1.75, 1.0)),          # the tall box; the foot of the back wall behind the boxes; the wall's top
+    "config2_sphere": ((0.0, 1.2, 0.0), (0.0, 0.1, 1.0), (0.0, 1.9, 1.0)),       # the displaced sphere; the wall's foot below it (its shadow); the wall above it
+    "config2_mound": ((0.0, 0.3, 0.1), (0.0, 0.9, 1.0), (0.0, 1.75, 1.0)),       # the heightfield's crest; the wall behind it; the wall's top
+    "glass": ((-0.35, 0.6, -0.5), (0.45, 0.5, -0.35), (0.0, 1.6, 1.0)),          # through the glass Sphere; through the glass box (caustics behind both); the back wall
 }
 
 

@@ -2,6 +2,7 @@
 
 #include "ggx_lut.hpp"
 #include "image_readers.hpp"
+#include "sky_bake.hpp"
 
 #include <algorithm>
 #include <fstream>
@@ -1729,13 +1730,45 @@ void Engine::compileSky() {
     setWorldTransformation(sky_.sky, Transformation{splat(0.f), splat(1.f), quaternionMul(qx, qy)});
     const float sun_elevation = -std::asin(sun_direction[1]);
 
+    // Sky.bakeSky (sky.zig:172-221): the Prague model evaluated over the sun's disc and the canopy (host/sky_bake.hpp), when its
+    // library (zyg_amd/libarpraguesky.so, built from the reference's thirdparty/arpraguesky) and its dataset
+    // (sky/SkyModelDataset.dat.gz, looked up through the mounts like every file: su_mount) are there.  The reference caches the two
+    // images as ../cache/{sky,sun}_<hash>.exr; here the bake is kept while (visibility, albedo, elevation) stay what they were.
+    bool baked = false;
     if (!sky_.tables_given) {
+        const float key[3] = {sky_.visibility, sky_.albedo, sun_direction[1]};
+        if (sky_.baked && 0 == std::memcmp(key, sky_.baked_key, sizeof(key))) {
+            baked = true;
+        } else {
+            static skybake::PragueLibrary library;
+            std::string                   why;
+            const std::string             dataset = resolveFile("sky/SkyModelDataset.dat.gz");
+            if (!std::ifstream(dataset)) why = "sky/SkyModelDataset.dat.gz is in none of the mounted directories";
+            std::vector<float> sun_rgb, sky_rgb;
+            if (why.empty() && library.load(why) &&
+                skybake::bake(library, dataset, sun_direction[1], sky_.visibility, sky_.albedo, kSkyRadius, kSkySunSamples, kSkyBakeDimension, sun_rgb,
+                              sky_rgb, why)) {
+                sky_.sun_rgb = std::move(sun_rgb);
+                HostImage& img = images_[sky_.image];
+                img.width = img.height = kSkyBakeDimension;
+                img.pixels.resize(sky_rgb.size() * 4);
+                std::memcpy(img.pixels.data(), sky_rgb.data(), img.pixels.size());
+                std::memcpy(sky_.baked_key, key, sizeof(key));
+                sky_.baked = baked = true;
+            } else {
+                sky_.bake_refusal = why;
+                sky_.baked = false;
+            }
+        }
+    }
+    if (!sky_.tables_given && !baked) {
         // The reference bakes both tables from the Prague sky model (sky.zig:172-269), whose dataset
         // (sky/SkyModelDataset.dat.gz) does not ship with it.  What stands in, until a client hands over the products of a
         // bake (setSkyTables): a solar disc with limb darkening whose colour reddens with the air mass, and a hemisphere that
         // is bluer towards the zenith and brighter around the sun, written through the bake's own mappings (sunWiDotZ; the
         // clipped canopy mapping with the model's axes: x right, y up, the sun in the direction -z at its elevation).
-        warnings_.push_back("Sky: the Prague sky model's dataset is not available; the sun's radiance table and the sky image are a procedural stand-in");
+        warnings_.push_back("Sky: the Prague sky model's dataset is not available; the sun's radiance table and the sky image are a procedural stand-in (" +
+                            sky_.bake_refusal + ")");
         sky_.sun_rgb.resize(size_t(kSkySunSamples) * 3);
         const float n = float(kSkySunSamples - 1);
         for (uint32_t i = 0; i < kSkySunSamples; ++i) {

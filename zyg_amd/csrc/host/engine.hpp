@@ -295,6 +295,9 @@ class Engine {
         float    visibility = 100.f, albedo = 0.25f;                                                   // sky.zig:39-40
         Mat3x3   sun_rotation{{vec(1.f, 0.f, 0.f), vec(0.f, 0.f, 1.f), vec(0.f, -1.f, 0.f)}};          // sky.zig:42
         bool     tables_given = false;
+        bool     baked = false;       // sun_rgb and the sky image are the Prague model's (host/sky_bake.hpp) for baked_key
+        float    baked_key[3] = {0.f, 0.f, 0.f};  // visibility, albedo, the sun direction's y
+        std::string bake_refusal;     // why the bake did not run (no library, no dataset)
         std::vector<float> sun_rgb;  // kSkySunSamples x 3, as given or as generated
     } sky_;
     std::vector<float> c_sun_radiance_;  // 4 per sample
