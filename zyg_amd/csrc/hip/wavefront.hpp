@@ -1795,8 +1795,50 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         Hit        queued_hit{0.f, 0.f, 0.f, 0u, kNull};
         float      stochastic_r = 0.f;
         const bool queued = nullptr != P.hit_q;
+#ifndef ZYG_SORT_BLOCK
+#define ZYG_SORT_BLOCK 0
+#endif
+        uint32_t sorted_slot = kNull;
+        if (WIDE && !FIRST && ZYG_SORT_BLOCK) {
+            // -DZYG_SORT_BLOCK=1 (experiment): the block's 256 extension rays are dealt to its threads in the order of a 6-bit key: the
+            // octant of the cell (2 x 2 x 2 over the first large mesh's bounds) in which the ray enters those bounds, and the octant of
+            // its direction, so that a wave's rays start their walk in one region and visit a node's children in one order.
+            __shared__ uint32_t bins[64];
+            __shared__ uint32_t dealt[kTraceShadeBlock];
+            const bool valid = i < n;
+            uint32_t   mine = kNull, key = 63u;
+            if (valid) {
+                mine = P.q.ext[cur][at];
+                const float4 o = P.pool.ray_o[mine], d = P.pool.ray_d[mine];
+                const f3     lo = xyz4(scene.heavy_aabbs[0]), hi = xyz4(scene.heavy_aabbs[1]);
+                const f3     inv = S3(1.f) / xyz4(d);
+                const f3     t0 = (lo - xyz4(o)) * inv, t1 = (hi - xyz4(o)) * inv;
+                const float  enter = mx(mx(mn(t0.x, t1.x), mn(t0.y, t1.y)), mx(mn(t0.z, t1.z), 0.f));
+                const f3     p = (xyz4(o) + S3(enter) * xyz4(d) - lo) / (hi - lo);
+                const uint32_t cell = (p.x > 0.5f ? 1u : 0u) | (p.y > 0.5f ? 2u : 0u) | (p.z > 0.5f ? 4u : 0u);
+                const uint32_t octant = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+                key = cell * 8u + octant;
+            }
+            if (threadIdx.x < 64u) bins[threadIdx.x] = 0u;
+            __syncthreads();
+            const uint32_t rank = valid ? atomicAdd(&bins[key], 1u) : 0u;
+            __syncthreads();
+            if (threadIdx.x < 64u) {  // exclusive prefix over the 64 bins by the block's first wave
+                const uint32_t count = bins[threadIdx.x];
+                uint32_t       incl = count;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o);
+                    if (int(threadIdx.x) >= o) incl += up;
+                }
+                bins[threadIdx.x] = incl - count;
+            }
+            __syncthreads();
+            if (valid) dealt[bins[key] + rank] = mine;
+            __syncthreads();
+            if (valid) sorted_slot = dealt[threadIdx.x];  // (a block's valid entries are its first ones)
+        }
         if (i < n) {
-            slot = FIRST ? i : P.q.ext[cur][at];
+            slot = FIRST ? i : (WIDE && ZYG_SORT_BLOCK) ? sorted_slot : P.q.ext[cur][at];
             // the fresh path stays in registers until it is shaded, unless the traversal may draw from its sampler through the
             // pool (opacity masks: the MESHL instantiations)
             constexpr bool kFresh = FIRST && !MESHL;

@@ -292,8 +292,17 @@ __global__ void __launch_bounds__(256) calib_gather(const char* data, uint32_t n
 
 // bench.py's measured ceiling: a float4 grid-stride copy (MI355X_MICROARCH.md: 6.29 TB/s on this part in that shape)
 __global__ void __launch_bounds__(256) copy_float4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    // four independent 16 B loads per thread in flight before the first store (64 KB per 1024-thread CU share: what hides an HBM miss)
     const size_t stride = size_t(gridDim.x) * blockDim.x;
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    size_t       i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 __global__ void test_eval(uint32_t op, uint32_t n, const float* in, float* out) {
@@ -674,8 +683,12 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_ke
     ok = ok && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand) && m.alloc(paths * kMaxUnoccludingCandidates, &p.ucand_prim) &&
          m.alloc(qcap, &c->queues.ext[0]) && m.alloc(qcap, &c->queues.ext[1]) &&
          m.alloc(qcap * alive_keys, &c->queues.alive) &&  // a whole queue per sub-queue of the sorted alive queue: any one may get every path
-         m.alloc(paths, &c->stage_color) && m.alloc(paths, &c->stage_uv) && m.alloc(paths * std::max(1u, rounds), &p.picks) &&
-         m.alloc(paths, &p.sh_o) && m.alloc(paths, &p.sh_d) && m.alloc(paths, &p.contrib) && m.alloc(paths, &p.nee) && m.alloc(paths, &p.vis) &&
+         // (POOL: the staging buffer is by camera sample; the staged next-event estimation's arrays belong to kernels the POOL scenes never
+         // run: one element each.  3.7 KB per camera sample -> 2.9 KB: what lets a POOL batch hold 64 M samples)
+         m.alloc(c->pool_mode ? slots : paths, &c->stage_color) && m.alloc(c->pool_mode ? slots : paths, &c->stage_uv) &&
+         m.alloc((c->pool_mode ? size_t(1) : paths) * std::max(1u, rounds), &p.picks) && m.alloc(c->pool_mode ? size_t(1) : paths, &p.sh_o) &&
+         m.alloc(c->pool_mode ? size_t(1) : paths, &p.sh_d) && m.alloc(c->pool_mode ? size_t(1) : paths, &p.contrib) &&
+         m.alloc(c->pool_mode ? size_t(1) : paths, &p.nee) && m.alloc(c->pool_mode ? size_t(1) : paths, &p.vis) &&
          m.alloc(slots, &p.time) &&
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy) &&
          (!hit_q || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
@@ -1483,11 +1496,18 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     const int xb = v.crop[0] - fr, xe = v.crop[2] + fr;
     const size_t npix = size_t(xe - xb) * size_t(ye - yb);
 
-    // batch size: as many iterations as fit ~8M paths (bounded by what is left)
-    // POOL: 8 vertex records per slot, but rounds 1-3 are sparse; measured on a 1080p glass Cornell box 106 / 112 / 127
-    // Msamples/s at 4 / 8 / 16 M slots (and a collapse at 32 M, ~130 GB of pool)
-    const size_t   target_paths = (size_t(c->batch_mpaths) << 20) / (c->pool_mode ? 2 : 1);
-    const uint32_t per_batch = one_shot ? 1u : uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
+    // batch size: as many iterations as fit batch_mpaths x 2^20 paths (default 32 M; bounded by what is left), the call's iterations
+    // split evenly over the batches (16 iterations with room for 7 render as 6 + 5 + 5, not 7 + 7 + 2: a batch's ticks and their
+    // launches cost the same whatever it holds).
+    // POOL: twice as many camera samples (64 M by default, 2.9 KB each with their 8 vertex records: 186 GB of the part's 288).  Its ticks
+    // are many small launches (4 rounds x 4 kernels, a host round trip per tick), and deep ticks hold few vertices, so a batch's fixed
+    // cost is large: the outdoor scene at 3840x2160 (8.3 M pixels: 2 iterations per batch at 16 M samples) renders 239 / 285 / 321
+    // Msamples/s with batches of 16 / 32 / 64 M camera samples, cornell_glass at 1080p 124 / 133 / 138 with 8 / 16 / 32 M
+    // (gpurun_out/r04j, one call).
+    const size_t   target_paths = (size_t(c->batch_mpaths) << 20) * (c->pool_mode ? 2 : 1);
+    const uint32_t fit = uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
+    const uint32_t num_batches = (num_iterations + fit - 1u) / fit;
+    const uint32_t per_batch = one_shot ? 1u : (num_iterations + num_batches - 1u) / num_batches;
     // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
     const uint32_t rounds = nee ? std::min<uint32_t>(c->num_lights, 64u) : 0u;
@@ -2105,7 +2125,7 @@ int zygpu_measure_copy(ZygpuContext* c, uint64_t bytes, uint32_t repeats, double
     hipEvent_t a, b;
     HIP_OK(hipEventCreate(&a));
     HIP_OK(hipEventCreate(&b));
-    const dim3 grid(2048), block(256);
+    const dim3 grid(unsigned(std::max(1, c->num_cus)) * 8u), block(256);
     hipLaunchKernelGGL(copy_float4, grid, block, 0, c->stream, src, dst, n);  // warm-up
     (void)hipEventRecord(a, c->stream);
     for (uint32_t r = 0; r < repeats; ++r) hipLaunchKernelGGL(copy_float4, grid, block, 0, c->stream, src, dst, n);
