@@ -9,6 +9,7 @@
 //
 // Template parameters (wavefront.hpp):
 //   wf_generate<POOL>   wf_intersect<STATS, POOL, EXTRA>   wf_shade<STATS, MESHL, HEAVY, POOL>
+//   wf_light<MULTI, MASKS> + wf_scatter<.., PHASE 2>: the POOL scenes' complete wf_scatter in two kernels (wavefront.hpp scatterVertex)
 //   wf_trace_shade<STATS, MESHL, FIRST, UTLAS>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS>
 //   wf_rgenerate (1024-thread blocks)   wf_rtrace<WIDE>   wf_rscatter<SUBST, WIDE> (the regenerating kernels; Params::regen_*)
 //   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_shadow_u / wf_mesh_closest (persistent: launched with persistentGrid blocks)   wf_scatter_h<RESUME, SUBST>   wf_extend<SUBST, EXTRA>   wf_persistent<SUBST, MULTI, WIDE>   wf_tick<SUBST, MULTI, WIDE>
@@ -29,6 +30,8 @@
     X(0, K_SCATTER_STATS_POOL,   (wf_scatter<true, true, true, true, true>),          (P))  \
     X(1, K_SCATTER_MASKS_POOL,   (wf_scatter<false, true, true, true, true, true>),   (P))  \
     X(2, K_SCATTER_FULL_POOL,    (wf_scatter<false, true, true, true, true>),         (P))  \
+    X(1, K_LIGHT_POOL,           (wf_light<true, false>),                             (P))  \
+    X(2, K_SCATTER_EVAL_POOL,    (wf_scatter<false, true, true, true, true, false, false, false, 2>), (P))  \
     X(2, K_SCATTER_PLAIN_POOL,   (wf_scatter<false, true, false, false, true>),       (P))  \
     X(3, K_SCATTER_STATS,        (wf_scatter<true, true, true, true, false>),         (P))  \
     X(7, K_SCATTER_MASKS,        (wf_scatter<false, true, true, true, false, true>),  (P))  \

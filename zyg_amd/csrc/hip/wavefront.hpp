@@ -249,6 +249,12 @@ struct Params {
     // row.  Two uint4 per entry: (t, u, v, primitive), (prop, unoccluding count, stochastic_r, -).  wf_trace_shade / wf_shade write
     // them behind their append to the queue; the vertices deferred to wf_shade's second pass keep the slot-indexed record in between.
     uint4* hit_q;
+    // The split next-event estimation of the POOL scenes' complete kernels (wf_light + wf_scatter<.., PHASE 2>, below): per camera
+    // sample kMaxNeeStored light samples that reached their light (three float4 each: wi + light pdf; radiance + pick; transmittance +
+    // the pick's shadow-catcher flag) and their count (kNeeOverflow: the vertex took more and goes through the unsplit kernel)
+    float4*   nee_rec;
+    uint32_t* nee_count;
+    uint32_t  scatter_source;  // wf_scatter reads 0: the alive queue, 1: the overflow queue (Queues::shadow, shadow_count[0]) of wf_light
     uint32_t round;   // POOL: which vertex of the level this launch handles
     uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits
 };
@@ -2571,7 +2577,15 @@ struct ScatterOut {
 
 // One vertex of wf_scatter: sampleLights / evaluateLight with the shadow rays traced in the pick loop, then the bxdf sample
 // and the path extension (pathtracer_mis.zig:123-278).  Template parameters as wf_scatter's.
-template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE>
+// PHASE (the POOL scenes' complete instantiation only; 0 everywhere else: the vertex in one piece):
+//   1 (wf_light): the light half without a closure: light-tree picks, the light kinds' sampling, the shadow rays' walks, the lights'
+//     radiance and every sampler draw of sampleLights, in the reference's order; what each light sample that reached its light needs for
+//     its closure evaluation goes to Params::nee_rec, the sampler goes back to the pool.  The closure is built for the two bits that
+//     steer the light loop (can_evaluate, translucent) and dropped: the walk runs with ~100 registers fewer.
+//   2 (wf_scatter<.., 2>): the closure half: evaluates the stored samples in their order (same sums in the same grouping: the film is
+//     the same bits), then the bxdf sample and the path extension.
+constexpr uint32_t kMaxNeeStored = 4, kNeeOverflow = 0xFFFFFFFFu;
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE, int PHASE = 0>
 ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOut& out, Counters& cnt, unsigned long long& shadow_rays,
                       SectionTimer& tm, const HitRecord* record = nullptr) {
     const uint32_t nxt = P.parity ^ 1u;
@@ -2600,7 +2614,8 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     f3                    throughput = xyz4(thr4);
     const float           split_weight = POOL ? thr4.w : 1.f;
 
-    if (MESHL && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput, record);
+    if (2 == PHASE && kNeeOverflow == P.nee_count[ps]) return;  // wf_light sent the vertex through the unsplit kernel
+    if (MESHL && 1 != PHASE && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput, record);
     tm.mark(0);
 
     // POOL: the split budget of this vertex (Pool.maxSplits, vertex.zig:305-308; PathtracerMIS only: pathtracer.zig:73,
@@ -2621,6 +2636,50 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
 #ifndef ZYG_EXPERIMENT_SCATTER_PART
 #define ZYG_EXPERIMENT_SCATTER_PART 0  // register-pressure experiments (wrong images): 1 = the light samples alone, 2 = the bxdf sample alone
 #endif
+    uint32_t stored = 0;       // PHASE 1: light samples written to Params::nee_rec
+    bool     overflow = false;  //          more of them than the record holds
+    if (2 == PHASE) {
+        // the light samples wf_light stored, in its order; a pick's samples are summed by themselves first (evaluateLight's `result`),
+        // then added to the vertex' sum or, on a shadow catcher, to what the catcher lights send
+        if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {
+            const uint32_t count = P.nee_count[ps];
+            f3             nee = S3(0.f), occluded = S3(0.f), unoccluded = S3(0.f);
+            uint32_t       open_pick = kNull;
+            bool           open_catcher_light = false;
+            auto closePick = [&]() {
+                if (kNull == open_pick) return;
+                if (shadow_catcher && open_catcher_light) {  // pathtracer_mis.zig:274-276
+                    catcher_occluded = catcher_occluded + occluded;
+                    catcher_unoccluded = catcher_unoccluded + unoccluded;
+                } else {
+                    nee = nee + occluded;
+                }
+            };
+            for (uint32_t k = 0; k < count; ++k) {
+                const size_t at = size_t(3u * k) * batchPaths() + ps;
+                const float4 a = P.nee_rec[at], b = P.nee_rec[at + batchPaths()], c = P.nee_rec[at + 2 * size_t(batchPaths())];
+                if (__float_as_uint(b.w) != open_pick) {
+                    closePick();
+                    open_pick = __float_as_uint(b.w);
+                    open_catcher_light = 0.f != c.w;
+                    occluded = unoccluded = S3(0.f);
+                }
+                const f3         radiance = xyz4(b), tr = xyz4(c);
+                const BxdfResult bx = ms.template evaluate<SUBST, POOL, MESHL>(s, xyz4(a), POOL && max_splits > 1);
+                if (mis) {
+                    const float weight = predividedPowerHeuristic(a.w, bx.pdf);
+                    const f3    unocc = S3(weight) * radiance * bx.reflection;
+                    if (catcher_scene) unoccluded = unoccluded + unocc;
+                    occluded = occluded + tr * unocc;  // pathtracer_mis.zig:267-270
+                } else {
+                    const float weight = 1.f / a.w;
+                    occluded = occluded + S3(weight) * (tr * radiance * bx.reflection);
+                }
+            }
+            closePick();
+            ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
+        }
+    } else
     if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate && 2 != ZYG_EXPERIMENT_SCATTER_PART) {  // pathtracer_mis.zig:185-187: otherwise no draw at all
         const float     nee_threshold = splitThreshold(h.depth_surface);  // vertex.light_split_threshold of this vertex
         const float     select = h.smp.sample1D();
@@ -2674,6 +2733,18 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 }
                 const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
                 const f3         radiance = (ZYG_EXPERIMENT_NEE_SKIP & 8) ? S3(lr) : materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
+                if (1 == PHASE) {  // the closure's half of this sample happens in wf_scatter<.., 2>
+                    if (stored < kMaxNeeStored) {
+                        const size_t at = size_t(3u * stored) * batchPaths() + ps;
+                        P.nee_rec[at] = f4(ls.wi, ls.pdf * pick.pdf);
+                        P.nee_rec[at + batchPaths()] = f4(radiance, __uint_as_float(pk));
+                        P.nee_rec[at + 2 * size_t(batchPaths())] = f4(tr, light.shadow_catcher_light ? 1.f : 0.f);
+                        stored += 1;
+                    } else {
+                        overflow = true;
+                    }
+                    return;
+                }
                 BxdfResult       bx;
                 if (ZYG_EXPERIMENT_NEE_SKIP & 2) bx.reflection = ls.wi, bx.pdf = ls.pdf;
                 else if (kRebuild) {
@@ -2879,6 +2950,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                     if (rs.sample(u0, u1, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls)) connect(ls);
                 }
             }
+            if (1 == PHASE) continue;
             if (shadow_catcher && light.shadow_catcher_light) {  // pathtracer_mis.zig:274-276
                 catcher_occluded = catcher_occluded + occluded;
                 catcher_unoccluded = catcher_unoccluded + unoccluded;
@@ -2886,8 +2958,20 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 nee = nee + occluded;
             }
         }
-        ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
+        if (1 != PHASE) ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
         tm.mark(5);
+    }
+    if (1 == PHASE) {
+        // a vertex with more light samples than the record holds is left as it was (nothing of it has been stored) and goes through
+        // the unsplit kernel; every other vertex hands its sampler on, behind sampleLights' draws
+        if (overflow) {
+            P.nee_count[ps] = kNeeOverflow;
+            out.push = true;
+        } else {
+            P.nee_count[ps] = stored;
+            if (stored || (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate)) storeSamplers(P, ps, h);
+        }
+        return;
     }
     if (catcher_scene) {  // pathtracer_mis.zig:108-115 (whether or not the material could be evaluated)
         h.flags = shadow_catcher ? (h.flags | ST_FROM_CATCHER) : (h.flags & ~uint32_t(ST_FROM_CATCHER));
@@ -3049,14 +3133,50 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
 #ifndef ZYG_SCATTER_POOL_FULL_WAVES
 #define ZYG_SCATTER_POOL_FULL_WAVES 1
 #endif
-template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false>
-__global__ void __launch_bounds__(256) ZYG_WAVES((MESHL && POOL && !STATS) ? ZYG_SCATTER_POOL_FULL_WAVES : (SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
+#ifndef ZYG_LIGHT_WAVES
+#define ZYG_LIGHT_WAVES 2  // wf_light: waves per SIMD
+#endif
+#ifndef ZYG_SCATTER_EVAL_WAVES
+#define ZYG_SCATTER_EVAL_WAVES 2  // wf_scatter<.., PHASE 2>
+#endif
+// The light half of the POOL scenes' complete wf_scatter (scatterVertex PHASE 1): one lane per alive vertex, no closure, no queue
+// append but for the vertices that overflow the sample record (to Queues::shadow, which the unsplit kernel then reads).
+template <bool MULTI, bool MASKS>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_LIGHT_WAVES) wf_light(Params P) {
+    if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    bool           has_entry;
+    if (!aliveOpen(P, P.parity, i, at, has_entry)) return;  // whole blocks take part in queuePush
+    Counters           cnt{0, 0, 0};
+    unsigned long long shadow_rays = 0;
+    SectionTimer       tm;
+    tm.start(true);
+    ScatterOut out;
+    uint32_t   slot = 0;
+    if (has_entry) {
+        slot = P.alive_in[at];
+        scatterVertex<false, true, MULTI, true, true, MASKS, false, false, 1>(P, c_scene, slot, out, cnt, shadow_rays, tm, nullptr);
+    }
+    queuePush(P.q.shadow, &P.ctl->shadow_count[0], P.queue_capacity, out.push, slot);
+    tm.flush(P.ctl, 16);
+}
+
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false, int PHASE = 0>
+__global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_WAVES : (MESHL && POOL && !STATS) ? ZYG_SCATTER_POOL_FULL_WAVES : (SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
+    static_assert(0 == PHASE || (2 == PHASE && MESHL && POOL && !STATS), "the split next-event estimation: the POOL scenes' complete instantiation");
     const uint32_t     nxt = P.parity ^ 1u;
     if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t           at;
     bool               has_entry;
+    if (POOL && P.scatter_source) {  // wf_light's overflow queue: the vertices that took more light samples than its record holds
+        const uint32_t n = P.ctl->shadow_count[0].n[0];
+        if (blockIdx.x * blockDim.x >= n) return;
+        at = i;
+        has_entry = i < n;
+    } else
     if (!aliveOpen(P, P.parity, i, at, has_entry)) return;  // whole blocks take part in queuePush
     Counters           cnt{0, 0, 0};
     unsigned long long shadow_rays = 0;
@@ -3135,10 +3255,10 @@ __global__ void __launch_bounds__(256) ZYG_WAVES((MESHL && POOL && !STATS) ? ZYG
     }
 #else
     if (has_entry) {
-        slot = P.alive_in[at];
+        slot = (POOL && P.scatter_source) ? P.q.shadow[at] : P.alive_in[at];
         // Params::hit_q: the vertex' hit record sits at its place in the alive queue (its address does not wait for the slot)
         const HitRecord hr = (!POOL && P.hit_q) ? loadQueuedHit(P, at) : loadHitRecord(P, slot);
-        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE>(P, s, slot, out, cnt, shadow_rays, tm, &hr);
+        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE, PHASE>(P, s, slot, out, cnt, shadow_rays, tm, &hr);
     }
 #endif
     if (POOL) {

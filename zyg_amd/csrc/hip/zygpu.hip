@@ -491,6 +491,12 @@ struct ZygpuContext {
     // option "pool_tick_sync" (default 1): the POOL tick loop reads a level's queue lengths back and launches only the rounds that
     // have vertices, with exact grids (zygpu_render)
     bool          pool_tick_sync = true;
+    // option "split_nee" (default 1): the POOL scenes' complete wf_scatter as two kernels, wf_light (light sampling + shadow rays, no
+    // closure) and wf_scatter<.., PHASE 2> (closure evaluation + bxdf sample); scenes with opacity masks keep the one kernel
+    bool          split_nee = true;
+    uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
+    float4*       nee_rec = nullptr;       // Params::nee_rec / nee_count (POOL pool)
+    uint32_t*     nee_count = nullptr;
     bool          launch_failed = false;
     // option "uniform_tlas" (default on): scenes whose props fit the tables of dscene.hpp TlasEntry run the kernels that
     // walk them wave-wide instead of the top-level trees lane by lane (not the counting / MESHL / POOL instantiations)
@@ -692,7 +698,10 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_ke
          m.alloc(slots, &p.time) &&
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy) &&
          (!hit_q || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
+    c->nee_rec = nullptr;
+    c->nee_count = nullptr;
     if (ok && c->pool_mode) {
+        ok = m.alloc(slots * size_t(3u * kMaxNeeStored), &c->nee_rec) && m.alloc(slots, &c->nee_count);  // wf_light's records (192 + 4 B per camera sample)
         if (ok && c->catchers)
             ok = m.alloc(paths, &p.sc_occ) && m.alloc(paths, &p.sc_unocc) && m.alloc(paths, &p.sc_emis) && m.alloc(slots, &p.transp_rgb);
         for (uint32_t side = 0; side < 2; ++side) {
@@ -917,6 +926,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
 
     c->multi_sample_lights = false;
     c->mesh_lights = false;
+    c->max_light_samples = 0;
     for (uint32_t l = 0; l < d->num_lights; ++l) {
         if (d->lights[l].num_samples > 64) {  // shape.zig:44 MaxSamples
             g_error = "a light's emittance num_samples exceeds 64";
@@ -925,6 +935,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (d->lights[l].num_samples > 1) c->multi_sample_lights = true;
         const ZygpuProp& lp = d->props[d->lights[l].prop];
         const bool       is_mesh = ZYGPU_SHAPE_TRIANGLE_MESH == lp.shape;
+        // the most light samples one vertex can take (every light picked once, each with all its samples; a mesh light's primitive
+        // tree can pick up to 64 triangles): whether wf_light's record of kMaxNeeStored can overflow in this scene at all
+        c->max_light_samples += is_mesh ? 64u : std::max<uint32_t>(1u, d->lights[l].num_samples);
         const bool is_infinite = ZYGPU_SHAPE_DISTANT == lp.shape || ZYGPU_SHAPE_DOME == lp.shape || ZYGPU_SHAPE_CANOPY == lp.shape;
         if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && !is_infinite && ZYGPU_SHAPE_SPHERE != lp.shape && ZYGPU_SHAPE_DISK != lp.shape) {
             g_error = "only Rectangle, TriangleMesh, Sphere, Distant, Dome and Canopy lights are supported on the device path";
@@ -1554,6 +1567,9 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     P.regen_sample = nullptr;
     P.regen_slots = P.regen_samples = P.regen_report = 0;
     P.hit_q = nullptr;
+    P.nee_rec = c->nee_rec;
+    P.nee_count = c->nee_count;
+    P.scatter_source = 0;
     P.pixel_pcg = nullptr;
     if (one_shot) {
         if (c->pixel_pcg_capacity < npix) {
@@ -1766,7 +1782,17 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                         if (c->stats) launchKernel(c, K_SCATTER_STATS_POOL, grid.x, P, 0u);
                         else if (c->masks) launchKernel(c, K_SCATTER_MASKS_POOL, grid.x, P, 0u);
                         else if (plain) launchKernel(c, K_SCATTER_PLAIN_POOL, grid.x, P, 0u);
-                        else launchKernel(c, K_SCATTER_FULL_POOL, grid.x, P, 0u);
+                        else if (c->split_nee) {
+                            // the light half (no closure), the vertices that overflowed its record through the unsplit kernel (only in a
+                            // scene whose lights can send more than kMaxNeeStored samples to one vertex), the closure half
+                            launchKernel(c, K_LIGHT_POOL, grid.x, P, 0u);
+                            if (c->max_light_samples > kMaxNeeStored) {
+                                Params Q = P;
+                                Q.scatter_source = 1;
+                                launchKernel(c, K_SCATTER_FULL_POOL, grid.x, Q, 0u);
+                            }
+                            launchKernel(c, K_SCATTER_EVAL_POOL, grid.x, P, 0u);
+                        } else launchKernel(c, K_SCATTER_FULL_POOL, grid.x, P, 0u);
                     });
                 }
                 P.round = 0;
@@ -2185,6 +2211,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->pool_tick_sync = 0 != value;
         return 0;
     }
+    if (0 == std::strcmp(name, "split_nee")) {
+        c->split_nee = 0 != value;
+        return 0;
+    }
     if (0 == std::strcmp(name, "mesh_kernels")) {
         c->mesh_kernels = 0 != value;
         return 0;
@@ -2267,6 +2297,7 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"uniform_tlas", c->uniform_tlas ? 1 : 0},
                  {"pool_relaxed", c->pool_relaxed ? 1 : 0},
                  {"pool_tick_sync", c->pool_tick_sync ? 1 : 0},
+                 {"split_nee", c->split_nee ? 1 : 0},
                  {"tick_sync", c->tick_sync ? 1 : 0}};
     for (const auto& e : table)
         if (0 == std::strcmp(name, e.name)) {
