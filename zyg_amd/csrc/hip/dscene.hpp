@@ -32,6 +32,10 @@ struct DMesh {
     const float*    uvs;
     const float*    part_areas;
     const uint32_t* primitive_mapping;  // triangle -> index within its part; set when a part is a light
+    // 1: the relaxed units' per-lane any-hit walks of the reference's trees (the kernels that know every shape: MESHL / EXTRA / POOL)
+    // walk this mesh through its quantised four-wide re-layout (kWideBlasMinTriangles triangles or more, leaves and depth inside the
+    // walks' limits: zygpu_upload_scene), as the prop-table kernels do
+    uint32_t        wide;
 };
 
 // what a light-tree walk reads: the scene's tree over lights, or the primitive tree of one emissive mesh part
@@ -1234,6 +1238,10 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                         return stochasticOpacity(s, m, uv0, uv1, draw);
                     });
                 } else {
+                    // (the relaxed units' closest-hit walk stays on the BVH2 here: through the four-wide re-layout wf_intersect<POOL> measured
+                    // slower, cornell_glass 141 -> 180 ms per 4 steps with no mesh that qualifies, the outdoor scene 124 -> 136 with its
+                    // 1 M-triangle mesh: the walk's 32 KB of LDS stack per block and its registers cost the kernel more than the mesh's
+                    // shorter chain of loads returns; the any-hit walks below do take it)
                     found = meshIntersect<STATS>(mesh, local, h, cnt);
                 }
                 if (found) {
@@ -1511,8 +1519,9 @@ ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
                 float t, u, v;
                 if (rectangleIntersect(ray, trafo, t, u, v)) return true;
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
-                Ray local = worldToObjectRay(trafo, ray);
-                if (meshIntersectP<STATS>(s.meshes[prop.mesh], local, cnt)) return true;
+                Ray          local = worldToObjectRay(trafo, ray);
+                const DMesh& mesh = s.meshes[prop.mesh];
+                if ((ZYG_FAST && !STATS && mesh.wide) ? meshIntersectP<false, true>(mesh, local, cnt) : meshIntersectP<STATS>(mesh, local, cnt)) return true;
             } else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:148-172 intersectP: the same two roots
                 float t;
                 if (sphereIntersect(ray, trafo, t)) return true;
@@ -1629,7 +1638,7 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
                 Ray          local = worldToObjectRay(trafo, ray);
                 const DMesh& mesh = s.meshes[prop.mesh];
                 if (!evaluate) {
-                    if (meshIntersectP<STATS>(mesh, local, cnt)) return true;
+                    if ((ZYG_FAST && !STATS && mesh.wide) ? meshIntersectP<false, true>(mesh, local, cnt) : meshIntersectP<STATS>(mesh, local, cnt)) return true;
                     continue;
                 }
                 const bool mesh_blocked = bvhWalk<STATS>(mesh.nodes, 1u, local, cnt, [&](uint32_t tfirst, uint32_t tcount) {

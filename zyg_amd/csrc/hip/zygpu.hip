@@ -1077,7 +1077,9 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             else wide_ok = false;
             if (hm.num_triangles >= (1u << 24)) wide_ok = false;  // the walks' stack entries hold a 24-bit reference (dscene.hpp WideStack)
             // three parked children per level at most: a tree too deep for the walks' kStack4 entries would lose subtrees
-            if (3u * zyg::depth4(wide) > uint32_t(kStack4)) wide_ok = false;
+            const bool deep = 3u * zyg::depth4(wide) > uint32_t(kStack4);
+            if (deep) wide_ok = false;
+            dm.wide = (hm.num_triangles >= kWideBlasMinTriangles && !packed.empty() && hm.num_triangles < (1u << 24) && !deep) ? 1u : 0u;
         }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
         ok = ok && m.upload(hm.triangles, size_t(hm.num_triangles) * 3, &dm.triangles);
