@@ -539,7 +539,12 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * "pool_relaxed" (default 1): with "precise" 0 the scenes of the POOL kernels (Glass, shadow catchers) run the relaxed units as
  * every other scene does; 0 gives them the precise units whatever "precise" says (the reference's bits: where two surfaces of such
  * a scene coincide, a glass box standing on the floor, which of them a ray meets first hangs on the last bit of two formulas, and
- * only the precise units decide that as the reference does: DESIGN.md section 2). */
+ * only the precise units decide that as the reference does: DESIGN.md section 2);
+ * "pool_tick_sync" (default 1): the POOL tick loop reads a level's four queue lengths back once per tick and launches only the
+ * rounds that have vertices, with exact grids; a batch ends with its last living vertex;
+ * "split_nee" (default 1): the POOL scenes' complete wf_scatter runs as two kernels, wf_light (light sampling, shadow rays and every
+ * draw of sampleLights, without a closure) and wf_scatter<.., PHASE 2> (the closure's evaluation of the stored light samples, the
+ * bxdf sample, the path's extension); same film. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 /* Reads an option back, and what the library derived from the options and the uploaded scene (valid after zygpu_upload_scene):
  * "relaxed_units" 1 when the relaxed-arithmetic kernel units render this scene (option "precise" 0 and a scene they are inside
@@ -568,7 +573,7 @@ int zygpu_probe_closest(ZygpuContext* ctx, const float* ray8, float* out_t);
  * Run under `rocprofv3 --pmc FETCH_SIZE` it calibrates that counter on the access shape of the path-state blocks. */
 int zygpu_calibrate_gather(ZygpuContext* ctx, uint32_t stride_bytes, uint32_t num_records, uint32_t repeats, double* out_ms_per_launch);
 /* The copy rate this device reaches (bench.py's measured ceiling beside the nominal 8 TB/s): `repeats` launches of a float4
- * grid-stride copy kernel (2048 blocks of 256 threads, MI355X_MICROARCH.md's 6.29 TB/s shape) over two buffers of `bytes` each
+ * grid-stride copy kernel (8 blocks of 256 threads per CU, four 16 B loads in flight per thread) over two buffers of `bytes` each
  * on the context's stream, timed with HIP events; out_gbs = read + written bytes per second / 1e9. */
 int zygpu_measure_copy(ZygpuContext* ctx, uint64_t bytes, uint32_t repeats, double* out_gbs);
 
