@@ -2585,7 +2585,23 @@ struct ScatterOut {
 //   2 (wf_scatter<.., 2>): the closure half: evaluates the stored samples in their order (same sums in the same grouping: the film is
 //     the same bits), then the bxdf sample and the path extension.
 constexpr uint32_t kMaxNeeStored = 4, kNeeOverflow = 0xFFFFFFFFu;
-template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE, int PHASE = 0>
+// The light kinds of the MESHL instantiations' light loop (one sampling routine each).  KINDS: the kinds an instantiation compiles in
+// (bit 1 << kind); wf_light exists for the sets scenes mostly have (Rectangle lights only; a Sky entity's sun and sky map; all), and
+// zygpu_render launches the smallest one that holds the scene's kinds (lightKindOf below, the same decision on the host).
+enum LightKind : uint32_t { LK_NONE, LK_PORTAL, LK_IMAGE_FLAT, LK_IMAGE_SPHERE, LK_IMAGE_CANOPY, LK_MESH, LK_INFINITE, LK_SPHERE, LK_DISK, LK_RECTANGLE };
+constexpr uint32_t kAllLightKinds = 0xFFFFFFFFu;
+constexpr uint32_t kRectangleLightKinds = 1u << LK_RECTANGLE, kSkyLightKinds = (1u << LK_INFINITE) | (1u << LK_IMAGE_CANOPY);
+inline uint32_t lightKindOf(uint32_t light_class, uint32_t sampler, uint32_t shape) {  // (host: zygpu_upload_scene)
+    if (ZYGPU_LIGHT_PORTAL_IMAGE == light_class) return LK_PORTAL;
+    if (ZYGPU_LIGHT_PROP_IMAGE == light_class)
+        return (ZYGPU_SHAPE_DOME == shape || ZYGPU_SHAPE_RECTANGLE == shape || ZYGPU_SHAPE_DISK == shape) ? LK_IMAGE_FLAT
+               : ZYGPU_SHAPE_SPHERE == shape                                                           ? LK_IMAGE_SPHERE
+                                                                                                       : LK_IMAGE_CANOPY;
+    if (0xFFFFFFFFu != sampler) return LK_MESH;
+    if (ZYGPU_SHAPE_DISTANT == shape || ZYGPU_SHAPE_DOME == shape || ZYGPU_SHAPE_CANOPY == shape) return LK_INFINITE;
+    return ZYGPU_SHAPE_SPHERE == shape ? LK_SPHERE : ZYGPU_SHAPE_DISK == shape ? LK_DISK : LK_RECTANGLE;
+}
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE, int PHASE = 0, uint32_t KINDS = kAllLightKinds>
 ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOut& out, Counters& cnt, unsigned long long& shadow_rays,
                       SectionTimer& tm, const HitRecord* record = nullptr) {
     const uint32_t nxt = P.parity ^ 1u;
@@ -2789,7 +2805,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 // the first shadow test; phase 2 makes sample j from the replayed draws.  The per-light set-up (SphQuad, cone frame,
                 // chord, portal window) is made again in phase 2 instead of being carried across `connect`, whose registers it
                 // would add to: a light takes one sample but for the emittance's num_samples.
-                enum : uint32_t { LK_NONE, LK_PORTAL, LK_IMAGE_FLAT, LK_IMAGE_SPHERE, LK_IMAGE_CANOPY, LK_MESH, LK_INFINITE, LK_SPHERE, LK_DISK, LK_RECTANGLE };
+                constexpr auto has = [](uint32_t kind) { return 0 != (KINDS & (1u << kind)); };  // compiled into this instantiation
                 uint32_t lk = LK_NONE, n = 0;
                 Sampler  replay = h.smp;
                 float    mesh_r = 0.f;
@@ -2802,7 +2818,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 if (ZYG_EXPERIMENT_NEE_SKIP & 4) {
                     lk = LK_RECTANGLE;
                     n = 1;
-                } else if (ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {
+                } else if (has(LK_PORTAL) && ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {
                     // Light.propSamplePortalTo (light.zig:217-240) -> Rectangle.samplePortalTo (rectangle.zig:458-513): the window the
                     // point sees the portal through, then the map's windowed distribution; no window, no draw
                     Bounds2 bounds;
@@ -2811,17 +2827,17 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                         n = numSamples(light.num_samples, sample_threshold);
                         advance2D(n);
                     }
-                } else if (ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
+                } else if ((has(LK_IMAGE_FLAT) || has(LK_IMAGE_SPHERE) || has(LK_IMAGE_CANOPY)) && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
                     // Light.propSampleMaterialTo (light.zig:191-215): the emission map's distribution picks the direction
-                    if (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape || ZYGPU_SHAPE_DISK == light_shape) {
+                    if (has(LK_IMAGE_FLAT) && (ZYGPU_SHAPE_DOME == light_shape || ZYGPU_SHAPE_RECTANGLE == light_shape || ZYGPU_SHAPE_DISK == light_shape)) {
                         lk = LK_IMAGE_FLAT;
                         n = numSamples(light.num_samples, sample_threshold);
                         advance2D(n);
                     } else {
-                        lk = ZYGPU_SHAPE_SPHERE == light_shape ? LK_IMAGE_SPHERE : LK_IMAGE_CANOPY;  // one sample, drawn from the path's sampler
+                        lk = (has(LK_IMAGE_SPHERE) && ZYGPU_SHAPE_SPHERE == light_shape) ? LK_IMAGE_SPHERE : LK_IMAGE_CANOPY;  // one sample, drawn from the path's sampler
                         n = 1;
                     }
-                } else if (kNull != light.sampler) {
+                } else if (has(LK_MESH) && kNull != light.sampler) {
                     const DMeshLight&      ml = s.mesh_lights[light.sampler];
                     const MeshLightSampler msr = MeshLightSampler::init(sf.p, ms.geo_n, trafo);
                     mesh_r = h.smp.sample1D();
@@ -2830,10 +2846,10 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                     lk = LK_MESH;
                     n = ptree.randomLight(notimer, msr.op, msr.on, ms.translucent, mesh_r, sample_threshold, [](uint32_t, LightPick) {});
                     advance2D(n);
-                } else if (distant) {
+                } else if (has(LK_INFINITE) && distant) {
                     lk = LK_INFINITE;
                     n = 1;
-                } else if (ZYGPU_SHAPE_SPHERE == light_shape) {
+                } else if (has(LK_SPHERE) && ZYGPU_SHAPE_SPHERE == light_shape) {
                     const uint32_t      ns = numSamples(light.num_samples, sample_threshold);
                     const SphereSampler ss = SphereSampler::init(sf.p, trafo, ns);
                     if (ss.valid) {  // sphere.zig:331-337: a point inside the sphere takes no sample and no draw
@@ -2841,7 +2857,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                         n = ns;
                         advance2D(n);
                     }
-                } else if (ZYGPU_SHAPE_DISK == light_shape) {
+                } else if (has(LK_DISK) && ZYGPU_SHAPE_DISK == light_shape) {
                     const uint32_t    ns = numSamples(light.num_samples, sample_threshold);
                     const DiskSampler ds = DiskSampler::init(sf.p, trafo, ns);
                     if (ds.valid) {  // disk.zig:273-276: no sample, no draw
@@ -2854,7 +2870,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                             ds.sample(h.smp, sf.p, ms.geo_n, trafo, 0 != light.two_sided, ms.translucent, ls);
                         }
                     }
-                } else {
+                } else if (has(LK_RECTANGLE)) {
                     lk = LK_RECTANGLE;
                     n = MULTI ? numSamples(light.num_samples, sample_threshold) : 1u;  // shape_sampler.zig:35-41
                     if (MULTI) advance2D(n);
@@ -2866,7 +2882,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                     pin(pj);
                     pin(nj);
                     switch (lk) {
-                        case LK_PORTAL: {
+                        case LK_PORTAL: if (has(LK_PORTAL)) {
                             const DPortalLight& pl = s.portal_lights[light.sampler];
                             const Trafo         dome = loadTrafo(s, s.lights[pl.light_link].prop);  // (the host refuses an animated link)
                             Bounds2             bounds;
@@ -2876,7 +2892,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                             got = rectangleSamplePortal(pl, dome, bounds, r0, r1, float(n), pj, nj, trafo, ms.translucent, ls);
                             break;
                         }
-                        case LK_IMAGE_FLAT: {
+                        case LK_IMAGE_FLAT: if (has(LK_IMAGE_FLAT)) {
                             const DImageLight& il = s.image_lights[light.sampler];
                             float              r0, r1;
                             replay.sample2D(r0, r1);
@@ -2887,9 +2903,9 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                                       : rectangleSampleMaterial(il, r0, r1, float(n), pj, nj, trafo, 0 != light.two_sided, ms.translucent, ls);
                             break;
                         }
-                        case LK_IMAGE_SPHERE: got = sphereSampleMaterialTo(s.image_lights[light.sampler], pj, nj, trafo, ms.translucent, h.smp, ls); break;
-                        case LK_IMAGE_CANOPY: got = canopySampleMaterialTo(s.image_lights[light.sampler], nj, trafo, ms.translucent, h.smp, ls); break;
-                        case LK_MESH: {
+                        case LK_IMAGE_SPHERE: if (has(LK_IMAGE_SPHERE)) got = sphereSampleMaterialTo(s.image_lights[light.sampler], pj, nj, trafo, ms.translucent, h.smp, ls); break;
+                        case LK_IMAGE_CANOPY: if (has(LK_IMAGE_CANOPY)) got = canopySampleMaterialTo(s.image_lights[light.sampler], nj, trafo, ms.translucent, h.smp, ls); break;
+                        case LK_MESH: if (has(LK_MESH)) {
                             const DMeshLight&      ml = s.mesh_lights[light.sampler];
                             const DMesh&           mesh = s.meshes[ml.mesh];
                             const MeshLightSampler msr = MeshLightSampler::init(pj, nj, trafo);
@@ -2905,23 +2921,23 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                             break;
                         }
                         case LK_INFINITE:
-                            got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(nj, ms.translucent, h.smp, ls)
+                            if (has(LK_INFINITE)) got = ZYGPU_SHAPE_DOME == light_shape     ? domeSampleTo(nj, ms.translucent, h.smp, ls)
                                   : ZYGPU_SHAPE_CANOPY == light_shape ? canopySampleTo(nj, trafo, ms.translucent, h.smp, ls)
                                                                       : distantSampleTo(nj, trafo, ms.translucent, h.smp, ls);
                             break;
-                        case LK_SPHERE: {
+                        case LK_SPHERE: if (has(LK_SPHERE)) {
                             const SphereSampler ss = SphereSampler::init(pj, trafo, n);
                             float               s0, s1;
                             replay.sample2D(s0, s1);
                             got = ss.sample(s0, s1, pj, nj, trafo, ms.translucent, ls);
                             break;
                         }
-                        case LK_DISK: {
+                        case LK_DISK: if (has(LK_DISK)) {
                             const DiskSampler ds = DiskSampler::init(pj, trafo, n);
                             got = ds.sample(replay, pj, nj, trafo, 0 != light.two_sided, ms.translucent, ls);
                             break;
                         }
-                        default: {  // LK_RECTANGLE
+                        default: if (has(LK_RECTANGLE)) {  // LK_RECTANGLE
                             const RectangleSampler rs = RectangleSampler::init(pj, trafo, n);
                             float                  u0, u1;
                             if (MULTI) replay.sample2D(u0, u1);
@@ -3141,7 +3157,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
 #endif
 // The light half of the POOL scenes' complete wf_scatter (scatterVertex PHASE 1): one lane per alive vertex, no closure, no queue
 // append but for the vertices that overflow the sample record (to Queues::shadow, which the unsplit kernel then reads).
-template <bool MULTI, bool MASKS>
+template <bool MULTI, bool MASKS, uint32_t KINDS = kAllLightKinds>
 __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_LIGHT_WAVES) wf_light(Params P) {
     if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3156,7 +3172,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_LIGHT_WAVES) wf_light(Param
     uint32_t   slot = 0;
     if (has_entry) {
         slot = P.alive_in[at];
-        scatterVertex<false, true, MULTI, true, true, MASKS, false, false, 1>(P, c_scene, slot, out, cnt, shadow_rays, tm, nullptr);
+        scatterVertex<false, true, MULTI, true, true, MASKS, false, false, 1, KINDS>(P, c_scene, slot, out, cnt, shadow_rays, tm, nullptr);
     }
     queuePush(P.q.shadow, &P.ctl->shadow_count[0], P.queue_capacity, out.push, slot);
     tm.flush(P.ctl, 16);

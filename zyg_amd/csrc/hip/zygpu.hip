@@ -495,6 +495,7 @@ struct ZygpuContext {
     // closure) and wf_scatter<.., PHASE 2> (closure evaluation + bxdf sample); scenes with opacity masks keep the one kernel
     bool          split_nee = true;
     uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
+    uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
     float4*       nee_rec = nullptr;       // Params::nee_rec / nee_count (POOL pool)
     uint32_t*     nee_count = nullptr;
     bool          launch_failed = false;
@@ -927,6 +928,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     c->multi_sample_lights = false;
     c->mesh_lights = false;
     c->max_light_samples = 0;
+    c->light_kinds = 0;
     for (uint32_t l = 0; l < d->num_lights; ++l) {
         if (d->lights[l].num_samples > 64) {  // shape.zig:44 MaxSamples
             g_error = "a light's emittance num_samples exceeds 64";
@@ -938,6 +940,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         // the most light samples one vertex can take (every light picked once, each with all its samples; a mesh light's primitive
         // tree can pick up to 64 triangles): whether wf_light's record of kMaxNeeStored can overflow in this scene at all
         c->max_light_samples += is_mesh ? 64u : std::max<uint32_t>(1u, d->lights[l].num_samples);
+        c->light_kinds |= 1u << lightKindOf(d->lights[l].light_class, d->lights[l].sampler, lp.shape);
         const bool is_infinite = ZYGPU_SHAPE_DISTANT == lp.shape || ZYGPU_SHAPE_DOME == lp.shape || ZYGPU_SHAPE_CANOPY == lp.shape;
         if (ZYGPU_SHAPE_RECTANGLE != lp.shape && !is_mesh && !is_infinite && ZYGPU_SHAPE_SPHERE != lp.shape && ZYGPU_SHAPE_DISK != lp.shape) {
             g_error = "only Rectangle, TriangleMesh, Sphere, Distant, Dome and Canopy lights are supported on the device path";
@@ -1787,7 +1790,10 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                         else if (c->split_nee) {
                             // the light half (no closure), the vertices that overflowed its record through the unsplit kernel (only in a
                             // scene whose lights can send more than kMaxNeeStored samples to one vertex), the closure half
-                            launchKernel(c, K_LIGHT_POOL, grid.x, P, 0u);
+                            launchKernel(c, 0 == (c->light_kinds & ~kRectangleLightKinds) ? K_LIGHT_POOL_RECT
+                                            : 0 == (c->light_kinds & ~kSkyLightKinds)     ? K_LIGHT_POOL_SKY
+                                                                                          : K_LIGHT_POOL,
+                                         grid.x, P, 0u);
                             if (c->max_light_samples > kMaxNeeStored) {
                                 Params Q = P;
                                 Q.scatter_source = 1;
