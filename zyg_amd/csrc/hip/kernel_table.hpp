@@ -34,6 +34,7 @@
     X(0, K_LIGHT_POOL_RECT,      (wf_light<true, false, kRectangleLightKinds>),       (P))  \
     X(0, K_LIGHT_POOL_SKY,       (wf_light<true, false, kSkyLightKinds>),             (P))  \
     X(2, K_SCATTER_EVAL_POOL,    (wf_scatter<false, true, true, true, true, false, false, false, 2>), (P))  \
+    X(2, K_SCATTER_EVAL_POOL_PLAIN, (wf_scatter<false, true, false, false, true, false, false, false, 2>), (P))  \
     X(2, K_SCATTER_PLAIN_POOL,   (wf_scatter<false, true, false, false, true>),       (P))  \
     X(3, K_SCATTER_STATS,        (wf_scatter<true, true, true, true, false>),         (P))  \
     X(7, K_SCATTER_MASKS,        (wf_scatter<false, true, true, true, false, true>),  (P))  \

@@ -3152,13 +3152,19 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
 #ifndef ZYG_LIGHT_WAVES
 #define ZYG_LIGHT_WAVES 2  // wf_light: waves per SIMD
 #endif
+#ifndef ZYG_LIGHT_SKY_WAVES
+#define ZYG_LIGHT_SKY_WAVES 3  // ... of the instantiation for a sun and a sky map (217 registers without a spill; at 168: 40 spilled, and faster)
+#endif
 #ifndef ZYG_SCATTER_EVAL_WAVES
 #define ZYG_SCATTER_EVAL_WAVES 2  // wf_scatter<.., PHASE 2>
 #endif
 // The light half of the POOL scenes' complete wf_scatter (scatterVertex PHASE 1): one lane per alive vertex, no closure, no queue
 // append but for the vertices that overflow the sample record (to Queues::shadow, which the unsplit kernel then reads).
+// KINDS: the light kinds compiled in.  All of them: 256 registers with 87 spilled; Rectangle lights only: 256 with 6 (cornell_glass
+// 140 -> 149 Msamples/s); a Sky entity's sun and sky map: 217 with none, run at three waves per SIMD with 40 spilled (the outdoor scene
+// at 3840x2160 361 -> 367 at two waves -> 390 at three; the Rectangle one at three: 137): gpurun_out/r04r, one call.
 template <bool MULTI, bool MASKS, uint32_t KINDS = kAllLightKinds>
-__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_LIGHT_WAVES) wf_light(Params P) {
+__global__ void __launch_bounds__(256) ZYG_WAVES(kSkyLightKinds == KINDS ? ZYG_LIGHT_SKY_WAVES : ZYG_LIGHT_WAVES) wf_light(Params P) {
     if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
@@ -3181,7 +3187,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_LIGHT_WAVES) wf_light(Param
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false, int PHASE = 0>
 __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_WAVES : (MESHL && POOL && !STATS) ? ZYG_SCATTER_POOL_FULL_WAVES : (SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
-    static_assert(0 == PHASE || (2 == PHASE && MESHL && POOL && !STATS), "the split next-event estimation: the POOL scenes' complete instantiation");
+    static_assert(0 == PHASE || (2 == PHASE && POOL && !STATS), "the split next-event estimation: the POOL scenes' instantiations");
     const uint32_t     nxt = P.parity ^ 1u;
     if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;

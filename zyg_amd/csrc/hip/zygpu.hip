@@ -495,6 +495,7 @@ struct ZygpuContext {
     // closure) and wf_scatter<.., PHASE 2> (closure evaluation + bxdf sample); scenes with opacity masks keep the one kernel
     bool          split_nee = true;
     uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
+    bool          extended_materials = false;  // a material carries ZYGPU_MATF_EXTENDED (textures, coating, flakes ...): the complete closure
     uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
     float4*       nee_rec = nullptr;       // Params::nee_rec / nee_count (POOL pool)
     uint32_t*     nee_count = nullptr;
@@ -929,6 +930,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     c->mesh_lights = false;
     c->max_light_samples = 0;
     c->light_kinds = 0;
+    c->extended_materials = false;
     for (uint32_t l = 0; l < d->num_lights; ++l) {
         if (d->lights[l].num_samples > 64) {  // shape.zig:44 MaxSamples
             g_error = "a light's emittance num_samples exceeds 64";
@@ -1165,7 +1167,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                 return -2;
             }
             // the complete Substitute closure lives in the kernels that rebuild the whole fragment
-            if (mat.flags & ZYGPU_MATF_EXTENDED) c->mesh_lights = true;
+            if (mat.flags & ZYGPU_MATF_EXTENDED) c->mesh_lights = c->extended_materials = true;
         }
     }
 
@@ -1786,8 +1788,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                     timedLaunch(c, 5, [&] {
                         if (c->stats) launchKernel(c, K_SCATTER_STATS_POOL, grid.x, P, 0u);
                         else if (c->masks) launchKernel(c, K_SCATTER_MASKS_POOL, grid.x, P, 0u);
-                        else if (plain) launchKernel(c, K_SCATTER_PLAIN_POOL, grid.x, P, 0u);
-                        else if (c->split_nee) {
+                        else if (c->split_nee) {  // (scenes of the plain instantiations, too: wf_light's shapes and lights are a superset of theirs)
                             // the light half (no closure), the vertices that overflowed its record through the unsplit kernel (only in a
                             // scene whose lights can send more than kMaxNeeStored samples to one vertex), the closure half
                             launchKernel(c, 0 == (c->light_kinds & ~kRectangleLightKinds) ? K_LIGHT_POOL_RECT
@@ -1799,8 +1800,13 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                                 Q.scatter_source = 1;
                                 launchKernel(c, K_SCATTER_FULL_POOL, grid.x, Q, 0u);
                             }
-                            launchKernel(c, K_SCATTER_EVAL_POOL, grid.x, P, 0u);
-                        } else launchKernel(c, K_SCATTER_FULL_POOL, grid.x, P, 0u);
+                            // the closure half: the plain closures (Substitute without maps / coating / flakes, Glass) where the scene has no
+                            // other, no shadow catcher and records no AOVs (a Sphere or a sky map put the scene on the complete
+                            // kernels, not its materials)
+                            launchKernel(c, (!c->extended_materials && !c->catchers && 0 == v.aov_slots) ? K_SCATTER_EVAL_POOL_PLAIN : K_SCATTER_EVAL_POOL,
+                                         grid.x, P, 0u);
+                        } else if (plain) launchKernel(c, K_SCATTER_PLAIN_POOL, grid.x, P, 0u);
+                        else launchKernel(c, K_SCATTER_FULL_POOL, grid.x, P, 0u);
                     });
                 }
                 P.round = 0;
