@@ -54,6 +54,8 @@
     X(5, K_SHADE_PLAIN_HEAVY_POOL, (wf_shade<false, false, true, true>),              (P))  \
     X(5, K_SHADE_MESHL_LIGHT_POOL, (wf_shade<false, true, false, true>),              (P))  \
     X(5, K_SHADE_MESHL_HEAVY_POOL, (wf_shade<false, true, true, true>),               (P))  \
+    X(3, K_SHADE_MESHL_HEAVY_POOL_RECT, (wf_shade<false, true, true, true, kRectangleLightKinds>), (P))  \
+    X(3, K_SHADE_MESHL_HEAVY_POOL_SKY,  (wf_shade<false, true, true, true, kSkyLightKinds>),       (P))  \
     X(5, K_SHADE_STATS_HEAVY,    (wf_shade<true, true, true, false>),                 (P))  \
     X(5, K_SHADE_MESHL_HEAVY,    (wf_shade<false, true, true, false>),                (P))  \
     X(5, K_SHADE_PLAIN_HEAVY,    (wf_shade<false, false, true, false>),               (P))  \

@@ -1270,6 +1270,22 @@ ZD f3 materialRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, const Tra
     return emittanceRadiance<TEX>(s, m, wi, trafo.r2, area, in_camera, u, v, r);
 }
 
+// The light kinds of the MESHL instantiations' light loop (one sampling routine each).  KINDS: the kinds an instantiation compiles in
+// (bit 1 << kind); wf_light exists for the sets scenes mostly have (Rectangle lights only; a Sky entity's sun and sky map; all), and
+// zygpu_render launches the smallest one that holds the scene's kinds (lightKindOf below, the same decision on the host).
+enum LightKind : uint32_t { LK_NONE, LK_PORTAL, LK_IMAGE_FLAT, LK_IMAGE_SPHERE, LK_IMAGE_CANOPY, LK_MESH, LK_INFINITE, LK_SPHERE, LK_DISK, LK_RECTANGLE };
+constexpr uint32_t kAllLightKinds = 0xFFFFFFFFu;
+constexpr uint32_t kRectangleLightKinds = 1u << LK_RECTANGLE, kSkyLightKinds = (1u << LK_INFINITE) | (1u << LK_IMAGE_CANOPY);
+inline uint32_t lightKindOf(uint32_t light_class, uint32_t sampler, uint32_t shape) {  // (host: zygpu_upload_scene)
+    if (ZYGPU_LIGHT_PORTAL_IMAGE == light_class) return LK_PORTAL;
+    if (ZYGPU_LIGHT_PROP_IMAGE == light_class)
+        return (ZYGPU_SHAPE_DOME == shape || ZYGPU_SHAPE_RECTANGLE == shape || ZYGPU_SHAPE_DISK == shape) ? LK_IMAGE_FLAT
+               : ZYGPU_SHAPE_SPHERE == shape                                                           ? LK_IMAGE_SPHERE
+                                                                                                       : LK_IMAGE_CANOPY;
+    if (0xFFFFFFFFu != sampler) return LK_MESH;
+    if (ZYGPU_SHAPE_DISTANT == shape || ZYGPU_SHAPE_DOME == shape || ZYGPU_SHAPE_CANOPY == shape) return LK_INFINITE;
+    return ZYGPU_SHAPE_SPHERE == shape ? LK_SPHERE : ZYGPU_SHAPE_DISK == shape ? LK_DISK : LK_RECTANGLE;
+}
 struct VertexIn {  // what connectLight needs of the previous vertex (vertex.zig:45-65)
     f3       vorigin, vgeo_n;
     float    bxdf_pdf, light_split_threshold;
@@ -1277,8 +1293,9 @@ struct VertexIn {  // what connectLight needs of the previous vertex (vertex.zig
 };
 
 // Scene.lightPdf (scene.zig:624-634); MESHL: the scene has TriangleMesh lights
-template <bool MESHL>
+template <bool MESHL, uint32_t KINDS = kAllLightKinds>
 ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fragment& frag) {
+    constexpr auto has = [](uint32_t kind) { return 0 != (KINDS & (1u << kind)); };  // the light kinds compiled into this instantiation
     const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
     if ((v.flags & ST_SINGULAR) || kNull == light_id) return 1.f;
     const LightTree  lt{s, s.light_tree};
@@ -1286,10 +1303,12 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
     const float      select_pdf = lt.pdf(v.vorigin, v.vgeo_n, translucent, v.light_split_threshold, light_id);
     const ZygpuLight light = s.lights[light_id];
     float            sample_pdf;
-    if (MESHL && ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {  // light.zig:376-379 -> shape.zig:494-506 -> rectangle.zig:597-611
+    if (MESHL && has(LK_PORTAL) && ZYGPU_LIGHT_PORTAL_IMAGE == light.light_class) {  // light.zig:376-379 -> shape.zig:494-506 -> rectangle.zig:597-611
         sample_pdf = rectanglePortalPdf(s.portal_lights[light.sampler], ray_direction, v.vorigin, frag.trafo,
                                         float(numSamples(light.num_samples, v.light_split_threshold)));
-    } else if (MESHL && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {  // light.zig:371-374 -> shape.zig:509-526
+    } else if (MESHL && !has(LK_IMAGE_FLAT) && !has(LK_IMAGE_SPHERE) && has(LK_IMAGE_CANOPY) && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {
+        sample_pdf = imageLightPdf(s.image_lights[light.sampler], frag.uv0, frag.uv1) / (2.f * kPi);  // (a Canopy's map is the only image light here)
+    } else if (MESHL && (has(LK_IMAGE_FLAT) || has(LK_IMAGE_SPHERE) || has(LK_IMAGE_CANOPY)) && ZYGPU_LIGHT_PROP_IMAGE == light.light_class) {  // light.zig:371-374 -> shape.zig:509-526
         const DImageLight& il = s.image_lights[light.sampler];
         const uint32_t image_shape = s.props[light.prop].shape;
         sample_pdf = ZYGPU_SHAPE_DOME == image_shape ? domeMaterialPdf(il, frag.uv0, frag.uv1, numSamples(light.num_samples, v.light_split_threshold))
@@ -1302,33 +1321,35 @@ ZD float lightPdf(const DScene& s, const VertexIn& v, f3 ray_direction, const Fr
                      : ZYGPU_SHAPE_SPHERE == image_shape  // sphere.zig:489-502
                          ? sphereMaterialPdf(il, ray_direction, v.vorigin, frag.trafo, frag.p, frag.geo_n, frag.uv0, frag.uv1)
                          : imageLightPdf(il, frag.uv0, frag.uv1) / (2.f * kPi);
-    } else if (MESHL && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
+    } else if (MESHL && has(LK_MESH) && kNull != light.sampler) {  // light.zig:149-157 -> shape.zig:469-492 -> triangle_mesh.zig:647-691
         sample_pdf = meshLightPdf(s, s.mesh_lights[light.sampler], ray_direction, v.vorigin, v.vgeo_n, frag.trafo, frag.p, frag.geo_n,
                                   frag.primitive, translucent, v.light_split_threshold);
-    } else if (MESHL && ZYGPU_SHAPE_DISTANT == s.props[light.prop].shape) {  // -> distant.zig:139-141
+    } else if (MESHL && has(LK_INFINITE) && ZYGPU_SHAPE_DISTANT == s.props[light.prop].shape) {  // -> distant.zig:139-141
         sample_pdf = 1.f / distantSolidAngle(frag.trafo.scale.x);
-    } else if (MESHL && ZYGPU_SHAPE_SPHERE == s.props[light.prop].shape) {  // -> sphere.zig:469-485
+    } else if (MESHL && has(LK_SPHERE) && ZYGPU_SHAPE_SPHERE == s.props[light.prop].shape) {  // -> sphere.zig:469-485
         sample_pdf = spherePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
-    } else if (MESHL && ZYGPU_SHAPE_DISK == s.props[light.prop].shape) {  // -> disk.zig:492-533
+    } else if (MESHL && has(LK_DISK) && ZYGPU_SHAPE_DISK == s.props[light.prop].shape) {  // -> disk.zig:492-533
         sample_pdf = diskPdf(ray_direction, v.vorigin, frag.trafo, frag.p, numSamples(light.num_samples, v.light_split_threshold));
-    } else if (MESHL && ZYGPU_SHAPE_DOME == s.props[light.prop].shape) {  // -> dome.zig:214-220
+    } else if (MESHL && has(LK_INFINITE) && ZYGPU_SHAPE_DOME == s.props[light.prop].shape) {  // -> dome.zig:214-220
         sample_pdf = translucent ? 1.f / (4.f * kPi) : 1.f / (2.f * kPi);
-    } else if (MESHL && ZYGPU_SHAPE_CANOPY == s.props[light.prop].shape) {  // shape.zig:483
+    } else if (MESHL && has(LK_INFINITE) && ZYGPU_SHAPE_CANOPY == s.props[light.prop].shape) {  // shape.zig:483
         sample_pdf = 1.f / (2.f * kPi);
-    } else {  // -> rectangle.zig:554-575, with the light's sample count under the previous vertex's split threshold
+    } else if (has(LK_RECTANGLE)) {  // -> rectangle.zig:554-575, with the light's sample count under the previous vertex's split threshold
         sample_pdf = rectanglePdf(v.vorigin, frag.trafo, numSamples(light.num_samples, v.light_split_threshold));
+    } else {
+        sample_pdf = 0.f;  // (no light of this instantiation's kinds: zygpu_render launches the instantiation that holds the scene's)
     }
     return powerHeuristic(v.bxdf_pdf, sample_pdf * select_pdf);
 }
 
 // Vertex.evaluateRadiance (vertex.zig:183-212)
-template <bool MESHL>
+template <bool MESHL, uint32_t KINDS = kAllLightKinds>
 ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment& frag, Sampler& smp) {
     const ZygpuMaterial& m = s.materials[s.material_ids[s.props[frag.prop].parts_start + frag.part]];
     if (!(m.flags & ZYGPU_MATF_EMISSIVE) || (!(m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo))) return S3(0.f);
     // rs.uvw = scene.lightPortalUvw(vertex, frag) (scene.zig:636-648): through a Portal the map is read where the ray points
     float u = frag.uv0, vv = frag.uv1;
-    if (MESHL && s.portal_lights) {
+    if (MESHL && 0 != (KINDS & (1u << LK_PORTAL)) && s.portal_lights) {
         const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
         if (kNull != light_id && ZYGPU_LIGHT_PORTAL_IMAGE == s.lights[light_id].light_class) {
             const DPortalLight& pl = s.portal_lights[s.lights[light_id].sampler];
@@ -1337,7 +1358,7 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
     }
     const float stochastic_r = smp.sample1D();  // rs.stochastic_r
     const f3    energy = materialRadiance<MESHL>(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface, u, vv, stochastic_r);
-    const float weight = lightPdf<MESHL>(s, v, -wo, frag);
+    const float weight = lightPdf<MESHL, KINDS>(s, v, -wo, frag);
     return S3(weight) * energy;
 }
 
@@ -1347,7 +1368,7 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
 // `catcher` (PathtracerMIS on or behind a shadow catcher, pathtracer_mis.zig:303-337; `ray` then reaches to RayMaxT whatever was
 // hit): what a shadow-catcher light sends goes to catcher[1] (unoccluded) and, if the ray really left the scene (`escaped`), to
 // catcher[0] (occluded) as well, instead of into the returned emission
-template <bool STATS>
+template <bool STATS, uint32_t KINDS = kAllLightKinds>
 ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampler& smp, bool only_non_lights, Counters& cnt,
                        f3* catcher = nullptr, bool escaped = true) {
     f3       energy = S3(0.f);
@@ -1383,7 +1404,7 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
         frag.b = frag.trafo.r1;
         frag.part = 0;
         if (only_non_lights && !((v.flags & ST_SINGULAR) || kNull == s.light_ids[prop.parts_start])) continue;
-        const f3 local_energy = evaluateRadiance<true>(s, v, wo, frag, smp);
+        const f3 local_energy = evaluateRadiance<true, KINDS>(s, v, wo, frag, smp);
         if (catcher && (prop.flags & ZYGPU_PROP_SHADOW_CATCHER_LIGHT)) {
             if (escaped) catcher[0] = catcher[0] + local_energy;  // "The light was not occluded"
             catcher[1] = catcher[1] + local_energy;               // otherwise: "occluded, but we forced a hit"
@@ -1395,7 +1416,7 @@ ZD f3 infiniteEmission(const DScene& s, const VertexIn& v, const Ray& ray, Sampl
 }
 
 // the evaluation half of PropBvh.emission: the candidates wf_intersect recorded, in its traversal order
-template <bool MESHL>
+template <bool MESHL, uint32_t KINDS = kAllLightKinds>
 ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_t plane, const VertexIn& v, const Ray& ray, Sampler& smp) {
     f3             energy = S3(0.f);
     const uint32_t n = P.pool.ucount[slot];
@@ -1426,7 +1447,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
             frag.primitive = 0;
             rectangleFragment(ray, frag);
         }
-        energy = energy + evaluateRadiance<MESHL>(s, v, wo, frag, smp);
+        energy = energy + evaluateRadiance<MESHL, KINDS>(s, v, wo, frag, smp);
     };
     if (n > kMaxUnoccludingCandidates) {
         // more crossings than the list holds: walk the tree again, as PropBvh.emission itself does (prop_tree.zig:302-356), and
@@ -1449,7 +1470,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 // goes to the second pass untouched.
 // PRE: the caller holds the path's head (`pre`) and throughput (`pre_thr`).  1: a path generated in this kernel, nothing of it is
 // in the pool yet; 2: read from the pool before the traversal, so that the loads do not wait behind it
-template <bool STATS, bool MESHL, bool HEAVY, bool POOL, int PRE = 0>
+template <bool STATS, bool MESHL, bool HEAVY, bool POOL, int PRE = 0, uint32_t KINDS = kAllLightKinds>
 ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
                     Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr, float4 pre_thr = make_float4(1.f, 1.f, 1.f, 0.f),
                     float* sr_out = nullptr, uint32_t* material_out = nullptr) {
@@ -1535,39 +1556,41 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         v.flags = h.flags;
         v.depth_surface = h.depth_surface;
         v.light_split_threshold = 0.f;
-        if (ZYGPU_INTEGRATOR_PT == kind) {
-            v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
-            if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-            energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
-            if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
-        } else if (ZYGPU_INTEGRATOR_PTDL == kind) {
-            if (has_hit) {
-                const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
-                if ((h.flags & ST_SINGULAR) || kNull == light_id) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-            }
-            if (h.flags & ST_SINGULAR) energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
-            if (MESHL) energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, true, cnt);
-        } else {
-            v.light_split_threshold = splitThreshold(h.vdepth);
-            if (has_hit) energy = evaluateRadiance<MESHL>(s, v, wo, frag, h.smp);
-            tm.mark(1);
-            energy = energy + unoccludingEmission<MESHL>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
-            tm.mark(2);
-            if (POOL && MESHL && s.has_catcher) {
+        // The three integrators look at the same three places in the same order (the hit, the unoccluding emitters the ray crossed, the
+        // infinite props), each with its own conditions: one expansion of each place for all three (round 4: the complete pass of the
+        // kernels that know every light kind held a dozen expansions of the light's pdf and was 477 KB of code)
+        const bool is_pt = ZYGPU_INTEGRATOR_PT == kind, is_dl = ZYGPU_INTEGRATOR_PTDL == kind;
+        if (is_pt) v.flags |= ST_SINGULAR;  // pathtracer.zig:115-117: no MIS
+        if (!is_pt && !is_dl) v.light_split_threshold = splitThreshold(h.vdepth);
+        bool at_hit = has_hit;
+        if (is_dl && has_hit) {  // pathtracer_dl.zig:173-207: a light's own emission only where next-event estimation cannot have sampled it
+            const uint32_t light_id = s.light_ids[s.props[frag.prop].parts_start + frag.part];
+            at_hit = (h.flags & ST_SINGULAR) || kNull == light_id;
+        }
+        if (at_hit) energy = evaluateRadiance<MESHL, KINDS>(s, v, wo, frag, h.smp);
+        tm.mark(1);
+        if (!is_dl || (h.flags & ST_SINGULAR)) energy = energy + unoccludingEmission<MESHL, KINDS>(P, s, slot, vertexPlane<POOL>(), v, ray, h.smp);
+        tm.mark(2);
+        if (MESHL) {
+            Ray  far = ray;
+            f3*  catcher = nullptr;
+            bool escaped = true, look;
+            if (is_pt || is_dl) {
+                look = true;
+            } else if (POOL && s.has_catcher) {
                 // pathtracer_mis.zig:296-337: on a shadow catcher, or behind one, the infinite props are looked at as if nothing had
                 // been hit (the probe's max_t is RayMaxT for the loop)
                 shadow_catcher = has_hit && 0 != (s.props[hit_prop].flags & ZYGPU_PROP_SHADOW_CATCHER);
                 const bool handle = (h.flags & ST_FROM_CATCHER) || shadow_catcher;
-                const bool escaped = kRayMaxT == ray.max_t;
-                if (handle || escaped) {
-                    Ray far = ray;
-                    far.max_t = kRayMaxT;
-                    energy = energy + infiniteEmission<STATS>(s, v, far, h.smp, false, cnt, handle ? catcher_light : nullptr, escaped);
-                }
-            } else if (MESHL && !has_hit && kRayMaxT == ray.max_t) {
+                escaped = kRayMaxT == ray.max_t;
+                look = handle || escaped;
+                far.max_t = kRayMaxT;
+                catcher = handle ? catcher_light : nullptr;
+            } else {
                 // RayMaxT == max_t (pathtracer_mis.zig:313): not for a ray that ended at its medium's bounds
-                energy = energy + infiniteEmission<STATS>(s, v, ray, h.smp, false, cnt);
+                look = !has_hit && kRayMaxT == ray.max_t;
             }
+            if (look) energy = energy + infiniteEmission<STATS, KINDS>(s, v, far, h.smp, is_dl, cnt, catcher, escaped);
         }
     }
     const float4 thr4 = PRE ? pre_thr : float4(P.pool.thr[slot]);
@@ -1701,7 +1724,7 @@ ZD void storeQueuedHit(const Params& P, uint32_t position, const Hit& hit, uint3
 // no SphQuad), so that instantiation is small enough for twice the occupancy; the others go to the `heavy` queue, which
 // the HEAVY = true pass processes with the complete connectLight.
 // POOL: `slot` below is a vertex index
-template <bool STATS, bool MESHL, bool HEAVY, bool POOL>
+template <bool STATS, bool MESHL, bool HEAVY, bool POOL, uint32_t KINDS = kAllLightKinds>
 __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_WAVES : ZYG_SHADE_WAVES) : ZYG_SHADE_LIGHT_WAVES) wf_shade(Params P) {
     const uint32_t cur = P.parity;
     Counters       cnt{0, 0, 0};
@@ -1722,8 +1745,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             hit = Hit{__uint_as_float(hr.x), __uint_as_float(hr.y), __uint_as_float(hr.z), hr.w, P.pool.hit_prop[slot]};
             alive_key = hit.prop;
             ucount = P.pool.ucount[slot];
-            shadeVertex<STATS, MESHL, HEAVY, POOL>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, ucount, alive, defer, cnt, tm, nullptr,
-                                                   make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr, queued ? &material : nullptr);
+            shadeVertex<STATS, MESHL, HEAVY, POOL, 0, KINDS>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, ucount, alive, defer, cnt, tm, nullptr,
+                                                             make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr, queued ? &material : nullptr);
         }
         if (HEAVY && !POOL && P.regen_sample) {
             // the regenerating kernels: no queue behind this pass; a path that ended here leaves its slot to wf_rscatter
@@ -2585,22 +2608,6 @@ struct ScatterOut {
 //   2 (wf_scatter<.., 2>): the closure half: evaluates the stored samples in their order (same sums in the same grouping: the film is
 //     the same bits), then the bxdf sample and the path extension.
 constexpr uint32_t kMaxNeeStored = 4, kNeeOverflow = 0xFFFFFFFFu;
-// The light kinds of the MESHL instantiations' light loop (one sampling routine each).  KINDS: the kinds an instantiation compiles in
-// (bit 1 << kind); wf_light exists for the sets scenes mostly have (Rectangle lights only; a Sky entity's sun and sky map; all), and
-// zygpu_render launches the smallest one that holds the scene's kinds (lightKindOf below, the same decision on the host).
-enum LightKind : uint32_t { LK_NONE, LK_PORTAL, LK_IMAGE_FLAT, LK_IMAGE_SPHERE, LK_IMAGE_CANOPY, LK_MESH, LK_INFINITE, LK_SPHERE, LK_DISK, LK_RECTANGLE };
-constexpr uint32_t kAllLightKinds = 0xFFFFFFFFu;
-constexpr uint32_t kRectangleLightKinds = 1u << LK_RECTANGLE, kSkyLightKinds = (1u << LK_INFINITE) | (1u << LK_IMAGE_CANOPY);
-inline uint32_t lightKindOf(uint32_t light_class, uint32_t sampler, uint32_t shape) {  // (host: zygpu_upload_scene)
-    if (ZYGPU_LIGHT_PORTAL_IMAGE == light_class) return LK_PORTAL;
-    if (ZYGPU_LIGHT_PROP_IMAGE == light_class)
-        return (ZYGPU_SHAPE_DOME == shape || ZYGPU_SHAPE_RECTANGLE == shape || ZYGPU_SHAPE_DISK == shape) ? LK_IMAGE_FLAT
-               : ZYGPU_SHAPE_SPHERE == shape                                                           ? LK_IMAGE_SPHERE
-                                                                                                       : LK_IMAGE_CANOPY;
-    if (0xFFFFFFFFu != sampler) return LK_MESH;
-    if (ZYGPU_SHAPE_DISTANT == shape || ZYGPU_SHAPE_DOME == shape || ZYGPU_SHAPE_CANOPY == shape) return LK_INFINITE;
-    return ZYGPU_SHAPE_SPHERE == shape ? LK_SPHERE : ZYGPU_SHAPE_DISK == shape ? LK_DISK : LK_RECTANGLE;
-}
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE, int PHASE = 0, uint32_t KINDS = kAllLightKinds>
 ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOut& out, Counters& cnt, unsigned long long& shadow_rays,
                       SectionTimer& tm, const HitRecord* record = nullptr) {

@@ -1782,7 +1782,12 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                             launchKernel(c, K_SHADE_PLAIN_HEAVY_POOL, heavyGrid(c, grid.x), P, 0u);
                         } else {
                             launchKernel(c, K_SHADE_MESHL_LIGHT_POOL, grid.x, P, 0u);
-                            launchKernel(c, K_SHADE_MESHL_HEAVY_POOL, heavyGrid(c, grid.x), P, 0u);
+                            // the complete pass (emission at the hit, the crossed emitters, the infinite props, each with its light's pdf)
+                            // with the light kinds the scene has (wavefront.hpp LightKind)
+                            launchKernel(c, 0 == (c->light_kinds & ~kRectangleLightKinds) ? K_SHADE_MESHL_HEAVY_POOL_RECT
+                                            : 0 == (c->light_kinds & ~kSkyLightKinds)     ? K_SHADE_MESHL_HEAVY_POOL_SKY
+                                                                                          : K_SHADE_MESHL_HEAVY_POOL,
+                                         heavyGrid(c, grid.x), P, 0u);
                         }
                     });
                     timedLaunch(c, 5, [&] {
