@@ -32,8 +32,19 @@ ZD f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 ZD f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 
 // base/math/util.zig:17-29 (x86 forms)
+// The relaxed units take the hardware's v_min_f32 / v_max_f32 (one instruction, and v_min3 / v_max3 for nested ones) where the x86
+// form compiles to v_cmp + v_cndmask with the wait states gfx950 wants between a VALU write of vcc and its use: the two differ
+// only where the second operand is a NaN.  -DZYG_FAST_MINMAX=0: the x86 form in the relaxed units too.
+#ifndef ZYG_FAST_MINMAX
+#define ZYG_FAST_MINMAX ZYG_FAST
+#endif
+#if ZYG_FAST_MINMAX
+ZD float mn(float x, float y) { return __builtin_fminf(x, y); }
+ZD float mx(float x, float y) { return __builtin_fmaxf(x, y); }
+#else
 ZD float mn(float x, float y) { return x < y ? x : y; }
 ZD float mx(float x, float y) { return y < x ? x : y; }
+#endif
 ZD float clampf(float x, float lo, float hi) { return mn(mx(x, lo), hi); }
 ZD float saturate(float x) { return clampf(x, 0.f, 1.f); }
 ZD float stdClamp(float v, float lo, float hi) { return fmaxf(lo, fminf(v, hi)); }  // std.math.clamp

@@ -633,30 +633,67 @@ ZD bool bvh4Walk(const float4* nodes, Ray& ray, Leaf&& leaf) {
     }
 }
 
+// A triangle's corners as the walks' leaves read them (global_load: see Node4q::load)
+ZD void triangleVertices(const DMesh& mesh, uint32_t i, f3& a, f3& b, f3& c) {
+    typedef float                                            Corner __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(1))) Corner* v = (const __attribute__((address_space(1))) Corner*)(mesh.tri_verts + size_t(3) * i);
+    const Corner                                             va = v[0], vb = v[1], vc = v[2];
+    a = mk3(va.x, va.y, va.z);
+    b = mk3(vb.x, vb.y, vb.z);
+    c = mk3(vc.x, vc.y, vc.z);
+}
+
 // The four-wide nodes in their quantised form (bvh4.hpp compress4): one node = 64 B, half the bytes a walk pulls through the caches
 // (configs[2]: 484 -> 491.5 Msamples/s).  -DZYG_BVH4Q=0 walks the full-precision nodes.
 #ifndef ZYG_BVH4Q
 #define ZYG_BVH4Q 1
 #endif
+#ifndef ZYG_NODE4Q_GRID
+#define ZYG_NODE4Q_GRID 1  // 0: the child boxes are dequantised and tested as nodeIntersect tests a full-precision box
+#endif
 struct Node4q {
     uint4 a, b, c, d;
     ZD static Node4q load(const uint4* nodes, uint32_t i) {
-        const uint4* n = nodes + size_t(i) * 4;
-        return {n[0], n[1], n[2], n[3]};
+        // global_load instead of the flat_load a pointer out of the scene block gets (one counter to wait for, no LDS aperture check)
+        typedef uint32_t                                          Words __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(1))) Words* n = (const __attribute__((address_space(1))) Words*)(nodes + size_t(i) * 4);
+        const Words                                               a = n[0], b = n[1], c = n[2], d = n[3];
+        return {make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w), make_uint4(c.x, c.y, c.z, c.w), make_uint4(d.x, d.y, d.z, d.w)};
     }
-    // entry distance of child K, FLT_MAX for a miss or an empty slot
-    template <int K>
-    ZD float test(const Ray& ray, uint32_t& ref, uint32_t& count) const {
-        const uint32_t refs[4] = {c.z, c.w, d.x, d.y};
-        ref = refs[K];
-        count = (d.z >> (8 * K)) & 255u;
-        if (0xFFFFFFFFu == ref) return FLT_MAX;
+    // The ray in the node's quantisation grid: it crosses grid plane q of axis i at distance q * s[i] + c[i], so a child's six
+    // distances are six fmas of its bytes (the boxes are never dequantised: 4 x 9 instructions fewer per node).
+    struct Slabs {
+        f3 s, c;
+    };
+    ZD Slabs slabs(const Ray& ray) const {
         const f3 o = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
         const f3 sc = mk3(__uint_as_float((a.w & 255u) << 23), __uint_as_float(((a.w >> 8) & 255u) << 23), __uint_as_float(((a.w >> 16) & 255u) << 23));
+#if ZYG_NODE4Q_GRID
+        return {sc * ray.inv_direction, (o - ray.origin) * ray.inv_direction};
+#else
+        return {sc, o};
+#endif
+    }
+    // entry distance of child K, FLT_MAX for a miss or an empty slot; `packed` = the child's reference | its triangle count << 24
+    // (a WideStack entry)
+    template <int K>
+    ZD float test(const Slabs& g, const Ray& ray, uint32_t& packed) const {
+        const uint32_t refs[4] = {c.z, c.w, d.x, d.y};
+        const uint32_t ref = refs[K];
+        packed = __builtin_amdgcn_perm(d.z, ref, 0x00020100u | (uint32_t(4 + K) << 24));  // v_perm_b32: bytes 0-2 of ref, byte K of d.z on top
         const f3 qlo = mk3(float((b.x >> (8 * K)) & 255u), float((b.y >> (8 * K)) & 255u), float((b.z >> (8 * K)) & 255u));
         const f3 qhi = mk3(float((b.w >> (8 * K)) & 255u), float((c.x >> (8 * K)) & 255u), float((c.y >> (8 * K)) & 255u));
-        const f3 lo = fma3(qlo, sc, o), hi = fma3(qhi, sc, o);
+#if ZYG_NODE4Q_GRID
+        const f3    lower = fma3(qlo, g.s, g.c), upper = fma3(qhi, g.s, g.c);
+        const f3    t0 = min3v(lower, upper), t1 = max3v(lower, upper);
+        const float tboxmin = mx(mx(t0.x, t0.y), mx(t0.z, ray.min_t));
+        const float tboxmax = mn(mn(t1.x, t1.y), mn(t1.z, ray.max_t));
+        return ((0xFFFFFFFFu != ref) & (tboxmin <= tboxmax)) ? tboxmin : FLT_MAX;
+#else
+        if (0xFFFFFFFFu == ref) return FLT_MAX;
+        const f3 lo = fma3(qlo, g.s, g.c), hi = fma3(qhi, g.s, g.c);
         return nodeIntersect(make_float4(lo.x, lo.y, lo.z, 0.f), make_float4(hi.x, hi.y, hi.z, 0.f), ray);
+#endif
     }
 };
 
@@ -690,19 +727,36 @@ ZD uint32_t* wideStackLdsAny() {
     return entries;
 }
 
+// The entries past the LDS part.  A local of its own in the caller: an aggregate that is indexed by a variable is never split into
+// registers, and as members of WideStack these arrays kept its stack pointer and its LDS address in scratch with them (a scratch
+// load and a wait in front of every push and pop, the LDS entries read through flat loads).
+template <bool DIST>
+struct WideSpill {
+    uint32_t ref[kStack4 - kLdsStack];
+    float    dist[DIST ? kStack4 - kLdsStack : 1];
+};
+
+// The LDS part through pointers that carry their address space: with generic ones the compiler merges a pop's two sources (LDS entry
+// or spilled entry) into one flat load of a selected address.
+typedef uint32_t                                   WordPair __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) WordPair LdsUint2;
+typedef __attribute__((address_space(3))) uint32_t LdsUint;
+
 template <bool DIST>
 struct WideStack {
-    uint2*   lds;  // DIST: (reference | count, distance) per entry; otherwise one word, the lanes' words side by side
-    uint32_t spill_ref[kStack4 - kLdsStack];
-    float    spill_dist[DIST ? kStack4 - kLdsStack : 1];
-    int      sp = 0;
-    ZD WideStack() : lds(DIST ? wideStackLds() + threadIdx.x : reinterpret_cast<uint2*>(wideStackLdsAny() + threadIdx.x)) {}
-    ZD void push(uint32_t ref, uint32_t count, float dist) {
+    LdsUint2* lds2;  // DIST: (reference | count, distance) per entry
+    LdsUint*  lds1;  // otherwise one word, the lanes' words side by side
+    uint32_t* spill_ref;
+    float*    spill_dist;
+    int       sp = 0;
+    ZD explicit WideStack(WideSpill<DIST>& spill)
+        : lds2(DIST ? (LdsUint2*)(wideStackLds() + threadIdx.x) : nullptr), lds1(DIST ? nullptr : (LdsUint*)(wideStackLdsAny() + threadIdx.x)),
+          spill_ref(spill.ref), spill_dist(spill.dist) {}
+    ZD void push(uint32_t packed, float dist) {  // packed = reference | triangle count << 24 (Node4q::test)
         if (sp >= kStack4) return;
-        const uint32_t packed = ref | (count << 24);
         if (sp < kLdsStack) {
-            if (DIST) lds[sp * kLdsStackThreads] = make_uint2(packed, __float_as_uint(dist));
-            else reinterpret_cast<uint32_t*>(lds)[sp * kLdsStackThreads] = packed;
+            if (DIST) lds2[sp * kLdsStackThreads] = WordPair{packed, __float_as_uint(dist)};
+            else lds1[sp * kLdsStackThreads] = packed;
         } else {
             spill_ref[sp - kLdsStack] = packed;
             if (DIST) spill_dist[sp - kLdsStack] = dist;
@@ -715,11 +769,11 @@ struct WideStack {
         uint32_t packed;
         if (sp < kLdsStack) {
             if (DIST) {
-                const uint2 e = lds[sp * kLdsStackThreads];
+                const WordPair e = lds2[sp * kLdsStackThreads];
                 packed = e.x;
                 dist = __uint_as_float(e.y);
             } else {
-                packed = reinterpret_cast<const uint32_t*>(lds)[sp * kLdsStackThreads];
+                packed = lds1[sp * kLdsStackThreads];
             }
         } else {
             packed = spill_ref[sp - kLdsStack];
@@ -732,7 +786,8 @@ struct WideStack {
 
 template <typename Leaf>
 ZD bool bvh4qWalk(const uint4* nodes, Ray& ray, Leaf&& leaf) {
-    WideStack<true> stack;
+    WideSpill<true> spill;
+    WideStack<true> stack(spill);
     uint32_t        cur = 0, cur_count = 0;  // the root node
     auto pop = [&]() {
         while (stack.sp > 0) {
@@ -750,14 +805,15 @@ ZD bool bvh4qWalk(const uint4* nodes, Ray& ray, Leaf&& leaf) {
     for (;;) {
         while (0 == cur_count) {
             const Node4q n = Node4q::load(nodes, cur);
-            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
-            float        t0 = n.test<0>(ray, r0, n0), t1 = n.test<1>(ray, r1, n1), t2 = n.test<2>(ray, r2, n2), t3 = n.test<3>(ray, r3, n3);
-#define ZYG_CSWAP(i, j)                        \
-    if (t##j < t##i) {                         \
-        const float    tt = t##i;              \
-        const uint32_t rr = r##i, nn = n##i;   \
-        t##i = t##j, r##i = r##j, n##i = n##j; \
-        t##j = tt, r##j = rr, n##j = nn;       \
+            const Node4q::Slabs g = n.slabs(ray);
+            uint32_t     p0, p1, p2, p3;
+            float        t0 = n.test<0>(g, ray, p0), t1 = n.test<1>(g, ray, p1), t2 = n.test<2>(g, ray, p2), t3 = n.test<3>(g, ray, p3);
+#define ZYG_CSWAP(i, j)           \
+    if (t##j < t##i) {            \
+        const float    tt = t##i; \
+        const uint32_t pp = p##i; \
+        t##i = t##j, p##i = p##j; \
+        t##j = tt, p##j = pp;     \
     }
             ZYG_CSWAP(0, 1)
             ZYG_CSWAP(2, 3)
@@ -765,12 +821,12 @@ ZD bool bvh4qWalk(const uint4* nodes, Ray& ray, Leaf&& leaf) {
             ZYG_CSWAP(1, 3)
             ZYG_CSWAP(1, 2)
 #undef ZYG_CSWAP
-            if (FLT_MAX != t3) stack.push(r3, n3, t3);
-            if (FLT_MAX != t2) stack.push(r2, n2, t2);
-            if (FLT_MAX != t1) stack.push(r1, n1, t1);
+            if (FLT_MAX != t3) stack.push(p3, t3);
+            if (FLT_MAX != t2) stack.push(p2, t2);
+            if (FLT_MAX != t1) stack.push(p1, t1);
             if (FLT_MAX != t0) {
-                cur = r0;
-                cur_count = n0;
+                cur = p0 & 0xFFFFFFu;
+                cur_count = p0 >> 24;
             } else if (!pop()) {
                 return false;
             }
@@ -782,54 +838,58 @@ ZD bool bvh4qWalk(const uint4* nodes, Ray& ray, Leaf&& leaf) {
 
 template <typename Leaf>
 ZD bool bvh4qWalkAny(const uint4* nodes, const Ray& ray, Leaf&& leaf) {
-    WideStack<false> stack;
+    WideSpill<false> spill;
+    WideStack<false> stack(spill);
     uint32_t         cur = 0, cur_count = 0;
     float            unused = 0.f;
     for (;;) {
         while (0 == cur_count) {
             const Node4q n = Node4q::load(nodes, cur);
-            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
+            const Node4q::Slabs g = n.slabs(ray);
+            uint32_t     p0, p1, p2, p3;
 #if ZYG_ANY_NEAREST
             // the nearest child first, the others parked in storage order
-            const float  t0 = n.test<0>(ray, r0, n0), t1 = n.test<1>(ray, r1, n1), t2 = n.test<2>(ray, r2, n2), t3 = n.test<3>(ray, r3, n3);
+            const float  t0 = n.test<0>(g, ray, p0), t1 = n.test<1>(g, ray, p1), t2 = n.test<2>(g, ray, p2), t3 = n.test<3>(g, ray, p3);
             const float  tmin = mn(mn(t0, t1), mn(t2, t3));
             bool         have = FLT_MAX != tmin;
             uint32_t     nr = 0, nc = 0;
             bool         chosen = false;
-            auto         take = [&](float t, uint32_t r, uint32_t c) {
+            auto         take = [&](float t, uint32_t p) {
                 if (FLT_MAX == t) return;
                 if (!chosen && t == tmin) {
                     chosen = true;
-                    nr = r;
-                    nc = c;
+                    nr = p & 0xFFFFFFu;
+                    nc = p >> 24;
                 } else {
-                    stack.push(r, c, 0.f);
+                    stack.push(p, 0.f);
                 }
             };
-            take(t3, r3, n3);
-            take(t2, r2, n2);
-            take(t1, r1, n1);
-            take(t0, r0, n0);
+            take(t3, p3);
+            take(t2, p2);
+            take(t1, p1);
+            take(t0, p0);
 #else
-            const bool   h0 = FLT_MAX != n.test<0>(ray, r0, n0), h1 = FLT_MAX != n.test<1>(ray, r1, n1);
-            const bool   h2 = FLT_MAX != n.test<2>(ray, r2, n2), h3 = FLT_MAX != n.test<3>(ray, r3, n3);
+            const bool   h0 = FLT_MAX != n.test<0>(g, ray, p0), h1 = FLT_MAX != n.test<1>(g, ray, p1);
+            const bool   h2 = FLT_MAX != n.test<2>(g, ray, p2), h3 = FLT_MAX != n.test<3>(g, ray, p3);
             bool         have = false;
-            uint32_t     nr = 0, nc = 0;
-            auto         take = [&](bool h, uint32_t r, uint32_t c) {
+            uint32_t     np = 0;
+            auto         take = [&](bool h, uint32_t p) {
                 if (!h) return;
-                if (have) stack.push(nr, nc, 0.f);
-                nr = r;
-                nc = c;
+                if (have) stack.push(np, 0.f);
+                np = p;
                 have = true;
             };
-            take(h3, r3, n3);
-            take(h2, r2, n2);
-            take(h1, r1, n1);
-            take(h0, r0, n0);
+            take(h3, p3);
+            take(h2, p2);
+            take(h1, p1);
+            take(h0, p0);
+#endif
+#if ZYG_ANY_NEAREST
+            const uint32_t np = nr | (nc << 24);
 #endif
             if (have) {
-                cur = nr;
-                cur_count = nc;
+                cur = np & 0xFFFFFFu;
+                cur_count = np >> 24;
             } else {
                 if (0 == stack.sp) return false;
                 stack.pop(cur, cur_count, unused);
@@ -848,6 +908,7 @@ enum : int { kWalkRunning = 0, kWalkHit = 1, kWalkDone = 2 };
 struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
     WideStack<false> stack;
     uint32_t         cur = 0, cur_count = 0;
+    ZD explicit AnyWalk4q(WideSpill<false>& spill) : stack(spill) {}
     ZD void start() {
         stack.sp = 0;
         cur = 0;
@@ -857,25 +918,25 @@ struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
         float unused = 0.f;
         if (0 == cur_count) {
             const Node4q n = Node4q::load(mesh.nodes4q, cur);
-            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
-            const bool   h0 = FLT_MAX != n.test<0>(ray, r0, n0), h1 = FLT_MAX != n.test<1>(ray, r1, n1);
-            const bool   h2 = FLT_MAX != n.test<2>(ray, r2, n2), h3 = FLT_MAX != n.test<3>(ray, r3, n3);
+            const Node4q::Slabs g = n.slabs(ray);
+            uint32_t     p0, p1, p2, p3;
+            const bool   h0 = FLT_MAX != n.test<0>(g, ray, p0), h1 = FLT_MAX != n.test<1>(g, ray, p1);
+            const bool   h2 = FLT_MAX != n.test<2>(g, ray, p2), h3 = FLT_MAX != n.test<3>(g, ray, p3);
             bool         have = false;
-            uint32_t     nr = 0, nc = 0;
-            auto         take = [&](bool h, uint32_t r, uint32_t c) {
+            uint32_t     np = 0;
+            auto         take = [&](bool h, uint32_t p) {
                 if (!h) return;
-                if (have) stack.push(nr, nc, 0.f);
-                nr = r;
-                nc = c;
+                if (have) stack.push(np, 0.f);
+                np = p;
                 have = true;
             };
-            take(h3, r3, n3);
-            take(h2, r2, n2);
-            take(h1, r1, n1);
-            take(h0, r0, n0);
+            take(h3, p3);
+            take(h2, p2);
+            take(h1, p1);
+            take(h0, p0);
             if (have) {
-                cur = nr;
-                cur_count = nc;
+                cur = np & 0xFFFFFFu;
+                cur_count = np >> 24;
             } else {
                 if (0 == stack.sp) return kWalkDone;
                 stack.pop(cur, cur_count, unused);
@@ -883,7 +944,8 @@ struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
             return kWalkRunning;
         }
         for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
-            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            f3 a, b, c;
+            triangleVertices(mesh, i, a, b, c);
             float    t, u, v;
             if (triangleIntersect(ray, a, b, c, t, u, v)) return kWalkHit;
         }
@@ -896,6 +958,7 @@ struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
 struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks ray.max_t
     WideStack<true> stack;
     uint32_t        cur = 0, cur_count = 0;
+    ZD explicit ClosestWalk4q(WideSpill<true>& spill) : stack(spill) {}
     ZD void start() {
         stack.sp = 0;
         cur = 0;
@@ -919,14 +982,15 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
     ZD int step(const DMesh& mesh, Ray& ray, Found&& found) {
         if (0 == cur_count) {
             const Node4q n = Node4q::load(mesh.nodes4q, cur);
-            uint32_t     r0, r1, r2, r3, n0, n1, n2, n3;
-            float        t0 = n.test<0>(ray, r0, n0), t1 = n.test<1>(ray, r1, n1), t2 = n.test<2>(ray, r2, n2), t3 = n.test<3>(ray, r3, n3);
-#define ZYG_CSWAP(i, j)                        \
-    if (t##j < t##i) {                         \
-        const float    tt = t##i;              \
-        const uint32_t rr = r##i, nn = n##i;   \
-        t##i = t##j, r##i = r##j, n##i = n##j; \
-        t##j = tt, r##j = rr, n##j = nn;       \
+            const Node4q::Slabs g = n.slabs(ray);
+            uint32_t     p0, p1, p2, p3;
+            float        t0 = n.test<0>(g, ray, p0), t1 = n.test<1>(g, ray, p1), t2 = n.test<2>(g, ray, p2), t3 = n.test<3>(g, ray, p3);
+#define ZYG_CSWAP(i, j)           \
+    if (t##j < t##i) {            \
+        const float    tt = t##i; \
+        const uint32_t pp = p##i; \
+        t##i = t##j, p##i = p##j; \
+        t##j = tt, p##j = pp;     \
     }
             ZYG_CSWAP(0, 1)
             ZYG_CSWAP(2, 3)
@@ -934,18 +998,19 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
             ZYG_CSWAP(1, 3)
             ZYG_CSWAP(1, 2)
 #undef ZYG_CSWAP
-            if (FLT_MAX != t3) stack.push(r3, n3, t3);
-            if (FLT_MAX != t2) stack.push(r2, n2, t2);
-            if (FLT_MAX != t1) stack.push(r1, n1, t1);
+            if (FLT_MAX != t3) stack.push(p3, t3);
+            if (FLT_MAX != t2) stack.push(p2, t2);
+            if (FLT_MAX != t1) stack.push(p1, t1);
             if (FLT_MAX != t0) {
-                cur = r0;
-                cur_count = n0;
+                cur = p0 & 0xFFFFFFu;
+                cur_count = p0 >> 24;
                 return kWalkRunning;
             }
             return pop(ray) ? kWalkRunning : kWalkDone;
         }
         for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
-            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            f3 a, b, c;
+            triangleVertices(mesh, i, a, b, c);
             float    t, u, v;
             if (triangleIntersect(ray, a, b, c, t, u, v)) {
                 ray.max_t = t;
@@ -1015,7 +1080,8 @@ ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt
     auto     leaf = [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             if (STATS) cnt.tris += 1;
-            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            f3 a, b, c;
+            triangleVertices(mesh, i, a, b, c);
             float    t, u, v;
             if (triangleIntersect(local_ray, a, b, c, t, u, v) && accept(i, u, v)) {
                 local_ray.max_t = t;
@@ -1059,7 +1125,8 @@ ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
     auto leaf = [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             if (STATS) cnt.tris += 1;
-            const f3 a = xyz(mesh.tri_verts[3 * i]), b = xyz(mesh.tri_verts[3 * i + 1]), c = xyz(mesh.tri_verts[3 * i + 2]);
+            f3 a, b, c;
+            triangleVertices(mesh, i, a, b, c);
             float    t, u, v;
             if (triangleIntersect(local_ray, a, b, c, t, u, v)) return true;
         }

@@ -2232,7 +2232,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u
     bool           have = false, exhausted = false;
     uint32_t       slot = 0, entry = 0;
     Ray            local = Ray::init(S3(0.f), S3(0.f), 0.f, 0.f), world = local;
-    AnyWalk4q      walk;
+    WideSpill<false> spill;
+    AnyWalk4q      walk(spill);
     // the next large mesh at or behind solid_table[entry] whose bounds the ray enters: start its walk, or the ray is unoccluded
     auto nextMesh = [&]() {
         for (; entry < s.num_solid_table; ++entry) {
@@ -2303,7 +2304,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh
     uint32_t       slot = 0, entry = 0, depth = 0;
     Ray            local = Ray::init(S3(0.f), S3(0.f), 0.f, 0.f), world = local;
     Hit            hit;
-    ClosestWalk4q  walk;
+    WideSpill<true> spill;
+    ClosestWalk4q  walk(spill);
     auto nextMesh = [&]() {
         for (; entry < s.num_solid_table; ++entry) {
             const TlasEntry& e = s.solid_table[entry];
