@@ -31,6 +31,14 @@ ZD f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
 ZD f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 ZD f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 
+// `c ? a : b` between two lvalues is itself an lvalue: the compiler selects an ADDRESS and loads through it, and an aggregate whose
+// members are addressed by a variable is never split into registers (Sampler::buf kept every PathHead in scratch that way, the
+// medium stack's entries their record, the cube's axis the whole Fragment).  pick() selects between values.
+template <typename T>
+ZD T pick(bool c, T a, T b) {
+    return c ? T(a) : T(b);
+}
+
 // base/math/util.zig:17-29 (x86 forms)
 // The relaxed units take the hardware's v_min_f32 / v_max_f32 (one instruction, and v_min3 / v_max3 for nested ones) where the x86
 // form compiles to v_cmp + v_cndmask with the wait states gfx950 wants between a VALU write of vcc and its use: the two differ

@@ -166,8 +166,9 @@ struct Sampler {
         run_seed = sobol::hash(s + 1);
         dimension = 0;
     }
-    ZD float buf(uint32_t d) const {  // register-resident select instead of a dynamically indexed array
-        return d == 0 ? buffer[0] : d == 1 ? buffer[1] : d == 2 ? buffer[2] : d == 3 ? buffer[3] : buffer[4];
+    ZD float buf(uint32_t d) const {  // register-resident select instead of a dynamically indexed array (dmath.hpp pick)
+        const float b0 = buffer[0], b1 = buffer[1], b2 = buffer[2], b3 = buffer[3], b4 = buffer[4];
+        return pick(d == 0, b0, pick(d == 1, b1, pick(d == 2, b2, pick(d == 3, b3, b4))));
     }
     ZD float sample1D() {
         if (!isSobol()) return rng.randomFloat();

@@ -634,14 +634,15 @@ ZD bool bvh4Walk(const float4* nodes, Ray& ray, Leaf&& leaf) {
 }
 
 // A triangle's corners as the walks' leaves read them (global_load: see Node4q::load)
-ZD void triangleVertices(const DMesh& mesh, uint32_t i, f3& a, f3& b, f3& c) {
+ZD void triangleVertices(const float4* tri_verts, uint32_t i, f3& a, f3& b, f3& c) {
     typedef float                                            Corner __attribute__((ext_vector_type(4)));
-    const __attribute__((address_space(1))) Corner* v = (const __attribute__((address_space(1))) Corner*)(mesh.tri_verts + size_t(3) * i);
+    const __attribute__((address_space(1))) Corner* v = (const __attribute__((address_space(1))) Corner*)(tri_verts + size_t(3) * i);
     const Corner                                             va = v[0], vb = v[1], vc = v[2];
     a = mk3(va.x, va.y, va.z);
     b = mk3(vb.x, vb.y, vb.z);
     c = mk3(vc.x, vc.y, vc.z);
 }
+ZD void triangleVertices(const DMesh& mesh, uint32_t i, f3& a, f3& b, f3& c) { triangleVertices(mesh.tri_verts, i, a, b, c); }
 
 // The four-wide nodes in their quantised form (bvh4.hpp compress4): one node = 64 B, half the bytes a walk pulls through the caches
 // (configs[2]: 484 -> 491.5 Msamples/s).  -DZYG_BVH4Q=0 walks the full-precision nodes.
@@ -908,16 +909,22 @@ enum : int { kWalkRunning = 0, kWalkHit = 1, kWalkDone = 2 };
 struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
     WideStack<false> stack;
     uint32_t         cur = 0, cur_count = 0;
+    // the walked mesh's arrays, kept by the lane: read through the scene's mesh table at every step they were two dependent loads
+    // in front of each node's
+    const uint4*     nodes = nullptr;
+    const float4*    verts = nullptr;
     ZD explicit AnyWalk4q(WideSpill<false>& spill) : stack(spill) {}
-    ZD void start() {
+    ZD void start(const DMesh& mesh) {
+        nodes = mesh.nodes4q;
+        verts = mesh.tri_verts;
         stack.sp = 0;
         cur = 0;
         cur_count = 0;
     }
-    ZD int step(const DMesh& mesh, const Ray& ray) {
+    ZD int step(const Ray& ray) {
         float unused = 0.f;
         if (0 == cur_count) {
-            const Node4q n = Node4q::load(mesh.nodes4q, cur);
+            const Node4q n = Node4q::load(nodes, cur);
             const Node4q::Slabs g = n.slabs(ray);
             uint32_t     p0, p1, p2, p3;
             const bool   h0 = FLT_MAX != n.test<0>(g, ray, p0), h1 = FLT_MAX != n.test<1>(g, ray, p1);
@@ -945,7 +952,7 @@ struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
         }
         for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
             f3 a, b, c;
-            triangleVertices(mesh, i, a, b, c);
+            triangleVertices(verts, i, a, b, c);
             float    t, u, v;
             if (triangleIntersect(ray, a, b, c, t, u, v)) return kWalkHit;
         }
@@ -958,8 +965,12 @@ struct AnyWalk4q {  // = bvh4qWalkAny + meshIntersectP's leaf
 struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks ray.max_t
     WideStack<true> stack;
     uint32_t        cur = 0, cur_count = 0;
+    const uint4*    nodes = nullptr;  // as AnyWalk4q's
+    const float4*   verts = nullptr;
     ZD explicit ClosestWalk4q(WideSpill<true>& spill) : stack(spill) {}
-    ZD void start() {
+    ZD void start(const DMesh& mesh) {
+        nodes = mesh.nodes4q;
+        verts = mesh.tri_verts;
         stack.sp = 0;
         cur = 0;
         cur_count = 0;
@@ -979,9 +990,9 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
     }
     // `found(triangle, t, u, v)` for every hit nearer than the ray's end
     template <typename Found>
-    ZD int step(const DMesh& mesh, Ray& ray, Found&& found) {
+    ZD int step(Ray& ray, Found&& found) {
         if (0 == cur_count) {
-            const Node4q n = Node4q::load(mesh.nodes4q, cur);
+            const Node4q n = Node4q::load(nodes, cur);
             const Node4q::Slabs g = n.slabs(ray);
             uint32_t     p0, p1, p2, p3;
             float        t0 = n.test<0>(g, ray, p0), t1 = n.test<1>(g, ray, p1), t2 = n.test<2>(g, ray, p2), t3 = n.test<3>(g, ray, p3);
@@ -1010,7 +1021,7 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
         }
         for (uint32_t i = cur, e = cur + cur_count; i < e; ++i) {
             f3 a, b, c;
-            triangleVertices(mesh, i, a, b, c);
+            triangleVertices(verts, i, a, b, c);
             float    t, u, v;
             if (triangleIntersect(ray, a, b, c, t, u, v)) {
                 ray.max_t = t;
@@ -1309,7 +1320,10 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                     // slower, cornell_glass 141 -> 180 ms per 4 steps with no mesh that qualifies, the outdoor scene 124 -> 136 with its
                     // 1 M-triangle mesh: the walk's 32 KB of LDS stack per block and its registers cost the kernel more than the mesh's
                     // shorter chain of loads returns; the any-hit walks below do take it)
-                    found = meshIntersect<STATS>(mesh, local, h, cnt);
+#ifndef ZYG_WIDE_CLOSEST
+#define ZYG_WIDE_CLOSEST 0
+#endif
+                    found = (ZYG_WIDE_CLOSEST && ZYG_FAST && !STATS && mesh.wide) ? meshIntersect<false, true>(mesh, local, h, cnt) : meshIntersect<STATS>(mesh, local, h, cnt);
                 }
                 if (found) {
                     hit.t = h.t;
@@ -1866,8 +1880,11 @@ ZD void cubeFragment(const Ray& ray, Fragment& f) {  // cube.zig:41-61
     const f3    local_p = worldToObjectRay(f.trafo, ray).point(f.t_hit);
     const float d0 = fabsf(0.5f - fabsf(local_p.x)), d1 = fabsf(0.5f - fabsf(local_p.y)), d2 = fabsf(0.5f - fabsf(local_p.z));
     const int   i = d0 < d1 ? (d0 < d2 ? 0 : 2) : (d1 < d2 ? 1 : 2);  // indexMinComponent3
-    const float c = 0 == i ? local_p.x : 1 == i ? local_p.y : local_p.z;
-    const f3    axis = 0 == i ? f.trafo.r0 : 1 == i ? f.trafo.r1 : f.trafo.r2;
+    const float c = pick(0 == i, local_p.x, pick(1 == i, local_p.y, local_p.z));
+    // (component by component: a conditional between the three members themselves is an lvalue, i.e. a selected address, and a
+    // Fragment that is addressed by a variable stays in scratch as a whole, in every kernel that knows this shape)
+    const f3    r0 = f.trafo.r0, r1 = f.trafo.r1, r2 = f.trafo.r2;
+    const f3    axis = mk3(pick(0 == i, r0.x, pick(1 == i, r1.x, r2.x)), pick(0 == i, r0.y, pick(1 == i, r1.y, r2.y)), pick(0 == i, r0.z, pick(1 == i, r1.z, r2.z)));
     const f3    n = S3(copysignf(1.f, c)) * axis;
     f.part = 0;
     f.geo_n = f.n = n;

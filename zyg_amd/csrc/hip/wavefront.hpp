@@ -520,26 +520,35 @@ ZD uint32_t pathTime(const Params& P, uint32_t vertex) {
 
 struct Mediums {  // prop/medium.zig:30-153; an entry is its (prop, part): ior, priority and absorption are the material's
     uint32_t index;
-    uint32_t prop[3], part[3];  // push() stops at Num_entries - 1 = 3 entries
-    float    wavelength;        // probe.wavelength rides in the record's spare word: 0 until a dispersive Glass settles it
+    // push() stops at Num_entries - 1 = 3 entries.  Six words and selects, not arrays: an array that is indexed by a variable stays in
+    // scratch, and the record's other members with it
+    uint32_t p0, p1, p2, q0, q1, q2;
+    float    wavelength;  // probe.wavelength rides in the record's spare word: 0 until a dispersive Glass settles it
+    ZD uint32_t prop(uint32_t i) const { return pick(0 == i, p0, pick(1 == i, p1, p2)); }  // (dmath.hpp pick)
+    ZD uint32_t part(uint32_t i) const { return pick(0 == i, q0, pick(1 == i, q1, q2)); }
+    ZD void     set(uint32_t i, uint32_t fprop, uint32_t fpart) {
+        p0 = pick(0 == i, fprop, p0), q0 = pick(0 == i, fpart, q0);
+        p1 = pick(1 == i, fprop, p1), q1 = pick(1 == i, fpart, q1);
+        p2 = pick(2 == i, fprop, p2), q2 = pick(2 == i, fpart, q2);
+    }
     ZD void load(const Params& P, uint32_t vertex) {
         const uint4 a = P.pool.med0[vertex], b = P.pool.med1[vertex];
         index = a.x;
-        prop[0] = a.y, part[0] = a.z, prop[1] = a.w, part[1] = b.x, prop[2] = b.y, part[2] = b.z;
+        p0 = a.y, q0 = a.z, p1 = a.w, q1 = b.x, p2 = b.y, q2 = b.z;
         wavelength = __uint_as_float(b.w);
     }
     ZD void store(const Params& P, uint32_t vertex) const {
-        P.pool.med0[vertex] = make_uint4(index, prop[0], part[0], prop[1]);
-        P.pool.med1[vertex] = make_uint4(part[1], prop[2], part[2], __float_as_uint(wavelength));
+        P.pool.med0[vertex] = make_uint4(index, p0, q0, p1);
+        P.pool.med1[vertex] = make_uint4(q1, p2, q2, __float_as_uint(wavelength));
     }
     ZD const ZygpuMaterial& material(uint32_t i) const {
-        return c_scene.materials[c_scene.material_ids[c_scene.props[prop[i]].parts_start + part[i]]];
+        return c_scene.materials[c_scene.material_ids[c_scene.props[prop(i)].parts_start + part(i)]];
     }
     ZD float ior(uint32_t i) const {  // material.zig:140-146
         const ZygpuMaterial& m = material(i);
         return (ZYGPU_MAT_GLASS == m.kind || ZYGPU_MAT_SUBSTITUTE == m.kind) ? m.ior : 1.f;
     }
-    ZD bool  matches(uint32_t i, uint32_t fprop, uint32_t fpart) const { return prop[i] == fprop && part[i] == fpart; }
+    ZD bool  matches(uint32_t i, uint32_t fprop, uint32_t fpart) const { return prop(i) == fprop && part(i) == fpart; }
     ZD float topIor() const { return index > 0 ? ior(index - 1) : 1.f; }
     ZD float peekIor(uint32_t fprop, uint32_t fpart) const {
         if (index <= 1) return 1.f;
@@ -566,8 +575,7 @@ struct Mediums {  // prop/medium.zig:30-153; an entry is its (prop, part): ior, 
     }
     ZD void push(uint32_t fprop, uint32_t fpart) {
         if (index < 3) {
-            prop[index] = fprop;
-            part[index] = fpart;
+            set(index, fprop, fpart);
             index += 1;
         }
     }
@@ -576,8 +584,7 @@ struct Mediums {  // prop/medium.zig:30-153; an entry is its (prop, part): ior, 
         for (int32_t i = back; i >= 0; --i) {
             if (matches(uint32_t(i), fprop, fpart)) {
                 for (int32_t j = i; j < back; ++j) {
-                    prop[j] = prop[j + 1];
-                    part[j] = part[j + 1];
+                    set(uint32_t(j), prop(uint32_t(j + 1)), part(uint32_t(j + 1)));
                 }
                 index -= 1;
                 return;
@@ -1210,7 +1217,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
             Mediums md;
             md.load(P, slot);
             if (md.index > 0) {
-                const uint32_t mp = md.prop[md.index - 1];
+                const uint32_t mp = md.prop(md.index - 1);
                 const float    limit = aabbIntersectP(c_scene.aabbs[2 * mp], c_scene.aabbs[2 * mp + 1], ray);
                 ray.max_t = mn(offsetF(limit), o.w);
                 P.pool.ray_o[slot] = f4(ray.origin, ray.max_t);
@@ -2240,7 +2247,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u
             const TlasEntry& e = s.solid_table[entry];
             if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW) || !aabbIntersect(e.bmin, e.bmax, world)) continue;
             local = worldToObjectRay(entryTrafo(e), world);
-            walk.start();
+            walk.start(s.meshes[e.mesh]);
             return true;
         }
         return false;
@@ -2273,7 +2280,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U_WAVES) wf_shadow_u
 #pragma unroll 1
         for (int it = 0; it < ZYG_SHADOW_U_STEPS; ++it) {
             if (have) {
-                const int r = walk.step(s.meshes[s.solid_table[entry].mesh], local);
+                const int r = walk.step(local);
                 if (kWalkHit == r) {
                     P.pool.vis[slot] = 0u;
                     have = false;
@@ -2311,7 +2318,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh
             const TlasEntry& e = s.solid_table[entry];
             if (!propVisibleAtDepth(e.flags, depth) || !aabbIntersect(e.bmin, e.bmax, world)) continue;
             local = worldToObjectRay(entryTrafo(e), world);
-            walk.start();
+            walk.start(s.meshes[e.mesh]);
             return true;
         }
         return false;
@@ -2353,7 +2360,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh
         for (int it = 0; it < ZYG_SHADOW_U_STEPS; ++it) {
             if (have) {
                 const uint32_t prop = s.solid_table[entry].prop;
-                const int      r = walk.step(s.meshes[s.solid_table[entry].mesh], local, [&](uint32_t triangle, float t, float u, float v) {
+                const int      r = walk.step(local, [&](uint32_t triangle, float t, float u, float v) {
                     hit.t = t;
                     hit.u = u;
                     hit.v = v;
