@@ -194,13 +194,20 @@ struct LightTree {
         uint32_t st_node[12], st_depth[12];
         int      end = 0;
 
+        // (entry 0 is the reference's copy of the start state: popped last and never used, so it is neither written nor read here:
+        // a walk that does not split stays out of scratch)
         float    t_pdf = pd, t_random = (random - ip) / pd;
         uint32_t t_node = 0, t_depth = split ? 0u : max_split_depth;
-        st_pdf[0] = t_pdf;
-        st_random[0] = t_random;
-        st_node[0] = t_node;
-        st_depth[0] = t_depth;
         end = 1;
+        auto pop = [&]() {
+            end -= 1;
+            if (end > 0) {
+                t_pdf = st_pdf[end];
+                t_random = st_random[end];
+                t_node = st_node[end];
+                t_depth = st_depth[end];
+            }
+        };
 
         while (0 != end) {
             const ZygpuLightNode node = t.nodes[t_node];
@@ -223,11 +230,7 @@ struct LightTree {
                     float       p1 = nodeWeight(t.nodes[c1], p, n, total_sphere);
                     const float pt = p0 + p1;
                     if (0.f == pt) {
-                        end -= 1;
-                        t_pdf = st_pdf[end];
-                        t_random = st_random[end];
-                        t_node = st_node[end];
-                        t_depth = st_depth[end];
+                        pop();
                         continue;
                     }
                     p0 /= pt;
@@ -250,11 +253,7 @@ struct LightTree {
                     visit(current_light, LightPick{pick.offset, pick.pdf * t_pdf});
                     current_light += 1;
                 }
-                end -= 1;
-                t_pdf = st_pdf[end];
-                t_random = st_random[end];
-                t_node = st_node[end];
-                t_depth = st_depth[end];
+                pop();
             }
         }
         return current_light;

@@ -1257,7 +1257,10 @@ ZD bool sphereIntersectOpacity(const DScene& s, const ZygpuMaterial& m, const Ra
 // EXTRA: the scene has analytic shapes other than Rectangle (Sphere, Disk, Cube); kept out of the common instantiations,
 // where their code cost 12 % (registers of wf_shade's first pass and wf_intersect; measured 426 vs 374 Msamples/s)
 // `draw`: the path sampler's sample1D for the opacity masks (prop.zig:191-195 -> shape.intersectOpacity), EXTRA only
-template <bool STATS, bool EXTRA, typename Draw>
+// WIDEC (relaxed units, scenes with a mesh that has the quantised four-wide re-layout: DMesh::wide): such a mesh's closest hit
+// through that walk.  An instantiation of its own: the walk's LDS stack and registers cost a scene without such a mesh 3 %
+// (cornell_glass 176 -> 171 Msamples/s), the outdoor scene's 1 M-triangle mesh returns 2-6 % (3840x2160: 495 -> 505, 1080p: 428 -> 450).
+template <bool STATS, bool EXTRA, bool WIDEC = false, typename Draw>
 ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt, Draw& draw) {
     hit.prop = kNull;
     bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
@@ -1316,14 +1319,7 @@ ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& h
                         return stochasticOpacity(s, m, uv0, uv1, draw);
                     });
                 } else {
-                    // (the relaxed units' closest-hit walk stays on the BVH2 here: through the four-wide re-layout wf_intersect<POOL> measured
-                    // slower, cornell_glass 141 -> 180 ms per 4 steps with no mesh that qualifies, the outdoor scene 124 -> 136 with its
-                    // 1 M-triangle mesh: the walk's 32 KB of LDS stack per block and its registers cost the kernel more than the mesh's
-                    // shorter chain of loads returns; the any-hit walks below do take it)
-#ifndef ZYG_WIDE_CLOSEST
-#define ZYG_WIDE_CLOSEST 0
-#endif
-                    found = (ZYG_WIDE_CLOSEST && ZYG_FAST && !STATS && mesh.wide) ? meshIntersect<false, true>(mesh, local, h, cnt) : meshIntersect<STATS>(mesh, local, h, cnt);
+                    found = (WIDEC && ZYG_FAST && !STATS && mesh.wide) ? meshIntersect<false, true>(mesh, local, h, cnt) : meshIntersect<STATS>(mesh, local, h, cnt);
                 }
                 if (found) {
                     hit.t = h.t;

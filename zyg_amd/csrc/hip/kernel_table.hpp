@@ -85,6 +85,7 @@
     X(7, K_INTERSECT_STATS_POOL, (wf_intersect<true, true, true>),                    (P))  \
     X(7, K_INTERSECT_PLAIN_POOL, (wf_intersect<false, true, false>),                  (P))  \
     X(7, K_INTERSECT_EXTRA_POOL, (wf_intersect<false, true, true>),                   (P))  \
+    X(7, K_INTERSECT_EXTRA_POOL_WIDE, ZYG_WIDE((wf_intersect<false, true, true, true>), (wf_intersect<false, true, true>)), (P)) \
     X(7, K_INTERSECT_STATS,      (wf_intersect<true, false, true>),                   (P))  \
     X(7, K_INTERSECT_EXTRA,      (wf_intersect<false, false, true>),                  (P))  \
     X(7, K_INTERSECT_PLAIN,      (wf_intersect<false, false, false>),                 (P))  \

@@ -1185,7 +1185,7 @@ ZD uint32_t unoccludingCandidates(const Params& P, const DScene& s, uint32_t slo
 // ---------------------------------------------------------------- wf_intersect
 // EXTRA (= the scenes that run the MESHL instantiations): Sphere / Disk / Cube code (dscene.hpp), mesh lights as unoccluding
 // candidates
-template <bool STATS, bool POOL, bool EXTRA>
+template <bool STATS, bool POOL, bool EXTRA, bool WIDEC = false>
 __global__ void __launch_bounds__(256) wf_intersect(Params P) {
     const uint32_t cur = P.parity;
     // the previous tick's queue was no longer (POOL: a level can have more vertices than the one before)
@@ -1225,7 +1225,7 @@ __global__ void __launch_bounds__(256) wf_intersect(Params P) {
         }
         Hit            hit;
         typename MaskDraw<POOL, EXTRA>::type draw(P, slot);
-        sceneIntersect<STATS, EXTRA>(c_scene, ray, depth, hit, cnt, draw);
+        sceneIntersect<STATS, EXTRA, WIDEC>(c_scene, ray, depth, hit, cnt, draw);
         draw.flush();
         if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
         P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
@@ -2720,12 +2720,21 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         f3              nee = S3(0.f);
         // the picks first (Scene.randomLightSpatial fills a buffer too, scene.zig:592-610), then one loop over them: the
         // lanes of a wave leave the tree walk together instead of interleaving it with their shadow rays
+        // (the first pick, the only one unless the tree splits, in registers: the buffer is scratch)
+        // (as two scalars: copies between LightPick objects are selected by address again, dmath.hpp pick)
         LightPick      picks[kMaxLightPicks];
-        const uint32_t num_picks = lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold,
-                                                  [&](uint32_t k, LightPick pick) { picks[k] = pick; });
+        uint32_t       first_offset = 0;
+        float          first_pdf = 0.f;
+        const uint32_t num_picks = lt.randomLight(notimer, sf.p, ms.geo_n, ms.translucent, select, nee_threshold, [&](uint32_t k, LightPick pick) {
+            if (0 == k) first_offset = pick.offset, first_pdf = pick.pdf;
+            else picks[k] = pick;
+        });
         tm.mark(1);
         for (uint32_t pk = 0; pk < num_picks; ++pk) {
-            const LightPick      pick = picks[pk];
+            uint32_t pick_offset = first_offset;
+            float    pick_pdf = first_pdf;
+            if (pk > 0) pick_offset = picks[pk].offset, pick_pdf = picks[pk].pdf;
+            const LightPick pick{pick_offset, pick_pdf};
             const ZygpuLight     light = s.lights[pick.offset];
             // the light at the path's time (light.zig:84-107 <- scene.propTransformationAt): an animated light moves
             const Trafo          trafo = propTrafoAt<MESHL>(s, light.prop, pathTime<POOL, MESHL>(P, slot));

@@ -512,6 +512,7 @@ struct ZygpuContext {
     bool          tables_deduplicated = false;  // the solid tree references some prop from more than one leaf (the table holds it once)
     bool          large_mesh = false;  // a mesh of kWideBlasMinTriangles or more: the wide-BLAS kernel instantiations
     bool          huge_mesh = false;   // a mesh of kMeshKernelMinTriangles or more: wf_scatter_h + wf_shadow_u (option mesh_kernels)
+    bool          wide_mesh = false;   // a mesh with DMesh::wide: wf_intersect<POOL, EXTRA, WIDEC>
     // option "mesh_kernels" (default on): in the relaxed units the walks of the large meshes run in persistent kernels of their
     // own whose lanes fetch a new ray when theirs is done: wf_scatter_h suspends the vertices whose shadow ray enters a large mesh's
     // bounds, wf_shadow_u walks the meshes for them
@@ -1055,7 +1056,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         }
     }
 
-    c->large_mesh = c->huge_mesh = false;
+    c->large_mesh = c->huge_mesh = c->wide_mesh = false;
     bool wide_ok = true;
     std::vector<DMesh> meshes(d->num_meshes);
     for (uint32_t i = 0; i < d->num_meshes; ++i) {
@@ -1085,6 +1086,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             const bool deep = 3u * zyg::depth4(wide) > uint32_t(kStack4);
             if (deep) wide_ok = false;
             dm.wide = (hm.num_triangles >= kWideBlasMinTriangles && !packed.empty() && hm.num_triangles < (1u << 24) && !deep) ? 1u : 0u;
+            if (dm.wide) c->wide_mesh = true;
         }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
         ok = ok && m.upload(hm.triangles, size_t(hm.num_triangles) * 3, &dm.triangles);
@@ -1771,7 +1773,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                     timedLaunch(c, 0, [&] {
                         if (c->stats) launchKernel(c, K_INTERSECT_STATS_POOL, grid.x, P, 0u);
                         else if (plain) launchKernel(c, K_INTERSECT_PLAIN_POOL, grid.x, P, 0u);
-                        else launchKernel(c, K_INTERSECT_EXTRA_POOL, grid.x, P, 0u);
+                        else launchKernel(c, c->wide_mesh ? K_INTERSECT_EXTRA_POOL_WIDE : K_INTERSECT_EXTRA_POOL, grid.x, P, 0u);
                     });
                     timedLaunch(c, 1, [&] {
                         if (c->stats) {
