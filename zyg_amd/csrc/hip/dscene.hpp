@@ -36,6 +36,10 @@ struct DMesh {
     // walk this mesh through its quantised four-wide re-layout (kWideBlasMinTriangles triangles or more, leaves and depth inside the
     // walks' limits: zygpu_upload_scene), as the prop-table kernels do
     uint32_t        wide;
+    // what meshFragment reads, gathered per triangle (leaf order, 3 per triangle: 48 B): (the corners' packed normals, part),
+    // (uv a, uv b), (uv c, -, -); the corners' positions are tri_verts.  Through `triangles` into positions / normals / uvs a
+    // fragment was a fourth level of dependent loads and ten cache lines of a large mesh.
+    const uint4*    shade;
 };
 
 // what a light-tree walk reads: the scene's tree over lights, or the primitive tree of one emissive mesh part
@@ -1818,22 +1822,27 @@ ZD f3 meshShadingNormal(const DMesh& m, uint32_t i) {
 
 ZD void meshFragment(const DMesh& mesh, Fragment& f) {  // triangle_mesh.zig:310-335 + triangle_data.zig:106-149
     const uint32_t prim = f.primitive;
-    f.part = mesh.triangle_parts[prim];
-    const uint32_t ia = mesh.triangles[3 * prim], ib = mesh.triangles[3 * prim + 1], ic = mesh.triangles[3 * prim + 2];
-    const f3       pa = meshPosition(mesh, ia), pb = meshPosition(mesh, ib), pc = meshPosition(mesh, ic);
+    typedef uint32_t                                         Words __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(1))) Words* record = (const __attribute__((address_space(1))) Words*)(mesh.shade + size_t(3) * prim);
+    const Words                                              r0 = record[0], r1 = record[1], r2 = record[2];
+    f.part = r0.w;
+    f3 pa, pb, pc;
+    triangleVertices(mesh.tri_verts, prim, pa, pb, pc);
 
     const f3 geo_n = normalize3(cross3(pb - pa, pc - pa));
     f.geo_n = f.trafo.objectToWorldNormal(geo_n);
 
     const f3    p = interpolate3(pa, pb, pc, f.u, f.v);
-    const float uva0 = mesh.uvs[2 * ia], uva1 = mesh.uvs[2 * ia + 1];
-    const float uvb0 = mesh.uvs[2 * ib], uvb1 = mesh.uvs[2 * ib + 1];
-    const float uvc0 = mesh.uvs[2 * ic], uvc1 = mesh.uvs[2 * ic + 1];
+    const float uva0 = __uint_as_float(r1.x), uva1 = __uint_as_float(r1.y);
+    const float uvb0 = __uint_as_float(r1.z), uvb1 = __uint_as_float(r1.w);
+    const float uvc0 = __uint_as_float(r2.x), uvc1 = __uint_as_float(r2.y);
     const float w = 1.f - f.u - f.v;
     f.uv0 = __fmaf_rn(uva0, w, __fmaf_rn(uvb0, f.u, uvc0 * f.v));
     f.uv1 = __fmaf_rn(uva1, w, __fmaf_rn(uvb1, f.u, uvc1 * f.v));
 
-    const f3 nb = meshShadingNormal(mesh, ib), na = meshShadingNormal(mesh, ia), nc = meshShadingNormal(mesh, ic);
+    const f3 na = octDecode(snorm16ToFloat(r0.x & 0xFFFFu), snorm16ToFloat(r0.x >> 16));
+    const f3 nb = octDecode(snorm16ToFloat(r0.y & 0xFFFFu), snorm16ToFloat(r0.y >> 16));
+    const f3 nc = octDecode(snorm16ToFloat(r0.z & 0xFFFFu), snorm16ToFloat(r0.z >> 16));
     const f3 ni = normalize3(interpolate3(na, nb, nc, f.u, f.v));
 
     // triangle.zig:102-131 positionDifferentials

@@ -1089,6 +1089,28 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             if (dm.wide) c->wide_mesh = true;
         }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
+        {  // DMesh::shade
+            std::vector<uint4> shade(size_t(hm.num_triangles) * 3);
+            auto bits = [](float x) {
+                uint32_t u;
+                std::memcpy(&u, &x, 4);
+                return u;
+            };
+            for (uint32_t t = 0; t < hm.num_triangles; ++t) {
+                uint32_t nrm[3];
+                float    uv[6];
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t vi = hm.triangles[size_t(t) * 3 + k];
+                    nrm[k] = uint32_t(hm.normals[size_t(vi) * 2]) | (uint32_t(hm.normals[size_t(vi) * 2 + 1]) << 16);
+                    uv[2 * k] = hm.uvs[size_t(vi) * 2];
+                    uv[2 * k + 1] = hm.uvs[size_t(vi) * 2 + 1];
+                }
+                shade[size_t(t) * 3] = make_uint4(nrm[0], nrm[1], nrm[2], hm.triangle_parts[t]);
+                shade[size_t(t) * 3 + 1] = make_uint4(bits(uv[0]), bits(uv[1]), bits(uv[2]), bits(uv[3]));
+                shade[size_t(t) * 3 + 2] = make_uint4(bits(uv[4]), bits(uv[5]), 0u, 0u);
+            }
+            ok = ok && m.upload(shade.data(), shade.size(), &dm.shade);
+        }
         ok = ok && m.upload(hm.triangles, size_t(hm.num_triangles) * 3, &dm.triangles);
         ok = ok && m.upload(hm.triangle_parts, hm.num_triangles, &dm.triangle_parts);
         ok = ok && m.upload(hm.positions, size_t(hm.num_vertices) * 3 + 1, &dm.positions);
