@@ -86,6 +86,9 @@
     X(7, K_INTERSECT_PLAIN_POOL, (wf_intersect<false, true, false>),                  (P))  \
     X(7, K_INTERSECT_EXTRA_POOL, (wf_intersect<false, true, true>),                   (P))  \
     X(7, K_INTERSECT_EXTRA_POOL_WIDE, ZYG_WIDE((wf_intersect<false, true, true, true>), (wf_intersect<false, true, true>)), (P)) \
+    X(7, K_POOL_RESET,           (wf_pool_reset<true>),                               (P))  \
+    X(7, K_TRACE_SHADE_POOL,     (wf_trace_shade_pool<false>),                        (P))  \
+    X(7, K_TRACE_SHADE_POOL_WIDE, ZYG_WIDE((wf_trace_shade_pool<true>), (wf_trace_shade_pool<false>)), (P)) \
     X(7, K_INTERSECT_STATS,      (wf_intersect<true, false, true>),                   (P))  \
     X(7, K_INTERSECT_EXTRA,      (wf_intersect<false, false, true>),                  (P))  \
     X(7, K_INTERSECT_PLAIN,      (wf_intersect<false, false, false>),                 (P))  \

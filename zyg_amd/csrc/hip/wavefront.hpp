@@ -1794,6 +1794,78 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
     if (STATS) flushCounters(P, 1, cnt, 0);
 }
 
+// The same for the POOL scenes' complete instantiations (wf_intersect<false, true, true, WIDEC> + wf_shade<false, true, false, true>; option
+// "fuse_pool"): the vertex' first line is read once, the hit record goes to its second line together with the fragment's records (one
+// full line written, no 32 B write and no read of that line between the two kernels).  The rounds of a tick share the alive / heavy
+// counters, so they are reset by a launch of their own in front (wf_pool_reset) instead of by this kernel's first block.
+#ifndef ZYG_TRACE_SHADE_POOL_WAVES
+#define ZYG_TRACE_SHADE_POOL_WAVES 3
+#endif
+template <bool POOL>  // (a template so that only the unit that instantiates it emits it)
+__global__ void __launch_bounds__(256) wf_pool_reset(Params P) {  // one block
+    if (threadIdx.x >= 64) return;
+    const uint32_t cur = P.parity;
+    if (0 == P.round)
+        for (uint32_t k = 0; k < kPoolVertices; ++k) queueReset(&P.ctl->ext_pool_count[cur ^ 1u][k]);
+    aliveReset(P.ctl->alive_count[cur]);
+    queueReset(&P.ctl->shadow_count[0]);
+    queueReset(&P.ctl->shadow_count[1]);
+    queueReset(&P.ctl->heavy_count[cur]);
+}
+
+template <bool WIDEC>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_POOL_WAVES) wf_trace_shade_pool(Params P) {
+    const uint32_t cur = P.parity;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    const uint32_t n = queueOpen(extCount<true>(P, cur, P.round), P.queue_capacity, i, at);
+    if (0 == i) P.ctl->bound[cur] = n;
+    if (blockIdx.x * blockDim.x >= n) return;  // (whole blocks take part in queuePush)
+    Counters     cnt{0, 0, 0};
+    SectionTimer tm;
+    tm.start();
+    bool     alive = false, defer = false;
+    uint32_t slot = 0;
+    if (i < n) {
+        slot = extQueue<true>(P, cur, P.round)[at];  // a vertex index
+        const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+        const uint32_t meta = P.pool.vmeta.get(slot);
+        const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;
+        Ray            ray = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+        ray.time = pathTime<true, true>(P, slot);
+        float4 ray_o = o;
+        {
+            // inside a dielectric the ray ends where it leaves the medium prop's bounding box (wf_intersect)
+            Mediums md;
+            md.load(P, slot);
+            if (md.index > 0) {
+                const uint32_t mp = md.prop(md.index - 1);
+                const float    limit = aabbIntersectP(c_scene.aabbs[2 * mp], c_scene.aabbs[2 * mp + 1], ray);
+                ray.max_t = mn(offsetF(limit), o.w);
+                ray_o = f4(ray.origin, ray.max_t);
+                P.pool.ray_o[slot] = ray_o;  // (the complete pass and the scatter kernels read the shortened ray)
+            }
+        }
+        Hit                                  hit;
+        typename MaskDraw<true, true>::type draw(P, slot);
+        sceneIntersect<false, true, WIDEC>(c_scene, ray, depth, hit, cnt, draw);
+        draw.flush();
+        if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+        // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
+        const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<false, true>(P, c_scene, slot, vertexPlane<true>(), depth, ray, cnt) : 0u;
+        shadeVertex<false, true, false, true, 0, kAllLightKinds>(P, slot, ray_o, d, hit, ucount, alive, defer, cnt, tm, nullptr, make_float4(1.f, 1.f, 1.f, 0.f),
+                                                                 nullptr, nullptr);
+        if (alive || defer) {  // the complete pass, wf_light and the closure half read the hit
+            P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+            P.pool.hit_prop[slot] = hit.prop;
+            P.pool.ucount[slot] = ucount;
+        }
+    }
+    queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
+    __syncthreads();  // queuePush's shared words are reused below
+    queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
+}
+
 // wf_intersect and wf_shade's first pass in one kernel (non-POOL): the ray, the hit and the candidate count stay in
 // registers, so the path's line is read once instead of twice and the 32 B hit record is only written for the few vertices
 // the second pass will look at.  The alive / heavy queue counters are per tick parity here: this kernel appends to the

@@ -494,6 +494,9 @@ struct ZygpuContext {
     // option "split_nee" (default 1): the POOL scenes' complete wf_scatter as two kernels, wf_light (light sampling + shadow rays, no
     // closure) and wf_scatter<.., PHASE 2> (closure evaluation + bxdf sample); scenes with opacity masks keep the one kernel
     bool          split_nee = true;
+    // option "fuse_pool" (default 1): wf_trace_shade_pool instead of wf_intersect + wf_shade's first pass for the POOL scenes' complete
+    // instantiations
+    bool          fuse_pool = true;
     uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
     bool          extended_materials = false;  // a material carries ZYGPU_MATF_EXTENDED (textures, coating, flakes ...): the complete closure
     uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
@@ -1792,13 +1795,23 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                     P.round = k;
                     // the plain instantiations (Rectangle / mesh geometry, single-sample Rectangle lights) or the full ones
                     const bool plain = !c->stats && !c->mesh_lights && !c->multi_sample_lights;
+                    // option fuse_pool: closest hit + the first shading pass of the complete instantiations in one kernel (timed as kernel 0)
+                    const bool fused = c->fuse_pool && !c->stats && !plain;
                     timedLaunch(c, 0, [&] {
                         if (c->stats) launchKernel(c, K_INTERSECT_STATS_POOL, grid.x, P, 0u);
                         else if (plain) launchKernel(c, K_INTERSECT_PLAIN_POOL, grid.x, P, 0u);
-                        else launchKernel(c, c->wide_mesh ? K_INTERSECT_EXTRA_POOL_WIDE : K_INTERSECT_EXTRA_POOL, grid.x, P, 0u);
+                        else if (fused) {
+                            launchKernel(c, K_POOL_RESET, 1u, P, 0u);
+                            launchKernel(c, c->wide_mesh ? K_TRACE_SHADE_POOL_WIDE : K_TRACE_SHADE_POOL, grid.x, P, 0u);
+                        } else launchKernel(c, c->wide_mesh ? K_INTERSECT_EXTRA_POOL_WIDE : K_INTERSECT_EXTRA_POOL, grid.x, P, 0u);
                     });
                     timedLaunch(c, 1, [&] {
-                        if (c->stats) {
+                        if (fused) {
+                            launchKernel(c, 0 == (c->light_kinds & ~kRectangleLightKinds) ? K_SHADE_MESHL_HEAVY_POOL_RECT
+                                            : 0 == (c->light_kinds & ~kSkyLightKinds)     ? K_SHADE_MESHL_HEAVY_POOL_SKY
+                                                                                          : K_SHADE_MESHL_HEAVY_POOL,
+                                         heavyGrid(c, grid.x), P, 0u);
+                        } else if (c->stats) {
                             launchKernel(c, K_SHADE_STATS_LIGHT_POOL, grid.x, P, 0u);
                             launchKernel(c, K_SHADE_STATS_HEAVY_POOL, heavyGrid(c, grid.x), P, 0u);
                         } else if (plain) {
@@ -2258,6 +2271,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->split_nee = 0 != value;
         return 0;
     }
+    if (0 == std::strcmp(name, "fuse_pool")) {
+        c->fuse_pool = 0 != value;
+        return 0;
+    }
     if (0 == std::strcmp(name, "mesh_kernels")) {
         c->mesh_kernels = 0 != value;
         return 0;
@@ -2341,6 +2358,7 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"pool_relaxed", c->pool_relaxed ? 1 : 0},
                  {"pool_tick_sync", c->pool_tick_sync ? 1 : 0},
                  {"split_nee", c->split_nee ? 1 : 0},
+                 {"fuse_pool", c->fuse_pool ? 1 : 0},
                  {"tick_sync", c->tick_sync ? 1 : 0}};
     for (const auto& e : table)
         if (0 == std::strcmp(name, e.name)) {
