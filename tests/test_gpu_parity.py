@@ -378,6 +378,40 @@ def test_glass(engine, oracle, integrator, objects):
     _check(*out, 3)
 
 
+@pytest.mark.parametrize("scene", ["glass_box", "outdoor"])
+def test_pool_kernel_options_render_the_same_film(engine, oracle, scene):
+    """The POOL scenes' kernel layout options (zygpu.h: fuse_pool, split_nee, pool_tick_sync) choose between kernels that
+    compute the same thing: every setting gives the default's film bit for bit, in both arithmetic modes, and the default's
+    precise film is the oracle's.  (The defaults are the fused / split forms: the others run nowhere else in the suite.)"""
+    w, h, spp = 96, 64, 3
+
+    def render(precise, **options):
+        engine.release()
+        engine.__init__(engine.lib)
+        if "outdoor" == scene:
+            scenes.outdoor(engine, w, h, spp, integrator="PTMIS", material="substitute", showcase=True, max_depth=10,
+                           mesh=scenes.heightfield_mesh(48, size=1.2, height=0.5), sky="canopy", sun_radius=0.05)
+        else:
+            scenes.cornell(engine, w, h, spp, integrator="PTMIS", material="substitute",
+                           glass_objects={"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)})
+        engine.start_frame(0)
+        engine.set_option("precise", precise)
+        for name, value in options.items():
+            engine.set_option(name, value)
+        engine.render_iterations(spp)
+        engine.synchronize()
+        return engine.download_film(w, h)
+
+    for precise in (1, 0):
+        default = render(precise)
+        if precise:
+            sd = engine.lib.su_ext_scene_desc().contents
+            vd = engine.lib.su_ext_view_desc().contents
+            assert np.array_equal(default, oracle_render(oracle, sd, vd, spp))
+        for options in ({"fuse_pool": 0}, {"split_nee": 0}, {"pool_tick_sync": 0}, {"fuse_pool": 0, "split_nee": 0, "pool_tick_sync": 0}):
+            assert np.array_equal(render(precise, **options), default), (precise, options)
+
+
 def test_glass_alpha(engine, oracle):
     """Transparent sensor behind glass: the alpha of a split sample is the sum over its terminated vertices
     (Pool.consume, vertex.zig:240-262)."""
