@@ -399,7 +399,7 @@ enum ZygpuAovClass { ZYGPU_AOV_ALBEDO = 0, ZYGPU_AOV_DEPTH = 1, ZYGPU_AOV_MATERI
                      ZYGPU_AOV_SHADING_NORMAL = 4, ZYGPU_AOV_ROUGHNESS = 5, ZYGPU_AOV_EMISSION = 6, ZYGPU_AOV_DIRECT = 7,
                      ZYGPU_AOV_INDIRECT = 8, ZYGPU_AOV_NUM_CLASSES = 9 };
 
-#define ZYGPU_MAX_CAMERA_KEYFRAMES 4
+#define ZYGPU_MAX_CAMERA_KEYFRAMES 8
 
 typedef struct ZygpuViewDesc {
     int32_t  resolution[2];
@@ -442,7 +442,11 @@ typedef struct ZygpuViewDesc {
      * holds the Distribution2D over the shape image's values (no uv weight, no compensation, total_weight 1), or ZYGPU_NULL: the
      * lens is sampled as a disc.  A lens sample is 2 * distribution.sampleContinuous(lens_uv).uv - 1, times lens_radius. */
     uint32_t      aperture_shape;
-    uint32_t      reserved_;
+    /* The shutter (take_loader.zig:153-191 loadShutter -> camera_base.zig:43-75 setShutter): 1 = a camera sample's time goes
+     * through the Distribution1DN(63) whose cdf follows (camera_base.zig:121-127 sampleShutterTime, distribution_1d.zig:188-205:
+     * linear search, offset + (cdf[o + 1] - r) / (cdf[o + 1] - cdf[o]), over 63); 0 = the time is the sample itself. */
+    uint32_t      shutter_configured;
+    float         shutter_cdf[64];
 } ZygpuViewDesc;
 
 /* tonemapper.zig:9; AgX with the look the take loader picks (take_loader.zig:268-270: Substitute) */

@@ -381,8 +381,8 @@ def test_glass(engine, oracle, integrator, objects):
 @pytest.mark.parametrize("scene", ["glass_box", "outdoor"])
 def test_pool_kernel_options_render_the_same_film(engine, oracle, scene):
     """The POOL scenes' kernel layout options (zygpu.h: fuse_pool, split_nee, pool_tick_sync) choose between kernels that
-    compute the same thing: every setting gives the default's film bit for bit, in both arithmetic modes, and the default's
-    precise film is the oracle's.  (The defaults are the fused / split forms: the others run nowhere else in the suite.)"""
+    compute the same thing: every setting gives the default's film, bit for bit in the precise units (whose default film is the
+    oracle's), inside the relaxed units' tolerance in theirs.  (The defaults are the fused / split forms: the others run nowhere else in the suite.)"""
     w, h, spp = 96, 64, 3
 
     def render(precise, **options):
@@ -409,7 +409,11 @@ def test_pool_kernel_options_render_the_same_film(engine, oracle, scene):
             vd = engine.lib.su_ext_view_desc().contents
             assert np.array_equal(default, oracle_render(oracle, sd, vd, spp))
         for options in ({"fuse_pool": 0}, {"split_nee": 0}, {"pool_tick_sync": 0}, {"fuse_pool": 0, "split_nee": 0, "pool_tick_sync": 0}):
-            assert np.array_equal(render(precise, **options), default), (precise, options)
+            film = render(precise, **options)
+            if precise:
+                assert np.array_equal(film, default), options
+            else:  # (the relaxed units contract their arithmetic kernel by kernel: the same picture inside their tolerance)
+                assert np.array_equal(film[..., 3], default[..., 3]) and rms(film[..., :3] / spp, default[..., :3] / spp) <= RMS_TOL, options
 
 
 def test_glass_alpha(engine, oracle):

@@ -299,32 +299,138 @@ def test_camera_animation_in_the_take(product_lib, tmp_path):
                 np.testing.assert_allclose(list(vd.camera_keyframes[i].position)[:3], [0.4 * s, 1.0, -6.0], atol=2e-5)
 
 
+def _shutter_cdf(open_, close, slope):
+    """Base.setShutter + Distribution1DN(63).configure (camera_base.zig:43-118, distribution_1d.zig:167-186) in numpy float32: the
+    test's own statement of them."""
+    f32 = np.float32
+
+    def lerp(a, b, t):  # util.zig:3-8: fma(1 - t, a, t * b); the product in double and rounded once is that fma
+        return f32(np.float64(f32(1) - t) * np.float64(a) + np.float64(f32(t * b)))
+
+    def bezier(cp, u):
+        l = [tuple(lerp(cp[i][k], cp[i + 1][k], u) for k in range(2)) for i in range(3)]
+        m = [tuple(lerp(l[i][k], l[i + 1][k], u) for k in range(2)) for i in range(2)]
+        return tuple(lerp(m[0][k], m[1][k], u) for k in range(2))
+
+    def search(cp, x):
+        u, step, c = f32(0.5), f32(0.25), (f32(0), f32(0))
+        for _ in range(16):
+            c = bezier(cp, u)
+            if x < c[0]:
+                u = f32(u - step)
+            elif x > c[0]:
+                u = f32(u + step)
+            else:
+                break
+            step = f32(step * f32(0.5))
+        return c[1]
+
+    open_, close, slope = f32(open_), f32(close), [f32(v) for v in slope]
+    function = []
+    for i in range(63):
+        t = f32(f32(f32(i) + f32(0.5)) / f32(63))
+        if t < open_:
+            f = search([(f32(0), f32(0)), (slope[0], slope[1]), (slope[2], slope[3]), (open_, f32(1))], t) if len(slope) >= 4 \
+                else lerp(f32(0), f32(1), f32(t / open_))
+        elif t > close:
+            f = search([(close, f32(1)), (slope[4], slope[5]), (slope[6], slope[7]), (f32(1), f32(0))], t) if len(slope) >= 8 \
+                else lerp(f32(1), f32(0), f32(f32(t - close) / f32(f32(1) - close)))
+        else:
+            f = f32(1)
+        function.append(f)
+    integral = f32(0)
+    for f in function:
+        integral = f32(integral + f)
+    ii = f32(f32(1) / integral)
+    cdf, p = [f32(0)], f32(0)
+    for f in function[:-1]:
+        p = f32(np.float64(f) * np.float64(ii) + np.float64(p))
+        cdf.append(p)
+    cdf.append(f32(1))
+    return np.asarray(cdf, dtype=np.float32)
+
+
 def test_take_aov_and_shutter_keys(product_lib, tmp_path):
-    """The take's "aov" (take.zig:106-129) reaches the view's AOV slots.  A camera "shutter" (take_loader.zig:153-191) other than the
-    reference's default changes nothing in a scene at rest and loads; with an animated entity it would change the motion blur, and the
-    load fails by name."""
-    def load(shutter, aov=None, moving=True):
+    """The take's "aov" (take.zig:106-129) reaches the view's AOV slots.  A camera "shutter" (take_loader.zig:153-191 loadShutter ->
+    camera_base.zig:43-75 setShutter) sets the frame's step and duration (frames_per_second / frame_step, motion_blur) and configures
+    the distribution a camera sample's time goes through, flat when only the key is there; the scene's interpolation frames follow the
+    frame's length (scene.zig:254-257, 724-734).  A frame longer than the view block's keyframes is refused by name."""
+    tick = 705600000 // 60
+
+    def load(shutter, aov=None):
         lamp = dict(_LAMP, animation={"keyframes": [{"time": 0, "transformation": {"position": [0, 3, 0]}},
-                                                    {"time": 1, "transformation": {"position": [1, 3, 0]}}]}) if moving else _LAMP
+                                                    {"time": 1, "transformation": {"position": [1, 3, 0]}}]})
         with open(tmp_path / "c.scene", "w") as f:
             json.dump({"materials": _MATERIALS, "entities": [lamp]}, f)
-        take = {"scene": "c.scene", "camera": {"Perspective": {"resolution": [16, 12], "shutter": shutter}}}
+        camera = {"resolution": [16, 12]}
+        if shutter is not None:
+            camera["shutter"] = shutter
+        take = {"scene": "c.scene", "camera": {"Perspective": camera}}
         if aov:
             take["aov"] = aov
         with open(tmp_path / "c.take", "w") as f:
             json.dump(take, f)
         with zyg_amd.Engine(product_lib) as e:
             rc = e.lib.su_ext_load_take(str(tmp_path / "c.take").encode())
-            slots = None
-            if 0 == rc:
-                assert e.lib.su_ext_compile(0) == 0
-                slots = e.lib.su_ext_view_desc().contents.aov_slots
-            return rc, slots
-    assert (0, 0b110) == load({"frames_per_second": 60, "motion_blur": True}, {"Depth": True, "MaterialId": True, "Albedo": False})
-    assert -1 == load({"frames_per_second": 24})[0]
-    assert -1 == load({"motion_blur": False})[0]
-    assert -1 == load({"open": 0.25, "close": 0.75})[0]
-    assert 0 == load({"motion_blur": False, "frames_per_second": 24}, moving=False)[0]
+            if 0 != rc:
+                return rc, None, None
+            assert e.lib.su_ext_compile(0) == 0
+            vd = e.lib.su_ext_view_desc().contents
+            sd = e.lib.su_ext_scene_desc().contents
+            return rc, sd.num_interpolation_frames, (vd.aov_slots, vd.frame_step, vd.frame_duration, vd.shutter_configured,
+                                                     np.array(list(vd.shutter_cdf), dtype=np.float32))
+
+    rc, nif, (slots, step, duration, configured, cdf) = load(None, {"Depth": True, "MaterialId": True, "Albedo": False})
+    assert (0, 2, 0b110, tick, tick, 0) == (rc, nif, slots, step, duration, configured)
+    rc, nif, (_, step, duration, configured, cdf) = load({"frames_per_second": 60, "motion_blur": True})
+    assert (0, 2, tick, tick, 1) == (rc, nif, step, duration, configured)
+    assert np.array_equal(cdf, _shutter_cdf(0.0, 1.0, []))  # flat, and configured: the time sample is mirrored inside its bin
+    rc, nif, (_, step, duration, configured, cdf) = load({"frames_per_second": 24, "open": 0.25, "close": 0.75})
+    assert (0, 705600000 // 24, 705600000 // 24, 1) == (rc, step, duration, configured)
+    assert 5 == nif  # 2 whole ticks + the step and the duration each off the tick grid + 1
+    assert np.array_equal(cdf, _shutter_cdf(0.25, 0.75, [])) and cdf[0] == 0 and cdf[63] == 1 and np.all(np.diff(cdf) > 0)
+    slope = [0.1, 0.0, 0.2, 1.0, 0.8, 1.0, 0.9, 0.0]
+    rc, nif, (_, step, duration, configured, cdf) = load({"frame_step": 1 / 30, "open": 0.3, "close": 0.7, "slope": slope, "motion_blur": False})
+    assert (0, 2 * tick, 0, 1) == (rc, step, duration, configured) and 2 == nif
+    assert np.array_equal(cdf, _shutter_cdf(0.3, 0.7, slope))
+    assert -1 == load({"frames_per_second": 4})[0]  # 15 ticks per frame: more keyframes than the view block holds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shutter", [{"frames_per_second": 30, "open": 0.3, "close": 0.6, "slope": [0.1, 0.0, 0.2, 1.0, 0.7, 1.0, 0.9, 0.0]},
+                                     {"motion_blur": False}, {}, {"frames_per_second": 24, "open": 0.5}])
+def test_render_take_with_a_shutter(product_lib, oracle, tmp_path, shutter):
+    """A moving prop and a moving camera under a configured shutter: the frame's step and duration, the time samples drawn through
+    the shutter's distribution (camera_base.zig:121-136).  The device's film is the oracle's bit for bit, frame 1 differs from
+    frame 0 (the scene moves), and with motion_blur off every sample of a frame sees the same instant."""
+    from util import oracle_render
+    keys = [{"time": k / 20.0, "transformation": {"position": [-1.5 + 0.9 * k, 1.2, 0.4 * k], "scale": [0.7, 0.7, 0.7]}} for k in range(6)]
+    scene = {"materials": _MATERIALS,
+             "entities": [{"type": "Light", "shape": {"type": "Rectangle"}, "materials": ["lamp"],
+                           "transformation": {"position": [0, 4, 0], "rotation": [-90, 0, 0], "scale": [2, 2, 1]}},
+                          {"type": "Prop", "shape": {"type": "Rectangle"}, "materials": ["grey"], "transformation": {"rotation": [90, 0, 0], "scale": [12, 12, 1]}},
+                          {"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["red"], "animation": {"keyframes": keys}}]}
+    with open(tmp_path / "m.scene", "w") as f:
+        json.dump(scene, f)
+    camera_keys = [{"time": k / 10.0, "transformation": {"position": [0.3 * k, 1.0, -6.0]}} for k in range(3)]
+    with open(tmp_path / "m.take", "w") as f:
+        json.dump({"scene": "m.scene", "camera": {"Perspective": {"resolution": [24, 16], "shutter": shutter}, "transformation": {"position": [0, 1, -6]},
+                                                   "animation": {"keyframes": camera_keys}}}, f)
+    films = {}
+    with zyg_amd.Engine(product_lib) as e:
+        assert e.lib.su_ext_load_take(str(tmp_path / "m.take").encode()) == 0
+        for frame in (0, 1):
+            e.start_frame(frame)
+            e.render_iterations(8)
+            e.synchronize()
+            films[frame] = e.download_film(24, 16)
+            sd = e.lib.su_ext_scene_desc().contents
+            vd = e.lib.su_ext_view_desc().contents
+            assert 1 == vd.shutter_configured
+            assert np.isfinite(films[frame]).all() and films[frame][..., :3].max() > 0
+            assert np.array_equal(films[frame], oracle_render(oracle, sd, vd, 8, frame=frame)), f"frame {frame}"
+            assert e.lib.zygpu_clear_film(e.context(), ctypes.c_float(0.0)) == 0
+    assert not np.array_equal(films[0], films[1])
 
 
 def test_gltf_scene(product_lib, tmp_path):
@@ -569,7 +675,7 @@ def test_render_take_with_instancer_and_animation(product_lib, oracle, tmp_path)
             sd = e.lib.su_ext_scene_desc().contents
             vd = e.lib.su_ext_view_desc().contents
             assert np.isfinite(films[frame]).all() and films[frame][..., :3].max() > 0
-            assert np.array_equal(films[frame], oracle_render(oracle, sd, vd, 8)), f"frame {frame}"
+            assert np.array_equal(films[frame], oracle_render(oracle, sd, vd, 8, frame=frame)), f"frame {frame}"
             assert e.lib.zygpu_clear_film(e.context(), ctypes.c_float(0.0)) == 0
     assert not np.array_equal(films[0], films[2])
 

@@ -7,12 +7,14 @@ import zyg_amd
 
 
 def oracle_render(oracle, scene_desc, view_desc, iterations, threads=None, iteration0=0, y_range=None, stats=None,
-                  samples_per_call=1):
+                  samples_per_call=1, frame=0):
+    """`frame`: the frame the descriptions were compiled for (it matters where a frame does not start on a tick of 1/60 s: a camera
+    "shutter" with another frames_per_second)."""
     w, h = view_desc.resolution[0], view_desc.resolution[1]
     film = np.zeros((h, w, 4), dtype=np.float32)
     y0, y1 = y_range if y_range else (0, h)
     st = stats if stats is not None else zyg_amd.Stats()
-    rc = oracle.zyg_oracle_render(ctypes.addressof(scene_desc), ctypes.addressof(view_desc), 0, iteration0, iterations,
+    rc = oracle.zyg_oracle_render(ctypes.addressof(scene_desc), ctypes.addressof(view_desc), frame, iteration0, iterations,
                                   samples_per_call, y0, y1, film.ctypes.data, threads or (os.cpu_count() or 1),
                                   ctypes.byref(st))
     assert rc == 0

@@ -159,7 +159,8 @@ class ViewDesc(ctypes.Structure):
                 ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float),
                 ("alpha_transparency", ctypes.c_uint32), ("tonemapper", ctypes.c_uint32),
                 ("aov_slots", ctypes.c_uint32), ("camera_num_keyframes", ctypes.c_uint32), ("camera_origin", ctypes.c_float * 4),
-                ("camera_keyframes", Keyframe * 4), ("aperture_shape", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
+                ("camera_keyframes", Keyframe * 8), ("aperture_shape", ctypes.c_uint32), ("shutter_configured", ctypes.c_uint32),
+                ("shutter_cdf", ctypes.c_float * 64)]
 
 
 class Stats(ctypes.Structure):

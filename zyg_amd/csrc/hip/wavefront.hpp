@@ -1016,11 +1016,21 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
 
     float s0, s1, s2, s3;
     h.smp.sample4D(s0, s1, s2, s3);
-    const float shutter_sample = h.smp.sample1D();  // sensor.zig:157: the camera sample's time
+    // sensor.zig:157: the camera sample's time, through the shutter's distribution where the take configured one
+    // (Base.sampleShutterTime, camera_base.zig:121-127 -> Distribution1DN(63).sampleContinous, distribution_1d.zig:188-205)
+    const ZygpuViewDesc& v = c_view.v;
+    float                shutter_sample = h.smp.sample1D();
+    if (v.shutter_configured) {
+        const float r = shutter_sample;
+        uint32_t    i = 1;
+        while (i < 63u && !(v.shutter_cdf[i] >= r)) ++i;  // search(cdf, 1, N, r)
+        const uint32_t offset = i - 1u;
+        const float    c = v.shutter_cdf[offset + 1u], width = c - v.shutter_cdf[offset];
+        shutter_sample = 0.f == width ? 0.f : (float(offset) + (c - r) / width) / 63.f;
+    }
     h.smp.incrementPadding();
 
-    const float          cx = float(x) + s0, cy = float(y) + s1;
-    const ZygpuViewDesc& v = c_view.v;
+    const float cx = float(x) + s0, cy = float(y) + s1;
     f3 direction = mk3(v.left_top[0], v.left_top[1], v.left_top[2]) + mk3(v.d_x[0], v.d_x[1], v.d_x[2]) * S3(cx) +
                    mk3(v.d_y[0], v.d_y[1], v.d_y[2]) * S3(cy);
     f3 origin;

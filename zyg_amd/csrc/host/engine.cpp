@@ -924,8 +924,66 @@ int Engine::setTransformation(uint32_t prop, const float* m16) {  // capi.zig:48
     return 0;
 }
 
+// Base.setShutter (camera_base.zig:43-118): the shutter function at the centres of 63 bins (a ramp or a cubic Bezier segment while it
+// opens and closes, 1 between), and Distribution1DN.configure (distribution_1d.zig:167-186) over it
+void Engine::setShutter(float open, float close, const float* slope, uint32_t num_slope) {
+    constexpr int N = 63;
+    auto lerp = [](float a, float b, float t) { return std::fmaf(1.f - t, a, t * b); };  // util.zig:3-8
+    struct P2 {
+        float x, y;
+    };
+    auto lerp2 = [&](P2 a, P2 b, float t) { return P2{lerp(a.x, b.x, t), lerp(a.y, b.y, t)}; };
+    auto bezier = [&](const P2 (&cp)[4], float u) {  // cubicBezierEvaluate
+        const P2 a = lerp2(cp[0], cp[1], u), b = lerp2(cp[1], cp[2], u), c = lerp2(cp[2], cp[3], u);
+        return lerp2(lerp2(a, b, u), lerp2(b, c, u), u);
+    };
+    auto search = [&](const P2 (&cp)[4], float x) {  // searchBezier: 16 bisection steps on the curve's parameter
+        float u = 0.5f, step = u * 0.5f;
+        P2    c{0.f, 0.f};
+        for (int i = 0; i < 16; ++i) {
+            c = bezier(cp, u);
+            if (x < c.x) u -= step;
+            else if (x > c.x) u += step;
+            else break;
+            step *= 0.5f;
+        }
+        return c.y;
+    };
+    float function[N], integral = 0.f;
+    for (int i = 0; i < N; ++i) {
+        const float t = (float(i) + 0.5f) / float(N);
+        float       f = 1.f;
+        if (t < open) {
+            if (num_slope >= 4) {
+                const P2 cp[4] = {{0.f, 0.f}, {slope[0], slope[1]}, {slope[2], slope[3]}, {open, 1.f}};
+                f = search(cp, t);
+            } else {
+                f = lerp(0.f, 1.f, t / open);
+            }
+        } else if (t > close) {
+            if (num_slope >= 8) {
+                const P2 cp[4] = {{close, 1.f}, {slope[4], slope[5]}, {slope[6], slope[7]}, {1.f, 0.f}};
+                f = search(cp, t);
+            } else {
+                f = lerp(1.f, 0.f, (t - close) / (1.f - close));
+            }
+        }
+        function[i] = f;
+        integral += f;
+    }
+    const float ii = 1.f / integral;
+    float       p = 0.f;
+    shutter_cdf[0] = 0.f;
+    for (int i = 0; i < N - 1; ++i) {
+        p = std::fmaf(function[i], ii, p);
+        shutter_cdf[i + 1] = p;
+    }
+    shutter_cdf[N] = 1.f;
+    shutter_configured = true;  // (Distribution1DN.integral >= 0)
+}
+
 uint32_t Engine::numInterpolationFrames() const {  // scene.zig:254-257 + countFrames (724-734)
-    const uint64_t tick = 705600000ull / 60, frame_step = tick, frame_duration = tick;  // camera_base.zig:16,25-26
+    const uint64_t tick = 705600000ull / 60;
     auto matching = [](uint64_t a, uint64_t b) { return 0 == (a > b ? a % b : (0 == a ? 0 : b % a)); };
     const uint32_t a = std::max<uint32_t>(uint32_t(frame_duration / tick), 1u);
     const uint32_t b = matching(frame_step, tick) ? 0u : 1u, c = matching(frame_duration, tick) ? 0u : 1u;
@@ -1019,7 +1077,7 @@ Transformation interpolate(const Transformation& f0, const Transformation& f1, c
 // the reference's search does
 void Engine::simulate(uint32_t frame) {
     if (graph_nodes_.empty()) return;
-    const uint64_t tick = 705600000ull / 60, frame_step = tick, frame_duration = tick;  // camera_base.zig:16,25-26
+    const uint64_t tick = 705600000ull / 60;
     const uint64_t start = uint64_t(frame) * frame_step, end = start + frame_duration;
     const uint64_t frames_start = start - (start % tick);
     const uint64_t end_rem = end % tick;
@@ -2215,8 +2273,10 @@ int Engine::compile(uint32_t frame) {
             }
         }
     }
-    v.frame_step = 705600000ull / 60;      // camera_base.zig:16,25
-    v.frame_duration = 705600000ull / 60;  // camera_base.zig:26
+    v.frame_step = frame_step;
+    v.frame_duration = frame_duration;
+    v.shutter_configured = shutter_configured ? 1u : 0u;
+    std::memcpy(v.shutter_cdf, shutter_cdf, sizeof(v.shutter_cdf));
     v.integrator = integrator;
     v.max_depth_surface = max_depth_surface;
     v.max_depth_volume = max_depth_volume;

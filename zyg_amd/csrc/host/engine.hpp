@@ -205,6 +205,13 @@ class Engine {
     // camera/aperture.zig:22-53: "aperture": {"shape": file}: a one-channel image whose values weight the lens (Distribution2D)
     uint32_t aperture_shape_image = ZYGPU_NULL;
     std::string camera_error;  // a camera parameter this build refuses by name ("blades", "stereo"): compile() fails with it
+    // The camera's shutter (take_loader.zig:153-191 loadShutter -> camera_base.zig:43-75 setShutter): the frame's step and duration
+    // in ticks of 1 / 705 600 000 s (60 frames per second, motion blur on: camera_base.zig:16, 25-26) and, once configured, the cdf of
+    // the Distribution1DN(63) over the shutter function that a camera sample's time is drawn through (camera_base.zig:121-127)
+    uint64_t frame_step = 705600000ull / 60, frame_duration = 705600000ull / 60;
+    bool     shutter_configured = false;
+    float    shutter_cdf[64] = {};
+    void     setShutter(float open, float close, const float* slope, uint32_t num_slope);
     uint32_t camera_entity = ZYGPU_NULL;
     uint32_t num_samples_per_pixel = 1;  // capi.zig:99
     uint32_t aov_slots = 0;              // take.view.aovs (take.zig:106-129): bit = ZygpuAovClass

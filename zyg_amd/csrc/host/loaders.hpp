@@ -66,8 +66,6 @@ class TakeLoader {
         }
         if (exporter) loadExporters(*exporter);
         if (!loadSceneFile(scene->str, take_dir_, identity())) return false;
-        if (other_shutter_ && engine_.numGraphNodes() > 0)
-            return unsupported("animations with a camera \"shutter\" other than the default (60 frames per second, open for the whole frame, motion blur on)");
         return true;
     }
 
@@ -77,7 +75,6 @@ class TakeLoader {
     };
 
     Engine&                         engine_;
-    bool                            other_shutter_ = false;
     int                             parent_node_ = -1;  // the animated graph node (Engine::createGraphNode) the entities being loaded hang below, or -1
     std::string                     take_dir_;
     std::map<std::string, uint32_t> materials_by_name_, shapes_by_file_;
@@ -201,20 +198,32 @@ class TakeLoader {
         if (const JsonValue* p = cam->get("parameters"))
             if (!engine_.loadCameraParameters(*p)) error = engine_.camera_error;  // refused by name ("blades", "stereo", a shape that cannot be read)
         if (const JsonValue* sh = cam->get("shutter")) {
-            // loadShutter (take_loader.zig:153-191): the frame's length (frame_step / frames_per_second), the shutter's opening and
-            // slope, motion_blur off.  This build renders the reference's defaults (1/60 s frames, open the whole frame, motion blur
-            // on): any other setting changes the image of a scene in which something moves, and is refused by name there
-            bool other = false;
+            // loadShutter (take_loader.zig:153-191): the frame's step (frame_step in seconds, or frames_per_second), the shutter's
+            // opening, closing and slope (two cubic Bezier segments), motion_blur off = a frame of no duration.  Base.setShutter runs
+            // whenever the key is there, with the defaults too: a configured distribution maps a time sample even if it is flat
+            float       open = 0.f, close = 1.f, slope[8] = {};
+            uint32_t    num_slope = 0;
+            bool        motion_blur = true;
+            const double units_per_second = 705600000.0;  // Scene.UnitsPerSecond
             if (JsonValue::Object == sh->type)
                 for (const auto& kv : sh->obj) {
-                    if (kv.first == "frames_per_second") other |= 60.f != kv.second.f32(60.f);
-                    else if (kv.first == "frame_step") other |= std::fabs(kv.second.f32(1.f / 60.f) - 1.f / 60.f) > 1e-9f;
-                    else if (kv.first == "motion_blur") other |= !(JsonValue::Bool == kv.second.type && kv.second.b);
-                    else if (kv.first == "open") other |= 0.f != kv.second.f32(0.f);
-                    else if (kv.first == "close") other |= 1.f != kv.second.f32(1.f);
-                    else if (kv.first == "slope") other = true;
+                    if (kv.first == "frame_step") engine_.frame_step = uint64_t(std::llround(units_per_second * (JsonValue::Number == kv.second.type ? kv.second.num : 0.0)));
+                    else if (kv.first == "frames_per_second") {
+                        const double fps = JsonValue::Number == kv.second.type ? kv.second.num : 0.0;
+                        engine_.frame_step = 0.0 == fps ? 0u : uint64_t(std::llround(units_per_second / fps));
+                    } else if (kv.first == "open") open = kv.second.f32(0.f);
+                    else if (kv.first == "close") close = kv.second.f32(1.f);
+                    else if (kv.first == "slope" && JsonValue::Array == kv.second.type) {
+                        num_slope = uint32_t(std::min<size_t>(8, kv.second.arr.size()));
+                        for (uint32_t i = 0; i < num_slope; ++i) slope[i] = kv.second.arr[i].f32(0.f);
+                    } else if (kv.first == "motion_blur") motion_blur = JsonValue::Bool == kv.second.type ? kv.second.b : motion_blur;
                 }
-            other_shutter_ = other;  // (only matters to a scene in which something moves: loadTake looks once the scene is read)
+            engine_.setShutter(open, close, slope, num_slope);
+            engine_.frame_duration = motion_blur ? engine_.frame_step : 0u;
+            // (the view block holds ZYGPU_MAX_CAMERA_KEYFRAMES keyframes of a moving camera: frames longer than that many ticks of 1/60 s
+            // are refused by name)
+            if (engine_.numInterpolationFrames() > ZYGPU_MAX_CAMERA_KEYFRAMES)
+                error = "a camera \"shutter\" whose frame spans more than " + std::to_string(ZYGPU_MAX_CAMERA_KEYFRAMES - 1) + " ticks of 1/60 s";
         }
         Transformation t = identity();
         if (const JsonValue* tr = cam->get("transformation")) readTransformation(*tr, t);
