@@ -550,7 +550,8 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * draw of sampleLights, without a closure) and wf_scatter<.., PHASE 2> (the closure's evaluation of the stored light samples, the
  * bxdf sample, the path's extension); same film;
  * "fuse_pool" (default 1): the POOL scenes' complete instantiations find the closest hit and run the first shading pass in one
- * kernel (wf_trace_shade_pool) instead of wf_intersect + wf_shade; same film. */
+ * kernel (wf_trace_shade_pool) instead of wf_intersect + wf_shade; same film;
+ * "shadow_u_blocks" (default 4, 1-10): blocks per CU of the persistent any-hit walker of the large meshes (wf_shadow_u). */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 /* Reads an option back, and what the library derived from the options and the uploaded scene (valid after zygpu_upload_scene):
  * "relaxed_units" 1 when the relaxed-arithmetic kernel units render this scene (option "precise" 0 and a scene they are inside

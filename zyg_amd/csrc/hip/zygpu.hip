@@ -497,6 +497,10 @@ struct ZygpuContext {
     // option "fuse_pool" (default 1): wf_trace_shade_pool instead of wf_intersect + wf_shade's first pass for the POOL scenes' complete
     // instantiations
     bool          fuse_pool = true;
+    // option "shadow_u_blocks" (default 4): 256-thread blocks of the persistent wf_shadow_u per CU (= waves per SIMD; the kernel is
+    // compiled for up to ZYG_SHADOW_U_WAVES = 6 of them).  Measured on configs[2], ms per 4 steps: 2 blocks 130, 3: 118, 4: 119, 5: 120,
+    // 6: 124, 8 (compiled for 8): 131: past three waves per SIMD more rays in flight only add misses
+    int           shadow_u_blocks = 4;
     uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
     bool          extended_materials = false;  // a material carries ZYGPU_MATF_EXTENDED (textures, coating, flakes ...): the complete closure
     uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
@@ -1906,7 +1910,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 // the meshes for the round's suspended rays, the next launch takes the suspended vertices up again
                 timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_SUBST : K_SCATTER_H, aliveGrid(), P, 0u); });
                 for (uint32_t r = 1; r <= rounds; ++r) {
-                    timedLaunch(c, 3, [&] { launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, 6), P, r - 1u); });
+                    timedLaunch(c, 3, [&] { launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, unsigned(c->shadow_u_blocks)), P, r - 1u); });
                     timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_RESUME_SUBST : K_SCATTER_H_RESUME, grid.x, P, r); });
                 }
             } else if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
@@ -2273,6 +2277,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "fuse_pool")) {
         c->fuse_pool = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "shadow_u_blocks")) {
+        c->shadow_u_blocks = std::max(1, std::min(value, 10));
         return 0;
     }
     if (0 == std::strcmp(name, "mesh_kernels")) {
