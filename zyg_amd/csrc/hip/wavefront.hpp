@@ -257,6 +257,7 @@ struct Params {
     uint32_t  scatter_source;  // wf_scatter reads 0: the alive queue, 1: the overflow queue (Queues::shadow, shadow_count[0]) of wf_light
     uint32_t round;   // POOL: which vertex of the level this launch handles
     uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits
+    uint32_t lazy_head;  // 1 (option "lazy_head", with hit_q): the first shading pass leaves a vertex' sampler and throughput to wf_scatter (shadeVertex)
 };
 
 // one copy per translation unit (kernel_table.hpp): the units are built without relocatable device code
@@ -1490,7 +1491,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 template <bool STATS, bool MESHL, bool HEAVY, bool POOL, int PRE = 0, uint32_t KINDS = kAllLightKinds>
 ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
                     Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr, float4 pre_thr = make_float4(1.f, 1.f, 1.f, 0.f),
-                    float* sr_out = nullptr, uint32_t* material_out = nullptr) {
+                    float* sr_out = nullptr, uint32_t* material_out = nullptr, bool* lazy_out = nullptr) {
     const DScene&  s = c_scene;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -1673,7 +1674,13 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
             if (sr_out) *sr_out = stochastic_r;  // (the caller writes it with the hit, at the vertex' place in the alive queue)
             else P.pool.hit_sr[slot] = stochastic_r;
             if (material_out) *material_out = mat_id;
-            P.pool.thr[slot] = f4(throughput, POOL ? split_weight : thr4.w);  // (non-POOL: the spare lane may carry PrevVertex::alpha)
+            // `lazy_out` (the first pass of a later tick, hit records by queue position): this pass has drawn twice (Russian roulette,
+            // stochastic_r) and at most divided the throughput by the roulette's probability.  wf_scatter, which reads and rewrites the
+            // path's line anyway, makes the two draws again from the line as it is (HitRecord::lazy), so this kernel writes neither the
+            // sampler's 48 B nor the throughput back: two dirty sectors of the line less per vertex
+            const bool lazy = !POOL && !HEAVY && 1 != PRE && nullptr != lazy_out;
+            if (lazy_out) *lazy_out = lazy;
+            if (!lazy) P.pool.thr[slot] = f4(throughput, POOL ? split_weight : thr4.w);  // (non-POOL: the spare lane may carry PrevVertex::alpha)
             if (POOL) {
                 f3         geo_n = frag.geo_n, n = frag.n;
                 const bool flipped = (m.flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo);
@@ -1693,7 +1700,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
                 P.pool.rec_ior[slot] = make_float2(ior_outside, m.priority < md.highestPriority() ? 1.f : 0.f);
                 if (MESHL && (m.flags & ZYGPU_MATF_EXTENDED)) P.pool.rec_uv[slot] = make_float2(frag.uv0, frag.uv1);
             }
-            storeHead<POOL>(P, slot, h);
+            if (!lazy) storeHead<POOL>(P, slot, h);
             if (1 == PRE) commitFresh();
             alive = true;
         }
@@ -1723,17 +1730,19 @@ struct HitRecord {  // what wf_scatter's closure set-up reads of the vertex' hit
     // the hit part's material, which the shading pass has looked up (prop -> part -> material: three dependent loads that
     // loadSurface then does not repeat), or kNull: not recorded (the records by slot have no word for it)
     uint32_t material;
+    // the first shading pass left the path's line alone (shadeVertex `lazy_out`): wf_scatter makes its two draws again
+    bool     lazy;
 };
 ZD HitRecord loadHitRecord(const Params& P, uint32_t slot) {
-    return {P.pool.hit[slot], P.pool.hit_prop[slot], P.pool.ucount[slot], P.pool.hit_sr[slot], kNull};
+    return {P.pool.hit[slot], P.pool.hit_prop[slot], P.pool.ucount[slot], P.pool.hit_sr[slot], kNull, false};
 }
 ZD HitRecord loadQueuedHit(const Params& P, uint32_t position) {
     const uint4 a = P.hit_q[2u * size_t(position)], b = P.hit_q[2u * size_t(position) + 1u];
-    return {a, b.x, b.y, __uint_as_float(b.z), b.w};
+    return {a, b.x, b.y & 0x7FFFFFFFu, __uint_as_float(b.z), b.w, 0 != (b.y >> 31)};
 }
-ZD void storeQueuedHit(const Params& P, uint32_t position, const Hit& hit, uint32_t ucount, float stochastic_r, uint32_t material) {
+ZD void storeQueuedHit(const Params& P, uint32_t position, const Hit& hit, uint32_t ucount, float stochastic_r, uint32_t material, bool lazy) {
     P.hit_q[2u * size_t(position)] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
-    P.hit_q[2u * size_t(position) + 1u] = make_uint4(hit.prop, ucount, __float_as_uint(stochastic_r), material);
+    P.hit_q[2u * size_t(position) + 1u] = make_uint4(hit.prop, ucount | (lazy ? 0x80000000u : 0u), __float_as_uint(stochastic_r), material);
 }
 
 // Two passes share shadeVertex.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
@@ -1755,6 +1764,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
         Hit        hit{0.f, 0.f, 0.f, 0u, kNull};
         float      stochastic_r = 0.f;
         uint32_t   material = kNull;
+        bool       lazy = false;
         const bool queued = !POOL && nullptr != P.hit_q;
         if (i < total) {
             slot = HEAVY ? P.q.heavy[at] : extQueue<POOL>(P, cur, P.round)[at];
@@ -1763,7 +1773,8 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             alive_key = hit.prop;
             ucount = P.pool.ucount[slot];
             shadeVertex<STATS, MESHL, HEAVY, POOL, 0, KINDS>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, ucount, alive, defer, cnt, tm, nullptr,
-                                                             make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr, queued ? &material : nullptr);
+                                                             make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr, queued ? &material : nullptr,
+                                                             (queued && !HEAVY && P.lazy_head) ? &lazy : nullptr);
         }
         if (HEAVY && !POOL && P.regen_sample) {
             // the regenerating kernels: no queue behind this pass; a path that ended here leaves its slot to wf_rscatter
@@ -1775,7 +1786,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             }
             if (!POOL && P.alive_keys > 1) alivePushKeyed<4>(P, cur, false, alive, alive_key & (kAliveKeys - 1u), slot);
             else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot, false, &position);
-            if (queued && alive) storeQueuedHit(P, position, hit, ucount, stochastic_r, material);
+            if (queued && alive) storeQueuedHit(P, position, hit, ucount, stochastic_r, material, lazy);
         }
         tm.mark(5);
         tm.flush(P.ctl, 0);
@@ -1912,6 +1923,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         uint32_t   slot = 0, alive_key = 0, queued_ucount = 0, position = 0, queued_material = kNull;
         Hit        queued_hit{0.f, 0.f, 0.f, 0u, kNull};
         float      stochastic_r = 0.f;
+        bool       queued_lazy = false;
         const bool queued = nullptr != P.hit_q;
 #ifndef ZYG_SORT_BLOCK
 #define ZYG_SORT_BLOCK 0
@@ -2004,7 +2016,8 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
             const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<STATS, MESHL, UTLAS>(P, scene, slot, vertexPlane<false>(), depth, ray, cnt) : 0u;
             tm.mark(10);
             shadeVertex<STATS, MESHL, false, false, kPre>(P, slot, o, d, hit, ucount, alive, defer, shade_cnt, tm, &fresh, fresh_thr,
-                                                          queued ? &stochastic_r : nullptr, queued ? &queued_material : nullptr);
+                                                          queued ? &stochastic_r : nullptr, queued ? &queued_material : nullptr,
+                                                          (queued && !FIRST && P.lazy_head) ? &queued_lazy : nullptr);
             // wf_shade's second pass and wf_scatter's closure set-up read the hit from the pool: by slot, or (the vertices that go
             // straight on to wf_scatter, Params::hit_q) at their place in the alive queue, behind the append below
             if (defer || (alive && !queued)) {
@@ -2019,7 +2032,7 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
         // configs[1] wf_trace_shade 126.0 -> 123.9 ms per 8 steps against two queuePush calls
         if (UTLAS && P.alive_keys > 1) alivePushKeyed<kTraceShadeBlock / 64>(P, cur, defer, alive && !defer, alive_key & (kAliveKeys - 1u), slot);
         else queuePushTwo<kTraceShadeBlock / 64>(P.q.heavy, &P.ctl->heavy_count[cur], defer, P.alive_out, &P.ctl->alive_count[cur][0], alive && !defer, slot, &position);
-        if (queued && alive && !defer) storeQueuedHit(P, position, queued_hit, queued_ucount, stochastic_r, queued_material);
+        if (queued && alive && !defer) storeQueuedHit(P, position, queued_hit, queued_ucount, stochastic_r, queued_material, queued_lazy);
         tm.mark(11);
         tm.flush(P.ctl, 0);
     }
@@ -2727,6 +2740,15 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     const float4          thr4 = P.pool.thr[slot];
     f3                    throughput = xyz4(thr4);
     const float           split_weight = POOL ? thr4.w : 1.f;
+    if (!POOL && record && record->lazy) {
+        // the first shading pass drew twice and wrote nothing back (shadeVertex `lazy_out`): russianRoulette (helper.zig:75-89: the
+        // path is here, so it survived) and rs.stochastic_r (vertex.zig:165: its value came with the hit record), from the line as
+        // the previous wf_scatter left it
+        (void)h.smp.sample1D();
+        const float continuation_probability = hmax3(throughput) / 0.1f;
+        if (continuation_probability < 1.f) throughput = throughput / S3(continuation_probability);
+        (void)h.smp.sample1D();
+    }
 
     if (2 == PHASE && kNeeOverflow == P.nee_count[ps]) return;  // wf_light sent the vertex through the unsplit kernel
     if (MESHL && 1 != PHASE && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput, record);

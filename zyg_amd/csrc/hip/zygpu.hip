@@ -501,6 +501,9 @@ struct ZygpuContext {
     // compiled for up to ZYG_SHADOW_U_WAVES = 6 of them).  Measured on configs[2], ms per 4 steps: 2 blocks 130, 3: 118, 4: 119, 5: 120,
     // 6: 124, 8 (compiled for 8): 131: past three waves per SIMD more rays in flight only add misses
     int           shadow_u_blocks = 4;
+    // option "lazy_head" (default 1): where the hit records travel by queue position (hit_q), the first shading pass of a later tick
+    // does not write the sampler and the throughput back; wf_scatter makes its two draws again (wavefront.hpp shadeVertex)
+    bool          lazy_head = true;
     uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
     bool          extended_materials = false;  // a material carries ZYGPU_MATF_EXTENDED (textures, coating, flakes ...): the complete closure
     uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
@@ -1694,6 +1697,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                    !(c->persistent && plain_in_place) && !(c->regenerate && plain_in_place && !wide && !one_shot))
                       ? c->hit_q
                       : nullptr;
+        P.lazy_head = (c->lazy_head && nullptr != P.hit_q) ? 1u : 0u;
         const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
         P.mesh_pass = mesh_pass ? 1u : 0u;
         if (mesh_pass) {
@@ -2279,6 +2283,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->fuse_pool = 0 != value;
         return 0;
     }
+    if (0 == std::strcmp(name, "lazy_head")) {
+        c->lazy_head = 0 != value;
+        return 0;
+    }
     if (0 == std::strcmp(name, "shadow_u_blocks")) {
         c->shadow_u_blocks = std::max(1, std::min(value, 10));
         return 0;
@@ -2367,6 +2375,7 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"pool_tick_sync", c->pool_tick_sync ? 1 : 0},
                  {"split_nee", c->split_nee ? 1 : 0},
                  {"fuse_pool", c->fuse_pool ? 1 : 0},
+                 {"lazy_head", c->lazy_head ? 1 : 0},
                  {"tick_sync", c->tick_sync ? 1 : 0}};
     for (const auto& e : table)
         if (0 == std::strcmp(name, e.name)) {
