@@ -378,9 +378,10 @@ def test_glass(engine, oracle, integrator, objects):
     _check(*out, 3)
 
 
-@pytest.mark.parametrize("scene", ["glass_box", "outdoor"])
+@pytest.mark.parametrize("scene", ["glass_box", "outdoor", "cornell"])
 def test_pool_kernel_options_render_the_same_film(engine, oracle, scene):
-    """The POOL scenes' kernel layout options (zygpu.h: fuse_pool, split_nee, pool_tick_sync) choose between kernels that
+    """The kernel layout options (zygpu.h: fuse_pool, split_nee, pool_tick_sync for the POOL scenes; lazy_head for them and for
+    the plain Cornell box, where the hit records travel by queue position) choose between kernels that
     compute the same thing: every setting gives the default's film, bit for bit in the precise units (whose default film is the
     oracle's), inside the relaxed units' tolerance in theirs.  (The defaults are the fused / split forms: the others run nowhere else in the suite.)"""
     w, h, spp = 96, 64, 3
@@ -391,11 +392,15 @@ def test_pool_kernel_options_render_the_same_film(engine, oracle, scene):
         if "outdoor" == scene:
             scenes.outdoor(engine, w, h, spp, integrator="PTMIS", material="substitute", showcase=True, max_depth=10,
                            mesh=scenes.heightfield_mesh(48, size=1.2, height=0.5), sky="canopy", sun_radius=0.05)
+        elif "cornell" == scene:
+            scenes.cornell(engine, w, h, spp, integrator="PTMIS", max_depth=12)
         else:
             scenes.cornell(engine, w, h, spp, integrator="PTMIS", material="substitute",
                            glass_objects={"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)})
         engine.start_frame(0)
         engine.set_option("precise", precise)
+        if "cornell" == scene:
+            engine.set_option("nee_in_place", 1)
         for name, value in options.items():
             engine.set_option(name, value)
         engine.render_iterations(spp)
@@ -408,7 +413,8 @@ def test_pool_kernel_options_render_the_same_film(engine, oracle, scene):
             sd = engine.lib.su_ext_scene_desc().contents
             vd = engine.lib.su_ext_view_desc().contents
             assert np.array_equal(default, oracle_render(oracle, sd, vd, spp))
-        for options in ({"fuse_pool": 0}, {"split_nee": 0}, {"pool_tick_sync": 0}, {"fuse_pool": 0, "split_nee": 0, "pool_tick_sync": 0}):
+        for options in ({"fuse_pool": 0}, {"split_nee": 0}, {"pool_tick_sync": 0}, {"lazy_head": 0}, {"lazy_head": 0, "split_nee": 0},
+                        {"fuse_pool": 0, "split_nee": 0, "pool_tick_sync": 0}):
             film = render(precise, **options)
             if precise:
                 assert np.array_equal(film, default), options
