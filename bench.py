@@ -93,6 +93,8 @@ def parse_args():
     ap.add_argument("--pool-relaxed", type=int, default=1, choices=[0, 1],
                     help="zygpu option pool_relaxed: with --precise 0 the scenes with Glass run the relaxed units like every other scene (default); "
                          "0: they get the precise units whatever --precise says (the rule until round 4)")
+    ap.add_argument("--split-materials", type=int, default=1, choices=[0, 1],
+                    help="zygpu option split_materials: wf_scatter_h per material class over the sorted alive queue's sub-queues (default) or the Substitute instantiation for all")
     ap.add_argument("--lazy-head", type=int, default=1, choices=[0, 1],
                     help="zygpu option lazy_head: the first shading pass leaves a vertex' sampler and throughput to wf_scatter (default) or writes them back")
     ap.add_argument("--shadow-u-blocks", type=int, default=4, help="zygpu option shadow_u_blocks: blocks of the persistent wf_shadow_u per CU")
@@ -176,6 +178,7 @@ class Measurement:
         self.eng.set_option("fuse_pool", args.fuse_pool)
         self.eng.set_option("shadow_u_blocks", args.shadow_u_blocks)
         self.eng.set_option("lazy_head", args.lazy_head)
+        self.eng.set_option("split_materials", args.split_materials)
         self.eng.set_option("precise", args.precise)
         self.eng.set_option("persistent", args.persistent)
         self.eng.set_option("fuse_tick", args.fuse_tick)
@@ -318,7 +321,7 @@ def bench_config(args):
     # default, so that a profile of the default configuration keeps its key and any other run is refused by it
     defaults = parse_defaults()
     for key in ("regenerate", "regen_kslots", "sort_alive", "pack_prev", "compact_blocks", "hit_by_queue", "mesh_kernels", "mesh_closest",
-                "pair_small", "box_triangles", "extra_props", "fuse_tick", "persistent", "shard", "spp_total", "pool_relaxed", "split_nee", "fuse_pool", "shadow_u_blocks", "lazy_head"):
+                "pair_small", "box_triangles", "extra_props", "fuse_tick", "persistent", "shard", "spp_total", "pool_relaxed", "split_nee", "fuse_pool", "shadow_u_blocks", "lazy_head", "split_materials"):
         if getattr(args, key) != defaults[key]:
             cfg[key] = getattr(args, key)
     return cfg

@@ -553,7 +553,9 @@ int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
  * kernel (wf_trace_shade_pool) instead of wf_intersect + wf_shade; same film;
  * "shadow_u_blocks" (default 4, 1-10): blocks per CU of the persistent any-hit walker of the large meshes (wf_shadow_u);
  * "lazy_head" (default 1): where the hit records travel by queue position, the first shading pass of a later tick does not write
- * a surviving vertex' sampler and throughput back to its line: wf_scatter makes that pass's two draws again; same film. */
+ * a surviving vertex' sampler and throughput back to its line: wf_scatter makes that pass's two draws again; same film;
+ * "split_materials" (default 1): where the alive queue is sorted by hit prop (the large-mesh kernels), the sub-queues that hold no
+ * Substitute prop go through the lighter instantiation of wf_scatter_h. */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 /* Reads an option back, and what the library derived from the options and the uploaded scene (valid after zygpu_upload_scene):
  * "relaxed_units" 1 when the relaxed-arithmetic kernel units render this scene (option "precise" 0 and a scene they are inside

@@ -257,6 +257,7 @@ struct Params {
     uint32_t  scatter_source;  // wf_scatter reads 0: the alive queue, 1: the overflow queue (Queues::shadow, shadow_count[0]) of wf_light
     uint32_t round;   // POOL: which vertex of the level this launch handles
     uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits
+    uint32_t alive_key_mask;  // wf_scatter_h: bit k = the launch takes sub-queue k of the sorted alive queue
     uint32_t lazy_head;  // 1 (option "lazy_head", with hit_q): the first shading pass leaves a vertex' sampler and throughput to wf_scatter (shadeVertex)
 };
 
@@ -435,7 +436,7 @@ ZD void aliveReset(QueueCounts (&counts)[kAliveKeys]) {  // by one wave
 // whole blocks (its length rounded up to 256), so a block, and with it a wave, reads one sub-queue.  Returns whether the
 // thread belongs to a block that has entries at all (whole blocks take part in the queue appends that follow); `valid`: it has an
 // entry, at alive_in[at].
-ZD bool aliveOpen(const Params& P, uint32_t parity, uint32_t i, uint32_t& at, bool& valid) {
+ZD bool aliveOpen(const Params& P, uint32_t parity, uint32_t i, uint32_t& at, bool& valid, uint32_t* key = nullptr) {
     const uint32_t block_first = i & ~255u;  // (uniform over the block)
     uint32_t       begin = 0;
     valid = false;
@@ -446,6 +447,7 @@ ZD bool aliveOpen(const Params& P, uint32_t parity, uint32_t i, uint32_t& at, bo
         if (block_first < end) {
             at = k * P.queue_capacity + (i - begin);
             valid = i - begin < n;
+            if (key) *key = k;
             return true;
         }
         begin = end;
@@ -2596,8 +2598,11 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(SUBST ? ZYG_SCATTER_BIG_WAVES :
         const uint32_t total = P.ctl->shadow_count[(round + 1u) & 1u].n[0];
         if (i >= ((total + 255u) & ~255u)) return;  // whole blocks take part in the queue appends
         has_entry = i < total;
-    } else if (!aliveOpen(P, P.parity, i, at, has_entry)) {
-        return;
+    } else {
+        // Params::alive_key_mask: the sub-queues (= hit props, modulo kAliveKeys) this launch takes; a scene with Substitute and other
+        // materials runs the lighter instantiation on the sub-queues that hold no Substitute prop (a block reads one sub-queue)
+        uint32_t key = 0;
+        if (!aliveOpen(P, P.parity, i, at, has_entry, &key) || 0 == ((P.alive_key_mask >> key) & 1u)) return;
     }
     bool     push = false, back = false, suspend = false;
     uint32_t slot = 0;

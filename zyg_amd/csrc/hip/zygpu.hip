@@ -466,6 +466,7 @@ struct ZygpuContext {
     size_t        film_pixels = 0;
     bool          stats = false;
     bool          has_substitute = false;  // selects the kernels' material instantiation
+    uint32_t      subst_keys = 0;          // bit k: a prop p with p % kAliveKeys == k has a Substitute material (the sorted alive queue's sub-queues)
     bool          multi_sample_lights = false;  // a light has emittance num_samples > 1: wf_scatter<.., MULTI>
     bool          mesh_lights = false;          // TriangleMesh emitters: wf_shade<.., MESHL>, wf_scatter<.., MESHL>
     bool          masks = false;                // a material has an opacity mask: wf_scatter<.., MASKS>
@@ -504,6 +505,8 @@ struct ZygpuContext {
     // option "lazy_head" (default 1): where the hit records travel by queue position (hit_q), the first shading pass of a later tick
     // does not write the sampler and the throughput back; wf_scatter makes its two draws again (wavefront.hpp shadeVertex)
     bool          lazy_head = true;
+    // option "split_materials" (default 1): wf_scatter_h per material class over the sorted alive queue's sub-queues (zygpu_render)
+    bool          split_materials = true;
     uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
     bool          extended_materials = false;  // a material carries ZYGPU_MATF_EXTENDED (textures, coating, flakes ...): the complete closure
     uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
@@ -1057,6 +1060,12 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (d->props[p].flags & ZYGPU_PROP_SHADOW_CATCHER) c->catchers = true;
     if (c->catchers) c->pool_mode = c->mesh_lights = true;
     s.has_catcher = c->catchers ? 1u : 0u;
+    c->subst_keys = 0;
+    for (uint32_t p = 0; p < d->num_props; ++p) {
+        const uint32_t parts = ZYGPU_SHAPE_TRIANGLE_MESH == d->props[p].shape ? d->meshes[d->props[p].mesh].num_parts : 1u;
+        for (uint32_t k = 0; k < parts; ++k)
+            if (ZYGPU_MAT_SUBSTITUTE == d->materials[d->material_ids[d->props[p].parts_start + k]].kind) c->subst_keys |= 1u << (p & (kAliveKeys - 1u));
+    }
     c->has_substitute = false;
     for (uint32_t mi = 0; mi < d->num_materials; ++mi) {
         if (ZYGPU_MAT_SUBSTITUTE == d->materials[mi].kind) c->has_substitute = true;
@@ -1698,6 +1707,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                       ? c->hit_q
                       : nullptr;
         P.lazy_head = (c->lazy_head && nullptr != P.hit_q) ? 1u : 0u;
+        P.alive_key_mask = ~0u;
         const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
         P.mesh_pass = mesh_pass ? 1u : 0u;
         if (mesh_pass) {
@@ -1912,7 +1922,20 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             if (nee && c->nee_in_place && wide && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels && !c->multi_sample_lights) {
                 // wf_scatter_h: in place, but a vertex whose shadow ray has to walk a large mesh is suspended; wf_shadow_u walks
                 // the meshes for the round's suspended rays, the next launch takes the suspended vertices up again
-                timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_SUBST : K_SCATTER_H, aliveGrid(), P, 0u); });
+                timedLaunch(c, 5, [&] {
+                    // the sorted alive queue keeps a hit prop's vertices in one sub-queue: the sub-queues without a Substitute prop go through
+                    // the lighter instantiation (three waves per SIMD instead of two), the others through the Substitute one
+                    const uint32_t all = P.alive_keys > 1 ? (1u << P.alive_keys) - 1u : 1u, heavy = c->subst_keys & all;
+                    if (c->has_substitute && P.alive_keys > 1 && c->split_materials && heavy != all) {
+                        Params L = P;
+                        L.alive_key_mask = all & ~heavy;
+                        launchKernel(c, K_SCATTER_H, aliveGrid(), L, 0u);
+                        L.alive_key_mask = heavy;
+                        if (heavy) launchKernel(c, K_SCATTER_H_SUBST, aliveGrid(), L, 0u);
+                    } else {
+                        launchKernel(c, c->has_substitute ? K_SCATTER_H_SUBST : K_SCATTER_H, aliveGrid(), P, 0u);
+                    }
+                });
                 for (uint32_t r = 1; r <= rounds; ++r) {
                     timedLaunch(c, 3, [&] { launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, unsigned(c->shadow_u_blocks)), P, r - 1u); });
                     timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_RESUME_SUBST : K_SCATTER_H_RESUME, grid.x, P, r); });
@@ -2281,6 +2304,10 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     }
     if (0 == std::strcmp(name, "fuse_pool")) {
         c->fuse_pool = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "split_materials")) {
+        c->split_materials = 0 != value;
         return 0;
     }
     if (0 == std::strcmp(name, "lazy_head")) {
