@@ -787,6 +787,16 @@ constexpr bool kPackedAccumulators = false;
 ZD char* pathBlock(const Params&, uint32_t) { return nullptr; }
 #endif
 
+// where a record lives (the interleaved block's proxy, or a plain array in the builds without it)
+template <typename T, int STRIDE>
+ZD T* recordAddress(const Rec<T, STRIDE>& r, uint32_t slot) {
+    return r[slot].p;
+}
+template <typename T>
+ZD T* recordAddress(T* r, uint32_t slot) {
+    return r + slot;
+}
+
 template <bool PACKED>
 ZD void loadEmissionDirect(const Params& P, uint32_t slot, f3& e, f3& d) {
     if (PACKED && kPackedAccumulators && P.packed_acc) {
@@ -2745,6 +2755,18 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     const float4          thr4 = P.pool.thr[slot];
     f3                    throughput = xyz4(thr4);
     const float           split_weight = POOL ? thr4.w : 1.f;
+    // The sum this kernel may add to (IValue.add, helper.zig:11-19: the direct sum for the camera vertex' light samples, the indirect one
+    // behind it), read here, with the path's line, instead of where the light's contribution is known: there the add waited for a load
+    // of its own (a fifth of the kernel's wave cycles on configs[1], tools/sections.py)
+    constexpr bool kPreloadSum = !POOL && 0 == PHASE && kPackedAccumulators;
+    const bool     preload_sum = kPreloadSum && 0 != P.packed_acc;
+    const bool     sum_is_direct = h.depth_surface < 1u;
+    float4*        sum_at = nullptr;
+    float4         sum_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (preload_sum) {
+        sum_at = sum_is_direct ? reinterpret_cast<float4*>(pathBlock(P, slot) + 112) : recordAddress(P.pool.indirect, slot);
+        sum_old = *sum_at;
+    }
     if (!POOL && record && record->lazy) {
         // the first shading pass drew twice and wrote nothing back (shadeVertex `lazy_out`): russianRoulette (helper.zig:75-89: the
         // path is here, so it survived) and rs.stochastic_r (vertex.zig:165: its value came with the hit record), from the line as
@@ -3108,7 +3130,12 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                 nee = nee + occluded;
             }
         }
-        if (1 != PHASE) ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
+        if (preload_sum) {  // ivalueAdd's arithmetic on the sum read above (the direct sum shares its four words with emission.z: .x)
+            const f3 value = throughput * nee;
+            if (!(0.f == value.x && 0.f == value.y && 0.f == value.z))
+                *sum_at = sum_is_direct ? make_float4(sum_old.x, sum_old.y + value.x, sum_old.z + value.y, sum_old.w + value.z)
+                                        : f4(xyz4(sum_old) + value, sum_old.w);
+        } else if (1 != PHASE) ivalueAdd<!POOL>(P, ps, (POOL ? throughput * S3(split_weight) : throughput) * nee, h.depth_surface, 1u, false, false);
         tm.mark(5);
     }
     if (1 == PHASE) {
