@@ -401,10 +401,11 @@ class Oracle:
     baseline only: nothing of it is on the measured path."""
 
     def __init__(self, zyg_amd):
-        so = os.path.join(ROOT, "oracle", "liboracle.so")
-        if not os.path.exists(so):
-            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
-        self.lib = ctypes.CDLL(so)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("oracle_build", os.path.join(ROOT, "oracle", "build.py"))
+        oracle_build = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(oracle_build)  # compiled for this box's CPU (-march=native)
+        self.lib = ctypes.CDLL(oracle_build.ensure_built())
         self.lib.zyg_oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                ctypes.c_void_p]

@@ -123,11 +123,18 @@ int32_t su_ext_prop_set_visibility(uint32_t prop, bool in_camera, bool in_reflec
 int32_t su_ext_sky_create(const char* parameters_json);
 /* The products of the sky bake (sky.zig:172-269; what the reference keeps in its cache files, sky.zig:138-168): the sun's
  * radiance over its disc, 1024 rgb samples (Sky.BakeDimensionsSun), and the canopy image, sky_width x sky_height rgb floats
- * (1024 x 1024 in the reference).  Without this call compile bakes them as the reference does (csrc/host/sky_bake.hpp) when
- * libarpraguesky.so (built by zyg_amd/build.py from the reference's thirdparty/arpraguesky) lies beside this library and
- * sky/SkyModelDataset.dat.gz is found through the mounts; otherwise it fills in a procedural stand-in and says so, with the
- * reason, in the log: the Prague model's dataset does not ship with the reference. */
+ * (1024 x 1024 in the reference).  Without this call compile bakes them as the reference does (csrc/host/sky_bake.hpp over this
+ * library's own evaluator of the Prague model, csrc/host/prague_sky.hpp) when sky/SkyModelDataset.dat.gz is found through the
+ * mounts; otherwise it fills in a procedural stand-in and says so, with the reason, in the log: the model's dataset does not ship
+ * with the reference. */
 int32_t su_ext_sky_tables(const float* sun_rgb, const float* sky_rgb, uint32_t sky_width, uint32_t sky_height);
+/* The Prague sky model's evaluator by itself (csrc/host/prague_sky.hpp; what the reference gets from the C it links,
+ * thirdparty/arpraguesky/ArPragueSkyModelGround.h:170-216), so that it can be checked query by query: `count` queries of four doubles
+ * against the dataset file `dataset` (gzip or plain) for the state (solar elevation in radians, visibility in km, ground albedo).
+ * what = 0: sky radiance of (theta, gamma, shadow, wavelength); 1: solar radiance of (theta, wavelength, -, -); 2: transmittance of
+ * (theta, wavelength, distance, -).  out = count doubles.  0, or -1 when the dataset cannot be read.  Host-only: needs no device. */
+int32_t su_ext_sky_model_eval(const char* dataset, double elevation, double visibility, double albedo, uint32_t what, const double* queries,
+                              uint32_t count, double* out);
 uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,
                              uint8_t* out, uint64_t capacity);
 

@@ -14,12 +14,11 @@ def pytest_configure(config):
 
 
 def _build_oracle():
-    so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".cpp", ".hpp"))]
-    srcs.append(os.path.join(ROOT, "include", "zygpu.h"))
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-B"], check=True, capture_output=True)
-    return so
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oracle_build", os.path.join(ROOT, "oracle", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.ensure_built()
 
 
 def _build_product():

@@ -1,8 +1,9 @@
-"""The Sky entity's bake (reference core/sky/sky.zig:172-269, sky_model.zig:32-137; zyg_amd/csrc/host/sky_bake.hpp): with the Prague model's
-library (zyg_amd/libarpraguesky.so, built by zyg_amd/build.py from the reference's thirdparty/arpraguesky where a checkout is present)
-and a dataset in the library's file layout among the mounts, the sun's radiance table and the canopy image are the model's, not the
-procedural stand-in.  The real dataset does not ship with the reference: tools/make_sky_dataset.py writes a small synthetic one.  The
-bake's host code is checked against a numpy restatement that calls the same C library through ctypes."""
+"""The Sky entity's bake (reference core/sky/sky.zig:172-269, sky_model.zig:32-137; zyg_amd/csrc/host/sky_bake.hpp over the product's own
+evaluator of the Prague model, prague_sky.hpp): with a dataset in the model's file layout among the mounts, the sun's radiance table
+and the canopy image are the model's, not the procedural stand-in.  The real dataset does not ship with the reference:
+tools/make_sky_dataset.py writes a small synthetic one.  The baked tables are checked against a numpy restatement of the bake that asks
+the REFERENCE's library for the model's values (oracle/_ref/libarpraguesky.so: the C the reference links, compiled where it lies by
+oracle/Makefile; the product does not load it: tests/test_prague_sky.py)."""
 import ctypes
 import gzip
 import os
@@ -17,8 +18,8 @@ from zyg_amd import scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-PRAGUE = os.path.join(ROOT, "zyg_amd", "libarpraguesky.so")
-needs_library = pytest.mark.skipif(not os.path.exists(PRAGUE), reason="libarpraguesky.so is built from the reference's checkout (zyg_amd/build.py)")
+PRAGUE = os.path.join(ROOT, "oracle", "_ref", "libarpraguesky.so")
+needs_library = pytest.mark.skipif(not os.path.exists(PRAGUE), reason="oracle/_ref/libarpraguesky.so is compiled from the reference's checkout (make -C oracle ref)")
 SKY = {"parameters": {"sun": {"rotation": [-55, 20, 0]}, "visibility": 80.0, "albedo": 0.3}}
 f32 = np.float32
 
@@ -172,7 +173,6 @@ def test_without_the_dataset_the_stand_in_is_flagged(product_lib, tmp_path):
 
 
 @pytest.mark.gpu
-@needs_library
 def test_render_with_the_baked_sky(engine, oracle, tmp_path):
     """The device consumes the baked tables like any others: a small frame of the outdoor scene lit by the synthetic dataset's sky
     and sun, device film == the oracle's."""

@@ -188,8 +188,7 @@ def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
         os.remove(OUT + ".tag")
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(_compile, todo))
-    build_thirdparty(verbose)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-ldl", "-o", OUT]  # libz: the PNG reader (host/image_readers.hpp)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", OUT]  # libz: the PNG reader (host/image_readers.hpp)
     if verbose:
         print(f"compiled {len(todo)} of {len(objs)} translation units in {time.time() - t0:.0f} s; linking", flush=True)
     subprocess.run(cmd, check=True)
@@ -200,27 +199,6 @@ def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
     else:
         open(OUT + ".tag", "w").write(_library_tag(extra, mode))
     return OUT
-
-
-PRAGUE_SKY = os.path.join(HERE, "libarpraguesky.so")
-
-
-def build_thirdparty(verbose=True, reference=None):
-    """The Prague sky model (thirdparty/arpraguesky/ArPragueSkyModelGround.c: third-party C the reference vendors and links; the Sky
-    entity's bake evaluates it, csrc/host/sky_bake.hpp) as a shared library of its own beside libzyg_amd.so, compiled from the
-    reference's checkout where it lies: its sources are not part of this repository.  Without a checkout (the GPU box: the library
-    built here travels with the tree like the other .so files) nothing is built and what exists is kept; without the library the
-    engine renders the Sky entity with its procedural stand-in."""
-    src = os.path.join(reference or os.environ.get("ZYG_REFERENCE", "/root/reference"), "thirdparty", "arpraguesky", "ArPragueSkyModelGround.c")
-    if not os.path.exists(src):
-        return None
-    if os.path.exists(PRAGUE_SKY) and os.path.getmtime(PRAGUE_SKY) >= os.path.getmtime(src):
-        return PRAGUE_SKY
-    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-w", src, "-lm", "-o", PRAGUE_SKY]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    return PRAGUE_SKY
 
 
 def up_to_date():

@@ -495,6 +495,20 @@ int32_t su_ext_sky_tables(const float* sun_rgb, const float* sky_rgb, uint32_t s
     return 0 == g->engine.setSkyTables(sun_rgb, sky_rgb, sky_width, sky_height) ? 0 : -1;
 }
 
+int32_t su_ext_sky_model_eval(const char* dataset, double elevation, double visibility, double albedo, uint32_t what, const double* queries,
+                              uint32_t count, double* out) {
+    if (!dataset || !queries || !out || what > 2u) return -1;
+    auto        data = std::make_shared<zyg::prague::Dataset>();
+    std::string why;
+    if (!data->load(dataset, why)) return -1;
+    const zyg::prague::Model model(data, elevation, visibility, albedo);
+    for (uint32_t i = 0; i < count; ++i) {
+        const double* q = queries + 4 * size_t(i);
+        out[i] = 0 == what ? model.skyRadiance(q[0], q[1], q[2], q[3]) : 1 == what ? model.solarRadiance(q[0], q[1]) : model.transmittance(q[0], q[1], q[2]);
+    }
+    return 0;
+}
+
 uint64_t su_ext_encode_image(uint32_t format, uint32_t flags, uint32_t width, uint32_t height, const int32_t* crop, const float* rgba,
                              uint8_t* out, uint64_t capacity) {
     if (!rgba || !crop) return 0;

@@ -1788,24 +1788,31 @@ void Engine::compileSky() {
     setWorldTransformation(sky_.sky, Transformation{splat(0.f), splat(1.f), quaternionMul(qx, qy)});
     const float sun_elevation = -std::asin(sun_direction[1]);
 
-    // Sky.bakeSky (sky.zig:172-221): the Prague model evaluated over the sun's disc and the canopy (host/sky_bake.hpp), when its
-    // library (zyg_amd/libarpraguesky.so, built from the reference's thirdparty/arpraguesky) and its dataset
-    // (sky/SkyModelDataset.dat.gz, looked up through the mounts like every file: su_mount) are there.  The reference caches the two
-    // images as ../cache/{sky,sun}_<hash>.exr; here the bake is kept while (visibility, albedo, elevation) stay what they were.
+    // Sky.bakeSky (sky.zig:172-221): the Prague model (host/prague_sky.hpp) evaluated over the sun's disc and the canopy
+    // (host/sky_bake.hpp), when its dataset (sky/SkyModelDataset.dat.gz, looked up through the mounts like every file: su_mount) is
+    // there.  The reference caches the two images as ../cache/{sky,sun}_<hash>.exr; here the bake is kept while (visibility, albedo,
+    // elevation) stay what they were, and the parsed dataset while its file stays the one it was read from.
     bool baked = false;
     if (!sky_.tables_given) {
         const float key[3] = {sky_.visibility, sky_.albedo, sun_direction[1]};
         if (sky_.baked && 0 == std::memcmp(key, sky_.baked_key, sizeof(key))) {
             baked = true;
         } else {
-            static skybake::PragueLibrary library;
-            std::string                   why;
-            const std::string             dataset = resolveFile("sky/SkyModelDataset.dat.gz");
+            std::string       why;
+            const std::string dataset = resolveFile("sky/SkyModelDataset.dat.gz");
             if (!std::ifstream(dataset)) why = "sky/SkyModelDataset.dat.gz is in none of the mounted directories";
+            if (why.empty() && (!sky_.dataset || dataset != sky_.dataset_path)) {
+                auto parsed = std::make_shared<prague::Dataset>();
+                if (parsed->load(dataset, why)) {
+                    sky_.dataset = std::move(parsed);
+                    sky_.dataset_path = dataset;
+                } else {
+                    sky_.dataset.reset();
+                }
+            }
             std::vector<float> sun_rgb, sky_rgb;
-            if (why.empty() && library.load(why) &&
-                skybake::bake(library, dataset, sun_direction[1], sky_.visibility, sky_.albedo, kSkyRadius, kSkySunSamples, kSkyBakeDimension, sun_rgb,
-                              sky_rgb, why)) {
+            if (why.empty()) {
+                skybake::bake(sky_.dataset, sun_direction[1], sky_.visibility, sky_.albedo, kSkyRadius, kSkySunSamples, kSkyBakeDimension, sun_rgb, sky_rgb);
                 sky_.sun_rgb = std::move(sun_rgb);
                 HostImage& img = images_[sky_.image];
                 img.width = img.height = kSkyBakeDimension;

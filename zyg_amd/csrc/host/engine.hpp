@@ -11,6 +11,7 @@
 #pragma once
 
 #include <deque>
+#include <memory>
 #include <string>
 #include <map>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "hmath.hpp"
 #include "json.hpp"
 #include "light_tree_builder.hpp"
+#include "prague_sky.hpp"
 
 namespace zyg {
 
@@ -304,7 +306,9 @@ class Engine {
         bool     tables_given = false;
         bool     baked = false;       // sun_rgb and the sky image are the Prague model's (host/sky_bake.hpp) for baked_key
         float    baked_key[3] = {0.f, 0.f, 0.f};  // visibility, albedo, the sun direction's y
-        std::string bake_refusal;     // why the bake did not run (no library, no dataset)
+        std::string bake_refusal;     // why the bake did not run (no dataset, or not a dataset)
+        std::shared_ptr<const prague::Dataset> dataset;  // the parsed model dataset of dataset_path
+        std::string dataset_path;
         std::vector<float> sun_rgb;  // kSkySunSamples x 3, as given or as generated
     } sky_;
     std::vector<float> c_sun_radiance_;  // 4 per sample

@@ -1,9 +1,9 @@
 // The Sky entity's bake (core/sky/sky.zig:172-269, sky_model.zig:23-137): the sun's radiance over its disc and the canopy image,
-// computed from the Prague sky model (thirdparty/arpraguesky/ArPragueSkyModelGround.c, Wilkie et al.: third-party C the reference
-// vendors and links).  That library is not part of this repository: zyg_amd/build.py compiles it into zyg_amd/libarpraguesky.so from
-// the reference's checkout where one is present, this file loads it at run time (dlopen) and the model's dataset
-// (sky/SkyModelDataset.dat.gz, not shipped with the reference either) through the engine's mounts.  Without either, the engine's
-// procedural stand-in remains (Engine::compileSky), flagged in the log as before.
+// computed from the Prague sky model (Wilkie et al.; the reference links the authors' C, thirdparty/arpraguesky).  The model's
+// evaluator here is this repository's own (prague_sky.hpp: dataset reader, sky radiance, solar radiance, transmittance), checked
+// against the reference's library compiled as test infrastructure (oracle/_ref/libarpraguesky.so, tests/test_prague_sky.py); the
+// model's dataset (sky/SkyModelDataset.dat.gz, not shipped with the reference) comes through the engine's mounts.  Without it the
+// engine's procedural stand-in remains (Engine::compileSky), flagged in the log as before.
 //
 //   Model.init / evaluateSky / evaluateSun     sky_model.zig:32-137 (12 spectral bins over 380..740 nm, 24 golden-ratio wavelength
 //                                              samples per bin, XYZ -> ACES AP1)
@@ -11,8 +11,6 @@
 //   Sky.bakeSky, SkyContext.bakeSky, sunWiDotZ, clippedCanopyMapping   sky.zig:172-343
 #pragma once
 
-#include <dlfcn.h>
-#include <zlib.h>
 
 #include <atomic>
 #include <cmath>
@@ -25,6 +23,7 @@
 
 #include "cie_xyz_1931.hpp"
 #include "hmath.hpp"
+#include "prague_sky.hpp"
 
 namespace zyg {
 namespace skybake {
@@ -121,97 +120,52 @@ inline void goldenRatio1D(float* samples, int n, float r) {  // base/math/sample
     }
 }
 
-// The Prague model's C entry points (ArPragueSkyModelGround.h:170-216), bound at run time
-struct PragueLibrary {
-    using ReadFunc = size_t (*)(void*, size_t, size_t, FILE*);
-    void* handle = nullptr;
-    void* (*alloc_init_handle)(void*, ReadFunc, double, double, double) = nullptr;
-    void (*state_free)(void*) = nullptr;
-    double (*sky_radiance)(const void*, double, double, double, double) = nullptr;
-    double (*solar_radiance)(const void*, double, double) = nullptr;
-
-    bool load(std::string& why) {
-        if (handle) return true;
-        std::vector<std::string> candidates;
-        if (const char* e = std::getenv("ZYG_ARPRAGUESKY_LIB")) candidates.push_back(e);
-        Dl_info info;
-        if (dladdr(reinterpret_cast<void*>(&integrateCie), &info) && info.dli_fname) {  // beside libzyg_amd.so
-            std::string dir(info.dli_fname);
-            const size_t at = dir.find_last_of('/');
-            candidates.push_back((std::string::npos == at ? std::string(".") : dir.substr(0, at)) + "/libarpraguesky.so");
-        }
-        for (const std::string& c : candidates) {
-            handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
-            if (handle) break;
-        }
-        if (!handle) return why = "libarpraguesky.so is not beside libzyg_amd.so (zyg_amd/build.py builds it from the reference's thirdparty/arpraguesky)", false;
-        alloc_init_handle = reinterpret_cast<decltype(alloc_init_handle)>(dlsym(handle, "arpragueskymodelground_state_alloc_init_handle"));
-        state_free = reinterpret_cast<decltype(state_free)>(dlsym(handle, "arpragueskymodelground_state_free"));
-        sky_radiance = reinterpret_cast<decltype(sky_radiance)>(dlsym(handle, "arpragueskymodelground_sky_radiance"));
-        solar_radiance = reinterpret_cast<decltype(solar_radiance)>(dlsym(handle, "arpragueskymodelground_solar_radiance"));
-        if (!alloc_init_handle || !state_free || !sky_radiance || !solar_radiance) {
-            dlclose(handle);
-            handle = nullptr;
-            return why = "libarpraguesky.so lacks the model's entry points", false;
-        }
-        return true;
-    }
-};
-
-inline size_t readGz(void* buffer, size_t size, size_t count, FILE* stream) {  // Model.readStream (sky_model.zig:66-74) over zlib
-    if (!buffer || !stream || 0 == size) return 0;
-    const int got = gzread(reinterpret_cast<gzFile>(stream), buffer, unsigned(size * count));
-    return got <= 0 ? 0 : size_t(got) / size;
-}
-
-// sky_model.zig:23-137
+// sky_model.zig:23-137 over prague::Model.  The reference asks the model for one wavelength at a time (12 bins x 24 golden-ratio
+// samples per direction); the model's answer only depends on the wavelength's channel, so a direction's channels are evaluated once
+// and the samples pick theirs (prague_sky.hpp); the f32 sums run in the reference's order.
 struct Model {
-    PragueLibrary* lib = nullptr;
-    void*          state = nullptr;
-    Vec4f          sun_direction, shadow_direction;
+    std::unique_ptr<prague::Model> model;
+    Vec4f                          sun_direction, shadow_direction;
 
-    // dataset: the path of sky/SkyModelDataset.dat.gz (gzip or plain: zlib reads both)
-    bool init(PragueLibrary& library, const std::string& dataset, const Vec4f& sun_dir, float visibility, float albedo, std::string& why) {
-        gzFile f = gzopen(dataset.c_str(), "rb");
-        if (!f) return why = "cannot read " + dataset, false;
+    void init(std::shared_ptr<const prague::Dataset> dataset, const Vec4f& sun_dir, float visibility, float albedo) {
         const float sun_elevation = -std::asin(sun_dir[1]);
-        state = library.alloc_init_handle(f, readGz, double(sun_elevation), double(visibility), double(albedo));
-        gzclose(f);
-        if (!state) return why = "the sky model could not be initialised from " + dataset, false;
-        lib = &library;
+        model.reset(new prague::Model(std::move(dataset), double(sun_elevation), double(visibility), double(albedo)));
         sun_direction = sun_dir;
         const float d = std::sqrt(sun_dir[0] * sun_dir[0] + sun_dir[2] * sun_dir[2]);
         shadow_direction = vec((-sun_dir[0] / d) * sun_dir[1], std::sqrt(1.f - sun_dir[1] * sun_dir[1]), (-sun_dir[2] / d) * sun_dir[1], 0.f);
-        return true;
     }
-    ~Model() {
-        if (state) lib->state_free(state);
+    // per bin the mean over 24 wavelengths of value(wavelength), as sky_model.zig:88-107 / 118-134 accumulate it
+    template <class F>
+    Vec4f spectral(Pcg& rng, F value) const {
+        float    samples[24];
+        Spectrum radiance;
+        for (int i = 0; i < Spectrum::kBins; ++i) {
+            goldenRatio1D(samples, 24, rng.randomFloat());
+            float rwl = 0.f;
+            for (float s : samples) rwl += float(value(double(Spectrum::randomWavelength(i, s)))) / 24.f;
+            radiance.values[i] = rwl;
+        }
+        return XYZtoAP1(radiance.XYZ());
     }
     Vec4f evaluateSky(const Vec4f& wi, Pcg& rng) const {  // sky_model.zig:80-110
         const float theta = std::acos(clamp_(wi[1], -1.f, 1.f));
         const float gamma = std::acos(clamp_(-dot3(wi, sun_direction), -1.f, 1.f));
         const float shadow = std::acos(clamp_(dot3(wi, shadow_direction), -1.f, 1.f));
-        float       samples[24];
-        Spectrum    radiance;
-        for (int i = 0; i < Spectrum::kBins; ++i) {
-            goldenRatio1D(samples, 24, rng.randomFloat());
-            float rwl = 0.f;
-            for (float s : samples) rwl += float(lib->sky_radiance(state, double(theta), double(gamma), double(shadow), double(Spectrum::randomWavelength(i, s)))) / 24.f;
-            radiance.values[i] = rwl;
-        }
-        return XYZtoAP1(radiance.XYZ());
+        double      channel[prague::Model::kMaxChannels];
+        model->skyChannels(double(theta), double(gamma), double(shadow), channel);
+        return spectral(rng, [&](double wavelength) {
+            const int c = model->channelOf(wavelength);
+            return c < 0 || c >= prague::Model::kMaxChannels ? 0. : channel[c];
+        });
     }
     Vec4f evaluateSun(float wi_dot_z, Pcg& rng) const {  // sky_model.zig:112-137
         const float theta = std::acos(clamp_(wi_dot_z, 0.f, 1.f));
-        float       samples[24];
-        Spectrum    radiance;
-        for (int i = 0; i < Spectrum::kBins; ++i) {
-            goldenRatio1D(samples, 24, rng.randomFloat());
-            float rwl = 0.f;
-            for (float s : samples) rwl += float(lib->solar_radiance(state, double(theta), double(Spectrum::randomWavelength(i, s)))) / 24.f;
-            radiance.values[i] = rwl;
-        }
-        return XYZtoAP1(radiance.XYZ());
+        double      tau[prague::Model::kMaxChannels];
+        model->transmittanceChannels(double(theta), prague::kOutOfAtmosphere, tau);
+        return spectral(rng, [&](double wavelength) {
+            const int c = model->channelOf(wavelength);
+            return c < 0 || c >= prague::Model::kMaxChannels ? 0. : prague::Model::extraterrestrial(wavelength) * tau[c];
+        });
     }
 };
 
@@ -238,11 +192,11 @@ inline bool clippedCanopyMapping(float u, float v, float e, Vec4f& wi) {
 // Sky.bakeSky (sky.zig:172-221 + SkyContext.bakeSky 284-322): sun_rgb = sun_samples x 3 (the radiance across the disc, v = i / (n - 1)
 // through sunWiDotZ), sky_rgb = dimension^2 x 3 (the canopy image, its left half computed, the right half its mirror image).
 // sun_sin_elevation = sun_direction[1] of the Sky's rotation (sky.zig:176-180).
-inline bool bake(PragueLibrary& library, const std::string& dataset, float sun_sin_elevation, float visibility, float albedo, float sun_radius,
-                 uint32_t sun_samples, int32_t dimension, std::vector<float>& sun_rgb, std::vector<float>& sky_rgb, std::string& why) {
+inline void bake(std::shared_ptr<const prague::Dataset> dataset, float sun_sin_elevation, float visibility, float albedo, float sun_radius, uint32_t sun_samples,
+                 int32_t dimension, std::vector<float>& sun_rgb, std::vector<float>& sky_rgb) {
     const float sin_el = sun_sin_elevation;
     Model       model;
-    if (!model.init(library, dataset, vec(0.f, sin_el, std::sqrt(1.f - sin_el * sin_el), 0.f), visibility, albedo, why)) return false;
+    model.init(std::move(dataset), vec(0.f, sin_el, std::sqrt(1.f - sin_el * sin_el), 0.f), visibility, albedo);
     sun_rgb.assign(size_t(sun_samples) * 3, 0.f);
     const float n = float(sun_samples - 1);
     Pcg         rng;
@@ -281,7 +235,6 @@ inline bool bake(PragueLibrary& library, const std::string& dataset, float sun_s
     for (unsigned t = 1; t < workers; ++t) pool.emplace_back(rows);
     rows();
     for (std::thread& t : pool) t.join();
-    return true;
 }
 
 }  // namespace skybake
