@@ -89,6 +89,13 @@ def parse_args():
     ap.add_argument("--spp-total", type=int, default=0,
                     help="strong scaling: the whole job's samples per pixel, split over the ranks (and over --steps); 0 = weak scaling, "
                          "--steps x --iters-per-step per rank")
+    ap.add_argument("--spawn", type=int, default=0, choices=[0, 1],
+                    help="`--gpus N` started without a launcher: 0 (default) = ONE process drives the N devices through a ZygpuGroup "
+                         "(su_ext_set_devices: a host thread and a context per device, ncclReduce of the films from C++); 1 = this process "
+                         "starts N ranks, one process per GPU, as torch.distributed.run would")
+    ap.add_argument("--reduce", default="group", choices=["group", "torch"],
+                    help="who sums the ranks' films: group = zygpu_group_reduce (ncclReduce called from C++ behind the C ABI, default); "
+                         "torch = torch.distributed.reduce on the film tensor (the cross-check of rounds 1-4)")
     ap.add_argument("--print-config", action="store_true", help="print bench_config() (the key a committed profile is quoted under) and exit")
     ap.add_argument("--pool-relaxed", type=int, default=1, choices=[0, 1],
                     help="zygpu option pool_relaxed: with --precise 0 the scenes with Glass run the relaxed units like every other scene (default); "
@@ -154,22 +161,37 @@ def describe(name, material, w, h, ips, k, relaxed):
 class Measurement:
     """One scene on this rank's GPU: the stats iteration (algorithmic bytes), warm-up, the timed steps."""
 
-    def __init__(self, args, zyg_amd, scenes, torch, frame, device, scene, material, steps, warmup, size=None):
+    def __init__(self, args, zyg_amd, scenes, torch, frame, device, scene, material, steps, warmup, size=None, group_spec=None):
+        """group_spec: None (one context; the ranks' films, if any, are summed by torch.distributed), {"devices": [ids]} (this process is
+        the whole world: one ZygpuGroup over the listed devices) or {"devices": [id], "rank": r, "world": n, "dist": dist} (one process per
+        GPU: the ranks join one RCCL communicator made in C++, its id carried by torch.distributed); include/zygpu.h "Device groups"."""
         self.args, self.zyg_amd, self.torch, self.frame, self.device = args, zyg_amd, torch, frame, device
+        self.group_spec = group_spec
         self.scene, self.material, self.steps, self.warmup = scene, material, steps, warmup
         self.w, self.h = size or (args.width, args.height)
         self.ips = args.iters_per_step
         self.eng = zyg_amd.Engine()
         self.eng.log_to(sys.stderr)  # stdout carries the one JSON line and nothing else
         self.eng.set_device(device.index)
+        self.world = frame.world
+        if group_spec:
+            self.eng.set_devices(group_spec["devices"], 0 if "iterations" == frame.mode else 1, 1)  # (flag 1: RCCL also for a world of one)
+            if "world" in group_spec:
+                ident = [self.eng.unique_id() if 0 == group_spec["rank"] else None]
+                group_spec["dist"].broadcast_object_list(ident, src=0)
+                self.eng.set_world(ident[0], group_spec["rank"], group_spec["world"])
+            else:
+                self.world = len(group_spec["devices"])
         main = scene == args.scene  # the variants' knobs are the main scene's
-        build_scene(self.eng, scenes, scene, material, self.w, self.h, (frame.world if "iterations" == frame.mode else 1) * steps * self.ips,
+        build_scene(self.eng, scenes, scene, material, self.w, self.h, (self.world if "iterations" == frame.mode else 1) * steps * self.ips,
                     args.box_triangles if main else 12, args.extra_props if main else 0)
         self.eng.start_frame(0)
         if not args.pair_small:  # read when the scene is uploaded (the context exists from the first frame on): upload again
             self.eng.set_option("pair_small", 0)
             self.eng.start_frame(0)
         self.lib, self.ctx = self.eng.lib, self.eng.context()
+        self.group = self.eng.group()
+        assert (self.group is not None) == bool(group_spec)
         if args.batch_mpaths:
             self.eng.set_option("batch_mpaths", args.batch_mpaths)
         self.eng.set_option("fuse_trace_shade", args.fuse)
@@ -203,8 +225,26 @@ class Measurement:
             raise RuntimeError("zygpu_render: " + self.lib.zygpu_last_error().decode())
 
     def synchronize(self):
-        self.eng.synchronize()
+        self.eng.synchronize()  # (every device of a group)
         self.torch.cuda.synchronize(self.device)
+
+    def render_world(self, step):
+        """Step `step` of the whole job through the group: the world's iterations [step * W * ips, (step + 1) * W * ips) (or, sharded by
+        rows, the step's ips iterations of every row), of which every rank renders its share (zygpu_group_render)."""
+        shard = 0 if "iterations" == self.frame.mode else 1
+        count = self.world * self.ips if 0 == shard else self.ips
+        if 0 != self.lib.zygpu_group_render(self.group, 0, step * count, count, 0, self.h, shard):
+            raise RuntimeError("zygpu_group_render: " + self.lib.zygpu_last_error().decode())
+
+    def my_rows(self):
+        """rows [y0, y1) this rank's (first) context renders in a step"""
+        if self.group and "rows" == self.frame.mode:
+            first, length = ctypes.c_uint32(0), ctypes.c_uint32(0)
+            rank0 = self.group_spec.get("rank", 0)
+            assert 0 == self.lib.zygpu_group_share(self.h, self.world, rank0, ctypes.byref(first), ctypes.byref(length))
+            return first.value, first.value + length.value
+        _, _, y0, y1 = self.frame.step_range(0, self.ips, self.steps, self.h)
+        return y0, y1
 
     def run(self):
         lib, ctx, zyg_amd = self.lib, self.ctx, self.zyg_amd
@@ -247,13 +287,28 @@ class Measurement:
                 d["wf_shade"] = 0.0
 
         for i in range(self.warmup):
-            self.render(i * self.ips, self.ips, 0, self.h)
+            if self.group:
+                self.render_world(i)  # (every device allocates its pool and warms up)
+            else:
+                self.render(i * self.ips, self.ips, 0, self.h)
         self.synchronize()
+        if self.group:
+            assert 0 == lib.zygpu_group_clear_film(self.group, 0.0)  # every member's film (rank 0's is self.film)
+            self.synchronize()
         self.film.zero_()
         dtmp, ltmp = ctypes.c_double * len(KERNELS), ctypes.c_uint64 * len(KERNELS)
         lib.zygpu_kernel_time(ctx, dtmp(), ltmp(), 1)
 
         def body():
+            if self.group:
+                # the path's one exchange step behind the C ABI: ncclReduce of the ranks' films onto rank 0's, called from C++
+                # (csrc/hip/group.hip) in stream order behind each rank's kernels; the synchronize waits for it
+                for s in range(self.steps):
+                    self.render_world(s)
+                if 0 != lib.zygpu_group_reduce(self.group):
+                    raise RuntimeError("zygpu_group_reduce: " + lib.zygpu_last_error().decode())
+                self.eng.synchronize()
+                return
             for s in range(self.steps):
                 self.frame.render_step(self.render, s, self.ips, self.steps, self.h)
             self.eng.synchronize()
@@ -264,12 +319,12 @@ class Measurement:
             else:
                 self.frame.reduce(self.film)
 
-        elapsed = self.frame.timed(body, lambda: self.torch.cuda.synchronize(self.device))
+        elapsed = self.frame.timed(body, self.synchronize)
         ms, launches = dtmp(), ltmp()
         lib.zygpu_kernel_time(ctx, ms, launches, 0)
-        _, _, y0, y1 = self.frame.step_range(0, self.ips, self.steps, self.h)
+        y0, y1 = self.my_rows()
         samples_rank = float(self.w) * (y1 - y0) * self.ips * self.steps
-        samples_job = samples_rank * self.frame.world if "iterations" == self.frame.mode else float(self.w) * self.h * self.ips * self.steps
+        samples_job = samples_rank * self.world if "iterations" == self.frame.mode else float(self.w) * self.h * self.ips * self.steps
         times = {nm: ms[i] for i, nm in enumerate(KERNELS)}
         counts = {nm: int(launches[i]) for i, nm in enumerate(KERNELS)}
         # option mesh_kernels on a scene with a large mesh: the in-place stage is wf_scatter_h (+ its resume launches, timed as
@@ -523,12 +578,15 @@ def main():
         print(json.dumps(bench_config(args)))
         return
     n = args.gpus
-    if n > 1 and "WORLD_SIZE" not in os.environ:
+    launcher = "WORLD_SIZE" in os.environ
+    if n > 1 and not launcher and args.spawn:
         sys.exit(launch_ranks(args))
+    # without a launcher one process is the whole world: its ZygpuGroup holds the N devices
+    one_process = n > 1 and not launcher
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if n > 1 and world != n:
+    if n > 1 and launcher and world != n:
         raise SystemExit(f"--gpus {n} under a launcher needs WORLD_SIZE={n}, not {world}")
 
     # The library is built before any process group exists, under a file lock: whichever rank comes first builds it when it is
@@ -550,12 +608,26 @@ def main():
     # the process group first (device_id binds the RCCL communicator to this rank's GPU), then the device
     # ZYG_BENCH_GROUP=1: a process group also for one rank, so that the collectives (the film reduce on the device tensor, the
     # barrier, the max-over-ranks) run through RCCL on a box with a single GPU
-    grouped = n > 1 or bool(os.environ.get("ZYG_BENCH_GROUP"))
+    grouped = (n > 1 and not one_process) or bool(os.environ.get("ZYG_BENCH_GROUP"))
     dist = distributed.init_process_group(backend, rank, world, device) if grouped else None
     torch.cuda.set_device(device)
-    frame = distributed.ShardedFrame(rank, n, dist, args.shard, args.height)
+    frame = distributed.ShardedFrame(rank, 1 if one_process else n, dist, args.shard, args.height)
+    # The film reduce behind the C ABI (include/zygpu.h "Device groups"): this rank's device is one rank of an RCCL communicator that
+    # csrc/hip/group.hip makes and reduces over; torch.distributed only carries the communicator's id (and keeps the barrier and the
+    # max-over-ranks of the timing protocol).  --reduce torch (and the gloo test set-up, whose ranks share one GPU, which RCCL refuses)
+    # sums the films with torch.distributed instead.
+    group_spec = None
+    if one_process:
+        group_spec = {"devices": [0] * n if os.environ.get("ZYG_BENCH_ONE_DEVICE") else list(range(n))}
+    elif grouped and "group" == args.reduce and "nccl" == backend:
+        group_spec = {"devices": [device.index], "rank": rank, "world": world, "dist": dist}
+    collective = None if not (grouped or one_process) else (
+        ("ncclReduce from C++ (ZygpuGroup), " + ("one process, a host thread per device" if one_process else "one process per GPU")) if group_spec
+        else dist.get_backend() + " (torch.distributed.reduce)")
 
-    m = Measurement(args, zyg_amd, scenes, torch, frame, device, args.scene, args.material, args.steps, args.warmup)
+    m = Measurement(args, zyg_amd, scenes, torch, frame, device, args.scene, args.material, args.steps, args.warmup, group_spec=group_spec)
+    if group_spec and 1 != m.lib.zygpu_group_uses_rccl(m.group):
+        collective = "film_add kernel (ZygpuGroup whose members share a device: a test set-up)"
     r = m.run()
 
     if 0 == rank:
@@ -604,7 +676,7 @@ def main():
                        "arithmetic": "relaxed" if m.relaxed else "precise", "arithmetic_requested": "precise" if args.precise else "relaxed",
                        "parallelism": f"{args.shard} x{n}" + (f", {args.spp_total} spp in all (strong)" if args.spp_total else
                                                              ", the frame's rows split (strong)" if "rows" == args.shard else " (weak)"),
-                       "spp_per_rank": args.steps * args.iters_per_step, "collective": (dist.get_backend() if dist else None)},
+                       "spp_per_rank": args.steps * args.iters_per_step, "collective": collective},
             # What bounds the dominant kernel, most believable figure first:
             #   hbm:    the bytes that really cross HBM.  `state_frac`: the ray / hit / state records it must move (B_q, B_sq of
             #           SURVEY 8(d), no traversal data) over its duration and the peak; `traffic_frac`: the HBM-side bytes rocprofv3

@@ -83,6 +83,20 @@ int32_t su_ext_camera_set_parameters(const char* json);
 int32_t su_ext_sampler_kind(uint32_t kind);
 /* HIP device the engine renders on (default: env ZYG_DEVICE, else LOCAL_RANK, else 0). */
 int32_t su_ext_set_device(int32_t device_id);
+/* Several HIP devices behind the same su_* calls (before the first su_start_frame / su_render_frame): the engine renders with a
+ * ZygpuGroup (include/zygpu.h "Device groups": one context and one host thread per device, the scene replicated, the films summed
+ * onto the first device's with one ncclReduce over xGMI before a resolve).  Stands where the reference's Driver hands tiles to its
+ * worker threads (driver.zig:115-152, 293-348).  shard: how su_render_iterations splits a call: 0 = its iterations, 1 = the frame's
+ * rows, 2 = iterations when the call brings at least one per device, rows otherwise; su_render_frame always splits rows.
+ * flags: ZygpuGroupFlags.  A device may be listed twice (testing on one GPU).  su_ext_group: the group (NULL before the first
+ * frame, or without this call). */
+int32_t su_ext_set_devices(const int32_t* device_ids, uint32_t num_devices, uint32_t shard, uint32_t flags);
+/* The devices of su_ext_set_devices as ranks [first_rank, first_rank + num_devices) of a world of `world` ranks across processes (one
+ * process per GPU under a launcher): unique_id = the ZYGPU_UNIQUE_ID_BYTES that zygpu_group_unique_id produced in rank 0's process.
+ * su_render_iterations(n) then names the WORLD's iterations, of which this process renders its ranks' shares, and the resolve's
+ * reduce is collective: every process makes the same calls; rank 0's process holds the frame. */
+int32_t su_ext_set_world(const uint8_t* unique_id, int32_t first_rank, int32_t world);
+ZygpuGroup* su_ext_group(void);
 /* Scene.compile + camera.update only (driver.zig:154-180), no device work; fills the descriptors below. */
 int32_t su_ext_compile(uint32_t frame);
 const ZygpuSceneDesc* su_ext_scene_desc(void);

@@ -506,6 +506,12 @@ int zygpu_film_device_ptr(ZygpuContext* ctx, void** out_ptr, uint64_t* out_num_f
  * Call after zygpu_set_view. */
 int zygpu_set_external_film(ZygpuContext* ctx, void* device_rgbw);
 
+/* The alpha plane's device pointer (NULL and 0 floats for an opaque sensor), the context's HIP stream (a hipStream_t: what a caller's
+ * own collective on the film must be ordered behind) and its HIP device. */
+int zygpu_film_alpha_device_ptr(ZygpuContext* ctx, void** out_ptr, uint64_t* out_num_floats);
+int zygpu_stream(ZygpuContext* ctx, void** out_stream);
+int zygpu_device(ZygpuContext* ctx);
+
 /* Transparent sensor (ZygpuViewDesc.alpha_transparency): the second plane of buffer_transparent.zig:11-59, one float per
  * pixel = sum of weight * alpha (the film's float4 keeps {sum w r, sum w g, sum w b, sum w}).  download returns -1 for
  * an opaque sensor; an external plane (device pointer, W*H floats) follows the same rules as zygpu_set_external_film. */
@@ -616,6 +622,50 @@ int zygpu_resolve_aov(ZygpuContext* ctx, uint32_t aov_class, float* host_rgba, u
 int zygpu_download_aov(ZygpuContext* ctx, uint32_t aov_class, float* host_plane);
 
 const char* zygpu_last_error(void);
+
+/* ---- Device groups: the GPUs of a node behind this ABI (csrc/hip/group.hip) -----------------------------------
+ * Replaces, for N devices, what Driver.render / Driver.renderIterations do with the reference's worker threads (driver.zig:115-152,
+ * 293-348: threads.runParallel(self, renderTiles, 0)): one ZygpuContext and one host thread per device, the compiled scene
+ * replicated, a call's iterations (ZYGPU_SHARD_ITERATIONS) or rows (ZYGPU_SHARD_ROWS) split into one contiguous share per rank, each
+ * rank accumulating into its own film, and one exchange step, zygpu_group_reduce: ncclReduce(sum, float, 4 W H, root 0) of the films
+ * over xGMI (RCCL), in stream order behind each rank's kernels; rank 0's context then holds the frame (zygpu_resolve,
+ * zygpu_download_film on zygpu_group_context(g, 0)).  (pixel, iteration) samples are independent and the film is additive
+ * (buffer_opaque.zig:39-45), so nothing else is exchanged.  Rows: the film equals the single-device film bit for bit with the
+ * radius-0 sensor; iterations: up to the order of the float sums.
+ *
+ * zygpu_group_create: n contexts on the listed HIP devices = ranks [first_rank, first_rank + n) of a world of `world` ranks.
+ * unique_id NULL: this process is the whole world (first_rank and world are ignored, world = n).  Otherwise the 128 bytes that
+ * zygpu_group_unique_id produced in the process of rank 0 and the launcher carried to the others (one process per GPU under
+ * torch.distributed.run, an MPI-style host): the call returns when every rank of the world has joined.  A device may be listed
+ * twice (how a box with one GPU exercises the group): such members are driven one after the other and their films are added by a
+ * kernel instead of RCCL.  flags: ZYGPU_GROUP_ALWAYS_RCCL builds the communicator for a world of one as well.
+ * Every process of a world calls zygpu_group_reduce the same number of times.  Failures: -1, text in zygpu_last_error(). */
+typedef struct ZygpuGroup ZygpuGroup;
+#define ZYGPU_UNIQUE_ID_BYTES 128
+enum ZygpuShard { ZYGPU_SHARD_ITERATIONS = 0, ZYGPU_SHARD_ROWS = 1 };
+enum ZygpuGroupFlags { ZYGPU_GROUP_ALWAYS_RCCL = 1 };
+int zygpu_group_unique_id(uint8_t* out128);
+int zygpu_group_create(const int* device_ids, int n, const uint8_t* unique_id, int first_rank, int world, uint32_t flags, ZygpuGroup** out_group);
+int zygpu_group_destroy(ZygpuGroup* group);
+int zygpu_group_size(const ZygpuGroup* group);       /* members in this process */
+int zygpu_group_world(const ZygpuGroup* group);      /* ranks in the world */
+int zygpu_group_first_rank(const ZygpuGroup* group);
+int zygpu_group_uses_rccl(const ZygpuGroup* group);  /* 1: the reduce is ncclReduce; 0: a world of one, or members sharing a device */
+ZygpuContext* zygpu_group_context(ZygpuGroup* group, int member); /* options, statistics, and (rank 0) the film */
+int zygpu_group_upload_scene(ZygpuGroup* group, const ZygpuSceneDesc* scene);
+int zygpu_group_set_view(ZygpuGroup* group, const ZygpuViewDesc* view); /* AOVs are refused when world > 1: their planes are not reduced */
+int zygpu_group_set_option(ZygpuGroup* group, const char* name, int value);
+int zygpu_group_clear_film(ZygpuGroup* group, float weight);
+/* zygpu_render / zygpu_render_frame for the world: [iteration, iteration + num_iterations) and [y_begin, y_end) name the whole job,
+ * each rank renders its share.  One-shot rendering always splits rows (a pixel's PCG stream runs on across its samples). */
+int zygpu_group_render(ZygpuGroup* group, uint32_t frame, uint32_t iteration, uint32_t num_iterations, int32_t y_begin, int32_t y_end, uint32_t shard);
+int zygpu_group_render_frame(ZygpuGroup* group, uint32_t frame, uint32_t iteration, uint32_t num_samples, int32_t y_begin, int32_t y_end);
+int zygpu_group_reduce(ZygpuGroup* group);      /* asynchronous with RCCL: zygpu_group_synchronize waits */
+/* The split itself (a pure function: needs no device): rank `rank` of `world` takes [first, first + length) of `count` iterations or
+ * rows, contiguous shares in rank order, the first count % world of them one longer. */
+int zygpu_group_share(uint32_t count, int world, int rank, uint32_t* out_first, uint32_t* out_length);
+int zygpu_group_dirty(const ZygpuGroup* group); /* 1: something was rendered since the last reduce (world > 1) */
+int zygpu_group_synchronize(ZygpuGroup* group);
 
 #ifdef __cplusplus
 }

@@ -164,16 +164,33 @@ def test_bench_py_two_ranks_end_to_end():
     ways: the way the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1) and plainly
     (`python bench.py --gpus 2`: it starts its own ranks as fresh child processes before touching the GPU); the same line but
     for the measured times."""
-    outs = {launcher: _bench_two_ranks(launcher) for launcher in ("torchrun", "self")}
+    outs = {"torchrun": _bench_two_ranks("torchrun"), "self": _bench_two_ranks("self", ("--spawn", "1"))}
     for out in outs.values():
         assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-        assert out["config"]["parallelism"] == "iterations x2 (weak)" and out["config"]["collective"] == "gloo"
+        assert out["config"]["parallelism"] == "iterations x2 (weak)" and out["config"]["collective"] == "gloo (torch.distributed.reduce)"
         # two ranks x 2 steps x 4 iterations, summed into rank 0's film
         assert out["film_weight_min_max"] == [16.0, 16.0]
         assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     a, b = outs["torchrun"], outs["self"]
     assert a.keys() == b.keys() and a["config"] == b["config"] and a["rays_per_sample"] == b["rays_per_sample"]
     assert a["roofline"]["kernel_bytes"] == b["roofline"]["kernel_bytes"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["iterations", "rows"])
+def test_bench_py_one_process_drives_a_group(shard):
+    """`python bench.py --gpus 2` without a launcher: ONE process, the devices behind a ZygpuGroup (su_ext_set_devices: a context and a
+    host thread per device, the films summed from C++).  On this box both members sit on device 0 (ZYG_BENCH_ONE_DEVICE), which RCCL
+    refuses inside one communicator, so the sum is the group's film_add kernel; with two GPUs the same line says ncclReduce."""
+    out = _bench_two_ranks("self", ("--shard", shard))
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["collective"].startswith("film_add kernel (ZygpuGroup")
+    if "iterations" == shard:
+        assert out["scaling"] == "weak" and out["film_weight_min_max"] == [16.0, 16.0]  # 2 devices x 2 steps x 4 iterations
+        samples = 320 * 180 * 16
+    else:
+        assert out["scaling"] == "strong" and out["film_weight_min_max"] == [8.0, 8.0]  # every row rendered once, by its device
+        samples = 320 * 180 * 8
+    assert abs(out["value"] * 1e6 * out["ms_per_step"] * 1e-3 * out["steps"] / samples - 1.0) < 0.02
 
 
 @pytest.mark.gpu
@@ -255,15 +272,19 @@ def test_rccl_world_of_one_reduces_the_external_film(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_py_runs_its_collectives_over_rccl_on_one_gpu():
-    """bench.py itself with a process group of one rank over RCCL (ZYG_BENCH_GROUP=1): process group before the device is set,
-    the film reduce on the device tensor, barrier and max-over-ranks in the timed protocol."""
+@pytest.mark.parametrize("reduce", ["group", "torch"])
+def test_bench_py_runs_its_collectives_over_rccl_on_one_gpu(reduce):
+    """bench.py itself as one rank of a launcher's world (ZYG_BENCH_GROUP=1: the N > 1 protocol with WORLD_SIZE 1, what one GPU allows):
+    the process group before the device is set, barrier and max-over-ranks in the timed protocol, and the film reduce either as
+    ncclReduce from C++ over a communicator whose id rank 0 made and torch.distributed carried (--reduce group, the default:
+    zygpu_group_unique_id -> su_ext_set_world -> zygpu_group_reduce), or as torch.distributed.reduce on the film tensor."""
     import json
     import subprocess
     env = dict(os.environ, ZYG_BENCH_GROUP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180",
-           "--iters-per-step", "4", "--no-cpu-baseline", "--no-extra"]
+           "--iters-per-step", "4", "--no-cpu-baseline", "--no-extra", "--reduce", reduce]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][0])
-    assert out["config"]["collective"] == "nccl" and out["film_weight_min_max"] == [8.0, 8.0] and out["value"] > 0
+    want = "ncclReduce from C++ (ZygpuGroup), one process per GPU" if "group" == reduce else "nccl (torch.distributed.reduce)"
+    assert out["config"]["collective"] == want and out["film_weight_min_max"] == [8.0, 8.0] and out["value"] > 0

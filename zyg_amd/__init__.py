@@ -216,6 +216,24 @@ def load_library(path=None):
     lib.zygpu_upload_scene.argtypes = [ctypes.c_void_p, ctypes.POINTER(SceneDesc)]
     lib.zygpu_set_view.argtypes = [ctypes.c_void_p, ctypes.POINTER(ViewDesc)]
     lib.zygpu_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    # device groups (include/zygpu.h)
+    lib.su_ext_group.restype = ctypes.c_void_p
+    lib.su_ext_set_devices.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.zygpu_group_context.restype = ctypes.c_void_p
+    lib.zygpu_group_context.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.zygpu_group_unique_id.argtypes = [ctypes.c_void_p]
+    lib.zygpu_group_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                       ctypes.POINTER(ctypes.c_void_p)]
+    for name in ("zygpu_group_destroy", "zygpu_group_size", "zygpu_group_world", "zygpu_group_first_rank", "zygpu_group_uses_rccl", "zygpu_group_reduce",
+                 "zygpu_group_dirty", "zygpu_group_synchronize"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.zygpu_group_share.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    lib.zygpu_group_upload_scene.argtypes = [ctypes.c_void_p, ctypes.POINTER(SceneDesc)]
+    lib.zygpu_group_set_view.argtypes = [ctypes.c_void_p, ctypes.POINTER(ViewDesc)]
+    lib.zygpu_group_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    lib.zygpu_group_clear_film.argtypes = [ctypes.c_void_p, ctypes.c_float]
+    lib.zygpu_group_render.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32]
+    lib.zygpu_group_render_frame.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32]
     if path is None:
         _lib = lib
     return lib
@@ -308,7 +326,8 @@ class Engine:
 
     def set_option(self, name, value):
         """zygpu_set_option on the engine's context (after start_frame): e.g. "precise", "nee_in_place"."""
-        if self.lib.zygpu_set_option(self.context(), name.encode(), int(value)) != 0:
+        g = self.group()
+        if (self.lib.zygpu_group_set_option(g, name.encode(), int(value)) if g else self.lib.zygpu_set_option(self.context(), name.encode(), int(value))) != 0:
             raise RuntimeError("zygpu_set_option failed: " + (self.lib.zygpu_last_error() or b"").decode())
 
     def log_to(self, stream):
@@ -448,6 +467,28 @@ class Engine:
     def set_device(self, device_id):
         self.lib.su_ext_set_device(device_id)
 
+    def set_devices(self, device_ids, shard=2, flags=0):
+        """Several devices behind the same calls (su_ext_set_devices: a ZygpuGroup; shard 0 iterations, 1 rows, 2 the library's choice)."""
+        ids = (ctypes.c_int32 * len(device_ids))(*device_ids)
+        if self.lib.su_ext_set_devices(ids, len(device_ids), shard, flags) != 0:
+            raise RuntimeError("su_ext_set_devices failed (after the first frame?)")
+
+    def set_world(self, unique_id, first_rank, world):
+        """The devices of set_devices as ranks of a world across processes (su_ext_set_world; unique_id: bytes of unique_id())."""
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        if self.lib.su_ext_set_world(buf, first_rank, world) != 0:
+            raise RuntimeError("su_ext_set_world failed")
+
+    def unique_id(self):
+        buf = (ctypes.c_uint8 * 128)()
+        if self.lib.zygpu_group_unique_id(buf) != 0:
+            raise RuntimeError("zygpu_group_unique_id failed: " + (self.lib.zygpu_last_error() or b"").decode())
+        return bytes(buf)
+
+    def group(self):
+        g = self.lib.su_ext_group()
+        return ctypes.c_void_p(g) if g else None
+
     def start_frame(self, frame=0):
         if self.lib.su_start_frame(frame) != 0:
             raise RuntimeError("su_start_frame failed: " + (self.lib.zygpu_last_error() or b"").decode())
@@ -469,7 +510,8 @@ class Engine:
 
     def synchronize(self):
         """Waits for the device and raises on a device error flag (e.g. more crossed unoccluding emitters than slots)."""
-        rc = self.lib.zygpu_synchronize(self.context())
+        g = self.group()
+        rc = self.lib.zygpu_group_synchronize(g) if g else self.lib.zygpu_synchronize(self.context())
         if rc != 0:
             raise RuntimeError(f"zygpu_synchronize failed ({rc}): " + (self.lib.zygpu_last_error() or b"").decode())
 
@@ -482,6 +524,9 @@ class Engine:
 
     def download_film(self, width, height):
         out = np.zeros((height, width, 4), dtype=np.float32)
+        g = self.group()
+        if g and 1 == self.lib.zygpu_group_dirty(g) and 0 != self.lib.zygpu_group_reduce(g):  # the devices' films summed onto the first one's
+            raise RuntimeError("zygpu_group_reduce failed: " + (self.lib.zygpu_last_error() or b"").decode())
         if self.lib.zygpu_download_film(self.context(), out.ctypes.data) != 0:
             raise RuntimeError("zygpu_download_film failed")
         return out

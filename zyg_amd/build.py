@@ -28,7 +28,7 @@ HIP = os.path.join(HERE, "csrc", "hip")
 HOST = os.path.join(HERE, "csrc", "host")
 NUM_UNITS = 8  # kernel_table.hpp ZYG_NUM_UNITS
 
-SOURCES = [os.path.join(HIP, "zygpu.hip"), os.path.join(HIP, "kernels.hip"), os.path.join(HOST, "engine.cpp"),
+SOURCES = [os.path.join(HIP, "zygpu.hip"), os.path.join(HIP, "kernels.hip"), os.path.join(HIP, "group.hip"), os.path.join(HOST, "engine.cpp"),
            os.path.join(HOST, "capi.cpp")]
 
 # -disable-promote-alloca-to-vector: the per-lane traversal stacks stay in (sparsely touched) scratch instead of
@@ -105,7 +105,7 @@ def _read(path):
 
 def _objects(mode):
     """(object path, source, flags) of every translation unit"""
-    objs = [("zygpu.o", os.path.join(HIP, "zygpu.hip"), PRECISE), ("engine.o", os.path.join(HOST, "engine.cpp"), PRECISE),
+    objs = [("zygpu.o", os.path.join(HIP, "zygpu.hip"), PRECISE), ("group.o", os.path.join(HIP, "group.hip"), PRECISE), ("engine.o", os.path.join(HOST, "engine.cpp"), PRECISE),
             ("capi.o", os.path.join(HOST, "capi.cpp"), PRECISE)]
     for u in range(NUM_UNITS):
         if mode in ("both", "precise"):
@@ -159,7 +159,7 @@ def build_variant(name, units, extra, mode="both", verbose=True):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(_compile, todo))
     out = os.path.join(ROOT, "variants", f"lib_{name}.so")
-    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", out], check=True)
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-lrccl", "-o", out], check=True)
     return out
 
 
@@ -188,7 +188,7 @@ def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
         os.remove(OUT + ".tag")
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(_compile, todo))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", OUT]  # libz: the PNG reader (host/image_readers.hpp)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-lrccl", "-o", OUT]  # libz: the PNG reader (host/image_readers.hpp)
     if verbose:
         print(f"compiled {len(todo)} of {len(objs)} translation units in {time.time() - t0:.0f} s; linking", flush=True)
     subprocess.run(cmd, check=True)

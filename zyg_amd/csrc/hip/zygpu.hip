@@ -5,6 +5,7 @@
 // deterministic and, for the radius-0 sensor, bit-identical to sequential accumulation.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -798,8 +799,12 @@ std::pair<hipEvent_t, hipEvent_t>* nextEvents(ZygpuContext* c, int k) {
     return &ev[c->events_used[k]++];
 }
 
-// the __constant__ blocks are per process (one engine at a time, like the reference's global engine, capi.zig:55)
-uint64_t g_view_epoch = 0, g_unit_view_epoch[2][ZYG_NUM_UNITS] = {};
+// the __constant__ blocks are per process and device (one engine at a time, like the reference's global engine, capi.zig:55; a
+// ZygpuGroup, group.hip, has one context per device and one host thread per context: the table below is per device, so the
+// threads do not share an entry; contexts that share a device are driven one after the other)
+constexpr int         kMaxDevices = 64;
+std::atomic<uint64_t> g_view_epoch{0};
+uint64_t              g_unit_view_epoch[kMaxDevices][2][ZYG_NUM_UNITS] = {};
 
 // A unit's copy of the view block is brought up to date (in stream order) before the first launch that needs it
 // The device error flags (Control::error), read after the stream has drained.  Set by the kernels when a result would be
@@ -830,9 +835,10 @@ bool relaxedUnits(const ZygpuContext* c) { return c->relaxed && (!c->pool_mode |
 
 void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params& P, uint32_t arg) {
     const int mode = relaxedUnits(c) ? 1 : 0, unit = kUnitOf[id];
-    if (g_unit_view_epoch[mode][unit] != c->view_epoch) {
+    uint64_t& held = g_unit_view_epoch[c->device % kMaxDevices][mode][unit];
+    if (held != c->view_epoch) {
         if (0 != kUnitSet[mode][unit](ZYG_CONST_VIEW, &c->batch_view, sizeof(View), c->stream)) c->launch_failed = true;
-        g_unit_view_epoch[mode][unit] = c->view_epoch;
+        held = c->view_epoch;
     }
     if (0 != kUnitLaunch[mode][unit](id, blocks, c->stream, &P, arg)) c->launch_failed = true;
 }
@@ -858,6 +864,7 @@ void timedLaunch(ZygpuContext* c, int k, Launch&& launch) {
 extern "C" {
 
 const char* zygpu_last_error(void) { return g_error.c_str(); }
+void        zygpu_internal_set_error(const char* text) { g_error = text ? text : ""; }  // group.hip: a member thread's failure
 
 int zygpu_create(int device_id, ZygpuContext** out_ctx) {
     if (!out_ctx) return -1;
@@ -2036,6 +2043,21 @@ int zygpu_film_device_ptr(ZygpuContext* c, void** out_ptr, uint64_t* out_num_flo
     if (out_num_floats) *out_num_floats = uint64_t(c->film_pixels) * 4;
     return 0;
 }
+
+int zygpu_film_alpha_device_ptr(ZygpuContext* c, void** out_ptr, uint64_t* out_num_floats) {
+    if (!c || !c->has_view || !out_ptr) return -1;
+    *out_ptr = c->film_alpha_active;
+    if (out_num_floats) *out_num_floats = c->film_alpha_active ? uint64_t(c->film_pixels) : 0;
+    return 0;
+}
+
+int zygpu_stream(ZygpuContext* c, void** out_stream) {
+    if (!c || !out_stream) return -1;
+    *out_stream = c->stream;
+    return 0;
+}
+
+int zygpu_device(ZygpuContext* c) { return c ? c->device : -1; }
 
 int zygpu_download_film_alpha(ZygpuContext* c, float* host_alpha) {
     if (!c || !c->has_view || !host_alpha) return -1;

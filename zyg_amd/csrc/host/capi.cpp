@@ -16,7 +16,12 @@ namespace {
 
 struct Capi {
     zyg::Engine        engine;
-    ZygpuContext*      ctx = nullptr;
+    ZygpuContext*      ctx = nullptr;    // the device context; with a group: its rank 0's
+    ZygpuGroup*        group = nullptr;  // su_ext_set_devices: one context per device (include/zygpu.h "Device groups")
+    std::vector<int>   devices;
+    std::vector<uint8_t> world_id;       // su_ext_set_world: the communicator id of a world across processes
+    int                first_rank = 0, world = 0;
+    uint32_t           shard = 2, group_flags = 0;  // 0 iterations, 1 rows, 2: iterations when a call brings at least one per device
     int                device_id = -1;
     uint32_t           frame = 0;
     uint32_t           iteration = 0;
@@ -69,6 +74,15 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
         return -1;
     }
     for (const std::string& w : c.engine.warnings()) logf(1, "%s", w.c_str());
+    if (!c.ctx && !c.devices.empty()) {
+        if (0 != zygpu_group_create(c.devices.data(), int(c.devices.size()), c.world_id.empty() ? nullptr : c.world_id.data(), c.first_rank, c.world,
+                                    c.group_flags, &c.group)) {
+            logf(2, "zygpu_group_create failed: %s", zygpu_last_error());
+            c.group = nullptr;
+            return -1;
+        }
+        c.ctx = zygpu_group_context(c.group, 0);
+    }
     if (!c.ctx) {
         const int dev = c.device_id >= 0 ? c.device_id : defaultDevice();
         if (0 != zygpu_create(dev, &c.ctx)) {
@@ -77,7 +91,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
             return -1;
         }
     }
-    if (0 != zygpu_upload_scene(c.ctx, &c.engine.sceneDesc())) {
+    if (0 != (c.group ? zygpu_group_upload_scene(c.group, &c.engine.sceneDesc()) : zygpu_upload_scene(c.ctx, &c.engine.sceneDesc()))) {
         logf(2, "zygpu_upload_scene failed: %s", zygpu_last_error());
         return -1;
     }
@@ -93,7 +107,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
         }
         c.engine.applyFocusProbe(1 == hit, t);
     }
-    if (0 != zygpu_set_view(c.ctx, &c.engine.viewDesc())) {
+    if (0 != (c.group ? zygpu_group_set_view(c.group, &c.engine.viewDesc()) : zygpu_set_view(c.ctx, &c.engine.viewDesc()))) {
         logf(2, "zygpu_set_view failed: %s", zygpu_last_error());
         return -1;
     }
@@ -101,7 +115,7 @@ int32_t prepareFrame(uint32_t frame, bool clear) {
     c.frame = frame;
     if (clear) {
         c.iteration = 0;
-        if (0 != zygpu_clear_film(c.ctx, 0.f)) return -1;
+        if (0 != (c.group ? zygpu_group_clear_film(c.group, 0.f) : zygpu_clear_film(c.ctx, 0.f))) return -1;
     }
     c.uploaded = true;
     return 0;
@@ -121,7 +135,8 @@ int32_t su_init(void) {
 
 int32_t su_release(void) {
     if (!g) return -1;
-    if (g->ctx) zygpu_destroy(g->ctx);
+    if (g->group) zygpu_group_destroy(g->group);  // (its contexts with it)
+    else if (g->ctx) zygpu_destroy(g->ctx);
     g.reset();
     return 0;
 }
@@ -285,7 +300,11 @@ int32_t su_start_frame(uint32_t frame) {
 int32_t su_ext_render_rows(uint32_t num_steps, int32_t y_begin, int32_t y_end) {
     if (!g || !g->uploaded) return -1;
     if (g_progress_start) g_progress_start(num_steps);
-    if (0 != zygpu_render(g->ctx, g->frame, g->iteration, num_steps, y_begin, y_end)) {
+    // a group's devices share the call's iterations, or its rows when there are fewer iterations than devices (a client that asks for
+    // one iteration at a time, like the reference's Blender add-on, still uses every device)
+    const uint32_t shard = g->group ? (2 == g->shard ? (num_steps >= uint32_t(zygpu_group_world(g->group)) ? 0u : 1u) : g->shard) : 0u;
+    if (0 != (g->group ? zygpu_group_render(g->group, g->frame, g->iteration, num_steps, y_begin, y_end, shard)
+                       : zygpu_render(g->ctx, g->frame, g->iteration, num_steps, y_begin, y_end))) {
         logf(2, "zygpu_render failed: %s", zygpu_last_error());
         return -1;
     }
@@ -306,14 +325,15 @@ int32_t su_render_frame(uint32_t frame) {
     // Driver.render (driver.zig:115-152): one Worker.render call per tile with num_samples = the view's samples per pixel
     const uint32_t spp = g->engine.num_samples_per_pixel;
     if (g_progress_start) g_progress_start(spp);
-    if (0 != zygpu_render_frame(g->ctx, g->frame, 0, spp, 0, g->engine.resolution[1])) {
+    if (0 != (g->group ? zygpu_group_render_frame(g->group, g->frame, 0, spp, 0, g->engine.resolution[1])
+                       : zygpu_render_frame(g->ctx, g->frame, 0, spp, 0, g->engine.resolution[1]))) {
         logf(2, "zygpu_render_frame failed: %s", zygpu_last_error());
         return -1;
     }
     if (g_progress_tick)
         for (uint32_t i = 0; i < spp; ++i) g_progress_tick();
     g->iteration = spp;
-    if (0 != zygpu_synchronize(g->ctx)) {
+    if (0 != (g->group ? zygpu_group_synchronize(g->group) : zygpu_synchronize(g->ctx))) {
         logf(2, "su_render_frame: %s", zygpu_last_error());
         return -1;
     }
@@ -349,6 +369,11 @@ int32_t su_resolve_frame_to_buffer(uint32_t aov, uint32_t width, uint32_t height
     if (!g || !g->uploaded) return -1;
     const uint32_t film_pixels = uint32_t(g->engine.resolution[0]) * uint32_t(g->engine.resolution[1]);
     const uint32_t num_pixels = std::min(width * height, film_pixels);
+    // the group's one exchange step: the devices' films summed onto the first one's (RCCL), which is then resolved like any film
+    if (g->group && 1 == zygpu_group_dirty(g->group) && 0 != zygpu_group_reduce(g->group)) {
+        logf(2, "su_resolve_frame: %s", zygpu_last_error());
+        return -1;
+    }
     if (aov < ZYGPU_AOV_NUM_CLASSES) {  // capi.zig:637: -2 for a class the take does not record
         const int r = zygpu_resolve_aov(g->ctx, aov, buffer, num_pixels);
         if (0 != r && -2 != r) logf(2, "su_resolve_frame: %s", zygpu_last_error());
@@ -425,6 +450,24 @@ int32_t su_ext_sampler_kind(uint32_t kind) {
     g->engine.sampler_kind = kind;
     return 0;
 }
+
+int32_t su_ext_set_devices(const int32_t* device_ids, uint32_t num_devices, uint32_t shard, uint32_t flags) {
+    if (!g || g->ctx || !device_ids || 0 == num_devices || shard > 2u) return -1;
+    g->devices.assign(device_ids, device_ids + num_devices);
+    g->shard = shard;
+    g->group_flags = flags;
+    return 0;
+}
+
+int32_t su_ext_set_world(const uint8_t* unique_id, int32_t first_rank, int32_t world) {
+    if (!g || g->ctx || !unique_id || first_rank < 0 || world < 1) return -1;
+    g->world_id.assign(unique_id, unique_id + ZYGPU_UNIQUE_ID_BYTES);
+    g->first_rank = first_rank;
+    g->world = world;
+    return 0;
+}
+
+ZygpuGroup* su_ext_group(void) { return g ? g->group : nullptr; }
 
 int32_t su_ext_set_device(int32_t device_id) {
     if (!g || g->ctx) return -1;
