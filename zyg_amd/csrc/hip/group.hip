@@ -142,8 +142,12 @@ struct ZygpuGroup {
     int each(const std::function<int(Member&)>& fn) {
         int rc = 0;
         if (shared_device) {
+            // one after the other, each to the end of its device work: the next member's launches rewrite the device's __constant__ blocks
             for (Member& m : members) {
-                m.worker->start([&fn, &m] { return fn(m); });
+                m.worker->start([&fn, &m] {
+                    const int r = fn(m);
+                    return (0 == r && m.ctx) ? zygpu_synchronize(m.ctx) : r;
+                });
                 std::string e;
                 const int   r = m.worker->wait(e);
                 if (0 != r && 0 == rc) rc = r, error = e;
@@ -217,7 +221,7 @@ int zygpu_group_create(const int* device_ids, int n, const uint8_t* unique_id, i
     }
     // the communicator: one RCCL rank per member.  A world of one needs none (ZYGPU_GROUP_ALWAYS_RCCL asks for it all the same: the
     // path a box with one GPU can exercise); members that share a device cannot be RCCL ranks of one communicator.
-    const bool want = (world > 1 || 0 != (flags & ZYGPU_GROUP_ALWAYS_RCCL));
+    const bool want = (world > 1 || nullptr != unique_id || 0 != (flags & ZYGPU_GROUP_ALWAYS_RCCL));
     if (want && g->shared_device && unique_id) {
         zygpu_group_destroy(g);
         g_group_error = "zygpu_group_create: a world across processes cannot list a device twice";
