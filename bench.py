@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--mesh-kernels", type=int, default=1, choices=[0, 1],
                     help="zygpu option mesh_kernels: the large meshes' walks in persistent kernels whose lanes fetch their own rays")
     ap.add_argument("--mesh-closest", type=int, default=0, choices=[0, 1], help="zygpu option mesh_closest (wf_mesh_closest)")
+    ap.add_argument("--bvh8", type=int, default=1, choices=[0, 1], help="zygpu option bvh8: the persistent mesh walkers read the eight-wide compressed trees (wf_shadow_u8, wf_mesh_closest8)")
+    ap.add_argument("--mesh-closest8", type=int, default=1, choices=[0, 1], help="zygpu option mesh_closest8: with bvh8, the closest hits of the rays that enter a large mesh in the persistent walker too")
     ap.add_argument("--sort-alive", type=int, default=-1, choices=[-1, 0, 1],
                     help="zygpu option sort_alive: the surviving paths in one sub-queue per hit prop, so that the consumer's waves stand on one "
                          "surface (-1: the library's choice, on in the scenes of the mesh kernels)")
@@ -206,6 +208,8 @@ class Measurement:
         self.eng.set_option("fuse_tick", args.fuse_tick)
         self.eng.set_option("mesh_kernels", args.mesh_kernels)
         self.eng.set_option("mesh_closest", args.mesh_closest)
+        self.eng.set_option("bvh8", args.bvh8)
+        self.eng.set_option("mesh_closest8", args.mesh_closest8)
         self.eng.set_option("sort_alive", args.sort_alive)
         self.eng.set_option("regenerate", args.regenerate)
         self.eng.set_option("pack_prev", args.pack_prev)
@@ -376,7 +380,7 @@ def bench_config(args):
     # default, so that a profile of the default configuration keeps its key and any other run is refused by it
     defaults = parse_defaults()
     for key in ("regenerate", "regen_kslots", "sort_alive", "pack_prev", "compact_blocks", "hit_by_queue", "mesh_kernels", "mesh_closest",
-                "pair_small", "box_triangles", "extra_props", "fuse_tick", "persistent", "shard", "spp_total", "pool_relaxed", "split_nee", "fuse_pool", "shadow_u_blocks", "lazy_head", "split_materials"):
+                "bvh8", "mesh_closest8", "pair_small", "box_triangles", "extra_props", "fuse_tick", "persistent", "shard", "spp_total", "pool_relaxed", "split_nee", "fuse_pool", "shadow_u_blocks", "lazy_head", "split_materials"):
         if getattr(args, key) != defaults[key]:
             cfg[key] = getattr(args, key)
     return cfg

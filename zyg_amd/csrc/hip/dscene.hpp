@@ -40,6 +40,10 @@ struct DMesh {
     // (uv a, uv b), (uv c, -, -); the corners' positions are tri_verts.  Through `triangles` into positions / normals / uvs a
     // fragment was a fourth level of dependent loads and ten cache lines of a large mesh.
     const uint4*    shade;
+    // the eight-wide compressed tree of the persistent mesh walkers (bvh8.hpp; relaxed units, meshes of the mesh kernels): five uint4
+    // per node; its triangles in its own order, 3 float4 each, the first corner's w = the triangle's index in the reference's order
+    const uint4*    nodes8;
+    const float4*   tris8;
 };
 
 // what a light-tree walk reads: the scene's tree over lights, or the primitive tree of one emissive mesh part
@@ -1033,6 +1037,136 @@ struct ClosestWalk4q {  // = bvh4qWalk + meshIntersect's leaf; the hit shrinks r
             }
         }
         return pop(ray) ? kWalkRunning : kWalkDone;
+    }
+};
+
+// ---- The eight-wide compressed tree (bvh8.hpp) one step at a time: the persistent mesh walkers' form (wavefront.hpp wf_shadow_u8,
+// wf_mesh_closest8).  A lane's walk state is two *groups*, each a base index and hit bits: `ng` = the hit inner children of the node it
+// came through (bits 24-31, already in this ray's front-to-back order; the low byte keeps the node's inner-child mask, which turns a
+// slot into the child's index) and `tg` = the hit triangles among that node's leaves (bits 0-23).  What it cannot look at now goes
+// to the stack as a group: one entry per visited node, not one per parked child.  Node steps and triangle steps are separate calls
+// so that the kernel can let a wave's lanes do the one or the other together (leaves wait until enough lanes have one).
+#ifndef ZYG_NODE8_STRIDE
+#define ZYG_NODE8_STRIDE 20  // bvh8.hpp
+#endif
+#ifndef ZYG_STACK8_LDS
+#define ZYG_STACK8_LDS 16  // entries (of two words) per lane in LDS: 32 KB per 256-thread block; deeper ones in scratch
+#endif
+constexpr int kStack8Lds = ZYG_STACK8_LDS, kStack8 = 40;  // zygpu_upload_scene: 2 entries per level of the tree at most
+
+// the lanes' columns of the four-wide closest-hit walk's array: a lane runs one walk at a time (wf_mesh_closest8 tests the smaller
+// meshes four-wide when it fetches a ray, before its eight-wide walk starts)
+static_assert(!ZYG_LDS_STACK || kStack8Lds <= kLdsStack, "the group stack shares the wide stack's LDS");
+ZD uint2* groupStackLds() {
+#if ZYG_LDS_STACK
+    return wideStackLds();
+#else
+    __shared__ uint2 entries[kStack8Lds * kLdsStackThreads];
+    return entries;
+#endif
+}
+struct GroupSpill {
+    uint32_t x[kStack8 - kStack8Lds], y[kStack8 - kStack8Lds];
+};
+struct GroupStack {
+    LdsUint2* lds;
+    uint32_t *spill_x, *spill_y;
+    int       sp = 0;
+    ZD explicit GroupStack(GroupSpill& spill) : lds((LdsUint2*)(groupStackLds() + threadIdx.x)), spill_x(spill.x), spill_y(spill.y) {}
+    ZD void push(uint2 g) {
+        if (sp >= kStack8) return;
+        if (sp < kStack8Lds) lds[sp * kLdsStackThreads] = WordPair{g.x, g.y};
+        else spill_x[sp - kStack8Lds] = g.x, spill_y[sp - kStack8Lds] = g.y;
+        ++sp;
+    }
+    ZD uint2 pop() {  // sp > 0
+        --sp;
+        if (sp < kStack8Lds) {
+            const WordPair e = lds[sp * kLdsStackThreads];
+            return make_uint2(e.x, e.y);
+        }
+        return make_uint2(spill_x[sp - kStack8Lds], spill_y[sp - kStack8Lds]);
+    }
+};
+
+struct Walk8 {
+    GroupStack    stack;
+    uint2         ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    const uint4*  nodes = nullptr;
+    const float4* tris = nullptr;
+    // the ray in the walk's terms: origin, reciprocal direction (finite: a zero component counts as 1e-30), 7 - its octant in every
+    // byte of a word
+    f3            o, idir;
+    uint32_t      oct_inv4 = 0;
+    ZD explicit Walk8(GroupSpill& spill) : stack(spill) {}
+    ZD void start(const DMesh& mesh, const Ray& ray) {
+        nodes = mesh.nodes8;
+        tris = mesh.tris8;
+        o = ray.origin;
+        const f3 d = ray.direction;
+        auto     safe = [](float x) { return fabsf(x) > 1e-30f ? x : copysignf(1e-30f, x); };
+        idir = mk3(1.f / safe(d.x), 1.f / safe(d.y), 1.f / safe(d.z));
+        const uint32_t oct_inv = 7u ^ ((d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u));
+        oct_inv4 = oct_inv * 0x01010101u;
+        stack.sp = 0;
+        ng = make_uint2(0u, (1u << (24u + oct_inv)) | 1u);  // the root: the one inner child, in slot 0, of a group whose first child is node 0
+        tg = make_uint2(0u, 0u);
+    }
+    ZD bool nodePending() const { return 0u != (ng.y & 0xFF000000u); }
+    ZD bool trianglesPending() const { return 0u != tg.y; }
+    // the nearest hit child of `ng` becomes the node: its children against the ray over [min_t, max_t] -> new ng, tg (nodePending())
+    ZD void nodeStep(float min_t, float max_t) {
+        const uint32_t bit = 31u - uint32_t(__clz(int(ng.y)));
+        ng.y &= ~(1u << bit);
+        const uint32_t slot = (bit - 24u) ^ (oct_inv4 & 7u);
+        const uint32_t node = ng.x + uint32_t(__popc(ng.y & 0xFFu & ((1u << slot) - 1u)));
+        if (ng.y & 0xFF000000u) stack.push(ng);
+        typedef uint32_t                                   Words __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(1))) Words* n = (const __attribute__((address_space(1))) Words*)(nodes + size_t(node) * (ZYG_NODE8_STRIDE / 4));
+        const Words n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3], n4 = n[4];
+        const f3    sc = mk3(__uint_as_float((n0.w & 255u) << 23), __uint_as_float(((n0.w >> 8) & 255u) << 23), __uint_as_float(((n0.w >> 16) & 255u) << 23));
+        const f3    s = sc * idir, c = (mk3(__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z)) - o) * idir;
+        // per axis the plane the ray meets first: the low one for a positive direction
+        const bool  px = idir.x >= 0.f, py = idir.y >= 0.f, pz = idir.z >= 0.f;
+        uint32_t    hits = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t meta4 = half ? n1.w : n1.z;
+            const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
+            const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
+            const uint32_t nx = px ? lox : hix, fx = px ? hix : lox, ny = py ? loy : hiy, fy = py ? hiy : loy, nz = pz ? loz : hiz, fz = pz ? hiz : loz;
+            const uint32_t inner4 = ((meta4 & (meta4 << 1)) & 0x10101010u) >> 4;  // 1 in the bytes of inner children (position 24 and up)
+            const uint32_t index4 = (meta4 ^ (oct_inv4 & (inner4 * 0xFFu))) & 0x1F1F1F1Fu;
+            const uint32_t count4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float tnear = mx(mx(__fmaf_rn(float((nx >> (8 * k)) & 255u), s.x, c.x), __fmaf_rn(float((ny >> (8 * k)) & 255u), s.y, c.y)),
+                                       mx(__fmaf_rn(float((nz >> (8 * k)) & 255u), s.z, c.z), min_t));
+                const float tfar = mn(mn(__fmaf_rn(float((fx >> (8 * k)) & 255u), s.x, c.x), __fmaf_rn(float((fy >> (8 * k)) & 255u), s.y, c.y)),
+                                      mn(__fmaf_rn(float((fz >> (8 * k)) & 255u), s.z, c.z), max_t));
+                const uint32_t count = (count4 >> (8 * k)) & 7u, index = (index4 >> (8 * k)) & 31u;
+                if (tnear <= tfar) hits |= ((1u << count) - 1u) << index;  // (an empty slot counts nothing)
+            }
+        }
+        ng = make_uint2(n1.x, (hits & 0xFF000000u) | (n0.w >> 24));
+        tg = make_uint2(n1.y, hits & 0x00FFFFFFu);
+    }
+    // a popped group is a node group or a triangle group
+    ZD void adopt(uint2 g) {
+        if (g.y & 0xFF000000u) ng = g;
+        else tg = g, ng = make_uint2(0u, 0u);
+    }
+    // the next triangle of `tg` (trianglesPending()): corners and the reference's index
+    ZD void nextTriangle(f3& a, f3& b, f3& c, uint32_t& reference) {
+        const uint32_t bit = uint32_t(__ffs(int(tg.y))) - 1u;
+        tg.y &= tg.y - 1u;
+        typedef float                                            Corner __attribute__((ext_vector_type(4)));
+        const __attribute__((address_space(1))) Corner* v = (const __attribute__((address_space(1))) Corner*)(tris + size_t(3) * (tg.x + bit));
+        const Corner                                             va = v[0], vb = v[1], vc = v[2];
+        a = mk3(va.x, va.y, va.z);
+        b = mk3(vb.x, vb.y, vb.z);
+        c = mk3(vc.x, vc.y, vc.z);
+        reference = __float_as_uint(va.w);
     }
 };
 

@@ -104,6 +104,8 @@
     X(7, K_SCATTER_H_RESUME,     ZYG_WIDE((wf_scatter_h<true, false>), (wf_shadow<false>)),  (P, arg)) \
     X(7, K_SCATTER_H_RESUME_SUBST, ZYG_WIDE((wf_scatter_h<true, true>), (wf_shadow<false>)), (P, arg)) \
     X(7, K_MESH_CLOSEST,         ZYG_WIDE((wf_mesh_closest<true>), (wf_shadow<false>)),     (P, arg)) \
+    X(7, K_SHADOW_U8,            ZYG_WIDE((wf_shadow_u8<true>), (wf_shadow<false>)),        (P, arg)) \
+    X(7, K_MESH_CLOSEST8,        ZYG_WIDE((wf_mesh_closest8<true>), (wf_shadow<false>)),    (P, arg)) \
     X(6, K_RGENERATE,            (wf_rgenerate<false>),                               (P))  \
     X(6, K_RTRACE,               (wf_rtrace<false>),                                  (P))  \
     X(6, K_RSCATTER,             (wf_rscatter<false, false>),                         (P))  \

@@ -2485,6 +2485,211 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh
     }
 }
 
+// ---- The same two persistent walkers over the eight-wide compressed tree (bvh8.hpp, dscene.hpp Walk8; option "bvh8").  What
+// changes against the four-wide form above: a step is a node step for every lane that has a node to look at (eight children per 80 B
+// node, hit bits in front-to-back order by the ray's octant: no sorting network, one stack entry per node), then ONE triangle for the
+// lanes that have triangles pending, but only once ZYG_U8_POSTPONE lanes of the wave have some (or no lane has a node left): until
+// then a lane parks its triangle group on its stack and goes on with nodes, so that the triangle test runs with many lanes instead
+// of serialising the wave behind whichever lane happens to stand at a leaf.
+#ifndef ZYG_U8_POSTPONE
+#define ZYG_U8_POSTPONE 4  // of 64 lanes
+#endif
+#ifndef ZYG_U8_STEPS
+#define ZYG_U8_STEPS 16
+#endif
+#ifndef ZYG_U8_REFILL
+#define ZYG_U8_REFILL 32
+#endif
+#ifndef ZYG_SHADOW_U8_WAVES
+#define ZYG_SHADOW_U8_WAVES 4
+#endif
+#ifndef ZYG_MESH_CLOSEST8_WAVES
+#define ZYG_MESH_CLOSEST8_WAVES 4
+#endif
+template <bool WIDE>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U8_WAVES) wf_shadow_u8(Params P, uint32_t round) {
+    const DScene&   s = c_scene;
+    const uint32_t  n = P.ctl->shadow_count[round & 1u].n[0];
+    const uint32_t* queue = (round & 1u) ? P.q.heavy : P.q.shadow;
+    if (0 == blockIdx.x && threadIdx.x < 64) queueReset(&P.ctl->shadow_count[(round + 1u) & 1u]);
+    const uint32_t lane = __lane_id();
+    bool           have = false, exhausted = false;
+    uint32_t       slot = 0, entry = 0;
+    Ray            local = Ray::init(S3(0.f), S3(0.f), 0.f, 0.f), world = local;
+    GroupSpill     spill;
+    Walk8          walk(spill);
+    auto nextMesh = [&]() {
+        for (; entry < s.num_solid_table; ++entry) {
+            const TlasEntry& e = s.solid_table[entry];
+            if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW) || !aabbIntersect(e.bmin, e.bmax, world)) continue;
+            local = worldToObjectRay(entryTrafo(e), world);
+            walk.start(s.meshes[e.mesh], local);
+            return true;
+        }
+        return false;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t           num_idle = uint32_t(__popcll(idle));
+        if (!exhausted && num_idle >= uint32_t(ZYG_U8_REFILL)) {
+            const int first = __ffsll(static_cast<long long>(idle)) - 1;
+            uint32_t  base = 0;
+            if (int(lane) == first) base = atomicAdd(&P.ctl->shadow_fetch, num_idle);
+            base = __shfl(base, first);
+            exhausted = base + num_idle >= n;
+            if (!have) {
+                const uint32_t i = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+                if (i < n) {
+                    slot = queue[i];
+                    const float4 o = P.pool.sh_o[slot], d = P.pool.sh_d[slot];
+                    world = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+                    entry = s.first_large;
+                    have = nextMesh();
+                    if (!have) P.pool.vis[slot] = 1u;
+                }
+            }
+        }
+        if (0 == __ballot(have)) {
+            if (exhausted) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int it = 0; it < ZYG_U8_STEPS; ++it) {
+            if (have && walk.nodePending() && !walk.trianglesPending()) walk.nodeStep(local.min_t, local.max_t);  // (a node step makes a new triangle group)
+            const bool               tri = have && walk.trianglesPending();
+            const unsigned long long tri_lanes = __ballot(tri);
+            if (tri_lanes) {
+                // (a lane whose stack is filling up does not park another group: the node groups below need the room)
+                const bool test = __popcll(tri_lanes) >= ZYG_U8_POSTPONE || 0 == __ballot(have && walk.nodePending());
+                if (tri) {
+                    if (test || walk.stack.sp >= kStack8Lds - 4) {
+                        f3       a, b, c;
+                        uint32_t reference;
+                        float    t, u, v;
+                        walk.nextTriangle(a, b, c, reference);
+                        if (triangleIntersect(local, a, b, c, t, u, v)) {
+                            P.pool.vis[slot] = 0u;
+                            have = false;
+                        }
+                    } else {
+                        walk.stack.push(walk.tg);
+                        walk.tg.y = 0u;
+                    }
+                }
+            }
+            if (have && !walk.nodePending() && !walk.trianglesPending()) {
+                if (walk.stack.sp > 0) {
+                    walk.adopt(walk.stack.pop());
+                } else {
+                    entry += 1;
+                    have = nextMesh();
+                    if (!have) P.pool.vis[slot] = 1u;
+                }
+            }
+        }
+    }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST8_WAVES) wf_mesh_closest8(Params P, uint32_t) {
+    const DScene&  s = c_scene;
+    const uint32_t cur = P.parity;
+    const uint32_t n = P.ctl->ext_count[cur].n[kCountStride];  // the queue's back end
+    const uint32_t lane = __lane_id();
+    bool           have = false, exhausted = false;
+    uint32_t       slot = 0, entry = 0, depth = 0;
+    Ray            local = Ray::init(S3(0.f), S3(0.f), 0.f, 0.f), world = local;
+    Hit            hit;
+    GroupSpill     spill;
+    Walk8          walk(spill);
+    auto nextMesh = [&]() {
+        for (; entry < s.num_solid_table; ++entry) {
+            const TlasEntry& e = s.solid_table[entry];
+            if (!propVisibleAtDepth(e.flags, depth) || !aabbIntersect(e.bmin, e.bmax, world)) continue;
+            local = worldToObjectRay(entryTrafo(e), world);
+            walk.start(s.meshes[e.mesh], local);
+            return true;
+        }
+        return false;
+    };
+    auto finish = [&]() {
+        if (kNull == hit.prop) hit.t = hit.u = hit.v = 0.f, hit.primitive = 0;
+        P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
+        P.pool.hit_prop[slot] = hit.prop;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t           num_idle = uint32_t(__popcll(idle));
+        if (!exhausted && num_idle >= uint32_t(ZYG_U8_REFILL)) {
+            const int first = __ffsll(static_cast<long long>(idle)) - 1;
+            uint32_t  base = 0;
+            if (int(lane) == first) base = atomicAdd(&P.ctl->mesh_fetch, num_idle);
+            base = __shfl(base, first);
+            exhausted = base + num_idle >= n;
+            if (!have) {
+                const uint32_t i = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+                if (i < n) {
+                    slot = P.q.ext[cur][P.queue_capacity - 1u - i];
+                    const float4 o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
+                    depth = (P.pool.q0.get(slot).y >> 3) & 31u;
+                    world = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
+                    hit.prop = kNull;
+                    tableClosestBeforeLargeMeshes(s, world, depth, hit);
+                    entry = s.first_large;
+                    have = nextMesh();
+                    if (!have) finish();
+                }
+            }
+        }
+        if (0 == __ballot(have)) {
+            if (exhausted) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int it = 0; it < ZYG_U8_STEPS; ++it) {
+            if (have && walk.nodePending() && !walk.trianglesPending()) walk.nodeStep(local.min_t, local.max_t);  // (a node step makes a new triangle group)
+            const bool               tri = have && walk.trianglesPending();
+            const unsigned long long tri_lanes = __ballot(tri);
+            if (tri_lanes) {
+                // (a lane whose stack is filling up does not park another group: the node groups below need the room)
+                const bool test = __popcll(tri_lanes) >= ZYG_U8_POSTPONE || 0 == __ballot(have && walk.nodePending());
+                if (tri) {
+                    if (test || walk.stack.sp >= kStack8Lds - 4) {
+                        f3       a, b, c;
+                        uint32_t reference;
+                        float    t, u, v;
+                        walk.nextTriangle(a, b, c, reference);
+                        // (the order a lane meets its triangles in hangs on what the wave's other lanes do: of two triangles at one
+                        // distance, a ray through their shared edge, the one the reference's order names first wins, whatever the order)
+                        const uint32_t prop = s.solid_table[entry].prop;
+                        if (triangleIntersect(local, a, b, c, t, u, v) && (t < local.max_t || prop != hit.prop || reference < hit.primitive)) {
+                            local.max_t = t;
+                            world.max_t = t;
+                            hit.t = t;
+                            hit.u = u;
+                            hit.v = v;
+                            hit.primitive = reference;
+                            hit.prop = prop;
+                        }
+                    } else {
+                        walk.stack.push(walk.tg);
+                        walk.tg.y = 0u;
+                    }
+                }
+            }
+            if (have && !walk.nodePending() && !walk.trianglesPending()) {
+                if (walk.stack.sp > 0) {
+                    walk.adopt(walk.stack.pop());
+                } else {
+                    entry += 1;
+                    have = nextMesh();
+                    if (!have) finish();
+                }
+            }
+        }
+    }
+}
+
 // The bxdf sample and the path extension of a vertex whose light samples are done (pathtracer_mis.zig:123-166): the tail of
 // wf_extend and of wf_scatter_h.  `push`: the path goes on (its slot belongs into the next tick's extension queue, at the back
 // if the new ray enters a large mesh's bounds).

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "bvh4.hpp"
+#include "bvh8.hpp"
 #include "kernel_table.hpp"
 #include "wavefront.hpp"
 
@@ -534,6 +535,10 @@ struct ZygpuContext {
     // option "mesh_closest" (default off: measured -8 % on configs[2] with the mesh on the floor, +0 ... +10 % with it in the middle
     // of the box): the closest-hit walks of the rays that enter a large mesh's bounds in a persistent kernel too (wf_mesh_closest)
     bool          mesh_closest = false;
+    // option "bvh8" (default 1): the persistent mesh walkers read the meshes' eight-wide compressed trees (bvh8.hpp: wf_shadow_u8,
+    // wf_mesh_closest8) where every mesh of the mesh kernels has one (bvh8_ready); option "mesh_closest8" (default 1): with those trees
+    // the closest-hit walks of the rays that enter a large mesh's bounds run in the persistent walker too
+    bool          bvh8 = true, bvh8_ready = false, mesh_closest8 = true;
     // option "sort_alive" (1 on, 0 off, default -1: on in the scenes of the mesh kernels): wf_trace_shade's prop-table instantiations
     // append the surviving paths to one sub-queue per hit prop (mod kAliveKeys), the consumer's waves then read paths that stand on one
     // surface (wavefront.hpp kAliveKeys).  Measured in one call: configs[2] 240.3 / 241.2 -> 246.3 / 246.4 Msamples/s (wf_scatter_h
@@ -1083,7 +1088,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     }
 
     c->large_mesh = c->huge_mesh = c->wide_mesh = false;
-    bool wide_ok = true;
+    bool wide_ok = true, all8 = true;
     std::vector<DMesh> meshes(d->num_meshes);
     for (uint32_t i = 0; i < d->num_meshes; ++i) {
         const ZygpuMesh& hm = d->meshes[i];
@@ -1115,6 +1120,17 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             if (dm.wide) c->wide_mesh = true;
         }
         ok = ok && m.upload(tv.data(), tv.size(), &dm.tri_verts);
+        dm.nodes8 = nullptr;
+        dm.tris8 = nullptr;
+        if (hm.num_triangles >= kMeshKernelMinTriangles && modeAvailable(1)) {  // bvh8.hpp: what the relaxed units' persistent walkers read
+            const zyg::Bvh8 wide8 = zyg::build8(hm.nodes, hm.num_nodes, reinterpret_cast<const float*>(tv.data()), hm.num_triangles);
+            if (wide8.ok && 2u * wide8.depth <= uint32_t(kStack8)) {
+                ok = ok && m.upload(reinterpret_cast<const uint4*>(wide8.nodes.data()), wide8.nodes.size() / 4, &dm.nodes8);
+                ok = ok && m.upload(reinterpret_cast<const float4*>(wide8.triangles.data()), wide8.triangles.size() / 4, &dm.tris8);
+            } else {
+                all8 = false;
+            }
+        }
         {  // DMesh::shade
             std::vector<uint4> shade(size_t(hm.num_triangles) * 3);
             auto bits = [](float x) {
@@ -1147,6 +1163,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         if (!ok) return -1;
     }
     if (!wide_ok) c->large_mesh = c->huge_mesh = false;
+    c->bvh8_ready = all8 && c->huge_mesh;
     if (!m.upload(meshes.data(), meshes.size(), &s.meshes)) return -1;
 
     for (uint32_t i = 0; i < d->num_infinite_props; ++i) {
@@ -1715,9 +1732,14 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                       : nullptr;
         P.lazy_head = (c->lazy_head && nullptr != P.hit_q) ? 1u : 0u;
         P.alive_key_mask = ~0u;
-        const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && c->mesh_closest && c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
-        P.mesh_pass = mesh_pass ? 1u : 0u;
-        if (mesh_pass) {
+        const bool walk8 = c->bvh8 && c->bvh8_ready;
+        const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && (c->mesh_closest || (walk8 && c->mesh_closest8 && c->mesh_kernels)) &&
+                               c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
+        // the eight-wide walker takes the later ticks' rays only: the camera rays stay in the fused first tick (coherent, and generated in
+        // the kernel that traces them: what wf_generate + the queue cost the four-wide form of this pass, which keeps its round-3 shape)
+        const bool mesh_pass_first = mesh_pass && !(walk8 && c->mesh_closest8 && !c->mesh_closest);
+        P.mesh_pass = mesh_pass_first ? 1u : 0u;
+        if (mesh_pass_first) {
             HIP_OK(hipMemsetAsync(&c->ctl->mesh_fetch, 0, sizeof(uint32_t), c->stream));
             launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
         }
@@ -1882,12 +1904,14 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             }
             if (c->fuse_trace_shade) {
                 // closest hit + the first shading pass in one kernel (timed as kernel 0), then the second pass
-                if (mesh_pass) {
+                const bool mesh_pass_now = mesh_pass && (t > 0 || mesh_pass_first);
+                P.mesh_pass = mesh_pass_now ? 1u : 0u;
+                if (mesh_pass_now) {
                     // the rays that enter a large mesh's bounds first, in the persistent walker (timed with the trace kernel)
-                    timedLaunch(c, 0, [&] { launchKernel(c, K_MESH_CLOSEST, persistentGrid(c, grid.x, 5), P, 0u); });
+                    timedLaunch(c, 0, [&] { launchKernel(c, walk8 ? K_MESH_CLOSEST8 : K_MESH_CLOSEST, persistentGrid(c, grid.x, walk8 ? unsigned(c->shadow_u_blocks) : 5u), P, 0u); });
                 }
                 timedLaunch(c, 0, [&] {
-                    if (0 == t && !mesh_pass) {
+                    if (0 == t && !mesh_pass_now) {
                         if (c->stats) launchKernel(c, K_TRACE_SHADE_STATS_FIRST, grid.x, P, num_paths);
                         else if (c->mesh_lights) launchKernel(c, K_TRACE_SHADE_MESHL_FIRST, grid.x, P, num_paths);
                         else if (utlas) launchKernel(c, wide ? K_TRACE_SHADE_PLAIN_FIRST_UW : K_TRACE_SHADE_PLAIN_FIRST_U, grid.x, P, num_paths);
@@ -1944,7 +1968,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                     }
                 });
                 for (uint32_t r = 1; r <= rounds; ++r) {
-                    timedLaunch(c, 3, [&] { launchKernel(c, K_SHADOW_U, persistentGrid(c, grid.x, unsigned(c->shadow_u_blocks)), P, r - 1u); });
+                    timedLaunch(c, 3, [&] { launchKernel(c, walk8 ? K_SHADOW_U8 : K_SHADOW_U, persistentGrid(c, grid.x, unsigned(c->shadow_u_blocks)), P, r - 1u); });
                     timedLaunch(c, 5, [&] { launchKernel(c, c->has_substitute ? K_SCATTER_H_RESUME_SUBST : K_SCATTER_H_RESUME, grid.x, P, r); });
                 }
             } else if (nee && (c->nee_in_place || c->multi_sample_lights || c->mesh_lights)) {  // the staged rounds take one Rectangle sample per pick
@@ -2348,6 +2372,14 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         c->mesh_closest = 0 != value;
         return 0;
     }
+    if (0 == std::strcmp(name, "bvh8")) {
+        c->bvh8 = 0 != value;
+        return 0;
+    }
+    if (0 == std::strcmp(name, "mesh_closest8")) {
+        c->mesh_closest8 = 0 != value;
+        return 0;
+    }
     if (0 == std::strcmp(name, "hit_by_queue")) {
         c->hit_by_queue = 0 != value;
         return 0;
@@ -2411,6 +2443,9 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"nee_in_place", c->nee_in_place ? 1 : 0},
                  {"mesh_kernels", c->mesh_kernels ? 1 : 0},
                  {"mesh_closest", c->mesh_closest ? 1 : 0},
+                 {"bvh8", c->bvh8 ? 1 : 0},
+                 {"mesh_closest8", c->mesh_closest8 ? 1 : 0},
+                 {"bvh8_active", (c->bvh8 && c->bvh8_ready && c->huge_mesh && c->mesh_kernels && relaxedUnits(c)) ? 1 : 0},
                  {"sort_alive", c->sort_alive},
                  {"pack_prev", c->pack_prev ? 1 : 0},
                  {"hit_by_queue", c->hit_by_queue ? 1 : 0},
