@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters-per-step", type=int, default=ITER_PER_STEP)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_mesh", "cornell_mound", "cornell_glass", "outdoor"],
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "cornell_mesh", "cornell_mound", "cornell_glass", "outdoor", "outdoor_mound"],
                     help="cornell = BASELINE.json configs[1] (default), cornell_mesh = configs[2] (SURVEY 8(d): the closed displaced "
                          "sphere of 999 698 triangles hanging at 60 %% of the box's height), cornell_mound = the lighter variant "
                          "(the heightfield on the floor); cornell_glass and outdoor (configs[4]'s ingredients: glass, metal presets, "
@@ -131,11 +131,14 @@ def build_scene(eng, scenes, name, material, w, h, total_spp, box_triangles=12, 
     mesh = scenes.displaced_sphere_mesh() if name == "cornell_mesh" else scenes.heightfield_mesh() if name == "cornell_mound" else None
     mesh_position = scenes.MESH_CENTRE if name == "cornell_mesh" else (0, 0.02, 0.1)
     mesh_material = scenes.substitute((0.5, 0.5, 0.5)) if mesh is not None else None
-    if name == "outdoor":
+    if name in ("outdoor", "outdoor_mound"):
         # (box_lift: the boxes stand 1 mm above the ground: a glass box ON it has its bottom face in the ground's plane, and which of two
         # coincident surfaces a ray meets first hangs on the last bit; zygpu.hip relaxedUnits)
-        scenes.outdoor(eng, w, h, total_spp, integrator="PTMIS", material="substitute", showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16,
-                       sky_entity={"parameters": {"sun": {"rotation": [-55, 20, 0]}}}, box_lift=1e-3)
+        # outdoor: configs[4]'s "same ingredients": the mesh is configs[2]'s closed displaced sphere, standing just above the ground behind the boxes
+        sphere = "outdoor" == name
+        scenes.outdoor(eng, w, h, total_spp, integrator="PTMIS", material="substitute", showcase=True,
+                       mesh=scenes.displaced_sphere_mesh() if sphere else scenes.heightfield_mesh(), mesh_position=(0.0, 0.8, -1.6) if sphere else (0.0, 0.01, -1.6),
+                       max_depth=16, sky_entity={"parameters": {"sun": {"rotation": [-55, 20, 0]}}}, box_lift=1e-3)
     else:
         glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if name == "cornell_glass" else None
         scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=material, boxes=mesh is None, mesh=mesh,
@@ -148,8 +151,9 @@ def describe(name, material, w, h, ips, k, relaxed):
     """`relaxed`: the arithmetic the library really ran (zygpu_get_option "relaxed_units": a scene with Glass gets the precise
     units whatever --precise says)."""
     mode = "relaxed arithmetic (RMS <= 1e-3 contract)" if relaxed else "precise arithmetic (film bit-identical to the CPU oracle)"
-    if name == "outdoor":
-        return (f"outdoor scene (ground, 2 boxes (one glass) 1 mm above it, glass + gold Spheres, 999698-triangle mesh in polished iron, the Sky "
+    if name in ("outdoor", "outdoor_mound"):
+        which = "closed displaced sphere (configs[2]'s mesh)" if "outdoor" == name else "heightfield mesh on the ground (the lighter variant of rounds 3-4)"
+        return (f"outdoor scene (ground, 2 boxes (one glass) 1 mm above it, glass + gold Spheres, 999698-triangle {which} in polished iron, the Sky "
                 f"entity: sun with its radiance table + 1024^2 canopy image, both the procedural stand-in for the Prague bake), {w}x{h}, PTMIS depth 16, Sobol, box sensor, {ips} iterations per step, "
                 f"{k * ips} spp per GPU, {mode}")
     geometry = {"cornell": "2 boxes", "cornell_mesh": "999698-triangle closed displaced sphere (Substitute) centred at 60 % of the box's height",
@@ -401,7 +405,7 @@ def parse_defaults():
     return _DEFAULTS
 
 
-def committed_profile(args, name, kernel, source_hash):
+def committed_profile(args, name, kernel, source_hash, overrides=None):
     """One kernel's entry of a committed rocprofv3 --pmc summary (profiles/<name>: traffic.json from tools/pmc_traffic.py, the
     FETCH_SIZE and WRITE_SIZE passes; pmc_sq.json from tools/pmc_summary.py, the SQ pass).  Counters need profiler passes of
     their own, so this process cannot collect them; a profile is quoted only for the bench arguments it names AND for the
@@ -412,7 +416,9 @@ def committed_profile(args, name, kernel, source_hash):
         return None, {"profile": "profiles/" + name, "refused": "missing"}
     prof = json.load(open(path))
     meta = prof.get("_meta", {})
-    if meta.get("config") != bench_config(args):
+    want = bench_config(args)
+    want.update(overrides or {})  # (an `extra` scene: the run's arguments with that scene and its size)
+    if meta.get("config") != want:
         return None, {"profile": "profiles/" + name, "refused": "taken with other bench arguments"}
     # the kernels' sources (csrc/hip + include/: build.device_hash); a profile from before that field existed names all of csrc/
     from zyg_amd import build as zbuild
@@ -424,6 +430,53 @@ def committed_profile(args, name, kernel, source_hash):
             return val, {"profile": "profiles/" + name, "source_commit": meta.get("source_commit"), "device_hash": mine,
                          "fetch_size_factor": meta.get("fetch_size_factor")}
     return None, {"profile": "profiles/" + name, "refused": "kernel not in the profile"}
+
+
+_COUNTING = ("wf_scatter<true", "wf_trace_shade<true", "wf_shade<true", "wf_intersect<true", "wf_shadow<true", "wf_trace_shade_pool<true")
+
+
+def committed_step_traffic(args, name, source_hash, overrides, ms_per_step):
+    """What a scene's whole step moves across HBM according to the committed counter passes (profiles/<name>: tools/pmc_traffic.py's
+    summary of separate --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py with `steps` steps, corrected as MI355X_MICROARCH.md prescribes):
+    the sum over the wavefront kernels (the counting instantiations of the statistics iteration excluded) of bytes per launch x launches,
+    per step, and that over this run's measured step time and the 8 TB/s peak.  Quoted under the same rule as committed_profile: the
+    same bench arguments and the same kernels' sources, else refused."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return {"source": {"profile": "profiles/" + name, "refused": "missing"}}
+    prof = json.load(open(path))
+    meta = prof.get("_meta", {})
+    want = bench_config(args)
+    want.update(overrides or {})
+    if meta.get("config") != want:
+        return {"source": {"profile": "profiles/" + name, "refused": "taken with other bench arguments"}}
+    from zyg_amd import build as zbuild
+    mine, theirs = (zbuild.device_hash(), meta["device_hash"]) if "device_hash" in meta else (source_hash, meta.get("source_hash"))
+    if theirs != mine:
+        return {"source": {"profile": "profiles/" + name, "refused": f"taken with other sources ({theirs} != {mine})"}}
+    steps = float(meta.get("steps", 2))
+    kernels = {k: v for k, v in prof.items() if k.startswith("wf_") and not k.startswith(_COUNTING)}
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in kernels.values()) / steps
+    return {"traffic_bytes_per_step": round(total, 1),
+            "traffic_frac_step": round(total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_per_step else None,
+            "per_kernel_gb_per_launch": {k.split("(")[0][:64]: round(v["hbm_bytes_per_launch"] / 1e9, 4) for k, v in kernels.items()},
+            "source": {"profile": "profiles/" + name, "source_commit": meta.get("source_commit"), "device_hash": mine, "steps": steps}}
+
+
+def headline_frac(r, traffic_gbs):
+    """roofline.frac / frac_model / frac_source of one measurement (r: Measurement.run()'s result; traffic_gbs: the dominant kernel's
+    counted HBM traffic per second from a committed profile, or None)."""
+    seconds = r["avg_ms"] * 1e-3
+    model = r["achieved"] / HBM_PEAK_GBS
+    saturated = any(v["frac"] > 1.0 for v in r["per_kernel"].values())
+    state = r["state_bytes_per_launch"] / seconds / 1e9 / HBM_PEAK_GBS if seconds else None
+    if not saturated:
+        frac, source = model, "model (SURVEY 8(d) algorithmic bytes)"
+    elif traffic_gbs:
+        frac, source = traffic_gbs / HBM_PEAK_GBS, "hbm.traffic_frac (counted HBM bytes of the committed profile; the model is saturated)"
+    else:
+        frac, source = state, "hbm.state_frac (the records that must cross HBM; the model is saturated and no committed profile matches this build)"
+    return {"frac": round(frac, 5) if frac is not None else None, "frac_model": round(model, 5), "frac_source": source}
 
 
 def host_cpu():
@@ -508,6 +561,9 @@ def cpu_baseline(m, oracle, budget_s):
     dt = oracle.render(m.eng, film, 0, iters, 0, h, threads)
     rate = w * h * iters / dt / 1e6
     return {"value": round(rate, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "note": f"scalar C++ port of the reference's loop (the Zig reference, @Vector(4, f32) arithmetic, cannot be built here), compiled -O3 "
+                    f"-march=native on this box, {threads} thread(s) of a {cpu['usable']}-CPU quota"
+                    + (f" (cgroup {cpu['cgroup_quota']:g}; the host has {cpu['logical']} logical CPUs)" if cpu.get("cgroup_quota") else ""),
             "per_thread": round(rate / threads, 5), "cpu": cpu,
             "probe_seconds_per_iteration": {str(t): round(s, 3) for t, s in probes.items()},
             "sample": f"one call, {iters} iteration(s) of the same {w}x{h} frame ({w * h * iters} camera samples), {dt:.1f} s"}, rate, threads
@@ -690,14 +746,19 @@ def main():
             #   `achieved` / `frac`: the contract's figure, SURVEY 8(d)'s cache-less algorithmic bytes (B_trav included) over the
             #           duration.  For scenes whose traversal data sits in SGPRs / constant memory / L2 most of those bytes never
             #           reach HBM, so it can exceed 1: `model_saturated` lists the kernels where it does.
+            # `frac`: where SURVEY 8(d)'s cache-less model is saturated (some kernel's model bytes over its duration exceed the peak: most
+            # of them never reach HBM) the headline fraction is what does cross HBM: the counted traffic of the dominant kernel where a
+            # committed profile of this very library holds it, else the bytes it must move (state records): `frac_source` says which;
+            # the model's figure stays as `frac_model` / `achieved`.
             "roofline": {"bound": "hbm", "kernel": r["dominant"], "achieved": round(r["achieved"], 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(r["achieved"] / HBM_PEAK_GBS, 5),
+                         "unit": "GB/s", **headline_frac(r, traffic_gbs),
                          "traffic": round(hbm_bytes, 1) if hbm_bytes else None, "traffic_source": source,
                          "hbm": {"state_frac": round(r["state_bytes_per_launch"] / seconds / 1e9 / HBM_PEAK_GBS, 5) if seconds else None,
                                  "traffic_frac": round(traffic_gbs / HBM_PEAK_GBS, 5) if traffic_gbs else None,
                                  "traffic_frac_of_measured_copy": round(traffic_gbs / copy_gbs, 5) if traffic_gbs and copy_gbs else None,
                                  "waste": round(hbm_bytes / r["state_bytes_per_launch"], 3) if hbm_bytes and r["state_bytes_per_launch"] else None,
-                                 "state_bytes_per_launch": round(r["state_bytes_per_launch"], 1), "measured_copy_gbs": copy_gbs},
+                                 "state_bytes_per_launch": round(r["state_bytes_per_launch"], 1), "measured_copy_gbs": copy_gbs,
+                                 "step": committed_step_traffic(args, "traffic.json", source_hash, None, r["elapsed"] / args.steps * 1e3)},
                          "issue": issue,
                          "model_saturated": [k for k, v in r["per_kernel"].items() if v["frac"] > 1.0],
                          "per_kernel": r["per_kernel"],
@@ -726,14 +787,17 @@ def main():
         # configs[2] and its lighter variant at the run's size; configs[4]'s scene at its own 3840 x 2160 (depth 16, the Sky entity, glass
         # and conductors: the POOL kernels) and the glass Cornell box at 1080p: each with its own roofline figures, parity band and
         # the arithmetic the library really ran
-        for name, size in (("cornell_mesh", None), ("cornell_mound", None), ("outdoor", (3840, 2160)), ("cornell_glass", None)):
+        for name, size in (("cornell_mesh", None), ("cornell_mound", None), ("outdoor", (3840, 2160)), ("outdoor_mound", (3840, 2160)), ("cornell_glass", None)):
             m2 = Measurement(args, zyg_amd, scenes, torch, frame, device, name, "lambert", max(2, args.steps // (8 if size else 4)), 1, size)
             r2 = m2.run()
             extra = {"value": round(r2["value"], 3), "unit": "Msamples/s", "steps": m2.steps, "ms_per_step": round(r2["elapsed"] / m2.steps * 1e3, 3),
                      "workload": describe(name, "lambert", m2.w, m2.h, args.iters_per_step, m2.steps, m2.relaxed),
                      "arithmetic": "relaxed" if m2.relaxed else "precise", "size": [m2.w, m2.h],
-                     "kernel": r2["dominant"], "achieved": round(r2["achieved"], 2), "frac": round(r2["achieved"] / HBM_PEAK_GBS, 5),
+                     "kernel": r2["dominant"], "achieved": round(r2["achieved"], 2), **headline_frac(r2, None),
                      "state_frac": round(r2["state_bytes_per_launch"] / (r2["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if r2["avg_ms"] else None,
+                     # the scene's own committed counter passes (profiles/traffic_<scene>.json, pmc_sq_<scene>.json), same refusal rule as the main scene's
+                     "hbm": committed_step_traffic(args, f"traffic_{name}.json", source_hash, {"scene": name, "size": [m2.w, m2.h, args.iters_per_step]},
+                                                   r2["elapsed"] / m2.steps * 1e3),
                      "avg_launch_ms": round(r2["avg_ms"], 5), "launches": r2["launches"], "algorithmic_bytes_per_sample": round(r2["bytes_per_sample"], 1),
                      "state_bytes_per_sample": round(r2["state_bytes_per_sample"], 1), "kernel_ms": r2["kernel_ms"],
                      "per_kernel": r2["per_kernel"], "rays_per_sample": r2["rays_per_sample"],

@@ -256,7 +256,7 @@ struct Params {
     uint32_t* nee_count;
     uint32_t  scatter_source;  // wf_scatter reads 0: the alive queue, 1: the overflow queue (Queues::shadow, shadow_count[0]) of wf_light
     uint32_t round;   // POOL: which vertex of the level this launch handles
-    uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits
+    uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits; 2: wf_mesh_closest8 has walked the large meshes for them, wf_trace_shade tests the rest of the table
     uint32_t alive_key_mask;  // wf_scatter_h: bit k = the launch takes sub-queue k of the sorted alive queue
     uint32_t lazy_head;  // 1 (option "lazy_head", with hit_q): the first shading pass leaves a vertex' sampler and throughput to wf_scatter (shadeVertex)
 };
@@ -2011,6 +2011,8 @@ __global__ void __launch_bounds__((traceShadeBlock<UTLAS, WIDE>())) ZYG_WAVES(ZY
                 hit.v = __uint_as_float(h.z);
                 hit.primitive = h.w;
                 if (kNull != hit.prop) ray.max_t = hit.t;
+                // (wf_mesh_closest8 walks the large meshes only: the Rectangles and small meshes are tested here, by every lane together)
+                if (UTLAS && 2u == P.mesh_pass) tableClosestBeforeLargeMeshes(scene, ray, depth, hit);
             } else if (UTLAS) {
 #if ZYG_FAST
                 sceneIntersectUniform<false, WIDE>(scene, ray, depth, hit);
@@ -2634,7 +2636,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST8_WAVES) wf_mes
                     depth = (P.pool.q0.get(slot).y >> 3) & 31u;
                     world = Ray::init(xyz4(o), xyz4(d), 0.f, o.w);
                     hit.prop = kNull;
-                    tableClosestBeforeLargeMeshes(s, world, depth, hit);
+                    // (the Rectangles and small meshes in front of the large ones: wf_trace_shade, Params::mesh_pass 2)
                     entry = s.first_large;
                     have = nextMesh();
                     if (!have) finish();

@@ -1905,7 +1905,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             if (c->fuse_trace_shade) {
                 // closest hit + the first shading pass in one kernel (timed as kernel 0), then the second pass
                 const bool mesh_pass_now = mesh_pass && (t > 0 || mesh_pass_first);
-                P.mesh_pass = mesh_pass_now ? 1u : 0u;
+                P.mesh_pass = mesh_pass_now ? (walk8 ? 2u : 1u) : 0u;
                 if (mesh_pass_now) {
                     // the rays that enter a large mesh's bounds first, in the persistent walker (timed with the trace kernel)
                     timedLaunch(c, 0, [&] { launchKernel(c, walk8 ? K_MESH_CLOSEST8 : K_MESH_CLOSEST, persistentGrid(c, grid.x, walk8 ? unsigned(c->shadow_u_blocks) : 5u), P, 0u); });

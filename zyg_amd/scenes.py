@@ -614,7 +614,8 @@ def sky_tables(elevation_deg=35.0, size=64):
 
 def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun_direction=(0.35, 0.8, -0.45), material="lambert",
             extra_quad_light=False, max_depth=8, sky=None, sun=True, showcase=False, mesh=None, sky_map=None, sky_samples=1,
-            sky_spectrum=(0.35, 0.5, 0.8), sky_entity=None, shadow_catcher=False, alpha_transparency=False, box_lift=0.0):
+            sky_spectrum=(0.35, 0.5, 0.8), sky_entity=None, shadow_catcher=False, alpha_transparency=False, box_lift=0.0,
+            mesh_position=(0.0, 0.01, -1.6)):
     """An open scene for infinite lights: a large ground Rectangle, the two Cornell boxes and a Distant light ("sun",
     distant.zig) whose disc has angular radius atan(sun_radius); optionally one finite quad light next to it, so that the
     light tree mixes the infinite-light distribution with the BVH.  `sky`: "dome" (dome.zig, the whole sphere of
@@ -646,7 +647,7 @@ def outdoor(engine, width, height, spp, integrator="PTMIS", sun_radius=0.05, sun
     if mesh is not None:
         iron = engine.material(json.dumps({"rendering": {"Substitute": {"metal_preset": "Iron", "roughness": 0.1}}}))
         p = engine.prop(engine.triangle_mesh(*mesh), [iron])
-        engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0.0, 0.01, -1.6)))
+        engine.transformation(p, trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), mesh_position))
     for lo, hi, rot, mat in (((-0.72, 0.0, -0.05), (-0.12, 1.2, 0.55), 17.0, white), ((0.15, 0.0, -0.65), (0.75, 0.6, -0.05), -18.0, red)):
         if box_lift:  # (see cornell's box_lift)
             lo, hi = (lo[0], lo[1] + box_lift, lo[2]), (hi[0], hi[1] + box_lift, hi[2])
