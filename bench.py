@@ -200,25 +200,16 @@ class Measurement:
         assert (self.group is not None) == bool(group_spec)
         if args.batch_mpaths:
             self.eng.set_option("batch_mpaths", args.batch_mpaths)
-        self.eng.set_option("fuse_trace_shade", args.fuse)
-        self.eng.set_option("pool_relaxed", args.pool_relaxed)
-        self.eng.set_option("split_nee", args.split_nee)
-        self.eng.set_option("fuse_pool", args.fuse_pool)
-        self.eng.set_option("shadow_u_blocks", args.shadow_u_blocks)
-        self.eng.set_option("lazy_head", args.lazy_head)
-        self.eng.set_option("split_materials", args.split_materials)
-        self.eng.set_option("precise", args.precise)
-        self.eng.set_option("persistent", args.persistent)
-        self.eng.set_option("fuse_tick", args.fuse_tick)
-        self.eng.set_option("mesh_kernels", args.mesh_kernels)
-        self.eng.set_option("mesh_closest", args.mesh_closest)
-        self.eng.set_option("bvh8", args.bvh8)
-        self.eng.set_option("mesh_closest8", args.mesh_closest8)
-        self.eng.set_option("sort_alive", args.sort_alive)
-        self.eng.set_option("regenerate", args.regenerate)
-        self.eng.set_option("pack_prev", args.pack_prev)
-        self.eng.set_option("compact_blocks", args.compact_blocks)
-        self.eng.set_option("hit_by_queue", args.hit_by_queue)
+        defaults = parse_defaults()
+        # the shipped library's options, then the ones only variant builds know (ZYG_AMD_LIB=variants/lib_all.so): named when they are
+        # not at their default, so that a default run never asks for one
+        for option, arg in (("fuse_trace_shade", "fuse"), ("pool_relaxed", "pool_relaxed"), ("shadow_u_blocks", "shadow_u_blocks"), ("precise", "precise"),
+                            ("mesh_kernels", "mesh_kernels"), ("bvh8", "bvh8"), ("sort_alive", "sort_alive")):
+            self.eng.set_option(option, getattr(args, arg))
+        for option in ("split_nee", "fuse_pool", "lazy_head", "split_materials", "persistent", "fuse_tick", "mesh_closest", "mesh_closest8", "regenerate",
+                       "pack_prev", "compact_blocks", "hit_by_queue"):
+            if getattr(args, option) != defaults[option]:
+                self.eng.set_option(option, getattr(args, option))
         if args.regen_kslots:
             self.eng.set_option("regen_kslots", args.regen_kslots)
         self.eng.set_option("nee_in_place", 1 if args.nee == "in-place" else 0)

@@ -472,6 +472,11 @@ int zygpu_destroy(ZygpuContext* ctx);
  * Scene.compile leaves in host memory for the workers (scene.zig:185-223). */
 int zygpu_upload_scene(ZygpuContext* ctx, const ZygpuSceneDesc* scene);
 
+/* 1 when a surface of a Glass mesh lies in the plane of another solid surface (within 1e-5 of the scene's extent; a glass box standing
+ * on the floor): the condition under which option "pool_relaxed" -1 keeps a scene in the precise units (see zygpu_set_option).  What
+ * zygpu_upload_scene computes for the scenes of the POOL kernels; host-only: needs no device. */
+int zygpu_scene_has_coincident_dielectric(const ZygpuSceneDesc* scene);
+
 /* Camera/integrator/sensor state.  Replaces Driver.configure + camera.update (driver.zig:86-113,167-169). */
 int zygpu_set_view(ZygpuContext* ctx, const ZygpuViewDesc* view);
 
@@ -522,46 +527,40 @@ int zygpu_set_external_film_alpha(ZygpuContext* ctx, void* device_alpha);
  * -> AP1 -> sRGB; alpha 1, or |sum w alpha / w| for a Transparent sensor; writes min(num_pixels, film pixels) * 4 floats. */
 int zygpu_resolve(ZygpuContext* ctx, float* host_rgba, uint32_t num_pixels);
 
-/* Switches: "kernel_timing" (default 1) records a HIP event pair around every wavefront launch;
- * "tick_sync" (default 0) reads the next tick's queue length back after every tick (exact launch sizes, a batch ends with
- * its last living path; zygpu_render then returns only when the traced work is done) instead of keeping a batch fully
- * asynchronous with every launch sized for the whole batch - measured equal on BASELINE configs[1] (surplus blocks
- * leave on one scalar load), useful when max_depth is far above the depth paths really reach;
- * "nee_in_place" (default 1) runs next-event estimation, shadow rays and the bxdf sample of a vertex in one kernel
- * (wf_scatter); 0 runs them as wf_nee / wf_shadow rounds + wf_extend: same results, different cost profile (in place
- * is faster with the couple of light picks per vertex of BASELINE's scenes; the rounds keep every lane busy when a
- * vertex picks many lights; scenes with multi-sample or TriangleMesh lights always run in place);
- * "batch_mpaths" (default 32, 1..512) sets the number of paths per batch in units of 2^20 (the path pool takes about
- * 450 B per path);
- * "sort_alive" (default -1: the library's choice, on in the scenes whose large meshes run in the mesh kernels; 1 / 0) keeps the
- * paths that survive a tick's shading in one sub-queue per hit prop (16 of them), so that the waves of the kernel that
- * scatters them stand on one surface each; results are addressed by path slot, the film is the same bits either way;
- * "regenerate" (default 0) runs the regenerating kernels where the scene allows them (prop tables without a large mesh, in-place
- * next-event estimation, single-sample lights, progressive sampling): a pool of "regen_kslots" x 1024 slots (default 2048,
- * 1..65536) that are all alive, a slot taking the batch's next camera sample when its path ends; same film, measured slower
- * than the tick loop on BASELINE's scenes;
- * "pack_prev" (default 1) keeps the previous vertex's origin / geometric normal / roughness in words of the path's first 128 B
- * line that are dead while they are needed instead of in its second line (scenes without Glass and without opacity masks;
- * same film), "compact_blocks" (default 0) then places the paths' blocks 128 B apart instead of 256; "hit_by_queue" (default 1)
- * stores the hit records of the vertices that go on to wf_scatter at their place in the alive queue instead of by path slot;
- * "pair_small" (default 1; read by zygpu_upload_scene) lets two triangles of a small mesh that make a parallelogram be tested as
- * one item by the relaxed-arithmetic kernels;
- * "pool_relaxed" (default 1): with "precise" 0 the scenes of the POOL kernels (Glass, shadow catchers) run the relaxed units as
- * every other scene does; 0 gives them the precise units whatever "precise" says (the reference's bits: where two surfaces of such
- * a scene coincide, a glass box standing on the floor, which of them a ray meets first hangs on the last bit of two formulas, and
- * only the precise units decide that as the reference does: DESIGN.md section 2);
- * "pool_tick_sync" (default 1): the POOL tick loop reads a level's four queue lengths back once per tick and launches only the
- * rounds that have vertices, with exact grids; a batch ends with its last living vertex;
- * "split_nee" (default 1): the POOL scenes' complete wf_scatter runs as two kernels, wf_light (light sampling, shadow rays and every
- * draw of sampleLights, without a closure) and wf_scatter<.., PHASE 2> (the closure's evaluation of the stored light samples, the
- * bxdf sample, the path's extension); same film;
- * "fuse_pool" (default 1): the POOL scenes' complete instantiations find the closest hit and run the first shading pass in one
- * kernel (wf_trace_shade_pool) instead of wf_intersect + wf_shade; same film;
- * "shadow_u_blocks" (default 4, 1-10): blocks per CU of the persistent any-hit walker of the large meshes (wf_shadow_u);
- * "lazy_head" (default 1): where the hit records travel by queue position, the first shading pass of a later tick does not write
- * a surviving vertex' sampler and throughput back to its line: wf_scatter makes that pass's two draws again; same film;
- * "split_materials" (default 1): where the alive queue is sorted by hit prop (the large-mesh kernels), the sub-queues that hold no
- * Substitute prop go through the lighter instantiation of wf_scatter_h. */
+/* Options of the shipped library (twelve):
+ * "precise" (default 1): the reference's arithmetic bit for bit (the verification mode: the film is the oracle's); 0: the
+ *     relaxed-arithmetic kernel units (native divide / sqrt, contraction, OCML f32 functions, the wide BLAS walks), inside the contract
+ *     RMS <= 1e-3 against the reference; bench.py measures these;
+ * "pool_relaxed" (default -1): whether the scenes of the POOL kernels (Glass, shadow catchers) follow "precise" 0 into the relaxed
+ *     units.  -1: they do unless zygpu_upload_scene finds a dielectric surface lying in the plane of another surface (a glass box
+ *     standing on the floor): which of two coincident surfaces a ray meets first hangs on the last bit of two formulas, only the precise
+ *     units decide that as the reference does, and such a scene measures 1.3e-3 .. 2e-3 in the relaxed ones; then
+ *     it gets the precise units and zygpu_get_option "relaxed_units" says 0.  1: always follow; 0: POOL scenes always precise;
+ * "kernel_timing" (default 1): a HIP event pair around every wavefront launch (zygpu_kernel_time);
+ * "batch_mpaths" (default 32, 1..512): paths per batch in units of 2^20 (about 450 B of pool per path; POOL scenes: twice as many camera
+ *     samples of about 2.9 KB each; bounded by the device's free memory: zygpu_render halves a batch that does not fit);
+ * "tick_sync" (default 0): reads the next tick's queue length back after every tick (exact launch sizes, a batch ends with its last
+ *     living path) instead of keeping a batch asynchronous with every launch sized for the whole batch;
+ * "nee_in_place" (default 1): next-event estimation, shadow rays and the bxdf sample of a vertex in one kernel (wf_scatter); 0: as
+ *     wf_nee / wf_shadow rounds + wf_extend: the same film (scenes with multi-sample or TriangleMesh lights always run in place);
+ * "fuse_trace_shade" (default 1): closest hit and first shading pass in one kernel (wf_trace_shade); 0: wf_intersect + wf_shade;
+ * "uniform_tlas" (default 1): scenes of at most 112 Rectangle / mesh props are walked wave-wide from a table in constant memory;
+ *     0: the top-level trees lane by lane;
+ * "mesh_kernels" (default 1): in the relaxed units the walks of meshes of 4096 triangles or more run in persistent kernels whose
+ *     lanes fetch their own rays (wf_scatter_h suspends the vertices whose shadow ray enters such a mesh's bounds);
+ * "bvh8" (default 1): those walkers read the meshes' eight-wide compressed trees (csrc/hip/bvh8.hpp: wf_shadow_u8, wf_mesh_closest8,
+ *     the closest hits of the later ticks' rays included); 0, or a mesh the eight-wide form cannot hold: the four-wide wf_shadow_u;
+ * "sort_alive" (default -1: the library's choice, on in the scenes of the mesh kernels; 1 / 0): the paths that survive a tick's
+ *     shading in one sub-queue per hit prop (16), so that the waves of the kernel that scatters them stand on one surface each;
+ * "shadow_u_blocks" (default 4, 1-10): blocks per CU of the persistent mesh walkers.
+ * Within the precise mode the film is the same bits for every setting.
+ *
+ * Variant builds only (python -m zyg_amd.build --variant all --units 4,5,6,7,-1 -DZYG_VARIANTS=1 -> variants/lib_all.so; the shipped
+ * library answers -1): the kernels that measured slower on every BASELINE scene and the switches that turn a default off, kept for
+ * their tests and A/B tools (DESIGN.md section 4 has the numbers): "persistent" (wf_persistent), "fuse_tick" (wf_tick), "regenerate" /
+ * "regen_kslots" (wf_rscatter / wf_rgenerate / wf_rtrace), "mesh_closest" (the four-wide wf_mesh_closest), "compact_blocks";
+ * "mesh_closest8", "pack_prev", "hit_by_queue", "lazy_head", "pair_small", "split_materials", "split_nee", "fuse_pool",
+ * "pool_tick_sync" (all default 1; 0 = the layout of an earlier round). */
 int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
 /* Reads an option back, and what the library derived from the options and the uploaded scene (valid after zygpu_upload_scene):
  * "relaxed_units" 1 when the relaxed-arithmetic kernel units render this scene (option "precise" 0 and a scene they are inside

@@ -61,3 +61,37 @@ def engine(product_lib):
     e = zyg_amd.Engine(product_lib)
     yield e
     e.release()
+
+
+def _variant_library():
+    """variants/lib_all.so: the library with the kernels and options that lost their A/B (kernel_table.hpp ZYG_VARIANTS), built by
+    `python -m zyg_amd.build --variant all --units 4,5,6,7,-1 -DZYG_VARIANTS=1` from the same sources; None when it is absent or older than they."""
+    import zyg_amd
+    path = os.path.join(ROOT, "variants", "lib_all.so")
+    if not os.path.exists(path):
+        return None
+    src = os.path.join(ROOT, "zyg_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(d, f)) for d, _, files in os.walk(src) for f in files)
+    if os.path.getmtime(path) < newest and not os.environ.get("ZYG_VARIANT_LIB_ANY_AGE"):
+        return None
+    return zyg_amd.load_library(path)
+
+
+@pytest.fixture(scope="session")
+def variant_lib_or_none(product_lib):
+    return _variant_library()
+
+
+@pytest.fixture(scope="session")
+def variant_lib(variant_lib_or_none):
+    if variant_lib_or_none is None:
+        pytest.skip("variants/lib_all.so is not built for these sources (python -m zyg_amd.build --variant all --units 4,5,6,7,-1 -DZYG_VARIANTS=1)")
+    return variant_lib_or_none
+
+
+@pytest.fixture()
+def variant_engine(variant_lib):
+    import zyg_amd
+    e = zyg_amd.Engine(variant_lib)
+    yield e
+    e.release()

@@ -379,11 +379,12 @@ def test_glass(engine, oracle, integrator, objects):
 
 
 @pytest.mark.parametrize("scene", ["glass_box", "outdoor", "cornell"])
-def test_pool_kernel_options_render_the_same_film(engine, oracle, scene):
+def test_pool_kernel_options_render_the_same_film(variant_engine, oracle, scene):
     """The kernel layout options (zygpu.h: fuse_pool, split_nee, pool_tick_sync for the POOL scenes; lazy_head for them and for
     the plain Cornell box, where the hit records travel by queue position) choose between kernels that
     compute the same thing: every setting gives the default's film, bit for bit in the precise units (whose default film is the
     oracle's), inside the relaxed units' tolerance in theirs.  (The defaults are the fused / split forms: the others run nowhere else in the suite.)"""
+    engine = variant_engine  # (options of variant builds: conftest.py)
     w, h, spp = 96, 64, 3
 
     def render(precise, **options):
@@ -970,11 +971,13 @@ def test_shadow_catcher(engine, oracle, integrator, variant):
 
 # ---------------------------------------------------------------- the relaxed-arithmetic units (zygpu option "precise" = 0)
 
-def _render_mode(product_lib, build, w, h, spp, precise):
+def _render_mode(product_lib, build, w, h, spp, precise, **options):
     with zyg_amd.Engine(product_lib) as e:
         build(e)
         e.start_frame(0)
         e.set_option("precise", precise)
+        for name, value in options.items():
+            e.set_option(name, value)
         e.render_iterations(spp)
         e.synchronize()
         return e.download_film(w, h), e.resolve(w, h)
@@ -1132,30 +1135,32 @@ def test_coincident_glass_surfaces_need_the_precise_units(product_lib):
     floor's plane: a ray inside the box meets two surfaces at one distance, and whether it leaves the glass or meets the floor inside
     it first hangs on the last bit of two different intersection formulas.  The reference decides that by its own rounding and the
     precise units reproduce it (film == the oracle's, every Glass parity test); the relaxed units round otherwise and those paths go
-    another way: measured 1.3e-3 RMS at 256 spp against 1.5e-4 with the box 1 mm above the floor.  Here at 64 spp on a small frame:
-    lifting the box takes most of the relaxed-vs-precise difference away; option pool_relaxed = 0 gives such a scene the precise
-    units whatever option precise says."""
+    another way: measured 1.3e-3 RMS at 256 spp against 1.5e-4 with the box 1 mm above the floor.  Round 5: zygpu_upload_scene looks
+    for such surfaces (zygpu_scene_has_coincident_dielectric) and option pool_relaxed -1 (the default) keeps a scene that has them in
+    the precise units whatever option precise says: the un-lifted box renders the precise film with precise = 0; pool_relaxed = 1
+    forces the relaxed units (the measurement above: lifting the box takes most of the relaxed-vs-precise difference away)."""
     w, h, spp = 320, 180, 64
     glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)}
     result = {}
     for lift in (0.0, 1e-3):
         build = lambda e: scenes.cornell(e, w, h, spp, glass_objects=glass, box_lift=lift)
         pf, pi = _render_mode(product_lib, build, w, h, spp, 1)
-        rf, ri = _render_mode(product_lib, build, w, h, spp, 0)
+        rf, ri = _render_mode(product_lib, build, w, h, spp, 0, pool_relaxed=1)
         result[lift] = rms(pi, ri)
     print(f"relaxed vs precise, glass box on the floor {result[0.0]:.3e}, 1 mm above it {result[1e-3]:.3e}")
     assert result[1e-3] <= 0.5 * result[0.0], result
-    with zyg_amd.Engine(product_lib) as e:
-        scenes.cornell(e, w, h, spp, glass_objects=glass)
-        e.start_frame(0)
-        e.set_option("pool_relaxed", 0)
-        e.set_option("precise", 0)
-        assert 0 == e.get_option("relaxed_units") and 1 == e.get_option("pool_mode")
-        e.render_iterations(spp)
-        e.synchronize()
-        held = e.download_film(w, h)
     pf, _ = _render_mode(product_lib, lambda e: scenes.cornell(e, w, h, spp, glass_objects=glass), w, h, spp, 1)
-    assert np.array_equal(held, pf)
+    for lift, want_relaxed in ((0.0, 0), (1e-3, 1)):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, glass_objects=glass, box_lift=lift)
+            e.start_frame(0)
+            e.set_option("precise", 0)  # (pool_relaxed at its default: -1)
+            assert (0 if want_relaxed else 1) == e.get_option("coincident_dielectric") and 1 == e.get_option("pool_mode")
+            assert want_relaxed == e.get_option("relaxed_units")
+            if not want_relaxed:
+                e.render_iterations(spp)
+                e.synchronize()
+                assert np.array_equal(e.download_film(w, h), pf)  # the reference's bits, although the relaxed units were asked for
 
 
 @pytest.mark.parametrize("mode", ["iterations", "rows"])
@@ -1509,12 +1514,13 @@ def test_sorted_alive_queue_is_only_an_order(engine, oracle, variant):
 
 @pytest.mark.parametrize("material", ["lambert", "substitute"])
 @pytest.mark.parametrize("integrator", ["PTMIS", "PTDL", "PT"])
-def test_regenerating_kernels(engine, oracle, integrator, material):
+def test_regenerating_kernels(variant_engine, oracle, integrator, material):
     """Option regenerate (wavefront.hpp wf_rscatter / wf_rtrace): a pool of a few thousand slots, each of which takes the batch's next
     camera sample when its path ends; plain record arrays, no queues; the slot is no longer the sample's index (Params::regen_sample).
     The film is summed from the staging buffer in sample order, so in the precise units it is the tick loop's and the oracle's bit
     for bit, whatever the pool's size (here 1 K and 4 K slots for 27 648 samples of 4 iterations, so every slot carries several
     paths, and one larger than the batch)."""
+    engine = variant_engine  # (options of variant builds: conftest.py)
     w, h, spp = 96, 72, 4
     scenes.cornell(engine, w, h, spp, integrator=integrator, material=material)
     engine.start_frame(0)
@@ -1551,7 +1557,7 @@ def test_regenerating_kernels(engine, oracle, integrator, material):
 
 
 @pytest.mark.parametrize("variant", ["lambert", "regularize", "many_lights", "mesh_lights", "staged", "multi", "spheres", "ptdl", "stacked_lamps"])
-def test_previous_vertex_packed_into_the_first_line(engine, oracle, variant):
+def test_previous_vertex_packed_into_the_first_line(variant_engine, oracle, variant):
     """Option pack_prev (default on; wavefront.hpp PrevVertex): the previous vertex's origin / geometric normal / roughness, which the
     next vertex's emission pass needs for the light's pdf and the regularisation, travel in words of the path's first line that are
     dead meanwhile (the stale Sobol buffer, two spare lanes) instead of in two records of its second line.  The film is the same
@@ -1560,6 +1566,7 @@ def test_previous_vertex_packed_into_the_first_line(engine, oracle, variant):
     writer and reader:
     emission at hits with MIS (lamps seen by bounce rays), unoccluding lamps crossed by rays (stacked), mesh and sphere lights,
     regularize_roughness, the staged wf_nee / wf_extend kernels, multi-sample lights, PathtracerDL (which leaves the normal behind)."""
+    engine = variant_engine  # (options of variant builds: conftest.py)
     w, h, spp = 96, 72, 4
     kw = {"lambert": {}, "regularize": dict(material="substitute", regularize=0.75,
                                            overrides={"tall": scenes.substitute_full((0.9, 0.9, 0.9), roughness=0.05, metallic=1.0)}),
@@ -1618,3 +1625,28 @@ def test_many_props_past_the_first_table_size(engine, oracle, extra):
     assert engine.lib.zygpu_set_option(ctx, b"precise", 1) == 0
     # (8 samples per pixel: a path that an ulp sends another way weighs 1 / 8 of its pixel; the contract's number is for 256 spp)
     assert 0.0 < rms(relaxed, out[1]) <= 5e-3
+
+
+def test_a_batch_that_does_not_fit_the_free_memory_is_halved(product_lib, monkeypatch):
+    """zygpu_render sizes a batch by option batch_mpaths (a POOL batch of 64 M camera samples asks for ~190 GB) and failed
+    when the allocation did; now a batch is bounded by the device's free memory (with a tenth left over) and halved until its pool can be
+    allocated.  ZYG_POOL_ROOM_MB stands in for a nearly full device: 16 iterations of a small frame with room for about three of them
+    render in several batches, and the film is the one batch's, bit for bit (a batch boundary changes nothing: every (pixel, iteration)
+    is its own sample)."""
+    w, h, spp = 320, 180, 16
+
+    def render(glass):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, glass_objects={"sphere": scenes.glass(1.5)} if glass else None)
+            e.start_frame(0)
+            e.render_iterations(spp)
+            e.synchronize()
+            return e.download_film(w, h)
+
+    for glass in (False, True):
+        monkeypatch.delenv("ZYG_POOL_ROOM_MB", raising=False)
+        whole = render(glass)
+        monkeypatch.setenv("ZYG_POOL_ROOM_MB", "640" if glass else "96")  # ~3 KB / ~0.5 KB per camera sample, 57 600 samples per iteration
+        assert np.array_equal(render(glass), whole)
+        monkeypatch.setenv("ZYG_POOL_ROOM_MB", "1")  # not even one iteration: still one iteration per batch, by the allocation's own answer
+        assert np.array_equal(render(glass), whole)

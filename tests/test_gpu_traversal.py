@@ -155,10 +155,10 @@ def _film(product_lib, build, w, h, spp, **options):
 
 
 @pytest.mark.parametrize("scene", ["lambert", "substitute", "mesh", "three_lights"])
-def test_prop_table_and_persistent_kernels_give_the_same_film(product_lib, scene):
+def test_prop_table_and_persistent_kernels_give_the_same_film(product_lib, variant_lib_or_none, scene):
     """precise arithmetic: the wave-wide walk of the prop tables (default) == the per-lane tree walk (uniform_tlas = 0) ==
-    the persistent kernel with the path state in LDS (persistent = 1), bit for bit; with regeneration (more samples than
-    resident lanes) for the persistent one."""
+    the persistent kernel with the path state in LDS (persistent = 1: variant builds, conftest.py), bit for bit; with regeneration
+    (more samples than resident lanes) for the persistent one."""
     w, h, spp = 320, 180, 4
     build = {
         "lambert": lambda e: scenes.cornell(e, w, h, spp),
@@ -169,18 +169,20 @@ def test_prop_table_and_persistent_kernels_give_the_same_film(product_lib, scene
     base = _film(product_lib, build, w, h, spp, precise=1, uniform_tlas=0)
     assert np.isfinite(base).all() and base[..., :3].max() > 0
     assert np.array_equal(base, _film(product_lib, build, w, h, spp, precise=1, uniform_tlas=1))
-    assert np.array_equal(base, _film(product_lib, build, w, h, spp, precise=1, persistent=1))
+    if variant_lib_or_none is None:
+        return
+    assert np.array_equal(base, _film(variant_lib_or_none, build, w, h, spp, precise=1, persistent=1))
     # relaxed arithmetic: the same samples, but the compiler is free to fuse multiply-adds differently in the two kernel
     # families, so the films agree closely, not bit for bit
-    r0 = _film(product_lib, build, w, h, spp, precise=0)
-    r1 = _film(product_lib, build, w, h, spp, precise=0, persistent=1)
+    r0 = _film(variant_lib_or_none, build, w, h, spp, precise=0)
+    r1 = _film(variant_lib_or_none, build, w, h, spp, precise=0, persistent=1)
     assert np.isfinite(r1).all() and np.array_equal(r0[..., 3], r1[..., 3])
     close = np.isclose(r0, r1, rtol=1e-3, atol=1e-4).all(axis=-1)
     assert close.mean() > 0.98, close.mean()
 
 
 @pytest.mark.parametrize("material", ["lambert", "substitute"])
-def test_fused_tick_gives_the_same_film(product_lib, material):
+def test_fused_tick_gives_the_same_film(variant_lib, material):
     """Option fuse_tick (wf_tick: wf_scatter of vertex k and wf_trace_shade of vertex k + 1 in one launch) on a scene with a mesh
     above the wide-BLAS threshold (4096 triangles): in the relaxed units one block runs the any-hit and the closest-hit walk of the
     four-wide nodes back to back without a barrier; the two walks' parked children must not share LDS (kernels.hip: unit 5 keeps
@@ -189,18 +191,18 @@ def test_fused_tick_gives_the_same_film(product_lib, material):
     w, h, spp = 480, 270, 4
     build = lambda e: scenes.cornell(e, w, h, spp, material=material, boxes=False, mesh=scenes.displaced_sphere_mesh(n=96),
                                      mesh_position=scenes.MESH_CENTRE)
-    base = _film(product_lib, build, w, h, spp, precise=1)
-    assert np.array_equal(base, _film(product_lib, build, w, h, spp, precise=1, fuse_tick=1))
-    r0 = _film(product_lib, build, w, h, spp, precise=0)
-    r1 = _film(product_lib, build, w, h, spp, precise=0, fuse_tick=1)
+    base = _film(variant_lib, build, w, h, spp, precise=1)
+    assert np.array_equal(base, _film(variant_lib, build, w, h, spp, precise=1, fuse_tick=1))
+    r0 = _film(variant_lib, build, w, h, spp, precise=0)
+    r1 = _film(variant_lib, build, w, h, spp, precise=0, fuse_tick=1)
     assert np.isfinite(r1).all() and np.array_equal(r0[..., 3], r1[..., 3])
-    assert np.array_equal(r1, _film(product_lib, build, w, h, spp, precise=0, fuse_tick=1))
+    assert np.array_equal(r1, _film(variant_lib, build, w, h, spp, precise=0, fuse_tick=1))
     close = np.isclose(r0, r1, rtol=1e-3, atol=1e-4).all(axis=-1)
     assert close.mean() > 0.98, close.mean()
 
 
 @pytest.mark.parametrize("scene", ["sphere_lambert", "sphere_substitute", "mound", "four_lights"])
-def test_mesh_kernels_give_the_film_of_the_in_place_kernel(product_lib, scene):
+def test_mesh_kernels_give_the_film_of_the_in_place_kernel(product_lib, variant_lib_or_none, scene):
     """Option mesh_kernels (default on; relaxed units, scenes of the prop tables with a mesh above the wide-BLAS threshold):
     wf_scatter_h suspends the vertices whose shadow ray has to walk the large mesh, wf_shadow_u (persistent, its lanes fetch their
     own rays) walks it, the resume launches take the vertices up again; wf_mesh_closest (option mesh_closest) does the same for the
@@ -217,10 +219,14 @@ def test_mesh_kernels_give_the_film_of_the_in_place_kernel(product_lib, scene):
     base = _film(product_lib, build, w, h, spp, precise=0, mesh_kernels=0)
     assert np.isfinite(base).all() and base[..., :3].max() > 0
     # (bvh8 / mesh_closest8, both default on: the persistent walkers over the eight-wide compressed trees, bvh8.hpp)
-    for options in ({"mesh_kernels": 1, "bvh8": 0}, {"mesh_kernels": 1, "bvh8": 0, "mesh_closest": 1}, {"mesh_kernels": 1, "mesh_closest8": 0}, {"mesh_kernels": 1}):
-        film = _film(product_lib, build, w, h, spp, precise=0, **options)
+    # the four-wide closest-hit pass (mesh_closest) and the eight-wide walkers without theirs (mesh_closest8 = 0): variant builds
+    cases = [(product_lib, {"mesh_kernels": 1, "bvh8": 0}), (product_lib, {"mesh_kernels": 1})]
+    if variant_lib_or_none is not None:
+        cases += [(variant_lib_or_none, {"mesh_kernels": 1, "bvh8": 0, "mesh_closest": 1}), (variant_lib_or_none, {"mesh_kernels": 1, "mesh_closest8": 0})]
+    for lib, options in cases:
+        film = _film(lib, build, w, h, spp, precise=0, **options)
         assert np.isfinite(film).all() and np.array_equal(base[..., 3], film[..., 3])
-        again = _film(product_lib, build, w, h, spp, precise=0, **options)
+        again = _film(lib, build, w, h, spp, precise=0, **options)
         assert np.array_equal(film, again), (options, int((film != again).any(axis=-1).sum()))
         close = np.isclose(base, film, rtol=1e-3, atol=1e-4).all(axis=-1)
         assert close.mean() > 0.98, (options, close.mean())
@@ -268,7 +274,7 @@ def _patchwork_mesh(seed=5):
 
 
 @pytest.mark.parametrize("precise", [1, 0])
-def test_small_mesh_items_against_the_oracle(engine, oracle, precise):
+def test_small_mesh_items_against_the_oracle(engine, oracle, precise, variant_lib_or_none):
     """The relaxed units' test of the small meshes (unit-triangle frames, parallelogram halves as one item: dscene.hpp
     smallItemIntersect) reports the reference's primitive and barycentric coordinates whichever corner an item's frame starts at;
     option pair_small = 0 (every triangle its own item) gives the same answers."""
@@ -285,6 +291,12 @@ def test_small_mesh_items_against_the_oracle(engine, oracle, precise):
     assert on_mesh.mean() > 0.1 and len(np.unique(ref_hits[on_mesh, 3])) == 27  # every triangle is hit
     _bounded(out[3], ref_hits, ref_vis, 3)
     paired = out[3]
+    if variant_lib_or_none is None:  # (option pair_small: variant builds)
+        return
+    engine.release()
+    engine.__init__(variant_lib_or_none)
+    scenes.cornell(engine, 64, 48, 1, boxes=False, mesh=mesh, mesh_position=(0, 0, 0))
+    engine.start_frame(0)
     engine.set_option("pair_small", 0)
     engine.start_frame(0)  # the table is built when the scene is uploaded
     _, _, out = _both(engine, oracle, rays, precise=precise)

@@ -679,3 +679,32 @@ def test_focus_point_is_read(product_lib):
         scenes.cornell(e, 32, 24, 1, lens={"focus": {"point": [0.25, 0.75, 0.5], "distance": 2.5}})
         _, vd = e.compile()
         assert vd.lens_radius == 0.0 and vd.focus_distance == np.float32(2.5) and vd.aperture_shape == zyg_amd.NULL
+
+
+def test_coincident_dielectric_surfaces_are_found(product_lib):
+    """zygpu_scene_has_coincident_dielectric (what option pool_relaxed -1 decides with): a glass box standing ON the floor
+    (its bottom face in the floor Rectangle's plane), a glass box against the other box (mesh against mesh) are found; the same boxes
+    1 mm apart, a scene without Glass, a glass Sphere resting on the floor (a point of contact) are not."""
+    from zyg_amd import scenes
+    lib = product_lib
+    lib.zygpu_scene_has_coincident_dielectric.argtypes = [ctypes.POINTER(zyg_amd.SceneDesc)]
+    glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)}
+
+    def found(**kw):
+        with zyg_amd.Engine(lib) as e:
+            scenes.cornell(e, 32, 18, 1, **kw)
+            sd, _ = e.compile()
+            return lib.zygpu_scene_has_coincident_dielectric(ctypes.byref(sd))
+
+    assert 1 == found(glass_objects=glass)
+    assert 0 == found(glass_objects=glass, box_lift=1e-3)
+    assert 0 == found()
+    assert 0 == found(glass_objects={"sphere": scenes.glass(1.5)}, box_lift=1e-3)
+    with zyg_amd.Engine(lib) as e:  # the outdoor scene's glass box on the ground Rectangle
+        scenes.outdoor(e, 32, 18, 1, integrator="PTMIS", material="substitute", showcase=True)
+        sd, _ = e.compile()
+        assert 1 == lib.zygpu_scene_has_coincident_dielectric(ctypes.byref(sd))
+    with zyg_amd.Engine(lib) as e:
+        scenes.outdoor(e, 32, 18, 1, integrator="PTMIS", material="substitute", showcase=True, box_lift=1e-3)
+        sd, _ = e.compile()
+        assert 0 == lib.zygpu_scene_has_coincident_dielectric(ctypes.byref(sd))

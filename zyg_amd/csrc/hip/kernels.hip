@@ -34,6 +34,14 @@
 #define ZYG_UNIT_SYM(name) ZYG_CAT3(zyg_unit, ZYG_TU, _##name)
 #endif
 
+#if ZYG_VARIANTS
+#define ZYG_IS_PERSISTENT(kid) (kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W)
+#define ZYG_IS_REGENERATE(kid) (K_RGENERATE == kid)
+#else
+#define ZYG_IS_PERSISTENT(kid) false
+#define ZYG_IS_REGENERATE(kid) false
+#endif
+
 namespace zd {
 
 template <int UNIT>
@@ -52,8 +60,8 @@ static int launchIn(unsigned id, unsigned blocks, hipStream_t stream, const Para
             constexpr bool ts_u = K_TRACE_SHADE_PLAIN_FIRST_U == kid || K_TRACE_SHADE_PLAIN_U == kid ||              \
                                   (ZYG_TS_BLOCK_ALL && kid >= K_TRACE_SHADE_STATS_FIRST && kid <= K_TRACE_SHADE_PLAIN);      \
             constexpr bool ts_uw = K_TRACE_SHADE_PLAIN_FIRST_UW == kid || K_TRACE_SHADE_PLAIN_UW == kid;             \
-            constexpr bool persistent = kid >= K_PERSISTENT_LAMBERT && kid <= K_PERSISTENT_SUBST_W;                  \
-            constexpr bool regenerate = K_RGENERATE == kid;                                                          \
+            constexpr bool persistent = ZYG_IS_PERSISTENT(kid);                                                      \
+            constexpr bool regenerate = ZYG_IS_REGENERATE(kid);                                                      \
             hipLaunchKernelGGL(kernel, ts_u ? ts_u_grid : ts_uw ? ts_uw_grid : regenerate ? regen_grid : grid,       \
                                ts_u ? ts_u_block : ts_uw ? ts_uw_block : persistent ? persistent_block : regenerate ? regen_block : block, 0, stream, ZYG_UNPAREN args); \
             return 0;                                                                        \

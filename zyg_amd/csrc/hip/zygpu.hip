@@ -18,6 +18,14 @@
 #include "kernel_table.hpp"
 #include "wavefront.hpp"
 
+// Variant builds (kernel_table.hpp ZYG_VARIANTS): the kernels and the options that lost their A/B, for their tests and tools
+constexpr bool kVariants = 0 != ZYG_VARIANTS;
+#if ZYG_VARIANTS
+constexpr ZygKernelId kMeshClosest4 = K_MESH_CLOSEST;
+#else
+constexpr ZygKernelId kMeshClosest4 = K_MESH_CLOSEST8;  // (never launched: the four-wide pass needs option mesh_closest)
+#endif
+
 using namespace zd;
 
 // The wavefront kernels are compiled in ZYG_NUM_UNITS translation units per arithmetic mode (kernels.hip, kernel_table.hpp);
@@ -408,10 +416,12 @@ bool check(hipError_t e, const char* what) {
 
 struct DeviceBuffers {
     std::vector<void*> allocs;
+    size_t             bytes = 0;  // what the allocations hold
     ~DeviceBuffers() { release(); }
     void release() {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
+        bytes = 0;
     }
     template <typename T>
     bool upload(const T* src, size_t count, const T** out) {
@@ -420,6 +430,7 @@ struct DeviceBuffers {
         void*        d = nullptr;
         if (!check(hipMalloc(&d, bytes), "hipMalloc")) return false;
         allocs.push_back(d);
+        this->bytes += bytes;
         if (count && src && !check(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy")) return false;
         *out = static_cast<const T*>(d);
         return true;
@@ -429,10 +440,102 @@ struct DeviceBuffers {
         void* d = nullptr;
         if (!check(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc")) return false;
         allocs.push_back(d);
+        bytes += std::max<size_t>(count, 1) * sizeof(T);
         *out = static_cast<T*>(d);
         return true;
     }
 };
+
+// Whether a dielectric surface of the scene lies in the plane of another surface (a glass box standing on the floor, a pane against a
+// wall): zygpu_upload_scene asks for the POOL scenes.  Which of two coincident surfaces a ray meets first hangs on the last bit of
+// two different formulas; the reference decides it by its own rounding, the precise units reproduce that, the relaxed units round
+// otherwise and those paths go another way (1.3e-3 .. 2e-3 RMS at 256 spp instead of 1.5e-4: DESIGN.md section 2).  Looked for: a
+// triangle of a mesh with a Glass part, all three corners within eps of (a) a solid Rectangle's plane and over its area, or (b) an
+// axis-aligned plane that the mesh's bounds share with another solid mesh's bounds, where that mesh has a triangle too, with
+// overlapping extents.  Conservative towards "coincident" (the precise units are the safe answer).
+bool coincidentDielectric(const ZygpuSceneDesc* d) {
+    auto world = [](const ZygpuTrafo& t, const float* p, float* out) {
+        for (int a = 0; a < 3; ++a)
+            out[a] = t.position[a] + t.r[0][a] * (p[0] * t.r[0][3]) + t.r[1][a] * (p[1] * t.r[1][3]) + t.r[2][a] * (p[2] * t.r[2][3]);
+    };
+    auto solid = [&](uint32_t p) { return 0 != (d->props[p].flags & ZYGPU_PROP_SOLID) && 0 == (d->props[p].flags & ZYGPU_PROP_UNOCCLUDING); };
+    for (uint32_t g = 0; g < d->num_props; ++g) {
+        const ZygpuProp& gp = d->props[g];
+        if (ZYGPU_SHAPE_TRIANGLE_MESH != gp.shape || ZYGPU_NULL == gp.mesh || !solid(g)) continue;
+        const ZygpuMesh& gm = d->meshes[gp.mesh];
+        bool             glass = false;
+        for (uint32_t k = 0; k < gm.num_parts; ++k) glass = glass || ZYGPU_MAT_GLASS == d->materials[d->material_ids[gp.parts_start + k]].kind;
+        if (!glass) continue;
+        const ZygpuAabb& gb = d->aabbs[g];
+        float            reach = 1.f;
+        for (int a = 0; a < 3; ++a) reach = std::max(reach, std::max(std::fabs(gb.min[a]), std::fabs(gb.max[a])));
+        const float eps = 1e-5f * reach;
+        std::vector<float> gw;  // the glass mesh's corners in world space, on demand
+        auto corners = [&]() -> const std::vector<float>& {
+            if (gw.empty()) {
+                gw.resize(size_t(gm.num_triangles) * 9);
+                for (uint32_t t = 0; t < gm.num_triangles; ++t)
+                    for (int k = 0; k < 3; ++k) world(d->trafos[g], gm.positions + size_t(gm.triangles[size_t(t) * 3 + k]) * 3, &gw[size_t(t) * 9 + 3 * k]);
+            }
+            return gw;
+        };
+        for (uint32_t o = 0; o < d->num_props; ++o) {
+            if (o == g || !solid(o)) continue;
+            const ZygpuProp& op = d->props[o];
+            const ZygpuAabb& ob = d->aabbs[o];
+            bool             apart = false;
+            for (int a = 0; a < 3; ++a) apart = apart || gb.min[a] > ob.max[a] + eps || ob.min[a] > gb.max[a] + eps;
+            if (apart) continue;
+            if (ZYGPU_SHAPE_RECTANGLE == op.shape) {
+                const ZygpuTrafo& t = d->trafos[o];
+                const float*      n = t.r[2];
+                for (const float* v = corners().data(), *end = v + corners().size(); v < end; v += 9) {
+                    bool  in_plane = true;
+                    float lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
+                    for (int k = 0; k < 3 && in_plane; ++k) {
+                        const float rel[3] = {v[3 * k] - t.position[0], v[3 * k + 1] - t.position[1], v[3 * k + 2] - t.position[2]};
+                        in_plane = std::fabs(rel[0] * n[0] + rel[1] * n[1] + rel[2] * n[2]) <= eps;
+                        for (int e = 0; e < 2; ++e) {
+                            const float c = rel[0] * t.r[e][0] + rel[1] * t.r[e][1] + rel[2] * t.r[e][2];
+                            lo[e] = std::min(lo[e], c), hi[e] = std::max(hi[e], c);
+                        }
+                    }
+                    if (in_plane && lo[0] < 0.5f * t.r[0][3] && hi[0] > -0.5f * t.r[0][3] && lo[1] < 0.5f * t.r[1][3] && hi[1] > -0.5f * t.r[1][3]) return true;
+                }
+            } else if (ZYGPU_SHAPE_TRIANGLE_MESH == op.shape && ZYGPU_NULL != op.mesh) {
+                const ZygpuMesh& om = d->meshes[op.mesh];
+                for (int a = 0; a < 3; ++a) {
+                    for (float plane : {gb.min[a], gb.max[a]}) {
+                        if (std::fabs(plane - ob.min[a]) > eps && std::fabs(plane - ob.max[a]) > eps) continue;
+                        // the part of the plane that triangles of either mesh cover, as boxes over the other two axes
+                        auto covered = [&](const float* v, size_t count, float* lo, float* hi) {
+                            bool any = false;
+                            lo[0] = lo[1] = FLT_MAX, hi[0] = hi[1] = -FLT_MAX;
+                            for (size_t t = 0; t < count; ++t, v += 9) {
+                                if (std::fabs(v[a] - plane) > eps || std::fabs(v[3 + a] - plane) > eps || std::fabs(v[6 + a] - plane) > eps) continue;
+                                any = true;
+                                for (int k = 0; k < 3; ++k)
+                                    for (int e = 0; e < 2; ++e) {
+                                        const float c = v[3 * k + (a + 1 + e) % 3];
+                                        lo[e] = std::min(lo[e], c), hi[e] = std::max(hi[e], c);
+                                    }
+                            }
+                            return any;
+                        };
+                        float glo[2], ghi[2], olo[2], ohi[2];
+                        if (!covered(corners().data(), gm.num_triangles, glo, ghi)) continue;
+                        std::vector<float> ow(size_t(om.num_triangles) * 9);
+                        for (uint32_t t = 0; t < om.num_triangles; ++t)
+                            for (int k = 0; k < 3; ++k) world(d->trafos[o], om.positions + size_t(om.triangles[size_t(t) * 3 + k]) * 3, &ow[size_t(t) * 9 + 3 * k]);
+                        if (!covered(ow.data(), om.num_triangles, olo, ohi)) continue;
+                        if (glo[0] < ohi[0] && olo[0] < ghi[0] && glo[1] < ohi[1] && olo[1] < ghi[1]) return true;
+                    }
+                }
+            }
+        }
+    }
+    return false;
+}
 
 }  // namespace
 
@@ -490,7 +593,8 @@ struct ZygpuContext {
     bool          relaxed = false;
     // option "pool_relaxed" (default 1): with precise = 0, the POOL scenes (Glass, shadow catchers) run the relaxed units too; 0: they
     // get the precise units whatever the option says (relaxedUnits() below)
-    bool          pool_relaxed = true;
+    int           pool_relaxed = -1;  // -1: follow "precise" unless coincident_dielectric; 1: always; 0: never
+    bool          coincident_dielectric = false;  // zygpu_upload_scene: a Glass surface lies in another surface's plane (coincidentDielectric)
     // option "pool_tick_sync" (default 1): the POOL tick loop reads a level's queue lengths back and launches only the rounds that
     // have vertices, with exact grids (zygpu_render)
     bool          pool_tick_sync = true;
@@ -628,6 +732,18 @@ bool uploadLightTree(DeviceBuffers& m, const ZygpuLightTree& lt, DLightTree* out
 // `alive_keys`: sub-queues the alive queue must hold (1, or kAliveKeys when the sorted alive queue will run); `hit_q`: the hit records
 // by alive-queue position are wanted (option hit_by_queue in a scene that can use them).  Both are only allocated when asked for:
 // at the default batch the 16 sub-queues are 1.9 GiB and hit_q 1 GiB per context.
+// What ensurePool allocates per camera sample of a batch, roughly (its own allocations decide; this bounds a batch by the device's free memory)
+size_t poolBytesPerSample(const ZygpuContext* c, uint32_t rounds, uint32_t alive_keys, bool hit_q) {
+    if (c->pool_mode) {
+        // 2 x kPoolVertices vertices: the 256 B block + 4 unoccluding candidates (8 B each) + (catchers) three sums; the sample's line, staging,
+        // wf_light's records, time, eight extension queues + alive, shadow, heavy
+        const size_t vertex = 256 + kMaxUnoccludingCandidates * 8 + (c->catchers ? 48 : 0);
+        return 2 * kPoolVertices * vertex + 128 + 24 + 3 * kMaxNeeStored * 16 + 4 + 4 + (c->catchers ? 16 : 0) + (2 * kPoolVertices + 3) * 4 * 2;
+    }
+    return size_t(ZYG_POOL_STRIDE ? ZYG_POOL_STRIDE : 17 * 16) + ZYG_HIT_STRIDE + kMaxUnoccludingCandidates * 8 + 24 + 8 * std::max(1u, rounds) + 56 + 4 +
+           (4 + alive_keys) * 4 * 2 + (hit_q ? 64 : 0) + 48;
+}
+
 int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_keys, bool hit_q) {
     if (slots <= c->pool_capacity && rounds <= c->pool_rounds && c->pool_mode == c->pool_allocated && c->catchers == c->catchers_allocated &&
         alive_keys <= c->alive_keys_allocated && (!hit_q || c->hit_q))
@@ -836,7 +952,10 @@ int deviceErrorFlags(ZygpuContext* c) {
 // 1 mm above the ground (scenes.py box_lift), and a scene whose dielectric surfaces coincide with others renders the reference's
 // bits with precise = 1.
 // (a development library built without the precise units has nothing else to run them in)
-bool relaxedUnits(const ZygpuContext* c) { return c->relaxed && (!c->pool_mode || c->pool_relaxed || !modeAvailable(0)); }
+bool relaxedUnits(const ZygpuContext* c) {
+    const bool pool_follows = c->pool_relaxed > 0 || (c->pool_relaxed < 0 && !c->coincident_dielectric);
+    return c->relaxed && (!c->pool_mode || pool_follows || !modeAvailable(0));
+}
 
 void launchKernel(ZygpuContext* c, ZygKernelId id, unsigned blocks, const Params& P, uint32_t arg) {
     const int mode = relaxedUnits(c) ? 1 : 0, unit = kUnitOf[id];
@@ -941,6 +1060,8 @@ int zygpu_destroy(ZygpuContext* c) {
     delete c;
     return 0;
 }
+
+int zygpu_scene_has_coincident_dielectric(const ZygpuSceneDesc* d) { return d ? (coincidentDielectric(d) ? 1 : 0) : -1; }
 
 int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     if (!c || !d) return -1;
@@ -1071,6 +1192,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t p = 0; p < d->num_props; ++p)
         if (d->props[p].flags & ZYGPU_PROP_SHADOW_CATCHER) c->catchers = true;
     if (c->catchers) c->pool_mode = c->mesh_lights = true;
+    c->coincident_dielectric = c->pool_mode && coincidentDielectric(d);
     s.has_catcher = c->catchers ? 1u : 0u;
     c->subst_keys = 0;
     for (uint32_t p = 0; p < d->num_props; ++p) {
@@ -1593,15 +1715,36 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     // (gpurun_out/r04j, one call).
     const size_t   target_paths = (size_t(c->batch_mpaths) << 20) * (c->pool_mode ? 2 : 1);
     const uint32_t fit = uint32_t(std::max<size_t>(1, std::min<size_t>(num_iterations, target_paths / std::max<size_t>(npix, 1))));
-    const uint32_t num_batches = (num_iterations + fit - 1u) / fit;
-    const uint32_t per_batch = one_shot ? 1u : (num_iterations + num_batches - 1u) / num_batches;
+    uint32_t       num_batches = (num_iterations + fit - 1u) / fit;
+    uint32_t       per_batch = one_shot ? 1u : (num_iterations + num_batches - 1u) / num_batches;
     // NEE rounds per vertex = the most lights the tree can pick (light_tree.zig:249: at most 64)
     const bool     nee = ZYGPU_INTEGRATOR_PT != v.integrator && c->num_lights > 0;
     const uint32_t rounds = nee ? std::min<uint32_t>(c->num_lights, 64u) : 0u;
     // (supersets of the conditions the batch loop below decides with: what may run must have its arrays)
     const bool want_sorted = !c->pool_mode && (c->sort_alive > 0 || (c->sort_alive < 0 && c->large_mesh && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels));
     const bool want_hit_q = c->hit_by_queue && !c->pool_mode;
-    if (0 != ensurePool(c, npix * per_batch, rounds, want_sorted ? kAliveKeys : 1u, want_hit_q)) return -1;
+    // A batch that the device's memory does not hold is halved until it does (a POOL batch of 64 M samples asks for ~190 GB;
+    // a second context, torch's caching allocator, zygpu_measure_copy's 4 GiB or a part with less HBM may be in the way): first by the
+    // free memory (what the pool holds now is given back when it grows) with a tenth of it left over, then by the allocation's own answer.
+    if (npix * per_batch > c->pool_capacity) {
+        size_t free_b = 0, total_b = 0;
+        if (hipSuccess == hipMemGetInfo(&free_b, &total_b)) {
+            size_t room = size_t(double(free_b + c->pool_mem.bytes) * 0.9);
+            if (const char* e = std::getenv("ZYG_POOL_ROOM_MB")) room = std::min(room, size_t(std::max(1, std::atoi(e))) << 20);  // (tests)
+            const size_t each = poolBytesPerSample(c, rounds, want_sorted ? kAliveKeys : 1u, want_hit_q);
+            while (per_batch > 1u && npix * per_batch * each > room) per_batch = (per_batch + 1u) / 2u;
+        }
+    }
+    for (;;) {
+        if (0 == ensurePool(c, npix * per_batch, rounds, want_sorted ? kAliveKeys : 1u, want_hit_q)) break;
+        if (per_batch <= 1u) {
+            g_error = "zygpu_render: the path pool of one iteration of these rows does not fit the device's free memory (" + g_error + ")";
+            return -1;
+        }
+        per_batch = (per_batch + 1u) / 2u;
+    }
+    num_batches = (num_iterations + per_batch - 1u) / per_batch;
+    (void)num_batches;
     // AOVs: the staged aov.Value of every sample, and the kernel instantiations that write it (the MESHL ones)
     struct MeshlOverride {
         ZygpuContext* c;
@@ -1733,7 +1876,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         P.lazy_head = (c->lazy_head && nullptr != P.hit_q) ? 1u : 0u;
         P.alive_key_mask = ~0u;
         const bool walk8 = c->bvh8 && c->bvh8_ready;
-        const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && (c->mesh_closest || (walk8 && c->mesh_closest8 && c->mesh_kernels)) &&
+        const bool mesh_pass = wide && c->huge_mesh && relaxedUnits(c) && ((kVariants && c->mesh_closest) || (walk8 && c->mesh_closest8 && c->mesh_kernels)) &&
                                c->fuse_trace_shade && !c->fuse_tick && !c->persistent;
         // the eight-wide walker takes the later ticks' rays only: the camera rays stay in the fused first tick (coherent, and generated in
         // the kernel that traces them: what wf_generate + the queue cost the four-wide form of this pass, which keeps its round-3 shape)
@@ -1743,6 +1886,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
             HIP_OK(hipMemsetAsync(&c->ctl->mesh_fetch, 0, sizeof(uint32_t), c->stream));
             launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
         }
+#if ZYG_VARIANTS
         if (c->regenerate && plain_in_place && !wide && !one_shot && !c->fuse_tick && !c->persistent) {
             // the regenerating kernels (wavefront.hpp wf_rscatter / wf_rgenerate / wf_rtrace): a small pool whose slots are all alive; a
             // tick = scatter the living, start new paths in the free slots, closest hit + first shading pass, the second shading pass;
@@ -1815,6 +1959,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                              blocks, P, num_paths);
             });
         } else
+#endif
         for (uint32_t t = 0; t < ticks; ++t) {
             if (c->pool_mode) {
                 // one level of every sample's vertex pool: round k = vertex k of the level, in order (shared samplers)
@@ -1908,7 +2053,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 P.mesh_pass = mesh_pass_now ? (walk8 ? 2u : 1u) : 0u;
                 if (mesh_pass_now) {
                     // the rays that enter a large mesh's bounds first, in the persistent walker (timed with the trace kernel)
-                    timedLaunch(c, 0, [&] { launchKernel(c, walk8 ? K_MESH_CLOSEST8 : K_MESH_CLOSEST, persistentGrid(c, grid.x, walk8 ? unsigned(c->shadow_u_blocks) : 5u), P, 0u); });
+                    timedLaunch(c, 0, [&] { launchKernel(c, walk8 ? K_MESH_CLOSEST8 : kMeshClosest4, persistentGrid(c, grid.x, walk8 ? unsigned(c->shadow_u_blocks) : 5u), P, 0u); });
                 }
                 timedLaunch(c, 0, [&] {
                     if (0 == t && !mesh_pass_now) {
@@ -2302,6 +2447,17 @@ int zygpu_measure_copy(ZygpuContext* c, uint64_t bytes, uint32_t repeats, double
 
 int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
     if (!c || !name) return -1;
+    // the options of the shipped library: "precise", "kernel_timing", "batch_mpaths", "pool_relaxed", "nee_in_place", "uniform_tlas",
+    // "mesh_kernels", "bvh8", "sort_alive", "tick_sync", "shadow_u_blocks", "fuse_trace_shade".  The others below switch off something
+    // that is on by default, or on something that measured slower on every BASELINE scene: variant builds only (ZYG_VARIANTS), for
+    // the tests and tools that compare them; the shipped library answers -1 to their names.
+    static const char* const kVariantOnly[] = {"compact_blocks", "fuse_tick", "persistent", "regenerate", "regen_kslots", "mesh_closest", "mesh_closest8", "hit_by_queue", "lazy_head", "pack_prev", "pair_small", "split_materials", "split_nee", "fuse_pool", "pool_tick_sync"};
+    if (!kVariants)
+        for (const char* v : kVariantOnly)
+            if (0 == std::strcmp(name, v)) {
+                g_error = std::string("option \"") + name + "\" exists in variant builds of libzyg_amd.so only (python -m zyg_amd.build --variant all ... -DZYG_VARIANTS=1)";
+                return -1;
+            }
     if (0 == std::strcmp(name, "kernel_timing")) {
         c->timing = 0 != value;
         return 0;
@@ -2337,7 +2493,7 @@ int zygpu_set_option(ZygpuContext* c, const char* name, int value) {
         return 0;
     }
     if (0 == std::strcmp(name, "pool_relaxed")) {
-        c->pool_relaxed = 0 != value;
+        c->pool_relaxed = value < 0 ? -1 : (value ? 1 : 0);
         return 0;
     }
     if (0 == std::strcmp(name, "pool_tick_sync")) {
@@ -2442,6 +2598,7 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"fuse_trace_shade", c->fuse_trace_shade ? 1 : 0},
                  {"nee_in_place", c->nee_in_place ? 1 : 0},
                  {"mesh_kernels", c->mesh_kernels ? 1 : 0},
+                 {"variants", kVariants ? 1 : 0},
                  {"mesh_closest", c->mesh_closest ? 1 : 0},
                  {"bvh8", c->bvh8 ? 1 : 0},
                  {"mesh_closest8", c->mesh_closest8 ? 1 : 0},
@@ -2455,7 +2612,8 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"persistent", c->persistent ? 1 : 0},
                  {"fuse_tick", c->fuse_tick ? 1 : 0},
                  {"uniform_tlas", c->uniform_tlas ? 1 : 0},
-                 {"pool_relaxed", c->pool_relaxed ? 1 : 0},
+                 {"pool_relaxed", c->pool_relaxed},
+                 {"coincident_dielectric", c->coincident_dielectric ? 1 : 0},
                  {"pool_tick_sync", c->pool_tick_sync ? 1 : 0},
                  {"split_nee", c->split_nee ? 1 : 0},
                  {"fuse_pool", c->fuse_pool ? 1 : 0},
