@@ -387,9 +387,11 @@ def test_pool_kernel_options_render_the_same_film(variant_engine, oracle, scene)
     engine = variant_engine  # (options of variant builds: conftest.py)
     w, h, spp = 96, 64, 3
 
+    library = engine.lib
+
     def render(precise, **options):
         engine.release()
-        engine.__init__(engine.lib)
+        engine.__init__(library)
         if "outdoor" == scene:
             scenes.outdoor(engine, w, h, spp, integrator="PTMIS", material="substitute", showcase=True, max_depth=10,
                            mesh=scenes.heightfield_mesh(48, size=1.2, height=0.5), sky="canopy", sun_radius=0.05)
@@ -1102,8 +1104,8 @@ def _relaxed_against_the_oracle(engine, oracle, w, h, spp, points, camera, threa
 def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
     """The kernels bench.py times (option precise = 0: the wave-wide prop-table walk, constant-block triangles, the quantised
     four-wide BLAS with its LDS stack, the persistent mesh kernels; for the glass box the POOL kernels' relaxed units) against the
-    CPU oracle directly, at 1920x1080 and the configuration's 256 spp: RMS <= 1e-3, north_star's number, on three bands of 64 rows
-    each (3.5 % of the frame per band): through the object, its shadow or caustic, a wall; every band by itself inside the tolerance.
+    CPU oracle directly, at 1920x1080 and the configuration's 256 spp: RMS <= 1e-3, north_star's number, on three bands of 32 rows
+    each (1.7 % of the frame per band): through the object, its shadow or caustic, a wall; every band by itself inside the tolerance.
     Glass: the boxes stand 1 mm above the floor (box_lift), as in bench.py: a glass box ON the floor has its bottom face in the
     floor's plane, and the two coincident surfaces are told apart by the last bit (test_coincident_glass_surfaces_need_the_precise_units)."""
     w, h, spp = 1920, 1080, 256
@@ -1117,7 +1119,8 @@ def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
         scenes.cornell(engine, w, h, spp, integrator="PTMIS", box_subdivide=2)
     else:
         scenes.cornell(engine, w, h, spp, integrator="PTMIS", material="substitute" if "substitute" == config else "lambert")
-    _relaxed_against_the_oracle(engine, oracle, w, h, spp, _CORNELL_BANDS.get(config, _CORNELL_BANDS["cornell"]), _CORNELL_CAMERA)
+    # (bands of 32 rows since round 5: 61 440 pixels x 256 spp each; the oracle's share of the GPU suite's time halves)
+    _relaxed_against_the_oracle(engine, oracle, w, h, spp, _CORNELL_BANDS.get(config, _CORNELL_BANDS["cornell"]), _CORNELL_CAMERA, rows=32)
 
 
 def test_relaxed_arithmetic_meets_the_contract_at_config4(engine, oracle):
