@@ -1846,12 +1846,15 @@ __global__ void __launch_bounds__(256) wf_pool_reset(Params P) {  // one block
     queueReset(&P.ctl->heavy_count[cur]);
 }
 
-template <bool WIDEC>
-__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_POOL_WAVES) wf_trace_shade_pool(Params P) {
+// FIRST (round 5): the batch's first tick generates its camera samples itself (wf_generate<POOL>'s body: entry i is slot i, `first_paths` of
+// them) right in front of their trace: the sample's two lines are still in the caches when the trace reads them, and wf_generate's launch
+// and the round trip through the extension queue are gone (the outdoor scene at 3840x2160: wf_generate was 6 % of the frame).
+template <bool WIDEC, bool FIRST = false>
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_POOL_WAVES) wf_trace_shade_pool(Params P, uint32_t first_paths) {
     const uint32_t cur = P.parity;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t       at;
-    const uint32_t n = queueOpen(extCount<true>(P, cur, P.round), P.queue_capacity, i, at);
+    uint32_t       at = i;
+    const uint32_t n = FIRST ? first_paths : queueOpen(extCount<true>(P, cur, P.round), P.queue_capacity, i, at);
     if (0 == i) P.ctl->bound[cur] = n;
     if (blockIdx.x * blockDim.x >= n) return;  // (whole blocks take part in queuePush)
     Counters     cnt{0, 0, 0};
@@ -1860,7 +1863,12 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_POOL_WAVES) wf_
     bool     alive = false, defer = false;
     uint32_t slot = 0;
     if (i < n) {
-        slot = extQueue<true>(P, cur, P.round)[at];  // a vertex index
+        if (FIRST) {
+            slot = i;
+            generatePath<true, true>(P, slot);
+        } else {
+            slot = extQueue<true>(P, cur, P.round)[at];  // a vertex index
+        }
         const float4   o = P.pool.ray_o[slot], d = P.pool.ray_d[slot];
         const uint32_t meta = P.pool.vmeta.get(slot);
         const uint32_t depth = (meta >> 3) & 31u, flags = (meta >> 13) & 63u;

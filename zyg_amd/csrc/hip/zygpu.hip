@@ -1849,9 +1849,11 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         HIP_OK(hipMemsetAsync(&c->ctl->heavy_count[0], 0, 2 * sizeof(QueueCounts), c->stream));
         // the fused first tick generates the camera rays itself
         const bool generate_in_trace = !c->pool_mode && c->fuse_trace_shade;
+        // POOL: the complete instantiations' fused kernel generates the camera samples of the first tick itself (wf_trace_shade_pool<.., FIRST>)
+        const bool pool_first = c->pool_mode && c->fuse_pool && !c->stats && (c->mesh_lights || c->multi_sample_lights);
         if (c->pool_mode) {
             HIP_OK(hipMemsetAsync(&c->ctl->ext_pool_count[0][0], 0, sizeof(QueueCounts) * kPoolVertices, c->stream));
-            launchKernel(c, K_GENERATE_POOL, (num_paths + 255) / 256, P, num_paths);
+            if (!pool_first) launchKernel(c, K_GENERATE_POOL, (num_paths + 255) / 256, P, num_paths);
         } else if (!generate_in_trace) {
             launchKernel(c, K_GENERATE, (num_paths + 255) / 256, P, num_paths);
         }
@@ -1970,7 +1972,9 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 // 2 KB of scratch per lane are set up whether or not a wave finds an entry): 51 rounds per batch,
                 // 8 % of the outdoor scene's frame at 3840x2160 (profiles/r04a_cfg4_launch_times.txt).
                 uint32_t round_entries[kPoolVertices] = {num_paths, num_paths, num_paths, num_paths};
-                if (c->pool_tick_sync) {
+                if (0 == t && pool_first) {  // (nothing has been queued: the first tick's vertices are the camera samples)
+                    round_entries[1] = round_entries[2] = round_entries[3] = 0;
+                } else if (c->pool_tick_sync) {
                     HIP_OK(hipMemcpyAsync(c->host_count, &c->ctl->ext_pool_count[P.parity][0], sizeof(QueueCounts) * kPoolVertices, hipMemcpyDeviceToHost, c->stream));
                     HIP_OK(hipStreamSynchronize(c->stream));
                     uint32_t all = 0;
@@ -1982,7 +1986,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                     if (0 == all) break;
                 }
                 for (uint32_t k = 0; k < kPoolVertices; ++k) {
-                    if (c->pool_tick_sync && k > 0 && 0 == round_entries[k]) continue;  // (round 0 also prepares the next level's queues)
+                    if ((c->pool_tick_sync || (0 == t && pool_first)) && k > 0 && 0 == round_entries[k]) continue;  // (round 0 also prepares the next level's queues)
                     const dim3 grid((std::max(round_entries[k], 1u) + 255u) / 256u);    // (shadows the batch's: this round's entries)
                     P.round = k;
                     // the plain instantiations (Rectangle / mesh geometry, single-sample Rectangle lights) or the full ones
@@ -1994,7 +1998,8 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                         else if (plain) launchKernel(c, K_INTERSECT_PLAIN_POOL, grid.x, P, 0u);
                         else if (fused) {
                             launchKernel(c, K_POOL_RESET, 1u, P, 0u);
-                            launchKernel(c, c->wide_mesh ? K_TRACE_SHADE_POOL_WIDE : K_TRACE_SHADE_POOL, grid.x, P, 0u);
+                            if (0 == t && pool_first) launchKernel(c, c->wide_mesh ? K_TRACE_SHADE_POOL_FIRST_WIDE : K_TRACE_SHADE_POOL_FIRST, grid.x, P, num_paths);
+                            else launchKernel(c, c->wide_mesh ? K_TRACE_SHADE_POOL_WIDE : K_TRACE_SHADE_POOL, grid.x, P, 0u);
                         } else launchKernel(c, c->wide_mesh ? K_INTERSECT_EXTRA_POOL_WIDE : K_INTERSECT_EXTRA_POOL, grid.x, P, 0u);
                     });
                     timedLaunch(c, 1, [&] {
