@@ -126,7 +126,7 @@ def test_missing_files_fail_loudly(product_lib, tmp_path):
 
 
 _REFUSED = {
-    "Scatterer": {"type": "Scatterer", "prototypes": []},
+    "animated \"Scatterer\"": {"type": "Scatterer", "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]}, "prototypes": []},
     "animated \"Instancer\"": {"type": "Instancer", "animation": {"keyframes": [{"time": 0, "transformation": {"position": [0, 0, 0]}}]},
                               "prototypes": [{"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"]}],
                               "instances": {"prototypes": [0], "transformations": [{}]}},
@@ -205,6 +205,33 @@ def test_instancer_is_flattened_into_props(product_lib, tmp_path):
         assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[6] == b[6], name
         assert np.array_equal(a[1], b[1]), name
     assert 5 == len(compiled["flat"][0])  # camera, lamp, three instances: no prop for a prototype
+
+
+def test_scatterer_instances_are_props_of_the_scene(product_lib, tmp_path):
+    """A Scatterer (scene_loader.zig:225-227, 260-262, 561-610): a node without an entity of its own whose children are loaded like any
+    node's; then its prototypes (not rendered themselves) are instantiated: instance i = a prop with prototype[indices[i]]'s shape and
+    materials and the transformation scatterer o transformations[i], created behind the node's children.  The scene compiles to the
+    arrays of one that names those props directly below a Group with the scatterer's transformation."""
+    scatter_t = {"position": [-0.5, 0, 2], "rotation": [0, -20, 0], "scale": [1.5, 1.5, 1.5]}
+    instances = [{"position": [-1, 0.5, 0]}, {"position": [1, 0.5, 0], "rotation": [0, 45, 0], "scale": [0.5, 1, 0.5]}, {"position": [0, 2, 0]}]
+    child = {"type": "Prop", "shape": {"type": "Disk"}, "materials": ["red"], "transformation": {"position": [0, 0.1, 0], "rotation": [90, 0, 0]}}
+    scatterer = {"type": "Scatterer", "transformation": scatter_t, "entities": [child],
+                 "prototypes": [{"type": "Prop", "shape": {"type": "Sphere"}, "materials": ["grey"], "transformation": {"position": [9, 9, 9]}},
+                                {"type": "Prop", "shape": {"type": "Cube"}, "materials": ["red"]}],
+                 "instances": {"prototypes": [0, 1, 5], "transformations": instances}}
+    kinds = [{"shape": {"type": "Sphere"}, "materials": ["grey"]}, {"shape": {"type": "Cube"}, "materials": ["red"]}, {"shape": {"type": "Sphere"}, "materials": ["grey"]}]
+    flat = {"materials": _MATERIALS,
+            "entities": [_LAMP, {"type": "Group", "transformation": scatter_t,
+                                 "entities": [child] + [dict({"type": "Prop", "transformation": t}, **k) for k, t in zip(kinds, instances)]}]}
+    compiled = {}
+    for name, scene in (("scatterer", {"materials": _MATERIALS, "entities": [_LAMP, scatterer]}), ("flat", flat)):
+        with zyg_amd.Engine(product_lib) as e:
+            assert e.lib.su_ext_load_take(_write_take(tmp_path, scene, name)) == 0, name
+            compiled[name] = _compiled(e)
+    a, b = compiled["scatterer"], compiled["flat"]
+    assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[6] == b[6]
+    assert np.array_equal(a[1], b[1])
+    assert 6 == len(b[0])  # camera, lamp, the child, three instances: no prop for a prototype
 
 
 def test_animation_keyframes_become_interpolation_frames(product_lib, tmp_path):

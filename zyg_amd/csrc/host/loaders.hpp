@@ -8,7 +8,7 @@
 // File names resolve against the directory of the file that mentions them, then the take's directory (the mount stack of
 // core/file/system.zig, reduced to these two levels).  Sky entities create the sun and the sky (engine.cpp createSky; the bake's tables are a
 // procedural stand-in unless the client hands them over).  Refused by name (the load fails, nothing is skipped in silence):
-// scatterers.  Instancers are flattened into props, animations resampled per frame by the engine.  glTF 2 scene files (.gltf + .bin,
+// scatterers (their instances are props of the scene).  Instancers are flattened into props, animations resampled per frame by the engine.  glTF 2 scene files (.gltf + .bin,
 // materials without image textures) are read as util/gltf_loader.zig reads them.  Not read: gzip-compressed files.
 #pragma once
 
@@ -299,10 +299,12 @@ class TakeLoader {
             }
             Transformation world;
             int            node = -1;
+            scatterer = false;
             if (!loadEntity(e, parent, local_materials, dir, world, node)) {
                 if (!error.empty()) return false;  // something this build cannot render: never skipped in silence
                 continue;                          // scene_loader.zig:220 `catch continue` (an entity without type or shape)
             }
+            const bool is_scatterer = scatterer;
             if (const JsonValue* children = e.get("entities")) {
                 const int outer = parent_node_;
                 parent_node_ = node;  // (-1 below a static entity of a static parent)
@@ -310,9 +312,11 @@ class TakeLoader {
                 parent_node_ = outer;
                 if (!ok) return false;
             }
+            if (is_scatterer && !instantiate(e, world, local_materials, dir)) return false;  // (behind the children, scene_loader.zig:219-227)
         }
         return true;
     }
+    bool scatterer = false;  // loadEntity: the entity it has just read is a "Scatterer"
     // What the reference's loader reads and this build does not render fails the load by name: an entity type (scene_loader.zig:
     // 252-264), or a key that changes the image (`animation`, scene_graph.zig:184-203).  su_ext_load_take logs the message at error
     // level and returns -1.
@@ -351,7 +355,10 @@ class TakeLoader {
         } else if (type->str == "Instancer") {
             return loadInstancer(v, parent, local_materials, dir, world);
         } else if (type->str == "Scatterer") {
-            return unsupported("a \"Scatterer\" entity");
+            // loadScatterer (scene_loader.zig:561-610, called once the node's children are loaded: 225-227): a node without an entity of
+            // its own; its prototypes and instances are an Instancer's, the instances plain props of the scene below this node
+            if (v.get("animation") || parent_node_ >= 0) return unsupported("an animated \"Scatterer\"");
+            scatterer = true;
         }  // any other type is a node without an entity: its transformation applies to its children (scene_loader.zig:241-264)
         Transformation local = identity();
         if (const JsonValue* t = v.get("transformation")) readTransformation(*t, local);
@@ -452,8 +459,8 @@ class TakeLoader {
                 for (const JsonValue& pv : ps->arr) {
                     const JsonValue* type = pv.get("type");
                     if (!type || JsonValue::String != type->type) continue;  // loadEntity's Error.UndefinedType: `catch continue`
-                    if (type->str != "Prop") return unsupported("an Instancer prototype of type \"" + type->str + "\"");
-                    if (pv.get("animation") || pv.get("entities")) return unsupported("an Instancer prototype with an animation or children");
+                    if (type->str != "Prop") return unsupported("an Instancer prototype (or a Scatterer's) of type \"" + type->str + "\"");
+                    if (pv.get("animation") || pv.get("entities")) return unsupported("an Instancer prototype (or a Scatterer's) with an animation or children");
                     Prototype p;
                     if (!readProp(pv, local_materials, dir, false, p.src)) continue;  // Error.UndefinedShape
                     p.visibility = pv.get("visibility");
