@@ -2504,6 +2504,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST_WAVES) wf_mesh
 #ifndef ZYG_U8_POSTPONE
 #define ZYG_U8_POSTPONE 4  // of 64 lanes
 #endif
+#ifndef ZYG_U8_EAGER
+#define ZYG_U8_EAGER 0  // 1: a lane with a node to look at takes its node step every iteration, parking what is left of its triangle group
+#endif
 #ifndef ZYG_U8_STEPS
 #define ZYG_U8_STEPS 16
 #endif
@@ -2565,7 +2568,13 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_SHADOW_U8_WAVES) wf_shadow_
         }
 #pragma unroll 1
         for (int it = 0; it < ZYG_U8_STEPS; ++it) {
-            if (have && walk.nodePending() && !walk.trianglesPending()) walk.nodeStep(local.min_t, local.max_t);  // (a node step makes a new triangle group)
+            if (have && walk.nodePending()) {  // (a node step makes a new triangle group: an unfinished one waits on the stack meanwhile)
+                if (ZYG_U8_EAGER && walk.trianglesPending() && walk.stack.sp < kStack8Lds - 4) {
+                    walk.stack.push(walk.tg);
+                    walk.tg.y = 0u;
+                }
+                if (!walk.trianglesPending()) walk.nodeStep(local.min_t, local.max_t);
+            }
             const bool               tri = have && walk.trianglesPending();
             const unsigned long long tri_lanes = __ballot(tri);
             if (tri_lanes) {
@@ -2657,7 +2666,13 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_MESH_CLOSEST8_WAVES) wf_mes
         }
 #pragma unroll 1
         for (int it = 0; it < ZYG_U8_STEPS; ++it) {
-            if (have && walk.nodePending() && !walk.trianglesPending()) walk.nodeStep(local.min_t, local.max_t);  // (a node step makes a new triangle group)
+            if (have && walk.nodePending()) {  // (a node step makes a new triangle group: an unfinished one waits on the stack meanwhile)
+                if (ZYG_U8_EAGER && walk.trianglesPending() && walk.stack.sp < kStack8Lds - 4) {
+                    walk.stack.push(walk.tg);
+                    walk.tg.y = 0u;
+                }
+                if (!walk.trianglesPending()) walk.nodeStep(local.min_t, local.max_t);
+            }
             const bool               tri = have && walk.trianglesPending();
             const unsigned long long tri_lanes = __ballot(tri);
             if (tri_lanes) {
