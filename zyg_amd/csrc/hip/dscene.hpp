@@ -1170,6 +1170,38 @@ struct Walk8 {
     }
 };
 
+// The eight-wide tree walked to the end by one lane (the kernels that are not the persistent walkers: a mesh of the mesh kernels met by
+// wf_trace_shade's front entries and first tick, and by the POOL scenes' per-lane walks): found(reference, t, u, v) for every hit
+// inside the ray's range; `any`: stop at the first one.
+// Measured (round 5, same call): the any-hit walks of the per-lane tree walkers (wf_light / wf_scatter of the POOL scenes) gain 7 % on the
+// outdoor scene with configs[2]'s sphere (scatter stage 294 -> 272 ms per 2 steps); the closest-hit walk loses 5 % there (205 -> 215)
+// and the prop-table kernels lose with either (cornell_mesh 352 -> 344: the code sits in wf_scatter_h, whose large-mesh rays go to the
+// persistent walker anyway).  Bit 0: the any-hit walk of the per-lane tree walkers; bit 1: the closest-hit walks; bit 2: the
+// prop-table kernels' any-hit walk.
+#ifndef ZYG_WALK8_INLINE
+#define ZYG_WALK8_INLINE 1
+#endif
+template <bool ANY, typename Found>
+ZD bool bvh8Walk(const DMesh& mesh, Ray& ray, Found&& found) {
+    GroupSpill spill;
+    Walk8      walk(spill);
+    walk.start(mesh, ray);
+    for (;;) {
+        if (walk.nodePending() && !walk.trianglesPending()) walk.nodeStep(ray.min_t, ray.max_t);
+        while (walk.trianglesPending()) {
+            f3       a, b, c;
+            uint32_t reference;
+            float    t, u, v;
+            walk.nextTriangle(a, b, c, reference);
+            if (triangleIntersect(ray, a, b, c, t, u, v) && found(reference, t, u, v) && ANY) return true;
+        }
+        if (!walk.nodePending()) {
+            if (0 == walk.stack.sp) return false;
+            walk.adopt(walk.stack.pop());
+        }
+    }
+}
+
 // The any-hit form of the wide walk (shadow rays): the order the children are visited in does not change the answer, so nothing
 // is sorted and no entry distance is kept: a parked child is a reference and a count.
 template <typename Leaf>
@@ -1243,6 +1275,18 @@ ZD bool meshIntersect(const DMesh& mesh, Ray& local_ray, Hit& hit, Counters& cnt
         return false;
     };
     // the wide re-layout where the mesh has one (large meshes) and nothing is counted: the counters are the BVH2 walk's
+    if ((ZYG_WALK8_INLINE & 2) && !STATS && WIDE && mesh.nodes8) {  // (measured slower than the four-wide walk here: closest hits keep it)
+        bvh8Walk<false>(mesh, local_ray, [&](uint32_t reference, float t, float u, float v) {
+            if ((t < local_ray.max_t || kNull == primitive || reference < primitive) && accept(reference, u, v)) {
+                local_ray.max_t = t;
+                ht = t;
+                hu = u;
+                hv = v;
+                primitive = reference;
+            }
+            return false;
+        });
+    } else
 #if ZYG_BVH4Q
     if (!STATS && WIDE) bvh4qWalk(mesh.nodes4q, local_ray, leaf);
 #else
@@ -1269,7 +1313,7 @@ ZD void meshInterpolateUv(const DMesh& mesh, uint32_t prim, float u, float v, fl
 }
 
 // triangle_tree.zig:197-242
-template <bool STATS, bool WIDE = false>
+template <bool STATS, bool WIDE = false, bool TREE = false>  // TREE: called from a per-lane walk of the scene's trees (the POOL / MESHL / EXTRA kernels)
 ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
     auto leaf = [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
@@ -1281,6 +1325,7 @@ ZD bool meshIntersectP(const DMesh& mesh, Ray& local_ray, Counters& cnt) {
         }
         return false;
     };
+    if ((ZYG_WALK8_INLINE & (TREE ? 1 : 4)) && !STATS && WIDE && mesh.nodes8) return bvh8Walk<true>(mesh, local_ray, [](uint32_t, float, float, float) { return true; });
 #if ZYG_BVH4Q
     if (!STATS && WIDE) return bvh4qWalkAny(mesh.nodes4q, local_ray, leaf);
 #else
@@ -1736,7 +1781,7 @@ ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
             } else if (ZYGPU_SHAPE_TRIANGLE_MESH == prop.shape) {
                 Ray          local = worldToObjectRay(trafo, ray);
                 const DMesh& mesh = s.meshes[prop.mesh];
-                if ((ZYG_FAST && !STATS && mesh.wide) ? meshIntersectP<false, true>(mesh, local, cnt) : meshIntersectP<STATS>(mesh, local, cnt)) return true;
+                if ((ZYG_FAST && !STATS && mesh.wide) ? meshIntersectP<false, true, true>(mesh, local, cnt) : meshIntersectP<STATS>(mesh, local, cnt)) return true;
             } else if (EXTRA && ZYGPU_SHAPE_SPHERE == prop.shape) {  // sphere.zig:148-172 intersectP: the same two roots
                 float t;
                 if (sphereIntersect(ray, trafo, t)) return true;
@@ -1853,7 +1898,7 @@ ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw
                 Ray          local = worldToObjectRay(trafo, ray);
                 const DMesh& mesh = s.meshes[prop.mesh];
                 if (!evaluate) {
-                    if ((ZYG_FAST && !STATS && mesh.wide) ? meshIntersectP<false, true>(mesh, local, cnt) : meshIntersectP<STATS>(mesh, local, cnt)) return true;
+                    if ((ZYG_FAST && !STATS && mesh.wide) ? meshIntersectP<false, true, true>(mesh, local, cnt) : meshIntersectP<STATS>(mesh, local, cnt)) return true;
                     continue;
                 }
                 const bool mesh_blocked = bvhWalk<STATS>(mesh.nodes, 1u, local, cnt, [&](uint32_t tfirst, uint32_t tcount) {
