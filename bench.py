@@ -423,7 +423,7 @@ def committed_profile(args, name, kernel, source_hash, overrides=None):
     return None, {"profile": "profiles/" + name, "refused": "kernel not in the profile"}
 
 
-_COUNTING = ("wf_scatter<true", "wf_trace_shade<true", "wf_shade<true", "wf_intersect<true", "wf_shadow<true", "wf_trace_shade_pool<true")
+_COUNTING = ("wf_scatter<true", "wf_trace_shade<true", "wf_shade<true", "wf_intersect<true", "wf_shadow<true")  # (STATS is their first parameter)
 
 
 def committed_step_traffic(args, name, source_hash, overrides, ms_per_step):
