@@ -579,7 +579,8 @@ int zygpu_get_option(ZygpuContext* ctx, const char* name, int* out_value);
  * primitive, prop or ZYGPU_NULL, 3 x 0), the layout of the oracle's zyg_oracle_intersect; visible: 1 = unoccluded. */
 int zygpu_test_intersect(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t depth_surface, uint32_t mode, uint32_t* hits);
 int zygpu_test_visibility(ZygpuContext* ctx, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible);
-/* One closest-hit ray (8 floats as above) walked as the reference's Scene.intersect does (mode 0), always in precise arithmetic:
+/* One closest-hit ray (8 floats as above) walked as the reference's Scene.intersect does (mode 0), in precise arithmetic (a development
+ * library built without the precise kernel units answers with the relaxed units' walk of the same trees), at the frame's start time:
  * the camera's focus probe (Perspective.updateFocus, camera_perspective.zig:322-347), which the host traces between
  * zygpu_upload_scene and zygpu_set_view.  Returns 1 and the hit distance in *out_t, 0 for a miss, -1 on error. */
 int zygpu_probe_closest(ZygpuContext* ctx, const float* ray8, float* out_t);

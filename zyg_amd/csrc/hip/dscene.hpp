@@ -657,9 +657,13 @@ ZD void triangleVertices(const DMesh& mesh, uint32_t i, f3& a, f3& b, f3& c) { t
 #ifndef ZYG_BVH4Q
 #define ZYG_BVH4Q 1
 #endif
+// The grid form computes q * (scale * inv_dir) + (corner - origin) * inv_dir, which is 0 * inf or inf - inf = NaN for a ray with a zero
+// direction component: harmless only where mn / mx drop a NaN (the hardware v_min / v_max of the relaxed units, dmath.hpp
+// ZYG_FAST_MINMAX); with the x86 forms (the precise units' test hook, -DZYG_FAST_MINMAX=0) the boxes are dequantised instead.
 #ifndef ZYG_NODE4Q_GRID
-#define ZYG_NODE4Q_GRID 1  // 0: the child boxes are dequantised and tested as nodeIntersect tests a full-precision box
+#define ZYG_NODE4Q_GRID ZYG_FAST_MINMAX  // 0: the child boxes are dequantised and tested as nodeIntersect tests a full-precision box
 #endif
+static_assert(!ZYG_NODE4Q_GRID || ZYG_FAST_MINMAX, "the quantised-grid node test needs min / max that drop NaNs");
 struct Node4q {
     uint4 a, b, c, d;
     ZD static Node4q load(const uint4* nodes, uint32_t i) {

@@ -561,6 +561,7 @@ struct ZygpuContext {
     size_t        film_alpha_pixels = 0;
     float4*       resolve_tmp = nullptr;
     uint4*        hit_q = nullptr;        // the hit records by alive-queue position (wavefront.hpp Params::hit_q)
+    char*         probe_buffer = nullptr; // zygpu_probe_closest's ray and hit
     Pool          regen_pool{};           // the regenerating kernels' pool: every record in an array of its own (wavefront.hpp wf_rtrace)
     uint32_t*     regen_sample = nullptr;
     size_t        regen_slots = 0;
@@ -1056,6 +1057,7 @@ int zygpu_destroy(ZygpuContext* c) {
     if (c->host_count) (void)hipHostFree(c->host_count);
     if (c->sobol_lut) (void)hipFree(c->sobol_lut);
     if (c->pixel_pcg) (void)hipFree(c->pixel_pcg);
+    if (c->probe_buffer) (void)hipFree(c->probe_buffer);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1792,6 +1794,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
         if (c->pixel_pcg_capacity < npix) {
             HIP_OK(hipStreamSynchronize(c->stream));
             if (c->pixel_pcg) (void)hipFree(c->pixel_pcg);
+    if (c->probe_buffer) (void)hipFree(c->probe_buffer);
             c->pixel_pcg = nullptr;
             c->pixel_pcg_capacity = 0;
             HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pixel_pcg), npix * sizeof(uint2)));
@@ -2337,25 +2340,31 @@ int zygpu_test_intersect(ZygpuContext* c, uint32_t n, const float* rays, uint32_
 int zygpu_probe_closest(ZygpuContext* c, const float* ray8, float* out_t) {
     if (!c || !c->has_scene || !ray8 || !out_t) return -1;
     HIP_OK(hipSetDevice(c->device));
-    float*    din = nullptr;
-    uint32_t* dout = nullptr;
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&din), 32));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&dout), 32));
-    HIP_OK(hipMemcpy(din, ray8, 32, hipMemcpyHostToDevice));
+    // the precise units' hook (the reference's walk in the reference's arithmetic); a development library without them answers with
+    // the relaxed units' walk of the same trees, which include/zygpu.h says
     auto hook = zyg_unit7_test_rays ? zyg_unit7_test_rays : zyg_unit7f_test_rays;
-    int  rc = -1;
-    if (!hook || 0 != hook(0, 1u, din, 0u, 0u, dout, c->stream)) {
+    if (!hook) {
         g_error = "zygpu_probe_closest: the kernel unit with the ray hooks is not in this build";
-    } else if (check(hipGetLastError(), "probe") && check(hipStreamSynchronize(c->stream), "probe")) {
-        uint32_t h[8];
-        if (check(hipMemcpy(h, dout, 32, hipMemcpyDeviceToHost), "probe")) {
-            rc = ZYGPU_NULL != h[4] ? 1 : 0;
-            std::memcpy(out_t, &h[0], 4);
-        }
+        return -1;
     }
-    (void)hipFree(din);
-    (void)hipFree(dout);
-    return rc;
+    if (!c->probe_buffer) {  // 64 B kept by the context: a probe per su_start_frame
+        void* d = nullptr;
+        HIP_OK(hipMalloc(&d, 64));
+        c->probe_buffer = static_cast<char*>(d);
+    }
+    float*    din = reinterpret_cast<float*>(c->probe_buffer);
+    uint32_t* dout = reinterpret_cast<uint32_t*>(c->probe_buffer + 32);
+    HIP_OK(hipMemcpy(din, ray8, 32, hipMemcpyHostToDevice));
+    if (0 != hook(0, 1u, din, 0u, 0u, dout, c->stream)) {
+        g_error = "zygpu_probe_closest: the ray hook could not be launched";
+        return -1;
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(c->stream));
+    uint32_t h[8];
+    HIP_OK(hipMemcpy(h, dout, 32, hipMemcpyDeviceToHost));
+    std::memcpy(out_t, &h[0], 4);
+    return ZYGPU_NULL != h[4] ? 1 : 0;
 }
 
 int zygpu_test_visibility(ZygpuContext* c, uint32_t n, const float* rays, uint32_t mode, uint32_t* visible) {

@@ -1169,6 +1169,7 @@ void Engine::cameraCreate(uint32_t width, uint32_t height) {  // capi.zig:143-16
 
 // Perspective.setParameters (camera_perspective.zig:260-304) + loadFocus (348-361)
 bool Engine::loadCameraParameters(const JsonValue& v) {
+    camera_error.clear();  // (a refusal belongs to the call that caused it: a later valid call replaces the parameters)
     if (JsonValue::Object != v.type) return true;
     for (const auto& kv : v.obj) {
         if (kv.first == "fov") {
@@ -1178,6 +1179,7 @@ bool Engine::loadCameraParameters(const JsonValue& v) {
         } else if (kv.first == "aperture") {
             lens_radius = kv.second.memberF32("radius", lens_radius);
             const JsonValue* shape = kv.second.get("shape");
+            aperture_shape_image = ZYGPU_NULL;  // (Aperture is replaced with the node: a shape lasts as long as the node names it)
             if (shape && JsonValue::String == shape->type && !shape->str.empty()) {
                 // tx.Provider.loadFile with usage Opacity (camera_perspective.zig:274-283): one channel, the file's W (or only) one
                 aperture_shape_image = loadImageFile(shape->str, kUsageOpacity, std::string(), false);
@@ -1194,6 +1196,7 @@ bool Engine::loadCameraParameters(const JsonValue& v) {
             }
         } else if (kv.first == "focus") {
             if (JsonValue::Object != kv.second.type) continue;
+            focus_use_point = false;  // loadFocus makes a new Focus (camera_perspective.zig:348-361): a point lasts as long as the node names it
             for (const auto& f : kv.second.obj) {
                 if (f.first == "point" && JsonValue::Array == f.second.type && f.second.arr.size() >= 3) {
                     for (int i = 0; i < 3; ++i) focus_point[i] = f.second.arr[size_t(i)].f32();
