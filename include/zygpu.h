@@ -203,6 +203,11 @@ typedef struct ZygpuMaterial {
     float    flakes_alpha;      /* setFlakesRoughness: clampRoughness(r)^2, 0.01 */
     float    flakes_res;        /* setFlakesSize: max(4, ceil(sqrt(1.5396 / size^2 / 4))) */
     float    attenuation_distance; /* > 0: subsurface scattering, refused (compile returns -7) */
+    /* emittance.profile (emittance.zig:20, 45-52): a one-channel image over the octahedral map of the directions from the light (in its
+     * object space) to the point it lights: an IES photometric file resampled by the host (ies_reader.zig); ZYGPU_NULL = none */
+    uint32_t profile_image;
+    uint32_t profile_sampler; /* ZYGPU_TEX_* bits */
+    float    profile_scale[2];
 } ZygpuMaterial;
 
 /* ZYGPU_TEX_SNORM: a Byte2 image read as snorm (byte / 128 - 1, base/encoding.zig:18-20): what usage Normal makes of it

@@ -1068,11 +1068,18 @@ inline Ray shadowRay(V4 origin, const SampleTo& sample, bool infinite_shape = fa
     return Ray::init(origin, shadow_axis / S(shadow_len), 0.f, shadow_len);
 }
 
-// emittance.zig:29-59, no profile; trafo_r2 = rs.trafo.rotation.r[2]; (u, v) = rs.uv(), r = rs.stochastic_r for an emission map
-inline V4 emittanceRadiance(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, V4 wi, V4 trafo_r2, float area, bool in_camera, float u,
-                            float v, float r) {
-    if (-dot3(wi, trafo_r2) < m.cos_a) return S(0.f);
-    const float factor = in_camera ? m.camera_weight : 1.f;
+// emittance.zig:29-59; (u, v) = rs.uv(), r = rs.stochastic_r for an emission map and a profile; origin = rs.origin
+inline V4 emittanceRadiance(const ZygpuSceneDesc& scene, const ZygpuMaterial& m, V4 wi, const Trafo& trafo, float area, bool in_camera, float u,
+                            float v, float r, V4 origin) {
+    if (-dot3(wi, trafo.r[2]) < m.cos_a) return S(0.f);
+    float factor = in_camera ? m.camera_weight : 1.f;
+    if (kNull != m.profile_image) {  // emittance.zig:45-52: the profile at octEncode(-normalize(worldToObjectPoint(rs.origin)))
+        const V4    lwi = -normalize3(trafo.worldToObjectPoint(origin));
+        const float inorm = 1.f / (std::fabs(lwi[0]) + std::fabs(lwi[1]) + std::fabs(lwi[2]));  // base/encoding.zig:82-87
+        const float t = mx(lwi[2], 0.f);
+        const float ox = (lwi[0] + (lwi[0] > 0.f ? t : -t)) * inorm, oy = (lwi[1] + (lwi[1] > 0.f ? t : -t)) * inorm;
+        factor *= sampleImageMap1(scene, m.profile_image, m.profile_sampler, m.profile_scale, (ox + 1.f) * 0.5f, (oy + 1.f) * 0.5f, r);
+    }
     const V4    texel = kNull != m.emission_image ? sampleImageMap(scene, m.emission_image, m.emission_sampler, m.emission_scale, u, v, r)
                                                   : S(1.f);
     const V4    intensity = mk(m.emission[0], m.emission[1], m.emission[2], 0.f) * texel;

@@ -67,7 +67,8 @@ class Material(ctypes.Structure):
                 ("coating_scale", ctypes.c_float), ("coating_roughness", ctypes.c_float), ("coating_thickness", ctypes.c_float),
                 ("coating_ior", ctypes.c_float), ("coating_absorption", ctypes.c_float * 3), ("flakes_coverage", ctypes.c_float),
                 ("flakes_color", ctypes.c_float * 3), ("flakes_alpha", ctypes.c_float), ("flakes_res", ctypes.c_float),
-                ("attenuation_distance", ctypes.c_float)]
+                ("attenuation_distance", ctypes.c_float), ("profile_image", ctypes.c_uint32), ("profile_sampler", ctypes.c_uint32),
+                ("profile_scale", ctypes.c_float * 2)]
 
 
 class Image(ctypes.Structure):

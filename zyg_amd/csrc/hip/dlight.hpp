@@ -1275,11 +1275,19 @@ ZD void shadowRay(f3 origin, const SampleTo& sample, f3& dir, float& len, bool i
     dir = shadow_axis / S3(len);
 }
 
-// emittance.zig:29-59, no profile; TEX: the scene can have emission maps, (u, v) = rs.uv(), r = rs.stochastic_r
+// emittance.zig:29-59; TEX: the scene can have emission maps and profiles, (u, v) = rs.uv(), r = rs.stochastic_r, origin = rs.origin
+// (the point the light is seen from: the previous vertex for a ray that hits the light, the shaded point for a light sample)
 template <bool TEX>
-ZD f3 emittanceRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, f3 trafo_r2, float area, bool in_camera, float u, float v, float r) {
-    if (-dot3(wi, trafo_r2) < m.cos_a) return S3(0.f);
-    const float factor = in_camera ? m.camera_weight : 1.f;
+ZD f3 emittanceRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, const Trafo& trafo, float area, bool in_camera, float u, float v, float r, f3 origin) {
+    if (-dot3(wi, trafo.r2) < m.cos_a) return S3(0.f);
+    float factor = in_camera ? m.camera_weight : 1.f;
+    if (TEX && kNull != m.profile_image) {  // the profile over the octahedral map of the direction light -> origin in the light's space (:45-52)
+        const f3    lwi = -normalize3(trafo.worldToObjectPoint(origin));
+        const float inorm = 1.f / (fabsf(lwi.x) + fabsf(lwi.y) + fabsf(lwi.z));  // octEncode (base/encoding.zig:82-87)
+        const float t = mx(lwi.z, 0.f);
+        const float ox = (lwi.x + (lwi.x > 0.f ? t : -t)) * inorm, oy = (lwi.y + (lwi.y > 0.f ? t : -t)) * inorm;
+        factor *= sampleImageMap1(s, m.profile_image, m.profile_sampler, m.profile_scale, (ox + 1.f) * 0.5f, (oy + 1.f) * 0.5f, r);
+    }
     const f3    texel = (TEX && kNull != m.emission_image) ? sampleImageMap(s, m.emission_image, m.emission_sampler, m.emission_scale, u, v, r)
                                                            : S3(1.f);
     const f3    intensity = mk3(m.emission[0], m.emission[1], m.emission[2]) * texel;

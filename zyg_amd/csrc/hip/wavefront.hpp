@@ -1293,11 +1293,11 @@ ZD f3 sunRadiance(const DScene& s, const Trafo& trafo, f3 wi) {
 // TEX (= the MESHL instantiations): emission maps, addressed by (u, v) with the stochastic filter's r
 template <bool TEX = false>
 ZD f3 materialRadiance(const DScene& s, const ZygpuMaterial& m, f3 wi, const Trafo& trafo, uint32_t prop, uint32_t part,
-                       bool in_camera, float u = 0.f, float v = 0.f, float r = 0.f) {
+                       bool in_camera, float u = 0.f, float v = 0.f, float r = 0.f, f3 origin = f3{0.f, 0.f, 0.f}) {
     if (TEX && ZYGPU_MAT_SKY == m.kind) return sunRadiance(s, trafo, wi);  // the Sky's sun (the sky itself is a Light with a map)
     if (ZYGPU_MAT_LIGHT != m.kind && ZYGPU_MAT_SUBSTITUTE != m.kind) return S3(0.f);
     const float area = m.emission_normalize ? shapeArea(s, prop, part, trafo) : 1.f;
-    return emittanceRadiance<TEX>(s, m, wi, trafo.r2, area, in_camera, u, v, r);
+    return emittanceRadiance<TEX>(s, m, wi, trafo, area, in_camera, u, v, r, origin);
 }
 
 // The light kinds of the MESHL instantiations' light loop (one sampling routine each).  KINDS: the kinds an instantiation compiles in
@@ -1387,7 +1387,7 @@ ZD f3 evaluateRadiance(const DScene& s, const VertexIn& v, f3 wo, const Fragment
         }
     }
     const float stochastic_r = smp.sample1D();  // rs.stochastic_r
-    const f3    energy = materialRadiance<MESHL>(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface, u, vv, stochastic_r);
+    const f3    energy = materialRadiance<MESHL>(s, m, wo, frag.trafo, frag.prop, frag.part, 0 == v.depth_surface, u, vv, stochastic_r, v.vorigin);
     const float weight = lightPdf<MESHL, KINDS>(s, v, -wo, frag);
     return S3(weight) * energy;
 }
@@ -3134,7 +3134,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
                     tr = S3(0.f);  // pathtracer_mis.zig:251-257
                 }
                 const float      lr = h.smp.sample1D();  // light.zig:127 rs.stochastic_r: drawn only for unoccluded samples
-                const f3         radiance = (ZYG_EXPERIMENT_NEE_SKIP & 8) ? S3(lr) : materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr);
+                const f3         radiance = (ZYG_EXPERIMENT_NEE_SKIP & 8) ? S3(lr) : materialRadiance<MESHL>(s, lm, ls.wi, trafo, light.prop, light.part, false, ls.u, ls.v, lr, sf.p);
                 if (1 == PHASE) {  // the closure's half of this sample happens in wf_scatter<.., 2>
                     if (stored < kMaxNeeStored) {
                         const size_t at = size_t(3u * stored) * batchPaths() + ps;

@@ -1126,7 +1126,8 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t mi = 0; mi < d->num_materials; ++mi)
         if (ZYGPU_NULL != d->materials[mi].mask_image) c->masks = true;
     for (uint32_t mi = 0; mi < d->num_materials; ++mi)  // texture fetches live in the MESHL instantiations, too
-        if (ZYGPU_NULL != d->materials[mi].color_image || ZYGPU_NULL != d->materials[mi].emission_image || ZYGPU_NULL != d->materials[mi].mask_image)
+        if (ZYGPU_NULL != d->materials[mi].color_image || ZYGPU_NULL != d->materials[mi].emission_image || ZYGPU_NULL != d->materials[mi].mask_image ||
+            ZYGPU_NULL != d->materials[mi].profile_image)
             c->mesh_lights = true;
     c->extra_shapes = false;
     for (uint32_t p = 0; p < d->num_props; ++p) {
@@ -1413,6 +1414,12 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t mi = 0; mi < d->num_materials; ++mi)
         if (ZYGPU_NULL != d->materials[mi].emission_image && d->materials[mi].emission_image >= d->num_images) {
             g_error = "a material's emission map refers to an image that does not exist";
+            return -2;
+        }
+    for (uint32_t mi = 0; mi < d->num_materials; ++mi)
+        if (ZYGPU_NULL != d->materials[mi].profile_image &&
+            (d->materials[mi].profile_image >= d->num_images || ZYGPU_IMAGE_FLOAT1 != d->images[d->materials[mi].profile_image].format)) {
+            g_error = "a material's emittance profile must be a one-channel float image (an IES file resampled by the host)";
             return -2;
         }
     s.specular_threshold = d->specular_threshold;

@@ -317,8 +317,12 @@ uint32_t Engine::loadImageFileUnguarded(const std::string& name, uint32_t usage,
         const bool         color = kUsageColor == usage || kUsageEmission == usage;  // texture_provider.zig:37-40
         if (!imgr::readExr(data, uint32_t(swizzle.size()), color, w, h, out_channels, values, error)) return file_error = "\"" + name + "\": " + error, ZYGPU_NULL;
         image = createImage(ZYGPU_NULL, 4, out_channels, uint32_t(w), uint32_t(h), 1, 4 * out_channels, reinterpret_cast<const uint8_t*>(values.data()));
+    } else if (data.size() >= 3 && 0 == data.compare(0, 3, "IES")) {  // file.zig:34-35 -> ies_reader.zig: a Half1 image, whatever the usage
+        std::vector<float> values;
+        if (!imgr::readIes(data, w, h, values, error)) return file_error = "\"" + name + "\": " + error, ZYGPU_NULL;
+        image = createImage(ZYGPU_NULL, 4, 1, uint32_t(w), uint32_t(h), 1, 4, reinterpret_cast<const uint8_t*>(values.data()));
     } else {
-        return file_error = "\"" + name + "\": an image type this build does not read (PNG, Radiance RGBE and ZIP-compressed OpenEXR are)", ZYGPU_NULL;
+        return file_error = "\"" + name + "\": an image type this build does not read (PNG, Radiance RGBE, ZIP-compressed OpenEXR and IES are)", ZYGPU_NULL;
     }
     if (ZYGPU_NULL == image) return file_error = "\"" + name + "\": the image could not be created", ZYGPU_NULL;
     image_files_[key] = image;
@@ -343,6 +347,7 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
         m.color_image = ZYGPU_NULL;
         m.emission_image = ZYGPU_NULL;
         m.mask_image = ZYGPU_NULL;
+        m.profile_image = ZYGPU_NULL;
         m.roughness = 0.8f;
         m.metallic = 0.f;
         m.specular = 1.f;
@@ -380,9 +385,36 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
         m.emission[1] = em[1];
         m.emission[2] = em[2];
         m.emission_normalize = e.memberBool("normalize", false) ? 1u : 0u;
-        // angleFromProfile without a profile = pi (emittance.zig:75-78) -> 180 degrees
-        const float profile_angle = float(M_PI) * (180.f / float(M_PI));
-        m.cos_a = std::cos(e.memberF32("angle", profile_angle) * (float(M_PI) / 180.f));
+        // "profile" (material_provider.zig:412-414): a texture of usage Emission, in practice an IES file (image_provider.zig:48)
+        m.profile_image = ZYGPU_NULL;
+        if (const JsonValue* pv = e.get("profile")) readImageTexture(*pv, m.profile_image, m.profile_sampler, m.profile_scale, kUsageEmission);
+        // angleFromProfile (emittance.zig:73-103): without a profile pi; with one the widest angle from the light's axis at which a texel
+        // of the octahedral map is lit, plus a texel
+        float profile_angle = float(M_PI);
+        if (ZYGPU_NULL != m.profile_image && m.profile_image < images_.size() && ZYGPU_IMAGE_FLOAT1 == images_[m.profile_image].format) {
+            const HostImage& img = images_[m.profile_image];
+            const float*     px = reinterpret_cast<const float*>(img.pixels.data());
+            const float      idf0 = 1.f / float(img.width), idf1 = 1.f / float(img.height);
+            float            cos_a = 1.f;
+            for (int32_t y = 0; y < img.height; ++y) {
+                const float vv = idf1 * (float(y) + 0.5f);
+                for (int32_t x = 0; x < img.width; ++x) {
+                    if (!(px[size_t(y) * size_t(img.width) + size_t(x)] > 0.f)) continue;
+                    const float u = idf0 * (float(x) + 0.5f);
+                    Vec4f       d = vec(2.f * (u - 0.5f), 2.f * (vv - 0.5f), 0.f, 0.f);  // octDecode (base/encoding.zig:89-98)
+                    d[2] = -1.f + std::fabs(d[0]) + std::fabs(d[1]);
+                    const float tt = fmax_(d[2], 0.f);
+                    d[0] += d[0] > 0.f ? -tt : tt;
+                    d[1] += d[1] > 0.f ? -tt : tt;
+                    d = normalize3(d);
+                    cos_a = fmin_(cos_a, -d[2]);
+                }
+            }
+            profile_angle = std::acos(fmax_(cos_a - fmax_(idf0, idf1), -1.f));
+        } else if (ZYGPU_NULL != m.profile_image) {
+            t_unsupported_texture = true;  // (a profile that is not a one-channel float image: only IES files are read as profiles)
+        }
+        m.cos_a = std::cos(e.memberF32("angle", profile_angle * (180.f / float(M_PI))) * (float(M_PI) / 180.f));
         m.camera_weight = e.memberF32("camera_weight", 1.f);
         m.emission_num_samples = std::min<uint32_t>(e.memberU32("num_samples", 1), 64u);
         if (const JsonValue* em = e.get("emission_map")) {
@@ -391,8 +423,8 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
             if (m.emission_sampler & ZYGPU_TEX_TRIPLANAR) t_unsupported_texture = true;
             m.emission_sampler &= ~uint32_t(ZYGPU_TEX_OBJECTPOS);
         }
-        // IES profiles (emittance.zig:20, 60-78) and black-body temperature maps: not built
-        if (e.get("profile") || e.get("temperature_map")) t_unsupported_texture = true;
+        // black-body temperature maps: not built
+        if (e.get("temperature_map")) t_unsupported_texture = true;
     };
 
     // material_provider.zig:177-178, 244-245, 265-266: Glass, Light and Substitute read "mask" (usage Opacity)

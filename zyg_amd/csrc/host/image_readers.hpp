@@ -12,7 +12,9 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -168,6 +170,172 @@ inline bool readRgbe(const std::string& file, int& width, int& height, std::vect
             const unsigned char rgbe[4] = {scanline[size_t(x)], scanline[size_t(width) + size_t(x)], scanline[2 * size_t(width) + size_t(x)],
                                            scanline[3 * size_t(width) + size_t(x)]};
             store(size_t(y) * size_t(width) + size_t(x), rgbe);
+        }
+    }
+    return true;
+}
+
+// ---- IES photometric files (image/encoding/ies/ies_reader.zig:16-394): the luminaire's candela table, resampled into a square
+// one-channel image over the octahedral map of directions (the light material's "profile", emittance.zig:20, 45-52).  Read: the
+// "IES" header line, everything up to the "TILT=NONE" line is skipped, then whitespace-separated numbers: lamps, lumens, multiplier,
+// vertical count, horizontal count, photometric type, seven more that are skipped, the vertical angles, the horizontal angles, the
+// candela values (one run of vertical values per horizontal angle).  Resolution = round(360 / the smallest angle step); texel (x, y) =
+// the table at the direction octDecode(2 (uv - 0.5)) turned to the file's axes, relative to the table's maximum, saturated, as f16.
+struct IesTable {
+    uint32_t           type = 1;  // 1: type C (vertical angle from the nadir, horizontal around it); otherwise type A / B angles
+    std::vector<float> vertical, horizontal, candela;
+
+    static float catmullRom(const float c[4], float t) {  // ies_reader.zig:224-232
+        const float t2 = t * t;
+        const float a0 = -0.5f * c[0] + 1.5f * c[1] - 1.5f * c[2] + 0.5f * c[3];
+        const float a1 = c[0] - 2.5f * c[1] + 2.0f * c[2] - 0.5f * c[3];
+        const float a2 = -0.5f * c[0] + 0.5f * c[2];
+        const float a3 = c[1];
+        return a0 * t * t2 + a1 * t2 + a2 * t + a3;
+    }
+    // a neighbour index: mirrored below the first angle, held back from the end (ies_reader.zig:208-216)
+    static uint32_t neighbour(int32_t x, int32_t i, int32_t b) {
+        const int32_t y = x + i;
+        if (y < 0) return uint32_t(1 - y);
+        return uint32_t(y >= b ? b - i : y);
+    }
+    // the candela value towards (phi around the axis, theta from it), radians (Data.sample, ies_reader.zig:31-206)
+    float at(float rad_phi, float rad_theta) const {
+        float phi = rad_phi * (180.f / 3.14159265358979323846f), theta = rad_theta * (180.f / 3.14159265358979323846f);
+        bool  vertical_symmetric = false, non_symmetric = false;
+        const float vf = vertical.front(), vb = vertical.back(), hf = horizontal.front(), hb = horizontal.back();
+        if (1 == type) {
+            if (0.f == hb) {
+                phi = 0.f;
+                vertical_symmetric = true;
+            } else if (90.f == hb) {
+                if (phi > 90.f && phi < 180.f) phi = 180.f - phi;
+                if (phi > 180.f && phi < 270.f) phi -= 180.f;
+                if (phi > 270.f && phi < 360.f) phi = 360.f - phi;
+                if (phi < 0.f || phi > 90.f || theta < 0.f || theta > 180.f) return 0.f;
+            } else if (180.f == hb) {
+                if (phi > 180.f) phi = 360.f - phi;
+                if (phi < 0.f || phi > 180.f || theta < 0.f || theta > 180.f) return 0.f;
+            } else if (90.f == hf && 270.f == hb) {
+                if (phi < 90.f || phi > 270.f) phi = 180.f - phi;
+                if (phi < 90.f || phi > 270.f) return 0.f;
+            } else {
+                non_symmetric = true;
+            }
+        } else {
+            theta -= 90.f;
+            phi -= 180.f;
+            if (vf >= 0.f) theta = std::fabs(theta);
+            if (hf >= 0.f) phi = std::fabs(phi);
+            if (phi < hf || phi > hb) return 0.f;
+            if (theta < vf || theta > vb) return 0.f;
+        }
+        if (vertical_symmetric && (phi < hf || phi > hb)) return 0.f;
+        if (theta < vf || theta > vb) return 0.f;
+        // the last angle below the value (std.sort.lowerBound - 1; an exact first angle stays on the first interval)
+        auto below = [](const std::vector<float>& a, float x) {
+            const size_t lb = size_t(std::lower_bound(a.begin(), a.end(), x) - a.begin());
+            return lb > 0 ? lb - 1 : size_t(0);
+        };
+        const size_t hit = below(horizontal, phi), vit = below(vertical, theta);
+        const size_t nv = vertical.size(), nh = horizontal.size();
+        float        next_phi;
+        if (non_symmetric) {
+            if (vit >= nv - 1) return 0.f;
+            next_phi = hit < nh - 1 ? horizontal[hit + 1] : horizontal[(hit + 1) % nh];
+        } else {
+            if (!vertical_symmetric && (hit >= nh - 1 || vit >= nv - 1)) return 0.f;
+            next_phi = hit < nh - 1 ? horizontal[hit + 1] : horizontal[hit];
+        }
+        const float next_theta = vit < nv - 1 ? vertical[vit + 1] : vertical[vit];
+        const float d_theta = (theta - vertical[vit]) / (next_theta - vertical[vit]);
+        if (vertical_symmetric) {
+            const float in0 = candela[vit], in1 = candela[(vit + 1) % nv];
+            return std::fmaf(1.f - d_theta, in0, d_theta * in1);  // math.lerp (util.zig:3-16)
+        }
+        const float   d_phi = (phi - horizontal[hit]) / (next_phi - horizontal[hit]);
+        const int32_t iv = int32_t(vit), ih = int32_t(hit), bv = int32_t(nv), bh = int32_t(nh);
+        float         rows[4];
+        for (int32_t j = -1; j <= 2; ++j) {
+            const size_t h = size_t(neighbour(ih, j, bh)) * nv;
+            const float  c[4] = {candela[neighbour(iv, -1, bv) + h], candela[neighbour(iv, 0, bv) + h], candela[neighbour(iv, 1, bv) + h], candela[neighbour(iv, 2, bv) + h]};
+            rows[j + 1] = catmullRom(c, d_theta);
+        }
+        return catmullRom(rows, d_phi);
+    }
+};
+
+inline bool readIes(const std::string& file, int& width, int& height, std::vector<float>& values, std::string& error) {
+    if (file.size() < 3 || 0 != file.compare(0, 3, "IES")) return error = "not an IES file", false;
+    size_t at = file.find('\n');
+    bool   tilt = false;
+    while (std::string::npos != at && !tilt) {
+        const size_t begin = at + 1, end = file.find('\n', begin);
+        tilt = 0 == file.compare(begin, 9, "TILT=NONE");
+        at = end;
+    }
+    if (!tilt || std::string::npos == at) return error = "an IES file without a TILT=NONE line (tilted luminaires are not read)", false;
+    std::vector<double> numbers;
+    const char*         p = file.c_str() + at;
+    for (;;) {
+        while (*p && (' ' == *p || '\r' == *p || '\n' == *p || '\t' == *p || ',' == *p)) ++p;
+        if (!*p) break;
+        char*        stop = nullptr;
+        const double x = std::strtod(p, &stop);
+        if (stop == p) return error = "an IES file with something that is not a number in its table", false;
+        numbers.push_back(x);
+        p = stop;
+    }
+    if (numbers.size() < 13) return error = "an IES file that ends before its angles", false;
+    const double nv = numbers[3], nh = numbers[4];
+    if (!(nv >= 1) || !(nh >= 1) || nv > 4096 || nh > 4096) return error = "an IES file with implausible angle counts", false;
+    IesTable t;
+    t.type = uint32_t(numbers[5]);
+    const size_t v = size_t(nv), h = size_t(nh);
+    if (numbers.size() < 13 + v + h + v * h) return error = "an IES file that ends before its candela values", false;
+    float min_angle = 360.f;
+    auto  angles = [&](size_t first, size_t count, std::vector<float>& out) {
+        out.resize(count);
+        float previous = float(numbers[first]);
+        out[0] = previous;
+        for (size_t i = 1; i < count; ++i) {
+            const float c = float(numbers[first + i]);
+            min_angle = std::min(min_angle, std::fabs(c - previous));
+            out[i] = c;
+            previous = c;
+        }
+    };
+    angles(13, v, t.vertical);
+    angles(13 + v, h, t.horizontal);
+    t.candela.resize(v * h);
+    float most = 0.f;
+    for (size_t i = 0; i < v * h; ++i) {
+        t.candela[i] = float(numbers[13 + v + h + i]);
+        most = std::max(most, t.candela[i]);
+    }
+    if (!(min_angle > 0.f) || !(most > 0.f)) return error = "an IES file without an angle step or without light", false;
+    const int res = int(360.f / min_angle + 0.5f);
+    if (res < 1 || res > 4096) return error = "an IES file whose angle step gives an implausible resolution", false;
+    width = height = res;
+    values.resize(size_t(res) * size_t(res));
+    const float idf = 1.f / float(res), imi = 1.f / most;
+    for (int y = 0; y < res; ++y) {
+        const float vv = idf * (float(y) + 0.5f);
+        for (int x = 0; x < res; ++x) {
+            const float u = idf * (float(x) + 0.5f);
+            // octDecode (base/encoding.zig:89-98) of 2 (uv - 0.5)
+            float       d[3] = {2.f * (u - 0.5f), 2.f * (vv - 0.5f), 0.f};
+            d[2] = -1.f + std::fabs(d[0]) + std::fabs(d[1]);
+            const float tt = std::max(d[2], 0.f);
+            d[0] += d[0] > 0.f ? -tt : tt;
+            d[1] += d[1] > 0.f ? -tt : tt;
+            const float len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            for (float& c : d) c /= len;
+            // dirToLatlong of (x, -z, -y) (ies_reader.zig:371-391)
+            const float lx = d[0], ly = -d[2], lz = -d[1];
+            const float phi = std::atan2(lx, lz), theta = std::acos(ly);
+            const float value = t.at(phi < 0.f ? 2.f * 3.14159265358979323846f + phi : phi, theta);
+            values[size_t(y) * size_t(res) + size_t(x)] = halfRounded(std::min(std::max(value * imi, 0.f), 1.f));
         }
     }
     return true;
