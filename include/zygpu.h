@@ -625,6 +625,10 @@ int zygpu_test_eval(ZygpuContext* ctx, uint32_t op, uint32_t n, const float* in,
  * record that class (capi.zig:620, 637). zygpu_download_aov: the class' raw Pack4f plane (tests). */
 int zygpu_resolve_aov(ZygpuContext* ctx, uint32_t aov_class, float* host_rgba, uint32_t num_pixels);
 int zygpu_download_aov(ZygpuContext* ctx, uint32_t aov_class, float* host_plane);
+/* A class' plane on the device (NULL and 0 floats when the view does not record it) and its clear (aov_buffer.zig:36-46: zero; Depth:
+ * f32 max), on the context's stream: what a ZygpuGroup reduces and resets. */
+int zygpu_aov_device_ptr(ZygpuContext* ctx, uint32_t aov_class, void** out_ptr, uint64_t* out_num_floats);
+int zygpu_clear_aov(ZygpuContext* ctx, uint32_t aov_class);
 
 const char* zygpu_last_error(void);
 
@@ -636,7 +640,9 @@ const char* zygpu_last_error(void);
  * over xGMI (RCCL), in stream order behind each rank's kernels; rank 0's context then holds the frame (zygpu_resolve,
  * zygpu_download_film on zygpu_group_context(g, 0)).  (pixel, iteration) samples are independent and the film is additive
  * (buffer_opaque.zig:39-45), so nothing else is exchanged.  Rows: the film equals the single-device film bit for bit with the
- * radius-0 sensor; iterations: up to the order of the float sums.
+ * radius-0 sensor; iterations: up to the order of the float sums.  A view that records AOVs always splits rows (Depth keeps a pixel's
+ * minimum and MaterialId its heaviest sample over the pixel's own samples, aov_buffer.zig:101-119: with its rows on one device a pixel's
+ * planes are complete there), and the reduce sums the planes too (Depth: ncclMin).
  *
  * zygpu_group_create: n contexts on the listed HIP devices = ranks [first_rank, first_rank + n) of a world of `world` ranks.
  * unique_id NULL: this process is the whole world (first_rank and world are ignored, world = n).  Otherwise the 128 bytes that
@@ -658,7 +664,7 @@ int zygpu_group_first_rank(const ZygpuGroup* group);
 int zygpu_group_uses_rccl(const ZygpuGroup* group);  /* 1: the reduce is ncclReduce; 0: a world of one, or members sharing a device */
 ZygpuContext* zygpu_group_context(ZygpuGroup* group, int member); /* options, statistics, and (rank 0) the film */
 int zygpu_group_upload_scene(ZygpuGroup* group, const ZygpuSceneDesc* scene);
-int zygpu_group_set_view(ZygpuGroup* group, const ZygpuViewDesc* view); /* AOVs are refused when world > 1: their planes are not reduced */
+int zygpu_group_set_view(ZygpuGroup* group, const ZygpuViewDesc* view); /* with AOVs a world > 1 splits rows whatever `shard` says (below) */
 int zygpu_group_set_option(ZygpuGroup* group, const char* name, int value);
 int zygpu_group_clear_film(ZygpuGroup* group, float weight);
 /* zygpu_render / zygpu_render_frame for the world: [iteration, iteration + num_iterations) and [y_begin, y_end) name the whole job,

@@ -155,10 +155,29 @@ def test_world_joined_through_a_communicator_id(product_lib, oracle):
 
 
 @pytest.mark.gpu
-def test_group_refuses_what_it_cannot_reduce(product_lib):
-    with zyg_amd.Engine(product_lib) as e:
-        scenes.cornell(e, W, H, 2, integrator="PTMIS")
-        e.aovs(["Albedo"])
-        e.set_devices([0, 0])
-        assert -1 == e.lib.su_start_frame(0)
-        assert b"AOV" in e.lib.zygpu_last_error()
+def test_group_reduces_the_aov_planes(product_lib):
+    """A view that records AOVs splits rows whatever the sharding asked for (Depth keeps a pixel's minimum and MaterialId its heaviest
+    sample over the pixel's OWN samples: with its rows on one device a pixel's planes are complete there), and the reduce sums the planes
+    (Depth: a minimum): every plane of a two-context group is the single context's, bit for bit."""
+    names = ["Albedo", "Depth", "MaterialId", "ShadingNormal", "Direct"]
+
+    def planes(devices):
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, W, H, 4, integrator="PTMIS")
+            e.aovs(names)
+            if devices:
+                e.set_devices(devices, shard=0)  # (iterations asked for: rows are what runs)
+            e.start_frame(0)
+            e.render_iterations(3)
+            e.render_iterations(1)
+            e.synchronize()
+            film = e.download_film(W, H)  # (reduces)
+            return film, {k: e.download_aov(k, W, H) for k in range(9)}
+
+    film1, one = planes(None)
+    film2, two = planes([0, 0])
+    assert np.array_equal(film1, film2)
+    recorded = [k for k in range(9) if one[k] is not None]
+    assert len(recorded) == len(names)
+    for k in recorded:
+        assert two[k] is not None and np.array_equal(one[k], two[k]), k

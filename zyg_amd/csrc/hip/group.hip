@@ -44,6 +44,13 @@ __global__ void __launch_bounds__(256) film_add(float4* __restrict__ into, const
     into[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+__global__ void __launch_bounds__(256) film_min(float4* __restrict__ into, const float4* __restrict__ from, size_t n) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = into[i], b = from[i];
+    into[i] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w));
+}
+
 __global__ void __launch_bounds__(256) plane_add(float* __restrict__ into, const float* __restrict__ from, size_t n) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) into[i] += from[i];
@@ -136,6 +143,7 @@ struct ZygpuGroup {
     bool                rccl = false;
     bool                dirty = false;  // films other than rank 0's may hold samples
     bool                has_view = false;
+    bool                rows_only = false;  // the view records AOVs: a pixel's samples stay on one device
     std::string         error;
 
     // fn(member) on every member's thread at once (or one after the other where members share a device); the first failure's text
@@ -275,10 +283,7 @@ int zygpu_group_upload_scene(ZygpuGroup* g, const ZygpuSceneDesc* scene) {
 
 int zygpu_group_set_view(ZygpuGroup* g, const ZygpuViewDesc* view) {
     if (!g || !view) return -1;
-    if (g->world > 1 && 0 != view->aov_slots) {
-        g_group_error = "zygpu_group_set_view: AOV planes are not reduced across devices; render AOVs with a group of one";
-        return done(-1);
-    }
+    g->rows_only = g->world > 1 && 0 != view->aov_slots;
     const int rc = g->each([view](Member& m) { return zygpu_set_view(m.ctx, view); });
     g->has_view = 0 == rc;
     return done(rc);
@@ -300,6 +305,7 @@ int zygpu_group_clear_film(ZygpuGroup* g, float weight) {
 
 int zygpu_group_render(ZygpuGroup* g, uint32_t frame, uint32_t iteration, uint32_t num_iterations, int32_t y_begin, int32_t y_end, uint32_t shard) {
     if (!g || shard > ZYGPU_SHARD_ROWS) return -1;
+    if (g->rows_only) shard = ZYGPU_SHARD_ROWS;
     const int world = g->world;
     g->dirty = g->dirty || world > 1;
     return done(g->each([=](Member& m) {
@@ -352,6 +358,14 @@ int zygpu_group_reduce(ZygpuGroup* g) {
                 if (!hipOk(hipMemsetAsync(film, 0, size_t(nf) * sizeof(float), s), "hipMemsetAsync")) return -1;
                 if (alpha && !hipOk(hipMemsetAsync(alpha, 0, size_t(na) * sizeof(float), s), "hipMemsetAsync")) return -1;
             }
+            for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES; ++k) {  // the AOV planes: sums, Depth a minimum (the rows were split)
+                void*    plane = nullptr;
+                uint64_t np = 0;
+                if (0 != zygpu_aov_device_ptr(m.ctx, k, &plane, &np)) return -1;
+                if (!plane) continue;
+                if (!ncclOk(ncclReduce(plane, plane, size_t(np), ncclFloat, ZYGPU_AOV_DEPTH == k ? ncclMin : ncclSum, 0, m.comm, s), "ncclReduce(aov)")) return -1;
+                if (0 != m.rank && 0 != zygpu_clear_aov(m.ctx, k)) return -1;
+            }
             return 0;
         });
     } else {
@@ -372,8 +386,22 @@ int zygpu_group_reduce(ZygpuGroup* g) {
                 if (alpha0 && alpha) hipLaunchKernelGGL(plane_add, dim3(unsigned((na + 255) / 256)), dim3(256), 0, s, static_cast<float*>(alpha0), static_cast<const float*>(alpha), size_t(na));
                 if (!hipOk(hipMemsetAsync(film, 0, size_t(nf) * sizeof(float), s), "hipMemsetAsync")) rc = -1;
                 if (alpha && !hipOk(hipMemsetAsync(alpha, 0, size_t(na) * sizeof(float), s), "hipMemsetAsync")) rc = -1;
+                for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES && 0 == rc; ++k) {
+                    void *plane0 = nullptr, *plane = nullptr;
+                    if (0 != zygpu_aov_device_ptr(root.ctx, k, &plane0, nullptr) || 0 != zygpu_aov_device_ptr(g->members[i].ctx, k, &plane, nullptr)) return -1;
+                    if (!plane0 || !plane) continue;
+                    if (ZYGPU_AOV_DEPTH == k) hipLaunchKernelGGL(film_min, dim3(unsigned((pixels + 255) / 256)), dim3(256), 0, s, static_cast<float4*>(plane0), static_cast<const float4*>(plane), pixels);
+                    else hipLaunchKernelGGL(film_add, dim3(unsigned((pixels + 255) / 256)), dim3(256), 0, s, static_cast<float4*>(plane0), static_cast<const float4*>(plane), pixels);
+                }
             }
+            // (the members' planes are cleared on their own streams once the root's stream has read them)
             if (0 == rc && !hipOk(hipStreamSynchronize(s), "film_add")) rc = -1;
+            for (size_t i = 1; i < g->members.size() && 0 == rc; ++i)
+                for (uint32_t k = 0; k < ZYGPU_AOV_NUM_CLASSES; ++k) {
+                    const int r = zygpu_clear_aov(g->members[i].ctx, k);
+                    if (0 != r && -2 != r) rc = -1;
+                }
+            for (size_t i = 1; i < g->members.size() && 0 == rc; ++i) rc = zygpu_synchronize(g->members[i].ctx);
         }
     }
     if (0 == rc) g->dirty = false;

@@ -2279,6 +2279,23 @@ int zygpu_resolve_aov(ZygpuContext* c, uint32_t cls, float* host_rgba, uint32_t 
     HIP_OK(hipMemcpy(host_rgba, c->resolve_tmp, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));
     return deviceErrorFlags(c);
 }
+int zygpu_aov_device_ptr(ZygpuContext* c, uint32_t cls, void** out_ptr, uint64_t* out_num_floats) {
+    if (!c || !c->has_view || !out_ptr || cls >= ZYGPU_AOV_NUM_CLASSES) return -1;
+    *out_ptr = c->aov_film[cls];
+    if (out_num_floats) *out_num_floats = c->aov_film[cls] ? uint64_t(c->film_pixels) * 4 : 0;
+    return 0;
+}
+
+int zygpu_clear_aov(ZygpuContext* c, uint32_t cls) {
+    if (!c || !c->has_view || cls >= ZYGPU_AOV_NUM_CLASSES) return -1;
+    if (!c->aov_film[cls]) return -2;
+    HIP_OK(hipSetDevice(c->device));
+    const uint32_t n = uint32_t(c->film_pixels);
+    hipLaunchKernelGGL(aov_clear, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->aov_film[cls], n, ZYGPU_AOV_DEPTH == cls ? FLT_MAX : 0.f);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int zygpu_download_aov(ZygpuContext* c, uint32_t cls, float* host_plane) {
     if (!c || !c->has_view || !host_plane || cls >= ZYGPU_AOV_NUM_CLASSES) return -1;
     if (!c->aov_film[cls]) return -2;
