@@ -119,8 +119,11 @@ enum ZygpuMaterialFlags {
     /* Substitute with anything beyond the uniform opaque base: a texture in one of `tex`, a normal map, a coating,
      * translucency, flakes or a rotated tangent frame (set by the host; the device runs its complete closure for it) */
     ZYGPU_MATF_EXTENDED = 1u << 4,
-    /* the description the material was made from asked for something that is not built (a procedural texture, an image file,
-     * an IES profile ...): zygpu_upload_scene refuses a scene that uses it */
+    /* one of the material's textures (the colour map or an entry of `tex`) is procedural (ZYGPU_TEX_PROCEDURAL; set by the host):
+     * the device evaluates them per vertex in wf_textures before the closure is built */
+    ZYGPU_MATF_PROCEDURAL = 1u << 5,
+    /* the description the material was made from asked for something that is not built (a procedural texture as a mask or an
+     * emission map, an image file that cannot be read ...): zygpu_upload_scene refuses a scene that uses it */
     ZYGPU_MATF_UNSUPPORTED = 1u << 31
 };
 
@@ -216,8 +219,35 @@ typedef struct ZygpuMaterial {
  * the image at the fragment's object-space position projected along the dominant axis of its geometric normal
  * (renderstate.zig:44-49), for a normal map both also choose the frame the mapped normal lives in (material_helper.zig:24-41);
  * Substitute's and Glass' textures only (masks take the uv, material_base.zig:35-41) */
+/* ZYGPU_TEX_PROCEDURAL: the texture is procedural (texture.zig:60-63, 91-93): `image` indexes ZygpuSceneDesc.procedurals, the
+ * address and tex_coord bits are the procedural's mode; Substitute's and Glass' colour, weight and normal textures only */
 enum { ZYGPU_TEX_LINEAR = 1u, ZYGPU_TEX_REPEAT_U = 2u, ZYGPU_TEX_REPEAT_V = 4u, ZYGPU_TEX_SNORM = 8u, ZYGPU_TEX_TRIPLANAR = 16u,
-       ZYGPU_TEX_OBJECTPOS = 32u };
+       ZYGPU_TEX_OBJECTPOS = 32u, ZYGPU_TEX_PROCEDURAL = 64u };
+
+/* Procedural textures (texture/procedural.zig:27-35, the order of Procedural.Type; material_provider.zig:465-578).
+ * Checker (procedural_checker.zig): value[0] / value[1] = the two colours, checker_scale; filtered with the texture-space
+ * footprint of a pixel (context.zig:139-200).  Noise (procedural_noise.zig): `levels` octaves of gradient (Perlin) or cellular
+ * (Worley) noise over the uv, the triplanar st or the object-space position, remapped by ratio / transition; as a normal map its
+ * finite differences.  ChannelMix: value[k] = the row that makes output channel k of the source's colour.  Max / Mul / Mix / DetailNormal
+ * combine their children (Mix picks a or b stochastically by its weight: one sampler dimension per evaluation).
+ * Children: child[0] = a / base / source, child[1] = b / detail, child[2] = Mix's weight; a child with image == ZYGPU_NULL is the
+ * uniform child_uniform[k]; a child may be an image or (ZYGPU_TEX_PROCEDURAL) another procedural, ZYGPU_PROCEDURAL_MAX_DEPTH deep */
+enum ZygpuProceduralKind { ZYGPU_PROC_CHANNEL_MIX = 0, ZYGPU_PROC_CHECKER = 1, ZYGPU_PROC_DETAIL_NORMAL = 2, ZYGPU_PROC_MAX = 3,
+                           ZYGPU_PROC_MIX = 4, ZYGPU_PROC_MUL = 5, ZYGPU_PROC_NOISE = 6 };
+enum { ZYGPU_NOISE_CELLULAR = 1u, ZYGPU_NOISE_ABSOLUTE = 2u, ZYGPU_NOISE_INVERT = 4u };
+#define ZYGPU_PROCEDURAL_MAX_DEPTH 4
+typedef struct ZygpuProcedural {
+    uint32_t kind;  /* ZygpuProceduralKind */
+    uint32_t flags; /* ZYGPU_NOISE_* */
+    uint32_t levels;
+    float    checker_scale;
+    float    attenuation, ratio, transition, pad;
+    float    scale[4];
+    float    period[4];
+    float    value[3][4];
+    ZygpuTexture child[3];
+    float    child_uniform[3][4];
+} ZygpuProcedural;
 
 /* 2-D images behind textures (capi.zig:236-298, texture_provider.zig:67-84): Byte3 is read as sRGB and converted to AP1 per
  * fetch (texture.zig:196-199), Float3 is taken as is (213-216); the one-channel formats serve masks: Byte1 is unorm
@@ -391,6 +421,9 @@ typedef struct ZygpuSceneDesc {
     /* ZygpuLight.sampler of the ZYGPU_LIGHT_PORTAL_IMAGE lights */
     uint32_t             num_portal_lights;
     const ZygpuPortalLight* portal_lights;
+    /* what the ZYGPU_TEX_PROCEDURAL textures index */
+    const ZygpuProcedural* procedurals;
+    uint32_t             num_procedurals;
 } ZygpuSceneDesc;
 
 enum ZygpuIntegrator { ZYGPU_INTEGRATOR_PT = 1, ZYGPU_INTEGRATOR_PTDL = 2, ZYGPU_INTEGRATOR_PTMIS = 3 };

@@ -17,6 +17,7 @@
 //                               fresnel.dielectric material/fresnel.zig:31-43
 #pragma once
 
+#include "procedural.hpp"
 #include "sampler.hpp"
 #include "scene.hpp"
 #include "texture.hpp"
@@ -56,6 +57,9 @@ struct Renderstate {  // renderstate.zig:10-45 (subset in scope)
     V4       p, geo_n, t, b, n, origin, uvw;
     float    stochastic_r, ior;
     uint32_t prop, part;
+    uint32_t primitive = 0;                     // frag.isec.primitive (vertex.zig:172): a mesh's surface differentials
+    Sampler* sampler = nullptr;                 // procedural textures may draw (Mix, procedural_mix.zig:17-26)
+    const ProceduralContext* pctx = nullptr;    // context.camera at rs.time
     bool     caustics;
     int32_t  highest_priority = -128;  // mediums.highestPriority() (prop/medium.zig:75-83)
     float    wavelength = 0.f;                   // probe.wavelength (vertex.zig:167): 0 until a dispersive Glass picks one
@@ -863,12 +867,256 @@ inline void Renderstate::st(uint32_t sampler, float out[2]) const {
     }
 }
 
+// ---- ts.sample2D_1 / _2 / _3 (texture_sampler.zig:22-76) over ZygpuTexture: uniform, image or procedural
+inline float texture1(const ZygpuSceneDesc& scene, const ZygpuTexture& t, const float* uniform, const Renderstate& rs);
+inline void  texture2(const ZygpuSceneDesc& scene, const ZygpuTexture& t, const float* uniform, const Renderstate& rs, float out[2]);
+inline V4    texture3(const ZygpuSceneDesc& scene, const ZygpuTexture& t, const float* uniform, const Renderstate& rs);
+
+// Context.screenspaceDifferentials (context.zig:139-149)
+inline V4 screenspaceDifferentials(const ZygpuSceneDesc& scene, const Renderstate& rs, uint32_t mode) {
+    const RayDifferential     rd = cameraRayDifferential(*rs.pctx, rs.p);
+    const bool                uv0 = 0 == (mode & (ZYGPU_TEX_TRIPLANAR | ZYGPU_TEX_OBJECTPOS));
+    const DifferentialSurface ds = uv0 ? surfaceDifferentials(scene, rs.prop, rs.primitive, rs.trafo) : triplanarDifferentials(rs.geo_n, rs.trafo);
+    return calculateScreenspaceDifferentials(rs.p, rs.geo_n, rd, ds.dpdu, ds.dpdv);
+}
+
+// Checker.evaluate (procedural_checker.zig:46-84)
+inline V4 checkerEvaluate(const ZygpuSceneDesc& scene, const ZygpuProcedural& c, uint32_t mode, const Renderstate& rs) {
+    const V4 dd = screenspaceDifferentials(scene, rs, mode);
+    float    st[2];
+    rs.st(mode, st);  // Triplanar: rs.triplanarSt(), else rs.uv()
+    const float scale = c.checker_scale;
+    const float uv[2] = {scale * texAddress(0 != (mode & ZYGPU_TEX_REPEAT_U), st[0]), scale * texAddress(0 != (mode & ZYGPU_TEX_REPEAT_V), st[1])};
+    const float ddx[2] = {scale * dd[0], scale * dd[1]}, ddy[2] = {scale * dd[2], scale * dd[3]};
+    float       i[2];
+    for (int k = 0; k < 2; ++k) {  // checkersGrad: the triangle-filtered integral
+        const float w = mx(std::fabs(ddx[k]), std::fabs(ddy[k])) + 0.0001f;
+        auto        pf = [](float x) {
+            const float h = ((x * 0.5f) - std::floor(x * 0.5f)) - 0.5f;
+            return x * 0.5f + h * (1.f - 2.f * std::fabs(h));
+        };
+        i[k] = (pf(uv[k] + w) - 2.f * pf(uv[k]) + pf(uv[k] - w)) / (w * w);
+    }
+    const float t = 0.5f - 0.5f * i[0] * i[1];
+    return lerp4(ld3(c.value[0]), ld3(c.value[1]), S(t));
+}
+
+// Noise.evaluate1 (procedural_noise.zig:44-101)
+inline float noiseEvaluate1(const ZygpuProcedural& n, uint32_t mode, const Renderstate& rs, V4 offset) {
+    const bool  cellular = 0 != (n.flags & ZYGPU_NOISE_CELLULAR);
+    const float att = n.attenuation;
+    float       weight = 0.f, amplitude = 1.f, value = 0.f;
+    if (mode & ZYGPU_TEX_OBJECTPOS) {
+        V4       scale = mk(n.scale[0], n.scale[1], n.scale[2], n.scale[3]);
+        const V4 uvw = rs.trafo.worldToObjectPoint(rs.p - offset);
+        for (uint32_t l = 0; l < n.levels; ++l) {
+            const float local_weight = noise::powZ(amplitude, att);
+            const float local = cellular ? noise::worley3D(uvw * scale, 1.f) : noise::perlin3D(uvw * scale);
+            value += local * local_weight;
+            weight += local_weight;
+            amplitude *= 0.5f;
+            scale = scale * S(2.f);
+        }
+    } else {
+        float scale[2] = {n.scale[0], n.scale[1]}, period[2] = {n.period[0], n.period[1]};
+        float st[2];
+        rs.st(mode, st);
+        const float uv[2] = {st[0] - offset[0], st[1] - offset[1]};
+        for (uint32_t l = 0; l < n.levels; ++l) {
+            const float local_weight = noise::powZ(amplitude, att);
+            const float local = cellular ? noise::worley2D(uv[0] * scale[0], uv[1] * scale[1], 1.f)
+                                         : noise::perlin2D(uv[0] * scale[0], uv[1] * scale[1], period[0], period[1]);
+            value += local * local_weight;
+            weight += local_weight;
+            amplitude *= 0.5f;
+            scale[0] *= 2.f, scale[1] *= 2.f;
+            period[0] *= 2.f, period[1] *= 2.f;
+        }
+    }
+    value /= weight;
+    const float unsigned_ = cellular ? value : ((n.flags & ZYGPU_NOISE_ABSOLUTE) ? std::fabs(value) : (value + 1.f) * 0.5f);
+    const float a = n.ratio - n.transition, b = n.ratio + n.transition;
+    const float result = saturate((unsigned_ - a) / (b - a));
+    return (n.flags & ZYGPU_NOISE_INVERT) ? 1.f - result : result;
+}
+
+// Noise.evaluateNormalmap (procedural_noise.zig:103-135)
+inline void noiseNormalmap(const ZygpuSceneDesc& scene, const ZygpuProcedural& n, uint32_t mode, const Renderstate& rs, float out[2]) {
+    float nx, ny, nz;
+    if (mode & ZYGPU_TEX_OBJECTPOS) {
+        V4 dpdx, dpdy;
+        approximateDpDxy(*rs.pctx, rs.p, rs.geo_n, dpdx, dpdy);
+        const float center = noiseEvaluate1(n, mode, rs, S(0.f));
+        const float left = noiseEvaluate1(n, mode, rs, dpdx);
+        const float bottom = noiseEvaluate1(n, mode, rs, dpdy);
+        nx = left - center;
+        ny = bottom - center;
+        nz = length3(dpdx + dpdy);
+    } else {
+        const V4    dd = abs4(screenspaceDifferentials(scene, rs, mode));
+        const float shift_x = dd[0] + dd[2], shift_y = dd[1] + dd[3];
+        const float center = noiseEvaluate1(n, mode, rs, S(0.f));
+        const float left = noiseEvaluate1(n, mode, rs, mk(shift_x, 0.f, 0.f));
+        const float top = noiseEvaluate1(n, mode, rs, mk(0.f, shift_y, 0.f));
+        nx = left - center;
+        ny = top - center;
+        nz = std::sqrt(shift_x * shift_x + shift_y * shift_y);  // math.length2
+    }
+    const V4 nn = normalize3(mk(nx, ny, nz));
+    out[0] = nn[0];
+    out[1] = nn[1];
+}
+
+// Procedural.sample2D_1 / _2 / _3 (procedural.zig:82-130)
+inline float procedural1(const ZygpuSceneDesc& scene, uint32_t index, uint32_t mode, const Renderstate& rs);
+inline void  procedural2(const ZygpuSceneDesc& scene, uint32_t index, uint32_t mode, const Renderstate& rs, float out[2]);
+inline V4    procedural3(const ZygpuSceneDesc& scene, uint32_t index, uint32_t mode, const Renderstate& rs);
+
+inline float texture1(const ZygpuSceneDesc& scene, const ZygpuTexture& t, const float* uniform, const Renderstate& rs) {
+    if (kNull == t.image) return uniform[0];
+    if (t.sampler & ZYGPU_TEX_PROCEDURAL) return procedural1(scene, t.image, t.sampler, rs);
+    const uint32_t format = scene.images[t.image].format;
+    if (ZYGPU_IMAGE_BYTE1_UNORM != format && ZYGPU_IMAGE_FLOAT1 != format) return 0.f;  // image2D_1 of another width (texture.zig:166-175)
+    float st[2];
+    rs.st(t.sampler, st);
+    return sampleImageMap1(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r);
+}
+inline void texture2(const ZygpuSceneDesc& scene, const ZygpuTexture& t, const float* uniform, const Renderstate& rs, float out[2]) {
+    if (kNull == t.image) {
+        out[0] = uniform[0], out[1] = uniform[1];
+        return;
+    }
+    if (t.sampler & ZYGPU_TEX_PROCEDURAL) return procedural2(scene, t.image, t.sampler, rs, out);
+    const uint32_t format = scene.images[t.image].format;
+    if (ZYGPU_IMAGE_BYTE2 != format && ZYGPU_IMAGE_FLOAT2 != format) {  // image2D_2 (texture.zig:177-186)
+        out[0] = out[1] = 0.f;
+        return;
+    }
+    float st[2];
+    rs.st(t.sampler, st);
+    sampleImageMap2(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r, out);
+}
+inline V4 texture3(const ZygpuSceneDesc& scene, const ZygpuTexture& t, const float* uniform, const Renderstate& rs) {
+    if (kNull == t.image) return mk(uniform[0], uniform[1], uniform[2]);
+    if (t.sampler & ZYGPU_TEX_PROCEDURAL) return procedural3(scene, t.image, t.sampler, rs);
+    float st[2];
+    rs.st(t.sampler, st);
+    const uint32_t format = scene.images[t.image].format;
+    if (ZYGPU_IMAGE_BYTE1_UNORM == format || ZYGPU_IMAGE_FLOAT1 == format)  // image2D_3 of a one-channel image (texture.zig:192-195)
+        return mk(sampleImageMap1(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r), 0.f, 0.f);
+    if (ZYGPU_IMAGE_BYTE3_SRGB != format && ZYGPU_IMAGE_FLOAT3 != format) return S(0.f);
+    return sampleImageMap(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r);
+}
+
+inline V4 detailReconstruct(const ZygpuSceneDesc& scene, const ZygpuTexture& t, const float* uniform, const Renderstate& rs) {  // procedural_detail_normal.zig:31-35
+    float nm[2];
+    texture2(scene, t, uniform, rs, nm);
+    const float nmz = std::sqrt(mx(1.f - (nm[0] * nm[0] + nm[1] * nm[1]), 0.01f));
+    return normalize3(mk(nm[0], nm[1], nmz));
+}
+
+inline float procedural1(const ZygpuSceneDesc& scene, uint32_t index, uint32_t mode, const Renderstate& rs) {
+    const ZygpuProcedural& p = scene.procedurals[index];
+    switch (p.kind) {
+        case ZYGPU_PROC_CHANNEL_MIX: {
+            const V4 c = texture3(scene, p.child[0], p.child_uniform[0], rs);
+            return clampf(dot3(c, ld3(p.value[0])), 0.f, 1.f);
+        }
+        case ZYGPU_PROC_CHECKER: return checkerEvaluate(scene, p, mode, rs)[0];
+        case ZYGPU_PROC_MAX: {
+            const float a = texture1(scene, p.child[0], p.child_uniform[0], rs), b = texture1(scene, p.child[1], p.child_uniform[1], rs);
+            return mx(a, b);
+        }
+        case ZYGPU_PROC_MIX: {
+            const float weight = texture1(scene, p.child[2], p.child_uniform[2], rs);
+            const float r = rs.sampler->sample1D();
+            return weight < r ? texture1(scene, p.child[0], p.child_uniform[0], rs) : texture1(scene, p.child[1], p.child_uniform[1], rs);
+        }
+        case ZYGPU_PROC_MUL: {
+            const float a = texture1(scene, p.child[0], p.child_uniform[0], rs), b = texture1(scene, p.child[1], p.child_uniform[1], rs);
+            return a * b;
+        }
+        case ZYGPU_PROC_NOISE: return noiseEvaluate1(p, mode, rs, S(0.f));
+        default: return 0.f;  // DetailNormal
+    }
+}
+
+inline void procedural2(const ZygpuSceneDesc& scene, uint32_t index, uint32_t mode, const Renderstate& rs, float out[2]) {
+    const ZygpuProcedural& p = scene.procedurals[index];
+    float                  a[2], b[2];
+    switch (p.kind) {
+        case ZYGPU_PROC_CHANNEL_MIX: {
+            const V4 c = texture3(scene, p.child[0], p.child_uniform[0], rs);
+            out[0] = clampf(dot3(c, ld3(p.value[0])), 0.f, 1.f);
+            out[1] = clampf(dot3(c, ld3(p.value[1])), 0.f, 1.f);
+            return;
+        }
+        case ZYGPU_PROC_CHECKER: {
+            const V4 c = checkerEvaluate(scene, p, mode, rs);
+            out[0] = c[0], out[1] = c[1];
+            return;
+        }
+        case ZYGPU_PROC_DETAIL_NORMAL: {  // procedural_detail_normal.zig:19-29
+            const V4 n1 = detailReconstruct(scene, p.child[0], p.child_uniform[0], rs);
+            const V4 n2 = detailReconstruct(scene, p.child[1], p.child_uniform[1], rs);
+            V4       x, y;
+            orthonormalBasis3(n1, x, y);
+            const V4 r = S(n2[0]) * x + S(n2[1]) * y + S(n2[2]) * n1;
+            out[0] = r[0], out[1] = r[1];
+            return;
+        }
+        case ZYGPU_PROC_MAX:
+            texture2(scene, p.child[0], p.child_uniform[0], rs, a);
+            texture2(scene, p.child[1], p.child_uniform[1], rs, b);
+            out[0] = mx(a[0], b[0]), out[1] = mx(a[1], b[1]);
+            return;
+        case ZYGPU_PROC_MIX: {
+            const float weight = texture1(scene, p.child[2], p.child_uniform[2], rs);
+            const float r = rs.sampler->sample1D();
+            if (weight < r) texture2(scene, p.child[0], p.child_uniform[0], rs, out);
+            else texture2(scene, p.child[1], p.child_uniform[1], rs, out);
+            return;
+        }
+        case ZYGPU_PROC_MUL:
+            texture2(scene, p.child[0], p.child_uniform[0], rs, a);
+            texture2(scene, p.child[1], p.child_uniform[1], rs, b);
+            out[0] = a[0] * b[0], out[1] = a[1] * b[1];
+            return;
+        default: noiseNormalmap(scene, p, mode, rs, out); return;
+    }
+}
+
+inline V4 procedural3(const ZygpuSceneDesc& scene, uint32_t index, uint32_t mode, const Renderstate& rs) {
+    const ZygpuProcedural& p = scene.procedurals[index];
+    switch (p.kind) {
+        case ZYGPU_PROC_CHANNEL_MIX: {
+            const V4 c = texture3(scene, p.child[0], p.child_uniform[0], rs);
+            return mk(clampf(dot3(c, ld3(p.value[0])), 0.f, 1.f), clampf(dot3(c, ld3(p.value[1])), 0.f, 1.f), clampf(dot3(c, ld3(p.value[2])), 0.f, 1.f));
+        }
+        case ZYGPU_PROC_CHECKER: return checkerEvaluate(scene, p, mode, rs);
+        case ZYGPU_PROC_MAX: {
+            const V4 a = texture3(scene, p.child[0], p.child_uniform[0], rs), b = texture3(scene, p.child[1], p.child_uniform[1], rs);
+            return max4(a, b);
+        }
+        case ZYGPU_PROC_MIX: {
+            const float weight = texture1(scene, p.child[2], p.child_uniform[2], rs);
+            const float r = rs.sampler->sample1D();
+            return weight < r ? texture3(scene, p.child[0], p.child_uniform[0], rs) : texture3(scene, p.child[1], p.child_uniform[1], rs);
+        }
+        case ZYGPU_PROC_MUL: {
+            const V4 a = texture3(scene, p.child[0], p.child_uniform[0], rs), b = texture3(scene, p.child[1], p.child_uniform[1], rs);
+            return a * b;
+        }
+        case ZYGPU_PROC_NOISE: return S(noiseEvaluate1(p, mode, rs, S(0.f)));
+        default: return S(0.f);  // DetailNormal
+    }
+}
+
 // hlp.sampleNormal (material_helper.zig:16-78), tex_coord UV0: the normal map's xy in the tangent frame, z reconstructed, then the
 // "iray" adaption that keeps the reflection of wo above the geometric surface
 inline V4 sampleNormal(const ZygpuSceneDesc& scene, const ZygpuTexture& map, V4 wo, const Renderstate& rs) {
-    float nmxy[2], st[2];
-    rs.st(map.sampler, st);
-    sampleImageMap2(scene, map.image, map.sampler, map.scale, st[0], st[1], rs.stochastic_r, nmxy);
+    float nmxy[2];
+    texture2(scene, map, nullptr, rs, nmxy);
     const float nmz = std::sqrt(mx(1.f - (nmxy[0] * nmxy[0] + nmxy[1] * nmxy[1]), 0.01f));
     const V4    nm = mk(nmxy[0], nmxy[1], nmz);
     V4          n;
@@ -983,15 +1231,10 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.can_evaluate = false;
     } else if (ZYGPU_MAT_GLASS == m.kind) {
         // Glass.sample / Sample.init (glass_material.zig:49-79, glass_sample.zig:33-66)
-        auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
-            const ZygpuTexture& t = m.tex[slot];
-            if (kNull == t.image) return uniform;
-            float st[2];
-            rs.st(t.sampler, st);
-            return sampleImageMap1(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r);
-        };
+        auto weight = [&](uint32_t slot, float uniform) { return texture1(scene, m.tex[slot], &uniform, rs); };  // ts.sample2D_1
         const float raw_r = weight(ZYGPU_STEX_ROUGHNESS, m.roughness);
         const float r = 0.f == raw_r ? 0.f : ggx::clampRoughness(raw_r);
+        const float glass_specular = weight(ZYGPU_STEX_SPECULAR, m.specular);  // (before the normal map: a Mix draws in this order)
         if (kNull != m.tex[ZYGPU_STEX_NORMAL].image) s.frame = Frame::init(sampleNormal(scene, m.tex[ZYGPU_STEX_NORMAL], wo, rs));
         else s.frame = {rs.t, rs.b, rs.n};
         s.alpha[0] = s.alpha[1] = r * r;
@@ -1007,20 +1250,13 @@ inline MaterialSample materialSample(const ZygpuMaterial& m, const ZygpuSceneDes
         s.wavelength = rs.wavelength;
         s.translucent = m.thickness > 0.f;
         s.specular_threshold = scene.specular_threshold;
-        s.specular = weight(ZYGPU_STEX_SPECULAR, m.specular);
+        s.specular = glass_specular;
         s.lower_priority = m.priority < rs.highest_priority;  // sample_base.zig:44
     } else {
         // Substitute.sample (substitute_material.zig:114-221) without the volumetric branches
-        auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
-            const ZygpuTexture& t = m.tex[slot];
-            if (kNull == t.image) return uniform;
-            float st[2];
-            rs.st(t.sampler, st);
-            return sampleImageMap1(scene, t.image, t.sampler, t.scale, st[0], st[1], rs.stochastic_r);
-        };
-        float cst[2];
-        rs.st(m.color_sampler, cst);
-        const V4    color = kNull != m.color_image ? sampleColorMap(scene, m, cst[0], cst[1], rs.stochastic_r) : ld3(m.color_a);
+        auto weight = [&](uint32_t slot, float uniform) { return texture1(scene, m.tex[slot], &uniform, rs); };  // ts.sample2D_1
+        const ZygpuTexture color_map{m.color_image, m.color_sampler, {m.color_scale[0], m.color_scale[1]}};
+        const V4           color = texture3(scene, color_map, m.color_a, rs);
         const float roughness = ggx::clampRoughness(weight(ZYGPU_STEX_ROUGHNESS, m.roughness));
         const float metallic = weight(ZYGPU_STEX_METALLIC, m.metallic);
         const float specular = weight(ZYGPU_STEX_SPECULAR, m.specular);

@@ -50,6 +50,11 @@ class Texture(ctypes.Structure):
 
 
 STEX_COUNT = 10  # enum ZygpuSubstituteTexture
+(STEX_ROUGHNESS, STEX_METALLIC, STEX_SPECULAR, STEX_ROTATION, STEX_TRANSLUCENCY, STEX_COATING_SCALE, STEX_COATING_ROUGHNESS,
+ STEX_FLAKES_COVERAGE, STEX_NORMAL, STEX_COATING_NORMAL) = range(STEX_COUNT)
+# ZYGPU_TEX_* sampler bits, ZYGPU_MATF_* material flags (include/zygpu.h)
+TEX_LINEAR, TEX_REPEAT_U, TEX_REPEAT_V, TEX_SNORM, TEX_TRIPLANAR, TEX_OBJECTPOS, TEX_PROCEDURAL = 1, 2, 4, 8, 16, 32, 64
+MATF_TWO_SIDED, MATF_EVALUATE_VISIBILITY, MATF_CAUSTIC, MATF_EMISSIVE, MATF_EXTENDED, MATF_PROCEDURAL = 1, 2, 4, 8, 16, 32
 
 
 class Material(ctypes.Structure):
@@ -127,6 +132,13 @@ class Keyframe(ctypes.Structure):
     _fields_ = [("position", ctypes.c_float * 4), ("scale", ctypes.c_float * 4), ("rotation", ctypes.c_float * 4)]
 
 
+class Procedural(ctypes.Structure):  # include/zygpu.h ZygpuProcedural
+    _fields_ = [("kind", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("levels", ctypes.c_uint32), ("checker_scale", ctypes.c_float),
+                ("attenuation", ctypes.c_float), ("ratio", ctypes.c_float), ("transition", ctypes.c_float), ("pad", ctypes.c_float),
+                ("scale", ctypes.c_float * 4), ("period", ctypes.c_float * 4), ("value", (ctypes.c_float * 4) * 3),
+                ("child", Texture * 3), ("child_uniform", (ctypes.c_float * 4) * 3)]
+
+
 class SceneDesc(ctypes.Structure):
     _fields_ = [("props", ctypes.POINTER(Prop)), ("trafos", ctypes.POINTER(Trafo)), ("aabbs", ctypes.POINTER(Aabb)),
                 ("material_ids", ctypes.POINTER(ctypes.c_uint32)), ("light_ids", ctypes.POINTER(ctypes.c_uint32)),
@@ -143,7 +155,8 @@ class SceneDesc(ctypes.Structure):
                 ("keyframes", ctypes.POINTER(Keyframe)), ("prop_frames", ctypes.POINTER(ctypes.c_uint32)),
                 ("num_keyframes", ctypes.c_uint32), ("num_interpolation_frames", ctypes.c_uint32), ("origin", ctypes.c_float * 4),
                 ("sun_radiance", ctypes.POINTER(ctypes.c_float)), ("num_sun_radiance", ctypes.c_uint32),
-                ("num_portal_lights", ctypes.c_uint32), ("portal_lights", ctypes.POINTER(PortalLight))]
+                ("num_portal_lights", ctypes.c_uint32), ("portal_lights", ctypes.POINTER(PortalLight)),
+                ("procedurals", ctypes.POINTER(Procedural)), ("num_procedurals", ctypes.c_uint32)]
 
 
 class ViewDesc(ctypes.Structure):

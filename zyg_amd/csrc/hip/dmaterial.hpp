@@ -797,19 +797,39 @@ ZD f3 sampleColorMapAt(const DScene& s, const ZygpuMaterial& m, float u, float v
     return sampleImageMap(s, m.color_image, m.color_sampler, m.color_scale, su, sv, r);
 }
 
+// Where wf_textures (wavefront.hpp, dprocedural.hpp) leaves the values of a vertex' procedural textures: planes of Params::tex_values,
+// one float per vertex and plane
+enum : uint32_t {
+    kTexColor = 0,                                // 3 planes
+    kTexWeight = 3,                               // + ZYGPU_STEX_ROUGHNESS .. ZYGPU_STEX_FLAKES_COVERAGE
+    kTexNormal = kTexWeight + ZYGPU_STEX_NORMAL,  // 2 planes
+    kTexCoatingNormal = kTexNormal + 2,           // 2 planes
+    kTexDraws = kTexCoatingNormal + 2,            // the sampler dimensions the vertex' Mix textures drew (an integer's bits)
+    kTexPlanes = kTexDraws + 1
+};
+
 // What the complete Substitute closure reads of the fragment beyond its frame (Renderstate: uv, stochastic_r, p, trafo)
+// `tex`: the vertex' entry of the first plane of its procedural textures' values (null: the scene has none)
 struct FragmentExtra {
     float u, v, stochastic_r;
     f3    p;
     Trafo trafo;
+    const float* tex = nullptr;
+    size_t       tex_plane = 0;
+    ZD float texValue(uint32_t plane) const { return tex[size_t(plane) * tex_plane]; }
 };
 
 // hlp.sampleNormal (material_helper.zig:16-78), tex_coord UV0: the normal map's xy in the tangent frame, z reconstructed, then the
 // "iray" adaption that keeps the reflection of wo above the geometric surface
-ZD f3 sampleNormal(const DScene& s, const ZygpuTexture& map, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, const FragmentExtra& fx) {
+ZD f3 sampleNormal(const DScene& s, const ZygpuTexture& map, f3 wo, f3 geo_n, f3 t, f3 b, f3 n, const FragmentExtra& fx, uint32_t plane = kTexNormal) {
     float nx, ny, su, sv;
-    textureSt(map.sampler, fx.u, fx.v, fx.p, geo_n, fx.trafo, su, sv);
-    sampleImageMap2(s, map.image, map.sampler, map.scale, su, sv, fx.stochastic_r, nx, ny);
+    if (map.sampler & ZYGPU_TEX_PROCEDURAL) {  // evaluated by wf_textures
+        nx = fx.texValue(plane);
+        ny = fx.texValue(plane + 1u);
+    } else {
+        textureSt(map.sampler, fx.u, fx.v, fx.p, geo_n, fx.trafo, su, sv);
+        sampleImageMap2(s, map.image, map.sampler, map.scale, su, sv, fx.stochastic_r, nx, ny);
+    }
     const float nz = sqrtf(mx(1.f - (nx * nx + ny * ny), 0.01f));
     f3          nn;
     if (map.sampler & ZYGPU_TEX_OBJECTPOS) {  // a frame around the interpolated normal (material_helper.zig:24-29)
@@ -948,12 +968,20 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
             const ZygpuTexture & tr = m.tex[ZYGPU_STEX_ROUGHNESS], &tsp = m.tex[ZYGPU_STEX_SPECULAR], &tn = m.tex[ZYGPU_STEX_NORMAL];
             float su, sv;
             if (kNull != tr.image) {
-                textureSt(tr.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
-                raw_r = sampleImageMap1(s, tr.image, tr.sampler, tr.scale, su, sv, f.stochastic_r);
+                if (tr.sampler & ZYGPU_TEX_PROCEDURAL) {
+                    raw_r = f.texValue(kTexWeight + ZYGPU_STEX_ROUGHNESS);
+                } else {
+                    textureSt(tr.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
+                    raw_r = sampleImageMap1(s, tr.image, tr.sampler, tr.scale, su, sv, f.stochastic_r);
+                }
             }
             if (kNull != tsp.image) {
-                textureSt(tsp.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
-                specular = sampleImageMap1(s, tsp.image, tsp.sampler, tsp.scale, su, sv, f.stochastic_r);
+                if (tsp.sampler & ZYGPU_TEX_PROCEDURAL) {
+                    specular = f.texValue(kTexWeight + ZYGPU_STEX_SPECULAR);
+                } else {
+                    textureSt(tsp.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
+                    specular = sampleImageMap1(s, tsp.image, tsp.sampler, tsp.scale, su, sv, f.stochastic_r);
+                }
             }
             if (kNull != tn.image) ms.frame = Frame::init(sampleNormal(s, tn, wo, geo_n, t, b, n, f));
         }
@@ -974,6 +1002,7 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
         auto weight = [&](uint32_t slot, float uniform) {  // ts.sample2D_1
             const ZygpuTexture& tx = m.tex[slot];
             if (kNull == tx.image) return uniform;
+            if (tx.sampler & ZYGPU_TEX_PROCEDURAL) return f.texValue(kTexWeight + slot);  // evaluated by wf_textures
             float su, sv;
             textureSt(tx.sampler, f.u, f.v, f.p, geo_n, f.trafo, su, sv);
             return sampleImageMap1(s, tx.image, tx.sampler, tx.scale, su, sv, f.stochastic_r);
@@ -1009,7 +1038,7 @@ ZD MaterialSample makeMaterialSample(const DScene& s, const ZygpuMaterial& m, f3
             // Texture.equal: the same description (two uniform maps are equal, too)
             const bool same = nm.image == cnm.image && (kNull == nm.image || (nm.sampler == cnm.sampler && nm.scale[0] == cnm.scale[0] && nm.scale[1] == cnm.scale[1]));
             if (same) ms.coating.n = ms.frame.z;
-            else if (kNull != cnm.image) ms.coating.n = sampleNormal(s, cnm, wo, geo_n, t, b, n, f);
+            else if (kNull != cnm.image) ms.coating.n = sampleNormal(s, cnm, wo, geo_n, t, b, n, f, kTexCoatingNormal);
             else ms.coating.n = n;
             const float r = mx(weight(ZYGPU_STEX_COATING_ROUGHNESS, m.coating_roughness), kMinRoughness);
             ms.coating.absorption_coef = mk3(m.coating_absorption[0], m.coating_absorption[1], m.coating_absorption[2]);

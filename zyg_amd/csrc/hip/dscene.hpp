@@ -169,6 +169,7 @@ struct DScene {
     const uint32_t*      infinite_props;
     uint32_t             num_infinite_props;
     const DImage*        images;
+    const ZygpuProcedural* procedurals;  // what the ZYGPU_TEX_PROCEDURAL textures index (null: the scene has none); dprocedural.hpp
     const float*         srgb_to_float;
     const float*         lut_e_m;
     const float*         lut_e_m_avg;

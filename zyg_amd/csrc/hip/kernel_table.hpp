@@ -12,6 +12,7 @@
 //   wf_light<MULTI, MASKS> + wf_scatter<.., PHASE 2>: the POOL scenes' complete wf_scatter in two kernels (wavefront.hpp scatterVertex)
 //   wf_trace_shade<STATS, MESHL, FIRST, UTLAS>   wf_scatter<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS>
 //   wf_rgenerate (1024-thread blocks)   wf_rtrace<WIDE>   wf_rscatter<SUBST, WIDE> (the regenerating kernels; Params::regen_*)
+//   wf_textures<POOL> (the vertices' procedural textures, dprocedural.hpp; unit ZYG_TEXTURES_UNIT)
 //   wf_nee<FIRST, SUBST>   wf_shadow<STATS>   wf_shadow_u / wf_mesh_closest (persistent: launched with persistentGrid blocks)   wf_scatter_h<RESUME, SUBST>   wf_extend<SUBST, EXTRA>   wf_persistent<SUBST, MULTI, WIDE>   wf_tick<SUBST, MULTI, WIDE>
 #pragma once
 
@@ -79,6 +80,8 @@
     X(7, K_INTERSECT_EXTRA_POOL, (wf_intersect<false, true, true>),                   (P)) \
     X(7, K_INTERSECT_EXTRA_POOL_WIDE, ZYG_WIDE((wf_intersect<false, true, true, true>), (wf_intersect<false, true, true>)), (P)) \
     X(7, K_POOL_RESET,           (wf_pool_reset<true>),                               (P)) \
+    X(2, K_TEXTURES,             (wf_textures<false>),                                (P)) \
+    X(2, K_TEXTURES_POOL,        (wf_textures<true>),                                 (P)) \
     X(7, K_TRACE_SHADE_POOL,     (wf_trace_shade_pool<false>),                        (P, arg)) \
     X(7, K_TRACE_SHADE_POOL_WIDE, ZYG_WIDE((wf_trace_shade_pool<true>), (wf_trace_shade_pool<false>)), (P, arg)) \
     X(6, K_TRACE_SHADE_POOL_FIRST, (wf_trace_shade_pool<false, true>),                (P, arg)) \

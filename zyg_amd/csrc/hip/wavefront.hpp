@@ -259,6 +259,11 @@ struct Params {
     uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits; 2: wf_mesh_closest8 has walked the large meshes for them, wf_trace_shade tests the rest of the table
     uint32_t alive_key_mask;  // wf_scatter_h: bit k = the launch takes sub-queue k of the sorted alive queue
     uint32_t lazy_head;  // 1 (option "lazy_head", with hit_q): the first shading pass leaves a vertex' sampler and throughput to wf_scatter (shadeVertex)
+    // The values of the vertices' procedural textures (dprocedural.hpp; null: the scene has none): kTexPlanes planes of tex_plane floats,
+    // indexed like the pool's records (by path slot; POOL: by vertex).  wf_textures writes them between the shading passes and the
+    // kernels that build the closure, which read them where they would have fetched a texel (FragmentExtra::tex, loadSurface)
+    float*   tex_values;
+    size_t   tex_plane;
 };
 
 // one copy per translation unit (kernel_table.hpp): the units are built without relocatable device code
@@ -932,16 +937,19 @@ ZD bool entersMeshBounds(f3 origin, f3 direction) {
 // keyframe interval and the weight (space.zig:127-137), math.Transformation.lerp interpolates position and scale linearly and
 // the rotation with quaternion.slerp (transformation.zig:36-44, quaternion.zig:217-245), ComposedTransformation.init rebuilds
 // the rotation rows (composed_transformation.zig:17-29, quaternion.zig:72-116).  Keyframes are one tick (1/60 s) apart.
+// `since`: the time in ticks since the start of the frame's first keyframe interval (scene.zig:186-187: what Pool::time holds)
+ZD Trafo cameraTrafoSince(const ZygpuViewDesc& v, uint64_t since);
 ZD Trafo cameraTrafoAt(const ZygpuViewDesc& v, uint32_t frame, float shutter_sample) {
     const uint64_t tick = 705600000ull / 60;  // space.zig:18-19
     // Base.absoluteTime (camera_base.zig:129-136); no shutter distribution, so the shutter time is the sample (121-127)
     const uint64_t fdi = uint64_t(llround(double(shutter_sample) * double(v.frame_duration)));
     const uint64_t start_time = uint64_t(frame) * v.frame_step;
-    const uint64_t time = start_time + fdi;
-    const uint64_t frame_start = start_time - (start_time % tick);  // scene.zig:186-187
-    uint64_t       i = (time - frame_start) / tick;
-    const uint64_t a_time = frame_start + i * tick;
-    float          wgt = float(double(time - a_time) / double(tick));
+    return cameraTrafoSince(v, fdi + (start_time % tick));
+}
+ZD Trafo cameraTrafoSince(const ZygpuViewDesc& v, uint64_t since) {
+    const uint64_t tick = 705600000ull / 60;
+    uint64_t       i = since / tick;
+    float          wgt = float(double(since - i * tick) / double(tick));
     // a shutter sample of exactly 1.0 lands on the last keyframe, where the reference reads one keyframe past its array
     if (i + 1 >= v.camera_num_keyframes) {
         i = v.camera_num_keyframes - 2;
@@ -1106,7 +1114,9 @@ ZD void generatePath(const Params& P, uint32_t slot, PathHead* keep = nullptr, f
         clearAccumulators<!POOL>(P, slot);  // (the indirect sum's spare lane = 0 = the packed geo_n.z)
     }
     P.stage_uv[sample] = make_float2(s0, s1);
-    if (AOV && c_scene.prop_frames) {  // AOV = the MESHL instantiations: Probe.time for the animated props (camera_base.zig:129-136)
+    // AOV = the MESHL instantiations: Probe.time for the animated props (camera_base.zig:129-136), and for the camera's transformation
+    // at a vertex where a procedural texture asks for the pixel's footprint (context.zig:140)
+    if (AOV && (c_scene.prop_frames || (c_scene.procedurals && v.camera_num_keyframes > 1))) {
         const uint64_t tick = 705600000ull / 60, start_time = uint64_t(c_view.frame) * v.frame_step;
         const uint64_t fdi = uint64_t(llround(double(shutter_sample) * double(v.frame_duration)));
         P.pool.time[slot] = uint32_t(fdi + (start_time % tick));
@@ -1703,7 +1713,7 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
                 P.pool.rec_p[slot] = f4(frag.p, __uint_as_float(mat_id));
                 P.pool.rec_gn[slot] = f4(geo_n, flipped ? 1.f : 0.f);
                 f3 color = S3(0.f);  // Substitute.sample's colour fetch (substitute_material.zig:120), for image maps
-                if (MESHL && kNull != m.color_image) color = sampleColorMapAt(s, m, frag.uv0, frag.uv1, stochastic_r, frag.p, geo_n, frag.trafo);
+                if (MESHL && kNull != m.color_image && !(m.color_sampler & ZYGPU_TEX_PROCEDURAL)) color = sampleColorMapAt(s, m, frag.uv0, frag.uv1, stochastic_r, frag.p, geo_n, frag.trafo);
                 P.pool.rec_n[slot] = f4(n, color.x);
                 P.pool.rec_t[slot] = f4(frag.t, color.y);
                 P.pool.rec_b[slot] = f4(frag.b, color.z);
@@ -2086,6 +2096,21 @@ ZD Regularize loadRegularize(const Params& P, uint32_t slot) {
     return r;
 }
 
+// a procedural colour as wf_textures left it
+ZD f3 textureColor(const Params& P, uint32_t slot) {
+    const float* t = P.tex_values + slot;
+    return mk3(t[size_t(kTexColor) * P.tex_plane], t[size_t(kTexColor + 1u) * P.tex_plane], t[size_t(kTexColor + 2u) * P.tex_plane]);
+}
+// The sampler dimensions the vertex' procedural textures drew in wf_textures (a Mix picks one of its two children with one,
+// procedural_mix.zig:17-26): Material.sample comes before the vertex' light and bxdf samples (pathtracer_mis.zig:93), so the kernel
+// that draws those skips as many first
+ZD uint32_t skipTextureDraws(const Params& P, uint32_t slot, uint32_t material, PathHead& h) {
+    if (!P.tex_values || !(c_scene.materials[material].flags & ZYGPU_MATF_PROCEDURAL)) return 0u;
+    const uint32_t n = __float_as_uint(P.tex_values[size_t(kTexDraws) * P.tex_plane + slot]);
+    for (uint32_t k = 0; k < n; ++k) (void)h.smp.sample1D();
+    return n;
+}
+
 // POOL: from the record wf_shade wrote.  Otherwise from the hit: the fragment is rebuilt here (Shape.fragment), followed by
 // Vertex.sample's two-sided flip (vertex.zig:155-161) and the colour-map fetch with the stochastic_r wf_shade drew: the path
 // carries 36 B of hit instead of an 80 B record.  EXTRA: Sphere / Disk / Cube fragments.
@@ -2115,7 +2140,8 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
             n = -n;
         }
         f3 color = mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
-        if (EXTRA && kNull != m.color_image) color = sampleColorMapAt(s, m, frag.uv0, frag.uv1, hit_sr, frag.p, geo_n, frag.trafo);
+        if (EXTRA && kNull != m.color_image)
+            color = (m.color_sampler & ZYGPU_TEX_PROCEDURAL) ? textureColor(P, slot) : sampleColorMapAt(s, m, frag.uv0, frag.uv1, hit_sr, frag.p, geo_n, frag.trafo);
         const bool caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
         Surface    sf;
         sf.p = frag.p;
@@ -2124,7 +2150,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
         sf.material = material;
         const Regularize reg = loadRegularize(P, slot);
         if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
-            const FragmentExtra fx{frag.uv0, frag.uv1, hit_sr, frag.p, frag.trafo};
+            const FragmentExtra fx{frag.uv0, frag.uv1, hit_sr, frag.p, frag.trafo, P.tex_values ? P.tex_values + slot : nullptr, P.tex_plane};
             sf.ms = makeMaterialSample<EXTRA>(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, &fx, reg);
         } else {
             sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, nullptr, reg);
@@ -2140,7 +2166,8 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
     const f3     wo = -xyz4(prd);
     const ZygpuMaterial& m = c_scene.materials[__float_as_uint(rp.w)];
     // a colour map was sampled by wf_shade (it has the uv and the stochastic_r draw) into the records' spare lanes
-    const f3     color = kNull != m.color_image ? mk3(rn.w, rt.w, rb.w) : mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
+    const f3     color = kNull != m.color_image ? ((EXTRA && (m.color_sampler & ZYGPU_TEX_PROCEDURAL)) ? textureColor(P, slot) : mk3(rn.w, rt.w, rb.w))
+                                                : mk3(m.color_a[0], m.color_a[1], m.color_a[2]);
     const bool   caustics = (flags & ST_PRIMARY) ? true : 0 != c_view.v.caustics_path;  // causticsResolve
     Surface      sf;
     sf.p = xyz4(rp);
@@ -2153,7 +2180,8 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
         if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
             const float2        uv = P.pool.rec_uv[slot];
             const FragmentExtra fx{uv.x, uv.y, P.pool.hit_sr[slot], sf.p,
-                                   propTrafoAt<true>(c_scene, P.pool.hit_prop[slot], pathTime<true, true>(P, slot))};
+                                   propTrafoAt<true>(c_scene, P.pool.hit_prop[slot], pathTime<true, true>(P, slot)),
+                                   P.tex_values ? P.tex_values + slot : nullptr, P.tex_plane};
             sf.ms = makeMaterialSample<EXTRA>(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, &fx, reg);
         } else {
             sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, nullptr, reg);
@@ -2785,6 +2813,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_EXTEND_WAVES) wf_extend(Par
         loadHead(P, slot, h);
         const Surface sf = loadSurface<false, EXTRA>(P, slot, h.flags);
         f3            throughput = xyz4(P.pool.thr[slot]);
+        if (EXTRA) skipTextureDraws(P, slot, sf.material, h);
         if (EXTRA && c_view.v.aov_slots) commonAov(P, slot, slot, h, sf, throughput);
 
         if (h.nee & kNeePending) finishLightPick(P, slot, h);
@@ -3006,6 +3035,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         if (continuation_probability < 1.f) throughput = throughput / S3(continuation_probability);
         (void)h.smp.sample1D();
     }
+    const uint32_t texture_draws = (MESHL && 2 != PHASE) ? skipTextureDraws(P, slot, sf.material, h) : 0u;
 
     if (2 == PHASE && kNeeOverflow == P.nee_count[ps]) return;  // wf_light sent the vertex through the unsplit kernel
     if (MESHL && 1 != PHASE && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput, record);
@@ -3376,7 +3406,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
             out.push = true;
         } else {
             P.nee_count[ps] = stored;
-            if (stored || (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate)) storeSamplers(P, ps, h);
+            if (stored || texture_draws || (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate)) storeSamplers(P, ps, h);
         }
         return;
     }
@@ -3688,6 +3718,143 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_W
     tm.flush(P.ctl, 16);
     if (STATS) flushCounters(P, 2, cnt, shadow_rays);
 }
+
+// ---------------------------------------------------------------- wf_textures
+// The procedural textures of the tick's surviving vertices (dprocedural.hpp), launched between the shading passes and the kernels that
+// build the closure, in scenes that have a material with ZYGPU_MATF_PROCEDURAL only.  One thread per entry of the alive queue (POOL:
+// of the round's).  The vertex' Renderstate is rebuilt as loadSurface rebuilds it; the textures are evaluated in the order
+// Material.sample reads them (substitute_material.zig:121-187, glass_material.zig:50-73), so that the sampler dimensions Mix textures
+// draw are the reference's; the draws are not written back: the kernel that takes the vertex' light and bxdf samples repeats them
+// (skipTextureDraws).  Compiled in one kernel unit (kernel_table.hpp); the others see the declaration.
+#ifndef ZYG_TEXTURES_UNIT
+#define ZYG_TEXTURES_UNIT 2
+#endif
+template <bool POOL>
+__global__ void wf_textures(Params P);
+
+#if defined(ZYG_TU) && ZYG_TEXTURES_UNIT == ZYG_TU
+}  // namespace zd
+#include "dprocedural.hpp"
+namespace zd {
+
+template <bool POOL>
+__global__ void __launch_bounds__(256) wf_textures(Params P) {
+    if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       at;
+    bool           has_entry;
+    if (!aliveOpen(P, P.parity, i, at, has_entry)) return;
+    if (!has_entry) return;
+    const DScene&  s = c_scene;
+    const uint32_t slot = P.alive_in[at];
+    const uint32_t ps = sampleSlot<POOL>(slot);
+    PathHead       h;
+    loadHead<POOL>(P, slot, h);
+    TexState rs;
+    uint32_t material;
+    f3       wo;
+    if (!POOL) {
+        const HitRecord hr = P.hit_q ? loadQueuedHit(P, at) : loadHitRecord(P, slot);
+        if (hr.lazy) {  // the first shading pass' two draws (scatterVertex repeats them the same way)
+            (void)h.smp.sample1D();
+            (void)h.smp.sample1D();
+        }
+        const float4 ro = P.pool.ray_o[slot], rd = P.pool.ray_d[slot];
+        const Hit    hit{__uint_as_float(hr.hit.x), __uint_as_float(hr.hit.y), __uint_as_float(hr.hit.z), hr.hit.w, hr.prop};
+        Ray          ray = Ray::init(xyz4(ro), xyz4(rd), 0.f, hit.t);
+        ray.time = pathTime<false, true>(P, slot);
+        Fragment frag;
+        makeFragment<true>(s, ray, hit, frag);
+        wo = -ray.direction;
+        material = s.material_ids[s.props[frag.prop].parts_start + frag.part];
+        rs.p = frag.p;
+        rs.geo_n = frag.geo_n;
+        if ((s.materials[material].flags & ZYGPU_MATF_TWO_SIDED) && !frag.sameHemisphere(wo)) rs.geo_n = -frag.geo_n;  // vertex.zig:155-161
+        rs.trafo = frag.trafo;
+        rs.u = frag.uv0;
+        rs.v = frag.uv1;
+        rs.stochastic_r = hr.stochastic_r;
+        rs.prop = frag.prop;
+        rs.primitive = hit.primitive;
+    } else {
+        const float4 rp = P.pool.rec_p[slot], rg = P.pool.rec_gn[slot];
+        const float2 uv = P.pool.rec_uv[slot];
+        material = __float_as_uint(rp.w);
+        rs.p = xyz4(rp);
+        rs.geo_n = xyz4(rg);  // (flipped by wf_shade where the material is two-sided)
+        rs.prop = P.pool.hit_prop[slot];
+        rs.trafo = propTrafoAt<true>(s, rs.prop, pathTime<true, true>(P, slot));
+        rs.u = uv.x;
+        rs.v = uv.y;
+        rs.stochastic_r = P.pool.hit_sr[slot];
+        rs.primitive = P.pool.hit.get(slot).w;
+    }
+    const ZygpuMaterial& m = s.materials[material];
+    if (!(m.flags & ZYGPU_MATF_PROCEDURAL)) return;
+    {  // context.camera at rs.time (scene.propTransformationAt, context.zig:140, 213)
+        const ZygpuViewDesc& v = c_view.v;
+        if (v.camera_num_keyframes > 1) {
+            rs.camera = cameraTrafoSince(v, P.pool.time[ps]);
+        } else {
+            rs.camera.r0 = mk3(v.camera_trafo.r[0][0], v.camera_trafo.r[0][1], v.camera_trafo.r[0][2]);
+            rs.camera.r1 = mk3(v.camera_trafo.r[1][0], v.camera_trafo.r[1][1], v.camera_trafo.r[1][2]);
+            rs.camera.r2 = mk3(v.camera_trafo.r[2][0], v.camera_trafo.r[2][1], v.camera_trafo.r[2][2]);
+            rs.camera.scale = mk3(v.camera_trafo.r[0][3], v.camera_trafo.r[1][3], v.camera_trafo.r[2][3]);
+            rs.camera.position = mk3(v.camera_trafo.position[0], v.camera_trafo.position[1], v.camera_trafo.position[2]);
+        }
+    }
+    rs.smp = &h.smp;
+    rs.draws = 0;
+    constexpr int kTop = ZYGPU_PROCEDURAL_MAX_DEPTH - 1;
+    float*        out = P.tex_values + slot;
+    const size_t  plane = P.tex_plane;
+    auto procedural = [](const ZygpuTexture& t) { return kNull != t.image && 0 != (t.sampler & ZYGPU_TEX_PROCEDURAL); };
+    // ts.sample2D_1 of tex[k]: the value where the kernel needs it itself (coating_scale), stored where the texture is procedural
+    auto weight = [&](uint32_t k, float uniform) {
+        const ZygpuTexture& t = m.tex[k];
+        if (!procedural(t)) return kNull == t.image ? uniform : texture1<0>(s, t, &uniform, rs);
+        const float value = procedural1<kTop>(s, t.image, t.sampler, rs);
+        out[size_t(kTexWeight + k) * plane] = value;
+        return value;
+    };
+    auto weightIfProcedural = [&](uint32_t k) {
+        if (procedural(m.tex[k])) out[size_t(kTexWeight + k) * plane] = procedural1<kTop>(s, m.tex[k].image, m.tex[k].sampler, rs);
+    };
+    auto normalIfProcedural = [&](uint32_t k, uint32_t at_plane) {
+        if (!procedural(m.tex[k])) return;
+        const float2 n = procedural2<kTop>(s, m.tex[k].image, m.tex[k].sampler, rs);
+        out[size_t(at_plane) * plane] = n.x;
+        out[size_t(at_plane + 1u) * plane] = n.y;
+    };
+    if (ZYGPU_MAT_GLASS == m.kind) {  // glass_material.zig:50-73: roughness, specular, the normal map
+        weightIfProcedural(ZYGPU_STEX_ROUGHNESS);
+        weightIfProcedural(ZYGPU_STEX_SPECULAR);
+        normalIfProcedural(ZYGPU_STEX_NORMAL, kTexNormal);
+    } else {  // substitute_material.zig:121-187
+        if (kNull != m.color_image && (m.color_sampler & ZYGPU_TEX_PROCEDURAL)) {
+            const f3 c = procedural3<kTop>(s, m.color_image, m.color_sampler, rs);
+            out[size_t(kTexColor) * plane] = c.x;
+            out[size_t(kTexColor + 1u) * plane] = c.y;
+            out[size_t(kTexColor + 2u) * plane] = c.z;
+        }
+        weightIfProcedural(ZYGPU_STEX_ROUGHNESS);
+        weightIfProcedural(ZYGPU_STEX_METALLIC);
+        weightIfProcedural(ZYGPU_STEX_SPECULAR);
+        const float coating_scale = weight(ZYGPU_STEX_COATING_SCALE, m.coating_scale);
+        weightIfProcedural(ZYGPU_STEX_TRANSLUCENCY);
+        normalIfProcedural(ZYGPU_STEX_NORMAL, kTexNormal);
+        if (coating_scale * m.coating_thickness > 0.f) {
+            const ZygpuTexture &nm = m.tex[ZYGPU_STEX_NORMAL], &cnm = m.tex[ZYGPU_STEX_COATING_NORMAL];
+            const bool same = nm.image == cnm.image && (kNull == nm.image || (nm.sampler == cnm.sampler && nm.scale[0] == cnm.scale[0] && nm.scale[1] == cnm.scale[1]));
+            if (!same) normalIfProcedural(ZYGPU_STEX_COATING_NORMAL, kTexCoatingNormal);
+            weightIfProcedural(ZYGPU_STEX_COATING_ROUGHNESS);
+        }
+        weightIfProcedural(ZYGPU_STEX_ROTATION);
+        weightIfProcedural(ZYGPU_STEX_FLAKES_COVERAGE);
+    }
+    out[size_t(kTexDraws) * plane] = __uint_as_float(rs.draws);
+}
+#endif
 
 // ---------------------------------------------------------------- wf_tick
 // wf_scatter for vertex k and wf_trace_shade for vertex k + 1 of the same path in one launch (option "fuse_tick"; scenes

@@ -616,6 +616,10 @@ struct ZygpuContext {
     bool          split_materials = true;
     uint32_t      max_light_samples = 0;   // upper bound of the light samples of one vertex (zygpu_upload_scene)
     bool          extended_materials = false;  // a material carries ZYGPU_MATF_EXTENDED (textures, coating, flakes ...): the complete closure
+    bool          procedurals = false;         // a material in use carries ZYGPU_MATF_PROCEDURAL: wf_textures runs, the pool holds Params::tex_values
+    bool          procedurals_allocated = false;
+    float*        tex_values = nullptr;
+    size_t        tex_plane = 0;
     uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
     float4*       nee_rec = nullptr;       // Params::nee_rec / nee_count (POOL pool)
     uint32_t*     nee_count = nullptr;
@@ -738,16 +742,16 @@ size_t poolBytesPerSample(const ZygpuContext* c, uint32_t rounds, uint32_t alive
     if (c->pool_mode) {
         // 2 x kPoolVertices vertices: the 256 B block + 4 unoccluding candidates (8 B each) + (catchers) three sums; the sample's line, staging,
         // wf_light's records, time, eight extension queues + alive, shadow, heavy
-        const size_t vertex = 256 + kMaxUnoccludingCandidates * 8 + (c->catchers ? 48 : 0);
+        const size_t vertex = 256 + kMaxUnoccludingCandidates * 8 + (c->catchers ? 48 : 0) + (c->procedurals ? kTexPlanes * 4 : 0);
         return 2 * kPoolVertices * vertex + 128 + 24 + 3 * kMaxNeeStored * 16 + 4 + 4 + (c->catchers ? 16 : 0) + (2 * kPoolVertices + 3) * 4 * 2;
     }
     return size_t(ZYG_POOL_STRIDE ? ZYG_POOL_STRIDE : 17 * 16) + ZYG_HIT_STRIDE + kMaxUnoccludingCandidates * 8 + 24 + 8 * std::max(1u, rounds) + 56 + 4 +
-           (4 + alive_keys) * 4 * 2 + (hit_q ? 64 : 0) + 48;
+           (4 + alive_keys) * 4 * 2 + (hit_q ? 64 : 0) + 48 + (c->procedurals ? kTexPlanes * 4 : 0);
 }
 
 int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_keys, bool hit_q) {
     if (slots <= c->pool_capacity && rounds <= c->pool_rounds && c->pool_mode == c->pool_allocated && c->catchers == c->catchers_allocated &&
-        alive_keys <= c->alive_keys_allocated && (!hit_q || c->hit_q))
+        alive_keys <= c->alive_keys_allocated && (!hit_q || c->hit_q) && (!c->procedurals || c->procedurals_allocated))
         return 0;
     slots = std::max(slots, c->pool_capacity);
     rounds = std::max(rounds, c->pool_rounds);
@@ -837,6 +841,14 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_ke
          m.alloc(slots, &p.time) &&
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy) &&
          (!hit_q || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
+    c->tex_values = nullptr;
+    c->tex_plane = 0;
+    c->procedurals_allocated = false;
+    if (ok && c->procedurals) {  // Params::tex_values: kTexPlanes floats per path slot (POOL: per vertex)
+        ok = m.alloc(paths * size_t(kTexPlanes), &c->tex_values);
+        c->tex_plane = paths;
+        c->procedurals_allocated = ok;
+    }
     c->nee_rec = nullptr;
     c->nee_count = nullptr;
     if (ok && c->pool_mode) {
@@ -1317,9 +1329,54 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     }
     if (!m.upload(images.data(), images.size(), &s.images)) return -1;
     if (!m.upload(d->srgb_to_float, d->srgb_to_float ? 256 : 0, &s.srgb_to_float)) return -1;
+    // procedural textures (dprocedural.hpp): the table, and every index a material or a procedural's child holds checked against it
+    s.procedurals = nullptr;
+    c->procedurals = false;
+    {
+        auto bad = [&](const ZygpuTexture& t, bool normal_or_weight) {
+            (void)normal_or_weight;
+            if (ZYGPU_NULL == t.image) return false;
+            if (t.sampler & ZYGPU_TEX_PROCEDURAL) return t.image >= d->num_procedurals || !d->procedurals;
+            return t.image >= d->num_images;
+        };
+        for (uint32_t k = 0; k < d->num_procedurals && d->procedurals; ++k) {
+            const ZygpuProcedural& pr = d->procedurals[k];
+            bool wrong = pr.kind > ZYGPU_PROC_NOISE || (ZYGPU_PROC_NOISE == pr.kind && pr.levels > 32u);
+            for (const ZygpuTexture& t : pr.child) wrong = wrong || bad(t, true);
+            // a child names an earlier entry (the host appends a procedural after its children): no cycles, and the depth is the host's to bound
+            for (const ZygpuTexture& t : pr.child) wrong = wrong || (ZYGPU_NULL != t.image && (t.sampler & ZYGPU_TEX_PROCEDURAL) && t.image >= k);
+            if (wrong) {
+                g_error = "ZygpuSceneDesc.procedurals: an entry with an unknown kind, more than 32 noise levels or a child that is not an earlier entry / an image";
+                return -2;
+            }
+        }
+        for (uint32_t pi = 0; pi < d->num_parts; ++pi) {
+            const ZygpuMaterial& pm = d->materials[d->material_ids[pi]];
+            bool                 wrong = false, any = false;
+            if (ZYGPU_NULL != pm.color_image && (pm.color_sampler & ZYGPU_TEX_PROCEDURAL)) {
+                any = true;
+                wrong = pm.color_image >= d->num_procedurals || !d->procedurals;
+            }
+            for (const ZygpuTexture& t : pm.tex)
+                if (ZYGPU_NULL != t.image && (t.sampler & ZYGPU_TEX_PROCEDURAL)) any = true, wrong = wrong || bad(t, true);
+            for (const uint32_t sampler : {pm.emission_sampler, pm.mask_sampler, pm.profile_sampler})
+                if (sampler & ZYGPU_TEX_PROCEDURAL) wrong = true;  // (evaluated as images only)
+            if (any && !(pm.flags & ZYGPU_MATF_PROCEDURAL)) wrong = true;
+            if (any && ZYGPU_MAT_SUBSTITUTE != pm.kind && ZYGPU_MAT_GLASS != pm.kind) wrong = true;
+            if (wrong) {
+                g_error = "a material's procedural texture: an index outside ZygpuSceneDesc.procedurals, a procedural mask / emission map / profile, or ZYGPU_MATF_PROCEDURAL not set";
+                return -2;
+            }
+            if (any) c->procedurals = true;
+        }
+        if (c->procedurals) {
+            if (!m.upload(d->procedurals, d->num_procedurals, &s.procedurals)) return -1;
+            c->mesh_lights = true;  // the complete instantiations read the values (FragmentExtra::tex)
+        }
+    }
     for (uint32_t mi = 0; mi < d->num_materials; ++mi) {
         const ZygpuMaterial& mat = d->materials[mi];
-        if (ZYGPU_NULL != mat.color_image && (mat.color_image >= d->num_images || !d->srgb_to_float)) {
+        if (ZYGPU_NULL != mat.color_image && !(mat.color_sampler & ZYGPU_TEX_PROCEDURAL) && (mat.color_image >= d->num_images || !d->srgb_to_float)) {
             g_error = "a material's colour map names an image that is not in ZygpuSceneDesc.images";
             return -2;
         }
@@ -1339,9 +1396,11 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             for (uint32_t t = 0; t < ZYGPU_STEX_COUNT; ++t) {
                 const uint32_t image = mat.tex[t].image;
                 if (ZYGPU_NULL == image) continue;
+                const bool     procedural = 0 != (mat.tex[t].sampler & ZYGPU_TEX_PROCEDURAL);  // (its index: checked with the table above)
                 const uint32_t f = image < d->num_images ? d->images[image].format : kNull;
                 const bool     normal = ZYGPU_STEX_NORMAL == t || ZYGPU_STEX_COATING_NORMAL == t;
-                if (normal ? (ZYGPU_IMAGE_BYTE2 != f && ZYGPU_IMAGE_FLOAT2 != f) : (ZYGPU_IMAGE_BYTE1_UNORM != f && ZYGPU_IMAGE_FLOAT1 != f)) {
+                if (procedural) {
+                } else if (normal ? (ZYGPU_IMAGE_BYTE2 != f && ZYGPU_IMAGE_FLOAT2 != f) : (ZYGPU_IMAGE_BYTE1_UNORM != f && ZYGPU_IMAGE_FLOAT1 != f)) {
                     g_error = "a Substitute texture names an image that is missing or has the wrong number of channels";
                     return -2;
                 }
@@ -1795,6 +1854,8 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     P.hit_q = nullptr;
     P.nee_rec = c->nee_rec;
     P.nee_count = c->nee_count;
+    P.tex_values = c->procedurals ? c->tex_values : nullptr;
+    P.tex_plane = c->tex_plane;
     P.scatter_source = 0;
     P.pixel_pcg = nullptr;
     if (one_shot) {
@@ -2034,6 +2095,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                                          heavyGrid(c, grid.x), P, 0u);
                         }
                     });
+                    if (c->procedurals) timedLaunch(c, 1, [&] { launchKernel(c, K_TEXTURES_POOL, grid.x, P, 0u); });
                     timedLaunch(c, 5, [&] {
                         if (c->stats) launchKernel(c, K_SCATTER_STATS_POOL, grid.x, P, 0u);
                         else if (c->masks) launchKernel(c, K_SCATTER_MASKS_POOL, grid.x, P, 0u);
@@ -2110,6 +2172,8 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 }
             });
             }
+            // the survivors' procedural textures, ahead of the kernels that build their closures (wavefront.hpp wf_textures)
+            if (c->procedurals) timedLaunch(c, 1, [&] { launchKernel(c, K_TEXTURES, aliveGrid(), P, 0u); });
             if (nee && c->nee_in_place && wide && c->huge_mesh && relaxedUnits(c) && c->mesh_kernels && !c->multi_sample_lights) {
                 // wf_scatter_h: in place, but a vertex whose shadow ray has to walk a large mesh is suspended; wf_shadow_u walks
                 // the meshes for the round's suspended rays, the next launch takes the suspended vertices up again

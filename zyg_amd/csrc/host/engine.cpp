@@ -41,21 +41,126 @@ static thread_local Engine* t_engine = nullptr;
 // files, swizzles, inversion, Triplanar / ObjectPos coordinates): the material gets ZYGPU_MATF_UNSUPPORTED and a scene that
 // uses it does not compile, instead of rendering with a default in that place.
 static thread_local bool t_unsupported_texture = false;
+static thread_local int  t_procedural_depth = 0;
+
+// readValue / readTypedValue (material_provider.zig:741-815) for a procedural's child: a number or an array is the uniform value of
+// the usage's type, an object a texture (an image or another procedural)
+static void readProceduralChild(const JsonValue& x, uint32_t usage, ZygpuTexture& t, float uniform[4]) {
+    t = ZygpuTexture{ZYGPU_NULL, 0u, {1.f, 1.f}};
+    uniform[0] = uniform[1] = uniform[2] = uniform[3] = 0.f;
+    if (JsonValue::Object == x.type) {
+        if (readImageTexture(x, t.image, t.sampler, t.scale, usage)) {
+            if (kUsageNormal == usage && !(t.sampler & ZYGPU_TEX_PROCEDURAL)) t.sampler |= ZYGPU_TEX_SNORM;  // texture_provider.zig:70
+        }
+        return;  // (an object that names no texture: readImageTexture has flagged the material)
+    }
+    if (kUsageColor == usage) {
+        const Vec4f c = readColor(x);
+        uniform[0] = c[0], uniform[1] = c[1], uniform[2] = c[2];
+    } else if (kUsageNormal == usage) {
+        if (JsonValue::Array == x.type && x.arr.size() >= 2) uniform[0] = x.arr[0].f32(0.f), uniform[1] = x.arr[1].f32(0.f);
+    } else {
+        uniform[0] = x.f32(0.f);
+    }
+}
+
+// TextureDescriptor.init's procedural entries (material_provider.zig:465-578) -> Engine::procedurals_; the entry's index or ZYGPU_NULL
+static uint32_t readProcedural(const std::string& name, const JsonValue& body, uint32_t usage) {
+    ZygpuProcedural pr;
+    std::memset(&pr, 0, sizeof(pr));
+    for (ZygpuTexture& t : pr.child) t = ZygpuTexture{ZYGPU_NULL, 0u, {1.f, 1.f}};
+    if (JsonValue::Object != body.type || !t_engine) return ZYGPU_NULL;
+    if (++t_procedural_depth > ZYGPU_PROCEDURAL_MAX_DEPTH) {  // (the device evaluates a bounded nesting without recursion)
+        --t_procedural_depth;
+        t_unsupported_texture = true;
+        return ZYGPU_NULL;
+    }
+    auto child = [&](const char* key, uint32_t k, uint32_t child_usage) {
+        if (const JsonValue* c = body.get(key)) readProceduralChild(*c, child_usage, pr.child[k], pr.child_uniform[k]);
+    };
+    if (name == "ChannelMix") {
+        pr.kind = ZYGPU_PROC_CHANNEL_MIX;
+        child("source", 0, usage);
+        if (const JsonValue* ch = body.get("channels"))
+            if (JsonValue::Array == ch->type && ch->arr.size() >= 3)
+                for (int k = 0; k < 3; ++k) {
+                    const Vec4f row = readVec4f3(ch->arr[size_t(k)]);
+                    for (int i = 0; i < 3; ++i) pr.value[k][i] = row[i];
+                }
+    } else if (name == "Checker") {  // procedural_checker.zig:20-41
+        pr.kind = ZYGPU_PROC_CHECKER;
+        pr.checker_scale = body.memberF32("scale", 1.f);
+        if (const JsonValue* cs = body.get("colors"))
+            if (JsonValue::Array == cs->type && cs->arr.size() >= 2)
+                for (int k = 0; k < 2; ++k) {
+                    const Vec4f c = readColor(cs->arr[size_t(k)]);
+                    for (int i = 0; i < 3; ++i) pr.value[k][i] = c[i];
+                }
+    } else if (name == "DetailNormal") {
+        pr.kind = ZYGPU_PROC_DETAIL_NORMAL;
+        child("base", 0, usage);
+        child("detail", 1, usage);
+    } else if (name == "Max" || name == "Mul") {
+        pr.kind = name == "Max" ? ZYGPU_PROC_MAX : ZYGPU_PROC_MUL;
+        child("a", 0, usage);
+        child("b", 1, usage);
+    } else if (name == "Mix") {
+        pr.kind = ZYGPU_PROC_MIX;
+        child("a", 0, usage);
+        child("b", 1, usage);
+        child("weight", 2, kUsageOpacity);  // material_provider.zig:536
+    } else {  // Noise (material_provider.zig:558-578)
+        pr.kind = ZYGPU_PROC_NOISE;
+        const JsonValue* cl = body.get("class");
+        if (cl && JsonValue::String == cl->type && cl->str == "Cellular") pr.flags |= ZYGPU_NOISE_CELLULAR;
+        if (body.memberBool("absolute", false)) pr.flags |= ZYGPU_NOISE_ABSOLUTE;
+        if (body.memberBool("invert", false)) pr.flags |= ZYGPU_NOISE_INVERT;
+        pr.levels = body.memberU32("levels", 1);
+        pr.attenuation = body.memberF32("attenuation", 0.f);
+        pr.ratio = body.memberF32("ratio", 0.5f);
+        pr.transition = body.memberF32("transition", 0.5f);
+        const JsonValue* sc = body.get("scale");
+        const JsonValue* pe = body.get("period");
+        const Vec4f      scale = sc ? readVec4f3(*sc) : splat(1.f), period = pe ? readVec4f3(*pe) : splat(0.f);
+        for (int i = 0; i < 3; ++i) pr.scale[i] = scale[i], pr.period[i] = period[i];
+    }
+    --t_procedural_depth;
+    return t_engine->appendProcedural(pr);
+}
+
+static bool proceduralName(const std::string& k) {
+    return k == "ChannelMix" || k == "Checker" || k == "DetailNormal" || k == "Max" || k == "Mix" || k == "Mul" || k == "Noise";
+}
 
 // material_provider.zig:438-632: {"usage": .., "id": n, "sampler": {"filter", "address"}, "scale"}
 static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& sampler_out, float scale_out[2], uint32_t usage) {
     if (JsonValue::Object != v.type) return false;
     const JsonValue* id = v.get("id");
     const JsonValue* file = v.get("file");
+    uint32_t         procedural = ZYGPU_NULL;
+    bool             is_procedural = false;
     for (const auto& kv : v.obj) {
         const std::string& k = kv.first;
         // "swizzle" and "invert" are options of the image-file loader: with an image id the reference ignores them, too
         // (createTexture, material_provider.zig:700-736)
         if (k == "id" || k == "file" || k == "usage" || k == "scale" || k == "swizzle" || k == "invert") continue;
         if (k == "sampler") continue;
-        t_unsupported_texture = true;  // ChannelMix, Checker, DetailNormal, Max, Mix, Mul, Noise ...
+        if (proceduralName(k) && (kUsageColor == usage || kUsageWeight == usage || kUsageNormal == usage || (kUsageOpacity == usage && t_procedural_depth > 0))) {
+            // (the last one named wins: every entry overwrites desc.procedural; masks and emission maps take images only)
+            procedural = readProcedural(k, kv.second, usage);
+            is_procedural = true;
+            continue;
+        }
+        t_unsupported_texture = true;  // (a key the reference does not know, or a procedural where only images are evaluated)
     }
     struct { uint32_t color_image, color_sampler; float color_scale[2]; } m;
+    if (is_procedural) {  // a procedural wins over "file" and "id" (createTexture, material_provider.zig:712-713)
+        if (ZYGPU_NULL == procedural) {
+            t_unsupported_texture = true;
+            return false;
+        }
+        m.color_image = procedural;
+    } else
     if (file && JsonValue::String == file->type && t_engine) {  // "file" wins over "id" (createTexture, material_provider.zig:715-733)
         const JsonValue* sw = v.get("swizzle");
         m.color_image = t_engine->loadImageFile(file->str, usage, sw && JsonValue::String == sw->type ? sw->str : std::string(), v.memberBool("invert", false));
@@ -103,6 +208,10 @@ static bool readImageTexture(const JsonValue& v, uint32_t& image, uint32_t& samp
         } else {
             m.color_scale[0] = m.color_scale[1] = sc->f32(1.f);
         }
+    }
+    if (is_procedural) {  // Texture.initProcedural (texture.zig:91-93): id, data and the mode; no image scale
+        m.color_sampler |= ZYGPU_TEX_PROCEDURAL;
+        m.color_scale[0] = m.color_scale[1] = 1.f;
     }
     image = m.color_image;
     sampler_out = m.color_sampler;
@@ -573,7 +682,18 @@ void Engine::parseMaterialBody(ZygpuMaterial& m, const JsonValue& v, uint32_t ki
     }
 }
 
+uint32_t Engine::appendProcedural(const ZygpuProcedural& p) {
+    procedurals_.push_back(p);
+    return uint32_t(procedurals_.size() - 1);
+}
+
 void Engine::commitMaterial(ZygpuMaterial& m) {
+    {  // a procedural colour or weight: evaluated per vertex ahead of the closure (wf_textures), which then needs the complete form
+        bool procedural = ZYGPU_NULL != m.color_image && (m.color_sampler & ZYGPU_TEX_PROCEDURAL);
+        for (const ZygpuTexture& t : m.tex) procedural = procedural || (ZYGPU_NULL != t.image && (t.sampler & ZYGPU_TEX_PROCEDURAL));
+        if (procedural && (ZYGPU_MAT_SUBSTITUTE == m.kind || ZYGPU_MAT_GLASS == m.kind)) m.flags |= ZYGPU_MATF_PROCEDURAL;
+        else m.flags &= ~uint32_t(ZYGPU_MATF_PROCEDURAL);
+    }
     // light_material.zig:45-51 / substitute_material.zig:62-75
     const bool masked = ZYGPU_NULL != m.mask_image;  // mask.isImage()
     if (ZYGPU_MAT_LIGHT == m.kind || ZYGPU_MAT_SUBSTITUTE == m.kind) {
@@ -589,7 +709,7 @@ void Engine::commitMaterial(ZygpuMaterial& m) {
         bool extended = m.rotation > 0.f || m.translucency > 0.f || m.coating_thickness > 0.f || m.flakes_coverage > 0.f;
         for (const ZygpuTexture& t : m.tex) extended = extended || ZYGPU_NULL != t.image;
         // a Triplanar colour map reads the fragment's position, like the complete closure
-        extended = extended || (ZYGPU_NULL != m.color_image && (m.color_sampler & ZYGPU_TEX_TRIPLANAR));
+        extended = extended || (ZYGPU_NULL != m.color_image && (m.color_sampler & (ZYGPU_TEX_TRIPLANAR | ZYGPU_TEX_PROCEDURAL)));
         if (extended) m.flags |= ZYGPU_MATF_EXTENDED;
         else m.flags &= ~uint32_t(ZYGPU_MATF_EXTENDED);
     }
@@ -2224,6 +2344,8 @@ int Engine::compile(uint32_t frame) {
         c_portal_lights_[i] = ZygpuPortalLight{portal_lights_[i].sat.data(), portal_lights_[i].func.data(), portal_lights_[i].dim, portal_lights_[i].light_link};
     d.portal_lights = c_portal_lights_.empty() ? nullptr : c_portal_lights_.data();
     d.num_portal_lights = uint32_t(c_portal_lights_.size());
+    d.procedurals = procedurals_.empty() ? nullptr : procedurals_.data();
+    d.num_procedurals = uint32_t(procedurals_.size());
     auto channels = [&](uint32_t image) {
         const uint32_t f = images_[image].format;
         return (ZYGPU_IMAGE_BYTE3_SRGB == f || ZYGPU_IMAGE_FLOAT3 == f) ? 3 : (ZYGPU_IMAGE_BYTE2 == f || ZYGPU_IMAGE_FLOAT2 == f) ? 2 : 1;
@@ -2234,14 +2356,24 @@ int Engine::compile(uint32_t frame) {
             for (uint32_t t = 0; t < ZYGPU_STEX_COUNT; ++t) {
                 const uint32_t image = m.tex[t].image;
                 if (ZYGPU_NULL == image) continue;
+                if (m.tex[t].sampler & ZYGPU_TEX_PROCEDURAL) {
+                    if (image >= procedurals_.size()) return -4;
+                    continue;
+                }
                 const int want = (ZYGPU_STEX_NORMAL == t || ZYGPU_STEX_COATING_NORMAL == t) ? 2 : 1;
                 if (image >= images_.size() || want != channels(image)) return -4;
             }
         }
+        if (ZYGPU_NULL != m.color_image && (m.color_sampler & ZYGPU_TEX_PROCEDURAL)) {
+            if (m.color_image >= procedurals_.size()) return -4;
+        } else
         if (ZYGPU_NULL != m.color_image && (m.color_image >= images_.size() || 3 != channels(m.color_image))) return -4;  // a colour map without its image
         if (ZYGPU_NULL != m.emission_image && m.emission_image < images_.size() && 3 != channels(m.emission_image)) return -4;
         if (ZYGPU_NULL != m.mask_image && (m.mask_image >= images_.size() || 1 != channels(m.mask_image))) return -4;  // image2D_1 reads one channel
     }
+    for (const ZygpuProcedural& pr : procedurals_)  // a child is uniform, an image or an earlier procedural (any channel count: a fetch
+        for (const ZygpuTexture& t : pr.child)      // of another width reads 0, texture.zig:166-219)
+            if (ZYGPU_NULL != t.image && t.image >= ((t.sampler & ZYGPU_TEX_PROCEDURAL) ? procedurals_.size() : images_.size())) return -4;
     if (unsupported_integrator_) return -10;
     for (uint32_t mid : material_ids_) {
         const ZygpuMaterial& m = materials_[mid];

@@ -116,6 +116,7 @@ class Engine {
     std::string              file_error;
     std::string resolveFile(const std::string& name) const;
     uint32_t    loadImageFile(const std::string& name, uint32_t usage, const std::string& swizzle, bool invert);
+    uint32_t    appendProcedural(const ZygpuProcedural& p);  // resources.procedural.append (procedural.zig:54-80)
     uint32_t    loadImageFileUnguarded(const std::string& name, uint32_t usage, const std::string& swizzle, bool invert);
     uint32_t createImage(uint32_t id, uint32_t format, uint32_t num_channels, uint32_t width, uint32_t height, uint32_t depth,
                          uint32_t pixel_stride, const uint8_t* data);
@@ -246,6 +247,7 @@ class Engine {
     std::vector<HostMesh>      meshes_;
     std::vector<ZygpuMaterial> materials_;
     uint32_t                   fallback_material_ = 0;
+    std::vector<ZygpuProcedural> procedurals_;  // resources.procedural's lists in one (texture/procedural.zig:37-43), append-only
 
     std::vector<HostProp>       props_;
     std::vector<Transformation> world_transformations_;
