@@ -47,7 +47,8 @@ def parse_args():
                          "sphere of 999 698 triangles hanging at 60 %% of the box's height), cornell_mound = the lighter variant "
                          "(the heightfield on the floor); cornell_glass and outdoor (configs[4]'s ingredients: glass, metal presets, "
                          "1 M-triangle mesh, image-lit canopy + sun) run the POOL kernels")
-    ap.add_argument("--material", default="lambert", choices=["lambert", "substitute"])
+    ap.add_argument("--material", default="lambert", choices=["lambert", "substitute", "procedural"],
+                    help="procedural: Substitute whose colours, roughness and normals are procedural textures (Checker, Noise, Mix: wf_textures)")
     ap.add_argument("--box-triangles", type=int, default=12, choices=[12, 18, 48, 108, 972],
                     help="triangles of each of the two Cornell boxes (12 = BASELINE.json configs[1]); the others measure what a scene "
                          "just past the kernels' thresholds costs (meshes of at most 16 triangles are tested from the constant block)")
@@ -141,8 +142,20 @@ def build_scene(eng, scenes, name, material, w, h, total_spp, box_triangles=12, 
                        max_depth=16, sky_entity={"parameters": {"sun": {"rotation": [-55, 20, 0]}}}, box_lift=1e-3)
     else:
         glass = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)} if name == "cornell_glass" else None
+        overrides = None
+        if "procedural" == material:  # every surface with procedural textures: a filtered checker, octaves of noise, a stochastic Mix, a noise normal map
+            S, noise = scenes.substitute_full, lambda **kw: {"Noise": kw}
+            checker = lambda scale, a, b: {"Checker": {"scale": scale, "colors": [list(a), list(b)]}}  # noqa: E731
+            overrides = {"floor": S(checker(6.0, (0.9, 0.85, 0.8), (0.15, 0.1, 0.1)), roughness=noise(scale=[7, 5, 1], levels=3, attenuation=0.6)),
+                         "back": S({"Mix": {"a": checker(3.0, (0.1, 0.6, 0.2), (0.8, 0.8, 0.2)), "b": [0.25, 0.3, 0.7], "weight": noise(scale=[3, 3, 3], transition=0.1)}},
+                                   roughness=0.4, normal=noise(scale=[11, 11, 11], levels=2, attenuation=1.0)),
+                         "left": S(checker(5.0, (0.8, 0.2, 0.2), (0.9, 0.7, 0.6)), roughness=0.6),
+                         "right": S(noise(scale=[9, 9, 9], levels=4, attenuation=1.0), roughness=0.5),
+                         "tall": S(noise(scale=[5, 5, 5], levels=4, attenuation=1.7), roughness=0.25, metallic=1.0, normal=noise(scale=[13, 13, 13])),
+                         "short": S(checker(4.0, (0.9, 0.9, 0.9), (0.2, 0.3, 0.8)), roughness=noise(scale=[3, 3, 3]))}
+            material = "substitute"
         scenes.cornell(eng, w, h, total_spp, integrator="PTMIS", material=material, boxes=mesh is None, mesh=mesh,
-                       mesh_material=mesh_material, glass_objects=glass, mesh_position=mesh_position,
+                       mesh_material=mesh_material, glass_objects=glass, mesh_position=mesh_position, overrides=overrides,
                        box_subdivide={12: 1, 18: 1, 48: 2, 108: 3, 972: 9}[box_triangles], box_first_face=(1, 4) if 18 == box_triangles else None,
                        extra_props=extra_props, box_lift=1e-3 if glass else 0.0)
 
@@ -159,7 +172,8 @@ def describe(name, material, w, h, ips, k, relaxed):
     geometry = {"cornell": "2 boxes", "cornell_mesh": "999698-triangle closed displaced sphere (Substitute) centred at 60 % of the box's height",
                 "cornell_mound": "999698-triangle heightfield mesh (Substitute) on the floor",
                 "cornell_glass": "tall box, glass box (ior 1.5, absorbing), both 1 mm above the floor, glass Sphere"}[name]
-    bsdf = "Lambertian" if material == "lambert" else "Substitute (roughness 0.8)"
+    bsdf = ("Lambertian" if material == "lambert" else "Substitute with procedural textures on every surface (Checker, Noise, Mix, a noise normal map)"
+            if material == "procedural" else "Substitute (roughness 0.8)")
     return (f"Cornell box (5 Rectangle walls, {geometry}, 2 unoccluding Rectangle lights) + {bsdf} BSDF, {w}x{h}, PTMIS depth 16, "
             f"Sobol, box sensor, {ips} iterations per step, {k * ips} spp per GPU, {mode}")
 

@@ -408,10 +408,11 @@ def test_malformed_meshes_are_refused(product_lib):
 
 
 @pytest.mark.parametrize("material", [
-    '{"rendering": {"Substitute": {"color": {"Checker": {"scale": 4}}}}}',                       # procedural texture
+    '{"rendering": {"Substitute": {"color": [0.5, 0.5, 0.5], "mask": {"Checker": {"scale": 4}}}}}',   # a procedural opacity mask
     '{"rendering": {"Substitute": {"roughness": {"file": "rough.png"}}}}',                        # image file
     '{"rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "emission_map": {"id": 0, "sampler": {"texcoord": "Triplanar"}}}}}}',
-    '{"rendering": {"Glass": {"ior": 1.5, "normal": {"Checker": {}}}}}',
+    '{"rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "emission_map": {"Noise": {}}}}}}',  # a procedural emission map
+    '{"rendering": {"Substitute": {"roughness": {"Turbulence": {"levels": 3}}}}}',                # a procedural the reference does not have
     '{"rendering": {"Light": {"emittance": {"spectrum": [1, 1, 1], "profile": {"file": "lamp.ies"}}}}}',
 ])
 def test_unsupported_texture_features_do_not_compile(product_lib, material):
@@ -439,7 +440,7 @@ def test_file_loader_options_on_an_image_id_are_ignored(product_lib):
 def test_unused_unsupported_material_is_harmless(product_lib):
     with zyg_amd.Engine(product_lib) as e:
         scenes.cornell(e, 8, 8, 1, material="substitute")
-        e.material('{"rendering": {"Substitute": {"color": {"Checker": {"scale": 4}}}}}')
+        e.material('{"rendering": {"Substitute": {"color": [0.5, 0.5, 0.5], "mask": {"Checker": {"scale": 4}}}}}')
         assert e.lib.su_ext_compile(0) == 0
 
 

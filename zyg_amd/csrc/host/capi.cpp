@@ -57,8 +57,8 @@ void logCompileError(int rc) {
     logf(2, -7 == rc ? "a Substitute material has an attenuation_distance: subsurface scattering is a volume, not supported"
             : -8 == rc ? "an emissive Substitute material with a coating is not supported"
             : -10 == rc ? "su_integrators_create asked for the light tracer (\"particle\"), photon mapping or the AOV integrator: only PT, PTDL and PTMIS are supported"
-            : -9 == rc ? "a material in use asks for a texture feature that is not supported (procedural textures, image files "
-                         "other than PNG / Radiance RGBE or that could not be read, IES profiles, Triplanar emission maps)"
+            : -9 == rc ? "a material in use asks for a texture feature that is not supported (a procedural texture as opacity mask or emission map "
+                         "or nested more than four deep, an image file that is not PNG / Radiance RGBE / OpenEXR / IES or could not be read, Triplanar emission maps)"
             : -11 == rc ? g->engine.camera_error.c_str()
             : -4 == rc ? "a material names an image that does not exist or has the wrong number of channels for its use"
                        : "scene uses a feature outside the hot-path scope (scattering volumes, emission maps on meshes ...)");
