@@ -40,6 +40,7 @@
     X(3, K_SCATTER_STATS,        (wf_scatter<true, true, true, true, false>),         (P)) \
     X(7, K_SCATTER_MASKS,        (wf_scatter<false, true, true, true, false, true>),  (P)) \
     X(4, K_SCATTER_FULL,         (wf_scatter<false, true, true, true, false>),        (P)) \
+    X(6, K_SCATTER_FULL_RECT,    (wf_scatter<false, true, true, true, false, false, false, false, 0, kRectangleLightKinds>), (P)) \
     X(4, K_SCATTER_MULTI,        (wf_scatter<false, true, true, false, false>),       (P)) \
     X(4, K_SCATTER_SUBST,        (wf_scatter<false, true, false, false, false>),      (P)) \
     X(4, K_SCATTER_LAMBERT,      (wf_scatter<false, false, false, false, false>),     (P)) \

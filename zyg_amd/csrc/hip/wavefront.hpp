@@ -3605,7 +3605,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(kSkyLightKinds == KINDS ? ZYG_L
     tm.flush(P.ctl, 16);
 }
 
-template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false, int PHASE = 0>
+// KINDS: the light kinds the scene has (the complete instantiations of scenes whose lights are all plain Rectangles: a scene is on the
+// complete kernels for its textures, shapes or keyframes as often as for its lights)
+template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false, int PHASE = 0, uint32_t KINDS = kAllLightKinds>
 __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_WAVES : (MESHL && POOL && !STATS) ? ZYG_SCATTER_POOL_FULL_WAVES : (SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
     static_assert(0 == PHASE || (2 == PHASE && POOL && !STATS), "the split next-event estimation: the POOL scenes' instantiations");
@@ -3701,7 +3703,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_W
         slot = (POOL && P.scatter_source) ? P.q.shadow[at] : P.alive_in[at];
         // Params::hit_q: the vertex' hit record sits at its place in the alive queue (its address does not wait for the slot)
         const HitRecord hr = (!POOL && P.hit_q) ? loadQueuedHit(P, at) : loadHitRecord(P, slot);
-        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE, PHASE>(P, s, slot, out, cnt, shadow_rays, tm, &hr);
+        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE, PHASE, KINDS>(P, s, slot, out, cnt, shadow_rays, tm, &hr);
     }
 #endif
     if (POOL) {

@@ -2199,7 +2199,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                 timedLaunch(c, 5, [&] {
                     if (c->stats) launchKernel(c, K_SCATTER_STATS, aliveGrid(), P, 0u);
                     else if (c->masks) launchKernel(c, K_SCATTER_MASKS, aliveGrid(), P, 0u);
-                    else if (c->mesh_lights) launchKernel(c, K_SCATTER_FULL, aliveGrid(), P, 0u);
+                    else if (c->mesh_lights) launchKernel(c, (0 == (c->light_kinds & ~kRectangleLightKinds)) ? K_SCATTER_FULL_RECT : K_SCATTER_FULL, aliveGrid(), P, 0u);
                     else if (c->multi_sample_lights) launchKernel(c, wide ? K_SCATTER_MULTI_UW : utlas ? K_SCATTER_MULTI_U : K_SCATTER_MULTI, aliveGrid(), P, 0u);
                     else if (c->has_substitute) launchKernel(c, wide ? K_SCATTER_SUBST_UW : utlas ? K_SCATTER_SUBST_U : K_SCATTER_SUBST, aliveGrid(), P, 0u);
                     else launchKernel(c, wide ? K_SCATTER_LAMBERT_UW : utlas ? K_SCATTER_LAMBERT_U : K_SCATTER_LAMBERT, aliveGrid(), P, 0u);
