@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, prefix = sys.argv[1], sys.argv[2]
 out = os.path.join(ROOT, "profiles")
-scenes = {"cfg1": None, "cfg2": "cornell_mesh", "cfg4": "outdoor", "cfg4m": "outdoor_mound", "glass": "cornell_glass", "mound": "cornell_mound"}
+scenes = {"cfg1": None, "cfg2": "cornell_mesh", "cfg4": "outdoor", "cfg4m": "outdoor_mound", "glass": "cornell_glass", "mound": "cornell_mound",
+          "proc": "SKIP"}  # (--material procedural: no `extra` entry of bench.py quotes it)
 for short, scene in scenes.items():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{short}")
     if not os.path.isdir(src):
@@ -20,7 +21,7 @@ for short, scene in scenes.items():
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(out, f"{prefix}_{short}_{name}"))
-    for name in ("traffic.json", "pmc_sq.json"):
+    for name in ("traffic.json", "pmc_sq.json") if "SKIP" != scene else ():
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             stem, ext = os.path.splitext(name)
