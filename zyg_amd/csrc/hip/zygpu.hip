@@ -1333,8 +1333,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     s.procedurals = nullptr;
     c->procedurals = false;
     {
-        auto bad = [&](const ZygpuTexture& t, bool normal_or_weight) {
-            (void)normal_or_weight;
+        auto bad = [&](const ZygpuTexture& t) {
             if (ZYGPU_NULL == t.image) return false;
             if (t.sampler & ZYGPU_TEX_PROCEDURAL) return t.image >= d->num_procedurals || !d->procedurals;
             return t.image >= d->num_images;
@@ -1342,7 +1341,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         for (uint32_t k = 0; k < d->num_procedurals && d->procedurals; ++k) {
             const ZygpuProcedural& pr = d->procedurals[k];
             bool wrong = pr.kind > ZYGPU_PROC_NOISE || (ZYGPU_PROC_NOISE == pr.kind && pr.levels > 32u);
-            for (const ZygpuTexture& t : pr.child) wrong = wrong || bad(t, true);
+            for (const ZygpuTexture& t : pr.child) wrong = wrong || bad(t);
             // a child names an earlier entry (the host appends a procedural after its children): no cycles, and the depth is the host's to bound
             for (const ZygpuTexture& t : pr.child) wrong = wrong || (ZYGPU_NULL != t.image && (t.sampler & ZYGPU_TEX_PROCEDURAL) && t.image >= k);
             if (wrong) {
@@ -1358,7 +1357,7 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                 wrong = pm.color_image >= d->num_procedurals || !d->procedurals;
             }
             for (const ZygpuTexture& t : pm.tex)
-                if (ZYGPU_NULL != t.image && (t.sampler & ZYGPU_TEX_PROCEDURAL)) any = true, wrong = wrong || bad(t, true);
+                if (ZYGPU_NULL != t.image && (t.sampler & ZYGPU_TEX_PROCEDURAL)) any = true, wrong = wrong || bad(t);
             for (const uint32_t sampler : {pm.emission_sampler, pm.mask_sampler, pm.profile_sampler})
                 if (sampler & ZYGPU_TEX_PROCEDURAL) wrong = true;  // (evaluated as images only)
             if (any && !(pm.flags & ZYGPU_MATF_PROCEDURAL)) wrong = true;
