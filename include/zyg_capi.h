@@ -74,9 +74,10 @@ int32_t su_ext_sensor_create(const char* json);
 /* Camera "parameters" node (Perspective.setParameters, camera_perspective.zig:260-304): fov (degrees), lens.radius / aperture.radius,
  * aperture.shape (a one-channel square image file, found through the mounts: the lens is sampled by its Distribution2D,
  * camera/aperture.zig:22-53), focus.distance, focus.point [x, y, z] (x, y in [0, 1] of the frame: su_start_frame traces
- * Perspective.updateFocus' probe ray on the device and focuses on its hit distance + z, camera_perspective.zig:322-347).
- * Returns -1 and logs the key for what is refused by name: aperture.blades (drawn by rendering/shaper.zig in the reference),
- * stereo (two layers), a shape file that cannot be read. */
+ * Perspective.updateFocus' probe ray on the device and focuses on its hit distance + z, camera_perspective.zig:322-347),
+ * aperture.blades / roundness (more than 3 blades: the polygon rendering/shaper.zig draws into a 128 x 128 image, which then is the
+ * aperture's shape, camera_perspective.zig:284-300).
+ * Returns -1 and logs the key for what is refused by name: stereo (two layers), a shape file that cannot be read. */
 int32_t su_ext_camera_set_parameters(const char* json);
 /* The take's sampler class (take_loader.zig:232-244: {"Random": ...} | {"Sobol": ...}): 0 = Random (PCG only), 1 = Sobol
  * (the C ABI's default; su_sampler_create only sets the sample count, capi.zig:215-221). */

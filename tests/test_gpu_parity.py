@@ -795,6 +795,29 @@ def test_aperture_shape(engine, oracle, tmp_path):
         assert not np.array_equal(shaped, e.download_film(96, 64))
 
 
+def test_aperture_blades(engine, oracle):
+    """"aperture": {"blades": n, "roundness": r} (camera_perspective.zig:284-300): the polygon the host draws (tests/test_host.py checks it
+    against a second implementation) is the aperture's shape: device and oracle bit-identical, and neither the disc's image nor another
+    polygon's."""
+    films = {}
+    for blades in (5, 7):
+        engine.release()
+        engine.__init__(engine.lib)
+        lens = {"aperture": {"radius": 0.15, "blades": blades, "roundness": 0.25}, "focus": {"distance": 3.2}}
+        out = _render_both(engine, oracle, 96, 64, 4, stats=5 == blades, integrator="PTMIS", lens=lens)
+        _check(*out, 4)
+        assert engine.lib.su_ext_view_desc().contents.aperture_shape != zyg_amd.NULL
+        films[blades] = out[0]
+    assert not np.array_equal(films[5], films[7])
+    engine.release()
+    with zyg_amd.Engine() as e:
+        scenes.cornell(e, 96, 64, 4, lens={"lens": {"radius": 0.15}, "focus": {"distance": 3.2}})
+        e.start_frame(0)
+        e.render_iterations(4)
+        e.synchronize()
+        assert not np.array_equal(films[5], e.download_film(96, 64))
+
+
 @pytest.mark.parametrize("point", [(0.5, 0.5, 0.0), (0.3, 0.8, 0.25), (0.05, 0.02, 0.0)])
 def test_focus_point_autofocus(engine, oracle, point):
     """"focus": {"point": [x, y, z]} (Perspective.updateFocus, camera_perspective.zig:322-347): su_start_frame traces one closest-hit

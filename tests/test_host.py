@@ -653,12 +653,69 @@ def test_aperture_shape_distribution(product_lib, tmp_path):
             assert np.array_equal(cdf[offset:offset + size], np.array(want, dtype=np.float32)), y
 
 
-@pytest.mark.parametrize("parameters,word", [({"aperture": {"radius": 0.1, "blades": 6}}, "blades"), ({"stereo": {"ipd": 0.062}}, "stereo"),
+def _shaper_aperture(blades, roundness, dim=128):
+    """rendering/shaper.zig:156-301 drawAperture(color 1, centre (0.5, 0.5), blades, radius 0.5, roundness, rotation pi) + resolve(Byte1),
+    in numpy float32 (a second implementation: vectorised over the 4 x 4 sub-samples of every pixel)."""
+    f = np.float32
+    pi = f(np.pi)
+    delta = f(f(2.0) * pi) / f(blades)
+    ss = f(1.0) / f(4)
+    so, step = f(0.5) * ss, ss / f(dim)
+    base = (np.arange(dim, dtype=np.float32) + so) / f(dim)
+    coords = np.stack([base + f(k) * step for k in range(4)], axis=1)  # [pixel][sub-sample]; the reference adds the step k times
+    for k in range(1, 4):  # u += ssx, repeatedly (not k * ssx)
+        coords[:, k] = coords[:, k - 1] + step
+    u = coords[None, :, None, :]  # [y][x][sy][sx]
+    v = coords[:, None, :, None]
+    cx, cy = (u - f(0.5)) + f(0) * v, (v - f(0.5)) + f(0) * u
+    lc = np.sqrt(cx * cx + cy * cy)
+    mt = np.zeros_like(lc)
+    bx, by = np.sin(pi), np.cos(pi)
+    for i in range(blades):
+        angle = f(i + 1) * delta + pi
+        ccx, ccy = np.sin(angle), np.cos(angle)
+        ex, ey = f(ccx - bx), f(ccy - by)
+        length = np.sqrt(f(ey * ey + ex * ex))
+        nx, ny = f(ey / length), f(-ex / length)
+        d = f(nx * bx + ny * by)
+        mt = np.maximum(mt, (nx * cx + ny * cy) / d)
+        bx, by = ccx, ccy
+    inside = (lc <= f(0.5)) & ((f(1.0) - f(roundness)) * mt + f(roundness) * lc <= f(0.5))
+    w = inside.sum(axis=(2, 3)).astype(np.float32) * f(1.0 / 16.0)
+    return np.floor(np.minimum(w, f(1.0)) * f(255.0) + f(0.5)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("blades,roundness", [(5, 0.0), (6, 0.35), (8, 1.0), (11, 0.2)])
+def test_aperture_blades_are_drawn_like_the_shaper(product_lib, blades, roundness):
+    """camera_perspective.zig:284-300: `blades` > 3 draws a regular polygon (rendering/shaper.zig) into a 128 x 128 one-channel image,
+    which becomes the aperture's shape (its Distribution2D rides with the image lights, like a shape given as a file)."""
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, 32, 24, 1, lens={"aperture": {"radius": 0.05, "blades": blades, "roundness": roundness}, "focus": {"distance": 3.0}})
+        sd, vd = e.compile()
+        assert vd.aperture_shape != zyg_amd.NULL and vd.lens_radius == np.float32(0.05)
+        img = sd.images[sd.num_images - 1]
+        assert (img.width, img.height) == (128, 128)
+        got = np.ctypeslib.as_array(ctypes.cast(img.pixels, ctypes.POINTER(ctypes.c_uint8)), shape=(128, 128)).copy()
+    want = _shaper_aperture(blades, roundness)
+    # sin / cos of the host's libm against numpy's: a sub-sample exactly on an edge may fall the other way
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 16 and (got != want).mean() < 0.01
+    assert got[64, 64] == 255 and got[0, 0] == 0 and got[127, 127] == 0 and got[10, 10] == 0
+    area = got.astype(np.float64).sum() / 255.0 / (128 * 128)
+    polygon = 0.5 * blades * 0.25 * np.sin(2 * np.pi / blades)  # a regular polygon inscribed in the circle of radius 0.5
+    circle = np.pi * 0.25
+    assert polygon - 0.004 <= area <= circle + 0.004
+    if roundness == 0.0:
+        assert abs(area - polygon) < 0.004
+    if roundness == 1.0:
+        assert abs(area - circle) < 0.004
+
+
+@pytest.mark.parametrize("parameters,word", [({"aperture": {"radius": 0.1, "blades": 65}}, "blades"), ({"stereo": {"ipd": 0.062}}, "stereo"),
                                              ({"aperture": {"radius": 0.1, "shape": "missing.png"}}, "missing.png")])
 def test_camera_parameters_refused_by_name(product_lib, parameters, word):
-    """camera_perspective.zig:284-303: an aperture drawn from `blades` (rendering/shaper.zig) and a stereo camera are not provided, and a
-    shape file that cannot be read is no aperture: su_ext_camera_set_parameters fails and the log names the key; a frame does not
-    start with the parameter silently ignored."""
+    """camera_perspective.zig:284-303: a stereo camera is not provided, and a shape file that cannot be read (or an absurd number of
+    blades) is no aperture: su_ext_camera_set_parameters fails and the log names the key; a frame does not start with the parameter
+    silently ignored."""
     lines = []
     callback = zyg_amd.LOG_CALLBACK(lambda level, text: lines.append((level, text.decode())))
     with zyg_amd.Engine(product_lib) as e:

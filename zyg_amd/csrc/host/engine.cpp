@@ -1319,6 +1319,51 @@ void Engine::cameraCreate(uint32_t width, uint32_t height) {  // capi.zig:143-16
     if (ZYGPU_NULL == camera_entity) camera_entity = createEntity();
 }
 
+// Shaper.drawAperture + resolve(Byte1) (rendering/shaper.zig:156-301, 36-48) as camera_perspective.zig:284-300 calls them: a regular
+// polygon of `blades` edges (up to 8: ApertureN's edge planes, 96-131; more: the same planes on the fly, 262-286), radius 0.5 around the
+// centre of a 128 x 128 image, rotated by pi, its edges blended towards the circle by `roundness`; 4 x 4 samples per pixel, a pixel's
+// coverage as a unorm byte
+static std::vector<uint8_t> drawApertureBlades(uint32_t blades, float roundness, int dim) {
+    std::vector<uint8_t> out(size_t(dim) * size_t(dim), 0);
+    const float    pi = 3.14159265358979323846f, rot = pi, radius = 0.5f, px = 0.5f, py = 0.5f;
+    const float    delta = (2.f * pi) / float(blades);
+    const int      sub_samples = 4;
+    const float    end = float(dim), ss = 1.f / float(sub_samples), ssx = ss / end, so = 0.5f * ss, ss2 = 1.f / float(sub_samples * sub_samples);
+    auto inside = [&](float u, float v) {
+        const float cx = u - px, cy = v - py;
+        const float lc = std::sqrt(cx * cx + cy * cy);
+        if (lc > radius) return false;
+        float bx = std::sin(rot), by = std::cos(rot), mt = 0.f;
+        for (uint32_t i = 0; i < blades; ++i) {
+            const float angle = float(i + 1) * delta + rot;
+            const float ccx = std::sin(angle), ccy = std::cos(angle);
+            const float ex = ccx - bx, ey = ccy - by;
+            const float len = std::sqrt(ey * ey + ex * ex);  // normalize2(.{cb[1], -cb[0]})
+            const float nx = ey / len, ny = -ex / len;
+            const float d = nx * bx + ny * by;
+            mt = fmax_(mt, (nx * cx + ny * cy) / d);
+            bx = ccx, by = ccy;
+        }
+        return std::fmaf(1.f - roundness, mt, roundness * lc) <= radius;  // math.lerp(mt, lc, roundness)
+    };
+    const int begin = int((px - radius) * end), finish = int((px + radius) * end);
+    for (int y = begin; y < finish; ++y)
+        for (int x = begin; x < finish; ++x) {
+            float w = 0.f, v = (float(y) + so) / end;
+            for (int sy = 0; sy < sub_samples; ++sy) {
+                float u = (float(x) + so) / end;
+                for (int sx = 0; sx < sub_samples; ++sx) {
+                    if (inside(u, v)) w += ss2;
+                    u += ssx;
+                }
+                v += ssx;
+            }
+            // pixel = lerp(0, 1, w) = w; resolve: floatToUnorm8(clamp(w, 0, 1)) (base/encoding.zig:6-8)
+            if (w > 0.f) out[size_t(y) * size_t(dim) + size_t(x)] = uint8_t(fmin_(w, 1.f) * 255.f + 0.5f);
+        }
+    return out;
+}
+
 // Perspective.setParameters (camera_perspective.zig:260-304) + loadFocus (348-361)
 bool Engine::loadCameraParameters(const JsonValue& v) {
     camera_error.clear();  // (a refusal belongs to the call that caused it: a later valid call replaces the parameters)
@@ -1343,8 +1388,12 @@ bool Engine::loadCameraParameters(const JsonValue& v) {
                 if (ZYGPU_IMAGE_BYTE1_UNORM != img.format && ZYGPU_IMAGE_FLOAT1 != img.format)
                     return camera_error = "the camera's aperture shape must be a one-channel image", false;
             } else if (kv.second.memberU32("blades", 0) > 3) {
-                // camera_perspective.zig:284-300 rasterises the blades with rendering/shaper.zig, which is outside the hot-path scope
-                return camera_error = "a camera aperture with \"blades\" (the reference draws it with rendering/shaper.zig: not provided; give the shape as an image with \"shape\")", false;
+                // camera_perspective.zig:284-300: the blades drawn into a 128 x 128 Byte1 image, which then is the aperture's shape
+                const uint32_t blades = kv.second.memberU32("blades", 0);
+                if (blades > 64) return camera_error = "a camera aperture with more than 64 \"blades\"", false;
+                const std::vector<uint8_t> shape_pixels = drawApertureBlades(blades, kv.second.memberF32("roundness", 0.f), 128);
+                aperture_shape_image = createImage(ZYGPU_NULL, 0, 1, 128, 128, 1, 1, shape_pixels.data());
+                if (ZYGPU_NULL == aperture_shape_image) return camera_error = "the camera's aperture blades: the image could not be created", false;
             }
         } else if (kv.first == "focus") {
             if (JsonValue::Object != kv.second.type) continue;
