@@ -343,13 +343,15 @@ def test_procedural_textures_next_to_glass(engine, oracle, integrator):
 
 
 @pytest.mark.gpu
-def test_procedural_textures_with_a_moving_camera(product_lib, oracle):
+@pytest.mark.parametrize("glass", [False, True])
+def test_procedural_textures_with_a_moving_camera(product_lib, oracle, glass):
     """The footprint comes from the camera where it was at the vertex' time (context.zig:140): the path carries its time when the
-    camera has keyframes and the scene a procedural texture."""
+    camera has keyframes and the scene a procedural texture; next to Glass the POOL kernels' camera samples do."""
     from ctypes import POINTER, c_float
     with zyg_amd.Engine(product_lib) as e:
         ov = {"floor": S(checker(9.0, (0.9, 0.9, 0.9), (0.1, 0.1, 0.1))), "back": S((0.5, 0.5, 0.5), normal=noise(scale=[12, 12, 12]))}
-        ids = scenes.cornell(e, 96, 64, 4, integrator="PTMIS", material="substitute", overrides=ov)
+        more = {"glass_objects": {"sphere": scenes.glass(1.5, roughness=noise(scale=[5, 5, 5]))}} if glass else {}
+        ids = scenes.cornell(e, 96, 64, 4, integrator="PTMIS", material="substitute", overrides=ov, **more)
         base = scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (0.0, 1.0, -3.9))
         for k, off in enumerate((-0.3, 0.3)):
             m = np.array(base, dtype=np.float32).reshape(16).copy()
