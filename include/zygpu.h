@@ -437,7 +437,9 @@ enum ZygpuAovClass { ZYGPU_AOV_ALBEDO = 0, ZYGPU_AOV_DEPTH = 1, ZYGPU_AOV_MATERI
                      ZYGPU_AOV_SHADING_NORMAL = 4, ZYGPU_AOV_ROUGHNESS = 5, ZYGPU_AOV_EMISSION = 6, ZYGPU_AOV_DIRECT = 7,
                      ZYGPU_AOV_INDIRECT = 8, ZYGPU_AOV_NUM_CLASSES = 9 };
 
-#define ZYGPU_MAX_CAMERA_KEYFRAMES 8
+#ifndef ZYGPU_MAX_CAMERA_KEYFRAMES
+#define ZYGPU_MAX_CAMERA_KEYFRAMES 64 /* frames of up to 63 ticks of 1/60 s: a 1-second exposure and more */
+#endif
 
 typedef struct ZygpuViewDesc {
     int32_t  resolution[2];

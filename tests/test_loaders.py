@@ -420,7 +420,10 @@ def test_take_aov_and_shutter_keys(product_lib, tmp_path):
     rc, nif, (_, step, duration, configured, cdf) = load({"frame_step": 1 / 30, "open": 0.3, "close": 0.7, "slope": slope, "motion_blur": False})
     assert (0, 2 * tick, 0, 1) == (rc, step, duration, configured) and 2 == nif
     assert np.array_equal(cdf, _shutter_cdf(0.3, 0.7, slope))
-    assert -1 == load({"frames_per_second": 4})[0]  # 15 ticks per frame: more keyframes than the view block holds
+    rc, nif, (_, step, duration, configured, cdf) = load({"frames_per_second": 4})  # 15 ticks per frame
+    assert (0, 705600000 // 4, 705600000 // 4) == (rc, step, duration) and 16 == nif
+    assert 0 == load({"frames_per_second": 1})[0]       # a one-second exposure: 61 keyframes
+    assert -1 == load({"frames_per_second": 0.9})[0]    # 66.7 ticks per frame: more keyframes than the view block holds
 
 
 @pytest.mark.gpu

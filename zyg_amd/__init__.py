@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("ZYG_AMD_LIB", os.path.join(_HERE, "libzyg_amd.so"))
 
 NULL = 0xFFFFFFFF
 FILTER_TAPS = 30
+MAX_CAMERA_KEYFRAMES = 64  # ZYGPU_MAX_CAMERA_KEYFRAMES
 
 
 class BvhNode(ctypes.Structure):
@@ -173,7 +174,7 @@ class ViewDesc(ctypes.Structure):
                 ("clamp_indirect", ctypes.c_float), ("exposure_factor", ctypes.c_float),
                 ("alpha_transparency", ctypes.c_uint32), ("tonemapper", ctypes.c_uint32),
                 ("aov_slots", ctypes.c_uint32), ("camera_num_keyframes", ctypes.c_uint32), ("camera_origin", ctypes.c_float * 4),
-                ("camera_keyframes", Keyframe * 8), ("aperture_shape", ctypes.c_uint32), ("shutter_configured", ctypes.c_uint32),
+                ("camera_keyframes", Keyframe * MAX_CAMERA_KEYFRAMES), ("aperture_shape", ctypes.c_uint32), ("shutter_configured", ctypes.c_uint32),
                 ("shutter_cdf", ctypes.c_float * 64)]
 
 

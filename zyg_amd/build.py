@@ -182,7 +182,8 @@ def build(verbose=True, extra=(), mode="both", units=None, jobs=None):
         elif not fresh:
             todo.append((name, src, flags, extra, verbose))
     # the longest compiles first (measured seconds per unit, precise / relaxed; kernel_table.hpp says what each holds)
-    weight = {"unit5.o": 40, "unit5f.o": 34, "unit7f.o": 32, "unit4.o": 29, "unit7.o": 26, "unit3f.o": 26, "unit3.o": 22, "unit1.o": 22, "unit1f.o": 24}
+    weight = {"unit5.o": 40, "unit5f.o": 34, "unit7f.o": 32, "unit4.o": 29, "unit7.o": 26, "unit3f.o": 26, "unit3.o": 22, "unit1.o": 22, "unit1f.o": 24,
+              "unit6.o": 27, "unit6f.o": 30, "unit2.o": 21, "unit2f.o": 23, "unit0.o": 28, "unit0f.o": 27}
     todo.sort(key=lambda j: (-weight.get(j[0], 18 if j[0].startswith("unit") else 5), j[0]))
     t0 = time.time()
     if os.path.exists(OUT + ".tag"):
