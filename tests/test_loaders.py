@@ -428,7 +428,8 @@ def test_take_aov_and_shutter_keys(product_lib, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shutter", [{"frames_per_second": 30, "open": 0.3, "close": 0.6, "slope": [0.1, 0.0, 0.2, 1.0, 0.7, 1.0, 0.9, 0.0]},
-                                     {"motion_blur": False}, {}, {"frames_per_second": 24, "open": 0.5}])
+                                     {"motion_blur": False}, {}, {"frames_per_second": 24, "open": 0.5},
+                                     {"frames_per_second": 4, "open": 0.1, "close": 0.9}])  # a quarter of a second: 16 camera keyframes
 def test_render_take_with_a_shutter(product_lib, oracle, tmp_path, shutter):
     """A moving prop and a moving camera under a configured shutter: the frame's step and duration, the time samples drawn through
     the shutter's distribution (camera_base.zig:121-136).  The device's film is the oracle's bit for bit, frame 1 differs from
