@@ -1123,6 +1123,42 @@ def _relaxed_against_the_oracle(engine, oracle, w, h, spp, points, camera, threa
     return r
 
 
+@pytest.mark.parametrize("glass", [False, True])
+def test_complete_kernels_walk_the_prop_table(product_lib, oracle, glass, monkeypatch):
+    """DScene::table_complete: in a scene of a few static props without masks or thin Glass the relaxed units' complete kernels (MESHL,
+    and POOL next to Glass) walk the prop table wave-wide, Spheres, a Disk and a Cube included, instead of the top-level tree lane by
+    lane.  With the table and (ZYG_TABLE_COMPLETE=0) without it the image is the oracle's within the contract, and the option reports
+    which walk ran."""
+    w, h, spp = 256, 192, 256
+    kw = dict(integrator="PTMIS", material="substitute", spheres=True, disk_and_cube=True)
+    if glass:
+        kw["glass_objects"] = {"box": scenes.glass(1.5, (0.6, 0.9, 0.7), 0.3), "sphere": scenes.glass(1.5)}
+        kw["box_lift"] = 1e-3
+    images = {}
+    for allowed in ("1", "0"):
+        monkeypatch.setenv("ZYG_TABLE_COMPLETE", allowed)
+        with zyg_amd.Engine(product_lib) as e:
+            scenes.cornell(e, w, h, spp, **kw)
+            e.start_frame(0)
+            e.set_option("precise", 0)
+            assert 1 == e.get_option("relaxed_units")
+            assert int(allowed) == e.get_option("table_complete")
+            e.render_iterations(spp)
+            e.synchronize()
+            film = e.download_film(w, h)
+            assert np.isfinite(film).all()
+            sd = e.lib.su_ext_scene_desc().contents
+            vd = e.lib.su_ext_view_desc().contents
+            if "1" == allowed:
+                cpu = oracle_resolve(oracle, vd, oracle_render(oracle, sd, vd, spp, threads=16))
+            images[allowed] = oracle_resolve(oracle, vd, film)
+    for allowed, image in images.items():
+        r = rms(image, cpu)
+        print(f"table_complete {allowed}: RMS vs oracle {r:.3e}")
+        assert r <= RMS_TOL
+    assert not np.array_equal(images["1"], images["0"])  # (two walks, two roundings: the table's Rectangles are tested in their own frame)
+
+
 @pytest.mark.parametrize("config", ["cornell", "config2_sphere", "config2_mound", "glass", "substitute", "boxes48"])
 def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
     """The kernels bench.py times (option precise = 0: the wave-wide prop-table walk, constant-block triangles, the quantised

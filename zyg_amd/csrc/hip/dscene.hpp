@@ -140,6 +140,10 @@ struct DScene {
     float4               small_tris[kSmallItemWords * kSmallTriangles];  // items of one or two triangles, mesh (= leaf) order
     uint32_t             num_solid_table, num_unocc_table;
     uint32_t             first_large;  // solid_table[first_large ..]: the meshes of kMeshKernelMinTriangles triangles or more (they come last)
+    // 1: the table holds every solid prop of the scene, Spheres, Disks and Cubes included, none of them animated, masked or of thin
+    // Glass (no material evaluates visibility): the relaxed units' complete kernels (MESHL / POOL) walk it wave-wide in place of the
+    // top-level tree (sceneIntersect / sceneVisibility / sceneVisibilityTr below)
+    uint32_t             table_complete;
     const ZygpuProp*     props;
     // animated props (ZygpuSceneDesc.keyframes): 3 float4 per keyframe (position, scale, rotation quaternion); prop_frames[p] =
     // first keyframe or kNull; null pointers: no prop is animated
@@ -1448,8 +1452,13 @@ ZD bool sphereIntersectOpacity(const DScene& s, const ZygpuMaterial& m, const Ra
 // WIDEC (relaxed units, scenes with a mesh that has the quantised four-wide re-layout: DMesh::wide): such a mesh's closest hit
 // through that walk.  An instantiation of its own: the walk's LDS stack and registers cost a scene without such a mesh 3 %
 // (cornell_glass 176 -> 171 Msamples/s), the outdoor scene's 1 M-triangle mesh returns 2-6 % (3840x2160: 495 -> 505, 1080p: 428 -> 450).
+template <bool WIDEC>
+ZD bool tableIntersectComplete(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit);
+ZD bool tableVisibilityComplete(const DScene& s, Ray& ray);
+
 template <bool STATS, bool EXTRA, bool WIDEC = false, typename Draw>
 ZD bool sceneIntersect(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit, Counters& cnt, Draw& draw) {
+    if (ZYG_FAST && !STATS && EXTRA && s.table_complete) return tableIntersectComplete<WIDEC>(s, ray, depth_surface, hit);  // (uniform; no masks: `draw` idle)
     hit.prop = kNull;
     bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
@@ -1769,9 +1778,103 @@ ZD bool sceneVisibilityUniform(const DScene& s, Ray& ray) {
     return !blocked;
 }
 
+// The prop table in the complete kernels (DScene::table_complete; relaxed units): the walks above with the shapes the complete
+// kernels know (Sphere, Disk, Cube: sceneIntersect's / sceneVisibility's own tests) and a mesh walked as those kernels' per-lane walk
+// walks it (its wide re-layout where it has one: the walk's stack is the one these kernels carry anyway).  What the wave gains is what
+// the plain kernels gained in round 2: no per-lane walk of the top-level tree, the props' records through the scalar cache, all lanes in
+// the same shape test, cheap shapes first.
+template <bool WIDEC>
+ZD bool tableIntersectComplete(const DScene& s, Ray& ray, uint32_t depth_surface, Hit& hit) {
+    hit.prop = kNull;
+    Counters none{0, 0, 0};
+    for (uint32_t k = 0; k < s.num_solid_table; ++k) {
+        const TlasEntry& e = s.solid_table[k];
+        if (!propVisibleAtDepth(e.flags, depth_surface)) continue;  // uniform
+        if (!entryBoundsHit<true>(e, ray)) continue;
+        Hit  h;
+        bool found;
+        h.u = h.v = 0.f;
+        h.primitive = 0;
+        if (ZYGPU_SHAPE_RECTANGLE == e.shape) {
+            found = unitRectangleIntersect(ray, e, h.t, h.u, h.v);
+        } else if (ZYGPU_SHAPE_TRIANGLE_MESH == e.shape) {
+            const Trafo trafo = entryTrafo(e);
+            Ray         local = worldToObjectRay(trafo, ray);
+            if (e.small_count > 0) {
+                found = false;
+                forSmallItems(s, e.small_first, e.small_count, [&](const SmallItem& item) {
+                    float    t, u, v;
+                    uint32_t primitive;
+                    if (smallItemIntersect(local, item, t, u, v, primitive)) {
+                        local.max_t = t;
+                        h.t = t;
+                        h.u = u;
+                        h.v = v;
+                        h.primitive = primitive;
+                        found = true;
+                    }
+                });
+            } else {
+                const DMesh& mesh = s.meshes[e.mesh];
+                found = (WIDEC && mesh.wide) ? meshIntersect<false, true>(mesh, local, h, none) : meshIntersect<false>(mesh, local, h, none);
+            }
+        } else if (ZYGPU_SHAPE_SPHERE == e.shape) {
+            found = sphereIntersect(ray, entryTrafo(e), h.t);
+        } else if (ZYGPU_SHAPE_CUBE == e.shape) {
+            found = cubeIntersect(ray, entryTrafo(e), h.t);
+        } else {
+            found = diskIntersect(ray, entryTrafo(e), h.t, h.u, h.v);
+        }
+        if (found) {
+            hit.t = h.t;
+            hit.u = h.u;
+            hit.v = h.v;
+            hit.primitive = h.primitive;
+            hit.prop = e.prop;
+            ray.max_t = h.t;
+        }
+    }
+    return kNull != hit.prop;
+}
+
+ZD bool tableVisibilityComplete(const DScene& s, Ray& ray) {  // true = unoccluded
+    Counters none{0, 0, 0};
+    bool     blocked = false;
+    for (uint32_t k = 0; k < s.num_solid_table; ++k) {
+        const TlasEntry& e = s.solid_table[k];
+        if (0 == (e.flags & ZYGPU_PROP_VISIBLE_IN_SHADOW)) continue;  // uniform
+        if (ZYGPU_SHAPE_RECTANGLE == e.shape) {                      // uniform
+            float t, u, v;
+            if (!blocked) blocked = unitRectangleIntersect(ray, e, t, u, v);
+        } else if (!blocked && aabbIntersect(e.bmin, e.bmax, ray)) {
+            const Trafo trafo = entryTrafo(e);
+            if (ZYGPU_SHAPE_TRIANGLE_MESH == e.shape) {
+                Ray local = worldToObjectRay(trafo, ray);
+                if (e.small_count > 0) {
+                    forSmallItems(s, e.small_first, e.small_count, [&](const SmallItem& item) { blocked = blocked || smallItemBlocks(local, item); });
+                } else {
+                    const DMesh& mesh = s.meshes[e.mesh];
+                    blocked = mesh.wide ? meshIntersectP<false, true, true>(mesh, local, none) : meshIntersectP<false>(mesh, local, none);
+                }
+            } else if (ZYGPU_SHAPE_SPHERE == e.shape) {
+                float t;
+                blocked = sphereIntersect(ray, trafo, t);
+            } else if (ZYGPU_SHAPE_CUBE == e.shape) {
+                blocked = cubeIntersectP(ray, trafo);
+            } else {
+                float t, u, v;
+                blocked = diskIntersect(ray, trafo, t, u, v);
+            }
+        }
+        if (0 == __ballot(!blocked)) break;  // every lane of the wave has its occluder
+    }
+    return !blocked;
+}
+
 // prop_tree.zig:185-240 + prop.zig:199-237: true = unoccluded
 template <bool STATS, bool EXTRA>
 ZD bool sceneVisibility(const DScene& s, Ray& ray, Counters& cnt) {
+    if (ZYG_FAST && !STATS && EXTRA && s.table_complete) return tableVisibilityComplete(s, ray);  // uniform
     const bool blocked = bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             const uint32_t  p = s.solid_indices[i];
@@ -1859,6 +1962,7 @@ ZD bool materialVisibility(const DScene& s, const ZygpuMaterial& m, f3 wi, f3 ge
 // sphere.zig:176-228, disk.zig:136-170, triangle_tree.zig:244-306); true = not blocked
 template <bool STATS, bool MASKS, typename Draw>
 ZD bool sceneVisibilityTr(const DScene& s, Ray& ray, Counters& cnt, f3& tr, Draw& draw) {
+    if (ZYG_FAST && !STATS && s.table_complete) return tableVisibilityComplete(s, ray);  // (uniform; nothing in such a scene attenuates: tr stays)
     const bool blocked = bvhWalk<STATS>(s.solid_nodes, s.num_solid_nodes, ray, cnt, [&](uint32_t first, uint32_t count) {
         for (uint32_t i = first, e = first + count; i < e; ++i) {
             const uint32_t  p = s.solid_indices[i];

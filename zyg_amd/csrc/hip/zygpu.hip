@@ -627,6 +627,8 @@ struct ZygpuContext {
     // option "uniform_tlas" (default on): scenes whose props fit the tables of dscene.hpp TlasEntry run the kernels that
     // walk them wave-wide instead of the top-level trees lane by lane (not the counting / MESHL / POOL instantiations)
     bool          uniform_tlas = true, uniform_tables = false;
+    // ZYG_TABLE_COMPLETE=0 in the environment (read at zygpu_create): the complete kernels keep their per-lane walk of the top-level tree (A/B)
+    bool          table_complete_allowed = true;
     // option "persistent": the whole path in one kernel with its state in LDS (wavefront.hpp wf_persistent) where the scene
     // allows it (the plain instantiations with the prop tables, in-place NEE, single-sample lights)
     bool          persistent = false;
@@ -1013,6 +1015,7 @@ int zygpu_create(int device_id, ZygpuContext** out_ctx) {
     }
     HIP_OK(hipSetDevice(device_id));
     auto* c = new ZygpuContext();
+    if (const char* tc = std::getenv("ZYG_TABLE_COMPLETE")) c->table_complete_allowed = 0 != std::atoi(tc);
     c->device = device_id;
     if (!check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) {
         delete c;
@@ -1509,6 +1512,10 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     // only (what the kernels without the EXTRA shapes know), Rectangles first; the unoccluding props when their tree is a
     // single leaf of at most 4 Rectangles, in the leaf's order.
     s.num_solid_table = s.num_unocc_table = s.first_large = 0;
+    bool extra_in_table = false;  // a Sphere, Disk or Cube: the table then serves the complete kernels only (table_complete)
+    // nothing in the scene attenuates a shadow ray or draws in the traversal: no prop whose materials evaluate visibility
+    bool plain_visibility = true;
+    for (uint32_t p = 0; p < d->num_props; ++p) plain_visibility = plain_visibility && 0 == (d->props[p].flags & ZYGPU_PROP_EVALUATE_VISIBILITY);
     {
         uint32_t num_small = 0;
         bool     wide_needed = false;
@@ -1638,8 +1645,11 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
         bool ok_solid = !order.empty() && order.size() <= kUniformProps && !s.prop_frames;  // static props only
         for (size_t i = 0; ok_solid && i < order.size(); ++i) {
             const uint32_t sh = d->props[order[i]].shape;
-            ok_solid = ZYGPU_SHAPE_RECTANGLE == sh || ZYGPU_SHAPE_TRIANGLE_MESH == sh;
+            const bool     extra = ZYGPU_SHAPE_SPHERE == sh || ZYGPU_SHAPE_DISK == sh || ZYGPU_SHAPE_CUBE == sh;
+            extra_in_table = extra_in_table || extra;
+            ok_solid = ZYGPU_SHAPE_RECTANGLE == sh || ZYGPU_SHAPE_TRIANGLE_MESH == sh || (extra && c->table_complete_allowed);
         }
+
         bool ok_unocc = 0 == d->unoccluding.num_nodes || (d->unoccluding.num_nodes >= 1 && 0 != d->unoccluding.nodes[0].count &&
                                                            d->unoccluding.nodes[0].count <= 4);
         if (ok_unocc && d->unoccluding.num_nodes)
@@ -1647,7 +1657,10 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
                 ok_unocc = ok_unocc && ZYGPU_SHAPE_RECTANGLE == d->props[d->unoccluding.indices[d->unoccluding.nodes[0].children_or_first + i]].shape;
         if (ok_solid && ok_unocc) {
             // Rectangles first, then meshes by size: the cheap tests shorten the ray before the expensive bounds are tested
-            auto weight = [&](uint32_t p) { return ZYGPU_SHAPE_RECTANGLE == d->props[p].shape ? 0u : 1u + d->meshes[d->props[p].mesh].num_triangles; };
+            auto weight = [&](uint32_t p) {
+                const uint32_t sh = d->props[p].shape;
+                return ZYGPU_SHAPE_RECTANGLE == sh ? 0u : ZYGPU_SHAPE_TRIANGLE_MESH == sh ? 2u + d->meshes[d->props[p].mesh].num_triangles : 1u;  // Rectangles, the analytic shapes, meshes by size
+            };
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight(a) < weight(b); });
             for (uint32_t p : order) s.solid_table[s.num_solid_table++] = entry(p);
             s.first_large = s.num_solid_table;
@@ -1664,7 +1677,10 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
             c->large_mesh = c->large_mesh && wide_needed;
         }
     }
-    c->uniform_tables = s.num_solid_table > 0;
+    // the complete kernels' wave-wide walk of the table (dscene.hpp DScene::table_complete); a table with a Sphere, Disk or Cube in it is
+    // theirs alone: the plain kernels (which such a scene never runs: its shapes put it on the complete ones) do not know those shapes
+    s.table_complete = (s.num_solid_table > 0 && plain_visibility && c->table_complete_allowed) ? 1u : 0u;
+    c->uniform_tables = s.num_solid_table > 0 && !extra_in_table;
     c->tables_deduplicated = c->uniform_tables && s.num_solid_table != d->solid.num_indices;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemsetAsync(&c->ctl->error, 0, sizeof(uint32_t), c->stream));
@@ -2715,6 +2731,7 @@ int zygpu_get_option(ZygpuContext* c, const char* name, int* out) {
                  {"uniform_tlas", c->uniform_tlas ? 1 : 0},
                  {"pool_relaxed", c->pool_relaxed},
                  {"coincident_dielectric", c->coincident_dielectric ? 1 : 0},
+                 {"table_complete", (c->has_scene && c->scene.table_complete) ? 1 : 0},  // read-only: the complete kernels walk the prop table
                  {"pool_tick_sync", c->pool_tick_sync ? 1 : 0},
                  {"split_nee", c->split_nee ? 1 : 0},
                  {"fuse_pool", c->fuse_pool ? 1 : 0},
