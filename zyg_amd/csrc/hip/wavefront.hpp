@@ -1152,7 +1152,9 @@ ZD bool walksUnoccluding(uint32_t flags) {
 template <bool STATS, bool EXTRA, bool UTLAS = false, typename Record>
 ZD void walkUnoccluding(const DScene& s, uint32_t depth_surface, const Ray& ray_in, Counters& cnt, Record&& record) {
     Ray ray = ray_in;
-    if (UTLAS) {  // the unoccluding tree is one leaf of Rectangles (dscene.hpp TlasEntry): its order is the leaf's order
+    // the unoccluding tree is one leaf of Rectangles (dscene.hpp TlasEntry): its order is the leaf's order; the complete kernels of the
+    // relaxed units take the table too where the scene's tables stand in for its trees (DScene::table_complete)
+    if (UTLAS || (ZYG_FAST && !STATS && EXTRA && s.table_complete)) {
         for (uint32_t k = 0; k < s.num_unocc_table; ++k) {
             const TlasEntry& e = s.unocc_table[k];
             if (!propVisibleAtDepth(e.flags, depth_surface)) continue;
