@@ -92,7 +92,7 @@ __global__ void test_intersect(uint32_t n, const float* rays, uint32_t depth_sur
     Hit          hit;
     Counters     cnt{0, 0, 0};
     bool         found;
-    if (0 == mode) found = sceneIntersect<false, true>(c_scene, ray, depth_surface, hit, cnt);
+    if (0 == mode) found = sceneIntersect<true, true>(c_scene, ray, depth_surface, hit, cnt);  // (the counting form: never the table, DScene::table_complete)
     else if (1 == mode) found = sceneIntersectUniform<true, false>(c_scene, ray, depth_surface, hit);
     else if (2 == mode) found = sceneIntersectUniform<true, true>(c_scene, ray, depth_surface, hit);
     else found = sceneIntersectUniform<false, true>(c_scene, ray, depth_surface, hit);  // no tie rule, small meshes triangle by triangle
@@ -112,7 +112,7 @@ __global__ void test_visibility(uint32_t n, const float* rays, uint32_t mode, ui
     const float* r = rays + size_t(i) * 8;
     Ray          ray = Ray::init(mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]);
     Counters     cnt{0, 0, 0};
-    visible[i] = (0 == mode   ? sceneVisibility<false, true>(c_scene, ray, cnt)
+    visible[i] = (0 == mode   ? sceneVisibility<true, true>(c_scene, ray, cnt)  // (the counting form: the tree, not the table)
                   : 1 == mode ? sceneVisibilityUniform<false>(c_scene, ray)
                   : 2 == mode ? sceneVisibilityUniform<true>(c_scene, ray)
                               : sceneVisibilityUniform<true, true>(c_scene, ray))
