@@ -1446,8 +1446,39 @@ int zygpu_upload_scene(ZygpuContext* c, const ZygpuSceneDesc* d) {
     for (uint32_t i = 0; i < d->num_image_lights; ++i) {
         const ZygpuImageLight& hl = d->image_lights[i];
         DImageLight&           dl = image_lights[i];
-        ok = m.upload(hl.cdf, hl.num_cdf, &dl.cdf) && m.upload(hl.lut, hl.num_lut, &dl.lut) &&
-             m.upload(reinterpret_cast<const uint4*>(hl.rows), size_t(hl.num_rows) + 1, &dl.rows);
+        // The look-up tables of the rows are rebuilt with one bucket per entry (the reference's, which the scene description carries,
+        // have one per 16: distribution_1d.zig:104-131).  A table only says where the search for the first cdf entry >= r begins, and
+        // here also where it ends (dlight.hpp Dist1D::sample): the entry found is the same, in one or two dependent loads instead of
+        // five (or, scanned, eight on average).
+        std::vector<uint32_t> fine_lut, fine_rows(hl.rows, hl.rows + 4 * (size_t(hl.num_rows) + 1));
+        for (uint32_t r = 0; r <= hl.num_rows; ++r) {
+            uint32_t*      w = fine_rows.data() + 4 * size_t(r);
+            const uint32_t size = w[1];
+            if (size < 2 || size_t(w[0]) + size > hl.num_cdf) {
+                g_error = "ZygpuImageLight: a row's cdf lies outside the array";
+                return -2;
+            }
+            const float*   cdf = hl.cdf + w[0];
+            const uint32_t lut_size = size - 1;
+            const float    lut_range = float(lut_size);
+            const size_t   base = fine_lut.size();
+            fine_lut.resize(base + lut_size + 1, 0u);
+            uint32_t* lut = fine_lut.data() + base;
+            lut[0] = 1;
+            uint32_t border = 0;
+            for (uint32_t i = 1; i < size; ++i) {
+                const uint32_t mapped = std::min(uint32_t(cdf[i] * lut_range), lut_size);
+                if (mapped > border) {
+                    for (uint32_t k = border + 1; k <= mapped; ++k) lut[k] = i;
+                    border = mapped;
+                }
+            }
+            for (uint32_t k = border + 1; k <= lut_size; ++k) lut[k] = size - 1;  // (a cdf that does not reach 1: the search ends at the last entry)
+            w[2] = uint32_t(base);
+            std::memcpy(&w[3], &lut_range, 4);
+        }
+        ok = m.upload(hl.cdf, hl.num_cdf, &dl.cdf) && m.upload(fine_lut.data(), fine_lut.size(), &dl.lut) &&
+             m.upload(reinterpret_cast<const uint4*>(fine_rows.data()), size_t(hl.num_rows) + 1, &dl.rows);
         if (!ok) return -1;
         dl.num_rows = hl.num_rows;
         dl.total_weight = hl.total_weight;
