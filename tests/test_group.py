@@ -114,6 +114,27 @@ def test_group_one_shot_frame_and_glass(product_lib, oracle):
 
 
 @pytest.mark.gpu
+def test_group_renders_procedural_textures(product_lib, oracle):
+    """Every context of a group has its own pool, the values of its vertices' procedural textures (Params::tex_values) included:
+    two contexts, the frame's rows split between them, a Checker floor, a Mix on the back wall and a noise normal map render the
+    oracle's film bit for bit."""
+    S = scenes.substitute_full
+    ov = {"floor": S({"Checker": {"scale": 6.0, "colors": [[0.9, 0.9, 0.9], [0.1, 0.1, 0.1]]}}, roughness={"Noise": {"scale": [5, 5, 5]}}),
+          "back": S({"Mix": {"a": [0.8, 0.2, 0.2], "b": [0.2, 0.2, 0.8], "weight": {"Noise": {"scale": [3, 3, 3]}}}}, normal={"Noise": {"scale": [9, 9, 9]}})}
+    with zyg_amd.Engine(product_lib) as e:
+        scenes.cornell(e, W, H, SPP, integrator="PTMIS", material="substitute", overrides=ov)
+        e.set_devices([0, 0], shard=1)
+        e.start_frame(0)
+        e.render_iterations(SPP)
+        e.synchronize()
+        film = e.download_film(W, H)
+        sd, vd = e.lib.su_ext_scene_desc().contents, e.lib.su_ext_view_desc().contents
+        assert sd.num_procedurals >= 5
+        want = oracle_render(oracle, sd, vd, SPP)
+    assert np.array_equal(film, want)
+
+
+@pytest.mark.gpu
 def test_group_of_one_reduces_through_rccl(product_lib, oracle):
     """ZYGPU_GROUP_ALWAYS_RCCL: a world of one still builds its communicator (ncclGetUniqueId + ncclCommInitRank on the member's thread)
     and the reduce is ncclReduce on the member's stream: the RCCL path of group.hip on the hardware there is.  Film == oracle."""
