@@ -264,6 +264,10 @@ struct Params {
     // kernels that build the closure, which read them where they would have fetched a texel (FragmentExtra::tex, loadSurface)
     float*   tex_values;
     size_t   tex_plane;
+    // POOL scenes: the alive queue has two ends.  A vertex whose closure cannot be evaluated whatever its fragment (smooth Glass without a
+    // roughness map or regularisation: no light sample is taken or evaluated there, pathtracer_mis.zig:185-187) is appended from the back;
+    // wf_light reads the front entries only (alive_ends 2), every other consumer both ends (1).  0: one end (the other scenes)
+    uint32_t alive_ends;
 };
 
 // one copy per translation unit (kernel_table.hpp): the units are built without relocatable device code
@@ -435,6 +439,7 @@ ZD void queueReset(QueueCounts* counts) {  // by one wave
 }
 ZD void aliveReset(QueueCounts (&counts)[kAliveKeys]) {  // by one wave
     if (__lane_id() < kAliveKeys) counts[__lane_id()].n[0] = 0;
+    if (kAliveKeys == __lane_id()) counts[0].n[kCountStride] = 0;  // (the back end of the POOL scenes' two-ended queue)
 }
 
 // Consumer side of the (sorted) alive queue for 256-thread blocks: thread i's entry.  Sub-queue k's entries come first to last in
@@ -442,6 +447,13 @@ ZD void aliveReset(QueueCounts (&counts)[kAliveKeys]) {  // by one wave
 // thread belongs to a block that has entries at all (whole blocks take part in the queue appends that follow); `valid`: it has an
 // entry, at alive_in[at].
 ZD bool aliveOpen(const Params& P, uint32_t parity, uint32_t i, uint32_t& at, bool& valid, uint32_t* key = nullptr) {
+    if (P.alive_ends) {  // the POOL scenes' two-ended queue: front entries first, then (unless the launch is wf_light's) the back ones
+        const uint32_t front = P.ctl->alive_count[parity][0].n[0], rear = 2u == P.alive_ends ? 0u : P.ctl->alive_count[parity][0].n[kCountStride];
+        valid = i < front + rear;
+        at = i < front ? i : P.queue_capacity - 1u - (i - front);
+        if (key) *key = i < front ? 0u : 1u;
+        return (i & ~255u) < front + rear;
+    }
     const uint32_t block_first = i & ~255u;  // (uniform over the block)
     uint32_t       begin = 0;
     valid = false;
@@ -1515,7 +1527,7 @@ ZD f3 unoccludingEmission(const Params& P, const DScene& s, uint32_t slot, size_
 template <bool STATS, bool MESHL, bool HEAVY, bool POOL, int PRE = 0, uint32_t KINDS = kAllLightKinds>
 ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const Hit& hit, uint32_t ucount, bool& alive, bool& defer,
                     Counters& cnt, SectionTimer& tm, const PathHead* pre = nullptr, float4 pre_thr = make_float4(1.f, 1.f, 1.f, 0.f),
-                    float* sr_out = nullptr, uint32_t* material_out = nullptr, bool* lazy_out = nullptr) {
+                    float* sr_out = nullptr, uint32_t* material_out = nullptr, bool* lazy_out = nullptr, bool* unlit_out = nullptr) {
     const DScene&  s = c_scene;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -1697,6 +1709,11 @@ ZD void shadeVertex(const Params& P, uint32_t slot, float4 ro, float4 rd, const 
         } else {
             if (sr_out) *sr_out = stochastic_r;  // (the caller writes it with the hit, at the vertex' place in the alive queue)
             else P.pool.hit_sr[slot] = stochastic_r;
+            // a closure that cannot be evaluated whatever the fragment: Glass whose roughness is the uniform 0 and stays 0 (no regularisation,
+            // renderstate.zig:60-69): Sample.init's can_evaluate is false (glass_sample.zig:33-66), sampleLights draws and samples nothing
+            if (POOL && unlit_out)
+                *unlit_out = ZYGPU_MAT_GLASS == m.kind && 0.f == m.roughness && kNull == m.tex[ZYGPU_STEX_ROUGHNESS].image &&
+                             (!mis || 0.f == c_view.v.regularize_roughness);
             if (material_out) *material_out = mat_id;
             // `lazy_out` (the first pass of a later tick, hit records by queue position): this pass has drawn twice (Russian roulette,
             // stochastic_r) and at most divided the throughput by the roulette's probability.  wf_scatter, which reads and rewrites the
@@ -1788,7 +1805,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
         Hit        hit{0.f, 0.f, 0.f, 0u, kNull};
         float      stochastic_r = 0.f;
         uint32_t   material = kNull;
-        bool       lazy = false;
+        bool       lazy = false, unlit = false;
         const bool queued = !POOL && nullptr != P.hit_q;
         if (i < total) {
             slot = HEAVY ? P.q.heavy[at] : extQueue<POOL>(P, cur, P.round)[at];
@@ -1798,7 +1815,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
             ucount = P.pool.ucount[slot];
             shadeVertex<STATS, MESHL, HEAVY, POOL, 0, KINDS>(P, slot, P.pool.ray_o[slot], P.pool.ray_d[slot], hit, ucount, alive, defer, cnt, tm, nullptr,
                                                              make_float4(1.f, 1.f, 1.f, 0.f), queued ? &stochastic_r : nullptr, queued ? &material : nullptr,
-                                                             (queued && !HEAVY && P.lazy_head) ? &lazy : nullptr);
+                                                             (queued && !HEAVY && P.lazy_head) ? &lazy : nullptr, POOL ? &unlit : nullptr);
         }
         if (HEAVY && !POOL && P.regen_sample) {
             // the regenerating kernels: no queue behind this pass; a path that ended here leaves its slot to wf_rscatter
@@ -1809,7 +1826,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(HEAVY ? (MESHL ? ZYG_SHADE_BIG_
                 __syncthreads();  // queuePush's shared words are reused below
             }
             if (!POOL && P.alive_keys > 1) alivePushKeyed<4>(P, cur, false, alive, alive_key & (kAliveKeys - 1u), slot);
-            else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot, false, &position);
+            else queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot, POOL && unlit && 0 != P.alive_ends, &position);
             if (queued && alive) storeQueuedHit(P, position, hit, ucount, stochastic_r, material, lazy);
         }
         tm.mark(5);
@@ -1872,7 +1889,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_POOL_WAVES) wf_
     Counters     cnt{0, 0, 0};
     SectionTimer tm;
     tm.start();
-    bool     alive = false, defer = false;
+    bool     alive = false, defer = false, unlit = false;
     uint32_t slot = 0;
     if (i < n) {
         if (FIRST) {
@@ -1907,7 +1924,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_POOL_WAVES) wf_
         // after Scene.intersect the probe's max_t is the hit distance (prop_tree.zig:76-79)
         const uint32_t ucount = walksUnoccluding(flags) ? unoccludingCandidates<false, true>(P, c_scene, slot, vertexPlane<true>(), depth, ray, cnt) : 0u;
         shadeVertex<false, true, false, true, 0, kAllLightKinds>(P, slot, ray_o, d, hit, ucount, alive, defer, cnt, tm, nullptr, make_float4(1.f, 1.f, 1.f, 0.f),
-                                                                 nullptr, nullptr);
+                                                                 nullptr, nullptr, nullptr, &unlit);
         if (alive || defer) {  // the complete pass, wf_light and the closure half read the hit
             P.pool.hit[slot] = make_uint4(__float_as_uint(hit.t), __float_as_uint(hit.u), __float_as_uint(hit.v), hit.primitive);
             P.pool.hit_prop[slot] = hit.prop;
@@ -1916,7 +1933,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TRACE_SHADE_POOL_WAVES) wf_
     }
     queuePush(P.q.heavy, &P.ctl->heavy_count[cur], P.queue_capacity, defer, slot);
     __syncthreads();  // queuePush's shared words are reused below
-    queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot);
+    queuePush(P.alive_out, &P.ctl->alive_count[cur][0], P.queue_capacity, alive, slot, unlit && 0 != P.alive_ends);
 }
 
 // wf_intersect and wf_shade's first pass in one kernel (non-POOL): the ray, the hit and the candidate count stay in
@@ -2990,7 +3007,7 @@ struct ScatterOut {
 constexpr uint32_t kMaxNeeStored = 4, kNeeOverflow = 0xFFFFFFFFu;
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS, bool UTLAS, bool WIDE, int PHASE = 0, uint32_t KINDS = kAllLightKinds>
 ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOut& out, Counters& cnt, unsigned long long& shadow_rays,
-                      SectionTimer& tm, const HitRecord* record = nullptr) {
+                      SectionTimer& tm, const HitRecord* record = nullptr, bool unlit = false) {
     const uint32_t nxt = P.parity ^ 1u;
     const uint32_t kind = c_view.v.integrator;
     const bool     mis = ZYGPU_INTEGRATOR_PTMIS == kind;
@@ -3039,7 +3056,8 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
     }
     const uint32_t texture_draws = (MESHL && 2 != PHASE) ? skipTextureDraws(P, slot, sf.material, h) : 0u;
 
-    if (2 == PHASE && kNeeOverflow == P.nee_count[ps]) return;  // wf_light sent the vertex through the unsplit kernel
+    // (`unlit`: the vertex came through the alive queue's back end and skipped wf_light: it has no stored samples, P.nee_count is another vertex')
+    if (2 == PHASE && !unlit && kNeeOverflow == P.nee_count[ps]) return;  // wf_light sent the vertex through the unsplit kernel
     if (MESHL && 1 != PHASE && c_view.v.aov_slots) commonAov(P, slot, ps, h, sf, throughput, record);
     tm.mark(0);
 
@@ -3067,7 +3085,7 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
         // the light samples wf_light stored, in its order; a pick's samples are summed by themselves first (evaluateLight's `result`),
         // then added to the vertex' sum or, on a shadow catcher, to what the catcher lights send
         if (ZYGPU_INTEGRATOR_PT != kind && ms.can_evaluate) {
-            const uint32_t count = P.nee_count[ps];
+            const uint32_t count = unlit ? 0u : uint32_t(P.nee_count[ps]);
             f3             nee = S3(0.f), occluded = S3(0.f), unoccluded = S3(0.f);
             uint32_t       open_pick = kNull;
             bool           open_catcher_light = false;
@@ -3616,7 +3634,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_W
     const uint32_t     nxt = P.parity ^ 1u;
     if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t     i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t           at;
+    uint32_t           at, alive_end = 0;  // alive_end 1: an entry of the alive queue's back end (Params::alive_ends): wf_light has not seen the vertex
     bool               has_entry;
     if (POOL && P.scatter_source) {  // wf_light's overflow queue: the vertices that took more light samples than its record holds
         const uint32_t n = P.ctl->shadow_count[0].n[0];
@@ -3624,7 +3642,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_W
         at = i;
         has_entry = i < n;
     } else
-    if (!aliveOpen(P, P.parity, i, at, has_entry)) return;  // whole blocks take part in queuePush
+    if (!aliveOpen(P, P.parity, i, at, has_entry, &alive_end)) return;  // whole blocks take part in queuePush
     Counters           cnt{0, 0, 0};
     unsigned long long shadow_rays = 0;
     const DScene& s = c_scene;
@@ -3705,7 +3723,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_W
         slot = (POOL && P.scatter_source) ? P.q.shadow[at] : P.alive_in[at];
         // Params::hit_q: the vertex' hit record sits at its place in the alive queue (its address does not wait for the slot)
         const HitRecord hr = (!POOL && P.hit_q) ? loadQueuedHit(P, at) : loadHitRecord(P, slot);
-        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE, PHASE, KINDS>(P, s, slot, out, cnt, shadow_rays, tm, &hr);
+        scatterVertex<STATS, SUBST, MULTI, MESHL, POOL, MASKS, UTLAS, WIDE, PHASE, KINDS>(P, s, slot, out, cnt, shadow_rays, tm, &hr, POOL && 0 != alive_end);
     }
 #endif
     if (POOL) {

@@ -629,6 +629,7 @@ struct ZygpuContext {
     bool          uniform_tlas = true, uniform_tables = false;
     // ZYG_TABLE_COMPLETE=0 in the environment (read at zygpu_create): the complete kernels keep their per-lane walk of the top-level tree (A/B)
     bool          table_complete_allowed = true;
+    bool          alive_two_ends = true;  // ZYG_ALIVE_ENDS=0 in the environment: the POOL scenes' alive queue keeps one end (A/B)
     // option "persistent": the whole path in one kernel with its state in LDS (wavefront.hpp wf_persistent) where the scene
     // allows it (the plain instantiations with the prop tables, in-place NEE, single-sample lights)
     bool          persistent = false;
@@ -1016,6 +1017,7 @@ int zygpu_create(int device_id, ZygpuContext** out_ctx) {
     HIP_OK(hipSetDevice(device_id));
     auto* c = new ZygpuContext();
     if (const char* tc = std::getenv("ZYG_TABLE_COMPLETE")) c->table_complete_allowed = 0 != std::atoi(tc);
+    if (const char* ae = std::getenv("ZYG_ALIVE_ENDS")) c->alive_two_ends = 0 != std::atoi(ae);
     c->device = device_id;
     if (!check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) {
         delete c;
@@ -1902,6 +1904,7 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     P.nee_count = c->nee_count;
     P.tex_values = c->procedurals ? c->tex_values : nullptr;
     P.tex_plane = c->tex_plane;
+    P.alive_ends = (c->pool_mode && c->alive_two_ends) ? 1u : 0u;
     P.scatter_source = 0;
     P.pixel_pcg = nullptr;
     if (one_shot) {
@@ -2148,10 +2151,12 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
                         else if (c->split_nee) {  // (scenes of the plain instantiations, too: wf_light's shapes and lights are a superset of theirs)
                             // the light half (no closure), the vertices that overflowed its record through the unsplit kernel (only in a
                             // scene whose lights can send more than kMaxNeeStored samples to one vertex), the closure half
+                            Params L = P;
+                            if (L.alive_ends) L.alive_ends = 2;  // the front end only: the vertices whose closure may be evaluated
                             launchKernel(c, 0 == (c->light_kinds & ~kRectangleLightKinds) ? K_LIGHT_POOL_RECT
                                             : 0 == (c->light_kinds & ~kSkyLightKinds)     ? K_LIGHT_POOL_SKY
                                                                                           : K_LIGHT_POOL,
-                                         grid.x, P, 0u);
+                                         grid.x, L, 0u);
                             if (c->max_light_samples > kMaxNeeStored) {
                                 Params Q = P;
                                 Q.scatter_source = 1;
