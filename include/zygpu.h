@@ -608,7 +608,7 @@ int zygpu_set_option(ZygpuContext* ctx, const char* name, int value);
  * instantiations (Glass / shadow catchers: split paths, medium stack); "prop_tables" / "wide_blas" / "mesh_kernels_active":
  * the prop-table walk, the four-wide BLAS and the persistent mesh kernels are what this scene renders with; "table_complete" 1
  * when the complete kernels (scenes with Spheres, image lights, textures, Glass ...) may walk the prop table wave-wide in their
- * relaxed units: at most 112 static solid props, Spheres / Disks / Cubes among them, no opacity mask and no thin Glass
+ * relaxed units: at most 88 static solid props, Spheres / Disks / Cubes among them, no opacity mask and no thin Glass
  * (ZYG_TABLE_COMPLETE=0 in the environment of zygpu_create keeps the per-lane walk of the top-level tree: an A/B switch).
  * bench.py reports `config.arithmetic` from it. -1: unknown name. */
 int zygpu_get_option(ZygpuContext* ctx, const char* name, int* out_value);
