@@ -1159,6 +1159,37 @@ def test_complete_kernels_walk_the_prop_table(product_lib, oracle, glass, monkey
     assert not np.array_equal(images["1"], images["0"])  # (two walks, two roundings: the table's Rectangles are tested in their own frame)
 
 
+@pytest.mark.parametrize("why", ["many_props", "mask", "thin_glass", "moving_prop"])
+def test_scenes_that_keep_the_complete_kernels_on_the_tree(product_lib, why):
+    """DScene::table_complete is 0 where the table cannot stand in for the tree: more than 88 solid props (the tree is faster there),
+    a prop whose material evaluates visibility (an opacity mask, thin Glass: the traversal draws or attenuates), an animated prop."""
+    from ctypes import POINTER, c_float
+    with zyg_amd.Engine(product_lib) as e:
+        kw = dict(integrator="PTMIS", material="substitute", spheres=True)
+        if "many_props" == why:
+            kw["extra_props"] = 100
+        elif "mask" == why:
+            kw["masked"] = {"image": scenes.weight_image(8, 0.0, 1.0)}
+        elif "thin_glass" == why:
+            kw["glass_objects"] = {"box": scenes.glass(1.5, thickness=0.01)}
+        ids = scenes.cornell(e, 64, 48, 1, **kw)
+        if "moving_prop" == why:
+            prop = ids["meshes"][0]
+            for k, dx in enumerate((0.0, 0.1)):
+                m = np.array(scenes.trafo((1, 0, 0), (0, 1, 0), (1, 1, 1), (dx, 0.0, 0.0)), dtype=np.float32).reshape(16).copy()
+                assert e.lib.su_prop_set_transformation_frame(prop, k, m.ctypes.data_as(POINTER(c_float))) == 0
+        e.start_frame(0)
+        e.set_option("precise", 0)
+        assert 0 == e.get_option("table_complete")
+        e.render_iterations(1)
+        e.synchronize()
+        assert np.isfinite(e.download_film(64, 48)).all()
+    with zyg_amd.Engine(product_lib) as e:  # (and the same box without the reason has it)
+        scenes.cornell(e, 64, 48, 1, integrator="PTMIS", material="substitute", spheres=True)
+        e.start_frame(0)
+        assert 1 == e.get_option("table_complete")
+
+
 @pytest.mark.parametrize("config", ["cornell", "config2_sphere", "config2_mound", "glass", "substitute", "boxes48"])
 def test_relaxed_arithmetic_meets_the_contract_at_1080p(engine, oracle, config):
     """The kernels bench.py times (option precise = 0: the wave-wide prop-table walk, constant-block triangles, the quantised
