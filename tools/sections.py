@@ -17,7 +17,10 @@ if os.environ.get("ZYG_SCENE") == "mesh":  # BASELINE.json configs[2]
     kw = dict(boxes=False, mesh=scenes.displaced_sphere_mesh(), mesh_position=scenes.MESH_CENTRE, mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
 elif os.environ.get("ZYG_SCENE") == "mound":
     kw = dict(boxes=False, mesh=scenes.heightfield_mesh(), mesh_material=scenes.substitute((0.5, 0.5, 0.5)))
-if os.environ.get("ZYG_SCENE") == "outdoor":  # BASELINE.json configs[4]'s scene (POOL kernels)
+if os.environ.get("ZYG_SCENE") == "proc":  # bench.py --material procedural: the complete closures outside the POOL kernels
+    import bench
+    bench.build_scene(eng, scenes, "cornell", "procedural", w, h, iters)
+elif os.environ.get("ZYG_SCENE") == "outdoor":  # BASELINE.json configs[4]'s scene (POOL kernels)
     scenes.outdoor(eng, w, h, iters, integrator="PTMIS", material="substitute", showcase=True, mesh=scenes.heightfield_mesh(), max_depth=16,
                    sky_entity={"parameters": {"sun": {"rotation": [-55, 20, 0]}}}, box_lift=1e-3)
 else:

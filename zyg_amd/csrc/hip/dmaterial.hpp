@@ -797,8 +797,8 @@ ZD f3 sampleColorMapAt(const DScene& s, const ZygpuMaterial& m, float u, float v
     return sampleImageMap(s, m.color_image, m.color_sampler, m.color_scale, su, sv, r);
 }
 
-// Where wf_textures (wavefront.hpp, dprocedural.hpp) leaves the values of a vertex' procedural textures: planes of Params::tex_values,
-// one float per vertex and plane
+// Where wf_textures (wavefront.hpp, dprocedural.hpp) leaves the values of a vertex' procedural textures: the floats of the vertex' block
+// of Params::tex_values
 enum : uint32_t {
     kTexColor = 0,                                // 3 planes
     kTexWeight = 3,                               // + ZYGPU_STEX_ROUGHNESS .. ZYGPU_STEX_FLAKES_COVERAGE
@@ -809,14 +809,13 @@ enum : uint32_t {
 };
 
 // What the complete Substitute closure reads of the fragment beyond its frame (Renderstate: uv, stochastic_r, p, trafo)
-// `tex`: the vertex' entry of the first plane of its procedural textures' values (null: the scene has none)
+// `tex`: the vertex' block of its procedural textures' values (null: the scene has none)
 struct FragmentExtra {
     float u, v, stochastic_r;
     f3    p;
     Trafo trafo;
     const float* tex = nullptr;
-    size_t       tex_plane = 0;
-    ZD float texValue(uint32_t plane) const { return tex[size_t(plane) * tex_plane]; }
+    ZD float texValue(uint32_t plane) const { return tex[plane]; }
 };
 
 // hlp.sampleNormal (material_helper.zig:16-78), tex_coord UV0: the normal map's xy in the tangent frame, z reconstructed, then the

@@ -259,11 +259,12 @@ struct Params {
     uint32_t mesh_pass;  // 1: wf_mesh_closest has traced the back entries of the extension queue; wf_trace_shade reads their hits; 2: wf_mesh_closest8 has walked the large meshes for them, wf_trace_shade tests the rest of the table
     uint32_t alive_key_mask;  // wf_scatter_h: bit k = the launch takes sub-queue k of the sorted alive queue
     uint32_t lazy_head;  // 1 (option "lazy_head", with hit_q): the first shading pass leaves a vertex' sampler and throughput to wf_scatter (shadeVertex)
-    // The values of the vertices' procedural textures (dprocedural.hpp; null: the scene has none): kTexPlanes planes of tex_plane floats,
-    // indexed like the pool's records (by path slot; POOL: by vertex).  wf_textures writes them between the shading passes and the
-    // kernels that build the closure, which read them where they would have fetched a texel (FragmentExtra::tex, loadSurface)
+    // The values of the vertices' procedural textures (dprocedural.hpp; null: the scene has none): a block of kTexPlanes floats (64 B, half
+    // a line: one fill, one write) per path slot (POOL: per vertex), indexed like the pool's records.  wf_textures writes the whole block
+    // between the shading passes and the kernels that build the closure, which read it where they would have fetched a texel
+    // (FragmentExtra::tex, loadSurface).  (One plane per value, the round's first layout, cost a sector per value and vertex: the living
+    // slots are sparse.)
     float*   tex_values;
-    size_t   tex_plane;
     // POOL scenes: the alive queue has two ends.  A vertex whose closure cannot be evaluated whatever its fragment (smooth Glass without a
     // roughness map or regularisation: no light sample is taken or evaluated there, pathtracer_mis.zig:185-187) is appended from the back;
     // wf_light reads the front entries only (alive_ends 2), every other consumer both ends (1).  0: one end (the other scenes)
@@ -2115,17 +2116,18 @@ ZD Regularize loadRegularize(const Params& P, uint32_t slot) {
     return r;
 }
 
+ZD float* texBlock(const Params& P, uint32_t slot) { return P.tex_values + size_t(slot) * kTexPlanes; }
 // a procedural colour as wf_textures left it
 ZD f3 textureColor(const Params& P, uint32_t slot) {
-    const float* t = P.tex_values + slot;
-    return mk3(t[size_t(kTexColor) * P.tex_plane], t[size_t(kTexColor + 1u) * P.tex_plane], t[size_t(kTexColor + 2u) * P.tex_plane]);
+    const float* t = texBlock(P, slot);
+    return mk3(t[kTexColor], t[kTexColor + 1u], t[kTexColor + 2u]);
 }
 // The sampler dimensions the vertex' procedural textures drew in wf_textures (a Mix picks one of its two children with one,
 // procedural_mix.zig:17-26): Material.sample comes before the vertex' light and bxdf samples (pathtracer_mis.zig:93), so the kernel
 // that draws those skips as many first
 ZD uint32_t skipTextureDraws(const Params& P, uint32_t slot, uint32_t material, PathHead& h) {
     if (!P.tex_values || !(c_scene.materials[material].flags & ZYGPU_MATF_PROCEDURAL)) return 0u;
-    const uint32_t n = __float_as_uint(P.tex_values[size_t(kTexDraws) * P.tex_plane + slot]);
+    const uint32_t n = __float_as_uint(texBlock(P, slot)[kTexDraws]);
     for (uint32_t k = 0; k < n; ++k) (void)h.smp.sample1D();
     return n;
 }
@@ -2169,7 +2171,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
         sf.material = material;
         const Regularize reg = loadRegularize(P, slot);
         if (EXTRA && (m.flags & ZYGPU_MATF_EXTENDED)) {
-            const FragmentExtra fx{frag.uv0, frag.uv1, hit_sr, frag.p, frag.trafo, P.tex_values ? P.tex_values + slot : nullptr, P.tex_plane};
+            const FragmentExtra fx{frag.uv0, frag.uv1, hit_sr, frag.p, frag.trafo, P.tex_values ? texBlock(P, slot) : nullptr};
             sf.ms = makeMaterialSample<EXTRA>(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, &fx, reg);
         } else {
             sf.ms = makeMaterialSample(s, m, wo, geo_n, frag.t, frag.b, n, caustics, color, 1.f, false, nullptr, reg);
@@ -2200,7 +2202,7 @@ ZD Surface loadSurface(const Params& P, uint32_t slot, uint32_t flags, const Hit
             const float2        uv = P.pool.rec_uv[slot];
             const FragmentExtra fx{uv.x, uv.y, P.pool.hit_sr[slot], sf.p,
                                    propTrafoAt<true>(c_scene, P.pool.hit_prop[slot], pathTime<true, true>(P, slot)),
-                                   P.tex_values ? P.tex_values + slot : nullptr, P.tex_plane};
+                                   P.tex_values ? texBlock(P, slot) : nullptr};
             sf.ms = makeMaterialSample<EXTRA>(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, &fx, reg);
         } else {
             sf.ms = makeMaterialSample(c_scene, m, wo, geo_n, t, b, n, caustics, color, ri.x, 0.f != ri.y, nullptr, reg);
@@ -3596,6 +3598,9 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
 #ifndef ZYG_LIGHT_SKY_WAVES
 #define ZYG_LIGHT_SKY_WAVES 3  // ... of the instantiation for a sun and a sky map (217 registers without a spill; at 168: 40 spilled, and faster)
 #endif
+#ifndef ZYG_SCATTER_COMPLETE_WAVES
+#define ZYG_SCATTER_COMPLETE_WAVES 2  // the complete closures outside POOL scenes (textured / coated Substitute, mesh lights)
+#endif
 #ifndef ZYG_SCATTER_EVAL_WAVES
 #define ZYG_SCATTER_EVAL_WAVES 2  // wf_scatter<.., PHASE 2>
 #endif
@@ -3628,7 +3633,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(kSkyLightKinds == KINDS ? ZYG_L
 // KINDS: the light kinds the scene has (the complete instantiations of scenes whose lights are all plain Rectangles: a scene is on the
 // complete kernels for its textures, shapes or keyframes as often as for its lights)
 template <bool STATS, bool SUBST, bool MULTI, bool MESHL, bool POOL, bool MASKS = STATS, bool UTLAS = false, bool WIDE = false, int PHASE = 0, uint32_t KINDS = kAllLightKinds>
-__global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_WAVES : (MESHL && POOL && !STATS) ? ZYG_SCATTER_POOL_FULL_WAVES : (SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
+__global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_WAVES : (MESHL && POOL && !STATS) ? ZYG_SCATTER_POOL_FULL_WAVES : (MESHL && !STATS) ? ZYG_SCATTER_COMPLETE_WAVES : (SUBST || MULTI || MESHL) ? ZYG_SCATTER_BIG_WAVES : ZYG_SCATTER_WAVES) wf_scatter(Params P) {
     static_assert(!UTLAS || (!STATS && !MESHL && !POOL && !MASKS), "the prop table holds Rectangles and meshes only and counts nothing");
     static_assert(0 == PHASE || (2 == PHASE && POOL && !STATS), "the split next-event estimation: the POOL scenes' instantiations");
     const uint32_t     nxt = P.parity ^ 1u;
@@ -3828,25 +3833,28 @@ __global__ void __launch_bounds__(256) wf_textures(Params P) {
     rs.smp = &h.smp;
     rs.draws = 0;
     constexpr int kTop = ZYGPU_PROCEDURAL_MAX_DEPTH - 1;
-    float*        out = P.tex_values + slot;
-    const size_t  plane = P.tex_plane;
+    // the block's values are collected here and stored whole (a block written in part is fetched first); every index is a constant once
+    // the lambdas are inlined, so the array lives in registers
+    float out[kTexPlanes];
+    static_assert(16 == kTexPlanes, "the block is stored as four float4");
+    for (uint32_t k = 0; k < kTexPlanes; ++k) out[k] = 0.f;
     auto procedural = [](const ZygpuTexture& t) { return kNull != t.image && 0 != (t.sampler & ZYGPU_TEX_PROCEDURAL); };
     // ts.sample2D_1 of tex[k]: the value where the kernel needs it itself (coating_scale), stored where the texture is procedural
-    auto weight = [&](uint32_t k, float uniform) {
+    auto weight = [&](uint32_t k, float uniform) __attribute__((always_inline)) {
         const ZygpuTexture& t = m.tex[k];
         if (!procedural(t)) return kNull == t.image ? uniform : texture1<0>(s, t, &uniform, rs);
         const float value = procedural1<kTop>(s, t.image, t.sampler, rs);
-        out[size_t(kTexWeight + k) * plane] = value;
+        out[kTexWeight + k] = value;
         return value;
     };
-    auto weightIfProcedural = [&](uint32_t k) {
-        if (procedural(m.tex[k])) out[size_t(kTexWeight + k) * plane] = procedural1<kTop>(s, m.tex[k].image, m.tex[k].sampler, rs);
+    auto weightIfProcedural = [&](uint32_t k) __attribute__((always_inline)) {
+        if (procedural(m.tex[k])) out[kTexWeight + k] = procedural1<kTop>(s, m.tex[k].image, m.tex[k].sampler, rs);
     };
-    auto normalIfProcedural = [&](uint32_t k, uint32_t at_plane) {
+    auto normalIfProcedural = [&](uint32_t k, uint32_t at_plane) __attribute__((always_inline)) {
         if (!procedural(m.tex[k])) return;
         const float2 n = procedural2<kTop>(s, m.tex[k].image, m.tex[k].sampler, rs);
-        out[size_t(at_plane) * plane] = n.x;
-        out[size_t(at_plane + 1u) * plane] = n.y;
+        out[at_plane] = n.x;
+        out[at_plane + 1u] = n.y;
     };
     if (ZYGPU_MAT_GLASS == m.kind) {  // glass_material.zig:50-73: roughness, specular, the normal map
         weightIfProcedural(ZYGPU_STEX_ROUGHNESS);
@@ -3855,9 +3863,9 @@ __global__ void __launch_bounds__(256) wf_textures(Params P) {
     } else {  // substitute_material.zig:121-187
         if (kNull != m.color_image && (m.color_sampler & ZYGPU_TEX_PROCEDURAL)) {
             const f3 c = procedural3<kTop>(s, m.color_image, m.color_sampler, rs);
-            out[size_t(kTexColor) * plane] = c.x;
-            out[size_t(kTexColor + 1u) * plane] = c.y;
-            out[size_t(kTexColor + 2u) * plane] = c.z;
+            out[kTexColor] = c.x;
+            out[kTexColor + 1u] = c.y;
+            out[kTexColor + 2u] = c.z;
         }
         weightIfProcedural(ZYGPU_STEX_ROUGHNESS);
         weightIfProcedural(ZYGPU_STEX_METALLIC);
@@ -3874,7 +3882,9 @@ __global__ void __launch_bounds__(256) wf_textures(Params P) {
         weightIfProcedural(ZYGPU_STEX_ROTATION);
         weightIfProcedural(ZYGPU_STEX_FLAKES_COVERAGE);
     }
-    out[size_t(kTexDraws) * plane] = __uint_as_float(rs.draws);
+    out[kTexDraws] = __uint_as_float(rs.draws);
+    float4* block = reinterpret_cast<float4*>(texBlock(P, slot));
+    for (uint32_t k = 0; k < kTexPlanes / 4u; ++k) block[k] = make_float4(out[4u * k], out[4u * k + 1u], out[4u * k + 2u], out[4u * k + 3u]);
 }
 #endif
 

@@ -619,7 +619,6 @@ struct ZygpuContext {
     bool          procedurals = false;         // a material in use carries ZYGPU_MATF_PROCEDURAL: wf_textures runs, the pool holds Params::tex_values
     bool          procedurals_allocated = false;
     float*        tex_values = nullptr;
-    size_t        tex_plane = 0;
     uint32_t      light_kinds = 0;         // bit 1 << LightKind for every kind of light in the scene: which wf_light instantiation holds them
     float4*       nee_rec = nullptr;       // Params::nee_rec / nee_count (POOL pool)
     uint32_t*     nee_count = nullptr;
@@ -845,11 +844,9 @@ int ensurePool(ZygpuContext* c, size_t slots, uint32_t rounds, uint32_t alive_ke
          m.alloc(qcap, &c->queues.shadow) && m.alloc(qcap, &c->queues.heavy) &&
          (!hit_q || m.alloc(qcap * 2, &c->hit_q));  // Params::hit_q: two uint4 per alive-queue entry
     c->tex_values = nullptr;
-    c->tex_plane = 0;
     c->procedurals_allocated = false;
     if (ok && c->procedurals) {  // Params::tex_values: kTexPlanes floats per path slot (POOL: per vertex)
         ok = m.alloc(paths * size_t(kTexPlanes), &c->tex_values);
-        c->tex_plane = paths;
         c->procedurals_allocated = ok;
     }
     c->nee_rec = nullptr;
@@ -1905,7 +1902,6 @@ static int renderRange(ZygpuContext* c, uint32_t frame, uint32_t iteration, uint
     P.nee_rec = c->nee_rec;
     P.nee_count = c->nee_count;
     P.tex_values = c->procedurals ? c->tex_values : nullptr;
-    P.tex_plane = c->tex_plane;
     P.alive_ends = (c->pool_mode && c->alive_two_ends) ? 1u : 0u;
     P.scatter_source = 0;
     P.pixel_pcg = nullptr;
