@@ -1160,7 +1160,7 @@ def test_complete_kernels_walk_the_prop_table(product_lib, oracle, glass, monkey
 
 
 @pytest.mark.parametrize("why", ["many_props", "mask", "thin_glass", "moving_prop"])
-def test_scenes_that_keep_the_complete_kernels_on_the_tree(product_lib, why):
+def test_scenes_that_keep_the_complete_kernels_on_the_tree(product_lib, why, monkeypatch):
     """DScene::table_complete is 0 where the table cannot stand in for the tree: more than 88 solid props (the tree is faster there),
     a prop whose material evaluates visibility (an opacity mask, thin Glass: the traversal draws or attenuates), an animated prop."""
     from ctypes import POINTER, c_float
@@ -1184,6 +1184,7 @@ def test_scenes_that_keep_the_complete_kernels_on_the_tree(product_lib, why):
         e.render_iterations(1)
         e.synchronize()
         assert np.isfinite(e.download_film(64, 48)).all()
+    monkeypatch.delenv("ZYG_TABLE_COMPLETE", raising=False)  # (the switch is read when a context is created: this one is the default's)
     with zyg_amd.Engine(product_lib) as e:  # (and the same box without the reason has it)
         scenes.cornell(e, 64, 48, 1, integrator="PTMIS", material="substitute", spheres=True)
         e.start_frame(0)
