@@ -1787,6 +1787,34 @@ ZD void storeQueuedHit(const Params& P, uint32_t position, const Hit& hit, uint3
     P.hit_q[2u * size_t(position) + 1u] = make_uint4(hit.prop, ucount | (lazy ? 0x80000000u : 0u), __float_as_uint(stochastic_r), material);
 }
 
+// A block of 256 threads deals its alive-queue entries to its threads prop by prop (a counting sort by the hit prop's low bits in LDS:
+// the vertices of a prop share their materials and, on a flat one, their side of every light), so that a wave works on one or two
+// surfaces and not on every surface of the scene, as it does past the first tick.  Which thread works on which vertex changes nothing in
+// what is stored for the vertex; the order of what the block appends to a queue changes, which nothing reads.  Whole blocks only.
+template <bool POOL>
+ZD void dealByProp(const Params& P, uint32_t& at, bool& has_entry) {
+    __shared__ uint32_t bucket[16];
+    __shared__ uint32_t entry[256];
+    if (threadIdx.x < 16u) bucket[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t key = 0, position = 0;
+    if (has_entry) {
+        key = ((!POOL && P.hit_q) ? P.hit_q[2u * size_t(at) + 1u].x : P.pool.hit_prop[P.alive_in[at]]) & 15u;
+        position = atomicAdd(&bucket[key], 1u);
+    }
+    __syncthreads();
+    uint32_t first = 0, total = 0;
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const uint32_t n = bucket[k];
+        first += k < key ? n : 0u;
+        total += n;
+    }
+    if (has_entry) entry[first + position] = at;
+    __syncthreads();
+    has_entry = threadIdx.x < total;
+    at = has_entry ? entry[threadIdx.x] : 0u;
+}
+
 // Two passes share shadeVertex.  HEAVY = false walks the extension queue and keeps the common case: a vertex whose hit is not
 // emissive and whose ray crossed no unoccluding light has no emission to evaluate (no sampler draw, no light-tree pdf,
 // no SphQuad), so that instantiation is small enough for twice the occupancy; the others go to the `heavy` queue, which
@@ -3601,6 +3629,9 @@ ZD void scatterVertex(const Params& P, const DScene& s, uint32_t slot, ScatterOu
 #ifndef ZYG_SCATTER_COMPLETE_WAVES
 #define ZYG_SCATTER_COMPLETE_WAVES 2  // the complete closures outside POOL scenes (textured / coated Substitute, mesh lights)
 #endif
+#ifndef ZYG_SCATTER_SORT
+#define ZYG_SCATTER_SORT 0  // 1: the complete instantiations outside POOL scenes deal their vertices prop by prop (dealByProp); 3: the plain ones too
+#endif
 #ifndef ZYG_SCATTER_EVAL_WAVES
 #define ZYG_SCATTER_EVAL_WAVES 2  // wf_scatter<.., PHASE 2>
 #endif
@@ -3648,6 +3679,9 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_W
         has_entry = i < n;
     } else
     if (!aliveOpen(P, P.parity, i, at, has_entry, &alive_end)) return;  // whole blocks take part in queuePush
+#if ZYG_SCATTER_SORT
+    if (!POOL && !STATS && ((ZYG_SCATTER_SORT & 2) || MESHL)) dealByProp<false>(P, at, has_entry);
+#endif
     Counters           cnt{0, 0, 0};
     unsigned long long shadow_rays = 0;
     const DScene& s = c_scene;
@@ -3764,13 +3798,22 @@ __global__ void wf_textures(Params P);
 #include "dprocedural.hpp"
 namespace zd {
 
+#ifndef ZYG_TEXTURES_SORT
+#define ZYG_TEXTURES_SORT 1  // 0: thread i evaluates alive entry i
+#endif
+#ifndef ZYG_TEXTURES_WAVES
+#define ZYG_TEXTURES_WAVES 4  // waves per SIMD (127 registers, none spilled; 2 / 3 / 4 / 5 / 6 / 8: 347 / 367 / 379 / 369 / 363 / 344 Msamples/s on the procedural Cornell box)
+#endif
 template <bool POOL>
-__global__ void __launch_bounds__(256) wf_textures(Params P) {
+__global__ void __launch_bounds__(256) ZYG_WAVES(ZYG_TEXTURES_WAVES) wf_textures(Params P) {
     if (blockIdx.x * blockDim.x >= aliveBound(P, P.parity)) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t       at;
     bool           has_entry;
     if (!aliveOpen(P, P.parity, i, at, has_entry)) return;
+#if ZYG_TEXTURES_SORT
+    dealByProp<POOL>(P, at, has_entry);
+#endif
     if (!has_entry) return;
     const DScene&  s = c_scene;
     const uint32_t slot = P.alive_in[at];
