@@ -75,9 +75,13 @@ def source_hash(source=None):
 
 
 def device_hash():
-    """Hash of what the device code is compiled from (csrc/hip and include/): what a committed rocprofv3 profile of the kernels is
-    valid for (bench.py committed_profile); a change on the host side (loaders, scene compile) leaves it alone."""
+    """Hash of what the device code is compiled from (csrc/hip and include/) and with (the kernel units' flags): what a committed
+    rocprofv3 profile of the kernels is valid for (bench.py committed_profile); a change on the host side (loaders, scene compile)
+    leaves it alone."""
     h = hashlib.sha256()
+    for name, _, flags in _objects("both"):
+        if name.startswith("unit"):
+            h.update(" ".join([name] + COMMON + list(flags)).encode())
     for d in (HIP, os.path.join(ROOT, "include")):
         for f in sorted(os.listdir(d)):
             p = os.path.join(d, f)
@@ -115,7 +119,11 @@ def _objects(mode):
             libm = ["-DZYG_LIBM_CALLS=1"] if u not in (4, 6) else []
             objs.append((f"unit{u}.o", os.path.join(HIP, "kernels.hip"), PRECISE + libm + [f"-DZYG_TU={u}"]))
         if mode in ("both", "relaxed"):
-            objs.append((f"unit{u}f.o", os.path.join(HIP, "kernels.hip"), RELAXED + [f"-DZYG_TU={u}"]))
+            # the scheduler that favours instruction-level parallelism over occupancy (the kernels' waves per SIMD are pinned anyway,
+            # wavefront.hpp ZYG_WAVES): configs[1] +2.0 %, outdoor_mound at 3840x2160 +2.1 %, cornell_glass +1.2 %, configs[2] +0.5 %
+            # (tools/ab_lib_args.sh, two pairs each); unit 7 (the mesh walkers, wf_scatter_h) gains nothing from it and keeps the default
+            sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if 7 != u else []
+            objs.append((f"unit{u}f.o", os.path.join(HIP, "kernels.hip"), RELAXED + sched + [f"-DZYG_TU={u}"]))
     return objs
 
 
