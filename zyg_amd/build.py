@@ -122,7 +122,8 @@ def _objects(mode):
             # the scheduler that favours instruction-level parallelism over occupancy (the kernels' waves per SIMD are pinned anyway,
             # wavefront.hpp ZYG_WAVES): configs[1] +2.0 %, outdoor_mound at 3840x2160 +2.1 %, cornell_glass +1.2 %, configs[2] +0.5 %
             # (tools/ab_lib_args.sh, two pairs each); unit 7 (the mesh walkers, wf_scatter_h) gains nothing from it and keeps the default
-            sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if 7 != u else []
+            # (ZYG_SCHED_DEFAULT=1 in the environment of a --variant build: the A/B's other side)
+            sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if 7 != u and not os.environ.get("ZYG_SCHED_DEFAULT") else []
             objs.append((f"unit{u}f.o", os.path.join(HIP, "kernels.hip"), RELAXED + sched + [f"-DZYG_TU={u}"]))
     return objs
 
