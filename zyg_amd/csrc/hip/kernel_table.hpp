@@ -81,8 +81,8 @@
     X(7, K_INTERSECT_EXTRA_POOL, (wf_intersect<false, true, true>),                   (P)) \
     X(7, K_INTERSECT_EXTRA_POOL_WIDE, ZYG_WIDE((wf_intersect<false, true, true, true>), (wf_intersect<false, true, true>)), (P)) \
     X(7, K_POOL_RESET,           (wf_pool_reset<true>),                               (P)) \
-    X(2, K_TEXTURES,             (wf_textures<false>),                                (P)) \
-    X(2, K_TEXTURES_POOL,        (wf_textures<true>),                                 (P)) \
+    X(7, K_TEXTURES,             (wf_textures<false>),                                (P)) \
+    X(7, K_TEXTURES_POOL,        (wf_textures<true>),                                 (P)) \
     X(7, K_TRACE_SHADE_POOL,     (wf_trace_shade_pool<false>),                        (P, arg)) \
     X(7, K_TRACE_SHADE_POOL_WIDE, ZYG_WIDE((wf_trace_shade_pool<true>), (wf_trace_shade_pool<false>)), (P, arg)) \
     X(6, K_TRACE_SHADE_POOL_FIRST, (wf_trace_shade_pool<false, true>),                (P, arg)) \

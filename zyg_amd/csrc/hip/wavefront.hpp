@@ -3788,7 +3788,7 @@ __global__ void __launch_bounds__(256) ZYG_WAVES(2 == PHASE ? ZYG_SCATTER_EVAL_W
 // draw are the reference's; the draws are not written back: the kernel that takes the vertex' light and bxdf samples repeats them
 // (skipTextureDraws).  Compiled in one kernel unit (kernel_table.hpp); the others see the declaration.
 #ifndef ZYG_TEXTURES_UNIT
-#define ZYG_TEXTURES_UNIT 2
+#define ZYG_TEXTURES_UNIT 7  // a unit compiled with the default scheduler (build.py): max-ilp costs this kernel 8 %
 #endif
 template <bool POOL>
 __global__ void wf_textures(Params P);
