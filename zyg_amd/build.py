@@ -11,7 +11,8 @@ linked as they are, and the library is marked partial, so up_to_date() is false 
 Precise units: -ffp-contract=off (the reference, Zig, fuses a*b+c only at its explicit @mulAdd sites, which the sources
 reproduce with fmaf / __fmaf_rn); correctly rounded f32 divide/sqrt is hipcc's default.  Relaxed units (-DZYG_FAST=1): native
 divide / sqrt, contraction allowed, f32 denormals flushed, OCML f32 transcendentals (dmath.hpp); no -ffast-math: the slab tests
-rely on inf and NaN.
+rely on inf and NaN.  The relaxed units 0-6 are scheduled with -mllvm -amdgpu-sched-strategy=max-ilp (_objects; ZYG_SCHED_DEFAULT=1 in the
+environment of a --variant build compiles the named units with the default scheduler instead: the A/B's other side).
 """
 import concurrent.futures
 import hashlib
