@@ -766,3 +766,18 @@ def test_coincident_dielectric_surfaces_are_found(product_lib):
         scenes.outdoor(e, 32, 18, 1, integrator="PTMIS", material="substitute", showcase=True, box_lift=1e-3)
         sd, _ = e.compile()
         assert 0 == lib.zygpu_scene_has_coincident_dielectric(ctypes.byref(sd))
+
+
+def test_device_hash_follows_the_kernel_units_flags(monkeypatch):
+    """bench.py quotes a committed rocprofv3 profile only for the library it was taken with (build.device_hash): the hash covers the
+    kernel sources and the flags the kernel units are compiled with, and leaves the host side alone."""
+    import zyg_amd.build as zbuild
+    mine = zbuild.device_hash()
+    assert mine == zbuild.device_hash()
+    monkeypatch.setattr(zbuild, "RELAXED", zbuild.RELAXED + ["-DZYG_SOME_OTHER_BUILD=1"])
+    assert zbuild.device_hash() != mine
+    monkeypatch.undo()
+    monkeypatch.setenv("ZYG_SCHED_DEFAULT", "1")  # (the A/B's other side is another library)
+    assert zbuild.device_hash() != mine
+    monkeypatch.undo()
+    assert zbuild.device_hash() == mine
